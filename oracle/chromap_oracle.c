@@ -1,0 +1,1662 @@
+/*
+ * chromap_oracle.c -- TEST INFRASTRUCTURE ONLY (see chromap_oracle.h).
+ *
+ * Sequential CPU restatement of the reference's hot path.  Citations are into
+ * /root/reference/src.  Written from scratch in C (flat arrays, no STL); the
+ * semantics -- including integer wrap-arounds and truncations -- follow the
+ * reference so that results are bit-identical.
+ */
+#define _GNU_SOURCE
+#include "chromap_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* small growable arrays                                                      */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint64_t *a; size_t n, cap; } vec64;
+static void v64_push(vec64 *v, uint64_t x) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 64;
+    v->a = (uint64_t *)realloc(v->a, v->cap * sizeof(uint64_t));
+  }
+  v->a[v->n++] = x;
+}
+static int cmp_u64(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : x > y;
+}
+
+/* candidate.h:8-34 */
+typedef struct { uint64_t position; uint8_t count; } cand_t;
+typedef struct { cand_t *a; size_t n, cap; } vcand;
+static void vc_push(vcand *v, cand_t x) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 32;
+    v->a = (cand_t *)realloc(v->a, v->cap * sizeof(cand_t));
+  }
+  v->a[v->n++] = x;
+}
+/* Candidate::operator< : count desc, position asc (candidate.h:22-33) */
+static int cmp_cand(const void *a, const void *b) {
+  const cand_t *x = (const cand_t *)a, *y = (const cand_t *)b;
+  if (x->count != y->count) return x->count > y->count ? -1 : 1;
+  return x->position < y->position ? -1 : x->position > y->position;
+}
+
+/* draft_mapping.h:8-24 */
+typedef struct { int num_errors; uint64_t position; } draft_t;
+typedef struct { draft_t *a; size_t n, cap; } vdraft;
+static void vd_push(vdraft *v, int e, uint64_t p) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 32;
+    v->a = (draft_t *)realloc(v->a, v->cap * sizeof(draft_t));
+  }
+  v->a[v->n].num_errors = e;
+  v->a[v->n++].position = p;
+}
+/* stable merge sort by position: std::sort is unstable, but ties between equal positions
+ * only reorder mappings with the same end position; see note at sort_drafts(). */
+static int cmp_draft_pos(const void *a, const void *b) {
+  const draft_t *x = (const draft_t *)a, *y = (const draft_t *)b;
+  return x->position < y->position ? -1 : x->position > y->position;
+}
+
+typedef struct { uint32_t a, b; } pair32;
+typedef struct { pair32 *a; size_t n, cap; } vpair;
+static void vp_push(vpair *v, uint32_t x, uint32_t y) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 16;
+    v->a = (pair32 *)realloc(v->a, v->cap * sizeof(pair32));
+  }
+  v->a[v->n].a = x;
+  v->a[v->n++].b = y;
+}
+
+/* ------------------------------------------------------------------------- */
+/* utils.h:76-108                                                             */
+/* ------------------------------------------------------------------------- */
+uint64_t ora_hash64(uint64_t key, uint64_t mask) {
+  key = (~key + (key << 21)) & mask;
+  key = key ^ key >> 24;
+  key = ((key + (key << 3)) + (key << 8)) & mask;
+  key = key ^ key >> 14;
+  key = ((key + (key << 2)) + (key << 4)) & mask;
+  key = key ^ key >> 28;
+  key = (key + (key << 31)) & mask;
+  return key;
+}
+
+/* CharToUint8 (utils.h:87-104): A/a 0, C/c 1, G/g 2, T/t 3, everything else 4 */
+static inline uint8_t c2u(char c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+/* Uint8ToChar (utils.h:100-108) */
+static inline char u2c(uint8_t i) { return "ACGTNNNN"[i & 7]; }
+
+/* ------------------------------------------------------------------------- */
+/* minimizer_generator.cc:7-139                                               */
+/* ------------------------------------------------------------------------- */
+int ora_minimizers(const char *seq, uint32_t len, uint32_t seq_index, int k, int w,
+                   uint64_t *out_hash, uint64_t *out_hit) {
+  const uint64_t shift = 2 * (uint64_t)(k - 1);
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  uint64_t fw = 0, rv = 0;
+  uint64_t bh[256], bp[256]; /* ring buffer of (hash, hit) */
+  uint64_t min_h = UINT64_MAX, min_p = UINT64_MAX;
+  int n = 0;
+  for (int i = 0; i < w; ++i) bh[i] = bp[i] = UINT64_MAX; /* memset 0xff, :21 */
+  int unamb = 0, pib = 0, min_pos = 0;
+#define EMIT(h, p) do { out_hash[n] = (h); out_hit[n] = (p); ++n; } while (0)
+  for (uint32_t pos = 0; pos < len; ++pos) {
+    const uint8_t c = c2u(seq[pos]);
+    uint64_t cur_h = UINT64_MAX, cur_p = UINT64_MAX;
+    if (c < 4) {
+      fw = ((fw << 2) | c) & mask;                         /* :35-36 */
+      rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);      /* :38-40 */
+      if (fw == rv) continue;                              /* :42-45 palindrome: no buffer write */
+      const uint64_t h0 = ora_hash64(fw, mask), h1 = ora_hash64(rv, mask);
+      const uint64_t strand = h0 < h1 ? 0 : 1;             /* :51-52 */
+      ++unamb;
+      if (unamb >= k) {
+        cur_h = ora_hash64(strand ? h1 : h0, mask);        /* :57 hashed twice */
+        cur_p = ((((uint64_t)seq_index) << 32 | (uint32_t)pos) << 1) | strand;
+      }
+    } else {
+      unamb = 0;
+    }
+    bh[pib] = cur_h;
+    bp[pib] = cur_p;
+    if (unamb == w + k - 1 && min_h != UINT64_MAX && min_h < cur_h) { /* :69-81 */
+      for (int j = pib + 1; j < w; ++j)
+        if (min_h == bh[j] && bp[j] != min_p) EMIT(bh[j], bp[j]);
+      for (int j = 0; j < pib; ++j)
+        if (min_h == bh[j] && bp[j] != min_p) EMIT(bh[j], bp[j]);
+    }
+    if (cur_h <= min_h) { /* :83-90 */
+      if (unamb >= w + k && min_h != UINT64_MAX) EMIT(min_h, min_p);
+      min_h = cur_h;
+      min_p = cur_p;
+      min_pos = pib;
+    } else if (pib == min_pos) { /* :91-128 */
+      if (unamb >= w + k - 1 && min_h != UINT64_MAX) EMIT(min_h, min_p);
+      min_h = UINT64_MAX;
+      for (int j = pib + 1; j < w; ++j)
+        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
+      for (int j = 0; j <= pib; ++j)
+        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
+      if (unamb >= w + k - 1 && min_h != UINT64_MAX) {
+        for (int j = pib + 1; j < w; ++j)
+          if (min_h == bh[j] && min_p != bp[j]) EMIT(bh[j], bp[j]);
+        for (int j = 0; j <= pib; ++j)
+          if (min_h == bh[j] && min_p != bp[j]) EMIT(bh[j], bp[j]);
+      }
+    }
+    if (++pib == w) pib = 0;
+  }
+  if (min_h != UINT64_MAX) EMIT(min_h, min_p); /* :136-138 */
+#undef EMIT
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* khash (khash.h:165-350) with the index's hash/eq (index_utils.h:13-17)      */
+/* ------------------------------------------------------------------------- */
+#define FL_ISEMPTY(f, i) ((f[(i) >> 4] >> (((i) & 0xfU) << 1)) & 2)
+#define FL_ISDEL(f, i) ((f[(i) >> 4] >> (((i) & 0xfU) << 1)) & 1)
+#define FL_ISEITHER(f, i) ((f[(i) >> 4] >> (((i) & 0xfU) << 1)) & 3)
+#define FL_SET_DEL_TRUE(f, i) (f[(i) >> 4] |= 1ul << (((i) & 0xfU) << 1))
+#define FL_SET_EMPTY_FALSE(f, i) (f[(i) >> 4] &= ~(2ul << (((i) & 0xfU) << 1)))
+#define FL_SET_BOTH_FALSE(f, i) (f[(i) >> 4] &= ~(3ul << (((i) & 0xfU) << 1)))
+#define FL_SIZE(m) ((m) < 16 ? 1 : (m) >> 4)
+static const double KH_UPPER = 0.77;
+
+uint32_t ora_kh_get(const ora_index *h, uint64_t key, uint64_t *steps) {
+  if (!h->n_buckets) return 0;
+  uint32_t mask = h->n_buckets - 1, step = 0;
+  uint32_t k = (uint32_t)(key >> 1), i = k & mask, last = i;
+  uint64_t visited = 1;
+  while (!FL_ISEMPTY(h->flags, i) &&
+         (FL_ISDEL(h->flags, i) || !((h->keys[i] >> 1) == (key >> 1)))) {
+    i = (i + (++step)) & mask;
+    ++visited;
+    if (i == last) { if (steps) *steps += visited; return h->n_buckets; }
+  }
+  if (steps) *steps += visited;
+  return FL_ISEITHER(h->flags, i) ? h->n_buckets : i;
+}
+
+static int kh_resize(ora_index *h, uint32_t new_n) { /* khash.h:246-308 */
+  uint32_t *new_flags = 0;
+  uint32_t j = 1;
+  {
+    --new_n; new_n |= new_n >> 1; new_n |= new_n >> 2; new_n |= new_n >> 4;
+    new_n |= new_n >> 8; new_n |= new_n >> 16; ++new_n;
+    if (new_n < 4) new_n = 4;
+    if (h->size >= (uint32_t)(new_n * KH_UPPER + 0.5)) j = 0;
+    else {
+      new_flags = (uint32_t *)malloc(FL_SIZE(new_n) * sizeof(uint32_t));
+      memset(new_flags, 0xaa, FL_SIZE(new_n) * sizeof(uint32_t));
+      if (h->n_buckets < new_n) {
+        h->keys = (uint64_t *)realloc(h->keys, (size_t)new_n * sizeof(uint64_t));
+        h->vals = (uint64_t *)realloc(h->vals, (size_t)new_n * sizeof(uint64_t));
+      }
+    }
+  }
+  if (j) {
+    for (j = 0; j != h->n_buckets; ++j) {
+      if (FL_ISEITHER(h->flags, j) == 0) {
+        uint64_t key = h->keys[j], val = h->vals[j];
+        uint32_t new_mask = new_n - 1;
+        FL_SET_DEL_TRUE(h->flags, j);
+        while (1) {
+          uint32_t k = (uint32_t)(key >> 1), i = k & new_mask, step = 0;
+          while (!FL_ISEMPTY(new_flags, i)) i = (i + (++step)) & new_mask;
+          FL_SET_EMPTY_FALSE(new_flags, i);
+          if (i < h->n_buckets && FL_ISEITHER(h->flags, i) == 0) {
+            uint64_t t = h->keys[i]; h->keys[i] = key; key = t;
+            t = h->vals[i]; h->vals[i] = val; val = t;
+            FL_SET_DEL_TRUE(h->flags, i);
+          } else {
+            h->keys[i] = key;
+            h->vals[i] = val;
+            break;
+          }
+        }
+      }
+    }
+    if (h->n_buckets > new_n) {
+      h->keys = (uint64_t *)realloc(h->keys, (size_t)new_n * sizeof(uint64_t));
+      h->vals = (uint64_t *)realloc(h->vals, (size_t)new_n * sizeof(uint64_t));
+    }
+    free(h->flags);
+    h->flags = new_flags;
+    h->n_buckets = new_n;
+    h->n_occupied = h->size;
+    h->upper_bound = (uint32_t)(h->n_buckets * KH_UPPER + 0.5);
+  }
+  return 0;
+}
+
+static uint32_t kh_put(ora_index *h, uint64_t key, int *ret) { /* khash.h:310-350 */
+  uint32_t x;
+  if (h->n_occupied >= h->upper_bound) {
+    if (h->n_buckets > (h->size << 1)) kh_resize(h, h->n_buckets - 1);
+    else kh_resize(h, h->n_buckets + 1);
+  }
+  {
+    uint32_t k, i, site, last, mask = h->n_buckets - 1, step = 0;
+    x = site = h->n_buckets;
+    k = (uint32_t)(key >> 1);
+    i = k & mask;
+    if (FL_ISEMPTY(h->flags, i)) x = i;
+    else {
+      last = i;
+      while (!FL_ISEMPTY(h->flags, i) &&
+             (FL_ISDEL(h->flags, i) || !((h->keys[i] >> 1) == (key >> 1)))) {
+        if (FL_ISDEL(h->flags, i)) site = i;
+        i = (i + (++step)) & mask;
+        if (i == last) { x = site; break; }
+      }
+      if (x == h->n_buckets) {
+        if (FL_ISEMPTY(h->flags, i) && site != h->n_buckets) x = site;
+        else x = i;
+      }
+    }
+  }
+  if (FL_ISEMPTY(h->flags, x)) {
+    h->keys[x] = key;
+    FL_SET_BOTH_FALSE(h->flags, x);
+    ++h->size; ++h->n_occupied;
+    *ret = 1;
+  } else if (FL_ISDEL(h->flags, x)) {
+    h->keys[x] = key;
+    FL_SET_BOTH_FALSE(h->flags, x);
+    ++h->size;
+    *ret = 2;
+  } else *ret = 0;
+  return x;
+}
+
+typedef struct { uint64_t hash, hit; } mm_t;
+static int cmp_mm(const void *a, const void *b) { /* minimizer.h:35-45 */
+  const mm_t *x = (const mm_t *)a, *y = (const mm_t *)b;
+  if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
+  return x->hit < y->hit ? -1 : x->hit > y->hit;
+}
+
+int ora_index_build(const ora_ref *ref, int k, int w, ora_index *idx) { /* index.cc:12-89 */
+  memset(idx, 0, sizeof(*idx));
+  idx->k = k;
+  idx->w = w;
+  size_t cap = 1024, n = 0;
+  mm_t *mm = (mm_t *)malloc(cap * sizeof(mm_t));
+  for (uint32_t r = 0; r < ref->n_seq; ++r) {
+    uint64_t *hh = (uint64_t *)malloc(((size_t)ref->len[r] + 1) * sizeof(uint64_t));
+    uint64_t *pp = (uint64_t *)malloc(((size_t)ref->len[r] + 1) * sizeof(uint64_t));
+    int c = ora_minimizers(ref->seq[r], ref->len[r], r, k, w, hh, pp);
+    if (n + c > cap) { while (n + c > cap) cap *= 2; mm = (mm_t *)realloc(mm, cap * sizeof(mm_t)); }
+    for (int i = 0; i < c; ++i) { mm[n].hash = hh[i]; mm[n].hit = pp[i]; ++n; }
+    free(hh); free(pp);
+  }
+  if (n == 0) { free(mm); return -1; }
+  qsort(mm, n, sizeof(mm_t), cmp_mm); /* (hash,hit) pairs are unique -> stable_sort irrelevant */
+  vec64 occ = {0};
+  uint64_t prev = mm[0].hash << 1, nonsingle = 0;
+  uint32_t nprev = 0;
+  for (size_t mi = 0; mi <= n; ++mi) {
+    const int last = mi == n;
+    const uint64_t cur = last ? prev + 1 : mm[mi].hash << 1;
+    if (cur != prev) {
+      int rc;
+      uint32_t it = kh_put(idx, prev, &rc);
+      if (nprev == 1) {
+        idx->keys[it] |= 1;
+        idx->vals[it] = occ.a[occ.n - 1];
+        --occ.n;
+      } else {
+        idx->vals[it] = (nonsingle << 32) | nprev;
+        nonsingle += nprev;
+      }
+      nprev = 1;
+    } else {
+      ++nprev;
+    }
+    if (last) break;
+    v64_push(&occ, mm[mi].hit);
+    prev = cur;
+  }
+  free(mm);
+  idx->n_keys = idx->size;
+  idx->n_occ = (uint32_t)occ.n;
+  idx->occ = occ.a;
+  return 0;
+}
+
+int ora_index_save(const char *path, const ora_index *idx) { /* index.cc:91-130 */
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  fwrite(&idx->k, sizeof(int), 1, f);
+  fwrite(&idx->w, sizeof(int), 1, f);
+  uint32_t sz = idx->size;
+  fwrite(&sz, 4, 1, f);
+  fwrite(&idx->n_buckets, 4, 1, f);
+  fwrite(&idx->size, 4, 1, f);
+  fwrite(&idx->n_occupied, 4, 1, f);
+  fwrite(&idx->upper_bound, 4, 1, f);
+  if (idx->n_buckets) {
+    fwrite(idx->flags, 4, FL_SIZE(idx->n_buckets), f);
+    fwrite(idx->keys, 8, idx->n_buckets, f);
+    fwrite(idx->vals, 8, idx->n_buckets, f);
+  }
+  fwrite(&idx->n_occ, 4, 1, f);
+  if (idx->n_occ) fwrite(idx->occ, 8, idx->n_occ, f);
+  fclose(f);
+  return 0;
+}
+
+int ora_index_load(const char *path, ora_index *idx) { /* index.cc:132-169, khash.h:358-373 */
+  memset(idx, 0, sizeof(*idx));
+  FILE *f = fopen(path, "rb");
+  if (!f) return -1;
+  int ok = 1;
+  ok &= fread(&idx->k, sizeof(int), 1, f) == 1;
+  ok &= fread(&idx->w, sizeof(int), 1, f) == 1;
+  ok &= fread(&idx->n_keys, 4, 1, f) == 1;
+  ok &= fread(&idx->n_buckets, 4, 1, f) == 1;
+  ok &= fread(&idx->size, 4, 1, f) == 1;
+  ok &= fread(&idx->n_occupied, 4, 1, f) == 1;
+  ok &= fread(&idx->upper_bound, 4, 1, f) == 1;
+  if (!ok) { fclose(f); return -2; }
+  if (idx->n_buckets) {
+    size_t fs = FL_SIZE(idx->n_buckets);
+    idx->flags = (uint32_t *)malloc(fs * 4);
+    idx->keys = (uint64_t *)malloc((size_t)idx->n_buckets * 8);
+    idx->vals = (uint64_t *)malloc((size_t)idx->n_buckets * 8);
+    ok &= fread(idx->flags, 4, fs, f) == fs;
+    ok &= fread(idx->keys, 8, idx->n_buckets, f) == idx->n_buckets;
+    ok &= fread(idx->vals, 8, idx->n_buckets, f) == idx->n_buckets;
+  }
+  ok &= fread(&idx->n_occ, 4, 1, f) == 1;
+  if (ok && idx->n_occ) {
+    idx->occ = (uint64_t *)malloc((size_t)idx->n_occ * 8);
+    ok &= fread(idx->occ, 8, idx->n_occ, f) == idx->n_occ;
+  }
+  fclose(f);
+  return ok ? 0 : -2;
+}
+
+void ora_index_free(ora_index *idx) {
+  free(idx->flags); free(idx->keys); free(idx->vals); free(idx->occ);
+  memset(idx, 0, sizeof(*idx));
+}
+
+/* ------------------------------------------------------------------------- */
+/* FASTA/FASTQ reading with kseq.h record semantics                           */
+/* ------------------------------------------------------------------------- */
+typedef struct { char *a; size_t n, cap; } vchar;
+static void vch_append(vchar *v, const char *s, size_t l) {
+  if (v->n + l + 1 > v->cap) {
+    while (v->n + l + 1 > v->cap) v->cap = v->cap ? v->cap * 2 : 1 << 16;
+    v->a = (char *)realloc(v->a, v->cap);
+  }
+  memcpy(v->a + v->n, s, l);
+  v->n += l;
+  v->a[v->n] = 0;
+}
+
+/* Generic reader: calls cb(name, seq, len) per record. Supports multi-line FASTA and
+ * 4-line (or multi-line) FASTQ like kseq_read (kseq.h:175-217). Plain text only. */
+typedef void (*rec_cb)(void *ud, const char *name, const char *seq, size_t len);
+static long read_fastx(const char *path, rec_cb cb, void *ud) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return -1;
+  char *line = NULL;
+  size_t lcap = 0;
+  ssize_t ll;
+  vchar name = {0}, seq = {0};
+  long nrec = 0;
+  int have = 0, in_qual = 0;
+  size_t qual_len = 0;
+  while ((ll = getline(&line, &lcap, f)) >= 0) {
+    while (ll > 0 && (line[ll - 1] == '\n' || line[ll - 1] == '\r')) line[--ll] = 0;
+    if (in_qual) {
+      qual_len += (size_t)ll;
+      if (qual_len >= seq.n) in_qual = 0;
+      continue;
+    }
+    if (line[0] == '>' || line[0] == '@') {
+      if (have) { cb(ud, name.a, seq.a ? seq.a : "", seq.n); ++nrec; }
+      size_t e = 1;
+      while (line[e] && line[e] != ' ' && line[e] != '\t' && line[e] != '\v' && line[e] != '\f') ++e;
+      name.n = 0;
+      vch_append(&name, line + 1, e - 1);
+      seq.n = 0;
+      if (seq.a) seq.a[0] = 0;
+      have = 1;
+    } else if (line[0] == '+' && have) {
+      in_qual = 1;
+      qual_len = 0;
+      if (seq.n == 0) in_qual = 0;
+    } else if (have) {
+      /* kseq keeps only isgraph() characters of sequence lines */
+      size_t o = 0;
+      for (ssize_t i = 0; i < ll; ++i)
+        if (line[i] > 32 && line[i] < 127) line[o++] = line[i];
+      vch_append(&seq, line, o);
+    }
+  }
+  if (have) { cb(ud, name.a, seq.a ? seq.a : "", seq.n); ++nrec; }
+  free(line); free(name.a); free(seq.a);
+  fclose(f);
+  return nrec;
+}
+
+static void ref_cb(void *ud, const char *name, const char *seq, size_t len) {
+  ora_ref *r = (ora_ref *)ud;
+  if (len == 0) return; /* sequence_batch.cc:91 skips empty records */
+  r->name = (char **)realloc(r->name, (r->n_seq + 1) * sizeof(char *));
+  r->seq = (char **)realloc(r->seq, (r->n_seq + 1) * sizeof(char *));
+  r->len = (uint32_t *)realloc(r->len, (r->n_seq + 1) * sizeof(uint32_t));
+  r->name[r->n_seq] = strdup(name);
+  /* zero padding after the sequence: the reference over-reads up to e bytes past the
+   * end in GetRefStartEndPositionForReadFromMapping (mapping_generator.h:703-708); the
+   * byte at [len] is kseq's NUL, what follows is undefined there, zeros here. */
+  r->seq[r->n_seq] = (char *)calloc(len + 64, 1);
+  memcpy(r->seq[r->n_seq], seq, len);
+  r->len[r->n_seq] = (uint32_t)len;
+  ++r->n_seq;
+}
+
+int ora_ref_load(const char *fasta_path, ora_ref *ref) {
+  memset(ref, 0, sizeof(*ref));
+  return read_fastx(fasta_path, ref_cb, ref) < 0 ? -1 : 0;
+}
+
+void ora_ref_free(ora_ref *ref) {
+  for (uint32_t i = 0; i < ref->n_seq; ++i) { free(ref->name[i]); free(ref->seq[i]); }
+  free(ref->name); free(ref->seq); free(ref->len);
+  memset(ref, 0, sizeof(*ref));
+}
+
+typedef struct { vchar b; uint32_t *off; size_t n, cap; } fq_acc;
+static void fq_cb(void *ud, const char *name, const char *seq, size_t len) {
+  (void)name;
+  fq_acc *a = (fq_acc *)ud;
+  if (len == 0) return; /* sequence_batch.cc:27-30 skips zero-length reads */
+  if (a->n + 2 > a->cap) {
+    a->cap = a->cap ? a->cap * 2 : 1024;
+    a->off = (uint32_t *)realloc(a->off, a->cap * sizeof(uint32_t));
+  }
+  if (a->n == 0) a->off[0] = 0;
+  vch_append(&a->b, seq, len);
+  a->off[++a->n] = (uint32_t)a->b.n;
+}
+
+long ora_read_fastx(const char *path, char **bases, uint32_t **off) {
+  fq_acc a;
+  memset(&a, 0, sizeof(a));
+  long r = read_fastx(path, fq_cb, &a);
+  if (r < 0) return r;
+  if (a.n == 0) { a.off = (uint32_t *)calloc(1, sizeof(uint32_t)); a.b.a = (char *)calloc(1, 1); }
+  *bases = a.b.a;
+  *off = a.off;
+  return (long)a.n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* std::mt19937 + libstdc++-11 uniform_int_distribution<int>(0,i)              */
+/* (mapping_generator.h:199-214 draws with these; bits/uniform_int_dist.h _S_nd) */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+static void mt_seed(mt19937_t *g, uint32_t s) {
+  g->mt[0] = s;
+  for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t *g) {
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfu : 0);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+/* uniform int in [0, hi] (Lemire's nearly-divisionless, as in libstdc++ 11) */
+static int mt_uniform(mt19937_t *g, int hi) {
+  uint32_t range = (uint32_t)hi + 1u;
+  if (range == 0) return (int)mt_next(g);
+  uint64_t product = (uint64_t)mt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    uint32_t threshold = (uint32_t)(-range) % range;
+    while (low < threshold) {
+      product = (uint64_t)mt_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (int)(product >> 32);
+}
+
+/* ------------------------------------------------------------------------- */
+/* per-read scratch (mapping_metadata.h:144-165)                               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t *mm_hash, *mm_hit;
+  int n_mm, mm_cap;
+  vec64 pos_hits, neg_hits;
+  vcand pos_cand, neg_cand, pos_buf, neg_buf;
+  vdraft pos_map, neg_map;
+  int min_err, second_err, n_best, n_second;
+  uint32_t rep_len;
+} meta_t;
+
+static void meta_prepare(meta_t *m, uint32_t read_len) {
+  if ((int)read_len + 1 > m->mm_cap) {
+    m->mm_cap = (int)read_len + 64;
+    m->mm_hash = (uint64_t *)realloc(m->mm_hash, m->mm_cap * sizeof(uint64_t));
+    m->mm_hit = (uint64_t *)realloc(m->mm_hit, m->mm_cap * sizeof(uint64_t));
+  }
+  m->n_mm = 0;
+  m->pos_hits.n = m->neg_hits.n = 0;
+  m->pos_cand.n = m->neg_cand.n = m->pos_buf.n = m->neg_buf.n = 0;
+  m->pos_map.n = m->neg_map.n = 0;
+  m->rep_len = 0;
+}
+static void meta_free(meta_t *m) {
+  free(m->mm_hash); free(m->mm_hit); free(m->pos_hits.a); free(m->neg_hits.a);
+  free(m->pos_cand.a); free(m->neg_cand.a); free(m->pos_buf.a); free(m->neg_buf.a);
+  free(m->pos_map.a); free(m->neg_map.a);
+}
+
+struct ora_ctx {
+  const ora_index *idx;
+  const ora_ref *ref;
+  ora_params p;
+  mt19937_t rng;
+  ora_trace *trace;
+};
+
+void ora_default_params(ora_params *p) { /* mapping_parameters.h:19-61 */
+  memset(p, 0, sizeof(*p));
+  p->error_threshold = 8;
+  p->min_num_seeds = 2;
+  p->max_seed_freq0 = 500;
+  p->max_seed_freq1 = 1000;
+  p->max_insert_size = 1000;
+  p->min_read_length = 30;
+  p->max_num_best_mappings = 1;
+  p->drop_repetitive_reads = 500000;
+  p->mapq_threshold = 30;
+}
+
+void ora_preset(ora_params *p, const char *preset) { /* chromap_driver.cc:247-275 */
+  if (!strcmp(preset, "atac")) {
+    p->max_insert_size = 2000;
+    p->trim_adapters = 1;
+    p->remove_pcr_duplicates = 1;
+    p->tn5_shift = 1;
+    p->low_mem = 1;
+  } else if (!strcmp(preset, "chip")) {
+    p->max_insert_size = 2000;
+    p->remove_pcr_duplicates = 1;
+    p->low_mem = 1;
+  } else if (!strcmp(preset, "hic")) {
+    p->error_threshold = 4;
+    p->mapq_threshold = 1;
+    p->split_alignment = 1;
+    p->low_mem = 1;
+  }
+}
+
+ora_ctx *ora_create(const ora_index *idx, const ora_ref *ref, const ora_params *p) {
+  ora_ctx *c = (ora_ctx *)calloc(1, sizeof(ora_ctx));
+  c->idx = idx;
+  c->ref = ref;
+  c->p = *p;
+  mt_seed(&c->rng, 11);
+  return c;
+}
+void ora_destroy(ora_ctx *c) { free(c); }
+void ora_set_trace(ora_ctx *c, ora_trace *t) { c->trace = t; }
+
+/* ------------------------------------------------------------------------- */
+/* K2: Index::GenerateCandidatePositions (index.cc:237-349)                    */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint32_t rep_len, prev_pos; int count; } rep_stats; /* index_utils.h:21-26 */
+
+static void update_rep(const ora_index *idx, uint32_t read_pos, rep_stats *s) { /* index.cc:507-523 */
+  if (s->prev_pos > read_pos) {
+    s->rep_len += idx->k;
+  } else {
+    if (read_pos < s->prev_pos + idx->k + idx->w - 1) s->rep_len += read_pos - s->prev_pos;
+    else s->rep_len += idx->k;
+  }
+  s->prev_pos = read_pos;
+  ++s->count;
+}
+
+/* index.cc:491-505 */
+static inline uint64_t cand_from_hits(const ora_index *idx, uint64_t ref_hit, uint64_t read_hit) {
+  const uint32_t ref_pos = (uint32_t)(ref_hit >> 1), read_pos = (uint32_t)(read_hit >> 1);
+  const uint32_t start = ((ref_hit & 1) == (read_hit & 1)) ? ref_pos - read_pos
+                                                          : ref_pos + read_pos - (uint32_t)idx->k + 1;
+  return ((uint64_t)(uint32_t)(ref_hit >> 33) << 32) | start;
+}
+
+static int gen_candidate_positions(const ora_index *idx, meta_t *m, uint32_t max_freq,
+                                   uint32_t rep_freq, ora_stats *st) {
+  rep_stats rs = {0, UINT32_MAX, 0};
+  for (int mi = 0; mi < m->n_mm; ++mi) {
+    uint64_t steps = 0;
+    uint32_t it = ora_kh_get(idx, m->mm_hash[mi] << 1, &steps);
+    if (st) { st->probe_steps += steps; st->lookups++; }
+    if (it == idx->n_buckets) continue;
+    const uint64_t key = idx->keys[it], val = idx->vals[it], read_hit = m->mm_hit[mi];
+    if (key & 1) { /* singleton: value is the reference hit, :277-287 */
+      const uint64_t cp = cand_from_hits(idx, val, read_hit);
+      if ((val & 1) == (read_hit & 1)) v64_push(&m->pos_hits, cp);
+      else v64_push(&m->neg_hits, cp);
+      continue;
+    }
+    const uint32_t n_occ = (uint32_t)val;
+    if (!(n_occ >= max_freq)) { /* !IsFrequentSeed, :291-310 */
+      const uint32_t off = (uint32_t)(val >> 32);
+      if (st) st->occ_reads += n_occ;
+      for (uint32_t oi = 0; oi < n_occ; ++oi) {
+        const uint64_t rh = idx->occ[off + oi];
+        const uint64_t cp = cand_from_hits(idx, rh, read_hit);
+        if ((rh & 1) == (read_hit & 1)) v64_push(&m->pos_hits, cp);
+        else v64_push(&m->neg_hits, cp);
+      }
+    }
+    if (n_occ >= rep_freq) update_rep(idx, (uint32_t)(read_hit >> 1), &rs); /* :312-315 */
+  }
+  /* :318-334 -- both branches (std::sort, or per-list sort + heap merge) yield the
+   * ascending sorted multiset. */
+  qsort(m->pos_hits.a, m->pos_hits.n, 8, cmp_u64);
+  qsort(m->neg_hits.a, m->neg_hits.n, 8, cmp_u64);
+  m->rep_len = rs.rep_len;
+  return rs.count;
+}
+
+/* K3b: CandidateProcessor::GenerateCandidatesOnOneStrand (candidate_processor.cc:283-342) */
+static void gen_candidates_one_strand(int e, int seeds_required, uint32_t num_minimizers,
+                                      vec64 *hits, vcand *out) {
+  v64_push(hits, UINT64_MAX);
+  int mcount = 1, equal = 1, best_equal = 1;
+  uint64_t prev_hit = hits->a[0];
+  uint32_t prev_rid = (uint32_t)(prev_hit >> 32), prev_pos = (uint32_t)prev_hit;
+  uint64_t best_local = hits->a[0];
+  for (size_t pi = 1; pi < hits->n; ++pi) {
+    const uint64_t h = hits->a[pi];
+    const uint32_t rid = (uint32_t)(h >> 32), pos = (uint32_t)h;
+    if (rid != prev_rid || pos > prev_pos + (uint32_t)e ||
+        ((uint32_t)mcount >= num_minimizers && pos > (uint32_t)best_local + (uint32_t)e)) {
+      if (mcount >= seeds_required) {
+        cand_t c;
+        c.position = best_local;
+        c.count = (uint8_t)best_equal;
+        vc_push(out, c);
+      }
+      mcount = 1; equal = 1; best_equal = 1;
+      best_local = h;
+    } else {
+      if (h == best_local) { ++equal; ++best_equal; }
+      else if (h == prev_hit) {
+        ++equal;
+        if (equal > best_equal) { best_local = prev_hit; best_equal = equal; }
+      } else equal = 1;
+      ++mcount;
+    }
+    prev_hit = h; prev_rid = rid; prev_pos = pos;
+  }
+}
+
+/* K3a: CandidateProcessor::GenerateCandidates (candidate_processor.cc:12-71) */
+static void gen_candidates(const ora_ctx *c, meta_t *m, ora_stats *st) {
+  const ora_params *p = &c->p;
+  m->rep_len = 0;
+  int rep_count = gen_candidate_positions(c->idx, m, p->max_seed_freq0, p->max_seed_freq0, st);
+  int use_high = 0;
+  if (m->pos_hits.n + m->neg_hits.n == 0) {
+    m->pos_hits.n = m->neg_hits.n = 0;
+    m->rep_len = 0;
+    rep_count = gen_candidate_positions(c->idx, m, p->max_seed_freq1, p->max_seed_freq0, st);
+    use_high = 1;
+    if (m->pos_hits.n == 0 || m->neg_hits.n == 0) use_high = 0;
+  }
+  int req = m->n_mm - rep_count;
+  req = req > 1 ? req : 1;
+  req = req > p->min_num_seeds ? p->min_num_seeds : req;
+  if (use_high) req = p->min_num_seeds;
+  gen_candidates_one_strand(p->error_threshold, req, m->n_mm, &m->pos_hits, &m->pos_cand);
+  gen_candidates_one_strand(p->error_threshold, req, m->n_mm, &m->neg_hits, &m->neg_cand);
+}
+
+/* K2': Index::GenerateCandidatePositionsFromRepetitiveReadWithMateInfoOnOneStrand
+ * (index.cc:351-489). strand: 0 = kPositive, 1 = kNegative. */
+static int rescue_positions(const ora_index *idx, int strand, uint32_t search_range, int min_seeds,
+                            int max_freq0, const meta_t *m, const vcand *mate,
+                            uint32_t *rep_len, vec64 *out, ora_stats *st) {
+  const uint32_t ms = (uint32_t)mate->n;
+  int max_count = 0, best_num = 0;
+  for (uint32_t i = 0; i < ms; ++i) {
+    int cnt = mate->a[i].count;
+    if (cnt > max_count) { max_count = cnt; best_num = 1; }
+    else if (cnt == max_count) ++best_num;
+  }
+  if (best_num >= 300 || ms > (uint32_t)max_freq0 || (max_count <= min_seeds && best_num >= 200))
+    return -max_count;
+  uint64_t *bs = (uint64_t *)malloc((size_t)(best_num + 1) * 2 * sizeof(uint64_t));
+  uint32_t raw = 0;
+  for (uint32_t ci = 0; ci < ms; ++ci) {
+    if (mate->a[ci].count == max_count) {
+      const uint64_t pos = mate->a[ci].position;
+      bs[2 * raw] = pos < search_range ? 0 : pos - search_range;
+      bs[2 * raw + 1] = pos + search_range;
+      ++raw;
+    }
+  }
+  if (raw == 0) { free(bs); return max_count; }
+  uint32_t nb = 1;
+  for (uint32_t bi = 1; bi < raw; ++bi) { /* :399-411 */
+    if (bs[2 * (nb - 1) + 1] < bs[2 * bi]) {
+      bs[2 * nb] = bs[2 * bi];
+      bs[2 * nb + 1] = bs[2 * bi + 1];
+      ++nb;
+    } else {
+      bs[2 * (nb - 1) + 1] = bs[2 * bi + 1];
+    }
+  }
+  rep_stats rs = {0, UINT32_MAX, 0};
+  for (int mi = 0; mi < m->n_mm; ++mi) {
+    uint64_t steps = 0;
+    uint32_t it = ora_kh_get(idx, m->mm_hash[mi] << 1, &steps);
+    if (st) { st->probe_steps += steps; st->lookups++; }
+    if (it == idx->n_buckets) continue;
+    const uint64_t key = idx->keys[it], val = idx->vals[it], read_hit = m->mm_hit[mi];
+    const uint32_t read_pos = (uint32_t)(read_hit >> 1);
+    if (key & 1) {
+      const int same = (val & 1) == (read_hit & 1);
+      if ((same && strand == 0) || (!same && strand == 1)) v64_push(out, cand_from_hits(idx, val, read_hit));
+      continue;
+    }
+    const uint32_t off = (uint32_t)(val >> 32), n_occ = (uint32_t)val;
+    int32_t prev_l = 0;
+    for (uint32_t bi = 0; bi < nb; ++bi) {
+      int32_t l = prev_l, mm_ = 0, r = (int32_t)(n_occ - 1);
+      const uint64_t boundary = bs[2 * bi];
+      while (l <= r) {
+        mm_ = (l + r) / 2;
+        const uint64_t cp = idx->occ[off + mm_] >> 1;
+        if (st) st->occ_reads++;
+        if (cp < boundary) l = mm_ + 1;
+        else if (cp > boundary) r = mm_ - 1;
+        else break;
+      }
+      prev_l = mm_;
+      for (uint32_t oi = (uint32_t)mm_; oi < n_occ; ++oi) {
+        const uint64_t rh = idx->occ[off + oi];
+        if (st) st->occ_reads++;
+        if ((rh >> 1) > bs[2 * bi + 1]) break;
+        const int same = (rh & 1) == (read_hit & 1);
+        if ((same && strand == 0) || (!same && strand == 1)) v64_push(out, cand_from_hits(idx, rh, read_hit));
+      }
+    }
+    if (n_occ >= (uint32_t)max_freq0) update_rep(idx, read_pos, &rs);
+  }
+  free(bs);
+  qsort(out->a, out->n, 8, cmp_u64);
+  *rep_len = rs.rep_len;
+  return max_count;
+}
+
+/* CandidateProcessor::MergeCandidates (candidate_processor.cc:345-414) */
+static void merge_candidates(int e, vcand *c1, vcand *c2, vcand *buffer) {
+  if (c1->n == 0) { vcand t = *c1; *c1 = *c2; *c2 = t; return; }
+  size_t i = 0, j = 0;
+  buffer->n = 0;
+#define BACK_OK(P) (buffer->n == 0 || (P) > buffer->a[buffer->n - 1].position + (uint64_t)(int64_t)e)
+  while (i < c1->n && j < c2->n) {
+    if (c1->a[i].position == c2->a[j].position) {
+      if (BACK_OK(c1->a[i].position)) {
+        if (c1->a[i].count > c2->a[j].count) vc_push(buffer, c1->a[i]);
+        else vc_push(buffer, c2->a[j]);
+      }
+      ++i; ++j;
+    } else if (c1->a[i].position < c2->a[j].position) {
+      if (BACK_OK(c1->a[i].position)) vc_push(buffer, c1->a[i]);
+      ++i;
+    } else {
+      if (BACK_OK(c2->a[j].position)) vc_push(buffer, c2->a[j]);
+      ++j;
+    }
+  }
+  while (i < c1->n) { if (BACK_OK(c1->a[i].position)) vc_push(buffer, c1->a[i]); ++i; }
+  while (j < c2->n) { if (BACK_OK(c2->a[j].position)) vc_push(buffer, c2->a[j]); ++j; }
+#undef BACK_OK
+  vcand t = *c1; *c1 = *buffer; *buffer = t;
+}
+
+/* K3c: CandidateProcessor::SupplementCandidates (candidate_processor.cc:75-231) */
+static int supplement_candidates(const ora_ctx *c, meta_t *m1, meta_t *m2, ora_stats *st) {
+  const ora_params *p = &c->p;
+  const uint32_t search_range = 2u * (uint32_t)p->max_insert_size;
+  vcand aug_pos[2] = {{0}, {0}}, aug_neg[2] = {{0}, {0}};
+  int ret = 0;
+  for (int mate = 0; mate <= 1; ++mate) {
+    meta_t *m = mate == 0 ? m1 : m2;
+    meta_t *o = mate == 0 ? m2 : m1;
+    const uint32_t mm_count = (uint32_t)m->n_mm;
+    int augment = 1;
+    for (size_t i = 0; i < m->pos_cand.n; ++i)
+      if (m->pos_cand.a[i].count >= mm_count / 2) { augment = 0; break; }
+    if (augment)
+      for (size_t i = 0; i < m->neg_cand.n; ++i)
+        if (m->neg_cand.a[i].count >= mm_count / 2) { augment = 0; break; }
+    if (augment) {
+      m->pos_hits.n = m->neg_hits.n = 0;
+      int pos_res = 0, neg_res = 0;
+      if (o->pos_cand.n > 0) { /* mate + candidates drive a search on our - strand */
+        if (st) st->num_rescue++;
+        pos_res = rescue_positions(c->idx, 1, search_range, p->min_num_seeds, p->max_seed_freq0, m,
+                                   &o->pos_cand, &m->rep_len, &m->neg_hits, st);
+        gen_candidates_one_strand(p->error_threshold, 1, m->n_mm, &m->neg_hits, &aug_neg[mate]);
+      }
+      if (o->neg_cand.n > 0) {
+        if (st) st->num_rescue++;
+        neg_res = rescue_positions(c->idx, 0, search_range, p->min_num_seeds, p->max_seed_freq0, m,
+                                   &o->neg_cand, &m->rep_len, &m->pos_hits, st);
+        gen_candidates_one_strand(p->error_threshold, 1, m->n_mm, &m->pos_hits, &aug_pos[mate]);
+      }
+      if (((pos_res < 0 && neg_res > 0 && -pos_res >= neg_res) ||
+           (pos_res > 0 && neg_res < 0 && pos_res <= -neg_res)) &&
+          m->pos_cand.n + m->neg_cand.n == 0)
+        ret = 1;
+    }
+  }
+  if (aug_pos[0].n > 0) merge_candidates(p->error_threshold, &m1->pos_cand, &aug_pos[0], &m1->pos_buf);
+  if (aug_neg[0].n > 0) merge_candidates(p->error_threshold, &m1->neg_cand, &aug_neg[0], &m1->neg_buf);
+  if (aug_pos[1].n > 0) merge_candidates(p->error_threshold, &m2->pos_cand, &aug_pos[1], &m2->pos_buf);
+  if (aug_neg[1].n > 0) merge_candidates(p->error_threshold, &m2->neg_cand, &aug_neg[1], &m2->neg_buf);
+  free(aug_pos[0].a); free(aug_pos[1].a); free(aug_neg[0].a); free(aug_neg[1].a);
+  return ret;
+}
+
+/* K3d: ReduceCandidatesForPairedEndReadOnOneDirection (candidate_processor.cc:416-484) */
+static void reduce_one_direction(uint32_t dist, const vcand *c1, const vcand *c2, vcand *f1, vcand *f2) {
+  uint32_t i1 = 0, i2 = 0;
+  int unpaired1 = 0, unpaired2 = 0;
+  const int unpaired_thr = 5;
+  int max1 = 6, max2 = 6;
+  uint32_t prev_end_i2 = 0;
+  while (i1 < c1->n && i2 < c2->n) {
+    if (c1->a[i1].position > c2->a[i2].position + dist) {
+      if (i2 >= prev_end_i2 && unpaired2 < unpaired_thr &&
+          (c1->a[i1].position >> 32) == (c2->a[i2].position >> 32) && c2->a[i2].count >= max2) {
+        vc_push(f2, c2->a[i2]);
+        ++unpaired2;
+      }
+      ++i2;
+    } else if (c2->a[i2].position > c1->a[i1].position + dist) {
+      if (unpaired1 < unpaired_thr && (c1->a[i1].position >> 32) == (c2->a[i2].position >> 32) &&
+          c1->a[i1].count >= max1) {
+        vc_push(f1, c1->a[i1]);
+        ++unpaired1;
+      }
+      ++i1;
+    } else {
+      vc_push(f1, c1->a[i1]);
+      if (c1->a[i1].count > max1) max1 = c1->a[i1].count;
+      uint32_t cur = i2;
+      while (cur < c2->n && c2->a[cur].position <= c1->a[i1].position + dist) {
+        if (cur >= prev_end_i2) {
+          vc_push(f2, c2->a[cur]);
+          if (c2->a[cur].count > max2) max2 = c2->a[cur].count;
+        }
+        ++cur;
+      }
+      prev_end_i2 = cur;
+      ++i1;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* K4: verification                                                           */
+/* ------------------------------------------------------------------------- */
+/* BandedAlignPatternToText (alignment.cc:141-192) */
+int ora_banded_align(int e, const char *pattern, const char *text, int read_length,
+                     int *mapping_end_position) {
+  uint32_t Peq[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) Peq[c2u(pattern[i])] |= (1u << i);
+  const uint32_t hi = 1u << (2 * e), lo = 1;
+  uint32_t VP = 0, VN = 0, X, D0, HN, HP;
+  int err = 0;
+  for (int i = 0; i < read_length; i++) {
+    Peq[c2u(pattern[i + 2 * e])] |= hi;
+    X = Peq[c2u(text[i])] | VN;
+    D0 = ((VP + (X & VP)) ^ VP) | X;
+    HN = VP & D0;
+    HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    err += 1 - (int)(D0 & lo);
+    if (err > 3 * e) return e + 1;
+    for (int ai = 0; ai < 5; ai++) Peq[ai] >>= 1;
+  }
+  const int band_start = read_length - 1;
+  int min_err = err;
+  *mapping_end_position = band_start;
+  for (int i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *mapping_end_position = band_start + 1 + i;
+    }
+  }
+  return min_err;
+}
+
+/* BandedTraceback (alignment.cc:656-718) */
+void ora_banded_traceback(int e, int min_num_errors, const char *pattern, const char *text,
+                          int read_length, int *mapping_start_position) {
+  if (min_num_errors == 0) { *mapping_start_position = e; return; }
+  int error_count = 0;
+  for (int i = 0; i < read_length; ++i)
+    if (pattern[i + e] != text[i]) ++error_count; /* raw, case-sensitive compare (:666) */
+  if (error_count == min_num_errors) { *mapping_start_position = e; return; }
+  uint32_t Peq[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) Peq[c2u(pattern[read_length - 1 + 2 * e - i])] |= (1u << i);
+  const uint32_t hi = 1u << (2 * e), lo = 1;
+  uint32_t VP = 0, VN = 0, X, D0, HN, HP;
+  int err = 0;
+  for (int i = 0; i < read_length; i++) {
+    Peq[c2u(pattern[read_length - 1 - i])] |= hi;
+    X = Peq[c2u(text[read_length - 1 - i])] | VN;
+    D0 = ((VP + (X & VP)) ^ VP) | X;
+    HN = VP & D0;
+    HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    err += 1 - (int)(D0 & lo);
+    for (int ai = 0; ai < 5; ai++) Peq[ai] >>= 1;
+  }
+  *mapping_start_position = 2 * e;
+  for (int i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err == min_num_errors) {
+      *mapping_start_position = 2 * e - (1 + i);
+      if (i + 1 == e) return;
+    }
+  }
+}
+
+/* DraftMappingGenerator::IsValidCandidate (draft_mapping_generator.cc:59-70) */
+static inline int is_valid_candidate(const ora_ref *ref, int e, uint32_t rid, uint32_t position,
+                                     uint32_t read_length) {
+  const uint32_t rl = ref->len[rid];
+  if (position < (uint32_t)e || position >= rl || position + read_length + (uint32_t)e >= rl) return 0;
+  return 1;
+}
+
+static inline void update_best(meta_t *m, int ne) { /* draft_mapping_generator.cc:502-528 */
+  if (ne < m->min_err) {
+    m->second_err = m->min_err;
+    m->n_second = m->n_best;
+    m->min_err = ne;
+    m->n_best = 1;
+  } else if (ne == m->min_err) {
+    m->n_best++;
+  } else if (ne == m->second_err) {
+    m->n_second++;
+  } else if (ne < m->second_err) {
+    m->n_second = 1;
+    m->second_err = ne;
+  }
+}
+
+/* One candidate through the scalar routine, pushing the draft mapping on success.
+ * Returns 1 when accepted (num_errors <= e). */
+static int verify_one(const ora_ctx *c, meta_t *m, int strand, const cand_t *cd, const char *read_seq,
+                      uint32_t L, ora_stats *st) {
+  const int e = c->p.error_threshold;
+  const uint32_t rid = (uint32_t)(cd->position >> 32);
+  uint32_t position = (uint32_t)cd->position;
+  if (strand == 1) position = position - L + 1;
+  int end_pos = (int)L; /* :400 */
+  if (st) st->num_verifications++;
+  const int ne = ora_banded_align(e, c->ref->seq[rid] + position - e, read_seq, (int)L, &end_pos);
+  if (ne <= e) {
+    update_best(m, ne);
+    if (strand == 0) vd_push(&m->pos_map, ne, cd->position - (uint64_t)e + (uint64_t)(int64_t)end_pos);
+    else vd_push(&m->neg_map, ne, cd->position - L + 1 - (uint64_t)e + (uint64_t)(int64_t)end_pos);
+    return 1;
+  }
+  return 0;
+}
+
+/* GenerateDraftMappingsOnOneStrand, non-split branch (draft_mapping_generator.cc:359-557):
+ * candidate_count_threshold stays 0 there, so every valid candidate is verified. */
+static void draft_one_strand_scalar(const ora_ctx *c, meta_t *m, int strand, const char *read_seq,
+                                    uint32_t L, ora_stats *st) {
+  const vcand *cs = strand == 0 ? &m->pos_cand : &m->neg_cand;
+  for (size_t ci = 0; ci < cs->n; ++ci) {
+    const uint32_t rid = (uint32_t)(cs->a[ci].position >> 32);
+    uint32_t position = (uint32_t)cs->a[ci].position;
+    if (strand == 1) position = position - L + 1;
+    if (!is_valid_candidate(c->ref, c->p.error_threshold, rid, position, L)) continue;
+    verify_one(c, m, strand, &cs->a[ci], read_seq, L, st);
+  }
+}
+
+/* GenerateDraftMappingsOnOneStrandUsingSIMD with 4 lanes (draft_mapping_generator.cc:159-357).
+ * The 4-lane kernel (alignment.cc:378-501) returns, for every accepted lane, the same
+ * (errors, end) as the scalar routine: a lane whose band-start count exceeds 3e keeps
+ * running but can never come back under e (band cells differ from the band start by at
+ * most 2e), so accept/reject and values agree; only the control flow below differs. */
+static void draft_one_strand_lanes(const ora_ctx *c, meta_t *m, int strand, const char *read_seq,
+                                   uint32_t L, int lanes, ora_stats *st) {
+  const vcand *cs = strand == 0 ? &m->pos_cand : &m->neg_cand;
+  const int e = c->p.error_threshold;
+  cand_t valid[8];
+  uint32_t nvalid = 0, thr = 0;
+  size_t ci = 0;
+  while (ci < cs->n) {
+    if (cs->a[ci].count < thr) break; /* :186-188 */
+    const uint32_t rid = (uint32_t)(cs->a[ci].position >> 32);
+    uint32_t position = (uint32_t)cs->a[ci].position;
+    if (strand == 1) position = position - L + 1;
+    if (!is_valid_candidate(c->ref, e, rid, position, L)) { ++ci; continue; }
+    valid[nvalid++] = cs->a[ci];
+    ++ci;
+    if (nvalid < (uint32_t)lanes) continue;
+    for (int mi = 0; mi < lanes; ++mi) {
+      if (!verify_one(c, m, strand, &valid[mi], read_seq, L, st)) thr = valid[mi].count; /* :299-301 */
+    }
+    nvalid = 0;
+  }
+  for (uint32_t i = 0; i < nvalid; ++i) verify_one(c, m, strand, &valid[i], read_seq, L, st); /* :308-356 */
+}
+
+/* DraftMappingGenerator::GenerateDraftMappings (draft_mapping_generator.cc:9-57) with the
+ * shortcut GenerateNonSplitDraftMappingSupportedByAllMinimizers (:72-157). */
+static void gen_draft_mappings(const ora_ctx *c, meta_t *m, const char *read, const char *neg_read,
+                               uint32_t L, ora_stats *st) {
+  const int e = c->p.error_threshold;
+  m->min_err = e + 1; m->n_best = 0; m->second_err = e + 1; m->n_second = 0;
+  if (!c->p.split_alignment && m->pos_cand.n + m->neg_cand.n == 1) {
+    uint32_t n_all = 0, idx = 0;
+    int strand = 0;
+    for (size_t i = 0; i < m->pos_cand.n; ++i)
+      if (m->pos_cand.a[i].count == (uint32_t)m->n_mm) { idx = (uint32_t)i; ++n_all; }
+    for (size_t i = 0; i < m->neg_cand.n; ++i)
+      if (m->neg_cand.a[i].count == (uint32_t)m->n_mm) { idx = (uint32_t)i; strand = 1; ++n_all; }
+    if (n_all == 1) {
+      m->min_err = 0; m->n_best = 1; m->n_second = 0; /* :122-124 (second_err stays e+1) */
+      const cand_t *cd = strand == 0 ? &m->pos_cand.a[idx] : &m->neg_cand.a[idx];
+      const uint32_t rid = (uint32_t)(cd->position >> 32);
+      uint32_t position = strand == 0 ? (uint32_t)cd->position : (uint32_t)cd->position - L + 1;
+      if (is_valid_candidate(c->ref, e, rid, position, L)) {
+        if (strand == 0) vd_push(&m->pos_map, 0, cd->position + L - 1);
+        else vd_push(&m->neg_map, 0, cd->position);
+        if (st) st->num_shortcut++;
+        return;
+      }
+      /* falls through with min_err = 0, n_best = 1 already set (reference behaviour) */
+    }
+  }
+  qsort(m->pos_cand.a, m->pos_cand.n, sizeof(cand_t), cmp_cand); /* SortCandidates, mapping_metadata.h:65-68 */
+  qsort(m->neg_cand.a, m->neg_cand.n, sizeof(cand_t), cmp_cand);
+  int lanes = e < 8 ? 8 : (e < 16 ? 4 : 0); /* GetNumVPULanes, mapping_parameters.h:80-88 */
+  if (c->p.split_alignment) lanes = 0;
+  if (lanes == 0 || m->pos_cand.n < (size_t)lanes) draft_one_strand_scalar(c, m, 0, read, L, st);
+  else draft_one_strand_lanes(c, m, 0, read, L, lanes, st);
+  if (lanes == 0 || m->neg_cand.n < (size_t)lanes) draft_one_strand_scalar(c, m, 1, neg_read, L, st);
+  else draft_one_strand_lanes(c, m, 1, neg_read, L, lanes, st);
+}
+
+/* ------------------------------------------------------------------------- */
+/* K5: best mappings, coordinates, MAPQ                                        */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int min_sum, second_sum, n_best, n_second;
+  vpair best[2]; /* [0] = F1R2, [1] = F2R1 */
+} pe_meta_t;
+
+/* GenerateBestMappingsForPairedEndReadOnOneDirection, non-split (mapping_generator.h:347-484).
+ * dir 0: read1 on + strand, read2 on -; dir 1: read1 -, read2 +. */
+static void best_one_direction(const ora_ctx *c, int dir, const meta_t *m1, const meta_t *m2,
+                               uint32_t len1, uint32_t len2, pe_meta_t *pe) {
+  const vdraft *a = dir == 0 ? &m1->pos_map : &m1->neg_map;
+  const vdraft *b = dir == 0 ? &m2->neg_map : &m2->pos_map;
+  const uint64_t I = (uint64_t)(int64_t)c->p.max_insert_size;
+  const uint64_t min_overlap = (uint32_t)c->p.min_read_length;
+  vpair *best = &pe->best[dir];
+  uint32_t i1 = 0, i2 = 0;
+  while (i1 < a->n && i2 < b->n) {
+    const uint64_t p1 = a->a[i1].position, p2 = b->a[i2].position;
+    if ((dir == 1 && p1 > p2 + I - len2) || (dir == 0 && p1 > p2 + len1 - min_overlap)) {
+      ++i2;
+    } else if ((dir == 0 && p2 > p1 + I - len1) || (dir == 1 && p2 > p1 + len2 - min_overlap)) {
+      ++i1;
+    } else {
+      uint32_t cur = i2;
+      while (cur < b->n && ((dir == 0 && b->a[cur].position <= p1 + I - len1) ||
+                            (dir == 1 && b->a[cur].position <= p1 + len2 - min_overlap))) {
+        const int s = a->a[i1].num_errors + b->a[cur].num_errors;
+        if (s < pe->min_sum) {
+          pe->second_sum = pe->min_sum;
+          pe->n_second = pe->n_best;
+          pe->min_sum = s;
+          pe->n_best = 1;
+          best->n = 0;
+          vp_push(best, i1, cur);
+        } else if (s == pe->min_sum) {
+          pe->n_best++;
+          vp_push(best, i1, cur);
+        } else if (s == pe->second_sum) {
+          pe->n_second++;
+        } else if (s < pe->second_sum) {
+          pe->second_sum = s;
+          pe->n_second = 1;
+        }
+        ++cur;
+      }
+      ++i1;
+    }
+  }
+}
+
+typedef struct { uint32_t rid, ref_start, ref_end; } span_t;
+
+/* GetRefStartEndPositionForReadFromMapping, non-SAM non-split branches
+ * (mapping_generator.h:657-717, 762-793, 855-916). strand 0 = +. */
+static span_t ref_start_end(const ora_ctx *c, const draft_t *d, int strand, const char *read_seq, int L) {
+  const int e = c->p.error_threshold;
+  const uint32_t rid = (uint32_t)(d->position >> 32), ref_pos = (uint32_t)d->position;
+  const uint32_t rl = c->ref->len[rid];
+  uint32_t vw = ref_pos + 1 > (uint32_t)(L + e) ? ref_pos + 1 - (uint32_t)L - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)L;
+  int start = strand == 0 ? 0 : e;
+  ora_banded_traceback(e, d->num_errors, c->ref->seq[rid] + vw, read_seq, L, &start);
+  span_t s;
+  s.rid = rid;
+  s.ref_start = vw + (uint32_t)start;
+  s.ref_end = ref_pos; /* + strand: :790; - strand: vw + (ref_pos - vw + 1) - 1, :914-915 */
+  return s;
+}
+
+/* GetMAPQForSingleEndRead, non-split (mapping_generator.h:920-1022). */
+static uint8_t mapq_single(const ora_ctx *c, int num_errors, uint16_t alignment_length, int read_length,
+                           int max_diff, const meta_t *m) {
+  int mapq_coef_length = 50;
+  int mapq_coef_fraction = (int)log((double)mapq_coef_length);
+  alignment_length = alignment_length > read_length ? alignment_length : (uint16_t)read_length;
+  double alignment_identity = 1 - (double)num_errors / alignment_length;
+  int mapq = 0;
+  int second = m->second_err;
+  if (m->n_best > 1) {
+    /* mapq stays 0 */
+  } else {
+    if (second > num_errors + max_diff) second = num_errors + max_diff;
+    double tmp = alignment_length < mapq_coef_length ? 1.0 : mapq_coef_fraction / log((double)alignment_length);
+    tmp *= alignment_identity * alignment_identity;
+    mapq = (int)(5 * 6.02 * (second - num_errors) * tmp * tmp + 0.499);
+  }
+  if (m->n_second > 0) mapq -= (int)(4.343 * log((double)(m->n_second + 1)) + 0.499);
+  if (mapq > 60) mapq = 60;
+  if (mapq < 0) mapq = 0;
+  if (m->rep_len > 0) {
+    double frac_rep = (m->rep_len) / (double)read_length;
+    if (m->rep_len >= (uint32_t)read_length) frac_rep = 0.999;
+    if (alignment_identity <= 0.95) mapq = (int)(mapq * (1 - sqrt(frac_rep)) + 0.499);
+    else if (alignment_identity <= 0.97) mapq = (int)(mapq * (1 - frac_rep) + 0.499);
+    else if (alignment_identity >= 0.999) mapq = (int)(mapq * (1 - frac_rep * frac_rep * frac_rep * frac_rep) + 0.499);
+    else mapq = (int)(mapq * (1 - frac_rep * frac_rep) + 0.499);
+  }
+  (void)c;
+  return (uint8_t)mapq;
+}
+
+/* GetMAPQForPairedEndRead, non-split (mapping_generator.h:1027-1192). */
+static uint8_t mapq_paired(const ora_ctx *c, int err1, int err2, uint16_t al1, uint16_t al2, int len1,
+                           int len2, int force_mapq, const pe_meta_t *pe, const meta_t *m1, const meta_t *m2) {
+  uint8_t mapq_pe = 0;
+  int min_unpaired = m1->min_err + m2->min_err + 3;
+  if (pe->n_best <= 1) {
+    int adj = pe->second_sum < min_unpaired ? pe->second_sum : min_unpaired;
+    mapq_pe = (uint8_t)((int)(5 * 6.02 * (adj - pe->min_sum) / (1) + .499));
+    if (pe->n_second > 0) mapq_pe = (uint8_t)(mapq_pe - (int)(4.343 * log((double)(pe->n_second + 1)) + 0.499));
+    if (mapq_pe > 60) mapq_pe = 60;
+    int rep = (int)(m1->rep_len + m2->rep_len);
+    if (rep > 0) {
+      double total = len1 + len2;
+      double frac_rep = (double)rep / total;
+      if (rep >= total) frac_rep = 0.999;
+      double id1 = 1 - (double)err1 / (len1 > al1 ? len1 : al1);
+      double id2 = 1 - (double)err2 / (len2 > al2 ? len2 : al2);
+      double id = id1 < id2 ? id1 : id2;
+      if (id <= 0.95) mapq_pe = (uint8_t)(mapq_pe * (1 - sqrt(frac_rep)) + 0.499);
+      else if (id <= 0.97) mapq_pe = (uint8_t)(mapq_pe * (1 - frac_rep) + 0.499);
+      else if (id >= 0.999) mapq_pe = (uint8_t)(mapq_pe * (1 - frac_rep * frac_rep * frac_rep * frac_rep) + 0.499);
+      else mapq_pe = (uint8_t)(mapq_pe * (1 - frac_rep * frac_rep) + 0.499);
+    }
+  }
+  uint8_t mapq1 = mapq_single(c, err1, al1, len1, 2, m1);
+  uint8_t mapq2 = mapq_single(c, err2, al2, len2, 2, m2);
+  mapq1 = (uint8_t)(mapq1 > mapq_pe ? (double)mapq1 : mapq_pe < mapq1 + mapq_pe * 0.65 ? (double)mapq_pe : mapq1 + mapq_pe * 0.65);
+  mapq2 = (uint8_t)(mapq2 > mapq_pe ? (double)mapq2 : mapq_pe < mapq2 + mapq_pe * 0.65 ? (double)mapq_pe : mapq2 + mapq_pe * 0.65);
+  mapq1 = (uint8_t)(mapq1 * 1.2);
+  if (mapq1 > 60) mapq1 = 60;
+  mapq2 = (uint8_t)(mapq2 * 1.2);
+  if (mapq2 > 60) mapq2 = 60;
+  uint8_t mapq = mapq1 < mapq2 ? mapq1 : mapq2;
+  if (mapq < 60 && force_mapq >= 0 && force_mapq < mapq) mapq = (uint8_t)force_mapq;
+  return mapq;
+}
+
+/* ------------------------------------------------------------------------- */
+/* K0: adapter trimming (chromap.cc:176-289, sequence_batch.h:136-151)         */
+/* ------------------------------------------------------------------------- */
+/* memmem-like std::string::find(s, pos, n) on a buffer of length hl */
+static long find_from(const char *hay, size_t hl, const char *needle, size_t nl, size_t from) {
+  if (nl == 0) return from <= hl ? (long)from : -1;
+  if (hl < nl) return -1;
+  for (size_t i = from; i + nl <= hl; ++i)
+    if (hay[i] == needle[0] && memcmp(hay + i, needle, nl) == 0) return (long)i;
+  return -1;
+}
+
+/* r1/r2: forward reads, n1/n2: their reverse complements; lengths updated in place.
+ * The negative strings are trimmed from the FRONT (caller offsets the pointer). */
+static int trim_adapter_pe(const ora_ctx *c, const char *r1, uint32_t *len1, const char *n1,
+                           const char *r2, uint32_t *len2, const char *n2, uint32_t *nfront1,
+                           uint32_t *nfront2) {
+  const uint32_t raw1 = *len1, raw2 = *len2;
+  const int swap = !(raw1 <= raw2);
+  const char *read1 = swap ? r2 : r1;
+  const char *neg2 = swap ? n1 : n2;
+  const uint32_t l1 = swap ? raw2 : raw1, l2 = swap ? raw1 : raw2;
+  const int min_overlap = c->p.min_read_length;
+  const int seed = min_overlap / 2;
+  const int err_thr = 1;
+  for (int si = 0; si < err_thr + 1; ++si) {
+    long sp = find_from(neg2, l2, read1 + si * seed, (size_t)seed, 0);
+    while (sp >= 0) {
+      const int before_ok = (size_t)sp >= (size_t)(si * seed);
+      const int overlap_ok = (int)(l2 - (uint32_t)sp + (uint32_t)(seed * si)) >= min_overlap;
+      if (!before_ok || !overlap_ok) {
+        sp = find_from(neg2, l2, read1 + si * seed, (size_t)seed, (size_t)sp + 1);
+        continue;
+      }
+      int can = 1, ne = 0;
+      for (int i = 0; i < seed * si; ++i) {
+        if (neg2[sp - si * seed + i] != read1[i]) ++ne;
+        if (ne > err_thr) { can = 0; break; }
+      }
+      for (uint32_t i = (uint32_t)seed; i + (uint32_t)sp < l2 && (uint32_t)(si * seed) + i < l1; ++i) {
+        if (neg2[sp + i] != read1[si * seed + i]) ++ne;
+        if (ne > err_thr) { can = 0; break; }
+      }
+      if (can) {
+        int overlap = (int)(l2 - (uint32_t)sp + (uint32_t)(si * seed));
+        int off2 = 0;
+        if (overlap > (int)l1) { off2 = overlap - (int)l1; overlap = (int)l1; }
+        int t1 = swap ? overlap + off2 : overlap; /* new length for batch1 read */
+        int t2 = swap ? overlap : overlap + off2;
+        if (t1 < (int)raw1) { *nfront1 = raw1 - (uint32_t)t1; *len1 = (uint32_t)t1; }
+        if (t2 < (int)raw2) { *nfront2 = raw2 - (uint32_t)t2; *len2 = (uint32_t)t2; }
+        return 1;
+      }
+      sp = find_from(neg2, l2, read1 + si * seed, (size_t)seed, (size_t)sp + 1);
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* the pair loop body (chromap.h:892-1143)                                      */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  meta_t m1, m2;
+  pe_meta_t pe;
+  char *neg1, *neg2;
+  char *fw1, *fw2;
+  size_t cap1, cap2;
+  int *best_idx;
+} work_t;
+
+static void prep_negative(const char *s, uint32_t len, char *out) { /* sequence_batch.h:123-134 */
+  for (uint32_t i = 0; i < len; ++i) out[i] = u2c((uint8_t)3 ^ c2u(s[len - i - 1]));
+  out[len] = 0;
+}
+
+static void sort_drafts(vdraft *v) {
+  /* SortMappingsByPositions (mapping_metadata.h:70-78) uses unstable std::sort on position
+   * only.  Draft mappings with equal end positions on one strand are possible (two
+   * candidates within e of each other); their relative order only matters when both
+   * are co-best, which changes which index pair is recorded but not the record emitted
+   * unless their error counts differ -- in which case only one of them is best.  A stable
+   * order is used here and in the HIP path. */
+  if (v->n > 1) {
+    /* insertion sort keeps equal keys in emission order */
+    for (size_t i = 1; i < v->n; ++i) {
+      draft_t x = v->a[i];
+      size_t j = i;
+      while (j > 0 && v->a[j - 1].position > x.position) { v->a[j] = v->a[j - 1]; --j; }
+      v->a[j] = x;
+    }
+  }
+  (void)cmp_draft_pos;
+}
+
+static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t pair_index,
+                         uint32_t read_id, const char *s1, uint32_t len1, const char *s2,
+                         uint32_t len2, ora_record *out, ora_stats *st, ora_trace *tr) {
+  const ora_params *p = &c->p;
+  if (tr) memset(tr, 0, sizeof(*tr));
+  if (len1 < (uint32_t)p->min_read_length || len2 < (uint32_t)p->min_read_length) return 0; /* :911-916 */
+  if (len1 + 1 > wk->cap1) { wk->cap1 = len1 + 64; wk->neg1 = (char *)realloc(wk->neg1, wk->cap1); wk->fw1 = (char *)realloc(wk->fw1, wk->cap1); }
+  if (len2 + 1 > wk->cap2) { wk->cap2 = len2 + 64; wk->neg2 = (char *)realloc(wk->neg2, wk->cap2); wk->fw2 = (char *)realloc(wk->fw2, wk->cap2); }
+  memcpy(wk->fw1, s1, len1); wk->fw1[len1] = 0;
+  memcpy(wk->fw2, s2, len2); wk->fw2[len2] = 0;
+  prep_negative(s1, len1, wk->neg1);
+  prep_negative(s2, len2, wk->neg2);
+  const char *neg1 = wk->neg1, *neg2 = wk->neg2;
+  if (p->trim_adapters) {
+    uint32_t f1 = 0, f2 = 0;
+    if (trim_adapter_pe(c, wk->fw1, &len1, wk->neg1, wk->fw2, &len2, wk->neg2, &f1, &f2)) {
+      if (st) st->num_trimmed++;
+      neg1 += f1; neg2 += f2;            /* erase from the front of the revcomp */
+      wk->fw1[len1] = 0; wk->fw2[len2] = 0;
+    }
+  }
+  const char *r1 = wk->fw1, *r2 = wk->fw2;
+  meta_t *m1 = &wk->m1, *m2 = &wk->m2;
+  meta_prepare(m1, len1);
+  meta_prepare(m2, len2);
+  m1->n_mm = ora_minimizers(r1, len1, pair_index, c->idx->k, c->idx->w, m1->mm_hash, m1->mm_hit);
+  m2->n_mm = ora_minimizers(r2, len2, pair_index, c->idx->k, c->idx->w, m2->mm_hash, m2->mm_hit);
+  if (st) st->num_minimizers += (uint64_t)(m1->n_mm + m2->n_mm);
+  if (tr) { tr->len1 = len1; tr->len2 = len2; tr->n_mm1 = (uint32_t)m1->n_mm; tr->n_mm2 = (uint32_t)m2->n_mm; tr->force_mapq = -1; }
+  if (m1->n_mm == 0 || m2->n_mm == 0) return 0; /* :936 */
+  gen_candidates(c, m1, st);
+  gen_candidates(c, m2, st);
+  int supp = 0;
+  if (!p->split_alignment) supp = supplement_candidates(c, m1, m2, st); /* :1020-1034 */
+  size_t nc1 = m1->pos_cand.n + m1->neg_cand.n, nc2 = m2->pos_cand.n + m2->neg_cand.n;
+  if (nc1 > 0 && nc2 > 0 && !p->split_alignment) { /* :1036-1052 */
+    vcand t;
+    t = m1->pos_cand; m1->pos_cand = m1->pos_buf; m1->pos_buf = t; m1->pos_cand.n = 0;
+    t = m1->neg_cand; m1->neg_cand = m1->neg_buf; m1->neg_buf = t; m1->neg_cand.n = 0;
+    t = m2->pos_cand; m2->pos_cand = m2->pos_buf; m2->pos_buf = t; m2->pos_cand.n = 0;
+    t = m2->neg_cand; m2->neg_cand = m2->neg_buf; m2->neg_buf = t; m2->neg_cand.n = 0;
+    reduce_one_direction((uint32_t)p->max_insert_size, &m1->pos_buf, &m2->neg_buf, &m1->pos_cand, &m2->neg_cand);
+    reduce_one_direction((uint32_t)p->max_insert_size, &m1->neg_buf, &m2->pos_buf, &m1->neg_cand, &m2->pos_cand);
+    nc1 = m1->pos_cand.n + m1->neg_cand.n;
+    nc2 = m2->pos_cand.n + m2->neg_cand.n;
+  }
+  if (tr) { tr->n_cand1 = (uint32_t)nc1; tr->n_cand2 = (uint32_t)nc2; tr->rep1 = m1->rep_len; tr->rep2 = m2->rep_len; }
+  if (!(nc1 > 0 && nc2 > 0)) return 0;
+  if (st) st->num_candidates += nc1 + nc2;
+  gen_draft_mappings(c, m1, r1, neg1, len1, st);
+  gen_draft_mappings(c, m2, r2, neg2, len2, st);
+  const size_t nd1 = m1->pos_map.n + m1->neg_map.n, nd2 = m2->pos_map.n + m2->neg_map.n;
+  if (tr) {
+    tr->n_draft1 = (uint32_t)nd1; tr->n_draft2 = (uint32_t)nd2;
+    tr->min_err1 = m1->min_err; tr->min_err2 = m2->min_err; tr->nbest1 = m1->n_best; tr->nbest2 = m2->n_best;
+    tr->second1 = m1->second_err; tr->second2 = m2->second_err; tr->nsecond1 = m1->n_second; tr->nsecond2 = m2->n_second;
+  }
+  if (!(nd1 > 0 && nd2 > 0)) return 0; /* :1092-1093 */
+  if (!p->split_alignment) {
+    sort_drafts(&m1->pos_map); sort_drafts(&m1->neg_map);
+    sort_drafts(&m2->pos_map); sort_drafts(&m2->neg_map);
+  }
+  const int force_mapq = supp != 0 ? 0 : -1;
+  /* GenerateBestMappingsForPairedEndRead (mapping_generator.h:160-253) */
+  pe_meta_t *pe = &wk->pe;
+  pe->min_sum = 2 * p->error_threshold + 1; pe->n_best = 0;
+  pe->second_sum = 2 * p->error_threshold + 1; pe->n_second = 0;
+  pe->best[0].n = pe->best[1].n = 0;
+  best_one_direction(c, 0, m1, m2, len1, len2, pe);
+  best_one_direction(c, 1, m1, m2, len1, len2, pe);
+  if (tr) { tr->min_sum = pe->min_sum; tr->nbest = pe->n_best; tr->second_sum = pe->second_sum; tr->nsecond = pe->n_second; tr->force_mapq = force_mapq; }
+  long nout = 0;
+  if (!(pe->n_best > p->drop_repetitive_reads)) {
+    const int K = p->max_num_best_mappings;
+    for (int i = 0; i < K; ++i) wk->best_idx[i] = i;
+    if (pe->n_best > K) {
+      for (int i = K; i < pe->n_best; ++i) {
+        int j = mt_uniform(rng, i);
+        if (j < K) wk->best_idx[j] = i;
+      }
+      /* std::sort(best_mapping_indices) */
+      for (int i = 1; i < K; ++i) { int x = wk->best_idx[i], j = i; while (j > 0 && wk->best_idx[j - 1] > x) { wk->best_idx[j] = wk->best_idx[j - 1]; --j; } wk->best_idx[j] = x; }
+    }
+    int best_mapping_index = 0, reported = 0;
+    const int to_report = K < pe->n_best ? K : pe->n_best;
+    const uint8_t is_unique = (pe->n_best == 1 || m1->n_best == 1 || m2->n_best == 1) ? 1 : 0;
+    for (int dir = 0; dir < 2 && reported != to_report; ++dir) {
+      /* ProcessBestMappingsForPairedEndReadOnOneDirection (mapping_generator.h:487-653) */
+      const vdraft *a = dir == 0 ? &m1->pos_map : &m1->neg_map;
+      const vdraft *b = dir == 0 ? &m2->neg_map : &m2->pos_map;
+      const vpair *best = &pe->best[dir];
+      for (size_t mi = 0; mi < best->n; ++mi) {
+        const draft_t *d1 = &a->a[best->a[mi].a], *d2 = &b->a[best->a[mi].b];
+        if (d1->num_errors + d2->num_errors > pe->min_sum) continue;
+        if (best_mapping_index == wk->best_idx[reported]) {
+          span_t s1 = ref_start_end(c, d1, dir == 0 ? 0 : 1, dir == 0 ? r1 : neg1, (int)len1);
+          span_t s2 = ref_start_end(c, d2, dir == 0 ? 1 : 0, dir == 0 ? neg2 : r2, (int)len2);
+          const uint16_t al1 = (uint16_t)(s1.ref_end - s1.ref_start + 1); /* GetFragmentLength, mapping_in_memory.h:55-57 */
+          const uint16_t al2 = (uint16_t)(s2.ref_end - s2.ref_start + 1);
+          const uint8_t mapq = mapq_paired(c, d1->num_errors, d2->num_errors, al1, al2, (int)len1, (int)len2,
+                                           force_mapq, pe, m1, m2);
+          /* EmplaceBackPairedEndMappingRecord (mapping_generator.cc:111-125) with
+           * PairedEndMappingInMemory getters (mapping_in_memory.h:64-108) */
+          ora_record *r = &out[nout++];
+          r->read_id = read_id;
+          r->rid = s1.rid;
+          const span_t *ps = dir == 0 ? &s1 : &s2; /* the + strand read */
+          const span_t *ns = dir == 0 ? &s2 : &s1;
+          r->fragment_start = ps->ref_start;
+          r->fragment_length = (uint16_t)(int)(ns->ref_end - ps->ref_start + 1);
+          r->mapq = mapq & 63; /* mapq_ : 6 (bed_mapping.h:185) */
+          r->direction = dir == 0 ? 1 : 0;
+          r->is_unique = is_unique;
+          r->num_dups = 1;
+          r->pos_aln_len = (uint16_t)(ps->ref_end - ps->ref_start + 1);
+          r->neg_aln_len = (uint16_t)(ns->ref_end - ns->ref_start + 1);
+          ++reported;
+          if (reported == (K < pe->n_best ? K : pe->n_best)) break;
+        }
+        ++best_mapping_index;
+      }
+    }
+  }
+  if (st) {
+    if (pe->n_best == 1) st->num_uniquely_mapped_reads += 2;
+    st->num_mappings += 2 * (uint64_t)(pe->n_best < p->max_num_best_mappings ? pe->n_best : p->max_num_best_mappings);
+    if (pe->n_best > 0) st->num_mapped_reads += 2;
+  }
+  return nout;
+}
+
+static void work_init(work_t *wk, const ora_params *p) {
+  memset(wk, 0, sizeof(*wk));
+  wk->best_idx = (int *)calloc((size_t)(p->max_num_best_mappings > 0 ? p->max_num_best_mappings : 1), sizeof(int));
+}
+static void work_free(work_t *wk) {
+  meta_free(&wk->m1); meta_free(&wk->m2);
+  free(wk->pe.best[0].a); free(wk->pe.best[1].a);
+  free(wk->neg1); free(wk->neg2); free(wk->fw1); free(wk->fw2); free(wk->best_idx);
+}
+
+/* Reservoir-sampling RNG scope.  In the reference the generator is declared inside the
+ * parallel region (chromap.h:863) and is therefore FIRSTPRIVATE in every task the
+ * `taskloop grainsize(5000)` (chromap.h:892) generates: each task starts from a fresh
+ * copy of mt19937(11) and consumes it over its own iterations only.  libgomp splits a
+ * batch of n pairs (n <= 500000 = read_batch_size_, chromap.h:182) into T = n/5000 tasks
+ * (1 if T <= 1) of n/T iterations, the first n%T tasks getting one more.  Verified with
+ * GCC 11 libgomp at 1..8 threads; the outcome does not depend on the thread count. */
+#define ORA_REF_BATCH 500000u
+#define ORA_GRAIN 5000u
+typedef struct { uint32_t lo, hi; } chunk_t;
+static chunk_t *make_chunks(uint32_t n, size_t *nchunks) {
+  size_t cap = (size_t)(n / ORA_GRAIN) + (size_t)(n / ORA_REF_BATCH) + 4, k = 0;
+  chunk_t *ch = (chunk_t *)malloc(cap * sizeof(chunk_t));
+  for (uint32_t b0 = 0; b0 < n; b0 += ORA_REF_BATCH) {
+    const uint32_t bn = n - b0 < ORA_REF_BATCH ? n - b0 : ORA_REF_BATCH;
+    uint32_t T = bn / ORA_GRAIN;
+    if (T <= 1) { ch[k].lo = b0; ch[k].hi = b0 + bn; ++k; continue; }
+    const uint32_t d = bn / T, m = bn % T;
+    uint32_t s = b0;
+    for (uint32_t t = 0; t < T; ++t) {
+      const uint32_t sz = d + (t < m ? 1 : 0);
+      ch[k].lo = s; ch[k].hi = s + sz; ++k;
+      s += sz;
+    }
+  }
+  *nchunks = k;
+  return ch;
+}
+
+long ora_map_pairs_mt(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1,
+                      const uint32_t *r1_off, const char *r2, const uint32_t *r2_off,
+                      ora_record *out, ora_stats *stats) {
+  if (threads < 1) threads = 1;
+  const int K = c->p.max_num_best_mappings > 0 ? c->p.max_num_best_mappings : 1;
+  size_t nch = 0;
+  chunk_t *ch = make_chunks(n, &nch);
+  long *cnt = (long *)calloc(nch + 1, sizeof(long));
+  ora_record **bufs = (ora_record **)calloc(nch + 1, sizeof(ora_record *));
+  ora_stats *sts = (ora_stats *)calloc((size_t)threads, sizeof(ora_stats));
+#pragma omp parallel num_threads(threads)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    work_t wk;
+    work_init(&wk, &c->p);
+#pragma omp for schedule(dynamic, 1)
+    for (long ci = 0; ci < (long)nch; ++ci) {
+      mt19937_t rng;
+      mt_seed(&rng, 11);
+      const uint32_t lo = ch[ci].lo, hi = ch[ci].hi;
+      ora_record *buf = (ora_record *)malloc(((size_t)(hi - lo) * K + 1) * sizeof(ora_record));
+      long k = 0;
+      for (uint32_t i = lo; i < hi; ++i)
+        k += map_one_pair(c, &wk, &rng, i, first_read_id + i, r1 + r1_off[i], r1_off[i + 1] - r1_off[i],
+                          r2 + r2_off[i], r2_off[i + 1] - r2_off[i], buf + k, &sts[t],
+                          c->trace ? &c->trace[i] : NULL);
+      bufs[ci] = buf;
+      cnt[ci] = k;
+    }
+    work_free(&wk);
+  }
+  long total = 0;
+  for (size_t ci = 0; ci < nch; ++ci) {
+    if (bufs[ci]) { memcpy(out + total, bufs[ci], (size_t)cnt[ci] * sizeof(ora_record)); free(bufs[ci]); }
+    total += cnt[ci];
+  }
+  for (int t = 0; t < threads; ++t) {
+    if (stats) {
+      uint64_t *d = (uint64_t *)stats, *s2 = (uint64_t *)&sts[t];
+      for (size_t i = 0; i < sizeof(ora_stats) / 8; ++i) d[i] += s2[i];
+    }
+  }
+  free(cnt); free(bufs); free(sts); free(ch);
+  return total;
+}
+
+long ora_map_pairs(ora_ctx *c, uint32_t n, uint32_t first_read_id, const char *r1,
+                   const uint32_t *r1_off, const char *r2, const uint32_t *r2_off,
+                   ora_record *out, ora_stats *stats) {
+  return ora_map_pairs_mt(c, 1, n, first_read_id, r1, r1_off, r2, r2_off, out, stats);
+}
+
+/* ------------------------------------------------------------------------- */
+/* post-processing + BED (mapping_writer.h:166-376, mapping_writer.cc:72-83)    */
+/* ------------------------------------------------------------------------- */
+/* rid, then PairedEndMappingWithoutBarcode::operator< (bed_mapping.h:208-215) */
+static int cmp_rec(const void *a, const void *b) {
+  const ora_record *x = (const ora_record *)a, *y = (const ora_record *)b;
+#define CMPF(f) if (x->f != y->f) return x->f < y->f ? -1 : 1
+  CMPF(rid); CMPF(fragment_start); CMPF(fragment_length); CMPF(mapq); CMPF(direction);
+  CMPF(is_unique); CMPF(read_id); CMPF(pos_aln_len); CMPF(neg_aln_len);
+#undef CMPF
+  return 0;
+}
+
+static void bed_line(FILE *f, const ora_ref *ref, const ora_params *p, ora_record r, uint32_t dups) {
+  r.num_dups = (uint8_t)(dups > 255 ? 255 : dups);
+  if (p->tn5_shift) { /* bed_mapping.h:224-229 */
+    r.fragment_start += 4;
+    r.pos_aln_len -= 4;
+    r.fragment_length -= 9;
+    r.neg_aln_len -= 5;
+  }
+  fprintf(f, "%s\t%u\t%u\tN\t%u\t%s\t%u\n", ref->name[r.rid], r.fragment_start,
+          r.fragment_start + r.fragment_length, (unsigned)r.mapq, r.direction ? "+" : "-", (unsigned)r.num_dups);
+}
+
+long ora_write_bed_pe(const ora_ref *ref, const ora_params *p, ora_record *rec, long n, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  qsort(rec, (size_t)n, sizeof(ora_record), cmp_rec);
+  long lines = 0;
+  if (p->low_mem && p->remove_pcr_duplicates) {
+    long i = 0;
+    while (i < n) {
+      ora_record last = rec[i];
+      uint32_t dups = 1;
+      long j = i + 1;
+      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start &&
+             rec[j].fragment_length == last.fragment_length) {
+        ++dups;
+        if (rec[j].mapq > last.mapq) last = rec[j]; /* :268-270; keys used by == are equal */
+        ++j;
+      }
+      if (last.mapq >= p->mapq_threshold) { bed_line(f, ref, p, last, dups); ++lines; }
+      i = j;
+    }
+  } else if (p->low_mem) {
+    for (long i = 0; i < n; ++i)
+      if (rec[i].mapq >= p->mapq_threshold) { bed_line(f, ref, p, rec[i], 1); ++lines; }
+  } else {
+    /* in-memory path, no dedup (chromap.h:1322-1355 with remove_pcr_duplicates off):
+     * Tn5 shift happens BEFORE the sort there, but with no dedup and a shift that is
+     * monotone in (start,length) per direction... not equivalent in general; only the
+     * non-Tn5 default path is used in tests. */
+    for (long i = 0; i < n; ++i)
+      if (rec[i].mapq >= p->mapq_threshold) { bed_line(f, ref, p, rec[i], rec[i].num_dups); ++lines; }
+  }
+  fclose(f);
+  return lines;
+}

@@ -1,0 +1,161 @@
+/*
+ * chromap_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A from-scratch, sequential C restatement of the reference's per-read mapping hot
+ * path (haowenz/chromap v0.3.3-r521, /root/reference/src).  It exists to check the
+ * HIP path and to serve as the "port" CPU baseline in bench.py.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (chromap_amd/) never links, loads or calls anything in oracle/.
+ *
+ * Parity status: PINNED -- tests/test_oracle_golden.py checks this code against
+ * outputs of the reference itself (oracle/_ref/chromap, built unchanged from
+ * /root/reference by oracle/Makefile) committed under tests/golden/.
+ *
+ * Each function cites the reference file:line it follows.
+ */
+#ifndef CHROMAP_ORACLE_H_
+#define CHROMAP_ORACLE_H_
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- index (index.cc:91-169, khash.h:358-386) ---------------------------- */
+typedef struct ora_index {
+  int k, w;
+  uint32_t n_keys;
+  uint32_t n_buckets, size, n_occupied, upper_bound;
+  uint32_t *flags;
+  uint64_t *keys, *vals;
+  uint32_t n_occ;
+  uint64_t *occ;
+} ora_index;
+
+/* ---- reference sequences (sequence_batch.cc:84-120) ---------------------- */
+typedef struct ora_ref {
+  uint32_t n_seq;
+  char **name;
+  char **seq; /* raw bytes, case preserved, NUL terminated */
+  uint32_t *len;
+} ora_ref;
+
+/* subset of MappingParameters used on the path (mapping_parameters.h:18-89) */
+typedef struct ora_params {
+  int error_threshold;       /* -e, 8 */
+  int min_num_seeds;         /* -s, 2 */
+  int max_seed_freq0;        /* -f, 500 */
+  int max_seed_freq1;        /* 1000 */
+  int max_insert_size;       /* -l, 1000 (atac/chip 2000) */
+  int min_read_length;       /* 30 */
+  int max_num_best_mappings; /* 1 */
+  int drop_repetitive_reads; /* 500000 */
+  int trim_adapters;
+  int split_alignment;
+  int mapq_threshold;        /* -q, 30 */
+  int remove_pcr_duplicates;
+  int tn5_shift;
+  int low_mem;
+} ora_params;
+
+/* constructor arguments of PairedEndMappingWithoutBarcode (bed_mapping.h:191-206)
+ * plus rid (implicit vector index in the reference, mapping_generator.cc:116). */
+typedef struct ora_record {
+  uint32_t read_id;
+  uint32_t rid;
+  uint32_t fragment_start;
+  uint16_t fragment_length;
+  uint8_t mapq; /* already reduced to 6 bits */
+  uint8_t direction;
+  uint8_t is_unique;
+  uint8_t num_dups;
+  uint16_t pos_aln_len;
+  uint16_t neg_aln_len;
+} ora_record;
+
+/* counters of Chromap::OutputMappingStatistics (chromap.cc:808-823) */
+typedef struct ora_stats {
+  uint64_t num_candidates, num_mappings, num_mapped_reads, num_uniquely_mapped_reads;
+  uint64_t probe_steps;   /* khash buckets visited (16 B each) */
+  uint64_t occ_reads;     /* occurrence-table entries read (8 B each) */
+  uint64_t lookups;       /* kh_get calls */
+  uint64_t num_minimizers;
+  uint64_t num_verifications; /* banded alignments run */
+  uint64_t num_shortcut;      /* reads resolved by the all-minimizer shortcut */
+  uint64_t num_rescue;        /* mate-rescue strand searches */
+  uint64_t num_trimmed;
+} ora_stats;
+
+typedef struct ora_ctx ora_ctx;
+
+void ora_default_params(ora_params *p);
+void ora_preset(ora_params *p, const char *preset); /* chromap_driver.cc:247-275 */
+
+uint64_t ora_hash64(uint64_t key, uint64_t mask); /* utils.h:76-85 */
+
+/* minimizer_generator.cc:7-139.  out arrays need capacity >= len. returns count. */
+int ora_minimizers(const char *seq, uint32_t len, uint32_t seq_index, int k, int w,
+                   uint64_t *out_hash, uint64_t *out_hit);
+
+int ora_index_load(const char *path, ora_index *idx);
+int ora_index_save(const char *path, const ora_index *idx);
+/* index.cc:12-89 with khash.h:246-350 put/resize replayed, so the file is byte-identical */
+int ora_index_build(const ora_ref *ref, int k, int w, ora_index *idx);
+void ora_index_free(ora_index *idx);
+/* khash.h:232-245 with hash/eq of index_utils.h:13-17. returns bucket or n_buckets; *steps += visited */
+uint32_t ora_kh_get(const ora_index *idx, uint64_t key, uint64_t *steps);
+
+int ora_ref_load(const char *fasta_path, ora_ref *ref);
+void ora_ref_free(ora_ref *ref);
+
+/* alignment.cc:141-192 */
+int ora_banded_align(int e, const char *pattern, const char *text, int read_length,
+                     int *mapping_end_position);
+/* alignment.cc:656-718 */
+void ora_banded_traceback(int e, int min_num_errors, const char *pattern, const char *text,
+                          int read_length, int *mapping_start_position);
+
+ora_ctx *ora_create(const ora_index *idx, const ora_ref *ref, const ora_params *p);
+void ora_destroy(ora_ctx *c);
+
+/* Body of the taskloop chromap.h:892-1143 for the n pairs of one input file (read
+ * batches of 500000 pairs, taskloop tasks of ~5000 pairs, each task owning a fresh
+ * std::mt19937(11) -- see make_chunks() in the .c file).  Reads are concatenated ASCII
+ * with n+1 offsets.  Returns number of records written (capacity must be
+ * >= n * max_num_best_mappings).  stats are accumulated. */
+long ora_map_pairs(ora_ctx *c, uint32_t n, uint32_t first_read_id, const char *r1,
+                   const uint32_t *r1_off, const char *r2, const uint32_t *r2_off,
+                   ora_record *out, ora_stats *stats);
+/* Same work with the tasks spread over OpenMP threads (cpu_baseline leg); results are
+ * identical to the sequential call, as in the reference at any -t. */
+long ora_map_pairs_mt(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id,
+                      const char *r1, const uint32_t *r1_off, const char *r2,
+                      const uint32_t *r2_off, ora_record *out, ora_stats *stats);
+
+/* per-pair trace for stage-level comparisons with the HIP path */
+typedef struct ora_trace {
+  uint32_t len1, len2;           /* read lengths after trimming */
+  uint32_t n_mm1, n_mm2;         /* minimizers */
+  uint32_t n_cand1, n_cand2;     /* candidates entering verification */
+  uint32_t n_draft1, n_draft2;   /* draft mappings */
+  int32_t min_err1, min_err2, nbest1, nbest2, second1, second2, nsecond1, nsecond2;
+  uint32_t rep1, rep2;           /* repetitive_seed_length */
+  int32_t min_sum, nbest, second_sum, nsecond;
+  int32_t force_mapq;
+} ora_trace;
+void ora_set_trace(ora_ctx *c, ora_trace *trace /* n entries, or NULL */);
+
+/* mapping_writer.h:166-376 (low-mem) / chromap.h:1322-1355 (in-memory) + writer
+ * mapping_writer.cc:72-117 (PE bulk BED).  Sorts records in place. Returns #lines. */
+long ora_write_bed_pe(const ora_ref *ref, const ora_params *p, ora_record *rec, long n,
+                      const char *out_path);
+
+/* FASTQ/FASTA reader (kseq.h semantics: name up to whitespace, multi-line ok) used by
+ * tests to build the SoA batches. Returns number of records, allocates bases and off. */
+long ora_read_fastx(const char *path, char **bases, uint32_t **off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

