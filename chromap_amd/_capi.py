@@ -1,0 +1,126 @@
+"""ctypes declarations of include/chromap_amd.h and loader of the in-tree HIP library.
+
+The library is libchromap_amd.so next to this file (built by `make -C chromap_amd/csrc`
+or __graft_entry__.build()).  There is no fallback: a missing library is an ImportError-like
+failure at load time, a missing GPU makes cmgpu_create fail with CMGPU_ENODEVICE.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libchromap_amd.so")
+
+
+class IndexView(C.Structure):
+    _fields_ = [("kmer_size", C.c_int32), ("window_size", C.c_int32), ("n_buckets", C.c_uint32),
+                ("flags", C.POINTER(C.c_uint32)), ("keys", C.POINTER(C.c_uint64)), ("vals", C.POINTER(C.c_uint64)),
+                ("n_occurrences", C.c_uint32), ("occurrences", C.POINTER(C.c_uint64))]
+
+
+class RefView(C.Structure):
+    _fields_ = [("n_sequences", C.c_uint32), ("names", C.POINTER(C.c_char_p)),
+                ("sequences", C.POINTER(C.c_void_p)), ("lengths", C.POINTER(C.c_uint32))]
+
+
+PARAM_FIELDS = ("error_threshold", "min_num_seeds", "max_seed_frequency0", "max_seed_frequency1", "max_insert_size",
+                "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
+                "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_memory_mode",
+                "read_batch_size", "taskloop_grain_size")
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in PARAM_FIELDS]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint32), ("first_read_id", C.c_uint32), ("read1_bases", C.c_void_p),
+                ("read1_offsets", C.c_void_p), ("read2_bases", C.c_void_p), ("read2_offsets", C.c_void_p)]
+
+
+class Record(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("rid", C.c_uint32), ("fragment_start", C.c_uint32),
+                ("fragment_length", C.c_uint16), ("mapq", C.c_uint8), ("direction", C.c_uint8),
+                ("is_unique", C.c_uint8), ("num_dups", C.c_uint8), ("positive_alignment_length", C.c_uint16),
+                ("negative_alignment_length", C.c_uint16)]
+
+
+STAT_FIELDS = ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "num_minimizers",
+               "probe_steps", "occurrences_read", "num_pairs_rescued", "num_multi_mappers")
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS] + [("reserved", C.c_uint64 * 7)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in STAT_FIELDS}
+
+
+assert C.sizeof(Record) == 24
+
+# every symbol include/chromap_amd.h declares
+SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_destroy",
+           "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_upload_batch", "cmgpu_map_resident",
+           "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench",
+           "cmgpu_last_timings", "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe",
+           "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
+
+_LIB = None
+
+
+def declare(L):
+    """attach argtypes/restypes (shared with tests/hostemu, which exports a subset)"""
+    def sig(name, res, args):
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+    P = C.POINTER
+    sig("cmgpu_default_params", None, [P(Params)])
+    sig("cmgpu_apply_preset", C.c_int, [P(Params), C.c_char_p])
+    sig("cmgpu_create", C.c_int, [P(IndexView), P(RefView), P(Params), C.c_int, P(C.c_void_p)])
+    sig("cmgpu_create_synthetic", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, P(Params),
+                                            C.c_int, P(C.c_void_p)])
+    sig("cmgpu_destroy", C.c_int, [C.c_void_p])
+    sig("cmgpu_last_error", C.c_char_p, [C.c_void_p])
+    sig("cmgpu_map_pairs", C.c_int, [C.c_void_p, P(Batch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
+    sig("cmgpu_upload_batch", C.c_int, [C.c_void_p, P(Batch)])
+    sig("cmgpu_map_resident", C.c_int, [C.c_void_p, P(C.c_uint64), P(Stats)])
+    sig("cmgpu_download_records", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)])
+    sig("cmgpu_generate_resident_batch", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                   C.c_double, C.c_uint64])
+    sig("cmgpu_download_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+    sig("cmgpu_probe_bench", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, P(C.c_double), P(C.c_uint64),
+                                       P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_last_timings", C.c_int, [C.c_void_p, P(C.c_char_p), P(C.c_float), C.c_int])
+    sig("cmgpu_export_reference", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32])
+    sig("cmgpu_reference_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
+    sig("cmgpu_write_bed_pe", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
+    sig("cmgpu_load_index_file", C.c_int, [C.c_char_p, P(IndexView)])
+    sig("cmgpu_free_host_index", None, [P(IndexView)])
+    sig("cmgpu_load_reference_fasta", C.c_int, [C.c_char_p, P(RefView)])
+    sig("cmgpu_free_host_ref", None, [P(RefView)])
+    return L
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C chromap_amd/csrc` (hipcc, gfx950). "
+                               "chromap_amd has no CPU fallback." % LIB_PATH)
+        _LIB = declare(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+def default_params(preset=None, **overrides):
+    L = lib()
+    p = Params()
+    L.cmgpu_default_params(C.byref(p))
+    if preset:
+        if L.cmgpu_apply_preset(C.byref(p), preset.encode()) != 0:
+            raise ValueError("unknown preset %r" % preset)
+    for k, v in overrides.items():
+        if k not in PARAM_FIELDS:
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p

@@ -1,0 +1,484 @@
+// cm_api.hip -- C ABI (include/chromap_amd.h): context, HBM residency of index and
+// reference, per-batch orchestration of the stage kernels.  No CPU path: every entry
+// point that computes needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/chromap_amd.h"
+#include "cm_ctx.h"
+#include "cm_kernels.h"
+#include "cm_mapq_tables.h"
+
+static std::string g_last_error;
+
+#define HIPCHECK(ctx, call)                                                                      \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      cm_set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                     \
+      return CMGPU_EHIP;                                                                         \
+    }                                                                                            \
+  } while (0)
+
+void cm_set_error(cmgpu_ctx *ctx, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  g_last_error = msg;
+}
+
+int DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return 0;
+  if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+  size_t want = bytes + bytes / 4 + 256;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return -1; }
+  }
+  cap = want;
+  return 0;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+extern "C" const char *cmgpu_last_error(const cmgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------------------
+// index re-pack: khash (flags, keys, vals) -> 16-byte {key,val} buckets at the same bucket
+// index; empty -> CM_EMPTY_KEY, deleted -> CM_DELETED_KEY (khash.h:165-173)
+// ---------------------------------------------------------------------------------------
+__global__ void k_repack(const uint32_t *__restrict__ flags, const uint64_t *__restrict__ keys,
+                         const uint64_t *__restrict__ vals, uint64_t *__restrict__ bkt, uint32_t i0, uint32_t n) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = i0 + j;
+  const uint32_t f = (flags[i >> 4] >> ((i & 0xfU) << 1)) & 3u;
+  uint64_t k = keys[j], v = vals[j];
+  if (f & 2u) { k = CM_EMPTY_KEY; v = 0; }
+  else if (f & 1u) { k = CM_DELETED_KEY; v = 0; }
+  bkt[2 * (uint64_t)i] = k;
+  bkt[2 * (uint64_t)i + 1] = v;
+}
+
+static int build_mapq_tables(cmgpu_ctx *c) {
+  // mapping_generator.h:924-925, 963-966: mapq_coef_fraction = (int)log(50) = 3
+  std::vector<double> coef;
+  std::vector<uint32_t> brk;
+  cm_build_len_coef(coef);
+  cm_build_nsec_break(brk);
+  c->n_break = (int)brk.size();
+  if (c->len_coef.ensure(coef.size() * 8) || c->nsec_break.ensure(brk.size() * 4)) return CMGPU_ENOMEM;
+  HIPCHECK(c, hipMemcpy(c->len_coef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(c->nsec_break.p, brk.data(), brk.size() * 4, hipMemcpyHostToDevice));
+  return CMGPU_OK;
+}
+
+int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id) {
+  c->device = device_id;
+  c->hp = *params;
+  if (params->split_alignment) { cm_set_error(c, "split alignment (--preset hic) is not supported yet"); return CMGPU_EINVAL; }
+  if (params->max_num_best_mappings != 1) { cm_set_error(c, "max_num_best_mappings must be 1"); return CMGPU_EINVAL; }
+  if (kmer < 1 || kmer > 28 || window < 1 || window > CM_MAX_W_HOST) { cm_set_error(c, "unsupported k/w"); return CMGPU_EINVAL; }
+  if (params->error_threshold < 1 || params->error_threshold > 15) { cm_set_error(c, "error_threshold must be 1..15"); return CMGPU_EINVAL; }
+  CmParams &p = c->p;
+  p.e = params->error_threshold;
+  p.min_seeds = params->min_num_seeds;
+  p.f0 = params->max_seed_frequency0;
+  p.f1 = params->max_seed_frequency1;
+  p.max_insert = params->max_insert_size;
+  p.min_read_len = params->min_read_length;
+  p.max_best = params->max_num_best_mappings;
+  p.drop_rep = params->drop_repetitive_reads;
+  p.trim = params->trim_adapters;
+  p.k = kmer;
+  p.w = window;
+  p.lanes = p.e < 8 ? 8 : (p.e < 16 ? 4 : 0);  // GetNumVPULanes (mapping_parameters.h:80-88)
+  p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
+  p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
+  HIPCHECK(c, hipStreamCreate(&c->stream));
+  if (c->stats.ensure(CM_ST_N * 8)) return CMGPU_ENOMEM;
+  HIPCHECK(c, hipMemset(c->stats.p, 0, CM_ST_N * 8));
+  for (int i = 0; i < CM_MAX_EVENTS; ++i) HIPCHECK(c, hipEventCreate(&c->ev[i]));
+  return build_mapq_tables(c);
+}
+
+static int select_device(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    cm_set_error(nullptr, "no HIP device available (this library has no CPU path)");
+    return CMGPU_ENODEVICE;
+  }
+  if (device_id < 0 || device_id >= n) { cm_set_error(nullptr, "device_id out of range"); return CMGPU_EINVAL; }
+  if (hipSetDevice(device_id) != hipSuccess) { cm_set_error(nullptr, "hipSetDevice failed"); return CMGPU_EHIP; }
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                            int device_id, cmgpu_ctx **out) {
+  if (!index || !ref || !params || !out) { cm_set_error(nullptr, "null argument"); return CMGPU_EINVAL; }
+  *out = nullptr;
+  int rc = select_device(device_id);
+  if (rc) return rc;
+  const uint32_t nb = index->n_buckets;
+  if (nb == 0 || (nb & (nb - 1))) { cm_set_error(nullptr, "n_buckets must be a power of two"); return CMGPU_EINVAL; }
+  cmgpu_ctx *c = new cmgpu_ctx();
+  rc = cm_ctx_init_common(c, params, index->kmer_size, index->window_size, device_id);
+  if (rc) { g_last_error = c->err; cmgpu_destroy(c); return rc; }
+  // ---- index -> HBM, re-packed in slabs so host staging stays small
+  if (c->bkt.ensure((size_t)nb * 16)) { cm_set_error(nullptr, "out of device memory (index)"); cmgpu_destroy(c); return CMGPU_ENOMEM; }
+  {
+    const size_t fwords = nb < 16 ? 1 : nb >> 4;
+    DevBuf dflags, dk, dv;
+    const uint32_t slab = 1u << 24;
+    if (dflags.ensure(fwords * 4) || dk.ensure((size_t)(nb < slab ? nb : slab) * 8) || dv.ensure((size_t)(nb < slab ? nb : slab) * 8)) {
+      cm_set_error(nullptr, "out of device memory (index staging)"); cmgpu_destroy(c); return CMGPU_ENOMEM;
+    }
+    hipError_t e = hipMemcpy(dflags.p, index->flags, fwords * 4, hipMemcpyHostToDevice);
+    for (uint32_t i0 = 0; e == hipSuccess && i0 < nb; i0 += slab) {
+      const uint32_t m = nb - i0 < slab ? nb - i0 : slab;
+      e = hipMemcpy(dk.p, index->keys + i0, (size_t)m * 8, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(dv.p, index->vals + i0, (size_t)m * 8, hipMemcpyHostToDevice);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_repack, dim3((m + 255) / 256), dim3(256), 0, 0, (const uint32_t *)dflags.p,
+                           (const uint64_t *)dk.p, (const uint64_t *)dv.p, (uint64_t *)c->bkt.p, i0, m);
+        e = hipDeviceSynchronize();
+      }
+      if (i0 + m == nb) break;
+    }
+    dflags.release(); dk.release(); dv.release();
+    if (e != hipSuccess) { cm_set_error(nullptr, std::string("index upload: ") + hipGetErrorString(e)); cmgpu_destroy(c); return CMGPU_EHIP; }
+  }
+  c->bmask = nb - 1;
+  c->n_occ = index->n_occurrences;
+  if (c->occ.ensure((size_t)(c->n_occ ? c->n_occ : 1) * 8)) { cm_set_error(nullptr, "out of device memory (occurrences)"); cmgpu_destroy(c); return CMGPU_ENOMEM; }
+  if (c->n_occ && hipMemcpy(c->occ.p, index->occurrences, (size_t)c->n_occ * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    cm_set_error(nullptr, "occurrence upload failed"); cmgpu_destroy(c); return CMGPU_EHIP;
+  }
+  // ---- reference -> HBM: raw bytes, 64 zero bytes after every sequence
+  c->n_seq = ref->n_sequences;
+  c->h_ref_off.resize(c->n_seq);
+  c->h_ref_len.assign(ref->lengths, ref->lengths + c->n_seq);
+  uint64_t tot = 64;
+  for (uint32_t i = 0; i < c->n_seq; ++i) {
+    c->h_ref_off[i] = tot;
+    tot += (uint64_t)ref->lengths[i] + 64;
+    tot = (tot + 15) & ~15ull;
+  }
+  c->ref_bytes = tot;
+  if (c->ref.ensure(tot) || c->ref_off.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 8) || c->ref_len.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 4)) {
+    cm_set_error(nullptr, "out of device memory (reference)"); cmgpu_destroy(c); return CMGPU_ENOMEM;
+  }
+  hipError_t e = hipMemset(c->ref.p, 0, tot);
+  for (uint32_t i = 0; e == hipSuccess && i < c->n_seq; ++i)
+    e = hipMemcpy((uint8_t *)c->ref.p + c->h_ref_off[i], ref->sequences[i], ref->lengths[i], hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_off.p, c->h_ref_off.data(), (size_t)c->n_seq * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_len.p, c->h_ref_len.data(), (size_t)c->n_seq * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { cm_set_error(nullptr, std::string("reference upload: ") + hipGetErrorString(e)); cmgpu_destroy(c); return CMGPU_EHIP; }
+  *out = c;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
+  if (!c) return CMGPU_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (DevBuf *b : c->all_bufs()) b->release();
+  for (int i = 0; i < CM_MAX_EVENTS; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// batch upload / residency
+// ---------------------------------------------------------------------------------------
+static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
+  const size_t n2 = 2 * (size_t)n;
+#define ENS(buf, bytes) if (c->buf.ensure(bytes)) { cm_set_error(c, "out of device memory (" #buf ")"); return CMGPU_ENOMEM; }
+  ENS(rlen, n2 * 4) ENS(cap, n2 * 4) ENS(mm_cap_off, (n2 + 1) * 4) ENS(mm_cnt, n2 * 4) ENS(mm_off, (n2 + 1) * 4)
+  ENS(hit_tot, n2 * 4) ENS(hit_off, (n2 + 1) * 4) ENS(round2, n2) ENS(rep_cnt, n2 * 4) ENS(rep_len, n2 * 4)
+  ENS(n_pos_hit, n2 * 4) ENS(ncp, n2 * 4) ENS(ncn, n2 * 4) ENS(aug, n2) ENS(res_neg, n2 * 4) ENS(res_pos, n2 * 4)
+  ENS(resc_n, n2 * 4) ENS(resc_p, n2 * 4) ENS(m_tot, n2 * 4) ENS(m_off, (n2 + 1) * 4) ENS(mcp, n2 * 4) ENS(mcn, n2 * 4)
+  ENS(force0, n) ENS(fcp, n2 * 4) ENS(fcn, n2 * 4) ENS(alive, n) ENS(ndp, n2 * 4) ENS(ndn, n2 * 4)
+  ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
+  ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
+  ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4)
+  ENS(rec, (size_t)n * 24) ENS(rec_ok, n)
+  ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
+#undef ENS
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
+  if (!c || !in) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint32_t n = in->n_pairs;
+  if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
+  c->n_pairs = n;
+  c->first_read_id = in->first_read_id;
+  c->bases0 = n ? in->read1_offsets[n] : 0;
+  c->bases1 = n ? in->read2_offsets[n] : 0;
+  if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(c->bases1 + 16) || c->ro0.ensure(((size_t)n + 1) * 4) || c->ro1.ensure(((size_t)n + 1) * 4)) {
+    cm_set_error(c, "out of device memory (reads)");
+    return CMGPU_ENOMEM;
+  }
+  HIPCHECK(c, hipMemcpyAsync(c->rb0.p, in->read1_bases, c->bases0, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(c, hipMemcpyAsync(c->rb1.p, in->read2_bases, c->bases1, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(c, hipMemcpyAsync(c->ro0.p, in->read1_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(c, hipMemcpyAsync(c->ro1.p, in->read2_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(c, hipStreamSynchronize(c->stream));
+  return CMGPU_OK;
+}
+
+void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
+  memset(&d, 0, sizeof(d));
+  d.bkt = (const uint64_t *)c->bkt.p; d.bmask = c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
+  d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
+  d.n_seq = c->n_seq;
+  d.p = c->p;
+  d.mq.len_coef = (const double *)c->len_coef.p; d.mq.nsec_break = (const uint32_t *)c->nsec_break.p; d.mq.n_break = c->n_break;
+  d.n_pairs = c->n_pairs; d.first_read_id = c->first_read_id;
+  d.rb0 = (const uint8_t *)c->rb0.p; d.rb1 = (const uint8_t *)c->rb1.p;
+  d.ro0 = (const uint32_t *)c->ro0.p; d.ro1 = (const uint32_t *)c->ro1.p;
+#define PTR(f, T) d.f = (T *)c->f.p;
+  PTR(rlen, uint32_t) PTR(mm_cap_off, uint32_t) PTR(slot_hash, uint64_t) PTR(slot_ps, uint32_t) PTR(mm_cnt, uint32_t)
+  PTR(mm_off, uint32_t) PTR(mm_hash, uint64_t) PTR(mm_ps, uint32_t) PTR(pr_val, uint64_t) PTR(pr_kind, uint8_t)
+  PTR(hit_tot, uint32_t) PTR(hit_off, uint32_t) PTR(round2, uint8_t) PTR(rep_cnt, uint32_t) PTR(rep_len, uint32_t)
+  PTR(hbuf, uint64_t) PTR(hcnt, uint8_t) PTR(n_pos_hit, uint32_t) PTR(ncp, uint32_t) PTR(ncn, uint32_t)
+  PTR(aug, uint8_t) PTR(res_neg, int32_t) PTR(res_pos, int32_t) PTR(resc_n, uint32_t) PTR(resc_p, uint32_t)
+  PTR(m_tot, uint32_t) PTR(m_off, uint32_t) PTR(mbuf, uint64_t) PTR(mcnt, uint8_t) PTR(mcp, uint32_t) PTR(mcn, uint32_t)
+  PTR(force0, uint8_t) PTR(fbuf, uint64_t) PTR(fcnt, uint8_t) PTR(fcp, uint32_t) PTR(fcn, uint32_t) PTR(alive, uint8_t)
+  PTR(dpos, uint64_t) PTR(derr, int8_t) PTR(ndp, uint32_t) PTR(ndn, uint32_t)
+  PTR(min_err, int32_t) PTR(second_err, int32_t) PTR(n_best, int32_t) PTR(n_second, int32_t)
+  PTR(pe_min, int32_t) PTR(pe_second, int32_t) PTR(pe_nbest, int32_t) PTR(pe_nsecond, int32_t)
+  PTR(pe_first, uint32_t) PTR(pe_i1, uint32_t) PTR(pe_i2, uint32_t) PTR(pe_choice, uint32_t)
+  PTR(rec, uint8_t) PTR(rec_ok, uint8_t)
+#undef PTR
+  d.stats = (unsigned long long *)c->stats.p;
+}
+
+static inline void mark(cmgpu_ctx *c, const char *name) {
+  if (c->n_ev < CM_MAX_EVENTS) {
+    (void)hipEventRecord(c->ev[c->n_ev], c->stream);
+    c->ev_name[c->n_ev] = name;
+    ++c->n_ev;
+  }
+}
+
+// The pipeline on the resident batch.  Three small device->host reads size the
+// variable-length intermediates (minimizers, hits, candidate capacity).
+extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *stats) {
+  if (!c) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint32_t n = c->n_pairs, n2 = 2 * n;
+  c->n_ev = 0;
+  c->n_records = 0;
+  if (n_out) *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  int rc = ensure_pair_arrays(c, n);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  CmDev d;
+  HIPCHECK(c, hipMemsetAsync(c->stats.p, 0, CM_ST_N * 8, s));
+  cm_fill_dev(c, d);
+  mark(c, "begin");
+  // S0: length filter + adapter trimming
+  cm_launch_k_s0_prep(d, n, s);
+  mark(c, "s0_trim");
+  // S1: minimizers into per-read slot ranges
+  cm_launch_k_slot_cap(d, n2, (uint32_t *)c->cap.p, s);
+  cm_scan_u32((const uint32_t *)c->cap.p, d.mm_cap_off, n2, (uint32_t *)c->scan_tmp.p, s);
+  const size_t slot_cap = c->bases0 + c->bases1 + 1;  // sum over reads of (len-k+1) <= total bases
+  if (c->slot_hash.ensure(slot_cap * 8) || c->slot_ps.ensure(slot_cap * 4)) { cm_set_error(c, "out of device memory (minimizer slots)"); return CMGPU_ENOMEM; }
+  cm_fill_dev(c, d);
+  cm_launch_k_s1_minimizers(d, n2, s);
+  cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
+  uint32_t n_mm = 0;
+  HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipStreamSynchronize(s));
+  mark(c, "s1_minimizers");
+  if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
+      c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
+  cm_fill_dev(c, d);
+  cm_launch_k_s1b_compact(d, n2, s);
+  mark(c, "s1b_compact");
+  // S2: index probe (the graded kernel)
+  cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, d.stats + CM_ST_PROBE_STEPS, s);
+  mark(c, "s2_probe");
+  // S3: hit counts -> offsets -> candidates
+  cm_launch_k_s3a_count(d, n2, s);
+  cm_scan_u32(d.hit_tot, d.hit_off, n2, (uint32_t *)c->scan_tmp.p, s);
+  uint32_t n_hits = 0;
+  HIPCHECK(c, hipMemcpyAsync(&n_hits, d.hit_off + n2, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipStreamSynchronize(s));
+  if (c->hbuf.ensure((size_t)n_hits * 8 + 8) || c->hcnt.ensure((size_t)n_hits + 4)) { cm_set_error(c, "out of device memory (hits)"); return CMGPU_ENOMEM; }
+  cm_fill_dev(c, d);
+  mark(c, "s3a_count");
+  cm_launch_k_s3b_candidates(d, n2, s);
+  mark(c, "s3b_candidates");
+  // S4: mate rescue, merge, paired-end filter
+  cm_launch_k_s4a_rescue_count(d, n2, s);
+  cm_scan_u32(d.m_tot, d.m_off, n2, (uint32_t *)c->scan_tmp.p, s);
+  uint32_t n_m = 0;
+  HIPCHECK(c, hipMemcpyAsync(&n_m, d.m_off + n2, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipStreamSynchronize(s));
+  if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
+      c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m + 4)) {
+    cm_set_error(c, "out of device memory (candidates)");
+    return CMGPU_ENOMEM;
+  }
+  cm_fill_dev(c, d);
+  mark(c, "s4a_rescue_count");
+  cm_launch_k_s4b_rescue_merge(d, n2, s);
+  mark(c, "s4b_rescue_merge");
+  cm_launch_k_s4c_reduce(d, n, s);
+  mark(c, "s4c_pair_filter");
+  // S5: verification
+  cm_launch_k_s5_verify(d, n2, s);
+  mark(c, "s5_verify");
+  // S6: best pair, sampling of multi-mappers, records
+  cm_launch_k_s6a_pair(d, n, s);
+  mark(c, "s6a_pairing");
+  const uint32_t n_chunks = cm_num_chunks_host(n, (uint32_t)c->p.ref_batch, (uint32_t)c->p.grain);
+  cm_launch_k_s6b_sample(d, n_chunks, s);
+  cm_launch_k_s6c_multi(d, n, s);
+  mark(c, "s6bc_multimappers");
+  cm_launch_k_stats(d, n, s);
+  unsigned long long hst[CM_ST_N];
+  HIPCHECK(c, hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipStreamSynchronize(s));
+  mark(c, "stats");
+  HIPCHECK(c, hipStreamSynchronize(s));
+  if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
+  c->n_records = hst[CM_ST_RECORDS];
+  c->last_n_mm = n_mm; c->last_n_hits = n_hits; c->last_n_cand_cap = n_m;
+  if (stats) {
+    stats->num_candidates += hst[CM_ST_CAND];
+    stats->num_mappings += hst[CM_ST_MAPPINGS];
+    stats->num_mapped_reads += hst[CM_ST_MAPPED];
+    stats->num_uniquely_mapped_reads += hst[CM_ST_UNIQ];
+    stats->num_minimizers += n_mm;
+    stats->probe_steps += hst[CM_ST_PROBE_STEPS];
+    stats->occurrences_read += hst[CM_ST_OCC];
+    stats->num_pairs_rescued += hst[CM_ST_RESCUED];
+    stats->num_multi_mappers += hst[CM_ST_MULTI];
+  }
+  if (n_out) *n_out = c->n_records;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_download_records(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
+  if (!c || !out || !n_out) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint32_t n = c->n_pairs;
+  *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  std::vector<cmgpu_record> rec(n);
+  std::vector<uint8_t> ok(n);
+  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, n, hipMemcpyDeviceToHost));
+  uint64_t k = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!ok[i]) continue;
+    if (k >= out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
+    out[k++] = rec[i];
+  }
+  *n_out = k;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_map_pairs(cmgpu_ctx *c, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,
+                               uint64_t *n_out, cmgpu_stats *stats) {
+  int rc = cmgpu_upload_batch(c, in);
+  if (rc) return rc;
+  uint64_t k = 0;
+  rc = cmgpu_map_resident(c, &k, stats);
+  if (rc) return rc;
+  return cmgpu_download_records(c, out, out_capacity, n_out);
+}
+
+extern "C" int cmgpu_last_timings(const cmgpu_ctx *c, const char **names, float *ms, int cap) {
+  if (!c) return 0;
+  int k = 0;
+  for (int i = 1; i < c->n_ev && k < cap; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev[i - 1], c->ev[i]) != hipSuccess) t = -1;
+    names[k] = c->ev_name[i];
+    ms[k] = t;
+    ++k;
+  }
+  return k;
+}
+
+extern "C" int cmgpu_download_batch(cmgpu_ctx *c, char *r1, uint32_t *o1, char *r2, uint32_t *o2) {
+  if (!c) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint32_t n = c->n_pairs;
+  if (r1) HIPCHECK(c, hipMemcpy(r1, c->rb0.p, c->bases0, hipMemcpyDeviceToHost));
+  if (r2) HIPCHECK(c, hipMemcpy(r2, c->rb1.p, c->bases1, hipMemcpyDeviceToHost));
+  if (o1) HIPCHECK(c, hipMemcpy(o1, c->ro0.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+  if (o2) HIPCHECK(c, hipMemcpy(o2, c->ro1.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel-only measurement of the index probe
+// ---------------------------------------------------------------------------------------
+extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, int repeat, double *avg_ms,
+                                 uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences) {
+  if (!c || n == 0 || n > 0xffffff00ull || repeat < 1) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  if (hashes) {
+    if (c->mm_hash.ensure(n * 8)) { cm_set_error(c, "out of device memory (probe hashes)"); return CMGPU_ENOMEM; }
+    HIPCHECK(c, hipMemcpy(c->mm_hash.p, hashes, n * 8, hipMemcpyHostToDevice));
+  } else if (c->mm_hash.cap < n * 8) {
+    cm_set_error(c, "no resident hashes");
+    return CMGPU_EINVAL;
+  }
+  if (c->pr_val.ensure(n * 8) || c->pr_kind.ensure(n)) { cm_set_error(c, "out of device memory (probe results)"); return CMGPU_ENOMEM; }
+  hipStream_t s = c->stream;
+  unsigned long long *ctr = (unsigned long long *)c->stats.p;
+  HIPCHECK(c, hipMemsetAsync(ctr, 0, CM_ST_N * 8, s));
+  // warm-up + counted launch
+  cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
+                    (uint8_t *)c->pr_kind.p, (uint32_t)n, ctr + CM_ST_PROBE_STEPS, s);
+  unsigned long long h[CM_ST_N];
+  HIPCHECK(c, hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, hipEventRecord(c->ev[0], s));
+  for (int i = 0; i < repeat; ++i)
+    cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
+                      (uint8_t *)c->pr_kind.p, (uint32_t)n, nullptr, s);
+  HIPCHECK(c, hipEventRecord(c->ev[1], s));
+  HIPCHECK(c, hipEventSynchronize(c->ev[1]));
+  float ms = 0;
+  HIPCHECK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  if (avg_ms) *avg_ms = ms / repeat;
+  if (probe_steps) *probe_steps = h[CM_ST_PROBE_STEPS];
+  if (hits) *hits = h[CM_ST_PROBE_HITS];
+  if (occurrences) *occurrences = 0;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_reference_lengths(cmgpu_ctx *c, uint32_t *lengths, uint32_t capacity, uint32_t *n_sequences) {
+  if (!c) return CMGPU_EINVAL;
+  if (n_sequences) *n_sequences = c->n_seq;
+  for (uint32_t i = 0; lengths && i < c->n_seq && i < capacity; ++i) lengths[i] = c->h_ref_len[i];
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_export_reference(cmgpu_ctx *c, uint32_t seq, char *out, uint32_t capacity) {
+  if (!c || seq >= c->n_seq || !out || capacity < c->h_ref_len[seq]) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, hipMemcpy(out, (const uint8_t *)c->ref.p + c->h_ref_off[seq], c->h_ref_len[seq], hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}

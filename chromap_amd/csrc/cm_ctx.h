@@ -1,0 +1,77 @@
+// cm_ctx.h -- the context behind the C ABI: device buffers and per-batch state
+#ifndef CM_CTX_H_
+#define CM_CTX_H_
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/chromap_amd.h"
+#include "cm_types.h"
+
+#define CM_MAX_EVENTS 32
+#define CM_MAX_W_HOST 32
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes);  // grows (contents are NOT preserved); 0 on success
+  void release();
+};
+
+struct cmgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  cmgpu_params hp;
+  CmParams p;
+  // index + reference
+  DevBuf bkt, occ, ref, ref_off, ref_len, len_coef, nsec_break;
+  uint32_t bmask = 0, n_occ = 0, n_seq = 0;
+  int n_break = 0;
+  uint64_t ref_bytes = 0;
+  std::vector<uint64_t> h_ref_off;
+  std::vector<uint32_t> h_ref_len;
+  // resident batch
+  uint32_t n_pairs = 0, first_read_id = 0;
+  size_t bases0 = 0, bases1 = 0;
+  DevBuf rb0, rb1, ro0, ro1;
+  // per-read / per-pair arrays (names match CmDev)
+  DevBuf rlen, cap, mm_cap_off, slot_hash, slot_ps, mm_cnt, mm_off, mm_hash, mm_ps, pr_val, pr_kind;
+  DevBuf hit_tot, hit_off, round2, rep_cnt, rep_len, hbuf, hcnt, n_pos_hit, ncp, ncn;
+  DevBuf aug, res_neg, res_pos, resc_n, resc_p, m_tot, m_off, mbuf, mcnt, mcp, mcn, force0;
+  DevBuf fbuf, fcnt, fcp, fcn, alive, dpos, derr, ndp, ndn, min_err, second_err, n_best, n_second;
+  DevBuf pe_min, pe_second, pe_nbest, pe_nsecond, pe_first, pe_i1, pe_i2, pe_choice, rec, rec_ok;
+  DevBuf scan_tmp, stats;
+  uint64_t n_records = 0;
+  uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
+  uint64_t synth_n_minimizers = 0, synth_n_keys = 0;
+  // timing
+  hipEvent_t ev[CM_MAX_EVENTS] = {};
+  const char *ev_name[CM_MAX_EVENTS] = {};
+  int n_ev = 0;
+
+  std::vector<DevBuf *> all_bufs() {
+    return {&bkt, &occ, &ref, &ref_off, &ref_len, &len_coef, &nsec_break, &rb0, &rb1, &ro0, &ro1, &rlen, &cap,
+            &mm_cap_off, &slot_hash, &slot_ps, &mm_cnt, &mm_off, &mm_hash, &mm_ps, &pr_val, &pr_kind, &hit_tot,
+            &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
+            &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
+            &dpos, &derr, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats};
+  }
+};
+
+void cm_set_error(cmgpu_ctx *ctx, const std::string &msg);
+int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id);
+void cm_fill_dev(cmgpu_ctx *c, CmDev &d);
+
+static inline uint32_t cm_num_chunks_host(uint32_t n, uint32_t ref_batch, uint32_t grain) {
+  uint32_t tot = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += ref_batch) {
+    const uint32_t bn = n - b0 < ref_batch ? n - b0 : ref_batch;
+    const uint32_t T = bn / grain;
+    tot += T <= 1 ? 1 : T;
+  }
+  return tot;
+}
+#endif

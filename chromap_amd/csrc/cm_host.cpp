@@ -1,0 +1,232 @@
+// cm_host.cpp -- host-side pieces either side of the device path: the index-file and FASTA
+// loaders (byte-exact readers of the reference's formats) and the post-processing that
+// defines the final BED bytes (sort, PCR-duplicate removal, MAPQ filter, Tn5 shift, text).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/chromap_amd.h"
+
+extern "C" void cmgpu_default_params(cmgpu_params *p) {  // mapping_parameters.h:19-61
+  memset(p, 0, sizeof(*p));
+  p->error_threshold = 8;
+  p->min_num_seeds = 2;
+  p->max_seed_frequency0 = 500;
+  p->max_seed_frequency1 = 1000;
+  p->max_insert_size = 1000;
+  p->min_read_length = 30;
+  p->max_num_best_mappings = 1;
+  p->drop_repetitive_reads = 500000;
+  p->mapq_threshold = 30;
+  p->read_batch_size = 500000;
+  p->taskloop_grain_size = 5000;
+}
+
+extern "C" int cmgpu_apply_preset(cmgpu_params *p, const char *preset) {  // chromap_driver.cc:247-275
+  if (!strcmp(preset, "atac")) {
+    p->max_insert_size = 2000;
+    p->trim_adapters = 1;
+    p->remove_pcr_duplicates = 1;
+    p->tn5_shift = 1;
+    p->low_memory_mode = 1;
+  } else if (!strcmp(preset, "chip")) {
+    p->max_insert_size = 2000;
+    p->remove_pcr_duplicates = 1;
+    p->low_memory_mode = 1;
+  } else if (!strcmp(preset, "hic")) {
+    p->error_threshold = 4;
+    p->mapq_threshold = 1;
+    p->split_alignment = 1;
+    p->low_memory_mode = 1;
+  } else {
+    return CMGPU_EINVAL;
+  }
+  return CMGPU_OK;
+}
+
+// Index::Load (index.cc:132-169) + kh_load (khash.h:358-373): int k; int w; u32 n_keys;
+// {u32 n_buckets,size,n_occupied,upper_bound; u32 flags[max(1,nb/16)]; u64 keys[nb]; u64 vals[nb]};
+// u32 n_occ; u64 occ[n_occ].  Little-endian, no magic.
+extern "C" int cmgpu_load_index_file(const char *path, cmgpu_index_view *out) {
+  memset(out, 0, sizeof(*out));
+  FILE *f = fopen(path, "rb");
+  if (!f) return CMGPU_EIO;
+  int32_t k = 0, w = 0;
+  uint32_t n_keys = 0, hdr[4] = {0, 0, 0, 0};
+  bool ok = fread(&k, 4, 1, f) == 1 && fread(&w, 4, 1, f) == 1 && fread(&n_keys, 4, 1, f) == 1 && fread(hdr, 4, 4, f) == 4;
+  if (!ok) { fclose(f); return CMGPU_EIO; }
+  const uint32_t nb = hdr[0];
+  if (nb == 0 || (nb & (nb - 1))) { fclose(f); return CMGPU_EIO; }
+  const size_t fw = nb < 16 ? 1 : nb >> 4;
+  uint32_t *flags = (uint32_t *)malloc(fw * 4);
+  uint64_t *keys = (uint64_t *)malloc((size_t)nb * 8);
+  uint64_t *vals = (uint64_t *)malloc((size_t)nb * 8);
+  uint64_t *occ = nullptr;
+  uint32_t n_occ = 0;
+  ok = flags && keys && vals && fread(flags, 4, fw, f) == fw && fread(keys, 8, nb, f) == nb && fread(vals, 8, nb, f) == nb &&
+       fread(&n_occ, 4, 1, f) == 1;
+  if (ok && n_occ) {
+    occ = (uint64_t *)malloc((size_t)n_occ * 8);
+    ok = occ && fread(occ, 8, n_occ, f) == n_occ;
+  }
+  fclose(f);
+  if (!ok) { free(flags); free(keys); free(vals); free(occ); return CMGPU_EIO; }
+  out->kmer_size = k;
+  out->window_size = w;
+  out->n_buckets = nb;
+  out->flags = flags;
+  out->keys = keys;
+  out->vals = vals;
+  out->n_occurrences = n_occ;
+  out->occurrences = occ;
+  return CMGPU_OK;
+}
+
+extern "C" void cmgpu_free_host_index(cmgpu_index_view *v) {
+  free((void *)v->flags); free((void *)v->keys); free((void *)v->vals); free((void *)v->occurrences);
+  memset(v, 0, sizeof(*v));
+}
+
+// SequenceBatch::LoadAllSequences (sequence_batch.cc:84-120) over kseq (kseq.h): name up to
+// the first whitespace, sequence lines concatenated, empty records skipped.  Plain text.
+extern "C" int cmgpu_load_reference_fasta(const char *path, cmgpu_ref_view *out) {
+  memset(out, 0, sizeof(*out));
+  FILE *f = fopen(path, "rb");
+  if (!f) return CMGPU_EIO;
+  std::vector<std::string> names, seqs;
+  std::string name, seq;
+  bool have = false, in_qual = false;
+  size_t qual_len = 0;
+  char *line = nullptr;
+  size_t cap = 0;
+  ssize_t ll;
+  auto flush = [&]() {
+    if (have && !seq.empty()) { names.push_back(name); seqs.push_back(seq); }
+  };
+  while ((ll = getline(&line, &cap, f)) >= 0) {
+    while (ll > 0 && (line[ll - 1] == '\n' || line[ll - 1] == '\r')) line[--ll] = 0;
+    if (in_qual) { qual_len += (size_t)ll; if (qual_len >= seq.size()) in_qual = false; continue; }
+    if (line[0] == '>' || line[0] == '@') {
+      flush();
+      size_t e = 1;
+      while (line[e] && line[e] != ' ' && line[e] != '\t' && line[e] != '\v' && line[e] != '\f') ++e;
+      name.assign(line + 1, e - 1);
+      seq.clear();
+      have = true;
+    } else if (line[0] == '+' && have) {
+      in_qual = !seq.empty();
+      qual_len = 0;
+    } else if (have) {
+      for (ssize_t i = 0; i < ll; ++i) if (line[i] > 32 && line[i] < 127) seq.push_back(line[i]);
+    }
+  }
+  flush();
+  free(line);
+  fclose(f);
+  const uint32_t n = (uint32_t)names.size();
+  char **nm = (char **)calloc(n ? n : 1, sizeof(char *));
+  char **sq = (char **)calloc(n ? n : 1, sizeof(char *));
+  uint32_t *ln = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+  for (uint32_t i = 0; i < n; ++i) {
+    nm[i] = strdup(names[i].c_str());
+    sq[i] = (char *)malloc(seqs[i].size() + 1);
+    memcpy(sq[i], seqs[i].data(), seqs[i].size());
+    sq[i][seqs[i].size()] = 0;
+    ln[i] = (uint32_t)seqs[i].size();
+  }
+  out->n_sequences = n;
+  out->names = nm;
+  out->sequences = sq;
+  out->lengths = ln;
+  return CMGPU_OK;
+}
+
+extern "C" void cmgpu_free_host_ref(cmgpu_ref_view *v) {
+  for (uint32_t i = 0; i < v->n_sequences; ++i) { free((void *)v->names[i]); free((void *)v->sequences[i]); }
+  free((void *)v->names); free((void *)v->sequences); free((void *)v->lengths);
+  memset(v, 0, sizeof(*v));
+}
+
+// ---------------------------------------------------------------------------------------
+// BED output for paired-end bulk data
+//   sort:   per rid, PairedEndMappingWithoutBarcode::operator< (bed_mapping.h:208-215);
+//           the low-memory path's temp-file merge yields the same global order
+//           (mapping_processor.h:117-159, mapping_writer.h:166-376)
+//   dedup:  runs of operator== (same start and length, bed_mapping.h:216-219) collapse to
+//           the FIRST record with the maximal MAPQ, num_dups = min(255, run)
+//           (mapping_writer.h:247-289)
+//   filter: mapq >= mapq_threshold; then Tn5 shift (bed_mapping.h:224-229); line format
+//           mapping_writer.cc:72-83
+// ---------------------------------------------------------------------------------------
+static inline bool rec_less(const cmgpu_record &a, const cmgpu_record &b) {
+  return std::tie(a.rid, a.fragment_start, a.fragment_length, a.mapq, a.direction, a.is_unique, a.read_id,
+                  a.positive_alignment_length, a.negative_alignment_length) <
+         std::tie(b.rid, b.fragment_start, b.fragment_length, b.mapq, b.direction, b.is_unique, b.read_id,
+                  b.positive_alignment_length, b.negative_alignment_length);
+}
+
+static inline void put_u32(std::string &s, uint32_t v) {
+  char buf[12];
+  int n = 0;
+  do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) s.push_back(buf[--n]);
+}
+
+extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
+                                      cmgpu_record *rec, uint64_t n, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return CMGPU_EIO;
+  std::sort(rec, rec + n, rec_less);
+  std::string buf;
+  buf.reserve(1 << 20);
+  int64_t lines = 0;
+  auto emit = [&](cmgpu_record r, uint32_t dups) {
+    if (r.rid >= n_sequences) return;
+    r.num_dups = (uint8_t)(dups > 255 ? 255 : dups);
+    if (p->tn5_shift) {
+      r.fragment_start += 4;
+      r.positive_alignment_length -= 4;
+      r.fragment_length -= 9;
+      r.negative_alignment_length -= 5;
+    }
+    buf.append(names[r.rid]);
+    buf.push_back('\t');
+    put_u32(buf, r.fragment_start);
+    buf.push_back('\t');
+    put_u32(buf, r.fragment_start + r.fragment_length);
+    buf.append("\tN\t");
+    put_u32(buf, r.mapq);
+    buf.append(r.direction ? "\t+\t" : "\t-\t");
+    put_u32(buf, r.num_dups);
+    buf.push_back('\n');
+    ++lines;
+    if (buf.size() > (1 << 20) - 256) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+  };
+  if (p->low_memory_mode && p->remove_pcr_duplicates) {
+    uint64_t i = 0;
+    while (i < n) {
+      cmgpu_record last = rec[i];
+      uint32_t dups = 1;
+      uint64_t j = i + 1;
+      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start &&
+             rec[j].fragment_length == last.fragment_length) {
+        ++dups;
+        if (rec[j].mapq > last.mapq) last = rec[j];
+        ++j;
+      }
+      if (last.mapq >= p->mapq_threshold) emit(last, dups);
+      i = j;
+    }
+  } else {
+    for (uint64_t i = 0; i < n; ++i)
+      if (rec[i].mapq >= p->mapq_threshold) emit(rec[i], 1);
+  }
+  if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  return lines;
+}

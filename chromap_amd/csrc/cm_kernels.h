@@ -1,0 +1,37 @@
+// cm_kernels.h -- launch helpers implemented in cm_kernels.hip
+#ifndef CM_KERNELS_H_
+#define CM_KERNELS_H_
+#include <hip/hip_runtime.h>
+
+#include "cm_types.h"
+
+#define CM_DECL_LAUNCH(kname) void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s);
+CM_DECL_LAUNCH(k_s0_prep)
+CM_DECL_LAUNCH(k_s1_minimizers)
+CM_DECL_LAUNCH(k_s1b_compact)
+CM_DECL_LAUNCH(k_s3a_count)
+CM_DECL_LAUNCH(k_s3b_candidates)
+CM_DECL_LAUNCH(k_s4a_rescue_count)
+CM_DECL_LAUNCH(k_s4b_rescue_merge)
+CM_DECL_LAUNCH(k_s4c_reduce)
+CM_DECL_LAUNCH(k_s5_verify)
+CM_DECL_LAUNCH(k_s6a_pair)
+CM_DECL_LAUNCH(k_s6c_multi)
+CM_DECL_LAUNCH(k_stats)
+void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);
+void cm_launch_k_slot_cap(const CmDev &d, uint32_t n_reads, uint32_t *cap, hipStream_t s);
+void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,
+                       uint32_t n, unsigned long long *counters, hipStream_t s);
+
+size_t cm_scan_tmp_words(uint32_t n);
+// out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
+void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, hipStream_t s);
+
+// synthetic reference / reads / index construction on the device (cm_synth.hip)
+struct CmSynthRef {
+  uint8_t *ref;        // device, with 64-byte zero gaps
+  uint64_t *ref_off;   // device [n_seq]
+  uint32_t *ref_len;   // device [n_seq]
+  uint64_t total_bytes;
+};
+#endif

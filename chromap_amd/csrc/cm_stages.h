@@ -1,0 +1,1419 @@
+// cm_stages.h -- per-item stage functions of the mapping pipeline.
+//
+// Every function handles ONE item (pair, read, minimizer, task chunk) and is called from
+// a thin __global__ wrapper in cm_kernels.hip (one thread per item).  Semantics follow the
+// reference file:line cited at each function (paths relative to /root/reference/src);
+// integer wrap-arounds and truncations are deliberate.  The same header compiles with
+// g++ for tests/hostemu (test infrastructure; the library has no CPU path).
+#ifndef CM_STAGES_H_
+#define CM_STAGES_H_
+
+#include "cm_types.h"
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+// CharToUint8 (utils.h:87-104)
+CM_HD uint32_t cm_c2u(uint8_t c) {
+  const uint8_t u = c & 0xDF;
+  return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+}
+// Uint8ToChar(3 ^ CharToUint8(c)) as used by PrepareNegativeSequenceAt (sequence_batch.h:123-134)
+CM_HD uint8_t cm_negchar(uint8_t c) {
+  const uint32_t v = 3u ^ cm_c2u(c);
+  return v == 0 ? 'A' : v == 1 ? 'C' : v == 2 ? 'G' : v == 3 ? 'T' : 'N';
+}
+
+// Hash64 (utils.h:76-85)
+CM_HD uint64_t cm_hash64(uint64_t key, uint64_t mask) {
+  key = (~key + (key << 21)) & mask;
+  key = key ^ key >> 24;
+  key = ((key + (key << 3)) + (key << 8)) & mask;
+  key = key ^ key >> 14;
+  key = ((key + (key << 2)) + (key << 4)) & mask;
+  key = key ^ key >> 28;
+  key = (key + (key << 31)) & mask;
+  return key;
+}
+
+CM_HD const uint8_t *cm_read_ptr(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1;
+  return (r & 1) ? d.rb1 + d.ro1[pair] : d.rb0 + d.ro0[pair];
+}
+CM_HD uint32_t cm_raw_len(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1;
+  return (r & 1) ? d.ro1[pair + 1] - d.ro1[pair] : d.ro0[pair + 1] - d.ro0[pair];
+}
+
+// in-place ascending sort of a[0..n) -- insertion sort for short lists, heap sort otherwise
+CM_HD void cm_sort_u64(uint64_t *a, uint32_t n) {
+  if (n < 2) return;
+  if (n <= 24) {
+    for (uint32_t i = 1; i < n; ++i) {
+      const uint64_t x = a[i];
+      uint32_t j = i;
+      while (j > 0 && a[j - 1] > x) { a[j] = a[j - 1]; --j; }
+      a[j] = x;
+    }
+    return;
+  }
+  for (uint32_t start = n / 2; start-- > 0;) {
+    uint32_t root = start;
+    const uint64_t x = a[root];
+    for (;;) {
+      uint32_t child = 2 * root + 1;
+      if (child >= n) break;
+      if (child + 1 < n && a[child] < a[child + 1]) ++child;
+      if (!(x < a[child])) break;
+      a[root] = a[child];
+      root = child;
+    }
+    a[root] = x;
+  }
+  for (uint32_t end = n - 1; end > 0; --end) {
+    const uint64_t x = a[end];
+    a[end] = a[0];
+    uint32_t root = 0;
+    for (;;) {
+      uint32_t child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && a[child] < a[child + 1]) ++child;
+      if (!(x < a[child])) break;
+      a[root] = a[child];
+      root = child;
+    }
+    a[root] = x;
+  }
+}
+
+// Candidate::operator< (candidate.h:22-33): count desc, position asc.  "a before b"
+CM_HD bool cm_cand_before(uint64_t pa, uint8_t ca, uint64_t pb, uint8_t cb) {
+  if (ca != cb) return ca > cb;
+  return pa < pb;
+}
+// in-place sort of (pos[], cnt[]) by cm_cand_before (MappingMetadata::SortCandidates)
+CM_HD void cm_sort_cand(uint64_t *p, uint8_t *c, uint32_t n) {
+  if (n < 2) return;
+  if (n <= 24) {
+    for (uint32_t i = 1; i < n; ++i) {
+      const uint64_t xp = p[i];
+      const uint8_t xc = c[i];
+      uint32_t j = i;
+      while (j > 0 && cm_cand_before(xp, xc, p[j - 1], c[j - 1])) { p[j] = p[j - 1]; c[j] = c[j - 1]; --j; }
+      p[j] = xp;
+      c[j] = xc;
+    }
+    return;
+  }
+  // heap sort with "after" as the heap order (max-heap on the sort order)
+  for (uint32_t start = n / 2; start-- > 0;) {
+    uint32_t root = start;
+    const uint64_t xp = p[root];
+    const uint8_t xc = c[root];
+    for (;;) {
+      uint32_t child = 2 * root + 1;
+      if (child >= n) break;
+      if (child + 1 < n && cm_cand_before(p[child], c[child], p[child + 1], c[child + 1])) ++child;
+      if (!cm_cand_before(xp, xc, p[child], c[child])) break;
+      p[root] = p[child]; c[root] = c[child];
+      root = child;
+    }
+    p[root] = xp; c[root] = xc;
+  }
+  for (uint32_t end = n - 1; end > 0; --end) {
+    const uint64_t xp = p[end];
+    const uint8_t xc = c[end];
+    p[end] = p[0]; c[end] = c[0];
+    uint32_t root = 0;
+    for (;;) {
+      uint32_t child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && cm_cand_before(p[child], c[child], p[child + 1], c[child + 1])) ++child;
+      if (!cm_cand_before(xp, xc, p[child], c[child])) break;
+      p[root] = p[child]; c[root] = c[child];
+      root = child;
+    }
+    p[root] = xp; c[root] = xc;
+  }
+}
+
+// in-place sort of draft mappings (pos[], err[]) by position (SortMappingsByPositions,
+// mapping_metadata.h:70-78).  Order among equal positions does not affect results.
+CM_HD void cm_sort_draft(uint64_t *p, int8_t *e, uint32_t n) {
+  if (n < 2) return;
+  if (n <= 24) {
+    for (uint32_t i = 1; i < n; ++i) {
+      const uint64_t xp = p[i];
+      const int8_t xe = e[i];
+      uint32_t j = i;
+      while (j > 0 && p[j - 1] > xp) { p[j] = p[j - 1]; e[j] = e[j - 1]; --j; }
+      p[j] = xp;
+      e[j] = xe;
+    }
+    return;
+  }
+  for (uint32_t start = n / 2; start-- > 0;) {
+    uint32_t root = start;
+    const uint64_t xp = p[root];
+    const int8_t xe = e[root];
+    for (;;) {
+      uint32_t child = 2 * root + 1;
+      if (child >= n) break;
+      if (child + 1 < n && p[child] < p[child + 1]) ++child;
+      if (!(xp < p[child])) break;
+      p[root] = p[child]; e[root] = e[child];
+      root = child;
+    }
+    p[root] = xp; e[root] = xe;
+  }
+  for (uint32_t end = n - 1; end > 0; --end) {
+    const uint64_t xp = p[end];
+    const int8_t xe = e[end];
+    p[end] = p[0]; e[end] = e[0];
+    uint32_t root = 0;
+    for (;;) {
+      uint32_t child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && p[child] < p[child + 1]) ++child;
+      if (!(xp < p[child])) break;
+      p[root] = p[child]; e[root] = e[child];
+      root = child;
+    }
+    p[root] = xp; e[root] = xe;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// S0: length filter + adapter trimming, one pair per item
+//   chromap.h:911-924, Chromap::TrimAdapterForPairedEndRead chromap.cc:176-289,
+//   SequenceBatch::TrimSequenceAt sequence_batch.h:136-151
+// After trimming, the stored reverse complement of a read is exactly the reverse
+// complement of its first new_len bases (the front of the revcomp string is erased), so
+// only the new lengths need to be kept.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
+  const uint32_t raw1 = d.ro0[pair + 1] - d.ro0[pair], raw2 = d.ro1[pair + 1] - d.ro1[pair];
+  uint32_t len1 = raw1, len2 = raw2;
+  const bool ok = raw1 >= (uint32_t)d.p.min_read_len && raw2 >= (uint32_t)d.p.min_read_len;
+  if (ok && d.p.trim) {
+    const uint8_t *s1 = d.rb0 + d.ro0[pair], *s2 = d.rb1 + d.ro1[pair];
+    const bool swap = !(raw1 <= raw2);
+    const uint8_t *rd1 = swap ? s2 : s1;        // "read1": the shorter read, forward
+    const uint8_t *lng = swap ? s1 : s2;        // "read2": its revcomp is searched
+    const uint32_t l1 = swap ? raw2 : raw1, l2 = swap ? raw1 : raw2;
+    const int min_overlap = d.p.min_read_len;
+    const int seed = min_overlap / 2;
+    bool merged = false;
+    // neg2[i] = cm_negchar(lng[l2 - 1 - i])
+    for (int si = 0; si < 2 && !merged; ++si) {
+      const uint8_t *needle = rd1 + si * seed;
+      for (uint32_t sp = 0; sp + (uint32_t)seed <= l2 && !merged; ++sp) {
+        // std::string::find: first position >= sp where the seed matches
+        bool hit = true;
+        for (int j = 0; j < seed; ++j)
+          if (cm_negchar(lng[l2 - 1 - (sp + j)]) != needle[j]) { hit = false; break; }
+        if (!hit) continue;
+        const bool before_ok = sp >= (uint32_t)(si * seed);
+        const bool overlap_ok = (int)(l2 - sp + (uint32_t)(seed * si)) >= min_overlap;
+        if (!before_ok || !overlap_ok) continue;
+        bool can = true;
+        int ne = 0;
+        for (int i = 0; i < seed * si; ++i) {
+          if (cm_negchar(lng[l2 - 1 - (sp - si * seed + i)]) != rd1[i]) ++ne;
+          if (ne > 1) { can = false; break; }
+        }
+        if (can) {
+          for (uint32_t i = (uint32_t)seed; i + sp < l2 && (uint32_t)(si * seed) + i < l1; ++i) {
+            if (cm_negchar(lng[l2 - 1 - (sp + i)]) != rd1[si * seed + i]) ++ne;
+            if (ne > 1) { can = false; break; }
+          }
+        }
+        if (can) {
+          int overlap = (int)(l2 - sp + (uint32_t)(si * seed));
+          int off2 = 0;
+          if (overlap > (int)l1) { off2 = overlap - (int)l1; overlap = (int)l1; }
+          const int t1 = swap ? overlap + off2 : overlap;
+          const int t2 = swap ? overlap : overlap + off2;
+          if (t1 < (int)raw1) len1 = (uint32_t)t1;
+          if (t2 < (int)raw2) len2 = (uint32_t)t2;
+          merged = true;
+        }
+      }
+    }
+  }
+  d.rlen[2 * pair] = ok ? len1 : 0;
+  d.rlen[2 * pair + 1] = ok ? len2 : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// S1: minimizers of one read (MinimizerGenerator::GenerateMinimizers,
+//     minimizer_generator.cc:7-139).  Writes (hash, (pos<<1)|strand) into the read's slot
+//     range and the count.  The read's sequence index inside the hit is not kept: no
+//     consumer on the mapping path looks at it (index.cc:491-505 uses position+strand).
+// ---------------------------------------------------------------------------------------
+#define CM_MAX_W 32
+CM_HD void cm_s1_minimizers(const CmDev &d, uint32_t r) {
+  const uint32_t len = d.rlen[r];
+  const int k = d.p.k, w = d.p.w;
+  const uint8_t *seq = cm_read_ptr(d, r);
+  const uint32_t base = d.mm_cap_off[r];
+  const uint32_t cap = d.mm_cap_off[r + 1] - base;
+  uint64_t *oh = d.slot_hash + base;
+  uint32_t *op = d.slot_ps + base;
+  uint32_t n = 0;
+  const uint64_t shift = 2 * (uint64_t)(k - 1);
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  uint64_t fw = 0, rv = 0;
+  uint64_t bh[CM_MAX_W];
+  uint32_t bp[CM_MAX_W];
+  uint64_t min_h = ~0ull;
+  uint32_t min_p = ~0u;
+  for (int i = 0; i < w; ++i) { bh[i] = ~0ull; bp[i] = ~0u; }
+  int unamb = 0, pib = 0, min_pos = 0;
+#define CM_EMIT(h, p) do { if (n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
+  for (uint32_t pos = 0; pos < len; ++pos) {
+    const uint32_t c = cm_c2u(seq[pos]);
+    uint64_t cur_h = ~0ull;
+    uint32_t cur_p = ~0u;
+    if (c < 4) {
+      fw = ((fw << 2) | c) & mask;
+      rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
+      if (fw == rv) continue;  // palindromic k-mer: ring index does not advance (:42-45)
+      const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+      const uint32_t strand = h0 < h1 ? 0u : 1u;
+      ++unamb;
+      if (unamb >= k) {
+        cur_h = cm_hash64(strand ? h1 : h0, mask);
+        cur_p = (pos << 1) | strand;
+      }
+    } else {
+      unamb = 0;
+    }
+    bh[pib] = cur_h;
+    bp[pib] = cur_p;
+    if (unamb == w + k - 1 && min_h != ~0ull && min_h < cur_h) {
+      for (int j = pib + 1; j < w; ++j)
+        if (min_h == bh[j] && bp[j] != min_p) CM_EMIT(bh[j], bp[j]);
+      for (int j = 0; j < pib; ++j)
+        if (min_h == bh[j] && bp[j] != min_p) CM_EMIT(bh[j], bp[j]);
+    }
+    if (cur_h <= min_h) {
+      if (unamb >= w + k && min_h != ~0ull) CM_EMIT(min_h, min_p);
+      min_h = cur_h;
+      min_p = cur_p;
+      min_pos = pib;
+    } else if (pib == min_pos) {
+      if (unamb >= w + k - 1 && min_h != ~0ull) CM_EMIT(min_h, min_p);
+      min_h = ~0ull;
+      for (int j = pib + 1; j < w; ++j)
+        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
+      for (int j = 0; j <= pib; ++j)
+        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
+      if (unamb >= w + k - 1 && min_h != ~0ull) {
+        for (int j = pib + 1; j < w; ++j)
+          if (min_h == bh[j] && min_p != bp[j]) CM_EMIT(bh[j], bp[j]);
+        for (int j = 0; j <= pib; ++j)
+          if (min_h == bh[j] && min_p != bp[j]) CM_EMIT(bh[j], bp[j]);
+      }
+    }
+    if (++pib == w) pib = 0;
+  }
+  if (min_h != ~0ull) CM_EMIT(min_h, min_p);
+#undef CM_EMIT
+  if (n > cap) { n = cap; d.stats[CM_ST_ERR] = 1; }  // cannot happen: <= one emission per k-mer position
+  // BothEndsHaveMinimizers gate (chromap.h:936) is applied by the consumer via mm_cnt
+  d.mm_cnt[r] = n;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Reference minimizers for index construction (Index::Construct, index.cc:19-23), one
+// chunk of `chunk` positions per item.  The state machine is the one of cm_s1_minimizers;
+// it is started `warm` positions early (>= 2w+k, so ring buffer, running minimum and the
+// unambiguous-length thresholds have converged to the sequential pass's state before the
+// first owned position) and run w+2 positions past the chunk; an emission is kept only
+// when the emitted k-mer's end position lies in [start, start+chunk).  Emitted hit =
+// ((rid<<32 | pos) << 1) | strand (minimizer_generator.cc:58-60).  Pass oh = nullptr to count.
+// ---------------------------------------------------------------------------------------
+CM_HD uint32_t cm_ref_chunk_minimizers(const uint8_t *seq, uint32_t len, uint32_t rid, uint32_t s, uint32_t chunk,
+                                       uint32_t warm, int k, int w, uint64_t *oh, uint64_t *ot) {
+  const uint32_t e = s + chunk < len ? s + chunk : len;  // owned positions [s,e)
+  const uint32_t begin = s > warm ? s - warm : 0;
+  const uint32_t end = e + 2 * (uint32_t)w + 2 < len ? e + 2 * (uint32_t)w + 2 : len;
+  const uint64_t shift = 2 * (uint64_t)(k - 1);
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  uint64_t fw = 0, rv = 0;
+  uint64_t bh[CM_MAX_W];
+  uint32_t bp[CM_MAX_W];
+  uint64_t min_h = ~0ull;
+  uint32_t min_p = ~0u;
+  for (int i = 0; i < w; ++i) { bh[i] = ~0ull; bp[i] = ~0u; }
+  int unamb = 0, pib = 0, min_pos = 0;
+  uint32_t n = 0;
+#define CM_REMIT(h, p)                                                                        \
+  do {                                                                                        \
+    const uint32_t pp_ = (p) >> 1;                                                            \
+    if (pp_ >= s && pp_ < e) {                                                                \
+      if (oh) { oh[n] = (h); ot[n] = (((uint64_t)rid << 32 | pp_) << 1) | ((p) & 1u); }       \
+      ++n;                                                                                    \
+    }                                                                                         \
+  } while (0)
+  for (uint32_t pos = begin; pos < end; ++pos) {
+    const uint32_t cb = cm_c2u(seq[pos]);
+    uint64_t cur_h = ~0ull;
+    uint32_t cur_p = ~0u;
+    if (cb < 4) {
+      fw = ((fw << 2) | cb) & mask;
+      rv = (rv >> 2) | (((uint64_t)(3 ^ cb)) << shift);
+      if (fw == rv) continue;
+      const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+      const uint32_t strand = h0 < h1 ? 0u : 1u;
+      ++unamb;
+      if (unamb >= k) {
+        cur_h = cm_hash64(strand ? h1 : h0, mask);
+        cur_p = (pos << 1) | strand;
+      }
+    } else {
+      unamb = 0;
+    }
+    bh[pib] = cur_h;
+    bp[pib] = cur_p;
+    if (unamb == w + k - 1 && min_h != ~0ull && min_h < cur_h) {
+      for (int j = pib + 1; j < w; ++j)
+        if (min_h == bh[j] && bp[j] != min_p) CM_REMIT(bh[j], bp[j]);
+      for (int j = 0; j < pib; ++j)
+        if (min_h == bh[j] && bp[j] != min_p) CM_REMIT(bh[j], bp[j]);
+    }
+    if (cur_h <= min_h) {
+      if (unamb >= w + k && min_h != ~0ull) CM_REMIT(min_h, min_p);
+      min_h = cur_h; min_p = cur_p; min_pos = pib;
+    } else if (pib == min_pos) {
+      if (unamb >= w + k - 1 && min_h != ~0ull) CM_REMIT(min_h, min_p);
+      min_h = ~0ull;
+      for (int j = pib + 1; j < w; ++j)
+        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
+      for (int j = 0; j <= pib; ++j)
+        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
+      if (unamb >= w + k - 1 && min_h != ~0ull) {
+        for (int j = pib + 1; j < w; ++j)
+          if (min_h == bh[j] && min_p != bp[j]) CM_REMIT(bh[j], bp[j]);
+        for (int j = 0; j <= pib; ++j)
+          if (min_h == bh[j] && min_p != bp[j]) CM_REMIT(bh[j], bp[j]);
+      }
+    }
+    if (++pib == w) pib = 0;
+  }
+  // final flush (minimizer_generator.cc:136-138): performed by every chunk whose run reaches
+  // the end of the sequence; the ownership test keeps exactly one copy
+  if (end == len && min_h != ~0ull) CM_REMIT(min_h, min_p);
+#undef CM_REMIT
+  return n;
+}
+
+// S1b: copy a read's minimizers from its slot range to the dense arrays
+CM_HD void cm_s1b_compact(const CmDev &d, uint32_t r) {
+  const uint32_t n = d.mm_cnt[r], src = d.mm_cap_off[r], dst = d.mm_off[r];
+  for (uint32_t i = 0; i < n; ++i) {
+    d.mm_hash[dst + i] = d.slot_hash[src + i];
+    d.mm_ps[dst + i] = d.slot_ps[src + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// S2: index probe of ONE minimizer (kh_get, khash.h:232-245, with the hash/equality of
+//     index_utils.h:13-17).  Device layout: one 16-B {key,val} bucket at the same bucket
+//     index as in the khash arrays, empty buckets hold CM_EMPTY_KEY, so the triangular
+//     probe sequence and the hit/miss outcome are those of the reference.
+//     Returns the number of buckets visited.
+// ---------------------------------------------------------------------------------------
+CM_HD uint32_t cm_probe(const uint64_t *bkt, uint32_t bmask, uint64_t hash, uint64_t *val_out,
+                        uint8_t *kind_out) {
+  uint32_t i = (uint32_t)hash & bmask;
+  const uint32_t last = i;
+  uint32_t step = 0, visited = 0;
+  for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one 16-byte load per visited bucket
+    const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)i);
+    const uint64_t key = kv.x, val = kv.y;
+#else
+    const uint64_t key = bkt[2 * (uint64_t)i], val = bkt[2 * (uint64_t)i + 1];
+#endif
+    ++visited;
+    if (key == CM_EMPTY_KEY) break;
+    if (key != CM_DELETED_KEY && (key >> 1) == hash) {
+      *val_out = val;
+      *kind_out = (key & 1) ? CM_PR_SINGLE : CM_PR_MULTI;
+      return visited;
+    }
+    i = (i + (++step)) & bmask;
+    if (i == last) break;
+  }
+  *val_out = 0;
+  *kind_out = CM_PR_MISS;
+  return visited;
+}
+
+// ---------------------------------------------------------------------------------------
+// S3a: per read, how many hits GenerateCandidatePositions will produce and which round
+//      is used (CandidateProcessor::GenerateCandidates candidate_processor.cc:12-71,
+//      Index::GenerateCandidatePositions index.cc:237-349, UpdateRepetitiveSeedStats
+//      index.cc:507-523).  Repetitive-seed statistics do not depend on the round.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s3a_count(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1;
+  // BothEndsHaveMinimizers (chromap.h:936)
+  const bool live = d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0;
+  uint32_t tot1 = 0, tot2 = 0, rep_len = 0, rep_cnt = 0, prev = ~0u;
+  if (live) {
+    const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint8_t kind = d.pr_kind[b + i];
+      if (kind == CM_PR_MISS) continue;
+      if (kind == CM_PR_SINGLE) { ++tot1; ++tot2; continue; }
+      const uint32_t nocc = (uint32_t)d.pr_val[b + i];
+      if (!(nocc >= (uint32_t)d.p.f0)) tot1 += nocc;
+      if (!(nocc >= (uint32_t)d.p.f1)) tot2 += nocc;
+      if (nocc >= (uint32_t)d.p.f0) {
+        const uint32_t rp = d.mm_ps[b + i] >> 1;
+        if (prev > rp) rep_len += (uint32_t)d.p.k;
+        else if (rp < prev + (uint32_t)d.p.k + (uint32_t)d.p.w - 1) rep_len += rp - prev;
+        else rep_len += (uint32_t)d.p.k;
+        prev = rp;
+        ++rep_cnt;
+      }
+    }
+  }
+  const bool r2 = live && tot1 == 0;
+  d.round2[r] = r2 ? 1 : 0;
+  d.hit_tot[r] = live ? (r2 ? tot2 : tot1) : 0;
+  d.rep_len[r] = rep_len;
+  d.rep_cnt[r] = rep_cnt;
+}
+
+// GenerateCandidatePositionFromHits (index.cc:491-505); ps = (read_pos<<1)|strand
+CM_HD uint64_t cm_cand_from_hit(uint64_t ref_hit, uint32_t ps, int k, bool *same) {
+  const uint32_t ref_pos = (uint32_t)(ref_hit >> 1), read_pos = ps >> 1;
+  *same = ((uint32_t)ref_hit & 1u) == (ps & 1u);
+  const uint32_t start = *same ? ref_pos - read_pos : ref_pos + read_pos - (uint32_t)k + 1u;
+  return ((uint64_t)(uint32_t)(ref_hit >> 33) << 32) | start;
+}
+
+// CandidateProcessor::GenerateCandidatesOnOneStrand (candidate_processor.cc:283-342) on a
+// sorted hit list h[0..n); candidates are written IN PLACE into h/cnt (the write index
+// never passes the read index).  Returns the number of candidates.
+CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
+  if (n == 0) return 0;
+  uint32_t out = 0;
+  int mcount = 1, equal = 1, best_equal = 1;
+  uint64_t prev_hit = h[0];
+  uint32_t prev_rid = (uint32_t)(prev_hit >> 32), prev_pos = (uint32_t)prev_hit;
+  uint64_t best_local = h[0];
+  for (uint32_t pi = 1; pi <= n; ++pi) {
+    const uint64_t x = pi < n ? h[pi] : ~0ull;  // UINT64_MAX sentinel (:286)
+    const uint32_t rid = (uint32_t)(x >> 32), pos = (uint32_t)x;
+    if (rid != prev_rid || pos > prev_pos + (uint32_t)e ||
+        ((uint32_t)mcount >= num_minimizers && pos > (uint32_t)best_local + (uint32_t)e)) {
+      if (mcount >= seeds_required) {
+        h[out] = best_local;
+        cnt[out] = (uint8_t)best_equal;
+        ++out;
+      }
+      mcount = 1; equal = 1; best_equal = 1;
+      best_local = x;
+    } else {
+      if (x == best_local) { ++equal; ++best_equal; }
+      else if (x == prev_hit) {
+        ++equal;
+        if (equal > best_equal) { best_local = prev_hit; best_equal = equal; }
+      } else equal = 1;
+      ++mcount;
+    }
+    prev_hit = x; prev_rid = rid; prev_pos = pos;
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// S3b: per read -- expand occurrences into the read's hit segment (+ list from the front,
+//      - list from the back), sort both, cluster into candidates in place.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s3b_candidates(const CmDev &d, uint32_t r) {
+  const uint32_t tot = d.hit_tot[r];
+  d.ncp[r] = 0; d.ncn[r] = 0; d.n_pos_hit[r] = 0;
+  if (tot == 0) return;
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  uint64_t *h = d.hbuf + d.hit_off[r];
+  uint8_t *hc = d.hcnt + d.hit_off[r];
+  const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
+  uint32_t np = 0, nn = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint8_t kind = d.pr_kind[b + i];
+    if (kind == CM_PR_MISS) continue;
+    const uint64_t val = d.pr_val[b + i];
+    const uint32_t ps = d.mm_ps[b + i];
+    bool same;
+    if (kind == CM_PR_SINGLE) {
+      const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
+      if (same) h[np++] = cp; else h[tot - 1 - nn++] = cp;
+      continue;
+    }
+    const uint32_t nocc = (uint32_t)val;
+    if (nocc >= maxf) continue;
+    const uint64_t *o = d.occ + (uint32_t)(val >> 32);
+    for (uint32_t oi = 0; oi < nocc; ++oi) {
+      const uint64_t cp = cm_cand_from_hit(o[oi], ps, d.p.k, &same);
+      if (same) h[np++] = cp; else h[tot - 1 - nn++] = cp;
+    }
+  }
+  cm_sort_u64(h, np);
+  cm_sort_u64(h + np, nn);
+  const bool use_high = d.round2[r] && np > 0 && nn > 0;
+  int req = (int)n - (int)d.rep_cnt[r];
+  req = req > 1 ? req : 1;
+  req = req > d.p.min_seeds ? d.p.min_seeds : req;
+  if (use_high) req = d.p.min_seeds;
+  d.n_pos_hit[r] = np;
+  d.ncp[r] = cm_sweep(h, hc, np, d.p.e, req, n);
+  d.ncn[r] = cm_sweep(h + np, hc + np, nn, d.p.e, req, n);
+}
+
+// ---------------------------------------------------------------------------------------
+// Mate rescue (Index::GenerateCandidatePositionsFromRepetitiveReadWithMateInfoOnOneStrand,
+// index.cc:351-489).  One function does both the counting pass (out == nullptr) and the
+// fill pass.  strand: 0 = kPositive, 1 = kNegative.  Mate candidates are (mp, mc, mn),
+// sorted by position.  The merged windows (:383-412) are re-derived per minimizer by a
+// streaming merge over the mate candidates instead of being stored.
+// Returns max_minimizer_count, or its negation when the search bails out (:371-380).
+// ---------------------------------------------------------------------------------------
+CM_HD int cm_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn,
+                    uint64_t *out, uint32_t *n_out, uint32_t *rep_len_out, unsigned long long *occ_reads) {
+  const uint32_t search_range = 2u * (uint32_t)d.p.max_insert;
+  int max_count = 0, best_num = 0;
+  for (uint32_t i = 0; i < mn; ++i) {
+    const int c = mc[i];
+    if (c > max_count) { max_count = c; best_num = 1; }
+    else if (c == max_count) ++best_num;
+  }
+  *n_out = 0;
+  if (best_num >= 300 || mn > (uint32_t)d.p.f0 || (max_count <= d.p.min_seeds && best_num >= 200)) return -max_count;
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  uint32_t cnt = 0, rep_len = 0, prev_rep = ~0u;
+  unsigned long long reads = 0;
+  for (uint32_t mi = 0; mi < n; ++mi) {
+    const uint8_t kind = d.pr_kind[b + mi];
+    if (kind == CM_PR_MISS) continue;
+    const uint64_t val = d.pr_val[b + mi];
+    const uint32_t ps = d.mm_ps[b + mi];
+    bool same;
+    if (kind == CM_PR_SINGLE) {
+      const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
+      if ((same && strand == 0) || (!same && strand == 1)) { if (out) out[cnt] = cp; ++cnt; }
+      continue;
+    }
+    const uint32_t off = (uint32_t)(val >> 32), nocc = (uint32_t)val;
+    const uint64_t *o = d.occ + off;
+    int32_t prev_l = 0;
+    // streaming merge of the windows of the best mate candidates
+    uint32_t ci = 0;
+    bool have = false;
+    uint64_t ws = 0, we = 0;
+    for (;;) {
+      // find next window [ws,we]
+      bool emit = false;
+      uint64_t es = 0, ee = 0;
+      while (ci < mn) {
+        if (mc[ci] != max_count) { ++ci; continue; }
+        const uint64_t pos = mp[ci];
+        const uint64_t s = pos < search_range ? 0 : pos - search_range;
+        const uint64_t en = pos + search_range;
+        ++ci;
+        if (!have) { ws = s; we = en; have = true; continue; }
+        if (we < s) { es = ws; ee = we; emit = true; ws = s; we = en; break; }
+        we = en;
+      }
+      if (!emit) {
+        if (!have) break;
+        es = ws; ee = we; have = false; emit = true;  // last window
+      }
+      // binary search for the window start (:443-460)
+      int32_t l = prev_l, m = 0, rr = (int32_t)(nocc - 1);
+      while (l <= rr) {
+        m = (l + rr) / 2;
+        const uint64_t cp = o[m] >> 1;
+        ++reads;
+        if (cp < es) l = m + 1;
+        else if (cp > es) rr = m - 1;
+        else break;
+      }
+      prev_l = m;
+      for (uint32_t oi = (uint32_t)m; oi < nocc; ++oi) {
+        const uint64_t rh = o[oi];
+        ++reads;
+        if ((rh >> 1) > ee) break;
+        const uint64_t cp = cm_cand_from_hit(rh, ps, d.p.k, &same);
+        if ((same && strand == 0) || (!same && strand == 1)) { if (out) out[cnt] = cp; ++cnt; }
+      }
+      if (!have && ci >= mn) break;
+    }
+    if (nocc >= (uint32_t)d.p.f0) {
+      const uint32_t rp = ps >> 1;
+      if (prev_rep > rp) rep_len += (uint32_t)d.p.k;
+      else if (rp < prev_rep + (uint32_t)d.p.k + (uint32_t)d.p.w - 1) rep_len += rp - prev_rep;
+      else rep_len += (uint32_t)d.p.k;
+      prev_rep = rp;
+    }
+  }
+  *n_out = cnt;
+  *rep_len_out = rep_len;
+  if (occ_reads) *occ_reads += reads;
+  return max_count;
+}
+
+// candidate lists after GenerateCandidates live in hbuf: + at hit_off[r], - at hit_off[r]+n_pos_hit[r]
+CM_HD const uint64_t *cm_c0_pos(const CmDev &d, uint32_t r) { return d.hbuf + d.hit_off[r]; }
+CM_HD const uint8_t *cm_c0_pcnt(const CmDev &d, uint32_t r) { return d.hcnt + d.hit_off[r]; }
+CM_HD const uint64_t *cm_c0_neg(const CmDev &d, uint32_t r) { return d.hbuf + d.hit_off[r] + d.n_pos_hit[r]; }
+CM_HD const uint8_t *cm_c0_ncnt(const CmDev &d, uint32_t r) { return d.hcnt + d.hit_off[r] + d.n_pos_hit[r]; }
+
+// ---------------------------------------------------------------------------------------
+// S4a: per read -- SupplementCandidates decision and rescue-hit counting
+//      (candidate_processor.cc:75-191)
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s4a_rescue_count(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1, o = r ^ 1u;
+  d.aug[r] = 0; d.res_neg[r] = 0; d.res_pos[r] = 0; d.resc_n[r] = 0; d.resc_p[r] = 0;
+  const bool live = d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0;
+  uint32_t ncp = d.ncp[r], ncn = d.ncn[r];
+  if (live) {
+    const uint32_t mm_count = d.mm_cnt[r];
+    bool augment = true;
+    const uint8_t *pc = cm_c0_pcnt(d, r), *nc = cm_c0_ncnt(d, r);
+    for (uint32_t i = 0; i < ncp; ++i) if (pc[i] >= mm_count / 2) { augment = false; break; }
+    if (augment) for (uint32_t i = 0; i < ncn; ++i) if (nc[i] >= mm_count / 2) { augment = false; break; }
+    if (augment) {
+      d.aug[r] = 1;
+      uint32_t cntn = 0, cntp = 0, rl = 0;
+      int res_neg = 0, res_pos = 0;
+      bool set_rl = false;
+      uint32_t rl_val = 0;
+      unsigned long long occ_reads = 0;
+      if (d.ncp[o] > 0) {  // mate + candidates drive a search on our - strand (:147-153)
+        res_neg = cm_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], nullptr, &cntn, &rl, &occ_reads);
+        if (res_neg >= 0) { set_rl = true; rl_val = rl; }
+      }
+      if (d.ncn[o] > 0) {
+        res_pos = cm_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], nullptr, &cntp, &rl, &occ_reads);
+        if (res_pos >= 0) { set_rl = true; rl_val = rl; }
+      }
+      d.res_neg[r] = res_neg; d.res_pos[r] = res_pos;
+      d.resc_n[r] = cntn; d.resc_p[r] = cntp;
+      if (set_rl) d.rep_len[r] = rl_val;  // repetitive_seed_length overwritten (:113,131, index.cc:487)
+    }
+  }
+  d.m_tot[r] = live ? ncp + ncn + d.resc_n[r] + d.resc_p[r] : 0;
+}
+
+// CandidateProcessor::MergeCandidates (candidate_processor.cc:345-414).  c1 = original list,
+// c2 = augmented list stored at out[n1 ..]; result written to out[0..] (see cm_s4b).
+CM_HD uint32_t cm_merge(const uint64_t *p1, const uint8_t *c1, uint32_t n1, uint64_t *out, uint8_t *outc,
+                        uint32_t n2, int e) {
+  const uint64_t *p2 = out + n1;
+  const uint8_t *c2 = outc + n1;
+  if (n1 == 0) return n2;  // c1.swap(c2): the augmented list is already in place
+  uint32_t i = 0, j = 0, k = 0;
+#define CM_BACK_OK(P) (k == 0 || (P) > out[k - 1] + (uint64_t)(int64_t)e)
+  while (i < n1 && j < n2) {
+    const uint64_t a = p1[i], b = p2[j];
+    if (a == b) {
+      if (CM_BACK_OK(a)) {
+        const uint8_t ca = c1[i], cb = c2[j];
+        if (ca > cb) { out[k] = a; outc[k] = ca; } else { out[k] = b; outc[k] = cb; }
+        ++k;
+      }
+      ++i; ++j;
+    } else if (a < b) {
+      if (CM_BACK_OK(a)) { const uint8_t ca = c1[i]; out[k] = a; outc[k] = ca; ++k; }
+      ++i;
+    } else {
+      if (CM_BACK_OK(b)) { const uint8_t cb = c2[j]; out[k] = b; outc[k] = cb; ++k; }
+      ++j;
+    }
+  }
+  while (i < n1) { const uint64_t a = p1[i]; if (CM_BACK_OK(a)) { const uint8_t ca = c1[i]; out[k] = a; outc[k] = ca; ++k; } ++i; }
+  while (j < n2) { const uint64_t b = p2[j]; if (CM_BACK_OK(b)) { const uint8_t cb = c2[j]; out[k] = b; outc[k] = cb; ++k; } ++j; }
+#undef CM_BACK_OK
+  return k;
+}
+
+// ---------------------------------------------------------------------------------------
+// S4b: per read -- fill rescue hits, cluster them (num_seeds_required = 1), merge with the
+//      original candidates (candidate_processor.cc:193-230, 265-281).
+//      Region layout in mbuf: + list at m_off[r] (capacity ncp+resc_p), - list right after
+//      (capacity ncn+resc_n).  Rescue hits are staged at the END of each region so the
+//      merge can write from the front without overtaking unread input.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s4b_rescue_merge(const CmDev &d, uint32_t r) {
+  const uint32_t o = r ^ 1u;
+  d.mcp[r] = 0; d.mcn[r] = 0;
+  if (d.m_tot[r] == 0) return;
+  const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
+  uint64_t *P = d.mbuf + d.m_off[r];
+  uint8_t *PC = d.mcnt + d.m_off[r];
+  uint64_t *N = P + ncp + rp;
+  uint8_t *NC = PC + ncp + rp;
+  const uint64_t *p0 = cm_c0_pos(d, r), *n0 = cm_c0_neg(d, r);
+  const uint8_t *pc0 = cm_c0_pcnt(d, r), *nc0 = cm_c0_ncnt(d, r);
+  uint32_t naug_p = 0, naug_n = 0;
+  if (d.aug[r]) {
+    uint32_t cnt = 0, rl = 0;
+    if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) {
+      cm_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], N + ncn, &cnt, &rl, nullptr);
+      cm_sort_u64(N + ncn, cnt);
+      naug_n = cm_sweep(N + ncn, NC + ncn, cnt, d.p.e, 1, d.mm_cnt[r]);
+    }
+    if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0) {
+      cm_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], P + ncp, &cnt, &rl, nullptr);
+      cm_sort_u64(P + ncp, cnt);
+      naug_p = cm_sweep(P + ncp, PC + ncp, cnt, d.p.e, 1, d.mm_cnt[r]);
+    }
+  }
+  if (naug_p > 0) {
+    d.mcp[r] = cm_merge(p0, pc0, ncp, P, PC, naug_p, d.p.e);
+  } else {
+    for (uint32_t i = 0; i < ncp; ++i) { P[i] = p0[i]; PC[i] = pc0[i]; }
+    d.mcp[r] = ncp;
+  }
+  if (naug_n > 0) {
+    d.mcn[r] = cm_merge(n0, nc0, ncn, N, NC, naug_n, d.p.e);
+  } else {
+    for (uint32_t i = 0; i < ncn; ++i) { N[i] = n0[i]; NC[i] = nc0[i]; }
+    d.mcn[r] = ncn;
+  }
+}
+
+// merged candidate list accessors
+CM_HD uint64_t *cm_m_pos(const CmDev &d, uint32_t r) { return d.mbuf + d.m_off[r]; }
+CM_HD uint8_t *cm_m_pcnt(const CmDev &d, uint32_t r) { return d.mcnt + d.m_off[r]; }
+CM_HD uint64_t *cm_m_neg(const CmDev &d, uint32_t r) { return d.mbuf + d.m_off[r] + d.ncp[r] + d.resc_p[r]; }
+CM_HD uint8_t *cm_m_ncnt(const CmDev &d, uint32_t r) { return d.mcnt + d.m_off[r] + d.ncp[r] + d.resc_p[r]; }
+CM_HD uint64_t *cm_f_pos(const CmDev &d, uint32_t r) { return d.fbuf + d.m_off[r]; }
+CM_HD uint8_t *cm_f_pcnt(const CmDev &d, uint32_t r) { return d.fcnt + d.m_off[r]; }
+CM_HD uint64_t *cm_f_neg(const CmDev &d, uint32_t r) { return d.fbuf + d.m_off[r] + d.ncp[r] + d.resc_p[r]; }
+CM_HD uint8_t *cm_f_ncnt(const CmDev &d, uint32_t r) { return d.fcnt + d.m_off[r] + d.ncp[r] + d.resc_p[r]; }
+
+// ReduceCandidatesForPairedEndReadOnOneDirection (candidate_processor.cc:416-484)
+CM_HD void cm_reduce_dir(uint32_t dist, const uint64_t *p1, const uint8_t *c1, uint32_t n1, const uint64_t *p2,
+                         const uint8_t *c2, uint32_t n2, uint64_t *f1, uint8_t *fc1, uint32_t *nf1, uint64_t *f2,
+                         uint8_t *fc2, uint32_t *nf2) {
+  uint32_t i1 = 0, i2 = 0, o1 = 0, o2 = 0;
+  int unpaired1 = 0, unpaired2 = 0;
+  int max1 = 6, max2 = 6;
+  uint32_t prev_end_i2 = 0;
+  while (i1 < n1 && i2 < n2) {
+    const uint64_t a = p1[i1], b = p2[i2];
+    if (a > b + dist) {
+      if (i2 >= prev_end_i2 && unpaired2 < 5 && (a >> 32) == (b >> 32) && (int)c2[i2] >= max2) {
+        f2[o2] = b; fc2[o2] = c2[i2]; ++o2;
+        ++unpaired2;
+      }
+      ++i2;
+    } else if (b > a + dist) {
+      if (unpaired1 < 5 && (a >> 32) == (b >> 32) && (int)c1[i1] >= max1) {
+        f1[o1] = a; fc1[o1] = c1[i1]; ++o1;
+        ++unpaired1;
+      }
+      ++i1;
+    } else {
+      f1[o1] = a; fc1[o1] = c1[i1]; ++o1;
+      if ((int)c1[i1] > max1) max1 = c1[i1];
+      uint32_t cur = i2;
+      while (cur < n2 && p2[cur] <= a + dist) {
+        if (cur >= prev_end_i2) {
+          f2[o2] = p2[cur]; fc2[o2] = c2[cur]; ++o2;
+          if ((int)c2[cur] > max2) max2 = c2[cur];
+        }
+        ++cur;
+      }
+      prev_end_i2 = cur;
+      ++i1;
+    }
+  }
+  *nf1 = o1;
+  *nf2 = o2;
+}
+
+// ---------------------------------------------------------------------------------------
+// S4c: per pair -- SupplementCandidates return value, candidate-count gates and the
+//      paired-end filter (chromap.h:1020-1056, candidate_processor.cc:183-191, 233-263)
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  d.fcp[r1] = d.fcn[r1] = d.fcp[r2] = d.fcn[r2] = 0;
+  d.alive[pair] = 0;
+  d.force0[pair] = 0;
+  if (d.m_tot[r1] == 0 && d.m_tot[r2] == 0 && !(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return;
+  if (!(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return;
+  int ret = 0;
+  for (uint32_t r = r1; r <= r2; ++r) {
+    if (!d.aug[r]) continue;
+    const int pr = d.res_neg[r], nr = d.res_pos[r];  // positive_rescue_result / negative_rescue_result
+    if (((pr < 0 && nr > 0 && -pr >= nr) || (pr > 0 && nr < 0 && pr <= -nr)) && d.ncp[r] + d.ncn[r] == 0) ret = 1;
+  }
+  d.force0[pair] = (uint8_t)ret;
+  const uint32_t nc1 = d.mcp[r1] + d.mcn[r1], nc2 = d.mcp[r2] + d.mcn[r2];
+  if (!(nc1 > 0 && nc2 > 0)) return;
+  uint32_t a, b;
+  cm_reduce_dir((uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2),
+                cm_m_ncnt(d, r2), d.mcn[r2], cm_f_pos(d, r1), cm_f_pcnt(d, r1), &a, cm_f_neg(d, r2), cm_f_ncnt(d, r2), &b);
+  d.fcp[r1] = a; d.fcn[r2] = b;
+  cm_reduce_dir((uint32_t)d.p.max_insert, cm_m_neg(d, r1), cm_m_ncnt(d, r1), d.mcn[r1], cm_m_pos(d, r2),
+                cm_m_pcnt(d, r2), d.mcp[r2], cm_f_neg(d, r1), cm_f_ncnt(d, r1), &a, cm_f_pos(d, r2), cm_f_pcnt(d, r2), &b);
+  d.fcn[r1] = a; d.fcp[r2] = b;
+  const uint32_t f1 = d.fcp[r1] + d.fcn[r1], f2 = d.fcp[r2] + d.fcn[r2];
+  d.alive[pair] = (f1 > 0 && f2 > 0) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: verification
+// ---------------------------------------------------------------------------------------
+// BandedAlignPatternToText (alignment.cc:141-192): Myers/Hyyro bit-vector banded edit
+// distance, 32-bit word, band 2e+1.  pattern = reference window, text = read.
+// neg: text is the reverse complement of `read` (read[len-1-i] complemented).
+CM_HD uint32_t cm_text_code(const uint8_t *read, int L, int i, bool neg) {
+  if (!neg) return cm_c2u(read[i]);
+  const uint32_t c = cm_c2u(read[L - 1 - i]);
+  return c < 4 ? 3u ^ c : 4u;
+}
+CM_HD uint8_t cm_text_char(const uint8_t *read, int L, int i, bool neg) {
+  return neg ? cm_negchar(read[L - 1 - i]) : read[i];
+}
+
+CM_HD uint32_t cm_peq_get(const uint32_t *P, uint32_t c) {
+  return c == 0 ? P[0] : c == 1 ? P[1] : c == 2 ? P[2] : c == 3 ? P[3] : P[4];
+}
+CM_HD void cm_peq_or(uint32_t *P, uint32_t c, uint32_t bit) {
+  P[0] |= c == 0 ? bit : 0u; P[1] |= c == 1 ? bit : 0u; P[2] |= c == 2 ? bit : 0u;
+  P[3] |= c == 3 ? bit : 0u; P[4] |= c == 4 ? bit : 0u;
+}
+
+CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, int L, bool neg, int *end_pos) {
+  uint32_t P[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pattern[i]), 1u << i);
+  const uint32_t hi = 1u << (2 * e);
+  uint32_t VP = 0, VN = 0;
+  int err = 0;
+  for (int i = 0; i < L; i++) {
+    cm_peq_or(P, cm_c2u(pattern[i + 2 * e]), hi);
+    uint32_t X = cm_peq_get(P, cm_text_code(read, L, i, neg)) | VN;
+    const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+    const uint32_t HN = VP & D0;
+    const uint32_t HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    err += 1 - (int)(D0 & 1u);
+    if (err > 3 * e) return e + 1;
+    P[0] >>= 1; P[1] >>= 1; P[2] >>= 1; P[3] >>= 1; P[4] >>= 1;
+  }
+  const int band_start = L - 1;
+  int min_err = err;
+  *end_pos = band_start;
+  for (int i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *end_pos = band_start + 1 + i;
+    }
+  }
+  return min_err;
+}
+
+// BandedTraceback (alignment.cc:656-718)
+CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int L, bool neg) {
+  if (min_num_errors == 0) return e;
+  int error_count = 0;
+  for (int i = 0; i < L; ++i)
+    if (pattern[i + e] != cm_text_char(read, L, i, neg)) ++error_count;  // raw, case-sensitive (:666)
+  if (error_count == min_num_errors) return e;
+  uint32_t P[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pattern[L - 1 + 2 * e - i]), 1u << i);
+  const uint32_t hi = 1u << (2 * e);
+  uint32_t VP = 0, VN = 0;
+  int err = 0;
+  for (int i = 0; i < L; i++) {
+    cm_peq_or(P, cm_c2u(pattern[L - 1 - i]), hi);
+    uint32_t X = cm_peq_get(P, cm_text_code(read, L, L - 1 - i, neg)) | VN;
+    const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+    const uint32_t HN = VP & D0;
+    const uint32_t HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    err += 1 - (int)(D0 & 1u);
+    P[0] >>= 1; P[1] >>= 1; P[2] >>= 1; P[3] >>= 1; P[4] >>= 1;
+  }
+  int start = 2 * e;
+  for (int i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err == min_num_errors) {
+      start = 2 * e - (1 + i);
+      if (i + 1 == e) return start;
+    }
+  }
+  return start;
+}
+
+// IsValidCandidate (draft_mapping_generator.cc:59-70)
+CM_HD bool cm_valid_candidate(const CmDev &d, uint32_t rid, uint32_t position, uint32_t L) {
+  const uint32_t rl = d.ref_len[rid];
+  return !(position < (uint32_t)d.p.e || position >= rl || position + L + (uint32_t)d.p.e >= rl);
+}
+
+struct CmBest { int min_err, second_err, n_best, n_second; };
+CM_HD void cm_update_best(CmBest &m, int ne) {  // draft_mapping_generator.cc:502-528
+  if (ne < m.min_err) { m.second_err = m.min_err; m.n_second = m.n_best; m.min_err = ne; m.n_best = 1; }
+  else if (ne == m.min_err) m.n_best++;
+  else if (ne == m.second_err) m.n_second++;
+  else if (ne < m.second_err) { m.n_second = 1; m.second_err = ne; }
+}
+
+// verify one candidate; on acceptance append the draft mapping. returns accepted
+CM_HD bool cm_verify_one(const CmDev &d, const uint8_t *read, uint32_t L, int strand, uint64_t cpos, CmBest &bst,
+                         uint64_t *dp, int8_t *de, uint32_t *nd) {
+  const int e = d.p.e;
+  const uint32_t rid = (uint32_t)(cpos >> 32);
+  uint32_t position = (uint32_t)cpos;
+  if (strand == 1) position = position - L + 1;
+  int end_pos = (int)L;
+  const int ne = cm_banded_align(e, d.ref + d.ref_off[rid] + position - e, read, (int)L, strand == 1, &end_pos);
+  if (ne <= e) {
+    cm_update_best(bst, ne);
+    dp[*nd] = strand == 0 ? cpos - (uint64_t)e + (uint64_t)(int64_t)end_pos
+                          : cpos - L + 1 - (uint64_t)e + (uint64_t)(int64_t)end_pos;
+    de[*nd] = (int8_t)ne;
+    ++*nd;
+    return true;
+  }
+  return false;
+}
+
+// one strand of GenerateDraftMappings: scalar loop (draft_mapping_generator.cc:359-557, non-split)
+// or the lane-grouped loop with the candidate_count_threshold break (:159-357)
+CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, int strand, const uint64_t *cp,
+                               const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int8_t *de) {
+  uint32_t nd = 0;
+  const int lanes = d.p.lanes;
+  if (lanes == 0 || nc < (uint32_t)lanes) {
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+      const uint32_t rid = (uint32_t)(cp[ci] >> 32);
+      uint32_t position = (uint32_t)cp[ci];
+      if (strand == 1) position = position - L + 1;
+      if (!cm_valid_candidate(d, rid, position, L)) continue;
+      cm_verify_one(d, read, L, strand, cp[ci], bst, dp, de, &nd);
+    }
+    return nd;
+  }
+  uint64_t vpos[8];
+  uint8_t vcnt[8];
+  uint32_t nvalid = 0, thr = 0, ci = 0;
+  while (ci < nc) {
+    if (cc[ci] < thr) break;
+    const uint32_t rid = (uint32_t)(cp[ci] >> 32);
+    uint32_t position = (uint32_t)cp[ci];
+    if (strand == 1) position = position - L + 1;
+    if (!cm_valid_candidate(d, rid, position, L)) { ++ci; continue; }
+    vpos[nvalid] = cp[ci];
+    vcnt[nvalid] = cc[ci];
+    ++nvalid;
+    ++ci;
+    if (nvalid < (uint32_t)lanes) continue;
+    for (int mi = 0; mi < lanes; ++mi)
+      if (!cm_verify_one(d, read, L, strand, vpos[mi], bst, dp, de, &nd)) thr = vcnt[mi];
+    nvalid = 0;
+  }
+  for (uint32_t i = 0; i < nvalid; ++i) cm_verify_one(d, read, L, strand, vpos[i], bst, dp, de, &nd);
+  return nd;
+}
+
+// ---------------------------------------------------------------------------------------
+// S5: per read -- DraftMappingGenerator::GenerateDraftMappings (draft_mapping_generator.cc:9-57)
+//      incl. the all-minimizer shortcut (:72-157).  Draft mappings go to dpos/derr at the
+//      same offsets as the filtered candidate lists.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1;
+  d.ndp[r] = 0; d.ndn[r] = 0;
+  const int e = d.p.e;
+  CmBest bst = {e + 1, e + 1, 0, 0};
+  if (d.alive[pair]) {
+    const uint32_t L = d.rlen[r];
+    const uint8_t *read = cm_read_ptr(d, r);
+    uint64_t *pp = cm_f_pos(d, r), *np = cm_f_neg(d, r);
+    uint8_t *pc = cm_f_pcnt(d, r), *nc = cm_f_ncnt(d, r);
+    const uint32_t ncp = d.fcp[r], ncn = d.fcn[r];
+    uint64_t *dpp = d.dpos + d.m_off[r], *dpn = d.dpos + d.m_off[r] + d.ncp[r] + d.resc_p[r];
+    int8_t *dep = d.derr + d.m_off[r], *den = d.derr + d.m_off[r] + d.ncp[r] + d.resc_p[r];
+    bool done = false;
+    if (ncp + ncn == 1) {
+      const int strand = ncp == 1 ? 0 : 1;
+      const uint64_t cpos = strand == 0 ? pp[0] : np[0];
+      const uint8_t cnt = strand == 0 ? pc[0] : nc[0];
+      if ((uint32_t)cnt == d.mm_cnt[r]) {
+        bst.min_err = 0; bst.n_best = 1; bst.n_second = 0;
+        const uint32_t rid = (uint32_t)(cpos >> 32);
+        const uint32_t position = strand == 0 ? (uint32_t)cpos : (uint32_t)cpos - L + 1;
+        if (cm_valid_candidate(d, rid, position, L)) {
+          if (strand == 0) { dpp[0] = cpos + L - 1; dep[0] = 0; d.ndp[r] = 1; }
+          else { dpn[0] = cpos; den[0] = 0; d.ndn[r] = 1; }
+          done = true;
+        }
+      }
+    }
+    if (!done) {
+      cm_sort_cand(pp, pc, ncp);
+      cm_sort_cand(np, nc, ncn);
+      d.ndp[r] = cm_draft_strand(d, read, L, 0, pp, pc, ncp, bst, dpp, dep);
+      d.ndn[r] = cm_draft_strand(d, read, L, 1, np, nc, ncn, bst, dpn, den);
+    }
+  }
+  d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
+  d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
+}
+
+// ---------------------------------------------------------------------------------------
+// K5: best pair, coordinates, MAPQ
+// ---------------------------------------------------------------------------------------
+struct CmPe { int min_sum, second_sum, n_best, n_second; uint32_t f_dir, f_i1, f_i2; };
+
+// GenerateBestMappingsForPairedEndReadOnOneDirection, non-split (mapping_generator.h:347-484).
+// When want >= 0, stops at the want-th pair (0-based, counted across directions via *seen)
+// whose error sum equals final_min and returns it in (f_dir,f_i1,f_i2).
+CM_HD bool cm_pair_dir(const CmDev &d, int dir, const uint64_t *ap, const int8_t *ae, uint32_t na,
+                       const uint64_t *bp, const int8_t *be, uint32_t nb, uint32_t len1, uint32_t len2, CmPe &pe,
+                       int64_t want, int final_min, int64_t *seen) {
+  const uint64_t I = (uint64_t)(int64_t)d.p.max_insert;
+  const uint64_t mo = (uint32_t)d.p.min_read_len;
+  uint32_t i1 = 0, i2 = 0;
+  while (i1 < na && i2 < nb) {
+    const uint64_t p1 = ap[i1], p2 = bp[i2];
+    if ((dir == 1 && p1 > p2 + I - len2) || (dir == 0 && p1 > p2 + len1 - mo)) {
+      ++i2;
+    } else if ((dir == 0 && p2 > p1 + I - len1) || (dir == 1 && p2 > p1 + len2 - mo)) {
+      ++i1;
+    } else {
+      uint32_t cur = i2;
+      while (cur < nb && ((dir == 0 && bp[cur] <= p1 + I - len1) || (dir == 1 && bp[cur] <= p1 + len2 - mo))) {
+        const int s = (int)ae[i1] + (int)be[cur];
+        if (want >= 0) {
+          if (s == final_min) {
+            if (*seen == want) { pe.f_dir = (uint32_t)dir; pe.f_i1 = i1; pe.f_i2 = cur; return true; }
+            ++*seen;
+          }
+        } else if (s < pe.min_sum) {
+          pe.second_sum = pe.min_sum; pe.n_second = pe.n_best; pe.min_sum = s; pe.n_best = 1;
+          pe.f_dir = (uint32_t)dir; pe.f_i1 = i1; pe.f_i2 = cur;
+        } else if (s == pe.min_sum) {
+          pe.n_best++;
+        } else if (s == pe.second_sum) {
+          pe.n_second++;
+        } else if (s < pe.second_sum) {
+          pe.second_sum = s; pe.n_second = 1;
+        }
+        ++cur;
+      }
+      ++i1;
+    }
+  }
+  return false;
+}
+
+struct CmSpan { uint32_t rid, ref_start, ref_end; };
+// GetRefStartEndPositionForReadFromMapping, non-SAM non-split (mapping_generator.h:657-717,
+// 762-793, 855-916).  The reference reads up to e bytes past the end of a chromosome when
+// ref_pos + e >= length (:703-708); HBM holds zero padding there (kseq's NUL, then zeros).
+CM_HD CmSpan cm_ref_start_end(const CmDev &d, uint64_t dpos, int nerr, int strand, const uint8_t *read, int L) {
+  const int e = d.p.e;
+  const uint32_t rid = (uint32_t)(dpos >> 32), ref_pos = (uint32_t)dpos;
+  const uint32_t rl = d.ref_len[rid];
+  uint32_t vw = ref_pos + 1 > (uint32_t)(L + e) ? ref_pos + 1 - (uint32_t)L - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)L;
+  const int start = cm_banded_traceback(e, nerr, d.ref + d.ref_off[rid] + vw, read, L, strand == 1);
+  CmSpan s;
+  s.rid = rid;
+  s.ref_start = vw + (uint32_t)start;
+  s.ref_end = ref_pos;
+  return s;
+}
+
+// (int)(4.343 * log(n + 1) + 0.499) for n >= 1 via host-computed breakpoints:
+// nsec_break[v] = smallest n whose value is >= v (monotone step function)
+CM_HD int cm_nsec_penalty(const CmMapqTables &t, int n) {
+  int v = 0;
+  for (int i = 0; i < t.n_break; ++i) {
+    if ((uint32_t)n >= t.nsec_break[i]) v = i; else break;
+  }
+  return v;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_SQRT(x) __dsqrt_rn(x)
+#else
+#include <math.h>
+#define CM_SQRT(x) sqrt(x)
+#endif
+
+// GetMAPQForSingleEndRead, non-split (mapping_generator.h:920-1022)
+CM_HD uint8_t cm_mapq_single(const CmDev &d, int num_errors, uint16_t alignment_length, int read_length, int max_diff,
+                             int second_err, int n_best, int n_second, uint32_t rep_len) {
+  alignment_length = alignment_length > read_length ? alignment_length : (uint16_t)read_length;
+  const double alignment_identity = 1 - (double)num_errors / alignment_length;
+  int mapq = 0;
+  int second = second_err;
+  if (n_best > 1) {
+  } else {
+    if (second > num_errors + max_diff) second = num_errors + max_diff;
+    double tmp = d.mq.len_coef[alignment_length];
+    tmp *= alignment_identity * alignment_identity;
+    mapq = (int)(5 * 6.02 * (second - num_errors) * tmp * tmp + 0.499);
+  }
+  if (n_second > 0) mapq -= cm_nsec_penalty(d.mq, n_second);
+  if (mapq > 60) mapq = 60;
+  if (mapq < 0) mapq = 0;
+  if (rep_len > 0) {
+    double frac_rep = rep_len / (double)read_length;
+    if (rep_len >= (uint32_t)read_length) frac_rep = 0.999;
+    if (alignment_identity <= 0.95) mapq = (int)(mapq * (1 - CM_SQRT(frac_rep)) + 0.499);
+    else if (alignment_identity <= 0.97) mapq = (int)(mapq * (1 - frac_rep) + 0.499);
+    else if (alignment_identity >= 0.999) mapq = (int)(mapq * (1 - frac_rep * frac_rep * frac_rep * frac_rep) + 0.499);
+    else mapq = (int)(mapq * (1 - frac_rep * frac_rep) + 0.499);
+  }
+  return (uint8_t)mapq;
+}
+
+// GetMAPQForPairedEndRead, non-split (mapping_generator.h:1027-1192)
+CM_HD uint8_t cm_mapq_paired(const CmDev &d, uint32_t pair, int err1, int err2, uint16_t al1, uint16_t al2, int len1,
+                             int len2, int force_mapq, const CmPe &pe) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  uint8_t mapq_pe = 0;
+  const int min_unpaired = d.min_err[r1] + d.min_err[r2] + 3;
+  if (pe.n_best <= 1) {
+    const int adj = pe.second_sum < min_unpaired ? pe.second_sum : min_unpaired;
+    mapq_pe = (uint8_t)((int)(5 * 6.02 * (adj - pe.min_sum) / (1) + .499));
+    if (pe.n_second > 0) mapq_pe = (uint8_t)(mapq_pe - cm_nsec_penalty(d.mq, pe.n_second));
+    if (mapq_pe > 60) mapq_pe = 60;
+    const int rep = (int)(d.rep_len[r1] + d.rep_len[r2]);
+    if (rep > 0) {
+      const double total = len1 + len2;
+      double frac_rep = (double)rep / total;
+      if (rep >= total) frac_rep = 0.999;
+      const double id1 = 1 - (double)err1 / (len1 > al1 ? len1 : al1);
+      const double id2 = 1 - (double)err2 / (len2 > al2 ? len2 : al2);
+      const double id = id1 < id2 ? id1 : id2;
+      if (id <= 0.95) mapq_pe = (uint8_t)(mapq_pe * (1 - CM_SQRT(frac_rep)) + 0.499);
+      else if (id <= 0.97) mapq_pe = (uint8_t)(mapq_pe * (1 - frac_rep) + 0.499);
+      else if (id >= 0.999) mapq_pe = (uint8_t)(mapq_pe * (1 - frac_rep * frac_rep * frac_rep * frac_rep) + 0.499);
+      else mapq_pe = (uint8_t)(mapq_pe * (1 - frac_rep * frac_rep) + 0.499);
+    }
+  }
+  uint8_t mapq1 = cm_mapq_single(d, err1, al1, len1, 2, d.second_err[r1], d.n_best[r1], d.n_second[r1], d.rep_len[r1]);
+  uint8_t mapq2 = cm_mapq_single(d, err2, al2, len2, 2, d.second_err[r2], d.n_best[r2], d.n_second[r2], d.rep_len[r2]);
+  mapq1 = (uint8_t)(mapq1 > mapq_pe ? (double)mapq1 : mapq_pe < mapq1 + mapq_pe * 0.65 ? (double)mapq_pe : mapq1 + mapq_pe * 0.65);
+  mapq2 = (uint8_t)(mapq2 > mapq_pe ? (double)mapq2 : mapq_pe < mapq2 + mapq_pe * 0.65 ? (double)mapq_pe : mapq2 + mapq_pe * 0.65);
+  mapq1 = (uint8_t)(mapq1 * 1.2);
+  if (mapq1 > 60) mapq1 = 60;
+  mapq2 = (uint8_t)(mapq2 * 1.2);
+  if (mapq2 > 60) mapq2 = 60;
+  uint8_t mapq = mapq1 < mapq2 ? mapq1 : mapq2;
+  if (mapq < 60 && force_mapq >= 0 && force_mapq < mapq) mapq = (uint8_t)force_mapq;
+  return mapq;
+}
+
+CM_HD const uint64_t *cm_d_pos(const CmDev &d, uint32_t r, int strand) {
+  return d.dpos + d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0);
+}
+CM_HD const int8_t *cm_d_err(const CmDev &d, uint32_t r, int strand) {
+  return d.derr + d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0);
+}
+
+// Build the output record for the chosen best pair: ProcessBestMappingsForPairedEndReadOn-
+// OneDirection (mapping_generator.h:487-653) + EmplaceBackPairedEndMappingRecord
+// (mapping_generator.cc:111-125) + PairedEndMappingInMemory getters (mapping_in_memory.h:64-108)
+CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  const int dir = (int)pe.f_dir;
+  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  const int s1 = dir == 0 ? 0 : 1, s2 = dir == 0 ? 1 : 0;
+  const uint64_t dp1 = cm_d_pos(d, r1, s1)[pe.f_i1], dp2 = cm_d_pos(d, r2, s2)[pe.f_i2];
+  const int e1 = cm_d_err(d, r1, s1)[pe.f_i1], e2 = cm_d_err(d, r2, s2)[pe.f_i2];
+  const CmSpan a = cm_ref_start_end(d, dp1, e1, s1, cm_read_ptr(d, r1), (int)len1);
+  const CmSpan b = cm_ref_start_end(d, dp2, e2, s2, cm_read_ptr(d, r2), (int)len2);
+  const uint16_t al1 = (uint16_t)(a.ref_end - a.ref_start + 1), al2 = (uint16_t)(b.ref_end - b.ref_start + 1);
+  const int force_mapq = d.force0[pair] ? 0 : -1;
+  const uint8_t mapq = cm_mapq_paired(d, pair, e1, e2, al1, al2, (int)len1, (int)len2, force_mapq, pe);
+  const uint8_t is_unique = (pe.n_best == 1 || d.n_best[r1] == 1 || d.n_best[r2] == 1) ? 1 : 0;
+  const CmSpan &ps = dir == 0 ? a : b;  // the + strand read
+  const CmSpan &ns = dir == 0 ? b : a;
+  uint8_t *o = d.rec + (uint64_t)pair * 24;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+  uint16_t *o16 = reinterpret_cast<uint16_t *>(o);
+  o32[0] = d.first_read_id + pair;
+  o32[1] = a.rid;
+  o32[2] = ps.ref_start;
+  o16[6] = (uint16_t)(int)(ns.ref_end - ps.ref_start + 1);
+  o[14] = mapq & 63;
+  o[15] = dir == 0 ? 1 : 0;
+  o[16] = is_unique;
+  o[17] = 1;
+  o16[9] = (uint16_t)(ps.ref_end - ps.ref_start + 1);
+  o16[10] = (uint16_t)(ns.ref_end - ns.ref_start + 1);
+  o16[11] = 0;
+  d.rec_ok[pair] = 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// S6a: per pair -- sort draft mappings by position, pairing sweeps in both orientations
+//      (GenerateBestMappingsForPairedEndRead, mapping_generator.h:160-253), record for pairs
+//      with a single best pairing.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  d.rec_ok[pair] = 0;
+  d.pe_nbest[pair] = 0;
+  d.pe_choice[pair] = 0;
+  if (!d.alive[pair]) return;
+  const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
+  if (!(nd1 > 0 && nd2 > 0)) return;  // chromap.h:1092-1093
+  for (uint32_t r = r1; r <= r2; ++r) {
+    cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 0)), const_cast<int8_t *>(cm_d_err(d, r, 0)), d.ndp[r]);
+    cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 1)), const_cast<int8_t *>(cm_d_err(d, r, 1)), d.ndn[r]);
+  }
+  CmPe pe;
+  pe.min_sum = 2 * d.p.e + 1; pe.second_sum = 2 * d.p.e + 1; pe.n_best = 0; pe.n_second = 0;
+  pe.f_dir = 0; pe.f_i1 = 0; pe.f_i2 = 0;
+  int64_t seen = 0;
+  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  cm_pair_dir(d, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
+              len1, len2, pe, -1, 0, &seen);
+  cm_pair_dir(d, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
+              len1, len2, pe, -1, 0, &seen);
+  d.pe_min[pair] = pe.min_sum; d.pe_second[pair] = pe.second_sum;
+  d.pe_nbest[pair] = pe.n_best; d.pe_nsecond[pair] = pe.n_second;
+  d.pe_first[pair] = pe.f_dir; d.pe_i1[pair] = pe.f_i1; d.pe_i2[pair] = pe.f_i2;
+  if (pe.n_best == 1) cm_emit_record(d, pair, pe);
+}
+
+// ---------------------------------------------------------------------------------------
+// S6b: reservoir sampling of multi-mappers, one taskloop task ("chunk") per item.
+//   The reference's generator is firstprivate in each task of `taskloop grainsize(5000)`
+//   (chromap.h:863,892): every task starts from std::mt19937(11) and walks its own pairs
+//   in order; libgomp gives T = n/grain tasks (1 if T <= 1) of n/T iterations, the first
+//   n%T tasks one more.  Draws follow libstdc++'s uniform_int_distribution<int>(0,i)
+//   (Lemire's method on 32-bit output).  max_num_best_mappings == 1.
+// ---------------------------------------------------------------------------------------
+struct CmMt { uint32_t mt[624]; int idx; };
+CM_HD void cm_mt_seed(CmMt &g, uint32_t s) {
+  g.mt[0] = s;
+  for (int i = 1; i < 624; ++i) g.mt[i] = 1812433253u * (g.mt[i - 1] ^ (g.mt[i - 1] >> 30)) + (uint32_t)i;
+  g.idx = 624;
+}
+CM_HD uint32_t cm_mt_next(CmMt &g) {
+  if (g.idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const uint32_t y = (g.mt[i] & 0x80000000u) | (g.mt[(i + 1) % 624] & 0x7fffffffu);
+      g.mt[i] = g.mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfu : 0);
+    }
+    g.idx = 0;
+  }
+  uint32_t y = g.mt[g.idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+CM_HD int cm_mt_uniform(CmMt &g, int hi) {
+  const uint32_t range = (uint32_t)hi + 1u;
+  uint64_t product = (uint64_t)cm_mt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (uint32_t)(0u - range) % range;
+    while (low < threshold) {
+      product = (uint64_t)cm_mt_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (int)(product >> 32);
+}
+
+// chunk geometry: pairs [lo,hi) of chunk c within the batch
+CM_HD uint32_t cm_num_chunks(uint32_t n, uint32_t ref_batch, uint32_t grain) {
+  uint32_t tot = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += ref_batch) {
+    const uint32_t bn = n - b0 < ref_batch ? n - b0 : ref_batch;
+    const uint32_t T = bn / grain;
+    tot += T <= 1 ? 1 : T;
+  }
+  return tot;
+}
+CM_HD void cm_chunk_range(uint32_t n, uint32_t ref_batch, uint32_t grain, uint32_t c, uint32_t *lo, uint32_t *hi) {
+  for (uint32_t b0 = 0; b0 < n; b0 += ref_batch) {
+    const uint32_t bn = n - b0 < ref_batch ? n - b0 : ref_batch;
+    uint32_t T = bn / grain;
+    if (T <= 1) T = 1;
+    if (c >= T) { c -= T; continue; }
+    if (T == 1) { *lo = b0; *hi = b0 + bn; return; }
+    const uint32_t dv = bn / T, md = bn % T;
+    const uint32_t s = b0 + c * dv + (c < md ? c : md);
+    *lo = s;
+    *hi = s + dv + (c < md ? 1 : 0);
+    return;
+  }
+  *lo = *hi = n;
+}
+
+CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
+  uint32_t lo, hi;
+  cm_chunk_range(d.n_pairs, (uint32_t)d.p.ref_batch, (uint32_t)d.p.grain, chunk, &lo, &hi);
+  bool seeded = false;
+  for (uint32_t pair = lo; pair < hi; ++pair) {
+    const int nb = d.pe_nbest[pair];
+    if (nb <= 1) continue;
+    if (nb > d.p.drop_rep) continue;  // mapping_generator.h:193-196: returns before drawing
+    if (!seeded) { cm_mt_seed(g, 11); seeded = true; }
+    int choice = 0;
+    for (int i = 1; i < nb; ++i) {
+      const int j = cm_mt_uniform(g, i);
+      if (j < 1) choice = i;
+    }
+    d.pe_choice[pair] = (uint32_t)choice;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// S6c: per pair -- record for multi-mappers (re-runs the sweeps to find the chosen pair)
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
+  const int nb = d.pe_nbest[pair];
+  if (nb <= 1 || nb > d.p.drop_rep) return;
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  CmPe pe;
+  pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];
+  pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
+  const int64_t want = (int64_t)d.pe_choice[pair];
+  if (want > 0) {
+    int64_t seen = 0;
+    const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+    bool found = cm_pair_dir(d, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1),
+                             d.ndn[r2], len1, len2, pe, want, pe.min_sum, &seen);
+    if (!found)
+      found = cm_pair_dir(d, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0),
+                          d.ndp[r2], len1, len2, pe, want, pe.min_sum, &seen);
+    if (!found) { d.stats[CM_ST_ERR] = 2; return; }
+  }
+  cm_emit_record(d, pair, pe);
+}
+
+#endif  // CM_STAGES_H_

@@ -1,0 +1,138 @@
+// cm_types.h -- plain structs shared by host code, HIP kernels and the host-side
+// emulation harness under tests/hostemu (which compiles cm_stages.h with g++ to check the
+// per-item stage logic on a machine without a GPU; it is test infrastructure, the
+// library itself has no CPU path).
+#ifndef CM_TYPES_H_
+#define CM_TYPES_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CM_HD __host__ __device__ __forceinline__
+#define CM_D __device__ __forceinline__
+#else
+#define CM_HD inline
+#define CM_D inline
+#endif
+
+#define CM_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull   // bucket never written (khash "empty" flag)
+#define CM_DELETED_KEY 0xFFFFFFFFFFFFFFFEull // khash "deleted" flag (not produced by Index::Construct)
+
+// probe result kinds
+#define CM_PR_MISS 0
+#define CM_PR_SINGLE 1
+#define CM_PR_MULTI 2
+
+// Subset of MappingParameters used on the device.
+struct CmParams {
+  int32_t e;             // error_threshold
+  int32_t min_seeds;     // min_num_seeds_required_for_mapping
+  int32_t f0, f1;        // max_seed_frequencies
+  int32_t max_insert;    // max_insert_size
+  int32_t min_read_len;  // min_read_length
+  int32_t max_best;      // max_num_best_mappings (1)
+  int32_t drop_rep;      // drop_repetitive_reads
+  int32_t trim;          // trim_adapters
+  int32_t k, w;          // from the index file
+  int32_t lanes;         // GetNumVPULanes(): 8 if e<8, 4 if e<16, else 0
+  int32_t ref_batch;     // 500000
+  int32_t grain;         // 5000
+};
+
+// MAPQ tables computed on the host with libm so the device reproduces the reference's
+// double arithmetic without calling log() (mapping_generator.h:920-1192).
+struct CmMapqTables {
+  const double *len_coef;     // [65536]: alen < 50 ? 1.0 : 3 / log(alen)
+  const uint32_t *nsec_break; // [n_break]: smallest n with (int)(4.343*log(n+1)+0.499) >= v+1... see cm_api
+  int32_t n_break;
+};
+
+// All device pointers a stage needs.  Per-read arrays are indexed r = 2*pair + mate.
+struct CmDev {
+  // ---- index in HBM: bucket i = {key, val} at bkt[2i], bkt[2i+1] (16-B aligned)
+  const uint64_t *bkt;
+  uint32_t bmask;
+  const uint64_t *occ;
+  uint32_t n_occ;
+  // ---- reference in HBM: raw bytes, sequences separated by >= 64 zero bytes
+  const uint8_t *ref;
+  const uint64_t *ref_off;
+  const uint32_t *ref_len;
+  uint32_t n_seq;
+  CmParams p;
+  CmMapqTables mq;
+  // ---- batch
+  uint32_t n_pairs;
+  uint32_t first_read_id;
+  const uint8_t *rb0, *rb1;    // bases of mate 0 / mate 1
+  const uint32_t *ro0, *ro1;   // offsets (n_pairs+1)
+  // ---- per read
+  uint32_t *rlen;       // length after trimming; 0 when the pair was dropped
+  uint32_t *mm_cap_off; // [2n+1] prefix of slot capacities (max(0, raw_len-k+1))
+  uint64_t *slot_hash;  // slot arrays
+  uint32_t *slot_ps;    // (pos<<1)|strand
+  uint32_t *mm_cnt;     // [2n]
+  uint32_t *mm_off;     // [2n+1] dense prefix
+  uint64_t *mm_hash;    // dense
+  uint32_t *mm_ps;
+  uint64_t *pr_val;     // dense probe result value
+  uint8_t *pr_kind;
+  // ---- hits / first candidates
+  uint32_t *hit_tot;    // [2n] total hits of the round used
+  uint32_t *hit_off;    // [2n+1]
+  uint8_t *round2;      // [2n] 1 when the high-frequency round was used
+  uint32_t *rep_cnt;    // [2n]
+  uint32_t *rep_len;    // [2n]
+  uint64_t *hbuf;       // hits, then candidates in place
+  uint8_t *hcnt;        // candidate counts (same indexing as hbuf)
+  uint32_t *n_pos_hit;  // [2n] boundary P between + and - sub-lists
+  uint32_t *ncp, *ncn;  // [2n] candidates after GenerateCandidates
+  // ---- rescue / merged candidates
+  uint8_t *aug;         // [2n] augment flag
+  int32_t *res_neg;     // [2n] result of the search on the - strand (driven by mate + candidates)
+  int32_t *res_pos;     // [2n]
+  uint32_t *resc_n;     // [2n] rescue hits on - strand
+  uint32_t *resc_p;     // [2n] rescue hits on + strand
+  uint32_t *m_tot;      // [2n] capacity of merged lists (ncp+resc_p + ncn+resc_n)
+  uint32_t *m_off;      // [2n+1]
+  uint64_t *mbuf;       // merged candidates: + list at m_off[r], - list at m_off[r]+ncp+resc_p
+  uint8_t *mcnt;
+  uint32_t *mcp, *mcn;  // [2n] merged candidate counts
+  uint8_t *force0;      // [n] SupplementCandidates returned 1
+  // ---- filtered candidates (same offsets/capacities as merged)
+  uint64_t *fbuf;
+  uint8_t *fcnt;
+  uint32_t *fcp, *fcn;  // [2n]
+  uint8_t *alive;       // [n] pair still in play
+  // ---- draft mappings (same offsets as filtered candidates)
+  uint64_t *dpos;
+  int8_t *derr;
+  uint32_t *ndp, *ndn;  // [2n]
+  int32_t *min_err, *second_err, *n_best, *n_second; // [2n]
+  // ---- pair level
+  int32_t *pe_min, *pe_second, *pe_nbest, *pe_nsecond; // [n]
+  uint32_t *pe_first;   // [n] packed first best: dir<<31 | ... see cm_stages
+  uint32_t *pe_i1, *pe_i2; // [n]
+  uint32_t *pe_choice;  // [n] chosen best index (0 unless multi-mapper)
+  // ---- output
+  uint8_t *rec;         // n records of 24 bytes (cmgpu_record layout)
+  uint8_t *rec_ok;      // [n]
+  unsigned long long *stats; // device counters (see CM_ST_*)
+};
+
+#define CM_ST_CAND 0
+#define CM_ST_MAPPINGS 1
+#define CM_ST_MAPPED 2
+#define CM_ST_UNIQ 3
+#define CM_ST_MINIMIZERS 4
+#define CM_ST_PROBE_STEPS 5
+#define CM_ST_PROBE_HITS 6
+#define CM_ST_OCC 7
+#define CM_ST_RESCUED 8
+#define CM_ST_MULTI 9
+#define CM_ST_ERR 10
+#define CM_ST_RECORDS 11
+#define CM_ST_N 16
+
+#endif

@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's mapping entry point for paired-end bulk data
+(Chromap::MapPairedEndReads, src/chromap.h:636-1409) on top of the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import Batch, IndexView, Params, Record, RefView, Stats
+
+
+class ChromapError(RuntimeError):
+    pass
+
+
+def read_fastx(path):
+    """FASTA/FASTQ -> (bases uint8[total], offsets uint32[n+1], names list).  Plain text,
+    kseq record semantics (name up to first whitespace; zero-length records skipped)."""
+    names, chunks, lens = [], [], []
+    with open(path, "rb") as f:
+        data = f.read()
+    lines = data.split(b"\n")
+    i, nl = 0, len(lines)
+    while i < nl:
+        ln = lines[i].rstrip(b"\r")
+        if not ln:
+            i += 1
+            continue
+        if ln[:1] == b"@":  # FASTQ, sequence may span lines until '+'
+            name = ln[1:].split()[0] if len(ln) > 1 else b""
+            i += 1
+            seq = []
+            while i < nl and not lines[i].startswith(b"+"):
+                seq.append(lines[i].rstrip(b"\r"))
+                i += 1
+            s = b"".join(seq)
+            i += 1  # '+'
+            q = 0
+            while i < nl and q < len(s):
+                q += len(lines[i].rstrip(b"\r"))
+                i += 1
+        elif ln[:1] == b">":
+            name = ln[1:].split()[0] if len(ln) > 1 else b""
+            i += 1
+            seq = []
+            while i < nl and lines[i][:1] not in (b">", b"@"):
+                seq.append(lines[i].rstrip(b"\r"))
+                i += 1
+            s = b"".join(seq)
+        else:
+            i += 1
+            continue
+        if len(s) == 0:
+            continue
+        names.append(name)
+        chunks.append(s)
+        lens.append(len(s))
+    off = np.zeros(len(lens) + 1, dtype=np.uint32)
+    if lens:
+        off[1:] = np.cumsum(np.asarray(lens, dtype=np.uint64)).astype(np.uint32)
+    bases = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy() if chunks else np.zeros(0, dtype=np.uint8)
+    return bases, off, names
+
+
+def read_fastq_pairs(path1, path2):
+    b1, o1, _ = read_fastx(path1)
+    b2, o2, _ = read_fastx(path2)
+    if len(o1) != len(o2):
+        raise ChromapError("Numbers of reads and barcodes don't match!")  # chromap.cc:110
+    return b1, o1, b2, o2
+
+
+class ChromapGPU:
+    """One context per GPU: index + reference resident in HBM, batches mapped by HIP kernels."""
+
+    def __init__(self, index_path=None, ref_path=None, params=None, device=0, preset=None, synthetic=None,
+                 **overrides):
+        self.L = _capi.lib()
+        self.params = params if params is not None else _capi.default_params(preset, **overrides)
+        self.ctx = C.c_void_p()
+        self._idx = None
+        self._ref = None
+        self.names = None
+        if synthetic is not None:
+            total, nseq, seed = synthetic
+            rc = self.L.cmgpu_create_synthetic(total, nseq, seed, 17, 7, C.byref(self.params), device, C.byref(self.ctx))
+            self._check(rc, None)
+            self.names = [b"chr%d" % (i + 1) for i in range(nseq)]
+        else:
+            self._idx = IndexView()
+            self._ref = RefView()
+            if self.L.cmgpu_load_index_file(index_path.encode(), C.byref(self._idx)) != 0:
+                raise ChromapError("cannot read index file %s" % index_path)
+            if self.L.cmgpu_load_reference_fasta(ref_path.encode(), C.byref(self._ref)) != 0:
+                raise ChromapError("cannot read reference %s" % ref_path)
+            rc = self.L.cmgpu_create(C.byref(self._idx), C.byref(self._ref), C.byref(self.params), device,
+                                     C.byref(self.ctx))
+            self._check(rc, None)
+            self.names = [self._ref.names[i] for i in range(self._ref.n_sequences)]
+        self.stats = Stats()
+
+    def _check(self, rc, ctx):
+        if rc != 0:
+            msg = self.L.cmgpu_last_error(ctx)
+            raise ChromapError("chromap_amd error %d: %s" % (rc, (msg or b"").decode()))
+
+    def _batch(self, b1, o1, b2, o2, first_read_id):
+        self._keep = [np.ascontiguousarray(b1, dtype=np.uint8), np.ascontiguousarray(o1, dtype=np.uint32),
+                      np.ascontiguousarray(b2, dtype=np.uint8), np.ascontiguousarray(o2, dtype=np.uint32)]
+        k = self._keep
+        return Batch(len(k[1]) - 1, first_read_id, k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data,
+                     k[3].ctypes.data)
+
+    def map_pairs(self, b1, o1, b2, o2, first_read_id=0):
+        """returns a ctypes array of Record (length = number of mapped pairs)"""
+        bt = self._batch(b1, o1, b2, o2, first_read_id)
+        rec = (Record * max(1, bt.n_pairs))()
+        n = C.c_uint64(0)
+        rc = self.L.cmgpu_map_pairs(self.ctx, C.byref(bt), C.cast(rec, C.c_void_p), bt.n_pairs, C.byref(n),
+                                    C.byref(self.stats))
+        self._check(rc, self.ctx)
+        return rec, int(n.value)
+
+    def upload(self, b1, o1, b2, o2, first_read_id=0):
+        bt = self._batch(b1, o1, b2, o2, first_read_id)
+        self._check(self.L.cmgpu_upload_batch(self.ctx, C.byref(bt)), self.ctx)
+
+    def generate_resident(self, n_pairs, read_length=50, frag_min=100, frag_max=600, sub_rate=0.01, seed=1):
+        self._check(self.L.cmgpu_generate_resident_batch(self.ctx, n_pairs, read_length, frag_min, frag_max, sub_rate,
+                                                         seed), self.ctx)
+        self._n_resident = n_pairs
+
+    def map_resident(self, stats=None):
+        n = C.c_uint64(0)
+        st = stats if stats is not None else self.stats
+        self._check(self.L.cmgpu_map_resident(self.ctx, C.byref(n), C.byref(st)), self.ctx)
+        return int(n.value)
+
+    def download_records(self, capacity):
+        rec = (Record * max(1, capacity))()
+        n = C.c_uint64(0)
+        self._check(self.L.cmgpu_download_records(self.ctx, C.cast(rec, C.c_void_p), capacity, C.byref(n)), self.ctx)
+        return rec, int(n.value)
+
+    def timings(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        k = self.L.cmgpu_last_timings(self.ctx, names, ms, 32)
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    def write_bed(self, rec, n, path, params=None):
+        p = params if params is not None else self.params
+        names = (C.c_char_p * len(self.names))(*self.names)
+        k = self.L.cmgpu_write_bed_pe(names, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, path.encode())
+        if k < 0:
+            raise ChromapError("cannot write %s" % path)
+        return int(k)
+
+    def close(self):
+        if self.ctx:
+            self.L.cmgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+        if self._idx is not None:
+            self.L.cmgpu_free_host_index(C.byref(self._idx))
+            self._idx = None
+        if self._ref is not None:
+            self.L.cmgpu_free_host_ref(C.byref(self._ref))
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

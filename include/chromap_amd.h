@@ -1,0 +1,203 @@
+/*
+ * chromap_amd.h -- C ABI of the MI355X (gfx950) implementation of Chromap's per-read
+ * mapping hot path.
+ *
+ * The reference (haowenz/chromap v0.3.3, /root/reference) has no plugin or FFI seam; the
+ * replacement point is the body of the per-batch OpenMP taskloop in
+ * Chromap::MapPairedEndReads (src/chromap.h:892-1143) together with the one-time loads in
+ * front of it (src/chromap.h:641-670).  Each entry point below names the reference
+ * code it stands in for.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * All functions return 0 on success and a negative CMGPU_E* code on failure; the text of
+ * the last failure is available from cmgpu_last_error().  The reference's convention is
+ * to abort the process (ExitWithMessage -> exit(-1), src/utils.h:71-74); the host driver
+ * turns a non-zero status into exactly that.  There is no CPU fallback: without a HIP
+ * device cmgpu_create fails with CMGPU_ENODEVICE.
+ */
+#ifndef CHROMAP_AMD_H_
+#define CHROMAP_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMGPU_OK 0
+#define CMGPU_EINVAL (-1)
+#define CMGPU_ENODEVICE (-2)
+#define CMGPU_EHIP (-3)
+#define CMGPU_ENOMEM (-4)
+#define CMGPU_ECAPACITY (-5)
+#define CMGPU_EIO (-6)
+
+/* The minimizer index exactly as Index::Load leaves it in host memory
+ * (src/index.cc:132-169, kh_load src/khash.h:358-373): khash open-addressing arrays with
+ * 2-bit flags, keys = minimizer_hash<<1 | is_singleton, values, and the occurrence
+ * table.  The library re-packs it for HBM; the caller keeps ownership. */
+typedef struct cmgpu_index_view {
+  int32_t kmer_size;   /* Index::kmer_size_, read from the index file */
+  int32_t window_size; /* Index::window_size_ */
+  uint32_t n_buckets;  /* kh_n_buckets, a power of two */
+  const uint32_t *flags; /* n_buckets/16 words (at least 1) */
+  const uint64_t *keys;  /* n_buckets */
+  const uint64_t *vals;  /* n_buckets */
+  uint32_t n_occurrences;
+  const uint64_t *occurrences;
+} cmgpu_index_view;
+
+/* The reference sequences as SequenceBatch::LoadAllSequences holds them
+ * (src/sequence_batch.cc:84-120): raw bytes, case and N preserved, file order. */
+typedef struct cmgpu_ref_view {
+  uint32_t n_sequences;
+  const char *const *names;     /* used only by cmgpu_write_bed_pe */
+  const char *const *sequences; /* n_sequences pointers, lengths[] bytes each */
+  const uint32_t *lengths;
+} cmgpu_ref_view;
+
+/* The fields of MappingParameters the path reads (src/mapping_parameters.h:18-89). */
+typedef struct cmgpu_params {
+  int32_t error_threshold;        /* -e */
+  int32_t min_num_seeds;          /* -s */
+  int32_t max_seed_frequency0;    /* -f first value */
+  int32_t max_seed_frequency1;    /* -f second value */
+  int32_t max_insert_size;        /* -l */
+  int32_t min_read_length;        /* --min-read-length */
+  int32_t max_num_best_mappings;  /* must be 1 (the CLI never sets anything else) */
+  int32_t drop_repetitive_reads;  /* --drop-repetitive-reads */
+  int32_t trim_adapters;          /* --trim-adapters */
+  int32_t split_alignment;        /* --split-alignment: not supported yet (CMGPU_EINVAL) */
+  int32_t mapq_threshold;         /* -q; used by cmgpu_write_bed_pe only */
+  int32_t remove_pcr_duplicates;  /* used by cmgpu_write_bed_pe only */
+  int32_t tn5_shift;              /* used by cmgpu_write_bed_pe only */
+  int32_t low_memory_mode;        /* used by cmgpu_write_bed_pe only */
+  int32_t read_batch_size;        /* Chromap::read_batch_size_ = 500000 (chromap.h:182) */
+  int32_t taskloop_grain_size;    /* 5000 (chromap.h:887): scope of the reservoir RNG */
+} cmgpu_params;
+
+/* A batch of read pairs as SequenceBatch holds them after parsing (src/chromap.cc:93-174):
+ * concatenated ASCII bases (any case, N allowed) with n+1 offsets per mate.  read_id of
+ * pair i is first_read_id + i (src/sequence_batch.cc:38-39). */
+typedef struct cmgpu_batch {
+  uint32_t n_pairs;
+  uint32_t first_read_id;
+  const char *read1_bases;
+  const uint32_t *read1_offsets; /* n_pairs + 1 */
+  const char *read2_bases;
+  const uint32_t *read2_offsets; /* n_pairs + 1 */
+} cmgpu_batch;
+
+/* Constructor arguments of PairedEndMappingWithoutBarcode (src/bed_mapping.h:191-206) plus
+ * rid, which the reference keeps implicitly as the index of the per-chromosome vector
+ * (src/mapping_generator.cc:116). 24 bytes. */
+typedef struct cmgpu_record {
+  uint32_t read_id;
+  uint32_t rid;
+  uint32_t fragment_start;
+  uint16_t fragment_length;
+  uint8_t mapq;      /* 6-bit field in the reference */
+  uint8_t direction; /* 1: read1 maps to the + strand */
+  uint8_t is_unique;
+  uint8_t num_dups;  /* 1 */
+  uint16_t positive_alignment_length;
+  uint16_t negative_alignment_length;
+} cmgpu_record;
+
+/* Counters of Chromap::OutputMappingStatistics (src/chromap.cc:808-823) plus the
+ * quantities SURVEY.md 8(d) defines the index-probe kernel's algorithmic bytes from. */
+typedef struct cmgpu_stats {
+  uint64_t num_candidates;
+  uint64_t num_mappings;
+  uint64_t num_mapped_reads;
+  uint64_t num_uniquely_mapped_reads;
+  uint64_t num_minimizers;      /* lookups issued by the probe kernel */
+  uint64_t probe_steps;         /* hash buckets visited by the probe kernel (16 B each) */
+  uint64_t occurrences_read;    /* occurrence-table entries expanded (8 B each) */
+  uint64_t num_pairs_rescued;   /* reads that went through mate rescue */
+  uint64_t num_multi_mappers;   /* pairs resolved by reservoir sampling */
+  uint64_t reserved[7];
+} cmgpu_stats;
+
+typedef struct cmgpu_ctx cmgpu_ctx;
+
+/* Fills *p with the reference's defaults (src/mapping_parameters.h:19-61). */
+void cmgpu_default_params(cmgpu_params *p);
+/* Applies a CLI preset ("atac", "chip", "hic") the way chromap_driver.cc:247-275 does. */
+int cmgpu_apply_preset(cmgpu_params *p, const char *preset);
+
+/* Replaces: reference.LoadAllSequences() + index.Load() + construction of the stateless
+ * worker objects (src/chromap.h:641-670, 763-778).  Uploads index and reference to the
+ * HBM of device_id once. */
+int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                 int device_id, cmgpu_ctx **out);
+
+/* Bench/test helper standing in for Index::Construct (src/index.cc:12-89) on a synthetic
+ * genome: n_sequences chromosomes of uniform random bases (xorshift seeded with seed) are
+ * generated and indexed on the device (functionally identical lookup results; bucket
+ * placement differs from khash's).  total_bases may be GRCh38-sized (3.1e9). */
+int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
+                           int32_t window_size, const cmgpu_params *params, int device_id, cmgpu_ctx **out);
+
+int cmgpu_destroy(cmgpu_ctx *ctx);
+/* ctx may be NULL (returns the last error of a failed cmgpu_create*). */
+const char *cmgpu_last_error(const cmgpu_ctx *ctx);
+
+/* Replaces the taskloop body src/chromap.h:892-1143 for one batch: adapter trimming,
+ * minimizers, index probe, candidate generation, mate rescue, pair filter, verification,
+ * best-pair selection, coordinates and MAPQ.  `in` holds HOST pointers; records are
+ * written to the caller's host buffer `out` (capacity in records; n_pairs always
+ * suffices).  Record order is unspecified (a total-order sort follows in the reference:
+ * src/mapping_processor.h:117-159).  stats may be NULL; counters are ACCUMULATED.
+ * A batch must start on a read_batch_size boundary of the input file for the reservoir
+ * sampling of multi-mappers to reproduce the reference. */
+int cmgpu_map_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,
+                    uint64_t *n_out, cmgpu_stats *stats);
+
+/* Device-resident variant used for throughput measurement: inputs are uploaded once,
+ * mapping runs on HBM-resident data and leaves the records in HBM. */
+int cmgpu_upload_batch(cmgpu_ctx *ctx, const cmgpu_batch *in);
+int cmgpu_map_resident(cmgpu_ctx *ctx, uint64_t *n_out, cmgpu_stats *stats);
+int cmgpu_download_records(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out);
+/* Generates n_pairs synthetic read pairs from the ctx's reference directly in HBM
+ * (fragment length uniform in [frag_min, frag_max), substitution rate sub_rate, R1/R2
+ * swapped with p = 0.5) and makes them the resident batch. */
+int cmgpu_generate_resident_batch(cmgpu_ctx *ctx, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
+                                  uint32_t frag_max, double sub_rate, uint64_t seed);
+/* Copies the resident batch back to host SoA buffers (for checking against the oracle). */
+int cmgpu_download_batch(cmgpu_ctx *ctx, char *read1_bases, uint32_t *read1_offsets, char *read2_bases,
+                         uint32_t *read2_offsets);
+
+/* Kernel-level entry for the graded index-probe kernel: looks up n minimizer hashes
+ * (device-resident after the call) `repeat` times; returns average kernel time in ms
+ * measured with HIP events on the launch stream, and the probe-step / hit counts. */
+int cmgpu_probe_bench(cmgpu_ctx *ctx, const uint64_t *hashes, uint64_t n, int repeat, double *avg_ms,
+                      uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences);
+
+/* Per-stage timing of the last cmgpu_map_* call (HIP events on the launch stream).
+ * names/ms arrays of capacity cap; returns number of stages. */
+int cmgpu_last_timings(const cmgpu_ctx *ctx, const char **names, float *ms, int cap);
+
+/* Export of the synthetic reference / index for checking against the oracle (small sizes). */
+int cmgpu_export_reference(cmgpu_ctx *ctx, uint32_t seq, char *out, uint32_t capacity);
+int cmgpu_reference_lengths(cmgpu_ctx *ctx, uint32_t *lengths, uint32_t capacity, uint32_t *n_sequences);
+
+/* Host post-processing that defines the final BED bytes: sort by (rid, operator<),
+ * PCR-duplicate removal as in the low-memory merge, MAPQ filter, Tn5 shift, text
+ * formatting (src/mapping_writer.h:166-376, src/mapping_writer.cc:72-83). Sorts `records`
+ * in place.  names: n_sequences reference names. */
+int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
+                           cmgpu_record *records, uint64_t n_records, const char *out_path);
+
+/* Host loaders mirroring Index::Load and SequenceBatch::LoadAllSequences for callers
+ * that do not have the reference's own objects (the CLI, Python).  Free with
+ * cmgpu_free_host_index / cmgpu_free_host_ref. */
+int cmgpu_load_index_file(const char *path, cmgpu_index_view *out);
+void cmgpu_free_host_index(cmgpu_index_view *v);
+int cmgpu_load_reference_fasta(const char *path, cmgpu_ref_view *out);
+void cmgpu_free_host_ref(cmgpu_ref_view *v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHROMAP_AMD_H_ */

@@ -71,3 +71,26 @@ def flags_to_params(flags):
 
 
 ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
+
+
+def case_index(name):
+    """index file for a golden case, built with the oracle's indexer (the occupied buckets,
+    flags and occurrence table equal the reference's file; tests/test_oracle_golden.py)"""
+    import ctypes as C
+    import oracle_lib as ol
+    fa, _, _ = case_inputs(name)
+    meta = case_meta(name)
+    key = meta["input_md5"]["fa"][:12]
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "idx_" + key + ".idx")
+    if not os.path.exists(path):
+        L = ol.lib()
+        ref = ol.OraRef()
+        assert L.ora_ref_load(fa.encode(), C.byref(ref)) == 0
+        idx = ol.OraIndex()
+        assert L.ora_index_build(C.byref(ref), 17, 7, C.byref(idx)) == 0
+        assert L.ora_index_save((path + ".tmp").encode(), C.byref(idx)) == 0
+        os.replace(path + ".tmp", path)
+        L.ora_index_free(C.byref(idx))
+        L.ora_ref_free(C.byref(ref))
+    return path

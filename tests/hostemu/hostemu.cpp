@@ -1,0 +1,162 @@
+// hostemu.cpp -- TEST INFRASTRUCTURE.  Compiles the product's per-item stage functions
+// (chromap_amd/csrc/cm_stages.h) with g++ and drives them with plain loops in the same order
+// as cmgpu_map_resident (cm_api.hip), so the stage logic can be checked against the oracle
+// on a machine without a GPU.  Nothing here is part of, or reachable from, the library.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/chromap_amd.h"
+#include "../../chromap_amd/csrc/cm_mapq_tables.h"
+#include "../../chromap_amd/csrc/cm_stages.h"
+
+template <typename T>
+static void scan(const T *in, uint32_t *out, uint32_t n) {
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < n; ++i) { out[i] = s; s += in[i]; }
+  out[n] = s;
+}
+
+extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                 const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
+                                 uint32_t *dbg_mm_cnt /* 2n or NULL */, uint32_t *dbg_ncand /* 2n */,
+                                 uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */) {
+  const uint32_t n = in->n_pairs, n2 = 2 * n;
+  CmDev d;
+  memset(&d, 0, sizeof(d));
+  // ---- index re-pack (k_repack)
+  const uint32_t nb = index->n_buckets;
+  std::vector<uint64_t> bkt((size_t)nb * 2);
+  for (uint32_t i = 0; i < nb; ++i) {
+    const uint32_t f = (index->flags[i >> 4] >> ((i & 0xfU) << 1)) & 3u;
+    uint64_t k = index->keys[i], v = index->vals[i];
+    if (f & 2u) { k = CM_EMPTY_KEY; v = 0; } else if (f & 1u) { k = CM_DELETED_KEY; v = 0; }
+    bkt[2 * (size_t)i] = k; bkt[2 * (size_t)i + 1] = v;
+  }
+  d.bkt = bkt.data(); d.bmask = nb - 1; d.occ = index->occurrences; d.n_occ = index->n_occurrences;
+  // ---- reference layout
+  std::vector<uint64_t> roff(ref->n_sequences);
+  uint64_t tot = 64;
+  for (uint32_t i = 0; i < ref->n_sequences; ++i) { roff[i] = tot; tot += (uint64_t)ref->lengths[i] + 64; tot = (tot + 15) & ~15ull; }
+  std::vector<uint8_t> refb(tot, 0);
+  for (uint32_t i = 0; i < ref->n_sequences; ++i) memcpy(refb.data() + roff[i], ref->sequences[i], ref->lengths[i]);
+  d.ref = refb.data(); d.ref_off = roff.data(); d.ref_len = ref->lengths; d.n_seq = ref->n_sequences;
+  CmParams &p = d.p;
+  p.e = params->error_threshold; p.min_seeds = params->min_num_seeds; p.f0 = params->max_seed_frequency0;
+  p.f1 = params->max_seed_frequency1; p.max_insert = params->max_insert_size; p.min_read_len = params->min_read_length;
+  p.max_best = params->max_num_best_mappings; p.drop_rep = params->drop_repetitive_reads; p.trim = params->trim_adapters;
+  p.k = index->kmer_size; p.w = index->window_size; p.lanes = p.e < 8 ? 8 : (p.e < 16 ? 4 : 0);
+  p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
+  p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
+  std::vector<double> coef; std::vector<uint32_t> brk;
+  cm_build_len_coef(coef); cm_build_nsec_break(brk);
+  d.mq.len_coef = coef.data(); d.mq.nsec_break = brk.data(); d.mq.n_break = (int)brk.size();
+  d.n_pairs = n; d.first_read_id = in->first_read_id;
+  d.rb0 = (const uint8_t *)in->read1_bases; d.rb1 = (const uint8_t *)in->read2_bases;
+  d.ro0 = in->read1_offsets; d.ro1 = in->read2_offsets;
+  unsigned long long st[CM_ST_N];
+  memset(st, 0, sizeof(st));
+  d.stats = st;
+#define VEC(name, T, cnt) std::vector<T> v_##name((size_t)(cnt) + 1); d.name = v_##name.data();
+  VEC(rlen, uint32_t, n2) VEC(mm_cap_off, uint32_t, n2 + 1) VEC(mm_cnt, uint32_t, n2) VEC(mm_off, uint32_t, n2 + 1)
+  VEC(hit_tot, uint32_t, n2) VEC(hit_off, uint32_t, n2 + 1) VEC(round2, uint8_t, n2) VEC(rep_cnt, uint32_t, n2)
+  VEC(rep_len, uint32_t, n2) VEC(n_pos_hit, uint32_t, n2) VEC(ncp, uint32_t, n2) VEC(ncn, uint32_t, n2)
+  VEC(aug, uint8_t, n2) VEC(res_neg, int32_t, n2) VEC(res_pos, int32_t, n2) VEC(resc_n, uint32_t, n2) VEC(resc_p, uint32_t, n2)
+  VEC(m_tot, uint32_t, n2) VEC(m_off, uint32_t, n2 + 1) VEC(mcp, uint32_t, n2) VEC(mcn, uint32_t, n2) VEC(force0, uint8_t, n)
+  VEC(fcp, uint32_t, n2) VEC(fcn, uint32_t, n2) VEC(alive, uint8_t, n) VEC(ndp, uint32_t, n2) VEC(ndn, uint32_t, n2)
+  VEC(min_err, int32_t, n2) VEC(second_err, int32_t, n2) VEC(n_best, int32_t, n2) VEC(n_second, int32_t, n2)
+  VEC(pe_min, int32_t, n) VEC(pe_second, int32_t, n) VEC(pe_nbest, int32_t, n) VEC(pe_nsecond, int32_t, n)
+  VEC(pe_first, uint32_t, n) VEC(pe_i1, uint32_t, n) VEC(pe_i2, uint32_t, n) VEC(pe_choice, uint32_t, n)
+  VEC(rec, uint8_t, (size_t)n * 24) VEC(rec_ok, uint8_t, n)
+  for (uint32_t i = 0; i < n; ++i) cm_s0_prep(d, i);
+  std::vector<uint32_t> cap(n2 + 1);
+  for (uint32_t r = 0; r < n2; ++r) cap[r] = d.rlen[r] >= (uint32_t)p.k ? d.rlen[r] - p.k + 1 : 0;
+  scan(cap.data(), d.mm_cap_off, n2);
+  VEC(slot_hash, uint64_t, d.mm_cap_off[n2]) VEC(slot_ps, uint32_t, d.mm_cap_off[n2])
+  for (uint32_t r = 0; r < n2; ++r) cm_s1_minimizers(d, r);
+  scan(d.mm_cnt, d.mm_off, n2);
+  const uint32_t n_mm = d.mm_off[n2];
+  VEC(mm_hash, uint64_t, n_mm) VEC(mm_ps, uint32_t, n_mm) VEC(pr_val, uint64_t, n_mm) VEC(pr_kind, uint8_t, n_mm)
+  for (uint32_t r = 0; r < n2; ++r) cm_s1b_compact(d, r);
+  for (uint32_t i = 0; i < n_mm; ++i) {
+    const uint32_t steps = cm_probe(d.bkt, d.bmask, d.mm_hash[i], &d.pr_val[i], &d.pr_kind[i]);
+    st[CM_ST_PROBE_STEPS] += steps;
+    st[CM_ST_PROBE_HITS] += d.pr_kind[i] != CM_PR_MISS;
+  }
+  for (uint32_t r = 0; r < n2; ++r) cm_s3a_count(d, r);
+  scan(d.hit_tot, d.hit_off, n2);
+  VEC(hbuf, uint64_t, d.hit_off[n2]) VEC(hcnt, uint8_t, d.hit_off[n2])
+  for (uint32_t r = 0; r < n2; ++r) cm_s3b_candidates(d, r);
+  for (uint32_t r = 0; r < n2; ++r) cm_s4a_rescue_count(d, r);
+  scan(d.m_tot, d.m_off, n2);
+  const uint32_t n_m = d.m_off[n2];
+  VEC(mbuf, uint64_t, n_m) VEC(mcnt, uint8_t, n_m) VEC(fbuf, uint64_t, n_m) VEC(fcnt, uint8_t, n_m)
+  VEC(dpos, uint64_t, n_m) VEC(derr, int8_t, n_m)
+  for (uint32_t r = 0; r < n2; ++r) cm_s4b_rescue_merge(d, r);
+  for (uint32_t i = 0; i < n; ++i) cm_s4c_reduce(d, i);
+  for (uint32_t r = 0; r < n2; ++r) cm_s5_verify(d, r);
+  for (uint32_t i = 0; i < n; ++i) cm_s6a_pair(d, i);
+  const uint32_t nch = cm_num_chunks(n, (uint32_t)p.ref_batch, (uint32_t)p.grain);
+  CmMt *g = new CmMt();
+  for (uint32_t c = 0; c < nch; ++c) cm_s6b_sample(d, c, *g);
+  delete g;
+  for (uint32_t i = 0; i < n; ++i) cm_s6c_multi(d, i);
+  uint64_t k = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    // k_stats
+    const uint32_t r1 = 2 * i, r2 = r1 + 1;
+    if (d.alive[i]) {
+      st[CM_ST_CAND] += d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
+      const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
+      if (nd1 > 0 && nd2 > 0) {
+        const int nbst = d.pe_nbest[i];
+        if (nbst == 1) st[CM_ST_UNIQ] += 2;
+        st[CM_ST_MAPPINGS] += 2ull * (unsigned long long)(nbst < p.max_best ? nbst : p.max_best);
+        if (nbst > 0) st[CM_ST_MAPPED] += 2;
+        if (nbst > 1 && nbst <= p.drop_rep) st[CM_ST_MULTI] += 1;
+      }
+    }
+    st[CM_ST_RESCUED] += d.aug[r1] + d.aug[r2];
+    st[CM_ST_OCC] += d.hit_tot[r1] + d.hit_tot[r2];
+    if (d.rec_ok[i]) memcpy(&out[k++], d.rec + (size_t)i * 24, 24);
+    if (dbg_nbest) dbg_nbest[i] = d.pe_nbest[i];
+  }
+  for (uint32_t r = 0; r < n2; ++r) {
+    if (dbg_mm_cnt) dbg_mm_cnt[r] = d.mm_cnt[r];
+    if (dbg_ncand) dbg_ncand[r] = d.alive[r >> 1] ? d.fcp[r] + d.fcn[r] : 0;
+    if (dbg_ndraft) dbg_ndraft[r] = d.ndp[r] + d.ndn[r];
+  }
+  *n_out = k;
+  if (stats) {
+    stats->num_candidates += st[CM_ST_CAND];
+    stats->num_mappings += st[CM_ST_MAPPINGS];
+    stats->num_mapped_reads += st[CM_ST_MAPPED];
+    stats->num_uniquely_mapped_reads += st[CM_ST_UNIQ];
+    stats->num_minimizers += n_mm;
+    stats->probe_steps += st[CM_ST_PROBE_STEPS];
+    stats->occurrences_read += st[CM_ST_OCC];
+    stats->num_pairs_rescued += st[CM_ST_RESCUED];
+    stats->num_multi_mappers += st[CM_ST_MULTI];
+  }
+  return st[CM_ST_ERR] ? -(int)st[CM_ST_ERR] : 0;
+}
+
+// chunked reference-minimizer collection (cm_ref_chunk_minimizers) concatenated in chunk
+// order; compared by tests with the oracle's sequential pass
+extern "C" long hostemu_ref_minimizers(const cmgpu_ref_view *ref, int k, int w, uint32_t chunk, uint32_t warm,
+                                       uint64_t *out_hash, uint64_t *out_hit, long cap) {
+  long n = 0;
+  for (uint32_t r = 0; r < ref->n_sequences; ++r) {
+    std::vector<uint8_t> seq((size_t)ref->lengths[r] + 64, 0);
+    memcpy(seq.data(), ref->sequences[r], ref->lengths[r]);
+    for (uint64_t s = 0; s < ref->lengths[r]; s += chunk) {
+      const uint32_t c = cm_ref_chunk_minimizers(seq.data(), ref->lengths[r], r, (uint32_t)s, chunk, warm, k, w, nullptr, nullptr);
+      if (n + c > cap) return -1;
+      cm_ref_chunk_minimizers(seq.data(), ref->lengths[r], r, (uint32_t)s, chunk, warm, k, w, out_hash + n, out_hit + n);
+      n += c;
+    }
+  }
+  return n;
+}

@@ -1,0 +1,78 @@
+"""Loads tests/hostemu/libhostemu.so: the product's stage functions (cm_stages.h) compiled
+for the host and driven by plain loops.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys
+sys.path.insert(0, ROOT)
+from chromap_amd import _capi  # noqa: E402
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        so = os.path.join(ROOT, "tests", "hostemu", "libhostemu.so")
+        srcs = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + \
+               [os.path.join(ROOT, "chromap_amd", "csrc", f) for f in ("cm_stages.h", "cm_types.h", "cm_host.cpp",
+                                                                       "cm_mapq_tables.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-Wall", "-Wno-unused-function", "-o", so, srcs[0],
+                                   os.path.join(ROOT, "chromap_amd", "csrc", "cm_host.cpp")])
+        _L = _capi.declare(C.CDLL(so))
+        P = C.POINTER
+        _L.hostemu_map_pairs.restype = C.c_int
+        _L.hostemu_map_pairs.argtypes = [P(_capi.IndexView), P(_capi.RefView), P(_capi.Params), P(_capi.Batch),
+                                         C.c_void_p, P(C.c_uint64), P(_capi.Stats), C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+    return _L
+
+
+def params(preset=None, **kw):
+    L = lib()
+    p = _capi.Params()
+    L.cmgpu_default_params(C.byref(p))
+    if preset:
+        assert L.cmgpu_apply_preset(C.byref(p), preset.encode()) == 0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class HostEmu:
+    def __init__(self, index_path, ref_path, p):
+        self.L = lib()
+        self.idx = _capi.IndexView()
+        self.ref = _capi.RefView()
+        assert self.L.cmgpu_load_index_file(index_path.encode(), C.byref(self.idx)) == 0
+        assert self.L.cmgpu_load_reference_fasta(ref_path.encode(), C.byref(self.ref)) == 0
+        self.p = p
+        self.names = [self.ref.names[i] for i in range(self.ref.n_sequences)]
+
+    def map_pairs(self, b1, o1, b2, o2, first_read_id=0):
+        n = len(o1) - 1
+        keep = [np.ascontiguousarray(b1, dtype=np.uint8), np.ascontiguousarray(o1, dtype=np.uint32),
+                np.ascontiguousarray(b2, dtype=np.uint8), np.ascontiguousarray(o2, dtype=np.uint32)]
+        bt = _capi.Batch(n, first_read_id, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data,
+                         keep[3].ctypes.data)
+        rec = (_capi.Record * max(1, n))()
+        k = C.c_uint64(0)
+        st = _capi.Stats()
+        dbg = {"mm_cnt": np.zeros(2 * n, np.uint32), "ncand": np.zeros(2 * n, np.uint32),
+               "ndraft": np.zeros(2 * n, np.uint32), "nbest": np.zeros(n, np.int32)}
+        rc = self.L.hostemu_map_pairs(C.byref(self.idx), C.byref(self.ref), C.byref(self.p), C.byref(bt),
+                                      C.cast(rec, C.c_void_p), C.byref(k), C.byref(st), dbg["mm_cnt"].ctypes.data,
+                                      dbg["ncand"].ctypes.data, dbg["ndraft"].ctypes.data, dbg["nbest"].ctypes.data)
+        assert rc == 0, rc
+        return rec, int(k.value), st, dbg
+
+    def write_bed(self, rec, n, path):
+        names = (C.c_char_p * len(self.names))(*self.names)
+        return self.L.cmgpu_write_bed_pe(names, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n,
+                                         path.encode())
