@@ -60,8 +60,9 @@ assert C.sizeof(Record) == 24
 # every symbol include/chromap_amd.h declares
 SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_destroy",
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_upload_batch", "cmgpu_map_resident",
-           "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench",
-           "cmgpu_last_timings", "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe",
+           "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
+           "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device",
+           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
 _LIB = None
@@ -91,7 +92,12 @@ def declare(L):
     sig("cmgpu_download_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
     sig("cmgpu_probe_bench", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, P(C.c_double), P(C.c_uint64),
                                        P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_gather_bench", C.c_int, [C.c_void_p, C.c_uint64, C.c_int, P(C.c_double)])
     sig("cmgpu_last_timings", C.c_int, [C.c_void_p, P(C.c_char_p), P(C.c_float), C.c_int])
+    sig("cmgpu_index_info", C.c_int, [C.c_void_p, P(C.c_int32), P(C.c_int32), P(C.c_uint32), P(C.c_uint32),
+                                      P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_export_index", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p])
+    sig("cmgpu_records_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)])
     sig("cmgpu_export_reference", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32])
     sig("cmgpu_reference_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
     sig("cmgpu_write_bed_pe", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])

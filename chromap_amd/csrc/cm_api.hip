@@ -312,7 +312,8 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_launch_k_s1b_compact(d, n2, s);
   mark(c, "s1b_compact");
   // S2: index probe (the graded kernel)
-  cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, d.stats + CM_ST_PROBE_STEPS, s);
+  if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
+  cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);
   mark(c, "s2_probe");
   // S3: hit counts -> offsets -> candidates
   cm_launch_k_s3a_count(d, n2, s);
@@ -352,7 +353,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_launch_k_s6b_sample(d, n_chunks, s);
   cm_launch_k_s6c_multi(d, n, s);
   mark(c, "s6bc_multimappers");
-  cm_launch_k_stats(d, n, s);
+  cm_launch_k_stats(d, n, (unsigned long long *)c->partials.p, s);
   unsigned long long hst[CM_ST_N];
   HIPCHECK(c, hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, s));
   HIPCHECK(c, hipStreamSynchronize(s));
@@ -449,15 +450,16 @@ extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t 
   unsigned long long *ctr = (unsigned long long *)c->stats.p;
   HIPCHECK(c, hipMemsetAsync(ctr, 0, CM_ST_N * 8, s));
   // warm-up + counted launch
+  if (c->partials.ensure(cm_probe_partial_words((uint32_t)n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
   cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
-                    (uint8_t *)c->pr_kind.p, (uint32_t)n, ctr + CM_ST_PROBE_STEPS, s);
+                    (uint8_t *)c->pr_kind.p, (uint32_t)n, c->partials.p, ctr + CM_ST_PROBE_STEPS, s);
   unsigned long long h[CM_ST_N];
   HIPCHECK(c, hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, s));
   HIPCHECK(c, hipStreamSynchronize(s));
   HIPCHECK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < repeat; ++i)
     cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
-                      (uint8_t *)c->pr_kind.p, (uint32_t)n, nullptr, s);
+                      (uint8_t *)c->pr_kind.p, (uint32_t)n, nullptr, nullptr, s);
   HIPCHECK(c, hipEventRecord(c->ev[1], s));
   HIPCHECK(c, hipEventSynchronize(c->ev[1]));
   float ms = 0;
@@ -480,5 +482,111 @@ extern "C" int cmgpu_export_reference(cmgpu_ctx *c, uint32_t seq, char *out, uin
   if (!c || seq >= c->n_seq || !out || capacity < c->h_ref_len[seq]) return CMGPU_EINVAL;
   HIPCHECK(c, hipSetDevice(c->device));
   HIPCHECK(c, hipMemcpy(out, (const uint8_t *)c->ref.p + c->h_ref_off[seq], c->h_ref_len[seq], hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// exports used by bench.py / tests to hand the device-built index to the CPU baseline
+// ---------------------------------------------------------------------------------------
+extern "C" int cmgpu_index_info(cmgpu_ctx *c, int32_t *kmer_size, int32_t *window_size, uint32_t *n_buckets,
+                                uint32_t *n_occurrences, uint64_t *n_minimizers, uint64_t *n_keys) {
+  if (!c) return CMGPU_EINVAL;
+  if (kmer_size) *kmer_size = c->p.k;
+  if (window_size) *window_size = c->p.w;
+  if (n_buckets) *n_buckets = c->bmask + 1;
+  if (n_occurrences) *n_occurrences = c->n_occ;
+  if (n_minimizers) *n_minimizers = c->synth_n_minimizers;
+  if (n_keys) *n_keys = c->synth_n_keys;
+  return CMGPU_OK;
+}
+
+// buckets_out: 2*n_buckets uint64 ({key,val} interleaved, CM_EMPTY_KEY = all ones marks an
+// empty bucket); occurrences_out: n_occurrences uint64
+extern "C" int cmgpu_export_index(cmgpu_ctx *c, uint64_t *buckets_out, uint64_t *occurrences_out) {
+  if (!c || !buckets_out) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, hipMemcpy(buckets_out, c->bkt.p, ((size_t)c->bmask + 1) * 16, hipMemcpyDeviceToHost));
+  if (occurrences_out && c->n_occ) HIPCHECK(c, hipMemcpy(occurrences_out, c->occ.p, (size_t)c->n_occ * 8, hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense copy of the resident records into a caller-provided DEVICE buffer (e.g. a torch
+// tensor's data_ptr) for the multi-GPU record exchange
+// ---------------------------------------------------------------------------------------
+__global__ void k_rec_flag(const uint8_t *ok, uint32_t *flag, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = ok[i];
+}
+__global__ void k_rec_compact(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok,
+                              const uint32_t *__restrict__ pos, uint8_t *__restrict__ dst, uint32_t n, uint64_t cap) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !ok[i]) return;
+  const uint32_t o = pos[i];
+  if (o >= cap) return;
+  const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
+  uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)o * 24);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+extern "C" int cmgpu_records_to_device(cmgpu_ctx *c, void *device_dst, uint64_t capacity, uint64_t *n_out) {
+  if (!c || !device_dst || !n_out) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint32_t n = c->n_pairs;
+  *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  // reuse cap / mm_cap_off as scratch (free between batches)
+  uint32_t *flag = (uint32_t *)c->cap.p, *pos = (uint32_t *)c->mm_cap_off.p;
+  hipLaunchKernelGGL(k_rec_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint8_t *)c->rec_ok.p, flag, n);
+  cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, c->stream);
+  hipLaunchKernelGGL(k_rec_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint8_t *)c->rec.p,
+                     (const uint8_t *)c->rec_ok.p, (const uint32_t *)pos, (uint8_t *)device_dst, n, capacity);
+  uint32_t k = 0;
+  HIPCHECK(c, hipMemcpyAsync(&k, pos + n, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(c, hipStreamSynchronize(c->stream));
+  *n_out = k;
+  if (k > capacity) { cm_set_error(c, "device record buffer too small"); return CMGPU_ECAPACITY; }
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// HBM random-gather microbenchmark on the resident table (the measured
+// ceiling the probe kernel is compared with): n independent 16-byte loads at
+// pseudo-random bucket indices, 4 per thread in flight.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const uint64_t *__restrict__ bkt, uint32_t bmask, uint64_t n,
+                                                uint64_t seed, unsigned long long *__restrict__ sink) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t i = t * 4 + j;
+    if (i < n) {
+      uint64_t x = (i + seed) * 0x9E3779B97F4A7C15ull;
+      x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+      const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)((uint32_t)x & bmask));
+      acc ^= kv.x + kv.y;
+    }
+  }
+  if (acc == 0x123456789abcdefull) atomicAdd(sink, 1ull);  // keeps the loads alive
+}
+
+extern "C" int cmgpu_gather_bench(cmgpu_ctx *c, uint64_t n, int repeat, double *avg_ms) {
+  if (!c || n == 0 || repeat < 1 || !avg_ms) return CMGPU_EINVAL;
+  HIPCHECK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const unsigned blocks = (unsigned)((n + 1023) / 1024);
+  hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, s, (const uint64_t *)c->bkt.p, c->bmask, n, 1ull,
+                     (unsigned long long *)c->stats.p + CM_ST_N - 1);
+  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, hipEventRecord(c->ev[0], s));
+  for (int i = 0; i < repeat; ++i)
+    hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, s, (const uint64_t *)c->bkt.p, c->bmask, n, (uint64_t)(i + 2) * 7919ull,
+                       (unsigned long long *)c->stats.p + CM_ST_N - 1);
+  HIPCHECK(c, hipEventRecord(c->ev[1], s));
+  HIPCHECK(c, hipEventSynchronize(c->ev[1]));
+  float ms = 0;
+  HIPCHECK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  *avg_ms = ms / repeat;
   return CMGPU_OK;
 }

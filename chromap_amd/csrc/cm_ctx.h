@@ -42,7 +42,7 @@ struct cmgpu_ctx {
   DevBuf aug, res_neg, res_pos, resc_n, resc_p, m_tot, m_off, mbuf, mcnt, mcp, mcn, force0;
   DevBuf fbuf, fcnt, fcp, fcn, alive, dpos, derr, ndp, ndn, min_err, second_err, n_best, n_second;
   DevBuf pe_min, pe_second, pe_nbest, pe_nsecond, pe_first, pe_i1, pe_i2, pe_choice, rec, rec_ok;
-  DevBuf scan_tmp, stats;
+  DevBuf scan_tmp, stats, partials;
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;
@@ -57,7 +57,7 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials};
   }
 };
 

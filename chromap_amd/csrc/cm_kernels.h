@@ -17,11 +17,13 @@ CM_DECL_LAUNCH(k_s4c_reduce)
 CM_DECL_LAUNCH(k_s5_verify)
 CM_DECL_LAUNCH(k_s6a_pair)
 CM_DECL_LAUNCH(k_s6c_multi)
-CM_DECL_LAUNCH(k_stats)
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);
 void cm_launch_k_slot_cap(const CmDev &d, uint32_t n_reads, uint32_t *cap, hipStream_t s);
+size_t cm_probe_partial_words(uint32_t n);
 void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,
-                       uint32_t n, unsigned long long *counters, hipStream_t s);
+                       uint32_t n, void *partials, unsigned long long *counters, hipStream_t s);
+size_t cm_stats_partial_words(uint32_t n);
+void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials, hipStream_t s);
 
 size_t cm_scan_tmp_words(uint32_t n);
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total

@@ -25,11 +25,40 @@ CM_ITEM_KERNEL(k_s5_verify, cm_s5_verify)
 CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair)
 CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi)
 
+// S6b, one WAVE per taskloop chunk: the 64 lanes scan the chunk's n_best values coalesced
+// and ballot the multi-mappers; lane 0 then walks them in pair order with the chunk's
+// mt19937 (state in LDS).
 __global__ __launch_bounds__(64) void k_s6b_sample(CmDev d, uint32_t n_chunks) {
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n_chunks) return;
-  CmMt g;
-  cm_s6b_sample(d, i, g);
+  const uint32_t chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
+  __shared__ CmMt g;
+  uint32_t lo, hi;
+  cm_chunk_range(d.n_pairs, (uint32_t)d.p.ref_batch, (uint32_t)d.p.grain, chunk, &lo, &hi);
+  bool seeded = false;
+  for (uint32_t base = lo; base < hi; base += 64) {
+    const uint32_t pair = base + threadIdx.x;
+    int nb = 0;
+    if (pair < hi) nb = d.pe_nbest[pair];
+    const bool multi = nb > 1 && nb <= d.p.drop_rep;
+    unsigned long long m = __ballot(multi);
+    if (m == 0) continue;
+    if (threadIdx.x == 0) {
+      if (!seeded) { cm_mt_seed(g, 11); seeded = true; }
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t pr = base + (uint32_t)l;
+        const int nbl = d.pe_nbest[pr];
+        int choice = 0;
+        for (int i = 1; i < nbl; ++i) {
+          const int j = cm_mt_uniform(g, i);
+          if (j < 1) choice = i;
+        }
+        d.pe_choice[pr] = (uint32_t)choice;
+      }
+    }
+    seeded = __shfl((int)seeded, 0, 64) != 0;
+  }
 }
 
 // slot capacity of each read: one (hash,pos) per k-mer position at most
@@ -48,7 +77,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_slot_cap(CmDev d, uint32_t n_reads
 __global__ __launch_bounds__(CM_BLOCK) void k_probe(const uint64_t *__restrict__ bkt, uint32_t bmask,
                                                      const uint64_t *__restrict__ hash, uint64_t *__restrict__ val,
                                                      uint8_t *__restrict__ kind, uint32_t n,
-                                                     unsigned long long *__restrict__ counters) {
+                                                     uint2 *__restrict__ block_partials) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   uint32_t steps = 0, hit = 0;
   if (i < n) {
@@ -59,61 +88,95 @@ __global__ __launch_bounds__(CM_BLOCK) void k_probe(const uint64_t *__restrict__
     kind[i] = kd;
     hit = kd != CM_PR_MISS;
   }
-  if (counters) {
-    // wave64 reduction
+  if (block_partials) {
+    // probe-step accounting: wave reduction, then one plain store per block (a single
+    // device-scope counter would serialise ~10 ns per atomic)
+    __shared__ uint32_t sh_s[CM_BLOCK / 64], sh_h[CM_BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
       steps += __shfl_down(steps, off, 64);
       hit += __shfl_down(hit, off, 64);
     }
-    if ((threadIdx.x & 63) == 0 && steps) {
-      atomicAdd(&counters[0], (unsigned long long)steps);
-      atomicAdd(&counters[1], (unsigned long long)hit);
+    if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = steps; sh_h[threadIdx.x >> 6] = hit; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t a = 0, c = 0;
+      for (int j = 0; j < CM_BLOCK / 64; ++j) { a += sh_s[j]; c += sh_h[j]; }
+      block_partials[blockIdx.x] = make_uint2(a, c);
     }
   }
 }
 
-// per-pair counters of Chromap::OutputMappingStatistics (chromap.h:1057-1058, 1118-1137)
-__global__ __launch_bounds__(CM_BLOCK) void k_stats(CmDev d, uint32_t n) {
+// sums k_probe's per-block partials into counters[0] (steps) and counters[1] (hits)
+__global__ __launch_bounds__(CM_BLOCK) void k_probe_reduce(const uint2 *__restrict__ partials, uint32_t n_blocks,
+                                                            unsigned long long *__restrict__ counters) {
+  unsigned long long a = 0, c = 0;
+  for (uint32_t i = threadIdx.x; i < n_blocks; i += CM_BLOCK) { a += partials[i].x; c += partials[i].y; }
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    c += __shfl_down(c, off, 64);
+  }
+  __shared__ unsigned long long sa[CM_BLOCK / 64], sc[CM_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int j = 1; j < CM_BLOCK / 64; ++j) { a += sa[j]; c += sc[j]; }
+    counters[0] += a;
+    counters[1] += c;
+  }
+}
+
+// per-pair counters of Chromap::OutputMappingStatistics (chromap.h:1057-1058, 1118-1137);
+// block-level reduction in LDS, one row of 8 partials per block, summed by k_stats_reduce
+#define CM_NSTAT 8
+__global__ __launch_bounds__(CM_BLOCK) void k_stats(CmDev d, uint32_t n, unsigned long long *__restrict__ partials) {
   const uint32_t pair = blockIdx.x * CM_BLOCK + threadIdx.x;
-  unsigned long long cand = 0, mappings = 0, mapped = 0, uniq = 0, multi = 0, resc = 0, occ = 0, nrec = 0;
+  unsigned long long v[CM_NSTAT] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (pair < n) {
     const uint32_t r1 = 2 * pair, r2 = r1 + 1;
     if (d.alive[pair]) {
-      cand = d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
+      v[0] = d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
       const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
       if (nd1 > 0 && nd2 > 0) {
         const int nb = d.pe_nbest[pair];
-        if (nb == 1) uniq = 2;
-        mappings = 2ull * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
-        if (nb > 0) mapped = 2;
-        if (nb > 1 && nb <= d.p.drop_rep) multi = 1;
+        if (nb == 1) v[3] = 2;
+        v[1] = 2ull * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
+        if (nb > 0) v[2] = 2;
+        if (nb > 1 && nb <= d.p.drop_rep) v[4] = 1;
       }
     }
-    resc = (unsigned long long)d.aug[r1] + d.aug[r2];
-    occ = (unsigned long long)d.hit_tot[r1] + d.hit_tot[r2];
-    nrec = d.rec_ok[pair];
+    v[5] = (unsigned long long)d.aug[r1] + d.aug[r2];
+    v[6] = (unsigned long long)d.hit_tot[r1] + d.hit_tot[r2];
+    v[7] = d.rec_ok[pair];
   }
-  __shared__ unsigned long long sh[8];
-  if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+  __shared__ unsigned long long sh[CM_BLOCK / 64][CM_NSTAT];
+#pragma unroll
+  for (int k = 0; k < CM_NSTAT; ++k) {
+    unsigned long long x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = x;
+  }
   __syncthreads();
-  if (cand) atomicAdd(&sh[0], cand);
-  if (mappings) atomicAdd(&sh[1], mappings);
-  if (mapped) atomicAdd(&sh[2], mapped);
-  if (uniq) atomicAdd(&sh[3], uniq);
-  if (multi) atomicAdd(&sh[4], multi);
-  if (resc) atomicAdd(&sh[5], resc);
-  if (occ) atomicAdd(&sh[6], occ);
-  if (nrec) atomicAdd(&sh[7], nrec);
+  if (threadIdx.x < CM_NSTAT) {
+    unsigned long long x = 0;
+    for (int j = 0; j < CM_BLOCK / 64; ++j) x += sh[j][threadIdx.x];
+    partials[(uint64_t)blockIdx.x * CM_NSTAT + threadIdx.x] = x;
+  }
+}
+
+__global__ __launch_bounds__(CM_BLOCK) void k_stats_reduce(const unsigned long long *__restrict__ partials,
+                                                            uint32_t n_blocks, unsigned long long *__restrict__ stats) {
+  // thread t handles statistic t % 8 over rows t/8, t/8 + 32, ...
+  const int k = threadIdx.x % CM_NSTAT, lane_row = threadIdx.x / CM_NSTAT;
+  unsigned long long x = 0;
+  for (uint32_t r = lane_row; r < n_blocks; r += CM_BLOCK / CM_NSTAT) x += partials[(uint64_t)r * CM_NSTAT + k];
+  __shared__ unsigned long long sh[CM_BLOCK];
+  sh[threadIdx.x] = x;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (sh[0]) atomicAdd(&d.stats[CM_ST_CAND], sh[0]);
-    if (sh[1]) atomicAdd(&d.stats[CM_ST_MAPPINGS], sh[1]);
-    if (sh[2]) atomicAdd(&d.stats[CM_ST_MAPPED], sh[2]);
-    if (sh[3]) atomicAdd(&d.stats[CM_ST_UNIQ], sh[3]);
-    if (sh[4]) atomicAdd(&d.stats[CM_ST_MULTI], sh[4]);
-    if (sh[5]) atomicAdd(&d.stats[CM_ST_RESCUED], sh[5]);
-    if (sh[6]) atomicAdd(&d.stats[CM_ST_OCC], sh[6]);
-    if (sh[7]) atomicAdd(&d.stats[CM_ST_RECORDS], sh[7]);
+  if (threadIdx.x < CM_NSTAT) {
+    unsigned long long t = 0;
+    for (int j = 0; j < CM_BLOCK / CM_NSTAT; ++j) t += sh[j * CM_NSTAT + threadIdx.x];
+    const int slot[CM_NSTAT] = {CM_ST_CAND, CM_ST_MAPPINGS, CM_ST_MAPPED, CM_ST_UNIQ, CM_ST_MULTI, CM_ST_RESCUED, CM_ST_OCC, CM_ST_RECORDS};
+    stats[slot[threadIdx.x]] += t;
   }
 }
 
@@ -220,15 +283,29 @@ CM_LAUNCH(k_s4c_reduce)
 CM_LAUNCH(k_s5_verify)
 CM_LAUNCH(k_s6a_pair)
 CM_LAUNCH(k_s6c_multi)
-CM_LAUNCH(k_stats)
 
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s) {
-  if (n_chunks) hipLaunchKernelGGL(k_s6b_sample, dim3((n_chunks + 63) / 64), dim3(64), 0, s, d, n_chunks);
+  if (n_chunks) hipLaunchKernelGGL(k_s6b_sample, dim3(n_chunks), dim3(64), 0, s, d, n_chunks);
+}
+// partials: at least cm_stats_partial_words(n) unsigned long long
+size_t cm_stats_partial_words(uint32_t n) { return (size_t)((n + CM_BLOCK - 1) / CM_BLOCK) * CM_NSTAT + CM_NSTAT; }
+void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials, hipStream_t s) {
+  if (!n) return;
+  const uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
+  hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n, partials);
+  hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(CM_BLOCK), 0, s, (const unsigned long long *)partials, blocks, d.stats);
 }
 void cm_launch_k_slot_cap(const CmDev &d, uint32_t n_reads, uint32_t *cap, hipStream_t s) {
   if (n_reads) hipLaunchKernelGGL(k_slot_cap, grid_for(n_reads), dim3(CM_BLOCK), 0, s, d, n_reads, cap);
 }
+// partials: one uint2 per block (cm_probe_partial_words(n) uint2), or nullptr to skip the accounting;
+// counters[0] += probe steps, counters[1] += hits
+size_t cm_probe_partial_words(uint32_t n) { return (size_t)((n + CM_BLOCK - 1) / CM_BLOCK) + 1; }
 void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,
-                       uint32_t n, unsigned long long *counters, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_probe, grid_for(n), dim3(CM_BLOCK), 0, s, bkt, bmask, hash, val, kind, n, counters);
+                       uint32_t n, void *partials, unsigned long long *counters, hipStream_t s) {
+  if (!n) return;
+  const uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
+  hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(CM_BLOCK), 0, s, bkt, bmask, hash, val, kind, n, (uint2 *)partials);
+  if (partials && counters)
+    hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
 }

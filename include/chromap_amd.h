@@ -174,6 +174,10 @@ int cmgpu_download_batch(cmgpu_ctx *ctx, char *read1_bases, uint32_t *read1_offs
 int cmgpu_probe_bench(cmgpu_ctx *ctx, const uint64_t *hashes, uint64_t n, int repeat, double *avg_ms,
                       uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences);
 
+/* HBM random-gather microbenchmark on the resident table: n independent 16-byte loads at
+ * pseudo-random buckets, average kernel time over `repeat` launches (HIP events). */
+int cmgpu_gather_bench(cmgpu_ctx *ctx, uint64_t n, int repeat, double *avg_ms);
+
 /* Per-stage timing of the last cmgpu_map_* call (HIP events on the launch stream).
  * names/ms arrays of capacity cap; returns number of stages. */
 int cmgpu_last_timings(const cmgpu_ctx *ctx, const char **names, float *ms, int cap);
@@ -181,6 +185,17 @@ int cmgpu_last_timings(const cmgpu_ctx *ctx, const char **names, float *ms, int 
 /* Export of the synthetic reference / index for checking against the oracle (small sizes). */
 int cmgpu_export_reference(cmgpu_ctx *ctx, uint32_t seq, char *out, uint32_t capacity);
 int cmgpu_reference_lengths(cmgpu_ctx *ctx, uint32_t *lengths, uint32_t capacity, uint32_t *n_sequences);
+
+/* Size / content of the resident index (two-step: query sizes, then export).  buckets_out
+ * receives 2*n_buckets uint64 ({key,val} per bucket, key == all ones marks an empty bucket),
+ * occurrences_out n_occurrences uint64.  Used to give the CPU baseline the same index. */
+int cmgpu_index_info(cmgpu_ctx *ctx, int32_t *kmer_size, int32_t *window_size, uint32_t *n_buckets,
+                     uint32_t *n_occurrences, uint64_t *n_minimizers, uint64_t *n_keys);
+int cmgpu_export_index(cmgpu_ctx *ctx, uint64_t *buckets_out, uint64_t *occurrences_out);
+
+/* Dense copy of the resident batch's records into a caller-provided DEVICE buffer
+ * (capacity in records) -- the send buffer of the multi-GPU record exchange. */
+int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity, uint64_t *n_out);
 
 /* Host post-processing that defines the final BED bytes: sort by (rid, operator<),
  * PCR-duplicate removal as in the low-memory merge, MAPQ filter, Tn5 shift, text

@@ -398,6 +398,34 @@ int ora_index_load(const char *path, ora_index *idx) { /* index.cc:132-169, khas
   return ok ? 0 : -2;
 }
 
+/* Builds an ora_index from the device layout exported by cmgpu_export_index (interleaved
+ * {key,val} buckets, all-ones key = empty).  Test/bench plumbing, not a reference function. */
+int ora_index_from_buckets(const uint64_t *buckets, uint32_t n_buckets, const uint64_t *occ, uint32_t n_occ,
+                           int k, int w, ora_index *idx) {
+  memset(idx, 0, sizeof(*idx));
+  idx->k = k; idx->w = w; idx->n_buckets = n_buckets; idx->n_occ = n_occ;
+  const size_t fs = FL_SIZE(n_buckets);
+  idx->flags = (uint32_t *)malloc(fs * 4);
+  idx->keys = (uint64_t *)malloc((size_t)n_buckets * 8);
+  idx->vals = (uint64_t *)malloc((size_t)n_buckets * 8);
+  idx->occ = (uint64_t *)malloc((size_t)(n_occ ? n_occ : 1) * 8);
+  if (!idx->flags || !idx->keys || !idx->vals || !idx->occ) return -1;
+  memset(idx->flags, 0xaa, fs * 4);
+  uint32_t sz = 0;
+#pragma omp parallel for reduction(+ : sz) schedule(static, 1 << 16)
+  for (long i = 0; i < (long)n_buckets; ++i) {
+    idx->keys[i] = buckets[2 * (size_t)i];
+    idx->vals[i] = buckets[2 * (size_t)i + 1];
+    if (buckets[2 * (size_t)i] != UINT64_MAX) ++sz;
+  }
+  for (uint32_t i = 0; i < n_buckets; ++i)
+    if (idx->keys[i] != UINT64_MAX) FL_SET_BOTH_FALSE(idx->flags, i);
+  if (n_occ) memcpy(idx->occ, occ, (size_t)n_occ * 8);
+  idx->size = idx->n_occupied = idx->n_keys = sz;
+  idx->upper_bound = (uint32_t)(n_buckets * KH_UPPER + 0.5);
+  return 0;
+}
+
 void ora_index_free(ora_index *idx) {
   free(idx->flags); free(idx->keys); free(idx->vals); free(idx->occ);
   memset(idx, 0, sizeof(*idx));

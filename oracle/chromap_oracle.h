@@ -103,6 +103,9 @@ int ora_index_save(const char *path, const ora_index *idx);
 /* index.cc:12-89 with khash.h:246-350 put/resize replayed, so the file is byte-identical */
 int ora_index_build(const ora_ref *ref, int k, int w, ora_index *idx);
 void ora_index_free(ora_index *idx);
+/* plumbing for bench.py: index from the device layout exported by cmgpu_export_index */
+int ora_index_from_buckets(const uint64_t *buckets, uint32_t n_buckets, const uint64_t *occ, uint32_t n_occ,
+                           int k, int w, ora_index *idx);
 /* khash.h:232-245 with hash/eq of index_utils.h:13-17. returns bucket or n_buckets; *steps += visited */
 uint32_t ora_kh_get(const ora_index *idx, uint64_t key, uint64_t *steps);
 

@@ -69,6 +69,8 @@ def lib():
     L.ora_index_save.argtypes = [C.c_char_p, C.POINTER(OraIndex)]
     L.ora_index_build.argtypes = [C.POINTER(OraRef), C.c_int, C.c_int, C.POINTER(OraIndex)]
     L.ora_index_free.argtypes = [C.POINTER(OraIndex)]
+    L.ora_index_from_buckets.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
+                                         C.POINTER(OraIndex)]
     L.ora_kh_get.restype = C.c_uint32
     L.ora_kh_get.argtypes = [C.POINTER(OraIndex), C.c_uint64, C.POINTER(C.c_uint64)]
     L.ora_ref_load.argtypes = [C.c_char_p, C.POINTER(OraRef)]
