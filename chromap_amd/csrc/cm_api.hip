@@ -298,19 +298,18 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_launch_k_slot_cap(d, n2, (uint32_t *)c->cap.p, s);
   cm_scan_u32((const uint32_t *)c->cap.p, d.mm_cap_off, n2, (uint32_t *)c->scan_tmp.p, s);
   const size_t slot_cap = c->bases0 + c->bases1 + 1;  // sum over reads of (len-k+1) <= total bases
-  if (c->slot_hash.ensure(slot_cap * 8) || c->slot_ps.ensure(slot_cap * 4)) { cm_set_error(c, "out of device memory (minimizer slots)"); return CMGPU_ENOMEM; }
+  if (c->slot_hash.ensure(slot_cap * 8) || c->slot_ps.ensure(slot_cap * 4) || c->mm_hash.ensure(slot_cap * 8 + 8) ||
+      c->mm_ps.ensure(slot_cap * 4 + 4) || c->pr_val.ensure(slot_cap * 8 + 8) || c->pr_kind.ensure(slot_cap + 4)) {
+    cm_set_error(c, "out of device memory (minimizers)");
+    return CMGPU_ENOMEM;
+  }
   cm_fill_dev(c, d);
-  cm_launch_k_s1_minimizers(d, n2, s);
-  cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
+  uint32_t *mm_total = (uint32_t *)((unsigned long long *)c->stats.p + CM_ST_N - 2);
+  cm_launch_k_s1_minimizers(d, n2, mm_total, s);
   uint32_t n_mm = 0;
-  HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipMemcpyAsync(&n_mm, mm_total, 4, hipMemcpyDeviceToHost, s));
   HIPCHECK(c, hipStreamSynchronize(s));
   mark(c, "s1_minimizers");
-  if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
-      c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
-  cm_fill_dev(c, d);
-  cm_launch_k_s1b_compact(d, n2, s);
-  mark(c, "s1b_compact");
   // S2: index probe (the graded kernel)
   if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
   cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);

@@ -7,8 +7,7 @@
 
 #define CM_DECL_LAUNCH(kname) void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s);
 CM_DECL_LAUNCH(k_s0_prep)
-CM_DECL_LAUNCH(k_s1_minimizers)
-CM_DECL_LAUNCH(k_s1b_compact)
+void cm_launch_k_s1_minimizers(const CmDev &d, uint32_t n, uint32_t *total, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
 CM_DECL_LAUNCH(k_s3b_candidates)
 CM_DECL_LAUNCH(k_s4a_rescue_count)

@@ -14,8 +14,39 @@
   }
 
 CM_ITEM_KERNEL(k_s0_prep, cm_s0_prep)
-CM_ITEM_KERNEL(k_s1_minimizers, cm_s1_minimizers)
-CM_ITEM_KERNEL(k_s1b_compact, cm_s1b_compact)
+
+// S1 with fused compaction: every read's minimizers go to its slot range first (the state
+// machine emits a data-dependent number of them); the block then reserves one contiguous
+// range of the dense arrays with a single atomic and every lane copies its own entries
+// there.  The dense order is block-arrival order; consumers go through mm_off[r]/mm_cnt[r].
+__global__ __launch_bounds__(CM_BLOCK) void k_s1_minimizers(CmDev d, uint32_t n, uint32_t *__restrict__ total) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  uint32_t cnt = 0;
+  if (i < n) {
+    cm_s1_minimizers(d, i);
+    cnt = d.mm_cnt[i];
+  }
+  __shared__ uint32_t wsum[CM_BLOCK / 64];
+  __shared__ uint32_t block_base;
+  uint32_t inc = cnt;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int j = 0; j < CM_BLOCK / 64; ++j) { const uint32_t t = wsum[j]; wsum[j] = tot; tot += t; }
+    block_base = tot ? atomicAdd(total, tot) : 0;
+  }
+  __syncthreads();
+  if (i < n) {
+    d.mm_off[i] = block_base + wsum[wv] + inc - cnt;
+    cm_s1b_compact(d, i);
+  }
+}
 CM_ITEM_KERNEL(k_s3a_count, cm_s3a_count)
 CM_ITEM_KERNEL(k_s3b_candidates, cm_s3b_candidates)
 CM_ITEM_KERNEL(k_s4a_rescue_count, cm_s4a_rescue_count)
@@ -273,8 +304,6 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + CM_BLOCK - 1) / CM_BL
     if (n) hipLaunchKernelGGL(kname, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);         \
   }
 CM_LAUNCH(k_s0_prep)
-CM_LAUNCH(k_s1_minimizers)
-CM_LAUNCH(k_s1b_compact)
 CM_LAUNCH(k_s3a_count)
 CM_LAUNCH(k_s3b_candidates)
 CM_LAUNCH(k_s4a_rescue_count)
@@ -284,6 +313,9 @@ CM_LAUNCH(k_s5_verify)
 CM_LAUNCH(k_s6a_pair)
 CM_LAUNCH(k_s6c_multi)
 
+void cm_launch_k_s1_minimizers(const CmDev &d, uint32_t n, uint32_t *total, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_s1_minimizers, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, total);
+}
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s) {
   if (n_chunks) hipLaunchKernelGGL(k_s6b_sample, dim3(n_chunks), dim3(64), 0, s, d, n_chunks);
 }

@@ -252,14 +252,78 @@ CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
 //     consumer on the mapping path looks at it (index.cc:491-505 uses position+strand).
 // ---------------------------------------------------------------------------------------
 #define CM_MAX_W 32
-CM_HD void cm_s1_minimizers(const CmDev &d, uint32_t r) {
-  const uint32_t len = d.rlen[r];
-  const int k = d.p.k, w = d.p.w;
-  const uint8_t *seq = cm_read_ptr(d, r);
-  const uint32_t base = d.mm_cap_off[r];
-  const uint32_t cap = d.mm_cap_off[r + 1] - base;
-  uint64_t *oh = d.slot_hash + base;
-  uint32_t *op = d.slot_ps + base;
+// Window of the last W (hash, pos) entries kept in registers in chronological order
+// (index 0 = oldest).  Equivalent to the reference's ring buffer: its scans
+// `j = pib+1..w-1, then 0..pib` walk the ring oldest -> newest, "position_in_buffer ==
+// min_position" means the running minimum is the entry being evicted (mi < 0 after the
+// shift), and a palindromic k-mer neither writes nor advances (:42-45).
+template <int W>
+CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uint64_t *oh, uint32_t *op, uint32_t cap) {
+  uint32_t n = 0;
+  const uint64_t shift = 2 * (uint64_t)(k - 1);
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  uint64_t fw = 0, rv = 0;
+  uint64_t wh[W];
+  uint32_t wp[W];
+  uint64_t min_h = ~0ull;
+  uint32_t min_p = ~0u;
+#pragma unroll
+  for (int i = 0; i < W; ++i) { wh[i] = ~0ull; wp[i] = ~0u; }
+  int unamb = 0, mi = 0;
+#define CM_EMIT(h, p) do { if (n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
+  for (uint32_t pos = 0; pos < len; ++pos) {
+    const uint32_t c = cm_c2u(seq[pos]);
+    uint64_t cur_h = ~0ull;
+    uint32_t cur_p = ~0u;
+    if (c < 4) {
+      fw = ((fw << 2) | c) & mask;
+      rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
+      if (fw == rv) continue;
+      const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+      const uint32_t strand = h0 < h1 ? 0u : 1u;
+      ++unamb;
+      if (unamb >= k) {
+        cur_h = cm_hash64(strand ? h1 : h0, mask);
+        cur_p = (pos << 1) | strand;
+      }
+    } else {
+      unamb = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < W - 1; ++j) { wh[j] = wh[j + 1]; wp[j] = wp[j + 1]; }
+    wh[W - 1] = cur_h;
+    wp[W - 1] = cur_p;
+    --mi;
+    if (unamb == W + k - 1 && min_h != ~0ull && min_h < cur_h) {
+#pragma unroll
+      for (int j = 0; j < W - 1; ++j)
+        if (min_h == wh[j] && wp[j] != min_p) CM_EMIT(wh[j], wp[j]);
+    }
+    if (cur_h <= min_h) {
+      if (unamb >= W + k && min_h != ~0ull) CM_EMIT(min_h, min_p);
+      min_h = cur_h;
+      min_p = cur_p;
+      mi = W - 1;
+    } else if (mi < 0) {
+      if (unamb >= W + k - 1 && min_h != ~0ull) CM_EMIT(min_h, min_p);
+      min_h = ~0ull;
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (min_h >= wh[j]) { min_h = wh[j]; min_p = wp[j]; mi = j; }
+      if (unamb >= W + k - 1 && min_h != ~0ull) {
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (min_h == wh[j] && min_p != wp[j]) CM_EMIT(wh[j], wp[j]);
+      }
+    }
+  }
+  if (min_h != ~0ull) CM_EMIT(min_h, min_p);
+#undef CM_EMIT
+  return n;
+}
+
+// generic window size: ring buffer in private memory, literal transcription
+CM_HD uint32_t cm_minimizers_ring(const uint8_t *seq, uint32_t len, int k, int w, uint64_t *oh, uint32_t *op, uint32_t cap) {
   uint32_t n = 0;
   const uint64_t shift = 2 * (uint64_t)(k - 1);
   const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
@@ -320,11 +384,22 @@ CM_HD void cm_s1_minimizers(const CmDev &d, uint32_t r) {
   }
   if (min_h != ~0ull) CM_EMIT(min_h, min_p);
 #undef CM_EMIT
+  return n;
+}
+
+CM_HD void cm_s1_minimizers(const CmDev &d, uint32_t r) {
+  const uint32_t len = d.rlen[r];
+  const uint8_t *seq = cm_read_ptr(d, r);
+  const uint32_t base = d.mm_cap_off[r];
+  const uint32_t cap = d.mm_cap_off[r + 1] - base;
+  uint64_t *oh = d.slot_hash + base;
+  uint32_t *op = d.slot_ps + base;
+  uint32_t n = d.p.w == 7 ? cm_minimizers_window<7>(seq, len, d.p.k, oh, op, cap)
+                          : cm_minimizers_ring(seq, len, d.p.k, d.p.w, oh, op, cap);
   if (n > cap) { n = cap; d.stats[CM_ST_ERR] = 1; }  // cannot happen: <= one emission per k-mer position
   // BothEndsHaveMinimizers gate (chromap.h:936) is applied by the consumer via mm_cnt
   d.mm_cnt[r] = n;
 }
-
 
 // ---------------------------------------------------------------------------------------
 // Reference minimizers for index construction (Index::Construct, index.cc:19-23), one

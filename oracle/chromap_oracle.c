@@ -594,6 +594,7 @@ typedef struct {
   vec64 pos_hits, neg_hits;
   vcand pos_cand, neg_cand, pos_buf, neg_buf;
   vdraft pos_map, neg_map;
+  vec64 pos_split, neg_split; /* split sites (int), parallel to pos_map/neg_map */
   int min_err, second_err, n_best, n_second;
   uint32_t rep_len;
 } meta_t;
@@ -608,12 +609,13 @@ static void meta_prepare(meta_t *m, uint32_t read_len) {
   m->pos_hits.n = m->neg_hits.n = 0;
   m->pos_cand.n = m->neg_cand.n = m->pos_buf.n = m->neg_buf.n = 0;
   m->pos_map.n = m->neg_map.n = 0;
+  m->pos_split.n = m->neg_split.n = 0;
   m->rep_len = 0;
 }
 static void meta_free(meta_t *m) {
   free(m->mm_hash); free(m->mm_hit); free(m->pos_hits.a); free(m->neg_hits.a);
   free(m->pos_cand.a); free(m->neg_cand.a); free(m->pos_buf.a); free(m->neg_buf.a);
-  free(m->pos_map.a); free(m->neg_map.a);
+  free(m->pos_map.a); free(m->neg_map.a); free(m->pos_split.a); free(m->neg_split.a);
 }
 
 struct ora_ctx {
@@ -1044,6 +1046,115 @@ void ora_banded_traceback(int e, int min_num_errors, const char *pattern, const 
   }
 }
 
+
+/* BandedAlignPatternToTextWithDropOff (alignment.cc:197-283) */
+static int banded_align_dropoff(int e, const char *pattern, const char *text, int read_length,
+                                int *mapping_end_position, int *read_mapping_length) {
+  uint32_t Peq[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) Peq[c2u(pattern[i])] |= (1u << i);
+  const uint32_t hi = 1u << (2 * e), lo = 1;
+  uint32_t VP = 0, VN = 0, X, D0, HN, HP, prev_VP = 0, prev_VN = 0;
+  int err = 0, i = 0, fail_beginning = 0, prev_err = 0;
+  for (; i < read_length; i++) {
+    Peq[c2u(pattern[i + 2 * e])] |= hi;
+    X = Peq[c2u(text[i])] | VN;
+    D0 = ((VP + (X & VP)) ^ VP) | X;
+    HN = VP & D0;
+    HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    prev_VN = VN; prev_VP = VP;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    prev_err = err;
+    err += 1 - (int)(D0 & lo);
+    if (err > 2 * e) {
+      if (i < 4 * e && i < read_length / 2) fail_beginning = 1;
+      break;
+    }
+    for (int ai = 0; ai < 5; ai++) Peq[ai] >>= 1;
+  }
+  if (i < read_length) { err = prev_err; VN = prev_VN; VP = prev_VP; }
+  const int band_start = i - 1;
+  int min_err = err;
+  *read_mapping_length = i;
+  *mapping_end_position = band_start;
+  for (i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *mapping_end_position = band_start + 1 + i;
+    }
+  }
+  if (fail_beginning || (read_length > 60 && *mapping_end_position + 1 - e - min_err < 30))
+    *mapping_end_position = -*mapping_end_position;
+  return min_err;
+}
+
+/* BandedAlignPatternToTextWithDropOffFrom3End (alignment.cc:285-376) */
+static int banded_align_dropoff_3end(int e, const char *pattern, const char *text, int read_length,
+                                     int *mapping_end_position, int *read_mapping_length) {
+  uint32_t Peq[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) Peq[c2u(pattern[read_length + 2 * e - 1 - i])] |= (1u << i);
+  const uint32_t hi = 1u << (2 * e), lo = 1;
+  uint32_t VP = 0, VN = 0, X, D0, HN, HP, prev_VP = 0, prev_VN = 0;
+  int err = 0, i = 0, fail_beginning = 0, prev_err = 0;
+  for (; i < read_length; i++) {
+    Peq[c2u(pattern[read_length - 1 - i])] |= hi;
+    X = Peq[c2u(text[read_length - 1 - i])] | VN;
+    D0 = ((VP + (X & VP)) ^ VP) | X;
+    HN = VP & D0;
+    HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    prev_VN = VN; prev_VP = VP;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    prev_err = err;
+    err += 1 - (int)(D0 & lo);
+    if (err > 2 * e) {
+      if (i < 4 * e && i < read_length / 2) fail_beginning = 1;
+      break;
+    }
+    for (int ai = 0; ai < 5; ai++) Peq[ai] >>= 1;
+  }
+  if (i < read_length) { err = prev_err; VN = prev_VN; VP = prev_VP; }
+  const int band_start = i - 1;
+  int min_err = err;
+  *read_mapping_length = i;
+  *mapping_end_position = band_start;
+  for (i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *mapping_end_position = band_start + (1 + i);
+    }
+  }
+  if (fail_beginning || (read_length > 60 && *mapping_end_position + 1 - e - min_err < 30))
+    *mapping_end_position = -*mapping_end_position;
+  return min_err;
+}
+
+/* AdjustGapBeginning (alignment.cc:24-83), non-SAM use (no cigar). strand 0 = +.
+ * read is NUL-terminated at read_total_len, ref at ref_len (the loops of the - branch
+ * stop on the terminators). */
+static int adjust_gap_beginning(int strand, const char *ref, uint32_t ref_len, const char *read, int read_total_len,
+                                int *gap_beginning, int read_end, int ref_start_position, int ref_end_position) {
+  int i, j;
+  if (strand == 0) {
+    if (*gap_beginning <= 0) return ref_start_position;
+    for (i = *gap_beginning - 1, j = ref_start_position - 1; i >= 0 && j >= 0; --i, --j)
+      if (read[i] != ref[j] && read[i] != ref[j] - 'a' + 'A') break;
+    *gap_beginning = i + 1;
+    return j + 1;
+  }
+  if (*gap_beginning <= 0) return ref_end_position;
+  for (i = read_end + 1, j = ref_end_position + 1; i < read_total_len && (uint32_t)j < ref_len; ++i, ++j)
+    if (read[i] != ref[j] && read[i] != ref[j] - 'a' + 'A') break;
+  *gap_beginning = *gap_beginning + i - (read_end + 1);
+  return j - 1;
+}
+
 /* DraftMappingGenerator::IsValidCandidate (draft_mapping_generator.cc:59-70) */
 static inline int is_valid_candidate(const ora_ref *ref, int e, uint32_t rid, uint32_t position,
                                      uint32_t read_length) {
@@ -1099,6 +1210,67 @@ static void draft_one_strand_scalar(const ora_ctx *c, meta_t *m, int strand, con
     if (strand == 1) position = position - L + 1;
     if (!is_valid_candidate(c->ref, c->p.error_threshold, rid, position, L)) continue;
     verify_one(c, m, strand, &cs->a[ci], read_seq, L, st);
+  }
+}
+
+
+/* GenerateDraftMappingsOnOneStrand, split-alignment branch (draft_mapping_generator.cc:359-557).
+ * best_mapping_longest_match / longest_match are re-initialised per candidate in the
+ * reference (:404-405), so the second_min adjustment at :511-515 never fires. */
+static void draft_one_strand_split(const ora_ctx *c, meta_t *m, int strand, const char *read_seq, uint32_t L,
+                                   ora_stats *st) {
+  const vcand *cs = strand == 0 ? &m->pos_cand : &m->neg_cand;
+  const int e = c->p.error_threshold;
+  uint32_t thr = 0;
+  for (size_t ci = 0; ci < cs->n; ++ci) {
+    if (cs->a[ci].count < thr) break;
+    const uint32_t rid = (uint32_t)(cs->a[ci].position >> 32);
+    uint32_t position = (uint32_t)cs->a[ci].position;
+    if (strand == 1) position = position - L + 1;
+    if (!is_valid_candidate(c->ref, e, rid, position, L)) continue;
+    int mep = (int)L, gap_beginning = 0, num_errors = 0, actual = 0, rml = 0;
+    const int allow = 20 - e, len_thr = 30;
+    const char *pat = c->ref->seq[rid] + position - e;
+    if (st) st->num_verifications++;
+    if (strand == 0) {
+      num_errors = banded_align_dropoff(e, pat, read_seq, (int)L, &mep, &rml);
+      if (mep < 0 && allow > 0) {
+        const int b_err = num_errors, b_mep = -mep, b_rml = rml;
+        num_errors = banded_align_dropoff(e, pat + allow, read_seq + allow, (int)L - allow, &mep, &rml);
+        if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
+        else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
+      }
+    } else {
+      num_errors = banded_align_dropoff_3end(e, pat, read_seq, (int)L, &mep, &rml);
+      if (mep < 0 && allow > 0) {
+        const int b_err = num_errors, b_mep = -mep, b_rml = rml;
+        num_errors = banded_align_dropoff_3end(e, pat, read_seq, (int)L - allow, &mep, &rml);
+        if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
+        else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
+      }
+    }
+    if (mep + 1 - e - num_errors - gap_beginning >= len_thr) {
+      actual = num_errors;
+      num_errors = -(mep - e - num_errors - gap_beginning);
+    } else {
+      num_errors = e + 1;
+      actual = e + 1;
+    }
+    if (num_errors <= e) {
+      if (num_errors < m->min_err) {
+        m->second_err = m->min_err; m->n_second = m->n_best; m->min_err = num_errors; m->n_best = 1;
+        thr = cs->n > 50 ? cs->a[ci].count : cs->a[ci].count / 2;
+      } else if (num_errors == m->min_err) m->n_best++;
+      else if (num_errors == m->second_err) m->n_second++;
+      else if (num_errors < m->second_err) { m->n_second = 1; m->second_err = num_errors; }
+      if (strand == 0) {
+        vd_push(&m->pos_map, num_errors, cs->a[ci].position - (uint64_t)e + (uint64_t)(int64_t)mep);
+        v64_push(&m->pos_split, (uint64_t)(uint32_t)(((actual & 0xff) << 24) | ((gap_beginning & 0xff) << 16) | (rml & 0xffff)));
+      } else {
+        vd_push(&m->neg_map, num_errors, cs->a[ci].position - (uint64_t)(int64_t)gap_beginning); /* :534-537 */
+        v64_push(&m->neg_split, (uint64_t)(uint32_t)(((actual & 0xff) << 24) | ((gap_beginning & 0xff) << 16) | (rml & 0xffff)));
+      }
+    }
   }
 }
 
@@ -1160,8 +1332,12 @@ static void gen_draft_mappings(const ora_ctx *c, meta_t *m, const char *read, co
   }
   qsort(m->pos_cand.a, m->pos_cand.n, sizeof(cand_t), cmp_cand); /* SortCandidates, mapping_metadata.h:65-68 */
   qsort(m->neg_cand.a, m->neg_cand.n, sizeof(cand_t), cmp_cand);
+  if (c->p.split_alignment) { /* :31-39 */
+    draft_one_strand_split(c, m, 0, read, L, st);
+    draft_one_strand_split(c, m, 1, neg_read, L, st);
+    return;
+  }
   int lanes = e < 8 ? 8 : (e < 16 ? 4 : 0); /* GetNumVPULanes, mapping_parameters.h:80-88 */
-  if (c->p.split_alignment) lanes = 0;
   if (lanes == 0 || m->pos_cand.n < (size_t)lanes) draft_one_strand_scalar(c, m, 0, read, L, st);
   else draft_one_strand_lanes(c, m, 0, read, L, lanes, st);
   if (lanes == 0 || m->neg_cand.n < (size_t)lanes) draft_one_strand_scalar(c, m, 1, neg_read, L, st);
@@ -1173,7 +1349,7 @@ static void gen_draft_mappings(const ora_ctx *c, meta_t *m, const char *read, co
 /* ------------------------------------------------------------------------- */
 typedef struct {
   int min_sum, second_sum, n_best, n_second;
-  vpair best[2]; /* [0] = F1R2, [1] = F2R1 */
+  vpair best[4]; /* [0] = F1R2, [1] = F2R1, split only: [2] = F1F2, [3] = R1R2 */
 } pe_meta_t;
 
 /* GenerateBestMappingsForPairedEndReadOnOneDirection, non-split (mapping_generator.h:347-484).
@@ -1308,6 +1484,7 @@ static uint8_t mapq_paired(const ora_ctx *c, int err1, int err2, uint16_t al1, u
   return mapq;
 }
 
+
 /* ------------------------------------------------------------------------- */
 /* K0: adapter trimming (chromap.cc:176-289, sequence_batch.h:136-151)         */
 /* ------------------------------------------------------------------------- */
@@ -1403,6 +1580,180 @@ static void sort_drafts(vdraft *v) {
   (void)cmp_draft_pos;
 }
 
+/* ---- split alignment (--preset hic): K5 ------------------------------------------------ */
+/* GetRefStartEndPositionForReadFromMapping, split + non-SAM branches
+ * (mapping_generator.h:657-717, 762-793, 855-916). read_seq: forward read for +, reverse
+ * complement for -, both of full length full_len. */
+static span_t ref_start_end_split(const ora_ctx *c, const draft_t *d, int split_site_word, int strand,
+                                  const char *read_seq, int full_len) {
+  const int e = c->p.error_threshold;
+  const uint32_t rid = (uint32_t)(d->position >> 32), ref_pos = (uint32_t)d->position;
+  const uint32_t rl = c->ref->len[rid];
+  const int split_site = split_site_word & 0xffff;
+  int gap_beginning = (split_site_word >> 16) & 0xff;
+  const int actual = (split_site_word >> 24) & 0xff;
+  int read_length = split_site - gap_beginning;
+  uint32_t vw = ref_pos + 1 > (uint32_t)(read_length + e) ? ref_pos + 1 - (uint32_t)read_length - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)read_length;
+  span_t s;
+  s.rid = rid;
+  if (strand == 0) {
+    int start = 0;
+    ora_banded_traceback(e, actual, c->ref->seq[rid] + vw, read_seq + gap_beginning, read_length, &start);
+    if (gap_beginning > 0) {
+      const int nrs = adjust_gap_beginning(0, c->ref->seq[rid], rl, read_seq, full_len, &gap_beginning, read_length - 1,
+                                           (int)vw + start, (int)ref_pos);
+      start = nrs - (int)vw;
+    }
+    s.ref_start = vw + (uint32_t)start;
+    s.ref_end = ref_pos;
+    return s;
+  }
+  const int read_start_site = full_len - split_site;
+  const int start = e;
+  int mep = (int)(ref_pos - vw + 1);
+  ora_banded_align(e, c->ref->seq[rid] + vw, read_seq + read_start_site, read_length, &mep);
+  mep += 1;
+  if (gap_beginning > 0) {
+    const int nre = adjust_gap_beginning(1, c->ref->seq[rid], rl, read_seq + read_start_site, full_len - read_start_site,
+                                         &gap_beginning, read_length - 1, (int)vw + start, (int)vw + mep);
+    mep = nre - (int)vw + 1;
+  }
+  s.ref_start = vw + (uint32_t)start;
+  s.ref_end = vw + (uint32_t)mep - 1;
+  return s;
+}
+
+/* GetMAPQForSingleEndRead with split_alignment (mapping_generator.h:920-1022). strand_ncand:
+ * number of candidates on the mapping's strand. */
+static uint8_t mapq_single_split(const ora_ctx *c, int num_errors, uint16_t alignment_length, int read_length,
+                                 int max_diff, const meta_t *m, uint32_t strand_ncand) {
+  const int e = c->p.error_threshold;
+  int mapq_coef_length = 50;
+  int mapq_coef_fraction = (int)log((double)mapq_coef_length);
+  double alignment_identity = (double)(-num_errors) / alignment_length;
+  if (alignment_identity > 1) alignment_identity = 1;
+  int mapq = 0;
+  int second = m->second_err;
+  if (m->n_best > 1) {
+  } else {
+    if (second > num_errors + max_diff) second = num_errors + max_diff;
+    double tmp = alignment_length < mapq_coef_length ? 1.0 : mapq_coef_fraction / log((double)alignment_length);
+    tmp *= alignment_identity * alignment_identity;
+    mapq = (int)(5 * 6.02 * (second - num_errors) * tmp * tmp + 0.499);
+  }
+  if (m->n_second > 0) mapq -= (int)(4.343 * log((double)(m->n_second + 1)) + 0.499);
+  if (mapq > 60) mapq = 60;
+  if (mapq < 0) mapq = 0;
+  if (m->rep_len > 0) {
+    double frac_rep = (m->rep_len) / (double)read_length;
+    if (m->rep_len >= (uint32_t)read_length) frac_rep = 0.999;
+    if (alignment_identity <= 0.95) mapq = (int)(mapq * (1 - sqrt(frac_rep)) + 0.499);
+    else if (alignment_identity <= 0.97) mapq = (int)(mapq * (1 - frac_rep) + 0.499);
+    else if (alignment_identity >= 0.999) mapq = (int)(mapq * (1 - frac_rep * frac_rep * frac_rep * frac_rep) + 0.499);
+    else mapq = (int)(mapq * (1 - frac_rep * frac_rep) + 0.499);
+  }
+  if (alignment_length < read_length - e && second != num_errors) { /* :990-1019 */
+    if (m->rep_len >= alignment_length && m->rep_len < (uint32_t)read_length && alignment_length < read_length / 3) mapq = 0;
+    const int diff = second - num_errors;
+    if (second - num_errors <= e * 3 / 4 && strand_ncand >= 5) mapq = (int)((uint32_t)mapq - (strand_ncand / 5 / (uint32_t)diff));
+    if (mapq < 0) mapq = 0;
+    if (m->n_second > 0 && second - num_errors <= e * 3 / 4) mapq /= (m->n_second / diff + 1);
+  }
+  return (uint8_t)mapq;
+}
+
+/* GetMAPQForPairedEndRead with split_alignment (mapping_generator.h:1027-1192): mapq_pe is
+ * computed but only used by the non-split combination (:1163-1170). */
+static uint8_t mapq_paired_split(const ora_ctx *c, int s1, int s2, int err1, int err2, uint16_t al1, uint16_t al2,
+                                 int len1, int len2, int force_mapq, const meta_t *m1, const meta_t *m2) {
+  uint8_t mapq1 = mapq_single_split(c, err1, al1, len1, 2, m1, (uint32_t)(s1 == 0 ? m1->pos_cand.n : m1->neg_cand.n));
+  uint8_t mapq2 = mapq_single_split(c, err2, al2, len2, 2, m2, (uint32_t)(s2 == 0 ? m2->pos_cand.n : m2->neg_cand.n));
+  mapq1 = (uint8_t)(mapq1 * 1.2);
+  if (mapq1 > 60) mapq1 = 60;
+  mapq2 = (uint8_t)(mapq2 * 1.2);
+  if (mapq2 > 60) mapq2 = 60;
+  uint8_t mapq = mapq1 < mapq2 ? mapq1 : mapq2;
+  if (mapq < 60 && force_mapq >= 0 && force_mapq < mapq) mapq = (uint8_t)force_mapq;
+  return mapq;
+}
+
+/* GenerateBestMappingsForPairedEndRead + ProcessBestMappings... + EmplaceBack<PairsMapping>
+ * for split alignment (mapping_generator.h:160-253, 389-415, 487-653; mapping_generator.cc:169-210) */
+static long finish_pair_split(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t read_id, const char *r1,
+                              const char *neg1, uint32_t len1, const char *r2, const char *neg2, uint32_t len2,
+                              ora_record *out, ora_trace *tr) {
+  const ora_params *p = &c->p;
+  meta_t *m1 = &wk->m1, *m2 = &wk->m2;
+  pe_meta_t *pe = &wk->pe;
+  pe->min_sum = 2 * p->error_threshold + 1; pe->n_best = 0;
+  pe->second_sum = 2 * p->error_threshold + 1; pe->n_second = 0;
+  static const int S1[4] = {0, 1, 0, 1}, S2[4] = {1, 0, 0, 1}; /* (+,-) (-,+) (+,+) (-,-) */
+  for (int o = 0; o < 4; ++o) {
+    pe->best[o].n = 0;
+    const vdraft *a = S1[o] == 0 ? &m1->pos_map : &m1->neg_map;
+    const vdraft *b = S2[o] == 0 ? &m2->pos_map : &m2->neg_map;
+    if (a->n == 0 || b->n == 0) continue;
+    for (uint32_t i1 = 0; i1 < a->n; ++i1) {
+      if (a->a[i1].num_errors != m1->min_err) continue;
+      for (uint32_t i2 = 0; i2 < b->n; ++i2) {
+        if (b->a[i2].num_errors != m2->min_err) continue;
+        vp_push(&pe->best[o], i1, i2);
+        pe->min_sum = m1->min_err + m2->min_err;
+        pe->n_best++;
+      }
+    }
+  }
+  if (tr) { tr->min_sum = pe->min_sum; tr->nbest = pe->n_best; tr->second_sum = pe->second_sum; tr->nsecond = pe->n_second; tr->force_mapq = -1; }
+  long nout = 0;
+  if (pe->n_best > p->drop_repetitive_reads) return 0;
+  int choice = 0;
+  if (pe->n_best > 1) {
+    for (int i = 1; i < pe->n_best; ++i) {
+      int j = mt_uniform(rng, i);
+      if (j < 1) choice = i;
+    }
+  }
+  if (pe->n_best < 1) return 0;
+  const uint8_t is_unique = (pe->n_best == 1 || m1->n_best == 1 || m2->n_best == 1) ? 1 : 0;
+  int idx = 0;
+  for (int o = 0; o < 4 && nout == 0; ++o) {
+    const vdraft *a = S1[o] == 0 ? &m1->pos_map : &m1->neg_map;
+    const vdraft *b = S2[o] == 0 ? &m2->pos_map : &m2->neg_map;
+    const vec64 *sa = S1[o] == 0 ? &m1->pos_split : &m1->neg_split;
+    const vec64 *sb = S2[o] == 0 ? &m2->pos_split : &m2->neg_split;
+    for (size_t mi = 0; mi < pe->best[o].n; ++mi) {
+      const uint32_t i1 = pe->best[o].a[mi].a, i2 = pe->best[o].a[mi].b;
+      if (a->a[i1].num_errors + b->a[i2].num_errors > pe->min_sum) continue;
+      if (idx == choice) {
+        const span_t x = ref_start_end_split(c, &a->a[i1], (int)sa->a[i1], S1[o], S1[o] == 0 ? r1 : neg1, (int)len1);
+        const span_t y = ref_start_end_split(c, &b->a[i2], (int)sb->a[i2], S2[o], S2[o] == 0 ? r2 : neg2, (int)len2);
+        const uint16_t al1 = (uint16_t)(x.ref_end - x.ref_start + 1), al2 = (uint16_t)(y.ref_end - y.ref_start + 1);
+        const uint8_t mapq = mapq_paired_split(c, S1[o], S2[o], a->a[i1].num_errors, b->a[i2].num_errors, al1, al2,
+                                               (int)len1, (int)len2, -1, m1, m2);
+        /* EmplaceBackPairedEndMappingRecord<PairsMapping> (mapping_generator.cc:169-210); default
+         * rid ranks are the identity (chromap.cc:867-877) */
+        uint8_t st1 = S1[o] == 0 ? 1 : 0, st2 = S2[o] == 0 ? 1 : 0;
+        int pos1 = (int)(S1[o] == 0 ? x.ref_start : x.ref_end), pos2 = (int)(S2[o] == 0 ? y.ref_start : y.ref_end);
+        int rid1 = (int)x.rid, rid2 = (int)y.rid;
+        const int smaller = rid1 < rid2 || (rid1 == rid2 && pos1 < pos2);
+        if (!smaller) {
+          int t = rid1; rid1 = rid2; rid2 = t;
+          t = pos1; pos1 = pos2; pos2 = t;
+          uint8_t u = st1; st1 = st2; st2 = u;
+        }
+        ora_pairs_record *r = (ora_pairs_record *)&out[nout++];
+        r->read_id = read_id; r->rid1 = (uint32_t)rid1; r->rid2 = (uint32_t)rid2;
+        r->pos1 = (uint32_t)pos1; r->pos2 = (uint32_t)pos2;
+        r->strand1 = st1; r->strand2 = st2; r->mapq = mapq; r->is_unique = is_unique;
+        break;
+      }
+      ++idx;
+    }
+  }
+  return nout;
+}
+
 static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t pair_index,
                          uint32_t read_id, const char *s1, uint32_t len1, const char *s2,
                          uint32_t len2, ora_record *out, ora_stats *st, ora_trace *tr) {
@@ -1464,6 +1815,15 @@ static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t 
   if (!p->split_alignment) {
     sort_drafts(&m1->pos_map); sort_drafts(&m1->neg_map);
     sort_drafts(&m2->pos_map); sort_drafts(&m2->neg_map);
+  }
+  if (p->split_alignment) {
+    const long k = finish_pair_split(c, wk, rng, read_id, r1, neg1, len1, r2, neg2, len2, out, tr);
+    if (st) {
+      if (wk->pe.n_best == 1) st->num_uniquely_mapped_reads += 2;
+      st->num_mappings += 2 * (uint64_t)(wk->pe.n_best < p->max_num_best_mappings ? wk->pe.n_best : p->max_num_best_mappings);
+      if (wk->pe.n_best > 0) st->num_mapped_reads += 2;
+    }
+    return k;
   }
   const int force_mapq = supp != 0 ? 0 : -1;
   /* GenerateBestMappingsForPairedEndRead (mapping_generator.h:160-253) */
@@ -1540,7 +1900,7 @@ static void work_init(work_t *wk, const ora_params *p) {
 }
 static void work_free(work_t *wk) {
   meta_free(&wk->m1); meta_free(&wk->m2);
-  free(wk->pe.best[0].a); free(wk->pe.best[1].a);
+  free(wk->pe.best[0].a); free(wk->pe.best[1].a); free(wk->pe.best[2].a); free(wk->pe.best[3].a);
   free(wk->neg1); free(wk->neg2); free(wk->fw1); free(wk->fw2); free(wk->best_idx);
 }
 
@@ -1684,6 +2044,39 @@ long ora_write_bed_pe(const ora_ref *ref, const ora_params *p, ora_record *rec, 
      * non-Tn5 default path is used in tests. */
     for (long i = 0; i < n; ++i)
       if (rec[i].mapq >= p->mapq_threshold) { bed_line(f, ref, p, rec[i], rec[i].num_dups); ++lines; }
+  }
+  fclose(f);
+  return lines;
+}
+
+/* pairs output (--preset hic): sort by PairsMapping::operator< per rid1 (pairs_mapping.h:40-43;
+ * rid1 is also the per-chromosome vector index, mapping_generator.cc:205), MAPQ filter, no
+ * dedup unless remove_pcr_duplicates (== on rid1,pos1,rid2,pos2), header + lines
+ * (mapping_writer.cc:381-420).  read_names[i] = name of read1 of pair i. */
+static int cmp_pairs_rec(const void *a, const void *b) {
+  const ora_pairs_record *x = (const ora_pairs_record *)a, *y = (const ora_pairs_record *)b;
+#define CMPF(f) if (x->f != y->f) return x->f < y->f ? -1 : 1
+  CMPF(rid1); CMPF(rid2); CMPF(pos1); CMPF(pos2); CMPF(mapq); CMPF(read_id);
+#undef CMPF
+  return 0;
+}
+
+long ora_write_pairs(const ora_ref *ref, const ora_params *p, ora_pairs_record *rec, long n,
+                     const char *const *read_names, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  qsort(rec, (size_t)n, sizeof(ora_pairs_record), cmp_pairs_rec);
+  fprintf(f, "## pairs format v1.0.0\n#shape: upper triangle\n");
+  for (uint32_t i = 0; i < ref->n_seq; ++i) fprintf(f, "#chromsize: %s %u\n", ref->name[i], ref->len[i]);
+  fprintf(f, "#columns: readID chrom1 pos1 chrom2 pos2 strand1 strand2 pair_type mapq1 mapq2\n");
+  long lines = 0;
+  for (long i = 0; i < n; ++i) {
+    const ora_pairs_record *r = &rec[i];
+    if (r->mapq < p->mapq_threshold) continue;
+    fprintf(f, "%s\t%s\t%d\t%s\t%d\t%c\t%c\tUU\t%u\t%u\n", read_names[r->read_id], ref->name[r->rid1], (int)r->pos1 + 1,
+            ref->name[r->rid2], (int)r->pos2 + 1, r->strand1 ? '+' : '-', r->strand2 ? '+' : '-', (unsigned)r->mapq,
+            (unsigned)r->mapq);
+    ++lines;
   }
   fclose(f);
   return lines;

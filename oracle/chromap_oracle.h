@@ -74,6 +74,14 @@ typedef struct ora_record {
   uint16_t neg_aln_len;
 } ora_record;
 
+/* constructor arguments of PairsMapping (pairs_mapping.h:25-38) without name and barcode;
+ * written instead of ora_record (same 24-byte slot) when split_alignment is set */
+typedef struct ora_pairs_record {
+  uint32_t read_id, rid1, rid2, pos1, pos2;
+  uint8_t strand1, strand2; /* 1 = positive */
+  uint8_t mapq, is_unique;
+} ora_pairs_record;
+
 /* counters of Chromap::OutputMappingStatistics (chromap.cc:808-823) */
 typedef struct ora_stats {
   uint64_t num_candidates, num_mappings, num_mapped_reads, num_uniquely_mapped_reads;
@@ -153,6 +161,10 @@ void ora_set_trace(ora_ctx *c, ora_trace *trace /* n entries, or NULL */);
  * mapping_writer.cc:72-117 (PE bulk BED).  Sorts records in place. Returns #lines. */
 long ora_write_bed_pe(const ora_ref *ref, const ora_params *p, ora_record *rec, long n,
                       const char *out_path);
+
+/* pairs output for --preset hic (mapping_writer.cc:381-420); read_names[read_id] */
+long ora_write_pairs(const ora_ref *ref, const ora_params *p, ora_pairs_record *rec, long n,
+                     const char *const *read_names, const char *out_path);
 
 /* FASTQ/FASTA reader (kseq.h semantics: name up to whitespace, multi-line ok) used by
  * tests to build the SoA batches. Returns number of records, allocates bases and off. */

@@ -49,8 +49,13 @@ def case_inputs(name):
 
 
 def case_golden_bed(name):
-    with gzip.open(os.path.join(GOLD, name + ".bed.gz"), "rb") as f:
+    ext = ".pairs.gz" if is_hic(name) else ".bed.gz"
+    with gzip.open(os.path.join(GOLD, name + ext), "rb") as f:
         return f.read()
+
+
+def is_hic(name):
+    return "hic" in case_meta(name)["chromap_flags"]
 
 
 def flags_to_params(flags):
@@ -62,7 +67,7 @@ def flags_to_params(flags):
         if flags[i] == "--preset":
             preset = flags[i + 1]
             i += 2
-        elif flags[i] == "-q":
+        elif flags[i] == "-q":  # noqa: E501
             kw["mapq_threshold"] = int(flags[i + 1])
             i += 2
         else:
@@ -71,6 +76,8 @@ def flags_to_params(flags):
 
 
 ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
+BED_CASES = [c for c in ALL_CASES if not is_hic(c)]
+HIC_CASES = [c for c in ALL_CASES if is_hic(c)]
 
 
 def case_index(name):

@@ -35,6 +35,11 @@ CASES = {
                     "--varlen", "--seed", "7"], ["--preset", "atac", "-q", "0"]),
     "s3_chip": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",
                  "--indel", "0.003", "--sub", "0.02"], ["--preset", "chip"]),
+    "h1_hic": (["--genome", "3000000", "--chroms", "4", "--pairs", "20000", "--readlen", "150", "--frag-min", "300",
+                "--frag-max", "800", "--hic", "--seed", "21", "--indel", "0.001"], ["--preset", "hic"]),
+    "h2_hic_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
+                   "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
+                  ["--preset", "hic", "-q", "0"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
@@ -76,7 +81,8 @@ def main():
             meta = {"generator_args": gen, "chromap_flags": flags, "reference_version": "0.3.3-r521",
                     "input_md5": {"fa": md5(fa), "r1": md5(r1), "r2": md5(r2)},
                     "index_md5_reference_build": md5(idx), "bed_md5": md5(out), "reference_stderr_counters": stats}
-            with open(out, "rb") as f, gzip.GzipFile(os.path.join(HERE, name + ".bed.gz"), "wb", mtime=0) as g:
+            ext = ".pairs.gz" if "hic" in flags else ".bed.gz"
+            with open(out, "rb") as f, gzip.GzipFile(os.path.join(HERE, name + ext), "wb", mtime=0) as g:
                 shutil.copyfileobj(f, g)
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(meta, f, indent=1, sort_keys=True)

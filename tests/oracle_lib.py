@@ -179,3 +179,40 @@ class Oracle:
             self.ctx = None
             self.L.ora_index_free(C.byref(self.idx))
             self.L.ora_ref_free(C.byref(self.ref))
+
+
+class OraPairsRecord(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("rid1", C.c_uint32), ("rid2", C.c_uint32), ("pos1", C.c_uint32),
+                ("pos2", C.c_uint32), ("strand1", C.c_uint8), ("strand2", C.c_uint8), ("mapq", C.c_uint8),
+                ("is_unique", C.c_uint8)]
+
+
+assert C.sizeof(OraPairsRecord) == 24 == C.sizeof(OraRecord)
+
+
+def read_names(path):
+    """names (up to first whitespace) of a FASTA/FASTQ file's records, kseq style"""
+    out = []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if ln[:1] == b"@":
+            out.append(ln[1:].split()[0])
+            i += 4
+        elif ln[:1] == b">":
+            out.append(ln[1:].split()[0])
+            i += 1
+        else:
+            i += 1
+    return out
+
+
+def write_pairs(oracle, rec, k, names, path):
+    L = oracle.L
+    L.ora_write_pairs.restype = C.c_long
+    L.ora_write_pairs.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long,
+                                  C.POINTER(C.c_char_p), C.c_char_p]
+    arr = (C.c_char_p * len(names))(*names)
+    return L.ora_write_pairs(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, arr, path.encode())

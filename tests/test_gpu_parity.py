@@ -18,7 +18,7 @@ def _rec_tuple(r):
             getattr(r, "negative_alignment_length", None) if hasattr(r, "negative_alignment_length") else r.neg_aln_len)
 
 
-@pytest.mark.parametrize("case", datasets.ALL_CASES)
+@pytest.mark.parametrize("case", datasets.BED_CASES)
 def test_bed_and_counters_match_reference(case, tmp_path):
     from chromap_amd import ChromapGPU
     meta = datasets.case_meta(case)

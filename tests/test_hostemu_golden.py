@@ -11,7 +11,7 @@ import hostemu_lib as he
 import oracle_lib as ol
 
 
-@pytest.mark.parametrize("case", datasets.ALL_CASES)
+@pytest.mark.parametrize("case", datasets.BED_CASES)
 def test_stage_functions_match_reference(case, tmp_path):
     meta = datasets.case_meta(case)
     fa, r1, r2 = datasets.case_inputs(case)

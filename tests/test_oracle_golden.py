@@ -25,7 +25,12 @@ def test_oracle_bed_matches_reference(case, tmp_path):
     b2, o2 = ol.read_fastx(r2)
     rec, k, st, _ = o.map_pairs(b1, o1, b2, o2)
     out = str(tmp_path / "o.bed")
-    o.write_bed(rec, k, out)
+    hic = datasets.is_hic(case)
+    names = ol.read_names(r1) if hic else None
+    if hic:
+        ol.write_pairs(o, rec, k, names, out)
+    else:
+        o.write_bed(rec, k, out)
     got = open(out, "rb").read()
     assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
     assert got == datasets.case_golden_bed(case)
@@ -38,7 +43,10 @@ def test_oracle_bed_matches_reference(case, tmp_path):
     assert k2 == k
     assert bytes(rec2)[: k * C.sizeof(ol.OraRecord)] != b"" or k == 0
     out2 = str(tmp_path / "o2.bed")
-    o.write_bed(rec2, k2, out2)
+    if hic:
+        ol.write_pairs(o, rec2, k2, names, out2)
+    else:
+        o.write_bed(rec2, k2, out2)
     assert open(out2, "rb").read() == got
     o.close()
 

@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--barcodes", type=int, default=0, help="if >0: whitelist size; writes .bc.fq and .whitelist.txt")
     ap.add_argument("--reads-only", action="store_true", help="reuse existing <out>.fa")
     ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--hic", action="store_true",
+                    help="Hi-C like pairs: mates from two independent loci, some reads chimeric across the ligation junction")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     L = a.readlen
@@ -184,6 +186,21 @@ def main():
                 l2 = int(rng.integers(30, L + 30))
         fw = frag
         rv = revcomp(frag)
+        if a.hic:
+            # second locus for the mate; ligation junction inside a read with p=0.35
+            cj = int(rng.choice(len(chroms), p=cprob))
+            cc = chroms[cj]
+            sj = int(rng.integers(0, max(1, len(cc) - fl)))
+            other = cc[sj:sj + fl]
+            if rng.random() < 0.5:
+                other = revcomp(other)
+            rv = other
+            if rng.random() < 0.35:
+                cut = int(rng.integers(25, max(26, L - 25)))
+                if rng.random() < 0.5:
+                    fw = np.concatenate([fw[:cut], revcomp(other)[:max(0, fl - cut)]])
+                else:
+                    rv = np.concatenate([rv[:cut], revcomp(frag)[:max(0, fl - cut)]])
         r1 = np.concatenate([fw, ADAPTER1])[:l1] if len(fw) < l1 else fw[:l1]
         r2 = np.concatenate([rv, ADAPTER2])[:l2] if len(rv) < l2 else rv[:l2]
         r1 = mutate(rng, r1, a.sub, a.indel)
