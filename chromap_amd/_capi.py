@@ -44,6 +44,12 @@ class Record(C.Structure):
                 ("negative_alignment_length", C.c_uint16)]
 
 
+class PairsRecord(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("rid1", C.c_uint32), ("rid2", C.c_uint32), ("pos1", C.c_uint32),
+                ("pos2", C.c_uint32), ("strand1", C.c_uint8), ("strand2", C.c_uint8), ("mapq", C.c_uint8),
+                ("is_unique", C.c_uint8)]
+
+
 STAT_FIELDS = ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "num_minimizers",
                "probe_steps", "occurrences_read", "num_pairs_rescued", "num_multi_mappers")
 
@@ -55,14 +61,14 @@ class Stats(C.Structure):
         return {n: int(getattr(self, n)) for n in STAT_FIELDS}
 
 
-assert C.sizeof(Record) == 24
+assert C.sizeof(Record) == 24 == C.sizeof(PairsRecord)
 
 # every symbol include/chromap_amd.h declares
 SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_destroy",
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device",
-           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe",
+           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
 _LIB = None
@@ -101,6 +107,8 @@ def declare(L):
     sig("cmgpu_export_reference", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32])
     sig("cmgpu_reference_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
     sig("cmgpu_write_bed_pe", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
+    sig("cmgpu_write_pairs", C.c_int64, [P(C.c_char_p), P(C.c_uint32), C.c_uint32, P(Params), C.c_void_p, C.c_uint64,
+                                         P(C.c_char_p), C.c_uint32, C.c_char_p])
     sig("cmgpu_load_index_file", C.c_int, [C.c_char_p, P(IndexView)])
     sig("cmgpu_free_host_index", None, [P(IndexView)])
     sig("cmgpu_load_reference_fasta", C.c_int, [C.c_char_p, P(RefView)])

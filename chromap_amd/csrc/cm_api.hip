@@ -85,7 +85,6 @@ static int build_mapq_tables(cmgpu_ctx *c) {
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id) {
   c->device = device_id;
   c->hp = *params;
-  if (params->split_alignment) { cm_set_error(c, "split alignment (--preset hic) is not supported yet"); return CMGPU_EINVAL; }
   if (params->max_num_best_mappings != 1) { cm_set_error(c, "max_num_best_mappings must be 1"); return CMGPU_EINVAL; }
   if (kmer < 1 || kmer > 28 || window < 1 || window > CM_MAX_W_HOST) { cm_set_error(c, "unsupported k/w"); return CMGPU_EINVAL; }
   if (params->error_threshold < 1 || params->error_threshold > 15) { cm_set_error(c, "error_threshold must be 1..15"); return CMGPU_EINVAL; }
@@ -99,9 +98,11 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   p.max_best = params->max_num_best_mappings;
   p.drop_rep = params->drop_repetitive_reads;
   p.trim = params->trim_adapters;
+  p.split = params->split_alignment ? 1 : 0;
   p.k = kmer;
   p.w = window;
   p.lanes = p.e < 8 ? 8 : (p.e < 16 ? 4 : 0);  // GetNumVPULanes (mapping_parameters.h:80-88)
+  if (p.split) p.lanes = 0;                    // split alignment cannot use the lane-grouped loop (draft_mapping_generator.cc:31)
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
   HIPCHECK(c, hipStreamCreate(&c->stream));
@@ -257,7 +258,7 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   PTR(aug, uint8_t) PTR(res_neg, int32_t) PTR(res_pos, int32_t) PTR(resc_n, uint32_t) PTR(resc_p, uint32_t)
   PTR(m_tot, uint32_t) PTR(m_off, uint32_t) PTR(mbuf, uint64_t) PTR(mcnt, uint8_t) PTR(mcp, uint32_t) PTR(mcn, uint32_t)
   PTR(force0, uint8_t) PTR(fbuf, uint64_t) PTR(fcnt, uint8_t) PTR(fcp, uint32_t) PTR(fcn, uint32_t) PTR(alive, uint8_t)
-  PTR(dpos, uint64_t) PTR(derr, int8_t) PTR(ndp, uint32_t) PTR(ndn, uint32_t)
+  PTR(dpos, uint64_t) PTR(derr, int16_t) PTR(dsplit, uint32_t) PTR(ndp, uint32_t) PTR(ndn, uint32_t)
   PTR(min_err, int32_t) PTR(second_err, int32_t) PTR(n_best, int32_t) PTR(n_second, int32_t)
   PTR(pe_min, int32_t) PTR(pe_second, int32_t) PTR(pe_nbest, int32_t) PTR(pe_nsecond, int32_t)
   PTR(pe_first, uint32_t) PTR(pe_i1, uint32_t) PTR(pe_i2, uint32_t) PTR(pe_choice, uint32_t)
@@ -332,7 +333,8 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   HIPCHECK(c, hipMemcpyAsync(&n_m, d.m_off + n2, 4, hipMemcpyDeviceToHost, s));
   HIPCHECK(c, hipStreamSynchronize(s));
   if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
-      c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m + 4)) {
+      c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
+      c->dsplit.ensure((size_t)n_m * 4 + 4)) {
     cm_set_error(c, "out of device memory (candidates)");
     return CMGPU_ENOMEM;
   }

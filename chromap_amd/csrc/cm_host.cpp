@@ -230,3 +230,52 @@ extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_seque
   fclose(f);
   return lines;
 }
+
+// pairs output (mapping_writer.cc:381-420).  No duplicate removal unless requested (the hic
+// preset does not set it): the low-memory merge emits every record whose MAPQ passes.
+extern "C" int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
+                                     const cmgpu_params *p, cmgpu_pairs_record *rec, uint64_t n,
+                                     const char *const *read_names, uint32_t read_id_base, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return CMGPU_EIO;
+  std::sort(rec, rec + n, [](const cmgpu_pairs_record &a, const cmgpu_pairs_record &b) {
+    return std::tie(a.rid1, a.rid2, a.pos1, a.pos2, a.mapq, a.read_id) < std::tie(b.rid1, b.rid2, b.pos1, b.pos2, b.mapq, b.read_id);
+  });
+  std::string buf;
+  buf.reserve(1 << 20);
+  buf.append("## pairs format v1.0.0\n#shape: upper triangle\n");
+  for (uint32_t i = 0; i < n_sequences; ++i) {
+    buf.append("#chromsize: ");
+    buf.append(names[i]);
+    buf.push_back(' ');
+    put_u32(buf, lengths[i]);
+    buf.push_back('\n');
+  }
+  buf.append("#columns: readID chrom1 pos1 chrom2 pos2 strand1 strand2 pair_type mapq1 mapq2\n");
+  int64_t lines = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const cmgpu_pairs_record &r = rec[i];
+    if (r.mapq < p->mapq_threshold || r.rid1 >= n_sequences || r.rid2 >= n_sequences) continue;
+    buf.append(read_names[r.read_id - read_id_base]);
+    buf.push_back('\t');
+    buf.append(names[r.rid1]);
+    buf.push_back('\t');
+    put_u32(buf, r.pos1 + 1);
+    buf.push_back('\t');
+    buf.append(names[r.rid2]);
+    buf.push_back('\t');
+    put_u32(buf, r.pos2 + 1);
+    buf.append(r.strand1 ? "\t+" : "\t-");
+    buf.append(r.strand2 ? "\t+" : "\t-");
+    buf.append("\tUU\t");
+    put_u32(buf, r.mapq);
+    buf.push_back('\t');
+    put_u32(buf, r.mapq);
+    buf.push_back('\n');
+    ++lines;
+    if (buf.size() > (1 << 20) - 512) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+  }
+  if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  return lines;
+}

@@ -139,12 +139,12 @@ CM_HD void cm_sort_cand(uint64_t *p, uint8_t *c, uint32_t n) {
 
 // in-place sort of draft mappings (pos[], err[]) by position (SortMappingsByPositions,
 // mapping_metadata.h:70-78).  Order among equal positions does not affect results.
-CM_HD void cm_sort_draft(uint64_t *p, int8_t *e, uint32_t n) {
+CM_HD void cm_sort_draft(uint64_t *p, int16_t *e, uint32_t n) {
   if (n < 2) return;
   if (n <= 24) {
     for (uint32_t i = 1; i < n; ++i) {
       const uint64_t xp = p[i];
-      const int8_t xe = e[i];
+      const int16_t xe = e[i];
       uint32_t j = i;
       while (j > 0 && p[j - 1] > xp) { p[j] = p[j - 1]; e[j] = e[j - 1]; --j; }
       p[j] = xp;
@@ -155,7 +155,7 @@ CM_HD void cm_sort_draft(uint64_t *p, int8_t *e, uint32_t n) {
   for (uint32_t start = n / 2; start-- > 0;) {
     uint32_t root = start;
     const uint64_t xp = p[root];
-    const int8_t xe = e[root];
+    const int16_t xe = e[root];
     for (;;) {
       uint32_t child = 2 * root + 1;
       if (child >= n) break;
@@ -168,7 +168,7 @@ CM_HD void cm_sort_draft(uint64_t *p, int8_t *e, uint32_t n) {
   }
   for (uint32_t end = n - 1; end > 0; --end) {
     const uint64_t xp = p[end];
-    const int8_t xe = e[end];
+    const int16_t xe = e[end];
     p[end] = p[0]; e[end] = e[0];
     uint32_t root = 0;
     for (;;) {
@@ -762,9 +762,9 @@ CM_HD void cm_s4a_rescue_count(const CmDev &d, uint32_t r) {
   uint32_t ncp = d.ncp[r], ncn = d.ncn[r];
   if (live) {
     const uint32_t mm_count = d.mm_cnt[r];
-    bool augment = true;
+    bool augment = !d.p.split;  // split alignment never supplements (chromap.h:1021)
     const uint8_t *pc = cm_c0_pcnt(d, r), *nc = cm_c0_ncnt(d, r);
-    for (uint32_t i = 0; i < ncp; ++i) if (pc[i] >= mm_count / 2) { augment = false; break; }
+    for (uint32_t i = 0; augment && i < ncp; ++i) if (pc[i] >= mm_count / 2) { augment = false; break; }
     if (augment) for (uint32_t i = 0; i < ncn; ++i) if (nc[i] >= mm_count / 2) { augment = false; break; }
     if (augment) {
       d.aug[r] = 1;
@@ -938,6 +938,19 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
   d.force0[pair] = (uint8_t)ret;
   const uint32_t nc1 = d.mcp[r1] + d.mcn[r1], nc2 = d.mcp[r2] + d.mcn[r2];
   if (!(nc1 > 0 && nc2 > 0)) return;
+  if (d.p.split) {  // no paired-end filter (chromap.h:1036-1038): candidates pass through unchanged
+    for (uint32_t r = r1; r <= r2; ++r) {
+      const uint64_t *mp = cm_m_pos(d, r), *mn = cm_m_neg(d, r);
+      const uint8_t *mpc = cm_m_pcnt(d, r), *mnc = cm_m_ncnt(d, r);
+      uint64_t *fp = cm_f_pos(d, r), *fn = cm_f_neg(d, r);
+      uint8_t *fpc = cm_f_pcnt(d, r), *fnc = cm_f_ncnt(d, r);
+      for (uint32_t i = 0; i < d.mcp[r]; ++i) { fp[i] = mp[i]; fpc[i] = mpc[i]; }
+      for (uint32_t i = 0; i < d.mcn[r]; ++i) { fn[i] = mn[i]; fnc[i] = mnc[i]; }
+      d.fcp[r] = d.mcp[r]; d.fcn[r] = d.mcn[r];
+    }
+    d.alive[pair] = 1;
+    return;
+  }
   uint32_t a, b;
   cm_reduce_dir((uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2),
                 cm_m_ncnt(d, r2), d.mcn[r2], cm_f_pos(d, r1), cm_f_pcnt(d, r1), &a, cm_f_neg(d, r2), cm_f_ncnt(d, r2), &b);
@@ -972,7 +985,9 @@ CM_HD void cm_peq_or(uint32_t *P, uint32_t c, uint32_t bit) {
   P[3] |= c == 3 ? bit : 0u; P[4] |= c == 4 ? bit : 0u;
 }
 
-CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, int L, bool neg, int *end_pos) {
+// text = (neg ? revcomp(read[0..Lfull)) : read) + toff, length L
+CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
+                          int *end_pos) {
   uint32_t P[5] = {0, 0, 0, 0, 0};
   for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pattern[i]), 1u << i);
   const uint32_t hi = 1u << (2 * e);
@@ -980,7 +995,7 @@ CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, in
   int err = 0;
   for (int i = 0; i < L; i++) {
     cm_peq_or(P, cm_c2u(pattern[i + 2 * e]), hi);
-    uint32_t X = cm_peq_get(P, cm_text_code(read, L, i, neg)) | VN;
+    uint32_t X = cm_peq_get(P, cm_text_code(read, Lfull, toff + i, neg)) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1006,11 +1021,12 @@ CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, in
 }
 
 // BandedTraceback (alignment.cc:656-718)
-CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int L, bool neg) {
+CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg,
+                              int toff, int L) {
   if (min_num_errors == 0) return e;
   int error_count = 0;
   for (int i = 0; i < L; ++i)
-    if (pattern[i + e] != cm_text_char(read, L, i, neg)) ++error_count;  // raw, case-sensitive (:666)
+    if (pattern[i + e] != cm_text_char(read, Lfull, toff + i, neg)) ++error_count;  // raw, case-sensitive (:666)
   if (error_count == min_num_errors) return e;
   uint32_t P[5] = {0, 0, 0, 0, 0};
   for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pattern[L - 1 + 2 * e - i]), 1u << i);
@@ -1019,7 +1035,7 @@ CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern,
   int err = 0;
   for (int i = 0; i < L; i++) {
     cm_peq_or(P, cm_c2u(pattern[L - 1 - i]), hi);
-    uint32_t X = cm_peq_get(P, cm_text_code(read, L, L - 1 - i, neg)) | VN;
+    uint32_t X = cm_peq_get(P, cm_text_code(read, Lfull, toff + L - 1 - i, neg)) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1041,6 +1057,77 @@ CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern,
   return start;
 }
 
+
+// BandedAlignPatternToTextWithDropOff (alignment.cc:197-283) when from3 == false,
+// BandedAlignPatternToTextWithDropOffFrom3End (alignment.cc:285-376) when from3 == true.
+// text = (neg ? revcomp(read) : read) + toff, length L.
+CM_HD int cm_banded_align_dropoff(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
+                                  bool from3, int *end_pos, int *read_mapping_length) {
+  uint32_t P[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(from3 ? pattern[L + 2 * e - 1 - i] : pattern[i]), 1u << i);
+  const uint32_t hi = 1u << (2 * e);
+  uint32_t VP = 0, VN = 0, prev_VP = 0, prev_VN = 0;
+  int err = 0, i = 0, prev_err = 0;
+  bool fail_beginning = false;
+  for (; i < L; i++) {
+    cm_peq_or(P, cm_c2u(from3 ? pattern[L - 1 - i] : pattern[i + 2 * e]), hi);
+    uint32_t X = cm_peq_get(P, cm_text_code(read, Lfull, toff + (from3 ? L - 1 - i : i), neg)) | VN;
+    const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+    const uint32_t HN = VP & D0;
+    const uint32_t HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    prev_VN = VN; prev_VP = VP;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    prev_err = err;
+    err += 1 - (int)(D0 & 1u);
+    if (err > 2 * e) {
+      if (i < 4 * e && i < L / 2) fail_beginning = true;
+      break;
+    }
+    P[0] >>= 1; P[1] >>= 1; P[2] >>= 1; P[3] >>= 1; P[4] >>= 1;
+  }
+  if (i < L) { err = prev_err; VN = prev_VN; VP = prev_VP; }
+  const int band_start = i - 1;
+  int min_err = err;
+  *read_mapping_length = i;
+  *end_pos = band_start;
+  for (i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *end_pos = band_start + 1 + i;
+    }
+  }
+  if (fail_beginning || (L > 60 && *end_pos + 1 - e - min_err < 30)) *end_pos = -*end_pos;
+  return min_err;
+}
+
+// AdjustGapBeginning (alignment.cc:24-83) without cigar.  read string = (neg ? revcomp(read)
+// : read) + toff; the - branch's loops stop at the string terminators (end of the read
+// string, end of the chromosome).
+CM_HD int cm_adjust_gap_beginning(int strand, const uint8_t *ref, uint32_t ref_len, const uint8_t *read, int Lfull, bool neg,
+                                  int toff, int *gap_beginning, int read_end, int ref_start_position, int ref_end_position) {
+  int i, j;
+  if (strand == 0) {
+    if (*gap_beginning <= 0) return ref_start_position;
+    for (i = *gap_beginning - 1, j = ref_start_position - 1; i >= 0 && j >= 0; --i, --j) {
+      const uint8_t rc = cm_text_char(read, Lfull, toff + i, neg), fc = ref[j];
+      if (rc != fc && (int)rc != (int)fc - 'a' + 'A') break;
+    }
+    *gap_beginning = i + 1;
+    return j + 1;
+  }
+  if (*gap_beginning <= 0) return ref_end_position;
+  for (i = read_end + 1, j = ref_end_position + 1; toff + i < Lfull && (uint32_t)j < ref_len; ++i, ++j) {
+    const uint8_t rc = cm_text_char(read, Lfull, toff + i, neg), fc = ref[j];
+    if (rc != fc && (int)rc != (int)fc - 'a' + 'A') break;
+  }
+  *gap_beginning = *gap_beginning + i - (read_end + 1);
+  return j - 1;
+}
+
 // IsValidCandidate (draft_mapping_generator.cc:59-70)
 CM_HD bool cm_valid_candidate(const CmDev &d, uint32_t rid, uint32_t position, uint32_t L) {
   const uint32_t rl = d.ref_len[rid];
@@ -1057,18 +1144,18 @@ CM_HD void cm_update_best(CmBest &m, int ne) {  // draft_mapping_generator.cc:50
 
 // verify one candidate; on acceptance append the draft mapping. returns accepted
 CM_HD bool cm_verify_one(const CmDev &d, const uint8_t *read, uint32_t L, int strand, uint64_t cpos, CmBest &bst,
-                         uint64_t *dp, int8_t *de, uint32_t *nd) {
+                         uint64_t *dp, int16_t *de, uint32_t *nd) {
   const int e = d.p.e;
   const uint32_t rid = (uint32_t)(cpos >> 32);
   uint32_t position = (uint32_t)cpos;
   if (strand == 1) position = position - L + 1;
   int end_pos = (int)L;
-  const int ne = cm_banded_align(e, d.ref + d.ref_off[rid] + position - e, read, (int)L, strand == 1, &end_pos);
+  const int ne = cm_banded_align(e, d.ref + d.ref_off[rid] + position - e, read, (int)L, strand == 1, 0, (int)L, &end_pos);
   if (ne <= e) {
     cm_update_best(bst, ne);
     dp[*nd] = strand == 0 ? cpos - (uint64_t)e + (uint64_t)(int64_t)end_pos
                           : cpos - L + 1 - (uint64_t)e + (uint64_t)(int64_t)end_pos;
-    de[*nd] = (int8_t)ne;
+    de[*nd] = (int16_t)ne;
     ++*nd;
     return true;
   }
@@ -1078,7 +1165,7 @@ CM_HD bool cm_verify_one(const CmDev &d, const uint8_t *read, uint32_t L, int st
 // one strand of GenerateDraftMappings: scalar loop (draft_mapping_generator.cc:359-557, non-split)
 // or the lane-grouped loop with the candidate_count_threshold break (:159-357)
 CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, int strand, const uint64_t *cp,
-                               const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int8_t *de) {
+                               const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int16_t *de) {
   uint32_t nd = 0;
   const int lanes = d.p.lanes;
   if (lanes == 0 || nc < (uint32_t)lanes) {
@@ -1113,6 +1200,63 @@ CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, 
   return nd;
 }
 
+
+// GenerateDraftMappingsOnOneStrand, split-alignment branch (draft_mapping_generator.cc:359-557).
+// best_mapping_longest_match is re-initialised per candidate in the reference (:404-405), so
+// the second_min adjustment (:511-515) cannot fire and GetLongestMatchLength has no effect.
+CM_HD uint32_t cm_draft_strand_split(const CmDev &d, const uint8_t *read, uint32_t L, int strand, const uint64_t *cp,
+                                     const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int16_t *de, uint32_t *ds) {
+  const int e = d.p.e;
+  uint32_t nd = 0, thr = 0;
+  for (uint32_t ci = 0; ci < nc; ++ci) {
+    if (cc[ci] < thr) break;
+    const uint32_t rid = (uint32_t)(cp[ci] >> 32);
+    uint32_t position = (uint32_t)cp[ci];
+    if (strand == 1) position = position - L + 1;
+    if (!cm_valid_candidate(d, rid, position, L)) continue;
+    int mep = (int)L, gap_beginning = 0, num_errors = 0, actual = 0, rml = 0;
+    const int allow = 20 - e;
+    const uint8_t *pat = d.ref + d.ref_off[rid] + position - e;
+    if (strand == 0) {
+      num_errors = cm_banded_align_dropoff(e, pat, read, (int)L, false, 0, (int)L, false, &mep, &rml);
+      if (mep < 0 && allow > 0) {
+        const int b_err = num_errors, b_mep = -mep, b_rml = rml;
+        num_errors = cm_banded_align_dropoff(e, pat + allow, read, (int)L, false, allow, (int)L - allow, false, &mep, &rml);
+        if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
+        else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
+      }
+    } else {
+      num_errors = cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L, true, &mep, &rml);
+      if (mep < 0 && allow > 0) {
+        const int b_err = num_errors, b_mep = -mep, b_rml = rml;
+        num_errors = cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L - allow, true, &mep, &rml);
+        if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
+        else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
+      }
+    }
+    if (mep + 1 - e - num_errors - gap_beginning >= 30) {
+      actual = num_errors;
+      num_errors = -(mep - e - num_errors - gap_beginning);
+    } else {
+      num_errors = e + 1;
+      actual = e + 1;
+    }
+    if (num_errors <= e) {
+      if (num_errors < bst.min_err) {
+        bst.second_err = bst.min_err; bst.n_second = bst.n_best; bst.min_err = num_errors; bst.n_best = 1;
+        thr = nc > 50 ? cc[ci] : cc[ci] / 2;
+      } else if (num_errors == bst.min_err) bst.n_best++;
+      else if (num_errors == bst.second_err) bst.n_second++;
+      else if (num_errors < bst.second_err) { bst.n_second = 1; bst.second_err = num_errors; }
+      dp[nd] = strand == 0 ? cp[ci] - (uint64_t)e + (uint64_t)(int64_t)mep : cp[ci] - (uint64_t)(int64_t)gap_beginning;
+      de[nd] = (int16_t)num_errors;  // -(matched length) in split mode
+      ds[nd] = (uint32_t)(((actual & 0xff) << 24) | ((gap_beginning & 0xff) << 16) | (rml & 0xffff));
+      ++nd;
+    }
+  }
+  return nd;
+}
+
 // ---------------------------------------------------------------------------------------
 // S5: per read -- DraftMappingGenerator::GenerateDraftMappings (draft_mapping_generator.cc:9-57)
 //      incl. the all-minimizer shortcut (:72-157).  Draft mappings go to dpos/derr at the
@@ -1130,9 +1274,16 @@ CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
     uint8_t *pc = cm_f_pcnt(d, r), *nc = cm_f_ncnt(d, r);
     const uint32_t ncp = d.fcp[r], ncn = d.fcn[r];
     uint64_t *dpp = d.dpos + d.m_off[r], *dpn = d.dpos + d.m_off[r] + d.ncp[r] + d.resc_p[r];
-    int8_t *dep = d.derr + d.m_off[r], *den = d.derr + d.m_off[r] + d.ncp[r] + d.resc_p[r];
+    int16_t *dep = d.derr + d.m_off[r], *den = d.derr + d.m_off[r] + d.ncp[r] + d.resc_p[r];
     bool done = false;
-    if (ncp + ncn == 1) {
+    if (d.p.split) {  // draft_mapping_generator.cc:31-39: no shortcut, scalar drop-off verification
+      uint32_t *dsp = d.dsplit + d.m_off[r], *dsn = d.dsplit + d.m_off[r] + d.ncp[r] + d.resc_p[r];
+      cm_sort_cand(pp, pc, ncp);
+      cm_sort_cand(np, nc, ncn);
+      d.ndp[r] = cm_draft_strand_split(d, read, L, 0, pp, pc, ncp, bst, dpp, dep, dsp);
+      d.ndn[r] = cm_draft_strand_split(d, read, L, 1, np, nc, ncn, bst, dpn, den, dsn);
+      done = true;
+    } else if (ncp + ncn == 1) {
       const int strand = ncp == 1 ? 0 : 1;
       const uint64_t cpos = strand == 0 ? pp[0] : np[0];
       const uint8_t cnt = strand == 0 ? pc[0] : nc[0];
@@ -1166,8 +1317,8 @@ struct CmPe { int min_sum, second_sum, n_best, n_second; uint32_t f_dir, f_i1, f
 // GenerateBestMappingsForPairedEndReadOnOneDirection, non-split (mapping_generator.h:347-484).
 // When want >= 0, stops at the want-th pair (0-based, counted across directions via *seen)
 // whose error sum equals final_min and returns it in (f_dir,f_i1,f_i2).
-CM_HD bool cm_pair_dir(const CmDev &d, int dir, const uint64_t *ap, const int8_t *ae, uint32_t na,
-                       const uint64_t *bp, const int8_t *be, uint32_t nb, uint32_t len1, uint32_t len2, CmPe &pe,
+CM_HD bool cm_pair_dir(const CmDev &d, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na,
+                       const uint64_t *bp, const int16_t *be, uint32_t nb, uint32_t len1, uint32_t len2, CmPe &pe,
                        int64_t want, int final_min, int64_t *seen) {
   const uint64_t I = (uint64_t)(int64_t)d.p.max_insert;
   const uint64_t mo = (uint32_t)d.p.min_read_len;
@@ -1215,7 +1366,7 @@ CM_HD CmSpan cm_ref_start_end(const CmDev &d, uint64_t dpos, int nerr, int stran
   const uint32_t rl = d.ref_len[rid];
   uint32_t vw = ref_pos + 1 > (uint32_t)(L + e) ? ref_pos + 1 - (uint32_t)L - (uint32_t)e : 0;
   if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)L;
-  const int start = cm_banded_traceback(e, nerr, d.ref + d.ref_off[rid] + vw, read, L, strand == 1);
+  const int start = cm_banded_traceback(e, nerr, d.ref + d.ref_off[rid] + vw, read, L, strand == 1, 0, L);
   CmSpan s;
   s.rid = rid;
   s.ref_start = vw + (uint32_t)start;
@@ -1309,7 +1460,7 @@ CM_HD uint8_t cm_mapq_paired(const CmDev &d, uint32_t pair, int err1, int err2, 
 CM_HD const uint64_t *cm_d_pos(const CmDev &d, uint32_t r, int strand) {
   return d.dpos + d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0);
 }
-CM_HD const int8_t *cm_d_err(const CmDev &d, uint32_t r, int strand) {
+CM_HD const int16_t *cm_d_err(const CmDev &d, uint32_t r, int strand) {
   return d.derr + d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0);
 }
 
@@ -1348,6 +1499,181 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   d.rec_ok[pair] = 1;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// split alignment (--preset hic): coordinates, MAPQ, pairs record
+// ---------------------------------------------------------------------------------------
+// GetRefStartEndPositionForReadFromMapping, split + non-SAM branches
+// (mapping_generator.h:657-717, 762-793, 855-916)
+CM_HD CmSpan cm_ref_start_end_split(const CmDev &d, uint64_t dpos, uint32_t split_word, int strand, const uint8_t *read,
+                                    int full_len) {
+  const int e = d.p.e;
+  const uint32_t rid = (uint32_t)(dpos >> 32), ref_pos = (uint32_t)dpos;
+  const uint32_t rl = d.ref_len[rid];
+  const uint8_t *ref = d.ref + d.ref_off[rid];
+  const int split_site = (int)(split_word & 0xffff);
+  int gap_beginning = (int)((split_word >> 16) & 0xff);
+  const int actual = (int)((split_word >> 24) & 0xff);
+  const int read_length = split_site - gap_beginning;
+  uint32_t vw = ref_pos + 1 > (uint32_t)(read_length + e) ? ref_pos + 1 - (uint32_t)read_length - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)read_length;
+  CmSpan s;
+  s.rid = rid;
+  if (strand == 0) {
+    int start = cm_banded_traceback(e, actual, ref + vw, read, full_len, false, gap_beginning, read_length);
+    if (gap_beginning > 0) {
+      const int nrs = cm_adjust_gap_beginning(0, ref, rl, read, full_len, false, 0, &gap_beginning, read_length - 1,
+                                              (int)vw + start, (int)ref_pos);
+      start = nrs - (int)vw;
+    }
+    s.ref_start = vw + (uint32_t)start;
+    s.ref_end = ref_pos;
+    return s;
+  }
+  const int read_start_site = full_len - split_site;
+  const int start = e;
+  int mep = (int)(ref_pos - vw + 1);
+  cm_banded_align(e, ref + vw, read, full_len, true, read_start_site, read_length, &mep);
+  mep += 1;
+  if (gap_beginning > 0) {
+    const int nre = cm_adjust_gap_beginning(1, ref, rl, read, full_len, true, read_start_site, &gap_beginning, read_length - 1,
+                                            (int)vw + start, (int)vw + mep);
+    mep = nre - (int)vw + 1;
+  }
+  s.ref_start = vw + (uint32_t)start;
+  s.ref_end = vw + (uint32_t)mep - 1;
+  return s;
+}
+
+// GetMAPQForSingleEndRead with split_alignment (mapping_generator.h:920-1022)
+CM_HD uint8_t cm_mapq_single_split(const CmDev &d, int num_errors, uint16_t alignment_length, int read_length, int max_diff,
+                                   int second_err, int n_best, int n_second, uint32_t rep_len, uint32_t strand_ncand) {
+  const int e = d.p.e;
+  double alignment_identity = (double)(-num_errors) / alignment_length;
+  if (alignment_identity > 1) alignment_identity = 1;
+  int mapq = 0;
+  int second = second_err;
+  if (n_best > 1) {
+  } else {
+    if (second > num_errors + max_diff) second = num_errors + max_diff;
+    double tmp = d.mq.len_coef[alignment_length];
+    tmp *= alignment_identity * alignment_identity;
+    mapq = (int)(5 * 6.02 * (second - num_errors) * tmp * tmp + 0.499);
+  }
+  if (n_second > 0) mapq -= cm_nsec_penalty(d.mq, n_second);
+  if (mapq > 60) mapq = 60;
+  if (mapq < 0) mapq = 0;
+  if (rep_len > 0) {
+    double frac_rep = rep_len / (double)read_length;
+    if (rep_len >= (uint32_t)read_length) frac_rep = 0.999;
+    if (alignment_identity <= 0.95) mapq = (int)(mapq * (1 - CM_SQRT(frac_rep)) + 0.499);
+    else if (alignment_identity <= 0.97) mapq = (int)(mapq * (1 - frac_rep) + 0.499);
+    else if (alignment_identity >= 0.999) mapq = (int)(mapq * (1 - frac_rep * frac_rep * frac_rep * frac_rep) + 0.499);
+    else mapq = (int)(mapq * (1 - frac_rep * frac_rep) + 0.499);
+  }
+  if ((int)alignment_length < read_length - e && second != num_errors) {
+    if (rep_len >= alignment_length && rep_len < (uint32_t)read_length && (int)alignment_length < read_length / 3) mapq = 0;
+    const int diff = second - num_errors;
+    if (second - num_errors <= e * 3 / 4 && strand_ncand >= 5) mapq = (int)((uint32_t)mapq - (strand_ncand / 5 / (uint32_t)diff));
+    if (mapq < 0) mapq = 0;
+    if (n_second > 0 && second - num_errors <= e * 3 / 4) mapq /= (n_second / diff + 1);
+  }
+  return (uint8_t)mapq;
+}
+
+// orientation o of a split pairing: 0 (+,-), 1 (-,+), 2 (+,+), 3 (-,-)  (mapping_generator.h:176-191)
+CM_HD int cm_split_s1(int o) { return o & 1; }
+CM_HD int cm_split_s2(int o) { return o == 0 || o == 3 ? 1 : 0; }
+
+// the k-th draft mapping (0-based) of read r on `strand` whose error value equals `want_err`
+CM_HD uint32_t cm_kth_best_draft(const CmDev &d, uint32_t r, int strand, int want_err, uint32_t k) {
+  const int16_t *de = cm_d_err(d, r, strand);
+  const uint32_t n = strand ? d.ndn[r] : d.ndp[r];
+  for (uint32_t i = 0; i < n; ++i)
+    if ((int)de[i] == want_err) { if (k == 0) return i; --k; }
+  return 0;
+}
+CM_HD uint32_t cm_count_best_draft(const CmDev &d, uint32_t r, int strand, int want_err) {
+  const int16_t *de = cm_d_err(d, r, strand);
+  const uint32_t n = strand ? d.ndn[r] : d.ndp[r];
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < n; ++i) c += (int)de[i] == want_err;
+  return c;
+}
+
+// ProcessBestMappings... + EmplaceBackPairedEndMappingRecord<PairsMapping> for the pairing
+// (orientation pe.f_dir, draft indices pe.f_i1 / pe.f_i2) (mapping_generator.h:487-653,
+// mapping_generator.cc:169-210 with the default identity rid ranks, chromap.cc:867-877).
+// Record layout = cmgpu_pairs_record (24 bytes).
+CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  const int o = (int)pe.f_dir, s1 = cm_split_s1(o), s2 = cm_split_s2(o);
+  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  const uint64_t dp1 = cm_d_pos(d, r1, s1)[pe.f_i1], dp2 = cm_d_pos(d, r2, s2)[pe.f_i2];
+  const int e1 = cm_d_err(d, r1, s1)[pe.f_i1], e2 = cm_d_err(d, r2, s2)[pe.f_i2];
+  const uint32_t w1 = (d.dsplit + d.m_off[r1] + (s1 ? d.ncp[r1] + d.resc_p[r1] : 0))[pe.f_i1];
+  const uint32_t w2 = (d.dsplit + d.m_off[r2] + (s2 ? d.ncp[r2] + d.resc_p[r2] : 0))[pe.f_i2];
+  const CmSpan a = cm_ref_start_end_split(d, dp1, w1, s1, cm_read_ptr(d, r1), (int)len1);
+  const CmSpan b = cm_ref_start_end_split(d, dp2, w2, s2, cm_read_ptr(d, r2), (int)len2);
+  const uint16_t al1 = (uint16_t)(a.ref_end - a.ref_start + 1), al2 = (uint16_t)(b.ref_end - b.ref_start + 1);
+  uint8_t mapq1 = cm_mapq_single_split(d, e1, al1, (int)len1, 2, d.second_err[r1], d.n_best[r1], d.n_second[r1], d.rep_len[r1],
+                                       s1 == 0 ? d.fcp[r1] : d.fcn[r1]);
+  uint8_t mapq2 = cm_mapq_single_split(d, e2, al2, (int)len2, 2, d.second_err[r2], d.n_best[r2], d.n_second[r2], d.rep_len[r2],
+                                       s2 == 0 ? d.fcp[r2] : d.fcn[r2]);
+  mapq1 = (uint8_t)(mapq1 * 1.2);
+  if (mapq1 > 60) mapq1 = 60;
+  mapq2 = (uint8_t)(mapq2 * 1.2);
+  if (mapq2 > 60) mapq2 = 60;
+  const uint8_t mapq = mapq1 < mapq2 ? mapq1 : mapq2;  // force_mapq is -1: no supplement in split mode
+  const uint8_t is_unique = (pe.n_best == 1 || d.n_best[r1] == 1 || d.n_best[r2] == 1) ? 1 : 0;
+  uint8_t st1 = s1 == 0 ? 1 : 0, st2 = s2 == 0 ? 1 : 0;
+  int pos1 = (int)(s1 == 0 ? a.ref_start : a.ref_end), pos2 = (int)(s2 == 0 ? b.ref_start : b.ref_end);
+  int rid1 = (int)a.rid, rid2 = (int)b.rid;
+  if (!(rid1 < rid2 || (rid1 == rid2 && pos1 < pos2))) {
+    int t = rid1; rid1 = rid2; rid2 = t;
+    t = pos1; pos1 = pos2; pos2 = t;
+    const uint8_t u = st1; st1 = st2; st2 = u;
+  }
+  uint8_t *o8 = d.rec + (uint64_t)pair * 24;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
+  o32[0] = d.first_read_id + pair;
+  o32[1] = (uint32_t)rid1;
+  o32[2] = (uint32_t)rid2;
+  o32[3] = (uint32_t)pos1;
+  o32[4] = (uint32_t)pos2;
+  o8[20] = st1; o8[21] = st2; o8[22] = mapq; o8[23] = is_unique;
+  d.rec_ok[pair] = 1;
+}
+
+// split-mode pairing (mapping_generator.h:389-415): every (best of read1, best of read2)
+// combination in the four orientations; returns the pairing with enumeration index `want`
+CM_HD void cm_split_pairing(const CmDev &d, uint32_t pair, int64_t want, CmPe &pe) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  const int m1 = d.min_err[r1], m2 = d.min_err[r2];
+  uint32_t c1[2], c2[2];
+  c1[0] = cm_count_best_draft(d, r1, 0, m1); c1[1] = cm_count_best_draft(d, r1, 1, m1);
+  c2[0] = cm_count_best_draft(d, r2, 0, m2); c2[1] = cm_count_best_draft(d, r2, 1, m2);
+  pe.min_sum = 2 * d.p.e + 1; pe.second_sum = 2 * d.p.e + 1; pe.n_best = 0; pe.n_second = 0;
+  pe.f_dir = 0; pe.f_i1 = 0; pe.f_i2 = 0;
+  bool located = false;
+  int64_t seen = 0;
+  for (int o = 0; o < 4; ++o) {
+    const int s1 = cm_split_s1(o), s2 = cm_split_s2(o);
+    const uint64_t prod = (uint64_t)c1[s1] * (uint64_t)c2[s2];
+    if (prod == 0) continue;
+    pe.min_sum = m1 + m2;
+    if (!located && want >= seen && want < seen + (int64_t)prod) {
+      const uint64_t k = (uint64_t)(want - seen);
+      pe.f_dir = (uint32_t)o;
+      pe.f_i1 = cm_kth_best_draft(d, r1, s1, m1, (uint32_t)(k / c2[s2]));
+      pe.f_i2 = cm_kth_best_draft(d, r2, s2, m2, (uint32_t)(k % c2[s2]));
+      located = true;
+    }
+    seen += (int64_t)prod;
+  }
+  pe.n_best = seen > 0x7fffffff ? 0x7fffffff : (int)seen;
+}
+
 // ---------------------------------------------------------------------------------------
 // S6a: per pair -- sort draft mappings by position, pairing sweeps in both orientations
 //      (GenerateBestMappingsForPairedEndRead, mapping_generator.h:160-253), record for pairs
@@ -1361,9 +1687,18 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
   if (!d.alive[pair]) return;
   const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
   if (!(nd1 > 0 && nd2 > 0)) return;  // chromap.h:1092-1093
+  if (d.p.split) {  // drafts stay in emission order (chromap.h:1099-1106)
+    CmPe sp;
+    cm_split_pairing(d, pair, 0, sp);
+    d.pe_min[pair] = sp.min_sum; d.pe_second[pair] = sp.second_sum;
+    d.pe_nbest[pair] = sp.n_best; d.pe_nsecond[pair] = sp.n_second;
+    d.pe_first[pair] = sp.f_dir; d.pe_i1[pair] = sp.f_i1; d.pe_i2[pair] = sp.f_i2;
+    if (sp.n_best == 1) cm_emit_pairs_record(d, pair, sp);
+    return;
+  }
   for (uint32_t r = r1; r <= r2; ++r) {
-    cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 0)), const_cast<int8_t *>(cm_d_err(d, r, 0)), d.ndp[r]);
-    cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 1)), const_cast<int8_t *>(cm_d_err(d, r, 1)), d.ndn[r]);
+    cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 0)), const_cast<int16_t *>(cm_d_err(d, r, 0)), d.ndp[r]);
+    cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 1)), const_cast<int16_t *>(cm_d_err(d, r, 1)), d.ndn[r]);
   }
   CmPe pe;
   pe.min_sum = 2 * d.p.e + 1; pe.second_sum = 2 * d.p.e + 1; pe.n_best = 0; pe.n_second = 0;
@@ -1478,6 +1813,12 @@ CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
   pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];
   pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
   const int64_t want = (int64_t)d.pe_choice[pair];
+  if (d.p.split) {
+    CmPe sp;
+    cm_split_pairing(d, pair, want, sp);
+    cm_emit_pairs_record(d, pair, sp);
+    return;
+  }
   if (want > 0) {
     int64_t seen = 0;
     const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];

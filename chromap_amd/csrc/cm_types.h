@@ -34,6 +34,7 @@ struct CmParams {
   int32_t max_best;      // max_num_best_mappings (1)
   int32_t drop_rep;      // drop_repetitive_reads
   int32_t trim;          // trim_adapters
+  int32_t split;         // split_alignment (--preset hic)
   int32_t k, w;          // from the index file
   int32_t lanes;         // GetNumVPULanes(): 8 if e<8, 4 if e<16, else 0
   int32_t ref_batch;     // 500000
@@ -107,7 +108,8 @@ struct CmDev {
   uint8_t *alive;       // [n] pair still in play
   // ---- draft mappings (same offsets as filtered candidates)
   uint64_t *dpos;
-  int8_t *derr;
+  int16_t *derr;
+  uint32_t *dsplit;     // split-alignment only: (actual_errors<<24 | gap_beginning<<16 | read_mapping_length)
   uint32_t *ndp, *ndn;  // [2n]
   int32_t *min_err, *second_err, *n_best, *n_second; // [2n]
   // ---- pair level

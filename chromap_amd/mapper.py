@@ -155,6 +155,21 @@ class ChromapGPU:
             raise ChromapError("cannot write %s" % path)
         return int(k)
 
+    def write_pairs(self, rec, n, read_names, path, read_id_base=0, params=None):
+        """rec: Record array returned by map_pairs with split_alignment set (holds PairsRecord entries)"""
+        p = params if params is not None else self.params
+        names = (C.c_char_p * len(self.names))(*self.names)
+        nseq = C.c_uint32(0)
+        self.L.cmgpu_reference_lengths(self.ctx, None, 0, C.byref(nseq))
+        lens = (C.c_uint32 * nseq.value)()
+        self.L.cmgpu_reference_lengths(self.ctx, lens, nseq.value, C.byref(nseq))
+        rn = (C.c_char_p * len(read_names))(*read_names)
+        k = self.L.cmgpu_write_pairs(names, lens, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, rn,
+                                     read_id_base, path.encode())
+        if k < 0:
+            raise ChromapError("cannot write %s" % path)
+        return int(k)
+
     def close(self):
         if self.ctx:
             self.L.cmgpu_destroy(self.ctx)

@@ -67,7 +67,7 @@ typedef struct cmgpu_params {
   int32_t max_num_best_mappings;  /* must be 1 (the CLI never sets anything else) */
   int32_t drop_repetitive_reads;  /* --drop-repetitive-reads */
   int32_t trim_adapters;          /* --trim-adapters */
-  int32_t split_alignment;        /* --split-alignment: not supported yet (CMGPU_EINVAL) */
+  int32_t split_alignment;        /* --split-alignment (records are then cmgpu_pairs_record) */
   int32_t mapq_threshold;         /* -q; used by cmgpu_write_bed_pe only */
   int32_t remove_pcr_duplicates;  /* used by cmgpu_write_bed_pe only */
   int32_t tn5_shift;              /* used by cmgpu_write_bed_pe only */
@@ -103,6 +103,20 @@ typedef struct cmgpu_record {
   uint16_t positive_alignment_length;
   uint16_t negative_alignment_length;
 } cmgpu_record;
+
+/* With params.split_alignment (--preset hic) the record is the constructor argument list of
+ * PairsMapping (src/pairs_mapping.h:25-38) without read name and barcode, already flipped so
+ * that (rid1,pos1) <= (rid2,pos2) (src/mapping_generator.cc:169-210); pos = ref start for a +
+ * read, ref end for a - read, 0-based.  Same 24-byte slot as cmgpu_record: the `out` buffers of
+ * cmgpu_map_pairs / cmgpu_download_records then hold cmgpu_pairs_record entries. */
+typedef struct cmgpu_pairs_record {
+  uint32_t read_id;
+  uint32_t rid1, rid2;
+  uint32_t pos1, pos2;
+  uint8_t strand1, strand2; /* 1 = positive */
+  uint8_t mapq;
+  uint8_t is_unique;
+} cmgpu_pairs_record;
 
 /* Counters of Chromap::OutputMappingStatistics (src/chromap.cc:808-823) plus the
  * quantities SURVEY.md 8(d) defines the index-probe kernel's algorithmic bytes from. */
@@ -203,6 +217,13 @@ int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity,
  * in place.  names: n_sequences reference names. */
 int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
                            cmgpu_record *records, uint64_t n_records, const char *out_path);
+
+/* pairs output of --preset hic (src/mapping_writer.cc:381-420): sort by PairsMapping::operator<
+ * (src/pairs_mapping.h:40-43), MAPQ filter, header + one line per record.  read_names[read_id -
+ * read_id_base] is the name of read 1 of the pair (names never go to the device). */
+int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
+                          const cmgpu_params *params, cmgpu_pairs_record *records, uint64_t n_records,
+                          const char *const *read_names, uint32_t read_id_base, const char *out_path);
 
 /* Host loaders mirroring Index::Load and SequenceBatch::LoadAllSequences for callers
  * that do not have the reference's own objects (the CLI, Python).  Free with

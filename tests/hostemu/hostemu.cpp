@@ -46,8 +46,8 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
   CmParams &p = d.p;
   p.e = params->error_threshold; p.min_seeds = params->min_num_seeds; p.f0 = params->max_seed_frequency0;
   p.f1 = params->max_seed_frequency1; p.max_insert = params->max_insert_size; p.min_read_len = params->min_read_length;
-  p.max_best = params->max_num_best_mappings; p.drop_rep = params->drop_repetitive_reads; p.trim = params->trim_adapters;
-  p.k = index->kmer_size; p.w = index->window_size; p.lanes = p.e < 8 ? 8 : (p.e < 16 ? 4 : 0);
+  p.max_best = params->max_num_best_mappings; p.drop_rep = params->drop_repetitive_reads; p.trim = params->trim_adapters; p.split = params->split_alignment ? 1 : 0;
+  p.k = index->kmer_size; p.w = index->window_size; p.lanes = p.split ? 0 : (p.e < 8 ? 8 : (p.e < 16 ? 4 : 0));
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
   std::vector<double> coef; std::vector<uint32_t> brk;
@@ -97,7 +97,7 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
   scan(d.m_tot, d.m_off, n2);
   const uint32_t n_m = d.m_off[n2];
   VEC(mbuf, uint64_t, n_m) VEC(mcnt, uint8_t, n_m) VEC(fbuf, uint64_t, n_m) VEC(fcnt, uint8_t, n_m)
-  VEC(dpos, uint64_t, n_m) VEC(derr, int8_t, n_m)
+  VEC(dpos, uint64_t, n_m) VEC(derr, int16_t, n_m) VEC(dsplit, uint32_t, n_m)
   for (uint32_t r = 0; r < n2; ++r) cm_s4b_rescue_merge(d, r);
   for (uint32_t i = 0; i < n; ++i) cm_s4c_reduce(d, i);
   for (uint32_t r = 0; r < n2; ++r) cm_s5_verify(d, r);

@@ -23,7 +23,7 @@ def lib():
                                                                        "cm_mapq_tables.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
-                                   "-Wall", "-Wno-unused-function", "-o", so, srcs[0],
+                                   "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so, srcs[0],
                                    os.path.join(ROOT, "chromap_amd", "csrc", "cm_host.cpp")])
         _L = _capi.declare(C.CDLL(so))
         P = C.POINTER
@@ -71,6 +71,13 @@ class HostEmu:
                                       dbg["ncand"].ctypes.data, dbg["ndraft"].ctypes.data, dbg["nbest"].ctypes.data)
         assert rc == 0, rc
         return rec, int(k.value), st, dbg
+
+    def write_pairs(self, rec, n, read_names, path):
+        names = (C.c_char_p * len(self.names))(*self.names)
+        lens = (C.c_uint32 * len(self.names))(*[self.ref.lengths[i] for i in range(len(self.names))])
+        rn = (C.c_char_p * len(read_names))(*read_names)
+        return self.L.cmgpu_write_pairs(names, lens, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n, rn, 0,
+                                        path.encode())
 
     def write_bed(self, rec, n, path):
         names = (C.c_char_p * len(self.names))(*self.names)

@@ -76,3 +76,27 @@ def test_empty_and_degenerate_batches():
     assert k == ok
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("case", datasets.HIC_CASES)
+def test_hic_pairs_match_reference(case, tmp_path):
+    """--preset hic: split alignment (drop-off bit-vector verification), pairs output"""
+    from chromap_amd import ChromapGPU
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    g = ChromapGPU(idx, fa, preset=preset, **kw)
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    rec, k = g.map_pairs(b1, o1, b2, o2)
+    out = str(tmp_path / "g.pairs")
+    g.write_pairs(rec, k, ol.read_names(r1), out)
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    assert got == datasets.case_golden_bed(case)
+    ref = meta["reference_stderr_counters"]
+    s = g.stats.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    g.close()

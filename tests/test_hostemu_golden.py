@@ -11,7 +11,7 @@ import hostemu_lib as he
 import oracle_lib as ol
 
 
-@pytest.mark.parametrize("case", datasets.BED_CASES)
+@pytest.mark.parametrize("case", datasets.ALL_CASES)
 def test_stage_functions_match_reference(case, tmp_path):
     meta = datasets.case_meta(case)
     fa, r1, r2 = datasets.case_inputs(case)
@@ -23,7 +23,10 @@ def test_stage_functions_match_reference(case, tmp_path):
     b2, o2 = ol.read_fastx(r2)
     rec, k, st, dbg = h.map_pairs(b1, o1, b2, o2)
     out = str(tmp_path / "e.bed")
-    h.write_bed(rec, k, out)
+    if datasets.is_hic(case):
+        h.write_pairs(rec, k, ol.read_names(r1), out)
+    else:
+        h.write_bed(rec, k, out)
     got = open(out, "rb").read()
     assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
     ref = meta["reference_stderr_counters"]
