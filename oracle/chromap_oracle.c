@@ -624,6 +624,13 @@ struct ora_ctx {
   ora_params p;
   mt19937_t rng;
   ora_trace *trace;
+  /* single-cell run (set by ora_map_pairs_bc for the duration of the call) */
+  const ora_whitelist *wl;
+  char *bc;
+  const char *bcq;
+  const uint32_t *bco;
+  uint64_t *bc_key;
+  uint64_t n_in_wl, n_corr;
 };
 
 void ora_default_params(ora_params *p) { /* mapping_parameters.h:19-61 */
@@ -637,6 +644,8 @@ void ora_default_params(ora_params *p) { /* mapping_parameters.h:19-61 */
   p->max_num_best_mappings = 1;
   p->drop_repetitive_reads = 500000;
   p->mapq_threshold = 30;
+  p->bc_error_threshold = 1;
+  p->bc_probability_threshold = 0.9;
 }
 
 void ora_preset(ora_params *p, const char *preset) { /* chromap_driver.cc:247-275 */
@@ -1485,6 +1494,199 @@ static uint8_t mapq_paired(const ora_ctx *c, int err1, int err2, uint16_t al1, u
 }
 
 
+
+/* ------------------------------------------------------------------------- */
+/* K6: barcode whitelist, abundance, correction                               */
+/* ------------------------------------------------------------------------- */
+uint64_t ora_seed_from_sequence(const char *seq, uint32_t seq_len, uint32_t start, uint32_t seed_len) {
+  uint64_t seed = 0;
+  for (uint32_t i = 0; i < seed_len; ++i) {
+    if (start + i < seq_len) {
+      const uint8_t b = c2u(seq[i + start]);
+      seed = b < 4 ? (seed << 2) | b : seed << 2; /* N -> A */
+    } else {
+      seed <<= 2; /* pad A */
+    }
+  }
+  return seed;
+}
+
+struct ora_whitelist {
+  uint64_t *keys;
+  uint32_t *cnt;
+  uint8_t *used;
+  uint32_t mask, size, bc_len;
+  uint64_t num_sample;
+  uint32_t *order; /* insertion order, for export */
+};
+
+static uint32_t wl_slot(const ora_whitelist *w, uint64_t key, int *found) {
+  uint64_t x = key * 0x9E3779B97F4A7C15ull;
+  uint32_t i = (uint32_t)(x >> 32) & w->mask;
+  while (w->used[i]) {
+    if (w->keys[i] == key) { *found = 1; return i; }
+    i = (i + 1) & w->mask;
+  }
+  *found = 0;
+  return i;
+}
+
+ora_whitelist *ora_whitelist_load(const char *path, uint32_t barcode_length) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  size_t cap = 1024, n = 0;
+  uint64_t *ks = (uint64_t *)malloc(cap * 8);
+  char line[300];
+  while (fgets(line, sizeof(line), f)) {
+    size_t l = strlen(line);
+    while (l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+    if (l != barcode_length || l > 32) { free(ks); fclose(f); return NULL; } /* chromap.cc:403-415 */
+    if (n == cap) { cap *= 2; ks = (uint64_t *)realloc(ks, cap * 8); }
+    ks[n++] = ora_seed_from_sequence(line, (uint32_t)l, 0, (uint32_t)l);
+  }
+  fclose(f);
+  ora_whitelist *w = (ora_whitelist *)calloc(1, sizeof(*w));
+  uint32_t nb = 16;
+  while (nb < 2 * n + 16) nb <<= 1;
+  w->mask = nb - 1;
+  w->keys = (uint64_t *)calloc(nb, 8);
+  w->cnt = (uint32_t *)calloc(nb, 4);
+  w->used = (uint8_t *)calloc(nb, 1);
+  w->order = (uint32_t *)calloc(n + 1, 4);
+  w->bc_len = barcode_length;
+  for (size_t i = 0; i < n; ++i) {
+    int found;
+    uint32_t sl = wl_slot(w, ks[i], &found);
+    if (!found) { w->used[sl] = 1; w->keys[sl] = ks[i]; w->order[w->size++] = sl; }
+  }
+  free(ks);
+  return w;
+}
+void ora_whitelist_free(ora_whitelist *w) {
+  if (!w) return;
+  free(w->keys); free(w->cnt); free(w->used); free(w->order); free(w);
+}
+uint32_t ora_whitelist_size(const ora_whitelist *w) { return w->size; }
+void ora_whitelist_export(const ora_whitelist *w, uint64_t *keys, uint32_t *counts) {
+  for (uint32_t i = 0; i < w->size; ++i) { keys[i] = w->keys[w->order[i]]; counts[i] = w->cnt[w->order[i]]; }
+}
+
+long ora_whitelist_abundance(ora_whitelist *w, const char *bc, const uint32_t *bc_off, uint32_t n) {
+  const uint64_t max_sample = 20000000ull; /* chromap.h:211 */
+  for (uint32_t b0 = 0; b0 < n; b0 += 500000u) {
+    const uint32_t bn = n - b0 < 500000u ? n - b0 : 500000u;
+    for (uint32_t i = b0; i < b0 + bn; ++i) {
+      const char *s = bc + bc_off[i];
+      const uint32_t l = bc_off[i + 1] - bc_off[i];
+      int has_n = 0;
+      for (uint32_t j = 0; j < l; ++j) if (s[j] == 'N') { has_n = 1; break; } /* GetSequenceNsAt tests 'N' only */
+      if (has_n) continue;
+      int found;
+      const uint32_t sl = wl_slot(w, ora_seed_from_sequence(s, l, 0, l), &found);
+      if (found) { w->cnt[sl] += 1; ++w->num_sample; }
+    }
+    if (w->num_sample * 20 < bn) return -1; /* chromap.cc:523-533 */
+    if (w->num_sample >= max_sample) break;
+  }
+  return (long)w->num_sample;
+}
+
+typedef struct { uint32_t idx1; char base1; uint32_t idx2; char base2; double score; } bc_cand; /* utils.h:23-35 */
+static int bc_cand_greater(const void *a, const void *b) { /* std::greater: descending */
+  const bc_cand *x = (const bc_cand *)a, *y = (const bc_cand *)b;
+  if (x->score != y->score) return x->score > y->score ? -1 : 1;
+  if (x->idx1 != y->idx1) return x->idx1 > y->idx1 ? -1 : 1;
+  if (x->base1 != y->base1) return x->base1 > y->base1 ? -1 : 1;
+  if (x->idx2 != y->idx2) return x->idx2 > y->idx2 ? -1 : 1;
+  if (x->base2 != y->base2) return x->base2 > y->base2 ? -1 : 1;
+  return 0;
+}
+
+int ora_correct_barcode(const ora_params *p, const ora_whitelist *w, char *bc, const char *qual, uint32_t len,
+                        uint64_t *num_in_whitelist, uint64_t *num_corrected) {
+  const uint64_t key = ora_seed_from_sequence(bc, len, 0, len);
+  int found;
+  wl_slot(w, key, &found);
+  int n_pos[64], nn = 0;
+  for (int i = (int)len - 1; i >= 0; --i) if (bc[i] == 'N' && nn < 64) n_pos[nn++] = (int)len - 1 - i; /* little endian */
+  if ((uint32_t)nn > (uint32_t)p->bc_error_threshold) return 0;
+  if (nn == 0 && found) { ++*num_in_whitelist; return 1; }
+  if (p->bc_error_threshold <= 0) return 0;
+  bc_cand *cs = NULL;
+  size_t nc = 0, cap = 0;
+  const uint64_t mask = 3;
+  uint32_t i_start = 0, i_end = len, ti_limit = 3;
+  if (nn > 0) { i_start = (uint32_t)n_pos[0]; i_end = i_start + 1; ti_limit = 4; }
+#define PUSH(I1, B1, I2, B2, S) do { if (nc == cap) { cap = cap ? cap * 2 : 64; cs = (bc_cand *)realloc(cs, cap * sizeof(bc_cand)); } \
+    cs[nc].idx1 = (I1); cs[nc].base1 = (B1); cs[nc].idx2 = (I2); cs[nc].base2 = (B2); cs[nc].score = (S); ++nc; } while (0)
+  for (uint32_t i = i_start; i < i_end; ++i) {
+    const uint64_t cleared = ~(mask << (2 * i)) & key;
+    uint64_t b1 = (key >> (2 * i)) & mask;
+    for (uint32_t ti = 0; ti < ti_limit; ++ti) {
+      b1 = (b1 + 1) & mask;
+      const uint64_t k1 = cleared | (b1 << (2 * i));
+      int f1;
+      const uint32_t s1 = wl_slot(w, k1, &f1);
+      if (f1) {
+        const double abundance = w->cnt[s1] / (double)w->num_sample;
+        int aq = qual[len - 1 - i] - 33;
+        aq = aq > 40 ? 40 : aq;
+        aq = aq < 3 ? 3 : aq;
+        const double score = pow(10.0, ((-aq) / 10.0)) * abundance;
+        PUSH(len - 1 - i, u2c((uint8_t)b1), 0, 0, score);
+      }
+      if (p->bc_error_threshold == 2) {
+        uint32_t j_start = i + 1, j_end = len, ti2_limit = 3;
+        if (nn == 2) { j_start = (uint32_t)n_pos[1]; j_end = j_start + 1; ti2_limit = 4; }
+        for (uint32_t j = j_start; j < j_end; ++j) {
+          const uint64_t cleared2 = ~(mask << (2 * j)) & k1;
+          uint64_t b2 = (k1 >> (2 * j)) & mask;
+          for (uint32_t ti2 = 0; ti2 < ti2_limit; ++ti2) {
+            b2 = (b2 + 1) & mask;
+            const uint64_t k2 = cleared2 | (b2 << (2 * j));
+            int f2;
+            const uint32_t s2 = wl_slot(w, k2, &f2);
+            if (f2) {
+              const double abundance = w->cnt[s2] / (double)w->num_sample;
+              int aq = qual[len - 1 - j] - 33;
+              aq = aq > 40 ? 40 : aq;
+              aq = aq < 3 ? 3 : aq;
+              int aq1 = qual[len - 1 - i] - 33;
+              aq1 = aq1 > 40 ? 40 : aq1;
+              aq1 = aq1 < 3 ? 3 : aq1;
+              aq += aq1;
+              const double score = pow(10.0, ((-aq) / 10.0)) * abundance;
+              PUSH(len - 1 - i, u2c((uint8_t)b1), len - 1 - j, u2c((uint8_t)b2), score);
+            }
+          }
+        }
+      }
+    }
+  }
+#undef PUSH
+  int ret = 0;
+  if (nc == 0) {
+    ret = 0;
+  } else {
+    size_t best = 0;
+    int apply = 1;
+    if (nc > 1) {
+      qsort(cs, nc, sizeof(bc_cand), bc_cand_greater);
+      double sum = 0;
+      for (size_t ci = 0; ci < nc; ++ci) sum += cs[ci].score;
+      apply = cs[0].score / sum > p->bc_probability_threshold;
+    }
+    if (apply) {
+      bc[cs[best].idx1] = cs[best].base1;
+      if (cs[best].base2 != 0) bc[cs[best].idx2] = cs[best].base2;
+      ++*num_corrected;
+      ret = 1;
+    }
+  }
+  free(cs);
+  return ret;
+}
+
 /* ------------------------------------------------------------------------- */
 /* K0: adapter trimming (chromap.cc:176-289, sequence_batch.h:136-151)         */
 /* ------------------------------------------------------------------------- */
@@ -1759,6 +1961,19 @@ static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t 
                          uint32_t len2, ora_record *out, ora_stats *st, ora_trace *tr) {
   const ora_params *p = &c->p;
   if (tr) memset(tr, 0, sizeof(*tr));
+  if (c->wl) { /* chromap.h:896-909: barcode correction comes first */
+    uint64_t a = 0, b = 0;
+    char *bs = c->bc + c->bco[pair_index];
+    const uint32_t bl = c->bco[pair_index + 1] - c->bco[pair_index];
+    const int ok = ora_correct_barcode(p, c->wl, bs, c->bcq + c->bco[pair_index], bl, &a, &b);
+    ora_ctx *mc = (ora_ctx *)c;
+#pragma omp atomic
+    mc->n_in_wl += a;
+#pragma omp atomic
+    mc->n_corr += b;
+    c->bc_key[pair_index] = ora_seed_from_sequence(bs, bl, 0, bl);
+    if (!ok && !p->output_mappings_not_in_whitelist) return 0;
+  }
   if (len1 < (uint32_t)p->min_read_length || len2 < (uint32_t)p->min_read_length) return 0; /* :911-916 */
   if (len1 + 1 > wk->cap1) { wk->cap1 = len1 + 64; wk->neg1 = (char *)realloc(wk->neg1, wk->cap1); wk->fw1 = (char *)realloc(wk->fw1, wk->cap1); }
   if (len2 + 1 > wk->cap2) { wk->cap2 = len2 + 64; wk->neg2 = (char *)realloc(wk->neg2, wk->cap2); wk->fw2 = (char *)realloc(wk->fw2, wk->cap2); }
@@ -2080,4 +2295,107 @@ long ora_write_pairs(const ora_ref *ref, const ora_params *p, ora_pairs_record *
   }
   fclose(f);
   return lines;
+}
+
+long ora_map_pairs_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1,
+                      const uint32_t *r1_off, const char *r2, const uint32_t *r2_off, char *bc,
+                      const char *bc_qual, const uint32_t *bc_off, const ora_whitelist *w,
+                      ora_record_bc *out, ora_stats *stats, uint64_t *num_in_whitelist, uint64_t *num_corrected) {
+  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  c->wl = w; c->bc = bc; c->bcq = bc_qual; c->bco = bc_off;
+  c->bc_key = (uint64_t *)calloc((size_t)n + 1, 8);
+  c->n_in_wl = c->n_corr = 0;
+  const long k = ora_map_pairs_mt(c, threads, n, first_read_id, r1, r1_off, r2, r2_off, tmp, stats);
+  for (long i = 0; i < k; ++i) {
+    out[i].r = tmp[i];
+    out[i].barcode = c->bc_key[tmp[i].read_id - first_read_id];
+  }
+  if (num_in_whitelist) *num_in_whitelist += c->n_in_wl;
+  if (num_corrected) *num_corrected += c->n_corr;
+  free(c->bc_key); free(tmp);
+  c->wl = NULL; c->bc = NULL; c->bcq = NULL; c->bco = NULL; c->bc_key = NULL;
+  return k;
+}
+
+/* PairedEndMappingWithBarcode::operator< (bed_mapping.h:145-153) within rid */
+static int cmp_rec_bc(const void *a, const void *b) {
+  const ora_record_bc *x = (const ora_record_bc *)a, *y = (const ora_record_bc *)b;
+#define CMPF(f) if (x->f != y->f) return x->f < y->f ? -1 : 1
+  CMPF(r.rid); CMPF(r.fragment_start); CMPF(r.fragment_length); CMPF(barcode); CMPF(r.mapq); CMPF(r.direction);
+  CMPF(r.is_unique); CMPF(r.read_id); CMPF(r.pos_aln_len); CMPF(r.neg_aln_len);
+#undef CMPF
+  return 0;
+}
+
+/* Low-memory merge with cell-level duplicate removal (remove_pcr_duplicates_at_bulk_level ==
+ * false, as --preset atac sets it): operator== is (barcode, start, length)
+ * (bed_mapping.h:154-159); writer mapping_writer.cc:119-131 with Seed2Sequence
+ * (barcode_translator.h:107-116). */
+long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
+                         const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  qsort(rec, (size_t)n, sizeof(ora_record_bc), cmp_rec_bc);
+  long lines = 0, i = 0;
+  char bcs[40];
+  while (i < n) {
+    ora_record_bc last = rec[i];
+    uint32_t dups = 1;
+    long j = i + 1;
+    if (p->remove_pcr_duplicates) {
+      while (j < n && rec[j].r.rid == last.r.rid && rec[j].barcode == last.barcode &&
+             rec[j].r.fragment_start == last.r.fragment_start && rec[j].r.fragment_length == last.r.fragment_length) {
+        ++dups;
+        if (rec[j].r.mapq > last.r.mapq) last = rec[j];
+        ++j;
+      }
+    }
+    if (last.r.mapq >= p->mapq_threshold) {
+      ora_record r = last.r;
+      r.num_dups = (uint8_t)(dups > 255 ? 255 : dups);
+      if (p->tn5_shift) { r.fragment_start += 4; r.pos_aln_len -= 4; r.fragment_length -= 9; r.neg_aln_len -= 5; }
+      for (uint32_t b = 0; b < barcode_length; ++b) bcs[b] = u2c((uint8_t)((last.barcode >> ((barcode_length - 1 - b) * 2)) & 3));
+      bcs[barcode_length] = 0;
+      fprintf(f, "%s\t%u\t%u\t%s\t%u\n", ref->name[r.rid], r.fragment_start, r.fragment_start + r.fragment_length, bcs,
+              (unsigned)r.num_dups);
+      ++lines;
+    }
+    i = j;
+  }
+  fclose(f);
+  return lines;
+}
+
+typedef struct { vchar b, q; uint32_t *off; size_t n, cap; } fqq_acc;
+long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t **off) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return -1;
+  fqq_acc a;
+  memset(&a, 0, sizeof(a));
+  char *line = NULL;
+  size_t lcap = 0;
+  ssize_t ll;
+  int state = 0;
+  size_t cur_len = 0;
+  a.cap = 1024;
+  a.off = (uint32_t *)malloc(a.cap * 4);
+  a.off[0] = 0;
+  while ((ll = getline(&line, &lcap, f)) >= 0) {
+    while (ll > 0 && (line[ll - 1] == '\n' || line[ll - 1] == '\r')) line[--ll] = 0;
+    if (state == 0) { if (line[0] == '@') state = 1; }
+    else if (state == 1) { vch_append(&a.b, line, (size_t)ll); cur_len = (size_t)ll; state = 2; }
+    else if (state == 2) { state = 3; }
+    else {
+      vch_append(&a.q, line, (size_t)ll);
+      if ((size_t)ll != cur_len) { free(line); fclose(f); return -2; }
+      if (a.n + 2 > a.cap) { a.cap *= 2; a.off = (uint32_t *)realloc(a.off, a.cap * 4); }
+      a.off[++a.n] = (uint32_t)a.b.n;
+      state = 0;
+    }
+  }
+  free(line);
+  fclose(f);
+  if (!a.b.a) { a.b.a = (char *)calloc(1, 1); a.q.a = (char *)calloc(1, 1); }
+  *bases = a.b.a; *quals = a.q.a; *off = a.off;
+  return (long)a.n;
 }

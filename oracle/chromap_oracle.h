@@ -57,6 +57,9 @@ typedef struct ora_params {
   int remove_pcr_duplicates;
   int tn5_shift;
   int low_mem;
+  int bc_error_threshold;               /* --bc-error-threshold, 1 */
+  int output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
+  double bc_probability_threshold;      /* --bc-probability-threshold, 0.9 */
 } ora_params;
 
 /* constructor arguments of PairedEndMappingWithoutBarcode (bed_mapping.h:191-206)
@@ -94,6 +97,29 @@ typedef struct ora_stats {
   uint64_t num_rescue;        /* mate-rescue strand searches */
   uint64_t num_trimmed;
 } ora_stats;
+
+/* PairedEndMappingWithBarcode constructor arguments (bed_mapping.h:128-144) + rid */
+typedef struct ora_record_bc {
+  ora_record r;
+  uint64_t barcode;
+} ora_record_bc;
+
+/* barcode whitelist with abundance (chromap.cc:388-548): khash k64_seq in the reference, any
+ * map here */
+typedef struct ora_whitelist ora_whitelist;
+ora_whitelist *ora_whitelist_load(const char *path, uint32_t barcode_length);
+void ora_whitelist_free(ora_whitelist *w);
+/* ComputeBarcodeAbundance (chromap.cc:492-548) over the n barcodes of the input (read batches
+ * of 500000, stops once 20000000 whitelisted barcodes were seen). returns -1 when fewer than
+ * 5% of the first batch are whitelisted (the reference exits), else num_sample_barcodes_. */
+long ora_whitelist_abundance(ora_whitelist *w, const char *bc, const uint32_t *bc_off, uint32_t n);
+uint32_t ora_whitelist_size(const ora_whitelist *w);
+/* export for the device table: keys[i], counts[i], i < size */
+void ora_whitelist_export(const ora_whitelist *w, uint64_t *keys, uint32_t *counts);
+uint64_t ora_seed_from_sequence(const char *seq, uint32_t seq_len, uint32_t start, uint32_t seed_len); /* utils.h:111-129 */
+/* Chromap::CorrectBarcodeAt (chromap.cc:572-799); bc is modified in place. returns whitelisted */
+int ora_correct_barcode(const ora_params *p, const ora_whitelist *w, char *bc, const char *qual, uint32_t len,
+                        uint64_t *num_in_whitelist, uint64_t *num_corrected);
 
 typedef struct ora_ctx ora_ctx;
 
@@ -143,6 +169,18 @@ long ora_map_pairs(ora_ctx *c, uint32_t n, uint32_t first_read_id, const char *r
 long ora_map_pairs_mt(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id,
                       const char *r1, const uint32_t *r1_off, const char *r2,
                       const uint32_t *r2_off, ora_record *out, ora_stats *stats);
+
+/* Single-cell variant: barcode correction in front of every pair (chromap.h:897-909), records
+ * carry the (corrected) barcode key.  bc is corrected in place. */
+long ora_map_pairs_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1,
+                      const uint32_t *r1_off, const char *r2, const uint32_t *r2_off, char *bc,
+                      const char *bc_qual, const uint32_t *bc_off, const ora_whitelist *w,
+                      ora_record_bc *out, ora_stats *stats, uint64_t *num_in_whitelist, uint64_t *num_corrected);
+/* BED for PairedEndMappingWithBarcode (mapping_writer.cc:119-131), cell-level dedup */
+long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
+                         const char *out_path);
+/* FASTQ with qualities: returns n, allocates bases, quals (same offsets) and off */
+long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t **off);
 
 /* per-pair trace for stage-level comparisons with the HIP path */
 typedef struct ora_trace {

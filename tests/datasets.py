@@ -42,10 +42,24 @@ def case_inputs(name):
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_synth.py"), "--out",
                                    os.path.join(d, "d")] + meta["generator_args"])
     got = {"fa": md5(paths[0]), "r1": md5(paths[1]), "r2": md5(paths[2])}
+    if "bc" in meta["input_md5"]:
+        got["bc"] = md5(os.path.join(d, "d_bc.fq"))
+        got["whitelist"] = md5(os.path.join(d, "d.whitelist.txt"))
     if got != meta["input_md5"]:
         raise RuntimeError("regenerated inputs of golden case %s differ from the ones the golden output was "
                            "made from (numpy RNG stream changed?)" % name)
     return paths
+
+
+def case_barcode_inputs(name):
+    """(barcode fastq, whitelist) of a single-cell golden case"""
+    fa, _, _ = case_inputs(name)
+    d = os.path.dirname(fa)
+    return os.path.join(d, "d_bc.fq"), os.path.join(d, "d.whitelist.txt")
+
+
+def has_barcodes(name):
+    return "bc" in case_meta(name)["input_md5"]
 
 
 def case_golden_bed(name):
@@ -67,6 +81,9 @@ def flags_to_params(flags):
         if flags[i] == "--preset":
             preset = flags[i + 1]
             i += 2
+        elif flags[i] == "--bc-error-threshold":
+            kw["bc_error_threshold"] = int(flags[i + 1])
+            i += 2
         elif flags[i] == "-q":  # noqa: E501
             kw["mapq_threshold"] = int(flags[i + 1])
             i += 2
@@ -76,7 +93,8 @@ def flags_to_params(flags):
 
 
 ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
-BED_CASES = [c for c in ALL_CASES if not is_hic(c)]
+BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c)]
+BC_CASES = [c for c in ALL_CASES if has_barcodes(c)]
 HIC_CASES = [c for c in ALL_CASES if is_hic(c)]
 
 

@@ -40,6 +40,10 @@ CASES = {
     "h2_hic_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
                    "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
                   ["--preset", "hic", "-q", "0"]),
+    "b1_atac_bc": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
+                    "--barcodes", "500", "--seed", "31"], ["--preset", "atac"]),
+    "b2_atac_bc2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "50", "--frag-min", "35",
+                        "--barcodes", "300", "--seed", "32"], ["--preset", "atac", "-q", "0", "--bc-error-threshold", "2"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
@@ -68,18 +72,24 @@ def main():
             idx = os.path.join(tmp, "d.idx")
             subprocess.check_call([REF, "-i", "-r", fa, "-o", idx], stderr=subprocess.DEVNULL)
             out = os.path.join(tmp, "out.bed")
-            log = subprocess.run([REF] + flags + ["-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out, "-t", "1"],
+            extra = []
+            if gen is not None and "--barcodes" in gen:
+                extra = ["-b", os.path.join(tmp, "d_bc.fq"), "--barcode-whitelist", os.path.join(tmp, "d.whitelist.txt")]
+            log = subprocess.run([REF] + flags + extra + ["-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out, "-t", "1"],
                                  stderr=subprocess.PIPE, check=True).stderr.decode()
             stats = {}
             for key, pat in (("num_reads", r"Number of reads: (\d+)"), ("num_mapped_reads", r"Number of mapped reads: (\d+)"),
                              ("num_uniquely_mapped_reads", r"Number of uniquely mapped reads: (\d+)"),
                              ("num_candidates", r"Number of candidates: (\d+)"),
                              ("num_mappings", r"Number of mappings: (\d+)"),
-                             ("num_output", r"Number of output mappings \(passed filters\): (\d+)")):
+                             ("num_output", r"Number of output mappings \(passed filters\): (\d+)"),
+                             ("num_barcode_in_whitelist", r"Number of barcodes in whitelist: (\d+)"),
+                             ("num_corrected_barcode", r"Number of corrected barcodes: (\d+)")):
                 m = re.search(pat, log)
                 stats[key] = int(m.group(1)) if m else None
             meta = {"generator_args": gen, "chromap_flags": flags, "reference_version": "0.3.3-r521",
-                    "input_md5": {"fa": md5(fa), "r1": md5(r1), "r2": md5(r2)},
+                    "input_md5": dict({"fa": md5(fa), "r1": md5(r1), "r2": md5(r2)},
+                                      **({"bc": md5(extra[1]), "whitelist": md5(extra[3])} if extra else {})),
                     "index_md5_reference_build": md5(idx), "bed_md5": md5(out), "reference_stderr_counters": stats}
             ext = ".pairs.gz" if "hic" in flags else ".bed.gz"
             with open(out, "rb") as f, gzip.GzipFile(os.path.join(HERE, name + ext), "wb", mtime=0) as g:

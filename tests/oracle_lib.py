@@ -23,7 +23,8 @@ class OraParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "error_threshold", "min_num_seeds", "max_seed_freq0", "max_seed_freq1", "max_insert_size",
         "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
-        "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_mem")]
+        "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_mem", "bc_error_threshold",
+        "output_mappings_not_in_whitelist")] + [("bc_probability_threshold", C.c_double)]
 
 
 class OraRecord(C.Structure):
@@ -216,3 +217,91 @@ def write_pairs(oracle, rec, k, names, path):
                                   C.POINTER(C.c_char_p), C.c_char_p]
     arr = (C.c_char_p * len(names))(*names)
     return L.ora_write_pairs(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, arr, path.encode())
+
+
+class OraRecordBc(C.Structure):
+    _fields_ = [("r", OraRecord), ("barcode", C.c_uint64)]
+
+
+assert C.sizeof(OraRecordBc) == 32
+
+
+def read_fastq_qual(path):
+    import numpy as np
+    L = lib()
+    L.ora_read_fastq_qual.restype = C.c_long
+    L.ora_read_fastq_qual.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    b = C.c_void_p(); q = C.c_void_p(); o = C.c_void_p()
+    n = L.ora_read_fastq_qual(path.encode(), C.byref(b), C.byref(q), C.byref(o))
+    if n < 0:
+        raise IOError(path)
+    off = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint32)), shape=(n + 1,)).copy()
+    tot = int(off[-1])
+    bases = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(tot, 1),)).copy()[:tot]
+    quals = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_uint8)), shape=(max(tot, 1),)).copy()[:tot]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for x in (b, q, o):
+        libc.free(x)
+    return bases, quals, off
+
+
+class Whitelist:
+    def __init__(self, path, barcode_length):
+        L = lib()
+        self.L = L
+        L.ora_whitelist_load.restype = C.c_void_p
+        L.ora_whitelist_load.argtypes = [C.c_char_p, C.c_uint32]
+        L.ora_whitelist_free.argtypes = [C.c_void_p]
+        L.ora_whitelist_abundance.restype = C.c_long
+        L.ora_whitelist_abundance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ora_whitelist_size.restype = C.c_uint32
+        L.ora_whitelist_size.argtypes = [C.c_void_p]
+        L.ora_whitelist_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.h = L.ora_whitelist_load(path.encode(), barcode_length)
+        if not self.h:
+            raise IOError(path)
+        self.barcode_length = barcode_length
+
+    def abundance(self, bc, bc_off):
+        import numpy as np
+        bc = np.ascontiguousarray(bc)
+        bc_off = np.ascontiguousarray(bc_off, dtype=np.uint32)
+        return self.L.ora_whitelist_abundance(self.h, bc.ctypes.data, bc_off.ctypes.data, len(bc_off) - 1)
+
+    def export(self):
+        import numpy as np
+        n = self.L.ora_whitelist_size(self.h)
+        k = np.zeros(n, np.uint64)
+        c = np.zeros(n, np.uint32)
+        self.L.ora_whitelist_export(self.h, k.ctypes.data, c.ctypes.data)
+        return k, c
+
+
+def map_pairs_bc(oracle, b1, o1, b2, o2, bc, bcq, bco, wl, threads=1):
+    """returns (records OraRecordBc[], k, stats, n_in_whitelist, n_corrected); bc is corrected in place"""
+    import numpy as np
+    L = oracle.L
+    L.ora_map_pairs_bc.restype = C.c_long
+    L.ora_map_pairs_bc.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 7 + \
+                                  [C.c_void_p, C.c_void_p, C.POINTER(OraStats), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    n = len(o1) - 1
+    rec = (OraRecordBc * max(1, n))()
+    st = OraStats()
+    a = C.c_uint64(0)
+    b = C.c_uint64(0)
+    arrs = [np.ascontiguousarray(x) for x in (b1, o1, b2, o2, bc, bcq, bco)]
+    k = L.ora_map_pairs_bc(oracle.ctx, threads, n, 0, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                           arrs[3].ctypes.data, arrs[4].ctypes.data, arrs[5].ctypes.data, arrs[6].ctypes.data, wl.h,
+                           C.cast(rec, C.c_void_p), C.byref(st), C.byref(a), C.byref(b))
+    if arrs[4] is not bc:
+        bc[:] = arrs[4]
+    return rec, k, st, int(a.value), int(b.value)
+
+
+def write_bed_bc(oracle, rec, k, barcode_length, path):
+    L = oracle.L
+    L.ora_write_bed_pe_bc.restype = C.c_long
+    L.ora_write_bed_pe_bc.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_uint32, C.c_char_p]
+    return L.ora_write_bed_pe_bc(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, barcode_length,
+                                 path.encode())

@@ -23,6 +23,10 @@ def test_oracle_bed_matches_reference(case, tmp_path):
     o = ol.Oracle(None, fa, p)  # index built by the oracle's own indexer
     b1, o1 = ol.read_fastx(r1)
     b2, o2 = ol.read_fastx(r2)
+    if datasets.has_barcodes(case):
+        _check_barcode_case(case, meta, o, b1, o1, b2, o2, tmp_path)
+        o.close()
+        return
     rec, k, st, _ = o.map_pairs(b1, o1, b2, o2)
     out = str(tmp_path / "o.bed")
     hic = datasets.is_hic(case)
@@ -49,6 +53,23 @@ def test_oracle_bed_matches_reference(case, tmp_path):
         o.write_bed(rec2, k2, out2)
     assert open(out2, "rb").read() == got
     o.close()
+
+
+def _check_barcode_case(case, meta, o, b1, o1, b2, o2, tmp_path):
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+    assert wl.abundance(bc, bco) > 0
+    rec, k, st, n_in, n_corr = ol.map_pairs_bc(o, b1, o1, b2, o2, bc, bcq, bco, wl, threads=2)
+    out = str(tmp_path / "o.bed")
+    ol.write_bed_bc(o, rec, k, wl.barcode_length, out)
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    assert n_in == ref["num_barcode_in_whitelist"] and n_corr == ref["num_corrected_barcode"]
 
 
 def test_oracle_index_matches_reference_on_defined_bytes():
