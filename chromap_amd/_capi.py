@@ -25,11 +25,12 @@ class RefView(C.Structure):
 PARAM_FIELDS = ("error_threshold", "min_num_seeds", "max_seed_frequency0", "max_seed_frequency1", "max_insert_size",
                 "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
                 "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_memory_mode",
-                "read_batch_size", "taskloop_grain_size")
+                "read_batch_size", "taskloop_grain_size", "bc_error_threshold", "output_mappings_not_in_whitelist",
+                "bc_probability_threshold")
 
 
 class Params(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in PARAM_FIELDS]
+    _fields_ = [(n, C.c_int32) for n in PARAM_FIELDS[:-1]] + [("bc_probability_threshold", C.c_double)]
 
 
 class Batch(C.Structure):
@@ -51,24 +52,35 @@ class PairsRecord(C.Structure):
 
 
 STAT_FIELDS = ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "num_minimizers",
-               "probe_steps", "occurrences_read", "num_pairs_rescued", "num_multi_mappers")
+               "probe_steps", "occurrences_read", "num_pairs_rescued", "num_multi_mappers", "num_barcode_in_whitelist",
+               "num_corrected_barcode")
+
+
+class RecordBc(C.Structure):
+    _fields_ = [("r", Record), ("barcode", C.c_uint64)]
+
+
+class BarcodeBatch(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("qualities", C.c_void_p), ("offsets", C.c_void_p)]
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS] + [("reserved", C.c_uint64 * 7)]
+    _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS] + [("reserved", C.c_uint64 * 5)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in STAT_FIELDS}
 
 
 assert C.sizeof(Record) == 24 == C.sizeof(PairsRecord)
+assert C.sizeof(RecordBc) == 32
 
 # every symbol include/chromap_amd.h declares
 SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_destroy",
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device",
-           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs",
+           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
+           "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
 _LIB = None
@@ -109,6 +121,13 @@ def declare(L):
     sig("cmgpu_write_bed_pe", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_write_pairs", C.c_int64, [P(C.c_char_p), P(C.c_uint32), C.c_uint32, P(Params), C.c_void_p, C.c_uint64,
                                          P(C.c_char_p), C.c_uint32, C.c_char_p])
+    sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
+    sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])
+    sig("cmgpu_compute_barcode_abundance", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint64)])
+    sig("cmgpu_map_pairs_barcoded", C.c_int, [C.c_void_p, P(Batch), P(BarcodeBatch), C.c_void_p, C.c_uint64, P(C.c_uint64),
+                                               P(Stats)])
+    sig("cmgpu_write_bed_pe_bc", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_uint32,
+                                             C.c_char_p])
     sig("cmgpu_load_index_file", C.c_int, [C.c_char_p, P(IndexView)])
     sig("cmgpu_free_host_index", None, [P(IndexView)])
     sig("cmgpu_load_reference_fasta", C.c_int, [C.c_char_p, P(RefView)])

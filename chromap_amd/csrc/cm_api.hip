@@ -99,6 +99,10 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   p.drop_rep = params->drop_repetitive_reads;
   p.trim = params->trim_adapters;
   p.split = params->split_alignment ? 1 : 0;
+  p.bc_err = params->bc_error_threshold;
+  p.bc_keep = params->output_mappings_not_in_whitelist ? 1 : 0;
+  p.bc_prob = params->bc_probability_threshold;
+  if (p.bc_err < 0 || p.bc_err > 1) { cm_set_error(c, "bc_error_threshold must be 0 or 1 on the device"); return CMGPU_EINVAL; }
   p.k = kmer;
   p.w = window;
   p.lanes = p.e < 8 ? 8 : (p.e < 16 ? 4 : 0);  // GetNumVPULanes (mapping_parameters.h:80-88)
@@ -225,6 +229,7 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   const uint32_t n = in->n_pairs;
   if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
   c->n_pairs = n;
+  c->has_barcodes = false;
   c->first_read_id = in->first_read_id;
   c->bases0 = n ? in->read1_offsets[n] : 0;
   c->bases1 = n ? in->read2_offsets[n] : 0;
@@ -265,6 +270,12 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   PTR(rec, uint8_t) PTR(rec_ok, uint8_t)
 #undef PTR
   d.stats = (unsigned long long *)c->stats.p;
+  if (c->has_barcodes) {
+    d.bcb = (const uint8_t *)c->bcb.p; d.bcq = (const uint8_t *)c->bcq.p; d.bco = (const uint32_t *)c->bco.p;
+    d.wl = (const uint64_t *)c->wl.p; d.wl_mask = c->wl_mask; d.wl_num_sample = (double)c->wl_num_sample;
+    d.pow10_tab = (const double *)c->pow10_tab.p;
+    d.bc_key = (uint64_t *)c->bc_key.p; d.bc_ok = (uint8_t *)c->bc_ok.p;
+  }
 }
 
 static inline void mark(cmgpu_ctx *c, const char *name) {
@@ -292,6 +303,12 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   HIPCHECK(c, hipMemsetAsync(c->stats.p, 0, CM_ST_N * 8, s));
   cm_fill_dev(c, d);
   mark(c, "begin");
+  if (c->has_barcodes) {  // K6: barcode correction (chromap.h:896-909)
+    if (c->bc_key.ensure((size_t)n * 8) || c->bc_ok.ensure(n)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
+    cm_fill_dev(c, d);
+    cm_launch_k_s0b_barcode(d, n, s);
+    mark(c, "s0b_barcode");
+  }
   // S0: length filter + adapter trimming
   cm_launch_k_s0_prep(d, n, s);
   mark(c, "s0_trim");
@@ -373,6 +390,8 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     stats->occurrences_read += hst[CM_ST_OCC];
     stats->num_pairs_rescued += hst[CM_ST_RESCUED];
     stats->num_multi_mappers += hst[CM_ST_MULTI];
+    stats->num_barcode_in_whitelist += hst[CM_ST_BC_INWL];
+    stats->num_corrected_barcode += hst[CM_ST_BC_CORR];
   }
   if (n_out) *n_out = c->n_records;
   return CMGPU_OK;
@@ -589,5 +608,105 @@ extern "C" int cmgpu_gather_bench(cmgpu_ctx *c, uint64_t n, int repeat, double *
   float ms = 0;
   HIPCHECK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
   *avg_ms = ms / repeat;
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// single-cell barcodes (K6)
+// ---------------------------------------------------------------------------------------
+extern "C" int cmgpu_set_whitelist(cmgpu_ctx *c, const uint64_t *keys, uint32_t n_keys, uint32_t barcode_length) {
+  if (!c || !keys || n_keys == 0 || barcode_length == 0 || barcode_length > 32) { cm_set_error(c, "bad whitelist"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  uint32_t nb = 16;
+  while (nb < 2ull * n_keys + 16) nb <<= 1;
+  std::vector<uint64_t> tab((size_t)nb * 2);
+  for (uint32_t i = 0; i < nb; ++i) { tab[2 * (size_t)i] = ~0ull; tab[2 * (size_t)i + 1] = 0; }
+  uint32_t size = 0;
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    const uint64_t x = keys[i] * 0x9E3779B97F4A7C15ull;
+    uint32_t b = (uint32_t)(x >> 32) & (nb - 1);
+    while (tab[2 * (size_t)b] != ~0ull && tab[2 * (size_t)b] != keys[i]) b = (b + 1) & (nb - 1);
+    if (tab[2 * (size_t)b] == ~0ull) { tab[2 * (size_t)b] = keys[i]; ++size; }
+  }
+  // pow(10, -q/10) for q = 0..80, libm on the host (chromap.cc:639-640, 688-689)
+  std::vector<double> pw(81);
+  for (int q = 0; q <= 80; ++q) pw[q] = pow(10.0, ((-q) / 10.0));
+  if (c->wl.ensure(tab.size() * 8) || c->pow10_tab.ensure(pw.size() * 8) || c->wl_num.ensure(8)) { cm_set_error(c, "out of device memory (whitelist)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemcpy(c->wl.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(c->pow10_tab.p, pw.data(), pw.size() * 8, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemset(c->wl_num.p, 0, 8));
+  c->wl_mask = nb - 1;
+  c->wl_size = size;
+  c->bc_len = barcode_length;
+  c->wl_num_sample = 0;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, const uint32_t *offsets, uint32_t n,
+                                               uint64_t *num_sample_barcodes) {
+  if (!c || !bases || !offsets || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint64_t max_sample = 20000000ull;   // initial_num_sample_barcodes_ (chromap.h:211)
+  const uint32_t batch = (uint32_t)(c->p.ref_batch > 0 ? c->p.ref_batch : 500000);
+  DevBuf db, dofs;
+  const size_t nbytes = n ? offsets[n] : 0;
+  if (db.ensure(nbytes + 16) || dofs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemcpy(db.p, bases, nbytes, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(dofs.p, offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+  unsigned long long ns = c->wl_num_sample;
+  int rc = CMGPU_OK;
+  for (uint32_t b0 = 0; b0 < n; b0 += batch) {
+    const uint32_t bn = n - b0 < batch ? n - b0 : batch;
+    cm_launch_k_bc_abundance((const uint8_t *)db.p, (const uint32_t *)dofs.p, b0, b0 + bn, (uint64_t *)c->wl.p, c->wl_mask,
+                             (unsigned long long *)c->wl_num.p, c->stream);
+    hipError_t e = hipMemcpyAsync(&ns, c->wl_num.p, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { cm_set_error(c, std::string("barcode abundance: ") + hipGetErrorString(e)); rc = CMGPU_EHIP; break; }
+    if (ns * 20 < bn) {  // chromap.cc:523-533
+      cm_set_error(c, "Less than 5% barcodes can be found or corrected based on the barcode whitelist.");
+      rc = CMGPU_EINVAL;
+      break;
+    }
+    if (ns >= max_sample) break;
+  }
+  db.release(); dofs.release();
+  c->wl_num_sample = ns;
+  if (num_sample_barcodes) *num_sample_barcodes = ns;
+  return rc;
+}
+
+extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, const cmgpu_barcode_batch *bc, cmgpu_record_bc *out,
+                                        uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats) {
+  if (!c || !in || !bc || !out || !n_out) return CMGPU_EINVAL;
+  if (c->wl_size == 0 || c->wl_num_sample == 0) { cm_set_error(c, "whitelist / barcode abundance not set"); return CMGPU_EINVAL; }
+  int rc = cmgpu_upload_batch(c, in);
+  if (rc) return rc;
+  const uint32_t n = in->n_pairs;
+  *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  const size_t nbytes = bc->offsets[n];
+  if (c->bcb.ensure(nbytes + 16) || c->bcq.ensure(nbytes + 16) || c->bco.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemcpy(c->bcb.p, bc->bases, nbytes, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(c->bcq.p, bc->qualities, nbytes, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(c->bco.p, bc->offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+  c->has_barcodes = true;
+  uint64_t k = 0;
+  rc = cmgpu_map_resident(c, &k, stats);
+  if (rc) return rc;
+  std::vector<cmgpu_record> rec(n);
+  std::vector<uint8_t> ok(n);
+  std::vector<uint64_t> keys(n);
+  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, n, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(keys.data(), c->bc_key.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  uint64_t o = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!ok[i]) continue;
+    if (o >= out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
+    out[o].r = rec[i];
+    out[o].barcode = keys[i];
+    ++o;
+  }
+  *n_out = o;
   return CMGPU_OK;
 }

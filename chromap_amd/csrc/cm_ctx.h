@@ -43,6 +43,11 @@ struct cmgpu_ctx {
   DevBuf fbuf, fcnt, fcp, fcn, alive, dpos, derr, dsplit, ndp, ndn, min_err, second_err, n_best, n_second;
   DevBuf pe_min, pe_second, pe_nbest, pe_nsecond, pe_first, pe_i1, pe_i2, pe_choice, rec, rec_ok;
   DevBuf scan_tmp, stats, partials;
+  // single-cell barcodes
+  DevBuf wl, pow10_tab, bcb, bcq, bco, bc_key, bc_ok, wl_num;
+  uint32_t wl_mask = 0, wl_size = 0, bc_len = 0;
+  uint64_t wl_num_sample = 0;
+  bool has_barcodes = false;  // resident batch carries barcodes
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;
@@ -57,7 +62,7 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num};
   }
 };
 

@@ -25,6 +25,8 @@ extern "C" void cmgpu_default_params(cmgpu_params *p) {  // mapping_parameters.h
   p->mapq_threshold = 30;
   p->read_batch_size = 500000;
   p->taskloop_grain_size = 5000;
+  p->bc_error_threshold = 1;
+  p->bc_probability_threshold = 0.9;
 }
 
 extern "C" int cmgpu_apply_preset(cmgpu_params *p, const char *preset) {  // chromap_driver.cc:247-275
@@ -274,6 +276,87 @@ extern "C" int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *l
     buf.push_back('\n');
     ++lines;
     if (buf.size() > (1 << 20) - 512) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+  }
+  if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  return lines;
+}
+
+// Chromap::LoadBarcodeWhitelist (chromap.cc:388-490): one barcode per line, key =
+// GenerateSeedFromSequence (utils.h:111-129).  Plain text.
+extern "C" int cmgpu_load_whitelist_file(const char *path, uint32_t barcode_length, uint64_t **keys_out, uint32_t *n_out) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return CMGPU_EIO;
+  std::vector<uint64_t> keys;
+  char line[300];
+  while (fgets(line, sizeof(line), f)) {
+    size_t l = strlen(line);
+    while (l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+    if (l > 32 || l != barcode_length) { fclose(f); return CMGPU_EINVAL; }  // chromap.cc:403-415
+    uint64_t seed = 0;
+    for (size_t i = 0; i < l; ++i) {
+      const char ch = line[i] & 0xDF;
+      const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+      seed = b < 4 ? (seed << 2) | b : seed << 2;
+    }
+    keys.push_back(seed);
+  }
+  fclose(f);
+  uint64_t *k = (uint64_t *)malloc((keys.size() ? keys.size() : 1) * 8);
+  memcpy(k, keys.data(), keys.size() * 8);
+  *keys_out = k;
+  *n_out = (uint32_t)keys.size();
+  return CMGPU_OK;
+}
+
+// BED for PairedEndMappingWithBarcode: sort by operator< (bed_mapping.h:145-153) within rid,
+// cell-level duplicate removal on (barcode, start, length) (:154-159) keeping the first record
+// with the maximal MAPQ (mapping_writer.h:247-289), MAPQ filter, Tn5 shift, line
+// `chr start end barcode num_dups` with Seed2Sequence (mapping_writer.cc:119-131,
+// barcode_translator.h:107-116).
+extern "C" int64_t cmgpu_write_bed_pe_bc(const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
+                                         cmgpu_record_bc *rec, uint64_t n, uint32_t barcode_length, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return CMGPU_EIO;
+  std::sort(rec, rec + n, [](const cmgpu_record_bc &a, const cmgpu_record_bc &b) {
+    return std::tie(a.r.rid, a.r.fragment_start, a.r.fragment_length, a.barcode, a.r.mapq, a.r.direction, a.r.is_unique, a.r.read_id,
+                    a.r.positive_alignment_length, a.r.negative_alignment_length) <
+           std::tie(b.r.rid, b.r.fragment_start, b.r.fragment_length, b.barcode, b.r.mapq, b.r.direction, b.r.is_unique, b.r.read_id,
+                    b.r.positive_alignment_length, b.r.negative_alignment_length);
+  });
+  std::string buf;
+  buf.reserve(1 << 20);
+  int64_t lines = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    cmgpu_record_bc last = rec[i];
+    uint32_t dups = 1;
+    uint64_t j = i + 1;
+    if (p->remove_pcr_duplicates) {
+      while (j < n && rec[j].r.rid == last.r.rid && rec[j].barcode == last.barcode &&
+             rec[j].r.fragment_start == last.r.fragment_start && rec[j].r.fragment_length == last.r.fragment_length) {
+        ++dups;
+        if (rec[j].r.mapq > last.r.mapq) last = rec[j];
+        ++j;
+      }
+    }
+    if (last.r.mapq >= p->mapq_threshold && last.r.rid < n_sequences) {
+      cmgpu_record r = last.r;
+      if (p->tn5_shift) { r.fragment_start += 4; r.fragment_length -= 9; }
+      buf.append(names[r.rid]);
+      buf.push_back('\t');
+      put_u32(buf, r.fragment_start);
+      buf.push_back('\t');
+      put_u32(buf, r.fragment_start + r.fragment_length);
+      buf.push_back('\t');
+      for (uint32_t b = 0; b < barcode_length; ++b) buf.push_back("ACGT"[(last.barcode >> ((barcode_length - 1 - b) * 2)) & 3]);
+      buf.push_back('\t');
+      put_u32(buf, dups > 255 ? 255 : dups);
+      buf.push_back('\n');
+      ++lines;
+      if (buf.size() > (1 << 20) - 256) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    }
+    i = j;
   }
   if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
   fclose(f);

@@ -17,6 +17,9 @@ CM_DECL_LAUNCH(k_s5_verify)
 CM_DECL_LAUNCH(k_s6a_pair)
 CM_DECL_LAUNCH(k_s6c_multi)
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);
+void cm_launch_k_s0b_barcode(const CmDev &d, uint32_t n, hipStream_t s);
+void cm_launch_k_bc_abundance(const uint8_t *bcb, const uint32_t *bco, uint32_t lo, uint32_t hi, uint64_t *wl, uint32_t wl_mask,
+                              unsigned long long *num_sample, hipStream_t s);
 void cm_launch_k_slot_cap(const CmDev &d, uint32_t n_reads, uint32_t *cap, hipStream_t s);
 size_t cm_probe_partial_words(uint32_t n);
 void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,

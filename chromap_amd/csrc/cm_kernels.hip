@@ -92,6 +92,53 @@ __global__ __launch_bounds__(64) void k_s6b_sample(CmDev d, uint32_t n_chunks) {
   }
 }
 
+// K6: barcode correction; per-block reduction of the two counters, one atomic pair per block
+__global__ __launch_bounds__(CM_BLOCK) void k_s0b_barcode(CmDev d, uint32_t n) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  uint32_t a = 0, b = 0;
+  if (i < n) cm_s0b_barcode(d, i, &a, &b);
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  __shared__ uint32_t sa[CM_BLOCK / 64], sb[CM_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int j = 1; j < CM_BLOCK / 64; ++j) { a += sa[j]; b += sb[j]; }
+    if (a) atomicAdd(&d.stats[CM_ST_BC_INWL], (unsigned long long)a);
+    if (b) atomicAdd(&d.stats[CM_ST_BC_CORR], (unsigned long long)b);
+  }
+}
+
+// ComputeBarcodeAbundance (chromap.cc:492-548) for barcodes [lo, hi): whitelist hits without N
+// increment the entry's count; *num_sample += hits
+__global__ __launch_bounds__(CM_BLOCK) void k_bc_abundance(const uint8_t *__restrict__ bcb, const uint32_t *__restrict__ bco,
+                                                            uint32_t lo, uint32_t hi, uint64_t *__restrict__ wl,
+                                                            uint32_t wl_mask, unsigned long long *__restrict__ num_sample) {
+  const uint32_t i = lo + blockIdx.x * CM_BLOCK + threadIdx.x;
+  uint32_t hit = 0;
+  if (i < hi) {
+    const uint8_t *s = bcb + bco[i];
+    const uint32_t l = bco[i + 1] - bco[i];
+    bool has_n = false;
+    for (uint32_t j = 0; j < l; ++j) has_n |= s[j] == 'N';
+    if (!has_n) {
+      const uint64_t key = cm_seed_from_sequence(s, l);
+      const uint64_t x = key * 0x9E3779B97F4A7C15ull;
+      uint32_t b = (uint32_t)(x >> 32) & wl_mask;
+      for (;;) {
+        const uint64_t k = wl[2 * (uint64_t)b];
+        if (k == ~0ull) break;
+        if (k == key) { atomicAdd(reinterpret_cast<unsigned long long *>(wl + 2 * (uint64_t)b + 1), 1ull); hit = 1; break; }
+        b = (b + 1) & wl_mask;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) hit += __shfl_down(hit, off, 64);
+  if ((threadIdx.x & 63) == 0 && hit) atomicAdd(num_sample, (unsigned long long)hit);
+}
+
 // slot capacity of each read: one (hash,pos) per k-mer position at most
 __global__ __launch_bounds__(CM_BLOCK) void k_slot_cap(CmDev d, uint32_t n_reads, uint32_t *cap) {
   const uint32_t r = blockIdx.x * CM_BLOCK + threadIdx.x;
@@ -315,6 +362,13 @@ CM_LAUNCH(k_s6c_multi)
 
 void cm_launch_k_s1_minimizers(const CmDev &d, uint32_t n, uint32_t *total, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_s1_minimizers, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, total);
+}
+void cm_launch_k_s0b_barcode(const CmDev &d, uint32_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_s0b_barcode, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);
+}
+void cm_launch_k_bc_abundance(const uint8_t *bcb, const uint32_t *bco, uint32_t lo, uint32_t hi, uint64_t *wl, uint32_t wl_mask,
+                              unsigned long long *num_sample, hipStream_t s) {
+  if (hi > lo) hipLaunchKernelGGL(k_bc_abundance, grid_for(hi - lo), dim3(CM_BLOCK), 0, s, bcb, bco, lo, hi, wl, wl_mask, num_sample);
 }
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s) {
   if (n_chunks) hipLaunchKernelGGL(k_s6b_sample, dim3(n_chunks), dim3(64), 0, s, d, n_chunks);

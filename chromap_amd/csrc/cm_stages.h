@@ -183,6 +183,99 @@ CM_HD void cm_sort_draft(uint64_t *p, int16_t *e, uint32_t n) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// K6: barcode correction, one pair per item (Chromap::CorrectBarcodeAt, chromap.cc:572-799,
+//     GenerateSeedFromSequence utils.h:111-129).  bc_error_threshold 0 or 1.  The corrected
+//     barcode is kept as its 2-bit key (what the record carries); the bases in HBM are
+//     not rewritten.  Candidate scores are pow(10,-q/10) (host table) * count/num_sample in
+//     double; several candidates are sorted descending by (score, index, base) and summed in
+//     that order like the reference (:733-740).
+// ---------------------------------------------------------------------------------------
+CM_HD uint64_t cm_seed_from_sequence(const uint8_t *seq, uint32_t len) {
+  uint64_t seed = 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    const uint32_t b = cm_c2u(seq[i]);
+    seed = b < 4 ? (seed << 2) | b : seed << 2;
+  }
+  return seed;
+}
+// whitelist lookup; returns count via *cnt
+CM_HD bool cm_wl_get(const CmDev &d, uint64_t key, uint32_t *cnt) {
+  const uint64_t x = key * 0x9E3779B97F4A7C15ull;
+  uint32_t i = (uint32_t)(x >> 32) & d.wl_mask;
+  for (;;) {
+    const uint64_t k = d.wl[2 * (uint64_t)i];
+    if (k == ~0ull) return false;
+    if (k == key) { *cnt = (uint32_t)d.wl[2 * (uint64_t)i + 1]; return true; }
+    i = (i + 1) & d.wl_mask;
+  }
+}
+#define CM_BC_MAXC 132  // 32 positions x 4 + slack
+CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32_t *corrected) {
+  const uint8_t *bc = d.bcb + d.bco[pair];
+  const uint8_t *q = d.bcq + d.bco[pair];
+  const uint32_t len = d.bco[pair + 1] - d.bco[pair];
+  const uint64_t key = cm_seed_from_sequence(bc, len);
+  d.bc_key[pair] = key;
+  d.bc_ok[pair] = 0;
+  uint32_t cnt = 0;
+  const bool found = cm_wl_get(d, key, &cnt);
+  int nn = 0, n0 = 0;
+  for (int i = (int)len - 1; i >= 0; --i)
+    if (bc[i] == 'N') { if (nn == 0) n0 = (int)len - 1 - i; ++nn; }  // GetSequenceNsAt: 'N' only, little endian
+  if ((uint32_t)nn > (uint32_t)d.p.bc_err) return;
+  if (nn == 0 && found) { ++*in_wl; d.bc_ok[pair] = 1; return; }
+  if (d.p.bc_err <= 0) return;
+  double sc[CM_BC_MAXC];
+  uint64_t ck[CM_BC_MAXC];
+  uint32_t ci[CM_BC_MAXC];  // idx1 << 8 | base char
+  uint32_t nc = 0;
+  uint32_t i_start = 0, i_end = len, ti_limit = 3;
+  if (nn > 0) { i_start = (uint32_t)n0; i_end = i_start + 1; ti_limit = 4; }
+  for (uint32_t i = i_start; i < i_end; ++i) {
+    const uint64_t cleared = ~(3ull << (2 * i)) & key;
+    uint64_t b1 = (key >> (2 * i)) & 3ull;
+    for (uint32_t ti = 0; ti < ti_limit; ++ti) {
+      b1 = (b1 + 1) & 3ull;
+      const uint64_t k1 = cleared | (b1 << (2 * i));
+      uint32_t c1;
+      if (cm_wl_get(d, k1, &c1) && nc < CM_BC_MAXC) {
+        const double abundance = c1 / d.wl_num_sample;
+        int aq = (int)q[len - 1 - i] - 33;
+        aq = aq > 40 ? 40 : aq;
+        aq = aq < 3 ? 3 : aq;
+        sc[nc] = d.pow10_tab[aq] * abundance;
+        ck[nc] = k1;
+        ci[nc] = ((len - 1 - i) << 8) | (uint32_t)"ACGT"[b1];
+        ++nc;
+      }
+    }
+  }
+  if (nc == 0) return;
+  uint32_t best = 0;
+  bool apply = true;
+  if (nc > 1) {
+    // insertion sort, descending by (score, idx1, base1): std::greater<BarcodeWithQual> (utils.h:29-35)
+    for (uint32_t a = 1; a < nc; ++a) {
+      const double xs = sc[a];
+      const uint64_t xk = ck[a];
+      const uint32_t xi = ci[a];
+      uint32_t b = a;
+      while (b > 0 && (sc[b - 1] < xs || (sc[b - 1] == xs && ci[b - 1] < xi))) { sc[b] = sc[b - 1]; ck[b] = ck[b - 1]; ci[b] = ci[b - 1]; --b; }
+      sc[b] = xs; ck[b] = xk; ci[b] = xi;
+    }
+    double sum = 0;
+    for (uint32_t a = 0; a < nc; ++a) sum += sc[a];
+    apply = sc[0] / sum > d.p.bc_prob;
+  }
+  if (apply) {
+    d.bc_key[pair] = ck[best];
+    d.bc_ok[pair] = 1;
+    ++*corrected;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // S0: length filter + adapter trimming, one pair per item
 //   chromap.h:911-924, Chromap::TrimAdapterForPairedEndRead chromap.cc:176-289,
@@ -194,7 +287,9 @@ CM_HD void cm_sort_draft(uint64_t *p, int16_t *e, uint32_t n) {
 CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
   const uint32_t raw1 = d.ro0[pair + 1] - d.ro0[pair], raw2 = d.ro1[pair + 1] - d.ro1[pair];
   uint32_t len1 = raw1, len2 = raw2;
-  const bool ok = raw1 >= (uint32_t)d.p.min_read_len && raw2 >= (uint32_t)d.p.min_read_len;
+  bool ok = raw1 >= (uint32_t)d.p.min_read_len && raw2 >= (uint32_t)d.p.min_read_len;
+  // pairs whose barcode is not (correctable to) a whitelisted one are skipped (chromap.h:908-909)
+  if (d.bcb && !d.bc_ok[pair] && !d.p.bc_keep) ok = false;
   if (ok && d.p.trim) {
     const uint8_t *s1 = d.rb0 + d.ro0[pair], *s2 = d.rb1 + d.ro1[pair];
     const bool swap = !(raw1 <= raw2);

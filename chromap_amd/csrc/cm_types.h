@@ -35,6 +35,9 @@ struct CmParams {
   int32_t drop_rep;      // drop_repetitive_reads
   int32_t trim;          // trim_adapters
   int32_t split;         // split_alignment (--preset hic)
+  int32_t bc_err;        // barcode_correction_error_threshold (0 or 1 on the device)
+  int32_t bc_keep;       // output_mappings_not_in_whitelist
+  double bc_prob;        // barcode_correction_probability_threshold
   int32_t k, w;          // from the index file
   int32_t lanes;         // GetNumVPULanes(): 8 if e<8, 4 if e<16, else 0
   int32_t ref_batch;     // 500000
@@ -68,6 +71,15 @@ struct CmDev {
   uint32_t first_read_id;
   const uint8_t *rb0, *rb1;    // bases of mate 0 / mate 1
   const uint32_t *ro0, *ro1;   // offsets (n_pairs+1)
+  // ---- single-cell barcodes (nullptr for bulk data)
+  const uint8_t *bcb, *bcq;    // barcode bases / qualities
+  const uint32_t *bco;         // offsets (n_pairs+1)
+  const uint64_t *wl;          // whitelist table: bucket i = {key, count} at wl[2i], wl[2i+1]; empty key = all ones
+  uint32_t wl_mask;
+  double wl_num_sample;        // num_sample_barcodes_ as double
+  const double *pow10_tab;     // [81]: pow(10, -q/10)
+  uint64_t *bc_key;            // [n] (corrected) barcode key
+  uint8_t *bc_ok;              // [n] CorrectBarcodeAt's return value
   // ---- per read
   uint32_t *rlen;       // length after trimming; 0 when the pair was dropped
   uint32_t *mm_cap_off; // [2n+1] prefix of slot capacities (max(0, raw_len-k+1))
@@ -135,6 +147,8 @@ struct CmDev {
 #define CM_ST_MULTI 9
 #define CM_ST_ERR 10
 #define CM_ST_RECORDS 11
+#define CM_ST_BC_INWL 12
+#define CM_ST_BC_CORR 13
 #define CM_ST_N 16
 
 #endif

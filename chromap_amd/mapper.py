@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import Batch, IndexView, Params, Record, RefView, Stats
+from ._capi import BarcodeBatch, Batch, IndexView, Params, Record, RecordBc, RefView, Stats
 
 
 class ChromapError(RuntimeError):
@@ -119,6 +119,45 @@ class ChromapGPU:
                                     C.byref(self.stats))
         self._check(rc, self.ctx)
         return rec, int(n.value)
+
+    # ---- single-cell barcodes
+    def set_whitelist_file(self, path, barcode_length):
+        keys = C.c_void_p()
+        n = C.c_uint32(0)
+        if self.L.cmgpu_load_whitelist_file(path.encode(), barcode_length, C.byref(keys), C.byref(n)) != 0:
+            raise ChromapError("cannot read whitelist %s" % path)
+        self._check(self.L.cmgpu_set_whitelist(self.ctx, keys, n.value, barcode_length), self.ctx)
+        C.CDLL(None).free(keys)
+        self.barcode_length = barcode_length
+
+    def compute_barcode_abundance(self, bc, bco):
+        bc = np.ascontiguousarray(bc, dtype=np.uint8)
+        bco = np.ascontiguousarray(bco, dtype=np.uint32)
+        ns = C.c_uint64(0)
+        self._check(self.L.cmgpu_compute_barcode_abundance(self.ctx, bc.ctypes.data, bco.ctypes.data, len(bco) - 1,
+                                                           C.byref(ns)), self.ctx)
+        return int(ns.value)
+
+    def map_pairs_barcoded(self, b1, o1, b2, o2, bc, bcq, bco, first_read_id=0):
+        bt = self._batch(b1, o1, b2, o2, first_read_id)
+        kb = [np.ascontiguousarray(bc, dtype=np.uint8), np.ascontiguousarray(bcq, dtype=np.uint8),
+              np.ascontiguousarray(bco, dtype=np.uint32)]
+        bb = BarcodeBatch(kb[0].ctypes.data, kb[1].ctypes.data, kb[2].ctypes.data)
+        rec = (RecordBc * max(1, bt.n_pairs))()
+        n = C.c_uint64(0)
+        rc = self.L.cmgpu_map_pairs_barcoded(self.ctx, C.byref(bt), C.byref(bb), C.cast(rec, C.c_void_p), bt.n_pairs,
+                                             C.byref(n), C.byref(self.stats))
+        self._check(rc, self.ctx)
+        return rec, int(n.value)
+
+    def write_bed_bc(self, rec, n, path, params=None):
+        p = params if params is not None else self.params
+        names = (C.c_char_p * len(self.names))(*self.names)
+        k = self.L.cmgpu_write_bed_pe_bc(names, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, self.barcode_length,
+                                         path.encode())
+        if k < 0:
+            raise ChromapError("cannot write %s" % path)
+        return int(k)
 
     def upload(self, b1, o1, b2, o2, first_read_id=0):
         bt = self._batch(b1, o1, b2, o2, first_read_id)

@@ -74,6 +74,9 @@ typedef struct cmgpu_params {
   int32_t low_memory_mode;        /* used by cmgpu_write_bed_pe only */
   int32_t read_batch_size;        /* Chromap::read_batch_size_ = 500000 (chromap.h:182) */
   int32_t taskloop_grain_size;    /* 5000 (chromap.h:887): scope of the reservoir RNG */
+  int32_t bc_error_threshold;     /* --bc-error-threshold (0 or 1 supported on the device) */
+  int32_t output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
+  double bc_probability_threshold; /* --bc-probability-threshold */
 } cmgpu_params;
 
 /* A batch of read pairs as SequenceBatch holds them after parsing (src/chromap.cc:93-174):
@@ -118,6 +121,21 @@ typedef struct cmgpu_pairs_record {
   uint8_t is_unique;
 } cmgpu_pairs_record;
 
+/* Single-cell data: PairedEndMappingWithBarcode (src/bed_mapping.h:128-144) = the bulk record
+ * plus the 2-bit-packed (corrected) cell barcode (GenerateSeedFromSequence, src/utils.h:111-129). */
+typedef struct cmgpu_record_bc {
+  cmgpu_record r;
+  uint64_t barcode;
+} cmgpu_record_bc;
+
+/* Cell barcodes of a batch as the barcode SequenceBatch holds them: bases + qualities
+ * (same offsets), n_pairs+1 offsets. */
+typedef struct cmgpu_barcode_batch {
+  const char *bases;
+  const char *qualities;
+  const uint32_t *offsets;
+} cmgpu_barcode_batch;
+
 /* Counters of Chromap::OutputMappingStatistics (src/chromap.cc:808-823) plus the
  * quantities SURVEY.md 8(d) defines the index-probe kernel's algorithmic bytes from. */
 typedef struct cmgpu_stats {
@@ -130,7 +148,9 @@ typedef struct cmgpu_stats {
   uint64_t occurrences_read;    /* occurrence-table entries expanded (8 B each) */
   uint64_t num_pairs_rescued;   /* reads that went through mate rescue */
   uint64_t num_multi_mappers;   /* pairs resolved by reservoir sampling */
-  uint64_t reserved[7];
+  uint64_t num_barcode_in_whitelist; /* Chromap::OutputBarcodeStatistics (chromap.cc:801-806) */
+  uint64_t num_corrected_barcode;
+  uint64_t reserved[5];
 } cmgpu_stats;
 
 typedef struct cmgpu_ctx cmgpu_ctx;
@@ -167,6 +187,26 @@ const char *cmgpu_last_error(const cmgpu_ctx *ctx);
  * sampling of multi-mappers to reproduce the reference. */
 int cmgpu_map_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,
                     uint64_t *n_out, cmgpu_stats *stats);
+
+/* ---- single-cell barcodes (K6) --------------------------------------------------------
+ * cmgpu_set_whitelist: Chromap::LoadBarcodeWhitelist (src/chromap.cc:388-490): keys =
+ * GenerateSeedFromSequence of every whitelist line (cmgpu_load_whitelist_file produces them).
+ * cmgpu_compute_barcode_abundance: Chromap::ComputeBarcodeAbundance (src/chromap.cc:492-548)
+ * over ALL barcodes of the input (host pointers), batch structure and stop rule included;
+ * fails with CMGPU_EINVAL when fewer than 5% of the first batch are whitelisted (the reference
+ * exits there).  cmgpu_map_pairs_barcoded: the taskloop body with CorrectBarcodeAt in front
+ * (src/chromap.h:896-909, src/chromap.cc:572-799). */
+int cmgpu_load_whitelist_file(const char *path, uint32_t barcode_length, uint64_t **keys_out, uint32_t *n_out);
+int cmgpu_set_whitelist(cmgpu_ctx *ctx, const uint64_t *keys, uint32_t n_keys, uint32_t barcode_length);
+int cmgpu_compute_barcode_abundance(cmgpu_ctx *ctx, const char *barcode_bases, const uint32_t *barcode_offsets,
+                                    uint32_t n_barcodes, uint64_t *num_sample_barcodes);
+int cmgpu_map_pairs_barcoded(cmgpu_ctx *ctx, const cmgpu_batch *in, const cmgpu_barcode_batch *barcodes,
+                             cmgpu_record_bc *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
+/* BED with the barcode column and cell-level duplicate removal (src/mapping_writer.cc:119-131,
+ * src/bed_mapping.h:145-159; remove_pcr_duplicates_at_bulk_level == false as --preset atac sets). */
+int64_t cmgpu_write_bed_pe_bc(const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
+                              cmgpu_record_bc *records, uint64_t n_records, uint32_t barcode_length,
+                              const char *out_path);
 
 /* Device-resident variant used for throughput measurement: inputs are uploaded once,
  * mapping runs on HBM-resident data and leaves the records in HBM. */

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
 #include <vector>
 
 #include "../../include/chromap_amd.h"
@@ -19,10 +20,17 @@ static void scan(const T *in, uint32_t *out, uint32_t n) {
   out[n] = s;
 }
 
-extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
-                                 const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
-                                 uint32_t *dbg_mm_cnt /* 2n or NULL */, uint32_t *dbg_ncand /* 2n */,
-                                 uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */) {
+struct EmuBarcodes {
+  const cmgpu_barcode_batch *bc;
+  const uint64_t *wl_keys;
+  uint32_t n_keys;
+  uint64_t *bc_key_out;  // [n]
+};
+
+static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                         const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
+                         uint32_t *dbg_mm_cnt /* 2n or NULL */, uint32_t *dbg_ncand /* 2n */,
+                         uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */, const EmuBarcodes *eb) {
   const uint32_t n = in->n_pairs, n2 = 2 * n;
   CmDev d;
   memset(&d, 0, sizeof(d));
@@ -47,6 +55,7 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
   p.e = params->error_threshold; p.min_seeds = params->min_num_seeds; p.f0 = params->max_seed_frequency0;
   p.f1 = params->max_seed_frequency1; p.max_insert = params->max_insert_size; p.min_read_len = params->min_read_length;
   p.max_best = params->max_num_best_mappings; p.drop_rep = params->drop_repetitive_reads; p.trim = params->trim_adapters; p.split = params->split_alignment ? 1 : 0;
+  p.bc_err = params->bc_error_threshold; p.bc_keep = params->output_mappings_not_in_whitelist ? 1 : 0; p.bc_prob = params->bc_probability_threshold;
   p.k = index->kmer_size; p.w = index->window_size; p.lanes = p.split ? 0 : (p.e < 8 ? 8 : (p.e < 16 ? 4 : 0));
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
@@ -70,6 +79,50 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
   VEC(pe_min, int32_t, n) VEC(pe_second, int32_t, n) VEC(pe_nbest, int32_t, n) VEC(pe_nsecond, int32_t, n)
   VEC(pe_first, uint32_t, n) VEC(pe_i1, uint32_t, n) VEC(pe_i2, uint32_t, n) VEC(pe_choice, uint32_t, n)
   VEC(rec, uint8_t, (size_t)n * 24) VEC(rec_ok, uint8_t, n)
+  // ---- K6 (cmgpu_set_whitelist + cmgpu_compute_barcode_abundance + k_s0b_barcode)
+  std::vector<uint64_t> wl_tab;
+  std::vector<double> pw(81);
+  std::vector<uint64_t> v_bc_key(n + 1);
+  std::vector<uint8_t> v_bc_ok(n + 1);
+  if (eb) {
+    uint32_t wnb = 16;
+    while (wnb < 2ull * eb->n_keys + 16) wnb <<= 1;
+    wl_tab.assign((size_t)wnb * 2, 0);
+    for (uint32_t i = 0; i < wnb; ++i) wl_tab[2 * (size_t)i] = ~0ull;
+    for (uint32_t i = 0; i < eb->n_keys; ++i) {
+      const uint64_t x = eb->wl_keys[i] * 0x9E3779B97F4A7C15ull;
+      uint32_t b = (uint32_t)(x >> 32) & (wnb - 1);
+      while (wl_tab[2 * (size_t)b] != ~0ull && wl_tab[2 * (size_t)b] != eb->wl_keys[i]) b = (b + 1) & (wnb - 1);
+      wl_tab[2 * (size_t)b] = eb->wl_keys[i];
+    }
+    for (int q = 0; q <= 80; ++q) pw[q] = pow(10.0, ((-q) / 10.0));
+    d.bcb = (const uint8_t *)eb->bc->bases; d.bcq = (const uint8_t *)eb->bc->qualities; d.bco = eb->bc->offsets;
+    d.wl = wl_tab.data(); d.wl_mask = wnb - 1; d.pow10_tab = pw.data();
+    d.bc_key = v_bc_key.data(); d.bc_ok = v_bc_ok.data();
+    // abundance over all barcodes of the input (one reference batch here)
+    uint64_t ns = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint8_t *sq = d.bcb + d.bco[i];
+      const uint32_t l = d.bco[i + 1] - d.bco[i];
+      bool has_n = false;
+      for (uint32_t j = 0; j < l; ++j) has_n |= sq[j] == 'N';
+      if (has_n) continue;
+      const uint64_t key = cm_seed_from_sequence(sq, l);
+      const uint64_t x = key * 0x9E3779B97F4A7C15ull;
+      uint32_t b = (uint32_t)(x >> 32) & d.wl_mask;
+      while (wl_tab[2 * (size_t)b] != ~0ull) {
+        if (wl_tab[2 * (size_t)b] == key) { wl_tab[2 * (size_t)b + 1] += 1; ++ns; break; }
+        b = (b + 1) & d.wl_mask;
+      }
+    }
+    d.wl_num_sample = (double)ns;
+    for (uint32_t i = 0; i < n; ++i) {
+      uint32_t a = 0, b = 0;
+      cm_s0b_barcode(d, i, &a, &b);
+      st[CM_ST_BC_INWL] += a;
+      st[CM_ST_BC_CORR] += b;
+    }
+  }
   for (uint32_t i = 0; i < n; ++i) cm_s0_prep(d, i);
   std::vector<uint32_t> cap(n2 + 1);
   for (uint32_t r = 0; r < n2; ++r) cap[r] = d.rlen[r] >= (uint32_t)p.k ? d.rlen[r] - p.k + 1 : 0;
@@ -124,7 +177,7 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
     }
     st[CM_ST_RESCUED] += d.aug[r1] + d.aug[r2];
     st[CM_ST_OCC] += d.hit_tot[r1] + d.hit_tot[r2];
-    if (d.rec_ok[i]) memcpy(&out[k++], d.rec + (size_t)i * 24, 24);
+    if (d.rec_ok[i]) { if (eb) eb->bc_key_out[k] = d.bc_key[i]; memcpy(&out[k++], d.rec + (size_t)i * 24, 24); }
     if (dbg_nbest) dbg_nbest[i] = d.pe_nbest[i];
   }
   for (uint32_t r = 0; r < n2; ++r) {
@@ -143,8 +196,27 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
     stats->occurrences_read += st[CM_ST_OCC];
     stats->num_pairs_rescued += st[CM_ST_RESCUED];
     stats->num_multi_mappers += st[CM_ST_MULTI];
+    stats->num_barcode_in_whitelist += st[CM_ST_BC_INWL];
+    stats->num_corrected_barcode += st[CM_ST_BC_CORR];
   }
   return st[CM_ST_ERR] ? -(int)st[CM_ST_ERR] : 0;
+}
+
+extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                 const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
+                                 uint32_t *dbg_mm_cnt, uint32_t *dbg_ncand, uint32_t *dbg_ndraft, int32_t *dbg_nbest) {
+  return emu_map_pairs(index, ref, params, in, out, n_out, stats, dbg_mm_cnt, dbg_ncand, dbg_ndraft, dbg_nbest, nullptr);
+}
+
+extern "C" int hostemu_map_pairs_bc(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                    const cmgpu_batch *in, const cmgpu_barcode_batch *bc, const uint64_t *wl_keys,
+                                    uint32_t n_keys, cmgpu_record_bc *out, uint64_t *n_out, cmgpu_stats *stats) {
+  std::vector<cmgpu_record> rec(in->n_pairs + 1);
+  std::vector<uint64_t> keys(in->n_pairs + 1);
+  EmuBarcodes eb{bc, wl_keys, n_keys, keys.data()};
+  const int rc = emu_map_pairs(index, ref, params, in, rec.data(), n_out, stats, nullptr, nullptr, nullptr, nullptr, &eb);
+  for (uint64_t i = 0; i < *n_out; ++i) { out[i].r = rec[i]; out[i].barcode = keys[i]; }
+  return rc;
 }
 
 // chunked reference-minimizer collection (cm_ref_chunk_minimizers) concatenated in chunk

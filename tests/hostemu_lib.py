@@ -72,6 +72,29 @@ class HostEmu:
         assert rc == 0, rc
         return rec, int(k.value), st, dbg
 
+    def map_pairs_bc(self, b1, o1, b2, o2, bc, bcq, bco, wl_keys):
+        n = len(o1) - 1
+        keep = [np.ascontiguousarray(x) for x in (b1, o1, b2, o2, bc, bcq, bco, wl_keys)]
+        bt = _capi.Batch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data)
+        bb = _capi.BarcodeBatch(keep[4].ctypes.data, keep[5].ctypes.data, keep[6].ctypes.data)
+        rec = (_capi.RecordBc * max(1, n))()
+        k = C.c_uint64(0)
+        st = _capi.Stats()
+        f = self.L.hostemu_map_pairs_bc
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(_capi.IndexView), C.POINTER(_capi.RefView), C.POINTER(_capi.Params), C.POINTER(_capi.Batch),
+                      C.POINTER(_capi.BarcodeBatch), C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
+                      C.POINTER(_capi.Stats)]
+        rc = f(C.byref(self.idx), C.byref(self.ref), C.byref(self.p), C.byref(bt), C.byref(bb), keep[7].ctypes.data,
+               len(keep[7]), C.cast(rec, C.c_void_p), C.byref(k), C.byref(st))
+        assert rc == 0, rc
+        return rec, int(k.value), st
+
+    def write_bed_bc(self, rec, n, barcode_length, path):
+        names = (C.c_char_p * len(self.names))(*self.names)
+        return self.L.cmgpu_write_bed_pe_bc(names, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n,
+                                            barcode_length, path.encode())
+
     def write_pairs(self, rec, n, read_names, path):
         names = (C.c_char_p * len(self.names))(*self.names)
         lens = (C.c_uint32 * len(self.names))(*[self.ref.lengths[i] for i in range(len(self.names))])

@@ -100,3 +100,32 @@ def test_hic_pairs_match_reference(case, tmp_path):
     for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
         assert s[key] == ref[key], key
     g.close()
+
+
+@pytest.mark.parametrize("case", [c for c in datasets.BC_CASES if "bc2" not in c])
+def test_barcoded_bed_matches_reference(case, tmp_path):
+    """scATAC: whitelist + abundance + barcode correction (K6) on the device, barcoded BED"""
+    from chromap_amd import ChromapGPU
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    g = ChromapGPU(idx, fa, preset=preset, **kw)
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    g.set_whitelist_file(wlf, int(bco[1] - bco[0]))
+    ns = g.compute_barcode_abundance(bc, bco)
+    rec, k = g.map_pairs_barcoded(b1, o1, b2, o2, bc, bcq, bco)
+    out = str(tmp_path / "g.bed")
+    g.write_bed_bc(rec, k, out)
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    s = g.stats.as_dict()
+    assert ns == ref["num_barcode_in_whitelist"]  # abundance pre-pass counts the same barcodes
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads",
+                "num_barcode_in_whitelist", "num_corrected_barcode"):
+        assert s[key] == ref[key], key
+    g.close()

@@ -11,7 +11,32 @@ import hostemu_lib as he
 import oracle_lib as ol
 
 
-@pytest.mark.parametrize("case", datasets.ALL_CASES)
+@pytest.mark.parametrize("case", [c for c in datasets.BC_CASES if "bc2" not in c])
+def test_barcode_stage_matches_reference(case, tmp_path):
+    """K6 (bc-error-threshold 1) + barcoded records through the stage functions"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    h = he.HostEmu(idx, fa, he.params(preset, **kw))
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+    keys, _ = wl.export()
+    rec, k, st = h.map_pairs_bc(b1, o1, b2, o2, bc, bcq, bco, keys)
+    out = str(tmp_path / "e.bed")
+    h.write_bed_bc(rec, k, wl.barcode_length, out)
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads",
+                "num_barcode_in_whitelist", "num_corrected_barcode"):
+        assert s[key] == ref[key], key
+
+
+@pytest.mark.parametrize("case", datasets.BED_CASES + datasets.HIC_CASES)
 def test_stage_functions_match_reference(case, tmp_path):
     meta = datasets.case_meta(case)
     fa, r1, r2 = datasets.case_inputs(case)
