@@ -2399,3 +2399,127 @@ long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t 
   *bases = a.b.a; *quals = a.q.a; *off = a.off;
   return (long)a.n;
 }
+
+/* ------------------------------------------------------------------------- */
+/* single-end: taskloop body chromap.h:385-472, GenerateBestMappingsForSingleEndRead           */
+/* (mapping_generator.h:115-157, 256-344), bulk records MappingWithoutBarcode                  */
+/* ------------------------------------------------------------------------- */
+static long map_one_read(const ora_ctx *c, work_t *wk, uint32_t read_index, uint32_t read_id, const char *s1,
+                         uint32_t len1, ora_record *out, ora_stats *st) {
+  const ora_params *p = &c->p;
+  if (len1 < (uint32_t)p->min_read_length) return 0;
+  if (len1 + 1 > wk->cap1) { wk->cap1 = len1 + 64; wk->neg1 = (char *)realloc(wk->neg1, wk->cap1); wk->fw1 = (char *)realloc(wk->fw1, wk->cap1); }
+  memcpy(wk->fw1, s1, len1); wk->fw1[len1] = 0;
+  prep_negative(s1, len1, wk->neg1);
+  meta_t *m = &wk->m1;
+  meta_prepare(m, len1);
+  m->n_mm = ora_minimizers(wk->fw1, len1, read_index, c->idx->k, c->idx->w, m->mm_hash, m->mm_hit);
+  if (st) st->num_minimizers += (uint64_t)m->n_mm;
+  if (m->n_mm == 0) return 0;
+  gen_candidates(c, m, st);
+  const size_t nc = m->pos_cand.n + m->neg_cand.n;
+  if (nc == 0) return 0;
+  if (st) st->num_candidates += nc;
+  gen_draft_mappings(c, m, wk->fw1, wk->neg1, len1, st);
+  if (m->pos_map.n + m->neg_map.n == 0) return 0;
+  /* a fresh std::mt19937(11) per read (mapping_generator.h:128-139) */
+  int choice = 0;
+  if (m->n_best > 1) {
+    mt19937_t g;
+    mt_seed(&g, 11);
+    for (int i = 1; i < m->n_best; ++i) { int j = mt_uniform(&g, i); if (j < 1) choice = i; }
+  }
+  long nout = 0;
+  int idx = 0;
+  for (int strand = 0; strand < 2 && nout == 0; ++strand) {
+    const vdraft *v = strand == 0 ? &m->pos_map : &m->neg_map;
+    for (size_t mi = 0; mi < v->n; ++mi) {
+      if (v->a[mi].num_errors > m->min_err) continue;
+      if (idx == choice) {
+        const span_t sp = ref_start_end(c, &v->a[mi], strand, strand == 0 ? wk->fw1 : wk->neg1, (int)len1);
+        const uint16_t al = (uint16_t)(sp.ref_end - sp.ref_start + 1);
+        const uint8_t mapq = mapq_single(c, v->a[mi].num_errors, al, (int)len1, p->error_threshold, m);
+        ora_record *r = &out[nout++];
+        memset(r, 0, sizeof(*r));
+        r->read_id = read_id; r->rid = sp.rid; r->fragment_start = sp.ref_start; r->fragment_length = al;
+        r->mapq = mapq & 63; r->direction = strand == 0 ? 1 : 0; r->is_unique = m->n_best == 1; r->num_dups = 1;
+        break;
+      }
+      ++idx;
+    }
+  }
+  if (st) {
+    st->num_mappings += (uint64_t)(m->n_best < p->max_num_best_mappings ? m->n_best : p->max_num_best_mappings);
+    st->num_mapped_reads += 1;
+    if (m->n_best == 1) st->num_uniquely_mapped_reads += 1;
+  }
+  return nout;
+}
+
+long ora_map_single(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
+                    ora_record *out, ora_stats *stats) {
+  if (threads < 1) threads = 1;
+  uint8_t *has = (uint8_t *)calloc((size_t)n + 1, 1);
+  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  ora_stats *sts = (ora_stats *)calloc((size_t)threads, sizeof(ora_stats));
+#pragma omp parallel num_threads(threads)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    work_t wk;
+    work_init(&wk, &c->p);
+#pragma omp for schedule(dynamic, 1024)
+    for (long i = 0; i < (long)n; ++i)
+      has[i] = (uint8_t)map_one_read(c, &wk, (uint32_t)i, first_read_id + (uint32_t)i, r + r_off[i], r_off[i + 1] - r_off[i], &tmp[i], &sts[t]);
+    work_free(&wk);
+  }
+  long k = 0;
+  for (uint32_t i = 0; i < n; ++i) if (has[i]) out[k++] = tmp[i];
+  for (int t = 0; t < threads && stats; ++t) {
+    uint64_t *d = (uint64_t *)stats, *s2 = (uint64_t *)&sts[t];
+    for (size_t i = 0; i < sizeof(ora_stats) / 8; ++i) d[i] += s2[i];
+  }
+  free(has); free(tmp); free(sts);
+  return k;
+}
+
+/* MappingWithoutBarcode: sort (bed_mapping.h:90-95), dedup on fragment_start only (:96-99),
+ * Tn5 shift (:104-110), line mapping_writer.cc:44-52 */
+static int cmp_rec_se(const void *a, const void *b) {
+  const ora_record *x = (const ora_record *)a, *y = (const ora_record *)b;
+#define CMPF(f) if (x->f != y->f) return x->f < y->f ? -1 : 1
+  CMPF(rid); CMPF(fragment_start); CMPF(fragment_length); CMPF(mapq); CMPF(direction); CMPF(is_unique); CMPF(read_id);
+#undef CMPF
+  return 0;
+}
+long ora_write_bed_se(const ora_ref *ref, const ora_params *p, ora_record *rec, long n, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  qsort(rec, (size_t)n, sizeof(ora_record), cmp_rec_se);
+  long lines = 0, i = 0;
+  while (i < n) {
+    ora_record last = rec[i];
+    uint32_t dups = 1;
+    long j = i + 1;
+    if (p->remove_pcr_duplicates && p->low_mem) {
+      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start) {
+        ++dups;
+        if (rec[j].mapq > last.mapq) last = rec[j];
+        ++j;
+      }
+    }
+    if (last.mapq >= p->mapq_threshold) {
+      if (p->tn5_shift) { if (last.direction == 1) last.fragment_start += 4; else last.fragment_length -= 5; }
+      fprintf(f, "%s\t%u\t%u\tN\t%u\t%s\t%u\n", ref->name[last.rid], last.fragment_start,
+              last.fragment_start + last.fragment_length, (unsigned)last.mapq, last.direction ? "+" : "-",
+              dups > 255 ? 255u : dups);
+      ++lines;
+    }
+    i = j;
+  }
+  fclose(f);
+  return lines;
+}

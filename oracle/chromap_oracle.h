@@ -182,6 +182,11 @@ long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc 
 /* FASTQ with qualities: returns n, allocates bases, quals (same offsets) and off */
 long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t **off);
 
+/* single-end reads (chromap.h:385-472): bulk records, positive/negative_alignment_length 0 */
+long ora_map_single(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
+                    ora_record *out, ora_stats *stats);
+long ora_write_bed_se(const ora_ref *ref, const ora_params *p, ora_record *rec, long n, const char *out_path);
+
 /* per-pair trace for stage-level comparisons with the HIP path */
 typedef struct ora_trace {
   uint32_t len1, len2;           /* read lengths after trimming */

@@ -58,6 +58,10 @@ def case_barcode_inputs(name):
     return os.path.join(d, "d_bc.fq"), os.path.join(d, "d.whitelist.txt")
 
 
+def single_end_mate(name):
+    return case_meta(name).get("single_end_mate", 0)
+
+
 def has_barcodes(name):
     return "bc" in case_meta(name)["input_md5"]
 
@@ -93,7 +97,8 @@ def flags_to_params(flags):
 
 
 ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
-BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c)]
+BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c) and not single_end_mate(c)]
+SE_CASES = [c for c in ALL_CASES if single_end_mate(c)]
 BC_CASES = [c for c in ALL_CASES if has_barcodes(c)]
 HIC_CASES = [c for c in ALL_CASES if is_hic(c)]
 

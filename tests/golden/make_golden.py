@@ -23,6 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref", "chromap")
 GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 
+# single-end cases: which mate file is mapped alone
+SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2}
+
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
     "toy_chip": (None, ["--preset", "chip"]),
@@ -44,6 +47,10 @@ CASES = {
                     "--barcodes", "500", "--seed", "31"], ["--preset", "atac"]),
     "b2_atac_bc2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "50", "--frag-min", "35",
                         "--barcodes", "300", "--seed", "32"], ["--preset", "atac", "-q", "0", "--bc-error-threshold", "2"]),
+    "s1_se_chip": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                   ["--preset", "chip"]),
+    "s4_se_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                       "--seed", "5"], ["--preset", "atac", "-q", "0"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
@@ -75,7 +82,10 @@ def main():
             extra = []
             if gen is not None and "--barcodes" in gen:
                 extra = ["-b", os.path.join(tmp, "d_bc.fq"), "--barcode-whitelist", os.path.join(tmp, "d.whitelist.txt")]
-            log = subprocess.run([REF] + flags + extra + ["-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out, "-t", "1"],
+            reads = ["-1", r1, "-2", r2]
+            if name in SINGLE_END:
+                reads = ["-1", r1 if SINGLE_END[name] == 1 else r2]
+            log = subprocess.run([REF] + flags + extra + ["-x", idx, "-r", fa] + reads + ["-o", out, "-t", "1"],
                                  stderr=subprocess.PIPE, check=True).stderr.decode()
             stats = {}
             for key, pat in (("num_reads", r"Number of reads: (\d+)"), ("num_mapped_reads", r"Number of mapped reads: (\d+)"),
@@ -87,7 +97,7 @@ def main():
                              ("num_corrected_barcode", r"Number of corrected barcodes: (\d+)")):
                 m = re.search(pat, log)
                 stats[key] = int(m.group(1)) if m else None
-            meta = {"generator_args": gen, "chromap_flags": flags, "reference_version": "0.3.3-r521",
+            meta = {"generator_args": gen, "chromap_flags": flags, "single_end_mate": SINGLE_END.get(name, 0), "reference_version": "0.3.3-r521",
                     "input_md5": dict({"fa": md5(fa), "r1": md5(r1), "r2": md5(r2)},
                                       **({"bc": md5(extra[1]), "whitelist": md5(extra[3])} if extra else {})),
                     "index_md5_reference_build": md5(idx), "bed_md5": md5(out), "reference_stderr_counters": stats}

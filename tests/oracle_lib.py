@@ -305,3 +305,25 @@ def write_bed_bc(oracle, rec, k, barcode_length, path):
     L.ora_write_bed_pe_bc.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_uint32, C.c_char_p]
     return L.ora_write_bed_pe_bc(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, barcode_length,
                                  path.encode())
+
+
+def map_single(oracle, b, off, threads=1):
+    import numpy as np
+    L = oracle.L
+    L.ora_map_single.restype = C.c_long
+    L.ora_map_single.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(OraStats)]
+    n = len(off) - 1
+    rec = (OraRecord * max(1, n))()
+    st = OraStats()
+    b = np.ascontiguousarray(b)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    k = L.ora_map_single(oracle.ctx, threads, n, 0, b.ctypes.data, off.ctypes.data, C.cast(rec, C.c_void_p), C.byref(st))
+    return rec, k, st
+
+
+def write_bed_se(oracle, rec, k, path):
+    L = oracle.L
+    L.ora_write_bed_se.restype = C.c_long
+    L.ora_write_bed_se.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_char_p]
+    return L.ora_write_bed_se(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, path.encode())

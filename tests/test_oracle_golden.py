@@ -23,6 +23,18 @@ def test_oracle_bed_matches_reference(case, tmp_path):
     o = ol.Oracle(None, fa, p)  # index built by the oracle's own indexer
     b1, o1 = ol.read_fastx(r1)
     b2, o2 = ol.read_fastx(r2)
+    if datasets.single_end_mate(case):
+        b, off = (b1, o1) if datasets.single_end_mate(case) == 1 else (b2, o2)
+        rec, k, st = ol.map_single(o, b, off, threads=2)
+        out = str(tmp_path / "o.bed")
+        ol.write_bed_se(o, rec, k, out)
+        assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["bed_md5"]
+        ref = meta["reference_stderr_counters"]
+        s = st.as_dict()
+        for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+            assert s[key] == ref[key], key
+        o.close()
+        return
     if datasets.has_barcodes(case):
         _check_barcode_case(case, meta, o, b1, o1, b2, o2, tmp_path)
         o.close()
