@@ -38,6 +38,10 @@ class Batch(C.Structure):
                 ("read1_offsets", C.c_void_p), ("read2_bases", C.c_void_p), ("read2_offsets", C.c_void_p)]
 
 
+class SingleBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("first_read_id", C.c_uint32), ("bases", C.c_void_p), ("offsets", C.c_void_p)]
+
+
 class Record(C.Structure):
     _fields_ = [("read_id", C.c_uint32), ("rid", C.c_uint32), ("fragment_start", C.c_uint32),
                 ("fragment_length", C.c_uint16), ("mapq", C.c_uint8), ("direction", C.c_uint8),
@@ -79,7 +83,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device",
-           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
+           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
@@ -121,6 +125,8 @@ def declare(L):
     sig("cmgpu_write_bed_pe", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_write_pairs", C.c_int64, [P(C.c_char_p), P(C.c_uint32), C.c_uint32, P(Params), C.c_void_p, C.c_uint64,
                                          P(C.c_char_p), C.c_uint32, C.c_char_p])
+    sig("cmgpu_map_single", C.c_int, [C.c_void_p, P(SingleBatch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
+    sig("cmgpu_write_bed_se", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
     sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])
     sig("cmgpu_compute_barcode_abundance", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint64)])

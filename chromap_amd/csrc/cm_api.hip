@@ -230,6 +230,7 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
   c->n_pairs = n;
   c->has_barcodes = false;
+  c->single = false;
   c->first_read_id = in->first_read_id;
   c->bases0 = n ? in->read1_offsets[n] : 0;
   c->bases1 = n ? in->read2_offsets[n] : 0;
@@ -251,6 +252,7 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
   d.n_seq = c->n_seq;
   d.p = c->p;
+  d.p.single = c->single ? 1 : 0;
   d.mq.len_coef = (const double *)c->len_coef.p; d.mq.nsec_break = (const uint32_t *)c->nsec_break.p; d.mq.n_break = c->n_break;
   d.n_pairs = c->n_pairs; d.first_read_id = c->first_read_id;
   d.rb0 = (const uint8_t *)c->rb0.p; d.rb1 = (const uint8_t *)c->rb1.p;
@@ -709,4 +711,36 @@ extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, con
   }
   *n_out = o;
   return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// single-end reads: the taskloop body of Chromap::MapSingleEndReads (chromap.h:385-472).
+// The batch is held as pairs whose second mate is empty.
+// ---------------------------------------------------------------------------------------
+extern "C" int cmgpu_map_single(cmgpu_ctx *c, const cmgpu_single_batch *in, cmgpu_record *out, uint64_t out_capacity,
+                                uint64_t *n_out, cmgpu_stats *stats) {
+  if (!c || !in || !out || !n_out) return CMGPU_EINVAL;
+  if (c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint32_t n = in->n_reads;
+  c->n_pairs = n;
+  c->has_barcodes = false;
+  c->single = true;
+  c->first_read_id = in->first_read_id;
+  c->bases0 = n ? in->offsets[n] : 0;
+  c->bases1 = 0;
+  *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(16) || c->ro0.ensure(((size_t)n + 1) * 4) || c->ro1.ensure(((size_t)n + 1) * 4)) {
+    cm_set_error(c, "out of device memory (reads)");
+    return CMGPU_ENOMEM;
+  }
+  HIPCHECK(c, hipMemcpyAsync(c->rb0.p, in->bases, c->bases0, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(c, hipMemcpyAsync(c->ro0.p, in->offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(c, hipMemsetAsync(c->ro1.p, 0, ((size_t)n + 1) * 4, c->stream));
+  HIPCHECK(c, hipStreamSynchronize(c->stream));
+  uint64_t k = 0;
+  int rc = cmgpu_map_resident(c, &k, stats);
+  if (rc) return rc;
+  return cmgpu_download_records(c, out, out_capacity, n_out);
 }

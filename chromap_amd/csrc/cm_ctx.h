@@ -48,6 +48,7 @@ struct cmgpu_ctx {
   uint32_t wl_mask = 0, wl_size = 0, bc_len = 0;
   uint64_t wl_num_sample = 0;
   bool has_barcodes = false;  // resident batch carries barcodes
+  bool single = false;        // resident batch is single-end
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;

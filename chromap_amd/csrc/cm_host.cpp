@@ -362,3 +362,49 @@ extern "C" int64_t cmgpu_write_bed_pe_bc(const char *const *names, uint32_t n_se
   fclose(f);
   return lines;
 }
+
+// single-end bulk BED (MappingWithoutBarcode): see include/chromap_amd.h
+extern "C" int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_sequences, const cmgpu_params *p, cmgpu_record *rec,
+                                      uint64_t n, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return CMGPU_EIO;
+  std::sort(rec, rec + n, [](const cmgpu_record &a, const cmgpu_record &b) {
+    return std::tie(a.rid, a.fragment_start, a.fragment_length, a.mapq, a.direction, a.is_unique, a.read_id) <
+           std::tie(b.rid, b.fragment_start, b.fragment_length, b.mapq, b.direction, b.is_unique, b.read_id);
+  });
+  std::string buf;
+  buf.reserve(1 << 20);
+  int64_t lines = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    cmgpu_record last = rec[i];
+    uint32_t dups = 1;
+    uint64_t j = i + 1;
+    if (p->remove_pcr_duplicates && p->low_memory_mode) {
+      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start) {
+        ++dups;
+        if (rec[j].mapq > last.mapq) last = rec[j];
+        ++j;
+      }
+    }
+    if (last.mapq >= p->mapq_threshold && last.rid < n_sequences) {
+      if (p->tn5_shift) { if (last.direction == 1) last.fragment_start += 4; else last.fragment_length -= 5; }
+      buf.append(names[last.rid]);
+      buf.push_back('\t');
+      put_u32(buf, last.fragment_start);
+      buf.push_back('\t');
+      put_u32(buf, last.fragment_start + last.fragment_length);
+      buf.append("\tN\t");
+      put_u32(buf, last.mapq);
+      buf.append(last.direction ? "\t+\t" : "\t-\t");
+      put_u32(buf, dups > 255 ? 255 : dups);
+      buf.push_back('\n');
+      ++lines;
+      if (buf.size() > (1 << 20) - 256) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    }
+    i = j;
+  }
+  if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  return lines;
+}

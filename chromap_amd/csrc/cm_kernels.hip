@@ -74,8 +74,8 @@ __global__ __launch_bounds__(64) void k_s6b_sample(CmDev d, uint32_t n_chunks) {
     unsigned long long m = __ballot(multi);
     if (m == 0) continue;
     if (threadIdx.x == 0) {
-      if (!seeded) { cm_mt_seed(g, 11); seeded = true; }
       while (m) {
+        if (!seeded || d.p.single) { cm_mt_seed(g, 11); seeded = true; }  // single-end: fresh generator per read
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
         const uint32_t pr = base + (uint32_t)l;
@@ -214,11 +214,12 @@ __global__ __launch_bounds__(CM_BLOCK) void k_stats(CmDev d, uint32_t n, unsigne
     if (d.alive[pair]) {
       v[0] = d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
       const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
-      if (nd1 > 0 && nd2 > 0) {
+      const unsigned long long per = d.p.single ? 1ull : 2ull;  // reads per item
+      if (nd1 > 0 && (d.p.single || nd2 > 0)) {
         const int nb = d.pe_nbest[pair];
-        if (nb == 1) v[3] = 2;
-        v[1] = 2ull * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
-        if (nb > 0) v[2] = 2;
+        if (nb == 1) v[3] = per;
+        v[1] = per * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
+        if (nb > 0) v[2] = per;
         if (nb > 1 && nb <= d.p.drop_rep) v[4] = 1;
       }
     }

@@ -287,10 +287,10 @@ CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32
 CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
   const uint32_t raw1 = d.ro0[pair + 1] - d.ro0[pair], raw2 = d.ro1[pair + 1] - d.ro1[pair];
   uint32_t len1 = raw1, len2 = raw2;
-  bool ok = raw1 >= (uint32_t)d.p.min_read_len && raw2 >= (uint32_t)d.p.min_read_len;
+  bool ok = raw1 >= (uint32_t)d.p.min_read_len && (d.p.single || raw2 >= (uint32_t)d.p.min_read_len);
   // pairs whose barcode is not (correctable to) a whitelisted one are skipped (chromap.h:908-909)
   if (d.bcb && !d.bc_ok[pair] && !d.p.bc_keep) ok = false;
-  if (ok && d.p.trim) {
+  if (ok && d.p.trim && !d.p.single) {
     const uint8_t *s1 = d.rb0 + d.ro0[pair], *s2 = d.rb1 + d.ro1[pair];
     const bool swap = !(raw1 <= raw2);
     const uint8_t *rd1 = swap ? s2 : s1;        // "read1": the shorter read, forward
@@ -337,7 +337,7 @@ CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
     }
   }
   d.rlen[2 * pair] = ok ? len1 : 0;
-  d.rlen[2 * pair + 1] = ok ? len2 : 0;
+  d.rlen[2 * pair + 1] = (ok && !d.p.single) ? len2 : 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -632,8 +632,8 @@ CM_HD uint32_t cm_probe(const uint64_t *bkt, uint32_t bmask, uint64_t hash, uint
 // ---------------------------------------------------------------------------------------
 CM_HD void cm_s3a_count(const CmDev &d, uint32_t r) {
   const uint32_t pair = r >> 1;
-  // BothEndsHaveMinimizers (chromap.h:936)
-  const bool live = d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0;
+  // BothEndsHaveMinimizers (chromap.h:936); single-end: minimizers_.size() > 0 (chromap.h:416)
+  const bool live = d.p.single ? ((r & 1) == 0 && d.mm_cnt[r] > 0) : (d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0);
   uint32_t tot1 = 0, tot2 = 0, rep_len = 0, rep_cnt = 0, prev = ~0u;
   if (live) {
     const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
@@ -853,11 +853,11 @@ CM_HD const uint8_t *cm_c0_ncnt(const CmDev &d, uint32_t r) { return d.hcnt + d.
 CM_HD void cm_s4a_rescue_count(const CmDev &d, uint32_t r) {
   const uint32_t pair = r >> 1, o = r ^ 1u;
   d.aug[r] = 0; d.res_neg[r] = 0; d.res_pos[r] = 0; d.resc_n[r] = 0; d.resc_p[r] = 0;
-  const bool live = d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0;
+  const bool live = d.p.single ? ((r & 1) == 0 && d.mm_cnt[r] > 0) : (d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0);
   uint32_t ncp = d.ncp[r], ncn = d.ncn[r];
   if (live) {
     const uint32_t mm_count = d.mm_cnt[r];
-    bool augment = !d.p.split;  // split alignment never supplements (chromap.h:1021)
+    bool augment = !d.p.split && !d.p.single;  // split alignment / single-end never supplement (chromap.h:1021)
     const uint8_t *pc = cm_c0_pcnt(d, r), *nc = cm_c0_ncnt(d, r);
     for (uint32_t i = 0; augment && i < ncp; ++i) if (pc[i] >= mm_count / 2) { augment = false; break; }
     if (augment) for (uint32_t i = 0; i < ncn; ++i) if (nc[i] >= mm_count / 2) { augment = false; break; }
@@ -1022,7 +1022,18 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
   d.fcp[r1] = d.fcn[r1] = d.fcp[r2] = d.fcn[r2] = 0;
   d.alive[pair] = 0;
   d.force0[pair] = 0;
-  if (d.m_tot[r1] == 0 && d.m_tot[r2] == 0 && !(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return;
+  if (d.p.single) {  // chromap.h:442-445: candidates go straight to verification
+    if (d.mm_cnt[r1] == 0 || d.mcp[r1] + d.mcn[r1] == 0) return;
+    const uint64_t *mp = cm_m_pos(d, r1), *mn = cm_m_neg(d, r1);
+    const uint8_t *mpc = cm_m_pcnt(d, r1), *mnc = cm_m_ncnt(d, r1);
+    uint64_t *fp = cm_f_pos(d, r1), *fn = cm_f_neg(d, r1);
+    uint8_t *fpc = cm_f_pcnt(d, r1), *fnc = cm_f_ncnt(d, r1);
+    for (uint32_t i = 0; i < d.mcp[r1]; ++i) { fp[i] = mp[i]; fpc[i] = mpc[i]; }
+    for (uint32_t i = 0; i < d.mcn[r1]; ++i) { fn[i] = mn[i]; fnc[i] = mnc[i]; }
+    d.fcp[r1] = d.mcp[r1]; d.fcn[r1] = d.mcn[r1];
+    d.alive[pair] = 1;
+    return;
+  }
   if (!(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return;
   int ret = 0;
   for (uint32_t r = r1; r <= r2; ++r) {
@@ -1769,6 +1780,46 @@ CM_HD void cm_split_pairing(const CmDev &d, uint32_t pair, int64_t want, CmPe &p
   pe.n_best = seen > 0x7fffffff ? 0x7fffffff : (int)seen;
 }
 
+
+// single-end: ProcessBestMappingsForSingleEndRead (mapping_generator.h:256-344) for the
+// `choice`-th best mapping (draft mappings in emission order, + strand first), MAPQ with
+// max_num_error_difference = error_threshold, EmplaceBackSingleEndMappingRecord
+// <MappingWithoutBarcode> (mapping_generator.cc:7-16)
+CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice) {
+  const uint32_t r = 2 * pair;
+  const int me = d.min_err[r];
+  uint32_t idx = 0;
+  for (int strand = 0; strand < 2; ++strand) {
+    const uint64_t *dp = cm_d_pos(d, r, strand);
+    const int16_t *de = cm_d_err(d, r, strand);
+    const uint32_t n = strand ? d.ndn[r] : d.ndp[r];
+    for (uint32_t mi = 0; mi < n; ++mi) {
+      if ((int)de[mi] > me) continue;
+      if (idx == choice) {
+        const uint32_t L = d.rlen[r];
+        const CmSpan sp = cm_ref_start_end(d, dp[mi], de[mi], strand, cm_read_ptr(d, r), (int)L);
+        const uint16_t al = (uint16_t)(sp.ref_end - sp.ref_start + 1);
+        const uint8_t mapq = cm_mapq_single(d, de[mi], al, (int)L, d.p.e, d.second_err[r], d.n_best[r], d.n_second[r], d.rep_len[r]);
+        uint8_t *o = d.rec + (uint64_t)pair * 24;
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+        uint16_t *o16 = reinterpret_cast<uint16_t *>(o);
+        o32[0] = d.first_read_id + pair;
+        o32[1] = sp.rid;
+        o32[2] = sp.ref_start;
+        o16[6] = al;
+        o[14] = mapq & 63;
+        o[15] = strand == 0 ? 1 : 0;
+        o[16] = d.n_best[r] == 1 ? 1 : 0;
+        o[17] = 1;
+        o16[9] = 0; o16[10] = 0; o16[11] = 0;
+        d.rec_ok[pair] = 1;
+        return;
+      }
+      ++idx;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // S6a: per pair -- sort draft mappings by position, pairing sweeps in both orientations
 //      (GenerateBestMappingsForPairedEndRead, mapping_generator.h:160-253), record for pairs
@@ -1781,6 +1832,13 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
   d.pe_choice[pair] = 0;
   if (!d.alive[pair]) return;
   const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
+  if (d.p.single) {  // GenerateBestMappingsForSingleEndRead (mapping_generator.h:115-157)
+    if (nd1 == 0) return;
+    d.pe_nbest[pair] = d.n_best[r1];
+    d.pe_min[pair] = d.min_err[r1]; d.pe_second[pair] = d.second_err[r1]; d.pe_nsecond[pair] = d.n_second[r1];
+    if (d.n_best[r1] == 1) cm_emit_single_record(d, pair, 0);
+    return;
+  }
   if (!(nd1 > 0 && nd2 > 0)) return;  // chromap.h:1092-1093
   if (d.p.split) {  // drafts stay in emission order (chromap.h:1099-1106)
     CmPe sp;
@@ -1887,7 +1945,7 @@ CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
     const int nb = d.pe_nbest[pair];
     if (nb <= 1) continue;
     if (nb > d.p.drop_rep) continue;  // mapping_generator.h:193-196: returns before drawing
-    if (!seeded) { cm_mt_seed(g, 11); seeded = true; }
+    if (!seeded || d.p.single) { cm_mt_seed(g, 11); seeded = true; }  // single-end: a fresh generator per read (mapping_generator.h:128)
     int choice = 0;
     for (int i = 1; i < nb; ++i) {
       const int j = cm_mt_uniform(g, i);
@@ -1908,6 +1966,7 @@ CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
   pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];
   pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
   const int64_t want = (int64_t)d.pe_choice[pair];
+  if (d.p.single) { cm_emit_single_record(d, pair, (uint32_t)want); return; }
   if (d.p.split) {
     CmPe sp;
     cm_split_pairing(d, pair, want, sp);

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import BarcodeBatch, Batch, IndexView, Params, Record, RecordBc, RefView, Stats
+from ._capi import SingleBatch, BarcodeBatch, Batch, IndexView, Params, Record, RecordBc, RefView, Stats
 
 
 class ChromapError(RuntimeError):
@@ -119,6 +119,25 @@ class ChromapGPU:
                                     C.byref(self.stats))
         self._check(rc, self.ctx)
         return rec, int(n.value)
+
+    # ---- single-end
+    def map_single(self, b, off, first_read_id=0):
+        self._keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
+        n = len(self._keep[1]) - 1
+        bt = SingleBatch(n, first_read_id, self._keep[0].ctypes.data, self._keep[1].ctypes.data)
+        rec = (Record * max(1, n))()
+        k = C.c_uint64(0)
+        self._check(self.L.cmgpu_map_single(self.ctx, C.byref(bt), C.cast(rec, C.c_void_p), n, C.byref(k), C.byref(self.stats)),
+                    self.ctx)
+        return rec, int(k.value)
+
+    def write_bed_se(self, rec, n, path, params=None):
+        p = params if params is not None else self.params
+        names = (C.c_char_p * len(self.names))(*self.names)
+        k = self.L.cmgpu_write_bed_se(names, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, path.encode())
+        if k < 0:
+            raise ChromapError("cannot write %s" % path)
+        return int(k)
 
     # ---- single-cell barcodes
     def set_whitelist_file(self, path, barcode_length):

@@ -188,6 +188,23 @@ const char *cmgpu_last_error(const cmgpu_ctx *ctx);
 int cmgpu_map_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,
                     uint64_t *n_out, cmgpu_stats *stats);
 
+/* Single-end reads: replaces the taskloop body of Chromap::MapSingleEndReads
+ * (src/chromap.h:385-472) for bulk data; records are MappingWithoutBarcode's constructor
+ * arguments (src/bed_mapping.h:67-83) stored in the cmgpu_record layout: alignment-length
+ * fields 0, fragment = the read's alignment, direction 1 = + strand. */
+typedef struct cmgpu_single_batch {
+  uint32_t n_reads;
+  uint32_t first_read_id;
+  const char *bases;
+  const uint32_t *offsets; /* n_reads + 1 */
+} cmgpu_single_batch;
+int cmgpu_map_single(cmgpu_ctx *ctx, const cmgpu_single_batch *in, cmgpu_record *out, uint64_t out_capacity,
+                     uint64_t *n_out, cmgpu_stats *stats);
+/* BED for single-end bulk records: sort (src/bed_mapping.h:90-95), duplicate removal on the
+ * start position (:96-99), MAPQ filter, Tn5 shift (:104-110), line src/mapping_writer.cc:44-52 */
+int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
+                           cmgpu_record *records, uint64_t n_records, const char *out_path);
+
 /* ---- single-cell barcodes (K6) --------------------------------------------------------
  * cmgpu_set_whitelist: Chromap::LoadBarcodeWhitelist (src/chromap.cc:388-490): keys =
  * GenerateSeedFromSequence of every whitelist line (cmgpu_load_whitelist_file produces them).

@@ -30,7 +30,7 @@ struct EmuBarcodes {
 static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
                          const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
                          uint32_t *dbg_mm_cnt /* 2n or NULL */, uint32_t *dbg_ncand /* 2n */,
-                         uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */, const EmuBarcodes *eb) {
+                         uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */, const EmuBarcodes *eb, bool single = false) {
   const uint32_t n = in->n_pairs, n2 = 2 * n;
   CmDev d;
   memset(&d, 0, sizeof(d));
@@ -56,6 +56,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   p.f1 = params->max_seed_frequency1; p.max_insert = params->max_insert_size; p.min_read_len = params->min_read_length;
   p.max_best = params->max_num_best_mappings; p.drop_rep = params->drop_repetitive_reads; p.trim = params->trim_adapters; p.split = params->split_alignment ? 1 : 0;
   p.bc_err = params->bc_error_threshold; p.bc_keep = params->output_mappings_not_in_whitelist ? 1 : 0; p.bc_prob = params->bc_probability_threshold;
+  p.single = single ? 1 : 0;
   p.k = index->kmer_size; p.w = index->window_size; p.lanes = p.split ? 0 : (p.e < 8 ? 8 : (p.e < 16 ? 4 : 0));
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
@@ -167,11 +168,12 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     if (d.alive[i]) {
       st[CM_ST_CAND] += d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
       const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
-      if (nd1 > 0 && nd2 > 0) {
+      const unsigned long long per = single ? 1ull : 2ull;
+      if (nd1 > 0 && (single || nd2 > 0)) {
         const int nbst = d.pe_nbest[i];
-        if (nbst == 1) st[CM_ST_UNIQ] += 2;
-        st[CM_ST_MAPPINGS] += 2ull * (unsigned long long)(nbst < p.max_best ? nbst : p.max_best);
-        if (nbst > 0) st[CM_ST_MAPPED] += 2;
+        if (nbst == 1) st[CM_ST_UNIQ] += per;
+        st[CM_ST_MAPPINGS] += per * (unsigned long long)(nbst < p.max_best ? nbst : p.max_best);
+        if (nbst > 0) st[CM_ST_MAPPED] += per;
         if (nbst > 1 && nbst <= p.drop_rep) st[CM_ST_MULTI] += 1;
       }
     }
@@ -206,6 +208,13 @@ extern "C" int hostemu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_
                                  const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
                                  uint32_t *dbg_mm_cnt, uint32_t *dbg_ncand, uint32_t *dbg_ndraft, int32_t *dbg_nbest) {
   return emu_map_pairs(index, ref, params, in, out, n_out, stats, dbg_mm_cnt, dbg_ncand, dbg_ndraft, dbg_nbest, nullptr);
+}
+
+extern "C" int hostemu_map_single(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                  const cmgpu_single_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats) {
+  std::vector<uint32_t> zero((size_t)in->n_reads + 1, 0);
+  cmgpu_batch b{in->n_reads, in->first_read_id, in->bases, in->offsets, "", zero.data()};
+  return emu_map_pairs(index, ref, params, &b, out, n_out, stats, nullptr, nullptr, nullptr, nullptr, nullptr, true);
 }
 
 extern "C" int hostemu_map_pairs_bc(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,

@@ -72,6 +72,25 @@ class HostEmu:
         assert rc == 0, rc
         return rec, int(k.value), st, dbg
 
+    def map_single(self, b, off):
+        n = len(off) - 1
+        keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
+        bt = _capi.SingleBatch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data)
+        rec = (_capi.Record * max(1, n))()
+        k = C.c_uint64(0)
+        st = _capi.Stats()
+        f = self.L.hostemu_map_single
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(_capi.IndexView), C.POINTER(_capi.RefView), C.POINTER(_capi.Params),
+                      C.POINTER(_capi.SingleBatch), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(_capi.Stats)]
+        assert f(C.byref(self.idx), C.byref(self.ref), C.byref(self.p), C.byref(bt), C.cast(rec, C.c_void_p), C.byref(k),
+                 C.byref(st)) == 0
+        return rec, int(k.value), st
+
+    def write_bed_se(self, rec, n, path):
+        names = (C.c_char_p * len(self.names))(*self.names)
+        return self.L.cmgpu_write_bed_se(names, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n, path.encode())
+
     def map_pairs_bc(self, b1, o1, b2, o2, bc, bcq, bco, wl_keys):
         n = len(o1) - 1
         keep = [np.ascontiguousarray(x) for x in (b1, o1, b2, o2, bc, bcq, bco, wl_keys)]

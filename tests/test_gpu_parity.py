@@ -129,3 +129,23 @@ def test_barcoded_bed_matches_reference(case, tmp_path):
                 "num_barcode_in_whitelist", "num_corrected_barcode"):
         assert s[key] == ref[key], key
     g.close()
+
+
+@pytest.mark.parametrize("case", datasets.SE_CASES)
+def test_single_end_bed_matches_reference(case, tmp_path):
+    from chromap_amd import ChromapGPU
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    g = ChromapGPU(idx, fa, preset=preset, **kw)
+    b, off = ol.read_fastx(r1 if datasets.single_end_mate(case) == 1 else r2)
+    rec, k = g.map_single(b, off)
+    out = str(tmp_path / "g.bed")
+    g.write_bed_se(rec, k, out)
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    s = g.stats.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    g.close()

@@ -36,6 +36,24 @@ def test_barcode_stage_matches_reference(case, tmp_path):
         assert s[key] == ref[key], key
 
 
+@pytest.mark.parametrize("case", datasets.SE_CASES)
+def test_single_end_stage_matches_reference(case, tmp_path):
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    h = he.HostEmu(idx, fa, he.params(preset, **kw))
+    b, off = ol.read_fastx(r1 if datasets.single_end_mate(case) == 1 else r2)
+    rec, k, st = h.map_single(b, off)
+    out = str(tmp_path / "e.bed")
+    h.write_bed_se(rec, k, out)
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+
+
 @pytest.mark.parametrize("case", datasets.BED_CASES + datasets.HIC_CASES)
 def test_stage_functions_match_reference(case, tmp_path):
     meta = datasets.case_meta(case)
