@@ -149,3 +149,21 @@ def test_single_end_bed_matches_reference(case, tmp_path):
     for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
         assert s[key] == ref[key], key
     g.close()
+
+
+import fuzz_data  # noqa: E402
+import test_hostemu_fuzz as _fz  # noqa: E402
+
+
+@pytest.mark.parametrize("cfg", fuzz_data.CONFIGS, ids=[str(c[0]) for c in fuzz_data.CONFIGS])
+def test_fuzz_gpu_vs_oracle(cfg, tmp_path):
+    """adversarial repeat-rich data: every record field and the counters, GPU vs oracle"""
+    from chromap_amd import ChromapGPU
+
+    def factory(idx, fa, preset, gkw, b1, o1, b2, o2):
+        g = ChromapGPU(idx, fa, preset=preset, **gkw)
+        rec, k = g.map_pairs(b1, o1, b2, o2)
+        st = g.stats.as_dict()
+        g.close()
+        return rec, k, st
+    _fz.run_case(factory, cfg, tmp_path)

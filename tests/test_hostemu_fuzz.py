@@ -1,0 +1,62 @@
+"""Oracle vs the product's stage functions (host emulation) on adversarial repeat-rich data."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fuzz_data
+import hostemu_lib as he
+import oracle_lib as ol
+
+CAPI_NAMES = {"max_seed_freq0": "max_seed_frequency0", "max_seed_freq1": "max_seed_frequency1"}
+
+
+def _tuples_o(rec, k, hic):
+    if hic:
+        pr = C.cast(rec, C.POINTER(ol.OraPairsRecord))
+        return sorted((pr[i].read_id, pr[i].rid1, pr[i].rid2, pr[i].pos1, pr[i].pos2, pr[i].strand1, pr[i].strand2, pr[i].mapq,
+                       pr[i].is_unique) for i in range(k))
+    return sorted((rec[i].read_id, rec[i].rid, rec[i].fragment_start, rec[i].fragment_length, rec[i].mapq, rec[i].direction,
+                   rec[i].is_unique, rec[i].pos_aln_len, rec[i].neg_aln_len) for i in range(k))
+
+
+def _tuples_g(rec, k, hic):
+    from chromap_amd import _capi
+    if hic:
+        pr = C.cast(rec, C.POINTER(_capi.PairsRecord))
+        return sorted((pr[i].read_id, pr[i].rid1, pr[i].rid2, pr[i].pos1, pr[i].pos2, pr[i].strand1, pr[i].strand2, pr[i].mapq,
+                       pr[i].is_unique) for i in range(k))
+    return sorted((rec[i].read_id, rec[i].rid, rec[i].fragment_start, rec[i].fragment_length, rec[i].mapq, rec[i].direction,
+                   rec[i].is_unique, rec[i].positive_alignment_length, rec[i].negative_alignment_length) for i in range(k))
+
+
+def run_case(mapper_factory, cfg, tmp_path):
+    seed, preset, kw, gen = cfg
+    fa, b1, o1, b2, o2 = fuzz_data.write_case(str(tmp_path), seed, **gen)
+    okw = dict(kw)
+    if preset == "hic":
+        okw.setdefault("error_threshold", 4)
+    o = ol.Oracle(None, fa, ol.params(preset, **kw))
+    idx = str(tmp_path / "f.idx")
+    assert o.L.ora_index_save(idx.encode(), C.byref(o.idx)) == 0
+    orec, ok, ost, _ = o.map_pairs(b1, o1, b2, o2)
+    gkw = {CAPI_NAMES.get(k, k): v for k, v in kw.items()}
+    grec, gk, gst = mapper_factory(idx, fa, preset, gkw, b1, o1, b2, o2)
+    hic = preset == "hic"
+    assert gk == ok
+    assert _tuples_g(grec, gk, hic) == _tuples_o(orec, ok, hic)
+    od = ost.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert gst[key] == od[key], key
+    # the data really is adversarial: multi-mappers and rescue are exercised
+    return od, gst
+
+
+@pytest.mark.parametrize("cfg", fuzz_data.CONFIGS, ids=[str(c[0]) for c in fuzz_data.CONFIGS])
+def test_fuzz_stage_functions(cfg, tmp_path):
+    def factory(idx, fa, preset, gkw, b1, o1, b2, o2):
+        h = he.HostEmu(idx, fa, he.params(preset, **gkw))
+        rec, k, st, _ = h.map_pairs(b1, o1, b2, o2)
+        return rec, k, st.as_dict()
+    od, gst = run_case(factory, cfg, tmp_path)
+    assert od["num_mapped_reads"] > 0
