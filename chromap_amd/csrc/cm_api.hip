@@ -234,6 +234,13 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   c->first_read_id = in->first_read_id;
   c->bases0 = n ? in->read1_offsets[n] : 0;
   c->bases1 = n ? in->read2_offsets[n] : 0;
+  uint32_t mx = 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t l1 = in->read1_offsets[i + 1] - in->read1_offsets[i], l2 = in->read2_offsets[i + 1] - in->read2_offsets[i];
+    mx = l1 > mx ? l1 : mx;
+    mx = l2 > mx ? l2 : mx;
+  }
+  c->max_read_len = mx;
   if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(c->bases1 + 16) || c->ro0.ensure(((size_t)n + 1) * 4) || c->ro1.ensure(((size_t)n + 1) * 4)) {
     cm_set_error(c, "out of device memory (reads)");
     return CMGPU_ENOMEM;
@@ -311,25 +318,19 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     cm_launch_k_s0b_barcode(d, n, s);
     mark(c, "s0b_barcode");
   }
-  // S0: length filter + adapter trimming
-  cm_launch_k_s0_prep(d, n, s);
-  mark(c, "s0_trim");
-  // S1: minimizers into per-read slot ranges
-  cm_launch_k_slot_cap(d, n2, (uint32_t *)c->cap.p, s);
-  cm_scan_u32((const uint32_t *)c->cap.p, d.mm_cap_off, n2, (uint32_t *)c->scan_tmp.p, s);
-  const size_t slot_cap = c->bases0 + c->bases1 + 1;  // sum over reads of (len-k+1) <= total bases
-  if (c->slot_hash.ensure(slot_cap * 8) || c->slot_ps.ensure(slot_cap * 4) || c->mm_hash.ensure(slot_cap * 8 + 8) ||
-      c->mm_ps.ensure(slot_cap * 4 + 4) || c->pr_val.ensure(slot_cap * 8 + 8) || c->pr_kind.ensure(slot_cap + 4)) {
-    cm_set_error(c, "out of device memory (minimizers)");
-    return CMGPU_ENOMEM;
-  }
-  cm_fill_dev(c, d);
-  uint32_t *mm_total = (uint32_t *)((unsigned long long *)c->stats.p + CM_ST_N - 2);
-  cm_launch_k_s1_minimizers(d, n2, mm_total, s);
+  // S0 + S1a: length filter, adapter trimming, minimizer counts (reads staged through LDS)
+  cm_launch_k_prep_count(d, n, c->max_read_len, s);
+  cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
   uint32_t n_mm = 0;
-  HIPCHECK(c, hipMemcpyAsync(&n_mm, mm_total, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
   HIPCHECK(c, hipStreamSynchronize(s));
-  mark(c, "s1_minimizers");
+  mark(c, "s0_s1a_trim_count");
+  if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
+      c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
+  cm_fill_dev(c, d);
+  // S1b: minimizers written to their dense positions
+  cm_launch_k_mm_fill(d, n, c->max_read_len, s);
+  mark(c, "s1b_minimizers");
   // S2: index probe (the graded kernel)
   if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
   cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);
@@ -729,6 +730,9 @@ extern "C" int cmgpu_map_single(cmgpu_ctx *c, const cmgpu_single_batch *in, cmgp
   c->first_read_id = in->first_read_id;
   c->bases0 = n ? in->offsets[n] : 0;
   c->bases1 = 0;
+  uint32_t mx = 1;
+  for (uint32_t i = 0; i < n; ++i) { const uint32_t l = in->offsets[i + 1] - in->offsets[i]; mx = l > mx ? l : mx; }
+  c->max_read_len = mx;
   *n_out = 0;
   if (n == 0) return CMGPU_OK;
   if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(16) || c->ro0.ensure(((size_t)n + 1) * 4) || c->ro1.ensure(((size_t)n + 1) * 4)) {

@@ -35,6 +35,7 @@ struct cmgpu_ctx {
   // resident batch
   uint32_t n_pairs = 0, first_read_id = 0;
   size_t bases0 = 0, bases1 = 0;
+  uint32_t max_read_len = 1;
   DevBuf rb0, rb1, ro0, ro1;
   // per-read / per-pair arrays (names match CmDev)
   DevBuf rlen, cap, mm_cap_off, slot_hash, slot_ps, mm_cnt, mm_off, mm_hash, mm_ps, pr_val, pr_kind;

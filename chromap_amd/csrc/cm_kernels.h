@@ -6,8 +6,8 @@
 #include "cm_types.h"
 
 #define CM_DECL_LAUNCH(kname) void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s);
-CM_DECL_LAUNCH(k_s0_prep)
-void cm_launch_k_s1_minimizers(const CmDev &d, uint32_t n, uint32_t *total, hipStream_t s);
+void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
+void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
 CM_DECL_LAUNCH(k_s3b_candidates)
 CM_DECL_LAUNCH(k_s4a_rescue_count)

@@ -13,40 +13,59 @@
     if (i < n) fn(d, i);                                                     \
   }
 
-CM_ITEM_KERNEL(k_s0_prep, cm_s0_prep)
 
-// S1 with fused compaction: every read's minimizers go to its slot range first (the state
-// machine emits a data-dependent number of them); the block then reserves one contiguous
-// range of the dense arrays with a single atomic and every lane copies its own entries
-// there.  The dense order is block-arrival order; consumers go through mm_off[r]/mm_cnt[r].
-__global__ __launch_bounds__(CM_BLOCK) void k_s1_minimizers(CmDev d, uint32_t n, uint32_t *__restrict__ total) {
-  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  uint32_t cnt = 0;
-  if (i < n) {
-    cm_s1_minimizers(d, i);
-    cnt = d.mm_cnt[i];
-  }
-  __shared__ uint32_t wsum[CM_BLOCK / 64];
-  __shared__ uint32_t block_base;
-  uint32_t inc = cnt;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) wsum[wv] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int j = 0; j < CM_BLOCK / 64; ++j) { const uint32_t t = wsum[j]; wsum[j] = tot; tot += t; }
-    block_base = tot ? atomicAdd(total, tot) : 0;
-  }
-  __syncthreads();
-  if (i < n) {
-    d.mm_off[i] = block_base + wsum[wv] + inc - cnt;
-    cm_s1b_compact(d, i);
-  }
+
+// ---------------------------------------------------------------------------------------
+// Read staging: a block owns PB consecutive pairs; the bytes of their mate-0 reads are one
+// contiguous range of rb0 (likewise rb1), copied to LDS with coalesced 16-byte loads so that
+// every read byte leaves HBM once (per-thread strided byte loads thrash L1/L2: rocprofv3
+// FETCH_SIZE showed 14x-40x the read bytes for the first version of these kernels).
+// LDS layout: [mate-0 range][mate-1 range], each starting at the 16-byte-aligned address
+// below its first byte.  Returns this thread's read pointer in LDS.
+// ---------------------------------------------------------------------------------------
+extern __shared__ __align__(16) uint8_t cm_lds[];
+
+__device__ __forceinline__ void cm_stage_range(uint8_t *dst, const uint8_t *src, uint64_t a0, uint64_t g1) {
+  for (uint64_t off = a0 + (uint64_t)threadIdx.x * 16; off < g1; off += (uint64_t)blockDim.x * 16)
+    *reinterpret_cast<uint4 *>(dst + (off - a0)) = *reinterpret_cast<const uint4 *>(src + off);
 }
+
+// stages the reads of pairs [p0, p1) and returns the LDS pointers of pair `pair`'s reads
+struct CmStaged { const uint8_t *m0, *m1; };
+__device__ __forceinline__ CmStaged cm_stage_pairs(const CmDev &d, uint32_t p0, uint32_t p1, uint32_t pair, uint32_t lds_half) {
+  const uint64_t g0a = d.ro0[p0], g0b = d.ro0[p1], g1a = d.ro1[p0], g1b = d.ro1[p1];
+  const uint64_t a0 = g0a & ~15ull, a1 = g1a & ~15ull;
+  uint8_t *l0 = cm_lds, *l1 = cm_lds + lds_half;
+  cm_stage_range(l0, d.rb0, a0, g0b);
+  cm_stage_range(l1, d.rb1, a1, g1b);
+  __syncthreads();
+  CmStaged s;
+  s.m0 = l0 + (d.ro0[pair < p1 ? pair : p0] - a0);
+  s.m1 = l1 + (d.ro1[pair < p1 ? pair : p0] - a1);
+  return s;
+}
+
+// S0 + S1 count, fused: threads [0,PB) trim their pair, then all 2*PB threads (one per read)
+// run the minimizer state machine in counting mode.  blockDim.x = 2*PB.
+__global__ void k_prep_count(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
+  const uint32_t PB = blockDim.x >> 1;
+  const uint32_t p0 = blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
+  const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp;
+  const CmStaged s = cm_stage_pairs(d, p0, p1, pair, lds_half);
+  if (t < PB && pair < p1) cm_s0_prep_ptr(d, pair, s.m0, s.m1);
+  __syncthreads();  // rlen of both mates is read below by other threads of this block
+  if (pair < p1) cm_s1_count(d, 2 * pair + (t < PB ? 0 : 1), t < PB ? s.m0 : s.m1);
+}
+
+// S1 fill: same staging, minimizers written directly to their dense positions
+__global__ void k_mm_fill(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
+  const uint32_t PB = blockDim.x >> 1;
+  const uint32_t p0 = blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
+  const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp;
+  const CmStaged s = cm_stage_pairs(d, p0, p1, pair, lds_half);
+  if (pair < p1) cm_s1_fill(d, 2 * pair + (t < PB ? 0 : 1), t < PB ? s.m0 : s.m1);
+}
+
 CM_ITEM_KERNEL(k_s3a_count, cm_s3a_count)
 CM_ITEM_KERNEL(k_s3b_candidates, cm_s3b_candidates)
 CM_ITEM_KERNEL(k_s4a_rescue_count, cm_s4a_rescue_count)
@@ -351,7 +370,6 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + CM_BLOCK - 1) / CM_BL
   void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s) {                  \
     if (n) hipLaunchKernelGGL(kname, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);         \
   }
-CM_LAUNCH(k_s0_prep)
 CM_LAUNCH(k_s3a_count)
 CM_LAUNCH(k_s3b_candidates)
 CM_LAUNCH(k_s4a_rescue_count)
@@ -361,8 +379,26 @@ CM_LAUNCH(k_s5_verify)
 CM_LAUNCH(k_s6a_pair)
 CM_LAUNCH(k_s6c_multi)
 
-void cm_launch_k_s1_minimizers(const CmDev &d, uint32_t n, uint32_t *total, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_s1_minimizers, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, total);
+// threads per block / LDS bytes for the read-staging kernels, from the longest read of the batch
+static inline void staging_geometry(uint32_t max_read_len, uint32_t *threads, uint32_t *lds_half) {
+  uint32_t pb = 128;  // pairs per block
+  while (pb > 16 && (uint64_t)pb * max_read_len + 64 > 24 * 1024) pb >>= 1;
+  *threads = 2 * pb;
+  *lds_half = (uint32_t)(((uint64_t)pb * max_read_len + 64 + 15) & ~15ull);
+}
+void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s) {
+  if (!n_pairs) return;
+  uint32_t threads, half;
+  staging_geometry(max_read_len, &threads, &half);
+  const uint32_t pb = threads / 2;
+  hipLaunchKernelGGL(k_prep_count, dim3((n_pairs + pb - 1) / pb), dim3(threads), 2 * half, s, d, n_pairs, half);
+}
+void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s) {
+  if (!n_pairs) return;
+  uint32_t threads, half;
+  staging_geometry(max_read_len, &threads, &half);
+  const uint32_t pb = threads / 2;
+  hipLaunchKernelGGL(k_mm_fill, dim3((n_pairs + pb - 1) / pb), dim3(threads), 2 * half, s, d, n_pairs, half);
 }
 void cm_launch_k_s0b_barcode(const CmDev &d, uint32_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_s0b_barcode, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);

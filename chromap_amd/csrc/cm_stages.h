@@ -284,14 +284,15 @@ CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32
 // complement of its first new_len bases (the front of the revcomp string is erased), so
 // only the new lengths need to be kept.
 // ---------------------------------------------------------------------------------------
-CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
+// s1p / s2p: the pair's reads (global memory, or the block's LDS copy of them)
+CM_HD void cm_s0_prep_ptr(const CmDev &d, uint32_t pair, const uint8_t *s1p, const uint8_t *s2p) {
   const uint32_t raw1 = d.ro0[pair + 1] - d.ro0[pair], raw2 = d.ro1[pair + 1] - d.ro1[pair];
   uint32_t len1 = raw1, len2 = raw2;
   bool ok = raw1 >= (uint32_t)d.p.min_read_len && (d.p.single || raw2 >= (uint32_t)d.p.min_read_len);
   // pairs whose barcode is not (correctable to) a whitelisted one are skipped (chromap.h:908-909)
   if (d.bcb && !d.bc_ok[pair] && !d.p.bc_keep) ok = false;
   if (ok && d.p.trim && !d.p.single) {
-    const uint8_t *s1 = d.rb0 + d.ro0[pair], *s2 = d.rb1 + d.ro1[pair];
+    const uint8_t *s1 = s1p, *s2 = s2p;
     const bool swap = !(raw1 <= raw2);
     const uint8_t *rd1 = swap ? s2 : s1;        // "read1": the shorter read, forward
     const uint8_t *lng = swap ? s1 : s2;        // "read2": its revcomp is searched
@@ -340,6 +341,10 @@ CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
   d.rlen[2 * pair + 1] = (ok && !d.p.single) ? len2 : 0;
 }
 
+CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
+  cm_s0_prep_ptr(d, pair, d.rb0 + d.ro0[pair], d.rb1 + d.ro1[pair]);
+}
+
 // ---------------------------------------------------------------------------------------
 // S1: minimizers of one read (MinimizerGenerator::GenerateMinimizers,
 //     minimizer_generator.cc:7-139).  Writes (hash, (pos<<1)|strand) into the read's slot
@@ -365,7 +370,7 @@ CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uin
 #pragma unroll
   for (int i = 0; i < W; ++i) { wh[i] = ~0ull; wp[i] = ~0u; }
   int unamb = 0, mi = 0;
-#define CM_EMIT(h, p) do { if (n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
+#define CM_EMIT(h, p) do { if (oh && n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
   for (uint32_t pos = 0; pos < len; ++pos) {
     const uint32_t c = cm_c2u(seq[pos]);
     uint64_t cur_h = ~0ull;
@@ -429,7 +434,7 @@ CM_HD uint32_t cm_minimizers_ring(const uint8_t *seq, uint32_t len, int k, int w
   uint32_t min_p = ~0u;
   for (int i = 0; i < w; ++i) { bh[i] = ~0ull; bp[i] = ~0u; }
   int unamb = 0, pib = 0, min_pos = 0;
-#define CM_EMIT(h, p) do { if (n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
+#define CM_EMIT(h, p) do { if (oh && n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
   for (uint32_t pos = 0; pos < len; ++pos) {
     const uint32_t c = cm_c2u(seq[pos]);
     uint64_t cur_h = ~0ull;
@@ -480,6 +485,23 @@ CM_HD uint32_t cm_minimizers_ring(const uint8_t *seq, uint32_t len, int k, int w
   if (min_h != ~0ull) CM_EMIT(min_h, min_p);
 #undef CM_EMIT
   return n;
+}
+
+// Two-pass form used by the kernels: count (writes mm_cnt[r]) and fill (writes the read's
+// minimizers straight into the dense arrays at mm_off[r]); seq = the read (global or LDS copy).
+CM_HD void cm_s1_count(const CmDev &d, uint32_t r, const uint8_t *seq) {
+  const uint32_t len = d.rlen[r];
+  d.mm_cnt[r] = d.p.w == 7 ? cm_minimizers_window<7>(seq, len, d.p.k, nullptr, nullptr, 0)
+                           : cm_minimizers_ring(seq, len, d.p.k, d.p.w, nullptr, nullptr, 0);
+}
+CM_HD void cm_s1_fill(const CmDev &d, uint32_t r, const uint8_t *seq) {
+  const uint32_t len = d.rlen[r], cnt = d.mm_cnt[r];
+  if (cnt == 0) return;
+  uint64_t *oh = d.mm_hash + d.mm_off[r];
+  uint32_t *op = d.mm_ps + d.mm_off[r];
+  const uint32_t n = d.p.w == 7 ? cm_minimizers_window<7>(seq, len, d.p.k, oh, op, cnt)
+                                : cm_minimizers_ring(seq, len, d.p.k, d.p.w, oh, op, cnt);
+  if (n != cnt) d.stats[CM_ST_ERR] = 3;
 }
 
 CM_HD void cm_s1_minimizers(const CmDev &d, uint32_t r) {

@@ -326,6 +326,9 @@ extern "C" int cmgpu_generate_resident_batch(cmgpu_ctx *c, uint32_t n_pairs, uin
   c->n_pairs = n_pairs;
   c->first_read_id = 0;
   c->bases0 = c->bases1 = (size_t)n_pairs * read_length;
+  c->max_read_len = read_length;
+  c->has_barcodes = false;
+  c->single = false;
   if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(c->bases1 + 16) || c->ro0.ensure(((size_t)n_pairs + 1) * 4) ||
       c->ro1.ensure(((size_t)n_pairs + 1) * 4)) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
   uint64_t total = 0;

@@ -125,19 +125,12 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     }
   }
   for (uint32_t i = 0; i < n; ++i) cm_s0_prep(d, i);
-  std::vector<uint32_t> cap(n2 + 1);
-  for (uint32_t r = 0; r < n2; ++r) cap[r] = d.rlen[r] >= (uint32_t)p.k ? d.rlen[r] - p.k + 1 : 0;
-  scan(cap.data(), d.mm_cap_off, n2);
-  VEC(slot_hash, uint64_t, d.mm_cap_off[n2]) VEC(slot_ps, uint32_t, d.mm_cap_off[n2])
-  for (uint32_t r = 0; r < n2; ++r) cm_s1_minimizers(d, r);
-  // k_s1_minimizers reserves dense ranges per block in arrival order; emulate a scrambled order
-  VEC(mm_hash, uint64_t, d.mm_cap_off[n2]) VEC(mm_ps, uint32_t, d.mm_cap_off[n2]) VEC(pr_val, uint64_t, d.mm_cap_off[n2])
-  VEC(pr_kind, uint8_t, d.mm_cap_off[n2])
-  uint32_t n_mm = 0;
-  for (int pass = 0; pass < 2; ++pass)
-    for (uint32_t b0 = 0; b0 < n2; b0 += 256)
-      if (((b0 / 256) & 1) == (uint32_t)(1 - pass))
-        for (uint32_t r = b0; r < b0 + 256 && r < n2; ++r) { d.mm_off[r] = n_mm; n_mm += d.mm_cnt[r]; cm_s1b_compact(d, r); }
+  // k_prep_count (above: cm_s0_prep per pair) + cm_s1_count per read, scan, k_mm_fill
+  for (uint32_t r = 0; r < n2; ++r) cm_s1_count(d, r, cm_read_ptr(d, r));
+  scan(d.mm_cnt, d.mm_off, n2);
+  const uint32_t n_mm = d.mm_off[n2];
+  VEC(mm_hash, uint64_t, n_mm) VEC(mm_ps, uint32_t, n_mm) VEC(pr_val, uint64_t, n_mm) VEC(pr_kind, uint8_t, n_mm)
+  for (uint32_t r = 0; r < n2; ++r) cm_s1_fill(d, r, cm_read_ptr(d, r));
   for (uint32_t i = 0; i < n_mm; ++i) {
     const uint32_t steps = cm_probe(d.bkt, d.bmask, d.mm_hash[i], &d.pr_val[i], &d.pr_kind[i]);
     st[CM_ST_PROBE_STEPS] += steps;
