@@ -67,7 +67,17 @@ __global__ void k_mm_fill(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
 }
 
 CM_ITEM_KERNEL(k_s3a_count, cm_s3a_count)
-CM_ITEM_KERNEL(k_s3b_candidates, cm_s3b_candidates)
+// S3b with the per-read hit list staged in LDS ([entry][thread] layout: 16 x 8-byte entries and
+// 16 count bytes per thread = 36 KB per block).  The first version sorted every list in its
+// global segment; per-thread read-modify-write of small segments thrashed L2 (rocprofv3: 10 GB
+// of HBM traffic per launch for 0.55 GB of hits).
+#define CM_S3B_LDS_CAP 16
+__global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n) {
+  __shared__ uint64_t sh_h[CM_S3B_LDS_CAP * CM_BLOCK];
+  __shared__ uint8_t sh_c[CM_S3B_LDS_CAP * CM_BLOCK];
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i < n) cm_s3b_candidates_lds(d, i, sh_h + threadIdx.x, sh_c + threadIdx.x, CM_S3B_LDS_CAP, CM_BLOCK);
+}
 CM_ITEM_KERNEL(k_s4a_rescue_count, cm_s4a_rescue_count)
 CM_ITEM_KERNEL(k_s4b_rescue_merge, cm_s4b_rescue_merge)
 CM_ITEM_KERNEL(k_s4c_reduce, cm_s4c_reduce)

@@ -45,46 +45,48 @@ CM_HD uint32_t cm_raw_len(const CmDev &d, uint32_t r) {
   return (r & 1) ? d.ro1[pair + 1] - d.ro1[pair] : d.ro0[pair + 1] - d.ro0[pair];
 }
 
-// in-place ascending sort of a[0..n) -- insertion sort for short lists, heap sort otherwise
-CM_HD void cm_sort_u64(uint64_t *a, uint32_t n) {
+// in-place ascending sort of a[0], a[st], ..., a[(n-1)*st] -- insertion sort for short lists,
+// heap sort otherwise.  st > 1 is the LDS layout [entry][thread] (conflict-free across lanes).
+CM_HD void cm_sort_u64_strided(uint64_t *a, uint32_t n, uint32_t st) {
   if (n < 2) return;
   if (n <= 24) {
     for (uint32_t i = 1; i < n; ++i) {
-      const uint64_t x = a[i];
+      const uint64_t x = a[i * st];
       uint32_t j = i;
-      while (j > 0 && a[j - 1] > x) { a[j] = a[j - 1]; --j; }
-      a[j] = x;
+      while (j > 0 && a[(j - 1) * st] > x) { a[j * st] = a[(j - 1) * st]; --j; }
+      a[j * st] = x;
     }
     return;
   }
   for (uint32_t start = n / 2; start-- > 0;) {
     uint32_t root = start;
-    const uint64_t x = a[root];
+    const uint64_t x = a[root * st];
     for (;;) {
       uint32_t child = 2 * root + 1;
       if (child >= n) break;
-      if (child + 1 < n && a[child] < a[child + 1]) ++child;
-      if (!(x < a[child])) break;
-      a[root] = a[child];
+      if (child + 1 < n && a[child * st] < a[(child + 1) * st]) ++child;
+      if (!(x < a[child * st])) break;
+      a[root * st] = a[child * st];
       root = child;
     }
-    a[root] = x;
+    a[root * st] = x;
   }
   for (uint32_t end = n - 1; end > 0; --end) {
-    const uint64_t x = a[end];
-    a[end] = a[0];
+    const uint64_t x = a[end * st];
+    a[end * st] = a[0];
     uint32_t root = 0;
     for (;;) {
       uint32_t child = 2 * root + 1;
       if (child >= end) break;
-      if (child + 1 < end && a[child] < a[child + 1]) ++child;
-      if (!(x < a[child])) break;
-      a[root] = a[child];
+      if (child + 1 < end && a[child * st] < a[(child + 1) * st]) ++child;
+      if (!(x < a[child * st])) break;
+      a[root * st] = a[child * st];
       root = child;
     }
-    a[root] = x;
+    a[root * st] = x;
   }
 }
+CM_HD void cm_sort_u64(uint64_t *a, uint32_t n) { cm_sort_u64_strided(a, n, 1); }
 
 // Candidate::operator< (candidate.h:22-33): count desc, position asc.  "a before b"
 CM_HD bool cm_cand_before(uint64_t pa, uint8_t ca, uint64_t pb, uint8_t cb) {
@@ -694,7 +696,8 @@ CM_HD uint64_t cm_cand_from_hit(uint64_t ref_hit, uint32_t ps, int k, bool *same
 // CandidateProcessor::GenerateCandidatesOnOneStrand (candidate_processor.cc:283-342) on a
 // sorted hit list h[0..n); candidates are written IN PLACE into h/cnt (the write index
 // never passes the read index).  Returns the number of candidates.
-CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
+CM_HD uint32_t cm_sweep_strided(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers,
+                                uint32_t st) {
   if (n == 0) return 0;
   uint32_t out = 0;
   int mcount = 1, equal = 1, best_equal = 1;
@@ -702,13 +705,13 @@ CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_
   uint32_t prev_rid = (uint32_t)(prev_hit >> 32), prev_pos = (uint32_t)prev_hit;
   uint64_t best_local = h[0];
   for (uint32_t pi = 1; pi <= n; ++pi) {
-    const uint64_t x = pi < n ? h[pi] : ~0ull;  // UINT64_MAX sentinel (:286)
+    const uint64_t x = pi < n ? h[pi * st] : ~0ull;  // UINT64_MAX sentinel (:286)
     const uint32_t rid = (uint32_t)(x >> 32), pos = (uint32_t)x;
     if (rid != prev_rid || pos > prev_pos + (uint32_t)e ||
         ((uint32_t)mcount >= num_minimizers && pos > (uint32_t)best_local + (uint32_t)e)) {
       if (mcount >= seeds_required) {
-        h[out] = best_local;
-        cnt[out] = (uint8_t)best_equal;
+        h[out * st] = best_local;
+        cnt[out * st] = (uint8_t)best_equal;
         ++out;
       }
       mcount = 1; equal = 1; best_equal = 1;
@@ -726,17 +729,20 @@ CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_
   return out;
 }
 
+CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
+  return cm_sweep_strided(h, cnt, n, e, seeds_required, num_minimizers, 1);
+}
+
 // ---------------------------------------------------------------------------------------
 // S3b: per read -- expand occurrences into the read's hit segment (+ list from the front,
 //      - list from the back), sort both, cluster into candidates in place.
 // ---------------------------------------------------------------------------------------
-CM_HD void cm_s3b_candidates(const CmDev &d, uint32_t r) {
+// work buffer h/hc with element stride st (1 = the read's global segment, blockDim = LDS
+// [entry][thread] layout).  Candidates end up at h[0..ncp) and h[np..np+ncn) (strided).
+CM_HD void cm_s3b_core(const CmDev &d, uint32_t r, uint64_t *h, uint8_t *hc, uint32_t st, uint32_t *np_out,
+                       uint32_t *ncp_out, uint32_t *ncn_out) {
   const uint32_t tot = d.hit_tot[r];
-  d.ncp[r] = 0; d.ncn[r] = 0; d.n_pos_hit[r] = 0;
-  if (tot == 0) return;
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
-  uint64_t *h = d.hbuf + d.hit_off[r];
-  uint8_t *hc = d.hcnt + d.hit_off[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   uint32_t np = 0, nn = 0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -747,7 +753,7 @@ CM_HD void cm_s3b_candidates(const CmDev &d, uint32_t r) {
     bool same;
     if (kind == CM_PR_SINGLE) {
       const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
-      if (same) h[np++] = cp; else h[tot - 1 - nn++] = cp;
+      if (same) h[(np++) * st] = cp; else h[(tot - 1 - nn++) * st] = cp;
       continue;
     }
     const uint32_t nocc = (uint32_t)val;
@@ -755,20 +761,45 @@ CM_HD void cm_s3b_candidates(const CmDev &d, uint32_t r) {
     const uint64_t *o = d.occ + (uint32_t)(val >> 32);
     for (uint32_t oi = 0; oi < nocc; ++oi) {
       const uint64_t cp = cm_cand_from_hit(o[oi], ps, d.p.k, &same);
-      if (same) h[np++] = cp; else h[tot - 1 - nn++] = cp;
+      if (same) h[(np++) * st] = cp; else h[(tot - 1 - nn++) * st] = cp;
     }
   }
-  cm_sort_u64(h, np);
-  cm_sort_u64(h + np, nn);
+  cm_sort_u64_strided(h, np, st);
+  cm_sort_u64_strided(h + (size_t)np * st, nn, st);
   const bool use_high = d.round2[r] && np > 0 && nn > 0;
   int req = (int)n - (int)d.rep_cnt[r];
   req = req > 1 ? req : 1;
   req = req > d.p.min_seeds ? d.p.min_seeds : req;
   if (use_high) req = d.p.min_seeds;
-  d.n_pos_hit[r] = np;
-  d.ncp[r] = cm_sweep(h, hc, np, d.p.e, req, n);
-  d.ncn[r] = cm_sweep(h + np, hc + np, nn, d.p.e, req, n);
+  *np_out = np;
+  *ncp_out = cm_sweep_strided(h, hc, np, d.p.e, req, n, st);
+  *ncn_out = cm_sweep_strided(h + (size_t)np * st, hc + (size_t)np * st, nn, d.p.e, req, n, st);
 }
+
+// lds_h / lds_c: per-block LDS work buffers of lds_cap entries per thread ([entry][thread]
+// layout, this thread's column), or nullptr.  Reads with at most lds_cap hits are expanded,
+// sorted and clustered in LDS and only their candidates are written to the global segment;
+// longer lists work in place in the global segment.
+CM_HD void cm_s3b_candidates_lds(const CmDev &d, uint32_t r, uint64_t *lds_h, uint8_t *lds_c, uint32_t lds_cap,
+                                 uint32_t lds_stride) {
+  const uint32_t tot = d.hit_tot[r];
+  d.ncp[r] = 0; d.ncn[r] = 0; d.n_pos_hit[r] = 0;
+  if (tot == 0) return;
+  uint64_t *h = d.hbuf + d.hit_off[r];
+  uint8_t *hc = d.hcnt + d.hit_off[r];
+  uint32_t np, ncp, ncn;
+  if (lds_h && tot <= lds_cap) {
+    cm_s3b_core(d, r, lds_h, lds_c, lds_stride, &np, &ncp, &ncn);
+    for (uint32_t i = 0; i < ncp; ++i) { h[i] = lds_h[i * lds_stride]; hc[i] = lds_c[i * lds_stride]; }
+    for (uint32_t i = 0; i < ncn; ++i) { h[np + i] = lds_h[(np + i) * lds_stride]; hc[np + i] = lds_c[(np + i) * lds_stride]; }
+  } else {
+    cm_s3b_core(d, r, h, hc, 1, &np, &ncp, &ncn);
+  }
+  d.n_pos_hit[r] = np;
+  d.ncp[r] = ncp;
+  d.ncn[r] = ncn;
+}
+CM_HD void cm_s3b_candidates(const CmDev &d, uint32_t r) { cm_s3b_candidates_lds(d, r, nullptr, nullptr, 0, 1); }
 
 // ---------------------------------------------------------------------------------------
 // Mate rescue (Index::GenerateCandidatePositionsFromRepetitiveReadWithMateInfoOnOneStrand,

@@ -139,7 +139,11 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   for (uint32_t r = 0; r < n2; ++r) cm_s3a_count(d, r);
   scan(d.hit_tot, d.hit_off, n2);
   VEC(hbuf, uint64_t, d.hit_off[n2]) VEC(hcnt, uint8_t, d.hit_off[n2])
-  for (uint32_t r = 0; r < n2; ++r) cm_s3b_candidates(d, r);
+  {  // k_s3b_candidates: lists of <= 16 hits are worked on in a strided (LDS-like) buffer
+    std::vector<uint64_t> wh(16 * 7 + 8);
+    std::vector<uint8_t> wc(16 * 7 + 8);
+    for (uint32_t r = 0; r < n2; ++r) cm_s3b_candidates_lds(d, r, wh.data() + (r % 7), wc.data() + (r % 7), 16, 7);
+  }
   for (uint32_t r = 0; r < n2; ++r) cm_s4a_rescue_count(d, r);
   scan(d.m_tot, d.m_off, n2);
   const uint32_t n_m = d.m_off[n2];
