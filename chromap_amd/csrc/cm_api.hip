@@ -213,6 +213,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(hit_tot, n2 * 4) ENS(hit_off, (n2 + 1) * 4) ENS(round2, n2) ENS(rep_cnt, n2 * 4) ENS(rep_len, n2 * 4)
   ENS(n_pos_hit, n2 * 4) ENS(ncp, n2 * 4) ENS(ncn, n2 * 4) ENS(aug, n2) ENS(res_neg, n2 * 4) ENS(res_pos, n2 * 4)
   ENS(resc_n, n2 * 4) ENS(resc_p, n2 * 4) ENS(m_tot, n2 * 4) ENS(m_off, (n2 + 1) * 4) ENS(mcp, n2 * 4) ENS(mcn, n2 * 4)
+  ENS(nv, n2 * 4) ENS(v_off, (n2 + 1) * 4)
   ENS(force0, n) ENS(fcp, n2 * 4) ENS(fcn, n2 * 4) ENS(alive, n) ENS(ndp, n2 * 4) ENS(ndn, n2 * 4)
   ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
@@ -272,7 +273,7 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   PTR(aug, uint8_t) PTR(res_neg, int32_t) PTR(res_pos, int32_t) PTR(resc_n, uint32_t) PTR(resc_p, uint32_t)
   PTR(m_tot, uint32_t) PTR(m_off, uint32_t) PTR(mbuf, uint64_t) PTR(mcnt, uint8_t) PTR(mcp, uint32_t) PTR(mcn, uint32_t)
   PTR(force0, uint8_t) PTR(fbuf, uint64_t) PTR(fcnt, uint8_t) PTR(fcp, uint32_t) PTR(fcn, uint32_t) PTR(alive, uint8_t)
-  PTR(dpos, uint64_t) PTR(derr, int16_t) PTR(dsplit, uint32_t) PTR(ndp, uint32_t) PTR(ndn, uint32_t)
+  PTR(dpos, uint64_t) PTR(derr, int16_t) PTR(dsplit, uint32_t) PTR(nv, uint32_t) PTR(v_off, uint32_t) PTR(v_err, int16_t) PTR(v_end, int16_t) PTR(ndp, uint32_t) PTR(ndn, uint32_t)
   PTR(min_err, int32_t) PTR(second_err, int32_t) PTR(n_best, int32_t) PTR(n_second, int32_t)
   PTR(pe_min, int32_t) PTR(pe_second, int32_t) PTR(pe_nbest, int32_t) PTR(pe_nsecond, int32_t)
   PTR(pe_first, uint32_t) PTR(pe_i1, uint32_t) PTR(pe_i2, uint32_t) PTR(pe_choice, uint32_t)
@@ -354,7 +355,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   HIPCHECK(c, hipStreamSynchronize(s));
   if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
       c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
-      c->dsplit.ensure((size_t)n_m * 4 + 4)) {
+      c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4)) {
     cm_set_error(c, "out of device memory (candidates)");
     return CMGPU_ENOMEM;
   }
@@ -364,9 +365,18 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   mark(c, "s4b_rescue_merge");
   cm_launch_k_s4c_reduce(d, n, s);
   mark(c, "s4c_pair_filter");
-  // S5: verification
-  cm_launch_k_s5_verify(d, n2, s);
-  mark(c, "s5_verify");
+  // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
+  // candidate, (c) the sequential acceptance loop per read
+  cm_launch_k_s5a_prepare(d, n2, s);
+  cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);
+  uint32_t n_v = 0;
+  HIPCHECK(c, hipMemcpyAsync(&n_v, d.v_off + n2, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipStreamSynchronize(s));
+  mark(c, "s5a_prepare");
+  cm_launch_k_s5b_verify(d, n_v, n2, s);
+  mark(c, "s5b_verify");
+  cm_launch_k_s5c_finalize(d, n2, s);
+  mark(c, "s5c_accept");
   // S6: best pair, sampling of multi-mappers, records
   cm_launch_k_s6a_pair(d, n, s);
   mark(c, "s6a_pairing");

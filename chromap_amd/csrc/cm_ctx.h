@@ -41,7 +41,7 @@ struct cmgpu_ctx {
   DevBuf rlen, cap, mm_cap_off, slot_hash, slot_ps, mm_cnt, mm_off, mm_hash, mm_ps, pr_val, pr_kind;
   DevBuf hit_tot, hit_off, round2, rep_cnt, rep_len, hbuf, hcnt, n_pos_hit, ncp, ncn;
   DevBuf aug, res_neg, res_pos, resc_n, resc_p, m_tot, m_off, mbuf, mcnt, mcp, mcn, force0;
-  DevBuf fbuf, fcnt, fcp, fcn, alive, dpos, derr, dsplit, ndp, ndn, min_err, second_err, n_best, n_second;
+  DevBuf fbuf, fcnt, fcp, fcn, alive, dpos, derr, dsplit, nv, v_off, v_err, v_end, ndp, ndn, min_err, second_err, n_best, n_second;
   DevBuf pe_min, pe_second, pe_nbest, pe_nsecond, pe_first, pe_i1, pe_i2, pe_choice, rec, rec_ok;
   DevBuf scan_tmp, stats, partials;
   // single-cell barcodes
@@ -63,7 +63,7 @@ struct cmgpu_ctx {
             &mm_cap_off, &slot_hash, &slot_ps, &mm_cnt, &mm_off, &mm_hash, &mm_ps, &pr_val, &pr_kind, &hit_tot,
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
-            &dpos, &derr, &dsplit, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
+            &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num};
   }
 };

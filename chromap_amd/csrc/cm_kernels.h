@@ -13,7 +13,9 @@ CM_DECL_LAUNCH(k_s3b_candidates)
 CM_DECL_LAUNCH(k_s4a_rescue_count)
 CM_DECL_LAUNCH(k_s4b_rescue_merge)
 CM_DECL_LAUNCH(k_s4c_reduce)
-CM_DECL_LAUNCH(k_s5_verify)
+CM_DECL_LAUNCH(k_s5a_prepare)
+CM_DECL_LAUNCH(k_s5c_finalize)
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s);
 CM_DECL_LAUNCH(k_s6a_pair)
 CM_DECL_LAUNCH(k_s6c_multi)
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);

@@ -81,7 +81,12 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n
 CM_ITEM_KERNEL(k_s4a_rescue_count, cm_s4a_rescue_count)
 CM_ITEM_KERNEL(k_s4b_rescue_merge, cm_s4b_rescue_merge)
 CM_ITEM_KERNEL(k_s4c_reduce, cm_s4c_reduce)
-CM_ITEM_KERNEL(k_s5_verify, cm_s5_verify)
+CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare)
+CM_ITEM_KERNEL(k_s5c_finalize, cm_s5c_finalize)
+__global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_items, uint32_t n_reads) {
+  const uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (j < n_items) cm_s5b_verify_item(d, j, n_reads);
+}
 CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair)
 CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi)
 
@@ -385,7 +390,11 @@ CM_LAUNCH(k_s3b_candidates)
 CM_LAUNCH(k_s4a_rescue_count)
 CM_LAUNCH(k_s4b_rescue_merge)
 CM_LAUNCH(k_s4c_reduce)
-CM_LAUNCH(k_s5_verify)
+CM_LAUNCH(k_s5a_prepare)
+CM_LAUNCH(k_s5c_finalize)
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s) {
+  if (n_items) hipLaunchKernelGGL(k_s5b_verify, grid_for(n_items), dim3(CM_BLOCK), 0, s, d, n_items, n_reads);
+}
 CM_LAUNCH(k_s6a_pair)
 CM_LAUNCH(k_s6c_multi)
 

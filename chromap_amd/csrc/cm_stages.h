@@ -1127,6 +1127,52 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
 // BandedAlignPatternToText (alignment.cc:141-192): Myers/Hyyro bit-vector banded edit
 // distance, 32-bit word, band 2e+1.  pattern = reference window, text = read.
 // neg: text is the reverse complement of `read` (read[len-1-i] complemented).
+// ---- byte sources -----------------------------------------------------------------------
+// CmDirect reads bytes where they are.  CmBytes first copies a byte range into a small
+// per-lane array with independent 8-byte loads (issued back to back, one memory latency)
+// and then serves bytes from it: the bit-vector loops below consume one reference byte and one
+// read byte per step, and a dependent global load per step made them latency-bound.
+struct CmDirect {
+  const uint8_t *p;
+  CM_HD uint8_t get(int i) const { return p[i]; }
+};
+#define CM_PF_WORDS 42  // 336 bytes: windows up to L + 2e <= 320
+struct CmBytes {
+  uint64_t w[CM_PF_WORDS];
+  uint32_t sh;
+  CM_HD bool load(const uint8_t *p, uint32_t n) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    sh = (uint32_t)(a & 7);
+    const uint32_t nw = (sh + n + 7) >> 3;
+    if (nw > CM_PF_WORDS) return false;
+    const uint64_t *ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+    for (uint32_t k = 0; k < nw; ++k) w[k] = ap[k];
+    return true;
+  }
+  CM_HD uint8_t get(int i) const {
+    const uint32_t j = (uint32_t)i + sh;
+    return (uint8_t)(w[j >> 3] >> ((j & 7) * 8));
+  }
+};
+// text = (neg ? revcomp(read[0..Lfull)) : read) + toff
+template <class B>
+struct CmText {
+  const B &b;
+  int Lfull;
+  bool neg;
+  int toff;
+  CM_HD uint32_t code(int i) const {
+    const int j = toff + i;
+    if (!neg) return cm_c2u(b.get(j));
+    const uint32_t c = cm_c2u(b.get(Lfull - 1 - j));
+    return c < 4 ? 3u ^ c : 4u;
+  }
+  CM_HD uint8_t raw(int i) const {
+    const int j = toff + i;
+    return neg ? cm_negchar(b.get(Lfull - 1 - j)) : b.get(j);
+  }
+};
+
 CM_HD uint32_t cm_text_code(const uint8_t *read, int L, int i, bool neg) {
   if (!neg) return cm_c2u(read[i]);
   const uint32_t c = cm_c2u(read[L - 1 - i]);
@@ -1144,17 +1190,17 @@ CM_HD void cm_peq_or(uint32_t *P, uint32_t c, uint32_t bit) {
   P[3] |= c == 3 ? bit : 0u; P[4] |= c == 4 ? bit : 0u;
 }
 
-// text = (neg ? revcomp(read[0..Lfull)) : read) + toff, length L
-CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
-                          int *end_pos) {
+// BandedAlignPatternToText (alignment.cc:141-192) over byte sources
+template <class PS, class TS>
+CM_HD int cm_banded_align_t(int e, const PS &pat, const TS &txt, int L, int *end_pos) {
   uint32_t P[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pattern[i]), 1u << i);
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pat.get(i)), 1u << i);
   const uint32_t hi = 1u << (2 * e);
   uint32_t VP = 0, VN = 0;
   int err = 0;
   for (int i = 0; i < L; i++) {
-    cm_peq_or(P, cm_c2u(pattern[i + 2 * e]), hi);
-    uint32_t X = cm_peq_get(P, cm_text_code(read, Lfull, toff + i, neg)) | VN;
+    cm_peq_or(P, cm_c2u(pat.get(i + 2 * e)), hi);
+    uint32_t X = cm_peq_get(P, txt.code(i)) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1179,22 +1225,34 @@ CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, in
   return min_err;
 }
 
-// BandedTraceback (alignment.cc:656-718)
-CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg,
-                              int toff, int L) {
-  if (min_num_errors == 0) return e;
+// text = (neg ? revcomp(read[0..Lfull)) : read) + toff, length L
+CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
+                          int *end_pos) {
+  CmBytes pb, tb;
+  if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
+    const CmText<CmBytes> txt{tb, Lfull, neg, toff};
+    return cm_banded_align_t(e, pb, txt, L, end_pos);
+  }
+  const CmDirect pd{pattern}, td{read};
+  const CmText<CmDirect> txt{td, Lfull, neg, toff};
+  return cm_banded_align_t(e, pd, txt, L, end_pos);
+}
+
+// BandedTraceback (alignment.cc:656-718) over byte sources
+template <class PS, class TS>
+CM_HD int cm_banded_traceback_t(int e, int min_num_errors, const PS &pat, const TS &txt, int L) {
   int error_count = 0;
   for (int i = 0; i < L; ++i)
-    if (pattern[i + e] != cm_text_char(read, Lfull, toff + i, neg)) ++error_count;  // raw, case-sensitive (:666)
+    if (pat.get(i + e) != txt.raw(i)) ++error_count;  // raw, case-sensitive (:666)
   if (error_count == min_num_errors) return e;
   uint32_t P[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pattern[L - 1 + 2 * e - i]), 1u << i);
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pat.get(L - 1 + 2 * e - i)), 1u << i);
   const uint32_t hi = 1u << (2 * e);
   uint32_t VP = 0, VN = 0;
   int err = 0;
   for (int i = 0; i < L; i++) {
-    cm_peq_or(P, cm_c2u(pattern[L - 1 - i]), hi);
-    uint32_t X = cm_peq_get(P, cm_text_code(read, Lfull, toff + L - 1 - i, neg)) | VN;
+    cm_peq_or(P, cm_c2u(pat.get(L - 1 - i)), hi);
+    uint32_t X = cm_peq_get(P, txt.code(L - 1 - i)) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1216,6 +1274,18 @@ CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern,
   return start;
 }
 
+CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg,
+                              int toff, int L) {
+  if (min_num_errors == 0) return e;
+  CmBytes pb, tb;
+  if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
+    const CmText<CmBytes> txt{tb, Lfull, neg, toff};
+    return cm_banded_traceback_t(e, min_num_errors, pb, txt, L);
+  }
+  const CmDirect pd{pattern}, td{read};
+  const CmText<CmDirect> txt{td, Lfull, neg, toff};
+  return cm_banded_traceback_t(e, min_num_errors, pd, txt, L);
+}
 
 // BandedAlignPatternToTextWithDropOff (alignment.cc:197-283) when from3 == false,
 // BandedAlignPatternToTextWithDropOffFrom3End (alignment.cc:285-376) when from3 == true.
@@ -1302,14 +1372,26 @@ CM_HD void cm_update_best(CmBest &m, int ne) {  // draft_mapping_generator.cc:50
 }
 
 // verify one candidate; on acceptance append the draft mapping. returns accepted
-CM_HD bool cm_verify_one(const CmDev &d, const uint8_t *read, uint32_t L, int strand, uint64_t cpos, CmBest &bst,
-                         uint64_t *dp, int16_t *de, uint32_t *nd) {
+// banded alignment of one (valid) candidate: returns the edit distance (e+1 = rejected)
+CM_HD int cm_verify_compute(const CmDev &d, const uint8_t *read, uint32_t L, int strand, uint64_t cpos, int *end_pos) {
   const int e = d.p.e;
   const uint32_t rid = (uint32_t)(cpos >> 32);
   uint32_t position = (uint32_t)cpos;
   if (strand == 1) position = position - L + 1;
+  *end_pos = (int)L;
+  return cm_banded_align(e, d.ref + d.ref_off[rid] + position - e, read, (int)L, strand == 1, 0, (int)L, end_pos);
+}
+
+// pre_err/pre_end (may be null): results computed beforehand by the per-candidate kernel for
+// candidate index ci of this strand's list
+CM_HD bool cm_verify_one(const CmDev &d, const uint8_t *read, uint32_t L, int strand, uint64_t cpos, CmBest &bst,
+                         uint64_t *dp, int16_t *de, uint32_t *nd, const int16_t *pre_err, const int16_t *pre_end,
+                         uint32_t ci) {
+  const int e = d.p.e;
   int end_pos = (int)L;
-  const int ne = cm_banded_align(e, d.ref + d.ref_off[rid] + position - e, read, (int)L, strand == 1, 0, (int)L, &end_pos);
+  int ne;
+  if (pre_err) { ne = pre_err[ci]; end_pos = pre_end[ci]; }
+  else ne = cm_verify_compute(d, read, L, strand, cpos, &end_pos);
   if (ne <= e) {
     cm_update_best(bst, ne);
     dp[*nd] = strand == 0 ? cpos - (uint64_t)e + (uint64_t)(int64_t)end_pos
@@ -1324,7 +1406,8 @@ CM_HD bool cm_verify_one(const CmDev &d, const uint8_t *read, uint32_t L, int st
 // one strand of GenerateDraftMappings: scalar loop (draft_mapping_generator.cc:359-557, non-split)
 // or the lane-grouped loop with the candidate_count_threshold break (:159-357)
 CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, int strand, const uint64_t *cp,
-                               const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int16_t *de) {
+                               const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int16_t *de,
+                               const int16_t *pre_err = nullptr, const int16_t *pre_end = nullptr) {
   uint32_t nd = 0;
   const int lanes = d.p.lanes;
   if (lanes == 0 || nc < (uint32_t)lanes) {
@@ -1333,12 +1416,13 @@ CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, 
       uint32_t position = (uint32_t)cp[ci];
       if (strand == 1) position = position - L + 1;
       if (!cm_valid_candidate(d, rid, position, L)) continue;
-      cm_verify_one(d, read, L, strand, cp[ci], bst, dp, de, &nd);
+      cm_verify_one(d, read, L, strand, cp[ci], bst, dp, de, &nd, pre_err, pre_end, ci);
     }
     return nd;
   }
   uint64_t vpos[8];
   uint8_t vcnt[8];
+  uint32_t vidx[8];
   uint32_t nvalid = 0, thr = 0, ci = 0;
   while (ci < nc) {
     if (cc[ci] < thr) break;
@@ -1348,14 +1432,15 @@ CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, 
     if (!cm_valid_candidate(d, rid, position, L)) { ++ci; continue; }
     vpos[nvalid] = cp[ci];
     vcnt[nvalid] = cc[ci];
+    vidx[nvalid] = ci;
     ++nvalid;
     ++ci;
     if (nvalid < (uint32_t)lanes) continue;
     for (int mi = 0; mi < lanes; ++mi)
-      if (!cm_verify_one(d, read, L, strand, vpos[mi], bst, dp, de, &nd)) thr = vcnt[mi];
+      if (!cm_verify_one(d, read, L, strand, vpos[mi], bst, dp, de, &nd, pre_err, pre_end, vidx[mi])) thr = vcnt[mi];
     nvalid = 0;
   }
-  for (uint32_t i = 0; i < nvalid; ++i) cm_verify_one(d, read, L, strand, vpos[i], bst, dp, de, &nd);
+  for (uint32_t i = 0; i < nvalid; ++i) cm_verify_one(d, read, L, strand, vpos[i], bst, dp, de, &nd, pre_err, pre_end, vidx[i]);
   return nd;
 }
 
@@ -1464,6 +1549,85 @@ CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
       d.ndn[r] = cm_draft_strand(d, read, L, 1, np, nc, ncn, bst, dpn, den);
     }
   }
+  d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
+  d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// S5 as three kernels (non-split): (a) per read: shortcut, or sort the candidate lists and
+// publish nv = number of candidates; (b) per candidate: the banded alignment, all lanes busy;
+// (c) per read: the reference's sequential acceptance loop (lane grouping, count-threshold
+// break, best/second-best bookkeeping) over the precomputed (errors, end) results.  Candidates
+// beyond the loop's break point are aligned needlessly but never looked at.
+// ---------------------------------------------------------------------------------------
+CM_HD void cm_s5a_prepare(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1;
+  d.nv[r] = 0;
+  if (d.p.split || !d.alive[pair]) { cm_s5_verify(d, r); return; }  // split alignment keeps the in-place path
+  d.ndp[r] = 0; d.ndn[r] = 0;
+  const int e = d.p.e;
+  CmBest bst = {e + 1, e + 1, 0, 0};
+  const uint32_t L = d.rlen[r];
+  uint64_t *pp = cm_f_pos(d, r), *np = cm_f_neg(d, r);
+  uint8_t *pc = cm_f_pcnt(d, r), *nc = cm_f_ncnt(d, r);
+  const uint32_t ncp = d.fcp[r], ncn = d.fcn[r];
+  bool done = false;
+  if (ncp + ncn == 1) {
+    const int strand = ncp == 1 ? 0 : 1;
+    const uint64_t cpos = strand == 0 ? pp[0] : np[0];
+    const uint8_t cnt = strand == 0 ? pc[0] : nc[0];
+    if ((uint32_t)cnt == d.mm_cnt[r]) {
+      bst.min_err = 0; bst.n_best = 1; bst.n_second = 0;
+      const uint32_t rid = (uint32_t)(cpos >> 32);
+      const uint32_t position = strand == 0 ? (uint32_t)cpos : (uint32_t)cpos - L + 1;
+      if (cm_valid_candidate(d, rid, position, L)) {
+        if (strand == 0) { d.dpos[d.m_off[r]] = cpos + L - 1; d.derr[d.m_off[r]] = 0; d.ndp[r] = 1; }
+        else { const uint32_t o = d.m_off[r] + d.ncp[r] + d.resc_p[r]; d.dpos[o] = cpos; d.derr[o] = 0; d.ndn[r] = 1; }
+        done = true;
+      }
+    }
+  }
+  if (!done) {
+    cm_sort_cand(pp, pc, ncp);
+    cm_sort_cand(np, nc, ncn);
+    d.nv[r] = ncp + ncn;
+  }
+  d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
+  d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
+}
+
+// work item j -> (read, strand, candidate): binary search in the exclusive prefix v_off
+CM_HD void cm_s5b_verify_item(const CmDev &d, uint32_t j, uint32_t n_reads) {
+  uint32_t lo = 0, hi = n_reads;  // largest r with v_off[r] <= j
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (d.v_off[mid] <= j) lo = mid; else hi = mid;
+  }
+  const uint32_t r = lo, li = j - d.v_off[r];
+  const uint32_t ncp = d.fcp[r];
+  const int strand = li < ncp ? 0 : 1;
+  const uint32_t ci = strand ? li - ncp : li;
+  const uint32_t o = d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0) + ci;
+  const uint64_t cpos = d.fbuf[o];
+  const uint32_t L = d.rlen[r];
+  const uint32_t rid = (uint32_t)(cpos >> 32);
+  const uint32_t position = strand == 0 ? (uint32_t)cpos : (uint32_t)cpos - L + 1;
+  if (!cm_valid_candidate(d, rid, position, L)) { d.v_err[o] = CM_V_INVALID; d.v_end[o] = 0; return; }
+  int end_pos;
+  const int ne = cm_verify_compute(d, cm_read_ptr(d, r), L, strand, cpos, &end_pos);
+  d.v_err[o] = (int16_t)ne;
+  d.v_end[o] = (int16_t)end_pos;
+}
+
+CM_HD void cm_s5c_finalize(const CmDev &d, uint32_t r) {
+  if (d.nv[r] == 0) return;
+  CmBest bst = {d.min_err[r], d.second_err[r], d.n_best[r], d.n_second[r]};
+  const uint32_t L = d.rlen[r];
+  const uint8_t *read = cm_read_ptr(d, r);
+  const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
+  d.ndp[r] = cm_draft_strand(d, read, L, 0, d.fbuf + op, d.fcnt + op, d.fcp[r], bst, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
+  d.ndn[r] = cm_draft_strand(d, read, L, 1, d.fbuf + on, d.fcnt + on, d.fcn[r], bst, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
   d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
   d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
 }

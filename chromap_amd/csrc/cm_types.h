@@ -23,6 +23,7 @@
 #define CM_PR_MISS 0
 #define CM_PR_SINGLE 1
 #define CM_PR_MULTI 2
+#define CM_V_INVALID 0x7fff
 
 // Subset of MappingParameters used on the device.
 struct CmParams {
@@ -124,6 +125,11 @@ struct CmDev {
   int16_t *derr;
   uint32_t *dsplit;     // split-alignment only: (actual_errors<<24 | gap_beginning<<16 | read_mapping_length)
   uint32_t *ndp, *ndn;  // [2n]
+  // ---- verification work items (one per candidate of the reads that need banded alignment)
+  uint32_t *nv;         // [2n] candidates to verify (0: shortcut / dead / split handled in place)
+  uint32_t *v_off;      // [2n+1]
+  int16_t *v_err;       // per candidate (candidate offsets): edit distance, e+1 = rejected, CM_V_INVALID = invalid position
+  int16_t *v_end;       // per candidate: mapping end position in the window
   int32_t *min_err, *second_err, *n_best, *n_second; // [2n]
   // ---- pair level
   int32_t *pe_min, *pe_second, *pe_nbest, *pe_nsecond; // [n]

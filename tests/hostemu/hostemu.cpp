@@ -64,7 +64,10 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   cm_build_len_coef(coef); cm_build_nsec_break(brk);
   d.mq.len_coef = coef.data(); d.mq.nsec_break = brk.data(); d.mq.n_break = (int)brk.size();
   d.n_pairs = n; d.first_read_id = in->first_read_id;
-  d.rb0 = (const uint8_t *)in->read1_bases; d.rb1 = (const uint8_t *)in->read2_bases;
+  // padded copies: CmBytes::load reads whole aligned 8-byte words around a byte range
+  std::vector<uint64_t> pad0(((size_t)(n ? in->read1_offsets[n] : 0) + 31) / 8 + 2, 0), pad1(((size_t)(n ? in->read2_offsets[n] : 0) + 31) / 8 + 2, 0);
+  if (n) { memcpy(pad0.data(), in->read1_bases, in->read1_offsets[n]); memcpy(pad1.data(), in->read2_bases, in->read2_offsets[n]); }
+  d.rb0 = (const uint8_t *)pad0.data(); d.rb1 = (const uint8_t *)pad1.data();
   d.ro0 = in->read1_offsets; d.ro1 = in->read2_offsets;
   unsigned long long st[CM_ST_N];
   memset(st, 0, sizeof(st));
@@ -151,7 +154,11 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   VEC(dpos, uint64_t, n_m) VEC(derr, int16_t, n_m) VEC(dsplit, uint32_t, n_m)
   for (uint32_t r = 0; r < n2; ++r) cm_s4b_rescue_merge(d, r);
   for (uint32_t i = 0; i < n; ++i) cm_s4c_reduce(d, i);
-  for (uint32_t r = 0; r < n2; ++r) cm_s5_verify(d, r);
+  VEC(nv, uint32_t, n2) VEC(v_off, uint32_t, n2 + 1) VEC(v_err, int16_t, n_m) VEC(v_end, int16_t, n_m)
+  for (uint32_t r = 0; r < n2; ++r) cm_s5a_prepare(d, r);
+  scan(d.nv, d.v_off, n2);
+  for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
+  for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r);
   for (uint32_t i = 0; i < n; ++i) cm_s6a_pair(d, i);
   const uint32_t nch = cm_num_chunks(n, (uint32_t)p.ref_batch, (uint32_t)p.grain);
   CmMt *g = new CmMt();
