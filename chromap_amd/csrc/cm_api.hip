@@ -209,11 +209,11 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
 static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   const size_t n2 = 2 * (size_t)n;
 #define ENS(buf, bytes) if (c->buf.ensure(bytes)) { cm_set_error(c, "out of device memory (" #buf ")"); return CMGPU_ENOMEM; }
-  ENS(rlen, n2 * 4) ENS(cap, n2 * 4) ENS(mm_cap_off, (n2 + 1) * 4) ENS(mm_cnt, n2 * 4) ENS(mm_off, (n2 + 1) * 4)
-  ENS(hit_tot, n2 * 4) ENS(hit_off, (n2 + 1) * 4) ENS(round2, n2) ENS(rep_cnt, n2 * 4) ENS(rep_len, n2 * 4)
+  ENS(rlen, n2 * 4) ENS(cap, (n2 + 1) * 4) ENS(mm_cap_off, (n2 + 1) * 4) ENS(mm_cnt, (n2 + 1) * 4) ENS(mm_off, (n2 + 1) * 4)
+  ENS(hit_tot, (n2 + 1) * 4) ENS(hit_off, (n2 + 1) * 4) ENS(round2, n2) ENS(rep_cnt, n2 * 4) ENS(rep_len, n2 * 4)
   ENS(n_pos_hit, n2 * 4) ENS(ncp, n2 * 4) ENS(ncn, n2 * 4) ENS(aug, n2) ENS(res_neg, n2 * 4) ENS(res_pos, n2 * 4)
-  ENS(resc_n, n2 * 4) ENS(resc_p, n2 * 4) ENS(m_tot, n2 * 4) ENS(m_off, (n2 + 1) * 4) ENS(mcp, n2 * 4) ENS(mcn, n2 * 4)
-  ENS(nv, n2 * 4) ENS(v_off, (n2 + 1) * 4)
+  ENS(resc_n, n2 * 4) ENS(resc_p, n2 * 4) ENS(m_tot, (n2 + 1) * 4) ENS(m_off, (n2 + 1) * 4) ENS(mcp, n2 * 4) ENS(mcn, n2 * 4)
+  ENS(nv, (n2 + 1) * 4) ENS(v_off, (n2 + 1) * 4)
   ENS(force0, n) ENS(fcp, n2 * 4) ENS(fcn, n2 * 4) ENS(alive, n) ENS(ndp, n2 * 4) ENS(ndn, n2 * 4)
   ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)

@@ -1,6 +1,9 @@
 // cm_kernels.hip -- __global__ wrappers (one thread per item) around the stage functions of
 // cm_stages.h, the index-probe kernel, prefix scans and the launch helpers.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 #include "cm_kernels.h"
 #include "cm_stages.h"
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_probe(const uint64_t *__restrict__
 __global__ __launch_bounds__(CM_BLOCK) void k_probe_reduce(const uint2 *__restrict__ partials, uint32_t n_blocks,
                                                             unsigned long long *__restrict__ counters) {
   unsigned long long a = 0, c = 0;
-  for (uint32_t i = threadIdx.x; i < n_blocks; i += CM_BLOCK) { a += partials[i].x; c += partials[i].y; }
+  for (uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x; i < n_blocks; i += gridDim.x * CM_BLOCK) { a += partials[i].x; c += partials[i].y; }
   for (int off = 32; off > 0; off >>= 1) {
     a += __shfl_down(a, off, 64);
     c += __shfl_down(c, off, 64);
@@ -232,8 +235,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_probe_reduce(const uint2 *__restri
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int j = 1; j < CM_BLOCK / 64; ++j) { a += sa[j]; c += sc[j]; }
-    counters[0] += a;
-    counters[1] += c;
+    if (a) atomicAdd(&counters[0], a);
+    if (c) atomicAdd(&counters[1], c);
   }
 }
 
@@ -294,86 +297,22 @@ __global__ __launch_bounds__(CM_BLOCK) void k_stats_reduce(const unsigned long l
 }
 
 // ---------------------------------------------------------------------------------------
-// exclusive prefix sum of uint32 (n inputs -> n+1 outputs), three-phase, recursive
+// exclusive prefix sum of uint32: n inputs -> n+1 outputs (out[n] = total).  rocPRIM's
+// single-pass decoupled look-back scan over n+1 elements with in[n] forced to 0 (every
+// counted array is allocated with one spare element).
 // ---------------------------------------------------------------------------------------
-#define SCAN_ITEMS 8
-#define SCAN_TILE (CM_BLOCK * SCAN_ITEMS)
-
-__global__ __launch_bounds__(CM_BLOCK) void k_scan_tile(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                         uint32_t n, uint32_t *__restrict__ tile_sum) {
-  __shared__ uint32_t wsum[CM_BLOCK / 64];
-  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  uint32_t v[SCAN_ITEMS];
-  uint32_t s = 0;
-#pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    v[j] = base + j < n ? in[base + j] : 0;
-    s += v[j];
-  }
-  // inclusive scan of s across the wave
-  uint32_t inc = s;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) wsum[wv] = inc;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int j = 0; j < wv; ++j) woff += wsum[j];
-  uint32_t run = woff + inc - s;
-#pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    if (base + j < n) out[base + j] = run;
-    run += v[j];
-  }
-  if (threadIdx.x == CM_BLOCK - 1) tile_sum[blockIdx.x] = woff + inc;
-}
-
-__global__ __launch_bounds__(CM_BLOCK) void k_scan_add(uint32_t *__restrict__ out, uint32_t n,
-                                                        const uint32_t *__restrict__ tile_off) {
-  const uint32_t add = tile_off[blockIdx.x];
-  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j)
-    if (base + j < n) out[base + j] += add;
-}
-
-__global__ void k_scan_total(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *tile_off,
-                             const uint32_t *tile_sum, uint32_t n_tiles) {
-  // out[n] = total
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    (void)in;
-    out[n] = n == 0 ? 0 : tile_off[n_tiles - 1] + tile_sum[n_tiles - 1];
-  }
-}
-
-// tmp must hold at least cm_scan_tmp_words(n) uint32
 size_t cm_scan_tmp_words(uint32_t n) {
-  size_t words = 0;
-  uint32_t m = n;
-  while (true) {
-    const uint32_t tiles = (m + SCAN_TILE - 1) / SCAN_TILE;
-    words += 2 * (size_t)(tiles + 1) + 2;
-    if (tiles <= 1) break;
-    m = tiles;
-  }
-  return words + 16;
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n + 1,
+                                rocprim::plus<uint32_t>(), hipStream_t(0));
+  return bytes / 4 + 64;
 }
 
 void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, hipStream_t s) {
-  if (n == 0) { (void)hipMemsetAsync(out, 0, sizeof(uint32_t), s); return; }
-  const uint32_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  uint32_t *tile_sum = tmp;            // [tiles]
-  uint32_t *tile_off = tmp + tiles + 1; // [tiles+1]
-  hipLaunchKernelGGL(k_scan_tile, dim3(tiles), dim3(CM_BLOCK), 0, s, in, out, n, tile_sum);
-  if (tiles > 1) {
-    cm_scan_u32(tile_sum, tile_off, tiles, tmp + 2 * (size_t)(tiles + 1) + 2, s);
-    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(CM_BLOCK), 0, s, out, n, tile_off);
-  } else {
-    (void)hipMemsetAsync(tile_off, 0, sizeof(uint32_t), s);
-  }
-  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, s, in, out, n, tile_off, tile_sum, tiles);
+  (void)hipMemsetAsync(const_cast<uint32_t *>(in) + n, 0, sizeof(uint32_t), s);
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s);
+  (void)rocprim::exclusive_scan((void *)tmp, bytes, in, out, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -449,5 +388,5 @@ void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash
   const uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
   hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(CM_BLOCK), 0, s, bkt, bmask, hash, val, kind, n, (uint2 *)partials);
   if (partials && counters)
-    hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
+    hipLaunchKernelGGL(k_probe_reduce, dim3(blocks / (CM_BLOCK * 8) + 1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
 }

@@ -144,7 +144,7 @@ static int sy_build_index(cmgpu_ctx *c) {
   const uint32_t nch = (uint32_t)chunks.size();
   if (nch == 0) { cm_set_error(c, "empty reference"); return CMGPU_EINVAL; }
   DevBuf d_chunks, d_cnt, d_off, d_tmp;
-  if (d_chunks.ensure((size_t)nch * sizeof(SyChunk)) || d_cnt.ensure((size_t)nch * 4) || d_off.ensure(((size_t)nch + 1) * 4) ||
+  if (d_chunks.ensure((size_t)nch * sizeof(SyChunk)) || d_cnt.ensure(((size_t)nch + 1) * 4) || d_off.ensure(((size_t)nch + 1) * 4) ||
       d_tmp.ensure(cm_scan_tmp_words(nch) * 4)) { cm_set_error(c, "out of device memory (index build)"); return CMGPU_ENOMEM; }
   SYCHECK(c, hipMemcpyAsync(d_chunks.p, chunks.data(), (size_t)nch * sizeof(SyChunk), hipMemcpyHostToDevice, s));
   const dim3 g((nch + SY_BLOCK - 1) / SY_BLOCK), b(SY_BLOCK);
@@ -182,7 +182,7 @@ static int sy_build_index(cmgpu_ctx *c) {
   sort_tmp.release(); h1.release(); t1.release();
   // ---- singleton / multi flags, occurrence offsets, key count
   DevBuf multi, starts, opos, spos, tmp2;
-  if (multi.ensure((size_t)n_mm * 4) || starts.ensure((size_t)n_mm * 4) || opos.ensure(((size_t)n_mm + 1) * 4) ||
+  if (multi.ensure(((size_t)n_mm + 1) * 4) || starts.ensure(((size_t)n_mm + 1) * 4) || opos.ensure(((size_t)n_mm + 1) * 4) ||
       spos.ensure(((size_t)n_mm + 1) * 4) || tmp2.ensure(cm_scan_tmp_words(n_mm) * 4)) {
     cm_set_error(c, "out of device memory (index flags)"); return CMGPU_ENOMEM;
   }
