@@ -131,7 +131,15 @@ def main():
     ap.add_argument("--preset", default="atac")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--probe-repeat", type=int, default=10)
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the RCCL record exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
+
+    # RCCL prints a version banner on the process's stdout; the contract is ONE JSON line there.
+    # Everything below writes to stderr; the JSON goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -141,9 +149,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (chromap_amd has no CPU path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -155,7 +164,7 @@ def main():
         log("[bench] synthetic genome + index on device in %.1fs" % t_index)
     g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=1000 + rank)
     ex = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         from chromap_amd.distributed import RecordExchange
         ex = RecordExchange(args.pairs, torch.device("cuda", local_rank))
 
@@ -250,11 +259,17 @@ def main():
             "counters_per_step": {k: v // steps for k, v in s.items()},
             "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),
         }
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     g.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if result_line is not None:
+        os.write(json_fd, (result_line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
