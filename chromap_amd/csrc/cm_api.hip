@@ -127,6 +127,30 @@ static int select_device(int device_id) {
   return CMGPU_OK;
 }
 
+// reference -> HBM: raw bytes, 64 zero bytes after every sequence (so windows read past an end see 0)
+int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref) {
+  c->n_seq = ref->n_sequences;
+  c->h_ref_off.resize(c->n_seq);
+  c->h_ref_len.assign(ref->lengths, ref->lengths + c->n_seq);
+  uint64_t tot = 64;
+  for (uint32_t i = 0; i < c->n_seq; ++i) {
+    c->h_ref_off[i] = tot;
+    tot += (uint64_t)ref->lengths[i] + 64;
+    tot = (tot + 15) & ~15ull;
+  }
+  c->ref_bytes = tot;
+  if (c->ref.ensure(tot) || c->ref_off.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 8) || c->ref_len.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 4)) {
+    cm_set_error(c, "out of device memory (reference)"); return CMGPU_ENOMEM;
+  }
+  hipError_t e = hipMemset(c->ref.p, 0, tot);
+  for (uint32_t i = 0; e == hipSuccess && i < c->n_seq; ++i)
+    e = hipMemcpy((uint8_t *)c->ref.p + c->h_ref_off[i], ref->sequences[i], ref->lengths[i], hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_off.p, c->h_ref_off.data(), (size_t)c->n_seq * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_len.p, c->h_ref_len.data(), (size_t)c->n_seq * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { cm_set_error(c, std::string("reference upload: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
                             int device_id, cmgpu_ctx **out) {
   if (!index || !ref || !params || !out) { cm_set_error(nullptr, "null argument"); return CMGPU_EINVAL; }
@@ -168,26 +192,8 @@ extern "C" int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view 
   if (c->n_occ && hipMemcpy(c->occ.p, index->occurrences, (size_t)c->n_occ * 8, hipMemcpyHostToDevice) != hipSuccess) {
     cm_set_error(nullptr, "occurrence upload failed"); cmgpu_destroy(c); return CMGPU_EHIP;
   }
-  // ---- reference -> HBM: raw bytes, 64 zero bytes after every sequence
-  c->n_seq = ref->n_sequences;
-  c->h_ref_off.resize(c->n_seq);
-  c->h_ref_len.assign(ref->lengths, ref->lengths + c->n_seq);
-  uint64_t tot = 64;
-  for (uint32_t i = 0; i < c->n_seq; ++i) {
-    c->h_ref_off[i] = tot;
-    tot += (uint64_t)ref->lengths[i] + 64;
-    tot = (tot + 15) & ~15ull;
-  }
-  c->ref_bytes = tot;
-  if (c->ref.ensure(tot) || c->ref_off.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 8) || c->ref_len.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 4)) {
-    cm_set_error(nullptr, "out of device memory (reference)"); cmgpu_destroy(c); return CMGPU_ENOMEM;
-  }
-  hipError_t e = hipMemset(c->ref.p, 0, tot);
-  for (uint32_t i = 0; e == hipSuccess && i < c->n_seq; ++i)
-    e = hipMemcpy((uint8_t *)c->ref.p + c->h_ref_off[i], ref->sequences[i], ref->lengths[i], hipMemcpyHostToDevice);
-  if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_off.p, c->h_ref_off.data(), (size_t)c->n_seq * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_len.p, c->h_ref_len.data(), (size_t)c->n_seq * 4, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { cm_set_error(nullptr, std::string("reference upload: ") + hipGetErrorString(e)); cmgpu_destroy(c); return CMGPU_EHIP; }
+  rc = cm_upload_reference(c, ref);
+  if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
   *out = c;
   return CMGPU_OK;
 }

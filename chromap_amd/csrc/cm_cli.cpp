@@ -1,0 +1,296 @@
+// cm_cli.cpp -- `chromap-amd`: command-line host with chromap's flags for the mapping path
+// (chromap_driver.cc:216-761), driving the HIP path through the C ABI.  Host work only:
+// argument parsing, FASTQ(.gz) ingest into SoA batches (whole multiples of the reference's
+// 500000-pair read batch), statistics, and the post-processing that writes BED / pairs.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/chromap_amd.h"
+
+static void die(const std::string &m) {  // ExitWithMessage (utils.h:71-74)
+  fprintf(stderr, "%s\n", m.c_str());
+  exit(-1);
+}
+
+struct FastxReader {
+  gzFile f = nullptr;
+  std::vector<char> buf;
+  bool open(const std::string &path) {
+    f = gzopen(path.c_str(), "r");
+    if (f) gzbuffer(f, 1 << 20);
+    buf.resize(1 << 16);
+    return f != nullptr;
+  }
+  bool line(std::string &out) {
+    out.clear();
+    for (;;) {
+      if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
+      size_t l = strlen(buf.data());
+      const bool eol = l > 0 && buf[l - 1] == '\n';
+      while (l > 0 && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) --l;
+      out.append(buf.data(), l);
+      if (eol) return true;
+    }
+  }
+  // one FASTQ/FASTA record: name up to the first whitespace, sequence, quality (may be empty)
+  std::string pending;
+  bool record(std::string &name, std::string &seq, std::string &qual) {
+    std::string ln;
+    for (;;) {
+      if (!pending.empty()) { ln.swap(pending); pending.clear(); }
+      else if (!line(ln)) return false;
+      if (!ln.empty() && (ln[0] == '@' || ln[0] == '>')) break;
+    }
+    const bool fq = ln[0] == '@';
+    size_t e = 1;
+    while (e < ln.size() && ln[e] != ' ' && ln[e] != '\t') ++e;
+    name.assign(ln, 1, e - 1);
+    seq.clear();
+    qual.clear();
+    std::string s;
+    while (line(s)) {
+      if (fq && !s.empty() && s[0] == '+') break;
+      if (!fq && !s.empty() && s[0] == '>') { pending = s; break; }
+      seq += s;
+    }
+    if (fq) {
+      while (qual.size() < seq.size() && line(s)) qual += s;
+    }
+    return true;
+  }
+  void close() { if (f) gzclose(f); f = nullptr; }
+};
+
+struct Args {
+  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist;
+  std::vector<std::string> r1, r2;
+  cmgpu_params p;
+  bool build_index = false, out_bed = true, out_pairs = false;
+  int k = 17, w = 7, device = 0;
+  uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
+};
+
+static std::vector<std::string> split_commas(const std::string &s) {
+  std::vector<std::string> v;
+  size_t a = 0;
+  while (a <= s.size()) {
+    size_t b = s.find(',', a);
+    if (b == std::string::npos) b = s.size();
+    if (b > a) v.push_back(s.substr(a, b - a));
+    a = b + 1;
+  }
+  return v;
+}
+
+static Args parse(int argc, char **argv) {
+  Args a;
+  cmgpu_default_params(&a.p);
+  // presets first, explicit flags override (chromap_driver.cc:247-275)
+  for (int i = 1; i + 1 < argc; ++i)
+    if (!strcmp(argv[i], "--preset")) {
+      a.preset = argv[i + 1];
+      if (cmgpu_apply_preset(&a.p, argv[i + 1]) != 0) die(std::string("Unrecognized preset parameters ") + argv[i + 1] + "\n");
+      if (a.preset == "hic") { a.out_pairs = true; a.out_bed = false; }
+    }
+  for (int i = 1; i < argc; ++i) {
+    const std::string o = argv[i];
+    auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) die(std::string("missing value for ") + what); return argv[++i]; };
+    if (o == "--preset") { ++i; }
+    else if (o == "-i" || o == "--build-index") a.build_index = true;
+    else if (o == "-x" || o == "--index") a.index_path = need("-x");
+    else if (o == "-r" || o == "--ref") a.ref_path = need("-r");
+    else if (o == "-o" || o == "--output") a.out_path = need("-o");
+    else if (o == "-1" || o == "--read1") a.r1 = split_commas(need("-1"));
+    else if (o == "-2" || o == "--read2") a.r2 = split_commas(need("-2"));
+    else if (o == "-b" || o == "--barcode") a.barcode_file = need("-b");
+    else if (o == "--barcode-whitelist") a.whitelist = need("--barcode-whitelist");
+    else if (o == "-k" || o == "--kmer") a.k = atoi(need("-k"));
+    else if (o == "-w" || o == "--window") a.w = atoi(need("-w"));
+    else if (o == "-e" || o == "--error-threshold") a.p.error_threshold = atoi(need("-e"));
+    else if (o == "-s" || o == "--min-num-seeds") a.p.min_num_seeds = atoi(need("-s"));
+    else if (o == "-f" || o == "--max-seed-frequencies") {
+      auto v = split_commas(need("-f"));
+      if (v.size() != 2) die("Positive integers are required for max seed frequencies!");
+      a.p.max_seed_frequency0 = atoi(v[0].c_str());
+      a.p.max_seed_frequency1 = atoi(v[1].c_str());
+    }
+    else if (o == "-l" || o == "--max-insert-size") a.p.max_insert_size = atoi(need("-l"));
+    else if (o == "-q" || o == "--MAPQ-threshold") a.p.mapq_threshold = atoi(need("-q"));
+    else if (o == "--min-read-length") a.p.min_read_length = atoi(need("--min-read-length"));
+    else if (o == "--drop-repetitive-reads") a.p.drop_repetitive_reads = atoi(need("--drop-repetitive-reads"));
+    else if (o == "--bc-error-threshold") a.p.bc_error_threshold = atoi(need("--bc-error-threshold"));
+    else if (o == "--bc-probability-threshold") a.p.bc_probability_threshold = atof(need("--bc-probability-threshold"));
+    else if (o == "--output-mappings-not-in-whitelist") a.p.output_mappings_not_in_whitelist = 1;
+    else if (o == "--trim-adapters") a.p.trim_adapters = 1;
+    else if (o == "--remove-pcr-duplicates") a.p.remove_pcr_duplicates = 1;
+    else if (o == "--remove-pcr-duplicates-at-cell-level" || o == "--remove-pcr-duplicates-at-bulk-level") {}
+    else if (o == "--Tn5-shift") a.p.tn5_shift = 1;
+    else if (o == "--split-alignment") a.p.split_alignment = 1;
+    else if (o == "--low-mem") a.p.low_memory_mode = 1;
+    else if (o == "--BED") { a.out_bed = true; a.out_pairs = false; }
+    else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
+    else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
+    else if (o == "--device") a.device = atoi(need("--device"));
+    else if (o == "--batch-pairs") a.batch_pairs = (uint32_t)atol(need("--batch-pairs"));
+    else if (o == "-v" || o == "--version") { printf("chromap-amd 0.1 (hot path of chromap 0.3.3-r521 on gfx950)\n"); exit(0); }
+    else if (o == "-h" || o == "--help") {
+      printf("Usage: chromap-amd -i -r ref.fa -o index | chromap-amd [--preset atac|chip|hic] -x index -r ref.fa -1 r1.fq[.gz] [-2 r2.fq[.gz]]\n"
+             "       [-b barcode.fq --barcode-whitelist wl.txt] -o out [-e -s -f -l -q --min-read-length --trim-adapters\n"
+             "       --remove-pcr-duplicates --Tn5-shift --low-mem --BED|--pairs --bc-error-threshold ...]\n");
+      exit(0);
+    }
+    else die("unsupported option " + o + " (SAM/PAF/TagAlign, --chr-order and summary outputs are outside this build)");
+  }
+  if (a.batch_pairs < 500000) a.batch_pairs = 500000;
+  a.batch_pairs -= a.batch_pairs % 500000;
+  return a;
+}
+
+int main(int argc, char **argv) {
+  Args a = parse(argc, argv);
+  if (a.ref_path.empty() || a.out_path.empty()) die("No reference / output specified!");
+  cmgpu_ref_view ref;
+  if (cmgpu_load_reference_fasta(a.ref_path.c_str(), &ref) != 0) die("Cannot find sequence file " + a.ref_path);
+  fprintf(stderr, "Loaded all sequences successfully, number of sequences: %u.\n", ref.n_sequences);
+  if (a.build_index) {
+    cmgpu_ctx *bctx = nullptr;
+    if (cmgpu_create_from_reference(&ref, a.k, a.w, &a.p, a.device, &bctx) != CMGPU_OK) die(cmgpu_last_error(nullptr));
+    if (cmgpu_save_index_file(bctx, a.out_path.c_str()) != CMGPU_OK) die(cmgpu_last_error(bctx));
+    int32_t k, w; uint32_t nb, nocc; uint64_t nmm, nkeys;
+    cmgpu_index_info(bctx, &k, &w, &nb, &nocc, &nmm, &nkeys);
+    fprintf(stderr, "Collected %llu minimizers.\nLookup table size: %llu, # buckets: %u, occurrence table size: %u.\n",
+            (unsigned long long)nmm, (unsigned long long)nkeys, nb, nocc);
+    cmgpu_destroy(bctx);
+    cmgpu_free_host_ref(&ref);
+    return 0;
+  }
+  if (a.index_path.empty() || a.r1.empty()) die("No index / read files specified!");
+  const bool paired = !a.r2.empty();
+  if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
+  const bool barcoded = !a.barcode_file.empty();
+  if (barcoded && (a.whitelist.empty() || !paired)) die("this build supports barcodes only with a whitelist and paired-end reads");
+  cmgpu_index_view idx;
+  if (cmgpu_load_index_file(a.index_path.c_str(), &idx) != 0) die("Cannot read index " + a.index_path);
+  fprintf(stderr, "Kmer size: %d, window size: %d.\n", idx.kmer_size, idx.window_size);
+  cmgpu_ctx *ctx = nullptr;
+  if (cmgpu_create(&idx, &ref, &a.p, a.device, &ctx) != CMGPU_OK) die(cmgpu_last_error(nullptr));
+  cmgpu_free_host_index(&idx);
+
+  cmgpu_stats st;
+  memset(&st, 0, sizeof(st));
+  std::vector<cmgpu_record> recs;
+  std::vector<cmgpu_record_bc> recs_bc;
+  std::vector<std::string> read_names;  // pairs output needs read-1 names by read_id
+  uint64_t num_reads = 0;
+  uint32_t next_read_id = 0, bc_len = 0;
+
+  // single-cell: whitelist + abundance pre-pass over the whole barcode file (chromap.h:750-761)
+  if (barcoded) {
+    FastxReader br;
+    if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+    std::string nm, sq, ql;
+    std::vector<char> bb;
+    std::vector<uint32_t> bo(1, 0);
+    while (br.record(nm, sq, ql)) { if (sq.empty()) continue; bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
+    br.close();
+    if (bo.size() < 2) die("empty barcode file");
+    bc_len = bo[1] - bo[0];
+    uint64_t *keys = nullptr;
+    uint32_t nk = 0;
+    if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
+    if (cmgpu_set_whitelist(ctx, keys, nk, bc_len) != 0) die(cmgpu_last_error(ctx));
+    free(keys);
+    uint64_t ns = 0;
+    if (cmgpu_compute_barcode_abundance(ctx, bb.data(), bo.data(), (uint32_t)bo.size() - 1, &ns) != 0) die(cmgpu_last_error(ctx));
+    fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
+  }
+
+  for (size_t fi = 0; fi < a.r1.size(); ++fi) {
+    FastxReader f1, f2, fb;
+    if (!f1.open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
+    if (paired && !f2.open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);
+    if (barcoded && !fb.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+    bool more = true;
+    while (more) {
+      std::vector<char> b1, b2, bb, bq;
+      std::vector<uint32_t> o1(1, 0), o2(1, 0), bo(1, 0);
+      std::string n1, s1, q1, n2, s2, q2, nb, sb, qb;
+      uint32_t n = 0;
+      while (n < a.batch_pairs) {
+        const bool g1 = f1.record(n1, s1, q1);
+        const bool g2 = paired ? f2.record(n2, s2, q2) : g1;
+        const bool gb = barcoded ? fb.record(nb, sb, qb) : g1;
+        if (!g1 && !g2 && !gb) { more = false; break; }
+        if (!(g1 && g2 && gb)) die("Numbers of reads and barcodes don't match!");
+        if (s1.empty() || (paired && s2.empty())) continue;
+        b1.insert(b1.end(), s1.begin(), s1.end()); o1.push_back((uint32_t)b1.size());
+        if (paired) { b2.insert(b2.end(), s2.begin(), s2.end()); o2.push_back((uint32_t)b2.size()); }
+        if (barcoded) { bb.insert(bb.end(), sb.begin(), sb.end()); bq.insert(bq.end(), qb.begin(), qb.end()); bq.resize(bb.size(), 'I'); bo.push_back((uint32_t)bb.size()); }
+        if (a.out_pairs) read_names.push_back(n1);
+        ++n;
+      }
+      if (n == 0) break;
+      num_reads += paired ? 2ull * n : n;
+      uint64_t k = 0;
+      int rc;
+      if (barcoded) {
+        const size_t base = recs_bc.size();
+        recs_bc.resize(base + n);
+        cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
+        cmgpu_barcode_batch bc{bb.data(), bq.data(), bo.data()};
+        rc = cmgpu_map_pairs_barcoded(ctx, &bt, &bc, recs_bc.data() + base, n, &k, &st);
+        recs_bc.resize(base + k);
+      } else if (paired) {
+        const size_t base = recs.size();
+        recs.resize(base + n);
+        cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
+        rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, n, &k, &st);
+        recs.resize(base + k);
+      } else {
+        const size_t base = recs.size();
+        recs.resize(base + n);
+        cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};
+        rc = cmgpu_map_single(ctx, &bt, recs.data() + base, n, &k, &st);
+        recs.resize(base + k);
+      }
+      if (rc != CMGPU_OK) die(cmgpu_last_error(ctx));
+      next_read_id += n;
+      fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
+    }
+    f1.close(); f2.close(); fb.close();
+  }
+  // Chromap::OutputMappingStatistics (chromap.cc:808-823)
+  fprintf(stderr, "Number of reads: %llu.\nNumber of mapped reads: %llu.\nNumber of uniquely mapped reads: %llu.\n"
+                  "Number of reads have multi-mappings: %llu.\nNumber of candidates: %llu.\nNumber of mappings: %llu.\n"
+                  "Number of uni-mappings: %llu.\nNumber of multi-mappings: %llu.\n",
+          (unsigned long long)num_reads, (unsigned long long)st.num_mapped_reads, (unsigned long long)st.num_uniquely_mapped_reads,
+          (unsigned long long)(st.num_mapped_reads - st.num_uniquely_mapped_reads), (unsigned long long)st.num_candidates,
+          (unsigned long long)st.num_mappings, (unsigned long long)st.num_uniquely_mapped_reads,
+          (unsigned long long)(st.num_mappings - st.num_uniquely_mapped_reads));
+  if (barcoded)
+    fprintf(stderr, "Number of barcodes in whitelist: %llu.\nNumber of corrected barcodes: %llu.\n",
+            (unsigned long long)st.num_barcode_in_whitelist, (unsigned long long)st.num_corrected_barcode);
+  int64_t lines;
+  if (a.out_pairs) {
+    std::vector<const char *> rn(read_names.size());
+    for (size_t i = 0; i < rn.size(); ++i) rn[i] = read_names[i].c_str();
+    lines = cmgpu_write_pairs(ref.names, ref.lengths, ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
+                              a.out_path.c_str());
+  } else if (barcoded) {
+    lines = cmgpu_write_bed_pe_bc(ref.names, ref.n_sequences, &a.p, recs_bc.data(), recs_bc.size(), bc_len, a.out_path.c_str());
+  } else if (paired) {
+    lines = cmgpu_write_bed_pe(ref.names, ref.n_sequences, &a.p, recs.data(), recs.size(), a.out_path.c_str());
+  } else {
+    lines = cmgpu_write_bed_se(ref.names, ref.n_sequences, &a.p, recs.data(), recs.size(), a.out_path.c_str());
+  }
+  if (lines < 0) die("cannot write " + a.out_path);
+  fprintf(stderr, "Number of output mappings (passed filters): %lld\n", (long long)lines);
+  cmgpu_destroy(ctx);
+  cmgpu_free_host_ref(&ref);
+  return 0;
+}

@@ -71,6 +71,7 @@ struct cmgpu_ctx {
 void cm_set_error(cmgpu_ctx *ctx, const std::string &msg);
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id);
 void cm_fill_dev(cmgpu_ctx *c, CmDev &d);
+int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref);
 
 static inline uint32_t cm_num_chunks_host(uint32_t n, uint32_t ref_batch, uint32_t grain) {
   uint32_t tot = 0;

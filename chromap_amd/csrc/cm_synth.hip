@@ -270,6 +270,58 @@ extern "C" int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences
   return CMGPU_OK;
 }
 
+// Index::Construct (index.cc:12-89) on the device for a caller-provided reference: the same
+// builder as the synthetic genome's.  Lookups are identical to an index built by the
+// reference (same keys, values, occurrence order); only the bucket an entry lands in may
+// differ where khash's resize history would have placed it elsewhere along its probe path.
+extern "C" int cmgpu_create_from_reference(const cmgpu_ref_view *ref, int32_t kmer_size, int32_t window_size,
+                                           const cmgpu_params *params, int device_id, cmgpu_ctx **out) {
+  if (!ref || !params || !out || ref->n_sequences == 0) { cm_set_error(nullptr, "bad argument"); return CMGPU_EINVAL; }
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { cm_set_error(nullptr, "no HIP device available (this library has no CPU path)"); return CMGPU_ENODEVICE; }
+  if (device_id < 0 || device_id >= n || hipSetDevice(device_id) != hipSuccess) { cm_set_error(nullptr, "bad device"); return CMGPU_EINVAL; }
+  cmgpu_ctx *c = new cmgpu_ctx();
+  int rc = cm_ctx_init_common(c, params, kmer_size, window_size, device_id);
+  if (rc == CMGPU_OK) rc = cm_upload_reference(c, ref);
+  if (rc == CMGPU_OK) rc = sy_build_index(c);
+  if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
+  *out = c;
+  return CMGPU_OK;
+}
+
+// Index::Save (index.cc:91-121) of the resident index: kmer size, window size, key count,
+// kh_save's {n_buckets, size, n_occupied, upper_bound, flags, keys, vals} (khash.h:222-233),
+// occurrence count and table.  Empty buckets are written as zero key/value.
+extern "C" int cmgpu_save_index_file(cmgpu_ctx *c, const char *path) {
+  if (!c || !path) return CMGPU_EINVAL;
+  const uint32_t nb = c->bmask + 1;
+  std::vector<uint64_t> bk((size_t)nb * 2), occ(c->n_occ);
+  int rc = cmgpu_export_index(c, bk.data(), occ.data());
+  if (rc) return rc;
+  const size_t fw = nb < 16 ? 1 : nb >> 4;
+  std::vector<uint32_t> flags(fw, 0xaaaaaaaau);  // every bucket "empty" (khash.h:155-161)
+  std::vector<uint64_t> keys(nb, 0), vals(nb, 0);
+  uint32_t nk = 0;
+  for (uint32_t i = 0; i < nb; ++i) {
+    if (bk[2 * (size_t)i] == CM_EMPTY_KEY) continue;
+    keys[i] = bk[2 * (size_t)i];
+    vals[i] = bk[2 * (size_t)i + 1];
+    flags[i >> 4] &= ~(3u << ((i & 15) << 1));
+    ++nk;
+  }
+  FILE *f = fopen(path, "wb");
+  if (!f) { cm_set_error(c, std::string("cannot open ") + path); return CMGPU_EIO; }
+  const int32_t k = c->p.k, w = c->p.w;
+  const uint32_t hdr[4] = {nb, nk, nk, (uint32_t)((double)nb * 0.77 + 0.5)};
+  bool ok = fwrite(&k, 4, 1, f) == 1 && fwrite(&w, 4, 1, f) == 1 && fwrite(&nk, 4, 1, f) == 1 && fwrite(hdr, 4, 4, f) == 4 &&
+            fwrite(flags.data(), 4, fw, f) == fw && fwrite(keys.data(), 8, nb, f) == nb && fwrite(vals.data(), 8, nb, f) == nb &&
+            fwrite(&c->n_occ, 4, 1, f) == 1 && (c->n_occ == 0 || fwrite(occ.data(), 8, c->n_occ, f) == c->n_occ);
+  ok = fclose(f) == 0 && ok;
+  if (!ok) { cm_set_error(c, std::string("short write to ") + path); return CMGPU_EIO; }
+  return CMGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // synthetic read pairs drawn from the resident reference: fragment start
 // uniform, length uniform in [frag_min, frag_max), R1 = fragment head, R2 = head of the

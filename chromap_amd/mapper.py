@@ -73,7 +73,7 @@ class ChromapGPU:
     """One context per GPU: index + reference resident in HBM, batches mapped by HIP kernels."""
 
     def __init__(self, index_path=None, ref_path=None, params=None, device=0, preset=None, synthetic=None,
-                 **overrides):
+                 build_index=None, **overrides):
         self.L = _capi.lib()
         self.params = params if params is not None else _capi.default_params(preset, **overrides)
         self.ctx = C.c_void_p()
@@ -85,6 +85,16 @@ class ChromapGPU:
             rc = self.L.cmgpu_create_synthetic(total, nseq, seed, 17, 7, C.byref(self.params), device, C.byref(self.ctx))
             self._check(rc, None)
             self.names = [b"chr%d" % (i + 1) for i in range(nseq)]
+        elif index_path is None:
+            # Index::Construct on the device (kmer/window from `build_index=(k, w)`, default 17/7)
+            self._ref = RefView()
+            if self.L.cmgpu_load_reference_fasta(ref_path.encode(), C.byref(self._ref)) != 0:
+                raise ChromapError("cannot read reference %s" % ref_path)
+            k, w = build_index if build_index else (17, 7)
+            rc = self.L.cmgpu_create_from_reference(C.byref(self._ref), k, w, C.byref(self.params), device,
+                                                    C.byref(self.ctx))
+            self._check(rc, None)
+            self.names = [self._ref.names[i] for i in range(self._ref.n_sequences)]
         else:
             self._idx = IndexView()
             self._ref = RefView()
@@ -97,6 +107,10 @@ class ChromapGPU:
             self._check(rc, None)
             self.names = [self._ref.names[i] for i in range(self._ref.n_sequences)]
         self.stats = Stats()
+
+    def save_index(self, path):
+        """Index::Save of the resident index (loads in the reference's kh_load)"""
+        self._check(self.L.cmgpu_save_index_file(self.ctx, path.encode()), self.ctx)
 
     def _check(self, rc, ctx):
         if rc != 0:

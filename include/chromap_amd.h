@@ -173,6 +173,15 @@ int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const
 int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
                            int32_t window_size, const cmgpu_params *params, int device_id, cmgpu_ctx **out);
 
+/* Replaces: Index::Construct (src/index.cc:12-89) -- builds the minimizer index of `ref` on
+ * the device (chunked minimizer pass, radix sort by (hash, hit), khash-sized open-addressing
+ * table) and keeps it resident together with the reference; the ctx maps like one made by
+ * cmgpu_create.  cmgpu_save_index_file replaces Index::Save (src/index.cc:91-121): the file
+ * loads in the reference (kh_load) and answers every lookup identically. */
+int cmgpu_create_from_reference(const cmgpu_ref_view *ref, int32_t kmer_size, int32_t window_size,
+                                const cmgpu_params *params, int device_id, cmgpu_ctx **out);
+int cmgpu_save_index_file(cmgpu_ctx *ctx, const char *path);
+
 int cmgpu_destroy(cmgpu_ctx *ctx);
 /* ctx may be NULL (returns the last error of a failed cmgpu_create*). */
 const char *cmgpu_last_error(const cmgpu_ctx *ctx);

@@ -1,0 +1,81 @@
+"""The command-line host (chromap_amd/chromap-amd, cm_cli.cpp) run exactly like the reference
+was run for the golden outputs (tests/golden/make_golden.py): `-i` index build on the device,
+then mapping with the golden case's flags; output bytes and stderr counters must equal the
+reference's.  Where the built reference binary travelled to the box (oracle/_ref/chromap),
+the device-built index file is also loaded by the *reference* to show it is a valid index."""
+import hashlib
+import os
+import re
+import subprocess
+
+import pytest
+
+import datasets as ds
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ds.ROOT, "chromap_amd", "chromap-amd")
+REF = os.path.join(ds.ROOT, "oracle", "_ref", "chromap")
+CASES = ["toy_atac", "s1_atac", "s2_atac_q0", "s3_chip", "h1_hic", "b1_atac_bc", "s1_se_chip", "s4_se_atac_q0"]
+
+
+def _reads(name):
+    fa, r1, r2 = ds.case_inputs(name)
+    m = ds.single_end_mate(name)
+    reads = ["-1", r1, "-2", r2] if not m else ["-1", r1 if m == 1 else r2]
+    if ds.has_barcodes(name):
+        bc, wl = ds.case_barcode_inputs(name)
+        reads += ["-b", bc, "--barcode-whitelist", wl]
+    return fa, reads
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    assert os.path.exists(CLI), "chromap-amd not built (make -C chromap_amd/csrc)"
+    cache = {}
+
+    def get(name):
+        fa, _ = _reads(name)
+        if fa not in cache:
+            idx = str(tmp_path_factory.mktemp("idx") / "d.idx")
+            subprocess.run([CLI, "-i", "-r", fa, "-o", idx], check=True, stderr=subprocess.PIPE)
+            cache[fa] = idx
+        return cache[fa]
+    return get
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_cli_matches_reference_output(name, built, tmp_path):
+    meta = ds.case_meta(name)
+    fa, reads = _reads(name)
+    out = str(tmp_path / "out.txt")
+    r = subprocess.run([CLI] + meta["chromap_flags"] + ["-x", built(name), "-r", fa] + reads + ["-o", out, "-t", "1"],
+                       stderr=subprocess.PIPE, check=True)
+    with open(out, "rb") as f:
+        got = f.read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    assert got == ds.case_golden_bed(name)
+    log = r.stderr.decode()
+    for key, pat in (("num_reads", r"Number of reads: (\d+)"), ("num_mapped_reads", r"Number of mapped reads: (\d+)"),
+                     ("num_uniquely_mapped_reads", r"Number of uniquely mapped reads: (\d+)"),
+                     ("num_candidates", r"Number of candidates: (\d+)"), ("num_mappings", r"Number of mappings: (\d+)"),
+                     ("num_output", r"Number of output mappings \(passed filters\): (\d+)")):
+        want = meta["reference_stderr_counters"].get(key)
+        if want is not None:
+            assert int(re.search(pat, log).group(1)) == want, key
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="built reference binary not present")
+def test_device_built_index_loads_in_reference(built, tmp_path):
+    name = "s1_atac"
+    meta = ds.case_meta(name)
+    fa, reads = _reads(name)
+    out = str(tmp_path / "ref_out.bed")
+    subprocess.run([REF] + meta["chromap_flags"] + ["-x", built(name), "-r", fa] + reads + ["-o", out, "-t", "2"],
+                   check=True, stderr=subprocess.PIPE)
+    assert ds.md5(out) == meta["bed_md5"]
+
+
+def test_cli_rejects_unknown_option(tmp_path):
+    r = subprocess.run([CLI, "--SAM", "-x", "x", "-r", os.path.join(ds.GOLD, "toy", "ref.fa"), "-1", "a", "-o",
+                        str(tmp_path / "o")], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"unsupported option" in r.stderr
