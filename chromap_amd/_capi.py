@@ -86,7 +86,11 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device",
            "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
+           "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
+           "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
+
+TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC = 0, 1, 2
 
 _LIB = None
 
@@ -129,6 +133,14 @@ def declare(L):
     sig("cmgpu_write_pairs", C.c_int64, [P(C.c_char_p), P(C.c_uint32), C.c_uint32, P(Params), C.c_void_p, C.c_uint64,
                                          P(C.c_char_p), C.c_uint32, C.c_char_p])
     sig("cmgpu_map_single", C.c_int, [C.c_void_p, P(SingleBatch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
+    sig("cmgpu_store_clear", C.c_int, [C.c_void_p])
+    sig("cmgpu_store_append_resident", C.c_int, [C.c_void_p, P(C.c_uint64)])
+    sig("cmgpu_store_append", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int])
+    sig("cmgpu_store_format", C.c_int, [C.c_void_p, C.c_int, P(C.c_char_p), C.c_uint32, P(Params), C.c_uint32,
+                                        P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_store_text", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64])
+    sig("cmgpu_store_write_text", C.c_int, [C.c_void_p, C.c_char_p, C.c_int])
+    sig("cmgpu_store_info", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)])
     sig("cmgpu_write_bed_se", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
     sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])

@@ -50,6 +50,10 @@ struct cmgpu_ctx {
   uint64_t wl_num_sample = 0;
   bool has_barcodes = false;  // resident batch carries barcodes
   bool single = false;        // resident batch is single-end
+  // device-side record store + rendered text (cm_post.hip)
+  DevBuf store, store_bc, text;
+  uint64_t store_n = 0, store_cap = 0, text_bytes = 0, text_lines = 0;
+  bool store_has_bc = false;
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;
@@ -64,7 +68,7 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text};
   }
 };
 

@@ -183,6 +183,14 @@ extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_seque
                                       cmgpu_record *rec, uint64_t n, const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
+  // in-memory flavour (chromap.h:1322-1355): Tn5 shift first, sort, RemovePCRDuplicate keeps the
+  // LAST record of a run (mapping_processor.h:160-202); low-memory flavour: see above
+  const bool inmem = !p->low_memory_mode;
+  const bool shift_late = p->tn5_shift && !inmem;
+  if (inmem && p->tn5_shift)
+    for (uint64_t i = 0; i < n; ++i) {
+      rec[i].fragment_start += 4; rec[i].positive_alignment_length -= 4; rec[i].fragment_length -= 9; rec[i].negative_alignment_length -= 5;
+    }
   std::sort(rec, rec + n, rec_less);
   std::string buf;
   buf.reserve(1 << 20);
@@ -190,7 +198,7 @@ extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_seque
   auto emit = [&](cmgpu_record r, uint32_t dups) {
     if (r.rid >= n_sequences) return;
     r.num_dups = (uint8_t)(dups > 255 ? 255 : dups);
-    if (p->tn5_shift) {
+    if (shift_late) {
       r.fragment_start += 4;
       r.positive_alignment_length -= 4;
       r.fragment_length -= 9;
@@ -209,24 +217,21 @@ extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_seque
     ++lines;
     if (buf.size() > (1 << 20) - 256) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
   };
-  if (p->low_memory_mode && p->remove_pcr_duplicates) {
-    uint64_t i = 0;
-    while (i < n) {
-      cmgpu_record last = rec[i];
-      uint32_t dups = 1;
-      uint64_t j = i + 1;
-      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start &&
-             rec[j].fragment_length == last.fragment_length) {
+  uint64_t i = 0;
+  while (i < n) {
+    cmgpu_record last = rec[i];
+    uint32_t dups = 1;
+    uint64_t j = i + 1;
+    if (p->remove_pcr_duplicates) {
+      while (j < n && rec[j].rid == rec[i].rid && rec[j].fragment_start == rec[i].fragment_start &&
+             rec[j].fragment_length == rec[i].fragment_length) {
         ++dups;
-        if (rec[j].mapq > last.mapq) last = rec[j];
+        if (inmem || rec[j].mapq > last.mapq) last = rec[j];
         ++j;
       }
-      if (last.mapq >= p->mapq_threshold) emit(last, dups);
-      i = j;
     }
-  } else {
-    for (uint64_t i = 0; i < n; ++i)
-      if (rec[i].mapq >= p->mapq_threshold) emit(rec[i], 1);
+    if (last.mapq >= p->mapq_threshold) emit(last, dups);
+    i = j;
   }
   if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
   fclose(f);
@@ -318,6 +323,9 @@ extern "C" int64_t cmgpu_write_bed_pe_bc(const char *const *names, uint32_t n_se
                                          cmgpu_record_bc *rec, uint64_t n, uint32_t barcode_length, const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
+  const bool inmem = !p->low_memory_mode;
+  if (inmem && p->tn5_shift)
+    for (uint64_t t = 0; t < n; ++t) { rec[t].r.fragment_start += 4; rec[t].r.fragment_length -= 9; }
   std::sort(rec, rec + n, [](const cmgpu_record_bc &a, const cmgpu_record_bc &b) {
     return std::tie(a.r.rid, a.r.fragment_start, a.r.fragment_length, a.barcode, a.r.mapq, a.r.direction, a.r.is_unique, a.r.read_id,
                     a.r.positive_alignment_length, a.r.negative_alignment_length) <
@@ -336,13 +344,13 @@ extern "C" int64_t cmgpu_write_bed_pe_bc(const char *const *names, uint32_t n_se
       while (j < n && rec[j].r.rid == last.r.rid && rec[j].barcode == last.barcode &&
              rec[j].r.fragment_start == last.r.fragment_start && rec[j].r.fragment_length == last.r.fragment_length) {
         ++dups;
-        if (rec[j].r.mapq > last.r.mapq) last = rec[j];
+        if (inmem || rec[j].r.mapq > last.r.mapq) last = rec[j];
         ++j;
       }
     }
     if (last.r.mapq >= p->mapq_threshold && last.r.rid < n_sequences) {
       cmgpu_record r = last.r;
-      if (p->tn5_shift) { r.fragment_start += 4; r.fragment_length -= 9; }
+      if (p->tn5_shift && !inmem) { r.fragment_start += 4; r.fragment_length -= 9; }
       buf.append(names[r.rid]);
       buf.push_back('\t');
       put_u32(buf, r.fragment_start);
@@ -368,6 +376,9 @@ extern "C" int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_seque
                                       uint64_t n, const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
+  const bool inmem = !p->low_memory_mode;
+  if (inmem && p->tn5_shift)
+    for (uint64_t t = 0; t < n; ++t) { if (rec[t].direction == 1) rec[t].fragment_start += 4; else rec[t].fragment_length -= 5; }
   std::sort(rec, rec + n, [](const cmgpu_record &a, const cmgpu_record &b) {
     return std::tie(a.rid, a.fragment_start, a.fragment_length, a.mapq, a.direction, a.is_unique, a.read_id) <
            std::tie(b.rid, b.fragment_start, b.fragment_length, b.mapq, b.direction, b.is_unique, b.read_id);
@@ -380,15 +391,15 @@ extern "C" int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_seque
     cmgpu_record last = rec[i];
     uint32_t dups = 1;
     uint64_t j = i + 1;
-    if (p->remove_pcr_duplicates && p->low_memory_mode) {
-      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start) {
+    if (p->remove_pcr_duplicates) {
+      while (j < n && rec[j].rid == rec[i].rid && rec[j].fragment_start == rec[i].fragment_start) {
         ++dups;
-        if (rec[j].mapq > last.mapq) last = rec[j];
+        if (inmem || rec[j].mapq > last.mapq) last = rec[j];
         ++j;
       }
     }
     if (last.mapq >= p->mapq_threshold && last.rid < n_sequences) {
-      if (p->tn5_shift) { if (last.direction == 1) last.fragment_start += 4; else last.fragment_length -= 5; }
+      if (p->tn5_shift && !inmem) { if (last.direction == 1) last.fragment_start += 4; else last.fragment_length -= 5; }
       buf.append(names[last.rid]);
       buf.push_back('\t');
       put_u32(buf, last.fragment_start);

@@ -1,0 +1,483 @@
+// cm_post.hip -- device-side post-processing of the mapping records:
+// what MappingProcessor::SortOutputMappings / RemovePCRDuplicate (mapping_processor.h:100-202),
+// the low-memory merge (mapping_writer.h:166-376) and the BED writers (mapping_writer.cc:44-131)
+// do on the host, as radix sorts + one selection pass + one text-formatting pass in HBM.
+//
+//   record store   dense cmgpu_record array (+ parallel barcode array) that batches append to
+//   sort           LSD over 64-bit key words, payload = record index:
+//                    w0 = mapq | direction | is_unique | read_id            (40 bits)
+//                    [w1 = barcode]                                          (single-cell only)
+//                    wT = rid | fragment_start | fragment_length            (48 + rid bits)
+//                  == per-rid std::sort with the record's operator< (bed_mapping.h:32-38,
+//                  85-90, 145-153, 208-215); read_id is unique, so later tie fields never decide
+//   select         one thread per sorted position: head of an operator== run picks the run's
+//                  survivor (low-memory merge: first record with the maximal MAPQ; in-memory
+//                  RemovePCRDuplicate: last record of the run), num_dups = min(255, run length),
+//                  MAPQ filter, line length
+//   format         exclusive scan of line lengths; each block renders its lines into LDS and
+//                  stores them with coalesced writes
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "cm_ctx.h"
+#include "cm_kernels.h"
+
+#define PP_BLOCK 256
+#define PP_LDS_BYTES 32768
+
+#define PPCHECK(ctx, call)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cm_set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                  \
+      return CMGPU_EHIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+struct PpCfg {
+  int kind;       // CMGPU_TEXT_BED_PE / _SE / _PE_BC
+  int dedup;      // remove_pcr_duplicates
+  int inmem;      // !low_memory_mode: Tn5 shift before the sort, last-of-run survives
+  int tn5;
+  int mapq_thr;
+  uint32_t n_seq;
+  uint32_t bc_len;
+};
+
+struct PpRec {  // cmgpu_record, read with two 8-byte loads + one 8-byte load
+  uint32_t read_id, rid, start;
+  uint16_t len;
+  uint8_t mapq, dir, uniq, dups;
+  uint16_t pal, nal;
+};
+
+__device__ __forceinline__ PpRec pp_load(const uint8_t *store, uint32_t i) {
+  const uint64_t *p = reinterpret_cast<const uint64_t *>(store + (uint64_t)i * 24);
+  const uint64_t a = p[0], b = p[1], c = p[2];
+  PpRec r;
+  r.read_id = (uint32_t)a;
+  r.rid = (uint32_t)(a >> 32);
+  r.start = (uint32_t)b;
+  r.len = (uint16_t)(b >> 32);
+  r.mapq = (uint8_t)(b >> 48);
+  r.dir = (uint8_t)(b >> 56);
+  r.uniq = (uint8_t)c;
+  r.dups = (uint8_t)(c >> 8);
+  r.pal = (uint16_t)(c >> 16);
+  r.nal = (uint16_t)(c >> 32);
+  return r;
+}
+
+// Tn5Shift (bed_mapping.h:48-54, 100-106, 165-170, 224-229)
+__device__ __forceinline__ void pp_tn5(PpRec &r, int kind) {
+  if (kind == CMGPU_TEXT_BED_SE) {
+    if (r.dir == 1) r.start += 4; else r.len = (uint16_t)(r.len - 5);
+  } else {
+    r.start += 4;
+    r.len = (uint16_t)(r.len - 9);
+  }
+}
+
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_key0(const uint8_t *__restrict__ store, uint32_t n, uint64_t *__restrict__ key,
+                                                        uint32_t *__restrict__ idx) {
+  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const PpRec r = pp_load(store, i);
+  key[i] = ((uint64_t)(r.mapq & 63) << 34) | ((uint64_t)(r.dir & 1) << 33) | ((uint64_t)(r.uniq & 1) << 32) | r.read_id;
+  idx[i] = i;
+}
+
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_key_bc(const uint64_t *__restrict__ bc, const uint32_t *__restrict__ idx, uint32_t n,
+                                                          uint64_t *__restrict__ key) {
+  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (j < n) key[j] = bc[idx[j]];
+}
+
+// which = 0: (rid[low 16] , start, len); which = 1: rid >> 16 (only when n_seq > 65536)
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_key_top(const uint8_t *__restrict__ store, const uint32_t *__restrict__ idx, uint32_t n,
+                                                           PpCfg cfg, int which, uint64_t *__restrict__ key) {
+  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  PpRec r = pp_load(store, idx[j]);
+  if (cfg.inmem && cfg.tn5) pp_tn5(r, cfg.kind);
+  key[j] = which == 0 ? ((uint64_t)(r.rid & 0xffff) << 48) | ((uint64_t)r.start << 16) | r.len : (uint64_t)(r.rid >> 16);
+}
+
+__device__ __forceinline__ bool pp_same_run(const PpRec &a, uint64_t bca, const PpRec &b, uint64_t bcb, const PpCfg &cfg) {
+  if (a.rid != b.rid || a.start != b.start) return false;
+  if (cfg.kind == CMGPU_TEXT_BED_SE) return true;          // bed_mapping.h:91-94
+  if (a.len != b.len) return false;                        // :216-219
+  return cfg.kind != CMGPU_TEXT_BED_PE_BC || bca == bcb;   // :154-159
+}
+
+__device__ __forceinline__ uint32_t pp_digits(uint32_t v) {
+  return v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : v < 100000 ? 5 : v < 1000000 ? 6 : v < 10000000 ? 7
+       : v < 100000000 ? 8 : v < 1000000000 ? 9 : 10;
+}
+
+// survivor index (into the store), num_dups and line length per sorted position (0 = no line)
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restrict__ store, const uint64_t *__restrict__ bc,
+                                                          const uint32_t *__restrict__ idx, uint32_t n, PpCfg cfg,
+                                                          const uint32_t *__restrict__ name_off, uint32_t *__restrict__ win,
+                                                          uint32_t *__restrict__ dups_out, uint64_t *__restrict__ line_len) {
+  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  uint32_t wi = idx[j];
+  PpRec r = pp_load(store, wi);
+  const uint64_t rbc = cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[wi] : 0;
+  PpRec rs = r;  // the run identity is evaluated on what was sorted (shifted first in in-memory mode)
+  if (cfg.inmem && cfg.tn5) pp_tn5(rs, cfg.kind);
+  uint32_t dups = 1;
+  if (cfg.dedup) {
+    if (j > 0) {
+      const uint32_t pi = idx[j - 1];
+      PpRec p = pp_load(store, pi);
+      if (cfg.inmem && cfg.tn5) pp_tn5(p, cfg.kind);
+      if (pp_same_run(p, cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[pi] : 0, rs, rbc, cfg)) { line_len[j] = 0; return; }
+    }
+    for (uint32_t t = j + 1; t < n; ++t) {
+      const uint32_t qi = idx[t];
+      PpRec q = pp_load(store, qi), qs = q;
+      if (cfg.inmem && cfg.tn5) pp_tn5(qs, cfg.kind);
+      if (!pp_same_run(rs, rbc, qs, cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[qi] : 0, cfg)) break;
+      ++dups;
+      if (cfg.inmem || q.mapq > r.mapq) { r = q; wi = qi; }
+    }
+  }
+  if ((int)r.mapq < cfg.mapq_thr || r.rid >= cfg.n_seq) { line_len[j] = 0; return; }
+  if (cfg.tn5) pp_tn5(r, cfg.kind);
+  if (dups > 255) dups = 255;
+  const uint32_t nm = name_off[r.rid + 1] - name_off[r.rid];
+  uint32_t len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
+  if (cfg.kind == CMGPU_TEXT_BED_PE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;      // chr start end barcode dups
+  else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
+  win[j] = wi;
+  dups_out[j] = dups;
+  line_len[j] = len;
+}
+
+__device__ __forceinline__ uint8_t *pp_put_u32(uint8_t *p, uint32_t v) {
+  const uint32_t d = pp_digits(v);
+  for (uint32_t i = d; i-- > 0;) { p[i] = (uint8_t)('0' + v % 10); v /= 10; }
+  return p + d;
+}
+
+__device__ __forceinline__ void pp_render(uint8_t *p, const PpRec &r, uint64_t bcv, uint32_t dups, const PpCfg &cfg,
+                                          const uint8_t *__restrict__ names, const uint32_t *__restrict__ name_off) {
+  const uint32_t n0 = name_off[r.rid], n1 = name_off[r.rid + 1];
+  for (uint32_t i = n0; i < n1; ++i) *p++ = names[i];
+  *p++ = '\t';
+  p = pp_put_u32(p, r.start);
+  *p++ = '\t';
+  p = pp_put_u32(p, r.start + r.len);
+  *p++ = '\t';
+  if (cfg.kind == CMGPU_TEXT_BED_PE_BC) {
+    for (uint32_t b = 0; b < cfg.bc_len; ++b) *p++ = "ACGT"[(bcv >> ((cfg.bc_len - 1 - b) * 2)) & 3];  // Seed2Sequence
+    *p++ = '\t';
+  } else {
+    *p++ = 'N';
+    *p++ = '\t';
+    p = pp_put_u32(p, r.mapq);
+    *p++ = '\t';
+    *p++ = r.dir ? '+' : '-';
+    *p++ = '\t';
+  }
+  p = pp_put_u32(p, dups);
+  *p = '\n';
+}
+
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_format(const uint8_t *__restrict__ store, const uint64_t *__restrict__ bc,
+                                                          const uint32_t *__restrict__ win, const uint32_t *__restrict__ dups,
+                                                          const uint64_t *__restrict__ line_len, const uint64_t *__restrict__ line_off,
+                                                          uint32_t n, PpCfg cfg, const uint8_t *__restrict__ names,
+                                                          const uint32_t *__restrict__ name_off, uint8_t *__restrict__ text) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[PP_LDS_BYTES];
+  const uint32_t j0 = blockIdx.x * PP_BLOCK, j = j0 + threadIdx.x;
+  const uint32_t jend = j0 + PP_BLOCK < n ? j0 + PP_BLOCK : n;
+  const uint64_t base = line_off[j0], total = line_off[jend] - base;
+  const bool staged = total <= PP_LDS_BYTES;
+  if (j < n && line_len[j]) {
+    PpRec r = pp_load(store, win[j]);
+    if (cfg.tn5) pp_tn5(r, cfg.kind);
+    const uint64_t off = line_off[j];
+    pp_render(staged ? lds + (off - base) : text + off, r, cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[win[j]] : 0, dups[j], cfg, names,
+              name_off);
+  }
+  if (!staged) return;
+  __syncthreads();
+  // coalesced copy LDS -> text: bytes up to the first 16-byte boundary, aligned body, tail
+  uint8_t *dst = text + base;
+  const uint32_t tot = (uint32_t)total;
+  uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+  if (head > tot) head = tot;
+  for (uint32_t i = threadIdx.x; i < head; i += PP_BLOCK) dst[i] = lds[i];
+  const uint32_t body = (tot - head) >> 4;
+  for (uint32_t q = threadIdx.x; q < body; q += PP_BLOCK) {
+    const uint8_t *s = lds + head + (q << 4);
+    uint32_t w[4];
+    for (int k = 0; k < 4; ++k)
+      w[k] = (uint32_t)s[4 * k] | ((uint32_t)s[4 * k + 1] << 8) | ((uint32_t)s[4 * k + 2] << 16) | ((uint32_t)s[4 * k + 3] << 24);
+    *reinterpret_cast<uint4 *>(dst + head + (q << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  for (uint32_t i = head + (body << 4) + threadIdx.x; i < tot; i += PP_BLOCK) dst[i] = lds[i];
+}
+
+__global__ void k_pp_compact(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, const uint32_t *__restrict__ pos,
+                             const uint64_t *__restrict__ bc_in, uint8_t *__restrict__ dst, uint64_t *__restrict__ bc_dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (i >= n || !ok[i]) return;
+  const uint32_t o = pos[i];
+  const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
+  uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)o * 24);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+  if (bc_dst) bc_dst[o] = bc_in[i];
+}
+__global__ void k_pp_flag(const uint8_t *ok, uint32_t *flag, uint32_t n) {
+  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (i < n) flag[i] = ok[i];
+}
+__global__ void k_pp_split_bc(const uint8_t *__restrict__ in32, uint32_t n, uint8_t *__restrict__ dst, uint64_t *__restrict__ bc_dst) {
+  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t *s = reinterpret_cast<const uint64_t *>(in32 + (uint64_t)i * 32);
+  uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)i * 24);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+  bc_dst[i] = s[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// record store
+// ---------------------------------------------------------------------------------------
+static int store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc) {
+  if (need > 0xfffffff0ull) { cm_set_error(c, "record store is limited to 2^32 records"); return CMGPU_ECAPACITY; }
+  if (need > c->store_cap) {
+    uint64_t cap = c->store_cap ? c->store_cap * 2 : 1u << 20;
+    if (cap < need) cap = need;
+    DevBuf nb, nbc;
+    if (nb.ensure(cap * 24 + 16) || ((with_bc || c->store_has_bc) && nbc.ensure(cap * 8))) {
+      nb.release(); nbc.release();
+      cm_set_error(c, "out of device memory (record store)");
+      return CMGPU_ENOMEM;
+    }
+    if (c->store_n) {
+      PPCHECK(c, hipMemcpy(nb.p, c->store.p, c->store_n * 24, hipMemcpyDeviceToDevice));
+      if (c->store_has_bc) PPCHECK(c, hipMemcpy(nbc.p, c->store_bc.p, c->store_n * 8, hipMemcpyDeviceToDevice));
+    }
+    c->store.release(); c->store_bc.release();
+    c->store = nb; c->store_bc = nbc;
+    c->store_cap = cap;
+  } else if (with_bc && !c->store_bc.p) {
+    if (c->store_bc.ensure(c->store_cap * 8)) { cm_set_error(c, "out of device memory (record store)"); return CMGPU_ENOMEM; }
+  }
+  if (with_bc) c->store_has_bc = true;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_store_clear(cmgpu_ctx *c) {
+  if (!c) return CMGPU_EINVAL;
+  c->store_n = 0;
+  c->store_has_bc = false;
+  c->text_bytes = 0;
+  c->text_lines = 0;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
+  if (!c) return CMGPU_EINVAL;
+  PPCHECK(c, hipSetDevice(c->device));
+  if (c->p.split) { cm_set_error(c, "pairs records are post-processed on the host (cmgpu_write_pairs)"); return CMGPU_EINVAL; }
+  const uint32_t n = c->n_pairs;
+  if (c->store_n && c->store_has_bc != c->has_barcodes) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
+  if (n) {
+    int rc = store_reserve(c, c->store_n + n, c->has_barcodes);
+    if (rc) return rc;
+    uint32_t *flag = (uint32_t *)c->cap.p, *pos = (uint32_t *)c->mm_cap_off.p;  // free between batches
+    const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
+    hipLaunchKernelGGL(k_pp_flag, g, b, 0, c->stream, (const uint8_t *)c->rec_ok.p, flag, n);
+    cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, c->stream);
+    hipLaunchKernelGGL(k_pp_compact, g, b, 0, c->stream, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, (const uint32_t *)pos,
+                       (const uint64_t *)c->bc_key.p, (uint8_t *)c->store.p + c->store_n * 24,
+                       c->has_barcodes ? (uint64_t *)c->store_bc.p + c->store_n : (uint64_t *)nullptr, n);
+    uint32_t k = 0;
+    PPCHECK(c, hipMemcpyAsync(&k, pos + n, 4, hipMemcpyDeviceToHost, c->stream));
+    PPCHECK(c, hipStreamSynchronize(c->stream));
+    c->store_n += k;
+  }
+  if (n_total) *n_total = c->store_n;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_store_append(cmgpu_ctx *c, const void *records, uint64_t n, int on_device, int barcoded) {
+  if (!c || (!records && n)) return CMGPU_EINVAL;
+  PPCHECK(c, hipSetDevice(c->device));
+  if (c->store_n && c->store_has_bc != (barcoded != 0)) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
+  if (n == 0) return CMGPU_OK;
+  int rc = store_reserve(c, c->store_n + n, barcoded != 0);
+  if (rc) return rc;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (!barcoded) {
+    PPCHECK(c, hipMemcpy((uint8_t *)c->store.p + c->store_n * 24, records, n * 24, kind));
+  } else {
+    DevBuf tmp;
+    const void *src = records;
+    if (!on_device) {
+      if (tmp.ensure(n * 32)) { cm_set_error(c, "out of device memory (record staging)"); return CMGPU_ENOMEM; }
+      PPCHECK(c, hipMemcpy(tmp.p, records, n * 32, hipMemcpyHostToDevice));
+      src = tmp.p;
+    }
+    hipLaunchKernelGGL(k_pp_split_bc, dim3((unsigned)((n + PP_BLOCK - 1) / PP_BLOCK)), dim3(PP_BLOCK), 0, c->stream, (const uint8_t *)src,
+                       (uint32_t)n, (uint8_t *)c->store.p + c->store_n * 24, (uint64_t *)c->store_bc.p + c->store_n);
+    PPCHECK(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+  }
+  c->store_n += n;
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// sort + select + format
+// ---------------------------------------------------------------------------------------
+static int pp_sort_pass(cmgpu_ctx *c, DevBuf &tmp, uint64_t *kin, uint64_t *kout, uint32_t *vin, uint32_t *vout, size_t n, unsigned bits) {
+  size_t tb = 0;
+  PPCHECK(c, rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, 0, bits, c->stream));
+  if (tmp.ensure(tb + 256)) { cm_set_error(c, "out of device memory (sort)"); return CMGPU_ENOMEM; }
+  PPCHECK(c, rocprim::radix_sort_pairs(tmp.p, tb, kin, kout, vin, vout, n, 0, bits, c->stream));
+  return CMGPU_OK;
+}
+
+struct PpLinesOp {
+  __host__ __device__ uint64_t operator()(uint64_t l) const { return l ? 1 : 0; }
+};
+
+extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
+                                  uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes) {
+  if (!c || !names || !p || !n_lines || !n_bytes) return CMGPU_EINVAL;
+  if (kind != CMGPU_TEXT_BED_PE && kind != CMGPU_TEXT_BED_SE && kind != CMGPU_TEXT_BED_PE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
+  if ((kind == CMGPU_TEXT_BED_PE_BC) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
+  if (kind == CMGPU_TEXT_BED_PE_BC && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
+  PPCHECK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  *n_lines = 0;
+  *n_bytes = 0;
+  c->text_bytes = 0;
+  c->text_lines = 0;
+  const uint32_t n = (uint32_t)c->store_n;
+  if (n == 0) return CMGPU_OK;
+  PpCfg cfg;
+  cfg.kind = kind;
+  cfg.dedup = p->remove_pcr_duplicates != 0;
+  cfg.inmem = p->low_memory_mode == 0;
+  cfg.tn5 = p->tn5_shift != 0;
+  cfg.mapq_thr = p->mapq_threshold;
+  cfg.n_seq = n_sequences;
+  cfg.bc_len = barcode_length;
+  // names -> device
+  std::vector<uint32_t> noff(n_sequences + 1, 0);
+  std::string blob;
+  for (uint32_t i = 0; i < n_sequences; ++i) { blob += names[i]; noff[i + 1] = (uint32_t)blob.size(); }
+  DevBuf d_names, d_noff, k0, k1, v0, v1, tmp, win, dups, llen, loff;
+  auto fail = [&](int rc) { d_names.release(); d_noff.release(); k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
+                            win.release(); dups.release(); llen.release(); loff.release(); return rc; };
+  if (d_names.ensure(blob.size() + 16) || d_noff.ensure(noff.size() * 4) || k0.ensure((size_t)n * 8) || k1.ensure((size_t)n * 8) ||
+      v0.ensure((size_t)n * 4) || v1.ensure((size_t)n * 4)) { cm_set_error(c, "out of device memory (post-processing)"); return fail(CMGPU_ENOMEM); }
+  if (hipMemcpyAsync(d_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_noff.p, noff.data(), noff.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) { cm_set_error(c, "name upload failed"); return fail(CMGPU_EHIP); }
+  const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
+  const uint8_t *store = (const uint8_t *)c->store.p;
+  const uint64_t *bc = (const uint64_t *)c->store_bc.p;
+  uint64_t *ka = (uint64_t *)k0.p, *kb = (uint64_t *)k1.p;
+  uint32_t *va = (uint32_t *)v0.p, *vb = (uint32_t *)v1.p;
+  int rc;
+  hipLaunchKernelGGL(k_pp_key0, g, b, 0, s, store, n, ka, va);
+  if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 40))) return fail(rc);
+  std::swap(va, vb);
+  if (kind == CMGPU_TEXT_BED_PE_BC) {
+    hipLaunchKernelGGL(k_pp_key_bc, g, b, 0, s, bc, (const uint32_t *)va, n, ka);
+    if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 2 * barcode_length))) return fail(rc);
+    std::swap(va, vb);
+  }
+  unsigned rid_bits = 1;
+  while (rid_bits < 32 && (1ull << rid_bits) < (uint64_t)n_sequences + 1) ++rid_bits;
+  hipLaunchKernelGGL(k_pp_key_top, g, b, 0, s, store, (const uint32_t *)va, n, cfg, 0, ka);
+  if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 48 + (rid_bits > 16 ? 16 : rid_bits)))) return fail(rc);
+  std::swap(va, vb);
+  if (rid_bits > 16) {
+    hipLaunchKernelGGL(k_pp_key_top, g, b, 0, s, store, (const uint32_t *)va, n, cfg, 1, ka);
+    if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, rid_bits - 16))) return fail(rc);
+    std::swap(va, vb);
+  }
+  PPCHECK(c, hipStreamSynchronize(s));
+  tmp.release(); k0.release(); k1.release();
+  (va == (uint32_t *)v0.p ? v1 : v0).release();
+  // ---- select
+  if (win.ensure((size_t)n * 4) || dups.ensure((size_t)n * 4) || llen.ensure(((size_t)n + 1) * 8) || loff.ensure(((size_t)n + 1) * 8)) {
+    cm_set_error(c, "out of device memory (post-processing)"); return fail(CMGPU_ENOMEM);
+  }
+  hipLaunchKernelGGL(k_pp_select, g, b, 0, s, store, bc, (const uint32_t *)va, n, cfg, (const uint32_t *)d_noff.p, (uint32_t *)win.p,
+                     (uint32_t *)dups.p, (uint64_t *)llen.p);
+  if (hipMemsetAsync((uint64_t *)llen.p + n, 0, 8, s) != hipSuccess) { cm_set_error(c, "memset failed"); return fail(CMGPU_EHIP); }
+  size_t tb = 0, tb2 = 0;
+  (void)rocprim::exclusive_scan(nullptr, tb, (const uint64_t *)llen.p, (uint64_t *)loff.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), s);
+  auto lines_in = rocprim::make_transform_iterator((const uint64_t *)llen.p, PpLinesOp());
+  DevBuf d_count;
+  (void)rocprim::reduce(nullptr, tb2, lines_in, (uint64_t *)nullptr, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
+  if (tmp.ensure((tb > tb2 ? tb : tb2) + 256) || d_count.ensure(8)) { d_count.release(); cm_set_error(c, "out of device memory (scan)"); return fail(CMGPU_ENOMEM); }
+  hipError_t e = rocprim::exclusive_scan(tmp.p, tb, (const uint64_t *)llen.p, (uint64_t *)loff.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), s);
+  if (e == hipSuccess) e = rocprim::reduce(tmp.p, tb2, lines_in, (uint64_t *)d_count.p, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
+  uint64_t total = 0, lines = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint64_t *)loff.p + n, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&lines, d_count.p, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  d_count.release();
+  if (e != hipSuccess) { cm_set_error(c, std::string("post-processing scan: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
+  if (c->text.ensure(total + 64)) { cm_set_error(c, "out of device memory (text)"); return fail(CMGPU_ENOMEM); }
+  // ---- format
+  hipLaunchKernelGGL(k_pp_format, g, b, 0, s, store, bc, (const uint32_t *)win.p, (const uint32_t *)dups.p, (const uint64_t *)llen.p,
+                     (const uint64_t *)loff.p, n, cfg, (const uint8_t *)d_names.p, (const uint32_t *)d_noff.p, (uint8_t *)c->text.p);
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { cm_set_error(c, std::string("text formatting: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
+  c->text_bytes = total;
+  c->text_lines = lines;
+  *n_lines = lines;
+  *n_bytes = total;
+  return fail(CMGPU_OK);
+}
+
+extern "C" int cmgpu_store_text(cmgpu_ctx *c, char *out, uint64_t capacity) {
+  if (!c || (!out && c->text_bytes)) return CMGPU_EINVAL;
+  if (capacity < c->text_bytes) { cm_set_error(c, "text buffer too small"); return CMGPU_ECAPACITY; }
+  PPCHECK(c, hipSetDevice(c->device));
+  if (c->text_bytes) PPCHECK(c, hipMemcpy(out, c->text.p, c->text_bytes, hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_store_write_text(cmgpu_ctx *c, const char *path, int append) {
+  if (!c || !path) return CMGPU_EINVAL;
+  PPCHECK(c, hipSetDevice(c->device));
+  FILE *f = fopen(path, append ? "ab" : "wb");
+  if (!f) { cm_set_error(c, std::string("cannot open ") + path); return CMGPU_EIO; }
+  const size_t slab = 64u << 20;
+  void *h = nullptr;
+  if (hipHostMalloc(&h, slab, hipHostMallocDefault) != hipSuccess) { fclose(f); cm_set_error(c, "pinned staging allocation failed"); return CMGPU_ENOMEM; }
+  bool ok = true;
+  for (uint64_t o = 0; ok && o < c->text_bytes; o += slab) {
+    const size_t m = c->text_bytes - o < slab ? (size_t)(c->text_bytes - o) : slab;
+    ok = hipMemcpy(h, (const uint8_t *)c->text.p + o, m, hipMemcpyDeviceToHost) == hipSuccess && fwrite(h, 1, m, f) == m;
+  }
+  (void)hipHostFree(h);
+  ok = fclose(f) == 0 && ok;
+  if (!ok) { cm_set_error(c, std::string("short write to ") + path); return CMGPU_EIO; }
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_store_info(const cmgpu_ctx *c, uint64_t *n_records, uint64_t *text_bytes, uint64_t *text_lines) {
+  if (!c) return CMGPU_EINVAL;
+  if (n_records) *n_records = c->store_n;
+  if (text_bytes) *text_bytes = c->text_bytes;
+  if (text_lines) *text_lines = c->text_lines;
+  return CMGPU_OK;
+}

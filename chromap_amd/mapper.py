@@ -219,6 +219,40 @@ class ChromapGPU:
         k = self.L.cmgpu_last_timings(self.ctx, names, ms, 32)
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
 
+    # ---- device-side post-processing: record store -> sorted / deduplicated BED text in HBM
+    def store_clear(self):
+        self._check(self.L.cmgpu_store_clear(self.ctx), self.ctx)
+
+    def store_append_resident(self):
+        """appends the records of the last map_* call (still resident); returns the store size"""
+        n = C.c_uint64(0)
+        self._check(self.L.cmgpu_store_append_resident(self.ctx, C.byref(n)), self.ctx)
+        return n.value
+
+    def store_append(self, records, n, on_device=False, barcoded=False):
+        """records: ctypes array / address of Record (or RecordBc) entries, host or device"""
+        ptr = records if isinstance(records, int) else C.cast(records, C.c_void_p)
+        self._check(self.L.cmgpu_store_append(self.ctx, ptr, n, int(on_device), int(barcoded)), self.ctx)
+
+    def store_format(self, kind=_capi.TEXT_BED_PE, params=None, barcode_length=0):
+        """sort + duplicate removal + MAPQ filter + Tn5 shift + BED text, all in HBM; returns (lines, bytes)"""
+        p = params if params is not None else self.params
+        names = (C.c_char_p * len(self.names))(*self.names)
+        nl, nb = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.cmgpu_store_format(self.ctx, kind, names, len(self.names), C.byref(p), barcode_length,
+                                              C.byref(nl), C.byref(nb)), self.ctx)
+        return nl.value, nb.value
+
+    def store_text(self):
+        nb = C.c_uint64(0)
+        self.L.cmgpu_store_info(self.ctx, None, C.byref(nb), None)
+        buf = C.create_string_buffer(max(1, nb.value))
+        self._check(self.L.cmgpu_store_text(self.ctx, buf, nb.value), self.ctx)
+        return buf.raw[:nb.value]
+
+    def store_write_text(self, path, append=False):
+        self._check(self.L.cmgpu_store_write_text(self.ctx, path.encode(), int(append)), self.ctx)
+
     def write_bed(self, rec, n, path, params=None):
         p = params if params is not None else self.params
         names = (C.c_char_p * len(self.names))(*self.names)

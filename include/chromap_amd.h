@@ -277,6 +277,31 @@ int cmgpu_export_index(cmgpu_ctx *ctx, uint64_t *buckets_out, uint64_t *occurren
  * (capacity in records) -- the send buffer of the multi-GPU record exchange. */
 int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity, uint64_t *n_out);
 
+/* ---- device-side post-processing -------------------------------------
+ * Replaces, for BED output: MappingProcessor::SortOutputMappings / RemovePCRDuplicate
+ * (src/mapping_processor.h:100-202), the low-memory merge's duplicate handling
+ * (src/mapping_writer.h:166-376), ApplyTn5ShiftOnMappings, the MAPQ filter and
+ * MappingWriter::AppendMapping (src/mapping_writer.cc:44-52, 72-83, 119-131).
+ * Batches append their records to a store in HBM; one call sorts (radix sort on the
+ * operator< key), removes duplicates (low_memory_mode: first record with the maximal MAPQ of an
+ * operator== run; otherwise RemovePCRDuplicate's last record of the run, Tn5 shift applied
+ * before the sort as src/chromap.h:1323-1331 does), filters, and renders the text in HBM.
+ * The bytes equal cmgpu_write_bed_* / the reference's output file. */
+#define CMGPU_TEXT_BED_PE 0
+#define CMGPU_TEXT_BED_SE 1
+#define CMGPU_TEXT_BED_PE_BC 2
+int cmgpu_store_clear(cmgpu_ctx *ctx);
+/* appends the records of the last cmgpu_map_* call (still resident); n_total = store size */
+int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);
+/* appends n records from a host or device array of cmgpu_record (barcoded = 0) or
+ * cmgpu_record_bc (barcoded = 1) -- e.g. the receive buffer of the multi-GPU exchange */
+int cmgpu_store_append(cmgpu_ctx *ctx, const void *records, uint64_t n, int on_device, int barcoded);
+int cmgpu_store_format(cmgpu_ctx *ctx, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
+                       uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes);
+int cmgpu_store_text(cmgpu_ctx *ctx, char *out, uint64_t capacity);
+int cmgpu_store_write_text(cmgpu_ctx *ctx, const char *path, int append);
+int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_bytes, uint64_t *text_lines);
+
 /* Host post-processing that defines the final BED bytes: sort by (rid, operator<),
  * PCR-duplicate removal as in the low-memory merge, MAPQ filter, Tn5 shift, text
  * formatting (src/mapping_writer.h:166-376, src/mapping_writer.cc:72-83). Sorts `records`

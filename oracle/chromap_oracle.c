@@ -2229,36 +2229,36 @@ static void bed_line(FILE *f, const ora_ref *ref, const ora_params *p, ora_recor
           r.fragment_start + r.fragment_length, (unsigned)r.mapq, r.direction ? "+" : "-", (unsigned)r.num_dups);
 }
 
+/* Two post-processing flavours (chromap.h:1305-1355):
+ *  low_mem: sort, then the temp-file merge (mapping_writer.h:247-289) keeps the FIRST record with
+ *           the maximal MAPQ of every operator== run; Tn5 shift at output.
+ *  in-memory: ApplyTn5ShiftOnMappings first, then RemovePCRDuplicate (mapping_processor.h:160-202)
+ *           sorts and keeps the LAST record of every run. */
 long ora_write_bed_pe(const ora_ref *ref, const ora_params *p, ora_record *rec, long n, const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return -1;
+  const int inmem = !p->low_mem;
+  ora_params q = *p;
+  if (inmem && p->tn5_shift) {
+    for (long i = 0; i < n; ++i) { rec[i].fragment_start += 4; rec[i].pos_aln_len -= 4; rec[i].fragment_length -= 9; rec[i].neg_aln_len -= 5; }
+    q.tn5_shift = 0;
+  }
   qsort(rec, (size_t)n, sizeof(ora_record), cmp_rec);
-  long lines = 0;
-  if (p->low_mem && p->remove_pcr_duplicates) {
-    long i = 0;
-    while (i < n) {
-      ora_record last = rec[i];
-      uint32_t dups = 1;
-      long j = i + 1;
-      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start &&
-             rec[j].fragment_length == last.fragment_length) {
+  long lines = 0, i = 0;
+  while (i < n) {
+    ora_record last = rec[i];
+    uint32_t dups = 1;
+    long j = i + 1;
+    if (p->remove_pcr_duplicates) {
+      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == rec[i].fragment_start &&
+             rec[j].fragment_length == rec[i].fragment_length) {
         ++dups;
-        if (rec[j].mapq > last.mapq) last = rec[j]; /* :268-270; keys used by == are equal */
+        if (inmem || rec[j].mapq > last.mapq) last = rec[j]; /* :268-270; keys used by == are equal */
         ++j;
       }
-      if (last.mapq >= p->mapq_threshold) { bed_line(f, ref, p, last, dups); ++lines; }
-      i = j;
     }
-  } else if (p->low_mem) {
-    for (long i = 0; i < n; ++i)
-      if (rec[i].mapq >= p->mapq_threshold) { bed_line(f, ref, p, rec[i], 1); ++lines; }
-  } else {
-    /* in-memory path, no dedup (chromap.h:1322-1355 with remove_pcr_duplicates off):
-     * Tn5 shift happens BEFORE the sort there, but with no dedup and a shift that is
-     * monotone in (start,length) per direction... not equivalent in general; only the
-     * non-Tn5 default path is used in tests. */
-    for (long i = 0; i < n; ++i)
-      if (rec[i].mapq >= p->mapq_threshold) { bed_line(f, ref, p, rec[i], rec[i].num_dups); ++lines; }
+    if (last.mapq >= p->mapq_threshold) { bed_line(f, ref, &q, last, dups); ++lines; }
+    i = j;
   }
   fclose(f);
   return lines;
@@ -2335,6 +2335,9 @@ long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc 
                          const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return -1;
+  const int inmem = !p->low_mem;
+  if (inmem && p->tn5_shift)
+    for (long t = 0; t < n; ++t) { rec[t].r.fragment_start += 4; rec[t].r.pos_aln_len -= 4; rec[t].r.fragment_length -= 9; rec[t].r.neg_aln_len -= 5; }
   qsort(rec, (size_t)n, sizeof(ora_record_bc), cmp_rec_bc);
   long lines = 0, i = 0;
   char bcs[40];
@@ -2346,14 +2349,14 @@ long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc 
       while (j < n && rec[j].r.rid == last.r.rid && rec[j].barcode == last.barcode &&
              rec[j].r.fragment_start == last.r.fragment_start && rec[j].r.fragment_length == last.r.fragment_length) {
         ++dups;
-        if (rec[j].r.mapq > last.r.mapq) last = rec[j];
+        if (inmem || rec[j].r.mapq > last.r.mapq) last = rec[j];
         ++j;
       }
     }
     if (last.r.mapq >= p->mapq_threshold) {
       ora_record r = last.r;
       r.num_dups = (uint8_t)(dups > 255 ? 255 : dups);
-      if (p->tn5_shift) { r.fragment_start += 4; r.pos_aln_len -= 4; r.fragment_length -= 9; r.neg_aln_len -= 5; }
+      if (p->tn5_shift && !inmem) { r.fragment_start += 4; r.pos_aln_len -= 4; r.fragment_length -= 9; r.neg_aln_len -= 5; }
       for (uint32_t b = 0; b < barcode_length; ++b) bcs[b] = u2c((uint8_t)((last.barcode >> ((barcode_length - 1 - b) * 2)) & 3));
       bcs[barcode_length] = 0;
       fprintf(f, "%s\t%u\t%u\t%s\t%u\n", ref->name[r.rid], r.fragment_start, r.fragment_start + r.fragment_length, bcs,
@@ -2498,21 +2501,24 @@ static int cmp_rec_se(const void *a, const void *b) {
 long ora_write_bed_se(const ora_ref *ref, const ora_params *p, ora_record *rec, long n, const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return -1;
+  const int inmem = !p->low_mem;
+  if (inmem && p->tn5_shift) /* bed_mapping.h:100-106 */
+    for (long t = 0; t < n; ++t) { if (rec[t].direction == 1) rec[t].fragment_start += 4; else rec[t].fragment_length -= 5; }
   qsort(rec, (size_t)n, sizeof(ora_record), cmp_rec_se);
   long lines = 0, i = 0;
   while (i < n) {
     ora_record last = rec[i];
     uint32_t dups = 1;
     long j = i + 1;
-    if (p->remove_pcr_duplicates && p->low_mem) {
-      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == last.fragment_start) {
+    if (p->remove_pcr_duplicates) {
+      while (j < n && rec[j].rid == last.rid && rec[j].fragment_start == rec[i].fragment_start) {
         ++dups;
-        if (rec[j].mapq > last.mapq) last = rec[j];
+        if (inmem || rec[j].mapq > last.mapq) last = rec[j];
         ++j;
       }
     }
     if (last.mapq >= p->mapq_threshold) {
-      if (p->tn5_shift) { if (last.direction == 1) last.fragment_start += 4; else last.fragment_length -= 5; }
+      if (p->tn5_shift && !inmem) { if (last.direction == 1) last.fragment_start += 4; else last.fragment_length -= 5; }
       fprintf(f, "%s\t%u\t%u\tN\t%u\t%s\t%u\n", ref->name[last.rid], last.fragment_start,
               last.fragment_start + last.fragment_length, (unsigned)last.mapq, last.direction ? "+" : "-",
               dups > 255 ? 255u : dups);

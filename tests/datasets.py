@@ -88,6 +88,13 @@ def flags_to_params(flags):
         elif flags[i] == "--bc-error-threshold":
             kw["bc_error_threshold"] = int(flags[i + 1])
             i += 2
+        elif flags[i] == "-l":
+            kw["max_insert_size"] = int(flags[i + 1])
+            i += 2
+        elif flags[i] in ("--remove-pcr-duplicates", "--Tn5-shift", "--trim-adapters", "--low-mem"):
+            kw[{"--remove-pcr-duplicates": "remove_pcr_duplicates", "--Tn5-shift": "tn5_shift",
+                "--trim-adapters": "trim_adapters", "--low-mem": "low_memory_mode"}[flags[i]]] = 1
+            i += 1
         elif flags[i] == "-q":  # noqa: E501
             kw["mapq_threshold"] = int(flags[i + 1])
             i += 2

@@ -24,7 +24,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "chromap")
 GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 
 # single-end cases: which mate file is mapped alone
-SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2}
+SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -51,6 +51,15 @@ CASES = {
                    ["--preset", "chip"]),
     "s4_se_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                        "--seed", "5"], ["--preset", "atac", "-q", "0"]),
+    # in-memory post-processing (no --low-mem): Tn5 shift before the sort, RemovePCRDuplicate keeps the last of a run
+    "s4_inmem_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                     "--seed", "5"], ["-l", "2000", "--remove-pcr-duplicates", "--Tn5-shift", "--trim-adapters", "-q", "0"]),
+    "s4_se_inmem_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                        "--seed", "5"], ["--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"]),
+    "b1_inmem_bc": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
+                     "--barcodes", "500", "--seed", "31"], ["-l", "2000", "--remove-pcr-duplicates", "--Tn5-shift", "--trim-adapters"]),
+    "s1_inmem_nodedup": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                         ["-l", "2000", "--Tn5-shift"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
