@@ -443,6 +443,7 @@ extern "C" int cmgpu_map_pairs(cmgpu_ctx *c, const cmgpu_batch *in, cmgpu_record
   uint64_t k = 0;
   rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;
+  if (!out) { if (n_out) *n_out = k; return CMGPU_OK; }  // records stay resident (cmgpu_store_append_resident)
   return cmgpu_download_records(c, out, out_capacity, n_out);
 }
 
@@ -696,7 +697,7 @@ extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, 
 
 extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, const cmgpu_barcode_batch *bc, cmgpu_record_bc *out,
                                         uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats) {
-  if (!c || !in || !bc || !out || !n_out) return CMGPU_EINVAL;
+  if (!c || !in || !bc || !n_out) return CMGPU_EINVAL;
   if (c->wl_size == 0 || c->wl_num_sample == 0) { cm_set_error(c, "whitelist / barcode abundance not set"); return CMGPU_EINVAL; }
   int rc = cmgpu_upload_batch(c, in);
   if (rc) return rc;
@@ -712,6 +713,7 @@ extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, con
   uint64_t k = 0;
   rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;
+  if (!out) { *n_out = k; return CMGPU_OK; }
   std::vector<cmgpu_record> rec(n);
   std::vector<uint8_t> ok(n);
   std::vector<uint64_t> keys(n);
@@ -736,7 +738,7 @@ extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, con
 // ---------------------------------------------------------------------------------------
 extern "C" int cmgpu_map_single(cmgpu_ctx *c, const cmgpu_single_batch *in, cmgpu_record *out, uint64_t out_capacity,
                                 uint64_t *n_out, cmgpu_stats *stats) {
-  if (!c || !in || !out || !n_out) return CMGPU_EINVAL;
+  if (!c || !in || !n_out) return CMGPU_EINVAL;
   if (c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipSetDevice(c->device));
   const uint32_t n = in->n_reads;
@@ -762,5 +764,6 @@ extern "C" int cmgpu_map_single(cmgpu_ctx *c, const cmgpu_single_batch *in, cmgp
   uint64_t k = 0;
   int rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;
+  if (!out) { *n_out = k; return CMGPU_OK; }
   return cmgpu_download_records(c, out, out_capacity, n_out);
 }

@@ -70,7 +70,7 @@ struct Args {
   std::string index_path, ref_path, out_path, preset, barcode_file, whitelist;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
-  bool build_index = false, out_bed = true, out_pairs = false;
+  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false;
   int k = 17, w = 7, device = 0;
   uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
 };
@@ -96,6 +96,7 @@ static Args parse(int argc, char **argv) {
       a.preset = argv[i + 1];
       if (cmgpu_apply_preset(&a.p, argv[i + 1]) != 0) die(std::string("Unrecognized preset parameters ") + argv[i + 1] + "\n");
       if (a.preset == "hic") { a.out_pairs = true; a.out_bed = false; }
+      if (a.preset == "atac") a.cell_level_dedup = true;
     }
   for (int i = 1; i < argc; ++i) {
     const std::string o = argv[i];
@@ -128,7 +129,8 @@ static Args parse(int argc, char **argv) {
     else if (o == "--output-mappings-not-in-whitelist") a.p.output_mappings_not_in_whitelist = 1;
     else if (o == "--trim-adapters") a.p.trim_adapters = 1;
     else if (o == "--remove-pcr-duplicates") a.p.remove_pcr_duplicates = 1;
-    else if (o == "--remove-pcr-duplicates-at-cell-level" || o == "--remove-pcr-duplicates-at-bulk-level") {}
+    else if (o == "--remove-pcr-duplicates-at-cell-level") a.cell_level_dedup = true;
+    else if (o == "--remove-pcr-duplicates-at-bulk-level") a.cell_level_dedup = false;
     else if (o == "--Tn5-shift") a.p.tn5_shift = 1;
     else if (o == "--split-alignment") a.p.split_alignment = 1;
     else if (o == "--low-mem") a.p.low_memory_mode = 1;
@@ -174,6 +176,9 @@ int main(int argc, char **argv) {
   if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
   const bool barcoded = !a.barcode_file.empty();
   if (barcoded && (a.whitelist.empty() || !paired)) die("this build supports barcodes only with a whitelist and paired-end reads");
+  if (barcoded && a.p.remove_pcr_duplicates && a.p.low_memory_mode && !a.cell_level_dedup)
+    die("bulk-level duplicate removal for single-cell data (mapping_writer.h:205-208) is outside this build; "
+        "use --remove-pcr-duplicates-at-cell-level (as --preset atac does)");
   cmgpu_index_view idx;
   if (cmgpu_load_index_file(a.index_path.c_str(), &idx) != 0) die("Cannot read index " + a.index_path);
   fprintf(stderr, "Kmer size: %d, window size: %d.\n", idx.kmer_size, idx.window_size);
@@ -184,7 +189,6 @@ int main(int argc, char **argv) {
   cmgpu_stats st;
   memset(&st, 0, sizeof(st));
   std::vector<cmgpu_record> recs;
-  std::vector<cmgpu_record_bc> recs_bc;
   std::vector<std::string> read_names;  // pairs output needs read-1 names by read_id
   uint64_t num_reads = 0;
   uint32_t next_read_id = 0, bc_len = 0;
@@ -239,12 +243,12 @@ int main(int argc, char **argv) {
       uint64_t k = 0;
       int rc;
       if (barcoded) {
-        const size_t base = recs_bc.size();
-        recs_bc.resize(base + n);
         cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
         cmgpu_barcode_batch bc{bb.data(), bq.data(), bo.data()};
-        rc = cmgpu_map_pairs_barcoded(ctx, &bt, &bc, recs_bc.data() + base, n, &k, &st);
-        recs_bc.resize(base + k);
+        rc = cmgpu_map_pairs_barcoded(ctx, &bt, &bc, nullptr, 0, &k, &st);
+      } else if (paired && !a.out_pairs) {
+        cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
+        rc = cmgpu_map_pairs(ctx, &bt, nullptr, 0, &k, &st);
       } else if (paired) {
         const size_t base = recs.size();
         recs.resize(base + n);
@@ -252,13 +256,12 @@ int main(int argc, char **argv) {
         rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, n, &k, &st);
         recs.resize(base + k);
       } else {
-        const size_t base = recs.size();
-        recs.resize(base + n);
         cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};
-        rc = cmgpu_map_single(ctx, &bt, recs.data() + base, n, &k, &st);
-        recs.resize(base + k);
+        rc = cmgpu_map_single(ctx, &bt, nullptr, 0, &k, &st);
       }
       if (rc != CMGPU_OK) die(cmgpu_last_error(ctx));
+      // BED outputs: the records never leave HBM -- they join the device-side store
+      if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) die(cmgpu_last_error(ctx));
       next_read_id += n;
       fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
     }
@@ -276,17 +279,19 @@ int main(int argc, char **argv) {
     fprintf(stderr, "Number of barcodes in whitelist: %llu.\nNumber of corrected barcodes: %llu.\n",
             (unsigned long long)st.num_barcode_in_whitelist, (unsigned long long)st.num_corrected_barcode);
   int64_t lines;
+  uint64_t nl = 0, nbytes = 0;
   if (a.out_pairs) {
     std::vector<const char *> rn(read_names.size());
     for (size_t i = 0; i < rn.size(); ++i) rn[i] = read_names[i].c_str();
     lines = cmgpu_write_pairs(ref.names, ref.lengths, ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
                               a.out_path.c_str());
-  } else if (barcoded) {
-    lines = cmgpu_write_bed_pe_bc(ref.names, ref.n_sequences, &a.p, recs_bc.data(), recs_bc.size(), bc_len, a.out_path.c_str());
-  } else if (paired) {
-    lines = cmgpu_write_bed_pe(ref.names, ref.n_sequences, &a.p, recs.data(), recs.size(), a.out_path.c_str());
   } else {
-    lines = cmgpu_write_bed_se(ref.names, ref.n_sequences, &a.p, recs.data(), recs.size(), a.out_path.c_str());
+    // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
+    const int kind = barcoded ? CMGPU_TEXT_BED_PE_BC : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
+    if (cmgpu_store_format(ctx, kind, ref.names, ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK ||
+        cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK)
+      die(cmgpu_last_error(ctx));
+    lines = (int64_t)nl;
   }
   if (lines < 0) die("cannot write " + a.out_path);
   fprintf(stderr, "Number of output mappings (passed filters): %lld\n", (long long)lines);

@@ -194,6 +194,8 @@ const char *cmgpu_last_error(const cmgpu_ctx *ctx);
  * src/mapping_processor.h:117-159).  stats may be NULL; counters are ACCUMULATED.
  * A batch must start on a read_batch_size boundary of the input file for the reservoir
  * sampling of multi-mappers to reproduce the reference. */
+/* out may be NULL (capacity 0): the records then stay resident for cmgpu_store_append_resident /
+ * cmgpu_records_to_device and only their count is returned (same for the other cmgpu_map_* calls). */
 int cmgpu_map_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,
                     uint64_t *n_out, cmgpu_stats *stats);
 
@@ -293,8 +295,8 @@ int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity,
 int cmgpu_store_clear(cmgpu_ctx *ctx);
 /* appends the records of the last cmgpu_map_* call (still resident); n_total = store size */
 int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);
-/* appends n records from a host or device array of cmgpu_record (barcoded = 0) or
- * cmgpu_record_bc (barcoded = 1) -- e.g. the receive buffer of the multi-GPU exchange */
+/* appends n records from a host or device array; barcoded = 0: cmgpu_record entries,
+ * barcoded = 1: cmgpu_record_bc entries -- e.g. the receive buffer of the multi-GPU exchange */
 int cmgpu_store_append(cmgpu_ctx *ctx, const void *records, uint64_t n, int on_device, int barcoded);
 int cmgpu_store_format(cmgpu_ctx *ctx, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
                        uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes);
