@@ -266,6 +266,25 @@ def main():
         # back to the timed batch (the CPU baseline compares its records with the GPU's)
         g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=1000 + rank)
         g.map_resident(Stats())
+        # PCIe-inclusive rate of the host-buffer boundary (cmgpu_map_pairs: H2D reads, map, D2H records);
+        # reported beside `value`, never as `value`
+        pcie = None
+        try:
+            import numpy as np
+            n = args.pairs
+            o1 = np.zeros(n + 1, np.uint32)
+            o2 = np.zeros(n + 1, np.uint32)
+            b1 = np.zeros(n * args.readlen, np.uint8)
+            b2 = np.zeros(n * args.readlen, np.uint8)
+            assert g.L.cmgpu_download_batch(g.ctx, b1.ctypes.data, o1.ctypes.data, b2.ctypes.data, o2.ctypes.data) == 0
+            g.map_pairs(b1, o1, b2, o2)  # warm the host-side buffers
+            t1 = time.perf_counter()
+            _, kk = g.map_pairs(b1, o1, b2, o2)
+            t2 = time.perf_counter()
+            pcie = {"M pairs/s": round(n / (t2 - t1) / 1e6, 2), "ms": round((t2 - t1) * 1e3, 2), "records": int(kk),
+                    "note": "pageable host buffers, synchronous hipMemcpy, includes allocating the host record array"}
+        except Exception as e:
+            pcie = {"error": repr(e)}
         cpu = None
         if world == 1 and not args.skip_cpu:
             try:
@@ -281,7 +300,7 @@ def main():
                                    "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7) resident per GPU, "
                                    "%d pairs per GPU per step, reads resident in HBM" % (args.preset, args.readlen, args.genome, args.nseq, args.pairs),
                        "pairs_per_gpu_per_step": args.pairs, "parallelism": "read-shard x%d + RCCL all-gather of records" % world if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "postprocess_on_device": post,
+            "roofline": roof, "cpu_baseline": cpu, "postprocess_on_device": post, "pcie_inclusive": pcie,
             "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
             "counters_per_step": {k: v // steps for k, v in s.items()},
             "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),

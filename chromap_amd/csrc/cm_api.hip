@@ -102,7 +102,7 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   p.bc_err = params->bc_error_threshold;
   p.bc_keep = params->output_mappings_not_in_whitelist ? 1 : 0;
   p.bc_prob = params->bc_probability_threshold;
-  if (p.bc_err < 0 || p.bc_err > 1) { cm_set_error(c, "bc_error_threshold must be 0 or 1 on the device"); return CMGPU_EINVAL; }
+  if (p.bc_err < 0 || p.bc_err > 2) { cm_set_error(c, "bc_error_threshold must be 0, 1 or 2"); return CMGPU_EINVAL; }
   p.k = kmer;
   p.w = window;
   p.lanes = p.e < 8 ? 8 : (p.e < 16 ? 4 : 0);  // GetNumVPULanes (mapping_parameters.h:80-88)

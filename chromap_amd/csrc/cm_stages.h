@@ -213,26 +213,17 @@ CM_HD bool cm_wl_get(const CmDev &d, uint64_t key, uint32_t *cnt) {
     i = (i + 1) & d.wl_mask;
   }
 }
-#define CM_BC_MAXC 132  // 32 positions x 4 + slack
-CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32_t *corrected) {
-  const uint8_t *bc = d.bcb + d.bco[pair];
-  const uint8_t *q = d.bcq + d.bco[pair];
-  const uint32_t len = d.bco[pair + 1] - d.bco[pair];
-  const uint64_t key = cm_seed_from_sequence(bc, len);
-  d.bc_key[pair] = key;
-  d.bc_ok[pair] = 0;
-  uint32_t cnt = 0;
-  const bool found = cm_wl_get(d, key, &cnt);
-  int nn = 0, n0 = 0;
-  for (int i = (int)len - 1; i >= 0; --i)
-    if (bc[i] == 'N') { if (nn == 0) n0 = (int)len - 1 - i; ++nn; }  // GetSequenceNsAt: 'N' only, little endian
-  if ((uint32_t)nn > (uint32_t)d.p.bc_err) return;
-  if (nn == 0 && found) { ++*in_wl; d.bc_ok[pair] = 1; return; }
-  if (d.p.bc_err <= 0) return;
-  double sc[CM_BC_MAXC];
-  uint64_t ck[CM_BC_MAXC];
-  uint32_t ci[CM_BC_MAXC];  // idx1 << 8 | base char
-  uint32_t nc = 0;
+#define CM_BC_MAXC 132  // buffered candidates; more than that takes the selection path below
+CM_HD int cm_bc_qual(const uint8_t *q, uint32_t len, uint32_t i) {
+  int aq = (int)q[len - 1 - i] - 33;
+  aq = aq > 40 ? 40 : aq;
+  return aq < 3 ? 3 : aq;
+}
+// Enumerates the whitelisted barcodes within bc_err substitutions in the reference's order
+// (Chromap::CorrectBarcodeAt, chromap.cc:590-718) and calls f(score, key, tag) for each;
+// tag = idx1<<24 | base1<<16 | idx2<<8 | base2 orders like BarcodeWithQual (utils.h:23-35).
+template <class F>
+CM_HD void cm_bc_enumerate(const CmDev &d, uint64_t key, const uint8_t *q, uint32_t len, int nn, int n0, int n1, F &&f) {
   uint32_t i_start = 0, i_end = len, ti_limit = 3;
   if (nn > 0) { i_start = (uint32_t)n0; i_end = i_start + 1; ti_limit = 4; }
   for (uint32_t i = i_start; i < i_end; ++i) {
@@ -242,23 +233,61 @@ CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32
       b1 = (b1 + 1) & 3ull;
       const uint64_t k1 = cleared | (b1 << (2 * i));
       uint32_t c1;
-      if (cm_wl_get(d, k1, &c1) && nc < CM_BC_MAXC) {
-        const double abundance = c1 / d.wl_num_sample;
-        int aq = (int)q[len - 1 - i] - 33;
-        aq = aq > 40 ? 40 : aq;
-        aq = aq < 3 ? 3 : aq;
-        sc[nc] = d.pow10_tab[aq] * abundance;
-        ck[nc] = k1;
-        ci[nc] = ((len - 1 - i) << 8) | (uint32_t)"ACGT"[b1];
-        ++nc;
+      if (cm_wl_get(d, k1, &c1))
+        f(d.pow10_tab[cm_bc_qual(q, len, i)] * (c1 / d.wl_num_sample), k1, ((len - 1 - i) << 24) | ((uint32_t)"ACGT"[b1] << 16));
+      if (d.p.bc_err == 2) {
+        uint32_t j_start = i + 1, j_end = len, ti2_limit = 3;
+        if (nn == 2) { j_start = (uint32_t)n1; j_end = j_start + 1; ti2_limit = 4; }
+        for (uint32_t j = j_start; j < j_end; ++j) {
+          const uint64_t cleared2 = ~(3ull << (2 * j)) & k1;
+          uint64_t b2 = (k1 >> (2 * j)) & 3ull;
+          for (uint32_t ti2 = 0; ti2 < ti2_limit; ++ti2) {
+            b2 = (b2 + 1) & 3ull;
+            const uint64_t k2 = cleared2 | (b2 << (2 * j));
+            uint32_t c2;
+            if (cm_wl_get(d, k2, &c2))
+              f(d.pow10_tab[cm_bc_qual(q, len, j) + cm_bc_qual(q, len, i)] * (c2 / d.wl_num_sample), k2,
+                ((len - 1 - i) << 24) | ((uint32_t)"ACGT"[b1] << 16) | ((len - 1 - j) << 8) | (uint32_t)"ACGT"[b2]);
+          }
+        }
       }
     }
   }
+}
+
+CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32_t *corrected) {
+  const uint8_t *bc = d.bcb + d.bco[pair];
+  const uint8_t *q = d.bcq + d.bco[pair];
+  const uint32_t len = d.bco[pair + 1] - d.bco[pair];
+  const uint64_t key = cm_seed_from_sequence(bc, len);
+  d.bc_key[pair] = key;
+  d.bc_ok[pair] = 0;
+  uint32_t cnt = 0;
+  const bool found = cm_wl_get(d, key, &cnt);
+  int nn = 0, n0 = 0, n1 = 0;
+  for (int i = (int)len - 1; i >= 0; --i)
+    if (bc[i] == 'N') {  // GetSequenceNsAt: 'N' only, little-endian positions
+      if (nn == 0) n0 = (int)len - 1 - i;
+      if (nn == 1) n1 = (int)len - 1 - i;
+      ++nn;
+    }
+  if ((uint32_t)nn > (uint32_t)d.p.bc_err) return;
+  if (nn == 0 && found) { ++*in_wl; d.bc_ok[pair] = 1; return; }
+  if (d.p.bc_err <= 0) return;
+  double sc[CM_BC_MAXC];
+  uint64_t ck[CM_BC_MAXC];
+  uint32_t ci[CM_BC_MAXC];
+  uint32_t nc = 0;
+  cm_bc_enumerate(d, key, q, len, nn, n0, n1, [&](double score, uint64_t k, uint32_t tag) {
+    if (nc < CM_BC_MAXC) { sc[nc] = score; ck[nc] = k; ci[nc] = tag; }
+    ++nc;
+  });
   if (nc == 0) return;
-  uint32_t best = 0;
+  uint64_t best_key = ck[0];
   bool apply = true;
-  if (nc > 1) {
-    // insertion sort, descending by (score, idx1, base1): std::greater<BarcodeWithQual> (utils.h:29-35)
+  if (nc > 1 && nc <= CM_BC_MAXC) {
+    // insertion sort, descending by (score, tag): std::greater<BarcodeWithQual>; the sum runs in
+    // that order (double addition is not associative)
     for (uint32_t a = 1; a < nc; ++a) {
       const double xs = sc[a];
       const uint64_t xk = ck[a];
@@ -270,9 +299,29 @@ CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32
     double sum = 0;
     for (uint32_t a = 0; a < nc; ++a) sum += sc[a];
     apply = sc[0] / sum > d.p.bc_prob;
+    best_key = ck[0];
+  } else if (nc > CM_BC_MAXC) {
+    // dense whitelists (short barcodes): selection instead of a sort -- nc passes over the
+    // enumeration, each picking the next candidate in descending order
+    double prev_s = 0, sum = 0, first_s = 0;
+    uint32_t prev_t = 0;
+    for (uint32_t r = 0; r < nc; ++r) {
+      double bs = -1.0;
+      uint32_t bt = 0;
+      uint64_t bk = 0;
+      cm_bc_enumerate(d, key, q, len, nn, n0, n1, [&](double score, uint64_t k, uint32_t tag) {
+        if (r > 0 && !(score < prev_s || (score == prev_s && tag < prev_t))) return;
+        if (score > bs || (score == bs && tag > bt)) { bs = score; bt = tag; bk = k; }
+      });
+      if (r == 0) { first_s = bs; best_key = bk; }
+      sum += bs;
+      prev_s = bs;
+      prev_t = bt;
+    }
+    apply = first_s / sum > d.p.bc_prob;
   }
   if (apply) {
-    d.bc_key[pair] = ck[best];
+    d.bc_key[pair] = best_key;
     d.bc_ok[pair] = 1;
     ++*corrected;
   }

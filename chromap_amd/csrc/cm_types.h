@@ -37,7 +37,7 @@ struct CmParams {
   int32_t trim;          // trim_adapters
   int32_t split;         // split_alignment (--preset hic)
   int32_t single;        // single-end batch: mate 1 of every pair is empty (MapSingleEndReads, chromap.h:385-472)
-  int32_t bc_err;        // barcode_correction_error_threshold (0 or 1 on the device)
+  int32_t bc_err;        // barcode_correction_error_threshold (0, 1 or 2)
   int32_t bc_keep;       // output_mappings_not_in_whitelist
   double bc_prob;        // barcode_correction_probability_threshold
   int32_t k, w;          // from the index file

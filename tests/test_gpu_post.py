@@ -55,7 +55,7 @@ def test_device_bed_se_equals_reference(case):
     g.close()
 
 
-@pytest.mark.parametrize("case", [c for c in datasets.BC_CASES if "bc2" not in c])
+@pytest.mark.parametrize("case", datasets.BC_CASES)
 def test_device_bed_barcoded_equals_reference(case, tmp_path):
     from chromap_amd import _capi
     g, meta, r1, r2 = _gpu(case)

@@ -60,3 +60,20 @@ def test_fuzz_stage_functions(cfg, tmp_path):
         return rec, k, st.as_dict()
     od, gst = run_case(factory, cfg, tmp_path)
     assert od["num_mapped_reads"] > 0
+
+
+@pytest.mark.parametrize("bc_err", [1, 2])
+def test_barcode_correction_dense_whitelist(bc_err, tmp_path):
+    """short barcodes + nearly complete whitelist: > 132 candidates per uncorrectable barcode at
+    threshold 2 (selection path), N handling, quality clamps"""
+    import bc_fuzz
+    fa, idx, b1, o1, b2, o2, bc, bcq, bco, wl = bc_fuzz.build(str(tmp_path))
+    want, n_in, n_corr, keys = bc_fuzz.oracle_result(fa, idx, b1, o1, b2, o2, bc, bcq, bco, wl, bc_err)
+    h = he.HostEmu(idx, fa, he.params("atac", mapq_threshold=0, bc_error_threshold=bc_err))
+    rec, k, st = h.map_pairs_bc(b1, o1, b2, o2, bc, bcq, bco, keys)
+    got = sorted((rec[i].r.read_id, rec[i].r.rid, rec[i].r.fragment_start, rec[i].r.fragment_length, rec[i].r.mapq,
+                  rec[i].r.direction, rec[i].barcode) for i in range(k))
+    s = st.as_dict()
+    assert (s["num_barcode_in_whitelist"], s["num_corrected_barcode"]) == (n_in, n_corr)
+    assert n_corr > 10
+    assert got == want

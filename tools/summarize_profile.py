@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_bench.sh output directory into the small files kept under
+profiles/: kernel_stats.csv (rocprofv3 --stats as is), pmc_fetch_write.csv (per-kernel average
+FETCH_SIZE / WRITE_SIZE in KiB per launch, from the two separate PMC passes) and
+probe_traffic.json (what bench.py reports as roofline.traffic)."""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def pmc(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            a = acc[row["Kernel_Name"].split("(")[0]]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return acc
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "bench_under_rocprof.json"))
+    fe = pmc(os.path.join(src, "fetch", "bench_counter_collection.csv"), "FETCH_SIZE")
+    wr = pmc(os.path.join(src, "write", "bench_counter_collection.csv"), "WRITE_SIZE")
+    # rocprofv3 reports one row per dispatch and per XCD-summed counter; FETCH_SIZE / WRITE_SIZE are in KiB
+    with open(os.path.join(dst, "pmc_fetch_write.csv"), "w") as f:
+        f.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,avg_hbm_MB\n")
+        for k in sorted(set(fe) | set(wr), key=lambda k: -(fe[k][0] + wr[k][0])):
+            n = max(fe[k][1], wr[k][1], 1)
+            a = fe[k][0] / max(1, fe[k][1])
+            b = wr[k][0] / max(1, wr[k][1])
+            f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k, n, a, b, (a + b) * 1024 / 1e6))
+    out = {}
+    for k in fe:
+        if k.startswith("k_probe") and "reduce" not in k:
+            a = fe[k][0] / fe[k][1]
+            b = wr[k][0] / max(1, wr[k][1])
+            out = {"kernel": "k_probe", "workload": "bench.py default (4M pairs/step, GRCh38-sized synthetic index)",
+                   "FETCH_SIZE_KiB": round(a, 3), "WRITE_SIZE_KiB": round(b, 3), "hbm_bytes_per_launch": int((a + b) * 1024)}
+    for k in fe:
+        if k.startswith("k_gather"):
+            out["calibration"] = ("k_gather: 2^28 independent 16-B loads -> FETCH_SIZE %.1f KiB = %.1f B per access; "
+                                  "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes"
+                                  % (fe[k][0] / fe[k][1], fe[k][0] / fe[k][1] * 1024 / (1 << 28)))
+    with open(os.path.join(dst, "probe_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
