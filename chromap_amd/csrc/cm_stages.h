@@ -335,6 +335,67 @@ CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32
 // complement of its first new_len bases (the front of the revcomp string is erased), so
 // only the new lengths need to be kept.
 // ---------------------------------------------------------------------------------------
+// Fast path of the overlap search for reads made of upper-case A/C/G/T only (anything else takes
+// the byte-wise loop below, which is the definition).  With 2-bit codes the reference's search
+//   for si in {0,1}: for every position sp where seed si of read1 occurs in revcomp(read2):
+//       accept if the whole overlap has <= 1 mismatch          (chromap.cc:200-260)
+// becomes: for every alignment s0 = sp - si*seed in [0, l2 - min_overlap], D(s0) = mismatch bits of
+// read1[0,n) vs neg2[s0,s0+n), n = min(l1, l2-s0); alignment s0 is accepted through seed 0 if
+// popcount(D) <= 1 and D is zero on [0,seed), through seed 1 if zero on [seed,2*seed).  The
+// result is the smallest s0 accepted through seed 0, else the smallest accepted through seed 1
+// -- the order in which the reference tries them.  Code: (c>>1)&3 (A0 C1 T2 G3), complement = ^2.
+CM_HD bool cm_trim_pack(const uint8_t *s, uint32_t len, bool revcomp, uint64_t *w, int nw) {
+  for (int i = 0; i < nw; ++i) w[i] = 0;
+  bool valid = true;
+  for (uint32_t i = 0; i < len; ++i) {
+    const uint32_t c = s[revcomp ? len - 1 - i : i];
+    const uint32_t o = c - 'A';
+    valid = valid && o < 26u && ((0x00080045u >> o) & 1u);  // A, C, G, T
+    const uint64_t code = ((c >> 1) & 3u) ^ (revcomp ? 2u : 0u);
+    w[i >> 5] |= code << ((i & 31) << 1);
+  }
+  return valid;
+}
+template <int W>
+CM_HD bool cm_trim_fast(const uint8_t *rd1, uint32_t l1, const uint8_t *lng, uint32_t l2, int min_overlap, int seed,
+                        bool *found, uint32_t *s0_out) {
+  uint64_t a[W], b[W];
+  const bool va = cm_trim_pack(rd1, l1, false, a, W), vb = cm_trim_pack(lng, l2, true, b, W);
+  if (!va || !vb) return false;
+  const uint64_t m55 = 0x5555555555555555ull;
+  const uint64_t seedmask = seed >= 32 ? ~0ull : ((1ull << (2 * seed)) - 1);
+  bool fa = false, fb = false;
+  uint32_t sa = 0, sb = 0;
+  const uint32_t last = l2 - (uint32_t)min_overlap;
+  for (uint32_t s0 = 0; s0 <= last && !fa; ++s0) {
+    const uint32_t n = l1 < l2 - s0 ? l1 : l2 - s0;
+    uint32_t cnt = 0;
+    uint64_t d0 = 0, d1 = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const uint64_t x = a[w] ^ b[w];
+      uint64_t dd = (x | (x >> 1)) & m55;
+      const uint32_t lo = 32u * (uint32_t)w;
+      const uint64_t m = n >= lo + 32 ? ~0ull : n <= lo ? 0ull : ((1ull << (2 * (n - lo))) - 1);
+      dd &= m;
+      cnt += (uint32_t)__builtin_popcountll(dd);
+      if (w == 0) d0 = dd;
+      if (w == 1) d1 = dd;
+    }
+    const uint64_t r0 = d0 & seedmask;
+    const uint64_t r1 = seed >= 32 ? d1 : (((d0 >> (2 * seed)) | (d1 << (64 - 2 * seed))) & seedmask);
+    const bool ok = cnt <= 1;
+    if (ok && r0 == 0) { fa = true; sa = s0; }
+    if (ok && r1 == 0 && !fb) { fb = true; sb = s0; }
+#pragma unroll
+    for (int w = 0; w + 1 < W; ++w) b[w] = (b[w] >> 2) | (b[w + 1] << 62);
+    b[W - 1] >>= 2;
+  }
+  *found = fa || fb;
+  *s0_out = fa ? sa : sb;
+  return true;
+}
+
 // s1p / s2p: the pair's reads (global memory, or the block's LDS copy of them)
 CM_HD void cm_s0_prep_ptr(const CmDev &d, uint32_t pair, const uint8_t *s1p, const uint8_t *s2p) {
   const uint32_t raw1 = d.ro0[pair + 1] - d.ro0[pair], raw2 = d.ro1[pair + 1] - d.ro1[pair];
@@ -351,6 +412,26 @@ CM_HD void cm_s0_prep_ptr(const CmDev &d, uint32_t pair, const uint8_t *s1p, con
     const int min_overlap = d.p.min_read_len;
     const int seed = min_overlap / 2;
     bool merged = false;
+    // fast path (upper-case ACGT reads of <= 256 bases, seed <= 32): same result, 2-bit arithmetic
+    bool fast = false, ffound = false;
+    uint32_t fs0 = 0;
+    if (seed >= 1 && seed <= 32 && 2 * seed <= min_overlap && l1 >= (uint32_t)min_overlap) {
+      if (l2 <= 64) fast = cm_trim_fast<2>(rd1, l1, lng, l2, min_overlap, seed, &ffound, &fs0);
+      else if (l2 <= 160) fast = cm_trim_fast<5>(rd1, l1, lng, l2, min_overlap, seed, &ffound, &fs0);
+      else if (l2 <= 256) fast = cm_trim_fast<8>(rd1, l1, lng, l2, min_overlap, seed, &ffound, &fs0);
+    }
+    if (fast) {
+      merged = true;  // skips the byte-wise search
+      if (ffound) {
+        int overlap = (int)(l2 - fs0);
+        int off2 = 0;
+        if (overlap > (int)l1) { off2 = overlap - (int)l1; overlap = (int)l1; }
+        const int t1 = swap ? overlap + off2 : overlap;
+        const int t2 = swap ? overlap : overlap + off2;
+        if (t1 < (int)raw1) len1 = (uint32_t)t1;
+        if (t2 < (int)raw2) len2 = (uint32_t)t2;
+      }
+    }
     // neg2[i] = cm_negchar(lng[l2 - 1 - i])
     for (int si = 0; si < 2 && !merged; ++si) {
       const uint8_t *needle = rd1 + si * seed;

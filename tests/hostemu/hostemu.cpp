@@ -249,3 +249,16 @@ extern "C" long hostemu_ref_minimizers(const cmgpu_ref_view *ref, int k, int w, 
   }
   return n;
 }
+
+// S0 alone (length filter + adapter trimming): rlen[2*pair], rlen[2*pair+1] as cm_s0_prep leaves them
+extern "C" int hostemu_trim(const cmgpu_params *params, const cmgpu_batch *in, uint32_t *rlen) {
+  CmDev d;
+  memset(&d, 0, sizeof(d));
+  d.p.min_read_len = params->min_read_length;
+  d.p.trim = params->trim_adapters;
+  d.rb0 = (const uint8_t *)in->read1_bases; d.rb1 = (const uint8_t *)in->read2_bases;
+  d.ro0 = in->read1_offsets; d.ro1 = in->read2_offsets;
+  d.rlen = rlen;
+  for (uint32_t i = 0; i < in->n_pairs; ++i) cm_s0_prep(d, i);
+  return 0;
+}
