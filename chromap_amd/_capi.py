@@ -88,6 +88,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
+           "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
 TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC = 0, 1, 2
@@ -141,6 +142,10 @@ def declare(L):
     sig("cmgpu_store_text", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64])
     sig("cmgpu_store_write_text", C.c_int, [C.c_void_p, C.c_char_p, C.c_int])
     sig("cmgpu_store_info", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_fastq_scan", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
+    sig("cmgpu_fastq_take", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, P(C.c_uint64)])
+    sig("cmgpu_barcode_abundance_resident", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_int)])
+    sig("cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int])
     sig("cmgpu_write_bed_se", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
     sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])

@@ -662,23 +662,17 @@ extern "C" int cmgpu_set_whitelist(cmgpu_ctx *c, const uint64_t *keys, uint32_t 
   return CMGPU_OK;
 }
 
-extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, const uint32_t *offsets, uint32_t n,
-                                               uint64_t *num_sample_barcodes) {
-  if (!c || !bases || !offsets || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+// abundance counting over device-resident barcodes, in reference batches, until the sample is
+// large enough (chromap.cc:494-540: stops after the batch that reaches 20 M whitelisted barcodes)
+static int bc_abundance_run(cmgpu_ctx *c, const uint8_t *dbases, const uint32_t *doffs, uint32_t n, bool *done) {
   const uint64_t max_sample = 20000000ull;   // initial_num_sample_barcodes_ (chromap.h:211)
   const uint32_t batch = (uint32_t)(c->p.ref_batch > 0 ? c->p.ref_batch : 500000);
-  DevBuf db, dofs;
-  const size_t nbytes = n ? offsets[n] : 0;
-  if (db.ensure(nbytes + 16) || dofs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
-  HIPCHECK(c, hipMemcpy(db.p, bases, nbytes, hipMemcpyHostToDevice));
-  HIPCHECK(c, hipMemcpy(dofs.p, offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
   unsigned long long ns = c->wl_num_sample;
   int rc = CMGPU_OK;
-  for (uint32_t b0 = 0; b0 < n; b0 += batch) {
+  *done = ns >= max_sample;
+  for (uint32_t b0 = 0; b0 < n && !*done; b0 += batch) {
     const uint32_t bn = n - b0 < batch ? n - b0 : batch;
-    cm_launch_k_bc_abundance((const uint8_t *)db.p, (const uint32_t *)dofs.p, b0, b0 + bn, (uint64_t *)c->wl.p, c->wl_mask,
-                             (unsigned long long *)c->wl_num.p, c->stream);
+    cm_launch_k_bc_abundance(dbases, doffs, b0, b0 + bn, (uint64_t *)c->wl.p, c->wl_mask, (unsigned long long *)c->wl_num.p, c->stream);
     hipError_t e = hipMemcpyAsync(&ns, c->wl_num.p, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cm_set_error(c, std::string("barcode abundance: ") + hipGetErrorString(e)); rc = CMGPU_EHIP; break; }
@@ -687,11 +681,36 @@ extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, 
       rc = CMGPU_EINVAL;
       break;
     }
-    if (ns >= max_sample) break;
+    if (ns >= max_sample) *done = true;
   }
-  db.release(); dofs.release();
   c->wl_num_sample = ns;
-  if (num_sample_barcodes) *num_sample_barcodes = ns;
+  return rc;
+}
+
+extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, const uint32_t *offsets, uint32_t n,
+                                               uint64_t *num_sample_barcodes) {
+  if (!c || !bases || !offsets || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  DevBuf db, dofs;
+  const size_t nbytes = n ? offsets[n] : 0;
+  if (db.ensure(nbytes + 16) || dofs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemcpy(db.p, bases, nbytes, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(dofs.p, offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+  bool done = false;
+  const int rc = bc_abundance_run(c, (const uint8_t *)db.p, (const uint32_t *)dofs.p, n, &done);
+  db.release(); dofs.release();
+  if (num_sample_barcodes) *num_sample_barcodes = c->wl_num_sample;
+  return rc;
+}
+
+// same over the barcodes last taken from FASTQ stream 2 (cmgpu_fastq_take); call per chunk until *done
+extern "C" int cmgpu_barcode_abundance_resident(cmgpu_ctx *c, uint64_t *num_sample_barcodes, int *done) {
+  if (!c || !done || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  bool d = false;
+  const int rc = bc_abundance_run(c, (const uint8_t *)c->bcb.p, (const uint32_t *)c->bco.p, c->fq[2].taken, &d);
+  *done = d ? 1 : 0;
+  if (num_sample_barcodes) *num_sample_barcodes = c->wl_num_sample;
   return rc;
 }
 

@@ -66,11 +66,44 @@ struct FastxReader {
   void close() { if (f) gzclose(f); f = nullptr; }
 };
 
+// raw (inflated) file bytes in large chunks for the device-side FASTQ parser
+struct ChunkReader {
+  gzFile f = nullptr;
+  std::vector<char> buf;
+  size_t len = 0;
+  bool eof = false;
+  bool open(const std::string &path) {
+    f = gzopen(path.c_str(), "r");
+    if (f) gzbuffer(f, 1 << 20);
+    len = 0;
+    eof = false;
+    return f != nullptr;
+  }
+  void fill(size_t target) {
+    if (buf.size() < target) buf.resize(target);
+    while (len < target && !eof) {
+      const size_t want = target - len < (1u << 30) ? target - len : (1u << 30);
+      const int r = gzread(f, buf.data() + len, (unsigned)want);
+      if (r <= 0) eof = true; else len += (size_t)r;
+    }
+  }
+  void consume(size_t used) {
+    if (used < len) memmove(buf.data(), buf.data() + used, len - used);
+    len -= used;
+  }
+  bool only_whitespace() const {
+    for (size_t i = 0; i < len; ++i) if (buf[i] != '\n' && buf[i] != '\r' && buf[i] != ' ' && buf[i] != '\t') return false;
+    return true;
+  }
+  void close() { if (f) gzclose(f); f = nullptr; }
+};
+
 struct Args {
   std::string index_path, ref_path, out_path, preset, barcode_file, whitelist;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
-  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false;
+  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false;
+  size_t chunk_bytes = 256u << 20;
   int k = 17, w = 7, device = 0;
   uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
 };
@@ -138,6 +171,8 @@ static Args parse(int argc, char **argv) {
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
     else if (o == "--device") a.device = atoi(need("--device"));
+    else if (o == "--host-ingest") a.host_ingest = true;   // kseq-style host parser (FASTA / multi-line records)
+    else if (o == "--ingest-chunk-mb") a.chunk_bytes = (size_t)atol(need("--ingest-chunk-mb")) << 20;
     else if (o == "--batch-pairs") a.batch_pairs = (uint32_t)atol(need("--batch-pairs"));
     else if (o == "-v" || o == "--version") { printf("chromap-amd 0.1 (hot path of chromap 0.3.3-r521 on gfx950)\n"); exit(0); }
     else if (o == "-h" || o == "--help") {
@@ -193,79 +228,167 @@ int main(int argc, char **argv) {
   uint64_t num_reads = 0;
   uint32_t next_read_id = 0, bc_len = 0;
 
-  // single-cell: whitelist + abundance pre-pass over the whole barcode file (chromap.h:750-761)
-  if (barcoded) {
-    FastxReader br;
-    if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
-    std::string nm, sq, ql;
-    std::vector<char> bb;
-    std::vector<uint32_t> bo(1, 0);
-    while (br.record(nm, sq, ql)) { if (sq.empty()) continue; bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
-    br.close();
-    if (bo.size() < 2) die("empty barcode file");
-    bc_len = bo[1] - bo[0];
-    uint64_t *keys = nullptr;
-    uint32_t nk = 0;
-    if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
-    if (cmgpu_set_whitelist(ctx, keys, nk, bc_len) != 0) die(cmgpu_last_error(ctx));
-    free(keys);
-    uint64_t ns = 0;
-    if (cmgpu_compute_barcode_abundance(ctx, bb.data(), bo.data(), (uint32_t)bo.size() - 1, &ns) != 0) die(cmgpu_last_error(ctx));
-    fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
-  }
-
-  for (size_t fi = 0; fi < a.r1.size(); ++fi) {
-    FastxReader f1, f2, fb;
-    if (!f1.open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
-    if (paired && !f2.open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);
-    if (barcoded && !fb.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
-    bool more = true;
-    while (more) {
-      std::vector<char> b1, b2, bb, bq;
-      std::vector<uint32_t> o1(1, 0), o2(1, 0), bo(1, 0);
-      std::string n1, s1, q1, n2, s2, q2, nb, sb, qb;
-      uint32_t n = 0;
-      while (n < a.batch_pairs) {
-        const bool g1 = f1.record(n1, s1, q1);
-        const bool g2 = paired ? f2.record(n2, s2, q2) : g1;
-        const bool gb = barcoded ? fb.record(nb, sb, qb) : g1;
-        if (!g1 && !g2 && !gb) { more = false; break; }
-        if (!(g1 && g2 && gb)) die("Numbers of reads and barcodes don't match!");
-        if (s1.empty() || (paired && s2.empty())) continue;
-        b1.insert(b1.end(), s1.begin(), s1.end()); o1.push_back((uint32_t)b1.size());
-        if (paired) { b2.insert(b2.end(), s2.begin(), s2.end()); o2.push_back((uint32_t)b2.size()); }
-        if (barcoded) { bb.insert(bb.end(), sb.begin(), sb.end()); bq.insert(bq.end(), qb.begin(), qb.end()); bq.resize(bb.size(), 'I'); bo.push_back((uint32_t)bb.size()); }
-        if (a.out_pairs) read_names.push_back(n1);
-        ++n;
+  const bool device_ingest = !a.out_pairs && !a.host_ingest;  // pairs output needs read names: host parser
+  auto ck = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(ctx)); };
+  if (device_ingest) {
+    // ---- FASTQ text goes to the GPU in chunks; lines, records and the SoA batch are built there
+    if (barcoded) {
+      // whitelist + abundance pre-pass (chromap.h:750-761), barcode file streamed through the device
+      ChunkReader br;
+      if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+      size_t target = a.chunk_bytes;
+      int done = 0;
+      uint64_t ns = 0;
+      uint32_t nk = 0;
+      while (!done) {
+        br.fill(target);
+        if (br.len == 0) break;
+        if (bc_len == 0) {  // length of the first barcode: second line of the file
+          const char *p = (const char *)memchr(br.buf.data(), '\n', br.len);
+          const char *q = p ? (const char *)memchr(p + 1, '\n', br.len - (size_t)(p + 1 - br.buf.data())) : nullptr;
+          if (!p || !q) die("barcode file is not FASTQ");
+          bc_len = (uint32_t)(q - p - 1);
+          if (bc_len && p[bc_len] == '\r') --bc_len;
+          uint64_t *keys = nullptr;
+          if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
+          ck(cmgpu_set_whitelist(ctx, keys, nk, bc_len));
+          free(keys);
+        }
+        uint32_t cnt = 0;
+        ck(cmgpu_fastq_scan(ctx, 2, br.buf.data(), br.len, br.eof, &cnt));
+        uint32_t n = cnt;
+        if (!br.eof) n -= n % 500000;
+        if (n == 0 && !br.eof) { target *= 2; continue; }
+        uint64_t used = 0;
+        ck(cmgpu_fastq_take(ctx, 2, n, &used));
+        br.consume((size_t)used);
+        ck(cmgpu_barcode_abundance_resident(ctx, &ns, &done));
+        if (br.eof && n == cnt) break;
       }
-      if (n == 0) break;
-      num_reads += paired ? 2ull * n : n;
-      uint64_t k = 0;
-      int rc;
-      if (barcoded) {
-        cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
-        cmgpu_barcode_batch bc{bb.data(), bq.data(), bo.data()};
-        rc = cmgpu_map_pairs_barcoded(ctx, &bt, &bc, nullptr, 0, &k, &st);
-      } else if (paired && !a.out_pairs) {
-        cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
-        rc = cmgpu_map_pairs(ctx, &bt, nullptr, 0, &k, &st);
-      } else if (paired) {
-        const size_t base = recs.size();
-        recs.resize(base + n);
-        cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
-        rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, n, &k, &st);
-        recs.resize(base + k);
-      } else {
-        cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};
-        rc = cmgpu_map_single(ctx, &bt, nullptr, 0, &k, &st);
-      }
-      if (rc != CMGPU_OK) die(cmgpu_last_error(ctx));
-      // BED outputs: the records never leave HBM -- they join the device-side store
-      if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) die(cmgpu_last_error(ctx));
-      next_read_id += n;
-      fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
+      br.close();
+      fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
     }
-    f1.close(); f2.close(); fb.close();
+    for (size_t fi = 0; fi < a.r1.size(); ++fi) {
+      ChunkReader rd[3];
+      const int ns_streams = 1 + (paired ? 1 : 0) + (barcoded ? 1 : 0);
+      int sid[3] = {0, paired ? 1 : 2, 2};
+      if (!rd[0].open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
+      if (paired && !rd[1].open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);
+      if (barcoded && !rd[ns_streams - 1].open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+      size_t target = a.chunk_bytes;
+      for (;;) {
+        uint32_t cnt[3] = {0, 0, 0};
+        bool all_final = true;
+        for (int m = 0; m < ns_streams; ++m) {
+          rd[m].fill(target);
+          all_final = all_final && rd[m].eof;
+          const int rc = cmgpu_fastq_scan(ctx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
+          if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(ctx)) + " -- rerun with --host-ingest");
+          ck(rc);
+        }
+        uint32_t n = cnt[0];
+        for (int m = 1; m < ns_streams; ++m) n = cnt[m] < n ? cnt[m] : n;
+        if (n > a.batch_pairs) n = a.batch_pairs;
+        if (!all_final || n == a.batch_pairs) n -= n % 500000;  // whole reference batches except at the very end
+        if (n == 0) {
+          if (!all_final) { target *= 2; continue; }
+          for (int m = 0; m < ns_streams; ++m)
+            if (cnt[m] != 0) die("Numbers of reads and barcodes don't match!");
+          break;
+        }
+        for (int m = 0; m < ns_streams; ++m) {
+          uint64_t used = 0;
+          ck(cmgpu_fastq_take(ctx, sid[m], n, &used));
+          rd[m].consume((size_t)used);
+        }
+        ck(cmgpu_fastq_commit(ctx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));
+        uint64_t k = 0;
+        ck(cmgpu_map_resident(ctx, &k, &st));
+        ck(cmgpu_store_append_resident(ctx, nullptr));
+        num_reads += paired ? 2ull * n : n;
+        next_read_id += n;
+        fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
+      }
+      for (int m = 0; m < ns_streams; ++m) {
+        if (!rd[m].only_whitespace()) die("Didn't reach the end of sequence file, which might be corrupted!");
+        rd[m].close();
+      }
+    }
+  } else {
+    // single-cell: whitelist + abundance pre-pass over the whole barcode file (chromap.h:750-761)
+    if (barcoded) {
+      FastxReader br;
+      if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+      std::string nm, sq, ql;
+      std::vector<char> bb;
+      std::vector<uint32_t> bo(1, 0);
+      while (br.record(nm, sq, ql)) { if (sq.empty()) continue; bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
+      br.close();
+      if (bo.size() < 2) die("empty barcode file");
+      bc_len = bo[1] - bo[0];
+      uint64_t *keys = nullptr;
+      uint32_t nk = 0;
+      if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
+      if (cmgpu_set_whitelist(ctx, keys, nk, bc_len) != 0) die(cmgpu_last_error(ctx));
+      free(keys);
+      uint64_t ns = 0;
+      if (cmgpu_compute_barcode_abundance(ctx, bb.data(), bo.data(), (uint32_t)bo.size() - 1, &ns) != 0) die(cmgpu_last_error(ctx));
+      fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
+    }
+
+    for (size_t fi = 0; fi < a.r1.size(); ++fi) {
+      FastxReader f1, f2, fb;
+      if (!f1.open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
+      if (paired && !f2.open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);
+      if (barcoded && !fb.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+      bool more = true;
+      while (more) {
+        std::vector<char> b1, b2, bb, bq;
+        std::vector<uint32_t> o1(1, 0), o2(1, 0), bo(1, 0);
+        std::string n1, s1, q1, n2, s2, q2, nb, sb, qb;
+        uint32_t n = 0;
+        while (n < a.batch_pairs) {
+          const bool g1 = f1.record(n1, s1, q1);
+          const bool g2 = paired ? f2.record(n2, s2, q2) : g1;
+          const bool gb = barcoded ? fb.record(nb, sb, qb) : g1;
+          if (!g1 && !g2 && !gb) { more = false; break; }
+          if (!(g1 && g2 && gb)) die("Numbers of reads and barcodes don't match!");
+          if (s1.empty() || (paired && s2.empty())) continue;
+          b1.insert(b1.end(), s1.begin(), s1.end()); o1.push_back((uint32_t)b1.size());
+          if (paired) { b2.insert(b2.end(), s2.begin(), s2.end()); o2.push_back((uint32_t)b2.size()); }
+          if (barcoded) { bb.insert(bb.end(), sb.begin(), sb.end()); bq.insert(bq.end(), qb.begin(), qb.end()); bq.resize(bb.size(), 'I'); bo.push_back((uint32_t)bb.size()); }
+          if (a.out_pairs) read_names.push_back(n1);
+          ++n;
+        }
+        if (n == 0) break;
+        num_reads += paired ? 2ull * n : n;
+        uint64_t k = 0;
+        int rc;
+        if (barcoded) {
+          cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
+          cmgpu_barcode_batch bc{bb.data(), bq.data(), bo.data()};
+          rc = cmgpu_map_pairs_barcoded(ctx, &bt, &bc, nullptr, 0, &k, &st);
+        } else if (paired && !a.out_pairs) {
+          cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
+          rc = cmgpu_map_pairs(ctx, &bt, nullptr, 0, &k, &st);
+        } else if (paired) {
+          const size_t base = recs.size();
+          recs.resize(base + n);
+          cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
+          rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, n, &k, &st);
+          recs.resize(base + k);
+        } else {
+          cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};
+          rc = cmgpu_map_single(ctx, &bt, nullptr, 0, &k, &st);
+        }
+        if (rc != CMGPU_OK) die(cmgpu_last_error(ctx));
+        // BED outputs: the records never leave HBM -- they join the device-side store
+        if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) die(cmgpu_last_error(ctx));
+        next_read_id += n;
+        fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
+      }
+      f1.close(); f2.close(); fb.close();
+    }
   }
   // Chromap::OutputMappingStatistics (chromap.cc:808-823)
   fprintf(stderr, "Number of reads: %llu.\nNumber of mapped reads: %llu.\nNumber of uniquely mapped reads: %llu.\n"

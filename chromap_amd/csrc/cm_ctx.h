@@ -19,6 +19,14 @@ struct DevBuf {
   void release();
 };
 
+// one FASTQ text stream being parsed on the device (cm_ingest.hip)
+struct CmFqStream {
+  DevBuf text, cnt, off, nl, keep, pos, recidx, len, bad;
+  uint64_t n_bytes = 0;
+  uint32_t n_nl = 0, n_raw = 0, n_rec = 0, taken = 0, taken_bases = 0, taken_max_len = 0;
+  bool final_chunk = false;
+};
+
 struct cmgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -54,6 +62,7 @@ struct cmgpu_ctx {
   DevBuf store, store_bc, text;
   uint64_t store_n = 0, store_cap = 0, text_bytes = 0, text_lines = 0;
   bool store_has_bc = false;
+  CmFqStream fq[3];  // read 1, read 2, barcode
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;
@@ -63,6 +72,11 @@ struct cmgpu_ctx {
   int n_ev = 0;
 
   std::vector<DevBuf *> all_bufs() {
+    std::vector<DevBuf *> v = core_bufs();
+    for (CmFqStream &f : fq) for (DevBuf *b : {&f.text, &f.cnt, &f.off, &f.nl, &f.keep, &f.pos, &f.recidx, &f.len, &f.bad}) v.push_back(b);
+    return v;
+  }
+  std::vector<DevBuf *> core_bufs() {
     return {&bkt, &occ, &ref, &ref_off, &ref_len, &len_coef, &nsec_break, &rb0, &rb1, &ro0, &ro1, &rlen, &cap,
             &mm_cap_off, &slot_hash, &slot_ps, &mm_cnt, &mm_off, &mm_hash, &mm_ps, &pr_val, &pr_kind, &hit_tot,
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,

@@ -1,0 +1,253 @@
+// cm_ingest.hip -- FASTQ text -> SoA read batch on the device.
+// Replaces, for 4-line FASTQ, kseq_read + SequenceBatch::LoadOneSequenceAndSaveAt
+// (sequence_batch.cc:22-62, kseq.h): the host only moves (inflated) file bytes; line splitting,
+// record validation, the skip of empty sequences (sequence_batch.cc:27-30) and the packing of
+// bases / qualities / offsets run as scans and gathers in HBM.
+//
+//   scan:  16 bytes per thread -> newline counts -> exclusive scan -> newline positions;
+//          records = complete groups of four lines; '@' / '+' markers are checked;
+//          records with an empty sequence line are dropped from the stream
+//   take:  the first n records' sequence (and quality) lines are gathered into the resident
+//          batch arrays of that mate; bytes_consumed tells the host where the next chunk starts
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "cm_ctx.h"
+#include "cm_kernels.h"
+
+#define FQ_BLOCK 256
+#define FQCHECK(ctx, call)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cm_set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                  \
+      return CMGPU_EHIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+__device__ __forceinline__ uint32_t fq_nl_mask(const uint8_t *__restrict__ text, uint64_t base, uint64_t n) {
+  uint32_t m = 0;
+  if (base + 16 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + base);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (((w[k] >> (8 * b)) & 0xff) == '\n') m |= 1u << (4 * k + b);
+  } else {
+    for (uint32_t i = 0; base + i < n; ++i)
+      if (text[base + i] == '\n') m |= 1u << i;
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(FQ_BLOCK) void k_fq_count(const uint8_t *__restrict__ text, uint64_t n, uint32_t n_thr, uint32_t *__restrict__ cnt) {
+  const uint32_t t = blockIdx.x * FQ_BLOCK + threadIdx.x;
+  if (t < n_thr) cnt[t] = __popc(fq_nl_mask(text, (uint64_t)t * 16, n));
+}
+__global__ __launch_bounds__(FQ_BLOCK) void k_fq_fill(const uint8_t *__restrict__ text, uint64_t n, uint32_t n_thr,
+                                                        const uint32_t *__restrict__ off, uint32_t *__restrict__ nl) {
+  const uint32_t t = blockIdx.x * FQ_BLOCK + threadIdx.x;
+  if (t >= n_thr) return;
+  uint32_t m = fq_nl_mask(text, (uint64_t)t * 16, n), o = off[t];
+  while (m) { const int b = __ffs(m) - 1; nl[o++] = t * 16 + (uint32_t)b; m &= m - 1; }
+}
+
+// line L of the chunk: [start, end) without the terminator and without a trailing '\r'
+__device__ __forceinline__ void fq_line(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nl, uint32_t line, uint32_t *s, uint32_t *e) {
+  const uint32_t st = line == 0 ? 0u : nl[line - 1] + 1u;
+  uint32_t en = nl[line];
+  if (en > st && text[en - 1] == '\r') --en;
+  *s = st;
+  *e = en;
+}
+
+// per raw record: marker check, sequence length, keep flag (non-empty sequence)
+__global__ __launch_bounds__(FQ_BLOCK) void k_fq_records(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nl, uint32_t n_raw,
+                                                           int want_qual, uint32_t *__restrict__ keep, uint32_t *__restrict__ bad) {
+  const uint32_t r = blockIdx.x * FQ_BLOCK + threadIdx.x;
+  if (r >= n_raw) return;
+  uint32_t s0, e0, s1, e1, s2, e2, s3, e3;
+  fq_line(text, nl, 4 * r, &s0, &e0);
+  fq_line(text, nl, 4 * r + 1, &s1, &e1);
+  fq_line(text, nl, 4 * r + 2, &s2, &e2);
+  fq_line(text, nl, 4 * r + 3, &s3, &e3);
+  bool ok = e0 > s0 && text[s0] == '@' && e2 > s2 && text[s2] == '+';
+  if (want_qual && (e3 - s3) != (e1 - s1)) ok = false;  // kseq: quality and sequence lengths must agree
+  if (!ok) atomicMin(bad, r);
+  keep[r] = e1 > s1 ? 1u : 0u;
+}
+__global__ __launch_bounds__(FQ_BLOCK) void k_fq_compact(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint32_t n_raw,
+                                                           uint32_t *__restrict__ recidx) {
+  const uint32_t r = blockIdx.x * FQ_BLOCK + threadIdx.x;
+  if (r < n_raw && keep[r]) recidx[pos[r]] = r;
+}
+__global__ __launch_bounds__(FQ_BLOCK) void k_fq_len(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nl,
+                                                       const uint32_t *__restrict__ recidx, uint32_t n, uint32_t *__restrict__ len) {
+  const uint32_t j = blockIdx.x * FQ_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  uint32_t s, e;
+  fq_line(text, nl, 4 * recidx[j] + 1, &s, &e);
+  len[j] = e - s;
+}
+__global__ __launch_bounds__(FQ_BLOCK) void k_fq_gather(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nl,
+                                                          const uint32_t *__restrict__ recidx, const uint32_t *__restrict__ off, uint32_t n,
+                                                          uint8_t *__restrict__ bases, uint8_t *__restrict__ quals) {
+  const uint32_t j = blockIdx.x * FQ_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  uint32_t s, e;
+  fq_line(text, nl, 4 * recidx[j] + 1, &s, &e);
+  const uint32_t o = off[j], l = e - s;
+  for (uint32_t i = 0; i < l; ++i) bases[o + i] = text[s + i];
+  if (quals) {
+    uint32_t qs, qe;
+    fq_line(text, nl, 4 * recidx[j] + 3, &qs, &qe);
+    for (uint32_t i = 0; i < l; ++i) quals[o + i] = text[qs + i];
+  }
+}
+
+struct FqMaxOp {
+  __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+};
+
+extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records) {
+  if (!c || stream < 0 || stream > 2 || (!text && n_bytes) || !n_records) return CMGPU_EINVAL;
+  if (n_bytes > 0xfffffff0ull) { cm_set_error(c, "FASTQ chunk must be smaller than 4 GiB"); return CMGPU_EINVAL; }
+  FQCHECK(c, hipSetDevice(c->device));
+  CmFqStream &f = c->fq[stream];
+  hipStream_t s = c->stream;
+  *n_records = 0;
+  f.n_bytes = n_bytes; f.n_nl = 0; f.n_raw = 0; f.n_rec = 0; f.final_chunk = final_chunk != 0;
+  if (n_bytes == 0) return CMGPU_OK;
+  const uint32_t n_thr = (uint32_t)((n_bytes + 15) / 16);
+  if (f.text.ensure(n_bytes + 32) || f.cnt.ensure(((size_t)n_thr + 1) * 4) || f.off.ensure(((size_t)n_thr + 1) * 4) ||
+      c->scan_tmp.ensure(cm_scan_tmp_words(n_thr) * 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
+  FQCHECK(c, hipMemcpyAsync(f.text.p, text, n_bytes, hipMemcpyHostToDevice, s));
+  const dim3 g((n_thr + FQ_BLOCK - 1) / FQ_BLOCK), b(FQ_BLOCK);
+  hipLaunchKernelGGL(k_fq_count, g, b, 0, s, (const uint8_t *)f.text.p, n_bytes, n_thr, (uint32_t *)f.cnt.p);
+  cm_scan_u32((const uint32_t *)f.cnt.p, (uint32_t *)f.off.p, n_thr, (uint32_t *)c->scan_tmp.p, s);
+  uint32_t n_nl = 0;
+  FQCHECK(c, hipMemcpyAsync(&n_nl, (uint32_t *)f.off.p + n_thr, 4, hipMemcpyDeviceToHost, s));
+  FQCHECK(c, hipStreamSynchronize(s));
+  if (f.nl.ensure(((size_t)n_nl + 2) * 4)) { cm_set_error(c, "out of device memory (FASTQ lines)"); return CMGPU_ENOMEM; }
+  hipLaunchKernelGGL(k_fq_fill, g, b, 0, s, (const uint8_t *)f.text.p, n_bytes, n_thr, (const uint32_t *)f.off.p, (uint32_t *)f.nl.p);
+  // a final chunk whose last line has no terminator: the end of the text closes it
+  // (also an empty, unterminated quality line of the very last record: three lines seen)
+  if (final_chunk && (text[n_bytes - 1] != '\n' || n_nl % 4 == 3)) {
+    const uint32_t endpos = (uint32_t)n_bytes;
+    FQCHECK(c, hipMemcpy((uint32_t *)f.nl.p + n_nl, &endpos, 4, hipMemcpyHostToDevice));
+    ++n_nl;
+  }
+  f.n_nl = n_nl;
+  const uint32_t n_raw = n_nl / 4;
+  f.n_raw = n_raw;
+  if (n_raw == 0) return CMGPU_OK;
+  if (f.keep.ensure(((size_t)n_raw + 1) * 4) || f.pos.ensure(((size_t)n_raw + 1) * 4) || f.recidx.ensure((size_t)n_raw * 4) || f.bad.ensure(4) ||
+      c->scan_tmp.ensure(cm_scan_tmp_words(n_raw) * 4)) { cm_set_error(c, "out of device memory (FASTQ records)"); return CMGPU_ENOMEM; }
+  const uint32_t none = 0xffffffffu;
+  FQCHECK(c, hipMemcpyAsync(f.bad.p, &none, 4, hipMemcpyHostToDevice, s));
+  const dim3 gr((n_raw + FQ_BLOCK - 1) / FQ_BLOCK);
+  hipLaunchKernelGGL(k_fq_records, gr, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, n_raw, stream == 2 ? 1 : 0,
+                     (uint32_t *)f.keep.p, (uint32_t *)f.bad.p);
+  cm_scan_u32((const uint32_t *)f.keep.p, (uint32_t *)f.pos.p, n_raw, (uint32_t *)c->scan_tmp.p, s);
+  hipLaunchKernelGGL(k_fq_compact, gr, b, 0, s, (const uint32_t *)f.keep.p, (const uint32_t *)f.pos.p, n_raw, (uint32_t *)f.recidx.p);
+  uint32_t bad = 0, n_rec = 0;
+  FQCHECK(c, hipMemcpyAsync(&bad, f.bad.p, 4, hipMemcpyDeviceToHost, s));
+  FQCHECK(c, hipMemcpyAsync(&n_rec, (uint32_t *)f.pos.p + n_raw, 4, hipMemcpyDeviceToHost, s));
+  FQCHECK(c, hipStreamSynchronize(s));
+  if (bad != none) {
+    cm_set_error(c, "not a 4-line FASTQ record (missing '@' / '+' marker or quality length) at record " + std::to_string(bad) + " of the chunk");
+    f.n_raw = 0;
+    return CMGPU_EFORMAT;
+  }
+  f.n_rec = n_rec;
+  *n_records = n_rec;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *bytes_consumed) {
+  if (!c || stream < 0 || stream > 2 || !bytes_consumed) return CMGPU_EINVAL;
+  FQCHECK(c, hipSetDevice(c->device));
+  CmFqStream &f = c->fq[stream];
+  hipStream_t s = c->stream;
+  if (n > f.n_rec) { cm_set_error(c, "more records requested than the chunk holds"); return CMGPU_EINVAL; }
+  DevBuf &bases = stream == 0 ? c->rb0 : stream == 1 ? c->rb1 : c->bcb;
+  DevBuf &offs = stream == 0 ? c->ro0 : stream == 1 ? c->ro1 : c->bco;
+  f.taken = n;
+  f.taken_bases = 0;
+  f.taken_max_len = 0;
+  // where the host resumes: the end of the last raw record used; trailing empty records and,
+  // at the end of the file, blank lines go with it
+  uint32_t last_raw = 0;
+  bool have_last = false;
+  if (n == f.n_rec) { if (f.n_raw) { last_raw = f.n_raw - 1; have_last = true; } }
+  else if (n > 0) {
+    FQCHECK(c, hipMemcpy(&last_raw, (uint32_t *)f.recidx.p + (n - 1), 4, hipMemcpyDeviceToHost));
+    have_last = true;
+  }
+  uint64_t consumed = 0;
+  if (have_last) {
+    uint32_t endnl = 0;
+    FQCHECK(c, hipMemcpy(&endnl, (uint32_t *)f.nl.p + (4 * (size_t)last_raw + 3), 4, hipMemcpyDeviceToHost));
+    consumed = (uint64_t)endnl + 1;
+    if (consumed > f.n_bytes) consumed = f.n_bytes;
+  }
+  *bytes_consumed = consumed;
+  if (offs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (read offsets)"); return CMGPU_ENOMEM; }
+  if (n == 0) { FQCHECK(c, hipMemset(offs.p, 0, 4)); return CMGPU_OK; }
+  if (f.len.ensure(((size_t)n + 1) * 4) || c->scan_tmp.ensure(cm_scan_tmp_words(n) * 4) || f.bad.ensure(4)) {
+    cm_set_error(c, "out of device memory (FASTQ lengths)"); return CMGPU_ENOMEM;
+  }
+  const dim3 g((n + FQ_BLOCK - 1) / FQ_BLOCK), b(FQ_BLOCK);
+  hipLaunchKernelGGL(k_fq_len, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p, n, (uint32_t *)f.len.p);
+  cm_scan_u32((const uint32_t *)f.len.p, (uint32_t *)offs.p, n, (uint32_t *)c->scan_tmp.p, s);
+  size_t tb = 0;
+  (void)rocprim::reduce(nullptr, tb, (const uint32_t *)f.len.p, (uint32_t *)f.bad.p, 0u, (size_t)n, FqMaxOp(), s);
+  DevBuf rtmp;
+  if (rtmp.ensure(tb + 256)) { cm_set_error(c, "out of device memory (reduce)"); return CMGPU_ENOMEM; }
+  hipError_t e = rocprim::reduce(rtmp.p, tb, (const uint32_t *)f.len.p, (uint32_t *)f.bad.p, 0u, (size_t)n, FqMaxOp(), s);
+  uint32_t total = 0, mx = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint32_t *)offs.p + n, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&mx, f.bad.p, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  rtmp.release();
+  if (e != hipSuccess) { cm_set_error(c, std::string("FASTQ take: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
+  if (bases.ensure((size_t)total + 16) || (stream == 2 && c->bcq.ensure((size_t)total + 16))) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
+  hipLaunchKernelGGL(k_fq_gather, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p,
+                     (const uint32_t *)offs.p, n, (uint8_t *)bases.p, stream == 2 ? (uint8_t *)c->bcq.p : (uint8_t *)nullptr);
+  FQCHECK(c, hipStreamSynchronize(s));
+  f.taken_bases = total;
+  f.taken_max_len = mx;
+  return CMGPU_OK;
+}
+
+// declares the records taken from the streams the resident batch (what cmgpu_upload_batch does
+// for host SoA buffers); cmgpu_map_resident maps it
+extern "C" int cmgpu_fastq_commit(cmgpu_ctx *c, uint32_t n, uint32_t first_read_id, int paired, int barcoded) {
+  if (!c) return CMGPU_EINVAL;
+  FQCHECK(c, hipSetDevice(c->device));
+  if (c->fq[0].taken != n || (paired && c->fq[1].taken != n) || (barcoded && c->fq[2].taken != n)) {
+    cm_set_error(c, "streams hold different numbers of taken records"); return CMGPU_EINVAL;
+  }
+  if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
+  if (!paired && c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
+  if (barcoded && (c->wl_size == 0 || c->wl_num_sample == 0)) { cm_set_error(c, "whitelist / barcode abundance not set"); return CMGPU_EINVAL; }
+  c->n_pairs = n;
+  c->first_read_id = first_read_id;
+  c->single = !paired;
+  c->has_barcodes = barcoded != 0;
+  c->bases0 = c->fq[0].taken_bases;
+  c->bases1 = paired ? c->fq[1].taken_bases : 0;
+  uint32_t mx = c->fq[0].taken_max_len;
+  if (paired && c->fq[1].taken_max_len > mx) mx = c->fq[1].taken_max_len;
+  c->max_read_len = mx ? mx : 1;
+  if (!paired) {
+    if (c->ro1.ensure(((size_t)n + 1) * 4) || c->rb1.ensure(16)) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
+    FQCHECK(c, hipMemset(c->ro1.p, 0, ((size_t)n + 1) * 4));
+  }
+  return CMGPU_OK;
+}

@@ -219,6 +219,32 @@ class ChromapGPU:
         k = self.L.cmgpu_last_timings(self.ctx, names, ms, 32)
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
 
+    # ---- FASTQ ingest on the device
+    def fastq_scan(self, stream, text, final=True):
+        """text: bytes of a FASTQ chunk; returns the number of complete non-empty records in it"""
+        n = C.c_uint32(0)
+        self._check(self.L.cmgpu_fastq_scan(self.ctx, stream, text, len(text), int(final), C.byref(n)), self.ctx)
+        return n.value
+
+    def fastq_take(self, stream, n):
+        used = C.c_uint64(0)
+        self._check(self.L.cmgpu_fastq_take(self.ctx, stream, n, C.byref(used)), self.ctx)
+        return used.value
+
+    def fastq_commit(self, n, first_read_id=0, paired=True, barcoded=False):
+        self._check(self.L.cmgpu_fastq_commit(self.ctx, n, first_read_id, int(paired), int(barcoded)), self.ctx)
+        self._n_resident = n
+
+    def download_batch(self, n):
+        """resident batch back on the host: (b1, o1, b2, o2)"""
+        o1 = np.zeros(n + 1, np.uint32)
+        o2 = np.zeros(n + 1, np.uint32)
+        self._check(self.L.cmgpu_download_batch(self.ctx, None, o1.ctypes.data, None, o2.ctypes.data), self.ctx)
+        b1 = np.zeros(max(1, int(o1[n])), np.uint8)
+        b2 = np.zeros(max(1, int(o2[n])), np.uint8)
+        self._check(self.L.cmgpu_download_batch(self.ctx, b1.ctypes.data, None, b2.ctypes.data, None), self.ctx)
+        return b1[:int(o1[n])], o1, b2[:int(o2[n])], o2
+
     # ---- device-side post-processing: record store -> sorted / deduplicated BED text in HBM
     def store_clear(self):
         self._check(self.L.cmgpu_store_clear(self.ctx), self.ctx)

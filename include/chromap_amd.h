@@ -31,6 +31,7 @@ extern "C" {
 #define CMGPU_ENOMEM (-4)
 #define CMGPU_ECAPACITY (-5)
 #define CMGPU_EIO (-6)
+#define CMGPU_EFORMAT (-7)
 
 /* The minimizer index exactly as Index::Load leaves it in host memory
  * (src/index.cc:132-169, kh_load src/khash.h:358-373): khash open-addressing arrays with
@@ -303,6 +304,26 @@ int cmgpu_store_format(cmgpu_ctx *ctx, int kind, const char *const *names, uint3
 int cmgpu_store_text(cmgpu_ctx *ctx, char *out, uint64_t capacity);
 int cmgpu_store_write_text(cmgpu_ctx *ctx, const char *path, int append);
 int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_bytes, uint64_t *text_lines);
+
+/* ---- FASTQ ingest on the device ---------------------------------------
+ * Replaces, for 4-line FASTQ text, kseq_read + SequenceBatch::LoadOneSequenceAndSaveAt
+ * (src/sequence_batch.cc:22-62): the host hands over raw (inflated) file bytes chunk by chunk;
+ * lines, records, the skip of empty sequences and the SoA batch are built in HBM.
+ * stream: 0 = read 1, 1 = read 2, 2 = cell barcodes (bases + qualities).
+ *   cmgpu_fastq_scan   uploads one chunk (< 4 GiB) and counts its complete, non-empty records;
+ *                      final_chunk != 0: the text ends the file (a missing last newline is fine).
+ *                      CMGPU_EFORMAT: not 4-line FASTQ (multi-line records need a host parser).
+ *   cmgpu_fastq_take   makes the first n of them this stream's part of the resident batch and
+ *                      returns how many bytes of the chunk they (and skipped records) cover --
+ *                      the host resubmits the rest in front of the next chunk.
+ *   cmgpu_fastq_commit declares the batch (n records taken from every participating stream);
+ *                      cmgpu_map_resident then maps it. */
+int cmgpu_fastq_scan(cmgpu_ctx *ctx, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records);
+int cmgpu_fastq_take(cmgpu_ctx *ctx, int stream, uint32_t n, uint64_t *bytes_consumed);
+int cmgpu_fastq_commit(cmgpu_ctx *ctx, uint32_t n, uint32_t first_read_id, int paired, int barcoded);
+/* cmgpu_compute_barcode_abundance over the barcodes last taken from stream 2; feed the barcode
+ * file in whole reference batches and stop when *done is set (20 M sampled, src/chromap.h:211). */
+int cmgpu_barcode_abundance_resident(cmgpu_ctx *ctx, uint64_t *num_sample_barcodes, int *done);
 
 /* Host post-processing that defines the final BED bytes: sort by (rid, operator<),
  * PCR-duplicate removal as in the low-memory merge, MAPQ filter, Tn5 shift, text

@@ -65,6 +65,36 @@ def test_cli_matches_reference_output(name, built, tmp_path):
             assert int(re.search(pat, log).group(1)) == want, key
 
 
+@pytest.mark.parametrize("extra", [["--ingest-chunk-mb", "1"], ["--host-ingest"]])
+def test_cli_ingest_variants(extra, built, tmp_path):
+    """growing-chunk path of the device FASTQ parser, and the kseq-style host parser"""
+    for name in ("s2_atac_q0", "b1_atac_bc"):
+        meta = ds.case_meta(name)
+        fa, reads = _reads(name)
+        out = str(tmp_path / (name + ".txt"))
+        subprocess.run([CLI] + meta["chromap_flags"] + extra + ["-x", built(name), "-r", fa] + reads + ["-o", out], check=True,
+                       stderr=subprocess.PIPE)
+        assert ds.md5(out) == meta["bed_md5"]
+
+
+def test_cli_reads_gzip(built, tmp_path):
+    import gzip
+    import shutil
+    name = "s1_atac"
+    meta = ds.case_meta(name)
+    fa, r1, r2 = ds.case_inputs(name)
+    gz = []
+    for i, f in enumerate((r1, r2)):
+        g = str(tmp_path / ("r%d.fq.gz" % i))
+        with open(f, "rb") as src, gzip.open(g, "wb", compresslevel=1) as dst:
+            shutil.copyfileobj(src, dst)
+        gz.append(g)
+    out = str(tmp_path / "o.bed")
+    subprocess.run([CLI] + meta["chromap_flags"] + ["-x", built(name), "-r", fa, "-1", gz[0], "-2", gz[1], "-o", out], check=True,
+                   stderr=subprocess.PIPE)
+    assert ds.md5(out) == meta["bed_md5"]
+
+
 @pytest.mark.skipif(not os.path.exists(REF), reason="built reference binary not present")
 def test_device_built_index_loads_in_reference(built, tmp_path):
     name = "s1_atac"

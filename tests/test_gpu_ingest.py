@@ -1,0 +1,118 @@
+"""FASTQ ingest on the device (cm_ingest.hip): chunks of raw FASTQ text are
+split into lines and records in HBM and become the resident SoA batch.  The batch must equal what
+the oracle's kseq-style reader produces from the same files, for any chunking of the text."""
+import numpy as np
+import pytest
+
+import datasets
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    from chromap_amd import ChromapGPU
+    fa, _, _ = datasets.case_inputs("toy_chip")
+    return ChromapGPU(datasets.case_index("toy_chip"), fa, preset="chip")
+
+
+def _ingest_stream(g, text, chunk, stream=0, limit=None):
+    """feeds `text` in chunks of `chunk` bytes the way the CLI does; returns (bases, offsets)"""
+    bases, lens = [], []
+    pos, carry = 0, b""
+    while True:
+        piece = text[pos:pos + chunk]
+        pos += len(piece)
+        final = pos >= len(text)
+        buf = carry + piece
+        n = g.fastq_scan(stream, buf, final)
+        if limit:
+            n = min(n, limit)
+        used = g.fastq_take(stream, n)
+        if n:
+            g.fastq_commit(n, paired=False)
+            b1, o1, _, _ = g.download_batch(n)
+            bases.append(b1.copy())
+            lens.append(np.diff(o1))
+        carry = buf[used:]
+        if final and n == 0:
+            assert carry.strip() == b""
+            break
+        if final and not carry.strip():
+            break
+    b = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
+    ln = np.concatenate(lens) if lens else np.zeros(0, np.uint32)
+    off = np.zeros(len(ln) + 1, np.uint32)
+    off[1:] = np.cumsum(ln)
+    return b, off
+
+
+@pytest.mark.parametrize("chunk,limit", [(1 << 30, None), (100003, None), (4096, None), (1 << 20, 777)])
+def test_ingest_equals_host_reader(chunk, limit):
+    g = _gpu()
+    _, r1, _ = datasets.case_inputs("s2_atac_q0")  # variable read lengths
+    text = open(r1, "rb").read()
+    want_b, want_o = ol.read_fastx(r1)
+    b, off = _ingest_stream(g, text, chunk, limit=limit)
+    assert np.array_equal(off, want_o)
+    assert np.array_equal(b, want_b)
+    g.close()
+
+
+def test_ingest_line_ending_variants(tmp_path):
+    g = _gpu()
+    recs = [(b"r%d extra comment" % i, b"ACGTN"[i % 5:i % 5 + 1] * (20 + i % 37), b"I" * (20 + i % 37)) for i in range(500)]
+    recs[7] = (b"empty", b"", b"")          # skipped like kseq length 0 (sequence_batch.cc:27-30)
+    recs[499] = (b"lastempty", b"", b"")
+    def render(nl, trailing):
+        t = b"".join(b"@" + n + nl + s + nl + b"+" + nl + q + nl for n, s, q in recs)
+        return t[:-len(nl)] + trailing
+    want = [s for _, s, _ in recs if s]
+    for nl, trailing in ((b"\n", b"\n"), (b"\r\n", b"\r\n"), (b"\n", b""), (b"\n", b"\n\n\n")):
+        b, off = _ingest_stream(g, render(nl, trailing), 1500)
+        assert len(off) - 1 == len(want)
+        assert b.tobytes() == b"".join(want)
+    g.close()
+
+
+def test_ingest_rejects_multiline_fastq():
+    from chromap_amd import ChromapError
+    g = _gpu()
+    text = b"@a\nACGT\nACGT\n+\nIIIIIIII\n@b\nAC\n+\nII\n"
+    with pytest.raises(ChromapError, match="4-line FASTQ"):
+        g.fastq_scan(0, text, True)
+    g.close()
+
+
+def test_ingest_pairs_and_barcodes_map_like_host_buffers():
+    """reads + barcodes ingested on the device give the same records as the host-buffer entry"""
+    from chromap_amd import ChromapGPU
+    case = "b1_atac_bc"
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    g = ChromapGPU(datasets.case_index(case), fa, preset=preset, **kw)
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    g.set_whitelist_file(wlf, int(bco[1] - bco[0]))
+    g.compute_barcode_abundance(bc, bco)
+    rec, k = g.map_pairs_barcoded(b1, o1, b2, o2, bc, bcq, bco)
+    want = sorted((rec[i].r.read_id, rec[i].r.rid, rec[i].r.fragment_start, rec[i].r.fragment_length, rec[i].r.mapq, rec[i].barcode)
+                  for i in range(k))
+    ns = [g.fastq_scan(s, open(f, "rb").read(), True) for s, f in ((0, r1), (1, r2), (2, bcf))]
+    assert ns == [len(o1) - 1] * 3
+    for s in range(3):
+        g.fastq_take(s, ns[0])
+    g.fastq_commit(ns[0], paired=True, barcoded=True)
+    from chromap_amd import Stats
+    k2 = g.map_resident(Stats())
+    assert k2 == k
+    g.store_clear()
+    assert g.store_append_resident() == k
+    lines, _ = g.store_format(2, barcode_length=g.barcode_length)
+    import hashlib
+    assert hashlib.md5(g.store_text()).hexdigest() == meta["bed_md5"]
+    assert len(want) == k
+    g.close()
