@@ -145,7 +145,7 @@ def declare(L):
     sig("cmgpu_fastq_scan", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
     sig("cmgpu_fastq_take", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, P(C.c_uint64)])
     sig("cmgpu_barcode_abundance_resident", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_int)])
-    sig("cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int])
+    sig("cmgpu_fastq_commit", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int])
     sig("cmgpu_write_bed_se", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
     sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])

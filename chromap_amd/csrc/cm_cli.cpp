@@ -7,10 +7,14 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <chrono>
+
 #include <string>
 #include <vector>
 
 #include "../../include/chromap_amd.h"
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void die(const std::string &m) {  // ExitWithMessage (utils.h:71-74)
   fprintf(stderr, "%s\n", m.c_str());
@@ -228,6 +232,8 @@ int main(int argc, char **argv) {
   uint64_t num_reads = 0;
   uint32_t next_read_id = 0, bc_len = 0;
 
+  double t_read = 0, t_parse = 0, t_map = 0, t_post = 0;
+  const double t_begin = now_s();
   const bool device_ingest = !a.out_pairs && !a.host_ingest;  // pairs output needs read names: host parser
   auto ck = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(ctx)); };
   if (device_ingest) {
@@ -279,8 +285,11 @@ int main(int argc, char **argv) {
       for (;;) {
         uint32_t cnt[3] = {0, 0, 0};
         bool all_final = true;
+        double t0 = now_s();
+        for (int m = 0; m < ns_streams; ++m) rd[m].fill(target);
+        t_read += now_s() - t0;
+        t0 = now_s();
         for (int m = 0; m < ns_streams; ++m) {
-          rd[m].fill(target);
           all_final = all_final && rd[m].eof;
           const int rc = cmgpu_fastq_scan(ctx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
           if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(ctx)) + " -- rerun with --host-ingest");
@@ -302,9 +311,12 @@ int main(int argc, char **argv) {
           rd[m].consume((size_t)used);
         }
         ck(cmgpu_fastq_commit(ctx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));
+        t_parse += now_s() - t0;
+        t0 = now_s();
         uint64_t k = 0;
         ck(cmgpu_map_resident(ctx, &k, &st));
         ck(cmgpu_store_append_resident(ctx, nullptr));
+        t_map += now_s() - t0;
         num_reads += paired ? 2ull * n : n;
         next_read_id += n;
         fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
@@ -411,13 +423,20 @@ int main(int argc, char **argv) {
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
     const int kind = barcoded ? CMGPU_TEXT_BED_PE_BC : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
-    if (cmgpu_store_format(ctx, kind, ref.names, ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK ||
-        cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK)
-      die(cmgpu_last_error(ctx));
+    const double t0 = now_s();
+    if (cmgpu_store_format(ctx, kind, ref.names, ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    const double t1 = now_s();
+    if (cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    t_post = now_s() - t0;
+    fprintf(stderr, "Sorted, deduplicated and formatted %llu bytes on the device in %.3fs, wrote them in %.3fs.\n", (unsigned long long)nbytes,
+            t1 - t0, now_s() - t1);
     lines = (int64_t)nl;
   }
   if (lines < 0) die("cannot write " + a.out_path);
   fprintf(stderr, "Number of output mappings (passed filters): %lld\n", (long long)lines);
+  if (device_ingest)
+    fprintf(stderr, "Mapped all reads in %.2fs (file read + inflate %.2fs, H2D + device FASTQ parse %.2fs, mapping %.2fs, post-processing + write %.2fs).\n",
+            now_s() - t_begin, t_read, t_parse, t_map, t_post);
   cmgpu_destroy(ctx);
   cmgpu_free_host_ref(&ref);
   return 0;

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""End-to-end run of the CLI on the GPU box (SURVEY.md 8(d) "Mapped all reads" analogue):
+synthetic genome + index built on the device and written to disk in the reference's formats,
+synthetic read pairs written as FASTQ, then `chromap-amd --preset atac` from files to BED.
+Prints one JSON object; everything is written under --dir (default /tmp/chromap_amd_e2e)."""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def write_fastq(path, bases, n, L):
+    name = np.char.add("@r", np.char.zfill(np.arange(n).astype(str), 9)).astype("S11")
+    rec = np.empty((n, 11 + 1 + L + 3 + L + 1), np.uint8)
+    rec[:, :11] = np.frombuffer(name.tobytes(), np.uint8).reshape(n, 11)
+    rec[:, 11] = 10
+    rec[:, 12:12 + L] = bases.reshape(n, L)
+    rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", np.uint8)
+    rec[:, 15 + L:15 + 2 * L] = ord("I")
+    rec[:, 15 + 2 * L] = 10
+    rec.tofile(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=200_000_000)
+    ap.add_argument("--nseq", type=int, default=8)
+    ap.add_argument("--pairs", type=int, default=8_000_000)
+    ap.add_argument("--readlen", type=int, default=50)
+    ap.add_argument("--dir", default="/tmp/chromap_amd_e2e")
+    args = ap.parse_args()
+    os.makedirs(args.dir, exist_ok=True)
+    from chromap_amd import ChromapGPU
+    g = ChromapGPU(synthetic=(args.genome, args.nseq, 4242), preset="atac")
+    idx = os.path.join(args.dir, "g.index")
+    fa = os.path.join(args.dir, "g.fa")
+    g.save_index(idx)
+    nseq = C.c_uint32(0)
+    g.L.cmgpu_reference_lengths(g.ctx, None, 0, C.byref(nseq))
+    lens = (C.c_uint32 * nseq.value)()
+    g.L.cmgpu_reference_lengths(g.ctx, lens, nseq.value, C.byref(nseq))
+    with open(fa, "wb") as f:
+        for i in range(nseq.value):
+            buf = C.create_string_buffer(lens[i])
+            assert g.L.cmgpu_export_reference(g.ctx, i, buf, lens[i]) == 0
+            f.write(b">chr%d\n" % (i + 1))
+            f.write(buf.raw[:lens[i]])
+            f.write(b"\n")
+    g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=99)
+    b1, o1, b2, o2 = g.download_batch(args.pairs)
+    r1 = os.path.join(args.dir, "r1.fq")
+    r2 = os.path.join(args.dir, "r2.fq")
+    write_fastq(r1, b1, args.pairs, args.readlen)
+    write_fastq(r2, b2, args.pairs, args.readlen)
+    g.close()
+    out = os.path.join(args.dir, "out.bed")
+    cli = os.path.join(ROOT, "chromap_amd", "chromap-amd")
+    res = {}
+    for label, extra in (("device_ingest", []), ("host_ingest", ["--host-ingest"])):
+        t0 = time.time()
+        p = subprocess.run([cli, "--preset", "atac", "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out] + extra,
+                           stderr=subprocess.PIPE, check=True)
+        dt = time.time() - t0
+        log = p.stderr.decode()
+        tail = [ln for ln in log.splitlines() if ln.startswith("Mapped all reads") or ln.startswith("Sorted,")]
+        res[label] = {"wall_s": round(dt, 2), "M_pairs_per_s_wall": round(args.pairs / dt / 1e6, 2), "cli": tail,
+                      "bed_md5": subprocess.check_output(["md5sum", out]).split()[0].decode(),
+                      "bed_bytes": os.path.getsize(out)}
+    res["same_output"] = res["device_ingest"]["bed_md5"] == res["host_ingest"]["bed_md5"]
+    res["config"] = {"pairs": args.pairs, "readlen": args.readlen, "genome": args.genome,
+                     "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2), "index_bytes": os.path.getsize(idx)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
