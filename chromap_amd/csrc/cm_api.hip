@@ -200,6 +200,7 @@ extern "C" int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view 
 
 extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (!c) return CMGPU_OK;
+  if (c->in_flight) { c->worker.join(); c->in_flight = false; }
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (DevBuf *b : c->all_bufs()) b->release();
@@ -444,6 +445,38 @@ extern "C" int cmgpu_map_pairs(cmgpu_ctx *c, const cmgpu_batch *in, cmgpu_record
   rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;
   if (!out) { if (n_out) *n_out = k; return CMGPU_OK; }  // records stay resident (cmgpu_store_append_resident)
+  return cmgpu_download_records(c, out, out_capacity, n_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// one batch in flight: the caller's thread parses / packs the next batch while a worker thread
+// of the library uploads and maps this one -- the role of the "load the next batch" task next to
+// the mapping taskloop (chromap.h:871-877).  The ctx stays single-caller: between submit and
+// wait no other call on this ctx is allowed; the batch's host buffers must stay valid.
+// ---------------------------------------------------------------------------------------
+extern "C" int cmgpu_map_pairs_async(cmgpu_ctx *c, const cmgpu_batch *in, cmgpu_stats *stats) {
+  if (!c || !in) return CMGPU_EINVAL;
+  if (c->in_flight) { cm_set_error(c, "a batch is already in flight (call cmgpu_wait first)"); return CMGPU_EINVAL; }
+  const cmgpu_batch batch = *in;
+  c->in_flight = true;
+  c->async_rc = 0;
+  c->async_n = 0;
+  c->worker = std::thread([c, batch, stats]() {
+    uint64_t k = 0;
+    c->async_rc = cmgpu_map_pairs(c, &batch, nullptr, 0, &k, stats);
+    c->async_n = k;
+  });
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_wait(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
+  if (!c) return CMGPU_EINVAL;
+  if (!c->in_flight) { cm_set_error(c, "no batch in flight"); return CMGPU_EINVAL; }
+  c->worker.join();
+  c->in_flight = false;
+  if (n_out) *n_out = c->async_n;
+  if (c->async_rc) return c->async_rc;
+  if (!out) return CMGPU_OK;  // records stay resident (cmgpu_store_append_resident)
   return cmgpu_download_records(c, out, out_capacity, n_out);
 }
 

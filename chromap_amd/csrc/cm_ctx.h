@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/chromap_amd.h"
@@ -63,6 +64,11 @@ struct cmgpu_ctx {
   uint64_t store_n = 0, store_cap = 0, text_bytes = 0, text_lines = 0;
   bool store_has_bc = false;
   CmFqStream fq[3];  // read 1, read 2, barcode
+  // one batch in flight (cmgpu_map_pairs_async / cmgpu_wait)
+  std::thread worker;
+  bool in_flight = false;
+  int async_rc = 0;
+  uint64_t async_n = 0;
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;

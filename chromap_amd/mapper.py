@@ -135,6 +135,18 @@ class ChromapGPU:
         return rec, int(n.value)
 
     # ---- single-end
+    def map_pairs_async(self, b1, o1, b2, o2, first_read_id=0):
+        """submits the batch and returns; call wait() for the records (one batch in flight)"""
+        self._abatch = self._batch(b1, o1, b2, o2, first_read_id)
+        self._check(self.L.cmgpu_map_pairs_async(self.ctx, C.byref(self._abatch), C.byref(self.stats)), self.ctx)
+
+    def wait(self):
+        n = self._abatch.n_pairs
+        rec = (Record * max(1, n))()
+        k = C.c_uint64(0)
+        self._check(self.L.cmgpu_wait(self.ctx, C.cast(rec, C.c_void_p), n, C.byref(k)), self.ctx)
+        return rec, int(k.value)
+
     def map_single(self, b, off, first_read_id=0):
         self._keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
         n = len(self._keep[1]) - 1

@@ -200,6 +200,14 @@ const char *cmgpu_last_error(const cmgpu_ctx *ctx);
 int cmgpu_map_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,
                     uint64_t *n_out, cmgpu_stats *stats);
 
+/* One batch in flight: cmgpu_map_pairs_async returns at once and a worker thread of the library
+ * uploads and maps the batch while the caller parses the next one (the reference overlaps its
+ * "load next batch" task with the mapping taskloop the same way, src/chromap.h:871-877).
+ * cmgpu_wait joins it; out may be NULL to leave the records resident.  Between the two calls the
+ * ctx must not be used and the batch's buffers (and *stats) must stay valid. */
+int cmgpu_map_pairs_async(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_stats *stats);
+int cmgpu_wait(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out);
+
 /* Single-end reads: replaces the taskloop body of Chromap::MapSingleEndReads
  * (src/chromap.h:385-472) for bulk data; records are MappingWithoutBarcode's constructor
  * arguments (src/bed_mapping.h:67-83) stored in the cmgpu_record layout: alignment-length

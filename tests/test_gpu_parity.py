@@ -186,3 +186,24 @@ def test_barcode_correction_dense_whitelist_gpu(bc_err, tmp_path):
     assert (s["num_barcode_in_whitelist"], s["num_corrected_barcode"]) == (n_in, n_corr)
     assert got == want
     g.close()
+
+
+def test_async_submit_wait_equals_sync():
+    """one batch in flight on a worker thread of the library; the caller packs the next meanwhile"""
+    from chromap_amd import ChromapGPU
+    case = "s1_atac"
+    fa, r1, r2 = datasets.case_inputs(case)
+    g = ChromapGPU(datasets.case_index(case), fa, preset="atac")
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    rec, k = g.map_pairs(b1, o1, b2, o2)
+    want = sorted(_rec_tuple(rec[i]) for i in range(k))
+    for _ in range(2):
+        g.map_pairs_async(b1, o1, b2, o2)
+        busy = sum(int(x) for x in o1[:1000])  # the caller is free to work here
+        rec2, k2 = g.wait()
+        assert k2 == k and busy >= 0
+        assert sorted(_rec_tuple(rec2[i]) for i in range(k2)) == want
+    with pytest.raises(Exception):
+        g.wait()  # nothing in flight
+    g.close()
