@@ -631,6 +631,12 @@ struct ora_ctx {
   const uint32_t *bco;
   uint64_t *bc_key;
   uint64_t n_in_wl, n_corr;
+  /* --SAM run (set by ora_map_*_sam for the duration of the call) */
+  ora_sam_record *sam_rec;
+  uint32_t *sam_cigar;
+  char *sam_md;
+  uint32_t sam_md_cap, sam_first_read_id;
+  uint32_t *sam_len;
 };
 
 void ora_default_params(ora_params *p) { /* mapping_parameters.h:19-61 */
@@ -1424,6 +1430,127 @@ static span_t ref_start_end(const ora_ctx *c, const draft_t *d, int strand, cons
   return s;
 }
 
+/* ksw_semi_global3 (ksw.cc:505-626) with chromap's defaults (match 1, mismatch 4, gap open 6 /
+ * extend 1 for both kinds, ambiguous base 0; mapping_parameters.h:20-23, mapping_generator.h:660-671):
+ * affine-gap DP with the read as rows (target) and the reference window as columns (query).  Row
+ * i only visits columns [i, min(i+w+1, qlen)); the first row may start free in columns 0..w; the
+ * alignment ends in the best of the last w columns of the last row.  One byte per cell keeps the
+ * three move bits (h: bits 0-1, e-extension: bit 2, f-extension: bit 5). */
+int ora_ksw_semi_global3(int qlen, const char *query, int tlen, const char *target, int w, uint32_t *cigar, int cigar_cap,
+                         int *n_cigar_out, int *start, int *end) {
+  const int NEG = -0x40000000, o_del = 6, e_del = 1, o_ins = 6, e_ins = 1, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+  const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+  uint8_t *z = (uint8_t *)malloc((size_t)n_col * (size_t)(tlen > 0 ? tlen : 1));
+  int *H = (int *)malloc(((size_t)qlen + 2) * sizeof(int)), *E = (int *)malloc(((size_t)qlen + 2) * sizeof(int));
+  H[0] = 0; E[0] = NEG;
+  int j;
+  for (j = 1; j <= qlen && j <= w; ++j) { H[j] = 0; E[j] = NEG; }
+  for (; j <= qlen; ++j) H[j] = E[j] = NEG;
+  for (int i = 0; i < tlen; ++i) {
+    int f = NEG;
+    const uint8_t tc = c2u(target[i]);
+    const int beg = i, en = i + w + 1 < qlen ? i + w + 1 : qlen;
+    int h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : NEG;
+    uint8_t *zi = z + (size_t)i * n_col;
+    for (j = beg; j < en; ++j) {
+      const uint8_t qc = c2u(query[j]);
+      const int sc = (tc > 3 || qc > 3) ? 0 : (tc == qc ? 1 : -4);
+      int m = H[j], e = E[j];
+      H[j] = h1;
+      m += sc;
+      uint8_t d = m >= e ? 0 : 1;
+      int h = m >= e ? m : e;
+      d = h >= f ? d : 2;
+      h = h >= f ? h : f;
+      h1 = h;
+      int t = m - oe_del;
+      e -= e_del;
+      d |= e > t ? 1 << 2 : 0;
+      e = e > t ? e : t;
+      E[j] = e;
+      t = m - oe_ins;
+      f -= e_ins;
+      d |= f > t ? 2 << 4 : 0;
+      f = f > t ? f : t;
+      zi[j - beg] = d;
+    }
+    H[en] = h1; E[en] = NEG;
+  }
+  int score = H[qlen], maxpos = qlen;
+  for (j = 1; j < w; ++j)
+    if (H[qlen - j] > score) { score = H[qlen - j]; maxpos = qlen - j; }
+  *end = maxpos;
+  int n = 0, i = tlen - 1, k = maxpos - 1, which = 0, overflow = 0;
+#define PUSHC(op, len) do { if (n == 0 || (int)(cigar[n - 1] & 0xf) != (op)) { if (n < cigar_cap) cigar[n++] = (uint32_t)(len) << 4 | (uint32_t)(op); else overflow = 1; } \
+                            else cigar[n - 1] += (uint32_t)(len) << 4; } while (0)
+  while (i >= 0 && k >= 0) {
+    which = z[(size_t)i * n_col + (k - i)] >> (which << 1) & 3;
+    if (which == 0) { PUSHC(0, 1); --i; --k; }
+    else if (which == 1) { PUSHC(1, 1); --i; }
+    else { PUSHC(2, 1); --k; }
+  }
+  if (i >= 0) PUSHC(1, i + 1);
+#undef PUSHC
+  *start = k + 1;
+  for (i = 0; i < n >> 1; ++i) { const uint32_t t = cigar[i]; cigar[i] = cigar[n - 1 - i]; cigar[n - 1 - i] = t; }
+  *n_cigar_out = n;
+  free(z); free(H); free(E);
+  return overflow ? -1 : score;
+}
+
+static int put_dec(char *dst, int cap, int at, int v) {
+  char tmp[16];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) { if (at < cap) dst[at] = tmp[n - 1]; ++at; --n; }
+  return at;
+}
+
+/* GenerateNMAndMDTag (alignment.cc:85-139): `ref` points at the mapping start */
+static int nm_and_md(const char *ref, const char *read, const uint32_t *cigar, int n_cigar, char *md, int md_cap, int *md_len) {
+  int nm = 0, matches = 0, rp = 0, fp = 0, at = 0;
+  for (int ci = 0; ci < n_cigar; ++ci) {
+    const int op = (int)(cigar[ci] & 0xf), len = (int)(cigar[ci] >> 4);
+    if (op == 0) {
+      for (int t = 0; t < len; ++t) {
+        if (ref[fp] == read[rp] || ref[fp] - 'a' + 'A' == read[rp]) ++matches;
+        else { ++nm; at = put_dec(md, md_cap, at, matches); matches = 0; if (at < md_cap) md[at] = ref[fp]; ++at; }
+        ++fp; ++rp;
+      }
+    } else if (op == 1) { nm += len; rp += len; }
+    else if (op == 2) {
+      nm += len;
+      at = put_dec(md, md_cap, at, matches); matches = 0;
+      if (at < md_cap) md[at] = '^';
+      ++at;
+      for (int t = 0; t < len; ++t) { if (at < md_cap) md[at] = ref[fp]; ++at; ++fp; }
+    }
+  }
+  at = put_dec(md, md_cap, at, matches);
+  *md_len = at;
+  return nm;
+}
+
+/* GetRefStartEndPositionForReadFromMapping, SAM branches without split alignment
+ * (mapping_generator.h:657-717, 723-761, 807-854): for both strands the read (as mapped) is
+ * aligned against the window [vw, vw + L + 2e). */
+static span_t ref_start_end_sam(const ora_ctx *c, const draft_t *d, const char *read_seq, int L, uint32_t *cigar, int *n_cigar,
+                                char *md, int md_cap, int *md_len, int *nm) {
+  const int e = c->p.error_threshold;
+  const uint32_t rid = (uint32_t)(d->position >> 32), ref_pos = (uint32_t)d->position;
+  const uint32_t rl = c->ref->len[rid];
+  uint32_t vw = ref_pos + 1 > (uint32_t)(L + e) ? ref_pos + 1 - (uint32_t)L - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)L;
+  int st = 0, en = 0;
+  ora_ksw_semi_global3(L + 2 * e, c->ref->seq[rid] + vw, L, read_seq, 2 * e + 1, cigar, ORA_SAM_CIGAR_CAP, n_cigar, &st, &en);
+  *nm = nm_and_md(c->ref->seq[rid] + vw + st, read_seq, cigar, *n_cigar, md, md_cap, md_len);
+  span_t s;
+  s.rid = rid;
+  s.ref_start = vw + (uint32_t)st;
+  s.ref_end = vw + (uint32_t)en - 1;
+  return s;
+}
+
 /* GetMAPQForSingleEndRead, non-split (mapping_generator.h:920-1022). */
 static uint8_t mapq_single(const ora_ctx *c, int num_errors, uint16_t alignment_length, int read_length,
                            int max_diff, const meta_t *m) {
@@ -2073,8 +2200,19 @@ static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t 
         const draft_t *d1 = &a->a[best->a[mi].a], *d2 = &b->a[best->a[mi].b];
         if (d1->num_errors + d2->num_errors > pe->min_sum) continue;
         if (best_mapping_index == wk->best_idx[reported]) {
-          span_t s1 = ref_start_end(c, d1, dir == 0 ? 0 : 1, dir == 0 ? r1 : neg1, (int)len1);
-          span_t s2 = ref_start_end(c, d2, dir == 0 ? 1 : 0, dir == 0 ? neg2 : r2, (int)len2);
+          span_t s1, s2;
+          const int sam = p->output_format == 1 && c->sam_rec != NULL;
+          const size_t slot = 2 * (size_t)(read_id - c->sam_first_read_id);
+          int ncig1 = 0, ncig2 = 0, mdl1 = 0, mdl2 = 0, nm1 = 0, nm2 = 0;
+          if (sam) {
+            s1 = ref_start_end_sam(c, d1, dir == 0 ? r1 : neg1, (int)len1, c->sam_cigar + slot * ORA_SAM_CIGAR_CAP, &ncig1,
+                                   c->sam_md + slot * c->sam_md_cap, (int)c->sam_md_cap, &mdl1, &nm1);
+            s2 = ref_start_end_sam(c, d2, dir == 0 ? neg2 : r2, (int)len2, c->sam_cigar + (slot + 1) * ORA_SAM_CIGAR_CAP, &ncig2,
+                                   c->sam_md + (slot + 1) * c->sam_md_cap, (int)c->sam_md_cap, &mdl2, &nm2);
+          } else {
+            s1 = ref_start_end(c, d1, dir == 0 ? 0 : 1, dir == 0 ? r1 : neg1, (int)len1);
+            s2 = ref_start_end(c, d2, dir == 0 ? 1 : 0, dir == 0 ? neg2 : r2, (int)len2);
+          }
           const uint16_t al1 = (uint16_t)(s1.ref_end - s1.ref_start + 1); /* GetFragmentLength, mapping_in_memory.h:55-57 */
           const uint16_t al2 = (uint16_t)(s2.ref_end - s2.ref_start + 1);
           const uint8_t mapq = mapq_paired(c, d1->num_errors, d2->num_errors, al1, al2, (int)len1, (int)len2,
@@ -2094,6 +2232,24 @@ static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t 
           r->num_dups = 1;
           r->pos_aln_len = (uint16_t)(ps->ref_end - ps->ref_start + 1);
           r->neg_aln_len = (uint16_t)(ns->ref_end - ns->ref_start + 1);
+          if (sam) { /* EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108), flags :613-631 */
+            const int tlen = (int)(ns->ref_end - ps->ref_start + 1); /* PairedEndMappingInMemory::GetFragmentLength, int */
+            for (int w = 0; w < 2; ++w) {
+              ora_sam_record *q = &c->sam_rec[slot + (size_t)w];
+              const span_t *me = w == 0 ? &s1 : &s2, *mate = w == 0 ? &s2 : &s1;
+              const int plus = (w == 0) == (dir == 0); /* read 1 is + in direction 0 */
+              memset(q, 0, sizeof(*q));
+              q->read_id = read_id; q->rid = me->rid; q->pos = me->ref_start; q->mpos = mate->ref_start; q->mrid = (int32_t)mate->rid;
+              q->tlen = plus ? tlen : -tlen;
+              uint16_t flag = 3;
+              if (!plus) flag |= 16; else flag |= 32; /* in a proper F/R pair the mate is on the other strand */
+              flag |= w == 0 ? 64 : 128;
+              q->flag = flag;
+              q->mapq = mapq; q->strand = (uint8_t)plus; q->is_unique = is_unique; q->valid = 1;
+              q->n_cigar = (uint16_t)(w == 0 ? ncig1 : ncig2); q->md_len = (uint16_t)(w == 0 ? mdl1 : mdl2); q->nm = (uint32_t)(w == 0 ? nm1 : nm2);
+              c->sam_len[slot + (size_t)w] = w == 0 ? len1 : len2;
+            }
+          }
           ++reported;
           if (reported == (K < pe->n_best ? K : pe->n_best)) break;
         }
@@ -2439,13 +2595,27 @@ static long map_one_read(const ora_ctx *c, work_t *wk, uint32_t read_index, uint
     for (size_t mi = 0; mi < v->n; ++mi) {
       if (v->a[mi].num_errors > m->min_err) continue;
       if (idx == choice) {
-        const span_t sp = ref_start_end(c, &v->a[mi], strand, strand == 0 ? wk->fw1 : wk->neg1, (int)len1);
+        const int sam = p->output_format == 1 && c->sam_rec != NULL;
+        const size_t slot = (size_t)(read_id - c->sam_first_read_id);
+        int ncig = 0, mdl = 0, nm = 0;
+        const span_t sp = sam ? ref_start_end_sam(c, &v->a[mi], strand == 0 ? wk->fw1 : wk->neg1, (int)len1,
+                                                  c->sam_cigar + slot * ORA_SAM_CIGAR_CAP, &ncig, c->sam_md + slot * c->sam_md_cap,
+                                                  (int)c->sam_md_cap, &mdl, &nm)
+                                : ref_start_end(c, &v->a[mi], strand, strand == 0 ? wk->fw1 : wk->neg1, (int)len1);
         const uint16_t al = (uint16_t)(sp.ref_end - sp.ref_start + 1);
         const uint8_t mapq = mapq_single(c, v->a[mi].num_errors, al, (int)len1, p->error_threshold, m);
         ora_record *r = &out[nout++];
         memset(r, 0, sizeof(*r));
         r->read_id = read_id; r->rid = sp.rid; r->fragment_start = sp.ref_start; r->fragment_length = al;
         r->mapq = mapq & 63; r->direction = strand == 0 ? 1 : 0; r->is_unique = m->n_best == 1; r->num_dups = 1;
+        if (sam) { /* EmplaceBackSingleEndMappingRecord<SAMMapping> (mapping_generator.cc:43-57), flag :321-326 */
+          ora_sam_record *q = &c->sam_rec[slot];
+          memset(q, 0, sizeof(*q));
+          q->read_id = read_id; q->rid = sp.rid; q->pos = sp.ref_start; q->mpos = 0; q->mrid = -1; q->tlen = 0;
+          q->flag = strand == 0 ? 0 : 16; q->mapq = mapq; q->strand = strand == 0 ? 1 : 0; q->is_unique = m->n_best == 1; q->valid = 1;
+          q->n_cigar = (uint16_t)ncig; q->md_len = (uint16_t)mdl; q->nm = (uint32_t)nm;
+          c->sam_len[slot] = len1;
+        }
         break;
       }
       ++idx;
@@ -2526,6 +2696,116 @@ long ora_write_bed_se(const ora_ref *ref, const ora_params *p, ora_record *rec, 
     }
     i = j;
   }
+  fclose(f);
+  return lines;
+}
+
+/* ------------------------------------------------------------------------- */
+/* --SAM                                                                        */
+/* ------------------------------------------------------------------------- */
+long ora_map_pairs_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1, const uint32_t *r1_off,
+                       const char *r2, const uint32_t *r2_off, ora_sam_record *out, uint32_t *cigar_pool, char *md_pool,
+                       uint32_t md_cap, ora_stats *stats) {
+  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  uint32_t *lens = (uint32_t *)calloc(2 * (size_t)n + 1, 4);
+  memset(out, 0, 2 * (size_t)n * sizeof(ora_sam_record));
+  c->sam_rec = out; c->sam_cigar = cigar_pool; c->sam_md = md_pool; c->sam_md_cap = md_cap; c->sam_first_read_id = first_read_id;
+  c->sam_len = lens;
+  const int fmt = c->p.output_format;
+  c->p.output_format = 1;
+  ora_map_pairs_mt(c, threads, n, first_read_id, r1, r1_off, r2, r2_off, tmp, stats);
+  c->p.output_format = fmt;
+  long k = 0;
+  for (size_t i = 0; i < 2 * (size_t)n; ++i) { k += out[i].valid; out[i].reserved = (uint16_t)lens[i]; }
+  c->sam_rec = NULL; c->sam_cigar = NULL; c->sam_md = NULL; c->sam_len = NULL;
+  free(tmp); free(lens);
+  return k;
+}
+
+long ora_map_single_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
+                        ora_sam_record *out, uint32_t *cigar_pool, char *md_pool, uint32_t md_cap, ora_stats *stats) {
+  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  uint32_t *lens = (uint32_t *)calloc((size_t)n + 1, 4);
+  memset(out, 0, (size_t)n * sizeof(ora_sam_record));
+  c->sam_rec = out; c->sam_cigar = cigar_pool; c->sam_md = md_pool; c->sam_md_cap = md_cap; c->sam_first_read_id = first_read_id;
+  c->sam_len = lens;
+  const int fmt = c->p.output_format;
+  c->p.output_format = 1;
+  ora_map_single(c, threads, n, first_read_id, r, r_off, tmp, stats);
+  c->p.output_format = fmt;
+  long k = 0;
+  for (size_t i = 0; i < (size_t)n; ++i) { k += out[i].valid; out[i].reserved = (uint16_t)lens[i]; }
+  c->sam_rec = NULL; c->sam_cigar = NULL; c->sam_md = NULL; c->sam_len = NULL;
+  free(tmp); free(lens);
+  return k;
+}
+
+typedef struct { const ora_sam_record *r; long slot; } sam_ref_t;
+/* SAMMapping::operator< under the per-chromosome vectors (sam_mapping.h:193-199), barcode 0 */
+static int cmp_sam(const void *a, const void *b) {
+  const ora_sam_record *x = ((const sam_ref_t *)a)->r, *y = ((const sam_ref_t *)b)->r;
+#define CMPV(u, v) if ((u) != (v)) return (u) < (v) ? -1 : 1
+  CMPV(x->rid, y->rid); CMPV(x->pos, y->pos); CMPV(x->mrid, y->mrid); CMPV(x->mpos, y->mpos);
+  CMPV(x->flag & 64, y->flag & 64); CMPV(x->mapq, y->mapq); CMPV(x->read_id, y->read_id);
+#undef CMPV
+  return 0;
+}
+static int sam_same(const ora_sam_record *x, const ora_sam_record *y) { /* operator== (sam_mapping.h:200-205) */
+  return x->pos == y->pos && x->rid == y->rid && (x->flag & 64) == (y->flag & 64) && x->mrid == y->mrid && x->mpos == y->mpos;
+}
+
+long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
+                   const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
+                   const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
+                   const char *q2, const uint32_t *o2, const uint32_t *len_after_trim, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  for (uint32_t i = 0; i < ref->n_seq; ++i) fprintf(f, "@SQ\tSN:%s\tLN:%u\n", ref->name[i], ref->len[i]); /* mapping_writer.cc:312-321 */
+  sam_ref_t *v = (sam_ref_t *)malloc(((size_t)n_slots + 1) * sizeof(sam_ref_t));
+  long n = 0;
+  for (long i = 0; i < n_slots; ++i) if (rec[i].valid) { v[n].r = &rec[i]; v[n].slot = i; ++n; }
+  qsort(v, (size_t)n, sizeof(sam_ref_t), cmp_sam);
+  const int inmem = !p->low_mem;
+  long lines = 0, i = 0;
+  char *seq = NULL, *qual = NULL;
+  size_t cap = 0;
+  while (i < n) {
+    sam_ref_t last = v[i];
+    long j = i + 1;
+    if (p->remove_pcr_duplicates) {
+      while (j < n && sam_same(v[j].r, v[i].r)) {
+        if (inmem || v[j].r->mapq > last.r->mapq) last = v[j];
+        ++j;
+      }
+    }
+    const ora_sam_record *r = last.r;
+    if (r->mapq >= p->mapq_threshold) {
+      const long slot = last.slot;
+      const long item = paired ? slot / 2 : slot;
+      const int mate2 = paired && (slot & 1);
+      const char *name = mate2 ? names2[item] : names1[item];
+      const char *bs = (mate2 ? b2 : b1) + (mate2 ? o2 : o1)[item];
+      const char *qs = (mate2 ? q2 : q1) + (mate2 ? o2 : o1)[item];
+      uint32_t L = len_after_trim ? len_after_trim[slot] : r->reserved;
+      if (L + 1 > cap) { cap = L + 64; seq = (char *)realloc(seq, cap); qual = (char *)realloc(qual, cap); }
+      if (r->strand) { memcpy(seq, bs, L); memcpy(qual, qs, L); }
+      else for (uint32_t t = 0; t < L; ++t) { seq[t] = u2c((uint8_t)(3 ^ c2u(bs[L - 1 - t]))); qual[t] = qs[L - 1 - t]; }
+      /* sequence length deduced from the CIGAR (sam_mapping.h:180-188) */
+      const uint32_t *cg = cigar_pool + (size_t)slot * ORA_SAM_CIGAR_CAP;
+      uint32_t ql = 0;
+      for (int ci = 0; ci < r->n_cigar; ++ci) { const uint32_t op = cg[ci] & 0xf; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += cg[ci] >> 4; }
+      if (ql != L && ql < L) L = ql;
+      seq[L] = 0; qual[L] = 0;
+      fprintf(f, "%s\t%u\t%s\t%u\t%u\t", name, (unsigned)r->flag, ref->name[r->rid], r->pos + 1, (unsigned)r->mapq);
+      if (r->n_cigar == 0) fputc('*', f);
+      for (int ci = 0; ci < r->n_cigar; ++ci) fprintf(f, "%u%c", cg[ci] >> 4, "MIDNSHP=XB"[cg[ci] & 0xf]);
+      fprintf(f, "\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\tMD:Z:%.*s\n", r->mrid < 0 ? "*" : ((uint32_t)r->mrid == r->rid ? "=" : ref->name[r->mrid]),
+              r->mrid < 0 ? 0u : r->mpos + 1, r->tlen, seq, qual, r->nm, (int)r->md_len, md_pool + (size_t)slot * md_cap);
+      ++lines;
+    }
+    i = j;
+  }
+  free(seq); free(qual); free(v);
   fclose(f);
   return lines;
 }

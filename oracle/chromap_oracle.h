@@ -59,6 +59,7 @@ typedef struct ora_params {
   int low_mem;
   int bc_error_threshold;               /* --bc-error-threshold, 1 */
   int output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
+  int output_format;                    /* 0: BED / pairs records, 1: --SAM (ksw alignment, CIGAR, NM, MD) */
   double bc_probability_threshold;      /* --bc-probability-threshold, 0.9 */
 } ora_params;
 
@@ -122,6 +123,45 @@ int ora_correct_barcode(const ora_params *p, const ora_whitelist *w, char *bc, c
                         uint64_t *num_in_whitelist, uint64_t *num_corrected);
 
 typedef struct ora_ctx ora_ctx;
+
+/* --SAM: what SAMMapping's constructor receives (sam_mapping.h:151-190; mapping_generator.cc:43-57,
+ * 84-108) without the strings the host already holds (name, sequence, quality).  One slot per
+ * read: slot 2*i / 2*i+1 for pair i (read 1 / read 2), slot i for single-end read i; valid = 0
+ * when the read produced no record.  cigar and MD live in fixed-size slots of the pools passed to
+ * ora_map_*_sam: cigar_pool[slot * ORA_SAM_CIGAR_CAP ...], md_pool[slot * md_cap ...]. */
+#define ORA_SAM_CIGAR_CAP 64
+typedef struct ora_sam_record {
+  uint32_t read_id;
+  uint32_t rid;
+  uint32_t pos;      /* 0-based ref_start_position */
+  uint32_t mpos;
+  int32_t mrid;      /* -1: no mate */
+  int32_t tlen;
+  uint32_t nm;
+  uint16_t flag;
+  uint16_t n_cigar;
+  uint16_t md_len;
+  uint8_t mapq;
+  uint8_t strand;    /* 1 = + (SAMMapping::is_rev_ holds exactly this) */
+  uint8_t is_unique;
+  uint8_t valid;
+  uint16_t reserved;
+} ora_sam_record;
+
+long ora_map_pairs_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1, const uint32_t *r1_off,
+                       const char *r2, const uint32_t *r2_off, ora_sam_record *out /* 2n */, uint32_t *cigar_pool,
+                       char *md_pool, uint32_t md_cap, ora_stats *stats);
+long ora_map_single_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
+                        ora_sam_record *out /* n */, uint32_t *cigar_pool, char *md_pool, uint32_t md_cap, ora_stats *stats);
+/* SAM text (mapping_writer.cc:312-356): @SQ header, records sorted by SAMMapping::operator<
+ * (sam_mapping.h:193-199), duplicate removal on operator== when remove_pcr_duplicates, MAPQ filter.
+ * names/bases/quals: the batch (mate 2 arrays NULL for single-end); n_slots = 2n or n. */
+long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
+                   const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
+                   const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
+                   const char *q2, const uint32_t *o2, const uint32_t *len_after_trim /* per slot */, const char *out_path);
+int ora_ksw_semi_global3(int qlen, const char *query, int tlen, const char *target, int w, uint32_t *cigar, int cigar_cap,
+                         int *n_cigar, int *start, int *end);
 
 void ora_default_params(ora_params *p);
 void ora_preset(ora_params *p, const char *preset); /* chromap_driver.cc:247-275 */

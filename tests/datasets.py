@@ -67,9 +67,13 @@ def has_barcodes(name):
 
 
 def case_golden_bed(name):
-    ext = ".pairs.gz" if is_hic(name) else ".bed.gz"
+    ext = ".sam.gz" if is_sam(name) else ".pairs.gz" if is_hic(name) else ".bed.gz"
     with gzip.open(os.path.join(GOLD, name + ext), "rb") as f:
         return f.read()
+
+
+def is_sam(name):
+    return "--SAM" in case_meta(name)["chromap_flags"]
 
 
 def is_hic(name):
@@ -88,6 +92,9 @@ def flags_to_params(flags):
         elif flags[i] == "--bc-error-threshold":
             kw["bc_error_threshold"] = int(flags[i + 1])
             i += 2
+        elif flags[i] == "--SAM":
+            kw["output_format"] = 1
+            i += 1
         elif flags[i] == "-l":
             kw["max_insert_size"] = int(flags[i + 1])
             i += 2
@@ -104,8 +111,9 @@ def flags_to_params(flags):
 
 
 ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
-BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c) and not single_end_mate(c)]
-SE_CASES = [c for c in ALL_CASES if single_end_mate(c)]
+SAM_CASES = [c for c in ALL_CASES if is_sam(c)]
+BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c) and not single_end_mate(c) and not is_sam(c)]
+SE_CASES = [c for c in ALL_CASES if single_end_mate(c) and not is_sam(c)]
 BC_CASES = [c for c in ALL_CASES if has_barcodes(c)]
 HIC_CASES = [c for c in ALL_CASES if is_hic(c)]
 

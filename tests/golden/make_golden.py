@@ -24,7 +24,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "chromap")
 GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 
 # single-end cases: which mate file is mapped alone
-SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1}
+SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -60,6 +60,15 @@ CASES = {
                      "--barcodes", "500", "--seed", "31"], ["-l", "2000", "--remove-pcr-duplicates", "--Tn5-shift", "--trim-adapters"]),
     "s1_inmem_nodedup": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
                          ["-l", "2000", "--Tn5-shift"]),
+    # --SAM: ksw alignment, CIGAR / NM / MD, SAMMapping sort + dedup
+    "s1_chip_sam": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                    ["--preset", "chip", "--SAM"]),
+    "s3_sam_q0": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",
+                   "--indel", "0.003", "--sub", "0.02"], ["-l", "2000", "--SAM", "-q", "0"]),
+    "s2_atac_sam": (["--genome", "2000000", "--chroms", "3", "--pairs", "20000", "--readlen", "60", "--frag-min", "35",
+                     "--varlen", "--seed", "7"], ["--preset", "atac", "--SAM"]),
+    "s1_se_sam": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                  ["--SAM", "--remove-pcr-duplicates"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
@@ -110,7 +119,7 @@ def main():
                     "input_md5": dict({"fa": md5(fa), "r1": md5(r1), "r2": md5(r2)},
                                       **({"bc": md5(extra[1]), "whitelist": md5(extra[3])} if extra else {})),
                     "index_md5_reference_build": md5(idx), "bed_md5": md5(out), "reference_stderr_counters": stats}
-            ext = ".pairs.gz" if "hic" in flags else ".bed.gz"
+            ext = ".sam.gz" if "--SAM" in flags else ".pairs.gz" if "hic" in flags else ".bed.gz"
             with open(out, "rb") as f, gzip.GzipFile(os.path.join(HERE, name + ext), "wb", mtime=0) as g:
                 shutil.copyfileobj(f, g)
             with open(os.path.join(HERE, name + ".json"), "w") as f:

@@ -24,7 +24,7 @@ class OraParams(C.Structure):
         "error_threshold", "min_num_seeds", "max_seed_freq0", "max_seed_freq1", "max_insert_size",
         "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
         "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_mem", "bc_error_threshold",
-        "output_mappings_not_in_whitelist")] + [("bc_probability_threshold", C.c_double)]
+        "output_mappings_not_in_whitelist", "output_format")] + [("bc_probability_threshold", C.c_double)]
 
 
 class OraRecord(C.Structure):
@@ -327,3 +327,83 @@ def write_bed_se(oracle, rec, k, path):
     L.ora_write_bed_se.restype = C.c_long
     L.ora_write_bed_se.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_char_p]
     return L.ora_write_bed_se(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, path.encode())
+
+
+# ---- --SAM ---------------------------------------------------------------------------------
+SAM_CIGAR_CAP = 64
+
+
+class OraSamRecord(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("rid", C.c_uint32), ("pos", C.c_uint32), ("mpos", C.c_uint32),
+                ("mrid", C.c_int32), ("tlen", C.c_int32), ("nm", C.c_uint32), ("flag", C.c_uint16),
+                ("n_cigar", C.c_uint16), ("md_len", C.c_uint16), ("mapq", C.c_uint8), ("strand", C.c_uint8),
+                ("is_unique", C.c_uint8), ("valid", C.c_uint8), ("reserved", C.c_uint16)]
+
+
+class SamResult:
+    """records + cigar / MD pools of one batch (slot layout of ora_sam_record)"""
+    def __init__(self, n_slots, md_cap):
+        import numpy as np
+        self.rec = (OraSamRecord * max(1, n_slots))()
+        self.cigar = np.zeros(max(1, n_slots) * SAM_CIGAR_CAP, np.uint32)
+        self.md = np.zeros(max(1, n_slots) * md_cap, np.uint8)
+        self.md_cap = md_cap
+        self.n_slots = n_slots
+
+    def tuples(self):
+        out = []
+        for i in range(self.n_slots):
+            r = self.rec[i]
+            if not r.valid:
+                continue
+            cg = tuple(int(x) for x in self.cigar[i * SAM_CIGAR_CAP:i * SAM_CIGAR_CAP + r.n_cigar])
+            md = self.md[i * self.md_cap:i * self.md_cap + r.md_len].tobytes()
+            out.append((i, r.read_id, r.rid, r.pos, r.mpos, r.mrid, r.tlen, r.nm, r.flag, r.mapq, r.strand, r.is_unique, cg, md,
+                        r.reserved))
+        return out
+
+
+def map_pairs_sam(oracle, b1, o1, b2, o2, threads=1):
+    import numpy as np
+    L = oracle.L
+    n = len(o1) - 1
+    md_cap = 2 * int(max(np.diff(o1).max(initial=1), np.diff(o2).max(initial=1))) + 16
+    res = SamResult(2 * n, md_cap)
+    st = OraStats()
+    L.ora_map_pairs_sam.restype = C.c_long
+    L.ora_map_pairs_sam.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint32, C.POINTER(OraStats)]
+    arrs = [np.ascontiguousarray(x) for x in (b1, o1, b2, o2)]
+    k = L.ora_map_pairs_sam(oracle.ctx, threads, n, 0, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                            arrs[3].ctypes.data, C.cast(res.rec, C.c_void_p), res.cigar.ctypes.data, res.md.ctypes.data, md_cap,
+                            C.byref(st))
+    return res, k, st
+
+
+def map_single_sam(oracle, b, off, threads=1):
+    import numpy as np
+    L = oracle.L
+    n = len(off) - 1
+    md_cap = 2 * int(np.diff(off).max(initial=1)) + 16
+    res = SamResult(n, md_cap)
+    st = OraStats()
+    L.ora_map_single_sam.restype = C.c_long
+    L.ora_map_single_sam.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint32, C.POINTER(OraStats)]
+    arrs = [np.ascontiguousarray(x) for x in (b, off)]
+    k = L.ora_map_single_sam(oracle.ctx, threads, n, 0, arrs[0].ctypes.data, arrs[1].ctypes.data, C.cast(res.rec, C.c_void_p),
+                             res.cigar.ctypes.data, res.md.ctypes.data, md_cap, C.byref(st))
+    return res, k, st
+
+
+def write_sam(oracle, res, paired, names1, names2, b1, q1, o1, b2, q2, o2, path):
+    import numpy as np
+    L = oracle.L
+    L.ora_write_sam.restype = C.c_long
+    L.ora_write_sam.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)] + [C.c_void_p] * 7 + [C.c_char_p]
+    n1 = (C.c_char_p * len(names1))(*names1)
+    n2 = (C.c_char_p * max(1, len(names2 or [])))(*(names2 or [b""]))
+    keep = [np.ascontiguousarray(x) if x is not None else None for x in (b1, q1, o1, b2, q2, o2)]
+    ptr = [k.ctypes.data if k is not None else None for k in keep]
+    return L.ora_write_sam(C.byref(oracle.ref), C.byref(oracle.p), C.cast(res.rec, C.c_void_p), res.n_slots, int(paired),
+                           res.cigar.ctypes.data, res.md.ctypes.data, res.md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+                           ptr[5], None, path.encode())

@@ -14,7 +14,7 @@ import datasets
 import oracle_lib as ol
 
 
-@pytest.mark.parametrize("case", datasets.ALL_CASES)
+@pytest.mark.parametrize("case", [c for c in datasets.ALL_CASES if not datasets.is_sam(c)])
 def test_oracle_bed_matches_reference(case, tmp_path):
     meta = datasets.case_meta(case)
     fa, r1, r2 = datasets.case_inputs(case)
@@ -109,3 +109,38 @@ def test_hash64_known_values():
     xs = [0, 1, 2, 12345678901, mask]
     hs = [L.ora_hash64(x, mask) for x in xs]
     assert len(set(hs)) == len(xs) and all(h <= mask for h in hs)
+
+
+@pytest.mark.parametrize("case", datasets.SAM_CASES)
+def test_sam_matches_reference(case, tmp_path):
+    """--SAM: ksw_semi_global3 CIGARs, NM / MD tags, SAMMapping order and duplicate removal"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    o = ol.Oracle(idx, fa, ol.params(preset, **kw))
+    mate = datasets.single_end_mate(case)
+    out = str(tmp_path / "o.sam")
+    if mate:
+        f = r1 if mate == 1 else r2
+        b, q, off = ol.read_fastq_qual(f)
+        res, k, st = ol.map_single_sam(o, b, off)
+        lines = ol.write_sam(o, res, False, ol.read_names(f), None, b, q, off, None, None, None, out)
+    else:
+        b1, q1, o1 = ol.read_fastq_qual(r1)
+        b2, q2, o2 = ol.read_fastq_qual(r2)
+        res, k, st = ol.map_pairs_sam(o, b1, o1, b2, o2)
+        lines = ol.write_sam(o, res, True, ol.read_names(r1), ol.read_names(r2), b1, q1, o1, b2, q2, o2, out)
+    got = open(out, "rb").read()
+    want = datasets.case_golden_bed(case)
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        for i in range(min(len(g), len(w))):
+            assert g[i] == w[i], (i, g[i], w[i])
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    assert lines == ref["num_output"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    o.close()
