@@ -26,7 +26,7 @@ PARAM_FIELDS = ("error_threshold", "min_num_seeds", "max_seed_frequency0", "max_
                 "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
                 "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_memory_mode",
                 "read_batch_size", "taskloop_grain_size", "bc_error_threshold", "output_mappings_not_in_whitelist",
-                "bc_probability_threshold")
+                "output_format", "bc_probability_threshold")
 
 
 class Params(C.Structure):
@@ -68,6 +68,17 @@ class BarcodeBatch(C.Structure):
     _fields_ = [("bases", C.c_void_p), ("qualities", C.c_void_p), ("offsets", C.c_void_p)]
 
 
+class SamRecord(C.Structure):
+    _fields_ = [("read_id", C.c_uint32), ("rid", C.c_uint32), ("pos", C.c_uint32), ("mpos", C.c_uint32), ("mrid", C.c_int32),
+                ("tlen", C.c_int32), ("nm", C.c_uint32), ("flag", C.c_uint16), ("n_cigar", C.c_uint16), ("md_len", C.c_uint16),
+                ("mapq", C.c_uint8), ("strand", C.c_uint8), ("is_unique", C.c_uint8), ("valid", C.c_uint8),
+                ("length_after_trim", C.c_uint16)]
+
+
+SAM_CIGAR_CAP = 64
+FORMAT_SAM = 1
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS] + [("reserved", C.c_uint64 * 5)]
 
@@ -88,6 +99,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
+           "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam",
            "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
@@ -144,6 +156,10 @@ def declare(L):
     sig("cmgpu_store_text", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64])
     sig("cmgpu_store_write_text", C.c_int, [C.c_void_p, C.c_char_p, C.c_int])
     sig("cmgpu_store_info", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_sam_layout", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint32)])
+    sig("cmgpu_download_sam", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+    sig("cmgpu_write_sam", C.c_int64, [P(C.c_char_p), C.c_void_p, C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_uint32, P(C.c_char_p), P(C.c_char_p)] + [C.c_void_p] * 6 + [C.c_char_p])
     sig("cmgpu_fastq_scan", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
     sig("cmgpu_fastq_take", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, P(C.c_uint64)])
     sig("cmgpu_barcode_abundance_resident", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_int)])

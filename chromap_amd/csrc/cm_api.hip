@@ -109,6 +109,9 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   if (p.split) p.lanes = 0;                    // split alignment cannot use the lane-grouped loop (draft_mapping_generator.cc:31)
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
+  p.sam = params->output_format == CMGPU_FORMAT_SAM ? 1 : 0;
+  if (p.sam && p.split) { cm_set_error(c, "--SAM with split alignment is not supported"); return CMGPU_EINVAL; }
+  if (params->output_format != 0 && params->output_format != CMGPU_FORMAT_SAM) { cm_set_error(c, "unknown output_format"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipStreamCreate(&c->stream));
   if (c->stats.ensure(CM_ST_N * 8)) return CMGPU_ENOMEM;
   HIPCHECK(c, hipMemset(c->stats.p, 0, CM_ST_N * 8));
@@ -385,6 +388,18 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_launch_k_s5c_finalize(d, n2, s);
   mark(c, "s5c_accept");
   // S6: best pair, sampling of multi-mappers, records
+  if (c->p.sam) {  // per-slot record / CIGAR / MD pools and the backtrack cells of one alignment per pair
+    const uint64_t slots = c->single ? n : n2;
+    const uint32_t md_cap = 2 * c->max_read_len + 16;
+    const uint32_t zw = (2 * c->p.e + 2 <= 18) ? 5 : 8;
+    if (c->sam_rec.ensure(slots * 40 + 16) || c->sam_cigar.ensure(slots * CM_SAM_CIGAR_CAP * 4 + 16) || c->sam_md.ensure(slots * md_cap + 16) ||
+        c->sam_z.ensure((size_t)c->max_read_len * zw * 4 * n + 16)) { cm_set_error(c, "out of device memory (SAM buffers)"); return CMGPU_ENOMEM; }
+    HIPCHECK(c, hipMemsetAsync(c->sam_rec.p, 0, slots * 40, s));
+    c->sam_slots = slots;
+    c->sam_md_cap = md_cap;
+    d.sam_rec = (uint8_t *)c->sam_rec.p; d.sam_cigar = (uint32_t *)c->sam_cigar.p; d.sam_md = (uint8_t *)c->sam_md.p;
+    d.sam_z = (uint32_t *)c->sam_z.p; d.sam_md_cap = md_cap;
+  }
   cm_launch_k_s6a_pair(d, n, s);
   mark(c, "s6a_pairing");
   const uint32_t n_chunks = cm_num_chunks_host(n, (uint32_t)c->p.ref_batch, (uint32_t)c->p.grain);
@@ -478,6 +493,27 @@ extern "C" int cmgpu_wait(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity
   if (c->async_rc) return c->async_rc;
   if (!out) return CMGPU_OK;  // records stay resident (cmgpu_store_append_resident)
   return cmgpu_download_records(c, out, out_capacity, n_out);
+}
+
+extern "C" int cmgpu_sam_layout(const cmgpu_ctx *c, uint64_t *n_slots, uint32_t *md_cap) {
+  if (!c) return CMGPU_EINVAL;
+  if (n_slots) *n_slots = c->p.sam ? c->sam_slots : 0;
+  if (md_cap) *md_cap = c->sam_md_cap;
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_download_sam(cmgpu_ctx *c, cmgpu_sam_record *records, uint32_t *cigar_pool, char *md_pool) {
+  if (!c || !records || !cigar_pool || !md_pool) return CMGPU_EINVAL;
+  if (!c->p.sam) { cm_set_error(c, "the ctx was not created with output_format = CMGPU_FORMAT_SAM"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  const uint64_t ns = c->sam_slots;
+  if (ns == 0) return CMGPU_OK;
+  HIPCHECK(c, hipMemcpy(records, c->sam_rec.p, ns * 40, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(cigar_pool, c->sam_cigar.p, ns * CM_SAM_CIGAR_CAP * 4, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(md_pool, c->sam_md.p, ns * c->sam_md_cap, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < ns; ++i)
+    if (records[i].valid == 2) { cm_set_error(c, "an alignment needs more than CMGPU_SAM_CIGAR_CAP CIGAR operations"); return CMGPU_ECAPACITY; }
+  return CMGPU_OK;
 }
 
 extern "C" int cmgpu_last_timings(const cmgpu_ctx *c, const char **names, float *ms, int cap) {

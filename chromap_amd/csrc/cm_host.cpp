@@ -419,3 +419,108 @@ extern "C" int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_seque
   fclose(f);
   return lines;
 }
+
+// ---------------------------------------------------------------------------------------
+// SAM text (mapping_writer.cc:312-356).  Sort: SAMMapping::operator< under the per-chromosome
+// vectors (sam_mapping.h:193-199; barcode 0); duplicate runs: operator== (:200-205), survivor as
+// in the BED writers (low-memory merge: first maximal MAPQ; in-memory: last); MAPQ filter.
+// The sequence is printed as mapped (reverse complement for the - strand, PrepareNegativeSequenceAt),
+// the quality reversed with it (sam_mapping.h:172-179), both cut to the trimmed length.
+// ---------------------------------------------------------------------------------------
+extern "C" int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
+                                   const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                                   const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                                   const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                                   const char *quals2, const uint32_t *offsets2, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return CMGPU_EIO;
+  std::string buf;
+  buf.reserve(1 << 20);
+  for (uint32_t i = 0; i < n_sequences; ++i) {
+    buf.append("@SQ\tSN:");
+    buf.append(ref_names[i]);
+    buf.append("\tLN:");
+    put_u32(buf, ref_lengths[i]);
+    buf.push_back('\n');
+  }
+  std::vector<uint64_t> v;
+  v.reserve(n_slots);
+  for (uint64_t i = 0; i < n_slots; ++i) if (rec[i].valid) v.push_back(i);
+  std::sort(v.begin(), v.end(), [&](uint64_t a, uint64_t b) {
+    const cmgpu_sam_record &x = rec[a], &y = rec[b];
+    const int xf = x.flag & 64, yf = y.flag & 64;
+    return std::tie(x.rid, x.pos, x.mrid, x.mpos, xf, x.mapq, x.read_id) < std::tie(y.rid, y.pos, y.mrid, y.mpos, yf, y.mapq, y.read_id);
+  });
+  auto same = [&](uint64_t a, uint64_t b) {
+    const cmgpu_sam_record &x = rec[a], &y = rec[b];
+    return x.pos == y.pos && x.rid == y.rid && (x.flag & 64) == (y.flag & 64) && x.mrid == y.mrid && x.mpos == y.mpos;
+  };
+  const bool inmem = !p->low_memory_mode;
+  int64_t lines = 0;
+  size_t i = 0;
+  std::string seq, qual;
+  while (i < v.size()) {
+    uint64_t last = v[i];
+    size_t j = i + 1;
+    if (p->remove_pcr_duplicates) {
+      while (j < v.size() && same(v[j], v[i])) {
+        if (inmem || rec[v[j]].mapq > rec[last].mapq) last = v[j];
+        ++j;
+      }
+    }
+    const cmgpu_sam_record &r = rec[last];
+    if ((int)r.mapq >= p->mapq_threshold && r.rid < n_sequences) {
+      const uint64_t item = paired ? last / 2 : last;
+      const bool mate2 = paired && (last & 1);
+      const char *bs = (mate2 ? bases2 : bases1) + (mate2 ? offsets2 : offsets1)[item];
+      const char *qs = (mate2 ? quals2 : quals1) + (mate2 ? offsets2 : offsets1)[item];
+      uint32_t L = r.length_after_trim;
+      const uint32_t *cg = cigar_pool + last * CMGPU_SAM_CIGAR_CAP;
+      uint32_t ql = 0;  // SAMMapping::GetSequenceLength (sam_mapping.h:246-256)
+      for (uint32_t ci = 0; ci < r.n_cigar; ++ci) { const uint32_t op = cg[ci] & 0xf; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) ql += cg[ci] >> 4; }
+      seq.assign(L, 'N');
+      qual.assign(L, '!');
+      if (r.strand) { seq.assign(bs, L); qual.assign(qs, L); }
+      else
+        for (uint32_t t = 0; t < L; ++t) {
+          const char c = bs[L - 1 - t] & 0xDF;
+          seq[t] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+          qual[t] = qs[L - 1 - t];
+        }
+      if (ql < L) { seq.resize(ql); qual.resize(ql); }
+      buf.append(mate2 ? names2[item] : names1[item]);
+      buf.push_back('\t');
+      put_u32(buf, r.flag);
+      buf.push_back('\t');
+      buf.append(ref_names[r.rid]);
+      buf.push_back('\t');
+      put_u32(buf, r.pos + 1);
+      buf.push_back('\t');
+      put_u32(buf, r.mapq);
+      buf.push_back('\t');
+      if (r.n_cigar == 0) buf.push_back('*');
+      for (uint32_t ci = 0; ci < r.n_cigar; ++ci) { put_u32(buf, cg[ci] >> 4); buf.push_back("MIDNSHP=XB??????"[cg[ci] & 0xf]); }
+      buf.push_back('\t');
+      if (r.mrid < 0) buf.push_back('*'); else if ((uint32_t)r.mrid == r.rid) buf.push_back('='); else buf.append(ref_names[r.mrid]);
+      buf.push_back('\t');
+      put_u32(buf, r.mrid < 0 ? 0u : r.mpos + 1);
+      buf.push_back('\t');
+      if (r.tlen < 0) { buf.push_back('-'); put_u32(buf, (uint32_t)(-(int64_t)r.tlen)); } else put_u32(buf, (uint32_t)r.tlen);
+      buf.push_back('\t');
+      buf.append(seq);
+      buf.push_back('\t');
+      buf.append(qual);
+      buf.append("\tNM:i:");
+      put_u32(buf, r.nm);
+      buf.append("\tMD:Z:");
+      buf.append(md_pool + last * (uint64_t)md_cap, r.md_len);
+      buf.push_back('\n');
+      ++lines;
+      if (buf.size() > (1 << 20) - 4096) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    }
+    i = j;
+  }
+  if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  return lines;
+}

@@ -1827,6 +1827,178 @@ CM_HD CmSpan cm_ref_start_end(const CmDev &d, uint64_t dpos, int nerr, int stran
   return s;
 }
 
+// ---------------------------------------------------------------------------------------
+// --SAM: ksw_semi_global3 (ksw.cc:505-626) as chromap calls it (mapping_generator.h:723-738,
+// 807-821): query = reference window of L + 2e bytes, target = the read as mapped (L bases),
+// band w = 2e + 1, scores match 1 / mismatch -4 / gap open 6 + extend 1 / ambiguous 0
+// (mapping_parameters.h:20-23).  Row i visits columns [i, i + w + 1) (the last row one fewer),
+// so the H / E state is a window of W1 = w + 1 registers that shifts by one column per row.
+// The move bits of every cell go to sam_z (4 cells per word, interleaved over pairs so a wave's
+// stores coalesce); the backtrack walks them from the best of the last w columns.
+// W1T: compile-time window size (>= w + 1).
+// ---------------------------------------------------------------------------------------
+template <int W1T>
+CM_HD int cm_ksw_sg3(const uint8_t *query, const uint8_t *read, int L, bool neg, int e, uint32_t *z, uint64_t zstride,
+                     uint32_t *cigar, int *n_cigar, int *start, int *end) {
+  const int NEG = -0x40000000, o_del = 6, e_del = 1, e_ins = 1, oe_del = 7, oe_ins = 7;
+  const int w = 2 * e + 1, w1 = w + 1, qlen = L + 2 * e;
+  constexpr int ZW = (W1T + 3) / 4;
+  int h[W1T], ev[W1T];
+  uint32_t qc[W1T];
+#pragma unroll
+  for (int jj = 0; jj < W1T; ++jj) { h[jj] = 0; ev[jj] = NEG; qc[jj] = jj < w1 ? cm_c2u(query[jj]) : 4u; }
+  for (int i = 0; i < L; ++i) {
+    int f = NEG;
+    int h1 = i == 0 ? -(o_del + e_del) : NEG;
+    const uint32_t tc = cm_text_code(read, L, i, neg);
+    const int cnt = i == L - 1 ? w1 - 1 : w1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int jj = 0; jj < W1T; ++jj) {
+      if (jj < cnt) {
+        const int sc = (tc > 3 || qc[jj] > 3) ? 0 : (tc == qc[jj] ? 1 : -4);
+        int m = h[jj], ee = ev[jj];
+        h[jj] = h1;
+        m += sc;
+        uint32_t dbits = m >= ee ? 0u : 1u;
+        int hh = m >= ee ? m : ee;
+        dbits = hh >= f ? dbits : 2u;
+        hh = hh >= f ? hh : f;
+        h1 = hh;
+        int t = m - oe_del;
+        ee -= e_del;
+        dbits |= ee > t ? 4u : 0u;
+        ee = ee > t ? ee : t;
+        ev[jj] = ee;
+        t = m - oe_ins;
+        f -= e_ins;
+        dbits |= f > t ? 32u : 0u;
+        f = f > t ? f : t;
+        packed |= dbits << ((jj & 3) * 8);
+      }
+      if ((jj & 3) == 3 || jj == W1T - 1) {
+        if ((jj >> 2) * 4 < cnt) z[((uint64_t)i * ZW + (uint32_t)(jj >> 2)) * zstride] = packed;
+        packed = 0;
+      }
+    }
+    if (i != L - 1) {
+      const uint32_t nq = i + w1 < qlen ? cm_c2u(query[i + w1]) : 4u;
+#pragma unroll
+      for (int jj = 0; jj < W1T; ++jj) {
+        const bool top = jj == w1 - 1;
+        h[jj] = top ? h1 : (jj + 1 < W1T ? h[jj + 1] : NEG);
+        ev[jj] = top ? NEG : (jj + 1 < W1T ? ev[jj + 1] : NEG);
+        qc[jj] = top ? nq : (jj + 1 < W1T ? qc[jj + 1] : 4u);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < W1T; ++jj) if (jj == w1 - 1) h[jj] = h1;
+    }
+  }
+  // best of the last w columns: H[qlen - j] = h[w1 - 1 - j], j = 0 .. w-1, first maximum wins
+  int score = NEG, maxpos = qlen;
+#pragma unroll
+  for (int jj = W1T - 1; jj >= 1; --jj) {
+    if (jj <= w1 - 1) {
+      const int j = w1 - 1 - jj;
+      if (j == 0 || h[jj] > score) { score = h[jj]; maxpos = qlen - j; }
+    }
+  }
+  *end = maxpos;
+  int n = 0, i = L - 1, k = maxpos - 1;
+  uint32_t which = 0;
+  bool overflow = false;
+#define CM_PUSHC(op, len) do { if (n == 0 || (cigar[n - 1] & 0xfu) != (uint32_t)(op)) { if (n < CM_SAM_CIGAR_CAP) cigar[n++] = ((uint32_t)(len) << 4) | (uint32_t)(op); else overflow = true; } \
+                               else cigar[n - 1] += (uint32_t)(len) << 4; } while (0)
+  while (i >= 0 && k >= 0) {
+    const int jj = k - i;
+    const uint32_t cell = (z[((uint64_t)i * ZW + (uint32_t)(jj >> 2)) * zstride] >> ((jj & 3) * 8)) & 0xffu;
+    which = (cell >> (which << 1)) & 3u;
+    if (which == 0) { CM_PUSHC(0, 1); --i; --k; }
+    else if (which == 1) { CM_PUSHC(1, 1); --i; }
+    else { CM_PUSHC(2, 1); --k; }
+  }
+  if (i >= 0) CM_PUSHC(1, i + 1);
+#undef CM_PUSHC
+  *start = k + 1;
+  for (int a = 0; a < n >> 1; ++a) { const uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
+  *n_cigar = n;
+  return overflow ? -1 : score;
+}
+
+CM_HD uint32_t cm_put_dec(uint8_t *dst, uint32_t cap, uint32_t at, uint32_t v) {
+  uint32_t dgt = 1;
+  for (uint32_t t = v; t >= 10; t /= 10) ++dgt;
+  for (uint32_t i = dgt; i-- > 0;) { if (at + i < cap) dst[at + i] = (uint8_t)('0' + v % 10); v /= 10; }
+  return at + dgt;
+}
+
+// GenerateNMAndMDTag (alignment.cc:85-139); ref points at the mapping start, the read is taken as mapped
+CM_HD uint32_t cm_nm_and_md(const uint8_t *ref, const uint8_t *read, int L, bool neg, const uint32_t *cigar, int n_cigar,
+                            uint8_t *md, uint32_t md_cap, uint32_t *md_len) {
+  uint32_t nm = 0, matches = 0, at = 0;
+  int rp = 0, fp = 0;
+  for (int ci = 0; ci < n_cigar; ++ci) {
+    const uint32_t op = cigar[ci] & 0xfu, len = cigar[ci] >> 4;
+    if (op == 0) {
+      for (uint32_t t = 0; t < len; ++t) {
+        const uint8_t rc = ref[fp], tc = cm_text_char(read, L, rp, neg);
+        if (rc == tc || (int)rc - 'a' + 'A' == (int)tc) ++matches;
+        else { ++nm; at = cm_put_dec(md, md_cap, at, matches); matches = 0; if (at < md_cap) md[at] = rc; ++at; }
+        ++fp; ++rp;
+      }
+    } else if (op == 1) { nm += len; rp += (int)len; }
+    else if (op == 2) {
+      nm += len;
+      at = cm_put_dec(md, md_cap, at, matches); matches = 0;
+      if (at < md_cap) md[at] = '^';
+      ++at;
+      for (uint32_t t = 0; t < len; ++t) { if (at < md_cap) md[at] = ref[fp]; ++at; ++fp; }
+    }
+  }
+  at = cm_put_dec(md, md_cap, at, matches);
+  *md_len = at;
+  return nm;
+}
+
+struct CmSamAln { uint32_t n_cigar, md_len, nm; bool overflow; };
+// GetRefStartEndPositionForReadFromMapping, SAM branches (mapping_generator.h:657-717, 723-761, 807-854), no split
+CM_HD CmSpan cm_ref_start_end_sam(const CmDev &d, uint32_t pair, uint32_t slot, uint64_t dpos, int strand, const uint8_t *read, int L,
+                                  CmSamAln *aln) {
+  const int e = d.p.e;
+  const uint32_t rid = (uint32_t)(dpos >> 32), ref_pos = (uint32_t)dpos;
+  const uint32_t rl = d.ref_len[rid];
+  uint32_t vw = ref_pos + 1 > (uint32_t)(L + e) ? ref_pos + 1 - (uint32_t)L - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)L;
+  const uint8_t *win = d.ref + d.ref_off[rid] + vw;
+  uint32_t *cigar = d.sam_cigar + (uint64_t)slot * CM_SAM_CIGAR_CAP;
+  int n_cigar = 0, st = 0, en = 0, sc;
+  if (2 * e + 2 <= 18) sc = cm_ksw_sg3<18>(win, read, L, strand == 1, e, d.sam_z + pair, d.n_pairs, cigar, &n_cigar, &st, &en);
+  else sc = cm_ksw_sg3<32>(win, read, L, strand == 1, e, d.sam_z + pair, d.n_pairs, cigar, &n_cigar, &st, &en);
+  uint32_t md_len = 0;
+  aln->nm = cm_nm_and_md(win + st, read, L, strand == 1, cigar, n_cigar, d.sam_md + (uint64_t)slot * d.sam_md_cap, d.sam_md_cap, &md_len);
+  aln->n_cigar = (uint32_t)n_cigar;
+  aln->md_len = md_len;
+  aln->overflow = sc == -1 || md_len > d.sam_md_cap;
+  CmSpan s;
+  s.rid = rid;
+  s.ref_start = vw + (uint32_t)st;
+  s.ref_end = vw + (uint32_t)en - 1;
+  return s;
+}
+
+// one cmgpu_sam_record (40 bytes; include/chromap_amd.h)
+CM_HD void cm_put_sam_record(const CmDev &d, uint32_t slot, uint32_t read_id, const CmSpan &me, uint32_t mpos, int32_t mrid, int32_t tlen,
+                             uint32_t flag, uint8_t mapq, uint8_t plus, uint8_t is_unique, const CmSamAln &a, uint32_t len_after_trim) {
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(d.sam_rec + (uint64_t)slot * 40);
+  uint16_t *o16 = reinterpret_cast<uint16_t *>(o32);
+  uint8_t *o8 = reinterpret_cast<uint8_t *>(o32);
+  o32[0] = read_id; o32[1] = me.rid; o32[2] = me.ref_start; o32[3] = mpos; o32[4] = (uint32_t)mrid; o32[5] = (uint32_t)tlen; o32[6] = a.nm;
+  o16[14] = (uint16_t)flag; o16[15] = (uint16_t)a.n_cigar; o16[16] = (uint16_t)a.md_len;
+  o8[34] = mapq; o8[35] = plus; o8[36] = is_unique; o8[37] = a.overflow ? 2 : 1;
+  o16[19] = (uint16_t)len_after_trim;
+}
+
 // (int)(4.343 * log(n + 1) + 0.499) for n >= 1 via host-computed breakpoints:
 // nsec_break[v] = smallest n whose value is >= v (monotone step function)
 CM_HD int cm_nsec_penalty(const CmMapqTables &t, int n) {
@@ -1927,8 +2099,11 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   const int s1 = dir == 0 ? 0 : 1, s2 = dir == 0 ? 1 : 0;
   const uint64_t dp1 = cm_d_pos(d, r1, s1)[pe.f_i1], dp2 = cm_d_pos(d, r2, s2)[pe.f_i2];
   const int e1 = cm_d_err(d, r1, s1)[pe.f_i1], e2 = cm_d_err(d, r2, s2)[pe.f_i2];
-  const CmSpan a = cm_ref_start_end(d, dp1, e1, s1, cm_read_ptr(d, r1), (int)len1);
-  const CmSpan b = cm_ref_start_end(d, dp2, e2, s2, cm_read_ptr(d, r2), (int)len2);
+  CmSamAln sa1, sa2;
+  const CmSpan a = d.p.sam ? cm_ref_start_end_sam(d, pair, r1, dp1, s1, cm_read_ptr(d, r1), (int)len1, &sa1)
+                           : cm_ref_start_end(d, dp1, e1, s1, cm_read_ptr(d, r1), (int)len1);
+  const CmSpan b = d.p.sam ? cm_ref_start_end_sam(d, pair, r2, dp2, s2, cm_read_ptr(d, r2), (int)len2, &sa2)
+                           : cm_ref_start_end(d, dp2, e2, s2, cm_read_ptr(d, r2), (int)len2);
   const uint16_t al1 = (uint16_t)(a.ref_end - a.ref_start + 1), al2 = (uint16_t)(b.ref_end - b.ref_start + 1);
   const int force_mapq = d.force0[pair] ? 0 : -1;
   const uint8_t mapq = cm_mapq_paired(d, pair, e1, e2, al1, al2, (int)len1, (int)len2, force_mapq, pe);
@@ -1950,6 +2125,14 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   o16[10] = (uint16_t)(ns.ref_end - ns.ref_start + 1);
   o16[11] = 0;
   d.rec_ok[pair] = 1;
+  if (d.p.sam) {  // EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108), flags mapping_generator.h:613-631
+    const int tlen = (int)(ns.ref_end - ps.ref_start + 1);
+    const bool plus1 = dir == 0;
+    cm_put_sam_record(d, r1, d.first_read_id + pair, a, b.ref_start, (int32_t)b.rid, plus1 ? tlen : -tlen, 3u | (plus1 ? 32u : 16u) | 64u,
+                      mapq, plus1 ? 1 : 0, is_unique, sa1, len1);
+    cm_put_sam_record(d, r2, d.first_read_id + pair, b, a.ref_start, (int32_t)a.rid, plus1 ? -tlen : tlen, 3u | (plus1 ? 16u : 32u) | 128u,
+                      mapq, plus1 ? 0 : 1, is_unique, sa2, len2);
+  }
 }
 
 
@@ -2144,7 +2327,9 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
       if ((int)de[mi] > me) continue;
       if (idx == choice) {
         const uint32_t L = d.rlen[r];
-        const CmSpan sp = cm_ref_start_end(d, dp[mi], de[mi], strand, cm_read_ptr(d, r), (int)L);
+        CmSamAln sa;
+        const CmSpan sp = d.p.sam ? cm_ref_start_end_sam(d, pair, pair, dp[mi], strand, cm_read_ptr(d, r), (int)L, &sa)
+                                  : cm_ref_start_end(d, dp[mi], de[mi], strand, cm_read_ptr(d, r), (int)L);
         const uint16_t al = (uint16_t)(sp.ref_end - sp.ref_start + 1);
         const uint8_t mapq = cm_mapq_single(d, de[mi], al, (int)L, d.p.e, d.second_err[r], d.n_best[r], d.n_second[r], d.rep_len[r]);
         uint8_t *o = d.rec + (uint64_t)pair * 24;
@@ -2160,6 +2345,9 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
         o[17] = 1;
         o16[9] = 0; o16[10] = 0; o16[11] = 0;
         d.rec_ok[pair] = 1;
+        if (d.p.sam)  // EmplaceBackSingleEndMappingRecord<SAMMapping> (mapping_generator.cc:43-57), flag mapping_generator.h:321-326
+          cm_put_sam_record(d, pair, d.first_read_id + pair, sp, 0, -1, 0, strand == 0 ? 0u : 16u, mapq, strand == 0 ? 1 : 0,
+                            d.n_best[r] == 1 ? 1 : 0, sa, L);
         return;
       }
       ++idx;

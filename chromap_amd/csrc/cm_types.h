@@ -26,6 +26,7 @@
 #define CM_V_INVALID 0x7fff
 
 // Subset of MappingParameters used on the device.
+#define CM_SAM_CIGAR_CAP 64
 struct CmParams {
   int32_t e;             // error_threshold
   int32_t min_seeds;     // min_num_seeds_required_for_mapping
@@ -44,6 +45,7 @@ struct CmParams {
   int32_t lanes;         // GetNumVPULanes(): 8 if e<8, 4 if e<16, else 0
   int32_t ref_batch;     // 500000
   int32_t grain;         // 5000
+  int32_t sam;           // mapping_output_format == SAM: coordinates from ksw_semi_global3, CIGAR / NM / MD kept
 };
 
 // MAPQ tables computed on the host with libm so the device reproduces the reference's
@@ -139,6 +141,13 @@ struct CmDev {
   // ---- output
   uint8_t *rec;         // n records of 24 bytes (cmgpu_record layout)
   uint8_t *rec_ok;      // [n]
+  // ---- --SAM (per slot: 2*pair + mate): 40-byte cmgpu_sam_record, CM_SAM_CIGAR_CAP cigar words, sam_md_cap MD bytes;
+  //      sam_z: backtrack cells of the pair being aligned, word (row*ZW + q) * n_pairs + pair
+  uint8_t *sam_rec;
+  uint32_t *sam_cigar;
+  uint8_t *sam_md;
+  uint32_t *sam_z;
+  uint32_t sam_md_cap;
   unsigned long long *stats; // device counters (see CM_ST_*)
 };
 

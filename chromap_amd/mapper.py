@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import SingleBatch, BarcodeBatch, Batch, IndexView, Params, Record, RecordBc, RefView, Stats
+from ._capi import SamRecord, SingleBatch, BarcodeBatch, Batch, IndexView, Params, Record, RecordBc, RefView, Stats
 
 
 class ChromapError(RuntimeError):
@@ -230,6 +230,37 @@ class ChromapGPU:
         ms = (C.c_float * 32)()
         k = self.L.cmgpu_last_timings(self.ctx, names, ms, 32)
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    # ---- --SAM (create the mapper with output_format=_capi.FORMAT_SAM)
+    def download_sam(self):
+        """SAM records of the last mapped batch: (records, cigar_pool, md_pool, md_cap, n_slots)"""
+        ns, cap = C.c_uint64(0), C.c_uint32(0)
+        self._check(self.L.cmgpu_sam_layout(self.ctx, C.byref(ns), C.byref(cap)), self.ctx)
+        n = int(ns.value)
+        rec = (SamRecord * max(1, n))()
+        cigar = np.zeros(max(1, n) * _capi.SAM_CIGAR_CAP, np.uint32)
+        md = np.zeros(max(1, n) * max(1, cap.value), np.uint8)
+        self._check(self.L.cmgpu_download_sam(self.ctx, C.cast(rec, C.c_void_p), cigar.ctypes.data, md.ctypes.data), self.ctx)
+        return rec, cigar, md, int(cap.value), n
+
+    def write_sam(self, sam, paired, names1, names2, b1, q1, o1, b2, q2, o2, path, params=None):
+        rec, cigar, md, md_cap, n = sam
+        p = params if params is not None else self.params
+        rn = (C.c_char_p * len(self.names))(*self.names)
+        nseq = C.c_uint32(0)
+        self.L.cmgpu_reference_lengths(self.ctx, None, 0, C.byref(nseq))
+        lens = (C.c_uint32 * nseq.value)()
+        self.L.cmgpu_reference_lengths(self.ctx, lens, nseq.value, C.byref(nseq))
+        n1 = (C.c_char_p * len(names1))(*names1)
+        n2 = (C.c_char_p * max(1, len(names2 or [])))(*(names2 or [b""]))
+        keep = [np.ascontiguousarray(x) if x is not None else None for x in (b1, q1, o1, b2, q2, o2)]
+        ptr = [k.ctypes.data if k is not None else None for k in keep]
+        k = self.L.cmgpu_write_sam(rn, C.cast(lens, C.c_void_p), len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, int(paired),
+                                   cigar.ctypes.data, md.ctypes.data, md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5],
+                                   path.encode())
+        if k < 0:
+            raise ChromapError("cannot write %s" % path)
+        return int(k)
 
     # ---- FASTQ ingest on the device
     def fastq_scan(self, stream, text, final=True):

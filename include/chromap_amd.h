@@ -33,6 +33,8 @@ extern "C" {
 #define CMGPU_EIO (-6)
 #define CMGPU_EFORMAT (-7)
 
+#define CMGPU_FORMAT_SAM 1
+
 /* The minimizer index exactly as Index::Load leaves it in host memory
  * (src/index.cc:132-169, kh_load src/khash.h:358-373): khash open-addressing arrays with
  * 2-bit flags, keys = minimizer_hash<<1 | is_singleton, values, and the occurrence
@@ -77,6 +79,7 @@ typedef struct cmgpu_params {
   int32_t taskloop_grain_size;    /* 5000 (chromap.h:887): scope of the reservoir RNG */
   int32_t bc_error_threshold;     /* --bc-error-threshold (0 or 1 supported on the device) */
   int32_t output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
+  int32_t output_format;          /* 0: BED / pairs records; CMGPU_FORMAT_SAM: --SAM (alignment coordinates, CIGAR, NM, MD) */
   double bc_probability_threshold; /* --bc-probability-threshold */
 } cmgpu_params;
 
@@ -287,6 +290,48 @@ int cmgpu_export_index(cmgpu_ctx *ctx, uint64_t *buckets_out, uint64_t *occurren
 /* Dense copy of the resident batch's records into a caller-provided DEVICE buffer
  * (capacity in records) -- the send buffer of the multi-GPU record exchange. */
 int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity, uint64_t *n_out);
+
+/* ---- --SAM --------------------------------------------------------------
+ * With params.output_format == CMGPU_FORMAT_SAM the reported mappings are aligned with the
+ * banded affine-gap DP the reference uses for SAM (ksw_semi_global3, src/ksw.cc:505-626, called
+ * from src/mapping_generator.h:723-761, 807-854): start / end come from that alignment (MAPQ is
+ * computed from them), and every reported read carries CIGAR, NM and MD
+ * (GenerateNMAndMDTag, src/alignment.cc:85-139).  cmgpu_sam_record = the arguments of SAMMapping's
+ * constructor (src/sam_mapping.h:151-190, src/mapping_generator.cc:43-57, 84-108) except the
+ * strings the host already holds (name, sequence, quality).  Slots: 2*i / 2*i+1 for pair i
+ * (read 1 / read 2), i for single-end read i; valid == 0: the read has no record.
+ * CIGAR words (BAM encoding len<<4|op) and MD text sit in fixed-size slots of the pools. */
+#define CMGPU_SAM_CIGAR_CAP 64
+typedef struct cmgpu_sam_record {
+  uint32_t read_id;
+  uint32_t rid;
+  uint32_t pos;    /* 0-based start on the reference */
+  uint32_t mpos;
+  int32_t mrid;    /* -1: no mate */
+  int32_t tlen;
+  uint32_t nm;
+  uint16_t flag;
+  uint16_t n_cigar;
+  uint16_t md_len;
+  uint8_t mapq;
+  uint8_t strand;  /* 1 = + (SAMMapping::is_rev_ stores exactly this) */
+  uint8_t is_unique;
+  uint8_t valid;
+  uint16_t length_after_trim; /* bases of the read that were mapped (adapter trimming) */
+} cmgpu_sam_record;
+/* slots and MD bytes per slot of the last mapped batch */
+int cmgpu_sam_layout(const cmgpu_ctx *ctx, uint64_t *n_slots, uint32_t *md_cap);
+/* copies records, n_slots * CMGPU_SAM_CIGAR_CAP cigar words and n_slots * md_cap MD bytes to the host */
+int cmgpu_download_sam(cmgpu_ctx *ctx, cmgpu_sam_record *records, uint32_t *cigar_pool, char *md_pool);
+/* SAM text (src/mapping_writer.cc:312-356): @SQ header unless append, records sorted by
+ * SAMMapping::operator< (src/sam_mapping.h:193-199), duplicate removal on operator== in the
+ * low-memory or in-memory flavour, MAPQ filter.  names / bases / quals / offsets: the batch(es) the
+ * slots refer to (mate-2 arrays NULL for single-end data). */
+int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *params,
+                        const cmgpu_sam_record *records, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                        const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                        const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                        const char *quals2, const uint32_t *offsets2, const char *out_path);
 
 /* ---- device-side post-processing -------------------------------------
  * Replaces, for BED output: MappingProcessor::SortOutputMappings / RemovePCRDuplicate

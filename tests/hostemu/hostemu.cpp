@@ -20,6 +20,13 @@ static void scan(const T *in, uint32_t *out, uint32_t n) {
   out[n] = s;
 }
 
+struct EmuSam {
+  cmgpu_sam_record *rec;  // 2n (pairs) or n (single) slots
+  uint32_t *cigar;
+  char *md;
+  uint32_t md_cap;
+};
+
 struct EmuBarcodes {
   const cmgpu_barcode_batch *bc;
   const uint64_t *wl_keys;
@@ -30,7 +37,8 @@ struct EmuBarcodes {
 static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
                          const cmgpu_batch *in, cmgpu_record *out, uint64_t *n_out, cmgpu_stats *stats,
                          uint32_t *dbg_mm_cnt /* 2n or NULL */, uint32_t *dbg_ncand /* 2n */,
-                         uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */, const EmuBarcodes *eb, bool single = false) {
+                         uint32_t *dbg_ndraft /* 2n */, int32_t *dbg_nbest /* n */, const EmuBarcodes *eb, bool single = false,
+                         const EmuSam *sam = nullptr) {
   const uint32_t n = in->n_pairs, n2 = 2 * n;
   CmDev d;
   memset(&d, 0, sizeof(d));
@@ -159,6 +167,16 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   scan(d.nv, d.v_off, n2);
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
   for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r);
+  // --SAM buffers (cmgpu_map_resident allocates the same per batch)
+  std::vector<uint32_t> samz;
+  if (sam) {
+    uint32_t mx = 1;
+    for (uint32_t r = 0; r < n2; ++r) mx = d.rlen[r] > mx ? d.rlen[r] : mx;
+    samz.assign((size_t)mx * 8 * (n ? n : 1) + 8, 0);
+    d.p.sam = 1; d.sam_rec = (uint8_t *)sam->rec; d.sam_cigar = sam->cigar; d.sam_md = (uint8_t *)sam->md; d.sam_md_cap = sam->md_cap;
+    d.sam_z = samz.data();
+    memset(sam->rec, 0, (size_t)(single ? n : n2) * sizeof(cmgpu_sam_record));
+  }
   for (uint32_t i = 0; i < n; ++i) cm_s6a_pair(d, i);
   const uint32_t nch = cm_num_chunks(n, (uint32_t)p.ref_batch, (uint32_t)p.grain);
   CmMt *g = new CmMt();
@@ -261,4 +279,24 @@ extern "C" int hostemu_trim(const cmgpu_params *params, const cmgpu_batch *in, u
   d.rlen = rlen;
   for (uint32_t i = 0; i < in->n_pairs; ++i) cm_s0_prep(d, i);
   return 0;
+}
+
+extern "C" int hostemu_map_pairs_sam(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                     const cmgpu_batch *in, cmgpu_sam_record *rec, uint32_t *cigar, char *md, uint32_t md_cap,
+                                     cmgpu_stats *stats) {
+  std::vector<cmgpu_record> out(in->n_pairs + 1);
+  uint64_t k = 0;
+  const EmuSam sam{rec, cigar, md, md_cap};
+  return emu_map_pairs(index, ref, params, in, out.data(), &k, stats, nullptr, nullptr, nullptr, nullptr, nullptr, false, &sam);
+}
+
+extern "C" int hostemu_map_single_sam(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                      const cmgpu_single_batch *in, cmgpu_sam_record *rec, uint32_t *cigar, char *md, uint32_t md_cap,
+                                      cmgpu_stats *stats) {
+  std::vector<uint32_t> zero((size_t)in->n_reads + 1, 0);
+  cmgpu_batch b{in->n_reads, in->first_read_id, in->bases, in->offsets, "", zero.data()};
+  std::vector<cmgpu_record> out(in->n_reads + 1);
+  uint64_t k = 0;
+  const EmuSam sam{rec, cigar, md, md_cap};
+  return emu_map_pairs(index, ref, params, &b, out.data(), &k, stats, nullptr, nullptr, nullptr, nullptr, nullptr, true, &sam);
 }

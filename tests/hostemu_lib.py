@@ -125,3 +125,66 @@ class HostEmu:
         names = (C.c_char_p * len(self.names))(*self.names)
         return self.L.cmgpu_write_bed_pe(names, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n,
                                          path.encode())
+
+
+class SamOut:
+    """slot-addressed SAM records + pools (cmgpu_sam_record layout)"""
+    def __init__(self, n_slots, md_cap):
+        self.rec = (_capi.SamRecord * max(1, n_slots))()
+        self.cigar = np.zeros(max(1, n_slots) * _capi.SAM_CIGAR_CAP, np.uint32)
+        self.md = np.zeros(max(1, n_slots) * md_cap, np.uint8)
+        self.md_cap = md_cap
+        self.n_slots = n_slots
+
+    def tuples(self):
+        out = []
+        for i in range(self.n_slots):
+            r = self.rec[i]
+            if not r.valid:
+                continue
+            cg = tuple(int(x) for x in self.cigar[i * _capi.SAM_CIGAR_CAP:i * _capi.SAM_CIGAR_CAP + r.n_cigar])
+            md = self.md[i * self.md_cap:i * self.md_cap + r.md_len].tobytes()
+            out.append((i, r.read_id, r.rid, r.pos, r.mpos, r.mrid, r.tlen, r.nm, r.flag, r.mapq, r.strand, r.is_unique, cg, md,
+                        r.length_after_trim))
+        return out
+
+
+def write_sam(L, ref, p, so, paired, names1, names2, b1, q1, o1, b2, q2, o2, path):
+    """the product's host SAM writer (cm_host.cpp) over slot-addressed records"""
+    nseq = ref.n_sequences
+    rn = (C.c_char_p * nseq)(*[ref.names[i] for i in range(nseq)])
+    n1 = (C.c_char_p * len(names1))(*names1)
+    n2 = (C.c_char_p * max(1, len(names2 or [])))(*(names2 or [b""]))
+    keep = [np.ascontiguousarray(x) if x is not None else None for x in (b1, q1, o1, b2, q2, o2)]
+    ptr = [k.ctypes.data if k is not None else None for k in keep]
+    return L.cmgpu_write_sam(rn, C.cast(ref.lengths, C.c_void_p), nseq, C.byref(p), C.cast(so.rec, C.c_void_p), so.n_slots, int(paired),
+                             so.cigar.ctypes.data, so.md.ctypes.data, so.md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+                             ptr[5], path.encode())
+
+
+def map_sam(h, b1, o1, b2=None, o2=None):
+    """HostEmu h: stage functions in --SAM mode; returns (SamOut, Stats)"""
+    P = C.POINTER
+    n = len(o1) - 1
+    paired = b2 is not None
+    mx = int(np.diff(o1).max(initial=1))
+    if paired:
+        mx = max(mx, int(np.diff(o2).max(initial=1)))
+    so = SamOut(2 * n if paired else n, 2 * mx + 16)
+    st = _capi.Stats()
+    keep = [np.ascontiguousarray(x) for x in ((b1, o1, b2, o2) if paired else (b1, o1))]
+    if paired:
+        bt = _capi.Batch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data)
+        f = h.L.hostemu_map_pairs_sam
+        f.argtypes = [P(_capi.IndexView), P(_capi.RefView), P(_capi.Params), P(_capi.Batch), C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_uint32, P(_capi.Stats)]
+    else:
+        bt = _capi.SingleBatch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data)
+        f = h.L.hostemu_map_single_sam
+        f.argtypes = [P(_capi.IndexView), P(_capi.RefView), P(_capi.Params), P(_capi.SingleBatch), C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_uint32, P(_capi.Stats)]
+    f.restype = C.c_int
+    rc = f(C.byref(h.idx), C.byref(h.ref), C.byref(h.p), C.byref(bt), C.cast(so.rec, C.c_void_p), so.cigar.ctypes.data,
+           so.md.ctypes.data, so.md_cap, C.byref(st))
+    assert rc == 0, rc
+    return so, st

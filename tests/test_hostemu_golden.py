@@ -91,3 +91,32 @@ def test_stage_functions_match_reference(case, tmp_path):
             if t.n_draft1 > 0 and t.n_draft2 > 0:
                 assert dbg["nbest"][i] == t.nbest, i
     o.close()
+
+
+@pytest.mark.parametrize("case", datasets.SAM_CASES)
+def test_sam_stage_functions_match_reference(case, tmp_path):
+    """--SAM through the stage functions (register-window ksw, NM/MD, SAM records) and the host SAM writer"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    h = he.HostEmu(datasets.case_index(case), fa, he.params(preset, **kw))
+    mate = datasets.single_end_mate(case)
+    out = str(tmp_path / "e.sam")
+    if mate:
+        f = r1 if mate == 1 else r2
+        b, q, off = ol.read_fastq_qual(f)
+        so, st = he.map_sam(h, b, off)
+        lines = he.write_sam(h.L, h.ref, h.p, so, False, ol.read_names(f), None, b, q, off, None, None, None, out)
+    else:
+        b1, q1, o1 = ol.read_fastq_qual(r1)
+        b2, q2, o2 = ol.read_fastq_qual(r2)
+        so, st = he.map_sam(h, b1, o1, b2, o2)
+        lines = he.write_sam(h.L, h.ref, h.p, so, True, ol.read_names(r1), ol.read_names(r2), b1, q1, o1, b2, q2, o2, out)
+    got = open(out, "rb").read()
+    want = datasets.case_golden_bed(case)
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        for i in range(min(len(g), len(w))):
+            assert g[i] == w[i], (i, g[i], w[i])
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    assert lines == meta["reference_stderr_counters"]["num_output"]
