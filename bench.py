@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--preset", default="atac")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--probe-repeat", type=int, default=10)
+    ap.add_argument("--sam", action="store_true", help="--SAM mode: every reported read is aligned with the banded affine-gap DP "
+                                                         "(CIGAR / NM / MD); not the headline metric")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL record exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -158,7 +160,8 @@ def main():
 
     from chromap_amd import ChromapGPU, Stats
     t0 = time.time()
-    g = ChromapGPU(synthetic=(args.genome, args.nseq, 12345), preset=args.preset, device=local_rank)
+    g = ChromapGPU(synthetic=(args.genome, args.nseq, 12345), preset=args.preset, device=local_rank,
+                   **({"output_format": 1} if args.sam else {}))
     t_index = time.time() - t0
     if rank == 0:
         log("[bench] synthetic genome + index on device in %.1fs" % t_index)
@@ -286,7 +289,7 @@ def main():
         except Exception as e:
             pcie = {"error": repr(e)}
         cpu = None
-        if world == 1 and not args.skip_cpu:
+        if world == 1 and not args.skip_cpu and not args.sam:
             try:
                 cpu = cpu_baseline(g, args, args.pairs)
             except Exception as e:  # the GPU number must still be reported

@@ -400,11 +400,11 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     d.sam_rec = (uint8_t *)c->sam_rec.p; d.sam_cigar = (uint32_t *)c->sam_cigar.p; d.sam_md = (uint8_t *)c->sam_md.p;
     d.sam_z = (uint32_t *)c->sam_z.p; d.sam_md_cap = md_cap;
   }
-  cm_launch_k_s6a_pair(d, n, s);
+  if (c->p.sam) cm_launch_k_s6a_pair_sam(d, n, s); else cm_launch_k_s6a_pair(d, n, s);
   mark(c, "s6a_pairing");
   const uint32_t n_chunks = cm_num_chunks_host(n, (uint32_t)c->p.ref_batch, (uint32_t)c->p.grain);
   cm_launch_k_s6b_sample(d, n_chunks, s);
-  cm_launch_k_s6c_multi(d, n, s);
+  if (c->p.sam) cm_launch_k_s6c_multi_sam(d, n, s); else cm_launch_k_s6c_multi(d, n, s);
   mark(c, "s6bc_multimappers");
   cm_launch_k_stats(d, n, (unsigned long long *)c->partials.p, s);
   unsigned long long hst[CM_ST_N];

@@ -106,7 +106,7 @@ struct Args {
   std::string index_path, ref_path, out_path, preset, barcode_file, whitelist;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
-  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false;
+  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false;
   size_t chunk_bytes = 256u << 20;
   int k = 17, w = 7, device = 0;
   uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
@@ -171,7 +171,8 @@ static Args parse(int argc, char **argv) {
     else if (o == "--Tn5-shift") a.p.tn5_shift = 1;
     else if (o == "--split-alignment") a.p.split_alignment = 1;
     else if (o == "--low-mem") a.p.low_memory_mode = 1;
-    else if (o == "--BED") { a.out_bed = true; a.out_pairs = false; }
+    else if (o == "--BED") { a.out_bed = true; a.out_pairs = false; a.out_sam = false; }
+    else if (o == "--SAM") { a.out_sam = true; a.out_bed = false; a.out_pairs = false; }
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
     else if (o == "--device") a.device = atoi(need("--device"));
@@ -185,7 +186,11 @@ static Args parse(int argc, char **argv) {
              "       --remove-pcr-duplicates --Tn5-shift --low-mem --BED|--pairs --bc-error-threshold ...]\n");
       exit(0);
     }
-    else die("unsupported option " + o + " (SAM/PAF/TagAlign, --chr-order and summary outputs are outside this build)");
+    else die("unsupported option " + o + " (PAF/TagAlign, --chr-order and summary outputs are outside this build)");
+  }
+  if (a.out_sam) {
+    if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
+    a.p.output_format = CMGPU_FORMAT_SAM;
   }
   if (a.batch_pairs < 500000) a.batch_pairs = 500000;
   a.batch_pairs -= a.batch_pairs % 500000;
@@ -234,7 +239,17 @@ int main(int argc, char **argv) {
 
   double t_read = 0, t_parse = 0, t_map = 0, t_post = 0;
   const double t_begin = now_s();
-  const bool device_ingest = !a.out_pairs && !a.host_ingest;  // pairs output needs read names: host parser
+  if (barcoded && a.out_sam) die("--SAM with cell barcodes (CB tag) is outside this build");
+  const bool device_ingest = !a.out_pairs && !a.out_sam && !a.host_ingest;  // pairs / SAM output need read names (and qualities): host parser
+  // --SAM: everything the final sort needs, over all batches
+  std::vector<cmgpu_sam_record> sam_rec;
+  std::vector<uint32_t> sam_cigar;
+  std::vector<std::vector<char>> sam_md_batches;
+  std::vector<uint32_t> sam_md_caps;
+  std::vector<uint64_t> sam_batch_slots;
+  std::vector<std::string> sam_names1, sam_names2;
+  std::vector<char> sam_b1, sam_q1, sam_b2, sam_q2;
+  std::vector<uint32_t> sam_o1(1, 0), sam_o2(1, 0);
   auto ck = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(ctx)); };
   if (device_ingest) {
     // ---- FASTQ text goes to the GPU in chunks; lines, records and the SoA batch are built there
@@ -370,6 +385,17 @@ int main(int argc, char **argv) {
           if (paired) { b2.insert(b2.end(), s2.begin(), s2.end()); o2.push_back((uint32_t)b2.size()); }
           if (barcoded) { bb.insert(bb.end(), sb.begin(), sb.end()); bq.insert(bq.end(), qb.begin(), qb.end()); bq.resize(bb.size(), 'I'); bo.push_back((uint32_t)bb.size()); }
           if (a.out_pairs) read_names.push_back(n1);
+          if (a.out_sam) {
+            q1.resize(s1.size(), 'I');
+            sam_names1.push_back(n1); sam_b1.insert(sam_b1.end(), s1.begin(), s1.end()); sam_q1.insert(sam_q1.end(), q1.begin(), q1.end());
+            if (sam_b1.size() > 0xfffffff0ull) die("--SAM holds all reads of a run in host memory with 32-bit offsets: input too large");
+            sam_o1.push_back((uint32_t)sam_b1.size());
+            if (paired) {
+              q2.resize(s2.size(), 'I');
+              sam_names2.push_back(n2); sam_b2.insert(sam_b2.end(), s2.begin(), s2.end()); sam_q2.insert(sam_q2.end(), q2.begin(), q2.end());
+              sam_o2.push_back((uint32_t)sam_b2.size());
+            }
+          }
           ++n;
         }
         if (n == 0) break;
@@ -394,8 +420,22 @@ int main(int argc, char **argv) {
           rc = cmgpu_map_single(ctx, &bt, nullptr, 0, &k, &st);
         }
         if (rc != CMGPU_OK) die(cmgpu_last_error(ctx));
-        // BED outputs: the records never leave HBM -- they join the device-side store
-        if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) die(cmgpu_last_error(ctx));
+        if (a.out_sam) {  // alignment records + CIGAR / MD pools of this batch
+          uint64_t slots = 0;
+          uint32_t cap = 0;
+          cmgpu_sam_layout(ctx, &slots, &cap);
+          const size_t base = sam_rec.size();
+          sam_rec.resize(base + slots);
+          sam_cigar.resize((base + slots) * CMGPU_SAM_CIGAR_CAP);
+          sam_md_batches.emplace_back((size_t)slots * cap + 1);
+          sam_md_caps.push_back(cap);
+          sam_batch_slots.push_back(slots);
+          if (cmgpu_download_sam(ctx, sam_rec.data() + base, sam_cigar.data() + base * CMGPU_SAM_CIGAR_CAP, sam_md_batches.back().data()) != CMGPU_OK)
+            die(cmgpu_last_error(ctx));
+        } else if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) {
+          // BED outputs: the records never leave HBM -- they join the device-side store
+          die(cmgpu_last_error(ctx));
+        }
         next_read_id += n;
         fprintf(stderr, "Mapped %u read%s.\n", n, paired ? " pairs" : "s");
       }
@@ -415,7 +455,24 @@ int main(int argc, char **argv) {
             (unsigned long long)st.num_barcode_in_whitelist, (unsigned long long)st.num_corrected_barcode);
   int64_t lines;
   uint64_t nl = 0, nbytes = 0;
-  if (a.out_pairs) {
+  if (a.out_sam) {
+    uint32_t cap = 1;
+    for (uint32_t c : sam_md_caps) cap = c > cap ? c : cap;
+    std::vector<char> md(sam_rec.size() * (size_t)cap + 1);
+    size_t slot0 = 0;
+    for (size_t b = 0; b < sam_md_batches.size(); ++b) {
+      for (uint64_t t = 0; t < sam_batch_slots[b]; ++t)
+        memcpy(md.data() + (slot0 + t) * cap, sam_md_batches[b].data() + t * sam_md_caps[b], sam_md_caps[b]);
+      slot0 += sam_batch_slots[b];
+    }
+    std::vector<const char *> n1(sam_names1.size()), n2(sam_names2.size() ? sam_names2.size() : 1, "");
+    for (size_t i = 0; i < sam_names1.size(); ++i) n1[i] = sam_names1[i].c_str();
+    for (size_t i = 0; i < sam_names2.size(); ++i) n2[i] = sam_names2[i].c_str();
+    lines = cmgpu_write_sam(ref.names, ref.lengths, ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0, sam_cigar.data(),
+                            md.data(), cap, n1.data(), n2.data(), sam_b1.data(), sam_q1.data(), sam_o1.data(),
+                            paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,
+                            a.out_path.c_str());
+  } else if (a.out_pairs) {
     std::vector<const char *> rn(read_names.size());
     for (size_t i = 0; i < rn.size(); ++i) rn[i] = read_names[i].c_str();
     lines = cmgpu_write_pairs(ref.names, ref.lengths, ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,

@@ -18,6 +18,8 @@ CM_DECL_LAUNCH(k_s5c_finalize)
 void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s);
 CM_DECL_LAUNCH(k_s6a_pair)
 CM_DECL_LAUNCH(k_s6c_multi)
+CM_DECL_LAUNCH(k_s6a_pair_sam)
+CM_DECL_LAUNCH(k_s6c_multi_sam)
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);
 void cm_launch_k_s0b_barcode(const CmDev &d, uint32_t n, hipStream_t s);
 void cm_launch_k_bc_abundance(const uint8_t *bcb, const uint32_t *bco, uint32_t lo, uint32_t hi, uint64_t *wl, uint32_t wl_mask,

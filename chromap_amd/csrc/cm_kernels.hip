@@ -90,8 +90,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_ite
   const uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x;
   if (j < n_items) cm_s5b_verify_item(d, j, n_reads);
 }
-CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair)
-CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi)
+// --SAM has its own instantiations: the alignment's register window must not cost the BED path occupancy
+CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair<false>)
+CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi<false>)
+CM_ITEM_KERNEL(k_s6a_pair_sam, cm_s6a_pair<true>)
+CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>)
 
 // S6b, one WAVE per taskloop chunk: the 64 lanes scan the chunk's n_best values coalesced
 // and ballot the multi-mappers; lane 0 then walks them in pair order with the chunk's
@@ -331,6 +334,8 @@ CM_LAUNCH(k_s4b_rescue_merge)
 CM_LAUNCH(k_s4c_reduce)
 CM_LAUNCH(k_s5a_prepare)
 CM_LAUNCH(k_s5c_finalize)
+CM_LAUNCH(k_s6a_pair_sam)
+CM_LAUNCH(k_s6c_multi_sam)
 void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_s5b_verify, grid_for(n_items), dim3(CM_BLOCK), 0, s, d, n_items, n_reads);
 }

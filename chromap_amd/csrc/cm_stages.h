@@ -2092,6 +2092,7 @@ CM_HD const int16_t *cm_d_err(const CmDev &d, uint32_t r, int strand) {
 // Build the output record for the chosen best pair: ProcessBestMappingsForPairedEndReadOn-
 // OneDirection (mapping_generator.h:487-653) + EmplaceBackPairedEndMappingRecord
 // (mapping_generator.cc:111-125) + PairedEndMappingInMemory getters (mapping_in_memory.h:64-108)
+template <bool SAM>
 CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   const int dir = (int)pe.f_dir;
@@ -2100,10 +2101,14 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   const uint64_t dp1 = cm_d_pos(d, r1, s1)[pe.f_i1], dp2 = cm_d_pos(d, r2, s2)[pe.f_i2];
   const int e1 = cm_d_err(d, r1, s1)[pe.f_i1], e2 = cm_d_err(d, r2, s2)[pe.f_i2];
   CmSamAln sa1, sa2;
-  const CmSpan a = d.p.sam ? cm_ref_start_end_sam(d, pair, r1, dp1, s1, cm_read_ptr(d, r1), (int)len1, &sa1)
-                           : cm_ref_start_end(d, dp1, e1, s1, cm_read_ptr(d, r1), (int)len1);
-  const CmSpan b = d.p.sam ? cm_ref_start_end_sam(d, pair, r2, dp2, s2, cm_read_ptr(d, r2), (int)len2, &sa2)
-                           : cm_ref_start_end(d, dp2, e2, s2, cm_read_ptr(d, r2), (int)len2);
+  CmSpan a, b;
+  if constexpr (SAM) {
+    a = cm_ref_start_end_sam(d, pair, r1, dp1, s1, cm_read_ptr(d, r1), (int)len1, &sa1);
+    b = cm_ref_start_end_sam(d, pair, r2, dp2, s2, cm_read_ptr(d, r2), (int)len2, &sa2);
+  } else {
+    a = cm_ref_start_end(d, dp1, e1, s1, cm_read_ptr(d, r1), (int)len1);
+    b = cm_ref_start_end(d, dp2, e2, s2, cm_read_ptr(d, r2), (int)len2);
+  }
   const uint16_t al1 = (uint16_t)(a.ref_end - a.ref_start + 1), al2 = (uint16_t)(b.ref_end - b.ref_start + 1);
   const int force_mapq = d.force0[pair] ? 0 : -1;
   const uint8_t mapq = cm_mapq_paired(d, pair, e1, e2, al1, al2, (int)len1, (int)len2, force_mapq, pe);
@@ -2125,7 +2130,7 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   o16[10] = (uint16_t)(ns.ref_end - ns.ref_start + 1);
   o16[11] = 0;
   d.rec_ok[pair] = 1;
-  if (d.p.sam) {  // EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108), flags mapping_generator.h:613-631
+  if constexpr (SAM) {  // EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108), flags mapping_generator.h:613-631
     const int tlen = (int)(ns.ref_end - ps.ref_start + 1);
     const bool plus1 = dir == 0;
     cm_put_sam_record(d, r1, d.first_read_id + pair, a, b.ref_start, (int32_t)b.rid, plus1 ? tlen : -tlen, 3u | (plus1 ? 32u : 16u) | 64u,
@@ -2315,6 +2320,7 @@ CM_HD void cm_split_pairing(const CmDev &d, uint32_t pair, int64_t want, CmPe &p
 // `choice`-th best mapping (draft mappings in emission order, + strand first), MAPQ with
 // max_num_error_difference = error_threshold, EmplaceBackSingleEndMappingRecord
 // <MappingWithoutBarcode> (mapping_generator.cc:7-16)
+template <bool SAM>
 CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice) {
   const uint32_t r = 2 * pair;
   const int me = d.min_err[r];
@@ -2328,8 +2334,9 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
       if (idx == choice) {
         const uint32_t L = d.rlen[r];
         CmSamAln sa;
-        const CmSpan sp = d.p.sam ? cm_ref_start_end_sam(d, pair, pair, dp[mi], strand, cm_read_ptr(d, r), (int)L, &sa)
-                                  : cm_ref_start_end(d, dp[mi], de[mi], strand, cm_read_ptr(d, r), (int)L);
+        CmSpan sp;
+        if constexpr (SAM) sp = cm_ref_start_end_sam(d, pair, pair, dp[mi], strand, cm_read_ptr(d, r), (int)L, &sa);
+        else sp = cm_ref_start_end(d, dp[mi], de[mi], strand, cm_read_ptr(d, r), (int)L);
         const uint16_t al = (uint16_t)(sp.ref_end - sp.ref_start + 1);
         const uint8_t mapq = cm_mapq_single(d, de[mi], al, (int)L, d.p.e, d.second_err[r], d.n_best[r], d.n_second[r], d.rep_len[r]);
         uint8_t *o = d.rec + (uint64_t)pair * 24;
@@ -2345,7 +2352,7 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
         o[17] = 1;
         o16[9] = 0; o16[10] = 0; o16[11] = 0;
         d.rec_ok[pair] = 1;
-        if (d.p.sam)  // EmplaceBackSingleEndMappingRecord<SAMMapping> (mapping_generator.cc:43-57), flag mapping_generator.h:321-326
+        if constexpr (SAM)  // EmplaceBackSingleEndMappingRecord<SAMMapping> (mapping_generator.cc:43-57), flag mapping_generator.h:321-326
           cm_put_sam_record(d, pair, d.first_read_id + pair, sp, 0, -1, 0, strand == 0 ? 0u : 16u, mapq, strand == 0 ? 1 : 0,
                             d.n_best[r] == 1 ? 1 : 0, sa, L);
         return;
@@ -2360,6 +2367,7 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
 //      (GenerateBestMappingsForPairedEndRead, mapping_generator.h:160-253), record for pairs
 //      with a single best pairing.
 // ---------------------------------------------------------------------------------------
+template <bool SAM = false>
 CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   d.rec_ok[pair] = 0;
@@ -2371,7 +2379,7 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
     if (nd1 == 0) return;
     d.pe_nbest[pair] = d.n_best[r1];
     d.pe_min[pair] = d.min_err[r1]; d.pe_second[pair] = d.second_err[r1]; d.pe_nsecond[pair] = d.n_second[r1];
-    if (d.n_best[r1] == 1) cm_emit_single_record(d, pair, 0);
+    if (d.n_best[r1] == 1) cm_emit_single_record<SAM>(d, pair, 0);
     return;
   }
   if (!(nd1 > 0 && nd2 > 0)) return;  // chromap.h:1092-1093
@@ -2400,7 +2408,7 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
   d.pe_min[pair] = pe.min_sum; d.pe_second[pair] = pe.second_sum;
   d.pe_nbest[pair] = pe.n_best; d.pe_nsecond[pair] = pe.n_second;
   d.pe_first[pair] = pe.f_dir; d.pe_i1[pair] = pe.f_i1; d.pe_i2[pair] = pe.f_i2;
-  if (pe.n_best == 1) cm_emit_record(d, pair, pe);
+  if (pe.n_best == 1) cm_emit_record<SAM>(d, pair, pe);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2493,6 +2501,7 @@ CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
 // ---------------------------------------------------------------------------------------
 // S6c: per pair -- record for multi-mappers (re-runs the sweeps to find the chosen pair)
 // ---------------------------------------------------------------------------------------
+template <bool SAM = false>
 CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
   const int nb = d.pe_nbest[pair];
   if (nb <= 1 || nb > d.p.drop_rep) return;
@@ -2501,7 +2510,7 @@ CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
   pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];
   pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
   const int64_t want = (int64_t)d.pe_choice[pair];
-  if (d.p.single) { cm_emit_single_record(d, pair, (uint32_t)want); return; }
+  if (d.p.single) { cm_emit_single_record<SAM>(d, pair, (uint32_t)want); return; }
   if (d.p.split) {
     CmPe sp;
     cm_split_pairing(d, pair, want, sp);
@@ -2518,7 +2527,7 @@ CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
                           d.ndp[r2], len1, len2, pe, want, pe.min_sum, &seen);
     if (!found) { d.stats[CM_ST_ERR] = 2; return; }
   }
-  cm_emit_record(d, pair, pe);
+  cm_emit_record<SAM>(d, pair, pe);
 }
 
 #endif  // CM_STAGES_H_

@@ -177,12 +177,12 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     d.sam_z = samz.data();
     memset(sam->rec, 0, (size_t)(single ? n : n2) * sizeof(cmgpu_sam_record));
   }
-  for (uint32_t i = 0; i < n; ++i) cm_s6a_pair(d, i);
+  for (uint32_t i = 0; i < n; ++i) { if (sam) cm_s6a_pair<true>(d, i); else cm_s6a_pair<false>(d, i); }
   const uint32_t nch = cm_num_chunks(n, (uint32_t)p.ref_batch, (uint32_t)p.grain);
   CmMt *g = new CmMt();
   for (uint32_t c = 0; c < nch; ++c) cm_s6b_sample(d, c, *g);
   delete g;
-  for (uint32_t i = 0; i < n; ++i) cm_s6c_multi(d, i);
+  for (uint32_t i = 0; i < n; ++i) { if (sam) cm_s6c_multi<true>(d, i); else cm_s6c_multi<false>(d, i); }
   uint64_t k = 0;
   for (uint32_t i = 0; i < n; ++i) {
     // k_stats

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 CLI = os.path.join(ds.ROOT, "chromap_amd", "chromap-amd")
 REF = os.path.join(ds.ROOT, "oracle", "_ref", "chromap")
 CASES = ["toy_atac", "s1_atac", "s2_atac_q0", "s3_chip", "h1_hic", "b1_atac_bc", "b2_atac_bc2_q0", "s1_se_chip", "s4_se_atac_q0",
-         "s4_inmem_q0", "s4_se_inmem_q0", "b1_inmem_bc", "s1_inmem_nodedup"]
+         "s4_inmem_q0", "s4_se_inmem_q0", "b1_inmem_bc", "s1_inmem_nodedup", "s1_chip_sam", "s3_sam_q0", "s2_atac_sam", "s1_se_sam"]
 
 
 def _reads(name):
@@ -107,6 +107,6 @@ def test_device_built_index_loads_in_reference(built, tmp_path):
 
 
 def test_cli_rejects_unknown_option(tmp_path):
-    r = subprocess.run([CLI, "--SAM", "-x", "x", "-r", os.path.join(ds.GOLD, "toy", "ref.fa"), "-1", "a", "-o",
+    r = subprocess.run([CLI, "--PAF", "-x", "x", "-r", os.path.join(ds.GOLD, "toy", "ref.fa"), "-1", "a", "-o",
                         str(tmp_path / "o")], stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"unsupported option" in r.stderr
