@@ -174,14 +174,17 @@ def main():
     def step(stats):
         k = g.map_resident(stats)
         if ex is not None:
-            n = C.c_uint64(0)
-            rc = g.L.cmgpu_records_to_device(g.ctx, C.c_void_p(ex.send.data_ptr()), args.pairs, C.byref(n))
+            # records grouped by chromosome owner -> all-to-all -> the owner's device-side record store
+            counts = (C.c_uint64 * world)()
+            rc = g.L.cmgpu_records_partition(g.ctx, world, C.c_void_p(ex.send.data_ptr()), args.pairs, counts)
             assert rc == 0
-            ex.all_gather(int(n.value))
+            nrecv = ex.all_to_all(list(counts))
+            g.store_append(ex.recv.data_ptr(), nrecv, on_device=True)
         return k
 
     for _ in range(args.warmup):
         step(Stats())
+    g.store_clear()
     stage_ms = {}
     st = Stats()
     if dist is not None:
@@ -302,7 +305,7 @@ def main():
             "config": {"workload": "--preset %s, synthetic 2x%d bp pairs (fragments 30-600 bp, 1%% substitutions), "
                                    "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7) resident per GPU, "
                                    "%d pairs per GPU per step, reads resident in HBM" % (args.preset, args.readlen, args.genome, args.nseq, args.pairs),
-                       "pairs_per_gpu_per_step": args.pairs, "parallelism": "read-shard x%d + RCCL all-gather of records" % world if world > 1 else "single GPU"},
+                       "pairs_per_gpu_per_step": args.pairs, "parallelism": "read-shard x%d + RCCL all-to-all of records to chromosome owners" % world if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu, "postprocess_on_device": post, "pcie_inclusive": pcie,
             "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
             "counters_per_step": {k: v // steps for k, v in s.items()},

@@ -94,7 +94,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_save_index_file", "cmgpu_destroy",
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_map_pairs_async", "cmgpu_wait", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
-           "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device",
+           "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device", "cmgpu_records_partition",
            "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
@@ -148,6 +148,7 @@ def declare(L):
     sig("cmgpu_write_pairs", C.c_int64, [P(C.c_char_p), P(C.c_uint32), C.c_uint32, P(Params), C.c_void_p, C.c_uint64,
                                          P(C.c_char_p), C.c_uint32, C.c_char_p])
     sig("cmgpu_map_single", C.c_int, [C.c_void_p, P(SingleBatch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
+    sig("cmgpu_records_partition", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, P(C.c_uint64)])
     sig("cmgpu_store_clear", C.c_int, [C.c_void_p])
     sig("cmgpu_store_append_resident", C.c_int, [C.c_void_p, P(C.c_uint64)])
     sig("cmgpu_store_append", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int])

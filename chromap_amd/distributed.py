@@ -1,6 +1,9 @@
 """Multi-GPU record exchange: read pairs shard across ranks with no
-data-path collective; the only exchange is one all-gather of the fixed-size 24-byte records
-so that every rank can sort + PCR-dedup the chromosome range it owns.  torch.distributed is
+data-path collective; the only exchange is one all-to-all of the fixed-size 24-byte records,
+each routed to the rank that owns its chromosome, so that every rank sorts + PCR-dedups the
+chromosome range it owns (on the device: cmgpu_records_partition -> all_to_all ->
+cmgpu_store_append -> cmgpu_store_format).  Every record crosses xGMI once: (N-1)/N of a rank's
+records leave it, against N-1 copies of everything with an all-gather.  torch.distributed is
 plumbing here ("nccl" == RCCL over xGMI on ROCm, "gloo" in the CPU tests)."""
 import numpy as np
 
@@ -41,6 +44,18 @@ def owned_rids(n_seq, rank, world):
     return [r for r in range(n_seq) if (r * world) // n_seq == rank]
 
 
+def owner_of_rid(rid, n_seq, world):
+    """rank that sorts / de-duplicates chromosome rid (same rule as cmgpu_records_partition)"""
+    return np.minimum((np.asarray(rid, dtype=np.uint64) * np.uint64(world)) // np.uint64(n_seq), world - 1).astype(np.int64)
+
+
+def partition_by_owner(records, n_seq, world):
+    """host twin of cmgpu_records_partition: (records grouped by owner rank, counts[world])"""
+    own = owner_of_rid(records["rid"], n_seq, world)
+    order = np.argsort(own, kind="stable")
+    return records[order], np.bincount(own, minlength=world).astype(np.int64)
+
+
 class RecordExchange:
     """all-gather of per-rank record buffers.  send: uint8 tensor [capacity*24] on the
     device the process group works with; count: number of valid records in it."""
@@ -63,6 +78,26 @@ class RecordExchange:
         self.dist.all_gather_into_tensor(self.cnts, self.cnt, group=self.group)
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         return self.cnts
+
+    def all_to_all(self, send_counts):
+        """send buffer holds sum(send_counts) records grouped by destination rank; returns the number of
+        records received (they sit at the front of self.recv, grouped by source rank)"""
+        torch, dist = self.torch, self.dist
+        sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=self.send.device)
+        rc = torch.zeros(self.world, dtype=torch.int64, device=self.send.device)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        rcv = [int(x) for x in rc.cpu().tolist()]
+        in_split = [int(x) * RECORD_BYTES for x in send_counts]
+        out_split = [x * RECORD_BYTES for x in rcv]
+        if sum(out_split) > self.recv.numel():
+            raise RuntimeError("receive buffer too small for the records owned by this rank")
+        dist.all_to_all_single(self.recv[:sum(out_split)], self.send[:sum(in_split)], out_split, in_split, group=self.group)
+        self.n_recv = sum(rcv)
+        return self.n_recv
+
+    def received_records(self):
+        raw = self.recv[:self.n_recv * RECORD_BYTES].cpu().numpy()
+        return np.frombuffer(raw.tobytes(), dtype=REC_DTYPE)
 
     def gathered_records(self):
         """numpy structured array of all ranks' records (host copy)"""

@@ -290,6 +290,9 @@ int cmgpu_export_index(cmgpu_ctx *ctx, uint64_t *buckets_out, uint64_t *occurren
 /* Dense copy of the resident batch's records into a caller-provided DEVICE buffer
  * (capacity in records) -- the send buffer of the multi-GPU record exchange. */
 int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity, uint64_t *n_out);
+/* Same, grouped by the rank that owns the record's chromosome (owner = rid * world / n_sequences):
+ * counts[r] records for rank r, in rank order -- the send buffer and split sizes of an all-to-all. */
+int cmgpu_records_partition(cmgpu_ctx *ctx, uint32_t world, void *device_dst, uint64_t capacity, uint64_t *counts);
 
 /* ---- --SAM --------------------------------------------------------------
  * With params.output_format == CMGPU_FORMAT_SAM the reported mappings are aligned with the

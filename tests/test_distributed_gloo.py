@@ -1,5 +1,6 @@
 """world_size-2 (gloo, CPU) run of the multi-GPU flow: shard pairs -> map each shard ->
-all-gather the 24-byte records -> chromosome owners sort + dedup -> BED sections in rid order.
+all-to-all of the 24-byte records to their chromosome owners -> owners sort + dedup -> BED sections
+in rid order.
 The mapping itself runs through tests/hostemu (the product's stage functions compiled for the
 host); the sharding / exchange / ownership code is chromap_amd/distributed.py, the one the GPU
 path uses with the nccl (RCCL) backend."""
@@ -31,7 +32,7 @@ def _worker(rank, world, port, case, outdir):
     import hostemu_lib as he
     import oracle_lib as ol
     from chromap_amd import _capi
-    from chromap_amd.distributed import REC_DTYPE, RecordExchange, owned_rids, shard_batches
+    from chromap_amd.distributed import REC_DTYPE, RecordExchange, owned_rids, partition_by_owner, shard_batches
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     meta = datasets.case_meta(case)
     fa, r1, r2 = datasets.case_inputs(case)
@@ -48,15 +49,16 @@ def _worker(rank, world, port, case, outdir):
         rec, k, _, _ = h.map_pairs(b1, o1[lo:hi + 1], b2, o2[lo:hi + 1], first_read_id=lo)
         mine.append(np.frombuffer(bytes(rec)[: k * 24], dtype=REC_DTYPE).copy())
     mine = np.concatenate(mine) if mine else np.zeros(0, REC_DTYPE)
-    ex = RecordExchange(n, torch.device("cpu"))
-    raw = torch.from_numpy(mine.view(np.uint8).copy())
-    ex.send[: raw.numel()] = raw
-    ex.all_gather(len(mine))
-    allrec = ex.gathered_records()
-    # owner-side sort + dedup + BED for the chromosomes this rank owns
     nseq = len(h.names)
+    ex = RecordExchange(n, torch.device("cpu"))
+    grouped, counts = partition_by_owner(mine, nseq, world)
+    raw = torch.from_numpy(grouped.view(np.uint8).copy())
+    ex.send[: raw.numel()] = raw
+    ex.all_to_all(counts)
+    sel = ex.received_records().copy()
+    # owner-side sort + dedup + BED for the chromosomes this rank owns
     own = set(owned_rids(nseq, rank, world))
-    sel = allrec[np.isin(allrec["rid"], list(own))].copy()
+    assert set(np.unique(sel["rid"]).tolist()) <= own
     buf = (C.c_uint8 * max(1, sel.nbytes)).from_buffer_copy(sel.tobytes() if sel.nbytes else b"\0")
     out = os.path.join(outdir, "part%d.bed" % rank)
     names = (C.c_char_p * nseq)(*h.names)

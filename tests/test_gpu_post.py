@@ -146,3 +146,33 @@ def test_empty_store_formats_to_nothing():
     assert g.store_format(_capi.TEXT_BED_PE) == (0, 0)
     assert g.store_text() == b""
     g.close()
+
+
+def test_records_partition_by_owner_matches_host_twin():
+    """send side of the multi-GPU exchange: records grouped by chromosome owner on the device"""
+    import torch
+    from chromap_amd import ChromapGPU
+    from chromap_amd.distributed import REC_DTYPE, partition_by_owner
+    case = "s3_chip"  # 5 chromosomes
+    fa, r1, r2 = datasets.case_inputs(case)
+    g = ChromapGPU(datasets.case_index(case), fa, preset="chip")
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    rec, k = g.map_pairs(b1, o1, b2, o2)
+    host = np.frombuffer(bytes(rec)[:k * 24], dtype=REC_DTYPE)
+    n = len(o1) - 1
+    for world in (1, 2, 3, 8):
+        send = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+        counts = (C.c_uint64 * world)()
+        assert g.L.cmgpu_records_partition(g.ctx, world, C.c_void_p(send.data_ptr()), n, counts) == 0
+        want, wc = partition_by_owner(host, len(g.names), world)
+        assert list(counts) == wc.tolist() and sum(counts) == k
+        got = np.frombuffer(send[:k * 24].cpu().numpy().tobytes(), dtype=REC_DTYPE)
+        # same multiset per destination rank (order inside a destination is irrelevant: a sort follows)
+        lo = 0
+        for r in range(world):
+            a = np.sort(got[lo:lo + wc[r]], order=["read_id"])
+            b = np.sort(want[lo:lo + wc[r]], order=["read_id"])
+            assert np.array_equal(a, b)
+            lo += wc[r]
+    g.close()
