@@ -57,8 +57,8 @@ def partition_by_owner(records, n_seq, world):
 
 
 class RecordExchange:
-    """all-gather of per-rank record buffers.  send: uint8 tensor [capacity*24] on the
-    device the process group works with; count: number of valid records in it."""
+    """exchange of per-rank record buffers.  send: uint8 tensor [capacity*24] on the device the
+    process group works with (all_to_all: grouped by destination rank); recv: world * capacity records."""
 
     def __init__(self, capacity, device, group=None):
         import torch
@@ -92,6 +92,9 @@ class RecordExchange:
         if sum(out_split) > self.recv.numel():
             raise RuntimeError("receive buffer too small for the records owned by this rank")
         dist.all_to_all_single(self.recv[:sum(out_split)], self.send[:sum(in_split)], out_split, in_split, group=self.group)
+        if self.recv.is_cuda:
+            # the caller hands recv to the C ABI (its own HIP stream) next: the collective must have landed
+            torch.cuda.current_stream(self.recv.device).synchronize()
         self.n_recv = sum(rcv)
         return self.n_recv
 
