@@ -316,6 +316,10 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   c->n_records = 0;
   if (n_out) *n_out = 0;
   if (n == 0) return CMGPU_OK;
+  if (c->max_read_len > CM_MAX_READ_LEN) {  // LDS staging of a block's reads (cm_kernels.hip: staging_geometry)
+    cm_set_error(c, "reads longer than " + std::to_string(CM_MAX_READ_LEN) + " bases are not supported");
+    return CMGPU_EINVAL;
+  }
   int rc = ensure_pair_arrays(c, n);
   if (rc) return rc;
   hipStream_t s = c->stream;

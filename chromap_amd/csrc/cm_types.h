@@ -27,6 +27,7 @@
 
 // Subset of MappingParameters used on the device.
 #define CM_SAM_CIGAR_CAP 64
+#define CM_MAX_READ_LEN 1400   // 16 pairs of reads per block must fit the LDS staging area (2 x 24 KB)
 struct CmParams {
   int32_t e;             // error_threshold
   int32_t min_seeds;     // min_num_seeds_required_for_mapping

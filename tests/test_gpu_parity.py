@@ -207,3 +207,58 @@ def test_async_submit_wait_equals_sync():
     with pytest.raises(Exception):
         g.wait()  # nothing in flight
     g.close()
+
+
+def _long_read_batch(fa_path, rng, n, lmin, lmax):
+    """pairs of long reads (lmin..lmax bases) cut from the reference with substitutions"""
+    seqs = [s for s in open(fa_path, "rb").read().split(b">")[1:]]
+    chroms = [b"".join(s.split(b"\n")[1:]) for s in seqs]
+    comp = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
+    r1s, r2s = [], []
+    for _ in range(n):
+        c = chroms[rng.integers(0, len(chroms))]
+        l1, l2 = int(rng.integers(lmin, lmax + 1)), int(rng.integers(lmin, lmax + 1))
+        fl = max(l1, l2) + int(rng.integers(0, 400))
+        st = int(rng.integers(0, len(c) - fl))
+        frag = bytearray(c[st:st + fl].upper())
+        for p in rng.integers(0, fl, min(5, fl // 60)):
+            frag[p] = ord("ACGT"[rng.integers(0, 4)])
+        frag = bytes(frag)
+        r1s.append(frag[:l1])
+        r2s.append(frag.translate(comp)[::-1][:l2])
+    def pack(ss):
+        off = np.zeros(len(ss) + 1, np.uint32)
+        off[1:] = np.cumsum([len(s) for s in ss])
+        return np.frombuffer(b"".join(ss), np.uint8).copy(), off
+    return pack(r1s) + pack(r2s)
+
+
+@pytest.mark.parametrize("lmin,lmax", [(240, 400), (900, 1000)])
+def test_long_reads_match_oracle(lmin, lmax):
+    """read lengths well above the usual 50-150: LDS staging geometry, trimming beyond the 2-bit fast
+    path, long Myers bands"""
+    from chromap_amd import ChromapGPU
+    case = "s3_chip"
+    fa, _, _ = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    b1, o1, b2, o2 = _long_read_batch(fa, np.random.default_rng(lmin), 600, lmin, lmax)
+    for preset in ("chip", "atac"):
+        g = ChromapGPU(idx, fa, preset=preset, mapq_threshold=0)
+        o = ol.Oracle(idx, fa, ol.params(preset, mapq_threshold=0))
+        rec, k = g.map_pairs(b1, o1, b2, o2)
+        orec, ok, ost, _ = o.map_pairs(b1, o1, b2, o2)
+        assert k == ok and k > 300
+        assert sorted(_rec_tuple(rec[i]) for i in range(k)) == sorted(_rec_tuple(orec[i]) for i in range(ok))
+        g.close()
+        o.close()
+
+
+def test_reads_beyond_the_supported_length_are_rejected():
+    from chromap_amd import ChromapError, ChromapGPU
+    fa, _, _ = datasets.case_inputs("toy_chip")
+    g = ChromapGPU(datasets.case_index("toy_chip"), fa, preset="chip")
+    b = np.frombuffer(b"ACGT" * 1000, np.uint8).copy()
+    off = np.array([0, len(b)], np.uint32)
+    with pytest.raises(ChromapError, match="longer than"):
+        g.map_pairs(b, off, b, off)
+    g.close()
