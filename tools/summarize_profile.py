@@ -38,6 +38,18 @@ def main():
             a = fe[k][0] / max(1, fe[k][1])
             b = wr[k][0] / max(1, wr[k][1])
             f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k, n, a, b, (a + b) * 1024 / 1e6))
+    ldsf = os.path.join(src, "lds", "bench_counter_collection.csv")
+    if os.path.exists(ldsf):
+        bc = pmc(ldsf, "SQ_LDS_BANK_CONFLICT")
+        ia = pmc(ldsf, "SQ_LDS_IDX_ACTIVE")
+        with open(os.path.join(dst, "pmc_lds.csv"), "w") as f:
+            f.write("kernel,launches,avg_SQ_LDS_BANK_CONFLICT,avg_SQ_LDS_IDX_ACTIVE,conflict_fraction\n")
+            for k in sorted(ia, key=lambda k: -ia[k][0]):
+                if ia[k][0] <= 0:
+                    continue
+                a = bc[k][0] / max(1, bc[k][1])
+                b = ia[k][0] / max(1, ia[k][1])
+                f.write("%s,%d,%.0f,%.0f,%.3f\n" % (k, ia[k][1], a, b, a / b if b else 0.0))
     out = {}
     for k in fe:
         if k.startswith("k_probe") and "reduce" not in k:
