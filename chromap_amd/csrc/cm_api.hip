@@ -333,19 +333,41 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     cm_launch_k_s0b_barcode(d, n, s);
     mark(c, "s0b_barcode");
   }
-  // S0 + S1a: length filter, adapter trimming, minimizer counts (reads staged through LDS)
-  cm_launch_k_prep_count(d, n, c->max_read_len, s);
-  cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
   uint32_t n_mm = 0;
-  HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, hipStreamSynchronize(s));
-  mark(c, "s0_s1a_trim_count");
-  if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
-      c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
-  cm_fill_dev(c, d);
-  // S1b: minimizers written to their dense positions
-  cm_launch_k_mm_fill(d, n, c->max_read_len, s);
-  mark(c, "s1b_minimizers");
+  if (cm_prep_mm_supported(d, c->max_read_len)) {
+    // S0 + S1 fused: one pass of the minimizer state machine, block-level reservation of the dense arrays
+    uint64_t cap = (uint64_t)n2 * (c->max_read_len / 4 + 3);
+    const uint64_t bound = (uint64_t)c->bases0 + c->bases1 + 1;  // one emission per k-mer position at most
+    if (cap > bound) cap = bound;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (cap > 0xfffffff0ull) { cm_set_error(c, "batch too large (minimizers)"); return CMGPU_ECAPACITY; }
+      if (c->mm_hash.ensure((size_t)cap * 8 + 8) || c->mm_ps.ensure((size_t)cap * 4 + 4) || c->pr_val.ensure((size_t)cap * 8 + 8) ||
+          c->pr_kind.ensure((size_t)cap + 4) || c->mm_cursor.ensure(8)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
+      cm_fill_dev(c, d);
+      HIPCHECK(c, hipMemsetAsync(c->mm_cursor.p, 0, 8, s));
+      cm_launch_k_prep_mm(d, n, c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
+      unsigned long long tot = 0;
+      HIPCHECK(c, hipMemcpyAsync(&tot, c->mm_cursor.p, 8, hipMemcpyDeviceToHost, s));
+      HIPCHECK(c, hipStreamSynchronize(s));
+      if (tot <= cap) { n_mm = (uint32_t)tot; break; }
+      if (attempt == 1) { cm_set_error(c, "minimizer arrays overflowed twice"); return CMGPU_ECAPACITY; }
+      cap = bound;  // rerun with the worst-case size
+    }
+    mark(c, "s0_s1_trim_minimizers");
+  } else {
+    // S0 + S1a: length filter, adapter trimming, minimizer counts (reads staged through LDS)
+    cm_launch_k_prep_count(d, n, c->max_read_len, s);
+    cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
+    HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(c, hipStreamSynchronize(s));
+    mark(c, "s0_s1a_trim_count");
+    if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
+        c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
+    cm_fill_dev(c, d);
+    // S1b: minimizers written to their dense positions
+    cm_launch_k_mm_fill(d, n, c->max_read_len, s);
+    mark(c, "s1b_minimizers");
+  }
   // S2: index probe (the graded kernel)
   if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
   cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);

@@ -66,6 +66,7 @@ struct cmgpu_ctx {
   CmFqStream fq[3];  // read 1, read 2, barcode
   // --SAM outputs of the last batch (cm_stages.h: cm_ref_start_end_sam)
   DevBuf sam_rec, sam_cigar, sam_md, sam_z;
+  DevBuf mm_cursor;  // k_prep_mm: next free entry of the dense minimizer arrays
   DevBuf part_k, part_v, part_tmp, part_cnt;  // cmgpu_records_partition scratch (kept across steps)
   uint64_t sam_slots = 0;
   uint32_t sam_md_cap = 0;
@@ -93,7 +94,7 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_k, &part_v, &part_tmp, &part_cnt};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_k, &part_v, &part_tmp, &part_cnt, &mm_cursor};
   }
 };
 

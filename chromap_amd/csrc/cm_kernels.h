@@ -8,6 +8,8 @@
 #define CM_DECL_LAUNCH(kname) void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s);
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
+bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len);
+void cm_launch_k_prep_mm(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, uint32_t mm_cap, unsigned long long *cursor, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
 CM_DECL_LAUNCH(k_s3b_candidates)
 CM_DECL_LAUNCH(k_s4a_rescue_count)

@@ -69,6 +69,72 @@ __global__ void k_mm_fill(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
   if (pair < p1) cm_s1_fill(d, 2 * pair + (t < PB ? 0 : 1), t < PB ? s.m0 : s.m1);
 }
 
+// S0 + S1 in ONE pass (k = 17..26, w = 7): the minimizer state machine runs once per read; its
+// emissions are staged in LDS ([entry][thread], one packed u64 = hash | (pos<<1|strand) << 2k),
+// the block scans its counts, reserves a range of the dense arrays with one atomic and copies
+// the staged entries out.  mm_off is therefore not monotone in the read index across blocks --
+// every consumer addresses a read's list through (mm_off[r], mm_cnt[r]).  A read with more than
+// `stg` minimizers (never seen: stg = L/4 + 4 against an expected (L-16)/4) recomputes straight
+// into its range.  Replaces k_prep_count + scan + k_mm_fill (two passes of ~150 integer ops per base).
+__global__ void k_prep_mm(CmDev d, uint32_t n_pairs, uint32_t lds_half, uint32_t stg, uint32_t mm_cap, unsigned long long *cursor) {
+  const uint32_t T = blockDim.x, PB = T >> 1;
+  const uint32_t p0 = blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
+  const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp;
+  const CmStaged s = cm_stage_pairs(d, p0, p1, pair, lds_half);
+  if (t < PB && pair < p1) cm_s0_prep_ptr(d, pair, s.m0, s.m1);
+  __syncthreads();
+  uint64_t *sh_e = reinterpret_cast<uint64_t *>(cm_lds + 2 * lds_half);
+  uint32_t *sh_w = reinterpret_cast<uint32_t *>(sh_e + (size_t)stg * T);  // wave totals [8], base lo/hi [2]
+  const bool valid = pair < p1;
+  const uint32_t r = 2 * pair + (t < PB ? 0 : 1);
+  const uint8_t *seq = t < PB ? s.m0 : s.m1;
+  const int k = d.p.k;
+  const uint32_t hb = 2 * (uint32_t)k;
+  uint32_t cnt = 0, len = 0;
+  if (valid) {
+    len = d.rlen[r];
+    cnt = cm_minimizers_window_e<7>(seq, len, k, [&](uint32_t n, uint64_t h, uint32_t p) {
+      if (n < stg) sh_e[(size_t)n * T + t] = h | ((uint64_t)p << hb);
+    });
+  }
+  // block exclusive scan of cnt
+  const uint32_t lane = t & 63, wave = t >> 6;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const uint32_t v = __shfl_up(incl, dlt, 64);
+    if (lane >= (uint32_t)dlt) incl += v;
+  }
+  if (lane == 63 || t == T - 1) sh_w[wave] = incl;
+  __syncthreads();
+  const uint32_t n_waves = (T + 63) >> 6;
+  if (t == 0) {
+    uint32_t tot = 0;
+    for (uint32_t wv = 0; wv < n_waves; ++wv) { const uint32_t x = sh_w[wv]; sh_w[wv] = tot; tot += x; }
+    const unsigned long long base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    sh_w[8] = (uint32_t)base;
+    sh_w[9] = (uint32_t)(base >> 32);
+  }
+  __syncthreads();
+  if (!valid) return;
+  const unsigned long long base = (unsigned long long)sh_w[8] | ((unsigned long long)sh_w[9] << 32);
+  const unsigned long long off64 = base + sh_w[wave] + (incl - cnt);
+  d.mm_cnt[r] = cnt;
+  d.mm_off[r] = (uint32_t)off64;
+  if (cnt == 0 || off64 + cnt > mm_cap) return;  // overflow of the dense arrays: the host sees cursor > mm_cap and reruns
+  const uint32_t off = (uint32_t)off64;
+  if (cnt <= stg) {
+    const uint64_t hmask = (1ull << hb) - 1;
+    for (uint32_t e = 0; e < cnt; ++e) {
+      const uint64_t v = sh_e[(size_t)e * T + t];
+      d.mm_hash[off + e] = v & hmask;
+      d.mm_ps[off + e] = (uint32_t)(v >> hb);
+    }
+  } else {
+    cm_minimizers_window<7>(seq, len, k, d.mm_hash + off, d.mm_ps + off, cnt);
+  }
+}
+
 CM_ITEM_KERNEL(k_s3a_count, cm_s3a_count)
 // S3b with the per-read hit list staged in LDS ([entry][thread] layout: 16 x 8-byte entries and
 // 16 count bytes per thread = 36 KB per block).  The first version sorted every list in its
@@ -348,6 +414,33 @@ static inline void staging_geometry(uint32_t max_read_len, uint32_t *threads, ui
   while (pb > 16 && (uint64_t)pb * max_read_len + 64 > 24 * 1024) pb >>= 1;
   *threads = 2 * pb;
   *lds_half = (uint32_t)(((uint64_t)pb * max_read_len + 64 + 15) & ~15ull);
+}
+// fused trim + minimizers: geometry (threads per block, LDS) from the longest read; false when the
+// configuration needs the two-pass kernels (other k / w, or reads too long for the LDS staging)
+static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *threads, uint32_t *half, uint32_t *stg, size_t *lds) {
+  if (d.p.w != 7 || 2 * d.p.k + 12 > 64 || max_read_len > 2047) return false;
+  *stg = max_read_len / 4 + 4;
+  uint32_t t = 256;
+  for (;; t >>= 1) {
+    *half = (uint32_t)(((uint64_t)(t / 2) * max_read_len + 64 + 15) & ~15ull);
+    *lds = 2 * (size_t)*half + (size_t)*stg * t * 8 + 64;
+    if (*lds <= 60 * 1024) break;
+    if (t == 64) return false;
+  }
+  *threads = t;
+  return true;
+}
+bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len) {
+  uint32_t t, h, g;
+  size_t l;
+  return prep_mm_geometry(d, max_read_len, &t, &h, &g, &l);
+}
+void cm_launch_k_prep_mm(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, uint32_t mm_cap, unsigned long long *cursor, hipStream_t s) {
+  uint32_t threads, half, stg;
+  size_t lds;
+  if (!n_pairs || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds)) return;
+  const uint32_t pb = threads / 2;
+  hipLaunchKernelGGL(k_prep_mm, dim3((n_pairs + pb - 1) / pb), dim3(threads), lds, s, d, n_pairs, half, stg, mm_cap, cursor);
 }
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s) {
   if (!n_pairs) return;

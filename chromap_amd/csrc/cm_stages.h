@@ -489,8 +489,8 @@ CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
 // `j = pib+1..w-1, then 0..pib` walk the ring oldest -> newest, "position_in_buffer ==
 // min_position" means the running minimum is the entry being evicted (mi < 0 after the
 // shift), and a palindromic k-mer neither writes nor advances (:42-45).
-template <int W>
-CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uint64_t *oh, uint32_t *op, uint32_t cap) {
+template <int W, class Emit>
+CM_HD uint32_t cm_minimizers_window_e(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
   uint32_t n = 0;
   const uint64_t shift = 2 * (uint64_t)(k - 1);
   const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
@@ -502,7 +502,7 @@ CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uin
 #pragma unroll
   for (int i = 0; i < W; ++i) { wh[i] = ~0ull; wp[i] = ~0u; }
   int unamb = 0, mi = 0;
-#define CM_EMIT(h, p) do { if (oh && n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
+#define CM_EMIT(h, p) do { emit(n, (h), (p)); ++n; } while (0)
   for (uint32_t pos = 0; pos < len; ++pos) {
     const uint32_t c = cm_c2u(seq[pos]);
     uint64_t cur_h = ~0ull;
@@ -552,6 +552,11 @@ CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uin
   if (min_h != ~0ull) CM_EMIT(min_h, min_p);
 #undef CM_EMIT
   return n;
+}
+
+template <int W>
+CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uint64_t *oh, uint32_t *op, uint32_t cap) {
+  return cm_minimizers_window_e<W>(seq, len, k, [&](uint32_t n, uint64_t h, uint32_t p) { if (oh && n < cap) { oh[n] = h; op[n] = p; } });
 }
 
 // generic window size: ring buffer in private memory, literal transcription
