@@ -27,6 +27,35 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cpu_baseline_reference(args):
+    """the reference binary itself (oracle/_ref/chromap, built unchanged from the reference sources; it
+    travels with the repo) on the host cores: tools/ref_baseline.py writes the same GRCh38-sized
+    synthetic index / genome in the reference's file formats and two bench batches as FASTQ, runs
+    `chromap --preset atac -t <nproc>` and chromap-amd on them and compares the BED files"""
+    import subprocess
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "chromap")
+    if not os.path.exists(ref_bin):
+        return None
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_baseline.py"), "--genome", str(args.genome), "--nseq",
+                        str(args.nseq), "--pairs", str(args.pairs), "--batches", "2", "--readlen", str(args.readlen)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    try:
+        r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except Exception:
+        return None
+    ref = r.get("reference", {})
+    if "error" in r or "error" in ref or not ref.get("mapped_all_reads_s"):
+        log("[bench] reference baseline unavailable: %s" % (r.get("error") or ref.get("error")))
+        return None
+    return {"value": ref["M_pairs_per_s_mapping_loop"], "unit": "M pairs/s", "cores": r["threads"], "kind": "reference",
+            "sample": "%d pairs (two bench batches, seeds 1000/1001) as FASTQ through oracle/_ref/chromap --preset atac -t %d with the "
+                      "GRCh38-sized index written by the device builder: %.2f s in its mapping loop (\"Mapped all reads in\"), "
+                      "%.2f s summed over its %d batches" % (r["pairs"], r["threads"], ref["mapped_all_reads_s"],
+                                                             ref["sum_of_batch_times_s"], ref["batches"]),
+            "bed_identical_to_reference": r.get("bed_identical_to_reference"),
+            "bed_lines": ref.get("bed_lines"), "chromap_amd_cli_same_files": r.get("chromap_amd", {}).get("cli")}
+
+
 def cpu_baseline(g, args, n_sample_hint):
     """oracle ("port") on the host cores, same index, same reads, bounded sample"""
     import numpy as np
@@ -130,6 +159,8 @@ def main():
     ap.add_argument("--readlen", type=int, default=50)
     ap.add_argument("--preset", default="atac")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["auto", "reference", "port"], default="auto",
+                    help="reference: oracle/_ref/chromap itself; port: the oracle restatement with OpenMP; auto: reference if its binary is here")
     ap.add_argument("--probe-repeat", type=int, default=10)
     ap.add_argument("--sam", action="store_true", help="--SAM mode: every reported read is aligned with the banded affine-gap DP "
                                                          "(CIGAR / NM / MD); not the headline metric")
@@ -294,7 +325,10 @@ def main():
         cpu = None
         if world == 1 and not args.skip_cpu and not args.sam:
             try:
-                cpu = cpu_baseline(g, args, args.pairs)
+                if args.cpu_baseline in ("auto", "reference"):
+                    cpu = cpu_baseline_reference(args)
+                if cpu is None and args.cpu_baseline in ("auto", "port"):
+                    cpu = cpu_baseline(g, args, args.pairs)
             except Exception as e:  # the GPU number must still be reported
                 cpu = {"value": None, "unit": "M pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         out = {

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""The REFERENCE itself (oracle/_ref/chromap, built unchanged from the reference sources by
+`make -C oracle ref`; the binary travels to the GPU box) on the bench workload, on the GPU box's host
+cores: GRCh38-sized synthetic genome + index written in the reference's formats by the device
+builder, synthetic pairs as FASTQ, `chromap --preset atac -t <nproc>`; then the same files through
+chromap-amd, and the two BED files compared.  Prints one JSON object."""
+import argparse
+import ctypes as C
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=3_100_000_000)
+    ap.add_argument("--nseq", type=int, default=24)
+    ap.add_argument("--pairs", type=int, default=4_000_000)
+    ap.add_argument("--batches", type=int, default=2)
+    ap.add_argument("--readlen", type=int, default=50)
+    ap.add_argument("--dir", default="/tmp/chromap_amd_ref")
+    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    args = ap.parse_args()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "chromap")
+    if not os.path.exists(ref_bin):
+        print(json.dumps({"error": "oracle/_ref/chromap not present"}))
+        return
+    os.makedirs(args.dir, exist_ok=True)
+    free = shutil.disk_usage(args.dir).free
+    need = int(args.genome * 7.5) + args.batches * args.pairs * 300
+    if free < need:
+        print(json.dumps({"error": "not enough disk in %s: %.0f GB free, %.0f GB needed" % (args.dir, free / 1e9, need / 1e9)}))
+        return
+    from e2e_bench import write_fastq
+    from chromap_amd import ChromapGPU
+    t0 = time.time()
+    g = ChromapGPU(synthetic=(args.genome, args.nseq, 12345), preset="atac")
+    idx = os.path.join(args.dir, "g.index")
+    fa = os.path.join(args.dir, "g.fa")
+    g.save_index(idx)
+    nseq = C.c_uint32(0)
+    g.L.cmgpu_reference_lengths(g.ctx, None, 0, C.byref(nseq))
+    lens = (C.c_uint32 * nseq.value)()
+    g.L.cmgpu_reference_lengths(g.ctx, lens, nseq.value, C.byref(nseq))
+    with open(fa, "wb") as f:
+        for i in range(nseq.value):
+            buf = C.create_string_buffer(lens[i])
+            assert g.L.cmgpu_export_reference(g.ctx, i, buf, lens[i]) == 0
+            f.write(b">chr%d\n" % (i + 1))
+            f.write(buf.raw[:lens[i]])
+            f.write(b"\n")
+    r1 = os.path.join(args.dir, "r1.fq")
+    r2 = os.path.join(args.dir, "r2.fq")
+    for f in (r1, r2):
+        if os.path.exists(f):
+            os.remove(f)
+    for b in range(args.batches):
+        g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=1000 + b)
+        b1, o1, b2, o2 = g.download_batch(args.pairs)
+        for path, bases in ((r1, b1), (r2, b2)):
+            tmp = path + ".part"
+            write_fastq(tmp, bases, args.pairs, args.readlen)
+            with open(path, "ab") as dst, open(tmp, "rb") as src:
+                shutil.copyfileobj(src, dst, 1 << 24)
+            os.remove(tmp)
+    g.close()
+    t_setup = time.time() - t0
+    n_pairs = args.pairs * args.batches
+    res = {"setup_s": round(t_setup, 1), "pairs": n_pairs, "threads": args.threads,
+           "index_bytes": os.path.getsize(idx), "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2)}
+    # ---- the reference
+    out_ref = os.path.join(args.dir, "ref.bed")
+    t0 = time.time()
+    p = subprocess.run([ref_bin, "--preset", "atac", "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_ref, "-t", str(args.threads)],
+                       stderr=subprocess.PIPE)
+    wall = time.time() - t0
+    log = p.stderr.decode(errors="replace")
+    if p.returncode != 0:
+        res["reference"] = {"error": log[-2000:]}
+    else:
+        m_all = re.search(r"Mapped all reads in ([0-9.]+)s", log)
+        per_batch = [float(x) for x in re.findall(r"Mapped \d+ read pairs in ([0-9.]+)s", log)]
+        res["reference"] = {"wall_s": round(wall, 2), "mapped_all_reads_s": float(m_all.group(1)) if m_all else None,
+                            "sum_of_batch_times_s": round(sum(per_batch), 3), "batches": len(per_batch),
+                            "M_pairs_per_s_mapping_loop": round(n_pairs / float(m_all.group(1)) / 1e6, 3) if m_all else None,
+                            "M_pairs_per_s_batches": round(n_pairs / sum(per_batch) / 1e6, 3) if per_batch else None,
+                            "bed_md5": subprocess.check_output(["md5sum", out_ref]).split()[0].decode(),
+                            "bed_lines": int(subprocess.check_output(["wc", "-l", out_ref]).split()[0])}
+    # ---- chromap-amd on the same files
+    out_gpu = os.path.join(args.dir, "gpu.bed")
+    cli = os.path.join(ROOT, "chromap_amd", "chromap-amd")
+    t0 = time.time()
+    p = subprocess.run([cli, "--preset", "atac", "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_gpu], stderr=subprocess.PIPE)
+    wall = time.time() - t0
+    log = p.stderr.decode(errors="replace")
+    if p.returncode != 0:
+        res["chromap_amd"] = {"error": log[-2000:]}
+    else:
+        tail = [ln for ln in log.splitlines() if ln.startswith("Mapped all reads")]
+        res["chromap_amd"] = {"wall_s_incl_index_load": round(wall, 2), "cli": tail,
+                              "bed_md5": subprocess.check_output(["md5sum", out_gpu]).split()[0].decode()}
+    if "bed_md5" in res.get("reference", {}) and "bed_md5" in res.get("chromap_amd", {}):
+        res["bed_identical_to_reference"] = res["reference"]["bed_md5"] == res["chromap_amd"]["bed_md5"]
+    shutil.rmtree(args.dir, ignore_errors=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
