@@ -1,0 +1,72 @@
+"""chromap-amd against the REFERENCE BINARY itself (oracle/_ref/chromap travels with the repo) on
+the GPU box, at sizes well above the committed golden cases: adversarial synthetic data from
+tools/gen_synth.py (repeats, N runs, indels, adapters, duplicates, chimeric Hi-C reads, barcodes
+with errors), index built on the device and loaded by BOTH programs, outputs compared byte for
+byte.  Skipped where the reference binary is not present."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import datasets as ds
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ds.ROOT, "chromap_amd", "chromap-amd")
+REF = os.path.join(ds.ROOT, "oracle", "_ref", "chromap")
+GEN = os.path.join(ds.ROOT, "tools", "gen_synth.py")
+
+DATA = {
+    "short": ["--genome", "20000000", "--chroms", "6", "--pairs", "150000", "--readlen", "50", "--frag-min", "35", "--seed", "101",
+              "--barcodes", "5000"],
+    "long": ["--genome", "20000000", "--chroms", "6", "--pairs", "100000", "--readlen", "150", "--frag-min", "300", "--frag-max", "800",
+             "--hic", "--seed", "102", "--indel", "0.002"],
+    "mid": ["--genome", "20000000", "--chroms", "6", "--pairs", "100000", "--readlen", "100", "--seed", "103", "--indel", "0.003",
+            "--sub", "0.02"],
+}
+# name -> (dataset, flags, single-end?, barcodes?)
+RUNS = {
+    "atac_pe": ("short", ["--preset", "atac"], False, False),
+    "atac_pe_q0_inmem": ("short", ["-l", "2000", "--trim-adapters", "--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"], False, False),
+    "atac_barcodes": ("short", ["--preset", "atac"], False, True),
+    "chip_se": ("short", ["--preset", "chip"], True, False),
+    "hic_pairs": ("long", ["--preset", "hic"], False, False),
+    "chip_sam": ("mid", ["--preset", "chip", "--SAM"], False, False),
+    "sam_se_q0": ("mid", ["--SAM", "-q", "0"], True, False),
+}
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    if not os.path.exists(REF):
+        pytest.skip("built reference binary not present")
+    assert os.path.exists(CLI)
+    made = {}
+
+    def get(name):
+        if name not in made:
+            d = str(tmp_path_factory.mktemp(name))
+            pre = os.path.join(d, "d")
+            subprocess.check_call([sys.executable, GEN, "--out", pre] + DATA[name])
+            idx = pre + ".idx"
+            subprocess.run([CLI, "-i", "-r", pre + ".fa", "-o", idx], check=True, stderr=subprocess.PIPE)
+            made[name] = (pre, idx)
+        return made[name]
+    return get
+
+
+@pytest.mark.parametrize("run", sorted(RUNS))
+def test_output_equals_reference_binary(run, data, tmp_path):
+    dset, flags, single, barcoded = RUNS[run]
+    pre, idx = data(dset)
+    reads = ["-1", pre + "_1.fq"] + ([] if single else ["-2", pre + "_2.fq"])
+    if barcoded:
+        reads += ["-b", pre + "_bc.fq", "--barcode-whitelist", pre + ".whitelist.txt"]
+    out_ref, out_gpu = str(tmp_path / "ref.out"), str(tmp_path / "gpu.out")
+    common = flags + ["-x", idx, "-r", pre + ".fa"] + reads
+    r = subprocess.run([REF] + common + ["-o", out_ref, "-t", "32"], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    g = subprocess.run([CLI] + common + ["-o", out_gpu], stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()[-2000:]
+    assert os.path.getsize(out_ref) > 100000
+    assert ds.md5(out_gpu) == ds.md5(out_ref)
