@@ -219,7 +219,7 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
 static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   const size_t n2 = 2 * (size_t)n;
 #define ENS(buf, bytes) if (c->buf.ensure(bytes)) { cm_set_error(c, "out of device memory (" #buf ")"); return CMGPU_ENOMEM; }
-  ENS(rlen, n2 * 4) ENS(cap, (n2 + 1) * 4) ENS(mm_cap_off, (n2 + 1) * 4) ENS(mm_cnt, (n2 + 1) * 4) ENS(mm_off, (n2 + 1) * 4)
+  ENS(rlen, n2 * 4) ENS(scratch_a, (n2 + 1) * 4) ENS(scratch_b, (n2 + 1) * 4) ENS(mm_cnt, (n2 + 1) * 4) ENS(mm_off, (n2 + 1) * 4)
   ENS(hit_tot, (n2 + 1) * 4) ENS(hit_off, (n2 + 1) * 4) ENS(round2, n2) ENS(rep_cnt, n2 * 4) ENS(rep_len, n2 * 4)
   ENS(n_pos_hit, n2 * 4) ENS(ncp, n2 * 4) ENS(ncn, n2 * 4) ENS(aug, n2) ENS(res_neg, n2 * 4) ENS(res_pos, n2 * 4)
   ENS(resc_n, n2 * 4) ENS(resc_p, n2 * 4) ENS(m_tot, (n2 + 1) * 4) ENS(m_off, (n2 + 1) * 4) ENS(mcp, n2 * 4) ENS(mcn, n2 * 4)
@@ -276,7 +276,7 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   d.rb0 = (const uint8_t *)c->rb0.p; d.rb1 = (const uint8_t *)c->rb1.p;
   d.ro0 = (const uint32_t *)c->ro0.p; d.ro1 = (const uint32_t *)c->ro1.p;
 #define PTR(f, T) d.f = (T *)c->f.p;
-  PTR(rlen, uint32_t) PTR(mm_cap_off, uint32_t) PTR(slot_hash, uint64_t) PTR(slot_ps, uint32_t) PTR(mm_cnt, uint32_t)
+  PTR(rlen, uint32_t) PTR(mm_cnt, uint32_t)
   PTR(mm_off, uint32_t) PTR(mm_hash, uint64_t) PTR(mm_ps, uint32_t) PTR(pr_val, uint64_t) PTR(pr_kind, uint8_t)
   PTR(hit_tot, uint32_t) PTR(hit_off, uint32_t) PTR(round2, uint8_t) PTR(rep_cnt, uint32_t) PTR(rep_len, uint32_t)
   PTR(hbuf, uint64_t) PTR(hcnt, uint8_t) PTR(n_pos_hit, uint32_t) PTR(ncp, uint32_t) PTR(ncn, uint32_t)
@@ -670,8 +670,7 @@ extern "C" int cmgpu_records_to_device(cmgpu_ctx *c, void *device_dst, uint64_t 
   const uint32_t n = c->n_pairs;
   *n_out = 0;
   if (n == 0) return CMGPU_OK;
-  // reuse cap / mm_cap_off as scratch (free between batches)
-  uint32_t *flag = (uint32_t *)c->cap.p, *pos = (uint32_t *)c->mm_cap_off.p;
+  uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
   hipLaunchKernelGGL(k_rec_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint8_t *)c->rec_ok.p, flag, n);
   cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, c->stream);
   hipLaunchKernelGGL(k_rec_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint8_t *)c->rec.p,

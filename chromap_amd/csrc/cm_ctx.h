@@ -47,7 +47,7 @@ struct cmgpu_ctx {
   uint32_t max_read_len = 1;
   DevBuf rb0, rb1, ro0, ro1;
   // per-read / per-pair arrays (names match CmDev)
-  DevBuf rlen, cap, mm_cap_off, slot_hash, slot_ps, mm_cnt, mm_off, mm_hash, mm_ps, pr_val, pr_kind;
+  DevBuf rlen, scratch_a, scratch_b /* 2n+1 u32 each, free between batches */, mm_cnt, mm_off, mm_hash, mm_ps, pr_val, pr_kind;
   DevBuf hit_tot, hit_off, round2, rep_cnt, rep_len, hbuf, hcnt, n_pos_hit, ncp, ncn;
   DevBuf aug, res_neg, res_pos, resc_n, resc_p, m_tot, m_off, mbuf, mcnt, mcp, mcn, force0;
   DevBuf fbuf, fcnt, fcp, fcn, alive, dpos, derr, dsplit, nv, v_off, v_err, v_end, ndp, ndn, min_err, second_err, n_best, n_second;
@@ -89,8 +89,8 @@ struct cmgpu_ctx {
     return v;
   }
   std::vector<DevBuf *> core_bufs() {
-    return {&bkt, &occ, &ref, &ref_off, &ref_len, &len_coef, &nsec_break, &rb0, &rb1, &ro0, &ro1, &rlen, &cap,
-            &mm_cap_off, &slot_hash, &slot_ps, &mm_cnt, &mm_off, &mm_hash, &mm_ps, &pr_val, &pr_kind, &hit_tot,
+    return {&bkt, &occ, &ref, &ref_off, &ref_len, &len_coef, &nsec_break, &rb0, &rb1, &ro0, &ro1, &rlen, &scratch_a,
+            &scratch_b, &mm_cnt, &mm_off, &mm_hash, &mm_ps, &pr_val, &pr_kind, &hit_tot,
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,

@@ -26,7 +26,6 @@ void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);
 void cm_launch_k_s0b_barcode(const CmDev &d, uint32_t n, hipStream_t s);
 void cm_launch_k_bc_abundance(const uint8_t *bcb, const uint32_t *bco, uint32_t lo, uint32_t hi, uint64_t *wl, uint32_t wl_mask,
                               unsigned long long *num_sample, hipStream_t s);
-void cm_launch_k_slot_cap(const CmDev &d, uint32_t n_reads, uint32_t *cap, hipStream_t s);
 size_t cm_probe_partial_words(uint32_t n);
 void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,
                        uint32_t n, void *partials, unsigned long long *counters, hipStream_t s);
@@ -37,11 +36,4 @@ size_t cm_scan_tmp_words(uint32_t n);
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
 void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, hipStream_t s);
 
-// synthetic reference / reads / index construction on the device (cm_synth.hip)
-struct CmSynthRef {
-  uint8_t *ref;        // device, with 64-byte zero gaps
-  uint64_t *ref_off;   // device [n_seq]
-  uint32_t *ref_len;   // device [n_seq]
-  uint64_t total_bytes;
-};
 #endif

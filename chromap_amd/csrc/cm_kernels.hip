@@ -245,14 +245,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_bc_abundance(const uint8_t *__rest
   if ((threadIdx.x & 63) == 0 && hit) atomicAdd(num_sample, (unsigned long long)hit);
 }
 
-// slot capacity of each read: one (hash,pos) per k-mer position at most
-__global__ __launch_bounds__(CM_BLOCK) void k_slot_cap(CmDev d, uint32_t n_reads, uint32_t *cap) {
-  const uint32_t r = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (r >= n_reads) return;
-  const uint32_t len = d.rlen[r];
-  cap[r] = len >= (uint32_t)d.p.k ? len - (uint32_t)d.p.k + 1 : 0;
-}
-
 // ---------------------------------------------------------------------------------------
 // The index-probe kernel (graded roofline kernel): one minimizer per thread, dependent
 // 16-byte bucket gathers from the HBM-resident table; memory-level parallelism comes from
@@ -473,9 +465,6 @@ void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials,
   const uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
   hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n, partials);
   hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(CM_BLOCK), 0, s, (const unsigned long long *)partials, blocks, d.stats);
-}
-void cm_launch_k_slot_cap(const CmDev &d, uint32_t n_reads, uint32_t *cap, hipStream_t s) {
-  if (n_reads) hipLaunchKernelGGL(k_slot_cap, grid_for(n_reads), dim3(CM_BLOCK), 0, s, d, n_reads, cap);
 }
 // partials: one uint2 per block (cm_probe_partial_words(n) uint2), or nullptr to skip the accounting;
 // counters[0] += probe steps, counters[1] += hits

@@ -295,7 +295,7 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
   if (n) {
     int rc = store_reserve(c, c->store_n + n, c->has_barcodes);
     if (rc) return rc;
-    uint32_t *flag = (uint32_t *)c->cap.p, *pos = (uint32_t *)c->mm_cap_off.p;  // free between batches
+    uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
     const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
     hipLaunchKernelGGL(k_pp_flag, g, b, 0, c->stream, (const uint8_t *)c->rec_ok.p, flag, n);
     cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, c->stream);
@@ -527,7 +527,7 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   DevBuf &k1 = c->part_k, &v1 = c->part_v, &tmp = c->part_tmp, &dcnt = c->part_cnt;
   auto fail = [&](int rc) { return rc; };
   if (k1.ensure((size_t)n * 4) || v1.ensure((size_t)n * 4) || dcnt.ensure(64 * 8)) { cm_set_error(c, "out of device memory (partition)"); return fail(CMGPU_ENOMEM); }
-  uint32_t *k0 = (uint32_t *)c->cap.p, *v0 = (uint32_t *)c->mm_cap_off.p;  // free between batches
+  uint32_t *k0 = (uint32_t *)c->scratch_a.p, *v0 = (uint32_t *)c->scratch_b.p;  // free between batches
   if (hipMemsetAsync(dcnt.p, 0, 64 * 8, s) != hipSuccess) return fail(CMGPU_EHIP);
   const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
   hipLaunchKernelGGL(k_pp_owner_key, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, k0, v0,

@@ -641,23 +641,9 @@ CM_HD void cm_s1_fill(const CmDev &d, uint32_t r, const uint8_t *seq) {
   if (n != cnt) d.stats[CM_ST_ERR] = 3;
 }
 
-CM_HD void cm_s1_minimizers(const CmDev &d, uint32_t r) {
-  const uint32_t len = d.rlen[r];
-  const uint8_t *seq = cm_read_ptr(d, r);
-  const uint32_t base = d.mm_cap_off[r];
-  const uint32_t cap = d.mm_cap_off[r + 1] - base;
-  uint64_t *oh = d.slot_hash + base;
-  uint32_t *op = d.slot_ps + base;
-  uint32_t n = d.p.w == 7 ? cm_minimizers_window<7>(seq, len, d.p.k, oh, op, cap)
-                          : cm_minimizers_ring(seq, len, d.p.k, d.p.w, oh, op, cap);
-  if (n > cap) { n = cap; d.stats[CM_ST_ERR] = 1; }  // cannot happen: <= one emission per k-mer position
-  // BothEndsHaveMinimizers gate (chromap.h:936) is applied by the consumer via mm_cnt
-  d.mm_cnt[r] = n;
-}
-
 // ---------------------------------------------------------------------------------------
 // Reference minimizers for index construction (Index::Construct, index.cc:19-23), one
-// chunk of `chunk` positions per item.  The state machine is the one of cm_s1_minimizers;
+// chunk of `chunk` positions per item.  The state machine is the one of cm_minimizers_window;
 // it is started `warm` positions early (>= 2w+k, so ring buffer, running minimum and the
 // unambiguous-length thresholds have converged to the sequential pass's state before the
 // first owned position) and run w+2 positions past the chunk; an emission is kept only
@@ -739,14 +725,6 @@ CM_HD uint32_t cm_ref_chunk_minimizers(const uint8_t *seq, uint32_t len, uint32_
   return n;
 }
 
-// S1b: copy a read's minimizers from its slot range to the dense arrays
-CM_HD void cm_s1b_compact(const CmDev &d, uint32_t r) {
-  const uint32_t n = d.mm_cnt[r], src = d.mm_cap_off[r], dst = d.mm_off[r];
-  for (uint32_t i = 0; i < n; ++i) {
-    d.mm_hash[dst + i] = d.slot_hash[src + i];
-    d.mm_ps[dst + i] = d.slot_ps[src + i];
-  }
-}
 
 // ---------------------------------------------------------------------------------------
 // S2: index probe of ONE minimizer (kh_get, khash.h:232-245, with the hash/equality of

@@ -87,9 +87,6 @@ struct CmDev {
   uint8_t *bc_ok;              // [n] CorrectBarcodeAt's return value
   // ---- per read
   uint32_t *rlen;       // length after trimming; 0 when the pair was dropped
-  uint32_t *mm_cap_off; // [2n+1] prefix of slot capacities (max(0, raw_len-k+1))
-  uint64_t *slot_hash;  // slot arrays
-  uint32_t *slot_ps;    // (pos<<1)|strand
   uint32_t *mm_cnt;     // [2n]
   uint32_t *mm_off;     // [2n+1] dense prefix
   uint64_t *mm_hash;    // dense

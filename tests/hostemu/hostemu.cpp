@@ -81,7 +81,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   memset(st, 0, sizeof(st));
   d.stats = st;
 #define VEC(name, T, cnt) std::vector<T> v_##name((size_t)(cnt) + 1); d.name = v_##name.data();
-  VEC(rlen, uint32_t, n2) VEC(mm_cap_off, uint32_t, n2 + 1) VEC(mm_cnt, uint32_t, n2) VEC(mm_off, uint32_t, n2 + 1)
+  VEC(rlen, uint32_t, n2) VEC(mm_cnt, uint32_t, n2) VEC(mm_off, uint32_t, n2 + 1)
   VEC(hit_tot, uint32_t, n2) VEC(hit_off, uint32_t, n2 + 1) VEC(round2, uint8_t, n2) VEC(rep_cnt, uint32_t, n2)
   VEC(rep_len, uint32_t, n2) VEC(n_pos_hit, uint32_t, n2) VEC(ncp, uint32_t, n2) VEC(ncn, uint32_t, n2)
   VEC(aug, uint8_t, n2) VEC(res_neg, int32_t, n2) VEC(res_pos, int32_t, n2) VEC(resc_n, uint32_t, n2) VEC(resc_p, uint32_t, n2)
