@@ -103,7 +103,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
-TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC = 0, 1, 2
+TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC, TEXT_TAGALIGN_PE, TEXT_TAGALIGN_PE_BC = 0, 1, 2, 3, 4
 
 _LIB = None
 

@@ -106,7 +106,7 @@ struct Args {
   std::string index_path, ref_path, out_path, preset, barcode_file, whitelist;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
-  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false;
+  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
   size_t chunk_bytes = 256u << 20;
   int k = 17, w = 7, device = 0;
   uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
@@ -173,6 +173,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "--low-mem") a.p.low_memory_mode = 1;
     else if (o == "--BED") { a.out_bed = true; a.out_pairs = false; a.out_sam = false; }
     else if (o == "--SAM") { a.out_sam = true; a.out_bed = false; a.out_pairs = false; }
+    else if (o == "--TagAlign") { a.out_tagalign = true; a.out_bed = true; a.out_sam = false; a.out_pairs = false; }
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
     else if (o == "--device") a.device = atoi(need("--device"));
@@ -186,7 +187,7 @@ static Args parse(int argc, char **argv) {
              "       --remove-pcr-duplicates --Tn5-shift --low-mem --BED|--pairs --bc-error-threshold ...]\n");
       exit(0);
     }
-    else die("unsupported option " + o + " (PAF/TagAlign, --chr-order and summary outputs are outside this build)");
+    else die("unsupported option " + o + " (PAF, --chr-order and summary outputs are outside this build)");
   }
   if (a.out_sam) {
     if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
@@ -479,7 +480,8 @@ int main(int argc, char **argv) {
                               a.out_path.c_str());
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
-    const int kind = barcoded ? CMGPU_TEXT_BED_PE_BC : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
+    const int kind = a.out_tagalign && paired ? (barcoded ? CMGPU_TEXT_TAGALIGN_PE_BC : CMGPU_TEXT_TAGALIGN_PE)
+                                              : barcoded ? CMGPU_TEXT_BED_PE_BC : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
     const double t0 = now_s();
     if (cmgpu_store_format(ctx, kind, ref.names, ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
     const double t1 = now_s();

@@ -72,6 +72,8 @@ __device__ __forceinline__ PpRec pp_load(const uint8_t *store, uint32_t i) {
   return r;
 }
 
+__host__ __device__ __forceinline__ bool pp_has_bc(int kind) { return kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_TAGALIGN_PE_BC; }
+__host__ __device__ __forceinline__ bool pp_tagalign(int kind) { return kind == CMGPU_TEXT_TAGALIGN_PE || kind == CMGPU_TEXT_TAGALIGN_PE_BC; }
 // Tn5Shift (bed_mapping.h:48-54, 100-106, 165-170, 224-229)
 __device__ __forceinline__ void pp_tn5(PpRec &r, int kind) {
   if (kind == CMGPU_TEXT_BED_SE) {
@@ -79,6 +81,8 @@ __device__ __forceinline__ void pp_tn5(PpRec &r, int kind) {
   } else {
     r.start += 4;
     r.len = (uint16_t)(r.len - 9);
+    r.pal = (uint16_t)(r.pal - 4);
+    r.nal = (uint16_t)(r.nal - 5);
   }
 }
 
@@ -111,7 +115,7 @@ __device__ __forceinline__ bool pp_same_run(const PpRec &a, uint64_t bca, const 
   if (a.rid != b.rid || a.start != b.start) return false;
   if (cfg.kind == CMGPU_TEXT_BED_SE) return true;          // bed_mapping.h:91-94
   if (a.len != b.len) return false;                        // :216-219
-  return cfg.kind != CMGPU_TEXT_BED_PE_BC || bca == bcb;   // :154-159
+  return !pp_has_bc(cfg.kind) || bca == bcb;               // :154-159
 }
 
 __device__ __forceinline__ uint32_t pp_digits(uint32_t v) {
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
   if (j >= n) return;
   uint32_t wi = idx[j];
   PpRec r = pp_load(store, wi);
-  const uint64_t rbc = cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[wi] : 0;
+  const uint64_t rbc = pp_has_bc(cfg.kind) ? bc[wi] : 0;
   PpRec rs = r;  // the run identity is evaluated on what was sorted (shifted first in in-memory mode)
   if (cfg.inmem && cfg.tn5) pp_tn5(rs, cfg.kind);
   uint32_t dups = 1;
@@ -137,13 +141,13 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
       const uint32_t pi = idx[j - 1];
       PpRec p = pp_load(store, pi);
       if (cfg.inmem && cfg.tn5) pp_tn5(p, cfg.kind);
-      if (pp_same_run(p, cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[pi] : 0, rs, rbc, cfg)) { line_len[j] = 0; return; }
+      if (pp_same_run(p, pp_has_bc(cfg.kind) ? bc[pi] : 0, rs, rbc, cfg)) { line_len[j] = 0; return; }
     }
     for (uint32_t t = j + 1; t < n; ++t) {
       const uint32_t qi = idx[t];
       PpRec q = pp_load(store, qi), qs = q;
       if (cfg.inmem && cfg.tn5) pp_tn5(qs, cfg.kind);
-      if (!pp_same_run(rs, rbc, qs, cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[qi] : 0, cfg)) break;
+      if (!pp_same_run(rs, rbc, qs, pp_has_bc(cfg.kind) ? bc[qi] : 0, cfg)) break;
       ++dups;
       if (cfg.inmem || q.mapq > r.mapq) { r = q; wi = qi; }
     }
@@ -152,9 +156,18 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
   if (cfg.tn5) pp_tn5(r, cfg.kind);
   if (dups > 255) dups = 255;
   const uint32_t nm = name_off[r.rid + 1] - name_off[r.rid];
-  uint32_t len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
-  if (cfg.kind == CMGPU_TEXT_BED_PE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;      // chr start end barcode dups
-  else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
+  uint32_t len;
+  if (pp_tagalign(cfg.kind)) {
+    // two lines (mapping_writer.cc:84-117, 138-168): the + read's and the - read's alignment; bulk data
+    // prints num_dups on the second line, single-cell data prints neither barcode nor num_dups
+    const uint32_t pe = r.start + r.pal, ne = r.start + r.len, ns = ne - r.nal;
+    len = 2 * (nm + 1 + 2 + pp_digits(r.mapq) + 1 + 1 + 1) + pp_digits(r.start) + 1 + pp_digits(pe) + 1 + pp_digits(ns) + 1 + pp_digits(ne) + 1;
+    if (cfg.kind == CMGPU_TEXT_TAGALIGN_PE) len += 1 + pp_digits(dups);
+  } else {
+    len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
+    if (cfg.kind == CMGPU_TEXT_BED_PE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;      // chr start end barcode dups
+    else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
+  }
   win[j] = wi;
   dups_out[j] = dups;
   line_len[j] = len;
@@ -169,6 +182,24 @@ __device__ __forceinline__ uint8_t *pp_put_u32(uint8_t *p, uint32_t v) {
 __device__ __forceinline__ void pp_render(uint8_t *p, const PpRec &r, uint64_t bcv, uint32_t dups, const PpCfg &cfg,
                                           const uint8_t *__restrict__ names, const uint32_t *__restrict__ name_off) {
   const uint32_t n0 = name_off[r.rid], n1 = name_off[r.rid + 1];
+  if (pp_tagalign(cfg.kind)) {
+    const uint32_t pe = r.start + r.pal, ne = r.start + r.len, ns = ne - r.nal;
+    for (int half = 0; half < 2; ++half) {
+      const bool plus = (half == 0) == (r.dir != 0);  // the + read's line comes first when read 1 is on the + strand
+      for (uint32_t i = n0; i < n1; ++i) *p++ = names[i];
+      *p++ = '\t';
+      p = pp_put_u32(p, plus ? r.start : ns);
+      *p++ = '\t';
+      p = pp_put_u32(p, plus ? pe : ne);
+      *p++ = '\t'; *p++ = 'N'; *p++ = '\t';
+      p = pp_put_u32(p, r.mapq);
+      *p++ = '\t';
+      *p++ = plus ? '+' : '-';
+      if (half == 1 && cfg.kind == CMGPU_TEXT_TAGALIGN_PE) { *p++ = '\t'; p = pp_put_u32(p, dups); }
+      *p++ = '\n';
+    }
+    return;
+  }
   for (uint32_t i = n0; i < n1; ++i) *p++ = names[i];
   *p++ = '\t';
   p = pp_put_u32(p, r.start);
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_format(const uint8_t *__restric
     PpRec r = pp_load(store, win[j]);
     if (cfg.tn5) pp_tn5(r, cfg.kind);
     const uint64_t off = line_off[j];
-    pp_render(staged ? lds + (off - base) : text + off, r, cfg.kind == CMGPU_TEXT_BED_PE_BC ? bc[win[j]] : 0, dups[j], cfg, names,
+    pp_render(staged ? lds + (off - base) : text + off, r, pp_has_bc(cfg.kind) ? bc[win[j]] : 0, dups[j], cfg, names,
               name_off);
   }
   if (!staged) return;
@@ -356,9 +387,9 @@ struct PpLinesOp {
 extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
                                   uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes) {
   if (!c || !names || !p || !n_lines || !n_bytes) return CMGPU_EINVAL;
-  if (kind != CMGPU_TEXT_BED_PE && kind != CMGPU_TEXT_BED_SE && kind != CMGPU_TEXT_BED_PE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
-  if ((kind == CMGPU_TEXT_BED_PE_BC) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
-  if (kind == CMGPU_TEXT_BED_PE_BC && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
+  if (kind < CMGPU_TEXT_BED_PE || kind > CMGPU_TEXT_TAGALIGN_PE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
+  if (pp_has_bc(kind) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
+  if (pp_has_bc(kind) && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
   PPCHECK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   *n_lines = 0;
@@ -395,7 +426,7 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   hipLaunchKernelGGL(k_pp_key0, g, b, 0, s, store, n, ka, va);
   if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 40))) return fail(rc);
   std::swap(va, vb);
-  if (kind == CMGPU_TEXT_BED_PE_BC) {
+  if (pp_has_bc(kind)) {
     hipLaunchKernelGGL(k_pp_key_bc, g, b, 0, s, bc, (const uint32_t *)va, n, ka);
     if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 2 * barcode_length))) return fail(rc);
     std::swap(va, vb);

@@ -349,6 +349,8 @@ int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_length
 #define CMGPU_TEXT_BED_PE 0
 #define CMGPU_TEXT_BED_SE 1
 #define CMGPU_TEXT_BED_PE_BC 2
+#define CMGPU_TEXT_TAGALIGN_PE 3    /* --TagAlign, paired-end bulk: two lines per fragment (src/mapping_writer.cc:84-117) */
+#define CMGPU_TEXT_TAGALIGN_PE_BC 4 /* --TagAlign, single-cell (src/mapping_writer.cc:138-168) */
 int cmgpu_store_clear(cmgpu_ctx *ctx);
 /* appends the records of the last cmgpu_map_* call (still resident); n_total = store size */
 int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);

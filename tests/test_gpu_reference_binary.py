@@ -30,6 +30,9 @@ RUNS = {
     "atac_pe_q0_inmem": ("short", ["-l", "2000", "--trim-adapters", "--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"], False, False),
     "atac_barcodes": ("short", ["--preset", "atac"], False, True),
     "chip_se": ("short", ["--preset", "chip"], True, False),
+    "atac_tagalign": ("short", ["--preset", "atac", "--TagAlign"], False, False),
+    "atac_tagalign_barcodes": ("short", ["--preset", "atac", "--TagAlign"], False, True),
+    "chip_tagalign_se_q0": ("short", ["--preset", "chip", "--TagAlign", "-q", "0"], True, False),
     "hic_pairs": ("long", ["--preset", "hic"], False, False),
     "chip_sam": ("mid", ["--preset", "chip", "--SAM"], False, False),
     "sam_se_q0": ("mid", ["--SAM", "-q", "0"], True, False),
