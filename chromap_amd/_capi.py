@@ -26,7 +26,7 @@ PARAM_FIELDS = ("error_threshold", "min_num_seeds", "max_seed_frequency0", "max_
                 "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
                 "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_memory_mode",
                 "read_batch_size", "taskloop_grain_size", "bc_error_threshold", "output_mappings_not_in_whitelist",
-                "output_format", "bc_probability_threshold")
+                "output_format", "dedup_at_bulk_level", "bc_probability_threshold")
 
 
 class Params(C.Structure):

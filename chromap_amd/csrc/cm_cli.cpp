@@ -221,9 +221,7 @@ int main(int argc, char **argv) {
   if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
   const bool barcoded = !a.barcode_file.empty();
   if (barcoded && (a.whitelist.empty() || !paired)) die("this build supports barcodes only with a whitelist and paired-end reads");
-  if (barcoded && a.p.remove_pcr_duplicates && a.p.low_memory_mode && !a.cell_level_dedup)
-    die("bulk-level duplicate removal for single-cell data (mapping_writer.h:205-208) is outside this build; "
-        "use --remove-pcr-duplicates-at-cell-level (as --preset atac does)");
+  a.p.dedup_at_bulk_level = barcoded && !a.cell_level_dedup ? 1 : 0;  // remove_pcr_duplicates_at_bulk_level defaults to true (mapping_parameters.h:49)
   cmgpu_index_view idx;
   if (cmgpu_load_index_file(a.index_path.c_str(), &idx) != 0) die("Cannot read index " + a.index_path);
   fprintf(stderr, "Kmer size: %d, window size: %d.\n", idx.kmer_size, idx.window_size);

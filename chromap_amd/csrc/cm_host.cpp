@@ -324,6 +324,8 @@ extern "C" int64_t cmgpu_write_bed_pe_bc(const char *const *names, uint32_t n_se
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
   const bool inmem = !p->low_memory_mode;
+  // bulk-level duplicate removal needs the whitelist abundances, which live on the device: cmgpu_store_format does it
+  if (p->dedup_at_bulk_level && !inmem && p->remove_pcr_duplicates) { fclose(f); return CMGPU_EINVAL; }
   if (inmem && p->tn5_shift)
     for (uint64_t t = 0; t < n; ++t) { rec[t].r.fragment_start += 4; rec[t].r.fragment_length -= 9; }
   std::sort(rec, rec + n, [](const cmgpu_record_bc &a, const cmgpu_record_bc &b) {

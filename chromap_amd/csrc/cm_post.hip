@@ -46,6 +46,9 @@ struct PpCfg {
   int mapq_thr;
   uint32_t n_seq;
   uint32_t bc_len;
+  int bulk;       // single-cell data, duplicate removal at bulk level (mapping_writer.h:202-345)
+  const uint64_t *wl;  // whitelist table {key, abundance} (cm_api.hip: cmgpu_set_whitelist), linear probing
+  uint32_t wl_mask;
 };
 
 struct PpRec {  // cmgpu_record, read with two 8-byte loads + one 8-byte load
@@ -123,6 +126,17 @@ __device__ __forceinline__ uint32_t pp_digits(uint32_t v) {
        : v < 100000000 ? 8 : v < 1000000000 ? 9 : 10;
 }
 
+__device__ __forceinline__ uint32_t pp_abundance(const PpCfg &cfg, uint64_t key) {
+  const uint64_t x = key * 0x9E3779B97F4A7C15ull;
+  uint32_t b = (uint32_t)(x >> 32) & cfg.wl_mask;
+  for (;;) {
+    const uint64_t k = cfg.wl[2 * (uint64_t)b];
+    if (k == key) return (uint32_t)cfg.wl[2 * (uint64_t)b + 1];
+    if (k == ~0ull) return 0;
+    b = (b + 1) & cfg.wl_mask;
+  }
+}
+
 // survivor index (into the store), num_dups and line length per sorted position (0 = no line)
 __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restrict__ store, const uint64_t *__restrict__ bc,
                                                           const uint32_t *__restrict__ idx, uint32_t n, PpCfg cfg,
@@ -136,6 +150,45 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
   PpRec rs = r;  // the run identity is evaluated on what was sorted (shifted first in in-memory mode)
   if (cfg.inmem && cfg.tn5) pp_tn5(rs, cfg.kind);
   uint32_t dups = 1;
+  bool bulk_done = false;
+  if (cfg.dedup && cfg.bulk) {
+    // bulk-level runs: same (rid, start, length) whatever the barcode; barcode groups are consecutive.
+    // A group is represented by its last record and weighs 1 (single record) or 2 (any larger group);
+    // FindBestMappingIndexFromDuplicates: larger weight, then larger abundance, first on ties.
+    if (j > 0) {
+      PpRec p = pp_load(store, idx[j - 1]);
+      if (p.rid == r.rid && p.start == r.start && p.len == r.len) { line_len[j] = 0; return; }
+    }
+    uint32_t t = j, best_i = wi, best_nd = 0, best_ab = 0, maxq_mapq = r.mapq;
+    bool have = false;
+    while (t < n) {
+      const uint32_t gi = idx[t];
+      const PpRec gr = pp_load(store, gi);
+      if (gr.rid != r.rid || gr.start != r.start || gr.len != r.len) break;
+      const uint64_t gb = bc[gi];
+      uint32_t u = t + 1, rep = gi, gsize = 1;
+      if (gr.mapq > maxq_mapq) maxq_mapq = gr.mapq;
+      while (u < n) {
+        const uint32_t qi = idx[u];
+        const PpRec q = pp_load(store, qi);
+        if (q.rid != r.rid || q.start != r.start || q.len != r.len || bc[qi] != gb) break;
+        if (q.mapq > maxq_mapq) maxq_mapq = q.mapq;
+        rep = qi;
+        ++gsize;
+        ++u;
+      }
+      const uint32_t nd = gsize >= 2 ? 2u : 1u, ab = pp_abundance(cfg, gb);
+      if (!have || nd > best_nd || (nd == best_nd && ab > best_ab)) { have = true; best_i = rep; best_nd = nd; best_ab = ab; }
+      t = u;
+    }
+    dups = t - j;
+    wi = best_i;
+    r = pp_load(store, wi);
+    // the very last run of the output is filtered on the run's maximal MAPQ (mapping_writer.h:331-337)
+    const uint32_t filter_mapq = t == n ? maxq_mapq : (uint32_t)r.mapq;
+    if ((int)filter_mapq < cfg.mapq_thr) { line_len[j] = 0; return; }
+    bulk_done = true;
+  } else
   if (cfg.dedup) {
     if (j > 0) {
       const uint32_t pi = idx[j - 1];
@@ -152,7 +205,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
       if (cfg.inmem || q.mapq > r.mapq) { r = q; wi = qi; }
     }
   }
-  if ((int)r.mapq < cfg.mapq_thr || r.rid >= cfg.n_seq) { line_len[j] = 0; return; }
+  if ((!bulk_done && (int)r.mapq < cfg.mapq_thr) || r.rid >= cfg.n_seq) { line_len[j] = 0; return; }
   if (cfg.tn5) pp_tn5(r, cfg.kind);
   if (dups > 255) dups = 255;
   const uint32_t nm = name_off[r.rid + 1] - name_off[r.rid];
@@ -406,6 +459,10 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   cfg.mapq_thr = p->mapq_threshold;
   cfg.n_seq = n_sequences;
   cfg.bc_len = barcode_length;
+  cfg.bulk = pp_has_bc(kind) && p->dedup_at_bulk_level && p->low_memory_mode && p->remove_pcr_duplicates;
+  cfg.wl = (const uint64_t *)c->wl.p;
+  cfg.wl_mask = c->wl_mask;
+  if (cfg.bulk && c->wl_size == 0) { cm_set_error(c, "bulk-level duplicate removal needs the whitelist abundances (cmgpu_set_whitelist)"); return CMGPU_EINVAL; }
   // names -> device
   std::vector<uint32_t> noff(n_sequences + 1, 0);
   std::string blob;

@@ -80,6 +80,8 @@ typedef struct cmgpu_params {
   int32_t bc_error_threshold;     /* --bc-error-threshold (0 or 1 supported on the device) */
   int32_t output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
   int32_t output_format;          /* 0: BED / pairs records; CMGPU_FORMAT_SAM: --SAM (alignment coordinates, CIGAR, NM, MD) */
+  int32_t dedup_at_bulk_level;    /* single-cell BED, low-memory flavour: --remove-pcr-duplicates-at-bulk-level (the reference's
+                                   * default without --preset atac); applied by cmgpu_store_format only */
   double bc_probability_threshold; /* --bc-probability-threshold */
 } cmgpu_params;
 

@@ -2525,6 +2525,56 @@ long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc 
   return lines;
 }
 
+/* Single-cell BED with duplicate removal at BULK level (the default for barcoded data without
+ * --preset atac; low-memory merge only, mapping_writer.h:202-345): a run is every record with the
+ * same (rid, start, length) regardless of barcode.  Inside a run the records of one barcode are
+ * consecutive; each barcode group is represented by its last record with num_dups_ = 1 for a
+ * single record and 2 for any larger group (the merge assigns the incoming record, whose num_dups_
+ * is 1, and then adds one: :257-263).  FindBestMappingIndexFromDuplicates (:124-163) takes the
+ * group with the larger num_dups_, then the larger whitelist abundance, first one on ties.  The
+ * line carries num_dups = min(255, run size).  The MAPQ filter looks at the chosen record -- except
+ * for the very last run of the output, where it looks at the first record with the maximal MAPQ of
+ * the run (:331-337 test before the replacement). */
+long ora_write_bed_pe_bc_bulk(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
+                              const ora_whitelist *w, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  qsort(rec, (size_t)n, sizeof(ora_record_bc), cmp_rec_bc);
+  long lines = 0, i = 0;
+  char bcs[40];
+  while (i < n) {
+    long j = i + 1;
+    while (j < n && rec[j].r.rid == rec[i].r.rid && rec[j].r.fragment_start == rec[i].r.fragment_start &&
+           rec[j].r.fragment_length == rec[i].r.fragment_length) ++j;
+    long best = -1, maxq = i;
+    uint32_t best_nd = 0, best_ab = 0;
+    for (long g = i; g < j;) {
+      long h = g + 1;
+      while (h < j && rec[h].barcode == rec[g].barcode) ++h;
+      const uint32_t nd = h - g >= 2 ? 2 : 1;
+      int found = 0;
+      const uint32_t slot = wl_slot(w, rec[g].barcode, &found);
+      const uint32_t ab = found ? w->cnt[slot] : 0;
+      if (best < 0 || nd > best_nd || (nd == best_nd && ab > best_ab)) { best = h - 1; best_nd = nd; best_ab = ab; }
+      g = h;
+    }
+    for (long t = i + 1; t < j; ++t) if (rec[t].r.mapq > rec[maxq].r.mapq) maxq = t;
+    const uint8_t filter_mapq = j == n ? rec[maxq].r.mapq : rec[best].r.mapq;
+    if (filter_mapq >= p->mapq_threshold) {
+      ora_record r = rec[best].r;
+      const uint32_t dups = (uint32_t)(j - i);
+      if (p->tn5_shift) { r.fragment_start += 4; r.fragment_length -= 9; }
+      for (uint32_t b = 0; b < barcode_length; ++b) bcs[b] = u2c((uint8_t)((rec[best].barcode >> ((barcode_length - 1 - b) * 2)) & 3));
+      bcs[barcode_length] = 0;
+      fprintf(f, "%s\t%u\t%u\t%s\t%u\n", ref->name[r.rid], r.fragment_start, r.fragment_start + r.fragment_length, bcs, dups > 255 ? 255u : dups);
+      ++lines;
+    }
+    i = j;
+  }
+  fclose(f);
+  return lines;
+}
+
 typedef struct { vchar b, q; uint32_t *off; size_t n, cap; } fqq_acc;
 long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t **off) {
   FILE *f = fopen(path, "rb");

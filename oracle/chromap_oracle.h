@@ -60,6 +60,7 @@ typedef struct ora_params {
   int bc_error_threshold;               /* --bc-error-threshold, 1 */
   int output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
   int output_format;                    /* 0: BED / pairs records, 1: --SAM (ksw alignment, CIGAR, NM, MD) */
+  int dedup_at_bulk_level;              /* single-cell data: --remove-pcr-duplicates-at-bulk-level (ora_write_bed_pe_bc_bulk) */
   double bc_probability_threshold;      /* --bc-probability-threshold, 0.9 */
 } ora_params;
 
@@ -220,6 +221,9 @@ long ora_map_pairs_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_i
 long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
                          const char *out_path);
 /* FASTQ with qualities: returns n, allocates bases, quals (same offsets) and off */
+/* same with duplicate removal at bulk level (--remove-pcr-duplicates-at-bulk-level, the default without --preset atac) */
+long ora_write_bed_pe_bc_bulk(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
+                              const ora_whitelist *w, const char *out_path);
 long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t **off);
 
 /* single-end reads (chromap.h:385-472): bulk records, positive/negative_alignment_length 0 */

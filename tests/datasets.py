@@ -92,6 +92,9 @@ def flags_to_params(flags):
         elif flags[i] == "--bc-error-threshold":
             kw["bc_error_threshold"] = int(flags[i + 1])
             i += 2
+        elif flags[i] == "--remove-pcr-duplicates-at-bulk-level":
+            kw["dedup_at_bulk_level"] = 1
+            i += 1
         elif flags[i] == "--SAM":
             kw["output_format"] = 1
             i += 1

@@ -58,6 +58,10 @@ CASES = {
                         "--seed", "5"], ["--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"]),
     "b1_inmem_bc": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
                      "--barcodes", "500", "--seed", "31"], ["-l", "2000", "--remove-pcr-duplicates", "--Tn5-shift", "--trim-adapters"]),
+    # single-cell, duplicate removal at bulk level (default without --preset atac)
+    "b3_bulk_level_bc_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "30000", "--readlen", "50", "--frag-min", "40",
+                             "--barcodes", "40", "--seed", "33", "--dup-frac", "0.3"],
+                            ["--preset", "atac", "--remove-pcr-duplicates-at-bulk-level", "-q", "0"]),
     "s1_inmem_nodedup": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
                          ["-l", "2000", "--Tn5-shift"]),
     # --SAM: ksw alignment, CIGAR / NM / MD, SAMMapping sort + dedup

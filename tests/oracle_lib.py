@@ -24,7 +24,7 @@ class OraParams(C.Structure):
         "error_threshold", "min_num_seeds", "max_seed_freq0", "max_seed_freq1", "max_insert_size",
         "min_read_length", "max_num_best_mappings", "drop_repetitive_reads", "trim_adapters",
         "split_alignment", "mapq_threshold", "remove_pcr_duplicates", "tn5_shift", "low_mem", "bc_error_threshold",
-        "output_mappings_not_in_whitelist", "output_format")] + [("bc_probability_threshold", C.c_double)]
+        "output_mappings_not_in_whitelist", "output_format", "dedup_at_bulk_level")] + [("bc_probability_threshold", C.c_double)]
 
 
 class OraRecord(C.Structure):
@@ -305,6 +305,15 @@ def write_bed_bc(oracle, rec, k, barcode_length, path):
     L.ora_write_bed_pe_bc.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_uint32, C.c_char_p]
     return L.ora_write_bed_pe_bc(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, barcode_length,
                                  path.encode())
+
+
+def write_bed_bc_bulk(oracle, rec, k, barcode_length, wl, path):
+    L = oracle.L
+    L.ora_write_bed_pe_bc_bulk.restype = C.c_long
+    L.ora_write_bed_pe_bc_bulk.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_uint32, C.c_void_p,
+                                           C.c_char_p]
+    return L.ora_write_bed_pe_bc_bulk(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, barcode_length, wl.h,
+                                      path.encode())
 
 
 def map_single(oracle, b, off, threads=1):

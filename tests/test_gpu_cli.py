@@ -15,7 +15,7 @@ import datasets as ds
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(ds.ROOT, "chromap_amd", "chromap-amd")
 REF = os.path.join(ds.ROOT, "oracle", "_ref", "chromap")
-CASES = ["toy_atac", "s1_atac", "s2_atac_q0", "s3_chip", "h1_hic", "b1_atac_bc", "b2_atac_bc2_q0", "s1_se_chip", "s4_se_atac_q0",
+CASES = ["toy_atac", "s1_atac", "s2_atac_q0", "s3_chip", "h1_hic", "b1_atac_bc", "b2_atac_bc2_q0", "b3_bulk_level_bc_q0", "s1_se_chip", "s4_se_atac_q0",
          "s4_inmem_q0", "s4_se_inmem_q0", "b1_inmem_bc", "s1_inmem_nodedup", "s1_chip_sam", "s3_sam_q0", "s2_atac_sam", "s1_se_sam"]
 
 

@@ -102,7 +102,7 @@ def test_hic_pairs_match_reference(case, tmp_path):
     g.close()
 
 
-@pytest.mark.parametrize("case", datasets.BC_CASES)
+@pytest.mark.parametrize("case", [c for c in datasets.BC_CASES if "bulk_level" not in c])
 def test_barcoded_bed_matches_reference(case, tmp_path):
     """scATAC: whitelist + abundance + barcode correction (K6) on the device, barcoded BED"""
     from chromap_amd import ChromapGPU

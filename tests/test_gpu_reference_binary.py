@@ -29,6 +29,7 @@ RUNS = {
     "atac_pe": ("short", ["--preset", "atac"], False, False),
     "atac_pe_q0_inmem": ("short", ["-l", "2000", "--trim-adapters", "--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"], False, False),
     "atac_barcodes": ("short", ["--preset", "atac"], False, True),
+    "barcodes_bulk_level_dedup": ("short", ["--preset", "atac", "--remove-pcr-duplicates-at-bulk-level", "-q", "0"], False, True),
     "chip_se": ("short", ["--preset", "chip"], True, False),
     "atac_tagalign": ("short", ["--preset", "atac", "--TagAlign"], False, False),
     "atac_tagalign_barcodes": ("short", ["--preset", "atac", "--TagAlign"], False, True),

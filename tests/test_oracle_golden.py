@@ -74,7 +74,10 @@ def _check_barcode_case(case, meta, o, b1, o1, b2, o2, tmp_path):
     assert wl.abundance(bc, bco) > 0
     rec, k, st, n_in, n_corr = ol.map_pairs_bc(o, b1, o1, b2, o2, bc, bcq, bco, wl, threads=2)
     out = str(tmp_path / "o.bed")
-    ol.write_bed_bc(o, rec, k, wl.barcode_length, out)
+    if o.p.dedup_at_bulk_level and o.p.low_mem and o.p.remove_pcr_duplicates:
+        ol.write_bed_bc_bulk(o, rec, k, wl.barcode_length, wl, out)
+    else:
+        ol.write_bed_bc(o, rec, k, wl.barcode_length, out)
     got = open(out, "rb").read()
     assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
     ref = meta["reference_stderr_counters"]
