@@ -74,3 +74,23 @@ def test_output_equals_reference_binary(run, data, tmp_path):
     assert g.returncode == 0, g.stderr.decode()[-2000:]
     assert os.path.getsize(out_ref) > 100000
     assert ds.md5(out_gpu) == ds.md5(out_ref)
+
+
+@pytest.mark.parametrize("k,w", [(21, 11), (15, 5), (27, 7)])
+def test_other_kmer_and_window_sizes(k, w, data, tmp_path):
+    """non-default index geometry: ring-buffer minimizers (w != 7), two-pass kernels (k > 26), index
+    built by either program and read by the other"""
+    pre, _ = data("short")
+    idx_ref, idx_gpu = str(tmp_path / "ref.idx"), str(tmp_path / "gpu.idx")
+    subprocess.run([REF, "-i", "-k", str(k), "-w", str(w), "-r", pre + ".fa", "-o", idx_ref], check=True, stderr=subprocess.PIPE)
+    subprocess.run([CLI, "-i", "-k", str(k), "-w", str(w), "-r", pre + ".fa", "-o", idx_gpu], check=True, stderr=subprocess.PIPE)
+    reads = ["-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    outs = {}
+    for prog, tag in ((REF, "ref"), (CLI, "gpu")):
+        for idx, itag in ((idx_ref, "refidx"), (idx_gpu, "gpuidx")):
+            out = str(tmp_path / ("%s_%s.bed" % (tag, itag)))
+            cmd = [prog, "--preset", "atac", "-q", "0", "-x", idx, "-r", pre + ".fa"] + reads + ["-o", out] + (["-t", "32"] if prog == REF else [])
+            r = subprocess.run(cmd, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            outs[(tag, itag)] = ds.md5(out)
+    assert len(set(outs.values())) == 1, outs
