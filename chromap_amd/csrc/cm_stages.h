@@ -1387,9 +1387,62 @@ CM_HD int cm_banded_traceback_t(int e, int min_num_errors, const PS &pat, const 
   return start;
 }
 
+// ---------------------------------------------------------------------------------------
+// The first thing BandedTraceback does (alignment.cc:660-670) is a raw, case-sensitive Hamming
+// count of the read against the window at offset e; when it equals the edit distance the start is e
+// and nothing else runs -- the common case (substitution errors only).  Here that count works on
+// 8 bytes at a time in registers (aligned 8-byte loads + funnel shift, SWAR byte compare) instead
+// of byte-wise through the prefetched copies; for the - strand the read bytes are reversed and
+// complemented with the same mapping as cm_negchar (PrepareNegativeSequenceAt).
+// Reads up to 15 bytes past `pat + L` / the read's chunk: the buffers are padded (cm_api.hip).
+// ---------------------------------------------------------------------------------------
+CM_HD uint64_t cm_load8(const uint8_t *p) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t sh = (uint32_t)(a & 7) * 8;
+  const uint64_t *ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+  const uint64_t lo = ap[0];
+  if (sh == 0) return lo;
+  return (lo >> sh) | (ap[1] << (64 - sh));
+}
+CM_HD uint64_t cm_swar_eq(uint64_t v, uint64_t k) {  // 0xFF in every byte of v equal to the byte k, else 0x00
+  const uint64_t z = v ^ (k * 0x0101010101010101ull);
+  const uint64_t m = ~(((z & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | z) & 0x8080808080808080ull;
+  return (m >> 7) * 0xFFull;
+}
+CM_HD uint64_t cm_swar_negchar(uint64_t v) {
+  const uint64_t u = v & 0xDFDFDFDFDFDFDFDFull;
+  const uint64_t mA = cm_swar_eq(u, 'A'), mC = cm_swar_eq(u, 'C'), mG = cm_swar_eq(u, 'G'), mT = cm_swar_eq(u, 'T');
+  return (mA & 0x5454545454545454ull) | (mC & 0x4747474747474747ull) | (mG & 0x4343434343434343ull) | (mT & 0x4141414141414141ull) |
+         (~(mA | mC | mG | mT) & 0x4E4E4E4E4E4E4E4Eull);
+}
+CM_HD uint64_t cm_bswap64(uint64_t v) {
+  v = ((v & 0x00FF00FF00FF00FFull) << 8) | ((v >> 8) & 0x00FF00FF00FF00FFull);
+  v = ((v & 0x0000FFFF0000FFFFull) << 16) | ((v >> 16) & 0x0000FFFF0000FFFFull);
+  return (v << 32) | (v >> 32);
+}
+CM_HD int cm_swar_diff_bytes(uint64_t x) {  // number of non-zero bytes
+  x |= x >> 1; x |= x >> 2; x |= x >> 4;
+  return (int)__builtin_popcountll(x & 0x0101010101010101ull);
+}
+// #{ i in [0,L) : pat[i] != text(i) }, text = (neg ? revcomp(read[0..Lfull)) : read) + toff
+CM_HD int cm_hamming_diag(const uint8_t *pat, const uint8_t *read, int Lfull, bool neg, int toff, int L) {
+  int cnt = 0, i = 0;
+  if (!neg) {
+    const uint8_t *t = read + toff;
+    for (; i + 8 <= L; i += 8) cnt += cm_swar_diff_bytes(cm_load8(pat + i) ^ cm_load8(t + i));
+    for (; i < L; ++i) cnt += pat[i] != t[i];
+  } else {
+    const int R = Lfull - 1 - toff;  // text(i) = negchar(read[R - i])
+    for (; i + 8 <= L; i += 8) cnt += cm_swar_diff_bytes(cm_load8(pat + i) ^ cm_swar_negchar(cm_bswap64(cm_load8(read + (R - i - 7)))));
+    for (; i < L; ++i) cnt += pat[i] != cm_negchar(read[R - i]);
+  }
+  return cnt;
+}
+
 CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg,
                               int toff, int L) {
   if (min_num_errors == 0) return e;
+  if (cm_hamming_diag(pattern + e, read, Lfull, neg, toff, L) == min_num_errors) return e;
   CmBytes pb, tb;
   if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
     const CmText<CmBytes> txt{tb, Lfull, neg, toff};

@@ -300,3 +300,11 @@ extern "C" int hostemu_map_single_sam(const cmgpu_index_view *index, const cmgpu
   const EmuSam sam{rec, cigar, md, md_cap};
   return emu_map_pairs(index, ref, params, &b, out.data(), &k, stats, nullptr, nullptr, nullptr, nullptr, nullptr, true, &sam);
 }
+
+// cm_hamming_diag against the plain loop it replaces (BandedTraceback's first step), for tests
+extern "C" int hostemu_hamming(const uint8_t *pat, const uint8_t *read, int Lfull, int neg, int toff, int L, int *naive) {
+  int c = 0;
+  for (int i = 0; i < L; ++i) c += pat[i] != cm_text_char(read, Lfull, toff + i, neg != 0);
+  *naive = c;
+  return cm_hamming_diag(pat, read, Lfull, neg != 0, toff, L);
+}

@@ -84,3 +84,40 @@ def test_trim_lengths_match_oracle(seed, minlen):
         trimmed += rlen[2 * i] != len(r1s[i]) or rlen[2 * i + 1] != len(r2s[i])
     assert trimmed > 200
     o.close()
+
+
+def test_swar_hamming_equals_byte_loop():
+    """cm_hamming_diag (8 bytes at a time, reversed + complemented for the - strand) against the loop
+    it replaces: every alignment of both pointers, lengths 1..150, N / lower case / other bytes"""
+    L = he.lib()
+    L.hostemu_hamming.restype = C.c_int
+    L.hostemu_hamming.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTNacgtn*", np.uint8)
+    comp = bytes.maketrans(b"ACGTNacgtn", b"TGCANTGCAN")
+    for trial in range(3000):
+        Lfull = int(rng.integers(1, 151))
+        toff = int(rng.integers(0, Lfull)) if rng.random() < 0.3 else 0
+        Ln = int(rng.integers(1, Lfull - toff + 1))
+        neg = int(rng.integers(0, 2))
+        read = alphabet[rng.integers(0, len(alphabet), Lfull)]
+        text = bytes(read) if not neg else bytes(read).translate(comp)[::-1]
+        text = text[toff:toff + Ln]
+        pat = bytearray(text if rng.random() < 0.7 else bytes(alphabet[rng.integers(0, len(alphabet), Ln)]))
+        for p in rng.integers(0, Ln, int(rng.integers(0, 4))):
+            pat[p] = int(alphabet[rng.integers(0, len(alphabet))])
+        # buffers with padding and arbitrary alignment of both pointers
+        oa, ob = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+        bufp = np.zeros(oa + Ln + 32, np.uint8)
+        bufr = np.zeros(ob + Lfull + 32, np.uint8)
+        bufp[oa:oa + Ln] = np.frombuffer(bytes(pat), np.uint8)
+        bufr[ob:ob + Lfull] = read
+        base_p = (bufp.ctypes.data + 7) & ~7
+        base_r = (bufr.ctypes.data + 7) & ~7
+        # re-place the data at the chosen offsets from an 8-aligned base inside the arrays
+        pp = np.zeros(Ln + 48, np.uint8); rr = np.zeros(Lfull + 48, np.uint8)
+        sp = (-pp.ctypes.data) % 8 + oa; sr = (-rr.ctypes.data) % 8 + 8 + ob
+        pp[sp:sp + Ln] = np.frombuffer(bytes(pat), np.uint8); rr[sr:sr + Lfull] = read
+        naive = C.c_int(0)
+        got = L.hostemu_hamming(pp.ctypes.data + sp, rr.ctypes.data + sr, Lfull, neg, toff, Ln, C.byref(naive))
+        assert got == naive.value, (trial, Lfull, toff, Ln, neg)
