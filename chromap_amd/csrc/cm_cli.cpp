@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <chrono>
+#include <thread>
 
 #include <string>
 #include <vector>
@@ -300,7 +301,12 @@ int main(int argc, char **argv) {
         uint32_t cnt[3] = {0, 0, 0};
         bool all_final = true;
         double t0 = now_s();
-        for (int m = 0; m < ns_streams; ++m) rd[m].fill(target);
+        {  // one reader thread per file: gzip inflation of read 1 / read 2 / barcodes runs side by side
+          std::thread th[3];
+          for (int m = 1; m < ns_streams; ++m) th[m] = std::thread([&rd, m, target]() { rd[m].fill(target); });
+          rd[0].fill(target);
+          for (int m = 1; m < ns_streams; ++m) th[m].join();
+        }
         t_read += now_s() - t0;
         t0 = now_s();
         for (int m = 0; m < ns_streams; ++m) {

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=8_000_000)
     ap.add_argument("--readlen", type=int, default=50)
     ap.add_argument("--dir", default="/tmp/chromap_amd_e2e")
+    ap.add_argument("--gz", action="store_true", help="also time gzip-compressed input (inflated on the host, one thread per file)")
     args = ap.parse_args()
     os.makedirs(args.dir, exist_ok=True)
     from chromap_amd import ChromapGPU
@@ -74,6 +75,16 @@ def main():
         res[label] = {"wall_s": round(dt, 2), "M_pairs_per_s_wall": round(args.pairs / dt / 1e6, 2), "cli": tail,
                       "bed_md5": subprocess.check_output(["md5sum", out]).split()[0].decode(),
                       "bed_bytes": os.path.getsize(out)}
+    if args.gz:
+        for f in (r1, r2):
+            subprocess.check_call("gzip -1 -c %s > %s.gz" % (f, f), shell=True)
+        t0 = time.time()
+        p = subprocess.run([cli, "--preset", "atac", "-x", idx, "-r", fa, "-1", r1 + ".gz", "-2", r2 + ".gz", "-o", out], stderr=subprocess.PIPE,
+                           check=True)
+        dt = time.time() - t0
+        tail = [ln for ln in p.stderr.decode().splitlines() if ln.startswith("Mapped all reads")]
+        res["device_ingest_gz"] = {"wall_s": round(dt, 2), "cli": tail, "bed_md5": subprocess.check_output(["md5sum", out]).split()[0].decode(),
+                                   "gz_bytes": os.path.getsize(r1 + ".gz") + os.path.getsize(r2 + ".gz")}
     res["same_output"] = res["device_ingest"]["bed_md5"] == res["host_ingest"]["bed_md5"]
     res["config"] = {"pairs": args.pairs, "readlen": args.readlen, "genome": args.genome,
                      "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2), "index_bytes": os.path.getsize(idx)}
