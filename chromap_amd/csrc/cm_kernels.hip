@@ -147,8 +147,33 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   if (i < n) cm_s3b_candidates_lds(d, i, sh_h + threadIdx.x, sh_c + threadIdx.x, CM_S3B_LDS_CAP, CM_BLOCK);
 }
-CM_ITEM_KERNEL(k_s4a_rescue_count, cm_s4a_rescue_count)
-CM_ITEM_KERNEL(k_s4b_rescue_merge, cm_s4b_rescue_merge)
+// S4a / S4b: few reads (pairs whose mate has to be rescued, ~7 % here) run the long occurrence-run
+// searches.  Spread over all waves they keep every wave busy for one search's latency; the block
+// therefore packs them: every lane does the cheap part of its own read, the reads with a search
+// are listed in LDS and the first lanes of the block take one each.
+__global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t n) {
+  __shared__ uint32_t list[CM_BLOCK];
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i < n && cm_s4a_decide(d, i)) list[atomicAdd(&cnt, 1u)] = i;
+  __syncthreads();
+  if (threadIdx.x < cnt) cm_s4a_rescue(d, list[threadIdx.x]);
+}
+__global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n) {
+  __shared__ uint32_t list[CM_BLOCK];
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i < n) {
+    if (d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0) list[atomicAdd(&cnt, 1u)] = i;
+    else cm_s4b_rescue_merge(d, i);
+  }
+  __syncthreads();
+  if (threadIdx.x < cnt) cm_s4b_rescue_merge(d, list[threadIdx.x]);
+}
 CM_ITEM_KERNEL(k_s4c_reduce, cm_s4c_reduce)
 CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare)
 CM_ITEM_KERNEL(k_s5c_finalize, cm_s5c_finalize)

@@ -1016,38 +1016,46 @@ CM_HD const uint8_t *cm_c0_ncnt(const CmDev &d, uint32_t r) { return d.hcnt + d.
 // S4a: per read -- SupplementCandidates decision and rescue-hit counting
 //      (candidate_processor.cc:75-191)
 // ---------------------------------------------------------------------------------------
-CM_HD void cm_s4a_rescue_count(const CmDev &d, uint32_t r) {
-  const uint32_t pair = r >> 1, o = r ^ 1u;
+// S4a in two parts so that a block can run the (rare, long) rescue searches on packed lanes:
+// cm_s4a_decide: does this read supplement its candidates from its mate (candidate_processor.cc:
+// 75-146)?  cm_s4a_rescue: the counting pass of the two rescue searches for a read that does.
+CM_HD bool cm_s4a_decide(const CmDev &d, uint32_t r) {
+  const uint32_t pair = r >> 1;
   d.aug[r] = 0; d.res_neg[r] = 0; d.res_pos[r] = 0; d.resc_n[r] = 0; d.resc_p[r] = 0;
   const bool live = d.p.single ? ((r & 1) == 0 && d.mm_cnt[r] > 0) : (d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0);
-  uint32_t ncp = d.ncp[r], ncn = d.ncn[r];
-  if (live) {
-    const uint32_t mm_count = d.mm_cnt[r];
-    bool augment = !d.p.split && !d.p.single;  // split alignment / single-end never supplement (chromap.h:1021)
-    const uint8_t *pc = cm_c0_pcnt(d, r), *nc = cm_c0_ncnt(d, r);
-    for (uint32_t i = 0; augment && i < ncp; ++i) if (pc[i] >= mm_count / 2) { augment = false; break; }
-    if (augment) for (uint32_t i = 0; i < ncn; ++i) if (nc[i] >= mm_count / 2) { augment = false; break; }
-    if (augment) {
-      d.aug[r] = 1;
-      uint32_t cntn = 0, cntp = 0, rl = 0;
-      int res_neg = 0, res_pos = 0;
-      bool set_rl = false;
-      uint32_t rl_val = 0;
-      unsigned long long occ_reads = 0;
-      if (d.ncp[o] > 0) {  // mate + candidates drive a search on our - strand (:147-153)
-        res_neg = cm_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], nullptr, &cntn, &rl, &occ_reads);
-        if (res_neg >= 0) { set_rl = true; rl_val = rl; }
-      }
-      if (d.ncn[o] > 0) {
-        res_pos = cm_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], nullptr, &cntp, &rl, &occ_reads);
-        if (res_pos >= 0) { set_rl = true; rl_val = rl; }
-      }
-      d.res_neg[r] = res_neg; d.res_pos[r] = res_pos;
-      d.resc_n[r] = cntn; d.resc_p[r] = cntp;
-      if (set_rl) d.rep_len[r] = rl_val;  // repetitive_seed_length overwritten (:113,131, index.cc:487)
-    }
+  const uint32_t ncp = d.ncp[r], ncn = d.ncn[r];
+  d.m_tot[r] = live ? ncp + ncn : 0;
+  if (!live) return false;
+  const uint32_t mm_count = d.mm_cnt[r];
+  bool augment = !d.p.split && !d.p.single;  // split alignment / single-end never supplement (chromap.h:1021)
+  const uint8_t *pc = cm_c0_pcnt(d, r), *nc = cm_c0_ncnt(d, r);
+  for (uint32_t i = 0; augment && i < ncp; ++i) if (pc[i] >= mm_count / 2) { augment = false; break; }
+  if (augment) for (uint32_t i = 0; i < ncn; ++i) if (nc[i] >= mm_count / 2) { augment = false; break; }
+  return augment;
+}
+CM_HD void cm_s4a_rescue(const CmDev &d, uint32_t r) {
+  const uint32_t o = r ^ 1u;
+  d.aug[r] = 1;
+  uint32_t cntn = 0, cntp = 0, rl = 0;
+  int res_neg = 0, res_pos = 0;
+  bool set_rl = false;
+  uint32_t rl_val = 0;
+  unsigned long long occ_reads = 0;
+  if (d.ncp[o] > 0) {  // mate + candidates drive a search on our - strand (:147-153)
+    res_neg = cm_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], nullptr, &cntn, &rl, &occ_reads);
+    if (res_neg >= 0) { set_rl = true; rl_val = rl; }
   }
-  d.m_tot[r] = live ? ncp + ncn + d.resc_n[r] + d.resc_p[r] : 0;
+  if (d.ncn[o] > 0) {
+    res_pos = cm_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], nullptr, &cntp, &rl, &occ_reads);
+    if (res_pos >= 0) { set_rl = true; rl_val = rl; }
+  }
+  d.res_neg[r] = res_neg; d.res_pos[r] = res_pos;
+  d.resc_n[r] = cntn; d.resc_p[r] = cntp;
+  if (set_rl) d.rep_len[r] = rl_val;  // repetitive_seed_length overwritten (:113,131, index.cc:487)
+  d.m_tot[r] = d.ncp[r] + d.ncn[r] + cntn + cntp;
+}
+CM_HD void cm_s4a_rescue_count(const CmDev &d, uint32_t r) {
+  if (cm_s4a_decide(d, r)) cm_s4a_rescue(d, r);
 }
 
 // CandidateProcessor::MergeCandidates (candidate_processor.cc:345-414).  c1 = original list,
