@@ -113,6 +113,8 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   if (p.sam && p.split) { cm_set_error(c, "--SAM with split alignment is not supported"); return CMGPU_EINVAL; }
   if (params->output_format != 0 && params->output_format != CMGPU_FORMAT_SAM) { cm_set_error(c, "unknown output_format"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipStreamCreate(&c->stream));
+  HIPCHECK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  for (hipEvent_t &e : c->chunk_ev) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (c->stats.ensure(CM_ST_N * 8)) return CMGPU_ENOMEM;
   HIPCHECK(c, hipMemset(c->stats.p, 0, CM_ST_N * 8));
   for (int i = 0; i < CM_MAX_EVENTS; ++i) HIPCHECK(c, hipEventCreate(&c->ev[i]));
@@ -208,6 +210,8 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : c->all_bufs()) b->release();
   for (int i = 0; i < CM_MAX_EVENTS; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (hipEvent_t e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return CMGPU_OK;
@@ -339,21 +343,62 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     uint64_t cap = (uint64_t)n2 * (c->max_read_len / 4 + 3);
     const uint64_t bound = (uint64_t)c->bases0 + c->bases1 + 1;  // one emission per k-mer position at most
     if (cap > bound) cap = bound;
+    // The pairs go through in chunks: chunk c's minimizers (K0 + K1, VALU-bound) are followed on a second
+    // stream by their index probe (K2, latency-bound gather), which runs next to chunk c+1's minimizer
+    // pass.  A chunk's minimizers are the cursor range its launch covered (copied to mm_marks on the device).
+    const uint32_t ppb = cm_prep_mm_pairs_per_block(d, c->max_read_len);
+    const uint32_t n_chunks = n >= (1u << 20) ? CM_MM_CHUNKS : (n >= (1u << 17) ? 2 : 1);
+    const uint64_t per_read_bound = c->max_read_len > (uint32_t)c->p.k ? c->max_read_len - (uint32_t)c->p.k + 1 : 1;
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (cap > 0xfffffff0ull) { cm_set_error(c, "batch too large (minimizers)"); return CMGPU_ECAPACITY; }
+      // per chunk: probe grid = what the chunk can emit at most, but never more than the arrays hold
+      uint32_t lo[CM_MM_CHUNKS + 1];
+      uint64_t max_entries[CM_MM_CHUNKS];
+      uint32_t part_off[CM_MM_CHUNKS + 1];
+      lo[0] = 0; part_off[0] = 0;
+      for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+        uint64_t hi = (uint64_t)n * (ch + 1) / n_chunks;
+        hi = ch + 1 == n_chunks ? n : hi / ppb * ppb;
+        lo[ch + 1] = (uint32_t)hi;
+        uint64_t me = 2ull * (lo[ch + 1] - lo[ch]) * (attempt == 0 ? (uint64_t)(c->max_read_len / 4 + 3) : per_read_bound);
+        if (me > cap) me = cap;
+        max_entries[ch] = me;
+        part_off[ch + 1] = part_off[ch] + cm_probe_range_blocks(me);
+      }
       if (c->mm_hash.ensure((size_t)cap * 8 + 8) || c->mm_ps.ensure((size_t)cap * 4 + 4) || c->pr_val.ensure((size_t)cap * 8 + 8) ||
-          c->pr_kind.ensure((size_t)cap + 4) || c->mm_cursor.ensure(8)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
+          c->pr_kind.ensure((size_t)cap + 4) || c->mm_cursor.ensure(8) || c->mm_marks.ensure((CM_MM_CHUNKS + 1) * 8) ||
+          c->partials.ensure(((size_t)part_off[n_chunks] + 1) * 8 + cm_stats_partial_words(n) * 8)) {
+        cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM;
+      }
       cm_fill_dev(c, d);
       HIPCHECK(c, hipMemsetAsync(c->mm_cursor.p, 0, 8, s));
-      cm_launch_k_prep_mm(d, n, c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
+      HIPCHECK(c, hipMemsetAsync(c->mm_marks.p, 0, 8, s));
+      HIPCHECK(c, hipMemsetAsync(d.stats + CM_ST_PROBE_STEPS, 0, 2 * 8, s));
+      unsigned long long *marks = (unsigned long long *)c->mm_marks.p;
+      for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+        cm_launch_k_prep_mm(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
+        HIPCHECK(c, hipMemcpyAsync(marks + ch + 1, c->mm_cursor.p, 8, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(c, hipEventRecord(c->chunk_ev[ch], s));
+        HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[ch], 0));
+        cm_launch_k_probe_range(d, marks + ch, max_entries[ch], (uint32_t)cap, (uint2 *)c->partials.p + part_off[ch], c->stream2);
+      }
+      HIPCHECK(c, hipEventRecord(c->chunk_ev[CM_MM_CHUNKS], c->stream2));
+      HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[CM_MM_CHUNKS], 0));
+      cm_launch_k_probe_reduce(c->partials.p, part_off[n_chunks], d.stats + CM_ST_PROBE_STEPS, s);
       unsigned long long tot = 0;
       HIPCHECK(c, hipMemcpyAsync(&tot, c->mm_cursor.p, 8, hipMemcpyDeviceToHost, s));
       HIPCHECK(c, hipStreamSynchronize(s));
-      if (tot <= cap) { n_mm = (uint32_t)tot; break; }
+      bool grid_short = false;  // a chunk emitted more than its probe grid covers (cannot happen on attempt 1)
+      if (attempt == 0 && tot <= cap) {
+        unsigned long long hm[CM_MM_CHUNKS + 1];
+        HIPCHECK(c, hipMemcpy(hm, c->mm_marks.p, (CM_MM_CHUNKS + 1) * 8, hipMemcpyDeviceToHost));
+        for (uint32_t ch = 0; ch < n_chunks; ++ch) grid_short = grid_short || hm[ch + 1] - hm[ch] > max_entries[ch];
+      }
+      if (tot <= cap && !grid_short) { n_mm = (uint32_t)tot; break; }
       if (attempt == 1) { cm_set_error(c, "minimizer arrays overflowed twice"); return CMGPU_ECAPACITY; }
-      cap = bound;  // rerun with the worst-case size
+      cap = bound;  // rerun with the worst-case sizes
     }
-    mark(c, "s0_s1_trim_minimizers");
+    mark(c, "s0_s1_s2_trim_minimizers_probe");
   } else {
     // S0 + S1a: length filter, adapter trimming, minimizer counts (reads staged through LDS)
     cm_launch_k_prep_count(d, n, c->max_read_len, s);
@@ -367,11 +412,11 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     // S1b: minimizers written to their dense positions
     cm_launch_k_mm_fill(d, n, c->max_read_len, s);
     mark(c, "s1b_minimizers");
+    // S2: index probe, one launch (k_probe: the kernel the roofline is measured on, cmgpu_probe_bench)
+    if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
+    cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);
+    mark(c, "s2_probe");
   }
-  // S2: index probe (the graded kernel)
-  if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
-  cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);
-  mark(c, "s2_probe");
   // S3: hit counts -> offsets -> candidates
   cm_launch_k_s3a_count(d, n2, s);
   cm_scan_u32(d.hit_tot, d.hit_off, n2, (uint32_t *)c->scan_tmp.p, s);

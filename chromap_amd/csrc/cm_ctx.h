@@ -11,6 +11,7 @@
 #include "cm_types.h"
 
 #define CM_MAX_EVENTS 32
+#define CM_MM_CHUNKS 8   // chunks of a batch whose index probe overlaps the next chunk's minimizer pass
 #define CM_MAX_W_HOST 32
 
 struct DevBuf {
@@ -31,6 +32,8 @@ struct CmFqStream {
 struct cmgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;     // index probe of chunk c runs here next to the minimizer pass of chunk c+1
+  hipEvent_t chunk_ev[CM_MM_CHUNKS + 1] = {};  // minimizers of chunk c written / all probes done
   std::string err;
   cmgpu_params hp;
   CmParams p;
@@ -67,6 +70,7 @@ struct cmgpu_ctx {
   // --SAM outputs of the last batch (cm_stages.h: cm_ref_start_end_sam)
   DevBuf sam_rec, sam_cigar, sam_md, sam_z;
   DevBuf mm_cursor;  // k_prep_mm: next free entry of the dense minimizer arrays
+  DevBuf mm_marks;   // cursor after every chunk of pairs: the range of minimizers a chunk's probe launch covers
   DevBuf part_k, part_v, part_tmp, part_cnt;  // cmgpu_records_partition scratch (kept across steps)
   uint64_t sam_slots = 0;
   uint32_t sam_md_cap = 0;
@@ -94,7 +98,7 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_k, &part_v, &part_tmp, &part_cnt, &mm_cursor};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_k, &part_v, &part_tmp, &part_cnt, &mm_cursor, &mm_marks};
   }
 };
 

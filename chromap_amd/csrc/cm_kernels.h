@@ -9,7 +9,12 @@
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len);
-void cm_launch_k_prep_mm(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, uint32_t mm_cap, unsigned long long *cursor, hipStream_t s);
+uint32_t cm_prep_mm_pairs_per_block(const CmDev &d, uint32_t max_read_len);
+void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
+                         unsigned long long *cursor, hipStream_t s);
+uint32_t cm_probe_range_blocks(uint64_t max_entries);
+void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s);
+void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
 CM_DECL_LAUNCH(k_s3b_candidates)
 CM_DECL_LAUNCH(k_s4a_rescue_count)

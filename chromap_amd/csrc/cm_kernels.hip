@@ -76,9 +76,10 @@ __global__ void k_mm_fill(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
 // every consumer addresses a read's list through (mm_off[r], mm_cnt[r]).  A read with more than
 // `stg` minimizers (never seen: stg = L/4 + 4 against an expected (L-16)/4) recomputes straight
 // into its range.  Replaces k_prep_count + scan + k_mm_fill (two passes of ~150 integer ops per base).
-__global__ void k_prep_mm(CmDev d, uint32_t n_pairs, uint32_t lds_half, uint32_t stg, uint32_t mm_cap, unsigned long long *cursor) {
+__global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of this launch's pair range */, uint32_t lds_half, uint32_t stg,
+                          uint32_t mm_cap, unsigned long long *cursor) {
   const uint32_t T = blockDim.x, PB = T >> 1;
-  const uint32_t p0 = blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
+  const uint32_t p0 = pair_lo + blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
   const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp;
   const CmStaged s = cm_stage_pairs(d, p0, p1, pair, lds_half);
   if (t < PB && pair < p1) cm_s0_prep_ptr(d, pair, s.m0, s.m1);
@@ -307,6 +308,39 @@ __global__ __launch_bounds__(CM_BLOCK) void k_probe(const uint64_t *__restrict__
   }
 }
 
+// k_probe over the minimizers [range[0], range[1]) -- the range is only known on the device (it is where
+// the chunk's k_prep_mm launch moved the cursor), so the grid covers an upper bound and surplus blocks leave.
+__global__ __launch_bounds__(CM_BLOCK) void k_probe_range(const uint64_t *__restrict__ bkt, uint32_t bmask,
+                                                           const uint64_t *__restrict__ hash, uint64_t *__restrict__ val,
+                                                           uint8_t *__restrict__ kind, const unsigned long long *__restrict__ range,
+                                                           uint32_t cap, uint2 *__restrict__ block_partials) {
+  const unsigned long long lo = range[0];
+  unsigned long long hi = range[1];
+  if (hi > cap) hi = cap;  // overflow of the dense arrays: the host reruns with larger ones
+  const unsigned long long i = lo + (unsigned long long)blockIdx.x * CM_BLOCK + threadIdx.x;
+  uint32_t steps = 0, hit = 0;
+  if (i < hi) {
+    uint64_t v;
+    uint8_t kd;
+    steps = cm_probe(bkt, bmask, hash[i], &v, &kd);
+    val[i] = v;
+    kind[i] = kd;
+    hit = kd != CM_PR_MISS;
+  }
+  __shared__ uint32_t sh_s[CM_BLOCK / 64], sh_h[CM_BLOCK / 64];
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_down(steps, off, 64);
+    hit += __shfl_down(hit, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = steps; sh_h[threadIdx.x >> 6] = hit; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0, c = 0;
+    for (int j = 0; j < CM_BLOCK / 64; ++j) { a += sh_s[j]; c += sh_h[j]; }
+    block_partials[blockIdx.x] = make_uint2(a, c);
+  }
+}
+
 // sums k_probe's per-block partials into counters[0] (steps) and counters[1] (hits)
 __global__ __launch_bounds__(CM_BLOCK) void k_probe_reduce(const uint2 *__restrict__ partials, uint32_t n_blocks,
                                                             unsigned long long *__restrict__ counters) {
@@ -452,12 +486,29 @@ bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len) {
   size_t l;
   return prep_mm_geometry(d, max_read_len, &t, &h, &g, &l);
 }
-void cm_launch_k_prep_mm(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, uint32_t mm_cap, unsigned long long *cursor, hipStream_t s) {
+// pairs per block of k_prep_mm for this read length (chunk boundaries are multiples of it)
+uint32_t cm_prep_mm_pairs_per_block(const CmDev &d, uint32_t max_read_len) {
   uint32_t threads, half, stg;
   size_t lds;
-  if (!n_pairs || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds)) return;
+  return prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds) ? threads / 2 : 0;
+}
+// pairs [pair_lo, pair_hi)
+void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
+                         unsigned long long *cursor, hipStream_t s) {
+  uint32_t threads, half, stg;
+  size_t lds;
+  if (pair_hi <= pair_lo || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds)) return;
   const uint32_t pb = threads / 2;
-  hipLaunchKernelGGL(k_prep_mm, dim3((n_pairs + pb - 1) / pb), dim3(threads), lds, s, d, n_pairs, half, stg, mm_cap, cursor);
+  hipLaunchKernelGGL(k_prep_mm, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor);
+}
+// probe of the minimizers [range[0], range[1]) (device-side range), at most max_entries of them
+uint32_t cm_probe_range_blocks(uint64_t max_entries) { return (uint32_t)((max_entries + CM_BLOCK - 1) / CM_BLOCK); }
+void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s) {
+  const uint32_t blocks = cm_probe_range_blocks(max_entries);
+  if (blocks) hipLaunchKernelGGL(k_probe_range, dim3(blocks), dim3(CM_BLOCK), 0, s, d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, range, cap, (uint2 *)partials);
+}
+void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s) {
+  if (blocks) hipLaunchKernelGGL(k_probe_reduce, dim3(blocks / (CM_BLOCK * 8) + 1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
 }
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s) {
   if (!n_pairs) return;
