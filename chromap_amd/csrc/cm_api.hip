@@ -33,6 +33,7 @@ void cm_set_error(cmgpu_ctx *ctx, const std::string &msg) {
 
 int DevBuf::ensure(size_t bytes) {
   if (bytes <= cap) return 0;
+  if (!owned) return -1;
   if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
   size_t want = bytes + bytes / 4 + 256;
   hipError_t e = hipMalloc(&p, want);
@@ -45,7 +46,7 @@ int DevBuf::ensure(size_t bytes) {
   return 0;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p && owned) (void)hipFree(p);
   p = nullptr;
   cap = 0;
 }
@@ -199,6 +200,27 @@ extern "C" int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view 
   }
   rc = cm_upload_reference(c, ref);
   if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
+  *out = c;
+  return CMGPU_OK;
+}
+
+// A second context over the same resident index + reference (views, no copy): two host threads can
+// then keep two batches in flight on one GPU -- the kernels of one batch's latency-bound stages share the
+// CUs with the other's VALU-bound stages.  The parent must outlive its children.
+extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
+  if (!parent || !out) { cm_set_error(nullptr, "null argument"); return CMGPU_EINVAL; }
+  *out = nullptr;
+  int rc = select_device(parent->device);
+  if (rc) return rc;
+  cmgpu_ctx *c = new cmgpu_ctx();
+  rc = cm_ctx_init_common(c, &parent->hp, parent->p.k, parent->p.w, parent->device);
+  if (rc) { g_last_error = c->err; cmgpu_destroy(c); return rc; }
+  auto view = [](DevBuf &dst, const DevBuf &src) { dst.p = src.p; dst.cap = src.cap; dst.owned = false; };
+  view(c->bkt, parent->bkt); view(c->occ, parent->occ); view(c->ref, parent->ref);
+  view(c->ref_off, parent->ref_off); view(c->ref_len, parent->ref_len);
+  c->bmask = parent->bmask; c->n_occ = parent->n_occ; c->n_seq = parent->n_seq; c->ref_bytes = parent->ref_bytes;
+  c->h_ref_off = parent->h_ref_off; c->h_ref_len = parent->h_ref_len;
+  c->synth_n_minimizers = parent->synth_n_minimizers; c->synth_n_keys = parent->synth_n_keys;
   *out = c;
   return CMGPU_OK;
 }

@@ -17,6 +17,7 @@
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  bool owned = true;  // false: a view of another context's buffer (cmgpu_create_shared); never freed or regrown here
   int ensure(size_t bytes);  // grows (contents are NOT preserved); 0 on success
   void release();
 };

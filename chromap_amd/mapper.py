@@ -73,14 +73,20 @@ class ChromapGPU:
     """One context per GPU: index + reference resident in HBM, batches mapped by HIP kernels."""
 
     def __init__(self, index_path=None, ref_path=None, params=None, device=0, preset=None, synthetic=None,
-                 build_index=None, **overrides):
+                 build_index=None, shared_from=None, **overrides):
         self.L = _capi.lib()
         self.params = params if params is not None else _capi.default_params(preset, **overrides)
         self.ctx = C.c_void_p()
         self._idx = None
         self._ref = None
         self.names = None
-        if synthetic is not None:
+        if shared_from is not None:
+            # a further context over shared_from's resident index + reference (keep shared_from alive)
+            self.params = shared_from.params
+            self._check(self.L.cmgpu_create_shared(shared_from.ctx, C.byref(self.ctx)), None)
+            self.names = shared_from.names
+            self._parent = shared_from
+        elif synthetic is not None:
             total, nseq, seed = synthetic
             rc = self.L.cmgpu_create_synthetic(total, nseq, seed, 17, 7, C.byref(self.params), device, C.byref(self.ctx))
             self._check(rc, None)

@@ -188,6 +188,10 @@ int cmgpu_create_from_reference(const cmgpu_ref_view *ref, int32_t kmer_size, in
                                 const cmgpu_params *params, int device_id, cmgpu_ctx **out);
 int cmgpu_save_index_file(cmgpu_ctx *ctx, const char *path);
 
+/* A further context over the SAME resident index and reference (no copy; the parent must outlive it).
+ * Contexts are single-caller, so this is how one GPU keeps several batches in flight: one host
+ * thread and one context per batch; their kernels share the compute units. */
+int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out);
 int cmgpu_destroy(cmgpu_ctx *ctx);
 /* ctx may be NULL (returns the last error of a failed cmgpu_create*). */
 const char *cmgpu_last_error(const cmgpu_ctx *ctx);
