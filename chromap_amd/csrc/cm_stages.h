@@ -852,29 +852,48 @@ CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_
 // ---------------------------------------------------------------------------------------
 // work buffer h/hc with element stride st (1 = the read's global segment, blockDim = LDS
 // [entry][thread] layout).  Candidates end up at h[0..ncp) and h[np..np+ncn) (strided).
+#define CM_S3B_GROUP 4
 CM_HD void cm_s3b_core(const CmDev &d, uint32_t r, uint64_t *h, uint8_t *hc, uint32_t st, uint32_t *np_out,
                        uint32_t *ncp_out, uint32_t *ncn_out) {
   const uint32_t tot = d.hit_tot[r];
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   uint32_t np = 0, nn = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint8_t kind = d.pr_kind[b + i];
-    if (kind == CM_PR_MISS) continue;
-    const uint64_t val = d.pr_val[b + i];
-    const uint32_t ps = d.mm_ps[b + i];
-    bool same;
-    if (kind == CM_PR_SINGLE) {
-      const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
-      if (same) h[(np++) * st] = cp; else h[(tot - 1 - nn++) * st] = cp;
-      continue;
+  // minimizers are taken four at a time: their (kind, value, position) triples and the first
+  // occurrence of every run are requested together, so four independent gathers are in flight per
+  // lane instead of one dependent chain
+  for (uint32_t i0 = 0; i0 < n; i0 += CM_S3B_GROUP) {
+    uint8_t kind[CM_S3B_GROUP];
+    uint64_t val[CM_S3B_GROUP], first[CM_S3B_GROUP];
+    uint32_t ps[CM_S3B_GROUP];
+#pragma unroll
+    for (int q = 0; q < CM_S3B_GROUP; ++q) {
+      const bool in = i0 + q < n;
+      kind[q] = in ? d.pr_kind[b + i0 + q] : (uint8_t)CM_PR_MISS;
+      val[q] = in ? d.pr_val[b + i0 + q] : 0;
+      ps[q] = in ? d.mm_ps[b + i0 + q] : 0;
     }
-    const uint32_t nocc = (uint32_t)val;
-    if (nocc >= maxf) continue;
-    const uint64_t *o = d.occ + (uint32_t)(val >> 32);
-    for (uint32_t oi = 0; oi < nocc; ++oi) {
-      const uint64_t cp = cm_cand_from_hit(o[oi], ps, d.p.k, &same);
-      if (same) h[(np++) * st] = cp; else h[(tot - 1 - nn++) * st] = cp;
+#pragma unroll
+    for (int q = 0; q < CM_S3B_GROUP; ++q) {
+      const bool run = kind[q] != CM_PR_MISS && kind[q] != CM_PR_SINGLE && (uint32_t)val[q] < maxf && (uint32_t)val[q] > 0;
+      first[q] = run ? d.occ[(uint32_t)(val[q] >> 32)] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < CM_S3B_GROUP; ++q) {
+      if (kind[q] == CM_PR_MISS) continue;
+      bool same;
+      if (kind[q] == CM_PR_SINGLE) {
+        const uint64_t cp = cm_cand_from_hit(val[q], ps[q], d.p.k, &same);
+        if (same) h[(np++) * st] = cp; else h[(tot - 1 - nn++) * st] = cp;
+        continue;
+      }
+      const uint32_t nocc = (uint32_t)val[q];
+      if (nocc >= maxf) continue;
+      const uint64_t *o = d.occ + (uint32_t)(val[q] >> 32);
+      for (uint32_t oi = 0; oi < nocc; ++oi) {
+        const uint64_t cp = cm_cand_from_hit(oi == 0 ? first[q] : o[oi], ps[q], d.p.k, &same);
+        if (same) h[(np++) * st] = cp; else h[(tot - 1 - nn++) * st] = cp;
+      }
     }
   }
   cm_sort_u64_strided(h, np, st);
