@@ -94,3 +94,25 @@ def test_other_kmer_and_window_sizes(k, w, data, tmp_path):
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             outs[(tag, itag)] = ds.md5(out)
     assert len(set(outs.values())) == 1, outs
+
+
+def test_multi_batch_q0_multimappers(tmp_path):
+    """1.3 M pairs = three reference read batches (500 000 + 500 000 + 300 000) at -q 0 on a repeat-rich
+    genome: ~10^5 multi-mapped reads whose reported position depends on the per-task reservoir RNG
+    (DESIGN.md section 2).  One 1.3 M-pair call and explicit 500 000-pair calls must both equal the reference."""
+    if not os.path.exists(REF):
+        pytest.skip("built reference binary not present")
+    pre = str(tmp_path / "d")
+    subprocess.check_call([sys.executable, GEN, "--out", pre, "--genome", "30000000", "--chroms", "6", "--pairs", "1300000",
+                           "--readlen", "50", "--frag-min", "35", "--seed", "77"])
+    idx = pre + ".idx"
+    subprocess.run([CLI, "-i", "-r", pre + ".fa", "-o", idx], check=True, stderr=subprocess.PIPE)
+    common = ["--preset", "atac", "-q", "0", "-x", idx, "-r", pre + ".fa", "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    subprocess.run([REF] + common + ["-o", pre + ".ref.bed", "-t", "64"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([CLI] + common + ["-o", pre + ".gpu.bed"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([CLI] + common + ["--batch-pairs", "500000", "-o", pre + ".gpu2.bed"], check=True, stderr=subprocess.PIPE)
+    want = ds.md5(pre + ".ref.bed")
+    assert ds.md5(pre + ".gpu.bed") == want
+    assert ds.md5(pre + ".gpu2.bed") == want
+    mapq0 = sum(1 for ln in open(pre + ".ref.bed", "rb") if ln.split(b"\t")[4] == b"0")
+    assert mapq0 > 10000
