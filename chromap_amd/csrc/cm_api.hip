@@ -448,7 +448,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   if (c->hbuf.ensure((size_t)n_hits * 8 + 8) || c->hcnt.ensure((size_t)n_hits + 4)) { cm_set_error(c, "out of device memory (hits)"); return CMGPU_ENOMEM; }
   cm_fill_dev(c, d);
   mark(c, "s3a_count");
-  cm_launch_k_s3b_candidates(d, n2, s);
+  cm_launch_k_s3b_candidates(d, n2, c->max_read_len, s);
   mark(c, "s3b_candidates");
   // S4: mate rescue, merge, paired-end filter
   cm_launch_k_s4a_rescue_count(d, n2, s);

@@ -16,7 +16,7 @@ uint32_t cm_probe_range_blocks(uint64_t max_entries);
 void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s);
 void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
-CM_DECL_LAUNCH(k_s3b_candidates)
+void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
 CM_DECL_LAUNCH(k_s4a_rescue_count)
 CM_DECL_LAUNCH(k_s4b_rescue_merge)
 CM_DECL_LAUNCH(k_s4c_reduce)

@@ -141,12 +141,14 @@ CM_ITEM_KERNEL(k_s3a_count, cm_s3a_count)
 // 16 count bytes per thread = 36 KB per block).  The first version sorted every list in its
 // global segment; per-thread read-modify-write of small segments thrashed L2 (rocprofv3: 10 GB
 // of HBM traffic per launch for 0.55 GB of hits).
-#define CM_S3B_LDS_CAP 16
-__global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n) {
-  __shared__ uint64_t sh_h[CM_S3B_LDS_CAP * CM_BLOCK];
-  __shared__ uint8_t sh_c[CM_S3B_LDS_CAP * CM_BLOCK];
-  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i < n) cm_s3b_candidates_lds(d, i, sh_h + threadIdx.x, sh_c + threadIdx.x, CM_S3B_LDS_CAP, CM_BLOCK);
+// Geometry from the longest read of the batch: cap (hits per lane staged in LDS) and threads per block are
+// chosen so that cap * threads * 9 bytes stays at 36 KB -- 16 x 256 for 50-base reads (7.7 minimizers, ~9 hits),
+// 48 x 64 for 150-base reads (~34 minimizers); longer lists work in place in the global segment.
+__global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n, uint32_t cap) {
+  uint64_t *sh_h = reinterpret_cast<uint64_t *>(cm_lds);
+  uint8_t *sh_c = cm_lds + (size_t)cap * blockDim.x * 8;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cm_s3b_candidates_lds(d, i, sh_h + threadIdx.x, sh_c + threadIdx.x, cap, blockDim.x);
 }
 // S4a / S4b: few reads (pairs whose mate has to be rescued, ~7 % here) run the long occurrence-run
 // searches.  Spread over all waves they keep every wave busy for one search's latency; the block
@@ -445,7 +447,14 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + CM_BLOCK - 1) / CM_BL
     if (n) hipLaunchKernelGGL(kname, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);         \
   }
 CM_LAUNCH(k_s3a_count)
-CM_LAUNCH(k_s3b_candidates)
+void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
+  if (!n) return;
+  uint32_t cap = max_read_len / 3;
+  cap = cap < 16 ? 16 : (cap > 64 ? 64 : cap);
+  uint32_t threads = 256;
+  while (threads > 64 && (size_t)cap * threads * 9 > 36 * 1024 + 1024) threads >>= 1;
+  hipLaunchKernelGGL(k_s3b_candidates, dim3((n + threads - 1) / threads), dim3(threads), (size_t)cap * threads * 9, s, d, n, cap);
+}
 CM_LAUNCH(k_s4a_rescue_count)
 CM_LAUNCH(k_s4b_rescue_merge)
 CM_LAUNCH(k_s4c_reduce)
