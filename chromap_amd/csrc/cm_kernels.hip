@@ -476,9 +476,11 @@ static inline void staging_geometry(uint32_t max_read_len, uint32_t *threads, ui
   *lds_half = (uint32_t)(((uint64_t)pb * max_read_len + 64 + 15) & ~15ull);
 }
 // fused trim + minimizers: geometry (threads per block, LDS) from the longest read; false when the
-// configuration needs the two-pass kernels (other k / w, or reads too long for the LDS staging)
+// configuration needs the two-pass kernels: other k / w, or reads longer than 69 bases -- their emissions
+// would leave room for 128 or 64 lanes per block only, and at that occupancy the two-pass kernels are
+// as fast (2 x 100) or faster (2 x 150: 10.7 ms against 12.7 ms for 2 M pairs)
 static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *threads, uint32_t *half, uint32_t *stg, size_t *lds) {
-  if (d.p.w != 7 || 2 * d.p.k + 12 > 64 || max_read_len > 2047) return false;
+  if (d.p.w != 7 || 2 * d.p.k + 12 > 64 || max_read_len > 69) return false;
   *stg = max_read_len / 4 + 4;
   uint32_t t = 256;
   for (;; t >>= 1) {
