@@ -225,6 +225,31 @@ extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
   return CMGPU_OK;
 }
 
+// --chr-order: Chromap::GenerateCustomRidRanks + SequenceBatch::ReorderSequences (chromap.cc:867-913,
+// chromap.h:654-659).  rank[i] = place of reference sequence i in the output order.
+extern "C" int cmgpu_set_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t n) {
+  if (!c || !rank) return CMGPU_EINVAL;
+  if (n != c->n_seq) { cm_set_error(c, "rank table size differs from the number of reference sequences"); return CMGPU_EINVAL; }
+  std::vector<uint64_t> off(n);
+  std::vector<uint32_t> len(n);
+  std::vector<uint8_t> seen(n, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rank[i] >= n || seen[rank[i]]) { cm_set_error(c, "rank table is not a permutation"); return CMGPU_EINVAL; }
+    seen[rank[i]] = 1;
+    off[rank[i]] = c->h_ref_off[i];
+    len[rank[i]] = c->h_ref_len[i];
+  }
+  HIPCHECK(c, hipSetDevice(c->device));
+  if (c->rid_rank.ensure((size_t)n * 4) || c->ref_off_r.ensure((size_t)n * 8) || c->ref_len_r.ensure((size_t)n * 4)) {
+    cm_set_error(c, "out of device memory (chromosome order)"); return CMGPU_ENOMEM;
+  }
+  HIPCHECK(c, hipMemcpy(c->rid_rank.p, rank, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(c->ref_off_r.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+  HIPCHECK(c, hipMemcpy(c->ref_len_r.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  c->has_rank = true;
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (!c) return CMGPU_OK;
   if (c->in_flight) { c->worker.join(); c->in_flight = false; }
@@ -316,6 +341,11 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   PTR(rec, uint8_t) PTR(rec_ok, uint8_t)
 #undef PTR
   d.stats = (unsigned long long *)c->stats.p;
+  if (c->has_rank) {  // stages from verification on address the reference by rank
+    d.rid_rank = (const uint32_t *)c->rid_rank.p;
+    d.ref_off = (const uint64_t *)c->ref_off_r.p;
+    d.ref_len = (const uint32_t *)c->ref_len_r.p;
+  }
   if (c->has_barcodes) {
     d.bcb = (const uint8_t *)c->bcb.p; d.bcq = (const uint8_t *)c->bcq.p; d.bco = (const uint32_t *)c->bco.p;
     d.wl = (const uint64_t *)c->wl.p; d.wl_mask = c->wl_mask; d.wl_num_sample = (double)c->wl_num_sample;

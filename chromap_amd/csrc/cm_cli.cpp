@@ -10,6 +10,7 @@
 #include <chrono>
 #include <thread>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -104,7 +105,7 @@ struct ChunkReader {
 };
 
 struct Args {
-  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist;
+  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
@@ -177,6 +178,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "--TagAlign") { a.out_tagalign = true; a.out_bed = true; a.out_sam = false; a.out_pairs = false; }
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
+    else if (o == "--chr-order") a.chr_order_path = need("--chr-order");
     else if (o == "--device") a.device = atoi(need("--device"));
     else if (o == "--host-ingest") a.host_ingest = true;   // kseq-style host parser (FASTA / multi-line records)
     else if (o == "--ingest-chunk-mb") a.chunk_bytes = (size_t)atol(need("--ingest-chunk-mb")) << 20;
@@ -188,7 +190,7 @@ static Args parse(int argc, char **argv) {
              "       --remove-pcr-duplicates --Tn5-shift --low-mem --BED|--pairs --bc-error-threshold ...]\n");
       exit(0);
     }
-    else die("unsupported option " + o + " (PAF, --chr-order and summary outputs are outside this build)");
+    else die("unsupported option " + o + " (PAF, --pairs-natural-chr-order and summary outputs are outside this build)");
   }
   if (a.out_sam) {
     if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
@@ -229,6 +231,32 @@ int main(int argc, char **argv) {
   cmgpu_ctx *ctx = nullptr;
   if (cmgpu_create(&idx, &ref, &a.p, a.device, &ctx) != CMGPU_OK) die(cmgpu_last_error(nullptr));
   cmgpu_free_host_index(&idx);
+  // --chr-order (Chromap::GenerateCustomRidRanks, chromap.cc:867-913): ranks from the listed names, unlisted
+  // sequences follow in reference order; names / lengths for the writers are permuted the same way
+  std::vector<const char *> out_names(ref.names, ref.names + ref.n_sequences);
+  std::vector<uint32_t> out_lengths(ref.lengths, ref.lengths + ref.n_sequences);
+  if (!a.chr_order_path.empty()) {
+    FILE *of = fopen(a.chr_order_path.c_str(), "r");
+    if (!of) die("Cannot open chromosome order file " + a.chr_order_path);
+    std::vector<std::string> order;
+    char lb[4096];
+    while (fgets(lb, sizeof(lb), of)) { size_t l = strlen(lb); while (l && (lb[l - 1] == '\n' || lb[l - 1] == '\r')) lb[--l] = 0; order.push_back(lb); }
+    fclose(of);
+    std::vector<uint32_t> rank(ref.n_sequences, 0xffffffffu);
+    // later lines win for a repeated name, like the reference's map assignment
+    for (uint32_t i = 0; i < ref.n_sequences; ++i)
+      for (size_t j = 0; j < order.size(); ++j) if (order[j] == ref.names[i]) rank[i] = (uint32_t)j;
+    uint32_t k = 0;
+    {  // number of distinct names in the file = first free rank
+      std::vector<std::string> uniq(order);
+      std::sort(uniq.begin(), uniq.end());
+      k = (uint32_t)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
+    }
+    for (uint32_t i = 0; i < ref.n_sequences; ++i) if (rank[i] == 0xffffffffu) rank[i] = k++;
+    if (k > ref.n_sequences) die("ERROR: unknown chromsome names found in chromosome order file.");
+    if (cmgpu_set_chr_order(ctx, rank.data(), ref.n_sequences) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    for (uint32_t i = 0; i < ref.n_sequences; ++i) { out_names[rank[i]] = ref.names[i]; out_lengths[rank[i]] = ref.lengths[i]; }
+  }
 
   cmgpu_stats st;
   memset(&st, 0, sizeof(st));
@@ -473,21 +501,21 @@ int main(int argc, char **argv) {
     std::vector<const char *> n1(sam_names1.size()), n2(sam_names2.size() ? sam_names2.size() : 1, "");
     for (size_t i = 0; i < sam_names1.size(); ++i) n1[i] = sam_names1[i].c_str();
     for (size_t i = 0; i < sam_names2.size(); ++i) n2[i] = sam_names2[i].c_str();
-    lines = cmgpu_write_sam(ref.names, ref.lengths, ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0, sam_cigar.data(),
+    lines = cmgpu_write_sam(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0, sam_cigar.data(),
                             md.data(), cap, n1.data(), n2.data(), sam_b1.data(), sam_q1.data(), sam_o1.data(),
                             paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,
                             a.out_path.c_str());
   } else if (a.out_pairs) {
     std::vector<const char *> rn(read_names.size());
     for (size_t i = 0; i < rn.size(); ++i) rn[i] = read_names[i].c_str();
-    lines = cmgpu_write_pairs(ref.names, ref.lengths, ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
+    lines = cmgpu_write_pairs(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
                               a.out_path.c_str());
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
     const int kind = a.out_tagalign && paired ? (barcoded ? CMGPU_TEXT_TAGALIGN_PE_BC : CMGPU_TEXT_TAGALIGN_PE)
                                               : barcoded ? CMGPU_TEXT_BED_PE_BC : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
     const double t0 = now_s();
-    if (cmgpu_store_format(ctx, kind, ref.names, ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    if (cmgpu_store_format(ctx, kind, out_names.data(), ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
     const double t1 = now_s();
     if (cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK) die(cmgpu_last_error(ctx));
     t_post = now_s() - t0;

@@ -1210,6 +1210,15 @@ CM_HD void cm_reduce_dir(uint32_t dist, const uint64_t *p1, const uint8_t *c1, u
 // S4c: per pair -- SupplementCandidates return value, candidate-count gates and the
 //      paired-end filter (chromap.h:1020-1056, candidate_processor.cc:183-191, 233-263)
 // ---------------------------------------------------------------------------------------
+// Chromap::RerankCandidatesRid (chromap.cc:916-923): the candidates that go to verification get their rid
+// replaced by its rank in the custom chromosome order (chromap.h:416-420, 1060-1074)
+CM_HD void cm_rerank(const CmDev &d, uint32_t r) {
+  if (!d.rid_rank) return;
+  uint64_t *fp = cm_f_pos(d, r), *fn = cm_f_neg(d, r);
+  for (uint32_t i = 0; i < d.fcp[r]; ++i) fp[i] = (fp[i] & 0xffffffffull) | ((uint64_t)d.rid_rank[(uint32_t)(fp[i] >> 32)] << 32);
+  for (uint32_t i = 0; i < d.fcn[r]; ++i) fn[i] = (fn[i] & 0xffffffffull) | ((uint64_t)d.rid_rank[(uint32_t)(fn[i] >> 32)] << 32);
+}
+
 CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   d.fcp[r1] = d.fcn[r1] = d.fcp[r2] = d.fcn[r2] = 0;
@@ -1225,6 +1234,7 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
     for (uint32_t i = 0; i < d.mcn[r1]; ++i) { fn[i] = mn[i]; fnc[i] = mnc[i]; }
     d.fcp[r1] = d.mcp[r1]; d.fcn[r1] = d.mcn[r1];
     d.alive[pair] = 1;
+    cm_rerank(d, r1);
     return;
   }
   if (!(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return;
@@ -1248,6 +1258,7 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
       d.fcp[r] = d.mcp[r]; d.fcn[r] = d.mcn[r];
     }
     d.alive[pair] = 1;
+    cm_rerank(d, r1); cm_rerank(d, r2);
     return;
   }
   uint32_t a, b;
@@ -1259,6 +1270,7 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
   d.fcn[r1] = a; d.fcp[r2] = b;
   const uint32_t f1 = d.fcp[r1] + d.fcn[r1], f2 = d.fcp[r2] + d.fcn[r2];
   d.alive[pair] = (f1 > 0 && f2 > 0) ? 1 : 0;
+  if (d.alive[pair]) { cm_rerank(d, r1); cm_rerank(d, r2); }
 }
 
 // ---------------------------------------------------------------------------------------

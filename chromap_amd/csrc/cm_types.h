@@ -139,6 +139,9 @@ struct CmDev {
   // ---- output
   uint8_t *rec;         // n records of 24 bytes (cmgpu_record layout)
   uint8_t *rec_ok;      // [n]
+  // ---- --chr-order: rank of every index rid, or nullptr.  When set, ref_off / ref_len above are the arrays
+  //      REORDERED by rank: every stage from verification on works in rank space (cm_s4c_reduce re-ranks).
+  const uint32_t *rid_rank;
   // ---- --SAM (per slot: 2*pair + mate): 40-byte cmgpu_sam_record, CM_SAM_CIGAR_CAP cigar words, sam_md_cap MD bytes;
   //      sam_z: backtrack cells of the pair being aligned, word (row*ZW + q) * n_pairs + pair
   uint8_t *sam_rec;

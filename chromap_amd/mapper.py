@@ -75,6 +75,7 @@ class ChromapGPU:
     def __init__(self, index_path=None, ref_path=None, params=None, device=0, preset=None, synthetic=None,
                  build_index=None, shared_from=None, **overrides):
         self.L = _capi.lib()
+        chr_order = overrides.pop("chr_order", None)
         self.params = params if params is not None else _capi.default_params(preset, **overrides)
         self.ctx = C.c_void_p()
         self._idx = None
@@ -113,6 +114,42 @@ class ChromapGPU:
             self._check(rc, None)
             self.names = [self._ref.names[i] for i in range(self._ref.n_sequences)]
         self.stats = Stats()
+        self.rank = None
+        if chr_order:
+            self.set_chr_order(chr_order)
+
+    def set_chr_order(self, order):
+        """--chr-order: names in output order (unlisted sequences follow in reference order); from now on
+        records carry ranks as rid and self.names is in rank order"""
+        pos = {(n if isinstance(n, bytes) else n.encode()): i for i, n in enumerate(order)}
+        ranks = [pos.get(n, -1) for n in self.names]
+        k = len(pos)
+        for i, r in enumerate(ranks):
+            if r < 0:
+                ranks[i] = k
+                k += 1
+        if k != len(self.names):
+            raise ChromapError("ERROR: unknown chromsome names found in chromosome order file.")
+        arr = (C.c_uint32 * len(ranks))(*ranks)
+        self._check(self.L.cmgpu_set_chr_order(self.ctx, arr, len(ranks)), self.ctx)
+        names = [None] * len(ranks)
+        for i, r in enumerate(ranks):
+            names[r] = self.names[i]
+        self.names = names
+        self.rank = ranks
+
+    def reference_lengths(self):
+        """lengths in the order of self.names"""
+        nseq = C.c_uint32(0)
+        self.L.cmgpu_reference_lengths(self.ctx, None, 0, C.byref(nseq))
+        lens = (C.c_uint32 * nseq.value)()
+        self.L.cmgpu_reference_lengths(self.ctx, lens, nseq.value, C.byref(nseq))
+        out = list(lens)
+        if self.rank:
+            out = [0] * len(lens)
+            for i, r in enumerate(self.rank):
+                out[r] = lens[i]
+        return (C.c_uint32 * len(out))(*out)
 
     def save_index(self, path):
         """Index::Save of the resident index (loads in the reference's kh_load)"""
@@ -253,10 +290,7 @@ class ChromapGPU:
         rec, cigar, md, md_cap, n = sam
         p = params if params is not None else self.params
         rn = (C.c_char_p * len(self.names))(*self.names)
-        nseq = C.c_uint32(0)
-        self.L.cmgpu_reference_lengths(self.ctx, None, 0, C.byref(nseq))
-        lens = (C.c_uint32 * nseq.value)()
-        self.L.cmgpu_reference_lengths(self.ctx, lens, nseq.value, C.byref(nseq))
+        lens = self.reference_lengths()
         n1 = (C.c_char_p * len(names1))(*names1)
         n2 = (C.c_char_p * max(1, len(names2 or [])))(*(names2 or [b""]))
         keep = [np.ascontiguousarray(x) if x is not None else None for x in (b1, q1, o1, b2, q2, o2)]
@@ -340,10 +374,7 @@ class ChromapGPU:
         """rec: Record array returned by map_pairs with split_alignment set (holds PairsRecord entries)"""
         p = params if params is not None else self.params
         names = (C.c_char_p * len(self.names))(*self.names)
-        nseq = C.c_uint32(0)
-        self.L.cmgpu_reference_lengths(self.ctx, None, 0, C.byref(nseq))
-        lens = (C.c_uint32 * nseq.value)()
-        self.L.cmgpu_reference_lengths(self.ctx, lens, nseq.value, C.byref(nseq))
+        lens = self.reference_lengths()
         rn = (C.c_char_p * len(read_names))(*read_names)
         k = self.L.cmgpu_write_pairs(names, lens, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, rn,
                                      read_id_base, path.encode())

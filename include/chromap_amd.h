@@ -188,6 +188,10 @@ int cmgpu_create_from_reference(const cmgpu_ref_view *ref, int32_t kmer_size, in
                                 const cmgpu_params *params, int device_id, cmgpu_ctx **out);
 int cmgpu_save_index_file(cmgpu_ctx *ctx, const char *path);
 
+/* --chr-order (Chromap::GenerateCustomRidRanks + SequenceBatch::ReorderSequences + RerankCandidatesRid,
+ * src/chromap.cc:867-923, src/chromap.h:654-659, 1060-1074): rank[i] = place of reference sequence i in the
+ * output order.  Records then carry ranks in their rid fields; pass names / lengths in rank order to the writers. */
+int cmgpu_set_chr_order(cmgpu_ctx *ctx, const uint32_t *rank, uint32_t n_sequences);
 /* A further context over the SAME resident index and reference (no copy; the parent must outlive it).
  * Contexts are single-caller, so this is how one GPU keeps several batches in flight: one host
  * thread and one context per batch; their kernels share the compute units. */

@@ -631,6 +631,9 @@ struct ora_ctx {
   const uint32_t *bco;
   uint64_t *bc_key;
   uint64_t n_in_wl, n_corr;
+  /* --chr-order (ora_set_chr_order): rank of every reference sequence and the reference reordered by it */
+  uint32_t *rid_rank;
+  ora_ref ref_ranked;
   /* --SAM run (set by ora_map_*_sam for the duration of the call) */
   ora_sam_record *sam_rec;
   uint32_t *sam_cigar;
@@ -681,6 +684,36 @@ ora_ctx *ora_create(const ora_index *idx, const ora_ref *ref, const ora_params *
   mt_seed(&c->rng, 11);
   return c;
 }
+/* --chr-order (Chromap::GenerateCustomRidRanks chromap.cc:867-913, SequenceBatch::ReorderSequences, chromap.h:654-659):
+ * rank[i] = position of reference sequence i in the custom order.  From here on the context sees the
+ * reference reordered by rank (verification, coordinates, records, output names); candidates keep index
+ * rids until RerankCandidatesRid (chromap.cc:916-923) rewrites them right before verification. */
+int ora_set_chr_order(ora_ctx *c, const uint32_t *rank, uint32_t n) {
+  if (n != c->ref->n_seq) return -1;
+  c->rid_rank = (uint32_t *)malloc((size_t)n * 4);
+  memcpy(c->rid_rank, rank, (size_t)n * 4);
+  c->ref_ranked.n_seq = n;
+  c->ref_ranked.name = (char **)calloc(n, sizeof(char *));
+  c->ref_ranked.seq = (char **)calloc(n, sizeof(char *));
+  c->ref_ranked.len = (uint32_t *)calloc(n, 4);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rank[i] >= n || c->ref_ranked.seq[rank[i]]) return -1;
+    c->ref_ranked.name[rank[i]] = c->ref->name[i];
+    c->ref_ranked.seq[rank[i]] = c->ref->seq[i];
+    c->ref_ranked.len[rank[i]] = c->ref->len[i];
+  }
+  c->ref = &c->ref_ranked;
+  return 0;
+}
+const ora_ref *ora_ctx_ref(const ora_ctx *c) { return c->ref; }
+static void rerank_candidates(const ora_ctx *c, vcand *v) {
+  if (!c->rid_rank) return;
+  for (size_t i = 0; i < v->n; ++i) {
+    const uint64_t rid = c->rid_rank[(uint32_t)(v->a[i].position >> 32)];
+    v->a[i].position = (v->a[i].position & 0xffffffffull) | (rid << 32);
+  }
+}
+
 void ora_destroy(ora_ctx *c) { free(c); }
 void ora_set_trace(ora_ctx *c, ora_trace *t) { c->trace = t; }
 
@@ -2145,6 +2178,8 @@ static long map_one_pair(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint32_t 
   if (tr) { tr->n_cand1 = (uint32_t)nc1; tr->n_cand2 = (uint32_t)nc2; tr->rep1 = m1->rep_len; tr->rep2 = m2->rep_len; }
   if (!(nc1 > 0 && nc2 > 0)) return 0;
   if (st) st->num_candidates += nc1 + nc2;
+  rerank_candidates(c, &m1->pos_cand); rerank_candidates(c, &m1->neg_cand); /* chromap.h:1060-1074 */
+  rerank_candidates(c, &m2->pos_cand); rerank_candidates(c, &m2->neg_cand);
   gen_draft_mappings(c, m1, r1, neg1, len1, st);
   gen_draft_mappings(c, m2, r2, neg2, len2, st);
   const size_t nd1 = m1->pos_map.n + m1->neg_map.n, nd2 = m2->pos_map.n + m2->neg_map.n;
@@ -2629,6 +2664,7 @@ static long map_one_read(const ora_ctx *c, work_t *wk, uint32_t read_index, uint
   const size_t nc = m->pos_cand.n + m->neg_cand.n;
   if (nc == 0) return 0;
   if (st) st->num_candidates += nc;
+  rerank_candidates(c, &m->pos_cand); rerank_candidates(c, &m->neg_cand); /* chromap.h:416-420 */
   gen_draft_mappings(c, m, wk->fw1, wk->neg1, len1, st);
   if (m->pos_map.n + m->neg_map.n == 0) return 0;
   /* a fresh std::mt19937(11) per read (mapping_generator.h:128-139) */

@@ -196,6 +196,10 @@ void ora_banded_traceback(int e, int min_num_errors, const char *pattern, const 
 
 ora_ctx *ora_create(const ora_index *idx, const ora_ref *ref, const ora_params *p);
 void ora_destroy(ora_ctx *c);
+/* --chr-order: rank[i] = position of reference sequence i in the output order (every value 0..n-1 once) */
+int ora_set_chr_order(ora_ctx *c, const uint32_t *rank, uint32_t n);
+/* the reference as the mapping stages and the writers see it (reordered after ora_set_chr_order) */
+const ora_ref *ora_ctx_ref(const ora_ctx *c);
 
 /* Body of the taskloop chromap.h:892-1143 for the n pairs of one input file (read
  * batches of 500000 pairs, taskloop tasks of ~5000 pairs, each task owning a fresh

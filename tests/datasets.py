@@ -76,6 +76,19 @@ def is_sam(name):
     return "--SAM" in case_meta(name)["chromap_flags"]
 
 
+def chr_order_ranks(order, names):
+    """Chromap::GenerateCustomRidRanks (chromap.cc:867-913): rank per reference sequence"""
+    pos = {n: i for i, n in enumerate(order)}
+    ranks = [pos.get(n.decode() if isinstance(n, bytes) else n, -1) for n in names]
+    k = len(pos)
+    for i, r in enumerate(ranks):
+        if r < 0:
+            ranks[i] = k
+            k += 1
+    assert k == len(names), "unknown chromosome names in the order"
+    return ranks
+
+
 def is_hic(name):
     return "hic" in case_meta(name)["chromap_flags"]
 
@@ -95,6 +108,9 @@ def flags_to_params(flags):
         elif flags[i] == "--remove-pcr-duplicates-at-bulk-level":
             kw["dedup_at_bulk_level"] = 1
             i += 1
+        elif flags[i] == "--chr-order":
+            kw["chr_order"] = flags[i + 1].split(",")
+            i += 2
         elif flags[i] == "--SAM":
             kw["output_format"] = 1
             i += 1

@@ -73,6 +73,13 @@ CASES = {
                      "--varlen", "--seed", "7"], ["--preset", "atac", "--SAM"]),
     "s1_se_sam": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
                   ["--SAM", "--remove-pcr-duplicates"]),
+    # --chr-order: reference reordered, candidate rids re-ranked before verification (flag value: comma list,
+    # written to a file for the reference; unlisted chromosomes follow in reference order)
+    "s3_chip_chrorder": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",
+                          "--indel", "0.003", "--sub", "0.02"], ["--preset", "chip", "--chr-order", "chr4,chr2,chr5"]),
+    "h1_hic_chrorder_q0": (["--genome", "3000000", "--chroms", "4", "--pairs", "20000", "--readlen", "150", "--frag-min", "300",
+                            "--frag-max", "800", "--hic", "--seed", "21", "--indel", "0.001"],
+                           ["--preset", "hic", "-q", "0", "--chr-order", "chr3,chr1"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
@@ -107,7 +114,14 @@ def main():
             reads = ["-1", r1, "-2", r2]
             if name in SINGLE_END:
                 reads = ["-1", r1 if SINGLE_END[name] == 1 else r2]
-            log = subprocess.run([REF] + flags + extra + ["-x", idx, "-r", fa] + reads + ["-o", out, "-t", "1"],
+            run_flags = list(flags)
+            if "--chr-order" in run_flags:
+                k = run_flags.index("--chr-order")
+                order_file = os.path.join(tmp, "order.txt")
+                with open(order_file, "w") as f:
+                    f.write("\n".join(run_flags[k + 1].split(",")) + "\n")
+                run_flags[k + 1] = order_file
+            log = subprocess.run([REF] + run_flags + extra + ["-x", idx, "-r", fa] + reads + ["-o", out, "-t", "1"],
                                  stderr=subprocess.PIPE, check=True).stderr.decode()
             stats = {}
             for key, pat in (("num_reads", r"Number of reads: (\d+)"), ("num_mapped_reads", r"Number of mapped reads: (\d+)"),

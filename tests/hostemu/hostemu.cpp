@@ -20,6 +20,10 @@ static void scan(const T *in, uint32_t *out, uint32_t n) {
   out[n] = s;
 }
 
+// --chr-order for the next calls (empty: none); set by hostemu_set_chr_order
+static std::vector<uint32_t> g_rank;
+extern "C" void hostemu_set_chr_order(const uint32_t *rank, uint32_t n) { g_rank.assign(rank, rank + n); }
+
 struct EmuSam {
   cmgpu_sam_record *rec;  // 2n (pairs) or n (single) slots
   uint32_t *cigar;
@@ -59,6 +63,12 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   std::vector<uint8_t> refb(tot, 0);
   for (uint32_t i = 0; i < ref->n_sequences; ++i) memcpy(refb.data() + roff[i], ref->sequences[i], ref->lengths[i]);
   d.ref = refb.data(); d.ref_off = roff.data(); d.ref_len = ref->lengths; d.n_seq = ref->n_sequences;
+  std::vector<uint64_t> roff_r(ref->n_sequences);
+  std::vector<uint32_t> rlen_r(ref->n_sequences);
+  if (g_rank.size() == ref->n_sequences) {  // cmgpu_set_chr_order: the stages see the reference reordered by rank
+    for (uint32_t i = 0; i < ref->n_sequences; ++i) { roff_r[g_rank[i]] = roff[i]; rlen_r[g_rank[i]] = ref->lengths[i]; }
+    d.ref_off = roff_r.data(); d.ref_len = rlen_r.data(); d.rid_rank = g_rank.data();
+  }
   CmParams &p = d.p;
   p.e = params->error_threshold; p.min_seeds = params->min_num_seeds; p.f0 = params->max_seed_frequency0;
   p.f1 = params->max_seed_frequency1; p.max_insert = params->max_insert_size; p.min_read_len = params->min_read_length;

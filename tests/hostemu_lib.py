@@ -41,7 +41,10 @@ def params(preset=None, **kw):
     if preset:
         assert L.cmgpu_apply_preset(C.byref(p), preset.encode()) == 0
     for k, v in kw.items():
-        setattr(p, k, v)
+        if k == "chr_order":
+            p._chr_order = list(v)  # applied by HostEmu.__init__
+        else:
+            setattr(p, k, v)
     return p
 
 
@@ -54,6 +57,18 @@ class HostEmu:
         assert self.L.cmgpu_load_reference_fasta(ref_path.encode(), C.byref(self.ref)) == 0
         self.p = p
         self.names = [self.ref.names[i] for i in range(self.ref.n_sequences)]
+        self.rank = None
+        order = getattr(p, "_chr_order", None)
+        if order:
+            import datasets
+            self.rank = datasets.chr_order_ranks(order, self.names)
+            names = [None] * len(self.rank)
+            for i, r in enumerate(self.rank):
+                names[r] = self.names[i]
+            self.names = names
+        arr = (C.c_uint32 * max(1, len(self.rank or [])))(*(self.rank or [0]))
+        self.L.hostemu_set_chr_order.argtypes = [C.c_void_p, C.c_uint32]
+        self.L.hostemu_set_chr_order(arr, len(self.rank or []))
 
     def map_pairs(self, b1, o1, b2, o2, first_read_id=0):
         n = len(o1) - 1
@@ -116,7 +131,13 @@ class HostEmu:
 
     def write_pairs(self, rec, n, read_names, path):
         names = (C.c_char_p * len(self.names))(*self.names)
-        lens = (C.c_uint32 * len(self.names))(*[self.ref.lengths[i] for i in range(len(self.names))])
+        ll = [self.ref.lengths[i] for i in range(len(self.names))]
+        if self.rank:
+            ll2 = [0] * len(ll)
+            for i, r in enumerate(self.rank):
+                ll2[r] = ll[i]
+            ll = ll2
+        lens = (C.c_uint32 * len(self.names))(*ll)
         rn = (C.c_char_p * len(read_names))(*read_names)
         return self.L.cmgpu_write_pairs(names, lens, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n, rn, 0,
                                         path.encode())

@@ -108,7 +108,10 @@ def params(preset=None, **kw):
     if preset:
         L.ora_preset(C.byref(p), preset.encode())
     for k, v in kw.items():
-        setattr(p, k, v)
+        if k == "chr_order":
+            p._chr_order = list(v)  # applied by Oracle.__init__ (ora_set_chr_order)
+        else:
+            setattr(p, k, v)
     return p
 
 
@@ -146,6 +149,18 @@ class Oracle:
             raise IOError(index_path)
         self.p = p
         self.ctx = L.ora_create(C.byref(self.idx), C.byref(self.ref), C.byref(p))
+        order = getattr(p, "_chr_order", None)
+        if order:
+            import datasets
+            names = [self.ref.name[i] for i in range(self.ref.n_seq)]
+            ranks = datasets.chr_order_ranks(order, names)
+            arr = (C.c_uint32 * len(ranks))(*ranks)
+            L.ora_set_chr_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+            assert L.ora_set_chr_order(self.ctx, arr, len(ranks)) == 0
+            L.ora_ctx_ref.restype = C.POINTER(OraRef)
+            L.ora_ctx_ref.argtypes = [C.c_void_p]
+            self._ref_loaded = self.ref              # owns the sequences
+            self.ref = L.ora_ctx_ref(self.ctx).contents  # the reordered view the writers print from
 
     def map_pairs(self, b1, o1, b2, o2, first_read_id=0, threads=0, trace=False):
         import numpy as np
@@ -179,7 +194,7 @@ class Oracle:
             self.L.ora_destroy(self.ctx)
             self.ctx = None
             self.L.ora_index_free(C.byref(self.idx))
-            self.L.ora_ref_free(C.byref(self.ref))
+            self.L.ora_ref_free(C.byref(getattr(self, "_ref_loaded", self.ref)))
 
 
 class OraPairsRecord(C.Structure):
