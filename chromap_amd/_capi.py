@@ -91,7 +91,7 @@ assert C.sizeof(RecordBc) == 32
 
 # every symbol include/chromap_amd.h declares
 SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_create_from_reference",
-           "cmgpu_save_index_file", "cmgpu_create_shared", "cmgpu_set_chr_order", "cmgpu_destroy",
+           "cmgpu_save_index_file", "cmgpu_create_shared", "cmgpu_set_chr_order", "cmgpu_set_pairs_chr_order", "cmgpu_write_pairs_ranked", "cmgpu_destroy",
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_map_pairs_async", "cmgpu_wait", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device", "cmgpu_records_partition",
@@ -124,6 +124,9 @@ def declare(L):
     sig("cmgpu_create_from_reference", C.c_int, [P(RefView), C.c_int32, C.c_int32, P(Params), C.c_int, P(C.c_void_p)])
     sig("cmgpu_save_index_file", C.c_int, [C.c_void_p, C.c_char_p])
     sig("cmgpu_set_chr_order", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32])
+    sig("cmgpu_set_pairs_chr_order", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32])
+    sig("cmgpu_write_pairs_ranked", C.c_int64, [P(C.c_char_p), P(C.c_uint32), C.c_uint32, P(Params), C.c_void_p, C.c_uint64,
+                                                P(C.c_char_p), C.c_uint32, C.c_void_p, C.c_char_p])
     sig("cmgpu_create_shared", C.c_int, [C.c_void_p, P(C.c_void_p)])
     sig("cmgpu_destroy", C.c_int, [C.c_void_p])
     sig("cmgpu_last_error", C.c_char_p, [C.c_void_p])

@@ -250,6 +250,16 @@ extern "C" int cmgpu_set_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t 
   return CMGPU_OK;
 }
 
+extern "C" int cmgpu_set_pairs_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t n) {
+  if (!c || !rank) return CMGPU_EINVAL;
+  if (n != c->n_seq) { cm_set_error(c, "rank table size differs from the number of reference sequences"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  if (c->pairs_rank.ensure((size_t)n * 4)) { cm_set_error(c, "out of device memory (pairs order)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemcpy(c->pairs_rank.p, rank, (size_t)n * 4, hipMemcpyHostToDevice));
+  c->has_pairs_rank = true;
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (!c) return CMGPU_OK;
   if (c->in_flight) { c->worker.join(); c->in_flight = false; }
@@ -346,6 +356,7 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
     d.ref_off = (const uint64_t *)c->ref_off_r.p;
     d.ref_len = (const uint32_t *)c->ref_len_r.p;
   }
+  if (c->has_pairs_rank) d.pairs_rank = (const uint32_t *)c->pairs_rank.p;
   if (c->has_barcodes) {
     d.bcb = (const uint8_t *)c->bcb.p; d.bcq = (const uint8_t *)c->bcq.p; d.bco = (const uint32_t *)c->bco.p;
     d.wl = (const uint64_t *)c->wl.p; d.wl_mask = c->wl_mask; d.wl_num_sample = (double)c->wl_num_sample;

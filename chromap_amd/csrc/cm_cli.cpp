@@ -105,7 +105,7 @@ struct ChunkReader {
 };
 
 struct Args {
-  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path;
+  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path, pairs_order_path;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
@@ -179,6 +179,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
     else if (o == "--chr-order") a.chr_order_path = need("--chr-order");
+    else if (o == "--pairs-natural-chr-order") a.pairs_order_path = need("--pairs-natural-chr-order");
     else if (o == "--device") a.device = atoi(need("--device"));
     else if (o == "--host-ingest") a.host_ingest = true;   // kseq-style host parser (FASTA / multi-line records)
     else if (o == "--ingest-chunk-mb") a.chunk_bytes = (size_t)atol(need("--ingest-chunk-mb")) << 20;
@@ -190,7 +191,7 @@ static Args parse(int argc, char **argv) {
              "       --remove-pcr-duplicates --Tn5-shift --low-mem --BED|--pairs --bc-error-threshold ...]\n");
       exit(0);
     }
-    else die("unsupported option " + o + " (PAF, --pairs-natural-chr-order and summary outputs are outside this build)");
+    else die("unsupported option " + o + " (PAF and summary outputs are outside this build)");
   }
   if (a.out_sam) {
     if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
@@ -235,27 +236,34 @@ int main(int argc, char **argv) {
   // sequences follow in reference order; names / lengths for the writers are permuted the same way
   std::vector<const char *> out_names(ref.names, ref.names + ref.n_sequences);
   std::vector<uint32_t> out_lengths(ref.lengths, ref.lengths + ref.n_sequences);
-  if (!a.chr_order_path.empty()) {
-    FILE *of = fopen(a.chr_order_path.c_str(), "r");
-    if (!of) die("Cannot open chromosome order file " + a.chr_order_path);
+  // ranks of `names` under an order file (Chromap::GenerateCustomRidRanks)
+  auto ranks_from_file = [&](const std::string &path, const std::vector<const char *> &names) {
+    FILE *of = fopen(path.c_str(), "r");
+    if (!of) die("Cannot open chromosome order file " + path);
     std::vector<std::string> order;
     char lb[4096];
     while (fgets(lb, sizeof(lb), of)) { size_t l = strlen(lb); while (l && (lb[l - 1] == '\n' || lb[l - 1] == '\r')) lb[--l] = 0; order.push_back(lb); }
     fclose(of);
-    std::vector<uint32_t> rank(ref.n_sequences, 0xffffffffu);
+    std::vector<uint32_t> rank(names.size(), 0xffffffffu);
     // later lines win for a repeated name, like the reference's map assignment
-    for (uint32_t i = 0; i < ref.n_sequences; ++i)
-      for (size_t j = 0; j < order.size(); ++j) if (order[j] == ref.names[i]) rank[i] = (uint32_t)j;
-    uint32_t k = 0;
-    {  // number of distinct names in the file = first free rank
-      std::vector<std::string> uniq(order);
-      std::sort(uniq.begin(), uniq.end());
-      k = (uint32_t)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
-    }
-    for (uint32_t i = 0; i < ref.n_sequences; ++i) if (rank[i] == 0xffffffffu) rank[i] = k++;
-    if (k > ref.n_sequences) die("ERROR: unknown chromsome names found in chromosome order file.");
+    for (size_t i = 0; i < names.size(); ++i)
+      for (size_t j = 0; j < order.size(); ++j) if (order[j] == names[i]) rank[i] = (uint32_t)j;
+    std::vector<std::string> uniq(order);
+    std::sort(uniq.begin(), uniq.end());
+    uint32_t k = (uint32_t)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());  // distinct names = first free rank
+    for (size_t i = 0; i < names.size(); ++i) if (rank[i] == 0xffffffffu) rank[i] = k++;
+    if (k > names.size()) die("ERROR: unknown chromsome names found in chromosome order file.");
+    return rank;
+  };
+  if (!a.chr_order_path.empty()) {
+    const std::vector<uint32_t> rank = ranks_from_file(a.chr_order_path, out_names);
     if (cmgpu_set_chr_order(ctx, rank.data(), ref.n_sequences) != CMGPU_OK) die(cmgpu_last_error(ctx));
     for (uint32_t i = 0; i < ref.n_sequences; ++i) { out_names[rank[i]] = ref.names[i]; out_lengths[rank[i]] = ref.lengths[i]; }
+  }
+  std::vector<uint32_t> pairs_rank;  // over the (possibly reordered) sequences, like the reference computes it
+  if (!a.pairs_order_path.empty() && a.out_pairs) {
+    pairs_rank = ranks_from_file(a.pairs_order_path, out_names);
+    if (cmgpu_set_pairs_chr_order(ctx, pairs_rank.data(), ref.n_sequences) != CMGPU_OK) die(cmgpu_last_error(ctx));
   }
 
   cmgpu_stats st;
@@ -508,7 +516,8 @@ int main(int argc, char **argv) {
   } else if (a.out_pairs) {
     std::vector<const char *> rn(read_names.size());
     for (size_t i = 0; i < rn.size(); ++i) rn[i] = read_names[i].c_str();
-    lines = cmgpu_write_pairs(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
+    lines = cmgpu_write_pairs_ranked(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
+                                     pairs_rank.empty() ? nullptr : pairs_rank.data(),
                               a.out_path.c_str());
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device

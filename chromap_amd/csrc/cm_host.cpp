@@ -243,6 +243,15 @@ extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_seque
 extern "C" int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
                                      const cmgpu_params *p, cmgpu_pairs_record *rec, uint64_t n,
                                      const char *const *read_names, uint32_t read_id_base, const char *out_path) {
+  return cmgpu_write_pairs_ranked(names, lengths, n_sequences, p, rec, n, read_names, read_id_base, nullptr, out_path);
+}
+
+// pairs_rank (--pairs-natural-chr-order) only orders the #chromsize header lines here (mapping_writer.cc:385-399);
+// the flip of the two ends was done on the device with the same table (cmgpu_set_pairs_chr_order)
+extern "C" int64_t cmgpu_write_pairs_ranked(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
+                                            const cmgpu_params *p, cmgpu_pairs_record *rec, uint64_t n,
+                                            const char *const *read_names, uint32_t read_id_base, const uint32_t *pairs_rank,
+                                            const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
   std::sort(rec, rec + n, [](const cmgpu_pairs_record &a, const cmgpu_pairs_record &b) {
@@ -252,10 +261,12 @@ extern "C" int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *l
   buf.reserve(1 << 20);
   buf.append("## pairs format v1.0.0\n#shape: upper triangle\n");
   for (uint32_t i = 0; i < n_sequences; ++i) {
+    uint32_t rid = i;
+    if (pairs_rank) for (uint32_t j = 0; j < n_sequences; ++j) if (pairs_rank[j] == i) rid = j;
     buf.append("#chromsize: ");
-    buf.append(names[i]);
+    buf.append(names[rid]);
     buf.push_back(' ');
-    put_u32(buf, lengths[i]);
+    put_u32(buf, lengths[rid]);
     buf.push_back('\n');
   }
   buf.append("#columns: readID chrom1 pos1 chrom2 pos2 strand1 strand2 pair_type mapq1 mapq2\n");

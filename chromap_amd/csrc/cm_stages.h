@@ -2345,7 +2345,8 @@ CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   uint8_t st1 = s1 == 0 ? 1 : 0, st2 = s2 == 0 ? 1 : 0;
   int pos1 = (int)(s1 == 0 ? a.ref_start : a.ref_end), pos2 = (int)(s2 == 0 ? b.ref_start : b.ref_end);
   int rid1 = (int)a.rid, rid2 = (int)b.rid;
-  if (!(rid1 < rid2 || (rid1 == rid2 && pos1 < pos2))) {
+  const uint32_t k1 = d.pairs_rank ? d.pairs_rank[rid1] : (uint32_t)rid1, k2 = d.pairs_rank ? d.pairs_rank[rid2] : (uint32_t)rid2;
+  if (!(k1 < k2 || (rid1 == rid2 && pos1 < pos2))) {  // mapping_generator.cc:193-203
     int t = rid1; rid1 = rid2; rid2 = t;
     t = pos1; pos1 = pos2; pos2 = t;
     const uint8_t u = st1; st1 = st2; st2 = u;

@@ -142,6 +142,7 @@ struct CmDev {
   // ---- --chr-order: rank of every index rid, or nullptr.  When set, ref_off / ref_len above are the arrays
   //      REORDERED by rank: every stage from verification on works in rank space (cm_s4c_reduce re-ranks).
   const uint32_t *rid_rank;
+  const uint32_t *pairs_rank;  // --pairs-natural-chr-order: rank deciding the order of a pair's two ends, or nullptr
   // ---- --SAM (per slot: 2*pair + mate): 40-byte cmgpu_sam_record, CM_SAM_CIGAR_CAP cigar words, sam_md_cap MD bytes;
   //      sam_z: backtrack cells of the pair being aligned, word (row*ZW + q) * n_pairs + pair
   uint8_t *sam_rec;

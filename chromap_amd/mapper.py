@@ -76,6 +76,7 @@ class ChromapGPU:
                  build_index=None, shared_from=None, **overrides):
         self.L = _capi.lib()
         chr_order = overrides.pop("chr_order", None)
+        pairs_order = overrides.pop("pairs_order", None)
         self.params = params if params is not None else _capi.default_params(preset, **overrides)
         self.ctx = C.c_void_p()
         self._idx = None
@@ -115,8 +116,29 @@ class ChromapGPU:
             self.names = [self._ref.names[i] for i in range(self._ref.n_sequences)]
         self.stats = Stats()
         self.rank = None
+        self.pairs_rank = None
         if chr_order:
             self.set_chr_order(chr_order)
+        if pairs_order:
+            self.set_pairs_chr_order(pairs_order)
+
+    def _ranks(self, order):
+        pos = {(n if isinstance(n, bytes) else n.encode()): i for i, n in enumerate(order)}
+        ranks = [pos.get(n, -1) for n in self.names]
+        k = len(pos)
+        for i, r in enumerate(ranks):
+            if r < 0:
+                ranks[i] = k
+                k += 1
+        if k != len(self.names):
+            raise ChromapError("ERROR: unknown chromsome names found in chromosome order file.")
+        return ranks
+
+    def set_pairs_chr_order(self, order):
+        """--pairs-natural-chr-order: which end of a pair is written first, and the header order (call after set_chr_order)"""
+        self.pairs_rank = self._ranks(order)
+        arr = (C.c_uint32 * len(self.pairs_rank))(*self.pairs_rank)
+        self._check(self.L.cmgpu_set_pairs_chr_order(self.ctx, arr, len(self.pairs_rank)), self.ctx)
 
     def set_chr_order(self, order):
         """--chr-order: names in output order (unlisted sequences follow in reference order); from now on
@@ -376,8 +398,9 @@ class ChromapGPU:
         names = (C.c_char_p * len(self.names))(*self.names)
         lens = self.reference_lengths()
         rn = (C.c_char_p * len(read_names))(*read_names)
-        k = self.L.cmgpu_write_pairs(names, lens, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, rn,
-                                     read_id_base, path.encode())
+        pr = (C.c_uint32 * len(self.pairs_rank))(*self.pairs_rank) if self.pairs_rank else None
+        k = self.L.cmgpu_write_pairs_ranked(names, lens, len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, rn,
+                                            read_id_base, pr, path.encode())
         if k < 0:
             raise ChromapError("cannot write %s" % path)
         return int(k)

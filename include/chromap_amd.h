@@ -192,6 +192,9 @@ int cmgpu_save_index_file(cmgpu_ctx *ctx, const char *path);
  * src/chromap.cc:867-923, src/chromap.h:654-659, 1060-1074): rank[i] = place of reference sequence i in the
  * output order.  Records then carry ranks in their rid fields; pass names / lengths in rank order to the writers. */
 int cmgpu_set_chr_order(cmgpu_ctx *ctx, const uint32_t *rank, uint32_t n_sequences);
+/* --pairs-natural-chr-order (src/chromap.h:660-664, src/mapping_generator.cc:193-203): rank, over the sequences as the
+ * records number them, that decides which end of a pair is written first; cmgpu_write_pairs_ranked orders the header by it. */
+int cmgpu_set_pairs_chr_order(cmgpu_ctx *ctx, const uint32_t *rank, uint32_t n_sequences);
 /* A further context over the SAME resident index and reference (no copy; the parent must outlive it).
  * Contexts are single-caller, so this is how one GPU keeps several batches in flight: one host
  * thread and one context per batch; their kernels share the compute units. */
@@ -406,6 +409,10 @@ int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_sequences, const
 int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
                           const cmgpu_params *params, cmgpu_pairs_record *records, uint64_t n_records,
                           const char *const *read_names, uint32_t read_id_base, const char *out_path);
+int64_t cmgpu_write_pairs_ranked(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
+                                 const cmgpu_params *params, cmgpu_pairs_record *records, uint64_t n_records,
+                                 const char *const *read_names, uint32_t read_id_base, const uint32_t *pairs_rank,
+                                 const char *out_path);
 
 /* Host loaders mirroring Index::Load and SequenceBatch::LoadAllSequences for callers
  * that do not have the reference's own objects (the CLI, Python).  Free with

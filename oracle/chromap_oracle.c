@@ -634,6 +634,7 @@ struct ora_ctx {
   /* --chr-order (ora_set_chr_order): rank of every reference sequence and the reference reordered by it */
   uint32_t *rid_rank;
   ora_ref ref_ranked;
+  uint32_t *pairs_rank; /* --pairs-natural-chr-order: rank used by the pairs flip (mapping_generator.cc:193-203) */
   /* --SAM run (set by ora_map_*_sam for the duration of the call) */
   ora_sam_record *sam_rec;
   uint32_t *sam_cigar;
@@ -706,6 +707,12 @@ int ora_set_chr_order(ora_ctx *c, const uint32_t *rank, uint32_t n) {
   return 0;
 }
 const ora_ref *ora_ctx_ref(const ora_ctx *c) { return c->ref; }
+int ora_set_pairs_chr_order(ora_ctx *c, const uint32_t *rank, uint32_t n) {
+  if (n != c->ref->n_seq) return -1;
+  c->pairs_rank = (uint32_t *)malloc((size_t)n * 4);
+  memcpy(c->pairs_rank, rank, (size_t)n * 4);
+  return 0;
+}
 static void rerank_candidates(const ora_ctx *c, vcand *v) {
   if (!c->rid_rank) return;
   for (size_t i = 0; i < v->n; ++i) {
@@ -2098,7 +2105,8 @@ static long finish_pair_split(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint
         uint8_t st1 = S1[o] == 0 ? 1 : 0, st2 = S2[o] == 0 ? 1 : 0;
         int pos1 = (int)(S1[o] == 0 ? x.ref_start : x.ref_end), pos2 = (int)(S2[o] == 0 ? y.ref_start : y.ref_end);
         int rid1 = (int)x.rid, rid2 = (int)y.rid;
-        const int smaller = rid1 < rid2 || (rid1 == rid2 && pos1 < pos2);
+        const uint32_t k1 = c->pairs_rank ? c->pairs_rank[rid1] : (uint32_t)rid1, k2 = c->pairs_rank ? c->pairs_rank[rid2] : (uint32_t)rid2;
+        const int smaller = k1 < k2 || (rid1 == rid2 && pos1 < pos2);
         if (!smaller) {
           int t = rid1; rid1 = rid2; rid2 = t;
           t = pos1; pos1 = pos2; pos2 = t;
@@ -2467,13 +2475,25 @@ static int cmp_pairs_rec(const void *a, const void *b) {
   return 0;
 }
 
+static const uint32_t *g_pairs_header_rank; /* set by ora_write_pairs_ranked for one call */
+long ora_write_pairs_ranked(const ora_ref *ref, const ora_params *p, ora_pairs_record *rec, long n, const char *const *read_names,
+                            const uint32_t *pairs_rank, const char *out_path) {
+  g_pairs_header_rank = pairs_rank;
+  const long k = ora_write_pairs(ref, p, rec, n, read_names, out_path);
+  g_pairs_header_rank = NULL;
+  return k;
+}
 long ora_write_pairs(const ora_ref *ref, const ora_params *p, ora_pairs_record *rec, long n,
                      const char *const *read_names, const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return -1;
   qsort(rec, (size_t)n, sizeof(ora_pairs_record), cmp_pairs_rec);
   fprintf(f, "## pairs format v1.0.0\n#shape: upper triangle\n");
-  for (uint32_t i = 0; i < ref->n_seq; ++i) fprintf(f, "#chromsize: %s %u\n", ref->name[i], ref->len[i]);
+  for (uint32_t i = 0; i < ref->n_seq; ++i) { /* header in pairs-rank order (mapping_writer.cc:385-399) */
+    uint32_t rid = i;
+    if (g_pairs_header_rank) for (uint32_t j = 0; j < ref->n_seq; ++j) if (g_pairs_header_rank[j] == i) rid = j;
+    fprintf(f, "#chromsize: %s %u\n", ref->name[rid], ref->len[rid]);
+  }
   fprintf(f, "#columns: readID chrom1 pos1 chrom2 pos2 strand1 strand2 pair_type mapq1 mapq2\n");
   long lines = 0;
   for (long i = 0; i < n; ++i) {

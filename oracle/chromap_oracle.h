@@ -200,6 +200,10 @@ void ora_destroy(ora_ctx *c);
 int ora_set_chr_order(ora_ctx *c, const uint32_t *rank, uint32_t n);
 /* the reference as the mapping stages and the writers see it (reordered after ora_set_chr_order) */
 const ora_ref *ora_ctx_ref(const ora_ctx *c);
+/* --pairs-natural-chr-order: rank (over the possibly reordered reference) that decides which end of a pair comes first */
+int ora_set_pairs_chr_order(ora_ctx *c, const uint32_t *rank, uint32_t n);
+long ora_write_pairs_ranked(const ora_ref *ref, const ora_params *p, ora_pairs_record *rec, long n, const char *const *read_names,
+                            const uint32_t *pairs_rank, const char *out_path);
 
 /* Body of the taskloop chromap.h:892-1143 for the n pairs of one input file (read
  * batches of 500000 pairs, taskloop tasks of ~5000 pairs, each task owning a fresh

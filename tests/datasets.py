@@ -111,6 +111,9 @@ def flags_to_params(flags):
         elif flags[i] == "--chr-order":
             kw["chr_order"] = flags[i + 1].split(",")
             i += 2
+        elif flags[i] == "--pairs-natural-chr-order":
+            kw["pairs_order"] = flags[i + 1].split(",")
+            i += 2
         elif flags[i] == "--SAM":
             kw["output_format"] = 1
             i += 1

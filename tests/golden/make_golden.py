@@ -80,6 +80,9 @@ CASES = {
     "h1_hic_chrorder_q0": (["--genome", "3000000", "--chroms", "4", "--pairs", "20000", "--readlen", "150", "--frag-min", "300",
                             "--frag-max", "800", "--hic", "--seed", "21", "--indel", "0.001"],
                            ["--preset", "hic", "-q", "0", "--chr-order", "chr3,chr1"]),
+    "h2_hic_natural_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
+                           "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
+                          ["--preset", "hic", "-q", "0", "--pairs-natural-chr-order", "chr3,chr1,chr2"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
 }
@@ -115,12 +118,13 @@ def main():
             if name in SINGLE_END:
                 reads = ["-1", r1 if SINGLE_END[name] == 1 else r2]
             run_flags = list(flags)
-            if "--chr-order" in run_flags:
-                k = run_flags.index("--chr-order")
-                order_file = os.path.join(tmp, "order.txt")
-                with open(order_file, "w") as f:
-                    f.write("\n".join(run_flags[k + 1].split(",")) + "\n")
-                run_flags[k + 1] = order_file
+            for of in ("--chr-order", "--pairs-natural-chr-order"):
+                if of in run_flags:
+                    k = run_flags.index(of)
+                    order_file = os.path.join(tmp, of.strip("-") + ".txt")
+                    with open(order_file, "w") as f:
+                        f.write("\n".join(run_flags[k + 1].split(",")) + "\n")
+                    run_flags[k + 1] = order_file
             log = subprocess.run([REF] + run_flags + extra + ["-x", idx, "-r", fa] + reads + ["-o", out, "-t", "1"],
                                  stderr=subprocess.PIPE, check=True).stderr.decode()
             stats = {}

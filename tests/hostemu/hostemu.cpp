@@ -23,6 +23,8 @@ static void scan(const T *in, uint32_t *out, uint32_t n) {
 // --chr-order for the next calls (empty: none); set by hostemu_set_chr_order
 static std::vector<uint32_t> g_rank;
 extern "C" void hostemu_set_chr_order(const uint32_t *rank, uint32_t n) { g_rank.assign(rank, rank + n); }
+static std::vector<uint32_t> g_pairs_rank;
+extern "C" void hostemu_set_pairs_chr_order(const uint32_t *rank, uint32_t n) { g_pairs_rank.assign(rank, rank + n); }
 
 struct EmuSam {
   cmgpu_sam_record *rec;  // 2n (pairs) or n (single) slots
@@ -69,6 +71,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     for (uint32_t i = 0; i < ref->n_sequences; ++i) { roff_r[g_rank[i]] = roff[i]; rlen_r[g_rank[i]] = ref->lengths[i]; }
     d.ref_off = roff_r.data(); d.ref_len = rlen_r.data(); d.rid_rank = g_rank.data();
   }
+  if (g_pairs_rank.size() == ref->n_sequences) d.pairs_rank = g_pairs_rank.data();
   CmParams &p = d.p;
   p.e = params->error_threshold; p.min_seeds = params->min_num_seeds; p.f0 = params->max_seed_frequency0;
   p.f1 = params->max_seed_frequency1; p.max_insert = params->max_insert_size; p.min_read_len = params->min_read_length;

@@ -43,6 +43,8 @@ def params(preset=None, **kw):
     for k, v in kw.items():
         if k == "chr_order":
             p._chr_order = list(v)  # applied by HostEmu.__init__
+        elif k == "pairs_order":
+            p._pairs_order = list(v)
         else:
             setattr(p, k, v)
     return p
@@ -69,6 +71,14 @@ class HostEmu:
         arr = (C.c_uint32 * max(1, len(self.rank or [])))(*(self.rank or [0]))
         self.L.hostemu_set_chr_order.argtypes = [C.c_void_p, C.c_uint32]
         self.L.hostemu_set_chr_order(arr, len(self.rank or []))
+        self.pairs_rank = None
+        porder = getattr(p, "_pairs_order", None)
+        if porder:
+            import datasets
+            self.pairs_rank = datasets.chr_order_ranks(porder, self.names)
+        arr2 = (C.c_uint32 * max(1, len(self.pairs_rank or [])))(*(self.pairs_rank or [0]))
+        self.L.hostemu_set_pairs_chr_order.argtypes = [C.c_void_p, C.c_uint32]
+        self.L.hostemu_set_pairs_chr_order(arr2, len(self.pairs_rank or []))
 
     def map_pairs(self, b1, o1, b2, o2, first_read_id=0):
         n = len(o1) - 1
@@ -139,7 +149,8 @@ class HostEmu:
             ll = ll2
         lens = (C.c_uint32 * len(self.names))(*ll)
         rn = (C.c_char_p * len(read_names))(*read_names)
-        return self.L.cmgpu_write_pairs(names, lens, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n, rn, 0,
+        pr = (C.c_uint32 * len(self.pairs_rank))(*self.pairs_rank) if self.pairs_rank else None
+        return self.L.cmgpu_write_pairs_ranked(names, lens, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n, rn, 0, pr,
                                         path.encode())
 
     def write_bed(self, rec, n, path):

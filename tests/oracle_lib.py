@@ -110,6 +110,8 @@ def params(preset=None, **kw):
     for k, v in kw.items():
         if k == "chr_order":
             p._chr_order = list(v)  # applied by Oracle.__init__ (ora_set_chr_order)
+        elif k == "pairs_order":
+            p._pairs_order = list(v)
         else:
             setattr(p, k, v)
     return p
@@ -161,6 +163,15 @@ class Oracle:
             L.ora_ctx_ref.argtypes = [C.c_void_p]
             self._ref_loaded = self.ref              # owns the sequences
             self.ref = L.ora_ctx_ref(self.ctx).contents  # the reordered view the writers print from
+        self.pairs_rank = None
+        porder = getattr(p, "_pairs_order", None)
+        if porder:
+            import datasets
+            names = [self.ref.name[i] for i in range(self.ref.n_seq)]
+            self.pairs_rank = datasets.chr_order_ranks(porder, names)
+            arr = (C.c_uint32 * len(self.pairs_rank))(*self.pairs_rank)
+            L.ora_set_pairs_chr_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+            assert L.ora_set_pairs_chr_order(self.ctx, arr, len(self.pairs_rank)) == 0
 
     def map_pairs(self, b1, o1, b2, o2, first_read_id=0, threads=0, trace=False):
         import numpy as np
@@ -231,6 +242,12 @@ def write_pairs(oracle, rec, k, names, path):
     L.ora_write_pairs.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long,
                                   C.POINTER(C.c_char_p), C.c_char_p]
     arr = (C.c_char_p * len(names))(*names)
+    if oracle.pairs_rank:
+        L.ora_write_pairs_ranked.restype = C.c_long
+        L.ora_write_pairs_ranked.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.POINTER(C.c_char_p),
+                                             C.c_void_p, C.c_char_p]
+        pr = (C.c_uint32 * len(oracle.pairs_rank))(*oracle.pairs_rank)
+        return L.ora_write_pairs_ranked(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, arr, pr, path.encode())
     return L.ora_write_pairs(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, arr, path.encode())
 
 

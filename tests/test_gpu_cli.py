@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 CLI = os.path.join(ds.ROOT, "chromap_amd", "chromap-amd")
 REF = os.path.join(ds.ROOT, "oracle", "_ref", "chromap")
 CASES = ["toy_atac", "s1_atac", "s2_atac_q0", "s3_chip", "h1_hic", "b1_atac_bc", "b2_atac_bc2_q0", "b3_bulk_level_bc_q0", "s1_se_chip", "s4_se_atac_q0",
-         "s4_inmem_q0", "s4_se_inmem_q0", "b1_inmem_bc", "s1_inmem_nodedup", "s1_chip_sam", "s3_sam_q0", "s2_atac_sam", "s1_se_sam", "s3_chip_chrorder", "h1_hic_chrorder_q0"]
+         "s4_inmem_q0", "s4_se_inmem_q0", "b1_inmem_bc", "s1_inmem_nodedup", "s1_chip_sam", "s3_sam_q0", "s2_atac_sam", "s1_se_sam", "s3_chip_chrorder", "h1_hic_chrorder_q0", "h2_hic_natural_q0"]
 
 
 def _reads(name):
@@ -50,12 +50,13 @@ def test_cli_matches_reference_output(name, built, tmp_path):
     fa, reads = _reads(name)
     out = str(tmp_path / "out.txt")
     flags = list(meta["chromap_flags"])
-    if "--chr-order" in flags:  # the golden metadata keeps the order as a comma list; the programs read a file
-        k = flags.index("--chr-order")
-        order = str(tmp_path / "order.txt")
-        with open(order, "w") as f:
-            f.write("\n".join(flags[k + 1].split(",")) + "\n")
-        flags[k + 1] = order
+    for of in ("--chr-order", "--pairs-natural-chr-order"):  # the golden metadata keeps the order as a comma list; the programs read a file
+        if of in flags:
+            k = flags.index(of)
+            order = str(tmp_path / (of.strip("-") + ".txt"))
+            with open(order, "w") as f:
+                f.write("\n".join(flags[k + 1].split(",")) + "\n")
+            flags[k + 1] = order
     r = subprocess.run([CLI] + flags + ["-x", built(name), "-r", fa] + reads + ["-o", out, "-t", "1"],
                        stderr=subprocess.PIPE, check=True)
     with open(out, "rb") as f:
