@@ -104,12 +104,50 @@ struct ChunkReader {
   void close() { if (f) gzclose(f); f = nullptr; }
 };
 
+// --read-format (Chromap::ParseReadFormat chromap.cc:825-866, SequenceEffectiveRange): per stream up to four
+// [start, end] ranges and a strand
+struct ReadFormat {
+  std::vector<int32_t> starts, ends;
+  char strand = '+';
+  bool identity() const { return starts.empty() || (strand == '+' && starts[0] == 0 && ends[0] == -1); }
+  uint32_t eff_len(uint32_t len) const {
+    if (identity()) return len;
+    uint32_t out = 0;
+    for (size_t k = 0; k < starts.size(); ++k) {
+      int st = starts[k], en = ends[k] == -1 ? (int)len - 1 : ends[k];
+      if (en >= (int)len) en = (int)len - 1;
+      if (st < 0) st = 0;
+      if (en >= st) out += (uint32_t)(en - st + 1);
+    }
+    return out;
+  }
+  // SequenceEffectiveRange::Replace for the host parser (pairs / SAM output)
+  void apply(std::string &seq, std::string &qual) const {
+    if (identity()) return;
+    std::string ns, nq;
+    for (size_t k = 0; k < starts.size(); ++k) {
+      int st = starts[k], en = ends[k] == -1 ? (int)seq.size() - 1 : ends[k];
+      if (en >= (int)seq.size()) en = (int)seq.size() - 1;
+      if (st < 0) st = 0;
+      for (int p = st; p <= en; ++p) { ns.push_back(seq[p]); if ((size_t)p < qual.size()) nq.push_back(qual[p]); }
+    }
+    if (strand == '-') {
+      for (char &c : ns) { const char u = c & 0xDF; c = u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : 'N'; }
+      std::reverse(ns.begin(), ns.end());
+      std::reverse(nq.begin(), nq.end());
+    }
+    seq.swap(ns);
+    qual.swap(nq);
+  }
+};
+
 struct Args {
   std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path, pairs_order_path;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
   size_t chunk_bytes = 256u << 20;
+  ReadFormat fmt[3];  // read 1, read 2, barcode
   int k = 17, w = 7, device = 0;
   uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
 };
@@ -178,6 +216,26 @@ static Args parse(int argc, char **argv) {
     else if (o == "--TagAlign") { a.out_tagalign = true; a.out_bed = true; a.out_sam = false; a.out_pairs = false; }
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
+    else if (o == "--read-format") {
+      const std::string f = need("--read-format");
+      size_t i = 0;
+      while (i < f.size()) {
+        size_t j = f.find(',', i);
+        if (j == std::string::npos) j = f.size();
+        const std::string tok = f.substr(i, j - i);
+        int st = tok.compare(0, 2, "r1") == 0 ? 0 : tok.compare(0, 2, "r2") == 0 ? 1 : tok.compare(0, 2, "bc") == 0 ? 2 : -1;
+        if (st < 0 || tok.size() < 4 || tok[2] != ':') die("Unknown read format: " + f + "\n");
+        std::vector<std::string> fld;
+        size_t p = 3;
+        while (p <= tok.size()) { size_t q = tok.find(':', p); if (q == std::string::npos) q = tok.size(); fld.push_back(tok.substr(p, q - p)); p = q + 1; }
+        if (fld.size() < 2 || fld.size() > 3) die("Unknown read format: " + f + "\n");
+        a.fmt[st].starts.push_back(atoi(fld[0].c_str()));
+        a.fmt[st].ends.push_back(atoi(fld[1].c_str()));
+        if (fld.size() == 3 && !fld[2].empty()) a.fmt[st].strand = fld[2][0];
+        if (a.fmt[st].starts.size() > 4) die("at most four ranges per stream in --read-format");
+        i = j + 1;
+      }
+    }
     else if (o == "--chr-order") a.chr_order_path = need("--chr-order");
     else if (o == "--pairs-natural-chr-order") a.pairs_order_path = need("--pairs-natural-chr-order");
     else if (o == "--device") a.device = atoi(need("--device"));
@@ -276,6 +334,10 @@ int main(int argc, char **argv) {
   double t_read = 0, t_parse = 0, t_map = 0, t_post = 0;
   const double t_begin = now_s();
   if (barcoded && a.out_sam) die("--SAM with cell barcodes (CB tag) is outside this build");
+  for (int m = 0; m < 3; ++m)
+    if (!a.fmt[m].identity() &&
+        cmgpu_fastq_set_format(ctx, m, (int)a.fmt[m].starts.size(), a.fmt[m].starts.data(), a.fmt[m].ends.data(), a.fmt[m].strand) != CMGPU_OK)
+      die("bad --read-format");
   const bool device_ingest = !a.out_pairs && !a.out_sam && !a.host_ingest;  // pairs / SAM output need read names (and qualities): host parser
   // --SAM: everything the final sort needs, over all batches
   std::vector<cmgpu_sam_record> sam_rec;
@@ -306,6 +368,7 @@ int main(int argc, char **argv) {
           if (!p || !q) die("barcode file is not FASTQ");
           bc_len = (uint32_t)(q - p - 1);
           if (bc_len && p[bc_len] == '\r') --bc_len;
+          bc_len = a.fmt[2].eff_len(bc_len);
           uint64_t *keys = nullptr;
           if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
           ck(cmgpu_set_whitelist(ctx, keys, nk, bc_len));
@@ -390,7 +453,7 @@ int main(int argc, char **argv) {
       std::string nm, sq, ql;
       std::vector<char> bb;
       std::vector<uint32_t> bo(1, 0);
-      while (br.record(nm, sq, ql)) { if (sq.empty()) continue; bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
+      while (br.record(nm, sq, ql)) { if (sq.empty()) continue; a.fmt[2].apply(sq, ql); bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
       br.close();
       if (bo.size() < 2) die("empty barcode file");
       bc_len = bo[1] - bo[0];
@@ -422,6 +485,9 @@ int main(int argc, char **argv) {
           if (!g1 && !g2 && !gb) { more = false; break; }
           if (!(g1 && g2 && gb)) die("Numbers of reads and barcodes don't match!");
           if (s1.empty() || (paired && s2.empty())) continue;
+          a.fmt[0].apply(s1, q1);
+          if (paired) a.fmt[1].apply(s2, q2);
+          if (barcoded) a.fmt[2].apply(sb, qb);
           b1.insert(b1.end(), s1.begin(), s1.end()); o1.push_back((uint32_t)b1.size());
           if (paired) { b2.insert(b2.end(), s2.begin(), s2.end()); o2.push_back((uint32_t)b2.size()); }
           if (barcoded) { bb.insert(bb.end(), sb.begin(), sb.end()); bq.insert(bq.end(), qb.begin(), qb.end()); bq.resize(bb.size(), 'I'); bo.push_back((uint32_t)bb.size()); }

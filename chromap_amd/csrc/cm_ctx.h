@@ -28,6 +28,11 @@ struct CmFqStream {
   uint64_t n_bytes = 0;
   uint32_t n_nl = 0, n_raw = 0, n_rec = 0, taken = 0, taken_bases = 0, taken_max_len = 0;
   bool final_chunk = false;
+  // --read-format (SequenceEffectiveRange, sequence_effective_range.h): up to 4 [start, end] ranges (end -1 = to the
+  // last base) concatenated, then reverse-complemented when strand is '-'
+  int n_ranges = 0;
+  int rng_start[4] = {0, 0, 0, 0}, rng_end[4] = {-1, -1, -1, -1};
+  bool minus = false;
 };
 
 struct cmgpu_ctx {

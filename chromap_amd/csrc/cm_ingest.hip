@@ -86,27 +86,62 @@ __global__ __launch_bounds__(FQ_BLOCK) void k_fq_compact(const uint32_t *__restr
   const uint32_t r = blockIdx.x * FQ_BLOCK + threadIdx.x;
   if (r < n_raw && keep[r]) recidx[pos[r]] = r;
 }
+// --read-format: which bases of a record are kept (SequenceEffectiveRange::Replace, sequence_effective_range.h:84-122)
+struct FqFormat {
+  int n_ranges;      // 0: the whole sequence
+  int start[4], end[4];
+  int minus;         // reverse (and, for bases, complement) after extraction
+};
+__device__ __forceinline__ uint32_t fq_eff_len(const FqFormat &f, uint32_t len) {
+  if (f.n_ranges == 0) return len;
+  uint32_t out = 0;
+  for (int k = 0; k < f.n_ranges; ++k) {
+    int st = f.start[k], en = f.end[k] == -1 ? (int)len - 1 : f.end[k];
+    if (en >= (int)len) en = (int)len - 1;  // the reference reads past the end here; ranges are clamped instead
+    if (st < 0) st = 0;
+    if (en >= st) out += (uint32_t)(en - st + 1);
+  }
+  return out;
+}
 __global__ __launch_bounds__(FQ_BLOCK) void k_fq_len(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nl,
-                                                       const uint32_t *__restrict__ recidx, uint32_t n, uint32_t *__restrict__ len) {
+                                                       const uint32_t *__restrict__ recidx, uint32_t n, FqFormat fmt, uint32_t *__restrict__ len) {
   const uint32_t j = blockIdx.x * FQ_BLOCK + threadIdx.x;
   if (j >= n) return;
   uint32_t s, e;
   fq_line(text, nl, 4 * recidx[j] + 1, &s, &e);
-  len[j] = e - s;
+  len[j] = fq_eff_len(fmt, e - s);
 }
 __global__ __launch_bounds__(FQ_BLOCK) void k_fq_gather(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nl,
                                                           const uint32_t *__restrict__ recidx, const uint32_t *__restrict__ off, uint32_t n,
-                                                          uint8_t *__restrict__ bases, uint8_t *__restrict__ quals) {
+                                                          FqFormat fmt, uint8_t *__restrict__ bases, uint8_t *__restrict__ quals) {
   const uint32_t j = blockIdx.x * FQ_BLOCK + threadIdx.x;
   if (j >= n) return;
-  uint32_t s, e;
+  uint32_t s, e, qs = 0, qe = 0;
   fq_line(text, nl, 4 * recidx[j] + 1, &s, &e);
-  const uint32_t o = off[j], l = e - s;
-  for (uint32_t i = 0; i < l; ++i) bases[o + i] = text[s + i];
-  if (quals) {
-    uint32_t qs, qe;
-    fq_line(text, nl, 4 * recidx[j] + 3, &qs, &qe);
-    for (uint32_t i = 0; i < l; ++i) quals[o + i] = text[qs + i];
+  if (quals) fq_line(text, nl, 4 * recidx[j] + 3, &qs, &qe);
+  const uint32_t o = off[j], raw = e - s;
+  if (fmt.n_ranges == 0 && !fmt.minus) {
+    for (uint32_t i = 0; i < raw; ++i) bases[o + i] = text[s + i];
+    if (quals) for (uint32_t i = 0; i < raw; ++i) quals[o + i] = text[qs + i];
+    return;
+  }
+  const uint32_t l = fq_eff_len(fmt, raw);
+  uint32_t w = 0;
+  const int nr = fmt.n_ranges ? fmt.n_ranges : 1;
+  for (int k = 0; k < nr; ++k) {
+    int st = fmt.n_ranges ? fmt.start[k] : 0, en = fmt.n_ranges ? (fmt.end[k] == -1 ? (int)raw - 1 : fmt.end[k]) : (int)raw - 1;
+    if (en >= (int)raw) en = (int)raw - 1;
+    if (st < 0) st = 0;
+    for (int p = st; p <= en; ++p, ++w) {
+      const uint32_t dst = fmt.minus ? o + (l - 1 - w) : o + w;
+      uint8_t c = text[s + (uint32_t)p];
+      if (fmt.minus) {  // Uint8ToChar(3 ^ CharToUint8(c))
+        const uint8_t u = c & 0xDF;
+        c = u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : 'N';
+      }
+      bases[dst] = c;
+      if (quals) quals[dst] = text[qs + (uint32_t)p];
+    }
   }
 }
 
@@ -203,7 +238,11 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
     cm_set_error(c, "out of device memory (FASTQ lengths)"); return CMGPU_ENOMEM;
   }
   const dim3 g((n + FQ_BLOCK - 1) / FQ_BLOCK), b(FQ_BLOCK);
-  hipLaunchKernelGGL(k_fq_len, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p, n, (uint32_t *)f.len.p);
+  FqFormat fmt;
+  fmt.n_ranges = f.n_ranges;
+  for (int k = 0; k < 4; ++k) { fmt.start[k] = f.rng_start[k]; fmt.end[k] = f.rng_end[k]; }
+  fmt.minus = f.minus ? 1 : 0;
+  hipLaunchKernelGGL(k_fq_len, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p, n, fmt, (uint32_t *)f.len.p);
   cm_scan_u32((const uint32_t *)f.len.p, (uint32_t *)offs.p, n, (uint32_t *)c->scan_tmp.p, s);
   size_t tb = 0;
   (void)rocprim::reduce(nullptr, tb, (const uint32_t *)f.len.p, (uint32_t *)f.bad.p, 0u, (size_t)n, FqMaxOp(), s);
@@ -218,7 +257,7 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   if (e != hipSuccess) { cm_set_error(c, std::string("FASTQ take: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
   if (bases.ensure((size_t)total + 16) || (stream == 2 && c->bcq.ensure((size_t)total + 16))) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
   hipLaunchKernelGGL(k_fq_gather, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p,
-                     (const uint32_t *)offs.p, n, (uint8_t *)bases.p, stream == 2 ? (uint8_t *)c->bcq.p : (uint8_t *)nullptr);
+                     (const uint32_t *)offs.p, n, fmt, (uint8_t *)bases.p, stream == 2 ? (uint8_t *)c->bcq.p : (uint8_t *)nullptr);
   FQCHECK(c, hipStreamSynchronize(s));
   f.taken_bases = total;
   f.taken_max_len = mx;
@@ -249,5 +288,17 @@ extern "C" int cmgpu_fastq_commit(cmgpu_ctx *c, uint32_t n, uint32_t first_read_
     if (c->ro1.ensure(((size_t)n + 1) * 4) || c->rb1.ensure(16)) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
     FQCHECK(c, hipMemset(c->ro1.p, 0, ((size_t)n + 1) * 4));
   }
+  return CMGPU_OK;
+}
+
+// --read-format for one stream: n_ranges (0..4) [start, end] pairs (end = -1: up to the last base), strand '+' or '-'
+extern "C" int cmgpu_fastq_set_format(cmgpu_ctx *c, int stream, int n_ranges, const int32_t *starts, const int32_t *ends, char strand) {
+  if (!c || stream < 0 || stream > 2 || n_ranges < 0 || n_ranges > 4 || (n_ranges && (!starts || !ends)) || (strand != '+' && strand != '-')) return CMGPU_EINVAL;
+  CmFqStream &f = c->fq[stream];
+  f.n_ranges = n_ranges;
+  for (int k = 0; k < n_ranges; ++k) { f.rng_start[k] = starts[k]; f.rng_end[k] = ends[k]; }
+  f.minus = strand == '-';
+  // the full range on the + strand is the identity (IsFullRangeAndPositiveStrand)
+  if (n_ranges >= 1 && !f.minus && starts[0] == 0 && ends[0] == -1) f.n_ranges = 0;
   return CMGPU_OK;
 }

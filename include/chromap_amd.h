@@ -389,6 +389,10 @@ int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_b
  *                      the host resubmits the rest in front of the next chunk.
  *   cmgpu_fastq_commit declares the batch (n records taken from every participating stream);
  *                      cmgpu_map_resident then maps it. */
+/* --read-format for one stream (SequenceEffectiveRange, src/sequence_effective_range.h, src/chromap.cc:825-866):
+ * up to four [start, end] base ranges (0-based, inclusive, end -1 = last base) are concatenated, then the result is
+ * reverse-complemented (bases) / reversed (qualities) when strand is '-'.  Applies to the following cmgpu_fastq_take calls. */
+int cmgpu_fastq_set_format(cmgpu_ctx *ctx, int stream, int n_ranges, const int32_t *starts, const int32_t *ends, char strand);
 int cmgpu_fastq_scan(cmgpu_ctx *ctx, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records);
 int cmgpu_fastq_take(cmgpu_ctx *ctx, int stream, uint32_t n, uint64_t *bytes_consumed);
 int cmgpu_fastq_commit(cmgpu_ctx *ctx, uint32_t n, uint32_t first_read_id, int paired, int barcoded);

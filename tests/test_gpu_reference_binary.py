@@ -116,3 +116,27 @@ def test_multi_batch_q0_multimappers(tmp_path):
     assert ds.md5(pre + ".gpu2.bed") == want
     mapq0 = sum(1 for ln in open(pre + ".ref.bed", "rb") if ln.split(b"\t")[4] == b"0")
     assert mapq0 > 10000
+
+
+def test_read_format_ranges_and_strand(data, tmp_path):
+    """--read-format: barcodes embedded reverse-complemented in a longer read, reads cut to ranges
+    (SequenceEffectiveRange); device ingest and the host parser against the reference binary"""
+    pre, idx = data("short")
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    bc2 = str(tmp_path / "bc_padded.fq")
+    with open(pre + "_bc.fq", "rb") as f, open(bc2, "wb") as g:
+        lines = f.read().split(b"\n")
+        for i in range(0, len(lines) - 3, 4):
+            seq, qual = lines[i + 1], lines[i + 3]
+            g.write(lines[i] + b"\n" + b"GGA" + seq.translate(comp)[::-1] + b"TC\n+\n" + b"#!#" + qual[::-1] + b"!!\n")
+    fmt = "bc:3:18:-,r1:0:44,r2:2:-1"
+    common = ["--preset", "atac", "--read-format", fmt, "-x", idx, "-r", pre + ".fa", "-1", pre + "_1.fq", "-2", pre + "_2.fq", "-b", bc2,
+              "--barcode-whitelist", pre + ".whitelist.txt"]
+    outs = []
+    for prog, extra in ((REF, ["-t", "32"]), (CLI, []), (CLI, ["--host-ingest"])):
+        out = str(tmp_path / ("o%d.bed" % len(outs)))
+        r = subprocess.run([prog] + common + extra + ["-o", out], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(ds.md5(out))
+    assert os.path.getsize(out) > 100000
+    assert outs[1] == outs[0] and outs[2] == outs[0], outs
