@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/chromap_amd.h"
@@ -142,7 +143,7 @@ struct ReadFormat {
 };
 
 struct Args {
-  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path, pairs_order_path;
+  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path, pairs_order_path, translate_path;
   std::vector<std::string> r1, r2;
   cmgpu_params p;
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
@@ -216,6 +217,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "--TagAlign") { a.out_tagalign = true; a.out_bed = true; a.out_sam = false; a.out_pairs = false; }
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
+    else if (o == "--barcode-translate") a.translate_path = need("--barcode-translate");
     else if (o == "--read-format") {
       const std::string f = need("--read-format");
       size_t i = 0;
@@ -592,7 +594,58 @@ int main(int argc, char **argv) {
     const double t0 = now_s();
     if (cmgpu_store_format(ctx, kind, out_names.data(), ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
     const double t1 = now_s();
-    if (cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    if (barcoded && !a.translate_path.empty() && kind == CMGPU_TEXT_BED_PE_BC) {
+      // --barcode-translate (BarcodeTranslator, barcode_translator.h:43-101): the device rendered the corrected barcodes;
+      // column 4 is rewritten on the way to the file.  Table lines are "to<TAB or ,>from"; a barcode made of several
+      // segments of the table's length is translated segment by segment and joined with '-'.
+      std::unordered_map<std::string, std::string> table;
+      size_t from_len = 0;
+      gzFile tf = gzopen(a.translate_path.c_str(), "r");
+      if (!tf) die("Cannot open barcode translation file " + a.translate_path);
+      char lb[512];
+      while (gzgets(tf, lb, sizeof(lb))) {
+        size_t l = strlen(lb);
+        if (l && lb[l - 1] == '\n') lb[--l] = 0;
+        size_t i = 0;
+        while (i < l && lb[i] != ',' && lb[i] != '\t') ++i;
+        if (i >= l) continue;
+        from_len = l - i - 1;
+        table[std::string(lb + i + 1, from_len)] = std::string(lb, i);
+      }
+      gzclose(tf);
+      std::vector<char> text(nbytes + 1);
+      if (cmgpu_store_text(ctx, text.data(), nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
+      FILE *of = fopen(a.out_path.c_str(), "wb");
+      if (!of) die("cannot write " + a.out_path);
+      std::string outb;
+      outb.reserve(1 << 20);
+      const char *p = text.data(), *end = text.data() + nbytes;
+      while (p < end) {
+        const char *nlp = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!nlp) nlp = end;
+        const char *c1 = (const char *)memchr(p, '\t', (size_t)(nlp - p));
+        const char *c2 = c1 ? (const char *)memchr(c1 + 1, '\t', (size_t)(nlp - c1 - 1)) : nullptr;
+        const char *c3 = c2 ? (const char *)memchr(c2 + 1, '\t', (size_t)(nlp - c2 - 1)) : nullptr;
+        const char *c4 = c3 ? (const char *)memchr(c3 + 1, '\t', (size_t)(nlp - c3 - 1)) : nullptr;
+        if (!c4 || from_len == 0) { outb.append(p, (size_t)(nlp - p)); }
+        else {
+          outb.append(p, (size_t)(c3 + 1 - p));
+          const size_t bl = (size_t)(c4 - c3 - 1);
+          for (size_t sgm = 0; sgm < bl / from_len; ++sgm) {
+            auto it = table.find(std::string(c3 + 1 + sgm * from_len, from_len));
+            if (it == table.end()) die("Barcode does not exist in the translation table.");
+            if (sgm) outb.push_back('-');
+            outb.append(it->second);
+          }
+          outb.append(c4, (size_t)(nlp - c4));
+        }
+        outb.push_back('\n');
+        if (outb.size() > (1 << 20) - 4096) { fwrite(outb.data(), 1, outb.size(), of); outb.clear(); }
+        p = nlp + 1;
+      }
+      if (!outb.empty()) fwrite(outb.data(), 1, outb.size(), of);
+      fclose(of);
+    } else if (cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK) die(cmgpu_last_error(ctx));
     t_post = now_s() - t0;
     fprintf(stderr, "Sorted, deduplicated and formatted %llu bytes on the device in %.3fs, wrote them in %.3fs.\n", (unsigned long long)nbytes,
             t1 - t0, now_s() - t1);

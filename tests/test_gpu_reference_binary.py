@@ -140,3 +140,19 @@ def test_read_format_ranges_and_strand(data, tmp_path):
         outs.append(ds.md5(out))
     assert os.path.getsize(out) > 100000
     assert outs[1] == outs[0] and outs[2] == outs[0], outs
+
+
+def test_barcode_translate(data, tmp_path):
+    """--barcode-translate: column 4 of the single-cell BED goes through the translation table"""
+    pre, idx = data("short")
+    table = str(tmp_path / "tr.tsv")
+    with open(pre + ".whitelist.txt") as f, open(table, "w") as g:
+        for i, ln in enumerate(f):
+            g.write("CELL%05d\t%s\n" % (i, ln.strip()))
+    common = ["--preset", "atac", "--barcode-translate", table, "-x", idx, "-r", pre + ".fa", "-1", pre + "_1.fq", "-2", pre + "_2.fq",
+              "-b", pre + "_bc.fq", "--barcode-whitelist", pre + ".whitelist.txt"]
+    out_ref, out_gpu = str(tmp_path / "r.bed"), str(tmp_path / "g.bed")
+    subprocess.run([REF] + common + ["-o", out_ref, "-t", "32"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([CLI] + common + ["-o", out_gpu], check=True, stderr=subprocess.PIPE)
+    assert b"CELL" in open(out_ref, "rb").read(4096)
+    assert ds.md5(out_gpu) == ds.md5(out_ref)
