@@ -176,10 +176,15 @@ static Args parse(int argc, char **argv) {
       if (a.preset == "hic") { a.out_pairs = true; a.out_bed = false; }
       if (a.preset == "atac") a.cell_level_dedup = true;
     }
+  for (int i = 1; i + 1 < argc; ++i)
+    if (!strcmp(argv[i], "--min-frag-length")) {  // chromap_driver.cc:277-289; -k / -w override it
+      const int mfl = atoi(argv[i + 1]);
+      if (mfl <= 60) { a.k = 17; a.w = 7; } else if (mfl <= 80) { a.k = 19; a.w = 10; } else { a.k = 23; a.w = 11; }
+    }
   for (int i = 1; i < argc; ++i) {
     const std::string o = argv[i];
     auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) die(std::string("missing value for ") + what); return argv[++i]; };
-    if (o == "--preset") { ++i; }
+    if (o == "--preset" || o == "--min-frag-length") { ++i; }
     else if (o == "-i" || o == "--build-index") a.build_index = true;
     else if (o == "-x" || o == "--index") a.index_path = need("-x");
     else if (o == "-r" || o == "--ref") a.ref_path = need("-r");
