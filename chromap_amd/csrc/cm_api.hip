@@ -919,7 +919,8 @@ extern "C" int cmgpu_barcode_abundance_resident(cmgpu_ctx *c, uint64_t *num_samp
 extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, const cmgpu_barcode_batch *bc, cmgpu_record_bc *out,
                                         uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats) {
   if (!c || !in || !bc || !n_out) return CMGPU_EINVAL;
-  if (c->wl_size == 0 || c->wl_num_sample == 0) { cm_set_error(c, "whitelist / barcode abundance not set"); return CMGPU_EINVAL; }
+  // no whitelist at all: every barcode is kept as read (chromap.h:897-903); with one, the abundance pre-pass must have run
+  if (c->wl_size != 0 && c->wl_num_sample == 0) { cm_set_error(c, "barcode abundance not computed (cmgpu_compute_barcode_abundance)"); return CMGPU_EINVAL; }
   int rc = cmgpu_upload_batch(c, in);
   if (rc) return rc;
   const uint32_t n = in->n_pairs;

@@ -289,7 +289,9 @@ int main(int argc, char **argv) {
   const bool paired = !a.r2.empty();
   if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
   const bool barcoded = !a.barcode_file.empty();
-  if (barcoded && (a.whitelist.empty() || !paired)) die("this build supports barcodes only with a whitelist and paired-end reads");
+  if (barcoded && !paired) die("this build supports barcodes only with paired-end reads");
+  if (barcoded && a.whitelist.empty() && a.p.remove_pcr_duplicates && a.p.low_memory_mode && !a.cell_level_dedup)
+    die("bulk-level duplicate removal ranks barcodes by whitelist abundance: give --barcode-whitelist or --remove-pcr-duplicates-at-cell-level");
   a.p.dedup_at_bulk_level = barcoded && !a.cell_level_dedup ? 1 : 0;  // remove_pcr_duplicates_at_bulk_level defaults to true (mapping_parameters.h:49)
   cmgpu_index_view idx;
   if (cmgpu_load_index_file(a.index_path.c_str(), &idx) != 0) die("Cannot read index " + a.index_path);
@@ -356,9 +358,18 @@ int main(int argc, char **argv) {
   std::vector<char> sam_b1, sam_q1, sam_b2, sam_q2;
   std::vector<uint32_t> sam_o1(1, 0), sam_o2(1, 0);
   auto ck = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(ctx)); };
+  if (barcoded && a.whitelist.empty()) {  // no whitelist: every barcode is kept as read (chromap.h:897-903); only its length is needed
+    FastxReader pk;
+    if (!pk.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+    std::string nm, sq, ql;
+    if (!pk.record(nm, sq, ql)) die("empty barcode file");
+    pk.close();
+    a.fmt[2].apply(sq, ql);
+    bc_len = (uint32_t)sq.size();
+  }
   if (device_ingest) {
     // ---- FASTQ text goes to the GPU in chunks; lines, records and the SoA batch are built there
-    if (barcoded) {
+    if (barcoded && !a.whitelist.empty()) {
       // whitelist + abundance pre-pass (chromap.h:750-761), barcode file streamed through the device
       ChunkReader br;
       if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
@@ -454,7 +465,7 @@ int main(int argc, char **argv) {
     }
   } else {
     // single-cell: whitelist + abundance pre-pass over the whole barcode file (chromap.h:750-761)
-    if (barcoded) {
+    if (barcoded && !a.whitelist.empty()) {
       FastxReader br;
       if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
       std::string nm, sq, ql;
@@ -564,7 +575,7 @@ int main(int argc, char **argv) {
           (unsigned long long)(st.num_mapped_reads - st.num_uniquely_mapped_reads), (unsigned long long)st.num_candidates,
           (unsigned long long)st.num_mappings, (unsigned long long)st.num_uniquely_mapped_reads,
           (unsigned long long)(st.num_mappings - st.num_uniquely_mapped_reads));
-  if (barcoded)
+  if (barcoded && !a.whitelist.empty())
     fprintf(stderr, "Number of barcodes in whitelist: %llu.\nNumber of corrected barcodes: %llu.\n",
             (unsigned long long)st.num_barcode_in_whitelist, (unsigned long long)st.num_corrected_barcode);
   int64_t lines;

@@ -274,7 +274,7 @@ extern "C" int cmgpu_fastq_commit(cmgpu_ctx *c, uint32_t n, uint32_t first_read_
   }
   if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
   if (!paired && c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
-  if (barcoded && (c->wl_size == 0 || c->wl_num_sample == 0)) { cm_set_error(c, "whitelist / barcode abundance not set"); return CMGPU_EINVAL; }
+  if (barcoded && c->wl_size != 0 && c->wl_num_sample == 0) { cm_set_error(c, "barcode abundance not computed"); return CMGPU_EINVAL; }
   c->n_pairs = n;
   c->first_read_id = first_read_id;
   c->single = !paired;

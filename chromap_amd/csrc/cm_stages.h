@@ -268,6 +268,7 @@ CM_HD void cm_s0b_barcode(const CmDev &d, uint32_t pair, uint32_t *in_wl, uint32
   const uint32_t len = d.bco[pair + 1] - d.bco[pair];
   const uint64_t key = cm_seed_from_sequence(bc, len);
   d.bc_key[pair] = key;
+  if (!d.wl) { d.bc_ok[pair] = 1; return; }  // no whitelist given: the barcode is taken as read (chromap.h:897-903)
   d.bc_ok[pair] = 0;
   uint32_t cnt = 0;
   const bool found = cm_wl_get(d, key, &cnt);

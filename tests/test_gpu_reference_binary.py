@@ -156,3 +156,16 @@ def test_barcode_translate(data, tmp_path):
     subprocess.run([CLI] + common + ["-o", out_gpu], check=True, stderr=subprocess.PIPE)
     assert b"CELL" in open(out_ref, "rb").read(4096)
     assert ds.md5(out_gpu) == ds.md5(out_ref)
+
+
+def test_barcodes_without_whitelist(data, tmp_path):
+    """-b without --barcode-whitelist: every barcode is kept as read (no correction), cell-level duplicate removal"""
+    pre, idx = data("short")
+    common = ["--preset", "atac", "-x", idx, "-r", pre + ".fa", "-1", pre + "_1.fq", "-2", pre + "_2.fq", "-b", pre + "_bc.fq"]
+    outs = []
+    for prog, extra in ((REF, ["-t", "32"]), (CLI, []), (CLI, ["--host-ingest"])):
+        out = str(tmp_path / ("o%d.bed" % len(outs)))
+        r = subprocess.run([prog] + common + extra + ["-o", out], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(ds.md5(out))
+    assert outs[1] == outs[0] and outs[2] == outs[0], outs
