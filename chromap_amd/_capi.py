@@ -96,14 +96,14 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device", "cmgpu_records_partition",
            "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
-           "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_write_bed_pe_bc",
+           "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_map_single_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
            "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam",
            "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
-TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC, TEXT_TAGALIGN_PE, TEXT_TAGALIGN_PE_BC = 0, 1, 2, 3, 4
+TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC, TEXT_TAGALIGN_PE, TEXT_TAGALIGN_PE_BC, TEXT_BED_SE_BC = 0, 1, 2, 3, 4, 5
 
 _LIB = None
 
@@ -175,6 +175,7 @@ def declare(L):
     sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
     sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])
     sig("cmgpu_compute_barcode_abundance", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint64)])
+    sig("cmgpu_map_single_barcoded", C.c_int, [C.c_void_p, P(SingleBatch), P(BarcodeBatch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
     sig("cmgpu_map_pairs_barcoded", C.c_int, [C.c_void_p, P(Batch), P(BarcodeBatch), C.c_void_p, C.c_uint64, P(C.c_uint64),
                                                P(Stats)])
     sig("cmgpu_write_bed_pe_bc", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_uint32,

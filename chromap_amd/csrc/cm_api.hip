@@ -958,9 +958,22 @@ extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, con
 // single-end reads: the taskloop body of Chromap::MapSingleEndReads (chromap.h:385-472).
 // The batch is held as pairs whose second mate is empty.
 // ---------------------------------------------------------------------------------------
+static int map_single_impl(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmgpu_barcode_batch *bc, cmgpu_record *out,
+                           cmgpu_record_bc *out_bc, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
 extern "C" int cmgpu_map_single(cmgpu_ctx *c, const cmgpu_single_batch *in, cmgpu_record *out, uint64_t out_capacity,
                                 uint64_t *n_out, cmgpu_stats *stats) {
+  return map_single_impl(c, in, nullptr, out, nullptr, out_capacity, n_out, stats);
+}
+// single-end reads with cell barcodes (MappingWithBarcode, bed_mapping.h:11-56): out may be NULL (records stay resident)
+extern "C" int cmgpu_map_single_barcoded(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmgpu_barcode_batch *bc, cmgpu_record_bc *out,
+                                         uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats) {
+  if (!bc) return CMGPU_EINVAL;
+  return map_single_impl(c, in, bc, nullptr, out, out_capacity, n_out, stats);
+}
+static int map_single_impl(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmgpu_barcode_batch *bc, cmgpu_record *out,
+                           cmgpu_record_bc *out_bc, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats) {
   if (!c || !in || !n_out) return CMGPU_EINVAL;
+  if (bc && c->wl_size != 0 && c->wl_num_sample == 0) { cm_set_error(c, "barcode abundance not computed (cmgpu_compute_barcode_abundance)"); return CMGPU_EINVAL; }
   if (c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipSetDevice(c->device));
   const uint32_t n = in->n_reads;
@@ -982,10 +995,34 @@ extern "C" int cmgpu_map_single(cmgpu_ctx *c, const cmgpu_single_batch *in, cmgp
   HIPCHECK(c, hipMemcpyAsync(c->rb0.p, in->bases, c->bases0, hipMemcpyHostToDevice, c->stream));
   HIPCHECK(c, hipMemcpyAsync(c->ro0.p, in->offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHECK(c, hipMemsetAsync(c->ro1.p, 0, ((size_t)n + 1) * 4, c->stream));
+  if (bc) {
+    const size_t nbytes = bc->offsets[n];
+    if (c->bcb.ensure(nbytes + 16) || c->bcq.ensure(nbytes + 16) || c->bco.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
+    HIPCHECK(c, hipMemcpyAsync(c->bcb.p, bc->bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->bcq.p, bc->qualities, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->bco.p, bc->offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    c->has_barcodes = true;
+  }
   HIPCHECK(c, hipStreamSynchronize(c->stream));
   uint64_t k = 0;
   int rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;
-  if (!out) { *n_out = k; return CMGPU_OK; }
-  return cmgpu_download_records(c, out, out_capacity, n_out);
+  if (!out && !out_bc) { *n_out = k; return CMGPU_OK; }
+  if (!bc) return cmgpu_download_records(c, out, out_capacity, n_out);
+  std::vector<cmgpu_record> rec(n);
+  std::vector<uint8_t> ok(n);
+  std::vector<uint64_t> keys(n);
+  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, n, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(keys.data(), c->bc_key.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  uint64_t o = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!ok[i]) continue;
+    if (o >= out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
+    out_bc[o].r = rec[i];
+    out_bc[o].barcode = keys[i];
+    ++o;
+  }
+  *n_out = o;
+  return CMGPU_OK;
 }

@@ -289,7 +289,6 @@ int main(int argc, char **argv) {
   const bool paired = !a.r2.empty();
   if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
   const bool barcoded = !a.barcode_file.empty();
-  if (barcoded && !paired) die("this build supports barcodes only with paired-end reads");
   if (barcoded && a.whitelist.empty() && a.p.remove_pcr_duplicates && a.p.low_memory_mode && !a.cell_level_dedup)
     die("bulk-level duplicate removal ranks barcodes by whitelist abundance: give --barcode-whitelist or --remove-pcr-duplicates-at-cell-level");
   a.p.dedup_at_bulk_level = barcoded && !a.cell_level_dedup ? 1 : 0;  // remove_pcr_duplicates_at_bulk_level defaults to true (mapping_parameters.h:49)
@@ -527,7 +526,11 @@ int main(int argc, char **argv) {
         num_reads += paired ? 2ull * n : n;
         uint64_t k = 0;
         int rc;
-        if (barcoded) {
+        if (barcoded && !paired) {
+          cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};
+          cmgpu_barcode_batch bc{bb.data(), bq.data(), bo.data()};
+          rc = cmgpu_map_single_barcoded(ctx, &bt, &bc, nullptr, 0, &k, &st);
+        } else if (barcoded) {
           cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
           cmgpu_barcode_batch bc{bb.data(), bq.data(), bo.data()};
           rc = cmgpu_map_pairs_barcoded(ctx, &bt, &bc, nullptr, 0, &k, &st);
@@ -605,8 +608,9 @@ int main(int argc, char **argv) {
                               a.out_path.c_str());
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
+    if (a.out_tagalign && barcoded && !paired) die("TagAlign for single-end single-cell data is outside this build");
     const int kind = a.out_tagalign && paired ? (barcoded ? CMGPU_TEXT_TAGALIGN_PE_BC : CMGPU_TEXT_TAGALIGN_PE)
-                                              : barcoded ? CMGPU_TEXT_BED_PE_BC : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
+                                              : barcoded ? (paired ? CMGPU_TEXT_BED_PE_BC : CMGPU_TEXT_BED_SE_BC) : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
     const double t0 = now_s();
     if (cmgpu_store_format(ctx, kind, out_names.data(), ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
     const double t1 = now_s();

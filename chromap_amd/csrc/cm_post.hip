@@ -75,11 +75,12 @@ __device__ __forceinline__ PpRec pp_load(const uint8_t *store, uint32_t i) {
   return r;
 }
 
-__host__ __device__ __forceinline__ bool pp_has_bc(int kind) { return kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_TAGALIGN_PE_BC; }
+__host__ __device__ __forceinline__ bool pp_has_bc(int kind) { return kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_TAGALIGN_PE_BC || kind == CMGPU_TEXT_BED_SE_BC; }
+__host__ __device__ __forceinline__ bool pp_is_se(int kind) { return kind == CMGPU_TEXT_BED_SE || kind == CMGPU_TEXT_BED_SE_BC; }
 __host__ __device__ __forceinline__ bool pp_tagalign(int kind) { return kind == CMGPU_TEXT_TAGALIGN_PE || kind == CMGPU_TEXT_TAGALIGN_PE_BC; }
 // Tn5Shift (bed_mapping.h:48-54, 100-106, 165-170, 224-229)
 __device__ __forceinline__ void pp_tn5(PpRec &r, int kind) {
-  if (kind == CMGPU_TEXT_BED_SE) {
+  if (pp_is_se(kind)) {
     if (r.dir == 1) r.start += 4; else r.len = (uint16_t)(r.len - 5);
   } else {
     r.start += 4;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_key_top(const uint8_t *__restri
 __device__ __forceinline__ bool pp_same_run(const PpRec &a, uint64_t bca, const PpRec &b, uint64_t bcb, const PpCfg &cfg) {
   if (a.rid != b.rid || a.start != b.start) return false;
   if (cfg.kind == CMGPU_TEXT_BED_SE) return true;          // bed_mapping.h:91-94
+  if (cfg.kind == CMGPU_TEXT_BED_SE_BC) return bca == bcb;   // MappingWithBarcode: (barcode, start), :39-42
   if (a.len != b.len) return false;                        // :216-219
   return !pp_has_bc(cfg.kind) || bca == bcb;               // :154-159
 }
@@ -157,21 +159,21 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
     // FindBestMappingIndexFromDuplicates: larger weight, then larger abundance, first on ties.
     if (j > 0) {
       PpRec p = pp_load(store, idx[j - 1]);
-      if (p.rid == r.rid && p.start == r.start && p.len == r.len) { line_len[j] = 0; return; }
+      if (p.rid == r.rid && p.start == r.start && (pp_is_se(cfg.kind) || p.len == r.len)) { line_len[j] = 0; return; }
     }
     uint32_t t = j, best_i = wi, best_nd = 0, best_ab = 0, maxq_mapq = r.mapq;
     bool have = false;
     while (t < n) {
       const uint32_t gi = idx[t];
       const PpRec gr = pp_load(store, gi);
-      if (gr.rid != r.rid || gr.start != r.start || gr.len != r.len) break;
+      if (gr.rid != r.rid || gr.start != r.start || (!pp_is_se(cfg.kind) && gr.len != r.len)) break;
       const uint64_t gb = bc[gi];
       uint32_t u = t + 1, rep = gi, gsize = 1;
       if (gr.mapq > maxq_mapq) maxq_mapq = gr.mapq;
       while (u < n) {
         const uint32_t qi = idx[u];
         const PpRec q = pp_load(store, qi);
-        if (q.rid != r.rid || q.start != r.start || q.len != r.len || bc[qi] != gb) break;
+        if (q.rid != r.rid || q.start != r.start || (!pp_is_se(cfg.kind) && q.len != r.len) || bc[qi] != gb) break;
         if (q.mapq > maxq_mapq) maxq_mapq = q.mapq;
         rep = qi;
         ++gsize;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
     if (cfg.kind == CMGPU_TEXT_TAGALIGN_PE) len += 1 + pp_digits(dups);
   } else {
     len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
-    if (cfg.kind == CMGPU_TEXT_BED_PE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;      // chr start end barcode dups
+    if (cfg.kind == CMGPU_TEXT_BED_PE_BC || cfg.kind == CMGPU_TEXT_BED_SE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;  // chr start end barcode dups
     else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
   }
   win[j] = wi;
@@ -259,7 +261,7 @@ __device__ __forceinline__ void pp_render(uint8_t *p, const PpRec &r, uint64_t b
   *p++ = '\t';
   p = pp_put_u32(p, r.start + r.len);
   *p++ = '\t';
-  if (cfg.kind == CMGPU_TEXT_BED_PE_BC) {
+  if (cfg.kind == CMGPU_TEXT_BED_PE_BC || cfg.kind == CMGPU_TEXT_BED_SE_BC) {
     for (uint32_t b = 0; b < cfg.bc_len; ++b) *p++ = "ACGT"[(bcv >> ((cfg.bc_len - 1 - b) * 2)) & 3];  // Seed2Sequence
     *p++ = '\t';
   } else {
@@ -440,7 +442,7 @@ struct PpLinesOp {
 extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
                                   uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes) {
   if (!c || !names || !p || !n_lines || !n_bytes) return CMGPU_EINVAL;
-  if (kind < CMGPU_TEXT_BED_PE || kind > CMGPU_TEXT_TAGALIGN_PE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
+  if (kind < CMGPU_TEXT_BED_PE || kind > CMGPU_TEXT_BED_SE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
   PPCHECK(c, hipSetDevice(c->device));

@@ -251,6 +251,9 @@ int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_sequences, const
  * (src/chromap.h:896-909, src/chromap.cc:572-799). */
 int cmgpu_load_whitelist_file(const char *path, uint32_t barcode_length, uint64_t **keys_out, uint32_t *n_out);
 int cmgpu_set_whitelist(cmgpu_ctx *ctx, const uint64_t *keys, uint32_t n_keys, uint32_t barcode_length);
+/* single-end reads with cell barcodes: MappingWithBarcode (src/bed_mapping.h:11-56), src/chromap.h:385-472 */
+int cmgpu_map_single_barcoded(cmgpu_ctx *ctx, const cmgpu_single_batch *in, const cmgpu_barcode_batch *barcodes,
+                              cmgpu_record_bc *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
 int cmgpu_compute_barcode_abundance(cmgpu_ctx *ctx, const char *barcode_bases, const uint32_t *barcode_offsets,
                                     uint32_t n_barcodes, uint64_t *num_sample_barcodes);
 int cmgpu_map_pairs_barcoded(cmgpu_ctx *ctx, const cmgpu_batch *in, const cmgpu_barcode_batch *barcodes,
@@ -363,7 +366,8 @@ int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_length
 #define CMGPU_TEXT_BED_SE 1
 #define CMGPU_TEXT_BED_PE_BC 2
 #define CMGPU_TEXT_TAGALIGN_PE 3    /* --TagAlign, paired-end bulk: two lines per fragment (src/mapping_writer.cc:84-117) */
-#define CMGPU_TEXT_TAGALIGN_PE_BC 4 /* --TagAlign, single-cell (src/mapping_writer.cc:138-168) */
+#define CMGPU_TEXT_TAGALIGN_PE_BC 4
+#define CMGPU_TEXT_BED_SE_BC 5      /* single-end single-cell BED: MappingWithBarcode (src/bed_mapping.h:11-56, src/mapping_writer.cc:6-25) */ /* --TagAlign, single-cell (src/mapping_writer.cc:138-168) */
 int cmgpu_store_clear(cmgpu_ctx *ctx);
 /* appends the records of the last cmgpu_map_* call (still resident); n_total = store size */
 int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);

@@ -169,3 +169,20 @@ def test_barcodes_without_whitelist(data, tmp_path):
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(ds.md5(out))
     assert outs[1] == outs[0] and outs[2] == outs[0], outs
+
+
+@pytest.mark.parametrize("flags", [["--preset", "atac"], ["--preset", "atac", "--remove-pcr-duplicates-at-bulk-level", "-q", "0"],
+                                   ["--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"]],
+                         ids=["cell_level", "bulk_level_q0", "in_memory_q0"])
+def test_single_end_with_barcodes(flags, data, tmp_path):
+    """single-end single-cell data (MappingWithBarcode): device ingest and the host parser against the reference binary"""
+    pre, idx = data("short")
+    common = flags + ["-x", idx, "-r", pre + ".fa", "-1", pre + "_1.fq", "-b", pre + "_bc.fq", "--barcode-whitelist", pre + ".whitelist.txt"]
+    outs = []
+    for prog, extra in ((REF, ["-t", "32"]), (CLI, []), (CLI, ["--host-ingest"])):
+        out = str(tmp_path / ("o%d.bed" % len(outs)))
+        r = subprocess.run([prog] + common + extra + ["-o", out], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(ds.md5(out))
+    assert os.path.getsize(out) > 100000
+    assert outs[1] == outs[0] and outs[2] == outs[0], outs
