@@ -143,8 +143,8 @@ struct ReadFormat {
 };
 
 struct Args {
-  std::string index_path, ref_path, out_path, preset, barcode_file, whitelist, chr_order_path, pairs_order_path, translate_path;
-  std::vector<std::string> r1, r2;
+  std::string index_path, ref_path, out_path, preset, whitelist, chr_order_path, pairs_order_path, translate_path;
+  std::vector<std::string> r1, r2, bc;
   cmgpu_params p;
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
   size_t chunk_bytes = 256u << 20;
@@ -191,7 +191,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "-o" || o == "--output") a.out_path = need("-o");
     else if (o == "-1" || o == "--read1") a.r1 = split_commas(need("-1"));
     else if (o == "-2" || o == "--read2") a.r2 = split_commas(need("-2"));
-    else if (o == "-b" || o == "--barcode") a.barcode_file = need("-b");
+    else if (o == "-b" || o == "--barcode") a.bc = split_commas(need("-b"));
     else if (o == "--barcode-whitelist") a.whitelist = need("--barcode-whitelist");
     else if (o == "-k" || o == "--kmer") a.k = atoi(need("-k"));
     else if (o == "-w" || o == "--window") a.w = atoi(need("-w"));
@@ -288,7 +288,8 @@ int main(int argc, char **argv) {
   if (a.index_path.empty() || a.r1.empty()) die("No index / read files specified!");
   const bool paired = !a.r2.empty();
   if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
-  const bool barcoded = !a.barcode_file.empty();
+  const bool barcoded = !a.bc.empty();
+  if (barcoded && a.bc.size() != a.r1.size()) die("Numbers of read1 and barcode files don't match!");
   if (barcoded && a.whitelist.empty() && a.p.remove_pcr_duplicates && a.p.low_memory_mode && !a.cell_level_dedup)
     die("bulk-level duplicate removal ranks barcodes by whitelist abundance: give --barcode-whitelist or --remove-pcr-duplicates-at-cell-level");
   a.p.dedup_at_bulk_level = barcoded && !a.cell_level_dedup ? 1 : 0;  // remove_pcr_duplicates_at_bulk_level defaults to true (mapping_parameters.h:49)
@@ -359,7 +360,7 @@ int main(int argc, char **argv) {
   auto ck = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(ctx)); };
   if (barcoded && a.whitelist.empty()) {  // no whitelist: every barcode is kept as read (chromap.h:897-903); only its length is needed
     FastxReader pk;
-    if (!pk.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+    if (!pk.open(a.bc[0])) die("Cannot find sequence file " + a.bc[0]);
     std::string nm, sq, ql;
     if (!pk.record(nm, sq, ql)) die("empty barcode file");
     pk.close();
@@ -370,12 +371,13 @@ int main(int argc, char **argv) {
     // ---- FASTQ text goes to the GPU in chunks; lines, records and the SoA batch are built there
     if (barcoded && !a.whitelist.empty()) {
       // whitelist + abundance pre-pass (chromap.h:750-761), barcode file streamed through the device
-      ChunkReader br;
-      if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
-      size_t target = a.chunk_bytes;
       int done = 0;
       uint64_t ns = 0;
       uint32_t nk = 0;
+      for (size_t bi = 0; bi < a.bc.size() && !done; ++bi) {  // every barcode file in turn, batches restart per file (chromap.cc:495-543)
+      ChunkReader br;
+      if (!br.open(a.bc[bi])) die("Cannot find sequence file " + a.bc[bi]);
+      size_t target = a.chunk_bytes;
       while (!done) {
         br.fill(target);
         if (br.len == 0) break;
@@ -403,6 +405,7 @@ int main(int argc, char **argv) {
         if (br.eof && n == cnt) break;
       }
       br.close();
+      }
       fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
     }
     for (size_t fi = 0; fi < a.r1.size(); ++fi) {
@@ -411,7 +414,7 @@ int main(int argc, char **argv) {
       int sid[3] = {0, paired ? 1 : 2, 2};
       if (!rd[0].open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
       if (paired && !rd[1].open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);
-      if (barcoded && !rd[ns_streams - 1].open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+      if (barcoded && !rd[ns_streams - 1].open(a.bc[fi])) die("Cannot find sequence file " + a.bc[fi]);
       size_t target = a.chunk_bytes;
       for (;;) {
         uint32_t cnt[3] = {0, 0, 0};
@@ -465,22 +468,26 @@ int main(int argc, char **argv) {
   } else {
     // single-cell: whitelist + abundance pre-pass over the whole barcode file (chromap.h:750-761)
     if (barcoded && !a.whitelist.empty()) {
-      FastxReader br;
-      if (!br.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
-      std::string nm, sq, ql;
-      std::vector<char> bb;
-      std::vector<uint32_t> bo(1, 0);
-      while (br.record(nm, sq, ql)) { if (sq.empty()) continue; a.fmt[2].apply(sq, ql); bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
-      br.close();
-      if (bo.size() < 2) die("empty barcode file");
-      bc_len = bo[1] - bo[0];
-      uint64_t *keys = nullptr;
       uint32_t nk = 0;
-      if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
-      if (cmgpu_set_whitelist(ctx, keys, nk, bc_len) != 0) die(cmgpu_last_error(ctx));
-      free(keys);
       uint64_t ns = 0;
-      if (cmgpu_compute_barcode_abundance(ctx, bb.data(), bo.data(), (uint32_t)bo.size() - 1, &ns) != 0) die(cmgpu_last_error(ctx));
+      for (size_t bi = 0; bi < a.bc.size() && ns < 20000000ull; ++bi) {  // batches restart per file (chromap.cc:495-543)
+        FastxReader br;
+        if (!br.open(a.bc[bi])) die("Cannot find sequence file " + a.bc[bi]);
+        std::string nm, sq, ql;
+        std::vector<char> bb;
+        std::vector<uint32_t> bo(1, 0);
+        while (br.record(nm, sq, ql)) { if (sq.empty()) continue; a.fmt[2].apply(sq, ql); bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
+        br.close();
+        if (bo.size() < 2) { if (bi == 0) die("empty barcode file"); continue; }
+        if (bi == 0) {
+          bc_len = bo[1] - bo[0];
+          uint64_t *keys = nullptr;
+          if (cmgpu_load_whitelist_file(a.whitelist.c_str(), bc_len, &keys, &nk) != 0) die("ERROR: whitelist and input barcode lengths are not equal!");
+          if (cmgpu_set_whitelist(ctx, keys, nk, bc_len) != 0) die(cmgpu_last_error(ctx));
+          free(keys);
+        }
+        if (cmgpu_compute_barcode_abundance(ctx, bb.data(), bo.data(), (uint32_t)bo.size() - 1, &ns) != 0) die(cmgpu_last_error(ctx));
+      }
       fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
     }
 
@@ -488,7 +495,7 @@ int main(int argc, char **argv) {
       FastxReader f1, f2, fb;
       if (!f1.open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
       if (paired && !f2.open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);
-      if (barcoded && !fb.open(a.barcode_file)) die("Cannot find sequence file " + a.barcode_file);
+      if (barcoded && !fb.open(a.bc[fi])) die("Cannot find sequence file " + a.bc[fi]);
       bool more = true;
       while (more) {
         std::vector<char> b1, b2, bb, bq;

@@ -186,3 +186,29 @@ def test_single_end_with_barcodes(flags, data, tmp_path):
         outs.append(ds.md5(out))
     assert os.path.getsize(out) > 100000
     assert outs[1] == outs[0] and outs[2] == outs[0], outs
+
+
+def test_multiple_input_files(data, tmp_path):
+    """-1 a,b -2 c,d -b e,f: the reference keeps numbering reads across files (read ids feed the multi-mapper
+    RNG seeds) and restarts its 500 000-read batches per file; one of the files is gzip-compressed"""
+    import gzip
+    pre, idx = data("short")
+    cut = 60001 * 4  # lines: an uneven split
+    parts = {}
+    for tag in ("_1", "_2", "_bc"):
+        lines = open(pre + tag + ".fq", "rb").read().split(b"\n")
+        a, b = str(tmp_path / ("a%s.fq" % tag)), str(tmp_path / ("b%s.fq.gz" % tag))
+        open(a, "wb").write(b"\n".join(lines[:cut]) + b"\n")
+        with gzip.open(b, "wb", compresslevel=1) as g:
+            g.write(b"\n".join(lines[cut:]))
+        parts[tag] = a + "," + b
+    common = ["--preset", "atac", "-q", "0", "-x", idx, "-r", pre + ".fa", "-1", parts["_1"], "-2", parts["_2"], "-b", parts["_bc"],
+              "--barcode-whitelist", pre + ".whitelist.txt"]
+    outs = []
+    for prog, extra in ((REF, ["-t", "32"]), (CLI, []), (CLI, ["--host-ingest"])):
+        out = str(tmp_path / ("o%d.bed" % len(outs)))
+        r = subprocess.run([prog] + common + extra + ["-o", out], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(ds.md5(out))
+    assert os.path.getsize(out) > 100000
+    assert outs[1] == outs[0] and outs[2] == outs[0], outs
