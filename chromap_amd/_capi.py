@@ -99,11 +99,11 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_map_single_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
-           "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam",
+           "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded",
            "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
 
-TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC, TEXT_TAGALIGN_PE, TEXT_TAGALIGN_PE_BC, TEXT_BED_SE_BC = 0, 1, 2, 3, 4, 5
+TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC, TEXT_TAGALIGN_PE, TEXT_TAGALIGN_PE_BC, TEXT_BED_SE_BC, TEXT_TAGALIGN_SE_BC = 0, 1, 2, 3, 4, 5, 6
 
 _LIB = None
 
@@ -166,6 +166,11 @@ def declare(L):
     sig("cmgpu_download_sam", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
     sig("cmgpu_write_sam", C.c_int64, [P(C.c_char_p), C.c_void_p, C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_uint32, P(C.c_char_p), P(C.c_char_p)] + [C.c_void_p] * 6 + [C.c_char_p])
+    sig("cmgpu_download_barcode_keys", C.c_int, [C.c_void_p, C.c_void_p])
+    sig("cmgpu_set_barcode_check", C.c_int, [C.c_void_p, C.c_int])
+    sig("cmgpu_write_sam_barcoded", C.c_int64, [P(C.c_char_p), C.c_void_p, C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_uint32, P(C.c_char_p), P(C.c_char_p)] + [C.c_void_p] * 6 +
+        [C.c_void_p, C.c_uint32, C.c_char_p])
     sig("cmgpu_fastq_set_format", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char])
     sig("cmgpu_fastq_scan", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
     sig("cmgpu_fastq_take", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, P(C.c_uint64)])

@@ -650,6 +650,14 @@ extern "C" int cmgpu_download_sam(cmgpu_ctx *c, cmgpu_sam_record *records, uint3
   return CMGPU_OK;
 }
 
+extern "C" int cmgpu_download_barcode_keys(cmgpu_ctx *c, uint64_t *keys) {
+  if (!c || !keys) return CMGPU_EINVAL;
+  if (!c->has_barcodes) { cm_set_error(c, "the last batch had no barcodes"); return CMGPU_EINVAL; }
+  HIPCHECK(c, hipSetDevice(c->device));
+  if (c->n_pairs) HIPCHECK(c, hipMemcpy(keys, c->bc_key.p, (size_t)c->n_pairs * 8, hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_last_timings(const cmgpu_ctx *c, const char **names, float *ms, int cap) {
   if (!c) return 0;
   int k = 0;
@@ -878,7 +886,7 @@ static int bc_abundance_run(cmgpu_ctx *c, const uint8_t *dbases, const uint32_t 
     hipError_t e = hipMemcpyAsync(&ns, c->wl_num.p, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cm_set_error(c, std::string("barcode abundance: ") + hipGetErrorString(e)); rc = CMGPU_EHIP; break; }
-    if (ns * 20 < bn) {  // chromap.cc:523-533
+    if (!c->skip_barcode_check && ns * 20 < bn) {  // chromap.cc:523-533
       cm_set_error(c, "Less than 5% barcodes can be found or corrected based on the barcode whitelist.");
       rc = CMGPU_EINVAL;
       break;
@@ -887,6 +895,12 @@ static int bc_abundance_run(cmgpu_ctx *c, const uint8_t *dbases, const uint32_t 
   }
   c->wl_num_sample = ns;
   return rc;
+}
+
+extern "C" int cmgpu_set_barcode_check(cmgpu_ctx *c, int enabled) {
+  if (!c) return CMGPU_EINVAL;
+  c->skip_barcode_check = !enabled;
+  return CMGPU_OK;
 }
 
 extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, const uint32_t *offsets, uint32_t n,

@@ -146,7 +146,7 @@ struct Args {
   std::string index_path, ref_path, out_path, preset, whitelist, chr_order_path, pairs_order_path, translate_path;
   std::vector<std::string> r1, r2, bc;
   cmgpu_params p;
-  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false;
+  bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false, skip_bc_check = false;
   size_t chunk_bytes = 256u << 20;
   ReadFormat fmt[3];  // read 1, read 2, barcode
   int k = 17, w = 7, device = 0;
@@ -222,6 +222,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "--TagAlign") { a.out_tagalign = true; a.out_bed = true; a.out_sam = false; a.out_pairs = false; }
     else if (o == "--pairs") { a.out_pairs = true; a.out_bed = false; }
     else if (o == "-t" || o == "--num-threads") need("-t");  // host threads are irrelevant here
+    else if (o == "--skip-barcode-check") a.skip_bc_check = true;
     else if (o == "--barcode-translate") a.translate_path = need("--barcode-translate");
     else if (o == "--read-format") {
       const std::string f = need("--read-format");
@@ -342,7 +343,8 @@ int main(int argc, char **argv) {
 
   double t_read = 0, t_parse = 0, t_map = 0, t_post = 0;
   const double t_begin = now_s();
-  if (barcoded && a.out_sam) die("--SAM with cell barcodes (CB tag) is outside this build");
+  if (barcoded && a.out_sam && !a.translate_path.empty()) die("--SAM with --barcode-translate is outside this build");
+  if (a.skip_bc_check) cmgpu_set_barcode_check(ctx, 0);
   for (int m = 0; m < 3; ++m)
     if (!a.fmt[m].identity() &&
         cmgpu_fastq_set_format(ctx, m, (int)a.fmt[m].starts.size(), a.fmt[m].starts.data(), a.fmt[m].ends.data(), a.fmt[m].strand) != CMGPU_OK)
@@ -353,7 +355,7 @@ int main(int argc, char **argv) {
   std::vector<uint32_t> sam_cigar;
   std::vector<std::vector<char>> sam_md_batches;
   std::vector<uint32_t> sam_md_caps;
-  std::vector<uint64_t> sam_batch_slots;
+  std::vector<uint64_t> sam_batch_slots, sam_bc;
   std::vector<std::string> sam_names1, sam_names2;
   std::vector<char> sam_b1, sam_q1, sam_b2, sam_q2;
   std::vector<uint32_t> sam_o1(1, 0), sam_o2(1, 0);
@@ -567,6 +569,11 @@ int main(int argc, char **argv) {
           sam_batch_slots.push_back(slots);
           if (cmgpu_download_sam(ctx, sam_rec.data() + base, sam_cigar.data() + base * CMGPU_SAM_CIGAR_CAP, sam_md_batches.back().data()) != CMGPU_OK)
             die(cmgpu_last_error(ctx));
+          if (barcoded) {  // CB tag + the barcode's place in the sort key
+            const size_t kb = sam_bc.size();
+            sam_bc.resize(kb + n);
+            if (cmgpu_download_barcode_keys(ctx, sam_bc.data() + kb) != CMGPU_OK) die(cmgpu_last_error(ctx));
+          }
         } else if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) {
           // BED outputs: the records never leave HBM -- they join the device-side store
           die(cmgpu_last_error(ctx));
@@ -603,6 +610,12 @@ int main(int argc, char **argv) {
     std::vector<const char *> n1(sam_names1.size()), n2(sam_names2.size() ? sam_names2.size() : 1, "");
     for (size_t i = 0; i < sam_names1.size(); ++i) n1[i] = sam_names1[i].c_str();
     for (size_t i = 0; i < sam_names2.size(); ++i) n2[i] = sam_names2[i].c_str();
+    if (barcoded)
+      lines = cmgpu_write_sam_barcoded(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0,
+                                       sam_cigar.data(), md.data(), cap, n1.data(), n2.data(), sam_b1.data(), sam_q1.data(), sam_o1.data(),
+                                       paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,
+                                       sam_bc.data(), bc_len, a.out_path.c_str());
+    else
     lines = cmgpu_write_sam(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0, sam_cigar.data(),
                             md.data(), cap, n1.data(), n2.data(), sam_b1.data(), sam_q1.data(), sam_o1.data(),
                             paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,
@@ -615,13 +628,13 @@ int main(int argc, char **argv) {
                               a.out_path.c_str());
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
-    if (a.out_tagalign && barcoded && !paired) die("TagAlign for single-end single-cell data is outside this build");
     const int kind = a.out_tagalign && paired ? (barcoded ? CMGPU_TEXT_TAGALIGN_PE_BC : CMGPU_TEXT_TAGALIGN_PE)
-                                              : barcoded ? (paired ? CMGPU_TEXT_BED_PE_BC : CMGPU_TEXT_BED_SE_BC) : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
+                     : a.out_tagalign && barcoded ? CMGPU_TEXT_TAGALIGN_SE_BC
+                     : barcoded ? (paired ? CMGPU_TEXT_BED_PE_BC : CMGPU_TEXT_BED_SE_BC) : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
     const double t0 = now_s();
     if (cmgpu_store_format(ctx, kind, out_names.data(), ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
     const double t1 = now_s();
-    if (barcoded && !a.translate_path.empty() && kind == CMGPU_TEXT_BED_PE_BC) {
+    if (barcoded && !a.translate_path.empty() && (kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_BED_SE_BC)) {
       // --barcode-translate (BarcodeTranslator, barcode_translator.h:43-101): the device rendered the corrected barcodes;
       // column 4 is rewritten on the way to the file.  Table lines are "to<TAB or ,>from"; a barcode made of several
       // segments of the table's length is translated segment by segment and joined with '-'.

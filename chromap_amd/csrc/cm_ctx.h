@@ -66,6 +66,7 @@ struct cmgpu_ctx {
   DevBuf wl, pow10_tab, bcb, bcq, bco, bc_key, bc_ok, wl_num;
   uint32_t wl_mask = 0, wl_size = 0, bc_len = 0;
   uint64_t wl_num_sample = 0;
+  bool skip_barcode_check = false;  // --skip-barcode-check
   bool has_barcodes = false;  // resident batch carries barcodes
   bool single = false;        // resident batch is single-end
   // device-side record store + rendered text (cm_post.hip)

@@ -440,11 +440,12 @@ extern "C" int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_seque
 // The sequence is printed as mapped (reverse complement for the - strand, PrepareNegativeSequenceAt),
 // the quality reversed with it (sam_mapping.h:172-179), both cut to the trimmed length.
 // ---------------------------------------------------------------------------------------
-extern "C" int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
-                                   const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
-                                   const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
-                                   const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
-                                   const char *quals2, const uint32_t *offsets2, const char *out_path) {
+static int64_t write_sam_impl(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
+                              const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                              const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                              const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                              const char *quals2, const uint32_t *offsets2, const uint64_t *bck, uint32_t bc_len, const char *out_path) {
+  auto bc_of = [&](uint64_t slot) -> uint64_t { return bck ? bck[paired ? slot / 2 : slot] : 0; };
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
   std::string buf;
@@ -462,11 +463,12 @@ extern "C" int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t 
   std::sort(v.begin(), v.end(), [&](uint64_t a, uint64_t b) {
     const cmgpu_sam_record &x = rec[a], &y = rec[b];
     const int xf = x.flag & 64, yf = y.flag & 64;
-    return std::tie(x.rid, x.pos, x.mrid, x.mpos, xf, x.mapq, x.read_id) < std::tie(y.rid, y.pos, y.mrid, y.mpos, yf, y.mapq, y.read_id);
+    const uint64_t xb = bc_of(a), yb = bc_of(b);
+    return std::tie(x.rid, x.pos, xb, x.mrid, x.mpos, xf, x.mapq, x.read_id) < std::tie(y.rid, y.pos, yb, y.mrid, y.mpos, yf, y.mapq, y.read_id);
   });
   auto same = [&](uint64_t a, uint64_t b) {
     const cmgpu_sam_record &x = rec[a], &y = rec[b];
-    return x.pos == y.pos && x.rid == y.rid && (x.flag & 64) == (y.flag & 64) && x.mrid == y.mrid && x.mpos == y.mpos;
+    return x.pos == y.pos && x.rid == y.rid && bc_of(a) == bc_of(b) && (x.flag & 64) == (y.flag & 64) && x.mrid == y.mrid && x.mpos == y.mpos;
   };
   const bool inmem = !p->low_memory_mode;
   int64_t lines = 0;
@@ -527,6 +529,11 @@ extern "C" int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t 
       put_u32(buf, r.nm);
       buf.append("\tMD:Z:");
       buf.append(md_pool + last * (uint64_t)md_cap, r.md_len);
+      if (bck) {
+        buf.append("\tCB:Z:");
+        const uint64_t key = bc_of(last);
+        for (uint32_t b = 0; b < bc_len; ++b) buf.push_back("ACGT"[(key >> ((bc_len - 1 - b) * 2)) & 3]);  // Seed2Sequence
+      }
       buf.push_back('\n');
       ++lines;
       if (buf.size() > (1 << 20) - 4096) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
@@ -536,4 +543,24 @@ extern "C" int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t 
   if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
   fclose(f);
   return lines;
+}
+
+extern "C" int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
+                                   const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                                   const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                                   const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                                   const char *quals2, const uint32_t *offsets2, const char *out_path) {
+  return write_sam_impl(ref_names, ref_lengths, n_sequences, p, rec, n_slots, paired, cigar_pool, md_pool, md_cap, names1, names2, bases1, quals1,
+                        offsets1, bases2, quals2, offsets2, nullptr, 0, out_path);
+}
+
+extern "C" int64_t cmgpu_write_sam_barcoded(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
+                                            const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                                            const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                                            const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                                            const char *quals2, const uint32_t *offsets2, const uint64_t *barcode_keys, uint32_t barcode_length,
+                                            const char *out_path) {
+  if (!barcode_keys || barcode_length == 0 || barcode_length > 32) return CMGPU_EINVAL;
+  return write_sam_impl(ref_names, ref_lengths, n_sequences, p, rec, n_slots, paired, cigar_pool, md_pool, md_cap, names1, names2, bases1, quals1,
+                        offsets1, bases2, quals2, offsets2, barcode_keys, barcode_length, out_path);
 }

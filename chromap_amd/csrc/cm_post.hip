@@ -75,8 +75,9 @@ __device__ __forceinline__ PpRec pp_load(const uint8_t *store, uint32_t i) {
   return r;
 }
 
-__host__ __device__ __forceinline__ bool pp_has_bc(int kind) { return kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_TAGALIGN_PE_BC || kind == CMGPU_TEXT_BED_SE_BC; }
-__host__ __device__ __forceinline__ bool pp_is_se(int kind) { return kind == CMGPU_TEXT_BED_SE || kind == CMGPU_TEXT_BED_SE_BC; }
+__host__ __device__ __forceinline__ bool pp_se_bc(int kind) { return kind == CMGPU_TEXT_BED_SE_BC || kind == CMGPU_TEXT_TAGALIGN_SE_BC; }
+__host__ __device__ __forceinline__ bool pp_has_bc(int kind) { return kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_TAGALIGN_PE_BC || pp_se_bc(kind); }
+__host__ __device__ __forceinline__ bool pp_is_se(int kind) { return kind == CMGPU_TEXT_BED_SE || pp_se_bc(kind); }
 __host__ __device__ __forceinline__ bool pp_tagalign(int kind) { return kind == CMGPU_TEXT_TAGALIGN_PE || kind == CMGPU_TEXT_TAGALIGN_PE_BC; }
 // Tn5Shift (bed_mapping.h:48-54, 100-106, 165-170, 224-229)
 __device__ __forceinline__ void pp_tn5(PpRec &r, int kind) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_key_top(const uint8_t *__restri
 __device__ __forceinline__ bool pp_same_run(const PpRec &a, uint64_t bca, const PpRec &b, uint64_t bcb, const PpCfg &cfg) {
   if (a.rid != b.rid || a.start != b.start) return false;
   if (cfg.kind == CMGPU_TEXT_BED_SE) return true;          // bed_mapping.h:91-94
-  if (cfg.kind == CMGPU_TEXT_BED_SE_BC) return bca == bcb;   // MappingWithBarcode: (barcode, start), :39-42
+  if (pp_se_bc(cfg.kind)) return bca == bcb;               // MappingWithBarcode: (barcode, start), :39-42
   if (a.len != b.len) return false;                        // :216-219
   return !pp_has_bc(cfg.kind) || bca == bcb;               // :154-159
 }
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
   } else {
     len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
     if (cfg.kind == CMGPU_TEXT_BED_PE_BC || cfg.kind == CMGPU_TEXT_BED_SE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;  // chr start end barcode dups
+    else if (cfg.kind == CMGPU_TEXT_TAGALIGN_SE_BC) len += 2 + pp_digits(r.mapq) + 2 + 1;     // chr start end N mapq strand (mapping_writer.cc:26-34)
     else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
   }
   win[j] = wi;
@@ -270,6 +272,7 @@ __device__ __forceinline__ void pp_render(uint8_t *p, const PpRec &r, uint64_t b
     p = pp_put_u32(p, r.mapq);
     *p++ = '\t';
     *p++ = r.dir ? '+' : '-';
+    if (cfg.kind == CMGPU_TEXT_TAGALIGN_SE_BC) { *p = '\n'; return; }
     *p++ = '\t';
   }
   p = pp_put_u32(p, dups);
@@ -442,7 +445,7 @@ struct PpLinesOp {
 extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
                                   uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes) {
   if (!c || !names || !p || !n_lines || !n_bytes) return CMGPU_EINVAL;
-  if (kind < CMGPU_TEXT_BED_PE || kind > CMGPU_TEXT_BED_SE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
+  if (kind < CMGPU_TEXT_BED_PE || kind > CMGPU_TEXT_TAGALIGN_SE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
   PPCHECK(c, hipSetDevice(c->device));

@@ -308,7 +308,13 @@ class ChromapGPU:
         self._check(self.L.cmgpu_download_sam(self.ctx, C.cast(rec, C.c_void_p), cigar.ctypes.data, md.ctypes.data), self.ctx)
         return rec, cigar, md, int(cap.value), n
 
-    def write_sam(self, sam, paired, names1, names2, b1, q1, o1, b2, q2, o2, path, params=None):
+    def download_barcode_keys(self, n):
+        """(corrected) barcode keys of the last barcoded batch, one per pair / read"""
+        keys = np.zeros(max(1, n), np.uint64)
+        self._check(self.L.cmgpu_download_barcode_keys(self.ctx, keys.ctypes.data), self.ctx)
+        return keys[:n]
+
+    def write_sam(self, sam, paired, names1, names2, b1, q1, o1, b2, q2, o2, path, params=None, barcode_keys=None, barcode_length=0):
         rec, cigar, md, md_cap, n = sam
         p = params if params is not None else self.params
         rn = (C.c_char_p * len(self.names))(*self.names)
@@ -317,9 +323,15 @@ class ChromapGPU:
         n2 = (C.c_char_p * max(1, len(names2 or [])))(*(names2 or [b""]))
         keep = [np.ascontiguousarray(x) if x is not None else None for x in (b1, q1, o1, b2, q2, o2)]
         ptr = [k.ctypes.data if k is not None else None for k in keep]
-        k = self.L.cmgpu_write_sam(rn, C.cast(lens, C.c_void_p), len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, int(paired),
-                                   cigar.ctypes.data, md.ctypes.data, md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5],
-                                   path.encode())
+        if barcode_keys is not None:
+            bk = np.ascontiguousarray(barcode_keys, dtype=np.uint64)
+            k = self.L.cmgpu_write_sam_barcoded(rn, C.cast(lens, C.c_void_p), len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n,
+                                                int(paired), cigar.ctypes.data, md.ctypes.data, md_cap, n1, n2, ptr[0], ptr[1], ptr[2],
+                                                ptr[3], ptr[4], ptr[5], bk.ctypes.data, int(barcode_length), path.encode())
+        else:
+            k = self.L.cmgpu_write_sam(rn, C.cast(lens, C.c_void_p), len(self.names), C.byref(p), C.cast(rec, C.c_void_p), n, int(paired),
+                                       cigar.ctypes.data, md.ctypes.data, md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5],
+                                       path.encode())
         if k < 0:
             raise ChromapError("cannot write %s" % path)
         return int(k)

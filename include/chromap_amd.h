@@ -254,6 +254,8 @@ int cmgpu_set_whitelist(cmgpu_ctx *ctx, const uint64_t *keys, uint32_t n_keys, u
 /* single-end reads with cell barcodes: MappingWithBarcode (src/bed_mapping.h:11-56), src/chromap.h:385-472 */
 int cmgpu_map_single_barcoded(cmgpu_ctx *ctx, const cmgpu_single_batch *in, const cmgpu_barcode_batch *barcodes,
                               cmgpu_record_bc *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
+/* enabled = 0: --skip-barcode-check (src/chromap.cc:523), the 5% test of the abundance pre-pass is not applied */
+int cmgpu_set_barcode_check(cmgpu_ctx *ctx, int enabled);
 int cmgpu_compute_barcode_abundance(cmgpu_ctx *ctx, const char *barcode_bases, const uint32_t *barcode_offsets,
                                     uint32_t n_barcodes, uint64_t *num_sample_barcodes);
 int cmgpu_map_pairs_barcoded(cmgpu_ctx *ctx, const cmgpu_batch *in, const cmgpu_barcode_batch *barcodes,
@@ -351,6 +353,18 @@ int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_length
                         const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
                         const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
                         const char *quals2, const uint32_t *offsets2, const char *out_path);
+/* single-cell data: the (corrected) barcode keys of the batch last mapped with cmgpu_map_pairs_barcoded /
+ * cmgpu_map_single_barcoded, one per pair / read (what the reference keeps in SAMMapping::cell_barcode_) */
+int cmgpu_download_barcode_keys(cmgpu_ctx *ctx, uint64_t *keys);
+/* cmgpu_write_sam for single-cell data: cell_barcode_ takes part in operator< / operator==
+ * (src/sam_mapping.h:201-212) and every line ends with CB:Z:<barcode> (src/mapping_writer.cc:350-354).
+ * barcode_keys: one per pair / read, in slot order */
+int64_t cmgpu_write_sam_barcoded(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *params,
+                                 const cmgpu_sam_record *records, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                                 const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                                 const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                                 const char *quals2, const uint32_t *offsets2, const uint64_t *barcode_keys, uint32_t barcode_length,
+                                 const char *out_path);
 
 /* ---- device-side post-processing -------------------------------------
  * Replaces, for BED output: MappingProcessor::SortOutputMappings / RemovePCRDuplicate
@@ -367,7 +381,8 @@ int64_t cmgpu_write_sam(const char *const *ref_names, const uint32_t *ref_length
 #define CMGPU_TEXT_BED_PE_BC 2
 #define CMGPU_TEXT_TAGALIGN_PE 3    /* --TagAlign, paired-end bulk: two lines per fragment (src/mapping_writer.cc:84-117) */
 #define CMGPU_TEXT_TAGALIGN_PE_BC 4
-#define CMGPU_TEXT_BED_SE_BC 5      /* single-end single-cell BED: MappingWithBarcode (src/bed_mapping.h:11-56, src/mapping_writer.cc:6-25) */ /* --TagAlign, single-cell (src/mapping_writer.cc:138-168) */
+#define CMGPU_TEXT_BED_SE_BC 5      /* single-end single-cell BED: MappingWithBarcode (src/bed_mapping.h:11-56, src/mapping_writer.cc:6-25) */
+#define CMGPU_TEXT_TAGALIGN_SE_BC 6 /* --TagAlign, single-end single-cell: chr start end N mapq strand (src/mapping_writer.cc:26-34) */
 int cmgpu_store_clear(cmgpu_ctx *ctx);
 /* appends the records of the last cmgpu_map_* call (still resident); n_total = store size */
 int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);

@@ -2846,12 +2846,13 @@ long ora_map_single_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read
   return k;
 }
 
-typedef struct { const ora_sam_record *r; long slot; } sam_ref_t;
-/* SAMMapping::operator< under the per-chromosome vectors (sam_mapping.h:193-199), barcode 0 */
+typedef struct { const ora_sam_record *r; long slot; uint64_t bc; } sam_ref_t;
+/* SAMMapping::operator< under the per-chromosome vectors (sam_mapping.h:201-206); barcode 0 for bulk data */
 static int cmp_sam(const void *a, const void *b) {
   const ora_sam_record *x = ((const sam_ref_t *)a)->r, *y = ((const sam_ref_t *)b)->r;
+  const uint64_t xb = ((const sam_ref_t *)a)->bc, yb = ((const sam_ref_t *)b)->bc;
 #define CMPV(u, v) if ((u) != (v)) return (u) < (v) ? -1 : 1
-  CMPV(x->rid, y->rid); CMPV(x->pos, y->pos); CMPV(x->mrid, y->mrid); CMPV(x->mpos, y->mpos);
+  CMPV(x->rid, y->rid); CMPV(x->pos, y->pos); CMPV(xb, yb); CMPV(x->mrid, y->mrid); CMPV(x->mpos, y->mpos);
   CMPV(x->flag & 64, y->flag & 64); CMPV(x->mapq, y->mapq); CMPV(x->read_id, y->read_id);
 #undef CMPV
   return 0;
@@ -2860,16 +2861,17 @@ static int sam_same(const ora_sam_record *x, const ora_sam_record *y) { /* opera
   return x->pos == y->pos && x->rid == y->rid && (x->flag & 64) == (y->flag & 64) && x->mrid == y->mrid && x->mpos == y->mpos;
 }
 
-long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
-                   const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
-                   const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
-                   const char *q2, const uint32_t *o2, const uint32_t *len_after_trim, const char *out_path) {
+static long write_sam_impl(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
+                           const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
+                           const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
+                           const char *q2, const uint32_t *o2, const uint32_t *len_after_trim, const uint64_t *bck, uint32_t bc_len,
+                           const char *out_path) {
   FILE *f = fopen(out_path, "wb");
   if (!f) return -1;
   for (uint32_t i = 0; i < ref->n_seq; ++i) fprintf(f, "@SQ\tSN:%s\tLN:%u\n", ref->name[i], ref->len[i]); /* mapping_writer.cc:312-321 */
   sam_ref_t *v = (sam_ref_t *)malloc(((size_t)n_slots + 1) * sizeof(sam_ref_t));
   long n = 0;
-  for (long i = 0; i < n_slots; ++i) if (rec[i].valid) { v[n].r = &rec[i]; v[n].slot = i; ++n; }
+  for (long i = 0; i < n_slots; ++i) if (rec[i].valid) { v[n].r = &rec[i]; v[n].slot = i; v[n].bc = bck ? bck[paired ? i / 2 : i] : 0; ++n; }
   qsort(v, (size_t)n, sizeof(sam_ref_t), cmp_sam);
   const int inmem = !p->low_mem;
   long lines = 0, i = 0;
@@ -2879,7 +2881,7 @@ long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record
     sam_ref_t last = v[i];
     long j = i + 1;
     if (p->remove_pcr_duplicates) {
-      while (j < n && sam_same(v[j].r, v[i].r)) {
+      while (j < n && sam_same(v[j].r, v[i].r) && v[j].bc == v[i].bc) {
         if (inmem || v[j].r->mapq > last.r->mapq) last = v[j];
         ++j;
       }
@@ -2905,8 +2907,13 @@ long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record
       fprintf(f, "%s\t%u\t%s\t%u\t%u\t", name, (unsigned)r->flag, ref->name[r->rid], r->pos + 1, (unsigned)r->mapq);
       if (r->n_cigar == 0) fputc('*', f);
       for (int ci = 0; ci < r->n_cigar; ++ci) fprintf(f, "%u%c", cg[ci] >> 4, "MIDNSHP=XB"[cg[ci] & 0xf]);
-      fprintf(f, "\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\tMD:Z:%.*s\n", r->mrid < 0 ? "*" : ((uint32_t)r->mrid == r->rid ? "=" : ref->name[r->mrid]),
+      fprintf(f, "\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\tMD:Z:%.*s", r->mrid < 0 ? "*" : ((uint32_t)r->mrid == r->rid ? "=" : ref->name[r->mrid]),
               r->mrid < 0 ? 0u : r->mpos + 1, r->tlen, seq, qual, r->nm, (int)r->md_len, md_pool + (size_t)slot * md_cap);
+      if (bck) { /* mapping_writer.cc:350-354, Seed2Sequence */
+        fputs("\tCB:Z:", f);
+        for (uint32_t b = 0; b < bc_len; ++b) fputc("ACGT"[(last.bc >> ((bc_len - 1 - b) * 2)) & 3], f);
+      }
+      fputc('\n', f);
       ++lines;
     }
     i = j;
@@ -2914,4 +2921,36 @@ long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record
   free(seq); free(qual); free(v);
   fclose(f);
   return lines;
+}
+
+long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
+                   const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
+                   const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
+                   const char *q2, const uint32_t *o2, const uint32_t *len_after_trim, const char *out_path) {
+  return write_sam_impl(ref, p, rec, n_slots, paired, cigar_pool, md_pool, md_cap, names1, names2, b1, q1, o1, b2, q2, o2, len_after_trim,
+                        NULL, 0, out_path);
+}
+
+long ora_write_sam_bc(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
+                      const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
+                      const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
+                      const char *q2, const uint32_t *o2, const uint64_t *barcode_keys, uint32_t barcode_length, const char *out_path) {
+  return write_sam_impl(ref, p, rec, n_slots, paired, cigar_pool, md_pool, md_cap, names1, names2, b1, q1, o1, b2, q2, o2, NULL,
+                        barcode_keys, barcode_length, out_path);
+}
+
+/* --SAM with cell barcodes: CorrectBarcodeAt in front of the taskloop body (chromap.h:896-909), the
+ * corrected key of every pair goes to keys_per_pair (SAMMapping::cell_barcode_) */
+long ora_map_pairs_bc_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1, const uint32_t *r1_off,
+                          const char *r2, const uint32_t *r2_off, char *bc, const char *bc_qual, const uint32_t *bc_off,
+                          const ora_whitelist *w, ora_sam_record *out, uint32_t *cigar_pool, char *md_pool, uint32_t md_cap,
+                          uint64_t *keys_per_pair, ora_stats *stats) {
+  c->wl = w; c->bc = bc; c->bcq = bc_qual; c->bco = bc_off;
+  c->bc_key = (uint64_t *)calloc((size_t)n + 1, 8);
+  c->n_in_wl = c->n_corr = 0;
+  const long k = ora_map_pairs_sam(c, threads, n, first_read_id, r1, r1_off, r2, r2_off, out, cigar_pool, md_pool, md_cap, stats);
+  memcpy(keys_per_pair, c->bc_key, (size_t)n * 8);
+  free(c->bc_key);
+  c->wl = NULL; c->bc = NULL; c->bcq = NULL; c->bco = NULL; c->bc_key = NULL;
+  return k;
 }

@@ -161,6 +161,15 @@ long ora_write_sam(const ora_ref *ref, const ora_params *p, const ora_sam_record
                    const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
                    const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
                    const char *q2, const uint32_t *o2, const uint32_t *len_after_trim /* per slot */, const char *out_path);
+/* single-cell --SAM: barcode in the sort / duplicate keys and as CB:Z (sam_mapping.h:201-212, mapping_writer.cc:350-354) */
+long ora_write_sam_bc(const ora_ref *ref, const ora_params *p, const ora_sam_record *rec, long n_slots, int paired,
+                      const uint32_t *cigar_pool, const char *md_pool, uint32_t md_cap, const char *const *names1,
+                      const char *const *names2, const char *b1, const char *q1, const uint32_t *o1, const char *b2,
+                      const char *q2, const uint32_t *o2, const uint64_t *barcode_keys, uint32_t barcode_length, const char *out_path);
+long ora_map_pairs_bc_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r1, const uint32_t *r1_off,
+                          const char *r2, const uint32_t *r2_off, char *bc, const char *bc_qual, const uint32_t *bc_off,
+                          const ora_whitelist *w, ora_sam_record *out, uint32_t *cigar_pool, char *md_pool, uint32_t md_cap,
+                          uint64_t *keys_per_pair, ora_stats *stats);
 int ora_ksw_semi_global3(int qlen, const char *query, int tlen, const char *target, int w, uint32_t *cigar, int cigar_cap,
                          int *n_cigar, int *start, int *end);
 

@@ -73,6 +73,11 @@ CASES = {
                      "--varlen", "--seed", "7"], ["--preset", "atac", "--SAM"]),
     "s1_se_sam": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
                   ["--SAM", "--remove-pcr-duplicates"]),
+    # single-cell --SAM: barcode in the sort / duplicate keys, CB:Z tag
+    "b1_bc_sam": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
+                   "--barcodes", "500", "--seed", "31"], ["--preset", "atac", "--SAM"]),
+    "b3_bc_sam_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "30000", "--readlen", "50", "--frag-min", "40",
+                      "--barcodes", "40", "--seed", "33", "--dup-frac", "0.3"], ["--preset", "atac", "--SAM", "-q", "0"]),
     # --chr-order: reference reordered, candidate rids re-ranked before verification (flag value: comma list,
     # written to a file for the reference; unlisted chromosomes follow in reference order)
     "s3_chip_chrorder": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",

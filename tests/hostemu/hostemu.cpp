@@ -37,7 +37,8 @@ struct EmuBarcodes {
   const cmgpu_barcode_batch *bc;
   const uint64_t *wl_keys;
   uint32_t n_keys;
-  uint64_t *bc_key_out;  // [n]
+  uint64_t *bc_key_out;  // [n], packed like the records
+  uint64_t *bc_key_all;  // [n] per pair, or NULL
 };
 
 static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
@@ -217,6 +218,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     if (d.rec_ok[i]) { if (eb) eb->bc_key_out[k] = d.bc_key[i]; memcpy(&out[k++], d.rec + (size_t)i * 24, 24); }
     if (dbg_nbest) dbg_nbest[i] = d.pe_nbest[i];
   }
+  if (eb && eb->bc_key_all) for (uint32_t i = 0; i < n; ++i) eb->bc_key_all[i] = d.bc_key[i];
   for (uint32_t r = 0; r < n2; ++r) {
     if (dbg_mm_cnt) dbg_mm_cnt[r] = d.mm_cnt[r];
     if (dbg_ncand) dbg_ncand[r] = d.alive[r >> 1] ? d.fcp[r] + d.fcn[r] : 0;
@@ -257,7 +259,7 @@ extern "C" int hostemu_map_pairs_bc(const cmgpu_index_view *index, const cmgpu_r
                                     uint32_t n_keys, cmgpu_record_bc *out, uint64_t *n_out, cmgpu_stats *stats) {
   std::vector<cmgpu_record> rec(in->n_pairs + 1);
   std::vector<uint64_t> keys(in->n_pairs + 1);
-  EmuBarcodes eb{bc, wl_keys, n_keys, keys.data()};
+  EmuBarcodes eb{bc, wl_keys, n_keys, keys.data(), nullptr};
   const int rc = emu_map_pairs(index, ref, params, in, rec.data(), n_out, stats, nullptr, nullptr, nullptr, nullptr, &eb);
   for (uint64_t i = 0; i < *n_out; ++i) { out[i].r = rec[i]; out[i].barcode = keys[i]; }
   return rc;
@@ -301,6 +303,19 @@ extern "C" int hostemu_map_pairs_sam(const cmgpu_index_view *index, const cmgpu_
   uint64_t k = 0;
   const EmuSam sam{rec, cigar, md, md_cap};
   return emu_map_pairs(index, ref, params, in, out.data(), &k, stats, nullptr, nullptr, nullptr, nullptr, nullptr, false, &sam);
+}
+
+// --SAM for single-cell data: SAM records + the per-pair (corrected) barcode keys the writer sorts on and prints as CB:Z
+extern "C" int hostemu_map_pairs_bc_sam(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                        const cmgpu_batch *in, const cmgpu_barcode_batch *bc, const uint64_t *wl_keys, uint32_t n_keys,
+                                        cmgpu_sam_record *rec, uint32_t *cigar, char *md, uint32_t md_cap, uint64_t *keys_per_pair,
+                                        cmgpu_stats *stats) {
+  std::vector<cmgpu_record> out(in->n_pairs + 1);
+  std::vector<uint64_t> keys(in->n_pairs + 1);
+  uint64_t k = 0;
+  const EmuSam sam{rec, cigar, md, md_cap};
+  EmuBarcodes eb{bc, wl_keys, n_keys, keys.data(), keys_per_pair};
+  return emu_map_pairs(index, ref, params, in, out.data(), &k, stats, nullptr, nullptr, nullptr, nullptr, &eb, false, &sam);
 }
 
 extern "C" int hostemu_map_single_sam(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,

@@ -220,3 +220,39 @@ def map_sam(h, b1, o1, b2=None, o2=None):
            so.md.ctypes.data, so.md_cap, C.byref(st))
     assert rc == 0, rc
     return so, st
+
+
+def map_bc_sam(h, b1, o1, b2, o2, bc, bcq, bco, wl_keys):
+    """HostEmu h: stage functions in --SAM mode on single-cell data; returns (SamOut, per-pair barcode keys, Stats)"""
+    P = C.POINTER
+    n = len(o1) - 1
+    mx = max(int(np.diff(o1).max(initial=1)), int(np.diff(o2).max(initial=1)))
+    so = SamOut(2 * n, 2 * mx + 16)
+    st = _capi.Stats()
+    keep = [np.ascontiguousarray(x) for x in (b1, o1, b2, o2, bc, bcq, bco, wl_keys)]
+    bt = _capi.Batch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data)
+    bb = _capi.BarcodeBatch(keep[4].ctypes.data, keep[5].ctypes.data, keep[6].ctypes.data)
+    keys = np.zeros(max(1, n), np.uint64)
+    f = h.L.hostemu_map_pairs_bc_sam
+    f.restype = C.c_int
+    f.argtypes = [P(_capi.IndexView), P(_capi.RefView), P(_capi.Params), P(_capi.Batch), P(_capi.BarcodeBatch), C.c_void_p, C.c_uint32,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, P(_capi.Stats)]
+    rc = f(C.byref(h.idx), C.byref(h.ref), C.byref(h.p), C.byref(bt), C.byref(bb), keep[7].ctypes.data, len(keep[7]),
+           C.cast(so.rec, C.c_void_p), so.cigar.ctypes.data, so.md.ctypes.data, so.md_cap, keys.ctypes.data, C.byref(st))
+    assert rc == 0, rc
+    return so, keys[:n], st
+
+
+def write_sam_bc(L, ref, p, so, names1, names2, b1, q1, o1, b2, q2, o2, keys, barcode_length, path):
+    """the product's host SAM writer for single-cell data (CB:Z tag, barcode in the sort key)"""
+    _capi.declare(L)
+    nseq = ref.n_sequences
+    rn = (C.c_char_p * nseq)(*[ref.names[i] for i in range(nseq)])
+    n1 = (C.c_char_p * len(names1))(*names1)
+    n2 = (C.c_char_p * len(names2))(*names2)
+    keep = [np.ascontiguousarray(x) for x in (b1, q1, o1, b2, q2, o2)]
+    kk = np.ascontiguousarray(keys, dtype=np.uint64)
+    return L.cmgpu_write_sam_barcoded(rn, C.cast(ref.lengths, C.c_void_p), nseq, C.byref(p), C.cast(so.rec, C.c_void_p), so.n_slots, 1,
+                                      so.cigar.ctypes.data, so.md.ctypes.data, so.md_cap, n1, n2, keep[0].ctypes.data,
+                                      keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data, keep[4].ctypes.data,
+                                      keep[5].ctypes.data, kk.ctypes.data, barcode_length, path.encode())

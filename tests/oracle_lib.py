@@ -448,3 +448,38 @@ def write_sam(oracle, res, paired, names1, names2, b1, q1, o1, b2, q2, o2, path)
     return L.ora_write_sam(C.byref(oracle.ref), C.byref(oracle.p), C.cast(res.rec, C.c_void_p), res.n_slots, int(paired),
                            res.cigar.ctypes.data, res.md.ctypes.data, res.md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                            ptr[5], None, path.encode())
+
+
+def map_pairs_bc_sam(oracle, b1, o1, b2, o2, bc, bcq, bco, wl, threads=1):
+    """single-cell --SAM: (SamResult, per-pair barcode keys, stats)"""
+    import numpy as np
+    L = oracle.L
+    n = len(o1) - 1
+    md_cap = 2 * int(max(np.diff(o1).max(initial=1), np.diff(o2).max(initial=1))) + 16
+    res = SamResult(2 * n, md_cap)
+    st = OraStats()
+    keys = np.zeros(max(1, n), np.uint64)
+    L.ora_map_pairs_bc_sam.restype = C.c_long
+    L.ora_map_pairs_bc_sam.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 11 + [C.c_uint32, C.c_void_p,
+                                                                                                       C.POINTER(OraStats)]
+    arrs = [np.ascontiguousarray(x) for x in (b1, o1, b2, o2, bc, bcq, bco)]
+    L.ora_map_pairs_bc_sam(oracle.ctx, threads, n, 0, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
+                           arrs[4].ctypes.data, arrs[5].ctypes.data, arrs[6].ctypes.data, wl.h, C.cast(res.rec, C.c_void_p),
+                           res.cigar.ctypes.data, res.md.ctypes.data, md_cap, keys.ctypes.data, C.byref(st))
+    return res, keys[:n], st
+
+
+def write_sam_bc(oracle, res, paired, names1, names2, b1, q1, o1, b2, q2, o2, keys, barcode_length, path):
+    import numpy as np
+    L = oracle.L
+    L.ora_write_sam_bc.restype = C.c_long
+    L.ora_write_sam_bc.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)] + [C.c_void_p] * 7 + [C.c_uint32, C.c_char_p]
+    n1 = (C.c_char_p * len(names1))(*names1)
+    n2 = (C.c_char_p * max(1, len(names2 or [])))(*(names2 or [b""]))
+    keep = [np.ascontiguousarray(x) if x is not None else None for x in (b1, q1, o1, b2, q2, o2)]
+    ptr = [k.ctypes.data if k is not None else None for k in keep]
+    kk = np.ascontiguousarray(keys, dtype=np.uint64)
+    return L.ora_write_sam_bc(C.byref(oracle.ref), C.byref(oracle.p), C.cast(res.rec, C.c_void_p), res.n_slots, int(paired),
+                              res.cigar.ctypes.data, res.md.ctypes.data, res.md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+                              ptr[5], kk.ctypes.data, barcode_length, path.encode())

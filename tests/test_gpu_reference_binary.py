@@ -37,6 +37,10 @@ RUNS = {
     "hic_pairs": ("long", ["--preset", "hic"], False, False),
     "chip_sam": ("mid", ["--preset", "chip", "--SAM"], False, False),
     "sam_se_q0": ("mid", ["--SAM", "-q", "0"], True, False),
+    "sam_barcodes": ("short", ["--preset", "atac", "--SAM"], False, True),
+    "sam_se_barcodes_q0": ("short", ["--SAM", "--remove-pcr-duplicates", "-q", "0"], True, True),
+    # (single-end single-cell data in low-memory mode costs the reference ~30-60 s of fixed time in its merge; in-memory here)
+    "tagalign_se_barcodes": ("short", ["--TagAlign", "--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"], True, True),
 }
 
 
@@ -212,3 +216,19 @@ def test_multiple_input_files(data, tmp_path):
         outs.append(ds.md5(out))
     assert os.path.getsize(out) > 100000
     assert outs[1] == outs[0] and outs[2] == outs[0], outs
+
+
+def test_single_end_barcode_translate_and_skip_check(data, tmp_path):
+    """--barcode-translate on single-end single-cell BED, --skip-barcode-check accepted"""
+    pre, idx = data("short")
+    table = str(tmp_path / "tr.tsv")
+    with open(pre + ".whitelist.txt") as f, open(table, "w") as g:
+        for i, ln in enumerate(f):
+            g.write("C%d\t%s\n" % (i, ln.strip()))
+    common = ["--remove-pcr-duplicates", "--barcode-translate", table, "--skip-barcode-check", "-x", idx, "-r", pre + ".fa", "-1", pre + "_2.fq",
+              "-b", pre + "_bc.fq", "--barcode-whitelist", pre + ".whitelist.txt"]
+    out_ref, out_gpu = str(tmp_path / "r.bed"), str(tmp_path / "g.bed")
+    subprocess.run([REF] + common + ["-o", out_ref, "-t", "32"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([CLI] + common + ["-o", out_gpu], check=True, stderr=subprocess.PIPE)
+    assert os.path.getsize(out_ref) > 100000
+    assert ds.md5(out_gpu) == ds.md5(out_ref)

@@ -61,3 +61,34 @@ def test_sam_matches_reference_and_oracle(case, tmp_path):
         assert s[key] == ref[key], key
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("case", datasets.SAM_BC_CASES)
+def test_sam_with_barcodes_matches_reference(case, tmp_path):
+    """single-cell --SAM: barcode correction on the device, keys downloaded for the writer's sort and the CB:Z tag"""
+    from chromap_amd import ChromapGPU
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    g = ChromapGPU(datasets.case_index(case), fa, preset=preset, **kw)
+    b1, q1, o1 = ol.read_fastq_qual(r1)
+    b2, q2, o2 = ol.read_fastq_qual(r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    g.set_whitelist_file(wlf, int(bco[1] - bco[0]))
+    g.compute_barcode_abundance(bc, bco)
+    g.map_pairs_barcoded(b1, o1, b2, o2, bc, bcq, bco)
+    sam = g.download_sam()
+    keys = g.download_barcode_keys(len(o1) - 1)
+    out = str(tmp_path / "g.sam")
+    lines = g.write_sam(sam, True, ol.read_names(r1), ol.read_names(r2), b1, q1, o1, b2, q2, o2, out, barcode_keys=keys,
+                        barcode_length=int(bco[1] - bco[0]))
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    assert lines == ref["num_output"]
+    s = g.stats.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "num_barcode_in_whitelist",
+                "num_corrected_barcode"):
+        assert s[key] == ref[key], key
+    g.close()

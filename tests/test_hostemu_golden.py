@@ -120,3 +120,35 @@ def test_sam_stage_functions_match_reference(case, tmp_path):
             assert g[i] == w[i], (i, g[i], w[i])
     assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
     assert lines == meta["reference_stderr_counters"]["num_output"]
+
+
+@pytest.mark.parametrize("case", datasets.SAM_BC_CASES)
+def test_sam_with_barcodes_matches_reference(case, tmp_path):
+    """single-cell --SAM: barcode correction + SAM records through the stage functions; the host writer sorts on the
+    barcode and prints CB:Z"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    h = he.HostEmu(datasets.case_index(case), fa, he.params(preset, **kw))
+    b1, q1, o1 = ol.read_fastq_qual(r1)
+    b2, q2, o2 = ol.read_fastq_qual(r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+    keys, _ = wl.export()
+    so, bck, st = he.map_bc_sam(h, b1, o1, b2, o2, bc, bcq, bco, keys)
+    out = str(tmp_path / "e.sam")
+    lines = he.write_sam_bc(h.L, h.ref, h.p, so, ol.read_names(r1), ol.read_names(r2), b1, q1, o1, b2, q2, o2, bck, wl.barcode_length, out)
+    got = open(out, "rb").read()
+    want = datasets.case_golden_bed(case)
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        for i in range(min(len(g), len(w))):
+            assert g[i] == w[i], (i, g[i], w[i])
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    assert lines == ref["num_output"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "num_barcode_in_whitelist",
+                "num_corrected_barcode"):
+        assert s[key] == ref[key], key

@@ -147,3 +147,25 @@ def test_sam_matches_reference(case, tmp_path):
     for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
         assert s[key] == ref[key], key
     o.close()
+
+
+@pytest.mark.parametrize("case", datasets.SAM_BC_CASES)
+def test_sam_with_barcodes_matches_reference(case, tmp_path):
+    """single-cell --SAM: cell_barcode_ in SAMMapping's order / equality, CB:Z tag"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    o = ol.Oracle(datasets.case_index(case), fa, ol.params(preset, **kw))
+    b1, q1, o1 = ol.read_fastq_qual(r1)
+    b2, q2, o2 = ol.read_fastq_qual(r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+    assert wl.abundance(bc, bco) > 0
+    res, keys, st = ol.map_pairs_bc_sam(o, b1, o1, b2, o2, bc, bcq, bco, wl)
+    out = str(tmp_path / "o.sam")
+    lines = ol.write_sam_bc(o, res, True, ol.read_names(r1), ol.read_names(r2), b1, q1, o1, b2, q2, o2, keys, wl.barcode_length, out)
+    got = open(out, "rb").read()
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    assert lines == meta["reference_stderr_counters"]["num_output"]
+    o.close()
