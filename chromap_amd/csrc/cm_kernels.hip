@@ -94,7 +94,7 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
   uint32_t cnt = 0, len = 0;
   if (valid) {
     len = d.rlen[r];
-    cnt = cm_minimizers_window_e<7>(seq, len, k, [&](uint32_t n, uint64_t h, uint32_t p) {
+    cnt = cm_minimizers_w7(seq, len, k, [&](uint32_t n, uint64_t h, uint32_t p) {
       if (n < stg) sh_e[(size_t)n * T + t] = h | ((uint64_t)p << hb);
     });
   }

@@ -562,9 +562,98 @@ CM_HD uint32_t cm_minimizers_window_e(const uint8_t *seq, uint32_t len, int k, E
   return n;
 }
 
+// w = 7, odd k (every preset; an odd-length k-mer cannot be its own reverse complement, so the palindrome
+// branch never fires): the same emissions as cm_minimizers_window_e<7> without its data-dependent branches --
+// on a wave every branch of the state machine is taken by some lane at nearly every position, so the
+// wave pays for all of them (~300 instructions per base).  Closed form of what the state machine emits on
+// a read without ambiguous bases, k-mers h[0..m-1]:
+//   * k-mer j is emitted iff h[j] equals the minimum of some complete window h[i-6..i] containing it
+//     (the running minimum is emitted when it is replaced or leaves, equal hashes in the window are
+//     emitted by the duplicate scans), in increasing position;
+//   * except at the first complete window: if h[6] equals the minimum of h[0..5], those earlier equal
+//     k-mers are dropped (the replaced minimum is only emitted from unambiguous_length >= w + k on, and
+//     the duplicate scan of that step needs min < h[6]); every later window that holds them also holds
+//     k-mer 6, so they are simply struck out;
+//   * fewer than 7 k-mers: only the final flush fires, with the last occurrence of the minimum.
+// Per base: shift the 7-entry register window, one 7-way minimum, 7 equality tests into a flag mask,
+// and the entry that leaves the window is emitted if flagged.  A read with a base outside ACGT is redone by
+// the state machine (its behaviour across N runs is not a window rule).
+template <class Emit>
+CM_HD uint32_t cm_minimizers_w7_oddk(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+  const uint64_t shift = 2 * (uint64_t)(k - 1);
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  uint64_t fw = 0, rv = 0;
+  uint64_t H[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) H[j] = ~0ull;
+  uint32_t sb = 0, fl = 0, bad = 0, n = 0;
+  for (uint32_t pos = 0; pos < len; ++pos) {
+    uint32_t c = cm_c2u(seq[pos]);
+    bad |= c >> 2;
+    c &= 3;
+    fw = ((fw << 2) | c) & mask;
+    rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
+    if (pos + 1 < (uint32_t)k) continue;
+    const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+    const uint32_t strand = h0 < h1 ? 0u : 1u;
+    const uint64_t h = cm_hash64(strand ? h1 : h0, mask);
+    if (fl & 1u) { emit(n, H[0], ((pos - 7) << 1) | (sb & 1u)); ++n; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) H[j] = H[j + 1];
+    H[6] = h;
+    sb = (sb >> 1) | (strand << 6);
+    fl >>= 1;
+    const uint32_t i = pos + 1 - (uint32_t)k;  // index of this k-mer
+    if (i == 6) {
+      uint64_t v = H[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) v = H[j] < v ? H[j] : v;
+      if (h == v) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) H[j] = H[j] == v ? ~0ull : H[j];
+      }
+    }
+    if (i >= 6) {
+      uint64_t m = H[0];
+#pragma unroll
+      for (int j = 1; j < 7; ++j) m = H[j] < m ? H[j] : m;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) fl |= H[j] == m ? 1u << j : 0u;
+    }
+  }
+  if (bad) return ~0u;
+  if (len < (uint32_t)k) return 0;
+  const uint32_t m_k = len - (uint32_t)k + 1;
+  if (m_k < 7) {  // no complete window: the flush emits the running minimum, ties -> the last one
+    uint64_t v = ~0ull;
+    int at = -1;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j >= 7 - (int)m_k && H[j] <= v) { v = H[j]; at = j; }
+    if (at >= 0) { emit(n, v, ((len - 1 - (uint32_t)(6 - at)) << 1) | ((sb >> at) & 1u)); ++n; }
+    return n;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+    if ((fl >> j) & 1u) { emit(n, H[j], ((len - 1 - (uint32_t)(6 - j)) << 1) | ((sb >> j) & 1u)); ++n; }
+  return n;
+}
+
+// w = 7 front end: closed form for odd k, the state machine otherwise and for reads with ambiguous bases
+template <class Emit>
+CM_HD uint32_t cm_minimizers_w7(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+  if (k & 1) {
+    const uint32_t n = cm_minimizers_w7_oddk(seq, len, k, emit);
+    if (n != ~0u) return n;
+  }
+  return cm_minimizers_window_e<7>(seq, len, k, emit);
+}
+
 template <int W>
 CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uint64_t *oh, uint32_t *op, uint32_t cap) {
-  return cm_minimizers_window_e<W>(seq, len, k, [&](uint32_t n, uint64_t h, uint32_t p) { if (oh && n < cap) { oh[n] = h; op[n] = p; } });
+  auto put = [&](uint32_t n, uint64_t h, uint32_t p) { if (oh && n < cap) { oh[n] = h; op[n] = p; } };
+  if (W == 7) return cm_minimizers_w7(seq, len, k, put);
+  return cm_minimizers_window_e<W>(seq, len, k, put);
 }
 
 // generic window size: ring buffer in private memory, literal transcription

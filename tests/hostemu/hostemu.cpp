@@ -283,6 +283,12 @@ extern "C" long hostemu_ref_minimizers(const cmgpu_ref_view *ref, int k, int w, 
   return n;
 }
 
+// one read through the w = 7 minimizer front end (variant 1) or the state machine alone (variant 0)
+extern "C" int hostemu_minimizers_w7(const uint8_t *seq, uint32_t len, int k, int variant, uint64_t *out_hash, uint32_t *out_ps, uint32_t cap) {
+  auto put = [&](uint32_t n, uint64_t h, uint32_t p) { if (n < cap) { out_hash[n] = h; out_ps[n] = p; } };
+  return (int)(variant ? cm_minimizers_w7(seq, len, k, put) : cm_minimizers_window_e<7>(seq, len, k, put));
+}
+
 // S0 alone (length filter + adapter trimming): rlen[2*pair], rlen[2*pair+1] as cm_s0_prep leaves them
 extern "C" int hostemu_trim(const cmgpu_params *params, const cmgpu_batch *in, uint32_t *rlen) {
   CmDev d;

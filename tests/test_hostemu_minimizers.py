@@ -1,0 +1,66 @@
+"""The branch-light closed form of the w = 7 minimizer pass (cm_minimizers_w7_oddk, what k_prep_mm and the
+two-pass kernels run) against the oracle's transcription of MinimizerGenerator::GenerateMinimizers
+(minimizer_generator.cc:7-139) on reads built to hit its corner cases: equal hashes inside a window
+(homopolymers, short tandem repeats), the first-window rule, reads shorter than one window, N runs,
+lower case, even k (state machine)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hostemu_lib as he
+import oracle_lib as ol
+
+
+def _reads(rng, n):
+    out = []
+    for i in range(n):
+        kind = i % 8
+        ln = int(rng.integers(1, 130)) if kind != 7 else int(rng.integers(17, 31))
+        if kind in (0, 7):
+            s = rng.choice(list(b"ACGT"), ln)
+        elif kind == 1:  # two-letter alphabet: many equal canonical k-mers
+            s = rng.choice(list(b"AT"), ln)
+        elif kind == 2:  # tandem repeat of period 1..6 with a few substitutions
+            unit = rng.choice(list(b"ACGT"), int(rng.integers(1, 7)))
+            s = np.resize(unit, ln).copy()
+            for _ in range(int(rng.integers(0, 4))):
+                s[int(rng.integers(0, ln))] = rng.choice(list(b"ACGT"))
+        elif kind == 3:  # homopolymer stretches
+            s = np.concatenate([np.full(int(rng.integers(1, 40)), rng.choice(list(b"ACGT"))) for _ in range(6)])[:ln]
+        elif kind == 4:  # random with N runs
+            s = rng.choice(list(b"ACGT"), ln)
+            for _ in range(int(rng.integers(1, 4))):
+                a = int(rng.integers(0, ln))
+                s[a:a + int(rng.integers(1, 5))] = ord("N")
+        elif kind == 5:  # lower case mixed in (CharToUint8 maps it like upper case)
+            s = rng.choice(list(b"ACGTacgt"), ln)
+        else:  # repeat + N
+            unit = rng.choice(list(b"ACGT"), int(rng.integers(1, 5)))
+            s = np.resize(unit, ln).copy()
+            s[int(rng.integers(0, ln))] = ord("n")
+        out.append(np.asarray(s, dtype=np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("k", [17, 19, 23, 15, 27, 16, 18])
+def test_w7_minimizers_equal_the_reference_state_machine(k):
+    L = he.lib()
+    O = ol.lib()
+    f = L.hostemu_minimizers_w7
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(1000 + k)
+    oh, ot = np.zeros(256, np.uint64), np.zeros(256, np.uint64)
+    gh, gp = np.zeros(256, np.uint64), np.zeros(256, np.uint32)
+    n_emitted = 0
+    for s in _reads(rng, 24000):
+        buf = np.concatenate([s, np.zeros(8, np.uint8)])
+        c = O.ora_minimizers(buf.ctypes.data_as(C.c_char_p), len(s), 0, k, 7, oh.ctypes.data, ot.ctypes.data)
+        want = [(int(oh[i]), int(ot[i]) & 0x1FFFFFFFF) for i in range(c)]
+        for variant in (1, 0):
+            g = f(buf.ctypes.data, len(s), k, variant, gh.ctypes.data, gp.ctypes.data, 256)
+            got = [(int(gh[i]), int(gp[i])) for i in range(g)]
+            assert got == want, (variant, bytes(s), got, want)
+        n_emitted += c
+    assert n_emitted > 50000
