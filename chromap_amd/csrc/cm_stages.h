@@ -14,9 +14,14 @@
 // small helpers
 // ---------------------------------------------------------------------------------------
 // CharToUint8 (utils.h:87-104)
+// branch-free: A C G T are 0x41 0x43 0x47 0x54 once the case bit is cleared; bits 1-2 of those codes are
+// 00 01 11 10, Gray-decoded to 0 1 2 3; membership through a 20-bit set indexed by (u - 'A')
 CM_HD uint32_t cm_c2u(uint8_t c) {
-  const uint8_t u = c & 0xDF;
-  return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+  const uint32_t u = c & 0xDFu;
+  const uint32_t x = (u >> 1) & 3u;
+  const uint32_t o = u - 0x41u;
+  const bool acgt = o < 20u && ((0x80045u >> (o & 31u)) & 1u);
+  return acgt ? x ^ (x >> 1) : 4u;
 }
 // Uint8ToChar(3 ^ CharToUint8(c)) as used by PrepareNegativeSequenceAt (sequence_batch.h:123-134)
 CM_HD uint8_t cm_negchar(uint8_t c) {
