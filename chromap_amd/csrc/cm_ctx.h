@@ -82,7 +82,7 @@ struct cmgpu_ctx {
   bool has_rank = false;
   DevBuf mm_cursor;  // k_prep_mm: next free entry of the dense minimizer arrays
   DevBuf mm_marks;   // cursor after every chunk of pairs: the range of minimizers a chunk's probe launch covers
-  DevBuf part_k, part_v, part_tmp, part_cnt;  // cmgpu_records_partition scratch (kept across steps)
+  DevBuf part_cnt;  // cmgpu_records_partition: per-owner counts and cursors
   uint64_t sam_slots = 0;
   uint32_t sam_md_cap = 0;
   // one batch in flight (cmgpu_map_pairs_async / cmgpu_wait)
@@ -109,7 +109,7 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_k, &part_v, &part_tmp, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank};
   }
 };
 

@@ -580,34 +580,42 @@ extern "C" int cmgpu_store_info(const cmgpu_ctx *c, uint64_t *n_records, uint64_
 // chromosome (owner = rid * world / n_seq, chromap_amd/distributed.py:owned_rids) so that one
 // all-to-all delivers every record to the rank that sorts and de-duplicates its chromosomes.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PP_BLOCK) void k_pp_owner_key(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, uint32_t n,
-                                                             uint32_t world, uint32_t n_seq, uint32_t *__restrict__ key,
-                                                             uint32_t *__restrict__ idx, unsigned long long *__restrict__ counts) {
+__device__ __forceinline__ uint32_t pp_owner(const uint8_t *__restrict__ rec, uint32_t i, uint32_t world, uint32_t n_seq) {
+  const uint32_t rid = reinterpret_cast<const uint32_t *>(rec + (uint64_t)i * 24)[1];
+  const uint32_t k = (uint32_t)(((uint64_t)rid * world) / n_seq);
+  return k >= world ? world - 1 : k;
+}
+// pass 1: records per owner (block histogram in LDS, one global atomic per owner and block)
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_owner_count(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, uint32_t n,
+                                                               uint32_t world, uint32_t n_seq, unsigned long long *__restrict__ counts) {
   __shared__ uint32_t hist[64];
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
-  if (i < n) {
-    uint32_t k = world;  // records that do not exist sort behind every owner
-    if (ok[i]) {
-      const uint32_t rid = reinterpret_cast<const uint32_t *>(rec + (uint64_t)i * 24)[1];
-      k = (uint32_t)(((uint64_t)rid * world) / n_seq);
-      if (k >= world) k = world - 1;
-      atomicAdd(&hist[k], 1u);
-    }
-    key[i] = k;
-    idx[i] = i;
-  }
+  if (i < n && ok[i]) atomicAdd(&hist[pp_owner(rec, i, world, n_seq)], 1u);
   __syncthreads();
   if (threadIdx.x < world && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
-__global__ __launch_bounds__(PP_BLOCK) void k_pp_gather24(const uint8_t *__restrict__ rec, const uint32_t *__restrict__ idx, uint32_t n_valid,
-                                                            uint8_t *__restrict__ dst) {
-  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
-  if (j >= n_valid) return;
-  const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + (uint64_t)idx[j] * 24);
-  uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)j * 24);
-  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+// pass 2: every block reserves its share of each owner's section (cursors start at the sections' first
+// records) and its threads copy their records there; the order inside a section is irrelevant (a total-order sort follows)
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_owner_scatter(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, uint32_t n,
+                                                                 uint32_t world, uint32_t n_seq, unsigned long long *__restrict__ cursors,
+                                                                 uint8_t *__restrict__ dst) {
+  __shared__ uint32_t hist[64];
+  __shared__ unsigned long long base[64];
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
+  const bool have = i < n && ok[i];
+  uint32_t k = 0, local = 0;
+  if (have) { k = pp_owner(rec, i, world, n_seq); local = atomicAdd(&hist[k], 1u); }
+  __syncthreads();
+  if (threadIdx.x < world && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+  __syncthreads();
+  if (!have) return;
+  const uint64_t *sp = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
+  uint64_t *dp = reinterpret_cast<uint64_t *>(dst + (base[k] + local) * 24);
+  dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
 }
 
 extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *device_dst, uint64_t capacity, uint64_t *counts) {
@@ -617,32 +625,22 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   const uint32_t n = c->n_pairs;
   if (n == 0) return CMGPU_OK;
   hipStream_t s = c->stream;
-  DevBuf &k1 = c->part_k, &v1 = c->part_v, &tmp = c->part_tmp, &dcnt = c->part_cnt;
-  auto fail = [&](int rc) { return rc; };
-  if (k1.ensure((size_t)n * 4) || v1.ensure((size_t)n * 4) || dcnt.ensure(64 * 8)) { cm_set_error(c, "out of device memory (partition)"); return fail(CMGPU_ENOMEM); }
-  uint32_t *k0 = (uint32_t *)c->scratch_a.p, *v0 = (uint32_t *)c->scratch_b.p;  // free between batches
-  if (hipMemsetAsync(dcnt.p, 0, 64 * 8, s) != hipSuccess) return fail(CMGPU_EHIP);
+  DevBuf &dcnt = c->part_cnt;
+  if (dcnt.ensure(2 * 64 * 8)) { cm_set_error(c, "out of device memory (partition)"); return CMGPU_ENOMEM; }
+  unsigned long long *d_counts = (unsigned long long *)dcnt.p, *d_cursors = d_counts + 64;
+  PPCHECK(c, hipMemsetAsync(d_counts, 0, 64 * 8, s));
   const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
-  hipLaunchKernelGGL(k_pp_owner_key, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, k0, v0,
-                     (unsigned long long *)dcnt.p);
-  unsigned bits = 1;
-  while ((1u << bits) < world + 1) ++bits;
-  size_t tb = 0;
-  if (rocprim::radix_sort_pairs(nullptr, tb, k0, (uint32_t *)k1.p, v0, (uint32_t *)v1.p, (size_t)n, 0, bits, s) != hipSuccess || tmp.ensure(tb + 256)) {
-    cm_set_error(c, "partition sort setup failed"); return fail(CMGPU_ENOMEM);
-  }
-  if (rocprim::radix_sort_pairs(tmp.p, tb, k0, (uint32_t *)k1.p, v0, (uint32_t *)v1.p, (size_t)n, 0, bits, s) != hipSuccess) {
-    cm_set_error(c, "partition sort failed"); return fail(CMGPU_EHIP);
-  }
-  unsigned long long h[64];
-  if (hipMemcpyAsync(h, dcnt.p, (size_t)world * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-    cm_set_error(c, "partition counts failed"); return fail(CMGPU_EHIP);
-  }
+  hipLaunchKernelGGL(k_pp_owner_count, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, d_counts);
+  unsigned long long h[64], start[64];
+  PPCHECK(c, hipMemcpyAsync(h, d_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
+  PPCHECK(c, hipStreamSynchronize(s));
   uint64_t total = 0;
-  for (uint32_t r = 0; r < world; ++r) { counts[r] = h[r]; total += h[r]; }
-  if (total > capacity) { cm_set_error(c, "send buffer too small"); return fail(CMGPU_ECAPACITY); }
-  if (total) hipLaunchKernelGGL(k_pp_gather24, dim3((unsigned)((total + PP_BLOCK - 1) / PP_BLOCK)), b, 0, s, (const uint8_t *)c->rec.p,
-                                (const uint32_t *)v1.p, (uint32_t)total, (uint8_t *)device_dst);
-  if (hipStreamSynchronize(s) != hipSuccess) { cm_set_error(c, "partition gather failed"); return fail(CMGPU_EHIP); }
-  return fail(CMGPU_OK);
+  for (uint32_t r = 0; r < world; ++r) { counts[r] = h[r]; start[r] = total; total += h[r]; }
+  if (total > capacity) { cm_set_error(c, "send buffer too small"); return CMGPU_ECAPACITY; }
+  if (total == 0) return CMGPU_OK;
+  PPCHECK(c, hipMemcpyAsync(d_cursors, start, (size_t)world * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_pp_owner_scatter, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, d_cursors,
+                     (uint8_t *)device_dst);
+  PPCHECK(c, hipStreamSynchronize(s));
+  return CMGPU_OK;
 }
