@@ -15,7 +15,7 @@
 #include "cm_kernels.h"
 #include "cm_mapq_tables.h"
 
-static std::string g_last_error;
+static thread_local std::string g_last_error;  // errors without a ctx (creation), per calling thread
 
 #define HIPCHECK(ctx, call)                                                                      \
   do {                                                                                           \
@@ -38,6 +38,7 @@ int DevBuf::ensure(size_t bytes) {
   size_t want = bytes + bytes / 4 + 256;
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
+    (void)hipGetLastError();  // the retry below decides
     want = bytes;
     e = hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; return -1; }
@@ -130,6 +131,7 @@ static int select_device(int device_id) {
   }
   if (device_id < 0 || device_id >= n) { cm_set_error(nullptr, "device_id out of range"); return CMGPU_EINVAL; }
   if (hipSetDevice(device_id) != hipSuccess) { cm_set_error(nullptr, "hipSetDevice failed"); return CMGPU_EHIP; }
+  (void)hipGetLastError();  // clean slate: cm_stream_sync reports this call's launches only
   return CMGPU_OK;
 }
 
@@ -239,7 +241,7 @@ extern "C" int cmgpu_set_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t 
     off[rank[i]] = c->h_ref_off[i];
     len[rank[i]] = c->h_ref_len[i];
   }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   if (c->rid_rank.ensure((size_t)n * 4) || c->ref_off_r.ensure((size_t)n * 8) || c->ref_len_r.ensure((size_t)n * 4)) {
     cm_set_error(c, "out of device memory (chromosome order)"); return CMGPU_ENOMEM;
   }
@@ -253,7 +255,7 @@ extern "C" int cmgpu_set_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t 
 extern "C" int cmgpu_set_pairs_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t n) {
   if (!c || !rank) return CMGPU_EINVAL;
   if (n != c->n_seq) { cm_set_error(c, "rank table size differs from the number of reference sequences"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   if (c->pairs_rank.ensure((size_t)n * 4)) { cm_set_error(c, "out of device memory (pairs order)"); return CMGPU_ENOMEM; }
   HIPCHECK(c, hipMemcpy(c->pairs_rank.p, rank, (size_t)n * 4, hipMemcpyHostToDevice));
   c->has_pairs_rank = true;
@@ -297,7 +299,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
 
 extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   if (!c || !in) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint32_t n = in->n_pairs;
   if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
   c->n_pairs = n;
@@ -321,7 +323,7 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   HIPCHECK(c, hipMemcpyAsync(c->rb1.p, in->read2_bases, c->bases1, hipMemcpyHostToDevice, c->stream));
   HIPCHECK(c, hipMemcpyAsync(c->ro0.p, in->read1_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHECK(c, hipMemcpyAsync(c->ro1.p, in->read2_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(c, hipStreamSynchronize(c->stream));
+  HIPCHECK(c, cm_stream_sync(c->stream));
   return CMGPU_OK;
 }
 
@@ -377,7 +379,7 @@ static inline void mark(cmgpu_ctx *c, const char *name) {
 // variable-length intermediates (minimizers, hits, candidate capacity).
 extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *stats) {
   if (!c) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint32_t n = c->n_pairs, n2 = 2 * n;
   c->n_ev = 0;
   c->n_records = 0;
@@ -450,7 +452,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
       cm_launch_k_probe_reduce(c->partials.p, part_off[n_chunks], d.stats + CM_ST_PROBE_STEPS, s);
       unsigned long long tot = 0;
       HIPCHECK(c, hipMemcpyAsync(&tot, c->mm_cursor.p, 8, hipMemcpyDeviceToHost, s));
-      HIPCHECK(c, hipStreamSynchronize(s));
+      HIPCHECK(c, cm_stream_sync(s));
       bool grid_short = false;  // a chunk emitted more than its probe grid covers (cannot happen on attempt 1)
       if (attempt == 0 && tot <= cap) {
         unsigned long long hm[CM_MM_CHUNKS + 1];
@@ -467,7 +469,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     cm_launch_k_prep_count(d, n, c->max_read_len, s);
     cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
     HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(c, hipStreamSynchronize(s));
+    HIPCHECK(c, cm_stream_sync(s));
     mark(c, "s0_s1a_trim_count");
     if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
         c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
@@ -485,7 +487,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_scan_u32(d.hit_tot, d.hit_off, n2, (uint32_t *)c->scan_tmp.p, s);
   uint32_t n_hits = 0;
   HIPCHECK(c, hipMemcpyAsync(&n_hits, d.hit_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   if (c->hbuf.ensure((size_t)n_hits * 8 + 8) || c->hcnt.ensure((size_t)n_hits + 4)) { cm_set_error(c, "out of device memory (hits)"); return CMGPU_ENOMEM; }
   cm_fill_dev(c, d);
   mark(c, "s3a_count");
@@ -496,7 +498,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_scan_u32(d.m_tot, d.m_off, n2, (uint32_t *)c->scan_tmp.p, s);
   uint32_t n_m = 0;
   HIPCHECK(c, hipMemcpyAsync(&n_m, d.m_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
       c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
       c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4)) {
@@ -515,7 +517,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);
   uint32_t n_v = 0;
   HIPCHECK(c, hipMemcpyAsync(&n_v, d.v_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   mark(c, "s5a_prepare");
   cm_launch_k_s5b_verify(d, n_v, n2, s);
   mark(c, "s5b_verify");
@@ -543,9 +545,9 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   cm_launch_k_stats(d, n, (unsigned long long *)c->partials.p, s);
   unsigned long long hst[CM_ST_N];
   HIPCHECK(c, hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   mark(c, "stats");
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
   c->n_records = hst[CM_ST_RECORDS];
   c->last_n_mm = n_mm; c->last_n_hits = n_hits; c->last_n_cand_cap = n_m;
@@ -568,7 +570,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
 
 extern "C" int cmgpu_download_records(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
   if (!c || !out || !n_out) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint32_t n = c->n_pairs;
   *n_out = 0;
   if (n == 0) return CMGPU_OK;
@@ -639,7 +641,7 @@ extern "C" int cmgpu_sam_layout(const cmgpu_ctx *c, uint64_t *n_slots, uint32_t 
 extern "C" int cmgpu_download_sam(cmgpu_ctx *c, cmgpu_sam_record *records, uint32_t *cigar_pool, char *md_pool) {
   if (!c || !records || !cigar_pool || !md_pool) return CMGPU_EINVAL;
   if (!c->p.sam) { cm_set_error(c, "the ctx was not created with output_format = CMGPU_FORMAT_SAM"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint64_t ns = c->sam_slots;
   if (ns == 0) return CMGPU_OK;
   HIPCHECK(c, hipMemcpy(records, c->sam_rec.p, ns * 40, hipMemcpyDeviceToHost));
@@ -653,7 +655,7 @@ extern "C" int cmgpu_download_sam(cmgpu_ctx *c, cmgpu_sam_record *records, uint3
 extern "C" int cmgpu_download_barcode_keys(cmgpu_ctx *c, uint64_t *keys) {
   if (!c || !keys) return CMGPU_EINVAL;
   if (!c->has_barcodes) { cm_set_error(c, "the last batch had no barcodes"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   if (c->n_pairs) HIPCHECK(c, hipMemcpy(keys, c->bc_key.p, (size_t)c->n_pairs * 8, hipMemcpyDeviceToHost));
   return CMGPU_OK;
 }
@@ -673,7 +675,7 @@ extern "C" int cmgpu_last_timings(const cmgpu_ctx *c, const char **names, float 
 
 extern "C" int cmgpu_download_batch(cmgpu_ctx *c, char *r1, uint32_t *o1, char *r2, uint32_t *o2) {
   if (!c) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint32_t n = c->n_pairs;
   if (r1) HIPCHECK(c, hipMemcpy(r1, c->rb0.p, c->bases0, hipMemcpyDeviceToHost));
   if (r2) HIPCHECK(c, hipMemcpy(r2, c->rb1.p, c->bases1, hipMemcpyDeviceToHost));
@@ -688,7 +690,7 @@ extern "C" int cmgpu_download_batch(cmgpu_ctx *c, char *r1, uint32_t *o1, char *
 extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, int repeat, double *avg_ms,
                                  uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences) {
   if (!c || n == 0 || n > 0xffffff00ull || repeat < 1) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   if (hashes) {
     if (c->mm_hash.ensure(n * 8)) { cm_set_error(c, "out of device memory (probe hashes)"); return CMGPU_ENOMEM; }
     HIPCHECK(c, hipMemcpy(c->mm_hash.p, hashes, n * 8, hipMemcpyHostToDevice));
@@ -706,7 +708,7 @@ extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t 
                     (uint8_t *)c->pr_kind.p, (uint32_t)n, c->partials.p, ctr + CM_ST_PROBE_STEPS, s);
   unsigned long long h[CM_ST_N];
   HIPCHECK(c, hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   HIPCHECK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < repeat; ++i)
     cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
@@ -731,7 +733,7 @@ extern "C" int cmgpu_reference_lengths(cmgpu_ctx *c, uint32_t *lengths, uint32_t
 
 extern "C" int cmgpu_export_reference(cmgpu_ctx *c, uint32_t seq, char *out, uint32_t capacity) {
   if (!c || seq >= c->n_seq || !out || capacity < c->h_ref_len[seq]) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   HIPCHECK(c, hipMemcpy(out, (const uint8_t *)c->ref.p + c->h_ref_off[seq], c->h_ref_len[seq], hipMemcpyDeviceToHost));
   return CMGPU_OK;
 }
@@ -755,7 +757,7 @@ extern "C" int cmgpu_index_info(cmgpu_ctx *c, int32_t *kmer_size, int32_t *windo
 // empty bucket); occurrences_out: n_occurrences uint64
 extern "C" int cmgpu_export_index(cmgpu_ctx *c, uint64_t *buckets_out, uint64_t *occurrences_out) {
   if (!c || !buckets_out) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   HIPCHECK(c, hipMemcpy(buckets_out, c->bkt.p, ((size_t)c->bmask + 1) * 16, hipMemcpyDeviceToHost));
   if (occurrences_out && c->n_occ) HIPCHECK(c, hipMemcpy(occurrences_out, c->occ.p, (size_t)c->n_occ * 8, hipMemcpyDeviceToHost));
   return CMGPU_OK;
@@ -782,7 +784,7 @@ __global__ void k_rec_compact(const uint8_t *__restrict__ rec, const uint8_t *__
 
 extern "C" int cmgpu_records_to_device(cmgpu_ctx *c, void *device_dst, uint64_t capacity, uint64_t *n_out) {
   if (!c || !device_dst || !n_out) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint32_t n = c->n_pairs;
   *n_out = 0;
   if (n == 0) return CMGPU_OK;
@@ -793,7 +795,7 @@ extern "C" int cmgpu_records_to_device(cmgpu_ctx *c, void *device_dst, uint64_t 
                      (const uint8_t *)c->rec_ok.p, (const uint32_t *)pos, (uint8_t *)device_dst, n, capacity);
   uint32_t k = 0;
   HIPCHECK(c, hipMemcpyAsync(&k, pos + n, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHECK(c, hipStreamSynchronize(c->stream));
+  HIPCHECK(c, cm_stream_sync(c->stream));
   *n_out = k;
   if (k > capacity) { cm_set_error(c, "device record buffer too small"); return CMGPU_ECAPACITY; }
   return CMGPU_OK;
@@ -823,12 +825,12 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t *__restrict__ bkt
 
 extern "C" int cmgpu_gather_bench(cmgpu_ctx *c, uint64_t n, int repeat, double *avg_ms) {
   if (!c || n == 0 || repeat < 1 || !avg_ms) return CMGPU_EINVAL;
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   hipStream_t s = c->stream;
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
   hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, s, (const uint64_t *)c->bkt.p, c->bmask, n, 1ull,
                      (unsigned long long *)c->stats.p + CM_ST_N - 1);
-  HIPCHECK(c, hipStreamSynchronize(s));
+  HIPCHECK(c, cm_stream_sync(s));
   HIPCHECK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < repeat; ++i)
     hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, s, (const uint64_t *)c->bkt.p, c->bmask, n, (uint64_t)(i + 2) * 7919ull,
@@ -846,7 +848,7 @@ extern "C" int cmgpu_gather_bench(cmgpu_ctx *c, uint64_t n, int repeat, double *
 // ---------------------------------------------------------------------------------------
 extern "C" int cmgpu_set_whitelist(cmgpu_ctx *c, const uint64_t *keys, uint32_t n_keys, uint32_t barcode_length) {
   if (!c || !keys || n_keys == 0 || barcode_length == 0 || barcode_length > 32) { cm_set_error(c, "bad whitelist"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   uint32_t nb = 16;
   while (nb < 2ull * n_keys + 16) nb <<= 1;
   std::vector<uint64_t> tab((size_t)nb * 2);
@@ -884,7 +886,7 @@ static int bc_abundance_run(cmgpu_ctx *c, const uint8_t *dbases, const uint32_t 
     const uint32_t bn = n - b0 < batch ? n - b0 : batch;
     cm_launch_k_bc_abundance(dbases, doffs, b0, b0 + bn, (uint64_t *)c->wl.p, c->wl_mask, (unsigned long long *)c->wl_num.p, c->stream);
     hipError_t e = hipMemcpyAsync(&ns, c->wl_num.p, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = cm_stream_sync(c->stream);
     if (e != hipSuccess) { cm_set_error(c, std::string("barcode abundance: ") + hipGetErrorString(e)); rc = CMGPU_EHIP; break; }
     if (!c->skip_barcode_check && ns * 20 < bn) {  // chromap.cc:523-533
       cm_set_error(c, "Less than 5% barcodes can be found or corrected based on the barcode whitelist.");
@@ -906,7 +908,7 @@ extern "C" int cmgpu_set_barcode_check(cmgpu_ctx *c, int enabled) {
 extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, const uint32_t *offsets, uint32_t n,
                                                uint64_t *num_sample_barcodes) {
   if (!c || !bases || !offsets || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   DevBuf db, dofs;
   const size_t nbytes = n ? offsets[n] : 0;
   if (db.ensure(nbytes + 16) || dofs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
@@ -922,7 +924,7 @@ extern "C" int cmgpu_compute_barcode_abundance(cmgpu_ctx *c, const char *bases, 
 // same over the barcodes last taken from FASTQ stream 2 (cmgpu_fastq_take); call per chunk until *done
 extern "C" int cmgpu_barcode_abundance_resident(cmgpu_ctx *c, uint64_t *num_sample_barcodes, int *done) {
   if (!c || !done || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   bool d = false;
   const int rc = bc_abundance_run(c, (const uint8_t *)c->bcb.p, (const uint32_t *)c->bco.p, c->fq[2].taken, &d);
   *done = d ? 1 : 0;
@@ -989,7 +991,7 @@ static int map_single_impl(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmg
   if (!c || !in || !n_out) return CMGPU_EINVAL;
   if (bc && c->wl_size != 0 && c->wl_num_sample == 0) { cm_set_error(c, "barcode abundance not computed (cmgpu_compute_barcode_abundance)"); return CMGPU_EINVAL; }
   if (c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
-  HIPCHECK(c, hipSetDevice(c->device));
+  HIPCHECK(c, cm_enter(c));
   const uint32_t n = in->n_reads;
   c->n_pairs = n;
   c->has_barcodes = false;
@@ -1017,7 +1019,7 @@ static int map_single_impl(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmg
     HIPCHECK(c, hipMemcpyAsync(c->bco.p, bc->offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
     c->has_barcodes = true;
   }
-  HIPCHECK(c, hipStreamSynchronize(c->stream));
+  HIPCHECK(c, cm_stream_sync(c->stream));
   uint64_t k = 0;
   int rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;

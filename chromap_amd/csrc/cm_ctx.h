@@ -114,6 +114,19 @@ struct cmgpu_ctx {
 };
 
 void cm_set_error(cmgpu_ctx *ctx, const std::string &msg);
+
+// Kernel launches report a bad configuration (LDS size, grid) only through hipGetLastError; every
+// synchronisation point of the library therefore checks it too, and every entry point starts from a
+// clean slate so that only this call's own launches are seen.
+static inline hipError_t cm_enter(const cmgpu_ctx *c) {
+  (void)hipGetLastError();
+  return hipSetDevice(c->device);
+}
+static inline hipError_t cm_stream_sync(hipStream_t s) {
+  const hipError_t e = hipStreamSynchronize(s);
+  const hipError_t l = hipGetLastError();
+  return e != hipSuccess ? e : l;
+}
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id);
 void cm_fill_dev(cmgpu_ctx *c, CmDev &d);
 int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref);

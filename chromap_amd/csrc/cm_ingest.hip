@@ -152,7 +152,7 @@ struct FqMaxOp {
 extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records) {
   if (!c || stream < 0 || stream > 2 || (!text && n_bytes) || !n_records) return CMGPU_EINVAL;
   if (n_bytes > 0xfffffff0ull) { cm_set_error(c, "FASTQ chunk must be smaller than 4 GiB"); return CMGPU_EINVAL; }
-  FQCHECK(c, hipSetDevice(c->device));
+  FQCHECK(c, cm_enter(c));
   CmFqStream &f = c->fq[stream];
   hipStream_t s = c->stream;
   *n_records = 0;
@@ -167,7 +167,7 @@ extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint
   cm_scan_u32((const uint32_t *)f.cnt.p, (uint32_t *)f.off.p, n_thr, (uint32_t *)c->scan_tmp.p, s);
   uint32_t n_nl = 0;
   FQCHECK(c, hipMemcpyAsync(&n_nl, (uint32_t *)f.off.p + n_thr, 4, hipMemcpyDeviceToHost, s));
-  FQCHECK(c, hipStreamSynchronize(s));
+  FQCHECK(c, cm_stream_sync(s));
   if (f.nl.ensure(((size_t)n_nl + 2) * 4)) { cm_set_error(c, "out of device memory (FASTQ lines)"); return CMGPU_ENOMEM; }
   hipLaunchKernelGGL(k_fq_fill, g, b, 0, s, (const uint8_t *)f.text.p, n_bytes, n_thr, (const uint32_t *)f.off.p, (uint32_t *)f.nl.p);
   // a final chunk whose last line has no terminator: the end of the text closes it
@@ -193,7 +193,7 @@ extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint
   uint32_t bad = 0, n_rec = 0;
   FQCHECK(c, hipMemcpyAsync(&bad, f.bad.p, 4, hipMemcpyDeviceToHost, s));
   FQCHECK(c, hipMemcpyAsync(&n_rec, (uint32_t *)f.pos.p + n_raw, 4, hipMemcpyDeviceToHost, s));
-  FQCHECK(c, hipStreamSynchronize(s));
+  FQCHECK(c, cm_stream_sync(s));
   if (bad != none) {
     cm_set_error(c, "not a 4-line FASTQ record (missing '@' / '+' marker or quality length) at record " + std::to_string(bad) + " of the chunk");
     f.n_raw = 0;
@@ -206,7 +206,7 @@ extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint
 
 extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *bytes_consumed) {
   if (!c || stream < 0 || stream > 2 || !bytes_consumed) return CMGPU_EINVAL;
-  FQCHECK(c, hipSetDevice(c->device));
+  FQCHECK(c, cm_enter(c));
   CmFqStream &f = c->fq[stream];
   hipStream_t s = c->stream;
   if (n > f.n_rec) { cm_set_error(c, "more records requested than the chunk holds"); return CMGPU_EINVAL; }
@@ -252,13 +252,13 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   uint32_t total = 0, mx = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint32_t *)offs.p + n, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(&mx, f.bad.p, 4, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = cm_stream_sync(s);
   rtmp.release();
   if (e != hipSuccess) { cm_set_error(c, std::string("FASTQ take: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
   if (bases.ensure((size_t)total + 16) || (stream == 2 && c->bcq.ensure((size_t)total + 16))) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
   hipLaunchKernelGGL(k_fq_gather, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p,
                      (const uint32_t *)offs.p, n, fmt, (uint8_t *)bases.p, stream == 2 ? (uint8_t *)c->bcq.p : (uint8_t *)nullptr);
-  FQCHECK(c, hipStreamSynchronize(s));
+  FQCHECK(c, cm_stream_sync(s));
   f.taken_bases = total;
   f.taken_max_len = mx;
   return CMGPU_OK;
@@ -268,7 +268,7 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
 // for host SoA buffers); cmgpu_map_resident maps it
 extern "C" int cmgpu_fastq_commit(cmgpu_ctx *c, uint32_t n, uint32_t first_read_id, int paired, int barcoded) {
   if (!c) return CMGPU_EINVAL;
-  FQCHECK(c, hipSetDevice(c->device));
+  FQCHECK(c, cm_enter(c));
   if (c->fq[0].taken != n || (paired && c->fq[1].taken != n) || (barcoded && c->fq[2].taken != n)) {
     cm_set_error(c, "streams hold different numbers of taken records"); return CMGPU_EINVAL;
   }

@@ -377,7 +377,7 @@ extern "C" int cmgpu_store_clear(cmgpu_ctx *c) {
 
 extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
   if (!c) return CMGPU_EINVAL;
-  PPCHECK(c, hipSetDevice(c->device));
+  PPCHECK(c, cm_enter(c));
   if (c->p.split) { cm_set_error(c, "pairs records are post-processed on the host (cmgpu_write_pairs)"); return CMGPU_EINVAL; }
   const uint32_t n = c->n_pairs;
   if (c->store_n && c->store_has_bc != c->has_barcodes) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
@@ -393,7 +393,7 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
                        c->has_barcodes ? (uint64_t *)c->store_bc.p + c->store_n : (uint64_t *)nullptr, n);
     uint32_t k = 0;
     PPCHECK(c, hipMemcpyAsync(&k, pos + n, 4, hipMemcpyDeviceToHost, c->stream));
-    PPCHECK(c, hipStreamSynchronize(c->stream));
+    PPCHECK(c, cm_stream_sync(c->stream));
     c->store_n += k;
   }
   if (n_total) *n_total = c->store_n;
@@ -402,7 +402,7 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
 
 extern "C" int cmgpu_store_append(cmgpu_ctx *c, const void *records, uint64_t n, int on_device, int barcoded) {
   if (!c || (!records && n)) return CMGPU_EINVAL;
-  PPCHECK(c, hipSetDevice(c->device));
+  PPCHECK(c, cm_enter(c));
   if (c->store_n && c->store_has_bc != (barcoded != 0)) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (n == 0) return CMGPU_OK;
   int rc = store_reserve(c, c->store_n + n, barcoded != 0);
@@ -420,7 +420,7 @@ extern "C" int cmgpu_store_append(cmgpu_ctx *c, const void *records, uint64_t n,
     }
     hipLaunchKernelGGL(k_pp_split_bc, dim3((unsigned)((n + PP_BLOCK - 1) / PP_BLOCK)), dim3(PP_BLOCK), 0, c->stream, (const uint8_t *)src,
                        (uint32_t)n, (uint8_t *)c->store.p + c->store_n * 24, (uint64_t *)c->store_bc.p + c->store_n);
-    PPCHECK(c, hipStreamSynchronize(c->stream));
+    PPCHECK(c, cm_stream_sync(c->stream));
     tmp.release();
   }
   c->store_n += n;
@@ -448,7 +448,7 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   if (kind < CMGPU_TEXT_BED_PE || kind > CMGPU_TEXT_TAGALIGN_SE_BC) { cm_set_error(c, "unknown text kind"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
-  PPCHECK(c, hipSetDevice(c->device));
+  PPCHECK(c, cm_enter(c));
   hipStream_t s = c->stream;
   *n_lines = 0;
   *n_bytes = 0;
@@ -503,7 +503,7 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
     if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, rid_bits - 16))) return fail(rc);
     std::swap(va, vb);
   }
-  PPCHECK(c, hipStreamSynchronize(s));
+  PPCHECK(c, cm_stream_sync(s));
   tmp.release(); k0.release(); k1.release();
   (va == (uint32_t *)v0.p ? v1 : v0).release();
   // ---- select
@@ -524,14 +524,14 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   uint64_t total = 0, lines = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint64_t *)loff.p + n, 8, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(&lines, d_count.p, 8, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = cm_stream_sync(s);
   d_count.release();
   if (e != hipSuccess) { cm_set_error(c, std::string("post-processing scan: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
   if (c->text.ensure(total + 64)) { cm_set_error(c, "out of device memory (text)"); return fail(CMGPU_ENOMEM); }
   // ---- format
   hipLaunchKernelGGL(k_pp_format, g, b, 0, s, store, bc, (const uint32_t *)win.p, (const uint32_t *)dups.p, (const uint64_t *)llen.p,
                      (const uint64_t *)loff.p, n, cfg, (const uint8_t *)d_names.p, (const uint32_t *)d_noff.p, (uint8_t *)c->text.p);
-  e = hipStreamSynchronize(s);
+  e = cm_stream_sync(s);
   if (e != hipSuccess) { cm_set_error(c, std::string("text formatting: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
   c->text_bytes = total;
   c->text_lines = lines;
@@ -543,14 +543,14 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
 extern "C" int cmgpu_store_text(cmgpu_ctx *c, char *out, uint64_t capacity) {
   if (!c || (!out && c->text_bytes)) return CMGPU_EINVAL;
   if (capacity < c->text_bytes) { cm_set_error(c, "text buffer too small"); return CMGPU_ECAPACITY; }
-  PPCHECK(c, hipSetDevice(c->device));
+  PPCHECK(c, cm_enter(c));
   if (c->text_bytes) PPCHECK(c, hipMemcpy(out, c->text.p, c->text_bytes, hipMemcpyDeviceToHost));
   return CMGPU_OK;
 }
 
 extern "C" int cmgpu_store_write_text(cmgpu_ctx *c, const char *path, int append) {
   if (!c || !path) return CMGPU_EINVAL;
-  PPCHECK(c, hipSetDevice(c->device));
+  PPCHECK(c, cm_enter(c));
   FILE *f = fopen(path, append ? "ab" : "wb");
   if (!f) { cm_set_error(c, std::string("cannot open ") + path); return CMGPU_EIO; }
   const size_t slab = 64u << 20;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_owner_scatter(const uint8_t *__
 
 extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *device_dst, uint64_t capacity, uint64_t *counts) {
   if (!c || !device_dst || !counts || world == 0 || world > 64) return CMGPU_EINVAL;
-  PPCHECK(c, hipSetDevice(c->device));
+  PPCHECK(c, cm_enter(c));
   for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
   const uint32_t n = c->n_pairs;
   if (n == 0) return CMGPU_OK;
@@ -633,7 +633,7 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   hipLaunchKernelGGL(k_pp_owner_count, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, d_counts);
   unsigned long long h[64], start[64];
   PPCHECK(c, hipMemcpyAsync(h, d_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
-  PPCHECK(c, hipStreamSynchronize(s));
+  PPCHECK(c, cm_stream_sync(s));
   uint64_t total = 0;
   for (uint32_t r = 0; r < world; ++r) { counts[r] = h[r]; start[r] = total; total += h[r]; }
   if (total > capacity) { cm_set_error(c, "send buffer too small"); return CMGPU_ECAPACITY; }
@@ -641,6 +641,6 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   PPCHECK(c, hipMemcpyAsync(d_cursors, start, (size_t)world * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_pp_owner_scatter, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, d_cursors,
                      (uint8_t *)device_dst);
-  PPCHECK(c, hipStreamSynchronize(s));
+  PPCHECK(c, cm_stream_sync(s));
   return CMGPU_OK;
 }

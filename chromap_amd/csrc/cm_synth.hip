@@ -154,7 +154,7 @@ static int sy_build_index(cmgpu_ctx *c) {
   cm_scan_u32((const uint32_t *)d_cnt.p, (uint32_t *)d_off.p, nch, (uint32_t *)d_tmp.p, s);
   uint32_t n_mm = 0;
   SYCHECK(c, hipMemcpyAsync(&n_mm, (uint32_t *)d_off.p + nch, 4, hipMemcpyDeviceToHost, s));
-  SYCHECK(c, hipStreamSynchronize(s));
+  SYCHECK(c, cm_stream_sync(s));
   if (n_mm == 0) { cm_set_error(c, "reference has no minimizers"); return CMGPU_EINVAL; }
   if (n_mm > 0x7fffffffu) { cm_set_error(c, "more than INT_MAX minimizers (index.cc:33)"); return CMGPU_ECAPACITY; }
   DevBuf h0, t0, h1, t1;
@@ -178,7 +178,7 @@ static int sy_build_index(cmgpu_ctx *c) {
   if (sort_tmp.ensure(tb2 + 256)) { cm_set_error(c, "out of device memory (sort)"); return CMGPU_ENOMEM; }
   SYCHECK(c, rocprim::radix_sort_pairs(sort_tmp.p, tb2, (uint64_t *)h1.p, (uint64_t *)h0.p, (uint64_t *)t1.p, (uint64_t *)t0.p,
                                        (size_t)n_mm, 0, 2 * k, s));
-  SYCHECK(c, hipStreamSynchronize(s));
+  SYCHECK(c, cm_stream_sync(s));
   sort_tmp.release(); h1.release(); t1.release();
   // ---- singleton / multi flags, occurrence offsets, key count
   DevBuf multi, starts, opos, spos, tmp2;
@@ -193,7 +193,7 @@ static int sy_build_index(cmgpu_ctx *c) {
   uint32_t n_occ = 0, n_keys = 0;
   SYCHECK(c, hipMemcpyAsync(&n_occ, (uint32_t *)opos.p + n_mm, 4, hipMemcpyDeviceToHost, s));
   SYCHECK(c, hipMemcpyAsync(&n_keys, (uint32_t *)spos.p + n_mm, 4, hipMemcpyDeviceToHost, s));
-  SYCHECK(c, hipStreamSynchronize(s));
+  SYCHECK(c, cm_stream_sync(s));
   spos.release(); starts.release();
   const uint32_t nb = sy_buckets_for(n_keys);
   if (nb == 0) { cm_set_error(c, "too many distinct minimizers for a 32-bit khash"); return CMGPU_ECAPACITY; }
@@ -208,7 +208,7 @@ static int sy_build_index(cmgpu_ctx *c) {
                      (unsigned long long *)c->stats.p);
   unsigned long long err = 0;
   SYCHECK(c, hipMemcpyAsync(&err, c->stats.p, 8, hipMemcpyDeviceToHost, s));
-  SYCHECK(c, hipStreamSynchronize(s));
+  SYCHECK(c, cm_stream_sync(s));
   if (err) { cm_set_error(c, "hash table overflow during index build"); return CMGPU_ECAPACITY; }
   c->bmask = nb - 1;
   c->n_occ = n_occ;
@@ -226,6 +226,7 @@ extern "C" int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { cm_set_error(nullptr, "no HIP device available (this library has no CPU path)"); return CMGPU_ENODEVICE; }
   if (device_id < 0 || device_id >= n || hipSetDevice(device_id) != hipSuccess) { cm_set_error(nullptr, "bad device"); return CMGPU_EINVAL; }
+  (void)hipGetLastError();
   cmgpu_ctx *c = new cmgpu_ctx();
   int rc = cm_ctx_init_common(c, params, kmer_size, window_size, device_id);
   if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
@@ -262,7 +263,7 @@ extern "C" int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences
     hipLaunchKernelGGL(k_sy_genome, dim3((len + SY_BLOCK - 1) / SY_BLOCK), dim3(SY_BLOCK), 0, c->stream, (uint8_t *)c->ref.p,
                        c->h_ref_off[i], gstart[i], len, seed);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = cm_stream_sync(c->stream);
   if (e != hipSuccess) { cm_set_error(nullptr, std::string("genome generation: ") + hipGetErrorString(e)); cmgpu_destroy(c); return CMGPU_EHIP; }
   rc = sy_build_index(c);
   if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
@@ -281,6 +282,7 @@ extern "C" int cmgpu_create_from_reference(const cmgpu_ref_view *ref, int32_t km
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { cm_set_error(nullptr, "no HIP device available (this library has no CPU path)"); return CMGPU_ENODEVICE; }
   if (device_id < 0 || device_id >= n || hipSetDevice(device_id) != hipSuccess) { cm_set_error(nullptr, "bad device"); return CMGPU_EINVAL; }
+  (void)hipGetLastError();
   cmgpu_ctx *c = new cmgpu_ctx();
   int rc = cm_ctx_init_common(c, params, kmer_size, window_size, device_id);
   if (rc == CMGPU_OK) rc = cm_upload_reference(c, ref);
@@ -374,7 +376,7 @@ extern "C" int cmgpu_generate_resident_batch(cmgpu_ctx *c, uint32_t n_pairs, uin
     cm_set_error(c, "bad argument");
     return CMGPU_EINVAL;
   }
-  SYCHECK(c, hipSetDevice(c->device));
+  SYCHECK(c, cm_enter(c));
   c->n_pairs = n_pairs;
   c->first_read_id = 0;
   c->bases0 = c->bases1 = (size_t)n_pairs * read_length;
@@ -390,6 +392,6 @@ extern "C" int cmgpu_generate_resident_batch(cmgpu_ctx *c, uint32_t n_pairs, uin
                      (const uint8_t *)c->ref.p, (const uint64_t *)c->ref_off.p, (const uint32_t *)c->ref_len.p, c->n_seq, total,
                      n_pairs, read_length, frag_min, frag_max, thr, seed, (uint8_t *)c->rb0.p, (uint8_t *)c->rb1.p,
                      (uint32_t *)c->ro0.p, (uint32_t *)c->ro1.p);
-  SYCHECK(c, hipStreamSynchronize(c->stream));
+  SYCHECK(c, cm_stream_sync(c->stream));
   return CMGPU_OK;
 }
