@@ -2671,6 +2671,19 @@ long ora_read_fastq_qual(const char *path, char **bases, char **quals, uint32_t 
 static long map_one_read(const ora_ctx *c, work_t *wk, uint32_t read_index, uint32_t read_id, const char *s1,
                          uint32_t len1, ora_record *out, ora_stats *st) {
   const ora_params *p = &c->p;
+  if (c->wl) { /* chromap.h:389-401: barcode correction comes first */
+    uint64_t a = 0, b = 0;
+    char *bs = c->bc + c->bco[read_index];
+    const uint32_t bl = c->bco[read_index + 1] - c->bco[read_index];
+    const int ok = ora_correct_barcode(p, c->wl, bs, c->bcq + c->bco[read_index], bl, &a, &b);
+    ora_ctx *mc = (ora_ctx *)c;
+#pragma omp atomic
+    mc->n_in_wl += a;
+#pragma omp atomic
+    mc->n_corr += b;
+    c->bc_key[read_index] = ora_seed_from_sequence(bs, bl, 0, bl);
+    if (!ok && !p->output_mappings_not_in_whitelist) return 0;
+  }
   if (len1 < (uint32_t)p->min_read_length) return 0;
   if (len1 + 1 > wk->cap1) { wk->cap1 = len1 + 64; wk->neg1 = (char *)realloc(wk->neg1, wk->cap1); wk->fw1 = (char *)realloc(wk->fw1, wk->cap1); }
   memcpy(wk->fw1, s1, len1); wk->fw1[len1] = 0;
@@ -2953,4 +2966,145 @@ long ora_map_pairs_bc_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_re
   free(c->bc_key);
   c->wl = NULL; c->bc = NULL; c->bcq = NULL; c->bco = NULL; c->bc_key = NULL;
   return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* single-end reads with cell barcodes: MappingWithBarcode (bed_mapping.h:10-56)               */
+/* ------------------------------------------------------------------------- */
+long ora_map_single_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
+                       char *bc, const char *bc_qual, const uint32_t *bc_off, const ora_whitelist *w, ora_record_bc *out,
+                       ora_stats *stats, uint64_t *num_in_whitelist, uint64_t *num_corrected) {
+  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  c->wl = w; c->bc = bc; c->bcq = bc_qual; c->bco = bc_off;
+  c->bc_key = (uint64_t *)calloc((size_t)n + 1, 8);
+  c->n_in_wl = c->n_corr = 0;
+  const long k = ora_map_single(c, threads, n, first_read_id, r, r_off, tmp, stats);
+  for (long i = 0; i < k; ++i) {
+    out[i].r = tmp[i];
+    out[i].barcode = c->bc_key[tmp[i].read_id - first_read_id];
+  }
+  if (num_in_whitelist) *num_in_whitelist += c->n_in_wl;
+  if (num_corrected) *num_corrected += c->n_corr;
+  free(c->bc_key); free(tmp);
+  c->wl = NULL; c->bc = NULL; c->bcq = NULL; c->bco = NULL; c->bc_key = NULL;
+  return k;
+}
+
+/* operator< (bed_mapping.h:32-38) under the per-chromosome vectors */
+static int cmp_se_bc(const void *a, const void *b) {
+  const ora_record_bc *x = (const ora_record_bc *)a, *y = (const ora_record_bc *)b;
+#define CMPF(f) if (x->f != y->f) return x->f < y->f ? -1 : 1
+  CMPF(r.rid); CMPF(r.fragment_start); CMPF(r.fragment_length); CMPF(barcode); CMPF(r.mapq); CMPF(r.direction);
+  CMPF(r.is_unique); CMPF(r.read_id);
+#undef CMPF
+  return 0;
+}
+static int se_bc_equal(const ora_record_bc *x, const ora_record_bc *y) { /* operator== (:39-42) */
+  return x->barcode == y->barcode && x->r.fragment_start == y->r.fragment_start;
+}
+static int se_bc_same_position(const ora_record_bc *x, const ora_record_bc *y) { /* :43-46 */
+  return x->r.fragment_start == y->r.fragment_start;
+}
+static void se_bc_tn5(ora_record_bc *x) { /* :48-54 */
+  if (x->r.direction == 1) x->r.fragment_start += 4; else x->r.fragment_length = (uint16_t)(x->r.fragment_length - 5);
+}
+static void se_bc_print(FILE *f, const ora_ref *ref, const ora_record_bc *x, uint32_t barcode_length, int tagalign) {
+  if (tagalign) { /* mapping_writer.cc:26-34 */
+    fprintf(f, "%s\t%u\t%u\tN\t%u\t%c\n", ref->name[x->r.rid], x->r.fragment_start, x->r.fragment_start + x->r.fragment_length,
+            (unsigned)x->r.mapq, x->r.direction ? '+' : '-');
+    return;
+  }
+  char bcs[40]; /* mapping_writer.cc:14-25, Seed2Sequence */
+  for (uint32_t b = 0; b < barcode_length; ++b) bcs[b] = u2c((uint8_t)((x->barcode >> ((barcode_length - 1 - b) * 2)) & 3));
+  bcs[barcode_length] = 0;
+  fprintf(f, "%s\t%u\t%u\t%s\t%u\n", ref->name[x->r.rid], x->r.fragment_start, x->r.fragment_start + x->r.fragment_length, bcs,
+          (unsigned)x->r.num_dups);
+}
+/* FindBestMappingIndexFromDuplicates (mapping_writer.h:125-163) */
+static size_t se_bc_best_of(const ora_whitelist *w, const ora_record_bc *d, size_t nd) {
+  size_t best = 0;
+  int found = 0;
+  uint32_t slot = wl_slot(w, d[0].barcode, &found);
+  double best_ab = found ? (double)w->cnt[slot] : 0.0;
+  for (size_t i = 1; i < nd; ++i) {
+    slot = wl_slot(w, d[i].barcode, &found);
+    const double ab = found ? (double)w->cnt[slot] : 0.0;
+    if (d[i].r.num_dups > d[best].r.num_dups || (d[i].r.num_dups == d[best].r.num_dups && ab > best_ab)) { best = i; best_ab = ab; }
+  }
+  return best;
+}
+
+/* BED / TagAlign for MappingWithBarcode.  low_mem: the merge loop of ProcessAndOutputMappingsInLowMemory
+ * (mapping_writer.h:166-376) statement by statement over the globally sorted records (its k-way merge of
+ * sorted temp files yields exactly that order); otherwise Tn5 shift, sort, RemovePCRDuplicate
+ * (chromap.h:594-608, mapping_processor.h:164-202), OutputMappingsInVector (mapping_writer.h:404-437). */
+long ora_write_se_bc(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
+                     const ora_whitelist *w, int tagalign, const char *out_path) {
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return -1;
+  long lines = 0;
+  for (long t = 0; t < n; ++t) rec[t].r.num_dups = 1; /* constructor argument (mapping_generator.cc:27) */
+  if (!p->low_mem) {
+    if (p->tn5_shift) for (long t = 0; t < n; ++t) se_bc_tn5(&rec[t]);
+    qsort(rec, (size_t)n, sizeof(ora_record_bc), cmp_se_bc);
+    long i = 0;
+    while (i < n) {
+      long j = i + 1;
+      if (p->remove_pcr_duplicates)
+        while (j < n && rec[j].r.rid == rec[i].r.rid && se_bc_equal(&rec[j], &rec[j - 1])) ++j;
+      ora_record_bc keep = rec[j - 1]; /* the last of a run of pairwise-equal neighbours */
+      if (p->remove_pcr_duplicates) keep.r.num_dups = (uint8_t)(j - i > 255 ? 255 : j - i);
+      if (keep.r.mapq >= p->mapq_threshold) { se_bc_print(f, ref, &keep, barcode_length, tagalign); ++lines; }
+      i = j;
+    }
+    fclose(f);
+    return lines;
+  }
+  qsort(rec, (size_t)n, sizeof(ora_record_bc), cmp_se_bc);
+  const int bulk = p->remove_pcr_duplicates && p->dedup_at_bulk_level;
+  ora_record_bc *dups = (ora_record_bc *)malloc(((size_t)n + 1) * sizeof(ora_record_bc));
+  size_t nd = 0;
+  uint32_t last_rid = UINT32_MAX, num_last = 0;
+  ora_record_bc last;
+  memset(&last, 0, sizeof(last));
+  for (long t = 0; t < n; ++t) {
+    const ora_record_bc *cur = &rec[t];
+    const uint32_t min_rid = cur->r.rid;
+    const int first = t == 0;
+    const int dup_cell = !first && se_bc_equal(cur, &last);
+    const int dup_bulk = !first && bulk && se_bc_same_position(cur, &last);
+    const int dup = last_rid == min_rid && (dup_cell || dup_bulk);
+    if (p->remove_pcr_duplicates && dup) {
+      ++num_last;
+      if (bulk) {
+        if (nd && se_bc_equal(cur, &dups[nd - 1])) { dups[nd - 1] = *cur; dups[nd - 1].r.num_dups += 1; }
+        else { dups[nd] = *cur; dups[nd].r.num_dups = 1; ++nd; }
+      }
+      if (cur->r.mapq > last.r.mapq) last = *cur;
+    } else {
+      if (!first) {
+        if (bulk) { last = dups[se_bc_best_of(w, dups, nd)]; nd = 0; }
+        if (last.r.mapq >= p->mapq_threshold) {
+          last.r.num_dups = (uint8_t)(num_last > 255 ? 255 : num_last);
+          if (p->tn5_shift) se_bc_tn5(&last);
+          se_bc_print(f, ref, &last, barcode_length, tagalign);
+          ++lines;
+        }
+      }
+      last = *cur;
+      last_rid = min_rid;
+      num_last = 1;
+      if (bulk) { dups[nd] = *cur; dups[nd].r.num_dups = 1; ++nd; }
+    }
+  }
+  if (n > 0 && last.r.mapq >= p->mapq_threshold) {
+    if (bulk) { last = dups[se_bc_best_of(w, dups, nd)]; nd = 0; }
+    last.r.num_dups = (uint8_t)(num_last > 255 ? 255 : num_last);
+    if (p->tn5_shift) se_bc_tn5(&last);
+    se_bc_print(f, ref, &last, barcode_length, tagalign);
+    ++lines;
+  }
+  free(dups);
+  fclose(f);
+  return lines;
 }

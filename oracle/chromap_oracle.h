@@ -170,6 +170,14 @@ long ora_map_pairs_bc_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_re
                           const char *r2, const uint32_t *r2_off, char *bc, const char *bc_qual, const uint32_t *bc_off,
                           const ora_whitelist *w, ora_sam_record *out, uint32_t *cigar_pool, char *md_pool, uint32_t md_cap,
                           uint64_t *keys_per_pair, ora_stats *stats);
+/* single-end reads with cell barcodes (MappingWithBarcode, bed_mapping.h:10-56; chromap.h:385-472) */
+long ora_map_single_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
+                       char *bc, const char *bc_qual, const uint32_t *bc_off, const ora_whitelist *w, ora_record_bc *out,
+                       ora_stats *stats, uint64_t *num_in_whitelist, uint64_t *num_corrected);
+/* BED (tagalign = 0) or TagAlign text with the reference's low-memory merge or in-memory duplicate removal,
+ * cell-level or bulk-level (p->dedup_at_bulk_level) */
+long ora_write_se_bc(const ora_ref *ref, const ora_params *p, ora_record_bc *rec, long n, uint32_t barcode_length,
+                     const ora_whitelist *w, int tagalign, const char *out_path);
 int ora_ksw_semi_global3(int qlen, const char *query, int tlen, const char *target, int w, uint32_t *cigar, int cigar_cap,
                          int *n_cigar, int *start, int *end);
 

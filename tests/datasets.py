@@ -89,6 +89,10 @@ def chr_order_ranks(order, names):
     return ranks
 
 
+def is_tagalign(name):
+    return "--TagAlign" in case_meta(name)["chromap_flags"]
+
+
 def is_hic(name):
     return "hic" in case_meta(name)["chromap_flags"]
 
@@ -117,6 +121,8 @@ def flags_to_params(flags):
         elif flags[i] == "--SAM":
             kw["output_format"] = 1
             i += 1
+        elif flags[i] == "--TagAlign":  # text format only (is_tagalign)
+            i += 1
         elif flags[i] == "-l":
             kw["max_insert_size"] = int(flags[i + 1])
             i += 2
@@ -136,8 +142,9 @@ ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
 SAM_CASES = [c for c in ALL_CASES if is_sam(c) and not has_barcodes(c)]
 SAM_BC_CASES = [c for c in ALL_CASES if is_sam(c) and has_barcodes(c)]
 BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c) and not single_end_mate(c) and not is_sam(c)]
-SE_CASES = [c for c in ALL_CASES if single_end_mate(c) and not is_sam(c)]
-BC_CASES = [c for c in ALL_CASES if has_barcodes(c) and not is_sam(c)]
+SE_CASES = [c for c in ALL_CASES if single_end_mate(c) and not is_sam(c) and not has_barcodes(c)]
+BC_CASES = [c for c in ALL_CASES if has_barcodes(c) and not is_sam(c) and not single_end_mate(c)]
+SE_BC_CASES = [c for c in ALL_CASES if has_barcodes(c) and not is_sam(c) and single_end_mate(c)]
 HIC_CASES = [c for c in ALL_CASES if is_hic(c)]
 
 

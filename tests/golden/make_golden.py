@@ -24,7 +24,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "chromap")
 GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 
 # single-end cases: which mate file is mapped alone
-SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1}
+SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1,
+              "b1_se_bc": 1, "b3_se_bc_bulk_q0": 1, "b3_se_bc_inmem_q0": 2, "b1_se_bc_tagalign_q0": 1}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -78,6 +79,16 @@ CASES = {
                    "--barcodes", "500", "--seed", "31"], ["--preset", "atac", "--SAM"]),
     "b3_bc_sam_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "30000", "--readlen", "50", "--frag-min", "40",
                       "--barcodes", "40", "--seed", "33", "--dup-frac", "0.3"], ["--preset", "atac", "--SAM", "-q", "0"]),
+    # single-end reads with cell barcodes (MappingWithBarcode): cell-level and bulk-level low-memory merge, in-memory, TagAlign
+    "b1_se_bc": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
+                  "--barcodes", "500", "--seed", "31"], ["--preset", "atac"]),
+    "b3_se_bc_bulk_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "30000", "--readlen", "50", "--frag-min", "40",
+                          "--barcodes", "40", "--seed", "33", "--dup-frac", "0.3"],
+                         ["--preset", "atac", "--remove-pcr-duplicates-at-bulk-level", "-q", "0"]),
+    "b3_se_bc_inmem_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "30000", "--readlen", "50", "--frag-min", "40",
+                           "--barcodes", "40", "--seed", "33", "--dup-frac", "0.3"], ["--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"]),
+    "b1_se_bc_tagalign_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
+                              "--barcodes", "500", "--seed", "31"], ["--TagAlign", "--remove-pcr-duplicates", "-q", "0"]),
     # --chr-order: reference reordered, candidate rids re-ranked before verification (flag value: comma list,
     # written to a file for the reference; unlisted chromosomes follow in reference order)
     "s3_chip_chrorder": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",

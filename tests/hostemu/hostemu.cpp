@@ -265,6 +265,20 @@ extern "C" int hostemu_map_pairs_bc(const cmgpu_index_view *index, const cmgpu_r
   return rc;
 }
 
+// single-end reads with cell barcodes (cmgpu_map_single_barcoded's stage sequence)
+extern "C" int hostemu_map_single_bc(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const cmgpu_params *params,
+                                     const cmgpu_single_batch *in, const cmgpu_barcode_batch *bc, const uint64_t *wl_keys,
+                                     uint32_t n_keys, cmgpu_record_bc *out, uint64_t *n_out, cmgpu_stats *stats) {
+  std::vector<uint32_t> zero((size_t)in->n_reads + 1, 0);
+  cmgpu_batch b{in->n_reads, in->first_read_id, in->bases, in->offsets, "", zero.data()};
+  std::vector<cmgpu_record> rec(in->n_reads + 1);
+  std::vector<uint64_t> keys(in->n_reads + 1);
+  EmuBarcodes eb{bc, wl_keys, n_keys, keys.data(), nullptr};
+  const int rc = emu_map_pairs(index, ref, params, &b, rec.data(), n_out, stats, nullptr, nullptr, nullptr, nullptr, &eb, true);
+  for (uint64_t i = 0; i < *n_out; ++i) { out[i].r = rec[i]; out[i].barcode = keys[i]; }
+  return rc;
+}
+
 // chunked reference-minimizer collection (cm_ref_chunk_minimizers) concatenated in chunk
 // order; compared by tests with the oracle's sequential pass
 extern "C" long hostemu_ref_minimizers(const cmgpu_ref_view *ref, int k, int w, uint32_t chunk, uint32_t warm,

@@ -134,6 +134,24 @@ class HostEmu:
         assert rc == 0, rc
         return rec, int(k.value), st
 
+    def map_single_bc(self, b, off, bc, bcq, bco, wl_keys):
+        n = len(off) - 1
+        keep = [np.ascontiguousarray(x) for x in (b, off, bc, bcq, bco, wl_keys)]
+        bt = _capi.SingleBatch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data)
+        bb = _capi.BarcodeBatch(keep[2].ctypes.data, keep[3].ctypes.data, keep[4].ctypes.data)
+        rec = (_capi.RecordBc * max(1, n))()
+        k = C.c_uint64(0)
+        st = _capi.Stats()
+        f = self.L.hostemu_map_single_bc
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(_capi.IndexView), C.POINTER(_capi.RefView), C.POINTER(_capi.Params), C.POINTER(_capi.SingleBatch),
+                      C.POINTER(_capi.BarcodeBatch), C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
+                      C.POINTER(_capi.Stats)]
+        rc = f(C.byref(self.idx), C.byref(self.ref), C.byref(self.p), C.byref(bt), C.byref(bb), keep[5].ctypes.data,
+               len(keep[5]), C.cast(rec, C.c_void_p), C.byref(k), C.byref(st))
+        assert rc == 0, rc
+        return rec, int(k.value), st
+
     def write_bed_bc(self, rec, n, barcode_length, path):
         names = (C.c_char_p * len(self.names))(*self.names)
         return self.L.cmgpu_write_bed_pe_bc(names, len(self.names), C.byref(self.p), C.cast(rec, C.c_void_p), n,

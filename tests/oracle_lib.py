@@ -483,3 +483,29 @@ def write_sam_bc(oracle, res, paired, names1, names2, b1, q1, o1, b2, q2, o2, ke
     return L.ora_write_sam_bc(C.byref(oracle.ref), C.byref(oracle.p), C.cast(res.rec, C.c_void_p), res.n_slots, int(paired),
                               res.cigar.ctypes.data, res.md.ctypes.data, res.md_cap, n1, n2, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
                               ptr[5], kk.ctypes.data, barcode_length, path.encode())
+
+
+def map_single_bc(oracle, b, off, bc, bcq, bco, wl, threads=1):
+    """single-end reads with cell barcodes: (records OraRecordBc[], k, stats, n_in_whitelist, n_corrected)"""
+    import numpy as np
+    L = oracle.L
+    L.ora_map_single_bc.restype = C.c_long
+    L.ora_map_single_bc.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5 + \
+                                   [C.c_void_p, C.c_void_p, C.POINTER(OraStats), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    n = len(off) - 1
+    rec = (OraRecordBc * max(1, n))()
+    st = OraStats()
+    a, b2 = C.c_uint64(0), C.c_uint64(0)
+    arrs = [np.ascontiguousarray(x) for x in (b, off, bc, bcq, bco)]
+    k = L.ora_map_single_bc(oracle.ctx, threads, n, 0, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                            arrs[3].ctypes.data, arrs[4].ctypes.data, wl.h, C.cast(rec, C.c_void_p), C.byref(st), C.byref(a), C.byref(b2))
+    return rec, k, st, int(a.value), int(b2.value)
+
+
+def write_se_bc(oracle, rec, k, barcode_length, wl, tagalign, path):
+    L = oracle.L
+    L.ora_write_se_bc.restype = C.c_long
+    L.ora_write_se_bc.argtypes = [C.POINTER(OraRef), C.POINTER(OraParams), C.c_void_p, C.c_long, C.c_uint32, C.c_void_p, C.c_int,
+                                  C.c_char_p]
+    return L.ora_write_se_bc(C.byref(oracle.ref), C.byref(oracle.p), C.cast(rec, C.c_void_p), k, barcode_length, wl.h, int(tagalign),
+                             path.encode())

@@ -152,3 +152,38 @@ def test_sam_with_barcodes_matches_reference(case, tmp_path):
     for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads", "num_barcode_in_whitelist",
                 "num_corrected_barcode"):
         assert s[key] == ref[key], key
+
+
+@pytest.mark.parametrize("case", datasets.SE_BC_CASES)
+def test_single_end_barcode_stage_matches_reference(case, tmp_path):
+    """single-end reads with cell barcodes through the stage functions: records equal the oracle's, and the
+    oracle's writer (the reference's merge loop, pinned by the golden files) renders them to the golden text"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    h = he.HostEmu(idx, fa, he.params(preset, **kw))
+    b, off = ol.read_fastx(r1 if datasets.single_end_mate(case) == 1 else r2)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+    assert wl.abundance(bc, bco) > 0
+    keys, _ = wl.export()
+    rec, k, st = h.map_single_bc(b, off, bc.copy(), bcq, bco, keys)
+    o = ol.Oracle(idx, fa, ol.params(preset, **kw))
+    orec, ok_, _, _, _ = ol.map_single_bc(o, b, off, bc.copy(), bcq, bco, wl)
+
+    def tup(r):
+        return (r.r.read_id, r.r.rid, r.r.fragment_start, r.r.fragment_length, r.r.mapq, r.r.direction, r.r.is_unique, r.barcode)
+    assert k == ok_
+    assert sorted(tup(rec[i]) for i in range(k)) == sorted(tup(orec[i]) for i in range(ok_))
+    out = str(tmp_path / "e.bed")
+    lines = ol.write_se_bc(o, rec, k, wl.barcode_length, wl, datasets.is_tagalign(case), out)
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    assert lines == ref["num_output"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads",
+                "num_barcode_in_whitelist", "num_corrected_barcode"):
+        assert s[key] == ref[key], key
+    o.close()

@@ -23,6 +23,10 @@ def test_oracle_bed_matches_reference(case, tmp_path):
     o = ol.Oracle(None, fa, p)  # index built by the oracle's own indexer
     b1, o1 = ol.read_fastx(r1)
     b2, o2 = ol.read_fastx(r2)
+    if datasets.single_end_mate(case) and datasets.has_barcodes(case):
+        _check_single_end_barcode_case(case, meta, o, (b1, o1) if datasets.single_end_mate(case) == 1 else (b2, o2), tmp_path)
+        o.close()
+        return
     if datasets.single_end_mate(case):
         b, off = (b1, o1) if datasets.single_end_mate(case) == 1 else (b2, o2)
         rec, k, st = ol.map_single(o, b, off, threads=2)
@@ -81,6 +85,31 @@ def _check_barcode_case(case, meta, o, b1, o1, b2, o2, tmp_path):
     got = open(out, "rb").read()
     assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
     ref = meta["reference_stderr_counters"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    assert n_in == ref["num_barcode_in_whitelist"] and n_corr == ref["num_corrected_barcode"]
+
+
+def _check_single_end_barcode_case(case, meta, o, read, tmp_path):
+    """MappingWithBarcode: cell-level / bulk-level low-memory merge, in-memory duplicate removal, TagAlign"""
+    b, off = read
+    bcf, wlf = datasets.case_barcode_inputs(case)
+    bc, bcq, bco = ol.read_fastq_qual(bcf)
+    wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+    assert wl.abundance(bc, bco) > 0
+    rec, k, st, n_in, n_corr = ol.map_single_bc(o, b, off, bc, bcq, bco, wl, threads=2)
+    out = str(tmp_path / "o.bed")
+    lines = ol.write_se_bc(o, rec, k, wl.barcode_length, wl, datasets.is_tagalign(case), out)
+    got = open(out, "rb").read()
+    want = datasets.case_golden_bed(case)
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        for i in range(min(len(g), len(w))):
+            assert g[i] == w[i], (i, g[i], w[i])
+    assert hashlib.md5(got).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    assert lines == ref["num_output"]
     s = st.as_dict()
     for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
         assert s[key] == ref[key], key
