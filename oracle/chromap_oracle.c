@@ -2416,6 +2416,22 @@ static int cmp_rec(const void *a, const void *b) {
   return 0;
 }
 
+/* --TagAlign for paired-end records (mapping_writer.cc:84-117 bulk, :138-168 single-cell): the + read's and the
+ * - read's alignment on two lines, the + one first when read 1 is on the + strand; bulk data prints num_dups
+ * at the end of the second line, single-cell data prints neither barcode nor num_dups */
+static void tagalign_pe_lines(FILE *f, const ora_ref *ref, const ora_record *r, int with_dups) {
+  const uint32_t pe = r->fragment_start + r->pos_aln_len, ne = r->fragment_start + r->fragment_length, ns = ne - r->neg_aln_len;
+  const char *nm = ref->name[r->rid];
+  char tail[16] = "";
+  if (with_dups) snprintf(tail, sizeof(tail), "\t%u", (unsigned)r->num_dups);
+  if (r->direction)
+    fprintf(f, "%s\t%u\t%u\tN\t%u\t+\n%s\t%u\t%u\tN\t%u\t-%s\n", nm, r->fragment_start, pe, (unsigned)r->mapq, nm, ns, ne,
+            (unsigned)r->mapq, tail);
+  else
+    fprintf(f, "%s\t%u\t%u\tN\t%u\t-\n%s\t%u\t%u\tN\t%u\t+%s\n", nm, ns, ne, (unsigned)r->mapq, nm, r->fragment_start, pe,
+            (unsigned)r->mapq, tail);
+}
+
 static void bed_line(FILE *f, const ora_ref *ref, const ora_params *p, ora_record r, uint32_t dups) {
   r.num_dups = (uint8_t)(dups > 255 ? 255 : dups);
   if (p->tn5_shift) { /* bed_mapping.h:224-229 */
@@ -2424,6 +2440,7 @@ static void bed_line(FILE *f, const ora_ref *ref, const ora_params *p, ora_recor
     r.fragment_length -= 9;
     r.neg_aln_len -= 5;
   }
+  if (p->output_format == 2) { tagalign_pe_lines(f, ref, &r, 1); return; }
   fprintf(f, "%s\t%u\t%u\tN\t%u\t%s\t%u\n", ref->name[r.rid], r.fragment_start,
           r.fragment_start + r.fragment_length, (unsigned)r.mapq, r.direction ? "+" : "-", (unsigned)r.num_dups);
 }
@@ -2570,6 +2587,8 @@ long ora_write_bed_pe_bc(const ora_ref *ref, const ora_params *p, ora_record_bc 
       if (p->tn5_shift && !inmem) { r.fragment_start += 4; r.pos_aln_len -= 4; r.fragment_length -= 9; r.neg_aln_len -= 5; }
       for (uint32_t b = 0; b < barcode_length; ++b) bcs[b] = u2c((uint8_t)((last.barcode >> ((barcode_length - 1 - b) * 2)) & 3));
       bcs[barcode_length] = 0;
+      if (p->output_format == 2) tagalign_pe_lines(f, ref, &r, 0);
+      else
       fprintf(f, "%s\t%u\t%u\t%s\t%u\n", ref->name[r.rid], r.fragment_start, r.fragment_start + r.fragment_length, bcs,
               (unsigned)r.num_dups);
       ++lines;

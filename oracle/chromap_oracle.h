@@ -59,7 +59,7 @@ typedef struct ora_params {
   int low_mem;
   int bc_error_threshold;               /* --bc-error-threshold, 1 */
   int output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
-  int output_format;                    /* 0: BED / pairs records, 1: --SAM (ksw alignment, CIGAR, NM, MD) */
+  int output_format;                    /* 0: BED / pairs records, 1: --SAM (ksw alignment, CIGAR, NM, MD), 2: --TagAlign text from the BED writers */
   int dedup_at_bulk_level;              /* single-cell data: --remove-pcr-duplicates-at-bulk-level (ora_write_bed_pe_bc_bulk) */
   double bc_probability_threshold;      /* --bc-probability-threshold, 0.9 */
 } ora_params;

@@ -25,7 +25,8 @@ GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 
 # single-end cases: which mate file is mapped alone
 SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1,
-              "b1_se_bc": 1, "b3_se_bc_bulk_q0": 1, "b3_se_bc_inmem_q0": 2, "b1_se_bc_tagalign_q0": 1}
+              "b1_se_bc": 1, "b3_se_bc_bulk_q0": 1, "b3_se_bc_inmem_q0": 2, "b1_se_bc_tagalign_q0": 1,
+              "s4_se_tagalign_q0": 2}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -89,6 +90,13 @@ CASES = {
                            "--barcodes", "40", "--seed", "33", "--dup-frac", "0.3"], ["--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"]),
     "b1_se_bc_tagalign_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
                               "--barcodes", "500", "--seed", "31"], ["--TagAlign", "--remove-pcr-duplicates", "-q", "0"]),
+    # --TagAlign: paired-end bulk (num_dups on the second line), paired-end single-cell (no barcode, no num_dups), single-end bulk
+    "s2_tagalign_q0": (["--genome", "2000000", "--chroms", "3", "--pairs", "20000", "--readlen", "60", "--frag-min", "35",
+                        "--varlen", "--seed", "7"], ["--preset", "atac", "--TagAlign", "-q", "0"]),
+    "b2_tagalign_bc": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "50", "--frag-min", "35",
+                        "--barcodes", "300", "--seed", "32"], ["--preset", "atac", "--TagAlign"]),
+    "s4_se_tagalign_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                           "--seed", "5"], ["--preset", "chip", "--TagAlign", "-q", "0"]),
     # --chr-order: reference reordered, candidate rids re-ranked before verification (flag value: comma list,
     # written to a file for the reference; unlisted chromosomes follow in reference order)
     "s3_chip_chrorder": (["--genome", "6000000", "--chroms", "5", "--pairs", "30000", "--readlen", "100", "--seed", "99",

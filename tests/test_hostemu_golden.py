@@ -187,3 +187,42 @@ def test_single_end_barcode_stage_matches_reference(case, tmp_path):
                 "num_barcode_in_whitelist", "num_corrected_barcode"):
         assert s[key] == ref[key], key
     o.close()
+
+
+@pytest.mark.parametrize("case", datasets.TAGALIGN_CASES)
+def test_tagalign_records_render_to_reference_text(case, tmp_path):
+    """--TagAlign: records from the stage functions, text by the oracle's writer (pinned by the same golden files)"""
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    idx = datasets.case_index(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    h = he.HostEmu(idx, fa, he.params(preset, **kw))
+    o = ol.Oracle(idx, fa, ol.params(preset, **kw))
+    o.p.output_format = 2
+    out = str(tmp_path / "e.tagalign")
+    mate = datasets.single_end_mate(case)
+    if mate:
+        b, off = ol.read_fastx(r1 if mate == 1 else r2)
+        rec, k, st = h.map_single(b, off)
+        lines = ol.write_bed_se(o, rec, k, out)
+    elif datasets.has_barcodes(case):
+        bcf, wlf = datasets.case_barcode_inputs(case)
+        b1, o1 = ol.read_fastx(r1)
+        b2, o2 = ol.read_fastx(r2)
+        bc, bcq, bco = ol.read_fastq_qual(bcf)
+        wl = ol.Whitelist(wlf, int(bco[1] - bco[0]))
+        keys, _ = wl.export()
+        rec, k, st = h.map_pairs_bc(b1, o1, b2, o2, bc, bcq, bco, keys)
+        lines = ol.write_bed_bc(o, rec, k, wl.barcode_length, out)
+    else:
+        b1, o1 = ol.read_fastx(r1)
+        b2, o2 = ol.read_fastx(r2)
+        rec, k, st, _ = h.map_pairs(b1, o1, b2, o2)
+        lines = o.write_bed(rec, k, out)
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["bed_md5"]
+    ref = meta["reference_stderr_counters"]
+    assert lines == ref["num_output"]
+    s = st.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == ref[key], key
+    o.close()
