@@ -222,6 +222,21 @@ class ChromapGPU:
                     self.ctx)
         return rec, int(k.value)
 
+    def map_single_barcoded(self, b, off, bc, bcq, bco, first_read_id=0):
+        """single-end reads with cell barcodes (MappingWithBarcode); records also stay resident for the store"""
+        self._keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
+        n = len(self._keep[1]) - 1
+        bt = SingleBatch(n, first_read_id, self._keep[0].ctypes.data, self._keep[1].ctypes.data)
+        kb = [np.ascontiguousarray(bc, dtype=np.uint8), np.ascontiguousarray(bcq, dtype=np.uint8),
+              np.ascontiguousarray(bco, dtype=np.uint32)]
+        bb = BarcodeBatch(kb[0].ctypes.data, kb[1].ctypes.data, kb[2].ctypes.data)
+        rec = (RecordBc * max(1, n))()
+        k = C.c_uint64(0)
+        rc = self.L.cmgpu_map_single_barcoded(self.ctx, C.byref(bt), C.byref(bb), C.cast(rec, C.c_void_p), n, C.byref(k),
+                                              C.byref(self.stats))
+        self._check(rc, self.ctx)
+        return rec, int(k.value)
+
     def write_bed_se(self, rec, n, path, params=None):
         p = params if params is not None else self.params
         names = (C.c_char_p * len(self.names))(*self.names)
