@@ -1,0 +1,49 @@
+"""chromap-amd on a box without a GPU: argument handling works, and a mapping run refuses to start -- there is
+no CPU path behind the CLI either."""
+import os
+import subprocess
+
+import pytest
+
+import datasets
+
+CLI = os.path.join(datasets.ROOT, "chromap_amd", "chromap-amd")
+pytestmark = pytest.mark.skipif(not os.path.exists(CLI), reason="chromap-amd not built (python -c 'import __graft_entry__ as g; g.build()')")
+
+
+def _run(*args):
+    return subprocess.run([CLI] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def test_version_and_help():
+    r = _run("-v")
+    assert r.returncode == 0 and b"chromap-amd" in r.stdout
+    r = _run("-h")
+    assert r.returncode == 0 and b"Usage" in r.stdout
+
+
+def test_unknown_option_and_mismatched_inputs_are_errors():
+    r = _run("--PAF")
+    assert r.returncode != 0 and b"unsupported option" in r.stderr
+    fa, _, _ = datasets.case_inputs("toy_atac")
+    idx = datasets.case_index("toy_atac")
+    r = _run("-x", idx, "-r", fa, "-1", "a.fq,b.fq", "-2", "c.fq", "-o", "o")
+    assert r.returncode != 0 and b"don't match" in r.stderr, r.stderr
+    r = _run("-x", idx, "-r", fa, "-1", "a.fq,b.fq", "-2", "c.fq,d.fq", "-b", "e.fq", "-o", "o")
+    assert r.returncode != 0 and b"don't match" in r.stderr, r.stderr
+
+
+def test_mapping_refuses_to_run_without_a_gpu(tmp_path):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    case = "toy_atac"
+    fa, r1, r2 = datasets.case_inputs(case)
+    out = str(tmp_path / "o.bed")
+    r = _run("--preset", "atac", "-x", datasets.case_index(case), "-r", fa, "-1", r1, "-2", r2, "-o", out)
+    assert r.returncode != 0
+    assert not os.path.exists(out) or os.path.getsize(out) == 0
+    assert b"HIP" in r.stderr or b"device" in r.stderr or b"GPU" in r.stderr, r.stderr[-500:]
