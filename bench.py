@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- M read pairs mapped per second through the hot path (K0-K5) on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic read pairs that is
-already resident in HBM (inputs are generated on the device; the PCIe-inclusive rate is
-noted in DESIGN.md).  Workload (BASELINE.json metric / configs[2], per-GPU weak scaling):
---preset atac, synthetic 2x50 bp pairs, GRCh38-sized synthetic index (3.1e9 random bases in
-24 sequences, k=17, w=7) replicated on every GPU; at N>1 every rank maps its own batch and
-the records are all-gathered over RCCL inside the step (the exchange the final global
-sort/dedup needs).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one batch of synthetic read pairs that is already
+resident in HBM (inputs are generated on the device; the PCIe-inclusive rate of the host-buffer
+boundary is reported beside it, never as `value`).  Workload (BASELINE.json metric / configs[2],
+per-GPU weak scaling): --preset atac, synthetic 2x50 bp pairs, GRCh38-sized synthetic index
+(3.1e9 random bases in 24 sequences, k=17, w=7) replicated on every GPU.  Four distinct batches per
+rank stay resident and take turns.  At N>1 every rank maps its own batches and, inside the step,
+the records go to the ranks that own their chromosomes (device partition -> RCCL all-to-all issued
+by the library on its mapping stream -> the owner's device-side record store): the exchange the
+final sort / duplicate removal needs.
+
+`python bench.py --gpus N` starts its N ranks itself when it was not launched under
+torch.distributed.run (WORLD_SIZE unset); under the launcher it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*.  torch.distributed (gloo) carries the control plane only: the rendezvous of
+the RCCL unique id, the barriers around the timed region and the max over ranks.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,42 +31,64 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SLOTS = 4            # distinct resident batches per rank that take turns
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline_reference(args):
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """python bench.py --gpus N without a launcher: re-run under torch.distributed.run, one rank per GPU"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000):
     """the reference binary itself (oracle/_ref/chromap, built unchanged from the reference sources; it
     travels with the repo) on the host cores: tools/ref_baseline.py writes the same GRCh38-sized
     synthetic index / genome in the reference's file formats and two bench batches as FASTQ, runs
     `chromap --preset atac -t <nproc>` and chromap-amd on them and compares the BED files"""
-    import subprocess
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "chromap")
     if not os.path.exists(ref_bin):
         return None
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_baseline.py"), "--genome", str(args.genome), "--nseq",
-                        str(args.nseq), "--pairs", str(args.pairs), "--batches", "2", "--readlen", str(args.readlen)],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_baseline.py"), "--genome", str(args.genome), "--nseq",
+           str(args.nseq), "--pairs", str(args.pairs), "--batches", "2", "--readlen", str(args.readlen), "--preset", args.preset,
+           "--seed0", str(seed0), "--indel-rate", str(args.indel_rate)]
+    if repeats:
+        cmd += ["--repeats", ",".join(str(x) for x in repeats)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     try:
         r = json.loads(p.stdout.decode().strip().splitlines()[-1])
     except Exception:
+        log("[bench] reference baseline%s: no result (%s)" % (tag, p.stderr.decode(errors="replace")[-500:]))
         return None
     ref = r.get("reference", {})
     if "error" in r or "error" in ref or not ref.get("mapped_all_reads_s"):
-        log("[bench] reference baseline unavailable: %s" % (r.get("error") or ref.get("error")))
+        log("[bench] reference baseline%s unavailable: %s" % (tag, r.get("error") or ref.get("error")))
         return None
     return {"value": ref["M_pairs_per_s_mapping_loop"], "unit": "M pairs/s", "cores": r["threads"], "kind": "reference",
-            "sample": "%d pairs (two bench batches, seeds 1000/1001) as FASTQ through oracle/_ref/chromap --preset atac -t %d with the "
+            "sample": "%d pairs (two bench batches, seeds %d/%d) as FASTQ through oracle/_ref/chromap --preset %s -t %d with the "
                       "GRCh38-sized index written by the device builder: %.2f s in its mapping loop (\"Mapped all reads in\"), "
-                      "%.2f s summed over its %d batches" % (r["pairs"], r["threads"], ref["mapped_all_reads_s"],
+                      "%.2f s summed over its %d batches" % (r["pairs"], seed0, seed0 + 1, args.preset, r["threads"], ref["mapped_all_reads_s"],
                                                              ref["sum_of_batch_times_s"], ref["batches"]),
             "bed_identical_to_reference": r.get("bed_identical_to_reference"),
             "bed_lines": ref.get("bed_lines"), "chromap_amd_cli_same_files": r.get("chromap_amd", {}).get("cli")}
 
 
-def cpu_baseline(g, args, n_sample_hint):
+def cpu_baseline_port(g, args):
     """oracle ("port") on the host cores, same index, same reads, bounded sample"""
     import numpy as np
     import oracle_lib as ol
@@ -80,7 +112,6 @@ def cpu_baseline(g, args, n_sample_hint):
     idx = ol.OraIndex()
     assert O.ora_index_from_buckets(bk.ctypes.data, nb.value, oc.ctypes.data, nocc.value, k.value, w.value, C.byref(idx)) == 0
     del bk
-    # reference sequences
     nseq = C.c_uint32()
     L.cmgpu_reference_lengths(g.ctx, None, 0, C.byref(nseq))
     lens = (C.c_uint32 * nseq.value)()
@@ -101,7 +132,6 @@ def cpu_baseline(g, args, n_sample_hint):
     p = ol.params(args.preset)
     ctx = O.ora_create(C.byref(idx), C.byref(ref), C.byref(p))
     log("[bench] exported index to host in %.1fs" % (time.time() - t0))
-    # the resident batch
     n = args.pairs
     rl = args.readlen
     b1 = np.empty(n * rl, np.uint8)
@@ -119,7 +149,7 @@ def cpu_baseline(g, args, n_sample_hint):
                                 C.cast(rec, C.c_void_p), C.byref(st))
         return time.time() - t, kk, rec, st
 
-    m = n  # the whole timed batch, repeated until ~12 s of CPU work have been measured
+    m = n
     t_run, kk, rec, st = run(m)
     reps, t_total = 1, t_run
     while t_total < 12.0 and reps < 64:
@@ -127,7 +157,6 @@ def cpu_baseline(g, args, n_sample_hint):
         t_total += t_more
         reps += 1
     t_run = t_total / reps
-    # parity of the sample: the GPU records of the same pairs must be identical
     grec, gk = g.download_records(n)
     gset = {}
     for i in range(gk):
@@ -148,6 +177,101 @@ def cpu_baseline(g, args, n_sample_hint):
             "algorithmic_probe_steps_per_pair": round(st.probe_steps / m, 2)}
 
 
+def gen(g, args, seed):
+    g.generate_resident(args.pairs, read_length=args.readlen, frag_min=args.frag_min, frag_max=args.frag_max, sub_rate=0.01, seed=seed,
+                        indel_rate=args.indel_rate)
+
+
+def timed_run(g, args, rank, world, dist, seed0, exchange):
+    """parks N_SLOTS distinct batches, then warm-up + K timed steps; returns (dt of this rank, stage sums, Stats, mapped)"""
+    import torch
+    from chromap_amd import Stats
+    for b in range(N_SLOTS):
+        gen(g, args, seed0 + rank * 64 + b)
+        g.swap_resident(b)
+
+    def step(i, stats):
+        sl = i % N_SLOTS
+        g.swap_resident(sl)
+        k = g.map_resident(stats)
+        if exchange:
+            g.exchange_step()
+        tm = g.timings()
+        g.swap_resident(sl)
+        return k, tm
+
+    for i in range(args.warmup):
+        step(i, Stats())
+    g.store_clear()
+    stage_ms = {}
+    st = Stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mapped = 0
+    for i in range(args.steps):
+        k, tm = step(args.warmup + i, st)
+        mapped += k
+        for name, ms in tm:
+            stage_ms[name] = stage_ms.get(name, 0.0) + ms
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    return dt, stage_ms, st, mapped
+
+
+def roofline(g, args, s, steps, stage_ms):
+    """kernel-only measurement of the index probe (HIP events on the launch stream) against the swept random-gather
+    ceiling of the same table"""
+    n_mm = s["num_minimizers"] // steps
+    probe_steps = s["probe_steps"] / steps
+    alg_bytes = 16.0 * probe_steps  # SURVEY 8(d): one 8-B key + one 8-B value per visited bucket
+    avg, ps, hits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    probe_only, achieved, probe_ms = None, 0.0, 0.0
+    if g.L.cmgpu_probe_bench(g.ctx, None, n_mm, args.probe_repeat, C.byref(avg), C.byref(ps), C.byref(hits), None) == 0 and avg.value > 0:
+        probe_only = {"lookups": int(n_mm), "avg_ms": round(avg.value, 4), "probe_steps": int(ps.value), "hits": int(hits.value),
+                      "GB/s": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9, 1), "G_lookups/s": round(n_mm / (avg.value * 1e-3) / 1e9, 2)}
+        achieved, probe_ms = probe_only["GB/s"], avg.value
+    variants = []
+    for u in (1, 2, 4, 8):
+        for pair in (0, 1):
+            a = C.c_double(0)
+            if g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, max(3, args.probe_repeat // 2), u, pair, C.byref(a), None, None) == 0 and a.value > 0:
+                variants.append({"lookups_per_lane": u, "pair_prefetch": pair, "avg_ms": round(a.value, 4)})
+    ng = 1 << 28
+    sweep = []
+    for loads, width in ((1, 16), (2, 16), (4, 16), (8, 16), (16, 16), (1, 64), (2, 64), (4, 64), (8, 64)):
+        a = C.c_double(0)
+        if g.L.cmgpu_gather_sweep(g.ctx, ng, 3, loads, width, C.byref(a)) == 0 and a.value > 0:
+            sweep.append({"loads_per_lane": loads, "access_bytes": width, "avg_ms": round(a.value, 4),
+                          "G_accesses/s": round(ng / (a.value * 1e-3) / 1e9, 2), "sector_GB/s": round(64.0 * ng / (a.value * 1e-3) / 1e9, 1)})
+    best = max(sweep, key=lambda x: x["G_accesses/s"]) if sweep else None
+    traffic, sectors_per_lookup = None, None
+    prof = os.path.join(ROOT, "profiles", "probe_traffic.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            traffic = pj.get("hbm_bytes_per_launch")
+            sectors_per_lookup = pj.get("sectors_per_lookup")
+        except Exception:
+            pass
+    shape = {"lookups_per_lane": g.get_option("probe_lookups_per_lane"), "pair_prefetch": g.get_option("probe_pair_prefetch")}
+    roof = {"kernel": "k_probe", "kernel_shape": shape, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
+            "probe_variants": variants, "random_gather_sweep": sweep, "random_gather_ceiling": best}
+    if best and probe_only:
+        # useful: bucket reads of the probe against 16-byte accesses of the ceiling shape;
+        # sector: 64-byte sectors the probe fetched (PMC, profiles/probe_traffic.json) against the ceiling's sectors
+        roof["useful_frac"] = round((ps.value / (avg.value * 1e-3) / 1e9) / best["G_accesses/s"], 3)
+        if sectors_per_lookup:
+            roof["sector_frac"] = round((n_mm * sectors_per_lookup / (avg.value * 1e-3) / 1e9) / best["G_accesses/s"], 3)
+        roof["frac_of_measured_gather"] = roof["useful_frac"]
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +282,14 @@ def main():
     ap.add_argument("--nseq", type=int, default=24)
     ap.add_argument("--readlen", type=int, default=50)
     ap.add_argument("--preset", default="atac")
+    ap.add_argument("--frag-min", type=int, default=30)
+    ap.add_argument("--frag-max", type=int, default=600)
+    ap.add_argument("--indel-rate", type=float, default=0.0, help="1-base indels per base in the synthetic reads (SURVEY 8(d): 0.001 for config 5)")
+    ap.add_argument("--repeats", default="32,600,3000,0.02",
+                    help="planted repeat families of the second, repeat-bearing workload: families,copies,element_len,divergence ('' = skip it)")
+    ap.add_argument("--headline-repeats", default="", help="plant repeats in the headline workload's genome too (not the default)")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-extras", action="store_true", help="timed region and roofline only")
     ap.add_argument("--cpu-baseline", choices=["auto", "reference", "port"], default="auto",
                     help="reference: oracle/_ref/chromap itself; port: the oracle restatement with OpenMP; auto: reference if its binary is here")
     ap.add_argument("--probe-repeat", type=int, default=10)
@@ -166,7 +297,11 @@ def main():
                                                          "(CIGAR / NM / MD); not the headline metric")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL record exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--option", action="append", default=[], help="name=value for cmgpu_set_option (measurement knobs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     # RCCL prints a version banner on the process's stdout; the contract is ONE JSON line there.
     # Everything below writes to stderr; the JSON goes to the saved descriptor at the very end.
@@ -180,181 +315,182 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (chromap_amd has no CPU path)")
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
+    exchange = world > 1 or args.force_exchange
     dist = None
-    if world > 1 or args.force_exchange:
+    if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
 
     from chromap_amd import ChromapGPU, Stats
+
+    def parse_rep(txt):
+        if not txt:
+            return None
+        f = txt.split(",")
+        return (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
+
+    def make_ctx(rep):
+        g_ = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset, device=local_rank,
+                        **({"output_format": 1} if args.sam else {}))
+        for o in args.option:
+            k_, v_ = o.split("=")
+            g_.set_option(k_, int(v_))
+        return g_
+
     t0 = time.time()
-    g = ChromapGPU(synthetic=(args.genome, args.nseq, 12345), preset=args.preset, device=local_rank,
-                   **({"output_format": 1} if args.sam else {}))
+    g = make_ctx(parse_rep(args.headline_repeats))
     t_index = time.time() - t0
     if rank == 0:
         log("[bench] synthetic genome + index on device in %.1fs" % t_index)
-    g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=1000 + rank)
-    ex = None
-    if world > 1 or args.force_exchange:
-        from chromap_amd.distributed import RecordExchange
-        ex = RecordExchange(args.pairs, torch.device("cuda", local_rank))
-
-    def step(stats):
-        k = g.map_resident(stats)
-        if ex is not None:
-            # records grouped by chromosome owner -> all-to-all -> the owner's device-side record store
-            counts = (C.c_uint64 * world)()
-            rc = g.L.cmgpu_records_partition(g.ctx, world, C.c_void_p(ex.send.data_ptr()), args.pairs, counts)
-            assert rc == 0
-            nrecv = ex.all_to_all(list(counts))
-            g.store_append(ex.recv.data_ptr(), nrecv, on_device=True)
-        return k
-
-    for _ in range(args.warmup):
-        step(Stats())
-    g.store_clear()
-    stage_ms = {}
-    st = Stats()
+    if exchange:
+        uid = [g.exchange_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
+        g.exchange_init(uid[0], rank, world)
+    dt, stage_ms, st, mapped = timed_run(g, args, rank, world, dist, 1000, exchange)
+    info = {"rank": rank, "mapped_pairs": int(mapped), "dt_s": dt}
+    if exchange:
+        info.update(g.exchange_info())
+        info["records_owned"] = info.pop("records_received")
+    infos = [info]
+    if dist is not None:
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        dt = max(x["dt_s"] for x in infos)
+    if exchange:
+        g.exchange_finalize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    mapped = 0
-    for _ in range(args.steps):
-        mapped += step(st)
-        for name, ms in g.timings():
-            stage_ms[name] = stage_ms.get(name, 0.0) + ms
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dist.destroy_process_group()
+    if rank != 0:
+        g.close()
+        os.close(json_fd)
+        return
+    steps = max(1, args.steps)
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / dt / 1e6
-
-    if rank == 0:
-        s = st.as_dict()
-        steps = max(1, args.steps)
-        probe_ms = stage_ms.get("s2_probe", 0.0) / steps
-        probe_steps = s["probe_steps"] / steps
-        alg_bytes = 16.0 * probe_steps  # one 8-B key + one 8-B value per visited bucket
-        achieved = alg_bytes / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
-        # kernel-only re-measurement of the same launch (HIP events around `repeat` launches)
-        avg = C.c_double(0)
-        ps = C.c_uint64(0)
-        hits = C.c_uint64(0)
-        n_mm = s["num_minimizers"] // steps
-        rc = g.L.cmgpu_probe_bench(g.ctx, None, n_mm, args.probe_repeat, C.byref(avg), C.byref(ps), C.byref(hits), None)
-        probe_only = None
-        if rc == 0 and avg.value > 0:
-            probe_only = {"lookups": int(n_mm), "avg_ms": round(avg.value, 4), "probe_steps": int(ps.value),
-                          "hits": int(hits.value), "GB/s": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9, 1),
-                          "G_lookups/s": round(n_mm / (avg.value * 1e-3) / 1e9, 2)}
-            achieved = probe_only["GB/s"]
-            probe_ms = avg.value
-        gavg = C.c_double(0)
-        gather = None
-        ng = 1 << 28
-        if g.L.cmgpu_gather_bench(g.ctx, ng, 5, C.byref(gavg)) == 0 and gavg.value > 0:
-            gather = {"accesses": ng, "avg_ms": round(gavg.value, 4), "useful_GB/s": round(16.0 * ng / (gavg.value * 1e-3) / 1e9, 1),
-                      "sector_GB/s": round(64.0 * ng / (gavg.value * 1e-3) / 1e9, 1)}
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "probe_traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = {"kernel": "k_probe", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(probe_ms, 4),
-                "probe_only": probe_only, "random_gather_16B": gather,
-                "frac_of_measured_gather": round(achieved / gather["useful_GB/s"], 3) if gather and gather["useful_GB/s"] else None}
-        # device-side post-processing, outside the timed region: the last batch's
-        # records plus three freshly mapped batches go to the record store; one call sorts,
-        # de-duplicates, filters and renders the BED text in HBM
-        post = None
+    s = st.as_dict()
+    roof = roofline(g, args, s, steps, stage_ms)
+    post = pcie = cpu = rep_out = None
+    if not args.skip_extras:
+        # device-side post-processing, outside the timed region: the records of the four resident
+        # batches go to the record store; one call sorts, de-duplicates, filters and renders the BED text in HBM
         try:
             g.store_clear()
-            t1 = time.perf_counter()
-            nrec = g.store_append_resident()
-            for extra in range(3):
-                g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01,
-                                    seed=5000 + extra)
+            nrec = 0
+            for b in range(N_SLOTS):
+                g.swap_resident(b)
                 g.map_resident(Stats())
                 nrec = g.store_append_resident()
+                g.swap_resident(b)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             lines, nbytes = g.store_format(0)
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             post = {"records": int(nrec), "bed_lines": int(lines), "text_bytes": int(nbytes),
-                    "sort_dedup_format_ms": round((t3 - t2) * 1e3, 3),
-                    "M_records/s": round(nrec / (t3 - t2) / 1e6, 1)}
+                    "sort_dedup_format_ms": round((t3 - t2) * 1e3, 3), "M_records/s": round(nrec / (t3 - t2) / 1e6, 1)}
             g.store_clear()
         except Exception as e:
             post = {"error": repr(e)}
-        # back to the timed batch (the CPU baseline compares its records with the GPU's)
-        g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=1000 + rank)
-        g.map_resident(Stats())
         # PCIe-inclusive rate of the host-buffer boundary (cmgpu_map_pairs: H2D reads, map, D2H records);
         # reported beside `value`, never as `value`
-        pcie = None
         try:
             import numpy as np
             n = args.pairs
+            g.swap_resident(0)
             o1 = np.zeros(n + 1, np.uint32)
             o2 = np.zeros(n + 1, np.uint32)
             b1 = np.zeros(n * args.readlen, np.uint8)
             b2 = np.zeros(n * args.readlen, np.uint8)
             assert g.L.cmgpu_download_batch(g.ctx, b1.ctypes.data, o1.ctypes.data, b2.ctypes.data, o2.ctypes.data) == 0
+            g.swap_resident(0)
             g.map_pairs(b1, o1, b2, o2)  # warm the host-side buffers
             t1 = time.perf_counter()
             _, kk = g.map_pairs(b1, o1, b2, o2)
             t2 = time.perf_counter()
             pcie = {"M pairs/s": round(n / (t2 - t1) / 1e6, 2), "ms": round((t2 - t1) * 1e3, 2), "records": int(kk),
-                    "note": "pageable host buffers, synchronous hipMemcpy, includes allocating the host record array"}
+                    "note": "cmgpu_map_pairs on pageable host buffers (upload, map, record download)"}
+            if hasattr(g, "map_pairs_pipelined"):
+                pcie["pipelined"] = g.map_pairs_pipelined(b1, o1, b2, o2, repeats=4)
         except Exception as e:
             pcie = {"error": repr(e)}
-        cpu = None
         if world == 1 and not args.skip_cpu and not args.sam:
             try:
                 if args.cpu_baseline in ("auto", "reference"):
-                    cpu = cpu_baseline_reference(args)
+                    g.close()  # the baseline tool builds its own copy of the index on the device
+                    g = None
+                    cpu = cpu_baseline_reference(args, parse_rep(args.headline_repeats))
                 if cpu is None and args.cpu_baseline in ("auto", "port"):
-                    cpu = cpu_baseline(g, args, args.pairs)
+                    if g is None:
+                        g = make_ctx(parse_rep(args.headline_repeats))
+                    gen(g, args, 1000)
+                    g.map_resident(Stats())
+                    cpu = cpu_baseline_port(g, args)
             except Exception as e:  # the GPU number must still be reported
                 cpu = {"value": None, "unit": "M pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        out = {
-            "metric": "M paired reads mapped/s (ATAC preset, GRCh38 index)",
-            "value": round(value, 4), "unit": "M pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "--preset %s, synthetic 2x%d bp pairs (fragments 30-600 bp, 1%% substitutions), "
-                                   "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7) resident per GPU, "
-                                   "%d pairs per GPU per step, reads resident in HBM" % (args.preset, args.readlen, args.genome, args.nseq, args.pairs),
-                       "pairs_per_gpu_per_step": args.pairs, "parallelism": "read-shard x%d + RCCL all-to-all of records to chromosome owners" % world if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "postprocess_on_device": post, "pcie_inclusive": pcie,
-            "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
-            "counters_per_step": {k: v // steps for k, v in s.items()},
-            "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),
-        }
-        result_line = json.dumps(out)
-    else:
-        result_line = None
-    g.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # ---- the same measurement on a genome with planted repeat families: frequent seeds,
+        #      multi-mappers and mate rescue as on a real genome; reported beside the headline
+        rep = parse_rep(args.repeats)
+        if world == 1 and rep and not args.sam:
+            try:
+                if g is not None:
+                    g.close()
+                g = None
+                gr = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset, device=local_rank)
+                for o in args.option:
+                    k_, v_ = o.split("=")
+                    gr.set_option(k_, int(v_))
+                rdt, rstage, rst, rmapped = timed_run(gr, args, 0, 1, None, 3000, False)
+                rs = rst.as_dict()
+                rep_out = {"value": round(args.pairs * args.steps / rdt / 1e6, 4), "unit": "M pairs/s", "ms_per_step": round(rdt / steps * 1e3, 3),
+                           "workload": "the headline workload on a genome with %d planted repeat families x %d copies of %d bases at %.1f %% "
+                                       "divergence (%.1f %% of the genome)" % (rep[0], rep[1], rep[2], rep[3] * 100,
+                                                                               100.0 * rep[0] * rep[1] * rep[2] / args.genome),
+                           "counters_per_step": {k: v // steps for k, v in rs.items()},
+                           "candidates_per_read": round(rs["num_candidates"] / (2.0 * args.pairs * args.steps), 3),
+                           "stage_ms_per_step": {k: round(v / steps, 3) for k, v in rstage.items()},
+                           "mapped_pairs_per_step": rmapped // steps}
+                gr.close()
+                if not args.skip_cpu and args.cpu_baseline in ("auto", "reference"):
+                    rep_out["cpu_baseline"] = cpu_baseline_reference(args, rep, " (repeats)", seed0=3000)
+            except Exception as e:
+                rep_out = {"error": repr(e)}
+    out = {
+        "metric": "M paired reads mapped/s (ATAC preset, GRCh38 index)",
+        "value": round(value, 4), "unit": "M pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "--preset %s, synthetic 2x%d bp pairs (fragments %d-%d bp, 1%% substitutions%s), "
+                               "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7%s) resident per GPU, "
+                               "%d pairs per GPU per step, %d distinct batches per GPU resident in HBM taking turns"
+                               % (args.preset, args.readlen, args.frag_min, args.frag_max,
+                                  ", %.2f%% 1-base indels" % (args.indel_rate * 100) if args.indel_rate else "", args.genome, args.nseq,
+                                  ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS),
+                   "pairs_per_gpu_per_step": args.pairs,
+                   "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
+                                   "mapping stream inside every step" % world) if exchange else "single GPU"},
+        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
+        "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
+        "counters_per_step": {k: v // steps for k, v in s.items()},
+        "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),
+    }
+    if exchange:
+        out["exchange"] = {"ranks": world, "transport": "RCCL (ncclAllGather of counts + grouped ncclSend/ncclRecv) on the mapping stream",
+                           "per_rank": [{k: x[k] for k in ("rank", "mapped_pairs", "records_sent", "records_owned")} for x in infos]}
+    result_line = json.dumps(out)
+    if g is not None:
+        g.close()
     sys.stdout.flush()
-    if result_line is not None:
-        os.write(json_fd, (result_line + "\n").encode())
+    os.write(json_fd, (result_line + "\n").encode())
     os.close(json_fd)
 
 

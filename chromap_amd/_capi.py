@@ -101,7 +101,20 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
            "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded",
            "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
-           "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref")
+           "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref",
+           "cmgpu_create_synthetic_repeats", "cmgpu_generate_resident_batch_indels", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
+           "cmgpu_exchange_unique_id", "cmgpu_exchange_init", "cmgpu_exchange_init_all", "cmgpu_exchange_init_external",
+           "cmgpu_exchange_owner_table", "cmgpu_exchange_step", "cmgpu_exchange_info", "cmgpu_exchange_finalize", "cmgpu_memcpy", "cmgpu_copy_whitelist")
+
+UNIQUE_ID_BYTES = 128
+ALLGATHER_COUNTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32)
+
+
+class ExchangeTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather_counts", ALLGATHER_COUNTS_FN), ("alltoallv", ALLTOALLV_FN)]
+
+
 
 TEXT_BED_PE, TEXT_BED_SE, TEXT_BED_PE_BC, TEXT_TAGALIGN_PE, TEXT_TAGALIGN_PE_BC, TEXT_BED_SE_BC, TEXT_TAGALIGN_SE_BC = 0, 1, 2, 3, 4, 5, 6
 
@@ -185,6 +198,25 @@ def declare(L):
                                                P(Stats)])
     sig("cmgpu_write_bed_pe_bc", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_uint32,
                                              C.c_char_p])
+    sig("cmgpu_probe_bench_variant", C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, P(C.c_double), P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_create_synthetic_repeats", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, P(Params), C.c_int,
+                                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, P(C.c_void_p)])
+    sig("cmgpu_generate_resident_batch_indels", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                                          C.c_double, C.c_uint64])
+    sig("cmgpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64])
+    sig("cmgpu_get_option", C.c_int, [C.c_void_p, C.c_char_p, P(C.c_int64)])
+    sig("cmgpu_gather_sweep", C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, P(C.c_double)])
+    sig("cmgpu_swap_resident_batch", C.c_int, [C.c_void_p, C.c_int])
+    sig("cmgpu_exchange_unique_id", C.c_int, [C.c_void_p])
+    sig("cmgpu_exchange_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int])
+    sig("cmgpu_exchange_init_all", C.c_int, [P(C.c_void_p), C.c_int])
+    sig("cmgpu_exchange_init_external", C.c_int, [C.c_void_p, P(ExchangeTransport), C.c_int, C.c_int])
+    sig("cmgpu_exchange_owner_table", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32])
+    sig("cmgpu_exchange_step", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_exchange_info", C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_exchange_finalize", C.c_int, [C.c_void_p])
+    sig("cmgpu_copy_whitelist", C.c_int, [C.c_void_p, C.c_void_p])
+    sig("cmgpu_memcpy", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int])
     sig("cmgpu_load_index_file", C.c_int, [C.c_char_p, P(IndexView)])
     sig("cmgpu_free_host_index", None, [P(IndexView)])
     sig("cmgpu_load_reference_fasta", C.c_int, [C.c_char_p, P(RefView)])

@@ -52,6 +52,41 @@ void DevBuf::release() {
   cap = 0;
 }
 
+// tuning knobs for measurements (defaults are what the measurements chose)
+extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
+  if (!c || !name) return CMGPU_EINVAL;
+  const std::string n(name);
+  if (n == "probe_lookups_per_lane") {
+    if (value != 1 && value != 2 && value != 4 && value != 8) { cm_set_error(c, "probe_lookups_per_lane: 1, 2, 4 or 8"); return CMGPU_EINVAL; }
+    c->opt_probe_variant = (int)value | (c->opt_probe_variant & 16);
+  } else if (n == "probe_pair_prefetch") {
+    c->opt_probe_variant = (c->opt_probe_variant & 15) | (value ? 16 : 0);
+  } else if (n == "mm_chunks") {
+    if (value < 1 || value > CM_MM_CHUNKS) { cm_set_error(c, "mm_chunks: 1.." + std::to_string(CM_MM_CHUNKS)); return CMGPU_EINVAL; }
+    c->opt_mm_chunks = (int)value;
+  } else if (n == "prep_kernel") {
+    c->opt_prep_kernel = (int)value;
+  } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate
+    c->opt_item_limit = value > 0 ? (uint64_t)value : 0xfffffff0ull;
+  } else {
+    cm_set_error(c, "unknown option " + n);
+    return CMGPU_EINVAL;
+  }
+  return CMGPU_OK;
+}
+
+extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *value) {
+  if (!c || !name || !value) return CMGPU_EINVAL;
+  const std::string n(name);
+  if (n == "probe_lookups_per_lane") *value = c->opt_probe_variant & 15;
+  else if (n == "probe_pair_prefetch") *value = (c->opt_probe_variant & 16) ? 1 : 0;
+  else if (n == "mm_chunks") *value = c->opt_mm_chunks;
+  else if (n == "prep_kernel") *value = c->opt_prep_kernel;
+  else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
+  else return CMGPU_EINVAL;
+  return CMGPU_OK;
+}
+
 extern "C" const char *cmgpu_last_error(const cmgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
 // ---------------------------------------------------------------------------------------
@@ -223,6 +258,13 @@ extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
   c->bmask = parent->bmask; c->n_occ = parent->n_occ; c->n_seq = parent->n_seq; c->ref_bytes = parent->ref_bytes;
   c->h_ref_off = parent->h_ref_off; c->h_ref_len = parent->h_ref_len;
   c->synth_n_minimizers = parent->synth_n_minimizers; c->synth_n_keys = parent->synth_n_keys;
+  // --chr-order / --pairs-natural-chr-order of the parent apply to the child too (records carry ranks)
+  if (parent->has_rank) {
+    view(c->rid_rank, parent->rid_rank); view(c->ref_off_r, parent->ref_off_r); view(c->ref_len_r, parent->ref_len_r);
+    c->has_rank = true;
+    c->h_rank = parent->h_rank;
+  }
+  if (parent->has_pairs_rank) { view(c->pairs_rank, parent->pairs_rank); c->has_pairs_rank = true; }
   *out = c;
   return CMGPU_OK;
 }
@@ -249,6 +291,7 @@ extern "C" int cmgpu_set_chr_order(cmgpu_ctx *c, const uint32_t *rank, uint32_t 
   HIPCHECK(c, hipMemcpy(c->ref_off_r.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
   HIPCHECK(c, hipMemcpy(c->ref_len_r.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   c->has_rank = true;
+  c->h_rank.assign(rank, rank + n);
   return CMGPU_OK;
 }
 
@@ -267,6 +310,7 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (c->in_flight) { c->worker.join(); c->in_flight = false; }
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  cm_exchange_release(c);
   for (DevBuf *b : c->all_bufs()) b->release();
   for (int i = 0; i < CM_MAX_EVENTS; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (hipEvent_t e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
@@ -291,7 +335,6 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4)
-  ENS(rec, (size_t)n * 24) ENS(rec_ok, n)
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
 #undef ENS
   return CMGPU_OK;
@@ -327,7 +370,27 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   return CMGPU_OK;
 }
 
-void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
+// The resident batch (bulk paired-end reads) changes places with the batch parked in `slot` (either may be empty).
+extern "C" int cmgpu_swap_resident_batch(cmgpu_ctx *c, int slot) {
+  if (!c || slot < 0 || slot >= CM_BATCH_SLOTS) return CMGPU_EINVAL;
+  if (c->in_flight) { cm_set_error(c, "a batch is in flight"); return CMGPU_EINVAL; }
+  if (c->has_barcodes || c->single) { cm_set_error(c, "only bulk paired-end batches can be parked"); return CMGPU_EINVAL; }
+  HIPCHECK(c, cm_enter(c));
+  HIPCHECK(c, cm_stream_sync(c->stream));
+  CmBatchSlot &sl = c->slots[slot];
+  std::swap(c->rb0, sl.rb0); std::swap(c->rb1, sl.rb1); std::swap(c->ro0, sl.ro0); std::swap(c->ro1, sl.ro1);
+  std::swap(c->n_pairs, sl.n_pairs); std::swap(c->first_read_id, sl.first_read_id); std::swap(c->max_read_len, sl.max_read_len);
+  std::swap(c->bases0, sl.bases0); std::swap(c->bases1, sl.bases1);
+  c->n_records = 0;
+  return CMGPU_OK;
+}
+
+void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi);
+void cm_fill_dev(cmgpu_ctx *c, CmDev &d) { cm_fill_dev_range(c, d, 0, c->n_pairs); }
+
+// the stage kernels' view of pairs [lo, hi) of the resident batch: per-pair inputs and outputs are offset views,
+// the intermediates (indexed from 0) are reused by every sub-batch
+void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   memset(&d, 0, sizeof(d));
   d.bkt = (const uint64_t *)c->bkt.p; d.bmask = c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
@@ -335,9 +398,9 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   d.p = c->p;
   d.p.single = c->single ? 1 : 0;
   d.mq.len_coef = (const double *)c->len_coef.p; d.mq.nsec_break = (const uint32_t *)c->nsec_break.p; d.mq.n_break = c->n_break;
-  d.n_pairs = c->n_pairs; d.first_read_id = c->first_read_id;
+  d.n_pairs = hi - lo; d.first_read_id = c->first_read_id + lo;
   d.rb0 = (const uint8_t *)c->rb0.p; d.rb1 = (const uint8_t *)c->rb1.p;
-  d.ro0 = (const uint32_t *)c->ro0.p; d.ro1 = (const uint32_t *)c->ro1.p;
+  d.ro0 = (const uint32_t *)c->ro0.p + lo; d.ro1 = (const uint32_t *)c->ro1.p + lo;
 #define PTR(f, T) d.f = (T *)c->f.p;
   PTR(rlen, uint32_t) PTR(mm_cnt, uint32_t)
   PTR(mm_off, uint32_t) PTR(mm_hash, uint64_t) PTR(mm_ps, uint32_t) PTR(pr_val, uint64_t) PTR(pr_kind, uint8_t)
@@ -350,8 +413,9 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   PTR(min_err, int32_t) PTR(second_err, int32_t) PTR(n_best, int32_t) PTR(n_second, int32_t)
   PTR(pe_min, int32_t) PTR(pe_second, int32_t) PTR(pe_nbest, int32_t) PTR(pe_nsecond, int32_t)
   PTR(pe_first, uint32_t) PTR(pe_i1, uint32_t) PTR(pe_i2, uint32_t) PTR(pe_choice, uint32_t)
-  PTR(rec, uint8_t) PTR(rec_ok, uint8_t)
 #undef PTR
+  d.rec = (uint8_t *)c->rec.p + (size_t)lo * 24;
+  d.rec_ok = (uint8_t *)c->rec_ok.p + lo;
   d.stats = (unsigned long long *)c->stats.p;
   if (c->has_rank) {  // stages from verification on address the reference by rank
     d.rid_rank = (const uint32_t *)c->rid_rank.p;
@@ -360,10 +424,10 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) {
   }
   if (c->has_pairs_rank) d.pairs_rank = (const uint32_t *)c->pairs_rank.p;
   if (c->has_barcodes) {
-    d.bcb = (const uint8_t *)c->bcb.p; d.bcq = (const uint8_t *)c->bcq.p; d.bco = (const uint32_t *)c->bco.p;
+    d.bcb = (const uint8_t *)c->bcb.p; d.bcq = (const uint8_t *)c->bcq.p; d.bco = (const uint32_t *)c->bco.p + lo;
     d.wl = (const uint64_t *)c->wl.p; d.wl_mask = c->wl_mask; d.wl_num_sample = (double)c->wl_num_sample;
     d.pow10_tab = (const double *)c->pow10_tab.p;
-    d.bc_key = (uint64_t *)c->bc_key.p; d.bc_ok = (uint8_t *)c->bc_ok.p;
+    d.bc_key = c->bc_key.p ? (uint64_t *)c->bc_key.p + lo : nullptr; d.bc_ok = c->bc_ok.p ? (uint8_t *)c->bc_ok.p + lo : nullptr;
   }
 }
 
@@ -375,30 +439,36 @@ static inline void mark(cmgpu_ctx *c, const char *name) {
   }
 }
 
-// The pipeline on the resident batch.  Three small device->host reads size the
-// variable-length intermediates (minimizers, hits, candidate capacity).
-extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *stats) {
-  if (!c) return CMGPU_EINVAL;
-  HIPCHECK(c, cm_enter(c));
-  const uint32_t n = c->n_pairs, n2 = 2 * n;
+// exclusive scan of per-read counts (u32 offsets) together with their exact 64-bit total: the offsets are only
+// meaningful when the total fits the dense arrays' 32-bit indexing, which the caller checks on *total
+static int scan_with_total(cmgpu_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *total) {
+  hipStream_t s = c->stream;
+  unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_N - 2;  // spare counter slot
+  HIPCHECK(c, hipMemsetAsync(acc, 0, 8, s));
+  cm_launch_k_sum_u32(in, n, acc, s);
+  cm_scan_u32(in, out, n, (uint32_t *)c->scan_tmp.p, s);
+  HIPCHECK(c, hipMemcpyAsync(total, acc, 8, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, cm_stream_sync(s));
+  return CMGPU_OK;
+}
+
+#define CM_RC_SPLIT (-100)  // internal: a dense intermediate of this pair range exceeds the 32-bit item limit
+
+// The pipeline on pairs [rlo, rhi) of the resident batch.  Four small device->host reads size the
+// variable-length intermediates (minimizers, hits, candidate capacity, verification items).
+static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, cmgpu_stats *stats) {
+  const uint32_t n = rhi - rlo, n2 = 2 * n;
+  const uint64_t limit = c->opt_item_limit;
   c->n_ev = 0;
-  c->n_records = 0;
-  if (n_out) *n_out = 0;
-  if (n == 0) return CMGPU_OK;
-  if (c->max_read_len > CM_MAX_READ_LEN) {  // LDS staging of a block's reads (cm_kernels.hip: staging_geometry)
-    cm_set_error(c, "reads longer than " + std::to_string(CM_MAX_READ_LEN) + " bases are not supported");
-    return CMGPU_EINVAL;
-  }
+  *k_out = 0;
   int rc = ensure_pair_arrays(c, n);
   if (rc) return rc;
   hipStream_t s = c->stream;
   CmDev d;
   HIPCHECK(c, hipMemsetAsync(c->stats.p, 0, CM_ST_N * 8, s));
-  cm_fill_dev(c, d);
+  cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "begin");
   if (c->has_barcodes) {  // K6: barcode correction (chromap.h:896-909)
-    if (c->bc_key.ensure((size_t)n * 8) || c->bc_ok.ensure(n)) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
-    cm_fill_dev(c, d);
     cm_launch_k_s0b_barcode(d, n, s);
     mark(c, "s0b_barcode");
   }
@@ -412,10 +482,10 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     // stream by their index probe (K2, latency-bound gather), which runs next to chunk c+1's minimizer
     // pass.  A chunk's minimizers are the cursor range its launch covered (copied to mm_marks on the device).
     const uint32_t ppb = cm_prep_mm_pairs_per_block(d, c->max_read_len);
-    const uint32_t n_chunks = n >= (1u << 20) ? CM_MM_CHUNKS : (n >= (1u << 17) ? 2 : 1);
+    const uint32_t n_chunks = n >= (1u << 20) ? (uint32_t)c->opt_mm_chunks : (n >= (1u << 17) ? 2 : 1);
     const uint64_t per_read_bound = c->max_read_len > (uint32_t)c->p.k ? c->max_read_len - (uint32_t)c->p.k + 1 : 1;
     for (int attempt = 0; attempt < 2; ++attempt) {
-      if (cap > 0xfffffff0ull) { cm_set_error(c, "batch too large (minimizers)"); return CMGPU_ECAPACITY; }
+      if (cap > limit) return CM_RC_SPLIT;
       // per chunk: probe grid = what the chunk can emit at most, but never more than the arrays hold
       uint32_t lo[CM_MM_CHUNKS + 1];
       uint64_t max_entries[CM_MM_CHUNKS];
@@ -428,14 +498,14 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
         uint64_t me = 2ull * (lo[ch + 1] - lo[ch]) * (attempt == 0 ? (uint64_t)(c->max_read_len / 4 + 3) : per_read_bound);
         if (me > cap) me = cap;
         max_entries[ch] = me;
-        part_off[ch + 1] = part_off[ch] + cm_probe_range_blocks(me);
+        part_off[ch + 1] = part_off[ch] + cm_probe_range_blocks(me, c->opt_probe_variant);
       }
       if (c->mm_hash.ensure((size_t)cap * 8 + 8) || c->mm_ps.ensure((size_t)cap * 4 + 4) || c->pr_val.ensure((size_t)cap * 8 + 8) ||
           c->pr_kind.ensure((size_t)cap + 4) || c->mm_cursor.ensure(8) || c->mm_marks.ensure((CM_MM_CHUNKS + 1) * 8) ||
           c->partials.ensure(((size_t)part_off[n_chunks] + 1) * 8 + cm_stats_partial_words(n) * 8)) {
         cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM;
       }
-      cm_fill_dev(c, d);
+      cm_fill_dev_range(c, d, rlo, rhi);
       HIPCHECK(c, hipMemsetAsync(c->mm_cursor.p, 0, 8, s));
       HIPCHECK(c, hipMemsetAsync(c->mm_marks.p, 0, 8, s));
       HIPCHECK(c, hipMemsetAsync(d.stats + CM_ST_PROBE_STEPS, 0, 2 * 8, s));
@@ -445,7 +515,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
         HIPCHECK(c, hipMemcpyAsync(marks + ch + 1, c->mm_cursor.p, 8, hipMemcpyDeviceToDevice, s));
         HIPCHECK(c, hipEventRecord(c->chunk_ev[ch], s));
         HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[ch], 0));
-        cm_launch_k_probe_range(d, marks + ch, max_entries[ch], (uint32_t)cap, (uint2 *)c->partials.p + part_off[ch], c->stream2);
+        cm_launch_k_probe_range(d, marks + ch, max_entries[ch], (uint32_t)cap, (uint2 *)c->partials.p + part_off[ch], c->stream2, c->opt_probe_variant);
       }
       HIPCHECK(c, hipEventRecord(c->chunk_ev[CM_MM_CHUNKS], c->stream2));
       HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[CM_MM_CHUNKS], 0));
@@ -467,45 +537,46 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   } else {
     // S0 + S1a: length filter, adapter trimming, minimizer counts (reads staged through LDS)
     cm_launch_k_prep_count(d, n, c->max_read_len, s);
-    cm_scan_u32(d.mm_cnt, d.mm_off, n2, (uint32_t *)c->scan_tmp.p, s);
-    HIPCHECK(c, hipMemcpyAsync(&n_mm, d.mm_off + n2, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(c, cm_stream_sync(s));
+    unsigned long long mm_total = 0;
+    if ((rc = scan_with_total(c, d.mm_cnt, d.mm_off, n2, &mm_total))) return rc;
+    if (mm_total > limit) return CM_RC_SPLIT;
+    n_mm = (uint32_t)mm_total;
     mark(c, "s0_s1a_trim_count");
     if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
         c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
-    cm_fill_dev(c, d);
+    cm_fill_dev_range(c, d, rlo, rhi);
     // S1b: minimizers written to their dense positions
     cm_launch_k_mm_fill(d, n, c->max_read_len, s);
     mark(c, "s1b_minimizers");
     // S2: index probe, one launch (k_probe: the kernel the roofline is measured on, cmgpu_probe_bench)
     if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
-    cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s);
+    cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s, c->opt_probe_variant);
     mark(c, "s2_probe");
   }
   // S3: hit counts -> offsets -> candidates
   cm_launch_k_s3a_count(d, n2, s);
-  cm_scan_u32(d.hit_tot, d.hit_off, n2, (uint32_t *)c->scan_tmp.p, s);
-  uint32_t n_hits = 0;
-  HIPCHECK(c, hipMemcpyAsync(&n_hits, d.hit_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, cm_stream_sync(s));
+  unsigned long long hits_total = 0;
+  if ((rc = scan_with_total(c, d.hit_tot, d.hit_off, n2, &hits_total))) return rc;
+  if (hits_total > limit) return CM_RC_SPLIT;  // 2 x 150 reads on a repeat-rich genome: ~500 hits per read x 8 M reads wraps 2^32
+  const uint32_t n_hits = (uint32_t)hits_total;
   if (c->hbuf.ensure((size_t)n_hits * 8 + 8) || c->hcnt.ensure((size_t)n_hits + 4)) { cm_set_error(c, "out of device memory (hits)"); return CMGPU_ENOMEM; }
-  cm_fill_dev(c, d);
+  cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s3a_count");
   cm_launch_k_s3b_candidates(d, n2, c->max_read_len, s);
   mark(c, "s3b_candidates");
   // S4: mate rescue, merge, paired-end filter
   cm_launch_k_s4a_rescue_count(d, n2, s);
-  cm_scan_u32(d.m_tot, d.m_off, n2, (uint32_t *)c->scan_tmp.p, s);
-  uint32_t n_m = 0;
-  HIPCHECK(c, hipMemcpyAsync(&n_m, d.m_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, cm_stream_sync(s));
+  unsigned long long m_total = 0;
+  if ((rc = scan_with_total(c, d.m_tot, d.m_off, n2, &m_total))) return rc;
+  if (m_total > limit) return CM_RC_SPLIT;
+  const uint32_t n_m = (uint32_t)m_total;
   if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
       c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
       c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4)) {
     cm_set_error(c, "out of device memory (candidates)");
     return CMGPU_ENOMEM;
   }
-  cm_fill_dev(c, d);
+  cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
   cm_launch_k_s4b_rescue_merge(d, n2, s);
   mark(c, "s4b_rescue_merge");
@@ -514,10 +585,10 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
   // candidate, (c) the sequential acceptance loop per read
   cm_launch_k_s5a_prepare(d, n2, s);
-  cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);
-  uint32_t n_v = 0;
-  HIPCHECK(c, hipMemcpyAsync(&n_v, d.v_off + n2, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(c, cm_stream_sync(s));
+  unsigned long long v_total = 0;
+  if ((rc = scan_with_total(c, d.nv, d.v_off, n2, &v_total))) return rc;
+  if (v_total > 0xfffffff0ull) return CM_RC_SPLIT;  // never above m_total; kept for symmetry
+  const uint32_t n_v = (uint32_t)v_total;
   mark(c, "s5a_prepare");
   cm_launch_k_s5b_verify(d, n_v, n2, s);
   mark(c, "s5b_verify");
@@ -525,15 +596,14 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   mark(c, "s5c_accept");
   // S6: best pair, sampling of multi-mappers, records
   if (c->p.sam) {  // per-slot record / CIGAR / MD pools and the backtrack cells of one alignment per pair
-    const uint64_t slots = c->single ? n : n2;
-    const uint32_t md_cap = 2 * c->max_read_len + 16;
+    // the slot pools hold the whole batch (cmgpu_map_resident sized them); this range's slots start at slot0
+    const uint64_t slots = c->single ? n : n2, slot0 = c->single ? rlo : 2ull * rlo;
+    const uint32_t md_cap = c->sam_md_cap;
     const uint32_t zw = (2 * c->p.e + 2 <= 18) ? 5 : 8;
-    if (c->sam_rec.ensure(slots * 40 + 16) || c->sam_cigar.ensure(slots * CM_SAM_CIGAR_CAP * 4 + 16) || c->sam_md.ensure(slots * md_cap + 16) ||
-        c->sam_z.ensure((size_t)c->max_read_len * zw * 4 * n + 16)) { cm_set_error(c, "out of device memory (SAM buffers)"); return CMGPU_ENOMEM; }
-    HIPCHECK(c, hipMemsetAsync(c->sam_rec.p, 0, slots * 40, s));
-    c->sam_slots = slots;
-    c->sam_md_cap = md_cap;
-    d.sam_rec = (uint8_t *)c->sam_rec.p; d.sam_cigar = (uint32_t *)c->sam_cigar.p; d.sam_md = (uint8_t *)c->sam_md.p;
+    if (c->sam_z.ensure((size_t)c->max_read_len * zw * 4 * n + 16)) { cm_set_error(c, "out of device memory (SAM buffers)"); return CMGPU_ENOMEM; }
+    HIPCHECK(c, hipMemsetAsync((uint8_t *)c->sam_rec.p + slot0 * 40, 0, slots * 40, s));
+    d.sam_rec = (uint8_t *)c->sam_rec.p + slot0 * 40; d.sam_cigar = (uint32_t *)c->sam_cigar.p + slot0 * CM_SAM_CIGAR_CAP;
+    d.sam_md = (uint8_t *)c->sam_md.p + slot0 * md_cap;
     d.sam_z = (uint32_t *)c->sam_z.p; d.sam_md_cap = md_cap;
   }
   if (c->p.sam) cm_launch_k_s6a_pair_sam(d, n, s); else cm_launch_k_s6a_pair(d, n, s);
@@ -549,7 +619,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   mark(c, "stats");
   HIPCHECK(c, cm_stream_sync(s));
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
-  c->n_records = hst[CM_ST_RECORDS];
+  *k_out = hst[CM_ST_RECORDS];
   c->last_n_mm = n_mm; c->last_n_hits = n_hits; c->last_n_cand_cap = n_m;
   if (stats) {
     stats->num_candidates += hst[CM_ST_CAND];
@@ -564,9 +634,61 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     stats->num_barcode_in_whitelist += hst[CM_ST_BC_INWL];
     stats->num_corrected_barcode += hst[CM_ST_BC_CORR];
   }
-  if (n_out) *n_out = c->n_records;
   return CMGPU_OK;
 }
+
+// pairs [lo, hi): as one range, or -- when a dense intermediate would pass the item limit -- as two halves cut on a
+// reference-batch boundary (the multi-mapper sampling is defined per reference batch, so the records do not change)
+static int map_split(cmgpu_ctx *c, uint32_t lo, uint32_t hi, uint64_t *k_total, cmgpu_stats *stats) {
+  uint64_t k = 0;
+  int rc = map_range(c, lo, hi, &k, stats);
+  if (rc != CM_RC_SPLIT) { *k_total += k; return rc; }
+  const uint32_t rb = (uint32_t)c->p.ref_batch, n = hi - lo;
+  if (n <= rb) {
+    cm_set_error(c, "a reference batch of " + std::to_string(n) + " pairs needs more than " + std::to_string((unsigned long long)c->opt_item_limit) +
+                        " entries in one intermediate array (hits / candidates)");
+    return CMGPU_ECAPACITY;
+  }
+  uint32_t half = (n / 2) / rb * rb;
+  if (half == 0) half = rb;
+  rc = map_split(c, lo, lo + half, k_total, stats);
+  if (rc) return rc;
+  return map_split(c, lo + half, hi, k_total, stats);
+}
+
+extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *stats) {
+  if (!c) return CMGPU_EINVAL;
+  HIPCHECK(c, cm_enter(c));
+  const uint32_t n = c->n_pairs;
+  c->n_ev = 0;
+  c->n_records = 0;
+  c->batch_exchanged = false;
+  if (n_out) *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  if (c->max_read_len > CM_MAX_READ_LEN) {  // LDS staging of a block's reads (cm_kernels.hip: staging_geometry)
+    cm_set_error(c, "reads longer than " + std::to_string(CM_MAX_READ_LEN) + " bases are not supported");
+    return CMGPU_EINVAL;
+  }
+  // per-pair outputs of the whole batch; the intermediates are sized per range
+  if (c->rec.ensure((size_t)n * 24) || c->rec_ok.ensure(n)) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
+  if (c->has_barcodes && (c->bc_key.ensure((size_t)n * 8) || c->bc_ok.ensure(n))) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
+  if (c->p.sam) {  // per-slot record / CIGAR / MD pools
+    const uint64_t slots = c->single ? n : 2ull * n;
+    const uint32_t md_cap = 2 * c->max_read_len + 16;
+    if (c->sam_rec.ensure(slots * 40 + 16) || c->sam_cigar.ensure(slots * CM_SAM_CIGAR_CAP * 4 + 16) || c->sam_md.ensure(slots * md_cap + 16)) {
+      cm_set_error(c, "out of device memory (SAM buffers)"); return CMGPU_ENOMEM;
+    }
+    c->sam_slots = slots;
+    c->sam_md_cap = md_cap;
+  }
+  uint64_t k = 0;
+  const int rc = map_split(c, 0, n, &k, stats);
+  if (rc) return rc;
+  c->n_records = k;
+  if (n_out) *n_out = k;
+  return CMGPU_OK;
+}
+
 
 extern "C" int cmgpu_download_records(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
   if (!c || !out || !n_out) return CMGPU_EINVAL;
@@ -687,8 +809,19 @@ extern "C" int cmgpu_download_batch(cmgpu_ctx *c, char *r1, uint32_t *o1, char *
 // ---------------------------------------------------------------------------------------
 // kernel-only measurement of the index probe
 // ---------------------------------------------------------------------------------------
+static int probe_bench_impl(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, int repeat, int variant, double *avg_ms,
+                            uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences);
 extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, int repeat, double *avg_ms,
                                  uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences) {
+  return probe_bench_impl(c, hashes, n, repeat, 0, avg_ms, probe_steps, hits, occurrences);
+}
+extern "C" int cmgpu_probe_bench_variant(cmgpu_ctx *c, uint64_t n, int repeat, int lookups_per_lane, int pair_prefetch, double *avg_ms,
+                                         uint64_t *probe_steps, uint64_t *hits) {
+  if (lookups_per_lane != 1 && lookups_per_lane != 2 && lookups_per_lane != 4 && lookups_per_lane != 8) return CMGPU_EINVAL;
+  return probe_bench_impl(c, nullptr, n, repeat, lookups_per_lane | (pair_prefetch ? 16 : 0), avg_ms, probe_steps, hits, nullptr);
+}
+static int probe_bench_impl(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, int repeat, int variant, double *avg_ms,
+                            uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences) {
   if (!c || n == 0 || n > 0xffffff00ull || repeat < 1) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
   if (hashes) {
@@ -705,14 +838,14 @@ extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t 
   // warm-up + counted launch
   if (c->partials.ensure(cm_probe_partial_words((uint32_t)n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
   cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
-                    (uint8_t *)c->pr_kind.p, (uint32_t)n, c->partials.p, ctr + CM_ST_PROBE_STEPS, s);
+                    (uint8_t *)c->pr_kind.p, (uint32_t)n, c->partials.p, ctr + CM_ST_PROBE_STEPS, s, variant);
   unsigned long long h[CM_ST_N];
   HIPCHECK(c, hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, s));
   HIPCHECK(c, cm_stream_sync(s));
   HIPCHECK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < repeat; ++i)
     cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
-                      (uint8_t *)c->pr_kind.p, (uint32_t)n, nullptr, nullptr, s);
+                      (uint8_t *)c->pr_kind.p, (uint32_t)n, nullptr, nullptr, s, variant);
   HIPCHECK(c, hipEventRecord(c->ev[1], s));
   HIPCHECK(c, hipEventSynchronize(c->ev[1]));
   float ms = 0;
@@ -802,45 +935,69 @@ extern "C" int cmgpu_records_to_device(cmgpu_ctx *c, void *device_dst, uint64_t 
 }
 
 // ---------------------------------------------------------------------------------------
-// HBM random-gather microbenchmark on the resident table (the measured
-// ceiling the probe kernel is compared with): n independent 16-byte loads at
-// pseudo-random bucket indices, 4 per thread in flight.
+// HBM random-gather microbenchmark on the resident table (the measured ceiling the
+// probe kernel is compared with): n independent accesses at pseudo-random buckets, LOADS of them
+// requested back to back per lane before any is used.  WIDE = false: one 16-byte bucket per access;
+// WIDE = true: the whole 64-byte sector around it (four 16-byte loads), i.e. every fetched byte used.
 // ---------------------------------------------------------------------------------------
+template <int LOADS, bool WIDE>
 __global__ __launch_bounds__(256) void k_gather(const uint64_t *__restrict__ bkt, uint32_t bmask, uint64_t n,
                                                 uint64_t seed, unsigned long long *__restrict__ sink) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t acc = 0;
+  ulonglong2 kv[LOADS * (WIDE ? 4 : 1)];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t i = t * 4 + j;
-    if (i < n) {
-      uint64_t x = (i + seed) * 0x9E3779B97F4A7C15ull;
-      x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-      const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)((uint32_t)x & bmask));
-      acc ^= kv.x + kv.y;
+  for (int j = 0; j < LOADS; ++j) {
+    const uint64_t i = t * LOADS + j;
+    uint64_t x = (i + seed) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    const uint32_t b = (uint32_t)x & bmask;
+    if (WIDE) {
+      const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)(b & ~3u));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kv[4 * j + q] = i < n ? p[q] : make_ulonglong2(0, 0);
+    } else {
+      kv[j] = i < n ? *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)b) : make_ulonglong2(0, 0);
     }
   }
+#pragma unroll
+  for (int j = 0; j < LOADS * (WIDE ? 4 : 1); ++j) acc ^= kv[j].x + kv[j].y;
   if (acc == 0x123456789abcdefull) atomicAdd(sink, 1ull);  // keeps the loads alive
 }
 
-extern "C" int cmgpu_gather_bench(cmgpu_ctx *c, uint64_t n, int repeat, double *avg_ms) {
-  if (!c || n == 0 || repeat < 1 || !avg_ms) return CMGPU_EINVAL;
+template <int LOADS, bool WIDE>
+static void gather_launch(cmgpu_ctx *c, uint64_t n, uint64_t seed) {
+  const unsigned blocks = (unsigned)((n + 256ull * LOADS - 1) / (256ull * LOADS));
+  hipLaunchKernelGGL((k_gather<LOADS, WIDE>), dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->bkt.p, c->bmask, n, seed,
+                     (unsigned long long *)c->stats.p + CM_ST_N - 1);
+}
+static bool gather_dispatch(cmgpu_ctx *c, uint64_t n, uint64_t seed, int loads, int wide) {
+#define CM_G(L_) if (loads == L_) { if (wide) gather_launch<L_, true>(c, n, seed); else gather_launch<L_, false>(c, n, seed); return true; }
+  CM_G(1) CM_G(2) CM_G(4) CM_G(8)
+  if (loads == 16 && !wide) { gather_launch<16, false>(c, n, seed); return true; }
+#undef CM_G
+  return false;
+}
+
+// loads_per_lane 1 / 2 / 4 / 8 / 16 (16 only with 16-byte accesses); access_bytes 16 or 64
+extern "C" int cmgpu_gather_sweep(cmgpu_ctx *c, uint64_t n, int repeat, int loads_per_lane, int access_bytes, double *avg_ms) {
+  if (!c || n == 0 || repeat < 1 || !avg_ms || (access_bytes != 16 && access_bytes != 64)) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
   hipStream_t s = c->stream;
-  const unsigned blocks = (unsigned)((n + 1023) / 1024);
-  hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, s, (const uint64_t *)c->bkt.p, c->bmask, n, 1ull,
-                     (unsigned long long *)c->stats.p + CM_ST_N - 1);
+  if (!gather_dispatch(c, n, 1ull, loads_per_lane, access_bytes == 64)) { cm_set_error(c, "unsupported gather shape"); return CMGPU_EINVAL; }
   HIPCHECK(c, cm_stream_sync(s));
   HIPCHECK(c, hipEventRecord(c->ev[0], s));
-  for (int i = 0; i < repeat; ++i)
-    hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, s, (const uint64_t *)c->bkt.p, c->bmask, n, (uint64_t)(i + 2) * 7919ull,
-                       (unsigned long long *)c->stats.p + CM_ST_N - 1);
+  for (int i = 0; i < repeat; ++i) gather_dispatch(c, n, (uint64_t)(i + 2) * 7919ull, loads_per_lane, access_bytes == 64);
   HIPCHECK(c, hipEventRecord(c->ev[1], s));
   HIPCHECK(c, hipEventSynchronize(c->ev[1]));
   float ms = 0;
   HIPCHECK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
   *avg_ms = ms / repeat;
   return CMGPU_OK;
+}
+
+extern "C" int cmgpu_gather_bench(cmgpu_ctx *c, uint64_t n, int repeat, double *avg_ms) {
+  return cmgpu_gather_sweep(c, n, repeat, 4, 16, avg_ms);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -897,6 +1054,27 @@ static int bc_abundance_run(cmgpu_ctx *c, const uint8_t *dbases, const uint32_t 
   }
   c->wl_num_sample = ns;
   return rc;
+}
+
+// whitelist table with the abundances of the pre-pass, copied from another context (the contexts of a multi-GPU run:
+// the pre-pass streams the barcode file through one GPU, every GPU corrects barcodes against the same counts)
+extern "C" int cmgpu_copy_whitelist(cmgpu_ctx *dst, cmgpu_ctx *src) {
+  if (!dst || !src || src->wl_size == 0) return CMGPU_EINVAL;
+  const size_t bytes = ((size_t)src->wl_mask + 1) * 16;
+  std::vector<uint64_t> tab(bytes / 8);
+  std::vector<double> pw(81);
+  HIPCHECK(src, cm_enter(src));
+  HIPCHECK(src, hipMemcpy(tab.data(), src->wl.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHECK(src, hipMemcpy(pw.data(), src->pow10_tab.p, pw.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHECK(dst, cm_enter(dst));
+  if (dst->wl.ensure(bytes) || dst->pow10_tab.ensure(pw.size() * 8) || dst->wl_num.ensure(8)) { cm_set_error(dst, "out of device memory (whitelist)"); return CMGPU_ENOMEM; }
+  HIPCHECK(dst, hipMemcpy(dst->wl.p, tab.data(), bytes, hipMemcpyHostToDevice));
+  HIPCHECK(dst, hipMemcpy(dst->pow10_tab.p, pw.data(), pw.size() * 8, hipMemcpyHostToDevice));
+  const unsigned long long ns = src->wl_num_sample;
+  HIPCHECK(dst, hipMemcpy(dst->wl_num.p, &ns, 8, hipMemcpyHostToDevice));
+  dst->wl_mask = src->wl_mask; dst->wl_size = src->wl_size; dst->bc_len = src->bc_len; dst->wl_num_sample = src->wl_num_sample;
+  dst->skip_barcode_check = src->skip_barcode_check;
+  return CMGPU_OK;
 }
 
 extern "C" int cmgpu_set_barcode_check(cmgpu_ctx *c, int enabled) {

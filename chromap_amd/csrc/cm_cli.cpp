@@ -46,7 +46,13 @@ struct FastxReader {
   }
   // one FASTQ/FASTA record: name up to the first whitespace, sequence, quality (may be empty)
   std::string pending;
+  // like SequenceBatch::LoadOneSequenceAndSaveAt (sequence_batch.cc:22-62): a record with an empty sequence is skipped, per stream
   bool record(std::string &name, std::string &seq, std::string &qual) {
+    while (record_any(name, seq, qual))
+      if (!seq.empty()) return true;
+    return false;
+  }
+  bool record_any(std::string &name, std::string &seq, std::string &qual) {
     std::string ln;
     for (;;) {
       if (!pending.empty()) { ln.swap(pending); pending.clear(); }
@@ -91,7 +97,8 @@ struct ChunkReader {
     while (len < target && !eof) {
       const size_t want = target - len < (1u << 30) ? target - len : (1u << 30);
       const int r = gzread(f, buf.data() + len, (unsigned)want);
-      if (r <= 0) eof = true; else len += (size_t)r;
+      if (r < 0) { int en = 0; const char *msg = gzerror(f, &en); die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + (msg ? msg : "read error") + ")"); }
+      if (r == 0) eof = true; else len += (size_t)r;
     }
   }
   void consume(size_t used) {
@@ -149,7 +156,8 @@ struct Args {
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false, skip_bc_check = false;
   size_t chunk_bytes = 256u << 20;
   ReadFormat fmt[3];  // read 1, read 2, barcode
-  int k = 17, w = 7, device = 0;
+  int k = 17, w = 7, device = 0, gpus = 1;
+  bool force_exchange = false;
   uint32_t batch_pairs = 4000000;  // multiple of the reference's 500000-pair read batch
 };
 
@@ -247,6 +255,8 @@ static Args parse(int argc, char **argv) {
     else if (o == "--chr-order") a.chr_order_path = need("--chr-order");
     else if (o == "--pairs-natural-chr-order") a.pairs_order_path = need("--pairs-natural-chr-order");
     else if (o == "--device") a.device = atoi(need("--device"));
+    else if (o == "--gpus") a.gpus = atoi(need("--gpus"));           // one context + host thread per GPU, records exchanged to chromosome owners
+    else if (o == "--force-exchange") a.force_exchange = true;      // the multi-GPU code path with one GPU
     else if (o == "--host-ingest") a.host_ingest = true;   // kseq-style host parser (FASTA / multi-line records)
     else if (o == "--ingest-chunk-mb") a.chunk_bytes = (size_t)atol(need("--ingest-chunk-mb")) << 20;
     else if (o == "--batch-pairs") a.batch_pairs = (uint32_t)atol(need("--batch-pairs"));
@@ -263,6 +273,10 @@ static Args parse(int argc, char **argv) {
     if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
     a.p.output_format = CMGPU_FORMAT_SAM;
   }
+  // the reference accepts these combinations; this build has no record type for them -- refuse instead of writing garbage
+  if (a.out_pairs && !a.p.split_alignment) die("--pairs without --split-alignment (or --preset hic) is outside this build");
+  if (a.out_pairs && !a.bc.empty()) die("pairs output with cell barcodes is outside this build");
+  if (a.gpus < 1 || a.gpus > 64) die("--gpus must be 1..64");
   if (a.batch_pairs < 500000) a.batch_pairs = 500000;
   a.batch_pairs -= a.batch_pairs % 500000;
   return a;
@@ -297,8 +311,14 @@ int main(int argc, char **argv) {
   cmgpu_index_view idx;
   if (cmgpu_load_index_file(a.index_path.c_str(), &idx) != 0) die("Cannot read index " + a.index_path);
   fprintf(stderr, "Kmer size: %d, window size: %d.\n", idx.kmer_size, idx.window_size);
-  cmgpu_ctx *ctx = nullptr;
-  if (cmgpu_create(&idx, &ref, &a.p, a.device, &ctx) != CMGPU_OK) die(cmgpu_last_error(nullptr));
+  // one context (index + reference resident, own streams) per GPU; ctx = the first one, which also runs every single-GPU path
+  const bool exchange = a.gpus > 1 || a.force_exchange;
+  if (exchange && (a.out_pairs || a.out_sam || a.host_ingest))
+    die("--gpus > 1 needs BED / TagAlign output and device-side FASTQ ingest (pairs and SAM records are post-processed on the host)");
+  std::vector<cmgpu_ctx *> ctxs((size_t)a.gpus, nullptr);
+  for (int gi = 0; gi < a.gpus; ++gi)
+    if (cmgpu_create(&idx, &ref, &a.p, a.device + gi, &ctxs[gi]) != CMGPU_OK) die(cmgpu_last_error(nullptr));
+  cmgpu_ctx *ctx = ctxs[0];
   cmgpu_free_host_index(&idx);
   // --chr-order (Chromap::GenerateCustomRidRanks, chromap.cc:867-913): ranks from the listed names, unlisted
   // sequences follow in reference order; names / lengths for the writers are permuted the same way
@@ -325,7 +345,7 @@ int main(int argc, char **argv) {
   };
   if (!a.chr_order_path.empty()) {
     const std::vector<uint32_t> rank = ranks_from_file(a.chr_order_path, out_names);
-    if (cmgpu_set_chr_order(ctx, rank.data(), ref.n_sequences) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    for (cmgpu_ctx *cx : ctxs) if (cmgpu_set_chr_order(cx, rank.data(), ref.n_sequences) != CMGPU_OK) die(cmgpu_last_error(cx));
     for (uint32_t i = 0; i < ref.n_sequences; ++i) { out_names[rank[i]] = ref.names[i]; out_lengths[rank[i]] = ref.lengths[i]; }
   }
   std::vector<uint32_t> pairs_rank;  // over the (possibly reordered) sequences, like the reference computes it
@@ -344,11 +364,16 @@ int main(int argc, char **argv) {
   double t_read = 0, t_parse = 0, t_map = 0, t_post = 0;
   const double t_begin = now_s();
   if (barcoded && a.out_sam && !a.translate_path.empty()) die("--SAM with --barcode-translate is outside this build");
-  if (a.skip_bc_check) cmgpu_set_barcode_check(ctx, 0);
-  for (int m = 0; m < 3; ++m)
-    if (!a.fmt[m].identity() &&
-        cmgpu_fastq_set_format(ctx, m, (int)a.fmt[m].starts.size(), a.fmt[m].starts.data(), a.fmt[m].ends.data(), a.fmt[m].strand) != CMGPU_OK)
-      die("bad --read-format");
+  for (cmgpu_ctx *cx : ctxs) {
+    if (a.skip_bc_check) cmgpu_set_barcode_check(cx, 0);
+    for (int m = 0; m < 3; ++m)
+      if (!a.fmt[m].identity() &&
+          cmgpu_fastq_set_format(cx, m, (int)a.fmt[m].starts.size(), a.fmt[m].starts.data(), a.fmt[m].ends.data(), a.fmt[m].strand) != CMGPU_OK)
+        die("bad --read-format");
+  }
+  if (exchange) {  // records travel to the contexts that own their chromosomes (RCCL over xGMI, issued by the library)
+    if (cmgpu_exchange_init_all(ctxs.data(), a.gpus) != CMGPU_OK) die(cmgpu_last_error(ctxs[0]));
+  }
   const bool device_ingest = !a.out_pairs && !a.out_sam && !a.host_ingest;  // pairs / SAM output need read names (and qualities): host parser
   // --SAM: everything the final sort needs, over all batches
   std::vector<cmgpu_sam_record> sam_rec;
@@ -409,7 +434,28 @@ int main(int argc, char **argv) {
       br.close();
       }
       fprintf(stderr, "Loaded %u barcodes.\nCompute barcode abundance using %llu.\n", nk, (unsigned long long)ns);
+      for (size_t gi = 1; gi < ctxs.size(); ++gi) ck(cmgpu_copy_whitelist(ctxs[gi], ctx));
     }
+    // Batches are dealt to the contexts in turn; a context maps its batch on its own host thread while the next
+    // batch is read and parsed for the next context.  With more than one context a round ends with the record
+    // exchange (collective: every context takes part, with an empty batch when the input ran out).
+    const size_t NG = ctxs.size();
+    std::vector<std::thread> workers(NG);
+    std::vector<char> busy(NG, 0);
+    std::vector<int> wrc(NG, CMGPU_OK);
+    std::vector<cmgpu_stats> wst(NG);
+    for (cmgpu_stats &x : wst) memset(&x, 0, sizeof(x));
+    size_t turn = 0;
+    auto finish_round = [&]() {
+      for (size_t gi = 0; gi < NG; ++gi) if (busy[gi]) { workers[gi].join(); busy[gi] = 0; }
+      for (size_t gi = 0; gi < NG; ++gi) if (wrc[gi] != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));
+      if (exchange) {
+        for (size_t gi = 0; gi < NG; ++gi) workers[gi] = std::thread([&, gi]() { wrc[gi] = cmgpu_exchange_step(ctxs[gi], nullptr, nullptr); });
+        for (size_t gi = 0; gi < NG; ++gi) workers[gi].join();
+        for (size_t gi = 0; gi < NG; ++gi) if (wrc[gi] != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));
+      }
+      turn = 0;
+    };
     for (size_t fi = 0; fi < a.r1.size(); ++fi) {
       ChunkReader rd[3];
       const int ns_streams = 1 + (paired ? 1 : 0) + (barcoded ? 1 : 0);
@@ -430,11 +476,13 @@ int main(int argc, char **argv) {
         }
         t_read += now_s() - t0;
         t0 = now_s();
+        cmgpu_ctx *cx = ctxs[turn];
+        auto ckx = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(cx)); };
         for (int m = 0; m < ns_streams; ++m) {
           all_final = all_final && rd[m].eof;
-          const int rc = cmgpu_fastq_scan(ctx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
-          if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(ctx)) + " -- rerun with --host-ingest");
-          ck(rc);
+          const int rc = cmgpu_fastq_scan(cx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
+          if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(cx)) + " -- rerun with --host-ingest");
+          ckx(rc);
         }
         uint32_t n = cnt[0];
         for (int m = 1; m < ns_streams; ++m) n = cnt[m] < n ? cnt[m] : n;
@@ -448,15 +496,23 @@ int main(int argc, char **argv) {
         }
         for (int m = 0; m < ns_streams; ++m) {
           uint64_t used = 0;
-          ck(cmgpu_fastq_take(ctx, sid[m], n, &used));
+          ckx(cmgpu_fastq_take(cx, sid[m], n, &used));
           rd[m].consume((size_t)used);
         }
-        ck(cmgpu_fastq_commit(ctx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));
+        ckx(cmgpu_fastq_commit(cx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));
         t_parse += now_s() - t0;
         t0 = now_s();
-        uint64_t k = 0;
-        ck(cmgpu_map_resident(ctx, &k, &st));
-        ck(cmgpu_store_append_resident(ctx, nullptr));
+        {
+          const size_t gi = turn;
+          workers[gi] = std::thread([&, gi, cx]() {
+            uint64_t k = 0;
+            int rc = cmgpu_map_resident(cx, &k, &wst[gi]);
+            if (rc == CMGPU_OK && !exchange) rc = cmgpu_store_append_resident(cx, nullptr);
+            wrc[gi] = rc;
+          });
+          busy[gi] = 1;
+        }
+        if (++turn == NG) finish_round();
         t_map += now_s() - t0;
         num_reads += paired ? 2ull * n : n;
         next_read_id += n;
@@ -466,6 +522,16 @@ int main(int argc, char **argv) {
         if (!rd[m].only_whitespace()) die("Didn't reach the end of sequence file, which might be corrupted!");
         rd[m].close();
       }
+    }
+    {
+      const double t0 = now_s();
+      if (turn > 0 || exchange) finish_round();  // the last, partial round (empty batches for the contexts beyond it)
+      t_map += now_s() - t0;
+    }
+    for (const cmgpu_stats &x : wst) {
+      st.num_candidates += x.num_candidates; st.num_mappings += x.num_mappings; st.num_mapped_reads += x.num_mapped_reads;
+      st.num_uniquely_mapped_reads += x.num_uniquely_mapped_reads; st.num_barcode_in_whitelist += x.num_barcode_in_whitelist;
+      st.num_corrected_barcode += x.num_corrected_barcode;
     }
   } else {
     // single-cell: whitelist + abundance pre-pass over the whole barcode file (chromap.h:750-761)
@@ -478,7 +544,7 @@ int main(int argc, char **argv) {
         std::string nm, sq, ql;
         std::vector<char> bb;
         std::vector<uint32_t> bo(1, 0);
-        while (br.record(nm, sq, ql)) { if (sq.empty()) continue; a.fmt[2].apply(sq, ql); bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
+        while (br.record(nm, sq, ql)) { a.fmt[2].apply(sq, ql); bb.insert(bb.end(), sq.begin(), sq.end()); bo.push_back((uint32_t)bb.size()); }
         br.close();
         if (bo.size() < 2) { if (bi == 0) die("empty barcode file"); continue; }
         if (bi == 0) {
@@ -510,7 +576,6 @@ int main(int argc, char **argv) {
           const bool gb = barcoded ? fb.record(nb, sb, qb) : g1;
           if (!g1 && !g2 && !gb) { more = false; break; }
           if (!(g1 && g2 && gb)) die("Numbers of reads and barcodes don't match!");
-          if (s1.empty() || (paired && s2.empty())) continue;
           a.fmt[0].apply(s1, q1);
           if (paired) a.fmt[1].apply(s2, q2);
           if (barcoded) a.fmt[2].apply(sb, qb);
@@ -526,6 +591,7 @@ int main(int argc, char **argv) {
             if (paired) {
               q2.resize(s2.size(), 'I');
               sam_names2.push_back(n2); sam_b2.insert(sam_b2.end(), s2.begin(), s2.end()); sam_q2.insert(sam_q2.end(), q2.begin(), q2.end());
+              if (sam_b2.size() > 0xfffffff0ull) die("--SAM holds all reads of a run in host memory with 32-bit offsets: input too large");
               sam_o2.push_back((uint32_t)sam_b2.size());
             }
           }
@@ -632,8 +698,22 @@ int main(int argc, char **argv) {
                      : a.out_tagalign && barcoded ? CMGPU_TEXT_TAGALIGN_SE_BC
                      : barcoded ? (paired ? CMGPU_TEXT_BED_PE_BC : CMGPU_TEXT_BED_SE_BC) : paired ? CMGPU_TEXT_BED_PE : CMGPU_TEXT_BED_SE;
     const double t0 = now_s();
-    if (cmgpu_store_format(ctx, kind, out_names.data(), ref.n_sequences, &a.p, bc_len, &nl, &nbytes) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    {
+      // every context sorts, de-duplicates and renders the chromosomes it owns (all of them with one context)
+      std::vector<std::thread> th(ctxs.size());
+      std::vector<int> rcs(ctxs.size(), CMGPU_OK);
+      std::vector<uint64_t> nls(ctxs.size(), 0), nbs(ctxs.size(), 0);
+      for (size_t gi = 0; gi < ctxs.size(); ++gi)
+        th[gi] = std::thread([&, gi]() { rcs[gi] = cmgpu_store_format(ctxs[gi], kind, out_names.data(), ref.n_sequences, &a.p, bc_len, &nls[gi], &nbs[gi]); });
+      for (size_t gi = 0; gi < ctxs.size(); ++gi) th[gi].join();
+      for (size_t gi = 0; gi < ctxs.size(); ++gi) {
+        if (rcs[gi] != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));
+        nl += nls[gi];
+        nbytes += nbs[gi];
+      }
+    }
     const double t1 = now_s();
+    if (ctxs.size() > 1 && barcoded && !a.translate_path.empty()) die("--barcode-translate with --gpus > 1 is outside this build");
     if (barcoded && !a.translate_path.empty() && (kind == CMGPU_TEXT_BED_PE_BC || kind == CMGPU_TEXT_BED_SE_BC)) {
       // --barcode-translate (BarcodeTranslator, barcode_translator.h:43-101): the device rendered the corrected barcodes;
       // column 4 is rewritten on the way to the file.  Table lines are "to<TAB or ,>from"; a barcode made of several
@@ -685,7 +765,11 @@ int main(int argc, char **argv) {
       }
       if (!outb.empty()) fwrite(outb.data(), 1, outb.size(), of);
       fclose(of);
-    } else if (cmgpu_store_write_text(ctx, a.out_path.c_str(), 0) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    } else {
+      // sections in rank order: the owners hold contiguous, increasing chromosome ranges
+      for (size_t gi = 0; gi < ctxs.size(); ++gi)
+        if (cmgpu_store_write_text(ctxs[gi], a.out_path.c_str(), gi ? 1 : 0) != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));
+    }
     t_post = now_s() - t0;
     fprintf(stderr, "Sorted, deduplicated and formatted %llu bytes on the device in %.3fs, wrote them in %.3fs.\n", (unsigned long long)nbytes,
             t1 - t0, now_s() - t1);
@@ -696,7 +780,7 @@ int main(int argc, char **argv) {
   if (device_ingest)
     fprintf(stderr, "Mapped all reads in %.2fs (file read + inflate %.2fs, H2D + device FASTQ parse %.2fs, mapping %.2fs, post-processing + write %.2fs).\n",
             now_s() - t_begin, t_read, t_parse, t_map, t_post);
-  cmgpu_destroy(ctx);
+  for (cmgpu_ctx *cx : ctxs) cmgpu_destroy(cx);
   cmgpu_free_host_ref(&ref);
   return 0;
 }

@@ -35,6 +35,26 @@ struct CmFqStream {
   bool minus = false;
 };
 
+// multi-GPU record exchange (cm_exchange.hip): this context's place in a group of `world` contexts, one per GPU
+struct CmExchange {
+  int transport = 0;        // 0: none, 1: RCCL (library-owned communicator on the mapping stream), 2: caller-provided callbacks
+  int rank = 0, world = 0;
+  void *comm = nullptr;     // ncclComm_t
+  cmgpu_exchange_transport ext = {};
+  std::vector<uint8_t> h_owner;   // owner rank of every rid (length-weighted, contiguous rid ranges)
+  DevBuf owner, send, counts /* counts[64], cursors[64], matrix[64*64] */, stage;
+  unsigned long long *h_matrix = nullptr;  // pinned, world*world
+  uint64_t sent_total = 0, recv_total = 0, steps = 0;
+};
+
+// a parked resident batch (cmgpu_swap_resident_batch): the measurement rotates several distinct batches
+#define CM_BATCH_SLOTS 8
+struct CmBatchSlot {
+  DevBuf rb0, rb1, ro0, ro1;
+  uint32_t n_pairs = 0, first_read_id = 0, max_read_len = 1;
+  size_t bases0 = 0, bases1 = 0;
+};
+
 struct cmgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -83,6 +103,15 @@ struct cmgpu_ctx {
   DevBuf mm_cursor;  // k_prep_mm: next free entry of the dense minimizer arrays
   DevBuf mm_marks;   // cursor after every chunk of pairs: the range of minimizers a chunk's probe launch covers
   DevBuf part_cnt;  // cmgpu_records_partition: per-owner counts and cursors
+  CmExchange ex;
+  bool batch_exchanged = false;  // the resident batch's records have been through cmgpu_exchange_step
+  CmBatchSlot slots[CM_BATCH_SLOTS];
+  // cmgpu_set_option
+  int opt_probe_variant = 4 | 16;  // lookups per lane | 16: second probe step requested with the first
+  int opt_mm_chunks = CM_MM_CHUNKS;
+  int opt_prep_kernel = 1;         // 1: position-parallel minimizer kernel where it applies, 0: lane-per-read kernels
+  uint64_t opt_item_limit = 0xfffffff0ull;
+  std::vector<uint32_t> h_rank;  // --chr-order: rank of every index rid (host copy of rid_rank)
   uint64_t sam_slots = 0;
   uint32_t sam_md_cap = 0;
   // one batch in flight (cmgpu_map_pairs_async / cmgpu_wait)
@@ -101,6 +130,7 @@ struct cmgpu_ctx {
   std::vector<DevBuf *> all_bufs() {
     std::vector<DevBuf *> v = core_bufs();
     for (CmFqStream &f : fq) for (DevBuf *b : {&f.text, &f.cnt, &f.off, &f.nl, &f.keep, &f.pos, &f.recidx, &f.len, &f.bad}) v.push_back(b);
+    for (CmBatchSlot &sl : slots) for (DevBuf *b : {&sl.rb0, &sl.rb1, &sl.ro0, &sl.ro1}) v.push_back(b);
     return v;
   }
   std::vector<DevBuf *> core_bufs() {
@@ -109,7 +139,8 @@ struct cmgpu_ctx {
             &hit_off, &round2, &rep_cnt, &rep_len, &hbuf, &hcnt, &n_pos_hit, &ncp, &ncn, &aug, &res_neg, &res_pos,
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
-            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank};
+            &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
+            &ex.owner, &ex.send, &ex.counts, &ex.stage};
   }
 };
 
@@ -130,6 +161,14 @@ static inline hipError_t cm_stream_sync(hipStream_t s) {
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id);
 void cm_fill_dev(cmgpu_ctx *c, CmDev &d);
 int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref);
+// cm_post.hip: room for `need` records in the device-side store (with_bc: the parallel barcode array too)
+int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc);
+// cm_post.hip: n 32-byte {record, barcode} entries -> the store's record / barcode arrays at position store_n
+void cm_store_split_bc(cmgpu_ctx *c, const void *in32, uint64_t n, hipStream_t s);
+// cm_exchange.hip
+void cm_exchange_release(cmgpu_ctx *c);
+// owner rank of every sequence for `world` ranks: contiguous rid ranges of (nearly) equal total length
+std::vector<uint8_t> cm_owner_table(const cmgpu_ctx *c, uint32_t world);
 
 static inline uint32_t cm_num_chunks_host(uint32_t n, uint32_t ref_batch, uint32_t grain) {
   uint32_t tot = 0;

@@ -12,8 +12,8 @@ bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len);
 uint32_t cm_prep_mm_pairs_per_block(const CmDev &d, uint32_t max_read_len);
 void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
                          unsigned long long *cursor, hipStream_t s);
-uint32_t cm_probe_range_blocks(uint64_t max_entries);
-void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s);
+uint32_t cm_probe_range_blocks(uint64_t max_entries, int variant);
+void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s, int variant);
 void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
@@ -33,10 +33,11 @@ void cm_launch_k_bc_abundance(const uint8_t *bcb, const uint32_t *bco, uint32_t 
                               unsigned long long *num_sample, hipStream_t s);
 size_t cm_probe_partial_words(uint32_t n);
 void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,
-                       uint32_t n, void *partials, unsigned long long *counters, hipStream_t s);
+                       uint32_t n, void *partials, unsigned long long *counters, hipStream_t s, int variant = 0);
 size_t cm_stats_partial_words(uint32_t n);
 void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials, hipStream_t s);
 
+void cm_launch_k_sum_u32(const uint32_t *in, uint32_t n, unsigned long long *out, hipStream_t s);
 size_t cm_scan_tmp_words(uint32_t n);
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
 void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, hipStream_t s);

@@ -274,61 +274,100 @@ __global__ __launch_bounds__(CM_BLOCK) void k_bc_abundance(const uint8_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------
-// The index-probe kernel (graded roofline kernel): one minimizer per thread, dependent
-// 16-byte bucket gathers from the HBM-resident table; memory-level parallelism comes from
-// the number of resident waves.  Probe steps are reduced per wave before the atomic.
+// The index-probe kernel (graded roofline kernel).  A lookup is a chain of dependent 16-byte bucket
+// gathers from the HBM-resident table (kh_get's triangular probing, 1.7 buckets per lookup on the
+// GRCh38-sized table); what bounds it is how many of them the memory system has in flight.  With one
+// lookup per lane a wave issues 64 gathers, then waits on the few lanes that need a second, third, ...
+// bucket while its other lanes idle.  Here every lane carries U independent lookups:
+//   * the U first buckets are requested back to back (U gathers in flight per lane);
+//   * bucket i+1 -- the second probe step -- is requested together with bucket i whenever both lie in one
+//     64-byte sector (i mod 4 != 3): no extra HBM traffic, and 3 of 4 second steps no longer cost a
+//     dependent round trip;
+//   * the remaining steps of the U lookups advance together, one gather per unfinished lookup per round.
+// A block covers U*256 consecutive minimizers, lane t takes t, t+256, ...: loads and stores stay coalesced.
+// Results (hit / miss, value, number of buckets visited) are kh_get's, bucket for bucket.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CM_BLOCK) void k_probe(const uint64_t *__restrict__ bkt, uint32_t bmask,
-                                                     const uint64_t *__restrict__ hash, uint64_t *__restrict__ val,
-                                                     uint8_t *__restrict__ kind, uint32_t n,
-                                                     uint2 *__restrict__ block_partials) {
-  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  uint32_t steps = 0, hit = 0;
-  if (i < n) {
-    uint64_t v;
-    uint8_t kd;
-    steps = cm_probe(bkt, bmask, hash[i], &v, &kd);
-    val[i] = v;
-    kind[i] = kd;
-    hit = kd != CM_PR_MISS;
+#define CM_PROBE_U 4
+template <int U, bool PAIR>
+__device__ __forceinline__ void cm_probe_lanes(const uint64_t *__restrict__ bkt, uint32_t bmask, const uint64_t *__restrict__ hash,
+                                               uint64_t *__restrict__ val, uint8_t *__restrict__ kind, unsigned long long lo,
+                                               unsigned long long hi, unsigned long long tile0, uint32_t *steps_out, uint32_t *hits_out) {
+  uint64_t h[U], v[U];
+  uint32_t idx[U], first[U], step[U];
+  uint8_t kd[U];
+  bool live[U];
+  uint32_t visited = 0, hits = 0;
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    const unsigned long long i = tile0 + (unsigned long long)j * CM_BLOCK + threadIdx.x;
+    live[j] = i >= lo && i < hi;
+    h[j] = live[j] ? hash[i] : 0;
+    idx[j] = (uint32_t)h[j] & bmask;
+    first[j] = idx[j];
+    step[j] = 0;
+    v[j] = 0;
+    kd[j] = CM_PR_MISS;
   }
-  if (block_partials) {
-    // probe-step accounting: wave reduction, then one plain store per block (a single
-    // device-scope counter would serialise ~10 ns per atomic)
-    __shared__ uint32_t sh_s[CM_BLOCK / 64], sh_h[CM_BLOCK / 64];
-    for (int off = 32; off > 0; off >>= 1) {
-      steps += __shfl_down(steps, off, 64);
-      hit += __shfl_down(hit, off, 64);
+  // round 0: bucket i and, when it shares the sector, bucket i+1 (= probe step 1)
+  {
+    ulonglong2 a[U], b[U];
+    bool two[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      two[j] = PAIR && live[j] && (idx[j] & 3u) != 3u && idx[j] != bmask;
+      if (live[j]) a[j] = *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)idx[j]);
+      if (two[j]) b[j] = *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)idx[j] + 2);
     }
-    if ((threadIdx.x & 63) == 0) { sh_s[threadIdx.x >> 6] = steps; sh_h[threadIdx.x >> 6] = hit; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t a = 0, c = 0;
-      for (int j = 0; j < CM_BLOCK / 64; ++j) { a += sh_s[j]; c += sh_h[j]; }
-      block_partials[blockIdx.x] = make_uint2(a, c);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (!live[j]) continue;
+      ++visited;
+      if (a[j].x == CM_EMPTY_KEY) { live[j] = false; continue; }
+      if (a[j].x != CM_DELETED_KEY && (a[j].x >> 1) == h[j]) { v[j] = a[j].y; kd[j] = (a[j].x & 1) ? CM_PR_SINGLE : CM_PR_MULTI; ++hits; live[j] = false; continue; }
+      idx[j] = (idx[j] + (++step[j])) & bmask;  // step 1: bucket i+1
+      if (idx[j] == first[j]) { live[j] = false; continue; }
+      if (two[j]) {
+        ++visited;
+        if (b[j].x == CM_EMPTY_KEY) { live[j] = false; continue; }
+        if (b[j].x != CM_DELETED_KEY && (b[j].x >> 1) == h[j]) { v[j] = b[j].y; kd[j] = (b[j].x & 1) ? CM_PR_SINGLE : CM_PR_MULTI; ++hits; live[j] = false; continue; }
+        idx[j] = (idx[j] + (++step[j])) & bmask;
+        if (idx[j] == first[j]) live[j] = false;
+      }
     }
   }
+  // further rounds: one gather per unfinished lookup
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < U; ++j) any = any || live[j];
+  while (any) {
+    ulonglong2 a[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (live[j]) a[j] = *reinterpret_cast<const ulonglong2 *>(bkt + 2 * (uint64_t)idx[j]);
+    any = false;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (!live[j]) continue;
+      ++visited;
+      if (a[j].x == CM_EMPTY_KEY) { live[j] = false; continue; }
+      if (a[j].x != CM_DELETED_KEY && (a[j].x >> 1) == h[j]) { v[j] = a[j].y; kd[j] = (a[j].x & 1) ? CM_PR_SINGLE : CM_PR_MULTI; ++hits; live[j] = false; continue; }
+      idx[j] = (idx[j] + (++step[j])) & bmask;
+      if (idx[j] == first[j]) { live[j] = false; continue; }
+      any = true;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    const unsigned long long i = tile0 + (unsigned long long)j * CM_BLOCK + threadIdx.x;
+    if (i >= lo && i < hi) { val[i] = v[j]; kind[i] = kd[j]; }
+  }
+  *steps_out = visited;
+  *hits_out = hits;
 }
 
-// k_probe over the minimizers [range[0], range[1]) -- the range is only known on the device (it is where
-// the chunk's k_prep_mm launch moved the cursor), so the grid covers an upper bound and surplus blocks leave.
-__global__ __launch_bounds__(CM_BLOCK) void k_probe_range(const uint64_t *__restrict__ bkt, uint32_t bmask,
-                                                           const uint64_t *__restrict__ hash, uint64_t *__restrict__ val,
-                                                           uint8_t *__restrict__ kind, const unsigned long long *__restrict__ range,
-                                                           uint32_t cap, uint2 *__restrict__ block_partials) {
-  const unsigned long long lo = range[0];
-  unsigned long long hi = range[1];
-  if (hi > cap) hi = cap;  // overflow of the dense arrays: the host reruns with larger ones
-  const unsigned long long i = lo + (unsigned long long)blockIdx.x * CM_BLOCK + threadIdx.x;
-  uint32_t steps = 0, hit = 0;
-  if (i < hi) {
-    uint64_t v;
-    uint8_t kd;
-    steps = cm_probe(bkt, bmask, hash[i], &v, &kd);
-    val[i] = v;
-    kind[i] = kd;
-    hit = kd != CM_PR_MISS;
-  }
+// per-block (probe steps, hits): wave reduction, then one plain store per block (a single device-scope
+// counter would serialise ~10 ns per atomic)
+__device__ __forceinline__ void cm_probe_account(uint32_t steps, uint32_t hit, uint2 *__restrict__ block_partials) {
   __shared__ uint32_t sh_s[CM_BLOCK / 64], sh_h[CM_BLOCK / 64];
   for (int off = 32; off > 0; off >>= 1) {
     steps += __shfl_down(steps, off, 64);
@@ -341,6 +380,32 @@ __global__ __launch_bounds__(CM_BLOCK) void k_probe_range(const uint64_t *__rest
     for (int j = 0; j < CM_BLOCK / 64; ++j) { a += sh_s[j]; c += sh_h[j]; }
     block_partials[blockIdx.x] = make_uint2(a, c);
   }
+}
+
+template <int U, bool PAIR>
+__global__ __launch_bounds__(CM_BLOCK) void k_probe(const uint64_t *__restrict__ bkt, uint32_t bmask,
+                                                     const uint64_t *__restrict__ hash, uint64_t *__restrict__ val,
+                                                     uint8_t *__restrict__ kind, uint32_t n,
+                                                     uint2 *__restrict__ block_partials) {
+  uint32_t steps = 0, hit = 0;
+  cm_probe_lanes<U, PAIR>(bkt, bmask, hash, val, kind, 0ull, (unsigned long long)n, (unsigned long long)blockIdx.x * (U * CM_BLOCK), &steps, &hit);
+  if (block_partials) cm_probe_account(steps, hit, block_partials);
+}
+
+// k_probe over the minimizers [range[0], range[1]) -- the range is only known on the device (it is where
+// the chunk's minimizer launch moved the cursor), so the grid covers an upper bound and surplus blocks leave.
+template <int U, bool PAIR>
+__global__ __launch_bounds__(CM_BLOCK) void k_probe_range(const uint64_t *__restrict__ bkt, uint32_t bmask,
+                                                           const uint64_t *__restrict__ hash, uint64_t *__restrict__ val,
+                                                           uint8_t *__restrict__ kind, const unsigned long long *__restrict__ range,
+                                                           uint32_t cap, uint2 *__restrict__ block_partials) {
+  const unsigned long long lo = range[0];
+  unsigned long long hi = range[1];
+  if (hi > cap) hi = cap;  // overflow of the dense arrays: the host reruns with larger ones
+  uint32_t steps = 0, hit = 0;
+  const unsigned long long tile0 = lo + (unsigned long long)blockIdx.x * (U * CM_BLOCK);
+  if (tile0 < hi) cm_probe_lanes<U, PAIR>(bkt, bmask, hash, val, kind, lo, hi, tile0, &steps, &hit);
+  cm_probe_account(steps, hit, block_partials);
 }
 
 // sums k_probe's per-block partials into counters[0] (steps) and counters[1] (hits)
@@ -437,6 +502,27 @@ void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, h
   (void)rocprim::exclusive_scan((void *)tmp, bytes, in, out, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s);
 }
 
+// *out += sum of in[0..n) in 64 bits (the u32 prefix sums above wrap silently; the callers size and bound the
+// dense arrays from this total)
+__global__ __launch_bounds__(CM_BLOCK) void k_sum_u32(const uint32_t *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out) {
+  unsigned long long a = 0;
+  for (uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x; i < n; i += gridDim.x * CM_BLOCK) a += in[i];
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  __shared__ unsigned long long sa[CM_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int j = 1; j < CM_BLOCK / 64; ++j) a += sa[j];
+    if (a) atomicAdd(out, a);
+  }
+}
+void cm_launch_k_sum_u32(const uint32_t *in, uint32_t n, unsigned long long *out, hipStream_t s) {
+  if (!n) return;
+  uint32_t blocks = (n + CM_BLOCK * 8 - 1) / (CM_BLOCK * 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_sum_u32, dim3(blocks), dim3(CM_BLOCK), 0, s, in, n, out);
+}
+
 // ---------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------
@@ -513,10 +599,27 @@ void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uin
   hipLaunchKernelGGL(k_prep_mm, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor);
 }
 // probe of the minimizers [range[0], range[1]) (device-side range), at most max_entries of them
-uint32_t cm_probe_range_blocks(uint64_t max_entries) { return (uint32_t)((max_entries + CM_BLOCK - 1) / CM_BLOCK); }
-void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s) {
-  const uint32_t blocks = cm_probe_range_blocks(max_entries);
-  if (blocks) hipLaunchKernelGGL(k_probe_range, dim3(blocks), dim3(CM_BLOCK), 0, s, d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, range, cap, (uint2 *)partials);
+static inline int probe_variant_norm(int variant) {
+  if (variant == 0) variant = CM_PROBE_U + 16;
+  const int u = variant & 15;
+  return ((u == 1 || u == 2 || u == 8) ? u : 4) | (variant & 16);
+}
+uint32_t cm_probe_range_blocks(uint64_t max_entries, int variant) {
+  const uint64_t per = (uint64_t)(probe_variant_norm(variant) & 15) * CM_BLOCK;
+  return (uint32_t)((max_entries + per - 1) / per);
+}
+void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s, int variant) {
+  const uint32_t blocks = cm_probe_range_blocks(max_entries, variant);
+  if (!blocks) return;
+  variant = probe_variant_norm(variant);
+  const int u = variant & 15;
+  const bool pair = (variant & 16) != 0;
+#define CM_PROBE_CASE(U_, P_) hipLaunchKernelGGL((k_probe_range<U_, P_>), dim3(blocks), dim3(CM_BLOCK), 0, s, d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, range, cap, (uint2 *)partials)
+  if (u == 1) { if (pair) CM_PROBE_CASE(1, true); else CM_PROBE_CASE(1, false); }
+  else if (u == 2) { if (pair) CM_PROBE_CASE(2, true); else CM_PROBE_CASE(2, false); }
+  else if (u == 8) { if (pair) CM_PROBE_CASE(8, true); else CM_PROBE_CASE(8, false); }
+  else { if (pair) CM_PROBE_CASE(4, true); else CM_PROBE_CASE(4, false); }
+#undef CM_PROBE_CASE
 }
 void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s) {
   if (blocks) hipLaunchKernelGGL(k_probe_reduce, dim3(blocks / (CM_BLOCK * 8) + 1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
@@ -554,13 +657,22 @@ void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials,
   hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(CM_BLOCK), 0, s, (const unsigned long long *)partials, blocks, d.stats);
 }
 // partials: one uint2 per block (cm_probe_partial_words(n) uint2), or nullptr to skip the accounting;
-// counters[0] += probe steps, counters[1] += hits
+// counters[0] += probe steps, counters[1] += hits.  variant: lookups per lane (1, 2, 4, 8), + 16 to request the
+// second probe step together with the first when both share a sector; 0 = the pipeline's setting.
 size_t cm_probe_partial_words(uint32_t n) { return (size_t)((n + CM_BLOCK - 1) / CM_BLOCK) + 1; }
 void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash, uint64_t *val, uint8_t *kind,
-                       uint32_t n, void *partials, unsigned long long *counters, hipStream_t s) {
+                       uint32_t n, void *partials, unsigned long long *counters, hipStream_t s, int variant) {
   if (!n) return;
-  const uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
-  hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(CM_BLOCK), 0, s, bkt, bmask, hash, val, kind, n, (uint2 *)partials);
+  variant = probe_variant_norm(variant);
+  const int u = variant & 15;
+  const bool pair = (variant & 16) != 0;
+  const uint32_t blocks = (n + u * CM_BLOCK - 1) / (u * CM_BLOCK);
+#define CM_PROBE_CASE(U_, P_) hipLaunchKernelGGL((k_probe<U_, P_>), dim3(blocks), dim3(CM_BLOCK), 0, s, bkt, bmask, hash, val, kind, n, (uint2 *)partials)
+  if (u == 1) { if (pair) CM_PROBE_CASE(1, true); else CM_PROBE_CASE(1, false); }
+  else if (u == 2) { if (pair) CM_PROBE_CASE(2, true); else CM_PROBE_CASE(2, false); }
+  else if (u == 8) { if (pair) CM_PROBE_CASE(8, true); else CM_PROBE_CASE(8, false); }
+  else { if (pair) CM_PROBE_CASE(4, true); else CM_PROBE_CASE(4, false); }
+#undef CM_PROBE_CASE
   if (partials && counters)
     hipLaunchKernelGGL(k_probe_reduce, dim3(blocks / (CM_BLOCK * 8) + 1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
 }

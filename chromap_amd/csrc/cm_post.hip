@@ -341,7 +341,7 @@ __global__ void k_pp_split_bc(const uint8_t *__restrict__ in32, uint32_t n, uint
 // ---------------------------------------------------------------------------------------
 // record store
 // ---------------------------------------------------------------------------------------
-static int store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc) {
+int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc) {
   if (need > 0xfffffff0ull) { cm_set_error(c, "record store is limited to 2^32 records"); return CMGPU_ECAPACITY; }
   if (need > c->store_cap) {
     uint64_t cap = c->store_cap ? c->store_cap * 2 : 1u << 20;
@@ -382,7 +382,7 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
   const uint32_t n = c->n_pairs;
   if (c->store_n && c->store_has_bc != c->has_barcodes) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (n) {
-    int rc = store_reserve(c, c->store_n + n, c->has_barcodes);
+    int rc = cm_store_reserve(c, c->store_n + n, c->has_barcodes);
     if (rc) return rc;
     uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
     const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
@@ -405,7 +405,7 @@ extern "C" int cmgpu_store_append(cmgpu_ctx *c, const void *records, uint64_t n,
   PPCHECK(c, cm_enter(c));
   if (c->store_n && c->store_has_bc != (barcoded != 0)) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (n == 0) return CMGPU_OK;
-  int rc = store_reserve(c, c->store_n + n, barcoded != 0);
+  int rc = cm_store_reserve(c, c->store_n + n, barcoded != 0);
   if (rc) return rc;
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (!barcoded) {
@@ -575,72 +575,10 @@ extern "C" int cmgpu_store_info(const cmgpu_ctx *c, uint64_t *n_records, uint64_
   return CMGPU_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// multi-GPU record exchange, send side: the batch's records grouped by the rank that owns their
-// chromosome (owner = rid * world / n_seq, chromap_amd/distributed.py:owned_rids) so that one
-// all-to-all delivers every record to the rank that sorts and de-duplicates its chromosomes.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pp_owner(const uint8_t *__restrict__ rec, uint32_t i, uint32_t world, uint32_t n_seq) {
-  const uint32_t rid = reinterpret_cast<const uint32_t *>(rec + (uint64_t)i * 24)[1];
-  const uint32_t k = (uint32_t)(((uint64_t)rid * world) / n_seq);
-  return k >= world ? world - 1 : k;
-}
-// pass 1: records per owner (block histogram in LDS, one global atomic per owner and block)
-__global__ __launch_bounds__(PP_BLOCK) void k_pp_owner_count(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, uint32_t n,
-                                                               uint32_t world, uint32_t n_seq, unsigned long long *__restrict__ counts) {
-  __shared__ uint32_t hist[64];
-  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
-  if (i < n && ok[i]) atomicAdd(&hist[pp_owner(rec, i, world, n_seq)], 1u);
-  __syncthreads();
-  if (threadIdx.x < world && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-}
-// pass 2: every block reserves its share of each owner's section (cursors start at the sections' first
-// records) and its threads copy their records there; the order inside a section is irrelevant (a total-order sort follows)
-__global__ __launch_bounds__(PP_BLOCK) void k_pp_owner_scatter(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, uint32_t n,
-                                                                 uint32_t world, uint32_t n_seq, unsigned long long *__restrict__ cursors,
-                                                                 uint8_t *__restrict__ dst) {
-  __shared__ uint32_t hist[64];
-  __shared__ unsigned long long base[64];
-  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
-  const bool have = i < n && ok[i];
-  uint32_t k = 0, local = 0;
-  if (have) { k = pp_owner(rec, i, world, n_seq); local = atomicAdd(&hist[k], 1u); }
-  __syncthreads();
-  if (threadIdx.x < world && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-  __syncthreads();
-  if (!have) return;
-  const uint64_t *sp = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
-  uint64_t *dp = reinterpret_cast<uint64_t *>(dst + (base[k] + local) * 24);
-  dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
-}
-
-extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *device_dst, uint64_t capacity, uint64_t *counts) {
-  if (!c || !device_dst || !counts || world == 0 || world > 64) return CMGPU_EINVAL;
-  PPCHECK(c, cm_enter(c));
-  for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
-  const uint32_t n = c->n_pairs;
-  if (n == 0) return CMGPU_OK;
-  hipStream_t s = c->stream;
-  DevBuf &dcnt = c->part_cnt;
-  if (dcnt.ensure(2 * 64 * 8)) { cm_set_error(c, "out of device memory (partition)"); return CMGPU_ENOMEM; }
-  unsigned long long *d_counts = (unsigned long long *)dcnt.p, *d_cursors = d_counts + 64;
-  PPCHECK(c, hipMemsetAsync(d_counts, 0, 64 * 8, s));
-  const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
-  hipLaunchKernelGGL(k_pp_owner_count, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, d_counts);
-  unsigned long long h[64], start[64];
-  PPCHECK(c, hipMemcpyAsync(h, d_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
-  PPCHECK(c, cm_stream_sync(s));
-  uint64_t total = 0;
-  for (uint32_t r = 0; r < world; ++r) { counts[r] = h[r]; start[r] = total; total += h[r]; }
-  if (total > capacity) { cm_set_error(c, "send buffer too small"); return CMGPU_ECAPACITY; }
-  if (total == 0) return CMGPU_OK;
-  PPCHECK(c, hipMemcpyAsync(d_cursors, start, (size_t)world * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_pp_owner_scatter, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, world, c->n_seq, d_cursors,
-                     (uint8_t *)device_dst);
-  PPCHECK(c, cm_stream_sync(s));
-  return CMGPU_OK;
+// n 32-byte {record, barcode} entries (the receive side of the multi-GPU exchange, cm_exchange.hip) -> the store's
+// record and barcode arrays at position store_n; the caller advances store_n
+void cm_store_split_bc(cmgpu_ctx *c, const void *in32, uint64_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_pp_split_bc, dim3((unsigned)((n + PP_BLOCK - 1) / PP_BLOCK)), dim3(PP_BLOCK), 0, s, (const uint8_t *)in32, (uint32_t)n,
+                     (uint8_t *)c->store.p + c->store_n * 24, (uint64_t *)c->store_bc.p + c->store_n);
 }

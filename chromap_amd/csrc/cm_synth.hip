@@ -47,11 +47,41 @@ CM_HD uint8_t sy_base(uint64_t seed, uint64_t g) {
   return (uint8_t)("ACGT"[(h >> (2 * (g & 31))) & 3]);
 }
 
+// Planted repeat families ("3 kb element x 600 copies, 2 % divergence" so that the seed-frequency
+// thresholds, multi-mapper sampling and mate rescue fire): the genome is cut into n_families * copies equal slots,
+// slot ci carries one copy of family ci % n_families at a pseudo-random offset, in either orientation, every base
+// of the copy replaced by a random one with probability `divergence`.  O(1) per position, no tables.
+struct SyRepeats {
+  uint32_t n_families, copies, element_len, div_thresh;  // div_thresh = divergence * 2^32
+  uint64_t slot;                                         // slot size in bases (0 = no repeats)
+};
+CM_HD uint8_t sy_genome_base(uint64_t seed, uint64_t g, const SyRepeats &rp) {
+  if (rp.slot) {
+    const uint64_t ci = g / rp.slot;
+    if (ci < (uint64_t)rp.n_families * rp.copies) {
+      const uint64_t hc = sy_mix(seed ^ 0xA5A5A5A5F00DULL ^ (ci * 0xC2B2AE3D27D4EB4Full));
+      const uint64_t start = ci * rp.slot + hc % (rp.slot - rp.element_len);
+      if (g >= start && g < start + rp.element_len) {
+        uint32_t within = (uint32_t)(g - start);
+        const bool rev = ((hc >> 40) & 1) != 0;
+        if (rev) within = rp.element_len - 1 - within;
+        const uint32_t fam = (uint32_t)(ci % rp.n_families);
+        uint8_t b = sy_base(seed ^ 0x5EEDFA11ull ^ ((uint64_t)(fam + 1) << 40), within);
+        if (rev) b = cm_negchar(b);
+        const uint64_t hm = sy_mix(hc ^ ((uint64_t)(g - start) * 0x9E3779B97F4A7C15ull));
+        if ((uint32_t)hm < rp.div_thresh) b = (uint8_t)("ACGT"[(hm >> 32) & 3]);
+        return b;
+      }
+    }
+  }
+  return sy_base(seed, g);
+}
+
 __global__ __launch_bounds__(SY_BLOCK) void k_sy_genome(uint8_t *ref, uint64_t ref_off, uint64_t gstart, uint32_t len,
-                                                         uint64_t seed) {
+                                                         uint64_t seed, SyRepeats rp) {
   const uint64_t i = (uint64_t)blockIdx.x * SY_BLOCK + threadIdx.x;
   if (i >= len) return;
-  ref[ref_off + i] = sy_base(seed, gstart + i);
+  ref[ref_off + i] = sy_genome_base(seed, gstart + i, rp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -221,7 +251,20 @@ static int sy_build_index(cmgpu_ctx *c) {
 
 extern "C" int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
                                       int32_t window_size, const cmgpu_params *params, int device_id, cmgpu_ctx **out) {
+  return cmgpu_create_synthetic_repeats(total_bases, n_sequences, seed, kmer_size, window_size, params, device_id, 0, 0, 0, 0.0, out);
+}
+
+extern "C" int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
+                                              int32_t window_size, const cmgpu_params *params, int device_id, uint32_t n_families,
+                                              uint32_t copies, uint32_t element_len, double divergence, cmgpu_ctx **out) {
   if (!params || !out || n_sequences == 0 || total_bases < n_sequences * 1000ull) { cm_set_error(nullptr, "bad argument"); return CMGPU_EINVAL; }
+  SyRepeats rp = {0, 0, 0, 0, 0};
+  if (n_families && copies && element_len) {
+    rp.n_families = n_families; rp.copies = copies; rp.element_len = element_len;
+    rp.div_thresh = (uint32_t)(divergence * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (divergence < 0 ? 0 : divergence * 4294967296.0));
+    rp.slot = total_bases / ((uint64_t)n_families * copies);
+    if (rp.slot < 2ull * element_len) { cm_set_error(nullptr, "repeat copies do not fit the genome (slot < 2 x element length)"); return CMGPU_EINVAL; }
+  }
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { cm_set_error(nullptr, "no HIP device available (this library has no CPU path)"); return CMGPU_ENODEVICE; }
@@ -261,7 +304,7 @@ extern "C" int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences
   for (uint32_t i = 0; e == hipSuccess && i < n_sequences; ++i) {
     const uint32_t len = c->h_ref_len[i];
     hipLaunchKernelGGL(k_sy_genome, dim3((len + SY_BLOCK - 1) / SY_BLOCK), dim3(SY_BLOCK), 0, c->stream, (uint8_t *)c->ref.p,
-                       c->h_ref_off[i], gstart[i], len, seed);
+                       c->h_ref_off[i], gstart[i], len, seed, rp);
   }
   if (e == hipSuccess) e = cm_stream_sync(c->stream);
   if (e != hipSuccess) { cm_set_error(nullptr, std::string("genome generation: ") + hipGetErrorString(e)); cmgpu_destroy(c); return CMGPU_EHIP; }
@@ -337,7 +380,7 @@ __constant__ char sy_adapter2[SY_ADAPTER_LEN + 1] = "CTGTCTCTTATACACATCTGACGCTGC
 __global__ __launch_bounds__(SY_BLOCK) void k_sy_reads(const uint8_t *__restrict__ ref, const uint64_t *__restrict__ ref_off,
                                                         const uint32_t *__restrict__ ref_len, uint32_t n_seq,
                                                         uint64_t total_len, uint32_t n_pairs, uint32_t L, uint32_t fmin,
-                                                        uint32_t fmax, uint32_t sub_thresh, uint64_t seed,
+                                                        uint32_t fmax, uint32_t sub_thresh, uint32_t indel_thresh, uint64_t seed,
                                                         uint8_t *__restrict__ r1, uint8_t *__restrict__ r2,
                                                         uint32_t *__restrict__ o1, uint32_t *__restrict__ o2) {
   const uint32_t i = blockIdx.x * SY_BLOCK + threadIdx.x;
@@ -359,10 +402,26 @@ __global__ __launch_bounds__(SY_BLOCK) void k_sy_reads(const uint8_t *__restrict
   uint8_t *a = (swap ? r2 : r1) + (uint64_t)i * L;  // receives the forward head
   uint8_t *b = (swap ? r1 : r2) + (uint64_t)i * L;  // receives the reverse-complement head
   uint64_t rs = ctr + 3;
+  // fa / fb: next fragment base of the forward / reverse-complement read; a 1-base insertion emits a random base
+  // without consuming one, a 1-base deletion skips one ("+0.1 % 1-bp indels for config 5")
+  uint32_t fa = 0, fb = 0;
   for (uint32_t j = 0; j < L; ++j) {
-    uint8_t x = j < fl ? frag[j] : (uint8_t)sy_adapter1[(j - fl) % SY_ADAPTER_LEN];
-    uint8_t y = j < fl ? cm_negchar(frag[fl - 1 - j]) : (uint8_t)sy_adapter2[(j - fl) % SY_ADAPTER_LEN];
     const uint64_t h1 = sy_mix(rs + 2 * j), h2 = sy_mix(rs + 2 * j + 1);
+    uint8_t x, y;
+    if (indel_thresh) {
+      const uint64_t g1 = sy_mix(rs + 0x10000 + 2 * j), g2 = sy_mix(rs + 0x10001 + 2 * j);
+      const bool ev1 = (uint32_t)g1 < indel_thresh, ev2 = (uint32_t)g2 < indel_thresh;
+      const bool ins1 = ev1 && ((g1 >> 40) & 1), ins2 = ev2 && ((g2 >> 40) & 1);
+      if (ev1 && !ins1) ++fa;
+      if (ev2 && !ins2) ++fb;
+      x = ins1 ? (uint8_t)("ACGT"[(g1 >> 32) & 3]) : (fa < fl ? frag[fa] : (uint8_t)sy_adapter1[(fa - fl) % SY_ADAPTER_LEN]);
+      y = ins2 ? (uint8_t)("ACGT"[(g2 >> 32) & 3]) : (fb < fl ? cm_negchar(frag[fl - 1 - fb]) : (uint8_t)sy_adapter2[(fb - fl) % SY_ADAPTER_LEN]);
+      if (!ins1) ++fa;
+      if (!ins2) ++fb;
+    } else {
+      x = j < fl ? frag[j] : (uint8_t)sy_adapter1[(j - fl) % SY_ADAPTER_LEN];
+      y = j < fl ? cm_negchar(frag[fl - 1 - j]) : (uint8_t)sy_adapter2[(j - fl) % SY_ADAPTER_LEN];
+    }
     if ((uint32_t)(h1 & 0xffffffffu) < sub_thresh) x = (uint8_t)("ACGT"[(h1 >> 32) & 3]);
     if ((uint32_t)(h2 & 0xffffffffu) < sub_thresh) y = (uint8_t)("ACGT"[(h2 >> 32) & 3]);
     a[j] = x;
@@ -372,6 +431,11 @@ __global__ __launch_bounds__(SY_BLOCK) void k_sy_reads(const uint8_t *__restrict
 
 extern "C" int cmgpu_generate_resident_batch(cmgpu_ctx *c, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
                                              uint32_t frag_max, double sub_rate, uint64_t seed) {
+  return cmgpu_generate_resident_batch_indels(c, n_pairs, read_length, frag_min, frag_max, sub_rate, 0.0, seed);
+}
+
+extern "C" int cmgpu_generate_resident_batch_indels(cmgpu_ctx *c, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
+                                                    uint32_t frag_max, double sub_rate, double indel_rate, uint64_t seed) {
   if (!c || read_length == 0 || read_length > 250 || frag_min == 0 || (uint64_t)n_pairs * read_length > 0xfffffff0ull) {
     cm_set_error(c, "bad argument");
     return CMGPU_EINVAL;
@@ -388,9 +452,10 @@ extern "C" int cmgpu_generate_resident_batch(cmgpu_ctx *c, uint32_t n_pairs, uin
   uint64_t total = 0;
   for (uint32_t i = 0; i < c->n_seq; ++i) total += c->h_ref_len[i];
   const uint32_t thr = (uint32_t)(sub_rate * 4294967296.0 > 4294967295.0 ? 4294967295.0 : sub_rate * 4294967296.0);
+  const uint32_t ithr = (uint32_t)(indel_rate * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (indel_rate < 0 ? 0 : indel_rate * 4294967296.0));
   hipLaunchKernelGGL(k_sy_reads, dim3((n_pairs + 1 + SY_BLOCK - 1) / SY_BLOCK), dim3(SY_BLOCK), 0, c->stream,
                      (const uint8_t *)c->ref.p, (const uint64_t *)c->ref_off.p, (const uint32_t *)c->ref_len.p, c->n_seq, total,
-                     n_pairs, read_length, frag_min, frag_max, thr, seed, (uint8_t *)c->rb0.p, (uint8_t *)c->rb1.p,
+                     n_pairs, read_length, frag_min, frag_max, thr, ithr, seed, (uint8_t *)c->rb0.p, (uint8_t *)c->rb1.p,
                      (uint32_t *)c->ro0.p, (uint32_t *)c->ro1.p);
   SYCHECK(c, cm_stream_sync(c->stream));
   return CMGPU_OK;

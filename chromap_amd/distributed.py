@@ -38,22 +38,79 @@ def shard_batches(n_pairs, rank, world, ref_batch=500000):
     return out
 
 
-def owned_rids(n_seq, rank, world):
+def owner_table(lengths, world):
+    """owner rank of every sequence -- the twin of cmgpu_exchange_owner_table: contiguous rid ranges whose largest
+    total length B is minimal (B by bisection on the greedy in-order packing into bins of B bases, then that packing)"""
+    lengths = [int(x) for x in lengths]
+
+    def bins(b):
+        p, cur = 1, 0
+        for ln in lengths:
+            if cur + ln > b:
+                p, cur = p + 1, ln
+            else:
+                cur += ln
+        return p
+
+    lo, hi = (max(lengths) if lengths else 0), sum(lengths)
+    while lo < hi:
+        mid = lo + (hi - lo) // 2
+        if bins(mid) <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    out, k, cur = [], 0, 0
+    for ln in lengths:
+        if cur + ln > lo and cur > 0:
+            k, cur = k + 1, 0
+        cur += ln
+        out.append(min(k, world - 1))
+    return np.asarray(out, dtype=np.int64)
+
+
+def owned_rids(lengths, rank, world):
     """chromosome ownership for the final sort/dedup: rid-major output order means owners
     write disjoint, ordered sections"""
-    return [r for r in range(n_seq) if (r * world) // n_seq == rank]
+    return [r for r, k in enumerate(owner_table(lengths, world)) if k == rank]
 
 
-def owner_of_rid(rid, n_seq, world):
-    """rank that sorts / de-duplicates chromosome rid (same rule as cmgpu_records_partition)"""
-    return np.minimum((np.asarray(rid, dtype=np.uint64) * np.uint64(world)) // np.uint64(n_seq), world - 1).astype(np.int64)
-
-
-def partition_by_owner(records, n_seq, world):
+def partition_by_owner(records, lengths, world):
     """host twin of cmgpu_records_partition: (records grouped by owner rank, counts[world])"""
-    own = owner_of_rid(records["rid"], n_seq, world)
+    own = owner_table(lengths, world)[records["rid"].astype(np.int64)] if len(records) else np.zeros(0, np.int64)
     order = np.argsort(own, kind="stable")
     return records[order], np.bincount(own, minlength=world).astype(np.int64)
+
+
+class HostStagedTransport:
+    """exchange transport for cmgpu_exchange_init_external over any torch.distributed group whose backend
+    works on host tensors (gloo): device buffers are staged through host memory with hipMemcpy.  Used where
+    RCCL cannot run -- several ranks sharing one GPU in the tests; the product path is the library's own RCCL."""
+
+    def __init__(self, mapper, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        self.C, self.torch, self.dist, self.group = C, torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.g = mapper  # copies go through the library's own HIP runtime (cmgpu_memcpy)
+
+    def allgather_counts(self, mine):
+        t = self.torch.tensor(mine, dtype=self.torch.int64)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return [o.tolist() for o in out]
+
+    def alltoallv(self, send_dev, send_counts, recv_dev, recv_counts, record_bytes):
+        torch, C = self.torch, self.C
+        ns, nr = sum(send_counts) * record_bytes, sum(recv_counts) * record_bytes
+        send = torch.zeros(max(1, ns), dtype=torch.uint8)
+        recv = torch.zeros(max(1, nr), dtype=torch.uint8)
+        if ns and self.g.L.cmgpu_memcpy(self.g.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(send_dev), ns, 2) != 0:
+            raise RuntimeError("device -> host copy failed")
+        self.dist.all_to_all_single(recv[:nr], send[:ns], [c * record_bytes for c in recv_counts],
+                                    [c * record_bytes for c in send_counts], group=self.group)
+        if nr and self.g.L.cmgpu_memcpy(self.g.ctx, C.c_void_p(recv_dev), C.c_void_p(recv.data_ptr()), nr, 1) != 0:
+            raise RuntimeError("host -> device copy failed")
 
 
 class RecordExchange:

@@ -88,9 +88,12 @@ class ChromapGPU:
             self._check(self.L.cmgpu_create_shared(shared_from.ctx, C.byref(self.ctx)), None)
             self.names = shared_from.names
             self._parent = shared_from
+            self._inherit = (shared_from.rank, shared_from.pairs_rank)
         elif synthetic is not None:
-            total, nseq, seed = synthetic
-            rc = self.L.cmgpu_create_synthetic(total, nseq, seed, 17, 7, C.byref(self.params), device, C.byref(self.ctx))
+            total, nseq, seed = synthetic[:3]
+            fam, copies, elen, div = synthetic[3] if len(synthetic) > 3 and synthetic[3] else (0, 0, 0, 0.0)
+            rc = self.L.cmgpu_create_synthetic_repeats(total, nseq, seed, 17, 7, C.byref(self.params), device, fam, copies, elen,
+                                                       float(div), C.byref(self.ctx))
             self._check(rc, None)
             self.names = [b"chr%d" % (i + 1) for i in range(nseq)]
         elif index_path is None:
@@ -117,6 +120,9 @@ class ChromapGPU:
         self.stats = Stats()
         self.rank = None
         self.pairs_rank = None
+        if shared_from is not None:  # the library hands the parent's chromosome orders to the child as well
+            self.rank, self.pairs_rank = self._inherit
+        self._ex_keep = None
         if chr_order:
             self.set_chr_order(chr_order)
         if pairs_order:
@@ -288,10 +294,22 @@ class ChromapGPU:
         bt = self._batch(b1, o1, b2, o2, first_read_id)
         self._check(self.L.cmgpu_upload_batch(self.ctx, C.byref(bt)), self.ctx)
 
-    def generate_resident(self, n_pairs, read_length=50, frag_min=100, frag_max=600, sub_rate=0.01, seed=1):
-        self._check(self.L.cmgpu_generate_resident_batch(self.ctx, n_pairs, read_length, frag_min, frag_max, sub_rate,
-                                                         seed), self.ctx)
+    def generate_resident(self, n_pairs, read_length=50, frag_min=100, frag_max=600, sub_rate=0.01, seed=1, indel_rate=0.0):
+        self._check(self.L.cmgpu_generate_resident_batch_indels(self.ctx, n_pairs, read_length, frag_min, frag_max, sub_rate,
+                                                                indel_rate, seed), self.ctx)
         self._n_resident = n_pairs
+
+    def swap_resident(self, slot):
+        """the resident batch changes places with the one parked in `slot` (0..7)"""
+        self._check(self.L.cmgpu_swap_resident_batch(self.ctx, slot), self.ctx)
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._check(self.L.cmgpu_get_option(self.ctx, name.encode(), C.byref(v)), self.ctx)
+        return int(v.value)
+
+    def set_option(self, name, value):
+        self._check(self.L.cmgpu_set_option(self.ctx, name.encode(), int(value)), self.ctx)
 
     def map_resident(self, stats=None):
         n = C.c_uint64(0)
@@ -431,6 +449,66 @@ class ChromapGPU:
         if k < 0:
             raise ChromapError("cannot write %s" % path)
         return int(k)
+
+    # ---- multi-GPU record exchange (include/chromap_amd.h: cmgpu_exchange_*)
+    def exchange_unique_id(self):
+        buf = C.create_string_buffer(_capi.UNIQUE_ID_BYTES)
+        self._check(self.L.cmgpu_exchange_unique_id(buf), None)
+        return buf.raw
+
+    def exchange_init(self, unique_id, rank, world):
+        """RCCL communicator of this context's device (collective over the `world` contexts)"""
+        self._check(self.L.cmgpu_exchange_init(self.ctx, C.c_char_p(unique_id), rank, world), self.ctx)
+
+    def exchange_init_external(self, transport, rank, world):
+        """transport: object with allgather_counts(mine: list) -> list of rows, and
+        alltoallv(send_dev, send_counts, recv_dev, recv_counts, record_bytes) working on DEVICE addresses"""
+        def _ag(user, mine, matrix, n):
+            try:
+                rows = transport.allgather_counts([int(mine[i]) for i in range(n)])
+                for r, row in enumerate(rows):
+                    for i in range(n):
+                        matrix[r * n + i] = int(row[i])
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                self._ex_error = e
+                return -1
+
+        def _a2a(user, send_dev, send_counts, recv_dev, recv_counts, w, rb):
+            try:
+                transport.alltoallv(send_dev, [int(send_counts[i]) for i in range(w)], recv_dev,
+                                    [int(recv_counts[i]) for i in range(w)], rb)
+                return 0
+            except Exception as e:
+                self._ex_error = e
+                return -1
+
+        t = _capi.ExchangeTransport(None, _capi.ALLGATHER_COUNTS_FN(_ag), _capi.ALLTOALLV_FN(_a2a))
+        self._ex_keep = t  # the callbacks must outlive the exchange
+        self._ex_error = None
+        self._check(self.L.cmgpu_exchange_init_external(self.ctx, C.byref(t), rank, world), self.ctx)
+
+    def exchange_owner_table(self, world):
+        out = (C.c_uint8 * len(self.names))()
+        self._check(self.L.cmgpu_exchange_owner_table(self.ctx, world, out, len(self.names)), self.ctx)
+        return list(out)
+
+    def exchange_step(self, world=None):
+        """records of the resident batch -> their chromosomes' owners; returns (sent per rank, received)"""
+        w = C.c_int(0)
+        self.L.cmgpu_exchange_info(self.ctx, None, C.byref(w), None, None)
+        sent = (C.c_uint64 * max(1, w.value))()
+        nr = C.c_uint64(0)
+        self._check(self.L.cmgpu_exchange_step(self.ctx, sent, C.byref(nr)), self.ctx)
+        return [int(x) for x in sent[:w.value]], int(nr.value)
+
+    def exchange_info(self):
+        r, w, a, b = C.c_int(0), C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        self.L.cmgpu_exchange_info(self.ctx, C.byref(r), C.byref(w), C.byref(a), C.byref(b))
+        return {"rank": r.value, "world": w.value, "records_sent": int(a.value), "records_received": int(b.value)}
+
+    def exchange_finalize(self):
+        self._check(self.L.cmgpu_exchange_finalize(self.ctx), self.ctx)
 
     def close(self):
         if self.ctx:

@@ -179,6 +179,13 @@ int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view *ref, const
 int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
                            int32_t window_size, const cmgpu_params *params, int device_id, cmgpu_ctx **out);
 
+/* The same with planted repeat families: n_families elements of element_len random bases, `copies`
+ * copies each, spread over the genome in either orientation, every copy's bases replaced with probability
+ * `divergence` -- so that frequent seeds, multi-mappers and mate rescue occur as on a real genome. */
+int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
+                                   int32_t window_size, const cmgpu_params *params, int device_id, uint32_t n_families,
+                                   uint32_t copies, uint32_t element_len, double divergence, cmgpu_ctx **out);
+
 /* Replaces: Index::Construct (src/index.cc:12-89) -- builds the minimizer index of `ref` on
  * the device (chunked minimizer pass, radix sort by (hash, hit), khash-sized open-addressing
  * table) and keeps it resident together with the reference; the ctx maps like one made by
@@ -251,6 +258,9 @@ int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_sequences, const
  * (src/chromap.h:896-909, src/chromap.cc:572-799). */
 int cmgpu_load_whitelist_file(const char *path, uint32_t barcode_length, uint64_t **keys_out, uint32_t *n_out);
 int cmgpu_set_whitelist(cmgpu_ctx *ctx, const uint64_t *keys, uint32_t n_keys, uint32_t barcode_length);
+/* the whitelist with the abundances of the pre-pass, copied to another context (one context per GPU: the pre-pass
+ * runs on one of them) */
+int cmgpu_copy_whitelist(cmgpu_ctx *dst, cmgpu_ctx *src);
 /* single-end reads with cell barcodes: MappingWithBarcode (src/bed_mapping.h:11-56), src/chromap.h:385-472 */
 int cmgpu_map_single_barcoded(cmgpu_ctx *ctx, const cmgpu_single_batch *in, const cmgpu_barcode_batch *barcodes,
                               cmgpu_record_bc *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
@@ -276,6 +286,12 @@ int cmgpu_download_records(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capac
  * swapped with p = 0.5) and makes them the resident batch. */
 int cmgpu_generate_resident_batch(cmgpu_ctx *ctx, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
                                   uint32_t frag_max, double sub_rate, uint64_t seed);
+/* The same with 1-base insertions / deletions at rate indel_rate per base (half each). */
+int cmgpu_generate_resident_batch_indels(cmgpu_ctx *ctx, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
+                                         uint32_t frag_max, double sub_rate, double indel_rate, uint64_t seed);
+/* The resident batch changes places with the one parked in `slot` (0..7; either may be empty): several distinct
+ * batches stay in HBM and take turns (the measurement must not map one batch over and over). */
+int cmgpu_swap_resident_batch(cmgpu_ctx *ctx, int slot);
 /* Copies the resident batch back to host SoA buffers (for checking against the oracle). */
 int cmgpu_download_batch(cmgpu_ctx *ctx, char *read1_bases, uint32_t *read1_offsets, char *read2_bases,
                          uint32_t *read2_offsets);
@@ -286,9 +302,24 @@ int cmgpu_download_batch(cmgpu_ctx *ctx, char *read1_bases, uint32_t *read1_offs
 int cmgpu_probe_bench(cmgpu_ctx *ctx, const uint64_t *hashes, uint64_t n, int repeat, double *avg_ms,
                       uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences);
 
+/* The same kernel in its other shapes, on the hashes left resident by the last mapped batch:
+ * lookups_per_lane 1 / 2 / 4 / 8 independent lookups interleaved per lane, pair_prefetch != 0: the second
+ * probe step is requested with the first when both buckets share a 64-byte sector. */
+int cmgpu_probe_bench_variant(cmgpu_ctx *ctx, uint64_t n, int repeat, int lookups_per_lane, int pair_prefetch,
+                              double *avg_ms, uint64_t *probe_steps, uint64_t *hits);
+
 /* HBM random-gather microbenchmark on the resident table: n independent 16-byte loads at
  * pseudo-random buckets, average kernel time over `repeat` launches (HIP events). */
 int cmgpu_gather_bench(cmgpu_ctx *ctx, uint64_t n, int repeat, double *avg_ms);
+/* its sweep: loads_per_lane (1, 2, 4, 8, 16) requests in flight per lane, access_bytes 16 (one bucket) or
+ * 64 (the whole aligned sector, every fetched byte used) -- the best shape is the ceiling k_probe is held to */
+int cmgpu_gather_sweep(cmgpu_ctx *ctx, uint64_t n, int repeat, int loads_per_lane, int access_bytes, double *avg_ms);
+
+/* Measurement knobs (the defaults are the measured best): "probe_lookups_per_lane" 1/2/4/8,
+ * "probe_pair_prefetch" 0/1, "mm_chunks" 1..8, "prep_kernel" 0/1, "item_limit" (largest dense
+ * intermediate array, in entries; batches that need more are mapped in sub-batches). */
+int cmgpu_set_option(cmgpu_ctx *ctx, const char *name, int64_t value);
+int cmgpu_get_option(const cmgpu_ctx *ctx, const char *name, int64_t *value);
 
 /* Per-stage timing of the last cmgpu_map_* call (HIP events on the launch stream).
  * names/ms arrays of capacity cap; returns number of stages. */
@@ -308,9 +339,55 @@ int cmgpu_export_index(cmgpu_ctx *ctx, uint64_t *buckets_out, uint64_t *occurren
 /* Dense copy of the resident batch's records into a caller-provided DEVICE buffer
  * (capacity in records) -- the send buffer of the multi-GPU record exchange. */
 int cmgpu_records_to_device(cmgpu_ctx *ctx, void *device_dst, uint64_t capacity, uint64_t *n_out);
-/* Same, grouped by the rank that owns the record's chromosome (owner = rid * world / n_sequences):
+/* Same, grouped by the rank that owns the record's chromosome (cmgpu_exchange_owner_table):
  * counts[r] records for rank r, in rank order -- the send buffer and split sizes of an all-to-all. */
 int cmgpu_records_partition(cmgpu_ctx *ctx, uint32_t world, void *device_dst, uint64_t capacity, uint64_t *counts);
+
+/* ---- multi-GPU record exchange ----------------------------------------------
+ * Read batches shard across GPUs with no collective on the mapping path; what the reference does
+ * once per run on one host -- sort every chromosome's records and drop PCR duplicates
+ * (MappingProcessor / MappingWriter::OutputTempMappings..., src/mapping_processor.h:100-202,
+ * src/mapping_writer.h:166-376, fed by src/chromap.h:1305-1355) -- is done per chromosome OWNER:
+ * after every batch each context sends its records to the rank that owns their chromosome (one
+ * all-to-all, every record crosses xGMI once) and appends what it receives to its device-side record
+ * store; cmgpu_store_format on every rank then yields that rank's section of the output, sections
+ * concatenate in rank order (the output is chromosome-major).
+ *   owner table   contiguous rid ranges (in the --chr-order rank space when one is set) such that the largest
+ *                 owner's total sequence length is minimal: greedy in-order packing into bins of the smallest
+ *                 size for which `world` bins suffice
+ *   transport     RCCL, called by the library on the context's mapping stream (communicator made from a
+ *                 ncclUniqueId the host distributes, or by cmgpu_exchange_init_all for the contexts of one
+ *                 process), or two callbacks of the host's own communicator (MPI, a test harness).
+ * cmgpu_exchange_step is collective: every rank calls it once per round, with an empty resident batch
+ * when it has nothing to contribute. */
+#define CMGPU_UNIQUE_ID_BYTES 128
+typedef struct cmgpu_exchange_transport {
+  void *user;
+  /* mine[n] (n = world + 1: records this rank sends to each rank, then its record size) ->
+   * matrix[world * n], row r = rank r's `mine` */
+  int (*allgather_counts)(void *user, const uint64_t *mine, uint64_t *matrix, uint32_t n);
+  /* send_dev: records grouped by destination rank (send_counts[world]); recv_dev: room for sum(recv_counts)
+   * records, to be filled grouped by source rank; both are DEVICE pointers, record_bytes = 24 (32 with barcodes) */
+  int (*alltoallv)(void *user, const void *send_dev, const uint64_t *send_counts, void *recv_dev,
+                   const uint64_t *recv_counts, uint32_t world, uint32_t record_bytes);
+} cmgpu_exchange_transport;
+/* ncclGetUniqueId (call on one rank, hand the bytes to the others) */
+int cmgpu_exchange_unique_id(void *id_out);
+/* ncclCommInitRank on the context's device; collective over the `world` contexts */
+int cmgpu_exchange_init(cmgpu_ctx *ctx, const void *unique_id, int rank, int world);
+/* the contexts of ONE process, ctxs[i] becomes rank i (ncclCommInitAll over their devices) */
+int cmgpu_exchange_init_all(cmgpu_ctx *const *ctxs, int n);
+/* caller-provided transport instead of RCCL */
+int cmgpu_exchange_init_external(cmgpu_ctx *ctx, const cmgpu_exchange_transport *t, int rank, int world);
+/* owner rank of every sequence for `world` ranks (no exchange needs to be initialised) */
+int cmgpu_exchange_owner_table(const cmgpu_ctx *ctx, uint32_t world, uint8_t *owner_out, uint32_t n_sequences);
+/* partition the resident batch's records by owner -> exchange -> append the received records to this
+ * context's store.  sent_per_rank: world entries or NULL. */
+int cmgpu_exchange_step(cmgpu_ctx *ctx, uint64_t *sent_per_rank, uint64_t *n_received);
+int cmgpu_exchange_info(const cmgpu_ctx *ctx, int *rank, int *world, uint64_t *records_sent, uint64_t *records_received);
+int cmgpu_exchange_finalize(cmgpu_ctx *ctx);
+/* host <-> device copy through the library's HIP runtime, for a host-staged transport; kind 1: host -> device, 2: device -> host */
+int cmgpu_memcpy(cmgpu_ctx *ctx, void *dst, const void *src, uint64_t bytes, int kind);
 
 /* ---- --SAM --------------------------------------------------------------
  * With params.output_format == CMGPU_FORMAT_SAM the reported mappings are aligned with the

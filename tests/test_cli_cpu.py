@@ -47,3 +47,13 @@ def test_mapping_refuses_to_run_without_a_gpu(tmp_path):
     assert r.returncode != 0
     assert not os.path.exists(out) or os.path.getsize(out) == 0
     assert b"HIP" in r.stderr or b"device" in r.stderr or b"GPU" in r.stderr, r.stderr[-500:]
+
+
+def test_flag_combinations_without_a_record_type_are_refused():
+    """argument checks happen before any device work: the refusals are testable without a GPU"""
+    r = _run("--pairs", "-x", "x", "-r", "y", "-1", "a", "-2", "b", "-o", "o")
+    assert r.returncode != 0 and b"--pairs without --split-alignment" in r.stderr
+    r = _run("--preset", "hic", "-x", "x", "-r", "y", "-1", "a", "-2", "b", "-b", "c", "-o", "o")
+    assert r.returncode != 0 and b"cell barcodes" in r.stderr
+    r = _run("--gpus", "0", "-x", "x", "-r", "y", "-1", "a", "-o", "o")
+    assert r.returncode != 0 and b"--gpus" in r.stderr

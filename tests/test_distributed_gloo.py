@@ -50,14 +50,15 @@ def _worker(rank, world, port, case, outdir):
         mine.append(np.frombuffer(bytes(rec)[: k * 24], dtype=REC_DTYPE).copy())
     mine = np.concatenate(mine) if mine else np.zeros(0, REC_DTYPE)
     nseq = len(h.names)
+    lengths = [int(h.ref.lengths[i]) for i in range(nseq)]
     ex = RecordExchange(n, torch.device("cpu"))
-    grouped, counts = partition_by_owner(mine, nseq, world)
+    grouped, counts = partition_by_owner(mine, lengths, world)
     raw = torch.from_numpy(grouped.view(np.uint8).copy())
     ex.send[: raw.numel()] = raw
     ex.all_to_all(counts)
     sel = ex.received_records().copy()
     # owner-side sort + dedup + BED for the chromosomes this rank owns
-    own = set(owned_rids(nseq, rank, world))
+    own = set(owned_rids(lengths, rank, world))
     assert set(np.unique(sel["rid"]).tolist()) <= own
     buf = (C.c_uint8 * max(1, sel.nbytes)).from_buffer_copy(sel.tobytes() if sel.nbytes else b"\0")
     out = os.path.join(outdir, "part%d.bed" % rank)
@@ -84,6 +85,16 @@ def test_shard_helpers():
     from chromap_amd.distributed import owned_rids, shard_batches
     assert shard_batches(1_200_000, 0, 2) == [(0, 500000), (1000000, 1200000)]
     assert shard_batches(1_200_000, 1, 2) == [(500000, 1000000)]
-    allr = sorted(sum((owned_rids(24, r, 8) for r in range(8)), []))
+    from chromap_amd.distributed import owner_table
+    # equal lengths: the plain rid * world / n_seq split
+    allr = sorted(sum((owned_rids([1000] * 24, r, 8) for r in range(8)), []))
     assert allr == list(range(24))
-    assert owned_rids(24, 0, 8) == [0, 1, 2]
+    assert owned_rids([1000] * 24, 0, 8) == [0, 1, 2]
+    # GRCh38-like lengths: owners are contiguous rid ranges of nearly equal total length
+    grch38 = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50, 156, 57]
+    own = owner_table(grch38, 8)
+    assert list(own) == sorted(own) and own[0] == 0 and own[-1] == 7 and set(own) == set(range(8))
+    assert list(owner_table([5, 5, 5], 8)) == [0, 1, 2]
+    share = [sum(l for l, k in zip(grch38, own) if k == r) / sum(grch38) for r in range(8)]
+    assert max(share) < 0.155 and min(share) > 0.08  # rid * world / n_seq gave rank 0 chr1-3 = 22 %
+    assert list(owner_table(grch38, 1)) == [0] * 24

@@ -85,6 +85,34 @@ def test_cli_ingest_variants(extra, built, tmp_path):
         assert ds.md5(out) == meta["bed_md5"]
 
 
+@pytest.mark.parametrize("name", ["s1_atac", "s3_chip", "b1_atac_bc", "s4_se_atac_q0", "s2_tagalign_q0"])
+def test_cli_multi_gpu_path_with_one_gpu(name, built, tmp_path):
+    """--gpus N code path (one context + host thread per GPU, RCCL record exchange to the chromosome owners issued by the
+    library, every owner formats its section) with N = 1: same bytes and counters"""
+    meta = ds.case_meta(name)
+    fa, reads = _reads(name)
+    out = str(tmp_path / "out.txt")
+    r = subprocess.run([CLI] + list(meta["chromap_flags"]) + ["--force-exchange", "-x", built(name), "-r", fa] + reads + ["-o", out],
+                       stderr=subprocess.PIPE, check=True)
+    assert ds.md5(out) == meta["bed_md5"]
+    log = r.stderr.decode()
+    assert int(re.search(r"Number of mapped reads: (\d+)", log).group(1)) == meta["reference_stderr_counters"]["num_mapped_reads"]
+
+
+def test_cli_refuses_what_it_cannot_write(built, tmp_path):
+    """flag combinations the reference accepts and this build has no record type for end with a message, not with garbage"""
+    name = "s1_atac"
+    fa, reads = _reads(name)
+    out = str(tmp_path / "o")
+    r = subprocess.run([CLI, "--pairs", "-x", built(name), "-r", fa] + reads + ["-o", out], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"outside this build" in r.stderr and not os.path.exists(out)
+    fa, reads = _reads("b1_atac_bc")
+    r = subprocess.run([CLI, "--preset", "hic", "-x", built("b1_atac_bc"), "-r", fa] + reads + ["-o", out], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"outside this build" in r.stderr
+    r = subprocess.run([CLI, "--preset", "hic", "--gpus", "2", "-x", built(name), "-r", fa] + _reads(name)[1] + ["-o", out], stderr=subprocess.PIPE)
+    assert r.returncode != 0
+
+
 def test_cli_reads_gzip(built, tmp_path):
     import gzip
     import shutil

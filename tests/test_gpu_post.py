@@ -168,7 +168,8 @@ def test_records_partition_by_owner_matches_host_twin():
         send = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
         counts = (C.c_uint64 * world)()
         assert g.L.cmgpu_records_partition(g.ctx, world, C.c_void_p(send.data_ptr()), n, counts) == 0
-        want, wc = partition_by_owner(host, len(g.names), world)
+        want, wc = partition_by_owner(host, list(g.reference_lengths()), world)
+        assert g.exchange_owner_table(world) == [int(x) for x in __import__('chromap_amd.distributed', fromlist=['owner_table']).owner_table(list(g.reference_lengths()), world)]
         assert list(counts) == wc.tolist() and sum(counts) == k
         got = np.frombuffer(send[:k * 24].cpu().numpy().tobytes(), dtype=REC_DTYPE)
         # same multiset per destination rank (order inside a destination is irrelevant: a sort follows)

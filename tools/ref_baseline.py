@@ -30,7 +30,17 @@ def main():
     ap.add_argument("--readlen", type=int, default=50)
     ap.add_argument("--dir", default="/tmp/chromap_amd_ref")
     ap.add_argument("--threads", type=int, default=os.cpu_count())
+    ap.add_argument("--preset", default="atac")
+    ap.add_argument("--repeats", default="", help="families,copies,element_len,divergence of the planted repeats (bench.py --repeats)")
+    ap.add_argument("--indel-rate", type=float, default=0.0)
+    ap.add_argument("--frag-min", type=int, default=30)
+    ap.add_argument("--frag-max", type=int, default=600)
+    ap.add_argument("--seed0", type=int, default=1000)
     args = ap.parse_args()
+    rep = None
+    if args.repeats:
+        f = args.repeats.split(",")
+        rep = (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "chromap")
     if not os.path.exists(ref_bin):
         print(json.dumps({"error": "oracle/_ref/chromap not present"}))
@@ -44,7 +54,7 @@ def main():
     from e2e_bench import write_fastq
     from chromap_amd import ChromapGPU
     t0 = time.time()
-    g = ChromapGPU(synthetic=(args.genome, args.nseq, 12345), preset="atac")
+    g = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset)
     idx = os.path.join(args.dir, "g.index")
     fa = os.path.join(args.dir, "g.fa")
     g.save_index(idx)
@@ -65,7 +75,8 @@ def main():
         if os.path.exists(f):
             os.remove(f)
     for b in range(args.batches):
-        g.generate_resident(args.pairs, read_length=args.readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=1000 + b)
+        g.generate_resident(args.pairs, read_length=args.readlen, frag_min=args.frag_min, frag_max=args.frag_max, sub_rate=0.01,
+                            seed=args.seed0 + b, indel_rate=args.indel_rate)
         b1, o1, b2, o2 = g.download_batch(args.pairs)
         for path, bases in ((r1, b1), (r2, b2)):
             tmp = path + ".part"
@@ -79,9 +90,9 @@ def main():
     res = {"setup_s": round(t_setup, 1), "pairs": n_pairs, "threads": args.threads,
            "index_bytes": os.path.getsize(idx), "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2)}
     # ---- the reference
-    out_ref = os.path.join(args.dir, "ref.bed")
+    out_ref = os.path.join(args.dir, "ref.out")
     t0 = time.time()
-    p = subprocess.run([ref_bin, "--preset", "atac", "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_ref, "-t", str(args.threads)],
+    p = subprocess.run([ref_bin, "--preset", args.preset, "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_ref, "-t", str(args.threads)],
                        stderr=subprocess.PIPE)
     wall = time.time() - t0
     log = p.stderr.decode(errors="replace")
@@ -97,10 +108,10 @@ def main():
                             "bed_md5": subprocess.check_output(["md5sum", out_ref]).split()[0].decode(),
                             "bed_lines": int(subprocess.check_output(["wc", "-l", out_ref]).split()[0])}
     # ---- chromap-amd on the same files
-    out_gpu = os.path.join(args.dir, "gpu.bed")
+    out_gpu = os.path.join(args.dir, "gpu.out")
     cli = os.path.join(ROOT, "chromap_amd", "chromap-amd")
     t0 = time.time()
-    p = subprocess.run([cli, "--preset", "atac", "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_gpu], stderr=subprocess.PIPE)
+    p = subprocess.run([cli, "--preset", args.preset, "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_gpu], stderr=subprocess.PIPE)
     wall = time.time() - t0
     log = p.stderr.decode(errors="replace")
     if p.returncode != 0:

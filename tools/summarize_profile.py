@@ -17,7 +17,10 @@ def pmc(path, counter):
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            a = acc[row["Kernel_Name"].split("(")[0]]
+            nm = row["Kernel_Name"].split("(")[0]
+            if nm.startswith("void "):
+                nm = nm[5:]
+            a = acc[nm.replace(",", ";")]  # template arguments keep their shape, the CSV its columns
             a[0] += float(row["Counter_Value"])
             a[1] += 1
     return acc
@@ -50,16 +53,34 @@ def main():
                 a = bc[k][0] / max(1, bc[k][1])
                 b = ia[k][0] / max(1, ia[k][1])
                 f.write("%s,%d,%.0f,%.0f,%.3f\n" % (k, ia[k][1], a, b, a / b if b else 0.0))
+    # what bench.py reports as roofline.traffic: the probe kernel in the shape the pipeline uses (bench line:
+    # roofline.kernel_shape), its 64-byte sectors per lookup, and the calibration of FETCH_SIZE on the gather
+    # microbenchmark of known byte count (same access width, 4 loads per lane)
     out = {}
+    shape, lookups = None, None
+    try:
+        bj = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        shape = bj["roofline"].get("kernel_shape")
+        lookups = bj["roofline"]["probe_only"]["lookups"]
+    except Exception:
+        pass
+    want = "k_probe<%d; %s>" % (shape["lookups_per_lane"], "true" if shape["pair_prefetch"] else "false") if shape else None
+    per_shape = {}
     for k in fe:
-        if k.startswith("k_probe") and "reduce" not in k:
+        if k.startswith("k_probe<"):
             a = fe[k][0] / fe[k][1]
-            b = wr[k][0] / max(1, wr[k][1])
-            out = {"kernel": "k_probe", "workload": "bench.py default (4M pairs/step, GRCh38-sized synthetic index)",
-                   "FETCH_SIZE_KiB": round(a, 3), "WRITE_SIZE_KiB": round(b, 3), "hbm_bytes_per_launch": int((a + b) * 1024)}
+            b = wr[k][0] / max(1, wr[k][1]) if k in wr else 0.0
+            per_shape[k] = {"FETCH_SIZE_KiB": round(a, 3), "WRITE_SIZE_KiB": round(b, 3), "hbm_bytes_per_launch": int((a + b) * 1024)}
+            if lookups:
+                per_shape[k]["sectors_per_lookup"] = round(a * 1024 / 64 / lookups, 4)
+    pick = want if want in per_shape else (sorted(per_shape)[0] if per_shape else None)
+    if pick:
+        out = {"kernel": pick, "workload": "bench.py default (4M pairs/step, GRCh38-sized synthetic index)"}
+        out.update(per_shape[pick])
+        out["all_shapes"] = per_shape
     for k in fe:
-        if k.startswith("k_gather"):
-            out["calibration"] = ("k_gather: 2^28 independent 16-B loads -> FETCH_SIZE %.1f KiB = %.1f B per access; "
+        if k.startswith("k_gather<4; false>"):
+            out["calibration"] = ("k_gather<4, false>: 2^28 independent 16-B loads -> FETCH_SIZE %.1f KiB = %.1f B per access; "
                                   "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes"
                                   % (fe[k][0] / fe[k][1], fe[k][0] / fe[k][1] * 1024 / (1 << 28)))
     with open(os.path.join(dst, "probe_traffic.json"), "w") as f:
