@@ -66,6 +66,10 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_mm_chunks = (int)value;
   } else if (n == "prep_kernel") {
     c->opt_prep_kernel = (int)value;
+  } else if (n == "heavy_wave_max" || n == "heavy_block_max" || n == "heavy_big_max") {  // tests: force the size classes
+    c->opt_heavy_max[n == "heavy_wave_max" ? 0 : n == "heavy_block_max" ? 1 : 2] = (int)value;
+  } else if (n == "heavy_last") {
+    c->opt_heavy_last = (int)value;
   } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate
     c->opt_item_limit = value > 0 ? (uint64_t)value : 0xfffffff0ull;
   } else {
@@ -336,6 +340,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4)
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
+  ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4)
 #undef ENS
   return CMGPU_OK;
 }
@@ -417,6 +422,17 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.rec = (uint8_t *)c->rec.p + (size_t)lo * 24;
   d.rec_ok = (uint8_t *)c->rec_ok.p + lo;
   d.stats = (unsigned long long *)c->stats.p;
+  d.hv_cnt = (uint32_t *)c->hv_cnt.p;
+  d.hv_list = (uint32_t *)c->hv_list.p;
+  d.hv_stride = 2 * (hi - lo) + 1;
+  d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
+  d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
+  d.s3b_cap = cm_s3b_lane_cap(c->max_read_len);
+  if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
+    cm_s3b_heavy_classes(d.hv_max);
+    for (int q = 0; q < 3; ++q) if (c->opt_heavy_max[q] > 0 && (uint32_t)c->opt_heavy_max[q] < d.hv_max[q]) d.hv_max[q] = (uint32_t)c->opt_heavy_max[q];
+    if (c->opt_heavy_max[0] < 0) d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0;  // everything long goes to the one-lane path
+  } else d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0;
   if (c->has_rank) {  // stages from verification on address the reference by rank
     d.rid_rank = (const uint32_t *)c->rid_rank.p;
     d.ref_off = (const uint64_t *)c->ref_off_r.p;
@@ -460,6 +476,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   const uint32_t n = rhi - rlo, n2 = 2 * n;
   const uint64_t limit = c->opt_item_limit;
   c->n_ev = 0;
+  c->use_perm = false;
   *k_out = 0;
   int rc = ensure_pair_arrays(c, n);
   if (rc) return rc;
@@ -554,7 +571,10 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     mark(c, "s2_probe");
   }
   // S3: hit counts -> offsets -> candidates
+  HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 16, s));
   cm_launch_k_s3a_count(d, n2, s);
+  uint32_t n_heavy[4] = {0, 0, 0, 0};
+  HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, 16, hipMemcpyDeviceToHost, s));
   unsigned long long hits_total = 0;
   if ((rc = scan_with_total(c, d.hit_tot, d.hit_off, n2, &hits_total))) return rc;
   if (hits_total > limit) return CM_RC_SPLIT;  // 2 x 150 reads on a repeat-rich genome: ~500 hits per read x 8 M reads wraps 2^32
@@ -563,6 +583,16 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s3a_count");
   cm_launch_k_s3b_candidates(d, n2, c->max_read_len, s);
+  cm_launch_k_s3b_heavy(d, n_heavy, s);  // reads with long hit lists: a wave or a block each
+  // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
+  c->use_perm = (uint64_t)n_heavy[0] + n_heavy[1] + n_heavy[2] + n_heavy[3] > n2 / 2048;
+  if (c->opt_heavy_last) c->use_perm = c->opt_heavy_last > 0;
+  if (c->use_perm) {
+    uint32_t *tmp = (uint32_t *)c->hv_tmp.p;
+    cm_build_heavy_last(d, n, (uint32_t *)c->scratch_a.p, tmp, (uint32_t *)c->scratch_b.p, tmp + n2 + 1, (uint32_t *)c->perm_reads.p,
+                        (uint32_t *)c->perm_pairs.p, (uint32_t *)c->scan_tmp.p, s);
+  }
+  cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s3b_candidates");
   // S4: mate rescue, merge, paired-end filter
   cm_launch_k_s4a_rescue_count(d, n2, s);

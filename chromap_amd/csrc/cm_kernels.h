@@ -16,6 +16,9 @@ uint32_t cm_probe_range_blocks(uint64_t max_entries, int variant);
 void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s, int variant);
 void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
+uint32_t cm_s3b_lane_cap(uint32_t max_read_len);
+void cm_s3b_heavy_classes(uint32_t *hv_max);
+void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s);
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
 CM_DECL_LAUNCH(k_s4a_rescue_count)
 CM_DECL_LAUNCH(k_s4b_rescue_merge)
@@ -37,6 +40,8 @@ void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash
 size_t cm_stats_partial_words(uint32_t n);
 void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials, hipStream_t s);
 
+void cm_build_heavy_last(const CmDev &d, uint32_t n_pairs, uint32_t *fr, uint32_t *sr, uint32_t *fp, uint32_t *sp, uint32_t *perm_reads,
+                         uint32_t *perm_pairs, uint32_t *scan_tmp, hipStream_t s);
 void cm_launch_k_sum_u32(const uint32_t *in, uint32_t n, unsigned long long *out, hipStream_t s);
 size_t cm_scan_tmp_words(uint32_t n);
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total

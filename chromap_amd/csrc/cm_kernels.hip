@@ -10,10 +10,13 @@
 
 #define CM_BLOCK 256
 
-#define CM_ITEM_KERNEL(kname, fn)                                            \
+// One item per lane.  `perm` (d.perm_reads / d.perm_pairs, or nullptr) lists the items with the few heavy ones -- reads
+// from repeats, whose candidate lists are a hundred times longer -- at the end: a wave then holds either light items or
+// heavy items, instead of 63 light lanes waiting for one heavy lane in nearly every wave.
+#define CM_ITEM_KERNEL(kname, fn, perm)                                      \
   __global__ __launch_bounds__(CM_BLOCK) void kname(CmDev d, uint32_t n) {   \
     const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;                  \
-    if (i < n) fn(d, i);                                                     \
+    if (i < n) fn(d, d.perm ? d.perm[i] : i);                                \
   }
 
 
@@ -27,6 +30,7 @@
 // below its first byte.  Returns this thread's read pointer in LDS.
 // ---------------------------------------------------------------------------------------
 extern __shared__ __align__(16) uint8_t cm_lds[];
+static inline dim3 grid_for_n(uint32_t n) { return dim3((n + CM_BLOCK - 1) / CM_BLOCK); }
 
 __device__ __forceinline__ void cm_stage_range(uint8_t *dst, const uint8_t *src, uint64_t a0, uint64_t g1) {
   for (uint64_t off = a0 + (uint64_t)threadIdx.x * 16; off < g1; off += (uint64_t)blockDim.x * 16)
@@ -136,20 +140,176 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
   }
 }
 
-CM_ITEM_KERNEL(k_s3a_count, cm_s3a_count)
+// S3a: hit counts per read; reads whose hit list will not fit a lane's LDS slots in k_s3b_candidates are listed by
+// size class for the cooperative kernel below
+__global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  cm_s3a_count(d, i);
+  const uint32_t tot = d.hit_tot[i];
+  if (tot > d.s3b_cap) {
+    const uint32_t c = tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : 3u;
+    d.hv_list[(size_t)c * d.hv_stride + atomicAdd(&d.hv_cnt[c], 1u)] = i;
+  }
+}
 // S3b with the per-read hit list staged in LDS ([entry][thread] layout: 16 x 8-byte entries and
 // 16 count bytes per thread = 36 KB per block).  The first version sorted every list in its
 // global segment; per-thread read-modify-write of small segments thrashed L2 (rocprofv3: 10 GB
 // of HBM traffic per launch for 0.55 GB of hits).
 // Geometry from the longest read of the batch: cap (hits per lane staged in LDS) and threads per block are
 // chosen so that cap * threads * 9 bytes stays at 36 KB -- 16 x 256 for 50-base reads (7.7 minimizers, ~9 hits),
-// 48 x 64 for 150-base reads (~34 minimizers); longer lists work in place in the global segment.
+// 48 x 64 for 150-base reads (~34 minimizers); longer lists go to k_s3b_heavy.
 __global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n, uint32_t cap) {
   uint64_t *sh_h = reinterpret_cast<uint64_t *>(cm_lds);
   uint8_t *sh_c = cm_lds + (size_t)cap * blockDim.x * 8;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) cm_s3b_candidates_lds(d, i, sh_h + threadIdx.x, sh_c + threadIdx.x, cap, blockDim.x);
+  if (i < n && d.hit_tot[i] <= cap) cm_s3b_candidates_lds(d, i, sh_h + threadIdx.x, sh_c + threadIdx.x, cap, blockDim.x);
 }
+
+// ---------------------------------------------------------------------------------------
+// S3b for long hit lists (reads from repeats: hundreds to thousands of hits).  One lane sorting such a list
+// in its global segment took ~28 ms and held its whole wave for that long (a genome with 2 % of its bases in
+// 600-copy repeat families: 452 ms per 4 M-pair batch in this stage).  Here a GROUP of lanes -- a wave for
+// lists up to 1024 hits, a block beyond -- works on one read:
+//   expand   the occurrence runs of the read's minimizers are copied by the group's lanes into LDS (slots handed
+//            out by an LDS counter; the order is irrelevant), strand in bit 63 of the key so that one sort yields
+//            the + list followed by the - list (a sequence id needs bit 31 free: checked on the host);
+//   sort     bitonic network in LDS over the next power of two (padding = all ones);
+//   cluster  the sweep is sequential only inside a LOCAL cluster (cm_sweep_cluster, cm_stages.h): every lane
+//            takes the local clusters whose first hit it owns, counts their candidates, the group scans the
+//            counts, the lanes sweep again and write the candidates to the read's global segment in list order.
+// Results are those of cm_s3b_core, element for element.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void cm_group_sync() {
+  if (G == 64) {
+    // one wave: its LDS operations execute in order; make them complete and keep the compiler from moving accesses across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P) {
+  constexpr int GPB = CM_BLOCK / G;  // groups per block
+  const uint32_t grp = threadIdx.x / G, t = threadIdx.x % G;
+  const uint32_t gid = blockIdx.x * GPB + grp;
+  if (gid >= n_list) return;  // whole group (a wave, or the block)
+  uint64_t *S = reinterpret_cast<uint64_t *>(cm_lds) + (size_t)grp * P;
+  uint16_t *oc = reinterpret_cast<uint16_t *>(cm_lds + (size_t)GPB * P * 8) + (size_t)grp * P;
+  uint32_t *ctr = reinterpret_cast<uint32_t *>(cm_lds + (size_t)GPB * P * 10) + (size_t)grp * (G + 8);
+  const uint32_t r = list[gid];
+  const uint32_t tot = d.hit_tot[r];
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
+  const uint64_t SB = 1ull << 63;
+  uint32_t P2 = 2;
+  while (P2 < tot) P2 <<= 1;
+  if (t == 0) { ctr[0] = 0; ctr[1] = 0; }
+  for (uint32_t i = tot + t; i < P2; i += G) S[i] = ~0ull;
+  cm_group_sync<G>();
+  // ---- expand
+  uint32_t my_pos = 0;
+  for (uint32_t mi = 0; mi < n; ++mi) {
+    const uint8_t kind = d.pr_kind[b + mi];
+    if (kind == CM_PR_MISS) continue;
+    const uint64_t val = d.pr_val[b + mi];
+    const uint32_t ps = d.mm_ps[b + mi];
+    bool same;
+    if (kind == CM_PR_SINGLE) {
+      if (t == 0) {
+        const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
+        S[atomicAdd(&ctr[0], 1u)] = same ? cp : (cp | SB);
+        my_pos += same ? 1u : 0u;
+      }
+      continue;
+    }
+    const uint32_t nocc = (uint32_t)val;
+    if (nocc >= maxf) continue;
+    const uint64_t *o = d.occ + (uint32_t)(val >> 32);
+    for (uint32_t oi = t; oi < nocc; oi += G) {
+      const uint64_t cp = cm_cand_from_hit(o[oi], ps, d.p.k, &same);
+      S[atomicAdd(&ctr[0], 1u)] = same ? cp : (cp | SB);
+      my_pos += same ? 1u : 0u;
+    }
+  }
+  if (my_pos) atomicAdd(&ctr[1], my_pos);
+  cm_group_sync<G>();
+  const uint32_t np = ctr[1], nn = tot - np;
+  // ---- sort (ascending; keys with bit 63 -- the - strand -- follow the + strand's)
+  for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
+    for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = t; i < (P2 >> 1); i += G) {
+        const uint32_t a = 2 * j * (i / j) + (i % j), c = a + j;
+        const uint64_t x = S[a], y = S[c];
+        const bool up = (a & k2) == 0;
+        if ((x > y) == up) { S[a] = y; S[c] = x; }
+      }
+      cm_group_sync<G>();
+    }
+  }
+  // ---- cluster: count pass
+  const bool use_high = d.round2[r] && np > 0 && nn > 0;
+  int req = (int)n - (int)d.rep_cnt[r];
+  req = req > 1 ? req : 1;
+  req = req > d.p.min_seeds ? d.p.min_seeds : req;
+  if (use_high) req = d.p.min_seeds;
+  const int e = d.p.e;
+  for (uint32_t i = t; i < tot; i += G) {
+    uint32_t c = 0;
+    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) {
+      uint32_t end = i + 1;
+      while (end < tot && !cm_sweep_local_break(S[end - 1], S[end], e)) ++end;
+      c = cm_sweep_cluster(S, 1, i, end, e, req, n, nullptr, nullptr);
+    }
+    oc[i] = (uint16_t)c;
+  }
+  cm_group_sync<G>();
+  // exclusive scan of oc[0..tot): per-lane chunk sums, lane 0 scans the G sums, lanes rewrite their chunks
+  const uint32_t chunk = (tot + G - 1) / G, c0 = t * chunk, c1 = c0 + chunk < tot ? c0 + chunk : tot;
+  {
+    uint32_t sum = 0;
+    for (uint32_t i = c0; i < c1; ++i) sum += oc[i];
+    ctr[8 + t] = sum;
+  }
+  cm_group_sync<G>();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < (uint32_t)G; ++q) { const uint32_t x = ctr[8 + q]; ctr[8 + q] = run; run += x; }
+    ctr[2] = run;  // all candidates
+  }
+  cm_group_sync<G>();
+  {
+    uint32_t run = ctr[8 + t];
+    for (uint32_t i = c0; i < c1; ++i) { const uint32_t x = oc[i]; oc[i] = (uint16_t)run; run += x; }
+  }
+  cm_group_sync<G>();
+  const uint32_t total = ctr[2];
+  const uint32_t ncp = np < tot ? (np > 0 ? oc[np] : 0u) : total, ncn = total - ncp;
+  // ---- cluster: write pass (candidates of the + list at h[0..ncp), of the - list at h[np..np+ncn))
+  uint64_t *h = d.hbuf + d.hit_off[r];
+  uint8_t *hc = d.hcnt + d.hit_off[r];
+  for (uint32_t i = t; i < tot; i += G) {
+    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) {
+      uint32_t end = i + 1;
+      while (end < tot && !cm_sweep_local_break(S[end - 1], S[end], e)) ++end;
+      const uint32_t off = oc[i];
+      const uint32_t at = i < np ? off : np + (off - ncp);
+      cm_sweep_cluster(S, 1, i, end, e, req, n, h + at, hc + at, ~SB);
+    }
+  }
+  if (t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
+}
+
+// lists too long for the groups' LDS: one lane each, in the read's global segment (rare: > 8192 hits)
+__global__ __launch_bounds__(64) void k_s3b_serial(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n_list) cm_s3b_candidates(d, list[i]);
+}
+
 // S4a / S4b: few reads (pairs whose mate has to be rescued, ~7 % here) run the long occurrence-run
 // searches.  Spread over all waves they keep every wave busy for one search's latency; the block
 // therefore packs them: every lane does the cheap part of its own read, the reads with a search
@@ -159,8 +319,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t
   __shared__ uint32_t cnt;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i < n && cm_s4a_decide(d, i)) list[atomicAdd(&cnt, 1u)] = i;
+  const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
+  const uint32_t i = i0 < n && d.perm_reads ? d.perm_reads[i0] : i0;
+  if (i0 < n && cm_s4a_decide(d, i)) list[atomicAdd(&cnt, 1u)] = i;
   __syncthreads();
   if (threadIdx.x < cnt) cm_s4a_rescue(d, list[threadIdx.x]);
 }
@@ -169,26 +330,27 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t
   __shared__ uint32_t cnt;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i < n) {
+  const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i0 < n) {
+    const uint32_t i = d.perm_reads ? d.perm_reads[i0] : i0;
     if (d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0) list[atomicAdd(&cnt, 1u)] = i;
     else cm_s4b_rescue_merge(d, i);
   }
   __syncthreads();
   if (threadIdx.x < cnt) cm_s4b_rescue_merge(d, list[threadIdx.x]);
 }
-CM_ITEM_KERNEL(k_s4c_reduce, cm_s4c_reduce)
-CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare)
-CM_ITEM_KERNEL(k_s5c_finalize, cm_s5c_finalize)
+CM_ITEM_KERNEL(k_s4c_reduce, cm_s4c_reduce, perm_pairs)
+CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare, perm_reads)
+CM_ITEM_KERNEL(k_s5c_finalize, cm_s5c_finalize, perm_reads)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_items, uint32_t n_reads) {
   const uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x;
   if (j < n_items) cm_s5b_verify_item(d, j, n_reads);
 }
 // --SAM has its own instantiations: the alignment's register window must not cost the BED path occupancy
-CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair<false>)
-CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi<false>)
-CM_ITEM_KERNEL(k_s6a_pair_sam, cm_s6a_pair<true>)
-CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>)
+CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair<false>, perm_pairs)
+CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi<false>, perm_pairs)
+CM_ITEM_KERNEL(k_s6a_pair_sam, cm_s6a_pair<true>, perm_pairs)
+CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>, perm_pairs)
 
 // S6b, one WAVE per taskloop chunk: the 64 lanes scan the chunk's n_best values coalesced
 // and ballot the multi-mappers; lane 0 then walks them in pair order with the chunk's
@@ -287,7 +449,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_bc_abundance(const uint8_t *__rest
 // A block covers U*256 consecutive minimizers, lane t takes t, t+256, ...: loads and stores stay coalesced.
 // Results (hit / miss, value, number of buckets visited) are kh_get's, bucket for bucket.
 // ---------------------------------------------------------------------------------------
-#define CM_PROBE_U 4
+#define CM_PROBE_U 1
 template <int U, bool PAIR>
 __device__ __forceinline__ void cm_probe_lanes(const uint64_t *__restrict__ bkt, uint32_t bmask, const uint64_t *__restrict__ hash,
                                                uint64_t *__restrict__ val, uint8_t *__restrict__ kind, unsigned long long lo,
@@ -502,6 +664,34 @@ void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, h
   (void)rocprim::exclusive_scan((void *)tmp, bytes, in, out, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s);
 }
 
+// heavy-last order of reads and pairs: flags (a read is heavy when its hit list went to the cooperative kernel, a pair when
+// either read is), exclusive scans of the flags, scatter: light items keep their order in front, heavy items follow
+__global__ __launch_bounds__(CM_BLOCK) void k_hv_flags(CmDev d, uint32_t n_pairs, uint32_t *__restrict__ fr, uint32_t *__restrict__ fp) {
+  const uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint32_t a = d.hit_tot[2 * p] > d.s3b_cap ? 1u : 0u, b = d.hit_tot[2 * p + 1] > d.s3b_cap ? 1u : 0u;
+  fr[2 * p] = a; fr[2 * p + 1] = b;
+  fp[p] = a | b;
+}
+// scan[i] = heavy items before i, scan[n] = all heavy items
+__global__ __launch_bounds__(CM_BLOCK) void k_hv_scatter(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan, uint32_t n,
+                                                          uint32_t *__restrict__ perm) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t heavy_before = scan[i], n_light = n - scan[n];
+  perm[flag[i] ? n_light + heavy_before : i - heavy_before] = i;
+}
+// fr / sr: 2 n_pairs + 1 words each, fp / sp: n_pairs + 1 words each (scratch)
+void cm_build_heavy_last(const CmDev &d, uint32_t n_pairs, uint32_t *fr, uint32_t *sr, uint32_t *fp, uint32_t *sp, uint32_t *perm_reads,
+                         uint32_t *perm_pairs, uint32_t *scan_tmp, hipStream_t s) {
+  if (!n_pairs) return;
+  hipLaunchKernelGGL(k_hv_flags, grid_for_n(n_pairs), dim3(CM_BLOCK), 0, s, d, n_pairs, fr, fp);
+  cm_scan_u32(fr, sr, 2 * n_pairs, scan_tmp, s);
+  cm_scan_u32(fp, sp, n_pairs, scan_tmp, s);
+  hipLaunchKernelGGL(k_hv_scatter, grid_for_n(2 * n_pairs), dim3(CM_BLOCK), 0, s, (const uint32_t *)fr, (const uint32_t *)sr, 2 * n_pairs, perm_reads);
+  hipLaunchKernelGGL(k_hv_scatter, grid_for_n(n_pairs), dim3(CM_BLOCK), 0, s, (const uint32_t *)fp, (const uint32_t *)sp, n_pairs, perm_pairs);
+}
+
 // *out += sum of in[0..n) in 64 bits (the u32 prefix sums above wrap silently; the callers size and bound the
 // dense arrays from this total)
 __global__ __launch_bounds__(CM_BLOCK) void k_sum_u32(const uint32_t *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out) {
@@ -532,11 +722,36 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + CM_BLOCK - 1) / CM_BL
   void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s) {                  \
     if (n) hipLaunchKernelGGL(kname, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);         \
   }
-CM_LAUNCH(k_s3a_count)
+void cm_launch_k_s3a_count(const CmDev &d, uint32_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_s3a_count, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);
+}
+uint32_t cm_s3b_lane_cap(uint32_t max_read_len) {
+  uint32_t cap = max_read_len / 3;
+  return cap < 16 ? 16 : (cap > 64 ? 64 : cap);
+}
+// the cooperative kernel's size classes: hits per wave-group, per block, per block with a large LDS allocation
+void cm_s3b_heavy_classes(uint32_t *hv_max) {
+  static int big_ok = -1;
+  if (big_ok < 0) {
+    big_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s3b_heavy<CM_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10 + (CM_BLOCK + 8) * 4) == hipSuccess ? 1 : 0;
+    (void)hipGetLastError();
+  }
+  hv_max[0] = 1024; hv_max[1] = 4096; hv_max[2] = big_ok ? 8192 : 4096;
+}
+// n_cls[c]: reads of class c (k_s3a_count's lists)
+void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s) {
+  const uint32_t *l0 = d.hv_list, *l1 = d.hv_list + d.hv_stride, *l2 = d.hv_list + 2 * (size_t)d.hv_stride, *l3 = d.hv_list + 3 * (size_t)d.hv_stride;
+  if (n_cls[0]) {
+    const uint32_t P = d.hv_max[0], gpb = CM_BLOCK / 64;
+    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((n_cls[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, l0, n_cls[0], P);
+  }
+  if (n_cls[1]) hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)d.hv_max[1] * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], d.hv_max[1]);
+  if (n_cls[2]) hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)d.hv_max[2] * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], d.hv_max[2]);
+  if (n_cls[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((n_cls[3] + 63) / 64), dim3(64), 0, s, d, l3, n_cls[3]);
+}
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
   if (!n) return;
-  uint32_t cap = max_read_len / 3;
-  cap = cap < 16 ? 16 : (cap > 64 ? 64 : cap);
+  const uint32_t cap = cm_s3b_lane_cap(max_read_len);
   uint32_t threads = 256;
   while (threads > 64 && (size_t)cap * threads * 9 > 36 * 1024 + 1024) threads >>= 1;
   hipLaunchKernelGGL(k_s3b_candidates, dim3((n + threads - 1) / threads), dim3(threads), (size_t)cap * threads * 9, s, d, n, cap);
@@ -600,9 +815,9 @@ void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uin
 }
 // probe of the minimizers [range[0], range[1]) (device-side range), at most max_entries of them
 static inline int probe_variant_norm(int variant) {
-  if (variant == 0) variant = CM_PROBE_U + 16;
+  if (variant == 0) variant = CM_PROBE_U;
   const int u = variant & 15;
-  return ((u == 1 || u == 2 || u == 8) ? u : 4) | (variant & 16);
+  return ((u == 2 || u == 4 || u == 8) ? u : 1) | (variant & 16);
 }
 uint32_t cm_probe_range_blocks(uint64_t max_entries, int variant) {
   const uint64_t per = (uint64_t)(probe_variant_norm(variant) & 15) * CM_BLOCK;

@@ -944,6 +944,44 @@ CM_HD uint32_t cm_sweep_strided(uint64_t *h, uint8_t *cnt, uint32_t n, int e, in
   return out;
 }
 
+// The sweep cut at its state-free breaks, for lists that a group of lanes clusters together (k_s3b_heavy): a hit
+// starts a LOCAL cluster when its rid differs from its predecessor's or its position lies more than e beyond it --
+// the first two break conditions of cm_sweep_strided, which look at the two neighbours only.  At such a break the
+// sweep's state is reset to (1, 1, 1, x), so the hits [b, end) of one local cluster can be swept on their own; the
+// third, state-dependent break (enough minimizers and e beyond the best hit) is applied inside.  Candidates are
+// appended to out_h / out_c (nullptr: count only); the concatenation over the local clusters in list order is what
+// cm_sweep_strided produces.  Source list with element stride st, outputs dense.
+CM_HD bool cm_sweep_local_break(uint64_t prev, uint64_t x, int e) {
+  return (uint32_t)(x >> 32) != (uint32_t)(prev >> 32) || (uint32_t)x > (uint32_t)prev + (uint32_t)e;
+}
+CM_HD uint32_t cm_sweep_cluster(const uint64_t *h, uint32_t st, uint32_t b, uint32_t end, int e, int seeds_required,
+                                uint32_t num_minimizers, uint64_t *out_h, uint8_t *out_c, uint64_t out_mask = ~0ull) {
+  uint32_t out = 0;
+  int mcount = 1, equal = 1, best_equal = 1;
+  uint64_t prev_hit = h[(size_t)b * st], best_local = prev_hit;
+  for (uint32_t pi = b + 1; pi <= end; ++pi) {
+    const bool last = pi == end;
+    const uint64_t x = last ? ~0ull : h[(size_t)pi * st];
+    if (last || ((uint32_t)mcount >= num_minimizers && (uint32_t)x > (uint32_t)best_local + (uint32_t)e)) {
+      if (mcount >= seeds_required) {
+        if (out_h) { out_h[out] = best_local & out_mask; out_c[out] = (uint8_t)best_equal; }
+        ++out;
+      }
+      mcount = 1; equal = 1; best_equal = 1;
+      best_local = x;
+    } else {
+      if (x == best_local) { ++equal; ++best_equal; }
+      else if (x == prev_hit) {
+        ++equal;
+        if (equal > best_equal) { best_local = prev_hit; best_equal = equal; }
+      } else equal = 1;
+      ++mcount;
+    }
+    prev_hit = x;
+  }
+  return out;
+}
+
 CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
   return cm_sweep_strided(h, cnt, n, e, seeds_required, num_minimizers, 1);
 }

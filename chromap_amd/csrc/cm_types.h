@@ -103,6 +103,12 @@ struct CmDev {
   uint8_t *hcnt;        // candidate counts (same indexing as hbuf)
   uint32_t *n_pos_hit;  // [2n] boundary P between + and - sub-lists
   uint32_t *ncp, *ncn;  // [2n] candidates after GenerateCandidates
+  // ---- reads whose hit list does not fit a lane's LDS slots, by size class (k_s3a_count fills, k_s3b_heavy consumes):
+  //      hv_cnt[c] reads of class c listed at hv_list + c * hv_stride; class 0: <= hv_max[0] hits (a wave each),
+  //      1: <= hv_max[1] (a block each), 2: <= hv_max[2] (a block, large LDS), 3: longer (one lane, in global memory)
+  const uint32_t *perm_reads, *perm_pairs;  // heavy-last processing order of reads / pairs, or nullptr (identity)
+  uint32_t *hv_cnt, *hv_list;
+  uint32_t hv_stride, s3b_cap, hv_max[3];
   // ---- rescue / merged candidates
   uint8_t *aug;         // [2n] augment flag
   int32_t *res_neg;     // [2n] result of the search on the - strand (driven by mate + candidates)

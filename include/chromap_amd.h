@@ -317,7 +317,9 @@ int cmgpu_gather_sweep(cmgpu_ctx *ctx, uint64_t n, int repeat, int loads_per_lan
 
 /* Measurement knobs (the defaults are the measured best): "probe_lookups_per_lane" 1/2/4/8,
  * "probe_pair_prefetch" 0/1, "mm_chunks" 1..8, "prep_kernel" 0/1, "item_limit" (largest dense
- * intermediate array, in entries; batches that need more are mapped in sub-batches). */
+ * intermediate array, in entries; batches that need more are mapped in sub-batches), "heavy_wave_max" /
+ * "heavy_block_max" / "heavy_big_max" (size classes of the cooperative kernel for long hit lists; -1 on the first:
+ * one-lane path), "heavy_last" (reads with long hit lists processed in waves of their own: 0 auto, 1 always, -1 never). */
 int cmgpu_set_option(cmgpu_ctx *ctx, const char *name, int64_t value);
 int cmgpu_get_option(const cmgpu_ctx *ctx, const char *name, int64_t *value);
 

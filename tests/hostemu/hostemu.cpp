@@ -356,3 +356,24 @@ extern "C" int hostemu_hamming(const uint8_t *pat, const uint8_t *read, int Lful
   *naive = c;
   return cm_hamming_diag(pat, read, Lfull, neg != 0, toff, L);
 }
+
+// cm_sweep_cluster over the local clusters of a sorted list against cm_sweep_strided (k_s3b_heavy clusters a long hit
+// list with one lane per local cluster): returns 0 when the two candidate lists are equal
+extern "C" int hostemu_sweep_clusters(const uint64_t *sorted, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
+  std::vector<uint64_t> a(sorted, sorted + n), oh(n + 1);
+  std::vector<uint8_t> ac(n + 1), oc(n + 1);
+  const uint32_t want = cm_sweep_strided(a.data(), ac.data(), n, e, seeds_required, num_minimizers, 1);
+  uint32_t got = 0;
+  for (uint32_t b = 0; b < n;) {
+    uint32_t end = b + 1;
+    while (end < n && !cm_sweep_local_break(sorted[end - 1], sorted[end], e)) ++end;
+    const uint32_t c0 = cm_sweep_cluster(sorted, 1, b, end, e, seeds_required, num_minimizers, nullptr, nullptr);
+    const uint32_t c1 = cm_sweep_cluster(sorted, 1, b, end, e, seeds_required, num_minimizers, oh.data() + got, oc.data() + got);
+    if (c0 != c1) return 2;
+    got += c1;
+    b = end;
+  }
+  if (got != want) return 1;
+  for (uint32_t i = 0; i < want; ++i) if (oh[i] != a[i] || oc[i] != ac[i]) return 3;
+  return 0;
+}

@@ -165,8 +165,8 @@ def test_item_limit_maps_in_sub_batches():
     case = "s4_atac_q0"  # repeat families: multi-mappers, so the per-chunk sampling is exercised as well
     out = []
     # 20000 pairs of 50 bases: a range of n pairs sizes its minimizer arrays at 30 n entries, so 450000 cuts the batch into
-    # two ranges of 10000 pairs and 160000 into four of 5000 (the reference batch here; chunks of 5000 pairs either way)
-    for limit in (0, 450000, 160000):
+    # two ranges of 10000 pairs and 250000 into four of 5000 (the reference batch here; chunks of 5000 pairs either way)
+    for limit in (0, 450000, 250000):
         g, meta, r1, r2 = _gpu(case, read_batch_size=5000)
         if limit:
             g.set_option("item_limit", limit)

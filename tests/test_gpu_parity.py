@@ -169,6 +169,32 @@ def test_fuzz_gpu_vs_oracle(cfg, tmp_path):
     _fz.run_case(factory, cfg, tmp_path)
 
 
+HEAVY_SETTINGS = {
+    "wave": {"heavy_last": 1},                                             # long hit lists: a wave each, heavy reads last
+    "block": {"heavy_wave_max": 20, "heavy_last": 1},                      # ... a block each
+    "block_big_lds": {"heavy_wave_max": 18, "heavy_block_max": 19},        # ... a block with the large LDS allocation
+    "one_lane": {"heavy_wave_max": -1, "heavy_last": -1},                  # ... the sequential path in global memory
+}
+
+
+@pytest.mark.parametrize("setting", sorted(HEAVY_SETTINGS))
+@pytest.mark.parametrize("cfg", fuzz_data.CONFIGS[:4], ids=[str(c[0]) for c in fuzz_data.CONFIGS[:4]])
+def test_fuzz_long_hit_lists_every_path(cfg, setting, tmp_path):
+    """the cooperative kernel for long hit lists (k_s3b_heavy) in each of its size classes, and the heavy-last
+    processing order of the later stages, on the repeat-rich fuzz data: every record field and the counters"""
+    from chromap_amd import ChromapGPU
+
+    def factory(idx, fa, preset, gkw, b1, o1, b2, o2):
+        g = ChromapGPU(idx, fa, preset=preset, **gkw)
+        for k_, v_ in HEAVY_SETTINGS[setting].items():
+            g.set_option(k_, v_)
+        rec, k = g.map_pairs(b1, o1, b2, o2)
+        st = g.stats.as_dict()
+        g.close()
+        return rec, k, st
+    _fz.run_case(factory, cfg, tmp_path)
+
+
 @pytest.mark.parametrize("bc_err", [1, 2])
 def test_barcode_correction_dense_whitelist_gpu(bc_err, tmp_path):
     """as tests/test_hostemu_fuzz.py::test_barcode_correction_dense_whitelist, on the device"""
