@@ -340,7 +340,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4)
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
-  ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4)
+  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4)
 #undef ENS
   return CMGPU_OK;
 }
@@ -422,6 +422,8 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.rec = (uint8_t *)c->rec.p + (size_t)lo * 24;
   d.rec_ok = (uint8_t *)c->rec_ok.p + lo;
   d.stats = (unsigned long long *)c->stats.p;
+  d.srt_cnt = (uint32_t *)c->srt_cnt.p;
+  d.srt_list = (uint32_t *)c->srt_list.p;
   d.hv_cnt = (uint32_t *)c->hv_cnt.p;
   d.hv_list = (uint32_t *)c->hv_list.p;
   d.hv_stride = 2 * (hi - lo) + 1;
@@ -610,7 +612,9 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s4a_rescue_count");
   cm_launch_k_s4b_rescue_merge(d, n2, s);
   mark(c, "s4b_rescue_merge");
+  HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s4c_reduce(d, n, s);
+  if (c->use_perm) cm_launch_k_sort_lists(d, 0, s);  // long candidate lists: a wave each, before S5a wants them in order
   mark(c, "s4c_pair_filter");
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
   // candidate, (c) the sequential acceptance loop per read
@@ -622,7 +626,9 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s5a_prepare");
   cm_launch_k_s5b_verify(d, n_v, n2, s);
   mark(c, "s5b_verify");
+  HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s5c_finalize(d, n2, s);
+  if (c->use_perm) cm_launch_k_sort_lists(d, 1, s);  // long draft-mapping lists, before S6a pairs them
   mark(c, "s5c_accept");
   // S6: best pair, sampling of multi-mappers, records
   if (c->p.sam) {  // per-slot record / CIGAR / MD pools and the backtrack cells of one alignment per pair

@@ -16,6 +16,7 @@ uint32_t cm_probe_range_blocks(uint64_t max_entries, int variant);
 void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s, int variant);
 void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s);
 CM_DECL_LAUNCH(k_s3a_count)
+void cm_launch_k_sort_lists(const CmDev &d, int mode, hipStream_t s);
 uint32_t cm_s3b_lane_cap(uint32_t max_read_len);
 void cm_s3b_heavy_classes(uint32_t *hv_max);
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s);

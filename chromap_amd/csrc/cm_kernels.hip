@@ -339,9 +339,90 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t
   __syncthreads();
   if (threadIdx.x < cnt) cm_s4b_rescue_merge(d, list[threadIdx.x]);
 }
-CM_ITEM_KERNEL(k_s4c_reduce, cm_s4c_reduce, perm_pairs)
+// S4c; long filtered candidate lists are queued for k_sort_lists
+__global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t pair = d.perm_pairs ? d.perm_pairs[i] : i;
+  cm_s4c_reduce(d, pair);
+  if (!d.alive[pair]) return;
+  for (uint32_t r = 2 * pair; r <= 2 * pair + 1; ++r) {
+    if (d.fcp[r] > CM_SORT_SERIAL_MAX && d.fcp[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
+    if (d.fcn[r] > CM_SORT_SERIAL_MAX && d.fcn[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
+  }
+}
 CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare, perm_reads)
-CM_ITEM_KERNEL(k_s5c_finalize, cm_s5c_finalize, perm_reads)
+// S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
+__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = d.perm_reads ? d.perm_reads[i] : i;
+  cm_s5c_finalize(d, r);
+  if (d.p.split || d.p.single || !d.alive[r >> 1]) return;
+  if (d.ndp[r] > CM_SORT_SERIAL_MAX && d.ndp[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
+  if (d.ndn[r] > CM_SORT_SERIAL_MAX && d.ndn[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
+}
+
+// ---------------------------------------------------------------------------------------
+// Long candidate / draft-mapping lists (reads from repeats: hundreds of entries) sorted by a wave each, in LDS, before
+// the per-read stage that needs them in order -- a lane heap-sorting 300 entries in global memory took milliseconds and
+// there are ~10^5 such reads in a batch.  MODE 0: candidates of (read, strand) by Candidate::operator< (count descending,
+// position ascending; the (count, position) pairs of a list are distinct); MODE 1: draft mappings by position (the order
+// among equal positions does not matter, mapping_metadata.h:70-78).  Persistent waves pull items off the queue.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(CM_BLOCK) void k_sort_lists(CmDev d) {
+  const uint32_t wv = threadIdx.x >> 6, t = threadIdx.x & 63;
+  uint64_t *K = reinterpret_cast<uint64_t *>(cm_lds) + (size_t)wv * CM_SORT_WAVE_MAX;
+  uint16_t *V = reinterpret_cast<uint16_t *>(cm_lds + (size_t)(CM_BLOCK / 64) * CM_SORT_WAVE_MAX * 8) + (size_t)wv * CM_SORT_WAVE_MAX;
+  const uint32_t n_items = d.srt_cnt[0];
+  for (;;) {
+    uint32_t item = 0;
+    if (t == 0) item = atomicAdd(&d.srt_cnt[1], 1u);
+    item = __shfl(item, 0, 64);
+    if (item >= n_items) return;
+    const uint32_t code = d.srt_list[item], r = code >> 1, strand = code & 1u;
+    const uint32_t base = d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0);
+    const uint32_t n = MODE == 0 ? (strand ? d.fcn[r] : d.fcp[r]) : (strand ? d.ndn[r] : d.ndp[r]);
+    uint64_t *gk = (MODE == 0 ? d.fbuf : d.dpos) + base;
+    uint32_t P2 = 2;
+    while (P2 < n) P2 <<= 1;
+    for (uint32_t i = t; i < P2; i += 64) {
+      if (i < n) {
+        K[i] = gk[i];
+        V[i] = MODE == 0 ? (uint16_t)(255u - d.fcnt[base + i]) : (uint16_t)d.derr[base + i];
+      } else {
+        K[i] = ~0ull;
+        V[i] = 0xffffu;  // padding sorts last in both modes (MODE 0: behind every count)
+      }
+    }
+    cm_group_sync<64>();
+    for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
+      for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = t; i < (P2 >> 1); i += 64) {
+          const uint32_t a = 2 * j * (i / j) + (i % j), c = a + j;
+          const uint64_t xa = K[a], xc = K[c];
+          const uint16_t va = V[a], vc = V[c];
+          // "a sorts after c"
+          const bool gt = MODE == 0 ? (va != vc ? va > vc : xa > xc) : (xa != xc ? xa > xc : va > vc);
+          const bool up = (a & k2) == 0;
+          if (gt == up && (xa != xc || va != vc)) { K[a] = xc; K[c] = xa; V[a] = vc; V[c] = va; }
+        }
+        cm_group_sync<64>();
+      }
+    }
+    for (uint32_t i = t; i < n; i += 64) {
+      gk[i] = K[i];
+      if (MODE == 0) d.fcnt[base + i] = (uint8_t)(255u - V[i]); else d.derr[base + i] = (int16_t)V[i];
+    }
+    cm_group_sync<64>();
+  }
+}
+void cm_launch_k_sort_lists(const CmDev &d, int mode, hipStream_t s) {
+  const size_t lds = (size_t)(CM_BLOCK / 64) * CM_SORT_WAVE_MAX * 10;
+  if (mode == 0) hipLaunchKernelGGL(k_sort_lists<0>, dim3(1024), dim3(CM_BLOCK), lds, s, d);
+  else hipLaunchKernelGGL(k_sort_lists<1>, dim3(1024), dim3(CM_BLOCK), lds, s, d);
+}
 __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_items, uint32_t n_reads) {
   const uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x;
   if (j < n_items) cm_s5b_verify_item(d, j, n_reads);
@@ -741,12 +822,13 @@ void cm_s3b_heavy_classes(uint32_t *hv_max) {
 // n_cls[c]: reads of class c (k_s3a_count's lists)
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s) {
   const uint32_t *l0 = d.hv_list, *l1 = d.hv_list + d.hv_stride, *l2 = d.hv_list + 2 * (size_t)d.hv_stride, *l3 = d.hv_list + 3 * (size_t)d.hv_stride;
+  auto pow2 = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };  // the sort network's size: a power of two
   if (n_cls[0]) {
-    const uint32_t P = d.hv_max[0], gpb = CM_BLOCK / 64;
+    const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
     hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((n_cls[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, l0, n_cls[0], P);
   }
-  if (n_cls[1]) hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)d.hv_max[1] * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], d.hv_max[1]);
-  if (n_cls[2]) hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)d.hv_max[2] * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], d.hv_max[2]);
+  if (n_cls[1]) { const uint32_t P = pow2(d.hv_max[1]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], P); }
+  if (n_cls[2]) { const uint32_t P = pow2(d.hv_max[2]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], P); }
   if (n_cls[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((n_cls[3] + 63) / 64), dim3(64), 0, s, d, l3, n_cls[3]);
 }
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {

@@ -119,6 +119,11 @@ CM_HD void cm_sort_cand(uint64_t *p, uint8_t *c, uint32_t n) {
     }
     return;
   }
+  {  // long lists are sorted beforehand by a wave each (k_sort_lists): nothing left to do then
+    bool sorted = true;
+    for (uint32_t i = 1; i < n && sorted; ++i) sorted = !cm_cand_before(p[i], c[i], p[i - 1], c[i - 1]);
+    if (sorted) return;
+  }
   // heap sort with "after" as the heap order (max-heap on the sort order)
   for (uint32_t start = n / 2; start-- > 0;) {
     uint32_t root = start;
@@ -165,6 +170,11 @@ CM_HD void cm_sort_draft(uint64_t *p, int16_t *e, uint32_t n) {
       e[j] = xe;
     }
     return;
+  }
+  {  // long lists are sorted beforehand by a wave each (k_sort_lists)
+    bool sorted = true;
+    for (uint32_t i = 1; i < n && sorted; ++i) sorted = !(p[i] < p[i - 1]);
+    if (sorted) return;
   }
   for (uint32_t start = n / 2; start-- > 0;) {
     uint32_t root = start;
