@@ -345,7 +345,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n) {
   if (i >= n) return;
   const uint32_t pair = d.perm_pairs ? d.perm_pairs[i] : i;
   cm_s4c_reduce(d, pair);
-  if (!d.alive[pair]) return;
+  if (!d.perm_pairs || !d.alive[pair]) return;  // the queue is only served in a batch with heavy reads
   for (uint32_t r = 2 * pair; r <= 2 * pair + 1; ++r) {
     if (d.fcp[r] > CM_SORT_SERIAL_MAX && d.fcp[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
     if (d.fcn[r] > CM_SORT_SERIAL_MAX && d.fcn[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) 
   if (i >= n) return;
   const uint32_t r = d.perm_reads ? d.perm_reads[i] : i;
   cm_s5c_finalize(d, r);
-  if (d.p.split || d.p.single || !d.alive[r >> 1]) return;
+  if (!d.perm_reads || d.p.split || d.p.single || !d.alive[r >> 1]) return;  // the queue is only served in a batch with heavy reads
   if (d.ndp[r] > CM_SORT_SERIAL_MAX && d.ndp[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
   if (d.ndn[r] > CM_SORT_SERIAL_MAX && d.ndn[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
 }
