@@ -66,6 +66,9 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_mm_chunks = (int)value;
   } else if (n == "prep_kernel") {
     c->opt_prep_kernel = (int)value;
+  } else if (n == "prep_tile_reads") {
+    if (value < 8 || value > 128) { cm_set_error(c, "prep_tile_reads: 8..128"); return CMGPU_EINVAL; }
+    c->opt_prep_tile_reads = (int)value;
   } else if (n == "heavy_wave_max" || n == "heavy_block_max" || n == "heavy_big_max") {  // tests: force the size classes
     c->opt_heavy_max[n == "heavy_wave_max" ? 0 : n == "heavy_block_max" ? 1 : 2] = (int)value;
   } else if (n == "heavy_last") {
@@ -86,6 +89,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n == "probe_pair_prefetch") *value = (c->opt_probe_variant & 16) ? 1 : 0;
   else if (n == "mm_chunks") *value = c->opt_mm_chunks;
   else if (n == "prep_kernel") *value = c->opt_prep_kernel;
+  else if (n == "prep_tile_reads") *value = c->opt_prep_tile_reads;
   else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
   else return CMGPU_EINVAL;
   return CMGPU_OK;
@@ -492,7 +496,8 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     mark(c, "s0b_barcode");
   }
   uint32_t n_mm = 0;
-  if (cm_prep_mm_supported(d, c->max_read_len)) {
+  const bool flat = c->opt_prep_kernel == 1 && cm_prep_flat_supported(d, c->max_read_len, (uint32_t)c->opt_prep_tile_reads);
+  if (flat || cm_prep_mm_supported(d, c->max_read_len)) {
     // S0 + S1 fused: one pass of the minimizer state machine, block-level reservation of the dense arrays
     uint64_t cap = (uint64_t)n2 * (c->max_read_len / 4 + 3);
     const uint64_t bound = (uint64_t)c->bases0 + c->bases1 + 1;  // one emission per k-mer position at most
@@ -500,7 +505,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     // The pairs go through in chunks: chunk c's minimizers (K0 + K1, VALU-bound) are followed on a second
     // stream by their index probe (K2, latency-bound gather), which runs next to chunk c+1's minimizer
     // pass.  A chunk's minimizers are the cursor range its launch covered (copied to mm_marks on the device).
-    const uint32_t ppb = cm_prep_mm_pairs_per_block(d, c->max_read_len);
+    const uint32_t ppb = flat ? 128u : cm_prep_mm_pairs_per_block(d, c->max_read_len);
     const uint32_t n_chunks = n >= (1u << 20) ? (uint32_t)c->opt_mm_chunks : (n >= (1u << 17) ? 2 : 1);
     const uint64_t per_read_bound = c->max_read_len > (uint32_t)c->p.k ? c->max_read_len - (uint32_t)c->p.k + 1 : 1;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -530,7 +535,8 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       HIPCHECK(c, hipMemsetAsync(d.stats + CM_ST_PROBE_STEPS, 0, 2 * 8, s));
       unsigned long long *marks = (unsigned long long *)c->mm_marks.p;
       for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-        cm_launch_k_prep_mm(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
+        if (flat) cm_launch_k_prep_flat(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)c->opt_prep_tile_reads, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
+        else cm_launch_k_prep_mm(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
         HIPCHECK(c, hipMemcpyAsync(marks + ch + 1, c->mm_cursor.p, 8, hipMemcpyDeviceToDevice, s));
         HIPCHECK(c, hipEventRecord(c->chunk_ev[ch], s));
         HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[ch], 0));
@@ -656,6 +662,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   HIPCHECK(c, cm_stream_sync(s));
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
   *k_out = hst[CM_ST_RECORDS];
+  c->last_range_lo = rlo; c->last_range_hi = rhi;
   c->last_n_mm = n_mm; c->last_n_hits = n_hits; c->last_n_cand_cap = n_m;
   if (stats) {
     stats->num_candidates += hst[CM_ST_CAND];
@@ -815,6 +822,80 @@ extern "C" int cmgpu_download_barcode_keys(cmgpu_ctx *c, uint64_t *keys) {
   if (!c->has_barcodes) { cm_set_error(c, "the last batch had no barcodes"); return CMGPU_EINVAL; }
   HIPCHECK(c, cm_enter(c));
   if (c->n_pairs) HIPCHECK(c, hipMemcpy(keys, c->bc_key.p, (size_t)c->n_pairs * 8, hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// stage-level view of the last mapped batch for parity tests on the gfx950 build: per pair what the oracle's trace
+// (oracle/chromap_oracle.h: ora_trace, same layout) records after trimming, minimizers, candidate generation +
+// pair filter, verification and pairing -- so that a kernel change that breaks parity fails at the stage that broke.
+// ---------------------------------------------------------------------------------------
+extern "C" int cmgpu_debug_trace(cmgpu_ctx *c, cmgpu_trace *out, uint64_t capacity) {
+  if (!c || !out) return CMGPU_EINVAL;
+  HIPCHECK(c, cm_enter(c));
+  const uint32_t n = c->n_pairs;
+  if (capacity < n) { cm_set_error(c, "trace buffer too small"); return CMGPU_ECAPACITY; }
+  if (c->single) { cm_set_error(c, "the trace is defined for paired-end batches"); return CMGPU_EINVAL; }
+  if (c->last_range_lo != 0 || c->last_range_hi != n) { cm_set_error(c, "the batch was mapped in sub-batches: only the last one's intermediates are resident"); return CMGPU_EINVAL; }
+  memset(out, 0, (size_t)n * sizeof(cmgpu_trace));
+  if (n == 0) return CMGPU_OK;
+  const size_t n2 = 2 * (size_t)n;
+  std::vector<uint32_t> rlen(n2), mm(n2), mcp(n2), mcn(n2), fcp(n2), fcn(n2), ndp(n2), ndn(n2), rep(n2);
+  std::vector<int32_t> me(n2), nb(n2), se(n2), ns(n2), pmin(n), pnb(n), psec(n), pns(n);
+  std::vector<uint8_t> f0(n);
+#define DL(v, buf) HIPCHECK(c, hipMemcpy(v.data(), c->buf.p, v.size() * sizeof(v[0]), hipMemcpyDeviceToHost));
+  DL(rlen, rlen) DL(mm, mm_cnt) DL(mcp, mcp) DL(mcn, mcn) DL(fcp, fcp) DL(fcn, fcn) DL(ndp, ndp) DL(ndn, ndn) DL(rep, rep_len)
+  DL(me, min_err) DL(nb, n_best) DL(se, second_err) DL(ns, n_second) DL(pmin, pe_min) DL(pnb, pe_nbest) DL(psec, pe_second) DL(pns, pe_nsecond)
+  DL(f0, force0)
+#undef DL
+  for (uint32_t i = 0; i < n; ++i) {
+    cmgpu_trace &t = out[i];
+    const size_t a = 2 * (size_t)i, b = a + 1;
+    t.len1 = rlen[a]; t.len2 = rlen[b]; t.n_mm1 = mm[a]; t.n_mm2 = mm[b]; t.force_mapq = -1;
+    if (t.len1 == 0 && t.len2 == 0) { t.n_mm1 = t.n_mm2 = 0; continue; }
+    if (mm[a] == 0 || mm[b] == 0) continue;
+    uint32_t nc1 = mcp[a] + mcn[a], nc2 = mcp[b] + mcn[b];
+    if (nc1 > 0 && nc2 > 0 && !c->p.split) { nc1 = fcp[a] + fcn[a]; nc2 = fcp[b] + fcn[b]; }
+    t.n_cand1 = nc1; t.n_cand2 = nc2; t.rep1 = rep[a]; t.rep2 = rep[b];
+    if (!(nc1 > 0 && nc2 > 0)) continue;
+    t.n_draft1 = ndp[a] + ndn[a]; t.n_draft2 = ndp[b] + ndn[b];
+    t.min_err1 = me[a]; t.min_err2 = me[b]; t.nbest1 = nb[a]; t.nbest2 = nb[b];
+    t.second1 = se[a]; t.second2 = se[b]; t.nsecond1 = ns[a]; t.nsecond2 = ns[b];
+    if (!(t.n_draft1 > 0 && t.n_draft2 > 0)) continue;
+    t.min_sum = pmin[i]; t.nbest = pnb[i]; t.second_sum = psec[i]; t.nsecond = pns[i];
+    t.force_mapq = c->p.split ? -1 : (f0[i] ? 0 : -1);
+  }
+  return CMGPU_OK;
+}
+
+// one read's minimizers of the last mapped batch: (hash, position << 1 | strand) in emission order
+extern "C" int cmgpu_debug_minimizers(cmgpu_ctx *c, uint32_t read, uint64_t *hash_out, uint32_t *ps_out, uint32_t capacity, uint32_t *n_out) {
+  if (!c || !n_out || read >= 2 * c->n_pairs) return CMGPU_EINVAL;
+  HIPCHECK(c, cm_enter(c));
+  if (c->last_range_lo != 0 || c->last_range_hi != c->n_pairs) { cm_set_error(c, "the batch was mapped in sub-batches"); return CMGPU_EINVAL; }
+  uint32_t cnt = 0, off = 0;
+  HIPCHECK(c, hipMemcpy(&cnt, (const uint32_t *)c->mm_cnt.p + read, 4, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(&off, (const uint32_t *)c->mm_off.p + read, 4, hipMemcpyDeviceToHost));
+  *n_out = cnt;
+  if (cnt > capacity) { cm_set_error(c, "minimizer buffer too small"); return CMGPU_ECAPACITY; }
+  if (cnt && hash_out) HIPCHECK(c, hipMemcpy(hash_out, (const uint64_t *)c->mm_hash.p + off, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+  if (cnt && ps_out) HIPCHECK(c, hipMemcpy(ps_out, (const uint32_t *)c->mm_ps.p + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  return CMGPU_OK;
+}
+// all of them at once: counts / offsets per read (2 n_pairs each) and the dense arrays (n_total entries)
+extern "C" int cmgpu_debug_minimizers_all(cmgpu_ctx *c, uint32_t *cnt_out, uint32_t *off_out, uint64_t *hash_out, uint32_t *ps_out, uint64_t capacity,
+                                          uint64_t *n_total) {
+  if (!c || !cnt_out || !off_out || !n_total) return CMGPU_EINVAL;
+  HIPCHECK(c, cm_enter(c));
+  if (c->last_range_lo != 0 || c->last_range_hi != c->n_pairs) { cm_set_error(c, "the batch was mapped in sub-batches"); return CMGPU_EINVAL; }
+  const size_t n2 = 2 * (size_t)c->n_pairs;
+  *n_total = c->last_n_mm;
+  if (n2 == 0) return CMGPU_OK;
+  HIPCHECK(c, hipMemcpy(cnt_out, c->mm_cnt.p, n2 * 4, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(off_out, c->mm_off.p, n2 * 4, hipMemcpyDeviceToHost));
+  if (c->last_n_mm > capacity) { cm_set_error(c, "minimizer buffer too small"); return CMGPU_ECAPACITY; }
+  if (c->last_n_mm && hash_out) HIPCHECK(c, hipMemcpy(hash_out, c->mm_hash.p, c->last_n_mm * 8, hipMemcpyDeviceToHost));
+  if (c->last_n_mm && ps_out) HIPCHECK(c, hipMemcpy(ps_out, c->mm_ps.p, c->last_n_mm * 4, hipMemcpyDeviceToHost));
   return CMGPU_OK;
 }
 

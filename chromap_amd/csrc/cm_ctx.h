@@ -112,6 +112,7 @@ struct cmgpu_ctx {
   int opt_probe_variant = 1;       // lookups per lane | 16: second probe step requested with the first (measured: more requests in
                                    // flight per lane only slow the probe down -- the table's random-access rate is the bound)
   int opt_mm_chunks = CM_MM_CHUNKS;
+  int opt_prep_tile_reads = 64;    // reads per tile of the position-parallel minimizer kernel
   int opt_prep_kernel = 1;         // 1: position-parallel minimizer kernel where it applies, 0: lane-per-read kernels
   uint64_t opt_item_limit = 0xfffffff0ull;
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
@@ -126,6 +127,7 @@ struct cmgpu_ctx {
   uint64_t async_n = 0;
   uint64_t n_records = 0;
   uint64_t last_n_mm = 0, last_n_hits = 0, last_n_cand_cap = 0;
+  uint32_t last_range_lo = 0, last_range_hi = 0;  // pair range whose intermediates are resident (cmgpu_debug_*)
   uint64_t synth_n_minimizers = 0, synth_n_keys = 0;
   // timing
   hipEvent_t ev[CM_MAX_EVENTS] = {};

@@ -9,6 +9,9 @@
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len);
+bool cm_prep_flat_supported(const CmDev &d, uint32_t max_read_len, uint32_t tile_reads);
+void cm_launch_k_prep_flat(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t tile_reads, uint32_t mm_cap,
+                           unsigned long long *cursor, hipStream_t s);
 uint32_t cm_prep_mm_pairs_per_block(const CmDev &d, uint32_t max_read_len);
 void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
                          unsigned long long *cursor, hipStream_t s);

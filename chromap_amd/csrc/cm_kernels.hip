@@ -140,6 +140,195 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// S0 + S1 with one lane per K-MER POSITION (w = 7, odd k <= 26, reads up to 69 bases): k_prep_mm above keeps one lane
+// per read -- a sequential 7-entry window per base, lanes idle while shorter (trimmed) reads of their wave are done,
+// half the block idle during trimming, byte loads from LDS at a 50-byte stride (bank conflicts 0.32 of the LDS cycles).
+// Here a block
+//   stages its pairs' bytes in LDS (as before) and packs them to 2 bits per base (16 bases per word, SWAR, one mask
+//   of non-ACGT bytes per word);
+//   trims (one lane per pair, cm_s0_prep_ptr);
+//   lays the k-mer positions of its reads end to end (block scan of len - k + 1) and takes them in tiles of whole
+//   reads: every lane extracts the k-mer of one position from the packed words, hashes it (cm_mmf_hash: the three
+//   Hash64 of minimizer_generator.cc:47-57), stores the hash in LDS; two sliding extrema over the read's hashes
+//   (window minima, then the maximum of the window minima that contain the position) flag the minimizers -- the
+//   closed form of cm_minimizers_w7_oddk, cm_stages.h; a block scan of the flags gives every minimizer its slot in
+//   the dense arrays (one atomic per tile reserves the range), in read and position order;
+//   redoes the few reads the closed form does not cover with the sequential code (non-ACGT bases, fewer than
+//   7 k-mers, first-window tie), from global memory.
+// ---------------------------------------------------------------------------------------
+struct CmFlatRead { uint32_t at; uint16_t cnt; uint8_t fb; uint8_t mate; };
+
+__global__ __launch_bounds__(CM_BLOCK) void k_prep_flat(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of this launch's pair range */,
+                                                        uint32_t lds_half, uint32_t nt_max, uint32_t tile_reads, uint32_t mm_cap,
+                                                        unsigned long long *cursor) {
+  constexpr uint32_t T = CM_BLOCK, PB = T / 2;
+  const uint32_t p0 = pair_lo + blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
+  const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp, mate = t < PB ? 0u : 1u;
+  const int k = d.p.k;
+  // ---- LDS carve-up
+  const uint32_t region0 = 2 * lds_half > 16 * nt_max ? 2 * lds_half : 16 * nt_max;
+  const uint32_t nw = lds_half / 16 + 1;
+  uint64_t *H = reinterpret_cast<uint64_t *>(cm_lds), *M = H + nt_max;
+  uint32_t *pk0 = reinterpret_cast<uint32_t *>(cm_lds + region0), *pk1 = pk0 + nw + 3;
+  uint16_t *bd0 = reinterpret_cast<uint16_t *>(pk1 + nw + 3), *bd1 = bd0 + nw + 1;
+  CmFlatRead *ri = reinterpret_cast<CmFlatRead *>(reinterpret_cast<uint8_t *>(bd1 + nw + 1) + ((8 - ((uintptr_t)(2 * (nw + 1) * 2)) % 8) % 8));
+  uint32_t *pos_off = reinterpret_cast<uint32_t *>(ri + T);
+  uint16_t *meta = reinterpret_cast<uint16_t *>(pos_off + T + 1 + 1);
+  uint16_t *pref = meta + nt_max + (nt_max & 1);
+  uint32_t *misc = reinterpret_cast<uint32_t *>(pref + nt_max + 2 + (nt_max & 1));
+  // ---- stage + trim
+  const uint64_t g0a = d.ro0[p0], g0b = d.ro0[p1], g1a = d.ro1[p0], g1b = d.ro1[p1];
+  const uint64_t a0 = g0a & ~15ull, a1 = g1a & ~15ull;
+  uint8_t *l0 = cm_lds, *l1 = cm_lds + lds_half;
+  cm_stage_range(l0, d.rb0, a0, g0b);
+  cm_stage_range(l1, d.rb1, a1, g1b);
+  __syncthreads();
+  const bool valid = pair < p1;
+  const uint32_t off_m0 = valid ? (uint32_t)(d.ro0[pair] - a0) : 0u, off_m1 = valid ? (uint32_t)(d.ro1[pair] - a1) : 0u;
+  // pack: 16 staged bytes -> one word of codes + a mask of bytes that are no base letter
+  {
+    const uint32_t n0 = (uint32_t)(g0b - a0), n1 = (uint32_t)(g1b - a1);
+    const uint32_t w0 = (n0 + 15) / 16, w1 = (n1 + 15) / 16;
+    for (uint32_t w = t; w < w0 + w1; w += T) {
+      const bool second = w >= w0;
+      const uint32_t wi = second ? w - w0 : w;
+      const uint4 q = *reinterpret_cast<const uint4 *>((second ? l1 : l0) + 16 * wi);
+      uint32_t b0, b1, b2, b3;
+      const uint32_t word = cm_mmf_pack4(q.x, &b0) | (cm_mmf_pack4(q.y, &b1) << 8) | (cm_mmf_pack4(q.z, &b2) << 16) | (cm_mmf_pack4(q.w, &b3) << 24);
+      (second ? pk1 : pk0)[wi] = word;
+      (second ? bd1 : bd0)[wi] = (uint16_t)(b0 | (b1 << 4) | (b2 << 8) | (b3 << 12));
+    }
+    if (t < 3) { pk0[w0 + t] = 0; pk1[w1 + t] = 0; }
+    if (t == 3) { bd0[w0] = 0; bd1[w1] = 0; }
+  }
+  if (t < PB && valid) cm_s0_prep_ptr(d, pair, l0 + off_m0, l1 + off_m1);
+  __syncthreads();
+  // ---- one read per lane: k-mer count, or the sequential route
+  const uint32_t r = 2 * pair + mate;
+  uint32_t len = 0, cnt = 0, fb = 0;
+  const uint32_t at = mate ? off_m1 : off_m0;
+  if (valid) {
+    len = d.rlen[r];
+    const uint32_t m = len >= (uint32_t)k ? len - (uint32_t)k + 1 : 0;
+    bool bad = false;
+    if (m) {
+      const uint16_t *bd = mate ? bd1 : bd0;
+      const uint32_t wa = at >> 4, wb = (at + len - 1) >> 4;
+      for (uint32_t w = wa; w <= wb; ++w) {
+        uint32_t mk = bd[w];
+        if (w == wa) mk &= 0xFFFFu << (at & 15u);
+        if (w == wb) mk &= 0xFFFFu >> (15u - ((at + len - 1) & 15u));
+        bad = bad || mk != 0;
+      }
+    }
+    if (m && (bad || m < 7)) fb = 1; else cnt = m;
+  }
+  ri[t].at = at; ri[t].cnt = (uint16_t)cnt; ri[t].fb = (uint8_t)fb; ri[t].mate = (uint8_t)mate;
+  {  // block exclusive scan of cnt -> pos_off[0..T]
+    const uint32_t lane = t & 63, wave = t >> 6;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t v = __shfl_up(incl, dlt, 64);
+      if (lane >= (uint32_t)dlt) incl += v;
+    }
+    if (lane == 63) misc[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t q = 0; q < wave; ++q) wbase += misc[q];
+    pos_off[t] = wbase + incl - cnt;
+    if (t == T - 1) pos_off[T] = wbase + incl;
+  }
+  __syncthreads();
+  // ---- tiles of whole reads
+  for (uint32_t r0 = 0; r0 < T; r0 += tile_reads) {
+    const uint32_t r1 = r0 + tile_reads < T ? r0 + tile_reads : T;
+    const uint32_t P0 = pos_off[r0], NT = pos_off[r1] - P0;
+    // (a) hash of every position
+    for (uint32_t p = t; p < NT; p += T) {
+      uint32_t lr = r0 + (uint32_t)(((uint64_t)p * (r1 - r0)) / NT);
+      while (pos_off[lr + 1] - P0 <= p) ++lr;
+      while (pos_off[lr] - P0 > p) --lr;
+      const uint32_t i = p - (pos_off[lr] - P0);
+      uint32_t sd;
+      H[p] = cm_mmf_hash(cm_mmf_kmer(ri[lr].mate ? pk1 : pk0, ri[lr].at + i, k), k, &sd);
+      meta[p] = (uint16_t)(((lr - r0) << 7) | (i << 1) | sd);  // read in tile (<= 127) | k-mer index (<= 63) | strand
+    }
+    __syncthreads();
+    // (b) window minima; the first window also decides whether the read needs the sequential route
+    for (uint32_t p = t; p < NT; p += T) {
+      const uint32_t mt = meta[p], lr = r0 + (mt >> 7), i = (mt >> 1) & 63u, m = ri[lr].cnt;
+      if (i + 7 <= m) {
+        uint64_t x = H[p];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) x = H[p + q] < x ? H[p + q] : x;
+        const uint64_t h6 = H[p + 6];
+        if (i == 0 && h6 == x) ri[lr].fb = 2;
+        M[p] = h6 < x ? h6 : x;
+      }
+    }
+    __syncthreads();
+    // (c) minimizer <=> own hash equals the largest minimum of the windows that hold it
+    for (uint32_t p = t; p < NT; p += T) {
+      const uint32_t mt = meta[p], lr = r0 + (mt >> 7), i = (mt >> 1) & 63u, m = ri[lr].cnt;
+      const uint32_t j0 = i >= 6 ? i - 6 : 0, j1 = i + 7 <= m ? i : m - 7, b = p - i;
+      uint64_t x = 0;
+      for (uint32_t j = j0; j <= j1; ++j) x = M[b + j] > x ? M[b + j] : x;
+      const bool fl = x == H[p] && ri[lr].fb == 0;
+      meta[p] = (uint16_t)(mt | (fl ? 0x8000u : 0u));
+    }
+    __syncthreads();
+    // (d) slots: exclusive scan of the flags in position order, one reservation per tile
+    {
+      const uint32_t chunk = (NT + T - 1) / T, c0 = t * chunk < NT ? t * chunk : NT, c1 = c0 + chunk < NT ? c0 + chunk : NT;
+      uint32_t sum = 0;
+      for (uint32_t p = c0; p < c1; ++p) sum += meta[p] >> 15;
+      const uint32_t lane = t & 63, wave = t >> 6;
+      uint32_t incl = sum;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const uint32_t v = __shfl_up(incl, dlt, 64);
+        if (lane >= (uint32_t)dlt) incl += v;
+      }
+      if (lane == 63) misc[8 + wave] = incl;
+      __syncthreads();
+      uint32_t run = incl - sum;
+      for (uint32_t q = 0; q < wave; ++q) run += misc[8 + q];
+      for (uint32_t p = c0; p < c1; ++p) { pref[p] = (uint16_t)run; run += meta[p] >> 15; }
+      if (t == T - 1) {
+        pref[NT] = (uint16_t)run;
+        const unsigned long long base = run ? atomicAdd(cursor, (unsigned long long)run) : 0ull;
+        misc[16] = (uint32_t)base; misc[17] = (uint32_t)(base >> 32);
+      }
+    }
+    __syncthreads();
+    const unsigned long long base = (unsigned long long)misc[16] | ((unsigned long long)misc[17] << 32);
+    for (uint32_t p = t; p < NT; p += T) {
+      const uint32_t mt = meta[p];
+      if (mt >> 15) {
+        const unsigned long long o = base + pref[p];
+        if (o < mm_cap) { d.mm_hash[o] = H[p]; d.mm_ps[o] = ((((mt >> 1) & 63u) + (uint32_t)k - 1u) << 1) | (mt & 1u); }
+      }
+    }
+    if (t >= r0 && t < r1 && valid && ri[t].fb == 0) {  // this lane's read lies in the tile
+      const uint32_t a = pos_off[t] - P0, b = pos_off[t + 1] - P0;
+      d.mm_cnt[r] = (uint32_t)pref[b] - (uint32_t)pref[a];
+      d.mm_off[r] = (uint32_t)(base + pref[a]);
+    }
+    __syncthreads();
+  }
+  // ---- the reads the closed form does not cover: sequentially, from global memory (the staged bytes are gone)
+  if (valid && ri[t].fb) {
+    const uint8_t *seq = cm_read_ptr(d, r);
+    const uint32_t c = cm_minimizers_window<7>(seq, len, k, nullptr, nullptr, 0);
+    const unsigned long long off = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
+    d.mm_cnt[r] = c;
+    d.mm_off[r] = (uint32_t)off;
+    if (c && off + c <= mm_cap) cm_minimizers_window<7>(seq, len, k, d.mm_hash + off, d.mm_ps + off, c);
+  }
+}
+
 // S3a: hit counts per read; reads whose hit list will not fit a lane's LDS slots in k_s3b_candidates are listed by
 // size class for the cooperative kernel below
 __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
@@ -874,6 +1063,29 @@ static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *th
   }
   *threads = t;
   return true;
+}
+// position-parallel kernel: odd k (the closed form), k <= 26 (k-mer + shift inside 96 packed bits), reads up to 69 bases (6-bit k-mer index)
+static bool prep_flat_geometry(const CmDev &d, uint32_t max_read_len, uint32_t tile_reads, uint32_t *half, uint32_t *nt_max, size_t *lds) {
+  if (d.p.w != 7 || !(d.p.k & 1) || d.p.k > 26 || max_read_len > 69 || max_read_len < (uint32_t)d.p.k + 6) return false;
+  *half = (uint32_t)(((uint64_t)(CM_BLOCK / 2) * max_read_len + 64 + 15) & ~15ull);
+  *nt_max = tile_reads * (max_read_len - (uint32_t)d.p.k + 1);
+  const size_t region0 = 2 * (size_t)*half > 16 * (size_t)*nt_max ? 2 * (size_t)*half : 16 * (size_t)*nt_max;
+  const size_t nw = *half / 16 + 1;
+  *lds = region0 + 2 * (nw + 3) * 4 + 2 * (nw + 1) * 2 + 8 + CM_BLOCK * sizeof(CmFlatRead) + (CM_BLOCK + 2) * 4 + ((size_t)*nt_max + 2) * 2 * 2 + 8 + 32 * 4;
+  return *lds <= 64 * 1024;
+}
+bool cm_prep_flat_supported(const CmDev &d, uint32_t max_read_len, uint32_t tile_reads) {
+  uint32_t h, n;
+  size_t l;
+  return prep_flat_geometry(d, max_read_len, tile_reads, &h, &n, &l);
+}
+void cm_launch_k_prep_flat(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t tile_reads, uint32_t mm_cap,
+                           unsigned long long *cursor, hipStream_t s) {
+  uint32_t half, nt_max;
+  size_t lds;
+  if (pair_hi <= pair_lo || !prep_flat_geometry(d, max_read_len, tile_reads, &half, &nt_max, &lds)) return;
+  const uint32_t pb = CM_BLOCK / 2;
+  hipLaunchKernelGGL(k_prep_flat, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(CM_BLOCK), lds, s, d, pair_lo, pair_hi, half, nt_max, tile_reads, mm_cap, cursor);
 }
 bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len) {
   uint32_t t, h, g;

@@ -654,6 +654,82 @@ CM_HD uint32_t cm_minimizers_w7_oddk(const uint8_t *seq, uint32_t len, int k, Em
   return n;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same closed form with one LANE PER K-MER POSITION instead of one lane per read (k_prep_flat): the reads of a
+// block are packed to 2 bits per base, every lane hashes the k-mer of one position (three Hash64, nothing sequential),
+// and the selection is two sliding extrema over the per-read hash arrays:
+//   M[j] = min(h[j..j+6])                    for every complete window j of the read
+//   k-mer i is emitted  <=>  h[i] == max{ M[j] : j in [i-6, i], j a complete window }
+// (every window that contains i has a minimum <= h[i], so the largest of them equals h[i] exactly when one does).
+// What the position-parallel form leaves to the sequential code: reads with a base outside ACGT / acgt, reads with
+// fewer than 7 k-mers, and reads whose seventh k-mer ties with the minimum of the first six (the first-window rule
+// strikes earlier k-mers out there) -- all rare, all redone by cm_minimizers_w7.
+// ---------------------------------------------------------------------------------------
+// 16 bytes -> 16 2-bit codes (CharToUint8's: A0 C1 G2 T3; byte j at bits 2j) + a mask of the bytes that are not A/C/G/T
+// in either case.  Four bytes at a time: bits 1-2 of a letter Gray-decode to the code (cm_c2u); the letter is
+// rebuilt from the code and compared with the case-folded byte.
+CM_HD uint32_t cm_mmf_pack4(uint32_t w, uint32_t *bad4) {
+  const uint32_t x = (w >> 1) & 0x03030303u;
+  const uint32_t code = x ^ ((x >> 1) & 0x01010101u);
+  const uint32_t b0 = code & 0x01010101u, b1 = (code >> 1) & 0x01010101u;
+  const uint32_t canon = 0x41414141u + 2u * b0 + 6u * b1 + 11u * (b0 & b1);  // A C G T = 0x41 + {0, 2, 6, 0x13}
+  const uint32_t diff = (w & 0xDFDFDFDFu) ^ canon;
+  // non-zero bytes of diff -> one bit each
+  const uint32_t nz = ((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff;
+  const uint32_t m = (nz >> 7) & 0x01010101u;
+  *bad4 = (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+  uint32_t t = (code | (code >> 6)) & 0x000F000Fu;
+  t = (t | (t >> 12)) & 0xFFu;
+  return t;
+}
+// the 2k-bit little-endian k-mer (base s+j at bits 2j) that starts at base `at` of a packed range (16 bases per word)
+CM_HD uint64_t cm_mmf_kmer(const uint32_t *pk, uint32_t at, int k) {
+  const uint32_t w = at >> 4, sh = (at & 15u) << 1;
+  const uint64_t lo = (uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32);
+  uint64_t v = lo >> sh;
+  if (sh) v |= (uint64_t)pk[w + 2] << (64 - sh);
+  return v & ((((uint64_t)1) << (2 * k)) - 1);
+}
+// reversal of the k 2-bit groups of v
+CM_HD uint64_t cm_mmf_revgroups(uint64_t v, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t x = __brevll(v) >> (64 - 2 * k);
+#else
+  uint64_t x = 0;
+  for (int i = 0; i < 64; ++i) x |= ((v >> i) & 1ull) << (63 - i);
+  x >>= (64 - 2 * k);
+#endif
+  return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+// minimizer hash and strand of the k-mer v (minimizer_generator.cc:47-57): fw has the first base in its top bits,
+// rv = the reverse complement = the complemented little-endian k-mer
+CM_HD uint64_t cm_mmf_hash(uint64_t v, int k, uint32_t *strand) {
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  const uint64_t fw = cm_mmf_revgroups(v, k), rv = ~v & mask;
+  const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+  *strand = h0 < h1 ? 0u : 1u;
+  return cm_hash64(*strand ? h1 : h0, mask);
+}
+// selection over one read's hashes h[0..m) (m >= 7); Mbuf: m entries of scratch.  Returns false when the read has to be
+// redone sequentially (first-window tie); otherwise flag[i] = k-mer i is a minimizer.
+CM_HD bool cm_mmf_select(const uint64_t *h, uint32_t m, uint64_t *Mbuf, uint8_t *flag) {
+  uint64_t v5 = h[0];
+  for (int j = 1; j < 6; ++j) v5 = h[j] < v5 ? h[j] : v5;
+  if (h[6] == v5) return false;
+  for (uint32_t j = 0; j + 7 <= m; ++j) {
+    uint64_t x = h[j];
+    for (int q = 1; q < 7; ++q) x = h[j + q] < x ? h[j + q] : x;
+    Mbuf[j] = x;
+  }
+  for (uint32_t i = 0; i < m; ++i) {
+    const uint32_t j0 = i >= 6 ? i - 6 : 0, j1 = i + 7 <= m ? i : m - 7;
+    uint64_t x = 0;
+    for (uint32_t j = j0; j <= j1; ++j) x = Mbuf[j] > x ? Mbuf[j] : x;
+    flag[i] = x == h[i] ? 1 : 0;
+  }
+  return true;
+}
+
 // w = 7 front end: closed form for odd k, the state machine otherwise and for reads with ambiguous bases
 template <class Emit>
 CM_HD uint32_t cm_minimizers_w7(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {

@@ -323,6 +323,23 @@ int cmgpu_gather_sweep(cmgpu_ctx *ctx, uint64_t n, int repeat, int loads_per_lan
 int cmgpu_set_option(cmgpu_ctx *ctx, const char *name, int64_t value);
 int cmgpu_get_option(const cmgpu_ctx *ctx, const char *name, int64_t *value);
 
+/* ---- stage-level view of the last mapped batch (parity tests of the gfx950 build against the oracle's trace) ----
+ * cmgpu_trace has the layout of oracle/chromap_oracle.h: ora_trace: per pair the read lengths after trimming
+ * (chromap.cc:176-289), minimizer counts (minimizer_generator.cc:7-139), candidates entering verification
+ * (candidate_processor.cc:12-263), draft mappings and error bookkeeping (draft_mapping_generator.cc:9-557),
+ * pairing (mapping_generator.h:160-253).  Paired-end batches mapped in one piece only. */
+typedef struct cmgpu_trace {
+  uint32_t len1, len2, n_mm1, n_mm2, n_cand1, n_cand2, n_draft1, n_draft2;
+  int32_t min_err1, min_err2, nbest1, nbest2, second1, second2, nsecond1, nsecond2;
+  uint32_t rep1, rep2;
+  int32_t min_sum, nbest, second_sum, nsecond, force_mapq;
+} cmgpu_trace;
+int cmgpu_debug_trace(cmgpu_ctx *ctx, cmgpu_trace *out, uint64_t capacity);
+/* minimizers of one read (index 2 * pair + mate) / of all reads of the last mapped batch: hash and position << 1 | strand */
+int cmgpu_debug_minimizers(cmgpu_ctx *ctx, uint32_t read, uint64_t *hash_out, uint32_t *ps_out, uint32_t capacity, uint32_t *n_out);
+int cmgpu_debug_minimizers_all(cmgpu_ctx *ctx, uint32_t *cnt_out, uint32_t *off_out, uint64_t *hash_out, uint32_t *ps_out,
+                               uint64_t capacity, uint64_t *n_total);
+
 /* Per-stage timing of the last cmgpu_map_* call (HIP events on the launch stream).
  * names/ms arrays of capacity cap; returns number of stages. */
 int cmgpu_last_timings(const cmgpu_ctx *ctx, const char **names, float *ms, int cap);

@@ -377,3 +377,47 @@ extern "C" int hostemu_sweep_clusters(const uint64_t *sorted, uint32_t n, int e,
   for (uint32_t i = 0; i < want; ++i) if (oh[i] != a[i] || oc[i] != ac[i]) return 3;
   return 0;
 }
+
+// one read through the position-parallel formulation of the w = 7 minimizer pass (what k_prep_flat does per lane):
+// pack -> k-mer of every position -> hash -> sliding-extrema selection, sequential fallback where the kernel takes it.
+// *path: 0 position-parallel, 1 fallback
+extern "C" int hostemu_minimizers_flat(const uint8_t *seq, uint32_t len, int k, uint64_t *out_hash, uint32_t *out_ps, uint32_t cap, int *path) {
+  auto put = [&](uint32_t n, uint64_t h, uint32_t p) { if (n < cap) { out_hash[n] = h; out_ps[n] = p; } };
+  *path = 1;
+  if (!(k & 1) || len < (uint32_t)k + 6) return (int)cm_minimizers_w7(seq, len, k, put);
+  // pack with an arbitrary start offset inside the packed range, like a read somewhere in a block's staged bytes
+  const uint32_t lead = 5;
+  std::vector<uint8_t> raw(lead + len + 32, (uint8_t)'A');
+  memcpy(raw.data() + lead, seq, len);
+  std::vector<uint32_t> pk((raw.size() + 15) / 16 + 3, 0);
+  bool bad = false;
+  for (size_t w = 0; w * 16 + 16 <= raw.size(); ++w) {
+    uint32_t word = 0;
+    for (int q = 0; q < 4; ++q) {
+      uint32_t in;
+      memcpy(&in, raw.data() + w * 16 + q * 4, 4);
+      uint32_t b4;
+      word |= cm_mmf_pack4(in, &b4) << (8 * q);
+      for (int b = 0; b < 4; ++b) {
+        const size_t pos = w * 16 + q * 4 + b;
+        if (((b4 >> b) & 1u) && pos >= lead && pos < lead + len) bad = true;
+      }
+    }
+    pk[w] = word;
+  }
+  if (bad) return (int)cm_minimizers_w7(seq, len, k, put);
+  const uint32_t m = len - (uint32_t)k + 1;
+  std::vector<uint64_t> h(m), M(m);
+  std::vector<uint8_t> st(m), fl(m);
+  for (uint32_t i = 0; i < m; ++i) {
+    uint32_t sd;
+    h[i] = cm_mmf_hash(cm_mmf_kmer(pk.data(), lead + i, k), k, &sd);
+    st[i] = (uint8_t)sd;
+  }
+  if (!cm_mmf_select(h.data(), m, M.data(), fl.data())) return (int)cm_minimizers_w7(seq, len, k, put);
+  *path = 0;
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < m; ++i)
+    if (fl[i]) { put(n, h[i], ((i + (uint32_t)k - 1) << 1) | st[i]); ++n; }
+  return (int)n;
+}

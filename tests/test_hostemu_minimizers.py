@@ -64,3 +64,31 @@ def test_w7_minimizers_equal_the_reference_state_machine(k):
             assert got == want, (variant, bytes(s), got, want)
         n_emitted += c
     assert n_emitted > 50000
+
+
+@pytest.mark.parametrize("k", [17, 19, 23, 15, 25])
+def test_position_parallel_minimizers_equal_the_reference_state_machine(k):
+    """the per-lane pieces of k_prep_flat (2-bit packing, k-mer extraction, strand / hash, sliding-extrema selection,
+    and the cases it hands to the sequential code) against the oracle's state machine"""
+    L = he.lib()
+    O = ol.lib()
+    f = L.hostemu_minimizers_flat
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(7000 + k)
+    oh, ot = np.zeros(256, np.uint64), np.zeros(256, np.uint64)
+    gh, gp = np.zeros(256, np.uint64), np.zeros(256, np.uint32)
+    n_flat = n_fallback = 0
+    for s in _reads(rng, 24000):
+        buf = np.concatenate([s, np.zeros(8, np.uint8)])
+        c = O.ora_minimizers(buf.ctypes.data_as(C.c_char_p), len(s), 0, k, 7, oh.ctypes.data, ot.ctypes.data)
+        want = [(int(oh[i]), int(ot[i]) & 0x1FFFFFFFF) for i in range(c)]
+        path = C.c_int(0)
+        g = f(buf.ctypes.data, len(s), k, gh.ctypes.data, gp.ctypes.data, 256, C.byref(path))
+        got = [(int(gh[i]), int(gp[i])) for i in range(g)]
+        assert got == want, (path.value, bytes(s), got, want)
+        if path.value == 0:
+            n_flat += 1
+        else:
+            n_fallback += 1
+    assert n_flat > 8000 and n_fallback > 1000  # both routes exercised
