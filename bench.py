@@ -200,6 +200,8 @@ def timed_run(g, args, rank, world, dist, seed0, exchange):
         g.swap_resident(sl)
         return k, tm
 
+    if exchange:  # a run knows how many pairs it maps: the owner's store is sized once, not doubled on the way
+        g.store_reserve(int((args.warmup + args.steps + 1) * args.pairs * 1.3))
     for i in range(args.warmup):
         step(i, Stats())
     g.store_clear()

@@ -97,7 +97,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device", "cmgpu_records_partition",
            "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_map_single_barcoded", "cmgpu_write_bed_pe_bc",
-           "cmgpu_store_clear", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
+           "cmgpu_store_clear", "cmgpu_store_reserve", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
            "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded",
            "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
@@ -169,6 +169,7 @@ def declare(L):
     sig("cmgpu_map_single", C.c_int, [C.c_void_p, P(SingleBatch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
     sig("cmgpu_records_partition", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, P(C.c_uint64)])
     sig("cmgpu_store_clear", C.c_int, [C.c_void_p])
+    sig("cmgpu_store_reserve", C.c_int, [C.c_void_p, C.c_uint64, C.c_int])
     sig("cmgpu_store_append_resident", C.c_int, [C.c_void_p, P(C.c_uint64)])
     sig("cmgpu_store_append", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int])
     sig("cmgpu_store_format", C.c_int, [C.c_void_p, C.c_int, P(C.c_char_p), C.c_uint32, P(Params), C.c_uint32,

@@ -366,6 +366,18 @@ int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc) {
   return CMGPU_OK;
 }
 
+// room for n_records in the store ahead of time (a run knows roughly how many pairs it will map: growing the store on
+// demand doubles it with an allocation, a device-to-device copy and a synchronous free each time)
+extern "C" int cmgpu_store_reserve(cmgpu_ctx *c, uint64_t n_records, int barcoded) {
+  if (!c) return CMGPU_EINVAL;
+  PPCHECK(c, cm_enter(c));
+  if (c->store_n && c->store_has_bc != (barcoded != 0)) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
+  const bool had_bc = c->store_has_bc;
+  const int rc = cm_store_reserve(c, n_records, barcoded != 0);
+  if (c->store_n == 0) c->store_has_bc = had_bc;  // an empty store takes the kind of the first append
+  return rc;
+}
+
 extern "C" int cmgpu_store_clear(cmgpu_ctx *c) {
   if (!c) return CMGPU_EINVAL;
   c->store_n = 0;

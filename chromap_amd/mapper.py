@@ -399,6 +399,9 @@ class ChromapGPU:
     def store_clear(self):
         self._check(self.L.cmgpu_store_clear(self.ctx), self.ctx)
 
+    def store_reserve(self, n_records, barcoded=False):
+        self._check(self.L.cmgpu_store_reserve(self.ctx, n_records, int(barcoded)), self.ctx)
+
     def store_append_resident(self):
         """appends the records of the last map_* call (still resident); returns the store size"""
         n = C.c_uint64(0)

@@ -480,6 +480,8 @@ int64_t cmgpu_write_sam_barcoded(const char *const *ref_names, const uint32_t *r
 #define CMGPU_TEXT_BED_SE_BC 5      /* single-end single-cell BED: MappingWithBarcode (src/bed_mapping.h:11-56, src/mapping_writer.cc:6-25) */
 #define CMGPU_TEXT_TAGALIGN_SE_BC 6 /* --TagAlign, single-end single-cell: chr start end N mapq strand (src/mapping_writer.cc:26-34) */
 int cmgpu_store_clear(cmgpu_ctx *ctx);
+/* room for n_records ahead of time (the store otherwise doubles on demand: allocation + copy + synchronous free) */
+int cmgpu_store_reserve(cmgpu_ctx *ctx, uint64_t n_records, int barcoded);
 /* appends the records of the last cmgpu_map_* call (still resident); n_total = store size */
 int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);
 /* appends n records from a host or device array; barcoded = 0: cmgpu_record entries,

@@ -2,7 +2,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 T=${1:-r02b}
 mkdir -p gpurun_out/$T
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_exchange.py tests/test_gpu_synthetic.py -m gpu -q --maxfail=15 -p no:cacheprovider > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/$T/pytest.log
+timeout 1500 python -m pytest tests/test_gpu_stages.py tests/test_gpu_parity.py tests/test_gpu_exchange.py tests/test_gpu_synthetic.py -m gpu -q --maxfail=15 -p no:cacheprovider > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/$T/pytest.log
 tail -12 gpurun_out/$T/pytest.log
 timeout 900 python bench.py --steps 10 --warmup 2 --skip-cpu > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.log; echo "bench rc $?"
 tail -3 gpurun_out/$T/bench_default.log
