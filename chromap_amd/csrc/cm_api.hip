@@ -851,8 +851,8 @@ extern "C" int cmgpu_debug_trace(cmgpu_ctx *c, cmgpu_trace *out, uint64_t capaci
   for (uint32_t i = 0; i < n; ++i) {
     cmgpu_trace &t = out[i];
     const size_t a = 2 * (size_t)i, b = a + 1;
+    if (rlen[a] == 0 && rlen[b] == 0) continue;  // dropped by the length filter: nothing is traced (the entry stays zero)
     t.len1 = rlen[a]; t.len2 = rlen[b]; t.n_mm1 = mm[a]; t.n_mm2 = mm[b]; t.force_mapq = -1;
-    if (t.len1 == 0 && t.len2 == 0) { t.n_mm1 = t.n_mm2 = 0; continue; }
     if (mm[a] == 0 || mm[b] == 0) continue;
     uint32_t nc1 = mcp[a] + mcn[a], nc2 = mcp[b] + mcn[b];
     if (nc1 > 0 && nc2 > 0 && !c->p.split) { nc1 = fcp[a] + fcn[a]; nc2 = fcp[b] + fcn[b]; }

@@ -245,9 +245,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_prep_flat(CmDev d, uint32_t pair_l
   for (uint32_t r0 = 0; r0 < T; r0 += tile_reads) {
     const uint32_t r1 = r0 + tile_reads < T ? r0 + tile_reads : T;
     const uint32_t P0 = pos_off[r0], NT = pos_off[r1] - P0;
+    const float per_pos = NT ? (float)(r1 - r0) / (float)NT : 0.0f;  // reads per position: first guess of a position's read
     // (a) hash of every position
     for (uint32_t p = t; p < NT; p += T) {
-      uint32_t lr = r0 + (uint32_t)(((uint64_t)p * (r1 - r0)) / NT);
+      uint32_t lr = r0 + (uint32_t)((float)p * per_pos);
+      lr = lr < r1 ? lr : r1 - 1;
       while (pos_off[lr + 1] - P0 <= p) ++lr;
       while (pos_off[lr] - P0 > p) --lr;
       const uint32_t i = p - (pos_off[lr] - P0);
@@ -430,9 +432,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t 
   const uint32_t np = ctr[1], nn = tot - np;
   // ---- sort (ascending; keys with bit 63 -- the - strand -- follow the + strand's)
   for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
-    for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+    for (uint32_t j = k2 >> 1, lj = 31u - (uint32_t)__clz(k2 >> 1); j > 0; j >>= 1, --lj) {
       for (uint32_t i = t; i < (P2 >> 1); i += G) {
-        const uint32_t a = 2 * j * (i / j) + (i % j), c = a + j;
+        const uint32_t a = ((i >> lj) << (lj + 1)) | (i & (j - 1)), c = a + j;  // j = 1 << lj
         const uint64_t x = S[a], y = S[c];
         const bool up = (a & k2) == 0;
         if ((x > y) == up) { S[a] = y; S[c] = x; }
@@ -587,9 +589,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_sort_lists(CmDev d) {
     }
     cm_group_sync<64>();
     for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
-      for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+      for (uint32_t j = k2 >> 1, lj = 31u - (uint32_t)__clz(k2 >> 1); j > 0; j >>= 1, --lj) {
         for (uint32_t i = t; i < (P2 >> 1); i += 64) {
-          const uint32_t a = 2 * j * (i / j) + (i % j), c = a + j;
+          const uint32_t a = ((i >> lj) << (lj + 1)) | (i & (j - 1)), c = a + j;  // j = 1 << lj
           const uint64_t xa = K[a], xc = K[c];
           const uint16_t va = V[a], vc = V[c];
           // "a sorts after c"

@@ -41,6 +41,51 @@ CM_HD uint64_t cm_hash64(uint64_t key, uint64_t mask) {
   return key;
 }
 
+// Hash64 (utils.h:76-85) for 32 < 2k <= 52 bits on a (low word, high bits) pair: every step of the hash is a multiplication
+// by a small odd constant or an xor with a right shift, both of which split cleanly -- the products' upper halves carry
+// into the high bits, the shifts funnel high bits into the low word.  The 64-bit formulation costs six 64-bit multiply-adds
+// per call (the compiler turns its shift-adds into them); this one two 32 x 32 -> 64 products.  hm = mask of the high bits.
+CM_HD uint64_t cm_hash64_split(uint32_t lo, uint32_t hi, uint32_t hm) {
+  // key = (~key + (key << 21)) & mask
+  {
+    const uint64_t t = (uint64_t)(uint32_t)~lo + (uint64_t)(uint32_t)(lo << 21);
+    hi = ((~hi) + ((hi << 21) | (lo >> 11)) + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  // key ^= key >> 24
+  lo ^= (lo >> 24) | (hi << 8);
+  hi ^= hi >> 24;
+  // key = key * 265 & mask
+  {
+    const uint64_t t = (uint64_t)lo * 265u;
+    hi = (hi * 265u + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  // key ^= key >> 14
+  lo ^= (lo >> 14) | (hi << 18);
+  hi ^= hi >> 14;
+  // key = key * 21 & mask
+  {
+    const uint64_t t = (uint64_t)lo * 21u;
+    hi = (hi * 21u + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  // key ^= key >> 28
+  lo ^= (lo >> 28) | (hi << 4);
+  hi ^= hi >> 28;
+  // key = (key + (key << 31)) & mask
+  {
+    const uint64_t t = (uint64_t)lo + (uint64_t)(uint32_t)(lo << 31);
+    hi = (hi + ((hi << 31) | (lo >> 1)) + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
+CM_HD uint64_t cm_hash64_k(uint64_t key, int k, uint64_t mask) {
+  if (2 * k > 32 && 2 * k <= 52) return cm_hash64_split((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(mask >> 32));
+  return cm_hash64(key, mask);
+}
+
 CM_HD const uint8_t *cm_read_ptr(const CmDev &d, uint32_t r) {
   const uint32_t pair = r >> 1;
   return (r & 1) ? d.rb1 + d.ro1[pair] : d.rb0 + d.ro0[pair];
@@ -609,9 +654,9 @@ CM_HD uint32_t cm_minimizers_w7_oddk(const uint8_t *seq, uint32_t len, int k, Em
     fw = ((fw << 2) | c) & mask;
     rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
     if (pos + 1 < (uint32_t)k) continue;
-    const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+    const uint64_t h0 = cm_hash64_k(fw, k, mask), h1 = cm_hash64_k(rv, k, mask);
     const uint32_t strand = h0 < h1 ? 0u : 1u;
-    const uint64_t h = cm_hash64(strand ? h1 : h0, mask);
+    const uint64_t h = cm_hash64_k(strand ? h1 : h0, k, mask);
     if (fl & 1u) { emit(n, H[0], ((pos - 7) << 1) | (sb & 1u)); ++n; }
 #pragma unroll
     for (int j = 0; j < 6; ++j) H[j] = H[j + 1];
@@ -706,9 +751,9 @@ CM_HD uint64_t cm_mmf_revgroups(uint64_t v, int k) {
 CM_HD uint64_t cm_mmf_hash(uint64_t v, int k, uint32_t *strand) {
   const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
   const uint64_t fw = cm_mmf_revgroups(v, k), rv = ~v & mask;
-  const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
+  const uint64_t h0 = cm_hash64_k(fw, k, mask), h1 = cm_hash64_k(rv, k, mask);
   *strand = h0 < h1 ? 0u : 1u;
-  return cm_hash64(*strand ? h1 : h0, mask);
+  return cm_hash64_k(*strand ? h1 : h0, k, mask);
 }
 // selection over one read's hashes h[0..m) (m >= 7); Mbuf: m entries of scratch.  Returns false when the read has to be
 // redone sequentially (first-window tie); otherwise flag[i] = k-mer i is a minimizer.
