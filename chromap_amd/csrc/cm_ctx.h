@@ -112,8 +112,9 @@ struct cmgpu_ctx {
   int opt_probe_variant = 1;       // lookups per lane | 16: second probe step requested with the first (measured: more requests in
                                    // flight per lane only slow the probe down -- the table's random-access rate is the bound)
   int opt_mm_chunks = CM_MM_CHUNKS;
-  int opt_prep_tile_reads = 64;    // reads per tile of the position-parallel minimizer kernel
-  int opt_prep_kernel = 1;         // 1: position-parallel minimizer kernel where it applies, 0: lane-per-read kernels
+  int opt_prep_tile_reads = 32;    // reads per tile of the position-parallel minimizer kernel
+  int opt_prep_kernel = 0;         // 0: lane-per-read minimizer kernels; 1: the position-parallel kernel where it applies (k_prep_flat:
+                                   // half the instructions, but 7 barriers + one global reservation per tile -- measured slower)
   uint64_t opt_item_limit = 0xfffffff0ull;
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
   int opt_heavy_last = 0;            // heavy-last processing order: 0 auto, 1 always, -1 never
