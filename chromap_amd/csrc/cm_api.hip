@@ -71,6 +71,9 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_prep_tile_reads = (int)value;
   } else if (n == "heavy_wave_max" || n == "heavy_block_max" || n == "heavy_big_max") {  // tests: force the size classes
     c->opt_heavy_max[n == "heavy_wave_max" ? 0 : n == "heavy_block_max" ? 1 : 2] = (int)value;
+  } else if (n == "lanes") {
+    if (value < 1 || value > 8) { cm_set_error(c, "lanes: 1..8"); return CMGPU_EINVAL; }
+    c->opt_lanes = (int)value;
   } else if (n == "heavy_last") {
     c->opt_heavy_last = (int)value;
   } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate
@@ -91,6 +94,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n == "prep_kernel") *value = c->opt_prep_kernel;
   else if (n == "prep_tile_reads") *value = c->opt_prep_tile_reads;
   else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
+  else if (n == "lanes") *value = c->opt_lanes;
   else return CMGPU_EINVAL;
   return CMGPU_OK;
 }
@@ -316,6 +320,8 @@ extern "C" int cmgpu_set_pairs_chr_order(cmgpu_ctx *c, const uint32_t *rank, uin
 extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (!c) return CMGPU_OK;
   if (c->in_flight) { c->worker.join(); c->in_flight = false; }
+  for (cmgpu_ctx *l : c->lanes) cmgpu_destroy(l);
+  c->lanes.clear();
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   cm_exchange_release(c);
@@ -551,7 +557,8 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       bool grid_short = false;  // a chunk emitted more than its probe grid covers (cannot happen on attempt 1)
       if (attempt == 0 && tot <= cap) {
         unsigned long long hm[CM_MM_CHUNKS + 1];
-        HIPCHECK(c, hipMemcpy(hm, c->mm_marks.p, (CM_MM_CHUNKS + 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(c, hipMemcpyAsync(hm, c->mm_marks.p, (CM_MM_CHUNKS + 1) * 8, hipMemcpyDeviceToHost, s));  // (not the null stream: lanes run side by side)
+        HIPCHECK(c, cm_stream_sync(s));
         for (uint32_t ch = 0; ch < n_chunks; ++ch) grid_short = grid_short || hm[ch + 1] - hm[ch] > max_entries[ch];
       }
       if (tot <= cap && !grid_short) { n_mm = (uint32_t)tot; break; }
@@ -699,6 +706,33 @@ static int map_split(cmgpu_ctx *c, uint32_t lo, uint32_t hi, uint64_t *k_total, 
   return map_split(c, lo + half, hi, k_total, stats);
 }
 
+// A further lane of `c`: a context of its own (streams, events, intermediates, counters) over c's index and reference,
+// which sees c's resident batch and writes into c's record arrays.  The views are refreshed before every use -- c's
+// buffers move when they grow or when parked batches change places.
+static int lane_prepare(cmgpu_ctx *c, size_t i) {
+  while (c->lanes.size() <= i) {
+    cmgpu_ctx *l = nullptr;
+    const int rc = cmgpu_create_shared(c, &l);
+    if (rc) { cm_set_error(c, std::string("lane context: ") + cmgpu_last_error(nullptr)); return rc; }
+    c->lanes.push_back(l);
+  }
+  cmgpu_ctx *l = c->lanes[i];
+  auto view = [](DevBuf &dst, const DevBuf &src) { dst.p = src.p; dst.cap = src.cap; dst.owned = false; };
+  view(l->rb0, c->rb0); view(l->rb1, c->rb1); view(l->ro0, c->ro0); view(l->ro1, c->ro1);
+  view(l->rec, c->rec); view(l->rec_ok, c->rec_ok);
+  view(l->bcb, c->bcb); view(l->bcq, c->bcq); view(l->bco, c->bco); view(l->bc_key, c->bc_key); view(l->bc_ok, c->bc_ok);
+  view(l->wl, c->wl); view(l->pow10_tab, c->pow10_tab);
+  view(l->sam_rec, c->sam_rec); view(l->sam_cigar, c->sam_cigar); view(l->sam_md, c->sam_md);
+  l->wl_mask = c->wl_mask; l->wl_size = c->wl_size; l->bc_len = c->bc_len; l->wl_num_sample = c->wl_num_sample;
+  l->n_pairs = c->n_pairs; l->first_read_id = c->first_read_id; l->bases0 = c->bases0; l->bases1 = c->bases1;
+  l->max_read_len = c->max_read_len; l->has_barcodes = c->has_barcodes; l->single = c->single;
+  l->sam_slots = c->sam_slots; l->sam_md_cap = c->sam_md_cap;
+  l->opt_probe_variant = c->opt_probe_variant; l->opt_mm_chunks = c->opt_mm_chunks; l->opt_prep_kernel = c->opt_prep_kernel;
+  l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last;
+  for (int q = 0; q < 3; ++q) l->opt_heavy_max[q] = c->opt_heavy_max[q];
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *stats) {
   if (!c) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
@@ -724,14 +758,50 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     c->sam_slots = slots;
     c->sam_md_cap = md_cap;
   }
+  // Lanes: the batch cut on reference-batch boundaries into up to opt_lanes ranges that are mapped side by side, each on
+  // its own streams with its own intermediates -- the latency-bound stages of one range fill the gaps of the others'.
+  const uint32_t rb = (uint32_t)c->p.ref_batch;
+  uint32_t L = (uint32_t)(c->opt_lanes < 1 ? 1 : c->opt_lanes);
+  const uint32_t n_rb = (n + rb - 1) / rb;
+  if (L > n_rb) L = n_rb;
+  if (n < (1u << 20)) L = 1;
   uint64_t k = 0;
-  const int rc = map_split(c, 0, n, &k, stats);
-  if (rc) return rc;
+  if (L <= 1) {
+    const int rc = map_split(c, 0, n, &k, stats);
+    if (rc) return rc;
+  } else {
+    std::vector<uint32_t> cut(L + 1, 0);
+    for (uint32_t i = 1; i < L; ++i) cut[i] = (uint32_t)(((uint64_t)n_rb * i / L) * rb);
+    cut[L] = n;
+    for (uint32_t i = 1; i < L; ++i) { const int rc = lane_prepare(c, i - 1); if (rc) return rc; }
+    std::vector<int> rcs(L, CMGPU_OK);
+    std::vector<uint64_t> ks(L, 0);
+    std::vector<cmgpu_stats> sts(L);
+    for (cmgpu_stats &x : sts) memset(&x, 0, sizeof(x));
+    std::vector<std::thread> th;
+    for (uint32_t i = 1; i < L; ++i)
+      th.emplace_back([&, i]() {
+        cmgpu_ctx *l = c->lanes[i - 1];
+        (void)hipSetDevice(l->device);
+        rcs[i] = map_split(l, cut[i], cut[i + 1], &ks[i], &sts[i]);
+      });
+    rcs[0] = map_split(c, cut[0], cut[1], &ks[0], &sts[0]);
+    for (std::thread &t : th) t.join();
+    for (uint32_t i = 0; i < L; ++i) {
+      if (rcs[i]) { if (i) cm_set_error(c, c->lanes[i - 1]->err); return rcs[i]; }
+      k += ks[i];
+      if (stats) {
+        uint64_t *dst = reinterpret_cast<uint64_t *>(stats);
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&sts[i]);
+        for (size_t q = 0; q < sizeof(cmgpu_stats) / 8; ++q) dst[q] += src[q];
+      }
+    }
+    c->last_range_lo = 0; c->last_range_hi = cut[1];
+  }
   c->n_records = k;
   if (n_out) *n_out = k;
   return CMGPU_OK;
 }
-
 
 extern "C" int cmgpu_download_records(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
   if (!c || !out || !n_out) return CMGPU_EINVAL;

@@ -116,6 +116,8 @@ struct cmgpu_ctx {
   int opt_prep_kernel = 0;         // 0: lane-per-read minimizer kernels; 1: the position-parallel kernel where it applies (k_prep_flat:
                                    // half the instructions, but 7 barriers + one global reservation per tile -- measured slower)
   uint64_t opt_item_limit = 0xfffffff0ull;
+  int opt_lanes = 1;                 // sub-batches of one cmgpu_map_* call mapped side by side (own streams and intermediates each)
+  std::vector<cmgpu_ctx *> lanes;    // the further lanes' contexts (views of this context's index, reference, batch and record arrays)
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
   int opt_heavy_last = 0;            // heavy-last processing order: 0 auto, 1 always, -1 never
   std::vector<uint32_t> h_rank;  // --chr-order: rank of every index rid (host copy of rid_rank)

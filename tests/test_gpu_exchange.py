@@ -259,3 +259,27 @@ def test_synthetic_repeats_and_indels_match_oracle(tmp_path):
     assert s["num_candidates"] == ost.as_dict()["num_candidates"]
     g.close()
     o.close()
+
+
+def test_lanes_map_ranges_side_by_side():
+    """one batch cut on reference-batch boundaries into ranges that are mapped concurrently (own streams and
+    intermediates): records and counters are those of the one-piece run"""
+    from chromap_amd import ChromapGPU, Stats
+    g = ChromapGPU(synthetic=(3_000_000, 5, 77, (2, 40, 1200, 0.02)), preset="atac", read_batch_size=300000)
+    n = 1_200_000
+    g.generate_resident(n, read_length=50, frag_min=30, frag_max=500, sub_rate=0.01, seed=5)
+    out = []
+    for lanes in (1, 2, 3, 4):
+        g.set_option("lanes", lanes)
+        st = Stats()
+        k = g.map_resident(st)
+        rec, k2 = g.download_records(n)
+        assert k2 == k
+        a = np.frombuffer(bytes(rec)[:k * 24], dtype=np.uint8).reshape(k, 24)
+        key = a.view(np.uint32)[:, 0]
+        out.append((a[np.argsort(key, kind="stable")].tobytes(), {x: v for x, v in st.as_dict().items()}))
+    for i in (1, 2, 3):
+        assert out[i][0] == out[0][0], i
+        assert out[i][1] == out[0][1], i
+    assert out[0][1]["num_multi_mappers"] > 0
+    g.close()
