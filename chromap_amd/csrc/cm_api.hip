@@ -328,6 +328,9 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   for (DevBuf *b : c->all_bufs()) b->release();
   for (int i = 0; i < CM_MAX_EVENTS; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (hipEvent_t e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
+  if (c->h_maxlen) (void)hipHostFree(c->h_maxlen);
+  for (hipEvent_t e : c->ev_h2d) if (e) (void)hipEventDestroy(e);
+  if (c->stream_h2d) (void)hipStreamDestroy(c->stream_h2d);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -355,6 +358,109 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   return CMGPU_OK;
 }
 
+// longest read of a batch from its offset arrays (n + 1 entries each; o2 may be null), on the device: a host loop over
+// 4 M offsets costs milliseconds of the upload path
+__global__ __launch_bounds__(256) void k_max_len(const uint32_t *__restrict__ o1, const uint32_t *__restrict__ o2, uint32_t n, uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t a = o1[i + 1] - o1[i], b = o2 ? o2[i + 1] - o2[i] : 0u;
+    m = a > m ? a : m;
+    m = b > m ? b : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t v = __shfl_down(m, off, 64); m = v > m ? v : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+static int launch_max_len(cmgpu_ctx *c, const DevBuf &o1, const DevBuf *o2, uint32_t n, hipStream_t s, int word = 0) {
+  if (c->maxlen_dev.ensure(16)) { cm_set_error(c, "out of device memory"); return CMGPU_ENOMEM; }
+  if (!c->h_maxlen) HIPCHECK(c, hipHostMalloc((void **)&c->h_maxlen, 16, hipHostMallocDefault));
+  uint32_t *dev = (uint32_t *)c->maxlen_dev.p + word;
+  HIPCHECK(c, hipMemsetAsync(dev, 0, 4, s));
+  if (n) {
+    uint32_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_max_len, dim3(blocks), dim3(256), 0, s, (const uint32_t *)o1.p, o2 ? (const uint32_t *)o2->p : (const uint32_t *)nullptr, n, dev);
+  }
+  HIPCHECK(c, hipMemcpyAsync(c->h_maxlen + word, dev, 4, hipMemcpyDeviceToHost, s));
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// page-locked host memory for the caller's batch buffers and record arrays: copies from / to it run at the link's rate
+// and asynchronously (pageable memory goes through the driver's staging buffer at a fraction of it)
+// ---------------------------------------------------------------------------------------
+extern "C" void *cmgpu_host_alloc(uint64_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+extern "C" void cmgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int cmgpu_host_register(void *p, uint64_t bytes) {
+  if (!p || !bytes) return CMGPU_EINVAL;
+  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); cm_set_error(nullptr, "hipHostRegister failed"); return CMGPU_EHIP; }
+  return CMGPU_OK;
+}
+extern "C" int cmgpu_host_unregister(void *p) {
+  if (!p) return CMGPU_EINVAL;
+  if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return CMGPU_EHIP; }
+  return CMGPU_OK;
+}
+
+// Pipelined host-buffer entry -- the load-next-batch task beside the mapping taskloop (chromap.h:871-877): the upload of
+// batch c+1 runs on a copy stream into the last parking slot while batch c is mapped.
+//   cmgpu_submit_pairs(b0); for (c = 0; ...) { cmgpu_submit_pairs(b[c+1]); cmgpu_map_submitted(out[c], ...); }
+// Up to two batches may be submitted and not yet mapped (parking slots 6 and 7 take turns).
+extern "C" int cmgpu_submit_pairs(cmgpu_ctx *c, const cmgpu_batch *in) {
+  if (!c || !in) return CMGPU_EINVAL;
+  HIPCHECK(c, cm_enter(c));
+  if (c->sub_count >= 2) { cm_set_error(c, "two submitted batches are waiting (cmgpu_map_submitted)"); return CMGPU_EINVAL; }
+  const uint32_t n = in->n_pairs;
+  if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
+  if (!c->stream_h2d) {
+    HIPCHECK(c, hipStreamCreateWithFlags(&c->stream_h2d, hipStreamNonBlocking));
+    for (hipEvent_t &e : c->ev_h2d) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int which = (int)(c->sub_total & 1u);
+  CmBatchSlot &sl = c->slots[CM_BATCH_SLOTS - 1 - which];
+  sl.n_pairs = n;
+  sl.first_read_id = in->first_read_id;
+  sl.bases0 = n ? in->read1_offsets[n] : 0;
+  sl.bases1 = n ? in->read2_offsets[n] : 0;
+  if (sl.rb0.ensure(sl.bases0 + 16) || sl.rb1.ensure(sl.bases1 + 16) || sl.ro0.ensure(((size_t)n + 1) * 4) || sl.ro1.ensure(((size_t)n + 1) * 4)) {
+    cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM;
+  }
+  hipStream_t s = c->stream_h2d;
+  HIPCHECK(c, hipMemcpyAsync(sl.ro0.p, in->read1_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPCHECK(c, hipMemcpyAsync(sl.ro1.p, in->read2_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPCHECK(c, hipMemcpyAsync(sl.rb0.p, in->read1_bases, sl.bases0, hipMemcpyHostToDevice, s));
+  HIPCHECK(c, hipMemcpyAsync(sl.rb1.p, in->read2_bases, sl.bases1, hipMemcpyHostToDevice, s));
+  int rc = launch_max_len(c, sl.ro0, &sl.ro1, n, s, 1 + which);
+  if (rc) return rc;
+  HIPCHECK(c, hipEventRecord(c->ev_h2d[which], s));
+  ++c->sub_total;
+  ++c->sub_count;
+  return CMGPU_OK;
+}
+
+static int download_dense(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out);
+extern "C" int cmgpu_map_submitted(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats) {
+  if (!c) return CMGPU_EINVAL;
+  if (c->sub_count == 0) { cm_set_error(c, "no submitted batch (cmgpu_submit_pairs)"); return CMGPU_EINVAL; }
+  if (c->has_barcodes || c->single) { c->has_barcodes = false; c->single = false; }
+  HIPCHECK(c, cm_enter(c));
+  const int which = (int)((c->sub_total - c->sub_count) & 1u);  // the oldest submitted batch
+  HIPCHECK(c, hipEventSynchronize(c->ev_h2d[which]));
+  --c->sub_count;
+  int rc = cmgpu_swap_resident_batch(c, CM_BATCH_SLOTS - 1 - which);
+  if (rc) return rc;
+  c->max_read_len = c->h_maxlen[1 + which] ? c->h_maxlen[1 + which] : 1;
+  uint64_t k = 0;
+  rc = cmgpu_map_resident(c, &k, stats);
+  if (rc) return rc;
+  if (n_out) *n_out = k;
+  if (!out) return CMGPU_OK;
+  return download_dense(c, out, out_capacity, n_out);
+}
+
 extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   if (!c || !in) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
@@ -366,13 +472,6 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   c->first_read_id = in->first_read_id;
   c->bases0 = n ? in->read1_offsets[n] : 0;
   c->bases1 = n ? in->read2_offsets[n] : 0;
-  uint32_t mx = 1;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t l1 = in->read1_offsets[i + 1] - in->read1_offsets[i], l2 = in->read2_offsets[i + 1] - in->read2_offsets[i];
-    mx = l1 > mx ? l1 : mx;
-    mx = l2 > mx ? l2 : mx;
-  }
-  c->max_read_len = mx;
   if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(c->bases1 + 16) || c->ro0.ensure(((size_t)n + 1) * 4) || c->ro1.ensure(((size_t)n + 1) * 4)) {
     cm_set_error(c, "out of device memory (reads)");
     return CMGPU_ENOMEM;
@@ -381,7 +480,10 @@ extern "C" int cmgpu_upload_batch(cmgpu_ctx *c, const cmgpu_batch *in) {
   HIPCHECK(c, hipMemcpyAsync(c->rb1.p, in->read2_bases, c->bases1, hipMemcpyHostToDevice, c->stream));
   HIPCHECK(c, hipMemcpyAsync(c->ro0.p, in->read1_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHECK(c, hipMemcpyAsync(c->ro1.p, in->read2_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  const int rc = launch_max_len(c, c->ro0, &c->ro1, n, c->stream);
+  if (rc) return rc;
   HIPCHECK(c, cm_stream_sync(c->stream));
+  c->max_read_len = *c->h_maxlen ? *c->h_maxlen : 1;
   return CMGPU_OK;
 }
 
@@ -803,24 +905,42 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   return CMGPU_OK;
 }
 
+// the batch's records, compacted on the device, in one copy (the order of the pairs is kept)
+__global__ void k_rec_flag2(const uint8_t *ok, uint32_t *flag, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = ok[i];
+}
+__global__ void k_rec_compact2(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, const uint32_t *__restrict__ pos,
+                               uint8_t *__restrict__ dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !ok[i]) return;
+  const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
+  uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)pos[i] * 24);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+static int download_dense(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
+  const uint32_t n = c->n_pairs;
+  if (n_out) *n_out = 0;
+  if (n == 0) return CMGPU_OK;
+  if (c->rec_dense.ensure((size_t)n * 24 + 16)) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
+  uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
+  hipStream_t s = c->stream;
+  hipLaunchKernelGGL(k_rec_flag2, dim3((n + 255) / 256), dim3(256), 0, s, (const uint8_t *)c->rec_ok.p, flag, n);
+  cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, s);
+  hipLaunchKernelGGL(k_rec_compact2, dim3((n + 255) / 256), dim3(256), 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p,
+                     (const uint32_t *)pos, (uint8_t *)c->rec_dense.p, n);
+  const uint64_t k = c->n_records;  // counted by the mapping call
+  if (k > out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
+  if (k) HIPCHECK(c, hipMemcpyAsync(out, c->rec_dense.p, (size_t)k * 24, hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, cm_stream_sync(s));
+  if (n_out) *n_out = k;
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_download_records(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
   if (!c || !out || !n_out) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
-  const uint32_t n = c->n_pairs;
-  *n_out = 0;
-  if (n == 0) return CMGPU_OK;
-  std::vector<cmgpu_record> rec(n);
-  std::vector<uint8_t> ok(n);
-  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, (size_t)n * 24, hipMemcpyDeviceToHost));
-  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, n, hipMemcpyDeviceToHost));
-  uint64_t k = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    if (!ok[i]) continue;
-    if (k >= out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
-    out[k++] = rec[i];
-  }
-  *n_out = k;
-  return CMGPU_OK;
+  return download_dense(c, out, out_capacity, n_out);
 }
 
 extern "C" int cmgpu_map_pairs(cmgpu_ctx *c, const cmgpu_batch *in, cmgpu_record *out, uint64_t out_capacity,

@@ -108,6 +108,13 @@ struct cmgpu_ctx {
   CmExchange ex;
   bool batch_exchanged = false;  // the resident batch's records have been through cmgpu_exchange_step
   CmBatchSlot slots[CM_BATCH_SLOTS];
+  // pipelined host-buffer entry (cmgpu_submit_pairs / cmgpu_map_submitted): the next batch is uploaded on a copy stream into the
+  // last parking slot while the current one is mapped
+  hipStream_t stream_h2d = nullptr;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+  uint32_t sub_total = 0, sub_count = 0;  // batches submitted so far / submitted and not yet mapped (<= 2: parking slots 6 and 7 take turns)
+  DevBuf rec_dense, maxlen_dev;
+  uint32_t *h_maxlen = nullptr;  // pinned: longest read of the submitted batch, computed on the device
   // cmgpu_set_option
   int opt_probe_variant = 1;       // lookups per lane | 16: second probe step requested with the first (measured: more requests in
                                    // flight per lane only slow the probe down -- the table's random-access rate is the bound)
@@ -150,7 +157,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list};
   }
 };
 

@@ -218,6 +218,63 @@ class ChromapGPU:
         self._check(self.L.cmgpu_wait(self.ctx, C.cast(rec, C.c_void_p), n, C.byref(k)), self.ctx)
         return rec, int(k.value)
 
+    # ---- page-locked host memory and the pipelined host-buffer entry
+    def host_array(self, n, dtype):
+        """numpy array of n items in page-locked host memory (cmgpu_host_alloc); kept alive by the mapper"""
+        import numpy as np
+        dt = np.dtype(dtype)
+        nbytes = max(1, n * dt.itemsize)
+        ptr = self.L.cmgpu_host_alloc(nbytes)
+        if not ptr:
+            raise ChromapError("cmgpu_host_alloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(ptr)
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dt, count=n)
+
+    def submit_pairs(self, b1, o1, b2, o2, first_read_id=0):
+        """starts the upload of a batch on the copy stream (cmgpu_submit_pairs); the arrays must stay alive until map_submitted"""
+        bt = self._batch(b1, o1, b2, o2, first_read_id)
+        self._sub_keep = getattr(self, "_sub_keep", [])
+        self._sub_keep.append((bt, b1, o1, b2, o2))
+        self._check(self.L.cmgpu_submit_pairs(self.ctx, C.byref(bt)), self.ctx)
+
+    def map_submitted(self, out=None, capacity=0, stats=None):
+        """maps the oldest submitted batch; out: Record array (or pinned numpy uint8 array of capacity * 24 bytes) or None"""
+        n = C.c_uint64(0)
+        st = stats if stats is not None else self.stats
+        ptr = None if out is None else (C.c_void_p(out.ctypes.data) if hasattr(out, "ctypes") else C.cast(out, C.c_void_p))
+        self._check(self.L.cmgpu_map_submitted(self.ctx, ptr, capacity, C.byref(n), C.byref(st)), self.ctx)
+        self._sub_keep.pop(0)
+        return int(n.value)
+
+    def map_pairs_pipelined(self, b1, o1, b2, o2, repeats=4):
+        """throughput of the host-buffer boundary with page-locked buffers and the upload of batch c+1 under the kernels of
+        batch c (bench.py: pcie_inclusive.pipelined)"""
+        import time
+        import numpy as np
+        n = len(o1) - 1
+        bufs = []
+        for _ in range(2):  # two sets of pinned input buffers, one pinned record array each
+            pb1, pb2 = self.host_array(len(b1), np.uint8), self.host_array(len(b2), np.uint8)
+            po1, po2 = self.host_array(n + 1, np.uint32), self.host_array(n + 1, np.uint32)
+            pb1[:] = b1; pb2[:] = b2; po1[:] = o1; po2[:] = o2
+            bufs.append((pb1, po1, pb2, po2, self.host_array(n * 24, np.uint8)))
+        self.submit_pairs(*bufs[0][:4])
+        self.submit_pairs(*bufs[1][:4])
+        k0 = self.map_submitted(bufs[0][4], n, Stats())   # warm-up of both buffer sets
+        self.submit_pairs(*bufs[0][:4])
+        self.map_submitted(bufs[1][4], n, Stats())
+        t0 = time.perf_counter()
+        for i in range(repeats):
+            self.submit_pairs(*bufs[(i + 1) & 1][:4])
+            k = self.map_submitted(bufs[i & 1][4], n, Stats())
+            assert k == k0
+        dt = time.perf_counter() - t0
+        self.map_submitted(bufs[repeats & 1][4], n, Stats())  # drain
+        return {"M pairs/s": round(n * repeats / dt / 1e6, 2), "ms_per_batch": round(dt / repeats * 1e3, 2), "records": int(k0),
+                "note": "page-locked host buffers, cmgpu_submit_pairs of batch c+1 before cmgpu_map_submitted of batch c (upload under "
+                        "the kernels), records compacted on the device and downloaded in one copy"}
+
     def map_single(self, b, off, first_read_id=0):
         self._keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
         n = len(self._keep[1]) - 1
@@ -517,6 +574,9 @@ class ChromapGPU:
         if self.ctx:
             self.L.cmgpu_destroy(self.ctx)
             self.ctx = C.c_void_p()
+        for ptr in getattr(self, "_pinned", []):
+            self.L.cmgpu_host_free(ptr)
+        self._pinned = []
         if self._idx is not None:
             self.L.cmgpu_free_host_index(C.byref(self._idx))
             self._idx = None

@@ -231,6 +231,23 @@ int cmgpu_map_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_record *out, ui
 int cmgpu_map_pairs_async(cmgpu_ctx *ctx, const cmgpu_batch *in, cmgpu_stats *stats);
 int cmgpu_wait(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out);
 
+/* ---- the host-buffer boundary at the link's rate --------------------------------------------------------
+ * Page-locked host memory for batch buffers and record arrays (cmgpu_host_alloc, or cmgpu_host_register on the caller's
+ * own allocation), and a pipelined entry: cmgpu_submit_pairs starts the upload of the NEXT batch on a copy stream and
+ * returns; cmgpu_map_submitted waits for that upload, maps the batch and downloads its records compacted (pair order
+ * kept) -- so the upload of batch c+1 runs under the kernels of batch c, like the reference's load-next-batch task
+ * beside its mapping taskloop (src/chromap.h:871-877):
+ *     cmgpu_submit_pairs(ctx, &b[0]);
+ *     for (c = 0; c < n; ++c) { if (c + 1 < n) cmgpu_submit_pairs(ctx, &b[c + 1]); cmgpu_map_submitted(ctx, out[c], cap, &k, &st); }
+ * Up to two batches may be submitted and not yet mapped.  A submitted batch's buffers must stay valid until its
+ * cmgpu_map_submitted returns; parking slots 6 and 7 of cmgpu_swap_resident_batch serve the uploads. */
+void *cmgpu_host_alloc(uint64_t bytes);
+void cmgpu_host_free(void *p);
+int cmgpu_host_register(void *p, uint64_t bytes);
+int cmgpu_host_unregister(void *p);
+int cmgpu_submit_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in);
+int cmgpu_map_submitted(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
+
 /* Single-end reads: replaces the taskloop body of Chromap::MapSingleEndReads
  * (src/chromap.h:385-472) for bulk data; records are MappingWithoutBarcode's constructor
  * arguments (src/bed_mapping.h:67-83) stored in the cmgpu_record layout: alignment-length
