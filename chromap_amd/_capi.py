@@ -218,6 +218,12 @@ def declare(L):
     sig("cmgpu_exchange_step", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)])
     sig("cmgpu_exchange_info", C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_uint64), P(C.c_uint64)])
     sig("cmgpu_exchange_finalize", C.c_int, [C.c_void_p])
+    sig("cmgpu_host_alloc", C.c_void_p, [C.c_uint64])
+    sig("cmgpu_host_free", None, [C.c_void_p])
+    sig("cmgpu_host_register", C.c_int, [C.c_void_p, C.c_uint64])
+    sig("cmgpu_host_unregister", C.c_int, [C.c_void_p])
+    sig("cmgpu_submit_pairs", C.c_int, [C.c_void_p, P(Batch)])
+    sig("cmgpu_map_submitted", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
     sig("cmgpu_debug_trace", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64])
     sig("cmgpu_debug_minimizers", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
     sig("cmgpu_debug_minimizers_all", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)])

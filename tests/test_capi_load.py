@@ -24,6 +24,8 @@ def test_exports_every_declared_symbol():
     assert declared == set(capi.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
+        # every entry point has its signature declared to ctypes (a missing one silently truncates pointers to 32 bits)
+        assert getattr(L, s).argtypes is not None, "no ctypes signature for %s in chromap_amd/_capi.py" % s
 
 
 def test_presets_and_defaults():
