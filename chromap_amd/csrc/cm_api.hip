@@ -71,6 +71,9 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_prep_tile_reads = (int)value;
   } else if (n == "heavy_wave_max" || n == "heavy_block_max" || n == "heavy_big_max") {  // tests: force the size classes
     c->opt_heavy_max[n == "heavy_wave_max" ? 0 : n == "heavy_block_max" ? 1 : 2] = (int)value;
+  } else if (n == "s3b_lane_cap") {  // hits a lane clusters in its own LDS slots; longer lists go to a wave / block each
+    if (value < 0 || value > 64) { cm_set_error(c, "s3b_lane_cap: 0 (by read length) or 1..64"); return CMGPU_EINVAL; }
+    c->opt_s3b_cap = (int)value;
   } else if (n == "lanes") {
     if (value < 1 || value > 8) { cm_set_error(c, "lanes: 1..8"); return CMGPU_EINVAL; }
     c->opt_lanes = (int)value;
@@ -541,7 +544,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.hv_stride = 2 * (hi - lo) + 1;
   d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
-  d.s3b_cap = cm_s3b_lane_cap(c->max_read_len);
+  d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
     cm_s3b_heavy_classes(d.hv_max);
     for (int q = 0; q < 3; ++q) if (c->opt_heavy_max[q] > 0 && (uint32_t)c->opt_heavy_max[q] < d.hv_max[q]) d.hv_max[q] = (uint32_t)c->opt_heavy_max[q];
@@ -830,7 +833,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   l->max_read_len = c->max_read_len; l->has_barcodes = c->has_barcodes; l->single = c->single;
   l->sam_slots = c->sam_slots; l->sam_md_cap = c->sam_md_cap;
   l->opt_probe_variant = c->opt_probe_variant; l->opt_mm_chunks = c->opt_mm_chunks; l->opt_prep_kernel = c->opt_prep_kernel;
-  l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last;
+  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last;
   for (int q = 0; q < 3; ++q) l->opt_heavy_max[q] = c->opt_heavy_max[q];
   return CMGPU_OK;
 }

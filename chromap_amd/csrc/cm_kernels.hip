@@ -1024,7 +1024,8 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s)
 }
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
   if (!n) return;
-  const uint32_t cap = cm_s3b_lane_cap(max_read_len);
+  const uint32_t cap = d.s3b_cap;  // cm_s3b_lane_cap(max_read_len) unless overridden (cmgpu_set_option "s3b_lane_cap")
+  (void)max_read_len;
   uint32_t threads = 256;
   while (threads > 64 && (size_t)cap * threads * 9 > 36 * 1024 + 1024) threads >>= 1;
   hipLaunchKernelGGL(k_s3b_candidates, dim3((n + threads - 1) / threads), dim3(threads), (size_t)cap * threads * 9, s, d, n, cap);

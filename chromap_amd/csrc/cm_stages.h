@@ -1766,17 +1766,17 @@ CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern,
 // BandedAlignPatternToTextWithDropOff (alignment.cc:197-283) when from3 == false,
 // BandedAlignPatternToTextWithDropOffFrom3End (alignment.cc:285-376) when from3 == true.
 // text = (neg ? revcomp(read) : read) + toff, length L.
-CM_HD int cm_banded_align_dropoff(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
-                                  bool from3, int *end_pos, int *read_mapping_length) {
+template <class PS, class TS>
+CM_HD int cm_banded_align_dropoff_t(int e, const PS &pat, const TS &txt, int L, bool from3, int *end_pos, int *read_mapping_length) {
   uint32_t P[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(from3 ? pattern[L + 2 * e - 1 - i] : pattern[i]), 1u << i);
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(from3 ? pat.get(L + 2 * e - 1 - i) : pat.get(i)), 1u << i);
   const uint32_t hi = 1u << (2 * e);
   uint32_t VP = 0, VN = 0, prev_VP = 0, prev_VN = 0;
   int err = 0, i = 0, prev_err = 0;
   bool fail_beginning = false;
   for (; i < L; i++) {
-    cm_peq_or(P, cm_c2u(from3 ? pattern[L - 1 - i] : pattern[i + 2 * e]), hi);
-    uint32_t X = cm_peq_get(P, cm_text_code(read, Lfull, toff + (from3 ? L - 1 - i : i), neg)) | VN;
+    cm_peq_or(P, cm_c2u(from3 ? pat.get(L - 1 - i) : pat.get(i + 2 * e)), hi);
+    uint32_t X = cm_peq_get(P, txt.code(from3 ? L - 1 - i : i)) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1807,6 +1807,19 @@ CM_HD int cm_banded_align_dropoff(int e, const uint8_t *pattern, const uint8_t *
   }
   if (fail_beginning || (L > 60 && *end_pos + 1 - e - min_err < 30)) *end_pos = -*end_pos;
   return min_err;
+}
+// pattern window and read are first copied into registers with independent 8-byte loads (CmBytes); the bit-vector loop
+// then has no dependent global load per step (as in cm_banded_align)
+CM_HD int cm_banded_align_dropoff(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
+                                  bool from3, int *end_pos, int *read_mapping_length) {
+  CmBytes pb, tb;
+  if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
+    const CmText<CmBytes> txt{tb, Lfull, neg, toff};
+    return cm_banded_align_dropoff_t(e, pb, txt, L, from3, end_pos, read_mapping_length);
+  }
+  const CmDirect pd{pattern}, td{read};
+  const CmText<CmDirect> txt{td, Lfull, neg, toff};
+  return cm_banded_align_dropoff_t(e, pd, txt, L, from3, end_pos, read_mapping_length);
 }
 
 // AdjustGapBeginning (alignment.cc:24-83) without cigar.  read string = (neg ? revcomp(read)
