@@ -335,12 +335,23 @@ __global__ __launch_bounds__(CM_BLOCK) void k_prep_flat(CmDev d, uint32_t pair_l
 // size class for the cooperative kernel below
 __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  cm_s3a_count(d, i);
-  const uint32_t tot = d.hit_tot[i];
-  if (tot > d.s3b_cap) {
-    const uint32_t c = tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : 3u;
-    d.hv_list[(size_t)c * d.hv_stride + atomicAdd(&d.hv_cnt[c], 1u)] = i;
+  uint32_t tot = 0;
+  if (i < n) {
+    cm_s3a_count(d, i);
+    tot = d.hit_tot[i];
+  }
+  // one atomic per wave and class (millions of lanes adding to one counter serialise at ~10 ns each)
+  const uint32_t cls = tot <= d.s3b_cap ? 4u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : 3u;
+  if (__ballot(cls < 4u) == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (m == 0) continue;
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&d.hv_cnt[c], (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    if (cls == c) d.hv_list[(size_t)c * d.hv_stride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
   }
 }
 // S3b with the per-read hit list staged in LDS ([entry][thread] layout: 16 x 8-byte entries and
