@@ -541,28 +541,41 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t
   __syncthreads();
   if (threadIdx.x < cnt) cm_s4b_rescue_merge(d, list[threadIdx.x]);
 }
+// every lane with `pred` appends `value` to a device list: one atomic per wave (called by all lanes of the wave)
+__device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool pred, uint32_t value) {
+  const unsigned long long m = __ballot(pred);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)(__ffsll((long long)m) - 1);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, (int)leader, 64);
+  if (pred) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
 // S4c; long filtered candidate lists are queued for k_sort_lists
 __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t pair = d.perm_pairs ? d.perm_pairs[i] : i;
-  cm_s4c_reduce(d, pair);
-  if (!d.perm_pairs || !d.alive[pair]) return;  // the queue is only served in a batch with heavy reads
-  for (uint32_t r = 2 * pair; r <= 2 * pair + 1; ++r) {
-    if (d.fcp[r] > CM_SORT_SERIAL_MAX && d.fcp[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
-    if (d.fcn[r] > CM_SORT_SERIAL_MAX && d.fcn[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
+  const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
+  if (i < n) cm_s4c_reduce(d, pair);
+  if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
+  const bool live = i < n && d.alive[pair];
+  for (uint32_t q = 0; q < 4; ++q) {  // (read, strand) lists of the pair
+    const uint32_t r = 2 * pair + (q >> 1);
+    const uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
+    cm_wave_append(d.srt_list, &d.srt_cnt[0], cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX, (r << 1) | (q & 1u));
   }
 }
 CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare, perm_reads)
 // S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t r = d.perm_reads ? d.perm_reads[i] : i;
-  cm_s5c_finalize(d, r);
-  if (!d.perm_reads || d.p.split || d.p.single || !d.alive[r >> 1]) return;  // the queue is only served in a batch with heavy reads
-  if (d.ndp[r] > CM_SORT_SERIAL_MAX && d.ndp[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
-  if (d.ndn[r] > CM_SORT_SERIAL_MAX && d.ndn[r] <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
+  const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
+  if (i < n) cm_s5c_finalize(d, r);
+  if (!d.perm_reads || d.p.split || d.p.single) return;  // the queue is only served in a batch with heavy reads
+  const bool live = i < n && d.alive[r >> 1];
+  const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
+  cm_wave_append(d.srt_list, &d.srt_cnt[0], a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX, r << 1);
+  cm_wave_append(d.srt_list, &d.srt_cnt[0], b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX, (r << 1) | 1u);
 }
 
 // ---------------------------------------------------------------------------------------
