@@ -79,21 +79,95 @@ struct FastxReader {
   void close() { if (f) gzclose(f); f = nullptr; }
 };
 
-// raw (inflated) file bytes in large chunks for the device-side FASTQ parser
+// raw (inflated) file bytes in large chunks for the device-side FASTQ parser.
+// Plain text and ordinary gzip go through zlib's gzread (one inflating thread per file).  BGZF (bgzip; SAM spec 4.1: a
+// series of gzip members of at most 64 KiB, each carrying its compressed size in a 'BC' extra field) is inflated block-
+// parallel: the block headers are walked without decoding, the ISIZE trailers give every block's place in the output,
+// and a team of threads inflates the blocks of a chunk side by side -- SURVEY.md 8(f)-2: kseq behind one gzread per
+// file (sequence_batch.cc:22-62) caps the reference's ingest at the rate of one inflating core.
 struct ChunkReader {
   gzFile f = nullptr;
+  FILE *raw = nullptr;   // BGZF: the compressed file itself
+  bool bgzf = false;
+  int team = 4;          // inflating threads for BGZF input
   std::vector<char> buf;
+  std::vector<unsigned char> cbuf;
   size_t len = 0;
   bool eof = false;
   bool open(const std::string &path) {
-    f = gzopen(path.c_str(), "r");
-    if (f) gzbuffer(f, 1 << 20);
     len = 0;
     eof = false;
+    bgzf = false;
+    raw = fopen(path.c_str(), "rb");
+    if (!raw) return false;
+    unsigned char h[18];
+    const size_t got = fread(h, 1, 18, raw);
+    if (got == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0) {
+      bgzf = true;
+      fseek(raw, 0, SEEK_SET);
+      return true;
+    }
+    fclose(raw);
+    raw = nullptr;
+    f = gzopen(path.c_str(), "r");
+    if (f) gzbuffer(f, 1 << 20);
     return f != nullptr;
+  }
+  struct Block { size_t coff, csize, isize, ooff; };
+  void fill_bgzf(size_t target) {
+    while (len < target && !eof) {
+      std::vector<Block> blocks;
+      size_t csum = 0, isum = 0;
+      cbuf.clear();
+      while (isum < target - len && blocks.size() < 16384) {
+        unsigned char h[18];
+        const size_t got = fread(h, 1, 18, raw);
+        if (got == 0) { eof = true; break; }
+        if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C')
+          die("Didn't reach the end of sequence file, which might be corrupted! (not a BGZF block)");
+        const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;  // whole block
+        if (bsize < 26) die("Didn't reach the end of sequence file, which might be corrupted! (BGZF block size)");
+        cbuf.resize(csum + bsize);
+        memcpy(cbuf.data() + csum, h, 18);
+        if (fread(cbuf.data() + csum + 18, 1, bsize - 18, raw) != bsize - 18)
+          die("Didn't reach the end of sequence file, which might be corrupted! (truncated BGZF block)");
+        const unsigned char *t = cbuf.data() + csum + bsize - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        blocks.push_back({csum, bsize, isize, isum});
+        csum += bsize;
+        isum += isize;
+      }
+      if (blocks.empty()) break;
+      if (buf.size() < len + isum) buf.resize(len + isum);
+      const int nt = (int)std::min<size_t>((size_t)team, blocks.size());
+      std::vector<std::thread> th;
+      std::vector<int> bad((size_t)nt, 0);
+      for (int ti = 0; ti < nt; ++ti)
+        th.emplace_back([&, ti]() {
+          z_stream zs;
+          memset(&zs, 0, sizeof(zs));
+          if (inflateInit2(&zs, -15) != Z_OK) { bad[ti] = 1; return; }
+          for (size_t bi = (size_t)ti; bi < blocks.size(); bi += (size_t)nt) {
+            const Block &b = blocks[bi];
+            if (b.isize == 0) continue;
+            inflateReset(&zs);
+            zs.next_in = cbuf.data() + b.coff + 18;
+            zs.avail_in = (uInt)(b.csize - 26);
+            zs.next_out = reinterpret_cast<Bytef *>(buf.data() + len + b.ooff);
+            zs.avail_out = (uInt)b.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad[ti] = 1; break; }
+          }
+          inflateEnd(&zs);
+        });
+      for (std::thread &t : th) t.join();
+      for (int x : bad) if (x) die("Didn't reach the end of sequence file, which might be corrupted! (BGZF inflate)");
+      len += isum;
+    }
   }
   void fill(size_t target) {
     if (buf.size() < target) buf.resize(target);
+    if (bgzf) { fill_bgzf(target); return; }
     while (len < target && !eof) {
       const size_t want = target - len < (1u << 30) ? target - len : (1u << 30);
       const int r = gzread(f, buf.data() + len, (unsigned)want);
@@ -109,7 +183,7 @@ struct ChunkReader {
     for (size_t i = 0; i < len; ++i) if (buf[i] != '\n' && buf[i] != '\r' && buf[i] != ' ' && buf[i] != '\t') return false;
     return true;
   }
-  void close() { if (f) gzclose(f); f = nullptr; }
+  void close() { if (f) gzclose(f); f = nullptr; if (raw) fclose(raw); raw = nullptr; }
 };
 
 // --read-format (Chromap::ParseReadFormat chromap.cc:825-866, SequenceEffectiveRange): per stream up to four
@@ -283,6 +357,21 @@ static Args parse(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
+  if (argc == 3 && !strcmp(argv[1], "--inflate-only")) {  // the ingest reader on its own (tests): inflated bytes of a file to stdout
+    ChunkReader rd;
+    if (!rd.open(argv[2])) die(std::string("Cannot find sequence file ") + argv[2]);
+    rd.team = 4;
+    for (;;) {
+      rd.fill(3u << 20);
+      if (rd.len == 0) break;
+      const size_t take = rd.eof ? rd.len : rd.len - rd.len / 3;  // leave a tail, like the FASTQ parser does
+      fwrite(rd.buf.data(), 1, take, stdout);
+      rd.consume(take);
+    }
+    fprintf(stderr, "%s\n", rd.bgzf ? "bgzf" : "gzread");
+    rd.close();
+    return 0;
+  }
   Args a = parse(argc, argv);
   if (a.ref_path.empty() || a.out_path.empty()) die("No reference / output specified!");
   cmgpu_ref_view ref;
@@ -459,6 +548,11 @@ int main(int argc, char **argv) {
     for (size_t fi = 0; fi < a.r1.size(); ++fi) {
       ChunkReader rd[3];
       const int ns_streams = 1 + (paired ? 1 : 0) + (barcoded ? 1 : 0);
+      {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int team = (int)std::max(2u, std::min(32u, (hw ? hw : 8u) / (unsigned)ns_streams));
+        for (ChunkReader &x : rd) x.team = team;
+      }
       int sid[3] = {0, paired ? 1 : 2, 2};
       if (!rd[0].open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
       if (paired && !rd[1].open(a.r2[fi])) die("Cannot find sequence file " + a.r2[fi]);

@@ -57,3 +57,34 @@ def test_flag_combinations_without_a_record_type_are_refused():
     assert r.returncode != 0 and b"cell barcodes" in r.stderr
     r = _run("--gpus", "0", "-x", "x", "-r", "y", "-1", "a", "-o", "o")
     assert r.returncode != 0 and b"--gpus" in r.stderr
+
+
+def test_ingest_reader_inflates_bgzf_gzip_and_plain_text(tmp_path):
+    """the CLI's chunk reader on its own (--inflate-only): BGZF is recognised and inflated block-parallel, ordinary gzip and
+    plain text go through gzread; the bytes are the file's; a truncated BGZF file is an error, not a short read"""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.join(datasets.ROOT, "tools"))
+    import bgzf
+    import numpy as np
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(120000):
+        s = bytes(rng.choice(list(b"ACGT"), 50).astype(np.uint8))
+        lines.append(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * 50))
+    text = b"".join(lines)
+    plain = str(tmp_path / "r.fq")
+    open(plain, "wb").write(text)
+    bg = str(tmp_path / "r.bgzf.gz")
+    bgzf.compress_file(plain, bg)
+    assert gzip.open(bg, "rb").read() == text  # the writer produces valid multi-member gzip
+    gz = str(tmp_path / "r.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(text)
+    for path, kind in ((bg, b"bgzf"), (gz, b"gzread"), (plain, b"gzread")):
+        r = _run("--inflate-only", path)
+        assert r.returncode == 0 and r.stdout == text and r.stderr.strip() == kind, (path, r.stderr[-200:])
+    cut = str(tmp_path / "cut.gz")
+    open(cut, "wb").write(open(bg, "rb").read()[:-5000])
+    r = _run("--inflate-only", cut)
+    assert r.returncode != 0 and b"corrupted" in r.stderr
