@@ -299,6 +299,7 @@ def main():
                                                          "(CIGAR / NM / MD); not the headline metric")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL record exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--lanes", type=int, default=3, help="ranges of a batch mapped side by side (cmgpu_set_option lanes); measured best for resident batches")
     ap.add_argument("--option", action="append", default=[], help="name=value for cmgpu_set_option (measurement knobs)")
     args = ap.parse_args()
 
@@ -342,6 +343,7 @@ def main():
     def make_ctx(rep):
         g_ = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset, device=local_rank,
                         **({"output_format": 1} if args.sam else {}))
+        g_.set_option("lanes", args.lanes)
         for o in args.option:
             k_, v_ = o.split("=")
             g_.set_option(k_, int(v_))
@@ -380,7 +382,13 @@ def main():
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / dt / 1e6
     s = st.as_dict()
+    # the kernel-only probe measurement wants one batch's minimizers resident in one piece
+    g.set_option("lanes", 1)
+    g.swap_resident(0)
+    g.map_resident(Stats())
+    g.swap_resident(0)
     roof = roofline(g, args, s, steps, stage_ms)
+    g.set_option("lanes", args.lanes)
     post = pcie = cpu = rep_out = None
     if not args.skip_extras:
         # device-side post-processing, outside the timed region: the records of the four resident
@@ -415,6 +423,7 @@ def main():
             b2 = np.zeros(n * args.readlen, np.uint8)
             assert g.L.cmgpu_download_batch(g.ctx, b1.ctypes.data, o1.ctypes.data, b2.ctypes.data, o2.ctypes.data) == 0
             g.swap_resident(0)
+            g.set_option("lanes", 1)  # the copy engine and the lanes' host threads get in each other's way (measured)
             g.map_pairs(b1, o1, b2, o2)  # warm the host-side buffers
             t1 = time.perf_counter()
             _, kk = g.map_pairs(b1, o1, b2, o2)
@@ -447,10 +456,7 @@ def main():
                 if g is not None:
                     g.close()
                 g = None
-                gr = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset, device=local_rank)
-                for o in args.option:
-                    k_, v_ = o.split("=")
-                    gr.set_option(k_, int(v_))
+                gr = make_ctx(rep)
                 rdt, rstage, rst, rmapped = timed_run(gr, args, 0, 1, None, 3000, False)
                 rs = rst.as_dict()
                 rep_out = {"value": round(args.pairs * args.steps / rdt / 1e6, 4), "unit": "M pairs/s", "ms_per_step": round(rdt / steps * 1e3, 3),
@@ -477,11 +483,12 @@ def main():
                                % (args.preset, args.readlen, args.frag_min, args.frag_max,
                                   ", %.2f%% 1-base indels" % (args.indel_rate * 100) if args.indel_rate else "", args.genome, args.nseq,
                                   ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS),
-                   "pairs_per_gpu_per_step": args.pairs,
+                   "pairs_per_gpu_per_step": args.pairs, "lanes": args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
         "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
         "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
+        "stage_ms_note": "HIP events of the calling thread's lane (1 / %d of the batch when lanes > 1; the lanes overlap)" % args.lanes,
         "counters_per_step": {k: v // steps for k, v in s.items()},
         "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),
     }

@@ -1,21 +1,24 @@
 set -x
 cd $GRAFT_REPO_ROOT
-T=${1:-r02b}
+T=${1:-r02f}
 mkdir -p gpurun_out/$T
-timeout 1500 python -m pytest tests/test_gpu_stages.py tests/test_gpu_parity.py tests/test_gpu_exchange.py tests/test_gpu_synthetic.py -m gpu -q --maxfail=15 -p no:cacheprovider > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/$T/pytest.log
-tail -12 gpurun_out/$T/pytest.log
-timeout 900 python bench.py --steps 10 --warmup 2 --skip-cpu > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.log; echo "bench rc $?"
+timeout 1800 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/$T/pytest.log
+tail -8 gpurun_out/$T/pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.log; echo "bench rc $?"
 tail -3 gpurun_out/$T/bench_default.log
 python - <<PY
 import json
 j=json.loads(open('gpurun_out/$T/bench_default.json').read().strip().splitlines()[-1])
 print(j['value'], j['ms_per_step'], j['stage_ms_per_step'])
 r=j.get('repeat_workload') or {}
-print('repeat', r.get('value'), r.get('ms_per_step'), r.get('stage_ms_per_step'), r.get('error'))
-print(j['pcie_inclusive'])
+print('repeat', r.get('value'), r.get('ms_per_step'), r.get('stage_ms_per_step'), r.get('error'), (r.get('cpu_baseline') or {}).get('bed_identical_to_reference'))
+print(j['pcie_inclusive']); print(j['cpu_baseline'])
+print({k:j['roofline'][k] for k in ('achieved','frac','useful_frac','launch_ms') if k in j['roofline']})
 PY
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$T/rep_stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --skip-extras --headline-repeats 32,600,3000,0.02 --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/$T/bench_repeats_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/$T/rep_stats.log
-cd $GRAFT_REPO_ROOT
-find gpurun_out/$T/rep_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -25 {} | cut -c1-200'
-find gpurun_out/$T/rep_stats -name "*kernel_trace.csv" -delete
+timeout 300 python bench.py --steps 20 --warmup 5 --force-exchange --skip-extras > gpurun_out/$T/bench_exchange.json 2> gpurun_out/$T/bench_exchange.log; echo "bench-ex rc $?"
+python -c "
+import json
+j=json.loads(open('gpurun_out/$T/bench_exchange.json').read().strip().splitlines()[-1]); print('exchange', j['value'], j['ms_per_step'], j.get('exchange'))"
+timeout 600 python tools/e2e_bench.py --gz > gpurun_out/$T/e2e_cli.json 2> gpurun_out/$T/e2e_cli.log; cat gpurun_out/$T/e2e_cli.json | cut -c1-1500
+bash tools/profile_bench.sh ${T}_prof > gpurun_out/$T/profile.log 2>&1; tail -5 gpurun_out/$T/profile.log
+find gpurun_out/${T}_prof -name "*kernel_trace.csv" -delete; find gpurun_out/${T}_prof -name "*counter_collection.csv" -size +20M -delete
