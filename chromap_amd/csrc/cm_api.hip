@@ -648,7 +648,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       for (uint32_t ch = 0; ch < n_chunks; ++ch) {
         if (flat) cm_launch_k_prep_flat(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)c->opt_prep_tile_reads, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
         else cm_launch_k_prep_mm(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
-        HIPCHECK(c, hipMemcpyAsync(marks + ch + 1, c->mm_cursor.p, 8, hipMemcpyDeviceToDevice, s));
+        cm_launch_k_copy_u64((const unsigned long long *)c->mm_cursor.p, marks + ch + 1, s);
         HIPCHECK(c, hipEventRecord(c->chunk_ev[ch], s));
         HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[ch], 0));
         cm_launch_k_probe_range(d, marks + ch, max_entries[ch], (uint32_t)cap, (uint2 *)c->partials.p + part_off[ch], c->stream2, c->opt_probe_variant);

@@ -44,6 +44,9 @@ struct CmExchange {
   std::vector<uint8_t> h_owner;   // owner rank of every rid (length-weighted, contiguous rid ranges)
   DevBuf owner, send, counts /* counts[64], cursors[64], matrix[64*64] */, stage;
   unsigned long long *h_matrix = nullptr;  // pinned, world*world
+  hipStream_t stream = nullptr;            // the payload (grouped send / recv) runs here, under the next batch's kernels
+  hipEvent_t ev_part = nullptr, ev_payload = nullptr;
+  bool payload_pending = false;
   uint64_t sent_total = 0, recv_total = 0, steps = 0;
 };
 
@@ -185,6 +188,8 @@ int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc);
 void cm_store_split_bc(cmgpu_ctx *c, const void *in32, uint64_t n, hipStream_t s);
 // cm_exchange.hip
 void cm_exchange_release(cmgpu_ctx *c);
+// waits for an exchange payload still in flight (it lands in the record store): before anything reads or moves the store
+int cm_exchange_quiesce(cmgpu_ctx *c);
 // owner rank of every sequence for `world` ranks: contiguous rid ranges of (nearly) equal total length
 std::vector<uint8_t> cm_owner_table(const cmgpu_ctx *c, uint32_t world);
 

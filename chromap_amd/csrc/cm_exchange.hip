@@ -260,6 +260,12 @@ static int ex_common_init(cmgpu_ctx *c, int rank, int world) {
   if (rc) return rc;
   if (x.counts.ensure((2 * (EX_MAX_WORLD + 1) + EX_MAX_WORLD * (EX_MAX_WORLD + 1)) * 8)) { cm_set_error(c, "out of device memory (exchange counts)"); return CMGPU_ENOMEM; }
   if (!x.h_matrix) EXCHECK(c, hipHostMalloc((void **)&x.h_matrix, EX_MAX_WORLD * (EX_MAX_WORLD + 1) * 8, hipHostMallocDefault));
+  if (!x.stream) {
+    EXCHECK(c, hipStreamCreate(&x.stream));
+    EXCHECK(c, hipEventCreateWithFlags(&x.ev_part, hipEventDisableTiming));
+    EXCHECK(c, hipEventCreateWithFlags(&x.ev_payload, hipEventDisableTiming));
+  }
+  x.payload_pending = false;
   return CMGPU_OK;
 }
 
@@ -317,8 +323,23 @@ extern "C" int cmgpu_exchange_init_external(cmgpu_ctx *c, const cmgpu_exchange_t
   return CMGPU_OK;
 }
 
+int cm_exchange_quiesce(cmgpu_ctx *c) {
+  CmExchange &x = c->ex;
+  if (x.stream && x.payload_pending) {
+    (void)hipSetDevice(c->device);
+    const hipError_t e = hipStreamSynchronize(x.stream);
+    x.payload_pending = false;
+    if (e != hipSuccess) { cm_set_error(c, std::string("exchange payload: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
+  }
+  return CMGPU_OK;
+}
+
 void cm_exchange_release(cmgpu_ctx *c) {
   CmExchange &x = c->ex;
+  (void)cm_exchange_quiesce(c);
+  if (x.ev_part) { (void)hipEventDestroy(x.ev_part); x.ev_part = nullptr; }
+  if (x.ev_payload) { (void)hipEventDestroy(x.ev_payload); x.ev_payload = nullptr; }
+  if (x.stream) { (void)hipStreamDestroy(x.stream); x.stream = nullptr; }
   if (x.comm) {
     const RcclApi *api = rccl_api();
     if (api) (void)api->CommDestroy((ncclComm_t)x.comm);
@@ -332,6 +353,7 @@ extern "C" int cmgpu_exchange_finalize(cmgpu_ctx *c) {
   if (!c) return CMGPU_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)cm_exchange_quiesce(c);
   cm_exchange_release(c);
   return CMGPU_OK;
 }
@@ -370,7 +392,13 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
   // empty store).  It travels as entry `world` of the count vector so that every rank uses the same size.
   const uint32_t rb_local = n ? (c->has_barcodes ? 32u : 24u) : (c->store_n ? (c->store_has_bc ? 32u : 24u) : 0u);
   if (n_received) *n_received = 0;
+  if (x.send.cap < (size_t)(n ? n : 1) * 32 + 16) {  // growing the send buffer frees the old one: no payload may be reading it
+    int qrc = cm_exchange_quiesce(c);
+    if (qrc) return qrc;
+  }
   if (x.send.ensure((size_t)(n ? n : 1) * 32 + 16)) { cm_set_error(c, "out of device memory (exchange send buffer)"); return CMGPU_ENOMEM; }
+  // the previous round's payload still reads the send buffer (and it was issued on the payload stream)
+  if (x.payload_pending) EXCHECK(c, hipStreamWaitEvent(s, x.ev_payload, 0));
   unsigned long long *d_counts = (unsigned long long *)x.counts.p, *d_cursors = d_counts + EX_MAX_WORLD + 1, *d_matrix = d_cursors + EX_MAX_WORLD + 1;
   int rc = ex_partition(c, n, world, (const uint8_t *)x.owner.p, (uint8_t *)x.send.p, rb_local ? rb_local : 24u, d_counts, d_cursors);
   if (rc) return rc;
@@ -411,12 +439,17 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
   }
   if (c->store_n && tot_r && c->store_has_bc != bc) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (tot_r) {
+    if (c->store_n + tot_r > c->store_cap || (bc && !c->store_bc.p)) {  // the store moves: the previous payload must have landed
+      rc = cm_exchange_quiesce(c);
+      if (rc) return rc;
+    }
     rc = cm_store_reserve(c, c->store_n + tot_r, bc);
     if (rc) return rc;
   }
   uint8_t *dest = nullptr;
   if (tot_r) {
     if (bc) {
+      if (x.stage.cap < (size_t)tot_r * 32 + 16) { rc = cm_exchange_quiesce(c); if (rc) return rc; }
       if (x.stage.ensure((size_t)tot_r * 32 + 16)) { cm_set_error(c, "out of device memory (exchange staging)"); return CMGPU_ENOMEM; }
       dest = (uint8_t *)x.stage.p;
     } else {
@@ -424,20 +457,28 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
     }
   }
   if (x.transport == 1) {
+    // the payload goes out on its own stream: the caller's next cmgpu_map_* call runs beside it (the send buffer and the
+    // store's tail are its only operands; both are guarded above and in cm_exchange_quiesce)
     const RcclApi *api = rccl_api();
+    hipStream_t ps = x.stream;
+    EXCHECK(c, hipEventRecord(x.ev_part, s));
+    EXCHECK(c, hipStreamWaitEvent(ps, x.ev_part, 0));
     NCCLCHECK(c, api, api->GroupStart());
     for (uint32_t d = 0; d < world; ++d) {
       const uint32_t peer = (me + d) % world;  // staggered so that no rank is everybody's first target
-      if (send_cnt[peer]) NCCLCHECK(c, api, api->Send((const uint8_t *)x.send.p + send_off[peer] * rb, send_cnt[peer] * rb, ncclUint8, (int)peer, (ncclComm_t)x.comm, s));
+      if (send_cnt[peer]) NCCLCHECK(c, api, api->Send((const uint8_t *)x.send.p + send_off[peer] * rb, send_cnt[peer] * rb, ncclUint8, (int)peer, (ncclComm_t)x.comm, ps));
       const uint32_t src = (me + world - d) % world;
-      if (recv_cnt[src]) NCCLCHECK(c, api, api->Recv(dest + recv_off[src] * rb, recv_cnt[src] * rb, ncclUint8, (int)src, (ncclComm_t)x.comm, s));
+      if (recv_cnt[src]) NCCLCHECK(c, api, api->Recv(dest + recv_off[src] * rb, recv_cnt[src] * rb, ncclUint8, (int)src, (ncclComm_t)x.comm, ps));
     }
     NCCLCHECK(c, api, api->GroupEnd());
+    if (tot_r && bc) cm_store_split_bc(c, dest, tot_r, ps);
+    EXCHECK(c, hipEventRecord(x.ev_payload, ps));
+    x.payload_pending = true;
   } else {
     // the callbacks run outside the stream: the send buffer is complete (synchronised above)
     if (x.ext.alltoallv(x.ext.user, x.send.p, send_cnt, dest, recv_cnt, world, rb) != 0) { cm_set_error(c, "exchange transport: alltoallv failed"); return CMGPU_EIO; }
   }
-  if (tot_r && bc) cm_store_split_bc(c, dest, tot_r, s);
+  if (x.transport != 1 && tot_r && bc) cm_store_split_bc(c, dest, tot_r, s);
   c->store_n += tot_r;
   c->batch_exchanged = true;
   x.sent_total += tot_s;

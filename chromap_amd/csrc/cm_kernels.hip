@@ -988,6 +988,13 @@ void cm_build_heavy_last(const CmDev &d, uint32_t n_pairs, uint32_t *fr, uint32_
   hipLaunchKernelGGL(k_hv_scatter, grid_for_n(n_pairs), dim3(CM_BLOCK), 0, s, (const uint32_t *)fp, (const uint32_t *)sp, n_pairs, perm_pairs);
 }
 
+// dst[0] = src[0]: the cursor value after a chunk's minimizer launch (a device-to-device hipMemcpyAsync of 8 bytes runs as a
+// ~35 us blit kernel, eight of them sat between the chunks' minimizer and probe launches)
+__global__ void k_copy_u64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst) { dst[0] = src[0]; }
+void cm_launch_k_copy_u64(const unsigned long long *src, unsigned long long *dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, s, src, dst);
+}
+
 // *out += sum of in[0..n) in 64 bits (the u32 prefix sums above wrap silently; the callers size and bound the
 // dense arrays from this total)
 __global__ __launch_bounds__(CM_BLOCK) void k_sum_u32(const uint32_t *__restrict__ in, uint32_t n, unsigned long long *__restrict__ out) {

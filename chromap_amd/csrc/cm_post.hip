@@ -371,6 +371,7 @@ int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc) {
 extern "C" int cmgpu_store_reserve(cmgpu_ctx *c, uint64_t n_records, int barcoded) {
   if (!c) return CMGPU_EINVAL;
   PPCHECK(c, cm_enter(c));
+  { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
   if (c->store_n && c->store_has_bc != (barcoded != 0)) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   const bool had_bc = c->store_has_bc;
   const int rc = cm_store_reserve(c, n_records, barcoded != 0);
@@ -380,6 +381,7 @@ extern "C" int cmgpu_store_reserve(cmgpu_ctx *c, uint64_t n_records, int barcode
 
 extern "C" int cmgpu_store_clear(cmgpu_ctx *c) {
   if (!c) return CMGPU_EINVAL;
+  (void)cm_exchange_quiesce(c);
   c->store_n = 0;
   c->store_has_bc = false;
   c->text_bytes = 0;
@@ -390,6 +392,7 @@ extern "C" int cmgpu_store_clear(cmgpu_ctx *c) {
 extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
   if (!c) return CMGPU_EINVAL;
   PPCHECK(c, cm_enter(c));
+  { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
   if (c->p.split) { cm_set_error(c, "pairs records are post-processed on the host (cmgpu_write_pairs)"); return CMGPU_EINVAL; }
   const uint32_t n = c->n_pairs;
   if (c->store_n && c->store_has_bc != c->has_barcodes) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
@@ -415,6 +418,7 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
 extern "C" int cmgpu_store_append(cmgpu_ctx *c, const void *records, uint64_t n, int on_device, int barcoded) {
   if (!c || (!records && n)) return CMGPU_EINVAL;
   PPCHECK(c, cm_enter(c));
+  { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
   if (c->store_n && c->store_has_bc != (barcoded != 0)) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (n == 0) return CMGPU_OK;
   int rc = cm_store_reserve(c, c->store_n + n, barcoded != 0);
@@ -461,6 +465,7 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   if (pp_has_bc(kind) != c->store_has_bc && c->store_n) { cm_set_error(c, "text kind does not match the stored records"); return CMGPU_EINVAL; }
   if (pp_has_bc(kind) && (barcode_length == 0 || barcode_length > 32)) { cm_set_error(c, "barcode length must be 1..32"); return CMGPU_EINVAL; }
   PPCHECK(c, cm_enter(c));
+  { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
   hipStream_t s = c->stream;
   *n_lines = 0;
   *n_bytes = 0;
