@@ -74,6 +74,8 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "s3b_lane_cap") {  // hits a lane clusters in its own LDS slots; longer lists go to a wave / block each
     if (value < 0 || value > 64) { cm_set_error(c, "s3b_lane_cap: 0 (by read length) or 1..64"); return CMGPU_EINVAL; }
     c->opt_s3b_cap = (int)value;
+  } else if (n == "exchange_overlap") {
+    c->opt_exchange_overlap = value ? 1 : 0;
   } else if (n == "lanes") {
     if (value < 1 || value > 8) { cm_set_error(c, "lanes: 1..8"); return CMGPU_EINVAL; }
     c->opt_lanes = (int)value;

@@ -126,6 +126,7 @@ struct cmgpu_ctx {
   int opt_prep_kernel = 0;         // 0: lane-per-read minimizer kernels; 1: the position-parallel kernel where it applies (k_prep_flat:
                                    // half the instructions, but 7 barriers + one global reservation per tile -- measured slower)
   uint64_t opt_item_limit = 0xfffffff0ull;
+  int opt_exchange_overlap = 0;      // exchange payload on a stream of its own (under the next batch's kernels)
   int opt_s3b_cap = 0;               // 0: by read length (cm_s3b_lane_cap)
   int opt_lanes = 1;                 // sub-batches of one cmgpu_map_* call mapped side by side (own streams and intermediates each)
   std::vector<cmgpu_ctx *> lanes;    // the further lanes' contexts (views of this context's index, reference, batch and record arrays)

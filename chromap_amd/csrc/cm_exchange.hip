@@ -457,23 +457,34 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
     }
   }
   if (x.transport == 1) {
-    // the payload goes out on its own stream: the caller's next cmgpu_map_* call runs beside it (the send buffer and the
-    // store's tail are its only operands; both are guarded above and in cm_exchange_quiesce)
+    // The payload: this rank's own records by a device-to-device copy, the peers' by one grouped send / recv.  By default on
+    // the mapping stream; with the "exchange_overlap" option on a stream of its own, under the next batch's kernels (the
+    // send buffer and the store's tail are its only operands; both are guarded above and in cm_exchange_quiesce) --
+    // measured slower on one GPU with several lanes mapping beside it, so it is not the default.
     const RcclApi *api = rccl_api();
-    hipStream_t ps = x.stream;
-    EXCHECK(c, hipEventRecord(x.ev_part, s));
-    EXCHECK(c, hipStreamWaitEvent(ps, x.ev_part, 0));
-    NCCLCHECK(c, api, api->GroupStart());
-    for (uint32_t d = 0; d < world; ++d) {
-      const uint32_t peer = (me + d) % world;  // staggered so that no rank is everybody's first target
-      if (send_cnt[peer]) NCCLCHECK(c, api, api->Send((const uint8_t *)x.send.p + send_off[peer] * rb, send_cnt[peer] * rb, ncclUint8, (int)peer, (ncclComm_t)x.comm, ps));
-      const uint32_t src = (me + world - d) % world;
-      if (recv_cnt[src]) NCCLCHECK(c, api, api->Recv(dest + recv_off[src] * rb, recv_cnt[src] * rb, ncclUint8, (int)src, (ncclComm_t)x.comm, ps));
+    const bool overlap = c->opt_exchange_overlap != 0;
+    hipStream_t ps = overlap ? x.stream : s;
+    if (overlap) {
+      EXCHECK(c, hipEventRecord(x.ev_part, s));
+      EXCHECK(c, hipStreamWaitEvent(ps, x.ev_part, 0));
     }
-    NCCLCHECK(c, api, api->GroupEnd());
+    if (send_cnt[me])
+      EXCHECK(c, hipMemcpyAsync(dest + recv_off[me] * rb, (const uint8_t *)x.send.p + send_off[me] * rb, send_cnt[me] * rb, hipMemcpyDeviceToDevice, ps));
+    if (world > 1) {
+      NCCLCHECK(c, api, api->GroupStart());
+      for (uint32_t d = 1; d < world; ++d) {
+        const uint32_t peer = (me + d) % world;  // staggered so that no rank is everybody's first target
+        if (send_cnt[peer]) NCCLCHECK(c, api, api->Send((const uint8_t *)x.send.p + send_off[peer] * rb, send_cnt[peer] * rb, ncclUint8, (int)peer, (ncclComm_t)x.comm, ps));
+        const uint32_t src = (me + world - d) % world;
+        if (recv_cnt[src]) NCCLCHECK(c, api, api->Recv(dest + recv_off[src] * rb, recv_cnt[src] * rb, ncclUint8, (int)src, (ncclComm_t)x.comm, ps));
+      }
+      NCCLCHECK(c, api, api->GroupEnd());
+    }
     if (tot_r && bc) cm_store_split_bc(c, dest, tot_r, ps);
-    EXCHECK(c, hipEventRecord(x.ev_payload, ps));
-    x.payload_pending = true;
+    if (overlap) {
+      EXCHECK(c, hipEventRecord(x.ev_payload, ps));
+      x.payload_pending = true;
+    }
   } else {
     // the callbacks run outside the stream: the send buffer is complete (synchronised above)
     if (x.ext.alltoallv(x.ext.user, x.send.p, send_cnt, dest, recv_cnt, world, rb) != 0) { cm_set_error(c, "exchange transport: alltoallv failed"); return CMGPU_EIO; }
