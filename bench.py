@@ -343,7 +343,9 @@ def main():
     def make_ctx(rep):
         g_ = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset, device=local_rank,
                         **({"output_format": 1} if args.sam else {}))
-        g_.set_option("lanes", args.lanes)
+        # lanes and the record exchange do not mix well on one GPU (measured: 3 lanes 429 -> 366 M pairs/s with the exchange,
+        # 1 lane 404 -> 388): ranks that exchange map their batch in one piece
+        g_.set_option("lanes", 1 if exchange else args.lanes)
         for o in args.option:
             k_, v_ = o.split("=")
             g_.set_option(k_, int(v_))
@@ -483,7 +485,7 @@ def main():
                                % (args.preset, args.readlen, args.frag_min, args.frag_max,
                                   ", %.2f%% 1-base indels" % (args.indel_rate * 100) if args.indel_rate else "", args.genome, args.nseq,
                                   ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS),
-                   "pairs_per_gpu_per_step": args.pairs, "lanes": args.lanes,
+                   "pairs_per_gpu_per_step": args.pairs, "lanes": 1 if exchange else args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
         "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
