@@ -48,6 +48,7 @@ struct CmExchange {
   hipEvent_t ev_part = nullptr, ev_payload = nullptr;
   bool payload_pending = false;
   uint64_t sent_total = 0, recv_total = 0, steps = 0;
+  uint64_t owned_by[64] = {};  // records every rank's store has received so far (column sums of the count matrices)
 };
 
 // a parked resident batch (cmgpu_swap_resident_batch): the measurement rotates several distinct batches

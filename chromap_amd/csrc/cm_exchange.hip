@@ -265,6 +265,7 @@ static int ex_common_init(cmgpu_ctx *c, int rank, int world) {
   x.rank = rank;
   x.world = world;
   x.sent_total = x.recv_total = x.steps = 0;
+  for (uint64_t &v : x.owned_by) v = 0;
   int rc = ex_owner_upload(c, (uint32_t)world);
   if (rc) return rc;
   if (x.counts.ensure((2 * (EX_MAX_WORLD + 1) + EX_MAX_WORLD * (EX_MAX_WORLD + 1)) * 8)) { cm_set_error(c, "out of device memory (exchange counts)"); return CMGPU_ENOMEM; }
@@ -446,6 +447,8 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
     recv_off[r] = tot_r; tot_r += recv_cnt[r];
     if (sent_per_rank) sent_per_rank[r] = send_cnt[r];
   }
+  for (uint32_t j = 0; j < world; ++j)
+    for (uint32_t r = 0; r < world; ++r) x.owned_by[j] += M[(size_t)r * stride + j];
   if (c->store_n && tot_r && c->store_has_bc != bc) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (tot_r) {
     if (c->store_n + tot_r > c->store_cap || (bc && !c->store_bc.p)) {  // the store moves: the previous payload must have landed

@@ -47,6 +47,7 @@ struct PpCfg {
   uint32_t n_seq;
   uint32_t bc_len;
   int bulk;       // single-cell data, duplicate removal at bulk level (mapping_writer.h:202-345)
+  int last_section;   // this store ends the output (always, unless a higher rank of a multi-GPU run owns records too)
   const uint64_t *wl;  // whitelist table {key, abundance} (cm_api.hip: cmgpu_set_whitelist), linear probing
   uint32_t wl_mask;
 };
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
     wi = best_i;
     r = pp_load(store, wi);
     // the very last run of the output is filtered on the run's maximal MAPQ (mapping_writer.h:331-337)
-    const uint32_t filter_mapq = t == n ? maxq_mapq : (uint32_t)r.mapq;
+    const uint32_t filter_mapq = t == n && cfg.last_section ? maxq_mapq : (uint32_t)r.mapq;
     if ((int)filter_mapq < cfg.mapq_thr) { line_len[j] = 0; return; }
     bulk_done = true;
   } else
@@ -482,6 +483,9 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   cfg.n_seq = n_sequences;
   cfg.bc_len = barcode_length;
   cfg.bulk = pp_has_bc(kind) && p->dedup_at_bulk_level && p->low_memory_mode && p->remove_pcr_duplicates;
+  cfg.last_section = 1;
+  if (c->ex.transport)  // the merge loop's end-of-output rule (mapping_writer.h:331-337) belongs to the last rank that owns records
+    for (int r = c->ex.rank + 1; r < c->ex.world; ++r) if (c->ex.owned_by[r]) cfg.last_section = 0;
   cfg.wl = (const uint64_t *)c->wl.p;
   cfg.wl_mask = c->wl_mask;
   if (cfg.bulk && c->wl_size == 0) { cm_set_error(c, "bulk-level duplicate removal needs the whitelist abundances (cmgpu_set_whitelist)"); return CMGPU_EINVAL; }
