@@ -139,7 +139,12 @@ static int build_mapq_tables(cmgpu_ctx *c) {
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id) {
   c->device = device_id;
   c->hp = *params;
-  if (params->max_num_best_mappings != 1) { cm_set_error(c, "max_num_best_mappings must be 1"); return CMGPU_EINVAL; }
+  if (params->max_num_best_mappings < 1 || params->max_num_best_mappings > CM_MAX_BEST) {
+    cm_set_error(c, "max_num_best_mappings must be in [1, " + std::to_string(CM_MAX_BEST) + "]"); return CMGPU_EINVAL;
+  }
+  if (params->max_num_best_mappings > 1 && params->output_format == 1) {  // one SAM slot per read on the device
+    cm_set_error(c, "--SAM with more than one best mapping per read is outside this build"); return CMGPU_EINVAL;
+  }
   if (kmer < 1 || kmer > 28 || window < 1 || window > CM_MAX_W_HOST) { cm_set_error(c, "unsupported k/w"); return CMGPU_EINVAL; }
   if (params->error_threshold < 1 || params->error_threshold > 15) { cm_set_error(c, "error_threshold must be 1..15"); return CMGPU_EINVAL; }
   CmParams &p = c->p;
@@ -345,6 +350,15 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
 // ---------------------------------------------------------------------------------------
 // batch upload / residency
 // ---------------------------------------------------------------------------------------
+int cm_ensure_slot_scratch(cmgpu_ctx *c, uint64_t slots) {
+  if (slots + 1 > 0xffffffffull) { cm_set_error(c, "too many record slots in one batch"); return CMGPU_EINVAL; }
+  if (c->scratch_a.ensure((slots + 1) * 4) || c->scratch_b.ensure((slots + 1) * 4) ||
+      c->scan_tmp.ensure(cm_scan_tmp_words((uint32_t)slots + 1) * 4)) {
+    cm_set_error(c, "out of device memory (record compaction)"); return CMGPU_ENOMEM;
+  }
+  return CMGPU_OK;
+}
+
 static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   const size_t n2 = 2 * (size_t)n;
 #define ENS(buf, bytes) if (c->buf.ensure(bytes)) { cm_set_error(c, "out of device memory (" #buf ")"); return CMGPU_ENOMEM; }
@@ -356,7 +370,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(force0, n) ENS(fcp, n2 * 4) ENS(fcn, n2 * 4) ENS(alive, n) ENS(ndp, n2 * 4) ENS(ndn, n2 * 4)
   ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
-  ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4)
+  ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
   ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4)
 #undef ENS
@@ -536,8 +550,8 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   PTR(pe_min, int32_t) PTR(pe_second, int32_t) PTR(pe_nbest, int32_t) PTR(pe_nsecond, int32_t)
   PTR(pe_first, uint32_t) PTR(pe_i1, uint32_t) PTR(pe_i2, uint32_t) PTR(pe_choice, uint32_t)
 #undef PTR
-  d.rec = (uint8_t *)c->rec.p + (size_t)lo * 24;
-  d.rec_ok = (uint8_t *)c->rec_ok.p + lo;
+  d.rec = (uint8_t *)c->rec.p + (size_t)lo * 24 * cm_rec_per_pair(c);
+  d.rec_ok = (uint8_t *)c->rec_ok.p + (size_t)lo * cm_rec_per_pair(c);
   d.stats = (unsigned long long *)c->stats.p;
   d.srt_cnt = (uint32_t *)c->srt_cnt.p;
   d.srt_list = (uint32_t *)c->srt_list.p;
@@ -854,7 +868,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     return CMGPU_EINVAL;
   }
   // per-pair outputs of the whole batch; the intermediates are sized per range
-  if (c->rec.ensure((size_t)n * 24) || c->rec_ok.ensure(n)) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
+  if (c->rec.ensure(cm_rec_slots(c) * 24) || c->rec_ok.ensure(cm_rec_slots(c))) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
   if (c->has_barcodes && (c->bc_key.ensure((size_t)n * 8) || c->bc_ok.ensure(n))) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
   if (c->p.sam) {  // per-slot record / CIGAR / MD pools
     const uint64_t slots = c->single ? n : 2ull * n;
@@ -924,9 +938,10 @@ __global__ void k_rec_compact2(const uint8_t *__restrict__ rec, const uint8_t *_
   d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
 static int download_dense(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
-  const uint32_t n = c->n_pairs;
+  const uint32_t n = (uint32_t)cm_rec_slots(c);
   if (n_out) *n_out = 0;
   if (n == 0) return CMGPU_OK;
+  { const int rc = cm_ensure_slot_scratch(c, n); if (rc) return rc; }
   if (c->rec_dense.ensure((size_t)n * 24 + 16)) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
   uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
   hipStream_t s = c->stream;
@@ -1230,9 +1245,10 @@ __global__ void k_rec_compact(const uint8_t *__restrict__ rec, const uint8_t *__
 extern "C" int cmgpu_records_to_device(cmgpu_ctx *c, void *device_dst, uint64_t capacity, uint64_t *n_out) {
   if (!c || !device_dst || !n_out) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
-  const uint32_t n = c->n_pairs;
+  const uint32_t n = (uint32_t)cm_rec_slots(c);
   *n_out = 0;
   if (n == 0) return CMGPU_OK;
+  { const int rc = cm_ensure_slot_scratch(c, n); if (rc) return rc; }
   uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
   hipLaunchKernelGGL(k_rec_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint8_t *)c->rec_ok.p, flag, n);
   cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, c->stream);
@@ -1442,18 +1458,20 @@ extern "C" int cmgpu_map_pairs_barcoded(cmgpu_ctx *c, const cmgpu_batch *in, con
   rc = cmgpu_map_resident(c, &k, stats);
   if (rc) return rc;
   if (!out) { *n_out = k; return CMGPU_OK; }
-  std::vector<cmgpu_record> rec(n);
-  std::vector<uint8_t> ok(n);
+  const uint32_t K = cm_rec_per_pair(c);
+  const size_t ns = (size_t)n * K;  // K record slots per pair, one key per pair
+  std::vector<cmgpu_record> rec(ns);
+  std::vector<uint8_t> ok(ns);
   std::vector<uint64_t> keys(n);
-  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, (size_t)n * 24, hipMemcpyDeviceToHost));
-  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, n, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, ns * 24, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, ns, hipMemcpyDeviceToHost));
   HIPCHECK(c, hipMemcpy(keys.data(), c->bc_key.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   uint64_t o = 0;
-  for (uint32_t i = 0; i < n; ++i) {
+  for (size_t i = 0; i < ns; ++i) {
     if (!ok[i]) continue;
     if (o >= out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
     out[o].r = rec[i];
-    out[o].barcode = keys[i];
+    out[o].barcode = keys[i / K];
     ++o;
   }
   *n_out = o;
@@ -1515,18 +1533,20 @@ static int map_single_impl(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmg
   if (rc) return rc;
   if (!out && !out_bc) { *n_out = k; return CMGPU_OK; }
   if (!bc) return cmgpu_download_records(c, out, out_capacity, n_out);
-  std::vector<cmgpu_record> rec(n);
-  std::vector<uint8_t> ok(n);
+  const uint32_t K = cm_rec_per_pair(c);
+  const size_t ns = (size_t)n * K;  // K record slots per pair, one key per pair
+  std::vector<cmgpu_record> rec(ns);
+  std::vector<uint8_t> ok(ns);
   std::vector<uint64_t> keys(n);
-  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, (size_t)n * 24, hipMemcpyDeviceToHost));
-  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, n, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(rec.data(), c->rec.p, ns * 24, hipMemcpyDeviceToHost));
+  HIPCHECK(c, hipMemcpy(ok.data(), c->rec_ok.p, ns, hipMemcpyDeviceToHost));
   HIPCHECK(c, hipMemcpy(keys.data(), c->bc_key.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   uint64_t o = 0;
-  for (uint32_t i = 0; i < n; ++i) {
+  for (size_t i = 0; i < ns; ++i) {
     if (!ok[i]) continue;
     if (o >= out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
     out_bc[o].r = rec[i];
-    out_bc[o].barcode = keys[i];
+    out_bc[o].barcode = keys[i / K];
     ++o;
   }
   *n_out = o;

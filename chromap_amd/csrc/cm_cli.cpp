@@ -287,6 +287,7 @@ static Args parse(int argc, char **argv) {
     }
     else if (o == "-l" || o == "--max-insert-size") a.p.max_insert_size = atoi(need("-l"));
     else if (o == "-q" || o == "--MAPQ-threshold") a.p.mapq_threshold = atoi(need("-q"));
+    else if (o == "-n" || o == "--max-num-best-mappings") a.p.max_num_best_mappings = atoi(need("-n"));
     else if (o == "--min-read-length") a.p.min_read_length = atoi(need("--min-read-length"));
     else if (o == "--drop-repetitive-reads") a.p.drop_repetitive_reads = atoi(need("--drop-repetitive-reads"));
     else if (o == "--bc-error-threshold") a.p.bc_error_threshold = atoi(need("--bc-error-threshold"));
@@ -343,8 +344,17 @@ static Args parse(int argc, char **argv) {
     }
     else die("unsupported option " + o + " (PAF and summary outputs are outside this build)");
   }
+  if (a.p.max_num_best_mappings > a.p.drop_repetitive_reads) {  // chromap_driver.cc:630-641
+    fprintf(stderr, "WARNING: you want to drop mapped reads with more than %d mappings. But you want to output top %d best mappings. "
+                    "In this case, only reads with <=%d best mappings will be output.\n",
+            a.p.drop_repetitive_reads, a.p.max_num_best_mappings, a.p.drop_repetitive_reads);
+    a.p.max_num_best_mappings = a.p.drop_repetitive_reads;
+  }
+  if (a.p.max_num_best_mappings < 1) die("-n must be at least 1");
+  if (a.p.max_num_best_mappings > 64) die("-n above 64 is outside this build (64 record slots per read at most)");
   if (a.out_sam) {
     if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
+    if (a.p.max_num_best_mappings > 1) die("--SAM with -n > 1 is outside this build");
     a.p.output_format = CMGPU_FORMAT_SAM;
   }
   // the reference accepts these combinations; this build has no record type for them -- refuse instead of writing garbage
@@ -708,9 +718,10 @@ int main(int argc, char **argv) {
           rc = cmgpu_map_pairs(ctx, &bt, nullptr, 0, &k, &st);
         } else if (paired) {
           const size_t base = recs.size();
-          recs.resize(base + n);
+          const size_t cap = (size_t)n * (size_t)(a.p.max_num_best_mappings > 1 ? a.p.max_num_best_mappings : 1);  // -n records per pair
+          recs.resize(base + cap);
           cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
-          rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, n, &k, &st);
+          rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, cap, &k, &st);
           recs.resize(base + k);
         } else {
           cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};

@@ -186,6 +186,11 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d);
 int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref);
 // cm_post.hip: room for `need` records in the device-side store (with_bc: the parallel barcode array too)
 int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc);
+// record slots of the resident batch: max_num_best_mappings per pair (cm_emit_record); flag / position scratch for a
+// compaction over them (scratch_a, scratch_b, scan_tmp sized for `slots` entries)
+static inline uint32_t cm_rec_per_pair(const cmgpu_ctx *c) { return (uint32_t)(c->p.max_best > 0 ? c->p.max_best : 1); }
+static inline uint64_t cm_rec_slots(const cmgpu_ctx *c) { return (uint64_t)c->n_pairs * cm_rec_per_pair(c); }
+int cm_ensure_slot_scratch(cmgpu_ctx *c, uint64_t slots);
 // cm_post.hip: n 32-byte {record, barcode} entries -> the store's record / barcode arrays at position store_n
 void cm_store_split_bc(cmgpu_ctx *c, const void *in32, uint64_t n, hipStream_t s);
 // cm_exchange.hip

@@ -178,7 +178,7 @@ __global__ void k_ex_starts(const unsigned long long *__restrict__ counts, unsig
 __global__ __launch_bounds__(EX_BLOCK) void k_ex_scatter(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok,
                                                           const uint64_t *__restrict__ bc, uint32_t n, const uint8_t *__restrict__ owner,
                                                           uint32_t n_seq, uint32_t world, unsigned long long *__restrict__ cursors,
-                                                          uint8_t *__restrict__ dst, uint32_t rb) {
+                                                          uint8_t *__restrict__ dst, uint32_t rb, uint32_t per_pair) {
   __shared__ uint32_t hist[EX_MAX_WORLD];
   __shared__ unsigned long long base[EX_MAX_WORLD];
   if (threadIdx.x < EX_MAX_WORLD) hist[threadIdx.x] = 0;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_ex_scatter(const uint8_t *__restri
   const uint64_t *sp = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
   uint64_t *dp = reinterpret_cast<uint64_t *>(dst + (base[k] + local) * rb);
   dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
-  if (rb == 32) dp[3] = bc[i];
+  if (rb == 32) dp[3] = bc[i / per_pair];
 }
 
 // this rank's own records go from the send buffer to the store by a plain copy kernel (a device-to-device hipMemcpyAsync of
@@ -224,7 +224,7 @@ static int ex_partition(cmgpu_ctx *c, uint32_t n, uint32_t world, const uint8_t 
     hipLaunchKernelGGL(k_ex_count, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, d_owner, c->n_seq, world, d_counts);
     hipLaunchKernelGGL(k_ex_starts, dim3(1), dim3(64), 0, s, d_counts, d_cursors, world);
     hipLaunchKernelGGL(k_ex_scatter, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p,
-                       rb == 32 ? (const uint64_t *)c->bc_key.p : (const uint64_t *)nullptr, n, d_owner, c->n_seq, world, d_cursors, dst, rb);
+                       rb == 32 ? (const uint64_t *)c->bc_key.p : (const uint64_t *)nullptr, n, d_owner, c->n_seq, world, d_cursors, dst, rb, cm_rec_per_pair(c));
   }
   return CMGPU_OK;
 }
@@ -236,7 +236,7 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   EXCHECK(c, cm_enter(c));
   for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
   if (c->n_pairs == 0) return CMGPU_OK;
-  if (capacity < c->n_pairs) { cm_set_error(c, "send buffer too small (one slot per pair of the batch is needed)"); return CMGPU_ECAPACITY; }
+  if (capacity < cm_rec_slots(c)) { cm_set_error(c, "send buffer too small (one slot per pair of the batch -- times max_num_best_mappings -- is needed)"); return CMGPU_ECAPACITY; }
   if (c->p.split) { cm_set_error(c, "pairs records are not partitioned by chromosome"); return CMGPU_EINVAL; }
   const std::vector<uint8_t> t = cm_owner_table(c, world);
   DevBuf &dcnt = c->part_cnt;
@@ -244,7 +244,7 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   unsigned long long *d_counts = (unsigned long long *)dcnt.p, *d_cursors = d_counts + EX_MAX_WORLD + 1;
   uint8_t *d_owner = (uint8_t *)(d_cursors + EX_MAX_WORLD + 1);
   EXCHECK(c, hipMemcpyAsync(d_owner, t.data(), t.size(), hipMemcpyHostToDevice, c->stream));
-  int rc = ex_partition(c, c->n_pairs, world, d_owner, (uint8_t *)device_dst, 24, d_counts, d_cursors);
+  int rc = ex_partition(c, (uint32_t)cm_rec_slots(c), world, d_owner, (uint8_t *)device_dst, 24, d_counts, d_cursors);
   if (rc) return rc;
   unsigned long long h[EX_MAX_WORLD];
   EXCHECK(c, hipMemcpyAsync(h, d_counts, (size_t)world * 8, hipMemcpyDeviceToHost, c->stream));
@@ -397,7 +397,7 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
   hipStream_t s = c->stream;
   // a batch takes part once: a second step without a new cmgpu_map_* call contributes an empty batch (a rank that
   // ran out of input keeps calling while the others finish)
-  const uint32_t world = (uint32_t)x.world, me = (uint32_t)x.rank, n = c->batch_exchanged ? 0 : c->n_pairs, stride = world + 1;
+  const uint32_t world = (uint32_t)x.world, me = (uint32_t)x.rank, n = c->batch_exchanged ? 0 : (uint32_t)cm_rec_slots(c), stride = world + 1;
   // record kind of this rank: 24-byte bulk records or 32-byte {record, barcode}; 0 = nothing to say (empty batch,
   // empty store).  It travels as entry `world` of the count vector so that every rank uses the same size.
   const uint32_t rb_local = n ? (c->has_barcodes ? 32u : 24u) : (c->store_n ? (c->store_has_bc ? 32u : 24u) : 0u);

@@ -671,13 +671,7 @@ __global__ __launch_bounds__(64) void k_s6b_sample(CmDev d, uint32_t n_chunks) {
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
         const uint32_t pr = base + (uint32_t)l;
-        const int nbl = d.pe_nbest[pr];
-        int choice = 0;
-        for (int i = 1; i < nbl; ++i) {
-          const int j = cm_mt_uniform(g, i);
-          if (j < 1) choice = i;
-        }
-        d.pe_choice[pr] = (uint32_t)choice;
+        cm_reservoir(d, pr, d.pe_nbest[pr], g);
       }
     }
     seeded = __shfl((int)seeded, 0, 64) != 0;
@@ -907,7 +901,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_stats(CmDev d, uint32_t n, unsigne
     }
     v[5] = (unsigned long long)d.aug[r1] + d.aug[r2];
     v[6] = (unsigned long long)d.hit_tot[r1] + d.hit_tot[r2];
-    v[7] = d.rec_ok[pair];
+    for (uint32_t t = 0; t < (uint32_t)d.p.max_best; ++t) v[7] += d.rec_ok[(uint64_t)pair * (uint32_t)d.p.max_best + t];
   }
   __shared__ unsigned long long sh[CM_BLOCK / 64][CM_NSTAT];
 #pragma unroll

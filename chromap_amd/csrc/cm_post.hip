@@ -317,14 +317,15 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_format(const uint8_t *__restric
 }
 
 __global__ void k_pp_compact(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, const uint32_t *__restrict__ pos,
-                             const uint64_t *__restrict__ bc_in, uint8_t *__restrict__ dst, uint64_t *__restrict__ bc_dst, uint32_t n) {
+                             const uint64_t *__restrict__ bc_in, uint8_t *__restrict__ dst, uint64_t *__restrict__ bc_dst, uint32_t n,
+                             uint32_t per_pair) {  // per_pair record slots share one barcode key
   const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
   if (i >= n || !ok[i]) return;
   const uint32_t o = pos[i];
   const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
   uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)o * 24);
   d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
-  if (bc_dst) bc_dst[o] = bc_in[i];
+  if (bc_dst) bc_dst[o] = bc_in[i / per_pair];
 }
 __global__ void k_pp_flag(const uint8_t *ok, uint32_t *flag, uint32_t n) {
   const uint32_t i = blockIdx.x * PP_BLOCK + threadIdx.x;
@@ -395,10 +396,12 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
   PPCHECK(c, cm_enter(c));
   { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
   if (c->p.split) { cm_set_error(c, "pairs records are post-processed on the host (cmgpu_write_pairs)"); return CMGPU_EINVAL; }
-  const uint32_t n = c->n_pairs;
+  const uint32_t n = (uint32_t)cm_rec_slots(c);
   if (c->store_n && c->store_has_bc != c->has_barcodes) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (n) {
     int rc = cm_store_reserve(c, c->store_n + n, c->has_barcodes);
+    if (rc) return rc;
+    rc = cm_ensure_slot_scratch(c, n);
     if (rc) return rc;
     uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
     const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
@@ -406,7 +409,7 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
     cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, c->stream);
     hipLaunchKernelGGL(k_pp_compact, g, b, 0, c->stream, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, (const uint32_t *)pos,
                        (const uint64_t *)c->bc_key.p, (uint8_t *)c->store.p + c->store_n * 24,
-                       c->has_barcodes ? (uint64_t *)c->store_bc.p + c->store_n : (uint64_t *)nullptr, n);
+                       c->has_barcodes ? (uint64_t *)c->store_bc.p + c->store_n : (uint64_t *)nullptr, n, cm_rec_per_pair(c));
     uint32_t k = 0;
     PPCHECK(c, hipMemcpyAsync(&k, pos + n, 4, hipMemcpyDeviceToHost, c->stream));
     PPCHECK(c, cm_stream_sync(c->stream));

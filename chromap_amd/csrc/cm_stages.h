@@ -2452,8 +2452,9 @@ CM_HD const int16_t *cm_d_err(const CmDev &d, uint32_t r, int strand) {
 // OneDirection (mapping_generator.h:487-653) + EmplaceBackPairedEndMappingRecord
 // (mapping_generator.cc:111-125) + PairedEndMappingInMemory getters (mapping_in_memory.h:64-108)
 template <bool SAM>
-CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
+CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe, uint32_t nth = 0) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  const uint64_t slot = (uint64_t)pair * (uint32_t)d.p.max_best + nth;  // max_best record slots per pair
   const int dir = (int)pe.f_dir;
   const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
   const int s1 = dir == 0 ? 0 : 1, s2 = dir == 0 ? 1 : 0;
@@ -2474,7 +2475,7 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   const uint8_t is_unique = (pe.n_best == 1 || d.n_best[r1] == 1 || d.n_best[r2] == 1) ? 1 : 0;
   const CmSpan &ps = dir == 0 ? a : b;  // the + strand read
   const CmSpan &ns = dir == 0 ? b : a;
-  uint8_t *o = d.rec + (uint64_t)pair * 24;
+  uint8_t *o = d.rec + slot * 24;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
   uint16_t *o16 = reinterpret_cast<uint16_t *>(o);
   o32[0] = d.first_read_id + pair;
@@ -2488,7 +2489,7 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   o16[9] = (uint16_t)(ps.ref_end - ps.ref_start + 1);
   o16[10] = (uint16_t)(ns.ref_end - ns.ref_start + 1);
   o16[11] = 0;
-  d.rec_ok[pair] = 1;
+  d.rec_ok[slot] = 1;
   if constexpr (SAM) {  // EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108), flags mapping_generator.h:613-631
     const int tlen = (int)(ns.ref_end - ps.ref_start + 1);
     const bool plus1 = dir == 0;
@@ -2605,7 +2606,7 @@ CM_HD uint32_t cm_count_best_draft(const CmDev &d, uint32_t r, int strand, int w
 // (orientation pe.f_dir, draft indices pe.f_i1 / pe.f_i2) (mapping_generator.h:487-653,
 // mapping_generator.cc:169-210 with the default identity rid ranks, chromap.cc:867-877).
 // Record layout = cmgpu_pairs_record (24 bytes).
-CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
+CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe, uint32_t nth = 0) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   const int o = (int)pe.f_dir, s1 = cm_split_s1(o), s2 = cm_split_s2(o);
   const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
@@ -2635,7 +2636,8 @@ CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
     t = pos1; pos1 = pos2; pos2 = t;
     const uint8_t u = st1; st1 = st2; st2 = u;
   }
-  uint8_t *o8 = d.rec + (uint64_t)pair * 24;
+  const uint64_t slot = (uint64_t)pair * (uint32_t)d.p.max_best + nth;
+  uint8_t *o8 = d.rec + slot * 24;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
   o32[0] = d.first_read_id + pair;
   o32[1] = (uint32_t)rid1;
@@ -2643,7 +2645,7 @@ CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe) {
   o32[3] = (uint32_t)pos1;
   o32[4] = (uint32_t)pos2;
   o8[20] = st1; o8[21] = st2; o8[22] = mapq; o8[23] = is_unique;
-  d.rec_ok[pair] = 1;
+  d.rec_ok[slot] = 1;
 }
 
 // split-mode pairing (mapping_generator.h:389-415): every (best of read1, best of read2)
@@ -2681,8 +2683,9 @@ CM_HD void cm_split_pairing(const CmDev &d, uint32_t pair, int64_t want, CmPe &p
 // max_num_error_difference = error_threshold, EmplaceBackSingleEndMappingRecord
 // <MappingWithoutBarcode> (mapping_generator.cc:7-16)
 template <bool SAM>
-CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice) {
+CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice, uint32_t nth = 0) {
   const uint32_t r = 2 * pair;
+  const uint64_t slot = (uint64_t)pair * (uint32_t)d.p.max_best + nth;
   const int me = d.min_err[r];
   uint32_t idx = 0;
   for (int strand = 0; strand < 2; ++strand) {
@@ -2699,7 +2702,7 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
         else sp = cm_ref_start_end(d, dp[mi], de[mi], strand, cm_read_ptr(d, r), (int)L);
         const uint16_t al = (uint16_t)(sp.ref_end - sp.ref_start + 1);
         const uint8_t mapq = cm_mapq_single(d, de[mi], al, (int)L, d.p.e, d.second_err[r], d.n_best[r], d.n_second[r], d.rep_len[r]);
-        uint8_t *o = d.rec + (uint64_t)pair * 24;
+        uint8_t *o = d.rec + slot * 24;
         uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
         uint16_t *o16 = reinterpret_cast<uint16_t *>(o);
         o32[0] = d.first_read_id + pair;
@@ -2711,7 +2714,7 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
         o[16] = d.n_best[r] == 1 ? 1 : 0;
         o[17] = 1;
         o16[9] = 0; o16[10] = 0; o16[11] = 0;
-        d.rec_ok[pair] = 1;
+        d.rec_ok[slot] = 1;
         if constexpr (SAM)  // EmplaceBackSingleEndMappingRecord<SAMMapping> (mapping_generator.cc:43-57), flag mapping_generator.h:321-326
           cm_put_sam_record(d, pair, d.first_read_id + pair, sp, 0, -1, 0, strand == 0 ? 0u : 16u, mapq, strand == 0 ? 1 : 0,
                             d.n_best[r] == 1 ? 1 : 0, sa, L);
@@ -2730,9 +2733,8 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice)
 template <bool SAM = false>
 CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
-  d.rec_ok[pair] = 0;
+  for (uint32_t t = 0; t < (uint32_t)d.p.max_best; ++t) d.rec_ok[(uint64_t)pair * (uint32_t)d.p.max_best + t] = 0;
   d.pe_nbest[pair] = 0;
-  d.pe_choice[pair] = 0;
   if (!d.alive[pair]) return;
   const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
   if (d.p.single) {  // GenerateBestMappingsForSingleEndRead (mapping_generator.h:115-157)
@@ -2777,7 +2779,7 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
 //   (chromap.h:863,892): every task starts from std::mt19937(11) and walks its own pairs
 //   in order; libgomp gives T = n/grain tasks (1 if T <= 1) of n/T iterations, the first
 //   n%T tasks one more.  Draws follow libstdc++'s uniform_int_distribution<int>(0,i)
-//   (Lemire's method on 32-bit output).  max_num_best_mappings == 1.
+//   (Lemire's method on 32-bit output).
 // ---------------------------------------------------------------------------------------
 struct CmMt { uint32_t mt[624]; int idx; };
 CM_HD void cm_mt_seed(CmMt &g, uint32_t s) {
@@ -2840,6 +2842,25 @@ CM_HD void cm_chunk_range(uint32_t n, uint32_t ref_batch, uint32_t grain, uint32
   *lo = *hi = n;
 }
 
+// reservoir sampling of K = max_num_best_mappings of nb best mappings (mapping_generator.h:121-139,
+// 199-214): slots start as 0..K-1, draws only when nb > K, the chosen indices sorted increasing
+CM_HD void cm_reservoir(const CmDev &d, uint32_t pair, int nb, CmMt &g) {
+  const int K = d.p.max_best;
+  uint32_t *ch = d.pe_choice + (uint64_t)pair * (uint32_t)K;
+  for (int i = 0; i < K; ++i) ch[i] = (uint32_t)i;
+  if (nb <= K) return;
+  for (int i = K; i < nb; ++i) {
+    const int j = cm_mt_uniform(g, i);
+    if (j < K) ch[j] = (uint32_t)i;
+  }
+  for (int a = 1; a < K; ++a) {
+    const uint32_t v = ch[a];
+    int b = a - 1;
+    while (b >= 0 && ch[b] > v) { ch[b + 1] = ch[b]; --b; }
+    ch[b + 1] = v;
+  }
+}
+
 CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
   uint32_t lo, hi;
   cm_chunk_range(d.n_pairs, (uint32_t)d.p.ref_batch, (uint32_t)d.p.grain, chunk, &lo, &hi);
@@ -2849,12 +2870,7 @@ CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
     if (nb <= 1) continue;
     if (nb > d.p.drop_rep) continue;  // mapping_generator.h:193-196: returns before drawing
     if (!seeded || d.p.single) { cm_mt_seed(g, 11); seeded = true; }  // single-end: a fresh generator per read (mapping_generator.h:128)
-    int choice = 0;
-    for (int i = 1; i < nb; ++i) {
-      const int j = cm_mt_uniform(g, i);
-      if (j < 1) choice = i;
-    }
-    d.pe_choice[pair] = (uint32_t)choice;
+    cm_reservoir(d, pair, nb, g);
   }
 }
 
@@ -2869,25 +2885,31 @@ CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
   CmPe pe;
   pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];
   pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
-  const int64_t want = (int64_t)d.pe_choice[pair];
-  if (d.p.single) { cm_emit_single_record<SAM>(d, pair, (uint32_t)want); return; }
-  if (d.p.split) {
-    CmPe sp;
-    cm_split_pairing(d, pair, want, sp);
-    cm_emit_pairs_record(d, pair, sp);
-    return;
+  const uint32_t K = (uint32_t)d.p.max_best;
+  const uint32_t to_report = (uint32_t)nb < K ? (uint32_t)nb : K;
+  for (uint32_t t = 0; t < to_report; ++t) {  // the chosen indices are increasing, so are the records of a pair
+    const int64_t want = (int64_t)d.pe_choice[(uint64_t)pair * K + t];
+    if (d.p.single) { cm_emit_single_record<SAM>(d, pair, (uint32_t)want, t); continue; }
+    if (d.p.split) {
+      CmPe sp;
+      cm_split_pairing(d, pair, want, sp);
+      cm_emit_pairs_record(d, pair, sp, t);
+      continue;
+    }
+    if (want > 0) {
+      int64_t seen = 0;
+      const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+      bool found = cm_pair_dir(d, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1),
+                               d.ndn[r2], len1, len2, pe, want, pe.min_sum, &seen);
+      if (!found)
+        found = cm_pair_dir(d, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0),
+                            d.ndp[r2], len1, len2, pe, want, pe.min_sum, &seen);
+      if (!found) { d.stats[CM_ST_ERR] = 2; return; }
+    } else {
+      pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
+    }
+    cm_emit_record<SAM>(d, pair, pe, t);
   }
-  if (want > 0) {
-    int64_t seen = 0;
-    const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
-    bool found = cm_pair_dir(d, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1),
-                             d.ndn[r2], len1, len2, pe, want, pe.min_sum, &seen);
-    if (!found)
-      found = cm_pair_dir(d, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0),
-                          d.ndp[r2], len1, len2, pe, want, pe.min_sum, &seen);
-    if (!found) { d.stats[CM_ST_ERR] = 2; return; }
-  }
-  cm_emit_record<SAM>(d, pair, pe);
 }
 
 #endif  // CM_STAGES_H_

@@ -24,6 +24,7 @@
 #define CM_PR_SINGLE 1
 #define CM_PR_MULTI 2
 #define CM_V_INVALID 0x7fff
+#define CM_MAX_BEST 64          // upper bound on max_num_best_mappings (-n)
 #define CM_SORT_SERIAL_MAX 24   // cm_sort_cand / cm_sort_draft: insertion sort up to here, heap sort beyond
 #define CM_SORT_WAVE_MAX 1024   // longest list a wave sorts in LDS (k_sort_lists)
 
@@ -36,7 +37,7 @@ struct CmParams {
   int32_t f0, f1;        // max_seed_frequencies
   int32_t max_insert;    // max_insert_size
   int32_t min_read_len;  // min_read_length
-  int32_t max_best;      // max_num_best_mappings (1)
+  int32_t max_best;      // max_num_best_mappings: record slots (and reservoir entries) per pair, 1..CM_MAX_BEST
   int32_t drop_rep;      // drop_repetitive_reads
   int32_t trim;          // trim_adapters
   int32_t split;         // split_alignment (--preset hic)
@@ -146,10 +147,10 @@ struct CmDev {
   int32_t *pe_min, *pe_second, *pe_nbest, *pe_nsecond; // [n]
   uint32_t *pe_first;   // [n] packed first best: dir<<31 | ... see cm_stages
   uint32_t *pe_i1, *pe_i2; // [n]
-  uint32_t *pe_choice;  // [n] chosen best index (0 unless multi-mapper)
+  uint32_t *pe_choice;  // [n * max_best] chosen best indices of a multi-mapper, increasing
   // ---- output
   uint8_t *rec;         // n records of 24 bytes (cmgpu_record layout)
-  uint8_t *rec_ok;      // [n]
+  uint8_t *rec_ok;      // [n * max_best]
   // ---- --chr-order: rank of every index rid, or nullptr.  When set, ref_off / ref_len above are the arrays
   //      REORDERED by rank: every stage from verification on works in rank space (cm_s4c_reduce re-ranks).
   const uint32_t *rid_rank;

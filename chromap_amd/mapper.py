@@ -195,12 +195,17 @@ class ChromapGPU:
         return Batch(len(k[1]) - 1, first_read_id, k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data,
                      k[3].ctypes.data)
 
+    def _slots(self, n):
+        """record capacity of a batch of n pairs / reads: max_num_best_mappings records each (-n)"""
+        return max(1, n * max(1, int(self.p.max_num_best_mappings)))
+
     def map_pairs(self, b1, o1, b2, o2, first_read_id=0):
         """returns a ctypes array of Record (length = number of mapped pairs)"""
         bt = self._batch(b1, o1, b2, o2, first_read_id)
-        rec = (Record * max(1, bt.n_pairs))()
+        cap = self._slots(bt.n_pairs)
+        rec = (Record * cap)()
         n = C.c_uint64(0)
-        rc = self.L.cmgpu_map_pairs(self.ctx, C.byref(bt), C.cast(rec, C.c_void_p), bt.n_pairs, C.byref(n),
+        rc = self.L.cmgpu_map_pairs(self.ctx, C.byref(bt), C.cast(rec, C.c_void_p), cap, C.byref(n),
                                     C.byref(self.stats))
         self._check(rc, self.ctx)
         return rec, int(n.value)
@@ -212,8 +217,8 @@ class ChromapGPU:
         self._check(self.L.cmgpu_map_pairs_async(self.ctx, C.byref(self._abatch), C.byref(self.stats)), self.ctx)
 
     def wait(self):
-        n = self._abatch.n_pairs
-        rec = (Record * max(1, n))()
+        n = self._slots(self._abatch.n_pairs)
+        rec = (Record * n)()
         k = C.c_uint64(0)
         self._check(self.L.cmgpu_wait(self.ctx, C.cast(rec, C.c_void_p), n, C.byref(k)), self.ctx)
         return rec, int(k.value)
@@ -279,9 +284,9 @@ class ChromapGPU:
         self._keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
         n = len(self._keep[1]) - 1
         bt = SingleBatch(n, first_read_id, self._keep[0].ctypes.data, self._keep[1].ctypes.data)
-        rec = (Record * max(1, n))()
+        rec = (Record * self._slots(n))()
         k = C.c_uint64(0)
-        self._check(self.L.cmgpu_map_single(self.ctx, C.byref(bt), C.cast(rec, C.c_void_p), n, C.byref(k), C.byref(self.stats)),
+        self._check(self.L.cmgpu_map_single(self.ctx, C.byref(bt), C.cast(rec, C.c_void_p), self._slots(n), C.byref(k), C.byref(self.stats)),
                     self.ctx)
         return rec, int(k.value)
 
@@ -293,9 +298,9 @@ class ChromapGPU:
         kb = [np.ascontiguousarray(bc, dtype=np.uint8), np.ascontiguousarray(bcq, dtype=np.uint8),
               np.ascontiguousarray(bco, dtype=np.uint32)]
         bb = BarcodeBatch(kb[0].ctypes.data, kb[1].ctypes.data, kb[2].ctypes.data)
-        rec = (RecordBc * max(1, n))()
+        rec = (RecordBc * self._slots(n))()
         k = C.c_uint64(0)
-        rc = self.L.cmgpu_map_single_barcoded(self.ctx, C.byref(bt), C.byref(bb), C.cast(rec, C.c_void_p), n, C.byref(k),
+        rc = self.L.cmgpu_map_single_barcoded(self.ctx, C.byref(bt), C.byref(bb), C.cast(rec, C.c_void_p), self._slots(n), C.byref(k),
                                               C.byref(self.stats))
         self._check(rc, self.ctx)
         return rec, int(k.value)
@@ -331,9 +336,9 @@ class ChromapGPU:
         kb = [np.ascontiguousarray(bc, dtype=np.uint8), np.ascontiguousarray(bcq, dtype=np.uint8),
               np.ascontiguousarray(bco, dtype=np.uint32)]
         bb = BarcodeBatch(kb[0].ctypes.data, kb[1].ctypes.data, kb[2].ctypes.data)
-        rec = (RecordBc * max(1, bt.n_pairs))()
+        rec = (RecordBc * self._slots(bt.n_pairs))()
         n = C.c_uint64(0)
-        rc = self.L.cmgpu_map_pairs_barcoded(self.ctx, C.byref(bt), C.byref(bb), C.cast(rec, C.c_void_p), bt.n_pairs,
+        rc = self.L.cmgpu_map_pairs_barcoded(self.ctx, C.byref(bt), C.byref(bb), C.cast(rec, C.c_void_p), self._slots(bt.n_pairs),
                                              C.byref(n), C.byref(self.stats))
         self._check(rc, self.ctx)
         return rec, int(n.value)

@@ -67,7 +67,8 @@ typedef struct cmgpu_params {
   int32_t max_seed_frequency1;    /* -f second value */
   int32_t max_insert_size;        /* -l */
   int32_t min_read_length;        /* --min-read-length */
-  int32_t max_num_best_mappings;  /* must be 1 (the CLI never sets anything else) */
+  int32_t max_num_best_mappings;  /* -n: up to this many records per read / pair (1..64), reservoir-sampled when there are more
+                                   * best mappings (mapping_generator.h:121-139,199-214); not with CMGPU_FORMAT_SAM */
   int32_t drop_repetitive_reads;  /* --drop-repetitive-reads */
   int32_t trim_adapters;          /* --trim-adapters */
   int32_t split_alignment;        /* --split-alignment (records are then cmgpu_pairs_record) */
@@ -213,8 +214,8 @@ const char *cmgpu_last_error(const cmgpu_ctx *ctx);
 /* Replaces the taskloop body src/chromap.h:892-1143 for one batch: adapter trimming,
  * minimizers, index probe, candidate generation, mate rescue, pair filter, verification,
  * best-pair selection, coordinates and MAPQ.  `in` holds HOST pointers; records are
- * written to the caller's host buffer `out` (capacity in records; n_pairs always
- * suffices).  Record order is unspecified (a total-order sort follows in the reference:
+ * written to the caller's host buffer `out` (capacity in records; n_pairs *
+ * max_num_best_mappings always suffices; a pair's records are adjacent, best-mapping index increasing).  Record order is unspecified (a total-order sort follows in the reference:
  * src/mapping_processor.h:117-159).  stats may be NULL; counters are ACCUMULATED.
  * A batch must start on a read_batch_size boundary of the input file for the reservoir
  * sampling of multi-mappers to reproduce the reference. */

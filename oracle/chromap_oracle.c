@@ -2076,17 +2076,21 @@ static long finish_pair_split(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint
   if (tr) { tr->min_sum = pe->min_sum; tr->nbest = pe->n_best; tr->second_sum = pe->second_sum; tr->nsecond = pe->n_second; tr->force_mapq = -1; }
   long nout = 0;
   if (pe->n_best > p->drop_repetitive_reads) return 0;
-  int choice = 0;
-  if (pe->n_best > 1) {
-    for (int i = 1; i < pe->n_best; ++i) {
+  /* reservoir sampling over the best pairings (mapping_generator.h:199-214) */
+  const int K = p->max_num_best_mappings > 0 ? p->max_num_best_mappings : 1;
+  for (int i = 0; i < K; ++i) wk->best_idx[i] = i;
+  if (pe->n_best > K) {
+    for (int i = K; i < pe->n_best; ++i) {
       int j = mt_uniform(rng, i);
-      if (j < 1) choice = i;
+      if (j < K) wk->best_idx[j] = i;
     }
+    for (int i = 1; i < K; ++i) { int x = wk->best_idx[i], j = i; while (j > 0 && wk->best_idx[j - 1] > x) { wk->best_idx[j] = wk->best_idx[j - 1]; --j; } wk->best_idx[j] = x; }
   }
+  const int to_report = K < pe->n_best ? K : pe->n_best;
   if (pe->n_best < 1) return 0;
   const uint8_t is_unique = (pe->n_best == 1 || m1->n_best == 1 || m2->n_best == 1) ? 1 : 0;
   int idx = 0;
-  for (int o = 0; o < 4 && nout == 0; ++o) {
+  for (int o = 0; o < 4 && nout < to_report; ++o) { /* mapping_generator.h:222-253 */
     const vdraft *a = S1[o] == 0 ? &m1->pos_map : &m1->neg_map;
     const vdraft *b = S2[o] == 0 ? &m2->pos_map : &m2->neg_map;
     const vec64 *sa = S1[o] == 0 ? &m1->pos_split : &m1->neg_split;
@@ -2094,7 +2098,7 @@ static long finish_pair_split(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint
     for (size_t mi = 0; mi < pe->best[o].n; ++mi) {
       const uint32_t i1 = pe->best[o].a[mi].a, i2 = pe->best[o].a[mi].b;
       if (a->a[i1].num_errors + b->a[i2].num_errors > pe->min_sum) continue;
-      if (idx == choice) {
+      if (idx == wk->best_idx[nout]) {
         const span_t x = ref_start_end_split(c, &a->a[i1], (int)sa->a[i1], S1[o], S1[o] == 0 ? r1 : neg1, (int)len1);
         const span_t y = ref_start_end_split(c, &b->a[i2], (int)sb->a[i2], S2[o], S2[o] == 0 ? r2 : neg2, (int)len2);
         const uint16_t al1 = (uint16_t)(x.ref_end - x.ref_start + 1), al2 = (uint16_t)(y.ref_end - y.ref_start + 1);
@@ -2116,7 +2120,7 @@ static long finish_pair_split(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint
         r->read_id = read_id; r->rid1 = (uint32_t)rid1; r->rid2 = (uint32_t)rid2;
         r->pos1 = (uint32_t)pos1; r->pos2 = (uint32_t)pos2;
         r->strand1 = st1; r->strand2 = st2; r->mapq = mapq; r->is_unique = is_unique;
-        break;
+        if (nout == to_report) break;
       }
       ++idx;
     }
@@ -2529,7 +2533,7 @@ long ora_map_pairs_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_i
                       const uint32_t *r1_off, const char *r2, const uint32_t *r2_off, char *bc,
                       const char *bc_qual, const uint32_t *bc_off, const ora_whitelist *w,
                       ora_record_bc *out, ora_stats *stats, uint64_t *num_in_whitelist, uint64_t *num_corrected) {
-  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  ora_record *tmp = (ora_record *)malloc(((size_t)n * (size_t)(c->p.max_num_best_mappings > 0 ? c->p.max_num_best_mappings : 1) + 1) * sizeof(ora_record));
   c->wl = w; c->bc = bc; c->bcq = bc_qual; c->bco = bc_off;
   c->bc_key = (uint64_t *)calloc((size_t)n + 1, 8);
   c->n_in_wl = c->n_corr = 0;
@@ -2719,20 +2723,30 @@ static long map_one_read(const ora_ctx *c, work_t *wk, uint32_t read_index, uint
   rerank_candidates(c, &m->pos_cand); rerank_candidates(c, &m->neg_cand); /* chromap.h:416-420 */
   gen_draft_mappings(c, m, wk->fw1, wk->neg1, len1, st);
   if (m->pos_map.n + m->neg_map.n == 0) return 0;
-  /* a fresh std::mt19937(11) per read (mapping_generator.h:128-139) */
-  int choice = 0;
-  if (m->n_best > 1) {
+  /* a fresh std::mt19937(11) per read, reservoir sampling when there are more best mappings than
+   * max_num_best_mappings (mapping_generator.h:121-139); the chosen indices are reported in increasing order */
+  const int K = p->max_num_best_mappings > 0 ? p->max_num_best_mappings : 1;
+  int *choices = wk->best_idx;
+  for (int i = 0; i < K; ++i) choices[i] = i;
+  if (m->n_best > K) {
     mt19937_t g;
     mt_seed(&g, 11);
-    for (int i = 1; i < m->n_best; ++i) { int j = mt_uniform(&g, i); if (j < 1) choice = i; }
+    for (int i = K; i < m->n_best; ++i) { int j = mt_uniform(&g, i); if (j < K) choices[j] = i; }
+    for (int a = 1; a < K; ++a) { /* std::sort */
+      const int v = choices[a];
+      int b = a - 1;
+      while (b >= 0 && choices[b] > v) { choices[b + 1] = choices[b]; --b; }
+      choices[b + 1] = v;
+    }
   }
+  const int to_report = m->n_best < K ? m->n_best : K;
   long nout = 0;
   int idx = 0;
-  for (int strand = 0; strand < 2 && nout == 0; ++strand) {
+  for (int strand = 0; strand < 2 && nout < to_report; ++strand) {
     const vdraft *v = strand == 0 ? &m->pos_map : &m->neg_map;
-    for (size_t mi = 0; mi < v->n; ++mi) {
+    for (size_t mi = 0; mi < v->n && nout < to_report; ++mi) {
       if (v->a[mi].num_errors > m->min_err) continue;
-      if (idx == choice) {
+      if (idx == choices[nout]) {
         const int sam = p->output_format == 1 && c->sam_rec != NULL;
         const size_t slot = (size_t)(read_id - c->sam_first_read_id);
         int ncig = 0, mdl = 0, nm = 0;
@@ -2754,7 +2768,6 @@ static long map_one_read(const ora_ctx *c, work_t *wk, uint32_t read_index, uint
           q->n_cigar = (uint16_t)ncig; q->md_len = (uint16_t)mdl; q->nm = (uint32_t)nm;
           c->sam_len[slot] = len1;
         }
-        break;
       }
       ++idx;
     }
@@ -2771,7 +2784,8 @@ long ora_map_single(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id,
                     ora_record *out, ora_stats *stats) {
   if (threads < 1) threads = 1;
   uint8_t *has = (uint8_t *)calloc((size_t)n + 1, 1);
-  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  const size_t K = c->p.max_num_best_mappings > 0 ? (size_t)c->p.max_num_best_mappings : 1; /* up to K records per read; K < 256 */
+  ora_record *tmp = (ora_record *)malloc(((size_t)n * K + 1) * sizeof(ora_record));
   ora_stats *sts = (ora_stats *)calloc((size_t)threads, sizeof(ora_stats));
 #pragma omp parallel num_threads(threads)
   {
@@ -2784,11 +2798,12 @@ long ora_map_single(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id,
     work_init(&wk, &c->p);
 #pragma omp for schedule(dynamic, 1024)
     for (long i = 0; i < (long)n; ++i)
-      has[i] = (uint8_t)map_one_read(c, &wk, (uint32_t)i, first_read_id + (uint32_t)i, r + r_off[i], r_off[i + 1] - r_off[i], &tmp[i], &sts[t]);
+      has[i] = (uint8_t)map_one_read(c, &wk, (uint32_t)i, first_read_id + (uint32_t)i, r + r_off[i], r_off[i + 1] - r_off[i], &tmp[(size_t)i * K], &sts[t]);
     work_free(&wk);
   }
   long k = 0;
-  for (uint32_t i = 0; i < n; ++i) if (has[i]) out[k++] = tmp[i];
+  for (uint32_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < has[i]; ++j) out[k++] = tmp[(size_t)i * K + j];
   for (int t = 0; t < threads && stats; ++t) {
     uint64_t *d = (uint64_t *)stats, *s2 = (uint64_t *)&sts[t];
     for (size_t i = 0; i < sizeof(ora_stats) / 8; ++i) d[i] += s2[i];
@@ -2993,7 +3008,7 @@ long ora_map_pairs_bc_sam(ora_ctx *c, int threads, uint32_t n, uint32_t first_re
 long ora_map_single_bc(ora_ctx *c, int threads, uint32_t n, uint32_t first_read_id, const char *r, const uint32_t *r_off,
                        char *bc, const char *bc_qual, const uint32_t *bc_off, const ora_whitelist *w, ora_record_bc *out,
                        ora_stats *stats, uint64_t *num_in_whitelist, uint64_t *num_corrected) {
-  ora_record *tmp = (ora_record *)malloc(((size_t)n + 1) * sizeof(ora_record));
+  ora_record *tmp = (ora_record *)malloc(((size_t)n * (size_t)(c->p.max_num_best_mappings > 0 ? c->p.max_num_best_mappings : 1) + 1) * sizeof(ora_record));
   c->wl = w; c->bc = bc; c->bcq = bc_qual; c->bco = bc_off;
   c->bc_key = (uint64_t *)calloc((size_t)n + 1, 8);
   c->n_in_wl = c->n_corr = 0;

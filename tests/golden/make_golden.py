@@ -26,7 +26,7 @@ GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 # single-end cases: which mate file is mapped alone
 SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1,
               "b1_se_bc": 1, "b3_se_bc_bulk_q0": 1, "b3_se_bc_inmem_q0": 2, "b1_se_bc_tagalign_q0": 1,
-              "s4_se_tagalign_q0": 2}
+              "s4_se_tagalign_q0": 2, "s4_se_n2_q0": 2}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -109,6 +109,14 @@ CASES = {
                           ["--preset", "hic", "-q", "0", "--pairs-natural-chr-order", "chr3,chr1,chr2"]),
     "s4_atac_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                     "--seed", "5"], ["--preset", "atac", "-q", "0"]),
+    # -n > 1: up to n best mappings per read (pair), reservoir sampling when there are more (mapping_generator.h:121-139,199-214)
+    "s4_atac_n3_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                       "--seed", "5"], ["--preset", "atac", "-q", "0", "-n", "3"]),
+    "s4_se_n2_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                     "--seed", "5"], ["--preset", "chip", "-q", "0", "-n", "2"]),
+    "h2_hic_n2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
+                      "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
+                     ["--preset", "hic", "-q", "0", "-n", "2"]),
 }
 
 

@@ -103,8 +103,8 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   VEC(fcp, uint32_t, n2) VEC(fcn, uint32_t, n2) VEC(alive, uint8_t, n) VEC(ndp, uint32_t, n2) VEC(ndn, uint32_t, n2)
   VEC(min_err, int32_t, n2) VEC(second_err, int32_t, n2) VEC(n_best, int32_t, n2) VEC(n_second, int32_t, n2)
   VEC(pe_min, int32_t, n) VEC(pe_second, int32_t, n) VEC(pe_nbest, int32_t, n) VEC(pe_nsecond, int32_t, n)
-  VEC(pe_first, uint32_t, n) VEC(pe_i1, uint32_t, n) VEC(pe_i2, uint32_t, n) VEC(pe_choice, uint32_t, n)
-  VEC(rec, uint8_t, (size_t)n * 24) VEC(rec_ok, uint8_t, n)
+  VEC(pe_first, uint32_t, n) VEC(pe_i1, uint32_t, n) VEC(pe_i2, uint32_t, n) VEC(pe_choice, uint32_t, (size_t)n * (size_t)(p.max_best > 0 ? p.max_best : 1))
+  VEC(rec, uint8_t, (size_t)n * 24 * (size_t)(p.max_best > 0 ? p.max_best : 1)) VEC(rec_ok, uint8_t, (size_t)n * (size_t)(p.max_best > 0 ? p.max_best : 1))
   // ---- K6 (cmgpu_set_whitelist + cmgpu_compute_barcode_abundance + k_s0b_barcode)
   std::vector<uint64_t> wl_tab;
   std::vector<double> pw(81);
@@ -215,7 +215,8 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     }
     st[CM_ST_RESCUED] += d.aug[r1] + d.aug[r2];
     st[CM_ST_OCC] += d.hit_tot[r1] + d.hit_tot[r2];
-    if (d.rec_ok[i]) { if (eb) eb->bc_key_out[k] = d.bc_key[i]; memcpy(&out[k++], d.rec + (size_t)i * 24, 24); }
+    for (size_t sl = (size_t)i * (size_t)p.max_best; sl < ((size_t)i + 1) * (size_t)p.max_best; ++sl)  // max_best record slots per pair
+      if (d.rec_ok[sl]) { if (eb) eb->bc_key_out[k] = d.bc_key[i]; memcpy(&out[k++], d.rec + sl * 24, 24); }
     if (dbg_nbest) dbg_nbest[i] = d.pe_nbest[i];
   }
   if (eb && eb->bc_key_all) for (uint32_t i = 0; i < n; ++i) eb->bc_key_all[i] = d.bc_key[i];

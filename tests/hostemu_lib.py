@@ -86,7 +86,7 @@ class HostEmu:
                 np.ascontiguousarray(b2, dtype=np.uint8), np.ascontiguousarray(o2, dtype=np.uint32)]
         bt = _capi.Batch(n, first_read_id, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data,
                          keep[3].ctypes.data)
-        rec = (_capi.Record * max(1, n))()
+        rec = (_capi.Record * max(1, n * max(1, self.p.max_num_best_mappings)))()
         k = C.c_uint64(0)
         st = _capi.Stats()
         dbg = {"mm_cnt": np.zeros(2 * n, np.uint32), "ncand": np.zeros(2 * n, np.uint32),
@@ -101,7 +101,7 @@ class HostEmu:
         n = len(off) - 1
         keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]
         bt = _capi.SingleBatch(n, 0, keep[0].ctypes.data, keep[1].ctypes.data)
-        rec = (_capi.Record * max(1, n))()
+        rec = (_capi.Record * max(1, n * max(1, self.p.max_num_best_mappings)))()
         k = C.c_uint64(0)
         st = _capi.Stats()
         f = self.L.hostemu_map_single

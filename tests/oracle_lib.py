@@ -355,7 +355,7 @@ def map_single(oracle, b, off, threads=1):
     L.ora_map_single.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(OraStats)]
     n = len(off) - 1
-    rec = (OraRecord * max(1, n))()
+    rec = (OraRecord * max(1, n * max(1, oracle.p.max_num_best_mappings)))()
     st = OraStats()
     b = np.ascontiguousarray(b)
     off = np.ascontiguousarray(off, dtype=np.uint32)

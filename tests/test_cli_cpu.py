@@ -57,6 +57,13 @@ def test_flag_combinations_without_a_record_type_are_refused():
     assert r.returncode != 0 and b"cell barcodes" in r.stderr
     r = _run("--gpus", "0", "-x", "x", "-r", "y", "-1", "a", "-o", "o")
     assert r.returncode != 0 and b"--gpus" in r.stderr
+    # -n: BED / TagAlign / pairs carry up to n records per read; one SAM slot per read on the device
+    r = _run("--SAM", "-n", "2", "-x", "x", "-r", "y", "-1", "a", "-o", "o")
+    assert r.returncode != 0 and b"--SAM with -n > 1" in r.stderr
+    r = _run("-n", "65", "-x", "x", "-r", "y", "-1", "a", "-o", "o")
+    assert r.returncode != 0 and b"-n above 64" in r.stderr
+    r = _run("-n", "0", "-x", "x", "-r", "y", "-1", "a", "-o", "o")
+    assert r.returncode != 0 and b"at least 1" in r.stderr
 
 
 def test_ingest_reader_inflates_bgzf_gzip_and_plain_text(tmp_path):
