@@ -552,26 +552,33 @@ CM_HD void cm_s0_prep(const CmDev &d, uint32_t pair) {
 //     consumer on the mapping path looks at it (index.cc:491-505 uses position+strand).
 // ---------------------------------------------------------------------------------------
 #define CM_MAX_W 32
-// Window of the last W (hash, pos) entries kept in registers in chronological order
-// (index 0 = oldest).  Equivalent to the reference's ring buffer: its scans
-// `j = pib+1..w-1, then 0..pib` walk the ring oldest -> newest, "position_in_buffer ==
-// min_position" means the running minimum is the entry being evicted (mi < 0 after the
-// shift), and a palindromic k-mer neither writes nor advances (:42-45).
-template <int W, class Emit>
-CM_HD uint32_t cm_minimizers_window_e(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+// THE minimizer state machine -- every caller that does not use the w = 7 closed form below runs this one
+// (reads with a generic window, even k, and the reference chunks of index construction).
+// The last w (hash, pos) entries are kept in chronological order (index 0 = oldest).  Equivalent to the
+// reference's ring buffer: its scans `j = pib+1..w-1, then 0..pib` walk the ring oldest -> newest,
+// "position_in_buffer == min_position" means the running minimum is the entry being evicted (mi < 0 after
+// the shift), and a palindromic k-mer neither writes nor advances (:42-45).
+//   WT > 0: the window size is a compile-time constant and the window lives in registers;
+//   WT == 0: runtime w <= CM_MAX_W (private memory; the rare non-default index).
+// Positions [begin, end) of seq are run; `flush` performs the final emission (:136-138).
+// emit(n, hash, pos_strand) -> bool: n = emissions counted so far, return value = whether this one counts.
+template <int WT, class Emit>
+CM_HD uint32_t cm_minimizers_core(const uint8_t *seq, uint32_t begin, uint32_t end, bool flush, int k, int w, Emit &&emit) {
+  constexpr int CAP = WT ? WT : CM_MAX_W;
+  const int W = WT ? WT : w;
   uint32_t n = 0;
   const uint64_t shift = 2 * (uint64_t)(k - 1);
   const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
   uint64_t fw = 0, rv = 0;
-  uint64_t wh[W];
-  uint32_t wp[W];
+  uint64_t wh[CAP];
+  uint32_t wp[CAP];
   uint64_t min_h = ~0ull;
   uint32_t min_p = ~0u;
 #pragma unroll
-  for (int i = 0; i < W; ++i) { wh[i] = ~0ull; wp[i] = ~0u; }
+  for (int i = 0; i < CAP; ++i) { wh[i] = ~0ull; wp[i] = ~0u; }
   int unamb = 0, mi = 0;
-#define CM_EMIT(h, p) do { emit(n, (h), (p)); ++n; } while (0)
-  for (uint32_t pos = 0; pos < len; ++pos) {
+#define CM_EMIT(h, p) do { if (emit(n, (h), (p))) ++n; } while (0)
+  for (uint32_t pos = begin; pos < end; ++pos) {
     const uint32_t c = cm_c2u(seq[pos]);
     uint64_t cur_h = ~0ull;
     uint32_t cur_p = ~0u;
@@ -617,9 +624,15 @@ CM_HD uint32_t cm_minimizers_window_e(const uint8_t *seq, uint32_t len, int k, E
       }
     }
   }
-  if (min_h != ~0ull) CM_EMIT(min_h, min_p);
+  if (flush && min_h != ~0ull) CM_EMIT(min_h, min_p);
 #undef CM_EMIT
   return n;
+}
+
+// a whole read, window size W in registers; emit(n, hash, pos_strand)
+template <int W, class Emit>
+CM_HD uint32_t cm_minimizers_window_e(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+  return cm_minimizers_core<W>(seq, 0, len, true, k, W, [&](uint32_t n, uint64_t h, uint32_t p) { emit(n, h, p); return true; });
 }
 
 // w = 7, odd k (every preset; an odd-length k-mer cannot be its own reverse complement, so the palindrome
@@ -792,69 +805,12 @@ CM_HD uint32_t cm_minimizers_window(const uint8_t *seq, uint32_t len, int k, uin
   return cm_minimizers_window_e<W>(seq, len, k, put);
 }
 
-// generic window size: ring buffer in private memory, literal transcription
+// generic window size (runtime w): the same state machine with its window in private memory
 CM_HD uint32_t cm_minimizers_ring(const uint8_t *seq, uint32_t len, int k, int w, uint64_t *oh, uint32_t *op, uint32_t cap) {
-  uint32_t n = 0;
-  const uint64_t shift = 2 * (uint64_t)(k - 1);
-  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
-  uint64_t fw = 0, rv = 0;
-  uint64_t bh[CM_MAX_W];
-  uint32_t bp[CM_MAX_W];
-  uint64_t min_h = ~0ull;
-  uint32_t min_p = ~0u;
-  for (int i = 0; i < w; ++i) { bh[i] = ~0ull; bp[i] = ~0u; }
-  int unamb = 0, pib = 0, min_pos = 0;
-#define CM_EMIT(h, p) do { if (oh && n < cap) { oh[n] = (h); op[n] = (p); } ++n; } while (0)
-  for (uint32_t pos = 0; pos < len; ++pos) {
-    const uint32_t c = cm_c2u(seq[pos]);
-    uint64_t cur_h = ~0ull;
-    uint32_t cur_p = ~0u;
-    if (c < 4) {
-      fw = ((fw << 2) | c) & mask;
-      rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
-      if (fw == rv) continue;  // palindromic k-mer: ring index does not advance (:42-45)
-      const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
-      const uint32_t strand = h0 < h1 ? 0u : 1u;
-      ++unamb;
-      if (unamb >= k) {
-        cur_h = cm_hash64(strand ? h1 : h0, mask);
-        cur_p = (pos << 1) | strand;
-      }
-    } else {
-      unamb = 0;
-    }
-    bh[pib] = cur_h;
-    bp[pib] = cur_p;
-    if (unamb == w + k - 1 && min_h != ~0ull && min_h < cur_h) {
-      for (int j = pib + 1; j < w; ++j)
-        if (min_h == bh[j] && bp[j] != min_p) CM_EMIT(bh[j], bp[j]);
-      for (int j = 0; j < pib; ++j)
-        if (min_h == bh[j] && bp[j] != min_p) CM_EMIT(bh[j], bp[j]);
-    }
-    if (cur_h <= min_h) {
-      if (unamb >= w + k && min_h != ~0ull) CM_EMIT(min_h, min_p);
-      min_h = cur_h;
-      min_p = cur_p;
-      min_pos = pib;
-    } else if (pib == min_pos) {
-      if (unamb >= w + k - 1 && min_h != ~0ull) CM_EMIT(min_h, min_p);
-      min_h = ~0ull;
-      for (int j = pib + 1; j < w; ++j)
-        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
-      for (int j = 0; j <= pib; ++j)
-        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
-      if (unamb >= w + k - 1 && min_h != ~0ull) {
-        for (int j = pib + 1; j < w; ++j)
-          if (min_h == bh[j] && min_p != bp[j]) CM_EMIT(bh[j], bp[j]);
-        for (int j = 0; j <= pib; ++j)
-          if (min_h == bh[j] && min_p != bp[j]) CM_EMIT(bh[j], bp[j]);
-      }
-    }
-    if (++pib == w) pib = 0;
-  }
-  if (min_h != ~0ull) CM_EMIT(min_h, min_p);
-#undef CM_EMIT
-  return n;
+  return cm_minimizers_core<0>(seq, 0, len, true, k, w, [&](uint32_t n, uint64_t h, uint32_t p) {
+    if (oh && n < cap) { oh[n] = h; op[n] = p; }
+    return true;
+  });
 }
 
 // Two-pass form used by the kernels: count (writes mm_cnt[r]) and fill (writes the read's
@@ -876,7 +832,7 @@ CM_HD void cm_s1_fill(const CmDev &d, uint32_t r, const uint8_t *seq) {
 
 // ---------------------------------------------------------------------------------------
 // Reference minimizers for index construction (Index::Construct, index.cc:19-23), one
-// chunk of `chunk` positions per item.  The state machine is the one of cm_minimizers_window;
+// chunk of `chunk` positions per item.  The state machine is cm_minimizers_core;
 // it is started `warm` positions early (>= 2w+k, so ring buffer, running minimum and the
 // unambiguous-length thresholds have converged to the sequential pass's state before the
 // first owned position) and run w+2 positions past the chunk; an emission is kept only
@@ -888,74 +844,15 @@ CM_HD uint32_t cm_ref_chunk_minimizers(const uint8_t *seq, uint32_t len, uint32_
   const uint32_t e = s + chunk < len ? s + chunk : len;  // owned positions [s,e)
   const uint32_t begin = s > warm ? s - warm : 0;
   const uint32_t end = e + 2 * (uint32_t)w + 2 < len ? e + 2 * (uint32_t)w + 2 : len;
-  const uint64_t shift = 2 * (uint64_t)(k - 1);
-  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
-  uint64_t fw = 0, rv = 0;
-  uint64_t bh[CM_MAX_W];
-  uint32_t bp[CM_MAX_W];
-  uint64_t min_h = ~0ull;
-  uint32_t min_p = ~0u;
-  for (int i = 0; i < w; ++i) { bh[i] = ~0ull; bp[i] = ~0u; }
-  int unamb = 0, pib = 0, min_pos = 0;
-  uint32_t n = 0;
-#define CM_REMIT(h, p)                                                                        \
-  do {                                                                                        \
-    const uint32_t pp_ = (p) >> 1;                                                            \
-    if (pp_ >= s && pp_ < e) {                                                                \
-      if (oh) { oh[n] = (h); ot[n] = (((uint64_t)rid << 32 | pp_) << 1) | ((p) & 1u); }       \
-      ++n;                                                                                    \
-    }                                                                                         \
-  } while (0)
-  for (uint32_t pos = begin; pos < end; ++pos) {
-    const uint32_t cb = cm_c2u(seq[pos]);
-    uint64_t cur_h = ~0ull;
-    uint32_t cur_p = ~0u;
-    if (cb < 4) {
-      fw = ((fw << 2) | cb) & mask;
-      rv = (rv >> 2) | (((uint64_t)(3 ^ cb)) << shift);
-      if (fw == rv) continue;
-      const uint64_t h0 = cm_hash64(fw, mask), h1 = cm_hash64(rv, mask);
-      const uint32_t strand = h0 < h1 ? 0u : 1u;
-      ++unamb;
-      if (unamb >= k) {
-        cur_h = cm_hash64(strand ? h1 : h0, mask);
-        cur_p = (pos << 1) | strand;
-      }
-    } else {
-      unamb = 0;
-    }
-    bh[pib] = cur_h;
-    bp[pib] = cur_p;
-    if (unamb == w + k - 1 && min_h != ~0ull && min_h < cur_h) {
-      for (int j = pib + 1; j < w; ++j)
-        if (min_h == bh[j] && bp[j] != min_p) CM_REMIT(bh[j], bp[j]);
-      for (int j = 0; j < pib; ++j)
-        if (min_h == bh[j] && bp[j] != min_p) CM_REMIT(bh[j], bp[j]);
-    }
-    if (cur_h <= min_h) {
-      if (unamb >= w + k && min_h != ~0ull) CM_REMIT(min_h, min_p);
-      min_h = cur_h; min_p = cur_p; min_pos = pib;
-    } else if (pib == min_pos) {
-      if (unamb >= w + k - 1 && min_h != ~0ull) CM_REMIT(min_h, min_p);
-      min_h = ~0ull;
-      for (int j = pib + 1; j < w; ++j)
-        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
-      for (int j = 0; j <= pib; ++j)
-        if (min_h >= bh[j]) { min_h = bh[j]; min_p = bp[j]; min_pos = j; }
-      if (unamb >= w + k - 1 && min_h != ~0ull) {
-        for (int j = pib + 1; j < w; ++j)
-          if (min_h == bh[j] && min_p != bp[j]) CM_REMIT(bh[j], bp[j]);
-        for (int j = 0; j <= pib; ++j)
-          if (min_h == bh[j] && min_p != bp[j]) CM_REMIT(bh[j], bp[j]);
-      }
-    }
-    if (++pib == w) pib = 0;
-  }
+  auto own = [&](uint32_t n, uint64_t h, uint32_t p) {
+    const uint32_t pp = p >> 1;
+    if (pp < s || pp >= e) return false;
+    if (oh) { oh[n] = h; ot[n] = (((uint64_t)rid << 32 | pp) << 1) | (p & 1u); }
+    return true;
+  };
   // final flush (minimizer_generator.cc:136-138): performed by every chunk whose run reaches
   // the end of the sequence; the ownership test keeps exactly one copy
-  if (end == len && min_h != ~0ull) CM_REMIT(min_h, min_p);
-#undef CM_REMIT
-  return n;
+  return w == 7 ? cm_minimizers_core<7>(seq, begin, end, end == len, k, w, own) : cm_minimizers_core<0>(seq, begin, end, end == len, k, w, own);
 }
 
 

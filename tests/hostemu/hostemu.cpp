@@ -304,6 +304,11 @@ extern "C" int hostemu_minimizers_w7(const uint8_t *seq, uint32_t len, int k, in
   return (int)(variant ? cm_minimizers_w7(seq, len, k, put) : cm_minimizers_window_e<7>(seq, len, k, put));
 }
 
+// one read through the runtime-window form (cm_minimizers_core<0>: any w <= CM_MAX_W)
+extern "C" int hostemu_minimizers_ring(const uint8_t *seq, uint32_t len, int k, int w, uint64_t *out_hash, uint32_t *out_ps, uint32_t cap) {
+  return (int)cm_minimizers_ring(seq, len, k, w, out_hash, out_ps, cap);
+}
+
 // S0 alone (length filter + adapter trimming): rlen[2*pair], rlen[2*pair+1] as cm_s0_prep leaves them
 extern "C" int hostemu_trim(const cmgpu_params *params, const cmgpu_batch *in, uint32_t *rlen) {
   CmDev d;

@@ -66,6 +66,28 @@ def test_w7_minimizers_equal_the_reference_state_machine(k):
     assert n_emitted > 50000
 
 
+@pytest.mark.parametrize("k,w", [(17, 5), (21, 11), (15, 3), (16, 10), (27, 7), (19, 1), (23, 32)])
+def test_runtime_window_minimizers_equal_the_reference_state_machine(k, w):
+    """cm_minimizers_core with a runtime window size (indexes built with -w other than 7) against the oracle"""
+    L = he.lib()
+    O = ol.lib()
+    f = L.hostemu_minimizers_ring
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(3000 + 100 * k + w)
+    oh, ot = np.zeros(512, np.uint64), np.zeros(512, np.uint64)
+    gh, gp = np.zeros(512, np.uint64), np.zeros(512, np.uint32)
+    n_emitted = 0
+    for s in _reads(rng, 8000):
+        buf = np.concatenate([s, np.zeros(8, np.uint8)])
+        c = O.ora_minimizers(buf.ctypes.data_as(C.c_char_p), len(s), 0, k, w, oh.ctypes.data, ot.ctypes.data)
+        g = f(buf.ctypes.data, len(s), k, w, gh.ctypes.data, gp.ctypes.data, 512)
+        assert g == c, (bytes(s), g, c)
+        assert [(int(gh[i]), int(gp[i])) for i in range(g)] == [(int(oh[i]), int(ot[i]) & 0x1FFFFFFFF) for i in range(c)], bytes(s)
+        n_emitted += c
+    assert n_emitted > 5000
+
+
 @pytest.mark.parametrize("k", [17, 19, 23, 15, 25])
 def test_position_parallel_minimizers_equal_the_reference_state_machine(k):
     """the per-lane pieces of k_prep_flat (2-bit packing, k-mer extraction, strand / hash, sliding-extrema selection,
