@@ -372,7 +372,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
-  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4)
+  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
 #undef ENS
   return CMGPU_OK;
 }
@@ -557,6 +557,8 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.srt_list = (uint32_t *)c->srt_list.p;
   d.hv_cnt = (uint32_t *)c->hv_cnt.p;
   d.hv_list = (uint32_t *)c->hv_list.p;
+  d.rs_cnt = (uint32_t *)c->rs_cnt.p;
+  d.rs_list = (uint32_t *)c->rs_list.p;
   d.hv_stride = 2 * (hi - lo) + 1;
   d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
@@ -731,7 +733,9 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s3b_candidates");
   // S4: mate rescue, merge, paired-end filter
-  cm_launch_k_s4a_rescue_count(d, n2, s);
+  HIPCHECK(c, hipMemsetAsync(c->rs_cnt.p, 0, CM_RS_SEGS * 64, s));
+  cm_launch_k_s4a_rescue_count(d, n2, s);  // decision per read + the packed list of reads that supplement
+  cm_launch_k_s4a_rescue_list(d, n2, s);   // their searches, one read per lane of full waves
   unsigned long long m_total = 0;
   if ((rc = scan_with_total(c, d.m_tot, d.m_off, n2, &m_total))) return rc;
   if (m_total > limit) return CM_RC_SPLIT;
@@ -745,6 +749,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
   cm_launch_k_s4b_rescue_merge(d, n2, s);
+  cm_launch_k_s4b_rescue_list(d, n2, s);
   mark(c, "s4b_rescue_merge");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s4c_reduce(d, n, s);

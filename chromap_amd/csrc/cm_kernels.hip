@@ -512,35 +512,6 @@ __global__ __launch_bounds__(64) void k_s3b_serial(CmDev d, const uint32_t *__re
   if (i < n_list) cm_s3b_candidates(d, list[i]);
 }
 
-// S4a / S4b: few reads (pairs whose mate has to be rescued, ~7 % here) run the long occurrence-run
-// searches.  Spread over all waves they keep every wave busy for one search's latency; the block
-// therefore packs them: every lane does the cheap part of its own read, the reads with a search
-// are listed in LDS and the first lanes of the block take one each.
-__global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t n) {
-  __shared__ uint32_t list[CM_BLOCK];
-  __shared__ uint32_t cnt;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
-  const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
-  const uint32_t i = i0 < n && d.perm_reads ? d.perm_reads[i0] : i0;
-  if (i0 < n && cm_s4a_decide(d, i)) list[atomicAdd(&cnt, 1u)] = i;
-  __syncthreads();
-  if (threadIdx.x < cnt) cm_s4a_rescue(d, list[threadIdx.x]);
-}
-__global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n) {
-  __shared__ uint32_t list[CM_BLOCK];
-  __shared__ uint32_t cnt;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
-  const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i0 < n) {
-    const uint32_t i = d.perm_reads ? d.perm_reads[i0] : i0;
-    if (d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0) list[atomicAdd(&cnt, 1u)] = i;
-    else cm_s4b_rescue_merge(d, i);
-  }
-  __syncthreads();
-  if (threadIdx.x < cnt) cm_s4b_rescue_merge(d, list[threadIdx.x]);
-}
 // every lane with `pred` appends `value` to a device list: one atomic per wave (called by all lanes of the wave)
 __device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool pred, uint32_t value) {
   const unsigned long long m = __ballot(pred);
@@ -552,6 +523,57 @@ __device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint
   if (pred) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
+// S4a / S4b: few reads (pairs whose mate has to be rescued, ~7 % here) run the long occurrence-run
+// searches.  Spread over all waves they keep every wave busy for one search's latency at 4-5 active lanes;
+// packed per block (r01h) one wave per block still ran them at a quarter of its lanes.  Every lane now does the
+// cheap part of its own read and the reads with a search go to ONE device list (a wave-aggregated append),
+// which k_s4a_rescue_list / k_s4b_rescue_list work through with full waves.
+// The list is kept in CM_RS_SEGS segments, each with a counter on a cache line of its own: same-address device atomics
+// retire at ~90 per microsecond (one per wave of an 8 M-read batch on ONE counter measured 1.4 ms); a block appends with
+// one atomic to segment blockIdx % CM_RS_SEGS.  Segment g starts at rs_list + g * seg_cap.
+__global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t n, uint32_t seg_cap) {
+  __shared__ uint32_t sh_cnt, sh_base;
+  if (threadIdx.x == 0) sh_cnt = 0;
+  __syncthreads();
+  const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
+  const uint32_t i = i0 < n && d.perm_reads ? d.perm_reads[i0] : i0;
+  const bool aug = i0 < n && cm_s4a_decide(d, i);
+  // slot inside the block: wave-aggregated LDS atomic
+  const unsigned long long m = __ballot(aug);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t wbase = 0;
+  if (m) {
+    const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
+    if (lane == leader) wbase = atomicAdd(&sh_cnt, (uint32_t)__popcll(m));
+    wbase = __shfl(wbase, (int)leader, 64);
+  }
+  __syncthreads();
+  const uint32_t seg = blockIdx.x % CM_RS_SEGS;
+  if (threadIdx.x == 0 && sh_cnt) sh_base = atomicAdd(&d.rs_cnt[seg * 16], sh_cnt);
+  __syncthreads();
+  if (aug) d.rs_list[(uint64_t)seg * seg_cap + sh_base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+// the searches of the listed reads: blockIdx.y = segment, the x blocks stride over it (its length is only known on the device)
+__global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_cap) {
+  const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
+  const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
+  for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) cm_s4a_rescue(d, list[j]);
+}
+__global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n) {
+  const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
+  if (i0 >= n) return;
+  const uint32_t i = d.perm_reads ? d.perm_reads[i0] : i0;
+  if (d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0) return;  // k_s4b_rescue_list
+  cm_s4b_rescue_merge(d, i);
+}
+__global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap) {
+  const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
+  const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
+  for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) {
+    const uint32_t r = list[j];
+    if (d.resc_n[r] + d.resc_p[r] > 0) cm_s4b_rescue_merge(d, r);
+  }
+}
 // S4c; long filtered candidate lists are queued for k_sort_lists
 __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
@@ -1055,8 +1077,24 @@ void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_le
   while (threads > 64 && (size_t)cap * threads * 9 > 36 * 1024 + 1024) threads >>= 1;
   hipLaunchKernelGGL(k_s3b_candidates, dim3((n + threads - 1) / threads), dim3(threads), (size_t)cap * threads * 9, s, d, n, cap);
 }
-CM_LAUNCH(k_s4a_rescue_count)
 CM_LAUNCH(k_s4b_rescue_merge)
+// capacity of one list segment: the reads of every CM_RS_SEGS-th block
+uint32_t cm_rescue_seg_cap(uint32_t n_reads) { return ((n_reads + CM_BLOCK - 1) / CM_BLOCK / CM_RS_SEGS + 1) * CM_BLOCK; }
+void cm_launch_k_s4a_rescue_count(const CmDev &d, uint32_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_s4a_rescue_count, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, cm_rescue_seg_cap(n));
+}
+// list kernels: enough waves for every listed read of a typical batch to get a lane at once, grid-stride beyond that
+static inline dim3 rescue_list_grid(uint32_t n_reads) {
+  uint32_t b = n_reads / 64 / CM_RS_SEGS / 4 + 1;  // a quarter of the reads listed: one pass
+  if (b > 256u) b = 256u;
+  return dim3(b, CM_RS_SEGS);
+}
+void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s) {
+  if (n_reads) hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads));
+}
+void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s) {
+  if (n_reads) hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads));
+}
 CM_LAUNCH(k_s4c_reduce)
 CM_LAUNCH(k_s5a_prepare)
 CM_LAUNCH(k_s5c_finalize)

@@ -24,6 +24,7 @@
 #define CM_PR_SINGLE 1
 #define CM_PR_MULTI 2
 #define CM_V_INVALID 0x7fff
+#define CM_RS_SEGS 64           // rescue list segments (one counter each, on its own cache line)
 #define CM_MAX_BEST 64          // upper bound on max_num_best_mappings (-n)
 #define CM_SORT_SERIAL_MAX 24   // cm_sort_cand / cm_sort_draft: insertion sort up to here, heap sort beyond
 #define CM_SORT_WAVE_MAX 1024   // longest list a wave sorts in LDS (k_sort_lists)
@@ -111,6 +112,9 @@ struct CmDev {
   //      1: <= hv_max[1] (a block each), 2: <= hv_max[2] (a block, large LDS), 3: longer (one lane, in global memory)
   const uint32_t *perm_reads, *perm_pairs;  // heavy-last processing order of reads / pairs, or nullptr (identity)
   uint32_t *hv_cnt, *hv_list;
+  // reads that supplement their candidates from the mate (S4a/S4b), packed in CM_RS_SEGS list segments:
+  // rs_cnt[16 * g] reads at rs_list + g * cm_rescue_seg_cap(n_reads)
+  uint32_t *rs_cnt, *rs_list;
   // lists longer than CM_SORT_SERIAL_MAX (candidates after the pair filter, draft mappings) that a wave sorts before the per-read
   // stage looks at them: srt_cnt[0] items (read << 1 | strand) at srt_list, srt_cnt[1] the work cursor
   uint32_t *srt_cnt, *srt_list;

@@ -197,7 +197,7 @@ class ChromapGPU:
 
     def _slots(self, n):
         """record capacity of a batch of n pairs / reads: max_num_best_mappings records each (-n)"""
-        return max(1, n * max(1, int(self.p.max_num_best_mappings)))
+        return max(1, n * max(1, int(self.params.max_num_best_mappings)))
 
     def map_pairs(self, b1, o1, b2, o2, first_read_id=0):
         """returns a ctypes array of Record (length = number of mapped pairs)"""
