@@ -433,7 +433,9 @@ def main():
             pcie = {"M pairs/s": round(n / (t2 - t1) / 1e6, 2), "ms": round((t2 - t1) * 1e3, 2), "records": int(kk),
                     "note": "cmgpu_map_pairs on pageable host buffers (upload, map, record download)"}
             if hasattr(g, "map_pairs_pipelined"):
-                pcie["pipelined"] = g.map_pairs_pipelined(b1, o1, b2, o2, repeats=4)
+                g.set_option("lanes", 1 if exchange else args.lanes)  # the upload runs on a stream (and hardware queue) of its own
+                pcie["pipelined"] = g.map_pairs_pipelined(b1, o1, b2, o2, repeats=6)
+                pcie["pipelined"]["lanes"] = 1 if exchange else args.lanes
         except Exception as e:
             pcie = {"error": repr(e)}
         if world == 1 and not args.skip_cpu and not args.sam:

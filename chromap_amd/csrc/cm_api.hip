@@ -61,6 +61,12 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_probe_variant = (int)value | (c->opt_probe_variant & 16);
   } else if (n == "probe_pair_prefetch") {
     c->opt_probe_variant = (c->opt_probe_variant & 15) | (value ? 16 : 0);
+  } else if (n == "h2d_copy_blocks") {  // 0: hipMemcpyAsync; else blocks of the copy kernel that reads page-locked host memory
+    if (value < 0 || value > 4096) { cm_set_error(c, "h2d_copy_blocks: 0..4096"); return CMGPU_EINVAL; }
+    c->opt_h2d_kernel = (int)value;
+  } else if (n == "d2h_copy_blocks") {  // the record download the same way (0: hipMemcpyAsync)
+    if (value < 0 || value > 4096) { cm_set_error(c, "d2h_copy_blocks: 0..4096"); return CMGPU_EINVAL; }
+    c->opt_d2h_kernel = (int)value;
   } else if (n == "mm_chunks") {
     if (value < 1 || value > CM_MM_CHUNKS) { cm_set_error(c, "mm_chunks: 1.." + std::to_string(CM_MM_CHUNKS)); return CMGPU_EINVAL; }
     c->opt_mm_chunks = (int)value;
@@ -96,6 +102,8 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   if (n == "probe_lookups_per_lane") *value = c->opt_probe_variant & 15;
   else if (n == "probe_pair_prefetch") *value = (c->opt_probe_variant & 16) ? 1 : 0;
   else if (n == "mm_chunks") *value = c->opt_mm_chunks;
+  else if (n == "h2d_copy_blocks") *value = c->opt_h2d_kernel;
+  else if (n == "d2h_copy_blocks") *value = c->opt_d2h_kernel;
   else if (n == "prep_kernel") *value = c->opt_prep_kernel;
   else if (n == "prep_tile_reads") *value = c->opt_prep_tile_reads;
   else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
@@ -428,6 +436,55 @@ extern "C" int cmgpu_host_unregister(void *p) {
 // batch c+1 runs on a copy stream into the last parking slot while batch c is mapped.
 //   cmgpu_submit_pairs(b0); for (c = 0; ...) { cmgpu_submit_pairs(b[c+1]); cmgpu_map_submitted(out[c], ...); }
 // Up to two batches may be submitted and not yet mapped (parking slots 6 and 7 take turns).
+//
+// Upload of one buffer: page-locked memory the device can address (cmgpu_host_alloc / cmgpu_host_register) is read by a copy
+// KERNEL straight over the link -- one SDMA engine moved 22-32 GB/s here (less while the mapping kernels load HBM), a few
+// waves with 16-byte loads in flight fill the link; anything else goes through hipMemcpyAsync.
+typedef unsigned int cm_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_host_copy(const cm_u32x4 *__restrict__ src, cm_u32x4 *__restrict__ dst, uint64_t n16,
+                                                  const uint8_t *__restrict__ src_tail, uint8_t *__restrict__ dst_tail, uint32_t tail) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16-byte loads per lane in flight
+    const cm_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const cm_u32x4 e = __builtin_nontemporal_load(src + i + 2 * stride), f = __builtin_nontemporal_load(src + i + 3 * stride);
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = e; dst[i + 3 * stride] = f;
+  }
+  for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+  if (blockIdx.x == 0 && threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+static int host_to_device(cmgpu_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return CMGPU_OK;
+  void *dev_view = nullptr;
+  if (c->opt_h2d_kernel && bytes >= 65536 && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0 &&
+      hipHostGetDevicePointer(&dev_view, const_cast<void *>(src), 0) == hipSuccess && dev_view) {
+    const uint64_t n16 = bytes >> 4;
+    const uint32_t tail = (uint32_t)(bytes & 15u);
+    hipLaunchKernelGGL(k_host_copy, dim3((unsigned)c->opt_h2d_kernel), dim3(256), 0, s, (const cm_u32x4 *)dev_view, (cm_u32x4 *)dst, n16,
+                       (const uint8_t *)dev_view + (n16 << 4), (uint8_t *)dst + (n16 << 4), tail);
+    return CMGPU_OK;
+  }
+  (void)hipGetLastError();  // hipHostGetDevicePointer on pageable memory
+  HIPCHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+  return CMGPU_OK;
+}
+// the other direction (records): the same kernel writing to page-locked host memory when asked to (d2h_copy_blocks)
+static int device_to_host(cmgpu_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return CMGPU_OK;
+  void *dev_view = nullptr;
+  if (c->opt_d2h_kernel && bytes >= 65536 && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0 &&
+      hipHostGetDevicePointer(&dev_view, dst, 0) == hipSuccess && dev_view) {
+    const uint64_t n16 = bytes >> 4;
+    const uint32_t tail = (uint32_t)(bytes & 15u);
+    hipLaunchKernelGGL(k_host_copy, dim3((unsigned)c->opt_d2h_kernel), dim3(256), 0, s, (const cm_u32x4 *)src, (cm_u32x4 *)dev_view, n16,
+                       (const uint8_t *)src + (n16 << 4), (uint8_t *)dev_view + (n16 << 4), tail);
+    return CMGPU_OK;
+  }
+  (void)hipGetLastError();
+  HIPCHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_submit_pairs(cmgpu_ctx *c, const cmgpu_batch *in) {
   if (!c || !in) return CMGPU_EINVAL;
   HIPCHECK(c, cm_enter(c));
@@ -435,7 +492,12 @@ extern "C" int cmgpu_submit_pairs(cmgpu_ctx *c, const cmgpu_batch *in) {
   const uint32_t n = in->n_pairs;
   if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
   if (!c->stream_h2d) {
-    HIPCHECK(c, hipStreamCreateWithFlags(&c->stream_h2d, hipStreamNonBlocking));
+    // a priority of its own: the runtime spreads streams of one priority over a few hardware queues (4 by default), and
+    // with the lanes' streams alive the upload stream landed behind the mapping kernels' queue -- 11.5 -> 19.1 ms per
+    // 4 M-pair batch; streams of another priority get queues of their own
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    HIPCHECK(c, hipStreamCreateWithPriority(&c->stream_h2d, hipStreamNonBlocking, prio_greatest));
     for (hipEvent_t &e : c->ev_h2d) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const int which = (int)(c->sub_total & 1u);
@@ -448,10 +510,11 @@ extern "C" int cmgpu_submit_pairs(cmgpu_ctx *c, const cmgpu_batch *in) {
     cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM;
   }
   hipStream_t s = c->stream_h2d;
-  HIPCHECK(c, hipMemcpyAsync(sl.ro0.p, in->read1_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
-  HIPCHECK(c, hipMemcpyAsync(sl.ro1.p, in->read2_offsets, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
-  HIPCHECK(c, hipMemcpyAsync(sl.rb0.p, in->read1_bases, sl.bases0, hipMemcpyHostToDevice, s));
-  HIPCHECK(c, hipMemcpyAsync(sl.rb1.p, in->read2_bases, sl.bases1, hipMemcpyHostToDevice, s));
+  int rc0 = host_to_device(c, sl.ro0.p, in->read1_offsets, ((size_t)n + 1) * 4, s);
+  if (!rc0) rc0 = host_to_device(c, sl.ro1.p, in->read2_offsets, ((size_t)n + 1) * 4, s);
+  if (!rc0) rc0 = host_to_device(c, sl.rb0.p, in->read1_bases, sl.bases0, s);
+  if (!rc0) rc0 = host_to_device(c, sl.rb1.p, in->read2_bases, sl.bases1, s);
+  if (rc0) return rc0;
   int rc = launch_max_len(c, sl.ro0, &sl.ro1, n, s, 1 + which);
   if (rc) return rc;
   HIPCHECK(c, hipEventRecord(c->ev_h2d[which], s));
@@ -956,7 +1019,7 @@ static int download_dense(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity
                      (const uint32_t *)pos, (uint8_t *)c->rec_dense.p, n);
   const uint64_t k = c->n_records;  // counted by the mapping call
   if (k > out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
-  if (k) HIPCHECK(c, hipMemcpyAsync(out, c->rec_dense.p, (size_t)k * 24, hipMemcpyDeviceToHost, s));
+  if (k) { const int rc = device_to_host(c, out, c->rec_dense.p, (size_t)k * 24, s); if (rc) return rc; }
   HIPCHECK(c, cm_stream_sync(s));
   if (n_out) *n_out = k;
   return CMGPU_OK;

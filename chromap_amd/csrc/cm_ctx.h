@@ -115,6 +115,9 @@ struct cmgpu_ctx {
   // pipelined host-buffer entry (cmgpu_submit_pairs / cmgpu_map_submitted): the next batch is uploaded on a copy stream into the
   // last parking slot while the current one is mapped
   hipStream_t stream_h2d = nullptr;
+  int opt_d2h_kernel = 0;
+  int opt_h2d_kernel = 0;   // blocks of k_host_copy for uploads from page-locked memory; 0 = hipMemcpyAsync (measured faster: the copy
+                            // kernel's waves slow the mapping kernels more than the copy engine's lower rate costs)
   hipEvent_t ev_h2d[2] = {nullptr, nullptr};
   uint32_t sub_total = 0, sub_count = 0;  // batches submitted so far / submitted and not yet mapped (<= 2: parking slots 6 and 7 take turns)
   DevBuf rec_dense, maxlen_dev;

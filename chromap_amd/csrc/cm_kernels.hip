@@ -904,25 +904,26 @@ __global__ __launch_bounds__(CM_BLOCK) void k_probe_reduce(const uint2 *__restri
 // per-pair counters of Chromap::OutputMappingStatistics (chromap.h:1057-1058, 1118-1137);
 // block-level reduction in LDS, one row of 8 partials per block, summed by k_stats_reduce
 #define CM_NSTAT 8
+#define CM_STATS_BLOCKS 2048u
 __global__ __launch_bounds__(CM_BLOCK) void k_stats(CmDev d, uint32_t n, unsigned long long *__restrict__ partials) {
-  const uint32_t pair = blockIdx.x * CM_BLOCK + threadIdx.x;
   unsigned long long v[CM_NSTAT] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (pair < n) {
+  // the grid strides over the pairs: at most CM_STATS_BLOCKS rows of partials for k_stats_reduce's single block
+  for (uint32_t pair = blockIdx.x * CM_BLOCK + threadIdx.x; pair < n; pair += gridDim.x * CM_BLOCK) {
     const uint32_t r1 = 2 * pair, r2 = r1 + 1;
     if (d.alive[pair]) {
-      v[0] = d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
+      v[0] += d.fcp[r1] + d.fcn[r1] + d.fcp[r2] + d.fcn[r2];
       const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
       const unsigned long long per = d.p.single ? 1ull : 2ull;  // reads per item
       if (nd1 > 0 && (d.p.single || nd2 > 0)) {
         const int nb = d.pe_nbest[pair];
-        if (nb == 1) v[3] = per;
-        v[1] = per * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
-        if (nb > 0) v[2] = per;
-        if (nb > 1 && nb <= d.p.drop_rep) v[4] = 1;
+        if (nb == 1) v[3] += per;
+        v[1] += per * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
+        if (nb > 0) v[2] += per;
+        if (nb > 1 && nb <= d.p.drop_rep) v[4] += 1;
       }
     }
-    v[5] = (unsigned long long)d.aug[r1] + d.aug[r2];
-    v[6] = (unsigned long long)d.hit_tot[r1] + d.hit_tot[r2];
+    v[5] += (unsigned long long)d.aug[r1] + d.aug[r2];
+    v[6] += (unsigned long long)d.hit_tot[r1] + d.hit_tot[r2];
     for (uint32_t t = 0; t < (uint32_t)d.p.max_best; ++t) v[7] += d.rec_ok[(uint64_t)pair * (uint32_t)d.p.max_best + t];
   }
   __shared__ unsigned long long sh[CM_BLOCK / 64][CM_NSTAT];
@@ -1227,7 +1228,8 @@ void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s) {
 size_t cm_stats_partial_words(uint32_t n) { return (size_t)((n + CM_BLOCK - 1) / CM_BLOCK) * CM_NSTAT + CM_NSTAT; }
 void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials, hipStream_t s) {
   if (!n) return;
-  const uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
+  uint32_t blocks = (n + CM_BLOCK - 1) / CM_BLOCK;
+  if (blocks > CM_STATS_BLOCKS) blocks = CM_STATS_BLOCKS;
   hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n, partials);
   hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(CM_BLOCK), 0, s, (const unsigned long long *)partials, blocks, d.stats);
 }
