@@ -180,7 +180,8 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   if (p.sam && p.split) { cm_set_error(c, "--SAM with split alignment is not supported"); return CMGPU_EINVAL; }
   if (params->output_format != 0 && params->output_format != CMGPU_FORMAT_SAM) { cm_set_error(c, "unknown output_format"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipStreamCreate(&c->stream));
-  HIPCHECK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIPCHECK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));  // same priority as `stream`: a probe stream of higher or lower
+                                                                             // priority measured 3-5 % slower end to end
   for (hipEvent_t &e : c->chunk_ev) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (c->stats.ensure(CM_ST_N * 8)) return CMGPU_ENOMEM;
   HIPCHECK(c, hipMemset(c->stats.p, 0, CM_ST_N * 8));
@@ -786,7 +787,9 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_launch_k_s3b_candidates(d, n2, c->max_read_len, s);
   cm_launch_k_s3b_heavy(d, n_heavy, s);  // reads with long hit lists: a wave or a block each
   // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
-  c->use_perm = (uint64_t)n_heavy[0] + n_heavy[1] + n_heavy[2] + n_heavy[3] > n2 / 2048;
+  // (lists of class 0 -- up to heavy_wave_max hits, a wave each here -- cost the later per-lane stages little; a uniform genome
+  // still has a few thousand of them per batch, and the permutation's scans and scatters cost more than they save there)
+  c->use_perm = (uint64_t)n_heavy[1] + n_heavy[2] + n_heavy[3] > n2 / 65536 || n_heavy[0] > n2 / 256;
   if (c->opt_heavy_last) c->use_perm = c->opt_heavy_last > 0;
   if (c->use_perm) {
     uint32_t *tmp = (uint32_t *)c->hv_tmp.p;

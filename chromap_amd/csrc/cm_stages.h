@@ -1123,11 +1123,25 @@ CM_HD int cm_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, 
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   uint32_t cnt = 0, rep_len = 0, prev_rep = ~0u;
   unsigned long long reads = 0;
-  for (uint32_t mi = 0; mi < n; ++mi) {
-    const uint8_t kind = d.pr_kind[b + mi];
+  // the lookup results of four minimizers are requested together (one round trip instead of four dependent ones: the
+  // rescued reads are few and every one of them is a chain of such trips -- the kernel's duration is the chain's length)
+  for (uint32_t mi0 = 0; mi0 < n; mi0 += CM_S3B_GROUP) {
+    uint8_t kind_g[CM_S3B_GROUP];
+    uint64_t val_g[CM_S3B_GROUP];
+    uint32_t ps_g[CM_S3B_GROUP];
+#pragma unroll
+    for (int q = 0; q < CM_S3B_GROUP; ++q) {
+      const bool in = mi0 + q < n;
+      kind_g[q] = in ? d.pr_kind[b + mi0 + q] : (uint8_t)CM_PR_MISS;
+      val_g[q] = in ? d.pr_val[b + mi0 + q] : 0;
+      ps_g[q] = in ? d.mm_ps[b + mi0 + q] : 0;
+    }
+#pragma unroll
+   for (int q = 0; q < CM_S3B_GROUP; ++q) {
+    const uint8_t kind = kind_g[q];
     if (kind == CM_PR_MISS) continue;
-    const uint64_t val = d.pr_val[b + mi];
-    const uint32_t ps = d.mm_ps[b + mi];
+    const uint64_t val = val_g[q];
+    const uint32_t ps = ps_g[q];
     bool same;
     if (kind == CM_PR_SINGLE) {
       const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
@@ -1186,6 +1200,7 @@ CM_HD int cm_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, 
       else rep_len += (uint32_t)d.p.k;
       prev_rep = rp;
     }
+   }
   }
   *n_out = cnt;
   *rep_len_out = rep_len;
