@@ -1525,17 +1525,76 @@ CM_HD void cm_peq_or(uint32_t *P, uint32_t c, uint32_t bit) {
   P[3] |= c == 3 ? bit : 0u; P[4] |= c == 4 ? bit : 0u;
 }
 
-// BandedAlignPatternToText (alignment.cc:141-192) over byte sources
-template <class PS, class TS>
-CM_HD int cm_banded_align_t(int e, const PS &pat, const TS &txt, int L, int *end_pos) {
+// Sequential byte readers over global memory: one aligned 8-byte load per eight bytes, the next word requested while the
+// current one is consumed.  (The prefetched copies above -- CmBytes -- are arrays indexed at run time, i.e. scratch memory:
+// 700 bytes written and read back per alignment; the verification kernel moved more scratch than anything else.)
+// n = bytes that will be read; no word outside [first, last] of them is touched.
+struct CmFwdReader {  // p[0], p[1], ...
+  const uint64_t *ap;
+  uint64_t cur, nxt;
+  uint32_t left, words;  // bytes left in cur; words not yet requested
+  CM_HD void init(const uint8_t *p, uint32_t n) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = (uint32_t)(a & 7);
+    ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+    words = n ? (sh + n + 7) >> 3 : 0;
+    cur = 0; nxt = 0; left = 0;
+    if (words) { cur = *ap++ >> (sh * 8); left = 8 - sh; --words; }
+    if (words) { nxt = *ap++; --words; }
+  }
+  CM_HD uint8_t next() {
+    if (left == 0) {
+      cur = nxt; left = 8;
+      if (words) { nxt = *ap++; --words; }
+    }
+    const uint8_t b = (uint8_t)cur;
+    cur >>= 8; --left;
+    return b;
+  }
+};
+struct CmBwdReader {  // p[0], p[-1], p[-2], ...
+  const uint64_t *ap;
+  uint64_t cur, nxt;
+  uint32_t left, words;
+  CM_HD void init(const uint8_t *p, uint32_t n) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t pos = (uint32_t)(a & 7);  // byte of p inside its word
+    ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+    words = n ? ((7 - pos) + n + 7) >> 3 : 0;
+    cur = 0; nxt = 0; left = 0;
+    if (words) { cur = *ap-- << ((7 - pos) * 8); left = pos + 1; --words; }
+    if (words) { nxt = *ap--; --words; }
+  }
+  CM_HD uint8_t next() {
+    if (left == 0) {
+      cur = nxt; left = 8;
+      if (words) { nxt = *ap--; --words; }
+    }
+    const uint8_t b = (uint8_t)(cur >> 56);
+    cur <<= 8; --left;
+    return b;
+  }
+};
+
+// BandedAlignPatternToText (alignment.cc:141-192) with the pattern and the text streamed; NEG: the text is the reverse
+// complement of the read (bytes read backwards, codes complemented)
+template <bool NEG>
+CM_HD int cm_banded_align_stream(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, int toff, int L, int *end_pos) {
+  CmFwdReader pr;
+  pr.init(pattern, (uint32_t)(L + 2 * e));
+  CmFwdReader tf;
+  CmBwdReader tb;
+  if (NEG) tb.init(read + (Lfull - 1 - toff), (uint32_t)L); else tf.init(read + toff, (uint32_t)L);
   uint32_t P[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pat.get(i)), 1u << i);
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pr.next()), 1u << i);
   const uint32_t hi = 1u << (2 * e);
   uint32_t VP = 0, VN = 0;
   int err = 0;
   for (int i = 0; i < L; i++) {
-    cm_peq_or(P, cm_c2u(pat.get(i + 2 * e)), hi);
-    uint32_t X = cm_peq_get(P, txt.code(i)) | VN;
+    cm_peq_or(P, cm_c2u(pr.next()), hi);
+    uint32_t tc;
+    if (NEG) { const uint32_t c = cm_c2u(tb.next()); tc = c < 4 ? 3u ^ c : 4u; } else tc = cm_c2u(tf.next());
+    uint32_t X = cm_peq_get(P, tc) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1563,14 +1622,8 @@ CM_HD int cm_banded_align_t(int e, const PS &pat, const TS &txt, int L, int *end
 // text = (neg ? revcomp(read[0..Lfull)) : read) + toff, length L
 CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
                           int *end_pos) {
-  CmBytes pb, tb;
-  if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
-    const CmText<CmBytes> txt{tb, Lfull, neg, toff};
-    return cm_banded_align_t(e, pb, txt, L, end_pos);
-  }
-  const CmDirect pd{pattern}, td{read};
-  const CmText<CmDirect> txt{td, Lfull, neg, toff};
-  return cm_banded_align_t(e, pd, txt, L, end_pos);
+  return neg ? cm_banded_align_stream<true>(e, pattern, read, Lfull, toff, L, end_pos)
+             : cm_banded_align_stream<false>(e, pattern, read, Lfull, toff, L, end_pos);
 }
 
 // BandedTraceback (alignment.cc:656-718) over byte sources
