@@ -1462,52 +1462,6 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
 // BandedAlignPatternToText (alignment.cc:141-192): Myers/Hyyro bit-vector banded edit
 // distance, 32-bit word, band 2e+1.  pattern = reference window, text = read.
 // neg: text is the reverse complement of `read` (read[len-1-i] complemented).
-// ---- byte sources -----------------------------------------------------------------------
-// CmDirect reads bytes where they are.  CmBytes first copies a byte range into a small
-// per-lane array with independent 8-byte loads (issued back to back, one memory latency)
-// and then serves bytes from it: the bit-vector loops below consume one reference byte and one
-// read byte per step, and a dependent global load per step made them latency-bound.
-struct CmDirect {
-  const uint8_t *p;
-  CM_HD uint8_t get(int i) const { return p[i]; }
-};
-#define CM_PF_WORDS 42  // 336 bytes: windows up to L + 2e <= 320
-struct CmBytes {
-  uint64_t w[CM_PF_WORDS];
-  uint32_t sh;
-  CM_HD bool load(const uint8_t *p, uint32_t n) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    sh = (uint32_t)(a & 7);
-    const uint32_t nw = (sh + n + 7) >> 3;
-    if (nw > CM_PF_WORDS) return false;
-    const uint64_t *ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
-    for (uint32_t k = 0; k < nw; ++k) w[k] = ap[k];
-    return true;
-  }
-  CM_HD uint8_t get(int i) const {
-    const uint32_t j = (uint32_t)i + sh;
-    return (uint8_t)(w[j >> 3] >> ((j & 7) * 8));
-  }
-};
-// text = (neg ? revcomp(read[0..Lfull)) : read) + toff
-template <class B>
-struct CmText {
-  const B &b;
-  int Lfull;
-  bool neg;
-  int toff;
-  CM_HD uint32_t code(int i) const {
-    const int j = toff + i;
-    if (!neg) return cm_c2u(b.get(j));
-    const uint32_t c = cm_c2u(b.get(Lfull - 1 - j));
-    return c < 4 ? 3u ^ c : 4u;
-  }
-  CM_HD uint8_t raw(int i) const {
-    const int j = toff + i;
-    return neg ? cm_negchar(b.get(Lfull - 1 - j)) : b.get(j);
-  }
-};
-
 CM_HD uint32_t cm_text_code(const uint8_t *read, int L, int i, bool neg) {
   if (!neg) return cm_c2u(read[i]);
   const uint32_t c = cm_c2u(read[L - 1 - i]);
@@ -1526,8 +1480,9 @@ CM_HD void cm_peq_or(uint32_t *P, uint32_t c, uint32_t bit) {
 }
 
 // Sequential byte readers over global memory: one aligned 8-byte load per eight bytes, the next word requested while the
-// current one is consumed.  (The prefetched copies above -- CmBytes -- are arrays indexed at run time, i.e. scratch memory:
-// 700 bytes written and read back per alignment; the verification kernel moved more scratch than anything else.)
+// current one is consumed.  (Their predecessor copied window and read into per-lane arrays first; indexed at run time those
+// arrays were scratch memory -- 700 bytes written and read back per alignment; a byte load per step from global memory,
+// before that, made every step a dependent round trip.)
 // n = bytes that will be read; no word outside [first, last] of them is touched.
 struct CmFwdReader {  // p[0], p[1], ...
   const uint64_t *ap;
@@ -1626,42 +1581,6 @@ CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, in
              : cm_banded_align_stream<false>(e, pattern, read, Lfull, toff, L, end_pos);
 }
 
-// BandedTraceback (alignment.cc:656-718) over byte sources
-template <class PS, class TS>
-CM_HD int cm_banded_traceback_t(int e, int min_num_errors, const PS &pat, const TS &txt, int L) {
-  int error_count = 0;
-  for (int i = 0; i < L; ++i)
-    if (pat.get(i + e) != txt.raw(i)) ++error_count;  // raw, case-sensitive (:666)
-  if (error_count == min_num_errors) return e;
-  uint32_t P[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pat.get(L - 1 + 2 * e - i)), 1u << i);
-  const uint32_t hi = 1u << (2 * e);
-  uint32_t VP = 0, VN = 0;
-  int err = 0;
-  for (int i = 0; i < L; i++) {
-    cm_peq_or(P, cm_c2u(pat.get(L - 1 - i)), hi);
-    uint32_t X = cm_peq_get(P, txt.code(L - 1 - i)) | VN;
-    const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
-    const uint32_t HN = VP & D0;
-    const uint32_t HP = VN | ~(VP | D0);
-    X = D0 >> 1;
-    VN = X & HP;
-    VP = HN | ~(X | HP);
-    err += 1 - (int)(D0 & 1u);
-    P[0] >>= 1; P[1] >>= 1; P[2] >>= 1; P[3] >>= 1; P[4] >>= 1;
-  }
-  int start = 2 * e;
-  for (int i = 0; i < 2 * e; i++) {
-    err += (int)((VP >> i) & 1u);
-    err -= (int)((VN >> i) & 1u);
-    if (err == min_num_errors) {
-      start = 2 * e - (1 + i);
-      if (i + 1 == e) return start;
-    }
-  }
-  return start;
-}
-
 // ---------------------------------------------------------------------------------------
 // The first thing BandedTraceback does (alignment.cc:660-670) is a raw, case-sensitive Hamming
 // count of the read against the window at offset e; when it equals the edit distance the start is e
@@ -1714,34 +1633,84 @@ CM_HD int cm_hamming_diag(const uint8_t *pat, const uint8_t *read, int Lfull, bo
   return cnt;
 }
 
+// BandedTraceback's bit-vector pass (alignment.cc:672-718) with both strings streamed backwards; its leading Hamming
+// count is cm_hamming_diag (the caller below)
+template <bool NEG>
+CM_HD int cm_banded_traceback_stream(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int Lfull, int toff, int L) {
+  CmBwdReader pb;
+  pb.init(pattern + (L - 1 + 2 * e), (uint32_t)(L + 2 * e));
+  CmFwdReader tf;
+  CmBwdReader tb;
+  {
+    const int j0 = toff + L - 1;  // text string index of the first column
+    if (NEG) tf.init(read + (Lfull - 1 - j0), (uint32_t)L); else tb.init(read + j0, (uint32_t)L);
+  }
+  uint32_t P[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(pb.next()), 1u << i);
+  const uint32_t hi = 1u << (2 * e);
+  uint32_t VP = 0, VN = 0;
+  int err = 0;
+  for (int i = 0; i < L; i++) {
+    cm_peq_or(P, cm_c2u(pb.next()), hi);
+    uint32_t tc = cm_c2u(NEG ? tf.next() : tb.next());
+    if (NEG) tc = tc < 4 ? 3u ^ tc : 4u;
+    uint32_t X = cm_peq_get(P, tc) | VN;
+    const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+    const uint32_t HN = VP & D0;
+    const uint32_t HP = VN | ~(VP | D0);
+    X = D0 >> 1;
+    VN = X & HP;
+    VP = HN | ~(X | HP);
+    err += 1 - (int)(D0 & 1u);
+    P[0] >>= 1; P[1] >>= 1; P[2] >>= 1; P[3] >>= 1; P[4] >>= 1;
+  }
+  int start = 2 * e;
+  for (int i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err == min_num_errors) {
+      start = 2 * e - (1 + i);
+      if (i + 1 == e) return start;
+    }
+  }
+  return start;
+}
 CM_HD int cm_banded_traceback(int e, int min_num_errors, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg,
                               int toff, int L) {
   if (min_num_errors == 0) return e;
   if (cm_hamming_diag(pattern + e, read, Lfull, neg, toff, L) == min_num_errors) return e;
-  CmBytes pb, tb;
-  if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
-    const CmText<CmBytes> txt{tb, Lfull, neg, toff};
-    return cm_banded_traceback_t(e, min_num_errors, pb, txt, L);
-  }
-  const CmDirect pd{pattern}, td{read};
-  const CmText<CmDirect> txt{td, Lfull, neg, toff};
-  return cm_banded_traceback_t(e, min_num_errors, pd, txt, L);
+  return neg ? cm_banded_traceback_stream<true>(e, min_num_errors, pattern, read, Lfull, toff, L)
+             : cm_banded_traceback_stream<false>(e, min_num_errors, pattern, read, Lfull, toff, L);
 }
 
-// BandedAlignPatternToTextWithDropOff (alignment.cc:197-283) when from3 == false,
-// BandedAlignPatternToTextWithDropOffFrom3End (alignment.cc:285-376) when from3 == true.
-// text = (neg ? revcomp(read) : read) + toff, length L.
-template <class PS, class TS>
-CM_HD int cm_banded_align_dropoff_t(int e, const PS &pat, const TS &txt, int L, bool from3, int *end_pos, int *read_mapping_length) {
+// BandedAlignPatternToTextWithDropOff (alignment.cc:197-283) when FROM3 == false,
+// BandedAlignPatternToTextWithDropOffFrom3End (alignment.cc:285-376) when FROM3 == true.
+// text = (NEG ? revcomp(read) : read) + toff, length L.  Pattern and text are streamed (CmFwdReader / CmBwdReader):
+// from the 3' end both run backwards over their strings, and the reverse complement flips the read's direction in memory.
+template <bool FROM3, bool NEG>
+CM_HD int cm_banded_align_dropoff_stream(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, int toff, int L, int *end_pos,
+                                         int *read_mapping_length) {
+  constexpr bool TBWD = FROM3 != NEG;  // direction of the text in the read's memory
+  CmFwdReader pf, tf;
+  CmBwdReader pb, tb;
+  if (FROM3) pb.init(pattern + (L + 2 * e - 1), (uint32_t)(L + 2 * e)); else pf.init(pattern, (uint32_t)(L + 2 * e));
+  {
+    // first text string index: FROM3 ? L - 1 : 0, i.e. j = toff + that; memory index NEG ? Lfull - 1 - j : j
+    const int j0 = toff + (FROM3 ? L - 1 : 0);
+    const uint8_t *t0 = read + (NEG ? Lfull - 1 - j0 : j0);
+    if (TBWD) tb.init(t0, (uint32_t)L); else tf.init(t0, (uint32_t)L);
+  }
   uint32_t P[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(from3 ? pat.get(L + 2 * e - 1 - i) : pat.get(i)), 1u << i);
+  for (int i = 0; i < 2 * e; i++) cm_peq_or(P, cm_c2u(FROM3 ? pb.next() : pf.next()), 1u << i);
   const uint32_t hi = 1u << (2 * e);
   uint32_t VP = 0, VN = 0, prev_VP = 0, prev_VN = 0;
   int err = 0, i = 0, prev_err = 0;
   bool fail_beginning = false;
   for (; i < L; i++) {
-    cm_peq_or(P, cm_c2u(from3 ? pat.get(L - 1 - i) : pat.get(i + 2 * e)), hi);
-    uint32_t X = cm_peq_get(P, txt.code(from3 ? L - 1 - i : i)) | VN;
+    cm_peq_or(P, cm_c2u(FROM3 ? pb.next() : pf.next()), hi);
+    uint32_t tc = cm_c2u(TBWD ? tb.next() : tf.next());
+    if (NEG) tc = tc < 4 ? 3u ^ tc : 4u;
+    uint32_t X = cm_peq_get(P, tc) | VN;
     const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
     const uint32_t HN = VP & D0;
     const uint32_t HP = VN | ~(VP | D0);
@@ -1773,18 +1742,12 @@ CM_HD int cm_banded_align_dropoff_t(int e, const PS &pat, const TS &txt, int L, 
   if (fail_beginning || (L > 60 && *end_pos + 1 - e - min_err < 30)) *end_pos = -*end_pos;
   return min_err;
 }
-// pattern window and read are first copied into registers with independent 8-byte loads (CmBytes); the bit-vector loop
-// then has no dependent global load per step (as in cm_banded_align)
 CM_HD int cm_banded_align_dropoff(int e, const uint8_t *pattern, const uint8_t *read, int Lfull, bool neg, int toff, int L,
                                   bool from3, int *end_pos, int *read_mapping_length) {
-  CmBytes pb, tb;
-  if (pb.load(pattern, (uint32_t)(L + 2 * e)) && tb.load(read, (uint32_t)Lfull)) {
-    const CmText<CmBytes> txt{tb, Lfull, neg, toff};
-    return cm_banded_align_dropoff_t(e, pb, txt, L, from3, end_pos, read_mapping_length);
-  }
-  const CmDirect pd{pattern}, td{read};
-  const CmText<CmDirect> txt{td, Lfull, neg, toff};
-  return cm_banded_align_dropoff_t(e, pd, txt, L, from3, end_pos, read_mapping_length);
+  if (from3) return neg ? cm_banded_align_dropoff_stream<true, true>(e, pattern, read, Lfull, toff, L, end_pos, read_mapping_length)
+                        : cm_banded_align_dropoff_stream<true, false>(e, pattern, read, Lfull, toff, L, end_pos, read_mapping_length);
+  return neg ? cm_banded_align_dropoff_stream<false, true>(e, pattern, read, Lfull, toff, L, end_pos, read_mapping_length)
+             : cm_banded_align_dropoff_stream<false, false>(e, pattern, read, Lfull, toff, L, end_pos, read_mapping_length);
 }
 
 // AdjustGapBeginning (alignment.cc:24-83) without cigar.  read string = (neg ? revcomp(read)

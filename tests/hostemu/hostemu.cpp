@@ -86,7 +86,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   cm_build_len_coef(coef); cm_build_nsec_break(brk);
   d.mq.len_coef = coef.data(); d.mq.nsec_break = brk.data(); d.mq.n_break = (int)brk.size();
   d.n_pairs = n; d.first_read_id = in->first_read_id;
-  // padded copies: CmBytes::load reads whole aligned 8-byte words around a byte range
+  // padded copies: the byte readers (cm_stages.h) load whole aligned 8-byte words around a byte range
   std::vector<uint64_t> pad0(((size_t)(n ? in->read1_offsets[n] : 0) + 31) / 8 + 2, 0), pad1(((size_t)(n ? in->read2_offsets[n] : 0) + 31) / 8 + 2, 0);
   if (n) { memcpy(pad0.data(), in->read1_bases, in->read1_offsets[n]); memcpy(pad1.data(), in->read2_bases, in->read2_offsets[n]); }
   d.rb0 = (const uint8_t *)pad0.data(); d.rb1 = (const uint8_t *)pad1.data();
