@@ -26,6 +26,7 @@
 #include "cm_ctx.h"
 #include "cm_kernels.h"
 
+#define PP_RUN_SERIAL 128u  // records of a duplicate run its head walks alone (k_pp_select); longer runs: k_pp_select_long
 #define PP_BLOCK 256
 #define PP_LDS_BYTES 32768
 
@@ -141,11 +142,38 @@ __device__ __forceinline__ uint32_t pp_abundance(const PpCfg &cfg, uint64_t key)
   }
 }
 
+// the survivor of sorted position j: MAPQ filter, Tn5 shift, line length; win / dups / line_len of the position
+__device__ __forceinline__ void pp_finish(uint32_t j, PpRec r, uint32_t wi, uint32_t dups, bool bulk_done, const PpCfg &cfg,
+                                          const uint32_t *__restrict__ name_off, uint32_t *__restrict__ win,
+                                          uint32_t *__restrict__ dups_out, uint64_t *__restrict__ line_len) {
+  if ((!bulk_done && (int)r.mapq < cfg.mapq_thr) || r.rid >= cfg.n_seq) { line_len[j] = 0; return; }
+  if (cfg.tn5) pp_tn5(r, cfg.kind);
+  if (dups > 255) dups = 255;
+  const uint32_t nm = name_off[r.rid + 1] - name_off[r.rid];
+  uint32_t len;
+  if (pp_tagalign(cfg.kind)) {
+    // two lines (mapping_writer.cc:84-117, 138-168): the + read's and the - read's alignment; bulk data
+    // prints num_dups on the second line, single-cell data prints neither barcode nor num_dups
+    const uint32_t pe = r.start + r.pal, ne = r.start + r.len, ns = ne - r.nal;
+    len = 2 * (nm + 1 + 2 + pp_digits(r.mapq) + 1 + 1 + 1) + pp_digits(r.start) + 1 + pp_digits(pe) + 1 + pp_digits(ns) + 1 + pp_digits(ne) + 1;
+    if (cfg.kind == CMGPU_TEXT_TAGALIGN_PE) len += 1 + pp_digits(dups);
+  } else {
+    len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
+    if (cfg.kind == CMGPU_TEXT_BED_PE_BC || cfg.kind == CMGPU_TEXT_BED_SE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;  // chr start end barcode dups
+    else if (cfg.kind == CMGPU_TEXT_TAGALIGN_SE_BC) len += 2 + pp_digits(r.mapq) + 2 + 1;     // chr start end N mapq strand (mapping_writer.cc:26-34)
+    else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
+  }
+  win[j] = wi;
+  dups_out[j] = dups;
+  line_len[j] = len;
+}
+
 // survivor index (into the store), num_dups and line length per sorted position (0 = no line)
 __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restrict__ store, const uint64_t *__restrict__ bc,
                                                           const uint32_t *__restrict__ idx, uint32_t n, PpCfg cfg,
                                                           const uint32_t *__restrict__ name_off, uint32_t *__restrict__ win,
-                                                          uint32_t *__restrict__ dups_out, uint64_t *__restrict__ line_len) {
+                                                          uint32_t *__restrict__ dups_out, uint64_t *__restrict__ line_len,
+                                                          uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_cnt) {
   const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
   if (j >= n) return;
   uint32_t wi = idx[j];
@@ -200,35 +228,74 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
       if (cfg.inmem && cfg.tn5) pp_tn5(p, cfg.kind);
       if (pp_same_run(p, pp_has_bc(cfg.kind) ? bc[pi] : 0, rs, rbc, cfg)) { line_len[j] = 0; return; }
     }
-    for (uint32_t t = j + 1; t < n; ++t) {
+    uint32_t t = j + 1;
+    bool ended = false;
+    for (; t < n && t <= j + PP_RUN_SERIAL; ++t) {
       const uint32_t qi = idx[t];
       PpRec q = pp_load(store, qi), qs = q;
       if (cfg.inmem && cfg.tn5) pp_tn5(qs, cfg.kind);
-      if (!pp_same_run(rs, rbc, qs, pp_has_bc(cfg.kind) ? bc[qi] : 0, cfg)) break;
+      if (!pp_same_run(rs, rbc, qs, pp_has_bc(cfg.kind) ? bc[qi] : 0, cfg)) { ended = true; break; }
       ++dups;
       if (cfg.inmem || q.mapq > r.mapq) { r = q; wi = qi; }
     }
+    if (!ended && t < n) {  // a pile-up (PCR duplicates at a hot spot run to 10^5 records): a wave takes the run, k_pp_select_long
+      long_list[atomicAdd(long_cnt, 1u)] = j;
+      line_len[j] = 0;
+      return;
+    }
   }
-  if ((!bulk_done && (int)r.mapq < cfg.mapq_thr) || r.rid >= cfg.n_seq) { line_len[j] = 0; return; }
-  if (cfg.tn5) pp_tn5(r, cfg.kind);
-  if (dups > 255) dups = 255;
-  const uint32_t nm = name_off[r.rid + 1] - name_off[r.rid];
-  uint32_t len;
-  if (pp_tagalign(cfg.kind)) {
-    // two lines (mapping_writer.cc:84-117, 138-168): the + read's and the - read's alignment; bulk data
-    // prints num_dups on the second line, single-cell data prints neither barcode nor num_dups
-    const uint32_t pe = r.start + r.pal, ne = r.start + r.len, ns = ne - r.nal;
-    len = 2 * (nm + 1 + 2 + pp_digits(r.mapq) + 1 + 1 + 1) + pp_digits(r.start) + 1 + pp_digits(pe) + 1 + pp_digits(ns) + 1 + pp_digits(ne) + 1;
-    if (cfg.kind == CMGPU_TEXT_TAGALIGN_PE) len += 1 + pp_digits(dups);
-  } else {
-    len = nm + 1 + pp_digits(r.start) + 1 + pp_digits(r.start + r.len) + 1;
-    if (cfg.kind == CMGPU_TEXT_BED_PE_BC || cfg.kind == CMGPU_TEXT_BED_SE_BC) len += cfg.bc_len + 1 + pp_digits(dups) + 1;  // chr start end barcode dups
-    else if (cfg.kind == CMGPU_TEXT_TAGALIGN_SE_BC) len += 2 + pp_digits(r.mapq) + 2 + 1;     // chr start end N mapq strand (mapping_writer.cc:26-34)
-    else len += 2 + pp_digits(r.mapq) + 3 + pp_digits(dups) + 1;                              // chr start end N mapq strand dups
+  pp_finish(j, r, wi, dups, bulk_done, cfg, name_off, win, dups_out, line_len);
+}
+
+// Duplicate runs longer than PP_RUN_SERIAL, one wave each: the lanes test 64 records per step for membership (the run is the
+// contiguous prefix of members), keep the first record of maximal MAPQ (low-memory rule: a later record replaces the survivor
+// only with a strictly larger MAPQ, mapping_writer.h:252-262) or the run's last record (in-memory rule), and lane 0 finishes
+// the position as k_pp_select does.  Not used for bulk-level de-duplication of single-cell data (barcode groups inside a run).
+__global__ __launch_bounds__(64) void k_pp_select_long(const uint8_t *__restrict__ store, const uint64_t *__restrict__ bc,
+                                                       const uint32_t *__restrict__ idx, uint32_t n, PpCfg cfg,
+                                                       const uint32_t *__restrict__ name_off, uint32_t *__restrict__ win,
+                                                       uint32_t *__restrict__ dups_out, uint64_t *__restrict__ line_len,
+                                                       const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_cnt) {
+  const uint32_t lane = threadIdx.x, cnt = *long_cnt;
+  for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+    const uint32_t j = long_list[e];
+    const uint32_t wi0 = idx[j];
+    const PpRec r0 = pp_load(store, wi0);
+    const uint64_t rbc = pp_has_bc(cfg.kind) ? bc[wi0] : 0;
+    PpRec rs = r0;
+    if (cfg.inmem && cfg.tn5) pp_tn5(rs, cfg.kind);
+    int my_mapq = -1;
+    uint32_t my_pos = ~0u, run_end = n;
+    for (uint32_t base = j + 1; base < n; base += 64) {
+      const uint32_t t = base + lane;
+      bool same = false;
+      int qm = -1;
+      if (t < n) {
+        const uint32_t qi = idx[t];
+        PpRec q = pp_load(store, qi), qs = q;
+        if (cfg.inmem && cfg.tn5) pp_tn5(qs, cfg.kind);
+        same = pp_same_run(rs, rbc, qs, pp_has_bc(cfg.kind) ? bc[qi] : 0, cfg);
+        qm = (int)q.mapq;
+      }
+      const unsigned long long m = __ballot(same);
+      const uint32_t pre = m == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);  // members before the first non-member
+      if (lane < pre && qm > my_mapq) { my_mapq = qm; my_pos = t; }
+      if (pre < 64) { run_end = base + pre; break; }
+    }
+    // first record of maximal MAPQ over the lanes
+    for (int off = 32; off > 0; off >>= 1) {
+      const int om = __shfl_down(my_mapq, off, 64);
+      const uint32_t op = __shfl_down(my_pos, off, 64);
+      if (om > my_mapq || (om == my_mapq && op < my_pos)) { my_mapq = om; my_pos = op; }
+    }
+    if (lane == 0) {
+      PpRec r = r0;
+      uint32_t wi = wi0;
+      if (cfg.inmem) { wi = idx[run_end - 1]; r = pp_load(store, wi); }
+      else if (my_mapq > (int)r0.mapq) { wi = idx[my_pos]; r = pp_load(store, wi); }
+      pp_finish(j, r, wi, run_end - j, false, cfg, name_off, win, dups_out, line_len);
+    }
   }
-  win[j] = wi;
-  dups_out[j] = dups;
-  line_len[j] = len;
 }
 
 __device__ __forceinline__ uint8_t *pp_put_u32(uint8_t *p, uint32_t v) {
@@ -496,8 +563,8 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   std::vector<uint32_t> noff(n_sequences + 1, 0);
   std::string blob;
   for (uint32_t i = 0; i < n_sequences; ++i) { blob += names[i]; noff[i + 1] = (uint32_t)blob.size(); }
-  DevBuf d_names, d_noff, k0, k1, v0, v1, tmp, win, dups, llen, loff;
-  auto fail = [&](int rc) { d_names.release(); d_noff.release(); k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
+  DevBuf d_names, d_noff, k0, k1, v0, v1, tmp, win, dups, llen, loff, longs;
+  auto fail = [&](int rc) { longs.release(); d_names.release(); d_noff.release(); k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
                             win.release(); dups.release(); llen.release(); loff.release(); return rc; };
   if (d_names.ensure(blob.size() + 16) || d_noff.ensure(noff.size() * 4) || k0.ensure((size_t)n * 8) || k1.ensure((size_t)n * 8) ||
       v0.ensure((size_t)n * 4) || v1.ensure((size_t)n * 4)) { cm_set_error(c, "out of device memory (post-processing)"); return fail(CMGPU_ENOMEM); }
@@ -534,8 +601,14 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   if (win.ensure((size_t)n * 4) || dups.ensure((size_t)n * 4) || llen.ensure(((size_t)n + 1) * 8) || loff.ensure(((size_t)n + 1) * 8)) {
     cm_set_error(c, "out of device memory (post-processing)"); return fail(CMGPU_ENOMEM);
   }
+  // heads of long duplicate runs: at most n / PP_RUN_SERIAL of them, + the counter
+  if (longs.ensure(((size_t)n / PP_RUN_SERIAL + 2) * 4)) { cm_set_error(c, "out of device memory (post-processing)"); return fail(CMGPU_ENOMEM); }
+  uint32_t *long_cnt = (uint32_t *)longs.p, *long_list = long_cnt + 1;
+  if (hipMemsetAsync(long_cnt, 0, 4, s) != hipSuccess) { cm_set_error(c, "memset failed"); return fail(CMGPU_EHIP); }
   hipLaunchKernelGGL(k_pp_select, g, b, 0, s, store, bc, (const uint32_t *)va, n, cfg, (const uint32_t *)d_noff.p, (uint32_t *)win.p,
-                     (uint32_t *)dups.p, (uint64_t *)llen.p);
+                     (uint32_t *)dups.p, (uint64_t *)llen.p, long_list, long_cnt);
+  hipLaunchKernelGGL(k_pp_select_long, dim3(1024), dim3(64), 0, s, store, bc, (const uint32_t *)va, n, cfg, (const uint32_t *)d_noff.p,
+                     (uint32_t *)win.p, (uint32_t *)dups.p, (uint64_t *)llen.p, (const uint32_t *)long_list, (const uint32_t *)long_cnt);
   if (hipMemsetAsync((uint64_t *)llen.p + n, 0, 8, s) != hipSuccess) { cm_set_error(c, "memset failed"); return fail(CMGPU_EHIP); }
   size_t tb = 0, tb2 = 0;
   (void)rocprim::exclusive_scan(nullptr, tb, (const uint64_t *)llen.p, (uint64_t *)loff.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), s);

@@ -106,7 +106,8 @@ def _random_records(rng, n, n_seq, span, bc=False):
 
 @pytest.mark.parametrize("kind,n_seq,span,dedup,lowmem,tn5,q", [
     (0, 3, 40, 1, 1, 1, 30), (0, 3, 40, 1, 0, 1, 0), (0, 70000, 3, 1, 1, 0, 1), (0, 5, 100000, 0, 1, 0, 0),
-    (0, 1, 1, 1, 1, 0, 0), (0, 1, 1, 1, 0, 1, 0),
+    (0, 1, 1, 1, 1, 0, 0), (0, 1, 1, 1, 0, 1, 0),  # pile-ups: runs of ~15 000 duplicates (k_pp_select_long)
+    (1, 1, 1, 1, 1, 0, 0), (1, 1, 1, 1, 0, 0, 30), (2, 1, 1, 1, 1, 1, 0), (2, 1, 1, 1, 0, 0, 0), (0, 2, 3, 1, 1, 1, 3), (2, 2, 2, 1, 0, 1, 1),
     (1, 4, 60, 1, 1, 1, 0), (1, 4, 60, 1, 0, 1, 30), (1, 4, 60, 0, 0, 1, 0),
     (2, 4, 30, 1, 1, 1, 0), (2, 4, 30, 1, 0, 1, 30), (2, 4, 30, 0, 1, 0, 0)])
 def test_device_text_equals_host_writer_on_random_records(kind, n_seq, span, dedup, lowmem, tn5, q, tmp_path):
