@@ -85,6 +85,9 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "lanes") {
     if (value < 1 || value > 8) { cm_set_error(c, "lanes: 1..8"); return CMGPU_EINVAL; }
     c->opt_lanes = (int)value;
+  } else if (n == "first_read_id") {  // read id of the resident batch's first pair (device-generated batches start at 0)
+    if (value < 0 || value > 0xffffffffll) { cm_set_error(c, "first_read_id: 0..2^32-1"); return CMGPU_EINVAL; }
+    c->first_read_id = (uint32_t)value;
   } else if (n == "heavy_last") {
     c->opt_heavy_last = (int)value;
   } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate

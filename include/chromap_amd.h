@@ -337,7 +337,10 @@ int cmgpu_gather_sweep(cmgpu_ctx *ctx, uint64_t n, int repeat, int loads_per_lan
  * "probe_pair_prefetch" 0/1, "mm_chunks" 1..8, "prep_kernel" 0/1, "item_limit" (largest dense
  * intermediate array, in entries; batches that need more are mapped in sub-batches), "heavy_wave_max" /
  * "heavy_block_max" / "heavy_big_max" (size classes of the cooperative kernel for long hit lists; -1 on the first:
- * one-lane path), "heavy_last" (reads with long hit lists processed in waves of their own: 0 auto, 1 always, -1 never). */
+ * one-lane path), "heavy_last" (reads with long hit lists processed in waves of their own: 0 auto, 1 always, -1 never),
+ * "lanes" 1..8 (ranges of a batch mapped side by side), "h2d_copy_blocks" / "d2h_copy_blocks" (blocks of the copy kernel
+ * that moves page-locked host memory over the link instead of the copy engine; 0 = hipMemcpyAsync),
+ * "first_read_id" (read id of the resident batch's first pair; device-generated batches start at 0). */
 int cmgpu_set_option(cmgpu_ctx *ctx, const char *name, int64_t value);
 int cmgpu_get_option(const cmgpu_ctx *ctx, const char *name, int64_t *value);
 
