@@ -88,6 +88,8 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "first_read_id") {  // read id of the resident batch's first pair (device-generated batches start at 0)
     if (value < 0 || value > 0xffffffffll) { cm_set_error(c, "first_read_id: 0..2^32-1"); return CMGPU_EINVAL; }
     c->first_read_id = (uint32_t)value;
+  } else if (n == "heavy_mid_max") {  // longest hit list a group of 16 lanes takes (default 64; -1: no such class)
+    c->opt_heavy_mid = (int)value;
   } else if (n == "heavy_last") {
     c->opt_heavy_last = (int)value;
   } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate
@@ -384,7 +386,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
-  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 4 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
+  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 5 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
 #undef ENS
   return CMGPU_OK;
 }
@@ -634,7 +636,12 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
     cm_s3b_heavy_classes(d.hv_max);
     for (int q = 0; q < 3; ++q) if (c->opt_heavy_max[q] > 0 && (uint32_t)c->opt_heavy_max[q] < d.hv_max[q]) d.hv_max[q] = (uint32_t)c->opt_heavy_max[q];
     if (c->opt_heavy_max[0] < 0) d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0;  // everything long goes to the one-lane path
-  } else d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0;
+    d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
+    if (d.hv_mid > 256) d.hv_mid = 256;
+    if (d.hv_max[0] == 0) d.hv_mid = 0;
+    // with the 16-lane groups taking the lists up to hv_mid, a lane keeps the short ones only (16 hits: 256-thread blocks)
+    if (d.hv_mid && c->opt_s3b_cap <= 0 && d.s3b_cap > 16) d.s3b_cap = 16;
+  } else { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0; d.hv_mid = 0; }
   if (c->has_rank) {  // stages from verification on address the reference by rank
     d.rid_rank = (const uint32_t *)c->rid_rank.p;
     d.ref_off = (const uint64_t *)c->ref_off_r.p;
@@ -776,10 +783,10 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     mark(c, "s2_probe");
   }
   // S3: hit counts -> offsets -> candidates
-  HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 16, s));
+  HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 32, s));
   cm_launch_k_s3a_count(d, n2, s);
-  uint32_t n_heavy[4] = {0, 0, 0, 0};
-  HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, 16, hipMemcpyDeviceToHost, s));
+  uint32_t n_heavy[5] = {0, 0, 0, 0, 0};  // classes 0..3 by size, 4: the short lists of the 16-lane groups
+  HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, 20, hipMemcpyDeviceToHost, s));
   unsigned long long hits_total = 0;
   if ((rc = scan_with_total(c, d.hit_tot, d.hit_off, n2, &hits_total))) return rc;
   if (hits_total > limit) return CM_RC_SPLIT;  // 2 x 150 reads on a repeat-rich genome: ~500 hits per read x 8 M reads wraps 2^32
@@ -923,7 +930,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   l->max_read_len = c->max_read_len; l->has_barcodes = c->has_barcodes; l->single = c->single;
   l->sam_slots = c->sam_slots; l->sam_md_cap = c->sam_md_cap;
   l->opt_probe_variant = c->opt_probe_variant; l->opt_mm_chunks = c->opt_mm_chunks; l->opt_prep_kernel = c->opt_prep_kernel;
-  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last;
+  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid;
   for (int q = 0; q < 3; ++q) l->opt_heavy_max[q] = c->opt_heavy_max[q];
   return CMGPU_OK;
 }

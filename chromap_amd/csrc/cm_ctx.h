@@ -134,6 +134,7 @@ struct cmgpu_ctx {
   int opt_s3b_cap = 0;               // 0: by read length (cm_s3b_lane_cap)
   int opt_lanes = 1;                 // sub-batches of one cmgpu_map_* call mapped side by side (own streams and intermediates each)
   std::vector<cmgpu_ctx *> lanes;    // the further lanes' contexts (views of this context's index, reference, batch and record arrays)
+  int opt_heavy_mid = 0;             // 0: 64 hits; -1: no 16-lane class
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
   int opt_heavy_last = 0;            // heavy-last processing order: 0 auto, 1 always, -1 never
   std::vector<uint32_t> h_rank;  // --chr-order: rank of every index rid (host copy of rid_rank)

@@ -341,11 +341,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
     tot = d.hit_tot[i];
   }
   // one atomic per wave and class (millions of lanes adding to one counter serialise at ~10 ns each)
-  const uint32_t cls = tot <= d.s3b_cap ? 4u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : 3u;
-  if (__ballot(cls < 4u) == 0) return;
+  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : 3u;
+  if (__ballot(cls < 5u) == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-  for (uint32_t c = 0; c < 4; ++c) {
+  for (uint32_t c = 0; c < 5; ++c) {
     const unsigned long long m = __ballot(cls == c);
     if (m == 0) continue;
     uint32_t base = 0;
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_candidates(CmDev d, uint32_t n
 // ---------------------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ void cm_group_sync() {
-  if (G == 64) {
-    // one wave: its LDS operations execute in order; make them complete and keep the compiler from moving accesses across
+  if (G <= 64) {
+    // a wave or a part of one: its LDS operations execute in order; make them complete and keep the compiler from moving accesses across
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -415,6 +415,30 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t 
   cm_group_sync<G>();
   // ---- expand
   uint32_t my_pos = 0;
+  if (G < 64) {
+    // short lists of many minimizers (2 x 150 reads: ~37 hits of ~34 minimizers): a lane per minimizer, its few occurrences too
+    for (uint32_t mi = t; mi < n; mi += G) {
+      const uint8_t kind = d.pr_kind[b + mi];
+      if (kind == CM_PR_MISS) continue;
+      const uint64_t val = d.pr_val[b + mi];
+      const uint32_t ps = d.mm_ps[b + mi];
+      bool same;
+      if (kind == CM_PR_SINGLE) {
+        const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
+        S[atomicAdd(&ctr[0], 1u)] = same ? cp : (cp | SB);
+        my_pos += same ? 1u : 0u;
+        continue;
+      }
+      const uint32_t nocc = (uint32_t)val;
+      if (nocc >= maxf) continue;
+      const uint64_t *o = d.occ + (uint32_t)(val >> 32);
+      for (uint32_t oi = 0; oi < nocc; ++oi) {
+        const uint64_t cp = cm_cand_from_hit(o[oi], ps, d.p.k, &same);
+        S[atomicAdd(&ctr[0], 1u)] = same ? cp : (cp | SB);
+        my_pos += same ? 1u : 0u;
+      }
+    }
+  } else
   for (uint32_t mi = 0; mi < n; ++mi) {
     const uint8_t kind = d.pr_kind[b + mi];
     if (kind == CM_PR_MISS) continue;
@@ -982,7 +1006,8 @@ void cm_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *tmp, h
 __global__ __launch_bounds__(CM_BLOCK) void k_hv_flags(CmDev d, uint32_t n_pairs, uint32_t *__restrict__ fr, uint32_t *__restrict__ fp) {
   const uint32_t p = blockIdx.x * CM_BLOCK + threadIdx.x;
   if (p >= n_pairs) return;
-  const uint32_t a = d.hit_tot[2 * p] > d.s3b_cap ? 1u : 0u, b = d.hit_tot[2 * p + 1] > d.s3b_cap ? 1u : 0u;
+  const uint32_t lim = d.hv_mid > d.s3b_cap ? d.hv_mid : d.s3b_cap;
+  const uint32_t a = d.hit_tot[2 * p] > lim ? 1u : 0u, b = d.hit_tot[2 * p + 1] > lim ? 1u : 0u;
   fr[2 * p] = a; fr[2 * p + 1] = b;
   fp[p] = a | b;
 }
@@ -1069,6 +1094,11 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s)
   if (n_cls[1]) { const uint32_t P = pow2(d.hv_max[1]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], P); }
   if (n_cls[2]) { const uint32_t P = pow2(d.hv_max[2]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], P); }
   if (n_cls[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((n_cls[3] + 63) / 64), dim3(64), 0, s, d, l3, n_cls[3]);
+  if (n_cls[4]) {  // groups of 16 lanes, 16 reads per block
+    const uint32_t *l4 = d.hv_list + 4 * (size_t)d.hv_stride;
+    const uint32_t P = pow2(d.hv_mid), gpb = CM_BLOCK / 16;
+    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((n_cls[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, l4, n_cls[4], P);
+  }
 }
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
   if (!n) return;

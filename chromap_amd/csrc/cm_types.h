@@ -109,7 +109,8 @@ struct CmDev {
   uint32_t *ncp, *ncn;  // [2n] candidates after GenerateCandidates
   // ---- reads whose hit list does not fit a lane's LDS slots, by size class (k_s3a_count fills, k_s3b_heavy consumes):
   //      hv_cnt[c] reads of class c listed at hv_list + c * hv_stride; class 0: <= hv_max[0] hits (a wave each),
-  //      1: <= hv_max[1] (a block each), 2: <= hv_max[2] (a block, large LDS), 3: longer (one lane, in global memory)
+  //      1: <= hv_max[1] (a block each), 2: <= hv_max[2] (a block, large LDS), 3: longer (one lane, in global memory),
+  //      4: <= hv_mid (a group of 16 lanes each, four reads per wave)
   const uint32_t *perm_reads, *perm_pairs;  // heavy-last processing order of reads / pairs, or nullptr (identity)
   uint32_t *hv_cnt, *hv_list;
   // reads that supplement their candidates from the mate (S4a/S4b), packed in CM_RS_SEGS list segments:
@@ -119,6 +120,7 @@ struct CmDev {
   // stage looks at them: srt_cnt[0] items (read << 1 | strand) at srt_list, srt_cnt[1] the work cursor
   uint32_t *srt_cnt, *srt_list;
   uint32_t hv_stride, s3b_cap, hv_max[3];
+  uint32_t hv_mid;  // class 4: lists of s3b_cap < hits <= hv_mid go to groups of 16 lanes (k_s3b_heavy<16>); 0 = no such class
   // ---- rescue / merged candidates
   uint8_t *aug;         // [2n] augment flag
   int32_t *res_neg;     // [2n] result of the search on the - strand (driven by mate + candidates)

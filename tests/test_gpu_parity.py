@@ -174,6 +174,8 @@ HEAVY_SETTINGS = {
     "block": {"heavy_wave_max": 20, "heavy_last": 1},                      # ... a block each
     "block_big_lds": {"heavy_wave_max": 18, "heavy_block_max": 19},        # ... a block with the large LDS allocation
     "one_lane": {"heavy_wave_max": -1, "heavy_last": -1},                  # ... the sequential path in global memory
+    "groups_of_16": {"heavy_mid_max": 256, "s3b_lane_cap": 4},             # ... four reads per wave (lists up to 256 hits here)
+    "no_groups": {"heavy_mid_max": -1},                                    # ... without that class: a lane up to its LDS slots, waves beyond
 }
 
 
