@@ -81,7 +81,37 @@ CM_HD uint64_t cm_hash64_split(uint32_t lo, uint32_t hi, uint32_t hm) {
   }
   return ((uint64_t)hi << 32) | lo;
 }
+// The same when at most two bits lie above the low word (k = 17, the default): the odd multipliers are 1 modulo 4, so the
+// high bits pass through the multiplications unchanged (their own products -- two quarter-rate 32-bit multiplies per call in
+// the general form -- disappear), their right shifts vanish, and their left shifts by 21 and 31 fall outside the mask.
+CM_HD uint64_t cm_hash64_split2(uint32_t lo, uint32_t hi, uint32_t hm) {
+  {
+    const uint64_t t = (uint64_t)(uint32_t)~lo + (uint64_t)(uint32_t)(lo << 21);
+    hi = ((~hi) + (lo >> 11) + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  lo ^= (lo >> 24) | (hi << 8);
+  {
+    const uint64_t t = (uint64_t)lo * 265u;
+    hi = (hi + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  lo ^= (lo >> 14) | (hi << 18);
+  {
+    const uint64_t t = (uint64_t)lo * 21u;
+    hi = (hi + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  lo ^= (lo >> 28) | (hi << 4);
+  {
+    const uint64_t t = (uint64_t)lo + (uint64_t)(uint32_t)(lo << 31);
+    hi = (hi + (lo >> 1) + (uint32_t)(t >> 32)) & hm;
+    lo = (uint32_t)t;
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
 CM_HD uint64_t cm_hash64_k(uint64_t key, int k, uint64_t mask) {
+  if (2 * k == 34) return cm_hash64_split2((uint32_t)key, (uint32_t)(key >> 32), 3u);
   if (2 * k > 32 && 2 * k <= 52) return cm_hash64_split((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(mask >> 32));
   return cm_hash64(key, mask);
 }
