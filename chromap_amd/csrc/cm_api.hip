@@ -748,16 +748,14 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       HIPCHECK(c, hipEventRecord(c->chunk_ev[CM_MM_CHUNKS], c->stream2));
       HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[CM_MM_CHUNKS], 0));
       cm_launch_k_probe_reduce(c->partials.p, part_off[n_chunks], d.stats + CM_ST_PROBE_STEPS, s);
-      unsigned long long tot = 0;
-      HIPCHECK(c, hipMemcpyAsync(&tot, c->mm_cursor.p, 8, hipMemcpyDeviceToHost, s));
+      // one read-back: the marks (cursor after every chunk; the last one is the total)
+      unsigned long long hm[CM_MM_CHUNKS + 1];
+      HIPCHECK(c, hipMemcpyAsync(hm, c->mm_marks.p, ((size_t)n_chunks + 1) * 8, hipMemcpyDeviceToHost, s));  // (not the null stream: lanes run side by side)
       HIPCHECK(c, cm_stream_sync(s));
+      const unsigned long long tot = hm[n_chunks];
       bool grid_short = false;  // a chunk emitted more than its probe grid covers (cannot happen on attempt 1)
-      if (attempt == 0 && tot <= cap) {
-        unsigned long long hm[CM_MM_CHUNKS + 1];
-        HIPCHECK(c, hipMemcpyAsync(hm, c->mm_marks.p, (CM_MM_CHUNKS + 1) * 8, hipMemcpyDeviceToHost, s));  // (not the null stream: lanes run side by side)
-        HIPCHECK(c, cm_stream_sync(s));
+      if (attempt == 0 && tot <= cap)
         for (uint32_t ch = 0; ch < n_chunks; ++ch) grid_short = grid_short || hm[ch + 1] - hm[ch] > max_entries[ch];
-      }
       if (tot <= cap && !grid_short) { n_mm = (uint32_t)tot; break; }
       if (attempt == 1) { cm_set_error(c, "minimizer arrays overflowed twice"); return CMGPU_ECAPACITY; }
       cap = bound;  // rerun with the worst-case sizes
