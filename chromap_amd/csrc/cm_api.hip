@@ -772,13 +772,33 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     if (c->mm_hash.ensure((size_t)n_mm * 8 + 8) || c->mm_ps.ensure((size_t)n_mm * 4 + 4) || c->pr_val.ensure((size_t)n_mm * 8 + 8) ||
         c->pr_kind.ensure((size_t)n_mm + 4)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
     cm_fill_dev_range(c, d, rlo, rhi);
-    // S1b: minimizers written to their dense positions
-    cm_launch_k_mm_fill(d, n, c->max_read_len, s);
-    mark(c, "s1b_minimizers");
-    // S2: index probe, one launch (k_probe: the kernel the roofline is measured on, cmgpu_probe_bench)
-    if (c->partials.ensure(cm_probe_partial_words(n_mm) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
-    cm_launch_k_probe(d.bkt, d.bmask, d.mm_hash, d.pr_val, d.pr_kind, n_mm, c->partials.p, d.stats + CM_ST_PROBE_STEPS, s, c->opt_probe_variant);
-    mark(c, "s2_probe");
+    // S1b + S2: the minimizers are written to their dense positions chunk by chunk, and the index probe of a chunk (second
+    // stream) runs under the next chunk's fill pass -- the offsets are known, so a chunk's minimizer range is
+    // [mm_off[2 lo], mm_off[2 hi]) (k_mm_marks; read back once to size the probe grids)
+    const uint32_t n_chunks = n >= (1u << 20) ? (uint32_t)c->opt_mm_chunks : (n >= (1u << 17) ? 2 : 1);
+    uint32_t lo[CM_MM_CHUNKS + 1];
+    for (uint32_t ch = 0; ch <= n_chunks; ++ch) lo[ch] = (uint32_t)((uint64_t)n * ch / n_chunks);
+    if (c->mm_marks.ensure((CM_MM_CHUNKS + 1) * 8)) { cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM; }
+    unsigned long long *marks = (unsigned long long *)c->mm_marks.p;
+    unsigned long long hm[CM_MM_CHUNKS + 1];
+    cm_launch_k_mm_marks(d.mm_off, lo, n_chunks + 1, marks, s);
+    HIPCHECK(c, hipMemcpyAsync(hm, marks, ((size_t)n_chunks + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(c, cm_stream_sync(s));
+    uint32_t part_off[CM_MM_CHUNKS + 1];
+    part_off[0] = 0;
+    for (uint32_t ch = 0; ch < n_chunks; ++ch) part_off[ch + 1] = part_off[ch] + cm_probe_range_blocks(hm[ch + 1] - hm[ch], c->opt_probe_variant);
+    if (c->partials.ensure(((size_t)part_off[n_chunks] + 1) * 8 + cm_stats_partial_words(n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
+    HIPCHECK(c, hipMemsetAsync(d.stats + CM_ST_PROBE_STEPS, 0, 2 * 8, s));
+    for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+      cm_launch_k_mm_fill(d, lo[ch], lo[ch + 1], c->max_read_len, s);
+      HIPCHECK(c, hipEventRecord(c->chunk_ev[ch], s));
+      HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[ch], 0));
+      cm_launch_k_probe_range(d, marks + ch, hm[ch + 1] - hm[ch], n_mm, (uint2 *)c->partials.p + part_off[ch], c->stream2, c->opt_probe_variant);
+    }
+    HIPCHECK(c, hipEventRecord(c->chunk_ev[CM_MM_CHUNKS], c->stream2));
+    HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[CM_MM_CHUNKS], 0));
+    cm_launch_k_probe_reduce(c->partials.p, part_off[n_chunks], d.stats + CM_ST_PROBE_STEPS, s);
+    mark(c, "s1b_s2_minimizers_probe");
   }
   // S3: hit counts -> offsets -> candidates
   HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 32, s));

@@ -11,7 +11,6 @@
 #include "cm_types.h"
 
 #define CM_MAX_EVENTS 32
-#define CM_MM_CHUNKS 8   // chunks of a batch whose index probe overlaps the next chunk's minimizer pass
 #define CM_MAX_W_HOST 32
 
 struct DevBuf {

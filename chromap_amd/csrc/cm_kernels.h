@@ -7,7 +7,8 @@
 
 #define CM_DECL_LAUNCH(kname) void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s);
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
-void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
+void cm_launch_k_mm_fill(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, hipStream_t s);
+void cm_launch_k_mm_marks(const uint32_t *mm_off, const uint32_t *lo, uint32_t n_marks, unsigned long long *marks, hipStream_t s);
 bool cm_prep_mm_supported(const CmDev &d, uint32_t max_read_len);
 bool cm_prep_flat_supported(const CmDev &d, uint32_t max_read_len, uint32_t tile_reads);
 void cm_launch_k_prep_flat(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t tile_reads, uint32_t mm_cap,

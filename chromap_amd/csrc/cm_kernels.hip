@@ -65,9 +65,9 @@ __global__ void k_prep_count(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
 }
 
 // S1 fill: same staging, minimizers written directly to their dense positions
-__global__ void k_mm_fill(CmDev d, uint32_t n_pairs, uint32_t lds_half) {
+__global__ void k_mm_fill(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of this launch's pair range */, uint32_t lds_half) {
   const uint32_t PB = blockDim.x >> 1;
-  const uint32_t p0 = blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
+  const uint32_t p0 = pair_lo + blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
   const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp;
   const CmStaged s = cm_stage_pairs(d, p0, p1, pair, lds_half);
   if (pair < p1) cm_s1_fill(d, 2 * pair + (t < PB ? 0 : 1), t < PB ? s.m0 : s.m1);
@@ -1237,12 +1237,23 @@ void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_
   const uint32_t pb = threads / 2;
   hipLaunchKernelGGL(k_prep_count, dim3((n_pairs + pb - 1) / pb), dim3(threads), 2 * half, s, d, n_pairs, half);
 }
-void cm_launch_k_mm_fill(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s) {
-  if (!n_pairs) return;
+// pairs [pair_lo, pair_hi)
+void cm_launch_k_mm_fill(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, hipStream_t s) {
+  if (pair_hi <= pair_lo) return;
   uint32_t threads, half;
   staging_geometry(max_read_len, &threads, &half);
   const uint32_t pb = threads / 2;
-  hipLaunchKernelGGL(k_mm_fill, dim3((n_pairs + pb - 1) / pb), dim3(threads), 2 * half, s, d, n_pairs, half);
+  hipLaunchKernelGGL(k_mm_fill, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), 2 * half, s, d, pair_lo, pair_hi, half);
+}
+// minimizer ranges of pair chunks from the scanned offsets: marks[ch] = mm_off[2 * lo[ch]] (mm_off has 2 n + 1 entries)
+struct CmChunkLo { uint32_t lo[CM_MM_CHUNKS + 1]; };
+__global__ void k_mm_marks(const uint32_t *__restrict__ mm_off, CmChunkLo cl, uint32_t n_marks, unsigned long long *__restrict__ marks) {
+  if (threadIdx.x < n_marks) marks[threadIdx.x] = mm_off[2 * (size_t)cl.lo[threadIdx.x]];
+}
+void cm_launch_k_mm_marks(const uint32_t *mm_off, const uint32_t *lo, uint32_t n_marks, unsigned long long *marks, hipStream_t s) {
+  CmChunkLo cl;
+  for (uint32_t i = 0; i < n_marks && i <= CM_MM_CHUNKS; ++i) cl.lo[i] = lo[i];
+  hipLaunchKernelGGL(k_mm_marks, dim3(1), dim3(64), 0, s, mm_off, cl, n_marks, marks);
 }
 void cm_launch_k_s0b_barcode(const CmDev &d, uint32_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_s0b_barcode, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);
