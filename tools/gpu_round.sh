@@ -4,6 +4,7 @@ T=${1:-r02f}
 mkdir -p gpurun_out/$T
 timeout 1800 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/$T/pytest.log
 tail -8 gpurun_out/$T/pytest.log
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' 2>&1 | tail -1
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.log; echo "bench rc $?"
 tail -3 gpurun_out/$T/bench_default.log
 python - <<PY
