@@ -182,7 +182,6 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
   p.sam = params->output_format == CMGPU_FORMAT_SAM ? 1 : 0;
-  if (p.sam && p.split) { cm_set_error(c, "--SAM with split alignment is not supported"); return CMGPU_EINVAL; }
   if (params->output_format != 0 && params->output_format != CMGPU_FORMAT_SAM) { cm_set_error(c, "unknown output_format"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipStreamCreate(&c->stream));
   HIPCHECK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));  // same priority as `stream`: a probe stream of higher or lower

@@ -353,7 +353,6 @@ static Args parse(int argc, char **argv) {
   if (a.p.max_num_best_mappings < 1) die("-n must be at least 1");
   if (a.p.max_num_best_mappings > 64) die("-n above 64 is outside this build (64 record slots per read at most)");
   if (a.out_sam) {
-    if (a.p.split_alignment) die("--SAM with split alignment is outside this build");
     if (a.p.max_num_best_mappings > 1) die("--SAM with -n > 1 is outside this build");
     a.p.output_format = CMGPU_FORMAT_SAM;
   }

@@ -1939,7 +1939,9 @@ CM_HD uint32_t cm_draft_strand_split(const CmDev &d, const uint8_t *read, uint32
       } else if (num_errors == bst.min_err) bst.n_best++;
       else if (num_errors == bst.second_err) bst.n_second++;
       else if (num_errors < bst.second_err) { bst.n_second = 1; bst.second_err = num_errors; }
-      dp[nd] = strand == 0 ? cp[ci] - (uint64_t)e + (uint64_t)(int64_t)mep : cp[ci] - (uint64_t)(int64_t)gap_beginning;
+      // - strand: --SAM keeps the non-split position rule (draft_mapping_generator.cc:535-547)
+      dp[nd] = strand == 0 ? cp[ci] - (uint64_t)e + (uint64_t)(int64_t)mep
+                           : (d.p.sam ? cp[ci] - (uint64_t)L + 1 - (uint64_t)e + (uint64_t)(int64_t)mep : cp[ci] - (uint64_t)(int64_t)gap_beginning);
       de[nd] = (int16_t)num_errors;  // -(matched length) in split mode
       ds[nd] = (uint32_t)(((actual & 0xff) << 24) | ((gap_beginning & 0xff) << 16) | (rml & 0xffff));
       ++nd;
@@ -2155,8 +2157,11 @@ CM_HD CmSpan cm_ref_start_end(const CmDev &d, uint64_t dpos, int nerr, int stran
 // W1T: compile-time window size (>= w + 1).
 // ---------------------------------------------------------------------------------------
 template <int W1T>
+// The target is text[toff .. toff + L) of the read as mapped (neg: reverse complement of read[0 .. Lfull)); Lfull < 0: the
+// whole read (Lfull = L, toff = 0).
 CM_HD int cm_ksw_sg3(const uint8_t *query, const uint8_t *read, int L, bool neg, int e, uint32_t *z, uint64_t zstride,
-                     uint32_t *cigar, int *n_cigar, int *start, int *end) {
+                     uint32_t *cigar, int *n_cigar, int *start, int *end, int Lfull = -1, int toff = 0) {
+  if (Lfull < 0) Lfull = L;
   const int NEG = -0x40000000, o_del = 6, e_del = 1, e_ins = 1, oe_del = 7, oe_ins = 7;
   const int w = 2 * e + 1, w1 = w + 1, qlen = L + 2 * e;
   constexpr int ZW = (W1T + 3) / 4;
@@ -2167,7 +2172,7 @@ CM_HD int cm_ksw_sg3(const uint8_t *query, const uint8_t *read, int L, bool neg,
   for (int i = 0; i < L; ++i) {
     int f = NEG;
     int h1 = i == 0 ? -(o_del + e_del) : NEG;
-    const uint32_t tc = cm_text_code(read, L, i, neg);
+    const uint32_t tc = cm_text_code(read, Lfull, toff + i, neg);
     const int cnt = i == L - 1 ? w1 - 1 : w1;
     uint32_t packed = 0;
 #pragma unroll
@@ -2252,9 +2257,9 @@ CM_HD uint32_t cm_put_dec(uint8_t *dst, uint32_t cap, uint32_t at, uint32_t v) {
 
 // GenerateNMAndMDTag (alignment.cc:85-139); ref points at the mapping start, the read is taken as mapped
 CM_HD uint32_t cm_nm_and_md(const uint8_t *ref, const uint8_t *read, int L, bool neg, const uint32_t *cigar, int n_cigar,
-                            uint8_t *md, uint32_t md_cap, uint32_t *md_len) {
+                            uint8_t *md, uint32_t md_cap, uint32_t *md_len, int toff = 0) {
   uint32_t nm = 0, matches = 0, at = 0;
-  int rp = 0, fp = 0;
+  int rp = toff, fp = 0;  // L = full read length; the alignment starts at text[toff]
   for (int ci = 0; ci < n_cigar; ++ci) {
     const uint32_t op = cigar[ci] & 0xfu, len = cigar[ci] >> 4;
     if (op == 0) {
@@ -2301,6 +2306,61 @@ CM_HD CmSpan cm_ref_start_end_sam(const CmDev &d, uint32_t pair, uint32_t slot, 
   s.rid = rid;
   s.ref_start = vw + (uint32_t)st;
   s.ref_end = vw + (uint32_t)en - 1;
+  return s;
+}
+
+// GetRefStartEndPositionForReadFromMapping, split + SAM branches (mapping_generator.h:657-761 for +, 806-850 for -): ksw on
+// the aligned part of the read (the split site pulled in by 3e when the read was cut, :711-717), AdjustGapBeginning extending
+// the first / last M of the CIGAR over the matching bases of the gap (alignment.cc:24-83), NM / MD over the extended
+// alignment.  The window start is the one of the unshortened part, and the - strand hands AdjustGapBeginning reference
+// coordinates without read_start_site -- both as the reference has them.
+CM_HD CmSpan cm_ref_start_end_split_sam(const CmDev &d, uint32_t pair, uint32_t slot, uint64_t dpos, uint32_t split_word, int strand,
+                                        const uint8_t *read, int full_len, CmSamAln *aln) {
+  const int e = d.p.e;
+  const uint32_t rid = (uint32_t)(dpos >> 32), ref_pos = (uint32_t)dpos;
+  const uint32_t rl = d.ref_len[rid];
+  const uint8_t *ref = d.ref + d.ref_off[rid];
+  int split_site = (int)(split_word & 0xffff);
+  int gap_beginning = (int)((split_word >> 16) & 0xff);
+  int read_length = split_site - gap_beginning;
+  uint32_t vw = ref_pos + 1 > (uint32_t)(read_length + e) ? ref_pos + 1 - (uint32_t)read_length - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)read_length;
+  if (split_site < full_len && split_site > 3 * e) split_site -= 3 * e;
+  read_length = split_site - gap_beginning;
+  uint32_t *cigar = d.sam_cigar + (uint64_t)slot * CM_SAM_CIGAR_CAP;
+  int n_cigar = 0, st = 0, en = 0, sc;
+  uint32_t md_len = 0;
+  CmSpan s;
+  s.rid = rid;
+  if (strand == 0) {
+    if (2 * e + 2 <= 18) sc = cm_ksw_sg3<18>(ref + vw, read, read_length, false, e, d.sam_z + pair, d.n_pairs, cigar, &n_cigar, &st, &en, full_len, gap_beginning);
+    else sc = cm_ksw_sg3<32>(ref + vw, read, read_length, false, e, d.sam_z + pair, d.n_pairs, cigar, &n_cigar, &st, &en, full_len, gap_beginning);
+    if (gap_beginning > 0) {
+      const int rs = (int)vw + st;
+      const int nrs = cm_adjust_gap_beginning(0, ref, rl, read, full_len, false, 0, &gap_beginning, read_length - 1, rs, (int)vw + en - 1);
+      if (n_cigar > 0 && (cigar[0] & 0xfu) == 0) cigar[0] += (uint32_t)(rs - nrs) << 4;
+      st = nrs - (int)vw;
+    }
+    aln->nm = cm_nm_and_md(ref + vw + st, read, full_len, false, cigar, n_cigar, d.sam_md + (uint64_t)slot * d.sam_md_cap, d.sam_md_cap, &md_len, gap_beginning);
+    s.ref_start = vw + (uint32_t)st;
+    s.ref_end = vw + (uint32_t)en - 1;
+  } else {
+    const int rss = full_len - split_site;  // read_start_site
+    if (2 * e + 2 <= 18) sc = cm_ksw_sg3<18>(ref + vw + rss, read, read_length, true, e, d.sam_z + pair, d.n_pairs, cigar, &n_cigar, &st, &en, full_len, rss);
+    else sc = cm_ksw_sg3<32>(ref + vw + rss, read, read_length, true, e, d.sam_z + pair, d.n_pairs, cigar, &n_cigar, &st, &en, full_len, rss);
+    if (gap_beginning > 0) {
+      const int re = (int)vw + en - 1;
+      const int nre = cm_adjust_gap_beginning(1, ref, rl, read, full_len, true, rss, &gap_beginning, read_length - 1, (int)vw + st, re);
+      if (n_cigar > 0 && (cigar[n_cigar - 1] & 0xfu) == 0) cigar[n_cigar - 1] += (uint32_t)(nre - re) << 4;
+      en = nre + 1 - (int)vw - rss;
+    }
+    aln->nm = cm_nm_and_md(ref + vw + rss + st, read, full_len, true, cigar, n_cigar, d.sam_md + (uint64_t)slot * d.sam_md_cap, d.sam_md_cap, &md_len, rss);
+    s.ref_start = vw + (uint32_t)rss + (uint32_t)st;
+    s.ref_end = vw + (uint32_t)rss + (uint32_t)en - 1;
+  }
+  aln->n_cigar = (uint32_t)n_cigar;
+  aln->md_len = md_len;
+  aln->overflow = sc == -1 || md_len > d.sam_md_cap;
   return s;
 }
 
@@ -2564,6 +2624,7 @@ CM_HD uint32_t cm_count_best_draft(const CmDev &d, uint32_t r, int strand, int w
 // (orientation pe.f_dir, draft indices pe.f_i1 / pe.f_i2) (mapping_generator.h:487-653,
 // mapping_generator.cc:169-210 with the default identity rid ranks, chromap.cc:867-877).
 // Record layout = cmgpu_pairs_record (24 bytes).
+template <bool SAM = false>
 CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe, uint32_t nth = 0) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   const int o = (int)pe.f_dir, s1 = cm_split_s1(o), s2 = cm_split_s2(o);
@@ -2572,8 +2633,15 @@ CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe, u
   const int e1 = cm_d_err(d, r1, s1)[pe.f_i1], e2 = cm_d_err(d, r2, s2)[pe.f_i2];
   const uint32_t w1 = (d.dsplit + d.m_off[r1] + (s1 ? d.ncp[r1] + d.resc_p[r1] : 0))[pe.f_i1];
   const uint32_t w2 = (d.dsplit + d.m_off[r2] + (s2 ? d.ncp[r2] + d.resc_p[r2] : 0))[pe.f_i2];
-  const CmSpan a = cm_ref_start_end_split(d, dp1, w1, s1, cm_read_ptr(d, r1), (int)len1);
-  const CmSpan b = cm_ref_start_end_split(d, dp2, w2, s2, cm_read_ptr(d, r2), (int)len2);
+  CmSamAln sa1, sa2;
+  CmSpan a, b;
+  if constexpr (SAM) {
+    a = cm_ref_start_end_split_sam(d, pair, r1, dp1, w1, s1, cm_read_ptr(d, r1), (int)len1, &sa1);
+    b = cm_ref_start_end_split_sam(d, pair, r2, dp2, w2, s2, cm_read_ptr(d, r2), (int)len2, &sa2);
+  } else {
+    a = cm_ref_start_end_split(d, dp1, w1, s1, cm_read_ptr(d, r1), (int)len1);
+    b = cm_ref_start_end_split(d, dp2, w2, s2, cm_read_ptr(d, r2), (int)len2);
+  }
   const uint16_t al1 = (uint16_t)(a.ref_end - a.ref_start + 1), al2 = (uint16_t)(b.ref_end - b.ref_start + 1);
   uint8_t mapq1 = cm_mapq_single_split(d, e1, al1, (int)len1, 2, d.second_err[r1], d.n_best[r1], d.n_second[r1], d.rep_len[r1],
                                        s1 == 0 ? d.fcp[r1] : d.fcn[r1]);
@@ -2585,6 +2653,18 @@ CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe, u
   if (mapq2 > 60) mapq2 = 60;
   const uint8_t mapq = mapq1 < mapq2 ? mapq1 : mapq2;  // force_mapq is -1: no supplement in split mode
   const uint8_t is_unique = (pe.n_best == 1 || d.n_best[r1] == 1 || d.n_best[r2] == 1) ? 1 : 0;
+  if constexpr (SAM) {  // flags mapping_generator.h:613-631, EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108),
+                        // PairedEndMappingInMemory::GetFragmentLength (mapping_in_memory.h:83-90) whatever the chromosomes
+    const int tlen = s1 == 0 ? (int)(b.ref_end - a.ref_start + 1) : (int)(a.ref_end - b.ref_start + 1);
+    const uint32_t f1 = 3u | (s1 ? 16u : 0u) | (s2 ? 32u : 0u) | 64u, f2 = 3u | (s2 ? 16u : 0u) | (s1 ? 32u : 0u) | 128u;
+    cm_put_sam_record(d, r1, d.first_read_id + pair, a, b.ref_start, (int32_t)b.rid, s1 ? -tlen : tlen, f1, mapq, s1 ? 0 : 1, is_unique, sa1, len1);
+    cm_put_sam_record(d, r2, d.first_read_id + pair, b, a.ref_start, (int32_t)a.rid, s2 ? -tlen : tlen, f2, mapq, s2 ? 0 : 1, is_unique, sa2, len2);
+    const uint64_t slot = (uint64_t)pair * (uint32_t)d.p.max_best + nth;  // the pair counts as one record; its content is the two SAM slots
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(d.rec + slot * 24);
+    o32[0] = d.first_read_id + pair; o32[1] = a.rid; o32[2] = b.rid; o32[3] = a.ref_start; o32[4] = b.ref_start; o32[5] = 0;
+    d.rec_ok[slot] = 1;
+    return;
+  }
   uint8_t st1 = s1 == 0 ? 1 : 0, st2 = s2 == 0 ? 1 : 0;
   int pos1 = (int)(s1 == 0 ? a.ref_start : a.ref_end), pos2 = (int)(s2 == 0 ? b.ref_start : b.ref_end);
   int rid1 = (int)a.rid, rid2 = (int)b.rid;
@@ -2709,7 +2789,7 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
     d.pe_min[pair] = sp.min_sum; d.pe_second[pair] = sp.second_sum;
     d.pe_nbest[pair] = sp.n_best; d.pe_nsecond[pair] = sp.n_second;
     d.pe_first[pair] = sp.f_dir; d.pe_i1[pair] = sp.f_i1; d.pe_i2[pair] = sp.f_i2;
-    if (sp.n_best == 1) cm_emit_pairs_record(d, pair, sp);
+    if (sp.n_best == 1) cm_emit_pairs_record<SAM>(d, pair, sp);
     return;
   }
   for (uint32_t r = r1; r <= r2; ++r) {
@@ -2851,7 +2931,7 @@ CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
     if (d.p.split) {
       CmPe sp;
       cm_split_pairing(d, pair, want, sp);
-      cm_emit_pairs_record(d, pair, sp, t);
+      cm_emit_pairs_record<SAM>(d, pair, sp, t);
       continue;
     }
     if (want > 0) {

@@ -1322,7 +1322,10 @@ static void draft_one_strand_split(const ora_ctx *c, meta_t *m, int strand, cons
         vd_push(&m->pos_map, num_errors, cs->a[ci].position - (uint64_t)e + (uint64_t)(int64_t)mep);
         v64_push(&m->pos_split, (uint64_t)(uint32_t)(((actual & 0xff) << 24) | ((gap_beginning & 0xff) << 16) | (rml & 0xffff)));
       } else {
-        vd_push(&m->neg_map, num_errors, cs->a[ci].position - (uint64_t)(int64_t)gap_beginning); /* :534-537 */
+        if (c->p.output_format == 1) /* --SAM keeps the non-split position rule (draft_mapping_generator.cc:535-547) */
+          vd_push(&m->neg_map, num_errors, cs->a[ci].position - (uint64_t)L + 1 - (uint64_t)e + (uint64_t)(int64_t)mep);
+        else
+          vd_push(&m->neg_map, num_errors, cs->a[ci].position - (uint64_t)(int64_t)gap_beginning); /* :534-537 */
         v64_push(&m->neg_split, (uint64_t)(uint32_t)(((actual & 0xff) << 24) | ((gap_beginning & 0xff) << 16) | (rml & 0xffff)));
       }
     }
@@ -1993,6 +1996,56 @@ static span_t ref_start_end_split(const ora_ctx *c, const draft_t *d, int split_
   return s;
 }
 
+/* GetRefStartEndPositionForReadFromMapping, split + SAM branches (mapping_generator.h:657-761 for +, 806-850 for -):
+ * ksw_semi_global3 on the aligned part of the read (the split site pulled in by 3e when the read was cut, :711-717),
+ * AdjustGapBeginning extending the first / last M of the CIGAR over the matching bases of the gap (alignment.cc:24-83),
+ * NM / MD over the extended alignment.  The window start is the one of the unshortened part, and the - strand hands
+ * AdjustGapBeginning reference coordinates without read_start_site -- both as the reference has them. */
+static span_t ref_start_end_split_sam(const ora_ctx *c, const draft_t *d, int split_site_word, int strand, const char *read_seq,
+                                      int full_len, uint32_t *cigar, int *n_cigar, char *md, int md_cap, int *md_len, int *nm) {
+  const int e = c->p.error_threshold;
+  const uint32_t rid = (uint32_t)(d->position >> 32), ref_pos = (uint32_t)d->position;
+  const uint32_t rl = c->ref->len[rid];
+  const char *ref = c->ref->seq[rid];
+  int split_site = split_site_word & 0xffff;
+  int gap_beginning = (split_site_word >> 16) & 0xff;
+  int read_length = split_site - gap_beginning;
+  uint32_t vw = ref_pos + 1 > (uint32_t)(read_length + e) ? ref_pos + 1 - (uint32_t)read_length - (uint32_t)e : 0;
+  if (ref_pos + (uint32_t)e >= rl) vw = rl - (uint32_t)e - (uint32_t)read_length;
+  if (split_site < full_len && split_site > 3 * e) split_site -= 3 * e;
+  read_length = split_site - gap_beginning;
+  span_t s;
+  s.rid = rid;
+  int st = 0, en = 0;
+  if (strand == 0) {
+    ora_ksw_semi_global3(read_length + 2 * e, ref + vw, read_length, read_seq + gap_beginning, 2 * e + 1, cigar, ORA_SAM_CIGAR_CAP, n_cigar, &st, &en);
+    if (gap_beginning > 0) {
+      const int rs = (int)vw + st;
+      const int nrs = adjust_gap_beginning(0, ref, rl, read_seq, full_len, &gap_beginning, read_length - 1, rs, (int)vw + en - 1);
+      if (*n_cigar > 0 && (cigar[0] & 0xf) == 0) cigar[0] += (uint32_t)(rs - nrs) << 4;
+      st = nrs - (int)vw;
+    }
+    *nm = nm_and_md(ref + vw + st, read_seq + gap_beginning, cigar, *n_cigar, md, md_cap, md_len);
+    s.ref_start = vw + (uint32_t)st;
+    s.ref_end = vw + (uint32_t)en - 1;
+    return s;
+  }
+  const int read_start_site = full_len - split_site;
+  ora_ksw_semi_global3(read_length + 2 * e, ref + vw + read_start_site, read_length, read_seq + read_start_site, 2 * e + 1, cigar,
+                       ORA_SAM_CIGAR_CAP, n_cigar, &st, &en);
+  if (gap_beginning > 0) {
+    const int re = (int)vw + en - 1;
+    const int nre = adjust_gap_beginning(1, ref, rl, read_seq + read_start_site, full_len - read_start_site, &gap_beginning, read_length - 1,
+                                         (int)vw + st, re);
+    if (*n_cigar > 0 && (cigar[*n_cigar - 1] & 0xf) == 0) cigar[*n_cigar - 1] += (uint32_t)(nre - re) << 4;
+    en = nre + 1 - (int)vw - read_start_site;
+  }
+  *nm = nm_and_md(ref + vw + read_start_site + st, read_seq + read_start_site, cigar, *n_cigar, md, md_cap, md_len);
+  s.ref_start = vw + (uint32_t)read_start_site + (uint32_t)st;
+  s.ref_end = vw + (uint32_t)read_start_site + (uint32_t)en - 1;
+  return s;
+}
+
 /* GetMAPQForSingleEndRead with split_alignment (mapping_generator.h:920-1022). strand_ncand:
  * number of candidates on the mapping's strand. */
 static uint8_t mapq_single_split(const ora_ctx *c, int num_errors, uint16_t alignment_length, int read_length,
@@ -2099,11 +2152,39 @@ static long finish_pair_split(const ora_ctx *c, work_t *wk, mt19937_t *rng, uint
       const uint32_t i1 = pe->best[o].a[mi].a, i2 = pe->best[o].a[mi].b;
       if (a->a[i1].num_errors + b->a[i2].num_errors > pe->min_sum) continue;
       if (idx == wk->best_idx[nout]) {
-        const span_t x = ref_start_end_split(c, &a->a[i1], (int)sa->a[i1], S1[o], S1[o] == 0 ? r1 : neg1, (int)len1);
-        const span_t y = ref_start_end_split(c, &b->a[i2], (int)sb->a[i2], S2[o], S2[o] == 0 ? r2 : neg2, (int)len2);
+        const int sam = p->output_format == 1 && c->sam_rec != NULL;
+        const size_t slot = 2 * (size_t)(read_id - c->sam_first_read_id);
+        int ncig1 = 0, ncig2 = 0, mdl1 = 0, mdl2 = 0, nm1 = 0, nm2 = 0;
+        span_t x, y;
+        if (sam) {
+          x = ref_start_end_split_sam(c, &a->a[i1], (int)sa->a[i1], S1[o], S1[o] == 0 ? r1 : neg1, (int)len1,
+                                      c->sam_cigar + slot * ORA_SAM_CIGAR_CAP, &ncig1, c->sam_md + slot * c->sam_md_cap, (int)c->sam_md_cap, &mdl1, &nm1);
+          y = ref_start_end_split_sam(c, &b->a[i2], (int)sb->a[i2], S2[o], S2[o] == 0 ? r2 : neg2, (int)len2,
+                                      c->sam_cigar + (slot + 1) * ORA_SAM_CIGAR_CAP, &ncig2, c->sam_md + (slot + 1) * c->sam_md_cap, (int)c->sam_md_cap,
+                                      &mdl2, &nm2);
+        } else {
+          x = ref_start_end_split(c, &a->a[i1], (int)sa->a[i1], S1[o], S1[o] == 0 ? r1 : neg1, (int)len1);
+          y = ref_start_end_split(c, &b->a[i2], (int)sb->a[i2], S2[o], S2[o] == 0 ? r2 : neg2, (int)len2);
+        }
         const uint16_t al1 = (uint16_t)(x.ref_end - x.ref_start + 1), al2 = (uint16_t)(y.ref_end - y.ref_start + 1);
         const uint8_t mapq = mapq_paired_split(c, S1[o], S2[o], a->a[i1].num_errors, b->a[i2].num_errors, al1, al2,
                                                (int)len1, (int)len2, -1, m1, m2);
+        if (sam) { /* flags mapping_generator.h:613-631, EmplaceBackPairedEndMappingRecord<SAMMapping> (mapping_generator.cc:84-108);
+                    * PairedEndMappingInMemory::GetFragmentLength (mapping_in_memory.h:83-90) whatever the chromosomes */
+          const int tlen = S1[o] == 0 ? (int)(y.ref_end - x.ref_start + 1) : (int)(x.ref_end - y.ref_start + 1);
+          for (int w = 0; w < 2; ++w) {
+            ora_sam_record *q = &c->sam_rec[slot + (size_t)w];
+            const span_t *me = w == 0 ? &x : &y, *mate = w == 0 ? &y : &x;
+            const int my_neg = w == 0 ? S1[o] : S2[o], mate_neg = w == 0 ? S2[o] : S1[o];
+            memset(q, 0, sizeof(*q));
+            q->read_id = read_id; q->rid = me->rid; q->pos = me->ref_start; q->mpos = mate->ref_start; q->mrid = (int32_t)mate->rid;
+            q->tlen = my_neg ? -tlen : tlen;
+            q->flag = (uint16_t)(3 | (my_neg ? 16 : 0) | (mate_neg ? 32 : 0) | (w == 0 ? 64 : 128) | (nout >= 1 ? 256 : 0));
+            q->mapq = mapq; q->strand = (uint8_t)(my_neg ? 0 : 1); q->is_unique = is_unique; q->valid = 1;
+            q->n_cigar = (uint16_t)(w == 0 ? ncig1 : ncig2); q->md_len = (uint16_t)(w == 0 ? mdl1 : mdl2); q->nm = (uint32_t)(w == 0 ? nm1 : nm2);
+            c->sam_len[slot + (size_t)w] = w == 0 ? len1 : len2;
+          }
+        }
         /* EmplaceBackPairedEndMappingRecord<PairsMapping> (mapping_generator.cc:169-210); default
          * rid ranks are the identity (chromap.cc:867-877) */
         uint8_t st1 = S1[o] == 0 ? 1 : 0, st2 = S2[o] == 0 ? 1 : 0;

@@ -142,7 +142,8 @@ def flags_to_params(flags):
 
 
 ALL_CASES = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
-SAM_CASES = [c for c in ALL_CASES if is_sam(c) and not has_barcodes(c)]
+SAM_CASES = [c for c in ALL_CASES if is_sam(c) and not has_barcodes(c) and not is_hic(c)]
+HIC_SAM_CASES = [c for c in ALL_CASES if is_sam(c) and is_hic(c)]
 SAM_BC_CASES = [c for c in ALL_CASES if is_sam(c) and has_barcodes(c)]
 # BED text through the product's writers (host and device); TagAlign cases of the same record types are listed apart
 BED_CASES = [c for c in ALL_CASES if not is_hic(c) and not has_barcodes(c) and not single_end_mate(c) and not is_sam(c) and not is_tagalign(c)]
@@ -150,7 +151,7 @@ SE_CASES = [c for c in ALL_CASES if single_end_mate(c) and not is_sam(c) and not
 BC_CASES = [c for c in ALL_CASES if has_barcodes(c) and not is_sam(c) and not single_end_mate(c) and not is_tagalign(c)]
 SE_BC_CASES = [c for c in ALL_CASES if has_barcodes(c) and not is_sam(c) and single_end_mate(c)]
 TAGALIGN_CASES = [c for c in ALL_CASES if is_tagalign(c) and not (has_barcodes(c) and single_end_mate(c))]
-HIC_CASES = [c for c in ALL_CASES if is_hic(c)]
+HIC_CASES = [c for c in ALL_CASES if is_hic(c) and not is_sam(c)]
 
 
 def case_index(name):

@@ -114,6 +114,13 @@ CASES = {
                        "--seed", "5"], ["--preset", "atac", "-q", "0", "-n", "3"]),
     "s4_se_n2_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                      "--seed", "5"], ["--preset", "chip", "-q", "0", "-n", "2"]),
+    # --preset hic --SAM: split alignment with ksw on the aligned part of the read, AdjustGapBeginning on the CIGAR, SEQ cut to the
+    # CIGAR's query length (sam_mapping.h:186-193), all four strand combinations
+    "h2_hic_sam_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
+                       "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
+                      ["--preset", "hic", "--SAM", "-q", "0"]),
+    "h1_hic_sam": (["--genome", "3000000", "--chroms", "4", "--pairs", "20000", "--readlen", "150", "--frag-min", "300",
+                    "--frag-max", "800", "--hic", "--seed", "21", "--indel", "0.001"], ["--preset", "hic", "--SAM"]),
     "h2_hic_n2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
                       "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
                      ["--preset", "hic", "-q", "0", "-n", "2"]),

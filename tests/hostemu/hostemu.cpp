@@ -79,6 +79,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   p.max_best = params->max_num_best_mappings; p.drop_rep = params->drop_repetitive_reads; p.trim = params->trim_adapters; p.split = params->split_alignment ? 1 : 0;
   p.bc_err = params->bc_error_threshold; p.bc_keep = params->output_mappings_not_in_whitelist ? 1 : 0; p.bc_prob = params->bc_probability_threshold;
   p.single = single ? 1 : 0;
+  p.sam = sam ? 1 : 0;  // also read by the split-alignment draft mappings (position rule of the - strand)
   p.k = index->kmer_size; p.w = index->window_size; p.lanes = p.split ? 0 : (p.e < 8 ? 8 : (p.e < 16 ? 4 : 0));
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;

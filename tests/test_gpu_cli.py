@@ -17,7 +17,7 @@ CLI = os.path.join(ds.ROOT, "chromap_amd", "chromap-amd")
 REF = os.path.join(ds.ROOT, "oracle", "_ref", "chromap")
 CASES = ["toy_atac", "s1_atac", "s2_atac_q0", "s3_chip", "h1_hic", "b1_atac_bc", "b2_atac_bc2_q0", "b3_bulk_level_bc_q0", "s1_se_chip", "s4_se_atac_q0",
          "s4_inmem_q0", "s4_se_inmem_q0", "b1_inmem_bc", "s1_inmem_nodedup", "s1_chip_sam", "s3_sam_q0", "s2_atac_sam", "s1_se_sam", "s3_chip_chrorder", "h1_hic_chrorder_q0", "h2_hic_natural_q0",
-         "s4_atac_n3_q0", "s4_se_n2_q0", "h2_hic_n2_q0"]
+         "s4_atac_n3_q0", "s4_se_n2_q0", "h2_hic_n2_q0", "h2_hic_sam_q0", "h1_hic_sam"]
 
 
 def _reads(name):

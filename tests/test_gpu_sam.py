@@ -25,7 +25,7 @@ def _tuples(sam):
     return out
 
 
-@pytest.mark.parametrize("case", datasets.SAM_CASES)
+@pytest.mark.parametrize("case", datasets.SAM_CASES + datasets.HIC_SAM_CASES)
 def test_sam_matches_reference_and_oracle(case, tmp_path):
     from chromap_amd import ChromapGPU
     meta = datasets.case_meta(case)

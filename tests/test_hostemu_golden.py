@@ -93,7 +93,7 @@ def test_stage_functions_match_reference(case, tmp_path):
     o.close()
 
 
-@pytest.mark.parametrize("case", datasets.SAM_CASES)
+@pytest.mark.parametrize("case", datasets.SAM_CASES + datasets.HIC_SAM_CASES)
 def test_sam_stage_functions_match_reference(case, tmp_path):
     """--SAM through the stage functions (register-window ksw, NM/MD, SAM records) and the host SAM writer"""
     meta = datasets.case_meta(case)

@@ -145,7 +145,7 @@ def test_hash64_known_values():
     assert len(set(hs)) == len(xs) and all(h <= mask for h in hs)
 
 
-@pytest.mark.parametrize("case", datasets.SAM_CASES)
+@pytest.mark.parametrize("case", datasets.SAM_CASES + datasets.HIC_SAM_CASES)
 def test_sam_matches_reference(case, tmp_path):
     """--SAM: ksw_semi_global3 CIGARs, NM / MD tags, SAMMapping order and duplicate removal"""
     meta = datasets.case_meta(case)
