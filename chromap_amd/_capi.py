@@ -95,7 +95,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_map_pairs_async", "cmgpu_wait", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device", "cmgpu_records_partition",
-           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist",
+           "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist", "cmgpu_store_format_pairs", "cmgpu_write_pairs_header",
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_map_single_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_reserve", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
@@ -195,6 +195,9 @@ def declare(L):
     sig("cmgpu_write_bed_se", C.c_int64, [P(C.c_char_p), C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_load_whitelist_file", C.c_int, [C.c_char_p, C.c_uint32, P(C.c_void_p), P(C.c_uint32)])
     sig("cmgpu_set_whitelist", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32])
+    sig("cmgpu_store_format_pairs", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
+    sig("cmgpu_write_pairs_header", C.c_int, [C.POINTER(C.c_char_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p])
     sig("cmgpu_compute_barcode_abundance", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint64)])
     sig("cmgpu_map_single_barcoded", C.c_int, [C.c_void_p, P(SingleBatch), P(BarcodeBatch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
     sig("cmgpu_map_pairs_barcoded", C.c_int, [C.c_void_p, P(Batch), P(BarcodeBatch), C.c_void_p, C.c_uint64, P(C.c_uint64),

@@ -454,7 +454,6 @@ int main(int argc, char **argv) {
 
   cmgpu_stats st;
   memset(&st, 0, sizeof(st));
-  std::vector<cmgpu_record> recs;
   std::vector<std::string> read_names;  // pairs output needs read-1 names by read_id
   uint64_t num_reads = 0;
   uint32_t next_read_id = 0, bc_len = 0;
@@ -715,13 +714,9 @@ int main(int argc, char **argv) {
         } else if (paired && !a.out_pairs) {
           cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
           rc = cmgpu_map_pairs(ctx, &bt, nullptr, 0, &k, &st);
-        } else if (paired) {
-          const size_t base = recs.size();
-          const size_t cap = (size_t)n * (size_t)(a.p.max_num_best_mappings > 1 ? a.p.max_num_best_mappings : 1);  // -n records per pair
-          recs.resize(base + cap);
+        } else if (paired) {  // pairs records: they stay in HBM too (sorted and rendered by cmgpu_store_format_pairs)
           cmgpu_batch bt{n, next_read_id, b1.data(), o1.data(), b2.data(), o2.data()};
-          rc = cmgpu_map_pairs(ctx, &bt, recs.data() + base, cap, &k, &st);
-          recs.resize(base + k);
+          rc = cmgpu_map_pairs(ctx, &bt, nullptr, 0, &k, &st);
         } else {
           cmgpu_single_batch bt{n, next_read_id, b1.data(), o1.data()};
           rc = cmgpu_map_single(ctx, &bt, nullptr, 0, &k, &st);
@@ -744,8 +739,8 @@ int main(int argc, char **argv) {
             sam_bc.resize(kb + n);
             if (cmgpu_download_barcode_keys(ctx, sam_bc.data() + kb) != CMGPU_OK) die(cmgpu_last_error(ctx));
           }
-        } else if (!a.out_pairs && cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) {
-          // BED outputs: the records never leave HBM -- they join the device-side store
+        } else if (cmgpu_store_append_resident(ctx, nullptr) != CMGPU_OK) {
+          // BED and pairs outputs: the records never leave HBM -- they join the device-side store
           die(cmgpu_last_error(ctx));
         }
         next_read_id += n;
@@ -791,11 +786,17 @@ int main(int argc, char **argv) {
                             paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,
                             a.out_path.c_str());
   } else if (a.out_pairs) {
-    std::vector<const char *> rn(read_names.size());
-    for (size_t i = 0; i < rn.size(); ++i) rn[i] = read_names[i].c_str();
-    lines = cmgpu_write_pairs_ranked(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, (cmgpu_pairs_record *)recs.data(), recs.size(), rn.data(), 0,
-                                     pairs_rank.empty() ? nullptr : pairs_rank.data(),
-                              a.out_path.c_str());
+    // sort + MAPQ filter + text on the device; the read names go up once as a blob
+    std::string blob;
+    std::vector<uint64_t> roff(read_names.size() + 1, 0);
+    for (size_t i = 0; i < read_names.size(); ++i) { blob += read_names[i]; roff[i + 1] = blob.size(); }
+    uint64_t nl = 0, nbytes = 0;
+    if (cmgpu_store_format_pairs(ctx, out_names.data(), ref.n_sequences, &a.p, blob.data(), roff.data(), (uint32_t)read_names.size(), 0, &nl, &nbytes) != CMGPU_OK)
+      die(cmgpu_last_error(ctx));
+    if (cmgpu_write_pairs_header(out_names.data(), out_lengths.data(), ref.n_sequences, pairs_rank.empty() ? nullptr : pairs_rank.data(), a.out_path.c_str()) != CMGPU_OK)
+      die("Cannot write " + a.out_path);
+    if (cmgpu_store_write_text(ctx, a.out_path.c_str(), 1) != CMGPU_OK) die(cmgpu_last_error(ctx));
+    lines = (long long)nl;
   } else {
     // sort + duplicate removal + MAPQ filter + Tn5 shift + text, all on the device
     const int kind = a.out_tagalign && paired ? (barcoded ? CMGPU_TEXT_TAGALIGN_PE_BC : CMGPU_TEXT_TAGALIGN_PE)

@@ -240,6 +240,32 @@ extern "C" int64_t cmgpu_write_bed_pe(const char *const *names, uint32_t n_seque
 
 // pairs output (mapping_writer.cc:381-420).  No duplicate removal unless requested (the hic
 // preset does not set it): the low-memory merge emits every record whose MAPQ passes.
+// MappingWriter<PairsMapping>::OutputHeader (mapping_writer.cc:385-399)
+static void pairs_header(std::string &buf, const char *const *names, const uint32_t *lengths, uint32_t n_sequences, const uint32_t *pairs_rank) {
+  buf.append("## pairs format v1.0.0\n#shape: upper triangle\n");
+  for (uint32_t i = 0; i < n_sequences; ++i) {
+    uint32_t rid = i;
+    if (pairs_rank) for (uint32_t j = 0; j < n_sequences; ++j) if (pairs_rank[j] == i) rid = j;
+    buf.append("#chromsize: ");
+    buf.append(names[rid]);
+    buf.push_back(' ');
+    put_u32(buf, lengths[rid]);
+    buf.push_back('\n');
+  }
+  buf.append("#columns: readID chrom1 pos1 chrom2 pos2 strand1 strand2 pair_type mapq1 mapq2\n");
+}
+// the header alone, to a new file: the lines of cmgpu_store_format_pairs follow (cmgpu_store_write_text with append = 1)
+extern "C" int cmgpu_write_pairs_header(const char *const *names, const uint32_t *lengths, uint32_t n_sequences, const uint32_t *pairs_rank,
+                                        const char *out_path) {
+  if (!names || !lengths || !out_path) return CMGPU_EINVAL;
+  FILE *f = fopen(out_path, "wb");
+  if (!f) return CMGPU_EIO;
+  std::string buf;
+  pairs_header(buf, names, lengths, n_sequences, pairs_rank);
+  const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+  return fclose(f) == 0 && ok ? CMGPU_OK : CMGPU_EIO;
+}
+
 extern "C" int64_t cmgpu_write_pairs(const char *const *names, const uint32_t *lengths, uint32_t n_sequences,
                                      const cmgpu_params *p, cmgpu_pairs_record *rec, uint64_t n,
                                      const char *const *read_names, uint32_t read_id_base, const char *out_path) {
@@ -259,17 +285,7 @@ extern "C" int64_t cmgpu_write_pairs_ranked(const char *const *names, const uint
   });
   std::string buf;
   buf.reserve(1 << 20);
-  buf.append("## pairs format v1.0.0\n#shape: upper triangle\n");
-  for (uint32_t i = 0; i < n_sequences; ++i) {
-    uint32_t rid = i;
-    if (pairs_rank) for (uint32_t j = 0; j < n_sequences; ++j) if (pairs_rank[j] == i) rid = j;
-    buf.append("#chromsize: ");
-    buf.append(names[rid]);
-    buf.push_back(' ');
-    put_u32(buf, lengths[rid]);
-    buf.push_back('\n');
-  }
-  buf.append("#columns: readID chrom1 pos1 chrom2 pos2 strand1 strand2 pair_type mapq1 mapq2\n");
+  pairs_header(buf, names, lengths, n_sequences, pairs_rank);
   int64_t lines = 0;
   for (uint64_t i = 0; i < n; ++i) {
     const cmgpu_pairs_record &r = rec[i];

@@ -462,7 +462,6 @@ extern "C" int cmgpu_store_append_resident(cmgpu_ctx *c, uint64_t *n_total) {
   if (!c) return CMGPU_EINVAL;
   PPCHECK(c, cm_enter(c));
   { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
-  if (c->p.split) { cm_set_error(c, "pairs records are post-processed on the host (cmgpu_write_pairs)"); return CMGPU_EINVAL; }
   const uint32_t n = (uint32_t)cm_rec_slots(c);
   if (c->store_n && c->store_has_bc != c->has_barcodes) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
   if (n) {
@@ -628,6 +627,151 @@ extern "C" int cmgpu_store_format(cmgpu_ctx *c, int kind, const char *const *nam
   // ---- format
   hipLaunchKernelGGL(k_pp_format, g, b, 0, s, store, bc, (const uint32_t *)win.p, (const uint32_t *)dups.p, (const uint64_t *)llen.p,
                      (const uint64_t *)loff.p, n, cfg, (const uint8_t *)d_names.p, (const uint32_t *)d_noff.p, (uint8_t *)c->text.p);
+  e = cm_stream_sync(s);
+  if (e != hipSuccess) { cm_set_error(c, std::string("text formatting: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
+  c->text_bytes = total;
+  c->text_lines = lines;
+  *n_lines = lines;
+  *n_bytes = total;
+  return fail(CMGPU_OK);
+}
+
+// ---------------------------------------------------------------------------------------
+// pairs text (--preset hic) on the device: the store holds cmgpu_pairs_record entries, sorted by
+// (rid1, rid2, pos1, pos2, mapq, read_id) as cmgpu_write_pairs / MappingWriter<PairsMapping> do (pairs_mapping.h:41-47),
+// one line per record that passes the MAPQ filter: readID chrom1 pos1 chrom2 pos2 strand1 strand2 UU mapq mapq
+// (mapping_writer.cc:400-423).  Read names: a blob + offsets indexed by read_id - read_id_base.  The "## pairs" header lines
+// stay with the caller (cmgpu_pairs_header_text).
+// ---------------------------------------------------------------------------------------
+struct PpPairs { uint32_t read_id, rid1, rid2, pos1, pos2; uint8_t st1, st2, mapq, uniq; };
+__device__ __forceinline__ PpPairs pp_load_pairs(const uint8_t *store, uint32_t i) {
+  const uint64_t *p = reinterpret_cast<const uint64_t *>(store + (uint64_t)i * 24);
+  const uint64_t a = p[0], b = p[1], c = p[2];
+  PpPairs r;
+  r.read_id = (uint32_t)a; r.rid1 = (uint32_t)(a >> 32); r.rid2 = (uint32_t)b; r.pos1 = (uint32_t)(b >> 32); r.pos2 = (uint32_t)c;
+  r.st1 = (uint8_t)(c >> 32); r.st2 = (uint8_t)(c >> 40); r.mapq = (uint8_t)(c >> 48); r.uniq = (uint8_t)(c >> 56);
+  return r;
+}
+// which: 0 = (mapq, read_id), 1 = (pos1, pos2), 2 = (rid1, rid2) with rid_bits each
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_pairs_key(const uint8_t *__restrict__ store, const uint32_t *__restrict__ idx, uint32_t n, int which,
+                                                             unsigned rid_bits, uint64_t *__restrict__ key, uint32_t *__restrict__ idx_out) {
+  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = idx ? idx[j] : j;
+  const PpPairs r = pp_load_pairs(store, i);
+  key[j] = which == 0 ? ((uint64_t)r.mapq << 32) | r.read_id : which == 1 ? ((uint64_t)r.pos1 << 32) | r.pos2 : ((uint64_t)r.rid1 << rid_bits) | r.rid2;
+  if (idx_out) idx_out[j] = i;
+}
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_pairs_len(const uint8_t *__restrict__ store, const uint32_t *__restrict__ idx, uint32_t n, int mapq_thr,
+                                                             uint32_t n_seq, const uint32_t *__restrict__ name_off, const uint64_t *__restrict__ rn_off,
+                                                             uint32_t rn_base, uint32_t rn_count, uint64_t *__restrict__ line_len) {
+  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const PpPairs r = pp_load_pairs(store, idx[j]);
+  const uint32_t q = r.read_id - rn_base;
+  if ((int)r.mapq < mapq_thr || r.rid1 >= n_seq || r.rid2 >= n_seq || q >= rn_count) { line_len[j] = 0; return; }
+  const uint32_t rn = (uint32_t)(rn_off[q + 1] - rn_off[q]);
+  line_len[j] = rn + 1 + (name_off[r.rid1 + 1] - name_off[r.rid1]) + 1 + pp_digits(r.pos1 + 1) + 1 + (name_off[r.rid2 + 1] - name_off[r.rid2]) + 1 +
+                pp_digits(r.pos2 + 1) + 2 + 2 + 4 + pp_digits(r.mapq) + 1 + pp_digits(r.mapq) + 1;
+}
+__global__ __launch_bounds__(PP_BLOCK) void k_pp_pairs_format(const uint8_t *__restrict__ store, const uint32_t *__restrict__ idx, uint32_t n,
+                                                                const uint64_t *__restrict__ line_len, const uint64_t *__restrict__ line_off,
+                                                                const uint8_t *__restrict__ names, const uint32_t *__restrict__ name_off,
+                                                                const uint8_t *__restrict__ rn, const uint64_t *__restrict__ rn_off, uint32_t rn_base,
+                                                                uint8_t *__restrict__ text) {
+  const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (j >= n || line_len[j] == 0) return;
+  const PpPairs r = pp_load_pairs(store, idx[j]);
+  uint8_t *p = text + line_off[j];
+  const uint32_t q = r.read_id - rn_base;
+  for (uint64_t i = rn_off[q]; i < rn_off[q + 1]; ++i) *p++ = rn[i];
+  *p++ = '\t';
+  for (uint32_t i = name_off[r.rid1]; i < name_off[r.rid1 + 1]; ++i) *p++ = names[i];
+  *p++ = '\t';
+  p = pp_put_u32(p, r.pos1 + 1);
+  *p++ = '\t';
+  for (uint32_t i = name_off[r.rid2]; i < name_off[r.rid2 + 1]; ++i) *p++ = names[i];
+  *p++ = '\t';
+  p = pp_put_u32(p, r.pos2 + 1);
+  *p++ = '\t'; *p++ = r.st1 ? '+' : '-';
+  *p++ = '\t'; *p++ = r.st2 ? '+' : '-';
+  *p++ = '\t'; *p++ = 'U'; *p++ = 'U'; *p++ = '\t';
+  p = pp_put_u32(p, r.mapq);
+  *p++ = '\t';
+  p = pp_put_u32(p, r.mapq);
+  *p++ = '\n';
+}
+
+extern "C" int cmgpu_store_format_pairs(cmgpu_ctx *c, const char *const *names, uint32_t n_sequences, const cmgpu_params *p,
+                                        const char *read_names, const uint64_t *read_name_offsets, uint32_t n_read_names,
+                                        uint32_t read_id_base, uint64_t *n_lines, uint64_t *n_bytes) {
+  if (!c || !names || !p || !n_lines || !n_bytes || (!read_names && n_read_names) || (!read_name_offsets && n_read_names)) return CMGPU_EINVAL;
+  if (!c->p.split) { cm_set_error(c, "pairs text needs pairs records (split alignment)"); return CMGPU_EINVAL; }
+  if (c->store_has_bc) { cm_set_error(c, "pairs text with cell barcodes is not supported"); return CMGPU_EINVAL; }
+  PPCHECK(c, cm_enter(c));
+  { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
+  hipStream_t s = c->stream;
+  *n_lines = 0;
+  *n_bytes = 0;
+  c->text_bytes = 0;
+  c->text_lines = 0;
+  const uint32_t n = (uint32_t)c->store_n;
+  if (n == 0) return CMGPU_OK;
+  std::vector<uint32_t> noff(n_sequences + 1, 0);
+  std::string blob;
+  for (uint32_t i = 0; i < n_sequences; ++i) { blob += names[i]; noff[i + 1] = (uint32_t)blob.size(); }
+  const uint64_t rn_bytes = n_read_names ? read_name_offsets[n_read_names] : 0;
+  DevBuf d_names, d_noff, d_rn, d_rnoff, k0, k1, v0, v1, tmp, llen, loff;
+  auto fail = [&](int rc) { d_names.release(); d_noff.release(); d_rn.release(); d_rnoff.release(); k0.release(); k1.release(); v0.release();
+                            v1.release(); tmp.release(); llen.release(); loff.release(); return rc; };
+  if (d_names.ensure(blob.size() + 16) || d_noff.ensure(noff.size() * 4) || d_rn.ensure(rn_bytes + 16) || d_rnoff.ensure(((size_t)n_read_names + 1) * 8) ||
+      k0.ensure((size_t)n * 8) || k1.ensure((size_t)n * 8) || v0.ensure((size_t)n * 4) || v1.ensure((size_t)n * 4) || llen.ensure(((size_t)n + 1) * 8) ||
+      loff.ensure(((size_t)n + 1) * 8)) { cm_set_error(c, "out of device memory (post-processing)"); return fail(CMGPU_ENOMEM); }
+  const uint64_t zero = 0;
+  if (hipMemcpyAsync(d_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_noff.p, noff.data(), noff.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+      (rn_bytes && hipMemcpyAsync(d_rn.p, read_names, rn_bytes, hipMemcpyHostToDevice, s) != hipSuccess) ||
+      hipMemcpyAsync(d_rnoff.p, n_read_names ? (const void *)read_name_offsets : (const void *)&zero, ((size_t)n_read_names + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+    cm_set_error(c, "name upload failed"); return fail(CMGPU_EHIP);
+  }
+  const dim3 g((n + PP_BLOCK - 1) / PP_BLOCK), b(PP_BLOCK);
+  const uint8_t *store = (const uint8_t *)c->store.p;
+  uint64_t *ka = (uint64_t *)k0.p, *kb = (uint64_t *)k1.p;
+  uint32_t *va = (uint32_t *)v0.p, *vb = (uint32_t *)v1.p;
+  unsigned rid_bits = 1;
+  while (rid_bits < 32 && (1ull << rid_bits) < (uint64_t)n_sequences + 1) ++rid_bits;
+  int rc;
+  // least significant key first: (mapq, read_id), then (pos1, pos2), then (rid1, rid2) -- stable radix passes
+  hipLaunchKernelGGL(k_pp_pairs_key, g, b, 0, s, store, (const uint32_t *)nullptr, n, 0, rid_bits, ka, va);
+  if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 40))) return fail(rc);
+  std::swap(va, vb);
+  hipLaunchKernelGGL(k_pp_pairs_key, g, b, 0, s, store, (const uint32_t *)va, n, 1, rid_bits, ka, (uint32_t *)nullptr);
+  if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 64))) return fail(rc);
+  std::swap(va, vb);
+  hipLaunchKernelGGL(k_pp_pairs_key, g, b, 0, s, store, (const uint32_t *)va, n, 2, rid_bits, ka, (uint32_t *)nullptr);
+  if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 2 * rid_bits))) return fail(rc);
+  std::swap(va, vb);
+  hipLaunchKernelGGL(k_pp_pairs_len, g, b, 0, s, store, (const uint32_t *)va, n, p->mapq_threshold, n_sequences, (const uint32_t *)d_noff.p,
+                     (const uint64_t *)d_rnoff.p, read_id_base, n_read_names, (uint64_t *)llen.p);
+  if (hipMemsetAsync((uint64_t *)llen.p + n, 0, 8, s) != hipSuccess) { cm_set_error(c, "memset failed"); return fail(CMGPU_EHIP); }
+  size_t tb = 0, tb2 = 0;
+  auto lines_in = rocprim::make_transform_iterator((const uint64_t *)llen.p, PpLinesOp());
+  (void)rocprim::exclusive_scan(nullptr, tb, (const uint64_t *)llen.p, (uint64_t *)loff.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), s);
+  (void)rocprim::reduce(nullptr, tb2, lines_in, (uint64_t *)nullptr, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
+  DevBuf d_count;
+  if (tmp.ensure((tb > tb2 ? tb : tb2) + 256) || d_count.ensure(8)) { d_count.release(); cm_set_error(c, "out of device memory (scan)"); return fail(CMGPU_ENOMEM); }
+  hipError_t e = rocprim::exclusive_scan(tmp.p, tb, (const uint64_t *)llen.p, (uint64_t *)loff.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), s);
+  if (e == hipSuccess) e = rocprim::reduce(tmp.p, tb2, lines_in, (uint64_t *)d_count.p, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
+  uint64_t total = 0, lines = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint64_t *)loff.p + n, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&lines, d_count.p, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = cm_stream_sync(s);
+  d_count.release();
+  if (e != hipSuccess) { cm_set_error(c, std::string("post-processing scan: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
+  if (c->text.ensure(total + 64)) { cm_set_error(c, "out of device memory (text)"); return fail(CMGPU_ENOMEM); }
+  hipLaunchKernelGGL(k_pp_pairs_format, g, b, 0, s, store, (const uint32_t *)va, n, (const uint64_t *)llen.p, (const uint64_t *)loff.p,
+                     (const uint8_t *)d_names.p, (const uint32_t *)d_noff.p, (const uint8_t *)d_rn.p, (const uint64_t *)d_rnoff.p, read_id_base,
+                     (uint8_t *)c->text.p);
   e = cm_stream_sync(s);
   if (e != hipSuccess) { cm_set_error(c, std::string("text formatting: ") + hipGetErrorString(e)); return fail(CMGPU_EHIP); }
   c->text_bytes = total;

@@ -515,6 +515,25 @@ class ChromapGPU:
             raise ChromapError("cannot write %s" % path)
         return int(k)
 
+    def store_format_pairs(self, read_names, read_id_base=0, params=None):
+        """pairs text of the stored pairs records on the device (sort, MAPQ filter, lines); returns (lines, bytes);
+        the text is fetched with store_text() / store_write_text(); the header lines: write_pairs_header()"""
+        p = params if params is not None else self.params
+        names = (C.c_char_p * len(self.names))(*self.names)
+        blob = b"".join(read_names)
+        off = np.zeros(len(read_names) + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in read_names], dtype=np.uint64)
+        nl, nb = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.cmgpu_store_format_pairs(self.ctx, names, len(self.names), C.byref(p), blob, off.ctypes.data, len(read_names),
+                                                    read_id_base, C.byref(nl), C.byref(nb)), self.ctx)
+        return int(nl.value), int(nb.value)
+
+    def write_pairs_header(self, path):
+        names = (C.c_char_p * len(self.names))(*self.names)
+        pr = (C.c_uint32 * len(self.pairs_rank))(*self.pairs_rank) if self.pairs_rank else None
+        if self.L.cmgpu_write_pairs_header(names, self.reference_lengths(), len(self.names), pr, path.encode()) != 0:
+            raise ChromapError("cannot write %s" % path)
+
     # ---- multi-GPU record exchange (include/chromap_amd.h: cmgpu_exchange_*)
     def exchange_unique_id(self):
         buf = C.create_string_buffer(_capi.UNIQUE_ID_BYTES)

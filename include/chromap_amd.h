@@ -510,6 +510,16 @@ int cmgpu_store_append_resident(cmgpu_ctx *ctx, uint64_t *n_total);
 int cmgpu_store_append(cmgpu_ctx *ctx, const void *records, uint64_t n, int on_device, int barcoded);
 int cmgpu_store_format(cmgpu_ctx *ctx, int kind, const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
                        uint32_t barcode_length, uint64_t *n_lines, uint64_t *n_bytes);
+/* --preset hic: the store holds cmgpu_pairs_record entries (cmgpu_store_append_resident after a split-alignment batch);
+ * sorted as MappingWriter<PairsMapping> sorts them (src/pairs_mapping.h:41-47), MAPQ filter, one text line per record
+ * (src/mapping_writer.cc:400-423).  read_names: the names of reads read_id_base .. read_id_base + n_read_names - 1
+ * concatenated, read_name_offsets[n_read_names + 1] into it.  The header lines: cmgpu_write_pairs_header.
+ * The bytes equal cmgpu_write_pairs' lines. */
+int cmgpu_store_format_pairs(cmgpu_ctx *ctx, const char *const *names, uint32_t n_sequences, const cmgpu_params *params,
+                             const char *read_names, const uint64_t *read_name_offsets, uint32_t n_read_names, uint32_t read_id_base,
+                             uint64_t *n_lines, uint64_t *n_bytes);
+int cmgpu_write_pairs_header(const char *const *names, const uint32_t *lengths, uint32_t n_sequences, const uint32_t *pairs_rank,
+                             const char *out_path);
 int cmgpu_store_text(cmgpu_ctx *ctx, char *out, uint64_t capacity);
 int cmgpu_store_write_text(cmgpu_ctx *ctx, const char *path, int append);
 int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_bytes, uint64_t *text_lines);

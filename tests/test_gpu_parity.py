@@ -99,6 +99,15 @@ def test_hic_pairs_match_reference(case, tmp_path):
     s = g.stats.as_dict()
     for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
         assert s[key] == ref[key], key
+    # the same text from the device: the records of the batch (still resident) join the store, sorted and rendered in HBM
+    g.store_clear()
+    assert g.store_append_resident() == k
+    lines, nbytes = g.store_format_pairs(ol.read_names(r1))
+    out2 = str(tmp_path / "d.pairs")
+    g.write_pairs_header(out2)
+    g.store_write_text(out2, append=True)
+    got2 = open(out2, "rb").read()
+    assert got2 == got and lines == got.count(b"\n") - sum(1 for ln in got.split(b"\n") if ln.startswith(b"#"))
     g.close()
 
 
