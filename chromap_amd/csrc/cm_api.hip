@@ -965,6 +965,10 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     cm_set_error(c, "reads longer than " + std::to_string(CM_MAX_READ_LEN) + " bases are not supported");
     return CMGPU_EINVAL;
   }
+  if (cm_rec_slots(c) > 0xfffffff0ull) {  // record slots are addressed with 32 bits (compaction scans, store indices)
+    cm_set_error(c, "batch too large: n_pairs * max_num_best_mappings must stay below 2^32");
+    return CMGPU_EINVAL;
+  }
   // per-pair outputs of the whole batch; the intermediates are sized per range
   if (c->rec.ensure(cm_rec_slots(c) * 24) || c->rec_ok.ensure(cm_rec_slots(c))) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
   if (c->has_barcodes && (c->bc_key.ensure((size_t)n * 8) || c->bc_ok.ensure(n))) { cm_set_error(c, "out of device memory (barcodes)"); return CMGPU_ENOMEM; }
