@@ -121,6 +121,8 @@ CASES = {
                       ["--preset", "hic", "--SAM", "-q", "0"]),
     "h1_hic_sam": (["--genome", "3000000", "--chroms", "4", "--pairs", "20000", "--readlen", "150", "--frag-min", "300",
                     "--frag-max", "800", "--hic", "--seed", "21", "--indel", "0.001"], ["--preset", "hic", "--SAM"]),
+    "b2_atac_bc_n2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "50", "--frag-min", "35",
+                          "--barcodes", "300", "--seed", "32"], ["--preset", "atac", "-q", "0", "-n", "2"]),
     "h2_hic_n2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
                       "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
                      ["--preset", "hic", "-q", "0", "-n", "2"]),
