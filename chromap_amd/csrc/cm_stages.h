@@ -1139,9 +1139,88 @@ CM_HD void cm_s3b_candidates(const CmDev &d, uint32_t r) { cm_s3b_candidates_lds
 // streaming merge over the mate candidates instead of being stored.
 // Returns max_minimizer_count, or its negation when the search bails out (:371-380).
 // ---------------------------------------------------------------------------------------
+// The search is split into pieces a group of lanes can share (k_s4a/4b_rescue_list): the best count among the mate
+// candidates, the bail-out test, ONE minimizer's hits inside the merged windows (independent of the other minimizers; inside a
+// minimizer the windows are chained: a window's binary search starts at the midpoint where the previous one ended, and the scan
+// that follows starts at that midpoint without a lower-bound test, :443-470), and the repetitive-seed length over the
+// minimizers in order.  cm_rescue is their sequential composition.
+CM_HD bool cm_rescue_bails(const CmDev &d, int max_count, int best_num, uint32_t mn) {  // :371-380
+  return best_num >= 300 || mn > (uint32_t)d.p.f0 || (max_count <= d.p.min_seeds && best_num >= 200);
+}
+CM_HD uint32_t cm_rescue_minimizer(const CmDev &d, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn, int max_count,
+                                   uint8_t kind, uint64_t val, uint32_t ps, uint64_t *out, unsigned long long *reads_out) {
+  if (kind == CM_PR_MISS) return 0;
+  const uint32_t search_range = 2u * (uint32_t)d.p.max_insert;
+  uint32_t cnt = 0;
+  unsigned long long reads = 0;
+  bool same;
+  if (kind == CM_PR_SINGLE) {
+    const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
+    if ((same && strand == 0) || (!same && strand == 1)) { if (out) out[cnt] = cp; ++cnt; }
+    return cnt;
+  }
+  const uint32_t off = (uint32_t)(val >> 32), nocc = (uint32_t)val;
+  const uint64_t *o = d.occ + off;
+  int32_t prev_l = 0;
+  // streaming merge of the windows of the best mate candidates
+  uint32_t ci = 0;
+  bool have = false;
+  uint64_t ws = 0, we = 0;
+  for (;;) {
+    // find next window [ws,we]
+    bool emit = false;
+    uint64_t es = 0, ee = 0;
+    while (ci < mn) {
+      if (mc[ci] != max_count) { ++ci; continue; }
+      const uint64_t pos = mp[ci];
+      const uint64_t s = pos < search_range ? 0 : pos - search_range;
+      const uint64_t en = pos + search_range;
+      ++ci;
+      if (!have) { ws = s; we = en; have = true; continue; }
+      if (we < s) { es = ws; ee = we; emit = true; ws = s; we = en; break; }
+      we = en;
+    }
+    if (!emit) {
+      if (!have) break;
+      es = ws; ee = we; have = false; emit = true;  // last window
+    }
+    // binary search for the window start (:443-460)
+    int32_t l = prev_l, m = 0, rr = (int32_t)(nocc - 1);
+    while (l <= rr) {
+      m = (l + rr) / 2;
+      const uint64_t cp = o[m] >> 1;
+      ++reads;
+      if (cp < es) l = m + 1;
+      else if (cp > es) rr = m - 1;
+      else break;
+    }
+    prev_l = m;
+    for (uint32_t oi = (uint32_t)m; oi < nocc; ++oi) {
+      const uint64_t rh = o[oi];
+      ++reads;
+      if ((rh >> 1) > ee) break;
+      const uint64_t cp = cm_cand_from_hit(rh, ps, d.p.k, &same);
+      if ((same && strand == 0) || (!same && strand == 1)) { if (out) out[cnt] = cp; ++cnt; }
+    }
+    if (!have && ci >= mn) break;
+  }
+  if (reads_out) *reads_out += reads;
+  return cnt;
+}
+// repetitive_seed_length over the minimizers in order (:474-486, index.cc:507-523)
+CM_HD void cm_rescue_rep(const CmDev &d, uint8_t kind, uint64_t val, uint32_t ps, uint32_t *rep_len, uint32_t *prev_rep) {
+  if (kind == CM_PR_MISS || kind == CM_PR_SINGLE) return;
+  const uint32_t nocc = (uint32_t)val;
+  if (nocc >= (uint32_t)d.p.f0) {
+    const uint32_t rp = ps >> 1;
+    if (*prev_rep > rp) *rep_len += (uint32_t)d.p.k;
+    else if (rp < *prev_rep + (uint32_t)d.p.k + (uint32_t)d.p.w - 1) *rep_len += rp - *prev_rep;
+    else *rep_len += (uint32_t)d.p.k;
+    *prev_rep = rp;
+  }
+}
 CM_HD int cm_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn,
                     uint64_t *out, uint32_t *n_out, uint32_t *rep_len_out, unsigned long long *occ_reads) {
-  const uint32_t search_range = 2u * (uint32_t)d.p.max_insert;
   int max_count = 0, best_num = 0;
   for (uint32_t i = 0; i < mn; ++i) {
     const int c = mc[i];
@@ -1149,7 +1228,7 @@ CM_HD int cm_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, 
     else if (c == max_count) ++best_num;
   }
   *n_out = 0;
-  if (best_num >= 300 || mn > (uint32_t)d.p.f0 || (max_count <= d.p.min_seeds && best_num >= 200)) return -max_count;
+  if (cm_rescue_bails(d, max_count, best_num, mn)) return -max_count;
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   uint32_t cnt = 0, rep_len = 0, prev_rep = ~0u;
   unsigned long long reads = 0;
@@ -1167,70 +1246,10 @@ CM_HD int cm_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, 
       ps_g[q] = in ? d.mm_ps[b + mi0 + q] : 0;
     }
 #pragma unroll
-   for (int q = 0; q < CM_S3B_GROUP; ++q) {
-    const uint8_t kind = kind_g[q];
-    if (kind == CM_PR_MISS) continue;
-    const uint64_t val = val_g[q];
-    const uint32_t ps = ps_g[q];
-    bool same;
-    if (kind == CM_PR_SINGLE) {
-      const uint64_t cp = cm_cand_from_hit(val, ps, d.p.k, &same);
-      if ((same && strand == 0) || (!same && strand == 1)) { if (out) out[cnt] = cp; ++cnt; }
-      continue;
+    for (int q = 0; q < CM_S3B_GROUP; ++q) {
+      cnt += cm_rescue_minimizer(d, strand, mp, mc, mn, max_count, kind_g[q], val_g[q], ps_g[q], out ? out + cnt : nullptr, &reads);
+      cm_rescue_rep(d, kind_g[q], val_g[q], ps_g[q], &rep_len, &prev_rep);
     }
-    const uint32_t off = (uint32_t)(val >> 32), nocc = (uint32_t)val;
-    const uint64_t *o = d.occ + off;
-    int32_t prev_l = 0;
-    // streaming merge of the windows of the best mate candidates
-    uint32_t ci = 0;
-    bool have = false;
-    uint64_t ws = 0, we = 0;
-    for (;;) {
-      // find next window [ws,we]
-      bool emit = false;
-      uint64_t es = 0, ee = 0;
-      while (ci < mn) {
-        if (mc[ci] != max_count) { ++ci; continue; }
-        const uint64_t pos = mp[ci];
-        const uint64_t s = pos < search_range ? 0 : pos - search_range;
-        const uint64_t en = pos + search_range;
-        ++ci;
-        if (!have) { ws = s; we = en; have = true; continue; }
-        if (we < s) { es = ws; ee = we; emit = true; ws = s; we = en; break; }
-        we = en;
-      }
-      if (!emit) {
-        if (!have) break;
-        es = ws; ee = we; have = false; emit = true;  // last window
-      }
-      // binary search for the window start (:443-460)
-      int32_t l = prev_l, m = 0, rr = (int32_t)(nocc - 1);
-      while (l <= rr) {
-        m = (l + rr) / 2;
-        const uint64_t cp = o[m] >> 1;
-        ++reads;
-        if (cp < es) l = m + 1;
-        else if (cp > es) rr = m - 1;
-        else break;
-      }
-      prev_l = m;
-      for (uint32_t oi = (uint32_t)m; oi < nocc; ++oi) {
-        const uint64_t rh = o[oi];
-        ++reads;
-        if ((rh >> 1) > ee) break;
-        const uint64_t cp = cm_cand_from_hit(rh, ps, d.p.k, &same);
-        if ((same && strand == 0) || (!same && strand == 1)) { if (out) out[cnt] = cp; ++cnt; }
-      }
-      if (!have && ci >= mn) break;
-    }
-    if (nocc >= (uint32_t)d.p.f0) {
-      const uint32_t rp = ps >> 1;
-      if (prev_rep > rp) rep_len += (uint32_t)d.p.k;
-      else if (rp < prev_rep + (uint32_t)d.p.k + (uint32_t)d.p.w - 1) rep_len += rp - prev_rep;
-      else rep_len += (uint32_t)d.p.k;
-      prev_rep = rp;
-    }
-   }
   }
   *n_out = cnt;
   *rep_len_out = rep_len;
