@@ -578,10 +578,85 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t
   if (aug) d.rs_list[(uint64_t)seg * seg_cap + sh_base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 // the searches of the listed reads: blockIdx.y = segment, the x blocks stride over it (its length is only known on the device)
+// A read whose mate has many candidates (a read pair from a repeat family) walks hundreds of windows per minimizer: one lane
+// doing that kept its list kernel alive for milliseconds.  Such reads (CM_RS_HEAVY mate candidates or more on a strand) are left
+// to the second half of the kernel, where a GROUP of 16 lanes takes one read, a lane per minimizer (cm_rescue_minimizer: the
+// minimizers are independent, the windows inside one are not).
+#define CM_RS_HEAVY 8u
+#define CM_RS_G 16
+#define CM_RS_MAXMM 192  // minimizers of a read the group path holds counts for in LDS (longer reads: the one-lane path)
+__device__ __forceinline__ bool cm_rescue_is_heavy(const CmDev &d, uint32_t r) {
+  const uint32_t o = r ^ 1u;
+  return (d.ncp[o] >= CM_RS_HEAVY || d.ncn[o] >= CM_RS_HEAVY) && d.mm_cnt[r] <= CM_RS_MAXMM;
+}
+// best count among the mate candidates and how many have it, over the group's lanes (all lanes return the same)
+__device__ __forceinline__ void cm_group_best(const uint8_t *mc, uint32_t mn, uint32_t t, int *max_count, int *best_num) {
+  int lmax = 0, lnum = 0;
+  for (uint32_t i = t; i < mn; i += CM_RS_G) {
+    const int c = mc[i];
+    if (c > lmax) { lmax = c; lnum = 1; } else if (c == lmax) ++lnum;
+  }
+  for (int off = CM_RS_G / 2; off > 0; off >>= 1) {
+    const int om = __shfl_xor(lmax, off, CM_RS_G), on = __shfl_xor(lnum, off, CM_RS_G);
+    if (om > lmax) { lmax = om; lnum = on; } else if (om == lmax) lnum += on;
+  }
+  *max_count = lmax;
+  *best_num = lnum;
+}
+// counting pass of one direction by a group; returns max_count or its negation (bail-out); *cnt = hits, *rl = repetitive length
+__device__ __forceinline__ int cm_group_rescue_count(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn,
+                                                     uint32_t t, uint32_t *cnt, uint32_t *rl) {
+  int max_count, best_num;
+  cm_group_best(mc, mn, t, &max_count, &best_num);
+  *cnt = 0;
+  if (cm_rescue_bails(d, max_count, best_num, mn)) return -max_count;
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  uint32_t lc = 0;
+  for (uint32_t mi = t; mi < n; mi += CM_RS_G)
+    lc += cm_rescue_minimizer(d, strand, mp, mc, mn, max_count, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], nullptr, nullptr);
+  for (int off = CM_RS_G / 2; off > 0; off >>= 1) lc += __shfl_xor(lc, off, CM_RS_G);
+  uint32_t rep_len = 0;
+  if (t == 0) {
+    uint32_t prev_rep = ~0u;
+    for (uint32_t mi = 0; mi < n; ++mi) cm_rescue_rep(d, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], &rep_len, &prev_rep);
+  }
+  *rl = __shfl(rep_len, 0, CM_RS_G);
+  *cnt = lc;
+  return max_count;
+}
 __global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_cap) {
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
-  for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) cm_s4a_rescue(d, list[j]);
+  // reads with few mate candidates: a lane each
+  for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) {
+    const uint32_t r = list[j];
+    if (!cm_rescue_is_heavy(d, r)) cm_s4a_rescue(d, r);
+  }
+  // the others: a group of 16 lanes each (cm_s4a_rescue, its two searches shared out over the minimizers)
+  const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
+  for (uint32_t j = blockIdx.x * gpb + grp; j < cnt; j += gridDim.x * gpb) {
+    const uint32_t r = list[j];
+    if (!cm_rescue_is_heavy(d, r)) continue;  // uniform in the group
+    const uint32_t o = r ^ 1u;
+    uint32_t cntn = 0, cntp = 0, rl = 0, rl_val = 0;
+    int res_neg = 0, res_pos = 0;
+    bool set_rl = false;
+    if (d.ncp[o] > 0) {
+      res_neg = cm_group_rescue_count(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], t, &cntn, &rl);
+      if (res_neg >= 0) { set_rl = true; rl_val = rl; }
+    }
+    if (d.ncn[o] > 0) {
+      res_pos = cm_group_rescue_count(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], t, &cntp, &rl);
+      if (res_pos >= 0) { set_rl = true; rl_val = rl; }
+    }
+    if (t == 0) {
+      d.aug[r] = 1;
+      d.res_neg[r] = res_neg; d.res_pos[r] = res_pos;
+      d.resc_n[r] = cntn; d.resc_p[r] = cntp;
+      if (set_rl) d.rep_len[r] = rl_val;
+      d.m_tot[r] = d.ncp[r] + d.ncn[r] + cntn + cntp;
+    }
+  }
 }
 __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n) {
   const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
@@ -590,12 +665,48 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t
   if (d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0) return;  // k_s4b_rescue_list
   cm_s4b_rescue_merge(d, i);
 }
+// fill pass of one direction by a group: per-minimizer counts to LDS, lane 0 turns them into offsets (minimizer order = the
+// order cm_rescue writes in), the lanes write their minimizers' hits there
+__device__ __forceinline__ void cm_group_rescue_fill(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn,
+                                                     uint32_t t, uint32_t *lds_cnt, uint64_t *out) {
+  int max_count, best_num;
+  cm_group_best(mc, mn, t, &max_count, &best_num);
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  for (uint32_t mi = t; mi < n; mi += CM_RS_G)
+    lds_cnt[mi] = cm_rescue_minimizer(d, strand, mp, mc, mn, max_count, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], nullptr, nullptr);
+  cm_group_sync<CM_RS_G>();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (uint32_t mi = 0; mi < n; ++mi) { const uint32_t x = lds_cnt[mi]; lds_cnt[mi] = run; run += x; }
+  }
+  cm_group_sync<CM_RS_G>();
+  for (uint32_t mi = t; mi < n; mi += CM_RS_G)
+    (void)cm_rescue_minimizer(d, strand, mp, mc, mn, max_count, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], out + lds_cnt[mi], nullptr);
+  cm_group_sync<CM_RS_G>();
+}
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap) {
+  __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
   for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) {
     const uint32_t r = list[j];
-    if (d.resc_n[r] + d.resc_p[r] > 0) cm_s4b_rescue_merge(d, r);
+    if (d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r)) cm_s4b_rescue_merge(d, r);
+  }
+  const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
+  for (uint32_t j = blockIdx.x * gpb + grp; j < cnt; j += gridDim.x * gpb) {
+    const uint32_t r = list[j];
+    if (!cm_rescue_is_heavy(d, r) || d.resc_n[r] + d.resc_p[r] == 0) continue;  // uniform in the group
+    const uint32_t o = r ^ 1u;
+    const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
+    uint64_t *P = d.mbuf + d.m_off[r];
+    uint64_t *N = P + ncp + rp;
+    // same conditions and destinations as cm_s4b_rescue_merge
+    if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0)
+      cm_group_rescue_fill(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], t, sh_cnt[grp], N + ncn);
+    if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0)
+      cm_group_rescue_fill(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], t, sh_cnt[grp], P + ncp);
+    __threadfence_block();
+    if (t == 0) cm_s4b_rescue_merge(d, r, true);  // sort, cluster, merge of the hits the group wrote
   }
 }
 // S4c; long filtered candidate lists are queued for k_sort_lists
