@@ -52,3 +52,35 @@ def test_no_cpu_fallback():
     rc = L.cmgpu_create(C.byref(idx), C.byref(ref), C.byref(p), 0, C.byref(ctx))
     assert rc == -2  # CMGPU_ENODEVICE
     assert b"no HIP device" in L.cmgpu_last_error(None)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/chromap_amd.h compiles as C99 (-pedantic), a C program links against the
+    library, and without a device cmgpu_create* fails with a message instead of falling back to anything"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "chromap_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libchromap_amd.so")):
+        pytest.skip("library not built")
+    src = tmp_path / "t.c"
+    src.write_text('#include "chromap_amd.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n  cmgpu_params p;\n  cmgpu_default_params(&p);\n'
+                   '  if (cmgpu_apply_preset(&p, "atac") != 0) return 2;\n  cmgpu_ctx *ctx = 0;\n'
+                   '  int rc = cmgpu_create_synthetic(1000000, 2, 1, 17, 7, &p, 0, &ctx);\n'
+                   '  printf("%d %d %s\\n", p.max_insert_size, rc, cmgpu_last_error(0));\n  return 0;\n}\n')
+    exe = str(tmp_path / "t")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", exe,
+                        "-L" + lib_dir, "-lchromap_amd", "-Wl,-rpath," + lib_dir], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    out = subprocess.run([exe], stdout=subprocess.PIPE).stdout.decode().split(None, 2)
+    assert out[0] == "2000"
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except ImportError:
+        has_gpu = False
+    if not has_gpu:
+        assert int(out[1]) != 0 and "HIP" in out[2]
