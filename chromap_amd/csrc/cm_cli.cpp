@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <chrono>
@@ -98,6 +99,15 @@ struct ChunkReader {
     len = 0;
     eof = false;
     bgzf = false;
+    // only a regular file is sniffed for BGZF: the 18 bytes read from a FIFO, a process substitution or /dev/stdin would be
+    // lost to the gzopen below (the reference opens every input with one gzopen, which works on pipes)
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0) return false;
+    if (!S_ISREG(sb.st_mode)) {
+      f = gzopen(path.c_str(), "r");
+      if (f) gzbuffer(f, 1 << 20);
+      return f != nullptr;
+    }
     raw = fopen(path.c_str(), "rb");
     if (!raw) return false;
     unsigned char h[18];

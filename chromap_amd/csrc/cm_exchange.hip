@@ -449,24 +449,44 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
   }
   for (uint32_t j = 0; j < world; ++j)
     for (uint32_t r = 0; r < world; ++r) x.owned_by[j] += M[(size_t)r * stride + j];
-  if (c->store_n && tot_r && c->store_has_bc != bc) { cm_set_error(c, "record store mixes barcoded and bulk batches"); return CMGPU_EINVAL; }
-  if (tot_r) {
-    if (c->store_n + tot_r > c->store_cap || (bc && !c->store_bc.p)) {  // the store moves: the previous payload must have landed
-      rc = cm_exchange_quiesce(c);
-      if (rc) return rc;
-    }
-    rc = cm_store_reserve(c, c->store_n + tot_r, bc);
-    if (rc) return rc;
-  }
+  // Everything that can fail on THIS rank alone (store kind, store / staging growth) happens before any payload is posted,
+  // and its outcome is agreed on by all ranks: a rank that returned early here while its peers posted the matching
+  // Send / Recv would leave them waiting in RCCL forever.
+  int local_rc = CMGPU_OK;
   uint8_t *dest = nullptr;
-  if (tot_r) {
-    if (bc) {
-      if (x.stage.cap < (size_t)tot_r * 32 + 16) { rc = cm_exchange_quiesce(c); if (rc) return rc; }
-      if (x.stage.ensure((size_t)tot_r * 32 + 16)) { cm_set_error(c, "out of device memory (exchange staging)"); return CMGPU_ENOMEM; }
-      dest = (uint8_t *)x.stage.p;
-    } else {
+  if (c->store_n && tot_r && c->store_has_bc != bc) { cm_set_error(c, "record store mixes barcoded and bulk batches"); local_rc = CMGPU_EINVAL; }
+  if (!local_rc && tot_r) {
+    if (c->store_n + tot_r > c->store_cap || (bc && !c->store_bc.p)) local_rc = cm_exchange_quiesce(c);  // the store moves: the previous payload must have landed
+    if (!local_rc) local_rc = cm_store_reserve(c, c->store_n + tot_r, bc);
+    if (!local_rc && bc) {
+      if (x.stage.cap < (size_t)tot_r * 32 + 16) local_rc = cm_exchange_quiesce(c);
+      if (!local_rc && x.stage.ensure((size_t)tot_r * 32 + 16)) { cm_set_error(c, "out of device memory (exchange staging)"); local_rc = CMGPU_ENOMEM; }
+      if (!local_rc) dest = (uint8_t *)x.stage.p;
+    } else if (!local_rc) {
       dest = (uint8_t *)c->store.p + c->store_n * 24;
     }
+  }
+  if (world > 1) {  // one status word per rank; any failure makes every rank leave this step together
+    uint64_t status[EX_MAX_WORLD];
+    const uint64_t mine = (uint64_t)(uint32_t)(-local_rc);
+    if (x.transport == 1) {
+      const RcclApi *api = rccl_api();
+      M[0] = mine;
+      EXCHECK(c, hipMemcpyAsync(d_counts, M, 8, hipMemcpyHostToDevice, s));
+      NCCLCHECK(c, api, api->AllGather(d_counts, d_matrix, 1, ncclUint64, (ncclComm_t)x.comm, s));
+      EXCHECK(c, hipMemcpyAsync(M, d_matrix, (size_t)world * 8, hipMemcpyDeviceToHost, s));
+      EXCHECK(c, cm_stream_sync(s));
+      for (uint32_t r = 0; r < world; ++r) status[r] = M[r];
+    } else {
+      uint64_t all[EX_MAX_WORLD * 2];
+      if (x.ext.allgather_counts(x.ext.user, &mine, all, 1) != 0) { cm_set_error(c, "exchange transport: allgather_counts failed"); return CMGPU_EIO; }
+      for (uint32_t r = 0; r < world; ++r) status[r] = all[r];
+    }
+    if (local_rc) return local_rc;
+    for (uint32_t r = 0; r < world; ++r)
+      if (status[r]) { cm_set_error(c, "exchange: rank " + std::to_string(r) + " failed before the payload (status -" + std::to_string((unsigned long long)status[r]) + ")"); return CMGPU_EIO; }
+  } else if (local_rc) {
+    return local_rc;
   }
   if (x.transport == 1) {
     // The payload: this rank's own records by a device-to-device copy, the peers' by one grouped send / recv.  By default on

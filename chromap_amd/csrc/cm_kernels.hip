@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <cstring>
+#include <atomic>
 #include <rocprim/rocprim.hpp>
 
 #include "cm_kernels.h"
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(64) void k_s6b_sample(CmDev d, uint32_t n_chunks) {
     const uint32_t pair = base + threadIdx.x;
     int nb = 0;
     if (pair < hi) nb = d.pe_nbest[pair];
-    const bool multi = nb > 1 && nb <= d.p.drop_rep;
+    const bool multi = nb > 1 && (d.p.single || nb <= d.p.drop_rep);
     unsigned long long m = __ballot(multi);
     if (m == 0) continue;
     if (threadIdx.x == 0) {
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_stats(CmDev d, uint32_t n, unsigne
         if (nb == 1) v[3] += per;
         v[1] += per * (unsigned long long)(nb < d.p.max_best ? nb : d.p.max_best);
         if (nb > 0) v[2] += per;
-        if (nb > 1 && nb <= d.p.drop_rep) v[4] += 1;
+        if (nb > 1 && (d.p.single || nb <= d.p.drop_rep)) v[4] += 1;
       }
     }
     v[5] += (unsigned long long)d.aug[r1] + d.aug[r2];
@@ -1187,12 +1188,19 @@ uint32_t cm_s3b_lane_cap(uint32_t max_read_len) {
 }
 // the cooperative kernel's size classes: hits per wave-group, per block, per block with a large LDS allocation
 void cm_s3b_heavy_classes(uint32_t *hv_max) {
-  static int big_ok = -1;
-  if (big_ok < 0) {
-    big_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s3b_heavy<CM_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10 + (CM_BLOCK + 8) * 4) == hipSuccess ? 1 : 0;
+  // HIP function attributes belong to the device the call is made on (one process may drive several: chromap-amd --gpus N),
+  // so the large-LDS opt-in is made -- and remembered -- per device; lane threads of one device may race here, hence atomics
+  static std::atomic<int> big_ok[64];  // 0 unknown, 1 granted, 2 refused
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int slot = dev >= 0 && dev < 64 ? dev : 0;
+  int st = big_ok[slot].load(std::memory_order_acquire);
+  if (st == 0 || dev != slot) {
+    st = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_s3b_heavy<CM_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10 + (CM_BLOCK + 8) * 4) == hipSuccess ? 1 : 2;
     (void)hipGetLastError();
+    if (dev == slot) big_ok[slot].store(st, std::memory_order_release);
   }
-  hv_max[0] = 1024; hv_max[1] = 4096; hv_max[2] = big_ok ? 8192 : 4096;
+  hv_max[0] = 1024; hv_max[1] = 4096; hv_max[2] = st == 1 ? 8192 : 4096;
 }
 // n_cls[c]: reads of class c (k_s3a_count's lists)
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s) {

@@ -2927,7 +2927,7 @@ CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
   for (uint32_t pair = lo; pair < hi; ++pair) {
     const int nb = d.pe_nbest[pair];
     if (nb <= 1) continue;
-    if (nb > d.p.drop_rep) continue;  // mapping_generator.h:193-196: returns before drawing
+    if (!d.p.single && nb > d.p.drop_rep) continue;  // mapping_generator.h:190-193: returns before drawing (paired-end only: GenerateBestMappingsForSingleEndRead, :115-157, has no such test)
     if (!seeded || d.p.single) { cm_mt_seed(g, 11); seeded = true; }  // single-end: a fresh generator per read (mapping_generator.h:128)
     cm_reservoir(d, pair, nb, g);
   }
@@ -2939,7 +2939,7 @@ CM_HD void cm_s6b_sample(const CmDev &d, uint32_t chunk, CmMt &g) {
 template <bool SAM = false>
 CM_HD void cm_s6c_multi(const CmDev &d, uint32_t pair) {
   const int nb = d.pe_nbest[pair];
-  if (nb <= 1 || nb > d.p.drop_rep) return;
+  if (nb <= 1 || (!d.p.single && nb > d.p.drop_rep)) return;  // --drop-repetitive-reads applies to pairs only
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   CmPe pe;
   pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];

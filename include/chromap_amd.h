@@ -403,8 +403,9 @@ int cmgpu_records_partition(cmgpu_ctx *ctx, uint32_t world, void *device_dst, ui
 #define CMGPU_UNIQUE_ID_BYTES 128
 typedef struct cmgpu_exchange_transport {
   void *user;
-  /* mine[n] (n = world + 1: records this rank sends to each rank, then its record size) ->
-   * matrix[world * n], row r = rank r's `mine` */
+  /* mine[n] -> matrix[world * n], row r = rank r's `mine`.  Called twice per step: with n = world + 1 (records this
+   * rank sends to each rank, then its record size) and, when world > 1, with n = 1 (a status word: a rank that cannot
+   * take its share makes every rank leave the step before any payload moves) */
   int (*allgather_counts)(void *user, const uint64_t *mine, uint64_t *matrix, uint32_t n);
   /* send_dev: records grouped by destination rank (send_counts[world]); recv_dev: room for sum(recv_counts)
    * records, to be filled grouped by source rank; both are DEVICE pointers, record_bytes = 24 (32 with barcodes) */

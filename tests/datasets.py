@@ -129,6 +129,9 @@ def flags_to_params(flags):
         elif flags[i] == "-n":
             kw["max_num_best_mappings"] = int(flags[i + 1])
             i += 2
+        elif flags[i] == "--drop-repetitive-reads":
+            kw["drop_repetitive_reads"] = int(flags[i + 1])
+            i += 2
         elif flags[i] in ("--remove-pcr-duplicates", "--Tn5-shift", "--trim-adapters", "--low-mem"):
             kw[{"--remove-pcr-duplicates": "remove_pcr_duplicates", "--Tn5-shift": "tn5_shift",
                 "--trim-adapters": "trim_adapters", "--low-mem": "low_memory_mode"}[flags[i]]] = 1

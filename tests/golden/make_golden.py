@@ -26,7 +26,7 @@ GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 # single-end cases: which mate file is mapped alone
 SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1,
               "b1_se_bc": 1, "b3_se_bc_bulk_q0": 1, "b3_se_bc_inmem_q0": 2, "b1_se_bc_tagalign_q0": 1,
-              "s4_se_tagalign_q0": 2, "s4_se_n2_q0": 2}
+              "s4_se_tagalign_q0": 2, "s4_se_n2_q0": 2, "s4_se_drop2_q0": 2}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -114,6 +114,12 @@ CASES = {
                        "--seed", "5"], ["--preset", "atac", "-q", "0", "-n", "3"]),
     "s4_se_n2_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                      "--seed", "5"], ["--preset", "chip", "-q", "0", "-n", "2"]),
+    # --drop-repetitive-reads: pairs with more best mappings than this are dropped (mapping_generator.h:190-193); single-end
+    # reads are NOT (GenerateBestMappingsForSingleEndRead has no such test)
+    "s4_atac_drop2_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                          "--seed", "5"], ["--preset", "atac", "-q", "0", "--drop-repetitive-reads", "2"]),
+    "s4_se_drop2_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                        "--seed", "5"], ["--preset", "chip", "-q", "0", "--drop-repetitive-reads", "2"]),
     # --preset hic --SAM: split alignment with ksw on the aligned part of the read, AdjustGapBeginning on the CIGAR, SEQ cut to the
     # CIGAR's query length (sam_mapping.h:186-193), all four strand combinations
     "h2_hic_sam_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",

@@ -211,7 +211,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
         if (nbst == 1) st[CM_ST_UNIQ] += per;
         st[CM_ST_MAPPINGS] += per * (unsigned long long)(nbst < p.max_best ? nbst : p.max_best);
         if (nbst > 0) st[CM_ST_MAPPED] += per;
-        if (nbst > 1 && nbst <= p.drop_rep) st[CM_ST_MULTI] += 1;
+        if (nbst > 1 && (single || nbst <= p.drop_rep)) st[CM_ST_MULTI] += 1;
       }
     }
     st[CM_ST_RESCUED] += d.aug[r1] + d.aug[r2];
