@@ -12,6 +12,8 @@
 #include "../../include/chromap_amd.h"
 #include "../../chromap_amd/csrc/cm_mapq_tables.h"
 #include "../../chromap_amd/csrc/cm_stages.h"
+#include "../../chromap_amd/csrc/cm_coop.h"
+#include "emu_group.h"
 
 template <typename T>
 static void scan(const T *in, uint32_t *out, uint32_t n) {
@@ -25,6 +27,33 @@ static std::vector<uint32_t> g_rank;
 extern "C" void hostemu_set_chr_order(const uint32_t *rank, uint32_t n) { g_rank.assign(rank, rank + n); }
 static std::vector<uint32_t> g_pairs_rank;
 extern "C" void hostemu_set_pairs_chr_order(const uint32_t *rank, uint32_t n) { g_pairs_rank.assign(rank, rank + n); }
+
+// cooperative stage functions (cm_coop.h) for the reads / pairs with long lists: group size (0 = off), the list length
+// above which an item goes to a group, and the geometry of the group's shared work area
+struct EmuCoop { int G; uint32_t thr, P, MM, RB; };
+static EmuCoop g_coop = {0, 0, 0, 0, 0};
+static unsigned long long g_coop_items[8];  // items that went through each cooperative stage / fell back (tests look at them)
+extern "C" void hostemu_set_coop(int G, uint32_t thr, uint32_t P, uint32_t MM, uint32_t RB) {
+  g_coop = EmuCoop{G, thr, P, MM, RB};
+  memset(g_coop_items, 0, sizeof(g_coop_items));
+}
+static bool g_coop_reverse = false;  // lanes take their turns in descending order (emu_group.h)
+extern "C" void hostemu_set_coop_order(int reverse) { g_coop_reverse = reverse != 0; }
+extern "C" void hostemu_coop_items(unsigned long long *out) { memcpy(out, g_coop_items, sizeof(g_coop_items)); }
+
+template <int G>
+static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std::vector<uint8_t> &ok) {
+  std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB);
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      const bool done = cm_coop_s3b(d, list[i], g, m);
+      if (g.t == 0) ok[i] = done ? 1 : 0;
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
 
 struct EmuSam {
   cmgpu_sam_record *rec;  // 2n (pairs) or n (single) slots
@@ -168,7 +197,19 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   {  // k_s3b_candidates: lists of <= 16 hits are worked on in a strided (LDS-like) buffer
     std::vector<uint64_t> wh(16 * 7 + 8);
     std::vector<uint8_t> wc(16 * 7 + 8);
-    for (uint32_t r = 0; r < n2; ++r) cm_s3b_candidates_lds(d, r, wh.data() + (r % 7), wc.data() + (r % 7), 16, 7);
+    std::vector<uint32_t> heavy;
+    for (uint32_t r = 0; r < n2; ++r) {
+      if (g_coop.G && d.hit_tot[r] > g_coop.thr) { heavy.push_back(r); continue; }
+      cm_s3b_candidates_lds(d, r, wh.data() + (r % 7), wc.data() + (r % 7), 16, 7);
+    }
+    if (!heavy.empty()) {  // k_s3b_coop: a group of lanes per read; what it declines goes to the one-lane path
+      std::vector<uint8_t> ok(heavy.size(), 0);
+      if (g_coop.G == 16) emu_coop_s3b<16>(d, heavy, ok); else if (g_coop.G == 64) emu_coop_s3b<64>(d, heavy, ok); else emu_coop_s3b<256>(d, heavy, ok);
+      for (size_t i = 0; i < heavy.size(); ++i) {
+        g_coop_items[ok[i] ? 0 : 1] += 1;
+        if (!ok[i]) cm_s3b_candidates(d, heavy[i]);
+      }
+    }
   }
   for (uint32_t r = 0; r < n2; ++r) cm_s4a_rescue_count(d, r);
   scan(d.m_tot, d.m_off, n2);

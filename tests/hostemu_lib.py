@@ -19,11 +19,12 @@ def lib():
     if _L is None:
         so = os.path.join(ROOT, "tests", "hostemu", "libhostemu.so")
         srcs = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + \
-               [os.path.join(ROOT, "chromap_amd", "csrc", f) for f in ("cm_stages.h", "cm_types.h", "cm_host.cpp",
+               [os.path.join(ROOT, "tests", "hostemu", "emu_group.h")] + \
+               [os.path.join(ROOT, "chromap_amd", "csrc", f) for f in ("cm_stages.h", "cm_coop.h", "cm_types.h", "cm_host.cpp",
                                                                        "cm_mapq_tables.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
-                                   "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so, srcs[0],
+                                   "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-o", so, srcs[0],
                                    os.path.join(ROOT, "chromap_amd", "csrc", "cm_host.cpp")])
         _L = _capi.declare(C.CDLL(so))
         P = C.POINTER
