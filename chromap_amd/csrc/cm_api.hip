@@ -92,6 +92,8 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_heavy_mid = (int)value;
   } else if (n == "heavy_last") {
     c->opt_heavy_last = (int)value;
+  } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
+    c->opt_coop = (int)value;
   } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate
     c->opt_item_limit = value > 0 ? (uint64_t)value : 0xfffffff0ull;
   } else {
@@ -113,6 +115,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n == "prep_tile_reads") *value = c->opt_prep_tile_reads;
   else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
   else if (n == "lanes") *value = c->opt_lanes;
+  else if (n == "coop") *value = c->opt_coop;
   else return CMGPU_EINVAL;
   return CMGPU_OK;
 }
@@ -385,7 +388,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
-  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 64) ENS(hv_list, 5 * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
+  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 256) ENS(hv_list, CM_HV_LISTS * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
 #undef ENS
   return CMGPU_OK;
 }
@@ -800,7 +803,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     mark(c, "s1b_s2_minimizers_probe");
   }
   // S3: hit counts -> offsets -> candidates
-  HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 32, s));
+  HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
   cm_launch_k_s3a_count(d, n2, s);
   uint32_t n_heavy[5] = {0, 0, 0, 0, 0};  // classes 0..3 by size, 4: the short lists of the 16-lane groups
   HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, 20, hipMemcpyDeviceToHost, s));
@@ -812,7 +815,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s3a_count");
   cm_launch_k_s3b_candidates(d, n2, c->max_read_len, s);
-  cm_launch_k_s3b_heavy(d, n_heavy, s);  // reads with long hit lists: a wave or a block each
+  cm_launch_k_s3b_heavy(d, n_heavy, s, (c->opt_coop & 1) != 0, c->max_read_len);  // reads with long hit lists: a wave or a block each
   // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
   // (lists of class 0 -- up to heavy_wave_max hits, a wave each here -- cost the later per-lane stages little; a uniform genome
   // still has a few thousand of them per batch, and the permutation's scans and scatters cost more than they save there)
@@ -842,7 +845,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
   cm_launch_k_s4b_rescue_merge(d, n2, s);
-  cm_launch_k_s4b_rescue_list(d, n2, s);
+  cm_launch_k_s4b_rescue_list(d, n2, s, (c->opt_coop & 2) != 0, c->max_read_len);
   mark(c, "s4b_rescue_merge");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s4c_reduce(d, n, s);
@@ -947,7 +950,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   l->max_read_len = c->max_read_len; l->has_barcodes = c->has_barcodes; l->single = c->single;
   l->sam_slots = c->sam_slots; l->sam_md_cap = c->sam_md_cap;
   l->opt_probe_variant = c->opt_probe_variant; l->opt_mm_chunks = c->opt_mm_chunks; l->opt_prep_kernel = c->opt_prep_kernel;
-  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid;
+  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid; l->opt_coop = c->opt_coop;
   for (int q = 0; q < 3; ++q) l->opt_heavy_max[q] = c->opt_heavy_max[q];
   return CMGPU_OK;
 }

@@ -275,4 +275,142 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// S4b for one read whose rescue hits are many (cm_s4b_rescue_merge's results, element for element).  The hits of one
+// direction are already in place (out + n1 .., written minimizer by minimizer: ascending runs); the group
+//   sorts   them (natural runs + merge sort) and sweeps them with seeds_required = 1 into the augmented list X;
+//   merges  X with the read's own candidates c0 (MergeCandidates, candidate_processor.cc:345-414): the two lists are
+//           strictly ascending, so the sequential loop emits the merged sequence Z (equal positions once, with the larger
+//           count), keeping an entry iff it lies more than e beyond the last KEPT entry.  An entry more than e beyond its
+//           predecessor in Z is kept whatever came before ("sure start"); between sure starts the greedy rule runs
+//           sequentially -- every lane replays the (short) chain that reaches into its chunk of Z.  Z is laid out in the
+//           read's segment of the filtered-candidate arrays (zp / zc: same capacity, written only by S4c later).
+// Returns the merged list's length (every lane).  active == false: no augmentation in this direction, c0 is copied.
+// ---------------------------------------------------------------------------------------
+template <class GT>
+CM_HD uint32_t cm_coop_bcast0(GT &g, uint32_t v) { return (uint32_t)g.max64(g.t == 0 ? (uint64_t)v : 0ull); }
+
+template <class GT>
+CM_HD void cm_coop_copy_list(GT &g, const uint64_t *sp, const uint8_t *sc, uint64_t *dp, uint8_t *dc, uint32_t n) {
+  for (uint32_t i = g.t; i < n; i += (uint32_t)GT::G) { dp[i] = sp[i]; dc[i] = sc[i]; }
+}
+
+// the greedy rule over the lane's chunk [z0, z1) of Z: counts the kept entries, or (dp != nullptr) writes them from off on
+CM_HD uint32_t cm_coop_accept_walk(const uint64_t *zp, const uint8_t *zc, uint32_t nz, uint32_t z0, uint32_t z1, uint64_t E, uint64_t *dp,
+                                   uint8_t *dc, uint32_t off) {
+  if (z0 >= z1) return 0;
+  uint64_t last = 0;
+  if (z0 > 0 && !(zp[z0] > zp[z0 - 1] + E)) {  // the chunk starts inside a chain: replay it from its sure start
+    uint32_t s = z0 - 1;
+    while (s > 0 && !(zp[s] > zp[s - 1] + E)) --s;
+    last = zp[s];
+    for (uint32_t i = s + 1; i < z0; ++i)
+      if (zp[i] > last + E) last = zp[i];
+  }
+  uint32_t cnt = 0;
+  for (uint32_t i = z0; i < z1; ++i) {
+    const uint64_t x = zp[i];
+    const bool keep = i == 0 || x > zp[i - 1] + E || x > last + E;
+    if (!keep) continue;
+    last = x;
+    if (dp) {
+      uint8_t c = zc[i];
+      if (i + 1 < nz && zp[i + 1] == x && zc[i + 1] > c) c = zc[i + 1];
+      dp[off + cnt] = x;
+      dc[off + cnt] = c;
+    }
+    ++cnt;
+  }
+  return cnt;
+}
+
+template <class GT>
+CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m, uint64_t *out, uint8_t *outc, uint32_t n1, uint32_t cnt,
+                                  bool active, const uint64_t *c0p, const uint8_t *c0c, uint64_t *zp, uint8_t *zc) {
+  const int e = d.p.e;
+  if (!active || cnt == 0) {
+    cm_coop_copy_list(g, c0p, c0c, out, outc, n1);
+    return n1;
+  }
+  uint32_t nr = 0;
+  if (cnt <= m.P) {
+    for (uint32_t i = g.t; i < cnt; i += (uint32_t)GT::G) m.A[i] = out[n1 + i];
+    g.sync();
+    nr = cm_coop_natural_runs(g, m.A, cnt, m.rb, m.RB);
+  }
+  if (nr == 0) {  // more hits or runs than the work area holds: the one-lane definition
+    uint32_t k = 0;
+    if (g.t == 0) {
+      cm_sort_u64(out + n1, cnt);
+      const uint32_t naug = cm_sweep(out + n1, outc + n1, cnt, e, 1, d.mm_cnt[r]);
+      if (naug > 0) k = cm_merge(c0p, c0c, n1, out, outc, naug, e);
+      else { for (uint32_t i = 0; i < n1; ++i) { out[i] = c0p[i]; outc[i] = c0c[i]; } k = n1; }
+    }
+    return cm_coop_bcast0(g, k);
+  }
+  uint64_t *S = cm_coop_merge_runs(g, m.A, m.B, m.rb, m.rb2, nr, cnt);
+  uint64_t *X = S == m.A ? m.B : m.A;
+  uint32_t naug, none;
+  cm_coop_sweep(g, S, cnt, cnt, e, 1, d.mm_cnt[r], m.oc, X, m.cc, X, m.cc, &naug, &none);
+  g.sync();  // X / cc complete, S free
+  if (naug == 0) {
+    cm_coop_copy_list(g, c0p, c0c, out, outc, n1);
+    return n1;
+  }
+  if (n1 == 0) {  // c1.swap(c2): the augmented list as it is (no distance rule)
+    for (uint32_t i = g.t; i < naug; i += (uint32_t)GT::G) { out[i] = X[i]; outc[i] = m.cc[i]; }
+    return naug;
+  }
+  // ---- Z = merge of c0 (staged in S when it fits) and X, ties: c0 first
+  const uint64_t *a = c0p;
+  if (n1 <= m.P) {
+    for (uint32_t i = g.t; i < n1; i += (uint32_t)GT::G) S[i] = c0p[i];
+    g.sync();
+    a = S;
+  }
+  const uint32_t nz = n1 + naug;
+  const uint32_t VT = (nz + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t z0 = cm_min_u32(nz, g.t * VT), z1 = cm_min_u32(nz, z0 + VT);
+  if (z0 < z1) {
+    uint32_t lo = z0 > naug ? z0 - naug : 0, hi = z0 < n1 ? z0 : n1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a[mid] <= X[z0 - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    uint32_t ia = lo, ib = z0 - lo;
+    for (uint32_t z = z0; z < z1; ++z) {
+      const bool take_a = ib >= naug || (ia < n1 && a[ia] <= X[ib]);
+      if (take_a) { zp[z] = a[ia]; zc[z] = c0c[ia]; ++ia; }
+      else { zp[z] = X[ib]; zc[z] = m.cc[ib]; ++ib; }
+    }
+  }
+  g.sync();
+  // ---- keep / drop, compaction
+  const uint64_t E = (uint64_t)(int64_t)e;
+  const uint32_t mine = cm_coop_accept_walk(zp, zc, nz, z0, z1, E, nullptr, nullptr, 0);
+  uint32_t total;
+  const uint32_t off = g.scan(mine, &total);
+  (void)cm_coop_accept_walk(zp, zc, nz, z0, z1, E, out, outc, off);
+  return total;
+}
+
+template <class GT>
+CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
+  const uint32_t o = r ^ 1u;
+  const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
+  uint64_t *P = d.mbuf + d.m_off[r];
+  uint8_t *PC = d.mcnt + d.m_off[r];
+  uint64_t *N = P + ncp + rp;
+  uint8_t *NC = PC + ncp + rp;
+  uint64_t *ZP = d.fbuf + d.m_off[r];
+  uint8_t *ZC = d.fcnt + d.m_off[r];
+  const bool aug = d.aug[r] != 0;
+  const bool do_n = aug && d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0;
+  const bool do_p = aug && d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0;
+  const uint32_t mcn = cm_coop_rescue_dir(d, r, g, m, N, NC, ncn, rn, do_n, cm_c0_neg(d, r), cm_c0_ncnt(d, r), ZP + ncp + rp, ZC + ncp + rp);
+  g.sync();  // the work area is reused
+  const uint32_t mcp = cm_coop_rescue_dir(d, r, g, m, P, PC, ncp, rp, do_p, cm_c0_pos(d, r), cm_c0_pcnt(d, r), ZP, ZC);
+  if (g.t == 0) { d.mcp[r] = mcp; d.mcn[r] = mcn; }
+}
+
 #endif

@@ -23,13 +23,13 @@ CM_DECL_LAUNCH(k_s3a_count)
 void cm_launch_k_sort_lists(const CmDev &d, int mode, hipStream_t s);
 uint32_t cm_s3b_lane_cap(uint32_t max_read_len);
 void cm_s3b_heavy_classes(uint32_t *hv_max);
-void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s);
+void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len);
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
 CM_DECL_LAUNCH(k_s4a_rescue_count)
 CM_DECL_LAUNCH(k_s4b_rescue_merge)
 uint32_t cm_rescue_seg_cap(uint32_t n_reads);
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s);
-void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s);
+void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len);
 CM_DECL_LAUNCH(k_s4c_reduce)
 CM_DECL_LAUNCH(k_s5a_prepare)
 CM_DECL_LAUNCH(k_s5c_finalize)

@@ -4,10 +4,14 @@
 #include <string.h>
 #include <cstring>
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <rocprim/rocprim.hpp>
 
 #include "cm_kernels.h"
 #include "cm_stages.h"
+#include "cm_coop.h"
 
 #define CM_BLOCK 256
 
@@ -395,15 +399,18 @@ __device__ __forceinline__ void cm_group_sync() {
   }
 }
 
+// n_list_dev (or nullptr): the list's length when only the device knows it (reads the merge-sort kernel declined); the
+// grid then strides over the list
 template <int G>
-__global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P) {
+__global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P,
+                                                        const uint32_t *__restrict__ n_list_dev) {
   constexpr int GPB = CM_BLOCK / G;  // groups per block
   const uint32_t grp = threadIdx.x / G, t = threadIdx.x % G;
-  const uint32_t gid = blockIdx.x * GPB + grp;
-  if (gid >= n_list) return;  // whole group (a wave, or the block)
+  if (n_list_dev) n_list = *n_list_dev;
   uint64_t *S = reinterpret_cast<uint64_t *>(cm_lds) + (size_t)grp * P;
   uint16_t *oc = reinterpret_cast<uint16_t *>(cm_lds + (size_t)GPB * P * 8) + (size_t)grp * P;
   uint32_t *ctr = reinterpret_cast<uint32_t *>(cm_lds + (size_t)GPB * P * 10) + (size_t)grp * (G + 8);
+  for (uint32_t gid = blockIdx.x * GPB + grp; gid < n_list; gid += gridDim.x * GPB) {  // whole group (a wave, or the block)
   const uint32_t r = list[gid];
   const uint32_t tot = d.hit_tot[r];
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
@@ -529,6 +536,87 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t 
     }
   }
   if (t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
+  cm_group_sync<G>();  // the next read of this group reuses S / oc / ctr
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The group type of cm_coop.h on the device: G = 16 (a quarter wave), 64 (a wave) or CM_BLOCK lanes.  rank() is a
+// ballot, scan() a shuffle scan inside the wave part plus, for a block, the wave totals through LDS (xw).
+// ---------------------------------------------------------------------------------------
+template <int G_>
+struct CmDevGroup {
+  static constexpr int G = G_;
+  static constexpr int W = G_ < 64 ? G_ : 64;
+  uint32_t t;
+  uint32_t *xw;  // LDS, 2 * (G / W) words of this group (unused when G <= 64)
+  __device__ __forceinline__ void sync() { cm_group_sync<G_>(); }
+  __device__ __forceinline__ uint32_t rank(bool p, uint32_t *total) {
+    unsigned long long m = __ballot(p);
+    if (W < 64) m = (m >> ((threadIdx.x & 63u) / W * W)) & ((1ull << W) - 1ull);
+    *total = (uint32_t)__popcll(m);
+    return (uint32_t)__popcll(m & ((1ull << (t % W)) - 1ull));
+  }
+  __device__ __forceinline__ uint32_t scan(uint32_t v, uint32_t *total) {
+    const uint32_t wl = t % W;
+    uint32_t incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < W; dlt <<= 1) {
+      const uint32_t x = __shfl_up(incl, dlt, W);
+      if (wl >= (uint32_t)dlt) incl += x;
+    }
+    if (G <= 64) {
+      *total = __shfl(incl, W - 1, W);
+      return incl - v;
+    }
+    const uint32_t wv = t / W;
+    if (wl == W - 1) xw[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < G / W; ++q) { const uint32_t x = xw[q]; base += (uint32_t)q < wv ? x : 0u; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+  }
+  __device__ __forceinline__ uint64_t max64(uint64_t v) {
+#pragma unroll
+    for (int dlt = W / 2; dlt > 0; dlt >>= 1) {
+      const uint64_t x = __shfl_xor(v, dlt, W);
+      v = x > v ? x : v;
+    }
+    if (G <= 64) return v;
+    uint64_t *xq = reinterpret_cast<uint64_t *>(xw);
+    if (t % W == 0) xq[t / W] = v;
+    __syncthreads();
+    uint64_t mx = 0;
+#pragma unroll
+    for (int q = 0; q < G / W; ++q) mx = xq[q] > mx ? xq[q] : mx;
+    __syncthreads();
+    return mx;
+  }
+  __device__ __forceinline__ uint64_t min64(uint64_t v) { return ~max64(~v); }
+  __device__ __forceinline__ uint32_t sum(uint32_t v) { uint32_t tot; (void)scan(v, &tot); return tot; }
+};
+// per-group LDS: the cooperative work area, then the group's cross-wave words
+__host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, uint32_t RB) { return ((cm_coop_mem_bytes(P, MM, RB) + 15) & ~(size_t)15) + 64; }
+
+// S3b for long hit lists, merge-sort form (cm_coop_s3b): blockDim.x / G groups per block, one listed read each.  What the
+// function declines (more occurrence runs than its tables hold) is appended to fb_list for the bitonic kernel above.
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
+                                                       uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt) {
+  const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
+  const uint32_t gid = blockIdx.x * gpb + grp;
+  if (gid >= n_list) return;  // a whole group
+  const size_t gb = cm_coop_group_bytes(P, MM, RB);
+  uint8_t *base = cm_lds + (size_t)grp * gb;
+  const CmCoopMem m = cm_coop_mem_at(base, P, MM, RB);
+  CmDevGroup<G> g;
+  g.t = threadIdx.x % G;
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - 64);
+  const uint32_t r = list[gid];
+  if (!cm_coop_s3b(d, r, g, m) && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
 }
 
 // lists too long for the groups' LDS: one lane each, in the read's global segment (rare: > 8192 hits)
@@ -685,29 +773,65 @@ __device__ __forceinline__ void cm_group_rescue_fill(const CmDev &d, uint32_t r,
     (void)cm_rescue_minimizer(d, strand, mp, mc, mn, max_count, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], out + lds_cnt[mi], nullptr);
   cm_group_sync<CM_RS_G>();
 }
-__global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap) {
+// Reads with many rescue hits (more than CM_RS_COOP_MIN on a strand) only get their hits written here; sorting, clustering and
+// merging them is the work of a group of lanes (k_s4b_coop), by size class: list 6 up to hv_max[0] hits (a wave each), 7 up to
+// hv_max[1], 8 up to hv_max[2] (a block each).  coop == 0: everything by one lane, as before.
+#define CM_RS_COOP_MIN 32u
+__device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_t r, uint32_t coop) {
+  const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
+  if (!coop || big <= CM_RS_COOP_MIN || d.hv_max[0] == 0) return 0;
+  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : 0u;
+}
+__global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
-  for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) {
-    const uint32_t r = list[j];
-    if (d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r)) cm_s4b_rescue_merge(d, r);
+  for (uint32_t j0 = blockIdx.x * 64; j0 < cnt; j0 += gridDim.x * 64) {  // whole waves (the appends below are wave-wide)
+    const uint32_t j = j0 + threadIdx.x;
+    const uint32_t r = j < cnt ? list[j] : 0u;
+    const bool mine = j < cnt && d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r);
+    const uint32_t cls = mine ? cm_rescue_coop_class(d, r, coop) : 0u;
+    if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
+    for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
   }
   const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < cnt; j += gridDim.x * gpb) {
-    const uint32_t r = list[j];
-    if (!cm_rescue_is_heavy(d, r) || d.resc_n[r] + d.resc_p[r] == 0) continue;  // uniform in the group
-    const uint32_t o = r ^ 1u;
-    const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
-    uint64_t *P = d.mbuf + d.m_off[r];
-    uint64_t *N = P + ncp + rp;
-    // same conditions and destinations as cm_s4b_rescue_merge
-    if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0)
-      cm_group_rescue_fill(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], t, sh_cnt[grp], N + ncn);
-    if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0)
-      cm_group_rescue_fill(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], t, sh_cnt[grp], P + ncp);
-    __threadfence_block();
-    if (t == 0) cm_s4b_rescue_merge(d, r, true);  // sort, cluster, merge of the hits the group wrote
+  for (uint32_t j0 = blockIdx.x * gpb; j0 < cnt; j0 += gridDim.x * gpb) {
+    const uint32_t j = j0 + grp;
+    const uint32_t r = j < cnt ? list[j] : 0u;
+    const bool mine = j < cnt && cm_rescue_is_heavy(d, r) && d.resc_n[r] + d.resc_p[r] > 0;  // uniform in the group
+    uint32_t cls = 0;
+    if (mine) {
+      const uint32_t o = r ^ 1u;
+      const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
+      uint64_t *P = d.mbuf + d.m_off[r];
+      uint64_t *N = P + ncp + rp;
+      // same conditions and destinations as cm_s4b_rescue_merge
+      if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0)
+        cm_group_rescue_fill(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], t, sh_cnt[grp], N + ncn);
+      if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0)
+        cm_group_rescue_fill(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], t, sh_cnt[grp], P + ncp);
+      __threadfence_block();
+      cls = cm_rescue_coop_class(d, r, coop);
+      if (t == 0 && !cls) cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);  // sort, cluster, merge of the hits the group wrote
+    }
+    for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, t == 0 && cls == c, r);
+  }
+}
+// S4b for the reads listed above: a group per read sorts its rescue hits, clusters them and merges them with the read's
+// candidates (cm_coop_rescue_merge).  The list's length is only known on the device: the grid strides over it.
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s4b_coop(CmDev d, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev, uint32_t P, uint32_t RB) {
+  const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
+  const uint32_t n_list = *n_list_dev;
+  const size_t gb = cm_coop_group_bytes(P, 1, RB);
+  uint8_t *base = cm_lds + (size_t)grp * gb;
+  const CmCoopMem m = cm_coop_mem_at(base, P, 1, RB);
+  CmDevGroup<G> g;
+  g.t = threadIdx.x % G;
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - 64);
+  for (uint32_t gid = blockIdx.x * gpb + grp; gid < n_list; gid += gridDim.x * gpb) {
+    cm_coop_rescue_merge(d, list[gid], g, m);
+    g.sync();  // the work area is reused
   }
 }
 // S4c; long filtered candidate lists are queued for k_sort_lists
@@ -1202,21 +1326,75 @@ void cm_s3b_heavy_classes(uint32_t *hv_max) {
   }
   hv_max[0] = 1024; hv_max[1] = 4096; hv_max[2] = st == 1 ? 8192 : 4096;
 }
-// n_cls[c]: reads of class c (k_s3a_count's lists)
-void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s) {
+// the largest dynamic LDS allocation a kernel of this device may ask for, opted in once per device and kernel
+template <class K>
+static bool cm_lds_optin(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;
+  if (bytes > 160 * 1024) return false;
+  // function attributes belong to the device the call is made on; remember the largest size granted (or refused) per device
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, std::pair<size_t, size_t>> seen;  // -> (granted up to, refused from)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::pair<int, const void *> key(dev, reinterpret_cast<const void *>(kernel));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = seen.find(key);
+  if (it != seen.end()) {
+    if (bytes <= it->second.first) return true;
+    if (it->second.second && bytes >= it->second.second) return false;
+  }
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  (void)hipGetLastError();
+  std::pair<size_t, size_t> &v = seen[key];
+  if (e == hipSuccess) { if (bytes > v.first) v.first = bytes; } else if (!v.second || bytes < v.second) v.second = bytes;
+  return e == hipSuccess;
+}
+// n_cls[c]: reads of class c (k_s3a_count's lists).  coop: classes 0..2 go through the merge-sort kernel (tables sized for
+// reads of up to max_read_len bases); what it declines -- hv_cnt[5] reads at list 5 -- is taken by the bitonic kernel.
+void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len) {
   const uint32_t *l0 = d.hv_list, *l1 = d.hv_list + d.hv_stride, *l2 = d.hv_list + 2 * (size_t)d.hv_stride, *l3 = d.hv_list + 3 * (size_t)d.hv_stride;
   auto pow2 = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };  // the sort network's size: a power of two
+  bool any_coop = false;
+  if (coop) {
+    // a read of L bases has at most L - k + 1 minimizers; the tables hold that many (capped), two runs per minimizer
+    uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
+    if (MM > 256) MM = 256;
+    const uint32_t RB = 2 * MM + 2;
+    uint32_t *fb_list = d.hv_list + 5 * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + 5;
+    uint32_t rest[3] = {n_cls[0], n_cls[1], n_cls[2]};
+    if (n_cls[0]) {  // a wave per read, two reads per block
+      const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB);
+      if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
+        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, l0, n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt);
+        rest[0] = 0; any_coop = true;
+      }
+    }
+    for (int c = 1; c <= 2; ++c) {
+      if (!n_cls[c] || (c == 2 && d.hv_max[2] == d.hv_max[1])) continue;
+      const size_t lds = cm_coop_group_bytes(d.hv_max[c], MM, RB);
+      if (!cm_lds_optin(&k_s3b_coop<CM_BLOCK>, lds)) continue;
+      hipLaunchKernelGGL(k_s3b_coop<CM_BLOCK>, dim3(n_cls[c]), dim3(CM_BLOCK), lds, s, d, c == 1 ? l1 : l2, n_cls[c], d.hv_max[c], MM, RB, fb_list, fb_cnt);
+      rest[c] = 0; any_coop = true;
+    }
+    if (any_coop) {  // the declined reads: up to hv_max[2] hits, a block each, the grid strides over the device-side list
+      const uint32_t P = pow2(d.hv_max[2]);
+      hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(512), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, (const uint32_t *)fb_list, 0u, P, (const uint32_t *)fb_cnt);
+    }
+    uint32_t n2[5] = {rest[0], rest[1], rest[2], n_cls[3], n_cls[4]};
+    cm_launch_k_s3b_heavy(d, n2, s, false, max_read_len);
+    return;
+  }
   if (n_cls[0]) {
     const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
-    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((n_cls[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, l0, n_cls[0], P);
+    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((n_cls[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, l0, n_cls[0], P, (const uint32_t *)nullptr);
   }
-  if (n_cls[1]) { const uint32_t P = pow2(d.hv_max[1]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], P); }
-  if (n_cls[2]) { const uint32_t P = pow2(d.hv_max[2]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], P); }
+  if (n_cls[1]) { const uint32_t P = pow2(d.hv_max[1]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], P, (const uint32_t *)nullptr); }
+  if (n_cls[2]) { const uint32_t P = pow2(d.hv_max[2]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], P, (const uint32_t *)nullptr); }
   if (n_cls[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((n_cls[3] + 63) / 64), dim3(64), 0, s, d, l3, n_cls[3]);
   if (n_cls[4]) {  // groups of 16 lanes, 16 reads per block
     const uint32_t *l4 = d.hv_list + 4 * (size_t)d.hv_stride;
     const uint32_t P = pow2(d.hv_mid), gpb = CM_BLOCK / 16;
-    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((n_cls[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, l4, n_cls[4], P);
+    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((n_cls[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, l4, n_cls[4], P, (const uint32_t *)nullptr);
   }
 }
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
@@ -1242,8 +1420,28 @@ static inline dim3 rescue_list_grid(uint32_t n_reads) {
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s) {
   if (n_reads) hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads));
 }
-void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s) {
-  if (n_reads) hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads));
+// coop: reads with many rescue hits are only filled by the list kernel and finished by groups of lanes (k_s4b_coop)
+void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len) {
+  if (!n_reads) return;
+  uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
+  if (MM > 256) MM = 256;
+  const uint32_t RB = 2 * MM + 2;  // ascending runs the sorter's tables hold: one per minimizer unless a diagonal wraps
+  bool ok[3] = {false, false, false};
+  size_t lds[3] = {0, 0, 0};
+  if (coop && d.hv_max[0]) {
+    lds[0] = 2 * cm_coop_group_bytes(d.hv_max[0], 1, RB);
+    ok[0] = cm_lds_optin(&k_s4b_coop<64>, lds[0]);
+    for (int c = 1; c <= 2; ++c) { lds[c] = cm_coop_group_bytes(d.hv_max[c], 1, RB); ok[c] = cm_lds_optin(&k_s4b_coop<CM_BLOCK>, lds[c]); }
+  }
+  const bool all = ok[0] && ok[1] && ok[2];
+  hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
+  if (!all) return;
+  uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, (const uint32_t *)(d.hv_list + 6 * (size_t)d.hv_stride), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB);
+  hipLaunchKernelGGL(k_s4b_coop<CM_BLOCK>, dim3(blocks), dim3(CM_BLOCK), lds[1], s, d, (const uint32_t *)(d.hv_list + 7 * (size_t)d.hv_stride), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB);
+  if (d.hv_max[2] > d.hv_max[1])
+    hipLaunchKernelGGL(k_s4b_coop<CM_BLOCK>, dim3(blocks > 256 ? 256 : blocks), dim3(CM_BLOCK), lds[2], s, d, (const uint32_t *)(d.hv_list + 8 * (size_t)d.hv_stride), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB);
 }
 CM_LAUNCH(k_s4c_reduce)
 CM_LAUNCH(k_s5a_prepare)

@@ -1348,11 +1348,16 @@ CM_HD uint32_t cm_merge(const uint64_t *p1, const uint8_t *c1, uint32_t n1, uint
 //      (capacity ncn+resc_n).  Rescue hits are staged at the END of each region so the
 //      merge can write from the front without overtaking unread input.
 // ---------------------------------------------------------------------------------------
-// prefilled: the rescue hits are already in place (a group of lanes wrote them, k_s4b_rescue_list); their numbers are the
-// counts of S4a
-CM_HD void cm_s4b_rescue_merge(const CmDev &d, uint32_t r, bool prefilled = false) {
+// mode CM_S4B_ALL: fill, sort, cluster, merge.  CM_S4B_PREFILLED: the rescue hits are already in place (a group of lanes
+// wrote them, k_s4b_rescue_list); their numbers are the counts of S4a.  CM_S4B_FILL_ONLY: only write the rescue hits -- a
+// group of lanes sorts and merges them afterwards (cm_coop_rescue_merge, cm_coop.h).
+#define CM_S4B_ALL 0
+#define CM_S4B_PREFILLED 1
+#define CM_S4B_FILL_ONLY 2
+CM_HD void cm_s4b_rescue_merge(const CmDev &d, uint32_t r, int mode = CM_S4B_ALL) {
+  const bool prefilled = mode == CM_S4B_PREFILLED;
   const uint32_t o = r ^ 1u;
-  d.mcp[r] = 0; d.mcn[r] = 0;
+  if (mode != CM_S4B_FILL_ONLY) { d.mcp[r] = 0; d.mcn[r] = 0; }
   if (d.m_tot[r] == 0) return;
   const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
   uint64_t *P = d.mbuf + d.m_off[r];
@@ -1366,15 +1371,20 @@ CM_HD void cm_s4b_rescue_merge(const CmDev &d, uint32_t r, bool prefilled = fals
     uint32_t cnt = 0, rl = 0;
     if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) {
       if (prefilled) cnt = rn; else cm_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], N + ncn, &cnt, &rl, nullptr);
-      cm_sort_u64(N + ncn, cnt);
-      naug_n = cm_sweep(N + ncn, NC + ncn, cnt, d.p.e, 1, d.mm_cnt[r]);
+      if (mode != CM_S4B_FILL_ONLY) {
+        cm_sort_u64(N + ncn, cnt);
+        naug_n = cm_sweep(N + ncn, NC + ncn, cnt, d.p.e, 1, d.mm_cnt[r]);
+      }
     }
     if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0) {
       if (prefilled) cnt = rp; else cm_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], P + ncp, &cnt, &rl, nullptr);
-      cm_sort_u64(P + ncp, cnt);
-      naug_p = cm_sweep(P + ncp, PC + ncp, cnt, d.p.e, 1, d.mm_cnt[r]);
+      if (mode != CM_S4B_FILL_ONLY) {
+        cm_sort_u64(P + ncp, cnt);
+        naug_p = cm_sweep(P + ncp, PC + ncp, cnt, d.p.e, 1, d.mm_cnt[r]);
+      }
     }
   }
+  if (mode == CM_S4B_FILL_ONLY) return;
   if (naug_p > 0) {
     d.mcp[r] = cm_merge(p0, pc0, ncp, P, PC, naug_p, d.p.e);
   } else {

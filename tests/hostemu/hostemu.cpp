@@ -55,6 +55,19 @@ static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std:
   }, g_coop_reverse);
 }
 
+template <int G>
+static void emu_coop_rescue(const CmDev &d, const std::vector<uint32_t> &list) {
+  std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB);
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      cm_coop_rescue_merge(d, list[i], g, m);
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
+
 struct EmuSam {
   cmgpu_sam_record *rec;  // 2n (pairs) or n (single) slots
   uint32_t *cigar;
@@ -216,7 +229,22 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   const uint32_t n_m = d.m_off[n2];
   VEC(mbuf, uint64_t, n_m) VEC(mcnt, uint8_t, n_m) VEC(fbuf, uint64_t, n_m) VEC(fcnt, uint8_t, n_m)
   VEC(dpos, uint64_t, n_m) VEC(derr, int16_t, n_m) VEC(dsplit, uint32_t, n_m)
-  for (uint32_t r = 0; r < n2; ++r) cm_s4b_rescue_merge(d, r);
+  {
+    std::vector<uint32_t> heavy;
+    for (uint32_t r = 0; r < n2; ++r) {
+      const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
+      if (g_coop.G && d.aug[r] && big > g_coop.thr) {  // k_s4b_rescue_list fills, k_s4b_coop sorts and merges
+        cm_s4b_rescue_merge(d, r, CM_S4B_FILL_ONLY);
+        heavy.push_back(r);
+      } else {
+        cm_s4b_rescue_merge(d, r);
+      }
+    }
+    if (!heavy.empty()) {
+      g_coop_items[2] += heavy.size();
+      if (g_coop.G == 16) emu_coop_rescue<16>(d, heavy); else if (g_coop.G == 64) emu_coop_rescue<64>(d, heavy); else emu_coop_rescue<256>(d, heavy);
+    }
+  }
   for (uint32_t i = 0; i < n; ++i) cm_s4c_reduce(d, i);
   VEC(nv, uint32_t, n2) VEC(v_off, uint32_t, n2 + 1) VEC(v_err, int16_t, n_m) VEC(v_end, int16_t, n_m)
   for (uint32_t r = 0; r < n2; ++r) cm_s5a_prepare(d, r);
@@ -468,4 +496,48 @@ extern "C" int hostemu_minimizers_flat(const uint8_t *seq, uint32_t len, int k, 
   for (uint32_t i = 0; i < m; ++i)
     if (fl[i]) { put(n, h[i], ((i + (uint32_t)k - 1) << 1) | st[i]); ++n; }
   return (int)n;
+}
+
+// cm_coop_rescue_dir (sort + sweep + MergeCandidates by a group) against the one-lane sequence cm_sort_u64, cm_sweep,
+// cm_merge on caller-made lists: c0 (strictly ascending positions + counts) and unsorted rescue hits.  Returns 0 when equal.
+template <int G>
+static int emu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c, uint32_t n1, const uint64_t *hits, uint32_t cnt, int e, uint32_t nm,
+                                uint32_t P, uint32_t RB, bool reverse) {
+  CmDev d;
+  memset(&d, 0, sizeof(d));
+  d.p.e = e;
+  uint32_t mmc[1] = {nm};
+  d.mm_cnt = mmc;
+  // sequential
+  std::vector<uint64_t> so((size_t)n1 + cnt + 1);
+  std::vector<uint8_t> soc((size_t)n1 + cnt + 1);
+  for (uint32_t i = 0; i < cnt; ++i) so[n1 + i] = hits[i];
+  uint32_t want;
+  {
+    cm_sort_u64(so.data() + n1, cnt);
+    const uint32_t naug = cm_sweep(so.data() + n1, soc.data() + n1, cnt, e, 1, nm);
+    if (naug > 0) want = cm_merge(c0p, c0c, n1, so.data(), soc.data(), naug, e);
+    else { for (uint32_t i = 0; i < n1; ++i) { so[i] = c0p[i]; soc[i] = c0c[i]; } want = n1; }
+  }
+  // cooperative
+  std::vector<uint64_t> go((size_t)n1 + cnt + 1), zp((size_t)n1 + cnt + 1);
+  std::vector<uint8_t> goc((size_t)n1 + cnt + 1), zc((size_t)n1 + cnt + 1);
+  for (uint32_t i = 0; i < cnt; ++i) go[n1 + i] = hits[i];
+  std::vector<uint8_t> mem(cm_coop_mem_bytes(P, 4, RB) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopMem m = cm_coop_mem_at(base, P, 4, RB);
+  uint32_t got = 0;
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    const uint32_t k = cm_coop_rescue_dir(d, 0, g, m, go.data(), goc.data(), n1, cnt, true, c0p, c0c, zp.data(), zc.data());
+    if (g.t == 0) got = k;
+  }, reverse);
+  if (got != want) return 1;
+  for (uint32_t i = 0; i < want; ++i) if (go[i] != so[i] || goc[i] != soc[i]) return 2;
+  return 0;
+}
+extern "C" int hostemu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c, uint32_t n1, const uint64_t *hits, uint32_t cnt, int e, uint32_t nm,
+                                        int G, uint32_t P, uint32_t RB, int reverse) {
+  if (G == 16) return emu_rescue_dir_check<16>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
+  if (G == 64) return emu_rescue_dir_check<64>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
+  return emu_rescue_dir_check<256>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
 }
