@@ -92,6 +92,8 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_heavy_mid = (int)value;
   } else if (n == "heavy_last") {
     c->opt_heavy_last = (int)value;
+  } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
+    c->opt_coop_rb = (int)value;
   } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
     c->opt_coop = (int)value;
   } else if (n == "item_limit") {  // forces the sub-batch path (tests): largest dense intermediate the pipeline may allocate
@@ -633,6 +635,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.hv_stride = 2 * (hi - lo) + 1;
   d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
+  d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
     cm_s3b_heavy_classes(d.hv_max);
@@ -950,7 +953,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   l->max_read_len = c->max_read_len; l->has_barcodes = c->has_barcodes; l->single = c->single;
   l->sam_slots = c->sam_slots; l->sam_md_cap = c->sam_md_cap;
   l->opt_probe_variant = c->opt_probe_variant; l->opt_mm_chunks = c->opt_mm_chunks; l->opt_prep_kernel = c->opt_prep_kernel;
-  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid; l->opt_coop = c->opt_coop;
+  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid; l->opt_coop = c->opt_coop; l->opt_coop_rb = c->opt_coop_rb;
   for (int q = 0; q < 3; ++q) l->opt_heavy_max[q] = c->opt_heavy_max[q];
   return CMGPU_OK;
 }

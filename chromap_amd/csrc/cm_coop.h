@@ -144,10 +144,11 @@ struct CmCoopMem {
   uint32_t *moff;       // MM + 1: start of an included minimizer's segment
   uint32_t *mpc;        // MM: its + hits
   uint32_t *mmi;        // MM: its index in the read's minimizer list
+  uint32_t *mps, *mns;  // MM each: start of its + / - sub-list in the compacted list
   uint32_t P, MM, RB;
 };
 CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB) {
-  return (size_t)P * 19 + ((size_t)2 * (RB + 1) + (size_t)MM * 3 + 1) * 4 + 32;
+  return (size_t)P * 19 + ((size_t)2 * (RB + 1) + (size_t)MM * 5 + 1) * 4 + 32;
 }
 // carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB) bytes)
 CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB) {
@@ -160,7 +161,9 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
   m.moff = m.rb2 + RB + 1;
   m.mpc = m.moff + MM + 1;
   m.mmi = m.mpc + MM;
-  m.oc = reinterpret_cast<uint16_t *>(m.mmi + MM);
+  m.mps = m.mmi + MM;
+  m.mns = m.mps + MM;
+  m.oc = reinterpret_cast<uint16_t *>(m.mns + MM);
   m.cc = reinterpret_cast<uint8_t *>(m.oc + P);
   return m;
 }
@@ -229,7 +232,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
     if (g.t % (uint32_t)GT::W == 0) m.mpc[ri] = pc;
   }
   g.sync();
-  // ---- compact: starts of every minimizer's + and - sub-list in A (rb / rb2 as scratch)
+  // ---- compact: starts of every minimizer's + and - sub-list in A
   uint32_t np = 0;
   {
     uint32_t accp = 0, accn = 0;
@@ -238,7 +241,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
       const uint32_t pc = ri < R ? m.mpc[ri] : 0u, len = ri < R ? m.moff[ri + 1] - m.moff[ri] : 0u;
       uint32_t tp, tn;
       const uint32_t sp = g.scan(pc, &tp), sn = g.scan(len - pc, &tn);
-      if (ri < R) { m.rb[ri] = accp + sp; m.rb2[ri] = accn + sn; }
+      if (ri < R) { m.mps[ri] = accp + sp; m.mns[ri] = accn + sn; }
       accp += tp;
       accn += tn;
     }
@@ -252,8 +255,8 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
       if (m.moff[mid] <= x) lo = mid; else hi = mid;
     }
     const uint32_t local = x - m.moff[lo], pc = m.mpc[lo], len = m.moff[lo + 1] - m.moff[lo];
-    if (local < pc) m.A[m.rb[lo] + local] = m.B[x];
-    else m.A[np + m.rb2[lo] + (len - 1 - local)] = m.B[x];
+    if (local < pc) m.A[m.mps[lo] + local] = m.B[x];
+    else m.A[np + m.mns[lo] + (len - 1 - local)] = m.B[x];
   }
   g.sync();
   // ---- sort

@@ -1359,7 +1359,7 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     // a read of L bases has at most L - k + 1 minimizers; the tables hold that many (capped), two runs per minimizer
     uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
     if (MM > 256) MM = 256;
-    const uint32_t RB = 2 * MM + 2;
+    const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;
     uint32_t *fb_list = d.hv_list + 5 * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + 5;
     uint32_t rest[3] = {n_cls[0], n_cls[1], n_cls[2]};
     if (n_cls[0]) {  // a wave per read, two reads per block
@@ -1425,7 +1425,7 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   if (!n_reads) return;
   uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
   if (MM > 256) MM = 256;
-  const uint32_t RB = 2 * MM + 2;  // ascending runs the sorter's tables hold: one per minimizer unless a diagonal wraps
+  const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;  // ascending runs the sorter's tables hold: one per minimizer unless a diagonal wraps
   bool ok[3] = {false, false, false};
   size_t lds[3] = {0, 0, 0};
   if (coop && d.hv_max[0]) {

@@ -122,6 +122,7 @@ struct CmDev {
   // stage looks at them: srt_cnt[0] items (read << 1 | strand) at srt_list, srt_cnt[1] the work cursor
   uint32_t *srt_cnt, *srt_list;
   uint32_t hv_stride, s3b_cap, hv_max[3];
+  uint32_t coop_rb; // tests: run-table size of the cooperative sorters (0: two per minimizer of the longest read)
   uint32_t hv_mid;  // class 4: lists of s3b_cap < hits <= hv_mid go to groups of 16 lanes (k_s3b_heavy<16>); 0 = no such class
   // ---- rescue / merged candidates
   uint8_t *aug;         // [2n] augment flag

@@ -185,6 +185,13 @@ HEAVY_SETTINGS = {
     "one_lane": {"heavy_wave_max": -1, "heavy_last": -1},                  # ... the sequential path in global memory
     "groups_of_16": {"heavy_mid_max": 256, "s3b_lane_cap": 4},             # ... four reads per wave (lists up to 256 hits here)
     "no_groups": {"heavy_mid_max": -1},                                    # ... without that class: a lane up to its LDS slots, waves beyond
+    # the settings above sort hit lists and rescue hits as merges of their occurrence runs (cm_coop.h); the round-2 kernels:
+    "wave_bitonic": {"heavy_last": 1, "coop": 0},
+    "block_bitonic": {"heavy_wave_max": 20, "heavy_last": 1, "coop": 0},
+    "block_big_lds_bitonic": {"heavy_wave_max": 18, "heavy_block_max": 19, "coop": 0},
+    # run tables too small for most reads: the merge-sort kernels decline them (bitonic kernel over a device-side list; lane 0 for rescue hits)
+    "declined": {"coop_run_table": 3},
+    "declined_block": {"heavy_wave_max": 20, "coop_run_table": 3},
 }
 
 
