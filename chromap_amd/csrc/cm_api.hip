@@ -639,14 +639,18 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
     cm_s3b_heavy_classes(d.hv_max);
-    for (int q = 0; q < 3; ++q) if (c->opt_heavy_max[q] > 0 && (uint32_t)c->opt_heavy_max[q] < d.hv_max[q]) d.hv_max[q] = (uint32_t)c->opt_heavy_max[q];
-    if (c->opt_heavy_max[0] < 0) d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0;  // everything long goes to the one-lane path
+    // tests force the classes: heavy_wave_max caps the wave class, heavy_block_max the two middle classes, heavy_big_max the largest
+    if (c->opt_heavy_max[0] > 0 && (uint32_t)c->opt_heavy_max[0] < d.hv_max[0]) d.hv_max[0] = (uint32_t)c->opt_heavy_max[0];
+    for (int q = 1; q <= 2; ++q) if (c->opt_heavy_max[1] > 0 && (uint32_t)c->opt_heavy_max[1] < d.hv_max[q]) d.hv_max[q] = (uint32_t)c->opt_heavy_max[1];
+    if (c->opt_heavy_max[2] > 0 && (uint32_t)c->opt_heavy_max[2] < d.hv_max[3]) d.hv_max[3] = (uint32_t)c->opt_heavy_max[2];
+    for (int q = 1; q < 4; ++q) if (d.hv_max[q] < d.hv_max[q - 1]) d.hv_max[q] = d.hv_max[q - 1];
+    if (c->opt_heavy_max[0] < 0) d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0;  // everything long goes to the one-lane path
     d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
     if (d.hv_mid > 256) d.hv_mid = 256;
     if (d.hv_max[0] == 0) d.hv_mid = 0;
     // with the 16-lane groups taking the lists up to hv_mid, a lane keeps the short ones only (16 hits: 256-thread blocks)
     if (d.hv_mid && c->opt_s3b_cap <= 0 && d.s3b_cap > 16) d.s3b_cap = 16;
-  } else { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = 0; d.hv_mid = 0; }
+  } else { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_mid = 0; }
   if (c->has_rank) {  // stages from verification on address the reference by rank
     d.rid_rank = (const uint32_t *)c->rid_rank.p;
     d.ref_off = (const uint64_t *)c->ref_off_r.p;
@@ -808,8 +812,8 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // S3: hit counts -> offsets -> candidates
   HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
   cm_launch_k_s3a_count(d, n2, s);
-  uint32_t n_heavy[5] = {0, 0, 0, 0, 0};  // classes 0..3 by size, 4: the short lists of the 16-lane groups
-  HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, 20, hipMemcpyDeviceToHost, s));
+  uint32_t n_heavy[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lists 0..2, 10 by size, 3: one lane each, 4: the short lists of the 16-lane groups
+  HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, sizeof(n_heavy), hipMemcpyDeviceToHost, s));
   unsigned long long hits_total = 0;
   if ((rc = scan_with_total(c, d.hit_tot, d.hit_off, n2, &hits_total))) return rc;
   if (hits_total > limit) return CM_RC_SPLIT;  // 2 x 150 reads on a repeat-rich genome: ~500 hits per read x 8 M reads wraps 2^32
@@ -822,7 +826,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
   // (lists of class 0 -- up to heavy_wave_max hits, a wave each here -- cost the later per-lane stages little; a uniform genome
   // still has a few thousand of them per batch, and the permutation's scans and scatters cost more than they save there)
-  c->use_perm = (uint64_t)n_heavy[1] + n_heavy[2] + n_heavy[3] > n2 / 65536 || n_heavy[0] > n2 / 256;
+  c->use_perm = (uint64_t)n_heavy[1] + n_heavy[2] + n_heavy[3] + n_heavy[10] > n2 / 65536 || n_heavy[0] > n2 / 256;
   if (c->opt_heavy_last) c->use_perm = c->opt_heavy_last > 0;
   if (c->use_perm) {
     uint32_t *tmp = (uint32_t *)c->hv_tmp.p;
@@ -847,11 +851,11 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   }
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
-  cm_launch_k_s4b_rescue_merge(d, n2, s);
+  cm_launch_k_s4b_rescue_merge(d, n2, s, (c->opt_coop & 2) != 0, c->max_read_len);
   cm_launch_k_s4b_rescue_list(d, n2, s, (c->opt_coop & 2) != 0, c->max_read_len);
   mark(c, "s4b_rescue_merge");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
-  cm_launch_k_s4c_reduce(d, n, s);
+  cm_launch_k_s4c_reduce(d, n, s, (c->opt_coop & 4) != 0);
   if (c->use_perm) cm_launch_k_sort_lists(d, 0, s);  // long candidate lists: a wave each, before S5a wants them in order
   mark(c, "s4c_pair_filter");
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
@@ -865,7 +869,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_launch_k_s5b_verify(d, n_v, n2, s);
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
-  cm_launch_k_s5c_finalize(d, n2, s);
+  cm_launch_k_s5c_finalize(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   if (c->use_perm) cm_launch_k_sort_lists(d, 1, s);  // long draft-mapping lists, before S6a pairs them
   mark(c, "s5c_accept");
   // S6: best pair, sampling of multi-mappers, records
@@ -880,7 +884,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     d.sam_md = (uint8_t *)c->sam_md.p + slot0 * md_cap;
     d.sam_z = (uint32_t *)c->sam_z.p; d.sam_md_cap = md_cap;
   }
-  if (c->p.sam) cm_launch_k_s6a_pair_sam(d, n, s); else cm_launch_k_s6a_pair(d, n, s);
+  if (c->p.sam) cm_launch_k_s6a_pair_sam(d, n, s); else cm_launch_k_s6a_pair(d, n, s, (c->opt_coop & 16) != 0);
   mark(c, "s6a_pairing");
   const uint32_t n_chunks = cm_num_chunks_host(n, (uint32_t)c->p.ref_batch, (uint32_t)c->p.grain);
   cm_launch_k_s6b_sample(d, n_chunks, s);

@@ -10,7 +10,8 @@
 //   void sync()                    barrier of the group; shared and global writes before it are visible after it
 //   uint32_t rank(bool p, uint32_t *total)     lanes of my wave part with p and a lower index; *total = all with p
 //   uint32_t scan(uint32_t v, uint32_t *total) exclusive prefix sum over the group (contains barriers)
-//   uint64_t max64(uint64_t v)     maximum over the group (contains barriers)
+//   uint32_t scanmax(uint32_t v, uint32_t *total)  exclusive prefix maximum (0 in front) and the overall maximum
+//   uint64_t max64(uint64_t v), min64  maximum / minimum over the group (contain barriers)
 // Every lane of the group calls these the same number of times (uniform control flow around them).
 // cm_kernels.hip instantiates them with the device group (wave shuffles, ballots, LDS); tests/hostemu runs the same text
 // with one OS thread per lane -- test infrastructure, like the rest of hostemu.
@@ -135,45 +136,46 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   *ncn_out = ncn;
 }
 
-// shared-memory work area of one group for the hit-list stages (sizes in entries)
+// shared-memory work area of one group for the hit-list stages (sizes in entries).  own_oc: the sweep's offsets and the
+// candidates' counts get arrays of their own (S4b keeps its candidates in the second list buffer); otherwise oc lies in
+// whichever list buffer the sort left free (S3b writes its candidates to global memory).
 struct CmCoopMem {
   uint64_t *A, *B;      // P each
-  uint16_t *oc;         // P
-  uint8_t *cc;          // P
+  uint16_t *oc;         // P (own_oc), else nullptr
+  uint8_t *cc;          // P (own_oc), else nullptr
   uint32_t *rb, *rb2;   // RB + 1 each: run boundaries
-  uint32_t *moff;       // MM + 1: start of an included minimizer's segment
-  uint32_t *mpc;        // MM: its + hits
-  uint32_t *mmi;        // MM: its index in the read's minimizer list
-  uint32_t *mps, *mns;  // MM each: start of its + / - sub-list in the compacted list
+  uint32_t *moff;       // MM + 1: start of an included minimizer's occurrences in the hit list
+  uint64_t *mval;       // MM: index of its first occurrence in the occurrence table (a singleton: the occurrence itself)
+  uint32_t *mps;        // MM: (read position << 1 | strand) of the minimizer, bit 31: singleton
   uint32_t P, MM, RB;
 };
-CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB) {
-  return (size_t)P * 19 + ((size_t)2 * (RB + 1) + (size_t)MM * 5 + 1) * 4 + 32;
+CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) {
+  return (size_t)P * (own_oc ? 19 : 16) + ((size_t)2 * (RB + 1) + (size_t)MM * 4 + 2) * 4 + 32;
 }
-// carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB) bytes)
-CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB) {
+// carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB, own_oc) bytes)
+CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) {
   CmCoopMem m;
   m.P = P; m.MM = MM; m.RB = RB;
   m.A = reinterpret_cast<uint64_t *>(base);
   m.B = m.A + P;
-  m.rb = reinterpret_cast<uint32_t *>(m.B + P);
+  m.mval = m.B + P;
+  m.rb = reinterpret_cast<uint32_t *>(m.mval + MM);
   m.rb2 = m.rb + RB + 1;
   m.moff = m.rb2 + RB + 1;
-  m.mpc = m.moff + MM + 1;
-  m.mmi = m.mpc + MM;
-  m.mps = m.mmi + MM;
-  m.mns = m.mps + MM;
-  m.oc = reinterpret_cast<uint16_t *>(m.mns + MM);
-  m.cc = reinterpret_cast<uint8_t *>(m.oc + P);
+  m.mps = m.moff + MM + 1;
+  m.oc = own_oc ? reinterpret_cast<uint16_t *>(m.mps + MM + 1) : nullptr;
+  m.cc = own_oc ? reinterpret_cast<uint8_t *>(m.oc + P) : nullptr;
   return m;
 }
 
 // ---------------------------------------------------------------------------------------
 // S3b for one read with a long hit list (cm_s3b_core's results, element for element):
-//   expand   one wave part per minimizer: its occurrence run goes to the run's segment of B, + hits ascending from the
-//            front, - hits (bit 63 set) from the back -- the run is sorted by (sequence, position) and a read position
-//            is added or subtracted, so either sub-list is ascending unless a diagonal wraps below zero;
-//   compact  B -> A: the + sub-lists of all minimizers, then the - sub-lists read backwards (ascending);
+//   expand   the hit list in minimizer order, occurrence order inside a minimizer: every lane takes hits x, x + G, ... --
+//            which minimizer's occurrence it is comes from the table of run starts -- four independent occurrence loads
+//            in flight per lane; the - strand's keys get bit 63;
+//   split    stable partition (one scan): the + hits in order, then the - hits in order.  An occurrence run is sorted by
+//            (sequence, position) and a read position is added or subtracted, so each minimizer leaves one ascending run per
+//            strand unless a diagonal wraps below zero;
 //   sort     boundaries of the ascending runs actually present (a wrapped diagonal just starts another run), merge sort;
 //   sweep    cm_coop_sweep, candidates straight to the read's global segment (+ at h[0..), - at h[np..)).
 // Returns false -- nothing written -- when the read has more included minimizers than m.MM or more runs than m.RB
@@ -181,25 +183,31 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
 // ---------------------------------------------------------------------------------------
 template <class GT>
 CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
+  const uint32_t G = (uint32_t)GT::G;
   const uint32_t tot = d.hit_tot[r];
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   const uint64_t SB = 1ull << 63;
   if (tot > m.P) return false;
-  // ---- included minimizers and their segments
+  // ---- included minimizers and where their occurrences start in the list
   uint32_t R = 0, off = 0;
-  for (uint32_t base = 0; base < n; base += (uint32_t)GT::G) {
+  for (uint32_t base = 0; base < n; base += G) {
     const uint32_t mi = base + g.t;
-    uint32_t len = 0;
+    uint32_t len = 0, ps = 0;
+    uint64_t val = 0;
     if (mi < n) {
       const uint8_t kind = d.pr_kind[b + mi];
-      if (kind == CM_PR_SINGLE) len = 1;
-      else if (kind == CM_PR_MULTI) { const uint32_t nocc = (uint32_t)d.pr_val[b + mi]; if (nocc < maxf) len = nocc; }
+      if (kind != CM_PR_MISS) {
+        val = d.pr_val[b + mi];
+        ps = d.mm_ps[b + mi];
+        if (kind == CM_PR_SINGLE) { len = 1; ps |= 1u << 31; }
+        else { const uint32_t nocc = (uint32_t)val; if (nocc < maxf) len = nocc; val >>= 32; }
+      }
     }
     uint32_t tv;
     const uint32_t sv = g.scan((len ? 1u << 20 : 0u) | len, &tv);  // tot <= 8192 < 2^20: both sums in one scan
     const uint32_t ri = R + (sv >> 20), o = off + (sv & 0xfffffu);
-    if (len && ri < m.MM) { m.mmi[ri] = mi; m.moff[ri] = o; }
+    if (len && ri < m.MM) { m.moff[ri] = o; m.mval[ri] = val; m.mps[ri] = ps; }
     R += tv >> 20;
     off += tv & 0xfffffu;
   }
@@ -207,62 +215,53 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   if (g.t == 0) m.moff[R] = tot;
   g.sync();
   // ---- expand
-  for (uint32_t ri = g.t / (uint32_t)GT::W; ri < R; ri += (uint32_t)(GT::G / GT::W)) {
-    const uint32_t mi = m.mmi[ri], seg = m.moff[ri], len = m.moff[ri + 1] - seg;
-    const uint8_t kind = d.pr_kind[b + mi];
-    const uint64_t val = d.pr_val[b + mi];
-    const uint32_t ps = d.mm_ps[b + mi];
-    const uint64_t *o = d.occ + (uint32_t)(val >> 32);
-    uint32_t pc = 0, nc = 0;
-    for (uint32_t base = 0; base < len; base += (uint32_t)GT::W) {
-      const uint32_t oi = base + g.t % (uint32_t)GT::W;
-      const bool v = oi < len;
-      bool same = false;
-      uint64_t cp = 0;
-      if (v) cp = cm_cand_from_hit(kind == CM_PR_SINGLE ? val : o[oi], ps, d.p.k, &same);
-      uint32_t tp, tn;
-      const uint32_t rp = g.rank(v && same, &tp), rn = g.rank(v && !same, &tn);
-      if (v) {
-        if (same) m.B[seg + pc + rp] = cp;
-        else m.B[seg + len - 1 - (nc + rn)] = cp | SB;
+  for (uint32_t x0 = g.t; x0 < tot; x0 += 4 * G) {
+    uint64_t hit[4];
+    uint32_t ps[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t x = x0 + (uint32_t)q * G;
+      hit[q] = 0; ps[q] = 0;
+      if (x < tot) {
+        uint32_t lo = 0, hi = R;  // the largest ri with moff[ri] <= x
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (m.moff[mid] <= x) lo = mid; else hi = mid;
+        }
+        ps[q] = m.mps[lo];
+        const uint64_t v = m.mval[lo];
+        hit[q] = (ps[q] >> 31) ? v : d.occ[(uint32_t)v + (x - m.moff[lo])];
       }
-      pc += tp;
-      nc += tn;
     }
-    if (g.t % (uint32_t)GT::W == 0) m.mpc[ri] = pc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t x = x0 + (uint32_t)q * G;
+      if (x < tot) {
+        bool same;
+        const uint64_t cp = cm_cand_from_hit(hit[q], ps[q] & 0x7fffffffu, d.p.k, &same);
+        m.B[x] = same ? cp : (cp | SB);
+      }
+    }
   }
   g.sync();
-  // ---- compact: starts of every minimizer's + and - sub-list in A
-  uint32_t np = 0;
+  // ---- split: + hits in order, then - hits in order
+  uint32_t np;
   {
-    uint32_t accp = 0, accn = 0;
-    for (uint32_t base = 0; base < R; base += (uint32_t)GT::G) {
-      const uint32_t ri = base + g.t;
-      const uint32_t pc = ri < R ? m.mpc[ri] : 0u, len = ri < R ? m.moff[ri + 1] - m.moff[ri] : 0u;
-      uint32_t tp, tn;
-      const uint32_t sp = g.scan(pc, &tp), sn = g.scan(len - pc, &tn);
-      if (ri < R) { m.mps[ri] = accp + sp; m.mns[ri] = accn + sn; }
-      accp += tp;
-      accn += tn;
+    const uint32_t VT = (tot + G - 1) / G;
+    const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
+    uint32_t cnt = 0;
+    for (uint32_t x = c0; x < c1; ++x) cnt += (m.B[x] >> 63) ? 0u : 1u;
+    uint32_t pos = g.scan(cnt, &np);
+    for (uint32_t x = c0; x < c1; ++x) {
+      const uint64_t v = m.B[x];
+      if (v >> 63) m.A[np + (x - pos)] = v; else m.A[pos++] = v;
     }
-    np = accp;
-  }
-  g.sync();
-  for (uint32_t x = g.t; x < tot; x += (uint32_t)GT::G) {
-    uint32_t lo = 0, hi = R;  // the largest ri with moff[ri] <= x
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (m.moff[mid] <= x) lo = mid; else hi = mid;
-    }
-    const uint32_t local = x - m.moff[lo], pc = m.mpc[lo], len = m.moff[lo + 1] - m.moff[lo];
-    if (local < pc) m.A[m.mps[lo] + local] = m.B[x];
-    else m.A[np + m.mns[lo] + (len - 1 - local)] = m.B[x];
   }
   g.sync();
   // ---- sort
   const uint32_t nr = cm_coop_natural_runs(g, m.A, tot, m.rb, m.RB);
   if (nr == 0) return false;
-  const uint64_t *S = cm_coop_merge_runs(g, m.A, m.B, m.rb, m.rb2, nr, tot);
+  uint64_t *S = cm_coop_merge_runs(g, m.A, m.B, m.rb, m.rb2, nr, tot);
   // ---- sweep
   const uint32_t nn = tot - np;
   const bool use_high = d.round2[r] && np > 0 && nn > 0;
@@ -272,8 +271,9 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   if (use_high) req = d.p.min_seeds;
   uint64_t *h = d.hbuf + d.hit_off[r];
   uint8_t *hc = d.hcnt + d.hit_off[r];
+  uint16_t *oc = m.oc ? m.oc : reinterpret_cast<uint16_t *>(S == m.A ? m.B : m.A);
   uint32_t ncp, ncn;
-  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, m.oc, h, hc, h + np, hc + np, &ncp, &ncn);
+  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, oc, h, hc, h + np, hc + np, &ncp, &ncn);
   if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
   return true;
 }
@@ -414,6 +414,397 @@ CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopM
   g.sync();  // the work area is reused
   const uint32_t mcp = cm_coop_rescue_dir(d, r, g, m, P, PC, ncp, rp, do_p, cm_c0_pos(d, r), cm_c0_pcnt(d, r), ZP, ZC);
   if (g.t == 0) { d.mcp[r] = mcp; d.mcn[r] = mcn; }
+}
+
+// ---------------------------------------------------------------------------------------
+// Array helpers over the group: exclusive prefix sum / exclusive prefix maximum of a[0..n) in place (shared memory),
+// every lane a contiguous chunk, the chunk totals through the group.  Return the total / the overall maximum.
+// ---------------------------------------------------------------------------------------
+template <class GT>
+CM_HD uint32_t cm_coop_array_scan_add(GT &g, uint16_t *a, uint32_t n) {
+  const uint32_t VT = (n + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
+  uint32_t sum = 0;
+  for (uint32_t i = c0; i < c1; ++i) sum += a[i];
+  uint32_t total;
+  uint32_t run = g.scan(sum, &total);
+  for (uint32_t i = c0; i < c1; ++i) { const uint32_t x = a[i]; a[i] = (uint16_t)run; run += x; }
+  g.sync();
+  return total;
+}
+template <class GT>
+CM_HD uint32_t cm_coop_array_scan_max(GT &g, uint8_t *a, uint32_t n) {
+  const uint32_t VT = (n + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
+  uint32_t mx = 0;
+  for (uint32_t i = c0; i < c1; ++i) mx = a[i] > mx ? a[i] : mx;
+  uint32_t total;
+  uint32_t run = g.scanmax(mx, &total);
+  for (uint32_t i = c0; i < c1; ++i) { const uint32_t x = a[i]; a[i] = (uint8_t)run; run = x > run ? x : run; }
+  g.sync();
+  return total;
+}
+
+// ---------------------------------------------------------------------------------------
+// ReduceCandidatesForPairedEndReadOnOneDirection (candidate_processor.cc:416-484; cm_reduce_dir in cm_stages.h) by a
+// group.  The sequential two-pointer loop over the ascending lists p1 (n1) and p2 (n2) is equivalent to:
+//   lo(i)   = first j with p2[j] + dist >= p1[i]   (where the loop's i2 stands when it looks at p1[i]; monotone)
+//   the loop ends before the first i with lo(i) == n2 (i_end): later entries of list 1 are never looked at
+//   paired(i)  <=> lo(i) < n2 and p2[lo(i)] <= p1[i] + dist; such an entry is kept and raises max1 = max(6, counts of kept paired)
+//   an unpaired i < i_end is kept iff same sequence as p2[lo(i)], count >= max1 so far, and it is one of the first five such
+//   covered(j) <=> some i has |p1[i] - p2[j]| <= dist  (first i with p1[i] + dist >= p2[j] has p1[i] <= p2[j] + dist): kept,
+//              raises max2 = max(6, counts of covered entries before)
+//   an uncovered j is looked at by sk(j) = first i with p1[i] > p2[j] + dist, if there is one; kept iff same sequence,
+//              count >= max2 so far, one of the first five such   (the loop's "i2 >= prev_end" test holds exactly for the
+//              uncovered entries)
+// Outputs in list order.  Work arrays (shared): lo1, of1, of2 (u16), k1, k2, x1, x2 (u8), n1 / n2 entries.
+// ---------------------------------------------------------------------------------------
+struct CmCoopPairMem {
+  uint16_t *lo1, *of1, *of2;  // P each
+  uint8_t *k1, *k2, *x1, *x2; // P each
+  uint32_t P;
+};
+CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P) { return (size_t)P * 10 + 32; }
+CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P) {
+  CmCoopPairMem m;
+  m.P = P;
+  m.lo1 = reinterpret_cast<uint16_t *>(base);
+  m.of1 = m.lo1 + P;
+  m.of2 = m.of1 + P;
+  m.k1 = reinterpret_cast<uint8_t *>(m.of2 + P);
+  m.k2 = m.k1 + P;
+  m.x1 = m.k2 + P;
+  m.x2 = m.x1 + P;
+  return m;
+}
+template <class GT>
+CM_HD void cm_coop_reduce_dir(GT &g, const CmCoopPairMem &m, uint32_t dist, const uint64_t *p1, const uint8_t *c1, uint32_t n1, const uint64_t *p2,
+                              const uint8_t *c2, uint32_t n2, uint64_t *f1, uint8_t *fc1, uint32_t *nf1, uint64_t *f2, uint8_t *fc2, uint32_t *nf2) {
+  const uint32_t G = (uint32_t)GT::G;
+  // ---- list 1: lo, paired; x1 = count of a paired entry (for max1), else 0
+  uint32_t my_end = n1;
+  for (uint32_t i = g.t; i < n1; i += G) {
+    const uint64_t a = p1[i];
+    uint32_t lo = 0, hi = n2;  // first j with p2[j] + dist >= a
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a > p2[mid] + dist) lo = mid + 1; else hi = mid;
+    }
+    m.lo1[i] = (uint16_t)lo;
+    const bool paired = lo < n2 && !(p2[lo] > a + dist);
+    m.k1[i] = paired ? 1 : 0;
+    m.x1[i] = paired ? c1[i] : 0;
+    if (lo == n2 && i < my_end) my_end = i;
+  }
+  const uint32_t i_end = (uint32_t)g.min64((uint64_t)my_end);
+  // ---- list 2: covered; x2 = count of a covered entry (for max2), else 0
+  for (uint32_t j = g.t; j < n2; j += G) {
+    const uint64_t b = p2[j];
+    uint32_t lo = 0, hi = n1;  // first i with p1[i] + dist >= b
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (b > p1[mid] + dist) lo = mid + 1; else hi = mid;
+    }
+    const bool covered = lo < n1 && !(p1[lo] > b + dist);
+    m.k2[j] = covered ? 1 : 0;
+    m.x2[j] = covered ? c2[j] : 0;
+  }
+  g.sync();
+  (void)cm_coop_array_scan_max(g, m.x1, n1);  // x1[i] = largest count of a paired entry before i
+  (void)cm_coop_array_scan_max(g, m.x2, n2);
+  // ---- the unpaired / uncovered entries that meet the sequence and count conditions
+  for (uint32_t i = g.t; i < n1; i += G) {
+    uint32_t cond = 0;
+    if (!m.k1[i] && i < i_end) {
+      const uint32_t mx = m.x1[i] > 6 ? m.x1[i] : 6;
+      cond = ((p1[i] >> 32) == (p2[m.lo1[i]] >> 32) && (uint32_t)c1[i] >= mx) ? 1u : 0u;
+    }
+    m.of1[i] = (uint16_t)cond;
+  }
+  for (uint32_t j = g.t; j < n2; j += G) {
+    uint32_t cond = 0;
+    if (!m.k2[j]) {
+      const uint64_t b = p2[j];
+      uint32_t lo = 0, hi = n1;  // sk(j): first i with p1[i] > b + dist
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p1[mid] > b + dist) hi = mid; else lo = mid + 1;
+      }
+      if (lo < n1) {
+        const uint32_t mx = m.x2[j] > 6 ? m.x2[j] : 6;
+        cond = ((p1[lo] >> 32) == (b >> 32) && (uint32_t)c2[j] >= mx) ? 1u : 0u;
+      }
+    }
+    m.of2[j] = (uint16_t)cond;
+  }
+  g.sync();
+  // keep flags: paired / covered, or among the first five that meet the conditions (of = rank after the scan)
+  for (uint32_t i = g.t; i < n1; i += G) m.x1[i] = (uint8_t)m.of1[i];
+  for (uint32_t j = g.t; j < n2; j += G) m.x2[j] = (uint8_t)m.of2[j];
+  g.sync();
+  (void)cm_coop_array_scan_add(g, m.of1, n1);
+  (void)cm_coop_array_scan_add(g, m.of2, n2);
+  for (uint32_t i = g.t; i < n1; i += G) {
+    const bool keep = (m.k1[i] && i < i_end) || (m.x1[i] && m.of1[i] < 5);
+    m.k1[i] = keep ? 1 : 0;
+  }
+  for (uint32_t j = g.t; j < n2; j += G) {
+    const bool keep = m.k2[j] || (m.x2[j] && m.of2[j] < 5);
+    m.k2[j] = keep ? 1 : 0;
+  }
+  g.sync();
+  for (uint32_t i = g.t; i < n1; i += G) m.of1[i] = m.k1[i];
+  for (uint32_t j = g.t; j < n2; j += G) m.of2[j] = m.k2[j];
+  g.sync();
+  const uint32_t t1 = cm_coop_array_scan_add(g, m.of1, n1);
+  const uint32_t t2 = cm_coop_array_scan_add(g, m.of2, n2);
+  for (uint32_t i = g.t; i < n1; i += G)
+    if (m.k1[i]) { f1[m.of1[i]] = p1[i]; fc1[m.of1[i]] = c1[i]; }
+  for (uint32_t j = g.t; j < n2; j += G)
+    if (m.k2[j]) { f2[m.of2[j]] = p2[j]; fc2[m.of2[j]] = c2[j]; }
+  *nf1 = t1;
+  *nf2 = t2;
+}
+
+// S4c for one pair with long candidate lists: the two directions of the paired-end filter by the group, the pair's fate,
+// the re-ranking (cm_s4c_filter + cm_s4c_post; cm_s4c_pre ran in the per-pair kernel and asked for the filter).
+template <class GT>
+CM_HD void cm_coop_s4c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPairMem &m) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  const uint32_t G = (uint32_t)GT::G;
+  if (d.mcp[r1] > m.P || d.mcn[r1] > m.P || d.mcp[r2] > m.P || d.mcn[r2] > m.P) {  // longer than the work arrays: one lane
+    if (g.t == 0) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
+    return;
+  }
+  uint32_t a, b, c, e2;
+  cm_coop_reduce_dir(g, m, (uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2), cm_m_ncnt(d, r2), d.mcn[r2],
+                     cm_f_pos(d, r1), cm_f_pcnt(d, r1), &a, cm_f_neg(d, r2), cm_f_ncnt(d, r2), &b);
+  g.sync();
+  cm_coop_reduce_dir(g, m, (uint32_t)d.p.max_insert, cm_m_neg(d, r1), cm_m_ncnt(d, r1), d.mcn[r1], cm_m_pos(d, r2), cm_m_pcnt(d, r2), d.mcp[r2],
+                     cm_f_neg(d, r1), cm_f_ncnt(d, r1), &c, cm_f_pos(d, r2), cm_f_pcnt(d, r2), &e2);
+  g.sync();
+  const bool alive = a + c > 0 && b + e2 > 0;
+  if (g.t == 0) {
+    d.fcp[r1] = a; d.fcn[r2] = b; d.fcn[r1] = c; d.fcp[r2] = e2;
+    d.alive[pair] = alive ? 1 : 0;
+  }
+  if (alive && d.rid_rank) {  // cm_rerank of both reads
+    uint64_t *l[4] = {cm_f_pos(d, r1), cm_f_neg(d, r1), cm_f_pos(d, r2), cm_f_neg(d, r2)};
+    const uint32_t n[4] = {a, c, e2, b};
+    for (int q = 0; q < 4; ++q)
+      for (uint32_t i = g.t; i < n[q]; i += G) l[q][i] = (l[q][i] & 0xffffffffull) | ((uint64_t)d.rid_rank[(uint32_t)(l[q][i] >> 32)] << 32);
+  }
+}
+
+template <class GT>
+CM_HD uint32_t cm_coop_array_scan_max16(GT &g, uint16_t *a, uint32_t n) {  // exclusive prefix maximum in place; returns the maximum
+  const uint32_t VT = (n + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
+  uint32_t mx = 0;
+  for (uint32_t i = c0; i < c1; ++i) mx = a[i] > mx ? a[i] : mx;
+  uint32_t total;
+  uint32_t run = g.scanmax(mx, &total);
+  for (uint32_t i = c0; i < c1; ++i) { const uint32_t x = a[i]; a[i] = (uint16_t)run; run = x > run ? x : run; }
+  g.sync();
+  return total;
+}
+
+// the two smallest distinct values of a multiset with their counts, as cm_update_best / the pairing loop keep them:
+// (lo, n_lo, hi, n_hi), an unseen slot is (none, 0).  cm_two_add puts cnt copies of v in.
+struct CmTwo { int lo, n_lo, hi, n_hi; };
+CM_HD void cm_two_add(CmTwo &s, int v, int cnt) {
+  if (cnt <= 0) return;
+  if (v < s.lo) { s.hi = s.lo; s.n_hi = s.n_lo; s.lo = v; s.n_lo = cnt; }
+  else if (v == s.lo) s.n_lo += cnt;
+  else if (v == s.hi) s.n_hi += cnt;
+  else if (v < s.hi) { s.hi = v; s.n_hi = cnt; }
+}
+// the lanes' sets merged; `none` = the value of an unseen slot (larger than every real value).  Every lane gets the result.
+template <class GT>
+CM_HD CmTwo cm_coop_two_merge(GT &g, const CmTwo &mine, int none) {
+  const int BIAS = 1 << 20;  // values may be negative (split mode keeps -length); order is kept under the bias
+  CmTwo out;
+  out.lo = (int)g.min64((uint64_t)(mine.lo + BIAS)) - BIAS;
+  out.n_lo = (int)g.sum(mine.lo == out.lo ? (uint32_t)mine.n_lo : 0u);
+  const int c2 = mine.lo > out.lo ? mine.lo : mine.hi;
+  out.hi = (int)g.min64((uint64_t)(c2 + BIAS)) - BIAS;
+  out.n_hi = (int)g.sum((mine.lo == out.hi ? (uint32_t)mine.n_lo : 0u) + (mine.hi == out.hi ? (uint32_t)mine.n_hi : 0u));
+  if (out.lo == none) { out.n_lo = 0; out.hi = none; out.n_hi = 0; }
+  if (out.hi == none) out.n_hi = 0;
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// S5c for one read with many candidates (cm_s5c_finalize's results): the acceptance loop of
+// DraftMappingGenerator::GenerateDraftMappingsOnOneStrand over the precomputed alignments (cm_draft_strand with pre_err).
+// With `lanes` > 0 the reference verifies the valid candidates in groups of `lanes` and, after a group, lowers its count
+// threshold to the count of the group's last rejected candidate; it stops at the first candidate whose count is below the
+// threshold.  Candidate ci (v valid candidates before it) therefore sees the threshold of the LAST rejected candidate among
+// the first lanes * floor(v / lanes) valid ones -- a prefix maximum over the valid candidates' ranks -- and the loop stops
+// at B = the first ci whose count is below its threshold; every valid candidate before B is verified (the unfinished group
+// at the end too).  Accepted = verified with at most e errors, in list order; best / second best = the two smallest error
+// counts with their multiplicities.
+// Work arrays (shared, P entries each): of, fr, pm (u16), vf (u8).
+// ---------------------------------------------------------------------------------------
+struct CmCoopVerMem {
+  uint16_t *of, *fr, *pm;  // P + 1 each
+  uint8_t *vf;             // P
+  uint32_t P;
+};
+CM_HD size_t cm_coop_ver_mem_bytes(uint32_t P) { return (size_t)(P + 1) * 6 + P + 32; }
+CM_HD CmCoopVerMem cm_coop_ver_mem_at(uint8_t *base, uint32_t P) {
+  CmCoopVerMem m;
+  m.P = P;
+  m.of = reinterpret_cast<uint16_t *>(base);
+  m.fr = m.of + P + 1;
+  m.pm = m.fr + P + 1;
+  m.vf = reinterpret_cast<uint8_t *>(m.pm + P + 1);
+  return m;
+}
+template <class GT>
+CM_HD uint32_t cm_coop_draft_strand(const CmDev &d, GT &g, const CmCoopVerMem &m, uint32_t L, int strand, const uint64_t *cp, const uint8_t *cc,
+                                    uint32_t nc, CmTwo &best, uint64_t *dp, int16_t *de, const int16_t *pre_err, const int16_t *pre_end) {
+  const uint32_t G = (uint32_t)GT::G;
+  const int e = d.p.e;
+  const uint32_t lanes = (uint32_t)d.p.lanes;
+  if (nc == 0) return 0;
+  for (uint32_t ci = g.t; ci < nc; ci += G) {
+    const uint32_t rid = (uint32_t)(cp[ci] >> 32);
+    uint32_t position = (uint32_t)cp[ci];
+    if (strand == 1) position = position - L + 1;
+    const bool valid = cm_valid_candidate(d, rid, position, L);
+    m.vf[ci] = valid ? 1 : 0;
+    m.of[ci] = valid ? 1 : 0;
+  }
+  g.sync();
+  const uint32_t nvalid = cm_coop_array_scan_add(g, m.of, nc);  // of[ci] = valid candidates before ci
+  uint32_t B = nc;
+  if (lanes != 0 && nc >= lanes) {
+    for (uint32_t ci = g.t; ci < nc; ci += G)
+      if (m.vf[ci]) { const uint32_t k = m.of[ci]; m.fr[k] = (uint16_t)ci; m.pm[k] = pre_err[ci] > e ? (uint16_t)(k + 1) : 0; }
+    if (g.t == 0) m.pm[nvalid] = 0;
+    g.sync();
+    (void)cm_coop_array_scan_max16(g, m.pm, nvalid + 1);  // pm[k] = 1 + rank of the last rejected candidate among ranks < k (0: none)
+    uint32_t mine = nc;
+    for (uint32_t ci = g.t; ci < nc; ci += G) {
+      const uint32_t done = m.of[ci] / lanes * lanes;  // valid candidates in finished groups when the loop looks at ci
+      const uint32_t lf = m.pm[done];
+      const uint32_t thr = lf ? cc[m.fr[lf - 1]] : 0u;
+      if ((uint32_t)cc[ci] < thr && ci < mine) mine = ci;
+    }
+    B = (uint32_t)g.min64((uint64_t)mine);
+  }
+  g.sync();  // of is rewritten
+  CmTwo mineb = {e + 1, 0, e + 1, 0};
+  for (uint32_t ci = g.t; ci < nc; ci += G) {
+    const bool acc = m.vf[ci] && ci < B && pre_err[ci] <= e;
+    m.vf[ci] = acc ? 1 : 0;
+    if (acc) cm_two_add(mineb, (int)pre_err[ci], 1);
+  }
+  g.sync();
+  for (uint32_t ci = g.t; ci < nc; ci += G) m.of[ci] = m.vf[ci];
+  g.sync();
+  const uint32_t nd = cm_coop_array_scan_add(g, m.of, nc);
+  for (uint32_t ci = g.t; ci < nc; ci += G) {
+    if (!m.vf[ci]) continue;
+    const uint64_t cpos = cp[ci];
+    const int end_pos = pre_end[ci];
+    dp[m.of[ci]] = strand == 0 ? cpos - (uint64_t)e + (uint64_t)(int64_t)end_pos : cpos - L + 1 - (uint64_t)e + (uint64_t)(int64_t)end_pos;
+    de[m.of[ci]] = pre_err[ci];
+  }
+  const CmTwo all = cm_coop_two_merge(g, mineb, e + 1);
+  cm_two_add(best, all.lo, all.n_lo);
+  cm_two_add(best, all.hi, all.n_hi);
+  g.sync();
+  return nd;
+}
+template <class GT>
+CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m) {
+  if (d.nv[r] == 0) return;
+  const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
+  if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: one lane
+    if (g.t == 0) cm_s5c_finalize(d, r);
+    return;
+  }
+  CmTwo best = {d.min_err[r], d.n_best[r], d.second_err[r], d.n_second[r]};
+  const uint32_t L = d.rlen[r];
+  const uint32_t ndp = cm_coop_draft_strand(d, g, m, L, 0, d.fbuf + op, d.fcnt + op, d.fcp[r], best, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
+  const uint32_t ndn = cm_coop_draft_strand(d, g, m, L, 1, d.fbuf + on, d.fcnt + on, d.fcn[r], best, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
+  if (g.t == 0) {
+    d.ndp[r] = ndp; d.ndn[r] = ndn;
+    d.min_err[r] = best.lo; d.second_err[r] = best.hi; d.n_best[r] = best.n_lo; d.n_second[r] = best.n_hi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// S6a for one pair with many draft mappings (cm_s6a_pair's paired-end, non-split part): the two sweeps of
+// GenerateBestMappingsForPairedEndReadOnOneDirection (mapping_generator.h:347-484, cm_pair_dir).  For the mapping i1 of the first
+// list the sweep pairs it with the range [lo(i1), hi(i1)) of the second (sorted) list -- lo: the first entry not too far below,
+// hi: the first entry too far above; both monotone in i1, so the sequential pointer stands at lo(i1) -- and keeps the two
+// smallest error sums with their multiplicities and the first pairing (direction, i1, i2 order) that reaches the minimum.
+// A lane takes the mappings i1 = t, t + G, ...; the lanes' results are merged (the first minimal pairing: the smallest packed
+// (sum, direction, i1, i2) key).
+// ---------------------------------------------------------------------------------------
+template <class GT>
+CM_HD void cm_coop_pair_dir(const CmDev &d, GT &g, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na, const uint64_t *bp, const int16_t *be,
+                            uint32_t nb, uint32_t len1, uint32_t len2, CmTwo &mine, uint64_t &first_key) {
+  const uint64_t I = (uint64_t)(int64_t)d.p.max_insert;
+  const uint64_t mo = (uint32_t)d.p.min_read_len;
+  const uint64_t X = dir == 1 ? I - len2 : (uint64_t)len1 - mo;  // an entry p2 is too far below p1 when p1 > p2 + X
+  const uint64_t Y = dir == 0 ? I - len1 : (uint64_t)len2 - mo;  // ... too far above when p2 > p1 + Y
+  for (uint32_t i1 = g.t; i1 < na; i1 += (uint32_t)GT::G) {
+    const uint64_t p1 = ap[i1];
+    uint32_t lo = 0, hi = nb;  // first i2 with !(p1 > bp[i2] + X)
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (p1 > bp[mid] + X) lo = mid + 1; else hi = mid;
+    }
+    for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur) {
+      const int s = (int)ae[i1] + (int)be[cur];
+      cm_two_add(mine, s, 1);
+      const uint64_t key = ((uint64_t)(uint32_t)(s + 1024) << 49) | ((uint64_t)(uint32_t)dir << 48) | ((uint64_t)i1 << 24) | (uint64_t)cur;
+      if (key < first_key) first_key = key;
+    }
+  }
+}
+// true when p[0..n) is ascending (every lane gets the answer)
+template <class GT>
+CM_HD bool cm_coop_is_sorted(GT &g, const uint64_t *p, uint32_t n) {
+  uint32_t bad = 0;
+  for (uint32_t i = g.t + 1; i < n; i += (uint32_t)GT::G) bad += p[i] < p[i - 1] ? 1u : 0u;
+  return g.sum(bad) == 0;
+}
+template <bool SAM, class GT>
+CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g) {
+  // cm_s6a_pair's prologue ran in the per-pair kernel (record slots cleared, pe_nbest = 0, both reads have draft mappings)
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  for (uint32_t r = r1; r <= r2; ++r)
+    for (int st = 0; st < 2; ++st) {
+      const uint32_t n = st ? d.ndn[r] : d.ndp[r];
+      uint64_t *p = const_cast<uint64_t *>(cm_d_pos(d, r, st));
+      if (!cm_coop_is_sorted(g, p, n)) {  // lists beyond the sorting waves' size
+        if (g.t == 0) cm_sort_draft(p, const_cast<int16_t *>(cm_d_err(d, r, st)), n);
+        g.sync();
+      }
+    }
+  const int none = 2 * d.p.e + 1;
+  CmTwo mine = {none, 0, none, 0};
+  uint64_t first_key = ~0ull;
+  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  cm_coop_pair_dir(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2], len1, len2, mine, first_key);
+  cm_coop_pair_dir(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2], len1, len2, mine, first_key);
+  const CmTwo all = cm_coop_two_merge(g, mine, none);
+  const uint64_t fk = g.min64(first_key);
+  CmPe pe;
+  pe.min_sum = all.lo; pe.second_sum = all.hi; pe.n_best = all.n_lo; pe.n_second = all.n_hi;
+  pe.f_dir = 0; pe.f_i1 = 0; pe.f_i2 = 0;
+  if (fk != ~0ull) { pe.f_dir = (uint32_t)(fk >> 48) & 1u; pe.f_i1 = (uint32_t)(fk >> 24) & 0xffffffu; pe.f_i2 = (uint32_t)fk & 0xffffffu; }
+  if (g.t == 0) {
+    d.pe_min[pair] = pe.min_sum; d.pe_second[pair] = pe.second_sum;
+    d.pe_nbest[pair] = pe.n_best; d.pe_nsecond[pair] = pe.n_second;
+    d.pe_first[pair] = pe.f_dir; d.pe_i1[pair] = pe.f_i1; d.pe_i2[pair] = pe.f_i2;
+    if (pe.n_best == 1) cm_emit_record<SAM>(d, pair, pe);
+  }
 }
 
 #endif

@@ -26,15 +26,15 @@ void cm_s3b_heavy_classes(uint32_t *hv_max);
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len);
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
 CM_DECL_LAUNCH(k_s4a_rescue_count)
-CM_DECL_LAUNCH(k_s4b_rescue_merge)
+void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, bool coop, uint32_t max_read_len);
 uint32_t cm_rescue_seg_cap(uint32_t n_reads);
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s);
 void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len);
-CM_DECL_LAUNCH(k_s4c_reduce)
+void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 CM_DECL_LAUNCH(k_s5a_prepare)
-CM_DECL_LAUNCH(k_s5c_finalize)
+void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s);
-CM_DECL_LAUNCH(k_s6a_pair)
+void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 CM_DECL_LAUNCH(k_s6c_multi)
 CM_DECL_LAUNCH(k_s6a_pair_sam)
 CM_DECL_LAUNCH(k_s6c_multi_sam)

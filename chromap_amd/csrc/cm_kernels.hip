@@ -346,11 +346,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
     tot = d.hit_tot[i];
   }
   // one atomic per wave and class (millions of lanes adding to one counter serialise at ~10 ns each)
-  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : 3u;
-  if (__ballot(cls < 5u) == 0) return;
+  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : tot <= d.hv_max[3] ? 10u : 3u;
+  if (__ballot(cls != 5u) == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t ids[6] = {0u, 1u, 2u, 3u, 4u, 10u};
 #pragma unroll
-  for (uint32_t c = 0; c < 5; ++c) {
+  for (uint32_t q = 0; q < 6; ++q) {
+    const uint32_t c = ids[q];
     const unsigned long long m = __ballot(cls == c);
     if (m == 0) continue;
     uint32_t base = 0;
@@ -549,7 +551,7 @@ struct CmDevGroup {
   static constexpr int G = G_;
   static constexpr int W = G_ < 64 ? G_ : 64;
   uint32_t t;
-  uint32_t *xw;  // LDS, 2 * (G / W) words of this group (unused when G <= 64)
+  uint32_t *xw;  // LDS, 256 bytes of this group: the wave parts' totals (unused when G <= 64)
   __device__ __forceinline__ void sync() { cm_group_sync<G_>(); }
   __device__ __forceinline__ uint32_t rank(bool p, uint32_t *total) {
     unsigned long long m = __ballot(p);
@@ -579,6 +581,30 @@ struct CmDevGroup {
     *total = tot;
     return base + incl - v;
   }
+  __device__ __forceinline__ uint32_t scanmax(uint32_t v, uint32_t *total) {
+    const uint32_t wl = t % W;
+    uint32_t incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < W; dlt <<= 1) {
+      const uint32_t x = __shfl_up(incl, dlt, W);
+      if (wl >= (uint32_t)dlt && x > incl) incl = x;
+    }
+    uint32_t excl = __shfl_up(incl, 1, W);
+    if (wl == 0) excl = 0;
+    if (G <= 64) {
+      *total = __shfl(incl, W - 1, W);
+      return excl;
+    }
+    const uint32_t wv = t / W;
+    if (wl == W - 1) xw[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < G / W; ++q) { const uint32_t x = xw[q]; if ((uint32_t)q < wv && x > base) base = x; if (x > tot) tot = x; }
+    __syncthreads();
+    *total = tot;
+    return excl > base ? excl : base;
+  }
   __device__ __forceinline__ uint64_t max64(uint64_t v) {
 #pragma unroll
     for (int dlt = W / 2; dlt > 0; dlt >>= 1) {
@@ -599,22 +625,23 @@ struct CmDevGroup {
   __device__ __forceinline__ uint32_t sum(uint32_t v) { uint32_t tot; (void)scan(v, &tot); return tot; }
 };
 // per-group LDS: the cooperative work area, then the group's cross-wave words
-__host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, uint32_t RB) { return ((cm_coop_mem_bytes(P, MM, RB) + 15) & ~(size_t)15) + 64; }
+#define CM_XW_BYTES 256
+__host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) { return ((cm_coop_mem_bytes(P, MM, RB, own_oc) + 15) & ~(size_t)15) + CM_XW_BYTES; }
 
 // S3b for long hit lists, merge-sort form (cm_coop_s3b): blockDim.x / G groups per block, one listed read each.  What the
 // function declines (more occurrence runs than its tables hold) is appended to fb_list for the bitonic kernel above.
 template <int G>
-__global__ __launch_bounds__(CM_BLOCK) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
-                                                       uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt) {
+__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
+                                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t gid = blockIdx.x * gpb + grp;
   if (gid >= n_list) return;  // a whole group
-  const size_t gb = cm_coop_group_bytes(P, MM, RB);
+  const size_t gb = cm_coop_group_bytes(P, MM, RB, false);
   uint8_t *base = cm_lds + (size_t)grp * gb;
-  const CmCoopMem m = cm_coop_mem_at(base, P, MM, RB);
+  const CmCoopMem m = cm_coop_mem_at(base, P, MM, RB, false);
   CmDevGroup<G> g;
   g.t = threadIdx.x % G;
-  g.xw = reinterpret_cast<uint32_t *>(base + gb - 64);
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   const uint32_t r = list[gid];
   if (!cm_coop_s3b(d, r, g, m) && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
 }
@@ -747,12 +774,16 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_ca
     }
   }
 }
-__global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n) {
+// coop: a read without rescue hits but with a long candidate list (a read from a repeat whose mate is one too) only has that list
+// copied -- hundreds of entries by one lane; such reads join list 6, where a wave copies them (cm_coop_rescue_merge)
+#define CM_S4B_COPY_MIN 64u
+__global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n, uint32_t coop) {
   const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (i0 >= n) return;
-  const uint32_t i = d.perm_reads ? d.perm_reads[i0] : i0;
-  if (d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0) return;  // k_s4b_rescue_list
-  cm_s4b_rescue_merge(d, i);
+  const uint32_t i = i0 < n ? (d.perm_reads ? d.perm_reads[i0] : i0) : 0u;
+  const bool mine = i0 < n && !(d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0);  // the others: k_s4b_rescue_list
+  const bool to_wave = mine && coop && d.m_tot[i] > CM_S4B_COPY_MIN;
+  if (mine && !to_wave) cm_s4b_rescue_merge(d, i);
+  if (coop) cm_wave_append(d.hv_list + (size_t)6 * d.hv_stride, d.hv_cnt + 6, to_wave, i);
 }
 // fill pass of one direction by a group: per-minimizer counts to LDS, lane 0 turns them into offsets (minimizer order = the
 // order cm_rescue writes in), the lanes write their minimizers' hits there
@@ -774,13 +805,13 @@ __device__ __forceinline__ void cm_group_rescue_fill(const CmDev &d, uint32_t r,
   cm_group_sync<CM_RS_G>();
 }
 // Reads with many rescue hits (more than CM_RS_COOP_MIN on a strand) only get their hits written here; sorting, clustering and
-// merging them is the work of a group of lanes (k_s4b_coop), by size class: list 6 up to hv_max[0] hits (a wave each), 7 up to
-// hv_max[1], 8 up to hv_max[2] (a block each).  coop == 0: everything by one lane, as before.
+// merging them is the work of a group of lanes (k_s4b_coop), by size class: list 6 up to hv_max[0] hits (a wave each), 7 / 8 / 11
+// up to hv_max[1] / [2] / [3] (a block of 256 / 512 / 1024 lanes each).  coop == 0: everything by one lane, as before.
 #define CM_RS_COOP_MIN 32u
 __device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
   if (!coop || big <= CM_RS_COOP_MIN || d.hv_max[0] == 0) return 0;
-  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : 0u;
+  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= d.hv_max[3] ? 11u : 0u;
 }
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
@@ -793,6 +824,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     const uint32_t cls = mine ? cm_rescue_coop_class(d, r, coop) : 0u;
     if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
+    cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, cls == 11u, r);
   }
   const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
   for (uint32_t j0 = blockIdx.x * gpb; j0 < cnt; j0 += gridDim.x * gpb) {
@@ -815,49 +847,114 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
       if (t == 0 && !cls) cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);  // sort, cluster, merge of the hits the group wrote
     }
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, t == 0 && cls == c, r);
+    cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, t == 0 && cls == 11u, r);
   }
 }
 // S4b for the reads listed above: a group per read sorts its rescue hits, clusters them and merges them with the read's
 // candidates (cm_coop_rescue_merge).  The list's length is only known on the device: the grid strides over it.
 template <int G>
-__global__ __launch_bounds__(CM_BLOCK) void k_s4b_coop(CmDev d, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev, uint32_t P, uint32_t RB) {
+__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev d, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev, uint32_t P, uint32_t RB) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = *n_list_dev;
-  const size_t gb = cm_coop_group_bytes(P, 1, RB);
+  const size_t gb = cm_coop_group_bytes(P, 1, RB, true);
   uint8_t *base = cm_lds + (size_t)grp * gb;
-  const CmCoopMem m = cm_coop_mem_at(base, P, 1, RB);
+  const CmCoopMem m = cm_coop_mem_at(base, P, 1, RB, true);
   CmDevGroup<G> g;
   g.t = threadIdx.x % G;
-  g.xw = reinterpret_cast<uint32_t *>(base + gb - 64);
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t gid = blockIdx.x * gpb + grp; gid < n_list; gid += gridDim.x * gpb) {
     cm_coop_rescue_merge(d, list[gid], g, m);
     g.sync();  // the work area is reused
   }
 }
-// S4c; long filtered candidate lists are queued for k_sort_lists
-__global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n) {
-  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
-  const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
-  if (i < n) cm_s4c_reduce(d, pair);
-  if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
-  const bool live = i < n && d.alive[pair];
+// S4c; long filtered candidate lists are queued for k_sort_lists.  coop: a pair with a merged candidate list longer than
+// CM_S4C_COOP_MIN entries only gets the part before the filter here and goes to list 9 for k_s4c_coop (a wave per pair).
+#define CM_S4C_COOP_MIN 48u
+__device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair, bool live) {
   for (uint32_t q = 0; q < 4; ++q) {  // (read, strand) lists of the pair
     const uint32_t r = 2 * pair + (q >> 1);
     const uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
     cm_wave_append(d.srt_list, &d.srt_cnt[0], cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX, (r << 1) | (q & 1u));
   }
 }
+__global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, uint32_t coop) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
+  bool to_group = false;
+  if (i < n && cm_s4c_pre(d, pair)) {
+    const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+    uint32_t big = d.mcp[r1] > d.mcn[r1] ? d.mcp[r1] : d.mcn[r1];
+    big = d.mcp[r2] > big ? d.mcp[r2] : big;
+    big = d.mcn[r2] > big ? d.mcn[r2] : big;
+    to_group = coop && big > CM_S4C_COOP_MIN;
+    if (!to_group) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
+  }
+  if (coop) cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, to_group, pair);
+  if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
+  cm_s4c_queue_sort(d, pair, i < n && !to_group && d.alive[pair]);
+}
+// the pairs of list 9: the filter's two directions by a wave each (cm_coop_s4c); the list's length is on the device
+__global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P) {
+  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
+  const uint32_t n_list = d.hv_cnt[9];
+  const uint32_t *list = d.hv_list + 9 * (size_t)d.hv_stride;
+  const size_t gb = ((cm_coop_pair_mem_bytes(P) + 15) & ~(size_t)15);
+  const CmCoopPairMem m = cm_coop_pair_mem_at(cm_lds + (size_t)grp * gb, P);
+  CmDevGroup<64> g;
+  g.t = threadIdx.x % 64;
+  g.xw = nullptr;
+  for (uint32_t j0 = blockIdx.x * gpb; j0 < n_list; j0 += gridDim.x * gpb) {
+    const uint32_t j = j0 + grp;
+    const uint32_t pair = j < n_list ? list[j] : 0u;
+    if (j < n_list) cm_coop_s4c(d, pair, g, m);
+    g.sync();
+    if (d.perm_pairs) {  // long filtered lists: queued for the sorting waves
+      const bool live = j < n_list && d.alive[pair];
+      for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t r = 2 * pair + (q >> 1);
+        const uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
+        if (g.t == 0 && cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | (q & 1u);
+      }
+    }
+  }
+}
 CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare, perm_reads)
-// S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
-__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) {
+// S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order).
+// coop: a read with more than CM_S5C_COOP_MIN candidates goes to list 12, where a wave runs its acceptance loop (k_s5c_coop).
+#define CM_S5C_COOP_MIN 48u
+__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, uint32_t coop) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
-  if (i < n) cm_s5c_finalize(d, r);
+  const bool to_wave = i < n && coop && d.nv[r] > CM_S5C_COOP_MIN;
+  if (i < n && !to_wave) cm_s5c_finalize(d, r);
+  if (coop) cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave, r);
   if (!d.perm_reads || d.p.split || d.p.single) return;  // the queue is only served in a batch with heavy reads
-  const bool live = i < n && d.alive[r >> 1];
+  const bool live = i < n && !to_wave && d.alive[r >> 1];
   const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
   cm_wave_append(d.srt_list, &d.srt_cnt[0], a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX, r << 1);
   cm_wave_append(d.srt_list, &d.srt_cnt[0], b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX, (r << 1) | 1u);
+}
+__global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P) {
+  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
+  const uint32_t n_list = d.hv_cnt[12];
+  const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
+  const size_t gb = ((cm_coop_ver_mem_bytes(P) + 15) & ~(size_t)15);
+  const CmCoopVerMem m = cm_coop_ver_mem_at(cm_lds + (size_t)grp * gb, P);
+  CmDevGroup<64> g;
+  g.t = threadIdx.x % 64;
+  g.xw = nullptr;
+  for (uint32_t j0 = blockIdx.x * gpb; j0 < n_list; j0 += gridDim.x * gpb) {
+    const uint32_t j = j0 + grp;
+    const uint32_t r = j < n_list ? list[j] : 0u;
+    if (j < n_list) cm_coop_s5c(d, r, g, m);
+    g.sync();
+    if (d.perm_reads && !d.p.split && !d.p.single) {
+      const bool live = j < n_list && d.alive[r >> 1];
+      const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
+      if (g.t == 0 && a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
+      if (g.t == 0 && b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -925,7 +1022,31 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_ite
   if (j < n_items) cm_s5b_verify_item(d, j, n_reads);
 }
 // --SAM has its own instantiations: the alignment's register window must not cost the BED path occupancy
-CM_ITEM_KERNEL(k_s6a_pair, cm_s6a_pair<false>, perm_pairs)
+// S6a.  coop: a pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 13, where a wave runs its two sweeps
+#define CM_S6A_COOP_MIN 48u
+__global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint32_t coop) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
+  bool to_wave = false;
+  if (i < n && cm_s6a_pre<false>(d, pair)) {
+    const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+    uint32_t big = d.ndp[r1] > d.ndn[r1] ? d.ndp[r1] : d.ndn[r1];
+    big = d.ndp[r2] > big ? d.ndp[r2] : big;
+    big = d.ndn[r2] > big ? d.ndn[r2] : big;
+    to_wave = coop && big > CM_S6A_COOP_MIN;
+    if (!to_wave) cm_s6a_sweeps<false>(d, pair);
+  }
+  if (coop) cm_wave_append(d.hv_list + (size_t)13 * d.hv_stride, d.hv_cnt + 13, to_wave, pair);
+}
+__global__ __launch_bounds__(CM_BLOCK) void k_s6a_coop(CmDev d) {
+  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
+  const uint32_t n_list = d.hv_cnt[13];
+  const uint32_t *list = d.hv_list + (size_t)13 * d.hv_stride;
+  CmDevGroup<64> g;
+  g.t = threadIdx.x % 64;
+  g.xw = nullptr;
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6a<false>(d, list[j], g);
+}
 CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi<false>, perm_pairs)
 CM_ITEM_KERNEL(k_s6a_pair_sam, cm_s6a_pair<true>, perm_pairs)
 CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>, perm_pairs)
@@ -1324,7 +1445,7 @@ void cm_s3b_heavy_classes(uint32_t *hv_max) {
     (void)hipGetLastError();
     if (dev == slot) big_ok[slot].store(st, std::memory_order_release);
   }
-  hv_max[0] = 1024; hv_max[1] = 4096; hv_max[2] = st == 1 ? 8192 : 4096;
+  hv_max[0] = 1024; hv_max[1] = 2048; hv_max[2] = 4096; hv_max[3] = st == 1 ? 8192 : 4096;
 }
 // the largest dynamic LDS allocation a kernel of this device may ask for, opted in once per device and kernel
 template <class K>
@@ -1349,52 +1470,63 @@ static bool cm_lds_optin(K kernel, size_t bytes) {
   if (e == hipSuccess) { if (bytes > v.first) v.first = bytes; } else if (!v.second || bytes < v.second) v.second = bytes;
   return e == hipSuccess;
 }
-// n_cls[c]: reads of class c (k_s3a_count's lists).  coop: classes 0..2 go through the merge-sort kernel (tables sized for
-// reads of up to max_read_len bases); what it declines -- hv_cnt[5] reads at list 5 -- is taken by the bitonic kernel.
+// n_cls[c]: reads of list c (k_s3a_count; 11 entries).  coop: lists 0, 1, 2, 10 go through the merge-sort kernel (tables sized for
+// reads of up to max_read_len bases) with a wave / 256 / 512 / 1024 lanes per read; what it declines -- hv_cnt[5] reads at list 5 --
+// is taken by the bitonic kernel.
+static inline uint32_t cm_coop_mm(const CmDev &d, uint32_t max_read_len) {
+  // a read of L bases has at most L - k + 1 minimizers; the tables hold that many (capped)
+  uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
+  return MM > 256 ? 256 : MM;
+}
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len) {
-  const uint32_t *l0 = d.hv_list, *l1 = d.hv_list + d.hv_stride, *l2 = d.hv_list + 2 * (size_t)d.hv_stride, *l3 = d.hv_list + 3 * (size_t)d.hv_stride;
   auto pow2 = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };  // the sort network's size: a power of two
-  bool any_coop = false;
-  if (coop) {
-    // a read of L bases has at most L - k + 1 minimizers; the tables hold that many (capped), two runs per minimizer
-    uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
-    if (MM > 256) MM = 256;
-    const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;
+  auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
+  uint32_t rest[11];
+  for (int c = 0; c < 11; ++c) rest[c] = n_cls[c];
+  if (coop && d.hv_max[0]) {
+    const uint32_t MM = cm_coop_mm(d, max_read_len);
+    const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;  // two runs per minimizer unless a diagonal wraps
     uint32_t *fb_list = d.hv_list + 5 * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + 5;
-    uint32_t rest[3] = {n_cls[0], n_cls[1], n_cls[2]};
+    bool any_coop = false;
     if (n_cls[0]) {  // a wave per read, two reads per block
-      const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB);
+      const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB, false);
       if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
-        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, l0, n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt);
+        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt);
         rest[0] = 0; any_coop = true;
       }
     }
-    for (int c = 1; c <= 2; ++c) {
-      if (!n_cls[c] || (c == 2 && d.hv_max[2] == d.hv_max[1])) continue;
-      const size_t lds = cm_coop_group_bytes(d.hv_max[c], MM, RB);
-      if (!cm_lds_optin(&k_s3b_coop<CM_BLOCK>, lds)) continue;
-      hipLaunchKernelGGL(k_s3b_coop<CM_BLOCK>, dim3(n_cls[c]), dim3(CM_BLOCK), lds, s, d, c == 1 ? l1 : l2, n_cls[c], d.hv_max[c], MM, RB, fb_list, fb_cnt);
-      rest[c] = 0; any_coop = true;
+#define CM_S3B_COOP_CLASS(C_, Q_, G_)                                                                                                              \
+    if (n_cls[C_] && d.hv_max[Q_] > d.hv_max[Q_ - 1]) {                                                                                            \
+      const size_t lds = cm_coop_group_bytes(d.hv_max[Q_], MM, RB, false);                                                                         \
+      if (cm_lds_optin(&k_s3b_coop<G_>, lds)) {                                                                                                    \
+        hipLaunchKernelGGL(k_s3b_coop<G_>, dim3(n_cls[C_]), dim3(G_), lds, s, d, lst(C_), n_cls[C_], d.hv_max[Q_], MM, RB, fb_list, fb_cnt);      \
+        rest[C_] = 0; any_coop = true;                                                                                                             \
+      }                                                                                                                                            \
     }
-    if (any_coop) {  // the declined reads: up to hv_max[2] hits, a block each, the grid strides over the device-side list
-      const uint32_t P = pow2(d.hv_max[2]);
+    CM_S3B_COOP_CLASS(1, 1, 256)
+    CM_S3B_COOP_CLASS(2, 2, 512)
+    CM_S3B_COOP_CLASS(10, 3, 1024)
+#undef CM_S3B_COOP_CLASS
+    if (any_coop) {  // the declined reads: up to hv_max[3] hits, a block each, the grid strides over the device-side list
+      const uint32_t P = pow2(d.hv_max[3]);
       hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(512), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, (const uint32_t *)fb_list, 0u, P, (const uint32_t *)fb_cnt);
     }
-    uint32_t n2[5] = {rest[0], rest[1], rest[2], n_cls[3], n_cls[4]};
-    cm_launch_k_s3b_heavy(d, n2, s, false, max_read_len);
-    return;
   }
-  if (n_cls[0]) {
+  if (rest[0]) {
     const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
-    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((n_cls[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, l0, n_cls[0], P, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((rest[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, lst(0), rest[0], P, (const uint32_t *)nullptr);
   }
-  if (n_cls[1]) { const uint32_t P = pow2(d.hv_max[1]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[1]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l1, n_cls[1], P, (const uint32_t *)nullptr); }
-  if (n_cls[2]) { const uint32_t P = pow2(d.hv_max[2]); hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(n_cls[2]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, l2, n_cls[2], P, (const uint32_t *)nullptr); }
-  if (n_cls[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((n_cls[3] + 63) / 64), dim3(64), 0, s, d, l3, n_cls[3]);
-  if (n_cls[4]) {  // groups of 16 lanes, 16 reads per block
-    const uint32_t *l4 = d.hv_list + 4 * (size_t)d.hv_stride;
+  const uint32_t blk[3][2] = {{1, 1}, {2, 2}, {10, 3}};  // list, size class
+  for (int q = 0; q < 3; ++q) {
+    const uint32_t c = blk[q][0];
+    if (!rest[c]) continue;
+    const uint32_t P = pow2(d.hv_max[blk[q][1]]);
+    hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[c]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(c), rest[c], P, (const uint32_t *)nullptr);
+  }
+  if (rest[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((rest[3] + 63) / 64), dim3(64), 0, s, d, lst(3), rest[3]);
+  if (rest[4]) {  // groups of 16 lanes, 16 reads per block
     const uint32_t P = pow2(d.hv_mid), gpb = CM_BLOCK / 16;
-    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((n_cls[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, l4, n_cls[4], P, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((rest[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, lst(4), rest[4], P, (const uint32_t *)nullptr);
   }
 }
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
@@ -1405,7 +1537,6 @@ void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_le
   while (threads > 64 && (size_t)cap * threads * 9 > 36 * 1024 + 1024) threads >>= 1;
   hipLaunchKernelGGL(k_s3b_candidates, dim3((n + threads - 1) / threads), dim3(threads), (size_t)cap * threads * 9, s, d, n, cap);
 }
-CM_LAUNCH(k_s4b_rescue_merge)
 // capacity of one list segment: the reads of every CM_RS_SEGS-th block
 uint32_t cm_rescue_seg_cap(uint32_t n_reads) { return ((n_reads + CM_BLOCK - 1) / CM_BLOCK / CM_RS_SEGS + 1) * CM_BLOCK; }
 void cm_launch_k_s4a_rescue_count(const CmDev &d, uint32_t n, hipStream_t s) {
@@ -1420,38 +1551,75 @@ static inline dim3 rescue_list_grid(uint32_t n_reads) {
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s) {
   if (n_reads) hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads));
 }
+// the per-read part (reads without rescue hits) and, coop: the reads whose long lists a wave copies
+static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {
+  if (!d.hv_max[0]) return false;
+  lds[0] = 2 * cm_coop_group_bytes(d.hv_max[0], 1, RB, true);
+  lds[1] = cm_coop_group_bytes(d.hv_max[1], 1, RB, true);
+  lds[2] = cm_coop_group_bytes(d.hv_max[2], 1, RB, true);
+  lds[3] = cm_coop_group_bytes(d.hv_max[3], 1, RB, true);
+  return cm_lds_optin(&k_s4b_coop<64>, lds[0]) && cm_lds_optin(&k_s4b_coop<256>, lds[1]) && cm_lds_optin(&k_s4b_coop<512>, lds[2]) &&
+         cm_lds_optin(&k_s4b_coop<1024>, lds[3]);
+}
+static inline uint32_t cm_s4b_rb(const CmDev &d, uint32_t max_read_len) {
+  return d.coop_rb ? d.coop_rb : 2 * cm_coop_mm(d, max_read_len) + 2;  // ascending runs the sorter's tables hold: one per minimizer unless a diagonal wraps
+}
+void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, bool coop, uint32_t max_read_len) {
+  if (!n) return;
+  size_t lds[4];
+  const bool all = coop && cm_s4b_coop_ready(d, cm_s4b_rb(d, max_read_len), lds);
+  hipLaunchKernelGGL(k_s4b_rescue_merge, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, all ? 1u : 0u);
+}
 // coop: reads with many rescue hits are only filled by the list kernel and finished by groups of lanes (k_s4b_coop)
 void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len) {
   if (!n_reads) return;
-  uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
-  if (MM > 256) MM = 256;
-  const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;  // ascending runs the sorter's tables hold: one per minimizer unless a diagonal wraps
-  bool ok[3] = {false, false, false};
-  size_t lds[3] = {0, 0, 0};
-  if (coop && d.hv_max[0]) {
-    lds[0] = 2 * cm_coop_group_bytes(d.hv_max[0], 1, RB);
-    ok[0] = cm_lds_optin(&k_s4b_coop<64>, lds[0]);
-    for (int c = 1; c <= 2; ++c) { lds[c] = cm_coop_group_bytes(d.hv_max[c], 1, RB); ok[c] = cm_lds_optin(&k_s4b_coop<CM_BLOCK>, lds[c]); }
-  }
-  const bool all = ok[0] && ok[1] && ok[2];
+  const uint32_t RB = cm_s4b_rb(d, max_read_len);
+  size_t lds[4];
+  const bool all = coop && cm_s4b_coop_ready(d, RB, lds);
   hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
   if (!all) return;
   uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, (const uint32_t *)(d.hv_list + 6 * (size_t)d.hv_stride), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB);
-  hipLaunchKernelGGL(k_s4b_coop<CM_BLOCK>, dim3(blocks), dim3(CM_BLOCK), lds[1], s, d, (const uint32_t *)(d.hv_list + 7 * (size_t)d.hv_stride), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB);
-  if (d.hv_max[2] > d.hv_max[1])
-    hipLaunchKernelGGL(k_s4b_coop<CM_BLOCK>, dim3(blocks > 256 ? 256 : blocks), dim3(CM_BLOCK), lds[2], s, d, (const uint32_t *)(d.hv_list + 8 * (size_t)d.hv_stride), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB);
+  auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
+  hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB);
+  if (d.hv_max[1] > d.hv_max[0]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB);
+  if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB);
+  if (d.hv_max[3] > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.hv_max[3], RB);
 }
-CM_LAUNCH(k_s4c_reduce)
+void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+  if (!n) return;
+  const uint32_t P = 2048;  // entries of a candidate list the wave's work arrays hold (longer lists: its lane 0)
+  const size_t gb = ((cm_coop_pair_mem_bytes(P) + 15) & ~(size_t)15);
+  hipLaunchKernelGGL(k_s4c_reduce, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  if (!coop) return;
+  uint32_t blocks = n / 4096 + 64;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s4c_coop, dim3(blocks), dim3(128), 2 * gb, s, d, P);
+}
 CM_LAUNCH(k_s5a_prepare)
-CM_LAUNCH(k_s5c_finalize)
+void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  if (!coop) return;
+  const uint32_t P = 2048;  // candidates of a strand the wave's work arrays hold (longer lists: its lane 0)
+  const size_t gb = ((cm_coop_ver_mem_bytes(P) + 15) & ~(size_t)15);
+  uint32_t blocks = n / 4096 + 64;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s5c_coop, dim3(blocks), dim3(CM_BLOCK), 4 * gb, s, d, P);
+}
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
 void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_s5b_verify, grid_for(n_items), dim3(CM_BLOCK), 0, s, d, n_items, n_reads);
 }
-CM_LAUNCH(k_s6a_pair)
+void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_s6a_pair, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  if (!coop) return;
+  uint32_t blocks = n / 4096 + 64;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s6a_coop, dim3(blocks), dim3(CM_BLOCK), 0, s, d);
+}
 CM_LAUNCH(k_s6c_multi)
 
 // threads per block / LDS bytes for the read-staging kernels, from the longest read of the batch

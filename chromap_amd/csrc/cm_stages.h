@@ -1463,13 +1463,16 @@ CM_HD void cm_rerank(const CmDev &d, uint32_t r) {
   for (uint32_t i = 0; i < d.fcn[r]; ++i) fn[i] = (fn[i] & 0xffffffffull) | ((uint64_t)d.rid_rank[(uint32_t)(fn[i] >> 32)] << 32);
 }
 
-CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
+// cm_s4c_reduce in three parts so that a group of lanes can run the filter of a pair with long candidate lists
+// (cm_coop_s4c, cm_coop.h): cm_s4c_pre does everything up to the filter and says whether it has to run, cm_s4c_filter is
+// the two directions, cm_s4c_post the pair's fate and the re-ranking.
+CM_HD bool cm_s4c_pre(const CmDev &d, uint32_t pair) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   d.fcp[r1] = d.fcn[r1] = d.fcp[r2] = d.fcn[r2] = 0;
   d.alive[pair] = 0;
   d.force0[pair] = 0;
   if (d.p.single) {  // chromap.h:442-445: candidates go straight to verification
-    if (d.mm_cnt[r1] == 0 || d.mcp[r1] + d.mcn[r1] == 0) return;
+    if (d.mm_cnt[r1] == 0 || d.mcp[r1] + d.mcn[r1] == 0) return false;
     const uint64_t *mp = cm_m_pos(d, r1), *mn = cm_m_neg(d, r1);
     const uint8_t *mpc = cm_m_pcnt(d, r1), *mnc = cm_m_ncnt(d, r1);
     uint64_t *fp = cm_f_pos(d, r1), *fn = cm_f_neg(d, r1);
@@ -1479,9 +1482,9 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
     d.fcp[r1] = d.mcp[r1]; d.fcn[r1] = d.mcn[r1];
     d.alive[pair] = 1;
     cm_rerank(d, r1);
-    return;
+    return false;
   }
-  if (!(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return;
+  if (!(d.mm_cnt[r1] > 0 && d.mm_cnt[r2] > 0)) return false;
   int ret = 0;
   for (uint32_t r = r1; r <= r2; ++r) {
     if (!d.aug[r]) continue;
@@ -1490,7 +1493,7 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
   }
   d.force0[pair] = (uint8_t)ret;
   const uint32_t nc1 = d.mcp[r1] + d.mcn[r1], nc2 = d.mcp[r2] + d.mcn[r2];
-  if (!(nc1 > 0 && nc2 > 0)) return;
+  if (!(nc1 > 0 && nc2 > 0)) return false;
   if (d.p.split) {  // no paired-end filter (chromap.h:1036-1038): candidates pass through unchanged
     for (uint32_t r = r1; r <= r2; ++r) {
       const uint64_t *mp = cm_m_pos(d, r), *mn = cm_m_neg(d, r);
@@ -1503,8 +1506,12 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
     }
     d.alive[pair] = 1;
     cm_rerank(d, r1); cm_rerank(d, r2);
-    return;
+    return false;
   }
+  return true;
+}
+CM_HD void cm_s4c_filter(const CmDev &d, uint32_t pair) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   uint32_t a, b;
   cm_reduce_dir((uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2),
                 cm_m_ncnt(d, r2), d.mcn[r2], cm_f_pos(d, r1), cm_f_pcnt(d, r1), &a, cm_f_neg(d, r2), cm_f_ncnt(d, r2), &b);
@@ -1512,9 +1519,17 @@ CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
   cm_reduce_dir((uint32_t)d.p.max_insert, cm_m_neg(d, r1), cm_m_ncnt(d, r1), d.mcn[r1], cm_m_pos(d, r2),
                 cm_m_pcnt(d, r2), d.mcp[r2], cm_f_neg(d, r1), cm_f_ncnt(d, r1), &a, cm_f_pos(d, r2), cm_f_pcnt(d, r2), &b);
   d.fcn[r1] = a; d.fcp[r2] = b;
+}
+CM_HD void cm_s4c_post(const CmDev &d, uint32_t pair) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   const uint32_t f1 = d.fcp[r1] + d.fcn[r1], f2 = d.fcp[r2] + d.fcn[r2];
   d.alive[pair] = (f1 > 0 && f2 > 0) ? 1 : 0;
   if (d.alive[pair]) { cm_rerank(d, r1); cm_rerank(d, r2); }
+}
+CM_HD void cm_s4c_reduce(const CmDev &d, uint32_t pair) {
+  if (!cm_s4c_pre(d, pair)) return;
+  cm_s4c_filter(d, pair);
+  cm_s4c_post(d, pair);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2799,21 +2814,23 @@ CM_HD void cm_emit_single_record(const CmDev &d, uint32_t pair, uint32_t choice,
 //      (GenerateBestMappingsForPairedEndRead, mapping_generator.h:160-253), record for pairs
 //      with a single best pairing.
 // ---------------------------------------------------------------------------------------
+// in two parts so that a group of lanes can run the sweeps of a pair with many draft mappings (cm_coop_s6a, cm_coop.h):
+// cm_s6a_pre does everything else and says whether the paired-end sweeps have to run
 template <bool SAM = false>
-CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
+CM_HD bool cm_s6a_pre(const CmDev &d, uint32_t pair) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   for (uint32_t t = 0; t < (uint32_t)d.p.max_best; ++t) d.rec_ok[(uint64_t)pair * (uint32_t)d.p.max_best + t] = 0;
   d.pe_nbest[pair] = 0;
-  if (!d.alive[pair]) return;
+  if (!d.alive[pair]) return false;
   const uint32_t nd1 = d.ndp[r1] + d.ndn[r1], nd2 = d.ndp[r2] + d.ndn[r2];
   if (d.p.single) {  // GenerateBestMappingsForSingleEndRead (mapping_generator.h:115-157)
-    if (nd1 == 0) return;
+    if (nd1 == 0) return false;
     d.pe_nbest[pair] = d.n_best[r1];
     d.pe_min[pair] = d.min_err[r1]; d.pe_second[pair] = d.second_err[r1]; d.pe_nsecond[pair] = d.n_second[r1];
     if (d.n_best[r1] == 1) cm_emit_single_record<SAM>(d, pair, 0);
-    return;
+    return false;
   }
-  if (!(nd1 > 0 && nd2 > 0)) return;  // chromap.h:1092-1093
+  if (!(nd1 > 0 && nd2 > 0)) return false;  // chromap.h:1092-1093
   if (d.p.split) {  // drafts stay in emission order (chromap.h:1099-1106)
     CmPe sp;
     cm_split_pairing(d, pair, 0, sp);
@@ -2821,8 +2838,13 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
     d.pe_nbest[pair] = sp.n_best; d.pe_nsecond[pair] = sp.n_second;
     d.pe_first[pair] = sp.f_dir; d.pe_i1[pair] = sp.f_i1; d.pe_i2[pair] = sp.f_i2;
     if (sp.n_best == 1) cm_emit_pairs_record<SAM>(d, pair, sp);
-    return;
+    return false;
   }
+  return true;
+}
+template <bool SAM = false>
+CM_HD void cm_s6a_sweeps(const CmDev &d, uint32_t pair) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   for (uint32_t r = r1; r <= r2; ++r) {
     cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 0)), const_cast<int16_t *>(cm_d_err(d, r, 0)), d.ndp[r]);
     cm_sort_draft(const_cast<uint64_t *>(cm_d_pos(d, r, 1)), const_cast<int16_t *>(cm_d_err(d, r, 1)), d.ndn[r]);
@@ -2840,6 +2862,10 @@ CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
   d.pe_nbest[pair] = pe.n_best; d.pe_nsecond[pair] = pe.n_second;
   d.pe_first[pair] = pe.f_dir; d.pe_i1[pair] = pe.f_i1; d.pe_i2[pair] = pe.f_i2;
   if (pe.n_best == 1) cm_emit_record<SAM>(d, pair, pe);
+}
+template <bool SAM = false>
+CM_HD void cm_s6a_pair(const CmDev &d, uint32_t pair) {
+  if (cm_s6a_pre<SAM>(d, pair)) cm_s6a_sweeps<SAM>(d, pair);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -120,6 +120,19 @@ struct EmuGroup {
     *total = tot;
     return r;
   }
+  uint32_t scanmax(uint32_t v, uint32_t *total) {
+    team->slot[t] = v;
+    sync();
+    uint32_t r = 0, tot = 0;
+    for (uint32_t i = 0; i < (uint32_t)G; ++i) {
+      const uint32_t x = (uint32_t)team->slot[i];
+      if (i < t && x > r) r = x;
+      if (x > tot) tot = x;
+    }
+    sync();
+    *total = tot;
+    return r;
+  }
   uint64_t max64(uint64_t v) {
     team->slot[t] = v;
     sync();

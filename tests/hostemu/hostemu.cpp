@@ -43,9 +43,9 @@ extern "C" void hostemu_coop_items(unsigned long long *out) { memcpy(out, g_coop
 
 template <int G>
 static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std::vector<uint8_t> &ok) {
-  std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB) + 16);
+  std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB, false) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
-  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB);
+  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, false);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
       const bool done = cm_coop_s3b(d, list[i], g, m);
@@ -57,12 +57,49 @@ static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std:
 
 template <int G>
 static void emu_coop_rescue(const CmDev &d, const std::vector<uint32_t> &list) {
-  std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB) + 16);
+  std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB, true) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
-  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB);
+  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, true);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
       cm_coop_rescue_merge(d, list[i], g, m);
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
+
+template <int G>
+static void emu_coop_s4c(const CmDev &d, const std::vector<uint32_t> &list) {
+  const uint32_t P = g_coop.P > 60000 ? 60000 : g_coop.P;
+  std::vector<uint8_t> mem(cm_coop_pair_mem_bytes(P) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopPairMem m = cm_coop_pair_mem_at(base, P);
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      cm_coop_s4c(d, list[i], g, m);
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
+
+template <int G>
+static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list) {
+  const uint32_t P = g_coop.P > 60000 ? 60000 : g_coop.P;
+  std::vector<uint8_t> mem(cm_coop_ver_mem_bytes(P) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopVerMem m = cm_coop_ver_mem_at(base, P);
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      cm_coop_s5c(d, list[i], g, m);
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
+template <int G>
+static void emu_coop_s6a(const CmDev &d, const std::vector<uint32_t> &list) {
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      cm_coop_s6a<false>(d, list[i], g);
       g.sync();
     }
   }, g_coop_reverse);
@@ -217,7 +254,8 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     }
     if (!heavy.empty()) {  // k_s3b_coop: a group of lanes per read; what it declines goes to the one-lane path
       std::vector<uint8_t> ok(heavy.size(), 0);
-      if (g_coop.G == 16) emu_coop_s3b<16>(d, heavy, ok); else if (g_coop.G == 64) emu_coop_s3b<64>(d, heavy, ok); else emu_coop_s3b<256>(d, heavy, ok);
+      if (g_coop.G == 16) emu_coop_s3b<16>(d, heavy, ok); else if (g_coop.G == 64) emu_coop_s3b<64>(d, heavy, ok);
+      else if (g_coop.G == 256) emu_coop_s3b<256>(d, heavy, ok); else emu_coop_s3b<1024>(d, heavy, ok);
       for (size_t i = 0; i < heavy.size(); ++i) {
         g_coop_items[ok[i] ? 0 : 1] += 1;
         if (!ok[i]) cm_s3b_candidates(d, heavy[i]);
@@ -242,15 +280,41 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     }
     if (!heavy.empty()) {
       g_coop_items[2] += heavy.size();
-      if (g_coop.G == 16) emu_coop_rescue<16>(d, heavy); else if (g_coop.G == 64) emu_coop_rescue<64>(d, heavy); else emu_coop_rescue<256>(d, heavy);
+      if (g_coop.G == 16) emu_coop_rescue<16>(d, heavy); else if (g_coop.G == 64) emu_coop_rescue<64>(d, heavy);
+      else if (g_coop.G == 256) emu_coop_rescue<256>(d, heavy); else emu_coop_rescue<1024>(d, heavy);
     }
   }
-  for (uint32_t i = 0; i < n; ++i) cm_s4c_reduce(d, i);
+  {
+    std::vector<uint32_t> heavy;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (!cm_s4c_pre(d, i)) continue;
+      uint32_t big = 0;
+      for (uint32_t r = 2 * i; r <= 2 * i + 1; ++r) { big = d.mcp[r] > big ? d.mcp[r] : big; big = d.mcn[r] > big ? d.mcn[r] : big; }
+      if (g_coop.G && big > g_coop.thr) { heavy.push_back(i); continue; }
+      cm_s4c_filter(d, i);
+      cm_s4c_post(d, i);
+    }
+    if (!heavy.empty()) {  // k_s4c_coop
+      g_coop_items[3] += heavy.size();
+      if (g_coop.G == 16) emu_coop_s4c<16>(d, heavy); else if (g_coop.G == 64) emu_coop_s4c<64>(d, heavy);
+      else if (g_coop.G == 256) emu_coop_s4c<256>(d, heavy); else emu_coop_s4c<1024>(d, heavy);
+    }
+  }
   VEC(nv, uint32_t, n2) VEC(v_off, uint32_t, n2 + 1) VEC(v_err, int16_t, n_m) VEC(v_end, int16_t, n_m)
   for (uint32_t r = 0; r < n2; ++r) cm_s5a_prepare(d, r);
   scan(d.nv, d.v_off, n2);
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
-  for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r);
+  {
+    std::vector<uint32_t> heavy;
+    for (uint32_t r = 0; r < n2; ++r) {
+      if (g_coop.G && !d.p.split && d.nv[r] > g_coop.thr) heavy.push_back(r); else cm_s5c_finalize(d, r);
+    }
+    if (!heavy.empty()) {  // k_s5c_coop
+      g_coop_items[4] += heavy.size();
+      if (g_coop.G == 16) emu_coop_s5c<16>(d, heavy); else if (g_coop.G == 64) emu_coop_s5c<64>(d, heavy);
+      else if (g_coop.G == 256) emu_coop_s5c<256>(d, heavy); else emu_coop_s5c<1024>(d, heavy);
+    }
+  }
   // --SAM buffers (cmgpu_map_resident allocates the same per batch)
   std::vector<uint32_t> samz;
   if (sam) {
@@ -261,7 +325,21 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     d.sam_z = samz.data();
     memset(sam->rec, 0, (size_t)(single ? n : n2) * sizeof(cmgpu_sam_record));
   }
-  for (uint32_t i = 0; i < n; ++i) { if (sam) cm_s6a_pair<true>(d, i); else cm_s6a_pair<false>(d, i); }
+  {
+    std::vector<uint32_t> heavy;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (sam) { cm_s6a_pair<true>(d, i); continue; }
+      if (!cm_s6a_pre<false>(d, i)) continue;
+      uint32_t big = 0;
+      for (uint32_t r = 2 * i; r <= 2 * i + 1; ++r) { big = d.ndp[r] > big ? d.ndp[r] : big; big = d.ndn[r] > big ? d.ndn[r] : big; }
+      if (g_coop.G && big > g_coop.thr) heavy.push_back(i); else cm_s6a_sweeps<false>(d, i);
+    }
+    if (!heavy.empty()) {  // k_s6a_coop
+      g_coop_items[5] += heavy.size();
+      if (g_coop.G == 16) emu_coop_s6a<16>(d, heavy); else if (g_coop.G == 64) emu_coop_s6a<64>(d, heavy);
+      else if (g_coop.G == 256) emu_coop_s6a<256>(d, heavy); else emu_coop_s6a<1024>(d, heavy);
+    }
+  }
   const uint32_t nch = cm_num_chunks(n, (uint32_t)p.ref_batch, (uint32_t)p.grain);
   CmMt *g = new CmMt();
   for (uint32_t c = 0; c < nch; ++c) cm_s6b_sample(d, c, *g);
@@ -523,9 +601,9 @@ static int emu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c, uint32_
   std::vector<uint64_t> go((size_t)n1 + cnt + 1), zp((size_t)n1 + cnt + 1);
   std::vector<uint8_t> goc((size_t)n1 + cnt + 1), zc((size_t)n1 + cnt + 1);
   for (uint32_t i = 0; i < cnt; ++i) go[n1 + i] = hits[i];
-  std::vector<uint8_t> mem(cm_coop_mem_bytes(P, 4, RB) + 16);
+  std::vector<uint8_t> mem(cm_coop_mem_bytes(P, 4, RB, true) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
-  const CmCoopMem m = cm_coop_mem_at(base, P, 4, RB);
+  const CmCoopMem m = cm_coop_mem_at(base, P, 4, RB, true);
   uint32_t got = 0;
   emu_run_group<G>([&](EmuGroup<G> &g) {
     const uint32_t k = cm_coop_rescue_dir(d, 0, g, m, go.data(), goc.data(), n1, cnt, true, c0p, c0c, zp.data(), zc.data());
@@ -540,4 +618,111 @@ extern "C" int hostemu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c,
   if (G == 16) return emu_rescue_dir_check<16>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
   if (G == 64) return emu_rescue_dir_check<64>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
   return emu_rescue_dir_check<256>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
+}
+
+
+// cm_coop_reduce_dir against cm_reduce_dir on caller-made ascending lists.  Returns 0 when equal.
+template <int G>
+static int emu_reduce_dir_check(uint32_t dist, const uint64_t *p1, const uint8_t *c1, uint32_t n1, const uint64_t *p2, const uint8_t *c2, uint32_t n2,
+                                bool reverse) {
+  std::vector<uint64_t> sf1(n1 + 1), sf2(n2 + 1), gf1(n1 + 1), gf2(n2 + 1);
+  std::vector<uint8_t> sc1(n1 + 1), sc2(n2 + 1), gc1(n1 + 1), gc2(n2 + 1);
+  uint32_t sa, sb, ga = 0, gb = 0;
+  cm_reduce_dir(dist, p1, c1, n1, p2, c2, n2, sf1.data(), sc1.data(), &sa, sf2.data(), sc2.data(), &sb);
+  const uint32_t P = (n1 > n2 ? n1 : n2) + 1;
+  std::vector<uint8_t> mem(cm_coop_pair_mem_bytes(P) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopPairMem m = cm_coop_pair_mem_at(base, P);
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    uint32_t a, b;
+    cm_coop_reduce_dir(g, m, dist, p1, c1, n1, p2, c2, n2, gf1.data(), gc1.data(), &a, gf2.data(), gc2.data(), &b);
+    if (g.t == 0) { ga = a; gb = b; }
+  }, reverse);
+  if (ga != sa || gb != sb) return 1;
+  for (uint32_t i = 0; i < sa; ++i) if (gf1[i] != sf1[i] || gc1[i] != sc1[i]) return 2;
+  for (uint32_t i = 0; i < sb; ++i) if (gf2[i] != sf2[i] || gc2[i] != sc2[i]) return 3;
+  return 0;
+}
+extern "C" int hostemu_reduce_dir_check(uint32_t dist, const uint64_t *p1, const uint8_t *c1, uint32_t n1, const uint64_t *p2, const uint8_t *c2,
+                                        uint32_t n2, int G, int reverse) {
+  if (G == 16) return emu_reduce_dir_check<16>(dist, p1, c1, n1, p2, c2, n2, reverse != 0);
+  if (G == 64) return emu_reduce_dir_check<64>(dist, p1, c1, n1, p2, c2, n2, reverse != 0);
+  return emu_reduce_dir_check<256>(dist, p1, c1, n1, p2, c2, n2, reverse != 0);
+}
+
+// cm_coop_draft_strand against cm_draft_strand (the acceptance loop over precomputed alignments) on caller-made candidate
+// lists (sorted by count descending): returns 0 when the draft mappings and the best / second-best bookkeeping are equal
+template <int G>
+static int emu_draft_strand_check(const uint64_t *cp, const uint8_t *cc, uint32_t nc, const int16_t *pre_err, const int16_t *pre_end, uint32_t L,
+                                  int strand, int e, int lanes, const uint32_t *ref_len, uint32_t n_seq, bool reverse) {
+  CmDev d;
+  memset(&d, 0, sizeof(d));
+  d.p.e = e; d.p.lanes = lanes;
+  d.ref_len = ref_len; d.n_seq = n_seq;
+  std::vector<uint64_t> sdp(nc + 1), gdp(nc + 1);
+  std::vector<int16_t> sde(nc + 1), gde(nc + 1);
+  CmBest sb = {e + 1, e + 1, 0, 0};
+  const uint32_t want = cm_draft_strand(d, nullptr, L, strand, cp, cc, nc, sb, sdp.data(), sde.data(), pre_err, pre_end);
+  const uint32_t P = nc + 1;
+  std::vector<uint8_t> mem(cm_coop_ver_mem_bytes(P) + 16);
+  uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
+  const CmCoopVerMem m = cm_coop_ver_mem_at(base, P);
+  uint32_t got = 0;
+  CmTwo gb = {e + 1, 0, e + 1, 0};
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    CmTwo b = {e + 1, 0, e + 1, 0};
+    const uint32_t k = cm_coop_draft_strand(d, g, m, L, strand, cp, cc, nc, b, gdp.data(), gde.data(), pre_err, pre_end);
+    if (g.t == 0) { got = k; gb = b; }
+  }, reverse);
+  if (got != want) return 1;
+  for (uint32_t i = 0; i < want; ++i) if (gdp[i] != sdp[i] || gde[i] != sde[i]) return 2;
+  if (gb.lo != sb.min_err || gb.n_lo != sb.n_best || gb.hi != sb.second_err || gb.n_hi != sb.n_second) return 3;
+  return 0;
+}
+extern "C" int hostemu_draft_strand_check(const uint64_t *cp, const uint8_t *cc, uint32_t nc, const int16_t *pre_err, const int16_t *pre_end, uint32_t L,
+                                          int strand, int e, int lanes, const uint32_t *ref_len, uint32_t n_seq, int G, int reverse) {
+  if (G == 16) return emu_draft_strand_check<16>(cp, cc, nc, pre_err, pre_end, L, strand, e, lanes, ref_len, n_seq, reverse != 0);
+  if (G == 64) return emu_draft_strand_check<64>(cp, cc, nc, pre_err, pre_end, L, strand, e, lanes, ref_len, n_seq, reverse != 0);
+  return emu_draft_strand_check<256>(cp, cc, nc, pre_err, pre_end, L, strand, e, lanes, ref_len, n_seq, reverse != 0);
+}
+
+// cm_coop_pair_dir (both directions, merged) against two cm_pair_dir sweeps: returns 0 when the best / second-best sums, their
+// multiplicities and the first best pairing are equal
+template <int G>
+static int emu_pairing_check(const uint64_t *ap0, const int16_t *ae0, uint32_t na0, const uint64_t *bp0, const int16_t *be0, uint32_t nb0,
+                             const uint64_t *ap1, const int16_t *ae1, uint32_t na1, const uint64_t *bp1, const int16_t *be1, uint32_t nb1,
+                             uint32_t len1, uint32_t len2, int e, int max_insert, int min_read_len, bool reverse) {
+  CmDev d;
+  memset(&d, 0, sizeof(d));
+  d.p.e = e; d.p.max_insert = max_insert; d.p.min_read_len = min_read_len;
+  CmPe pe;
+  pe.min_sum = 2 * e + 1; pe.second_sum = 2 * e + 1; pe.n_best = 0; pe.n_second = 0; pe.f_dir = 0; pe.f_i1 = 0; pe.f_i2 = 0;
+  int64_t seen = 0;
+  cm_pair_dir(d, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, pe, -1, 0, &seen);
+  cm_pair_dir(d, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, pe, -1, 0, &seen);
+  CmTwo all = {0, 0, 0, 0};
+  uint64_t fk = 0;
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    const int none = 2 * e + 1;
+    CmTwo mine = {none, 0, none, 0};
+    uint64_t first_key = ~0ull;
+    cm_coop_pair_dir(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, mine, first_key);
+    cm_coop_pair_dir(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, mine, first_key);
+    const CmTwo a = cm_coop_two_merge(g, mine, none);
+    const uint64_t k = g.min64(first_key);
+    if (g.t == 0) { all = a; fk = k; }
+  }, reverse);
+  if (all.lo != pe.min_sum || all.n_lo != pe.n_best || all.hi != pe.second_sum || all.n_hi != pe.n_second) return 1;
+  if (pe.n_best > 0) {
+    if (fk == ~0ull) return 2;
+    if (((uint32_t)(fk >> 48) & 1u) != pe.f_dir || ((uint32_t)(fk >> 24) & 0xffffffu) != pe.f_i1 || ((uint32_t)fk & 0xffffffu) != pe.f_i2) return 3;
+  } else if (fk != ~0ull) return 4;
+  return 0;
+}
+extern "C" int hostemu_pairing_check(const uint64_t *ap0, const int16_t *ae0, uint32_t na0, const uint64_t *bp0, const int16_t *be0, uint32_t nb0,
+                                     const uint64_t *ap1, const int16_t *ae1, uint32_t na1, const uint64_t *bp1, const int16_t *be1, uint32_t nb1,
+                                     uint32_t len1, uint32_t len2, int e, int max_insert, int min_read_len, int G, int reverse) {
+  if (G == 16) return emu_pairing_check<16>(ap0, ae0, na0, bp0, be0, nb0, ap1, ae1, na1, bp1, be1, nb1, len1, len2, e, max_insert, min_read_len, reverse != 0);
+  if (G == 64) return emu_pairing_check<64>(ap0, ae0, na0, bp0, be0, nb0, ap1, ae1, na1, bp1, be1, nb1, len1, len2, e, max_insert, min_read_len, reverse != 0);
+  return emu_pairing_check<256>(ap0, ae0, na0, bp0, be0, nb0, ap1, ae1, na1, bp1, be1, nb1, len1, len2, e, max_insert, min_read_len, reverse != 0);
 }

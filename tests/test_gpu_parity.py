@@ -192,6 +192,8 @@ HEAVY_SETTINGS = {
     # run tables too small for most reads: the merge-sort kernels decline them (bitonic kernel over a device-side list; lane 0 for rescue hits)
     "declined": {"coop_run_table": 3},
     "declined_block": {"heavy_wave_max": 20, "coop_run_table": 3},
+    "declined_hits_only": {"coop": 1, "coop_run_table": 3},
+    "declined_rescue_only": {"coop": 2, "coop_run_table": 3},
 }
 
 

@@ -25,11 +25,17 @@ def _items(L):
 
 # (group size, list length above which a read goes to the group, hits the work area holds, minimizer table, run table)
 # + whether the emulated lanes take their turns in descending order
-GEOMETRIES = [(64, 8, 8192, 64, 130, 0), (256, 16, 8192, 64, 130, 1), (16, 8, 2048, 64, 130, 1), (64, 8, 700, 5, 11, 1)]
+GEOMETRIES = [(64, 8, 8192, 64, 130, 0), (256, 16, 8192, 64, 130, 1), (16, 8, 2048, 64, 130, 1), (64, 8, 700, 5, 11, 1),
+              (1024, 64, 8192, 64, 130, 0)]
 
 
-@pytest.mark.parametrize("geo", GEOMETRIES, ids=["G%d_P%d_MM%d" % (g[0], g[2], g[3]) for g in GEOMETRIES])
-@pytest.mark.parametrize("cfg", fuzz_data.CONFIGS[:4], ids=[str(c[0]) for c in fuzz_data.CONFIGS[:4]])
+# every fuzz configuration through wave-sized groups; the other group sizes and the decline path on one or two of them
+CASES = [(c, GEOMETRIES[0]) for c in fuzz_data.CONFIGS[:4]] + [(fuzz_data.CONFIGS[0], GEOMETRIES[1]), (fuzz_data.CONFIGS[3], GEOMETRIES[1]),
+                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[2]), (fuzz_data.CONFIGS[0], GEOMETRIES[3]),
+                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[4])]
+
+
+@pytest.mark.parametrize("cfg,geo", CASES, ids=["%d-G%d_P%d_MM%d" % (c[0], g[0], g[2], g[3]) for c, g in CASES])
 def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
     L = he.lib()
 
@@ -45,9 +51,14 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
         return rec, k, st.as_dict()
     run_case(factory, cfg, tmp_path)
     done, declined = factory.items[0], factory.items[1]
+    if cfg[0] == 3 and geo[1] >= 64:
+        return  # this configuration's seed-frequency caps leave no list that long
     assert done > 0, "no read went through the cooperative hit-list stage"
     if cfg[1] != "hic":  # split alignment never supplements from the mate
         assert factory.items[2] > 0, "no read went through the cooperative rescue stage"
+        assert factory.items[3] > 0, "no pair went through the cooperative pair filter"
+        assert factory.items[4] > 0, "no read went through the cooperative acceptance stage"
+        assert factory.items[5] > 0, "no pair went through the cooperative pairing stage"
     if geo[3] < 10:
         assert declined > 0, "the decline path was not taken"
 
@@ -93,3 +104,95 @@ def test_cooperative_sort_sweep_merge_on_adversarial_lists():
         hits = np.ascontiguousarray(hits, np.uint64)
         rc = f(c0.ctypes.data, c0c.ctypes.data, len(c0), hits.ctypes.data, len(hits), e, int(rng.integers(1, 12)), G, P, RB, it & 1)
         assert rc == 0, (it, mode, e, len(c0), len(hits), G, P, RB, rc)
+
+
+def test_cooperative_pair_filter_on_adversarial_lists():
+    """cm_coop_reduce_dir against cm_reduce_dir: lists that pair densely, sparsely or not at all, more than five unpaired
+    entries with qualifying counts (the first-five rule), counts around the running maxima, several sequences, one list
+    running out first (entries never looked at), empty lists."""
+    import numpy as np
+    L = he.lib()
+    f = L.hostemu_reduce_dir_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+    rng = np.random.default_rng(99)
+    for it in range(1500):
+        dist = int(rng.choice([0, 5, 300, 1000]))
+        mode = it % 5
+        n1 = int(rng.integers(0, 400))
+        n2 = int(rng.integers(0, 400))
+        span = {0: 3000, 1: 200000, 2: 1 << 22, 3: 40000, 4: 3000}[mode]
+        nrid = 1 if mode in (0, 3) else 4
+
+        def mk(n, shift):
+            pos = rng.integers(0, span, n) + shift
+            rid = rng.integers(0, nrid, n).astype(np.uint64)
+            k = np.unique((rid << np.uint64(32)) | pos.astype(np.uint64))
+            c = rng.integers(1, 12 if mode != 3 else 9, len(k)).astype(np.uint8)
+            return np.ascontiguousarray(k), c
+        p1, c1 = mk(n1, 0)
+        p2, c2 = mk(n2, 0 if mode != 4 else span + 2 * dist + 5)  # mode 4: list 2 entirely beyond list 1
+        if it % 7 == 0:
+            p1, c1, p2, c2 = p2, c2, p1, c1
+        G = int(rng.choice([16, 64, 256]))
+        rc = f(dist, p1.ctypes.data, c1.ctypes.data, len(p1), p2.ctypes.data, c2.ctypes.data, len(p2), G, it & 1)
+        assert rc == 0, (it, mode, dist, len(p1), len(p2), G, rc)
+
+
+def test_cooperative_acceptance_loop_on_adversarial_lists():
+    """cm_coop_draft_strand against cm_draft_strand: candidate lists sorted by count, rejected candidates at every place
+    of a verification group, invalid positions between them, count ties around the threshold, lists shorter than a group,
+    no grouping at all (lanes = 0)."""
+    import numpy as np
+    L = he.lib()
+    f = L.hostemu_draft_strand_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                  C.c_int, C.c_int]
+    rng = np.random.default_rng(5)
+    ref_len = np.array([100000, 5000], np.uint32)
+    for it in range(2500):
+        e = int(rng.choice([3, 8]))
+        lanes = int(rng.choice([0, 4, 8]))
+        nc = int(rng.integers(1, 300)) if it % 10 else int(rng.integers(1, 7))
+        rl = 50
+        cc = np.sort(rng.integers(1, int(rng.choice([3, 9])), nc).astype(np.uint8))[::-1].copy()
+        rid = rng.integers(0, 2, nc).astype(np.uint64)
+        # positions: mostly valid, some at the sequence edges (invalid)
+        pos = rng.integers(0, 6000, nc).astype(np.uint64)
+        strand = int(it & 1)
+        if strand:
+            pos += rl
+        cp = (rid << np.uint64(32)) | pos
+        p_rej = float(rng.choice([0.0, 0.1, 0.5, 0.95]))
+        ne = np.where(rng.random(nc) < p_rej, e + 1, rng.integers(0, e + 1, nc)).astype(np.int16)
+        end = rng.integers(40, 60, nc).astype(np.int16)
+        G = int(rng.choice([16, 64, 256]))
+        rc = f(cp.ctypes.data, cc.ctypes.data, nc, ne.ctypes.data, end.ctypes.data, rl, strand, e, lanes, ref_len.ctypes.data, 2, G, (it >> 1) & 1)
+        assert rc == 0, (it, e, lanes, nc, strand, G, rc)
+
+
+def test_cooperative_pairing_on_adversarial_lists():
+    """cm_coop_pair_dir against cm_pair_dir: sorted draft-mapping lists with equal positions, dense and sparse partner
+    ranges, ties of the minimal error sum across directions (the first one in sweep order counts), empty lists."""
+    import numpy as np
+    L = he.lib()
+    f = L.hostemu_pairing_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                  C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(6)
+    for it in range(1500):
+        e = int(rng.choice([3, 8]))
+        span = int(rng.choice([2000, 50000, 1 << 21]))
+
+        def mk(n):
+            pos = np.sort(((rng.integers(0, 3, n).astype(np.uint64)) << np.uint64(32)) | rng.integers(1000, 1000 + span, n).astype(np.uint64))
+            err = rng.integers(0, int(rng.choice([2, e + 1])), n).astype(np.int16)
+            return np.ascontiguousarray(pos), err
+        lists = [mk(int(rng.integers(0, 250))) for _ in range(4)]
+        G = int(rng.choice([16, 64, 256]))
+        rc = f(lists[0][0].ctypes.data, lists[0][1].ctypes.data, len(lists[0][0]), lists[1][0].ctypes.data, lists[1][1].ctypes.data, len(lists[1][0]),
+               lists[2][0].ctypes.data, lists[2][1].ctypes.data, len(lists[2][0]), lists[3][0].ctypes.data, lists[3][1].ctypes.data, len(lists[3][0]),
+               int(rng.integers(30, 51)), int(rng.integers(30, 51)), e, int(rng.choice([300, 1000, 2000])), 30, G, it & 1)
+        assert rc == 0, (it, e, span, [len(x[0]) for x in lists], G, rc)
