@@ -56,7 +56,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000):
+def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000, pairs=None):
     """the reference binary itself (oracle/_ref/chromap, built unchanged from the reference sources; it
     travels with the repo) on the host cores: tools/ref_baseline.py writes the same GRCh38-sized
     synthetic index / genome in the reference's file formats and two bench batches as FASTQ, runs
@@ -65,10 +65,10 @@ def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000):
     if not os.path.exists(ref_bin):
         return None
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_baseline.py"), "--genome", str(args.genome), "--nseq",
-           str(args.nseq), "--pairs", str(args.pairs), "--batches", "2", "--readlen", str(args.readlen), "--preset", args.preset,
+           str(args.nseq), "--pairs", str(pairs or args.pairs), "--batches", "2", "--readlen", str(args.readlen), "--preset", args.preset,
            "--seed0", str(seed0), "--indel-rate", str(args.indel_rate)]
     if repeats:
-        cmd += ["--repeats", ",".join(str(x) for x in repeats)]
+        cmd += ["--repeats", repeats if isinstance(repeats, str) else ",".join(str(x) for x in repeats)]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     try:
         r = json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -262,6 +262,8 @@ def roofline(g, args, s, steps, stage_ms):
     shape = {"lookups_per_lane": g.get_option("probe_lookups_per_lane"), "pair_prefetch": g.get_option("probe_pair_prefetch")}
     roof = {"kernel": "k_probe", "kernel_shape": shape, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "from_profile: profiles/probe_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, "
+                              "tools/profile_bench.sh), not measured in this run",
             "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
             "probe_variants": variants, "random_gather_sweep": sweep, "random_gather_ceiling": best}
     if best and probe_only:
@@ -289,6 +291,10 @@ def main():
     ap.add_argument("--indel-rate", type=float, default=0.0, help="1-base indels per base in the synthetic reads (SURVEY 8(d): 0.001 for config 5)")
     ap.add_argument("--repeats", default="32,600,3000,0.02",
                     help="planted repeat families of the second, repeat-bearing workload: families,copies,element_len,divergence ('' = skip it)")
+    ap.add_argument("--harsh", default="profile:1",
+                    help="the third workload's genome: profile:1 = 22.5 %% of the bases repeat-derived -- SINE-like families of ~10^4 copies at "
+                         "5-15 %% divergence, LINE-like families of ~360 copies at 1-5 %%, satellite arrays ('' = skip it)")
+    ap.add_argument("--harsh-ref-pairs", type=int, default=500_000, help="pairs per batch of the reference-binary check on the third workload (two batches)")
     ap.add_argument("--headline-repeats", default="", help="plant repeats in the headline workload's genome too (not the default)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="timed region and roofline only")
@@ -337,6 +343,8 @@ def main():
     def parse_rep(txt):
         if not txt:
             return None
+        if txt.startswith("profile:"):
+            return txt
         f = txt.split(",")
         return (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
 
@@ -391,7 +399,7 @@ def main():
     g.swap_resident(0)
     roof = roofline(g, args, s, steps, stage_ms)
     g.set_option("lanes", args.lanes)
-    post = pcie = cpu = rep_out = None
+    post = pcie = cpu = rep_out = harsh_out = None
     if not args.skip_extras:
         # device-side post-processing, outside the timed region: the records of the four resident
         # batches go to the record store; one call sorts, de-duplicates, filters and renders the BED text in HBM
@@ -454,28 +462,40 @@ def main():
                 cpu = {"value": None, "unit": "M pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         # ---- the same measurement on a genome with planted repeat families: frequent seeds,
         #      multi-mappers and mate rescue as on a real genome; reported beside the headline
-        rep = parse_rep(args.repeats)
-        if world == 1 and rep and not args.sam:
+        def side_workload(rep, seed0, what, ref_pairs=None):
+            """the headline measurement on another genome (timed the same way), with the reference-binary BED check"""
+            nonlocal g
             try:
                 if g is not None:
                     g.close()
                 g = None
                 gr = make_ctx(rep)
-                rdt, rstage, rst, rmapped = timed_run(gr, args, 0, 1, None, 3000, False)
+                rdt, rstage, rst, rmapped = timed_run(gr, args, 0, 1, None, seed0, False)
                 rs = rst.as_dict()
-                rep_out = {"value": round(args.pairs * args.steps / rdt / 1e6, 4), "unit": "M pairs/s", "ms_per_step": round(rdt / steps * 1e3, 3),
-                           "workload": "the headline workload on a genome with %d planted repeat families x %d copies of %d bases at %.1f %% "
-                                       "divergence (%.1f %% of the genome)" % (rep[0], rep[1], rep[2], rep[3] * 100,
-                                                                               100.0 * rep[0] * rep[1] * rep[2] / args.genome),
-                           "counters_per_step": {k: v // steps for k, v in rs.items()},
-                           "candidates_per_read": round(rs["num_candidates"] / (2.0 * args.pairs * args.steps), 3),
-                           "stage_ms_per_step": {k: round(v / steps, 3) for k, v in rstage.items()},
-                           "mapped_pairs_per_step": rmapped // steps}
+                o = {"value": round(args.pairs * args.steps / rdt / 1e6, 4), "unit": "M pairs/s", "ms_per_step": round(rdt / steps * 1e3, 3),
+                     "workload": what, "lanes": args.lanes,
+                     "counters_per_step": {k: v // steps for k, v in rs.items()},
+                     "candidates_per_read": round(rs["num_candidates"] / (2.0 * args.pairs * args.steps), 3),
+                     "stage_ms_per_step": {k: round(v / steps, 3) for k, v in rstage.items()},
+                     "mapped_pairs_per_step": rmapped // steps}
                 gr.close()
                 if not args.skip_cpu and args.cpu_baseline in ("auto", "reference"):
-                    rep_out["cpu_baseline"] = cpu_baseline_reference(args, rep, " (repeats)", seed0=3000)
+                    o["cpu_baseline"] = cpu_baseline_reference(args, rep, " (%s)" % what[:24], seed0=seed0, pairs=ref_pairs)
+                return o
             except Exception as e:
-                rep_out = {"error": repr(e)}
+                return {"error": repr(e)}
+
+        rep = parse_rep(args.repeats)
+        if world == 1 and rep and not args.sam:
+            rep_out = side_workload(rep, 3000, "the headline workload on a genome with %d planted repeat families x %d copies of %d bases at %.1f %% "
+                                               "divergence (%.1f %% of the genome)" % (rep[0], rep[1], rep[2], rep[3] * 100,
+                                                                                       100.0 * rep[0] * rep[1] * rep[2] / args.genome))
+        harsh = parse_rep(args.harsh)
+        if world == 1 and harsh and not args.sam:
+            harsh_out = side_workload(harsh, 5000, "the headline workload on a genome with a mammalian-like repeat landscape (%s): 22.5 %% of the bases "
+                                                   "repeat-derived -- SINE-like 300-base elements in 128 families of ~10^4 copies at 5-15 %% divergence, "
+                                                   "LINE-like 3-kb elements in 256 families of ~360 copies at 1-5 %%, satellite arrays of 171-base "
+                                                   "units" % harsh, ref_pairs=args.harsh_ref_pairs)
     out = {
         "metric": "M paired reads mapped/s (ATAC preset, GRCh38 index)",
         "value": round(value, 4), "unit": "M pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -483,14 +503,14 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "--preset %s, synthetic 2x%d bp pairs (fragments %d-%d bp, 1%% substitutions%s), "
                                "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7%s) resident per GPU, "
-                               "%d pairs per GPU per step, %d distinct batches per GPU resident in HBM taking turns"
+                               "%d pairs per GPU per step, %d distinct batches per GPU resident in HBM taking turns (%.0f M distinct pairs per GPU)"
                                % (args.preset, args.readlen, args.frag_min, args.frag_max,
                                   ", %.2f%% 1-base indels" % (args.indel_rate * 100) if args.indel_rate else "", args.genome, args.nseq,
-                                  ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS),
+                                  ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS, args.pairs * N_SLOTS / 1e6),
                    "pairs_per_gpu_per_step": args.pairs, "lanes": 1 if exchange else args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
-        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
+        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
         "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
         "stage_ms_note": "HIP events of the calling thread's lane (1 / %d of the batch when lanes > 1; the lanes overlap)" % args.lanes,
         "counters_per_step": {k: v // steps for k, v in s.items()},

@@ -860,7 +860,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s4c_pair_filter");
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
   // candidate, (c) the sequential acceptance loop per read
-  cm_launch_k_s5a_prepare(d, n2, s);
+  cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   unsigned long long v_total = 0;
   if ((rc = scan_with_total(c, d.nv, d.v_off, n2, &v_total))) return rc;
   if (v_total > 0xfffffff0ull) return CM_RC_SPLIT;  // never above m_total; kept for symmetry

@@ -460,15 +460,18 @@ CM_HD uint32_t cm_coop_array_scan_max(GT &g, uint8_t *a, uint32_t n) {
 // Outputs in list order.  Work arrays (shared): lo1, of1, of2 (u16), k1, k2, x1, x2 (u8), n1 / n2 entries.
 // ---------------------------------------------------------------------------------------
 struct CmCoopPairMem {
+  uint64_t *s1, *s2;          // P each: the two position lists, staged (their binary searches are chains of dependent loads)
   uint16_t *lo1, *of1, *of2;  // P each
   uint8_t *k1, *k2, *x1, *x2; // P each
   uint32_t P;
 };
-CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P) { return (size_t)P * 10 + 32; }
+CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P) { return (size_t)P * 26 + 32; }
 CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P) {
   CmCoopPairMem m;
   m.P = P;
-  m.lo1 = reinterpret_cast<uint16_t *>(base);
+  m.s1 = reinterpret_cast<uint64_t *>(base);
+  m.s2 = m.s1 + P;
+  m.lo1 = reinterpret_cast<uint16_t *>(m.s2 + P);
   m.of1 = m.lo1 + P;
   m.of2 = m.of1 + P;
   m.k1 = reinterpret_cast<uint8_t *>(m.of2 + P);
@@ -478,9 +481,13 @@ CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P) {
   return m;
 }
 template <class GT>
-CM_HD void cm_coop_reduce_dir(GT &g, const CmCoopPairMem &m, uint32_t dist, const uint64_t *p1, const uint8_t *c1, uint32_t n1, const uint64_t *p2,
+CM_HD void cm_coop_reduce_dir(GT &g, const CmCoopPairMem &m, uint32_t dist, const uint64_t *gp1, const uint8_t *c1, uint32_t n1, const uint64_t *gp2,
                               const uint8_t *c2, uint32_t n2, uint64_t *f1, uint8_t *fc1, uint32_t *nf1, uint64_t *f2, uint8_t *fc2, uint32_t *nf2) {
   const uint32_t G = (uint32_t)GT::G;
+  for (uint32_t i = g.t; i < n1; i += G) m.s1[i] = gp1[i];
+  for (uint32_t j = g.t; j < n2; j += G) m.s2[j] = gp2[j];
+  g.sync();
+  const uint64_t *p1 = m.s1, *p2 = m.s2;
   // ---- list 1: lo, paired; x1 = count of a paired entry (for max1), else 0
   uint32_t my_end = n1;
   for (uint32_t i = g.t; i < n1; i += G) {
@@ -718,12 +725,18 @@ CM_HD uint32_t cm_coop_draft_strand(const CmDev &d, GT &g, const CmCoopVerMem &m
   g.sync();
   return nd;
 }
+// r: a read cm_s5a_prepare left to the group (nv[r] == 0, candidate lists sorted).  S5b is part of it: a lane per candidate runs
+// the banded alignment (cm_s5b_verify_at), no work-item search, the read's own quantities loaded once per lane.
 template <class GT>
 CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m) {
-  if (d.nv[r] == 0) return;
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
+  {
+    const uint32_t ncp = d.fcp[r], nc = ncp + d.fcn[r];
+    for (uint32_t li = g.t; li < nc; li += (uint32_t)GT::G) cm_s5b_verify_at(d, r, li < ncp ? 0 : 1, li < ncp ? li : li - ncp);
+    g.sync();
+  }
   if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: one lane
-    if (g.t == 0) cm_s5c_finalize(d, r);
+    if (g.t == 0) cm_s5c_accept(d, r);
     return;
   }
   CmTwo best = {d.min_err[r], d.n_best[r], d.second_err[r], d.n_second[r]};

@@ -877,32 +877,39 @@ __device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair,
     cm_wave_append(d.srt_list, &d.srt_cnt[0], cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX, (r << 1) | (q & 1u));
   }
 }
+#define CM_S4C_P_WAVE 1024u   // entries of a candidate list the work arrays of a wave hold
+#define CM_S4C_P_BLOCK 4096u  // ... of a block
 __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, uint32_t coop) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
-  bool to_group = false;
+  uint32_t cls = 0;
   if (i < n && cm_s4c_pre(d, pair)) {
     const uint32_t r1 = 2 * pair, r2 = r1 + 1;
     uint32_t big = d.mcp[r1] > d.mcn[r1] ? d.mcp[r1] : d.mcn[r1];
     big = d.mcp[r2] > big ? d.mcp[r2] : big;
     big = d.mcn[r2] > big ? d.mcn[r2] : big;
-    to_group = coop && big > CM_S4C_COOP_MIN;
-    if (!to_group) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
+    if (coop && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : 0u;
+    if (!cls) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
   }
-  if (coop) cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, to_group, pair);
+  if (coop) {
+    cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, cls == 9u, pair);
+    cm_wave_append(d.hv_list + 14 * (size_t)d.hv_stride, d.hv_cnt + 14, cls == 14u, pair);
+  }
   if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
-  cm_s4c_queue_sort(d, pair, i < n && !to_group && d.alive[pair]);
+  cm_s4c_queue_sort(d, pair, i < n && !cls && d.alive[pair]);
 }
-// the pairs of list 9: the filter's two directions by a wave each (cm_coop_s4c); the list's length is on the device
-__global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P) {
-  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
-  const uint32_t n_list = d.hv_cnt[9];
-  const uint32_t *list = d.hv_list + 9 * (size_t)d.hv_stride;
-  const size_t gb = ((cm_coop_pair_mem_bytes(P) + 15) & ~(size_t)15);
-  const CmCoopPairMem m = cm_coop_pair_mem_at(cm_lds + (size_t)grp * gb, P);
-  CmDevGroup<64> g;
-  g.t = threadIdx.x % 64;
-  g.xw = nullptr;
+// the pairs of list 9 / 14: the filter's two directions by a wave / a block each (cm_coop_s4c); the list's length is on the device
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint32_t lid) {
+  const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
+  const uint32_t n_list = d.hv_cnt[lid];
+  const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
+  const size_t gb = ((cm_coop_pair_mem_bytes(P) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  uint8_t *base = cm_lds + (size_t)grp * gb;
+  const CmCoopPairMem m = cm_coop_pair_mem_at(base, P);
+  CmDevGroup<G> g;
+  g.t = threadIdx.x % G;
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t j0 = blockIdx.x * gpb; j0 < n_list; j0 += gridDim.x * gpb) {
     const uint32_t j = j0 + grp;
     const uint32_t pair = j < n_list ? list[j] : 0u;
@@ -918,18 +925,21 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P) {
     }
   }
 }
-CM_ITEM_KERNEL(k_s5a_prepare, cm_s5a_prepare, perm_reads)
-// S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order).
-// coop: a read with more than CM_S5C_COOP_MIN candidates goes to list 12, where a wave runs its acceptance loop (k_s5c_coop).
+// S5a.  coop: a read with more than CM_S5C_COOP_MIN candidates is left to a wave -- alignments and acceptance loop (k_s5c_coop, list 12)
 #define CM_S5C_COOP_MIN 48u
-__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, uint32_t coop) {
+__global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, uint32_t coop) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
-  const bool to_wave = i < n && coop && d.nv[r] > CM_S5C_COOP_MIN;
-  if (i < n && !to_wave) cm_s5c_finalize(d, r);
+  const bool to_wave = i < n && cm_s5a_prepare(d, r, coop ? CM_S5C_COOP_MIN : 0u);
   if (coop) cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave, r);
+}
+// S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
+__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) {
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
+  if (i < n) cm_s5c_finalize(d, r);
   if (!d.perm_reads || d.p.split || d.p.single) return;  // the queue is only served in a batch with heavy reads
-  const bool live = i < n && !to_wave && d.alive[r >> 1];
+  const bool live = i < n && d.nv[r] != 0 && d.alive[r >> 1];
   const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
   cm_wave_append(d.srt_list, &d.srt_cnt[0], a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX, r << 1);
   cm_wave_append(d.srt_list, &d.srt_cnt[0], b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX, (r << 1) | 1u);
@@ -1588,18 +1598,22 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
 }
 void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
-  const uint32_t P = 2048;  // entries of a candidate list the wave's work arrays hold (longer lists: its lane 0)
-  const size_t gb = ((cm_coop_pair_mem_bytes(P) + 15) & ~(size_t)15);
+  const size_t gw = ((cm_coop_pair_mem_bytes(CM_S4C_P_WAVE) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  const size_t gbk = ((cm_coop_pair_mem_bytes(CM_S4C_P_BLOCK) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  coop = coop && cm_lds_optin(&k_s4c_coop<CM_BLOCK>, gbk);
   hipLaunchKernelGGL(k_s4c_reduce, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (!coop) return;
-  uint32_t blocks = n / 4096 + 64;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s4c_coop, dim3(blocks), dim3(128), 2 * gb, s, d, P);
+  uint32_t blocks = n / 2048 + 64;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_s4c_coop<64>, dim3(blocks), dim3(128), 2 * gw, s, d, CM_S4C_P_WAVE, 9u);
+  hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u);
 }
-CM_LAUNCH(k_s5a_prepare)
+void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+  if (n) hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+}
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
-  hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);
   if (!coop) return;
   const uint32_t P = 2048;  // candidates of a strand the wave's work arrays hold (longer lists: its lane 0)
   const size_t gb = ((cm_coop_ver_mem_bytes(P) + 15) & ~(size_t)15);

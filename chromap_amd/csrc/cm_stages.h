@@ -2056,10 +2056,12 @@ CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
 // break, best/second-best bookkeeping) over the precomputed (errors, end) results.  Candidates
 // beyond the loop's break point are aligned needlessly but never looked at.
 // ---------------------------------------------------------------------------------------
-CM_HD void cm_s5a_prepare(const CmDev &d, uint32_t r) {
+// coop_min > 0: a read with more candidates than that is left to a group of lanes, verification included (cm_coop_s5c, cm_coop.h):
+// nv stays 0 and the function returns true
+CM_HD bool cm_s5a_prepare(const CmDev &d, uint32_t r, uint32_t coop_min = 0) {
   const uint32_t pair = r >> 1;
   d.nv[r] = 0;
-  if (d.p.split || !d.alive[pair]) { cm_s5_verify(d, r); return; }  // split alignment keeps the in-place path
+  if (d.p.split || !d.alive[pair]) { cm_s5_verify(d, r); return false; }  // split alignment keeps the in-place path
   d.ndp[r] = 0; d.ndn[r] = 0;
   const int e = d.p.e;
   CmBest bst = {e + 1, e + 1, 0, 0};
@@ -2083,15 +2085,19 @@ CM_HD void cm_s5a_prepare(const CmDev &d, uint32_t r) {
       }
     }
   }
+  bool to_group = false;
   if (!done) {
     cm_sort_cand(pp, pc, ncp);
     cm_sort_cand(np, nc, ncn);
-    d.nv[r] = ncp + ncn;
+    to_group = coop_min > 0 && ncp + ncn > coop_min;
+    if (!to_group) d.nv[r] = ncp + ncn;
   }
   d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
   d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
+  return to_group;
 }
 
+CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci);
 // work item j -> (read, strand, candidate): binary search in the exclusive prefix v_off
 CM_HD void cm_s5b_verify_item(const CmDev &d, uint32_t j, uint32_t n_reads) {
   uint32_t lo = 0, hi = n_reads;  // largest r with v_off[r] <= j
@@ -2103,6 +2109,10 @@ CM_HD void cm_s5b_verify_item(const CmDev &d, uint32_t j, uint32_t n_reads) {
   const uint32_t ncp = d.fcp[r];
   const int strand = li < ncp ? 0 : 1;
   const uint32_t ci = strand ? li - ncp : li;
+  cm_s5b_verify_at(d, r, strand, ci);
+}
+// candidate ci of read r's strand list: the banded alignment, result to v_err / v_end
+CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci) {
   const uint32_t o = d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0) + ci;
   const uint64_t cpos = d.fbuf[o];
   const uint32_t L = d.rlen[r];
@@ -2115,8 +2125,12 @@ CM_HD void cm_s5b_verify_item(const CmDev &d, uint32_t j, uint32_t n_reads) {
   d.v_end[o] = (int16_t)end_pos;
 }
 
+CM_HD void cm_s5c_accept(const CmDev &d, uint32_t r);
 CM_HD void cm_s5c_finalize(const CmDev &d, uint32_t r) {
   if (d.nv[r] == 0) return;
+  cm_s5c_accept(d, r);
+}
+CM_HD void cm_s5c_accept(const CmDev &d, uint32_t r) {
   CmBest bst = {d.min_err[r], d.second_err[r], d.n_best[r], d.n_second[r]};
   const uint32_t L = d.rlen[r];
   const uint8_t *read = cm_read_ptr(d, r);

@@ -54,8 +54,59 @@ CM_HD uint8_t sy_base(uint64_t seed, uint64_t g) {
 struct SyRepeats {
   uint32_t n_families, copies, element_len, div_thresh;  // div_thresh = divergence * 2^32
   uint64_t slot;                                         // slot size in bases (0 = no repeats)
+  uint32_t profile;                                      // 1: the mosaic below instead
 };
+// one base of a planted element copy: family `fam` of the element kind `salt`, position `within` of `len`, orientation, and
+// a per-base replacement with probability div_thresh / 2^32 (hc: the copy's hash)
+CM_HD uint8_t sy_copy_base(uint64_t seed, uint64_t salt, uint32_t fam, uint32_t within, uint32_t len, bool rev, uint32_t div_thresh, uint64_t hc) {
+  const uint32_t at = rev ? len - 1 - within : within;
+  uint8_t b = sy_base(seed ^ salt ^ ((uint64_t)(fam + 1) << 40), at);
+  if (rev) b = cm_negchar(b);
+  const uint64_t hm = sy_mix(hc ^ ((uint64_t)within * 0x9E3779B97F4A7C15ull));
+  if ((uint32_t)hm < div_thresh) b = (uint8_t)("ACGT"[(hm >> 32) & 3]);
+  return b;
+}
+// Profile 1, a repeat landscape of the kind a mammalian genome has (what the verdict of round 2 asked the benchmark to face:
+// >= 20 % of the bases in families of 10 .. 10^4 copies at 1 .. 15 % divergence, plus satellite runs).  The genome is tiled
+// in 64-kb tiles; a tile's hash makes it
+//   SINE-like   (20 % of the tiles): 300-base elements, one per 512-base cell at a random offset, 128 families -- on 3.1 Gb
+//               about 9 500 copies per family -- every copy with its own divergence between 5 and 15 %;
+//   LINE-like   (12 %): 3 000-base elements, one per 4 096-base cell, 256 families (~360 copies each), divergence 1 .. 5 %;
+//   satellite   (2 %): the whole tile a tandem array of one of 64 units of 171 bases, 2 % of its bases replaced;
+//   unique      (66 %).
+// 11.7 % + 8.8 % + 2 % = 22.5 % of the bases are repeat-derived.  O(1) per position, no tables.
+#define SY_TILE 65536ull
+CM_HD uint8_t sy_mosaic_base(uint64_t seed, uint64_t g) {
+  const uint64_t tile = g / SY_TILE, in_tile = g % SY_TILE;
+  const uint64_t th = sy_mix(seed ^ 0x7113D00DCAFEull ^ (tile * 0xA0761D6478BD642Full));
+  const uint32_t kind = (uint32_t)(th % 100);
+  if (kind < 20 || kind < 32) {
+    const bool sine = kind < 20;
+    const uint32_t cell_len = sine ? 512u : 4096u, elem = sine ? 300u : 3000u, n_fam = sine ? 128u : 256u;
+    const uint64_t cell = tile * (SY_TILE / cell_len) + in_tile / cell_len;
+    const uint64_t hc = sy_mix(seed ^ (sine ? 0x51AEull : 0x11AEull) ^ (cell * 0xC2B2AE3D27D4EB4Full));
+    const uint32_t start = (uint32_t)(hc % (cell_len - elem)), at = (uint32_t)(in_tile % cell_len);
+    if (at >= start && at < start + elem) {
+      const uint32_t fam = (uint32_t)((hc >> 20) % n_fam);
+      const bool rev = ((hc >> 40) & 1) != 0;
+      // divergence of this copy: 5 .. 15 % (SINE-like) or 1 .. 5 %
+      const uint64_t f = (hc >> 44) & 1023u;
+      const uint32_t div = sine ? (uint32_t)(214748365ull + f * 419430ull) : (uint32_t)(42949673ull + f * 167772ull);
+      return sy_copy_base(seed, sine ? 0x5EED51AEull : 0x5EED11AEull, fam, at - start, elem, rev, div, hc);
+    }
+    return sy_base(seed, g);
+  }
+  if (kind < 34) {
+    const uint32_t fam = (uint32_t)((th >> 8) % 64);
+    uint8_t b = sy_base(seed ^ 0x5A7E111EEull ^ ((uint64_t)(fam + 1) << 40), in_tile % 171u);
+    const uint64_t hm = sy_mix(th ^ (in_tile * 0x9E3779B97F4A7C15ull));
+    if ((uint32_t)hm < 85899346u) b = (uint8_t)("ACGT"[(hm >> 32) & 3]);  // 2 %
+    return b;
+  }
+  return sy_base(seed, g);
+}
 CM_HD uint8_t sy_genome_base(uint64_t seed, uint64_t g, const SyRepeats &rp) {
+  if (rp.profile == 1) return sy_mosaic_base(seed, g);
   if (rp.slot) {
     const uint64_t ci = g / rp.slot;
     if (ci < (uint64_t)rp.n_families * rp.copies) {
@@ -254,12 +305,20 @@ extern "C" int cmgpu_create_synthetic(uint64_t total_bases, uint32_t n_sequences
   return cmgpu_create_synthetic_repeats(total_bases, n_sequences, seed, kmer_size, window_size, params, device_id, 0, 0, 0, 0.0, out);
 }
 
+extern "C" int cmgpu_create_synthetic_profile(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size, int32_t window_size,
+                                              const cmgpu_params *params, int device_id, uint32_t profile, cmgpu_ctx **out) {
+  return cmgpu_create_synthetic_repeats(total_bases, n_sequences, seed, kmer_size, window_size, params, device_id, 0xffffffffu, profile, 0, 0.0, out);
+}
+
 extern "C" int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
                                               int32_t window_size, const cmgpu_params *params, int device_id, uint32_t n_families,
                                               uint32_t copies, uint32_t element_len, double divergence, cmgpu_ctx **out) {
   if (!params || !out || n_sequences == 0 || total_bases < n_sequences * 1000ull) { cm_set_error(nullptr, "bad argument"); return CMGPU_EINVAL; }
-  SyRepeats rp = {0, 0, 0, 0, 0};
-  if (n_families && copies && element_len) {
+  SyRepeats rp = {0, 0, 0, 0, 0, 0};
+  if (n_families == 0xffffffffu) {  // cmgpu_create_synthetic_profile
+    rp.profile = copies;
+    if (rp.profile != 1) { cm_set_error(nullptr, "unknown synthetic genome profile"); return CMGPU_EINVAL; }
+  } else if (n_families && copies && element_len) {
     rp.n_families = n_families; rp.copies = copies; rp.element_len = element_len;
     rp.div_thresh = (uint32_t)(divergence * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (divergence < 0 ? 0 : divergence * 4294967296.0));
     rp.slot = total_bases / ((uint64_t)n_families * copies);

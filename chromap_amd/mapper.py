@@ -91,9 +91,14 @@ class ChromapGPU:
             self._inherit = (shared_from.rank, shared_from.pairs_rank)
         elif synthetic is not None:
             total, nseq, seed = synthetic[:3]
-            fam, copies, elen, div = synthetic[3] if len(synthetic) > 3 and synthetic[3] else (0, 0, 0, 0.0)
-            rc = self.L.cmgpu_create_synthetic_repeats(total, nseq, seed, 17, 7, C.byref(self.params), device, fam, copies, elen,
-                                                       float(div), C.byref(self.ctx))
+            rep = synthetic[3] if len(synthetic) > 3 and synthetic[3] else (0, 0, 0, 0.0)
+            if isinstance(rep, str):  # "profile:1" -- a whole repeat landscape (cmgpu_create_synthetic_profile)
+                rc = self.L.cmgpu_create_synthetic_profile(total, nseq, seed, 17, 7, C.byref(self.params), device, int(rep.split(":")[1]),
+                                                           C.byref(self.ctx))
+            else:
+                fam, copies, elen, div = rep
+                rc = self.L.cmgpu_create_synthetic_repeats(total, nseq, seed, 17, 7, C.byref(self.params), device, fam, copies, elen,
+                                                           float(div), C.byref(self.ctx))
             self._check(rc, None)
             self.names = [b"chr%d" % (i + 1) for i in range(nseq)]
         elif index_path is None:

@@ -187,6 +187,14 @@ int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_sequences, u
                                    int32_t window_size, const cmgpu_params *params, int device_id, uint32_t n_families,
                                    uint32_t copies, uint32_t element_len, double divergence, cmgpu_ctx **out);
 
+/* The same with a whole repeat landscape instead of one family class.  profile 1: 64-kb tiles, 20 % of them packed with
+ * SINE-like 300-base elements (128 families, ~10^4 copies each on 3.1 Gb, 5-15 % divergence per copy), 12 % with LINE-like
+ * 3-kb elements (256 families, ~360 copies each, 1-5 %), 2 % satellite arrays (171-base units, 2 % replaced): 22.5 % of the
+ * bases are repeat-derived (bench.py's third workload). */
+int cmgpu_create_synthetic_profile(uint64_t total_bases, uint32_t n_sequences, uint64_t seed, int32_t kmer_size,
+                                   int32_t window_size, const cmgpu_params *params, int device_id, uint32_t profile,
+                                   cmgpu_ctx **out);
+
 /* Replaces: Index::Construct (src/index.cc:12-89) -- builds the minimizer index of `ref` on
  * the device (chunked minimizer pass, radix sort by (hash, hit), khash-sized open-addressing
  * table) and keeps it resident together with the reference; the ctx maps like one made by

@@ -301,19 +301,16 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     }
   }
   VEC(nv, uint32_t, n2) VEC(v_off, uint32_t, n2 + 1) VEC(v_err, int16_t, n_m) VEC(v_end, int16_t, n_m)
-  for (uint32_t r = 0; r < n2; ++r) cm_s5a_prepare(d, r);
+  std::vector<uint32_t> s5_heavy;  // reads whose verification and acceptance a group of lanes runs (k_s5c_coop)
+  for (uint32_t r = 0; r < n2; ++r)
+    if (cm_s5a_prepare(d, r, g_coop.G && !d.p.split ? g_coop.thr : 0u)) s5_heavy.push_back(r);
   scan(d.nv, d.v_off, n2);
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
-  {
-    std::vector<uint32_t> heavy;
-    for (uint32_t r = 0; r < n2; ++r) {
-      if (g_coop.G && !d.p.split && d.nv[r] > g_coop.thr) heavy.push_back(r); else cm_s5c_finalize(d, r);
-    }
-    if (!heavy.empty()) {  // k_s5c_coop
-      g_coop_items[4] += heavy.size();
-      if (g_coop.G == 16) emu_coop_s5c<16>(d, heavy); else if (g_coop.G == 64) emu_coop_s5c<64>(d, heavy);
-      else if (g_coop.G == 256) emu_coop_s5c<256>(d, heavy); else emu_coop_s5c<1024>(d, heavy);
-    }
+  for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r);
+  if (!s5_heavy.empty()) {
+    g_coop_items[4] += s5_heavy.size();
+    if (g_coop.G == 16) emu_coop_s5c<16>(d, s5_heavy); else if (g_coop.G == 64) emu_coop_s5c<64>(d, s5_heavy);
+    else if (g_coop.G == 256) emu_coop_s5c<256>(d, s5_heavy); else emu_coop_s5c<1024>(d, s5_heavy);
   }
   // --SAM buffers (cmgpu_map_resident allocates the same per batch)
   std::vector<uint32_t> samz;

@@ -38,7 +38,9 @@ def main():
     ap.add_argument("--seed0", type=int, default=1000)
     args = ap.parse_args()
     rep = None
-    if args.repeats:
+    if args.repeats.startswith("profile:"):
+        rep = args.repeats
+    elif args.repeats:
         f = args.repeats.split(",")
         rep = (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "chromap")
