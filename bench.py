@@ -69,6 +69,8 @@ def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000, pairs=None):
            "--seed0", str(seed0), "--indel-rate", str(args.indel_rate)]
     if repeats:
         cmd += ["--repeats", repeats if isinstance(repeats, str) else ",".join(str(x) for x in repeats)]
+    if args.hic >= 0:
+        cmd += ["--hic", str(args.hic)]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     try:
         r = json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -179,7 +181,7 @@ def cpu_baseline_port(g, args):
 
 def gen(g, args, seed):
     g.generate_resident(args.pairs, read_length=args.readlen, frag_min=args.frag_min, frag_max=args.frag_max, sub_rate=0.01, seed=seed,
-                        indel_rate=args.indel_rate)
+                        indel_rate=args.indel_rate, hic=args.hic if args.hic >= 0 else None)
 
 
 def timed_run(g, args, rank, world, dist, seed0, exchange):
@@ -291,6 +293,10 @@ def main():
     ap.add_argument("--indel-rate", type=float, default=0.0, help="1-base indels per base in the synthetic reads (SURVEY 8(d): 0.001 for config 5)")
     ap.add_argument("--repeats", default="32,600,3000,0.02",
                     help="planted repeat families of the second, repeat-bearing workload: families,copies,element_len,divergence ('' = skip it)")
+    ap.add_argument("--hic", type=float, default=-1.0, help="Hi-C shaped pairs (mates from independent loci) with this fraction of reads chimeric "
+                                                             "across a ligation junction; default: fragments")
+    ap.add_argument("--hic-workload", default="150,0.001,0.35,2000000",
+                    help="the fourth workload, BASELINE config 5: --preset hic, read length, indel rate, chimeric fraction, pairs per step ('' = skip it)")
     ap.add_argument("--harsh", default="profile:1",
                     help="the third workload's genome: profile:1 = 22.5 %% of the bases repeat-derived -- SINE-like families of ~10^4 copies at "
                          "5-15 %% divergence, LINE-like families of ~360 copies at 1-5 %%, satellite arrays ('' = skip it)")
@@ -348,8 +354,8 @@ def main():
         f = txt.split(",")
         return (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
 
-    def make_ctx(rep):
-        g_ = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=args.preset, device=local_rank,
+    def make_ctx(rep, preset=None):
+        g_ = ChromapGPU(synthetic=(args.genome, args.nseq, 12345, rep), preset=preset or args.preset, device=local_rank,
                         **({"output_format": 1} if args.sam else {}))
         # lanes and the record exchange do not mix well on one GPU (measured: 3 lanes 429 -> 366 M pairs/s with the exchange,
         # 1 lane 404 -> 388): ranks that exchange map their batch in one piece
@@ -399,7 +405,7 @@ def main():
     g.swap_resident(0)
     roof = roofline(g, args, s, steps, stage_ms)
     g.set_option("lanes", args.lanes)
-    post = pcie = cpu = rep_out = harsh_out = None
+    post = pcie = cpu = rep_out = harsh_out = hic_out = None
     if not args.skip_extras:
         # device-side post-processing, outside the timed region: the records of the four resident
         # batches go to the record store; one call sorts, de-duplicates, filters and renders the BED text in HBM
@@ -496,6 +502,30 @@ def main():
                                                    "repeat-derived -- SINE-like 300-base elements in 128 families of ~10^4 copies at 5-15 %% divergence, "
                                                    "LINE-like 3-kb elements in 256 families of ~360 copies at 1-5 %%, satellite arrays of 171-base "
                                                    "units" % harsh, ref_pairs=args.harsh_ref_pairs)
+        if world == 1 and args.hic_workload and not args.sam and args.hic < 0:
+            # BASELINE config 5: --preset hic, 2 x 150 with 0.1 % indels, Hi-C shaped pairs with chimeric reads (split alignment)
+            try:
+                import copy
+                f = args.hic_workload.split(",")
+                ha = copy.copy(args)
+                ha.readlen, ha.indel_rate, ha.hic, ha.pairs, ha.preset = int(f[0]), float(f[1]), float(f[2]), int(f[3]), "hic"
+                if g is not None:
+                    g.close()
+                g = None
+                gh = make_ctx(None, "hic")
+                hdt, hstage, hst, hmapped = timed_run(gh, ha, 0, 1, None, 7000, False)
+                hs = hst.as_dict()
+                hic_out = {"value": round(ha.pairs * ha.steps / hdt / 1e6, 4), "unit": "M pairs/s", "ms_per_step": round(hdt / steps * 1e3, 3),
+                           "workload": "--preset hic, synthetic 2x%d bp Hi-C shaped pairs (mates from independent loci, 60 %% within 1 Mb; %.0f %% of the "
+                                       "pairs with a ligation junction inside a read; 1 %% substitutions, %.2f %% 1-base indels), the headline's "
+                                       "GRCh38-sized index, %d pairs per step" % (ha.readlen, ha.hic * 100, ha.indel_rate * 100, ha.pairs),
+                           "lanes": args.lanes, "counters_per_step": {k: v // steps for k, v in hs.items()},
+                           "stage_ms_per_step": {k: round(v / steps, 3) for k, v in hstage.items()}, "mapped_pairs_per_step": hmapped // steps}
+                gh.close()
+                if not args.skip_cpu and args.cpu_baseline in ("auto", "reference"):
+                    hic_out["cpu_baseline"] = cpu_baseline_reference(ha, None, " (hic)", seed0=7000, pairs=500_000)
+            except Exception as e:
+                hic_out = {"error": repr(e)}
     out = {
         "metric": "M paired reads mapped/s (ATAC preset, GRCh38 index)",
         "value": round(value, 4), "unit": "M pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -510,7 +540,7 @@ def main():
                    "pairs_per_gpu_per_step": args.pairs, "lanes": 1 if exchange else args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
-        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
+        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "hic_workload": hic_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
         "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
         "stage_ms_note": "HIP events of the calling thread's lane (1 / %d of the batch when lanes > 1; the lanes overlap)" % args.lanes,
         "counters_per_step": {k: v // steps for k, v in s.items()},

@@ -102,7 +102,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded",
            "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref",
-           "cmgpu_create_synthetic_repeats", "cmgpu_create_synthetic_profile", "cmgpu_generate_resident_batch_indels", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
+           "cmgpu_create_synthetic_repeats", "cmgpu_create_synthetic_profile", "cmgpu_generate_resident_batch_indels", "cmgpu_generate_resident_batch_hic", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
            "cmgpu_exchange_unique_id", "cmgpu_exchange_init", "cmgpu_exchange_init_all", "cmgpu_exchange_init_external",
            "cmgpu_exchange_owner_table", "cmgpu_exchange_step", "cmgpu_exchange_info", "cmgpu_exchange_finalize", "cmgpu_memcpy", "cmgpu_copy_whitelist",
            "cmgpu_host_alloc", "cmgpu_host_free", "cmgpu_host_register", "cmgpu_host_unregister", "cmgpu_submit_pairs", "cmgpu_map_submitted",
@@ -209,6 +209,7 @@ def declare(L):
                                                     P(C.c_void_p)])
     sig("cmgpu_create_synthetic_repeats", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int32, C.c_int32, P(Params), C.c_int,
                                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, P(C.c_void_p)])
+    sig("cmgpu_generate_resident_batch_hic", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint64])
     sig("cmgpu_generate_resident_batch_indels", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                                           C.c_double, C.c_uint64])
     sig("cmgpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64])

@@ -488,6 +488,108 @@ __global__ __launch_bounds__(SY_BLOCK) void k_sy_reads(const uint8_t *__restrict
   }
 }
 
+// Hi-C shaped pairs (BASELINE config 5): the two mates come from two INDEPENDENT loci -- 60 % of the pairs within 1 Mb on one
+// sequence (cis contacts), the others anywhere in the genome -- each in either orientation, and chim_thresh / 2^32 of the pairs
+// carry a ligation junction inside one read: its first `cut` bases (25 .. L - 25) from its own locus, the rest the reverse
+// complement of the partner's fragment, which is what split alignment (draft_mapping_generator.cc:410-487) exists for.
+// Same substitutions / 1-base indels as k_sy_reads.
+__global__ __launch_bounds__(SY_BLOCK) void k_sy_reads_hic(const uint8_t *__restrict__ ref, const uint64_t *__restrict__ ref_off,
+                                                            const uint32_t *__restrict__ ref_len, uint32_t n_seq, uint64_t total_len,
+                                                            uint32_t n_pairs, uint32_t L, uint32_t sub_thresh, uint32_t indel_thresh,
+                                                            uint32_t chim_thresh, uint64_t seed, uint8_t *__restrict__ r1,
+                                                            uint8_t *__restrict__ r2, uint32_t *__restrict__ o1, uint32_t *__restrict__ o2) {
+  const uint32_t i = blockIdx.x * SY_BLOCK + threadIdx.x;
+  if (i > n_pairs) return;
+  o1[i] = i * L;
+  o2[i] = i * L;
+  if (i == n_pairs) return;
+  const uint32_t F = 2 * L;  // fragment kept at either locus
+  const uint64_t ctr = sy_mix(seed ^ 0x41C0FFEEull ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
+  // locus A
+  uint64_t g = sy_mix(ctr) % total_len;
+  uint32_t ra = 0;
+  while (ra + 1 < n_seq && g >= ref_len[ra]) { g -= ref_len[ra]; ++ra; }
+  const uint32_t la = ref_len[ra];
+  uint32_t sa = (uint32_t)g;
+  if (sa + F > la) sa = la > F ? la - F : 0;
+  // locus B: cis within 1 Mb, or anywhere
+  uint32_t rb = ra, sb;
+  const uint64_t hb = sy_mix(ctr + 1);
+  if ((hb & 1023u) < 614u) {
+    const int64_t d = (int64_t)((hb >> 10) % 2000001ull) - 1000000;
+    int64_t p = (int64_t)sa + d;
+    if (p < 0) p = 0;
+    if (p + (int64_t)F > (int64_t)la) p = la > F ? (int64_t)la - F : 0;
+    sb = (uint32_t)p;
+  } else {
+    uint64_t g2 = sy_mix(ctr + 2) % total_len;
+    rb = 0;
+    while (rb + 1 < n_seq && g2 >= ref_len[rb]) { g2 -= ref_len[rb]; ++rb; }
+    sb = (uint32_t)g2;
+    if (sb + F > ref_len[rb]) sb = ref_len[rb] > F ? ref_len[rb] - F : 0;
+  }
+  const uint8_t *fa_ = ref + ref_off[ra] + sa, *fb_ = ref + ref_off[rb] + sb;
+  const bool oa = (hb >> 40) & 1, ob = (hb >> 41) & 1;  // orientation of either fragment
+  auto SA = [&](uint32_t j) -> uint8_t { return oa ? cm_negchar(fa_[F - 1 - j]) : fa_[j]; };
+  auto SB = [&](uint32_t j) -> uint8_t { return ob ? cm_negchar(fb_[F - 1 - j]) : fb_[j]; };
+  const uint64_t hc = sy_mix(ctr + 3);
+  const bool chim = (uint32_t)hc < chim_thresh && L >= 52;
+  const uint32_t cut = chim ? 25u + (uint32_t)((hc >> 32) % (uint64_t)(L - 50 + 1)) : L;
+  const bool chim_on_a = ((hc >> 62) & 1) != 0;
+  const bool swap = (sy_mix(ctr + 4) & 1) != 0;
+  uint8_t *a = (swap ? r2 : r1) + (uint64_t)i * L;
+  uint8_t *b = (swap ? r1 : r2) + (uint64_t)i * L;
+  const uint64_t rs = ctr + 5;
+  uint32_t ia = 0, ib = 0;  // next clean base of either read (1-base indels as in k_sy_reads)
+  for (uint32_t j = 0; j < L; ++j) {
+    const uint64_t h1 = sy_mix(rs + 2 * j), h2 = sy_mix(rs + 2 * j + 1);
+    bool ins1 = false, ins2 = false;
+    uint64_t g1 = 0, g2 = 0;
+    if (indel_thresh) {
+      g1 = sy_mix(rs + 0x10000 + 2 * j); g2 = sy_mix(rs + 0x10001 + 2 * j);
+      const bool ev1 = (uint32_t)g1 < indel_thresh, ev2 = (uint32_t)g2 < indel_thresh;
+      ins1 = ev1 && ((g1 >> 40) & 1); ins2 = ev2 && ((g2 >> 40) & 1);
+      if (ev1 && !ins1) ++ia;
+      if (ev2 && !ins2) ++ib;
+    }
+    const uint32_t ka = ia < F ? ia : F - 1, kb = ib < F ? ib : F - 1;
+    // clean base k of read a / b: own fragment up to the junction, then the partner's fragment read backwards on the other strand
+    uint8_t x = (chim && chim_on_a && ka >= cut) ? cm_negchar(SB(F - 1 - (ka - cut))) : SA(ka);
+    uint8_t y = (chim && !chim_on_a && kb >= cut) ? cm_negchar(SA(F - 1 - (kb - cut))) : SB(kb);
+    if (ins1) x = (uint8_t)("ACGT"[(g1 >> 32) & 3]); else ++ia;
+    if (ins2) y = (uint8_t)("ACGT"[(g2 >> 32) & 3]); else ++ib;
+    if ((uint32_t)(h1 & 0xffffffffu) < sub_thresh) x = (uint8_t)("ACGT"[(h1 >> 32) & 3]);
+    if ((uint32_t)(h2 & 0xffffffffu) < sub_thresh) y = (uint8_t)("ACGT"[(h2 >> 32) & 3]);
+    a[j] = x;
+    b[j] = y;
+  }
+}
+
+extern "C" int cmgpu_generate_resident_batch_hic(cmgpu_ctx *c, uint32_t n_pairs, uint32_t read_length, double sub_rate, double indel_rate,
+                                                 double chimeric_fraction, uint64_t seed) {
+  if (!c || read_length < 30 || read_length > 250 || (uint64_t)n_pairs * read_length > 0xfffffff0ull) { cm_set_error(c, "bad argument"); return CMGPU_EINVAL; }
+  SYCHECK(c, cm_enter(c));
+  for (uint32_t i = 0; i < c->n_seq; ++i)
+    if (c->h_ref_len[i] < 2 * read_length) { cm_set_error(c, "a sequence is shorter than two read lengths"); return CMGPU_EINVAL; }
+  c->n_pairs = n_pairs;
+  c->first_read_id = 0;
+  c->bases0 = c->bases1 = (size_t)n_pairs * read_length;
+  c->max_read_len = read_length;
+  c->has_barcodes = false;
+  c->single = false;
+  if (c->rb0.ensure(c->bases0 + 16) || c->rb1.ensure(c->bases1 + 16) || c->ro0.ensure(((size_t)n_pairs + 1) * 4) ||
+      c->ro1.ensure(((size_t)n_pairs + 1) * 4)) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < c->n_seq; ++i) total += c->h_ref_len[i];
+  auto thresh = [](double r) { return (uint32_t)(r * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (r < 0 ? 0 : r * 4294967296.0)); };
+  hipLaunchKernelGGL(k_sy_reads_hic, dim3((n_pairs + 1 + SY_BLOCK - 1) / SY_BLOCK), dim3(SY_BLOCK), 0, c->stream,
+                     (const uint8_t *)c->ref.p, (const uint64_t *)c->ref_off.p, (const uint32_t *)c->ref_len.p, c->n_seq, total,
+                     n_pairs, read_length, thresh(sub_rate), thresh(indel_rate), thresh(chimeric_fraction), seed, (uint8_t *)c->rb0.p,
+                     (uint8_t *)c->rb1.p, (uint32_t *)c->ro0.p, (uint32_t *)c->ro1.p);
+  SYCHECK(c, cm_stream_sync(c->stream));
+  return CMGPU_OK;
+}
+
 extern "C" int cmgpu_generate_resident_batch(cmgpu_ctx *c, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
                                              uint32_t frag_max, double sub_rate, uint64_t seed) {
   return cmgpu_generate_resident_batch_indels(c, n_pairs, read_length, frag_min, frag_max, sub_rate, 0.0, seed);

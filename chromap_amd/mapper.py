@@ -361,9 +361,14 @@ class ChromapGPU:
         bt = self._batch(b1, o1, b2, o2, first_read_id)
         self._check(self.L.cmgpu_upload_batch(self.ctx, C.byref(bt)), self.ctx)
 
-    def generate_resident(self, n_pairs, read_length=50, frag_min=100, frag_max=600, sub_rate=0.01, seed=1, indel_rate=0.0):
-        self._check(self.L.cmgpu_generate_resident_batch_indels(self.ctx, n_pairs, read_length, frag_min, frag_max, sub_rate,
-                                                                indel_rate, seed), self.ctx)
+    def generate_resident(self, n_pairs, read_length=50, frag_min=100, frag_max=600, sub_rate=0.01, seed=1, indel_rate=0.0, hic=None):
+        """synthetic pairs on the device; hic = fraction of pairs with a ligation junction inside a read: Hi-C shaped pairs
+        (mates from independent loci) instead of fragments"""
+        if hic is not None:
+            self._check(self.L.cmgpu_generate_resident_batch_hic(self.ctx, n_pairs, read_length, sub_rate, indel_rate, float(hic), seed), self.ctx)
+        else:
+            self._check(self.L.cmgpu_generate_resident_batch_indels(self.ctx, n_pairs, read_length, frag_min, frag_max, sub_rate,
+                                                                    indel_rate, seed), self.ctx)
         self._n_resident = n_pairs
 
     def swap_resident(self, slot):

@@ -315,6 +315,12 @@ int cmgpu_generate_resident_batch(cmgpu_ctx *ctx, uint32_t n_pairs, uint32_t rea
 /* The same with 1-base insertions / deletions at rate indel_rate per base (half each). */
 int cmgpu_generate_resident_batch_indels(cmgpu_ctx *ctx, uint32_t n_pairs, uint32_t read_length, uint32_t frag_min,
                                          uint32_t frag_max, double sub_rate, double indel_rate, uint64_t seed);
+/* Hi-C shaped pairs (BASELINE config 5): the mates come from two independent loci (60 % within 1 Mb on one sequence, the
+ * others anywhere), either orientation each; `chimeric_fraction` of the pairs carry a ligation junction inside one read
+ * (25 .. L - 25 bases of its own locus, then the partner's fragment on the other strand) -- the input split alignment
+ * (draft_mapping_generator.cc:410-487, alignment.cc:197-376) is for. */
+int cmgpu_generate_resident_batch_hic(cmgpu_ctx *ctx, uint32_t n_pairs, uint32_t read_length, double sub_rate, double indel_rate,
+                                      double chimeric_fraction, uint64_t seed);
 /* The resident batch changes places with the one parked in `slot` (0..7; either may be empty): several distinct
  * batches stay in HBM and take turns (the measurement must not map one batch over and over). */
 int cmgpu_swap_resident_batch(cmgpu_ctx *ctx, int slot);

@@ -73,3 +73,59 @@ def test_synthetic_index_and_reads_match_oracle(preset, readlen, fmin, fmax, tmp
         assert rec[i].fragment_start + rec[i].fragment_length <= lens[rec[i].rid]
     g.close()
     o.close()
+
+
+def test_mosaic_genome_profile_matches_oracle(tmp_path):
+    """the repeat-landscape genome of bench.py's third workload (cmgpu_create_synthetic_profile): about a fifth of the bases
+    repeat-derived; every record of 20 000 pairs equal to the oracle's, and the repeats do what they are there for --
+    multi-mapped pairs and reads with long candidate lists"""
+    from chromap_amd import ChromapGPU
+    g = ChromapGPU(synthetic=(12_000_000, 3, 99, "profile:1"), preset="atac")
+    fa = str(tmp_path / "mosaic.fa")
+    lens = _export_fasta(g, fa)
+    n, readlen = 20000, 50
+    g.generate_resident(n, read_length=readlen, frag_min=30, frag_max=600, sub_rate=0.01, seed=11)
+    b1, o1, b2, o2 = g.download_batch(n)
+    k = g.map_resident()
+    rec, k2 = g.download_records(n)
+    o = ol.Oracle(None, fa, ol.params("atac"))
+    orec, ok, ost, _ = o.map_pairs(b1, o1, b2, o2)
+    assert ok == k
+    assert _tuples(rec, k, True) == _tuples(orec, ok, False)
+    s, od = g.stats.as_dict(), ost.as_dict()
+    for key in ("num_candidates", "num_mappings", "num_mapped_reads", "num_uniquely_mapped_reads"):
+        assert s[key] == od[key], key
+    assert s["num_mapped_reads"] - s["num_uniquely_mapped_reads"] > 0  # repeats make multi-mappers
+    assert s["num_candidates"] > s["num_mapped_reads"]
+    print("mosaic: mapped %d unique %d candidates %d" % (s["num_mapped_reads"], s["num_uniquely_mapped_reads"], s["num_candidates"]))
+    g.close()
+    o.close()
+
+
+def test_hic_shaped_pairs_match_oracle(tmp_path):
+    """Hi-C shaped synthetic pairs (mates from independent loci, a third of the pairs with a ligation junction inside a read)
+    under --preset hic: every pairs record equal to the oracle's; the chimeric reads really take the split-alignment branch
+    (a junction read maps although half of it belongs elsewhere)"""
+    from chromap_amd import ChromapGPU, _capi
+    g = ChromapGPU(synthetic=(6_000_000, 4, 4243), preset="hic")
+    fa = str(tmp_path / "syn.fa")
+    _export_fasta(g, fa)
+    n, readlen = 20000, 150
+    g.generate_resident(n, read_length=readlen, sub_rate=0.01, indel_rate=0.001, seed=5, hic=0.35)
+    b1, o1, b2, o2 = g.download_batch(n)
+    k = g.map_resident()
+    rec, k2 = g.download_records(n)
+    assert k2 == k
+    o = ol.Oracle(None, fa, ol.params("hic"))
+    orec, ok, ost, _ = o.map_pairs(b1, o1, b2, o2)
+    assert ok == k and k > 0.9 * n
+    pg = C.cast(rec, C.POINTER(_capi.PairsRecord))
+    po = C.cast(orec, C.POINTER(ol.OraPairsRecord))
+    tg = sorted((pg[i].read_id, pg[i].rid1, pg[i].rid2, pg[i].pos1, pg[i].pos2, pg[i].strand1, pg[i].strand2, pg[i].mapq, pg[i].is_unique) for i in range(k))
+    to = sorted((po[i].read_id, po[i].rid1, po[i].rid2, po[i].pos1, po[i].pos2, po[i].strand1, po[i].strand2, po[i].mapq, po[i].is_unique) for i in range(ok))
+    assert tg == to
+    # mates from independent loci: many pairs span sequences or lie far apart
+    far = sum(1 for t in tg if t[1] != t[2] or abs(int(t[3]) - int(t[4])) > 5000)
+    assert far > 0.5 * k
+    g.close()
+    o.close()

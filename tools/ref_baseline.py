@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--frag-min", type=int, default=30)
     ap.add_argument("--frag-max", type=int, default=600)
     ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--hic", type=float, default=-1.0, help="Hi-C shaped pairs with this fraction of chimeric reads (default: fragments)")
     args = ap.parse_args()
     rep = None
     if args.repeats.startswith("profile:"):
@@ -78,7 +79,7 @@ def main():
             os.remove(f)
     for b in range(args.batches):
         g.generate_resident(args.pairs, read_length=args.readlen, frag_min=args.frag_min, frag_max=args.frag_max, sub_rate=0.01,
-                            seed=args.seed0 + b, indel_rate=args.indel_rate)
+                            seed=args.seed0 + b, indel_rate=args.indel_rate, hic=args.hic if args.hic >= 0 else None)
         b1, o1, b2, o2 = g.download_batch(args.pairs)
         for path, bases in ((r1, b1), (r2, b2)):
             tmp = path + ".part"
