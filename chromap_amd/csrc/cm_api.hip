@@ -708,6 +708,9 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     mark(c, "s0b_barcode");
   }
   uint32_t n_mm = 0;
+  bool s3a_done = false;
+  uint32_t n_heavy[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lists 0..2, 10 by size, 3: one lane each, 4: the short lists of the 16-lane groups
+  unsigned long long hits_total = 0;
   const bool flat = c->opt_prep_kernel == 1 && cm_prep_flat_supported(d, c->max_read_len, (uint32_t)c->opt_prep_tile_reads);
   if (flat || cm_prep_mm_supported(d, c->max_read_len)) {
     // S0 + S1 fused: one pass of the minimizer state machine, block-level reservation of the dense arrays
@@ -757,6 +760,20 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       HIPCHECK(c, hipEventRecord(c->chunk_ev[CM_MM_CHUNKS], c->stream2));
       HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[CM_MM_CHUNKS], 0));
       cm_launch_k_probe_reduce(c->partials.p, part_off[n_chunks], d.stats + CM_ST_PROBE_STEPS, s);
+      // S3a (hit counts, size classes) and the scan of the counts follow at once: their totals come back with the minimizer
+      // marks in ONE read (a read's minimizer range is checked against the arrays' capacity, so an overflow leaves them idle)
+      d.mm_cap = (uint32_t)cap;
+      HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
+      cm_launch_k_s3a_count(d, n2, s);
+      {
+        unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_N - 2;
+        HIPCHECK(c, hipMemsetAsync(acc, 0, 8, s));
+        cm_launch_k_sum_u32(d.hit_tot, n2, acc, s);
+        cm_scan_u32(d.hit_tot, d.hit_off, n2, (uint32_t *)c->scan_tmp.p, s);
+        HIPCHECK(c, hipMemcpyAsync(&hits_total, acc, 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, sizeof(n_heavy), hipMemcpyDeviceToHost, s));
+      }
+      s3a_done = true;
       // one read-back: the marks (cursor after every chunk; the last one is the total)
       unsigned long long hm[CM_MM_CHUNKS + 1];
       HIPCHECK(c, hipMemcpyAsync(hm, c->mm_marks.p, ((size_t)n_chunks + 1) * 8, hipMemcpyDeviceToHost, s));  // (not the null stream: lanes run side by side)
@@ -810,12 +827,12 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     mark(c, "s1b_s2_minimizers_probe");
   }
   // S3: hit counts -> offsets -> candidates
-  HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
-  cm_launch_k_s3a_count(d, n2, s);
-  uint32_t n_heavy[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lists 0..2, 10 by size, 3: one lane each, 4: the short lists of the 16-lane groups
-  HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, sizeof(n_heavy), hipMemcpyDeviceToHost, s));
-  unsigned long long hits_total = 0;
-  if ((rc = scan_with_total(c, d.hit_tot, d.hit_off, n2, &hits_total))) return rc;
+  if (!s3a_done) {
+    HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
+    cm_launch_k_s3a_count(d, n2, s);
+    HIPCHECK(c, hipMemcpyAsync(n_heavy, c->hv_cnt.p, sizeof(n_heavy), hipMemcpyDeviceToHost, s));
+    if ((rc = scan_with_total(c, d.hit_tot, d.hit_off, n2, &hits_total))) return rc;
+  }
   if (hits_total > limit) return CM_RC_SPLIT;  // 2 x 150 reads on a repeat-rich genome: ~500 hits per read x 8 M reads wraps 2^32
   const uint32_t n_hits = (uint32_t)hits_total;
   if (c->hbuf.ensure((size_t)n_hits * 8 + 8) || c->hcnt.ensure((size_t)n_hits + 4)) { cm_set_error(c, "out of device memory (hits)"); return CMGPU_ENOMEM; }
@@ -861,12 +878,9 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
   // candidate, (c) the sequential acceptance loop per read
   cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
-  unsigned long long v_total = 0;
-  if ((rc = scan_with_total(c, d.nv, d.v_off, n2, &v_total))) return rc;
-  if (v_total > 0xfffffff0ull) return CM_RC_SPLIT;  // never above m_total; kept for symmetry
-  const uint32_t n_v = (uint32_t)v_total;
+  cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
   mark(c, "s5a_prepare");
-  cm_launch_k_s5b_verify(d, n_v, n2, s);
+  cm_launch_k_s5b_verify(d, n_m, n2, s);
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s5c_finalize(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);

@@ -1027,9 +1027,10 @@ void cm_launch_k_sort_lists(const CmDev &d, int mode, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL(k_sort_lists<0>, dim3(1024), dim3(CM_BLOCK), lds, s, d);
   else hipLaunchKernelGGL(k_sort_lists<1>, dim3(1024), dim3(CM_BLOCK), lds, s, d);
 }
-__global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_items, uint32_t n_reads) {
-  const uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (j < n_items) cm_s5b_verify_item(d, j, n_reads);
+// the number of work items is v_off[n_reads] (device side); the grid covers an upper bound, surplus blocks leave
+__global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_reads) {
+  const uint32_t n_items = d.v_off[n_reads];
+  for (uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x; j < n_items; j += gridDim.x * CM_BLOCK) cm_s5b_verify_item(d, j, n_reads);
 }
 // --SAM has its own instantiations: the alignment's register window must not cost the BED path occupancy
 // S6a.  coop: a pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 13, where a wave runs its two sweeps
@@ -1623,8 +1624,12 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
 }
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
-void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s) {
-  if (n_items) hipLaunchKernelGGL(k_s5b_verify, grid_for(n_items), dim3(CM_BLOCK), 0, s, d, n_items, n_reads);
+// max_items: an upper bound of the item count (the capacity of the candidate arrays)
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s) {
+  if (!max_items) return;
+  uint32_t blocks = (max_items + CM_BLOCK - 1) / CM_BLOCK;
+  if (blocks > 65536) blocks = 65536;  // grid-stride beyond
+  hipLaunchKernelGGL(k_s5b_verify, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n_reads);
 }
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;

@@ -930,7 +930,9 @@ CM_HD uint32_t cm_probe(const uint64_t *bkt, uint32_t bmask, uint64_t hash, uint
 CM_HD void cm_s3a_count(const CmDev &d, uint32_t r) {
   const uint32_t pair = r >> 1;
   // BothEndsHaveMinimizers (chromap.h:936); single-end: minimizers_.size() > 0 (chromap.h:416)
-  const bool live = d.p.single ? ((r & 1) == 0 && d.mm_cnt[r] > 0) : (d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0);
+  bool live = d.p.single ? ((r & 1) == 0 && d.mm_cnt[r] > 0) : (d.mm_cnt[2 * pair] > 0 && d.mm_cnt[2 * pair + 1] > 0);
+  // minimizer arrays that overflowed (the host sees it in the same read-back and reruns with larger ones): nothing to look at
+  if (d.mm_cap && (uint64_t)d.mm_off[r] + d.mm_cnt[r] > d.mm_cap) live = false;
   uint32_t tot1 = 0, tot2 = 0, rep_len = 0, rep_cnt = 0, prev = ~0u;
   if (live) {
     const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];

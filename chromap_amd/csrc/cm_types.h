@@ -122,6 +122,7 @@ struct CmDev {
   // stage looks at them: srt_cnt[0] items (read << 1 | strand) at srt_list, srt_cnt[1] the work cursor
   uint32_t *srt_cnt, *srt_list;
   uint32_t hv_stride, s3b_cap, hv_max[4];  // hv_max: hit-list size classes -- a wave, a block of 256 / 512 / 1024 lanes (lists 0, 1, 2, 10)
+  uint32_t mm_cap;  // capacity of the dense minimizer arrays (0: not checked): S3a leaves a read whose range passes it idle
   uint32_t coop_rb; // tests: run-table size of the cooperative sorters (0: two per minimizer of the longest read)
   uint32_t hv_mid;  // class 4: lists of s3b_cap < hits <= hv_mid go to groups of 16 lanes (k_s3b_heavy<16>); 0 = no such class
   // ---- rescue / merged candidates

@@ -120,6 +120,13 @@ CASES = {
                           "--seed", "5"], ["--preset", "atac", "-q", "0", "--drop-repetitive-reads", "2"]),
     "s4_se_drop2_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                         "--seed", "5"], ["--preset", "chip", "-q", "0", "--drop-repetitive-reads", "2"]),
+    # 24 sequences (more owners than a 4- or 8-rank exchange has ranks to give them to, and empty owners at 8): bulk and single-cell
+    # with duplicate removal at bulk level (the end-of-output MAPQ rule belongs to the last rank that owns records)
+    "s5_atac_24chr_q0": (["--genome", "6000000", "--chroms", "24", "--pairs", "30000", "--readlen", "50", "--frag-min", "35", "--seed", "41"],
+                         ["--preset", "atac", "-q", "0"]),
+    "b4_bulk_level_bc_24chr_q0": (["--genome", "3000000", "--chroms", "24", "--pairs", "30000", "--readlen", "50", "--frag-min", "40",
+                                   "--barcodes", "60", "--seed", "43", "--dup-frac", "0.3"],
+                                  ["--preset", "atac", "--remove-pcr-duplicates-at-bulk-level", "-q", "0"]),
     # --preset hic --SAM: split alignment with ksw on the aligned part of the read, AdjustGapBeginning on the CIGAR, SEQ cut to the
     # CIGAR's query length (sam_mapping.h:186-193), all four strand combinations
     "h2_hic_sam_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",

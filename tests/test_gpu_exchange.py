@@ -99,6 +99,83 @@ def test_two_ranks_map_partition_exchange_store_format_equals_golden(case, tmp_p
     assert got == datasets.case_golden_bed(case)
 
 
+def _worker_wide(rank, world, port, case, outdir):
+    """one of `world` ranks sharing the box's GPU: bulk or single-cell records of a 24-sequence case, shards of 5000 pairs dealt
+    in rounds (ranks run out of input at different rounds and keep taking part with empty batches), every record to its
+    sequence's owner, the owner's device-side sort / duplicate removal / text"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.zeros(1, device="cuda")
+    from chromap_amd import _capi
+    from chromap_amd.distributed import HostStagedTransport, owned_rids, shard_batches
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    g, meta, r1, r2 = _gpu(case)
+    b1, o1 = ol.read_fastx(r1)
+    b2, o2 = ol.read_fastx(r2)
+    n = len(o1) - 1
+    bc = None
+    if datasets.has_barcodes(case):
+        bcf, wlf = datasets.case_barcode_inputs(case)
+        bc, bcq, bco = ol.read_fastq_qual(bcf)
+        g.set_whitelist_file(wlf, int(bco[1] - bco[0]))
+        g.compute_barcode_abundance(bc, bco)  # the pre-pass sees the whole input on every rank
+    g.exchange_init_external(HostStagedTransport(g), rank, world)
+    shard = 5000
+    mine = shard_batches(n, rank, world, ref_batch=shard)
+    rounds = (n + shard * world - 1) // (shard * world)
+    sent_total = 0
+    for rd in range(rounds):
+        lo, hi = mine[rd] if rd < len(mine) else (0, 0)
+        oo1 = (o1[lo:hi + 1] - o1[lo]).astype(np.uint32)
+        oo2 = (o2[lo:hi + 1] - o2[lo]).astype(np.uint32)
+        if bc is None:
+            g.upload(b1[o1[lo]:o1[hi]].copy(), oo1, b2[o2[lo]:o2[hi]].copy(), oo2, first_read_id=lo)
+            k = g.map_resident()
+        else:
+            oob = (bco[lo:hi + 1] - bco[lo]).astype(np.uint32)
+            _, k = g.map_pairs_barcoded(b1[o1[lo]:o1[hi]].copy(), oo1, b2[o2[lo]:o2[hi]].copy(), oo2, bc[bco[lo]:bco[hi]].copy(),
+                                        bcq[bco[lo]:bco[hi]].copy(), oob, first_read_id=lo)
+        sent, nrecv = g.exchange_step()
+        assert sum(sent) == k
+        sent_total += k
+    info = g.exchange_info()
+    assert info["records_sent"] == sent_total and info["world"] == world
+    if bc is None:
+        g.store_format(_capi.TEXT_BED_PE)
+    else:
+        g.store_format(_capi.TEXT_BED_PE_BC, barcode_length=g.barcode_length)
+    text = g.store_text()
+    own = {g.names[r] for r in owned_rids(list(g.reference_lengths()), rank, world)}
+    assert {ln.split(b"\t")[0] for ln in text.splitlines()} <= own
+    with open(os.path.join(outdir, "part%d.bed" % rank), "wb") as f:
+        f.write(text)
+    tot = torch.tensor([info["records_received"], info["records_sent"], 1 if len(text) == 0 else 0], dtype=torch.int64)
+    dist.all_reduce(tot)
+    assert int(tot[0]) == int(tot[1])
+    with open(os.path.join(outdir, "empty%d" % rank), "w") as f:
+        f.write(str(int(tot[2])))
+    g.exchange_finalize()
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("case", ["s5_atac_24chr_q0", "b4_bulk_level_bc_24chr_q0"])
+def test_four_and_eight_ranks_equal_golden(case, world, tmp_path):
+    """SURVEY 8(e) at the widths the driver's scaling run uses: 24 sequences over 4 / 8 owners, ranks that run out of input
+    early, bulk records and single-cell records with duplicate removal at bulk level (its end-of-output MAPQ rule is applied by
+    the last rank that owns records); the concatenated sections equal the reference's BED"""
+    import torch.multiprocessing as mp
+    datasets.case_inputs(case)
+    datasets.case_index(case)
+    mp.spawn(_worker_wide, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    got = b"".join(open(str(tmp_path / ("part%d.bed" % r)), "rb").read() for r in range(world))
+    assert got == datasets.case_golden_bed(case)
+
+
 @pytest.mark.parametrize("case", ["s1_atac", "s3_chip"])
 def test_rccl_exchange_one_rank_equals_golden(case):
     """the library's RCCL transport: communicator of one rank, collectives issued on the mapping stream"""
