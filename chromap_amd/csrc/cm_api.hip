@@ -13,6 +13,7 @@
 #include "../../include/chromap_amd.h"
 #include "cm_ctx.h"
 #include "cm_kernels.h"
+#include "cm_coop.h"
 #include "cm_mapq_tables.h"
 
 static thread_local std::string g_last_error;  // errors without a ctx (creation), per calling thread
@@ -390,7 +391,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
   ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
-  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(hv_cnt, 256) ENS(hv_list, CM_HV_LISTS * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
+  ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(coop_slab, (size_t)CM_SLAB_BLOCKS * cm_coop_slab_bytes(CM_SLAB_CAP)) ENS(hv_cnt, 256) ENS(hv_list, CM_HV_LISTS * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
 #undef ENS
   return CMGPU_OK;
 }
@@ -635,6 +636,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.hv_stride = 2 * (hi - lo) + 1;
   d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
+  d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
@@ -872,7 +874,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_launch_k_s4b_rescue_list(d, n2, s, (c->opt_coop & 2) != 0, c->max_read_len);
   mark(c, "s4b_rescue_merge");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
-  cm_launch_k_s4c_reduce(d, n, s, (c->opt_coop & 4) != 0);
+  cm_launch_k_s4c_reduce(d, n, s, (uint32_t)c->opt_coop & (c->p.split ? ~8u : ~0u));
   if (c->use_perm) cm_launch_k_sort_lists(d, 0, s);  // long candidate lists: a wave each, before S5a wants them in order
   mark(c, "s4c_pair_filter");
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
@@ -880,7 +882,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
   mark(c, "s5a_prepare");
-  cm_launch_k_s5b_verify(d, n_m, n2, s);
+  cm_launch_k_s5b_verify(d, n_m, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s5c_finalize(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);

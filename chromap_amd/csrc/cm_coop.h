@@ -148,7 +148,21 @@ struct CmCoopMem {
   uint64_t *mval;       // MM: index of its first occurrence in the occurrence table (a singleton: the occurrence itself)
   uint32_t *mps;        // MM: (read position << 1 | strand) of the minimizer, bit 31: singleton
   uint32_t P, MM, RB;
+  // lists longer than P: the same algorithms on a slab of global memory that belongs to the group (slower per step, but
+  // hundreds of lanes instead of one); gcap entries each, nullptr when the launch brought none
+  uint64_t *gA, *gB;
+  uint16_t *goc;
+  uint8_t *gcc;
+  uint32_t gcap;
 };
+CM_HD size_t cm_coop_slab_bytes(uint32_t gcap) { return (size_t)gcap * 19 + 64; }
+CM_HD void cm_coop_slab_at(CmCoopMem &m, uint8_t *slab, uint32_t gcap) {
+  m.gcap = slab ? gcap : 0;
+  m.gA = reinterpret_cast<uint64_t *>(slab);
+  m.gB = slab ? m.gA + gcap : nullptr;
+  m.goc = slab ? reinterpret_cast<uint16_t *>(m.gB + gcap) : nullptr;
+  m.gcc = slab ? reinterpret_cast<uint8_t *>(m.goc + gcap) : nullptr;
+}
 CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) {
   return (size_t)P * (own_oc ? 19 : 16) + ((size_t)2 * (RB + 1) + (size_t)MM * 4 + 2) * 4 + 32;
 }
@@ -165,6 +179,7 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
   m.mps = m.moff + MM + 1;
   m.oc = own_oc ? reinterpret_cast<uint16_t *>(m.mps + MM + 1) : nullptr;
   m.cc = own_oc ? reinterpret_cast<uint8_t *>(m.oc + P) : nullptr;
+  m.gA = m.gB = nullptr; m.goc = nullptr; m.gcc = nullptr; m.gcap = 0;
   return m;
 }
 
@@ -188,7 +203,9 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   const uint64_t SB = 1ull << 63;
-  if (tot > m.P) return false;
+  const bool slab = tot > m.P;  // the list does not fit the shared work area: the group's slab of global memory
+  if (slab && (tot > m.gcap || tot > 0xffffu)) return false;  // the sweep's offsets are 16-bit
+  uint64_t *const A = slab ? m.gA : m.A, *const B = slab ? m.gB : m.B;
   // ---- included minimizers and where their occurrences start in the list
   uint32_t R = 0, off = 0;
   for (uint32_t base = 0; base < n; base += G) {
@@ -239,7 +256,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
       if (x < tot) {
         bool same;
         const uint64_t cp = cm_cand_from_hit(hit[q], ps[q] & 0x7fffffffu, d.p.k, &same);
-        m.B[x] = same ? cp : (cp | SB);
+        B[x] = same ? cp : (cp | SB);
       }
     }
   }
@@ -250,18 +267,18 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
     const uint32_t VT = (tot + G - 1) / G;
     const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
     uint32_t cnt = 0;
-    for (uint32_t x = c0; x < c1; ++x) cnt += (m.B[x] >> 63) ? 0u : 1u;
+    for (uint32_t x = c0; x < c1; ++x) cnt += (B[x] >> 63) ? 0u : 1u;
     uint32_t pos = g.scan(cnt, &np);
     for (uint32_t x = c0; x < c1; ++x) {
-      const uint64_t v = m.B[x];
-      if (v >> 63) m.A[np + (x - pos)] = v; else m.A[pos++] = v;
+      const uint64_t v = B[x];
+      if (v >> 63) A[np + (x - pos)] = v; else A[pos++] = v;
     }
   }
   g.sync();
   // ---- sort
-  const uint32_t nr = cm_coop_natural_runs(g, m.A, tot, m.rb, m.RB);
+  const uint32_t nr = cm_coop_natural_runs(g, A, tot, m.rb, m.RB);
   if (nr == 0) return false;
-  uint64_t *S = cm_coop_merge_runs(g, m.A, m.B, m.rb, m.rb2, nr, tot);
+  uint64_t *S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot);
   // ---- sweep
   const uint32_t nn = tot - np;
   const bool use_high = d.round2[r] && np > 0 && nn > 0;
@@ -271,7 +288,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   if (use_high) req = d.p.min_seeds;
   uint64_t *h = d.hbuf + d.hit_off[r];
   uint8_t *hc = d.hcnt + d.hit_off[r];
-  uint16_t *oc = m.oc ? m.oc : reinterpret_cast<uint16_t *>(S == m.A ? m.B : m.A);
+  uint16_t *oc = slab ? m.goc : (m.oc ? m.oc : reinterpret_cast<uint16_t *>(S == A ? B : A));
   uint32_t ncp, ncn;
   cm_coop_sweep(g, S, tot, np, d.p.e, req, n, oc, h, hc, h + np, hc + np, &ncp, &ncn);
   if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
@@ -336,11 +353,16 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     return n1;
   }
   uint32_t nr = 0;
-  if (cnt <= m.P) {
+  // the work buffers: shared memory, or -- a list longer than that -- the hits where they are and the group's slab of global memory
+  const bool slab = cnt > m.P;
+  uint64_t *const A = slab ? out + n1 : m.A, *const B = slab ? m.gB : m.B;
+  uint16_t *const oc = slab ? m.goc : m.oc;
+  uint8_t *const cc = slab ? m.gcc : m.cc;
+  if (!slab) {
     for (uint32_t i = g.t; i < cnt; i += (uint32_t)GT::G) m.A[i] = out[n1 + i];
     g.sync();
-    nr = cm_coop_natural_runs(g, m.A, cnt, m.rb, m.RB);
   }
+  if (!slab || (cnt <= m.gcap && cnt <= 0xffffu)) nr = cm_coop_natural_runs(g, A, cnt, m.rb, m.RB);
   if (nr == 0) {  // more hits or runs than the work area holds: the one-lane definition
     uint32_t k = 0;
     if (g.t == 0) {
@@ -351,22 +373,22 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     }
     return cm_coop_bcast0(g, k);
   }
-  uint64_t *S = cm_coop_merge_runs(g, m.A, m.B, m.rb, m.rb2, nr, cnt);
-  uint64_t *X = S == m.A ? m.B : m.A;
+  uint64_t *S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, cnt);
+  uint64_t *X = S == A ? B : A;
   uint32_t naug, none;
-  cm_coop_sweep(g, S, cnt, cnt, e, 1, d.mm_cnt[r], m.oc, X, m.cc, X, m.cc, &naug, &none);
+  cm_coop_sweep(g, S, cnt, cnt, e, 1, d.mm_cnt[r], oc, X, cc, X, cc, &naug, &none);
   g.sync();  // X / cc complete, S free
   if (naug == 0) {
     cm_coop_copy_list(g, c0p, c0c, out, outc, n1);
     return n1;
   }
   if (n1 == 0) {  // c1.swap(c2): the augmented list as it is (no distance rule)
-    for (uint32_t i = g.t; i < naug; i += (uint32_t)GT::G) { out[i] = X[i]; outc[i] = m.cc[i]; }
+    for (uint32_t i = g.t; i < naug; i += (uint32_t)GT::G) { const uint64_t x = X[i]; const uint8_t c = cc[i]; out[i] = x; outc[i] = c; }
     return naug;
   }
   // ---- Z = merge of c0 (staged in S when it fits) and X, ties: c0 first
   const uint64_t *a = c0p;
-  if (n1 <= m.P) {
+  if (!slab && n1 <= m.P) {
     for (uint32_t i = g.t; i < n1; i += (uint32_t)GT::G) S[i] = c0p[i];
     g.sync();
     a = S;
@@ -384,7 +406,7 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     for (uint32_t z = z0; z < z1; ++z) {
       const bool take_a = ib >= naug || (ia < n1 && a[ia] <= X[ib]);
       if (take_a) { zp[z] = a[ia]; zc[z] = c0c[ia]; ++ia; }
-      else { zp[z] = X[ib]; zc[z] = m.cc[ib]; ++ib; }
+      else { zp[z] = X[ib]; zc[z] = cc[ib]; ++ib; }
     }
   }
   g.sync();
@@ -725,16 +747,71 @@ CM_HD uint32_t cm_coop_draft_strand(const CmDev &d, GT &g, const CmCoopVerMem &m
   g.sync();
   return nd;
 }
-// r: a read cm_s5a_prepare left to the group (nv[r] == 0, candidate lists sorted).  S5b is part of it: a lane per candidate runs
-// the banded alignment (cm_s5b_verify_at), no work-item search, the read's own quantities loaded once per lane.
+// ---------------------------------------------------------------------------------------
+// MappingMetadata::SortCandidates for one long list by the group: Candidate::operator< is (count descending, position
+// ascending) and the list arrives in position order, so the sort is a STABLE partition by count -- a counting sort: every lane
+// counts the counts of its contiguous chunk (hist: G x nb_cap 16-bit bins of shared memory), the bins are scanned over the
+// lanes from the largest count down, the chunk is scattered to (sp, sc) and copied back.  A list that is not in position
+// order (--chr-order re-ranks the sequence ids after the filter) or has a count >= nb_cap is sorted by the group's lane 0.
+// ---------------------------------------------------------------------------------------
+template <class GT>
+CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_t *sp, uint8_t *sc, uint16_t *hist, uint32_t nb_cap) {
+  const uint32_t G = (uint32_t)GT::G;
+  if (n < 2) return;
+  uint32_t bad = 0;
+  uint64_t mx = 0;
+  for (uint32_t i = g.t; i < n; i += G) {
+    if (i > 0 && p[i] < p[i - 1]) bad = 1;
+    mx = c[i] > mx ? c[i] : mx;
+  }
+  bad = g.sum(bad);
+  mx = g.max64(mx);
+  if (bad || mx >= nb_cap || n > 0xffffu) {
+    if (g.t == 0) cm_sort_cand(p, c, n);
+    g.sync();
+    return;
+  }
+  const uint32_t nb = (uint32_t)mx + 1;
+  uint16_t *mine = hist + (size_t)g.t * nb_cap;
+  for (uint32_t b = 0; b < nb; ++b) mine[b] = 0;
+  const uint32_t VT = (n + G - 1) / G;
+  const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
+  for (uint32_t i = c0; i < c1; ++i) mine[c[i]] += 1;
+  uint32_t base = 0;
+  for (uint32_t b = nb; b-- > 0;) {  // the largest count first
+    uint32_t tot;
+    const uint32_t off = g.scan(mine[b], &tot);
+    mine[b] = (uint16_t)(base + off);
+    base += tot;
+  }
+  for (uint32_t i = c0; i < c1; ++i) {
+    const uint8_t ci = c[i];
+    const uint32_t dst = mine[ci]++;
+    sp[dst] = p[i];
+    sc[dst] = ci;
+  }
+  g.sync();
+  for (uint32_t i = g.t; i < n; i += G) { p[i] = sp[i]; c[i] = sc[i]; }
+  g.sync();
+}
+
+// S5b for a read cm_s5a_prepare left to the groups (nv[r] == 0, candidate lists NOT yet sorted): the group sorts the two lists
+// (cm_coop_sort_cand), then a lane per candidate runs the banded alignment (cm_s5b_verify_at) -- no work-item search, the read's
+// own quantities loaded once per lane.
+template <class GT>
+CM_HD void cm_coop_s5b(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap) {
+  const uint32_t ncp = d.fcp[r], nc = ncp + d.fcn[r];
+  {  // the candidate lists were left unsorted (cm_s5a_prepare); scratch: the read's draft-mapping arrays, written by S5c only
+    const uint32_t op = d.m_off[r], on = op + d.ncp[r] + d.resc_p[r];
+    cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, ncp, d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap);
+    cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap);
+  }
+  for (uint32_t li = g.t; li < nc; li += (uint32_t)GT::G) cm_s5b_verify_at(d, r, li < ncp ? 0 : 1, li < ncp ? li : li - ncp);
+}
+// S5c for such a read, after cm_coop_s5b
 template <class GT>
 CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m) {
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
-  {
-    const uint32_t ncp = d.fcp[r], nc = ncp + d.fcn[r];
-    for (uint32_t li = g.t; li < nc; li += (uint32_t)GT::G) cm_s5b_verify_at(d, r, li < ncp ? 0 : 1, li < ncp ? li : li - ncp);
-    g.sync();
-  }
   if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: one lane
     if (g.t == 0) cm_s5c_accept(d, r);
     return;

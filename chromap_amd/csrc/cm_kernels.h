@@ -5,6 +5,8 @@
 
 #include "cm_types.h"
 
+#define CM_SLAB_CAP 65535u   // entries of a slab (the cooperative sweep's offsets are 16-bit)
+#define CM_SLAB_BLOCKS 128u  // blocks of a launch that works on slabs
 #define CM_DECL_LAUNCH(kname) void cm_launch_##kname(const CmDev &d, uint32_t n, hipStream_t s);
 void cm_launch_k_prep_count(const CmDev &d, uint32_t n_pairs, uint32_t max_read_len, hipStream_t s);
 void cm_launch_k_mm_fill(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, hipStream_t s);
@@ -30,10 +32,10 @@ void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, boo
 uint32_t cm_rescue_seg_cap(uint32_t n_reads);
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s);
 void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len);
-void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
+void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop);
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
-void cm_launch_k_s5b_verify(const CmDev &d, uint32_t n_items, uint32_t n_reads, hipStream_t s);
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s, bool coop);
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 CM_DECL_LAUNCH(k_s6c_multi)
 CM_DECL_LAUNCH(k_s6a_pair_sam)

@@ -630,26 +630,29 @@ __host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, u
 
 // S3b for long hit lists, merge-sort form (cm_coop_s3b): blockDim.x / G groups per block, one listed read each.  What the
 // function declines (more occurrence runs than its tables hold) is appended to fb_list for the bitonic kernel above.
+// use_slab: the launch has at most d.coop_slab_blocks blocks of one group each, block b works on slab b (lists longer than P)
 template <int G>
 __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
-                                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt) {
+                                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, uint32_t use_slab) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
-  const uint32_t gid = blockIdx.x * gpb + grp;
-  if (gid >= n_list) return;  // a whole group
   const size_t gb = cm_coop_group_bytes(P, MM, RB, false);
   uint8_t *base = cm_lds + (size_t)grp * gb;
-  const CmCoopMem m = cm_coop_mem_at(base, P, MM, RB, false);
+  CmCoopMem m = cm_coop_mem_at(base, P, MM, RB, false);
+  if (use_slab) cm_coop_slab_at(m, d.coop_slab + (size_t)blockIdx.x * cm_coop_slab_bytes(d.coop_slab_cap), d.coop_slab_cap);
   CmDevGroup<G> g;
   g.t = threadIdx.x % G;
   g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
-  const uint32_t r = list[gid];
-  if (!cm_coop_s3b(d, r, g, m) && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
+  for (uint32_t gid = blockIdx.x * gpb + grp; gid < n_list; gid += gridDim.x * gpb) {  // a whole group
+    const uint32_t r = list[gid];
+    if (!cm_coop_s3b(d, r, g, m) && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
+    g.sync();  // the work area is reused
+  }
 }
 
 // lists too long for the groups' LDS: one lane each, in the read's global segment (rare: > 8192 hits)
-__global__ __launch_bounds__(64) void k_s3b_serial(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list) {
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i < n_list) cm_s3b_candidates(d, list[i]);
+__global__ __launch_bounds__(64) void k_s3b_serial(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, const uint32_t *__restrict__ n_list_dev) {
+  if (n_list_dev) n_list = *n_list_dev;
+  for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < n_list; i += gridDim.x * 64) cm_s3b_candidates(d, list[i]);
 }
 
 // every lane with `pred` appends `value` to a device list: one atomic per wave (called by all lanes of the wave)
@@ -811,7 +814,7 @@ __device__ __forceinline__ void cm_group_rescue_fill(const CmDev &d, uint32_t r,
 __device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
   if (!coop || big <= CM_RS_COOP_MIN || d.hv_max[0] == 0) return 0;
-  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= d.hv_max[3] ? 11u : 0u;
+  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= d.hv_max[3] ? 11u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
 }
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
     cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, cls == 11u, r);
+    cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, cls == 15u, r);
   }
   const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
   for (uint32_t j0 = blockIdx.x * gpb; j0 < cnt; j0 += gridDim.x * gpb) {
@@ -848,17 +852,20 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     }
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, t == 0 && cls == c, r);
     cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, t == 0 && cls == 11u, r);
+    cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, t == 0 && cls == 15u, r);
   }
 }
 // S4b for the reads listed above: a group per read sorts its rescue hits, clusters them and merges them with the read's
 // candidates (cm_coop_rescue_merge).  The list's length is only known on the device: the grid strides over it.
 template <int G>
-__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev d, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev, uint32_t P, uint32_t RB) {
+__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev d, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev, uint32_t P, uint32_t RB,
+                                                                      uint32_t use_slab) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = *n_list_dev;
   const size_t gb = cm_coop_group_bytes(P, 1, RB, true);
   uint8_t *base = cm_lds + (size_t)grp * gb;
-  const CmCoopMem m = cm_coop_mem_at(base, P, 1, RB, true);
+  CmCoopMem m = cm_coop_mem_at(base, P, 1, RB, true);
+  if (use_slab) cm_coop_slab_at(m, d.coop_slab + (size_t)blockIdx.x * cm_coop_slab_bytes(d.coop_slab_cap), d.coop_slab_cap);
   CmDevGroup<G> g;
   g.t = threadIdx.x % G;
   g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
@@ -870,10 +877,12 @@ __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev 
 // S4c; long filtered candidate lists are queued for k_sort_lists.  coop: a pair with a merged candidate list longer than
 // CM_S4C_COOP_MIN entries only gets the part before the filter here and goes to list 9 for k_s4c_coop (a wave per pair).
 #define CM_S4C_COOP_MIN 48u
-__device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair, bool live) {
+#define CM_S5C_COOP_MIN 48u  // candidates of a read above which S5 (sorting the lists, alignments, acceptance) is a wave's work
+__device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair, bool live, uint32_t coop) {
   for (uint32_t q = 0; q < 4; ++q) {  // (read, strand) lists of the pair
     const uint32_t r = 2 * pair + (q >> 1);
-    const uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
+    uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
+    if ((coop & 8u) && !d.p.split && live && d.fcp[r] + d.fcn[r] > CM_S5C_COOP_MIN) cnt = 0;  // the S5 waves sort this read's lists themselves
     cm_wave_append(d.srt_list, &d.srt_cnt[0], cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX, (r << 1) | (q & 1u));
   }
 }
@@ -888,19 +897,19 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, ui
     uint32_t big = d.mcp[r1] > d.mcn[r1] ? d.mcp[r1] : d.mcn[r1];
     big = d.mcp[r2] > big ? d.mcp[r2] : big;
     big = d.mcn[r2] > big ? d.mcn[r2] : big;
-    if (coop && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : 0u;
+    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : 0u;
     if (!cls) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
   }
-  if (coop) {
+  if (coop & 4u) {
     cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, cls == 9u, pair);
     cm_wave_append(d.hv_list + 14 * (size_t)d.hv_stride, d.hv_cnt + 14, cls == 14u, pair);
   }
   if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
-  cm_s4c_queue_sort(d, pair, i < n && !cls && d.alive[pair]);
+  cm_s4c_queue_sort(d, pair, i < n && !cls && d.alive[pair], coop);
 }
 // the pairs of list 9 / 14: the filter's two directions by a wave / a block each (cm_coop_s4c); the list's length is on the device
 template <int G>
-__global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint32_t lid) {
+__global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint32_t lid, uint32_t coop) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = d.hv_cnt[lid];
   const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
@@ -919,14 +928,14 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint
       const bool live = j < n_list && d.alive[pair];
       for (uint32_t q = 0; q < 4; ++q) {
         const uint32_t r = 2 * pair + (q >> 1);
-        const uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
+        uint32_t cnt = live ? ((q & 1u) ? d.fcn[r] : d.fcp[r]) : 0u;
+        if ((coop & 8u) && live && d.fcp[r] + d.fcn[r] > CM_S5C_COOP_MIN) cnt = 0;  // sorted by the S5 waves
         if (g.t == 0 && cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | (q & 1u);
       }
     }
   }
 }
 // S5a.  coop: a read with more than CM_S5C_COOP_MIN candidates is left to a wave -- alignments and acceptance loop (k_s5c_coop, list 12)
-#define CM_S5C_COOP_MIN 48u
 __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, uint32_t coop) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
@@ -943,6 +952,18 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) 
   const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
   cm_wave_append(d.srt_list, &d.srt_cnt[0], a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX, r << 1);
   cm_wave_append(d.srt_list, &d.srt_cnt[0], b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX, (r << 1) | 1u);
+}
+// S5b of the reads in list 12: a wave per read, its lanes over the read's candidates (cm_coop_s5b)
+#define CM_SORT_NB 64u  // counts below this go through the groups' counting sort of a candidate list
+__global__ __launch_bounds__(CM_BLOCK) void k_s5b_coop(CmDev d) {
+  __shared__ uint16_t hist[CM_BLOCK * CM_SORT_NB];
+  const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
+  const uint32_t n_list = d.hv_cnt[12];
+  const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
+  CmDevGroup<64> g;
+  g.t = threadIdx.x % 64;
+  g.xw = nullptr;
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s5b(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB);
 }
 __global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P) {
   const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
@@ -1502,7 +1523,7 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     if (n_cls[0]) {  // a wave per read, two reads per block
       const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB, false);
       if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
-        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt);
+        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt, 0u);
         rest[0] = 0; any_coop = true;
       }
     }
@@ -1510,14 +1531,24 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     if (n_cls[C_] && d.hv_max[Q_] > d.hv_max[Q_ - 1]) {                                                                                            \
       const size_t lds = cm_coop_group_bytes(d.hv_max[Q_], MM, RB, false);                                                                         \
       if (cm_lds_optin(&k_s3b_coop<G_>, lds)) {                                                                                                    \
-        hipLaunchKernelGGL(k_s3b_coop<G_>, dim3(n_cls[C_]), dim3(G_), lds, s, d, lst(C_), n_cls[C_], d.hv_max[Q_], MM, RB, fb_list, fb_cnt);      \
+        hipLaunchKernelGGL(k_s3b_coop<G_>, dim3(n_cls[C_]), dim3(G_), lds, s, d, lst(C_), n_cls[C_], d.hv_max[Q_], MM, RB, fb_list, fb_cnt, 0u);  \
         rest[C_] = 0; any_coop = true;                                                                                                             \
       }                                                                                                                                            \
     }
-    CM_S3B_COOP_CLASS(1, 1, 256)
-    CM_S3B_COOP_CLASS(2, 2, 512)
+    CM_S3B_COOP_CLASS(1, 1, 512)
+    CM_S3B_COOP_CLASS(2, 2, 1024)
     CM_S3B_COOP_CLASS(10, 3, 1024)
 #undef CM_S3B_COOP_CLASS
+    if (n_cls[3] && d.coop_slab && d.hv_max[3]) {  // lists beyond the largest class: 1024 lanes on a slab of global memory each
+      const size_t lds = cm_coop_group_bytes(d.hv_max[3], MM, RB, false);
+      if (cm_lds_optin(&k_s3b_coop<1024>, lds)) {
+        const uint32_t blocks = n_cls[3] < d.coop_slab_blocks ? n_cls[3] : d.coop_slab_blocks;
+        uint32_t *sl = d.hv_list + 16 * (size_t)d.hv_stride, *sc = d.hv_cnt + 16;  // what even that declines: one lane each
+        hipLaunchKernelGGL(k_s3b_coop<1024>, dim3(blocks), dim3(1024), lds, s, d, lst(3), n_cls[3], d.hv_max[3], MM, RB, sl, sc, 1u);
+        hipLaunchKernelGGL(k_s3b_serial, dim3(64), dim3(64), 0, s, d, (const uint32_t *)sl, 0u, (const uint32_t *)sc);
+        rest[3] = 0;
+      }
+    }
     if (any_coop) {  // the declined reads: up to hv_max[3] hits, a block each, the grid strides over the device-side list
       const uint32_t P = pow2(d.hv_max[3]);
       hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(512), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, (const uint32_t *)fb_list, 0u, P, (const uint32_t *)fb_cnt);
@@ -1534,7 +1565,7 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     const uint32_t P = pow2(d.hv_max[blk[q][1]]);
     hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[c]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(c), rest[c], P, (const uint32_t *)nullptr);
   }
-  if (rest[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((rest[3] + 63) / 64), dim3(64), 0, s, d, lst(3), rest[3]);
+  if (rest[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((rest[3] + 63) / 64), dim3(64), 0, s, d, lst(3), rest[3], (const uint32_t *)nullptr);
   if (rest[4]) {  // groups of 16 lanes, 16 reads per block
     const uint32_t P = pow2(d.hv_mid), gpb = CM_BLOCK / 16;
     hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((rest[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, lst(4), rest[4], P, (const uint32_t *)nullptr);
@@ -1592,22 +1623,25 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
   if (blocks > 2048) blocks = 2048;
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
-  hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB);
-  if (d.hv_max[1] > d.hv_max[0]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB);
-  if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB);
-  if (d.hv_max[3] > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.hv_max[3], RB);
+  hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB, 0u);
+  if (d.hv_max[1] > d.hv_max[0]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB, 0u);
+  if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
+  if (d.hv_max[3] > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.hv_max[3], RB, 0u);
+  if (d.coop_slab)  // lists beyond the largest class: on the blocks' slabs of global memory
+    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[3], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), d.hv_max[3], RB, 1u);
 }
-void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+// coop: the cmgpu_set_option "coop" bit mask (bit 2: pairs with long lists to groups; bit 3: the S5 waves sort the heavy reads' lists)
+void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop) {
   if (!n) return;
   const size_t gw = ((cm_coop_pair_mem_bytes(CM_S4C_P_WAVE) + 15) & ~(size_t)15) + CM_XW_BYTES;
   const size_t gbk = ((cm_coop_pair_mem_bytes(CM_S4C_P_BLOCK) + 15) & ~(size_t)15) + CM_XW_BYTES;
-  coop = coop && cm_lds_optin(&k_s4c_coop<CM_BLOCK>, gbk);
-  hipLaunchKernelGGL(k_s4c_reduce, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
-  if (!coop) return;
+  if (!cm_lds_optin(&k_s4c_coop<CM_BLOCK>, gbk)) coop &= ~4u;
+  hipLaunchKernelGGL(k_s4c_reduce, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop);
+  if (!(coop & 4u)) return;
   uint32_t blocks = n / 2048 + 64;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_s4c_coop<64>, dim3(blocks), dim3(128), 2 * gw, s, d, CM_S4C_P_WAVE, 9u);
-  hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u);
+  hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
+  hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
 }
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (n) hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
@@ -1625,11 +1659,13 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
 // max_items: an upper bound of the item count (the capacity of the candidate arrays)
-void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s) {
+// coop: the reads k_s5a_prepare listed get their alignments from waves of their own
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s, bool coop) {
   if (!max_items) return;
   uint32_t blocks = (max_items + CM_BLOCK - 1) / CM_BLOCK;
   if (blocks > 65536) blocks = 65536;  // grid-stride beyond
   hipLaunchKernelGGL(k_s5b_verify, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n_reads);
+  if (coop) hipLaunchKernelGGL(k_s5b_coop, dim3(8192), dim3(CM_BLOCK), 0, s, d);
 }
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;

@@ -37,6 +37,8 @@ extern "C" void hostemu_set_coop(int G, uint32_t thr, uint32_t P, uint32_t MM, u
   g_coop = EmuCoop{G, thr, P, MM, RB};
   memset(g_coop_items, 0, sizeof(g_coop_items));
 }
+static uint32_t g_coop_slab = 0;  // entries of the global-memory slab lists longer than P use (0: none -- such lists are declined)
+extern "C" void hostemu_set_coop_slab(uint32_t cap) { g_coop_slab = cap; }
 static bool g_coop_reverse = false;  // lanes take their turns in descending order (emu_group.h)
 extern "C" void hostemu_set_coop_order(int reverse) { g_coop_reverse = reverse != 0; }
 extern "C" void hostemu_coop_items(unsigned long long *out) { memcpy(out, g_coop_items, sizeof(g_coop_items)); }
@@ -45,7 +47,9 @@ template <int G>
 static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std::vector<uint8_t> &ok) {
   std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB, false) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
-  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, false);
+  CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, false);
+  std::vector<uint8_t> slab(g_coop_slab ? cm_coop_slab_bytes(g_coop_slab) + 16 : 0);
+  if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
       const bool done = cm_coop_s3b(d, list[i], g, m);
@@ -59,7 +63,9 @@ template <int G>
 static void emu_coop_rescue(const CmDev &d, const std::vector<uint32_t> &list) {
   std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB, true) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
-  const CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, true);
+  CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, true);
+  std::vector<uint8_t> slab(g_coop_slab ? cm_coop_slab_bytes(g_coop_slab) + 16 : 0);
+  if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
       cm_coop_rescue_merge(d, list[i], g, m);
@@ -88,8 +94,11 @@ static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list) {
   std::vector<uint8_t> mem(cm_coop_ver_mem_bytes(P) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
   const CmCoopVerMem m = cm_coop_ver_mem_at(base, P);
+  std::vector<uint16_t> hist((size_t)G * 64);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
+      cm_coop_s5b(d, list[i], g, hist.data(), 64);
+      g.sync();
       cm_coop_s5c(d, list[i], g, m);
       g.sync();
     }
@@ -600,7 +609,9 @@ static int emu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c, uint32_
   for (uint32_t i = 0; i < cnt; ++i) go[n1 + i] = hits[i];
   std::vector<uint8_t> mem(cm_coop_mem_bytes(P, 4, RB, true) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
-  const CmCoopMem m = cm_coop_mem_at(base, P, 4, RB, true);
+  CmCoopMem m = cm_coop_mem_at(base, P, 4, RB, true);
+  std::vector<uint8_t> slab(g_coop_slab ? cm_coop_slab_bytes(g_coop_slab) + 16 : 0);
+  if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   uint32_t got = 0;
   emu_run_group<G>([&](EmuGroup<G> &g) {
     const uint32_t k = cm_coop_rescue_dir(d, 0, g, m, go.data(), goc.data(), n1, cnt, true, c0p, c0c, zp.data(), zc.data());
@@ -722,4 +733,21 @@ extern "C" int hostemu_pairing_check(const uint64_t *ap0, const int16_t *ae0, ui
   if (G == 16) return emu_pairing_check<16>(ap0, ae0, na0, bp0, be0, nb0, ap1, ae1, na1, bp1, be1, nb1, len1, len2, e, max_insert, min_read_len, reverse != 0);
   if (G == 64) return emu_pairing_check<64>(ap0, ae0, na0, bp0, be0, nb0, ap1, ae1, na1, bp1, be1, nb1, len1, len2, e, max_insert, min_read_len, reverse != 0);
   return emu_pairing_check<256>(ap0, ae0, na0, bp0, be0, nb0, ap1, ae1, na1, bp1, be1, nb1, len1, len2, e, max_insert, min_read_len, reverse != 0);
+}
+
+// cm_coop_sort_cand against cm_sort_cand on caller-made candidate lists.  Returns 0 when equal.
+template <int G>
+static int emu_sort_cand_check(const uint64_t *p, const uint8_t *c, uint32_t n, uint32_t nb_cap, bool reverse) {
+  std::vector<uint64_t> sp(p, p + n), gp(p, p + n), tp(n + 1);
+  std::vector<uint8_t> sc(c, c + n), gc(c, c + n), tc(n + 1);
+  cm_sort_cand(sp.data(), sc.data(), n);
+  std::vector<uint16_t> hist((size_t)G * nb_cap);
+  emu_run_group<G>([&](EmuGroup<G> &g) { cm_coop_sort_cand(g, gp.data(), gc.data(), n, tp.data(), tc.data(), hist.data(), nb_cap); }, reverse);
+  for (uint32_t i = 0; i < n; ++i) if (gp[i] != sp[i] || gc[i] != sc[i]) return 1;
+  return 0;
+}
+extern "C" int hostemu_sort_cand_check(const uint64_t *p, const uint8_t *c, uint32_t n, uint32_t nb_cap, int G, int reverse) {
+  if (G == 16) return emu_sort_cand_check<16>(p, c, n, nb_cap, reverse != 0);
+  if (G == 64) return emu_sort_cand_check<64>(p, c, n, nb_cap, reverse != 0);
+  return emu_sort_cand_check<256>(p, c, n, nb_cap, reverse != 0);
 }

@@ -11,10 +11,12 @@ import hostemu_lib as he
 from test_hostemu_fuzz import run_case
 
 
-def _set(L, G, thr, P, MM, RB, reverse=0):
+def _set(L, G, thr, P, MM, RB, reverse=0, slab=0):
     L.hostemu_set_coop.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.hostemu_set_coop(G, thr, P, MM, RB)
     L.hostemu_set_coop_order(int(reverse))
+    L.hostemu_set_coop_slab.argtypes = [C.c_uint32]
+    L.hostemu_set_coop_slab(int(slab))
 
 
 def _items(L):
@@ -25,17 +27,19 @@ def _items(L):
 
 # (group size, list length above which a read goes to the group, hits the work area holds, minimizer table, run table)
 # + whether the emulated lanes take their turns in descending order
-GEOMETRIES = [(64, 8, 8192, 64, 130, 0), (256, 16, 8192, 64, 130, 1), (16, 8, 2048, 64, 130, 1), (64, 8, 700, 5, 11, 1),
-              (1024, 64, 8192, 64, 130, 0)]
+# + the entries of the global-memory slab that lists longer than the work area use (0: such lists are declined)
+GEOMETRIES = [(64, 8, 8192, 64, 130, 0, 0), (256, 16, 8192, 64, 130, 1, 0), (16, 8, 2048, 64, 130, 1, 0), (64, 8, 700, 5, 11, 1, 0),
+              (1024, 64, 8192, 64, 130, 0, 0), (64, 8, 40, 64, 130, 1, 20000)]
 
 
 # every fuzz configuration through wave-sized groups; the other group sizes and the decline path on one or two of them
 CASES = [(c, GEOMETRIES[0]) for c in fuzz_data.CONFIGS[:4]] + [(fuzz_data.CONFIGS[0], GEOMETRIES[1]), (fuzz_data.CONFIGS[3], GEOMETRIES[1]),
                                                                 (fuzz_data.CONFIGS[1], GEOMETRIES[2]), (fuzz_data.CONFIGS[0], GEOMETRIES[3]),
-                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[4])]
+                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[4]), (fuzz_data.CONFIGS[0], GEOMETRIES[5]),
+                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[5])]
 
 
-@pytest.mark.parametrize("cfg,geo", CASES, ids=["%d-G%d_P%d_MM%d" % (c[0], g[0], g[2], g[3]) for c, g in CASES])
+@pytest.mark.parametrize("cfg,geo", CASES, ids=["%d-G%d_P%d_MM%d%s" % (c[0], g[0], g[2], g[3], "_slab" if g[6] else "") for c, g in CASES])
 def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
     L = he.lib()
 
@@ -46,7 +50,7 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
             rec, k, st, _ = h.map_pairs(b1, o1, b2, o2)
             items = _items(L)
         finally:
-            _set(L, 0, 0, 0, 0, 0, 0)
+            _set(L, 0, 0, 0, 0, 0, 0, 0)
         factory.items = items
         return rec, k, st.as_dict()
     run_case(factory, cfg, tmp_path)
@@ -98,11 +102,14 @@ def test_cooperative_sort_sweep_merge_on_adversarial_lists():
         hits = np.concatenate([np.sort(hits[p]) for p in parts]) if len(hits) else hits
         c0c = rng.integers(1, 9, len(c0)).astype(np.uint8)
         G = int(rng.choice([16, 64, 256]))
-        P = int(rng.choice([64, 1024])) if it % 9 == 0 else 1024
+        P = int(rng.choice([64, 1024])) if it % 4 == 0 else 1024
         RB = int(rng.choice([3, 90]))
         c0 = np.ascontiguousarray(c0, np.uint64)
         hits = np.ascontiguousarray(hits, np.uint64)
+        L.hostemu_set_coop_slab.argtypes = [C.c_uint32]
+        L.hostemu_set_coop_slab(2000 if it % 3 == 0 else 0)  # lists longer than P: on the slab, or (no slab) by one lane
         rc = f(c0.ctypes.data, c0c.ctypes.data, len(c0), hits.ctypes.data, len(hits), e, int(rng.integers(1, 12)), G, P, RB, it & 1)
+        L.hostemu_set_coop_slab(0)
         assert rc == 0, (it, mode, e, len(c0), len(hits), G, P, RB, rc)
 
 
@@ -196,3 +203,24 @@ def test_cooperative_pairing_on_adversarial_lists():
                lists[2][0].ctypes.data, lists[2][1].ctypes.data, len(lists[2][0]), lists[3][0].ctypes.data, lists[3][1].ctypes.data, len(lists[3][0]),
                int(rng.integers(30, 51)), int(rng.integers(30, 51)), e, int(rng.choice([300, 1000, 2000])), 30, G, it & 1)
         assert rc == 0, (it, e, span, [len(x[0]) for x in lists], G, rc)
+
+
+def test_cooperative_candidate_sort():
+    """cm_coop_sort_cand (counting sort by count of a position-ordered list) against cm_sort_cand: few and many distinct
+    counts, counts at and above the bin capacity (one-lane path), lists that are not in position order (one-lane path)"""
+    import numpy as np
+    L = he.lib()
+    f = L.hostemu_sort_cand_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    rng = np.random.default_rng(12)
+    for it in range(800):
+        n = int(rng.integers(0, 1500))
+        pos = np.unique((rng.integers(0, 3, n).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 22, n).astype(np.uint64))
+        if it % 11 == 0 and len(pos) > 3:
+            pos = pos[rng.permutation(len(pos))]  # --chr-order re-ranking leaves lists out of position order
+        cmax = int(rng.choice([2, 9, 40, 70]))
+        cnt = rng.integers(1, cmax + 1, len(pos)).astype(np.uint8)
+        pos = np.ascontiguousarray(pos)
+        rc = f(pos.ctypes.data, cnt.ctypes.data, len(pos), 64, int(rng.choice([16, 64, 256])), it & 1)
+        assert rc == 0, (it, len(pos), cmax)
