@@ -795,6 +795,45 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
   g.sync();
 }
 
+// ---------------------------------------------------------------------------------------
+// SortMappingsByPositions (mapping_metadata.h:70-78) for the draft mappings a read's acceptance loop just wrote, by the group.
+// They stand in candidate order -- count descending, position ascending -- i.e. a few ascending runs (one per count value):
+// natural runs + merge sort of the packed keys (position << 6 | errors; the order among equal positions is free).  Lists of up
+// to m.P entries in shared memory, longer ones in place with `scratch` (global memory, nd entries) as the second buffer.  Left
+// unsorted -- the pairing stage then sorts them as before -- when the keys cannot be packed (more than 2^25 sequences, an error
+// threshold above 62) or there are more runs than m.RB.
+// ---------------------------------------------------------------------------------------
+struct CmCoopSortMem { uint64_t *A, *B; uint32_t *rb, *rb2; uint32_t P, RB; };
+CM_HD size_t cm_coop_sort_mem_bytes(uint32_t P, uint32_t RB) { return (size_t)P * 16 + (size_t)(RB + 1) * 8 + 32; }
+CM_HD CmCoopSortMem cm_coop_sort_mem_at(uint8_t *base, uint32_t P, uint32_t RB) {
+  CmCoopSortMem m;
+  m.P = P; m.RB = RB;
+  m.A = reinterpret_cast<uint64_t *>(base);
+  m.B = m.A + P;
+  m.rb = reinterpret_cast<uint32_t *>(m.B + P);
+  m.rb2 = m.rb + RB + 1;
+  return m;
+}
+template <class GT>
+CM_HD void cm_coop_sort_draft(const CmDev &d, GT &g, const CmCoopSortMem &m, uint64_t *dp, int16_t *de, uint32_t nd, uint64_t *scratch) {
+  const uint32_t G = (uint32_t)GT::G;
+  if (nd < 2 || d.n_seq > (1u << 25) || d.p.e > 62) return;
+  const bool in_lds = nd <= m.P;
+  uint64_t *A = in_lds ? m.A : dp, *B = in_lds ? m.B : scratch;
+  for (uint32_t i = g.t; i < nd; i += G) A[i] = (dp[i] << 6) | (uint64_t)(uint16_t)de[i];
+  g.sync();
+  const uint32_t nr = cm_coop_natural_runs(g, A, nd, m.rb, m.RB);
+  const uint64_t *S = A;
+  if (nr > 1) S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, nd);
+  // unpack (nr == 0: too many runs -- the keys go back as they came)
+  if (S == dp) {  // in place: every lane its own entries
+    for (uint32_t i = g.t; i < nd; i += G) { const uint64_t k = dp[i]; dp[i] = k >> 6; de[i] = (int16_t)(k & 63u); }
+  } else {
+    for (uint32_t i = g.t; i < nd; i += G) { const uint64_t k = S[i]; dp[i] = k >> 6; de[i] = (int16_t)(k & 63u); }
+  }
+  g.sync();
+}
+
 // S5b for a read cm_s5a_prepare left to the groups (nv[r] == 0, candidate lists NOT yet sorted): the group sorts the two lists
 // (cm_coop_sort_cand), then a lane per candidate runs the banded alignment (cm_s5b_verify_at) -- no work-item search, the read's
 // own quantities loaded once per lane.
@@ -809,8 +848,9 @@ CM_HD void cm_coop_s5b(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32
   for (uint32_t li = g.t; li < nc; li += (uint32_t)GT::G) cm_s5b_verify_at(d, r, li < ncp ? 0 : 1, li < ncp ? li : li - ncp);
 }
 // S5c for such a read, after cm_coop_s5b
+// sm: work area of the draft-mapping sort that follows the acceptance loop (it may overlay m: the loop's arrays are dead by then)
 template <class GT>
-CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m) {
+CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m, const CmCoopSortMem &sm) {
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
   if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: one lane
     if (g.t == 0) cm_s5c_accept(d, r);
@@ -823,6 +863,11 @@ CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m)
   if (g.t == 0) {
     d.ndp[r] = ndp; d.ndn[r] = ndn;
     d.min_err[r] = best.lo; d.second_err[r] = best.hi; d.n_best[r] = best.n_lo; d.n_second[r] = best.n_hi;
+  }
+  if (!d.p.single) {  // the pairing stage wants them by position (single-end keeps the emission order)
+    g.sync();
+    cm_coop_sort_draft(d, g, sm, d.dpos + op, d.derr + op, ndp, d.fbuf + op);  // the candidate lists are dead: scratch
+    cm_coop_sort_draft(d, g, sm, d.dpos + on, d.derr + on, ndn, d.fbuf + on);
   }
 }
 

@@ -965,26 +965,22 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_coop(CmDev d) {
   g.xw = nullptr;
   for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s5b(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB);
 }
+#define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
+#define CM_S5C_SORT_RB 130u
 __global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P) {
   const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[12];
   const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
-  const size_t gb = ((cm_coop_ver_mem_bytes(P) + 15) & ~(size_t)15);
+  const size_t b1 = cm_coop_ver_mem_bytes(P), b2 = cm_coop_sort_mem_bytes(CM_S5C_SORT_P, CM_S5C_SORT_RB);
+  const size_t gb = (((b1 > b2 ? b1 : b2) + 15) & ~(size_t)15);  // the sort's buffers overlay the acceptance loop's arrays
   const CmCoopVerMem m = cm_coop_ver_mem_at(cm_lds + (size_t)grp * gb, P);
+  const CmCoopSortMem sm = cm_coop_sort_mem_at(cm_lds + (size_t)grp * gb, CM_S5C_SORT_P, CM_S5C_SORT_RB);
   CmDevGroup<64> g;
   g.t = threadIdx.x % 64;
   g.xw = nullptr;
-  for (uint32_t j0 = blockIdx.x * gpb; j0 < n_list; j0 += gridDim.x * gpb) {
-    const uint32_t j = j0 + grp;
-    const uint32_t r = j < n_list ? list[j] : 0u;
-    if (j < n_list) cm_coop_s5c(d, r, g, m);
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) {
+    cm_coop_s5c(d, list[j], g, m, sm);
     g.sync();
-    if (d.perm_reads && !d.p.split && !d.p.single) {
-      const bool live = j < n_list && d.alive[r >> 1];
-      const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
-      if (g.t == 0 && a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = r << 1;
-      if (g.t == 0 && b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX) d.srt_list[atomicAdd(&d.srt_cnt[0], 1u)] = (r << 1) | 1u;
-    }
   }
 }
 
@@ -1651,10 +1647,11 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
   hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);
   if (!coop) return;
   const uint32_t P = 2048;  // candidates of a strand the wave's work arrays hold (longer lists: its lane 0)
-  const size_t gb = ((cm_coop_ver_mem_bytes(P) + 15) & ~(size_t)15);
+  const size_t b1 = cm_coop_ver_mem_bytes(P), b2 = cm_coop_sort_mem_bytes(CM_S5C_SORT_P, CM_S5C_SORT_RB);
+  const size_t gb = (((b1 > b2 ? b1 : b2) + 15) & ~(size_t)15);
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s5c_coop, dim3(blocks), dim3(CM_BLOCK), 4 * gb, s, d, P);
+  hipLaunchKernelGGL(k_s5c_coop, dim3(blocks), dim3(192), 3 * gb, s, d, P);  // three waves per block: under the 64 KB a launch gets without asking
 }
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)

@@ -95,11 +95,14 @@ static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list) {
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
   const CmCoopVerMem m = cm_coop_ver_mem_at(base, P);
   std::vector<uint16_t> hist((size_t)G * 64);
+  // the sort's work area deliberately small: lists beyond 32 entries sort in global memory
+  std::vector<uint8_t> smem(cm_coop_sort_mem_bytes(32, 40) + 16);
+  const CmCoopSortMem sm = cm_coop_sort_mem_at(smem.data() + ((16 - ((uintptr_t)smem.data() & 15)) & 15), 32, 40);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
       cm_coop_s5b(d, list[i], g, hist.data(), 64);
       g.sync();
-      cm_coop_s5c(d, list[i], g, m);
+      cm_coop_s5c(d, list[i], g, m, sm);
       g.sync();
     }
   }, g_coop_reverse);
