@@ -230,14 +230,23 @@ def roofline(g, args, s, steps, stage_ms):
     """kernel-only measurement of the index probe (HIP events on the launch stream) against the swept random-gather
     ceiling of the same table"""
     n_mm = s["num_minimizers"] // steps
-    probe_steps = s["probe_steps"] / steps
-    alg_bytes = 16.0 * probe_steps  # SURVEY 8(d): one 8-B key + one 8-B value per visited bucket
+    # the file's table (khash layout, load 0.7): its probe steps are SURVEY 8(d)'s algorithmic unit -- what kh_get visits for these lookups
+    favg, fps, fhits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    file_layout = None
+    if g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, args.probe_repeat, 1, 2, C.byref(favg), C.byref(fps), C.byref(fhits)) == 0 and favg.value > 0:
+        file_layout = {"lookups": int(n_mm), "avg_ms": round(favg.value, 4), "probe_steps": int(fps.value), "hits": int(fhits.value),
+                       "GB/s": round(16.0 * fps.value / (favg.value * 1e-3) / 1e9, 1), "buckets": g.get_option("probe_table_buckets") >> max(0, args.probe_table_shift)}
+    probe_steps = fps.value if fps.value else s["probe_steps"] / steps
+    alg_bytes = 16.0 * probe_steps  # SURVEY 8(d): one 8-B key + one 8-B value per bucket kh_get visits
     avg, ps, hits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     probe_only, achieved, probe_ms = None, 0.0, 0.0
     if g.L.cmgpu_probe_bench(g.ctx, None, n_mm, args.probe_repeat, C.byref(avg), C.byref(ps), C.byref(hits), None) == 0 and avg.value > 0:
-        probe_only = {"lookups": int(n_mm), "avg_ms": round(avg.value, 4), "probe_steps": int(ps.value), "hits": int(hits.value),
-                      "GB/s": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9, 1), "G_lookups/s": round(n_mm / (avg.value * 1e-3) / 1e9, 2)}
+        probe_only = {"lookups": int(n_mm), "avg_ms": round(avg.value, 4), "buckets_visited": int(ps.value), "hits": int(hits.value),
+                      "table_buckets": g.get_option("probe_table_buckets"),
+                      "GB/s": round(alg_bytes / (avg.value * 1e-3) / 1e9, 1), "GB/s_of_buckets_visited": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9, 1),
+                      "G_lookups/s": round(n_mm / (avg.value * 1e-3) / 1e9, 2)}
         achieved, probe_ms = probe_only["GB/s"], avg.value
+        assert hits.value == fhits.value or not fps.value, "the re-hashed table answers differently"
     variants = []
     for u in (1, 2, 4, 8):
         for pair in (0, 1):
@@ -267,11 +276,17 @@ def roofline(g, args, s, steps, stage_ms):
             "traffic_source": "from_profile: profiles/probe_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, "
                               "tools/profile_bench.sh), not measured in this run",
             "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
+            "probe_on_file_layout": file_layout,
+            "table_note": "the graded launch probes the device's re-hashed copy of the table (cmgpu_set_option probe_table_shift = %d: %d buckets; same "
+                          "keys, values, hash and probe sequence, so hit / miss / value of every lookup are the file table's -- asserted here -- and "
+                          "fewer buckets are visited); algorithmic bytes = 16 B x the buckets kh_get visits in the FILE's table for the same lookups "
+                          "(SURVEY 8(d)); probe_on_file_layout is the same kernel on that table"
+                          % (args.probe_table_shift, g.get_option("probe_table_buckets")) if args.probe_table_shift else "the graded launch probes the file's table",
             "probe_variants": variants, "random_gather_sweep": sweep, "random_gather_ceiling": best}
     if best and probe_only:
         # useful: bucket reads of the probe against 16-byte accesses of the ceiling shape;
         # sector: 64-byte sectors the probe fetched (PMC, profiles/probe_traffic.json) against the ceiling's sectors
-        roof["useful_frac"] = round((ps.value / (avg.value * 1e-3) / 1e9) / best["G_accesses/s"], 3)
+        roof["useful_frac"] = round((ps.value / (avg.value * 1e-3) / 1e9) / best["G_accesses/s"], 3)  # bucket reads of this launch / ceiling
         if sectors_per_lookup:
             roof["sector_frac"] = round((n_mm * sectors_per_lookup / (avg.value * 1e-3) / 1e9) / best["G_accesses/s"], 3)
         roof["frac_of_measured_gather"] = roof["useful_frac"]
@@ -312,6 +327,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL record exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--lanes", type=int, default=3, help="ranges of a batch mapped side by side (cmgpu_set_option lanes); measured best for resident batches")
+    ap.add_argument("--probe-table-shift", type=int, default=2,
+                    help="the pipeline probes a device copy of the index table re-hashed into 2^shift times as many buckets (same keys, values, "
+                         "hash and probe sequence: identical lookups, fewer buckets visited); 0: the file's table")
     ap.add_argument("--option", action="append", default=[], help="name=value for cmgpu_set_option (measurement knobs)")
     args = ap.parse_args()
 
@@ -360,6 +378,8 @@ def main():
         # lanes and the record exchange do not mix well on one GPU (measured: 3 lanes 429 -> 366 M pairs/s with the exchange,
         # 1 lane 404 -> 388): ranks that exchange map their batch in one piece
         g_.set_option("lanes", 1 if exchange else args.lanes)
+        if args.probe_table_shift:
+            g_.set_option("probe_table_shift", args.probe_table_shift)
         for o in args.option:
             k_, v_ = o.split("=")
             g_.set_option(k_, int(v_))

@@ -54,6 +54,7 @@ void DevBuf::release() {
 }
 
 // tuning knobs for measurements (defaults are what the measurements chose)
+static int build_fast_table(cmgpu_ctx *c, int shift);
 extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   if (!c || !name) return CMGPU_EINVAL;
   const std::string n(name);
@@ -93,6 +94,9 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_heavy_mid = (int)value;
   } else if (n == "heavy_last") {
     c->opt_heavy_last = (int)value;
+  } else if (n == "probe_table_shift") {  // 0: probe the file's table; 1 / 2: a device copy with 2 / 4 times the buckets
+    if (value < 0 || value > 4) { cm_set_error(c, "probe_table_shift: 0..4"); return CMGPU_EINVAL; }
+    return build_fast_table(c, (int)value);
   } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
     c->opt_coop_rb = (int)value;
   } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
@@ -119,6 +123,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
   else if (n == "lanes") *value = c->opt_lanes;
   else if (n == "coop") *value = c->opt_coop;
+  else if (n == "probe_table_buckets") *value = c->fmask ? (int64_t)c->fmask + 1 : (int64_t)c->bmask + 1;
   else return CMGPU_EINVAL;
   return CMGPU_OK;
 }
@@ -140,6 +145,41 @@ __global__ void k_repack(const uint32_t *__restrict__ flags, const uint64_t *__r
   else if (f & 1u) { k = CM_DELETED_KEY; v = 0; }
   bkt[2 * (uint64_t)i] = k;
   bkt[2 * (uint64_t)i + 1] = v;
+}
+
+// the table re-hashed into `mask + 1` buckets (a power of two, larger): every occupied bucket of the file layout is inserted at
+// the first empty bucket of khash's own probe sequence (hash & mask, then += 1, 2, 3, ...), so kh_get's walk finds the same keys
+// with the same values and stops at an empty bucket for the others; only the number of buckets it visits changes
+__global__ __launch_bounds__(256) void k_rehash(const uint64_t *__restrict__ src, uint64_t n_src, uint64_t *__restrict__ dst, uint32_t mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_src) return;
+  const uint64_t key = src[2 * i], val = src[2 * i + 1];
+  if (key == CM_EMPTY_KEY || key == CM_DELETED_KEY) return;
+  uint32_t b = (uint32_t)(key >> 1) & mask, step = 0;
+  for (;;) {
+    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(dst + 2 * (uint64_t)b), (unsigned long long)CM_EMPTY_KEY, (unsigned long long)key);
+    if (old == CM_EMPTY_KEY) { dst[2 * (uint64_t)b + 1] = val; return; }
+    b = (b + (++step)) & mask;
+  }
+}
+static int build_fast_table(cmgpu_ctx *c, int shift) {
+  HIPCHECK(c, cm_enter(c));
+  HIPCHECK(c, cm_stream_sync(c->stream));
+  c->bkt_fast.release();
+  c->fmask = 0;
+  if (shift <= 0) return CMGPU_OK;
+  if (!c->bkt.p || !c->bkt.owned) { cm_set_error(c, "probe_table_shift: set it on the context that owns the index"); return CMGPU_EINVAL; }
+  const uint64_t nb = (uint64_t)c->bmask + 1;
+  uint64_t nf = nb << shift;
+  if (nf > (1ull << 32)) nf = 1ull << 32;  // khash starts at the low 32 bits of the hash
+  if (nf <= nb) return CMGPU_OK;
+  if (c->bkt_fast.ensure((size_t)nf * 16)) { cm_set_error(c, "out of device memory (re-hashed index table)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemsetAsync(c->bkt_fast.p, 0xff, (size_t)nf * 16, c->stream));
+  hipLaunchKernelGGL(k_rehash, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t *)c->bkt.p, nb, (uint64_t *)c->bkt_fast.p,
+                     (uint32_t)(nf - 1));
+  HIPCHECK(c, cm_stream_sync(c->stream));
+  c->fmask = (uint32_t)(nf - 1);
+  return CMGPU_OK;
 }
 
 static int build_mapq_tables(cmgpu_ctx *c) {
@@ -602,7 +642,7 @@ void cm_fill_dev(cmgpu_ctx *c, CmDev &d) { cm_fill_dev_range(c, d, 0, c->n_pairs
 // the intermediates (indexed from 0) are reused by every sub-batch
 void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   memset(&d, 0, sizeof(d));
-  d.bkt = (const uint64_t *)c->bkt.p; d.bmask = c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
+  d.bkt = (const uint64_t *)(c->fmask ? c->bkt_fast.p : c->bkt.p); d.bmask = c->fmask ? c->fmask : c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
   d.n_seq = c->n_seq;
   d.p = c->p;
@@ -882,7 +922,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
   mark(c, "s5a_prepare");
-  cm_launch_k_s5b_verify(d, n_m, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
+  cm_launch_k_s5b_verify(d, n_m, n2, s);
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s5c_finalize(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
@@ -963,6 +1003,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   }
   cmgpu_ctx *l = c->lanes[i];
   auto view = [](DevBuf &dst, const DevBuf &src) { dst.p = src.p; dst.cap = src.cap; dst.owned = false; };
+  view(l->bkt_fast, c->bkt_fast); l->fmask = c->fmask;
   view(l->rb0, c->rb0); view(l->rb1, c->rb1); view(l->ro0, c->ro0); view(l->ro1, c->ro1);
   view(l->rec, c->rec); view(l->rec_ok, c->rec_ok);
   view(l->bcb, c->bcb); view(l->bcq, c->bcq); view(l->bco, c->bco); view(l->bc_key, c->bc_key); view(l->bc_ok, c->bc_ok);
@@ -1273,7 +1314,8 @@ extern "C" int cmgpu_probe_bench(cmgpu_ctx *c, const uint64_t *hashes, uint64_t 
 extern "C" int cmgpu_probe_bench_variant(cmgpu_ctx *c, uint64_t n, int repeat, int lookups_per_lane, int pair_prefetch, double *avg_ms,
                                          uint64_t *probe_steps, uint64_t *hits) {
   if (lookups_per_lane != 1 && lookups_per_lane != 2 && lookups_per_lane != 4 && lookups_per_lane != 8) return CMGPU_EINVAL;
-  return probe_bench_impl(c, nullptr, n, repeat, lookups_per_lane | (pair_prefetch ? 16 : 0), avg_ms, probe_steps, hits, nullptr);
+  // pair_prefetch bit 0: second probe step requested with the first; bit 1: the file's table even when a re-hashed one is resident
+  return probe_bench_impl(c, nullptr, n, repeat, lookups_per_lane | ((pair_prefetch & 1) ? 16 : 0) | ((pair_prefetch & 2) ? 32 : 0), avg_ms, probe_steps, hits, nullptr);
 }
 static int probe_bench_impl(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, int repeat, int variant, double *avg_ms,
                             uint64_t *probe_steps, uint64_t *hits, uint64_t *occurrences) {
@@ -1292,14 +1334,18 @@ static int probe_bench_impl(cmgpu_ctx *c, const uint64_t *hashes, uint64_t n, in
   HIPCHECK(c, hipMemsetAsync(ctr, 0, CM_ST_N * 8, s));
   // warm-up + counted launch
   if (c->partials.ensure(cm_probe_partial_words((uint32_t)n) * 8)) { cm_set_error(c, "out of device memory (partials)"); return CMGPU_ENOMEM; }
-  cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
+  const bool file_layout = (variant & 32) != 0 || !c->fmask;  // + 32: the file's table even when a re-hashed one is resident
+  variant &= ~32;
+  const uint64_t *tab = (const uint64_t *)(file_layout ? c->bkt.p : c->bkt_fast.p);
+  const uint32_t tmask = file_layout ? c->bmask : c->fmask;
+  cm_launch_k_probe(tab, tmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
                     (uint8_t *)c->pr_kind.p, (uint32_t)n, c->partials.p, ctr + CM_ST_PROBE_STEPS, s, variant);
   unsigned long long h[CM_ST_N];
   HIPCHECK(c, hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, s));
   HIPCHECK(c, cm_stream_sync(s));
   HIPCHECK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < repeat; ++i)
-    cm_launch_k_probe((const uint64_t *)c->bkt.p, c->bmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
+    cm_launch_k_probe(tab, tmask, (const uint64_t *)c->mm_hash.p, (uint64_t *)c->pr_val.p,
                       (uint8_t *)c->pr_kind.p, (uint32_t)n, nullptr, nullptr, s, variant);
   HIPCHECK(c, hipEventRecord(c->ev[1], s));
   HIPCHECK(c, hipEventSynchronize(c->ev[1]));

@@ -21,6 +21,10 @@
 #include "cm_stages.h"
 
 CM_HD uint32_t cm_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// entries per lane when a list of n is cut into one contiguous chunk per lane: ceil(n / G) made ODD -- lane t starts at t * VT, and
+// with an odd VT sixteen consecutive lanes start in sixteen different 8-byte bank pairs of shared memory (an even chunk of 8 or 16
+// entries puts all of them on four or two: every pass over the chunks then runs at a quarter or an eighth of the LDS rate)
+CM_HD uint32_t cm_coop_chunk(uint32_t n, uint32_t G) { return ((n + G - 1) / G) | 1u; }
 
 // ---------------------------------------------------------------------------------------
 // Merge sort of nr contiguous ascending runs: src[0..tot) = runs [rb[i], rb[i+1]) (rb[0] = 0, rb[nr] = tot).  Bottom-up
@@ -31,7 +35,7 @@ CM_HD uint32_t cm_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // ---------------------------------------------------------------------------------------
 template <class GT>
 CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t *rb, uint32_t *rb2, uint32_t nr, uint32_t tot) {
-  const uint32_t VT = (tot + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
   while (nr > 1) {
     const uint32_t nr2 = (nr + 1) >> 1;
@@ -77,7 +81,7 @@ CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t
 // there are more than cap runs (rb holds cap + 1 entries; nothing useful is written then).  a must be complete (synced).
 template <class GT>
 CM_HD uint32_t cm_coop_natural_runs(GT &g, const uint64_t *a, uint32_t tot, uint32_t *rb, uint32_t cap) {
-  const uint32_t VT = (tot + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
   uint32_t cnt = 0;
   for (uint32_t i = c0; i < c1; ++i) cnt += (i == 0 || a[i] < a[i - 1]) ? 1u : 0u;
@@ -114,7 +118,7 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   }
   g.sync();
   // exclusive scan of oc in list order: per-lane chunk sums, group scan, rewrite
-  const uint32_t VT = (tot + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
   uint32_t sum = 0;
   for (uint32_t i = c0; i < c1; ++i) sum += oc[i];
@@ -264,7 +268,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   // ---- split: + hits in order, then - hits in order
   uint32_t np;
   {
-    const uint32_t VT = (tot + G - 1) / G;
+    const uint32_t VT = cm_coop_chunk(tot, G);
     const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
     uint32_t cnt = 0;
     for (uint32_t x = c0; x < c1; ++x) cnt += (B[x] >> 63) ? 0u : 1u;
@@ -394,7 +398,7 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     a = S;
   }
   const uint32_t nz = n1 + naug;
-  const uint32_t VT = (nz + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(nz, (uint32_t)GT::G);
   const uint32_t z0 = cm_min_u32(nz, g.t * VT), z1 = cm_min_u32(nz, z0 + VT);
   if (z0 < z1) {
     uint32_t lo = z0 > naug ? z0 - naug : 0, hi = z0 < n1 ? z0 : n1;
@@ -444,7 +448,7 @@ CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopM
 // ---------------------------------------------------------------------------------------
 template <class GT>
 CM_HD uint32_t cm_coop_array_scan_add(GT &g, uint16_t *a, uint32_t n) {
-  const uint32_t VT = (n + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(n, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
   uint32_t sum = 0;
   for (uint32_t i = c0; i < c1; ++i) sum += a[i];
@@ -456,7 +460,7 @@ CM_HD uint32_t cm_coop_array_scan_add(GT &g, uint16_t *a, uint32_t n) {
 }
 template <class GT>
 CM_HD uint32_t cm_coop_array_scan_max(GT &g, uint8_t *a, uint32_t n) {
-  const uint32_t VT = (n + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(n, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
   uint32_t mx = 0;
   for (uint32_t i = c0; i < c1; ++i) mx = a[i] > mx ? a[i] : mx;
@@ -627,7 +631,7 @@ CM_HD void cm_coop_s4c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPairMem
 
 template <class GT>
 CM_HD uint32_t cm_coop_array_scan_max16(GT &g, uint16_t *a, uint32_t n) {  // exclusive prefix maximum in place; returns the maximum
-  const uint32_t VT = (n + (uint32_t)GT::G - 1) / (uint32_t)GT::G;
+  const uint32_t VT = cm_coop_chunk(n, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
   uint32_t mx = 0;
   for (uint32_t i = c0; i < c1; ++i) mx = a[i] > mx ? a[i] : mx;
@@ -774,7 +778,7 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
   const uint32_t nb = (uint32_t)mx + 1;
   uint16_t *mine = hist + (size_t)g.t * nb_cap;
   for (uint32_t b = 0; b < nb; ++b) mine[b] = 0;
-  const uint32_t VT = (n + G - 1) / G;
+  const uint32_t VT = cm_coop_chunk(n, G);
   const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
   for (uint32_t i = c0; i < c1; ++i) mine[c[i]] += 1;
   uint32_t base = 0;
@@ -834,20 +838,15 @@ CM_HD void cm_coop_sort_draft(const CmDev &d, GT &g, const CmCoopSortMem &m, uin
   g.sync();
 }
 
-// S5b for a read cm_s5a_prepare left to the groups (nv[r] == 0, candidate lists NOT yet sorted): the group sorts the two lists
-// (cm_coop_sort_cand), then a lane per candidate runs the banded alignment (cm_s5b_verify_at) -- no work-item search, the read's
-// own quantities loaded once per lane.
+// The candidate lists of a read cm_s5a_prepare left to the groups, sorted (scratch: the read's draft-mapping arrays, written by
+// S5c only).  The alignments then run in the per-candidate kernel like everybody's.
 template <class GT>
-CM_HD void cm_coop_s5b(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap) {
-  const uint32_t ncp = d.fcp[r], nc = ncp + d.fcn[r];
-  {  // the candidate lists were left unsorted (cm_s5a_prepare); scratch: the read's draft-mapping arrays, written by S5c only
-    const uint32_t op = d.m_off[r], on = op + d.ncp[r] + d.resc_p[r];
-    cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, ncp, d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap);
-    cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap);
-  }
-  for (uint32_t li = g.t; li < nc; li += (uint32_t)GT::G) cm_s5b_verify_at(d, r, li < ncp ? 0 : 1, li < ncp ? li : li - ncp);
+CM_HD void cm_coop_s5_sort(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap) {
+  const uint32_t op = d.m_off[r], on = op + d.ncp[r] + d.resc_p[r];
+  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, d.fcp[r], d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap);
+  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap);
 }
-// S5c for such a read, after cm_coop_s5b
+// S5c for such a read (its alignments are in v_err / v_end)
 // sm: work area of the draft-mapping sort that follows the acceptance loop (it may overlay m: the loop's arrays are dead by then)
 template <class GT>
 CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m, const CmCoopSortMem &sm) {

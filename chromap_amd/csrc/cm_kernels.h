@@ -35,7 +35,7 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
 void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop);
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
-void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s, bool coop);
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s);
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 CM_DECL_LAUNCH(k_s6c_multi)
 CM_DECL_LAUNCH(k_s6a_pair_sam)

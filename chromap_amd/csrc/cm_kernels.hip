@@ -943,19 +943,21 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, u
   if (coop) cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave, r);
 }
 // S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
-__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n) {
+__global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, uint32_t coop) {
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
-  if (i < n) cm_s5c_finalize(d, r);
+  const uint32_t cmin = coop ? CM_S5C_COOP_MIN : 0u;
+  if (i < n) cm_s5c_finalize(d, r, cmin);
   if (!d.perm_reads || d.p.split || d.p.single) return;  // the queue is only served in a batch with heavy reads
-  const bool live = i < n && d.nv[r] != 0 && d.alive[r >> 1];
+  const bool live = i < n && !(cmin && d.nv[r] > cmin) && d.alive[r >> 1];  // (a wave's reads: sorted there)
   const uint32_t a = live ? d.ndp[r] : 0u, b = live ? d.ndn[r] : 0u;
   cm_wave_append(d.srt_list, &d.srt_cnt[0], a > CM_SORT_SERIAL_MAX && a <= CM_SORT_WAVE_MAX, r << 1);
   cm_wave_append(d.srt_list, &d.srt_cnt[0], b > CM_SORT_SERIAL_MAX && b <= CM_SORT_WAVE_MAX, (r << 1) | 1u);
 }
 // S5b of the reads in list 12: a wave per read, its lanes over the read's candidates (cm_coop_s5b)
 #define CM_SORT_NB 64u  // counts below this go through the groups' counting sort of a candidate list
-__global__ __launch_bounds__(CM_BLOCK) void k_s5b_coop(CmDev d) {
+// the candidate lists of the reads in list 12 (k_s5a_prepare left them unsorted): a wave each (cm_coop_s5_sort)
+__global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d) {
   __shared__ uint16_t hist[CM_BLOCK * CM_SORT_NB];
   const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[12];
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_coop(CmDev d) {
   CmDevGroup<64> g;
   g.t = threadIdx.x % 64;
   g.xw = nullptr;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s5b(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB);
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s5_sort(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB);
 }
 #define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
 #define CM_S5C_SORT_RB 130u
@@ -1531,8 +1533,8 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
         rest[C_] = 0; any_coop = true;                                                                                                             \
       }                                                                                                                                            \
     }
-    CM_S3B_COOP_CLASS(1, 1, 512)
-    CM_S3B_COOP_CLASS(2, 2, 1024)
+    CM_S3B_COOP_CLASS(1, 1, 256)
+    CM_S3B_COOP_CLASS(2, 2, 512)
     CM_S3B_COOP_CLASS(10, 3, 1024)
 #undef CM_S3B_COOP_CLASS
     if (n_cls[3] && d.coop_slab && d.hv_max[3]) {  // lists beyond the largest class: 1024 lanes on a slab of global memory each
@@ -1640,11 +1642,13 @@ void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t 
   hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
 }
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
-  if (n) hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  if (!n) return;
+  hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  if (coop) hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d);  // the lists it left unsorted: a wave per read
 }
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
-  hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n);
+  hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (!coop) return;
   const uint32_t P = 2048;  // candidates of a strand the wave's work arrays hold (longer lists: its lane 0)
   const size_t b1 = cm_coop_ver_mem_bytes(P), b2 = cm_coop_sort_mem_bytes(CM_S5C_SORT_P, CM_S5C_SORT_RB);
@@ -1656,13 +1660,11 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
 // max_items: an upper bound of the item count (the capacity of the candidate arrays)
-// coop: the reads k_s5a_prepare listed get their alignments from waves of their own
-void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s, bool coop) {
+void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s) {
   if (!max_items) return;
   uint32_t blocks = (max_items + CM_BLOCK - 1) / CM_BLOCK;
   if (blocks > 65536) blocks = 65536;  // grid-stride beyond
   hipLaunchKernelGGL(k_s5b_verify, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n_reads);
-  if (coop) hipLaunchKernelGGL(k_s5b_coop, dim3(8192), dim3(CM_BLOCK), 0, s, d);
 }
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;

@@ -2058,8 +2058,8 @@ CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
 // break, best/second-best bookkeeping) over the precomputed (errors, end) results.  Candidates
 // beyond the loop's break point are aligned needlessly but never looked at.
 // ---------------------------------------------------------------------------------------
-// coop_min > 0: a read with more candidates than that is left to a group of lanes -- sorting the lists, verification,
-// acceptance (cm_coop_s5b / cm_coop_s5c, cm_coop.h): nv stays 0 and the function returns true
+// coop_min > 0: a read with more candidates than that gets its lists sorted and its acceptance loop run by a group of lanes
+// (cm_coop_s5_sort / cm_coop_s5c, cm_coop.h; the alignments stay with the per-candidate kernel): the function returns true
 CM_HD bool cm_s5a_prepare(const CmDev &d, uint32_t r, uint32_t coop_min = 0) {
   const uint32_t pair = r >> 1;
   d.nv[r] = 0;
@@ -2089,12 +2089,12 @@ CM_HD bool cm_s5a_prepare(const CmDev &d, uint32_t r, uint32_t coop_min = 0) {
   }
   bool to_group = false;
   if (!done) {
-    to_group = coop_min > 0 && ncp + ncn > coop_min;  // the group sorts the lists too (cm_coop_sort_cand)
+    to_group = coop_min > 0 && ncp + ncn > coop_min;  // a group sorts these lists (cm_coop_sort_cand) before the alignments
     if (!to_group) {
       cm_sort_cand(pp, pc, ncp);
       cm_sort_cand(np, nc, ncn);
-      d.nv[r] = ncp + ncn;
     }
+    d.nv[r] = ncp + ncn;
   }
   d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
   d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
@@ -2130,8 +2130,10 @@ CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci)
 }
 
 CM_HD void cm_s5c_accept(const CmDev &d, uint32_t r);
-CM_HD void cm_s5c_finalize(const CmDev &d, uint32_t r) {
+// coop_min > 0: the reads cm_s5a_prepare left to the groups are skipped (same test)
+CM_HD void cm_s5c_finalize(const CmDev &d, uint32_t r, uint32_t coop_min = 0) {
   if (d.nv[r] == 0) return;
+  if (coop_min > 0 && d.nv[r] > coop_min) return;
   cm_s5c_accept(d, r);
 }
 CM_HD void cm_s5c_accept(const CmDev &d, uint32_t r) {

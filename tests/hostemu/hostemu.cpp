@@ -89,7 +89,7 @@ static void emu_coop_s4c(const CmDev &d, const std::vector<uint32_t> &list) {
 }
 
 template <int G>
-static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list) {
+static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list, int phase) {
   const uint32_t P = g_coop.P > 60000 ? 60000 : g_coop.P;
   std::vector<uint8_t> mem(cm_coop_ver_mem_bytes(P) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
@@ -100,9 +100,7 @@ static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list) {
   const CmCoopSortMem sm = cm_coop_sort_mem_at(smem.data() + ((16 - ((uintptr_t)smem.data() & 15)) & 15), 32, 40);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      cm_coop_s5b(d, list[i], g, hist.data(), 64);
-      g.sync();
-      cm_coop_s5c(d, list[i], g, m, sm);
+      if (phase == 0) cm_coop_s5_sort(d, list[i], g, hist.data(), 64); else cm_coop_s5c(d, list[i], g, m, sm);
       g.sync();
     }
   }, g_coop_reverse);
@@ -316,14 +314,18 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   std::vector<uint32_t> s5_heavy;  // reads whose verification and acceptance a group of lanes runs (k_s5c_coop)
   for (uint32_t r = 0; r < n2; ++r)
     if (cm_s5a_prepare(d, r, g_coop.G && !d.p.split ? g_coop.thr : 0u)) s5_heavy.push_back(r);
+  const uint32_t s5_min = g_coop.G && !d.p.split ? g_coop.thr : 0u;
+  auto s5_groups = [&](int phase) {
+    if (s5_heavy.empty()) return;
+    if (g_coop.G == 16) emu_coop_s5c<16>(d, s5_heavy, phase); else if (g_coop.G == 64) emu_coop_s5c<64>(d, s5_heavy, phase);
+    else if (g_coop.G == 256) emu_coop_s5c<256>(d, s5_heavy, phase); else emu_coop_s5c<1024>(d, s5_heavy, phase);
+  };
+  s5_groups(0);  // k_s5_sort_coop: the heavy reads' candidate lists
   scan(d.nv, d.v_off, n2);
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
-  for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r);
-  if (!s5_heavy.empty()) {
-    g_coop_items[4] += s5_heavy.size();
-    if (g_coop.G == 16) emu_coop_s5c<16>(d, s5_heavy); else if (g_coop.G == 64) emu_coop_s5c<64>(d, s5_heavy);
-    else if (g_coop.G == 256) emu_coop_s5c<256>(d, s5_heavy); else emu_coop_s5c<1024>(d, s5_heavy);
-  }
+  for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r, s5_min);
+  g_coop_items[4] += s5_heavy.size();
+  s5_groups(1);  // k_s5c_coop
   // --SAM buffers (cmgpu_map_resident allocates the same per batch)
   std::vector<uint32_t> samz;
   if (sam) {

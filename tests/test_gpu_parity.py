@@ -192,6 +192,8 @@ HEAVY_SETTINGS = {
     # run tables too small for most reads: the merge-sort kernels decline them (bitonic kernel over a device-side list; lane 0 for rescue hits)
     "declined": {"coop_run_table": 3},
     "declined_block": {"heavy_wave_max": 20, "coop_run_table": 3},
+    # the index table re-hashed on the device into 4 times as many buckets: same lookups, fewer buckets visited
+    "rehashed_table": {"probe_table_shift": 2},
     "declined_hits_only": {"coop": 1, "coop_run_table": 3},
     "declined_rescue_only": {"coop": 2, "coop_run_table": 3},
 }
