@@ -327,7 +327,7 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL record exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--lanes", type=int, default=3, help="ranges of a batch mapped side by side (cmgpu_set_option lanes); measured best for resident batches")
-    ap.add_argument("--probe-table-shift", type=int, default=2,
+    ap.add_argument("--probe-table-shift", type=int, default=1,
                     help="the pipeline probes a device copy of the index table re-hashed into 2^shift times as many buckets (same keys, values, "
                          "hash and probe sequence: identical lookups, fewer buckets visited); 0: the file's table")
     ap.add_argument("--option", action="append", default=[], help="name=value for cmgpu_set_option (measurement knobs)")

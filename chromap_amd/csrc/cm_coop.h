@@ -21,10 +21,10 @@
 #include "cm_stages.h"
 
 CM_HD uint32_t cm_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-// entries per lane when a list of n is cut into one contiguous chunk per lane: ceil(n / G) made ODD -- lane t starts at t * VT, and
-// with an odd VT sixteen consecutive lanes start in sixteen different 8-byte bank pairs of shared memory (an even chunk of 8 or 16
-// entries puts all of them on four or two: every pass over the chunks then runs at a quarter or an eighth of the LDS rate)
-CM_HD uint32_t cm_coop_chunk(uint32_t n, uint32_t G) { return ((n + G - 1) / G) | 1u; }
+// entries per lane when a list of n is cut into one contiguous chunk per lane.  (Making it odd, so that sixteen consecutive lanes
+// start in sixteen different 8-byte bank pairs of shared memory, was measured: every cooperative kernel got 15-20 % SLOWER --
+// k_s3b_coop<512> 8.6 -> 10.1 ms -- the idle lanes of the longer chunks cost more than the conflicts.)
+CM_HD uint32_t cm_coop_chunk(uint32_t n, uint32_t G) { return (n + G - 1) / G; }
 
 // ---------------------------------------------------------------------------------------
 // Merge sort of nr contiguous ascending runs: src[0..tot) = runs [rb[i], rb[i+1]) (rb[0] = 0, rb[nr] = tot).  Bottom-up

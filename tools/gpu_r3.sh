@@ -33,6 +33,24 @@ run harsh_l1 --lanes 1 --headline-repeats profile:1
 run harsh_l3 --lanes 3 --headline-repeats profile:1
 run hic_l3 --lanes 3 --preset hic --readlen 150 --indel-rate 0.001 --hic 0.35 --pairs 2000000
 run hic_l1 --lanes 1 --preset hic --readlen 150 --indel-rate 0.001 --hic 0.35 --pairs 2000000
+roof() {  # name, args: the headline quickly, roofline block printed
+  local name=$1; shift
+  timeout 500 python bench.py --steps 10 --warmup 3 --skip-extras "$@" > $O/$name.json 2> $O/$name.log
+  python - <<PY
+import json
+try:
+    j=json.loads(open('$O/$name.json').read().strip().splitlines()[-1])
+    r=j['roofline']
+    print('$name', j['value'], 'M pairs/s', j['ms_per_step'], 'ms | probe', r['launch_ms'], 'ms achieved', r['achieved'], 'frac', r['frac'], 'useful', r.get('useful_frac'))
+    print('   graded launch', r['probe_only']); print('   file layout  ', r.get('probe_on_file_layout'))
+    print('   stages', json.dumps(j['stage_ms_per_step']))
+except Exception as e:
+    print('$name', 'failed', e); print(open('$O/$name.log').read()[-1500:])
+PY
+}
+roof head_shift0 --probe-table-shift 0
+roof head_shift1 --probe-table-shift 1
+roof head_shift2 --probe-table-shift 2
 if [ "$DEF" = "default" ]; then
   timeout 1500 python bench.py --steps 10 --warmup 3 > $O/bench_default.json 2> $O/bench_default.log; echo "bench default rc $?"
   python - <<PY

@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--frag-min", type=int, default=30)
     ap.add_argument("--frag-max", type=int, default=600)
     ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--barcodes", type=int, default=0, help="single-cell run: a whitelist of this many random 16-mers, every pair draws one, "
+                                                            "10 %% of them with one substitution (BASELINE config 4: 737280)")
+    ap.add_argument("--bgzf-check", action="store_true", help="also run chromap-amd on BGZF-compressed copies of the read files: same output")
     ap.add_argument("--hic", type=float, default=-1.0, help="Hi-C shaped pairs with this fraction of chimeric reads (default: fragments)")
     args = ap.parse_args()
     rep = None
@@ -88,6 +91,35 @@ def main():
                 shutil.copyfileobj(src, dst, 1 << 24)
             os.remove(tmp)
     g.close()
+    extra = []
+    if args.barcodes:
+        import numpy as np
+        rng = np.random.default_rng(args.seed0)
+        n_all = args.pairs * args.batches
+        wl = np.unique(rng.integers(0, 1 << 32, size=args.barcodes, dtype=np.uint64))  # 16-mers as 32-bit codes
+        acgt = np.frombuffer(b"ACGT", np.uint8)
+        shifts = (2 * np.arange(15, -1, -1)).astype(np.uint64)
+
+        def letters(codes):
+            return acgt[((codes[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.int64)]
+        wl_path = os.path.join(args.dir, "whitelist.txt")
+        with open(wl_path, "wb") as f:
+            f.write(b"\n".join(bytes(x) for x in letters(wl)) + b"\n")
+        pick = wl[rng.integers(0, len(wl), size=n_all)]
+        seq = letters(pick)
+        hit = rng.random(n_all) < 0.10
+        col = rng.integers(0, 16, size=n_all)
+        rows = np.nonzero(hit)[0]
+        seq[rows, col[rows]] = acgt[rng.integers(0, 4, size=len(rows))]
+        rec = np.empty((n_all, 4 + 17 + 2 + 17), np.uint8)  # "@b\n" + 16 + "\n+\n" + 16 x 'I' + "\n"
+        rec[:, 0:3] = np.frombuffer(b"@b\n", np.uint8)
+        rec[:, 3:19] = seq
+        rec[:, 19:22] = np.frombuffer(b"\n+\n", np.uint8)
+        rec[:, 22:38] = ord("I")
+        rec[:, 38] = ord("\n")
+        bc_path = os.path.join(args.dir, "bc.fq")
+        rec[:, :39].tofile(bc_path)
+        extra = ["-b", bc_path, "--barcode-whitelist", wl_path]
     t_setup = time.time() - t0
     n_pairs = args.pairs * args.batches
     res = {"setup_s": round(t_setup, 1), "pairs": n_pairs, "threads": args.threads,
@@ -95,7 +127,7 @@ def main():
     # ---- the reference
     out_ref = os.path.join(args.dir, "ref.out")
     t0 = time.time()
-    p = subprocess.run([ref_bin, "--preset", args.preset, "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_ref, "-t", str(args.threads)],
+    p = subprocess.run([ref_bin, "--preset", args.preset, "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_ref, "-t", str(args.threads)] + extra,
                        stderr=subprocess.PIPE)
     wall = time.time() - t0
     log = p.stderr.decode(errors="replace")
@@ -114,7 +146,7 @@ def main():
     out_gpu = os.path.join(args.dir, "gpu.out")
     cli = os.path.join(ROOT, "chromap_amd", "chromap-amd")
     t0 = time.time()
-    p = subprocess.run([cli, "--preset", args.preset, "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_gpu], stderr=subprocess.PIPE)
+    p = subprocess.run([cli, "--preset", args.preset, "-x", idx, "-r", fa, "-1", r1, "-2", r2, "-o", out_gpu] + extra, stderr=subprocess.PIPE)
     wall = time.time() - t0
     log = p.stderr.decode(errors="replace")
     if p.returncode != 0:
@@ -125,6 +157,18 @@ def main():
                               "bed_md5": subprocess.check_output(["md5sum", out_gpu]).split()[0].decode()}
     if "bed_md5" in res.get("reference", {}) and "bed_md5" in res.get("chromap_amd", {}):
         res["bed_identical_to_reference"] = res["reference"]["bed_md5"] == res["chromap_amd"]["bed_md5"]
+    if args.bgzf_check and "bed_md5" in res.get("chromap_amd", {}):
+        # the same reads as BGZF (block-parallel inflate in the CLI's reader): the output must not change
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bgzf
+        z1, z2 = r1 + ".bgz", r2 + ".bgz"
+        bgzf.compress_file(r1, z1)
+        bgzf.compress_file(r2, z2)
+        out_z = os.path.join(args.dir, "gpu_bgzf.out")
+        zextra = list(extra)
+        p = subprocess.run([cli, "--preset", args.preset, "-x", idx, "-r", fa, "-1", z1, "-2", z2, "-o", out_z] + zextra, stderr=subprocess.PIPE)
+        res["bgzf"] = {"rc": p.returncode, "identical": p.returncode == 0 and
+                       subprocess.check_output(["md5sum", out_z]).split()[0].decode() == res["chromap_amd"]["bed_md5"]}
     shutil.rmtree(args.dir, ignore_errors=True)
     print(json.dumps(res))
 
