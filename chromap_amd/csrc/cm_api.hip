@@ -97,6 +97,8 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "probe_table_shift") {  // 0: probe the file's table; 1 / 2: a device copy with 2 / 4 times the buckets
     if (value < 0 || value > 4) { cm_set_error(c, "probe_table_shift: 0..4"); return CMGPU_EINVAL; }
     return build_fast_table(c, (int)value);
+  } else if (n == "coop_profile") {  // measurement aid: per-phase cycle sums of k_s3b_coop (cmgpu_get_option coop_profile_0 .. _15)
+    if (value) { if (c->coop_prof.ensure(16 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 16 * 8)); } else c->coop_prof.release();
   } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
     c->opt_coop_rb = (int)value;
   } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
@@ -123,6 +125,12 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n == "item_limit") *value = (int64_t)c->opt_item_limit;
   else if (n == "lanes") *value = c->opt_lanes;
   else if (n == "coop") *value = c->opt_coop;
+  else if (n.rfind("coop_profile_", 0) == 0) {
+    const int k = atoi(n.c_str() + 13);
+    unsigned long long v = 0;
+    if (k < 0 || k > 15 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
+    *value = (int64_t)v;
+  }
   else if (n == "probe_table_buckets") *value = c->fmask ? (int64_t)c->fmask + 1 : (int64_t)c->bmask + 1;
   else return CMGPU_EINVAL;
   return CMGPU_OK;
@@ -677,6 +685,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
   d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
+  d.prof = (unsigned long long *)c->coop_prof.p;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id

@@ -21,6 +21,16 @@
 #include "cm_stages.h"
 
 CM_HD uint32_t cm_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// measurement aid: lane 0 of a group adds the shader-clock cycles since its last mark to d.prof[k] (nullptr: nothing)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_PROF_BEGIN(d) long long cm_prof_t_ = (d).prof ? clock64() : 0
+#define CM_PROF_MARK(d, g, k) do { if ((d).prof && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(d).prof[k], (unsigned long long)(now_ - cm_prof_t_)); cm_prof_t_ = now_; } } while (0)
+#define CM_PROF_COUNT(d, g, k, v) do { if ((d).prof && (g).t == 0) atomicAdd(&(d).prof[k], (unsigned long long)(v)); } while (0)
+#else
+#define CM_PROF_BEGIN(d) do { } while (0)
+#define CM_PROF_MARK(d, g, k) do { } while (0)
+#define CM_PROF_COUNT(d, g, k, v) do { } while (0)
+#endif
 // entries per lane when a list of n is cut into one contiguous chunk per lane.  (Making it odd, so that sixteen consecutive lanes
 // start in sixteen different 8-byte bank pairs of shared memory, was measured: every cooperative kernel got 15-20 % SLOWER --
 // k_s3b_coop<512> 8.6 -> 10.1 ms -- the idle lanes of the longer chunks cost more than the conflicts.)
@@ -200,16 +210,19 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
 // Returns false -- nothing written -- when the read has more included minimizers than m.MM or more runs than m.RB
 // (the caller hands it to the bitonic-sort kernel); every lane returns the same value.
 // ---------------------------------------------------------------------------------------
-template <class GT>
+// SLAB (compile time): the list buffers are the group's slab of global memory instead of the shared work area.  A template
+// parameter, not a run-time choice: a pointer that may be either makes every access a FLAT instruction -- measured, the shared-
+// memory form then runs at less than half its speed (its loads are chains of dependent accesses).
+template <bool SLAB, class GT>
 CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   const uint32_t G = (uint32_t)GT::G;
   const uint32_t tot = d.hit_tot[r];
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   const uint64_t SB = 1ull << 63;
-  const bool slab = tot > m.P;  // the list does not fit the shared work area: the group's slab of global memory
-  if (slab && (tot > m.gcap || tot > 0xffffu)) return false;  // the sweep's offsets are 16-bit
-  uint64_t *const A = slab ? m.gA : m.A, *const B = slab ? m.gB : m.B;
+  if (SLAB ? (tot > m.gcap || tot > 0xffffu) : tot > m.P) return false;  // (the sweep's offsets are 16-bit)
+  uint64_t *const A = SLAB ? m.gA : m.A, *const B = SLAB ? m.gB : m.B;
+  CM_PROF_BEGIN(d);
   // ---- included minimizers and where their occurrences start in the list
   uint32_t R = 0, off = 0;
   for (uint32_t base = 0; base < n; base += G) {
@@ -235,6 +248,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   if (R > m.MM || off != tot) return false;
   if (g.t == 0) m.moff[R] = tot;
   g.sync();
+  CM_PROF_MARK(d, g, 0);
   // ---- expand
   for (uint32_t x0 = g.t; x0 < tot; x0 += 4 * G) {
     uint64_t hit[4];
@@ -265,6 +279,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
     }
   }
   g.sync();
+  CM_PROF_MARK(d, g, 1);
   // ---- split: + hits in order, then - hits in order
   uint32_t np;
   {
@@ -279,10 +294,14 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
     }
   }
   g.sync();
+  CM_PROF_MARK(d, g, 2);
   // ---- sort
   const uint32_t nr = cm_coop_natural_runs(g, A, tot, m.rb, m.RB);
   if (nr == 0) return false;
+  CM_PROF_MARK(d, g, 3);
   uint64_t *S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot);
+  CM_PROF_MARK(d, g, 4);
+  CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
   // ---- sweep
   const uint32_t nn = tot - np;
   const bool use_high = d.round2[r] && np > 0 && nn > 0;
@@ -292,9 +311,10 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   if (use_high) req = d.p.min_seeds;
   uint64_t *h = d.hbuf + d.hit_off[r];
   uint8_t *hc = d.hcnt + d.hit_off[r];
-  uint16_t *oc = slab ? m.goc : (m.oc ? m.oc : reinterpret_cast<uint16_t *>(S == A ? B : A));
+  uint16_t *oc = SLAB ? m.goc : reinterpret_cast<uint16_t *>(S == A ? B : A);
   uint32_t ncp, ncn;
   cm_coop_sweep(g, S, tot, np, d.p.e, req, n, oc, h, hc, h + np, hc + np, &ncp, &ncn);
+  CM_PROF_MARK(d, g, 5);
   if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
   return true;
 }
@@ -348,7 +368,7 @@ CM_HD uint32_t cm_coop_accept_walk(const uint64_t *zp, const uint8_t *zc, uint32
   return cnt;
 }
 
-template <class GT>
+template <bool SLAB, class GT>
 CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m, uint64_t *out, uint8_t *outc, uint32_t n1, uint32_t cnt,
                                   bool active, const uint64_t *c0p, const uint8_t *c0c, uint64_t *zp, uint8_t *zc) {
   const int e = d.p.e;
@@ -358,15 +378,17 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
   }
   uint32_t nr = 0;
   // the work buffers: shared memory, or -- a list longer than that -- the hits where they are and the group's slab of global memory
-  const bool slab = cnt > m.P;
-  uint64_t *const A = slab ? out + n1 : m.A, *const B = slab ? m.gB : m.B;
-  uint16_t *const oc = slab ? m.goc : m.oc;
-  uint8_t *const cc = slab ? m.gcc : m.cc;
-  if (!slab) {
+  // (SLAB is a template parameter for the reason given at cm_coop_s3b; the shared-memory form also wants the read's own candidates
+  // staged, so a list of those longer than the work area goes to the one-lane path too)
+  uint64_t *const A = SLAB ? out + n1 : m.A, *const B = SLAB ? m.gB : m.B;
+  uint16_t *const oc = SLAB ? m.goc : m.oc;
+  uint8_t *const cc = SLAB ? m.gcc : m.cc;
+  const bool fits = SLAB ? (cnt <= m.gcap && cnt <= 0xffffu) : (cnt <= m.P && n1 <= m.P);
+  if (!SLAB && fits) {
     for (uint32_t i = g.t; i < cnt; i += (uint32_t)GT::G) m.A[i] = out[n1 + i];
     g.sync();
   }
-  if (!slab || (cnt <= m.gcap && cnt <= 0xffffu)) nr = cm_coop_natural_runs(g, A, cnt, m.rb, m.RB);
+  if (fits) nr = cm_coop_natural_runs(g, A, cnt, m.rb, m.RB);
   if (nr == 0) {  // more hits or runs than the work area holds: the one-lane definition
     uint32_t k = 0;
     if (g.t == 0) {
@@ -391,11 +413,10 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     return naug;
   }
   // ---- Z = merge of c0 (staged in S when it fits) and X, ties: c0 first
-  const uint64_t *a = c0p;
-  if (!slab && n1 <= m.P) {
+  const uint64_t *a = SLAB ? c0p : S;
+  if (!SLAB) {
     for (uint32_t i = g.t; i < n1; i += (uint32_t)GT::G) S[i] = c0p[i];
     g.sync();
-    a = S;
   }
   const uint32_t nz = n1 + naug;
   const uint32_t VT = cm_coop_chunk(nz, (uint32_t)GT::G);
@@ -423,7 +444,7 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
   return total;
 }
 
-template <class GT>
+template <bool SLAB, class GT>
 CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   const uint32_t o = r ^ 1u;
   const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
@@ -436,9 +457,9 @@ CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopM
   const bool aug = d.aug[r] != 0;
   const bool do_n = aug && d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0;
   const bool do_p = aug && d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0;
-  const uint32_t mcn = cm_coop_rescue_dir(d, r, g, m, N, NC, ncn, rn, do_n, cm_c0_neg(d, r), cm_c0_ncnt(d, r), ZP + ncp + rp, ZC + ncp + rp);
+  const uint32_t mcn = cm_coop_rescue_dir<SLAB>(d, r, g, m, N, NC, ncn, rn, do_n, cm_c0_neg(d, r), cm_c0_ncnt(d, r), ZP + ncp + rp, ZC + ncp + rp);
   g.sync();  // the work area is reused
-  const uint32_t mcp = cm_coop_rescue_dir(d, r, g, m, P, PC, ncp, rp, do_p, cm_c0_pos(d, r), cm_c0_pcnt(d, r), ZP, ZC);
+  const uint32_t mcp = cm_coop_rescue_dir<SLAB>(d, r, g, m, P, PC, ncp, rp, do_p, cm_c0_pos(d, r), cm_c0_pcnt(d, r), ZP, ZC);
   if (g.t == 0) { d.mcp[r] = mcp; d.mcn[r] = mcn; }
 }
 
@@ -818,12 +839,10 @@ CM_HD CmCoopSortMem cm_coop_sort_mem_at(uint8_t *base, uint32_t P, uint32_t RB) 
   m.rb2 = m.rb + RB + 1;
   return m;
 }
-template <class GT>
-CM_HD void cm_coop_sort_draft(const CmDev &d, GT &g, const CmCoopSortMem &m, uint64_t *dp, int16_t *de, uint32_t nd, uint64_t *scratch) {
+template <bool IN_LDS, class GT>
+CM_HD void cm_coop_sort_draft_in(const CmDev &d, GT &g, const CmCoopSortMem &m, uint64_t *dp, int16_t *de, uint32_t nd, uint64_t *scratch) {
   const uint32_t G = (uint32_t)GT::G;
-  if (nd < 2 || d.n_seq > (1u << 25) || d.p.e > 62) return;
-  const bool in_lds = nd <= m.P;
-  uint64_t *A = in_lds ? m.A : dp, *B = in_lds ? m.B : scratch;
+  uint64_t *A = IN_LDS ? m.A : dp, *B = IN_LDS ? m.B : scratch;  // (compile-time choice: see cm_coop_s3b)
   for (uint32_t i = g.t; i < nd; i += G) A[i] = (dp[i] << 6) | (uint64_t)(uint16_t)de[i];
   g.sync();
   const uint32_t nr = cm_coop_natural_runs(g, A, nd, m.rb, m.RB);
@@ -836,6 +855,11 @@ CM_HD void cm_coop_sort_draft(const CmDev &d, GT &g, const CmCoopSortMem &m, uin
     for (uint32_t i = g.t; i < nd; i += G) { const uint64_t k = S[i]; dp[i] = k >> 6; de[i] = (int16_t)(k & 63u); }
   }
   g.sync();
+}
+template <class GT>
+CM_HD void cm_coop_sort_draft(const CmDev &d, GT &g, const CmCoopSortMem &m, uint64_t *dp, int16_t *de, uint32_t nd, uint64_t *scratch) {
+  if (nd < 2 || d.n_seq > (1u << 25) || d.p.e > 62) return;
+  if (nd <= m.P) cm_coop_sort_draft_in<true>(d, g, m, dp, de, nd, scratch); else cm_coop_sort_draft_in<false>(d, g, m, dp, de, nd, scratch);
 }
 
 // The candidate lists of a read cm_s5a_prepare left to the groups, sorted (scratch: the read's draft-mapping arrays, written by

@@ -71,7 +71,7 @@ struct cmgpu_ctx {
   uint32_t bmask = 0, n_occ = 0, n_seq = 0;
   // the same table re-hashed on the device into 2^shift times as many buckets (cmgpu_set_option "probe_table_shift"): the
   // pipeline probes it instead -- same keys, values, hash and probe sequence, fewer buckets visited per lookup
-  DevBuf bkt_fast;
+  DevBuf bkt_fast, coop_prof;
   uint32_t fmask = 0;
   int n_break = 0;
   uint64_t ref_bytes = 0;
@@ -173,7 +173,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
   }
 };
 

@@ -644,7 +644,8 @@ __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s3b_coop(CmDev 
   g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t gid = blockIdx.x * gpb + grp; gid < n_list; gid += gridDim.x * gpb) {  // a whole group
     const uint32_t r = list[gid];
-    if (!cm_coop_s3b(d, r, g, m) && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
+    const bool done = use_slab ? cm_coop_s3b<true>(d, r, g, m) : cm_coop_s3b<false>(d, r, g, m);
+    if (!done && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
     g.sync();  // the work area is reused
   }
 }
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev 
   g.t = threadIdx.x % G;
   g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t gid = blockIdx.x * gpb + grp; gid < n_list; gid += gridDim.x * gpb) {
-    cm_coop_rescue_merge(d, list[gid], g, m);
+    if (use_slab) cm_coop_rescue_merge<true>(d, list[gid], g, m); else cm_coop_rescue_merge<false>(d, list[gid], g, m);
     g.sync();  // the work area is reused
   }
 }

@@ -125,6 +125,7 @@ struct CmDev {
   uint8_t *coop_slab;      // global work memory of the groups that take lists longer than their shared memory holds:
   uint32_t coop_slab_cap;  // coop_slab_blocks slabs of cm_coop_slab_bytes(coop_slab_cap) bytes, one per block of those launches
   uint32_t coop_slab_blocks;
+  unsigned long long *prof;  // measurement aid (cmgpu_set_option "coop_profile"): shader-clock cycles per phase of k_s3b_coop, summed over groups
   uint32_t mm_cap;  // capacity of the dense minimizer arrays (0: not checked): S3a leaves a read whose range passes it idle
   uint32_t coop_rb; // tests: run-table size of the cooperative sorters (0: two per minimizer of the longest read)
   uint32_t hv_mid;  // class 4: lists of s3b_cap < hits <= hv_mid go to groups of 16 lanes (k_s3b_heavy<16>); 0 = no such class

@@ -52,7 +52,8 @@ static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std:
   if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      const bool done = cm_coop_s3b(d, list[i], g, m);
+      // a list longer than the work area goes to the slab (the device has a launch of its own for those)
+      const bool done = g_coop_slab && d.hit_tot[list[i]] > g_coop.P ? cm_coop_s3b<true>(d, list[i], g, m) : cm_coop_s3b<false>(d, list[i], g, m);
       if (g.t == 0) ok[i] = done ? 1 : 0;
       g.sync();
     }
@@ -68,7 +69,10 @@ static void emu_coop_rescue(const CmDev &d, const std::vector<uint32_t> &list) {
   if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      cm_coop_rescue_merge(d, list[i], g, m);
+      {
+        const uint32_t r_ = list[i], big_ = d.resc_p[r_] > d.resc_n[r_] ? d.resc_p[r_] : d.resc_n[r_];
+        if (g_coop_slab && big_ > g_coop.P) cm_coop_rescue_merge<true>(d, r_, g, m); else cm_coop_rescue_merge<false>(d, r_, g, m);
+      }
       g.sync();
     }
   }, g_coop_reverse);
@@ -619,7 +623,8 @@ static int emu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c, uint32_
   if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   uint32_t got = 0;
   emu_run_group<G>([&](EmuGroup<G> &g) {
-    const uint32_t k = cm_coop_rescue_dir(d, 0, g, m, go.data(), goc.data(), n1, cnt, true, c0p, c0c, zp.data(), zc.data());
+    const uint32_t k = g_coop_slab && cnt > P ? cm_coop_rescue_dir<true>(d, 0, g, m, go.data(), goc.data(), n1, cnt, true, c0p, c0c, zp.data(), zc.data())
+                                              : cm_coop_rescue_dir<false>(d, 0, g, m, go.data(), goc.data(), n1, cnt, true, c0p, c0c, zp.data(), zc.data());
     if (g.t == 0) got = k;
   }, reverse);
   if (got != want) return 1;

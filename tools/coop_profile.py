@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Where k_s3b_coop spends its cycles (measurement aid): shader-clock cycles of lane 0 of every group between the phases of
+cm_coop_s3b, summed over the groups of a few batches of the repeat-bearing workload.  python tools/coop_profile.py [repeats]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    torch.zeros(1, device="cuda")
+    from chromap_amd import ChromapGPU, Stats
+    rep = sys.argv[1] if len(sys.argv) > 1 else "32,600,3000,0.02"
+    if not rep.startswith("profile:"):
+        f = rep.split(",")
+        rep = (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
+    g = ChromapGPU(synthetic=(3_100_000_000, 24, 12345, rep), preset="atac")
+    g.set_option("lanes", 1)
+    g.generate_resident(4_000_000, read_length=50, frag_min=30, frag_max=600, sub_rate=0.01, seed=3000)
+    g.map_resident(Stats())
+    g.set_option("coop_profile", 1)
+    for _ in range(3):
+        g.map_resident(Stats())
+    v = [g.get_option("coop_profile_%d" % k) for k in range(16)]
+    names = ["run table + scan", "expand (occurrence loads)", "strand partition", "natural runs", "merge levels", "cluster sweep"]
+    tot = float(sum(v[:6])) or 1.0
+    n = max(1, v[8])
+    print("groups %d, mean hits %.0f, mean runs %.1f, mean cycles per group %.0f" % (n, v[10] / n, v[9] / n, tot / n))
+    for k, nm in enumerate(names):
+        print("  %-28s %5.1f %%  %8.0f cycles per group" % (nm, 100.0 * v[k] / tot, v[k] / n))
+    print("timings of the last batch:", g.timings())
+
+
+if __name__ == "__main__":
+    main()
