@@ -119,11 +119,7 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   const uint64_t SB = 1ull << 63;
   for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G) {
     uint32_t c = 0;
-    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) {
-      uint32_t end = i + 1;
-      while (end < tot && !cm_sweep_local_break(S[end - 1], S[end], e)) ++end;
-      c = cm_sweep_cluster(S, 1, i, end, e, req, num_minimizers, nullptr, nullptr);
-    }
+    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) c = cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, nullptr, nullptr);
     oc[i] = (uint16_t)c;
   }
   g.sync();
@@ -139,11 +135,9 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   const uint32_t ncp = np < tot ? (np > 0 ? (uint32_t)oc[np] : 0u) : total, ncn = total - ncp;
   for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G) {
     if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) {
-      uint32_t end = i + 1;
-      while (end < tot && !cm_sweep_local_break(S[end - 1], S[end], e)) ++end;
       const uint32_t off = oc[i];
-      if (i < np) cm_sweep_cluster(S, 1, i, end, e, req, num_minimizers, out_p + off, out_pc + off, ~SB);
-      else cm_sweep_cluster(S, 1, i, end, e, req, num_minimizers, out_n + (off - ncp), out_nc + (off - ncp), ~SB);
+      if (i < np) cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, out_p + off, out_pc + off, ~SB);
+      else cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, out_n + (off - ncp), out_nc + (off - ncp), ~SB);
     }
   }
   *ncp_out = ncp;

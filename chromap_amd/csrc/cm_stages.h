@@ -1042,6 +1042,38 @@ CM_HD uint32_t cm_sweep_cluster(const uint64_t *h, uint32_t st, uint32_t b, uint
   return out;
 }
 
+// the same for the local cluster that STARTS at b, its end found on the way (the first hit at or after b + 1 that
+// cm_sweep_local_break separates from its predecessor, or n): one walk over the cluster instead of two
+CM_HD uint32_t cm_sweep_cluster_from(const uint64_t *h, uint32_t b, uint32_t n, int e, int seeds_required, uint32_t num_minimizers,
+                                     uint64_t *out_h, uint8_t *out_c, uint64_t out_mask = ~0ull) {
+  uint32_t out = 0;
+  int mcount = 1, equal = 1, best_equal = 1;
+  uint64_t prev_hit = h[b], best_local = prev_hit;
+  for (uint32_t pi = b + 1;; ++pi) {
+    uint64_t x = pi < n ? h[pi] : ~0ull;
+    const bool last = pi >= n || cm_sweep_local_break(prev_hit, x, e);
+    if (last) x = ~0ull;
+    if (last || ((uint32_t)mcount >= num_minimizers && (uint32_t)x > (uint32_t)best_local + (uint32_t)e)) {
+      if (mcount >= seeds_required) {
+        if (out_h) { out_h[out] = best_local & out_mask; out_c[out] = (uint8_t)best_equal; }
+        ++out;
+      }
+      if (last) break;
+      mcount = 1; equal = 1; best_equal = 1;
+      best_local = x;
+    } else {
+      if (x == best_local) { ++equal; ++best_equal; }
+      else if (x == prev_hit) {
+        ++equal;
+        if (equal > best_equal) { best_local = prev_hit; best_equal = equal; }
+      } else equal = 1;
+      ++mcount;
+    }
+    prev_hit = x;
+  }
+  return out;
+}
+
 CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
   return cm_sweep_strided(h, cnt, n, e, seeds_required, num_minimizers, 1);
 }
@@ -1562,91 +1594,51 @@ CM_HD void cm_peq_or(uint32_t *P, uint32_t c, uint32_t bit) {
 // arrays were scratch memory -- 700 bytes written and read back per alignment; a byte load per step from global memory,
 // before that, made every step a dependent round trip.)
 // n = bytes that will be read; no word outside [first, last] of them is touched.
-// 16 bytes per load (one global_load_dwordx4), TWO loads in flight behind the chunk being consumed: a 66-byte reference window is
-// five round trips to HBM, three of them hidden, instead of nine with one hidden (8-byte words, one ahead: round 2).  Up to 15
-// bytes in front of p and behind p + n - 1 may be touched: the reference keeps 64 zero bytes around every sequence, the read
-// arrays 16 bytes of slack (cm_api.hip; tests/hostemu pads its copies).
-struct CmChunk16 { uint64_t lo, hi; };
-CM_HD CmChunk16 cm_load16(const uint64_t *p) {  // p 16-byte aligned
-#if defined(__HIP_DEVICE_COMPILE__)
-  const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
-  return CmChunk16{v.x, v.y};
-#else
-  return CmChunk16{p[0], p[1]};
-#endif
-}
+// (Round 3 tried 16-byte chunks with two loads in flight: fewer round trips, but every byte then costs a two-word shift --
+// k_s5b_verify 7.9 -> 9.4 ms on the repeat workload; the kernel hides its load latency with occupancy already.)
 struct CmFwdReader {  // p[0], p[1], ...
   const uint64_t *ap;
-  uint64_t cur, cur_hi;
-  CmChunk16 n1, n2;
-  uint32_t left, chunks;  // bytes left in (cur, cur_hi); chunks not yet requested
+  uint64_t cur, nxt;
+  uint32_t left, words;  // bytes left in cur; words not yet requested
   CM_HD void init(const uint8_t *p, uint32_t n) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t sh = (uint32_t)(a & 15);
-    ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)15);
-    chunks = n ? (sh + n + 15) >> 4 : 0;
-    cur = 0; cur_hi = 0; left = 0;
-    n1 = CmChunk16{0, 0}; n2 = CmChunk16{0, 0};
-    CmChunk16 c0 = CmChunk16{0, 0};
-    if (chunks) { c0 = cm_load16(ap); ap += 2; --chunks; }
-    if (chunks) { n1 = cm_load16(ap); ap += 2; --chunks; }
-    if (chunks) { n2 = cm_load16(ap); ap += 2; --chunks; }
-    if (n) {
-      // drop the sh bytes in front of p
-      if (sh >= 8) { cur = c0.hi >> ((sh - 8) * 8); cur_hi = 0; }
-      else if (sh) { cur = (c0.lo >> (sh * 8)) | (c0.hi << (64 - sh * 8)); cur_hi = c0.hi >> (sh * 8); }
-      else { cur = c0.lo; cur_hi = c0.hi; }
-      left = 16 - sh;
-    }
+    const uint32_t sh = (uint32_t)(a & 7);
+    ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+    words = n ? (sh + n + 7) >> 3 : 0;
+    cur = 0; nxt = 0; left = 0;
+    if (words) { cur = *ap++ >> (sh * 8); left = 8 - sh; --words; }
+    if (words) { nxt = *ap++; --words; }
   }
   CM_HD uint8_t next() {
     if (left == 0) {
-      cur = n1.lo; cur_hi = n1.hi; left = 16;
-      n1 = n2;
-      if (chunks) { n2 = cm_load16(ap); ap += 2; --chunks; }
+      cur = nxt; left = 8;
+      if (words) { nxt = *ap++; --words; }
     }
     const uint8_t b = (uint8_t)cur;
-    cur = (cur >> 8) | (cur_hi << 56);
-    cur_hi >>= 8;
-    --left;
+    cur >>= 8; --left;
     return b;
   }
 };
 struct CmBwdReader {  // p[0], p[-1], p[-2], ...
   const uint64_t *ap;
-  uint64_t cur, cur_lo;  // cur: the next bytes in its TOP byte downwards; cur_lo: the eight after those
-  CmChunk16 n1, n2;
-  uint32_t left, chunks;
+  uint64_t cur, nxt;
+  uint32_t left, words;
   CM_HD void init(const uint8_t *p, uint32_t n) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t pos = (uint32_t)(a & 15);  // byte of p inside its chunk
-    ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)15);
-    chunks = n ? ((15 - pos) + n + 15) >> 4 : 0;
-    cur = 0; cur_lo = 0; left = 0;
-    n1 = CmChunk16{0, 0}; n2 = CmChunk16{0, 0};
-    CmChunk16 c0 = CmChunk16{0, 0};
-    if (chunks) { c0 = cm_load16(ap); ap -= 2; --chunks; }
-    if (chunks) { n1 = cm_load16(ap); ap -= 2; --chunks; }
-    if (chunks) { n2 = cm_load16(ap); ap -= 2; --chunks; }
-    if (n) {
-      // byte pos of the chunk goes to the top byte of cur; the 15 - pos bytes above it are dropped
-      const uint32_t d = 15 - pos;
-      if (d >= 8) { cur = c0.lo << ((d - 8) * 8); cur_lo = 0; }
-      else if (d) { cur = (c0.hi << (d * 8)) | (c0.lo >> (64 - d * 8)); cur_lo = c0.lo << (d * 8); }
-      else { cur = c0.hi; cur_lo = c0.lo; }
-      left = pos + 1;
-    }
+    const uint32_t pos = (uint32_t)(a & 7);  // byte of p inside its word
+    ap = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+    words = n ? ((7 - pos) + n + 7) >> 3 : 0;
+    cur = 0; nxt = 0; left = 0;
+    if (words) { cur = *ap-- << ((7 - pos) * 8); left = pos + 1; --words; }
+    if (words) { nxt = *ap--; --words; }
   }
   CM_HD uint8_t next() {
     if (left == 0) {
-      cur = n1.hi; cur_lo = n1.lo; left = 16;
-      n1 = n2;
-      if (chunks) { n2 = cm_load16(ap); ap -= 2; --chunks; }
+      cur = nxt; left = 8;
+      if (words) { nxt = *ap--; --words; }
     }
     const uint8_t b = (uint8_t)(cur >> 56);
-    cur = (cur << 8) | (cur_lo >> 56);
-    cur_lo <<= 8;
-    --left;
+    cur <<= 8; --left;
     return b;
   }
 };

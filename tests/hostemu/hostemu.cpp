@@ -539,6 +539,13 @@ extern "C" int hostemu_sweep_clusters(const uint64_t *sorted, uint32_t n, int e,
     const uint32_t c0 = cm_sweep_cluster(sorted, 1, b, end, e, seeds_required, num_minimizers, nullptr, nullptr);
     const uint32_t c1 = cm_sweep_cluster(sorted, 1, b, end, e, seeds_required, num_minimizers, oh.data() + got, oc.data() + got);
     if (c0 != c1) return 2;
+    {  // the form that finds the cluster's end itself (cm_coop_sweep uses it)
+      std::vector<uint64_t> fh(c1 + 1);
+      std::vector<uint8_t> fc(c1 + 1);
+      if (cm_sweep_cluster_from(sorted, b, n, e, seeds_required, num_minimizers, nullptr, nullptr) != c1) return 4;
+      if (cm_sweep_cluster_from(sorted, b, n, e, seeds_required, num_minimizers, fh.data(), fc.data()) != c1) return 4;
+      for (uint32_t q = 0; q < c1; ++q) if (fh[q] != oh[got + q] || fc[q] != oc[got + q]) return 5;
+    }
     got += c1;
     b = end;
   }
