@@ -107,50 +107,59 @@ CM_HD uint32_t cm_coop_natural_runs(GT &g, const uint64_t *a, uint32_t tot, uint
 
 // ---------------------------------------------------------------------------------------
 // The cluster sweep of a sorted hit list by the group (CandidateProcessor::GenerateCandidatesOnOneStrand,
-// candidate_processor.cc:283-342, cut at its state-free breaks: cm_sweep_local_break / cm_sweep_cluster in cm_stages.h).
-// S[0..tot) sorted, the + list S[0..np) followed by the - list (keys with bit 63, cleared on output).  Every lane sweeps
-// the local clusters whose first hit it owns; oc[i] (tot entries of shared memory) first holds the candidate count of the
-// cluster starting at i, then its exclusive prefix.  Candidates of the + list go to out_p / out_pc, of the - list to
-// out_n / out_nc, in list order.  *ncp_out, *ncn_out: their numbers (every lane gets them).
+// candidate_processor.cc:283-342, cut at its state-free breaks: cm_sweep_local_break / cm_sweep_cluster_from in cm_stages.h).
+// S[0..tot) sorted, the + list S[0..np) followed by the - list (keys with bit 63, cleared on output).  ONE walk per local
+// cluster: the lane that owns a cluster's first hit sweeps it and parks its candidates in the staging arrays at the cluster's
+// own slots (xs / xc[i ..]: a cluster has at most as many candidates as hits), oc[i] = their number; after the scan of oc the
+// parked candidates are copied to out_p / out_pc (+ list) and out_n / out_nc (- list) in list order.  oc, xs, xc: tot entries
+// of the group's work memory, none of them S; the outputs may be S itself (it is dead after the walk).
+// *ncp_out, *ncn_out: the candidates' numbers (every lane gets them).
 // ---------------------------------------------------------------------------------------
 template <class GT>
-CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, int e, int req, uint32_t num_minimizers, uint16_t *oc,
-                         uint64_t *out_p, uint8_t *out_pc, uint64_t *out_n, uint8_t *out_nc, uint32_t *ncp_out, uint32_t *ncn_out) {
+CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, int e, int req, uint32_t num_minimizers, uint16_t *oc, uint64_t *xs,
+                         uint8_t *xc, uint64_t *out_p, uint8_t *out_pc, uint64_t *out_n, uint8_t *out_nc, uint32_t *ncp_out, uint32_t *ncn_out) {
   const uint64_t SB = 1ull << 63;
   for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G) {
     uint32_t c = 0;
-    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) c = cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, nullptr, nullptr);
+    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) c = cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);
     oc[i] = (uint16_t)c;
   }
   g.sync();
-  // exclusive scan of oc in list order: per-lane chunk sums, group scan, rewrite
+  // exclusive scan of oc in list order: per-lane chunk sums, group scan; the counts stay readable through the neighbour's prefix
   const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
   uint32_t sum = 0;
   for (uint32_t i = c0; i < c1; ++i) sum += oc[i];
   uint32_t total;
   uint32_t run = g.scan(sum, &total);
-  for (uint32_t i = c0; i < c1; ++i) { const uint32_t x = oc[i]; oc[i] = (uint16_t)run; run += x; }
-  g.sync();
-  const uint32_t ncp = np < tot ? (np > 0 ? (uint32_t)oc[np] : 0u) : total, ncn = total - ncp;
-  for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G) {
-    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) {
-      const uint32_t off = oc[i];
-      if (i < np) cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, out_p + off, out_pc + off, ~SB);
-      else cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, out_n + (off - ncp), out_nc + (off - ncp), ~SB);
+  // the + list's candidates: clusters that start before np
+  uint32_t ncp_mine = 0;
+  for (uint32_t i = c0; i < c1 && i < np; ++i) ncp_mine += oc[i];
+  uint32_t ncp;
+  (void)g.scan(ncp_mine, &ncp);
+  const uint32_t ncn = total - ncp;
+  // copy out: every lane the parked candidates of its chunk's clusters (slot i + k -> prefix(i) + k).  No barrier needed before:
+  // the scans above contain them -- all walks are done, S is no longer read (the outputs may overlay it)
+  for (uint32_t i = c0; i < c1; ++i) {
+    const uint32_t c = oc[i];
+    for (uint32_t k = 0; k < c; ++k) {
+      const uint64_t x = xs[i + k];
+      const uint8_t cc = xc[i + k];
+      if (i < np) { out_p[run + k] = x; out_pc[run + k] = cc; }
+      else { out_n[run + k - ncp] = x; out_nc[run + k - ncp] = cc; }
     }
+    run += c;
   }
   *ncp_out = ncp;
   *ncn_out = ncn;
 }
 
-// shared-memory work area of one group for the hit-list stages (sizes in entries).  own_oc: the sweep's offsets and the
-// candidates' counts get arrays of their own (S4b keeps its candidates in the second list buffer); otherwise oc lies in
-// whichever list buffer the sort left free (S3b writes its candidates to global memory).
+// shared-memory work area of one group for the hit-list stages (sizes in entries).  two_cc: S4b keeps its candidates' counts
+// (cc) next to the parked ones of the sweep (cc2); S3b writes its candidates to global memory and needs one count array.
 struct CmCoopMem {
   uint64_t *A, *B;      // P each
-  uint16_t *oc;         // P (own_oc), else nullptr
-  uint8_t *cc;          // P (own_oc), else nullptr
+  uint16_t *oc;         // P: candidates per local cluster
+  uint8_t *cc, *cc2;    // P each (cc2: two_cc only)
   uint32_t *rb, *rb2;   // RB + 1 each: run boundaries
   uint32_t *moff;       // MM + 1: start of an included minimizer's occurrences in the hit list
   uint64_t *mval;       // MM: index of its first occurrence in the occurrence table (a singleton: the occurrence itself)
@@ -171,11 +180,11 @@ CM_HD void cm_coop_slab_at(CmCoopMem &m, uint8_t *slab, uint32_t gcap) {
   m.goc = slab ? reinterpret_cast<uint16_t *>(m.gB + gcap) : nullptr;
   m.gcc = slab ? reinterpret_cast<uint8_t *>(m.goc + gcap) : nullptr;
 }
-CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) {
-  return (size_t)P * (own_oc ? 19 : 16) + ((size_t)2 * (RB + 1) + (size_t)MM * 4 + 2) * 4 + 32;
+CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool two_cc) {
+  return (size_t)P * (two_cc ? 20 : 19) + ((size_t)2 * (RB + 1) + (size_t)MM * 4 + 2) * 4 + 32;
 }
-// carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB, own_oc) bytes)
-CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) {
+// carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB, two_cc) bytes)
+CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB, bool two_cc) {
   CmCoopMem m;
   m.P = P; m.MM = MM; m.RB = RB;
   m.A = reinterpret_cast<uint64_t *>(base);
@@ -185,8 +194,9 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
   m.rb2 = m.rb + RB + 1;
   m.moff = m.rb2 + RB + 1;
   m.mps = m.moff + MM + 1;
-  m.oc = own_oc ? reinterpret_cast<uint16_t *>(m.mps + MM + 1) : nullptr;
-  m.cc = own_oc ? reinterpret_cast<uint8_t *>(m.oc + P) : nullptr;
+  m.oc = reinterpret_cast<uint16_t *>(m.mps + MM + 1);
+  m.cc = reinterpret_cast<uint8_t *>(m.oc + P);
+  m.cc2 = two_cc ? m.cc + P : nullptr;
   m.gA = m.gB = nullptr; m.goc = nullptr; m.gcc = nullptr; m.gcap = 0;
   return m;
 }
@@ -305,9 +315,8 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   if (use_high) req = d.p.min_seeds;
   uint64_t *h = d.hbuf + d.hit_off[r];
   uint8_t *hc = d.hcnt + d.hit_off[r];
-  uint16_t *oc = SLAB ? m.goc : reinterpret_cast<uint16_t *>(S == A ? B : A);
   uint32_t ncp, ncn;
-  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, oc, h, hc, h + np, hc + np, &ncp, &ncn);
+  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, SLAB ? m.goc : m.oc, S == A ? B : A, SLAB ? m.gcc : m.cc, h, hc, h + np, hc + np, &ncp, &ncn);
   CM_PROF_MARK(d, g, 5);
   if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
   return true;
@@ -393,11 +402,13 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     }
     return cm_coop_bcast0(g, k);
   }
-  uint64_t *S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, cnt);
-  uint64_t *X = S == A ? B : A;
+  uint64_t *Ssorted = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, cnt);
+  uint64_t *X = Ssorted;                      // the augmented list, dense: over the sorted hits once they are swept
+  uint64_t *S = Ssorted == A ? B : A;         // the other buffer: parking slots of the sweep, then the staged candidates c0
+  uint8_t *const cx = SLAB ? reinterpret_cast<uint8_t *>(m.gA) : m.cc2;  // the parked counts (slab mode: its first buffer is unused here)
   uint32_t naug, none;
-  cm_coop_sweep(g, S, cnt, cnt, e, 1, d.mm_cnt[r], oc, X, cc, X, cc, &naug, &none);
-  g.sync();  // X / cc complete, S free
+  cm_coop_sweep(g, Ssorted, cnt, cnt, e, 1, d.mm_cnt[r], oc, S, cx, X, cc, X, cc, &naug, &none);
+  g.sync();  // X / cc complete, the parking slots free
   if (naug == 0) {
     cm_coop_copy_list(g, c0p, c0c, out, outc, n1);
     return n1;
