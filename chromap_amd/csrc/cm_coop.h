@@ -204,7 +204,7 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
 // ---------------------------------------------------------------------------------------
 // S3b for one read with a long hit list (cm_s3b_core's results, element for element):
 //   expand   the hit list in minimizer order, occurrence order inside a minimizer: every lane takes hits x, x + G, ... --
-//            which minimizer's occurrence it is comes from the table of run starts -- four independent occurrence loads
+//            which minimizer's occurrence it is comes from the table of run starts -- eight independent occurrence loads
 //            in flight per lane; the - strand's keys get bit 63;
 //   split    stable partition (one scan): the + hits in order, then the - hits in order.  An occurrence run is sorted by
 //            (sequence, position) and a read position is added or subtracted, so each minimizer leaves one ascending run per
@@ -254,11 +254,11 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   g.sync();
   CM_PROF_MARK(d, g, 0);
   // ---- expand
-  for (uint32_t x0 = g.t; x0 < tot; x0 += 4 * G) {
-    uint64_t hit[4];
-    uint32_t ps[4];
+  for (uint32_t x0 = g.t; x0 < tot; x0 += 8 * G) {
+    uint64_t hit[8];
+    uint32_t ps[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const uint32_t x = x0 + (uint32_t)q * G;
       hit[q] = 0; ps[q] = 0;
       if (x < tot) {
@@ -273,7 +273,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const uint32_t x = x0 + (uint32_t)q * G;
       if (x < tot) {
         bool same;

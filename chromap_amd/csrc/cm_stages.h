@@ -1049,8 +1049,10 @@ CM_HD uint32_t cm_sweep_cluster_from(const uint64_t *h, uint32_t b, uint32_t n, 
   uint32_t out = 0;
   int mcount = 1, equal = 1, best_equal = 1;
   uint64_t prev_hit = h[b], best_local = prev_hit;
+  uint64_t ahead = b + 1 < n ? h[b + 1] : ~0ull;  // the next hit is requested while the current one is looked at
   for (uint32_t pi = b + 1;; ++pi) {
-    uint64_t x = pi < n ? h[pi] : ~0ull;
+    uint64_t x = ahead;
+    ahead = pi + 1 < n ? h[pi + 1] : ~0ull;
     const bool last = pi >= n || cm_sweep_local_break(prev_hit, x, e);
     if (last) x = ~0ull;
     if (last || ((uint32_t)mcount >= num_minimizers && (uint32_t)x > (uint32_t)best_local + (uint32_t)e)) {
