@@ -1,6 +1,7 @@
 // cm_kernels.hip -- __global__ wrappers (one thread per item) around the stage functions of
 // cm_stages.h, the index-probe kernel, prefix scans and the launch helpers.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 #include <cstring>
 #include <atomic>
@@ -812,10 +813,12 @@ __device__ __forceinline__ void cm_group_rescue_fill(const CmDev &d, uint32_t r,
 // merging them is the work of a group of lanes (k_s4b_coop), by size class: list 6 up to hv_max[0] hits (a wave each), 7 / 8 / 11
 // up to hv_max[1] / [2] / [3] (a block of 256 / 512 / 1024 lanes each).  coop == 0: everything by one lane, as before.
 #define CM_RS_COOP_MIN 32u
+#define CM_S4B_PMAX 7680u  // rescue hits the largest shared work area holds (20 bytes per hit: 8192 would pass the CU's 160 KB)
+__host__ __device__ inline uint32_t cm_s4b_pmax(const CmDev &d) { return d.hv_max[3] < CM_S4B_PMAX ? d.hv_max[3] : CM_S4B_PMAX; }
 __device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
   if (!coop || big <= CM_RS_COOP_MIN || d.hv_max[0] == 0) return 0;
-  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= d.hv_max[3] ? 11u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
+  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= cm_s4b_pmax(d) ? 11u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
 }
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
@@ -1598,9 +1601,14 @@ static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {
   lds[0] = 2 * cm_coop_group_bytes(d.hv_max[0], 1, RB, true);
   lds[1] = cm_coop_group_bytes(d.hv_max[1], 1, RB, true);
   lds[2] = cm_coop_group_bytes(d.hv_max[2], 1, RB, true);
-  lds[3] = cm_coop_group_bytes(d.hv_max[3], 1, RB, true);
-  return cm_lds_optin(&k_s4b_coop<64>, lds[0]) && cm_lds_optin(&k_s4b_coop<256>, lds[1]) && cm_lds_optin(&k_s4b_coop<512>, lds[2]) &&
-         cm_lds_optin(&k_s4b_coop<1024>, lds[3]);
+  lds[3] = cm_coop_group_bytes(cm_s4b_pmax(d), 1, RB, true);
+  const bool ok = cm_lds_optin(&k_s4b_coop<64>, lds[0]) && cm_lds_optin(&k_s4b_coop<256>, lds[1]) && cm_lds_optin(&k_s4b_coop<512>, lds[2]) &&
+                  cm_lds_optin(&k_s4b_coop<1024>, lds[3]);
+  if (!ok) {  // not an error (the one-lane forms take over), but never silently: it costs a factor on repeat-rich input
+    static std::atomic<int> told{0};
+    if (!told.exchange(1)) fprintf(stderr, "chromap_amd: the cooperative rescue kernels do not fit this device's shared memory (%zu / %zu / %zu / %zu bytes); using the one-lane forms\n", lds[0], lds[1], lds[2], lds[3]);
+  }
+  return ok;
 }
 static inline uint32_t cm_s4b_rb(const CmDev &d, uint32_t max_read_len) {
   return d.coop_rb ? d.coop_rb : 2 * cm_coop_mm(d, max_read_len) + 2;  // ascending runs the sorter's tables hold: one per minimizer unless a diagonal wraps
@@ -1625,9 +1633,9 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB, 0u);
   if (d.hv_max[1] > d.hv_max[0]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB, 0u);
   if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
-  if (d.hv_max[3] > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.hv_max[3], RB, 0u);
+  if (d.hv_max[3] > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), cm_s4b_pmax(d), RB, 0u);
   if (d.coop_slab)  // lists beyond the largest class: on the blocks' slabs of global memory
-    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[3], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), d.hv_max[3], RB, 1u);
+    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[3], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), cm_s4b_pmax(d), RB, 1u);
 }
 // coop: the cmgpu_set_option "coop" bit mask (bit 2: pairs with long lists to groups; bit 3: the S5 waves sort the heavy reads' lists)
 void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop) {
