@@ -233,7 +233,7 @@ def roofline(g, args, s, steps, stage_ms):
     # the file's table (khash layout, load 0.7): its probe steps are SURVEY 8(d)'s algorithmic unit -- what kh_get visits for these lookups
     favg, fps, fhits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     file_layout = None
-    if g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, args.probe_repeat, 1, 2, C.byref(favg), C.byref(fps), C.byref(fhits)) == 0 and favg.value > 0:
+    if not args.graded_probe_only and g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, args.probe_repeat, 1, 2, C.byref(favg), C.byref(fps), C.byref(fhits)) == 0 and favg.value > 0:
         file_layout = {"lookups": int(n_mm), "avg_ms": round(favg.value, 4), "probe_steps": int(fps.value), "hits": int(fhits.value),
                        "GB/s": round(16.0 * fps.value / (favg.value * 1e-3) / 1e9, 1), "buckets": g.get_option("probe_table_buckets") >> max(0, args.probe_table_shift)}
     probe_steps = fps.value if fps.value else s["probe_steps"] / steps
@@ -248,14 +248,14 @@ def roofline(g, args, s, steps, stage_ms):
         achieved, probe_ms = probe_only["GB/s"], avg.value
         assert hits.value == fhits.value or not fps.value, "the re-hashed table answers differently"
     variants = []
-    for u in (1, 2, 4, 8):
+    for u in (() if args.graded_probe_only else (1, 2, 4, 8)):
         for pair in (0, 1):
             a = C.c_double(0)
             if g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, max(3, args.probe_repeat // 2), u, pair, C.byref(a), None, None) == 0 and a.value > 0:
                 variants.append({"lookups_per_lane": u, "pair_prefetch": pair, "avg_ms": round(a.value, 4)})
     ng = 1 << 28
     sweep = []
-    for loads, width in ((1, 16), (2, 16), (4, 16), (8, 16), (16, 16), (1, 64), (2, 64), (4, 64), (8, 64)):
+    for loads, width in (((4, 16),) if args.graded_probe_only else ((1, 16), (2, 16), (4, 16), (8, 16), (16, 16), (1, 64), (2, 64), (4, 64), (8, 64))):
         a = C.c_double(0)
         if g.L.cmgpu_gather_sweep(g.ctx, ng, 3, loads, width, C.byref(a)) == 0 and a.value > 0:
             sweep.append({"loads_per_lane": loads, "access_bytes": width, "avg_ms": round(a.value, 4),
@@ -322,6 +322,9 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["auto", "reference", "port"], default="auto",
                     help="reference: oracle/_ref/chromap itself; port: the oracle restatement with OpenMP; auto: reference if its binary is here")
     ap.add_argument("--probe-repeat", type=int, default=10)
+    ap.add_argument("--graded-probe-only", action="store_true",
+                    help="roofline section: only the graded launch of k_probe and the gather calibration (the PMC passes of tools/profile_bench.sh: "
+                         "their per-kernel averages must not mix launches on different tables or shapes)")
     ap.add_argument("--sam", action="store_true", help="--SAM mode: every reported read is aligned with the banded affine-gap DP "
                                                          "(CIGAR / NM / MD); not the headline metric")
     ap.add_argument("--force-exchange", action="store_true",

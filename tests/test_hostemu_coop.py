@@ -32,11 +32,17 @@ GEOMETRIES = [(64, 8, 8192, 64, 130, 0, 0), (256, 16, 8192, 64, 130, 1, 0), (16,
               (1024, 64, 8192, 64, 130, 0, 0), (64, 8, 40, 64, 130, 1, 20000)]
 
 
-# every fuzz configuration through wave-sized groups; the other group sizes and the decline path on one or two of them
-CASES = [(c, GEOMETRIES[0]) for c in fuzz_data.CONFIGS[:4]] + [(fuzz_data.CONFIGS[0], GEOMETRIES[1]), (fuzz_data.CONFIGS[3], GEOMETRIES[1]),
-                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[2]), (fuzz_data.CONFIGS[0], GEOMETRIES[3]),
-                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[4]), (fuzz_data.CONFIGS[0], GEOMETRIES[5]),
-                                                                (fuzz_data.CONFIGS[1], GEOMETRIES[5])]
+# every fuzz configuration through wave-sized groups; the other group sizes, the decline path and the global-memory slab on
+# one of them each.  Half the pairs of the plain fuzz test: an emulated group costs milliseconds per read.
+def _small(cfg):
+    seed, preset, kw, gen = cfg
+    return (seed, preset, kw, dict(gen, pairs=1500))
+
+
+CASES = [(_small(c), GEOMETRIES[0]) for c in fuzz_data.CONFIGS[:4]] + [(_small(fuzz_data.CONFIGS[0]), GEOMETRIES[1]),
+                                                                        (_small(fuzz_data.CONFIGS[1]), GEOMETRIES[2]),
+                                                                        (_small(fuzz_data.CONFIGS[0]), GEOMETRIES[3]),
+                                                                        (_small(fuzz_data.CONFIGS[0]), GEOMETRIES[5])]
 
 
 @pytest.mark.parametrize("cfg,geo", CASES, ids=["%d-G%d_P%d_MM%d%s" % (c[0], g[0], g[2], g[3], "_slab" if g[6] else "") for c, g in CASES])
