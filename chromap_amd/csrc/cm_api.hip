@@ -97,6 +97,10 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "probe_table_shift") {  // 0: probe the file's table; 1 / 2: a device copy with 2 / 4 times the buckets
     if (value < 0 || value > 4) { cm_set_error(c, "probe_table_shift: 0..4"); return CMGPU_EINVAL; }
     return build_fast_table(c, (int)value);
+  } else if (n == "speculative_sizes") {  // 0: every batch waits for the total of its candidate lists before sizing their arrays
+    c->opt_spec = value ? 1 : 0;
+  } else if (n == "debug_candidate_capacity") {  // tests: pretend the previous batch left this much room (forces the re-run path)
+    c->pred_m_ok = value > 0; c->m_cap = (uint64_t)value; c->pred_n = 0xffffffffu;  // (any batch size)
   } else if (n == "coop_profile") {  // measurement aid: per-phase cycle sums of k_s3b_coop (cmgpu_get_option coop_profile_0 .. _15)
     if (value) { if (c->coop_prof.ensure(16 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 16 * 8)); } else c->coop_prof.release();
   } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
@@ -686,6 +690,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
   d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
   d.prof = (unsigned long long *)c->coop_prof.p;
+  d.abort = (const unsigned long long *)c->stats.p + CM_ST_ABORT;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
@@ -741,7 +746,7 @@ static int scan_with_total(cmgpu_ctx *c, const uint32_t *in, uint32_t *out, uint
 
 // The pipeline on pairs [rlo, rhi) of the resident batch.  Four small device->host reads size the
 // variable-length intermediates (minimizers, hits, candidate capacity, verification items).
-static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, cmgpu_stats *stats) {
+static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, cmgpu_stats *stats, bool allow_spec = true) {
   const uint32_t n = rhi - rlo, n2 = 2 * n;
   const uint64_t limit = c->opt_item_limit;
   c->n_ev = 0;
@@ -907,15 +912,33 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   HIPCHECK(c, hipMemsetAsync(c->rs_cnt.p, 0, CM_RS_SEGS * 64, s));
   cm_launch_k_s4a_rescue_count(d, n2, s);  // decision per read + the packed list of reads that supplement
   cm_launch_k_s4a_rescue_list(d, n2, s);   // their searches, one read per lane of full waves
+  // The candidate arrays.  A batch of the size of the previous one reuses that batch's arrays (sized with 25 % to spare) without
+  // waiting for its own total: the device compares the total with the capacity and, should it ever pass it, raises d.abort --
+  // every later kernel then leaves at once and the range is mapped again with exact sizes (the `spec` test below).
+  unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_TOTAL;
+  const bool spec = allow_spec && c->opt_spec && c->pred_m_ok && (c->pred_n == n || c->pred_n == 0xffffffffu) && c->m_cap > 0 && c->m_cap <= limit;
   unsigned long long m_total = 0;
-  if ((rc = scan_with_total(c, d.m_tot, d.m_off, n2, &m_total))) return rc;
-  if (m_total > limit) return CM_RC_SPLIT;
-  const uint32_t n_m = (uint32_t)m_total;
-  if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
-      c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
-      c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4)) {
-    cm_set_error(c, "out of device memory (candidates)");
-    return CMGPU_ENOMEM;
+  uint32_t n_m;
+  if (spec) {
+    HIPCHECK(c, hipMemsetAsync(acc, 0, 8, s));
+    cm_launch_k_sum_u32(d.m_tot, n2, acc, s);
+    cm_scan_u32(d.m_tot, d.m_off, n2, (uint32_t *)c->scan_tmp.p, s);
+    cm_launch_k_check_cap(acc, c->m_cap, (unsigned long long *)c->stats.p + CM_ST_ABORT, s);
+    n_m = (uint32_t)c->m_cap;
+  } else {
+    if ((rc = scan_with_total(c, d.m_tot, d.m_off, n2, &m_total))) return rc;
+    if (m_total > limit) return CM_RC_SPLIT;
+    uint64_t want = m_total + m_total / 4 + 1024;  // room for the next batch
+    if (want > limit) want = limit;
+    if (want < m_total) want = m_total;
+    n_m = (uint32_t)want;
+    if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
+        c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
+        c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4)) {
+      cm_set_error(c, "out of device memory (candidates)");
+      return CMGPU_ENOMEM;
+    }
+    c->m_cap = n_m;
   }
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
@@ -961,6 +984,12 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   HIPCHECK(c, cm_stream_sync(s));
   mark(c, "stats");
   HIPCHECK(c, cm_stream_sync(s));
+  if (spec && hst[CM_ST_ABORT]) {  // this batch needs more room than the previous one left: again, with its own totals
+    c->pred_m_ok = false;
+    return map_range(c, rlo, rhi, k_out, stats, false);
+  }
+  c->pred_m_ok = true;
+  c->pred_n = n;
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
   *k_out = hst[CM_ST_RECORDS];
   c->last_range_lo = rlo; c->last_range_hi = rhi;
@@ -1023,7 +1052,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   l->max_read_len = c->max_read_len; l->has_barcodes = c->has_barcodes; l->single = c->single;
   l->sam_slots = c->sam_slots; l->sam_md_cap = c->sam_md_cap;
   l->opt_probe_variant = c->opt_probe_variant; l->opt_mm_chunks = c->opt_mm_chunks; l->opt_prep_kernel = c->opt_prep_kernel;
-  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid; l->opt_coop = c->opt_coop; l->opt_coop_rb = c->opt_coop_rb;
+  l->opt_s3b_cap = c->opt_s3b_cap; l->opt_prep_tile_reads = c->opt_prep_tile_reads; l->opt_item_limit = c->opt_item_limit; l->opt_heavy_last = c->opt_heavy_last; l->opt_heavy_mid = c->opt_heavy_mid; l->opt_coop = c->opt_coop; l->opt_coop_rb = c->opt_coop_rb; l->opt_spec = c->opt_spec;
   for (int q = 0; q < 3; ++q) l->opt_heavy_max[q] = c->opt_heavy_max[q];
   return CMGPU_OK;
 }

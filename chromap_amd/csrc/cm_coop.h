@@ -802,21 +802,23 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
     return;
   }
   const uint32_t nb = (uint32_t)mx + 1;
-  uint16_t *mine = hist + (size_t)g.t * nb_cap;
-  for (uint32_t b = 0; b < nb; ++b) mine[b] = 0;
+  // bin b of lane t at hist[b * G + t]: the lanes of a wave touch consecutive 16-bit words (lane-major rows of nb_cap bins put
+  // every lane on the same bank: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.84, profiles/r03k_repeat_workload_pmc_lds.csv)
+  uint16_t *mine = hist + g.t;
+  for (uint32_t b = 0; b < nb; ++b) mine[(size_t)b * G] = 0;
   const uint32_t VT = cm_coop_chunk(n, G);
   const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
-  for (uint32_t i = c0; i < c1; ++i) mine[c[i]] += 1;
+  for (uint32_t i = c0; i < c1; ++i) mine[(size_t)c[i] * G] += 1;
   uint32_t base = 0;
   for (uint32_t b = nb; b-- > 0;) {  // the largest count first
     uint32_t tot;
-    const uint32_t off = g.scan(mine[b], &tot);
-    mine[b] = (uint16_t)(base + off);
+    const uint32_t off = g.scan(mine[(size_t)b * G], &tot);
+    mine[(size_t)b * G] = (uint16_t)(base + off);
     base += tot;
   }
   for (uint32_t i = c0; i < c1; ++i) {
     const uint8_t ci = c[i];
-    const uint32_t dst = mine[ci]++;
+    const uint32_t dst = mine[(size_t)ci * G]++;
     sp[dst] = p[i];
     sc[dst] = ci;
   }

@@ -140,6 +140,11 @@ struct cmgpu_ctx {
   int opt_heavy_mid = 0;             // 0: 64 hits; -1: no 16-lane class
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
   int opt_heavy_last = 0;            // heavy-last processing order: 0 auto, 1 always, -1 never
+  // candidate arrays sized from the previous batch of the same size (+ 25 %): no host wait for their total; the device checks it
+  bool pred_m_ok = false;
+  uint32_t pred_n = 0;
+  uint64_t m_cap = 0;
+  int opt_spec = 1;                  // 0: every batch waits for its totals
   int opt_coop_rb = 0;               // tests: run-table size of the cooperative sorters (0: their own)
   int opt_coop = 0xff;               // cooperative (group per item, cm_coop.h) forms of the stages for long lists: bit 0 S3b hit lists,
                                      // 1 S4b rescue hits, 2 S4c pair filter, 3 S5c acceptance, 4 S6 pairing; 0: the round-2 kernels

@@ -21,6 +21,7 @@
 // heavy items, instead of 63 light lanes waiting for one heavy lane in nearly every wave.
 #define CM_ITEM_KERNEL(kname, fn, perm)                                      \
   __global__ __launch_bounds__(CM_BLOCK) void kname(CmDev d, uint32_t n) {   \
+    if (d.abort && *d.abort) return;                                         \
     const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;                  \
     if (i < n) fn(d, d.perm ? d.perm[i] : i);                                \
   }
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_ca
 // copied -- hundreds of entries by one lane; such reads join list 6, where a wave copies them (cm_coop_rescue_merge)
 #define CM_S4B_COPY_MIN 64u
 __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t n, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t i = i0 < n ? (d.perm_reads ? d.perm_reads[i0] : i0) : 0u;
   const bool mine = i0 < n && !(d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0);  // the others: k_s4b_rescue_list
@@ -821,6 +823,7 @@ __device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_
   return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= cm_s4b_pmax(d) ? 11u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
 }
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
@@ -864,6 +867,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
 template <int G>
 __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev d, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev, uint32_t P, uint32_t RB,
                                                                       uint32_t use_slab) {
+  if (d.abort && *d.abort) return;
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = *n_list_dev;
   const size_t gb = cm_coop_group_bytes(P, 1, RB, true);
@@ -893,6 +897,7 @@ __device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair,
 #define CM_S4C_P_WAVE 1024u   // entries of a candidate list the work arrays of a wave hold
 #define CM_S4C_P_BLOCK 4096u  // ... of a block
 __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
   uint32_t cls = 0;
@@ -914,6 +919,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, ui
 // the pairs of list 9 / 14: the filter's two directions by a wave / a block each (cm_coop_s4c); the list's length is on the device
 template <int G>
 __global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint32_t lid, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = d.hv_cnt[lid];
   const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
@@ -941,6 +947,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint
 }
 // S5a.  coop: a read with more than CM_S5C_COOP_MIN candidates is left to a wave -- alignments and acceptance loop (k_s5c_coop, list 12)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
   const bool to_wave = i < n && cm_s5a_prepare(d, r, coop ? CM_S5C_COOP_MIN : 0u);
@@ -948,6 +955,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, u
 }
 // S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
   const uint32_t cmin = coop ? CM_S5C_COOP_MIN : 0u;
@@ -962,6 +970,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, 
 #define CM_SORT_NB 64u  // counts below this go through the groups' counting sort of a candidate list
 // the candidate lists of the reads in list 12 (k_s5a_prepare left them unsorted): a wave each (cm_coop_s5_sort)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d) {
+  if (d.abort && *d.abort) return;
   __shared__ uint16_t hist[CM_BLOCK * CM_SORT_NB];
   const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[12];
@@ -974,6 +983,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d) {
 #define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
 #define CM_S5C_SORT_RB 130u
 __global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P) {
+  if (d.abort && *d.abort) return;
   const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[12];
   const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
@@ -999,6 +1009,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P) {
 // ---------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(CM_BLOCK) void k_sort_lists(CmDev d) {
+  if (d.abort && *d.abort) return;
   const uint32_t wv = threadIdx.x >> 6, t = threadIdx.x & 63;
   uint64_t *K = reinterpret_cast<uint64_t *>(cm_lds) + (size_t)wv * CM_SORT_WAVE_MAX;
   uint16_t *V = reinterpret_cast<uint16_t *>(cm_lds + (size_t)(CM_BLOCK / 64) * CM_SORT_WAVE_MAX * 8) + (size_t)wv * CM_SORT_WAVE_MAX;
@@ -1052,6 +1063,7 @@ void cm_launch_k_sort_lists(const CmDev &d, int mode, hipStream_t s) {
 }
 // the number of work items is v_off[n_reads] (device side); the grid covers an upper bound, surplus blocks leave
 __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_reads) {
+  if (d.abort && *d.abort) return;
   const uint32_t n_items = d.v_off[n_reads];
   for (uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x; j < n_items; j += gridDim.x * CM_BLOCK) cm_s5b_verify_item(d, j, n_reads);
 }
@@ -1059,6 +1071,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_rea
 // S6a.  coop: a pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 13, where a wave runs its two sweeps
 #define CM_S6A_COOP_MIN 48u
 __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint32_t coop) {
+  if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
   bool to_wave = false;
@@ -1073,6 +1086,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint
   if (coop) cm_wave_append(d.hv_list + (size_t)13 * d.hv_stride, d.hv_cnt + 13, to_wave, pair);
 }
 __global__ __launch_bounds__(CM_BLOCK) void k_s6a_coop(CmDev d) {
+  if (d.abort && *d.abort) return;
   const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[13];
   const uint32_t *list = d.hv_list + (size_t)13 * d.hv_stride;
@@ -1089,6 +1103,7 @@ CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>, perm_pairs)
 // and ballot the multi-mappers; lane 0 then walks them in pair order with the chunk's
 // mt19937 (state in LDS).
 __global__ __launch_bounds__(64) void k_s6b_sample(CmDev d, uint32_t n_chunks) {
+  if (d.abort && *d.abort) return;
   const uint32_t chunk = blockIdx.x;
   if (chunk >= n_chunks) return;
   __shared__ CmMt g;
@@ -1424,6 +1439,13 @@ void cm_build_heavy_last(const CmDev &d, uint32_t n_pairs, uint32_t *fr, uint32_
 // dst[0] = src[0]: the cursor value after a chunk's minimizer launch (a device-to-device hipMemcpyAsync of 8 bytes runs as a
 // ~35 us blit kernel, eight of them sat between the chunks' minimizer and probe launches)
 __global__ void k_copy_u64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst) { dst[0] = src[0]; }
+// *flag = 1 when *total > cap (the arrays of this batch were sized ahead of its totals)
+__global__ void k_check_cap(const unsigned long long *__restrict__ total, unsigned long long cap, unsigned long long *__restrict__ flag) {
+  if (*total > cap) *flag = 1ull;
+}
+void cm_launch_k_check_cap(const unsigned long long *total, unsigned long long cap, unsigned long long *flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_check_cap, dim3(1), dim3(1), 0, s, total, cap, flag);
+}
 void cm_launch_k_copy_u64(const unsigned long long *src, unsigned long long *dst, hipStream_t s) {
   hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, s, src, dst);
 }

@@ -125,6 +125,8 @@ struct CmDev {
   uint8_t *coop_slab;      // global work memory of the groups that take lists longer than their shared memory holds:
   uint32_t coop_slab_cap;  // coop_slab_blocks slabs of cm_coop_slab_bytes(coop_slab_cap) bytes, one per block of those launches
   uint32_t coop_slab_blocks;
+  const unsigned long long *abort;  // nonzero: the candidate arrays were sized from the previous batch and this batch needs more --
+                                    // every stage from S4b on leaves at once, the host maps the range again with exact sizes
   unsigned long long *prof;  // measurement aid (cmgpu_set_option "coop_profile"): shader-clock cycles per phase of k_s3b_coop, summed over groups
   uint32_t mm_cap;  // capacity of the dense minimizer arrays (0: not checked): S3a leaves a read whose range passes it idle
   uint32_t coop_rb; // tests: run-table size of the cooperative sorters (0: two per minimizer of the longest read)
@@ -193,6 +195,8 @@ struct CmDev {
 #define CM_ST_RECORDS 11
 #define CM_ST_BC_INWL 12
 #define CM_ST_BC_CORR 13
+#define CM_ST_TOTAL 14   // scratch: the 64-bit total next to a 32-bit scan
+#define CM_ST_ABORT 15   // CmDev::abort
 #define CM_ST_N 16
 
 #endif

@@ -194,6 +194,10 @@ HEAVY_SETTINGS = {
     "declined_block": {"heavy_wave_max": 20, "coop_run_table": 3},
     # the index table re-hashed on the device into 4 times as many buckets: same lookups, fewer buckets visited
     "rehashed_table": {"probe_table_shift": 2},
+    # the candidate arrays "left by the previous batch" far too small: the device raises the abort flag, every later kernel leaves,
+    # the range is mapped again with exact sizes
+    "capacity_guess_too_small": {"debug_candidate_capacity": 64},
+    "no_speculative_sizes": {"speculative_sizes": 0},
     "declined_hits_only": {"coop": 1, "coop_run_table": 3},
     "declined_rescue_only": {"coop": 2, "coop_run_table": 3},
 }
