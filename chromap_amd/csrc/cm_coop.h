@@ -26,7 +26,11 @@ CM_HD uint32_t cm_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define CM_PROF_BEGIN(d) long long cm_prof_t_ = (d).prof ? clock64() : 0
 #define CM_PROF_MARK(d, g, k) do { if ((d).prof && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(d).prof[k], (unsigned long long)(now_ - cm_prof_t_)); cm_prof_t_ = now_; } } while (0)
 #define CM_PROF_COUNT(d, g, k, v) do { if ((d).prof && (g).t == 0) atomicAdd(&(d).prof[k], (unsigned long long)(v)); } while (0)
+#define CM_PROF_PTR_BEGIN(p) long long cm_prof_u_ = (p) ? clock64() : 0
+#define CM_PROF_PTR_MARK(p, g, k) do { if ((p) && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(p)[k], (unsigned long long)(now_ - cm_prof_u_)); cm_prof_u_ = now_; } } while (0)
 #else
+#define CM_PROF_PTR_BEGIN(p) do { } while (0)
+#define CM_PROF_PTR_MARK(p, g, k) do { } while (0)
 #define CM_PROF_BEGIN(d) do { } while (0)
 #define CM_PROF_MARK(d, g, k) do { } while (0)
 #define CM_PROF_COUNT(d, g, k, v) do { } while (0)
@@ -117,14 +121,18 @@ CM_HD uint32_t cm_coop_natural_runs(GT &g, const uint64_t *a, uint32_t tot, uint
 // ---------------------------------------------------------------------------------------
 template <class GT>
 CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, int e, int req, uint32_t num_minimizers, uint16_t *oc, uint64_t *xs,
-                         uint8_t *xc, uint64_t *out_p, uint8_t *out_pc, uint64_t *out_n, uint8_t *out_nc, uint32_t *ncp_out, uint32_t *ncn_out) {
+                         uint8_t *xc, uint64_t *out_p, uint8_t *out_pc, uint64_t *out_n, uint8_t *out_nc, uint32_t *ncp_out, uint32_t *ncn_out,
+                         unsigned long long *prof = nullptr) {
   const uint64_t SB = 1ull << 63;
+  CM_PROF_PTR_BEGIN(prof);
   for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G) {
     uint32_t c = 0;
     if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) c = cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);
     oc[i] = (uint16_t)c;
   }
+  CM_PROF_PTR_MARK(prof, g, 11);
   g.sync();
+  CM_PROF_PTR_MARK(prof, g, 12);
   // exclusive scan of oc in list order: per-lane chunk sums, group scan; the counts stay readable through the neighbour's prefix
   const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
@@ -138,6 +146,7 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   uint32_t ncp;
   (void)g.scan(ncp_mine, &ncp);
   const uint32_t ncn = total - ncp;
+  CM_PROF_PTR_MARK(prof, g, 13);
   // copy out: every lane the parked candidates of its chunk's clusters (slot i + k -> prefix(i) + k).  No barrier needed before:
   // the scans above contain them -- all walks are done, S is no longer read (the outputs may overlay it)
   for (uint32_t i = c0; i < c1; ++i) {
@@ -150,6 +159,7 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
     }
     run += c;
   }
+  CM_PROF_PTR_MARK(prof, g, 14);
   *ncp_out = ncp;
   *ncn_out = ncn;
 }
@@ -316,7 +326,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   uint64_t *h = d.hbuf + d.hit_off[r];
   uint8_t *hc = d.hcnt + d.hit_off[r];
   uint32_t ncp, ncn;
-  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, SLAB ? m.goc : m.oc, S == A ? B : A, SLAB ? m.gcc : m.cc, h, hc, h + np, hc + np, &ncp, &ncn);
+  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, SLAB ? m.goc : m.oc, S == A ? B : A, SLAB ? m.gcc : m.cc, h, hc, h + np, hc + np, &ncp, &ncn, d.prof);
   CM_PROF_MARK(d, g, 5);
   if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
   return true;

@@ -30,6 +30,8 @@ def main():
     print("groups %d, mean hits %.0f, mean runs %.1f, mean cycles per group %.0f" % (n, v[10] / n, v[9] / n, tot / n))
     for k, nm in enumerate(names):
         print("  %-28s %5.1f %%  %8.0f cycles per group" % (nm, 100.0 * v[k] / tot, v[k] / n))
+    print("  inside the sweep: walks %.0f, barrier after them %.0f, chunk sums + scans %.0f, copy-out %.0f cycles per group"
+          % (v[11] / n, v[12] / n, v[13] / n, v[14] / n))
     print("timings of the last batch:", g.timings())
 
 
