@@ -125,10 +125,25 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
                          unsigned long long *prof = nullptr) {
   const uint64_t SB = 1ull << 63;
   CM_PROF_PTR_BEGIN(prof);
-  for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G) {
-    uint32_t c = 0;
-    if (i == 0 || cm_sweep_local_break(S[i - 1], S[i], e)) c = cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);
-    oc[i] = (uint16_t)c;
+  // which of this lane's hits (t, t + G, ...) start a local cluster: a bit each (a lane has at most 64 of them: tot <= 64 G
+  // for every work area), then one walk per set bit.  The two loops are apart on purpose: a walk is a chain of dependent loads, and
+  // a wave pays for it in every round in which ANY of its lanes walks -- about one hit in eight starts a cluster, so with the test
+  // and the walk in one loop every round paid (5 rounds, 31 of the sweep's 38 k cycles), while a lane's own starts are 2-3 at most
+  unsigned long long starts = 0;
+  {
+    uint32_t j = 0;
+    for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G, ++j) {
+      const bool st = i == 0 || cm_sweep_local_break(S[i - 1], S[i], e);
+      if (st && j < 64) starts |= 1ull << j;
+      else if (st) oc[i] = (uint16_t)cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);  // (never: see above)
+      else oc[i] = 0;
+    }
+  }
+  while (starts) {
+    const uint32_t j = (uint32_t)__builtin_ctzll(starts);
+    starts &= starts - 1;
+    const uint32_t i = g.t + j * (uint32_t)GT::G;
+    oc[i] = (uint16_t)cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);
   }
   CM_PROF_PTR_MARK(prof, g, 11);
   g.sync();
@@ -136,15 +151,12 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   // exclusive scan of oc in list order: per-lane chunk sums, group scan; the counts stay readable through the neighbour's prefix
   const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
-  uint32_t sum = 0;
-  for (uint32_t i = c0; i < c1; ++i) sum += oc[i];
-  uint32_t total;
-  uint32_t run = g.scan(sum, &total);
-  // the + list's candidates: clusters that start before np
-  uint32_t ncp_mine = 0;
-  for (uint32_t i = c0; i < c1 && i < np; ++i) ncp_mine += oc[i];
-  uint32_t ncp;
-  (void)g.scan(ncp_mine, &ncp);
+  // (both sums in one scan: a list has at most 65535 hits -- the offsets are 16-bit -- and no more candidates than hits)
+  uint32_t sum = 0, ncp_mine = 0;
+  for (uint32_t i = c0; i < c1; ++i) { const uint32_t c = oc[i]; sum += c; if (i < np) ncp_mine += c; }
+  uint32_t both;
+  uint32_t run = g.scan(sum << 16 | ncp_mine, &both) >> 16;
+  const uint32_t total = both >> 16, ncp = both & 0xffffu;
   const uint32_t ncn = total - ncp;
   CM_PROF_PTR_MARK(prof, g, 13);
   // copy out: every lane the parked candidates of its chunk's clusters (slot i + k -> prefix(i) + k).  No barrier needed before:
