@@ -97,6 +97,9 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "probe_table_shift") {  // 0: probe the file's table; 1 / 2: a device copy with 2 / 4 times the buckets
     if (value < 0 || value > 4) { cm_set_error(c, "probe_table_shift: 0..4"); return CMGPU_EINVAL; }
     return build_fast_table(c, (int)value);
+  } else if (n == "verify_planes") {  // 0: k_s5b_verify aligns on the reference / read bytes (the round-2 form) instead of their bit planes
+    c->opt_planes = value ? 1 : 0;
+    if (!c->opt_planes) { c->ref_planes.release(); c->ref_pl_words = 0; }
   } else if (n == "speculative_sizes") {  // 0: every batch waits for the total of its candidate lists before sizing their arrays
     c->opt_spec = value ? 1 : 0;
   } else if (n == "debug_candidate_capacity") {  // tests: pretend the previous batch left this much room (forces the re-run path)
@@ -275,6 +278,7 @@ int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref) {
     tot = (tot + 15) & ~15ull;
   }
   c->ref_bytes = tot;
+  c->ref_planes.release(); c->ref_pl_words = 0;
   if (c->ref.ensure(tot) || c->ref_off.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 8) || c->ref_len.ensure((size_t)(c->n_seq ? c->n_seq : 1) * 4)) {
     cm_set_error(c, "out of device memory (reference)"); return CMGPU_ENOMEM;
   }
@@ -284,6 +288,17 @@ int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref) {
   if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_off.p, c->h_ref_off.data(), (size_t)c->n_seq * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess && c->n_seq) e = hipMemcpy(c->ref_len.p, c->h_ref_len.data(), (size_t)c->n_seq * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) { cm_set_error(c, std::string("reference upload: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
+  return CMGPU_OK;
+}
+
+// the reference bytes -> three bit planes (CmDev::ref_pl), 3/8 of a byte per base next to the bytes themselves
+int cm_build_ref_planes(cmgpu_ctx *c) {
+  const uint64_t words = (c->ref_bytes + 31) / 32 + 4;
+  if (c->ref_planes.ensure((size_t)words * 3 * 4)) { cm_set_error(c, "out of device memory (reference bit planes)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemsetAsync(c->ref_planes.p, 0, (size_t)words * 3 * 4, c->stream));
+  cm_launch_k_pack_ref((const uint8_t *)c->ref.p, c->ref_bytes, (uint32_t *)c->ref_planes.p, words, c->stream);
+  HIPCHECK(c, cm_stream_sync(c->stream));  // the lanes read them from streams of their own
+  c->ref_pl_words = words;
   return CMGPU_OK;
 }
 
@@ -349,6 +364,8 @@ extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
   view(c->bkt, parent->bkt); view(c->occ, parent->occ); view(c->ref, parent->ref);
   view(c->ref_off, parent->ref_off); view(c->ref_len, parent->ref_len);
   c->bmask = parent->bmask; c->n_occ = parent->n_occ; c->n_seq = parent->n_seq; c->ref_bytes = parent->ref_bytes;
+  c->opt_planes = parent->opt_planes;
+  if (parent->ref_pl_words) { view(c->ref_planes, parent->ref_planes); c->ref_pl_words = parent->ref_pl_words; }  // (else: its own, on its first call)
   c->h_ref_off = parent->h_ref_off; c->h_ref_len = parent->h_ref_len;
   c->synth_n_minimizers = parent->synth_n_minimizers; c->synth_n_keys = parent->synth_n_keys;
   // --chr-order / --pairs-natural-chr-order of the parent apply to the child too (records carry ranks)
@@ -657,6 +674,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.bkt = (const uint64_t *)(c->fmask ? c->bkt_fast.p : c->bkt.p); d.bmask = c->fmask ? c->fmask : c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
   d.n_seq = c->n_seq;
+  d.ref_pl = c->ref_pl_words ? (const uint32_t *)c->ref_planes.p : nullptr; d.ref_pl_words = c->ref_pl_words;
   d.p = c->p;
   d.p.single = c->single ? 1 : 0;
   d.mq.len_coef = (const double *)c->len_coef.p; d.mq.nsec_break = (const uint32_t *)c->nsec_break.p; d.mq.n_break = c->n_break;
@@ -882,6 +900,18 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     cm_launch_k_probe_reduce(c->partials.p, part_off[n_chunks], d.stats + CM_ST_PROBE_STEPS, s);
     mark(c, "s1b_s2_minimizers_probe");
   }
+  // the alignments of S5b run on bit planes: this range's reads, both orientations, packed on the second stream (idle from here
+  // on) under S3 and S4 -- the trimmed lengths are final
+  const bool planes = c->ref_pl_words && !c->p.split;
+  if (planes) {
+    const uint32_t pw = (c->max_read_len + 31) / 32;
+    if (c->read_planes.ensure((size_t)n2 * 6 * pw * 4 + 16)) { cm_set_error(c, "out of device memory (read planes)"); return CMGPU_ENOMEM; }
+    HIPCHECK(c, hipEventRecord(c->chunk_ev[1], s));
+    HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[1], 0));
+    d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = pw;
+    cm_launch_k_pack_reads(d, n2, c->stream2);
+    HIPCHECK(c, hipEventRecord(c->chunk_ev[0], c->stream2));
+  }
   // S3: hit counts -> offsets -> candidates
   if (!s3a_done) {
     HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
@@ -954,6 +984,10 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
   mark(c, "s5a_prepare");
+  if (planes) {
+    HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[0], 0));  // k_pack_reads (second stream) is done
+    d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = (c->max_read_len + 31) / 32;
+  }
   cm_launch_k_s5b_verify(d, n_m, n2, s);
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
@@ -1042,6 +1076,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   cmgpu_ctx *l = c->lanes[i];
   auto view = [](DevBuf &dst, const DevBuf &src) { dst.p = src.p; dst.cap = src.cap; dst.owned = false; };
   view(l->bkt_fast, c->bkt_fast); l->fmask = c->fmask;
+  view(l->ref_planes, c->ref_planes); l->ref_pl_words = c->ref_pl_words; l->opt_planes = c->opt_planes;
   view(l->rb0, c->rb0); view(l->rb1, c->rb1); view(l->ro0, c->ro0); view(l->ro1, c->ro1);
   view(l->rec, c->rec); view(l->rec_ok, c->rec_ok);
   view(l->bcb, c->bcb); view(l->bcq, c->bcq); view(l->bco, c->bco); view(l->bc_key, c->bc_key); view(l->bc_ok, c->bc_ok);
@@ -1085,6 +1120,10 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     }
     c->sam_slots = slots;
     c->sam_md_cap = md_cap;
+  }
+  if (c->opt_planes && !c->p.split && !c->ref_pl_words && c->ref_bytes) {  // once per reference: its bit planes (k_s5b_verify)
+    const int rc = cm_build_ref_planes(c);
+    if (rc) return rc;
   }
   // Lanes: the batch cut on reference-batch boundaries into up to opt_lanes ranges that are mapped side by side, each on
   // its own streams with its own intermediates -- the latency-bound stages of one range fill the gaps of the others'.

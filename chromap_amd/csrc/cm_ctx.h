@@ -73,6 +73,11 @@ struct cmgpu_ctx {
   // pipeline probes it instead -- same keys, values, hash and probe sequence, fewer buckets visited per lookup
   DevBuf bkt_fast, coop_prof;
   uint32_t fmask = 0;
+  // the reference as bit planes (CmDev::ref_pl; built on the first mapping call, views in the lanes) and the resident batch's
+  // reads as bit planes (CmDev::read_pl, per range): what k_s5b_verify aligns on.  cmgpu_set_option "verify_planes" 0: the byte form
+  DevBuf ref_planes, read_planes;
+  uint64_t ref_pl_words = 0;
+  int opt_planes = 1;
   int n_break = 0;
   uint64_t ref_bytes = 0;
   std::vector<uint64_t> h_ref_off;
@@ -178,7 +183,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
   }
 };
 
@@ -199,6 +204,7 @@ static inline hipError_t cm_stream_sync(hipStream_t s) {
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id);
 void cm_fill_dev(cmgpu_ctx *c, CmDev &d);
 int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref);
+int cm_build_ref_planes(cmgpu_ctx *c);
 // cm_post.hip: room for `need` records in the device-side store (with_bc: the parallel barcode array too)
 int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc);
 // record slots of the resident batch: max_num_best_mappings per pair (cm_emit_record); flag / position scratch for a

@@ -1696,6 +1696,185 @@ CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, in
 }
 
 // ---------------------------------------------------------------------------------------
+// BandedAlignPatternToText (alignment.cc:141-192) on BIT PLANES -- the form k_s5b_verify runs.  The byte form above spends
+// most of a column on getting at its two symbols (two streamed byte readers, two CharToUint8, five conditional ORs into the
+// Peq words, a five-way select out of them: ~130 instructions per column on gfx950, the select compiled to branches) and the
+// Myers step itself is twelve.  Here a sequence is three bit planes -- bit i of plane 0 / 1 = the two bits of base i's code,
+// plane 2 = the base is none of ACGTacgt (code 4, planes 0 / 1 then 0) -- packed once: the reference when it is loaded, every
+// read of the batch in both orientations before the alignments.  The Peq word of text symbol c at column i,
+//     bit j  <=>  code(pattern[i + j]) == c,   j = 0 .. 2e
+// is then bits [i, i + 2e] of   c < 4 ?  ~(R0 ^ m0) & ~(R1 ^ m1) & ~RN  :  RN    (m0, m1: bit 0 / 1 of c spread over the word),
+// a shift of three 64-bit windows and four logic operations; the windows slide by one 32-bit word per 32 columns.  Everything
+// after the Peq word is the byte form's code, so the two return the same (distance, end position) for every input.
+//   rp / rw:  reference planes (CmDev::ref_pl, ref_pl_words);  g: index of the window's first base in the reference bytes
+//             (the byte form's `pattern` - d.ref);  tp / tw: the text's planes in the wanted orientation (CmDev::read_pl)
+// ---------------------------------------------------------------------------------------
+CM_HD uint64_t cm_load8(const uint8_t *p);
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CM_GLOBAL_U32 const __attribute__((address_space(1))) uint32_t *
+#else
+#define CM_GLOBAL_U32 const uint32_t *
+#endif
+CM_HD uint32_t cm_funnel32(uint32_t lo, uint32_t hi, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo, sh < 32
+  return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+}
+CM_HD int cm_banded_align_planes(int e, const uint32_t *rp, uint64_t rw, uint64_t g, const uint32_t *tp, uint32_t tw, int L, int *end_pos) {
+  CM_GLOBAL_U32 r0 = (CM_GLOBAL_U32)rp + (g >> 5);
+  CM_GLOBAL_U32 r1 = r0 + rw;
+  CM_GLOBAL_U32 rn = r1 + rw;
+  CM_GLOBAL_U32 t0 = (CM_GLOBAL_U32)tp;
+  CM_GLOBAL_U32 t1 = t0 + tw;
+  CM_GLOBAL_U32 tn = t1 + tw;
+  const uint32_t sh = (uint32_t)g & 31u;
+  uint32_t a0 = r0[0], a1 = r1[0], an = rn[0], b0 = r0[1], b1 = r1[1], bn = rn[1];
+  uint32_t c0 = r0[2], c1 = r1[2], cn = rn[2];
+  uint32_t x0 = t0[0], x1 = t1[0], xn = tn[0];
+  const uint32_t band = (2u << (2 * e)) - 1u;
+  uint32_t VP = 0, VN = 0;
+  int err = 0;
+  const int nchunk = (L + 31) >> 5;
+  for (int c = 0; c < nchunk; ++c) {
+    // the next chunk's words are requested before this chunk's columns run
+    const bool more = c + 1 < nchunk;
+    const uint32_t d0 = more ? r0[c + 3] : 0u, d1 = more ? r1[c + 3] : 0u, dn = more ? rn[c + 3] : 0u;
+    const uint32_t y0 = more ? t0[c + 1] : 0u, y1 = more ? t1[c + 1] : 0u, yn = more ? tn[c + 1] : 0u;
+    const uint64_t W0 = (uint64_t)cm_funnel32(a0, b0, sh) | ((uint64_t)cm_funnel32(b0, c0, sh) << 32);
+    const uint64_t W1 = (uint64_t)cm_funnel32(a1, b1, sh) | ((uint64_t)cm_funnel32(b1, c1, sh) << 32);
+    const uint64_t WN = (uint64_t)cm_funnel32(an, bn, sh) | ((uint64_t)cm_funnel32(bn, cn, sh) << 32);
+    const int jn = L - 32 * c < 32 ? L - 32 * c : 32;
+    for (int j = 0; j < jn; ++j) {
+      const uint32_t B0 = (uint32_t)(W0 >> j), B1 = (uint32_t)(W1 >> j), BN = (uint32_t)(WN >> j);
+      const uint32_t m0 = 0u - ((x0 >> j) & 1u), m1 = 0u - ((x1 >> j) & 1u), mn = 0u - ((xn >> j) & 1u);
+      const uint32_t eq = ~(B0 ^ m0) & ~(B1 ^ m1) & ~BN;
+      uint32_t X = ((((eq ^ BN) & mn) ^ eq) & band) | VN;  // text symbol outside ACGT: the positions where the pattern's is too
+      const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+      const uint32_t HN = VP & D0;
+      const uint32_t HP = VN | ~(VP | D0);
+      X = D0 >> 1;
+      VN = X & HP;
+      VP = HN | ~(X | HP);
+      err += 1 - (int)(D0 & 1u);
+      if (err > 3 * e) return e + 1;
+    }
+    a0 = b0; b0 = c0; c0 = d0; a1 = b1; b1 = c1; c1 = d1; an = bn; bn = cn; cn = dn;
+    x0 = y0; x1 = y1; xn = yn;
+  }
+  const int band_start = L - 1;
+  int min_err = err;
+  *end_pos = band_start;
+  for (int i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *end_pos = band_start + 1 + i;
+    }
+  }
+  return min_err;
+}
+// 32 bases -> one word of each plane; n < 32: the bases beyond count as code 4
+CM_HD void cm_pack_planes32(const uint8_t *bytes, uint32_t n, uint32_t *p0, uint32_t *p1, uint32_t *pn) {
+  uint32_t q0 = 0, q1 = 0, qn = 0;
+  for (uint32_t j0 = 0; j0 < 32; j0 += 8) {
+    uint64_t v = j0 < n ? cm_load8(bytes + j0) : 0;
+    for (uint32_t j = j0; j < j0 + 8; ++j, v >>= 8) {
+      const uint32_t u = j < n ? cm_c2u((uint8_t)v) : 4u;
+      q0 |= (u & 1u) << j; q1 |= ((u >> 1) & 1u) << j; qn |= (u >> 2) << j;
+    }
+  }
+  *p0 = q0; *p1 = q1; *pn = qn;
+}
+CM_HD uint32_t cm_brev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(v);
+#else
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+  return (v >> 16) | (v << 16);
+#endif
+}
+// read r of the batch -> its planes, forward (the read as it is: the + strand's text) and reverse complement (base i =
+// complement of read[L - 1 - i], L the trimmed length: the - strand's text, PrepareNegativeSequenceAt); the second from the first:
+// word w of the reversed planes is the bit reversal of the forward planes' bits [L - 32 w - 32, L - 32 w).
+// Any number of words per plane, the forward words read back from memory:
+CM_HD void cm_pack_read_planes_any(const CmDev &d, uint32_t r) {
+  const uint32_t W = d.read_pl_w, L = d.rlen[r];
+  if (L == 0) return;
+  uint32_t *f = d.read_pl + (size_t)r * 6 * W, *v = f + 3 * (size_t)W;
+  const uint8_t *read = cm_read_ptr(d, r);
+  const uint32_t nw = (L + 31) >> 5;
+  for (uint32_t w = 0; w < nw; ++w) cm_pack_planes32(read + 32 * w, L - 32 * w, f + w, f + W + w, f + 2 * W + w);
+  for (uint32_t w = 0; w < nw; ++w) {
+    const int lo = (int)L - 32 * (int)w - 32;  // first source bit of this word
+    uint32_t F[3];
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t *src = f + (size_t)q * W;
+      if (lo >= 0) {
+        const uint32_t a = (uint32_t)lo >> 5, sh = (uint32_t)lo & 31u;
+        F[q] = cm_funnel32(src[a], a + 1 < nw ? src[a + 1] : 0u, sh);
+      } else F[q] = src[0] << (uint32_t)(-lo);
+    }
+    v[w] = ~cm_brev32(F[0]); v[W + w] = ~cm_brev32(F[1]); v[2 * W + w] = cm_brev32(F[2]);
+  }
+}
+// W words per plane known at compile time: everything in registers -- the reversed planes are the forward words bit-reversed in
+// reverse order, moved down by 32 W - L bits -- and the read's 6 W words leave in 16-byte stores (k_pack_reads: the reads of a
+// wave are neighbours in the batch, so are their planes)
+template <int W>
+CM_HD void cm_pack_read_planes_w(const CmDev &d, uint32_t r) {
+  const uint32_t L = d.rlen[r];
+  if (L == 0) return;
+  const uint8_t *read = cm_read_ptr(d, r);
+  uint32_t o[6 * W];  // [orientation][plane][word]
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    o[w] = 0; o[W + w] = 0; o[2 * W + w] = 0;
+    if (32u * (uint32_t)w < L) cm_pack_planes32(read + 32 * w, L - 32u * (uint32_t)w, &o[w], &o[W + w], &o[2 * W + w]);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    uint32_t *v = o + 3 * W + q * W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) v[w] = cm_brev32(o[q * W + (W - 1 - w)]);
+    uint32_t s = 32u * W - L;
+    while (s >= 32) {
+#pragma unroll
+      for (int w = 0; w + 1 < W; ++w) v[w] = v[w + 1];
+      v[W - 1] = 0;
+      s -= 32;
+    }
+    if (s) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) v[w] = (v[w] >> s) | (w + 1 < W ? v[w + 1] << (32u - s) : 0u);
+    }
+    if (q < 2) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) v[w] = ~v[w];
+    }
+  }
+  uint32_t *dst = d.read_pl + (size_t)r * 6 * W;
+  if ((6 * W) % 4 == 0) {
+    struct alignas(16) Q { uint32_t a, b, c, e; };
+#pragma unroll
+    for (int i = 0; i < 6 * W; i += 4) { Q x = {o[i], o[i + 1], o[i + 2], o[i + 3]}; *reinterpret_cast<Q *>(dst + i) = x; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6 * W; ++i) dst[i] = o[i];
+  }
+}
+CM_HD void cm_pack_read_planes(const CmDev &d, uint32_t r) {
+  switch (d.read_pl_w) {
+    case 1: cm_pack_read_planes_w<1>(d, r); break;
+    case 2: cm_pack_read_planes_w<2>(d, r); break;
+    case 3: cm_pack_read_planes_w<3>(d, r); break;
+    case 4: cm_pack_read_planes_w<4>(d, r); break;
+    default: cm_pack_read_planes_any(d, r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // The first thing BandedTraceback does (alignment.cc:660-670) is a raw, case-sensitive Hamming
 // count of the read against the window at offset e; when it equals the edit distance the start is e
 // and nothing else runs -- the common case (substitution errors only).  Here that count works on
@@ -2159,8 +2338,12 @@ CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci)
   const uint32_t rid = (uint32_t)(cpos >> 32);
   const uint32_t position = strand == 0 ? (uint32_t)cpos : (uint32_t)cpos - L + 1;
   if (!cm_valid_candidate(d, rid, position, L)) { d.v_err[o] = CM_V_INVALID; d.v_end[o] = 0; return; }
-  int end_pos;
-  const int ne = cm_verify_compute(d, cm_read_ptr(d, r), L, strand, cpos, &end_pos);
+  int end_pos = (int)L;
+  int ne;
+  if (d.ref_pl && d.read_pl)  // the same alignment on bit planes (cm_banded_align_planes)
+    ne = cm_banded_align_planes(d.p.e, d.ref_pl, d.ref_pl_words, d.ref_off[rid] + position - (uint32_t)d.p.e,
+                                d.read_pl + ((size_t)r * 2 + (size_t)strand) * 3 * d.read_pl_w, d.read_pl_w, (int)L, &end_pos);
+  else ne = cm_verify_compute(d, cm_read_ptr(d, r), L, strand, cpos, &end_pos);
   d.v_err[o] = (int16_t)ne;
   d.v_end[o] = (int16_t)end_pos;
 }

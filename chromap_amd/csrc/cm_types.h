@@ -75,6 +75,14 @@ struct CmDev {
   const uint64_t *ref_off;
   const uint32_t *ref_len;
   uint32_t n_seq;
+  // ---- the same bytes as bit planes (cm_pack_planes32, cm_stages.h): base i of `ref` is bit i of plane 0 / 1 (the two bits
+  //      of its CharToUint8 code) and of plane 2 (none of ACGTacgt); plane q at ref_pl + q * ref_pl_words.  nullptr: not built
+  const uint32_t *ref_pl;
+  uint64_t ref_pl_words;
+  // ---- the batch's reads as bit planes, forward and reverse complement (cm_pack_read_planes): read r, orientation o, plane q at
+  //      read_pl + ((r * 2 + o) * 3 + q) * read_pl_w, read_pl_w words of 32 bases each.  nullptr: not packed
+  uint32_t *read_pl;
+  uint32_t read_pl_w;
   CmParams p;
   CmMapqTables mq;
   // ---- batch

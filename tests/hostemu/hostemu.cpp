@@ -32,6 +32,8 @@ extern "C" void hostemu_set_pairs_chr_order(const uint32_t *rank, uint32_t n) { 
 // above which an item goes to a group, and the geometry of the group's shared work area
 struct EmuCoop { int G; uint32_t thr, P, MM, RB; };
 static EmuCoop g_coop = {0, 0, 0, 0, 0};
+static bool g_planes = true;  // the bit-plane verification (k_pack_ref / k_pack_reads + cm_banded_align_planes); 0: the byte form
+extern "C" void hostemu_set_planes(int on) { g_planes = on != 0; }
 static unsigned long long g_coop_items[8];  // items that went through each cooperative stage / fell back (tests look at them)
 extern "C" void hostemu_set_coop(int G, uint32_t thr, uint32_t P, uint32_t MM, uint32_t RB) {
   g_coop = EmuCoop{G, thr, P, MM, RB};
@@ -159,6 +161,15 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   std::vector<uint8_t> refb(tot, 0);
   for (uint32_t i = 0; i < ref->n_sequences; ++i) memcpy(refb.data() + roff[i], ref->sequences[i], ref->lengths[i]);
   d.ref = refb.data(); d.ref_off = roff.data(); d.ref_len = ref->lengths; d.n_seq = ref->n_sequences;
+  // the reference as bit planes (k_pack_ref): k_s5b_verify aligns on them
+  const uint64_t rplw = (tot + 31) / 32 + 4;
+  std::vector<uint32_t> refpl;
+  if (g_planes) {
+    refpl.assign((size_t)rplw * 3, 0);
+    for (uint64_t w = 0; w * 32 < tot; ++w)
+      cm_pack_planes32(refb.data() + 32 * w, (uint32_t)(tot - 32 * w < 32 ? tot - 32 * w : 32), &refpl[w], &refpl[rplw + w], &refpl[2 * rplw + w]);
+    d.ref_pl = refpl.data(); d.ref_pl_words = rplw;
+  }
   std::vector<uint64_t> roff_r(ref->n_sequences);
   std::vector<uint32_t> rlen_r(ref->n_sequences);
   if (g_rank.size() == ref->n_sequences) {  // cmgpu_set_chr_order: the stages see the reference reordered by rank
@@ -326,6 +337,15 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   };
   s5_groups(0);  // k_s5_sort_coop: the heavy reads' candidate lists
   scan(d.nv, d.v_off, n2);
+  std::vector<uint32_t> readpl;  // k_pack_reads
+  if (g_planes) {
+    uint32_t maxlen = 1;
+    for (uint32_t r = 0; r < n2; ++r) maxlen = d.rlen[r] > maxlen ? d.rlen[r] : maxlen;
+    d.read_pl_w = (maxlen + 31) / 32;
+    readpl.assign((size_t)n2 * 6 * d.read_pl_w + 4, 0xA5A5A5A5u);
+    d.read_pl = readpl.data();
+    for (uint32_t r = 0; r < n2; ++r) cm_pack_read_planes(d, r);
+  }
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
   for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r, s5_min);
   g_coop_items[4] += s5_heavy.size();
@@ -767,4 +787,66 @@ extern "C" int hostemu_sort_cand_check(const uint64_t *p, const uint8_t *c, uint
   if (G == 16) return emu_sort_cand_check<16>(p, c, n, nb_cap, reverse != 0);
   if (G == 64) return emu_sort_cand_check<64>(p, c, n, nb_cap, reverse != 0);
   return emu_sort_cand_check<256>(p, c, n, nb_cap, reverse != 0);
+}
+
+// cm_banded_align_planes against cm_banded_align (the byte form) on `rounds` random cases: a reference of ref_len bytes with
+// letters of both cases and a share of other bytes, reads cut from it with substitutions / insertions / deletions / Ns, both
+// strands, every window offset modulo 32, read lengths 1..max_len, error thresholds 1..max_e.  Returns the number of cases in
+// which (distance, end position) differ.
+extern "C" int hostemu_align_planes_check(uint64_t seed, uint32_t rounds, uint32_t max_len, int max_e) {
+  uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  const uint32_t ref_len = 4096;
+  std::vector<uint64_t> refw(ref_len / 8 + 8, 0);
+  uint8_t *ref = (uint8_t *)refw.data();
+  const char *alpha = "ACGTacgtACGTACGTNnRX";
+  for (uint32_t i = 0; i < ref_len; ++i) ref[i] = (uint8_t)alpha[rnd() % 20];
+  const uint64_t rw = ref_len / 32 + 4;
+  std::vector<uint32_t> rp((size_t)rw * 3, 0);
+  for (uint32_t w = 0; w * 32 < ref_len; ++w) cm_pack_planes32(ref + 32 * w, ref_len - 32 * w, &rp[w], &rp[rw + w], &rp[2 * rw + w]);
+  int bad = 0;
+  for (uint32_t it = 0; it < rounds; ++it) {
+    const int e = 1 + (int)(rnd() % (uint64_t)max_e);
+    const uint32_t L = 1 + (uint32_t)(rnd() % max_len);
+    const uint32_t g = (uint32_t)(rnd() % (ref_len - L - 2 * (uint32_t)e - 40));
+    const int strand = (int)(rnd() & 1);
+    // the read: the window's middle with edits (or something unrelated one time in eight)
+    std::vector<uint64_t> rdw((L + 31) / 8 + 3, 0);
+    uint8_t *fw = (uint8_t *)rdw.data();
+    const bool unrelated = rnd() % 8 == 0;
+    uint32_t src = g + (uint32_t)e + (uint32_t)(rnd() % 3) - 1;
+    for (uint32_t i = 0; i < L; ++i) {
+      uint8_t c = unrelated ? (uint8_t)"ACGT"[rnd() % 4] : ref[src < ref_len ? src : ref_len - 1];
+      const uint64_t x = rnd() % 64;
+      if (x == 0) c = (uint8_t)"ACGT"[rnd() % 4];
+      else if (x == 1) { ++src; }
+      else if (x == 2 && src > 0) { --src; }
+      else if (x == 3) c = 'N';
+      else if (x == 4) c = (uint8_t)(c | 0x20);
+      fw[i] = c;
+      ++src;
+    }
+    // the read as the batch holds it: for the - strand the stored read is the reverse complement of the text
+    std::vector<uint64_t> stw((L + 31) / 8 + 3, 0);
+    uint8_t *stored = (uint8_t *)stw.data();
+    for (uint32_t i = 0; i < L; ++i) stored[i] = strand ? cm_negchar(fw[L - 1 - i]) : fw[i];
+    int end_a = (int)L, end_b = (int)L;
+    const int na = cm_banded_align(e, ref + g, stored, (int)L, strand == 1, 0, (int)L, &end_a);
+    // planes of the stored read, both orientations, through the product's packer
+    CmDev d;
+    memset(&d, 0, sizeof(d));
+    uint32_t rlen[2] = {L, 0};
+    uint32_t ro[3] = {0, L, L};
+    d.rlen = rlen; d.rb0 = stored; d.rb1 = stored; d.ro0 = ro; d.ro1 = ro;
+    const uint32_t W = (L + 31) / 32;
+    std::vector<uint32_t> tp((size_t)6 * W + 2, 0x5A5A5A5Au);
+    d.read_pl = tp.data(); d.read_pl_w = W;
+    cm_pack_read_planes(d, 0);
+    const int nb = cm_banded_align_planes(e, rp.data(), rw, g, tp.data() + (size_t)strand * 3 * W, W, (int)L, &end_b);
+    if (na != nb || end_a != end_b) {
+      if (bad < 5) fprintf(stderr, "align planes: case %u e %d L %u g %u strand %d: bytes (%d, %d) planes (%d, %d)\n", it, e, L, g, strand, na, end_a, nb, end_b);
+      ++bad;
+    }
+  }
+  return bad;
 }

@@ -77,3 +77,17 @@ def test_barcode_correction_dense_whitelist(bc_err, tmp_path):
     assert (s["num_barcode_in_whitelist"], s["num_corrected_barcode"]) == (n_in, n_corr)
     assert n_corr > 10
     assert got == want
+
+
+def test_alignment_on_bit_planes_equals_byte_form():
+    """cm_banded_align_planes (what k_s5b_verify runs) against cm_banded_align on random windows: both cases of the letters,
+    bytes outside ACGT on both sides, indels, every window offset modulo 32, reads of 1..150 (one to five plane words) and
+    error thresholds 1..15, both strands through the product's packer (cm_pack_read_planes)"""
+    import hostemu_lib as hl
+    L = hl.lib()
+    f = L.hostemu_align_planes_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    assert f(1, 40000, 70, 8) == 0
+    assert f(2, 20000, 150, 15) == 0
+    assert f(3, 20000, 33, 4) == 0
