@@ -97,6 +97,8 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "probe_table_shift") {  // 0: probe the file's table; 1 / 2: a device copy with 2 / 4 times the buckets
     if (value < 0 || value > 4) { cm_set_error(c, "probe_table_shift: 0..4"); return CMGPU_EINVAL; }
     return build_fast_table(c, (int)value);
+  } else if (n == "long_read_fused") {  // 0: reads longer than 69 bases take the two-pass minimizer kernels (count, scan, fill)
+    c->opt_long_fused = value ? 1 : 0;
   } else if (n == "verify_planes") {  // 0: k_s5b_verify aligns on the reference / read bytes (the round-2 form) instead of their bit planes
     c->opt_planes = value ? 1 : 0;
     if (!c->opt_planes) { c->ref_planes.release(); c->ref_pl_words = 0; }
@@ -786,7 +788,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   uint32_t n_heavy[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lists 0..2, 10 by size, 3: one lane each, 4: the short lists of the 16-lane groups
   unsigned long long hits_total = 0;
   const bool flat = c->opt_prep_kernel == 1 && cm_prep_flat_supported(d, c->max_read_len, (uint32_t)c->opt_prep_tile_reads);
-  if (flat || cm_prep_mm_supported(d, c->max_read_len)) {
+  if (flat || (cm_prep_mm_supported(d, c->max_read_len) && (c->max_read_len <= 69 || c->opt_long_fused))) {
     // S0 + S1 fused: one pass of the minimizer state machine, block-level reservation of the dense arrays
     uint64_t cap = (uint64_t)n2 * (c->max_read_len / 4 + 3);
     const uint64_t bound = (uint64_t)c->bases0 + c->bases1 + 1;  // one emission per k-mer position at most
@@ -813,7 +815,10 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
         max_entries[ch] = me;
         part_off[ch + 1] = part_off[ch] + cm_probe_range_blocks(me, c->opt_probe_variant);
       }
+      uint32_t chunk_pairs = 0;
+      for (uint32_t ch = 0; ch < n_chunks; ++ch) chunk_pairs = lo[ch + 1] - lo[ch] > chunk_pairs ? lo[ch + 1] - lo[ch] : chunk_pairs;
       if (c->mm_hash.ensure((size_t)cap * 8 + 8) || c->mm_ps.ensure((size_t)cap * 4 + 4) || c->pr_val.ensure((size_t)cap * 8 + 8) ||
+          (!flat && c->mm_stage.ensure(cm_prep_mm_stage_bytes(d, c->max_read_len, chunk_pairs) + 8)) ||
           c->pr_kind.ensure((size_t)cap + 4) || c->mm_cursor.ensure(8) || c->mm_marks.ensure((CM_MM_CHUNKS + 1) * 8) ||
           c->partials.ensure(((size_t)part_off[n_chunks] + 1) * 8 + cm_stats_partial_words(n) * 8)) {
         cm_set_error(c, "out of device memory (minimizers)"); return CMGPU_ENOMEM;
@@ -825,7 +830,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       unsigned long long *marks = (unsigned long long *)c->mm_marks.p;
       for (uint32_t ch = 0; ch < n_chunks; ++ch) {
         if (flat) cm_launch_k_prep_flat(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)c->opt_prep_tile_reads, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
-        else cm_launch_k_prep_mm(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s);
+        else cm_launch_k_prep_mm(d, lo[ch], lo[ch + 1], c->max_read_len, (uint32_t)cap, (unsigned long long *)c->mm_cursor.p, s, c->mm_stage.p);
         cm_launch_k_copy_u64((const unsigned long long *)c->mm_cursor.p, marks + ch + 1, s);
         HIPCHECK(c, hipEventRecord(c->chunk_ev[ch], s));
         HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[ch], 0));
@@ -1076,7 +1081,7 @@ static int lane_prepare(cmgpu_ctx *c, size_t i) {
   cmgpu_ctx *l = c->lanes[i];
   auto view = [](DevBuf &dst, const DevBuf &src) { dst.p = src.p; dst.cap = src.cap; dst.owned = false; };
   view(l->bkt_fast, c->bkt_fast); l->fmask = c->fmask;
-  view(l->ref_planes, c->ref_planes); l->ref_pl_words = c->ref_pl_words; l->opt_planes = c->opt_planes;
+  view(l->ref_planes, c->ref_planes); l->ref_pl_words = c->ref_pl_words; l->opt_planes = c->opt_planes; l->opt_long_fused = c->opt_long_fused;
   view(l->rb0, c->rb0); view(l->rb1, c->rb1); view(l->ro0, c->ro0); view(l->ro1, c->ro1);
   view(l->rec, c->rec); view(l->rec_ok, c->rec_ok);
   view(l->bcb, c->bcb); view(l->bcq, c->bcq); view(l->bco, c->bco); view(l->bc_key, c->bc_key); view(l->bc_ok, c->bc_ok);

@@ -76,6 +76,10 @@ struct cmgpu_ctx {
   // the reference as bit planes (CmDev::ref_pl; built on the first mapping call, views in the lanes) and the resident batch's
   // reads as bit planes (CmDev::read_pl, per range): what k_s5b_verify aligns on.  cmgpu_set_option "verify_planes" 0: the byte form
   DevBuf ref_planes, read_planes;
+  // reads longer than 69 bases: k_prep_mm's emissions staged in global memory (one tile per block of a launch); cmgpu_set_option
+  // "long_read_fused" 0: the two-pass kernels with their scan and host waits (the round-2 form)
+  DevBuf mm_stage;
+  int opt_long_fused = 1;
   uint64_t ref_pl_words = 0;
   int opt_planes = 1;
   int n_break = 0;
@@ -183,7 +187,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
   }
 };
 

@@ -16,8 +16,9 @@ bool cm_prep_flat_supported(const CmDev &d, uint32_t max_read_len, uint32_t tile
 void cm_launch_k_prep_flat(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t tile_reads, uint32_t mm_cap,
                            unsigned long long *cursor, hipStream_t s);
 uint32_t cm_prep_mm_pairs_per_block(const CmDev &d, uint32_t max_read_len);
+size_t cm_prep_mm_stage_bytes(const CmDev &d, uint32_t max_read_len, uint32_t pairs);
 void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
-                         unsigned long long *cursor, hipStream_t s);
+                         unsigned long long *cursor, hipStream_t s, void *gstage);
 uint32_t cm_probe_range_blocks(uint64_t max_entries, int variant);
 void cm_launch_k_probe_range(const CmDev &d, const unsigned long long *range, uint64_t max_entries, uint32_t cap, void *partials, hipStream_t s, int variant);
 void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned long long *counters, hipStream_t s);

@@ -87,16 +87,23 @@ __global__ void k_mm_fill(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
 // every consumer addresses a read's list through (mm_off[r], mm_cnt[r]).  A read with more than
 // `stg` minimizers (never seen: stg = L/4 + 4 against an expected (L-16)/4) recomputes straight
 // into its range.  Replaces k_prep_count + scan + k_mm_fill (two passes of ~150 integer ops per base).
+// GSTAGE (reads longer than 69 bases): the emissions are staged in the block's tile of a global buffer instead -- the same
+// [entry][thread] layout, so the lanes of a wave fill whole lines -- because stg x threads x 8 bytes of LDS would leave one
+// block per CU to a VALU-bound kernel; the tile is copied out by OUTPUT position (which read a dense slot belongs to is a
+// search in the block's 256 offsets), so the dense arrays are written in whole lines too.  Before, such reads were hashed
+// twice (k_prep_count, k_mm_fill) around a scan and two host waits.
+template <bool GSTAGE>
 __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of this launch's pair range */, uint32_t lds_half, uint32_t stg,
-                          uint32_t mm_cap, unsigned long long *cursor) {
+                          uint32_t mm_cap, unsigned long long *cursor, uint64_t *gstage) {
   const uint32_t T = blockDim.x, PB = T >> 1;
   const uint32_t p0 = pair_lo + blockIdx.x * PB, p1 = p0 + PB < n_pairs ? p0 + PB : n_pairs;
   const uint32_t t = threadIdx.x, lp = t < PB ? t : t - PB, pair = p0 + lp;
   const CmStaged s = cm_stage_pairs(d, p0, p1, pair, lds_half);
   if (t < PB && pair < p1) cm_s0_prep_ptr(d, pair, s.m0, s.m1);
   __syncthreads();
-  uint64_t *sh_e = reinterpret_cast<uint64_t *>(cm_lds + 2 * lds_half);
-  uint32_t *sh_w = reinterpret_cast<uint32_t *>(sh_e + (size_t)stg * T);  // wave totals [8], base lo/hi [2]
+  uint64_t *sh_e = GSTAGE ? gstage + (size_t)blockIdx.x * stg * T : reinterpret_cast<uint64_t *>(cm_lds + 2 * lds_half);
+  uint32_t *sh_w = reinterpret_cast<uint32_t *>(cm_lds + 2 * lds_half + (GSTAGE ? 0 : (size_t)stg * T * 8));  // wave totals [8], base lo/hi [2]
+  uint32_t *sh_off = sh_w + 16, *sh_cnt = sh_off + T + 1;  // GSTAGE: the reads' offsets in the block's range [T + 1], their counts [T]
   const bool valid = pair < p1;
   const uint32_t r = 2 * pair + (t < PB ? 0 : 1);
   const uint8_t *seq = t < PB ? s.m0 : s.m1;
@@ -126,17 +133,41 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
     const unsigned long long base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
     sh_w[8] = (uint32_t)base;
     sh_w[9] = (uint32_t)(base >> 32);
+    sh_w[10] = tot;
   }
   __syncthreads();
-  if (!valid) return;
   const unsigned long long base = (unsigned long long)sh_w[8] | ((unsigned long long)sh_w[9] << 32);
-  const unsigned long long off64 = base + sh_w[wave] + (incl - cnt);
-  d.mm_cnt[r] = cnt;
-  d.mm_off[r] = (uint32_t)off64;
+  const uint32_t loc = sh_w[wave] + (incl - cnt);
+  const unsigned long long off64 = base + loc;
+  const uint64_t hmask = (1ull << hb) - 1;
+  if (valid) {
+    d.mm_cnt[r] = cnt;
+    d.mm_off[r] = (uint32_t)off64;
+  }
+  if (GSTAGE) {
+    sh_off[t] = loc;
+    sh_cnt[t] = cnt;
+    if (t == T - 1) sh_off[T] = loc + cnt;
+    __syncthreads();  // (also: the tile's entries, written by other lanes, are visible)
+    const uint32_t tot = sh_w[10];
+    for (uint32_t o = t; o < tot; o += T) {
+      uint32_t lo = 0, hi = T;  // the last read whose range starts at or before o (reads without minimizers share their neighbour's start)
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sh_off[mid] <= o) lo = mid; else hi = mid;
+      }
+      if (sh_cnt[lo] > stg || base + o >= mm_cap) continue;  // (a read with more emissions than the tile holds writes its own range below)
+      const uint64_t v = sh_e[(size_t)(o - sh_off[lo]) * T + lo];
+      d.mm_hash[base + o] = v & hmask;
+      d.mm_ps[base + o] = (uint32_t)(v >> hb);
+    }
+    if (valid && cnt > stg && off64 + cnt <= mm_cap) cm_minimizers_window<7>(seq, len, k, d.mm_hash + (uint32_t)off64, d.mm_ps + (uint32_t)off64, cnt);
+    return;
+  }
+  if (!valid) return;
   if (cnt == 0 || off64 + cnt > mm_cap) return;  // overflow of the dense arrays: the host sees cursor > mm_cap and reruns
   const uint32_t off = (uint32_t)off64;
   if (cnt <= stg) {
-    const uint64_t hmask = (1ull << hb) - 1;
     for (uint32_t e = 0; e < cnt; ++e) {
       const uint64_t v = sh_e[(size_t)e * T + t];
       d.mm_hash[off + e] = v & hmask;
@@ -1749,14 +1780,16 @@ static inline void staging_geometry(uint32_t max_read_len, uint32_t *threads, ui
 // configuration needs the two-pass kernels: other k / w, or reads longer than 69 bases -- their emissions
 // would leave room for 128 or 64 lanes per block only, and at that occupancy the two-pass kernels are
 // as fast (2 x 100) or faster (2 x 150: 10.7 ms against 12.7 ms for 2 M pairs)
-static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *threads, uint32_t *half, uint32_t *stg, size_t *lds) {
-  if (d.p.w != 7 || 2 * d.p.k + 12 > 64 || max_read_len > 69) return false;
+static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *threads, uint32_t *half, uint32_t *stg, size_t *lds, bool *gstage = nullptr) {
+  if (d.p.w != 7 || 2 * d.p.k + 12 > 64) return false;
   *stg = max_read_len / 4 + 4;
+  const bool g = max_read_len > 69;  // the emissions staged in global memory (k_prep_mm<true>)
+  if (gstage) *gstage = g;
   uint32_t t = 256;
   for (;; t >>= 1) {
     *half = (uint32_t)(((uint64_t)(t / 2) * max_read_len + 64 + 15) & ~15ull);
-    *lds = 2 * (size_t)*half + (size_t)*stg * t * 8 + 64;
-    if (*lds <= 60 * 1024) break;
+    *lds = 2 * (size_t)*half + (g ? (size_t)(2 * t + 1) * 4 : (size_t)*stg * t * 8) + 64;
+    if (*lds <= (g ? 48 : 60) * 1024) break;
     if (t == 64) return false;
   }
   *threads = t;
@@ -1796,14 +1829,25 @@ uint32_t cm_prep_mm_pairs_per_block(const CmDev &d, uint32_t max_read_len) {
   size_t lds;
   return prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds) ? threads / 2 : 0;
 }
-// pairs [pair_lo, pair_hi)
-void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
-                         unsigned long long *cursor, hipStream_t s) {
+// bytes of the global staging buffer a launch over `pairs` pairs needs (0: the emissions are staged in LDS)
+size_t cm_prep_mm_stage_bytes(const CmDev &d, uint32_t max_read_len, uint32_t pairs) {
   uint32_t threads, half, stg;
   size_t lds;
-  if (pair_hi <= pair_lo || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds)) return;
+  bool g = false;
+  if (!prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds, &g) || !g) return 0;
   const uint32_t pb = threads / 2;
-  hipLaunchKernelGGL(k_prep_mm, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor);
+  return (size_t)((pairs + pb - 1) / pb) * stg * threads * 8;
+}
+// pairs [pair_lo, pair_hi)
+void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uint32_t max_read_len, uint32_t mm_cap,
+                         unsigned long long *cursor, hipStream_t s, void *gstage) {
+  uint32_t threads, half, stg;
+  size_t lds;
+  bool g = false;
+  if (pair_hi <= pair_lo || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds, &g)) return;
+  const uint32_t pb = threads / 2;
+  if (g) hipLaunchKernelGGL(k_prep_mm<true>, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)gstage);
+  else hipLaunchKernelGGL(k_prep_mm<false>, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)nullptr);
 }
 // probe of the minimizers [range[0], range[1]) (device-side range), at most max_entries of them
 static inline int probe_variant_norm(int variant) {
