@@ -907,7 +907,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   }
   // the alignments of S5b run on bit planes: this range's reads, both orientations, packed on the second stream (idle from here
   // on) under S3 and S4 -- the trimmed lengths are final
-  const bool planes = c->ref_pl_words && !c->p.split;
+  const bool planes = c->ref_pl_words != 0;
   if (planes) {
     const uint32_t pw = (c->max_read_len + 31) / 32;
     if (c->read_planes.ensure((size_t)n2 * 6 * pw * 4 + 16)) { cm_set_error(c, "out of device memory (read planes)"); return CMGPU_ENOMEM; }
@@ -986,13 +986,13 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s4c_pair_filter");
   // S5: verification -- (a) shortcut / sort + work-item counts, (b) one banded alignment per
   // candidate, (c) the sequential acceptance loop per read
-  cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
-  cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
-  mark(c, "s5a_prepare");
-  if (planes) {
+  if (planes) {  // (split alignments are verified in S5a already)
     HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[0], 0));  // k_pack_reads (second stream) is done
     d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = (c->max_read_len + 31) / 32;
   }
+  cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
+  cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
+  mark(c, "s5a_prepare");
   cm_launch_k_s5b_verify(d, n_m, n2, s);
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
@@ -1126,7 +1126,7 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
     c->sam_slots = slots;
     c->sam_md_cap = md_cap;
   }
-  if (c->opt_planes && !c->p.split && !c->ref_pl_words && c->ref_bytes) {  // once per reference: its bit planes (k_s5b_verify)
+  if (c->opt_planes && !c->ref_pl_words && c->ref_bytes) {  // once per reference: its bit planes (k_s5b_verify)
     const int rc = cm_build_ref_planes(c);
     if (rc) return rc;
   }

@@ -1715,6 +1715,17 @@ CM_HD uint64_t cm_load8(const uint8_t *p);
 #else
 #define CM_GLOBAL_U32 const uint32_t *
 #endif
+CM_HD uint32_t cm_brev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(v);
+#else
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+  return (v >> 16) | (v << 16);
+#endif
+}
 CM_HD uint32_t cm_funnel32(uint32_t lo, uint32_t hi, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo, sh < 32
   return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
 }
@@ -1772,6 +1783,98 @@ CM_HD int cm_banded_align_planes(int e, const uint32_t *rp, uint64_t rw, uint64_
   }
   return min_err;
 }
+// BandedAlignPatternToTextWithDropOff / ...WithDropOffFrom3End (alignment.cc:197-376) on bit planes: the split-alignment
+// verification (cm_draft_strand_split), same planes, same Peq word, the byte form's (cm_banded_align_dropoff_stream) bookkeeping.
+//   REV = false (the + strand's calls): pattern = reference bases g, g + 1, ..; text = read bases tbit, tbit + 1, ..
+//   REV = true  (the - strand's calls, "from the 3' end" of the reverse complement): pattern = reference bases g, g - 1, ..
+//               (g: the window's LAST base); text = the COMPLEMENT of read bases tbit, tbit + 1, .. -- the reverse complement
+//               walked backwards is the read walked forwards, complemented
+// tp: the read's FORWARD planes (orientation 0 of CmDev::read_pl) in both cases.
+template <bool REV>
+CM_HD int cm_banded_align_dropoff_planes(int e, const uint32_t *rp, uint64_t rw, uint64_t g, const uint32_t *tp, uint32_t tw, uint32_t tbit, int L,
+                                         int *end_pos, int *read_mapping_length) {
+  // reference words: REV: the 64-bit field that ENDS at base g - 32 c, bit-reversed; else the field that starts at g + 32 c
+  const uint64_t f0 = REV ? g - 63 : g;  // first base of chunk 0's field
+  CM_GLOBAL_U32 r0 = (CM_GLOBAL_U32)rp + (f0 >> 5);
+  CM_GLOBAL_U32 r1 = r0 + rw;
+  CM_GLOBAL_U32 rn = r1 + rw;
+  const uint32_t sh = (uint32_t)f0 & 31u;
+  CM_GLOBAL_U32 t0 = (CM_GLOBAL_U32)tp + (tbit >> 5);
+  CM_GLOBAL_U32 t1 = t0 + tw;
+  CM_GLOBAL_U32 tn = t1 + tw;
+  const uint32_t tsh = tbit & 31u;
+  const uint32_t tlast = (tbit + (uint32_t)(L > 0 ? L - 1 : 0)) >> 5;  // last text word that holds a base of the text
+  const uint32_t tfirst = tbit >> 5;
+  uint32_t a0 = r0[0], a1 = r1[0], an = rn[0], b0 = r0[1], b1 = r1[1], bn = rn[1], c0 = r0[2], c1 = r1[2], cn = rn[2];
+  uint32_t xa0 = t0[0], xa1 = t1[0], xan = tn[0];
+  uint32_t xb0 = tfirst + 1 <= tlast ? t0[1] : 0u, xb1 = tfirst + 1 <= tlast ? t1[1] : 0u, xbn = tfirst + 1 <= tlast ? tn[1] : 0u;
+  const uint32_t band = (2u << (2 * e)) - 1u;
+  uint32_t VP = 0, VN = 0, prev_VP = 0, prev_VN = 0;
+  int err = 0, i = 0, prev_err = 0;
+  bool fail_beginning = false, stop = false;
+  const int nchunk = (L + 31) >> 5;
+  for (int c = 0; c < nchunk && !stop; ++c) {
+    // the next chunk's words: one reference word further up (down when REV), one text word further up
+    const bool more = c + 1 < nchunk;
+    uint32_t d0 = 0, d1 = 0, dn = 0, y0 = 0, y1 = 0, yn = 0;
+    if (more) {
+      const int ri = REV ? -(c + 1) : c + 3;
+      d0 = r0[ri]; d1 = r1[ri]; dn = rn[ri];
+      if (tfirst + (uint32_t)c + 2 <= tlast) { y0 = t0[c + 2]; y1 = t1[c + 2]; yn = tn[c + 2]; }
+    }
+    uint64_t W0 = (uint64_t)cm_funnel32(a0, b0, sh) | ((uint64_t)cm_funnel32(b0, c0, sh) << 32);
+    uint64_t W1 = (uint64_t)cm_funnel32(a1, b1, sh) | ((uint64_t)cm_funnel32(b1, c1, sh) << 32);
+    uint64_t WN = (uint64_t)cm_funnel32(an, bn, sh) | ((uint64_t)cm_funnel32(bn, cn, sh) << 32);
+    if (REV) {
+      W0 = ((uint64_t)cm_brev32((uint32_t)W0) << 32) | cm_brev32((uint32_t)(W0 >> 32));
+      W1 = ((uint64_t)cm_brev32((uint32_t)W1) << 32) | cm_brev32((uint32_t)(W1 >> 32));
+      WN = ((uint64_t)cm_brev32((uint32_t)WN) << 32) | cm_brev32((uint32_t)(WN >> 32));
+    }
+    const uint32_t x0 = cm_funnel32(xa0, xb0, tsh), x1 = cm_funnel32(xa1, xb1, tsh), xn = cm_funnel32(xan, xbn, tsh);
+    const int jn = L - 32 * c < 32 ? L - 32 * c : 32;
+    for (int j = 0; j < jn; ++j, ++i) {
+      const uint32_t B0 = (uint32_t)(W0 >> j), B1 = (uint32_t)(W1 >> j), BN = (uint32_t)(WN >> j);
+      uint32_t m0 = 0u - ((x0 >> j) & 1u), m1 = 0u - ((x1 >> j) & 1u);
+      const uint32_t mn = 0u - ((xn >> j) & 1u);
+      if (REV) { m0 = ~m0; m1 = ~m1; }
+      const uint32_t eq = ~(B0 ^ m0) & ~(B1 ^ m1) & ~BN;
+      uint32_t X = ((((eq ^ BN) & mn) ^ eq) & band) | VN;
+      const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+      const uint32_t HN = VP & D0;
+      const uint32_t HP = VN | ~(VP | D0);
+      X = D0 >> 1;
+      prev_VN = VN; prev_VP = VP;
+      VN = X & HP;
+      VP = HN | ~(X | HP);
+      prev_err = err;
+      err += 1 - (int)(D0 & 1u);
+      if (err > 2 * e) {
+        if (i < 4 * e && i < L / 2) fail_beginning = true;
+        stop = true;
+        break;
+      }
+    }
+    if (REV) { c0 = b0; b0 = a0; a0 = d0; c1 = b1; b1 = a1; a1 = d1; cn = bn; bn = an; an = dn; }
+    else { a0 = b0; b0 = c0; c0 = d0; a1 = b1; b1 = c1; c1 = d1; an = bn; bn = cn; cn = dn; }
+    xa0 = xb0; xb0 = y0; xa1 = xb1; xb1 = y1; xan = xbn; xbn = yn;
+  }
+  if (i < L) { err = prev_err; VN = prev_VN; VP = prev_VP; }
+  const int band_start = i - 1;
+  int min_err = err;
+  *read_mapping_length = i;
+  *end_pos = band_start;
+  for (i = 0; i < 2 * e; i++) {
+    err += (int)((VP >> i) & 1u);
+    err -= (int)((VN >> i) & 1u);
+    if (err < min_err || (err == min_err && i + 1 == e)) {
+      min_err = err;
+      *end_pos = band_start + 1 + i;
+    }
+  }
+  if (fail_beginning || (L > 60 && *end_pos + 1 - e - min_err < 30)) *end_pos = -*end_pos;
+  return min_err;
+}
+
 // 32 bases -> one word of each plane; n < 32: the bases beyond count as code 4
 CM_HD void cm_pack_planes32(const uint8_t *bytes, uint32_t n, uint32_t *p0, uint32_t *p1, uint32_t *pn) {
   uint32_t q0 = 0, q1 = 0, qn = 0;
@@ -1783,17 +1886,6 @@ CM_HD void cm_pack_planes32(const uint8_t *bytes, uint32_t n, uint32_t *p0, uint
     }
   }
   *p0 = q0; *p1 = q1; *pn = qn;
-}
-CM_HD uint32_t cm_brev32(uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __brev(v);
-#else
-  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
-  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
-  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
-  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
-  return (v >> 16) | (v << 16);
-#endif
 }
 // read r of the batch -> its planes, forward (the read as it is: the + strand's text) and reverse complement (base i =
 // complement of read[L - 1 - i], L the trimmed length: the - strand's text, PrepareNegativeSequenceAt); the second from the first:
@@ -2158,8 +2250,11 @@ CM_HD uint32_t cm_draft_strand(const CmDev &d, const uint8_t *read, uint32_t L, 
 // GenerateDraftMappingsOnOneStrand, split-alignment branch (draft_mapping_generator.cc:359-557).
 // best_mapping_longest_match is re-initialised per candidate in the reference (:404-405), so
 // the second_min adjustment (:511-515) cannot fire and GetLongestMatchLength has no effect.
+// tp: the read's forward bit planes (CmDev::read_pl, orientation 0) -- the alignments then run on planes
+// (cm_banded_align_dropoff_planes) -- or nullptr: on the bytes
 CM_HD uint32_t cm_draft_strand_split(const CmDev &d, const uint8_t *read, uint32_t L, int strand, const uint64_t *cp,
-                                     const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int16_t *de, uint32_t *ds) {
+                                     const uint8_t *cc, uint32_t nc, CmBest &bst, uint64_t *dp, int16_t *de, uint32_t *ds,
+                                     const uint32_t *tp = nullptr) {
   const int e = d.p.e;
   uint32_t nd = 0, thr = 0;
   for (uint32_t ci = 0; ci < nc; ++ci) {
@@ -2170,20 +2265,27 @@ CM_HD uint32_t cm_draft_strand_split(const CmDev &d, const uint8_t *read, uint32
     if (!cm_valid_candidate(d, rid, position, L)) continue;
     int mep = (int)L, gap_beginning = 0, num_errors = 0, actual = 0, rml = 0;
     const int allow = 20 - e;
-    const uint8_t *pat = d.ref + d.ref_off[rid] + position - e;
+    const uint64_t gpat = d.ref_off[rid] + position - (uint32_t)e;  // the window's first base
+    const uint8_t *pat = d.ref + gpat;
+    const bool pl = tp != nullptr && d.ref_pl != nullptr;
     if (strand == 0) {
-      num_errors = cm_banded_align_dropoff(e, pat, read, (int)L, false, 0, (int)L, false, &mep, &rml);
+      num_errors = pl ? cm_banded_align_dropoff_planes<false>(e, d.ref_pl, d.ref_pl_words, gpat, tp, d.read_pl_w, 0u, (int)L, &mep, &rml)
+                      : cm_banded_align_dropoff(e, pat, read, (int)L, false, 0, (int)L, false, &mep, &rml);
       if (mep < 0 && allow > 0) {
         const int b_err = num_errors, b_mep = -mep, b_rml = rml;
-        num_errors = cm_banded_align_dropoff(e, pat + allow, read, (int)L, false, allow, (int)L - allow, false, &mep, &rml);
+        num_errors = pl ? cm_banded_align_dropoff_planes<false>(e, d.ref_pl, d.ref_pl_words, gpat + (uint32_t)allow, tp, d.read_pl_w, (uint32_t)allow, (int)L - allow, &mep, &rml)
+                        : cm_banded_align_dropoff(e, pat + allow, read, (int)L, false, allow, (int)L - allow, false, &mep, &rml);
         if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
         else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
       }
     } else {
-      num_errors = cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L, true, &mep, &rml);
+      num_errors = pl ? cm_banded_align_dropoff_planes<true>(e, d.ref_pl, d.ref_pl_words, gpat + L + 2 * (uint32_t)e - 1, tp, d.read_pl_w, 0u, (int)L, &mep, &rml)
+                      : cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L, true, &mep, &rml);
       if (mep < 0 && allow > 0) {
         const int b_err = num_errors, b_mep = -mep, b_rml = rml;
-        num_errors = cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L - allow, true, &mep, &rml);
+        num_errors = pl ? cm_banded_align_dropoff_planes<true>(e, d.ref_pl, d.ref_pl_words, gpat + (L - (uint32_t)allow) + 2 * (uint32_t)e - 1, tp, d.read_pl_w, (uint32_t)allow,
+                                                               (int)L - allow, &mep, &rml)
+                        : cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L - allow, true, &mep, &rml);
         if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
         else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
       }
@@ -2236,8 +2338,9 @@ CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
       uint32_t *dsp = d.dsplit + d.m_off[r], *dsn = d.dsplit + d.m_off[r] + d.ncp[r] + d.resc_p[r];
       cm_sort_cand(pp, pc, ncp);
       cm_sort_cand(np, nc, ncn);
-      d.ndp[r] = cm_draft_strand_split(d, read, L, 0, pp, pc, ncp, bst, dpp, dep, dsp);
-      d.ndn[r] = cm_draft_strand_split(d, read, L, 1, np, nc, ncn, bst, dpn, den, dsn);
+      const uint32_t *tp = d.read_pl ? d.read_pl + (size_t)r * 6 * d.read_pl_w : nullptr;  // (the forward planes serve both strands)
+      d.ndp[r] = cm_draft_strand_split(d, read, L, 0, pp, pc, ncp, bst, dpp, dep, dsp, tp);
+      d.ndn[r] = cm_draft_strand_split(d, read, L, 1, np, nc, ncn, bst, dpn, den, dsn, tp);
       done = true;
     } else if (ncp + ncn == 1) {
       const int strand = ncp == 1 ? 0 : 1;

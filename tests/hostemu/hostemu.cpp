@@ -325,6 +325,15 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
       else if (g_coop.G == 256) emu_coop_s4c<256>(d, heavy); else emu_coop_s4c<1024>(d, heavy);
     }
   }
+  std::vector<uint32_t> readpl;  // k_pack_reads
+  if (g_planes) {
+    uint32_t maxlen = 1;
+    for (uint32_t r = 0; r < n2; ++r) maxlen = d.rlen[r] > maxlen ? d.rlen[r] : maxlen;
+    d.read_pl_w = (maxlen + 31) / 32;
+    readpl.assign((size_t)n2 * 6 * d.read_pl_w + 4, 0xA5A5A5A5u);
+    d.read_pl = readpl.data();
+    for (uint32_t r = 0; r < n2; ++r) cm_pack_read_planes(d, r);
+  }
   VEC(nv, uint32_t, n2) VEC(v_off, uint32_t, n2 + 1) VEC(v_err, int16_t, n_m) VEC(v_end, int16_t, n_m)
   std::vector<uint32_t> s5_heavy;  // reads whose verification and acceptance a group of lanes runs (k_s5c_coop)
   for (uint32_t r = 0; r < n2; ++r)
@@ -337,15 +346,6 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   };
   s5_groups(0);  // k_s5_sort_coop: the heavy reads' candidate lists
   scan(d.nv, d.v_off, n2);
-  std::vector<uint32_t> readpl;  // k_pack_reads
-  if (g_planes) {
-    uint32_t maxlen = 1;
-    for (uint32_t r = 0; r < n2; ++r) maxlen = d.rlen[r] > maxlen ? d.rlen[r] : maxlen;
-    d.read_pl_w = (maxlen + 31) / 32;
-    readpl.assign((size_t)n2 * 6 * d.read_pl_w + 4, 0xA5A5A5A5u);
-    d.read_pl = readpl.data();
-    for (uint32_t r = 0; r < n2; ++r) cm_pack_read_planes(d, r);
-  }
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
   for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r, s5_min);
   g_coop_items[4] += s5_heavy.size();
@@ -845,6 +845,74 @@ extern "C" int hostemu_align_planes_check(uint64_t seed, uint32_t rounds, uint32
     const int nb = cm_banded_align_planes(e, rp.data(), rw, g, tp.data() + (size_t)strand * 3 * W, W, (int)L, &end_b);
     if (na != nb || end_a != end_b) {
       if (bad < 5) fprintf(stderr, "align planes: case %u e %d L %u g %u strand %d: bytes (%d, %d) planes (%d, %d)\n", it, e, L, g, strand, na, end_a, nb, end_b);
+      ++bad;
+    }
+  }
+  return bad;
+}
+
+// cm_banded_align_dropoff_planes against cm_banded_align_dropoff in the four shapes cm_draft_strand_split calls it in (+ strand:
+// whole read / read without its first `allow` bases; - strand from the 3' end: whole read / without the last `allow` bases of the
+// reverse complement).  Reads are cut from the reference with edits, a share of them chimeric (the second half from elsewhere:
+// the drop-off case).  Returns the number of cases in which (distance, end position, mapped length) differ.
+extern "C" int hostemu_dropoff_planes_check(uint64_t seed, uint32_t rounds, uint32_t max_len, int max_e) {
+  uint64_t st = seed * 0x9E3779B97F4A7C15ull + 7;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  const uint32_t ref_len = 8192;
+  std::vector<uint64_t> refw(ref_len / 8 + 8, 0);
+  uint8_t *ref = (uint8_t *)refw.data();
+  const char *alpha = "ACGTacgtACGTACGTACGTACGTACGTNnRX";
+  for (uint32_t i = 0; i < ref_len; ++i) ref[i] = (uint8_t)alpha[rnd() % 32];
+  const uint64_t rw = ref_len / 32 + 4;
+  std::vector<uint32_t> rp((size_t)rw * 3, 0);
+  for (uint32_t w = 0; w * 32 < ref_len; ++w) cm_pack_planes32(ref + 32 * w, ref_len - 32 * w, &rp[w], &rp[rw + w], &rp[2 * rw + w]);
+  int bad = 0;
+  for (uint32_t it = 0; it < rounds; ++it) {
+    const int e = 1 + (int)(rnd() % (uint64_t)max_e);
+    const uint32_t L = 25 + (uint32_t)(rnd() % (max_len - 24));
+    const uint32_t g = 128 + (uint32_t)(rnd() % (ref_len - L - 2 * (uint32_t)e - 400));
+    const int strand = (int)(rnd() & 1);
+    const int allow = (int)(rnd() % 2) ? 20 - e : 0;  // 0: the whole-read call
+    if (allow < 0 || (uint32_t)allow + 2 >= L) continue;
+    std::vector<uint64_t> fww((L + 31) / 8 + 3, 0);
+    uint8_t *fw = (uint8_t *)fww.data();  // the text string (for the - strand: the reverse complement of the stored read)
+    const uint32_t brk = rnd() % 3 == 0 ? (uint32_t)(rnd() % L) : L;  // chimeric from here on
+    const uint32_t brk_lo = rnd() % 2 ? brk : 0, brk_hi = brk_lo ? L : brk;  // ... or up to here
+    uint32_t src = g + (uint32_t)e;
+    for (uint32_t i = 0; i < L; ++i) {
+      const bool foreign = brk < L && i >= brk_lo && i < brk_hi;
+      uint8_t c = foreign ? (uint8_t)"ACGT"[rnd() % 4] : ref[src];
+      const uint64_t x = rnd() % 80;
+      if (x == 0) c = (uint8_t)"ACGT"[rnd() % 4];
+      else if (x == 1) ++src;
+      else if (x == 2) --src;
+      else if (x == 3) c = 'N';
+      fw[i] = c;
+      ++src;
+    }
+    std::vector<uint64_t> stw((L + 31) / 8 + 3, 0);
+    uint8_t *stored = (uint8_t *)stw.data();
+    for (uint32_t i = 0; i < L; ++i) stored[i] = strand ? cm_negchar(fw[L - 1 - i]) : fw[i];
+    CmDev d;
+    memset(&d, 0, sizeof(d));
+    uint32_t rlen[2] = {L, 0};
+    uint32_t ro[3] = {0, L, L};
+    d.rlen = rlen; d.rb0 = stored; d.rb1 = stored; d.ro0 = ro; d.ro1 = ro;
+    const uint32_t W = (L + 31) / 32;
+    std::vector<uint32_t> tp((size_t)6 * W + 2, 0x5A5A5A5Au);
+    d.read_pl = tp.data(); d.read_pl_w = W;
+    cm_pack_read_planes(d, 0);
+    int ea = (int)L, eb = (int)L, la = 0, lb = 0, na, nb;
+    const uint8_t *pat = ref + g;
+    if (strand == 0) {
+      na = cm_banded_align_dropoff(e, pat + allow, stored, (int)L, false, allow, (int)L - allow, false, &ea, &la);
+      nb = cm_banded_align_dropoff_planes<false>(e, rp.data(), rw, (uint64_t)g + (uint32_t)allow, tp.data(), W, (uint32_t)allow, (int)L - allow, &eb, &lb);
+    } else {
+      na = cm_banded_align_dropoff(e, pat, stored, (int)L, true, 0, (int)L - allow, true, &ea, &la);
+      nb = cm_banded_align_dropoff_planes<true>(e, rp.data(), rw, (uint64_t)g + (L - (uint32_t)allow) + 2 * (uint32_t)e - 1, tp.data(), W, (uint32_t)allow, (int)L - allow, &eb, &lb);
+    }
+    if (na != nb || ea != eb || la != lb) {
+      if (bad < 5) fprintf(stderr, "dropoff planes: case %u e %d L %u g %u strand %d allow %d: bytes (%d, %d, %d) planes (%d, %d, %d)\n", it, e, L, g, strand, allow, na, ea, la, nb, eb, lb);
       ++bad;
     }
   }

@@ -91,3 +91,16 @@ def test_alignment_on_bit_planes_equals_byte_form():
     assert f(1, 40000, 70, 8) == 0
     assert f(2, 20000, 150, 15) == 0
     assert f(3, 20000, 33, 4) == 0
+
+
+def test_dropoff_alignment_on_bit_planes_equals_byte_form():
+    """cm_banded_align_dropoff_planes (split-alignment verification, --preset hic) against the byte form in the four shapes
+    cm_draft_strand_split calls it in, on reads with chimeric halves, indels and bytes outside ACGT"""
+    import hostemu_lib as hl
+    L = hl.lib()
+    f = L.hostemu_dropoff_planes_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    assert f(1, 40000, 160, 8) == 0
+    assert f(2, 20000, 70, 4) == 0
+    assert f(3, 20000, 300, 15) == 0

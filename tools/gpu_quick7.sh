@@ -10,6 +10,4 @@ j=json.loads(open('gpurun_out/q7/$n.json').read().strip().splitlines()[-1]); pri
 }
 run hic_l1 --steps 5 --warmup 2 --lanes 1 --preset hic --readlen 150 --hic 0.35 --indel-rate 0.001 --pairs 2000000
 run hic_l3 --steps 5 --warmup 2 --lanes 3 --preset hic --readlen 150 --hic 0.35 --indel-rate 0.001 --pairs 2000000
-run hic_l3_old --steps 5 --warmup 2 --lanes 3 --preset hic --readlen 150 --hic 0.35 --indel-rate 0.001 --pairs 2000000 --option long_read_fused=0
 run chip_l3 --steps 5 --warmup 2 --lanes 3 --preset chip --readlen 100 --frag-min 150 --frag-max 700
-run chip_l3_old --steps 5 --warmup 2 --lanes 3 --preset chip --readlen 100 --frag-min 150 --frag-max 700 --option long_read_fused=0
