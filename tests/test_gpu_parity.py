@@ -198,6 +198,10 @@ HEAVY_SETTINGS = {
     # the range is mapped again with exact sizes
     "capacity_guess_too_small": {"debug_candidate_capacity": 64},
     "no_speculative_sizes": {"speculative_sizes": 0},
+    # the round-2 forms of the verification (alignments on the bytes instead of bit planes) and of the minimizer pass of reads
+    # longer than 69 bases (count, scan, fill instead of the fused kernel with its global staging tile)
+    "verify_on_bytes": {"verify_planes": 0},
+    "long_reads_two_pass": {"long_read_fused": 0},
     "declined_hits_only": {"coop": 1, "coop_run_table": 3},
     "declined_rescue_only": {"coop": 2, "coop_run_table": 3},
 }

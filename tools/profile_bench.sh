@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- pyt
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > /dev/null 2> $O/fetch.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > /dev/null 2> $O/write.log
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/lds -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > /dev/null 2> $O/lds.log
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/valu -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > /dev/null 2> $O/valu.log
 rm -f $O/*/bench_kernel_trace.csv.bak
 python $R/tools/summarize_profile.py $O $R/gpurun_out/${TAG}_summary
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete

@@ -53,6 +53,24 @@ def main():
                 a = bc[k][0] / max(1, bc[k][1])
                 b = ia[k][0] / max(1, ia[k][1])
                 f.write("%s,%d,%.0f,%.0f,%.3f\n" % (k, ia[k][1], a, b, a / b if b else 0.0))
+    # instruction issue: VALU instructions per launch, and the share of the waves' resident time in which a VALU instruction was
+    # being issued (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, both in quad-cycles summed over waves) -- which kernels are VALU-bound
+    valf = os.path.join(src, "valu", "bench_counter_collection.csv")
+    if os.path.exists(valf):
+        iv = pmc(valf, "SQ_INSTS_VALU")
+        av = pmc(valf, "SQ_ACTIVE_INST_VALU")
+        wc = pmc(valf, "SQ_WAVE_CYCLES")
+        bc2 = pmc(valf, "SQ_BUSY_CYCLES")
+        with open(os.path.join(dst, "pmc_valu.csv"), "w") as f:
+            f.write("kernel,launches,avg_SQ_INSTS_VALU,avg_SQ_ACTIVE_INST_VALU,avg_SQ_WAVE_CYCLES,avg_SQ_BUSY_CYCLES,valu_active_over_wave_cycles\n")
+            for k in sorted(wc, key=lambda k: -wc[k][0]):
+                if wc[k][0] <= 0:
+                    continue
+                a = iv[k][0] / max(1, iv[k][1])
+                b = av[k][0] / max(1, av[k][1])
+                c = wc[k][0] / max(1, wc[k][1])
+                e = bc2[k][0] / max(1, bc2[k][1])
+                f.write("%s,%d,%.0f,%.0f,%.0f,%.0f,%.3f\n" % (k, wc[k][1], a, b, c, e, b / c if c else 0.0))
     # what bench.py reports as roofline.traffic: the probe kernel in the shape the pipeline uses (bench line:
     # roofline.kernel_shape), its 64-byte sectors per lookup, and the calibration of FETCH_SIZE on the gather
     # microbenchmark of known byte count (same access width, 4 loads per lane)
