@@ -1920,10 +1920,28 @@ CM_HD void cm_pack_read_planes_w(const CmDev &d, uint32_t r) {
   if (L == 0) return;
   const uint8_t *read = cm_read_ptr(d, r);
   uint32_t o[6 * W];  // [orientation][plane][word]
+  // the read's aligned 8-byte words, all requested before any is looked at (one round trip instead of a chain of them:
+  // k_pack_reads was latency-bound with a load per eight bases in turn); nothing beyond the word that holds the last base
+  const uintptr_t ra = reinterpret_cast<uintptr_t>(read);
+  const uint32_t sh8 = (uint32_t)(ra & 7) * 8;
+  const uint64_t *ap = reinterpret_cast<const uint64_t *>(ra & ~(uintptr_t)7);
+  uint64_t wv[4 * W + 1];
+#pragma unroll
+  for (int q = 0; q <= 4 * W; ++q) wv[q] = (uint32_t)q * 8u < (sh8 >> 3) + L ? ap[q] : 0ull;
 #pragma unroll
   for (int w = 0; w < W; ++w) {
-    o[w] = 0; o[W + w] = 0; o[2 * W + w] = 0;
-    if (32u * (uint32_t)w < L) cm_pack_planes32(read + 32 * w, L - 32u * (uint32_t)w, &o[w], &o[W + w], &o[2 * W + w]);
+    uint32_t q0 = 0, q1 = 0, qn = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint64_t v = sh8 ? (wv[4 * w + k] >> sh8) | (wv[4 * w + k + 1] << (64u - sh8)) : wv[4 * w + k];
+#pragma unroll
+      for (int b = 0; b < 8; ++b, v >>= 8) {
+        const uint32_t j = (uint32_t)(8 * k + b);
+        const uint32_t u = 32u * (uint32_t)w + j < L ? cm_c2u((uint8_t)v) : 4u;
+        q0 |= (u & 1u) << j; q1 |= ((u >> 1) & 1u) << j; qn |= (u >> 2) << j;
+      }
+    }
+    o[w] = q0; o[W + w] = q1; o[2 * W + w] = qn;
   }
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
