@@ -354,7 +354,14 @@ int cmgpu_gather_sweep(cmgpu_ctx *ctx, uint64_t n, int repeat, int loads_per_lan
  * one-lane path), "heavy_last" (reads with long hit lists processed in waves of their own: 0 auto, 1 always, -1 never),
  * "lanes" 1..8 (ranges of a batch mapped side by side), "h2d_copy_blocks" / "d2h_copy_blocks" (blocks of the copy kernel
  * that moves page-locked host memory over the link instead of the copy engine; 0 = hipMemcpyAsync),
- * "first_read_id" (read id of the resident batch's first pair; device-generated batches start at 0). */
+ * "first_read_id" (read id of the resident batch's first pair; device-generated batches start at 0),
+ * "probe_table_shift" 0..4 (the pipeline probes a device copy of the index table re-hashed into 2^shift times as many
+ * buckets: same lookups, fewer buckets visited; 0 = the file's table), "coop" (bit mask of the stages whose long lists go to
+ * groups of lanes: 1 hit lists, 2 rescue hits, 4 pair filter, 8 acceptance, 16 pairing; 0 = the one-lane / bitonic forms),
+ * "speculative_sizes" 0/1 (candidate arrays sized from the previous batch, checked on the device, one re-run when too small),
+ * "verify_planes" 0/1 (alignments of the verification on bit planes of the reference and the reads instead of their bytes),
+ * "long_read_fused" 0/1 (reads longer than 69 bases: trimming + minimizers in one pass instead of count / scan / fill).
+ * Every setting gives the same records (tests/test_gpu_parity.py runs the fuzz data under each). */
 int cmgpu_set_option(cmgpu_ctx *ctx, const char *name, int64_t value);
 int cmgpu_get_option(const cmgpu_ctx *ctx, const char *name, int64_t *value);
 

@@ -100,6 +100,27 @@ def test_cli_multi_gpu_path_with_one_gpu(name, built, tmp_path):
     assert int(re.search(r"Number of mapped reads: (\d+)", log).group(1)) == meta["reference_stderr_counters"]["num_mapped_reads"]
 
 
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (RCCL between real ranks; the 1-GPU box runs the same path with --force-exchange)")
+@pytest.mark.parametrize("name", ["s1_atac", "s3_chip", "b1_atac_bc", "s5_atac_24chr_q0"])
+def test_cli_two_gpus_equal_golden(name, built, tmp_path):
+    """chromap-amd --gpus 2: two contexts, two host threads, the records exchanged by owner chromosome over RCCL between two
+    real ranks -- the output must be the golden file's"""
+    meta = ds.case_meta(name)
+    fa, reads = _reads(name)
+    out = str(tmp_path / "out.txt")
+    subprocess.run([CLI] + list(meta["chromap_flags"]) + ["--gpus", "2", "-x", built(name), "-r", fa] + reads + ["-o", out],
+                   stderr=subprocess.PIPE, check=True, timeout=600)
+    assert ds.md5(out) == meta["bed_md5"]
+
+
 def test_cli_refuses_what_it_cannot_write(built, tmp_path):
     """flag combinations the reference accepts and this build has no record type for end with a message, not with garbage"""
     name = "s1_atac"
