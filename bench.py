@@ -471,7 +471,7 @@ def main():
                     "note": "cmgpu_map_pairs on pageable host buffers (upload, map, record download)"}
             if hasattr(g, "map_pairs_pipelined"):
                 g.set_option("lanes", 1 if exchange else args.lanes)  # the upload runs on a stream (and hardware queue) of its own
-                pcie["pipelined"] = g.map_pairs_pipelined(b1, o1, b2, o2, repeats=6)
+                pcie["pipelined"] = g.map_pairs_pipelined(b1, o1, b2, o2, repeats=10)
                 pcie["pipelined"]["lanes"] = 1 if exchange else args.lanes
         except Exception as e:
             pcie = {"error": repr(e)}

@@ -105,7 +105,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_create_synthetic_repeats", "cmgpu_create_synthetic_profile", "cmgpu_generate_resident_batch_indels", "cmgpu_generate_resident_batch_hic", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
            "cmgpu_exchange_unique_id", "cmgpu_exchange_init", "cmgpu_exchange_init_all", "cmgpu_exchange_init_external",
            "cmgpu_exchange_owner_table", "cmgpu_exchange_step", "cmgpu_exchange_info", "cmgpu_exchange_finalize", "cmgpu_memcpy", "cmgpu_copy_whitelist",
-           "cmgpu_host_alloc", "cmgpu_host_free", "cmgpu_host_register", "cmgpu_host_unregister", "cmgpu_submit_pairs", "cmgpu_map_submitted",
+           "cmgpu_host_alloc", "cmgpu_host_free", "cmgpu_host_register", "cmgpu_host_unregister", "cmgpu_submit_pairs", "cmgpu_map_submitted", "cmgpu_map_submitted_async", "cmgpu_records_wait",
            "cmgpu_debug_trace", "cmgpu_debug_minimizers", "cmgpu_debug_minimizers_all")
 
 UNIQUE_ID_BYTES = 128
@@ -230,6 +230,8 @@ def declare(L):
     sig("cmgpu_host_unregister", C.c_int, [C.c_void_p])
     sig("cmgpu_submit_pairs", C.c_int, [C.c_void_p, P(Batch)])
     sig("cmgpu_map_submitted", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
+    sig("cmgpu_map_submitted_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(Stats)])
+    sig("cmgpu_records_wait", C.c_int, [C.c_void_p, P(C.c_uint64)])
     sig("cmgpu_debug_trace", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64])
     sig("cmgpu_debug_minimizers", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
     sig("cmgpu_debug_minimizers_all", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)])

@@ -431,6 +431,9 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (c->h_maxlen) (void)hipHostFree(c->h_maxlen);
   for (hipEvent_t e : c->ev_h2d) if (e) (void)hipEventDestroy(e);
   if (c->stream_h2d) (void)hipStreamDestroy(c->stream_h2d);
+  for (hipEvent_t e : c->ev_d2h) if (e) (void)hipEventDestroy(e);
+  if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
+  if (c->stream_d2h) (void)hipStreamDestroy(c->stream_d2h);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1188,23 +1191,76 @@ __global__ void k_rec_compact2(const uint8_t *__restrict__ rec, const uint8_t *_
   uint64_t *d = reinterpret_cast<uint64_t *>(dst + (uint64_t)pos[i] * 24);
   d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
-static int download_dense(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
+// the resident batch's records, compacted into `dst` on the mapping stream (pair order kept); nothing is waited for
+static int compact_records(cmgpu_ctx *c, DevBuf &dst) {
   const uint32_t n = (uint32_t)cm_rec_slots(c);
-  if (n_out) *n_out = 0;
   if (n == 0) return CMGPU_OK;
   { const int rc = cm_ensure_slot_scratch(c, n); if (rc) return rc; }
-  if (c->rec_dense.ensure((size_t)n * 24 + 16)) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
+  if (dst.ensure((size_t)n * 24 + 16)) { cm_set_error(c, "out of device memory (records)"); return CMGPU_ENOMEM; }
   uint32_t *flag = (uint32_t *)c->scratch_a.p, *pos = (uint32_t *)c->scratch_b.p;  // free between batches
   hipStream_t s = c->stream;
   hipLaunchKernelGGL(k_rec_flag2, dim3((n + 255) / 256), dim3(256), 0, s, (const uint8_t *)c->rec_ok.p, flag, n);
   cm_scan_u32(flag, pos, n, (uint32_t *)c->scan_tmp.p, s);
   hipLaunchKernelGGL(k_rec_compact2, dim3((n + 255) / 256), dim3(256), 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p,
-                     (const uint32_t *)pos, (uint8_t *)c->rec_dense.p, n);
+                     (const uint32_t *)pos, (uint8_t *)dst.p, n);
+  return CMGPU_OK;
+}
+static int download_dense(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out) {
+  if (n_out) *n_out = 0;
+  if (cm_rec_slots(c) == 0) return CMGPU_OK;
+  if (c->pend_count && c->stream_d2h) HIPCHECK(c, hipStreamSynchronize(c->stream_d2h));  // (a pending asynchronous download reads rec_dense)
+  { const int rc = compact_records(c, c->rec_dense); if (rc) return rc; }
+  hipStream_t s = c->stream;
   const uint64_t k = c->n_records;  // counted by the mapping call
   if (k > out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
   if (k) { const int rc = device_to_host(c, out, c->rec_dense.p, (size_t)k * 24, s); if (rc) return rc; }
   HIPCHECK(c, cm_stream_sync(s));
   if (n_out) *n_out = k;
+  return CMGPU_OK;
+}
+
+// cmgpu_map_submitted with the record download left running: the oldest submitted batch is mapped, its records are compacted, and
+// their copy to `out` (page-locked memory, or the copy is not asynchronous) is queued on a copy stream of its own -- it runs under
+// the NEXT batch's kernels.  cmgpu_records_wait returns when the oldest pending download is complete.
+extern "C" int cmgpu_map_submitted_async(cmgpu_ctx *c, cmgpu_record *out, uint64_t out_capacity, cmgpu_stats *stats) {
+  if (!c || !out) return CMGPU_EINVAL;
+  if (c->sub_count == 0) { cm_set_error(c, "no submitted batch (cmgpu_submit_pairs)"); return CMGPU_EINVAL; }
+  if (c->pend_count >= 2) { cm_set_error(c, "two record downloads are pending (cmgpu_records_wait)"); return CMGPU_EINVAL; }
+  uint64_t k = 0;
+  int rc = cmgpu_map_submitted(c, nullptr, 0, &k, stats);
+  if (rc) return rc;
+  if (k > out_capacity) { cm_set_error(c, "record buffer too small"); return CMGPU_ECAPACITY; }
+  if (!c->stream_d2h) {
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHECK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPCHECK(c, hipStreamCreateWithPriority(&c->stream_d2h, hipStreamNonBlocking, prio_greatest));
+    HIPCHECK(c, hipEventCreateWithFlags(&c->ev_comp, hipEventDisableTiming));
+    for (hipEvent_t &e : c->ev_d2h) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const uint32_t slot = c->pend_total & 1u;
+  DevBuf &dst = slot ? c->rec_dense_b : c->rec_dense;
+  if (k) {
+    rc = compact_records(c, dst);
+    if (rc) return rc;
+    HIPCHECK(c, hipEventRecord(c->ev_comp, c->stream));
+    HIPCHECK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_comp, 0));
+    HIPCHECK(c, hipMemcpyAsync(out, dst.p, (size_t)k * 24, hipMemcpyDeviceToHost, c->stream_d2h));
+    // the next mapping call's lanes write the per-pair record arrays from streams of their own: the compaction has to be through
+    HIPCHECK(c, hipEventSynchronize(c->ev_comp));
+  }
+  HIPCHECK(c, hipEventRecord(c->ev_d2h[slot], c->stream_d2h));
+  c->pend_k[slot] = k;
+  ++c->pend_total; ++c->pend_count;
+  return CMGPU_OK;
+}
+extern "C" int cmgpu_records_wait(cmgpu_ctx *c, uint64_t *n_out) {
+  if (!c) return CMGPU_EINVAL;
+  if (c->pend_count == 0) { cm_set_error(c, "no record download pending (cmgpu_map_submitted_async)"); return CMGPU_EINVAL; }
+  HIPCHECK(c, cm_enter(c));
+  const uint32_t slot = (c->pend_total - c->pend_count) & 1u;
+  HIPCHECK(c, hipEventSynchronize(c->ev_d2h[slot]));
+  --c->pend_count;
+  if (n_out) *n_out = c->pend_k[slot];
   return CMGPU_OK;
 }
 

@@ -133,6 +133,13 @@ struct cmgpu_ctx {
   hipEvent_t ev_h2d[2] = {nullptr, nullptr};
   uint32_t sub_total = 0, sub_count = 0;  // batches submitted so far / submitted and not yet mapped (<= 2: parking slots 6 and 7 take turns)
   DevBuf rec_dense, maxlen_dev;
+  // cmgpu_map_submitted_async / cmgpu_records_wait: the compacted records of a batch go to the host on a copy stream of their
+  // own while the next batch is mapped; two downloads may be pending (their device buffers take turns)
+  hipStream_t stream_d2h = nullptr;
+  hipEvent_t ev_comp = nullptr, ev_d2h[2] = {nullptr, nullptr};
+  DevBuf rec_dense_b;
+  uint64_t pend_k[2] = {0, 0};
+  uint32_t pend_total = 0, pend_count = 0;
   uint32_t *h_maxlen = nullptr;  // pinned: longest read of the submitted batch, computed on the device
   // cmgpu_set_option
   int opt_probe_variant = 1;       // lookups per lane | 16: second probe step requested with the first (measured: more requests in
@@ -187,7 +194,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &rec_dense_b, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
   }
 };
 

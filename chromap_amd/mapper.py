@@ -257,6 +257,19 @@ class ChromapGPU:
         self._sub_keep.pop(0)
         return int(n.value)
 
+    def map_submitted_async(self, out, capacity, stats=None):
+        """maps the oldest submitted batch and leaves the download of its records to `out` (pinned) running; records_wait()"""
+        st = stats if stats is not None else self.stats
+        ptr = C.c_void_p(out.ctypes.data) if hasattr(out, "ctypes") else C.cast(out, C.c_void_p)
+        self._check(self.L.cmgpu_map_submitted_async(self.ctx, ptr, capacity, C.byref(st)), self.ctx)
+        self._sub_keep.pop(0)
+
+    def records_wait(self):
+        """the oldest pending record download is complete: its record count"""
+        n = C.c_uint64(0)
+        self._check(self.L.cmgpu_records_wait(self.ctx, C.byref(n)), self.ctx)
+        return int(n.value)
+
     def map_pairs_pipelined(self, b1, o1, b2, o2, repeats=4):
         """throughput of the host-buffer boundary with page-locked buffers and the upload of batch c+1 under the kernels of
         batch c (bench.py: pcie_inclusive.pipelined)"""
@@ -281,9 +294,30 @@ class ChromapGPU:
             assert k == k0
         dt = time.perf_counter() - t0
         self.map_submitted(bufs[repeats & 1][4], n, Stats())  # drain
-        return {"M pairs/s": round(n * repeats / dt / 1e6, 2), "ms_per_batch": round(dt / repeats * 1e3, 2), "records": int(k0),
-                "note": "page-locked host buffers, cmgpu_submit_pairs of batch c+1 before cmgpu_map_submitted of batch c (upload under "
-                        "the kernels), records compacted on the device and downloaded in one copy"}
+        out = {"M pairs/s": round(n * repeats / dt / 1e6, 2), "ms_per_batch": round(dt / repeats * 1e3, 2), "records": int(k0),
+               "note": "page-locked host buffers, cmgpu_submit_pairs of batch c+1 before cmgpu_map_submitted of batch c (upload under "
+                       "the kernels), records compacted on the device and downloaded in one copy"}
+        # the same with the record download of batch c under the kernels of batch c+1 (cmgpu_map_submitted_async / cmgpu_records_wait)
+        ref = bytes(bufs[0][4][:k0 * 24])  # (every batch here is the same reads: the synchronous path's records)
+        for b in bufs:
+            b[4][:] = 0
+        self.submit_pairs(*bufs[0][:4])
+        self.submit_pairs(*bufs[1][:4])
+        self.map_submitted_async(bufs[0][4], n, Stats())
+        t0 = time.perf_counter()
+        for i in range(1, repeats + 1):
+            self.submit_pairs(*bufs[(i + 1) & 1][:4])
+            self.map_submitted_async(bufs[i & 1][4], n, Stats())
+            k = self.records_wait()
+            assert k == k0
+        dt = time.perf_counter() - t0
+        same = bytes(bufs[(repeats - 1) & 1][4][:k0 * 24]) == ref
+        self.records_wait()
+        self.map_submitted(bufs[(repeats + 1) & 1][4], n, Stats())  # drain the last submitted batch
+        out["download_overlapped"] = {"M pairs/s": round(n * repeats / dt / 1e6, 2), "ms_per_batch": round(dt / repeats * 1e3, 2),
+                                      "records_identical_to_synchronous_path": bool(same),
+                                      "note": "cmgpu_map_submitted_async + cmgpu_records_wait: the records of batch c travel under the kernels of batch c+1"}
+        return out
 
     def map_single(self, b, off, first_read_id=0):
         self._keep = [np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint32)]

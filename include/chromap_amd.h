@@ -256,6 +256,21 @@ int cmgpu_host_register(void *p, uint64_t bytes);
 int cmgpu_host_unregister(void *p);
 int cmgpu_submit_pairs(cmgpu_ctx *ctx, const cmgpu_batch *in);
 int cmgpu_map_submitted(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capacity, uint64_t *n_out, cmgpu_stats *stats);
+/* The same with the record download left running: cmgpu_map_submitted_async maps the oldest submitted batch, compacts its
+ * records and queues their copy to `out` (page-locked: cmgpu_host_alloc / cmgpu_host_register) on a copy stream of its own, so
+ * the copy runs under the NEXT batch's kernels -- the reference hands a finished batch's mappings to its output task the same
+ * way while the next taskloop runs (src/chromap.h:871-877, mapping_writer.h:166-376).  cmgpu_records_wait returns when the
+ * oldest pending download is complete and gives its record count; `out` must not be read before.  Up to two downloads may be
+ * pending:
+ *     cmgpu_submit_pairs(ctx, &b[0]);
+ *     for (c = 0; c < n; ++c) {
+ *       if (c + 1 < n) cmgpu_submit_pairs(ctx, &b[c + 1]);
+ *       cmgpu_map_submitted_async(ctx, out[c & 1], cap, &st);
+ *       if (c > 0) { cmgpu_records_wait(ctx, &k); consume(out[(c - 1) & 1], k); }
+ *     }
+ *     cmgpu_records_wait(ctx, &k); consume(out[(n - 1) & 1], k); */
+int cmgpu_map_submitted_async(cmgpu_ctx *ctx, cmgpu_record *out, uint64_t out_capacity, cmgpu_stats *stats);
+int cmgpu_records_wait(cmgpu_ctx *ctx, uint64_t *n_out);
 
 /* Single-end reads: replaces the taskloop body of Chromap::MapSingleEndReads
  * (src/chromap.h:385-472) for bulk data; records are MappingWithoutBarcode's constructor

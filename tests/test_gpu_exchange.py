@@ -394,4 +394,21 @@ def test_pipelined_submit_equals_map_pairs():
     assert got == want  # half is a multiple of the 5000-pair chunk: even the multi-mappers agree
     with pytest.raises(Exception):
         g.map_submitted()
+    # the same with the record downloads left running (cmgpu_map_submitted_async / cmgpu_records_wait): both pending at once
+    for p in parts:
+        p[5][:] = 0
+    g.submit_pairs(*parts[0][:4], first_read_id=parts[0][4])
+    g.submit_pairs(*parts[1][:4], first_read_id=parts[1][4])
+    with pytest.raises(Exception):
+        g.records_wait()  # nothing pending yet
+    g.map_submitted_async(parts[0][5], parts[0][6], Stats())
+    g.map_submitted_async(parts[1][5], parts[1][6], Stats())
+    k0 = g.records_wait()
+    k1 = g.records_wait()
+    assert parts[0][5][:k0 * 24].tobytes() + parts[1][5][:k1 * 24].tobytes() == want
+    with pytest.raises(Exception):
+        g.records_wait()
+    # a synchronous call after it still works (and waits for nothing that is not there)
+    rec2, k2 = g.map_pairs(b1, o1, b2, o2)
+    assert bytes(rec2)[:k2 * 24] == want
     g.close()
