@@ -1018,7 +1018,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s6a_pairing");
   const uint32_t n_chunks = cm_num_chunks_host(n, (uint32_t)c->p.ref_batch, (uint32_t)c->p.grain);
   cm_launch_k_s6b_sample(d, n_chunks, s);
-  if (c->p.sam) cm_launch_k_s6c_multi_sam(d, n, s); else cm_launch_k_s6c_multi(d, n, s);
+  if (c->p.sam) cm_launch_k_s6c_multi_sam(d, n, s); else cm_launch_k_s6c_multi(d, n, s, (c->opt_coop & 16) != 0);
   mark(c, "s6bc_multimappers");
   cm_launch_k_stats(d, n, (unsigned long long *)c->partials.p, s);
   unsigned long long hst[CM_ST_N];

@@ -994,4 +994,88 @@ CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// S6c for a multi-mapped pair with long draft lists: the pairing the sampler chose (the want-th pairing with the minimal sum, in
+// the sweep's order: direction 0 before 1, first-list entries ascending, partners ascending) is found by the group instead of one
+// lane repeating both sweeps (cm_s6c_multi / cm_pair_dir with want >= 0): every lane counts the minimal-sum partners of its
+// first-list entry (partner range by binary search, as cm_coop_pair_dir), a scan places the target in one lane's range, that lane
+// walks to it.  *seen: minimal-sum pairings before this direction (in, uniform) / including it when not found (out).
+// ---------------------------------------------------------------------------------------
+template <class GT>
+CM_HD bool cm_coop_pair_find(const CmDev &d, GT &g, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na, const uint64_t *bp, const int16_t *be,
+                             uint32_t nb, uint32_t len1, uint32_t len2, int final_min, uint64_t want, uint64_t *seen, uint32_t *f_i1, uint32_t *f_i2) {
+  const uint32_t G = (uint32_t)GT::G;
+  const uint64_t I = (uint64_t)(int64_t)d.p.max_insert;
+  const uint64_t mo = (uint32_t)d.p.min_read_len;
+  const uint64_t X = dir == 1 ? I - len2 : (uint64_t)len1 - mo;
+  const uint64_t Y = dir == 0 ? I - len1 : (uint64_t)len2 - mo;
+  for (uint32_t base = 0; base < na; base += G) {
+    const uint32_t i1 = base + g.t;
+    uint32_t cnt = 0, lo = 0;
+    uint64_t p1 = 0;
+    if (i1 < na) {
+      p1 = ap[i1];
+      uint32_t hi = nb;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p1 > bp[mid] + X) lo = mid + 1; else hi = mid;
+      }
+      for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur) cnt += (int)ae[i1] + (int)be[cur] == final_min ? 1u : 0u;
+    }
+    uint32_t tot;
+    const uint32_t off = g.scan(cnt, &tot);
+    if (*seen + tot > want) {  // the target lies in this round: in the range of the lane whose count interval holds it
+      uint64_t found = 0;
+      const uint64_t first = *seen + off;
+      if (cnt && first <= want && want < first + cnt) {
+        uint64_t k = want - first;
+        for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur)
+          if ((int)ae[i1] + (int)be[cur] == final_min) {
+            if (k == 0) { found = (((uint64_t)i1 << 32) | cur) + 1; break; }
+            --k;
+          }
+      }
+      found = g.max64(found);
+      *f_i1 = (uint32_t)((found - 1) >> 32);
+      *f_i2 = (uint32_t)(found - 1);
+      return true;
+    }
+    *seen += tot;
+  }
+  return false;
+}
+// cm_s6c_multi for one pair (bulk paired-end, not split): the records of the sampled pairings
+template <bool SAM, class GT>
+CM_HD void cm_coop_s6c(const CmDev &d, uint32_t pair, GT &g) {
+  const int nb = d.pe_nbest[pair];
+  if (nb <= 1 || nb > d.p.drop_rep) return;
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  CmPe pe;
+  pe.min_sum = d.pe_min[pair]; pe.second_sum = d.pe_second[pair]; pe.n_best = nb; pe.n_second = d.pe_nsecond[pair];
+  pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
+  const uint32_t K = (uint32_t)d.p.max_best;
+  const uint32_t to_report = (uint32_t)nb < K ? (uint32_t)nb : K;
+  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  for (uint32_t t = 0; t < to_report; ++t) {
+    const int64_t want = (int64_t)d.pe_choice[(uint64_t)pair * K + t];
+    if (want > 0) {
+      uint64_t seen = 0;
+      uint32_t i1 = 0, i2 = 0;
+      int dir = 0;
+      bool found = cm_coop_pair_find(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
+                                     len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
+      if (!found) {
+        dir = 1;
+        found = cm_coop_pair_find(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
+                                  len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
+      }
+      if (!found) { if (g.t == 0) d.stats[CM_ST_ERR] = 2; return; }
+      pe.f_dir = (uint32_t)dir; pe.f_i1 = i1; pe.f_i2 = i2;
+    } else {
+      pe.f_dir = d.pe_first[pair]; pe.f_i1 = d.pe_i1[pair]; pe.f_i2 = d.pe_i2[pair];
+    }
+    if (g.t == 0) cm_emit_record<SAM>(d, pair, pe, t);
+  }
+}
+
 #endif

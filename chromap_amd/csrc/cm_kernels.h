@@ -38,7 +38,7 @@ void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coo
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads, hipStream_t s);
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
-CM_DECL_LAUNCH(k_s6c_multi)
+void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 CM_DECL_LAUNCH(k_s6a_pair_sam)
 CM_DECL_LAUNCH(k_s6c_multi_sam)
 void cm_launch_k_s6b_sample(const CmDev &d, uint32_t n_chunks, hipStream_t s);

@@ -1134,7 +1134,36 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6a_coop(CmDev d) {
   g.xw = nullptr;
   for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6a<false>(d, list[j], g);
 }
-CM_ITEM_KERNEL(k_s6c_multi, cm_s6c_multi<false>, perm_pairs)
+// S6c.  coop: a multi-mapped pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 17, where a wave finds the
+// sampled pairings (cm_coop_s6c) -- one lane repeating both pairing sweeps over lists of hundreds of entries held its wave for
+// the whole kernel (k_s6c_multi 1.6 ms for 28 k multi-mapped pairs of the repeat workload)
+__global__ __launch_bounds__(CM_BLOCK) void k_s6c_multi(CmDev d, uint32_t n, uint32_t coop) {
+  if (d.abort && *d.abort) return;
+  const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
+  const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
+  bool to_wave = false;
+  if (i < n) {
+    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) {
+      const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+      uint32_t big = d.ndp[r1] > d.ndn[r1] ? d.ndp[r1] : d.ndn[r1];
+      big = d.ndp[r2] > big ? d.ndp[r2] : big;
+      big = d.ndn[r2] > big ? d.ndn[r2] : big;
+      to_wave = big > CM_S6A_COOP_MIN;
+    }
+    if (!to_wave) cm_s6c_multi<false>(d, pair);
+  }
+  if (coop) cm_wave_append(d.hv_list + (size_t)17 * d.hv_stride, d.hv_cnt + 17, to_wave, pair);
+}
+__global__ __launch_bounds__(CM_BLOCK) void k_s6c_coop(CmDev d) {
+  if (d.abort && *d.abort) return;
+  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
+  const uint32_t n_list = d.hv_cnt[17];
+  const uint32_t *list = d.hv_list + (size_t)17 * d.hv_stride;
+  CmDevGroup<64> g;
+  g.t = threadIdx.x % 64;
+  g.xw = nullptr;
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6c<false>(d, list[j], g);
+}
 CM_ITEM_KERNEL(k_s6a_pair_sam, cm_s6a_pair<true>, perm_pairs)
 CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>, perm_pairs)
 
@@ -1767,7 +1796,14 @@ void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_s6a_coop, dim3(blocks), dim3(CM_BLOCK), 0, s, d);
 }
-CM_LAUNCH(k_s6c_multi)
+void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_s6c_multi, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
+  if (!coop) return;
+  uint32_t blocks = n / 4096 + 64;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s6c_coop, dim3(blocks), dim3(CM_BLOCK), 0, s, d);
+}
 
 // threads per block / LDS bytes for the read-staging kernels, from the longest read of the batch
 static inline void staging_geometry(uint32_t max_read_len, uint32_t *threads, uint32_t *lds_half) {

@@ -120,6 +120,15 @@ static void emu_coop_s6a(const CmDev &d, const std::vector<uint32_t> &list) {
     }
   }, g_coop_reverse);
 }
+template <int G>
+static void emu_coop_s6c(const CmDev &d, const std::vector<uint32_t> &list) {
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      cm_coop_s6c<false>(d, list[i], g);
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
 
 struct EmuSam {
   cmgpu_sam_record *rec;  // 2n (pairs) or n (single) slots
@@ -379,7 +388,25 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   CmMt *g = new CmMt();
   for (uint32_t c = 0; c < nch; ++c) cm_s6b_sample(d, c, *g);
   delete g;
-  for (uint32_t i = 0; i < n; ++i) { if (sam) cm_s6c_multi<true>(d, i); else cm_s6c_multi<false>(d, i); }
+  {
+    std::vector<uint32_t> heavy;  // k_s6c_coop: multi-mapped pairs with long draft lists
+    for (uint32_t i = 0; i < n; ++i) {
+      if (sam) { cm_s6c_multi<true>(d, i); continue; }
+      bool to_group = false;
+      if (g_coop.G && !d.p.single && !d.p.split && d.pe_nbest[i] > 1) {
+        uint32_t big = d.ndp[2 * i] > d.ndn[2 * i] ? d.ndp[2 * i] : d.ndn[2 * i];
+        big = d.ndp[2 * i + 1] > big ? d.ndp[2 * i + 1] : big;
+        big = d.ndn[2 * i + 1] > big ? d.ndn[2 * i + 1] : big;
+        to_group = big > g_coop.thr;
+      }
+      if (to_group) heavy.push_back(i); else cm_s6c_multi<false>(d, i);
+    }
+    if (!heavy.empty()) {
+      g_coop_items[6] += heavy.size();
+      if (g_coop.G == 16) emu_coop_s6c<16>(d, heavy); else if (g_coop.G == 64) emu_coop_s6c<64>(d, heavy);
+      else if (g_coop.G == 256) emu_coop_s6c<256>(d, heavy); else emu_coop_s6c<1024>(d, heavy);
+    }
+  }
   uint64_t k = 0;
   for (uint32_t i = 0; i < n; ++i) {
     // k_stats
