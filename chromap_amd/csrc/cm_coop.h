@@ -807,14 +807,25 @@ CM_HD uint32_t cm_coop_draft_strand(const CmDev &d, GT &g, const CmCoopVerMem &m
 // order (--chr-order re-ranks the sequence ids after the filter) or has a count >= nb_cap is sorted by the group's lane 0.
 // ---------------------------------------------------------------------------------------
 template <class GT>
-CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_t *sp, uint8_t *sc, uint16_t *hist, uint32_t nb_cap) {
+CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_t *sp, uint8_t *sc, uint16_t *hist, uint32_t nb_cap,
+                             uint64_t *lp = nullptr, uint8_t *lc = nullptr, uint32_t lcap = 0) {
   const uint32_t G = (uint32_t)GT::G;
   if (n < 2) return;
+  // lp / lc (shared memory, lcap entries): a list that fits is staged there once and scattered from there straight to its final
+  // places -- one read and one write of the list in global memory instead of three and two (k_s5_sort_coop was four rounds of
+  // global latency per list); longer lists go through sp / sc (global scratch) as before
+  const bool staged = lp != nullptr && n <= lcap;
   uint32_t bad = 0;
   uint64_t mx = 0;
-  for (uint32_t i = g.t; i < n; i += G) {
-    if (i > 0 && p[i] < p[i - 1]) bad = 1;
-    mx = c[i] > mx ? c[i] : mx;
+  if (staged) {
+    for (uint32_t i = g.t; i < n; i += G) { lp[i] = p[i]; const uint8_t ci = c[i]; lc[i] = ci; mx = ci > mx ? ci : mx; }
+    g.sync();
+    for (uint32_t i = g.t; i < n; i += G) if (i > 0 && lp[i] < lp[i - 1]) bad = 1;
+  } else {
+    for (uint32_t i = g.t; i < n; i += G) {
+      if (i > 0 && p[i] < p[i - 1]) bad = 1;
+      mx = c[i] > mx ? c[i] : mx;
+    }
   }
   bad = g.sum(bad);
   mx = g.max64(mx);
@@ -830,13 +841,24 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
   for (uint32_t b = 0; b < nb; ++b) mine[(size_t)b * G] = 0;
   const uint32_t VT = cm_coop_chunk(n, G);
   const uint32_t c0 = cm_min_u32(n, g.t * VT), c1 = cm_min_u32(n, c0 + VT);
-  for (uint32_t i = c0; i < c1; ++i) mine[(size_t)c[i] * G] += 1;
+  const uint8_t *cs = staged ? lc : c;
+  for (uint32_t i = c0; i < c1; ++i) mine[(size_t)cs[i] * G] += 1;
   uint32_t base = 0;
   for (uint32_t b = nb; b-- > 0;) {  // the largest count first
     uint32_t tot;
     const uint32_t off = g.scan(mine[(size_t)b * G], &tot);
     mine[(size_t)b * G] = (uint16_t)(base + off);
     base += tot;
+  }
+  if (staged) {
+    for (uint32_t i = c0; i < c1; ++i) {
+      const uint8_t ci = lc[i];
+      const uint32_t dst = mine[(size_t)ci * G]++;
+      p[dst] = lp[i];
+      c[dst] = ci;
+    }
+    g.sync();  // (the staging arrays serve the next list)
+    return;
   }
   for (uint32_t i = c0; i < c1; ++i) {
     const uint8_t ci = c[i];
@@ -894,10 +916,11 @@ CM_HD void cm_coop_sort_draft(const CmDev &d, GT &g, const CmCoopSortMem &m, uin
 // The candidate lists of a read cm_s5a_prepare left to the groups, sorted (scratch: the read's draft-mapping arrays, written by
 // S5c only).  The alignments then run in the per-candidate kernel like everybody's.
 template <class GT>
-CM_HD void cm_coop_s5_sort(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap) {
+CM_HD void cm_coop_s5_sort(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap, uint64_t *lp = nullptr, uint8_t *lc = nullptr,
+                           uint32_t lcap = 0) {
   const uint32_t op = d.m_off[r], on = op + d.ncp[r] + d.resc_p[r];
-  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, d.fcp[r], d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap);
-  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap);
+  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, d.fcp[r], d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap, lp, lc, lcap);
+  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap, lp, lc, lcap);
 }
 // S5c for such a read (its alignments are in v_err / v_end)
 // sm: work area of the draft-mapping sort that follows the acceptance loop (it may overlay m: the loop's arrays are dead by then)

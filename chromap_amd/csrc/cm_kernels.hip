@@ -1007,17 +1007,21 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, 
 }
 // S5b of the reads in list 12: a wave per read, its lanes over the read's candidates (cm_coop_s5b)
 #define CM_SORT_NB 64u  // counts below this go through the groups' counting sort of a candidate list
+#define CM_SORT_STAGE 512u  // candidates of a list the sorting wave stages in shared memory (32 + 18 KB per block of four waves)
 // the candidate lists of the reads in list 12 (k_s5a_prepare left them unsorted): a wave each (cm_coop_s5_sort)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d) {
   if (d.abort && *d.abort) return;
   __shared__ uint16_t hist[CM_BLOCK * CM_SORT_NB];
+  __shared__ uint64_t stage_p[(CM_BLOCK / 64) * CM_SORT_STAGE];  // a list of up to CM_SORT_STAGE candidates is staged here once
+  __shared__ uint8_t stage_c[(CM_BLOCK / 64) * CM_SORT_STAGE];
   const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[12];
   const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
   CmDevGroup<64> g;
   g.t = threadIdx.x % 64;
   g.xw = nullptr;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s5_sort(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB);
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb)
+    cm_coop_s5_sort(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB, stage_p + (size_t)grp * CM_SORT_STAGE, stage_c + (size_t)grp * CM_SORT_STAGE, CM_SORT_STAGE);
 }
 #define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
 #define CM_S5C_SORT_RB 130u

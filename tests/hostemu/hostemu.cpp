@@ -101,12 +101,14 @@ static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list, int 
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
   const CmCoopVerMem m = cm_coop_ver_mem_at(base, P);
   std::vector<uint16_t> hist((size_t)G * 64);
+  std::vector<uint64_t> stage_p(24);  // the candidate sort's staging area, deliberately small: longer lists take the scratch path
+  std::vector<uint8_t> stage_c(24);
   // the sort's work area deliberately small: lists beyond 32 entries sort in global memory
   std::vector<uint8_t> smem(cm_coop_sort_mem_bytes(32, 40) + 16);
   const CmCoopSortMem sm = cm_coop_sort_mem_at(smem.data() + ((16 - ((uintptr_t)smem.data() & 15)) & 15), 32, 40);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      if (phase == 0) cm_coop_s5_sort(d, list[i], g, hist.data(), 64); else cm_coop_s5c(d, list[i], g, m, sm);
+      if (phase == 0) cm_coop_s5_sort(d, list[i], g, hist.data(), 64, stage_p.data(), stage_c.data(), 24); else cm_coop_s5c(d, list[i], g, m, sm);
       g.sync();
     }
   }, g_coop_reverse);
@@ -808,6 +810,18 @@ static int emu_sort_cand_check(const uint64_t *p, const uint8_t *c, uint32_t n, 
   std::vector<uint16_t> hist((size_t)G * nb_cap);
   emu_run_group<G>([&](EmuGroup<G> &g) { cm_coop_sort_cand(g, gp.data(), gc.data(), n, tp.data(), tc.data(), hist.data(), nb_cap); }, reverse);
   for (uint32_t i = 0; i < n; ++i) if (gp[i] != sp[i] || gc[i] != sc[i]) return 1;
+  // the same with the list staged in (what stands for) shared memory: twice in a row through the same staging arrays, the way
+  // k_s5_sort_coop sorts a read's two strands; a staging area of n - 1 entries must leave the list to the scratch path
+  for (uint32_t cap : {n, n + 7, n > 1 ? n - 1 : 0u}) {
+    std::vector<uint64_t> lp(cap + 1);
+    std::vector<uint8_t> lc(cap + 1);
+    for (int round = 0; round < 2; ++round) {
+      std::vector<uint64_t> hp(p, p + n);
+      std::vector<uint8_t> hc(c, c + n);
+      emu_run_group<G>([&](EmuGroup<G> &g) { cm_coop_sort_cand(g, hp.data(), hc.data(), n, tp.data(), tc.data(), hist.data(), nb_cap, lp.data(), lc.data(), cap); }, reverse);
+      for (uint32_t i = 0; i < n; ++i) if (hp[i] != sp[i] || hc[i] != sc[i]) return 2 + round;
+    }
+  }
   return 0;
 }
 extern "C" int hostemu_sort_cand_check(const uint64_t *p, const uint8_t *c, uint32_t n, uint32_t nb_cap, int G, int reverse) {
