@@ -110,6 +110,13 @@ CM_HD uint64_t cm_hash64_split2(uint32_t lo, uint32_t hi, uint32_t hm) {
   }
   return ((uint64_t)hi << 32) | lo;
 }
+// the same with the choice made by the caller once (HV 0: k = 17, 1: 2k in 33..52, 2: any k) instead of per call
+template <int HV>
+CM_HD uint64_t cm_hash64_v(uint64_t key, uint64_t mask) {
+  if (HV == 0) return cm_hash64_split2((uint32_t)key, (uint32_t)(key >> 32), 3u);
+  if (HV == 1) return cm_hash64_split((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(mask >> 32));
+  return cm_hash64(key, mask);
+}
 CM_HD uint64_t cm_hash64_k(uint64_t key, int k, uint64_t mask) {
   if (2 * k == 34) return cm_hash64_split2((uint32_t)key, (uint32_t)(key >> 32), 3u);
   if (2 * k > 32 && 2 * k <= 52) return cm_hash64_split((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(mask >> 32));
@@ -682,7 +689,7 @@ CM_HD uint32_t cm_minimizers_window_e(const uint8_t *seq, uint32_t len, int k, E
 // and the entry that leaves the window is emitted if flagged.  A read with a base outside ACGT is redone by
 // the state machine (its behaviour across N runs is not a window rule).
 template <class Emit>
-CM_HD uint32_t cm_minimizers_w7_oddk(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+CM_HD uint32_t cm_minimizers_w7_oddk_seq(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
   const uint64_t shift = 2 * (uint64_t)(k - 1);
   const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
   uint64_t fw = 0, rv = 0;
@@ -740,6 +747,107 @@ CM_HD uint32_t cm_minimizers_w7_oddk(const uint8_t *seq, uint32_t len, int k, Em
   for (int j = 0; j < 7; ++j)
     if ((fl >> j) & 1u) { emit(n, H[j], ((len - 1 - (uint32_t)(6 - j)) << 1) | ((sb >> j) & 1u)); ++n; }
   return n;
+}
+
+// The same emissions with the selection done per BLOCK of seven k-mers instead of per k-mer (what the kernels run for reads of
+// seven k-mers and more).  The form above recomputes, for every base, the minimum of its window (six 64-bit minima) and tests all
+// seven entries against it (seven 64-bit compares): 13 two-word operations next to the three hashes.  Here, with the k-mers cut
+// into blocks of seven (h padded with 0 beyond the last k-mer: a window that holds a pad has minimum 0 and so never counts):
+//   window minima (van Herk / Gil-Werman): the window that starts at entry j of block c is the suffix of block c from j and the
+//     prefix of block c + 1 before j:   M = min(suffix_min_c[j], prefix_min_{c+1}[j - 1]);
+//   k-mer i is emitted  <=>  h[i] == max of the minima of the windows that hold it (the rule of k_prep_flat above), and those
+//     windows are a suffix of the previous block's seven windows and a prefix of its own block's:
+//                           F = max(suffix_max_{c-1}[j + 1], prefix_max_c[j]);
+// 36 minima / maxima and 7 compares per seven k-mers -- 6.1 two-word operations per base instead of 13.  The first window's rule
+// (the reference drops the earlier k-mers that tie with the seventh, see above) strikes those entries out (all ones) before
+// anything else looks at them.  Block c is settled while block c + 1 is hashed; one empty block runs last.
+template <int HV, class Emit>
+CM_HD uint32_t cm_minimizers_w7_oddk_blocks(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+  const uint64_t shift = 2 * (uint64_t)(k - 1);
+  const uint64_t mask = (((uint64_t)1) << (2 * k)) - 1;
+  uint64_t fw = 0, rv = 0;
+  uint32_t bad = 0, n = 0;
+  for (uint32_t pos = 0; pos + 1 < (uint32_t)k; ++pos) {
+    uint32_t c = cm_c2u(seq[pos]);
+    bad |= c >> 2;
+    c &= 3;
+    fw = ((fw << 2) | c) & mask;
+    rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
+  }
+  const uint32_t m = len - (uint32_t)k + 1, nblk = (m + 6) / 7;
+  uint64_t ep[7], Sp[7], SM[7];  // the previous block: hashes, their suffix minima; suffix maxima of the window minima before it
+  uint32_t sbp = 0;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { ep[j] = 0; Sp[j] = 0; SM[j] = 0; }
+  for (uint32_t b = 0; b <= nblk; ++b) {
+    uint64_t e[7];
+    uint32_t sb = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const uint32_t i = 7 * b + (uint32_t)j;
+      e[j] = 0;
+      if (i < m) {
+        uint32_t c = cm_c2u(seq[i + (uint32_t)k - 1]);
+        bad |= c >> 2;
+        c &= 3;
+        fw = ((fw << 2) | c) & mask;
+        rv = (rv >> 2) | (((uint64_t)(3 ^ c)) << shift);
+        const uint64_t h0 = cm_hash64_v<HV>(fw, mask), h1 = cm_hash64_v<HV>(rv, mask);
+        const uint32_t strand = h0 < h1 ? 0u : 1u;
+        e[j] = cm_hash64_v<HV>(strand ? h1 : h0, mask);
+        sb |= strand << j;
+      }
+    }
+    if (b == 0) {  // the first window's rule
+      uint64_t v = e[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) v = e[j] < v ? e[j] : v;
+      if (e[6] == v) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) e[j] = e[j] == v ? ~0ull : e[j];
+      }
+    }
+    // minima of the windows that start in the previous block, then their prefix maxima against the block before's suffix maxima
+    uint64_t Mw[7];
+    {
+      uint64_t P = e[0];
+      Mw[0] = Sp[0];
+#pragma unroll
+      for (int j = 1; j < 7; ++j) {
+        Mw[j] = Sp[j] < P ? Sp[j] : P;
+        P = e[j] < P ? e[j] : P;
+      }
+    }
+    if (b > 0) {
+      uint64_t PM = Mw[0];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (j > 0) PM = Mw[j] > PM ? Mw[j] : PM;
+        const uint64_t F = j < 6 ? (SM[j < 6 ? j + 1 : 6] > PM ? SM[j < 6 ? j + 1 : 6] : PM) : PM;
+        const uint32_t i = 7 * (b - 1) + (uint32_t)j;
+        if (F == ep[j] && i < m) { emit(n, ep[j], ((i + (uint32_t)k - 1) << 1) | ((sbp >> j) & 1u)); ++n; }
+      }
+    }
+    SM[6] = Mw[6];
+    Sp[6] = e[6];
+#pragma unroll
+    for (int j = 5; j >= 0; --j) {
+      SM[j] = Mw[j] > SM[j + 1] ? Mw[j] : SM[j + 1];
+      Sp[j] = e[j] < Sp[j + 1] ? e[j] : Sp[j + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) ep[j] = e[j];
+    sbp = sb;
+  }
+  if (bad) return ~0u;
+  return n;
+}
+template <class Emit>
+CM_HD uint32_t cm_minimizers_w7_oddk(const uint8_t *seq, uint32_t len, int k, Emit &&emit) {
+  if (len < (uint32_t)k + 6) return cm_minimizers_w7_oddk_seq(seq, len, k, emit);  // fewer than seven k-mers: the flush rule
+  if (2 * k == 34) return cm_minimizers_w7_oddk_blocks<0>(seq, len, k, emit);      // (which hash arithmetic: chosen once)
+  if (2 * k > 32 && 2 * k <= 52) return cm_minimizers_w7_oddk_blocks<1>(seq, len, k, emit);
+  return cm_minimizers_w7_oddk_blocks<2>(seq, len, k, emit);
 }
 
 // ---------------------------------------------------------------------------------------
