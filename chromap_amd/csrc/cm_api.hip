@@ -910,10 +910,10 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   }
   // the alignments of S5b run on bit planes: this range's reads, both orientations, packed on the second stream (idle from here
   // on) under S3 and S4 -- the trimmed lengths are final
-  const bool planes = c->ref_pl_words != 0;
+  bool planes = c->ref_pl_words != 0;
+  if (planes && c->read_planes.ensure((size_t)n2 * 6 * ((c->max_read_len + 31) / 32) * 4 + 16)) planes = false;  // (no room: this range on bytes)
   if (planes) {
     const uint32_t pw = (c->max_read_len + 31) / 32;
-    if (c->read_planes.ensure((size_t)n2 * 6 * pw * 4 + 16)) { cm_set_error(c, "out of device memory (read planes)"); return CMGPU_ENOMEM; }
     HIPCHECK(c, hipEventRecord(c->chunk_ev[1], s));
     HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[1], 0));
     d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = pw;
@@ -1131,7 +1131,10 @@ extern "C" int cmgpu_map_resident(cmgpu_ctx *c, uint64_t *n_out, cmgpu_stats *st
   }
   if (c->opt_planes && !c->ref_pl_words && c->ref_bytes) {  // once per reference: its bit planes (k_s5b_verify)
     const int rc = cm_build_ref_planes(c);
-    if (rc) return rc;
+    if (rc == CMGPU_ENOMEM) {  // no room for them: the alignments run on the bytes (same results, slower)
+      c->ref_planes.release(); c->ref_pl_words = 0; c->opt_planes = 0;
+      fprintf(stderr, "chromap_amd: no device memory for the reference bit planes, verifying on bytes\n");
+    } else if (rc) return rc;
   }
   // Lanes: the batch cut on reference-batch boundaries into up to opt_lanes ranges that are mapped side by side, each on
   // its own streams with its own intermediates -- the latency-bound stages of one range fill the gaps of the others'.

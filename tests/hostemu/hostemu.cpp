@@ -791,6 +791,29 @@ static int emu_pairing_check(const uint64_t *ap0, const int16_t *ae0, uint32_t n
     if (fk == ~0ull) return 2;
     if (((uint32_t)(fk >> 48) & 1u) != pe.f_dir || ((uint32_t)(fk >> 24) & 0xffffffu) != pe.f_i1 || ((uint32_t)fk & 0xffffffu) != pe.f_i2) return 3;
   } else if (fk != ~0ull) return 4;
+  // the want-th minimal-sum pairing in sweep order (what the sampler of a multi-mapped pair asks for): cm_coop_pair_find against the
+  // sweep that counts up to it -- every index when there are few, the ends and a spread of the others when there are many
+  const int nbest = pe.n_best;
+  for (int step = 0; step < nbest; ++step) {
+    const int want = nbest <= 48 ? step : (step < 16 ? step : (step < 32 ? nbest - 1 - (step - 16) : (int)(((uint64_t)step * 2654435761u) % (uint64_t)nbest)));
+    if (nbest > 48 && step >= 64) break;
+    CmPe q = pe;
+    int64_t s2 = 0;
+    bool found = cm_pair_dir(d, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, q, want, pe.min_sum, &s2);
+    if (!found) found = cm_pair_dir(d, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, q, want, pe.min_sum, &s2);
+    if (!found) return 5;
+    uint32_t gd = 9, gi1 = 0, gi2 = 0;
+    bool gfound = false;
+    emu_run_group<G>([&](EmuGroup<G> &g) {
+      uint64_t seen2 = 0;
+      uint32_t i1 = 0, i2 = 0;
+      int dir = 0;
+      bool fnd = cm_coop_pair_find(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2);
+      if (!fnd) { dir = 1; fnd = cm_coop_pair_find(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2); }
+      if (g.t == (uint32_t)(G - 1)) { gfound = fnd; gd = (uint32_t)dir; gi1 = i1; gi2 = i2; }  // (every lane holds the answer: the last one reports)
+    }, reverse);
+    if (!gfound || gd != q.f_dir || gi1 != q.f_i1 || gi2 != q.f_i2) return 6;
+  }
   return 0;
 }
 extern "C" int hostemu_pairing_check(const uint64_t *ap0, const int16_t *ae0, uint32_t na0, const uint64_t *bp0, const int16_t *be0, uint32_t nb0,

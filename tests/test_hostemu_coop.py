@@ -189,7 +189,9 @@ def test_cooperative_acceptance_loop_on_adversarial_lists():
 
 def test_cooperative_pairing_on_adversarial_lists():
     """cm_coop_pair_dir against cm_pair_dir: sorted draft-mapping lists with equal positions, dense and sparse partner
-    ranges, ties of the minimal error sum across directions (the first one in sweep order counts), empty lists."""
+    ranges, ties of the minimal error sum across directions (the first one in sweep order counts), empty lists; and
+    cm_coop_pair_find (the want-th minimal-sum pairing in sweep order, what k_s6c_coop reports for a multi-mapped pair) against
+    the counting sweep for every / a spread of the indices."""
     import numpy as np
     L = he.lib()
     f = L.hostemu_pairing_check
