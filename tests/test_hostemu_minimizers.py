@@ -114,3 +114,37 @@ def test_position_parallel_minimizers_equal_the_reference_state_machine(k):
         else:
             n_fallback += 1
     assert n_flat > 8000 and n_fallback > 1000  # both routes exercised
+
+
+@pytest.mark.parametrize("k", [17, 21, 27])
+def test_block_form_at_every_read_length(k):
+    """the block-of-seven selection (cm_minimizers_w7_oddk) at every read length from one k-mer to five blocks and a bit -- the
+    first-window rule alone in its block, last blocks of one to seven k-mers, the empty closing block -- on sequences that tie
+    (homopolymer, period 2 and 3), random ones, and random ones with the first window's tie forced"""
+    L = he.lib()
+    O = ol.lib()
+    f = L.hostemu_minimizers_w7
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(9000 + k)
+    oh, ot = np.zeros(256, np.uint64), np.zeros(256, np.uint64)
+    gh, gp = np.zeros(256, np.uint64), np.zeros(256, np.uint32)
+    n = 0
+    for ln in range(k, k + 40):
+        seqs = [np.full(ln, ord("A"), np.uint8), np.resize(np.frombuffer(b"AC", np.uint8), ln).copy(), np.resize(np.frombuffer(b"ACG", np.uint8), ln).copy()]
+        for _ in range(12):
+            seqs.append(rng.choice(list(b"ACGT"), ln).astype(np.uint8))
+        for _ in range(6):  # the seventh k-mer a copy of one of the first six: period p in the first k + 6 bases
+            p = int(rng.integers(1, 7))
+            s = rng.choice(list(b"ACGT"), ln).astype(np.uint8)
+            head = min(ln, k + 6)
+            s[:head] = np.resize(s[:p], head)
+            seqs.append(s)
+        for s in seqs:
+            buf = np.concatenate([s, np.zeros(8, np.uint8)])
+            c = O.ora_minimizers(buf.ctypes.data_as(C.c_char_p), len(s), 0, k, 7, oh.ctypes.data, ot.ctypes.data)
+            want = [(int(oh[i]), int(ot[i]) & 0x1FFFFFFFF) for i in range(c)]
+            g = f(buf.ctypes.data, len(s), k, 1, gh.ctypes.data, gp.ctypes.data, 256)
+            assert [(int(gh[i]), int(gp[i])) for i in range(g)] == want, (ln, bytes(s))
+            n += c
+    assert n > 3000
