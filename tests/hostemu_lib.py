@@ -23,7 +23,9 @@ def lib():
                [os.path.join(ROOT, "chromap_amd", "csrc", f) for f in ("cm_stages.h", "cm_coop.h", "cm_types.h", "cm_host.cpp",
                                                                        "cm_mapq_tables.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
+            # -fno-strict-aliasing: the stage functions read and write their byte / word arrays through wider types (aligned 8-
+            # and 16-byte accesses), which the device compiler takes as written
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing",
                                    "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-o", so, srcs[0],
                                    os.path.join(ROOT, "chromap_amd", "csrc", "cm_host.cpp")])
         _L = _capi.declare(C.CDLL(so))
