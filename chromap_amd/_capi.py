@@ -89,7 +89,7 @@ class Stats(C.Structure):
 assert C.sizeof(Record) == 24 == C.sizeof(PairsRecord)
 assert C.sizeof(RecordBc) == 32
 
-# every symbol include/chromap_amd.h declares
+# every symbol include/chromap_amd.h (the boundary) and include/chromap_amd_debug.h (measurement / test hooks) declare
 SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_create_from_reference",
            "cmgpu_save_index_file", "cmgpu_create_shared", "cmgpu_set_chr_order", "cmgpu_set_pairs_chr_order", "cmgpu_write_pairs_ranked", "cmgpu_destroy",
            "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_map_pairs_async", "cmgpu_wait", "cmgpu_upload_batch", "cmgpu_map_resident",
@@ -106,7 +106,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_exchange_unique_id", "cmgpu_exchange_init", "cmgpu_exchange_init_all", "cmgpu_exchange_init_external",
            "cmgpu_exchange_owner_table", "cmgpu_exchange_step", "cmgpu_exchange_info", "cmgpu_exchange_finalize", "cmgpu_memcpy", "cmgpu_copy_whitelist",
            "cmgpu_host_alloc", "cmgpu_host_free", "cmgpu_host_register", "cmgpu_host_unregister", "cmgpu_submit_pairs", "cmgpu_map_submitted", "cmgpu_map_submitted_async", "cmgpu_records_wait",
-           "cmgpu_debug_trace", "cmgpu_debug_minimizers", "cmgpu_debug_minimizers_all")
+           "cmgpu_debug_trace", "cmgpu_debug_minimizers", "cmgpu_debug_minimizers_all", "cmgpu_debug_array")
 
 UNIQUE_ID_BYTES = 128
 ALLGATHER_COUNTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32)
@@ -233,6 +233,7 @@ def declare(L):
     sig("cmgpu_map_submitted_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(Stats)])
     sig("cmgpu_records_wait", C.c_int, [C.c_void_p, P(C.c_uint64)])
     sig("cmgpu_debug_trace", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64])
+    sig("cmgpu_debug_array", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)])
     sig("cmgpu_debug_minimizers", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
     sig("cmgpu_debug_minimizers_all", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)])
     sig("cmgpu_copy_whitelist", C.c_int, [C.c_void_p, C.c_void_p])

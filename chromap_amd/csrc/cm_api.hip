@@ -293,12 +293,14 @@ int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref) {
   return CMGPU_OK;
 }
 
-// the reference bytes -> three bit planes (CmDev::ref_pl), 3/8 of a byte per base next to the bytes themselves
+// the reference bytes -> interleaved bit-plane records (CmDev::ref_pl: 16 bytes per 32 bases, half a byte per base next to the
+// bytes themselves), CM_PL_LEAD zero records in front of record 0
 int cm_build_ref_planes(cmgpu_ctx *c) {
   const uint64_t words = (c->ref_bytes + 31) / 32 + 4;
-  if (c->ref_planes.ensure((size_t)words * 3 * 4)) { cm_set_error(c, "out of device memory (reference bit planes)"); return CMGPU_ENOMEM; }
-  HIPCHECK(c, hipMemsetAsync(c->ref_planes.p, 0, (size_t)words * 3 * 4, c->stream));
-  cm_launch_k_pack_ref((const uint8_t *)c->ref.p, c->ref_bytes, (uint32_t *)c->ref_planes.p, words, c->stream);
+  const size_t bytes = (size_t)(words + CM_PL_LEAD) * sizeof(CmPlRec);
+  if (c->ref_planes.ensure(bytes)) { cm_set_error(c, "out of device memory (reference bit planes)"); return CMGPU_ENOMEM; }
+  HIPCHECK(c, hipMemsetAsync(c->ref_planes.p, 0, bytes, c->stream));
+  cm_launch_k_pack_ref((const uint8_t *)c->ref.p, c->ref_bytes, (CmPlRec *)c->ref_planes.p + CM_PL_LEAD, c->stream);
   HIPCHECK(c, cm_stream_sync(c->stream));  // the lanes read them from streams of their own
   c->ref_pl_words = words;
   return CMGPU_OK;
@@ -679,7 +681,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.bkt = (const uint64_t *)(c->fmask ? c->bkt_fast.p : c->bkt.p); d.bmask = c->fmask ? c->fmask : c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
   d.n_seq = c->n_seq;
-  d.ref_pl = c->ref_pl_words ? (const uint32_t *)c->ref_planes.p : nullptr; d.ref_pl_words = c->ref_pl_words;
+  d.ref_pl = c->ref_pl_words ? (const CmPlRec *)c->ref_planes.p + CM_PL_LEAD : nullptr; d.ref_pl_words = c->ref_pl_words;
   d.p = c->p;
   d.p.single = c->single ? 1 : 0;
   d.mq.len_coef = (const double *)c->len_coef.p; d.mq.nsec_break = (const uint32_t *)c->nsec_break.p; d.mq.n_break = c->n_break;
@@ -1386,6 +1388,28 @@ extern "C" int cmgpu_debug_trace(cmgpu_ctx *c, cmgpu_trace *out, uint64_t capaci
     t.force_mapq = c->p.split ? -1 : (f0[i] ? 0 : -1);
   }
   return CMGPU_OK;
+}
+
+// a per-read (2 n entries) or per-pair (n entries) 32-bit array of the last mapped batch by name: list lengths for the
+// distribution tools (tools/list_hist.py) -- measurement aid, declared in include/chromap_amd_debug.h
+extern "C" int cmgpu_debug_array(cmgpu_ctx *c, const char *name, uint32_t *out, uint64_t capacity, uint64_t *n_out) {
+  if (!c || !name || !out) return CMGPU_EINVAL;
+  HIPCHECK(c, cm_enter(c));
+  const std::string nm(name);
+  struct { const char *n; DevBuf *b; int per_pair; } tab[] = {
+    {"rlen", &c->rlen, 0}, {"mm_cnt", &c->mm_cnt, 0}, {"hit_tot", &c->hit_tot, 0}, {"ncp", &c->ncp, 0}, {"ncn", &c->ncn, 0},
+    {"resc_p", &c->resc_p, 0}, {"resc_n", &c->resc_n, 0}, {"mcp", &c->mcp, 0}, {"mcn", &c->mcn, 0}, {"fcp", &c->fcp, 0},
+    {"fcn", &c->fcn, 0}, {"ndp", &c->ndp, 0}, {"ndn", &c->ndn, 0}, {"nv", &c->nv, 0}, {"pe_nbest", &c->pe_nbest, 1}};
+  for (auto &t : tab)
+    if (nm == t.n) {
+      const uint64_t n = t.per_pair ? c->n_pairs : 2ull * c->n_pairs;
+      if (n_out) *n_out = n;
+      if (capacity < n || !t.b->p || t.b->cap < n * 4) { cm_set_error(c, "debug array: buffer too small or array not resident"); return CMGPU_ECAPACITY; }
+      HIPCHECK(c, hipMemcpy(out, t.b->p, n * 4, hipMemcpyDeviceToHost));
+      return CMGPU_OK;
+    }
+  cm_set_error(c, "debug array: unknown name " + nm);
+  return CMGPU_EINVAL;
 }
 
 // one read's minimizers of the last mapped batch: (hash, position << 1 | strand) in emission order

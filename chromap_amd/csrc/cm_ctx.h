@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/chromap_amd.h"
+#include "../../include/chromap_amd_debug.h"
 #include "cm_types.h"
 
 #define CM_MAX_EVENTS 32

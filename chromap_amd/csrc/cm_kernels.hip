@@ -1518,19 +1518,19 @@ __global__ void k_check_cap(const unsigned long long *__restrict__ total, unsign
 void cm_launch_k_check_cap(const unsigned long long *total, unsigned long long cap, unsigned long long *flag, hipStream_t s) {
   hipLaunchKernelGGL(k_check_cap, dim3(1), dim3(1), 0, s, total, cap, flag);
 }
-// the reference bytes as bit planes (CmDev::ref_pl): one lane per word of 32 bases
-__global__ __launch_bounds__(CM_BLOCK) void k_pack_ref(const uint8_t *__restrict__ ref, uint64_t n_bytes, uint32_t *__restrict__ pl, uint64_t words) {
+// the reference bytes as interleaved bit-plane records (CmDev::ref_pl): one lane per record of 32 bases, one 16-byte store
+__global__ __launch_bounds__(CM_BLOCK) void k_pack_ref(const uint8_t *__restrict__ ref, uint64_t n_bytes, CmPlRec *__restrict__ pl) {
   const uint64_t w = (uint64_t)blockIdx.x * CM_BLOCK + threadIdx.x;
   if (w * 32 >= n_bytes) return;
   const uint64_t left = n_bytes - w * 32;
-  uint32_t p0, p1, pn;
-  cm_pack_planes32(ref + w * 32, left < 32 ? (uint32_t)left : 32u, &p0, &p1, &pn);
-  pl[w] = p0; pl[words + w] = p1; pl[2 * words + w] = pn;
+  CmPlRec r;
+  cm_pack_planes32(ref + w * 32, left < 32 ? (uint32_t)left : 32u, &r.p0, &r.p1, &r.pn, &r.pc);
+  pl[w] = r;
 }
-void cm_launch_k_pack_ref(const uint8_t *ref, uint64_t n_bytes, uint32_t *pl, uint64_t words, hipStream_t s) {
+void cm_launch_k_pack_ref(const uint8_t *ref, uint64_t n_bytes, CmPlRec *pl, hipStream_t s) {
   const uint64_t n = (n_bytes + 31) / 32;
   if (!n) return;
-  hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((n + CM_BLOCK - 1) / CM_BLOCK)), dim3(CM_BLOCK), 0, s, ref, n_bytes, pl, words);
+  hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((n + CM_BLOCK - 1) / CM_BLOCK)), dim3(CM_BLOCK), 0, s, ref, n_bytes, pl);
 }
 // the batch's reads as bit planes, both orientations (CmDev::read_pl): one lane per read
 __global__ __launch_bounds__(CM_BLOCK) void k_pack_reads(CmDev d, uint32_t n_reads) {

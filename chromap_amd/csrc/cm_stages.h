@@ -1814,14 +1814,16 @@ CM_HD int cm_banded_align(int e, const uint8_t *pattern, const uint8_t *read, in
 // is then bits [i, i + 2e] of   c < 4 ?  ~(R0 ^ m0) & ~(R1 ^ m1) & ~RN  :  RN    (m0, m1: bit 0 / 1 of c spread over the word),
 // a shift of three 64-bit windows and four logic operations; the windows slide by one 32-bit word per 32 columns.  Everything
 // after the Peq word is the byte form's code, so the two return the same (distance, end position) for every input.
-//   rp / rw:  reference planes (CmDev::ref_pl, ref_pl_words);  g: index of the window's first base in the reference bytes
+//   rp:  reference plane records (CmDev::ref_pl);  g: index of the window's first base in the reference bytes
 //             (the byte form's `pattern` - d.ref);  tp / tw: the text's planes in the wanted orientation (CmDev::read_pl)
 // ---------------------------------------------------------------------------------------
 CM_HD uint64_t cm_load8(const uint8_t *p);
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CM_GLOBAL_U32 const __attribute__((address_space(1))) uint32_t *
+#define CM_GLOBAL_PL const __attribute__((address_space(1))) CmPlRec *
 #else
 #define CM_GLOBAL_U32 const uint32_t *
+#define CM_GLOBAL_PL const CmPlRec *
 #endif
 CM_HD uint32_t cm_brev32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1837,16 +1839,15 @@ CM_HD uint32_t cm_brev32(uint32_t v) {
 CM_HD uint32_t cm_funnel32(uint32_t lo, uint32_t hi, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo, sh < 32
   return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
 }
-CM_HD int cm_banded_align_planes(int e, const uint32_t *rp, uint64_t rw, uint64_t g, const uint32_t *tp, uint32_t tw, int L, int *end_pos) {
-  CM_GLOBAL_U32 r0 = (CM_GLOBAL_U32)rp + (g >> 5);
-  CM_GLOBAL_U32 r1 = r0 + rw;
-  CM_GLOBAL_U32 rn = r1 + rw;
+CM_HD int cm_banded_align_planes(int e, const CmPlRec *rp, uint64_t g, const uint32_t *tp, uint32_t tw, int L, int *end_pos) {
+  CM_GLOBAL_PL rr = (CM_GLOBAL_PL)rp + (g >> 5);  // one 16-byte load per record: the window's records are neighbours in memory
   CM_GLOBAL_U32 t0 = (CM_GLOBAL_U32)tp;
   CM_GLOBAL_U32 t1 = t0 + tw;
   CM_GLOBAL_U32 tn = t1 + tw;
   const uint32_t sh = (uint32_t)g & 31u;
-  uint32_t a0 = r0[0], a1 = r1[0], an = rn[0], b0 = r0[1], b1 = r1[1], bn = rn[1];
-  uint32_t c0 = r0[2], c1 = r1[2], cn = rn[2];
+  const CmPlRec ra = rr[0], rb = rr[1], rc = rr[2];
+  uint32_t a0 = ra.p0, a1 = ra.p1, an = ra.pn, b0 = rb.p0, b1 = rb.p1, bn = rb.pn;
+  uint32_t c0 = rc.p0, c1 = rc.p1, cn = rc.pn;
   uint32_t x0 = t0[0], x1 = t1[0], xn = tn[0];
   const uint32_t band = (2u << (2 * e)) - 1u;
   uint32_t VP = 0, VN = 0;
@@ -1855,7 +1856,9 @@ CM_HD int cm_banded_align_planes(int e, const uint32_t *rp, uint64_t rw, uint64_
   for (int c = 0; c < nchunk; ++c) {
     // the next chunk's words are requested before this chunk's columns run
     const bool more = c + 1 < nchunk;
-    const uint32_t d0 = more ? r0[c + 3] : 0u, d1 = more ? r1[c + 3] : 0u, dn = more ? rn[c + 3] : 0u;
+    CmPlRec rd = {0u, 0u, 0u, 0u};
+    if (more) rd = rr[c + 3];
+    const uint32_t d0 = rd.p0, d1 = rd.p1, dn = rd.pn;
     const uint32_t y0 = more ? t0[c + 1] : 0u, y1 = more ? t1[c + 1] : 0u, yn = more ? tn[c + 1] : 0u;
     const uint64_t W0 = (uint64_t)cm_funnel32(a0, b0, sh) | ((uint64_t)cm_funnel32(b0, c0, sh) << 32);
     const uint64_t W1 = (uint64_t)cm_funnel32(a1, b1, sh) | ((uint64_t)cm_funnel32(b1, c1, sh) << 32);
@@ -1899,21 +1902,23 @@ CM_HD int cm_banded_align_planes(int e, const uint32_t *rp, uint64_t rw, uint64_
 //               walked backwards is the read walked forwards, complemented
 // tp: the read's FORWARD planes (orientation 0 of CmDev::read_pl) in both cases.
 template <bool REV>
-CM_HD int cm_banded_align_dropoff_planes(int e, const uint32_t *rp, uint64_t rw, uint64_t g, const uint32_t *tp, uint32_t tw, uint32_t tbit, int L,
+CM_HD int cm_banded_align_dropoff_planes(int e, const CmPlRec *rp, uint64_t g, const uint32_t *tp, uint32_t tw, uint32_t tbit, int L,
                                          int *end_pos, int *read_mapping_length) {
-  // reference words: REV: the 64-bit field that ENDS at base g - 32 c, bit-reversed; else the field that starts at g + 32 c
-  const uint64_t f0 = REV ? g - 63 : g;  // first base of chunk 0's field
-  CM_GLOBAL_U32 r0 = (CM_GLOBAL_U32)rp + (f0 >> 5);
-  CM_GLOBAL_U32 r1 = r0 + rw;
-  CM_GLOBAL_U32 rn = r1 + rw;
-  const uint32_t sh = (uint32_t)f0 & 31u;
+  // reference words: REV: the 64-bit field that ENDS at base g - 32 c, bit-reversed; else the field that starts at g + 32 c.
+  // REV reaches below the window's first base (the byte form never did): the field of chunk 0 starts 63 bases below g and every
+  // further chunk one record lower -- down to record -2 for a window at the very start of the reference buffer, whose bits are
+  // not looked at.  The index is signed and CM_PL_LEAD zero records stand in front of record 0.
+  const int64_t f0 = REV ? (int64_t)g - 63 : (int64_t)g;  // first base of chunk 0's field
+  CM_GLOBAL_PL rr = (CM_GLOBAL_PL)rp + (f0 >> 5);         // (arithmetic shift: floor)
+  const uint32_t sh = (uint32_t)(f0 & 31);
   CM_GLOBAL_U32 t0 = (CM_GLOBAL_U32)tp + (tbit >> 5);
   CM_GLOBAL_U32 t1 = t0 + tw;
   CM_GLOBAL_U32 tn = t1 + tw;
   const uint32_t tsh = tbit & 31u;
   const uint32_t tlast = (tbit + (uint32_t)(L > 0 ? L - 1 : 0)) >> 5;  // last text word that holds a base of the text
   const uint32_t tfirst = tbit >> 5;
-  uint32_t a0 = r0[0], a1 = r1[0], an = rn[0], b0 = r0[1], b1 = r1[1], bn = rn[1], c0 = r0[2], c1 = r1[2], cn = rn[2];
+  const CmPlRec ra = rr[0], rb = rr[1], rc = rr[2];
+  uint32_t a0 = ra.p0, a1 = ra.p1, an = ra.pn, b0 = rb.p0, b1 = rb.p1, bn = rb.pn, c0 = rc.p0, c1 = rc.p1, cn = rc.pn;
   uint32_t xa0 = t0[0], xa1 = t1[0], xan = tn[0];
   uint32_t xb0 = tfirst + 1 <= tlast ? t0[1] : 0u, xb1 = tfirst + 1 <= tlast ? t1[1] : 0u, xbn = tfirst + 1 <= tlast ? tn[1] : 0u;
   const uint32_t band = (2u << (2 * e)) - 1u;
@@ -1927,7 +1932,8 @@ CM_HD int cm_banded_align_dropoff_planes(int e, const uint32_t *rp, uint64_t rw,
     uint32_t d0 = 0, d1 = 0, dn = 0, y0 = 0, y1 = 0, yn = 0;
     if (more) {
       const int ri = REV ? -(c + 1) : c + 3;
-      d0 = r0[ri]; d1 = r1[ri]; dn = rn[ri];
+      const CmPlRec rd = rr[ri];
+      d0 = rd.p0; d1 = rd.p1; dn = rd.pn;
       if (tfirst + (uint32_t)c + 2 <= tlast) { y0 = t0[c + 2]; y1 = t1[c + 2]; yn = tn[c + 2]; }
     }
     uint64_t W0 = (uint64_t)cm_funnel32(a0, b0, sh) | ((uint64_t)cm_funnel32(b0, c0, sh) << 32);
@@ -1984,16 +1990,19 @@ CM_HD int cm_banded_align_dropoff_planes(int e, const uint32_t *rp, uint64_t rw,
 }
 
 // 32 bases -> one word of each plane; n < 32: the bases beyond count as code 4
-CM_HD void cm_pack_planes32(const uint8_t *bytes, uint32_t n, uint32_t *p0, uint32_t *p1, uint32_t *pn) {
-  uint32_t q0 = 0, q1 = 0, qn = 0;
+// pc (optional): the base is a lower-case letter (bit 5 of a byte at or above 'a'; meaningful where pn is 0)
+CM_HD void cm_pack_planes32(const uint8_t *bytes, uint32_t n, uint32_t *p0, uint32_t *p1, uint32_t *pn, uint32_t *pc = nullptr) {
+  uint32_t q0 = 0, q1 = 0, qn = 0, qc = 0;
   for (uint32_t j0 = 0; j0 < 32; j0 += 8) {
     uint64_t v = j0 < n ? cm_load8(bytes + j0) : 0;
     for (uint32_t j = j0; j < j0 + 8; ++j, v >>= 8) {
       const uint32_t u = j < n ? cm_c2u((uint8_t)v) : 4u;
       q0 |= (u & 1u) << j; q1 |= ((u >> 1) & 1u) << j; qn |= (u >> 2) << j;
+      qc |= (j < n && (uint8_t)v >= 'a' && (uint8_t)v <= 'z' ? 1u : 0u) << j;
     }
   }
   *p0 = q0; *p1 = q1; *pn = qn;
+  if (pc) *pc = qc;
 }
 // read r of the batch -> its planes, forward (the read as it is: the + strand's text) and reverse complement (base i =
 // complement of read[L - 1 - i], L the trimmed length: the - strand's text, PrepareNegativeSequenceAt); the second from the first:
@@ -2395,21 +2404,21 @@ CM_HD uint32_t cm_draft_strand_split(const CmDev &d, const uint8_t *read, uint32
     const uint8_t *pat = d.ref + gpat;
     const bool pl = tp != nullptr && d.ref_pl != nullptr;
     if (strand == 0) {
-      num_errors = pl ? cm_banded_align_dropoff_planes<false>(e, d.ref_pl, d.ref_pl_words, gpat, tp, d.read_pl_w, 0u, (int)L, &mep, &rml)
+      num_errors = pl ? cm_banded_align_dropoff_planes<false>(e, d.ref_pl, gpat, tp, d.read_pl_w, 0u, (int)L, &mep, &rml)
                       : cm_banded_align_dropoff(e, pat, read, (int)L, false, 0, (int)L, false, &mep, &rml);
       if (mep < 0 && allow > 0) {
         const int b_err = num_errors, b_mep = -mep, b_rml = rml;
-        num_errors = pl ? cm_banded_align_dropoff_planes<false>(e, d.ref_pl, d.ref_pl_words, gpat + (uint32_t)allow, tp, d.read_pl_w, (uint32_t)allow, (int)L - allow, &mep, &rml)
+        num_errors = pl ? cm_banded_align_dropoff_planes<false>(e, d.ref_pl, gpat + (uint32_t)allow, tp, d.read_pl_w, (uint32_t)allow, (int)L - allow, &mep, &rml)
                         : cm_banded_align_dropoff(e, pat + allow, read, (int)L, false, allow, (int)L - allow, false, &mep, &rml);
         if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
         else { gap_beginning = allow; mep += gap_beginning; rml += gap_beginning; }
       }
     } else {
-      num_errors = pl ? cm_banded_align_dropoff_planes<true>(e, d.ref_pl, d.ref_pl_words, gpat + L + 2 * (uint32_t)e - 1, tp, d.read_pl_w, 0u, (int)L, &mep, &rml)
+      num_errors = pl ? cm_banded_align_dropoff_planes<true>(e, d.ref_pl, gpat + L + 2 * (uint32_t)e - 1, tp, d.read_pl_w, 0u, (int)L, &mep, &rml)
                       : cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L, true, &mep, &rml);
       if (mep < 0 && allow > 0) {
         const int b_err = num_errors, b_mep = -mep, b_rml = rml;
-        num_errors = pl ? cm_banded_align_dropoff_planes<true>(e, d.ref_pl, d.ref_pl_words, gpat + (L - (uint32_t)allow) + 2 * (uint32_t)e - 1, tp, d.read_pl_w, (uint32_t)allow,
+        num_errors = pl ? cm_banded_align_dropoff_planes<true>(e, d.ref_pl, gpat + (L - (uint32_t)allow) + 2 * (uint32_t)e - 1, tp, d.read_pl_w, (uint32_t)allow,
                                                                (int)L - allow, &mep, &rml)
                         : cm_banded_align_dropoff(e, pat, read, (int)L, true, 0, (int)L - allow, true, &mep, &rml);
         if (num_errors > e || mep < 0) { num_errors = b_err; mep = b_mep; rml = b_rml; }
@@ -2570,7 +2579,7 @@ CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci)
   int end_pos = (int)L;
   int ne;
   if (d.ref_pl && d.read_pl)  // the same alignment on bit planes (cm_banded_align_planes)
-    ne = cm_banded_align_planes(d.p.e, d.ref_pl, d.ref_pl_words, d.ref_off[rid] + position - (uint32_t)d.p.e,
+    ne = cm_banded_align_planes(d.p.e, d.ref_pl, d.ref_off[rid] + position - (uint32_t)d.p.e,
                                 d.read_pl + ((size_t)r * 2 + (size_t)strand) * 3 * d.read_pl_w, d.read_pl_w, (int)L, &end_pos);
   else ne = cm_verify_compute(d, cm_read_ptr(d, r), L, strand, cpos, &end_pos);
   d.v_err[o] = (int16_t)ne;

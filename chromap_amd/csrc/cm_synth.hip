@@ -54,7 +54,7 @@ CM_HD uint8_t sy_base(uint64_t seed, uint64_t g) {
 struct SyRepeats {
   uint32_t n_families, copies, element_len, div_thresh;  // div_thresh = divergence * 2^32
   uint64_t slot;                                         // slot size in bases (0 = no repeats)
-  uint32_t profile;                                      // 1: the mosaic below instead
+  uint32_t profile;                                      // 1, 2: the mosaic below instead
 };
 // one base of a planted element copy: family `fam` of the element kind `salt`, position `within` of `len`, orientation, and
 // a per-base replacement with probability div_thresh / 2^32 (hc: the copy's hash)
@@ -75,13 +75,17 @@ CM_HD uint8_t sy_copy_base(uint64_t seed, uint64_t salt, uint32_t fam, uint32_t 
 //   satellite   (2 %): the whole tile a tandem array of one of 64 units of 171 bases, 2 % of its bases replaced;
 //   unique      (66 %).
 // 11.7 % + 8.8 % + 2 % = 22.5 % of the bases are repeat-derived.  O(1) per position, no tables.
+// Profile 2 (round 4: GRCh38 is about half repeat-derived): the same element kinds with 40 % SINE-like, 28 % LINE-like and 3 %
+// satellite tiles -- 23.4 % + 20.5 % + 3 % = 47 % of the bases repeat-derived, ~19 000 copies per SINE-like family and ~830 per
+// LINE-like family on 3.1 Gb.
 #define SY_TILE 65536ull
-CM_HD uint8_t sy_mosaic_base(uint64_t seed, uint64_t g) {
+CM_HD uint8_t sy_mosaic_base(uint64_t seed, uint64_t g, uint32_t profile) {
+  const uint32_t t_sine = profile == 2 ? 40u : 20u, t_line = profile == 2 ? 68u : 32u, t_sat = profile == 2 ? 71u : 34u;
   const uint64_t tile = g / SY_TILE, in_tile = g % SY_TILE;
   const uint64_t th = sy_mix(seed ^ 0x7113D00DCAFEull ^ (tile * 0xA0761D6478BD642Full));
   const uint32_t kind = (uint32_t)(th % 100);
-  if (kind < 20 || kind < 32) {
-    const bool sine = kind < 20;
+  if (kind < t_line) {
+    const bool sine = kind < t_sine;
     const uint32_t cell_len = sine ? 512u : 4096u, elem = sine ? 300u : 3000u, n_fam = sine ? 128u : 256u;
     const uint64_t cell = tile * (SY_TILE / cell_len) + in_tile / cell_len;
     const uint64_t hc = sy_mix(seed ^ (sine ? 0x51AEull : 0x11AEull) ^ (cell * 0xC2B2AE3D27D4EB4Full));
@@ -96,7 +100,7 @@ CM_HD uint8_t sy_mosaic_base(uint64_t seed, uint64_t g) {
     }
     return sy_base(seed, g);
   }
-  if (kind < 34) {
+  if (kind < t_sat) {
     const uint32_t fam = (uint32_t)((th >> 8) % 64);
     uint8_t b = sy_base(seed ^ 0x5A7E111EEull ^ ((uint64_t)(fam + 1) << 40), in_tile % 171u);
     const uint64_t hm = sy_mix(th ^ (in_tile * 0x9E3779B97F4A7C15ull));
@@ -106,7 +110,7 @@ CM_HD uint8_t sy_mosaic_base(uint64_t seed, uint64_t g) {
   return sy_base(seed, g);
 }
 CM_HD uint8_t sy_genome_base(uint64_t seed, uint64_t g, const SyRepeats &rp) {
-  if (rp.profile == 1) return sy_mosaic_base(seed, g);
+  if (rp.profile) return sy_mosaic_base(seed, g, rp.profile);
   if (rp.slot) {
     const uint64_t ci = g / rp.slot;
     if (ci < (uint64_t)rp.n_families * rp.copies) {
@@ -317,7 +321,7 @@ extern "C" int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_s
   SyRepeats rp = {0, 0, 0, 0, 0, 0};
   if (n_families == 0xffffffffu) {  // cmgpu_create_synthetic_profile
     rp.profile = copies;
-    if (rp.profile != 1) { cm_set_error(nullptr, "unknown synthetic genome profile"); return CMGPU_EINVAL; }
+    if (rp.profile != 1 && rp.profile != 2) { cm_set_error(nullptr, "unknown synthetic genome profile"); return CMGPU_EINVAL; }
   } else if (n_families && copies && element_len) {
     rp.n_families = n_families; rp.copies = copies; rp.element_len = element_len;
     rp.div_thresh = (uint32_t)(divergence * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (divergence < 0 ? 0 : divergence * 4294967296.0));

@@ -63,6 +63,10 @@ struct CmMapqTables {
   int32_t n_break;
 };
 
+// one record of the reference's interleaved bit planes (CmDev::ref_pl)
+struct alignas(16) CmPlRec { uint32_t p0, p1, pn, pc; };
+#define CM_PL_LEAD 4
+
 // All device pointers a stage needs.  Per-read arrays are indexed r = 2*pair + mate.
 struct CmDev {
   // ---- index in HBM: bucket i = {key, val} at bkt[2i], bkt[2i+1] (16-B aligned)
@@ -75,9 +79,12 @@ struct CmDev {
   const uint64_t *ref_off;
   const uint32_t *ref_len;
   uint32_t n_seq;
-  // ---- the same bytes as bit planes (cm_pack_planes32, cm_stages.h): base i of `ref` is bit i of plane 0 / 1 (the two bits
-  //      of its CharToUint8 code) and of plane 2 (none of ACGTacgt); plane q at ref_pl + q * ref_pl_words.  nullptr: not built
-  const uint32_t *ref_pl;
+  // ---- the same bytes as bit planes (cm_pack_planes32, cm_stages.h), interleaved: record w = the four plane words of bases
+  //      32 w .. 32 w + 31 of `ref` -- bit i of p0 / p1 = the two bits of base i's CharToUint8 code, pn = none of ACGTacgt,
+  //      pc = a lower-case letter -- so that an alignment window (66 .. 100 bases) is ONE run of 48 .. 64 bytes (1-2 sectors)
+  //      instead of one run per plane.  CM_PL_LEAD zero records stand in front of record 0 (the backward windows of the split
+  //      alignment start up to two words below their first base).  ref_pl_words = records.  nullptr: not built
+  const CmPlRec *ref_pl;
   uint64_t ref_pl_words;
   // ---- the batch's reads as bit planes, forward and reverse complement (cm_pack_read_planes): read r, orientation o, plane q at
   //      read_pl + ((r * 2 + o) * 3 + q) * read_pl_w, read_pl_w words of 32 bases each.  nullptr: not packed
