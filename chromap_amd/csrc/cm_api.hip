@@ -107,7 +107,7 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "debug_candidate_capacity") {  // tests: pretend the previous batch left this much room (forces the re-run path)
     c->pred_m_ok = value > 0; c->m_cap = (uint64_t)value; c->pred_n = 0xffffffffu;  // (any batch size)
   } else if (n == "coop_profile") {  // measurement aid: per-phase cycle sums of k_s3b_coop (cmgpu_get_option coop_profile_0 .. _15)
-    if (value) { if (c->coop_prof.ensure(16 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 16 * 8)); } else c->coop_prof.release();
+    if (value) { if (c->coop_prof.ensure(32 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 32 * 8)); } else c->coop_prof.release();
   } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
     c->opt_coop_rb = (int)value;
   } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
@@ -137,7 +137,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n.rfind("coop_profile_", 0) == 0) {
     const int k = atoi(n.c_str() + 13);
     unsigned long long v = 0;
-    if (k < 0 || k > 15 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
+    if (k < 0 || k > 31 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
     *value = (int64_t)v;
   }
   else if (n == "probe_table_buckets") *value = c->fmask ? (int64_t)c->fmask + 1 : (int64_t)c->bmask + 1;
@@ -729,6 +729,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
     d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
     if (d.hv_mid > 256) d.hv_mid = 256;
     if (d.hv_max[0] == 0) d.hv_mid = 0;
+    d.hv_sub = d.hv_max[0] >= 1024 ? 256u : 0u;  // (the tests' small size classes: no sub-class)
     // with the 16-lane groups taking the lists up to hv_mid, a lane keeps the short ones only (16 hits: 256-thread blocks)
     if (d.hv_mid && c->opt_s3b_cap <= 0 && d.s3b_cap > 16) d.s3b_cap = 16;
   } else { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_mid = 0; }
@@ -790,7 +791,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   }
   uint32_t n_mm = 0;
   bool s3a_done = false;
-  uint32_t n_heavy[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // lists 0..2, 10 by size, 3: one lane each, 4: the short lists of the 16-lane groups
+  uint32_t n_heavy[CM_HV_LISTS] = {};  // lists 0..2, 10 by size, 3: one lane each, 4: the short lists of the 16-lane groups
   unsigned long long hits_total = 0;
   const bool flat = c->opt_prep_kernel == 1 && cm_prep_flat_supported(d, c->max_read_len, (uint32_t)c->opt_prep_tile_reads);
   if (flat || (cm_prep_mm_supported(d, c->max_read_len) && (c->max_read_len <= 69 || c->opt_long_fused))) {
@@ -939,7 +940,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
   // (lists of class 0 -- up to heavy_wave_max hits, a wave each here -- cost the later per-lane stages little; a uniform genome
   // still has a few thousand of them per batch, and the permutation's scans and scatters cost more than they save there)
-  c->use_perm = (uint64_t)n_heavy[1] + n_heavy[2] + n_heavy[3] + n_heavy[10] > n2 / 65536 || n_heavy[0] > n2 / 256;
+  c->use_perm = (uint64_t)n_heavy[1] + n_heavy[2] + n_heavy[3] + n_heavy[10] > n2 / 65536 || n_heavy[0] + n_heavy[21] > n2 / 256;
   if (c->opt_heavy_last) c->use_perm = c->opt_heavy_last > 0;
   if (c->use_perm) {
     uint32_t *tmp = (uint32_t *)c->hv_tmp.p;

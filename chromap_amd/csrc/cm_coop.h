@@ -491,6 +491,264 @@ CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopM
 }
 
 // ---------------------------------------------------------------------------------------
+// Mate rescue of one read and direction by a group (cm_rescue's results: the multiset of hits, their number, the
+// repetitive-seed length, the return value).  One lane per minimizer walks the merged windows of the mate's best candidates in
+// turn -- a binary search in the occurrence run (it starts where the previous window's ended: the chain of index.cc:443-470), then
+// the hits inside the window -- and a read whose mate has hundreds of best candidates keeps its lane for milliseconds (a search
+// with 300 windows in satellite arrays: ~8 ms, the whole of k_s4a/4b_rescue_list on the mosaic genome).  Here:
+//   windows  the best candidates (count == max_count, fewer than 300 or the search bails out) are compacted, the merged windows
+//            [es, ee] derived from neighbouring ones (a new window starts where the previous candidate's range ends below the
+//            next one's start): once per direction instead of once per minimizer;
+//   A        a lane per (minimizer, window) pair: lower bound of es and upper bound of ee in the minimizer's occurrence run (two
+//            binary searches, all pairs side by side);
+//   B        a lane per minimizer: the reference's search visits midpoints m and compares o[m] with es -- an occurrence run has
+//            distinct positions in ascending order, so "o[m] < es" is "m < lower bound" and "o[m] == es" is "m == lower bound and the
+//            bound is exact": the chain of searches (each starting at the previous one's last midpoint) is replayed on indices
+//            alone, no memory access; the scan that follows starts at that last midpoint (one below the bound or the bound
+//            itself, no lower-bound test in the reference: an occurrence just below the window is a hit too) and ends at the upper
+//            bound;
+//   C        the pairs' ranges are laid end to end (a scan of their lengths), the lanes take the occurrences x, x + G, ... --
+//            which pair an occurrence belongs to is a search in the offsets -- and count or write the ones on the wanted strand,
+//            in the order cm_rescue writes them (minimizer, window, occurrence).
+// Work arrays (shared memory): see CmCoopRescueMem.  Every lane returns the same values.
+// ---------------------------------------------------------------------------------------
+#define CM_RESCUE_WMAX 304u   // best mate candidates a search can have (cm_rescue_bails: fewer than 300)
+#define CM_RESCUE_PAIRS 640u  // (minimizer, window) pairs per round: at least two minimizers' worth
+#define CM_RESCUE_SLOTS 32u   // minimizers per round
+struct CmCoopRescueMem {
+  uint64_t *es, *ee;   // CM_RESCUE_WMAX each: the merged windows
+  uint64_t *bp;        // CM_RESCUE_WMAX: the best candidates' positions while the windows are built (overlays pa / pb)
+  uint64_t *mval;      // CM_RESCUE_SLOTS: lookup result of the round's minimizers (occurrence offset << 32 | count; a singleton: the occurrence)
+  uint32_t *mps;       // CM_RESCUE_SLOTS: position << 1 | strand, bit 31: singleton
+  uint32_t *pa, *pb;   // CM_RESCUE_PAIRS + 1 each: lower bound | occurrences equal to es << 30, upper bound -> first index, length -> first index, offset
+};
+CM_HD size_t cm_coop_rescue_mem_bytes() { return (size_t)CM_RESCUE_WMAX * 16 + (size_t)CM_RESCUE_SLOTS * 12 + ((size_t)CM_RESCUE_PAIRS + 1) * 8 + 32; }
+CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base) {
+  CmCoopRescueMem m;
+  m.es = reinterpret_cast<uint64_t *>(base);
+  m.ee = m.es + CM_RESCUE_WMAX;
+  m.mval = m.ee + CM_RESCUE_WMAX;
+  m.mps = reinterpret_cast<uint32_t *>(m.mval + CM_RESCUE_SLOTS);
+  m.pa = m.mps + CM_RESCUE_SLOTS;
+  m.pb = m.pa + CM_RESCUE_PAIRS + 1;
+  m.bp = reinterpret_cast<uint64_t *>(m.pa);  // (8-byte aligned: 32 words of mps behind 8-byte arrays; 2 x 641 words hold 304 positions)
+  return m;
+}
+template <class GT>
+CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn, GT &g, const CmCoopRescueMem &m,
+                         uint64_t *out, uint32_t *n_out, uint32_t *rep_len_out) {
+  const uint32_t G = (uint32_t)GT::G;
+  *n_out = 0;
+  *rep_len_out = 0;
+  // ---- the best count among the mate's candidates and how many have it
+  uint32_t lmax = 0;
+  for (uint32_t i = g.t; i < mn; i += G) lmax = mc[i] > lmax ? mc[i] : lmax;
+  const int max_count = (int)g.max64((uint64_t)lmax);
+  uint32_t lnum = 0;
+  for (uint32_t i = g.t; i < mn; i += G) lnum += (int)mc[i] == max_count ? 1u : 0u;
+  const int best_num = (int)g.sum(lnum);
+  if (cm_rescue_bails(d, max_count, best_num, mn)) return -max_count;
+  // ---- the best candidates' positions in order, then the merged windows
+  const uint64_t sr = 2ull * (uint64_t)(uint32_t)d.p.max_insert;
+  uint32_t nb = 0;
+  for (uint32_t base = 0; base < mn; base += G) {
+    const uint32_t i = base + g.t;
+    const bool is = i < mn && (int)mc[i] == max_count;
+    uint32_t tot;
+    const uint32_t at = g.scan(is ? 1u : 0u, &tot);
+    if (is) m.bp[nb + at] = mp[i];
+    nb += tot;
+  }
+  g.sync();
+  // candidate j starts a window when the previous candidate's range ends below its own start (index.cc:383-412: the ranges are
+  // merged in candidate order); it ends one when the next candidate starts one.  A window's number = the starts before it.
+  uint32_t W = 0;
+  for (uint32_t base = 0; base < nb; base += G) {
+    const uint32_t j = base + g.t;
+    bool st = false, last = false;
+    uint64_t pos = 0, s = 0;
+    if (j < nb) {
+      pos = m.bp[j];
+      s = pos < sr ? 0 : pos - sr;
+      st = j == 0 || m.bp[j - 1] + sr < s;
+      if (j + 1 == nb) last = true;
+      else { const uint64_t pn = m.bp[j + 1]; last = pos + sr < (pn < sr ? 0 : pn - sr); }
+    }
+    uint32_t tot;
+    const uint32_t at = g.scan(st ? 1u : 0u, &tot);
+    const uint32_t w = W + at + (st ? 1u : 0u) - 1u;  // the window candidate j lies in
+    if (st) m.es[w] = s;
+    if (last) m.ee[w] = pos + sr;
+    W += tot;
+  }
+  g.sync();  // (bp is dead from here on: pa / pb overlay it)
+  // ---- the minimizers, CM_RESCUE_SLOTS (or as many as CM_RESCUE_PAIRS pairs hold) per round
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  const bool no_window = W == 0;  // (no mate candidate: cm_rescue then finds the singletons only; callers do not ask)
+  if (no_window) { W = 1; if (g.t == 0) { m.es[0] = ~0ull; m.ee[0] = 0; } g.sync(); }
+  uint32_t per_round = CM_RESCUE_PAIRS / W;
+  if (per_round > CM_RESCUE_SLOTS) per_round = CM_RESCUE_SLOTS;
+  if (per_round == 0) per_round = 1;
+  uint32_t cnt = 0;  // hits so far (uniform)
+  for (uint32_t m0 = 0; m0 < n; m0 += per_round) {
+    const uint32_t ns = n - m0 < per_round ? n - m0 : per_round;
+    for (uint32_t s = g.t; s < ns; s += G) {
+      const uint8_t kind = d.pr_kind[b + m0 + s];
+      uint32_t ps = d.mm_ps[b + m0 + s];
+      uint64_t val = d.pr_val[b + m0 + s];
+      if (kind == CM_PR_MISS) val = 0;              // no occurrences
+      else if (kind == CM_PR_SINGLE) ps |= 1u << 31;
+      m.mval[s] = val;
+      m.mps[s] = ps;
+    }
+    g.sync();
+    const uint32_t np = ns * W;
+    // -- A: bounds of every (minimizer, window) pair
+    for (uint32_t q = g.t; q < np; q += G) {
+      const uint32_t s = q / W, w = q - s * W;
+      const uint32_t ps = m.mps[s];
+      uint32_t lbx = 0, ub = 0;
+      if (!(ps >> 31)) {
+        const uint64_t val = m.mval[s];
+        const uint32_t nocc = (uint32_t)val;
+        const uint64_t *o = d.occ + (uint32_t)(val >> 32);
+        const uint64_t es = m.es[w], ee = m.ee[w];
+        uint32_t lo = 0, hi = nocc;  // first index with o >> 1 >= es
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((o[mid] >> 1) < es) lo = mid + 1; else hi = mid;
+        }
+        // occurrences at exactly es (two at most: one per strand; none for an index built by the reference, whose minimizers have one
+        // strand per position): the search's "equal" outcome for the midpoints lo .. lo + eq - 1
+        const uint32_t eq = (lo < nocc && (o[lo] >> 1) == es ? 1u : 0u) + (lo + 1 < nocc && (o[lo + 1] >> 1) == es ? 1u : 0u);
+        lbx = lo | (eq << 30);
+        hi = nocc;  // first index with o >> 1 > ee (from the lower bound on)
+        uint32_t l2 = lo;
+        while (l2 < hi) {
+          const uint32_t mid = (l2 + hi) >> 1;
+          if ((o[mid] >> 1) <= ee) l2 = mid + 1; else hi = mid;
+        }
+        ub = l2;
+      }
+      m.pa[q] = lbx;
+      m.pb[q] = ub;
+    }
+    g.sync();
+    // -- B: the chain of searches per minimizer, on indices alone: first index and length of every pair's scan
+    for (uint32_t s = g.t; s < ns; s += G) {
+      const uint32_t ps = m.mps[s];
+      const uint64_t val = m.mval[s];
+      if (ps >> 31) {  // a singleton: its one occurrence, whatever the windows (cm_rescue_minimizer)
+        for (uint32_t w = 0; w < W; ++w) { m.pa[s * W + w] = 0; m.pb[s * W + w] = w == 0 ? 1u : 0u; }
+        continue;
+      }
+      const uint32_t nocc = (uint32_t)val;
+      int32_t prev_l = 0;
+      for (uint32_t w = 0; w < W; ++w) {
+        const uint32_t lbx = m.pa[s * W + w], ub = m.pb[s * W + w];
+        uint32_t first = 0, len = 0;
+        if (nocc) {
+          const int32_t lb = (int32_t)(lbx & 0x3fffffffu), le = lb + (int32_t)(lbx >> 30);
+          int32_t l = prev_l, mid = 0, rr = (int32_t)(nocc - 1);
+          while (l <= rr) {
+            mid = (l + rr) / 2;
+            if (mid < lb) l = mid + 1;
+            else if (mid >= le) rr = mid - 1;
+            else break;
+          }
+          prev_l = mid;
+          first = (uint32_t)mid;
+          len = ub > first && !no_window ? ub - first : 0u;
+        }
+        m.pa[s * W + w] = first;
+        m.pb[s * W + w] = len;
+      }
+    }
+    g.sync();
+    // -- C: exclusive scan of the lengths in pair order (pb), then the occurrences themselves
+    uint32_t total;
+    {
+      const uint32_t VT = cm_coop_chunk(np, G);
+      const uint32_t c0 = cm_min_u32(np, g.t * VT), c1 = cm_min_u32(np, c0 + VT);
+      uint32_t sum = 0;
+      for (uint32_t q = c0; q < c1; ++q) sum += m.pb[q];
+      uint32_t run = g.scan(sum, &total);
+      for (uint32_t q = c0; q < c1; ++q) { const uint32_t x = m.pb[q]; m.pb[q] = run; run += x; }
+      if (g.t == 0) m.pb[np] = total;
+      g.sync();
+    }
+    for (uint32_t x0 = 0; x0 < total; x0 += G) {
+      const uint32_t x = x0 + g.t;
+      bool match = false;
+      uint64_t cp = 0;
+      if (x < total) {
+        uint32_t lo = 0, hi = np;  // the largest q with pb[q] <= x (the pairs without occurrences share their successor's offset)
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (m.pb[mid] <= x) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo / W;
+        const uint32_t ps = m.mps[s];
+        const uint64_t val = m.mval[s];
+        const uint64_t hit = (ps >> 31) ? val : d.occ[(uint32_t)(val >> 32) + m.pa[lo] + (x - m.pb[lo])];
+        bool same;
+        cp = cm_cand_from_hit(hit, ps & 0x7fffffffu, d.p.k, &same);
+        match = (same && strand == 0) || (!same && strand == 1);
+      }
+      uint32_t tot;
+      const uint32_t at = g.scan(match ? 1u : 0u, &tot);
+      if (match && out) out[cnt + at] = cp;
+      cnt += tot;
+    }
+    g.sync();  // the tables serve the next round
+  }
+  // ---- repetitive_seed_length over the minimizers in order
+  uint32_t rep_len = 0;
+  if (g.t == 0) {
+    uint32_t prev_rep = ~0u;
+    for (uint32_t mi = 0; mi < n; ++mi) cm_rescue_rep(d, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], &rep_len, &prev_rep);
+  }
+  *rep_len_out = cm_coop_bcast0(g, rep_len);
+  *n_out = cnt;
+  return max_count;
+}
+
+// S4a's two searches for a read whose mate has many candidates (cm_s4a_rescue's results) ...
+template <class GT>
+CM_HD void cm_coop_s4a_rescue(const CmDev &d, uint32_t r, GT &g, const CmCoopRescueMem &m) {
+  const uint32_t o = r ^ 1u;
+  uint32_t cntn = 0, cntp = 0, rl = 0, rl_val = 0;
+  int res_neg = 0, res_pos = 0;
+  bool set_rl = false;
+  if (d.ncp[o] > 0) {  // the mate's + candidates drive a search on our - strand (candidate_processor.cc:147-153)
+    res_neg = cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, nullptr, &cntn, &rl);
+    if (res_neg >= 0) { set_rl = true; rl_val = rl; }
+  }
+  if (d.ncn[o] > 0) {
+    res_pos = cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, nullptr, &cntp, &rl);
+    if (res_pos >= 0) { set_rl = true; rl_val = rl; }
+  }
+  if (g.t == 0) {
+    d.aug[r] = 1;
+    d.res_neg[r] = res_neg; d.res_pos[r] = res_pos;
+    d.resc_n[r] = cntn; d.resc_p[r] = cntp;
+    if (set_rl) d.rep_len[r] = rl_val;  // repetitive_seed_length overwritten (:113,131, index.cc:487)
+    d.m_tot[r] = d.ncp[r] + d.ncn[r] + cntn + cntp;
+  }
+}
+// ... and S4b's fill pass for it: the rescue hits where cm_s4b_rescue_merge(CM_S4B_FILL_ONLY) writes them, in the same order
+template <class GT>
+CM_HD void cm_coop_s4b_fill(const CmDev &d, uint32_t r, GT &g, const CmCoopRescueMem &m) {
+  const uint32_t o = r ^ 1u;
+  const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
+  uint64_t *P = d.mbuf + d.m_off[r];
+  uint64_t *N = P + ncp + rp;
+  uint32_t cnt, rl;
+  if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) (void)cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, N + ncn, &cnt, &rl);
+  if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0) (void)cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, P + ncp, &cnt, &rl);
+}
+
+// ---------------------------------------------------------------------------------------
 // Array helpers over the group: exclusive prefix sum / exclusive prefix maximum of a[0..n) in place (shared memory),
 // every lane a contiguous chunk, the chunk totals through the group.  Return the total / the overall maximum.
 // ---------------------------------------------------------------------------------------
@@ -539,13 +797,15 @@ struct CmCoopPairMem {
   uint8_t *k1, *k2, *x1, *x2; // P each
   uint32_t P;
 };
-CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P) { return (size_t)P * 26 + 32; }
-CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P) {
+// staged == false: no room for the position lists (10 bytes per entry instead of 26) -- the form for the few pairs with lists
+// beyond the staged classes, whose searches then run on the lists where they are (cm_coop_reduce_dir<false>)
+CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P, bool staged = true) { return (size_t)P * (staged ? 26 : 10) + 32; }
+CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P, bool staged = true) {
   CmCoopPairMem m;
   m.P = P;
   m.s1 = reinterpret_cast<uint64_t *>(base);
-  m.s2 = m.s1 + P;
-  m.lo1 = reinterpret_cast<uint16_t *>(m.s2 + P);
+  m.s2 = m.s1 + (staged ? P : 0);
+  m.lo1 = reinterpret_cast<uint16_t *>(m.s2 + (staged ? P : 0));
   m.of1 = m.lo1 + P;
   m.of2 = m.of1 + P;
   m.k1 = reinterpret_cast<uint8_t *>(m.of2 + P);
@@ -554,14 +814,16 @@ CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P) {
   m.x2 = m.x1 + P;
   return m;
 }
-template <class GT>
+template <bool STAGED, class GT>
 CM_HD void cm_coop_reduce_dir(GT &g, const CmCoopPairMem &m, uint32_t dist, const uint64_t *gp1, const uint8_t *c1, uint32_t n1, const uint64_t *gp2,
                               const uint8_t *c2, uint32_t n2, uint64_t *f1, uint8_t *fc1, uint32_t *nf1, uint64_t *f2, uint8_t *fc2, uint32_t *nf2) {
   const uint32_t G = (uint32_t)GT::G;
-  for (uint32_t i = g.t; i < n1; i += G) m.s1[i] = gp1[i];
-  for (uint32_t j = g.t; j < n2; j += G) m.s2[j] = gp2[j];
+  if (STAGED) {
+    for (uint32_t i = g.t; i < n1; i += G) m.s1[i] = gp1[i];
+    for (uint32_t j = g.t; j < n2; j += G) m.s2[j] = gp2[j];
+  }
   g.sync();
-  const uint64_t *p1 = m.s1, *p2 = m.s2;
+  const uint64_t *p1 = STAGED ? m.s1 : gp1, *p2 = STAGED ? m.s2 : gp2;  // (compile-time choice: see cm_coop_s3b)
   // ---- list 1: lo, paired; x1 = count of a paired entry (for max1), else 0
   uint32_t my_end = n1;
   for (uint32_t i = g.t; i < n1; i += G) {
@@ -649,7 +911,7 @@ CM_HD void cm_coop_reduce_dir(GT &g, const CmCoopPairMem &m, uint32_t dist, cons
 
 // S4c for one pair with long candidate lists: the two directions of the paired-end filter by the group, the pair's fate,
 // the re-ranking (cm_s4c_filter + cm_s4c_post; cm_s4c_pre ran in the per-pair kernel and asked for the filter).
-template <class GT>
+template <bool STAGED, class GT>
 CM_HD void cm_coop_s4c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPairMem &m) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   const uint32_t G = (uint32_t)GT::G;
@@ -658,10 +920,10 @@ CM_HD void cm_coop_s4c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPairMem
     return;
   }
   uint32_t a, b, c, e2;
-  cm_coop_reduce_dir(g, m, (uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2), cm_m_ncnt(d, r2), d.mcn[r2],
+  cm_coop_reduce_dir<STAGED>(g, m, (uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2), cm_m_ncnt(d, r2), d.mcn[r2],
                      cm_f_pos(d, r1), cm_f_pcnt(d, r1), &a, cm_f_neg(d, r2), cm_f_ncnt(d, r2), &b);
   g.sync();
-  cm_coop_reduce_dir(g, m, (uint32_t)d.p.max_insert, cm_m_neg(d, r1), cm_m_ncnt(d, r1), d.mcn[r1], cm_m_pos(d, r2), cm_m_pcnt(d, r2), d.mcp[r2],
+  cm_coop_reduce_dir<STAGED>(g, m, (uint32_t)d.p.max_insert, cm_m_neg(d, r1), cm_m_ncnt(d, r1), d.mcn[r1], cm_m_pos(d, r2), cm_m_pcnt(d, r2), d.mcp[r2],
                      cm_f_neg(d, r1), cm_f_ncnt(d, r1), &c, cm_f_pos(d, r2), cm_f_pcnt(d, r2), &e2);
   g.sync();
   const bool alive = a + c > 0 && b + e2 > 0;
@@ -927,17 +1189,23 @@ CM_HD void cm_coop_s5_sort(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, ui
 template <class GT>
 CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m, const CmCoopSortMem &sm) {
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
-  if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: one lane
+  uint32_t ndp, ndn;
+  if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: the acceptance loop by one lane -- but the draft mappings it
+    // leaves are sorted by the group like everybody's (round 4: they used to stay in candidate order, and the pairing stage's lane 0
+    // then heap-sorted lists of thousands of entries in global memory: 38 + 18 ms per batch of the mosaic genome for ~200 reads)
     if (g.t == 0) cm_s5c_accept(d, r);
-    return;
-  }
-  CmTwo best = {d.min_err[r], d.n_best[r], d.second_err[r], d.n_second[r]};
-  const uint32_t L = d.rlen[r];
-  const uint32_t ndp = cm_coop_draft_strand(d, g, m, L, 0, d.fbuf + op, d.fcnt + op, d.fcp[r], best, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
-  const uint32_t ndn = cm_coop_draft_strand(d, g, m, L, 1, d.fbuf + on, d.fcnt + on, d.fcn[r], best, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
-  if (g.t == 0) {
-    d.ndp[r] = ndp; d.ndn[r] = ndn;
-    d.min_err[r] = best.lo; d.second_err[r] = best.hi; d.n_best[r] = best.n_lo; d.n_second[r] = best.n_hi;
+    g.sync();
+    ndp = cm_coop_bcast0(g, g.t == 0 ? d.ndp[r] : 0u);
+    ndn = cm_coop_bcast0(g, g.t == 0 ? d.ndn[r] : 0u);
+  } else {
+    CmTwo best = {d.min_err[r], d.n_best[r], d.second_err[r], d.n_second[r]};
+    const uint32_t L = d.rlen[r];
+    ndp = cm_coop_draft_strand(d, g, m, L, 0, d.fbuf + op, d.fcnt + op, d.fcp[r], best, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
+    ndn = cm_coop_draft_strand(d, g, m, L, 1, d.fbuf + on, d.fcnt + on, d.fcn[r], best, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
+    if (g.t == 0) {
+      d.ndp[r] = ndp; d.ndn[r] = ndn;
+      d.min_err[r] = best.lo; d.second_err[r] = best.hi; d.n_best[r] = best.n_lo; d.n_second[r] = best.n_hi;
+    }
   }
   if (!d.p.single) {  // the pairing stage wants them by position (single-end keeps the emission order)
     g.sync();
@@ -955,22 +1223,35 @@ CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m,
 // A lane takes the mappings i1 = t, t + G, ...; the lanes' results are merged (the first minimal pairing: the smallest packed
 // (sum, direction, i1, i2) key).
 // ---------------------------------------------------------------------------------------
-template <class GT>
-CM_HD void cm_coop_pair_dir(const CmDev &d, GT &g, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na, const uint64_t *bp, const int16_t *be,
-                            uint32_t nb, uint32_t len1, uint32_t len2, CmTwo &mine, uint64_t &first_key) {
+// STAGED (compile time, for the reason given at cm_coop_s3b): the second list is copied to the group's shared work arrays
+// (sp / se, nb entries) first -- its binary searches and partner walks are chains of dependent loads, ~12 + range per first-list
+// entry, and at global-memory latency they were ALL of k_s6a_coop (38 ms per 4 M pairs of the mosaic genome at 6 % VALU
+// activity, profiles/r04a_harsh_*).  The first list is read once, coalesced, from where it is.
+template <bool STAGED, class GT>
+CM_HD void cm_coop_pair_dir(const CmDev &d, GT &g, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na, const uint64_t *gbp, const int16_t *gbe,
+                            uint32_t nb, uint32_t len1, uint32_t len2, CmTwo &mine, uint64_t &first_key, uint64_t *sp = nullptr, int16_t *se = nullptr) {
   const uint64_t I = (uint64_t)(int64_t)d.p.max_insert;
   const uint64_t mo = (uint32_t)d.p.min_read_len;
   const uint64_t X = dir == 1 ? I - len2 : (uint64_t)len1 - mo;  // an entry p2 is too far below p1 when p1 > p2 + X
   const uint64_t Y = dir == 0 ? I - len1 : (uint64_t)len2 - mo;  // ... too far above when p2 > p1 + Y
+  if (na == 0 || nb == 0) return;  // (uniform)
+  if (STAGED) {
+    g.sync();  // the previous user of the work arrays is done
+    for (uint32_t j = g.t; j < nb; j += (uint32_t)GT::G) { sp[j] = gbp[j]; se[j] = gbe[j]; }
+    g.sync();
+  }
+  const uint64_t *bp = STAGED ? sp : gbp;
+  const int16_t *be = STAGED ? se : gbe;
   for (uint32_t i1 = g.t; i1 < na; i1 += (uint32_t)GT::G) {
     const uint64_t p1 = ap[i1];
+    const int e1 = (int)ae[i1];
     uint32_t lo = 0, hi = nb;  // first i2 with !(p1 > bp[i2] + X)
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       if (p1 > bp[mid] + X) lo = mid + 1; else hi = mid;
     }
     for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur) {
-      const int s = (int)ae[i1] + (int)be[cur];
+      const int s = e1 + (int)be[cur];
       cm_two_add(mine, s, 1);
       const uint64_t key = ((uint64_t)(uint32_t)(s + 1024) << 49) | ((uint64_t)(uint32_t)dir << 48) | ((uint64_t)i1 << 24) | (uint64_t)cur;
       if (key < first_key) first_key = key;
@@ -984,8 +1265,18 @@ CM_HD bool cm_coop_is_sorted(GT &g, const uint64_t *p, uint32_t n) {
   for (uint32_t i = g.t + 1; i < n; i += (uint32_t)GT::G) bad += p[i] < p[i - 1] ? 1u : 0u;
   return g.sum(bad) == 0;
 }
+// shared work arrays of a group for the pairing stages: the second list of one direction (positions, error counts), P entries
+struct CmCoopPeMem { uint64_t *sp; int16_t *se; uint32_t P; };
+CM_HD size_t cm_coop_pe_mem_bytes(uint32_t P) { return (size_t)P * 10 + 16; }
+CM_HD CmCoopPeMem cm_coop_pe_mem_at(uint8_t *base, uint32_t P) {
+  CmCoopPeMem m;
+  m.P = P;
+  m.sp = reinterpret_cast<uint64_t *>(base);
+  m.se = reinterpret_cast<int16_t *>(m.sp + P);
+  return m;
+}
 template <bool SAM, class GT>
-CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g) {
+CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g, const CmCoopPeMem &m) {
   // cm_s6a_pair's prologue ran in the per-pair kernel (record slots cleared, pe_nbest = 0, both reads have draft mappings)
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   for (uint32_t r = r1; r <= r2; ++r)
@@ -1001,8 +1292,15 @@ CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g) {
   CmTwo mine = {none, 0, none, 0};
   uint64_t first_key = ~0ull;
   const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
-  cm_coop_pair_dir(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2], len1, len2, mine, first_key);
-  cm_coop_pair_dir(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2], len1, len2, mine, first_key);
+  // a second list that fits the work arrays is staged there (every lane takes the same branch: the lengths are the pair's)
+  if (d.ndn[r2] <= m.P)
+    cm_coop_pair_dir<true>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2], len1, len2, mine, first_key, m.sp, m.se);
+  else
+    cm_coop_pair_dir<false>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2], len1, len2, mine, first_key);
+  if (d.ndp[r2] <= m.P)
+    cm_coop_pair_dir<true>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2], len1, len2, mine, first_key, m.sp, m.se);
+  else
+    cm_coop_pair_dir<false>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2], len1, len2, mine, first_key);
   const CmTwo all = cm_coop_two_merge(g, mine, none);
   const uint64_t fk = g.min64(first_key);
   CmPe pe;
@@ -1024,26 +1322,37 @@ CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g) {
 // first-list entry (partner range by binary search, as cm_coop_pair_dir), a scan places the target in one lane's range, that lane
 // walks to it.  *seen: minimal-sum pairings before this direction (in, uniform) / including it when not found (out).
 // ---------------------------------------------------------------------------------------
-template <class GT>
-CM_HD bool cm_coop_pair_find(const CmDev &d, GT &g, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na, const uint64_t *bp, const int16_t *be,
-                             uint32_t nb, uint32_t len1, uint32_t len2, int final_min, uint64_t want, uint64_t *seen, uint32_t *f_i1, uint32_t *f_i2) {
+template <bool STAGED, class GT>
+CM_HD bool cm_coop_pair_find(const CmDev &d, GT &g, int dir, const uint64_t *ap, const int16_t *ae, uint32_t na, const uint64_t *gbp, const int16_t *gbe,
+                             uint32_t nb, uint32_t len1, uint32_t len2, int final_min, uint64_t want, uint64_t *seen, uint32_t *f_i1, uint32_t *f_i2,
+                             uint64_t *sp = nullptr, int16_t *se = nullptr) {
   const uint32_t G = (uint32_t)GT::G;
   const uint64_t I = (uint64_t)(int64_t)d.p.max_insert;
   const uint64_t mo = (uint32_t)d.p.min_read_len;
   const uint64_t X = dir == 1 ? I - len2 : (uint64_t)len1 - mo;
   const uint64_t Y = dir == 0 ? I - len1 : (uint64_t)len2 - mo;
+  if (na == 0 || nb == 0) return false;  // (uniform; no pairing in this direction)
+  if (STAGED) {  // the second list in the group's work arrays (see cm_coop_pair_dir)
+    g.sync();
+    for (uint32_t j = g.t; j < nb; j += G) { sp[j] = gbp[j]; se[j] = gbe[j]; }
+    g.sync();
+  }
+  const uint64_t *bp = STAGED ? sp : gbp;
+  const int16_t *be = STAGED ? se : gbe;
   for (uint32_t base = 0; base < na; base += G) {
     const uint32_t i1 = base + g.t;
     uint32_t cnt = 0, lo = 0;
     uint64_t p1 = 0;
+    int e1 = 0;
     if (i1 < na) {
       p1 = ap[i1];
+      e1 = (int)ae[i1];
       uint32_t hi = nb;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if (p1 > bp[mid] + X) lo = mid + 1; else hi = mid;
       }
-      for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur) cnt += (int)ae[i1] + (int)be[cur] == final_min ? 1u : 0u;
+      for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur) cnt += e1 + (int)be[cur] == final_min ? 1u : 0u;
     }
     uint32_t tot;
     const uint32_t off = g.scan(cnt, &tot);
@@ -1053,7 +1362,7 @@ CM_HD bool cm_coop_pair_find(const CmDev &d, GT &g, int dir, const uint64_t *ap,
       if (cnt && first <= want && want < first + cnt) {
         uint64_t k = want - first;
         for (uint32_t cur = lo; cur < nb && bp[cur] <= p1 + Y; ++cur)
-          if ((int)ae[i1] + (int)be[cur] == final_min) {
+          if (e1 + (int)be[cur] == final_min) {
             if (k == 0) { found = (((uint64_t)i1 << 32) | cur) + 1; break; }
             --k;
           }
@@ -1069,7 +1378,7 @@ CM_HD bool cm_coop_pair_find(const CmDev &d, GT &g, int dir, const uint64_t *ap,
 }
 // cm_s6c_multi for one pair (bulk paired-end, not split): the records of the sampled pairings
 template <bool SAM, class GT>
-CM_HD void cm_coop_s6c(const CmDev &d, uint32_t pair, GT &g) {
+CM_HD void cm_coop_s6c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPeMem &m) {
   const int nb = d.pe_nbest[pair];
   if (nb <= 1 || nb > d.p.drop_rep) return;
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
@@ -1085,12 +1394,18 @@ CM_HD void cm_coop_s6c(const CmDev &d, uint32_t pair, GT &g) {
       uint64_t seen = 0;
       uint32_t i1 = 0, i2 = 0;
       int dir = 0;
-      bool found = cm_coop_pair_find(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
+      bool found = d.ndn[r2] <= m.P
+          ? cm_coop_pair_find<true>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
+                                    len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2, m.sp, m.se)
+          : cm_coop_pair_find<false>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
                                      len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
       if (!found) {
         dir = 1;
-        found = cm_coop_pair_find(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
-                                  len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
+        found = d.ndp[r2] <= m.P
+            ? cm_coop_pair_find<true>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
+                                      len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2, m.sp, m.se)
+            : cm_coop_pair_find<false>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
+                                       len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
       }
       if (!found) { if (g.t == 0) d.stats[CM_ST_ERR] = 2; return; }
       pe.f_dir = (uint32_t)dir; pe.f_i1 = i1; pe.f_i2 = i2;

@@ -381,15 +381,16 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
   // one atomic per BLOCK and class: millions of lanes adding to one counter serialise at ~10 ns each, and so do the waves of a
   // batch from a repeat-bearing genome, where nearly every wave holds a read of some class (k_s3a_count 1.4 ms against 0.45 ms
   // on the uniform genome with one atomic per wave).  The order inside a list is of no consequence.
-  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : tot <= d.hv_max[3] ? 10u : 3u;
-  __shared__ uint32_t sh_cnt[6], sh_base[6];
-  if (threadIdx.x < 6) sh_cnt[threadIdx.x] = 0;
+  // (class 21: the lists of the wave class that fit a quarter of its work area -- four reads per CU where the full-size area has one)
+  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_sub ? 21u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : tot <= d.hv_max[3] ? 10u : 3u;
+  __shared__ uint32_t sh_cnt[7], sh_base[7];
+  if (threadIdx.x < 7) sh_cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t ids[6] = {0u, 1u, 2u, 3u, 4u, 10u};
-  uint32_t slot = 0, mine = 6;
+  const uint32_t ids[7] = {0u, 1u, 2u, 3u, 4u, 10u, 21u};
+  uint32_t slot = 0, mine = 7;
 #pragma unroll
-  for (uint32_t q = 0; q < 6; ++q) {
+  for (uint32_t q = 0; q < 7; ++q) {
     const unsigned long long m = __ballot(cls == ids[q]);
     if (m == 0) continue;
     uint32_t base = 0;
@@ -398,9 +399,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
     if (cls == ids[q]) { slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); mine = q; }
   }
   __syncthreads();
-  if (threadIdx.x < 6 && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&d.hv_cnt[threadIdx.x == 5 ? 10u : threadIdx.x], sh_cnt[threadIdx.x]);
+  if (threadIdx.x < 7 && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&d.hv_cnt[ids[threadIdx.x]], sh_cnt[threadIdx.x]);
   __syncthreads();
-  if (mine < 6) d.hv_list[(size_t)(mine == 5 ? 10u : mine) * d.hv_stride + sh_base[mine] + slot] = i;
+  if (mine < 7) d.hv_list[(size_t)ids[mine] * d.hv_stride + sh_base[mine] + slot] = i;
 }
 // S3b with the per-read hit list staged in LDS ([entry][thread] layout: 16 x 8-byte entries and
 // 16 count bytes per thread = 36 KB per block).  The first version sorted every list in its
@@ -770,8 +771,18 @@ __device__ __forceinline__ int cm_group_rescue_count(const CmDev &d, uint32_t r,
   int max_count, best_num;
   cm_group_best(mc, mn, t, &max_count, &best_num);
   *cnt = 0;
-  if (cm_rescue_bails(d, max_count, best_num, mn)) return -max_count;
+  if (cm_rescue_bails(d, max_count, best_num, mn)) {
+    if (d.prof && t == 0) atomicAdd(&d.prof[26], 1ull);
+    return -max_count;
+  }
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  if (d.prof && t == 0) {  // measurement aid (tools/coop_profile.py): what the heavy rescue searches look like
+    unsigned long long so = 0;
+    for (uint32_t mi = 0; mi < n; ++mi) if (d.pr_kind[b + mi] == CM_PR_MULTI) so += (uint32_t)d.pr_val[b + mi];
+    atomicAdd(&d.prof[16], 1ull); atomicAdd(&d.prof[17], (unsigned long long)best_num); atomicAdd(&d.prof[18], (unsigned long long)mn);
+    atomicAdd(&d.prof[19], so); atomicAdd(&d.prof[20], (unsigned long long)n);
+    atomicAdd(&d.prof[best_num < 4 ? 22 : best_num < 16 ? 23 : best_num < 64 ? 24 : 25], 1ull);
+  }
   uint32_t lc = 0;
   for (uint32_t mi = t; mi < n; mi += CM_RS_G)
     lc += cm_rescue_minimizer(d, strand, mp, mc, mn, max_count, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], nullptr, nullptr);
@@ -783,6 +794,7 @@ __device__ __forceinline__ int cm_group_rescue_count(const CmDev &d, uint32_t r,
   }
   *rl = __shfl(rep_len, 0, CM_RS_G);
   *cnt = lc;
+  if (d.prof && t == 0) atomicAdd(&d.prof[21], (unsigned long long)lc);
   return max_count;
 }
 __global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_cap) {
@@ -925,6 +937,8 @@ __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev 
 // CM_S4C_COOP_MIN entries only gets the part before the filter here and goes to list 9 for k_s4c_coop (a wave per pair).
 #define CM_S4C_COOP_MIN 48u
 #define CM_S5C_COOP_MIN 48u  // candidates of a read above which S5 (sorting the lists, alignments, acceptance) is a wave's work
+#define CM_S5C_P_WAVE 2048u   // candidates of a strand the wave's work arrays hold
+#define CM_S5C_P_BLOCK 16384u // ... a block's (longer lists: the acceptance loop by one lane)
 __device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair, bool live, uint32_t coop) {
   for (uint32_t q = 0; q < 4; ++q) {  // (read, strand) lists of the pair
     const uint32_t r = 2 * pair + (q >> 1);
@@ -935,6 +949,8 @@ __device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair,
 }
 #define CM_S4C_P_WAVE 1024u   // entries of a candidate list the work arrays of a wave hold
 #define CM_S4C_P_BLOCK 4096u  // ... of a block
+#define CM_S4C_P_BIG 15360u   // ... of a block of 1024 lanes that leaves the position lists in global memory (a lane walking such a
+                              // pair's two-pointer loop at global latency was the whole 16 ms of k_s4c_reduce on the mosaic genome)
 __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, uint32_t coop) {
   if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
@@ -945,33 +961,34 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, ui
     uint32_t big = d.mcp[r1] > d.mcn[r1] ? d.mcp[r1] : d.mcn[r1];
     big = d.mcp[r2] > big ? d.mcp[r2] : big;
     big = d.mcn[r2] > big ? d.mcn[r2] : big;
-    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : 0u;
+    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : big <= d.s4c_pbig ? 19u : 0u;
     if (!cls) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
   }
   if (coop & 4u) {
     cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, cls == 9u, pair);
     cm_wave_append(d.hv_list + 14 * (size_t)d.hv_stride, d.hv_cnt + 14, cls == 14u, pair);
+    cm_wave_append(d.hv_list + 19 * (size_t)d.hv_stride, d.hv_cnt + 19, cls == 19u, pair);
   }
   if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
   cm_s4c_queue_sort(d, pair, i < n && !cls && d.alive[pair], coop);
 }
 // the pairs of list 9 / 14: the filter's two directions by a wave / a block each (cm_coop_s4c); the list's length is on the device
-template <int G>
-__global__ __launch_bounds__(CM_BLOCK) void k_s4c_coop(CmDev d, uint32_t P, uint32_t lid, uint32_t coop) {
+template <int G, bool STAGED>
+__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4c_coop(CmDev d, uint32_t P, uint32_t lid, uint32_t coop) {
   if (d.abort && *d.abort) return;
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = d.hv_cnt[lid];
   const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
-  const size_t gb = ((cm_coop_pair_mem_bytes(P) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  const size_t gb = ((cm_coop_pair_mem_bytes(P, STAGED) + 15) & ~(size_t)15) + CM_XW_BYTES;
   uint8_t *base = cm_lds + (size_t)grp * gb;
-  const CmCoopPairMem m = cm_coop_pair_mem_at(base, P);
+  const CmCoopPairMem m = cm_coop_pair_mem_at(base, P, STAGED);
   CmDevGroup<G> g;
   g.t = threadIdx.x % G;
   g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t j0 = blockIdx.x * gpb; j0 < n_list; j0 += gridDim.x * gpb) {
     const uint32_t j = j0 + grp;
     const uint32_t pair = j < n_list ? list[j] : 0u;
-    if (j < n_list) cm_coop_s4c(d, pair, g, m);
+    if (j < n_list) cm_coop_s4c<STAGED>(d, pair, g, m);
     g.sync();
     if (d.perm_pairs) {  // long filtered lists: queued for the sorting waves
       const bool live = j < n_list && d.alive[pair];
@@ -990,7 +1007,12 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, u
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t r = i < n ? (d.perm_reads ? d.perm_reads[i] : i) : 0u;
   const bool to_wave = i < n && cm_s5a_prepare(d, r, coop ? CM_S5C_COOP_MIN : 0u);
-  if (coop) cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave, r);
+  // list 12: a wave per read; list 22: a block per read -- a strand's list is longer than the wave's work arrays
+  const bool big = to_wave && (d.fcp[r] > CM_S5C_P_WAVE || d.fcn[r] > CM_S5C_P_WAVE);
+  if (coop) {
+    cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave && !big, r);
+    cm_wave_append(d.hv_list + (size_t)22 * d.hv_stride, d.hv_cnt + 22, big, r);
+  }
 }
 // S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, uint32_t coop) {
@@ -1009,14 +1031,14 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, 
 #define CM_SORT_NB 64u  // counts below this go through the groups' counting sort of a candidate list
 #define CM_SORT_STAGE 512u  // candidates of a list the sorting wave stages in shared memory (32 + 18 KB per block of four waves)
 // the candidate lists of the reads in list 12 (k_s5a_prepare left them unsorted): a wave each (cm_coop_s5_sort)
-__global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d) {
+__global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d, uint32_t lid) {
   if (d.abort && *d.abort) return;
   __shared__ uint16_t hist[CM_BLOCK * CM_SORT_NB];
   __shared__ uint64_t stage_p[(CM_BLOCK / 64) * CM_SORT_STAGE];  // a list of up to CM_SORT_STAGE candidates is staged here once
   __shared__ uint8_t stage_c[(CM_BLOCK / 64) * CM_SORT_STAGE];
   const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
-  const uint32_t n_list = d.hv_cnt[12];
-  const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
+  const uint32_t n_list = d.hv_cnt[lid];
+  const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
   CmDevGroup<64> g;
   g.t = threadIdx.x % 64;
   g.xw = nullptr;
@@ -1025,18 +1047,20 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d) {
 }
 #define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
 #define CM_S5C_SORT_RB 130u
-__global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P) {
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s5c_coop(CmDev d, uint32_t P, uint32_t lid) {
   if (d.abort && *d.abort) return;
-  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
-  const uint32_t n_list = d.hv_cnt[12];
-  const uint32_t *list = d.hv_list + (size_t)12 * d.hv_stride;
+  const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
+  const uint32_t n_list = d.hv_cnt[lid];
+  const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
   const size_t b1 = cm_coop_ver_mem_bytes(P), b2 = cm_coop_sort_mem_bytes(CM_S5C_SORT_P, CM_S5C_SORT_RB);
-  const size_t gb = (((b1 > b2 ? b1 : b2) + 15) & ~(size_t)15);  // the sort's buffers overlay the acceptance loop's arrays
-  const CmCoopVerMem m = cm_coop_ver_mem_at(cm_lds + (size_t)grp * gb, P);
-  const CmCoopSortMem sm = cm_coop_sort_mem_at(cm_lds + (size_t)grp * gb, CM_S5C_SORT_P, CM_S5C_SORT_RB);
-  CmDevGroup<64> g;
-  g.t = threadIdx.x % 64;
-  g.xw = nullptr;
+  const size_t gb = (((b1 > b2 ? b1 : b2) + 15) & ~(size_t)15) + CM_XW_BYTES;  // the sort's buffers overlay the acceptance loop's arrays
+  uint8_t *base = cm_lds + (size_t)grp * gb;
+  const CmCoopVerMem m = cm_coop_ver_mem_at(base, P);
+  const CmCoopSortMem sm = cm_coop_sort_mem_at(base, CM_S5C_SORT_P, CM_S5C_SORT_RB);
+  CmDevGroup<G> g;
+  g.t = threadIdx.x % G;
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) {
     cm_coop_s5c(d, list[j], g, m, sm);
     g.sync();
@@ -1111,62 +1135,78 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_rea
   for (uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x; j < n_items; j += gridDim.x * CM_BLOCK) cm_s5b_verify_item(d, j, n_reads);
 }
 // --SAM has its own instantiations: the alignment's register window must not cost the BED path occupancy
-// S6a.  coop: a pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 13, where a wave runs its two sweeps
+// S6a.  coop: a pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 13, where a wave runs its two sweeps with
+// the second list of each direction staged in shared memory -- or, when read 2 has a list longer than CM_S6A_P_WAVE, to list 18,
+// where a block does (lists up to CM_S6A_P_BLOCK staged, longer ones read where they are)
 #define CM_S6A_COOP_MIN 48u
+#define CM_S6A_P_WAVE 1024u
+#define CM_S6A_P_BLOCK 8192u
+__device__ __forceinline__ uint32_t cm_s6_class(const CmDev &d, uint32_t pair, uint32_t wave_list, uint32_t block_list) {
+  const uint32_t r1 = 2 * pair, r2 = r1 + 1;
+  uint32_t big2 = d.ndp[r2] > d.ndn[r2] ? d.ndp[r2] : d.ndn[r2], big = big2;
+  big = d.ndp[r1] > big ? d.ndp[r1] : big;
+  big = d.ndn[r1] > big ? d.ndn[r1] : big;
+  if (big <= CM_S6A_COOP_MIN) return 0;
+  return big2 <= CM_S6A_P_WAVE ? wave_list : block_list;
+}
 __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint32_t coop) {
   if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
-  bool to_wave = false;
+  uint32_t cls = 0;
   if (i < n && cm_s6a_pre<false>(d, pair)) {
-    const uint32_t r1 = 2 * pair, r2 = r1 + 1;
-    uint32_t big = d.ndp[r1] > d.ndn[r1] ? d.ndp[r1] : d.ndn[r1];
-    big = d.ndp[r2] > big ? d.ndp[r2] : big;
-    big = d.ndn[r2] > big ? d.ndn[r2] : big;
-    to_wave = coop && big > CM_S6A_COOP_MIN;
-    if (!to_wave) cm_s6a_sweeps<false>(d, pair);
+    cls = coop ? cm_s6_class(d, pair, 13u, 18u) : 0u;
+    if (!cls) cm_s6a_sweeps<false>(d, pair);
   }
-  if (coop) cm_wave_append(d.hv_list + (size_t)13 * d.hv_stride, d.hv_cnt + 13, to_wave, pair);
+  if (coop) {
+    cm_wave_append(d.hv_list + (size_t)13 * d.hv_stride, d.hv_cnt + 13, cls == 13u, pair);
+    cm_wave_append(d.hv_list + (size_t)18 * d.hv_stride, d.hv_cnt + 18, cls == 18u, pair);
+  }
 }
-__global__ __launch_bounds__(CM_BLOCK) void k_s6a_coop(CmDev d) {
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s6a_coop(CmDev d, uint32_t P, uint32_t lid) {
   if (d.abort && *d.abort) return;
-  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
-  const uint32_t n_list = d.hv_cnt[13];
-  const uint32_t *list = d.hv_list + (size_t)13 * d.hv_stride;
-  CmDevGroup<64> g;
-  g.t = threadIdx.x % 64;
-  g.xw = nullptr;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6a<false>(d, list[j], g);
+  const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
+  const uint32_t n_list = d.hv_cnt[lid];
+  const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
+  const size_t gb = ((cm_coop_pe_mem_bytes(P) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  uint8_t *base = cm_lds + (size_t)grp * gb;
+  const CmCoopPeMem m = cm_coop_pe_mem_at(base, P);
+  CmDevGroup<G> g;
+  g.t = threadIdx.x % G;
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6a<false>(d, list[j], g, m);
 }
-// S6c.  coop: a multi-mapped pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 17, where a wave finds the
-// sampled pairings (cm_coop_s6c) -- one lane repeating both pairing sweeps over lists of hundreds of entries held its wave for
-// the whole kernel (k_s6c_multi 1.6 ms for 28 k multi-mapped pairs of the repeat workload)
+// S6c.  coop: a multi-mapped pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 17 (a wave) / 20 (a block),
+// where the group finds the sampled pairings (cm_coop_s6c) -- one lane repeating both pairing sweeps over lists of hundreds of
+// entries held its wave for the whole kernel (k_s6c_multi 1.6 ms for 28 k multi-mapped pairs of the repeat workload)
 __global__ __launch_bounds__(CM_BLOCK) void k_s6c_multi(CmDev d, uint32_t n, uint32_t coop) {
   if (d.abort && *d.abort) return;
   const uint32_t i = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
-  bool to_wave = false;
+  uint32_t cls = 0;
   if (i < n) {
-    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) {
-      const uint32_t r1 = 2 * pair, r2 = r1 + 1;
-      uint32_t big = d.ndp[r1] > d.ndn[r1] ? d.ndp[r1] : d.ndn[r1];
-      big = d.ndp[r2] > big ? d.ndp[r2] : big;
-      big = d.ndn[r2] > big ? d.ndn[r2] : big;
-      to_wave = big > CM_S6A_COOP_MIN;
-    }
-    if (!to_wave) cm_s6c_multi<false>(d, pair);
+    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) cls = cm_s6_class(d, pair, 17u, 20u);
+    if (!cls) cm_s6c_multi<false>(d, pair);
   }
-  if (coop) cm_wave_append(d.hv_list + (size_t)17 * d.hv_stride, d.hv_cnt + 17, to_wave, pair);
+  if (coop) {
+    cm_wave_append(d.hv_list + (size_t)17 * d.hv_stride, d.hv_cnt + 17, cls == 17u, pair);
+    cm_wave_append(d.hv_list + (size_t)20 * d.hv_stride, d.hv_cnt + 20, cls == 20u, pair);
+  }
 }
-__global__ __launch_bounds__(CM_BLOCK) void k_s6c_coop(CmDev d) {
+template <int G>
+__global__ __launch_bounds__(CM_BLOCK) void k_s6c_coop(CmDev d, uint32_t P, uint32_t lid) {
   if (d.abort && *d.abort) return;
-  const uint32_t gpb = blockDim.x / 64, grp = threadIdx.x / 64;
-  const uint32_t n_list = d.hv_cnt[17];
-  const uint32_t *list = d.hv_list + (size_t)17 * d.hv_stride;
-  CmDevGroup<64> g;
-  g.t = threadIdx.x % 64;
-  g.xw = nullptr;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6c<false>(d, list[j], g);
+  const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
+  const uint32_t n_list = d.hv_cnt[lid];
+  const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
+  const size_t gb = ((cm_coop_pe_mem_bytes(P) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  uint8_t *base = cm_lds + (size_t)grp * gb;
+  const CmCoopPeMem m = cm_coop_pe_mem_at(base, P);
+  CmDevGroup<G> g;
+  g.t = threadIdx.x % G;
+  g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb) cm_coop_s6c<false>(d, list[j], g, m);
 }
 CM_ITEM_KERNEL(k_s6a_pair_sam, cm_s6a_pair<true>, perm_pairs)
 CM_ITEM_KERNEL(k_s6c_multi_sam, cm_s6c_multi<true>, perm_pairs)
@@ -1632,8 +1672,8 @@ static inline uint32_t cm_coop_mm(const CmDev &d, uint32_t max_read_len) {
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len) {
   auto pow2 = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };  // the sort network's size: a power of two
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
-  uint32_t rest[11];
-  for (int c = 0; c < 11; ++c) rest[c] = n_cls[c];
+  uint32_t rest[CM_HV_LISTS];
+  for (int c = 0; c < CM_HV_LISTS; ++c) rest[c] = n_cls[c];
   if (coop && d.hv_max[0]) {
     const uint32_t MM = cm_coop_mm(d, max_read_len);
     const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;  // two runs per minimizer unless a diagonal wraps
@@ -1644,6 +1684,13 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
       if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
         hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt, 0u);
         rest[0] = 0; any_coop = true;
+      }
+    }
+    if (n_cls[21] && d.hv_sub) {  // the wave class's short lists: four reads per block of 256 lanes, a quarter of the work area each
+      const size_t lds = 4 * cm_coop_group_bytes(d.hv_sub, MM, RB, false);
+      if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
+        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[21] + 3) / 4), dim3(256), lds, s, d, lst(21), n_cls[21], d.hv_sub, MM, RB, fb_list, fb_cnt, 0u);
+        rest[21] = 0; any_coop = true;
       }
     }
 #define CM_S3B_COOP_CLASS(C_, Q_, G_)                                                                                                              \
@@ -1672,6 +1719,10 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
       const uint32_t P = pow2(d.hv_max[3]);
       hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(512), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, (const uint32_t *)fb_list, 0u, P, (const uint32_t *)fb_cnt);
     }
+  }
+  if (rest[21]) {
+    const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
+    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((rest[21] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, lst(21), rest[21], P, (const uint32_t *)nullptr);
   }
   if (rest[0]) {
     const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
@@ -1759,29 +1810,44 @@ void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t 
   if (!n) return;
   const size_t gw = ((cm_coop_pair_mem_bytes(CM_S4C_P_WAVE) + 15) & ~(size_t)15) + CM_XW_BYTES;
   const size_t gbk = ((cm_coop_pair_mem_bytes(CM_S4C_P_BLOCK) + 15) & ~(size_t)15) + CM_XW_BYTES;
-  if (!cm_lds_optin(&k_s4c_coop<CM_BLOCK>, gbk)) coop &= ~4u;
-  hipLaunchKernelGGL(k_s4c_reduce, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop);
+  // the lists beyond that: as many entries as the shared memory a block may have holds at 10 bytes each
+  uint32_t pbig = CM_S4C_P_BIG;
+  while (pbig > CM_S4C_P_BLOCK && !cm_lds_optin(&k_s4c_coop<1024, false>, ((cm_coop_pair_mem_bytes(pbig, false) + 15) & ~(size_t)15) + CM_XW_BYTES)) pbig >>= 1;
+  if (!cm_lds_optin(&k_s4c_coop<CM_BLOCK, true>, gbk)) coop &= ~4u;
+  CmDev d2 = d;
+  d2.s4c_pbig = pbig > CM_S4C_P_BLOCK ? pbig : 0;
+  hipLaunchKernelGGL(k_s4c_reduce, grid_for(n), dim3(CM_BLOCK), 0, s, d2, n, coop);
   if (!(coop & 4u)) return;
   uint32_t blocks = n / 2048 + 64;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
-  hipLaunchKernelGGL(k_s4c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
+  hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
+  hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
+  if (d2.s4c_pbig)
+    hipLaunchKernelGGL((k_s4c_coop<1024, false>), dim3(128), dim3(1024), ((cm_coop_pair_mem_bytes(pbig, false) + 15) & ~(size_t)15) + CM_XW_BYTES, s, d, pbig, 19u, coop);
 }
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
   hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
-  if (coop) hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d);  // the lists it left unsorted: a wave per read
+  if (coop) {  // the lists it left unsorted: a wave per read
+    hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, 12u);
+    hipLaunchKernelGGL(k_s5_sort_coop, dim3(64), dim3(CM_BLOCK), 0, s, d, 22u);
+  }
 }
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
   hipLaunchKernelGGL(k_s5c_finalize, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (!coop) return;
-  const uint32_t P = 2048;  // candidates of a strand the wave's work arrays hold (longer lists: its lane 0)
-  const size_t b1 = cm_coop_ver_mem_bytes(P), b2 = cm_coop_sort_mem_bytes(CM_S5C_SORT_P, CM_S5C_SORT_RB);
-  const size_t gb = (((b1 > b2 ? b1 : b2) + 15) & ~(size_t)15);
+  auto gbytes = [](uint32_t P) {
+    const size_t b1 = cm_coop_ver_mem_bytes(P), b2 = cm_coop_sort_mem_bytes(CM_S5C_SORT_P, CM_S5C_SORT_RB);
+    return (((b1 > b2 ? b1 : b2) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  };
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s5c_coop, dim3(blocks), dim3(192), 3 * gb, s, d, P);  // three waves per block: under the 64 KB a launch gets without asking
+  hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(192), 3 * gbytes(CM_S5C_P_WAVE), s, d, CM_S5C_P_WAVE, 12u);  // three waves per block: under the 64 KB a launch gets without asking
+  // the reads with a longer list: a block each (what even its work arrays cannot hold: lane 0's acceptance loop, the group's sort)
+  uint32_t pb = CM_S5C_P_BLOCK;
+  while (pb > CM_S5C_P_WAVE && !cm_lds_optin(&k_s5c_coop<CM_BLOCK>, gbytes(pb))) pb >>= 1;
+  hipLaunchKernelGGL(k_s5c_coop<CM_BLOCK>, dim3(128), dim3(CM_BLOCK), gbytes(pb), s, d, pb, 22u);
 }
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
@@ -1792,21 +1858,30 @@ void cm_launch_k_s5b_verify(const CmDev &d, uint32_t max_items, uint32_t n_reads
   if (blocks > 65536) blocks = 65536;  // grid-stride beyond
   hipLaunchKernelGGL(k_s5b_verify, dim3(blocks), dim3(CM_BLOCK), 0, s, d, n_reads);
 }
+// the pairing stages' groups: a wave per pair with the second list staged (4 waves x 10 KB per block), a block per pair for the
+// few pairs whose read 2 has a list beyond CM_S6A_P_WAVE (80 KB)
+static inline size_t cm_s6_group_bytes(uint32_t P) { return ((cm_coop_pe_mem_bytes(P) + 15) & ~(size_t)15) + CM_XW_BYTES; }
 void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
+  const size_t lw = (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_WAVE), lb = cm_s6_group_bytes(CM_S6A_P_BLOCK);
+  if (coop && !(cm_lds_optin(&k_s6a_coop<64>, lw) && cm_lds_optin(&k_s6a_coop<CM_BLOCK>, lb))) coop = false;
   hipLaunchKernelGGL(k_s6a_pair, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s6a_coop, dim3(blocks), dim3(CM_BLOCK), 0, s, d);
+  hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 13u);
+  hipLaunchKernelGGL(k_s6a_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 18u);
 }
 void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
+  const size_t lw = (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_WAVE), lb = cm_s6_group_bytes(CM_S6A_P_BLOCK);
+  if (coop && !(cm_lds_optin(&k_s6c_coop<64>, lw) && cm_lds_optin(&k_s6c_coop<CM_BLOCK>, lb))) coop = false;
   hipLaunchKernelGGL(k_s6c_multi, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s6c_coop, dim3(blocks), dim3(CM_BLOCK), 0, s, d);
+  hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 17u);
+  hipLaunchKernelGGL(k_s6c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 20u);
 }
 
 // threads per block / LDS bytes for the read-staging kernels, from the longest read of the batch

@@ -2097,6 +2097,11 @@ CM_HD void cm_pack_read_planes(const CmDev &d, uint32_t r) {
     case 2: cm_pack_read_planes_w<2>(d, r); break;
     case 3: cm_pack_read_planes_w<3>(d, r); break;
     case 4: cm_pack_read_planes_w<4>(d, r); break;
+    // (2 x 150: the read-back form below took 7.7 ms per 2 M pairs, the largest kernel of the hic workload, profiles/r04a_hic_*)
+    case 5: cm_pack_read_planes_w<5>(d, r); break;
+    case 6: cm_pack_read_planes_w<6>(d, r); break;
+    case 7: cm_pack_read_planes_w<7>(d, r); break;
+    case 8: cm_pack_read_planes_w<8>(d, r); break;
     default: cm_pack_read_planes_any(d, r);
   }
 }

@@ -88,7 +88,9 @@ static void emu_coop_s4c(const CmDev &d, const std::vector<uint32_t> &list) {
   const CmCoopPairMem m = cm_coop_pair_mem_at(base, P);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      cm_coop_s4c(d, list[i], g, m);
+      // every other pair through the form that leaves the position lists in global memory (k_s4c_coop<1024, false>; the work
+      // arrays of the staged layout hold the unstaged one's)
+      if (list[i] & 1u) cm_coop_s4c<false>(d, list[i], g, m); else cm_coop_s4c<true>(d, list[i], g, m);
       g.sync();
     }
   }, g_coop_reverse);
@@ -113,20 +115,26 @@ static void emu_coop_s5c(const CmDev &d, const std::vector<uint32_t> &list, int 
     }
   }, g_coop_reverse);
 }
+// the pairing stages' staging arrays, deliberately small: second lists of up to 40 entries are staged, longer ones read in place
+#define EMU_PE_P 40u
 template <int G>
 static void emu_coop_s6a(const CmDev &d, const std::vector<uint32_t> &list) {
+  std::vector<uint64_t> pem(cm_coop_pe_mem_bytes(EMU_PE_P) / 8 + 2);
+  const CmCoopPeMem m = cm_coop_pe_mem_at((uint8_t *)pem.data(), EMU_PE_P);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      cm_coop_s6a<false>(d, list[i], g);
+      cm_coop_s6a<false>(d, list[i], g, m);
       g.sync();
     }
   }, g_coop_reverse);
 }
 template <int G>
 static void emu_coop_s6c(const CmDev &d, const std::vector<uint32_t> &list) {
+  std::vector<uint64_t> pem(cm_coop_pe_mem_bytes(EMU_PE_P) / 8 + 2);
+  const CmCoopPeMem m = cm_coop_pe_mem_at((uint8_t *)pem.data(), EMU_PE_P);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      cm_coop_s6c<false>(d, list[i], g);
+      cm_coop_s6c<false>(d, list[i], g, m);
       g.sync();
     }
   }, g_coop_reverse);
@@ -711,7 +719,8 @@ static int emu_reduce_dir_check(uint32_t dist, const uint64_t *p1, const uint8_t
   const CmCoopPairMem m = cm_coop_pair_mem_at(base, P);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     uint32_t a, b;
-    cm_coop_reduce_dir(g, m, dist, p1, c1, n1, p2, c2, n2, gf1.data(), gc1.data(), &a, gf2.data(), gc2.data(), &b);
+    if (n1 & 1u) cm_coop_reduce_dir<false>(g, m, dist, p1, c1, n1, p2, c2, n2, gf1.data(), gc1.data(), &a, gf2.data(), gc2.data(), &b);
+    else cm_coop_reduce_dir<true>(g, m, dist, p1, c1, n1, p2, c2, n2, gf1.data(), gc1.data(), &a, gf2.data(), gc2.data(), &b);
     if (g.t == 0) { ga = a; gb = b; }
   }, reverse);
   if (ga != sa || gb != sb) return 1;
@@ -778,12 +787,17 @@ static int emu_pairing_check(const uint64_t *ap0, const int16_t *ae0, uint32_t n
   cm_pair_dir(d, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, pe, -1, 0, &seen);
   CmTwo all = {0, 0, 0, 0};
   uint64_t fk = 0;
+  std::vector<uint64_t> stp(100);
+  std::vector<int16_t> ste(100);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     const int none = 2 * e + 1;
     CmTwo mine = {none, 0, none, 0};
     uint64_t first_key = ~0ull;
-    cm_coop_pair_dir(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, mine, first_key);
-    cm_coop_pair_dir(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, mine, first_key);
+    // second lists of up to 100 entries staged in the group's work arrays (k_s6a_coop), longer ones read where they are
+    if (nb0 <= 100) cm_coop_pair_dir<true>(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, mine, first_key, stp.data(), ste.data());
+    else cm_coop_pair_dir<false>(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, mine, first_key);
+    if (nb1 <= 100) cm_coop_pair_dir<true>(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, mine, first_key, stp.data(), ste.data());
+    else cm_coop_pair_dir<false>(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, mine, first_key);
     const CmTwo a = cm_coop_two_merge(g, mine, none);
     const uint64_t k = g.min64(first_key);
     if (g.t == 0) { all = a; fk = k; }
@@ -810,8 +824,13 @@ static int emu_pairing_check(const uint64_t *ap0, const int16_t *ae0, uint32_t n
       uint64_t seen2 = 0;
       uint32_t i1 = 0, i2 = 0;
       int dir = 0;
-      bool fnd = cm_coop_pair_find(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2);
-      if (!fnd) { dir = 1; fnd = cm_coop_pair_find(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2); }
+      bool fnd = nb0 <= 100 ? cm_coop_pair_find<true>(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2, stp.data(), ste.data())
+                            : cm_coop_pair_find<false>(d, g, 0, ap0, ae0, na0, bp0, be0, nb0, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2);
+      if (!fnd) {
+        dir = 1;
+        fnd = nb1 <= 100 ? cm_coop_pair_find<true>(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2, stp.data(), ste.data())
+                         : cm_coop_pair_find<false>(d, g, 1, ap1, ae1, na1, bp1, be1, nb1, len1, len2, pe.min_sum, (uint64_t)want, &seen2, &i1, &i2);
+      }
       if (g.t == (uint32_t)(G - 1)) { gfound = fnd; gd = (uint32_t)dir; gi1 = i1; gi2 = i2; }  // (every lane holds the answer: the last one reports)
     }, reverse);
     if (!gfound || gd != q.f_dir || gi1 != q.f_i1 || gi2 != q.f_i2) return 6;

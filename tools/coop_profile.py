@@ -23,7 +23,7 @@ def main():
     g.set_option("coop_profile", 1)
     for _ in range(3):
         g.map_resident(Stats())
-    v = [g.get_option("coop_profile_%d" % k) for k in range(16)]
+    v = [g.get_option("coop_profile_%d" % k) for k in range(32)]
     names = ["run table + scan", "expand (occurrence loads)", "strand partition", "natural runs", "merge levels", "cluster sweep"]
     tot = float(sum(v[:6])) or 1.0
     n = max(1, v[8])
@@ -32,6 +32,11 @@ def main():
         print("  %-28s %5.1f %%  %8.0f cycles per group" % (nm, 100.0 * v[k] / tot, v[k] / n))
     print("  inside the sweep: walks %.0f, barrier after them %.0f, chunk sums + scans %.0f, copy-out %.0f cycles per group"
           % (v[11] / n, v[12] / n, v[13] / n, v[14] / n))
+    nr = max(1, v[16])
+    print("heavy rescue searches (a group of 16 lanes per read and direction): %d searched + %d bailed out; per search: best mate candidates "
+          "(windows before merging) %.1f, mate candidates %.1f, minimizers %.1f, occurrences of its minimizers %.0f, hits %.1f"
+          % (v[16], v[26], v[17] / nr, v[18] / nr, v[20] / nr, v[19] / nr, v[21] / nr))
+    print("  windows < 4: %d, < 16: %d, < 64: %d, < 300: %d" % (v[22], v[23], v[24], v[25]))
     print("timings of the last batch:", g.timings())
 
 
