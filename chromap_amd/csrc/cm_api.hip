@@ -107,7 +107,7 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   } else if (n == "debug_candidate_capacity") {  // tests: pretend the previous batch left this much room (forces the re-run path)
     c->pred_m_ok = value > 0; c->m_cap = (uint64_t)value; c->pred_n = 0xffffffffu;  // (any batch size)
   } else if (n == "coop_profile") {  // measurement aid: per-phase cycle sums of k_s3b_coop (cmgpu_get_option coop_profile_0 .. _15)
-    if (value) { if (c->coop_prof.ensure(32 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 32 * 8)); } else c->coop_prof.release();
+    if (value) { if (c->coop_prof.ensure(48 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 48 * 8)); } else c->coop_prof.release();
   } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
     c->opt_coop_rb = (int)value;
   } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
@@ -137,7 +137,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n.rfind("coop_profile_", 0) == 0) {
     const int k = atoi(n.c_str() + 13);
     unsigned long long v = 0;
-    if (k < 0 || k > 31 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
+    if (k < 0 || k > 47 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
     *value = (int64_t)v;
   }
   else if (n == "probe_table_buckets") *value = c->fmask ? (int64_t)c->fmask + 1 : (int64_t)c->bmask + 1;
@@ -715,6 +715,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
   d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
   d.prof = (unsigned long long *)c->coop_prof.p;
+  d.rs_pool = (uint64_t *)c->rs_pool.p; d.rs_pool_cap = c->rs_pool.p ? c->rs_pool_cap : 0u; d.rs_pool_off = (uint32_t *)c->rs_pool_off.p;
   d.abort = (const unsigned long long *)c->stats.p + CM_ST_ABORT;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
@@ -759,7 +760,7 @@ static inline void mark(cmgpu_ctx *c, const char *name) {
 // meaningful when the total fits the dense arrays' 32-bit indexing, which the caller checks on *total
 static int scan_with_total(cmgpu_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *total) {
   hipStream_t s = c->stream;
-  unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_N - 2;  // spare counter slot
+  unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_TOTAL;  // spare counter slot
   HIPCHECK(c, hipMemsetAsync(acc, 0, 8, s));
   cm_launch_k_sum_u32(in, n, acc, s);
   cm_scan_u32(in, out, n, (uint32_t *)c->scan_tmp.p, s);
@@ -851,7 +852,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
       HIPCHECK(c, hipMemsetAsync(c->hv_cnt.p, 0, 256, s));
       cm_launch_k_s3a_count(d, n2, s);
       {
-        unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_N - 2;
+        unsigned long long *acc = (unsigned long long *)c->stats.p + CM_ST_TOTAL;
         HIPCHECK(c, hipMemsetAsync(acc, 0, 8, s));
         cm_launch_k_sum_u32(d.hit_tot, n2, acc, s);
         cm_scan_u32(d.hit_tot, d.hit_off, n2, (uint32_t *)c->scan_tmp.p, s);
@@ -951,8 +952,16 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s3b_candidates");
   // S4: mate rescue, merge, paired-end filter
   HIPCHECK(c, hipMemsetAsync(c->rs_cnt.p, 0, CM_RS_SEGS * 64, s));
+  if (c->opt_coop & 2) {  // the pool of rescue hits found while counting: sized from what the previous range asked for (+ 25 %)
+    uint64_t want = c->rs_pool_want + c->rs_pool_want / 4;
+    if (want < (1u << 22)) want = 1u << 22;
+    if (want > 0xfffffff0ull) want = 0xfffffff0ull;
+    if (c->rs_pool.ensure((size_t)want * 8) == 0 && c->rs_pool_off.ensure((size_t)n2 * 2 * 4 + 16) == 0) c->rs_pool_cap = (uint32_t)(c->rs_pool.cap / 8 > 0xfffffff0ull ? 0xfffffff0ull : c->rs_pool.cap / 8);
+    else { c->rs_pool.release(); c->rs_pool_cap = 0; }  // (no pool: the fill pass searches again)
+    cm_fill_dev_range(c, d, rlo, rhi);
+  }
   cm_launch_k_s4a_rescue_count(d, n2, s);  // decision per read + the packed list of reads that supplement
-  cm_launch_k_s4a_rescue_list(d, n2, s);   // their searches, one read per lane of full waves
+  cm_launch_k_s4a_rescue_list(d, n2, s, (c->opt_coop & 2) != 0);   // their searches: a lane, a group of 16 lanes or a wave per read
   // The candidate arrays.  A batch of the size of the previous one reuses that batch's arrays (sized with 25 % to spare) without
   // waiting for its own total: the device compares the total with the capacity and, should it ever pass it, raises d.abort --
   // every later kernel then leaves at once and the range is mapped again with exact sizes (the `spec` test below).
@@ -1035,6 +1044,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   }
   c->pred_m_ok = true;
   c->pred_n = n;
+  c->rs_pool_want = hst[CM_ST_POOL];
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
   *k_out = hst[CM_ST_RECORDS];
   c->last_range_lo = rlo; c->last_range_hi = rhi;
@@ -1637,7 +1647,7 @@ template <int LOADS, bool WIDE>
 static void gather_launch(cmgpu_ctx *c, uint64_t n, uint64_t seed) {
   const unsigned blocks = (unsigned)((n + 256ull * LOADS - 1) / (256ull * LOADS));
   hipLaunchKernelGGL((k_gather<LOADS, WIDE>), dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)c->bkt.p, c->bmask, n, seed,
-                     (unsigned long long *)c->stats.p + CM_ST_N - 1);
+                     (unsigned long long *)c->stats.p + CM_ST_TOTAL);
 }
 static bool gather_dispatch(cmgpu_ctx *c, uint64_t n, uint64_t seed, int loads, int wide) {
 #define CM_G(L_) if (loads == L_) { if (wide) gather_launch<L_, true>(c, n, seed); else gather_launch<L_, false>(c, n, seed); return true; }

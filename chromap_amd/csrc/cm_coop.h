@@ -21,6 +21,16 @@
 #include "cm_stages.h"
 
 CM_HD uint32_t cm_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// *p += v, the old value returned: atomic on the device (the emulated lanes of tests/hostemu take turns on one thread)
+CM_HD unsigned long long cm_fetch_add64(unsigned long long *p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(p, v);
+#else
+  const unsigned long long old = *p;
+  *p = old + v;
+  return old;
+#endif
+}
 // measurement aid: lane 0 of a group adds the shader-clock cycles since its last mark to d.prof[k] (nullptr: nothing)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CM_PROF_BEGIN(d) long long cm_prof_t_ = (d).prof ? clock64() : 0
@@ -522,6 +532,7 @@ struct CmCoopRescueMem {
   uint32_t *mps;       // CM_RESCUE_SLOTS: position << 1 | strand, bit 31: singleton
   uint32_t *pa, *pb;   // CM_RESCUE_PAIRS + 1 each: lower bound | occurrences equal to es << 30, upper bound -> first index, length -> first index, offset
 };
+#define CM_RESCUE_MEM_BYTES (CM_RESCUE_WMAX * 16 + CM_RESCUE_SLOTS * 12 + (CM_RESCUE_PAIRS + 1) * 8 + 32)
 CM_HD size_t cm_coop_rescue_mem_bytes() { return (size_t)CM_RESCUE_WMAX * 16 + (size_t)CM_RESCUE_SLOTS * 12 + ((size_t)CM_RESCUE_PAIRS + 1) * 8 + 32; }
 CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base) {
   CmCoopRescueMem m;
@@ -534,9 +545,51 @@ CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base) {
   m.bp = reinterpret_cast<uint64_t *>(m.pa);  // (8-byte aligned: 32 words of mps behind 8-byte arrays; 2 x 641 words hold 304 positions)
   return m;
 }
+// phase C of cm_coop_rescue: the occurrences of the pairs' ranges (first index pa, offsets pb, pb[np] = total) on the wanted strand,
+// counted (*cnt += their number) and, out != nullptr, written from out[*cnt] on in pair / occurrence order
+template <class GT>
+CM_HD void cm_coop_rescue_emit(const CmDev &d, GT &g, const CmCoopRescueMem &m, uint32_t np, uint32_t W, uint32_t total, int strand, uint64_t *out,
+                               uint32_t *cnt_io) {
+  const uint32_t G = (uint32_t)GT::G;
+  uint32_t cnt = *cnt_io;
+  for (uint32_t x0 = 0; x0 < total; x0 += 4 * G) {  // four occurrences per lane and round: their loads in flight together
+    uint64_t hit[4];
+    uint32_t psv[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t x = x0 + (uint32_t)u * G + g.t;
+      in[u] = x < total;
+      hit[u] = 0; psv[u] = 0;
+      if (in[u]) {
+        uint32_t lo = 0, hi = np;  // the largest q with pb[q] <= x (the pairs without occurrences share their successor's offset)
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (m.pb[mid] <= x) lo = mid; else hi = mid;
+        }
+        const uint32_t sl = lo / W;
+        const uint32_t ps = m.mps[sl];
+        const uint64_t val = m.mval[sl];
+        psv[u] = ps & 0x7fffffffu;
+        hit[u] = (ps >> 31) ? val : d.occ[(uint32_t)(val >> 32) + m.pa[lo] + (x - m.pb[lo])];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool same = false;
+      const uint64_t cp = cm_cand_from_hit(hit[u], psv[u], d.p.k, &same);
+      const bool match = in[u] && ((same && strand == 0) || (!same && strand == 1));
+      uint32_t tot;
+      const uint32_t at = g.scan(match ? 1u : 0u, &tot);
+      if (match && out) out[cnt + at] = cp;
+      cnt += tot;
+    }
+  }
+  *cnt_io = cnt;
+}
 template <class GT>
 CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t *mp, const uint8_t *mc, uint32_t mn, GT &g, const CmCoopRescueMem &m,
-                         uint64_t *out, uint32_t *n_out, uint32_t *rep_len_out) {
+                         uint64_t *out, uint32_t *n_out, uint32_t *rep_len_out, uint32_t *pool_off = nullptr) {
   const uint32_t G = (uint32_t)GT::G;
   *n_out = 0;
   *rep_len_out = 0;
@@ -603,35 +656,60 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
     }
     g.sync();
     const uint32_t np = ns * W;
-    // -- A: bounds of every (minimizer, window) pair
+    // -- A: bounds of every (minimizer, window) pair: 2 np binary searches (the lower bound of es, the upper bound of ee), four of
+    //    them interleaved per lane -- the searches are chains of dependent loads at global-memory latency and nothing else, so the
+    //    requests in flight per lane are what the phase's duration divides by
+    const uint32_t nsrch = 2 * np;
+    for (uint32_t b0 = g.t; b0 < nsrch; b0 += 4 * G) {
+      uint32_t lo[4], hi[4];
+      const uint64_t *o[4];
+      uint64_t key[4];
+      bool up[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t bb = b0 + (uint32_t)u * G;
+        lo[u] = 0; hi[u] = 0; o[u] = d.occ; key[u] = 0; up[u] = false;
+        if (bb < nsrch) {
+          const uint32_t q = bb >> 1, s = q / W, w = q - s * W;
+          if (!(m.mps[s] >> 31)) {
+            const uint64_t val = m.mval[s];
+            hi[u] = (uint32_t)val;
+            o[u] = d.occ + (uint32_t)(val >> 32);
+            up[u] = (bb & 1u) != 0;
+            key[u] = up[u] ? m.ee[w] : m.es[w];
+          }
+        }
+      }
+      for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (lo[u] < hi[u]) {
+            const uint32_t mid = (lo[u] + hi[u]) >> 1;
+            const uint64_t v = o[u][mid] >> 1;
+            if (up[u] ? v <= key[u] : v < key[u]) lo[u] = mid + 1; else hi[u] = mid;  // lower: first >= es; upper: first > ee
+            any = true;
+          }
+        if (!any) break;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t bb = b0 + (uint32_t)u * G;
+        if (bb < nsrch) { if (bb & 1u) m.pb[bb >> 1] = lo[u]; else m.pa[bb >> 1] = lo[u]; }
+      }
+    }
+    g.sync();
+    // occurrences at exactly es (two at most: one per strand; none for an index built by the reference, whose minimizers have one strand
+    // per position): the search's "equal" outcome for the midpoints lb .. lb + eq - 1
     for (uint32_t q = g.t; q < np; q += G) {
       const uint32_t s = q / W, w = q - s * W;
-      const uint32_t ps = m.mps[s];
-      uint32_t lbx = 0, ub = 0;
-      if (!(ps >> 31)) {
-        const uint64_t val = m.mval[s];
-        const uint32_t nocc = (uint32_t)val;
-        const uint64_t *o = d.occ + (uint32_t)(val >> 32);
-        const uint64_t es = m.es[w], ee = m.ee[w];
-        uint32_t lo = 0, hi = nocc;  // first index with o >> 1 >= es
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if ((o[mid] >> 1) < es) lo = mid + 1; else hi = mid;
-        }
-        // occurrences at exactly es (two at most: one per strand; none for an index built by the reference, whose minimizers have one
-        // strand per position): the search's "equal" outcome for the midpoints lo .. lo + eq - 1
-        const uint32_t eq = (lo < nocc && (o[lo] >> 1) == es ? 1u : 0u) + (lo + 1 < nocc && (o[lo + 1] >> 1) == es ? 1u : 0u);
-        lbx = lo | (eq << 30);
-        hi = nocc;  // first index with o >> 1 > ee (from the lower bound on)
-        uint32_t l2 = lo;
-        while (l2 < hi) {
-          const uint32_t mid = (l2 + hi) >> 1;
-          if ((o[mid] >> 1) <= ee) l2 = mid + 1; else hi = mid;
-        }
-        ub = l2;
-      }
-      m.pa[q] = lbx;
-      m.pb[q] = ub;
+      if (m.mps[s] >> 31) continue;
+      const uint64_t val = m.mval[s];
+      const uint32_t nocc = (uint32_t)val, lb = m.pa[q];
+      const uint64_t *o = d.occ + (uint32_t)(val >> 32);
+      const uint64_t es = m.es[w];
+      const uint64_t v0 = lb < nocc ? o[lb] >> 1 : ~0ull, v1 = lb + 1 < nocc ? o[lb + 1] >> 1 : ~0ull;
+      m.pa[q] = lb | (((v0 == es ? 1u : 0u) + (v1 == es ? 1u : 0u)) << 30);
     }
     g.sync();
     // -- B: the chain of searches per minimizer, on indices alone: first index and length of every pair's scan
@@ -677,28 +755,22 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       if (g.t == 0) m.pb[np] = total;
       g.sync();
     }
-    for (uint32_t x0 = 0; x0 < total; x0 += G) {
-      const uint32_t x = x0 + g.t;
-      bool match = false;
-      uint64_t cp = 0;
-      if (x < total) {
-        uint32_t lo = 0, hi = np;  // the largest q with pb[q] <= x (the pairs without occurrences share their successor's offset)
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (m.pb[mid] <= x) lo = mid; else hi = mid;
-        }
-        const uint32_t s = lo / W;
-        const uint32_t ps = m.mps[s];
-        const uint64_t val = m.mval[s];
-        const uint64_t hit = (ps >> 31) ? val : d.occ[(uint32_t)(val >> 32) + m.pa[lo] + (x - m.pb[lo])];
-        bool same;
-        cp = cm_cand_from_hit(hit, ps & 0x7fffffffu, d.p.k, &same);
-        match = (same && strand == 0) || (!same && strand == 1);
+    cm_coop_rescue_emit(d, g, m, np, W, total, strand, out, &cnt);
+    // counting pass with the pool at hand: a search whose tables fit one round writes its hits there right away -- the bounds (phase
+    // A: ~26 dependent random reads of the occurrence table per pair, which is what the search costs) are then not found a second
+    // time by the fill pass, which copies
+    if (!out && pool_off && m0 == 0 && ns == n && d.rs_pool && total > 0) {
+      uint32_t at = 0xffffffffu;
+      if (g.t == 0 && cnt > 0) {
+        const unsigned long long a0 = cm_fetch_add64(&d.stats[CM_ST_POOL], (unsigned long long)cnt);
+        if (a0 + cnt <= d.rs_pool_cap) at = (uint32_t)a0;
       }
-      uint32_t tot;
-      const uint32_t at = g.scan(match ? 1u : 0u, &tot);
-      if (match && out) out[cnt + at] = cp;
-      cnt += tot;
+      at = ~cm_coop_bcast0(g, ~at);
+      if (at != 0xffffffffu) {
+        uint32_t c2 = 0;
+        cm_coop_rescue_emit(d, g, m, np, W, total, strand, d.rs_pool + at, &c2);
+        if (g.t == 0) *pool_off = at;
+      }
     }
     g.sync();  // the tables serve the next round
   }
@@ -720,12 +792,14 @@ CM_HD void cm_coop_s4a_rescue(const CmDev &d, uint32_t r, GT &g, const CmCoopRes
   uint32_t cntn = 0, cntp = 0, rl = 0, rl_val = 0;
   int res_neg = 0, res_pos = 0;
   bool set_rl = false;
+  uint32_t *const po = d.rs_pool ? d.rs_pool_off + 2 * (size_t)r : nullptr;
+  if (po && g.t == 0) { po[0] = 0xffffffffu; po[1] = 0xffffffffu; }
   if (d.ncp[o] > 0) {  // the mate's + candidates drive a search on our - strand (candidate_processor.cc:147-153)
-    res_neg = cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, nullptr, &cntn, &rl);
+    res_neg = cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, nullptr, &cntn, &rl, po ? po + 1 : nullptr);
     if (res_neg >= 0) { set_rl = true; rl_val = rl; }
   }
   if (d.ncn[o] > 0) {
-    res_pos = cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, nullptr, &cntp, &rl);
+    res_pos = cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, nullptr, &cntp, &rl, po);
     if (res_pos >= 0) { set_rl = true; rl_val = rl; }
   }
   if (g.t == 0) {
@@ -744,8 +818,15 @@ CM_HD void cm_coop_s4b_fill(const CmDev &d, uint32_t r, GT &g, const CmCoopRescu
   uint64_t *P = d.mbuf + d.m_off[r];
   uint64_t *N = P + ncp + rp;
   uint32_t cnt, rl;
-  if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) (void)cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, N + ncn, &cnt, &rl);
-  if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0) (void)cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, P + ncp, &cnt, &rl);
+  const uint32_t off_p = d.rs_pool ? d.rs_pool_off[2 * (size_t)r] : 0xffffffffu, off_n = d.rs_pool ? d.rs_pool_off[2 * (size_t)r + 1] : 0xffffffffu;
+  if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) {
+    if (off_n != 0xffffffffu) { for (uint32_t i = g.t; i < rn; i += (uint32_t)GT::G) N[ncn + i] = d.rs_pool[off_n + i]; }  // found while counting
+    else (void)cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, N + ncn, &cnt, &rl);
+  }
+  if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0) {
+    if (off_p != 0xffffffffu) { for (uint32_t i = g.t; i < rp; i += (uint32_t)GT::G) P[ncp + i] = d.rs_pool[off_p + i]; }
+    else (void)cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, P + ncp, &cnt, &rl);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_le
 CM_DECL_LAUNCH(k_s4a_rescue_count)
 void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, bool coop, uint32_t max_read_len);
 uint32_t cm_rescue_seg_cap(uint32_t n_reads);
-void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s);
+void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop);
 void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len);
 void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop);
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop);

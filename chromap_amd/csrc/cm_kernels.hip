@@ -747,9 +747,17 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t
 #define CM_RS_HEAVY 8u
 #define CM_RS_G 16
 #define CM_RS_MAXMM 192  // minimizers of a read the group path holds counts for in LDS (longer reads: the one-lane path)
-__device__ __forceinline__ bool cm_rescue_is_heavy(const CmDev &d, uint32_t r) {
+// A read whose mate has CM_RS_WAVE candidates or more on a strand: a WAVE per read (cm_coop_rescue: the windows of the mate's best
+// candidates once per direction, a lane per (minimizer, window) pair for the bounds, the search chain replayed on indices) -- with a
+// lane per minimizer a search over ~300 windows took ~8 ms, the duration of the whole list kernel on the mosaic genome.
+#define CM_RS_WAVE 24u
+__device__ __forceinline__ bool cm_rescue_is_wave(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t o = r ^ 1u;
-  return (d.ncp[o] >= CM_RS_HEAVY || d.ncn[o] >= CM_RS_HEAVY) && d.mm_cnt[r] <= CM_RS_MAXMM;
+  return coop && (d.ncp[o] >= CM_RS_WAVE || d.ncn[o] >= CM_RS_WAVE);
+}
+__device__ __forceinline__ bool cm_rescue_is_heavy(const CmDev &d, uint32_t r, uint32_t coop) {
+  const uint32_t o = r ^ 1u;
+  return (d.ncp[o] >= CM_RS_HEAVY || d.ncn[o] >= CM_RS_HEAVY) && d.mm_cnt[r] <= CM_RS_MAXMM && !cm_rescue_is_wave(d, r, coop);
 }
 // best count among the mate candidates and how many have it, over the group's lanes (all lanes return the same)
 __device__ __forceinline__ void cm_group_best(const uint8_t *mc, uint32_t mn, uint32_t t, int *max_count, int *best_num) {
@@ -797,19 +805,37 @@ __device__ __forceinline__ int cm_group_rescue_count(const CmDev &d, uint32_t r,
   if (d.prof && t == 0) atomicAdd(&d.prof[21], (unsigned long long)lc);
   return max_count;
 }
-__global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_cap) {
+__global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
+  // reads whose mate has many candidates: the wave per read (first: they are the long ones)
+  if (coop) {
+    __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
+    const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
+    CmDevGroup<64> g;
+    g.t = threadIdx.x;
+    g.xw = nullptr;
+    const long long t0 = d.prof ? clock64() : 0;
+    uint32_t nw = 0;
+    for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+      const uint32_t r = list[j];
+      if (cm_rescue_is_wave(d, r, coop)) { cm_coop_s4a_rescue(d, r, g, m); g.sync(); ++nw; }
+    }
+    if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[27], dt); atomicMax(&d.prof[28], dt); atomicAdd(&d.prof[11], (unsigned long long)nw); }
+  }
   // reads with few mate candidates: a lane each
+  const long long t1 = d.prof ? clock64() : 0;
   for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) {
     const uint32_t r = list[j];
-    if (!cm_rescue_is_heavy(d, r)) cm_s4a_rescue(d, r);
+    if (!cm_rescue_is_heavy(d, r, coop) && !cm_rescue_is_wave(d, r, coop)) cm_s4a_rescue(d, r);
   }
+  const long long t2 = d.prof ? clock64() : 0;
+  if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(t2 - t1); atomicAdd(&d.prof[29], dt); atomicMax(&d.prof[30], dt); }
   // the others: a group of 16 lanes each (cm_s4a_rescue, its two searches shared out over the minimizers)
   const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
   for (uint32_t j = blockIdx.x * gpb + grp; j < cnt; j += gridDim.x * gpb) {
     const uint32_t r = list[j];
-    if (!cm_rescue_is_heavy(d, r)) continue;  // uniform in the group
+    if (!cm_rescue_is_heavy(d, r, coop)) continue;  // uniform in the group
     const uint32_t o = r ^ 1u;
     uint32_t cntn = 0, cntp = 0, rl = 0, rl_val = 0;
     int res_neg = 0, res_pos = 0;
@@ -830,6 +856,7 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_ca
       d.m_tot[r] = d.ncp[r] + d.ncn[r] + cntn + cntp;
     }
   }
+  if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t2); atomicAdd(&d.prof[31], dt); atomicMax(&d.prof[15], dt); }
 }
 // coop: a read without rescue hits but with a long candidate list (a read from a repeat whose mate is one too) only has that list
 // copied -- hundreds of entries by one lane; such reads join list 6, where a wave copies them (cm_coop_rescue_merge)
@@ -878,21 +905,46 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
+  // the wave's reads (k_s4a_rescue_list): their hits written by the wave, then sorted / merged by their size class's group -- or,
+  // a short list, by lane 0 here
+  if (coop) {
+    __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
+    const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
+    CmDevGroup<64> g;
+    g.t = threadIdx.x;
+    g.xw = nullptr;
+    const long long tw0 = d.prof ? clock64() : 0;
+    for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+      const uint32_t r = list[j];
+      if (!cm_rescue_is_wave(d, r, coop) || d.resc_n[r] + d.resc_p[r] == 0) continue;  // (uniform)
+      cm_coop_s4b_fill(d, r, g, m);
+      g.sync();
+      const uint32_t cls = cm_rescue_coop_class(d, r, coop);
+      if (threadIdx.x == 0) {
+        if (cls) d.hv_list[(size_t)cls * d.hv_stride + atomicAdd(d.hv_cnt + cls, 1u)] = r;
+        else cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);
+      }
+    }
+    if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - tw0); atomicAdd(&d.prof[32], dt); atomicMax(&d.prof[33], dt); }
+  }
+  const long long tl0 = d.prof ? clock64() : 0;
   for (uint32_t j0 = blockIdx.x * 64; j0 < cnt; j0 += gridDim.x * 64) {  // whole waves (the appends below are wave-wide)
     const uint32_t j = j0 + threadIdx.x;
     const uint32_t r = j < cnt ? list[j] : 0u;
-    const bool mine = j < cnt && d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r);
+    const bool mine = j < cnt && d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r, coop) && !cm_rescue_is_wave(d, r, coop);
     const uint32_t cls = mine ? cm_rescue_coop_class(d, r, coop) : 0u;
     if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
     cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, cls == 11u, r);
     cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, cls == 15u, r);
   }
+  const long long tg0 = d.prof ? clock64() : 0;
+  if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(tg0 - tl0); atomicAdd(&d.prof[34], dt); atomicMax(&d.prof[35], dt); }
   const uint32_t t = threadIdx.x % CM_RS_G, grp = threadIdx.x / CM_RS_G, gpb = 64 / CM_RS_G;
   for (uint32_t j0 = blockIdx.x * gpb; j0 < cnt; j0 += gridDim.x * gpb) {
     const uint32_t j = j0 + grp;
     const uint32_t r = j < cnt ? list[j] : 0u;
-    const bool mine = j < cnt && cm_rescue_is_heavy(d, r) && d.resc_n[r] + d.resc_p[r] > 0;  // uniform in the group
+    const bool mine = j < cnt && cm_rescue_is_heavy(d, r, coop) && d.resc_n[r] + d.resc_p[r] > 0;  // uniform in the group
     uint32_t cls = 0;
     if (mine) {
       const uint32_t o = r ^ 1u;
@@ -912,6 +964,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, t == 0 && cls == 11u, r);
     cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, t == 0 && cls == 15u, r);
   }
+  if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - tg0); atomicAdd(&d.prof[36], dt); atomicMax(&d.prof[37], dt); }
 }
 // S4b for the reads listed above: a group per read sorts its rescue hits, clusters them and merges them with the read's
 // candidates (cm_coop_rescue_merge).  The list's length is only known on the device: the grid strides over it.
@@ -1760,8 +1813,8 @@ static inline dim3 rescue_list_grid(uint32_t n_reads) {
   if (b > 256u) b = 256u;
   return dim3(b, CM_RS_SEGS);
 }
-void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s) {
-  if (n_reads) hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads));
+void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop) {
+  if (n_reads) hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), coop ? 1u : 0u);
 }
 // the per-read part (reads without rescue hits) and, coop: the reads whose long lists a wave copies
 static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {

@@ -143,6 +143,12 @@ struct CmDev {
   uint32_t coop_slab_blocks;
   const unsigned long long *abort;  // nonzero: the candidate arrays were sized from the previous batch and this batch needs more --
                                     // every stage from S4b on leaves at once, the host maps the range again with exact sizes
+  // ---- the rescue hits a wave found while it COUNTED them (k_s4a_rescue_list), kept for the fill pass: a bump-allocated pool.
+  //      rs_pool_off[2 r + strand]: where read r's hits of that direction start (0xffffffff: not kept -- no room, or a search whose
+  //      tables did not fit one round: k_s4b_rescue_list then searches again).  nullptr: no pool
+  uint64_t *rs_pool;
+  uint32_t rs_pool_cap;
+  uint32_t *rs_pool_off;
   unsigned long long *prof;  // measurement aid (cmgpu_set_option "coop_profile"): shader-clock cycles per phase of k_s3b_coop, summed over groups
   uint32_t mm_cap;  // capacity of the dense minimizer arrays (0: not checked): S3a leaves a read whose range passes it idle
   uint32_t coop_rb; // tests: run-table size of the cooperative sorters (0: two per minimizer of the longest read)
@@ -214,6 +220,7 @@ struct CmDev {
 #define CM_ST_BC_CORR 13
 #define CM_ST_TOTAL 14   // scratch: the 64-bit total next to a 32-bit scan
 #define CM_ST_ABORT 15   // CmDev::abort
-#define CM_ST_N 16
+#define CM_ST_POOL 16   // cursor of the rescue-hit pool (CmDev::rs_pool): entries asked for so far
+#define CM_ST_N 17
 
 #endif

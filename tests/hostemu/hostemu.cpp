@@ -34,7 +34,7 @@ struct EmuCoop { int G; uint32_t thr, P, MM, RB; };
 static EmuCoop g_coop = {0, 0, 0, 0, 0};
 static bool g_planes = true;  // the bit-plane verification (k_pack_ref / k_pack_reads + cm_banded_align_planes); 0: the byte form
 extern "C" void hostemu_set_planes(int on) { g_planes = on != 0; }
-static unsigned long long g_coop_items[8];  // items that went through each cooperative stage / fell back (tests look at them)
+static unsigned long long g_coop_items[10];  // items that went through each cooperative stage / fell back (tests look at them)
 extern "C" void hostemu_set_coop(int G, uint32_t thr, uint32_t P, uint32_t MM, uint32_t RB) {
   g_coop = EmuCoop{G, thr, P, MM, RB};
   memset(g_coop_items, 0, sizeof(g_coop_items));
@@ -75,6 +75,20 @@ static void emu_coop_rescue(const CmDev &d, const std::vector<uint32_t> &list) {
         const uint32_t r_ = list[i], big_ = d.resc_p[r_] > d.resc_n[r_] ? d.resc_p[r_] : d.resc_n[r_];
         if (g_coop_slab && big_ > g_coop.P) cm_coop_rescue_merge<true>(d, r_, g, m); else cm_coop_rescue_merge<false>(d, r_, g, m);
       }
+      g.sync();
+    }
+  }, g_coop_reverse);
+}
+
+// the rescue searches of the listed reads by a group each: the counting pass (k_s4a_rescue_list) or the fill pass (k_s4b_rescue_list)
+template <int G>
+static void emu_coop_rescue_search(const CmDev &d, const std::vector<uint32_t> &list, bool fill) {
+  std::vector<uint64_t> mem(cm_coop_rescue_mem_bytes() / 8 + 4);
+  const CmCoopRescueMem m = cm_coop_rescue_mem_at((uint8_t *)mem.data());
+  emu_run_group<G>([&](EmuGroup<G> &g) {
+    for (size_t i = 0; i < list.size(); ++i) {
+      if (fill) { if (d.resc_n[list[i]] + d.resc_p[list[i]] > 0) cm_coop_s4b_fill(d, list[i], g, m); }
+      else cm_coop_s4a_rescue(d, list[i], g, m);
       g.sync();
     }
   }, g_coop_reverse);
@@ -308,20 +322,43 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
       }
     }
   }
-  for (uint32_t r = 0; r < n2; ++r) cm_s4a_rescue_count(d, r);
+  // k_s4a_rescue_count / k_s4a_rescue_list: with the cooperative forms on, a read whose mate has 4 candidates or more on a strand
+  // has its rescue searches run by a group (cm_coop_rescue; the kernel takes a wave from 24 candidates on)
+  std::vector<uint32_t> rescue_wave;
+  std::vector<uint8_t> is_rescue_wave(n2, 0);
+  // the pool of rescue hits found while counting (CmDev::rs_pool), small enough to run out on the repeat-rich cases
+  std::vector<uint64_t> rs_pool(g_coop.G ? 3000 : 0);
+  std::vector<uint32_t> rs_pool_off(g_coop.G ? 2 * (size_t)n2 : 0, 0xffffffffu);
+  if (g_coop.G) { d.rs_pool = rs_pool.data(); d.rs_pool_cap = (uint32_t)rs_pool.size(); d.rs_pool_off = rs_pool_off.data(); }
+  for (uint32_t r = 0; r < n2; ++r) {
+    if (!cm_s4a_decide(d, r)) continue;
+    if (g_coop.G && (d.ncp[r ^ 1u] >= 4 || d.ncn[r ^ 1u] >= 4)) { rescue_wave.push_back(r); is_rescue_wave[r] = 1; }
+    else cm_s4a_rescue(d, r);
+  }
+  if (!rescue_wave.empty()) {
+    g_coop_items[7] += rescue_wave.size();
+    if (g_coop.G == 16) emu_coop_rescue_search<16>(d, rescue_wave, false); else if (g_coop.G == 64) emu_coop_rescue_search<64>(d, rescue_wave, false);
+    else if (g_coop.G == 256) emu_coop_rescue_search<256>(d, rescue_wave, false); else emu_coop_rescue_search<1024>(d, rescue_wave, false);
+  }
   scan(d.m_tot, d.m_off, n2);
   const uint32_t n_m = d.m_off[n2];
   VEC(mbuf, uint64_t, n_m) VEC(mcnt, uint8_t, n_m) VEC(fbuf, uint64_t, n_m) VEC(fcnt, uint8_t, n_m)
   VEC(dpos, uint64_t, n_m) VEC(derr, int16_t, n_m) VEC(dsplit, uint32_t, n_m)
   {
     std::vector<uint32_t> heavy;
+    if (!rescue_wave.empty()) {  // the fill pass of the reads whose searches a group ran
+      if (g_coop.G == 16) emu_coop_rescue_search<16>(d, rescue_wave, true); else if (g_coop.G == 64) emu_coop_rescue_search<64>(d, rescue_wave, true);
+      else if (g_coop.G == 256) emu_coop_rescue_search<256>(d, rescue_wave, true); else emu_coop_rescue_search<1024>(d, rescue_wave, true);
+    }
+    for (size_t q = 0; q < rs_pool_off.size(); ++q) g_coop_items[rs_pool_off[q] != 0xffffffffu ? 8 : 9] += is_rescue_wave[q >> 1] ? 1 : 0;
     for (uint32_t r = 0; r < n2; ++r) {
       const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
+      const bool filled = is_rescue_wave[r] && d.resc_p[r] + d.resc_n[r] > 0;
       if (g_coop.G && d.aug[r] && big > g_coop.thr) {  // k_s4b_rescue_list fills, k_s4b_coop sorts and merges
-        cm_s4b_rescue_merge(d, r, CM_S4B_FILL_ONLY);
+        if (!filled) cm_s4b_rescue_merge(d, r, CM_S4B_FILL_ONLY);
         heavy.push_back(r);
       } else {
-        cm_s4b_rescue_merge(d, r);
+        cm_s4b_rescue_merge(d, r, filled ? CM_S4B_PREFILLED : CM_S4B_ALL);
       }
     }
     if (!heavy.empty()) {
@@ -704,6 +741,109 @@ extern "C" int hostemu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c,
   return emu_rescue_dir_check<256>(c0p, c0c, n1, hits, cnt, e, nm, P, RB, reverse != 0);
 }
 
+
+// cm_coop_rescue against cm_rescue on made-up occurrence runs and mate candidates: runs of 1 .. 3000 occurrences (random, or
+// evenly spaced as in a satellite array), singletons and misses between them, 1 .. 40 minimizers (several rounds of the pair table),
+// 1 .. 420 mate candidates of which 1 .. 350 are the best ones (at 300 the search bails out), windows that touch, nest or start
+// exactly on an occurrence (the search's "equal" exit), occurrences on both strands.  Returns the number of cases that differ.
+static unsigned long long g_rescue_check_stats[4];  // searches with hits, hits, bail-outs, searches with 64 best candidates or more
+extern "C" void hostemu_rescue_search_stats(unsigned long long *out) { memcpy(out, g_rescue_check_stats, sizeof(g_rescue_check_stats)); }
+template <int G>
+static int emu_rescue_search_check(uint64_t seed, uint32_t rounds, bool reverse) {
+  uint64_t st = seed * 0x9E3779B97F4A7C15ull + 11;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  int bad = 0;
+  for (uint32_t it = 0; it < rounds; ++it) {
+    CmDev d;
+    memset(&d, 0, sizeof(d));
+    d.p.k = 17; d.p.max_insert = (int)(20 + rnd() % 1500); d.p.f0 = 500; d.p.min_seeds = 2;
+    const uint32_t n = 1 + (uint32_t)(rnd() % (it % 5 == 0 ? 40 : 10));
+    const uint32_t nrid = 1 + (uint32_t)(rnd() % 3);
+    const uint32_t span = (uint32_t)(2000 + rnd() % (it % 3 == 0 ? 60000 : 4000000));
+    std::vector<uint64_t> occ;
+    std::vector<uint8_t> kind(n);
+    std::vector<uint64_t> val(n);
+    std::vector<uint32_t> mps(n);
+    for (uint32_t mi = 0; mi < n; ++mi) {
+      mps[mi] = (uint32_t)(rnd() % 34) << 1 | (uint32_t)(rnd() & 1);
+      const uint32_t kk = (uint32_t)(rnd() % 8);
+      if (kk == 0) { kind[mi] = CM_PR_MISS; val[mi] = 0; continue; }
+      if (kk == 1) { kind[mi] = CM_PR_SINGLE; val[mi] = ((uint64_t)(rnd() % nrid) << 33) | ((uint64_t)(rnd() % span) << 1) | (rnd() & 1); continue; }
+      const uint32_t nocc = 2 + (uint32_t)(rnd() % (it % 4 == 0 ? 3000 : 300));
+      std::vector<uint64_t> run;
+      if (rnd() % 3 == 0) {  // evenly spaced
+        const uint32_t step = 1 + (uint32_t)(rnd() % 200), start = (uint32_t)(rnd() % 1000);
+        for (uint32_t i = 0; i < nocc; ++i) run.push_back(((uint64_t)(i * nrid / nocc) << 33) | ((uint64_t)(start + i * step) << 1) | (rnd() & 1));
+      } else {
+        for (uint32_t i = 0; i < nocc; ++i) run.push_back(((uint64_t)(rnd() % nrid) << 33) | ((uint64_t)(rnd() % span) << 1) | (rnd() & 1));
+      }
+      std::sort(run.begin(), run.end());
+      // one strand per position, as the reference's index has it (two occurrences at one position, one per strand, are kept one time in eight)
+      std::vector<uint64_t> u;
+      for (uint64_t x : run) if (u.empty() || (u.back() >> 1) != (x >> 1) || (it % 8 == 0 && u.back() != x)) u.push_back(x);
+      kind[mi] = CM_PR_MULTI;
+      val[mi] = ((uint64_t)occ.size() << 32) | (uint32_t)u.size();
+      occ.insert(occ.end(), u.begin(), u.end());
+    }
+    occ.push_back(0);
+    const uint32_t mn = 1 + (uint32_t)(rnd() % (it % 6 == 0 ? 420 : 60));
+    std::vector<uint64_t> mp(mn);
+    std::vector<uint8_t> mc(mn);
+    const uint64_t sr = 2ull * (uint64_t)d.p.max_insert;
+    for (uint32_t i = 0; i < mn; ++i) {
+      uint64_t pos = ((uint64_t)(rnd() % nrid) << 32) | (rnd() % span);
+      if (rnd() % 3 == 0 && occ.size() > 1) {  // a window that starts exactly on an occurrence
+        const uint64_t o = occ[rnd() % (occ.size() - 1)] >> 1;
+        pos = o + sr;
+      }
+      mp[i] = pos;
+    }
+    std::sort(mp.begin(), mp.end());
+    const uint32_t top = 2 + (uint32_t)(rnd() % 6);
+    const uint32_t share = (uint32_t)(rnd() % 4);  // how many get the best count: few .. all
+    for (uint32_t i = 0; i < mn; ++i) mc[i] = (uint8_t)((share == 3 || rnd() % (share + 2) == 0) ? top : 1 + rnd() % (top - 1));
+    uint32_t mm_off[2] = {0, n}, mm_cnt[1] = {n};
+    d.occ = occ.data(); d.n_occ = (uint32_t)occ.size();
+    d.pr_kind = kind.data(); d.pr_val = val.data(); d.mm_ps = mps.data(); d.mm_off = mm_off; d.mm_cnt = mm_cnt;
+    for (int strand = 0; strand < 2; ++strand) {
+      uint32_t c1 = 0, rl1 = 0, c2 = 0, rl2 = 0;
+      const int r1 = cm_rescue(d, 0, strand, mp.data(), mc.data(), mn, nullptr, &c1, &rl1, nullptr);
+      {
+        uint32_t nbest = 0;
+        for (uint32_t i = 0; i < mn; ++i) nbest += mc[i] == (uint8_t)(r1 < 0 ? -r1 : r1) ? 1u : 0u;
+        g_rescue_check_stats[0] += c1 > 0; g_rescue_check_stats[1] += c1; g_rescue_check_stats[2] += r1 < 0; g_rescue_check_stats[3] += nbest >= 64 && r1 >= 0;
+      }
+      std::vector<uint64_t> o1(c1 + 1), o2(c1 + 1);
+      if (r1 >= 0) (void)cm_rescue(d, 0, strand, mp.data(), mc.data(), mn, o1.data(), &c1, &rl1, nullptr);
+      std::vector<uint64_t> mem(cm_coop_rescue_mem_bytes() / 8 + 4);
+      const CmCoopRescueMem m = cm_coop_rescue_mem_at((uint8_t *)mem.data());
+      int r2 = 0;
+      emu_run_group<G>([&](EmuGroup<G> &g) {
+        uint32_t c = 0, rl = 0;
+        const int rr = cm_coop_rescue(d, 0, strand, mp.data(), mc.data(), mn, g, m, nullptr, &c, &rl);
+        if (g.t == (uint32_t)(G - 1)) { r2 = rr; c2 = c; rl2 = rl; }
+      }, reverse);
+      bool differ = r1 != r2 || (r1 >= 0 && (c1 != c2 || rl1 != rl2));
+      if (!differ && r1 >= 0 && c1 > 0) {
+        emu_run_group<G>([&](EmuGroup<G> &g) {
+          uint32_t c = 0, rl = 0;
+          (void)cm_coop_rescue(d, 0, strand, mp.data(), mc.data(), mn, g, m, o2.data(), &c, &rl);
+        }, reverse);
+        for (uint32_t i = 0; i < c1; ++i) if (o1[i] != o2[i]) { differ = true; break; }
+      }
+      if (differ) {
+        if (bad < 5) fprintf(stderr, "rescue search: case %u strand %d: one lane (%d, %u, %u) group (%d, %u, %u), %u minimizers, %u mate candidates\n", it, strand, r1, c1, rl1, r2, c2, rl2, n, mn);
+        ++bad;
+      }
+    }
+  }
+  return bad;
+}
+extern "C" int hostemu_rescue_search_check(uint64_t seed, uint32_t rounds, int G, int reverse) {
+  if (G == 16) return emu_rescue_search_check<16>(seed, rounds, reverse != 0);
+  if (G == 64) return emu_rescue_search_check<64>(seed, rounds, reverse != 0);
+  return emu_rescue_search_check<256>(seed, rounds, reverse != 0);
+}
 
 // cm_coop_reduce_dir against cm_reduce_dir on caller-made ascending lists.  Returns 0 when equal.
 template <int G>

@@ -20,7 +20,7 @@ def _set(L, G, thr, P, MM, RB, reverse=0, slab=0):
 
 
 def _items(L):
-    a = (C.c_ulonglong * 8)()
+    a = (C.c_ulonglong * 10)()
     L.hostemu_coop_items(a)
     return list(a)
 
@@ -69,6 +69,8 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
         assert factory.items[3] > 0, "no pair went through the cooperative pair filter"
         assert factory.items[4] > 0, "no read went through the cooperative acceptance stage"
         assert factory.items[5] > 0, "no pair went through the cooperative pairing stage"
+        assert factory.items[7] > 0, "no read had its rescue searches run by a group"
+        assert factory.items[8] > 0, "no search's hits were kept in the pool for the fill pass"
         if geo[1] <= 16:  # (thresholds of 64 and more leave no multi-mapped pair with lists that long in these cases)
             assert factory.items[6] > 0, "no multi-mapped pair went through the cooperative location of its sampled pairings"
     if geo[3] < 10:
@@ -119,6 +121,18 @@ def test_cooperative_sort_sweep_merge_on_adversarial_lists():
         rc = f(c0.ctypes.data, c0c.ctypes.data, len(c0), hits.ctypes.data, len(hits), e, int(rng.integers(1, 12)), G, P, RB, it & 1)
         L.hostemu_set_coop_slab(0)
         assert rc == 0, (it, mode, e, len(c0), len(hits), G, P, RB, rc)
+
+
+def test_cooperative_rescue_search_on_adversarial_runs():
+    """cm_coop_rescue (a group per read: merged windows once, bounds of every (minimizer, window) pair side by side, the chain of
+    binary searches replayed on indices) against cm_rescue: the same hits in the same order, count, repetitive-seed length and
+    return value -- bail-outs included"""
+    L = he.lib()
+    f = L.hostemu_rescue_search_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int]
+    for seed, G, rev in ((1, 64, 0), (2, 16, 1), (3, 256, 0), (4, 64, 1)):
+        assert f(seed, 400, G, rev) == 0, (seed, G, rev)
 
 
 def test_cooperative_pair_filter_on_adversarial_lists():

@@ -23,7 +23,7 @@ def main():
     g.set_option("coop_profile", 1)
     for _ in range(3):
         g.map_resident(Stats())
-    v = [g.get_option("coop_profile_%d" % k) for k in range(32)]
+    v = [g.get_option("coop_profile_%d" % k) for k in range(48)]
     names = ["run table + scan", "expand (occurrence loads)", "strand partition", "natural runs", "merge levels", "cluster sweep"]
     tot = float(sum(v[:6])) or 1.0
     n = max(1, v[8])
@@ -36,6 +36,9 @@ def main():
     print("heavy rescue searches (a group of 16 lanes per read and direction): %d searched + %d bailed out; per search: best mate candidates "
           "(windows before merging) %.1f, mate candidates %.1f, minimizers %.1f, occurrences of its minimizers %.0f, hits %.1f"
           % (v[16], v[26], v[17] / nr, v[18] / nr, v[20] / nr, v[19] / nr, v[21] / nr))
+    print("  k_s4a_rescue_list, cycles of a wave in its three loops (sum over waves / longest wave): wave-per-read %d / %d (%d reads), lane-per-read %d / %d, "
+          "16-lanes-per-read %d / %d" % (v[27], v[28], v[11], v[29], v[30], v[31], v[15]))
+    print("  k_s4b_rescue_list likewise: wave-per-read %d / %d, lane-per-read %d / %d, 16-lanes-per-read %d / %d" % (v[32], v[33], v[34], v[35], v[36], v[37]))
     print("  windows < 4: %d, < 16: %d, < 64: %d, < 300: %d" % (v[22], v[23], v[24], v[25]))
     print("timings of the last batch:", g.timings())
 
