@@ -960,7 +960,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     else { c->rs_pool.release(); c->rs_pool_cap = 0; }  // (no pool: the fill pass searches again)
     cm_fill_dev_range(c, d, rlo, rhi);
   }
-  cm_launch_k_s4a_rescue_count(d, n2, s);  // decision per read + the packed list of reads that supplement
+  cm_launch_k_s4a_rescue_count(d, n2, s, (c->opt_coop & 2) != 0);  // decision per read + the packed list of reads that supplement
   cm_launch_k_s4a_rescue_list(d, n2, s, (c->opt_coop & 2) != 0);   // their searches: a lane, a group of 16 lanes or a wave per read
   // The candidate arrays.  A batch of the size of the previous one reuses that batch's arrays (sized with 25 % to spare) without
   // waiting for its own total: the device compares the total with the capacity and, should it ever pass it, raises d.abort --

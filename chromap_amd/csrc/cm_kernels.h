@@ -28,7 +28,7 @@ uint32_t cm_s3b_lane_cap(uint32_t max_read_len);
 void cm_s3b_heavy_classes(uint32_t *hv_max);
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len);
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
-CM_DECL_LAUNCH(k_s4a_rescue_count)
+void cm_launch_k_s4a_rescue_count(const CmDev &d, uint32_t n, hipStream_t s, bool coop);
 void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, bool coop, uint32_t max_read_len);
 uint32_t cm_rescue_seg_cap(uint32_t n_reads);
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop);

@@ -709,6 +709,14 @@ __device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint
   if (pred) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
+// A read whose mate has CM_RS_WAVE candidates or more on a strand: a WAVE per read (cm_coop_rescue: the windows of the mate's best
+// candidates once per direction, a lane per (minimizer, window) pair for the bounds, the search chain replayed on indices) -- with a
+// lane per minimizer a search over ~300 windows took ~8 ms, the duration of the whole list kernel on the mosaic genome.
+#define CM_RS_WAVE 24u
+__device__ __forceinline__ bool cm_rescue_is_wave(const CmDev &d, uint32_t r, uint32_t coop) {
+  const uint32_t o = r ^ 1u;
+  return coop && (d.ncp[o] >= CM_RS_WAVE || d.ncn[o] >= CM_RS_WAVE);
+}
 // S4a / S4b: few reads (pairs whose mate has to be rescued, ~7 % here) run the long occurrence-run
 // searches.  Spread over all waves they keep every wave busy for one search's latency at 4-5 active lanes;
 // packed per block (r01h) one wave per block still ran them at a quarter of its lanes.  Every lane now does the
@@ -717,13 +725,17 @@ __device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint
 // The list is kept in CM_RS_SEGS segments, each with a counter on a cache line of its own: same-address device atomics
 // retire at ~90 per microsecond (one per wave of an 8 M-read batch on ONE counter measured 1.4 ms); a block appends with
 // one atomic to segment blockIdx % CM_RS_SEGS.  Segment g starts at rs_list + g * seg_cap.
-__global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t n, uint32_t seg_cap) {
+__global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t n, uint32_t seg_cap, uint32_t coop) {
   __shared__ uint32_t sh_cnt, sh_base;
   if (threadIdx.x == 0) sh_cnt = 0;
   __syncthreads();
   const uint32_t i0 = blockIdx.x * CM_BLOCK + threadIdx.x;
   const uint32_t i = i0 < n && d.perm_reads ? d.perm_reads[i0] : i0;
-  const bool aug = i0 < n && cm_s4a_decide(d, i);
+  const bool aug0 = i0 < n && cm_s4a_decide(d, i);
+  // a read whose mate has many candidates goes to list 23 instead: a wave each (k_s4a_rescue_wave / k_s4b_rescue_wave)
+  const bool wv = aug0 && cm_rescue_is_wave(d, i, coop);
+  cm_wave_append(d.hv_list + (size_t)23 * d.hv_stride, d.hv_cnt + 23, wv, i);
+  const bool aug = aug0 && !wv;
   // slot inside the block: wave-aggregated LDS atomic
   const unsigned long long m = __ballot(aug);
   const uint32_t lane = threadIdx.x & 63u;
@@ -747,14 +759,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t
 #define CM_RS_HEAVY 8u
 #define CM_RS_G 16
 #define CM_RS_MAXMM 192  // minimizers of a read the group path holds counts for in LDS (longer reads: the one-lane path)
-// A read whose mate has CM_RS_WAVE candidates or more on a strand: a WAVE per read (cm_coop_rescue: the windows of the mate's best
-// candidates once per direction, a lane per (minimizer, window) pair for the bounds, the search chain replayed on indices) -- with a
-// lane per minimizer a search over ~300 windows took ~8 ms, the duration of the whole list kernel on the mosaic genome.
-#define CM_RS_WAVE 24u
-__device__ __forceinline__ bool cm_rescue_is_wave(const CmDev &d, uint32_t r, uint32_t coop) {
-  const uint32_t o = r ^ 1u;
-  return coop && (d.ncp[o] >= CM_RS_WAVE || d.ncn[o] >= CM_RS_WAVE);
-}
 __device__ __forceinline__ bool cm_rescue_is_heavy(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t o = r ^ 1u;
   return (d.ncp[o] >= CM_RS_HEAVY || d.ncn[o] >= CM_RS_HEAVY) && d.mm_cnt[r] <= CM_RS_MAXMM && !cm_rescue_is_wave(d, r, coop);
@@ -808,26 +812,11 @@ __device__ __forceinline__ int cm_group_rescue_count(const CmDev &d, uint32_t r,
 __global__ __launch_bounds__(64) void k_s4a_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
-  // reads whose mate has many candidates: the wave per read (first: they are the long ones)
-  if (coop) {
-    __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
-    const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
-    CmDevGroup<64> g;
-    g.t = threadIdx.x;
-    g.xw = nullptr;
-    const long long t0 = d.prof ? clock64() : 0;
-    uint32_t nw = 0;
-    for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
-      const uint32_t r = list[j];
-      if (cm_rescue_is_wave(d, r, coop)) { cm_coop_s4a_rescue(d, r, g, m); g.sync(); ++nw; }
-    }
-    if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[27], dt); atomicMax(&d.prof[28], dt); atomicAdd(&d.prof[11], (unsigned long long)nw); }
-  }
   // reads with few mate candidates: a lane each
   const long long t1 = d.prof ? clock64() : 0;
   for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < cnt; j += gridDim.x * 64) {
     const uint32_t r = list[j];
-    if (!cm_rescue_is_heavy(d, r, coop) && !cm_rescue_is_wave(d, r, coop)) cm_s4a_rescue(d, r);
+    if (!cm_rescue_is_heavy(d, r, coop)) cm_s4a_rescue(d, r);
   }
   const long long t2 = d.prof ? clock64() : 0;
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(t2 - t1); atomicAdd(&d.prof[29], dt); atomicMax(&d.prof[30], dt); }
@@ -905,33 +894,11 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
   __shared__ uint32_t sh_cnt[64 / CM_RS_G][CM_RS_MAXMM];
   const uint32_t cnt = d.rs_cnt[blockIdx.y * 16];
   const uint32_t *list = d.rs_list + (uint64_t)blockIdx.y * seg_cap;
-  // the wave's reads (k_s4a_rescue_list): their hits written by the wave, then sorted / merged by their size class's group -- or,
-  // a short list, by lane 0 here
-  if (coop) {
-    __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
-    const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
-    CmDevGroup<64> g;
-    g.t = threadIdx.x;
-    g.xw = nullptr;
-    const long long tw0 = d.prof ? clock64() : 0;
-    for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
-      const uint32_t r = list[j];
-      if (!cm_rescue_is_wave(d, r, coop) || d.resc_n[r] + d.resc_p[r] == 0) continue;  // (uniform)
-      cm_coop_s4b_fill(d, r, g, m);
-      g.sync();
-      const uint32_t cls = cm_rescue_coop_class(d, r, coop);
-      if (threadIdx.x == 0) {
-        if (cls) d.hv_list[(size_t)cls * d.hv_stride + atomicAdd(d.hv_cnt + cls, 1u)] = r;
-        else cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);
-      }
-    }
-    if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - tw0); atomicAdd(&d.prof[32], dt); atomicMax(&d.prof[33], dt); }
-  }
   const long long tl0 = d.prof ? clock64() : 0;
   for (uint32_t j0 = blockIdx.x * 64; j0 < cnt; j0 += gridDim.x * 64) {  // whole waves (the appends below are wave-wide)
     const uint32_t j = j0 + threadIdx.x;
     const uint32_t r = j < cnt ? list[j] : 0u;
-    const bool mine = j < cnt && d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r, coop) && !cm_rescue_is_wave(d, r, coop);
+    const bool mine = j < cnt && d.resc_n[r] + d.resc_p[r] > 0 && !cm_rescue_is_heavy(d, r, coop);
     const uint32_t cls = mine ? cm_rescue_coop_class(d, r, coop) : 0u;
     if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
@@ -965,6 +932,48 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, t == 0 && cls == 15u, r);
   }
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - tg0); atomicAdd(&d.prof[36], dt); atomicMax(&d.prof[37], dt); }
+}
+// The reads of list 23 (their mate has CM_RS_WAVE candidates or more on a strand): a wave per read.  Kernels of their own so that the
+// list kernels above keep their shared memory free (three lanes' kernels share the CUs); the grid strides over the device-side list
+// and leaves at once when it is empty.
+__global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
+  __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
+  const uint32_t cnt = d.hv_cnt[23];
+  if (blockIdx.x >= cnt) return;
+  const uint32_t *list = d.hv_list + (size_t)23 * d.hv_stride;
+  const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
+  CmDevGroup<64> g;
+  g.t = threadIdx.x;
+  g.xw = nullptr;
+  const long long t0 = d.prof ? clock64() : 0;
+  for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) { cm_coop_s4a_rescue(d, list[j], g, m); g.sync(); }
+  if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[27], dt); atomicMax(&d.prof[28], dt); }
+}
+// the fill pass: the hits written (or copied out of the pool the counting pass left them in), then sorted / merged by the size class's
+// group (k_s4b_coop) -- or, a short list, by lane 0 here
+__global__ __launch_bounds__(64) void k_s4b_rescue_wave(CmDev d, uint32_t coop) {
+  if (d.abort && *d.abort) return;
+  __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
+  const uint32_t cnt = d.hv_cnt[23];
+  if (blockIdx.x >= cnt) return;
+  const uint32_t *list = d.hv_list + (size_t)23 * d.hv_stride;
+  const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
+  CmDevGroup<64> g;
+  g.t = threadIdx.x;
+  g.xw = nullptr;
+  const long long t0 = d.prof ? clock64() : 0;
+  for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+    const uint32_t r = list[j];
+    if (d.resc_n[r] + d.resc_p[r] == 0) continue;  // nothing found: k_s4b_rescue_merge copies the read's own candidates
+    cm_coop_s4b_fill(d, r, g, m);
+    g.sync();
+    const uint32_t cls = cm_rescue_coop_class(d, r, coop);
+    if (threadIdx.x == 0) {
+      if (cls) d.hv_list[(size_t)cls * d.hv_stride + atomicAdd(d.hv_cnt + cls, 1u)] = r;
+      else cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);
+    }
+  }
+  if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[32], dt); atomicMax(&d.prof[33], dt); }
 }
 // S4b for the reads listed above: a group per read sorts its rescue hits, clusters them and merges them with the read's
 // candidates (cm_coop_rescue_merge).  The list's length is only known on the device: the grid strides over it.
@@ -1804,17 +1813,23 @@ void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_le
 }
 // capacity of one list segment: the reads of every CM_RS_SEGS-th block
 uint32_t cm_rescue_seg_cap(uint32_t n_reads) { return ((n_reads + CM_BLOCK - 1) / CM_BLOCK / CM_RS_SEGS + 1) * CM_BLOCK; }
-void cm_launch_k_s4a_rescue_count(const CmDev &d, uint32_t n, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_s4a_rescue_count, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, cm_rescue_seg_cap(n));
+void cm_launch_k_s4a_rescue_count(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
+  if (n) hipLaunchKernelGGL(k_s4a_rescue_count, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, cm_rescue_seg_cap(n), coop ? 1u : 0u);
 }
 // list kernels: enough waves for every listed read of a typical batch to get a lane at once, grid-stride beyond that
+static inline uint32_t rescue_wave_blocks(uint32_t n_reads) {  // waves for list 23: a few per CU and more for large batches
+  uint32_t b = n_reads / 512 + 64;
+  return b > 8192u ? 8192u : b;
+}
 static inline dim3 rescue_list_grid(uint32_t n_reads) {
   uint32_t b = n_reads / 64 / CM_RS_SEGS / 4 + 1;  // a quarter of the reads listed: one pass
   if (b > 256u) b = 256u;
   return dim3(b, CM_RS_SEGS);
 }
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop) {
-  if (n_reads) hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), coop ? 1u : 0u);
+  if (!n_reads) return;
+  hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), coop ? 1u : 0u);
+  if (coop) hipLaunchKernelGGL(k_s4a_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);
 }
 // the per-read part (reads without rescue hits) and, coop: the reads whose long lists a wave copies
 static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {
@@ -1847,6 +1862,9 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   size_t lds[4];
   const bool all = coop && cm_s4b_coop_ready(d, RB, lds);
   hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
+  // list 23's reads were counted by waves whenever the option is on: they are filled by waves too (all == false: the groups that
+  // would sort long lists do not fit this device -- every list is then finished by the wave's lane 0)
+  if (coop) hipLaunchKernelGGL(k_s4b_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
   if (!all) return;
   uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
   if (blocks > 2048) blocks = 2048;
