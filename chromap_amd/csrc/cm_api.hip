@@ -720,20 +720,26 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
-    cm_s3b_heavy_classes(d.hv_max);
+    cm_s3b_heavy_classes(d.hv_max, &d.hv_big);
     // tests force the classes: heavy_wave_max caps the wave class, heavy_block_max the two middle classes, heavy_big_max the largest
     if (c->opt_heavy_max[0] > 0 && (uint32_t)c->opt_heavy_max[0] < d.hv_max[0]) d.hv_max[0] = (uint32_t)c->opt_heavy_max[0];
     for (int q = 1; q <= 2; ++q) if (c->opt_heavy_max[1] > 0 && (uint32_t)c->opt_heavy_max[1] < d.hv_max[q]) d.hv_max[q] = (uint32_t)c->opt_heavy_max[1];
     if (c->opt_heavy_max[2] > 0 && (uint32_t)c->opt_heavy_max[2] < d.hv_max[3]) d.hv_max[3] = (uint32_t)c->opt_heavy_max[2];
     for (int q = 1; q < 4; ++q) if (d.hv_max[q] < d.hv_max[q - 1]) d.hv_max[q] = d.hv_max[q - 1];
-    if (c->opt_heavy_max[0] < 0) d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0;  // everything long goes to the one-lane path
+    if (c->opt_heavy_max[2] > 0 && (uint32_t)c->opt_heavy_max[2] < d.hv_big) d.hv_big = (uint32_t)c->opt_heavy_max[2];
+    if (d.hv_big <= d.hv_max[3]) d.hv_big = 0;
+    if (c->opt_heavy_max[0] < 0) { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_big = 0; }  // everything long goes to the one-lane path
+    // the rescue lists' classes: the hit lists' up to 2048, then as many 20-byte entries as fit a CU's shared memory twice / once
+    d.rs_max3 = d.hv_max[3] < 3968u ? d.hv_max[3] : 3968u;
+    d.rs_big = d.hv_big ? (d.hv_big < 7680u ? d.hv_big : 7680u) : 0u;
+    if (d.rs_big <= d.rs_max3) d.rs_big = 0;
     d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
     if (d.hv_mid > 256) d.hv_mid = 256;
     if (d.hv_max[0] == 0) d.hv_mid = 0;
-    d.hv_sub = d.hv_max[0] >= 1024 ? 256u : 0u;  // (the tests' small size classes: no sub-class)
+    d.hv_sub = d.hv_max[0] >= 512 ? 256u : 0u;  // (the tests' small size classes: no sub-class)
     // with the 16-lane groups taking the lists up to hv_mid, a lane keeps the short ones only (16 hits: 256-thread blocks)
     if (d.hv_mid && c->opt_s3b_cap <= 0 && d.s3b_cap > 16) d.s3b_cap = 16;
-  } else { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_mid = 0; }
+  } else { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_mid = 0; d.hv_big = 0; d.rs_max3 = 0; d.rs_big = 0; }
   if (c->has_rank) {  // stages from verification on address the reference by rank
     d.rid_rank = (const uint32_t *)c->rid_rank.p;
     d.ref_off = (const uint64_t *)c->ref_off_r.p;
@@ -941,7 +947,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
   // (lists of class 0 -- up to heavy_wave_max hits, a wave each here -- cost the later per-lane stages little; a uniform genome
   // still has a few thousand of them per batch, and the permutation's scans and scatters cost more than they save there)
-  c->use_perm = (uint64_t)n_heavy[1] + n_heavy[2] + n_heavy[3] + n_heavy[10] > n2 / 65536 || n_heavy[0] + n_heavy[21] > n2 / 256;
+  c->use_perm = (uint64_t)n_heavy[2] + n_heavy[3] + n_heavy[10] + n_heavy[25] > n2 / 65536 || (uint64_t)n_heavy[0] + n_heavy[21] + n_heavy[1] > n2 / 256;  // (lists 21, 0, 1: up to 1024 hits)
   if (c->opt_heavy_last) c->use_perm = c->opt_heavy_last > 0;
   if (c->use_perm) {
     uint32_t *tmp = (uint32_t *)c->hv_tmp.p;

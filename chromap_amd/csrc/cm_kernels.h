@@ -25,7 +25,7 @@ void cm_launch_k_probe_reduce(const void *partials, uint32_t blocks, unsigned lo
 CM_DECL_LAUNCH(k_s3a_count)
 void cm_launch_k_sort_lists(const CmDev &d, int mode, hipStream_t s);
 uint32_t cm_s3b_lane_cap(uint32_t max_read_len);
-void cm_s3b_heavy_classes(uint32_t *hv_max);
+void cm_s3b_heavy_classes(uint32_t *hv_max, uint32_t *hv_big);
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len);
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s);
 void cm_launch_k_s4a_rescue_count(const CmDev &d, uint32_t n, hipStream_t s, bool coop);

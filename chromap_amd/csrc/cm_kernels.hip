@@ -382,15 +382,15 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
   // batch from a repeat-bearing genome, where nearly every wave holds a read of some class (k_s3a_count 1.4 ms against 0.45 ms
   // on the uniform genome with one atomic per wave).  The order inside a list is of no consequence.
   // (class 21: the lists of the wave class that fit a quarter of its work area -- four reads per CU where the full-size area has one)
-  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_sub ? 21u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : tot <= d.hv_max[3] ? 10u : 3u;
-  __shared__ uint32_t sh_cnt[7], sh_base[7];
-  if (threadIdx.x < 7) sh_cnt[threadIdx.x] = 0;
+  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_sub ? 21u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : tot <= d.hv_max[3] ? 10u : tot <= d.hv_big ? 25u : 3u;
+  __shared__ uint32_t sh_cnt[8], sh_base[8];
+  if (threadIdx.x < 8) sh_cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t ids[7] = {0u, 1u, 2u, 3u, 4u, 10u, 21u};
-  uint32_t slot = 0, mine = 7;
+  const uint32_t ids[8] = {0u, 1u, 2u, 3u, 4u, 10u, 21u, 25u};
+  uint32_t slot = 0, mine = 8;
 #pragma unroll
-  for (uint32_t q = 0; q < 7; ++q) {
+  for (uint32_t q = 0; q < 8; ++q) {
     const unsigned long long m = __ballot(cls == ids[q]);
     if (m == 0) continue;
     uint32_t base = 0;
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
     if (cls == ids[q]) { slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); mine = q; }
   }
   __syncthreads();
-  if (threadIdx.x < 7 && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&d.hv_cnt[ids[threadIdx.x]], sh_cnt[threadIdx.x]);
+  if (threadIdx.x < 8 && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&d.hv_cnt[ids[threadIdx.x]], sh_cnt[threadIdx.x]);
   __syncthreads();
-  if (mine < 7) d.hv_list[(size_t)ids[mine] * d.hv_stride + sh_base[mine] + slot] = i;
+  if (mine < 8) d.hv_list[(size_t)ids[mine] * d.hv_stride + sh_base[mine] + slot] = i;
 }
 // S3b with the per-read hit list staged in LDS ([entry][thread] layout: 16 x 8-byte entries and
 // 16 count bytes per thread = 36 KB per block).  The first version sorted every list in its
@@ -883,11 +883,11 @@ __device__ __forceinline__ void cm_group_rescue_fill(const CmDev &d, uint32_t r,
 // up to hv_max[1] / [2] / [3] (a block of 256 / 512 / 1024 lanes each).  coop == 0: everything by one lane, as before.
 #define CM_RS_COOP_MIN 32u
 #define CM_S4B_PMAX 7680u  // rescue hits the largest shared work area holds (20 bytes per hit: 8192 would pass the CU's 160 KB)
-__host__ __device__ inline uint32_t cm_s4b_pmax(const CmDev &d) { return d.hv_max[3] < CM_S4B_PMAX ? d.hv_max[3] : CM_S4B_PMAX; }
+__host__ __device__ inline uint32_t cm_s4b_pmax(const CmDev &d) { return d.rs_big; }
 __device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
   if (!coop || big <= CM_RS_COOP_MIN || d.hv_max[0] == 0) return 0;
-  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= cm_s4b_pmax(d) ? 11u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
+  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= d.rs_max3 ? 11u : big <= d.rs_big ? 26u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
 }
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   if (d.abort && *d.abort) return;
@@ -903,6 +903,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
     cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, cls == 11u, r);
+    cm_wave_append(d.hv_list + (size_t)26 * d.hv_stride, d.hv_cnt + 26, cls == 26u, r);
     cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, cls == 15u, r);
   }
   const long long tg0 = d.prof ? clock64() : 0;
@@ -929,6 +930,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     }
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, t == 0 && cls == c, r);
     cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, t == 0 && cls == 11u, r);
+    cm_wave_append(d.hv_list + (size_t)26 * d.hv_stride, d.hv_cnt + 26, t == 0 && cls == 26u, r);
     cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, t == 0 && cls == 15u, r);
   }
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - tg0); atomicAdd(&d.prof[36], dt); atomicMax(&d.prof[37], dt); }
@@ -1685,7 +1687,10 @@ uint32_t cm_s3b_lane_cap(uint32_t max_read_len) {
   return cap < 16 ? 16 : (cap > 64 ? 64 : cap);
 }
 // the cooperative kernel's size classes: hits per wave-group, per block, per block with a large LDS allocation
-void cm_s3b_heavy_classes(uint32_t *hv_max) {
+// Round 4: finer classes (a wave up to 256 / 512 hits, 256 lanes up to 1024 / 2048, 512 up to 4096, 1024 up to 8192 with the large
+// allocation): the stages are chains of shared-memory round trips, a group's work area is what limits the waves a CU holds, and a
+// work area of the list's own size class was worth 20 % of the stage on the mosaic genome.
+void cm_s3b_heavy_classes(uint32_t *hv_max, uint32_t *hv_big) {
   // HIP function attributes belong to the device the call is made on (one process may drive several: chromap-amd --gpus N),
   // so the large-LDS opt-in is made -- and remembered -- per device; lane threads of one device may race here, hence atomics
   static std::atomic<int> big_ok[64];  // 0 unknown, 1 granted, 2 refused
@@ -1698,7 +1703,8 @@ void cm_s3b_heavy_classes(uint32_t *hv_max) {
     (void)hipGetLastError();
     if (dev == slot) big_ok[slot].store(st, std::memory_order_release);
   }
-  hv_max[0] = 1024; hv_max[1] = 2048; hv_max[2] = 4096; hv_max[3] = st == 1 ? 8192 : 4096;
+  hv_max[0] = 512; hv_max[1] = 1024; hv_max[2] = 2048; hv_max[3] = 4096;
+  *hv_big = st == 1 ? 8192 : 0;
 }
 // the largest dynamic LDS allocation a kernel of this device may ask for, opted in once per device and kernel
 template <class K>
@@ -1764,9 +1770,16 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
       }                                                                                                                                            \
     }
     CM_S3B_COOP_CLASS(1, 1, 256)
-    CM_S3B_COOP_CLASS(2, 2, 512)
-    CM_S3B_COOP_CLASS(10, 3, 1024)
+    CM_S3B_COOP_CLASS(2, 2, 256)   // (512 lanes for 1024 .. 2048 hits and 1024 for 2048 .. 4096 were measured slower: more lanes
+    CM_S3B_COOP_CLASS(10, 3, 512)  //  per hit cost more in barriers than the shorter chunks save; ~8 hits per lane it is)
 #undef CM_S3B_COOP_CLASS
+    if (n_cls[25] && d.hv_big > d.hv_max[3]) {  // the largest work area: one block per CU
+      const size_t lds = cm_coop_group_bytes(d.hv_big, MM, RB, false);
+      if (cm_lds_optin(&k_s3b_coop<1024>, lds)) {
+        hipLaunchKernelGGL(k_s3b_coop<1024>, dim3(n_cls[25]), dim3(1024), lds, s, d, lst(25), n_cls[25], d.hv_big, MM, RB, fb_list, fb_cnt, 0u);
+        rest[25] = 0; any_coop = true;
+      }
+    }
     if (n_cls[3] && d.coop_slab && d.hv_max[3]) {  // lists beyond the largest class: 1024 lanes on a slab of global memory each
       const size_t lds = cm_coop_group_bytes(d.hv_max[3], MM, RB, false);
       if (cm_lds_optin(&k_s3b_coop<1024>, lds)) {
@@ -1777,8 +1790,8 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
         rest[3] = 0;
       }
     }
-    if (any_coop) {  // the declined reads: up to hv_max[3] hits, a block each, the grid strides over the device-side list
-      const uint32_t P = pow2(d.hv_max[3]);
+    if (any_coop) {  // the declined reads: up to hv_big hits, a block each, the grid strides over the device-side list
+      const uint32_t P = pow2(d.hv_big > d.hv_max[3] ? d.hv_big : d.hv_max[3]);
       hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(512), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, (const uint32_t *)fb_list, 0u, P, (const uint32_t *)fb_cnt);
     }
   }
@@ -1796,6 +1809,10 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     if (!rest[c]) continue;
     const uint32_t P = pow2(d.hv_max[blk[q][1]]);
     hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[c]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(c), rest[c], P, (const uint32_t *)nullptr);
+  }
+  if (rest[25]) {
+    const uint32_t P = pow2(d.hv_big);
+    hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[25]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(25), rest[25], P, (const uint32_t *)nullptr);
   }
   if (rest[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((rest[3] + 63) / 64), dim3(64), 0, s, d, lst(3), rest[3], (const uint32_t *)nullptr);
   if (rest[4]) {  // groups of 16 lanes, 16 reads per block
@@ -1837,12 +1854,13 @@ static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {
   lds[0] = 2 * cm_coop_group_bytes(d.hv_max[0], 1, RB, true);
   lds[1] = cm_coop_group_bytes(d.hv_max[1], 1, RB, true);
   lds[2] = cm_coop_group_bytes(d.hv_max[2], 1, RB, true);
-  lds[3] = cm_coop_group_bytes(cm_s4b_pmax(d), 1, RB, true);
-  const bool ok = cm_lds_optin(&k_s4b_coop<64>, lds[0]) && cm_lds_optin(&k_s4b_coop<256>, lds[1]) && cm_lds_optin(&k_s4b_coop<512>, lds[2]) &&
-                  cm_lds_optin(&k_s4b_coop<1024>, lds[3]);
+  lds[3] = cm_coop_group_bytes(d.rs_max3, 1, RB, true);
+  lds[4] = cm_coop_group_bytes(d.rs_big > d.rs_max3 ? d.rs_big : d.rs_max3, 1, RB, true);
+  const bool ok = cm_lds_optin(&k_s4b_coop<64>, lds[0]) && cm_lds_optin(&k_s4b_coop<256>, lds[1] > lds[2] ? lds[1] : lds[2]) && cm_lds_optin(&k_s4b_coop<512>, lds[3]) &&
+                  cm_lds_optin(&k_s4b_coop<1024>, lds[4]);
   if (!ok) {  // not an error (the one-lane forms take over), but never silently: it costs a factor on repeat-rich input
     static std::atomic<int> told{0};
-    if (!told.exchange(1)) fprintf(stderr, "chromap_amd: the cooperative rescue kernels do not fit this device's shared memory (%zu / %zu / %zu / %zu bytes); using the one-lane forms\n", lds[0], lds[1], lds[2], lds[3]);
+    if (!told.exchange(1)) fprintf(stderr, "chromap_amd: the cooperative rescue kernels do not fit this device's shared memory (%zu / %zu / %zu / %zu bytes); using the one-lane forms\n", lds[0], lds[1], lds[2], lds[4]);
   }
   return ok;
 }
@@ -1851,7 +1869,7 @@ static inline uint32_t cm_s4b_rb(const CmDev &d, uint32_t max_read_len) {
 }
 void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, bool coop, uint32_t max_read_len) {
   if (!n) return;
-  size_t lds[4];
+  size_t lds[5];
   const bool all = coop && cm_s4b_coop_ready(d, cm_s4b_rb(d, max_read_len), lds);
   hipLaunchKernelGGL(k_s4b_rescue_merge, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, all ? 1u : 0u);
 }
@@ -1859,7 +1877,7 @@ void cm_launch_k_s4b_rescue_merge(const CmDev &d, uint32_t n, hipStream_t s, boo
 void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop, uint32_t max_read_len) {
   if (!n_reads) return;
   const uint32_t RB = cm_s4b_rb(d, max_read_len);
-  size_t lds[4];
+  size_t lds[5];
   const bool all = coop && cm_s4b_coop_ready(d, RB, lds);
   hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
   // list 23's reads were counted by waves whenever the option is on: they are filled by waves too (all == false: the groups that
@@ -1871,10 +1889,11 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
   hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB, 0u);
   if (d.hv_max[1] > d.hv_max[0]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB, 0u);
-  if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
-  if (d.hv_max[3] > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), cm_s4b_pmax(d), RB, 0u);
+  if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
+  if (d.rs_max3 > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.rs_max3, RB, 0u);
+  if (d.rs_big > d.rs_max3) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[4], s, d, lst(26), (const uint32_t *)(d.hv_cnt + 26), d.rs_big, RB, 0u);
   if (d.coop_slab)  // lists beyond the largest class: on the blocks' slabs of global memory
-    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[3], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), cm_s4b_pmax(d), RB, 1u);
+    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[4], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), d.rs_big > d.rs_max3 ? d.rs_big : d.rs_max3, RB, 1u);
 }
 // coop: the cmgpu_set_option "coop" bit mask (bit 2: pairs with long lists to groups; bit 3: the S5 waves sort the heavy reads' lists)
 void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop) {

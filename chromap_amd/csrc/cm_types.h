@@ -25,7 +25,7 @@
 #define CM_PR_MULTI 2
 #define CM_V_INVALID 0x7fff
 #define CM_MM_CHUNKS 8            // chunks of a batch whose index probe overlaps the next chunk's minimizer pass
-#define CM_HV_LISTS 24           // device work lists of hv_stride entries each: 0-4 and 10 hit-list classes, 5 reads the merge-sort kernel declined, 6-8 and 11 rescue classes, 9 / 14 pairs for the filter (lists up to 1024 / 4096 entries), 12 reads / 13 pairs of the later stages, 15 rescue lists / 16 declined hit lists beyond the largest class, 17 multi-mapped pairs, 18 / 20 pairs / multi-mapped pairs for a block each, 19 pairs for the filter with lists beyond 4096 entries
+#define CM_HV_LISTS 27           // device work lists of hv_stride entries each: 0-4 and 10 hit-list classes, 5 reads the merge-sort kernel declined, 6-8 and 11 rescue classes, 9 / 14 pairs for the filter (lists up to 1024 / 4096 entries), 12 reads / 13 pairs of the later stages, 15 rescue lists / 16 declined hit lists beyond the largest class, 17 multi-mapped pairs, 18 / 20 pairs / multi-mapped pairs for a block each, 19 pairs for the filter with lists beyond 4096 entries
 #define CM_RS_SEGS 64           // rescue list segments (one counter each, on its own cache line)
 #define CM_MAX_BEST 64          // upper bound on max_num_best_mappings (-n)
 #define CM_SORT_SERIAL_MAX 24   // cm_sort_cand / cm_sort_draft: insertion sort up to here, heap sort beyond
@@ -136,6 +136,9 @@ struct CmDev {
   // lists longer than CM_SORT_SERIAL_MAX (candidates after the pair filter, draft mappings) that a wave sorts before the per-read
   // stage looks at them: srt_cnt[0] items (read << 1 | strand) at srt_list, srt_cnt[1] the work cursor
   uint32_t *srt_cnt, *srt_list;
+  // hv_big: hit lists of hv_max[3] < hits <= hv_big go to list 25 (a block of 1024 lanes with the largest work area); rs_max3 / rs_big:
+  // the rescue lists' two largest classes (lists 11 / 26: their entries take 20 bytes of the work area, not 19) -- 0: no such class
+  uint32_t hv_big, rs_max3, rs_big;
   uint32_t s4c_pbig;  // entries of a candidate list the pair filter's largest class takes (k_s4c_coop<1024, false>; 0: no such class)
   uint32_t hv_stride, s3b_cap, hv_max[4];  // hv_max: hit-list size classes -- a wave, a block of 256 / 512 / 1024 lanes (lists 0, 1, 2, 10)
   uint8_t *coop_slab;      // global work memory of the groups that take lists longer than their shared memory holds:
