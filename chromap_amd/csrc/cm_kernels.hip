@@ -1636,14 +1636,24 @@ void cm_launch_k_pack_ref(const uint8_t *ref, uint64_t n_bytes, CmPlRec *pl, hip
   if (!n) return;
   hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((n + CM_BLOCK - 1) / CM_BLOCK)), dim3(CM_BLOCK), 0, s, ref, n_bytes, pl);
 }
-// the batch's reads as bit planes, both orientations (CmDev::read_pl): one lane per read
+// the batch's reads as bit planes, both orientations (CmDev::read_pl): one lane per read.  The words per plane are a template
+// parameter of the KERNEL (W = 0: any number, the read-back form): with the choice inside the kernel its registers were those of the
+// largest case -- 17.8 ms per 4 M pairs of 50-base reads next to 1.3 ms, on the second stream under S3 / S4 (round 4, when the
+// cases for 150-base reads were added).
+template <int W>
 __global__ __launch_bounds__(CM_BLOCK) void k_pack_reads(CmDev d, uint32_t n_reads) {
   const uint32_t r = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (r < n_reads) cm_pack_read_planes(d, r);
+  if (r >= n_reads) return;
+  if (W == 0) cm_pack_read_planes_any(d, r); else cm_pack_read_planes_w<(W > 0 ? W : 1)>(d, r);
 }
 void cm_launch_k_pack_reads(const CmDev &d, uint32_t n_reads, hipStream_t s) {
   if (!n_reads) return;
-  hipLaunchKernelGGL(k_pack_reads, grid_for_n(n_reads), dim3(CM_BLOCK), 0, s, d, n_reads);
+#define CM_PACK_CASE(W_) case W_: hipLaunchKernelGGL(k_pack_reads<W_>, grid_for_n(n_reads), dim3(CM_BLOCK), 0, s, d, n_reads); break;
+  switch (d.read_pl_w) {
+    CM_PACK_CASE(1) CM_PACK_CASE(2) CM_PACK_CASE(3) CM_PACK_CASE(4) CM_PACK_CASE(5) CM_PACK_CASE(6) CM_PACK_CASE(7) CM_PACK_CASE(8)
+    default: hipLaunchKernelGGL(k_pack_reads<0>, grid_for_n(n_reads), dim3(CM_BLOCK), 0, s, d, n_reads);
+  }
+#undef CM_PACK_CASE
 }
 void cm_launch_k_copy_u64(const unsigned long long *src, unsigned long long *dst, hipStream_t s) {
   hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, s, src, dst);
