@@ -1001,6 +1001,7 @@ __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s4b_coop(CmDev 
 // CM_S4C_COOP_MIN entries only gets the part before the filter here and goes to list 9 for k_s4c_coop (a wave per pair).
 #define CM_S4C_COOP_MIN 48u
 #define CM_S5C_COOP_MIN 48u  // candidates of a read above which S5 (sorting the lists, alignments, acceptance) is a wave's work
+#define CM_S5C_P_SMALL 512u   // most reads of the wave class: work arrays of this size (more waves per CU)
 #define CM_S5C_P_WAVE 2048u   // candidates of a strand the wave's work arrays hold
 #define CM_S5C_P_BLOCK 16384u // ... a block's (longer lists: the acceptance loop by one lane)
 __device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair, bool live, uint32_t coop) {
@@ -1011,6 +1012,7 @@ __device__ __forceinline__ void cm_s4c_queue_sort(const CmDev &d, uint32_t pair,
     cm_wave_append(d.srt_list, &d.srt_cnt[0], cnt > CM_SORT_SERIAL_MAX && cnt <= CM_SORT_WAVE_MAX, (r << 1) | (q & 1u));
   }
 }
+#define CM_S4C_P_SMALL 256u   // most pairs with long lists: a wave each (the classes above take a block of 256 lanes per pair)
 #define CM_S4C_P_WAVE 1024u   // entries of a candidate list the work arrays of a wave hold
 #define CM_S4C_P_BLOCK 4096u  // ... of a block
 #define CM_S4C_P_BIG 15360u   // ... of a block of 1024 lanes that leaves the position lists in global memory (a lane walking such a
@@ -1025,11 +1027,12 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, ui
     uint32_t big = d.mcp[r1] > d.mcn[r1] ? d.mcp[r1] : d.mcn[r1];
     big = d.mcp[r2] > big ? d.mcp[r2] : big;
     big = d.mcn[r2] > big ? d.mcn[r2] : big;
-    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : big <= d.s4c_pbig ? 19u : 0u;
+    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_SMALL ? 27u : big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : big <= d.s4c_pbig ? 19u : 0u;
     if (!cls) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
   }
   if (coop & 4u) {
     cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, cls == 9u, pair);
+    cm_wave_append(d.hv_list + 27 * (size_t)d.hv_stride, d.hv_cnt + 27, cls == 27u, pair);
     cm_wave_append(d.hv_list + 14 * (size_t)d.hv_stride, d.hv_cnt + 14, cls == 14u, pair);
     cm_wave_append(d.hv_list + 19 * (size_t)d.hv_stride, d.hv_cnt + 19, cls == 19u, pair);
   }
@@ -1073,8 +1076,10 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, u
   const bool to_wave = i < n && cm_s5a_prepare(d, r, coop ? CM_S5C_COOP_MIN : 0u);
   // list 12: a wave per read; list 22: a block per read -- a strand's list is longer than the wave's work arrays
   const bool big = to_wave && (d.fcp[r] > CM_S5C_P_WAVE || d.fcn[r] > CM_S5C_P_WAVE);
+  const bool small = to_wave && d.fcp[r] <= CM_S5C_P_SMALL && d.fcn[r] <= CM_S5C_P_SMALL;  // list 28: a quarter of the work arrays
   if (coop) {
-    cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave && !big, r);
+    cm_wave_append(d.hv_list + (size_t)28 * d.hv_stride, d.hv_cnt + 28, small, r);
+    cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave && !big && !small, r);
     cm_wave_append(d.hv_list + (size_t)22 * d.hv_stride, d.hv_cnt + 22, big, r);
   }
 }
@@ -1203,15 +1208,16 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_rea
 // the second list of each direction staged in shared memory -- or, when read 2 has a list longer than CM_S6A_P_WAVE, to list 18,
 // where a block does (lists up to CM_S6A_P_BLOCK staged, longer ones read where they are)
 #define CM_S6A_COOP_MIN 48u
+#define CM_S6A_P_SMALL 256u
 #define CM_S6A_P_WAVE 1024u
 #define CM_S6A_P_BLOCK 8192u
-__device__ __forceinline__ uint32_t cm_s6_class(const CmDev &d, uint32_t pair, uint32_t wave_list, uint32_t block_list) {
+__device__ __forceinline__ uint32_t cm_s6_class(const CmDev &d, uint32_t pair, uint32_t small_list, uint32_t wave_list, uint32_t block_list) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   uint32_t big2 = d.ndp[r2] > d.ndn[r2] ? d.ndp[r2] : d.ndn[r2], big = big2;
   big = d.ndp[r1] > big ? d.ndp[r1] : big;
   big = d.ndn[r1] > big ? d.ndn[r1] : big;
   if (big <= CM_S6A_COOP_MIN) return 0;
-  return big2 <= CM_S6A_P_WAVE ? wave_list : block_list;
+  return big2 <= CM_S6A_P_SMALL ? small_list : big2 <= CM_S6A_P_WAVE ? wave_list : block_list;
 }
 __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint32_t coop) {
   if (d.abort && *d.abort) return;
@@ -1219,10 +1225,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
   uint32_t cls = 0;
   if (i < n && cm_s6a_pre<false>(d, pair)) {
-    cls = coop ? cm_s6_class(d, pair, 13u, 18u) : 0u;
+    cls = coop ? cm_s6_class(d, pair, 29u, 13u, 18u) : 0u;
     if (!cls) cm_s6a_sweeps<false>(d, pair);
   }
   if (coop) {
+    cm_wave_append(d.hv_list + (size_t)29 * d.hv_stride, d.hv_cnt + 29, cls == 29u, pair);
     cm_wave_append(d.hv_list + (size_t)13 * d.hv_stride, d.hv_cnt + 13, cls == 13u, pair);
     cm_wave_append(d.hv_list + (size_t)18 * d.hv_stride, d.hv_cnt + 18, cls == 18u, pair);
   }
@@ -1250,10 +1257,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6c_multi(CmDev d, uint32_t n, uin
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
   uint32_t cls = 0;
   if (i < n) {
-    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) cls = cm_s6_class(d, pair, 17u, 20u);
+    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) cls = cm_s6_class(d, pair, 30u, 17u, 20u);
     if (!cls) cm_s6c_multi<false>(d, pair);
   }
   if (coop) {
+    cm_wave_append(d.hv_list + (size_t)30 * d.hv_stride, d.hv_cnt + 30, cls == 30u, pair);
     cm_wave_append(d.hv_list + (size_t)17 * d.hv_stride, d.hv_cnt + 17, cls == 17u, pair);
     cm_wave_append(d.hv_list + (size_t)20 * d.hv_stride, d.hv_cnt + 20, cls == 20u, pair);
   }
@@ -1920,6 +1928,8 @@ void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t 
   if (!(coop & 4u)) return;
   uint32_t blocks = n / 2048 + 64;
   if (blocks > 4096) blocks = 4096;
+  const size_t gs = ((cm_coop_pair_mem_bytes(CM_S4C_P_SMALL) + 15) & ~(size_t)15) + CM_XW_BYTES;
+  hipLaunchKernelGGL((k_s4c_coop<64, true>), dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gs, s, d, CM_S4C_P_SMALL, 27u, coop);  // a wave per pair
   hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
   hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
   if (d2.s4c_pbig)
@@ -1929,7 +1939,8 @@ void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coo
   if (!n) return;
   hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (coop) {  // the lists it left unsorted: a wave per read
-    hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, 12u);
+    hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, 28u);
+    hipLaunchKernelGGL(k_s5_sort_coop, dim3(2048), dim3(CM_BLOCK), 0, s, d, 12u);
     hipLaunchKernelGGL(k_s5_sort_coop, dim3(64), dim3(CM_BLOCK), 0, s, d, 22u);
   }
 }
@@ -1943,6 +1954,7 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
   };
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gbytes(CM_S5C_P_SMALL), s, d, CM_S5C_P_SMALL, 28u);
   hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(192), 3 * gbytes(CM_S5C_P_WAVE), s, d, CM_S5C_P_WAVE, 12u);  // three waves per block: under the 64 KB a launch gets without asking
   // the reads with a longer list: a block each (what even its work arrays cannot hold: lane 0's acceptance loop, the group's sort)
   uint32_t pb = CM_S5C_P_BLOCK;
@@ -1969,6 +1981,7 @@ void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) 
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 29u);
   hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 13u);
   hipLaunchKernelGGL(k_s6a_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 18u);
 }
@@ -1980,6 +1993,7 @@ void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop)
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 30u);
   hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 17u);
   hipLaunchKernelGGL(k_s6c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 20u);
 }
