@@ -236,6 +236,10 @@ def roofline(g, args, s, steps, stage_ms):
     if not args.graded_probe_only and g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, args.probe_repeat, 1, 2, C.byref(favg), C.byref(fps), C.byref(fhits)) == 0 and favg.value > 0:
         file_layout = {"lookups": int(n_mm), "avg_ms": round(favg.value, 4), "probe_steps": int(fps.value), "hits": int(fhits.value),
                        "GB/s": round(16.0 * fps.value / (favg.value * 1e-3) / 1e9, 1), "buckets": g.get_option("probe_table_buckets") >> max(0, args.probe_table_shift)}
+    if args.graded_probe_only:
+        # the profiler passes: the file table's probe steps (a property of the data set) are counted by ONE launch of another shape
+        # (two lookups per lane: k_probe<2, false>), so that every k_probe<1, false> in the trace is the graded launch
+        g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, 1, 2, 2, C.byref(favg), C.byref(fps), C.byref(fhits))
     probe_steps = fps.value if fps.value else s["probe_steps"] / steps
     alg_bytes = 16.0 * probe_steps  # one 8-B key + one 8-B value per bucket kh_get visits
     avg, ps, hits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
@@ -272,7 +276,11 @@ def roofline(g, args, s, steps, stage_ms):
             pass
     shape = {"lookups_per_lane": g.get_option("probe_lookups_per_lane"), "pair_prefetch": g.get_option("probe_pair_prefetch")}
     roof = {"kernel": "k_probe", "kernel_shape": shape, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # the same launch counted in the buckets it really read (the re-hashed table's walk is shorter than kh_get's in the file's table)
+            "frac_visited": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg.value > 0 else None,
+            "extra_hbm_bytes_of_rehashed_table": int(16 * g.get_option("probe_table_buckets")) if args.probe_table_shift else 0,
+            "traffic": traffic,
             "traffic_source": "from_profile: profiles/probe_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, "
                               "tools/profile_bench.sh), not measured in this run",
             "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
@@ -315,7 +323,10 @@ def main():
     ap.add_argument("--harsh", default="profile:1",
                     help="the third workload's genome: profile:1 = 22.5 %% of the bases repeat-derived -- SINE-like families of ~10^4 copies at "
                          "5-15 %% divergence, LINE-like families of ~360 copies at 1-5 %%, satellite arrays ('' = skip it)")
-    ap.add_argument("--harsh-ref-pairs", type=int, default=500_000, help="pairs per batch of the reference-binary check on the third workload (two batches)")
+    ap.add_argument("--harsh-ref-pairs", type=int, default=2_000_000, help="pairs per batch of the reference-binary check on the third / fourth workload (two batches)")
+    ap.add_argument("--harsh2", default="profile:2",
+                    help="the fourth workload's genome: profile:2 = the same element kinds with 47 %% of the bases repeat-derived, as GRCh38 is "
+                         "(SINE-like families of ~19 000 copies, LINE-like of ~830) ('' = skip it)")
     ap.add_argument("--headline-repeats", default="", help="plant repeats in the headline workload's genome too (not the default)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="timed region and roofline only")
@@ -381,7 +392,7 @@ def main():
         # lanes and the record exchange do not mix well on one GPU (measured: 3 lanes 429 -> 366 M pairs/s with the exchange,
         # 1 lane 404 -> 388): ranks that exchange map their batch in one piece
         g_.set_option("lanes", 1 if exchange else args.lanes)
-        if args.probe_table_shift:
+        if args.probe_table_shift != 1:  # (1 is the library's own default: cmgpu_create* re-hash the table into twice the buckets)
             g_.set_option("probe_table_shift", args.probe_table_shift)
         for o in args.option:
             k_, v_ = o.split("=")
@@ -428,7 +439,7 @@ def main():
     g.swap_resident(0)
     roof = roofline(g, args, s, steps, stage_ms)
     g.set_option("lanes", args.lanes)
-    post = pcie = cpu = rep_out = harsh_out = hic_out = None
+    post = pcie = cpu = rep_out = harsh_out = harsh2_out = hic_out = None
     if not args.skip_extras:
         # device-side post-processing, outside the timed region: the records of the four resident
         # batches go to the record store; one call sorts, de-duplicates, filters and renders the BED text in HBM
@@ -525,6 +536,12 @@ def main():
                                                    "repeat-derived -- SINE-like 300-base elements in 128 families of ~10^4 copies at 5-15 %% divergence, "
                                                    "LINE-like 3-kb elements in 256 families of ~360 copies at 1-5 %%, satellite arrays of 171-base "
                                                    "units" % harsh, ref_pairs=args.harsh_ref_pairs)
+        harsh2 = parse_rep(args.harsh2)
+        if world == 1 and harsh2 and not args.sam:
+            harsh2_out = side_workload(harsh2, 6000, "the headline workload on a genome with the same repeat kinds at GRCh38's share (%s): 47 %% of the bases "
+                                                     "repeat-derived -- 40 %% of the 64-kb tiles SINE-like (128 families of ~19 000 copies at 5-15 %%), 28 %% "
+                                                     "LINE-like (256 families of ~830 copies at 1-5 %%), 3 %% satellite arrays" % harsh2,
+                                       ref_pairs=args.harsh_ref_pairs)
         if world == 1 and args.hic_workload and not args.sam and args.hic < 0:
             # BASELINE config 5: --preset hic, 2 x 150 with 0.1 % indels, Hi-C shaped pairs with chimeric reads (split alignment)
             try:
@@ -563,7 +580,7 @@ def main():
                    "pairs_per_gpu_per_step": args.pairs, "lanes": 1 if exchange else args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
-        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "hic_workload": hic_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
+        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "harsh2_repeat_workload": harsh2_out, "hic_workload": hic_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
         "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
         "stage_ms_note": "HIP events of the calling thread's lane (1 / %d of the batch when lanes > 1; the lanes overlap)" % args.lanes,
         "counters_per_step": {k: v // steps for k, v in s.items()},

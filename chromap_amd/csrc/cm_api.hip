@@ -55,6 +55,12 @@ void DevBuf::release() {
 
 // tuning knobs for measurements (defaults are what the measurements chose)
 static int build_fast_table(cmgpu_ctx *c, int shift);
+// the arrays indexed through m_off (merged / filtered candidates, draft mappings, alignment results): room for n_m entries
+static int cm_ensure_candidate_arrays(cmgpu_ctx *c, uint64_t n_m) {
+  return c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
+         c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
+         c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4);
+}
 extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
   if (!c || !name) return CMGPU_EINVAL;
   const std::string n(name);
@@ -96,15 +102,16 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_heavy_last = (int)value;
   } else if (n == "probe_table_shift") {  // 0: probe the file's table; 1 / 2: a device copy with 2 / 4 times the buckets
     if (value < 0 || value > 4) { cm_set_error(c, "probe_table_shift: 0..4"); return CMGPU_EINVAL; }
-    return build_fast_table(c, (int)value);
+    return cm_build_fast_table(c, (int)value);
   } else if (n == "long_read_fused") {  // 0: reads longer than 69 bases take the two-pass minimizer kernels (count, scan, fill)
     c->opt_long_fused = value ? 1 : 0;
   } else if (n == "verify_planes") {  // 0: k_s5b_verify aligns on the reference / read bytes (the round-2 form) instead of their bit planes
-    c->opt_planes = value ? 1 : 0;
-    if (!c->opt_planes) { c->ref_planes.release(); c->ref_pl_words = 0; }
+    c->opt_planes = value ? 1 : 0;  // (the planes stay where they are: contexts made by cmgpu_create_shared may hold views of them)
   } else if (n == "speculative_sizes") {  // 0: every batch waits for the total of its candidate lists before sizing their arrays
     c->opt_spec = value ? 1 : 0;
   } else if (n == "debug_candidate_capacity") {  // tests: pretend the previous batch left this much room (forces the re-run path)
+    // (the arrays are made to hold what is claimed: the device-side check trusts m_cap)
+    if (value > 0 && cm_ensure_candidate_arrays(c, (uint64_t)value)) { cm_set_error(c, "out of device memory (candidates)"); return CMGPU_ENOMEM; }
     c->pred_m_ok = value > 0; c->m_cap = (uint64_t)value; c->pred_n = 0xffffffffu;  // (any batch size)
   } else if (n == "coop_profile") {  // measurement aid: per-phase cycle sums of k_s3b_coop (cmgpu_get_option coop_profile_0 .. _15)
     if (value) { if (c->coop_prof.ensure(48 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 48 * 8)); } else c->coop_prof.release();
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void k_rehash(const uint64_t *__restrict__ src
     b = (b + (++step)) & mask;
   }
 }
-static int build_fast_table(cmgpu_ctx *c, int shift) {
+int cm_build_fast_table(cmgpu_ctx *c, int shift) {
   HIPCHECK(c, cm_enter(c));
   HIPCHECK(c, cm_stream_sync(c->stream));
   c->bkt_fast.release();
@@ -349,6 +356,10 @@ extern "C" int cmgpu_create(const cmgpu_index_view *index, const cmgpu_ref_view 
   }
   rc = cm_upload_reference(c, ref);
   if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
+  // the pipeline probes a copy of the table re-hashed into twice the buckets (same keys, values, hash and probe sequence: identical
+  // lookups, 1.18 instead of 1.69 buckets visited per lookup; + 16 bytes per bucket of HBM) unless memory is short; the file's table
+  // stays resident for export / save.  cmgpu_set_option "probe_table_shift" 0 releases the copy.
+  if (cm_build_fast_table(c, 1) != CMGPU_OK) { c->bkt_fast.release(); c->fmask = 0; c->err.clear(); }
   *out = c;
   return CMGPU_OK;
 }
@@ -369,7 +380,15 @@ extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
   view(c->ref_off, parent->ref_off); view(c->ref_len, parent->ref_len);
   c->bmask = parent->bmask; c->n_occ = parent->n_occ; c->n_seq = parent->n_seq; c->ref_bytes = parent->ref_bytes;
   c->opt_planes = parent->opt_planes;
+  // the reference's bit planes are built on the parent now, so that every child views them instead of building its own copy
+  // (half a byte per reference base each); the re-hashed probe table likewise is the parent's
+  if (!parent->ref_pl_words && parent->opt_planes && parent->ref_bytes && parent->ref_planes.owned) {
+    cmgpu_ctx *pp = const_cast<cmgpu_ctx *>(parent);
+    if (cm_build_ref_planes(pp) != CMGPU_OK) { pp->ref_planes.release(); pp->ref_pl_words = 0; pp->err.clear(); }
+    (void)select_device(parent->device);
+  }
   if (parent->ref_pl_words) { view(c->ref_planes, parent->ref_planes); c->ref_pl_words = parent->ref_pl_words; }  // (else: its own, on its first call)
+  if (parent->fmask) { view(c->bkt_fast, parent->bkt_fast); c->fmask = parent->fmask; }
   c->h_ref_off = parent->h_ref_off; c->h_ref_len = parent->h_ref_len;
   c->synth_n_minimizers = parent->synth_n_minimizers; c->synth_n_keys = parent->synth_n_keys;
   // --chr-order / --pairs-natural-chr-order of the parent apply to the child too (records carry ranks)
@@ -466,7 +485,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
-  ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
+  ENS(scan_tmp, cm_scan_tmp_words(2 * (uint32_t)n2 + 2) * 4)
   ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(coop_slab, (size_t)CM_SLAB_BLOCKS * cm_coop_slab_bytes(CM_SLAB_CAP)) ENS(hv_cnt, 256) ENS(hv_list, CM_HV_LISTS * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
 #undef ENS
   return CMGPU_OK;
@@ -681,7 +700,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.bkt = (const uint64_t *)(c->fmask ? c->bkt_fast.p : c->bkt.p); d.bmask = c->fmask ? c->fmask : c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
   d.n_seq = c->n_seq;
-  d.ref_pl = c->ref_pl_words ? (const CmPlRec *)c->ref_planes.p + CM_PL_LEAD : nullptr; d.ref_pl_words = c->ref_pl_words;
+  d.ref_pl = c->ref_pl_words && c->opt_planes ? (const CmPlRec *)c->ref_planes.p + CM_PL_LEAD : nullptr; d.ref_pl_words = c->ref_pl_words;
   d.p = c->p;
   d.p.single = c->single ? 1 : 0;
   d.mq.len_coef = (const double *)c->len_coef.p; d.mq.nsec_break = (const uint32_t *)c->nsec_break.p; d.mq.n_break = c->n_break;
@@ -715,6 +734,10 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
   d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
   d.prof = (unsigned long long *)c->coop_prof.p;
+  if (c->use_rounds) {
+    d.v_to = (uint32_t *)c->v_to.p; d.v_from = (uint32_t *)c->v_from.p; d.v_minrej = (uint32_t *)c->v_minrej.p; d.v_ninv = (uint32_t *)c->v_ninv.p;
+    d.v_rcnt = (uint32_t *)c->v_rcnt.p; d.v_roff = (uint32_t *)c->v_roff.p;
+  }
   d.rs_pool = (uint64_t *)c->rs_pool.p; d.rs_pool_cap = c->rs_pool.p ? c->rs_pool_cap : 0u; d.rs_pool_off = (uint32_t *)c->rs_pool_off.p;
   d.abort = (const unsigned long long *)c->stats.p + CM_ST_ABORT;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
@@ -988,9 +1011,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     if (want > limit) want = limit;
     if (want < m_total) want = m_total;
     n_m = (uint32_t)want;
-    if (c->mbuf.ensure((size_t)n_m * 8 + 8) || c->mcnt.ensure((size_t)n_m + 4) || c->fbuf.ensure((size_t)n_m * 8 + 8) ||
-        c->fcnt.ensure((size_t)n_m + 4) || c->dpos.ensure((size_t)n_m * 8 + 8) || c->derr.ensure((size_t)n_m * 2 + 4) ||
-        c->dsplit.ensure((size_t)n_m * 4 + 4) || c->v_err.ensure((size_t)n_m * 2 + 4) || c->v_end.ensure((size_t)n_m * 2 + 4)) {
+    if (cm_ensure_candidate_arrays(c, n_m)) {
       cm_set_error(c, "out of device memory (candidates)");
       return CMGPU_ENOMEM;
     }
@@ -1011,10 +1032,24 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[0], 0));  // k_pack_reads (second stream) is done
     d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = (c->max_read_len + 31) / 32;
   }
+  // a batch with long candidate lists is verified in rounds: a count level of every list at a time, until the acceptance loop's
+  // threshold is known to stop it (CmDev::v_to, cm_stages.h) -- three levels, then whatever is left
+  c->use_rounds = c->use_perm && !c->p.split && (c->opt_coop & 8) != 0 &&
+                  !(c->v_to.ensure((size_t)n2 * 8 + 8) || c->v_from.ensure((size_t)n2 * 8 + 8) || c->v_minrej.ensure((size_t)n2 * 8 + 8) ||
+                    c->v_ninv.ensure((size_t)n2 * 8 + 8) || c->v_rcnt.ensure((size_t)n2 * 8 + 8) || c->v_roff.ensure((size_t)n2 * 8 + 8));
+  if (c->use_rounds) cm_fill_dev_range(c, d, rlo, rhi);
+  if (planes) { d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = (c->max_read_len + 31) / 32; }
   cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
+  if (c->use_rounds) cm_launch_k_s5_round_setup(d, n2, s);
   mark(c, "s5a_prepare");
   cm_launch_k_s5b_verify(d, n_m, n2, s);
+  if (c->use_rounds)
+    for (int round = 1; round <= 3; ++round) {
+      cm_launch_k_s5_round_decide(d, 2 * n2, round == 3, s);
+      cm_scan_u32(d.v_rcnt, d.v_roff, 2 * n2, (uint32_t *)c->scan_tmp.p, s);
+      cm_launch_k_s5b_round(d, 2 * n2, s);
+    }
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s5c_finalize(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);

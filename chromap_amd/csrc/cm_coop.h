@@ -656,46 +656,74 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
     }
     g.sync();
     const uint32_t np = ns * W;
-    // -- A: bounds of every (minimizer, window) pair: 2 np binary searches (the lower bound of es, the upper bound of ee), four of
-    //    them interleaved per lane -- the searches are chains of dependent loads at global-memory latency and nothing else, so the
-    //    requests in flight per lane are what the phase's duration divides by
-    const uint32_t nsrch = 2 * np;
-    for (uint32_t b0 = g.t; b0 < nsrch; b0 += 4 * G) {
-      uint32_t lo[4], hi[4];
+    // -- A: bounds of every (minimizer, window) pair, four pairs interleaved per lane -- the searches are chains of dependent loads at
+    //    global-memory latency and nothing else, so the requests in flight per lane are what the phase's duration divides by.  The lower
+    //    bound of es by bisection; the upper bound of ee by galloping from there (a window holds a handful of a minimizer's occurrences:
+    //    two or three probes in the cache lines the lower bound just touched instead of another ~13 random ones -- the rescue searches
+    //    of a repeat-rich batch are bound by the number of random reads of the occurrence table, 4 G of them per 4 M pairs of profile 2)
+    for (uint32_t q0 = g.t; q0 < np; q0 += 4 * G) {
+      uint32_t lo[4], hi[4], st[4];
       const uint64_t *o[4];
-      uint64_t key[4];
-      bool up[4];
+      uint64_t kes[4], kee[4];
+      bool act[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t bb = b0 + (uint32_t)u * G;
-        lo[u] = 0; hi[u] = 0; o[u] = d.occ; key[u] = 0; up[u] = false;
-        if (bb < nsrch) {
-          const uint32_t q = bb >> 1, s = q / W, w = q - s * W;
+        const uint32_t q = q0 + (uint32_t)u * G;
+        lo[u] = 0; hi[u] = 0; st[u] = 1; o[u] = d.occ; kes[u] = 0; kee[u] = 0; act[u] = false;
+        if (q < np) {
+          const uint32_t s = q / W, w = q - s * W;
           if (!(m.mps[s] >> 31)) {
             const uint64_t val = m.mval[s];
             hi[u] = (uint32_t)val;
             o[u] = d.occ + (uint32_t)(val >> 32);
-            up[u] = (bb & 1u) != 0;
-            key[u] = up[u] ? m.ee[w] : m.es[w];
+            kes[u] = m.es[w]; kee[u] = m.ee[w];
+            act[u] = true;
           }
         }
       }
-      for (;;) {
+      for (;;) {  // lower bounds: first index with o >> 1 >= es
         bool any = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (lo[u] < hi[u]) {
             const uint32_t mid = (lo[u] + hi[u]) >> 1;
-            const uint64_t v = o[u][mid] >> 1;
-            if (up[u] ? v <= key[u] : v < key[u]) lo[u] = mid + 1; else hi[u] = mid;  // lower: first >= es; upper: first > ee
+            if ((o[u][mid] >> 1) < kes[u]) lo[u] = mid + 1; else hi[u] = mid;
             any = true;
           }
         if (!any) break;
       }
+      uint32_t l2[4], h2[4], nocc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t bb = b0 + (uint32_t)u * G;
-        if (bb < nsrch) { if (bb & 1u) m.pb[bb >> 1] = lo[u]; else m.pa[bb >> 1] = lo[u]; }
+        const uint32_t q = q0 + (uint32_t)u * G;
+        if (q < np) m.pa[q] = lo[u];
+        nocc[u] = 0;
+        if (act[u]) { const uint32_t s = q / W; nocc[u] = (uint32_t)m.mval[s]; }
+        l2[u] = lo[u]; h2[u] = 0xffffffffu;  // every index below l2 holds a position <= ee; h2: an index known to hold one above (none yet)
+      }
+      for (;;) {  // upper bounds: gallop (probe l2, l2 + 1, l2 + 3, ...) until a position above ee or the run's end, then bisect
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!act[u]) continue;
+          if (h2[u] == 0xffffffffu) {  // galloping
+            const uint32_t probe = l2[u] + st[u] - 1;
+            if (probe >= nocc[u]) { h2[u] = nocc[u]; }
+            else if ((o[u][probe] >> 1) <= kee[u]) { l2[u] = probe + 1; st[u] <<= 1; }
+            else h2[u] = probe;
+            any = true;
+          } else if (l2[u] < h2[u]) {
+            const uint32_t mid = (l2[u] + h2[u]) >> 1;
+            if ((o[u][mid] >> 1) <= kee[u]) l2[u] = mid + 1; else h2[u] = mid;
+            any = true;
+          }
+        }
+        if (!any) break;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = q0 + (uint32_t)u * G;
+        if (q < np) m.pb[q] = act[u] ? l2[u] : 0u;
       }
     }
     g.sync();
@@ -1271,7 +1299,9 @@ template <class GT>
 CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m, const CmCoopSortMem &sm) {
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
   uint32_t ndp, ndn;
-  if (d.fcp[r] > m.P || d.fcn[r] > m.P) {  // longer than the work arrays: the acceptance loop by one lane -- but the draft mappings it
+  // (verification in rounds, CmDev::v_to: the loop stops at or before v_to, so nothing behind it is looked at)
+  const uint32_t nc_p = d.v_to ? d.v_to[2 * r] : d.fcp[r], nc_n = d.v_to ? d.v_to[2 * r + 1] : d.fcn[r];
+  if (nc_p > m.P || nc_n > m.P) {  // longer than the work arrays: the acceptance loop by one lane -- but the draft mappings it
     // leaves are sorted by the group like everybody's (round 4: they used to stay in candidate order, and the pairing stage's lane 0
     // then heap-sorted lists of thousands of entries in global memory: 38 + 18 ms per batch of the mosaic genome for ~200 reads)
     if (g.t == 0) cm_s5c_accept(d, r);
@@ -1281,8 +1311,8 @@ CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m,
   } else {
     CmTwo best = {d.min_err[r], d.n_best[r], d.second_err[r], d.n_second[r]};
     const uint32_t L = d.rlen[r];
-    ndp = cm_coop_draft_strand(d, g, m, L, 0, d.fbuf + op, d.fcnt + op, d.fcp[r], best, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
-    ndn = cm_coop_draft_strand(d, g, m, L, 1, d.fbuf + on, d.fcnt + on, d.fcn[r], best, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
+    ndp = cm_coop_draft_strand(d, g, m, L, 0, d.fbuf + op, d.fcnt + op, nc_p, best, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
+    ndn = cm_coop_draft_strand(d, g, m, L, 1, d.fbuf + on, d.fcnt + on, nc_n, best, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
     if (g.t == 0) {
       d.ndp[r] = ndp; d.ndn[r] = ndn;
       d.min_err[r] = best.lo; d.second_err[r] = best.hi; d.n_best[r] = best.n_lo; d.n_second[r] = best.n_hi;

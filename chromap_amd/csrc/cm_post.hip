@@ -194,6 +194,11 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
     uint32_t t = j, best_i = wi, best_nd = 0, best_ab = 0, maxq_mapq = r.mapq;
     bool have = false;
     while (t < n) {
+      if (t > j + PP_RUN_SERIAL) {  // a pile-up: the barcode groups of the run by a wave (k_pp_select_long)
+        long_list[atomicAdd(long_cnt, 1u)] = j;
+        line_len[j] = 0;
+        return;
+      }
       const uint32_t gi = idx[t];
       const PpRec gr = pp_load(store, gi);
       if (gr.rid != r.rid || gr.start != r.start || (!pp_is_se(cfg.kind) && gr.len != r.len)) break;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
 // Duplicate runs longer than PP_RUN_SERIAL, one wave each: the lanes test 64 records per step for membership (the run is the
 // contiguous prefix of members), keep the first record of maximal MAPQ (low-memory rule: a later record replaces the survivor
 // only with a strictly larger MAPQ, mapping_writer.h:252-262) or the run's last record (in-memory rule), and lane 0 finishes
-// the position as k_pp_select does.  Not used for bulk-level de-duplication of single-cell data (barcode groups inside a run).
+// the position as k_pp_select does.  Bulk-level de-duplication of single-cell data (barcode groups inside a run): the first branch.
 __global__ __launch_bounds__(64) void k_pp_select_long(const uint8_t *__restrict__ store, const uint64_t *__restrict__ bc,
                                                        const uint32_t *__restrict__ idx, uint32_t n, PpCfg cfg,
                                                        const uint32_t *__restrict__ name_off, uint32_t *__restrict__ win,
@@ -261,6 +266,78 @@ __global__ __launch_bounds__(64) void k_pp_select_long(const uint8_t *__restrict
     const uint32_t j = long_list[e];
     const uint32_t wi0 = idx[j];
     const PpRec r0 = pp_load(store, wi0);
+    if (cfg.dedup && cfg.bulk) {
+      // Bulk-level duplicate removal of single-cell data (mapping_writer.h:126-163, 202-345) for a long run: the records with the
+      // run's (rid, start, length) in steps of 64; barcode groups are consecutive; a group is represented by its LAST record and
+      // weighs 2 (two records or more) or 1; the survivor is the group of largest (weight, abundance of its barcode), the first one
+      // on ties.  The lane that holds a group's last record knows the group's size (its first record: the nearest group start at or
+      // before it in this step, or the start carried over from earlier steps) and proposes it; the proposals are reduced per step.
+      unsigned long long best_key = 0;  // weight << 32 | abundance, + 1 so that 0 means none
+      uint32_t best_pos = 0, maxq = r0.mapq, run_end = n, carried_start = j;
+      for (uint32_t base = j; base < n; base += 64) {
+        const uint32_t t = base + lane;
+        bool mem = false, next_same = false;
+        uint64_t gb = 0;
+        uint32_t qm = 0;
+        if (t < n) {
+          const uint32_t qi = idx[t];
+          const PpRec q = pp_load(store, qi);
+          mem = q.rid == r0.rid && q.start == r0.start && (pp_is_se(cfg.kind) || q.len == r0.len);
+          gb = bc[qi];
+          qm = q.mapq;
+          if (mem && t + 1 < n) {
+            const uint32_t ni = idx[t + 1];
+            const PpRec nq = pp_load(store, ni);
+            next_same = nq.rid == r0.rid && nq.start == r0.start && (pp_is_se(cfg.kind) || nq.len == r0.len) && bc[ni] == gb;
+          }
+        }
+        const unsigned long long mm = __ballot(mem);
+        const uint32_t pre = mm == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~mm) - 1);  // members before the first non-member
+        const bool in = lane < pre;
+        // group starts in this step: the run's first record, or a barcode that differs from the previous record's
+        const uint64_t pb = __shfl_up(gb, 1, 64);
+        const bool first = in && (t == j || (lane > 0 ? pb != gb : false));
+        // (lane 0 of a later step: its predecessor is the previous step's lane 63, whose next_same said whether the group goes on)
+        unsigned long long fm = __ballot(first);
+        const bool last = in && !next_same;
+        uint32_t gstart = carried_start;
+        const unsigned long long below = fm & ((lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+        if (below) gstart = base + (63u - (uint32_t)__clzll((long long)below));
+        if (in && qm > maxq) maxq = qm;
+        unsigned long long key = 0;
+        if (last) {
+          const uint32_t gsize = t - gstart + 1;
+          key = (((unsigned long long)(gsize >= 2 ? 2u : 1u) << 32) | pp_abundance(cfg, gb)) + 1ull;
+        }
+        uint32_t pos = t;
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long ok = __shfl_down(key, off, 64);
+          const uint32_t op = __shfl_down(pos, off, 64);
+          const uint32_t om = __shfl_down(maxq, off, 64);
+          if (ok > key || (ok == key && ok && op < pos)) { key = ok; pos = op; }
+          if (om > maxq) maxq = om;
+        }
+        key = __shfl(key, 0, 64); pos = __shfl(pos, 0, 64); maxq = __shfl(maxq, 0, 64);
+        if (key > best_key) { best_key = key; best_pos = pos; }  // (an equal key of a later step: the earlier group stays)
+        // the group that runs over the end of this step started at: its start in this step, or further back
+        {
+          const unsigned long long lastm = __ballot(last);
+          const bool open = pre == 64 && !((lastm >> 63) & 1ull);  // lane 63's record is a member and its group goes on
+          if (open && fm) carried_start = base + (63u - (uint32_t)__clzll((long long)fm));
+          // (open without a start in this step: the carried start stays; not open: the next step's lane 0 starts a group itself)
+          if (!open) carried_start = base + 64;
+        }
+        if (pre < 64) { run_end = base + pre; break; }
+      }
+      if (lane == 0) {
+        const uint32_t wi = idx[best_pos];
+        const PpRec r = pp_load(store, wi);
+        const uint32_t filter_mapq = run_end == n && cfg.last_section ? maxq : (uint32_t)r.mapq;
+        if ((int)filter_mapq < cfg.mapq_thr) line_len[j] = 0;
+        else pp_finish(j, r, wi, run_end - j, true, cfg, name_off, win, dups_out, line_len);
+      }
+      continue;
+    }
     const uint64_t rbc = pp_has_bc(cfg.kind) ? bc[wi0] : 0;
     PpRec rs = r0;
     if (cfg.inmem && cfg.tn5) pp_tn5(rs, cfg.kind);

@@ -373,6 +373,7 @@ extern "C" int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_s
   if (e != hipSuccess) { cm_set_error(nullptr, std::string("genome generation: ") + hipGetErrorString(e)); cmgpu_destroy(c); return CMGPU_EHIP; }
   rc = sy_build_index(c);
   if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
+  if (cm_build_fast_table(c, 1) != CMGPU_OK) { c->bkt_fast.release(); c->fmask = 0; c->err.clear(); }  // (see cmgpu_create)
   *out = c;
   return CMGPU_OK;
 }
@@ -394,6 +395,7 @@ extern "C" int cmgpu_create_from_reference(const cmgpu_ref_view *ref, int32_t km
   if (rc == CMGPU_OK) rc = cm_upload_reference(c, ref);
   if (rc == CMGPU_OK) rc = sy_build_index(c);
   if (rc) { cm_set_error(nullptr, c->err); cmgpu_destroy(c); return rc; }
+  if (cm_build_fast_table(c, 1) != CMGPU_OK) { c->bkt_fast.release(); c->fmask = 0; c->err.clear(); }  // (see cmgpu_create)
   *out = c;
   return CMGPU_OK;
 }

@@ -143,6 +143,67 @@ def test_device_text_equals_host_writer_on_random_records(kind, n_seq, span, ded
     g.close()
 
 
+@pytest.mark.parametrize("span,q", [(1, 0), (1, 30), (3, 1), (400, 30)])
+def test_bulk_level_dedup_of_single_cell_records_long_runs(span, q, tmp_path):
+    """duplicate removal at bulk level for single-cell data (mapping_writer.h:126-163, 202-345) on random records with pile-ups of
+    thousands of duplicates (span 1: four runs of ~15 000 records, taken by a wave each, k_pp_select_long) and with short runs
+    (one thread each), against the rule written out in numpy: runs of equal (rid, start, length), barcode groups inside a run
+    weigh 2 (two records or more) or 1, the survivor is the group of largest (weight, barcode abundance), the first on ties,
+    represented by its last record; MAPQ filter on that record, on the run's maximum for the very last run"""
+    from chromap_amd import ChromapGPU, _capi
+    fa, _, _ = datasets.case_inputs("toy_chip")
+    g = ChromapGPU(datasets.case_index("toy_chip"), fa, preset="chip")
+    n_seq = 2
+    g.names = [b"seq%d" % i for i in range(n_seq)]
+    p = _capi.default_params(None, remove_pcr_duplicates=1, low_memory_mode=1, tn5_shift=0, mapq_threshold=q, dedup_at_bulk_level=1)
+    rng = np.random.default_rng(77 + span + q)
+    n = 60000
+    rb = _random_records(rng, n, n_seq, span, bc=True)
+    # seven barcodes, 16 bases each; their abundances come from a sample of barcode reads (two of them equally frequent: the tie)
+    bl = 16
+    keys = np.array([rng.integers(0, 1 << 32) for _ in range(7)], np.uint64)
+    rb["barcode"] = keys[rng.integers(0, 7, n)]
+    abundance = {int(keys[i]): a for i, a in enumerate([5, 9, 9, 2, 30, 1, 14])}
+    seq = lambda k: bytes(b"ACGT"[(int(k) >> (2 * (bl - 1 - j))) & 3] for j in range(bl))
+    sample = b"".join(seq(k) * abundance[int(k)] for k in keys)
+    bco = np.arange(0, len(sample) + 1, bl, dtype=np.uint32)
+    kk = np.ascontiguousarray(keys)
+    assert g.L.cmgpu_set_whitelist(g.ctx, kk.ctypes.data, len(kk), bl) == 0
+    g.barcode_length = bl
+    g.compute_barcode_abundance(np.frombuffer(sample, np.uint8), bco)
+    g.store_clear()
+    g.store_append(rb.ctypes.data, n, barcoded=True)
+    lines, nbytes = g.store_format(_capi.TEXT_BED_PE_BC, params=p, barcode_length=bl)
+    got = g.store_text()
+    g.close()
+    # the rule in numpy
+    r = rb["r"]
+    order = np.lexsort((r["read_id"], r["is_unique"], r["direction"], r["mapq"], rb["barcode"], r["fragment_length"], r["fragment_start"], r["rid"]))
+    R, B = r[order], rb["barcode"][order]
+    runkey = np.stack([R["rid"].astype(np.int64), R["fragment_start"].astype(np.int64), R["fragment_length"].astype(np.int64)], 1)
+    starts = np.flatnonzero(np.r_[True, (np.diff(runkey, axis=0) != 0).any(1)])
+    ends = np.r_[starts[1:], n]
+    want = []
+    for a, e in zip(starts, ends):
+        gb = B[a:e]
+        gs = np.flatnonzero(np.r_[True, gb[1:] != gb[:-1]]) + a
+        ge = np.r_[gs[1:], e]
+        best = None
+        for x, y in zip(gs, ge):
+            cand = (2 if y - x >= 2 else 1, abundance[int(B[x])])
+            if best is None or cand > best[0]:
+                best = (cand, y - 1)
+        rep = R[best[1]]
+        fm = int(R["mapq"][a:e].max()) if e == n else int(rep["mapq"])
+        if fm < q:
+            continue
+        want.append(b"seq%d\t%d\t%d\t%s\t%d\n" % (rep["rid"], rep["fragment_start"], rep["fragment_start"] + rep["fragment_length"],
+                                                   seq(B[best[1]]), min(255, e - a)))
+    want = b"".join(want)
+    assert lines == want.count(b"\n")
+    assert got == want
+
+
 def test_empty_store_formats_to_nothing():
     from chromap_amd import ChromapGPU, _capi
     fa, _, _ = datasets.case_inputs("toy_chip")
