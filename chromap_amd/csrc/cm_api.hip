@@ -485,7 +485,7 @@ static int ensure_pair_arrays(cmgpu_ctx *c, uint32_t n) {
   ENS(min_err, n2 * 4) ENS(second_err, n2 * 4) ENS(n_best, n2 * 4) ENS(n_second, n2 * 4)
   ENS(pe_min, (size_t)n * 4) ENS(pe_second, (size_t)n * 4) ENS(pe_nbest, (size_t)n * 4) ENS(pe_nsecond, (size_t)n * 4)
   ENS(pe_first, (size_t)n * 4) ENS(pe_i1, (size_t)n * 4) ENS(pe_i2, (size_t)n * 4) ENS(pe_choice, (size_t)n * 4 * cm_rec_per_pair(c))
-  ENS(scan_tmp, cm_scan_tmp_words(2 * (uint32_t)n2 + 2) * 4)
+  ENS(scan_tmp, cm_scan_tmp_words((uint32_t)n2 + 1) * 4)
   ENS(srt_cnt, 64) ENS(srt_list, (2 * n2 + 2) * 4) ENS(coop_slab, (size_t)CM_SLAB_BLOCKS * cm_coop_slab_bytes(CM_SLAB_CAP)) ENS(hv_cnt, 256) ENS(hv_list, CM_HV_LISTS * (n2 + 1) * 4) ENS(perm_reads, (n2 + 1) * 4) ENS(perm_pairs, ((size_t)n + 1) * 4) ENS(hv_tmp, (n2 + 1 + n + 1) * 4) ENS(rs_list, ((size_t)cm_rescue_seg_cap((uint32_t)n2) * CM_RS_SEGS + 1) * 4) ENS(rs_cnt, CM_RS_SEGS * 64)
 #undef ENS
   return CMGPU_OK;
@@ -734,10 +734,6 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
   d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
   d.prof = (unsigned long long *)c->coop_prof.p;
-  if (c->use_rounds) {
-    d.v_to = (uint32_t *)c->v_to.p; d.v_from = (uint32_t *)c->v_from.p; d.v_minrej = (uint32_t *)c->v_minrej.p; d.v_ninv = (uint32_t *)c->v_ninv.p;
-    d.v_rcnt = (uint32_t *)c->v_rcnt.p; d.v_roff = (uint32_t *)c->v_roff.p;
-  }
   d.rs_pool = (uint64_t *)c->rs_pool.p; d.rs_pool_cap = c->rs_pool.p ? c->rs_pool_cap : 0u; d.rs_pool_off = (uint32_t *)c->rs_pool_off.p;
   d.abort = (const unsigned long long *)c->stats.p + CM_ST_ABORT;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
@@ -1032,24 +1028,10 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     HIPCHECK(c, hipStreamWaitEvent(s, c->chunk_ev[0], 0));  // k_pack_reads (second stream) is done
     d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = (c->max_read_len + 31) / 32;
   }
-  // a batch with long candidate lists is verified in rounds: a count level of every list at a time, until the acceptance loop's
-  // threshold is known to stop it (CmDev::v_to, cm_stages.h) -- three levels, then whatever is left
-  c->use_rounds = c->use_perm && !c->p.split && (c->opt_coop & 8) != 0 &&
-                  !(c->v_to.ensure((size_t)n2 * 8 + 8) || c->v_from.ensure((size_t)n2 * 8 + 8) || c->v_minrej.ensure((size_t)n2 * 8 + 8) ||
-                    c->v_ninv.ensure((size_t)n2 * 8 + 8) || c->v_rcnt.ensure((size_t)n2 * 8 + 8) || c->v_roff.ensure((size_t)n2 * 8 + 8));
-  if (c->use_rounds) cm_fill_dev_range(c, d, rlo, rhi);
-  if (planes) { d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = (c->max_read_len + 31) / 32; }
   cm_launch_k_s5a_prepare(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);
   cm_scan_u32(d.nv, d.v_off, n2, (uint32_t *)c->scan_tmp.p, s);  // the items' number stays on the device: never above n_m
-  if (c->use_rounds) cm_launch_k_s5_round_setup(d, n2, s);
   mark(c, "s5a_prepare");
   cm_launch_k_s5b_verify(d, n_m, n2, s);
-  if (c->use_rounds)
-    for (int round = 1; round <= 3; ++round) {
-      cm_launch_k_s5_round_decide(d, 2 * n2, round == 3, s);
-      cm_scan_u32(d.v_rcnt, d.v_roff, 2 * n2, (uint32_t *)c->scan_tmp.p, s);
-      cm_launch_k_s5b_round(d, 2 * n2, s);
-    }
   mark(c, "s5b_verify");
   HIPCHECK(c, hipMemsetAsync(c->srt_cnt.p, 0, 8, s));
   cm_launch_k_s5c_finalize(d, n2, s, (c->opt_coop & 8) != 0 && !c->p.split);

@@ -1299,8 +1299,7 @@ template <class GT>
 CM_HD void cm_coop_s5c(const CmDev &d, uint32_t r, GT &g, const CmCoopVerMem &m, const CmCoopSortMem &sm) {
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
   uint32_t ndp, ndn;
-  // (verification in rounds, CmDev::v_to: the loop stops at or before v_to, so nothing behind it is looked at)
-  const uint32_t nc_p = d.v_to ? d.v_to[2 * r] : d.fcp[r], nc_n = d.v_to ? d.v_to[2 * r + 1] : d.fcn[r];
+  const uint32_t nc_p = d.fcp[r], nc_n = d.fcn[r];
   if (nc_p > m.P || nc_n > m.P) {  // longer than the work arrays: the acceptance loop by one lane -- but the draft mappings it
     // leaves are sorted by the group like everybody's (round 4: they used to stay in candidate order, and the pairing stage's lane 0
     // then heap-sorted lists of thousands of entries in global memory: 38 + 18 ms per batch of the mosaic genome for ~200 reads)

@@ -121,8 +121,6 @@ struct cmgpu_ctx {
   DevBuf mm_marks;   // cursor after every chunk of pairs: the range of minimizers a chunk's probe launch covers
   DevBuf part_cnt;  // cmgpu_records_partition: per-owner counts and cursors
   DevBuf rs_pool, rs_pool_off;  // CmDev::rs_pool
-  DevBuf v_to, v_from, v_minrej, v_ninv, v_rcnt, v_roff;  // verification in rounds (CmDev::v_to)
-  bool use_rounds = false;
   uint32_t rs_pool_cap = 0;
   uint64_t rs_pool_want = 0;   // entries the previous range asked of the pool
   DevBuf coop_slab, hv_cnt, hv_list, perm_reads, perm_pairs, hv_tmp, srt_cnt, srt_list, rs_list, rs_cnt;
@@ -200,7 +198,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &rec_dense_b, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &rs_pool, &rs_pool_off, &v_to, &v_from, &v_minrej, &v_ninv, &v_rcnt, &v_roff, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &rec_dense_b, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &rs_pool, &rs_pool_off, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
   }
 };
 

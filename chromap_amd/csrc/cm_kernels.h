@@ -53,9 +53,6 @@ void cm_launch_k_stats(const CmDev &d, uint32_t n, unsigned long long *partials,
 
 void cm_build_heavy_last(const CmDev &d, uint32_t n_pairs, uint32_t *fr, uint32_t *sr, uint32_t *fp, uint32_t *sp, uint32_t *perm_reads,
                          uint32_t *perm_pairs, uint32_t *scan_tmp, hipStream_t s);
-void cm_launch_k_s5_round_setup(const CmDev &d, uint32_t n_reads, hipStream_t s);
-void cm_launch_k_s5_round_decide(const CmDev &d, uint32_t n_lists, bool last, hipStream_t s);
-void cm_launch_k_s5b_round(const CmDev &d, uint32_t n_lists, hipStream_t s);
 void cm_launch_k_pack_ref(const uint8_t *ref, uint64_t n_bytes, CmPlRec *pl, hipStream_t s);
 void cm_launch_k_pack_reads(const CmDev &d, uint32_t n_reads, hipStream_t s);
 void cm_launch_k_check_cap(const unsigned long long *total, unsigned long long cap, unsigned long long *flag, hipStream_t s);

@@ -1203,31 +1203,6 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5b_verify(CmDev d, uint32_t n_rea
   const uint32_t n_items = d.v_off[n_reads];
   for (uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x; j < n_items; j += gridDim.x * CM_BLOCK) cm_s5b_verify_item(d, j, n_reads);
 }
-// verification in rounds (CmDev::v_to, cm_stages.h): round 0's ranges per read, the decision per list after a round, a later round's items
-__global__ __launch_bounds__(CM_BLOCK) void k_s5_round_setup(CmDev d, uint32_t n_reads) {
-  if (d.abort && *d.abort) return;
-  const uint32_t r = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (r < n_reads) cm_s5_round_setup(d, r);
-}
-__global__ __launch_bounds__(CM_BLOCK) void k_s5_round_decide(CmDev d, uint32_t n_lists, uint32_t last) {
-  if (d.abort && *d.abort) return;
-  const uint32_t l = blockIdx.x * CM_BLOCK + threadIdx.x;
-  if (l < n_lists) d.v_rcnt[l] = cm_s5_round_decide(d, l, last != 0);
-}
-__global__ __launch_bounds__(CM_BLOCK) void k_s5b_round(CmDev d, uint32_t n_lists) {
-  if (d.abort && *d.abort) return;
-  const uint32_t n_items = d.v_roff[n_lists];
-  for (uint32_t j = blockIdx.x * CM_BLOCK + threadIdx.x; j < n_items; j += gridDim.x * CM_BLOCK) cm_s5b_round_item(d, j, n_lists);
-}
-void cm_launch_k_s5_round_setup(const CmDev &d, uint32_t n_reads, hipStream_t s) {
-  if (n_reads) hipLaunchKernelGGL(k_s5_round_setup, grid_for_n(n_reads), dim3(CM_BLOCK), 0, s, d, n_reads);
-}
-void cm_launch_k_s5_round_decide(const CmDev &d, uint32_t n_lists, bool last, hipStream_t s) {
-  if (n_lists) hipLaunchKernelGGL(k_s5_round_decide, grid_for_n(n_lists), dim3(CM_BLOCK), 0, s, d, n_lists, last ? 1u : 0u);
-}
-void cm_launch_k_s5b_round(const CmDev &d, uint32_t n_lists, hipStream_t s) {
-  if (n_lists) hipLaunchKernelGGL(k_s5b_round, dim3(8192), dim3(CM_BLOCK), 0, s, d, n_lists);  // (a later round's items are few; the grid strides)
-}
 // --SAM has its own instantiations: the alignment's register window must not cost the BED path occupancy
 // S6a.  coop: a pair with a draft-mapping list longer than CM_S6A_COOP_MIN goes to list 13, where a wave runs its two sweeps with
 // the second list of each direction staged in shared memory -- or, when read 2 has a list longer than CM_S6A_P_WAVE, to list 18,

@@ -2573,89 +2573,14 @@ CM_HD void cm_s5b_verify_item(const CmDev &d, uint32_t j, uint32_t n_reads) {
   const uint32_t ci = strand ? li - ncp : li;
   cm_s5b_verify_at(d, r, strand, ci);
 }
-// ---- verification in rounds (CmDev::v_to) ------------------------------------------------------------------------------
-// The candidates are sorted by count, descending.  A round aligns the candidates of one count level; the loop of the reference goes
-// on into the next level -- whose counts are lower than every count so far -- iff its threshold is still 0 there, i.e. iff no
-// candidate of a FINISHED group has been rejected: with v valid candidates among the first K, the finished groups hold the first
-// floor(v / lanes) * lanes of them.  The rule below stops only when a rejected candidate's INDEX lies below that number (its rank
-// among the valid ones is not larger): sufficient, so a stopped list has K >= B, the loop's break position, and everything the loop
-// looks at has been aligned; a list that is not stopped just aligns more.  Lists shorter than a group, or with lanes == 0, have no
-// threshold: all of their candidates in round 0.
-CM_HD uint32_t cm_atomic_min_u32(uint32_t *p, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return atomicMin(p, v);
-#else
-  const uint32_t old = *p;
-  if (v < old) *p = v;
-  return old;
-#endif
-}
-CM_HD uint32_t cm_atomic_add_u32(uint32_t *p, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return atomicAdd(p, v);
-#else
-  const uint32_t old = *p;
-  *p = old + v;
-  return old;
-#endif
-}
-// first index behind `from` whose count is below cc[from] (cc descending)
-CM_HD uint32_t cm_s5_level_end(const uint8_t *cc, uint32_t from, uint32_t nc) {
-  const uint8_t c = cc[from];
-  uint32_t lo = from + 1, hi = nc;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (cc[mid] >= c) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-CM_HD const uint8_t *cm_s5_list_counts(const CmDev &d, uint32_t l, uint32_t *nc) {
-  const uint32_t r = l >> 1;
-  *nc = (l & 1u) ? d.fcn[r] : d.fcp[r];
-  return d.fcnt + d.m_off[r] + ((l & 1u) ? d.ncp[r] + d.resc_p[r] : 0u);
-}
-// round 0 of read r's two lists (after its candidate lists are sorted)
-CM_HD void cm_s5_round_setup(const CmDev &d, uint32_t r) {
-  for (uint32_t s = 0; s < 2; ++s) {
-    const uint32_t l = 2 * r + s;
-    uint32_t nc;
-    const uint8_t *cc = cm_s5_list_counts(d, l, &nc);
-    if (d.nv[r] == 0) nc = 0;
-    d.v_from[l] = 0; d.v_minrej[l] = 0xffffffffu; d.v_ninv[l] = 0;
-    d.v_to[l] = (nc == 0 || d.p.lanes == 0 || nc < (uint32_t)d.p.lanes) ? nc : cm_s5_level_end(cc, 0, nc);
-  }
-}
-// after a round: does list l go on?  Sets the next round's range; returns its number of candidates (0: the list is done).
-// last: the next round takes whatever is left.
-CM_HD uint32_t cm_s5_round_decide(const CmDev &d, uint32_t l, bool last) {
-  uint32_t nc;
-  const uint8_t *cc = cm_s5_list_counts(d, l, &nc);
-  if (d.nv[l >> 1] == 0) nc = 0;
-  const uint32_t K = d.v_to[l];
-  d.v_from[l] = K;
-  if (K >= nc) return 0;
-  const uint32_t lanes = (uint32_t)d.p.lanes;  // (> 0 and <= nc: round 0 took every other list whole)
-  const uint32_t finished = (K - d.v_ninv[l]) / lanes * lanes;
-  if (d.v_minrej[l] < finished) return 0;  // the loop's threshold is above the next level's count: it stops at or before K
-  const uint32_t to = last ? nc : cm_s5_level_end(cc, K, nc);
-  d.v_to[l] = to;
-  return to - K;
-}
-
 // candidate ci of read r's strand list: the banded alignment, result to v_err / v_end
 CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci) {
   const uint32_t o = d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0) + ci;
-  const uint32_t l = 2 * r + (uint32_t)strand;
-  if (d.v_to && ci >= d.v_to[l]) { d.v_err[o] = 0; d.v_end[o] = 0; return; }  // (not aligned unless a later round reaches it: the loop never looks)
   const uint64_t cpos = d.fbuf[o];
   const uint32_t L = d.rlen[r];
   const uint32_t rid = (uint32_t)(cpos >> 32);
   const uint32_t position = strand == 0 ? (uint32_t)cpos : (uint32_t)cpos - L + 1;
-  if (!cm_valid_candidate(d, rid, position, L)) {
-    d.v_err[o] = CM_V_INVALID; d.v_end[o] = 0;
-    if (d.v_to) (void)cm_atomic_add_u32(&d.v_ninv[l], 1u);
-    return;
-  }
+  if (!cm_valid_candidate(d, rid, position, L)) { d.v_err[o] = CM_V_INVALID; d.v_end[o] = 0; return; }
   int end_pos = (int)L;
   int ne;
   if (d.ref_pl && d.read_pl)  // the same alignment on bit planes (cm_banded_align_planes)
@@ -2664,16 +2589,6 @@ CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci)
   else ne = cm_verify_compute(d, cm_read_ptr(d, r), L, strand, cpos, &end_pos);
   d.v_err[o] = (int16_t)ne;
   d.v_end[o] = (int16_t)end_pos;
-  if (d.v_to && ne > d.p.e) (void)cm_atomic_min_u32(&d.v_minrej[l], ci);
-}
-// item j of a later round: the lists' ranges laid end to end (v_roff: exclusive scan of the rounds' counts, n_lists + 1 entries)
-CM_HD void cm_s5b_round_item(const CmDev &d, uint32_t j, uint32_t n_lists) {
-  uint32_t lo = 0, hi = n_lists;  // largest l with v_roff[l] <= j (lists without candidates share their successor's offset)
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (d.v_roff[mid] <= j) lo = mid; else hi = mid;
-  }
-  cm_s5b_verify_at(d, lo >> 1, (int)(lo & 1u), d.v_from[lo] + (j - d.v_roff[lo]));
 }
 
 CM_HD void cm_s5c_accept(const CmDev &d, uint32_t r);
@@ -2688,10 +2603,8 @@ CM_HD void cm_s5c_accept(const CmDev &d, uint32_t r) {
   const uint32_t L = d.rlen[r];
   const uint8_t *read = cm_read_ptr(d, r);
   const uint32_t op = d.m_off[r], on = d.m_off[r] + d.ncp[r] + d.resc_p[r];
-  // (verification in rounds: a list's loop stops at or before v_to, or v_to is its length)
-  const uint32_t np_ = d.v_to ? d.v_to[2 * r] : d.fcp[r], nn_ = d.v_to ? d.v_to[2 * r + 1] : d.fcn[r];
-  d.ndp[r] = cm_draft_strand(d, read, L, 0, d.fbuf + op, d.fcnt + op, np_, bst, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
-  d.ndn[r] = cm_draft_strand(d, read, L, 1, d.fbuf + on, d.fcnt + on, nn_, bst, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
+  d.ndp[r] = cm_draft_strand(d, read, L, 0, d.fbuf + op, d.fcnt + op, d.fcp[r], bst, d.dpos + op, d.derr + op, d.v_err + op, d.v_end + op);
+  d.ndn[r] = cm_draft_strand(d, read, L, 1, d.fbuf + on, d.fcnt + on, d.fcn[r], bst, d.dpos + on, d.derr + on, d.v_err + on, d.v_end + on);
   d.min_err[r] = bst.min_err; d.second_err[r] = bst.second_err;
   d.n_best[r] = bst.n_best; d.n_second[r] = bst.n_second;
 }

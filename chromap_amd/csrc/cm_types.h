@@ -184,12 +184,6 @@ struct CmDev {
   uint32_t *v_off;      // [2n+1]
   int16_t *v_err;       // per candidate (candidate offsets): edit distance, e+1 = rejected, CM_V_INVALID = invalid position
   int16_t *v_end;       // per candidate: mapping end position in the window
-  // ---- verification in rounds (batches with long candidate lists; nullptr: every candidate is aligned).  The acceptance loop
-  //      (draft_mapping_generator.cc:159-357) stops at the first candidate whose seed count is below its threshold, and the threshold
-  //      becomes non-zero with the first rejection inside a finished group of `lanes` candidates: a read from a repeat family verifies
-  //      the few candidates of its highest counts and leaves hundreds unaligned.  List l = 2 r + strand: v_to[l] candidates are (being)
-  //      aligned, v_from[l]: where the current round starts, v_minrej[l]: smallest index of a rejected one, v_ninv[l]: invalid ones.
-  uint32_t *v_to, *v_from, *v_minrej, *v_ninv, *v_rcnt, *v_roff;
   int32_t *min_err, *second_err, *n_best, *n_second; // [2n]
   // ---- pair level
   int32_t *pe_min, *pe_second, *pe_nbest, *pe_nsecond; // [n]

@@ -35,10 +35,7 @@ static EmuCoop g_coop = {0, 0, 0, 0, 0};
 static bool g_planes = true;  // the bit-plane verification (k_pack_ref / k_pack_reads + cm_banded_align_planes); 0: the byte form
 extern "C" void hostemu_set_planes(int on) { g_planes = on != 0; }
 static unsigned long long g_coop_items[10];
-static unsigned long long g_rounds_later = 0;    // candidates aligned in rounds 1..3
-extern "C" unsigned long long hostemu_rounds_later() { return g_rounds_later; }
-static unsigned long long g_rounds_skipped = 0;  // candidates the verification rounds left unaligned
-extern "C" unsigned long long hostemu_rounds_skipped() { return g_rounds_skipped; }  // items that went through each cooperative stage / fell back (tests look at them)
+  // items that went through each cooperative stage / fell back (tests look at them)
 extern "C" void hostemu_set_coop(int G, uint32_t thr, uint32_t P, uint32_t MM, uint32_t RB) {
   g_coop = EmuCoop{G, thr, P, MM, RB};
   memset(g_coop_items, 0, sizeof(g_coop_items));
@@ -408,32 +405,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   };
   s5_groups(0);  // k_s5_sort_coop: the heavy reads' candidate lists
   scan(d.nv, d.v_off, n2);
-  // verification in rounds (CmDev::v_to: what a batch with long candidate lists does) whenever the cooperative forms are on
-  std::vector<uint32_t> v_to, v_from, v_minrej, v_ninv, v_rcnt, v_roff;
-  const bool rounds = g_coop.G != 0 && !d.p.split;
-  if (rounds) {
-    const size_t nl = 2 * (size_t)n2 + 2;
-    v_to.assign(nl, 0); v_from.assign(nl, 0); v_minrej.assign(nl, 0); v_ninv.assign(nl, 0); v_rcnt.assign(nl, 0); v_roff.assign(nl, 0);
-    d.v_to = v_to.data(); d.v_from = v_from.data(); d.v_minrej = v_minrej.data(); d.v_ninv = v_ninv.data(); d.v_rcnt = v_rcnt.data(); d.v_roff = v_roff.data();
-    for (uint32_t r = 0; r < n2; ++r) cm_s5_round_setup(d, r);
-  }
   for (uint32_t j = 0; j < d.v_off[n2]; ++j) cm_s5b_verify_item(d, j, n2);
-  if (rounds)
-    for (int round = 1; round <= 3; ++round) {
-      for (uint32_t l = 0; l < 2 * n2; ++l) d.v_rcnt[l] = cm_s5_round_decide(d, l, round == 3);
-      scan(d.v_rcnt, d.v_roff, 2 * n2);
-      for (uint32_t j = 0; j < d.v_roff[2 * n2]; ++j) cm_s5b_round_item(d, j, 2 * n2);
-      g_rounds_later += d.v_roff[2 * n2];
-    }
-  if (rounds) {  // candidates the rounds left unaligned (the acceptance loop must never look at them: poisoned, not zero, here)
-    for (uint32_t l = 0; l < 2 * n2; ++l) {
-      uint32_t nc;
-      (void)cm_s5_list_counts(d, l, &nc);
-      if (d.nv[l >> 1] == 0) continue;
-      const uint32_t r = l >> 1, o = d.m_off[r] + ((l & 1u) ? d.ncp[r] + d.resc_p[r] : 0u);
-      for (uint32_t ci = d.v_to[l]; ci < nc; ++ci) { d.v_err[o + ci] = 0x7abc; d.v_end[o + ci] = 0x7abc; g_rounds_skipped += 1; }
-    }
-  }
   for (uint32_t r = 0; r < n2; ++r) cm_s5c_finalize(d, r, s5_min);
   g_coop_items[4] += s5_heavy.size();
   s5_groups(1);  // k_s5c_coop

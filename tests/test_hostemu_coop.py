@@ -59,14 +59,8 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
             _set(L, 0, 0, 0, 0, 0, 0, 0)
         factory.items = items
         return rec, k, st.as_dict()
-    L.hostemu_rounds_skipped.restype = C.c_ulonglong
-    L.hostemu_rounds_later.restype = C.c_ulonglong
-    skipped0, later0 = L.hostemu_rounds_skipped(), L.hostemu_rounds_later()
     run_case(factory, cfg, tmp_path)
     done, declined = factory.items[0], factory.items[1]
-    if cfg[1] != "hic":  # verification in rounds: some candidates were left unaligned (and poisoned), some aligned in a later round
-        assert L.hostemu_rounds_skipped() > skipped0, "the verification rounds skipped nothing"
-        assert L.hostemu_rounds_later() > later0, "no candidate was aligned in a later round"
     if cfg[0] == 3 and geo[1] >= 64:
         return  # this configuration's seed-frequency caps leave no list that long
     assert done > 0, "no read went through the cooperative hit-list stage"
