@@ -109,6 +109,7 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     c->opt_planes = value ? 1 : 0;  // (the planes stay where they are: contexts made by cmgpu_create_shared may hold views of them)
   } else if (n == "speculative_sizes") {  // 0: every batch waits for the total of its candidate lists before sizing their arrays
     c->opt_spec = value ? 1 : 0;
+    if (value < 0) { c->cls_seen = 0; memset(c->cls_age, 0, sizeof(c->cls_age)); }  // tests: an empty speculative launch set -- the next range finds classes with items and is mapped again
   } else if (n == "debug_candidate_capacity") {  // tests: pretend the previous batch left this much room (forces the re-run path)
     // (the arrays are made to hold what is claimed: the device-side check trusts m_cap)
     if (value > 0 && cm_ensure_candidate_arrays(c, (uint64_t)value)) { cm_set_error(c, "out of device memory (candidates)"); return CMGPU_ENOMEM; }
@@ -456,6 +457,7 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
   if (c->stream_d2h) (void)hipStreamDestroy(c->stream_d2h);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream_pack) (void)hipStreamDestroy(c->stream_pack);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return CMGPU_OK;
@@ -733,6 +735,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.perm_reads = c->use_perm ? (const uint32_t *)c->perm_reads.p : nullptr;
   d.perm_pairs = c->use_perm ? (const uint32_t *)c->perm_pairs.p : nullptr;
   d.coop_slab = (uint8_t *)c->coop_slab.p; d.coop_slab_cap = CM_SLAB_CAP; d.coop_slab_blocks = CM_SLAB_BLOCKS;
+  d.cls_mask = c->cls_all || !c->opt_spec ? ~0ull : c->cls_seen;
   d.prof = (unsigned long long *)c->coop_prof.p;
   d.rs_pool = (uint64_t *)c->rs_pool.p; d.rs_pool_cap = c->rs_pool.p ? c->rs_pool_cap : 0u; d.rs_pool_off = (uint32_t *)c->rs_pool_off.p;
   d.abort = (const unsigned long long *)c->stats.p + CM_ST_ABORT;
@@ -940,14 +943,21 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // the alignments of S5b run on bit planes: this range's reads, both orientations, packed on the second stream (idle from here
   // on) under S3 and S4 -- the trimmed lengths are final
   bool planes = c->ref_pl_words != 0;
-  if (planes && c->read_planes.ensure((size_t)n2 * 6 * ((c->max_read_len + 31) / 32) * 4 + 16)) planes = false;  // (no room: this range on bytes)
+  if (planes && c->read_planes.ensure((size_t)n2 * cm_read_pl_stride((c->max_read_len + 31) / 32) * 4 + 16)) planes = false;  // (no room: this range on bytes)
   if (planes) {
     const uint32_t pw = (c->max_read_len + 31) / 32;
+    // on a stream of the highest priority: at the mapping streams' priority the kernel only got the slots three lanes' S3 / S4 kernels
+    // left over and S5 waited for it (2 x 150: 4 ms of a 21 ms step once the empty class launches no longer padded S4)
+    if (!c->stream_pack) {
+      int prio_least = 0, prio_greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+      HIPCHECK(c, hipStreamCreateWithPriority(&c->stream_pack, hipStreamNonBlocking, prio_greatest));
+    }
     HIPCHECK(c, hipEventRecord(c->chunk_ev[1], s));
-    HIPCHECK(c, hipStreamWaitEvent(c->stream2, c->chunk_ev[1], 0));
+    HIPCHECK(c, hipStreamWaitEvent(c->stream_pack, c->chunk_ev[1], 0));
     d.read_pl = (uint32_t *)c->read_planes.p; d.read_pl_w = pw;
-    cm_launch_k_pack_reads(d, n2, c->stream2);
-    HIPCHECK(c, hipEventRecord(c->chunk_ev[0], c->stream2));
+    cm_launch_k_pack_reads(d, n2, c->stream_pack);
+    HIPCHECK(c, hipEventRecord(c->chunk_ev[0], c->stream_pack));
   }
   // S3: hit counts -> offsets -> candidates
   if (!s3a_done) {
@@ -1057,10 +1067,31 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   mark(c, "s6bc_multimappers");
   cm_launch_k_stats(d, n, (unsigned long long *)c->partials.p, s);
   unsigned long long hst[CM_ST_N];
+  uint32_t h_cls[CM_HV_LISTS];
   HIPCHECK(c, hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, s));
+  HIPCHECK(c, hipMemcpyAsync(h_cls, c->hv_cnt.p, sizeof(h_cls), hipMemcpyDeviceToHost, s));
   HIPCHECK(c, cm_stream_sync(s));
   mark(c, "stats");
   HIPCHECK(c, cm_stream_sync(s));
+  {  // speculative launch set: a class with items whose kernels were not launched -> the range again with every class on
+    unsigned long long seen = 0;
+    for (uint32_t l = 6; l < CM_HV_LISTS; ++l) if (h_cls[l]) seen |= 1ull << l;
+    const unsigned long long launched = c->cls_all || !c->opt_spec ? ~0ull : c->cls_seen;
+    if (!(spec && hst[CM_ST_ABORT]) && (seen & ~launched)) {
+      c->cls_all = true;
+      const int rc2 = map_range(c, rlo, rhi, k_out, stats, allow_spec);
+      c->cls_all = false;
+      return rc2;
+    }
+    if (!(spec && hst[CM_ST_ABORT])) {
+      unsigned long long keep = 0;
+      for (uint32_t l = 0; l < 64; ++l) {
+        if ((seen >> l) & 1ull) c->cls_age[l] = 32; else if (c->cls_age[l]) --c->cls_age[l];
+        if (c->cls_age[l]) keep |= 1ull << l;
+      }
+      c->cls_seen = keep;
+    }
+  }
   if (spec && hst[CM_ST_ABORT]) {  // this batch needs more room than the previous one left: again, with its own totals
     c->pred_m_ok = false;
     return map_range(c, rlo, rhi, k_out, stats, false);

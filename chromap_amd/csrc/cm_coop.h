@@ -846,6 +846,7 @@ CM_HD void cm_coop_s4b_fill(const CmDev &d, uint32_t r, GT &g, const CmCoopRescu
   uint64_t *P = d.mbuf + d.m_off[r];
   uint64_t *N = P + ncp + rp;
   uint32_t cnt, rl;
+  if (g.t == 0) { d.mcp[r] = 0; d.mcn[r] = 0; }  // (until the group that sorts and merges the hits has run)
   const uint32_t off_p = d.rs_pool ? d.rs_pool_off[2 * (size_t)r] : 0xffffffffu, off_n = d.rs_pool ? d.rs_pool_off[2 * (size_t)r + 1] : 0xffffffffu;
   if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) {
     if (off_n != 0xffffffffu) { for (uint32_t i = g.t; i < rn; i += (uint32_t)GT::G) N[ncn + i] = d.rs_pool[off_n + i]; }  // found while counting

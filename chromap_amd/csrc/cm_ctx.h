@@ -63,6 +63,7 @@ struct cmgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // index probe of chunk c runs here next to the minimizer pass of chunk c+1
+  hipStream_t stream_pack = nullptr; // k_pack_reads under S3 / S4, highest priority (a fraction of a millisecond of work that S5 waits for)
   hipEvent_t chunk_ev[CM_MM_CHUNKS + 1] = {};  // minimizers of chunk c written / all probes done
   std::string err;
   cmgpu_params hp;
@@ -120,6 +121,9 @@ struct cmgpu_ctx {
   DevBuf mm_cursor;  // k_prep_mm: next free entry of the dense minimizer arrays
   DevBuf mm_marks;   // cursor after every chunk of pairs: the range of minimizers a chunk's probe launch covers
   DevBuf part_cnt;  // cmgpu_records_partition: per-owner counts and cursors
+  unsigned long long cls_seen = ~0ull;  // long-list classes whose kernels the next range launches: those that had items in one of the last 32 ranges (all: nothing known yet)
+  uint8_t cls_age[64] = {};             // ranges a class stays in the set without items (a class with a handful of items per batch comes and goes)
+  bool cls_all = false;                 // this range is a re-run with every class on
   DevBuf rs_pool, rs_pool_off;  // CmDev::rs_pool
   uint32_t rs_pool_cap = 0;
   uint64_t rs_pool_want = 0;   // entries the previous range asked of the pool

@@ -857,6 +857,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t
   const bool mine = i0 < n && !(d.aug[i] && d.resc_n[i] + d.resc_p[i] > 0);  // the others: k_s4b_rescue_list
   const bool to_wave = mine && coop && d.m_tot[i] > CM_S4B_COPY_MIN;
   if (mine && !to_wave) cm_s4b_rescue_merge(d, i);
+  if (to_wave) { d.mcp[i] = 0; d.mcn[i] = 0; }  // (until list 6's wave has copied the lists)
   if (coop) cm_wave_append(d.hv_list + (size_t)6 * d.hv_stride, d.hv_cnt + 6, to_wave, i);
 }
 // fill pass of one direction by a group: per-minimizer counts to LDS, lane 0 turns them into offsets (minimizer order = the
@@ -924,6 +925,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
         cm_group_rescue_fill(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], t, sh_cnt[grp], N + ncn);
       if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0)
         cm_group_rescue_fill(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], t, sh_cnt[grp], P + ncp);
+      if (t == 0) { d.mcp[r] = 0; d.mcn[r] = 0; }  // (until the hits are sorted and merged: here, or by the class's group)
       __threadfence_block();
       cls = cm_rescue_coop_class(d, r, coop);
       if (t == 0 && !cls) cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);  // sort, cluster, merge of the hits the group wrote
@@ -1724,6 +1726,12 @@ void cm_s3b_heavy_classes(uint32_t *hv_max, uint32_t *hv_big) {
   hv_max[0] = 512; hv_max[1] = 1024; hv_max[2] = 2048; hv_max[3] = 4096;
   *hv_big = st == 1 ? 8192 : 0;
 }
+// Speculative launch set (CmDev::cls_mask): the kernels of a long-list class are launched when the class had items in the context's
+// previous range (or always: the first range, a re-run).  An empty launch is not free -- a class kernel asks for up to 150 KB of shared
+// memory and waits for a CU that has it, under three lanes' other kernels: 0.2-0.5 ms each, 8 % of a step of the hic workload
+// (profiles/r04p_hic_kernel_stats.csv: k_s4c_coop<1024, false> 0.49 ms with no pair to work on).  The host compares the lists' counts
+// with the mask at the end of the range and maps the range again with every class on if an unlaunched one had items.
+static inline bool cm_cls_on(const CmDev &d, uint32_t list) { return (d.cls_mask >> list) & 1ull; }
 // the largest dynamic LDS allocation a kernel of this device may ask for, opted in once per device and kernel
 template <class K>
 static bool cm_lds_optin(K kernel, size_t bytes) {
@@ -1864,7 +1872,7 @@ static inline dim3 rescue_list_grid(uint32_t n_reads) {
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop) {
   if (!n_reads) return;
   hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), coop ? 1u : 0u);
-  if (coop) hipLaunchKernelGGL(k_s4a_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);
+  if ((coop) && cm_cls_on(d, 23)) hipLaunchKernelGGL(k_s4a_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);
 }
 // the per-read part (reads without rescue hits) and, coop: the reads whose long lists a wave copies
 static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {
@@ -1900,17 +1908,17 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
   // list 23's reads were counted by waves whenever the option is on: they are filled by waves too (all == false: the groups that
   // would sort long lists do not fit this device -- every list is then finished by the wave's lane 0)
-  if (coop) hipLaunchKernelGGL(k_s4b_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
+  if ((coop) && cm_cls_on(d, 23)) hipLaunchKernelGGL(k_s4b_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
   if (!all) return;
   uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
   if (blocks > 2048) blocks = 2048;
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
-  hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB, 0u);
-  if (d.hv_max[1] > d.hv_max[0]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB, 0u);
-  if (d.hv_max[2] > d.hv_max[1]) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
-  if (d.rs_max3 > d.hv_max[2]) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.rs_max3, RB, 0u);
-  if (d.rs_big > d.rs_max3) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[4], s, d, lst(26), (const uint32_t *)(d.hv_cnt + 26), d.rs_big, RB, 0u);
-  if (d.coop_slab)  // lists beyond the largest class: on the blocks' slabs of global memory
+  if (cm_cls_on(d, 6)) hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB, 0u);
+  if ((d.hv_max[1] > d.hv_max[0]) && cm_cls_on(d, 7)) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB, 0u);
+  if ((d.hv_max[2] > d.hv_max[1]) && cm_cls_on(d, 8)) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
+  if ((d.rs_max3 > d.hv_max[2]) && cm_cls_on(d, 11)) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.rs_max3, RB, 0u);
+  if ((d.rs_big > d.rs_max3) && cm_cls_on(d, 26)) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[4], s, d, lst(26), (const uint32_t *)(d.hv_cnt + 26), d.rs_big, RB, 0u);
+  if (d.coop_slab && cm_cls_on(d, 15))  // lists beyond the largest class: on the blocks' slabs of global memory
     hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[4], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), d.rs_big > d.rs_max3 ? d.rs_big : d.rs_max3, RB, 1u);
 }
 // coop: the cmgpu_set_option "coop" bit mask (bit 2: pairs with long lists to groups; bit 3: the S5 waves sort the heavy reads' lists)
@@ -1929,19 +1937,19 @@ void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t 
   uint32_t blocks = n / 2048 + 64;
   if (blocks > 4096) blocks = 4096;
   const size_t gs = ((cm_coop_pair_mem_bytes(CM_S4C_P_SMALL) + 15) & ~(size_t)15) + CM_XW_BYTES;
-  hipLaunchKernelGGL((k_s4c_coop<64, true>), dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gs, s, d, CM_S4C_P_SMALL, 27u, coop);  // a wave per pair
-  hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
-  hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
-  if (d2.s4c_pbig)
+  if (cm_cls_on(d, 27)) hipLaunchKernelGGL((k_s4c_coop<64, true>), dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gs, s, d, CM_S4C_P_SMALL, 27u, coop);  // a wave per pair
+  if (cm_cls_on(d, 9)) hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
+  if (cm_cls_on(d, 14)) hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
+  if (d2.s4c_pbig && cm_cls_on(d, 19))
     hipLaunchKernelGGL((k_s4c_coop<1024, false>), dim3(128), dim3(1024), ((cm_coop_pair_mem_bytes(pbig, false) + 15) & ~(size_t)15) + CM_XW_BYTES, s, d, pbig, 19u, coop);
 }
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
   hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (coop) {  // the lists it left unsorted: a wave per read
-    hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, 28u);
-    hipLaunchKernelGGL(k_s5_sort_coop, dim3(2048), dim3(CM_BLOCK), 0, s, d, 12u);
-    hipLaunchKernelGGL(k_s5_sort_coop, dim3(64), dim3(CM_BLOCK), 0, s, d, 22u);
+    if (cm_cls_on(d, 28)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, 28u);
+    if (cm_cls_on(d, 12)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(2048), dim3(CM_BLOCK), 0, s, d, 12u);
+    if (cm_cls_on(d, 22)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(64), dim3(CM_BLOCK), 0, s, d, 22u);
   }
 }
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
@@ -1954,12 +1962,12 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
   };
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gbytes(CM_S5C_P_SMALL), s, d, CM_S5C_P_SMALL, 28u);
-  hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(192), 3 * gbytes(CM_S5C_P_WAVE), s, d, CM_S5C_P_WAVE, 12u);  // three waves per block: under the 64 KB a launch gets without asking
+  if (cm_cls_on(d, 28)) hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gbytes(CM_S5C_P_SMALL), s, d, CM_S5C_P_SMALL, 28u);
+  if (cm_cls_on(d, 12)) hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(192), 3 * gbytes(CM_S5C_P_WAVE), s, d, CM_S5C_P_WAVE, 12u);  // three waves per block: under the 64 KB a launch gets without asking
   // the reads with a longer list: a block each (what even its work arrays cannot hold: lane 0's acceptance loop, the group's sort)
   uint32_t pb = CM_S5C_P_BLOCK;
   while (pb > CM_S5C_P_WAVE && !cm_lds_optin(&k_s5c_coop<CM_BLOCK>, gbytes(pb))) pb >>= 1;
-  hipLaunchKernelGGL(k_s5c_coop<CM_BLOCK>, dim3(128), dim3(CM_BLOCK), gbytes(pb), s, d, pb, 22u);
+  if (cm_cls_on(d, 22)) hipLaunchKernelGGL(k_s5c_coop<CM_BLOCK>, dim3(128), dim3(CM_BLOCK), gbytes(pb), s, d, pb, 22u);
 }
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
@@ -1981,9 +1989,9 @@ void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) 
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 29u);
-  hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 13u);
-  hipLaunchKernelGGL(k_s6a_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 18u);
+  if (cm_cls_on(d, 29)) hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 29u);
+  if (cm_cls_on(d, 13)) hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 13u);
+  if (cm_cls_on(d, 18)) hipLaunchKernelGGL(k_s6a_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 18u);
 }
 void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
@@ -1993,9 +2001,9 @@ void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop)
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 30u);
-  hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 17u);
-  hipLaunchKernelGGL(k_s6c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 20u);
+  if (cm_cls_on(d, 30)) hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 30u);
+  if (cm_cls_on(d, 17)) hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 17u);
+  if (cm_cls_on(d, 20)) hipLaunchKernelGGL(k_s6c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 20u);
 }
 
 // threads per block / LDS bytes for the read-staging kernels, from the longest read of the batch

@@ -1501,7 +1501,7 @@ CM_HD uint32_t cm_merge(const uint64_t *p1, const uint8_t *c1, uint32_t n1, uint
 CM_HD void cm_s4b_rescue_merge(const CmDev &d, uint32_t r, int mode = CM_S4B_ALL) {
   const bool prefilled = mode == CM_S4B_PREFILLED;
   const uint32_t o = r ^ 1u;
-  if (mode != CM_S4B_FILL_ONLY) { d.mcp[r] = 0; d.mcn[r] = 0; }
+  d.mcp[r] = 0; d.mcn[r] = 0;  // (also when only filling: the group that finishes the read may not run -- speculative launch set -- and then nothing stale must be left)
   if (d.m_tot[r] == 0) return;
   const uint32_t ncp = d.ncp[r], ncn = d.ncn[r], rp = d.resc_p[r], rn = d.resc_n[r];
   uint64_t *P = d.mbuf + d.m_off[r];
@@ -2007,11 +2007,16 @@ CM_HD void cm_pack_planes32(const uint8_t *bytes, uint32_t n, uint32_t *p0, uint
 // read r of the batch -> its planes, forward (the read as it is: the + strand's text) and reverse complement (base i =
 // complement of read[L - 1 - i], L the trimmed length: the - strand's text, PrepareNegativeSequenceAt); the second from the first:
 // word w of the reversed planes is the bit reversal of the forward planes' bits [L - 32 w - 32, L - 32 w).
+// words a read's planes take in CmDev::read_pl: 6 W, rounded up to a multiple of four so that every read's planes start on a
+// 16-byte boundary and leave in 16-byte stores (30 scalar stores per read of 150 bases made k_pack_reads the largest kernel of the hic
+// workload)
+CM_HD uint32_t cm_read_pl_stride(uint32_t W) { return (6u * W + 3u) & ~3u; }
+CM_HD uint32_t *cm_read_pl_of(const CmDev &d, uint32_t r) { return d.read_pl + (size_t)r * cm_read_pl_stride(d.read_pl_w); }
 // Any number of words per plane, the forward words read back from memory:
 CM_HD void cm_pack_read_planes_any(const CmDev &d, uint32_t r) {
   const uint32_t W = d.read_pl_w, L = d.rlen[r];
   if (L == 0) return;
-  uint32_t *f = d.read_pl + (size_t)r * 6 * W, *v = f + 3 * (size_t)W;
+  uint32_t *f = cm_read_pl_of(d, r), *v = f + 3 * (size_t)W;
   const uint8_t *read = cm_read_ptr(d, r);
   const uint32_t nw = (L + 31) >> 5;
   for (uint32_t w = 0; w < nw; ++w) cm_pack_planes32(read + 32 * w, L - 32 * w, f + w, f + W + w, f + 2 * W + w);
@@ -2081,14 +2086,12 @@ CM_HD void cm_pack_read_planes_w(const CmDev &d, uint32_t r) {
       for (int w = 0; w < W; ++w) v[w] = ~v[w];
     }
   }
-  uint32_t *dst = d.read_pl + (size_t)r * 6 * W;
-  if ((6 * W) % 4 == 0) {
-    struct alignas(16) Q { uint32_t a, b, c, e; };
+  uint32_t *dst = cm_read_pl_of(d, r);
+  struct alignas(16) Q { uint32_t a, b, c, e; };
 #pragma unroll
-    for (int i = 0; i < 6 * W; i += 4) { Q x = {o[i], o[i + 1], o[i + 2], o[i + 3]}; *reinterpret_cast<Q *>(dst + i) = x; }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 6 * W; ++i) dst[i] = o[i];
+  for (int i = 0; i < 6 * W; i += 4) {  // (the stride is a multiple of four words: the last store may run into the read's own padding)
+    Q x = {o[i], i + 1 < 6 * W ? o[i + 1] : 0u, i + 2 < 6 * W ? o[i + 2] : 0u, i + 3 < 6 * W ? o[i + 3] : 0u};
+    *reinterpret_cast<Q *>(dst + i) = x;
   }
 }
 CM_HD void cm_pack_read_planes(const CmDev &d, uint32_t r) {
@@ -2478,7 +2481,7 @@ CM_HD void cm_s5_verify(const CmDev &d, uint32_t r) {
       uint32_t *dsp = d.dsplit + d.m_off[r], *dsn = d.dsplit + d.m_off[r] + d.ncp[r] + d.resc_p[r];
       cm_sort_cand(pp, pc, ncp);
       cm_sort_cand(np, nc, ncn);
-      const uint32_t *tp = d.read_pl ? d.read_pl + (size_t)r * 6 * d.read_pl_w : nullptr;  // (the forward planes serve both strands)
+      const uint32_t *tp = d.read_pl ? cm_read_pl_of(d, r) : nullptr;  // (the forward planes serve both strands)
       d.ndp[r] = cm_draft_strand_split(d, read, L, 0, pp, pc, ncp, bst, dpp, dep, dsp, tp);
       d.ndn[r] = cm_draft_strand_split(d, read, L, 1, np, nc, ncn, bst, dpn, den, dsn, tp);
       done = true;
@@ -2585,7 +2588,7 @@ CM_HD void cm_s5b_verify_at(const CmDev &d, uint32_t r, int strand, uint32_t ci)
   int ne;
   if (d.ref_pl && d.read_pl)  // the same alignment on bit planes (cm_banded_align_planes)
     ne = cm_banded_align_planes(d.p.e, d.ref_pl, d.ref_off[rid] + position - (uint32_t)d.p.e,
-                                d.read_pl + ((size_t)r * 2 + (size_t)strand) * 3 * d.read_pl_w, d.read_pl_w, (int)L, &end_pos);
+                                cm_read_pl_of(d, r) + (size_t)strand * 3 * d.read_pl_w, d.read_pl_w, (int)L, &end_pos);
   else ne = cm_verify_compute(d, cm_read_ptr(d, r), L, strand, cpos, &end_pos);
   d.v_err[o] = (int16_t)ne;
   d.v_end[o] = (int16_t)end_pos;

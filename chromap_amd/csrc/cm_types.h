@@ -87,7 +87,7 @@ struct CmDev {
   const CmPlRec *ref_pl;
   uint64_t ref_pl_words;
   // ---- the batch's reads as bit planes, forward and reverse complement (cm_pack_read_planes): read r, orientation o, plane q at
-  //      read_pl + ((r * 2 + o) * 3 + q) * read_pl_w, read_pl_w words of 32 bases each.  nullptr: not packed
+  //      read_pl + r * cm_read_pl_stride(read_pl_w) + (o * 3 + q) * read_pl_w, read_pl_w words of 32 bases each.  nullptr: not packed
   uint32_t *read_pl;
   uint32_t read_pl_w;
   CmParams p;
@@ -139,6 +139,7 @@ struct CmDev {
   // hv_big: hit lists of hv_max[3] < hits <= hv_big go to list 25 (a block of 1024 lanes with the largest work area); rs_max3 / rs_big:
   // the rescue lists' two largest classes (lists 11 / 26: their entries take 20 bytes of the work area, not 19) -- 0: no such class
   uint32_t hv_big, rs_max3, rs_big;
+  unsigned long long cls_mask;  // bit l: the kernels of long-list class (list) l are launched for this range (speculative launch set, cm_kernels.hip)
   uint32_t s4c_pbig;  // entries of a candidate list the pair filter's largest class takes (k_s4c_coop<1024, false>; 0: no such class)
   uint32_t hv_stride, s3b_cap, hv_max[4];  // hv_max: hit-list size classes -- a wave, a block of 256 / 512 / 1024 lanes (lists 0, 1, 2, 10)
   uint8_t *coop_slab;      // global work memory of the groups that take lists longer than their shared memory holds:

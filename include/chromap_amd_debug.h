@@ -89,7 +89,9 @@ int cmgpu_gather_sweep(cmgpu_ctx *ctx, uint64_t n, int repeat, int loads_per_lan
  * "probe_table_shift" 0..4 (the pipeline probes a device copy of the index table re-hashed into 2^shift times as many
  * buckets: same lookups, fewer buckets visited; 0 = the file's table), "coop" (bit mask of the stages whose long lists go to
  * groups of lanes: 1 hit lists, 2 rescue hits, 4 pair filter, 8 acceptance, 16 pairing; 0 = the one-lane / bitonic forms),
- * "speculative_sizes" 0/1 (candidate arrays sized from the previous batch, checked on the device, one re-run when too small),
+ * "speculative_sizes" 0/1 (candidate arrays sized from the previous batch, checked on the device, one re-run when too small; the
+ * kernels of the long-list classes launched for the classes the previous range used, one re-run when another class has items; -1: on,
+ * starting from an empty launch set -- the tests' way to force that re-run),
  * "verify_planes" 0/1 (alignments of the verification on bit planes of the reference and the reads instead of their bytes),
  * "long_read_fused" 0/1 (reads longer than 69 bases: trimming + minimizers in one pass instead of count / scan / fill).
  * Every setting gives the same records (tests/test_gpu_parity.py runs the fuzz data under each). */

@@ -389,7 +389,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     uint32_t maxlen = 1;
     for (uint32_t r = 0; r < n2; ++r) maxlen = d.rlen[r] > maxlen ? d.rlen[r] : maxlen;
     d.read_pl_w = (maxlen + 31) / 32;
-    readpl.assign((size_t)n2 * 6 * d.read_pl_w + 4, 0xA5A5A5A5u);
+    readpl.assign((size_t)n2 * cm_read_pl_stride(d.read_pl_w) + 4, 0xA5A5A5A5u);
     d.read_pl = readpl.data();
     for (uint32_t r = 0; r < n2; ++r) cm_pack_read_planes(d, r);
   }
@@ -1066,7 +1066,7 @@ extern "C" int hostemu_align_planes_check(uint64_t seed, uint32_t rounds, uint32
     uint32_t ro[3] = {0, L, L};
     d.rlen = rlen; d.rb0 = stored; d.rb1 = stored; d.ro0 = ro; d.ro1 = ro;
     const uint32_t W = (L + 31) / 32;
-    std::vector<uint32_t> tp((size_t)6 * W + 2, 0x5A5A5A5Au);
+    std::vector<uint32_t> tp((size_t)cm_read_pl_stride(W) + 8, 0x5A5A5A5Au);
     d.read_pl = tp.data(); d.read_pl_w = W;
     cm_pack_read_planes(d, 0);
     const int nb = cm_banded_align_planes(e, rp, g, tp.data() + (size_t)strand * 3 * W, W, (int)L, &end_b);
@@ -1129,7 +1129,7 @@ extern "C" int hostemu_dropoff_planes_check(uint64_t seed, uint32_t rounds, uint
     uint32_t ro[3] = {0, L, L};
     d.rlen = rlen; d.rb0 = stored; d.rb1 = stored; d.ro0 = ro; d.ro1 = ro;
     const uint32_t W = (L + 31) / 32;
-    std::vector<uint32_t> tp((size_t)6 * W + 2, 0x5A5A5A5Au);
+    std::vector<uint32_t> tp((size_t)cm_read_pl_stride(W) + 8, 0x5A5A5A5Au);
     d.read_pl = tp.data(); d.read_pl_w = W;
     cm_pack_read_planes(d, 0);
     int ea = (int)L, eb = (int)L, la = 0, lb = 0, na, nb;

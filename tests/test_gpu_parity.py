@@ -198,6 +198,9 @@ HEAVY_SETTINGS = {
     # the range is mapped again with exact sizes
     "capacity_guess_too_small": {"debug_candidate_capacity": 64},
     "no_speculative_sizes": {"speculative_sizes": 0},
+    # the kernels of the long-list classes are launched for the classes the previous range used; -1: none -- the range finds items in
+    # classes it did not launch for and is mapped again with all of them
+    "launch_set_empty": {"speculative_sizes": -1},
     # the round-2 forms of the verification (alignments on the bytes instead of bit planes) and of the minimizer pass of reads
     # longer than 69 bases (count, scan, fill instead of the fused kernel with its global staging tile)
     "verify_on_bytes": {"verify_planes": 0},

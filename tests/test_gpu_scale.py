@@ -7,6 +7,8 @@ chromap-amd on the same files and compares the output byte for byte.
   atac     --preset atac, 2 x 50 with adapter read-through, + the same reads as BGZF through the CLI's block-parallel inflate
   scATAC   --preset atac + 16-base cell barcodes against a 737 280-entry whitelist (10 % of the barcodes one substitution off)
   hic      --preset hic, 2 x 150 Hi-C shaped pairs, 35 % with a ligation junction inside a read, 0.1 % indels: pairs file
+  atac on a genome with planted repeat families (32 x 600 copies of 3 kb at 2 %) and on the mosaic genome (profile 2: 47 % of the
+  bases repeat-derived): the long-list paths of every stage
 
 oracle/_ref/chromap travels with the repository like the built libraries (tests are skipped where it is absent)."""
 import json
@@ -24,6 +26,9 @@ CONFIGS = {
     "chip": ["--preset", "chip", "--pairs", "2000000", "--batches", "2"],
     "atac_bgzf": ["--preset", "atac", "--pairs", "2000000", "--batches", "2", "--bgzf-check"],
     "scatac_737k": ["--preset", "atac", "--pairs", "2000000", "--batches", "2", "--barcodes", "737280"],
+    # repeat-bearing genomes (round 4): every cooperative size class, the wave rescue searches and their pool at scale
+    "atac_planted_repeats": ["--preset", "atac", "--pairs", "2000000", "--batches", "2", "--repeats", "32,600,3000,0.02"],
+    "atac_mosaic_genome": ["--preset", "atac", "--pairs", "2000000", "--batches", "2", "--repeats", "profile:2"],
     "hic_chimeric": ["--preset", "hic", "--pairs", "2000000", "--batches", "2", "--readlen", "150", "--hic", "0.35", "--indel-rate", "0.001"],
 }
 
