@@ -123,6 +123,48 @@ struct ChunkReader {
     if (f) gzbuffer(f, 1 << 20);
     return f != nullptr;
   }
+  // device inflate (one GPU): the blocks stay compressed -- zbuf[0 .. zready) holds whole blocks whose inflated size adds up to at
+  // least `target` more text (the device keeps the text itself, cmgpu_fastq_scan_bgzf), zbuf[zready .. zlen) what was read beyond
+  // them (the file is read in large pieces); pending: inflated bytes handed over and not yet taken
+  bool dev_inflate = false;
+  size_t pending = 0, zlen = 0, zready = 0;
+  std::vector<unsigned char> zbuf;
+  void fill_bgzf_compressed(size_t target) {
+    if (zready) { memmove(zbuf.data(), zbuf.data() + zready, zlen - zready); zlen -= zready; zready = 0; }
+    size_t isum = 0;
+    auto need = [&](size_t upto) {  // zbuf holds at least `upto` bytes, or the file has no more
+      while (zlen < upto && !eof) {
+        const size_t want = std::max(upto - zlen, (size_t)64 << 20);
+        if (zbuf.size() < zlen + want) zbuf.resize(zlen + want + (zlen + want) / 2);
+        const size_t got = fread(zbuf.data() + zlen, 1, want, raw);
+        zlen += got;
+        if (got < want) eof = true;
+      }
+      return zlen >= upto;
+    };
+    while (pending + isum < target) {
+      if (!need(zready + 18)) {
+        if (zlen == zready) break;  // the end of the file, at a block's end
+        die("Didn't reach the end of sequence file, which might be corrupted! (truncated BGZF block)");
+      }
+      const unsigned char *h = zbuf.data() + zready;
+      if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C')
+        die("Didn't reach the end of sequence file, which might be corrupted! (not a BGZF block)");
+      const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
+      if (bsize < 26) die("Didn't reach the end of sequence file, which might be corrupted! (BGZF block size)");
+      if (!need(zready + bsize)) die("Didn't reach the end of sequence file, which might be corrupted! (truncated BGZF block)");
+      const unsigned char *t = zbuf.data() + zready + bsize - 4;
+      isum += (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+      zready += bsize;
+    }
+    pending += isum;
+    // (`eof` for the caller: nothing left to hand over after these blocks)
+    if (!eof && zlen == zready) {
+      const int ch = fgetc(raw);
+      if (ch == EOF) eof = true; else ungetc(ch, raw);
+    }
+  }
+  bool dev_final() const { return eof && zlen == zready; }
   struct Block { size_t coff, csize, isize, ooff; };
   void fill_bgzf(size_t target) {
     while (len < target && !eof) {
@@ -176,6 +218,7 @@ struct ChunkReader {
     }
   }
   void fill(size_t target) {
+    if (bgzf && dev_inflate) { fill_bgzf_compressed(target); return; }
     if (buf.size() < target) buf.resize(target);
     if (bgzf) { fill_bgzf(target); return; }
     while (len < target && !eof) {
@@ -186,10 +229,12 @@ struct ChunkReader {
     }
   }
   void consume(size_t used) {
+    if (bgzf && dev_inflate) { pending -= used < pending ? used : pending; return; }  // (the device keeps the rest)
     if (used < len) memmove(buf.data(), buf.data() + used, len - used);
     len -= used;
   }
   bool only_whitespace() const {
+    if (bgzf && dev_inflate) return true;  // (what is left on the device at the end holds no record: cmgpu_fastq_scan_bgzf counted none)
     for (size_t i = 0; i < len; ++i) if (buf[i] != '\n' && buf[i] != '\r' && buf[i] != ' ' && buf[i] != '\t') return false;
     return true;
   }
@@ -569,7 +614,7 @@ int main(int argc, char **argv) {
       {
         const unsigned hw = std::thread::hardware_concurrency();
         const int team = (int)std::max(2u, std::min(32u, (hw ? hw : 8u) / (unsigned)ns_streams));
-        for (ChunkReader &x : rd) x.team = team;
+        for (ChunkReader &x : rd) { x.team = team; x.dev_inflate = NG == 1; }  // (several GPUs take turns: the text cannot stay on one)
       }
       int sid[3] = {0, paired ? 1 : 2, 2};
       if (!rd[0].open(a.r1[fi])) die("Cannot find sequence file " + a.r1[fi]);
@@ -582,8 +627,11 @@ int main(int argc, char **argv) {
         double t0 = now_s();
         {  // one reader thread per file: gzip inflation of read 1 / read 2 / barcodes runs side by side
           std::thread th[3];
-          for (int m = 1; m < ns_streams; ++m) th[m] = std::thread([&rd, m, target]() { rd[m].fill(target); });
-          rd[0].fill(target);
+          // (blocks inflated on the device: a scan per batch, not per chunk -- the first pass of the inflate takes the same time for
+          //  a few hundred blocks as for tens of thousands)
+          auto want = [&](int m) { return rd[m].bgzf && rd[m].dev_inflate && target < ((size_t)1 << 30) ? (size_t)1 << 30 : target; };
+          for (int m = 1; m < ns_streams; ++m) th[m] = std::thread([&rd, m, &want]() { rd[m].fill(want(m)); });
+          rd[0].fill(want(0));
           for (int m = 1; m < ns_streams; ++m) th[m].join();
         }
         t_read += now_s() - t0;
@@ -591,8 +639,13 @@ int main(int argc, char **argv) {
         cmgpu_ctx *cx = ctxs[turn];
         auto ckx = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(cx)); };
         for (int m = 0; m < ns_streams; ++m) {
-          all_final = all_final && rd[m].eof;
-          const int rc = cmgpu_fastq_scan(cx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
+          const bool dev = rd[m].bgzf && rd[m].dev_inflate;
+          const bool fin = dev ? rd[m].dev_final() : rd[m].eof;
+          all_final = all_final && fin;
+          const int rc = dev ? cmgpu_fastq_scan_bgzf(cx, sid[m], rd[m].zbuf.data(), rd[m].zready, fin, &cnt[m])
+                             : cmgpu_fastq_scan(cx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
+          if (rc == CMGPU_EFORMAT && dev && strstr(cmgpu_last_error(cx), "BGZF"))
+            die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + cmgpu_last_error(cx) + ")");
           if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(cx)) + " -- rerun with --host-ingest");
           ckx(rc);
         }

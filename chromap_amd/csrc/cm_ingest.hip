@@ -17,6 +17,7 @@
 
 #include "cm_ctx.h"
 #include "cm_kernels.h"
+#include "cm_inflate.h"
 
 #define FQ_BLOCK 256
 #define FQCHECK(ctx, call)                                                                   \
@@ -149,19 +150,29 @@ struct FqMaxOp {
   __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
 };
 
+// the scan of n_bytes of text resident in f.text (last_char: its last byte): lines, records, markers
+static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int final_chunk, char last_char, uint32_t *n_records);
+
 extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records) {
   if (!c || stream < 0 || stream > 2 || (!text && n_bytes) || !n_records) return CMGPU_EINVAL;
   if (n_bytes > 0xfffffff0ull) { cm_set_error(c, "FASTQ chunk must be smaller than 4 GiB"); return CMGPU_EINVAL; }
   FQCHECK(c, cm_enter(c));
   CmFqStream &f = c->fq[stream];
-  hipStream_t s = c->stream;
   *n_records = 0;
+  f.dev_mode = false; f.dev_len = 0;
   f.n_bytes = n_bytes; f.n_nl = 0; f.n_raw = 0; f.n_rec = 0; f.final_chunk = final_chunk != 0;
   if (n_bytes == 0) return CMGPU_OK;
+  if (f.text.ensure(n_bytes + 32)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
+  FQCHECK(c, hipMemcpyAsync(f.text.p, text, n_bytes, hipMemcpyHostToDevice, c->stream));
+  return fq_scan_resident(c, stream, n_bytes, final_chunk, text[n_bytes - 1], n_records);
+}
+
+static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int final_chunk, char last_char, uint32_t *n_records) {
+  CmFqStream &f = c->fq[stream];
+  hipStream_t s = c->stream;
   const uint32_t n_thr = (uint32_t)((n_bytes + 15) / 16);
-  if (f.text.ensure(n_bytes + 32) || f.cnt.ensure(((size_t)n_thr + 1) * 4) || f.off.ensure(((size_t)n_thr + 1) * 4) ||
+  if (f.cnt.ensure(((size_t)n_thr + 1) * 4) || f.off.ensure(((size_t)n_thr + 1) * 4) ||
       c->scan_tmp.ensure(cm_scan_tmp_words(n_thr) * 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
-  FQCHECK(c, hipMemcpyAsync(f.text.p, text, n_bytes, hipMemcpyHostToDevice, s));
   const dim3 g((n_thr + FQ_BLOCK - 1) / FQ_BLOCK), b(FQ_BLOCK);
   hipLaunchKernelGGL(k_fq_count, g, b, 0, s, (const uint8_t *)f.text.p, n_bytes, n_thr, (uint32_t *)f.cnt.p);
   cm_scan_u32((const uint32_t *)f.cnt.p, (uint32_t *)f.off.p, n_thr, (uint32_t *)c->scan_tmp.p, s);
@@ -172,7 +183,7 @@ extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint
   hipLaunchKernelGGL(k_fq_fill, g, b, 0, s, (const uint8_t *)f.text.p, n_bytes, n_thr, (const uint32_t *)f.off.p, (uint32_t *)f.nl.p);
   // a final chunk whose last line has no terminator: the end of the text closes it
   // (also an empty, unterminated quality line of the very last record: three lines seen)
-  if (final_chunk && (text[n_bytes - 1] != '\n' || n_nl % 4 == 3)) {
+  if (final_chunk && (last_char != '\n' || n_nl % 4 == 3)) {
     const uint32_t endpos = (uint32_t)n_bytes;
     FQCHECK(c, hipMemcpy((uint32_t *)f.nl.p + n_nl, &endpos, 4, hipMemcpyHostToDevice));
     ++n_nl;
@@ -204,6 +215,203 @@ extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint
   return CMGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// BGZF input inflated on the device (the reference: one zlib gzread per file, sequence_batch.cc:22-62).
+// The host walks the block headers (18 bytes each: the 'BC' field holds the block's size) and uploads the COMPRESSED bytes.
+// k_bgzf_tokens: a lane per block decodes its DEFLATE codes (cm_inflate.h pass 1) -- literals straight to the block's place in the
+// stream's text (the ISIZE trailers give the places), matches as tokens; k_bgzf_resolve: a wave per block with the block's text in
+// LDS copies the matches, checks the CRC-32 and writes the text back.  The text then stays on the device: what cmgpu_fastq_take
+// does not consume is kept in front of the next blocks (the host never sees inflated bytes and cannot resubmit them).
+// ---------------------------------------------------------------------------------------
+struct FqBgzfBlock { uint32_t coff, clen, ooff, isize, crc, toff; };
+#define FQ_INF_LANES 64
+#define FQ_INF_STEPS 2048u  // symbols per lane between two header phases of the wave
+__global__ __launch_bounds__(FQ_INF_LANES) void k_bgzf_tokens(const uint8_t *__restrict__ comp, const FqBgzfBlock *__restrict__ tab, uint32_t n_blocks,
+                                                                uint8_t *__restrict__ text, uint32_t *__restrict__ tok, uint32_t *__restrict__ ntok,
+                                                                uint32_t *__restrict__ status) {
+  __shared__ uint16_t sym[CM_INF_SYMS * FQ_INF_LANES];
+  __shared__ uint8_t len8[CM_INF_LENS * FQ_INF_LANES];
+  const uint32_t bi = blockIdx.x * FQ_INF_LANES + threadIdx.x;
+  const bool active = bi < n_blocks;  // (a lane without a block still walks the wave's phases)
+  FqBgzfBlock b = {0, 0, 0, 0, 0, 0};
+  if (active) b = tab[bi];
+  uint32_t n = 0;
+  const int rc = cm_inflate_tokens(comp + b.coff, b.clen, text + b.ooff, b.isize, tok + b.toff, &n, active, sym + threadIdx.x, len8 + threadIdx.x,
+                                   FQ_INF_LANES, FQ_INF_STEPS);
+  if (!active) return;
+  ntok[bi] = rc == CM_INF_OK ? n : 0xffffffffu;
+  if (rc != CM_INF_OK) atomicMin(status, (bi << 3) | (uint32_t)rc);  // the first damaged block and what is wrong with it
+}
+// the group type cm_inflate.h's second pass asks for: one wave
+struct FqWave {
+  static constexpr int G = 64;
+  uint32_t t;
+  __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }  // lane: uniform
+  __device__ __forceinline__ uint32_t rank(bool p, uint32_t *total) {
+    const unsigned long long m = __ballot(p);
+    *total = (uint32_t)__popcll(m);
+    return (uint32_t)__popcll(m & ((1ull << t) - 1ull));
+  }
+  __device__ __forceinline__ uint32_t scan(uint32_t v, uint32_t *total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t x = __shfl_up(incl, dlt, 64);
+      if (t >= (uint32_t)dlt) incl += x;
+    }
+    *total = __shfl(incl, 63, 64);
+    return incl - v;
+  }
+};
+__global__ __launch_bounds__(64) void k_bgzf_resolve(const FqBgzfBlock *__restrict__ tab, uint8_t *__restrict__ text, const uint32_t *__restrict__ tok,
+                                                     const uint32_t *__restrict__ ntok, CmCrcX2n x2n, uint32_t *__restrict__ status) {
+  __shared__ uint4 win16[65536 / 16 + 2];
+  __shared__ uint32_t ends[128];
+  __shared__ uint32_t red[64], crc_tab[256], x2[32];
+  FqWave g;
+  g.t = threadIdx.x;
+  const uint32_t bi = blockIdx.x;
+  const uint32_t n_tok = ntok[bi];
+  if (n_tok == 0xffffffffu) return;  // (pass 1 gave the block up)
+  const FqBgzfBlock b = tab[bi];
+  for (uint32_t i = g.t; i < 256; i += 64) crc_tab[i] = cm_crc32_entry(i);
+  if (g.t < 32) x2[g.t] = x2n.v[g.t];
+  // the block's text (literals in place) into LDS, 16 bytes per lane and step, at its alignment in the text
+  const uint32_t a = b.ooff & 15u;
+  const uint4 *src = reinterpret_cast<const uint4 *>(text + (b.ooff - a));
+  const uint32_t n16 = (a + b.isize + 15u) / 16u;
+  for (uint32_t i0 = 0; i0 < n16; i0 += 8u * 64u) {  // (eight loads in flight per lane: a load a step would wait out HBM's latency 64 times)
+    uint4 r[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 64u + g.t; r[u] = src[i < n16 ? i : n16 - 1u]; }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 64u + g.t; if (i < n16) win16[i] = r[u]; }
+  }
+  g.sync();
+  uint8_t *win = reinterpret_cast<uint8_t *>(win16) + a;
+  int rc = cm_bgzf_resolve(g, win, tok + b.toff, n_tok, b.isize, ends);
+  if (rc == CM_INF_OK && cm_bgzf_crc(g, win, b.isize, crc_tab, x2, red) != b.crc) rc = CM_INF_ECRC;
+  if (rc != CM_INF_OK) { if (g.t == 0) atomicMin(status, (bi << 3) | (uint32_t)rc); return; }
+  // back to the text: whole 16-byte pieces inside the block, its first and last bytes one by one (the neighbours' are not ours)
+  uint4 *dst = reinterpret_cast<uint4 *>(text + (b.ooff - a));
+  const uint32_t first16 = a ? 1u : 0u, end16 = (a + b.isize) / 16u;
+  for (uint32_t i0 = first16; i0 < end16; i0 += 4u * 64u) {
+    uint4 r[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64u + g.t; r[u] = win16[i < end16 ? i : first16]; }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64u + g.t; if (i < end16) dst[i] = r[u]; }
+  }
+  const uint32_t head = a ? (16u - a < b.isize ? 16u - a : b.isize) : 0u;
+  if (g.t < head) text[b.ooff + g.t] = win[g.t];
+  const uint32_t tail_at = end16 * 16u > a + head ? end16 * 16u - a : head;  // first byte after the whole pieces
+  if (tail_at + g.t < b.isize) text[b.ooff + tail_at + g.t] = win[tail_at + g.t];
+}
+// the stream's text buffer with room for `need` bytes, the first `keep` bytes preserved
+static int fq_text_room(cmgpu_ctx *c, CmFqStream &f, uint64_t need, uint64_t keep) {
+  if (f.text.cap >= need) return CMGPU_OK;
+  DevBuf bigger;
+  if (bigger.ensure(need + need / 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
+  if (keep) FQCHECK(c, hipMemcpyAsync(bigger.p, f.text.p, keep, hipMemcpyDeviceToDevice, c->stream));
+  FQCHECK(c, cm_stream_sync(c->stream));
+  f.text.release();
+  f.text = bigger;
+  bigger.p = nullptr; bigger.cap = 0;
+  return CMGPU_OK;
+}
+// after a take in device mode: the unconsumed rest of the text moves to the front (through the second buffer: the ranges may overlap)
+static int fq_retain_rest(cmgpu_ctx *c, CmFqStream &f, uint64_t consumed, bool end_of_file) {
+  uint64_t rest = f.n_bytes > consumed ? f.n_bytes - consumed : 0;
+  if (end_of_file && rest) {
+    // every record of the file is taken: what follows the last one may only be blank (the host check of a plain-text file:
+    // "Didn't reach the end of sequence file"); it is dropped so that the next file starts on an empty text
+    std::vector<char> tail(rest < 65536 ? rest : 65536);
+    FQCHECK(c, hipMemcpy(tail.data(), (const uint8_t *)f.text.p + consumed, tail.size(), hipMemcpyDeviceToHost));
+    bool blank = rest <= 65536;
+    for (char ch : tail) blank = blank && (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t');
+    if (!blank) { cm_set_error(c, "text after the last whole FASTQ record of the file"); return CMGPU_EFORMAT; }
+    rest = 0;
+  }
+  if (rest) {
+    // (sized like the first buffer: the two swap, and a buffer that is large enough is left alone)
+    if (f.text2.cap < rest + 32 && f.text2.ensure(rest + 32 > f.text.cap ? rest + 32 : f.text.cap)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
+    FQCHECK(c, hipMemcpyAsync(f.text2.p, (const uint8_t *)f.text.p + consumed, rest, hipMemcpyDeviceToDevice, c->stream));
+    FQCHECK(c, cm_stream_sync(c->stream));
+    DevBuf t = f.text; f.text = f.text2; f.text2 = t;
+  }
+  f.dev_len = rest;
+  f.n_bytes = rest; f.n_nl = 0; f.n_raw = 0; f.n_rec = 0;  // (the retained text is scanned again with the next blocks)
+  return CMGPU_OK;
+}
+extern "C" int cmgpu_fastq_scan_bgzf(cmgpu_ctx *c, int stream, const void *blocks, uint64_t n_bytes, int final_chunk, uint32_t *n_records) {
+  if (!c || stream < 0 || stream > 2 || (!blocks && n_bytes) || !n_records) return CMGPU_EINVAL;
+  FQCHECK(c, cm_enter(c));
+  CmFqStream &f = c->fq[stream];
+  hipStream_t s = c->stream;
+  *n_records = 0;
+  if (!f.dev_mode) { f.dev_mode = true; f.dev_len = 0; }
+  // ---- the blocks' table (host): whole blocks only
+  const uint8_t *p = static_cast<const uint8_t *>(blocks);
+  std::vector<FqBgzfBlock> tab;
+  uint64_t at = 0, out = f.dev_len, n_tok_cap = 0;
+  while (at < n_bytes) {
+    if (n_bytes - at < 28 || p[at] != 0x1f || p[at + 1] != 0x8b || p[at + 2] != 8 || !(p[at + 3] & 4) || p[at + 10] != 6 || p[at + 11] != 0 ||
+        p[at + 12] != 'B' || p[at + 13] != 'C' || p[at + 14] != 2 || p[at + 15] != 0) {
+      cm_set_error(c, "not a BGZF block at byte " + std::to_string((unsigned long long)at) + " of the chunk"); return CMGPU_EFORMAT;
+    }
+    const uint64_t bsize = ((uint64_t)p[at + 16] | ((uint64_t)p[at + 17] << 8)) + 1;
+    if (bsize < 28 || bsize > n_bytes - at) { cm_set_error(c, "truncated BGZF block at byte " + std::to_string((unsigned long long)at) + " of the chunk"); return CMGPU_EFORMAT; }
+    const uint8_t *t = p + at + bsize - 8;
+    const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    if (isize > 65536u) { cm_set_error(c, "BGZF block larger than 64 KiB at byte " + std::to_string((unsigned long long)at) + " of the chunk"); return CMGPU_EFORMAT; }
+    if (out + isize > 0xfffffff0ull) { cm_set_error(c, "FASTQ chunk must be smaller than 4 GiB"); return CMGPU_EINVAL; }
+    if (isize) { tab.push_back({(uint32_t)(at + 18), (uint32_t)(bsize - 26), (uint32_t)out, isize, crc, (uint32_t)n_tok_cap}); n_tok_cap += cm_inf_tok_cap(isize); }
+    out += isize;
+    at += bsize;
+  }
+  if (n_bytes > 0xfffffff0ull) { cm_set_error(c, "BGZF chunk must be smaller than 4 GiB"); return CMGPU_EINVAL; }
+  // ---- upload, inflate behind the text kept from the last take
+  int rc = fq_text_room(c, f, out + 32, f.dev_len);
+  if (rc) return rc;
+  if (!tab.empty()) {
+    if (f.comp.ensure(n_bytes + 16) || f.btab.ensure(tab.size() * sizeof(FqBgzfBlock)) || f.bad.ensure(4) || f.toks.ensure((size_t)n_tok_cap * 4) ||
+        f.ntok.ensure(tab.size() * 4)) {
+      cm_set_error(c, "out of device memory (BGZF blocks)"); return CMGPU_ENOMEM;
+    }
+    static const CmCrcX2n x2n = []() { CmCrcX2n x; cm_crc_x2n_table(x); return x; }();
+    const uint32_t none = 0xffffffffu;
+    FQCHECK(c, hipMemcpyAsync(f.comp.p, blocks, n_bytes, hipMemcpyHostToDevice, s));
+    FQCHECK(c, hipMemcpyAsync(f.btab.p, tab.data(), tab.size() * sizeof(FqBgzfBlock), hipMemcpyHostToDevice, s));
+    FQCHECK(c, hipMemcpyAsync(f.bad.p, &none, 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bgzf_tokens, dim3((unsigned)((tab.size() + FQ_INF_LANES - 1) / FQ_INF_LANES)), dim3(FQ_INF_LANES), 0, s,
+                       (const uint8_t *)f.comp.p, (const FqBgzfBlock *)f.btab.p, (uint32_t)tab.size(), (uint8_t *)f.text.p, (uint32_t *)f.toks.p,
+                       (uint32_t *)f.ntok.p, (uint32_t *)f.bad.p);
+    hipLaunchKernelGGL(k_bgzf_resolve, dim3((unsigned)tab.size()), dim3(64), 0, s, (const FqBgzfBlock *)f.btab.p, (uint8_t *)f.text.p,
+                       (const uint32_t *)f.toks.p, (const uint32_t *)f.ntok.p, x2n, (uint32_t *)f.bad.p);
+    uint32_t st = 0;
+    FQCHECK(c, hipMemcpyAsync(&st, f.bad.p, 4, hipMemcpyDeviceToHost, s));
+    FQCHECK(c, cm_stream_sync(s));
+    if (st != none) {
+      static const char *what[] = {"", "the stream runs past the block's end", "the inflated size differs from the block's ISIZE", "invalid code", "CRC mismatch"};
+      cm_set_error(c, std::string("damaged BGZF block ") + std::to_string(st >> 3) + " of the chunk (" + what[(st & 7) < 5 ? (st & 7) : 3] + ")");
+      return CMGPU_EFORMAT;
+    }
+  }
+  f.dev_len = out;
+  f.n_bytes = out; f.n_nl = 0; f.n_raw = 0; f.n_rec = 0; f.final_chunk = final_chunk != 0;
+  if (out == 0) return CMGPU_OK;
+  char last_char = 0;
+  FQCHECK(c, hipMemcpy(&last_char, (const uint8_t *)f.text.p + out - 1, 1, hipMemcpyDeviceToHost));
+  return fq_scan_resident(c, stream, out, final_chunk, last_char, n_records);
+}
+
 extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *bytes_consumed) {
   if (!c || stream < 0 || stream > 2 || !bytes_consumed) return CMGPU_EINVAL;
   FQCHECK(c, cm_enter(c));
@@ -233,7 +441,7 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   }
   *bytes_consumed = consumed;
   if (offs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (read offsets)"); return CMGPU_ENOMEM; }
-  if (n == 0) { FQCHECK(c, hipMemset(offs.p, 0, 4)); return CMGPU_OK; }
+  if (n == 0) { FQCHECK(c, hipMemset(offs.p, 0, 4)); return f.dev_mode ? fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec) : CMGPU_OK; }
   if (f.len.ensure(((size_t)n + 1) * 4) || c->scan_tmp.ensure(cm_scan_tmp_words(n) * 4) || f.bad.ensure(4)) {
     cm_set_error(c, "out of device memory (FASTQ lengths)"); return CMGPU_ENOMEM;
   }
@@ -261,6 +469,7 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   FQCHECK(c, cm_stream_sync(s));
   f.taken_bases = total;
   f.taken_max_len = mx;
+  if (f.dev_mode) return fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec);
   return CMGPU_OK;
 }
 

@@ -476,10 +476,11 @@ class ChromapGPU:
         return int(k)
 
     # ---- FASTQ ingest on the device
-    def fastq_scan(self, stream, text, final=True):
+    def fastq_scan(self, stream, text, final=True, bgzf=False):
         """text: bytes of a FASTQ chunk; returns the number of complete non-empty records in it"""
         n = C.c_uint32(0)
-        self._check(self.L.cmgpu_fastq_scan(self.ctx, stream, text, len(text), int(final), C.byref(n)), self.ctx)
+        f = self.L.cmgpu_fastq_scan_bgzf if bgzf else self.L.cmgpu_fastq_scan  # bgzf: whole compressed BGZF blocks, inflated on the device
+        self._check(f(self.ctx, stream, text, len(text), int(final), C.byref(n)), self.ctx)
         return n.value
 
     def fastq_take(self, stream, n):

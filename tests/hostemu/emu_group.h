@@ -93,6 +93,22 @@ struct EmuGroup {
   EmuTeam *team;
   void sync() { team->barrier_all(); }
   void wsync() { team->barrier_wave((int)(t / W)); }
+  uint64_t ballot(bool p) {  // (G <= 64)
+    team->slot[t] = p ? 1 : 0;
+    wsync();
+    uint64_t m = 0;
+    const uint32_t base = t / W * W;
+    for (uint32_t i = 0; i < (uint32_t)W; ++i) m |= (uint64_t)(team->slot[base + i] ? 1 : 0) << i;
+    wsync();
+    return m;
+  }
+  uint32_t bcast(uint32_t v, uint32_t lane) {  // lane: the same for the whole wave part
+    team->slot[t] = v;
+    wsync();
+    const uint32_t r = (uint32_t)team->slot[t / W * W + lane];
+    wsync();
+    return r;
+  }
   uint32_t rank(bool p, uint32_t *total) {
     team->slot[t] = p ? 1 : 0;
     wsync();

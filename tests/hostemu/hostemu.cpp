@@ -13,6 +13,7 @@
 #include "../../chromap_amd/csrc/cm_mapq_tables.h"
 #include "../../chromap_amd/csrc/cm_stages.h"
 #include "../../chromap_amd/csrc/cm_coop.h"
+#include "../../chromap_amd/csrc/cm_inflate.h"
 #include "emu_group.h"
 
 template <typename T>
@@ -1147,4 +1148,57 @@ extern "C" int hostemu_dropoff_planes_check(uint64_t seed, uint32_t rounds, uint
     }
   }
   return bad;
+}
+
+
+// The device's BGZF inflate (cm_inflate.h) on the host: in[0 .. n_in) -> out[0 .. n_out).  Pass 1 by one lane with the device's table
+// stride (64 lanes' entries interleaved) to exercise the same indexing: literals to `out`, matches to tokens; pass 2 by an emulated
+// wave on a copy of the text (the device's window in LDS): the matches, then the CRC.  Returns the decoder's code.
+uint32_t g_inflate_steps = 2048;
+extern "C" void hostemu_inflate_steps(uint32_t n) { g_inflate_steps = n; }
+extern "C" int hostemu_inflate_block(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out, uint32_t want_crc, uint32_t lane) {
+  static uint32_t crc_tab[256];
+  static CmCrcX2n x2n;
+  if (!crc_tab[1]) { for (uint32_t i = 0; i < 256; ++i) crc_tab[i] = cm_crc32_entry(i); cm_crc_x2n_table(x2n); }
+  const uint32_t stride = 64;
+  std::vector<uint16_t> sym((size_t)CM_INF_SYMS * stride, 0xABCD);
+  std::vector<uint8_t> len8((size_t)CM_INF_LENS * stride, 0xEE);
+  const uint32_t cap = cm_inf_tok_cap(n_out);
+  std::vector<uint32_t> tok((size_t)cap + 2, 0xDEADBEEFu);
+  uint32_t n_tok = 0;
+  int rc = cm_inflate_tokens(in, n_in, out, n_out, tok.data() + 1, &n_tok, true, sym.data() + (lane & 63u), len8.data() + (lane & 63u), stride, g_inflate_steps);
+  // the other lanes' entries and the words around the tokens must be untouched
+  for (size_t i = 0; i < sym.size(); ++i) if ((i & 63u) != (lane & 63u) && sym[i] != 0xABCD) return 100;
+  for (size_t i = 0; i < len8.size(); ++i) if ((i & 63u) != (lane & 63u) && len8[i] != 0xEE) return 101;
+  if (tok[0] != 0xDEADBEEFu || tok[(size_t)cap + 1] != 0xDEADBEEFu || n_tok > cap) return 102;
+  if (rc != CM_INF_OK) return rc;
+  std::vector<uint8_t> win((size_t)n_out + 16, 0xC3);  // (the 16 bytes behind the text: the resolver's pad)
+  memcpy(win.data(), out, n_out);
+  std::vector<uint32_t> ends(128), red(64);
+  int rc2 = 0;
+  uint32_t crc = 0;
+  emu_run_group<64>([&](EmuGroup<64> &g) {
+    const int r = cm_bgzf_resolve(g, win.data(), tok.data() + 1, n_tok, n_out, ends.data());
+    const uint32_t c = cm_bgzf_crc(g, win.data(), n_out, crc_tab, x2n.v, red.data());
+    if (g.t == 0) { rc2 = r; crc = c; }
+  }, (lane & 1u) != 0);
+  if (rc2 != CM_INF_OK) return rc2;
+  if (crc != want_crc) return CM_INF_ECRC;
+  memcpy(out, win.data(), n_out);
+  return CM_INF_OK;
+}
+
+// the second pass alone on given tokens (tests: token streams no compressor writes -- chains of overlapping matches, every length
+// and distance): win[0 .. isize) holds the literals, the matches' bytes anything.  `reverse`: the emulation's other lane order.
+extern "C" int hostemu_bgzf_resolve(uint8_t *win_io, uint32_t isize, const uint32_t *tok, uint32_t n_tok, int reverse) {
+  std::vector<uint8_t> win((size_t)isize + 16, 0xC3);
+  memcpy(win.data(), win_io, isize);
+  std::vector<uint32_t> ends(128);
+  int rc = 0;
+  emu_run_group<64>([&](EmuGroup<64> &g) {
+    const int r = cm_bgzf_resolve(g, win.data(), tok, n_tok, isize, ends.data());
+    if (g.t == 0) rc = r;
+  }, reverse != 0);
+  memcpy(win_io, win.data(), isize);
+  return rc;
 }

@@ -21,7 +21,7 @@ def lib():
         srcs = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + \
                [os.path.join(ROOT, "tests", "hostemu", "emu_group.h")] + \
                [os.path.join(ROOT, "chromap_amd", "csrc", f) for f in ("cm_stages.h", "cm_coop.h", "cm_types.h", "cm_host.cpp",
-                                                                       "cm_mapq_tables.h")]
+                                                                       "cm_mapq_tables.h", "cm_inflate.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             # -fno-strict-aliasing: the stage functions read and write their byte / word arrays through wider types (aligned 8-
             # and 16-byte accesses), which the device compiler takes as written

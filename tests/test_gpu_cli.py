@@ -153,6 +153,32 @@ def test_cli_reads_gzip(built, tmp_path):
     assert ds.md5(out) == meta["bed_md5"]
 
 
+def test_cli_reads_bgzf_inflated_on_the_device(built, tmp_path):
+    """block-compressed input stays compressed on the host: the blocks are inflated on the device (one GPU); the records equal the
+    plain-text run; a damaged block ends the run with the reference's corrupted-file message"""
+    import sys
+    sys.path.insert(0, os.path.join(ds.ROOT, "tools"))
+    import bgzf
+    name = "s1_atac"
+    meta = ds.case_meta(name)
+    fa, r1, r2 = ds.case_inputs(name)
+    bg = []
+    for i, f in enumerate((r1, r2)):
+        g = str(tmp_path / ("r%d.fq.gz" % i))
+        bgzf.compress_file(f, g, level=6 if i else 1)
+        bg.append(g)
+    out = str(tmp_path / "o.bed")
+    r = subprocess.run([CLI] + meta["chromap_flags"] + ["-x", built(name), "-r", fa, "-1", bg[0], "-2", bg[1], "-o", out], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert ds.md5(out) == meta["bed_md5"]
+    raw = bytearray(open(bg[1], "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    bad = str(tmp_path / "bad.fq.gz")
+    open(bad, "wb").write(raw)
+    r = subprocess.run([CLI] + meta["chromap_flags"] + ["-x", built(name), "-r", fa, "-1", bg[0], "-2", bad, "-o", out], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"corrupted" in r.stderr, r.stderr[-500:]
+
+
 @pytest.mark.skipif(not os.path.exists(REF), reason="built reference binary not present")
 def test_device_built_index_loads_in_reference(built, tmp_path):
     name = "s1_atac"

@@ -116,3 +116,121 @@ def test_ingest_pairs_and_barcodes_map_like_host_buffers():
     assert hashlib.md5(g.store_text()).hexdigest() == meta["bed_md5"]
     assert len(want) == k
     g.close()
+
+
+# ---- BGZF inflated on the device (cmgpu_fastq_scan_bgzf): the host hands over whole compressed blocks only ----
+def _bgzf_blocks(text, level=1, block=0xff00):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import bgzf
+    return [bgzf._block(text[i:i + block], level) for i in range(0, len(text), block)] + [bgzf._block(b"", level)]
+
+
+def _ingest_bgzf(g, blocks, per_call, stream=0, limit=None):
+    """feeds the blocks `per_call` at a time; the device keeps what a take leaves; returns (bases, offsets)"""
+    bases, lens = [], []
+    at = 0
+    while True:
+        piece = b"".join(blocks[at:at + per_call])
+        at += per_call
+        final = at >= len(blocks)
+        n = g.fastq_scan(stream, piece, final, bgzf=True)
+        if limit:
+            n = min(n, limit)
+        g.fastq_take(stream, n)
+        if n:
+            g.fastq_commit(n, paired=False)
+            b1, o1, _, _ = g.download_batch(n)
+            bases.append(b1.copy())
+            lens.append(np.diff(o1))
+        if final and n == 0:
+            break
+    b = np.concatenate(bases) if bases else np.zeros(0, np.uint8)
+    ln = np.concatenate(lens) if lens else np.zeros(0, np.uint32)
+    off = np.zeros(len(ln) + 1, np.uint32)
+    off[1:] = np.cumsum(ln)
+    return b, off
+
+
+@pytest.mark.parametrize("per_call,limit,level,block", [(1 << 20, None, 1, 0xff00), (7, None, 6, 0xff00), (1, None, 1, 5000), (50, 333, 9, 30011),
+                                                        (3, None, 0, 0xff00)])
+def test_bgzf_inflated_on_the_device_equals_host_reader(per_call, limit, level, block):
+    g = _gpu()
+    _, r1, _ = datasets.case_inputs("s2_atac_q0")
+    text = open(r1, "rb").read()
+    want_b, want_o = ol.read_fastx(r1)
+    b, off = _ingest_bgzf(g, _bgzf_blocks(text, level, block), per_call, limit=limit)
+    assert np.array_equal(off, want_o)
+    assert np.array_equal(b, want_b)
+    # a second file on the same stream starts clean (the blank rest of the first one is dropped)
+    b, off = _ingest_bgzf(g, _bgzf_blocks(text + b"\n\n", level, block), per_call, limit=limit)
+    assert np.array_equal(off, want_o) and np.array_equal(b, want_b)
+    g.close()
+
+
+def test_bgzf_damaged_blocks_are_rejected():
+    import struct, zlib
+    from chromap_amd import ChromapError
+    g = _gpu()
+    _, r1, _ = datasets.case_inputs("s2_atac_q0")
+    text = open(r1, "rb").read()[:400000]
+    text = text[:text.rindex(b"\n@") + 1]  # whole records
+    blocks = _bgzf_blocks(text, 6)
+    assert len(blocks) >= 5
+    good = b"".join(blocks)
+    assert g.fastq_scan(0, good, True, bgzf=True) > 0
+    g.fastq_take(0, 0)
+
+    def fresh():  # the text kept from the attempt before is dropped by a plain-text scan (leaves device mode)
+        g.fastq_scan(0, b"@a\nAC\n+\nII\n", True)
+        g.fastq_take(0, 1)
+
+    def damaged(i, f):
+        b = list(blocks)
+        b[i] = f(bytearray(b[i]))
+        return b"".join(bytes(x) for x in b)
+
+    def flip_crc(b):
+        b[-8] ^= 1
+        return b
+
+    def wrong_isize(b):
+        b[-4:] = struct.pack("<I", struct.unpack("<I", bytes(b[-4:]))[0] - 1)
+        return b
+
+    def payload_bits(b):
+        for k in range(40, 60):
+            b[k] ^= 0xA5
+        return b
+
+    def cut_payload(b):  # a shorter payload under the same trailer: the header's block size follows
+        nb = b[:18] + b[18:len(b) - 8 - 200] + b[-8:]
+        nb[16:18] = struct.pack("<H", len(nb) - 1)
+        return nb
+
+    for i, f, what in ((2, flip_crc, "CRC mismatch"), (1, wrong_isize, "ISIZE|past the block|invalid code|CRC"), (3, payload_bits, "damaged BGZF block 3"),
+                       (0, cut_payload, "damaged BGZF block 0")):
+        fresh()
+        with pytest.raises(ChromapError, match=what):
+            g.fastq_scan(0, damaged(i, f), True, bgzf=True)
+    # a chunk that ends inside a block, or does not start with one
+    fresh()
+    with pytest.raises(ChromapError, match="truncated BGZF block"):
+        g.fastq_scan(0, good[:len(blocks[0]) + 100], True, bgzf=True)
+    fresh()
+    with pytest.raises(ChromapError, match="not a BGZF block"):
+        g.fastq_scan(0, good[5:], True, bgzf=True)
+    # text after the last whole record of the file
+    fresh()
+    junk = b"".join(_bgzf_blocks(b"@a\nACGT\n+\nIIII\n@b\nAC", 6))
+    assert g.fastq_scan(0, junk, False, bgzf=True) == 1
+    g.fastq_take(0, 1)
+    fresh()
+    g.fastq_scan(0, b"".join(_bgzf_blocks(b"@a\nACGT\n+\nIIII\nxx", 6)), True, bgzf=True)
+    with pytest.raises(ChromapError, match="after the last whole FASTQ record"):
+        g.fastq_take(0, 1)
+    # the context still works
+    fresh()
+    b, off = _ingest_bgzf(g, blocks, 2)
+    assert len(off) - 1 == text.count(b"\n") // 4
+    g.close()
