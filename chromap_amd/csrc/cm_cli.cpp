@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <unistd.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
@@ -81,7 +84,30 @@ struct FastxReader {
 };
 
 // raw (inflated) file bytes in large chunks for the device-side FASTQ parser.
-// Plain text and ordinary gzip go through zlib's gzread (one inflating thread per file).  BGZF (bgzip; SAM spec 4.1: a
+// bytes grown without zero-filling (the file's bytes overwrite them); reserve keeps the first `keep` bytes
+struct RawBuf {
+  unsigned char *p = nullptr;
+  size_t cap = 0;
+  unsigned char *data() { return p; }
+  const unsigned char *data() const { return p; }
+  const char *text() const { return reinterpret_cast<const char *>(p); }
+  void reserve(size_t n, size_t keep) {
+    if (n <= cap) return;
+    void *qv = nullptr;
+    if (posix_memalign(&qv, (size_t)2 << 20, n) != 0 || !qv) die("out of memory (input buffer)");
+    (void)madvise(qv, n, MADV_HUGEPAGE);  // (hundreds of MB touched for the first time: 2 MiB pages where the system gives them)
+    unsigned char *q = static_cast<unsigned char *>(qv);
+    if (keep) memcpy(q, p, keep);
+    free(p);
+    p = q;
+    cap = n;
+  }
+  RawBuf() = default;
+  RawBuf(const RawBuf &) = delete;
+  RawBuf &operator=(const RawBuf &) = delete;
+  ~RawBuf() { free(p); }
+};
+// Plain text is read as it is, ordinary gzip goes through zlib's gzread (one inflating thread per file).  BGZF (bgzip; SAM spec 4.1: a
 // series of gzip members of at most 64 KiB, each carrying its compressed size in a 'BC' extra field) is inflated block-
 // parallel: the block headers are walked without decoding, the ISIZE trailers give every block's place in the output,
 // and a team of threads inflates the blocks of a chunk side by side -- SURVEY.md 8(f)-2: kseq behind one gzread per
@@ -90,15 +116,48 @@ struct ChunkReader {
   gzFile f = nullptr;
   FILE *raw = nullptr;   // BGZF: the compressed file itself
   bool bgzf = false;
+  bool plain = false;    // not gzip at all: `raw` is read directly (gzread would copy the bytes twice)
   int team = 4;          // inflating threads for BGZF input
-  std::vector<char> buf;
+  RawBuf bufs[2];        // the text: bufs[cur][off .. off + len); the other buffer takes the read-ahead (the two swap: their pages stay mapped)
+  int cur = 0;
   std::vector<unsigned char> cbuf;
-  size_t len = 0;
+  size_t off = 0, len = 0;
   bool eof = false;
+  // read-ahead: while the device parses and maps what fill() returned, a thread reads (plain text), inflates (gzip) or reads the
+  // compressed blocks of (BGZF for the device) the next piece behind the bytes in use; the next fill() takes it over
+  std::thread ahead;
+  bool ahead_on = false, ahead_eof = false;
+  size_t ahead_got = 0;
+  const char *text() const { return bufs[cur].text() + off; }
+  // up to `want` bytes of the (inflated) stream: plain text or gzip
+  size_t read_some(unsigned char *dst, size_t want, bool *hit_eof) {
+    size_t got = 0;
+    while (got < want && !*hit_eof) {
+      if (plain) {
+        const size_t r = fread(dst + got, 1, want - got, raw);
+        if (r == 0) { if (ferror(raw)) die("Didn't reach the end of sequence file, which might be corrupted! (read error)"); *hit_eof = true; }
+        got += r;
+      } else {
+        const size_t piece = want - got < (1u << 30) ? want - got : (1u << 30);
+        const int r = gzread(f, dst + got, (unsigned)piece);
+        if (r < 0) { int en = 0; const char *msg = gzerror(f, &en); die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + (msg ? msg : "read error") + ")"); }
+        if (r == 0) *hit_eof = true; else got += (size_t)r;
+      }
+    }
+    return got;
+  }
+  void join_ahead() {
+    if (!ahead_on) return;
+    ahead.join();
+    ahead_on = false;
+    if (bgzf) { zlen += ahead_got; if (ahead_eof) eof = true; }  // (plain text / gzip: fill() joins the two buffers)
+  }
   bool open(const std::string &path) {
+    off = 0;
     len = 0;
     eof = false;
     bgzf = false;
+    plain = false;
     // only a regular file is sniffed for BGZF: the 18 bytes read from a FIFO, a process substitution or /dev/stdin would be
     // lost to the gzopen below (the reference opens every input with one gzopen, which works on pipes)
     struct stat sb;
@@ -117,26 +176,40 @@ struct ChunkReader {
       fseek(raw, 0, SEEK_SET);
       return true;
     }
+    if (!(got >= 2 && h[0] == 0x1f && h[1] == 0x8b)) {
+      plain = true;
+      fseek(raw, 0, SEEK_SET);
+      return true;
+    }
     fclose(raw);
     raw = nullptr;
     f = gzopen(path.c_str(), "r");
     if (f) gzbuffer(f, 1 << 20);
     return f != nullptr;
   }
-  // device inflate (one GPU): the blocks stay compressed -- zbuf[0 .. zready) holds whole blocks whose inflated size adds up to at
-  // least `target` more text (the device keeps the text itself, cmgpu_fastq_scan_bgzf), zbuf[zready .. zlen) what was read beyond
+  // device inflate (one GPU): the blocks stay compressed -- zdata()[0 .. zready) holds whole blocks whose inflated size adds up to at
+  // least `target` more text (the device keeps the text itself, cmgpu_fastq_scan_bgzf), zdata()[zready .. zlen) what was read beyond
   // them (the file is read in large pieces); pending: inflated bytes handed over and not yet taken
   bool dev_inflate = false;
-  size_t pending = 0, zlen = 0, zready = 0;
-  std::vector<unsigned char> zbuf;
+  size_t pending = 0, zoff = 0, zlen = 0, zready = 0;  // (zbuf[zoff .. zoff + zlen) is in use)
+  RawBuf zbuf;
+  const unsigned char *zdata() const { return zbuf.data() + zoff; }
   void fill_bgzf_compressed(size_t target) {
-    if (zready) { memmove(zbuf.data(), zbuf.data() + zready, zlen - zready); zlen -= zready; zready = 0; }
+    join_ahead();
+    zoff += zready;  // (handed over by the last call)
+    zlen -= zready;
+    zready = 0;
     size_t isum = 0;
-    auto need = [&](size_t upto) {  // zbuf holds at least `upto` bytes, or the file has no more
+    auto room = [&](size_t more) {  // zbuf takes `more` bytes behind the ones in use
+      if (zoff + zlen + more <= zbuf.cap) return;
+      if (zoff) { memmove(zbuf.data(), zbuf.data() + zoff, zlen); zoff = 0; }
+      if (zlen + more > zbuf.cap) zbuf.reserve(zlen + more + (zlen + more) / 2, zlen);
+    };
+    auto need = [&](size_t upto) {  // at least `upto` bytes in use, or the file has no more
       while (zlen < upto && !eof) {
         const size_t want = std::max(upto - zlen, (size_t)64 << 20);
-        if (zbuf.size() < zlen + want) zbuf.resize(zlen + want + (zlen + want) / 2);
-        const size_t got = fread(zbuf.data() + zlen, 1, want, raw);
+        room(want);
+        const size_t got = fread(zbuf.data() + zoff + zlen, 1, want, raw);
         zlen += got;
         if (got < want) eof = true;
       }
@@ -147,13 +220,13 @@ struct ChunkReader {
         if (zlen == zready) break;  // the end of the file, at a block's end
         die("Didn't reach the end of sequence file, which might be corrupted! (truncated BGZF block)");
       }
-      const unsigned char *h = zbuf.data() + zready;
+      const unsigned char *h = zdata() + zready;
       if (h[0] != 0x1f || h[1] != 0x8b || h[12] != 'B' || h[13] != 'C')
         die("Didn't reach the end of sequence file, which might be corrupted! (not a BGZF block)");
       const size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
       if (bsize < 26) die("Didn't reach the end of sequence file, which might be corrupted! (BGZF block size)");
       if (!need(zready + bsize)) die("Didn't reach the end of sequence file, which might be corrupted! (truncated BGZF block)");
-      const unsigned char *t = zbuf.data() + zready + bsize - 4;
+      const unsigned char *t = zdata() + zready + bsize - 4;
       isum += (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
       zready += bsize;
     }
@@ -163,8 +236,15 @@ struct ChunkReader {
       const int ch = fgetc(raw);
       if (ch == EOF) eof = true; else ungetc(ch, raw);
     }
+    if (!eof) {  // as many bytes again, read while the device works on these
+      const size_t want = std::max(zready, (size_t)64 << 20);
+      room(want);
+      unsigned char *dst = zbuf.data() + zoff + zlen;
+      ahead_on = true; ahead_got = 0; ahead_eof = false;
+      ahead = std::thread([this, dst, want]() { ahead_got = fread(dst, 1, want, raw); if (ahead_got < want) ahead_eof = true; });
+    }
   }
-  bool dev_final() const { return eof && zlen == zready; }
+  bool dev_final() const { return !ahead_on && eof && zlen == zready; }
   struct Block { size_t coff, csize, isize, ooff; };
   void fill_bgzf(size_t target) {
     while (len < target && !eof) {
@@ -190,7 +270,7 @@ struct ChunkReader {
         isum += isize;
       }
       if (blocks.empty()) break;
-      if (buf.size() < len + isum) buf.resize(len + isum);
+      bufs[cur].reserve(len + isum, len);  // (off is 0 here)
       const int nt = (int)std::min<size_t>((size_t)team, blocks.size());
       std::vector<std::thread> th;
       std::vector<int> bad((size_t)nt, 0);
@@ -205,7 +285,7 @@ struct ChunkReader {
             inflateReset(&zs);
             zs.next_in = cbuf.data() + b.coff + 18;
             zs.avail_in = (uInt)(b.csize - 26);
-            zs.next_out = reinterpret_cast<Bytef *>(buf.data() + len + b.ooff);
+            zs.next_out = bufs[cur].data() + len + b.ooff;
             zs.avail_out = (uInt)b.isize;
             const int rc = inflate(&zs, Z_FINISH);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { bad[ti] = 1; break; }
@@ -217,28 +297,54 @@ struct ChunkReader {
       len += isum;
     }
   }
+  static constexpr size_t kGap = (size_t)64 << 20;  // room in front of the read-ahead for what the last batch left over
   void fill(size_t target) {
     if (bgzf && dev_inflate) { fill_bgzf_compressed(target); return; }
-    if (buf.size() < target) buf.resize(target);
-    if (bgzf) { fill_bgzf(target); return; }
-    while (len < target && !eof) {
-      const size_t want = target - len < (1u << 30) ? target - len : (1u << 30);
-      const int r = gzread(f, buf.data() + len, (unsigned)want);
-      if (r < 0) { int en = 0; const char *msg = gzerror(f, &en); die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + (msg ? msg : "read error") + ")"); }
-      if (r == 0) eof = true; else len += (size_t)r;
+    if (bgzf) {
+      if (off) { memmove(bufs[cur].data(), bufs[cur].data() + off, len); off = 0; }
+      bufs[cur].reserve(target, len);
+      fill_bgzf(target);
+      return;
+    }
+    if (ahead_on) {
+      // what was read ahead sits in the other buffer behind a gap: the bytes still in use go in front of it
+      join_ahead();
+      RawBuf &o = bufs[1 - cur];
+      if (len <= kGap) {
+        memcpy(o.data() + kGap - len, bufs[cur].data() + off, len);
+        off = kGap - len;
+      } else {  // (more left over than the gap takes: the read-ahead moves back)
+        o.reserve(len + ahead_got + target, kGap + ahead_got);
+        memmove(o.data() + len, o.data() + kGap, ahead_got);
+        memcpy(o.data(), bufs[cur].data() + off, len);
+        off = 0;
+      }
+      cur = 1 - cur;
+      len += ahead_got;
+      if (ahead_eof) eof = true;
+    }
+    bufs[cur].reserve(off + std::max(len, target), off + len);
+    if (len < target && !eof) len += read_some(bufs[cur].data() + off + len, target - len, &eof);
+    if (!eof) {
+      RawBuf &o = bufs[1 - cur];
+      o.reserve(kGap + target, 0);
+      unsigned char *dst = o.data() + kGap;
+      ahead_on = true; ahead_got = 0; ahead_eof = false;
+      ahead = std::thread([this, dst, target]() { ahead_got = read_some(dst, target, &ahead_eof); });
     }
   }
   void consume(size_t used) {
     if (bgzf && dev_inflate) { pending -= used < pending ? used : pending; return; }  // (the device keeps the rest)
-    if (used < len) memmove(buf.data(), buf.data() + used, len - used);
+    off += used;
     len -= used;
   }
-  bool only_whitespace() const {
+  bool only_whitespace() {
     if (bgzf && dev_inflate) return true;  // (what is left on the device at the end holds no record: cmgpu_fastq_scan_bgzf counted none)
-    for (size_t i = 0; i < len; ++i) if (buf[i] != '\n' && buf[i] != '\r' && buf[i] != ' ' && buf[i] != '\t') return false;
+    if (ahead_on) fill(1);  // (takes over what was read ahead; nothing more is read: the file has ended)
+    for (size_t i = 0; i < len; ++i) { const char ch = text()[i]; if (ch != '\n' && ch != '\r' && ch != ' ' && ch != '\t') return false; }
     return true;
   }
-  void close() { if (f) gzclose(f); f = nullptr; if (raw) fclose(raw); raw = nullptr; }
+  void close() { if (ahead_on) { ahead.join(); ahead_on = false; } if (f) gzclose(f); f = nullptr; if (raw) fclose(raw); raw = nullptr; }
 };
 
 // --read-format (Chromap::ParseReadFormat chromap.cc:825-866, SequenceEffectiveRange): per stream up to four
@@ -284,6 +390,7 @@ struct Args {
   cmgpu_params p;
   bool build_index = false, out_bed = true, out_pairs = false, cell_level_dedup = false, host_ingest = false, out_sam = false, out_tagalign = false, skip_bc_check = false;
   size_t chunk_bytes = 256u << 20;
+  bool chunk_given = false;  // (--ingest-chunk-mb: also the size of the pieces of block-compressed input handed to the device)
   ReadFormat fmt[3];  // read 1, read 2, barcode
   int k = 17, w = 7, device = 0, gpus = 1;
   bool force_exchange = false;
@@ -388,7 +495,7 @@ static Args parse(int argc, char **argv) {
     else if (o == "--gpus") a.gpus = atoi(need("--gpus"));           // one context + host thread per GPU, records exchanged to chromosome owners
     else if (o == "--force-exchange") a.force_exchange = true;      // the multi-GPU code path with one GPU
     else if (o == "--host-ingest") a.host_ingest = true;   // kseq-style host parser (FASTA / multi-line records)
-    else if (o == "--ingest-chunk-mb") a.chunk_bytes = (size_t)atol(need("--ingest-chunk-mb")) << 20;
+    else if (o == "--ingest-chunk-mb") { a.chunk_bytes = (size_t)atol(need("--ingest-chunk-mb")) << 20; a.chunk_given = true; }
     else if (o == "--batch-pairs") a.batch_pairs = (uint32_t)atol(need("--batch-pairs"));
     else if (o == "-v" || o == "--version") { printf("chromap-amd 0.1 (hot path of chromap 0.3.3-r521 on gfx950)\n"); exit(0); }
     else if (o == "-h" || o == "--help") {
@@ -429,7 +536,7 @@ int main(int argc, char **argv) {
       rd.fill(3u << 20);
       if (rd.len == 0) break;
       const size_t take = rd.eof ? rd.len : rd.len - rd.len / 3;  // leave a tail, like the FASTQ parser does
-      fwrite(rd.buf.data(), 1, take, stdout);
+      fwrite(rd.text(), 1, take, stdout);
       rd.consume(take);
     }
     fprintf(stderr, "%s\n", rd.bgzf ? "bgzf" : "gzread");
@@ -561,8 +668,8 @@ int main(int argc, char **argv) {
         br.fill(target);
         if (br.len == 0) break;
         if (bc_len == 0) {  // length of the first barcode: second line of the file
-          const char *p = (const char *)memchr(br.buf.data(), '\n', br.len);
-          const char *q = p ? (const char *)memchr(p + 1, '\n', br.len - (size_t)(p + 1 - br.buf.data())) : nullptr;
+          const char *p = (const char *)memchr(br.text(), '\n', br.len);
+          const char *q = p ? (const char *)memchr(p + 1, '\n', br.len - (size_t)(p + 1 - br.text())) : nullptr;
           if (!p || !q) die("barcode file is not FASTQ");
           bc_len = (uint32_t)(q - p - 1);
           if (bc_len && p[bc_len] == '\r') --bc_len;
@@ -573,7 +680,7 @@ int main(int argc, char **argv) {
           free(keys);
         }
         uint32_t cnt = 0;
-        ck(cmgpu_fastq_scan(ctx, 2, br.buf.data(), br.len, br.eof, &cnt));
+        ck(cmgpu_fastq_scan(ctx, 2, br.text(), br.len, br.eof, &cnt));
         uint32_t n = cnt;
         if (!br.eof) n -= n % 500000;
         if (n == 0 && !br.eof) { target *= 2; continue; }
@@ -629,7 +736,7 @@ int main(int argc, char **argv) {
           std::thread th[3];
           // (blocks inflated on the device: a scan per batch, not per chunk -- the first pass of the inflate takes the same time for
           //  a few hundred blocks as for tens of thousands)
-          auto want = [&](int m) { return rd[m].bgzf && rd[m].dev_inflate && target < ((size_t)1 << 30) ? (size_t)1 << 30 : target; };
+          auto want = [&](int m) { return rd[m].bgzf && rd[m].dev_inflate && !a.chunk_given && target < ((size_t)1 << 30) ? (size_t)1 << 30 : target; };
           for (int m = 1; m < ns_streams; ++m) th[m] = std::thread([&rd, m, &want]() { rd[m].fill(want(m)); });
           rd[0].fill(want(0));
           for (int m = 1; m < ns_streams; ++m) th[m].join();
@@ -642,8 +749,8 @@ int main(int argc, char **argv) {
           const bool dev = rd[m].bgzf && rd[m].dev_inflate;
           const bool fin = dev ? rd[m].dev_final() : rd[m].eof;
           all_final = all_final && fin;
-          const int rc = dev ? cmgpu_fastq_scan_bgzf(cx, sid[m], rd[m].zbuf.data(), rd[m].zready, fin, &cnt[m])
-                             : cmgpu_fastq_scan(cx, sid[m], rd[m].buf.data(), rd[m].len, rd[m].eof, &cnt[m]);
+          const int rc = dev ? cmgpu_fastq_scan_bgzf(cx, sid[m], rd[m].zdata(), rd[m].zready, fin, &cnt[m])
+                             : cmgpu_fastq_scan(cx, sid[m], rd[m].text(), rd[m].len, rd[m].eof, &cnt[m]);
           if (rc == CMGPU_EFORMAT && dev && strstr(cmgpu_last_error(cx), "BGZF"))
             die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + cmgpu_last_error(cx) + ")");
           if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(cx)) + " -- rerun with --host-ingest");

@@ -412,3 +412,40 @@ def test_pipelined_submit_equals_map_pairs():
     rec2, k2 = g.map_pairs(b1, o1, b2, o2)
     assert bytes(rec2)[:k2 * 24] == want
     g.close()
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.parametrize("world", [1, pytest.param(2, marks=pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (two real RCCL ranks)"))])
+def test_bench_ranks_exchange_every_record(world):
+    """bench.py launched the way the driver launches it (torch.distributed.run for two ranks; one rank with --force-exchange on a
+    1-GPU box): each rank maps its own batches and the records change hands by owner chromosome over RCCL Send/Recv inside every
+    step; what the ranks own after the run is what they sent, and the value is all ranks' pairs over the slowest rank's time"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--skip-extras", "--skip-cpu", "--genome", "400000000",
+            "--pairs", "1000000"]
+    if world == 1:
+        cmd = [sys.executable] + args + ["--force-exchange"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port())] + args
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    j = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert j["n_gpus"] == world and j["scaling"] == "weak"
+    ex = j["exchange"]
+    assert ex["ranks"] == world and len(ex["per_rank"]) == world
+    sent = sum(r["records_sent"] for r in ex["per_rank"])
+    owned = sum(r["records_owned"] for r in ex["per_rank"])
+    assert sent > 0 and owned == sent  # every record a rank produced arrived at its owner (a rank also 'sends' to itself)
+    assert all(r["mapped_pairs"] > 0.9 * 1000000 * 3 for r in ex["per_rank"])
+    assert abs(j["value"] - world * 1000000 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
