@@ -129,6 +129,49 @@ CM_HD int cm_inf_build(CmInfCnt &cnt, uint16_t *sym, const uint8_t *len8, uint32
   return 0;
 }
 
+// The literal / length and the distance code are walked differently from the (short, rare) code-length code above: the next 31
+// bits of the stream, first bit on top, compared against one limit per length -- canonical code words of length l, left-justified,
+// lie in [limit of l - 1, limit of l) -- so the length is 1 + the number of limits at or below the window: 14 compares without a
+// branch instead of a loop the lanes leave one by one.  delta (16 entries of this lane, shared memory): what is added to a code
+// word of a length to get its place in the symbol table.
+struct CmInfLim { uint32_t lim[16]; };
+CM_HD uint32_t cm_inf_rev32(uint32_t x) {
+#if defined(__clang__)
+  return __builtin_bitreverse32(x);
+#else
+  x = (x >> 16) | (x << 16);
+  x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+  x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+  x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+  return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+#endif
+}
+CM_HD void cm_inf_limits(CmInfLim &L, const CmInfCnt &cnt, int16_t *delta, uint32_t stride) {
+  uint32_t first = 0, offs = 0;
+  L.lim[0] = 0;
+#pragma unroll
+  for (int l = 1; l <= 15; ++l) {
+    const uint32_t c = cnt.c[l];
+    delta[(uint32_t)l * stride] = (int16_t)((int)offs - (int)first);
+    L.lim[l] = (first + c) << (31 - l);
+    offs += c;
+    first = (first + c) << 1;
+  }
+}
+CM_HD int cm_inf_decode_lim(CmInfBits &s, const CmInfLim &L, const uint16_t *sym, const int16_t *delta, uint32_t stride) {
+  if (s.bc < 15) cm_inf_fill(s);
+  const uint32_t v = cm_inf_rev32((uint32_t)s.bb) >> 1;
+  uint32_t len = 1;
+#pragma unroll
+  for (int l = 1; l <= 14; ++l) len += v >= L.lim[l] ? 1u : 0u;
+  if (v >= L.lim[15]) return -1;  // a code word no symbol has
+  if ((uint32_t)s.bc < len) { s.err = CM_INF_EINPUT; return -1; }
+  const int idx = (int)(v >> (31u - len)) + (int)delta[len * stride];
+  s.bb >>= len;
+  s.bc -= (int)len;
+  return sym[(uint32_t)idx * stride];
+}
+
 // crc_tab: the 256 entries of the reflected CRC-32 (polynomial 0xEDB88320)
 CM_HD uint32_t cm_crc32_entry(uint32_t i) {
   uint32_t c = i;
@@ -146,7 +189,7 @@ CM_HD uint32_t cm_inf_tok_cap(uint32_t isize) { return isize / 3u + isize / 511u
 #define CM_INF_PH_DONE 2
 struct CmInfLane {
   CmInfBits s;
-  CmInfCnt lc, dc;
+  CmInfLim ll, dl;  // the limits of the literal / length and of the distance code
   uint32_t op, lit, ntok;
   int phase, last, rc;
 };
@@ -160,12 +203,13 @@ CM_HD void cm_inf_literal(CmInfLane &L, uint8_t *out, uint32_t *tok, uint32_t ca
   if (++L.lit == CM_INF_TOK_SKIP) { cm_inf_push(L, tok, cap, CM_INF_TOK_SKIP); L.lit = 0; }
 }
 // the header of the next deflate block: a stored block is copied whole (literals), the fixed or the transmitted codes are built
-CM_HD void cm_inf_header(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *tok, uint32_t cap, uint16_t *sym, uint8_t *len8, uint32_t stride) {
+CM_HD void cm_inf_header(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *tok, uint32_t cap, uint16_t *sym, uint8_t *len8, int16_t *delta, uint32_t stride) {
   // the order of the code-length code's lengths as 5-bit fields: no table a lane would have to index in private memory
   const uint64_t clord_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
   const uint64_t clord_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
   CmInfBits &s = L.s;
   uint16_t *dsym = sym + 288u * stride;
+  CmInfCnt lc, dc;
   L.last = (int)cm_inf_bits(s, 1);
   const uint32_t type = cm_inf_bits(s, 2);
   if (s.err) return cm_inf_fail(L, s.err);
@@ -191,9 +235,9 @@ CM_HD void cm_inf_header(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *t
   if (type == 3) return cm_inf_fail(L, CM_INF_ECODE);
   if (type == 1) {  // the fixed codes
     for (uint32_t i = 0; i < 288; ++i) len8[i * stride] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
-    (void)cm_inf_build(L.lc, sym, len8, 288, stride);
+    (void)cm_inf_build(lc, sym, len8, 288, stride);
     for (uint32_t i = 0; i < 30; ++i) len8[i * stride] = 5;
-    (void)cm_inf_build(L.dc, dsym, len8, 30, stride);
+    (void)cm_inf_build(dc, dsym, len8, 30, stride);
   } else {
     const uint32_t nlen = cm_inf_bits(s, 5) + 257, ndist = cm_inf_bits(s, 5) + 1, ncode = cm_inf_bits(s, 4) + 4;
     if (s.err) return cm_inf_fail(L, s.err);
@@ -226,17 +270,19 @@ CM_HD void cm_inf_header(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *t
       i += rep;
     }
     if (len8[256 * stride] == 0) return cm_inf_fail(L, CM_INF_ECODE);  // no end-of-block code
-    if (cm_inf_build(L.lc, sym, len8, nlen, stride) != 0) return cm_inf_fail(L, CM_INF_ECODE);
-    if (cm_inf_build(L.dc, dsym, len8 + (size_t)nlen * stride, ndist, stride) != 0) return cm_inf_fail(L, CM_INF_ECODE);
+    if (cm_inf_build(lc, sym, len8, nlen, stride) != 0) return cm_inf_fail(L, CM_INF_ECODE);
+    if (cm_inf_build(dc, dsym, len8 + (size_t)nlen * stride, ndist, stride) != 0) return cm_inf_fail(L, CM_INF_ECODE);
   }
+  cm_inf_limits(L.ll, lc, delta, stride);
+  cm_inf_limits(L.dl, dc, delta + 16u * stride, stride);
   L.phase = CM_INF_PH_SYMBOLS;
 }
 // up to max_steps literals / matches of the current deflate block; its end-of-block code ends the phase
-CM_HD void cm_inf_symbols(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *tok, uint32_t cap, const uint16_t *sym, uint32_t stride, uint32_t max_steps) {
+CM_HD void cm_inf_symbols(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *tok, uint32_t cap, const uint16_t *sym, const int16_t *delta, uint32_t stride, uint32_t max_steps) {
   CmInfBits &s = L.s;
   const uint16_t *dsym = sym + 288u * stride;
   for (uint32_t step = 0; step < max_steps && L.phase == CM_INF_PH_SYMBOLS; ++step) {
-    const int c = cm_inf_decode(s, L.lc, sym, stride);
+    const int c = cm_inf_decode_lim(s, L.ll, sym, delta, stride);
     if (s.err) return cm_inf_fail(L, s.err);
     if (c < 0) return cm_inf_fail(L, CM_INF_ECODE);
     if (c < 256) {
@@ -251,7 +297,7 @@ CM_HD void cm_inf_symbols(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *
     // (RFC 1951 3.2.5 in closed form)
     const uint32_t le = li < 8 || li == 28 ? 0u : (li - 4) >> 2;
     const uint32_t len = (li == 28 ? 258u : li < 8 ? 3u + li : 3u + ((4u + (li & 3u)) << le)) + (le ? cm_inf_bits(s, (int)le) : 0u);
-    const int dcode = cm_inf_decode(s, L.dc, dsym, stride);
+    const int dcode = cm_inf_decode_lim(s, L.dl, dsym, delta + 16u * stride, stride);
     if (s.err) return cm_inf_fail(L, s.err);
     if (dcode < 0 || dcode >= 30) return cm_inf_fail(L, CM_INF_ECODE);
     const uint32_t de = dcode < 4 ? 0u : ((uint32_t)dcode >> 1) - 1u;
@@ -272,9 +318,9 @@ CM_HD void cm_inf_symbols(CmInfLane &L, uint8_t *out, uint32_t n_out, uint32_t *
 #endif
 // The codes of in[0 .. n_in): the literal bytes to their places in out[0 .. n_out), the matches to tok[0 .. *n_tok).  Exactly n_out
 // bytes of output or an error.  sym: CM_INF_SYMS entries of this lane (literal / length table, then 32 distance entries), len8:
-// CM_INF_LENS entries.  active: false for a lane without a block (it only keeps the wave's phases company).
+// CM_INF_LENS entries, delta: 32 entries.  active: false for a lane without a block (it only keeps the wave's phases company).
 CM_HD int cm_inflate_tokens(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out, uint32_t *tok, uint32_t *n_tok, bool active,
-                            uint16_t *sym, uint8_t *len8, uint32_t stride, uint32_t max_steps) {
+                            uint16_t *sym, uint8_t *len8, int16_t *delta, uint32_t stride, uint32_t max_steps) {
   CmInfLane L;
   L.s.in = in; L.s.n_in = n_in; L.s.ip = 0; L.s.bb = 0; L.s.bc = 0; L.s.err = 0; L.s.nw = 0;
   L.op = 0; L.lit = 0; L.ntok = 0; L.last = 0; L.rc = CM_INF_OK;
@@ -282,9 +328,9 @@ CM_HD int cm_inflate_tokens(const uint8_t *in, uint32_t n_in, uint8_t *out, uint
   const uint32_t cap = cm_inf_tok_cap(n_out);
   if (active) cm_inf_prime(L.s);
   while (CM_INF_ANY(L.phase != CM_INF_PH_DONE)) {
-    if (L.phase == CM_INF_PH_HEADER) cm_inf_header(L, out, n_out, tok, cap, sym, len8, stride);
+    if (L.phase == CM_INF_PH_HEADER) cm_inf_header(L, out, n_out, tok, cap, sym, len8, delta, stride);
     if (CM_INF_ANY(L.phase == CM_INF_PH_SYMBOLS)) {
-      if (L.phase == CM_INF_PH_SYMBOLS) cm_inf_symbols(L, out, n_out, tok, cap, sym, stride, max_steps);
+      if (L.phase == CM_INF_PH_SYMBOLS) cm_inf_symbols(L, out, n_out, tok, cap, sym, delta, stride, max_steps);
     }
   }
   if (L.rc == CM_INF_OK && L.op != n_out) L.rc = CM_INF_EOUTPUT;

@@ -231,13 +231,14 @@ __global__ __launch_bounds__(FQ_INF_LANES) void k_bgzf_tokens(const uint8_t *__r
                                                                 uint32_t *__restrict__ status) {
   __shared__ uint16_t sym[CM_INF_SYMS * FQ_INF_LANES];
   __shared__ uint8_t len8[CM_INF_LENS * FQ_INF_LANES];
+  __shared__ int16_t delta[32 * FQ_INF_LANES];
   const uint32_t bi = blockIdx.x * FQ_INF_LANES + threadIdx.x;
   const bool active = bi < n_blocks;  // (a lane without a block still walks the wave's phases)
   FqBgzfBlock b = {0, 0, 0, 0, 0, 0};
   if (active) b = tab[bi];
   uint32_t n = 0;
   const int rc = cm_inflate_tokens(comp + b.coff, b.clen, text + b.ooff, b.isize, tok + b.toff, &n, active, sym + threadIdx.x, len8 + threadIdx.x,
-                                   FQ_INF_LANES, FQ_INF_STEPS);
+                                   delta + threadIdx.x, FQ_INF_LANES, FQ_INF_STEPS);
   if (!active) return;
   ntok[bi] = rc == CM_INF_OK ? n : 0xffffffffu;
   if (rc != CM_INF_OK) atomicMin(status, (bi << 3) | (uint32_t)rc);  // the first damaged block and what is wrong with it

@@ -1163,13 +1163,15 @@ extern "C" int hostemu_inflate_block(const uint8_t *in, uint32_t n_in, uint8_t *
   const uint32_t stride = 64;
   std::vector<uint16_t> sym((size_t)CM_INF_SYMS * stride, 0xABCD);
   std::vector<uint8_t> len8((size_t)CM_INF_LENS * stride, 0xEE);
+  std::vector<int16_t> delta((size_t)32 * stride, 0x7A7A);
   const uint32_t cap = cm_inf_tok_cap(n_out);
   std::vector<uint32_t> tok((size_t)cap + 2, 0xDEADBEEFu);
   uint32_t n_tok = 0;
-  int rc = cm_inflate_tokens(in, n_in, out, n_out, tok.data() + 1, &n_tok, true, sym.data() + (lane & 63u), len8.data() + (lane & 63u), stride, g_inflate_steps);
+  int rc = cm_inflate_tokens(in, n_in, out, n_out, tok.data() + 1, &n_tok, true, sym.data() + (lane & 63u), len8.data() + (lane & 63u), delta.data() + (lane & 63u), stride, g_inflate_steps);
   // the other lanes' entries and the words around the tokens must be untouched
   for (size_t i = 0; i < sym.size(); ++i) if ((i & 63u) != (lane & 63u) && sym[i] != 0xABCD) return 100;
   for (size_t i = 0; i < len8.size(); ++i) if ((i & 63u) != (lane & 63u) && len8[i] != 0xEE) return 101;
+  for (size_t i = 0; i < delta.size(); ++i) if ((i & 63u) != (lane & 63u) && delta[i] != 0x7A7A) return 104;
   if (tok[0] != 0xDEADBEEFu || tok[(size_t)cap + 1] != 0xDEADBEEFu || n_tok > cap) return 102;
   if (rc != CM_INF_OK) return rc;
   std::vector<uint8_t> win((size_t)n_out + 16, 0xC3);  // (the 16 bytes behind the text: the resolver's pad)
