@@ -5,11 +5,13 @@
 //  1. cm_inflate_tokens: ONE LANE per block decodes the Huffman codes -- the part of DEFLATE that is serial per stream, so tens of
 //     thousands of streams run side by side.  Literal bytes go straight to their place in the text; a match is NOT copied (a lane
 //     copying bytes through global memory waits a memory round trip per byte) but written as a 32-bit token.  Canonical Huffman
-//     decoding bit by bit over the per-length code counts (kept in registers) and one symbol table per code in the workgroup's
-//     shared memory (`sym`: entry i of this lane at sym[i * stride]; `len8`: the code lengths while a dynamic header is read); a
-//     64-bit bit buffer refilled a 32-bit word at a time, the next word already on its way.  The lanes of a wave alternate between
-//     two phases -- block headers (long, rare), then up to `max_steps` symbols -- so that a lane that reaches a header does not
-//     make the 63 others sit through it at a random time each.
+//     codes: the code-length code of a dynamic header bit by bit over its per-length counts, the literal / length and distance
+//     codes by comparing the stream's next bits against one limit per length (cm_inf_decode_lim); one symbol table per code in
+//     the workgroup's shared memory (`sym`: entry i of this lane at sym[i * stride]; `len8`: the code lengths while a dynamic
+//     header is read; `delta`: per length, a code word's place in the table); a 64-bit bit buffer refilled a 32-bit word at a
+//     time, the next word already on its way.  The lanes of a wave alternate between two phases -- block headers (long, rare),
+//     then up to `max_steps` symbols -- so that a lane that reaches a header does not make the 63 others sit through it at a
+//     random time each.
 //  2. cm_bgzf_resolve + cm_bgzf_crc: ONE WAVE per block with the block's text in LDS: the tokens' output places by a prefix sum
 //     64 at a time, then the group's matches side by side -- a lane per short match -- in as many rounds as the longest chain of
 //     matches that read each other's output has links; the CRC-32 of the text from 4 slices per lane, combined with the shifts
