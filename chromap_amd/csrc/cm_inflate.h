@@ -353,9 +353,9 @@ CM_HD int cm_bgzf_resolve(GT &g, uint8_t *win, const uint32_t *tok, uint32_t n_t
   const uint32_t G = (uint32_t)GT::G;
   const uint64_t all = G >= 64 ? ~0ull : (1ull << (G & 63u)) - 1ull;
   uint32_t pos = 0;
+  uint32_t v = g.t < n_tok ? tok[g.t] : 0u;
   for (uint32_t base = 0; base < n_tok; base += G) {
     const uint32_t i = base + g.t;
-    const uint32_t v = i < n_tok ? tok[i] : 0u;
     const uint32_t lb = v & 511u;
     const bool skip = lb == CM_INF_TOK_SKIP;
     const uint32_t len = i < n_tok && !skip ? ((v >> 9) & 255u) + 3u : 0u, lits = i < n_tok ? lb : 0u, dist = (v >> 17) + 1u;
@@ -367,6 +367,8 @@ CM_HD int cm_bgzf_resolve(GT &g, uint8_t *win, const uint32_t *tok, uint32_t n_t
     ends[g.t] = i < n_tok ? dst + len : 0xffffffffu;  // (ascending; a token without a match starts and ends where its literals end)
     ends[G + g.t] = i < n_tok ? dst : 0xffffffffu;
     g.sync();
+    // (the next group's tokens: asked for here, after this group's have arrived, on their way while this group is copied)
+    const uint32_t v_next = i + G < n_tok ? tok[i + G] : 0u;
     // a source that ends before the group's first byte waits for nothing; another one for the group's matches [a, b) whose output
     // overlaps it: a tokens end at or before its first byte, b tokens start before its end (two bisections side by side)
     uint32_t a = g.t, b = g.t;
@@ -430,6 +432,7 @@ CM_HD int cm_bgzf_resolve(GT &g, uint8_t *win, const uint32_t *tok, uint32_t n_t
       g.sync();  // this round's bytes before the next round reads them
     }
     pos += total;
+    v = v_next;
   }
   return CM_INF_OK;
 }

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void k_bgzf_resolve(const FqBgzfBlock *__restri
 #pragma unroll
     for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 64u + g.t; r[u] = src[i < n16 ? i : n16 - 1u]; }
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 64u + g.t; if (i < n16) win16[i] = r[u]; }
+    for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 64u + g.t; win16[i < n16 ? i : 65536u / 16u + 1u] = r[u]; }  // (the last word: nobody's)
   }
   g.sync();
   uint8_t *win = reinterpret_cast<uint8_t *>(win16) + a;
