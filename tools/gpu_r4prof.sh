@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel stats + PMC passes (FETCH_SIZE / WRITE_SIZE / LDS conflicts / VALU) of the five bench workloads at one commit
 cd $GRAFT_REPO_ROOT
-T=${1:-r04p}
+T=${1:-r04q}
 bash tools/profile_bench.sh ${T}_headline > gpurun_out/${T}_headline.log 2>&1
 bash tools/profile_bench.sh ${T}_repeat --headline-repeats 32,600,3000,0.02 > gpurun_out/${T}_repeat.log 2>&1
 bash tools/profile_bench.sh ${T}_harsh --headline-repeats profile:1 > gpurun_out/${T}_harsh.log 2>&1
