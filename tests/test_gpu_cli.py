@@ -179,6 +179,36 @@ def test_cli_reads_bgzf_inflated_on_the_device(built, tmp_path):
     assert r.returncode != 0 and b"corrupted" in r.stderr, r.stderr[-500:]
 
 
+@pytest.mark.parametrize("name", ["b1_atac_bc", "s4_se_atac_q0", "s2_atac_q0"])
+def test_cli_bgzf_every_stream_kind(name, built, tmp_path):
+    """reads, mates and barcodes each block-compressed (their own levels and block sizes, small pieces so that several calls per
+    file hand blocks to the device): single-cell, single-end and variable-length inputs give the golden file"""
+    import sys
+    sys.path.insert(0, os.path.join(ds.ROOT, "tools"))
+    import bgzf
+    meta = ds.case_meta(name)
+    fa, reads = _reads(name)
+    args = []
+    k = 0
+    for a in reads:
+        if os.path.isfile(a) and not a.endswith(".txt") and args and args[-1] in ("-1", "-2", "-b"):
+            g = str(tmp_path / ("in%d.fq.gz" % k))
+            text = open(a, "rb").read()
+            block = (0xff00, 7001, 30000)[k % 3]
+            with open(g, "wb") as f:
+                for i in range(0, len(text), block):
+                    f.write(bgzf._block(text[i:i + block], (1, 6, 9)[k % 3]))
+                f.write(bgzf._block(b"", 1))
+            a = g
+            k += 1
+        args.append(a)
+    assert k >= 1
+    out = str(tmp_path / "o.bed")
+    r = subprocess.run([CLI] + list(meta["chromap_flags"]) + ["-x", built(name), "-r", fa] + args + ["-o", out, "--ingest-chunk-mb", "1"], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert ds.md5(out) == meta["bed_md5"]
+
+
 @pytest.mark.skipif(not os.path.exists(REF), reason="built reference binary not present")
 def test_device_built_index_loads_in_reference(built, tmp_path):
     name = "s1_atac"
