@@ -475,9 +475,9 @@ int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_b
 int cmgpu_fastq_set_format(cmgpu_ctx *ctx, int stream, int n_ranges, const int32_t *starts, const int32_t *ends, char strand);
 int cmgpu_fastq_scan(cmgpu_ctx *ctx, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records);
 /* BGZF input (bgzip: gzip members of at most 64 KiB with their size in a 'BC' extra field) inflated ON THE DEVICE: `blocks` holds
- * whole COMPRESSED blocks as they stand in the file (the end-of-file marker block may be among them); a lane per block inflates
- * its DEFLATE payload to the block's place in the stream's text and checks its CRC-32 -- what zlib's gzread does for the
- * reference, one stream per file (src/sequence_batch.cc:22-62).  The text stays on the device: what cmgpu_fastq_take does not
+ * whole COMPRESSED blocks as they stand in the file (the end-of-file marker block may be among them); a lane per block decodes
+ * its DEFLATE codes, a wave per block copies the matches inside the block's place in the stream's text and checks its CRC-32 --
+ * what zlib's gzread does for the reference, one stream per file (src/sequence_batch.cc:22-62).  The text stays on the device: what cmgpu_fastq_take does not
  * consume is kept in front of the blocks of the next call (the host does not resubmit anything; a call after which nothing is
  * taken simply extends the text).  CMGPU_EFORMAT: not BGZF, a truncated or a damaged block (cmgpu_last_error says which), or not
  * 4-line FASTQ.  A call of cmgpu_fastq_scan on the stream returns it to host-resubmitted text. */
