@@ -108,13 +108,15 @@ struct RawBuf {
   ~RawBuf() { free(p); }
 };
 // Plain text is read as it is, ordinary gzip goes through zlib's gzread (one inflating thread per file).  BGZF (bgzip; SAM spec 4.1: a
-// series of gzip members of at most 64 KiB, each carrying its compressed size in a 'BC' extra field) is inflated block-
-// parallel: the block headers are walked without decoding, the ISIZE trailers give every block's place in the output,
-// and a team of threads inflates the blocks of a chunk side by side -- SURVEY.md 8(f)-2: kseq behind one gzread per
-// file (sequence_batch.cc:22-62) caps the reference's ingest at the rate of one inflating core.
+// series of gzip members of at most 64 KiB, each carrying its compressed size in a 'BC' extra field) is not inflated here when one
+// GPU maps: the block headers are walked without decoding and whole compressed blocks go to the device (cmgpu_fastq_scan_bgzf).
+// With several GPUs taking turns (the text a batch leaves over lives on one of them) it is inflated block-parallel on the host: the
+// ISIZE trailers give every block's place in the output, and a team of threads inflates the blocks of a chunk side by side --
+// kseq behind one gzread per file (sequence_batch.cc:22-62) caps the reference's ingest at the rate of one
+// inflating core.  In every mode the next piece of the file is read (inflated) by a thread of its own while the device works.
 struct ChunkReader {
   gzFile f = nullptr;
-  FILE *raw = nullptr;   // BGZF: the compressed file itself
+  FILE *raw = nullptr;   // BGZF and plain text: the file itself
   bool bgzf = false;
   bool plain = false;    // not gzip at all: `raw` is read directly (gzread would copy the bytes twice)
   int team = 4;          // inflating threads for BGZF input
