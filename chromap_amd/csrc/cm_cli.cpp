@@ -113,7 +113,8 @@ struct RawBuf {
 // With several GPUs taking turns (the text a batch leaves over lives on one of them) it is inflated block-parallel on the host: the
 // ISIZE trailers give every block's place in the output, and a team of threads inflates the blocks of a chunk side by side --
 // kseq behind one gzread per file (sequence_batch.cc:22-62) caps the reference's ingest at the rate of one
-// inflating core.  In every mode the next piece of the file is read (inflated) by a thread of its own while the device works.
+// inflating core.  Except on that host path, the next piece of the file is read (gzip: inflated) by a thread of its own while the
+// device works on the one before.
 struct ChunkReader {
   gzFile f = nullptr;
   FILE *raw = nullptr;   // BGZF and plain text: the file itself
