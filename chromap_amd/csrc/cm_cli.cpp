@@ -767,11 +767,21 @@ int main(int argc, char **argv) {
           if (!all_final) { target *= 2; continue; }
           for (int m = 0; m < ns_streams; ++m)
             if (cnt[m] != 0) die("Numbers of reads and barcodes don't match!");
+          // (text inflated on the device: what is left of it must be blank, as only_whitespace() checks for text held here)
+          for (int m = 0; m < ns_streams; ++m)
+            if (rd[m].bgzf && rd[m].dev_inflate) {
+              uint64_t used = 0;
+              if (cmgpu_fastq_take(cx, sid[m], 0, &used) != CMGPU_OK)
+                die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + cmgpu_last_error(cx) + ")");
+            }
           break;
         }
         for (int m = 0; m < ns_streams; ++m) {
           uint64_t used = 0;
-          ckx(cmgpu_fastq_take(cx, sid[m], n, &used));
+          const int trc = cmgpu_fastq_take(cx, sid[m], n, &used);
+          if (trc == CMGPU_EFORMAT && rd[m].bgzf && rd[m].dev_inflate)  // (text behind the file's last whole record)
+            die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + cmgpu_last_error(cx) + ")");
+          ckx(trc);
           rd[m].consume((size_t)used);
         }
         ckx(cmgpu_fastq_commit(cx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));

@@ -171,6 +171,15 @@ def test_cli_reads_bgzf_inflated_on_the_device(built, tmp_path):
     r = subprocess.run([CLI] + meta["chromap_flags"] + ["-x", built(name), "-r", fa, "-1", bg[0], "-2", bg[1], "-o", out], stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr[-500:]
     assert ds.md5(out) == meta["bed_md5"]
+    # half a record behind the last whole one: an error, as it is for text held on the host
+    import bgzf as _b
+    tail = str(tmp_path / "tail.fq.gz")
+    with open(tail, "wb") as f:
+        f.write(open(bg[1], "rb").read()[:-28])  # (without the end-of-file marker block)
+        f.write(_b._block(b"@half\nACGT", 6))
+        f.write(_b._block(b"", 6))
+    r = subprocess.run([CLI] + meta["chromap_flags"] + ["-x", built(name), "-r", fa, "-1", bg[0], "-2", tail, "-o", out], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"corrupted" in r.stderr, r.stderr[-500:]
     raw = bytearray(open(bg[1], "rb").read())
     raw[len(raw) // 2] ^= 0x40
     bad = str(tmp_path / "bad.fq.gz")
