@@ -126,6 +126,19 @@ def flags_to_params(flags):
         elif flags[i] == "-l":
             kw["max_insert_size"] = int(flags[i + 1])
             i += 2
+        elif flags[i] == "-e":
+            kw["error_threshold"] = int(flags[i + 1])
+            i += 2
+        elif flags[i] == "-s":
+            kw["min_num_seeds"] = int(flags[i + 1])
+            i += 2
+        elif flags[i] == "-f":
+            f0, f1 = flags[i + 1].split(",")
+            kw["max_seed_frequency0"], kw["max_seed_frequency1"] = int(f0), int(f1)
+            i += 2
+        elif flags[i] == "--min-read-length":
+            kw["min_read_length"] = int(flags[i + 1])
+            i += 2
         elif flags[i] == "-n":
             kw["max_num_best_mappings"] = int(flags[i + 1])
             i += 2

@@ -26,7 +26,8 @@ GEN = os.path.join(ROOT, "tools", "gen_synth.py")
 # single-end cases: which mate file is mapped alone
 SINGLE_END = {"s1_se_chip": 1, "s4_se_atac_q0": 2, "s4_se_inmem_q0": 1, "s1_se_sam": 1,
               "b1_se_bc": 1, "b3_se_bc_bulk_q0": 1, "b3_se_bc_inmem_q0": 2, "b1_se_bc_tagalign_q0": 1,
-              "s4_se_tagalign_q0": 2, "s4_se_n2_q0": 2, "s4_se_drop2_q0": 2}
+              "s4_se_tagalign_q0": 2, "s4_se_n2_q0": 2, "s4_se_drop2_q0": 2,
+              "p1_se_e5_q0": 1, "p5_se_n5_e5_q0": 2}
 
 # name -> (generator args or None for the toy data, chromap mapping flags)
 CASES = {
@@ -139,6 +140,37 @@ CASES = {
     "h2_hic_n2_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
                       "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"],
                      ["--preset", "hic", "-q", "0", "-n", "2"]),
+    # off-preset parameters (round 5): the 8-lane verification form (error threshold below 8 without split alignment,
+    # alignment.cc:503-654, mapping_parameters.h:80-88), a wide band, min seeds, seed-frequency caps that force the second
+    # round (draft_mapping_generator / candidate_processor), a short insert limit, --min-read-length either side of 30
+    "p1_e5_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "70", "--seed", "51", "--sub", "0.02",
+                  "--indel", "0.003"], ["-e", "5", "-q", "0"]),
+    "p1_e5_atac": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                   ["--preset", "atac", "-e", "5"]),
+    "p1_e3_chip_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "70", "--seed", "51", "--sub", "0.02",
+                       "--indel", "0.003"], ["--preset", "chip", "-e", "3", "-q", "0"]),
+    "p1_se_e5_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "70", "--seed", "51", "--sub", "0.02",
+                     "--indel", "0.003"], ["-e", "5", "-q", "0"]),
+    "p1_e5_sam_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "70", "--seed", "51", "--sub", "0.02",
+                      "--indel", "0.003"], ["-e", "5", "-q", "0", "--SAM"]),
+    "p1_e12_chip_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "100", "--seed", "52", "--sub", "0.04",
+                        "--indel", "0.005"], ["--preset", "chip", "-e", "12", "-q", "0"]),
+    "p2_s3_l300_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                      ["--preset", "chip", "-s", "3", "-l", "300", "-q", "0"]),
+    "p2_s1_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                 ["--preset", "atac", "-s", "1", "-q", "0"]),
+    "p3_f40_90_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                     ["--preset", "atac", "-f", "40,90", "-q", "0"]),
+    "p3_f5_20_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35"],
+                    ["--preset", "chip", "-f", "5,20", "-q", "0"]),
+    "p4_minlen40_q0": (["--genome", "2000000", "--chroms", "3", "--pairs", "20000", "--readlen", "60", "--frag-min", "35",
+                        "--varlen", "--seed", "7"], ["--preset", "atac", "--min-read-length", "40", "-q", "0"]),
+    "p4_minlen20_q0": (["--genome", "2000000", "--chroms", "3", "--pairs", "20000", "--readlen", "60", "--frag-min", "35",
+                        "--varlen", "--seed", "7"], ["--preset", "atac", "--min-read-length", "20", "-q", "0"]),
+    "p5_n5_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                  "--seed", "5"], ["--preset", "atac", "-n", "5", "-q", "0"]),
+    "p5_se_n5_e5_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
+                        "--seed", "5"], ["--preset", "chip", "-n", "5", "-e", "5", "-q", "0"]),
 }
 
 

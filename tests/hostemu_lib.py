@@ -37,6 +37,10 @@ def lib():
     return _L
 
 
+# the oracle's names (oracle/chromap_oracle.h) for the same parameters
+CAPI_NAMES = {"max_seed_freq0": "max_seed_frequency0", "max_seed_freq1": "max_seed_frequency1", "low_mem": "low_memory_mode"}
+
+
 def params(preset=None, **kw):
     L = lib()
     p = _capi.Params()
@@ -49,6 +53,9 @@ def params(preset=None, **kw):
         elif k == "pairs_order":
             p._pairs_order = list(v)
         else:
+            k = CAPI_NAMES.get(k, k)
+            if k not in _capi.PARAM_FIELDS:  # a ctypes structure would take any attribute name silently
+                raise KeyError(k)
             setattr(p, k, v)
     return p
 

@@ -27,6 +27,11 @@ class OraParams(C.Structure):
         "output_mappings_not_in_whitelist", "output_format", "dedup_at_bulk_level")] + [("bc_probability_threshold", C.c_double)]
 
 
+PARAM_NAMES = {n for n, _ in OraParams._fields_}
+# the C ABI's names (include/chromap_amd.h) for the same parameters
+ORACLE_NAMES = {"max_seed_frequency0": "max_seed_freq0", "max_seed_frequency1": "max_seed_freq1", "low_memory_mode": "low_mem"}
+
+
 class OraRecord(C.Structure):
     _fields_ = [("read_id", C.c_uint32), ("rid", C.c_uint32), ("fragment_start", C.c_uint32),
                 ("fragment_length", C.c_uint16), ("mapq", C.c_uint8), ("direction", C.c_uint8),
@@ -113,6 +118,9 @@ def params(preset=None, **kw):
         elif k == "pairs_order":
             p._pairs_order = list(v)
         else:
+            k = ORACLE_NAMES.get(k, k)
+            if k not in PARAM_NAMES:  # a ctypes structure would take any attribute name silently
+                raise KeyError(k)
             setattr(p, k, v)
     return p
 

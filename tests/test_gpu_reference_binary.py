@@ -41,6 +41,23 @@ RUNS = {
     "sam_se_barcodes_q0": ("short", ["--SAM", "--remove-pcr-duplicates", "-q", "0"], True, True),
     # (single-end single-cell data in low-memory mode costs the reference ~30-60 s of fixed time in its merge; in-memory here)
     "tagalign_se_barcodes": ("short", ["--TagAlign", "--remove-pcr-duplicates", "--Tn5-shift", "-q", "0"], True, True),
+    # off the presets: the 8-lane verification form (error threshold < 8 without split alignment, alignment.cc:503-654), wide
+    # bands, min seeds, seed-frequency caps (second round, draft_mapping_generator.cc:159-357), insert limit, --min-read-length
+    # (K0's seed length, chromap.cc:176-216), several best mappings
+    "e5_pe_q0": ("mid", ["-e", "5", "-q", "0"], False, False),
+    "e5_atac": ("short", ["--preset", "atac", "-e", "5"], False, False),
+    "e3_se_q0": ("mid", ["--preset", "chip", "-e", "3", "-q", "0"], True, False),
+    "e5_sam_q0": ("mid", ["-e", "5", "--SAM", "-q", "0"], False, False),
+    "e12_chip_q0": ("mid", ["--preset", "chip", "-e", "12", "-q", "0"], False, False),
+    "e6_hic_q0": ("long", ["--preset", "hic", "-e", "6", "-q", "0"], False, False),
+    "s3_l300_q0": ("short", ["--preset", "chip", "-s", "3", "-l", "300", "-q", "0"], False, False),
+    "s1_q0": ("short", ["--preset", "atac", "-s", "1", "-q", "0"], False, False),
+    "f40_90_q0": ("short", ["--preset", "atac", "-f", "40,90", "-q", "0"], False, False),
+    "f5_20_se_q0": ("short", ["--preset", "chip", "-f", "5,20", "-q", "0"], True, False),
+    "minlen40_q0": ("short", ["--preset", "atac", "--min-read-length", "40", "-q", "0"], False, False),
+    "minlen20_barcodes": ("short", ["--preset", "atac", "--min-read-length", "20"], False, True),
+    "n5_q0": ("short", ["--preset", "atac", "-n", "5", "-q", "0"], False, False),
+    "n5_e5_se_q0": ("short", ["--preset", "chip", "-n", "5", "-e", "5", "-q", "0"], True, False),
 }
 
 
