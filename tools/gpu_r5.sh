@@ -7,7 +7,7 @@ TESTS=${1:-none}; shift
 O=gpurun_out/$T
 mkdir -p $O
 if [ "$TESTS" != "none" ]; then
-  timeout 1500 python -m pytest $TESTS -q --maxfail=10 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+  eval "timeout 1500 python -m pytest $TESTS -q --maxfail=10 -p no:cacheprovider" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
   tail -8 $O/pytest.log
 fi
 run() {  # name, args
