@@ -58,10 +58,11 @@ CM_HD uint32_t cm_coop_chunk(uint32_t n, uint32_t G) { return (n + G - 1) / G; }
 // The buffers ping-pong; returns the one that holds the sorted list.  rb, rb2: nr + 1 entries each.
 // ---------------------------------------------------------------------------------------
 template <class GT>
-CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t *rb, uint32_t *rb2, uint32_t nr, uint32_t tot) {
+CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t *rb, uint32_t *rb2, uint32_t nr, uint32_t tot, uint32_t levels = 32) {
   const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
-  while (nr > 1) {
+  // levels: stop after that many (the caller knows that the runs left then are what it wants: cm_coop_s3b keeps the two strands' lists apart)
+  for (; nr > 1 && levels > 0; --levels) {
     const uint32_t nr2 = (nr + 1) >> 1;
     uint32_t p = c0, j = 0;
     if (p < c1) {  // pair of p: the largest j with rb[2j] <= p
@@ -84,11 +85,16 @@ CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t
       }
       uint32_t ia = a0 + lo, ib = a1 + (diag - lo);
       const uint32_t pend = c1 < b1 ? c1 : b1;
-      uint64_t va = ia < a1 ? src[ia] : 0, vb = ib < b1 ? src[ib] : 0;
+      // an exhausted run reads as the largest value (no key is: a hit's sequence number never has all bits set), so one comparison
+      // decides; the next element of the run that gave is requested while the output is written
+      uint64_t va = ia < a1 ? src[ia] : ~0ull, vb = ib < b1 ? src[ib] : ~0ull;
       for (; p < pend; ++p) {
-        const bool take_a = ib >= b1 || (ia < a1 && va <= vb);
-        if (take_a) { dst[p] = va; ++ia; va = ia < a1 ? src[ia] : 0; }
-        else { dst[p] = vb; ++ib; vb = ib < b1 ? src[ib] : 0; }
+        const bool take_a = va <= vb;
+        dst[p] = take_a ? va : vb;
+        const uint32_t nx = take_a ? ++ia : ++ib;
+        const uint64_t nv = nx < (take_a ? a1 : b1) ? src[nx] : ~0ull;
+        va = take_a ? nv : va;
+        vb = take_a ? vb : nv;
       }
       ++j;
     }
@@ -135,51 +141,76 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
                          unsigned long long *prof = nullptr) {
   const uint64_t SB = 1ull << 63;
   CM_PROF_PTR_BEGIN(prof);
-  // which of this lane's hits (t, t + G, ...) start a local cluster: a bit each (a lane has at most 64 of them: tot <= 64 G
-  // for every work area), then one walk per set bit.  The two loops are apart on purpose: a walk is a chain of dependent loads, and
-  // a wave pays for it in every round in which ANY of its lanes walks -- about one hit in eight starts a cluster, so with the test
-  // and the walk in one loop every round paid (5 rounds, 31 of the sweep's 38 k cycles), while a lane's own starts are 2-3 at most
-  unsigned long long starts = 0;
-  {
-    uint32_t j = 0;
-    for (uint32_t i = g.t; i < tot; i += (uint32_t)GT::G, ++j) {
-      const bool st = i == 0 || cm_sweep_local_break(S[i - 1], S[i], e);
-      if (st && j < 64) starts |= 1ull << j;
-      else if (st) oc[i] = (uint16_t)cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);  // (never: see above)
-      else oc[i] = 0;
-    }
-  }
-  while (starts) {
-    const uint32_t j = (uint32_t)__builtin_ctzll(starts);
-    starts &= starts - 1;
-    const uint32_t i = g.t + j * (uint32_t)GT::G;
-    oc[i] = (uint16_t)cm_sweep_cluster_from(S, i, tot, e, req, num_minimizers, xs + i, xc + i, ~SB);
-  }
-  CM_PROF_PTR_MARK(prof, g, 11);
-  g.sync();
-  CM_PROF_PTR_MARK(prof, g, 12);
-  // exclusive scan of oc in list order: per-lane chunk sums, group scan; the counts stay readable through the neighbour's prefix
+  // Every lane walks its own chunk of the list, front to back: the hits up to the chunk's first local break continue a cluster that an
+  // earlier lane owns and are passed over; every cluster that STARTS in the chunk is swept to its end -- also beyond the chunk's.  So all
+  // lanes take about VT steps (plus the tail of their last cluster) instead of one lane in five walking while the others of its wave wait
+  // (round 4: a strided pass for the starts, then a walk per start -- 38 % of k_s3b_coop).  The two strands' lists never share a cluster:
+  // a walk ends at its list's end (the - keys may or may not carry bit 63).
   const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
-  // (both sums in one scan: a list has at most 65535 hits -- the offsets are 16-bit -- and no more candidates than hits)
+  const bool masked = VT <= 64;  // the chunk's cluster starts as a bit each; longer chunks (no work area has them today) mark them in oc
+  if (!masked) {
+    for (uint32_t i = c0; i < c1; ++i) oc[i] = 0;
+    g.sync();  // (a walk writes oc at its start only, but a start may be any lane's: all zeros first)
+  }
+  unsigned long long starts = 0;
   uint32_t sum = 0, ncp_mine = 0;
-  for (uint32_t i = c0; i < c1; ++i) { const uint32_t c = oc[i]; sum += c; if (i < np) ncp_mine += c; }
+  {
+    uint32_t i = c0;
+    if (i < c1 && i > 0 && i != np) {  // pass over the hits that belong to the cluster of the hit before the chunk
+      uint64_t prev = S[i - 1];
+      while (i < c1 && i != np) {
+        const uint64_t x = S[i];
+        if (cm_sweep_local_break(prev, x, e)) break;
+        prev = x;
+        ++i;
+      }
+    }
+    while (i < c1) {
+      uint32_t end;
+      const uint32_t c = cm_sweep_cluster_walk(S, i, i < np ? np : tot, e, req, num_minimizers, xs + i, xc + i, ~SB, &end);
+      if (c) {
+        oc[i] = (uint16_t)c;
+        if (masked) starts |= 1ull << (i - c0);
+        sum += c;
+        if (i < np) ncp_mine += c;
+      }
+      i = end;
+    }
+  }
+  CM_PROF_PTR_MARK(prof, g, 11);
+  // (both sums in one scan: a list has at most 65535 hits -- the offsets are 16-bit -- and no more candidates than hits.  The scan's
+  // barriers also end the walks: S is no longer read afterwards, the outputs may overlay it)
   uint32_t both;
   uint32_t run = g.scan(sum << 16 | ncp_mine, &both) >> 16;
   const uint32_t total = both >> 16, ncp = both & 0xffffu;
   const uint32_t ncn = total - ncp;
   CM_PROF_PTR_MARK(prof, g, 13);
-  // copy out: every lane the parked candidates of its chunk's clusters (slot i + k -> prefix(i) + k).  No barrier needed before:
-  // the scans above contain them -- all walks are done, S is no longer read (the outputs may overlay it)
-  for (uint32_t i = c0; i < c1; ++i) {
-    const uint32_t c = oc[i];
-    for (uint32_t k = 0; k < c; ++k) {
-      const uint64_t x = xs[i + k];
-      const uint8_t cc = xc[i + k];
-      if (i < np) { out_p[run + k] = x; out_pc[run + k] = cc; }
-      else { out_n[run + k - ncp] = x; out_nc[run + k - ncp] = cc; }
+  // copy out: every lane the parked candidates of its own clusters (slot i + k -> prefix + k), in list order
+  if (masked) {
+    while (starts) {
+      const uint32_t i = c0 + (uint32_t)__builtin_ctzll(starts);
+      starts &= starts - 1;
+      const uint32_t c = oc[i];
+      for (uint32_t k = 0; k < c; ++k) {
+        const uint64_t x = xs[i + k];
+        const uint8_t cc = xc[i + k];
+        if (i < np) { out_p[run + k] = x; out_pc[run + k] = cc; }
+        else { out_n[run + k - ncp] = x; out_nc[run + k - ncp] = cc; }
+      }
+      run += c;
     }
-    run += c;
+  } else {
+    for (uint32_t i = c0; i < c1; ++i) {
+      const uint32_t c = oc[i];
+      for (uint32_t k = 0; k < c; ++k) {
+        const uint64_t x = xs[i + k];
+        const uint8_t cc = xc[i + k];
+        if (i < np) { out_p[run + k] = x; out_pc[run + k] = cc; }
+        else { out_n[run + k - ncp] = x; out_nc[run + k - ncp] = cc; }
+      }
+      run += c;
+    }
   }
   CM_PROF_PTR_MARK(prof, g, 14);
   *ncp_out = ncp;
@@ -249,18 +280,31 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
 // SLAB (compile time): the list buffers are the group's slab of global memory instead of the shared work area.  A template
 // parameter, not a run-time choice: a pointer that may be either makes every access a FLAT instruction -- measured, the shared-
 // memory form then runs at less than half its speed (its loads are chains of dependent accesses).
-template <bool SLAB, class GT>
-CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
-  const uint32_t G = (uint32_t)GT::G;
-  const uint32_t tot = d.hit_tot[r];
+// ---- the shared-memory form's front end (round 5).  The hit list is never laid out lane by lane: the occurrence run of every included
+// minimizer is cut into pieces of W consecutive occurrences (W: the lanes of a wave part), and a wave part takes a piece at a time --
+//   pass 1   one coalesced load of the piece, the candidate position of every occurrence into B at its place in list order, bit 63
+//            for the - strand; the piece's number of + hits (a ballot) into a table; a + hit whose diagonal starts before its sequence
+//            does (the only way a run is not ascending) makes the group decline the read;
+//   scan     of the pieces' + counts: where every piece's + hits and - hits begin in the two strands' lists;
+//   pass 2   every piece again, from B: its + hits to the + list, its - hits to the - list, in order (ballot ranks).
+// A piece never straddles two minimizers, so the lists' ascending runs are known without looking at the keys: run i of the + list
+// starts where minimizer i's first piece does.  Both lists get one (possibly empty) run per minimizer, the + list's table is padded
+// with empty runs to a power of two P2 -- then log2(P2) merge levels never pair a + run with a - run, and the level that only
+// concatenated the two sorted lists (a quarter of the merge's work at 8 minimizers) is gone, like the passes that partitioned the
+// list by strand and looked for run boundaries.
+// Work memory: the pieces' tables overlay oc (2 * pieces + 2 entries of 16 bits, unused until the sweep).
+// Returns 0 (declined), or the number of merge levels + 1; *np_out: the + list's length, m.rb: the run table (*nr_out runs).
+template <class GT>
+CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m, uint32_t tot, uint32_t *np_out, uint32_t *nr_out) {
+  const uint32_t G = (uint32_t)GT::G, W = (uint32_t)GT::W, NW = G / W;
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   const uint64_t SB = 1ull << 63;
-  if (SLAB ? (tot > m.gcap || tot > 0xffffu) : tot > m.P) return false;  // (the sweep's offsets are 16-bit)
-  uint64_t *const A = SLAB ? m.gA : m.A, *const B = SLAB ? m.gB : m.B;
-  CM_PROF_BEGIN(d);
-  // ---- included minimizers and where their occurrences start in the list
-  uint32_t R = 0, off = 0;
+  const uint32_t wl = g.t % W, wv = g.t / W;
+  uint64_t *const A = m.A, *const B = m.B;
+  uint32_t *const choff = m.rb2;  // first piece of every run (R + 1 entries; rb2 is free until the merge)
+  // ---- included minimizers: where their occurrences start in the list, and their pieces
+  uint32_t R = 0, off = 0, NC = 0;
   for (uint32_t base = 0; base < n; base += G) {
     const uint32_t mi = base + g.t;
     uint32_t len = 0, ps = 0;
@@ -274,70 +318,199 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
         else { const uint32_t nocc = (uint32_t)val; if (nocc < maxf) len = nocc; val >>= 32; }
       }
     }
-    uint32_t tv;
+    uint32_t tv, tc;
     const uint32_t sv = g.scan((len ? 1u << 20 : 0u) | len, &tv);  // tot <= 8192 < 2^20: both sums in one scan
+    const uint32_t sc = g.scan((len + W - 1) / W, &tc);
     const uint32_t ri = R + (sv >> 20), o = off + (sv & 0xfffffu);
-    if (len && ri < m.MM) { m.moff[ri] = o; m.mval[ri] = val; m.mps[ri] = ps; }
+    if (len && ri < m.MM) { m.moff[ri] = o; m.mval[ri] = val; m.mps[ri] = ps; choff[ri] = NC + sc; }
     R += tv >> 20;
     off += tv & 0xfffffu;
+    NC += tc;
   }
-  if (R > m.MM || off != tot) return false;
-  if (g.t == 0) m.moff[R] = tot;
+  uint32_t P2 = 1, levels = 0;
+  while (P2 < R) { P2 <<= 1; ++levels; }
+  if (R == 0 || R > m.MM || off != tot || 2 * NC + 2 > m.P || P2 + R > m.RB) return 0;
+  uint16_t *const chrun = m.oc, *const cplus = m.oc + NC;  // a piece's run; its + hits, then (scan) the + hits before it
+  if (g.t == 0) { m.moff[R] = tot; choff[R] = NC; }
   g.sync();
-  CM_PROF_MARK(d, g, 0);
-  // ---- expand
-  for (uint32_t x0 = g.t; x0 < tot; x0 += 8 * G) {
-    uint64_t hit[8];
-    uint32_t ps[8];
+  for (uint32_t ri = g.t; ri < R; ri += G)
+    for (uint32_t c = choff[ri]; c < choff[ri + 1]; ++c) chrun[c] = (uint16_t)ri;
+  g.sync();
+  // ---- pass 1: four pieces per wave part and round, their loads in flight together
+  uint32_t wrapped = 0;
+  for (uint32_t cb = wv; cb < NC; cb += 4 * NW) {
+    uint64_t hit[4];
+    uint32_t ps[4], x[4];
+    bool in[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const uint32_t x = x0 + (uint32_t)q * G;
-      hit[q] = 0; ps[q] = 0;
-      if (x < tot) {
-        uint32_t lo = 0, hi = R;  // the largest ri with moff[ri] <= x
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (m.moff[mid] <= x) lo = mid; else hi = mid;
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t c = cb + (uint32_t)q * NW;
+      in[q] = false; hit[q] = 0; ps[q] = 0; x[q] = 0;
+      if (c < NC) {
+        const uint32_t ri = chrun[c], o0 = m.moff[ri], j = (c - choff[ri]) * W + wl;
+        in[q] = j < m.moff[ri + 1] - o0;
+        if (in[q]) {
+          ps[q] = m.mps[ri];
+          const uint64_t v = m.mval[ri];
+          x[q] = o0 + j;
+          hit[q] = (ps[q] >> 31) ? v : d.occ[(uint32_t)v + j];
         }
-        ps[q] = m.mps[lo];
-        const uint64_t v = m.mval[lo];
-        hit[q] = (ps[q] >> 31) ? v : d.occ[(uint32_t)v + (x - m.moff[lo])];
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const uint32_t x = x0 + (uint32_t)q * G;
-      if (x < tot) {
-        bool same;
-        const uint64_t cp = cm_cand_from_hit(hit[q], ps[q] & 0x7fffffffu, d.p.k, &same);
-        B[x] = same ? cp : (cp | SB);
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t c = cb + (uint32_t)q * NW;
+      bool same = false;
+      const uint64_t cp = cm_cand_from_hit(hit[q], ps[q] & 0x7fffffffu, d.p.k, &same);
+      if (in[q]) {
+        B[x[q]] = same ? cp : (cp | SB);
+        if (same && (uint32_t)(hit[q] >> 1) < ((ps[q] & 0x7fffffffu) >> 1)) wrapped = 1;
+      }
+      uint32_t np_c;
+      (void)g.rank(in[q] && same, &np_c);
+      if (c < NC && wl == 0) cplus[c] = (uint16_t)np_c;
+    }
+  }
+  g.sync();
+  // ---- + hits before every piece
+  uint32_t np = 0, any_wrapped = 0;
+  for (uint32_t base = 0; base < NC || base == 0; base += G) {
+    const uint32_t c = base + g.t;
+    const uint32_t v = c < NC ? cplus[c] : 0u;
+    uint32_t tv;
+    const uint32_t sv = g.scan(v | (base == 0 ? wrapped << 20 : 0u), &tv);
+    if (c < NC) cplus[c] = (uint16_t)(np + (sv & 0xfffffu));
+    np += tv & 0xfffffu;
+    any_wrapped |= tv >> 20;
+  }
+  if (any_wrapped) return 0;
+  if (g.t == 0) cplus[NC] = (uint16_t)np;
+  g.sync();
+  // ---- pass 2: the two lists, and their run tables: + runs 0 .. R - 1, empty ones up to P2, then the - runs
+  for (uint32_t c = wv; c < NC; c += NW) {
+    const uint32_t ri = chrun[c], o0 = m.moff[ri], j = (c - choff[ri]) * W + wl;
+    const bool in = j < m.moff[ri + 1] - o0;
+    const uint32_t xq = o0 + j;
+    const uint64_t v = in ? B[xq] : SB;
+    const bool plus = !(v >> 63);
+    uint32_t unused;
+    const uint32_t before = (uint32_t)cplus[c] + g.rank(plus, &unused);  // + hits in front of this one, in list order
+    if (in) A[plus ? before : np + (xq - before)] = v & ~SB;
+  }
+  for (uint32_t q = g.t; q <= P2 + R; q += G) {
+    uint32_t v;
+    if (q < R) v = cplus[choff[q]];
+    else if (q < P2) v = np;
+    else if (q < P2 + R) v = np + (m.moff[q - P2] - (uint32_t)cplus[choff[q - P2]]);
+    else v = tot;
+    m.rb[q] = v;
+  }
+  g.sync();
+  *np_out = np;
+  *nr_out = P2 + R;
+  return levels + 1;
+}
+
+template <bool SLAB, class GT>
+CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
+  const uint32_t G = (uint32_t)GT::G;
+  const uint32_t tot = d.hit_tot[r];
+  const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
+  const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
+  const uint64_t SB = 1ull << 63;
+  if (SLAB ? (tot > m.gcap || tot > 0xffffu) : tot > m.P) return false;  // (the sweep's offsets are 16-bit)
+  uint64_t *const A = SLAB ? m.gA : m.A, *const B = SLAB ? m.gB : m.B;
+  CM_PROF_BEGIN(d);
+  uint32_t np;
+  uint64_t *S;
+  if (!SLAB) {
+    uint32_t nr;
+    const uint32_t lv = cm_coop_s3b_expand(d, r, g, m, tot, &np, &nr);
+    if (lv == 0) return false;
+    CM_PROF_MARK(d, g, 1);
+    S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot, lv - 1);
+    CM_PROF_MARK(d, g, 4);
+    CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
+  } else {
+    // ---- included minimizers and where their occurrences start in the list
+    uint32_t R = 0, off = 0;
+    for (uint32_t base = 0; base < n; base += G) {
+      const uint32_t mi = base + g.t;
+      uint32_t len = 0, ps = 0;
+      uint64_t val = 0;
+      if (mi < n) {
+        const uint8_t kind = d.pr_kind[b + mi];
+        if (kind != CM_PR_MISS) {
+          val = d.pr_val[b + mi];
+          ps = d.mm_ps[b + mi];
+          if (kind == CM_PR_SINGLE) { len = 1; ps |= 1u << 31; }
+          else { const uint32_t nocc = (uint32_t)val; if (nocc < maxf) len = nocc; val >>= 32; }
+        }
+      }
+      uint32_t tv;
+      const uint32_t sv = g.scan((len ? 1u << 20 : 0u) | len, &tv);  // tot <= 8192 < 2^20: both sums in one scan
+      const uint32_t ri = R + (sv >> 20), o = off + (sv & 0xfffffu);
+      if (len && ri < m.MM) { m.moff[ri] = o; m.mval[ri] = val; m.mps[ri] = ps; }
+      R += tv >> 20;
+      off += tv & 0xfffffu;
+    }
+    if (R > m.MM || off != tot) return false;
+    if (g.t == 0) m.moff[R] = tot;
+    g.sync();
+    CM_PROF_MARK(d, g, 0);
+    // ---- expand
+    for (uint32_t x0 = g.t; x0 < tot; x0 += 8 * G) {
+      uint64_t hit[8];
+      uint32_t ps[8];
+  #pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t x = x0 + (uint32_t)q * G;
+        hit[q] = 0; ps[q] = 0;
+        if (x < tot) {
+          uint32_t lo = 0, hi = R;  // the largest ri with moff[ri] <= x
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (m.moff[mid] <= x) lo = mid; else hi = mid;
+          }
+          ps[q] = m.mps[lo];
+          const uint64_t v = m.mval[lo];
+          hit[q] = (ps[q] >> 31) ? v : d.occ[(uint32_t)v + (x - m.moff[lo])];
+        }
+      }
+  #pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t x = x0 + (uint32_t)q * G;
+        if (x < tot) {
+          bool same;
+          const uint64_t cp = cm_cand_from_hit(hit[q], ps[q] & 0x7fffffffu, d.p.k, &same);
+          B[x] = same ? cp : (cp | SB);
+        }
       }
     }
-  }
-  g.sync();
-  CM_PROF_MARK(d, g, 1);
-  // ---- split: + hits in order, then - hits in order
-  uint32_t np;
-  {
-    const uint32_t VT = cm_coop_chunk(tot, G);
-    const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
-    uint32_t cnt = 0;
-    for (uint32_t x = c0; x < c1; ++x) cnt += (B[x] >> 63) ? 0u : 1u;
-    uint32_t pos = g.scan(cnt, &np);
-    for (uint32_t x = c0; x < c1; ++x) {
-      const uint64_t v = B[x];
-      if (v >> 63) A[np + (x - pos)] = v; else A[pos++] = v;
+    g.sync();
+    CM_PROF_MARK(d, g, 1);
+    // ---- split: + hits in order, then - hits in order
+    {
+      const uint32_t VT = cm_coop_chunk(tot, G);
+      const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
+      uint32_t cnt = 0;
+      for (uint32_t x = c0; x < c1; ++x) cnt += (B[x] >> 63) ? 0u : 1u;
+      uint32_t pos = g.scan(cnt, &np);
+      for (uint32_t x = c0; x < c1; ++x) {
+        const uint64_t v = B[x];
+        if (v >> 63) A[np + (x - pos)] = v; else A[pos++] = v;
+      }
     }
+    g.sync();
+    CM_PROF_MARK(d, g, 2);
+    // ---- sort
+    const uint32_t nr = cm_coop_natural_runs(g, A, tot, m.rb, m.RB);
+    if (nr == 0) return false;
+    CM_PROF_MARK(d, g, 3);
+    S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot);
+    CM_PROF_MARK(d, g, 4);
+    CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
   }
-  g.sync();
-  CM_PROF_MARK(d, g, 2);
-  // ---- sort
-  const uint32_t nr = cm_coop_natural_runs(g, A, tot, m.rb, m.RB);
-  if (nr == 0) return false;
-  CM_PROF_MARK(d, g, 3);
-  uint64_t *S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot);
-  CM_PROF_MARK(d, g, 4);
-  CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
   // ---- sweep
   const uint32_t nn = tot - np;
   const bool use_high = d.round2[r] && np > 0 && nn > 0;

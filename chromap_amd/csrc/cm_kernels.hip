@@ -1770,7 +1770,7 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
   for (int c = 0; c < CM_HV_LISTS; ++c) rest[c] = n_cls[c];
   if (coop && d.hv_max[0]) {
     const uint32_t MM = cm_coop_mm(d, max_read_len);
-    const uint32_t RB = d.coop_rb ? d.coop_rb : 2 * MM + 2;  // two runs per minimizer unless a diagonal wraps
+    const uint32_t RB = d.coop_rb ? d.coop_rb : 3 * MM + 2;  // a run per minimizer and strand, the + list's table padded to a power of two (cm_coop_s3b_expand)
     uint32_t *fb_list = d.hv_list + 5 * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + 5;
     bool any_coop = false;
     if (n_cls[0]) {  // a wave per read, two reads per block

@@ -1184,6 +1184,41 @@ CM_HD uint32_t cm_sweep_cluster_from(const uint64_t *h, uint32_t b, uint32_t n, 
   return out;
 }
 
+// cm_sweep_cluster_from that also says where the local cluster ends (*end_out: the index of the first hit behind it, at most n)
+CM_HD uint32_t cm_sweep_cluster_walk(const uint64_t *h, uint32_t b, uint32_t n, int e, int seeds_required, uint32_t num_minimizers,
+                                     uint64_t *out_h, uint8_t *out_c, uint64_t out_mask, uint32_t *end_out) {
+  uint32_t out = 0;
+  int mcount = 1, equal = 1, best_equal = 1;
+  uint64_t prev_hit = h[b], best_local = prev_hit;
+  uint64_t ahead = b + 1 < n ? h[b + 1] : ~0ull;
+  uint32_t pi = b + 1;
+  for (;; ++pi) {
+    uint64_t x = ahead;
+    ahead = pi + 1 < n ? h[pi + 1] : ~0ull;
+    const bool last = pi >= n || cm_sweep_local_break(prev_hit, x, e);
+    if (last) x = ~0ull;
+    if (last || ((uint32_t)mcount >= num_minimizers && (uint32_t)x > (uint32_t)best_local + (uint32_t)e)) {
+      if (mcount >= seeds_required) {
+        out_h[out] = best_local & out_mask; out_c[out] = (uint8_t)best_equal;
+        ++out;
+      }
+      if (last) break;
+      mcount = 1; equal = 1; best_equal = 1;
+      best_local = x;
+    } else {
+      if (x == best_local) { ++equal; ++best_equal; }
+      else if (x == prev_hit) {
+        ++equal;
+        if (equal > best_equal) { best_local = prev_hit; best_equal = equal; }
+      } else equal = 1;
+      ++mcount;
+    }
+    prev_hit = x;
+  }
+  *end_out = pi;
+  return out;
+}
+
 CM_HD uint32_t cm_sweep(uint64_t *h, uint8_t *cnt, uint32_t n, int e, int seeds_required, uint32_t num_minimizers) {
   return cm_sweep_strided(h, cnt, n, e, seeds_required, num_minimizers, 1);
 }
