@@ -1075,7 +1075,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   HIPCHECK(c, cm_stream_sync(s));
   {  // speculative launch set: a class with items whose kernels were not launched -> the range again with every class on
     unsigned long long seen = 0;
-    for (uint32_t l = 6; l < CM_HV_LISTS; ++l) if (h_cls[l]) seen |= 1ull << l;
+    for (uint32_t l = 6; l < CM_HV_LISTS; ++l) if (h_cls[l]) seen |= 1ull << (l == 31 ? 23 : l);  // (list 31's kernels are launched with list 23's)
     const unsigned long long launched = c->cls_all || !c->opt_spec ? ~0ull : c->cls_seen;
     if (!(spec && hst[CM_ST_ABORT]) && (seen & ~launched)) {
       c->cls_all = true;

@@ -698,25 +698,57 @@ CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopM
 #define CM_RESCUE_WMAX 304u   // best mate candidates a search can have (cm_rescue_bails: fewer than 300)
 #define CM_RESCUE_PAIRS 640u  // (minimizer, window) pairs per round: at least two minimizers' worth
 #define CM_RESCUE_SLOTS 32u   // minimizers per round
+// the small layout (round 5): the rescue kernels are chains of dependent reads of the occurrence table, their rate is the number of
+// searches in flight -- measured on profile 2: a wave's tables of 10.4 KB allow 15 waves per CU; with 10 KB more (7 waves) the two
+// kernels take 33 + 28 ms longer, i.e. ~430 ms / (waves per CU) each.  Nearly every search has fewer than 64 best mate candidates
+// (tools/coop_profile.py: none above 64 on profile 2), so the common search gets tables of 4.5 KB (32 waves per CU: the wave
+// limit) and the few others are handed to a launch with the full tables.
+#define CM_RESCUE_WMAX_S 64u
+#define CM_RESCUE_PAIRS_S 384u
 struct CmCoopRescueMem {
-  uint64_t *es, *ee;   // CM_RESCUE_WMAX each: the merged windows
-  uint64_t *bp;        // CM_RESCUE_WMAX: the best candidates' positions while the windows are built (overlays pa / pb)
+  uint64_t *es, *ee;   // wmax each: the merged windows
+  uint64_t *bp;        // wmax: the best candidates' positions while the windows are built (overlays pa / pb)
   uint64_t *mval;      // CM_RESCUE_SLOTS: lookup result of the round's minimizers (occurrence offset << 32 | count; a singleton: the occurrence)
   uint32_t *mps;       // CM_RESCUE_SLOTS: position << 1 | strand, bit 31: singleton
-  uint32_t *pa, *pb;   // CM_RESCUE_PAIRS + 1 each: lower bound | occurrences equal to es << 30, upper bound -> first index, length -> first index, offset
+  uint32_t *pa, *pb;   // pairs + 1 each: lower bound | occurrences equal to es << 30, upper bound -> first index, length -> first index, offset
+  uint8_t *tq;         // pairs: where a window's search ends for each of the three places it can start (phase B)
+  uint32_t wmax, pairs;
 };
-#define CM_RESCUE_MEM_BYTES (CM_RESCUE_WMAX * 16 + CM_RESCUE_SLOTS * 12 + (CM_RESCUE_PAIRS + 1) * 8 + 32)
-CM_HD size_t cm_coop_rescue_mem_bytes() { return (size_t)CM_RESCUE_WMAX * 16 + (size_t)CM_RESCUE_SLOTS * 12 + ((size_t)CM_RESCUE_PAIRS + 1) * 8 + 32; }
-CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base) {
+#define CM_RESCUE_BYTES(WMAX_, PAIRS_) ((WMAX_) * 16 + CM_RESCUE_SLOTS * 12 + ((PAIRS_) + 1) * 8 + (PAIRS_) + 32)
+#define CM_RESCUE_MEM_BYTES CM_RESCUE_BYTES(CM_RESCUE_WMAX, CM_RESCUE_PAIRS)
+#define CM_RESCUE_MEM_BYTES_S CM_RESCUE_BYTES(CM_RESCUE_WMAX_S, CM_RESCUE_PAIRS_S)
+CM_HD size_t cm_coop_rescue_mem_bytes(uint32_t wmax = CM_RESCUE_WMAX, uint32_t pairs = CM_RESCUE_PAIRS) { return (size_t)CM_RESCUE_BYTES(wmax, pairs); }
+CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base, uint32_t wmax = CM_RESCUE_WMAX, uint32_t pairs = CM_RESCUE_PAIRS) {
   CmCoopRescueMem m;
+  m.wmax = wmax; m.pairs = pairs;
   m.es = reinterpret_cast<uint64_t *>(base);
-  m.ee = m.es + CM_RESCUE_WMAX;
-  m.mval = m.ee + CM_RESCUE_WMAX;
+  m.ee = m.es + wmax;
+  m.mval = m.ee + wmax;
   m.mps = reinterpret_cast<uint32_t *>(m.mval + CM_RESCUE_SLOTS);
   m.pa = m.mps + CM_RESCUE_SLOTS;
-  m.pb = m.pa + CM_RESCUE_PAIRS + 1;
-  m.bp = reinterpret_cast<uint64_t *>(m.pa);  // (8-byte aligned: 32 words of mps behind 8-byte arrays; 2 x 641 words hold 304 positions)
+  m.pb = m.pa + pairs + 1;
+  m.tq = reinterpret_cast<uint8_t *>(m.pb + pairs + 1);
+  m.bp = reinterpret_cast<uint64_t *>(m.pa);  // (8-byte aligned: 32 words of mps behind 8-byte arrays; 2 x (pairs + 1) words hold wmax positions)
   return m;
+}
+// how many of a mate's candidates have the best count (what cm_coop_rescue's tables must hold): every lane gets it
+template <class GT>
+CM_HD uint32_t cm_coop_rescue_best_num(GT &g, const uint8_t *mc, uint32_t mn) {
+  uint32_t lmax = 0;
+  for (uint32_t i = g.t; i < mn; i += (uint32_t)GT::G) lmax = mc[i] > lmax ? mc[i] : lmax;
+  const uint32_t mx = (uint32_t)g.max64((uint64_t)lmax);
+  uint32_t lnum = 0;
+  for (uint32_t i = g.t; i < mn; i += (uint32_t)GT::G) lnum += mc[i] == mx ? 1u : 0u;
+  return g.sum(lnum);
+}
+// do both searches of read r fit tables with room for wmax best candidates?  (cm_coop_s4a_rescue / cm_coop_s4b_fill with such tables)
+template <class GT>
+CM_HD bool cm_coop_rescue_fits(const CmDev &d, uint32_t r, GT &g, uint32_t wmax) {
+  const uint32_t o = r ^ 1u;
+  const uint32_t a = d.ncp[o] > wmax ? cm_coop_rescue_best_num(g, cm_c0_pcnt(d, o), d.ncp[o]) : 0u;
+  const uint32_t b = d.ncn[o] > wmax ? cm_coop_rescue_best_num(g, cm_c0_ncnt(d, o), d.ncn[o]) : 0u;
+  // (a search that bails out -- 300 best candidates or more, cm_rescue_bails -- needs no tables at all)
+  return (a <= wmax || a >= 300u) && (b <= wmax || b >= 300u);
 }
 // phase C of cm_coop_rescue: the occurrences of the pairs' ranges (first index pa, offsets pb, pb[np] = total) on the wanted strand,
 // counted (*cnt += their number) and, out != nullptr, written from out[*cnt] on in pair / occurrence order
@@ -808,11 +840,11 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
     W += tot;
   }
   g.sync();  // (bp is dead from here on: pa / pb overlay it)
-  // ---- the minimizers, CM_RESCUE_SLOTS (or as many as CM_RESCUE_PAIRS pairs hold) per round
+  // ---- the minimizers, CM_RESCUE_SLOTS (or as many as m.pairs pairs hold) per round
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const bool no_window = W == 0;  // (no mate candidate: cm_rescue then finds the singletons only; callers do not ask)
   if (no_window) { W = 1; if (g.t == 0) { m.es[0] = ~0ull; m.ee[0] = 0; } g.sync(); }
-  uint32_t per_round = CM_RESCUE_PAIRS / W;
+  uint32_t per_round = m.pairs / W;
   if (per_round > CM_RESCUE_SLOTS) per_round = CM_RESCUE_SLOTS;
   if (per_round == 0) per_round = 1;
   uint32_t cnt = 0;  // hits so far (uniform)
@@ -913,7 +945,44 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       m.pa[q] = lb | (((v0 == es ? 1u : 0u) + (v1 == es ? 1u : 0u)) << 30);
     }
     g.sync();
-    // -- B: the chain of searches per minimizer, on indices alone: first index and length of every pair's scan
+    // -- B: the chain of searches per minimizer, on indices alone: first index and length of every pair's scan.  The reference's search
+    //    for window w starts at l = the last midpoint of window w - 1's search, and a search that starts at or below the lower bound lb ends
+    //    with its last midpoint at lb - 1 or lb (nothing equal to es), or at lb / lb + 1 (something equal); one that starts above lb stays
+    //    where it started.  So a search starts at lb(w - 1) - 1, lb(w - 1) or lb(w - 1) + 1: B1 replays it for all three, a lane per
+    //    (minimizer, window) pair, and keeps where each ends relative to lb(w); B2, a lane per minimizer, only follows the chain through
+    //    these tables (a window whose numbers do not fit the scheme is replayed in full there: the result is the replay's whatever the
+    //    argument above is worth).  Round 4 replayed every window's ~12 steps in B2: W x 12 dependent iterations on 8 lanes of 64 --
+    //    as long as phase A's chains of loads for a search with 200 windows.
+    for (uint32_t q = g.t; q < np; q += G) {
+      const uint32_t s = q / W, w = q - s * W;
+      uint8_t t = 0xff;
+      const uint32_t nocc = (m.mps[s] >> 31) ? 0u : (uint32_t)m.mval[s];
+      if (nocc) {
+        const uint32_t lbx = m.pa[q];
+        const int32_t lb = (int32_t)(lbx & 0x3fffffffu), le = lb + (int32_t)(lbx >> 30);
+        const int32_t lbp = w ? (int32_t)(m.pa[q - 1] & 0x3fffffffu) : 0;
+        uint32_t enc = 0;
+        bool ok = true;
+#pragma unroll
+        for (int dl = -1; dl <= 1; ++dl) {
+          int32_t l = w ? lbp + dl : 0;
+          l = l < 0 ? 0 : (l > (int32_t)nocc - 1 ? (int32_t)nocc - 1 : l);  // (a start outside the run is one no search ends at)
+          int32_t mid = 0, rr = (int32_t)(nocc - 1);
+          while (l <= rr) {
+            mid = (l + rr) / 2;
+            if (mid < lb) l = mid + 1;
+            else if (mid >= le) rr = mid - 1;
+            else break;
+          }
+          const int32_t dd = mid - lb;
+          if (dd < -1 || dd > 1) ok = false;
+          enc |= (uint32_t)((dd + 1) & 3) << (2 * (dl + 1));
+        }
+        if (ok) t = (uint8_t)enc;
+      }
+      m.tq[q] = t;
+    }
+    g.sync();
     for (uint32_t s = g.t; s < ns; s += G) {
       const uint32_t ps = m.mps[s];
       const uint64_t val = m.mval[s];
@@ -922,20 +991,29 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
         continue;
       }
       const uint32_t nocc = (uint32_t)val;
-      int32_t prev_l = 0;
+      int32_t prev_l = 0, lbp = 0;
       for (uint32_t w = 0; w < W; ++w) {
         const uint32_t lbx = m.pa[s * W + w], ub = m.pb[s * W + w];
         uint32_t first = 0, len = 0;
         if (nocc) {
           const int32_t lb = (int32_t)(lbx & 0x3fffffffu), le = lb + (int32_t)(lbx >> 30);
-          int32_t l = prev_l, mid = 0, rr = (int32_t)(nocc - 1);
-          while (l <= rr) {
-            mid = (l + rr) / 2;
-            if (mid < lb) l = mid + 1;
-            else if (mid >= le) rr = mid - 1;
-            else break;
+          const uint32_t t = m.tq[s * W + w];
+          const int32_t dl = w ? prev_l - lbp : 0;
+          int32_t mid;
+          if (t != 0xff && dl >= -1 && dl <= 1 && (w == 0 || (prev_l >= 0 && prev_l <= (int32_t)nocc - 1))) {
+            mid = lb + (int32_t)((t >> (2 * (dl + 1))) & 3u) - 1;
+          } else {
+            int32_t l = prev_l, rr = (int32_t)(nocc - 1);
+            mid = 0;
+            while (l <= rr) {
+              mid = (l + rr) / 2;
+              if (mid < lb) l = mid + 1;
+              else if (mid >= le) rr = mid - 1;
+              else break;
+            }
           }
           prev_l = mid;
+          lbp = lb;
           first = (uint32_t)mid;
           len = ub > first && !no_window ? ub - first : 0u;
         }

@@ -940,28 +940,50 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
 // The reads of list 23 (their mate has CM_RS_WAVE candidates or more on a strand): a wave per read.  Kernels of their own so that the
 // list kernels above keep their shared memory free (three lanes' kernels share the CUs); the grid strides over the device-side list
 // and leaves at once when it is empty.
+// SMALL: tables for searches with up to CM_RESCUE_WMAX_S best mate candidates (4.5 KB: 32 waves per CU instead of 15, cm_coop.h) over
+// list 23; the reads with a longer search are appended to list 31, which the launch with the full tables (SMALL = false) works through.
+#define CM_LIST_RESCUE_WAVE 23u
+#define CM_LIST_RESCUE_WAVE_BIG 31u
+template <bool SMALL>
 __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
-  __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
-  const uint32_t cnt = d.hv_cnt[23];
+  __shared__ __attribute__((aligned(16))) uint8_t rmem[SMALL ? CM_RESCUE_MEM_BYTES_S : CM_RESCUE_MEM_BYTES];
+  const uint32_t li = SMALL ? CM_LIST_RESCUE_WAVE : CM_LIST_RESCUE_WAVE_BIG;
+  const uint32_t cnt = d.hv_cnt[li];
   if (blockIdx.x >= cnt) return;
-  const uint32_t *list = d.hv_list + (size_t)23 * d.hv_stride;
-  const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
+  const uint32_t *list = d.hv_list + (size_t)li * d.hv_stride;
+  const CmCoopRescueMem m = SMALL ? cm_coop_rescue_mem_at(rmem, CM_RESCUE_WMAX_S, CM_RESCUE_PAIRS_S) : cm_coop_rescue_mem_at(rmem);
   CmDevGroup<64> g;
   g.t = threadIdx.x;
   g.xw = nullptr;
   const long long t0 = d.prof ? clock64() : 0;
-  for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) { cm_coop_s4a_rescue(d, list[j], g, m); g.sync(); }
+  for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+    const uint32_t r = list[j];
+    if (SMALL && d.prof) {  // measurement aid (tools/coop_profile.py): the best mate candidates of the wave kernel's searches
+      const uint32_t o = r ^ 1u;
+      const uint32_t a = cm_coop_rescue_best_num(g, cm_c0_pcnt(d, o), d.ncp[o]), b = cm_coop_rescue_best_num(g, cm_c0_ncnt(d, o), d.ncn[o]);
+      const uint32_t mx = a > b ? a : b;
+      if (threadIdx.x == 0) atomicAdd(&d.prof[mx < 16 ? 40 : mx < 32 ? 41 : mx < 64 ? 42 : mx < 128 ? 43 : mx < 200 ? 44 : mx < 300 ? 45 : 46], 1ull);
+    }
+    if (SMALL && !cm_coop_rescue_fits(d, r, g, CM_RESCUE_WMAX_S)) {
+      if (threadIdx.x == 0) d.hv_list[(size_t)CM_LIST_RESCUE_WAVE_BIG * d.hv_stride + atomicAdd(d.hv_cnt + CM_LIST_RESCUE_WAVE_BIG, 1u)] = r;
+      continue;
+    }
+    cm_coop_s4a_rescue(d, r, g, m);
+    g.sync();
+  }
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[27], dt); atomicMax(&d.prof[28], dt); }
 }
 // the fill pass: the hits written (or copied out of the pool the counting pass left them in), then sorted / merged by the size class's
 // group (k_s4b_coop) -- or, a short list, by lane 0 here
+template <bool SMALL>
 __global__ __launch_bounds__(64) void k_s4b_rescue_wave(CmDev d, uint32_t coop) {
   if (d.abort && *d.abort) return;
-  __shared__ __attribute__((aligned(16))) uint8_t rmem[CM_RESCUE_MEM_BYTES];
-  const uint32_t cnt = d.hv_cnt[23];
+  __shared__ __attribute__((aligned(16))) uint8_t rmem[SMALL ? CM_RESCUE_MEM_BYTES_S : CM_RESCUE_MEM_BYTES];
+  const uint32_t li = SMALL ? CM_LIST_RESCUE_WAVE : CM_LIST_RESCUE_WAVE_BIG;
+  const uint32_t cnt = d.hv_cnt[li];
   if (blockIdx.x >= cnt) return;
-  const uint32_t *list = d.hv_list + (size_t)23 * d.hv_stride;
-  const CmCoopRescueMem m = cm_coop_rescue_mem_at(rmem);
+  const uint32_t *list = d.hv_list + (size_t)li * d.hv_stride;
+  const CmCoopRescueMem m = SMALL ? cm_coop_rescue_mem_at(rmem, CM_RESCUE_WMAX_S, CM_RESCUE_PAIRS_S) : cm_coop_rescue_mem_at(rmem);
   CmDevGroup<64> g;
   g.t = threadIdx.x;
   g.xw = nullptr;
@@ -969,6 +991,7 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_wave(CmDev d, uint32_t coop) 
   for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
     const uint32_t r = list[j];
     if (d.resc_n[r] + d.resc_p[r] == 0) continue;  // nothing found: k_s4b_rescue_merge copies the read's own candidates
+    if (SMALL && !cm_coop_rescue_fits(d, r, g, CM_RESCUE_WMAX_S)) continue;  // (list 31: the launch with the full tables)
     cm_coop_s4b_fill(d, r, g, m);
     g.sync();
     const uint32_t cls = cm_rescue_coop_class(d, r, coop);
@@ -1763,6 +1786,7 @@ static inline uint32_t cm_coop_mm(const CmDev &d, uint32_t max_read_len) {
   uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
   return MM > 256 ? 256 : MM;
 }
+static size_t cm_exp_pad() { const char *e = getenv("CM_COOP_LDS_PAD"); return e ? (size_t)atoi(e) * 1024 : 0; }  // EXPERIMENT (remove)
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len) {
   auto pow2 = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };  // the sort network's size: a power of two
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
@@ -1789,7 +1813,7 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     }
 #define CM_S3B_COOP_CLASS(C_, Q_, G_)                                                                                                              \
     if (n_cls[C_] && d.hv_max[Q_] > d.hv_max[Q_ - 1]) {                                                                                            \
-      const size_t lds = cm_coop_group_bytes(d.hv_max[Q_], MM, RB, false);                                                                         \
+      const size_t lds = cm_coop_group_bytes(d.hv_max[Q_], MM, RB, false) + cm_exp_pad();                                                          \
       if (cm_lds_optin(&k_s3b_coop<G_>, lds)) {                                                                                                    \
         hipLaunchKernelGGL(k_s3b_coop<G_>, dim3(n_cls[C_]), dim3(G_), lds, s, d, lst(C_), n_cls[C_], d.hv_max[Q_], MM, RB, fb_list, fb_cnt, 0u);  \
         rest[C_] = 0; any_coop = true;                                                                                                             \
@@ -1872,7 +1896,10 @@ static inline dim3 rescue_list_grid(uint32_t n_reads) {
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop) {
   if (!n_reads) return;
   hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), coop ? 1u : 0u);
-  if ((coop) && cm_cls_on(d, 23)) hipLaunchKernelGGL(k_s4a_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);
+  if ((coop) && cm_cls_on(d, 23)) {
+    hipLaunchKernelGGL(k_s4a_rescue_wave<true>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(k_s4a_rescue_wave<false>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);  // (what the small tables do not hold; leaves at once when there is none)
+  }
 }
 // the per-read part (reads without rescue hits) and, coop: the reads whose long lists a wave copies
 static bool cm_s4b_coop_ready(const CmDev &d, uint32_t RB, size_t *lds) {
@@ -1908,7 +1935,10 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
   // list 23's reads were counted by waves whenever the option is on: they are filled by waves too (all == false: the groups that
   // would sort long lists do not fit this device -- every list is then finished by the wave's lane 0)
-  if ((coop) && cm_cls_on(d, 23)) hipLaunchKernelGGL(k_s4b_rescue_wave, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
+  if ((coop) && cm_cls_on(d, 23)) {
+    hipLaunchKernelGGL(k_s4b_rescue_wave<true>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
+    hipLaunchKernelGGL(k_s4b_rescue_wave<false>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
+  }
   if (!all) return;
   uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
   if (blocks > 2048) blocks = 2048;

@@ -25,7 +25,7 @@
 #define CM_PR_MULTI 2
 #define CM_V_INVALID 0x7fff
 #define CM_MM_CHUNKS 8            // chunks of a batch whose index probe overlaps the next chunk's minimizer pass
-#define CM_HV_LISTS 31           // device work lists of hv_stride entries each: 0-4 and 10 hit-list classes, 5 reads the merge-sort kernel declined, 6-8 and 11 rescue classes, 9 / 14 pairs for the filter (lists up to 1024 / 4096 entries), 12 reads / 13 pairs of the later stages, 15 rescue lists / 16 declined hit lists beyond the largest class, 17 multi-mapped pairs, 18 / 20 pairs / multi-mapped pairs for a block each, 19 pairs for the filter with lists beyond 4096 entries
+#define CM_HV_LISTS 32           // device work lists of hv_stride entries each: 0-4 and 10 hit-list classes, 5 reads the merge-sort kernel declined, 6-8 and 11 rescue classes, 9 / 14 pairs for the filter (lists up to 1024 / 4096 entries), 12 reads / 13 pairs of the later stages, 15 rescue lists / 16 declined hit lists beyond the largest class, 17 multi-mapped pairs, 18 / 20 pairs / multi-mapped pairs for a block each, 19 pairs for the filter with lists beyond 4096 entries, 23 reads whose rescue searches a wave runs / 31 those of them that need the full tables
 #define CM_RS_SEGS 64           // rescue list segments (one counter each, on its own cache line)
 #define CM_MAX_BEST 64          // upper bound on max_num_best_mappings (-n)
 #define CM_SORT_SERIAL_MAX 24   // cm_sort_cand / cm_sort_draft: insertion sort up to here, heap sort beyond

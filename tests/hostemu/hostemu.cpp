@@ -35,7 +35,10 @@ struct EmuCoop { int G; uint32_t thr, P, MM, RB; };
 static EmuCoop g_coop = {0, 0, 0, 0, 0};
 static bool g_planes = true;  // the bit-plane verification (k_pack_ref / k_pack_reads + cm_banded_align_planes); 0: the byte form
 extern "C" void hostemu_set_planes(int on) { g_planes = on != 0; }
-static unsigned long long g_coop_items[10];
+static unsigned long long g_coop_items[12];
+// the rescue searches' small tables (tests make them smaller so that both layouts are used)
+static uint32_t g_rescue_wmax_s = CM_RESCUE_WMAX_S, g_rescue_pairs_s = CM_RESCUE_PAIRS_S;
+extern "C" void hostemu_set_rescue_small(uint32_t wmax, uint32_t pairs) { g_rescue_wmax_s = wmax ? wmax : CM_RESCUE_WMAX_S; g_rescue_pairs_s = pairs ? pairs : CM_RESCUE_PAIRS_S; }
   // items that went through each cooperative stage / fell back (tests look at them)
 extern "C" void hostemu_set_coop(int G, uint32_t thr, uint32_t P, uint32_t MM, uint32_t RB) {
   g_coop = EmuCoop{G, thr, P, MM, RB};
@@ -85,12 +88,17 @@ static void emu_coop_rescue(const CmDev &d, const std::vector<uint32_t> &list) {
 // the rescue searches of the listed reads by a group each: the counting pass (k_s4a_rescue_list) or the fill pass (k_s4b_rescue_list)
 template <int G>
 static void emu_coop_rescue_search(const CmDev &d, const std::vector<uint32_t> &list, bool fill) {
-  std::vector<uint64_t> mem(cm_coop_rescue_mem_bytes() / 8 + 4);
+  // as on the device (k_s4a/4b_rescue_wave): tables for searches of up to g_rescue_wmax_s best mate candidates; a read with a longer
+  // search goes to the full tables
+  std::vector<uint64_t> mem(cm_coop_rescue_mem_bytes() / 8 + 4), mem_s(cm_coop_rescue_mem_bytes(g_rescue_wmax_s, g_rescue_pairs_s) / 8 + 4);
   const CmCoopRescueMem m = cm_coop_rescue_mem_at((uint8_t *)mem.data());
+  const CmCoopRescueMem ms = cm_coop_rescue_mem_at((uint8_t *)mem_s.data(), g_rescue_wmax_s, g_rescue_pairs_s);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
-      if (fill) { if (d.resc_n[list[i]] + d.resc_p[list[i]] > 0) cm_coop_s4b_fill(d, list[i], g, m); }
-      else cm_coop_s4a_rescue(d, list[i], g, m);
+      const bool small = cm_coop_rescue_fits(d, list[i], g, ms.wmax);
+      if (g.t == 0) ++g_coop_items[small ? 10 : 11];
+      if (fill) { if (d.resc_n[list[i]] + d.resc_p[list[i]] > 0) cm_coop_s4b_fill(d, list[i], g, small ? ms : m); }
+      else cm_coop_s4a_rescue(d, list[i], g, small ? ms : m);
       g.sync();
     }
   }, g_coop_reverse);

@@ -20,7 +20,7 @@ def _set(L, G, thr, P, MM, RB, reverse=0, slab=0):
 
 
 def _items(L):
-    a = (C.c_ulonglong * 10)()
+    a = (C.c_ulonglong * 12)()
     L.hostemu_coop_items(a)
     return list(a)
 
@@ -75,6 +75,28 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
             assert factory.items[6] > 0, "no multi-mapped pair went through the cooperative location of its sampled pairings"
     if geo[3] < 10:
         assert declined > 0, "the decline path was not taken"
+
+
+def test_rescue_searches_with_small_and_full_tables(tmp_path):
+    """the rescue searches' two table sizes (k_s4a/4b_rescue_wave<true / false>): small tables made tiny, so that searches take
+    several rounds in them and others are handed to the full tables"""
+    L = he.lib()
+    cfg, geo = _small(fuzz_data.CONFIGS[0]), GEOMETRIES[0]
+
+    def factory(idx, fa, preset, gkw, b1, o1, b2, o2):
+        h = he.HostEmu(idx, fa, he.params(preset, **gkw))
+        _set(L, *geo)
+        L.hostemu_set_rescue_small.argtypes = [C.c_uint32, C.c_uint32]
+        L.hostemu_set_rescue_small(6, 40)
+        try:
+            rec, k, st, _ = h.map_pairs(b1, o1, b2, o2)
+            factory.items = _items(L)
+        finally:
+            L.hostemu_set_rescue_small(0, 0)
+            _set(L, 0, 0, 0, 0, 0, 0, 0)
+        return rec, k, st.as_dict()
+    run_case(factory, cfg, tmp_path)
+    assert factory.items[10] > 0 and factory.items[11] > 0, factory.items
 
 
 def test_cooperative_sort_sweep_merge_on_adversarial_lists():

@@ -40,6 +40,7 @@ def main():
           "16-lanes-per-read %d / %d" % (v[27], v[28], v[11], v[29], v[30], v[31], v[15]))
     print("  k_s4b_rescue_list likewise: wave-per-read %d / %d, lane-per-read %d / %d, 16-lanes-per-read %d / %d" % (v[32], v[33], v[34], v[35], v[36], v[37]))
     print("  windows < 4: %d, < 16: %d, < 64: %d, < 300: %d" % (v[22], v[23], v[24], v[25]))
+    print("  wave kernel (a wave per read), larger of the two searches' best mate candidates: < 16: %d, < 32: %d, < 64: %d, < 128: %d, < 200: %d, < 300: %d, more: %d" % tuple(v[40:47]))
     print("timings of the last batch:", g.timings())
 
 
