@@ -705,6 +705,7 @@ CM_HD void cm_coop_rescue_merge(const CmDev &d, uint32_t r, GT &g, const CmCoopM
 // limit) and the few others are handed to a launch with the full tables.
 #define CM_RESCUE_WMAX_S 64u
 #define CM_RESCUE_PAIRS_S 384u
+#define CM_POOL_GRANT 8192u  // (cm_coop_pool_take)
 struct CmCoopRescueMem {
   uint64_t *es, *ee;   // wmax each: the merged windows
   uint64_t *bp;        // wmax: the best candidates' positions while the windows are built (overlays pa / pb)
@@ -712,15 +713,17 @@ struct CmCoopRescueMem {
   uint32_t *mps;       // CM_RESCUE_SLOTS: position << 1 | strand, bit 31: singleton
   uint32_t *pa, *pb;   // pairs + 1 each: lower bound | occurrences equal to es << 30, upper bound -> first index, length -> first index, offset
   uint8_t *tq;         // pairs: where a window's search ends for each of the three places it can start (phase B)
+  uint32_t *arena;     // 2: the group's grant of the rescue-hit pool: next free entry, entries left (cm_coop_rescue_mem_reset before the first search)
   uint32_t wmax, pairs;
+  uint32_t grant;      // pool entries asked for at a time (CM_POOL_GRANT; tests: fewer)
 };
-#define CM_RESCUE_BYTES(WMAX_, PAIRS_) ((WMAX_) * 16 + CM_RESCUE_SLOTS * 12 + ((PAIRS_) + 1) * 8 + (PAIRS_) + 32)
+#define CM_RESCUE_BYTES(WMAX_, PAIRS_) ((WMAX_) * 16 + CM_RESCUE_SLOTS * 12 + ((PAIRS_) + 1) * 8 + (((PAIRS_) + 3u) & ~3u) + 8 + 32)
 #define CM_RESCUE_MEM_BYTES CM_RESCUE_BYTES(CM_RESCUE_WMAX, CM_RESCUE_PAIRS)
 #define CM_RESCUE_MEM_BYTES_S CM_RESCUE_BYTES(CM_RESCUE_WMAX_S, CM_RESCUE_PAIRS_S)
 CM_HD size_t cm_coop_rescue_mem_bytes(uint32_t wmax = CM_RESCUE_WMAX, uint32_t pairs = CM_RESCUE_PAIRS) { return (size_t)CM_RESCUE_BYTES(wmax, pairs); }
 CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base, uint32_t wmax = CM_RESCUE_WMAX, uint32_t pairs = CM_RESCUE_PAIRS) {
   CmCoopRescueMem m;
-  m.wmax = wmax; m.pairs = pairs;
+  m.wmax = wmax; m.pairs = pairs; m.grant = CM_POOL_GRANT;
   m.es = reinterpret_cast<uint64_t *>(base);
   m.ee = m.es + wmax;
   m.mval = m.ee + wmax;
@@ -728,8 +731,33 @@ CM_HD CmCoopRescueMem cm_coop_rescue_mem_at(uint8_t *base, uint32_t wmax = CM_RE
   m.pa = m.mps + CM_RESCUE_SLOTS;
   m.pb = m.pa + pairs + 1;
   m.tq = reinterpret_cast<uint8_t *>(m.pb + pairs + 1);
+  m.arena = reinterpret_cast<uint32_t *>(m.tq + ((pairs + 3u) & ~3u));
   m.bp = reinterpret_cast<uint64_t *>(m.pa);  // (8-byte aligned: 32 words of mps behind 8-byte arrays; 2 x (pairs + 1) words hold wmax positions)
   return m;
+}
+// Pool entries are handed out to a group in grants of CM_POOL_GRANT (or what a piece needs, if more): one atomic per grant -- same-address
+// atomics retire at ~90 per microsecond, and an atomic per piece (4 M of them per batch of profile 2) cost the counting kernel 60 ms
+template <class GT>
+CM_HD void cm_coop_rescue_mem_reset(GT &g, const CmCoopRescueMem &m) {
+  if (g.t == 0) { m.arena[0] = 0; m.arena[1] = 0; }
+  g.sync();
+}
+// `need` entries of the pool for this group: their first index, or all ones (no room); every lane gets it
+template <class GT>
+CM_HD uint32_t cm_coop_pool_take(const CmDev &d, GT &g, const CmCoopRescueMem &m, uint32_t need) {
+  uint32_t at = 0xffffffffu;
+  if (g.t == 0) {
+    if (m.arena[1] >= need) { at = m.arena[0]; m.arena[0] += need; m.arena[1] -= need; }
+    else {
+      // (a request the pool cannot meet adds what it needed to the cursor, not a grant: the host sizes the next range's pool from it)
+      const unsigned long long seen = d.stats[CM_ST_POOL];
+      const unsigned long long grant = seen + need > d.rs_pool_cap ? need : (need > m.grant ? need : m.grant);
+      const unsigned long long a0 = cm_fetch_add64(&d.stats[CM_ST_POOL], grant);
+      if (a0 + grant <= d.rs_pool_cap) { at = (uint32_t)a0; m.arena[0] = at + need; m.arena[1] = (uint32_t)grant - need; }
+      else if (a0 + need <= d.rs_pool_cap) { at = (uint32_t)a0; m.arena[0] = 0; m.arena[1] = 0; }  // (the pool's last entries)
+    }
+  }
+  return ~cm_coop_bcast0(g, ~at);
 }
 // how many of a mate's candidates have the best count (what cm_coop_rescue's tables must hold): every lane gets it
 template <class GT>
@@ -848,6 +876,8 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
   if (per_round > CM_RESCUE_SLOTS) per_round = CM_RESCUE_SLOTS;
   if (per_round == 0) per_round = 1;
   uint32_t cnt = 0;  // hits so far (uniform)
+  bool pool_ok = !out && pool_off && d.rs_pool;
+  uint32_t pool_first = 0xffffffffu, pool_last = 0xffffffffu, pool_last_cnt = 0;
   for (uint32_t m0 = 0; m0 < n; m0 += per_round) {
     const uint32_t ns = n - m0 < per_round ? n - m0 : per_round;
     for (uint32_t s = g.t; s < ns; s += G) {
@@ -1034,25 +1064,31 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       if (g.t == 0) m.pb[np] = total;
       g.sync();
     }
+    const uint32_t cnt_before = cnt;
     cm_coop_rescue_emit(d, g, m, np, W, total, strand, out, &cnt);
-    // counting pass with the pool at hand: a search whose tables fit one round writes its hits there right away -- the bounds (phase
-    // A: ~26 dependent random reads of the occurrence table per pair, which is what the search costs) are then not found a second
-    // time by the fill pass, which copies
-    if (!out && pool_off && m0 == 0 && ns == n && d.rs_pool && total > 0) {
-      uint32_t at = 0xffffffffu;
-      if (g.t == 0 && cnt > 0) {
-        const unsigned long long a0 = cm_fetch_add64(&d.stats[CM_ST_POOL], (unsigned long long)cnt);
-        if (a0 + cnt <= d.rs_pool_cap) at = (uint32_t)a0;
-      }
-      at = ~cm_coop_bcast0(g, ~at);
+    // counting pass with the pool at hand: the round's hits are written there right away, as a piece of their own -- one header entry
+    // (hits << 32 | index of the search's next piece, all ones: none), then the hits -- so that the fill pass copies instead of finding the
+    // bounds a second time (phase A: ~17 dependent random reads of the occurrence table per pair, which is what a search costs).  Round 4
+    // kept only searches whose tables fit one round; the searches that take several are the long ones (200 windows and more).
+    if (pool_ok && cnt > cnt_before) {
+      const uint32_t cr = cnt - cnt_before;
+      const uint32_t at = cm_coop_pool_take(d, g, m, cr + 1u);
       if (at != 0xffffffffu) {
         uint32_t c2 = 0;
-        cm_coop_rescue_emit(d, g, m, np, W, total, strand, d.rs_pool + at, &c2);
-        if (g.t == 0) *pool_off = at;
+        cm_coop_rescue_emit(d, g, m, np, W, total, strand, d.rs_pool + at + 1, &c2);
+        if (g.t == 0) {
+          d.rs_pool[at] = ((uint64_t)cr << 32) | 0xffffffffull;
+          if (pool_last != 0xffffffffu) d.rs_pool[pool_last] = ((uint64_t)pool_last_cnt << 32) | at;
+        }
+        if (pool_first == 0xffffffffu) pool_first = at;
+        pool_last = at; pool_last_cnt = cr;
+      } else {
+        pool_ok = false;  // no room: the fill pass searches again
       }
     }
     g.sync();  // the tables serve the next round
   }
+  if (pool_ok && g.t == 0) *pool_off = pool_first;
   // ---- repetitive_seed_length over the minimizers in order
   uint32_t rep_len = 0;
   if (g.t == 0) {
@@ -1089,6 +1125,18 @@ CM_HD void cm_coop_s4a_rescue(const CmDev &d, uint32_t r, GT &g, const CmCoopRes
     d.m_tot[r] = d.ncp[r] + d.ncn[r] + cntn + cntp;
   }
 }
+// the hits a counting search left in the pool (its pieces in order: cm_coop_rescue), copied to where the fill pass writes them
+template <class GT>
+CM_HD void cm_coop_pool_copy(const CmDev &d, GT &g, uint32_t at, uint64_t *dst) {
+  uint32_t o = 0;
+  while (at != 0xffffffffu) {
+    const uint64_t hdr = d.rs_pool[at];
+    const uint32_t c = (uint32_t)(hdr >> 32);
+    for (uint32_t i = g.t; i < c; i += (uint32_t)GT::G) dst[o + i] = d.rs_pool[at + 1 + i];
+    o += c;
+    at = (uint32_t)hdr;
+  }
+}
 // ... and S4b's fill pass for it: the rescue hits where cm_s4b_rescue_merge(CM_S4B_FILL_ONLY) writes them, in the same order
 template <class GT>
 CM_HD void cm_coop_s4b_fill(const CmDev &d, uint32_t r, GT &g, const CmCoopRescueMem &m) {
@@ -1100,11 +1148,11 @@ CM_HD void cm_coop_s4b_fill(const CmDev &d, uint32_t r, GT &g, const CmCoopRescu
   if (g.t == 0) { d.mcp[r] = 0; d.mcn[r] = 0; }  // (until the group that sorts and merges the hits has run)
   const uint32_t off_p = d.rs_pool ? d.rs_pool_off[2 * (size_t)r] : 0xffffffffu, off_n = d.rs_pool ? d.rs_pool_off[2 * (size_t)r + 1] : 0xffffffffu;
   if (d.ncp[o] > 0 && d.res_neg[r] >= 0 && rn > 0) {
-    if (off_n != 0xffffffffu) { for (uint32_t i = g.t; i < rn; i += (uint32_t)GT::G) N[ncn + i] = d.rs_pool[off_n + i]; }  // found while counting
+    if (off_n != 0xffffffffu) cm_coop_pool_copy(d, g, off_n, N + ncn);  // found while counting
     else (void)cm_coop_rescue(d, r, 1, cm_c0_pos(d, o), cm_c0_pcnt(d, o), d.ncp[o], g, m, N + ncn, &cnt, &rl);
   }
   if (d.ncn[o] > 0 && d.res_pos[r] >= 0 && rp > 0) {
-    if (off_p != 0xffffffffu) { for (uint32_t i = g.t; i < rp; i += (uint32_t)GT::G) P[ncp + i] = d.rs_pool[off_p + i]; }
+    if (off_p != 0xffffffffu) cm_coop_pool_copy(d, g, off_p, P + ncp);
     else (void)cm_coop_rescue(d, r, 0, cm_c0_neg(d, o), cm_c0_ncnt(d, o), d.ncn[o], g, m, P + ncp, &cnt, &rl);
   }
 }

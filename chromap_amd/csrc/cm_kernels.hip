@@ -955,6 +955,7 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
   CmDevGroup<64> g;
   g.t = threadIdx.x;
   g.xw = nullptr;
+  cm_coop_rescue_mem_reset(g, m);
   const long long t0 = d.prof ? clock64() : 0;
   for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
     const uint32_t r = list[j];

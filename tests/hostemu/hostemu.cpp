@@ -91,9 +91,12 @@ static void emu_coop_rescue_search(const CmDev &d, const std::vector<uint32_t> &
   // as on the device (k_s4a/4b_rescue_wave): tables for searches of up to g_rescue_wmax_s best mate candidates; a read with a longer
   // search goes to the full tables
   std::vector<uint64_t> mem(cm_coop_rescue_mem_bytes() / 8 + 4), mem_s(cm_coop_rescue_mem_bytes(g_rescue_wmax_s, g_rescue_pairs_s) / 8 + 4);
-  const CmCoopRescueMem m = cm_coop_rescue_mem_at((uint8_t *)mem.data());
-  const CmCoopRescueMem ms = cm_coop_rescue_mem_at((uint8_t *)mem_s.data(), g_rescue_wmax_s, g_rescue_pairs_s);
+  CmCoopRescueMem m = cm_coop_rescue_mem_at((uint8_t *)mem.data());
+  CmCoopRescueMem ms = cm_coop_rescue_mem_at((uint8_t *)mem_s.data(), g_rescue_wmax_s, g_rescue_pairs_s);
+  m.grant = ms.grant = 100;  // (the emulated pool holds 3000 entries)
   emu_run_group<G>([&](EmuGroup<G> &g) {
+    cm_coop_rescue_mem_reset(g, m);
+    cm_coop_rescue_mem_reset(g, ms);
     for (size_t i = 0; i < list.size(); ++i) {
       const bool small = cm_coop_rescue_fits(d, list[i], g, ms.wmax);
       if (g.t == 0) ++g_coop_items[small ? 10 : 11];
