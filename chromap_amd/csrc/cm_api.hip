@@ -14,6 +14,7 @@
 #include "cm_ctx.h"
 #include "cm_kernels.h"
 #include "cm_coop.h"
+#include <chrono>
 #include "cm_mapq_tables.h"
 
 static thread_local std::string g_last_error;  // errors without a ctx (creation), per calling thread
@@ -988,11 +989,17 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // S4: mate rescue, merge, paired-end filter
   HIPCHECK(c, hipMemsetAsync(c->rs_cnt.p, 0, CM_RS_SEGS * 64, s));
   if (c->opt_coop & 2) {  // the pool of rescue hits found while counting: sized from what the previous range asked for (+ 25 %)
-    uint64_t want = c->rs_pool_want + c->rs_pool_want / 4;
+    // (+ a grant per wave that can take one, cm_coop_pool_take: what the waves leave unused of their last grants)
+    uint64_t want = c->rs_pool_want + c->rs_pool_want / 4 + (uint64_t)8192 * CM_POOL_GRANT / 2;
+    // (a range that ran out of pool undercounts what it would have used -- the pieces behind the refusal are only estimated -- and
+    // growing the pool is a hipFree + hipMalloc of gigabytes, 0.3-0.5 s: grow once, generously)
+    if (c->rs_pool_want > c->rs_pool_cap) want = 2 * c->rs_pool_want + (uint64_t)8192 * CM_POOL_GRANT / 2;
     if (want < (1u << 22)) want = 1u << 22;
     if (want > 0xfffffff0ull) want = 0xfffffff0ull;
+    const auto dbg_t0 = std::chrono::steady_clock::now();
     if (c->rs_pool.ensure((size_t)want * 8) == 0 && c->rs_pool_off.ensure((size_t)n2 * 2 * 4 + 16) == 0) c->rs_pool_cap = (uint32_t)(c->rs_pool.cap / 8 > 0xfffffff0ull ? 0xfffffff0ull : c->rs_pool.cap / 8);
     else { c->rs_pool.release(); c->rs_pool_cap = 0; }  // (no pool: the fill pass searches again)
+    if (getenv("CM_DEBUG_POOL")) fprintf(stderr, "pool ensure want %llu: %.3f ms\n", (unsigned long long)want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
     cm_fill_dev_range(c, d, rlo, rhi);
   }
   cm_launch_k_s4a_rescue_count(d, n2, s, (c->opt_coop & 2) != 0);  // decision per read + the packed list of reads that supplement
@@ -1023,6 +1030,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     }
     c->m_cap = n_m;
   }
+  if (getenv("CM_DEBUG_POOL")) fprintf(stderr, "spec %d m_cap %llu m_total %llu\n", (int)spec, (unsigned long long)c->m_cap, (unsigned long long)m_total);
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
   cm_launch_k_s4b_rescue_merge(d, n2, s, (c->opt_coop & 2) != 0, c->max_read_len);
@@ -1099,6 +1107,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   c->pred_m_ok = true;
   c->pred_n = n;
   c->rs_pool_want = hst[CM_ST_POOL];
+  if (getenv("CM_DEBUG_POOL")) fprintf(stderr, "pool: cap %u entries, asked %llu\n", c->rs_pool_cap, (unsigned long long)hst[CM_ST_POOL]);
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
   *k_out = hst[CM_ST_RECORDS];
   c->last_range_lo = rlo; c->last_range_hi = rhi;

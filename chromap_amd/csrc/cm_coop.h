@@ -742,22 +742,29 @@ CM_HD void cm_coop_rescue_mem_reset(GT &g, const CmCoopRescueMem &m) {
   if (g.t == 0) { m.arena[0] = 0; m.arena[1] = 0; }
   g.sync();
 }
-// `need` entries of the pool for this group: their first index, or all ones (no room); every lane gets it
+// `need` entries of the pool for this group: their first index, or all ones (no room); every lane gets it.  Once the pool has
+// refused a request the group asks no more (arena[1] all ones) and only adds up what it would have needed: cm_coop_rescue_mem_flush
+// adds that to the cursor, from which the host sizes the next range's pool
 template <class GT>
 CM_HD uint32_t cm_coop_pool_take(const CmDev &d, GT &g, const CmCoopRescueMem &m, uint32_t need) {
   uint32_t at = 0xffffffffu;
   if (g.t == 0) {
-    if (m.arena[1] >= need) { at = m.arena[0]; m.arena[0] += need; m.arena[1] -= need; }
+    if (m.arena[1] == 0xffffffffu) m.arena[0] += need;
+    else if (m.arena[1] >= need) { at = m.arena[0]; m.arena[0] += need; m.arena[1] -= need; }
     else {
-      // (a request the pool cannot meet adds what it needed to the cursor, not a grant: the host sizes the next range's pool from it)
-      const unsigned long long seen = d.stats[CM_ST_POOL];
-      const unsigned long long grant = seen + need > d.rs_pool_cap ? need : (need > m.grant ? need : m.grant);
+      const unsigned long long grant = need > m.grant ? need : m.grant;
       const unsigned long long a0 = cm_fetch_add64(&d.stats[CM_ST_POOL], grant);
       if (a0 + grant <= d.rs_pool_cap) { at = (uint32_t)a0; m.arena[0] = at + need; m.arena[1] = (uint32_t)grant - need; }
       else if (a0 + need <= d.rs_pool_cap) { at = (uint32_t)a0; m.arena[0] = 0; m.arena[1] = 0; }  // (the pool's last entries)
+      else { m.arena[0] = 0; m.arena[1] = 0xffffffffu; }  // (the cursor has the grant: at least what was needed)
     }
   }
   return ~cm_coop_bcast0(g, ~at);
+}
+template <class GT>
+CM_HD void cm_coop_rescue_mem_flush(const CmDev &d, GT &g, const CmCoopRescueMem &m) {
+  g.sync();
+  if (g.t == 0 && m.arena[1] == 0xffffffffu && m.arena[0]) (void)cm_fetch_add64(&d.stats[CM_ST_POOL], (unsigned long long)m.arena[0]);
 }
 // how many of a mate's candidates have the best count (what cm_coop_rescue's tables must hold): every lane gets it
 template <class GT>
@@ -1506,8 +1513,59 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
     return;
   }
   const uint32_t nb = (uint32_t)mx + 1;
-  // bin b of lane t at hist[b * G + t]: the lanes of a wave touch consecutive 16-bit words (lane-major rows of nb_cap bins put
-  // every lane on the same bank: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.84, profiles/r03k_repeat_workload_pmc_lds.csv)
+  if (G == (uint32_t)GT::W && nb <= G) {
+    // One wave part per list (round 5): lane b keeps bin b -- first the number of candidates with count b, then where the next of them
+    // goes.  The list is taken 64 candidates at a time; the distinct counts among them (a handful) are handled one after the other: a
+    // ballot of the lanes that hold the count, its population to the bin's lane / the bin's value from that lane, the lane's rank
+    // among them.  No histogram per lane: the kernel's shared memory was 50 KB per four waves (12 waves per CU), and its time is
+    // the lists' global-memory latency.
+    const uint8_t *cs = staged ? lc : c;
+    uint32_t bin = 0;
+    for (uint32_t base = 0; base < n; base += G) {
+      const uint32_t i = base + g.t;
+      const bool in = i < n;
+      const uint32_t ci = in ? cs[i] : 0u;
+      unsigned long long rem = g.ballot(in);
+      while (rem) {
+        const uint32_t v = g.bcast(ci, (uint32_t)__builtin_ctzll(rem));
+        const unsigned long long mk = g.ballot(in && ci == v);
+        if (g.t == v) bin += (uint32_t)__builtin_popcountll(mk);
+        rem &= ~mk;
+      }
+    }
+    {  // the largest count first: bin b starts behind all candidates with a larger count
+      uint32_t tot;
+      const uint32_t below = g.scan(bin, &tot);
+      bin = tot - below - bin;
+    }
+    uint64_t *const dpp = staged ? p : sp;
+    uint8_t *const dcc = staged ? c : sc;
+    const uint64_t *const spp = staged ? lp : p;
+    for (uint32_t base = 0; base < n; base += G) {
+      const uint32_t i = base + g.t;
+      const bool in = i < n;
+      const uint32_t ci = in ? cs[i] : 0u;
+      const uint64_t pi = in ? spp[i] : 0ull;
+      unsigned long long rem = g.ballot(in);
+      uint32_t dst = 0;
+      while (rem) {
+        const uint32_t v = g.bcast(ci, (uint32_t)__builtin_ctzll(rem));
+        const unsigned long long mk = g.ballot(in && ci == v);
+        const uint32_t at = g.bcast(bin, v);
+        if (in && ci == v) dst = at + (uint32_t)__builtin_popcountll(mk & ((1ull << (g.t % (uint32_t)GT::W)) - 1ull));
+        if (g.t == v) bin += (uint32_t)__builtin_popcountll(mk);
+        rem &= ~mk;
+      }
+      if (in) { dpp[dst] = pi; dcc[dst] = (uint8_t)ci; }
+    }
+    g.sync();
+    if (!staged) {
+      for (uint32_t i = g.t; i < n; i += G) { p[i] = sp[i]; c[i] = sc[i]; }
+      g.sync();
+    }
+    return;
+  }
+  // (larger groups) bin b of lane t at hist[b * G + t]: the lanes of a wave touch consecutive 16-bit words
   uint16_t *mine = hist + g.t;
   for (uint32_t b = 0; b < nb; ++b) mine[(size_t)b * G] = 0;
   const uint32_t VT = cm_coop_chunk(n, G);

@@ -595,6 +595,12 @@ struct CmDevGroup {
   uint32_t t;
   uint32_t *xw;  // LDS, 256 bytes of this group: the wave parts' totals (unused when G <= 64)
   __device__ __forceinline__ void sync() { cm_group_sync<G_>(); }
+  __device__ __forceinline__ unsigned long long ballot(bool p) {  // of the wave part
+    unsigned long long m = __ballot(p);
+    if (W < 64) m = (m >> ((threadIdx.x & 63u) / W * W)) & ((1ull << W) - 1ull);
+    return m;
+  }
+  __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t lane) { return __shfl(v, (int)lane, W); }  // lane: the same for the wave part
   __device__ __forceinline__ uint32_t rank(bool p, uint32_t *total) {
     unsigned long long m = __ballot(p);
     if (W < 64) m = (m >> ((threadIdx.x & 63u) / W * W)) & ((1ull << W) - 1ull);
@@ -972,6 +978,7 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
     cm_coop_s4a_rescue(d, r, g, m);
     g.sync();
   }
+  cm_coop_rescue_mem_flush(d, g, m);
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[27], dt); atomicMax(&d.prof[28], dt); }
 }
 // the fill pass: the hits written (or copied out of the pool the counting pass left them in), then sorted / merged by the size class's
@@ -1128,7 +1135,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, 
 // the candidate lists of the reads in list 12 (k_s5a_prepare left them unsorted): a wave each (cm_coop_s5_sort)
 __global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d, uint32_t lid) {
   if (d.abort && *d.abort) return;
-  __shared__ uint16_t hist[CM_BLOCK * CM_SORT_NB];
+  // (a wave keeps the sort's bins in its lanes: no histogram array -- 18 KB per block, eight blocks per CU)
   __shared__ uint64_t stage_p[(CM_BLOCK / 64) * CM_SORT_STAGE];  // a list of up to CM_SORT_STAGE candidates is staged here once
   __shared__ uint8_t stage_c[(CM_BLOCK / 64) * CM_SORT_STAGE];
   const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
@@ -1138,7 +1145,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d, uint32_t lid
   g.t = threadIdx.x % 64;
   g.xw = nullptr;
   for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb)
-    cm_coop_s5_sort(d, list[j], g, hist + (size_t)grp * 64 * CM_SORT_NB, CM_SORT_NB, stage_p + (size_t)grp * CM_SORT_STAGE, stage_c + (size_t)grp * CM_SORT_STAGE, CM_SORT_STAGE);
+    cm_coop_s5_sort(d, list[j], g, nullptr, CM_SORT_NB, stage_p + (size_t)grp * CM_SORT_STAGE, stage_c + (size_t)grp * CM_SORT_STAGE, CM_SORT_STAGE);
 }
 #define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
 #define CM_S5C_SORT_RB 130u

@@ -104,6 +104,8 @@ static void emu_coop_rescue_search(const CmDev &d, const std::vector<uint32_t> &
       else cm_coop_s4a_rescue(d, list[i], g, small ? ms : m);
       g.sync();
     }
+    cm_coop_rescue_mem_flush(d, g, m);
+    cm_coop_rescue_mem_flush(d, g, ms);
   }, g_coop_reverse);
 }
 
