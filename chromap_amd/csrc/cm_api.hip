@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void k_rehash(const uint64_t *__restrict__ src
 int cm_build_fast_table(cmgpu_ctx *c, int shift) {
   HIPCHECK(c, cm_enter(c));
   HIPCHECK(c, cm_stream_sync(c->stream));
+  // contexts made by cmgpu_create_shared view this table (the lanes refresh their views, lane_prepare; a caller's own children do not)
+  if (c->shared_children > (int)c->lanes.size()) { cm_set_error(c, "probe_table_shift: set it before cmgpu_create_shared (contexts that share this index view the table)"); return CMGPU_EINVAL; }
   c->bkt_fast.release();
   c->fmask = 0;
   if (shift <= 0) return CMGPU_OK;
@@ -400,6 +402,8 @@ extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
     c->h_rank = parent->h_rank;
   }
   if (parent->has_pairs_rank) { view(c->pairs_rank, parent->pairs_rank); c->has_pairs_rank = true; }
+  c->shared_parent = const_cast<cmgpu_ctx *>(parent);
+  c->shared_parent->shared_children += 1;
   *out = c;
   return CMGPU_OK;
 }
@@ -445,6 +449,7 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   if (c->in_flight) { c->worker.join(); c->in_flight = false; }
   for (cmgpu_ctx *l : c->lanes) cmgpu_destroy(l);
   c->lanes.clear();
+  if (c->shared_parent) c->shared_parent->shared_children -= 1;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   cm_exchange_release(c);
@@ -702,6 +707,17 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   memset(&d, 0, sizeof(d));
   d.bkt = (const uint64_t *)(c->fmask ? c->bkt_fast.p : c->bkt.p); d.bmask = c->fmask ? c->fmask : c->bmask; d.occ = (const uint64_t *)c->occ.p; d.n_occ = c->n_occ;
   d.ref = (const uint8_t *)c->ref.p; d.ref_off = (const uint64_t *)c->ref_off.p; d.ref_len = (const uint32_t *)c->ref_len.p;
+  if (!c->goff_tried) {  // the sequences end to end in index order (candidate rids are re-ranked only behind the pair filter), gaps between
+    c->goff_tried = true;
+    std::vector<uint32_t> go(c->n_seq + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < c->n_seq; ++i) { go[i] = (uint32_t)acc; acc += (uint64_t)c->h_ref_len[i] + CM_GOFF_GAP; if (acc >= 0xffff0000ull) break; }
+    if (acc < 0xffff0000ull && c->n_seq && c->h_ref_len.size() == c->n_seq && !getenv("CM_NO_KEY32")) {
+      go[c->n_seq] = (uint32_t)acc;
+      if (c->goff.ensure(go.size() * 4) == 0 && hipMemcpy(c->goff.p, go.data(), go.size() * 4, hipMemcpyHostToDevice) != hipSuccess) c->goff.release();
+    }
+  }
+  d.goff = (const uint32_t *)c->goff.p;
   d.n_seq = c->n_seq;
   d.ref_pl = c->ref_pl_words && c->opt_planes ? (const CmPlRec *)c->ref_planes.p + CM_PL_LEAD : nullptr; d.ref_pl_words = c->ref_pl_words;
   d.p = c->p;
@@ -943,7 +959,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   }
   // the alignments of S5b run on bit planes: this range's reads, both orientations, packed on the second stream (idle from here
   // on) under S3 and S4 -- the trimmed lengths are final
-  bool planes = c->ref_pl_words != 0;
+  bool planes = c->ref_pl_words != 0 && c->opt_planes;  // (verify_planes 0 keeps the planes for the children but does not use them: no packed reads either)
   if (planes && c->read_planes.ensure((size_t)n2 * cm_read_pl_stride((c->max_read_len + 31) / 32) * 4 + 16)) planes = false;  // (no room: this range on bytes)
   if (planes) {
     const uint32_t pw = (c->max_read_len + 31) / 32;

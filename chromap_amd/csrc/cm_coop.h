@@ -57,8 +57,9 @@ CM_HD uint32_t cm_coop_chunk(uint32_t n, uint32_t G) { return (n + G - 1) / G; }
 // stages of a bitonic network: a hit list is the union of one sorted occurrence run per minimizer and strand.
 // The buffers ping-pong; returns the one that holds the sorted list.  rb, rb2: nr + 1 entries each.
 // ---------------------------------------------------------------------------------------
-template <class GT>
-CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t *rb, uint32_t *rb2, uint32_t nr, uint32_t tot, uint32_t levels = 32) {
+template <class GT, class K>
+CM_HD K *cm_coop_merge_runs(GT &g, K *src, K *dst, uint32_t *rb, uint32_t *rb2, uint32_t nr, uint32_t tot, uint32_t levels = 32) {
+  const K TOP = CmKeyOps<K>::top();
   const uint32_t VT = cm_coop_chunk(tot, (uint32_t)GT::G);
   const uint32_t c0 = cm_min_u32(tot, g.t * VT), c1 = cm_min_u32(tot, c0 + VT);
   // levels: stop after that many (the caller knows that the runs left then are what it wants: cm_coop_s3b keeps the two strands' lists apart)
@@ -87,12 +88,12 @@ CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t
       const uint32_t pend = c1 < b1 ? c1 : b1;
       // an exhausted run reads as the largest value (no key is: a hit's sequence number never has all bits set), so one comparison
       // decides; the next element of the run that gave is requested while the output is written
-      uint64_t va = ia < a1 ? src[ia] : ~0ull, vb = ib < b1 ? src[ib] : ~0ull;
+      K va = ia < a1 ? src[ia] : TOP, vb = ib < b1 ? src[ib] : TOP;
       for (; p < pend; ++p) {
         const bool take_a = va <= vb;
         dst[p] = take_a ? va : vb;
         const uint32_t nx = take_a ? ++ia : ++ib;
-        const uint64_t nv = nx < (take_a ? a1 : b1) ? src[nx] : ~0ull;
+        const K nv = nx < (take_a ? a1 : b1) ? src[nx] : TOP;
         va = take_a ? nv : va;
         vb = take_a ? vb : nv;
       }
@@ -100,7 +101,7 @@ CM_HD uint64_t *cm_coop_merge_runs(GT &g, uint64_t *src, uint64_t *dst, uint32_t
     }
     for (uint32_t q = g.t; q <= nr2; q += (uint32_t)GT::G) rb2[q] = q < nr2 ? rb[2 * q] : tot;
     g.sync();
-    { uint64_t *x = src; src = dst; dst = x; }
+    { K *x = src; src = dst; dst = x; }
     { uint32_t *x = rb; rb = rb2; rb2 = x; }
     nr = nr2;
   }
@@ -135,11 +136,13 @@ CM_HD uint32_t cm_coop_natural_runs(GT &g, const uint64_t *a, uint32_t tot, uint
 // of the group's work memory, none of them S; the outputs may be S itself (it is dead after the walk).
 // *ncp_out, *ncn_out: the candidates' numbers (every lane gets them).
 // ---------------------------------------------------------------------------------------
-template <class GT>
-CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, int e, int req, uint32_t num_minimizers, uint16_t *oc, uint64_t *xs,
-                         uint8_t *xc, uint64_t *out_p, uint8_t *out_pc, uint64_t *out_n, uint8_t *out_nc, uint32_t *ncp_out, uint32_t *ncn_out,
-                         unsigned long long *prof = nullptr) {
-  const uint64_t SB = 1ull << 63;
+// K: the keys' type (CmKeyOps); KO: the type of the outputs -- K (the candidates stay keys: cm_coop_rescue_dir) or uint64_t with 32-bit keys (the
+// candidates leave as sequence << 32 | position: goff / n_seq are CmDev's)
+template <class GT, class K, class KOUT>
+CM_HD void cm_coop_sweep(GT &g, const K *S, uint32_t tot, uint32_t np, int e, int req, uint32_t num_minimizers, uint16_t *oc, K *xs,
+                         uint8_t *xc, KOUT *out_p, uint8_t *out_pc, KOUT *out_n, uint8_t *out_nc, uint32_t *ncp_out, uint32_t *ncn_out,
+                         unsigned long long *prof = nullptr, const uint32_t *goff = nullptr, uint32_t n_seq = 0) {
+  typedef CmKeyOps<K> KO;
   CM_PROF_PTR_BEGIN(prof);
   // Every lane walks its own chunk of the list, front to back: the hits up to the chunk's first local break continue a cluster that an
   // earlier lane owns and are passed over; every cluster that STARTS in the chunk is swept to its end -- also beyond the chunk's.  So all
@@ -158,17 +161,17 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
   {
     uint32_t i = c0;
     if (i < c1 && i > 0 && i != np) {  // pass over the hits that belong to the cluster of the hit before the chunk
-      uint64_t prev = S[i - 1];
+      K prev = S[i - 1];
       while (i < c1 && i != np) {
-        const uint64_t x = S[i];
-        if (cm_sweep_local_break(prev, x, e)) break;
+        const K x = S[i];
+        if (KO::brk(prev, x, e)) break;
         prev = x;
         ++i;
       }
     }
     while (i < c1) {
       uint32_t end;
-      const uint32_t c = cm_sweep_cluster_walk(S, i, i < np ? np : tot, e, req, num_minimizers, xs + i, xc + i, ~SB, &end);
+      const uint32_t c = cm_sweep_cluster_walk(S, i, i < np ? np : tot, e, req, num_minimizers, xs + i, xc + i, &end);
       if (c) {
         oc[i] = (uint16_t)c;
         if (masked) starts |= 1ull << (i - c0);
@@ -193,7 +196,7 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
       starts &= starts - 1;
       const uint32_t c = oc[i];
       for (uint32_t k = 0; k < c; ++k) {
-        const uint64_t x = xs[i + k];
+        const KOUT x = CmKeyOut<K, KOUT>::get(xs[i + k], goff, n_seq);
         const uint8_t cc = xc[i + k];
         if (i < np) { out_p[run + k] = x; out_pc[run + k] = cc; }
         else { out_n[run + k - ncp] = x; out_nc[run + k - ncp] = cc; }
@@ -204,7 +207,7 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
     for (uint32_t i = c0; i < c1; ++i) {
       const uint32_t c = oc[i];
       for (uint32_t k = 0; k < c; ++k) {
-        const uint64_t x = xs[i + k];
+        const KOUT x = CmKeyOut<K, KOUT>::get(xs[i + k], goff, n_seq);
         const uint8_t cc = xc[i + k];
         if (i < np) { out_p[run + k] = x; out_pc[run + k] = cc; }
         else { out_n[run + k - ncp] = x; out_nc[run + k - ncp] = cc; }
@@ -220,7 +223,8 @@ CM_HD void cm_coop_sweep(GT &g, const uint64_t *S, uint32_t tot, uint32_t np, in
 // shared-memory work area of one group for the hit-list stages (sizes in entries).  two_cc: S4b keeps its candidates' counts
 // (cc) next to the parked ones of the sweep (cc2); S3b writes its candidates to global memory and needs one count array.
 struct CmCoopMem {
-  uint64_t *A, *B;      // P each
+  uint64_t *A, *B;      // P each (64-bit keys)
+  uint32_t *A32, *B32;  // P each (32-bit keys, cm_coop_mem_at(..., key32): the two layouts are alternatives)
   uint16_t *oc;         // P: candidates per local cluster
   uint8_t *cc, *cc2;    // P each (cc2: two_cc only)
   uint32_t *rb, *rb2;   // RB + 1 each: run boundaries
@@ -243,16 +247,18 @@ CM_HD void cm_coop_slab_at(CmCoopMem &m, uint8_t *slab, uint32_t gcap) {
   m.goc = slab ? reinterpret_cast<uint16_t *>(m.gB + gcap) : nullptr;
   m.gcc = slab ? reinterpret_cast<uint8_t *>(m.goc + gcap) : nullptr;
 }
-CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool two_cc) {
-  return (size_t)P * (two_cc ? 20 : 19) + ((size_t)2 * (RB + 1) + (size_t)MM * 4 + 2) * 4 + 32;
+CM_HD size_t cm_coop_mem_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool two_cc, bool key32 = false) {
+  return (size_t)P * ((two_cc ? 20 : 19) - (key32 ? 8 : 0)) + ((size_t)2 * (RB + 1) + (size_t)MM * 4 + 2) * 4 + 32;
 }
-// carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB, two_cc) bytes)
-CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB, bool two_cc) {
+// carve a group's area out of `base` (16-byte aligned, cm_coop_mem_bytes(P, MM, RB, two_cc, key32) bytes; P even)
+CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t RB, bool two_cc, bool key32 = false) {
   CmCoopMem m;
   m.P = P; m.MM = MM; m.RB = RB;
-  m.A = reinterpret_cast<uint64_t *>(base);
-  m.B = m.A + P;
-  m.mval = m.B + P;
+  m.A = key32 ? nullptr : reinterpret_cast<uint64_t *>(base);
+  m.B = key32 ? nullptr : m.A + P;
+  m.A32 = key32 ? reinterpret_cast<uint32_t *>(base) : nullptr;
+  m.B32 = key32 ? m.A32 + P : nullptr;
+  m.mval = reinterpret_cast<uint64_t *>(base + (size_t)P * (key32 ? 8 : 16));
   m.rb = reinterpret_cast<uint32_t *>(m.mval + MM);
   m.rb2 = m.rb + RB + 1;
   m.moff = m.rb2 + RB + 1;
@@ -294,14 +300,16 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
 // list by strand and looked for run boundaries.
 // Work memory: the pieces' tables overlay oc (2 * pieces + 2 entries of 16 bits, unused until the sweep).
 // Returns 0 (declined), or the number of merge levels + 1; *np_out: the + list's length, m.rb: the run table (*nr_out runs).
-template <class GT>
-CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m, uint32_t tot, uint32_t *np_out, uint32_t *nr_out) {
+// K = uint32_t: the keys are global coordinates (CmKeyOps; d.goff must be there); a hit's strand then goes to the count array cc
+// (free until the sweep) instead of the key's top bit.
+template <class K, class GT>
+CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m, K *const A, K *const B, uint32_t tot, uint32_t *np_out, uint32_t *nr_out) {
+  const bool K32 = sizeof(K) == 4;
   const uint32_t G = (uint32_t)GT::G, W = (uint32_t)GT::W, NW = G / W;
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const uint32_t maxf = d.round2[r] ? (uint32_t)d.p.f1 : (uint32_t)d.p.f0;
   const uint64_t SB = 1ull << 63;
   const uint32_t wl = g.t % W, wv = g.t / W;
-  uint64_t *const A = m.A, *const B = m.B;
   uint32_t *const choff = m.rb2;  // first piece of every run (R + 1 entries; rb2 is free until the merge)
   // ---- included minimizers: where their occurrences start in the list, and their pieces
   uint32_t R = 0, off = 0, NC = 0;
@@ -363,7 +371,8 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
       bool same = false;
       const uint64_t cp = cm_cand_from_hit(hit[q], ps[q] & 0x7fffffffu, d.p.k, &same);
       if (in[q]) {
-        B[x[q]] = same ? cp : (cp | SB);
+        if (K32) { B[x[q]] = (K)(d.goff[(uint32_t)(cp >> 32)] + (uint32_t)cp); m.cc[x[q]] = same ? 1 : 0; }
+        else B[x[q]] = (K)(same ? cp : (cp | SB));
         if (same && (uint32_t)(hit[q] >> 1) < ((ps[q] & 0x7fffffffu) >> 1)) wrapped = 1;
       }
       uint32_t np_c;
@@ -391,11 +400,11 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
     const uint32_t ri = chrun[c], o0 = m.moff[ri], j = (c - choff[ri]) * W + wl;
     const bool in = j < m.moff[ri + 1] - o0;
     const uint32_t xq = o0 + j;
-    const uint64_t v = in ? B[xq] : SB;
-    const bool plus = !(v >> 63);
+    const K v = in ? B[xq] : (K)0;
+    const bool plus = in && (K32 ? m.cc[xq] != 0 : !((uint64_t)v >> 63));
     uint32_t unused;
     const uint32_t before = (uint32_t)cplus[c] + g.rank(plus, &unused);  // + hits in front of this one, in list order
-    if (in) A[plus ? before : np + (xq - before)] = v & ~SB;
+    if (in) A[plus ? before : np + (xq - before)] = K32 ? v : (K)((uint64_t)v & ~SB);
   }
   for (uint32_t q = g.t; q <= P2 + R; q += G) {
     uint32_t v;
@@ -409,6 +418,36 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
   *np_out = np;
   *nr_out = P2 + R;
   return levels + 1;
+}
+
+// cm_coop_s3b with 32-bit keys (the shared-memory form only): 11 instead of 19 bytes of shared memory per hit -- the kernel's time is
+// the number of reads in flight (measured, round 5: 40 KB more per block, i.e. half the blocks per CU, and k_s3b_coop takes 57 % longer)
+template <class GT>
+CM_HD bool cm_coop_s3b_k32(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
+  const uint32_t tot = d.hit_tot[r];
+  const uint32_t n = d.mm_cnt[r];
+  if (tot > m.P || !d.goff || !m.A32) return false;
+  CM_PROF_BEGIN(d);
+  uint32_t np, nr;
+  const uint32_t lv = cm_coop_s3b_expand<uint32_t>(d, r, g, m, m.A32, m.B32, tot, &np, &nr);
+  if (lv == 0) return false;
+  CM_PROF_MARK(d, g, 1);
+  uint32_t *S = cm_coop_merge_runs(g, m.A32, m.B32, m.rb, m.rb2, nr, tot, lv - 1);
+  CM_PROF_MARK(d, g, 4);
+  CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
+  const uint32_t nn = tot - np;
+  const bool use_high = d.round2[r] && np > 0 && nn > 0;
+  int req = (int)n - (int)d.rep_cnt[r];
+  req = req > 1 ? req : 1;
+  req = req > d.p.min_seeds ? d.p.min_seeds : req;
+  if (use_high) req = d.p.min_seeds;
+  uint64_t *h = d.hbuf + d.hit_off[r];
+  uint8_t *hc = d.hcnt + d.hit_off[r];
+  uint32_t ncp, ncn;
+  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, m.oc, S == m.A32 ? m.B32 : m.A32, m.cc, h, hc, h + np, hc + np, &ncp, &ncn, d.prof, d.goff, d.n_seq);
+  CM_PROF_MARK(d, g, 5);
+  if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
+  return true;
 }
 
 template <bool SLAB, class GT>
@@ -425,7 +464,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   uint64_t *S;
   if (!SLAB) {
     uint32_t nr;
-    const uint32_t lv = cm_coop_s3b_expand(d, r, g, m, tot, &np, &nr);
+    const uint32_t lv = cm_coop_s3b_expand<uint64_t>(d, r, g, m, A, B, tot, &np, &nr);
     if (lv == 0) return false;
     CM_PROF_MARK(d, g, 1);
     S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot, lv - 1);

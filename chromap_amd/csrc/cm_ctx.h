@@ -129,6 +129,8 @@ struct cmgpu_ctx {
   uint8_t cls_age[64] = {};             // ranges a class stays in the set without items (a class with a handful of items per batch comes and goes)
   bool cls_all = false;                 // this range is a re-run with every class on
   DevBuf rs_pool, rs_pool_off;  // CmDev::rs_pool
+  DevBuf goff;                  // CmDev::goff (built on the first mapping call; stays empty when the reference does not fit 32 bits)
+  bool goff_tried = false;
   uint32_t rs_pool_cap = 0;
   uint64_t rs_pool_want = 0;   // entries the previous range asked of the pool
   DevBuf coop_slab, hv_cnt, hv_list, perm_reads, perm_pairs, hv_tmp, srt_cnt, srt_list, rs_list, rs_cnt;
@@ -165,6 +167,8 @@ struct cmgpu_ctx {
   int opt_s3b_cap = 0;               // 0: by read length (cm_s3b_lane_cap)
   int opt_lanes = 1;                 // sub-batches of one cmgpu_map_* call mapped side by side (own streams and intermediates each)
   std::vector<cmgpu_ctx *> lanes;    // the further lanes' contexts (views of this context's index, reference, batch and record arrays)
+  int shared_children = 0;           // contexts made by cmgpu_create_shared that view this one's buffers (the lanes among them refresh their views)
+  cmgpu_ctx *shared_parent = nullptr;
   int opt_heavy_mid = 0;             // 0: 64 hits; -1: no 16-lane class
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
   int opt_heavy_last = 0;            // heavy-last processing order: 0 auto, 1 always, -1 never
@@ -206,7 +210,7 @@ struct cmgpu_ctx {
             &resc_n, &resc_p, &m_tot, &m_off, &mbuf, &mcnt, &mcp, &mcn, &force0, &fbuf, &fcnt, &fcp, &fcn, &alive,
             &dpos, &derr, &dsplit, &nv, &v_off, &v_err, &v_end, &ndp, &ndn, &min_err, &second_err, &n_best, &n_second, &pe_min, &pe_second, &pe_nbest,
             &pe_nsecond, &pe_first, &pe_i1, &pe_i2, &pe_choice, &rec, &rec_ok, &scan_tmp, &stats, &partials, &wl, &pow10_tab, &bcb, &bcq, &bco, &bc_key, &bc_ok, &wl_num, &store, &store_bc, &text, &sam_rec, &sam_cigar, &sam_md, &sam_z, &part_cnt, &mm_cursor, &mm_marks, &rid_rank, &ref_off_r, &ref_len_r, &pairs_rank,
-            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &rec_dense_b, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &rs_pool, &rs_pool_off, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
+            &ex.owner, &ex.send, &ex.counts, &ex.stage, &rec_dense, &rec_dense_b, &maxlen_dev, &bkt_fast, &ref_planes, &read_planes, &mm_stage, &coop_prof, &rs_pool, &rs_pool_off, &goff, &coop_slab, &hv_cnt, &hv_list, &perm_reads, &perm_pairs, &hv_tmp, &srt_cnt, &srt_list, &rs_list, &rs_cnt};
   }
 };
 

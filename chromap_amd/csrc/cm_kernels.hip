@@ -674,25 +674,28 @@ struct CmDevGroup {
 };
 // per-group LDS: the cooperative work area, then the group's cross-wave words
 #define CM_XW_BYTES 256
-__host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool own_oc) { return ((cm_coop_mem_bytes(P, MM, RB, own_oc) + 15) & ~(size_t)15) + CM_XW_BYTES; }
+__host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, uint32_t RB, bool own_oc, bool key32 = false) { return ((cm_coop_mem_bytes(P, MM, RB, own_oc, key32) + 15) & ~(size_t)15) + CM_XW_BYTES; }
 
 // S3b for long hit lists, merge-sort form (cm_coop_s3b): blockDim.x / G groups per block, one listed read each.  What the
 // function declines (more occurrence runs than its tables hold) is appended to fb_list for the bitonic kernel above.
 // use_slab: the launch has at most d.coop_slab_blocks blocks of one group each, block b works on slab b (lists longer than P)
-template <int G>
+// K32: 32-bit hit keys (global coordinates, d.goff), 11 instead of 19 bytes of shared memory per hit -- not with use_slab
+template <int G, bool K32>
 __global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
                                                                       uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, uint32_t use_slab) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
-  const size_t gb = cm_coop_group_bytes(P, MM, RB, false);
+  const size_t gb = cm_coop_group_bytes(P, MM, RB, false, K32);
   uint8_t *base = cm_lds + (size_t)grp * gb;
-  CmCoopMem m = cm_coop_mem_at(base, P, MM, RB, false);
+  CmCoopMem m = cm_coop_mem_at(base, P, MM, RB, false, K32);
   if (use_slab) cm_coop_slab_at(m, d.coop_slab + (size_t)blockIdx.x * cm_coop_slab_bytes(d.coop_slab_cap), d.coop_slab_cap);
   CmDevGroup<G> g;
   g.t = threadIdx.x % G;
   g.xw = reinterpret_cast<uint32_t *>(base + gb - CM_XW_BYTES);
   for (uint32_t gid = blockIdx.x * gpb + grp; gid < n_list; gid += gridDim.x * gpb) {  // a whole group
     const uint32_t r = list[gid];
-    const bool done = use_slab ? cm_coop_s3b<true>(d, r, g, m) : cm_coop_s3b<false>(d, r, g, m);
+    bool done;
+    if constexpr (K32) done = cm_coop_s3b_k32(d, r, g, m);
+    else done = use_slab ? cm_coop_s3b<true>(d, r, g, m) : cm_coop_s3b<false>(d, r, g, m);
     if (!done && g.t == 0) fb_list[atomicAdd(fb_cnt, 1u)] = r;
     g.sync();  // the work area is reused
   }
@@ -1794,7 +1797,6 @@ static inline uint32_t cm_coop_mm(const CmDev &d, uint32_t max_read_len) {
   uint32_t MM = max_read_len > (uint32_t)d.p.k ? max_read_len - (uint32_t)d.p.k + 1 : 1;
   return MM > 256 ? 256 : MM;
 }
-static size_t cm_exp_pad() { const char *e = getenv("CM_COOP_LDS_PAD"); return e ? (size_t)atoi(e) * 1024 : 0; }  // EXPERIMENT (remove)
 void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s, bool coop, uint32_t max_read_len) {
   auto pow2 = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };  // the sort network's size: a power of two
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
@@ -1805,25 +1807,30 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     const uint32_t RB = d.coop_rb ? d.coop_rb : 3 * MM + 2;  // a run per minimizer and strand, the + list's table padded to a power of two (cm_coop_s3b_expand)
     uint32_t *fb_list = d.hv_list + 5 * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + 5;
     bool any_coop = false;
+    const bool k32 = d.goff != nullptr;  // (the reference fits 32-bit hit keys: every class's work area shrinks from 19 to 11 bytes per hit)
+#define CM_S3B_LAUNCH(G_, GRID_, BLOCK_, LDS_, ...)                                                                         \
+    do { if (k32) hipLaunchKernelGGL((k_s3b_coop<G_, true>), GRID_, BLOCK_, LDS_, s, __VA_ARGS__);                          \
+         else hipLaunchKernelGGL((k_s3b_coop<G_, false>), GRID_, BLOCK_, LDS_, s, __VA_ARGS__); } while (0)
+#define CM_S3B_OPTIN(G_, LDS_) (k32 ? cm_lds_optin(&k_s3b_coop<G_, true>, LDS_) : cm_lds_optin(&k_s3b_coop<G_, false>, LDS_))
     if (n_cls[0]) {  // a wave per read, two reads per block
-      const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB, false);
-      if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
-        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[0] + 1) / 2), dim3(128), lds, s, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt, 0u);
+      const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB, false, k32);
+      if (CM_S3B_OPTIN(64, lds)) {
+        CM_S3B_LAUNCH(64, dim3((n_cls[0] + 1) / 2), dim3(128), lds, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt, 0u);
         rest[0] = 0; any_coop = true;
       }
     }
     if (n_cls[21] && d.hv_sub) {  // the wave class's short lists: four reads per block of 256 lanes, a quarter of the work area each
-      const size_t lds = 4 * cm_coop_group_bytes(d.hv_sub, MM, RB, false);
-      if (cm_lds_optin(&k_s3b_coop<64>, lds)) {
-        hipLaunchKernelGGL(k_s3b_coop<64>, dim3((n_cls[21] + 3) / 4), dim3(256), lds, s, d, lst(21), n_cls[21], d.hv_sub, MM, RB, fb_list, fb_cnt, 0u);
+      const size_t lds = 4 * cm_coop_group_bytes(d.hv_sub, MM, RB, false, k32);
+      if (CM_S3B_OPTIN(64, lds)) {
+        CM_S3B_LAUNCH(64, dim3((n_cls[21] + 3) / 4), dim3(256), lds, d, lst(21), n_cls[21], d.hv_sub, MM, RB, fb_list, fb_cnt, 0u);
         rest[21] = 0; any_coop = true;
       }
     }
 #define CM_S3B_COOP_CLASS(C_, Q_, G_)                                                                                                              \
     if (n_cls[C_] && d.hv_max[Q_] > d.hv_max[Q_ - 1]) {                                                                                            \
-      const size_t lds = cm_coop_group_bytes(d.hv_max[Q_], MM, RB, false) + cm_exp_pad();                                                          \
-      if (cm_lds_optin(&k_s3b_coop<G_>, lds)) {                                                                                                    \
-        hipLaunchKernelGGL(k_s3b_coop<G_>, dim3(n_cls[C_]), dim3(G_), lds, s, d, lst(C_), n_cls[C_], d.hv_max[Q_], MM, RB, fb_list, fb_cnt, 0u);  \
+      const size_t lds = cm_coop_group_bytes(d.hv_max[Q_], MM, RB, false, k32);                                                                    \
+      if (CM_S3B_OPTIN(G_, lds)) {                                                                                                                 \
+        CM_S3B_LAUNCH(G_, dim3(n_cls[C_]), dim3(G_), lds, d, lst(C_), n_cls[C_], d.hv_max[Q_], MM, RB, fb_list, fb_cnt, 0u);                      \
         rest[C_] = 0; any_coop = true;                                                                                                             \
       }                                                                                                                                            \
     }
@@ -1832,18 +1839,18 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     CM_S3B_COOP_CLASS(10, 3, 512)  //  per hit cost more in barriers than the shorter chunks save; ~8 hits per lane it is)
 #undef CM_S3B_COOP_CLASS
     if (n_cls[25] && d.hv_big > d.hv_max[3]) {  // the largest work area: one block per CU
-      const size_t lds = cm_coop_group_bytes(d.hv_big, MM, RB, false);
-      if (cm_lds_optin(&k_s3b_coop<1024>, lds)) {
-        hipLaunchKernelGGL(k_s3b_coop<1024>, dim3(n_cls[25]), dim3(1024), lds, s, d, lst(25), n_cls[25], d.hv_big, MM, RB, fb_list, fb_cnt, 0u);
+      const size_t lds = cm_coop_group_bytes(d.hv_big, MM, RB, false, k32);
+      if (CM_S3B_OPTIN(1024, lds)) {
+        CM_S3B_LAUNCH(1024, dim3(n_cls[25]), dim3(1024), lds, d, lst(25), n_cls[25], d.hv_big, MM, RB, fb_list, fb_cnt, 0u);
         rest[25] = 0; any_coop = true;
       }
     }
     if (n_cls[3] && d.coop_slab && d.hv_max[3]) {  // lists beyond the largest class: 1024 lanes on a slab of global memory each
       const size_t lds = cm_coop_group_bytes(d.hv_max[3], MM, RB, false);
-      if (cm_lds_optin(&k_s3b_coop<1024>, lds)) {
+      if (cm_lds_optin(&k_s3b_coop<1024, false>, lds)) {
         const uint32_t blocks = n_cls[3] < d.coop_slab_blocks ? n_cls[3] : d.coop_slab_blocks;
         uint32_t *sl = d.hv_list + 16 * (size_t)d.hv_stride, *sc = d.hv_cnt + 16;  // what even that declines: one lane each
-        hipLaunchKernelGGL(k_s3b_coop<1024>, dim3(blocks), dim3(1024), lds, s, d, lst(3), n_cls[3], d.hv_max[3], MM, RB, sl, sc, 1u);
+        hipLaunchKernelGGL((k_s3b_coop<1024, false>), dim3(blocks), dim3(1024), lds, s, d, lst(3), n_cls[3], d.hv_max[3], MM, RB, sl, sc, 1u);
         hipLaunchKernelGGL(k_s3b_serial, dim3(64), dim3(64), 0, s, d, (const uint32_t *)sl, 0u, (const uint32_t *)sc);
         rest[3] = 0;
       }

@@ -1184,22 +1184,52 @@ CM_HD uint32_t cm_sweep_cluster_from(const uint64_t *h, uint32_t b, uint32_t n, 
   return out;
 }
 
-// cm_sweep_cluster_from that also says where the local cluster ends (*end_out: the index of the first hit behind it, at most n)
-CM_HD uint32_t cm_sweep_cluster_walk(const uint64_t *h, uint32_t b, uint32_t n, int e, int seeds_required, uint32_t num_minimizers,
-                                     uint64_t *out_h, uint8_t *out_c, uint64_t out_mask, uint32_t *end_out) {
+// Hit keys of the cooperative hit-list stages (cm_coop.h): the 64-bit key of the reference (sequence << 32 | position), or -- a
+// reference that fits -- the 32-bit GLOBAL coordinate goff[sequence] + position (CmDev::goff: the sequences laid end to end with gaps
+// wider than a read + the error threshold, so hits on different sequences are never within e of each other and the "same sequence"
+// test of the sweep is implied by the distance test).  Same order, same clusters, 4 instead of 8 bytes of shared memory per hit and
+// buffer.
+template <class K> struct CmKeyOps;
+template <> struct CmKeyOps<uint64_t> {
+  static CM_HD bool brk(uint64_t prev, uint64_t x, int e) { return cm_sweep_local_break(prev, x, e); }
+  static CM_HD uint32_t pos(uint64_t x) { return (uint32_t)x; }
+  static CM_HD uint64_t top() { return ~0ull; }
+  static CM_HD uint64_t cand(uint64_t x, const uint32_t *, uint32_t) { return x & ~(1ull << 63); }
+};
+template <> struct CmKeyOps<uint32_t> {
+  static CM_HD bool brk(uint32_t prev, uint32_t x, int e) { return x > prev + (uint32_t)e; }
+  static CM_HD uint32_t pos(uint32_t x) { return x; }
+  static CM_HD uint32_t top() { return ~0u; }
+  static CM_HD uint64_t cand(uint32_t x, const uint32_t *goff, uint32_t n_seq) {  // back to sequence << 32 | position
+    uint32_t lo = 0, hi = n_seq;  // the largest sequence with goff <= x
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (goff[mid] <= x) lo = mid; else hi = mid;
+    }
+    return ((uint64_t)lo << 32) | (x - goff[lo]);
+  }
+};
+// how a candidate leaves the sweep: as a key (32-bit keys stay keys) or as the reference's sequence << 32 | position
+template <class K, class KOUT> struct CmKeyOut { static CM_HD KOUT get(K x, const uint32_t *goff, uint32_t n_seq) { return (KOUT)CmKeyOps<K>::cand(x, goff, n_seq); } };
+template <> struct CmKeyOut<uint32_t, uint32_t> { static CM_HD uint32_t get(uint32_t x, const uint32_t *, uint32_t) { return x; } };
+// cm_sweep_cluster_from that also says where the local cluster ends (*end_out: the index of the first hit behind it, at most n); the
+// parked candidates keep the key type
+template <class K>
+CM_HD uint32_t cm_sweep_cluster_walk(const K *h, uint32_t b, uint32_t n, int e, int seeds_required, uint32_t num_minimizers,
+                                     K *out_h, uint8_t *out_c, uint32_t *end_out) {
+  typedef CmKeyOps<K> KO;
   uint32_t out = 0;
   int mcount = 1, equal = 1, best_equal = 1;
-  uint64_t prev_hit = h[b], best_local = prev_hit;
-  uint64_t ahead = b + 1 < n ? h[b + 1] : ~0ull;
+  K prev_hit = h[b], best_local = prev_hit;
+  K ahead = b + 1 < n ? h[b + 1] : KO::top();
   uint32_t pi = b + 1;
   for (;; ++pi) {
-    uint64_t x = ahead;
-    ahead = pi + 1 < n ? h[pi + 1] : ~0ull;
-    const bool last = pi >= n || cm_sweep_local_break(prev_hit, x, e);
-    if (last) x = ~0ull;
-    if (last || ((uint32_t)mcount >= num_minimizers && (uint32_t)x > (uint32_t)best_local + (uint32_t)e)) {
+    K x = ahead;
+    ahead = pi + 1 < n ? h[pi + 1] : KO::top();
+    const bool last = pi >= n || KO::brk(prev_hit, x, e);
+    if (last || ((uint32_t)mcount >= num_minimizers && KO::pos(x) > KO::pos(best_local) + (uint32_t)e)) {
       if (mcount >= seeds_required) {
-        out_h[out] = best_local & out_mask; out_c[out] = (uint8_t)best_equal;
+        out_h[out] = best_local; out_c[out] = (uint8_t)best_equal;
         ++out;
       }
       if (last) break;

@@ -33,6 +33,7 @@
 
 // Subset of MappingParameters used on the device.
 #define CM_SAM_CIGAR_CAP 64
+#define CM_GOFF_GAP 2048u       // > CM_MAX_READ_LEN + the largest error threshold: no hit of one sequence lies within e of another's
 #define CM_MAX_READ_LEN 1400   // 16 pairs of reads per block must fit the LDS staging area (2 x 24 KB)
 struct CmParams {
   int32_t e;             // error_threshold
@@ -79,6 +80,9 @@ struct CmDev {
   const uint64_t *ref_off;
   const uint32_t *ref_len;
   uint32_t n_seq;
+  // goff[i]: start of sequence i (index order) when the sequences are laid end to end with CM_GOFF_GAP positions between them, n_seq + 1
+  // entries -- the 32-bit hit keys of the cooperative hit-list stage (CmKeyOps, cm_stages.h); nullptr: the reference does not fit 32 bits
+  const uint32_t *goff;
   // ---- the same bytes as bit planes (cm_pack_planes32, cm_stages.h), interleaved: record w = the four plane words of bases
   //      32 w .. 32 w + 31 of `ref` -- bit i of p0 / p1 = the two bits of base i's CharToUint8 code, pn = none of ACGTacgt,
   //      pc = a lower-case letter -- so that an alignment window (66 .. 100 bases) is ONE run of 48 .. 64 bytes (1-2 sectors)

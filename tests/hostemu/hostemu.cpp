@@ -50,17 +50,21 @@ static bool g_coop_reverse = false;  // lanes take their turns in descending ord
 extern "C" void hostemu_set_coop_order(int reverse) { g_coop_reverse = reverse != 0; }
 extern "C" void hostemu_coop_items(unsigned long long *out) { memcpy(out, g_coop_items, sizeof(g_coop_items)); }
 
+static bool g_coop_key32 = true;  // 32-bit hit keys in the cooperative hit-list stage where the reference allows (as on the device)
+extern "C" void hostemu_set_coop_key32(int on) { g_coop_key32 = on != 0; }
 template <int G>
 static void emu_coop_s3b(const CmDev &d, const std::vector<uint32_t> &list, std::vector<uint8_t> &ok) {
   std::vector<uint8_t> mem(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB, false) + 16);
   uint8_t *base = mem.data() + ((16 - ((uintptr_t)mem.data() & 15)) & 15);
   CmCoopMem m = cm_coop_mem_at(base, g_coop.P, g_coop.MM, g_coop.RB, false);
+  std::vector<uint8_t> mem32(cm_coop_mem_bytes(g_coop.P, g_coop.MM, g_coop.RB, false, true) + 16);
+  const CmCoopMem m32 = cm_coop_mem_at(mem32.data() + ((16 - ((uintptr_t)mem32.data() & 15)) & 15), g_coop.P, g_coop.MM, g_coop.RB, false, true);
   std::vector<uint8_t> slab(g_coop_slab ? cm_coop_slab_bytes(g_coop_slab) + 16 : 0);
   if (g_coop_slab) cm_coop_slab_at(m, slab.data() + ((16 - ((uintptr_t)slab.data() & 15)) & 15), g_coop_slab);
   emu_run_group<G>([&](EmuGroup<G> &g) {
     for (size_t i = 0; i < list.size(); ++i) {
       // a list longer than the work area goes to the slab (the device has a launch of its own for those)
-      const bool done = g_coop_slab && d.hit_tot[list[i]] > g_coop.P ? cm_coop_s3b<true>(d, list[i], g, m) : cm_coop_s3b<false>(d, list[i], g, m);
+      const bool done = g_coop_slab && d.hit_tot[list[i]] > g_coop.P ? cm_coop_s3b<true>(d, list[i], g, m) : (d.goff ? cm_coop_s3b_k32(d, list[i], g, m32) : cm_coop_s3b<false>(d, list[i], g, m));
       if (g.t == 0) ok[i] = done ? 1 : 0;
       g.sync();
     }
@@ -209,6 +213,13 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
   std::vector<uint8_t> refb(tot, 0);
   for (uint32_t i = 0; i < ref->n_sequences; ++i) memcpy(refb.data() + roff[i], ref->sequences[i], ref->lengths[i]);
   d.ref = refb.data(); d.ref_off = roff.data(); d.ref_len = ref->lengths; d.n_seq = ref->n_sequences;
+  std::vector<uint32_t> goff(ref->n_sequences + 1);  // CmDev::goff as cm_fill_dev_range builds it
+  {
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < ref->n_sequences; ++i) { goff[i] = (uint32_t)acc; acc += (uint64_t)ref->lengths[i] + CM_GOFF_GAP; }
+    goff[ref->n_sequences] = (uint32_t)acc;
+    d.goff = acc < 0xffff0000ull && g_coop_key32 ? goff.data() : nullptr;
+  }
   // the reference as bit planes (k_pack_ref): k_s5b_verify aligns on them
   const uint64_t rplw = (tot + 31) / 32 + 4;
   std::vector<CmPlRec> refpl;

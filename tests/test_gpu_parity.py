@@ -349,5 +349,12 @@ def test_shared_index_contexts_map_concurrently():
     got = sorted(out[0] + out[1])
     uniq = lambda v: [t for t in v if t[4] > 0]
     assert uniq(got) == uniq(want)
+    # the child views the parent's re-hashed probe table: the parent may not rebuild or release it while the child lives
+    from chromap_amd.mapper import ChromapError
+    with pytest.raises(ChromapError, match="before cmgpu_create_shared"):
+        g0.set_option("probe_table_shift", 0)
     g1.close()
+    g0.set_option("probe_table_shift", 2)  # (no child left: allowed again)
+    rec2, k2 = g0.map_pairs(b1, o1, b2, o2)
+    assert sorted(_rec_tuple(rec2[i]) for i in range(k2)) == want
     g0.close()
