@@ -1010,7 +1010,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     // (a range that ran out of pool undercounts what it would have used -- the pieces behind the refusal are only estimated -- and
     // growing the pool is a hipFree + hipMalloc of gigabytes, 0.3-0.5 s: grow once, generously)
     if (c->rs_pool_want > c->rs_pool_cap) want = 2 * c->rs_pool_want + (uint64_t)8192 * CM_POOL_GRANT / 2;
-    if (want < (1u << 22)) want = 1u << 22;
+    if (want < (1u << 26)) want = 1u << 26;  // (512 MB to begin with: growing costs a hipFree + hipMalloc in the middle of a run)
     if (want > 0xfffffff0ull) want = 0xfffffff0ull;
     const auto dbg_t0 = std::chrono::steady_clock::now();
     if (c->rs_pool.ensure((size_t)want * 8) == 0 && c->rs_pool_off.ensure((size_t)n2 * 2 * 4 + 16) == 0) c->rs_pool_cap = (uint32_t)(c->rs_pool.cap / 8 > 0xfffffff0ull ? 0xfffffff0ull : c->rs_pool.cap / 8);

@@ -588,6 +588,11 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3b_heavy(CmDev d, const uint32_t 
 // The group type of cm_coop.h on the device: G = 16 (a quarter wave), 64 (a wave) or CM_BLOCK lanes.  rank() is a
 // ballot, scan() a shuffle scan inside the wave part plus, for a block, the wave totals through LDS (xw).
 // ---------------------------------------------------------------------------------------
+// Waves per SIMD the register allocation of k_s3b_coop aims at (second launch-bounds argument): at 76-85 registers a lane only five waves
+// fit a SIMD, i.e. two blocks of 512 lanes per CU whatever shared memory allows; 64 registers (6-13 of them spilled) bought 8 % of the
+// kernel's time.  Measured and NOT kept (round 5): the same for k_s5c_coop (146 -> 80 registers: 30 % slower), k_s4c_coop, k_s4b_coop
+// (slower), k_s4a/4b_rescue_wave (119 -> 80: no change -- beyond 16 waves per CU its searches are not short of waves)
+#define CM_WPE_S3B 8
 template <int G_>
 struct CmDevGroup {
   static constexpr int G = G_;
@@ -681,7 +686,7 @@ __host__ __device__ inline size_t cm_coop_group_bytes(uint32_t P, uint32_t MM, u
 // use_slab: the launch has at most d.coop_slab_blocks blocks of one group each, block b works on slab b (lists longer than P)
 // K32: 32-bit hit keys (global coordinates, d.goff), 11 instead of 19 bytes of shared memory per hit -- not with use_slab
 template <int G, bool K32>
-__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
+__global__ __launch_bounds__(G < CM_BLOCK ? CM_BLOCK : G, CM_WPE_S3B) void k_s3b_coop(CmDev d, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t P, uint32_t MM, uint32_t RB,
                                                                       uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, uint32_t use_slab) {
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const size_t gb = cm_coop_group_bytes(P, MM, RB, false, K32);
@@ -1136,7 +1141,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5c_finalize(CmDev d, uint32_t n, 
 #define CM_SORT_NB 64u  // counts below this go through the groups' counting sort of a candidate list
 #define CM_SORT_STAGE 512u  // candidates of a list the sorting wave stages in shared memory (32 + 18 KB per block of four waves)
 // the candidate lists of the reads in list 12 (k_s5a_prepare left them unsorted): a wave each (cm_coop_s5_sort)
-__global__ __launch_bounds__(CM_BLOCK) void k_s5_sort_coop(CmDev d, uint32_t lid) {
+__global__ __launch_bounds__(CM_BLOCK, 8) void k_s5_sort_coop(CmDev d, uint32_t lid) {
   if (d.abort && *d.abort) return;
   // (a wave keeps the sort's bins in its lanes: no histogram array -- 18 KB per block, eight blocks per CU)
   __shared__ uint64_t stage_p[(CM_BLOCK / 64) * CM_SORT_STAGE];  // a list of up to CM_SORT_STAGE candidates is staged here once
@@ -1271,7 +1276,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint
   }
 }
 template <int G>
-__global__ __launch_bounds__(CM_BLOCK) void k_s6a_coop(CmDev d, uint32_t P, uint32_t lid) {
+__global__ __launch_bounds__(CM_BLOCK, 6) void k_s6a_coop(CmDev d, uint32_t P, uint32_t lid) {
   if (d.abort && *d.abort) return;
   const uint32_t gpb = blockDim.x / G, grp = threadIdx.x / G;
   const uint32_t n_list = d.hv_cnt[lid];
