@@ -993,7 +993,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   // with more than a handful of such reads the later per-read / per-pair stages take them last, in waves of their own
   // (lists of class 0 -- up to heavy_wave_max hits, a wave each here -- cost the later per-lane stages little; a uniform genome
   // still has a few thousand of them per batch, and the permutation's scans and scatters cost more than they save there)
-  c->use_perm = (uint64_t)n_heavy[2] + n_heavy[3] + n_heavy[10] + n_heavy[25] > n2 / 65536 || (uint64_t)n_heavy[0] + n_heavy[21] + n_heavy[1] > n2 / 256;  // (lists 21, 0, 1: up to 1024 hits)
+  c->use_perm = (uint64_t)n_heavy[CM_L_HIT_B256B] + n_heavy[CM_L_HIT_SLAB] + n_heavy[CM_L_HIT_B512] + n_heavy[CM_L_HIT_B1024] > n2 / 65536 || (uint64_t)n_heavy[CM_L_HIT_WAVE] + n_heavy[CM_L_HIT_WAVE_SMALL] + n_heavy[CM_L_HIT_B256A] > n2 / 256;  // (lists 21, 0, 1: up to 1024 hits)
   if (c->opt_heavy_last) c->use_perm = c->opt_heavy_last > 0;
   if (c->use_perm) {
     uint32_t *tmp = (uint32_t *)c->hv_tmp.p;

@@ -382,12 +382,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s3a_count(CmDev d, uint32_t n) {
   // batch from a repeat-bearing genome, where nearly every wave holds a read of some class (k_s3a_count 1.4 ms against 0.45 ms
   // on the uniform genome with one atomic per wave).  The order inside a list is of no consequence.
   // (class 21: the lists of the wave class that fit a quarter of its work area -- four reads per CU where the full-size area has one)
-  const uint32_t cls = tot <= d.s3b_cap ? 5u : tot <= d.hv_mid ? 4u : tot <= d.hv_sub ? 21u : tot <= d.hv_max[0] ? 0u : tot <= d.hv_max[1] ? 1u : tot <= d.hv_max[2] ? 2u : tot <= d.hv_max[3] ? 10u : tot <= d.hv_big ? 25u : 3u;
+  const uint32_t cls = tot <= d.s3b_cap ? 5u /* (none: the lane's own slots) */ : tot <= d.hv_mid ? CM_L_HIT_G16 : tot <= d.hv_sub ? CM_L_HIT_WAVE_SMALL : tot <= d.hv_max[0] ? CM_L_HIT_WAVE : tot <= d.hv_max[1] ? CM_L_HIT_B256A
+                       : tot <= d.hv_max[2] ? CM_L_HIT_B256B : tot <= d.hv_max[3] ? CM_L_HIT_B512 : tot <= d.hv_big ? CM_L_HIT_B1024 : CM_L_HIT_SLAB;
   __shared__ uint32_t sh_cnt[8], sh_base[8];
   if (threadIdx.x < 8) sh_cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t ids[8] = {0u, 1u, 2u, 3u, 4u, 10u, 21u, 25u};
+  const uint32_t ids[8] = {CM_L_HIT_WAVE, CM_L_HIT_B256A, CM_L_HIT_B256B, CM_L_HIT_SLAB, CM_L_HIT_G16, CM_L_HIT_B512, CM_L_HIT_WAVE_SMALL, CM_L_HIT_B1024};
   uint32_t slot = 0, mine = 8;
 #pragma unroll
   for (uint32_t q = 0; q < 8; ++q) {
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4a_rescue_count(CmDev d, uint32_t
   const bool aug0 = i0 < n && cm_s4a_decide(d, i);
   // a read whose mate has many candidates goes to list 23 instead: a wave each (k_s4a_rescue_wave / k_s4b_rescue_wave)
   const bool wv = aug0 && cm_rescue_is_wave(d, i, coop);
-  cm_wave_append(d.hv_list + (size_t)23 * d.hv_stride, d.hv_cnt + 23, wv, i);
+  cm_wave_append(d.hv_list + (size_t)CM_L_SEARCH_WAVE * d.hv_stride, d.hv_cnt + CM_L_SEARCH_WAVE, wv, i);
   const bool aug = aug0 && !wv;
   // slot inside the block: wave-aggregated LDS atomic
   const unsigned long long m = __ballot(aug);
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4b_rescue_merge(CmDev d, uint32_t
   const bool to_wave = mine && coop && d.m_tot[i] > CM_S4B_COPY_MIN;
   if (mine && !to_wave) cm_s4b_rescue_merge(d, i);
   if (to_wave) { d.mcp[i] = 0; d.mcn[i] = 0; }  // (until list 6's wave has copied the lists)
-  if (coop) cm_wave_append(d.hv_list + (size_t)6 * d.hv_stride, d.hv_cnt + 6, to_wave, i);
+  if (coop) cm_wave_append(d.hv_list + (size_t)CM_L_RS_WAVE * d.hv_stride, d.hv_cnt + CM_L_RS_WAVE, to_wave, i);
 }
 // fill pass of one direction by a group: per-minimizer counts to LDS, lane 0 turns them into offsets (minimizer order = the
 // order cm_rescue writes in), the lanes write their minimizers' hits there
@@ -902,7 +903,8 @@ __host__ __device__ inline uint32_t cm_s4b_pmax(const CmDev &d) { return d.rs_bi
 __device__ __forceinline__ uint32_t cm_rescue_coop_class(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t big = d.resc_p[r] > d.resc_n[r] ? d.resc_p[r] : d.resc_n[r];
   if (!coop || big <= CM_RS_COOP_MIN || d.hv_max[0] == 0) return 0;
-  return big <= d.hv_max[0] ? 6u : big <= d.hv_max[1] ? 7u : big <= d.hv_max[2] ? 8u : big <= d.rs_max3 ? 11u : big <= d.rs_big ? 26u : (d.coop_slab && big <= d.coop_slab_cap) ? 15u : 0u;
+  return big <= d.hv_max[0] ? CM_L_RS_WAVE : big <= d.hv_max[1] ? CM_L_RS_B256A : big <= d.hv_max[2] ? CM_L_RS_B256B : big <= d.rs_max3 ? CM_L_RS_B512 : big <= d.rs_big ? CM_L_RS_B1024
+         : (d.coop_slab && big <= d.coop_slab_cap) ? CM_L_RS_SLAB : 0u;
 }
 __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_cap, uint32_t coop) {
   if (d.abort && *d.abort) return;
@@ -917,9 +919,9 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
     const uint32_t cls = mine ? cm_rescue_coop_class(d, r, coop) : 0u;
     if (mine) cm_s4b_rescue_merge(d, r, cls ? CM_S4B_FILL_ONLY : CM_S4B_ALL);
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, cls == c, r);
-    cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, cls == 11u, r);
-    cm_wave_append(d.hv_list + (size_t)26 * d.hv_stride, d.hv_cnt + 26, cls == 26u, r);
-    cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, cls == 15u, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_RS_B512 * d.hv_stride, d.hv_cnt + CM_L_RS_B512, cls == CM_L_RS_B512, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_RS_B1024 * d.hv_stride, d.hv_cnt + CM_L_RS_B1024, cls == CM_L_RS_B1024, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_RS_SLAB * d.hv_stride, d.hv_cnt + CM_L_RS_SLAB, cls == CM_L_RS_SLAB, r);
   }
   const long long tg0 = d.prof ? clock64() : 0;
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(tg0 - tl0); atomicAdd(&d.prof[34], dt); atomicMax(&d.prof[35], dt); }
@@ -945,9 +947,9 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
       if (t == 0 && !cls) cm_s4b_rescue_merge(d, r, CM_S4B_PREFILLED);  // sort, cluster, merge of the hits the group wrote
     }
     for (uint32_t c = 6; c <= 8; ++c) cm_wave_append(d.hv_list + (size_t)c * d.hv_stride, d.hv_cnt + c, t == 0 && cls == c, r);
-    cm_wave_append(d.hv_list + (size_t)11 * d.hv_stride, d.hv_cnt + 11, t == 0 && cls == 11u, r);
-    cm_wave_append(d.hv_list + (size_t)26 * d.hv_stride, d.hv_cnt + 26, t == 0 && cls == 26u, r);
-    cm_wave_append(d.hv_list + (size_t)15 * d.hv_stride, d.hv_cnt + 15, t == 0 && cls == 15u, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_RS_B512 * d.hv_stride, d.hv_cnt + CM_L_RS_B512, t == 0 && cls == CM_L_RS_B512, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_RS_B1024 * d.hv_stride, d.hv_cnt + CM_L_RS_B1024, t == 0 && cls == CM_L_RS_B1024, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_RS_SLAB * d.hv_stride, d.hv_cnt + CM_L_RS_SLAB, t == 0 && cls == CM_L_RS_SLAB, r);
   }
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - tg0); atomicAdd(&d.prof[36], dt); atomicMax(&d.prof[37], dt); }
 }
@@ -956,12 +958,10 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_list(CmDev d, uint32_t seg_ca
 // and leaves at once when it is empty.
 // SMALL: tables for searches with up to CM_RESCUE_WMAX_S best mate candidates (4.5 KB: 32 waves per CU instead of 15, cm_coop.h) over
 // list 23; the reads with a longer search are appended to list 31, which the launch with the full tables (SMALL = false) works through.
-#define CM_LIST_RESCUE_WAVE 23u
-#define CM_LIST_RESCUE_WAVE_BIG 31u
 template <bool SMALL>
 __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
   __shared__ __attribute__((aligned(16))) uint8_t rmem[SMALL ? CM_RESCUE_MEM_BYTES_S : CM_RESCUE_MEM_BYTES];
-  const uint32_t li = SMALL ? CM_LIST_RESCUE_WAVE : CM_LIST_RESCUE_WAVE_BIG;
+  const uint32_t li = SMALL ? CM_L_SEARCH_WAVE : CM_L_SEARCH_WAVE_BIG;
   const uint32_t cnt = d.hv_cnt[li];
   if (blockIdx.x >= cnt) return;
   const uint32_t *list = d.hv_list + (size_t)li * d.hv_stride;
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
       if (threadIdx.x == 0) atomicAdd(&d.prof[mx < 16 ? 40 : mx < 32 ? 41 : mx < 64 ? 42 : mx < 128 ? 43 : mx < 200 ? 44 : mx < 300 ? 45 : 46], 1ull);
     }
     if (SMALL && !cm_coop_rescue_fits(d, r, g, CM_RESCUE_WMAX_S)) {
-      if (threadIdx.x == 0) d.hv_list[(size_t)CM_LIST_RESCUE_WAVE_BIG * d.hv_stride + atomicAdd(d.hv_cnt + CM_LIST_RESCUE_WAVE_BIG, 1u)] = r;
+      if (threadIdx.x == 0) d.hv_list[(size_t)CM_L_SEARCH_WAVE_BIG * d.hv_stride + atomicAdd(d.hv_cnt + CM_L_SEARCH_WAVE_BIG, 1u)] = r;
       continue;
     }
     cm_coop_s4a_rescue(d, r, g, m);
@@ -995,7 +995,7 @@ template <bool SMALL>
 __global__ __launch_bounds__(64) void k_s4b_rescue_wave(CmDev d, uint32_t coop) {
   if (d.abort && *d.abort) return;
   __shared__ __attribute__((aligned(16))) uint8_t rmem[SMALL ? CM_RESCUE_MEM_BYTES_S : CM_RESCUE_MEM_BYTES];
-  const uint32_t li = SMALL ? CM_LIST_RESCUE_WAVE : CM_LIST_RESCUE_WAVE_BIG;
+  const uint32_t li = SMALL ? CM_L_SEARCH_WAVE : CM_L_SEARCH_WAVE_BIG;
   const uint32_t cnt = d.hv_cnt[li];
   if (blockIdx.x >= cnt) return;
   const uint32_t *list = d.hv_list + (size_t)li * d.hv_stride;
@@ -1068,14 +1068,14 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s4c_reduce(CmDev d, uint32_t n, ui
     uint32_t big = d.mcp[r1] > d.mcn[r1] ? d.mcp[r1] : d.mcn[r1];
     big = d.mcp[r2] > big ? d.mcp[r2] : big;
     big = d.mcn[r2] > big ? d.mcn[r2] : big;
-    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_SMALL ? 27u : big <= CM_S4C_P_WAVE ? 9u : big <= CM_S4C_P_BLOCK ? 14u : big <= d.s4c_pbig ? 19u : 0u;
+    if ((coop & 4u) && big > CM_S4C_COOP_MIN) cls = big <= CM_S4C_P_SMALL ? CM_L_PF_WAVE : big <= CM_S4C_P_WAVE ? CM_L_PF_BLOCK : big <= CM_S4C_P_BLOCK ? CM_L_PF_BLOCK_BIG : big <= d.s4c_pbig ? CM_L_PF_HUGE : 0u;
     if (!cls) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
   }
   if (coop & 4u) {
-    cm_wave_append(d.hv_list + 9 * (size_t)d.hv_stride, d.hv_cnt + 9, cls == 9u, pair);
-    cm_wave_append(d.hv_list + 27 * (size_t)d.hv_stride, d.hv_cnt + 27, cls == 27u, pair);
-    cm_wave_append(d.hv_list + 14 * (size_t)d.hv_stride, d.hv_cnt + 14, cls == 14u, pair);
-    cm_wave_append(d.hv_list + 19 * (size_t)d.hv_stride, d.hv_cnt + 19, cls == 19u, pair);
+    cm_wave_append(d.hv_list + CM_L_PF_BLOCK * (size_t)d.hv_stride, d.hv_cnt + CM_L_PF_BLOCK, cls == CM_L_PF_BLOCK, pair);
+    cm_wave_append(d.hv_list + CM_L_PF_WAVE * (size_t)d.hv_stride, d.hv_cnt + CM_L_PF_WAVE, cls == CM_L_PF_WAVE, pair);
+    cm_wave_append(d.hv_list + CM_L_PF_BLOCK_BIG * (size_t)d.hv_stride, d.hv_cnt + CM_L_PF_BLOCK_BIG, cls == CM_L_PF_BLOCK_BIG, pair);
+    cm_wave_append(d.hv_list + CM_L_PF_HUGE * (size_t)d.hv_stride, d.hv_cnt + CM_L_PF_HUGE, cls == CM_L_PF_HUGE, pair);
   }
   if (!d.perm_pairs) return;  // the queue is only served in a batch with heavy reads
   cm_s4c_queue_sort(d, pair, i < n && !cls && d.alive[pair], coop);
@@ -1119,9 +1119,9 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s5a_prepare(CmDev d, uint32_t n, u
   const bool big = to_wave && (d.fcp[r] > CM_S5C_P_WAVE || d.fcn[r] > CM_S5C_P_WAVE);
   const bool small = to_wave && d.fcp[r] <= CM_S5C_P_SMALL && d.fcn[r] <= CM_S5C_P_SMALL;  // list 28: a quarter of the work arrays
   if (coop) {
-    cm_wave_append(d.hv_list + (size_t)28 * d.hv_stride, d.hv_cnt + 28, small, r);
-    cm_wave_append(d.hv_list + (size_t)12 * d.hv_stride, d.hv_cnt + 12, to_wave && !big && !small, r);
-    cm_wave_append(d.hv_list + (size_t)22 * d.hv_stride, d.hv_cnt + 22, big, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S5_SMALL * d.hv_stride, d.hv_cnt + CM_L_S5_SMALL, small, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S5_WAVE * d.hv_stride, d.hv_cnt + CM_L_S5_WAVE, to_wave && !big && !small, r);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S5_BLOCK * d.hv_stride, d.hv_cnt + CM_L_S5_BLOCK, big, r);
   }
 }
 // S5c; long draft-mapping lists are queued for k_sort_lists (S6a sorts them by position; split alignment keeps emission order)
@@ -1266,13 +1266,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6a_pair(CmDev d, uint32_t n, uint
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
   uint32_t cls = 0;
   if (i < n && cm_s6a_pre<false>(d, pair)) {
-    cls = coop ? cm_s6_class(d, pair, 29u, 13u, 18u) : 0u;
+    cls = coop ? cm_s6_class(d, pair, CM_L_S6A_SMALL, CM_L_S6A_WAVE, CM_L_S6A_BLOCK) : 0u;
     if (!cls) cm_s6a_sweeps<false>(d, pair);
   }
   if (coop) {
-    cm_wave_append(d.hv_list + (size_t)29 * d.hv_stride, d.hv_cnt + 29, cls == 29u, pair);
-    cm_wave_append(d.hv_list + (size_t)13 * d.hv_stride, d.hv_cnt + 13, cls == 13u, pair);
-    cm_wave_append(d.hv_list + (size_t)18 * d.hv_stride, d.hv_cnt + 18, cls == 18u, pair);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S6A_SMALL * d.hv_stride, d.hv_cnt + CM_L_S6A_SMALL, cls == CM_L_S6A_SMALL, pair);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S6A_WAVE * d.hv_stride, d.hv_cnt + CM_L_S6A_WAVE, cls == CM_L_S6A_WAVE, pair);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S6A_BLOCK * d.hv_stride, d.hv_cnt + CM_L_S6A_BLOCK, cls == CM_L_S6A_BLOCK, pair);
   }
 }
 template <int G>
@@ -1298,13 +1298,13 @@ __global__ __launch_bounds__(CM_BLOCK) void k_s6c_multi(CmDev d, uint32_t n, uin
   const uint32_t pair = i < n ? (d.perm_pairs ? d.perm_pairs[i] : i) : 0u;
   uint32_t cls = 0;
   if (i < n) {
-    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) cls = cm_s6_class(d, pair, 30u, 17u, 20u);
+    if (coop && !d.p.single && !d.p.split && d.pe_nbest[pair] > 1) cls = cm_s6_class(d, pair, CM_L_S6C_SMALL, CM_L_S6C_WAVE, CM_L_S6C_BLOCK);
     if (!cls) cm_s6c_multi<false>(d, pair);
   }
   if (coop) {
-    cm_wave_append(d.hv_list + (size_t)30 * d.hv_stride, d.hv_cnt + 30, cls == 30u, pair);
-    cm_wave_append(d.hv_list + (size_t)17 * d.hv_stride, d.hv_cnt + 17, cls == 17u, pair);
-    cm_wave_append(d.hv_list + (size_t)20 * d.hv_stride, d.hv_cnt + 20, cls == 20u, pair);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S6C_SMALL * d.hv_stride, d.hv_cnt + CM_L_S6C_SMALL, cls == CM_L_S6C_SMALL, pair);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S6C_WAVE * d.hv_stride, d.hv_cnt + CM_L_S6C_WAVE, cls == CM_L_S6C_WAVE, pair);
+    cm_wave_append(d.hv_list + (size_t)CM_L_S6C_BLOCK * d.hv_stride, d.hv_cnt + CM_L_S6C_BLOCK, cls == CM_L_S6C_BLOCK, pair);
   }
 }
 template <int G>
@@ -1795,7 +1795,7 @@ static bool cm_lds_optin(K kernel, size_t bytes) {
   return e == hipSuccess;
 }
 // n_cls[c]: reads of list c (k_s3a_count; 11 entries).  coop: lists 0, 1, 2, 10 go through the merge-sort kernel (tables sized for
-// reads of up to max_read_len bases) with a wave / 256 / 512 / 1024 lanes per read; what it declines -- hv_cnt[5] reads at list 5 --
+// reads of up to max_read_len bases) with a wave / 256 / 512 / 1024 lanes per read; what it declines -- hv_cnt[CM_L_HIT_DECLINED] reads at list 5 --
 // is taken by the bitonic kernel.
 static inline uint32_t cm_coop_mm(const CmDev &d, uint32_t max_read_len) {
   // a read of L bases has at most L - k + 1 minimizers; the tables hold that many (capped)
@@ -1810,25 +1810,25 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
   if (coop && d.hv_max[0]) {
     const uint32_t MM = cm_coop_mm(d, max_read_len);
     const uint32_t RB = d.coop_rb ? d.coop_rb : 3 * MM + 2;  // a run per minimizer and strand, the + list's table padded to a power of two (cm_coop_s3b_expand)
-    uint32_t *fb_list = d.hv_list + 5 * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + 5;
+    uint32_t *fb_list = d.hv_list + CM_L_HIT_DECLINED * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + CM_L_HIT_DECLINED;
     bool any_coop = false;
     const bool k32 = d.goff != nullptr;  // (the reference fits 32-bit hit keys: every class's work area shrinks from 19 to 11 bytes per hit)
 #define CM_S3B_LAUNCH(G_, GRID_, BLOCK_, LDS_, ...)                                                                         \
     do { if (k32) hipLaunchKernelGGL((k_s3b_coop<G_, true>), GRID_, BLOCK_, LDS_, s, __VA_ARGS__);                          \
          else hipLaunchKernelGGL((k_s3b_coop<G_, false>), GRID_, BLOCK_, LDS_, s, __VA_ARGS__); } while (0)
 #define CM_S3B_OPTIN(G_, LDS_) (k32 ? cm_lds_optin(&k_s3b_coop<G_, true>, LDS_) : cm_lds_optin(&k_s3b_coop<G_, false>, LDS_))
-    if (n_cls[0]) {  // a wave per read, two reads per block
+    if (n_cls[CM_L_HIT_WAVE]) {  // a wave per read, two reads per block
       const size_t lds = 2 * cm_coop_group_bytes(d.hv_max[0], MM, RB, false, k32);
       if (CM_S3B_OPTIN(64, lds)) {
-        CM_S3B_LAUNCH(64, dim3((n_cls[0] + 1) / 2), dim3(128), lds, d, lst(0), n_cls[0], d.hv_max[0], MM, RB, fb_list, fb_cnt, 0u);
-        rest[0] = 0; any_coop = true;
+        CM_S3B_LAUNCH(64, dim3((n_cls[CM_L_HIT_WAVE] + 1) / 2), dim3(128), lds, d, lst(CM_L_HIT_WAVE), n_cls[CM_L_HIT_WAVE], d.hv_max[0], MM, RB, fb_list, fb_cnt, 0u);
+        rest[CM_L_HIT_WAVE] = 0; any_coop = true;
       }
     }
-    if (n_cls[21] && d.hv_sub) {  // the wave class's short lists: four reads per block of 256 lanes, a quarter of the work area each
+    if (n_cls[CM_L_HIT_WAVE_SMALL] && d.hv_sub) {  // the wave class's short lists: four reads per block of 256 lanes, a quarter of the work area each
       const size_t lds = 4 * cm_coop_group_bytes(d.hv_sub, MM, RB, false, k32);
       if (CM_S3B_OPTIN(64, lds)) {
-        CM_S3B_LAUNCH(64, dim3((n_cls[21] + 3) / 4), dim3(256), lds, d, lst(21), n_cls[21], d.hv_sub, MM, RB, fb_list, fb_cnt, 0u);
-        rest[21] = 0; any_coop = true;
+        CM_S3B_LAUNCH(64, dim3((n_cls[CM_L_HIT_WAVE_SMALL] + 3) / 4), dim3(256), lds, d, lst(CM_L_HIT_WAVE_SMALL), n_cls[CM_L_HIT_WAVE_SMALL], d.hv_sub, MM, RB, fb_list, fb_cnt, 0u);
+        rest[CM_L_HIT_WAVE_SMALL] = 0; any_coop = true;
       }
     }
 #define CM_S3B_COOP_CLASS(C_, Q_, G_)                                                                                                              \
@@ -1839,25 +1839,25 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
         rest[C_] = 0; any_coop = true;                                                                                                             \
       }                                                                                                                                            \
     }
-    CM_S3B_COOP_CLASS(1, 1, 256)
-    CM_S3B_COOP_CLASS(2, 2, 256)   // (512 lanes for 1024 .. 2048 hits and 1024 for 2048 .. 4096 were measured slower: more lanes
-    CM_S3B_COOP_CLASS(10, 3, 512)  //  per hit cost more in barriers than the shorter chunks save; ~8 hits per lane it is)
+    CM_S3B_COOP_CLASS(CM_L_HIT_B256A, 1, 256)
+    CM_S3B_COOP_CLASS(CM_L_HIT_B256B, 2, 256)   // (512 lanes for 1024 .. 2048 hits and 1024 for 2048 .. 4096 were measured slower: more lanes
+    CM_S3B_COOP_CLASS(CM_L_HIT_B512, 3, 512)  //  per hit cost more in barriers than the shorter chunks save; ~8 hits per lane it is)
 #undef CM_S3B_COOP_CLASS
-    if (n_cls[25] && d.hv_big > d.hv_max[3]) {  // the largest work area: one block per CU
+    if (n_cls[CM_L_HIT_B1024] && d.hv_big > d.hv_max[3]) {  // the largest work area: one block per CU
       const size_t lds = cm_coop_group_bytes(d.hv_big, MM, RB, false, k32);
       if (CM_S3B_OPTIN(1024, lds)) {
-        CM_S3B_LAUNCH(1024, dim3(n_cls[25]), dim3(1024), lds, d, lst(25), n_cls[25], d.hv_big, MM, RB, fb_list, fb_cnt, 0u);
-        rest[25] = 0; any_coop = true;
+        CM_S3B_LAUNCH(1024, dim3(n_cls[CM_L_HIT_B1024]), dim3(1024), lds, d, lst(CM_L_HIT_B1024), n_cls[CM_L_HIT_B1024], d.hv_big, MM, RB, fb_list, fb_cnt, 0u);
+        rest[CM_L_HIT_B1024] = 0; any_coop = true;
       }
     }
-    if (n_cls[3] && d.coop_slab && d.hv_max[3]) {  // lists beyond the largest class: 1024 lanes on a slab of global memory each
+    if (n_cls[CM_L_HIT_SLAB] && d.coop_slab && d.hv_max[3]) {  // lists beyond the largest class: 1024 lanes on a slab of global memory each
       const size_t lds = cm_coop_group_bytes(d.hv_max[3], MM, RB, false);
       if (cm_lds_optin(&k_s3b_coop<1024, false>, lds)) {
-        const uint32_t blocks = n_cls[3] < d.coop_slab_blocks ? n_cls[3] : d.coop_slab_blocks;
-        uint32_t *sl = d.hv_list + 16 * (size_t)d.hv_stride, *sc = d.hv_cnt + 16;  // what even that declines: one lane each
-        hipLaunchKernelGGL((k_s3b_coop<1024, false>), dim3(blocks), dim3(1024), lds, s, d, lst(3), n_cls[3], d.hv_max[3], MM, RB, sl, sc, 1u);
+        const uint32_t blocks = n_cls[CM_L_HIT_SLAB] < d.coop_slab_blocks ? n_cls[CM_L_HIT_SLAB] : d.coop_slab_blocks;
+        uint32_t *sl = d.hv_list + CM_L_HIT_SERIAL * (size_t)d.hv_stride, *sc = d.hv_cnt + CM_L_HIT_SERIAL;  // what even that declines: one lane each
+        hipLaunchKernelGGL((k_s3b_coop<1024, false>), dim3(blocks), dim3(1024), lds, s, d, lst(CM_L_HIT_SLAB), n_cls[CM_L_HIT_SLAB], d.hv_max[3], MM, RB, sl, sc, 1u);
         hipLaunchKernelGGL(k_s3b_serial, dim3(64), dim3(64), 0, s, d, (const uint32_t *)sl, 0u, (const uint32_t *)sc);
-        rest[3] = 0;
+        rest[CM_L_HIT_SLAB] = 0;
       }
     }
     if (any_coop) {  // the declined reads: up to hv_big hits, a block each, the grid strides over the device-side list
@@ -1865,13 +1865,13 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
       hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(512), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, (const uint32_t *)fb_list, 0u, P, (const uint32_t *)fb_cnt);
     }
   }
-  if (rest[21]) {
+  if (rest[CM_L_HIT_WAVE_SMALL]) {
     const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
-    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((rest[21] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, lst(21), rest[21], P, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((rest[CM_L_HIT_WAVE_SMALL] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, lst(CM_L_HIT_WAVE_SMALL), rest[CM_L_HIT_WAVE_SMALL], P, (const uint32_t *)nullptr);
   }
-  if (rest[0]) {
+  if (rest[CM_L_HIT_WAVE]) {
     const uint32_t P = pow2(d.hv_max[0]), gpb = CM_BLOCK / 64;
-    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((rest[0] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, lst(0), rest[0], P, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_s3b_heavy<64>, dim3((rest[CM_L_HIT_WAVE] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (64 + 8) * 4, s, d, lst(CM_L_HIT_WAVE), rest[CM_L_HIT_WAVE], P, (const uint32_t *)nullptr);
   }
   const uint32_t blk[3][2] = {{1, 1}, {2, 2}, {10, 3}};  // list, size class
   for (int q = 0; q < 3; ++q) {
@@ -1880,14 +1880,14 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     const uint32_t P = pow2(d.hv_max[blk[q][1]]);
     hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[c]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(c), rest[c], P, (const uint32_t *)nullptr);
   }
-  if (rest[25]) {
+  if (rest[CM_L_HIT_B1024]) {
     const uint32_t P = pow2(d.hv_big);
-    hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[25]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(25), rest[25], P, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_s3b_heavy<CM_BLOCK>, dim3(rest[CM_L_HIT_B1024]), dim3(CM_BLOCK), (size_t)P * 10 + (CM_BLOCK + 8) * 4, s, d, lst(CM_L_HIT_B1024), rest[CM_L_HIT_B1024], P, (const uint32_t *)nullptr);
   }
-  if (rest[3]) hipLaunchKernelGGL(k_s3b_serial, dim3((rest[3] + 63) / 64), dim3(64), 0, s, d, lst(3), rest[3], (const uint32_t *)nullptr);
-  if (rest[4]) {  // groups of 16 lanes, 16 reads per block
+  if (rest[CM_L_HIT_SLAB]) hipLaunchKernelGGL(k_s3b_serial, dim3((rest[CM_L_HIT_SLAB] + 63) / 64), dim3(64), 0, s, d, lst(CM_L_HIT_SLAB), rest[CM_L_HIT_SLAB], (const uint32_t *)nullptr);
+  if (rest[CM_L_HIT_G16]) {  // groups of 16 lanes, 16 reads per block
     const uint32_t P = pow2(d.hv_mid), gpb = CM_BLOCK / 16;
-    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((rest[4] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, lst(4), rest[4], P, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_s3b_heavy<16>, dim3((rest[CM_L_HIT_G16] + gpb - 1) / gpb), dim3(CM_BLOCK), (size_t)gpb * P * 10 + gpb * (16 + 8) * 4, s, d, lst(CM_L_HIT_G16), rest[CM_L_HIT_G16], P, (const uint32_t *)nullptr);
   }
 }
 void cm_launch_k_s3b_candidates(const CmDev &d, uint32_t n, uint32_t max_read_len, hipStream_t s) {
@@ -1916,7 +1916,7 @@ static inline dim3 rescue_list_grid(uint32_t n_reads) {
 void cm_launch_k_s4a_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s, bool coop) {
   if (!n_reads) return;
   hipLaunchKernelGGL(k_s4a_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), coop ? 1u : 0u);
-  if ((coop) && cm_cls_on(d, 23)) {
+  if ((coop) && cm_cls_on(d, CM_L_SEARCH_WAVE)) {
     hipLaunchKernelGGL(k_s4a_rescue_wave<true>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);
     hipLaunchKernelGGL(k_s4a_rescue_wave<false>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d);  // (what the small tables do not hold; leaves at once when there is none)
   }
@@ -1955,7 +1955,7 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   hipLaunchKernelGGL(k_s4b_rescue_list, rescue_list_grid(n_reads), dim3(64), 0, s, d, cm_rescue_seg_cap(n_reads), all ? 1u : 0u);
   // list 23's reads were counted by waves whenever the option is on: they are filled by waves too (all == false: the groups that
   // would sort long lists do not fit this device -- every list is then finished by the wave's lane 0)
-  if ((coop) && cm_cls_on(d, 23)) {
+  if ((coop) && cm_cls_on(d, CM_L_SEARCH_WAVE)) {
     hipLaunchKernelGGL(k_s4b_rescue_wave<true>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
     hipLaunchKernelGGL(k_s4b_rescue_wave<false>, dim3(rescue_wave_blocks(n_reads)), dim3(64), 0, s, d, all ? 1u : 0u);
   }
@@ -1963,13 +1963,13 @@ void cm_launch_k_s4b_rescue_list(const CmDev &d, uint32_t n_reads, hipStream_t s
   uint32_t blocks = n_reads / 2048 + 64;  // the listed reads are a few per cent of the batch; surplus blocks leave at once
   if (blocks > 2048) blocks = 2048;
   auto lst = [&](uint32_t c) { return (const uint32_t *)(d.hv_list + (size_t)c * d.hv_stride); };
-  if (cm_cls_on(d, 6)) hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(6), (const uint32_t *)(d.hv_cnt + 6), d.hv_max[0], RB, 0u);
-  if ((d.hv_max[1] > d.hv_max[0]) && cm_cls_on(d, 7)) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(7), (const uint32_t *)(d.hv_cnt + 7), d.hv_max[1], RB, 0u);
-  if ((d.hv_max[2] > d.hv_max[1]) && cm_cls_on(d, 8)) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[2], s, d, lst(8), (const uint32_t *)(d.hv_cnt + 8), d.hv_max[2], RB, 0u);
-  if ((d.rs_max3 > d.hv_max[2]) && cm_cls_on(d, 11)) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[3], s, d, lst(11), (const uint32_t *)(d.hv_cnt + 11), d.rs_max3, RB, 0u);
-  if ((d.rs_big > d.rs_max3) && cm_cls_on(d, 26)) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[4], s, d, lst(26), (const uint32_t *)(d.hv_cnt + 26), d.rs_big, RB, 0u);
-  if (d.coop_slab && cm_cls_on(d, 15))  // lists beyond the largest class: on the blocks' slabs of global memory
-    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[4], s, d, lst(15), (const uint32_t *)(d.hv_cnt + 15), d.rs_big > d.rs_max3 ? d.rs_big : d.rs_max3, RB, 1u);
+  if (cm_cls_on(d, CM_L_RS_WAVE)) hipLaunchKernelGGL(k_s4b_coop<64>, dim3(blocks), dim3(128), lds[0], s, d, lst(CM_L_RS_WAVE), (const uint32_t *)(d.hv_cnt + CM_L_RS_WAVE), d.hv_max[0], RB, 0u);
+  if ((d.hv_max[1] > d.hv_max[0]) && cm_cls_on(d, CM_L_RS_B256A)) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[1], s, d, lst(CM_L_RS_B256A), (const uint32_t *)(d.hv_cnt + CM_L_RS_B256A), d.hv_max[1], RB, 0u);
+  if ((d.hv_max[2] > d.hv_max[1]) && cm_cls_on(d, CM_L_RS_B256B)) hipLaunchKernelGGL(k_s4b_coop<256>, dim3(blocks), dim3(256), lds[2], s, d, lst(CM_L_RS_B256B), (const uint32_t *)(d.hv_cnt + CM_L_RS_B256B), d.hv_max[2], RB, 0u);
+  if ((d.rs_max3 > d.hv_max[2]) && cm_cls_on(d, CM_L_RS_B512)) hipLaunchKernelGGL(k_s4b_coop<512>, dim3(blocks > 512 ? 512 : blocks), dim3(512), lds[3], s, d, lst(CM_L_RS_B512), (const uint32_t *)(d.hv_cnt + CM_L_RS_B512), d.rs_max3, RB, 0u);
+  if ((d.rs_big > d.rs_max3) && cm_cls_on(d, CM_L_RS_B1024)) hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(blocks > 256 ? 256 : blocks), dim3(1024), lds[4], s, d, lst(CM_L_RS_B1024), (const uint32_t *)(d.hv_cnt + CM_L_RS_B1024), d.rs_big, RB, 0u);
+  if (d.coop_slab && cm_cls_on(d, CM_L_RS_SLAB))  // lists beyond the largest class: on the blocks' slabs of global memory
+    hipLaunchKernelGGL(k_s4b_coop<1024>, dim3(d.coop_slab_blocks), dim3(1024), lds[4], s, d, lst(CM_L_RS_SLAB), (const uint32_t *)(d.hv_cnt + CM_L_RS_SLAB), d.rs_big > d.rs_max3 ? d.rs_big : d.rs_max3, RB, 1u);
 }
 // coop: the cmgpu_set_option "coop" bit mask (bit 2: pairs with long lists to groups; bit 3: the S5 waves sort the heavy reads' lists)
 void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t coop) {
@@ -1987,19 +1987,19 @@ void cm_launch_k_s4c_reduce(const CmDev &d, uint32_t n, hipStream_t s, uint32_t 
   uint32_t blocks = n / 2048 + 64;
   if (blocks > 4096) blocks = 4096;
   const size_t gs = ((cm_coop_pair_mem_bytes(CM_S4C_P_SMALL) + 15) & ~(size_t)15) + CM_XW_BYTES;
-  if (cm_cls_on(d, 27)) hipLaunchKernelGGL((k_s4c_coop<64, true>), dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gs, s, d, CM_S4C_P_SMALL, 27u, coop);  // a wave per pair
-  if (cm_cls_on(d, 9)) hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, 9u, coop);
-  if (cm_cls_on(d, 14)) hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, 14u, coop);
-  if (d2.s4c_pbig && cm_cls_on(d, 19))
+  if (cm_cls_on(d, CM_L_PF_WAVE)) hipLaunchKernelGGL((k_s4c_coop<64, true>), dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gs, s, d, CM_S4C_P_SMALL, CM_L_PF_WAVE, coop);  // a wave per pair
+  if (cm_cls_on(d, CM_L_PF_BLOCK)) hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(blocks), dim3(CM_BLOCK), gw, s, d, CM_S4C_P_WAVE, CM_L_PF_BLOCK, coop);
+  if (cm_cls_on(d, CM_L_PF_BLOCK_BIG)) hipLaunchKernelGGL((k_s4c_coop<CM_BLOCK, true>), dim3(256), dim3(CM_BLOCK), gbk, s, d, CM_S4C_P_BLOCK, CM_L_PF_BLOCK_BIG, coop);
+  if (d2.s4c_pbig && cm_cls_on(d, CM_L_PF_HUGE))
     hipLaunchKernelGGL((k_s4c_coop<1024, false>), dim3(128), dim3(1024), ((cm_coop_pair_mem_bytes(pbig, false) + 15) & ~(size_t)15) + CM_XW_BYTES, s, d, pbig, 19u, coop);
 }
 void cm_launch_k_s5a_prepare(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
   hipLaunchKernelGGL(k_s5a_prepare, grid_for(n), dim3(CM_BLOCK), 0, s, d, n, coop ? 1u : 0u);
   if (coop) {  // the lists it left unsorted: a wave per read
-    if (cm_cls_on(d, 28)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, 28u);
-    if (cm_cls_on(d, 12)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(2048), dim3(CM_BLOCK), 0, s, d, 12u);
-    if (cm_cls_on(d, 22)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(64), dim3(CM_BLOCK), 0, s, d, 22u);
+    if (cm_cls_on(d, CM_L_S5_SMALL)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(4096), dim3(CM_BLOCK), 0, s, d, CM_L_S5_SMALL);
+    if (cm_cls_on(d, CM_L_S5_WAVE)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(2048), dim3(CM_BLOCK), 0, s, d, CM_L_S5_WAVE);
+    if (cm_cls_on(d, CM_L_S5_BLOCK)) hipLaunchKernelGGL(k_s5_sort_coop, dim3(64), dim3(CM_BLOCK), 0, s, d, CM_L_S5_BLOCK);
   }
 }
 void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
@@ -2012,12 +2012,12 @@ void cm_launch_k_s5c_finalize(const CmDev &d, uint32_t n, hipStream_t s, bool co
   };
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  if (cm_cls_on(d, 28)) hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gbytes(CM_S5C_P_SMALL), s, d, CM_S5C_P_SMALL, 28u);
-  if (cm_cls_on(d, 12)) hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(192), 3 * gbytes(CM_S5C_P_WAVE), s, d, CM_S5C_P_WAVE, 12u);  // three waves per block: under the 64 KB a launch gets without asking
+  if (cm_cls_on(d, CM_L_S5_SMALL)) hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * gbytes(CM_S5C_P_SMALL), s, d, CM_S5C_P_SMALL, CM_L_S5_SMALL);
+  if (cm_cls_on(d, CM_L_S5_WAVE)) hipLaunchKernelGGL(k_s5c_coop<64>, dim3(blocks), dim3(192), 3 * gbytes(CM_S5C_P_WAVE), s, d, CM_S5C_P_WAVE, CM_L_S5_WAVE);  // three waves per block: under the 64 KB a launch gets without asking
   // the reads with a longer list: a block each (what even its work arrays cannot hold: lane 0's acceptance loop, the group's sort)
   uint32_t pb = CM_S5C_P_BLOCK;
   while (pb > CM_S5C_P_WAVE && !cm_lds_optin(&k_s5c_coop<CM_BLOCK>, gbytes(pb))) pb >>= 1;
-  if (cm_cls_on(d, 22)) hipLaunchKernelGGL(k_s5c_coop<CM_BLOCK>, dim3(128), dim3(CM_BLOCK), gbytes(pb), s, d, pb, 22u);
+  if (cm_cls_on(d, CM_L_S5_BLOCK)) hipLaunchKernelGGL(k_s5c_coop<CM_BLOCK>, dim3(128), dim3(CM_BLOCK), gbytes(pb), s, d, pb, CM_L_S5_BLOCK);
 }
 CM_LAUNCH(k_s6a_pair_sam)
 CM_LAUNCH(k_s6c_multi_sam)
@@ -2039,9 +2039,9 @@ void cm_launch_k_s6a_pair(const CmDev &d, uint32_t n, hipStream_t s, bool coop) 
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  if (cm_cls_on(d, 29)) hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 29u);
-  if (cm_cls_on(d, 13)) hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 13u);
-  if (cm_cls_on(d, 18)) hipLaunchKernelGGL(k_s6a_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 18u);
+  if (cm_cls_on(d, CM_L_S6A_SMALL)) hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, CM_L_S6A_SMALL);
+  if (cm_cls_on(d, CM_L_S6A_WAVE)) hipLaunchKernelGGL(k_s6a_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, CM_L_S6A_WAVE);
+  if (cm_cls_on(d, CM_L_S6A_BLOCK)) hipLaunchKernelGGL(k_s6a_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, CM_L_S6A_BLOCK);
 }
 void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop) {
   if (!n) return;
@@ -2051,9 +2051,9 @@ void cm_launch_k_s6c_multi(const CmDev &d, uint32_t n, hipStream_t s, bool coop)
   if (!coop) return;
   uint32_t blocks = n / 4096 + 64;
   if (blocks > 2048) blocks = 2048;
-  if (cm_cls_on(d, 30)) hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, 30u);
-  if (cm_cls_on(d, 17)) hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, 17u);
-  if (cm_cls_on(d, 20)) hipLaunchKernelGGL(k_s6c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, 20u);
+  if (cm_cls_on(d, CM_L_S6C_SMALL)) hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), (CM_BLOCK / 64) * cm_s6_group_bytes(CM_S6A_P_SMALL), s, d, CM_S6A_P_SMALL, CM_L_S6C_SMALL);
+  if (cm_cls_on(d, CM_L_S6C_WAVE)) hipLaunchKernelGGL(k_s6c_coop<64>, dim3(blocks), dim3(CM_BLOCK), lw, s, d, CM_S6A_P_WAVE, CM_L_S6C_WAVE);
+  if (cm_cls_on(d, CM_L_S6C_BLOCK)) hipLaunchKernelGGL(k_s6c_coop<CM_BLOCK>, dim3(256), dim3(CM_BLOCK), lb, s, d, CM_S6A_P_BLOCK, CM_L_S6C_BLOCK);
 }
 
 // threads per block / LDS bytes for the read-staging kernels, from the longest read of the batch

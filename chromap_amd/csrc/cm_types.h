@@ -25,7 +25,46 @@
 #define CM_PR_MULTI 2
 #define CM_V_INVALID 0x7fff
 #define CM_MM_CHUNKS 8            // chunks of a batch whose index probe overlaps the next chunk's minimizer pass
-#define CM_HV_LISTS 32           // device work lists of hv_stride entries each: 0-4 and 10 hit-list classes, 5 reads the merge-sort kernel declined, 6-8 and 11 rescue classes, 9 / 14 pairs for the filter (lists up to 1024 / 4096 entries), 12 reads / 13 pairs of the later stages, 15 rescue lists / 16 declined hit lists beyond the largest class, 17 multi-mapped pairs, 18 / 20 pairs / multi-mapped pairs for a block each, 19 pairs for the filter with lists beyond 4096 entries, 23 reads whose rescue searches a wave runs / 31 those of them that need the full tables
+// Device work lists (CmDev::hv_list + id * hv_stride, their lengths at hv_cnt[id]): the reads / pairs whose lists are too long for the
+// one-lane-per-item kernel of a stage, by stage and size class.  P: entries of the class's shared work area; LDS: bytes per block.
+//   id  name                  items                                  kernel (lanes per item)             P / LDS per block
+//    0  CM_L_HIT_WAVE         reads, hits <= hv_max[0] (512)         k_s3b_coop<64> (two reads a block)   512 / 2 x 6 KB (32-bit keys; 10 KB with 64-bit keys)
+//   21  CM_L_HIT_WAVE_SMALL   reads, hits <= hv_sub (256)            k_s3b_coop<64> (four reads a block)  256 / 4 x 3 KB
+//    4  CM_L_HIT_G16          reads, hits <= hv_mid (64)             k_s3b_heavy<16> (16 lanes, bitonic)  64 / 10 B per slot
+//    1  CM_L_HIT_B256A        reads, hits <= hv_max[1] (1024)        k_s3b_coop<256>                      1024 / 12 KB
+//    2  CM_L_HIT_B256B        reads, hits <= hv_max[2] (2048)        k_s3b_coop<256>                      2048 / 23 KB
+//   10  CM_L_HIT_B512         reads, hits <= hv_max[3] (4096)        k_s3b_coop<512>                      4096 / 46 KB
+//   25  CM_L_HIT_B1024        reads, hits <= hv_big (8192)           k_s3b_coop<1024>                     8192 / 91 KB
+//    3  CM_L_HIT_SLAB         reads with more hits                   k_s3b_coop<1024, false>, use_slab    global slab (19 B per hit)
+//    5  CM_L_HIT_DECLINED     reads k_s3b_coop declined              k_s3b_heavy<CM_BLOCK> (bitonic)      pow2(hv_big) x 10 B
+//   16  CM_L_HIT_SERIAL       reads the slab launch declined         k_s3b_serial (a lane)                --
+//   23  CM_L_SEARCH_WAVE      reads whose mate has >= 24 candidates  k_s4a/4b_rescue_wave<true> (64)      64 windows / 4.9 KB
+//   31  CM_L_SEARCH_WAVE_BIG  ... with more than 64 best candidates  k_s4a/4b_rescue_wave<false> (64)     304 windows / 11 KB
+//    6  CM_L_RS_WAVE          reads, rescue hits <= hv_max[0]        k_s4b_coop<64> (two reads a block)   512 / 2 x 11 KB
+//  7/8  CM_L_RS_B256A / B     reads, rescue hits <= hv_max[1] / [2]  k_s4b_coop<256>                      1024 / 21 KB, 2048 / 41 KB
+//   11  CM_L_RS_B512          reads, rescue hits <= rs_max3 (3968)   k_s4b_coop<512>                      3968 / 79 KB
+//   26  CM_L_RS_B1024         reads, rescue hits <= rs_big (7680)    k_s4b_coop<1024>                     7680 / 153 KB
+//   15  CM_L_RS_SLAB          reads with more rescue hits            k_s4b_coop<1024>, use_slab           global slab
+//   27  CM_L_PF_WAVE          pairs, candidate lists <= 256          k_s4c_coop<64, true>                 CM_S4C_P_SMALL
+//    9  CM_L_PF_BLOCK         pairs, lists <= 1024                   k_s4c_coop<256, true>                CM_S4C_P_WAVE
+//   14  CM_L_PF_BLOCK_BIG     pairs, lists <= 4096                   k_s4c_coop<256, true>                CM_S4C_P_BLOCK
+//   19  CM_L_PF_HUGE          pairs, lists <= s4c_pbig (15360)       k_s4c_coop<1024, false>              lists stay in global memory, 10 B per entry
+//   28  CM_L_S5_SMALL         reads, candidates <= CM_S5C_P_SMALL    k_s5_sort_coop, k_s5c_coop<64>       a quarter of the wave class's arrays
+//   12  CM_L_S5_WAVE          reads, candidates <= CM_S5C_P_WAVE     k_s5_sort_coop, k_s5c_coop<64>       CM_S5C_P_WAVE
+//   22  CM_L_S5_BLOCK         reads with more candidates             k_s5_sort_coop, k_s5c_coop<256>      16384
+//   29  CM_L_S6A_SMALL        pairs, draft mappings <= 256           k_s6a_coop<64>                       CM_S6A_P_SMALL
+//   13  CM_L_S6A_WAVE         pairs, draft mappings <= 1024          k_s6a_coop<64>                       CM_S6A_P_WAVE
+//   18  CM_L_S6A_BLOCK        pairs with more                        k_s6a_coop<256>                      CM_S6A_P_BLOCK
+//   30 / 17 / 20  CM_L_S6C_SMALL / WAVE / BLOCK   multi-mapped pairs, the same classes   k_s6c_coop<64> / <64> / <256>
+// (24: free.)  A class's kernels are launched when the class had items lately (CmDev::cls_mask, cm_kernels.hip).
+enum CmList : uint32_t {
+  CM_L_HIT_WAVE = 0, CM_L_HIT_B256A = 1, CM_L_HIT_B256B = 2, CM_L_HIT_SLAB = 3, CM_L_HIT_G16 = 4, CM_L_HIT_DECLINED = 5, CM_L_RS_WAVE = 6, CM_L_RS_B256A = 7,
+  CM_L_RS_B256B = 8, CM_L_PF_BLOCK = 9, CM_L_HIT_B512 = 10, CM_L_RS_B512 = 11, CM_L_S5_WAVE = 12, CM_L_S6A_WAVE = 13, CM_L_PF_BLOCK_BIG = 14, CM_L_RS_SLAB = 15,
+  CM_L_HIT_SERIAL = 16, CM_L_S6C_WAVE = 17, CM_L_S6A_BLOCK = 18, CM_L_PF_HUGE = 19, CM_L_S6C_BLOCK = 20, CM_L_HIT_WAVE_SMALL = 21, CM_L_S5_BLOCK = 22,
+  CM_L_SEARCH_WAVE = 23, CM_L_HIT_B1024 = 25, CM_L_RS_B1024 = 26, CM_L_PF_WAVE = 27, CM_L_S5_SMALL = 28, CM_L_S6A_SMALL = 29, CM_L_S6C_SMALL = 30,
+  CM_L_SEARCH_WAVE_BIG = 31
+};
+#define CM_HV_LISTS 32
 #define CM_RS_SEGS 64           // rescue list segments (one counter each, on its own cache line)
 #define CM_MAX_BEST 64          // upper bound on max_num_best_mappings (-n)
 #define CM_SORT_SERIAL_MAX 24   // cm_sort_cand / cm_sort_draft: insertion sort up to here, heap sort beyond

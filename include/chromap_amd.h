@@ -78,7 +78,7 @@ typedef struct cmgpu_params {
   int32_t low_memory_mode;        /* used by cmgpu_write_bed_pe only */
   int32_t read_batch_size;        /* Chromap::read_batch_size_ = 500000 (chromap.h:182) */
   int32_t taskloop_grain_size;    /* 5000 (chromap.h:887): scope of the reservoir RNG */
-  int32_t bc_error_threshold;     /* --bc-error-threshold (0 or 1 supported on the device) */
+  int32_t bc_error_threshold;     /* --bc-error-threshold (0, 1 or 2 on the device) */
   int32_t output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
   int32_t output_format;          /* 0: BED / pairs records; CMGPU_FORMAT_SAM: --SAM (alignment coordinates, CIGAR, NM, MD) */
   int32_t dedup_at_bulk_level;    /* single-cell BED, low-memory flavour: --remove-pcr-duplicates-at-bulk-level (the reference's
