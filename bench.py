@@ -283,7 +283,10 @@ def roofline(g, args, s, steps, stage_ms):
             "traffic": traffic,
             "traffic_source": "from_profile: profiles/probe_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, "
                               "tools/profile_bench.sh), not measured in this run",
-            "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "algorithmic_bytes_cover": "16 B per bucket kh_get visits; the occurrence bytes of SURVEY 8(d) (8 B x occurrences) are read by the candidate "
+                                       "stage (S3b: k_s3b_*), not by k_probe, and are not in this figure",
+            "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
             "probe_on_file_layout": file_layout,
             "table_note": "the graded launch probes the device's re-hashed copy of the table (cmgpu_set_option probe_table_shift = %d: %d buckets; same "
                           "keys, values, hash and probe sequence, so hit / miss / value of every lookup are the file table's -- asserted here -- and "
@@ -344,6 +347,10 @@ def main():
     ap.add_argument("--probe-table-shift", type=int, default=1,
                     help="the pipeline probes a device copy of the index table re-hashed into 2^shift times as many buckets (same keys, values, "
                          "hash and probe sequence: identical lookups, fewer buckets visited); 0: the file's table")
+    ap.add_argument("--exchange-lanes", type=int, default=1, help="lanes of a rank that exchanges records (see make_ctx)")
+    ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_PAIRS",
+                    help="strong scaling: TOTAL_PAIRS read pairs per step over ALL ranks (each maps TOTAL_PAIRS / gpus), e.g. "
+                         "--strong 100000000 --steps 1 for BASELINE config 3's fixed 100 M pairs at 1/2/4/8 GPUs; the JSON line then says scaling: strong")
     ap.add_argument("--option", action="append", default=[], help="name=value for cmgpu_set_option (measurement knobs)")
     args = ap.parse_args()
 
@@ -362,6 +369,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (chromap_amd has no CPU path)")
+    if args.strong:
+        if args.strong % world or args.strong // world > 48_000_000:
+            raise SystemExit("--strong: TOTAL_PAIRS must divide by the number of GPUs and leave at most 48 M pairs per GPU and step")
+        args.pairs = args.strong // world
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
@@ -391,7 +402,7 @@ def main():
                         **({"output_format": 1} if args.sam else {}))
         # lanes and the record exchange do not mix well on one GPU (measured: 3 lanes 429 -> 366 M pairs/s with the exchange,
         # 1 lane 404 -> 388): ranks that exchange map their batch in one piece
-        g_.set_option("lanes", 1 if exchange else args.lanes)
+        g_.set_option("lanes", args.exchange_lanes if exchange else args.lanes)
         if args.probe_table_shift != 1:  # (1 is the library's own default: cmgpu_create* re-hash the table into twice the buckets)
             g_.set_option("probe_table_shift", args.probe_table_shift)
         for o in args.option:
@@ -569,7 +580,7 @@ def main():
     out = {
         "metric": "M paired reads mapped/s (ATAC preset, GRCh38 index)",
         "value": round(value, 4), "unit": "M pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "--preset %s, synthetic 2x%d bp pairs (fragments %d-%d bp, 1%% substitutions%s), "
                                "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7%s) resident per GPU, "
@@ -577,7 +588,7 @@ def main():
                                % (args.preset, args.readlen, args.frag_min, args.frag_max,
                                   ", %.2f%% 1-base indels" % (args.indel_rate * 100) if args.indel_rate else "", args.genome, args.nseq,
                                   ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS, args.pairs * N_SLOTS / 1e6),
-                   "pairs_per_gpu_per_step": args.pairs, "lanes": 1 if exchange else args.lanes,
+                   "pairs_per_gpu_per_step": args.pairs, "lanes": args.exchange_lanes if exchange else args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
         "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "harsh2_repeat_workload": harsh2_out, "hic_workload": hic_out, "postprocess_on_device": post, "pcie_inclusive": pcie,

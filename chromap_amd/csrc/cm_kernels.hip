@@ -92,7 +92,10 @@ __global__ void k_mm_fill(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
 // block per CU to a VALU-bound kernel; the tile is copied out by OUTPUT position (which read a dense slot belongs to is a
 // search in the block's 256 offsets), so the dense arrays are written in whole lines too.  Before, such reads were hashed
 // twice (k_prep_count, k_mm_fill) around a scan and two host waits.
-template <bool GSTAGE>
+// E6 (shared-memory staging only): an emission is staged as 32 + 16 bits (hash | position-strand << 2k fits 48 bits for k <= 20 and
+// reads of up to 127 bases) -- 24 instead of 32 KB of emissions per block of 256 lanes: four blocks per CU instead of three for this
+// VALU-bound kernel (three Hash64 per base are the reference's own: the minimizer hash is the hash of the smaller strand's hash)
+template <bool GSTAGE, bool E6>
 __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of this launch's pair range */, uint32_t lds_half, uint32_t stg,
                           uint32_t mm_cap, unsigned long long *cursor, uint64_t *gstage) {
   const uint32_t T = blockDim.x, PB = T >> 1;
@@ -102,7 +105,9 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
   if (t < PB && pair < p1) cm_s0_prep_ptr(d, pair, s.m0, s.m1);
   __syncthreads();
   uint64_t *sh_e = GSTAGE ? gstage + (size_t)blockIdx.x * stg * T : reinterpret_cast<uint64_t *>(cm_lds + 2 * lds_half);
-  uint32_t *sh_w = reinterpret_cast<uint32_t *>(cm_lds + 2 * lds_half + (GSTAGE ? 0 : (size_t)stg * T * 8));  // wave totals [8], base lo/hi [2]
+  uint32_t *sh_lo = reinterpret_cast<uint32_t *>(cm_lds + 2 * lds_half);  // E6: the emissions' low words, then their bits 32-47
+  uint16_t *sh_hi = reinterpret_cast<uint16_t *>(sh_lo + (size_t)stg * T);
+  uint32_t *sh_w = reinterpret_cast<uint32_t *>(cm_lds + 2 * lds_half + (GSTAGE ? 0 : (size_t)stg * T * (E6 ? 6 : 8)));  // wave totals [8], base lo/hi [2]
   uint32_t *sh_off = sh_w + 16, *sh_cnt = sh_off + T + 1;  // GSTAGE: the reads' offsets in the block's range [T + 1], their counts [T]
   const bool valid = pair < p1;
   const uint32_t r = 2 * pair + (t < PB ? 0 : 1);
@@ -113,7 +118,8 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
   if (valid) {
     len = d.rlen[r];
     cnt = cm_minimizers_w7(seq, len, k, [&](uint32_t n, uint64_t h, uint32_t p) {
-      if (n < stg) sh_e[(size_t)n * T + t] = h | ((uint64_t)p << hb);
+      const uint64_t v = h | ((uint64_t)p << hb);
+      if (n < stg) { if (E6) { sh_lo[(size_t)n * T + t] = (uint32_t)v; sh_hi[(size_t)n * T + t] = (uint16_t)(v >> 32); } else sh_e[(size_t)n * T + t] = v; }
     });
   }
   // block exclusive scan of cnt
@@ -169,7 +175,7 @@ __global__ void k_prep_mm(CmDev d, uint32_t pair_lo, uint32_t n_pairs /* end of 
   const uint32_t off = (uint32_t)off64;
   if (cnt <= stg) {
     for (uint32_t e = 0; e < cnt; ++e) {
-      const uint64_t v = sh_e[(size_t)e * T + t];
+      const uint64_t v = E6 ? ((uint64_t)sh_lo[(size_t)e * T + t] | ((uint64_t)sh_hi[(size_t)e * T + t] << 32)) : sh_e[(size_t)e * T + t];
       d.mm_hash[off + e] = v & hmask;
       d.mm_ps[off + e] = (uint32_t)(v >> hb);
     }
@@ -2067,15 +2073,17 @@ static inline void staging_geometry(uint32_t max_read_len, uint32_t *threads, ui
 // configuration needs the two-pass kernels: other k / w, or reads longer than 69 bases -- their emissions
 // would leave room for 128 or 64 lanes per block only, and at that occupancy the two-pass kernels are
 // as fast (2 x 100) or faster (2 x 150: 10.7 ms against 12.7 ms for 2 M pairs)
-static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *threads, uint32_t *half, uint32_t *stg, size_t *lds, bool *gstage = nullptr) {
+static bool prep_mm_geometry(const CmDev &d, uint32_t max_read_len, uint32_t *threads, uint32_t *half, uint32_t *stg, size_t *lds, bool *gstage = nullptr, bool *e6_out = nullptr) {
   if (d.p.w != 7 || 2 * d.p.k + 12 > 64) return false;
   *stg = max_read_len / 4 + 4;
   const bool g = max_read_len > 69;  // the emissions staged in global memory (k_prep_mm<true>)
+  const bool e6 = !g && 2 * d.p.k + 8 <= 48;  // (position << 1 | strand of a read of up to 69 bases: 8 bits)
   if (gstage) *gstage = g;
+  if (e6_out) *e6_out = e6;
   uint32_t t = 256;
   for (;; t >>= 1) {
     *half = (uint32_t)(((uint64_t)(t / 2) * max_read_len + 64 + 15) & ~15ull);
-    *lds = 2 * (size_t)*half + (g ? (size_t)(2 * t + 1) * 4 : (size_t)*stg * t * 8) + 64;
+    *lds = 2 * (size_t)*half + (g ? (size_t)(2 * t + 1) * 4 : (size_t)*stg * t * (e6 ? 6 : 8)) + 64;
     if (*lds <= (g ? 48 : 60) * 1024) break;
     if (t == 64) return false;
   }
@@ -2130,11 +2138,12 @@ void cm_launch_k_prep_mm(const CmDev &d, uint32_t pair_lo, uint32_t pair_hi, uin
                          unsigned long long *cursor, hipStream_t s, void *gstage) {
   uint32_t threads, half, stg;
   size_t lds;
-  bool g = false;
-  if (pair_hi <= pair_lo || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds, &g)) return;
+  bool g = false, e6 = false;
+  if (pair_hi <= pair_lo || !prep_mm_geometry(d, max_read_len, &threads, &half, &stg, &lds, &g, &e6)) return;
   const uint32_t pb = threads / 2;
-  if (g) hipLaunchKernelGGL(k_prep_mm<true>, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)gstage);
-  else hipLaunchKernelGGL(k_prep_mm<false>, dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)nullptr);
+  if (g) hipLaunchKernelGGL((k_prep_mm<true, false>), dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)gstage);
+  else if (e6) hipLaunchKernelGGL((k_prep_mm<false, true>), dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)nullptr);
+  else hipLaunchKernelGGL((k_prep_mm<false, false>), dim3((pair_hi - pair_lo + pb - 1) / pb), dim3(threads), lds, s, d, pair_lo, pair_hi, half, stg, mm_cap, cursor, (uint64_t *)nullptr);
 }
 // probe of the minimizers [range[0], range[1]) (device-side range), at most max_entries of them
 static inline int probe_variant_norm(int variant) {
