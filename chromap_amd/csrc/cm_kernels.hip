@@ -733,7 +733,8 @@ __device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint
 // A read whose mate has CM_RS_WAVE candidates or more on a strand: a WAVE per read (cm_coop_rescue: the windows of the mate's best
 // candidates once per direction, a lane per (minimizer, window) pair for the bounds, the search chain replayed on indices) -- with a
 // lane per minimizer a search over ~300 windows took ~8 ms, the duration of the whole list kernel on the mosaic genome.
-#define CM_RS_WAVE 24u
+#define CM_RS_WAVE 4u  // (round 5: 24 -> 4.  The wave's searches leave their hits in the pool, so its fill pass copies where the list kernels' lanes and
+                       //  16-lane groups search a second time: profile 1 51.2 -> 53.1, repeat workload 145.8 -> 148.9 M pairs/s; 8 and 4 measure alike)
 __device__ __forceinline__ bool cm_rescue_is_wave(const CmDev &d, uint32_t r, uint32_t coop) {
   const uint32_t o = r ^ 1u;
   return coop && (d.ncp[o] >= CM_RS_WAVE || d.ncn[o] >= CM_RS_WAVE);
