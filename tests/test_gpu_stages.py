@@ -93,6 +93,24 @@ def test_stage_trace_fuzz(cfg, prep_kernel, tmp_path):
     o.close()
 
 
+@pytest.mark.parametrize("cfg", fuzz_data.CONFIGS[:2], ids=[str(c[0]) for c in fuzz_data.CONFIGS[:2]])
+def test_stage_trace_fuzz_64_bit_hit_keys(cfg, tmp_path, monkeypatch):
+    """the cooperative hit-list stage on the reference's 64-bit keys (a reference too long for 32-bit global coordinates gets these;
+    CM_NO_KEY32 asks for them on any reference)"""
+    from chromap_amd import ChromapGPU
+    from test_hostemu_fuzz import CAPI_NAMES
+    monkeypatch.setenv("CM_NO_KEY32", "1")
+    seed, preset, kw, gen = cfg
+    fa, b1, o1, b2, o2 = fuzz_data.write_case(str(tmp_path), seed, **gen)
+    o = ol.Oracle(None, fa, ol.params(preset, **kw))
+    idx = str(tmp_path / "f.idx")
+    assert o.L.ora_index_save(idx.encode(), C.byref(o.idx)) == 0
+    g = ChromapGPU(idx, fa, preset=preset, **{CAPI_NAMES.get(k, k): v for k, v in kw.items()})
+    _check(g, o, b1, o1, b2, o2, 17, "fuzz %s, 64-bit keys" % seed)
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("tile", [8, 32, 128])
 def test_position_parallel_minimizers_tile_sizes(tile):
     """k_prep_flat with other tile geometries (reads per tile) on reads of mixed lengths incl. adapter-trimmed ones"""

@@ -77,6 +77,27 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
         assert declined > 0, "the decline path was not taken"
 
 
+def test_hit_lists_on_64_bit_keys(tmp_path):
+    """the cooperative hit-list stage with the reference's 64-bit keys (what a reference beyond 32-bit global coordinates gets;
+    every other case here runs on 32-bit keys, as the device does when the reference fits)"""
+    L = he.lib()
+    cfg, geo = _small(fuzz_data.CONFIGS[1]), GEOMETRIES[0]
+
+    def factory(idx, fa, preset, gkw, b1, o1, b2, o2):
+        L.hostemu_set_coop_key32(0)
+        try:
+            h = he.HostEmu(idx, fa, he.params(preset, **gkw))
+            _set(L, *geo)
+            rec, k, st, _ = h.map_pairs(b1, o1, b2, o2)
+            factory.items = _items(L)
+        finally:
+            L.hostemu_set_coop_key32(1)
+            _set(L, 0, 0, 0, 0, 0, 0, 0)
+        return rec, k, st.as_dict()
+    run_case(factory, cfg, tmp_path)
+    assert factory.items[0] > 0
+
+
 def test_rescue_searches_with_small_and_full_tables(tmp_path):
     """the rescue searches' two table sizes (k_s4a/4b_rescue_wave<true / false>): small tables made tiny, so that searches take
     several rounds in them and others are handed to the full tables"""
