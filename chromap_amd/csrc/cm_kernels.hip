@@ -1820,6 +1820,7 @@ void cm_launch_k_s3b_heavy(const CmDev &d, const uint32_t *n_cls, hipStream_t s,
     uint32_t *fb_list = d.hv_list + CM_L_HIT_DECLINED * (size_t)d.hv_stride, *fb_cnt = d.hv_cnt + CM_L_HIT_DECLINED;
     bool any_coop = false;
     const bool k32 = d.goff != nullptr;  // (the reference fits 32-bit hit keys: every class's work area shrinks from 19 to 11 bytes per hit)
+    // (a block per read: blocks that stride over the list -- 2048 / 8192 of them -- were measured 3-17 % slower, the reads differ too much in size)
 #define CM_S3B_LAUNCH(G_, GRID_, BLOCK_, LDS_, ...)                                                                         \
     do { if (k32) hipLaunchKernelGGL((k_s3b_coop<G_, true>), GRID_, BLOCK_, LDS_, s, __VA_ARGS__);                          \
          else hipLaunchKernelGGL((k_s3b_coop<G_, false>), GRID_, BLOCK_, LDS_, s, __VA_ARGS__); } while (0)
