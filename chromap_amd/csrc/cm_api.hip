@@ -15,6 +15,7 @@
 #include "cm_kernels.h"
 #include "cm_coop.h"
 #include <chrono>
+#include <mutex>
 #include "cm_mapq_tables.h"
 
 static thread_local std::string g_last_error;  // errors without a ctx (creation), per calling thread
@@ -29,6 +30,8 @@ static thread_local std::string g_last_error;  // errors without a ctx (creation
   } while (0)
 
 void cm_set_error(cmgpu_ctx *ctx, const std::string &msg) {
+  static std::mutex mu;  // (the scans of a batch's files may fail side by side)
+  std::lock_guard<std::mutex> lk(mu);
   if (ctx) ctx->err = msg;
   g_last_error = msg;
 }
@@ -454,6 +457,7 @@ extern "C" int cmgpu_destroy(cmgpu_ctx *c) {
   (void)hipDeviceSynchronize();
   cm_exchange_release(c);
   for (DevBuf *b : c->all_bufs()) b->release();
+  for (CmFqStream &f : c->fq) if (f.hs) (void)hipStreamDestroy(f.hs);
   for (int i = 0; i < CM_MAX_EVENTS; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (hipEvent_t e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
   if (c->h_maxlen) (void)hipHostFree(c->h_maxlen);
@@ -1010,7 +1014,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     // (a range that ran out of pool undercounts what it would have used -- the pieces behind the refusal are only estimated -- and
     // growing the pool is a hipFree + hipMalloc of gigabytes, 0.3-0.5 s: grow once, generously)
     if (c->rs_pool_want > c->rs_pool_cap) want = 2 * c->rs_pool_want + (uint64_t)8192 * CM_POOL_GRANT / 2;
-    if (want < (1u << 26)) want = 1u << 26;  // (512 MB to begin with: growing costs a hipFree + hipMalloc in the middle of a run)
+    if (want < (1u << 24)) want = 1u << 24;  // (128 MB to begin with: growing costs a hipFree + hipMalloc in the middle of a run)
     if (want > 0xfffffff0ull) want = 0xfffffff0ull;
     const auto dbg_t0 = std::chrono::steady_clock::now();
     if (c->rs_pool.ensure((size_t)want * 8) == 0 && c->rs_pool_off.ensure((size_t)n2 * 2 * 4 + 16) == 0) c->rs_pool_cap = (uint32_t)(c->rs_pool.cap / 8 > 0xfffffff0ull ? 0xfffffff0ull : c->rs_pool.cap / 8);

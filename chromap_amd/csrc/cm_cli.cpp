@@ -748,17 +748,33 @@ int main(int argc, char **argv) {
         t0 = now_s();
         cmgpu_ctx *cx = ctxs[turn];
         auto ckx = [&](int rc) { if (rc != CMGPU_OK) die(cmgpu_last_error(cx)); };
+        const bool dbg_times = getenv("CM_CLI_TIMES") != nullptr;
+        const double ts0 = now_s();
+        // the files' scans (upload, inflate, line index, record checks) run side by side: a host thread and a HIP stream per file
+        int src[3] = {CMGPU_OK, CMGPU_OK, CMGPU_OK};
+        {
+          std::thread th[3];
+          auto scan = [&](int m) {
+            const bool dev = rd[m].bgzf && rd[m].dev_inflate;
+            const bool fin = dev ? rd[m].dev_final() : rd[m].eof;
+            src[m] = dev ? cmgpu_fastq_scan_bgzf(cx, sid[m], rd[m].zdata(), rd[m].zready, fin, &cnt[m])
+                         : cmgpu_fastq_scan(cx, sid[m], rd[m].text(), rd[m].len, rd[m].eof, &cnt[m]);
+          };
+          for (int m = 1; m < ns_streams; ++m) th[m] = std::thread(scan, m);
+          scan(0);
+          for (int m = 1; m < ns_streams; ++m) th[m].join();
+        }
         for (int m = 0; m < ns_streams; ++m) {
           const bool dev = rd[m].bgzf && rd[m].dev_inflate;
           const bool fin = dev ? rd[m].dev_final() : rd[m].eof;
           all_final = all_final && fin;
-          const int rc = dev ? cmgpu_fastq_scan_bgzf(cx, sid[m], rd[m].zdata(), rd[m].zready, fin, &cnt[m])
-                             : cmgpu_fastq_scan(cx, sid[m], rd[m].text(), rd[m].len, rd[m].eof, &cnt[m]);
+          const int rc = src[m];
           if (rc == CMGPU_EFORMAT && dev && strstr(cmgpu_last_error(cx), "BGZF"))
             die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + cmgpu_last_error(cx) + ")");
           if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(cx)) + " -- rerun with --host-ingest");
           ckx(rc);
         }
+        const double ts1 = now_s();
         uint32_t n = cnt[0];
         for (int m = 1; m < ns_streams; ++m) n = cnt[m] < n ? cnt[m] : n;
         if (n > a.batch_pairs) n = a.batch_pairs;
@@ -786,13 +802,17 @@ int main(int argc, char **argv) {
         }
         ckx(cmgpu_fastq_commit(cx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));
         t_parse += now_s() - t0;
+        if (dbg_times) fprintf(stderr, "[times] scan %.4f take+commit %.4f\n", ts1 - ts0, now_s() - ts1);
         t0 = now_s();
         {
           const size_t gi = turn;
           workers[gi] = std::thread([&, gi, cx]() {
             uint64_t k = 0;
+            const double tm0 = now_s();
             int rc = cmgpu_map_resident(cx, &k, &wst[gi]);
+            const double tm1 = now_s();
             if (rc == CMGPU_OK && !exchange) rc = cmgpu_store_append_resident(cx, nullptr);
+            if (getenv("CM_CLI_TIMES")) fprintf(stderr, "[times] map %.4f store_append %.4f\n", tm1 - tm0, now_s() - tm1);
             wrc[gi] = rc;
           });
           busy[gi] = 1;

@@ -25,6 +25,8 @@ struct DevBuf {
 // one FASTQ text stream being parsed on the device (cm_ingest.hip)
 struct CmFqStream {
   DevBuf text, cnt, off, nl, keep, pos, recidx, len, bad;
+  DevBuf scan_tmp;            // scratch of this stream's prefix sums (the files' scans may run side by side, each on its own HIP stream)
+  hipStream_t hs = nullptr;   // created on first use (fq_hs, cm_ingest.hip), destroyed with the context
   DevBuf text2, comp, btab, toks, ntok;  // BGZF inflated on the device: second text buffer (the retained rest moves through it), compressed blocks,
                                          // their table, the match tokens of the first pass and their number per block
   bool dev_mode = false;      // the text lives on the device between calls (cmgpu_fastq_scan_bgzf)
@@ -199,7 +201,7 @@ struct cmgpu_ctx {
 
   std::vector<DevBuf *> all_bufs() {
     std::vector<DevBuf *> v = core_bufs();
-    for (CmFqStream &f : fq) for (DevBuf *b : {&f.text, &f.cnt, &f.off, &f.nl, &f.keep, &f.pos, &f.recidx, &f.len, &f.bad, &f.text2, &f.comp, &f.btab, &f.toks, &f.ntok}) v.push_back(b);
+    for (CmFqStream &f : fq) for (DevBuf *b : {&f.text, &f.cnt, &f.off, &f.nl, &f.keep, &f.pos, &f.recidx, &f.len, &f.bad, &f.text2, &f.comp, &f.btab, &f.toks, &f.ntok, &f.scan_tmp}) v.push_back(b);
     for (CmBatchSlot &sl : slots) for (DevBuf *b : {&sl.rb0, &sl.rb1, &sl.ro0, &sl.ro1}) v.push_back(b);
     return v;
   }

@@ -152,6 +152,12 @@ struct FqMaxOp {
 
 // the scan of n_bytes of text resident in f.text (last_char: its last byte): lines, records, markers
 static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int final_chunk, char last_char, uint32_t *n_records);
+// the HIP stream a FASTQ stream's scan runs on: one each, so that a host thread per file scans read 1, read 2 and the barcodes side by
+// side (cmgpu_fastq_scan / _scan_bgzf of DIFFERENT streams of one context may be called concurrently; every call ends synchronised)
+static hipStream_t fq_hs(cmgpu_ctx *c, CmFqStream &f) {
+  if (!f.hs && hipStreamCreateWithFlags(&f.hs, hipStreamNonBlocking) != hipSuccess) { f.hs = nullptr; (void)hipGetLastError(); return c->stream; }
+  return f.hs;
+}
 
 extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint64_t n_bytes, int final_chunk, uint32_t *n_records) {
   if (!c || stream < 0 || stream > 2 || (!text && n_bytes) || !n_records) return CMGPU_EINVAL;
@@ -163,19 +169,19 @@ extern "C" int cmgpu_fastq_scan(cmgpu_ctx *c, int stream, const char *text, uint
   f.n_bytes = n_bytes; f.n_nl = 0; f.n_raw = 0; f.n_rec = 0; f.final_chunk = final_chunk != 0;
   if (n_bytes == 0) return CMGPU_OK;
   if (f.text.ensure(n_bytes + 32)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
-  FQCHECK(c, hipMemcpyAsync(f.text.p, text, n_bytes, hipMemcpyHostToDevice, c->stream));
+  FQCHECK(c, hipMemcpyAsync(f.text.p, text, n_bytes, hipMemcpyHostToDevice, fq_hs(c, f)));
   return fq_scan_resident(c, stream, n_bytes, final_chunk, text[n_bytes - 1], n_records);
 }
 
 static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int final_chunk, char last_char, uint32_t *n_records) {
   CmFqStream &f = c->fq[stream];
-  hipStream_t s = c->stream;
+  hipStream_t s = fq_hs(c, f);
   const uint32_t n_thr = (uint32_t)((n_bytes + 15) / 16);
   if (f.cnt.ensure(((size_t)n_thr + 1) * 4) || f.off.ensure(((size_t)n_thr + 1) * 4) ||
-      c->scan_tmp.ensure(cm_scan_tmp_words(n_thr) * 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
+      f.scan_tmp.ensure(cm_scan_tmp_words(n_thr) * 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
   const dim3 g((n_thr + FQ_BLOCK - 1) / FQ_BLOCK), b(FQ_BLOCK);
   hipLaunchKernelGGL(k_fq_count, g, b, 0, s, (const uint8_t *)f.text.p, n_bytes, n_thr, (uint32_t *)f.cnt.p);
-  cm_scan_u32((const uint32_t *)f.cnt.p, (uint32_t *)f.off.p, n_thr, (uint32_t *)c->scan_tmp.p, s);
+  cm_scan_u32((const uint32_t *)f.cnt.p, (uint32_t *)f.off.p, n_thr, (uint32_t *)f.scan_tmp.p, s);
   uint32_t n_nl = 0;
   FQCHECK(c, hipMemcpyAsync(&n_nl, (uint32_t *)f.off.p + n_thr, 4, hipMemcpyDeviceToHost, s));
   FQCHECK(c, cm_stream_sync(s));
@@ -185,7 +191,8 @@ static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int fina
   // (also an empty, unterminated quality line of the very last record: three lines seen)
   if (final_chunk && (last_char != '\n' || n_nl % 4 == 3)) {
     const uint32_t endpos = (uint32_t)n_bytes;
-    FQCHECK(c, hipMemcpy((uint32_t *)f.nl.p + n_nl, &endpos, 4, hipMemcpyHostToDevice));
+    FQCHECK(c, hipMemcpyAsync((uint32_t *)f.nl.p + n_nl, &endpos, 4, hipMemcpyHostToDevice, s));
+    FQCHECK(c, cm_stream_sync(s));
     ++n_nl;
   }
   f.n_nl = n_nl;
@@ -193,13 +200,13 @@ static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int fina
   f.n_raw = n_raw;
   if (n_raw == 0) return CMGPU_OK;
   if (f.keep.ensure(((size_t)n_raw + 1) * 4) || f.pos.ensure(((size_t)n_raw + 1) * 4) || f.recidx.ensure((size_t)n_raw * 4) || f.bad.ensure(4) ||
-      c->scan_tmp.ensure(cm_scan_tmp_words(n_raw) * 4)) { cm_set_error(c, "out of device memory (FASTQ records)"); return CMGPU_ENOMEM; }
+      f.scan_tmp.ensure(cm_scan_tmp_words(n_raw) * 4)) { cm_set_error(c, "out of device memory (FASTQ records)"); return CMGPU_ENOMEM; }
   const uint32_t none = 0xffffffffu;
   FQCHECK(c, hipMemcpyAsync(f.bad.p, &none, 4, hipMemcpyHostToDevice, s));
   const dim3 gr((n_raw + FQ_BLOCK - 1) / FQ_BLOCK);
   hipLaunchKernelGGL(k_fq_records, gr, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, n_raw, stream == 2 ? 1 : 0,
                      (uint32_t *)f.keep.p, (uint32_t *)f.bad.p);
-  cm_scan_u32((const uint32_t *)f.keep.p, (uint32_t *)f.pos.p, n_raw, (uint32_t *)c->scan_tmp.p, s);
+  cm_scan_u32((const uint32_t *)f.keep.p, (uint32_t *)f.pos.p, n_raw, (uint32_t *)f.scan_tmp.p, s);
   hipLaunchKernelGGL(k_fq_compact, gr, b, 0, s, (const uint32_t *)f.keep.p, (const uint32_t *)f.pos.p, n_raw, (uint32_t *)f.recidx.p);
   uint32_t bad = 0, n_rec = 0;
   FQCHECK(c, hipMemcpyAsync(&bad, f.bad.p, 4, hipMemcpyDeviceToHost, s));
@@ -319,8 +326,8 @@ static int fq_text_room(cmgpu_ctx *c, CmFqStream &f, uint64_t need, uint64_t kee
   if (f.text.cap >= need) return CMGPU_OK;
   DevBuf bigger;
   if (bigger.ensure(need + need / 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
-  if (keep) FQCHECK(c, hipMemcpyAsync(bigger.p, f.text.p, keep, hipMemcpyDeviceToDevice, c->stream));
-  FQCHECK(c, cm_stream_sync(c->stream));
+  if (keep) FQCHECK(c, hipMemcpyAsync(bigger.p, f.text.p, keep, hipMemcpyDeviceToDevice, fq_hs(c, f)));
+  FQCHECK(c, cm_stream_sync(fq_hs(c, f)));
   f.text.release();
   f.text = bigger;
   bigger.p = nullptr; bigger.cap = 0;
@@ -354,7 +361,7 @@ extern "C" int cmgpu_fastq_scan_bgzf(cmgpu_ctx *c, int stream, const void *block
   if (!c || stream < 0 || stream > 2 || (!blocks && n_bytes) || !n_records) return CMGPU_EINVAL;
   FQCHECK(c, cm_enter(c));
   CmFqStream &f = c->fq[stream];
-  hipStream_t s = c->stream;
+  hipStream_t s = fq_hs(c, f);
   *n_records = 0;
   if (!f.dev_mode) { f.dev_mode = true; f.dev_len = 0; }
   // ---- the blocks' table (host): whole blocks only
@@ -409,7 +416,8 @@ extern "C" int cmgpu_fastq_scan_bgzf(cmgpu_ctx *c, int stream, const void *block
   f.n_bytes = out; f.n_nl = 0; f.n_raw = 0; f.n_rec = 0; f.final_chunk = final_chunk != 0;
   if (out == 0) return CMGPU_OK;
   char last_char = 0;
-  FQCHECK(c, hipMemcpy(&last_char, (const uint8_t *)f.text.p + out - 1, 1, hipMemcpyDeviceToHost));
+  FQCHECK(c, hipMemcpyAsync(&last_char, (const uint8_t *)f.text.p + out - 1, 1, hipMemcpyDeviceToHost, s));
+  FQCHECK(c, cm_stream_sync(s));
   return fq_scan_resident(c, stream, out, final_chunk, last_char, n_records);
 }
 
