@@ -770,11 +770,15 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
     if (c->opt_heavy_max[2] > 0 && (uint32_t)c->opt_heavy_max[2] < d.hv_max[3]) d.hv_max[3] = (uint32_t)c->opt_heavy_max[2];
     for (int q = 1; q < 4; ++q) if (d.hv_max[q] < d.hv_max[q - 1]) d.hv_max[q] = d.hv_max[q - 1];
     if (c->opt_heavy_max[2] > 0 && (uint32_t)c->opt_heavy_max[2] < d.hv_big) d.hv_big = (uint32_t)c->opt_heavy_max[2];
+    const uint32_t hv_big_area = d.hv_big;  // (what a CU's shared memory holds once: the rescue lists' largest class is sized from it)
+    // 32-bit hit keys: 11 bytes per hit -- 7 040 hits leave room for TWO blocks of 1 024 lanes per CU (k_s3b_coop<1024, true> on profile 2:
+    // 53.6 -> 43.0 ms of S3b per step against one block with 8 192; the few longer lists go to the slab launch)
+    if (c->goff.p && d.hv_big > 7040u) d.hv_big = 7040u;
     if (d.hv_big <= d.hv_max[3]) d.hv_big = 0;
     if (c->opt_heavy_max[0] < 0) { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_big = 0; }  // everything long goes to the one-lane path
     // the rescue lists' classes: the hit lists' up to 2048, then as many 20-byte entries as fit a CU's shared memory twice / once
     d.rs_max3 = d.hv_max[3] < 3968u ? d.hv_max[3] : 3968u;
-    d.rs_big = d.hv_big ? (d.hv_big < 7680u ? d.hv_big : 7680u) : 0u;
+    d.rs_big = d.hv_big ? (hv_big_area < 7680u ? hv_big_area : 7680u) : 0u;
     if (d.rs_big <= d.rs_max3) d.rs_big = 0;
     d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
     if (d.hv_mid > 256) d.hv_mid = 256;

@@ -34,7 +34,7 @@
 //    1  CM_L_HIT_B256A        reads, hits <= hv_max[1] (1024)        k_s3b_coop<256>                      1024 / 12 KB
 //    2  CM_L_HIT_B256B        reads, hits <= hv_max[2] (2048)        k_s3b_coop<256>                      2048 / 23 KB
 //   10  CM_L_HIT_B512         reads, hits <= hv_max[3] (4096)        k_s3b_coop<512>                      4096 / 46 KB
-//   25  CM_L_HIT_B1024        reads, hits <= hv_big (8192)           k_s3b_coop<1024>                     8192 / 91 KB
+//   25  CM_L_HIT_B1024        reads, hits <= hv_big (7040; 8192 with 64-bit keys)  k_s3b_coop<1024>          7040 / 79 KB: two blocks per CU
 //    3  CM_L_HIT_SLAB         reads with more hits                   k_s3b_coop<1024, false>, use_slab    global slab (19 B per hit)
 //    5  CM_L_HIT_DECLINED     reads k_s3b_coop declined              k_s3b_heavy<CM_BLOCK> (bitonic)      pow2(hv_big) x 10 B
 //   16  CM_L_HIT_SERIAL       reads the slab launch declined         k_s3b_serial (a lane)                --

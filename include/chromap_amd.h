@@ -464,6 +464,9 @@ int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_b
  *   cmgpu_fastq_scan   uploads one chunk (< 4 GiB) and counts its complete, non-empty records;
  *                      final_chunk != 0: the text ends the file (a missing last newline is fine).
  *                      CMGPU_EFORMAT: not 4-line FASTQ (multi-line records need a host parser).
+ *                      Scans (this call and cmgpu_fastq_scan_bgzf) of DIFFERENT streams of one context may be
+ *                      made from different host threads at the same time: each stream has a HIP stream and
+ *                      scratch of its own; every other call on a context is one thread at a time.
  *   cmgpu_fastq_take   makes the first n of them this stream's part of the resident batch and
  *                      returns how many bytes of the chunk they (and skipped records) cover --
  *                      the host resubmits the rest in front of the next chunk.
