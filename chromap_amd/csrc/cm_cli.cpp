@@ -739,7 +739,10 @@ int main(int argc, char **argv) {
           std::thread th[3];
           // (blocks inflated on the device: a scan per batch, not per chunk -- the first pass of the inflate takes the same time for
           //  a few hundred blocks as for tens of thousands)
-          auto want = [&](int m) { return rd[m].bgzf && rd[m].dev_inflate && !a.chunk_given && target < ((size_t)1 << 30) ? (size_t)1 << 30 : target; };
+          // (... sized to the batch: what a take leaves over is copied and scanned again with the next piece, so a piece far larger than
+          //  a batch -- 1 GiB against the ~125 MB of a 500 000-pair batch -- would be re-scanned many times)
+          const size_t piece = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)64 << 20, (size_t)a.batch_pairs * 256));
+          auto want = [&](int m) { return rd[m].bgzf && rd[m].dev_inflate && !a.chunk_given && target < piece ? piece : target; };
           for (int m = 1; m < ns_streams; ++m) th[m] = std::thread([&rd, m, &want]() { rd[m].fill(want(m)); });
           rd[0].fill(want(0));
           for (int m = 1; m < ns_streams; ++m) th[m].join();

@@ -326,24 +326,33 @@ static int fq_text_room(cmgpu_ctx *c, CmFqStream &f, uint64_t need, uint64_t kee
   if (f.text.cap >= need) return CMGPU_OK;
   DevBuf bigger;
   if (bigger.ensure(need + need / 4)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
-  if (keep) FQCHECK(c, hipMemcpyAsync(bigger.p, f.text.p, keep, hipMemcpyDeviceToDevice, fq_hs(c, f)));
-  FQCHECK(c, cm_stream_sync(fq_hs(c, f)));
+  {
+    hipError_t e = keep ? hipMemcpyAsync(bigger.p, f.text.p, keep, hipMemcpyDeviceToDevice, fq_hs(c, f)) : hipSuccess;
+    if (e == hipSuccess) e = cm_stream_sync(fq_hs(c, f));
+    if (e != hipSuccess) { bigger.release(); FQCHECK(c, e); }
+  }
   f.text.release();
   f.text = bigger;
   bigger.p = nullptr; bigger.cap = 0;
   return CMGPU_OK;
 }
 // after a take in device mode: the unconsumed rest of the text moves to the front (through the second buffer: the ranges may overlap)
-static int fq_retain_rest(cmgpu_ctx *c, CmFqStream &f, uint64_t consumed, bool end_of_file) {
+static int fq_retain_rest(cmgpu_ctx *c, CmFqStream &f, uint64_t consumed, bool end_of_file, uint64_t *consumed_out) {
   uint64_t rest = f.n_bytes > consumed ? f.n_bytes - consumed : 0;
   if (end_of_file && rest) {
     // every record of the file is taken: what follows the last one may only be blank (the host check of a plain-text file:
     // "Didn't reach the end of sequence file"); it is dropped so that the next file starts on an empty text
+    // (the whole tail, 64 KiB at a time: a file may end in any amount of blank lines, as the host path's only_whitespace() accepts)
     std::vector<char> tail(rest < 65536 ? rest : 65536);
-    FQCHECK(c, hipMemcpy(tail.data(), (const uint8_t *)f.text.p + consumed, tail.size(), hipMemcpyDeviceToHost));
-    bool blank = rest <= 65536;
-    for (char ch : tail) blank = blank && (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t');
+    bool blank = true;
+    for (uint64_t o = 0; blank && o < rest; o += tail.size()) {
+      const size_t m = rest - o < tail.size() ? (size_t)(rest - o) : tail.size();
+      FQCHECK(c, hipMemcpy(tail.data(), (const uint8_t *)f.text.p + consumed + o, m, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < m; ++i) { const char ch = tail[i]; blank = blank && (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t'); }
+    }
     if (!blank) { cm_set_error(c, "text after the last whole FASTQ record of the file"); return CMGPU_EFORMAT; }
+    consumed += rest;  // (the blank tail counts as consumed: the caller's byte accounting ends at the file's end)
+    if (consumed_out) *consumed_out = consumed;
     rest = 0;
   }
   if (rest) {
@@ -450,7 +459,7 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   }
   *bytes_consumed = consumed;
   if (offs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (read offsets)"); return CMGPU_ENOMEM; }
-  if (n == 0) { FQCHECK(c, hipMemset(offs.p, 0, 4)); return f.dev_mode ? fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec) : CMGPU_OK; }
+  if (n == 0) { FQCHECK(c, hipMemset(offs.p, 0, 4)); return f.dev_mode ? fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec, bytes_consumed) : CMGPU_OK; }
   if (f.len.ensure(((size_t)n + 1) * 4) || c->scan_tmp.ensure(cm_scan_tmp_words(n) * 4) || f.bad.ensure(4)) {
     cm_set_error(c, "out of device memory (FASTQ lengths)"); return CMGPU_ENOMEM;
   }
@@ -478,7 +487,7 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   FQCHECK(c, cm_stream_sync(s));
   f.taken_bases = total;
   f.taken_max_len = mx;
-  if (f.dev_mode) return fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec);
+  if (f.dev_mode) return fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec, bytes_consumed);
   return CMGPU_OK;
 }
 

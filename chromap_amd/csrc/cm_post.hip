@@ -213,6 +213,11 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_select(const uint8_t *__restric
         rep = qi;
         ++gsize;
         ++u;
+        if (u > j + PP_RUN_SERIAL) {  // one cell's pile-up at one position (10^4 .. 10^5 duplicates): the wave kernel's too
+          long_list[atomicAdd(long_cnt, 1u)] = j;
+          line_len[j] = 0;
+          return;
+        }
       }
       const uint32_t nd = gsize >= 2 ? 2u : 1u, ab = pp_abundance(cfg, gb);
       if (!have || nd > best_nd || (nd == best_nd && ab > best_ab)) { have = true; best_i = rep; best_nd = nd; best_ab = ab; }

@@ -168,6 +168,24 @@ def test_bgzf_inflated_on_the_device_equals_host_reader(per_call, limit, level, 
     g.close()
 
 
+def test_bgzf_file_ending_in_many_blank_lines():
+    """more than 64 KiB of blank lines behind the last record (the host reader's only_whitespace() accepts any amount): accepted,
+    counted as consumed, and the stream starts clean for the next file; text that is not blank there is refused"""
+    from chromap_amd import ChromapError
+    g = _gpu()
+    _, r1, _ = datasets.case_inputs("s2_atac_q0")
+    text = open(r1, "rb").read()
+    want_b, want_o = ol.read_fastx(r1)
+    for tail in (b"\n" * 200000, b" \r\n\t\n" * 40000):
+        b, off = _ingest_bgzf(g, _bgzf_blocks(text + tail, 1), 1 << 20)
+        assert np.array_equal(off, want_o) and np.array_equal(b, want_b)
+    blocks = _bgzf_blocks(text + b"\n" * 100000 + b"x\n", 1)
+    n = g.fastq_scan(0, b"".join(blocks), True, bgzf=True)
+    with pytest.raises(ChromapError, match="after the last whole FASTQ record"):
+        g.fastq_take(0, n)
+    g.close()
+
+
 def test_bgzf_damaged_blocks_are_rejected():
     import struct, zlib
     from chromap_amd import ChromapError
