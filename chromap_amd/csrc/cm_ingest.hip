@@ -79,8 +79,12 @@ __global__ __launch_bounds__(FQ_BLOCK) void k_fq_records(const uint8_t *__restri
   fq_line(text, nl, 4 * r + 3, &s3, &e3);
   bool ok = e0 > s0 && text[s0] == '@' && e2 > s2 && text[s2] == '+';
   if (want_qual && (e3 - s3) != (e1 - s1)) ok = false;  // kseq: quality and sequence lengths must agree
-  if (!ok) atomicMin(bad, r);
-  keep[r] = e1 > s1 ? 1u : 0u;
+  // four blank lines (spaces and tabs at most) are no record and no damage either: kseq looks for the next '@' and skips them -- a
+  // file may end in any number of blank lines
+  bool blank = true;
+  for (uint32_t i = s0; blank && i < e3; ++i) { const uint8_t ch = text[i]; blank = ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r'; }
+  if (!ok && !blank) atomicMin(bad, r);
+  keep[r] = !blank && e1 > s1 ? 1u : 0u;
 }
 __global__ __launch_bounds__(FQ_BLOCK) void k_fq_compact(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint32_t n_raw,
                                                            uint32_t *__restrict__ recidx) {
