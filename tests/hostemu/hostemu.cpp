@@ -349,7 +349,7 @@ static int emu_map_pairs(const cmgpu_index_view *index, const cmgpu_ref_view *re
     }
   }
   // k_s4a_rescue_count / k_s4a_rescue_list: with the cooperative forms on, a read whose mate has 4 candidates or more on a strand
-  // has its rescue searches run by a group (cm_coop_rescue; the kernel takes a wave from 24 candidates on)
+  // has its rescue searches run by a group (cm_coop_rescue; on the device: a wave, CM_RS_WAVE)
   std::vector<uint32_t> rescue_wave;
   std::vector<uint8_t> is_rescue_wave(n2, 0);
   // the pool of rescue hits found while counting (CmDev::rs_pool), small enough to run out on the repeat-rich cases
