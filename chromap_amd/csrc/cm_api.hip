@@ -29,6 +29,8 @@ static thread_local std::string g_last_error;  // errors without a ctx (creation
     }                                                                                            \
   } while (0)
 
+// environment knobs (include/chromap_amd_debug.h): read once
+static bool cm_debug_pool() { static const bool on = getenv("CM_DEBUG_POOL") != nullptr; return on; }
 void cm_set_error(cmgpu_ctx *ctx, const std::string &msg) {
   static std::mutex mu;  // (the scans of a batch's files may fail side by side)
   std::lock_guard<std::mutex> lk(mu);
@@ -1023,7 +1025,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     const auto dbg_t0 = std::chrono::steady_clock::now();
     if (c->rs_pool.ensure((size_t)want * 8) == 0 && c->rs_pool_off.ensure((size_t)n2 * 2 * 4 + 16) == 0) c->rs_pool_cap = (uint32_t)(c->rs_pool.cap / 8 > 0xfffffff0ull ? 0xfffffff0ull : c->rs_pool.cap / 8);
     else { c->rs_pool.release(); c->rs_pool_cap = 0; }  // (no pool: the fill pass searches again)
-    if (getenv("CM_DEBUG_POOL")) fprintf(stderr, "pool ensure want %llu: %.3f ms\n", (unsigned long long)want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
+    if (cm_debug_pool()) fprintf(stderr, "pool ensure want %llu: %.3f ms\n", (unsigned long long)want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
     cm_fill_dev_range(c, d, rlo, rhi);
   }
   cm_launch_k_s4a_rescue_count(d, n2, s, (c->opt_coop & 2) != 0);  // decision per read + the packed list of reads that supplement
@@ -1054,7 +1056,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
     }
     c->m_cap = n_m;
   }
-  if (getenv("CM_DEBUG_POOL")) fprintf(stderr, "spec %d m_cap %llu m_total %llu\n", (int)spec, (unsigned long long)c->m_cap, (unsigned long long)m_total);
+  if (cm_debug_pool()) fprintf(stderr, "spec %d m_cap %llu m_total %llu\n", (int)spec, (unsigned long long)c->m_cap, (unsigned long long)m_total);
   cm_fill_dev_range(c, d, rlo, rhi);
   mark(c, "s4a_rescue_count");
   cm_launch_k_s4b_rescue_merge(d, n2, s, (c->opt_coop & 2) != 0, c->max_read_len);
@@ -1131,7 +1133,7 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   c->pred_m_ok = true;
   c->pred_n = n;
   c->rs_pool_want = hst[CM_ST_POOL];
-  if (getenv("CM_DEBUG_POOL")) fprintf(stderr, "pool: cap %u entries, asked %llu\n", c->rs_pool_cap, (unsigned long long)hst[CM_ST_POOL]);
+  if (cm_debug_pool()) fprintf(stderr, "pool: cap %u entries, asked %llu\n", c->rs_pool_cap, (unsigned long long)hst[CM_ST_POOL]);
   if (hst[CM_ST_ERR]) { cm_set_error(c, "internal device error flag " + std::to_string((unsigned long long)hst[CM_ST_ERR])); return CMGPU_ECAPACITY; }
   *k_out = hst[CM_ST_RECORDS];
   c->last_range_lo = rlo; c->last_range_hi = rhi;

@@ -5,6 +5,12 @@
  * the profiling tools: synthetic genomes and read batches generated on the device, the kernel-only probe measurement,
  * measurement knobs, stage-level views of the last mapped batch and exports of the resident index / reference for the
  * oracle.  Plain C like the boundary header.
+ *
+ * Environment variables the library / CLI read (measurement and test aids, no effect on results):
+ *   CM_NO_KEY32     the cooperative hit-list stage keeps the reference's 64-bit keys although the reference would fit 32-bit
+ *                   global coordinates (the path of references beyond 4 Gbases; tests/test_gpu_stages.py)
+ *   CM_DEBUG_POOL   per mapped range: size of and demand on the rescue-hit pool, time of its (re)allocation, on stderr
+ *   CM_CLI_TIMES    chromap-amd: seconds of every scan / take + commit / map / store call on stderr
  */
 #ifndef CHROMAP_AMD_DEBUG_H_
 #define CHROMAP_AMD_DEBUG_H_
