@@ -86,3 +86,35 @@ CONFIGS = [
     (5, None, {"mapq_threshold": 0, "error_threshold": 5}, {"L": 70}),
     (6, "chip", {"mapq_threshold": 0, "min_num_seeds": 3, "max_insert_size": 300}, {"div": 0.0, "copies": 150}),
 ]
+
+
+def write_wrap_case(d):
+    """a repeat element that also stands at the very start of every chromosome, and reads that carry 15 foreign bases in front of the
+    element's first 35: the + hit at position 0 has its diagonal before the sequence start (candidate position wraps below zero)"""
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(77)
+    elem = ACGT[rng.integers(0, 4, 300)]
+    chroms = [ACGT[rng.integers(0, 4, 40000)].copy() for _ in range(3)]
+    for c in chroms:
+        c[:300] = elem
+        for _ in range(40):
+            p = int(rng.integers(400, len(c) - 400))
+            c[p:p + 300] = elem
+    fa = os.path.join(d, "w.fa")
+    with open(fa, "wb") as f:
+        for i, c in enumerate(chroms):
+            f.write(b">c%d\n" % i + c.tobytes() + b"\n")
+    r1, r2 = [], []
+    for i in range(300):
+        a = np.concatenate([ACGT[rng.integers(0, 4, 15)], elem[:35]])
+        b = COMP[chroms[i % 3][0:260][::-1]][:50]
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+
+    def pack(rs):
+        off = np.zeros(len(rs) + 1, np.uint32)
+        off[1:] = np.cumsum([len(r) for r in rs])
+        return np.frombuffer(b"".join(rs), np.uint8).copy(), off
+    b1, o1 = pack(r1)
+    b2, o2 = pack(r2)
+    return fa, b1, o1, b2, o2

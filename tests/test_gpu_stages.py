@@ -111,6 +111,20 @@ def test_stage_trace_fuzz_64_bit_hit_keys(cfg, tmp_path, monkeypatch):
     o.close()
 
 
+def test_hit_list_with_a_diagonal_before_the_sequence_start(tmp_path):
+    """a + hit whose candidate position wraps below zero (fuzz_data.write_wrap_case): the cooperative kernel declines the read, the
+    bitonic kernel takes it; every stage count equals the oracle's"""
+    from chromap_amd import ChromapGPU
+    fa, b1, o1, b2, o2 = fuzz_data.write_wrap_case(str(tmp_path))
+    o = ol.Oracle(None, fa, ol.params("atac", mapq_threshold=0))
+    idx = str(tmp_path / "w.idx")
+    assert o.L.ora_index_save(idx.encode(), C.byref(o.idx)) == 0
+    g = ChromapGPU(idx, fa, preset="atac", mapq_threshold=0)
+    _check(g, o, b1, o1, b2, o2, 17, "wrapped diagonal")
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("tile", [8, 32, 128])
 def test_position_parallel_minimizers_tile_sizes(tile):
     """k_prep_flat with other tile geometries (reads per tile) on reads of mixed lengths incl. adapter-trimmed ones"""

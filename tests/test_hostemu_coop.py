@@ -77,6 +77,31 @@ def test_cooperative_stages_equal_oracle(cfg, geo, tmp_path):
         assert declined > 0, "the decline path was not taken"
 
 
+def test_hit_list_with_a_diagonal_before_the_sequence_start(tmp_path):
+    """reads whose repeat element also stands at the very start of a chromosome, behind 15 bases that belong to nothing: the + hit there
+    has its diagonal before position 0 (the only way an occurrence run is not ascending in candidate positions) -- the group declines the
+    read (cm_coop_s3b_expand) and the one-lane definition takes it; results equal the oracle's"""
+    import oracle_lib as ol
+    from test_hostemu_fuzz import _tuples_g, _tuples_o
+    fa, b1, o1, b2, o2 = fuzz_data.write_wrap_case(str(tmp_path))
+    kw = {"mapq_threshold": 0}
+    o = ol.Oracle(None, fa, ol.params("atac", **kw))
+    idx = str(tmp_path / "w.idx")
+    assert o.L.ora_index_save(idx.encode(), C.byref(o.idx)) == 0
+    orec, ok, ost, _ = o.map_pairs(b1, o1, b2, o2)
+    L = he.lib()
+    h = he.HostEmu(idx, fa, he.params("atac", **kw))
+    _set(L, *GEOMETRIES[0])
+    try:
+        rec, k, st, _ = h.map_pairs(b1, o1, b2, o2)
+        items = _items(L)
+    finally:
+        _set(L, 0, 0, 0, 0, 0, 0, 0)
+    assert k == ok and _tuples_g(rec, k, False) == _tuples_o(orec, ok, False)
+    assert items[1] > 0, "no read was declined: the wrapped diagonal was not met"
+    o.close()
+
+
 def test_hit_lists_on_64_bit_keys(tmp_path):
     """the cooperative hit-list stage with the reference's 64-bit keys (what a reference beyond 32-bit global coordinates gets;
     every other case here runs on 32-bit keys, as the device does when the reference fits)"""
