@@ -271,7 +271,9 @@ CM_HD CmCoopMem cm_coop_mem_at(uint8_t *base, uint32_t P, uint32_t MM, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------
-// S3b for one read with a long hit list (cm_s3b_core's results, element for element):
+// S3b for one read with a long hit list (cm_s3b_core's results, element for element).  Two front ends: lists in the shared work area
+// go through cm_coop_s3b_expand (below: pieces, ballots, run tables without a look at the keys -- and through cm_coop_s3b_k32 on 32-bit
+// keys where the reference fits); lists on a slab of global memory (SLAB) keep the form of rounds 3-4:
 //   expand   the hit list in minimizer order, occurrence order inside a minimizer: every lane takes hits x, x + G, ... --
 //            which minimizer's occurrence it is comes from the table of run starts -- eight independent occurrence loads
 //            in flight per lane; the - strand's keys get bit 63;
