@@ -169,6 +169,13 @@ CASES = {
                         "--varlen", "--seed", "7"], ["--preset", "atac", "--min-read-length", "20", "-q", "0"]),
     "p5_n5_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                   "--seed", "5"], ["--preset", "atac", "-n", "5", "-q", "0"]),
+    # combinations: off-preset values together, with cell barcodes, with split alignment
+    "p6_combo_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "70", "--seed", "51", "--sub", "0.02",
+                     "--indel", "0.003"], ["--preset", "chip", "-e", "10", "-s", "3", "-f", "20,60", "-l", "500", "--min-read-length", "35", "-q", "0"]),
+    "b5_bc_e5_f40_q0": (["--genome", "2000000", "--chroms", "4", "--pairs", "20000", "--readlen", "50", "--frag-min", "35",
+                         "--barcodes", "500", "--seed", "31"], ["--preset", "atac", "-e", "5", "-f", "40,90", "-q", "0"]),
+    "h3_hic_e6_q0": (["--genome", "1000000", "--chroms", "3", "--pairs", "15000", "--readlen", "100", "--frag-min", "200",
+                      "--frag-max", "500", "--hic", "--seed", "22", "--indel", "0.004", "--sub", "0.02"], ["--preset", "hic", "-e", "6", "-q", "0"]),
     "p5_se_n5_e5_q0": (["--genome", "300000", "--chroms", "2", "--pairs", "20000", "--readlen", "50", "--frag-min", "40",
                         "--seed", "5"], ["--preset", "chip", "-n", "5", "-e", "5", "-q", "0"]),
 }
