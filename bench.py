@@ -179,31 +179,50 @@ def cpu_baseline_port(g, args):
             "algorithmic_probe_steps_per_pair": round(st.probe_steps / m, 2)}
 
 
-def gen(g, args, seed):
-    g.generate_resident(args.pairs, read_length=args.readlen, frag_min=args.frag_min, frag_max=args.frag_max, sub_rate=0.01, seed=seed,
+def gen(g, args, seed, pairs=None):
+    g.generate_resident(pairs or args.pairs, read_length=args.readlen, frag_min=args.frag_min, frag_max=args.frag_max, sub_rate=0.01, seed=seed,
                         indel_rate=args.indel_rate, hic=args.hic if args.hic >= 0 else None)
 
 
 SETUP_PASSES = 2
+MAPPED = {"pairs": 0}  # pairs this process has mapped so far (the profiler passes divide a kernel's summed counters by it)
+SUB_STEP_MAX = 25_000_000  # pairs mapped by one call inside a step (--strong: a rank's share of the total is cut into sub-steps of at most this)
+MAX_SLOTS = 8              # cmgpu_swap_resident_batch has eight parking slots
+
+
+def sub_steps(pairs):
+    """a rank's pairs of one step as the sizes of its sub-steps: [pairs] up to SUB_STEP_MAX, else equal parts (the last takes the remainder)"""
+    n = max(1, -(-pairs // SUB_STEP_MAX))
+    if n > MAX_SLOTS:
+        raise SystemExit("--strong: %d pairs per GPU and step need more than %d sub-steps of %d" % (pairs, MAX_SLOTS, SUB_STEP_MAX))
+    s = -(-pairs // n)
+    return [s] * (n - 1) + [pairs - s * (n - 1)]
 
 
 def timed_run(g, args, rank, world, dist, seed0, exchange):
-    """parks N_SLOTS distinct batches, then warm-up + K timed steps; returns (dt of this rank, stage sums, Stats, mapped)"""
+    """parks the distinct batches, then warm-up + K timed steps; returns (dt of this rank, stage sums, Stats, mapped).
+    A step maps args.pairs pairs: one resident batch (N_SLOTS distinct ones take turns), or -- more than SUB_STEP_MAX pairs,
+    --strong at few GPUs -- every one of its sub-steps' batches in turn, all of them distinct and resident"""
     import torch
     from chromap_amd import Stats
-    for b in range(N_SLOTS):
-        gen(g, args, seed0 + rank * 64 + b)
+    subs = sub_steps(args.pairs)
+    n_slots = N_SLOTS if len(subs) == 1 else len(subs)
+    for b in range(n_slots):
+        gen(g, args, seed0 + rank * 64 + b, subs[b % len(subs)])
         g.swap_resident(b)
 
     def step(i, stats):
-        sl = i % N_SLOTS
-        g.swap_resident(sl)
-        k = g.map_resident(stats)
-        if exchange:
-            g.exchange_step()
-        tm = g.timings()
-        g.swap_resident(sl)
-        return k, tm
+        k, tms = 0, {}
+        for sl in ([i % n_slots] if len(subs) == 1 else range(n_slots)):
+            g.swap_resident(sl)
+            k += g.map_resident(stats)
+            MAPPED["pairs"] += subs[sl % len(subs)]
+            if exchange:
+                g.exchange_step()
+            for name, ms in g.timings():
+                tms[name] = tms.get(name, 0.0) + ms
+            g.swap_resident(sl)
+        return k, list(tms.items())
 
     if exchange:  # a run knows how many pairs it maps: the owner's store is sized once, not doubled on the way
         g.store_reserve(int((SETUP_PASSES + args.warmup + args.steps + 1) * args.pairs * 1.3))
@@ -234,10 +253,61 @@ def timed_run(g, args, rank, world, dist, seed0, exchange):
     return dt, stage_ms, st, mapped
 
 
-def roofline(g, args, s, steps, stage_ms):
+GRADED_LOOKUPS_MIN = 100_000_000  # the graded launch of the probe kernel has at least 10^8 lookups
+GRADED_LAUNCHES = 30              # its duration is the MEDIAN of this many single launches, each bracketed by HIP events
+
+
+def probe_source_sha():
+    """sha of the sources the probe kernel is compiled from: profiles/probe_traffic.json names the one it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("cm_kernels.hip", "cm_stages.h", "cm_types.h"):
+        h.update(open(os.path.join(ROOT, "chromap_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def s3b_roofline(g, occurrences, pairs, label):
+    """SURVEY 8(d)'s second term: 8 B x occurrence entries read, over the time of the candidate stage's kernels (S3b: k_s3b_*) that
+    read them -- HIP events around the stage on the mapping stream, of the one-lane pass over the resident batch mapped last"""
+    ms = dict(g.timings()).get("s3b_candidates", 0.0)
+    if ms <= 0:
+        return None
+    traffic, src = None, None
+    prof = os.path.join(ROOT, "profiles", "s3b_traffic.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof)).get(label)
+            if pj and pj.get("source_sha") == probe_source_sha() and pj.get("pairs") == pairs:
+                traffic, src = pj["hbm_bytes_per_pass"], "profiles/s3b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_bench.sh)"
+            elif pj:
+                src = "profiles/s3b_traffic.json is stale (sources or batch size changed since): not reported"
+        except Exception:
+            pass
+    ach = 8.0 * occurrences / (ms * 1e-3) / 1e9
+    return {"kernels": "k_s3b_candidates + k_s3b_heavy<*> + k_s3b_coop<*> (the candidate stage of one batch)", "bound": "hbm", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_pass": int(8 * occurrences),
+            "occurrences_read": int(occurrences), "pairs": int(pairs), "stage_ms": round(ms, 3), "traffic": traffic, "traffic_source": src,
+            "note": "the stage sorts and sweeps the occurrences it reads (merge sort in shared memory): its bound is instruction issue / latency, not "
+                    "HBM -- the fraction is reported because SURVEY 8(d) counts these bytes, not as a claim that HBM limits the stage"}
+
+
+def roofline(g, args, steps):
     """kernel-only measurement of the index probe (HIP events on the launch stream) against the swept random-gather
-    ceiling of the same table"""
-    n_mm = s["num_minimizers"] // steps
+    ceiling of the same table.  The graded launch looks up the minimizers of ONE resident batch of >= 10^8 lookups (a batch of
+    enough pairs is generated and mapped in one piece); its duration is the median of GRADED_LAUNCHES single launches"""
+    from chromap_amd import Stats
+    import statistics
+    # a batch with >= 10^8 minimizers, mapped in one piece so that its hashes are resident together
+    per_pair = 15.2 * args.readlen / 50.0
+    gp = int(-(-GRADED_LOOKUPS_MIN * 1.03 // per_pair))
+    gp = max(args.pairs, -(-gp // 1_000_000) * 1_000_000)
+    gen(g, args, 999, gp)
+    gst = Stats()
+    g.map_resident(gst)
+    MAPPED["pairs"] += gp
+    gs = gst.as_dict()
+    n_mm = gs["num_minimizers"]
+    s3b = s3b_roofline(g, gs["occurrences_read"], gp, "headline" if not args.headline_repeats else args.headline_repeats)
     # the file's table (khash layout, load 0.7): its probe steps are SURVEY 8(d)'s algorithmic unit -- what kh_get visits for these lookups
     favg, fps, fhits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     file_layout = None
@@ -248,16 +318,26 @@ def roofline(g, args, s, steps, stage_ms):
         # the profiler passes: the file table's probe steps (a property of the data set) are counted by ONE launch of another shape
         # (two lookups per lane: k_probe<2, false>), so that every k_probe<1, false> in the trace is the graded launch
         g.L.cmgpu_probe_bench_variant(g.ctx, n_mm, 1, 2, 2, C.byref(favg), C.byref(fps), C.byref(fhits))
-    probe_steps = fps.value if fps.value else s["probe_steps"] / steps
+    probe_steps = fps.value if fps.value else gs["probe_steps"]
     alg_bytes = 16.0 * probe_steps  # one 8-B key + one 8-B value per bucket kh_get visits
     avg, ps, hits = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     probe_only, achieved, probe_ms = None, 0.0, 0.0
-    if g.L.cmgpu_probe_bench(g.ctx, None, n_mm, args.probe_repeat, C.byref(avg), C.byref(ps), C.byref(hits), None) == 0 and avg.value > 0:
-        probe_only = {"lookups": int(n_mm), "avg_ms": round(avg.value, 4), "buckets_visited": int(ps.value), "hits": int(hits.value),
+    singles = []
+    for _ in range(1 if args.graded_probe_only else GRADED_LAUNCHES):
+        # (every call: one counted launch, then `repeat` launches between two events; under the profiler one call of probe_repeat launches)
+        if g.L.cmgpu_probe_bench(g.ctx, None, n_mm, args.probe_repeat if args.graded_probe_only else 1, C.byref(avg), C.byref(ps), C.byref(hits), None) != 0 or avg.value <= 0:
+            break
+        singles.append(avg.value)
+    if singles:
+        med = statistics.median(singles)
+        probe_only = {"lookups": int(n_mm), "pairs_of_the_batch": int(gp), "launches_timed": len(singles), "median_ms": round(med, 4),
+                      "mean_ms": round(sum(singles) / len(singles), 4), "min_ms": round(min(singles), 4), "max_ms": round(max(singles), 4),
+                      "buckets_visited": int(ps.value), "hits": int(hits.value),
                       "table_buckets": g.get_option("probe_table_buckets"),
-                      "GB/s": round(alg_bytes / (avg.value * 1e-3) / 1e9, 1), "GB/s_of_buckets_visited": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9, 1),
-                      "G_lookups/s": round(n_mm / (avg.value * 1e-3) / 1e9, 2)}
-        achieved, probe_ms = probe_only["GB/s"], avg.value
+                      "GB/s": round(alg_bytes / (med * 1e-3) / 1e9, 1), "GB/s_of_buckets_visited": round(16.0 * ps.value / (med * 1e-3) / 1e9, 1),
+                      "G_lookups/s": round(n_mm / (med * 1e-3) / 1e9, 2)}
+        achieved, probe_ms = probe_only["GB/s"], med
+        avg.value = med
         assert hits.value == fhits.value or not fps.value, "the re-hashed table answers differently"
     variants = []
     for u in (() if args.graded_probe_only else (1, 2, 4, 8)):
@@ -273,13 +353,21 @@ def roofline(g, args, s, steps, stage_ms):
             sweep.append({"loads_per_lane": loads, "access_bytes": width, "avg_ms": round(a.value, 4),
                           "G_accesses/s": round(ng / (a.value * 1e-3) / 1e9, 2), "sector_GB/s": round(64.0 * ng / (a.value * 1e-3) / 1e9, 1)})
     best = max(sweep, key=lambda x: x["G_accesses/s"]) if sweep else None
-    traffic, sectors_per_lookup = None, None
+    traffic, sectors_per_lookup, traffic_src = None, None, "no profiles/probe_traffic.json"
     prof = os.path.join(ROOT, "profiles", "probe_traffic.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
-            traffic = pj.get("hbm_bytes_per_launch")
-            sectors_per_lookup = pj.get("sectors_per_lookup")
+            # the file names the sources and the launch it was measured on: another kernel text or launch size and it is refused
+            if pj.get("source_sha") == probe_source_sha() and pj.get("lookups") == n_mm:
+                traffic = pj.get("hbm_bytes_per_launch")
+                sectors_per_lookup = pj.get("sectors_per_lookup")
+                traffic_src = ("from_profile: profiles/probe_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this launch "
+                               "-- same sources (sha %s, commit %s), same %d lookups --, tools/profile_bench.sh), not measured in this run"
+                               % (pj.get("source_sha"), pj.get("commit"), n_mm))
+            else:
+                traffic_src = ("profiles/probe_traffic.json is stale (measured on sources %s / %s lookups, this run: %s / %d): not reported"
+                               % (pj.get("source_sha"), pj.get("lookups"), probe_source_sha(), n_mm))
         except Exception:
             pass
     shape = {"lookups_per_lane": g.get_option("probe_lookups_per_lane"), "pair_prefetch": g.get_option("probe_pair_prefetch")}
@@ -289,19 +377,18 @@ def roofline(g, args, s, steps, stage_ms):
             "frac_visited": round(16.0 * ps.value / (avg.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg.value > 0 else None,
             "extra_hbm_bytes_of_rehashed_table": int(16 * g.get_option("probe_table_buckets")) if args.probe_table_shift else 0,
             "traffic": traffic,
-            "traffic_source": "from_profile: profiles/probe_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, "
-                              "tools/profile_bench.sh), not measured in this run",
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "algorithmic_bytes_cover": "16 B per bucket kh_get visits; the occurrence bytes of SURVEY 8(d) (8 B x occurrences) are read by the candidate "
                                        "stage (S3b: k_s3b_*), not by k_probe, and are not in this figure",
-            "launch_ms": round(probe_ms, 4), "probe_only": probe_only,
+            "launch_ms": round(probe_ms, 4), "launch_ms_is": "median of %d single launches" % len(singles), "probe_only": probe_only,
             "probe_on_file_layout": file_layout,
             "table_note": "the graded launch probes the device's re-hashed copy of the table (cmgpu_set_option probe_table_shift = %d: %d buckets; same "
                           "keys, values, hash and probe sequence, so hit / miss / value of every lookup are the file table's -- asserted here -- and "
                           "fewer buckets are visited); algorithmic bytes = 16 B x the buckets kh_get visits in the FILE's table for the same lookups "
                           "(SURVEY 8(d)); probe_on_file_layout is the same kernel on that table"
                           % (args.probe_table_shift, g.get_option("probe_table_buckets")) if args.probe_table_shift else "the graded launch probes the file's table",
-            "probe_variants": variants, "random_gather_sweep": sweep, "random_gather_ceiling": best}
+            "probe_variants": variants, "random_gather_sweep": sweep, "random_gather_ceiling": best, "s3b": s3b}
     if best and probe_only:
         # useful: bucket reads of the probe against 16-byte accesses of the ceiling shape;
         # sector: 64-byte sectors the probe fetched (PMC, profiles/probe_traffic.json) against the ceiling's sectors
@@ -359,6 +446,8 @@ def main():
     ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_PAIRS",
                     help="strong scaling: TOTAL_PAIRS read pairs per step over ALL ranks (each maps TOTAL_PAIRS / gpus), e.g. "
                          "--strong 100000000 --steps 1 for BASELINE config 3's fixed 100 M pairs at 1/2/4/8 GPUs; the JSON line then says scaling: strong")
+    ap.add_argument("--config3-pairs", type=int, default=100_000_000,
+                    help="extra (N = 1): one timed pass over this many DISTINCT resident pairs, BASELINE config 3's size (0 = skip it)")
     ap.add_argument("--option", action="append", default=[], help="name=value for cmgpu_set_option (measurement knobs)")
     args = ap.parse_args()
 
@@ -378,9 +467,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (chromap_amd has no CPU path)")
     if args.strong:
-        if args.strong % world or args.strong // world > 48_000_000:
-            raise SystemExit("--strong: TOTAL_PAIRS must divide by the number of GPUs and leave at most 48 M pairs per GPU and step")
+        if args.strong % world:
+            raise SystemExit("--strong: TOTAL_PAIRS must divide by the number of GPUs")
         args.pairs = args.strong // world
+        sub_steps(args.pairs)  # (refuses what the parking slots cannot hold)
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
@@ -448,24 +538,39 @@ def main():
         os.close(json_fd)
         return
     steps = max(1, args.steps)
+    subs = sub_steps(args.pairs)
+    n_slots = N_SLOTS if len(subs) == 1 else len(subs)
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / dt / 1e6
     s = st.as_dict()
     # the kernel-only probe measurement wants one batch's minimizers resident in one piece
     g.set_option("lanes", 1)
-    g.swap_resident(0)
-    g.map_resident(Stats())
-    g.swap_resident(0)
-    roof = roofline(g, args, s, steps, stage_ms)
+    roof = roofline(g, args, steps)
     g.set_option("lanes", args.lanes)
-    post = pcie = cpu = rep_out = harsh_out = harsh2_out = hic_out = None
+    post = pcie = cpu = rep_out = harsh_out = harsh2_out = hic_out = cfg3 = None
+    if not args.skip_extras and world == 1 and args.config3_pairs and not args.strong:
+        # BASELINE config 3 at its stated size on this one GPU: 100 M DISTINCT pairs, generated on the device and resident, mapped
+        # once inside one timed step as sub-steps of <= SUB_STEP_MAX pairs (what --strong 100000000 --gpus 1 runs)
+        try:
+            import copy
+            ca = copy.copy(args)
+            ca.pairs, ca.steps, ca.warmup = args.config3_pairs, 1, 0
+            cdt, _, cst, cmapped = timed_run(g, ca, 0, 1, None, 2000, False)
+            cfg3 = {"distinct_pairs": ca.pairs, "sub_steps": sub_steps(ca.pairs), "value": round(ca.pairs / cdt / 1e6, 4), "unit": "M pairs/s",
+                    "ms": round(cdt * 1e3, 2), "mapped_pairs": int(cmapped), "lanes": args.lanes,
+                    "note": "one timed pass over all of the pairs (after %d untimed set-up passes over the same batches)" % SETUP_PASSES}
+            for b in range(len(sub_steps(ca.pairs))):  # the headline's batches back into their slots for what follows
+                gen(g, args, 1000 + b)
+                g.swap_resident(b)
+        except Exception as e:
+            cfg3 = {"error": repr(e)}
     if not args.skip_extras:
         # device-side post-processing, outside the timed region: the records of the four resident
         # batches go to the record store; one call sorts, de-duplicates, filters and renders the BED text in HBM
         try:
             g.store_clear()
             nrec = 0
-            for b in range(N_SLOTS):
+            for b in range(n_slots):
                 g.swap_resident(b)
                 g.map_resident(Stats())
                 nrec = g.store_append_resident()
@@ -484,7 +589,7 @@ def main():
         # reported beside `value`, never as `value`
         try:
             import numpy as np
-            n = args.pairs
+            n = subs[0]
             g.swap_resident(0)
             o1 = np.zeros(n + 1, np.uint32)
             o2 = np.zeros(n + 1, np.uint32)
@@ -537,6 +642,15 @@ def main():
                      "candidates_per_read": round(rs["num_candidates"] / (2.0 * args.pairs * args.steps), 3),
                      "stage_ms_per_step": {k: round(v / steps, 3) for k, v in rstage.items()},
                      "mapped_pairs_per_step": rmapped // steps}
+                try:  # SURVEY 8(d)'s occurrence bytes over the candidate stage's time, one-lane pass over one of the batches
+                    gr.set_option("lanes", 1)
+                    gr.swap_resident(0)
+                    ost = Stats()
+                    gr.map_resident(ost)
+                    o["roofline_s3b"] = s3b_roofline(gr, ost.as_dict()["occurrences_read"], args.pairs, rep if isinstance(rep, str) else ",".join(str(x) for x in rep))
+                    gr.swap_resident(0)
+                except Exception as e:
+                    o["roofline_s3b"] = {"error": repr(e)}
                 gr.close()
                 if not args.skip_cpu and args.cpu_baseline in ("auto", "reference"):
                     o["cpu_baseline"] = cpu_baseline_reference(args, rep, " (%s)" % what[:24], seed0=seed0, pairs=ref_pairs)
@@ -592,18 +706,22 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "--preset %s, synthetic 2x%d bp pairs (fragments %d-%d bp, 1%% substitutions%s), "
                                "GRCh38-sized synthetic index (%.2e bases, %d sequences, k=17 w=7%s) resident per GPU, "
-                               "%d pairs per GPU per step, %d distinct batches per GPU resident in HBM taking turns (%.0f M distinct pairs per GPU)"
+                               "%d pairs per GPU per step, %s (%.0f M distinct pairs per GPU)"
                                % (args.preset, args.readlen, args.frag_min, args.frag_max,
                                   ", %.2f%% 1-base indels" % (args.indel_rate * 100) if args.indel_rate else "", args.genome, args.nseq,
-                                  ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs, N_SLOTS, args.pairs * N_SLOTS / 1e6),
+                                  ", planted repeats " + args.headline_repeats if args.headline_repeats else "", args.pairs,
+                                  "%d distinct batches per GPU resident in HBM taking turns" % N_SLOTS if len(subs) == 1 else
+                                  "mapped as %d sub-steps of <= %d pairs, every sub-step a distinct batch resident in HBM" % (len(subs), subs[0]),
+                                  (args.pairs * N_SLOTS if len(subs) == 1 else args.pairs) / 1e6),
                    "pairs_per_gpu_per_step": args.pairs, "lanes": args.exchange_lanes if exchange else args.lanes,
                    "parallelism": ("read-shard x%d, records to chromosome owners by device partition + RCCL all-to-all on the library's "
                                    "mapping stream inside every step" % world) if exchange else "single GPU"},
-        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "harsh2_repeat_workload": harsh2_out, "hic_workload": hic_out, "postprocess_on_device": post, "pcie_inclusive": pcie,
+        "roofline": roof, "cpu_baseline": cpu, "repeat_workload": rep_out, "harsh_repeat_workload": harsh_out, "harsh2_repeat_workload": harsh2_out, "hic_workload": hic_out, "config3_full_size_pass": cfg3, "postprocess_on_device": post, "pcie_inclusive": pcie,
         "stage_ms_per_step": {k: round(v / steps, 3) for k, v in stage_ms.items()},
         "stage_ms_note": "HIP events of the calling thread's lane (1 / %d of the batch when lanes > 1; the lanes overlap)" % args.lanes,
         "counters_per_step": {k: v // steps for k, v in s.items()},
         "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),
+        "pairs_mapped_in_process": MAPPED["pairs"], "s3b_label": args.headline_repeats or "headline",
     }
     if exchange:
         out["exchange"] = {"ranks": world, "transport": "RCCL (ncclAllGather of counts + grouped ncclSend/ncclRecv) on the mapping stream",

@@ -104,7 +104,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref",
            "cmgpu_create_synthetic_repeats", "cmgpu_create_synthetic_profile", "cmgpu_generate_resident_batch_indels", "cmgpu_generate_resident_batch_hic", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
            "cmgpu_exchange_unique_id", "cmgpu_exchange_init", "cmgpu_exchange_init_all", "cmgpu_exchange_init_external",
-           "cmgpu_exchange_owner_table", "cmgpu_exchange_step", "cmgpu_exchange_info", "cmgpu_exchange_finalize", "cmgpu_memcpy", "cmgpu_copy_whitelist",
+           "cmgpu_exchange_owner_table", "cmgpu_exchange_step", "cmgpu_exchange_info", "cmgpu_exchange_plan", "cmgpu_exchange_finalize", "cmgpu_memcpy", "cmgpu_copy_whitelist",
            "cmgpu_host_alloc", "cmgpu_host_free", "cmgpu_host_register", "cmgpu_host_unregister", "cmgpu_submit_pairs", "cmgpu_map_submitted", "cmgpu_map_submitted_async", "cmgpu_records_wait",
            "cmgpu_debug_trace", "cmgpu_debug_minimizers", "cmgpu_debug_minimizers_all", "cmgpu_debug_array")
 

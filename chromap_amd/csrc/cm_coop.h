@@ -33,16 +33,23 @@ CM_HD unsigned long long cm_fetch_add64(unsigned long long *p, unsigned long lon
 }
 // measurement aid: lane 0 of a group adds the shader-clock cycles since its last mark to d.prof[k] (nullptr: nothing)
 #if defined(__HIP_DEVICE_COMPILE__)
-#define CM_PROF_BEGIN(d) long long cm_prof_t_ = (d).prof ? clock64() : 0
-#define CM_PROF_MARK(d, g, k) do { if ((d).prof && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(d).prof[k], (unsigned long long)(now_ - cm_prof_t_)); cm_prof_t_ = now_; } } while (0)
-#define CM_PROF_COUNT(d, g, k, v) do { if ((d).prof && (g).t == 0) atomicAdd(&(d).prof[k], (unsigned long long)(v)); } while (0)
-#define CM_PROF_PTR_BEGIN(p) long long cm_prof_u_ = (p) ? clock64() : 0
-#define CM_PROF_PTR_MARK(p, g, k) do { if ((p) && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(p)[k], (unsigned long long)(now_ - cm_prof_u_)); cm_prof_u_ = now_; } } while (0)
+// (one block in 32 is timed: an atomic per mark and group from every block of a launch -- millions on one address, which retire at
+// ~90 per microsecond -- made the global-memory phases read 5-10 x too long in round 5's tables)
+#define CM_PROF_ON(p) ((p) && (blockIdx.x & 31u) == 0u)
+#define CM_PROF_BEGIN(d) long long cm_prof_t_ = CM_PROF_ON((d).prof) ? clock64() : 0
+#define CM_PROF_MARK(d, g, k) do { if (CM_PROF_ON((d).prof) && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(d).prof[k], (unsigned long long)(now_ - cm_prof_t_)); cm_prof_t_ = clock64(); } } while (0)
+#define CM_PROF_RESET(d) do { if (CM_PROF_ON((d).prof)) cm_prof_t_ = clock64(); } while (0)
+#define CM_PROF_COUNT(d, g, k, v) do { if (CM_PROF_ON((d).prof) && (g).t == 0) atomicAdd(&(d).prof[k], (unsigned long long)(v)); } while (0)
+#define CM_PROF_PTR_COUNT(p, g, k, v) do { if ((p) && (g).t == 0) atomicAdd(&(p)[k], (unsigned long long)(v)); } while (0)
+#define CM_PROF_PTR_BEGIN(p) long long cm_prof_u_ = CM_PROF_ON(p) ? clock64() : 0
+#define CM_PROF_PTR_MARK(p, g, k) do { if (CM_PROF_ON(p) && (g).t == 0) { const long long now_ = clock64(); atomicAdd(&(p)[k], (unsigned long long)(now_ - cm_prof_u_)); cm_prof_u_ = clock64(); } } while (0)
 #else
+#define CM_PROF_PTR_COUNT(p, g, k, v) do { } while (0)
 #define CM_PROF_PTR_BEGIN(p) do { } while (0)
 #define CM_PROF_PTR_MARK(p, g, k) do { } while (0)
 #define CM_PROF_BEGIN(d) do { } while (0)
 #define CM_PROF_MARK(d, g, k) do { } while (0)
+#define CM_PROF_RESET(d) do { } while (0)
 #define CM_PROF_COUNT(d, g, k, v) do { } while (0)
 #endif
 // entries per lane when a list of n is cut into one contiguous chunk per lane.  (Making it odd, so that sixteen consecutive lanes
@@ -313,6 +320,7 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
   const uint64_t SB = 1ull << 63;
   const uint32_t wl = g.t % W, wv = g.t / W;
   uint32_t *const choff = m.rb2;  // first piece of every run (R + 1 entries; rb2 is free until the merge)
+  CM_PROF_BEGIN(d);
   // ---- included minimizers: where their occurrences start in the list, and their pieces
   uint32_t R = 0, off = 0, NC = 0;
   for (uint32_t base = 0; base < n; base += G) {
@@ -346,6 +354,7 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
   for (uint32_t ri = g.t; ri < R; ri += G)
     for (uint32_t c = choff[ri]; c < choff[ri + 1]; ++c) chrun[c] = (uint16_t)ri;
   g.sync();
+  CM_PROF_MARK(d, g, 0);
   // ---- pass 1: four pieces per wave part and round, their loads in flight together
   uint32_t wrapped = 0;
   for (uint32_t cb = wv; cb < NC; cb += 4 * NW) {
@@ -383,6 +392,7 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
     }
   }
   g.sync();
+  CM_PROF_MARK(d, g, 1);
   // ---- + hits before every piece
   uint32_t np = 0, any_wrapped = 0;
   for (uint32_t base = 0; base < NC || base == 0; base += G) {
@@ -397,6 +407,7 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
   if (any_wrapped) return 0;
   if (g.t == 0) cplus[NC] = (uint16_t)np;
   g.sync();
+  CM_PROF_MARK(d, g, 3);
   // ---- pass 2: the two lists, and their run tables: + runs 0 .. R - 1, empty ones up to P2, then the - runs
   for (uint32_t c = wv; c < NC; c += NW) {
     const uint32_t ri = chrun[c], o0 = m.moff[ri], j = (c - choff[ri]) * W + wl;
@@ -417,6 +428,7 @@ CM_HD uint32_t cm_coop_s3b_expand(const CmDev &d, uint32_t r, GT &g, const CmCoo
     m.rb[q] = v;
   }
   g.sync();
+  CM_PROF_MARK(d, g, 2);
   *np_out = np;
   *nr_out = P2 + R;
   return levels + 1;
@@ -433,7 +445,7 @@ CM_HD bool cm_coop_s3b_k32(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m
   uint32_t np, nr;
   const uint32_t lv = cm_coop_s3b_expand<uint32_t>(d, r, g, m, m.A32, m.B32, tot, &np, &nr);
   if (lv == 0) return false;
-  CM_PROF_MARK(d, g, 1);
+  CM_PROF_RESET(d);
   uint32_t *S = cm_coop_merge_runs(g, m.A32, m.B32, m.rb, m.rb2, nr, tot, lv - 1);
   CM_PROF_MARK(d, g, 4);
   CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
@@ -468,7 +480,7 @@ CM_HD bool cm_coop_s3b(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
     uint32_t nr;
     const uint32_t lv = cm_coop_s3b_expand<uint64_t>(d, r, g, m, A, B, tot, &np, &nr);
     if (lv == 0) return false;
-    CM_PROF_MARK(d, g, 1);
+    CM_PROF_RESET(d);
     S = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, tot, lv - 1);
     CM_PROF_MARK(d, g, 4);
     CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
@@ -1527,7 +1539,7 @@ CM_HD uint32_t cm_coop_draft_strand(const CmDev &d, GT &g, const CmCoopVerMem &m
 // ---------------------------------------------------------------------------------------
 template <class GT>
 CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_t *sp, uint8_t *sc, uint16_t *hist, uint32_t nb_cap,
-                             uint64_t *lp = nullptr, uint8_t *lc = nullptr, uint32_t lcap = 0) {
+                             uint64_t *lp = nullptr, uint8_t *lc = nullptr, uint32_t lcap = 0, unsigned long long *prof = nullptr) {
   const uint32_t G = (uint32_t)GT::G;
   if (n < 2) return;
   // lp / lc (shared memory, lcap entries): a list that fits is staged there once and scattered from there straight to its final
@@ -1549,6 +1561,7 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
   bad = g.sum(bad);
   mx = g.max64(mx);
   if (bad || mx >= nb_cap || n > 0xffffu) {
+    CM_PROF_PTR_COUNT(prof, g, bad ? 7 : 47, 1);
     if (g.t == 0) cm_sort_cand(p, c, n);
     g.sync();
     return;
@@ -1689,8 +1702,8 @@ template <class GT>
 CM_HD void cm_coop_s5_sort(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap, uint64_t *lp = nullptr, uint8_t *lc = nullptr,
                            uint32_t lcap = 0) {
   const uint32_t op = d.m_off[r], on = op + d.ncp[r] + d.resc_p[r];
-  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, d.fcp[r], d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap, lp, lc, lcap);
-  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap, lp, lc, lcap);
+  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, d.fcp[r], d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap, lp, lc, lcap, d.prof);
+  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap, lp, lc, lcap, d.prof);
 }
 // S5c for such a read (its alignments are in v_err / v_end)
 // sm: work area of the draft-mapping sort that follows the acceptance loop (it may overlay m: the loop's arrays are dead by then)

@@ -387,6 +387,39 @@ extern "C" int cmgpu_exchange_info(const cmgpu_ctx *c, int *rank, int *world, ui
 }
 
 // ---------------------------------------------------------------------------------------
+// The communication plan of one round for rank `me`, from the count matrix every rank holds after the first all-gather
+// (M[r * stride + j] = records rank r sends to rank j).  What cmgpu_exchange_step posts, in this order, and nothing else:
+//   CM_EX_ALLGATHER_COUNTS, CM_EX_ALLGATHER_STATUS   unconditional (world > 1 for the status word) -- an empty rank takes part;
+//   CM_EX_COPY_SELF                                  its own records (no peer involved);
+//   one group of CM_EX_SEND / CM_EX_RECV             for d = 1 .. world - 1: send to me + d, receive from me - d (staggered:
+//                                                    no rank is everybody's first target), a pair only when ITS matrix entry is
+//                                                    non-zero -- the sender reads M[me][peer], the receiver the same entry
+//                                                    M[src][me], so a Send is posted iff its Recv is.
+// A pure function of (me, world, M): tests/test_exchange_plan.py replays it for every rank of a world on the CPU and checks
+// that the rounds cannot deadlock (same collectives on every rank, every Send met by one Recv of the same size in the same group).
+// ---------------------------------------------------------------------------------------
+std::vector<cmgpu_exchange_op> cm_exchange_plan(uint32_t me, uint32_t world, const uint64_t *M, uint32_t stride) {
+  std::vector<cmgpu_exchange_op> ops;
+  ops.push_back({CMGPU_EX_ALLGATHER_COUNTS, 0, (uint64_t)stride});
+  if (world > 1) ops.push_back({CMGPU_EX_ALLGATHER_STATUS, 0, 1});
+  if (M[(size_t)me * stride + me]) ops.push_back({CMGPU_EX_COPY_SELF, me, M[(size_t)me * stride + me]});
+  for (uint32_t d = 1; d < world; ++d) {
+    const uint32_t peer = (me + d) % world, src = (me + world - d) % world;
+    if (M[(size_t)me * stride + peer]) ops.push_back({CMGPU_EX_SEND, peer, M[(size_t)me * stride + peer]});
+    if (M[(size_t)src * stride + me]) ops.push_back({CMGPU_EX_RECV, src, M[(size_t)src * stride + me]});
+  }
+  return ops;
+}
+extern "C" int cmgpu_exchange_plan(uint32_t rank, uint32_t world, const uint64_t *matrix, cmgpu_exchange_op *ops, uint32_t capacity, uint32_t *n_ops) {
+  if (!matrix || !n_ops || world == 0 || world > EX_MAX_WORLD || rank >= world) return CMGPU_EINVAL;
+  const std::vector<cmgpu_exchange_op> p = cm_exchange_plan(rank, world, matrix, world);
+  *n_ops = (uint32_t)p.size();
+  if (p.size() > capacity) return ops ? CMGPU_ECAPACITY : CMGPU_OK;
+  for (size_t i = 0; ops && i < p.size(); ++i) ops[i] = p[i];
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // one round
 // ---------------------------------------------------------------------------------------
 extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64_t *n_received) {
@@ -439,6 +472,7 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
   }
   if (rb == 0) rb = 24;
   const bool bc = rb == 32;
+  const std::vector<uint64_t> mat(M, M + (size_t)world * stride);  // (the status round below reuses M)
   uint64_t send_cnt[EX_MAX_WORLD], recv_cnt[EX_MAX_WORLD], send_off[EX_MAX_WORLD], recv_off[EX_MAX_WORLD], tot_s = 0, tot_r = 0;
   for (uint32_t r = 0; r < world; ++r) {
     send_cnt[r] = M[(size_t)me * stride + r];
@@ -500,22 +534,22 @@ extern "C" int cmgpu_exchange_step(cmgpu_ctx *c, uint64_t *sent_per_rank, uint64
       EXCHECK(c, hipEventRecord(x.ev_part, s));
       EXCHECK(c, hipStreamWaitEvent(ps, x.ev_part, 0));
     }
-    if (send_cnt[me]) {
-      const uint64_t bytes = send_cnt[me] * rb;
-      uint64_t blocks = (bytes / 8 + EX_BLOCK * 8 - 1) / (EX_BLOCK * 8);
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(k_ex_copy, dim3((unsigned)blocks), dim3(EX_BLOCK), 0, ps, (const uint8_t *)x.send.p + send_off[me] * rb, dest + recv_off[me] * rb, bytes);
-    }
-    if (world > 1) {
-      NCCLCHECK(c, api, api->GroupStart());
-      for (uint32_t d = 1; d < world; ++d) {
-        const uint32_t peer = (me + d) % world;  // staggered so that no rank is everybody's first target
-        if (send_cnt[peer]) NCCLCHECK(c, api, api->Send((const uint8_t *)x.send.p + send_off[peer] * rb, send_cnt[peer] * rb, ncclUint8, (int)peer, (ncclComm_t)x.comm, ps));
-        const uint32_t src = (me + world - d) % world;
-        if (recv_cnt[src]) NCCLCHECK(c, api, api->Recv(dest + recv_off[src] * rb, recv_cnt[src] * rb, ncclUint8, (int)src, (ncclComm_t)x.comm, ps));
+    // (the posts follow cm_exchange_plan: the all-gathers above were its first entries)
+    const std::vector<cmgpu_exchange_op> plan = cm_exchange_plan(me, world, mat.data(), stride);
+    bool in_group = false;
+    for (const cmgpu_exchange_op &op : plan) {
+      if (op.kind == CMGPU_EX_COPY_SELF) {
+        const uint64_t bytes = op.records * rb;
+        uint64_t blocks = (bytes / 8 + EX_BLOCK * 8 - 1) / (EX_BLOCK * 8);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_ex_copy, dim3((unsigned)blocks), dim3(EX_BLOCK), 0, ps, (const uint8_t *)x.send.p + send_off[me] * rb, dest + recv_off[me] * rb, bytes);
+      } else if (op.kind == CMGPU_EX_SEND || op.kind == CMGPU_EX_RECV) {
+        if (!in_group) { NCCLCHECK(c, api, api->GroupStart()); in_group = true; }
+        if (op.kind == CMGPU_EX_SEND) NCCLCHECK(c, api, api->Send((const uint8_t *)x.send.p + send_off[op.peer] * rb, op.records * rb, ncclUint8, (int)op.peer, (ncclComm_t)x.comm, ps));
+        else NCCLCHECK(c, api, api->Recv(dest + recv_off[op.peer] * rb, op.records * rb, ncclUint8, (int)op.peer, (ncclComm_t)x.comm, ps));
       }
-      NCCLCHECK(c, api, api->GroupEnd());
     }
+    if (in_group) NCCLCHECK(c, api, api->GroupEnd());
     if (tot_r && bc) cm_store_split_bc(c, dest, tot_r, ps);
     if (overlap) {
       EXCHECK(c, hipEventRecord(x.ev_payload, ps));

@@ -1159,8 +1159,14 @@ __global__ __launch_bounds__(CM_BLOCK, 8) void k_s5_sort_coop(CmDev d, uint32_t 
   CmDevGroup<64> g;
   g.t = threadIdx.x % 64;
   g.xw = nullptr;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb)
+  const long long t0 = d.prof ? clock64() : 0;
+  uint32_t mine = 0;
+  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb, ++mine)
     cm_coop_s5_sort(d, list[j], g, nullptr, CM_SORT_NB, stage_p + (size_t)grp * CM_SORT_STAGE, stage_c + (size_t)grp * CM_SORT_STAGE, CM_SORT_STAGE);
+  if (d.prof && g.t == 0 && mine) {  // measurement aid (tools/coop_profile.py): a sorting wave's cycles and reads
+    const unsigned long long dt = (unsigned long long)(clock64() - t0);
+    atomicAdd(&d.prof[38], dt); atomicMax(&d.prof[39], dt); atomicAdd(&d.prof[6], (unsigned long long)mine);
+  }
 }
 #define CM_S5C_SORT_P 1024u  // draft mappings a wave sorts in shared memory (longer lists: in global memory)
 #define CM_S5C_SORT_RB 130u

@@ -357,6 +357,18 @@ int cmgpu_exchange_owner_table(const cmgpu_ctx *ctx, uint32_t world, uint8_t *ow
  * context's store.  sent_per_rank: world entries or NULL. */
 int cmgpu_exchange_step(cmgpu_ctx *ctx, uint64_t *sent_per_rank, uint64_t *n_received);
 int cmgpu_exchange_info(const cmgpu_ctx *ctx, int *rank, int *world, uint64_t *records_sent, uint64_t *records_received);
+/* The communication plan of one cmgpu_exchange_step round for `rank`, given the world x world count matrix (row r = the
+ * records rank r sends to every rank) that the round's first all-gather hands to every rank: the collectives, the local copy
+ * and the grouped sends / receives the step posts, in its order.  A pure host function (no device, no RCCL): multi-process
+ * callers and tests replay it for all ranks to see that a round's posts meet (every send has its receive, every rank calls
+ * the same collectives -- also a rank without records).  capacity < *n_ops: CMGPU_ECAPACITY (ops == NULL: just the count). */
+typedef struct cmgpu_exchange_op {
+  uint32_t kind;    /* CMGPU_EX_* */
+  uint32_t peer;    /* send: destination, receive: source, copy: the rank itself */
+  uint64_t records; /* records moved (all-gathers: 64-bit words contributed per rank) */
+} cmgpu_exchange_op;
+enum { CMGPU_EX_ALLGATHER_COUNTS = 0, CMGPU_EX_ALLGATHER_STATUS = 1, CMGPU_EX_COPY_SELF = 2, CMGPU_EX_SEND = 3, CMGPU_EX_RECV = 4 };
+int cmgpu_exchange_plan(uint32_t rank, uint32_t world, const uint64_t *matrix, cmgpu_exchange_op *ops, uint32_t capacity, uint32_t *n_ops);
 int cmgpu_exchange_finalize(cmgpu_ctx *ctx);
 /* host <-> device copy through the library's HIP runtime, for a host-staged transport; kind 1: host -> device, 2: device -> host */
 int cmgpu_memcpy(cmgpu_ctx *ctx, void *dst, const void *src, uint64_t bytes, int kind);

@@ -24,7 +24,7 @@ def main():
     for _ in range(3):
         g.map_resident(Stats())
     v = [g.get_option("coop_profile_%d" % k) for k in range(48)]
-    names = ["run table + scan", "expand (occurrence loads)", "strand partition", "natural runs", "merge levels", "cluster sweep"]
+    names = ["run table + scan (header loads)", "expand pass 1 (occurrence loads)", "pass 2 (strand partition)", "scan of the pieces' + counts", "merge levels", "cluster sweep"]
     tot = float(sum(v[:6])) or 1.0
     n = max(1, v[8])
     print("groups %d, mean hits %.0f, mean runs %.1f, mean cycles per group %.0f" % (n, v[10] / n, v[9] / n, tot / n))
@@ -41,6 +41,8 @@ def main():
     print("  k_s4b_rescue_list likewise: wave-per-read %d / %d, lane-per-read %d / %d, 16-lanes-per-read %d / %d" % (v[32], v[33], v[34], v[35], v[36], v[37]))
     print("  windows < 4: %d, < 16: %d, < 64: %d, < 300: %d" % (v[22], v[23], v[24], v[25]))
     print("  wave kernel (a wave per read), larger of the two searches' best mate candidates: < 16: %d, < 32: %d, < 64: %d, < 128: %d, < 200: %d, < 300: %d, more: %d" % tuple(v[40:47]))
+    print("k_s5_sort_coop: %d reads, %.0f cycles of a wave per read, longest wave %d cycles; lists left to lane 0: %d not in position order, %d other"
+          % (v[6], v[38] / max(1, v[6]), v[39], v[7], v[47]))
     print("timings of the last batch:", g.timings())
 
 

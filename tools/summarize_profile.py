@@ -75,13 +75,18 @@ def main():
     # roofline.kernel_shape), its 64-byte sectors per lookup, and the calibration of FETCH_SIZE on the gather
     # microbenchmark of known byte count (same access width, 4 loads per lane)
     out = {}
-    shape, lookups = None, None
+    shape, lookups, bj = None, None, {}
     try:
         bj = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
         shape = bj["roofline"].get("kernel_shape")
         lookups = bj["roofline"]["probe_only"]["lookups"]
     except Exception:
         pass
+    # what the numbers were measured ON: bench.py refuses the file when its own sources / launch differ
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sha = bench.probe_source_sha()
+    commit = os.environ.get("GRAFT_HEAD", "unknown")
     want = "k_probe<%d; %s>" % (shape["lookups_per_lane"], "true" if shape["pair_prefetch"] else "false") if shape else None
     per_shape = {}
     for k in fe:
@@ -96,6 +101,9 @@ def main():
         out = {"kernel": pick, "workload": "bench.py default (4M pairs/step, GRCh38-sized synthetic index), the graded launch only "
                                            "(bench.py --graded-probe-only: the table the pipeline probes)"}
         out.update(per_shape[pick])
+        out["lookups"] = lookups
+        out["source_sha"] = sha
+        out["commit"] = commit
         out["all_shapes"] = per_shape
     for k in fe:
         if k.startswith("k_gather<4; false>"):
@@ -105,6 +113,23 @@ def main():
     with open(os.path.join(dst, "probe_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
+    # the candidate stage's HBM bytes per pass over one batch (bench.py: roofline.s3b / roofline_s3b): every k_s3b_* dispatch of the
+    # PMC passes, divided by the pairs those passes mapped (bench.py counts them: pairs_mapped_in_process), times the pass's pairs
+    try:
+        tot = sum((fe[k][0] if k in fe else 0.0) + (wr[k][0] if k in wr else 0.0) for k in set(fe) | set(wr) if k.startswith("k_s3b_")) * 1024.0
+        fj = json.loads(open(os.path.join(src, "fetch_bench.json")).read().strip().splitlines()[-1])  # the FETCH_SIZE pass's own line
+        pm = fj.get("pairs_mapped_in_process")
+        rs = bj.get("roofline", {}).get("s3b") or {}
+        if pm and rs:
+            label = bj.get("s3b_label", "headline")
+            s3 = {label: {"pairs": rs["pairs"], "hbm_bytes_per_pass": int(tot / pm * rs["pairs"]), "hbm_bytes_per_pair": round(tot / pm, 2),
+                          "pairs_mapped_in_pmc_pass": pm, "source_sha": sha, "commit": commit,
+                          "how": "sum of FETCH_SIZE + WRITE_SIZE (separate passes) over all k_s3b_* dispatches / pairs mapped in that process x pairs of the pass"}}
+            with open(os.path.join(dst, "s3b_traffic.json"), "w") as f:
+                json.dump(s3, f, indent=1)
+            print(json.dumps(s3))
+    except Exception as e:
+        print("s3b traffic: not derived (%r)" % (e,))
 
 
 if __name__ == "__main__":
