@@ -505,7 +505,7 @@ def main():
             g_.set_option("probe_table_shift", args.probe_table_shift)
         for o in args.option:
             k_, v_ = o.split("=")
-            g_.set_option(k_, int(v_))
+            g_.set_option(k_, int(v_, 0))
         return g_
 
     t0 = time.time()

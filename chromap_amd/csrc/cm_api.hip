@@ -121,7 +121,7 @@ extern "C" int cmgpu_set_option(cmgpu_ctx *c, const char *name, int64_t value) {
     if (value > 0 && cm_ensure_candidate_arrays(c, (uint64_t)value)) { cm_set_error(c, "out of device memory (candidates)"); return CMGPU_ENOMEM; }
     c->pred_m_ok = value > 0; c->m_cap = (uint64_t)value; c->pred_n = 0xffffffffu;  // (any batch size)
   } else if (n == "coop_profile") {  // measurement aid: per-phase cycle sums of k_s3b_coop (cmgpu_get_option coop_profile_0 .. _15)
-    if (value) { if (c->coop_prof.ensure(48 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 48 * 8)); } else c->coop_prof.release();
+    if (value) { if (c->coop_prof.ensure(64 * 8)) return CMGPU_ENOMEM; HIPCHECK(c, hipMemset(c->coop_prof.p, 0, 64 * 8)); } else c->coop_prof.release();
   } else if (n == "coop_run_table") {  // tests: a small table makes the cooperative sorters decline reads (their fallback paths)
     c->opt_coop_rb = (int)value;
   } else if (n == "coop") {  // bit mask of the stages whose long lists go to groups of lanes (cm_coop.h)
@@ -151,7 +151,7 @@ extern "C" int cmgpu_get_option(const cmgpu_ctx *c, const char *name, int64_t *v
   else if (n.rfind("coop_profile_", 0) == 0) {
     const int k = atoi(n.c_str() + 13);
     unsigned long long v = 0;
-    if (k < 0 || k > 47 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
+    if (k < 0 || k > 63 || !c->coop_prof.p || hipMemcpy(&v, (const unsigned long long *)c->coop_prof.p + k, 8, hipMemcpyDeviceToHost) != hipSuccess) return CMGPU_EINVAL;
     *value = (int64_t)v;
   }
   else if (n == "probe_table_buckets") *value = c->fmask ? (int64_t)c->fmask + 1 : (int64_t)c->bmask + 1;
@@ -763,6 +763,7 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
   d.rs_pool = (uint64_t *)c->rs_pool.p; d.rs_pool_cap = c->rs_pool.p ? c->rs_pool_cap : 0u; d.rs_pool_off = (uint32_t *)c->rs_pool_off.p;
   d.abort = (const unsigned long long *)c->stats.p + CM_ST_ABORT;
   d.coop_rb = c->opt_coop_rb > 0 ? (uint32_t)c->opt_coop_rb : 0u;
+  d.wq_dynamic = ((uint32_t)c->opt_coop >> 16) & 1u;
   d.s3b_cap = c->opt_s3b_cap > 0 ? (uint32_t)c->opt_s3b_cap : cm_s3b_lane_cap(c->max_read_len);
   if (c->n_seq < 0x80000000u) {  // the cooperative kernel keeps the strand in bit 31 of the sequence id
     cm_s3b_heavy_classes(d.hv_max, &d.hv_big);

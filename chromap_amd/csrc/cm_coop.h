@@ -886,6 +886,7 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
   const uint32_t G = (uint32_t)GT::G;
   *n_out = 0;
   *rep_len_out = 0;
+  CM_PROF_BEGIN(d);
   // ---- the best count among the mate's candidates and how many have it
   uint32_t lmax = 0;
   for (uint32_t i = g.t; i < mn; i += G) lmax = mc[i] > lmax ? mc[i] : lmax;
@@ -928,6 +929,8 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
     W += tot;
   }
   g.sync();  // (bp is dead from here on: pa / pb overlay it)
+  CM_PROF_MARK(d, g, 48);
+  CM_PROF_COUNT(d, g, 55, 1);
   // ---- the minimizers, CM_RESCUE_SLOTS (or as many as m.pairs pairs hold) per round
   const uint32_t b = d.mm_off[r], n = d.mm_cnt[r];
   const bool no_window = W == 0;  // (no mate candidate: cm_rescue then finds the singletons only; callers do not ask)
@@ -950,6 +953,7 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       m.mps[s] = ps;
     }
     g.sync();
+    CM_PROF_MARK(d, g, 49);
     const uint32_t np = ns * W;
     // -- A: bounds of every (minimizer, window) pair, four pairs interleaved per lane -- the searches are chains of dependent loads at
     //    global-memory latency and nothing else, so the requests in flight per lane are what the phase's duration divides by.  The lower
@@ -977,6 +981,9 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
         }
       }
       for (;;) {  // lower bounds: first index with o >> 1 >= es
+        // (round 6, measured and not kept: the range cut in four per step -- three probes requested together, ~7 dependent trips instead of
+        //  ~14 -- made the phase SLOWER, 70 k -> 88 k cycles per search on profile 2: with four pairs interleaved per lane and 20-30 waves
+        //  per CU the occurrence table's random reads are bound by their number, not by the chain's length)
         bool any = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -1022,6 +1029,7 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       }
     }
     g.sync();
+    CM_PROF_MARK(d, g, 50);
     // occurrences at exactly es (two at most: one per strand; none for an index built by the reference, whose minimizers have one strand
     // per position): the search's "equal" outcome for the midpoints lb .. lb + eq - 1
     for (uint32_t q = g.t; q < np; q += G) {
@@ -1073,17 +1081,74 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       m.tq[q] = t;
     }
     g.sync();
+    // Round 6: B2 in three steps.  (a) A lane per minimizer follows the chain through the tables ALONE -- state = where the previous window's
+    // search ended relative to its lower bound (0 .. 2, a table entry), one shift per window, the table bytes four at a time and not
+    // dependent on the state; an unusable table (0xff) yields state 3.  The state goes to the two free top bits of pb.  (b) A lane per
+    // pair checks what (a) took for granted: a usable table, and the start it implies inside the run; a minimizer with a window that
+    // fails is flagged (bit 30 of mps).  (c) A lane per pair writes first index / length from its own lower bound and state; the flagged
+    // minimizers are replayed window by window as in round 5 (exact whatever the tables are worth).  Round 5 did ALL of it in (a)'s
+    // loop: three dependent shared-memory reads, a dozen instructions and two writes per window on ns of 64 lanes -- for a search with
+    // 200 windows longer than phase A's loads (tools/coop_profile.py: 110 k of a search's 280 k cycles).
+    for (uint32_t s = g.t; s < ns; s += G) {
+      if ((m.mps[s] >> 31) || (uint32_t)m.mval[s] == 0 || (uint32_t)m.mval[s] >= (1u << 30)) continue;  // (a run that long: bounds take all 32 bits -- replayed)
+      const uint8_t *tqs = m.tq + (size_t)s * W;
+      uint32_t *pbs = m.pb + (size_t)s * W;
+      uint32_t st = 1;  // (window 0's three entries are equal: any state will do)
+      uint32_t w = 0;
+      for (; w + 4 <= W; w += 4) {
+        const uint32_t t0 = tqs[w], t1 = tqs[w + 1], t2 = tqs[w + 2], t3 = tqs[w + 3];
+        const uint32_t u0 = pbs[w], u1 = pbs[w + 1], u2 = pbs[w + 2], u3 = pbs[w + 3];
+        st = (t0 >> (2 * st)) & 3u; pbs[w] = u0 | st << 30;
+        st = (t1 >> (2 * st)) & 3u; pbs[w + 1] = u1 | st << 30;
+        st = (t2 >> (2 * st)) & 3u; pbs[w + 2] = u2 | st << 30;
+        st = (t3 >> (2 * st)) & 3u; pbs[w + 3] = u3 | st << 30;
+      }
+      for (; w < W; ++w) { st = ((uint32_t)tqs[w] >> (2 * st)) & 3u; pbs[w] |= st << 30; }
+    }
+    g.sync();
+    for (uint32_t q = g.t; q < np; q += G) {
+      const uint32_t s = q / W, w = q - s * W;
+      if (m.mps[s] >> 31) continue;
+      const uint32_t nocc = (uint32_t)m.mval[s];
+      if (!nocc) continue;
+      const uint32_t st = m.pb[q] >> 30;
+      bool ok = st != 3u && m.tq[q] != 0xff && nocc < (1u << 30);
+      if (w) {  // the start of this window's search: the previous window's last midpoint, inside the run
+        const uint32_t pst = m.pb[q - 1] >> 30;
+        const int32_t prev_l = (int32_t)(m.pa[q - 1] & 0x3fffffffu) + (int32_t)pst - 1;
+        ok = ok && pst != 3u && prev_l >= 0 && prev_l <= (int32_t)nocc - 1;
+      }
+#ifdef CM_DBG_FORCE_REPLAY
+      if (CM_DBG_FORCE_REPLAY && (s & 1u)) ok = false;  // (tests: no table has been seen to fail -- the replay is exercised by decree)
+#endif
+      if (!ok) m.mps[s] |= 1u << 30;  // (every lane that writes, writes the same bit)
+    }
+    g.sync();
+    for (uint32_t q = g.t; q < np; q += G) {
+      const uint32_t s = q / W, w = q - s * W;
+      const uint32_t ps = m.mps[s];
+      if (ps >> 31) { m.pa[q] = 0; m.pb[q] = w == 0 ? 1u : 0u; continue; }  // a singleton: its one occurrence, whatever the windows (cm_rescue_minimizer)
+      const uint32_t nocc = (uint32_t)m.mval[s];
+      if (!nocc) { m.pa[q] = 0; m.pb[q] = 0; continue; }
+      if (ps & (1u << 30)) continue;  // replayed below
+      const uint32_t x = m.pb[q], ub = x & 0x3fffffffu;
+      const uint32_t first = (uint32_t)((int32_t)(m.pa[q] & 0x3fffffffu) + (int32_t)(x >> 30) - 1);
+      m.pa[q] = first;
+      m.pb[q] = ub > first && !no_window ? ub - first : 0u;
+    }
+    g.sync();  // (the flags are read above and cleared below)
     for (uint32_t s = g.t; s < ns; s += G) {
       const uint32_t ps = m.mps[s];
+      if ((ps >> 31) || !(ps & (1u << 30))) continue;
+#ifdef CM_DBG_REPLAY
+      ++CM_DBG_REPLAY;
+#endif
+      m.mps[s] = ps & ~(1u << 30);
       const uint64_t val = m.mval[s];
-      if (ps >> 31) {  // a singleton: its one occurrence, whatever the windows (cm_rescue_minimizer)
-        for (uint32_t w = 0; w < W; ++w) { m.pa[s * W + w] = 0; m.pb[s * W + w] = w == 0 ? 1u : 0u; }
-        continue;
-      }
       const uint32_t nocc = (uint32_t)val;
       int32_t prev_l = 0, lbp = 0;
       for (uint32_t w = 0; w < W; ++w) {
-        const uint32_t lbx = m.pa[s * W + w], ub = m.pb[s * W + w];
+        const uint32_t lbx = m.pa[s * W + w], ub = nocc < (1u << 30) ? m.pb[s * W + w] & 0x3fffffffu : m.pb[s * W + w];
         uint32_t first = 0, len = 0;
         if (nocc) {
           const int32_t lb = (int32_t)(lbx & 0x3fffffffu), le = lb + (int32_t)(lbx >> 30);
@@ -1112,6 +1177,7 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       }
     }
     g.sync();
+    CM_PROF_MARK(d, g, 51);
     // -- C: exclusive scan of the lengths in pair order (pb), then the occurrences themselves
     uint32_t total;
     {
@@ -1124,38 +1190,73 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
       if (g.t == 0) m.pb[np] = total;
       g.sync();
     }
-    const uint32_t cnt_before = cnt;
-    cm_coop_rescue_emit(d, g, m, np, W, total, strand, out, &cnt);
     // counting pass with the pool at hand: the round's hits are written there right away, as a piece of their own -- one header entry
     // (hits << 32 | index of the search's next piece, all ones: none), then the hits -- so that the fill pass copies instead of finding the
     // bounds a second time (phase A: ~17 dependent random reads of the occurrence table per pair, which is what a search costs).  Round 4
     // kept only searches whose tables fit one round; the searches that take several are the long ones (200 windows and more).
-    if (pool_ok && cnt > cnt_before) {
-      const uint32_t cr = cnt - cnt_before;
-      const uint32_t at = cm_coop_pool_take(d, g, m, cr + 1u);
+    // Round 6: ONE pass over the occurrences instead of a counting one and a writing one -- the piece is taken for `total` hits (the
+    // ranges' occurrences on both strands), what the wanted strand leaves unused goes back to the group's grant.
+    bool emitted = false;
+    if (pool_ok && total > 0) {
+      const uint32_t at = cm_coop_pool_take(d, g, m, total + 1u);
       if (at != 0xffffffffu) {
         uint32_t c2 = 0;
         cm_coop_rescue_emit(d, g, m, np, W, total, strand, d.rs_pool + at + 1, &c2);
+        emitted = true;
+        cnt += c2;
         if (g.t == 0) {
-          d.rs_pool[at] = ((uint64_t)cr << 32) | 0xffffffffull;
-          if (pool_last != 0xffffffffu) d.rs_pool[pool_last] = ((uint64_t)pool_last_cnt << 32) | at;
+          // (give back: only when the piece is the last thing the grant handed out -- it is, unless it was cut from the pool's last entries)
+          const uint32_t used = c2 ? c2 + 1u : 0u;
+          if (m.arena[1] != 0xffffffffu && m.arena[0] == at + total + 1u) { m.arena[0] = at + used; m.arena[1] += total + 1u - used; }
+          if (c2) {
+            d.rs_pool[at] = ((uint64_t)c2 << 32) | 0xffffffffull;
+            if (pool_last != 0xffffffffu) d.rs_pool[pool_last] = ((uint64_t)pool_last_cnt << 32) | at;
+          }
         }
-        if (pool_first == 0xffffffffu) pool_first = at;
-        pool_last = at; pool_last_cnt = cr;
+        if (c2) {
+          if (pool_first == 0xffffffffu) pool_first = at;
+          pool_last = at; pool_last_cnt = c2;
+        }
       } else {
         pool_ok = false;  // no room: the fill pass searches again
       }
     }
+    if (!emitted) cm_coop_rescue_emit(d, g, m, np, W, total, strand, out, &cnt);
+    CM_PROF_MARK(d, g, 52);
+    CM_PROF_COUNT(d, g, 56, total);
     g.sync();  // the tables serve the next round
+    CM_PROF_MARK(d, g, 53);
+    CM_PROF_COUNT(d, g, 57, 1);
   }
   if (pool_ok && g.t == 0) *pool_off = pool_first;
   // ---- repetitive_seed_length over the minimizers in order
   uint32_t rep_len = 0;
-  if (g.t == 0) {
+  if (n <= m.pairs) {  // (round 6) every lane fetches a minimizer's lookup result, lane 0 adds up from shared memory: one trip to global memory, not n
+    for (uint32_t mi = g.t; mi < n; mi += G) {
+      const uint8_t kind = d.pr_kind[b + mi];
+      uint32_t rp = 0xffffffffu;  // not a repetitive seed (cm_rescue_rep)
+      if (kind != CM_PR_MISS && kind != CM_PR_SINGLE && (uint32_t)d.pr_val[b + mi] >= (uint32_t)d.p.f0) rp = d.mm_ps[b + mi] >> 1;
+      m.pa[mi] = rp;
+    }
+    g.sync();
+    if (g.t == 0) {
+      uint32_t prev_rep = ~0u;
+      const uint32_t kk = (uint32_t)d.p.k, ww = (uint32_t)d.p.w;
+      for (uint32_t mi = 0; mi < n; ++mi) {
+        const uint32_t rp = m.pa[mi];
+        if (rp == 0xffffffffu) continue;
+        if (prev_rep > rp) rep_len += kk;
+        else if (rp < prev_rep + kk + ww - 1) rep_len += rp - prev_rep;
+        else rep_len += kk;
+        prev_rep = rp;
+      }
+    }
+  } else if (g.t == 0) {
     uint32_t prev_rep = ~0u;
     for (uint32_t mi = 0; mi < n; ++mi) cm_rescue_rep(d, d.pr_kind[b + mi], d.pr_val[b + mi], d.mm_ps[b + mi], &rep_len, &prev_rep);
   }
   *rep_len_out = cm_coop_bcast0(g, rep_len);
+  CM_PROF_MARK(d, g, 54);
   *n_out = cnt;
   return max_count;
 }
@@ -1560,21 +1661,27 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
   }
   bad = g.sum(bad);
   mx = g.max64(mx);
-  if (bad || mx >= nb_cap || n > 0xffffu) {
+  const bool wave_bins = G == (uint32_t)GT::W && mx < 4 * G;  // (the bins live in the wave part's lanes: nb_cap limits the histogram form only)
+  if (bad || (!wave_bins && mx >= nb_cap) || n > 0xffffu) {
     CM_PROF_PTR_COUNT(prof, g, bad ? 7 : 47, 1);
     if (g.t == 0) cm_sort_cand(p, c, n);
     g.sync();
     return;
   }
   const uint32_t nb = (uint32_t)mx + 1;
-  if (G == (uint32_t)GT::W && nb <= G) {
+  if (G == (uint32_t)GT::W && nb <= 4 * G) {
     // One wave part per list (round 5): lane b keeps bin b -- first the number of candidates with count b, then where the next of them
     // goes.  The list is taken 64 candidates at a time; the distinct counts among them (a handful) are handled one after the other: a
     // ballot of the lanes that hold the count, its population to the bin's lane / the bin's value from that lane, the lane's rank
     // among them.  No histogram per lane: the kernel's shared memory was 50 KB per four waves (12 waves per CU), and its time is
     // the lists' global-memory latency.
+    // Round 6: FOUR bins per lane (count v: lane v % G, slot v / G), i.e. every value a count can take with a wave of 64 -- one list in
+    // ten of the repeat-rich genome (profile 2) holds a candidate with a count of 64 or more (the modal diagonal of a cluster in a
+    // satellite array collects the hits of every copy of the unit), fell through to lane 0's heap sort in global memory and made
+    // the sorting waves' mean 156 us per read: 10 % of the lists were 90 % of k_s5_sort_coop.
     const uint8_t *cs = staged ? lc : c;
-    uint32_t bin = 0;
+    const uint32_t NS = (nb + G - 1) / G;  // slots in use (uniform)
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     for (uint32_t base = 0; base < n; base += G) {
       const uint32_t i = base + g.t;
       const bool in = i < n;
@@ -1583,14 +1690,17 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
       while (rem) {
         const uint32_t v = g.bcast(ci, (uint32_t)__builtin_ctzll(rem));
         const unsigned long long mk = g.ballot(in && ci == v);
-        if (g.t == v) bin += (uint32_t)__builtin_popcountll(mk);
+        const uint32_t pc = (uint32_t)__builtin_popcountll(mk), sl = v / G;
+        if (g.t == v % G) { b0 += sl == 0 ? pc : 0u; b1 += sl == 1 ? pc : 0u; b2 += sl == 2 ? pc : 0u; b3 += sl == 3 ? pc : 0u; }
         rem &= ~mk;
       }
     }
-    {  // the largest count first: bin b starts behind all candidates with a larger count
-      uint32_t tot;
-      const uint32_t below = g.scan(bin, &tot);
-      bin = tot - below - bin;
+    {  // the largest count first: a bin starts behind all candidates with a larger count -- slot by slot from the top
+      uint32_t above = 0, tot, below;
+      if (NS > 3) { below = g.scan(b3, &tot); b3 = above + (tot - below - b3); above += tot; }
+      if (NS > 2) { below = g.scan(b2, &tot); b2 = above + (tot - below - b2); above += tot; }
+      if (NS > 1) { below = g.scan(b1, &tot); b1 = above + (tot - below - b1); above += tot; }
+      below = g.scan(b0, &tot); b0 = above + (tot - below - b0);
     }
     uint64_t *const dpp = staged ? p : sp;
     uint8_t *const dcc = staged ? c : sc;
@@ -1605,9 +1715,10 @@ CM_HD void cm_coop_sort_cand(GT &g, uint64_t *p, uint8_t *c, uint32_t n, uint64_
       while (rem) {
         const uint32_t v = g.bcast(ci, (uint32_t)__builtin_ctzll(rem));
         const unsigned long long mk = g.ballot(in && ci == v);
-        const uint32_t at = g.bcast(bin, v);
+        const uint32_t pc = (uint32_t)__builtin_popcountll(mk), sl = v / G;  // (sl: the same for all lanes)
+        const uint32_t at = g.bcast(sl == 0 ? b0 : sl == 1 ? b1 : sl == 2 ? b2 : b3, v % G);
         if (in && ci == v) dst = at + (uint32_t)__builtin_popcountll(mk & ((1ull << (g.t % (uint32_t)GT::W)) - 1ull));
-        if (g.t == v) bin += (uint32_t)__builtin_popcountll(mk);
+        if (g.t == v % G) { b0 += sl == 0 ? pc : 0u; b1 += sl == 1 ? pc : 0u; b2 += sl == 2 ? pc : 0u; b3 += sl == 3 ? pc : 0u; }
         rem &= ~mk;
       }
       if (in) { dpp[dst] = pi; dcc[dst] = (uint8_t)ci; }

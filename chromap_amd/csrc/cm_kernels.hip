@@ -730,6 +730,50 @@ __device__ __forceinline__ void cm_wave_append(uint32_t *__restrict__ list, uint
   if (pred) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
+// Dynamic distribution of a device work list over the waves of a launch (round 6; cmgpu_set_option "coop" bit 16, NOT the default).
+// The list kernels stride (item j to wave j % waves): with items whose cost spans two orders of magnitude (a rescue search over 4 or over
+// 300 windows) the waves' lifetimes average 43 % of the launch's duration (SQ_WAVE_CYCLES / waves against the dispatch's duration,
+// profile 2: k_s4a_rescue_wave<false> 4.5 of 10.5 ms) -- the launch waits for its unluckiest wave.  With the option a wave takes
+// CM_WQ_CHUNK consecutive items with ONE atomic on the list's cursor and comes back for more.  Measured (gpurun_out/r06g, A/B on one
+// box): one lane, profile 2, S4a 45.5 -> 38.8 ms -- but with three lanes, where another lane's kernels fill the tail anyway, profile 2
+// 20.85 -> 21.1 M pairs/s and the planted-repeat workload 156.5 -> 147.8: same-address atomics retire at ~90 per microsecond, and a
+// list of 200 k cheap items is 50 k atomics = 0.55 ms on a kernel of 1 ms.  Kept as an option for single-lane callers.
+// The cursors are words 32.. of hv_cnt (zeroed with the lists' counters before S3a); every launch that drains a list has its own.
+#define CM_WQ_CHUNK 4u
+enum { CM_WQ_S4A_SMALL = 32, CM_WQ_S4A_BIG, CM_WQ_S4B_SMALL, CM_WQ_S4B_BIG, CM_WQ_S5_SORT_SMALL, CM_WQ_S5_SORT_WAVE, CM_WQ_S5_SORT_BLOCK };
+struct CmWaveQueue {
+  uint32_t *cur;
+  uint32_t cnt, j, jend, stride;
+  // dynamic == 0 (the default, CmDev::wq_dynamic): item j to wave j % waves
+  __device__ __forceinline__ CmWaveQueue(uint32_t *cursor, uint32_t n, uint32_t dynamic = 0) : cur(cursor), cnt(n), j(0), jend(0), stride(0) {
+    if (!dynamic) {
+      const uint32_t wpb = blockDim.x >> 6;
+      stride = gridDim.x * wpb;
+      j = blockIdx.x * wpb + (threadIdx.x >> 6);
+      jend = 0xffffffffu;
+    }
+  }
+  // the next item's index in the list (all lanes of the wave get it), false when the list is drained
+  __device__ __forceinline__ bool next(uint32_t *item) {
+    if (stride) {
+      if (j >= cnt) return false;
+      *item = j;
+      j += stride;
+      return true;
+    }
+    if (j == jend) {
+      uint32_t b = 0;
+      if ((threadIdx.x & 63u) == 0) b = atomicAdd(cur, CM_WQ_CHUNK);
+      b = __shfl(b, 0, 64);
+      if (b >= cnt) return false;
+      j = b;
+      jend = b + CM_WQ_CHUNK < cnt ? b + CM_WQ_CHUNK : cnt;
+    }
+    *item = j++;
+    return true;
+  }
+};
+
 // A read whose mate has CM_RS_WAVE candidates or more on a strand: a WAVE per read (cm_coop_rescue: the windows of the mate's best
 // candidates once per direction, a lane per (minimizer, window) pair for the bounds, the search chain replayed on indices) -- with a
 // lane per minimizer a search over ~300 windows took ~8 ms, the duration of the whole list kernel on the mosaic genome.
@@ -978,7 +1022,8 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
   g.xw = nullptr;
   cm_coop_rescue_mem_reset(g, m);
   const long long t0 = d.prof ? clock64() : 0;
-  for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+  CmWaveQueue wq(d.hv_cnt + (SMALL ? CM_WQ_S4A_SMALL : CM_WQ_S4A_BIG), cnt, d.wq_dynamic);
+  for (uint32_t j; wq.next(&j);) {
     const uint32_t r = list[j];
     if (SMALL && d.prof) {  // measurement aid (tools/coop_profile.py): the best mate candidates of the wave kernel's searches
       const uint32_t o = r ^ 1u;
@@ -990,8 +1035,10 @@ __global__ __launch_bounds__(64) void k_s4a_rescue_wave(CmDev d) {
       if (threadIdx.x == 0) d.hv_list[(size_t)CM_L_SEARCH_WAVE_BIG * d.hv_stride + atomicAdd(d.hv_cnt + CM_L_SEARCH_WAVE_BIG, 1u)] = r;
       continue;
     }
+    const long long ti = d.prof ? clock64() : 0;
     cm_coop_s4a_rescue(d, r, g, m);
     g.sync();
+    if (d.prof && threadIdx.x == 0) atomicMax(&d.prof[22], (unsigned long long)(clock64() - ti));  // the longest single search pair
   }
   cm_coop_rescue_mem_flush(d, g, m);
   if (d.prof && threadIdx.x == 0) { const unsigned long long dt = (unsigned long long)(clock64() - t0); atomicAdd(&d.prof[27], dt); atomicMax(&d.prof[28], dt); }
@@ -1011,7 +1058,8 @@ __global__ __launch_bounds__(64) void k_s4b_rescue_wave(CmDev d, uint32_t coop) 
   g.t = threadIdx.x;
   g.xw = nullptr;
   const long long t0 = d.prof ? clock64() : 0;
-  for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+  CmWaveQueue wq(d.hv_cnt + (SMALL ? CM_WQ_S4B_SMALL : CM_WQ_S4B_BIG), cnt, d.wq_dynamic);
+  for (uint32_t j; wq.next(&j);) {
     const uint32_t r = list[j];
     if (d.resc_n[r] + d.resc_p[r] == 0) continue;  // nothing found: k_s4b_rescue_merge copies the read's own candidates
     if (SMALL && !cm_coop_rescue_fits(d, r, g, CM_RESCUE_WMAX_S)) continue;  // (list 31: the launch with the full tables)
@@ -1153,7 +1201,7 @@ __global__ __launch_bounds__(CM_BLOCK, 8) void k_s5_sort_coop(CmDev d, uint32_t 
   // (a wave keeps the sort's bins in its lanes: no histogram array -- 18 KB per block, eight blocks per CU)
   __shared__ uint64_t stage_p[(CM_BLOCK / 64) * CM_SORT_STAGE];  // a list of up to CM_SORT_STAGE candidates is staged here once
   __shared__ uint8_t stage_c[(CM_BLOCK / 64) * CM_SORT_STAGE];
-  const uint32_t gpb = CM_BLOCK / 64, grp = threadIdx.x / 64;
+  const uint32_t grp = threadIdx.x / 64;
   const uint32_t n_list = d.hv_cnt[lid];
   const uint32_t *list = d.hv_list + (size_t)lid * d.hv_stride;
   CmDevGroup<64> g;
@@ -1161,7 +1209,8 @@ __global__ __launch_bounds__(CM_BLOCK, 8) void k_s5_sort_coop(CmDev d, uint32_t 
   g.xw = nullptr;
   const long long t0 = d.prof ? clock64() : 0;
   uint32_t mine = 0;
-  for (uint32_t j = blockIdx.x * gpb + grp; j < n_list; j += gridDim.x * gpb, ++mine)
+  CmWaveQueue wq(d.hv_cnt + (lid == CM_L_S5_SMALL ? CM_WQ_S5_SORT_SMALL : lid == CM_L_S5_WAVE ? CM_WQ_S5_SORT_WAVE : CM_WQ_S5_SORT_BLOCK), n_list, d.wq_dynamic);
+  for (uint32_t j; wq.next(&j); ++mine)
     cm_coop_s5_sort(d, list[j], g, nullptr, CM_SORT_NB, stage_p + (size_t)grp * CM_SORT_STAGE, stage_c + (size_t)grp * CM_SORT_STAGE, CM_SORT_STAGE);
   if (d.prof && g.t == 0 && mine) {  // measurement aid (tools/coop_profile.py): a sorting wave's cycles and reads
     const unsigned long long dt = (unsigned long long)(clock64() - t0);

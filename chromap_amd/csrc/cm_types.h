@@ -196,6 +196,7 @@ struct CmDev {
   uint64_t *rs_pool;
   uint32_t rs_pool_cap;
   uint32_t *rs_pool_off;
+  uint32_t wq_dynamic;       // cmgpu_set_option "coop" bit 16: the wave-per-item list kernels take chunks of their lists from a cursor instead of striding (CmWaveQueue)
   unsigned long long *prof;  // measurement aid (cmgpu_set_option "coop_profile"): shader-clock cycles per phase of k_s3b_coop, summed over groups
   uint32_t mm_cap;  // capacity of the dense minimizer arrays (0: not checked): S3a leaves a read whose range passes it idle
   uint32_t coop_rb; // tests: run-table size of the cooperative sorters (0: two per minimizer of the longest read)

@@ -12,6 +12,12 @@
 #include "../../include/chromap_amd.h"
 #include "../../chromap_amd/csrc/cm_mapq_tables.h"
 #include "../../chromap_amd/csrc/cm_stages.h"
+// coverage counters the stage functions keep for the tests only (cm_coop.h: CM_DBG_REPLAY = minimizers whose rescue chain was replayed
+// window by window because a transition table did not apply)
+static unsigned long long g_dbg_rescue_replays = 0;
+#define CM_DBG_REPLAY g_dbg_rescue_replays
+static int g_dbg_force_replay = 0;  // tests: every second minimizer of a round is replayed although its tables apply
+#define CM_DBG_FORCE_REPLAY g_dbg_force_replay
 #include "../../chromap_amd/csrc/cm_coop.h"
 #include "../../chromap_amd/csrc/cm_inflate.h"
 #include "emu_group.h"
@@ -774,6 +780,8 @@ extern "C" int hostemu_rescue_dir_check(const uint64_t *c0p, const uint8_t *c0c,
 // exactly on an occurrence (the search's "equal" exit), occurrences on both strands.  Returns the number of cases that differ.
 static unsigned long long g_rescue_check_stats[4];  // searches with hits, hits, bail-outs, searches with 64 best candidates or more
 extern "C" void hostemu_rescue_search_stats(unsigned long long *out) { memcpy(out, g_rescue_check_stats, sizeof(g_rescue_check_stats)); }
+extern "C" unsigned long long hostemu_rescue_replays(void) { return g_dbg_rescue_replays; }
+extern "C" void hostemu_force_rescue_replay(int on) { g_dbg_force_replay = on; }
 template <int G>
 static int emu_rescue_search_check(uint64_t seed, uint32_t rounds, bool reverse) {
   uint64_t st = seed * 0x9E3779B97F4A7C15ull + 11;

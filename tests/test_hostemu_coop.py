@@ -199,8 +199,23 @@ def test_cooperative_rescue_search_on_adversarial_runs():
     f = L.hostemu_rescue_search_check
     f.restype = C.c_int
     f.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int]
+    L.hostemu_rescue_replays.restype = C.c_uint64
+    r0 = L.hostemu_rescue_replays()
     for seed, G, rev in ((1, 64, 0), (2, 16, 1), (3, 256, 0), (4, 64, 1)):
         assert f(seed, 400, G, rev) == 0, (seed, G, rev)
+    stats = (C.c_uint64 * 4)()
+    L.hostemu_rescue_search_stats(stats)
+    assert stats[0] > 50 * 4
+    # the chain of searches goes through the transition tables alone (no table has been seen not to apply: r1 == r0 here); the
+    # window-by-window replay that backs them up is taken by decree for every second minimizer, with the same results
+    r1 = L.hostemu_rescue_replays()
+    L.hostemu_force_rescue_replay(1)
+    try:
+        for seed, G, rev in ((5, 64, 0), (6, 16, 1), (7, 256, 1)):
+            assert f(seed, 300, G, rev) == 0, (seed, G, rev)
+    finally:
+        L.hostemu_force_rescue_replay(0)
+    assert L.hostemu_rescue_replays() - r1 > 1000, (r0, r1, L.hostemu_rescue_replays())
 
 
 def test_cooperative_pair_filter_on_adversarial_lists():
@@ -311,7 +326,7 @@ def test_cooperative_candidate_sort():
         pos = np.unique((rng.integers(0, 3, n).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 22, n).astype(np.uint64))
         if it % 11 == 0 and len(pos) > 3:
             pos = pos[rng.permutation(len(pos))]  # --chr-order re-ranking leaves lists out of position order
-        cmax = int(rng.choice([2, 9, 40, 70]))
+        cmax = int(rng.choice([2, 9, 40, 70, 130, 200, 255]))
         cnt = rng.integers(1, cmax + 1, len(pos)).astype(np.uint8)
         pos = np.ascontiguousarray(pos)
         rc = f(pos.ctypes.data, cnt.ctypes.data, len(pos), 64, int(rng.choice([16, 64, 256])), it & 1)

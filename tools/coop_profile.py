@@ -18,12 +18,14 @@ def main():
         rep = (int(f[0]), int(f[1]), int(f[2]), float(f[3]))
     g = ChromapGPU(synthetic=(3_100_000_000, 24, 12345, rep), preset="atac")
     g.set_option("lanes", 1)
+    if len(sys.argv) > 2:
+        g.set_option("coop", int(sys.argv[2], 0))
     g.generate_resident(4_000_000, read_length=50, frag_min=30, frag_max=600, sub_rate=0.01, seed=3000)
     g.map_resident(Stats())
     g.set_option("coop_profile", 1)
     for _ in range(3):
         g.map_resident(Stats())
-    v = [g.get_option("coop_profile_%d" % k) for k in range(48)]
+    v = [g.get_option("coop_profile_%d" % k) for k in range(64)]
     names = ["run table + scan (header loads)", "expand pass 1 (occurrence loads)", "pass 2 (strand partition)", "scan of the pieces' + counts", "merge levels", "cluster sweep"]
     tot = float(sum(v[:6])) or 1.0
     n = max(1, v[8])
@@ -39,8 +41,12 @@ def main():
     print("  k_s4a_rescue_list, cycles of a wave in its three loops (sum over waves / longest wave): wave-per-read %d / %d (%d reads), lane-per-read %d / %d, "
           "16-lanes-per-read %d / %d" % (v[27], v[28], v[11], v[29], v[30], v[31], v[15]))
     print("  k_s4b_rescue_list likewise: wave-per-read %d / %d, lane-per-read %d / %d, 16-lanes-per-read %d / %d" % (v[32], v[33], v[34], v[35], v[36], v[37]))
-    print("  windows < 4: %d, < 16: %d, < 64: %d, < 300: %d" % (v[22], v[23], v[24], v[25]))
+    print("  wave kernels: longest single read in k_s4a_rescue_wave %d cycles; waves' cycles sum / longest wave: s4a %d / %d, s4b %d / %d" % (v[22], v[27], v[28], v[32], v[33]))
     print("  wave kernel (a wave per read), larger of the two searches' best mate candidates: < 16: %d, < 32: %d, < 64: %d, < 128: %d, < 200: %d, < 300: %d, more: %d" % tuple(v[40:47]))
+    ns = max(1, v[55])
+    print("cm_coop_rescue (sampled waves: %d searches, %.1f rounds each, %.0f occurrences in the windows per search), cycles per search: best + windows %.0f, "
+          "minimizer tables %.0f, A (bounds) %.0f, eq + B (chain) %.0f, C (scan + emit) %.0f, pool emit %.0f, tail %.0f"
+          % (v[55], v[57] / ns, v[56] / ns, v[48] / ns, v[49] / ns, v[50] / ns, v[51] / ns, v[52] / ns, v[53] / ns, v[54] / ns))
     print("k_s5_sort_coop: %d reads, %.0f cycles of a wave per read, longest wave %d cycles; lists left to lane 0: %d not in position order, %d other"
           % (v[6], v[38] / max(1, v[6]), v[39], v[7], v[47]))
     print("timings of the last batch:", g.timings())
