@@ -99,7 +99,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_compute_barcode_abundance", "cmgpu_map_pairs_barcoded", "cmgpu_map_single_barcoded", "cmgpu_write_bed_pe_bc",
            "cmgpu_store_clear", "cmgpu_store_reserve", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
-           "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded",
+           "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded", "cmgpu_write_sam_barcoded_translated",
            "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_scan_bgzf", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref",
            "cmgpu_create_synthetic_repeats", "cmgpu_create_synthetic_profile", "cmgpu_generate_resident_batch_indels", "cmgpu_generate_resident_batch_hic", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
@@ -187,6 +187,9 @@ def declare(L):
     sig("cmgpu_write_sam_barcoded", C.c_int64, [P(C.c_char_p), C.c_void_p, C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_uint32, P(C.c_char_p), P(C.c_char_p)] + [C.c_void_p] * 6 +
         [C.c_void_p, C.c_uint32, C.c_char_p])
+    sig("cmgpu_write_sam_barcoded_translated", C.c_int64, [P(C.c_char_p), C.c_void_p, C.c_uint32, P(Params), C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
+                                                           C.c_void_p, C.c_uint32, P(C.c_char_p), P(C.c_char_p)] + [C.c_void_p] * 6 +
+        [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p])
     sig("cmgpu_fastq_set_format", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char])
     sig("cmgpu_fastq_scan", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
     sig("cmgpu_fastq_scan_bgzf", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
@@ -224,6 +227,7 @@ def declare(L):
     sig("cmgpu_exchange_owner_table", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32])
     sig("cmgpu_exchange_step", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)])
     sig("cmgpu_exchange_info", C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_uint64), P(C.c_uint64)])
+    sig("cmgpu_exchange_plan", C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32)])
     sig("cmgpu_exchange_finalize", C.c_int, [C.c_void_p])
     sig("cmgpu_host_alloc", C.c_void_p, [C.c_uint64])
     sig("cmgpu_host_free", None, [C.c_void_p])

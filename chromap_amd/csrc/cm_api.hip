@@ -261,7 +261,8 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   p.ref_batch = params->read_batch_size > 0 ? params->read_batch_size : 500000;
   p.grain = params->taskloop_grain_size > 0 ? params->taskloop_grain_size : 5000;
   p.sam = params->output_format == CMGPU_FORMAT_SAM ? 1 : 0;
-  if (params->output_format != 0 && params->output_format != CMGPU_FORMAT_SAM) { cm_set_error(c, "unknown output_format"); return CMGPU_EINVAL; }
+  p.pairs_out = params->output_format == CMGPU_FORMAT_PAIRS && !params->split_alignment ? 1 : 0;  // (split alignment writes pairs records anyway)
+  if (params->output_format != 0 && params->output_format != CMGPU_FORMAT_SAM && params->output_format != CMGPU_FORMAT_PAIRS) { cm_set_error(c, "unknown output_format"); return CMGPU_EINVAL; }
   HIPCHECK(c, hipStreamCreate(&c->stream));
   HIPCHECK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));  // same priority as `stream`: a probe stream of higher or lower
                                                                              // priority measured 3-5 % slower end to end

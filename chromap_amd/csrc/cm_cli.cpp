@@ -516,15 +516,23 @@ static Args parse(int argc, char **argv) {
     a.p.max_num_best_mappings = a.p.drop_repetitive_reads;
   }
   if (a.p.max_num_best_mappings < 1) die("-n must be at least 1");
-  if (a.p.max_num_best_mappings > 64) die("-n above 64 is outside this build (64 record slots per read at most)");
+  // every pair of a batch has -n record slots in HBM (24 + 5 bytes each), addressed with 32 bits: large -n values map smaller batches (whole
+  // reference batches of 500 000 pairs, so that the multi-mappers' sampling is the reference's); beyond 8192 one reference batch has more
+  // than 2^32 slots
+  if (a.p.max_num_best_mappings > 8192) die("-n above 8192 is outside this build (a 500000-pair batch then needs more than 2^32 record slots)");
   if (a.out_sam) {
     if (a.p.max_num_best_mappings > 1) die("--SAM with -n > 1 is outside this build");
     a.p.output_format = CMGPU_FORMAT_SAM;
   }
   // the reference accepts these combinations; this build has no record type for them -- refuse instead of writing garbage
-  if (a.out_pairs && !a.p.split_alignment) die("--pairs without --split-alignment (or --preset hic) is outside this build");
+  if (a.out_pairs && !a.p.split_alignment) a.p.output_format = CMGPU_FORMAT_PAIRS;  // MapPairedEndReads<PairsMapping> on the ordinary pairing (chromap_driver.cc:748-751)
   if (a.out_pairs && !a.bc.empty()) die("pairs output with cell barcodes is outside this build");
   if (a.gpus < 1 || a.gpus > 64) die("--gpus must be 1..64");
+  if (a.p.max_num_best_mappings > 64) {
+    const uint64_t budget = 1ull << 30;  // record slots per batch (31 GB of HBM)
+    const uint64_t fit = budget / (uint64_t)a.p.max_num_best_mappings;
+    if (a.batch_pairs > fit) a.batch_pairs = (uint32_t)fit;
+  }
   if (a.batch_pairs < 500000) a.batch_pairs = 500000;
   a.batch_pairs -= a.batch_pairs % 500000;
   return a;
@@ -565,6 +573,7 @@ int main(int argc, char **argv) {
   }
   if (a.index_path.empty() || a.r1.empty()) die("No index / read files specified!");
   const bool paired = !a.r2.empty();
+  if (a.out_pairs && !paired) die("No support for single-end HiC yet!");  // chromap_driver.cc:716-718
   if (paired && a.r1.size() != a.r2.size()) die("Numbers of read1 and read2 files don't match!");
   const bool barcoded = !a.bc.empty();
   if (barcoded && a.bc.size() != a.r1.size()) die("Numbers of read1 and barcode files don't match!");
@@ -625,7 +634,6 @@ int main(int argc, char **argv) {
 
   double t_read = 0, t_parse = 0, t_map = 0, t_post = 0;
   const double t_begin = now_s();
-  if (barcoded && a.out_sam && !a.translate_path.empty()) die("--SAM with --barcode-translate is outside this build");
   for (cmgpu_ctx *cx : ctxs) {
     if (a.skip_bc_check) cmgpu_set_barcode_check(cx, 0);
     for (int m = 0; m < 3; ++m)
@@ -981,7 +989,19 @@ int main(int argc, char **argv) {
     std::vector<const char *> n1(sam_names1.size()), n2(sam_names2.size() ? sam_names2.size() : 1, "");
     for (size_t i = 0; i < sam_names1.size(); ++i) n1[i] = sam_names1[i].c_str();
     for (size_t i = 0; i < sam_names2.size(); ++i) n2[i] = sam_names2[i].c_str();
-    if (barcoded)
+    if (barcoded && !a.translate_path.empty()) {  // CB:Z: through the translation table (read here: the table may be gzip-compressed)
+      std::string table;
+      gzFile tf = gzopen(a.translate_path.c_str(), "r");
+      if (!tf) die("Cannot open barcode translation file " + a.translate_path);
+      char tb[1 << 16];
+      for (int got; (got = gzread(tf, tb, sizeof(tb))) > 0;) table.append(tb, (size_t)got);
+      gzclose(tf);
+      lines = cmgpu_write_sam_barcoded_translated(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0,
+                                                  sam_cigar.data(), md.data(), cap, n1.data(), n2.data(), sam_b1.data(), sam_q1.data(), sam_o1.data(),
+                                                  paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,
+                                                  sam_bc.data(), bc_len, table.data(), table.size(), a.out_path.c_str());
+      if (lines == CMGPU_EFORMAT) die("Barcode does not exist in the translation table.");
+    } else if (barcoded)
       lines = cmgpu_write_sam_barcoded(out_names.data(), out_lengths.data(), ref.n_sequences, &a.p, sam_rec.data(), sam_rec.size(), paired ? 1 : 0,
                                        sam_cigar.data(), md.data(), cap, n1.data(), n2.data(), sam_b1.data(), sam_q1.data(), sam_o1.data(),
                                        paired ? sam_b2.data() : nullptr, paired ? sam_q2.data() : nullptr, paired ? sam_o2.data() : nullptr,

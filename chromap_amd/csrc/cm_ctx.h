@@ -241,6 +241,7 @@ int cm_store_reserve(cmgpu_ctx *c, uint64_t need, bool with_bc);
 // record slots of the resident batch: max_num_best_mappings per pair (cm_emit_record); flag / position scratch for a
 // compaction over them (scratch_a, scratch_b, scan_tmp sized for `slots` entries)
 static inline uint32_t cm_rec_per_pair(const cmgpu_ctx *c) { return (uint32_t)(c->p.max_best > 0 ? c->p.max_best : 1); }
+static inline bool cm_pairs_records(const cmgpu_ctx *c) { return c->p.split || c->p.pairs_out; }  // the records are cmgpu_pairs_record entries
 static inline uint64_t cm_rec_slots(const cmgpu_ctx *c) { return (uint64_t)c->n_pairs * cm_rec_per_pair(c); }
 int cm_ensure_slot_scratch(cmgpu_ctx *c, uint64_t slots);
 // cm_post.hip: n 32-byte {record, barcode} entries -> the store's record / barcode arrays at position store_n

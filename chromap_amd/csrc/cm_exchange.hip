@@ -237,7 +237,7 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
   for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
   if (c->n_pairs == 0) return CMGPU_OK;
   if (capacity < cm_rec_slots(c)) { cm_set_error(c, "send buffer too small (one slot per pair of the batch -- times max_num_best_mappings -- is needed)"); return CMGPU_ECAPACITY; }
-  if (c->p.split) { cm_set_error(c, "pairs records are not partitioned by chromosome"); return CMGPU_EINVAL; }
+  if (cm_pairs_records(c)) { cm_set_error(c, "pairs records are not partitioned by chromosome"); return CMGPU_EINVAL; }
   const std::vector<uint8_t> t = cm_owner_table(c, world);
   DevBuf &dcnt = c->part_cnt;
   if (dcnt.ensure(2 * (EX_MAX_WORLD + 1) * 8 + t.size() + 16)) { cm_set_error(c, "out of device memory (partition)"); return CMGPU_ENOMEM; }
@@ -259,7 +259,7 @@ extern "C" int cmgpu_records_partition(cmgpu_ctx *c, uint32_t world, void *devic
 static int ex_common_init(cmgpu_ctx *c, int rank, int world) {
   if (!c || world < 1 || world > EX_MAX_WORLD || rank < 0 || rank >= world) { cm_set_error(c, "bad rank / world"); return CMGPU_EINVAL; }
   if (c->ex.transport != 0) { cm_set_error(c, "the exchange is already initialised"); return CMGPU_EINVAL; }
-  if (c->p.split) { cm_set_error(c, "pairs records (split alignment) are post-processed on the host; no chromosome owners"); return CMGPU_EINVAL; }
+  if (cm_pairs_records(c)) { cm_set_error(c, "pairs records are post-processed by one rank; no chromosome owners"); return CMGPU_EINVAL; }
   EXCHECK(c, cm_enter(c));
   CmExchange &x = c->ex;
   x.rank = rank;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/chromap_amd.h"
@@ -287,8 +288,18 @@ extern "C" int64_t cmgpu_write_pairs_ranked(const char *const *names, const uint
   buf.reserve(1 << 20);
   pairs_header(buf, names, lengths, n_sequences, pairs_rank);
   int64_t lines = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    const cmgpu_pairs_record &r = rec[i];
+  auto same = [](const cmgpu_pairs_record &a, const cmgpu_pairs_record &b) {  // PairsMapping::operator== (pairs_mapping.h:45-50)
+    return a.rid1 == b.rid1 && a.pos1 == b.pos1 && a.rid2 == b.rid2 && a.pos2 == b.pos2;
+  };
+  for (uint64_t i = 0; i < n;) {
+    // --remove-pcr-duplicates: one record per run of equal positions -- the low-memory merge keeps the FIRST record with the run's largest
+    // MAPQ (mapping_writer.h:244-270), the in-memory RemovePCRDuplicate the LAST of the run (mapping_processor.h:178-195)
+    uint64_t pick = i, j = i + 1;
+    if (p->remove_pcr_duplicates)
+      for (; j < n && same(rec[j], rec[i]); ++j)
+        if (!p->low_memory_mode || rec[j].mapq > rec[pick].mapq) pick = j;
+    const cmgpu_pairs_record &r = rec[pick];
+    i = j;
     if (r.mapq < p->mapq_threshold || r.rid1 >= n_sequences || r.rid2 >= n_sequences) continue;
     buf.append(read_names[r.read_id - read_id_base]);
     buf.push_back('\t');
@@ -456,11 +467,45 @@ extern "C" int64_t cmgpu_write_bed_se(const char *const *names, uint32_t n_seque
 // The sequence is printed as mapped (reverse complement for the - strand, PrepareNegativeSequenceAt),
 // the quality reversed with it (sam_mapping.h:172-179), both cut to the trimmed length.
 // ---------------------------------------------------------------------------------------
+// --barcode-translate (BarcodeTranslator, barcode_translator.h:43-101): table lines are "to<TAB or ,>from"; the key is the 2-bit
+// packed `from` (GenerateSeedFromSequence, utils.h:111-129: other letters count as A); the LAST line's `from` length is the
+// segment length.  A barcode of several segments is translated segment by segment and joined with '-' -- the segments are cut
+// with the reference's own shifts (:80-82), which only isolate a segment when there is one.
+struct CmBarcodeTable {
+  std::unordered_map<uint64_t, std::string> to;
+  uint32_t from_len = 0;
+  uint64_t mask = 0;
+};
+static int parse_barcode_table(const char *text, uint64_t bytes, CmBarcodeTable *t) {
+  const char *p = text, *end = text + bytes;
+  while (p < end) {
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    if (!nl) nl = end;
+    const size_t l = (size_t)(nl - p);
+    size_t i = 0;
+    while (i < l && p[i] != ',' && p[i] != '\t') ++i;
+    if (i < l) {  // (a line without a separator gives the reference a `from` length of -1: such a table is not usable there either)
+      t->from_len = (uint32_t)(l - i - 1);
+      uint64_t seed = 0;
+      for (uint32_t k = 0; k < t->from_len; ++k) {
+        const char c = p[i + 1 + k];
+        const uint64_t b = (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 0;
+        seed = (seed << 2) | b;
+      }
+      t->to[seed] = std::string(p, i);
+    }
+    p = nl + 1;
+  }
+  t->mask = t->from_len >= 32 ? ~0ull : (1ull << (2 * t->from_len)) - 1;
+  return t->from_len ? CMGPU_OK : CMGPU_EINVAL;
+}
+
 static int64_t write_sam_impl(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
                               const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
                               const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
                               const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
-                              const char *quals2, const uint32_t *offsets2, const uint64_t *bck, uint32_t bc_len, const char *out_path) {
+                              const char *quals2, const uint32_t *offsets2, const uint64_t *bck, uint32_t bc_len, const char *out_path,
+                              const CmBarcodeTable *tr = nullptr) {
   auto bc_of = [&](uint64_t slot) -> uint64_t { return bck ? bck[paired ? slot / 2 : slot] : 0; };
   FILE *f = fopen(out_path, "wb");
   if (!f) return CMGPU_EIO;
@@ -548,7 +593,19 @@ static int64_t write_sam_impl(const char *const *ref_names, const uint32_t *ref_
       if (bck) {
         buf.append("\tCB:Z:");
         const uint64_t key = bc_of(last);
-        for (uint32_t b = 0; b < bc_len; ++b) buf.push_back("ACGT"[(key >> ((bc_len - 1 - b) * 2)) & 3]);  // Seed2Sequence
+        if (!tr) {
+          for (uint32_t b = 0; b < bc_len; ++b) buf.push_back("ACGT"[(key >> ((bc_len - 1 - b) * 2)) & 3]);  // Seed2Sequence
+        } else {
+          const uint64_t nseg = bc_len / tr->from_len;
+          for (uint64_t sg = 0; sg < nseg; ++sg) {
+            const uint64_t sh1 = 2 * sg * tr->from_len, sh2 = 2 * (nseg - 1) * tr->from_len;
+            const uint64_t seed = ((sh1 < 64 ? key << sh1 : 0) >> (sh2 < 64 ? sh2 : 63)) & tr->mask;
+            const auto it = tr->to.find(seed);
+            if (it == tr->to.end()) { fclose(f); return CMGPU_EFORMAT; }  // "Barcode does not exist in the translation table." (exit(-1) there)
+            if (sg) buf.push_back('-');
+            buf.append(it->second);
+          }
+        }
       }
       buf.push_back('\n');
       ++lines;
@@ -579,4 +636,18 @@ extern "C" int64_t cmgpu_write_sam_barcoded(const char *const *ref_names, const 
   if (!barcode_keys || barcode_length == 0 || barcode_length > 32) return CMGPU_EINVAL;
   return write_sam_impl(ref_names, ref_lengths, n_sequences, p, rec, n_slots, paired, cigar_pool, md_pool, md_cap, names1, names2, bases1, quals1,
                         offsets1, bases2, quals2, offsets2, barcode_keys, barcode_length, out_path);
+}
+
+extern "C" int64_t cmgpu_write_sam_barcoded_translated(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *p,
+                                                       const cmgpu_sam_record *rec, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                                                       const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                                                       const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                                                       const char *quals2, const uint32_t *offsets2, const uint64_t *barcode_keys, uint32_t barcode_length,
+                                                       const char *translate_table, uint64_t translate_table_bytes, const char *out_path) {
+  if (!barcode_keys || barcode_length == 0 || barcode_length > 32 || !translate_table) return CMGPU_EINVAL;
+  CmBarcodeTable tr;
+  const int rc = parse_barcode_table(translate_table, translate_table_bytes, &tr);
+  if (rc) return rc;
+  return write_sam_impl(ref_names, ref_lengths, n_sequences, p, rec, n_slots, paired, cigar_pool, md_pool, md_cap, names1, names2, bases1, quals1,
+                        offsets1, bases2, quals2, offsets2, barcode_keys, barcode_length, out_path, &tr);
 }

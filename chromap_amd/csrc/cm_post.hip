@@ -746,12 +746,33 @@ __global__ __launch_bounds__(PP_BLOCK) void k_pp_pairs_key(const uint8_t *__rest
 }
 __global__ __launch_bounds__(PP_BLOCK) void k_pp_pairs_len(const uint8_t *__restrict__ store, const uint32_t *__restrict__ idx, uint32_t n, int mapq_thr,
                                                              uint32_t n_seq, const uint32_t *__restrict__ name_off, const uint64_t *__restrict__ rn_off,
-                                                             uint32_t rn_base, uint32_t rn_count, uint64_t *__restrict__ line_len) {
+                                                             uint32_t rn_base, uint32_t rn_count, uint64_t *__restrict__ line_len, int dedup) {
   const uint32_t j = blockIdx.x * PP_BLOCK + threadIdx.x;
   if (j >= n) return;
   const PpPairs r = pp_load_pairs(store, idx[j]);
   const uint32_t q = r.read_id - rn_base;
   if ((int)r.mapq < mapq_thr || r.rid1 >= n_seq || r.rid2 >= n_seq || q >= rn_count) { line_len[j] = 0; return; }
+  // --remove-pcr-duplicates: one record per run of PairsMapping::operator== (rid1, pos1, rid2, pos2; pairs_mapping.h:45-50).  The records
+  // stand in operator< order, i.e. inside a run by (mapq, read_id).  dedup == 1, the low-memory merge (mapping_writer.h:244-270): the
+  // FIRST record with the run's largest MAPQ (a later one replaces the survivor only when its MAPQ is larger); dedup == 2, the
+  // in-memory RemovePCRDuplicate (mapping_processor.h:178-195): the LAST of the run.  The MAPQ filter above is the survivor's:
+  // the run's largest MAPQ either way, so a record below the threshold is never a survivor that would have passed.
+  if (dedup) {
+    auto same_key = [&](const PpPairs &x) { return x.rid1 == r.rid1 && x.pos1 == r.pos1 && x.rid2 == r.rid2 && x.pos2 == r.pos2; };
+    bool win;
+    if (dedup == 2) {
+      win = j + 1 == n || !same_key(pp_load_pairs(store, idx[j + 1]));
+    } else {
+      win = j == 0;
+      if (!win) { const PpPairs pr = pp_load_pairs(store, idx[j - 1]); win = !same_key(pr) || pr.mapq != r.mapq; }  // first of its (run, MAPQ) group ...
+      for (uint32_t t = j + 1; win && t < n; ++t) {                                                               // ... and no larger MAPQ follows in the run
+        const PpPairs nx = pp_load_pairs(store, idx[t]);
+        if (!same_key(nx)) break;
+        if (nx.mapq != r.mapq) win = false;
+      }
+    }
+    if (!win) { line_len[j] = 0; return; }
+  }
   const uint32_t rn = (uint32_t)(rn_off[q + 1] - rn_off[q]);
   line_len[j] = rn + 1 + (name_off[r.rid1 + 1] - name_off[r.rid1]) + 1 + pp_digits(r.pos1 + 1) + 1 + (name_off[r.rid2 + 1] - name_off[r.rid2]) + 1 +
                 pp_digits(r.pos2 + 1) + 2 + 2 + 4 + pp_digits(r.mapq) + 1 + pp_digits(r.mapq) + 1;
@@ -788,7 +809,7 @@ extern "C" int cmgpu_store_format_pairs(cmgpu_ctx *c, const char *const *names, 
                                         const char *read_names, const uint64_t *read_name_offsets, uint32_t n_read_names,
                                         uint32_t read_id_base, uint64_t *n_lines, uint64_t *n_bytes) {
   if (!c || !names || !p || !n_lines || !n_bytes || (!read_names && n_read_names) || (!read_name_offsets && n_read_names)) return CMGPU_EINVAL;
-  if (!c->p.split) { cm_set_error(c, "pairs text needs pairs records (split alignment)"); return CMGPU_EINVAL; }
+  if (!cm_pairs_records(c)) { cm_set_error(c, "pairs text needs pairs records (split alignment, or output_format = CMGPU_FORMAT_PAIRS)"); return CMGPU_EINVAL; }
   if (c->store_has_bc) { cm_set_error(c, "pairs text with cell barcodes is not supported"); return CMGPU_EINVAL; }
   PPCHECK(c, cm_enter(c));
   { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
@@ -834,7 +855,8 @@ extern "C" int cmgpu_store_format_pairs(cmgpu_ctx *c, const char *const *names, 
   if ((rc = pp_sort_pass(c, tmp, ka, kb, va, vb, n, 2 * rid_bits))) return fail(rc);
   std::swap(va, vb);
   hipLaunchKernelGGL(k_pp_pairs_len, g, b, 0, s, store, (const uint32_t *)va, n, p->mapq_threshold, n_sequences, (const uint32_t *)d_noff.p,
-                     (const uint64_t *)d_rnoff.p, read_id_base, n_read_names, (uint64_t *)llen.p);
+                     (const uint64_t *)d_rnoff.p, read_id_base, n_read_names, (uint64_t *)llen.p,
+                     p->remove_pcr_duplicates ? (p->low_memory_mode ? 1 : 2) : 0);
   if (hipMemsetAsync((uint64_t *)llen.p + n, 0, 8, s) != hipSuccess) { cm_set_error(c, "memset failed"); return fail(CMGPU_EHIP); }
   size_t tb = 0, tb2 = 0;
   auto lines_in = rocprim::make_transform_iterator((const uint64_t *)llen.p, PpLinesOp());

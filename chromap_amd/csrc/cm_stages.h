@@ -2841,7 +2841,7 @@ CM_HD int cm_ksw_sg3(const uint8_t *query, const uint8_t *read, int L, bool neg,
   *start = k + 1;
   for (int a = 0; a < n >> 1; ++a) { const uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
   *n_cigar = n;
-  return overflow ? -1 : score;
+  return overflow ? (int)0x80000000 : score;  // (not -1: a 39-base read with 8 mismatches scores exactly -1)
 }
 
 CM_HD uint32_t cm_put_dec(uint8_t *dst, uint32_t cap, uint32_t at, uint32_t v) {
@@ -2897,7 +2897,7 @@ CM_HD CmSpan cm_ref_start_end_sam(const CmDev &d, uint32_t pair, uint32_t slot, 
   aln->nm = cm_nm_and_md(win + st, read, L, strand == 1, cigar, n_cigar, d.sam_md + (uint64_t)slot * d.sam_md_cap, d.sam_md_cap, &md_len);
   aln->n_cigar = (uint32_t)n_cigar;
   aln->md_len = md_len;
-  aln->overflow = sc == -1 || md_len > d.sam_md_cap;
+  aln->overflow = sc == (int)0x80000000 || md_len > d.sam_md_cap;
   CmSpan s;
   s.rid = rid;
   s.ref_start = vw + (uint32_t)st;
@@ -2956,7 +2956,7 @@ CM_HD CmSpan cm_ref_start_end_split_sam(const CmDev &d, uint32_t pair, uint32_t 
   }
   aln->n_cigar = (uint32_t)n_cigar;
   aln->md_len = md_len;
-  aln->overflow = sc == -1 || md_len > d.sam_md_cap;
+  aln->overflow = sc == (int)0x80000000 || md_len > d.sam_md_cap;
   return s;
 }
 
@@ -3062,6 +3062,30 @@ CM_HD const int16_t *cm_d_err(const CmDev &d, uint32_t r, int strand) {
   return d.derr + d.m_off[r] + (strand ? d.ncp[r] + d.resc_p[r] : 0);
 }
 
+// EmplaceBackPairedEndMappingRecord<PairsMapping> (mapping_generator.cc:169-210): a read's position is its reference start on the
+// + strand and its reference END on the - strand; the end with the smaller (rank of the sequence, position) goes first.
+// Record layout = cmgpu_pairs_record (24 bytes).  a / b: read 1 / read 2 of the pair, s1 / s2 their strands (0: +).
+CM_HD void cm_put_pairs_record(const CmDev &d, uint64_t slot, uint32_t pair, const CmSpan &a, const CmSpan &b, int s1, int s2, uint8_t mapq, uint8_t is_unique) {
+  uint8_t st1 = s1 == 0 ? 1 : 0, st2 = s2 == 0 ? 1 : 0;
+  int pos1 = (int)(s1 == 0 ? a.ref_start : a.ref_end), pos2 = (int)(s2 == 0 ? b.ref_start : b.ref_end);
+  int rid1 = (int)a.rid, rid2 = (int)b.rid;
+  const uint32_t k1 = d.pairs_rank ? d.pairs_rank[rid1] : (uint32_t)rid1, k2 = d.pairs_rank ? d.pairs_rank[rid2] : (uint32_t)rid2;
+  if (!(k1 < k2 || (rid1 == rid2 && pos1 < pos2))) {  // mapping_generator.cc:193-203
+    int t = rid1; rid1 = rid2; rid2 = t;
+    t = pos1; pos1 = pos2; pos2 = t;
+    const uint8_t u = st1; st1 = st2; st2 = u;
+  }
+  uint8_t *o8 = d.rec + slot * 24;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
+  o32[0] = d.first_read_id + pair;
+  o32[1] = (uint32_t)rid1;
+  o32[2] = (uint32_t)rid2;
+  o32[3] = (uint32_t)pos1;
+  o32[4] = (uint32_t)pos2;
+  o8[20] = st1; o8[21] = st2; o8[22] = mapq; o8[23] = is_unique;
+  d.rec_ok[slot] = 1;
+}
+
 // Build the output record for the chosen best pair: ProcessBestMappingsForPairedEndReadOn-
 // OneDirection (mapping_generator.h:487-653) + EmplaceBackPairedEndMappingRecord
 // (mapping_generator.cc:111-125) + PairedEndMappingInMemory getters (mapping_in_memory.h:64-108)
@@ -3087,6 +3111,10 @@ CM_HD void cm_emit_record(const CmDev &d, uint32_t pair, const CmPe &pe, uint32_
   const int force_mapq = d.force0[pair] ? 0 : -1;
   const uint8_t mapq = cm_mapq_paired(d, pair, e1, e2, al1, al2, (int)len1, (int)len2, force_mapq, pe);
   const uint8_t is_unique = (pe.n_best == 1 || d.n_best[r1] == 1 || d.n_best[r2] == 1) ? 1 : 0;
+  if (!SAM && d.p.pairs_out) {  // --pairs without split alignment: the same pairing as a PairsMapping (mapq: the pair's)
+    cm_put_pairs_record(d, slot, pair, a, b, s1, s2, mapq, is_unique);
+    return;
+  }
   const CmSpan &ps = dir == 0 ? a : b;  // the + strand read
   const CmSpan &ns = dir == 0 ? b : a;
   uint8_t *o = d.rec + slot * 24;
@@ -3261,25 +3289,7 @@ CM_HD void cm_emit_pairs_record(const CmDev &d, uint32_t pair, const CmPe &pe, u
     d.rec_ok[slot] = 1;
     return;
   }
-  uint8_t st1 = s1 == 0 ? 1 : 0, st2 = s2 == 0 ? 1 : 0;
-  int pos1 = (int)(s1 == 0 ? a.ref_start : a.ref_end), pos2 = (int)(s2 == 0 ? b.ref_start : b.ref_end);
-  int rid1 = (int)a.rid, rid2 = (int)b.rid;
-  const uint32_t k1 = d.pairs_rank ? d.pairs_rank[rid1] : (uint32_t)rid1, k2 = d.pairs_rank ? d.pairs_rank[rid2] : (uint32_t)rid2;
-  if (!(k1 < k2 || (rid1 == rid2 && pos1 < pos2))) {  // mapping_generator.cc:193-203
-    int t = rid1; rid1 = rid2; rid2 = t;
-    t = pos1; pos1 = pos2; pos2 = t;
-    const uint8_t u = st1; st1 = st2; st2 = u;
-  }
-  const uint64_t slot = (uint64_t)pair * (uint32_t)d.p.max_best + nth;
-  uint8_t *o8 = d.rec + slot * 24;
-  uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
-  o32[0] = d.first_read_id + pair;
-  o32[1] = (uint32_t)rid1;
-  o32[2] = (uint32_t)rid2;
-  o32[3] = (uint32_t)pos1;
-  o32[4] = (uint32_t)pos2;
-  o8[20] = st1; o8[21] = st2; o8[22] = mapq; o8[23] = is_unique;
-  d.rec_ok[slot] = 1;
+  cm_put_pairs_record(d, (uint64_t)pair * (uint32_t)d.p.max_best + nth, pair, a, b, s1, s2, mapq, is_unique);
 }
 
 // split-mode pairing (mapping_generator.h:389-415): every (best of read1, best of read2)

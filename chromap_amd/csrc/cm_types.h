@@ -66,7 +66,7 @@ enum CmList : uint32_t {
 };
 #define CM_HV_LISTS 32
 #define CM_RS_SEGS 64           // rescue list segments (one counter each, on its own cache line)
-#define CM_MAX_BEST 64          // upper bound on max_num_best_mappings (-n)
+#define CM_MAX_BEST 8192        // upper bound on max_num_best_mappings (-n): a 500 000-pair batch then has 2^32 record slots, which are addressed with 32 bits
 #define CM_SORT_SERIAL_MAX 24   // cm_sort_cand / cm_sort_draft: insertion sort up to here, heap sort beyond
 #define CM_SORT_WAVE_MAX 1024   // longest list a wave sorts in LDS (k_sort_lists)
 
@@ -92,6 +92,7 @@ struct CmParams {
   int32_t lanes;         // GetNumVPULanes(): 8 if e<8, 4 if e<16, else 0
   int32_t ref_batch;     // 500000
   int32_t grain;         // 5000
+  int32_t pairs_out;     // mapping_output_format == PAIRS without split alignment: the pairing's record is a cmgpu_pairs_record
   int32_t sam;           // mapping_output_format == SAM: coordinates from ksw_semi_global3, CIGAR / NM / MD kept
 };
 

@@ -34,6 +34,7 @@ extern "C" {
 #define CMGPU_EFORMAT (-7)
 
 #define CMGPU_FORMAT_SAM 1
+#define CMGPU_FORMAT_PAIRS 2 /* --pairs WITHOUT split alignment: cmgpu_map_pairs leaves cmgpu_pairs_record entries (MapPairedEndReads<PairsMapping>, src/chromap_driver.cc:748-751) */
 
 /* The minimizer index exactly as Index::Load leaves it in host memory
  * (src/index.cc:132-169, kh_load src/khash.h:358-373): khash open-addressing arrays with
@@ -67,20 +68,21 @@ typedef struct cmgpu_params {
   int32_t max_seed_frequency1;    /* -f second value */
   int32_t max_insert_size;        /* -l */
   int32_t min_read_length;        /* --min-read-length */
-  int32_t max_num_best_mappings;  /* -n: up to this many records per read / pair (1..64), reservoir-sampled when there are more
+  int32_t max_num_best_mappings;  /* -n: up to this many records per read / pair (1..8192), reservoir-sampled when there are more
                                    * best mappings (mapping_generator.h:121-139,199-214); not with CMGPU_FORMAT_SAM */
   int32_t drop_repetitive_reads;  /* --drop-repetitive-reads */
   int32_t trim_adapters;          /* --trim-adapters */
   int32_t split_alignment;        /* --split-alignment (records are then cmgpu_pairs_record) */
   int32_t mapq_threshold;         /* -q; used by cmgpu_write_bed_pe only */
-  int32_t remove_pcr_duplicates;  /* used by cmgpu_write_bed_pe only */
+  int32_t remove_pcr_duplicates;  /* used by the writers / cmgpu_store_format* only */
   int32_t tn5_shift;              /* used by cmgpu_write_bed_pe only */
-  int32_t low_memory_mode;        /* used by cmgpu_write_bed_pe only */
+  int32_t low_memory_mode;        /* used by the writers / cmgpu_store_format* only */
   int32_t read_batch_size;        /* Chromap::read_batch_size_ = 500000 (chromap.h:182) */
   int32_t taskloop_grain_size;    /* 5000 (chromap.h:887): scope of the reservoir RNG */
   int32_t bc_error_threshold;     /* --bc-error-threshold (0, 1 or 2 on the device) */
   int32_t output_mappings_not_in_whitelist; /* --output-mappings-not-in-whitelist */
-  int32_t output_format;          /* 0: BED / pairs records; CMGPU_FORMAT_SAM: --SAM (alignment coordinates, CIGAR, NM, MD) */
+  int32_t output_format;          /* 0: BED records (pairs records with split_alignment); CMGPU_FORMAT_SAM: --SAM (alignment coordinates, CIGAR,
+                                   * NM, MD); CMGPU_FORMAT_PAIRS: pairs records from the ordinary (non-split) pairing */
   int32_t dedup_at_bulk_level;    /* single-cell BED, low-memory flavour: --remove-pcr-duplicates-at-bulk-level (the reference's
                                    * default without --preset atac); applied by cmgpu_store_format only */
   double bc_probability_threshold; /* --bc-probability-threshold */
@@ -426,6 +428,15 @@ int64_t cmgpu_write_sam_barcoded(const char *const *ref_names, const uint32_t *r
                                  const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
                                  const char *quals2, const uint32_t *offsets2, const uint64_t *barcode_keys, uint32_t barcode_length,
                                  const char *out_path);
+/* the same with --barcode-translate (src/barcode_translator.h:43-101, src/mapping_writer.cc:350-354): the CB:Z: value goes through the
+ * translation table, whose (inflated) text the caller hands over -- lines "to<TAB or ,>from".  A barcode that is not in the
+ * table: CMGPU_EFORMAT (the reference exits with "Barcode does not exist in the translation table."). */
+int64_t cmgpu_write_sam_barcoded_translated(const char *const *ref_names, const uint32_t *ref_lengths, uint32_t n_sequences, const cmgpu_params *params,
+                                            const cmgpu_sam_record *records, uint64_t n_slots, int paired, const uint32_t *cigar_pool,
+                                            const char *md_pool, uint32_t md_cap, const char *const *names1, const char *const *names2,
+                                            const char *bases1, const char *quals1, const uint32_t *offsets1, const char *bases2,
+                                            const char *quals2, const uint32_t *offsets2, const uint64_t *barcode_keys, uint32_t barcode_length,
+                                            const char *translate_table, uint64_t translate_table_bytes, const char *out_path);
 
 /* ---- device-side post-processing -------------------------------------
  * Replaces, for BED output: MappingProcessor::SortOutputMappings / RemovePCRDuplicate

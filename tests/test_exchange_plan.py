@@ -19,9 +19,9 @@ class Op(C.Structure):
 def plan(L, rank, world, matrix):
     flat = (C.c_uint64 * (world * world))(*[matrix[r][j] for r in range(world) for j in range(world)])
     n = C.c_uint32(0)
-    assert L.cmgpu_exchange_plan(rank, world, flat, None, 0, C.byref(n)) == 0
+    assert L.cmgpu_exchange_plan(rank, world, C.cast(flat, C.c_void_p), None, 0, C.byref(n)) == 0
     ops = (Op * max(1, n.value))()
-    assert L.cmgpu_exchange_plan(rank, world, flat, ops, n.value, C.byref(n)) == 0
+    assert L.cmgpu_exchange_plan(rank, world, C.cast(flat, C.c_void_p), C.cast(ops, C.c_void_p), n.value, C.byref(n)) == 0
     return [(ops[i].kind, ops[i].peer, ops[i].records) for i in range(n.value)]
 
 
@@ -64,7 +64,6 @@ def simulate_group(plans, world):
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 def test_rounds_cannot_deadlock(world):
     L = _capi.lib()
-    L.cmgpu_exchange_plan.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(Op), C.c_uint32, C.POINTER(C.c_uint32)]
     rng = random.Random(1234 + world)
     for name, m in matrices(world, rng):
         plans = [plan(L, r, world, m) for r in range(world)]
@@ -92,10 +91,10 @@ def test_rounds_cannot_deadlock(world):
 
 def test_plan_refuses_bad_arguments():
     L = _capi.lib()
-    L.cmgpu_exchange_plan.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(Op), C.c_uint32, C.POINTER(C.c_uint32)]
     m = (C.c_uint64 * 4)(1, 2, 3, 4)
     n = C.c_uint32(0)
-    assert L.cmgpu_exchange_plan(2, 2, m, None, 0, C.byref(n)) != 0   # rank outside the world
-    assert L.cmgpu_exchange_plan(0, 0, m, None, 0, C.byref(n)) != 0
+    mp = C.cast(m, C.c_void_p)
+    assert L.cmgpu_exchange_plan(2, 2, mp, None, 0, C.byref(n)) != 0   # rank outside the world
+    assert L.cmgpu_exchange_plan(0, 0, mp, None, 0, C.byref(n)) != 0
     ops = (Op * 1)()
-    assert L.cmgpu_exchange_plan(0, 2, m, ops, 1, C.byref(n)) != 0 and n.value == 5  # too small: the count is still reported
+    assert L.cmgpu_exchange_plan(0, 2, mp, C.cast(ops, C.c_void_p), 1, C.byref(n)) != 0 and n.value == 5  # too small: the count is still reported

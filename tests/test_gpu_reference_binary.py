@@ -58,6 +58,13 @@ RUNS = {
     "minlen20_barcodes": ("short", ["--preset", "atac", "--min-read-length", "20"], False, True),
     "n5_q0": ("short", ["--preset", "atac", "-n", "5", "-q", "0"], False, False),
     "n5_e5_se_q0": ("short", ["--preset", "chip", "-n", "5", "-e", "5", "-q", "0"], True, False),
+    # more best mappings than the 64 record slots per read rounds 1-5 had (the data has a family of ~300 exact copies)
+    "n100_q0": ("short", ["--preset", "atac", "-n", "100", "-q", "0"], False, False),
+    "n300_se_q0": ("short", ["--preset", "chip", "-n", "300", "-q", "0"], True, False),
+    # --pairs on the ordinary (non-split) pairing: MapPairedEndReads<PairsMapping> (chromap_driver.cc:748-751)
+    "pairs_nonsplit_q0": ("mid", ["--pairs", "-q", "0"], False, False),
+    "pairs_nonsplit_atac": ("short", ["--preset", "atac", "--pairs"], False, False),
+    "pairs_nonsplit_n3_q0": ("short", ["--pairs", "-l", "1500", "-n", "3", "-q", "0", "--remove-pcr-duplicates"], False, False),
 }
 
 
@@ -249,3 +256,80 @@ def test_single_end_barcode_translate_and_skip_check(data, tmp_path):
     subprocess.run([CLI] + common + ["-o", out_gpu], check=True, stderr=subprocess.PIPE)
     assert os.path.getsize(out_ref) > 100000
     assert ds.md5(out_gpu) == ds.md5(out_ref)
+
+
+def test_instrument_shaped_million_pairs(tmp_path):
+    """One million pairs shaped like an instrument's output (tools/gen_real.py): read lengths mixed per read, 36-151 bases,
+    per-base qualities from a position-dependent model with the substitutions drawn from them, 0.5 % of the bases N, adapter
+    read-through; a reference with 10 % soft-masked (lower-case) segments, IUPAC ambiguity codes and N runs.  --preset atac
+    (trimming, duplicate removal, Tn5 shift), --preset chip -q 0 (every mapping, MAPQ 0 included) and --SAM on a slice, BGZF
+    and plain text inputs: byte-identical to the reference binary."""
+    if not os.path.exists(REF):
+        pytest.skip("built reference binary not present")
+    pre = str(tmp_path / "d")
+    subprocess.check_call([sys.executable, os.path.join(ds.ROOT, "tools", "gen_real.py"), "--out", pre, "--genome", "60000000", "--chroms", "8",
+                           "--pairs", "1000000", "--seed", "606"])
+    idx = pre + ".idx"
+    subprocess.run([CLI, "-i", "-r", pre + ".fa", "-o", idx], check=True, stderr=subprocess.PIPE)
+    reads = ["-x", idx, "-r", pre + ".fa", "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    lens = set()
+    with open(pre + "_1.fq", "rb") as f:
+        for i, ln in enumerate(f):
+            if i % 4 == 1:
+                lens.add(len(ln) - 1)
+            if i > 40000:
+                break
+    assert min(lens) <= 40 and max(lens) == 151 and len(lens) > 100  # mixed lengths, as generated
+    for name, flags in (("atac", ["--preset", "atac"]), ("chip_q0", ["--preset", "chip", "-q", "0"])):
+        out_ref, out_gpu = pre + "." + name + ".ref", pre + "." + name + ".gpu"
+        r = subprocess.run([REF] + flags + reads + ["-o", out_ref, "-t", "64"], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        g = subprocess.run([CLI] + flags + reads + ["-o", out_gpu], stderr=subprocess.PIPE)
+        assert g.returncode == 0, g.stderr.decode()[-2000:]
+        assert os.path.getsize(out_ref) > 20_000_000, name
+        assert ds.md5(out_gpu) == ds.md5(out_ref), name
+    # --SAM (qualities and read names in the output) on the first 100 000 pairs
+    for tag in ("_1", "_2"):
+        with open(pre + tag + ".fq", "rb") as f, open(pre + tag + ".head.fq", "wb") as g:
+            for i, ln in enumerate(f):
+                if i >= 400000:
+                    break
+                g.write(ln)
+    sreads = ["-x", idx, "-r", pre + ".fa", "-1", pre + "_1.head.fq", "-2", pre + "_2.head.fq"]
+    r = subprocess.run([REF, "--preset", "chip", "--SAM"] + sreads + ["-o", pre + ".ref.sam", "-t", "64"], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    g = subprocess.run([CLI, "--preset", "chip", "--SAM"] + sreads + ["-o", pre + ".gpu.sam"], stderr=subprocess.PIPE)
+    assert g.returncode == 0, g.stderr.decode()[-2000:]
+    assert ds.md5(pre + ".gpu.sam") == ds.md5(pre + ".ref.sam")
+
+
+@pytest.mark.parametrize("single", [False, True], ids=["paired", "single_end"])
+def test_sam_barcode_translate(single, data, tmp_path):
+    """--SAM with --barcode-translate: the CB:Z: tag of every line goes through the translation table (a gzip-compressed one,
+    which the reference reads with gzopen); a table that lacks a barcode ends both programs with the same message"""
+    import gzip
+    pre, idx = data("short")
+    table = str(tmp_path / "tr.tsv.gz")
+    with open(pre + ".whitelist.txt") as f, gzip.open(table, "wt") as g:
+        for i, ln in enumerate(f):
+            g.write("CELL%05d\t%s\n" % (i, ln.strip()))
+    reads = ["-1", pre + "_1.fq"] + ([] if single else ["-2", pre + "_2.fq"])
+    common = ["--preset", "atac", "--SAM", "--barcode-translate", table, "-x", idx, "-r", pre + ".fa"] + reads + \
+             ["-b", pre + "_bc.fq", "--barcode-whitelist", pre + ".whitelist.txt"]
+    out_ref, out_gpu = str(tmp_path / "r.sam"), str(tmp_path / "g.sam")
+    subprocess.run([REF] + common + ["-o", out_ref, "-t", "32"], check=True, stderr=subprocess.PIPE)
+    subprocess.run([CLI] + common + ["-o", out_gpu], check=True, stderr=subprocess.PIPE)
+    assert b"CB:Z:CELL" in open(out_ref, "rb").read(1 << 16)
+    assert os.path.getsize(out_ref) > 1000000
+    assert ds.md5(out_gpu) == ds.md5(out_ref)
+    if not single:
+        short = str(tmp_path / "short.tsv")
+        with open(pre + ".whitelist.txt") as f, open(short, "w") as g:
+            for i, ln in enumerate(f):
+                if i < 10:
+                    g.write("C%d\t%s\n" % (i, ln.strip()))
+        bad = [x if x != table else short for x in common]
+        r = subprocess.run([REF] + bad + ["-o", out_ref, "-t", "32"], stderr=subprocess.PIPE)
+        g = subprocess.run([CLI] + bad + ["-o", out_gpu], stderr=subprocess.PIPE)
+        assert r.returncode != 0 and g.returncode != 0
+        assert b"Barcode does not exist in the translation table." in r.stderr and b"Barcode does not exist in the translation table." in g.stderr
