@@ -92,7 +92,7 @@ assert C.sizeof(RecordBc) == 32
 # every symbol include/chromap_amd.h (the boundary) and include/chromap_amd_debug.h (measurement / test hooks) declare
 SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_create_synthetic", "cmgpu_create_from_reference",
            "cmgpu_save_index_file", "cmgpu_create_shared", "cmgpu_set_chr_order", "cmgpu_set_pairs_chr_order", "cmgpu_write_pairs_ranked", "cmgpu_destroy",
-           "cmgpu_last_error", "cmgpu_map_pairs", "cmgpu_map_pairs_async", "cmgpu_wait", "cmgpu_upload_batch", "cmgpu_map_resident",
+           "cmgpu_last_error", "cmgpu_last_error_thread", "cmgpu_map_pairs", "cmgpu_map_pairs_async", "cmgpu_wait", "cmgpu_upload_batch", "cmgpu_map_resident",
            "cmgpu_download_records", "cmgpu_generate_resident_batch", "cmgpu_download_batch", "cmgpu_probe_bench", "cmgpu_gather_bench",
            "cmgpu_last_timings", "cmgpu_index_info", "cmgpu_export_index", "cmgpu_records_to_device", "cmgpu_records_partition",
            "cmgpu_export_reference", "cmgpu_reference_lengths", "cmgpu_write_bed_pe", "cmgpu_write_pairs", "cmgpu_map_single", "cmgpu_write_bed_se", "cmgpu_load_whitelist_file", "cmgpu_set_whitelist", "cmgpu_store_format_pairs", "cmgpu_write_pairs_header",
@@ -145,6 +145,7 @@ def declare(L):
     sig("cmgpu_create_shared", C.c_int, [C.c_void_p, P(C.c_void_p)])
     sig("cmgpu_destroy", C.c_int, [C.c_void_p])
     sig("cmgpu_last_error", C.c_char_p, [C.c_void_p])
+    sig("cmgpu_last_error_thread", C.c_char_p, [])
     sig("cmgpu_map_pairs", C.c_int, [C.c_void_p, P(Batch), C.c_void_p, C.c_uint64, P(C.c_uint64), P(Stats)])
     sig("cmgpu_map_pairs_async", C.c_int, [C.c_void_p, P(Batch), P(Stats)])
     sig("cmgpu_wait", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)])

@@ -31,12 +31,15 @@ static thread_local std::string g_last_error;  // errors without a ctx (creation
 
 // environment knobs (include/chromap_amd_debug.h): read once
 static bool cm_debug_pool() { static const bool on = getenv("CM_DEBUG_POOL") != nullptr; return on; }
+static thread_local std::string t_last_error;  // the calling thread's own last message (calls on one ctx from several threads: cmgpu_fastq_scan*)
 void cm_set_error(cmgpu_ctx *ctx, const std::string &msg) {
   static std::mutex mu;  // (the scans of a batch's files may fail side by side)
   std::lock_guard<std::mutex> lk(mu);
   if (ctx) ctx->err = msg;
   g_last_error = msg;
+  t_last_error = msg;
 }
+extern "C" const char *cmgpu_last_error_thread(void) { return t_last_error.c_str(); }
 
 int DevBuf::ensure(size_t bytes) {
   if (bytes <= cap) return 0;
@@ -290,6 +293,7 @@ int cm_upload_reference(cmgpu_ctx *c, const cmgpu_ref_view *ref) {
   c->n_seq = ref->n_sequences;
   c->h_ref_off.resize(c->n_seq);
   c->h_ref_len.assign(ref->lengths, ref->lengths + c->n_seq);
+  c->goff_tried = false; c->goff.release();  // (the 32-bit key offsets follow the reference's lengths)
   uint64_t tot = 64;
   for (uint32_t i = 0; i < c->n_seq; ++i) {
     c->h_ref_off[i] = tot;
@@ -400,6 +404,7 @@ extern "C" int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out) {
   if (parent->ref_pl_words) { view(c->ref_planes, parent->ref_planes); c->ref_pl_words = parent->ref_pl_words; }  // (else: its own, on its first call)
   if (parent->fmask) { view(c->bkt_fast, parent->bkt_fast); c->fmask = parent->fmask; }
   c->h_ref_off = parent->h_ref_off; c->h_ref_len = parent->h_ref_len;
+  c->goff_tried = false; c->goff.release();
   c->synth_n_minimizers = parent->synth_n_minimizers; c->synth_n_keys = parent->synth_n_keys;
   // --chr-order / --pairs-natural-chr-order of the parent apply to the child too (records carry ranks)
   if (parent->has_rank) {
@@ -718,8 +723,9 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
     c->goff_tried = true;
     std::vector<uint32_t> go(c->n_seq + 1);
     uint64_t acc = 0;
-    for (uint32_t i = 0; i < c->n_seq; ++i) { go[i] = (uint32_t)acc; acc += (uint64_t)c->h_ref_len[i] + CM_GOFF_GAP; if (acc >= 0xffff0000ull) break; }
-    if (acc < 0xffff0000ull && c->n_seq && c->h_ref_len.size() == c->n_seq && !getenv("CM_NO_KEY32")) {
+    const bool lens_ok = c->n_seq && c->h_ref_len.size() == c->n_seq;  // (checked BEFORE the loop reads h_ref_len[i])
+    for (uint32_t i = 0; lens_ok && i < c->n_seq; ++i) { go[i] = (uint32_t)acc; acc += (uint64_t)c->h_ref_len[i] + CM_GOFF_GAP; if (acc >= 0xffff0000ull) break; }
+    if (lens_ok && acc < 0xffff0000ull && !getenv("CM_NO_KEY32")) {
       go[c->n_seq] = (uint32_t)acc;
       if (c->goff.ensure(go.size() * 4) == 0 && hipMemcpy(c->goff.p, go.data(), go.size() * 4, hipMemcpyHostToDevice) != hipSuccess) c->goff.release();
     }
@@ -782,6 +788,11 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
     if (c->opt_heavy_max[0] < 0) { d.hv_max[0] = d.hv_max[1] = d.hv_max[2] = d.hv_max[3] = 0; d.hv_big = 0; }  // everything long goes to the one-lane path
     // the rescue lists' classes: the hit lists' up to 2048, then as many 20-byte entries as fit a CU's shared memory twice / once
     d.rs_max3 = d.hv_max[3] < 3968u ? d.hv_max[3] : 3968u;
+    // (round 6, measured and NOT kept: 32-bit keys in k_s4b_coop as in k_s3b_coop -- 12 instead of 20 bytes per entry, classes of 6 400 / 3 968
+    //  entries at two / three blocks per CU.  The stage got SLOWER, profile 2 46.5 -> 49.7 ms and profile 1 9.7 -> 18.3 ms per step: unlike the
+    //  hit lists, the rescue lists are merged with the read's own candidates and written back as sequence << 32 | position, so every hit
+    //  pays a lookup of its sequence's offset on the way in and every candidate a search of the offset table on the way out, and the
+    //  groups' time is not the number of reads in flight here)
     d.rs_big = d.hv_big ? (hv_big_area < 7680u ? hv_big_area : 7680u) : 0u;
     if (d.rs_big <= d.rs_max3) d.rs_big = 0;
     d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
@@ -1018,11 +1029,16 @@ static int map_range(cmgpu_ctx *c, uint32_t rlo, uint32_t rhi, uint64_t *k_out, 
   HIPCHECK(c, hipMemsetAsync(c->rs_cnt.p, 0, CM_RS_SEGS * 64, s));
   if (c->opt_coop & 2) {  // the pool of rescue hits found while counting: sized from what the previous range asked for (+ 25 %)
     // (+ a grant per wave that can take one, cm_coop_pool_take: what the waves leave unused of their last grants)
-    uint64_t want = c->rs_pool_want + c->rs_pool_want / 4 + (uint64_t)8192 * CM_POOL_GRANT / 2;
+    // slack: half a grant for every wave of the rescue-wave launch (rescue_wave_blocks: n / 512 + 64, at most 8192) -- but only once the
+    // waves have taken grants at all (a range whose searches never asked leaves rs_pool_want at 0: no 268 MB per lane for nothing)
+    uint64_t waves = (uint64_t)n2 / 512 + 64;
+    if (waves > 8192) waves = 8192;
+    const uint64_t slack = c->rs_pool_want ? waves * CM_POOL_GRANT / 2 : 0;
+    uint64_t want = c->rs_pool_want + c->rs_pool_want / 4 + slack;
     // (a range that ran out of pool undercounts what it would have used -- the pieces behind the refusal are only estimated -- and
     // growing the pool is a hipFree + hipMalloc of gigabytes, 0.3-0.5 s: grow once, generously)
-    if (c->rs_pool_want > c->rs_pool_cap) want = 2 * c->rs_pool_want + (uint64_t)8192 * CM_POOL_GRANT / 2;
-    if (want < (1u << 24)) want = 1u << 24;  // (128 MB to begin with: growing costs a hipFree + hipMalloc in the middle of a run)
+    if (c->rs_pool_want > c->rs_pool_cap) want = 2 * c->rs_pool_want + slack;
+    if (want < (1u << 22)) want = 1u << 22;  // (32 MB to begin with: a first grant per wave of a small batch; the pool then follows the demand)
     if (want > 0xfffffff0ull) want = 0xfffffff0ull;
     const auto dbg_t0 = std::chrono::steady_clock::now();
     if (c->rs_pool.ensure((size_t)want * 8) == 0 && c->rs_pool_off.ensure((size_t)n2 * 2 * 4 + 16) == 0) c->rs_pool_cap = (uint32_t)(c->rs_pool.cap / 8 > 0xfffffff0ull ? 0xfffffff0ull : c->rs_pool.cap / 8);

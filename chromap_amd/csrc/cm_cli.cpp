@@ -526,7 +526,6 @@ static Args parse(int argc, char **argv) {
   }
   // the reference accepts these combinations; this build has no record type for them -- refuse instead of writing garbage
   if (a.out_pairs && !a.p.split_alignment) a.p.output_format = CMGPU_FORMAT_PAIRS;  // MapPairedEndReads<PairsMapping> on the ordinary pairing (chromap_driver.cc:748-751)
-  if (a.out_pairs && !a.bc.empty()) die("pairs output with cell barcodes is outside this build");
   if (a.gpus < 1 || a.gpus > 64) die("--gpus must be 1..64");
   if (a.p.max_num_best_mappings > 64) {
     const uint64_t budget = 1ull << 30;  // record slots per batch (31 GB of HBM)
@@ -763,6 +762,7 @@ int main(int argc, char **argv) {
         const double ts0 = now_s();
         // the files' scans (upload, inflate, line index, record checks) run side by side: a host thread and a HIP stream per file
         int src[3] = {CMGPU_OK, CMGPU_OK, CMGPU_OK};
+        std::string serr[3];  // a failed scan's own message (two files may fail differently at the same time)
         {
           std::thread th[3];
           auto scan = [&](int m) {
@@ -770,6 +770,7 @@ int main(int argc, char **argv) {
             const bool fin = dev ? rd[m].dev_final() : rd[m].eof;
             src[m] = dev ? cmgpu_fastq_scan_bgzf(cx, sid[m], rd[m].zdata(), rd[m].zready, fin, &cnt[m])
                          : cmgpu_fastq_scan(cx, sid[m], rd[m].text(), rd[m].len, rd[m].eof, &cnt[m]);
+            if (src[m] != CMGPU_OK) serr[m] = cmgpu_last_error_thread();
           };
           for (int m = 1; m < ns_streams; ++m) th[m] = std::thread(scan, m);
           scan(0);
@@ -780,10 +781,10 @@ int main(int argc, char **argv) {
           const bool fin = dev ? rd[m].dev_final() : rd[m].eof;
           all_final = all_final && fin;
           const int rc = src[m];
-          if (rc == CMGPU_EFORMAT && dev && strstr(cmgpu_last_error(cx), "BGZF"))
-            die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + cmgpu_last_error(cx) + ")");
-          if (rc == CMGPU_EFORMAT) die(std::string(cmgpu_last_error(cx)) + " -- rerun with --host-ingest");
-          ckx(rc);
+          if (rc == CMGPU_EFORMAT && dev && strstr(serr[m].c_str(), "BGZF"))
+            die(std::string("Didn't reach the end of sequence file, which might be corrupted! (") + serr[m] + ")");
+          if (rc == CMGPU_EFORMAT) die(serr[m] + " -- rerun with --host-ingest");
+          if (rc != CMGPU_OK) die(serr[m]);
         }
         const double ts1 = now_s();
         uint32_t n = cnt[0];

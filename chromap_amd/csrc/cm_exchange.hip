@@ -154,15 +154,23 @@ __device__ __forceinline__ uint32_t ex_owner(const uint8_t *__restrict__ rec, ui
   const uint32_t rid = reinterpret_cast<const uint32_t *>(rec + (uint64_t)i * 24)[1];
   return rid < n_seq ? owner[rid] : 0u;
 }
-// pass 1: records per owner (block histogram in LDS, one global atomic per owner and block)
+// pass 1: records per owner (block histogram in LDS, one global atomic per owner and block).  A block takes EX_PER_BLOCK records -- a
+// block per 256 records was 15 625 blocks for a 4 M-pair batch, each with up to `world` atomics on the same `world` addresses, and
+// same-address atomics retire at ~90 per microsecond: 0.17 ms per pass of a 7 ms step spent queueing
+#define EX_ITEMS 16
+#define EX_PER_BLOCK (EX_BLOCK * EX_ITEMS)
 __global__ __launch_bounds__(EX_BLOCK) void k_ex_count(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok, uint32_t n,
                                                         const uint8_t *__restrict__ owner, uint32_t n_seq, uint32_t world,
                                                         unsigned long long *__restrict__ counts) {
   __shared__ uint32_t hist[EX_MAX_WORLD];
   if (threadIdx.x < EX_MAX_WORLD) hist[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * EX_BLOCK + threadIdx.x;
-  if (i < n && ok[i]) atomicAdd(&hist[ex_owner(rec, i, owner, n_seq)], 1u);
+  const uint32_t base = blockIdx.x * EX_PER_BLOCK;
+#pragma unroll 4
+  for (uint32_t k = 0; k < EX_ITEMS; ++k) {
+    const uint32_t i = base + k * EX_BLOCK + threadIdx.x;
+    if (i < n && ok[i]) atomicAdd(&hist[ex_owner(rec, i, owner, n_seq)], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < world && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
@@ -174,7 +182,7 @@ __global__ void k_ex_starts(const unsigned long long *__restrict__ counts, unsig
   }
 }
 // pass 2: every block reserves its share of each owner's section and copies its records there;
-// rb = 24: cmgpu_record, rb = 32: cmgpu_record_bc (barcode key appended)
+// rb = 24: cmgpu_record, rb = 32: cmgpu_record_bc (barcode key appended).  The same EX_PER_BLOCK records per block as pass 1.
 __global__ __launch_bounds__(EX_BLOCK) void k_ex_scatter(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ ok,
                                                           const uint64_t *__restrict__ bc, uint32_t n, const uint8_t *__restrict__ owner,
                                                           uint32_t n_seq, uint32_t world, unsigned long long *__restrict__ cursors,
@@ -183,18 +191,26 @@ __global__ __launch_bounds__(EX_BLOCK) void k_ex_scatter(const uint8_t *__restri
   __shared__ unsigned long long base[EX_MAX_WORLD];
   if (threadIdx.x < EX_MAX_WORLD) hist[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * EX_BLOCK + threadIdx.x;
-  const bool have = i < n && ok[i];
-  uint32_t k = 0, local = 0;
-  if (have) { k = ex_owner(rec, i, owner, n_seq); local = atomicAdd(&hist[k], 1u); }
+  const uint32_t b0 = blockIdx.x * EX_PER_BLOCK;
+  uint32_t own[EX_ITEMS], local[EX_ITEMS];
+#pragma unroll
+  for (uint32_t k = 0; k < EX_ITEMS; ++k) {
+    const uint32_t i = b0 + k * EX_BLOCK + threadIdx.x;
+    own[k] = 0xffffffffu; local[k] = 0;
+    if (i < n && ok[i]) { own[k] = ex_owner(rec, i, owner, n_seq); local[k] = atomicAdd(&hist[own[k]], 1u); }
+  }
   __syncthreads();
   if (threadIdx.x < world && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
   __syncthreads();
-  if (!have) return;
-  const uint64_t *sp = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
-  uint64_t *dp = reinterpret_cast<uint64_t *>(dst + (base[k] + local) * rb);
-  dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
-  if (rb == 32) dp[3] = bc[i / per_pair];
+#pragma unroll
+  for (uint32_t k = 0; k < EX_ITEMS; ++k) {
+    if (own[k] == 0xffffffffu) continue;
+    const uint32_t i = b0 + k * EX_BLOCK + threadIdx.x;
+    const uint64_t *sp = reinterpret_cast<const uint64_t *>(rec + (uint64_t)i * 24);
+    uint64_t *dp = reinterpret_cast<uint64_t *>(dst + (base[own[k]] + local[k]) * rb);
+    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
+    if (rb == 32) dp[3] = bc[i / per_pair];
+  }
 }
 
 // this rank's own records go from the send buffer to the store by a plain copy kernel (a device-to-device hipMemcpyAsync of
@@ -220,7 +236,7 @@ static int ex_partition(cmgpu_ctx *c, uint32_t n, uint32_t world, const uint8_t 
   hipStream_t s = c->stream;
   EXCHECK(c, hipMemsetAsync(d_counts, 0, (EX_MAX_WORLD + 1) * 8, s));
   if (n) {
-    const dim3 g((n + EX_BLOCK - 1) / EX_BLOCK), b(EX_BLOCK);
+    const dim3 g((n + EX_PER_BLOCK - 1) / EX_PER_BLOCK), b(EX_BLOCK);
     hipLaunchKernelGGL(k_ex_count, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p, n, d_owner, c->n_seq, world, d_counts);
     hipLaunchKernelGGL(k_ex_starts, dim3(1), dim3(64), 0, s, d_counts, d_cursors, world);
     hipLaunchKernelGGL(k_ex_scatter, g, b, 0, s, (const uint8_t *)c->rec.p, (const uint8_t *)c->rec_ok.p,

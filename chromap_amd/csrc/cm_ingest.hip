@@ -79,8 +79,10 @@ __global__ __launch_bounds__(FQ_BLOCK) void k_fq_records(const uint8_t *__restri
   fq_line(text, nl, 4 * r + 3, &s3, &e3);
   bool ok = e0 > s0 && text[s0] == '@' && e2 > s2 && text[s2] == '+';
   if (want_qual && (e3 - s3) != (e1 - s1)) ok = false;  // kseq: quality and sequence lengths must agree
-  // four blank lines (spaces and tabs at most) are no record and no damage either: kseq looks for the next '@' and skips them -- a
-  // file may end in any number of blank lines
+  // a GROUP of four blank lines (spaces and tabs at most) is no record and no damage either -- a file may end in any number of blank
+  // lines.  Narrower than kseq, which skips ANY junk up to the next '@': one to three blank lines between two records shift the
+  // four-line frame of every record after them here, the scan then fails with EFORMAT and the CLI says "rerun with --host-ingest"
+  // (the host parser is kseq's twin).  Tolerated on the device path: blank lines in groups of four only.
   bool blank = true;
   for (uint32_t i = s0; blank && i < e3; ++i) { const uint8_t ch = text[i]; blank = ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r'; }
   if (!ok && !blank) atomicMin(bad, r);

@@ -810,7 +810,8 @@ extern "C" int cmgpu_store_format_pairs(cmgpu_ctx *c, const char *const *names, 
                                         uint32_t read_id_base, uint64_t *n_lines, uint64_t *n_bytes) {
   if (!c || !names || !p || !n_lines || !n_bytes || (!read_names && n_read_names) || (!read_name_offsets && n_read_names)) return CMGPU_EINVAL;
   if (!cm_pairs_records(c)) { cm_set_error(c, "pairs text needs pairs records (split alignment, or output_format = CMGPU_FORMAT_PAIRS)"); return CMGPU_EINVAL; }
-  if (c->store_has_bc) { cm_set_error(c, "pairs text with cell barcodes is not supported"); return CMGPU_EINVAL; }
+  // (cell barcodes: they decided which pairs were mapped -- CorrectBarcodeAt, chromap.h:896-906 -- and go no further: a PairsMapping's barcode is
+  //  neither printed nor part of its order or equality, pairs_mapping.h:40-50, GetBarcode() == 0; the store's key array is left alone)
   PPCHECK(c, cm_enter(c));
   { const int qrc = cm_exchange_quiesce(c); if (qrc) return qrc; }
   hipStream_t s = c->stream;

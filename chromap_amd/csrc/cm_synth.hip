@@ -339,6 +339,7 @@ extern "C" int cmgpu_create_synthetic_repeats(uint64_t total_bases, uint32_t n_s
   // chromosome lengths: linear spread, largest three times the smallest (as tools/gen_synth.py)
   c->n_seq = n_sequences;
   c->h_ref_len.resize(n_sequences);
+  c->goff_tried = false; c->goff.release();  // (the 32-bit key offsets follow the reference's lengths)
   c->h_ref_off.resize(n_sequences);
   double wsum = 0;
   for (uint32_t i = 0; i < n_sequences; ++i) wsum += n_sequences > 1 ? 3.0 - 2.0 * i / (n_sequences - 1) : 1.0;

@@ -198,6 +198,9 @@ int cmgpu_create_shared(const cmgpu_ctx *parent, cmgpu_ctx **out);
 int cmgpu_destroy(cmgpu_ctx *ctx);
 /* ctx may be NULL (returns the last error of a failed cmgpu_create*). */
 const char *cmgpu_last_error(const cmgpu_ctx *ctx);
+/* the message of the last failed call made BY THE CALLING THREAD (the per-file scans of a batch -- cmgpu_fastq_scan / _scan_bgzf -- may run
+ * side by side on one ctx; cmgpu_last_error(ctx) then holds whichever failed last) */
+const char *cmgpu_last_error_thread(void);
 
 /* Replaces the taskloop body src/chromap.h:892-1143 for one batch: adapter trimming,
  * minimizers, index probe, candidate generation, mate rescue, pair filter, verification,

@@ -21,6 +21,8 @@ DATA = {
               "--barcodes", "5000"],
     "long": ["--genome", "20000000", "--chroms", "6", "--pairs", "100000", "--readlen", "150", "--frag-min", "300", "--frag-max", "800",
              "--hic", "--seed", "102", "--indel", "0.002"],
+    "long_bc": ["--genome", "20000000", "--chroms", "6", "--pairs", "60000", "--readlen", "150", "--frag-min", "300", "--frag-max", "800",
+                "--hic", "--seed", "104", "--indel", "0.002", "--barcodes", "2000"],
     "mid": ["--genome", "20000000", "--chroms", "6", "--pairs", "100000", "--readlen", "100", "--seed", "103", "--indel", "0.003",
             "--sub", "0.02"],
 }
@@ -64,6 +66,10 @@ RUNS = {
     # --pairs on the ordinary (non-split) pairing: MapPairedEndReads<PairsMapping> (chromap_driver.cc:748-751)
     "pairs_nonsplit_q0": ("mid", ["--pairs", "-q", "0"], False, False),
     "pairs_nonsplit_atac": ("short", ["--preset", "atac", "--pairs"], False, False),
+    # pairs with cell barcodes: the barcodes decide which pairs are mapped (correction against the whitelist) and are not printed
+    "pairs_nonsplit_barcodes": ("short", ["--preset", "atac", "--pairs"], False, True),
+    "hic_pairs_barcodes": ("long_bc", ["--preset", "hic"], False, True),
+    "hic_pairs_dedup_q0": ("long", ["--preset", "hic", "--remove-pcr-duplicates", "-q", "0"], False, False),
     "pairs_nonsplit_n3_q0": ("short", ["--pairs", "-l", "1500", "-n", "3", "-q", "0", "--remove-pcr-duplicates"], False, False),
 }
 
