@@ -637,6 +637,8 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     cm_coop_copy_list(g, c0p, c0c, out, outc, n1);
     return n1;
   }
+  CM_PROF_BEGIN(d);
+  CM_PROF_COUNT(d, g, 63, 1);
   uint32_t nr = 0;
   // the work buffers: shared memory, or -- a list longer than that -- the hits where they are and the group's slab of global memory
   // (SLAB is a template parameter for the reason given at cm_coop_s3b; the shared-memory form also wants the read's own candidates
@@ -649,6 +651,7 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     for (uint32_t i = g.t; i < cnt; i += (uint32_t)GT::G) m.A[i] = out[n1 + i];
     g.sync();
   }
+  CM_PROF_MARK(d, g, 58);
   if (fits) nr = cm_coop_natural_runs(g, A, cnt, m.rb, m.RB);
   if (nr == 0) {  // more hits or runs than the work area holds: the one-lane definition
     uint32_t k = 0;
@@ -661,12 +664,14 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     return cm_coop_bcast0(g, k);
   }
   uint64_t *Ssorted = cm_coop_merge_runs(g, A, B, m.rb, m.rb2, nr, cnt);
+  CM_PROF_MARK(d, g, 59);
   uint64_t *X = Ssorted;                      // the augmented list, dense: over the sorted hits once they are swept
   uint64_t *S = Ssorted == A ? B : A;         // the other buffer: parking slots of the sweep, then the staged candidates c0
   uint8_t *const cx = SLAB ? reinterpret_cast<uint8_t *>(m.gA) : m.cc2;  // the parked counts (slab mode: its first buffer is unused here)
   uint32_t naug, none;
   cm_coop_sweep(g, Ssorted, cnt, cnt, e, 1, d.mm_cnt[r], oc, S, cx, X, cc, X, cc, &naug, &none);
   g.sync();  // X / cc complete, the parking slots free
+  CM_PROF_MARK(d, g, 60);
   if (naug == 0) {
     cm_coop_copy_list(g, c0p, c0c, out, outc, n1);
     return n1;
@@ -698,12 +703,14 @@ CM_HD uint32_t cm_coop_rescue_dir(const CmDev &d, uint32_t r, GT &g, const CmCoo
     }
   }
   g.sync();
+  CM_PROF_MARK(d, g, 61);
   // ---- keep / drop, compaction
   const uint64_t E = (uint64_t)(int64_t)e;
   const uint32_t mine = cm_coop_accept_walk(zp, zc, nz, z0, z1, E, nullptr, nullptr, 0);
   uint32_t total;
   const uint32_t off = g.scan(mine, &total);
   (void)cm_coop_accept_walk(zp, zc, nz, z0, z1, E, out, outc, off);
+  CM_PROF_MARK(d, g, 62);
   return total;
 }
 
@@ -995,13 +1002,23 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
         if (!any) break;
       }
       uint32_t l2[4], h2[4], nocc[4];
+      uint64_t v0[4], v1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t q = q0 + (uint32_t)u * G;
-        if (q < np) m.pa[q] = lo[u];
         nocc[u] = 0;
         if (act[u]) { const uint32_t s = q / W; nocc[u] = (uint32_t)m.mval[s]; }
         l2[u] = lo[u]; h2[u] = 0xffffffffu;  // every index below l2 holds a position <= ee; h2: an index known to hold one above (none yet)
+        // occurrences at exactly es (two at most: one per strand; none for an index built by the reference, whose minimizers have one strand
+        // per position): the search's "equal" outcome for the midpoints lb .. lb + eq - 1.  Requested here, four pairs' worth together
+        // (round 6: a pass of its own after this loop cost a trip to the occurrence table per pair and lane -- a third of "eq + B")
+        v0[u] = act[u] && lo[u] < nocc[u] ? o[u][lo[u]] >> 1 : ~0ull;
+        v1[u] = act[u] && lo[u] + 1 < nocc[u] ? o[u][lo[u] + 1] >> 1 : ~0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = q0 + (uint32_t)u * G;
+        if (q < np) m.pa[q] = act[u] ? lo[u] | (((v0[u] == kes[u] ? 1u : 0u) + (v1[u] == kes[u] ? 1u : 0u)) << 30) : lo[u];
       }
       for (;;) {  // upper bounds: gallop (probe l2, l2 + 1, l2 + 3, ...) until a position above ee or the run's end, then bisect
         bool any = false;
@@ -1030,19 +1047,6 @@ CM_HD int cm_coop_rescue(const CmDev &d, uint32_t r, int strand, const uint64_t 
     }
     g.sync();
     CM_PROF_MARK(d, g, 50);
-    // occurrences at exactly es (two at most: one per strand; none for an index built by the reference, whose minimizers have one strand
-    // per position): the search's "equal" outcome for the midpoints lb .. lb + eq - 1
-    for (uint32_t q = g.t; q < np; q += G) {
-      const uint32_t s = q / W, w = q - s * W;
-      if (m.mps[s] >> 31) continue;
-      const uint64_t val = m.mval[s];
-      const uint32_t nocc = (uint32_t)val, lb = m.pa[q];
-      const uint64_t *o = d.occ + (uint32_t)(val >> 32);
-      const uint64_t es = m.es[w];
-      const uint64_t v0 = lb < nocc ? o[lb] >> 1 : ~0ull, v1 = lb + 1 < nocc ? o[lb + 1] >> 1 : ~0ull;
-      m.pa[q] = lb | (((v0 == es ? 1u : 0u) + (v1 == es ? 1u : 0u)) << 30);
-    }
-    g.sync();
     // -- B: the chain of searches per minimizer, on indices alone: first index and length of every pair's scan.  The reference's search
     //    for window w starts at l = the last midpoint of window w - 1's search, and a search that starts at or below the lower bound lb ends
     //    with its last midpoint at lb - 1 or lb (nothing equal to es), or at lb / lb + 1 (something equal); one that starts above lb stays
@@ -1365,11 +1369,13 @@ struct CmCoopPairMem {
   uint64_t *s1, *s2;          // P each: the two position lists, staged (their binary searches are chains of dependent loads)
   uint16_t *lo1, *of1, *of2;  // P each
   uint8_t *k1, *k2, *x1, *x2; // P each
+  uint8_t *sc1, *sc2;         // P each: the two count lists, staged with the positions (round 6: the counts were read where they lie in three of the
+                              // function's passes -- three more trips to global memory per direction in a function that is a dozen short passes)
   uint32_t P;
 };
-// staged == false: no room for the position lists (10 bytes per entry instead of 26) -- the form for the few pairs with lists
+// staged == false: no room for the position lists (10 bytes per entry instead of 28) -- the form for the few pairs with lists
 // beyond the staged classes, whose searches then run on the lists where they are (cm_coop_reduce_dir<false>)
-CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P, bool staged = true) { return (size_t)P * (staged ? 26 : 10) + 32; }
+CM_HD size_t cm_coop_pair_mem_bytes(uint32_t P, bool staged = true) { return (size_t)P * (staged ? 28 : 10) + 32; }
 CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P, bool staged = true) {
   CmCoopPairMem m;
   m.P = P;
@@ -1382,6 +1388,8 @@ CM_HD CmCoopPairMem cm_coop_pair_mem_at(uint8_t *base, uint32_t P, bool staged =
   m.k2 = m.k1 + P;
   m.x1 = m.k2 + P;
   m.x2 = m.x1 + P;
+  m.sc1 = staged ? m.x2 + P : nullptr;
+  m.sc2 = staged ? m.sc1 + P : nullptr;
   return m;
 }
 template <bool STAGED, class GT>
@@ -1389,11 +1397,12 @@ CM_HD void cm_coop_reduce_dir(GT &g, const CmCoopPairMem &m, uint32_t dist, cons
                               const uint8_t *c2, uint32_t n2, uint64_t *f1, uint8_t *fc1, uint32_t *nf1, uint64_t *f2, uint8_t *fc2, uint32_t *nf2) {
   const uint32_t G = (uint32_t)GT::G;
   if (STAGED) {
-    for (uint32_t i = g.t; i < n1; i += G) m.s1[i] = gp1[i];
-    for (uint32_t j = g.t; j < n2; j += G) m.s2[j] = gp2[j];
+    for (uint32_t i = g.t; i < n1; i += G) { m.s1[i] = gp1[i]; m.sc1[i] = c1[i]; }
+    for (uint32_t j = g.t; j < n2; j += G) { m.s2[j] = gp2[j]; m.sc2[j] = c2[j]; }
   }
   g.sync();
   const uint64_t *p1 = STAGED ? m.s1 : gp1, *p2 = STAGED ? m.s2 : gp2;  // (compile-time choice: see cm_coop_s3b)
+  if (STAGED) { c1 = m.sc1; c2 = m.sc2; }
   // ---- list 1: lo, paired; x1 = count of a paired entry (for max1), else 0
   uint32_t my_end = n1;
   for (uint32_t i = g.t; i < n1; i += G) {
@@ -1561,17 +1570,21 @@ CM_HD CmTwo cm_coop_two_merge(GT &g, const CmTwo &mine, int none) {
 // ---------------------------------------------------------------------------------------
 struct CmCoopVerMem {
   uint16_t *of, *fr, *pm;  // P + 1 each
-  uint8_t *vf;             // P
+  int16_t *pe;             // P: the candidates' error counts, staged (round 6: read where they lie in four of the function's passes, the
+  uint8_t *vf;             // P   counts in a fifth -- every pass then began with a trip to global memory)
+  uint8_t *sc;             // P: the candidates' counts, staged
   uint32_t P;
 };
-CM_HD size_t cm_coop_ver_mem_bytes(uint32_t P) { return (size_t)(P + 1) * 6 + P + 32; }
+CM_HD size_t cm_coop_ver_mem_bytes(uint32_t P) { return (size_t)(P + 1) * 6 + (size_t)P * 4 + 32; }
 CM_HD CmCoopVerMem cm_coop_ver_mem_at(uint8_t *base, uint32_t P) {
   CmCoopVerMem m;
   m.P = P;
   m.of = reinterpret_cast<uint16_t *>(base);
   m.fr = m.of + P + 1;
   m.pm = m.fr + P + 1;
-  m.vf = reinterpret_cast<uint8_t *>(m.pm + P + 1);
+  m.pe = reinterpret_cast<int16_t *>(m.pm + P + 1);
+  m.vf = reinterpret_cast<uint8_t *>(m.pe + P);
+  m.sc = m.vf + P;
   return m;
 }
 template <class GT>
@@ -1582,14 +1595,19 @@ CM_HD uint32_t cm_coop_draft_strand(const CmDev &d, GT &g, const CmCoopVerMem &m
   const uint32_t lanes = (uint32_t)d.p.lanes;
   if (nc == 0) return 0;
   for (uint32_t ci = g.t; ci < nc; ci += G) {
-    const uint32_t rid = (uint32_t)(cp[ci] >> 32);
-    uint32_t position = (uint32_t)cp[ci];
+    const uint64_t cpos = cp[ci];
+    m.pe[ci] = pre_err[ci];  // (one trip to global memory for everything the passes below look at)
+    m.sc[ci] = cc[ci];
+    const uint32_t rid = (uint32_t)(cpos >> 32);
+    uint32_t position = (uint32_t)cpos;
     if (strand == 1) position = position - L + 1;
     const bool valid = cm_valid_candidate(d, rid, position, L);
     m.vf[ci] = valid ? 1 : 0;
     m.of[ci] = valid ? 1 : 0;
   }
   g.sync();
+  pre_err = m.pe;
+  cc = m.sc;
   const uint32_t nvalid = cm_coop_array_scan_add(g, m.of, nc);  // of[ci] = valid candidates before ci
   uint32_t B = nc;
   if (lanes != 0 && nc >= lanes) {

@@ -47,6 +47,9 @@ def main():
     print("cm_coop_rescue (sampled waves: %d searches, %.1f rounds each, %.0f occurrences in the windows per search), cycles per search: best + windows %.0f, "
           "minimizer tables %.0f, A (bounds) %.0f, eq + B (chain) %.0f, C (scan + emit) %.0f, pool emit %.0f, tail %.0f"
           % (v[55], v[57] / ns, v[56] / ns, v[48] / ns, v[49] / ns, v[50] / ns, v[51] / ns, v[52] / ns, v[53] / ns, v[54] / ns))
+    nd = max(1, v[63])
+    print("cm_coop_rescue_dir (sampled blocks of k_s4b_coop: %d directions), cycles per direction: hits to shared memory %.0f, runs + merge sort %.0f, "
+          "sweep %.0f, own candidates staged + merge into Z %.0f, greedy walk + compaction %.0f" % (v[63], v[58] / nd, v[59] / nd, v[60] / nd, v[61] / nd, v[62] / nd))
     print("k_s5_sort_coop: %d reads, %.0f cycles of a wave per read, longest wave %d cycles; lists left to lane 0: %d not in position order, %d other"
           % (v[6], v[38] / max(1, v[6]), v[39], v[7], v[47]))
     print("timings of the last batch:", g.timings())
