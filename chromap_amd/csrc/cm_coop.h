@@ -440,6 +440,9 @@ template <class GT>
 CM_HD bool cm_coop_s3b_k32(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m) {
   const uint32_t tot = d.hit_tot[r];
   const uint32_t n = d.mm_cnt[r];
+  // (round 6: what the sweep needs of the read is requested HERE, with the list's length -- behind the merge's barriers each of these was
+  //  another trip to global memory on the group's critical path)
+  const uint32_t r2 = d.round2[r], repc = d.rep_cnt[r], hoff = d.hit_off[r];
   if (tot > m.P || !d.goff || !m.A32) return false;
   CM_PROF_BEGIN(d);
   uint32_t np, nr;
@@ -450,13 +453,13 @@ CM_HD bool cm_coop_s3b_k32(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m
   CM_PROF_MARK(d, g, 4);
   CM_PROF_COUNT(d, g, 8, 1); CM_PROF_COUNT(d, g, 9, nr); CM_PROF_COUNT(d, g, 10, tot);
   const uint32_t nn = tot - np;
-  const bool use_high = d.round2[r] && np > 0 && nn > 0;
-  int req = (int)n - (int)d.rep_cnt[r];
+  const bool use_high = r2 && np > 0 && nn > 0;
+  int req = (int)n - (int)repc;
   req = req > 1 ? req : 1;
   req = req > d.p.min_seeds ? d.p.min_seeds : req;
   if (use_high) req = d.p.min_seeds;
-  uint64_t *h = d.hbuf + d.hit_off[r];
-  uint8_t *hc = d.hcnt + d.hit_off[r];
+  uint64_t *h = d.hbuf + hoff;
+  uint8_t *hc = d.hcnt + hoff;
   uint32_t ncp, ncn;
   cm_coop_sweep(g, S, tot, np, d.p.e, req, n, m.oc, S == m.A32 ? m.B32 : m.A32, m.cc, h, hc, h + np, hc + np, &ncp, &ncn, d.prof, d.goff, d.n_seq);
   CM_PROF_MARK(d, g, 5);
@@ -1494,16 +1497,20 @@ template <bool STAGED, class GT>
 CM_HD void cm_coop_s4c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPairMem &m) {
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
   const uint32_t G = (uint32_t)GT::G;
-  if (d.mcp[r1] > m.P || d.mcn[r1] > m.P || d.mcp[r2] > m.P || d.mcn[r2] > m.P) {  // longer than the work arrays: one lane
+  // (round 6: the reads' offsets and list lengths are requested once, here -- taken where they are used, the second direction's came after
+  //  the first one's barriers: one more trip to global memory per pair)
+  const uint32_t mo1 = d.m_off[r1], mo2 = d.m_off[r2], sh1 = d.ncp[r1] + d.resc_p[r1], sh2 = d.ncp[r2] + d.resc_p[r2];
+  const uint32_t mcp1 = d.mcp[r1], mcn1 = d.mcn[r1], mcp2 = d.mcp[r2], mcn2 = d.mcn[r2];
+  if (mcp1 > m.P || mcn1 > m.P || mcp2 > m.P || mcn2 > m.P) {  // longer than the work arrays: one lane
     if (g.t == 0) { cm_s4c_filter(d, pair); cm_s4c_post(d, pair); }
     return;
   }
   uint32_t a, b, c, e2;
-  cm_coop_reduce_dir<STAGED>(g, m, (uint32_t)d.p.max_insert, cm_m_pos(d, r1), cm_m_pcnt(d, r1), d.mcp[r1], cm_m_neg(d, r2), cm_m_ncnt(d, r2), d.mcn[r2],
-                     cm_f_pos(d, r1), cm_f_pcnt(d, r1), &a, cm_f_neg(d, r2), cm_f_ncnt(d, r2), &b);
+  cm_coop_reduce_dir<STAGED>(g, m, (uint32_t)d.p.max_insert, d.mbuf + mo1, d.mcnt + mo1, mcp1, d.mbuf + mo2 + sh2, d.mcnt + mo2 + sh2, mcn2,
+                     d.fbuf + mo1, d.fcnt + mo1, &a, d.fbuf + mo2 + sh2, d.fcnt + mo2 + sh2, &b);
   g.sync();
-  cm_coop_reduce_dir<STAGED>(g, m, (uint32_t)d.p.max_insert, cm_m_neg(d, r1), cm_m_ncnt(d, r1), d.mcn[r1], cm_m_pos(d, r2), cm_m_pcnt(d, r2), d.mcp[r2],
-                     cm_f_neg(d, r1), cm_f_ncnt(d, r1), &c, cm_f_pos(d, r2), cm_f_pcnt(d, r2), &e2);
+  cm_coop_reduce_dir<STAGED>(g, m, (uint32_t)d.p.max_insert, d.mbuf + mo1 + sh1, d.mcnt + mo1 + sh1, mcn1, d.mbuf + mo2, d.mcnt + mo2, mcp2,
+                     d.fbuf + mo1 + sh1, d.fcnt + mo1 + sh1, &c, d.fbuf + mo2, d.fcnt + mo2, &e2);
   g.sync();
   const bool alive = a + c > 0 && b + e2 > 0;
   if (g.t == 0) {
@@ -1511,7 +1518,7 @@ CM_HD void cm_coop_s4c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPairMem
     d.alive[pair] = alive ? 1 : 0;
   }
   if (alive && d.rid_rank) {  // cm_rerank of both reads
-    uint64_t *l[4] = {cm_f_pos(d, r1), cm_f_neg(d, r1), cm_f_pos(d, r2), cm_f_neg(d, r2)};
+    uint64_t *l[4] = {d.fbuf + mo1, d.fbuf + mo1 + sh1, d.fbuf + mo2, d.fbuf + mo2 + sh2};
     const uint32_t n[4] = {a, c, e2, b};
     for (int q = 0; q < 4; ++q)
       for (uint32_t i = g.t; i < n[q]; i += G) l[q][i] = (l[q][i] & 0xffffffffull) | ((uint64_t)d.rid_rank[(uint32_t)(l[q][i] >> 32)] << 32);
@@ -1831,8 +1838,9 @@ template <class GT>
 CM_HD void cm_coop_s5_sort(const CmDev &d, uint32_t r, GT &g, uint16_t *hist, uint32_t nb_cap, uint64_t *lp = nullptr, uint8_t *lc = nullptr,
                            uint32_t lcap = 0) {
   const uint32_t op = d.m_off[r], on = op + d.ncp[r] + d.resc_p[r];
-  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, d.fcp[r], d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap, lp, lc, lcap, d.prof);
-  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, d.fcn[r], d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap, lp, lc, lcap, d.prof);
+  const uint32_t ncp_ = d.fcp[r], ncn_ = d.fcn[r];  // (both lengths before the first list's barriers)
+  cm_coop_sort_cand(g, d.fbuf + op, d.fcnt + op, ncp_, d.dpos + op, reinterpret_cast<uint8_t *>(d.derr + op), hist, nb_cap, lp, lc, lcap, d.prof);
+  cm_coop_sort_cand(g, d.fbuf + on, d.fcnt + on, ncn_, d.dpos + on, reinterpret_cast<uint8_t *>(d.derr + on), hist, nb_cap, lp, lc, lcap, d.prof);
 }
 // S5c for such a read (its alignments are in v_err / v_end)
 // sm: work area of the draft-mapping sort that follows the acceptance loop (it may overlay m: the loop's arrays are dead by then)
@@ -1930,28 +1938,37 @@ template <bool SAM, class GT>
 CM_HD void cm_coop_s6a(const CmDev &d, uint32_t pair, GT &g, const CmCoopPeMem &m) {
   // cm_s6a_pair's prologue ran in the per-pair kernel (record slots cleared, pe_nbest = 0, both reads have draft mappings)
   const uint32_t r1 = 2 * pair, r2 = r1 + 1;
-  for (uint32_t r = r1; r <= r2; ++r)
-    for (int st = 0; st < 2; ++st) {
-      const uint32_t n = st ? d.ndn[r] : d.ndp[r];
-      uint64_t *p = const_cast<uint64_t *>(cm_d_pos(d, r, st));
-      if (!cm_coop_is_sorted(g, p, n)) {  // lists beyond the sorting waves' size
-        if (g.t == 0) cm_sort_draft(p, const_cast<int16_t *>(cm_d_err(d, r, st)), n);
-        g.sync();
-      }
+  // (round 6: everything the function needs of the two reads is requested at once, and the four "already sorted?" passes read their lists
+  //  together -- taken one after the other, behind one another's barriers, they were a dozen dependent trips to global memory per pair)
+  const uint32_t mo1 = d.m_off[r1], mo2 = d.m_off[r2], sh1 = d.ncp[r1] + d.resc_p[r1], sh2 = d.ncp[r2] + d.resc_p[r2];
+  const uint32_t nd[4] = {d.ndp[r1], d.ndn[r1], d.ndp[r2], d.ndn[r2]};  // (read, strand): (1, +), (1, -), (2, +), (2, -)
+  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  uint64_t *const lp[4] = {d.dpos + mo1, d.dpos + mo1 + sh1, d.dpos + mo2, d.dpos + mo2 + sh2};
+  int16_t *const le[4] = {d.derr + mo1, d.derr + mo1 + sh1, d.derr + mo2, d.derr + mo2 + sh2};
+  uint32_t bad[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    for (uint32_t i = g.t + 1; i < nd[q]; i += (uint32_t)GT::G) bad[q] += lp[q][i] < lp[q][i - 1] ? 1u : 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bad[q] = g.sum(bad[q]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (bad[q]) {  // lists beyond the sorting waves' size
+      if (g.t == 0) cm_sort_draft(lp[q], le[q], nd[q]);
+      g.sync();
     }
   const int none = 2 * d.p.e + 1;
   CmTwo mine = {none, 0, none, 0};
   uint64_t first_key = ~0ull;
-  const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
   // a second list that fits the work arrays is staged there (every lane takes the same branch: the lengths are the pair's)
-  if (d.ndn[r2] <= m.P)
-    cm_coop_pair_dir<true>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2], len1, len2, mine, first_key, m.sp, m.se);
+  if (nd[3] <= m.P)
+    cm_coop_pair_dir<true>(d, g, 0, lp[0], le[0], nd[0], lp[3], le[3], nd[3], len1, len2, mine, first_key, m.sp, m.se);
   else
-    cm_coop_pair_dir<false>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2], len1, len2, mine, first_key);
-  if (d.ndp[r2] <= m.P)
-    cm_coop_pair_dir<true>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2], len1, len2, mine, first_key, m.sp, m.se);
+    cm_coop_pair_dir<false>(d, g, 0, lp[0], le[0], nd[0], lp[3], le[3], nd[3], len1, len2, mine, first_key);
+  if (nd[2] <= m.P)
+    cm_coop_pair_dir<true>(d, g, 1, lp[1], le[1], nd[1], lp[2], le[2], nd[2], len1, len2, mine, first_key, m.sp, m.se);
   else
-    cm_coop_pair_dir<false>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2], len1, len2, mine, first_key);
+    cm_coop_pair_dir<false>(d, g, 1, lp[1], le[1], nd[1], lp[2], le[2], nd[2], len1, len2, mine, first_key);
   const CmTwo all = cm_coop_two_merge(g, mine, none);
   const uint64_t fk = g.min64(first_key);
   CmPe pe;
@@ -2039,24 +2056,25 @@ CM_HD void cm_coop_s6c(const CmDev &d, uint32_t pair, GT &g, const CmCoopPeMem &
   const uint32_t K = (uint32_t)d.p.max_best;
   const uint32_t to_report = (uint32_t)nb < K ? (uint32_t)nb : K;
   const uint32_t len1 = d.rlen[r1], len2 = d.rlen[r2];
+  // (the lists' places and lengths once, before the searches' barriers: cm_coop_s6a)
+  const uint32_t mo1 = d.m_off[r1], mo2 = d.m_off[r2], sh1 = d.ncp[r1] + d.resc_p[r1], sh2 = d.ncp[r2] + d.resc_p[r2];
+  const uint32_t nd[4] = {d.ndp[r1], d.ndn[r1], d.ndp[r2], d.ndn[r2]};
+  const uint64_t *const lp[4] = {d.dpos + mo1, d.dpos + mo1 + sh1, d.dpos + mo2, d.dpos + mo2 + sh2};
+  const int16_t *const le[4] = {d.derr + mo1, d.derr + mo1 + sh1, d.derr + mo2, d.derr + mo2 + sh2};
   for (uint32_t t = 0; t < to_report; ++t) {
     const int64_t want = (int64_t)d.pe_choice[(uint64_t)pair * K + t];
     if (want > 0) {
       uint64_t seen = 0;
       uint32_t i1 = 0, i2 = 0;
       int dir = 0;
-      bool found = d.ndn[r2] <= m.P
-          ? cm_coop_pair_find<true>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
-                                    len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2, m.sp, m.se)
-          : cm_coop_pair_find<false>(d, g, 0, cm_d_pos(d, r1, 0), cm_d_err(d, r1, 0), d.ndp[r1], cm_d_pos(d, r2, 1), cm_d_err(d, r2, 1), d.ndn[r2],
-                                     len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
+      bool found = nd[3] <= m.P
+          ? cm_coop_pair_find<true>(d, g, 0, lp[0], le[0], nd[0], lp[3], le[3], nd[3], len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2, m.sp, m.se)
+          : cm_coop_pair_find<false>(d, g, 0, lp[0], le[0], nd[0], lp[3], le[3], nd[3], len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
       if (!found) {
         dir = 1;
-        found = d.ndp[r2] <= m.P
-            ? cm_coop_pair_find<true>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
-                                      len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2, m.sp, m.se)
-            : cm_coop_pair_find<false>(d, g, 1, cm_d_pos(d, r1, 1), cm_d_err(d, r1, 1), d.ndn[r1], cm_d_pos(d, r2, 0), cm_d_err(d, r2, 0), d.ndp[r2],
-                                       len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
+        found = nd[2] <= m.P
+            ? cm_coop_pair_find<true>(d, g, 1, lp[1], le[1], nd[1], lp[2], le[2], nd[2], len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2, m.sp, m.se)
+            : cm_coop_pair_find<false>(d, g, 1, lp[1], le[1], nd[1], lp[2], le[2], nd[2], len1, len2, pe.min_sum, (uint64_t)want, &seen, &i1, &i2);
       }
       if (!found) { if (g.t == 0) d.stats[CM_ST_ERR] = 2; return; }
       pe.f_dir = (uint32_t)dir; pe.f_i1 = i1; pe.f_i2 = i2;
