@@ -277,10 +277,13 @@ def s3b_roofline(g, occurrences, pairs, label):
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof)).get(label)
-            if pj and pj.get("source_sha") == probe_source_sha() and pj.get("pairs") == pairs:
-                traffic, src = pj["hbm_bytes_per_pass"], "profiles/s3b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_bench.sh)"
+            if pj and pj.get("source_sha") == probe_source_sha():
+                traffic = int(pj["hbm_bytes_per_pair"] * pairs)
+                src = ("profiles/s3b_traffic.json: %.1f HBM bytes per pair (FETCH_SIZE + WRITE_SIZE of every k_s3b_* dispatch in separate rocprofv3 --pmc passes "
+                       "over %d pairs of this workload, tools/profile_bench.sh; same sources, sha %s, commit %s) x the pairs of this pass"
+                       % (pj["hbm_bytes_per_pair"], pj.get("pairs_mapped_in_pmc_pass", 0), pj.get("source_sha"), pj.get("commit")))
             elif pj:
-                src = "profiles/s3b_traffic.json is stale (sources or batch size changed since): not reported"
+                src = "profiles/s3b_traffic.json is stale (measured on other sources: %s, this run %s): not reported" % (pj.get("source_sha"), probe_source_sha())
         except Exception:
             pass
     ach = 8.0 * occurrences / (ms * 1e-3) / 1e9
