@@ -551,7 +551,8 @@ def main():
     roof = roofline(g, args, steps)
     g.set_option("lanes", args.lanes)
     post = pcie = cpu = rep_out = harsh_out = harsh2_out = hic_out = cfg3 = None
-    if not args.skip_extras and world == 1 and args.config3_pairs and not args.strong:
+    # (on the headline genome only: a repeat-rich genome's candidate arrays for 25 M-pair sub-steps do not fit three lanes' worth of HBM)
+    if not args.skip_extras and world == 1 and args.config3_pairs and not args.strong and not args.headline_repeats:
         # BASELINE config 3 at its stated size on this one GPU: 100 M DISTINCT pairs, generated on the device and resident, mapped
         # once inside one timed step as sub-steps of <= SUB_STEP_MAX pairs (what --strong 100000000 --gpus 1 runs)
         try:

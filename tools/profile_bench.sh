@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --skip-cpu --repeats '' --harsh '' --harsh2 '' --hic-workload '' --graded-probe-only --steps 8 --warmup 2 "$@" > $O/bench_under_rocprof.json 2> $O/stats.log
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --skip-cpu --repeats '' --harsh '' --harsh2 '' --hic-workload '' --config3-pairs 0 --graded-probe-only --steps 8 --warmup 2 "$@" > $O/bench_under_rocprof.json 2> $O/stats.log
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > $O/fetch_bench.json 2> $O/fetch.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > /dev/null 2> $O/write.log
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/lds -o bench -- python $R/bench.py --skip-extras --graded-probe-only --steps 2 --warmup 0 --probe-repeat 2 "$@" > /dev/null 2> $O/lds.log
