@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/chromap_amd.h"
+#include "cm_pargz.h"
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -117,6 +118,8 @@ struct RawBuf {
 // device works on the one before.
 struct ChunkReader {
   gzFile f = nullptr;
+  ParGunzip pg;          // ordinary gzip of 16 MiB and more: inflated by several threads (cm_pargz.h); pargz says it is in use
+  bool pargz = false;
   FILE *raw = nullptr;   // BGZF and plain text: the file itself
   bool bgzf = false;
   bool plain = false;    // not gzip at all: `raw` is read directly (gzread would copy the bytes twice)
@@ -140,6 +143,12 @@ struct ChunkReader {
         const size_t r = fread(dst + got, 1, want - got, raw);
         if (r == 0) { if (ferror(raw)) die("Didn't reach the end of sequence file, which might be corrupted! (read error)"); *hit_eof = true; }
         got += r;
+      } else if (pargz) {
+        size_t g = 0;
+        bool e = false;
+        if (!pg.read(dst + got, want - got, &g, &e)) die("Didn't reach the end of sequence file, which might be corrupted! (" + pg.error + ")");
+        got += g;
+        if (e) *hit_eof = true;
       } else {
         const size_t piece = want - got < (1u << 30) ? want - got : (1u << 30);
         const int r = gzread(f, dst + got, (unsigned)piece);
@@ -186,6 +195,15 @@ struct ChunkReader {
     }
     fclose(raw);
     raw = nullptr;
+    // ordinary gzip: several inflating threads for a file of 16 MiB and more (CM_PARGZ=0: always zlib's gzread; CM_PARGZ_THREADS)
+    pargz = false;
+    const char *off_env = getenv("CM_PARGZ");
+    if (!(off_env && off_env[0] == '0')) {
+      unsigned hw = std::thread::hardware_concurrency();
+      int nt = (int)(hw / 4 < 2 ? 2 : (hw / 4 > 32 ? 32 : hw / 4));
+      if (getenv("CM_PARGZ_THREADS")) nt = atoi(getenv("CM_PARGZ_THREADS"));
+      if (pg.open(path.c_str(), nt)) { pargz = true; return true; }
+    }
     f = gzopen(path.c_str(), "r");
     if (f) gzbuffer(f, 1 << 20);
     return f != nullptr;
@@ -347,7 +365,7 @@ struct ChunkReader {
     for (size_t i = 0; i < len; ++i) { const char ch = text()[i]; if (ch != '\n' && ch != '\r' && ch != ' ' && ch != '\t') return false; }
     return true;
   }
-  void close() { if (ahead_on) { ahead.join(); ahead_on = false; } if (f) gzclose(f); f = nullptr; if (raw) fclose(raw); raw = nullptr; }
+  void close() { if (ahead_on) { ahead.join(); ahead_on = false; } if (f) gzclose(f); f = nullptr; if (raw) fclose(raw); raw = nullptr; if (pargz) { pg.close(); pargz = false; } }
 };
 
 // --read-format (Chromap::ParseReadFormat chromap.cc:825-866, SequenceEffectiveRange): per stream up to four
@@ -549,7 +567,8 @@ int main(int argc, char **argv) {
       fwrite(rd.text(), 1, take, stdout);
       rd.consume(take);
     }
-    fprintf(stderr, "%s\n", rd.bgzf ? "bgzf" : "gzread");
+    if (rd.pargz) fprintf(stderr, "pargz chunks=%llu accepted=%llu serial=%llu\n", (unsigned long long)rd.pg.n_spec, (unsigned long long)rd.pg.n_accepted, (unsigned long long)rd.pg.n_serial);
+    else fprintf(stderr, "%s\n", rd.bgzf ? "bgzf" : "gzread");
     rd.close();
     return 0;
   }

@@ -1,0 +1,470 @@
+// cm_pargz.h -- ordinary (single-stream) gzip inflated by several host threads, for the CLI's ingest (kseq sits behind ONE
+// gzread per file, sequence_batch.cc:22-62, which caps a .fastq.gz run at the rate of one inflating core -- 4.5 M pairs/s against 25-36 M
+// for BGZF, whose blocks the device inflates).  Host code only; zlib does all the decoding.
+//
+// A deflate stream has no entry points: a block can start at any BIT, and its back-references reach up to 32 KiB into output nobody has
+// produced yet.  The scheme (after pugz / rapidgzip, restated for zlib's own inflate):
+//   * the compressed bytes are cut into chunks; every chunk but the first SEARCHES the first position at or behind its start where a
+//     dynamic-Huffman block header is well-formed (complete code-length code, complete literal/length and distance codes, an end-of-block
+//     symbol: the tests of zlib's inflate_table) and from which zlib decodes on;
+//   * it then decodes from there to the first block boundary at or behind the next chunk's start -- TWICE, each time with a different
+//     made-up 32 KiB dictionary standing in for the unknown window: dict_A[k] = k & 255, dict_B[k] = 128 | k >> 8.  A byte that came
+//     from the stream itself is the same in both outputs; a byte copied (directly or through any chain of copies) from window position
+//     k reads (k & 255, 128 | k >> 8) -- A != B marks it, (A, B & 127) name k.  The one collision -- a byte >= 128 that is equal in both:
+//     a literal of binary data, or one of the 128 positions with k & 255 == 128 | k >> 8 -- is settled by a third decode with
+//     dict_C[k] = 255 ^ (k & 255) (A != C marks exactly the window bytes); text never needs it;
+//   * the consumer walks the chunks in order: the first chunk of a group is decoded with the TRUE window (it is known by then) to the first
+//     boundary at or behind the second chunk's start; a speculative chunk is accepted iff its start is EXACTLY where the decode before it
+//     ended -- then its start was a real block boundary and its decode is the real one, its marked bytes are filled in from the real
+//     window; otherwise the stretch is decoded again from the known position.  Nothing that was guessed is ever handed out: a wrong guess
+//     costs time, not correctness.  Every member's CRC-32 and length are checked against its trailer as gzread does.
+// What it does not take on (open() says no, the caller uses gzread): files under 16 MiB, anything but deflate.  Concatenated members are
+// followed; a file of many small members just runs at the serial rate.
+#ifndef CM_PARGZ_H_
+#define CM_PARGZ_H_
+
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct ParGunzip {
+  static constexpr size_t kChunk = (size_t)2 << 20;  // compressed bytes per chunk
+  static constexpr uint32_t kWin = 32768;
+  const uint8_t *z = nullptr;  // the file, mapped
+  size_t zn = 0;
+  int fd = -1;
+  int threads = 8;
+  bool active = false, done = false;
+  std::string error;           // set when the file is corrupt (the caller dies with it, as it does for gzread's errors)
+  uint64_t pos = 0;            // bit position the accepted output ends at (a block boundary; a member's first block after its header)
+  std::vector<uint8_t> win;    // the last <= 32 KiB of accepted output of the current member (its true window)
+  uint32_t crc = 0;            // of the current member's accepted output
+  uint64_t member_out = 0;
+  std::vector<uint8_t> spill;  // accepted output not yet taken by read()
+  size_t spill_off = 0;
+  // statistics (tests, --inflate-only)
+  uint64_t n_spec = 0, n_accepted = 0, n_serial = 0;
+
+  // ---- bit reader over the mapped file (deflate packs bits LSB first)
+  inline uint32_t bits(uint64_t bit, int n) const {  // n <= 24 bits at `bit`; past the end reads zeros
+    const size_t b = (size_t)(bit >> 3);
+    uint64_t v = 0;
+    for (int i = 0; i < 5; ++i) v |= (uint64_t)(b + (size_t)i < zn ? z[b + i] : 0) << (8 * i);
+    return (uint32_t)((v >> (bit & 7)) & ((1u << n) - 1u));
+  }
+  // is there a well-formed dynamic-block header (BFINAL = 0) at `bit`?  The checks of zlib's inflate (inflate.c: TABLE .. CODELENS)
+  bool plausible_header(uint64_t bit) const {
+    if (bits(bit, 3) != 4u) return false;  // BFINAL 0, BTYPE 2 (binary 10, LSB first: value 4)
+    const uint32_t h = bits(bit + 3, 14);
+    const uint32_t hlit = (h & 31u) + 257, hdist = ((h >> 5) & 31u) + 1, hclen = (h >> 10) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    uint64_t p = bit + 17;
+    for (uint32_t i = 0; i < hclen; ++i, p += 3) cl[order[i]] = (uint8_t)bits(p, 3);
+    // the code-length code must be complete (inflate_table, type CODES: an incomplete set is an error)
+    uint32_t cnt[8] = {0};
+    for (int s = 0; s < 19; ++s) cnt[cl[s]]++;
+    int left = 1;
+    for (int l = 1; l <= 7; ++l) { left = (left << 1) - (int)cnt[l]; if (left < 0) return false; }
+    if (left != 0) return false;
+    // canonical codes of the code-length code, decoded bit by bit (at most 7 bits)
+    uint32_t next[9] = {0}, code = 0;
+    cnt[0] = 0;
+    for (int l = 1; l <= 7; ++l) { code = (code + cnt[l - 1]) << 1; next[l] = code; }
+    uint32_t codes[19];
+    for (int s = 0; s < 19; ++s) codes[s] = cl[s] ? next[cl[s]]++ : 0;
+    auto decode = [&](uint64_t &q) -> int {
+      uint32_t c = 0;
+      for (int l = 1; l <= 7; ++l) {
+        c = (c << 1) | bits(q + (uint64_t)l - 1, 1);
+        for (int s = 0; s < 19; ++s) if (cl[s] == l && codes[s] == c) { q += (uint64_t)l; return s; }
+      }
+      return -1;
+    };
+    uint8_t len[320];
+    uint32_t n = 0;
+    const uint32_t total = hlit + hdist;
+    while (n < total) {
+      if ((p >> 3) + 8 > zn) return false;
+      const int s = decode(p);
+      if (s < 0) return false;
+      if (s < 16) { len[n++] = (uint8_t)s; continue; }
+      uint32_t rep, v = 0;
+      if (s == 16) { if (n == 0) return false; v = len[n - 1]; rep = 3 + bits(p, 2); p += 2; }
+      else if (s == 17) { rep = 3 + bits(p, 3); p += 3; }
+      else { rep = 11 + bits(p, 7); p += 7; }
+      if (n + rep > total) return false;
+      while (rep--) len[n++] = (uint8_t)v;
+    }
+    if (len[256] == 0) return false;  // no end-of-block code
+    auto complete = [](const uint8_t *l, uint32_t m) {  // inflate_table, types LENS / DISTS: over-subscribed is an error, incomplete only with one 1-bit code
+      uint32_t c[16] = {0};
+      uint32_t mx = 0;
+      for (uint32_t i = 0; i < m; ++i) { c[l[i]]++; if (l[i] > mx) mx = l[i]; }
+      if (mx == 0) return true;
+      int lf = 1;
+      for (int b = 1; b <= 15; ++b) { lf = (lf << 1) - (int)c[b]; if (lf < 0) return false; }
+      return lf == 0 || mx == 1;
+    };
+    return complete(len, hlit) && complete(len + hlit, hdist);
+  }
+
+  // ---- one zlib stream decoding from a bit position, block by block
+  struct Dec {
+    z_stream s;
+    const uint8_t *base = nullptr;  // the mapped file
+    size_t zn = 0;
+    bool on = false, ended = false;
+    uint64_t at = 0;                // bit position of the last block boundary reached
+    // the output: a plain growing buffer (a std::vector would zero-fill what zlib is about to overwrite, on every call)
+    struct Buf {
+      uint8_t *p = nullptr;
+      size_t len = 0, cap = 0;
+      uint8_t *data() { return p; }
+      const uint8_t *data() const { return p; }
+      size_t size() const { return len; }
+      void clear() { len = 0; }
+      void room(size_t more) {
+        if (cap - len >= more) return;
+        size_t nc = cap ? cap * 2 : (size_t)8 << 20;
+        while (nc - len < more) nc *= 2;
+        p = static_cast<uint8_t *>(realloc(p, nc));
+        cap = nc;
+      }
+      uint8_t &operator[](size_t i) { return p[i]; }
+      const uint8_t &operator[](size_t i) const { return p[i]; }
+      Buf() = default;
+      Buf(const Buf &) = delete;
+      Buf &operator=(const Buf &) = delete;
+      ~Buf() { free(p); }
+    } out;
+    bool start(const uint8_t *z, size_t n, uint64_t bit, const uint8_t *dict, uint32_t dict_len) {
+      base = z; zn = n;
+      memset(&s, 0, sizeof(s));
+      if (inflateInit2(&s, -15) != Z_OK) return false;
+      on = true; ended = false; at = bit;
+      out.clear();
+      if (dict_len && inflateSetDictionary(&s, dict, dict_len) != Z_OK) return false;
+      size_t byte = (size_t)(bit >> 3);
+      const int used = (int)(bit & 7);
+      if (used) {  // the rest of the byte the block starts in
+        if (byte >= zn || inflatePrime(&s, 8 - used, z[byte] >> used) != Z_OK) return false;
+        ++byte;
+      }
+      s.next_in = const_cast<Bytef *>(z + byte);
+      s.avail_in = 0;
+      return true;
+    }
+    // decodes until the first block boundary at or behind `stop` (or the stream's end); false: not a deflate stream here
+    bool run(uint64_t stop) {
+      for (;;) {
+        out.room((size_t)1 << 16);
+        const size_t have = out.len, room = out.cap - have;
+        s.next_out = out.p + have;
+        s.avail_out = (uInt)(room > (1u << 30) ? (1u << 30) : room);
+        const size_t in_left = (size_t)(base + zn - s.next_in);
+        if (s.avail_in == 0) s.avail_in = (uInt)(in_left > (1u << 30) ? (1u << 30) : in_left);
+        const uInt out0 = s.avail_out;
+        const int rc = inflate(&s, Z_BLOCK);
+        out.len = have + (out0 - s.avail_out);
+        if (rc == Z_STREAM_END) { ended = true; at = (uint64_t)(s.next_in - base) * 8; return true; }  // (the trailer starts on a byte)
+        if (rc != Z_OK && rc != Z_BUF_ERROR) return false;
+        if (rc == Z_BUF_ERROR && s.avail_in == 0 && (size_t)(base + zn - s.next_in) == 0 && s.avail_out != 0) return false;  // truncated
+        if ((s.data_type & 128) && !(rc == Z_BUF_ERROR)) {
+          at = (uint64_t)(s.next_in - base) * 8 - (uint64_t)(s.data_type & 63);
+          if (at >= stop) return true;
+        }
+      }
+    }
+    void stop() { if (on) { inflateEnd(&s); on = false; } }
+  };
+
+  struct Task {
+    size_t r0 = 0, r1 = 0;   // the chunk's compressed byte range
+    bool have = false;        // a start was found and the three decodes agree on where they ended
+    uint64_t S = 0, E = 0;
+    bool ended = false;
+    bool three = false;       // the third decode was needed (see decode_spec)
+    Dec d[3];
+  };
+
+  // ---- gzip framing
+  bool parse_header(size_t *off) const {  // RFC 1952; *off: the member's first byte -> its first deflate byte
+    size_t p = *off;
+    if (p + 18 > zn || z[p] != 0x1f || z[p + 1] != 0x8b || z[p + 2] != 8) return false;
+    const uint8_t flg = z[p + 3];
+    p += 10;
+    if (flg & 4) { if (p + 2 > zn) return false; p += 2 + ((size_t)z[p] | ((size_t)z[p + 1] << 8)); }
+    if (flg & 8) { while (p < zn && z[p]) ++p; ++p; }
+    if (flg & 16) { while (p < zn && z[p]) ++p; ++p; }
+    if (flg & 2) p += 2;
+    if (p >= zn) return false;
+    *off = p;
+    return true;
+  }
+
+  bool open(const char *path, int nthreads) {
+    struct stat sb;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < ((size_t)16 << 20)) return false;
+    fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    zn = (size_t)sb.st_size;
+    void *m = mmap(nullptr, zn, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+    (void)madvise(m, zn, MADV_SEQUENTIAL);
+    z = static_cast<const uint8_t *>(m);
+    size_t off = 0;
+    if (!parse_header(&off)) { close(); return false; }
+    pos = (uint64_t)off * 8;
+    threads = nthreads < 2 ? 2 : (nthreads > 64 ? 64 : nthreads);
+    win.clear(); crc = (uint32_t)crc32(0L, Z_NULL, 0); member_out = 0;
+    active = true; done = false;
+    return true;
+  }
+  void close() {
+    if (z) munmap(const_cast<uint8_t *>(z), zn);
+    z = nullptr;
+    if (fd >= 0) ::close(fd);
+    fd = -1;
+    active = false;
+  }
+
+  // ---- accepted output.  The consumer walks a group's chunks in order and only DECIDES (which decode counts, which window it sees);
+  // the bytes are moved, filled in and check-summed afterwards by all threads together (finish_pieces): one thread doing that for a
+  // gigabyte of text would take as long as inflating it.
+  struct Piece {
+    Dec::Buf *a = nullptr;        // the bytes (a speculative chunk: the decode with dictionary A)
+    const Dec::Buf *b = nullptr;  // ... with dictionary B (nullptr: nothing to fill in)
+    const Dec::Buf *c = nullptr;  // ... with dictionary C (nullptr: A != B marks a window byte, see decode_spec)
+    std::vector<uint8_t> w;       // the true window in front of the piece (kWin bytes, right-aligned)
+    size_t n = 0;
+    uint32_t crc = 0;
+  };
+  std::vector<Piece> pieces;
+  std::vector<Dec::Buf *> owned;  // buffers of serial decodes, freed after the pieces are finished
+
+  static inline uint8_t fill(const Piece &p, size_t x) {
+    const uint8_t va = (*p.a)[x], vb = (*p.b)[x];
+    const bool marked = p.c ? va != (*p.c)[x] : va != vb;
+    return marked ? p.w[(size_t)va | ((size_t)(vb & 127u) << 8)] : va;
+  }
+  // the window behind piece p (for the next one): the last kWin bytes of (p.w + p's filled-in bytes)
+  void window_after(const Piece &p) {
+    if (p.n >= kWin) {
+      win.resize(kWin);
+      for (size_t x = 0; x < kWin; ++x) win[x] = p.b ? fill(p, p.n - kWin + x) : (*p.a)[p.n - kWin + x];
+    } else {
+      std::vector<uint8_t> t(win);
+      for (size_t x = 0; x < p.n; ++x) t.push_back(p.b ? fill(p, x) : (*p.a)[x]);
+      if (t.size() > kWin) t.erase(t.begin(), t.begin() + (long)(t.size() - kWin));
+      win.swap(t);
+    }
+  }
+  void add_piece(Dec::Buf *a, const Dec::Buf *b, const Dec::Buf *c) {
+    if (a->len == 0) return;
+    Piece p;
+    p.a = a; p.b = b; p.c = c; p.n = a->len;
+    if (b) { p.w.assign(kWin, 0); if (!win.empty()) memcpy(p.w.data() + (kWin - win.size()), win.data(), win.size()); }
+    window_after(p);
+    pieces.push_back(std::move(p));
+  }
+  // all pieces so far: filled in, copied to the caller's buffer (or the spill) and check-summed, by `threads` threads; then the
+  // member's running CRC and length
+  void finish_pieces(unsigned char *dst, size_t want, size_t *got) {
+    if (pieces.empty()) return;
+    size_t total = 0;
+    std::vector<size_t> at(pieces.size());
+    for (size_t i = 0; i < pieces.size(); ++i) { at[i] = total; total += pieces[i].n; }
+    uint8_t *out;
+    if (spill_off >= spill.size() && want - *got >= total) { out = dst + *got; *got += total; }
+    else {
+      if (spill_off >= spill.size()) { spill.clear(); spill_off = 0; }
+      const size_t old = spill.size();
+      spill.resize(old + total);
+      out = spill.data() + old;
+    }
+    // work items of <= 1 MiB so that the threads share a group evenly
+    struct Item { size_t piece, x0, x1; };
+    std::vector<Item> items;
+    for (size_t i = 0; i < pieces.size(); ++i)
+      for (size_t x = 0; x < pieces[i].n; x += (size_t)1 << 20) items.push_back({i, x, x + ((size_t)1 << 20) < pieces[i].n ? x + ((size_t)1 << 20) : pieces[i].n});
+    std::vector<uint32_t> icrc(items.size());
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t k; (k = next.fetch_add(1)) < items.size();) {
+        const Item &it = items[k];
+        const Piece &p = pieces[it.piece];
+        uint8_t *o = out + at[it.piece];
+        if (p.b) for (size_t x = it.x0; x < it.x1; ++x) o[x] = fill(p, x);
+        else memcpy(o + it.x0, p.a->p + it.x0, it.x1 - it.x0);
+        icrc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), o + it.x0, (uInt)(it.x1 - it.x0));
+      }
+    };
+    std::vector<std::thread> th;
+    const int nt = (int)(items.size() < (size_t)threads ? items.size() : (size_t)threads);
+    for (int i = 1; i < nt; ++i) th.emplace_back(work);
+    work();
+    for (std::thread &x : th) x.join();
+    for (size_t k = 0; k < items.size(); ++k) crc = (uint32_t)crc32_combine(crc, icrc[k], (z_off_t)(items[k].x1 - items[k].x0));
+    member_out += total;
+    pieces.clear();
+    for (Dec::Buf *b : owned) delete b;
+    owned.clear();
+  }
+  // a member ended at byte `pos / 8`: trailer check (the pieces must be finished), then the next member's header (or the end of the file)
+  bool member_end() {
+    const size_t t = (size_t)(pos >> 3);
+    if (t + 8 > zn) { error = "unexpected end of file"; return false; }
+    const uint32_t want_crc = (uint32_t)z[t] | ((uint32_t)z[t + 1] << 8) | ((uint32_t)z[t + 2] << 16) | ((uint32_t)z[t + 3] << 24);
+    const uint32_t want_len = (uint32_t)z[t + 4] | ((uint32_t)z[t + 5] << 8) | ((uint32_t)z[t + 6] << 16) | ((uint32_t)z[t + 7] << 24);
+    if (want_crc != crc) { error = "incorrect data check"; return false; }
+    if (want_len != (uint32_t)member_out) { error = "incorrect length check"; return false; }
+    size_t off = t + 8;
+    while (off < zn && z[off] == 0) ++off;  // (zero padding behind a member, as gzread skips it)
+    if (off >= zn) { done = true; return true; }
+    if (!parse_header(&off)) { done = true; return true; }  // (trailing garbage: gzread ignores it)
+    pos = (uint64_t)off * 8;
+    win.clear(); crc = (uint32_t)crc32(0L, Z_NULL, 0); member_out = 0;
+    return true;
+  }
+  // decodes from `pos` with the true window up to the first block boundary at or behind `stop`: the slow path for a stretch no guess covers
+  bool serial_to(uint64_t stop, unsigned char *dst, size_t want, size_t *got) {
+    Dec d;
+    if (!d.start(z, zn, pos, win.data(), (uint32_t)win.size()) || !d.run(stop)) { d.stop(); error = "invalid deflate data"; return false; }
+    Dec::Buf *keep = new Dec::Buf();
+    keep->p = d.out.p; keep->len = d.out.len; keep->cap = d.out.cap;
+    d.out.p = nullptr; d.out.len = d.out.cap = 0;
+    owned.push_back(keep);
+    add_piece(keep, nullptr, nullptr);
+    pos = d.at;
+    const bool ended = d.ended;
+    d.stop();
+    ++n_serial;
+    if (ended) { finish_pieces(dst, want, got); return member_end(); }
+    return true;
+  }
+
+  // a chunk's speculative decodes from bit b: with dictionary A and B; when a byte reads the same value >= 128 in both -- a literal of
+  // binary data, or window position k with (k & 255) == (128 | k >> 8) -- a third one with dictionary C tells them apart (text never needs it)
+  bool decode_spec(Task &t, uint64_t b, const uint8_t *dA, const uint8_t *dB, const uint8_t *dC) {
+    const uint64_t stop = (uint64_t)t.r1 * 8;
+    if (!t.d[0].start(z, zn, b, dA, kWin) || !t.d[0].run(stop)) { t.d[0].stop(); return false; }  // zlib disagrees: not a block
+    t.S = b; t.E = t.d[0].at; t.ended = t.d[0].ended;
+    t.d[0].stop();
+    bool ok = t.d[1].start(z, zn, b, dB, kWin) && t.d[1].run(stop) && t.d[1].at == t.E && t.d[1].out.len == t.d[0].out.len;
+    t.d[1].stop();
+    t.three = false;
+    if (ok) {
+      const uint8_t *pa = t.d[0].out.p, *pb = t.d[1].out.p;
+      const size_t n = t.d[0].out.len;
+      for (size_t x = 0; x < n; ++x) if ((pa[x] & 128u) && pa[x] == pb[x]) { t.three = true; break; }
+      if (t.three) {
+        ok = t.d[2].start(z, zn, b, dC, kWin) && t.d[2].run(stop) && t.d[2].at == t.E && t.d[2].out.len == n;
+        t.d[2].stop();
+      }
+    }
+    t.have = ok;
+    return true;
+  }
+
+  // the next group of chunks: decoded side by side, walked in order, finished side by side
+  int fruitless = 0;  // groups in a row none of whose guesses counted (stored blocks: incompressible data): after two, plain serial decoding
+  bool produce(unsigned char *dst, size_t want, size_t *got) {
+    if (fruitless >= 2) {
+      if (!serial_to(pos + ((uint64_t)64 << 23), dst, want, got)) return false;
+      finish_pieces(dst, want, got);
+      return true;
+    }
+    const uint64_t accepted_before = n_accepted;
+    const size_t g0 = (size_t)(pos >> 3);
+    const int nt = threads;
+    std::vector<Task> tk((size_t)nt);
+    int used = 0;
+    for (int i = 0; i < nt; ++i) {
+      tk[i].r0 = g0 + (size_t)i * kChunk;
+      tk[i].r1 = tk[i].r0 + kChunk;
+      if (tk[i].r0 >= zn) break;
+      ++used;
+    }
+    static const std::vector<uint8_t> dictA = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(k & 255); return v; }();
+    static const std::vector<uint8_t> dictB = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(128u | (k >> 8)); return v; }();
+    static const std::vector<uint8_t> dictC = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(255 ^ (k & 255)); return v; }();
+    // task 0: the true decode from `pos`; tasks 1..: search + speculative decodes
+    Dec head;
+    bool head_ok = true;
+    std::vector<std::thread> th;
+    th.emplace_back([&]() { head_ok = head.start(z, zn, pos, win.data(), (uint32_t)win.size()) && head.run((uint64_t)tk[0].r1 * 8); });
+    for (int i = 1; i < used; ++i)
+      th.emplace_back([&, i]() {
+        Task &t = tk[i];
+        const uint64_t b0 = (uint64_t)t.r0 * 8, b1 = (uint64_t)(t.r1 < zn ? t.r1 : zn) * 8;
+        for (uint64_t b = b0; b < b1; ++b)
+          if (plausible_header(b) && decode_spec(t, b, dictA.data(), dictB.data(), dictC.data())) break;
+      });
+    for (std::thread &x : th) x.join();
+    n_spec += (uint64_t)(used > 1 ? used - 1 : 0);
+    if (!head_ok) { head.stop(); error = "invalid deflate data"; return false; }
+    add_piece(&head.out, nullptr, nullptr);
+    pos = head.at;
+    {
+      const bool ended = head.ended;
+      head.stop();
+      if (ended) { finish_pieces(dst, want, got); if (!member_end()) return false; }
+    }
+    // the chain: a speculative chunk counts iff it starts exactly where the accepted output ends
+    static const bool dbg = getenv("CM_PARGZ_DEBUG") != nullptr;
+    for (int i = 1; i < used && !done; ++i) {
+      Task &t = tk[i];
+      if (dbg) fprintf(stderr, "[pargz] chunk at byte %zu: have %d S %llu E %llu ended %d three %d | pos %llu\n", t.r0, (int)t.have, (unsigned long long)t.S,
+                       (unsigned long long)t.E, (int)t.ended, (int)t.three, (unsigned long long)pos);
+      if (t.have && t.S > pos && t.S < (uint64_t)t.r1 * 8) {  // a stretch the search skipped (stored / fixed blocks): decode up to the guess
+        if (!serial_to(t.S, dst, want, got)) return false;
+        if (done) break;
+      }
+      if (t.have && t.S == pos) {
+        add_piece(&t.d[0].out, &t.d[1].out, t.three ? &t.d[2].out : nullptr);
+        pos = t.E;
+        ++n_accepted;
+        if (t.ended) { finish_pieces(dst, want, got); if (!member_end()) return false; }
+      } else if (pos < (uint64_t)t.r1 * 8) {
+        if (!serial_to((uint64_t)t.r1 * 8, dst, want, got)) return false;  // no usable guess for this stretch
+      }
+    }
+    finish_pieces(dst, want, got);  // (the tasks' buffers die with this function: nothing may be left pointing at them)
+    if (used > 1) fruitless = n_accepted == accepted_before ? fruitless + 1 : 0;
+    return true;
+  }
+
+  // up to `want` decompressed bytes, in order; *eof once the last member has ended.  false: error (see `error`)
+  bool read(unsigned char *dst, size_t want, size_t *got_out, bool *eof) {
+    size_t got = 0;
+    while (got < want) {
+      if (spill_off < spill.size()) {
+        const size_t m = spill.size() - spill_off < want - got ? spill.size() - spill_off : want - got;
+        memcpy(dst + got, spill.data() + spill_off, m);
+        spill_off += m;
+        got += m;
+        continue;
+      }
+      if (done) break;
+      if (!produce(dst, want, &got)) { *got_out = got; return false; }
+    }
+    *got_out = got;
+    *eof = done && spill_off >= spill.size();
+    return true;
+  }
+};
+
+#endif  // CM_PARGZ_H_

@@ -96,3 +96,82 @@ def test_ingest_reader_inflates_bgzf_gzip_and_plain_text(tmp_path):
     open(cut, "wb").write(open(bg, "rb").read()[:-5000])
     r = _run("--inflate-only", cut)
     assert r.returncode != 0 and b"corrupted" in r.stderr
+
+
+def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
+    """cm_pargz.h (the CLI's reader for single-stream gzip of 16 MiB and more): chunks searched for block starts and decoded
+    speculatively with made-up windows, accepted only where they start exactly at the end of the decode before them.  The
+    bytes must be gzread's for FASTQ text at several compression levels (guesses accepted), for concatenated members, for
+    stored blocks and binary data (no guess counts: the serial path), and a truncated or damaged file must be an error"""
+    import gzip
+    import numpy as np
+    rng = np.random.default_rng(11)
+    n = 450000
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, 60))]
+    qual = (rng.integers(2, 41, (n, 60)) + 33).astype(np.uint8)
+    rec = np.empty((n, 8 + 1 + 60 + 3 + 60 + 1), np.uint8)
+    rec[:, :8] = np.frombuffer(b"".join(b"@r%06d" % i for i in range(n)), np.uint8).reshape(n, 8)
+    rec[:, 8] = 10
+    rec[:, 9:69] = seq
+    rec[:, 69:72] = np.frombuffer(b"\n+\n", np.uint8)
+    rec[:, 72:132] = qual
+    rec[:, 132] = 10
+    text = rec.tobytes()
+    env = dict(os.environ, CM_PARGZ_THREADS="4")
+
+    def run(path):
+        return subprocess.run([CLI, "--inflate-only", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+
+    def stats(r):
+        f = r.stderr.decode().strip().splitlines()[-1].split()
+        assert f[0] == "pargz", r.stderr[-300:]
+        return {k: int(v) for k, v in (x.split("=") for x in f[1:])}
+
+    files = {}
+    for lvl in (1, 6):
+        p = str(tmp_path / ("t%d.gz" % lvl))
+        with gzip.open(p, "wb", compresslevel=lvl) as g:
+            g.write(text)
+        assert os.path.getsize(p) > (16 << 20)
+        files[lvl] = p
+        r = run(p)
+        assert r.returncode == 0 and r.stdout == text
+        st = stats(r)
+        assert st["accepted"] >= st["chunks"] - 1 and st["accepted"] > 3 and st["serial"] <= 1, st  # the guesses counted
+    # the same file through gzread (CM_PARGZ=0) -- and a small file never takes the parallel reader
+    r = subprocess.run([CLI, "--inflate-only", files[6]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, CM_PARGZ="0"))
+    assert r.returncode == 0 and r.stdout == text and r.stderr.strip() == b"gzread"
+    # members one behind the other: deflate, stored (level 0: no dynamic block to find), deflate
+    stored = str(tmp_path / "l0.gz")
+    with gzip.open(stored, "wb", compresslevel=0) as g:
+        g.write(text[:20_000_000])
+    cat = str(tmp_path / "cat.gz")
+    with open(cat, "wb") as f:
+        for p in (files[1], stored, files[6]):
+            f.write(open(p, "rb").read())
+    r = run(cat)
+    assert r.returncode == 0 and r.stdout == text + text[:20_000_000] + text
+    assert stats(r)["accepted"] > 3
+    # binary data (bytes of all values: the third decode that tells a literal >= 128 from a window byte), partly incompressible
+    blob = bytearray()
+    base = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    words = [rng.integers(128, 256, int(rng.integers(3, 40)), dtype=np.uint8).tobytes() for _ in range(200)]
+    while len(blob) < 60_000_000:
+        blob += base[:int(rng.integers(1000, 200000))]
+        for _ in range(20000):
+            blob += words[int(rng.integers(0, 200))]
+    blob = bytes(blob)
+    bz = str(tmp_path / "bin.gz")
+    with gzip.open(bz, "wb", compresslevel=6) as g:
+        g.write(blob)
+    if os.path.getsize(bz) > (16 << 20):
+        r = run(bz)
+        assert r.returncode == 0 and r.stdout == blob
+    # damage: a truncated file, a flipped bit in the middle, a wrong CRC in the trailer
+    z = open(files[6], "rb").read()
+    for name, data in (("trunc.gz", z[:-500000]), ("flip.gz", z[:len(z) // 2] + bytes([z[len(z) // 2] ^ 0x10]) + z[len(z) // 2 + 1:]),
+                       ("crc.gz", z[:-6] + bytes([z[-6] ^ 1]) + z[-5:])):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        r = run(p)
+        assert r.returncode != 0 and b"corrupted" in r.stderr, name

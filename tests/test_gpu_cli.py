@@ -237,3 +237,26 @@ def test_cli_rejects_unknown_option(tmp_path):
     r = subprocess.run([CLI, "--PAF", "-x", "x", "-r", os.path.join(ds.GOLD, "toy", "ref.fa"), "-1", "a", "-o",
                         str(tmp_path / "o")], stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"unsupported option" in r.stderr
+
+
+def test_cli_reads_large_gzip_with_several_inflating_threads(tmp_path):
+    """ordinary gzip files of 16 MiB and more go through cm_pargz.h (speculative chunks, several threads): the BED must be the
+    one the plain-text files give, and gzread's (CM_PARGZ=0)"""
+    import sys
+    pre = str(tmp_path / "d")
+    subprocess.check_call([sys.executable, os.path.join(ds.ROOT, "tools", "gen_real.py"), "--out", pre, "--genome", "20000000", "--chroms", "4",
+                           "--pairs", "200000", "--seed", "77"])
+    for tag in ("_1", "_2"):
+        subprocess.check_call(["gzip", "-1", "-k", pre + tag + ".fq"])
+        assert os.path.getsize(pre + tag + ".fq.gz") > (16 << 20)
+    idx = pre + ".idx"
+    subprocess.run([CLI, "-i", "-r", pre + ".fa", "-o", idx], check=True, stderr=subprocess.PIPE)
+    outs = {}
+    for name, sfx, env in (("plain", ".fq", {}), ("pargz", ".fq.gz", {"CM_PARGZ_THREADS": "8"}), ("gzread", ".fq.gz", {"CM_PARGZ": "0"})):
+        out = str(tmp_path / (name + ".bed"))
+        r = subprocess.run([CLI, "--preset", "atac", "-x", idx, "-r", pre + ".fa", "-1", pre + "_1" + sfx, "-2", pre + "_2" + sfx, "-o", out],
+                           stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        outs[name] = ds.md5(out)
+    assert os.path.getsize(out) > 1000000
+    assert outs["pargz"] == outs["plain"] and outs["gzread"] == outs["plain"], outs
