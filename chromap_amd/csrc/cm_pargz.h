@@ -30,6 +30,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -55,6 +56,8 @@ struct ParGunzip {
   size_t spill_off = 0;
   // statistics (tests, --inflate-only)
   uint64_t n_spec = 0, n_accepted = 0, n_serial = 0;
+  double t_decode = 0, t_chain = 0, t_finish = 0;  // seconds in the groups' three phases (CM_PARGZ_DEBUG prints them)
+  static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
   // ---- bit reader over the mapped file (deflate packs bits LSB first)
   inline uint32_t bits(uint64_t bit, int n) const {  // n <= 24 bits at `bit`; past the end reads zeros
@@ -284,6 +287,7 @@ struct ParGunzip {
   // member's running CRC and length
   void finish_pieces(unsigned char *dst, size_t want, size_t *got) {
     if (pieces.empty()) return;
+    const double t_f0 = now();
     size_t total = 0;
     std::vector<size_t> at(pieces.size());
     for (size_t i = 0; i < pieces.size(); ++i) { at[i] = total; total += pieces[i].n; }
@@ -322,6 +326,7 @@ struct ParGunzip {
     pieces.clear();
     for (Dec::Buf *b : owned) delete b;
     owned.clear();
+    t_finish += now() - t_f0;
   }
   // a member ended at byte `pos / 8`: trailer check (the pieces must be finished), then the next member's header (or the end of the file)
   bool member_end() {
@@ -389,6 +394,9 @@ struct ParGunzip {
     }
     const uint64_t accepted_before = n_accepted;
     const size_t g0 = (size_t)(pos >> 3);
+    // a group: one chunk per thread.  (Three per thread, taken from a counter, to even out the chunks' costs before the group's barrier:
+    // measured worse -- 182 MB on 32 threads: decode 207 -> 240 ms, the walk 19 -> 210 ms, .fastq.gz -> BED 0.90 -> 1.47 s; a group's
+    // buffers then are gigabytes of fresh pages.)
     const int nt = threads;
     std::vector<Task> tk((size_t)nt);
     int used = 0;
@@ -402,18 +410,26 @@ struct ParGunzip {
     static const std::vector<uint8_t> dictB = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(128u | (k >> 8)); return v; }();
     static const std::vector<uint8_t> dictC = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(255 ^ (k & 255)); return v; }();
     // task 0: the true decode from `pos`; tasks 1..: search + speculative decodes
+    const double t_g0 = now();
     Dec head;
     bool head_ok = true;
     std::vector<std::thread> th;
-    th.emplace_back([&]() { head_ok = head.start(z, zn, pos, win.data(), (uint32_t)win.size()) && head.run((uint64_t)tk[0].r1 * 8); });
-    for (int i = 1; i < used; ++i)
-      th.emplace_back([&, i]() {
+    std::atomic<int> next_chunk{0};
+    auto worker = [&]() {
+      for (int i; (i = next_chunk.fetch_add(1)) < used;) {
+        if (i == 0) { head_ok = head.start(z, zn, pos, win.data(), (uint32_t)win.size()) && head.run((uint64_t)tk[0].r1 * 8); continue; }
         Task &t = tk[i];
         const uint64_t b0 = (uint64_t)t.r0 * 8, b1 = (uint64_t)(t.r1 < zn ? t.r1 : zn) * 8;
         for (uint64_t b = b0; b < b1; ++b)
           if (plausible_header(b) && decode_spec(t, b, dictA.data(), dictB.data(), dictC.data())) break;
-      });
+      }
+    };
+    const int nth = used < threads ? used : threads;
+    for (int i = 1; i < nth; ++i) th.emplace_back(worker);
+    worker();
     for (std::thread &x : th) x.join();
+    t_decode += now() - t_g0;
+    const double t_c0 = now();
     n_spec += (uint64_t)(used > 1 ? used - 1 : 0);
     if (!head_ok) { head.stop(); error = "invalid deflate data"; return false; }
     add_piece(&head.out, nullptr, nullptr);
@@ -442,7 +458,9 @@ struct ParGunzip {
         if (!serial_to((uint64_t)t.r1 * 8, dst, want, got)) return false;  // no usable guess for this stretch
       }
     }
+    t_chain += now() - t_c0;
     finish_pieces(dst, want, got);  // (the tasks' buffers die with this function: nothing may be left pointing at them)
+    if (dbg) fprintf(stderr, "[pargz] so far: decode %.3f s, chain %.3f s (incl. mid-group finishes), finish %.3f s\n", t_decode, t_chain, t_finish);
     if (used > 1) fruitless = n_accepted == accepted_before ? fruitless + 1 : 0;
     return true;
   }
