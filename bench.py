@@ -261,7 +261,7 @@ def probe_source_sha():
     """sha of the sources the probe kernel is compiled from: profiles/probe_traffic.json names the one it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("cm_kernels.hip", "cm_stages.h", "cm_types.h"):
+    for f in ("cm_kernels.hip", "cm_stages.h", "cm_coop.h", "cm_types.h"):
         h.update(open(os.path.join(ROOT, "chromap_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
