@@ -448,6 +448,14 @@ CM_HD bool cm_coop_s3b_k32(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m
   uint32_t np, nr;
   const uint32_t lv = cm_coop_s3b_expand<uint32_t>(d, r, g, m, m.A32, m.B32, tot, &np, &nr);
   if (lv == 0) return false;
+  // (round 6) the coordinate table next to the keys: every candidate the sweep writes searches it to become sequence << 32 | position
+  // again -- five dependent reads, from global memory until now.  m.mps is free once the hits are expanded; the merge's barriers
+  // come between this copy and its use.
+  const uint32_t *gl = d.goff;
+  if (d.n_seq + 1 <= m.MM + 1) {
+    for (uint32_t i = g.t; i <= d.n_seq; i += (uint32_t)GT::G) m.mps[i] = d.goff[i];
+    gl = m.mps;
+  }
   CM_PROF_RESET(d);
   uint32_t *S = cm_coop_merge_runs(g, m.A32, m.B32, m.rb, m.rb2, nr, tot, lv - 1);
   CM_PROF_MARK(d, g, 4);
@@ -461,7 +469,8 @@ CM_HD bool cm_coop_s3b_k32(const CmDev &d, uint32_t r, GT &g, const CmCoopMem &m
   uint64_t *h = d.hbuf + hoff;
   uint8_t *hc = d.hcnt + hoff;
   uint32_t ncp, ncn;
-  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, m.oc, S == m.A32 ? m.B32 : m.A32, m.cc, h, hc, h + np, hc + np, &ncp, &ncn, d.prof, d.goff, d.n_seq);
+  if (lv == 1) g.sync();  // (no merge level ran: the table's copy is not behind a barrier yet)
+  cm_coop_sweep(g, S, tot, np, d.p.e, req, n, m.oc, S == m.A32 ? m.B32 : m.A32, m.cc, h, hc, h + np, hc + np, &ncp, &ncn, d.prof, gl, d.n_seq);
   CM_PROF_MARK(d, g, 5);
   if (g.t == 0) { d.n_pos_hit[r] = np; d.ncp[r] = ncp; d.ncn[r] = ncn; }
   return true;
