@@ -1178,10 +1178,8 @@ static int map_split(cmgpu_ctx *c, uint32_t lo, uint32_t hi, uint64_t *k_total, 
   uint64_t k = 0;
   int rc = map_range(c, lo, hi, &k, stats);
   const uint32_t rb = (uint32_t)c->p.ref_batch, n = hi - lo;
-  // (round 6) a range whose intermediates do not FIT the device -- hits and candidates of a repeat-rich genome are ~36 bytes per entry,
-  // a lane of 8 M such pairs 75 GB -- is halved like one that passes the 32-bit item limit, down to one reference batch; the records
-  // do not change (the multi-mapper sampling is per reference batch).  map_range leaves nothing behind when an allocation fails.
-  if (rc == CMGPU_ENOMEM && n > rb) rc = CM_RC_SPLIT;
+  // (round 6, tried and removed: halving a range that got "out of device memory" like one that passes the item limit -- the buffers of a
+  //  context only grow, the other lanes keep theirs, and a 16 M-pair call on the profile-2 genome failed just the same: DESIGN.md 9-4)
   if (rc != CM_RC_SPLIT) { *k_total += k; return rc; }
   if (n <= rb) {
     cm_set_error(c, "a reference batch of " + std::to_string(n) + " pairs needs more than " + std::to_string((unsigned long long)c->opt_item_limit) +
