@@ -100,7 +100,7 @@ SYMBOLS = ("cmgpu_default_params", "cmgpu_apply_preset", "cmgpu_create", "cmgpu_
            "cmgpu_store_clear", "cmgpu_store_reserve", "cmgpu_store_append_resident", "cmgpu_store_append", "cmgpu_store_format",
            "cmgpu_store_text", "cmgpu_store_write_text", "cmgpu_store_info",
            "cmgpu_sam_layout", "cmgpu_download_sam", "cmgpu_write_sam", "cmgpu_download_barcode_keys", "cmgpu_set_barcode_check", "cmgpu_write_sam_barcoded", "cmgpu_write_sam_barcoded_translated",
-           "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_scan_bgzf", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
+           "cmgpu_warm_up", "cmgpu_fastq_set_format", "cmgpu_fastq_scan", "cmgpu_fastq_scan_bgzf", "cmgpu_fastq_take", "cmgpu_fastq_commit", "cmgpu_barcode_abundance_resident",
            "cmgpu_load_index_file", "cmgpu_free_host_index", "cmgpu_load_reference_fasta", "cmgpu_free_host_ref",
            "cmgpu_create_synthetic_repeats", "cmgpu_create_synthetic_profile", "cmgpu_generate_resident_batch_indels", "cmgpu_generate_resident_batch_hic", "cmgpu_probe_bench_variant", "cmgpu_gather_sweep", "cmgpu_set_option", "cmgpu_get_option", "cmgpu_swap_resident_batch",
            "cmgpu_exchange_unique_id", "cmgpu_exchange_init", "cmgpu_exchange_init_all", "cmgpu_exchange_init_external",
@@ -194,6 +194,7 @@ def declare(L):
     sig("cmgpu_fastq_set_format", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char])
     sig("cmgpu_fastq_scan", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
     sig("cmgpu_fastq_scan_bgzf", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint32)])
+    sig("cmgpu_warm_up", C.c_int, [C.c_int])
     sig("cmgpu_fastq_take", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, P(C.c_uint64)])
     sig("cmgpu_barcode_abundance_resident", C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_int)])
     sig("cmgpu_fastq_commit", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int])

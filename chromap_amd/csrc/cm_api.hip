@@ -44,9 +44,16 @@ extern "C" const char *cmgpu_last_error_thread(void) { return t_last_error.c_str
 int DevBuf::ensure(size_t bytes) {
   if (bytes <= cap) return 0;
   if (!owned) return -1;
+  // CM_ALLOC_TRACE=1: every growth with its size and the time hipFree / hipMalloc took, on stderr (what a job's first batch spends on memory)
+  static const bool trace = getenv("CM_ALLOC_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t had = cap;
   if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
   size_t want = bytes + bytes / 4 + 256;
   hipError_t e = hipMalloc(&p, want);
+  if (trace)
+    fprintf(stderr, "[alloc] %10.3f MB (had %10.3f) %8.3f ms\n", (double)want / 1e6, (double)had / 1e6,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (e != hipSuccess) {
     (void)hipGetLastError();  // the retry below decides
     want = bytes;
@@ -231,6 +238,7 @@ static int build_mapq_tables(cmgpu_ctx *c) {
   return CMGPU_OK;
 }
 
+static void cm_load_device_code(hipStream_t s);
 int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int window, int device_id) {
   c->device = device_id;
   c->hp = *params;
@@ -273,9 +281,31 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   if (c->stats.ensure(CM_ST_N * 8)) return CMGPU_ENOMEM;
   HIPCHECK(c, hipMemset(c->stats.p, 0, CM_ST_N * 8));
   for (int i = 0; i < CM_MAX_EVENTS; ++i) HIPCHECK(c, hipEventCreate(&c->ev[i]));
+  cm_load_device_code(c->stream);
   return build_mapq_tables(c);
 }
 
+// Every translation unit's device code, loaded now (the runtime defers it to the first launch: round 6 found 13 ms of a job's first FASTQ
+// scan inside the first prefix sum -- cm_kernels' code object being loaded -- and as much again in the first mapping and post-processing calls)
+void cm_touch_kernels(hipStream_t s);
+void cm_touch_post(hipStream_t s);
+void cm_touch_ingest(hipStream_t s);
+void cm_touch_exchange(hipStream_t s);
+void cm_touch_synth(hipStream_t s);
+__global__ void k_touch_api() {}
+static void cm_load_device_code(hipStream_t s) {
+  static std::once_flag once[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::call_once(once[dev], [s]() {
+    hipLaunchKernelGGL(k_touch_api, dim3(1), dim3(1), 0, s);
+    cm_touch_kernels(s); cm_touch_post(s); cm_touch_ingest(s); cm_touch_exchange(s); cm_touch_synth(s);
+    (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
+  });
+}
+
+static int select_device(int device_id);
 static int select_device(int device_id) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -1891,7 +1921,7 @@ extern "C" int cmgpu_barcode_abundance_resident(cmgpu_ctx *c, uint64_t *num_samp
   if (!c || !done || c->wl_size == 0) { cm_set_error(c, "no whitelist set"); return CMGPU_EINVAL; }
   HIPCHECK(c, cm_enter(c));
   bool d = false;
-  const int rc = bc_abundance_run(c, (const uint8_t *)c->bcb.p, (const uint32_t *)c->bco.p, c->fq[2].taken, &d);
+  const int rc = bc_abundance_run(c, (const uint8_t *)c->st_bcb.p, (const uint32_t *)c->st_bco.p, c->fq[2].taken, &d);  // (taken, not committed: the staging buffers)
   *done = d ? 1 : 0;
   if (num_sample_barcodes) *num_sample_barcodes = c->wl_num_sample;
   return rc;
@@ -2009,5 +2039,65 @@ static int map_single_impl(cmgpu_ctx *c, const cmgpu_single_batch *in, const cmg
     ++o;
   }
   *n_out = o;
+  return CMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// cmgpu_warm_up: what a process can do before it has an index to make a context with (chromap-amd calls it on a thread of its own while the
+// main thread reads the reference and the index file).  The runtime initialised on the device, the library's device code loaded, and ONE DRY
+// RUN of the whole path on a made-up 64 kb reference: 2 000 pairs from FASTQ text through scan / take / commit, mapping, the record store and
+// the BED text.  What a process otherwise pays inside its first batch (round 6, BGZF -> BED of 8 M pairs: the first 4 M-pair batch took
+// 33-64 ms to map, the second 7): the first stream of a priority makes the runtime create a hardware queue (14.5 ms in front of the first
+// k_pack_reads), the first kernel of a queue that needs scratch memory has it allocated (15 ms in front of the first k_s3b_candidates), the
+// first sort builds its plan.  Hardware queues, their scratch and the loaded code stay with the process when the dry run's context goes.
+// Errors are ignored: a warm-up that fails leaves the process as it would have been without it.
+// ---------------------------------------------------------------------------------------
+static void cm_dry_run(int device_id) {
+  const uint32_t L = 65536, n_pairs = 2000, rl = 50;
+  std::string seq(L, 'A');
+  uint64_t x = 0x9e3779b97f4a7c15ull;
+  for (uint32_t i = 0; i < L; ++i) { x = x * 6364136223846793005ull + 1442695040888963407ull; seq[i] = "ACGT"[(x >> 60) & 3]; }
+  const char *names[1] = {"warm"};
+  const char *seqs[1] = {seq.data()};
+  const uint32_t lens[1] = {L};
+  cmgpu_ref_view rv;
+  rv.n_sequences = 1; rv.names = names; rv.sequences = seqs; rv.lengths = lens;
+  cmgpu_params p;
+  cmgpu_default_params(&p);
+  p.max_insert_size = 2000; p.remove_pcr_duplicates = 1; p.low_memory_mode = 1; p.tn5_shift = 1; p.mapq_threshold = 30; p.trim_adapters = 1;  // (--preset atac)
+  cmgpu_ctx *ctx = nullptr;
+  if (cmgpu_create_from_reference(&rv, 17, 7, &p, device_id, &ctx) != CMGPU_OK || !ctx) return;
+  std::string t1, t2;
+  t1.reserve(n_pairs * (2 * rl + 16)); t2.reserve(n_pairs * (2 * rl + 16));
+  for (uint32_t i = 0; i < n_pairs; ++i) {
+    x = x * 6364136223846793005ull + 1442695040888963407ull;
+    const uint32_t at = (uint32_t)((x >> 33) % (L - 400)), frag = 120 + (uint32_t)((x >> 20) & 127);
+    std::string r1 = seq.substr(at, rl), r2(rl, 'A');
+    for (uint32_t k = 0; k < rl; ++k) { const char ch = seq[at + frag - 1 - k]; r2[k] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : 'A'; }
+    if ((i & 7) == 0) r1[rl / 2] = r1[rl / 2] == 'A' ? 'C' : 'A';  // (some with a mismatch: the alignment kernels see work)
+    t1 += "@w\n"; t1 += r1; t1 += "\n+\n"; t1.append(rl, 'I'); t1 += "\n";
+    t2 += "@w\n"; t2 += r2; t2 += "\n+\n"; t2.append(rl, 'I'); t2 += "\n";
+  }
+  uint32_t c1 = 0, c2 = 0;
+  uint64_t used = 0, k = 0, nl = 0, nb = 0;
+  cmgpu_stats st;
+  memset(&st, 0, sizeof(st));
+  const bool ok = cmgpu_fastq_scan(ctx, 0, t1.data(), t1.size(), 1, &c1) == CMGPU_OK && cmgpu_fastq_scan(ctx, 1, t2.data(), t2.size(), 1, &c2) == CMGPU_OK &&
+                  c1 == n_pairs && c2 == n_pairs && cmgpu_fastq_take(ctx, 0, n_pairs, &used) == CMGPU_OK && cmgpu_fastq_take(ctx, 1, n_pairs, &used) == CMGPU_OK &&
+                  cmgpu_fastq_commit(ctx, n_pairs, 0, 1, 0) == CMGPU_OK && cmgpu_map_resident(ctx, &k, &st) == CMGPU_OK &&
+                  cmgpu_store_append_resident(ctx, nullptr) == CMGPU_OK &&
+                  cmgpu_store_format(ctx, CMGPU_TEXT_BED_PE, names, 1, &p, 0, &nl, &nb) == CMGPU_OK;
+  (void)ok;
+  (void)cmgpu_destroy(ctx);
+  (void)hipGetLastError();
+}
+
+extern "C" int cmgpu_warm_up(int device_id) {
+  const int rc = select_device(device_id);
+  if (rc != CMGPU_OK) return rc;
+  cm_load_device_code(nullptr);
+  static std::once_flag dry[64];
+  if (device_id >= 0 && device_id < 64 && !getenv("CM_NO_DRY_RUN")) std::call_once(dry[device_id], [device_id]() { cm_dry_run(device_id); });
+  (void)hipSetDevice(device_id);
   return CMGPU_OK;
 }

@@ -135,6 +135,16 @@ struct ChunkReader {
   bool ahead_on = false, ahead_eof = false;
   size_t ahead_got = 0;
   const char *text() const { return bufs[cur].text() + off; }
+  // how much of the file the records handed out so far came from, 0: unknown (a pipe; gzip inflated by several threads).  What a run uses
+  // to size its record store once, after the first batch, instead of doubling it as it fills
+  uint64_t fsize = 0, fed = 0;  // fed: bytes of the file whose records have been consumed (BGZF for the device: blocks handed over)
+  double fraction() const {
+    if (!fsize) return 0;
+    if (bgzf && dev_inflate) return (double)(fed + zready) / (double)fsize;
+    if (plain) return (double)fed / (double)fsize;
+    if (f && !pargz) { const z_off_t o = gzoffset(f); return o > 0 ? (double)o / (double)fsize : 0; }
+    return 0;
+  }
   // up to `want` bytes of the (inflated) stream: plain text or gzip
   size_t read_some(unsigned char *dst, size_t want, bool *hit_eof) {
     size_t got = 0;
@@ -174,6 +184,8 @@ struct ChunkReader {
     // lost to the gzopen below (the reference opens every input with one gzopen, which works on pipes)
     struct stat sb;
     if (stat(path.c_str(), &sb) != 0) return false;
+    fsize = S_ISREG(sb.st_mode) ? (uint64_t)sb.st_size : 0;
+    fed = 0;
     if (!S_ISREG(sb.st_mode)) {
       f = gzopen(path.c_str(), "r");
       if (f) gzbuffer(f, 1 << 20);
@@ -217,6 +229,7 @@ struct ChunkReader {
   const unsigned char *zdata() const { return zbuf.data() + zoff; }
   void fill_bgzf_compressed(size_t target) {
     join_ahead();
+    fed += zready;
     zoff += zready;  // (handed over by the last call)
     zlen -= zready;
     zready = 0;
@@ -358,6 +371,7 @@ struct ChunkReader {
     if (bgzf && dev_inflate) { pending -= used < pending ? used : pending; return; }  // (the device keeps the rest)
     off += used;
     len -= used;
+    fed += used;
   }
   bool only_whitespace() {
     if (bgzf && dev_inflate) return true;  // (what is left on the device at the end holds no record: cmgpu_fastq_scan_bgzf counted none)
@@ -574,11 +588,32 @@ int main(int argc, char **argv) {
   }
   Args a = parse(argc, argv);
   if (a.ref_path.empty() || a.out_path.empty()) die("No reference / output specified!");
+  // the HIP runtime and the library's device code come up on a thread of their own while this one reads the reference and the index
+  // (an error, e.g. no device, is reported by cmgpu_create below)
+  struct Warm {
+    std::thread th;
+    void join() { if (th.joinable()) th.join(); }
+    ~Warm() { join(); }
+  } warm;
+  // ... and the output file is opened and emptied there too (the reference opens its output before it reads a read, chromap.h:277 / :777 -- the
+  // MappingWriter is constructed ahead of the loop): a path that cannot be written fails now, not after the mapping, and emptying an existing
+  // file of the last run's size -- tens of milliseconds per few hundred MB of page cache -- is not left for the moment the text is ready
+  const bool text_out = !a.build_index && !a.out_pairs && !a.out_sam;
+  bool out_opened = true;
+  {
+    const int dev0 = a.device, ndev = a.gpus;
+    const std::string outp = a.out_path;
+    warm.th = std::thread([dev0, ndev, text_out, outp, &out_opened]() {
+      if (text_out) { FILE *of = fopen(outp.c_str(), "wb"); if (of) fclose(of); else out_opened = false; }
+      for (int gi = 0; gi < ndev; ++gi) (void)cmgpu_warm_up(dev0 + gi);
+    });
+  }
   cmgpu_ref_view ref;
   if (cmgpu_load_reference_fasta(a.ref_path.c_str(), &ref) != 0) die("Cannot find sequence file " + a.ref_path);
   fprintf(stderr, "Loaded all sequences successfully, number of sequences: %u.\n", ref.n_sequences);
   if (a.build_index) {
     cmgpu_ctx *bctx = nullptr;
+    warm.join();
     if (cmgpu_create_from_reference(&ref, a.k, a.w, &a.p, a.device, &bctx) != CMGPU_OK) die(cmgpu_last_error(nullptr));
     if (cmgpu_save_index_file(bctx, a.out_path.c_str()) != CMGPU_OK) die(cmgpu_last_error(bctx));
     int32_t k, w; uint32_t nb, nocc; uint64_t nmm, nkeys;
@@ -606,6 +641,8 @@ int main(int argc, char **argv) {
   if (exchange && (a.out_pairs || a.out_sam || a.host_ingest))
     die("--gpus > 1 needs BED / TagAlign output and device-side FASTQ ingest (pairs and SAM records are post-processed on the host)");
   std::vector<cmgpu_ctx *> ctxs((size_t)a.gpus, nullptr);
+  warm.join();
+  if (!out_opened) die("cannot write " + a.out_path);
   for (int gi = 0; gi < a.gpus; ++gi)
     if (cmgpu_create(&idx, &ref, &a.p, a.device + gi, &ctxs[gi]) != CMGPU_OK) die(cmgpu_last_error(nullptr));
   cmgpu_ctx *ctx = ctxs[0];
@@ -734,6 +771,8 @@ int main(int argc, char **argv) {
     std::vector<cmgpu_stats> wst(NG);
     for (cmgpu_stats &x : wst) memset(&x, 0, sizeof(x));
     size_t turn = 0;
+    bool store_sized = false;
+    const bool overlap1 = NG == 1 && !exchange && !getenv("CM_CLI_NO_OVERLAP");  // (the variable: the serial order, for measurements)
     auto finish_round = [&]() {
       for (size_t gi = 0; gi < NG; ++gi) if (busy[gi]) { workers[gi].join(); busy[gi] = 0; }
       for (size_t gi = 0; gi < NG; ++gi) if (wrc[gi] != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));
@@ -768,7 +807,13 @@ int main(int argc, char **argv) {
           // (... sized to the batch: what a take leaves over is copied and scanned again with the next piece, so a piece far larger than
           //  a batch -- 1 GiB against the ~125 MB of a 500 000-pair batch -- would be re-scanned many times)
           const size_t piece = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)64 << 20, (size_t)a.batch_pairs * 256));
-          auto want = [&](int m) { return rd[m].bgzf && rd[m].dev_inflate && !a.chunk_given && target < piece ? piece : target; };
+          // (a file's FIRST piece is half that: the device starts on it while the rest of a small file -- or the next piece of a large
+          //  one -- is still being read; 8 M pairs in two 185 MB files: 30 ms of reading in front of everything else became 17)
+          static const size_t first_div = getenv("CM_FIRST_PIECE_DIV") ? (size_t)std::max(1, atoi(getenv("CM_FIRST_PIECE_DIV"))) : 2;
+          auto want = [&](int m) {
+            if (!(rd[m].bgzf && rd[m].dev_inflate && !a.chunk_given && target < piece)) return target;
+            return rd[m].fed == 0 && rd[m].zready == 0 ? std::max(target, piece / first_div) : piece;
+          };
           for (int m = 1; m < ns_streams; ++m) th[m] = std::thread([&rd, m, &want]() { rd[m].fill(want(m)); });
           rd[0].fill(want(0));
           for (int m = 1; m < ns_streams; ++m) th[m].join();
@@ -831,9 +876,31 @@ int main(int argc, char **argv) {
           ckx(trc);
           rd[m].consume((size_t)used);
         }
+        // (one context: its last batch was being mapped under this batch's read, scan and take -- the take gathers into staging buffers
+        //  that the commit swaps in, cm_ingest.hip; with several contexts the round's join below does the same job)
+        const double tj0 = now_s();
+        if (overlap1 && busy[0]) {
+          workers[0].join();
+          busy[0] = 0;
+          if (wrc[0] != CMGPU_OK) die(cmgpu_last_error(ctxs[0]));
+        }
+        const double tj1 = now_s();
+        if (!store_sized && overlap1 && a.p.max_num_best_mappings == 1) {
+          // the record store sized once from what the first piece says about the files (records scanned / share of the file they came
+          // from, over all input files): grown on demand it doubles each time with an allocation, a copy and a synchronous free
+          store_sized = true;
+          const double fr = rd[0].fraction();
+          if (fr > 0 && rd[0].fsize) {
+            uint64_t all = 0;
+            for (const std::string &pth : a.r1) { struct stat sb; if (stat(pth.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) all += (uint64_t)sb.st_size; }
+            const double est = (double)cnt[0] / fr * ((double)all / (double)rd[0].fsize);
+            if (est < 2.0e9) (void)cmgpu_store_reserve(cx, (uint64_t)(est * 1.01) + 1000000, barcoded ? 1 : 0);  // (no room: the store grows as before)
+          }
+        }
         ckx(cmgpu_fastq_commit(cx, n, next_read_id, paired ? 1 : 0, barcoded ? 1 : 0));
-        t_parse += now_s() - t0;
-        if (dbg_times) fprintf(stderr, "[times] scan %.4f take+commit %.4f\n", ts1 - ts0, now_s() - ts1);
+        t_parse += now_s() - t0 - (tj1 - tj0);
+        t_map += tj1 - tj0;
+        if (dbg_times) fprintf(stderr, "[times] scan %.4f take %.4f wait for the batch before %.4f\n", ts1 - ts0, tj0 - ts1, tj1 - tj0);
         t0 = now_s();
         {
           const size_t gi = turn;
@@ -848,7 +915,7 @@ int main(int argc, char **argv) {
           });
           busy[gi] = 1;
         }
-        if (++turn == NG) finish_round();
+        if (!overlap1 && ++turn == NG) finish_round();
         t_map += now_s() - t0;
         num_reads += paired ? 2ull * n : n;
         next_read_id += n;
@@ -861,7 +928,7 @@ int main(int argc, char **argv) {
     }
     {
       const double t0 = now_s();
-      if (turn > 0 || exchange) finish_round();  // the last, partial round (empty batches for the contexts beyond it)
+      if (turn > 0 || exchange || busy[0]) finish_round();  // the last, partial round (empty batches for the contexts beyond it)
       t_map += now_s() - t0;
     }
     for (const cmgpu_stats &x : wst) {
@@ -1119,7 +1186,7 @@ int main(int argc, char **argv) {
     } else {
       // sections in rank order: the owners hold contiguous, increasing chromosome ranges
       for (size_t gi = 0; gi < ctxs.size(); ++gi)
-        if (cmgpu_store_write_text(ctxs[gi], a.out_path.c_str(), gi ? 1 : 0) != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));
+        if (cmgpu_store_write_text(ctxs[gi], a.out_path.c_str(), 1) != CMGPU_OK) die(cmgpu_last_error(ctxs[gi]));  // (emptied at the start)
     }
     t_post = now_s() - t0;
     fprintf(stderr, "Sorted, deduplicated and formatted %llu bytes on the device in %.3fs, wrote them in %.3fs.\n", (unsigned long long)nbytes,

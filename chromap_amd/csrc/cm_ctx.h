@@ -27,6 +27,7 @@ struct CmFqStream {
   DevBuf text, cnt, off, nl, keep, pos, recidx, len, bad;
   DevBuf scan_tmp;            // scratch of this stream's prefix sums (the files' scans may run side by side, each on its own HIP stream)
   hipStream_t hs = nullptr;   // created on first use (fq_hs, cm_ingest.hip), destroyed with the context
+  DevBuf red_tmp;             // scratch of the take's reduction (kept: a hipFree per take would wait for the whole device)
   DevBuf text2, comp, btab, toks, ntok;  // BGZF inflated on the device: second text buffer (the retained rest moves through it), compressed blocks,
                                          // their table, the match tokens of the first pass and their number per block
   bool dev_mode = false;      // the text lives on the device between calls (cmgpu_fastq_scan_bgzf)
@@ -99,6 +100,9 @@ struct cmgpu_ctx {
   size_t bases0 = 0, bases1 = 0;
   uint32_t max_read_len = 1;
   DevBuf rb0, rb1, ro0, ro1;
+  // the batch being TAKEN from the FASTQ streams (cmgpu_fastq_take writes here, cmgpu_fastq_commit swaps these with the resident
+  // batch's buffers): the next batch is parsed and gathered while the resident one is being mapped on another host thread
+  DevBuf st_rb0, st_rb1, st_ro0, st_ro1, st_bcb, st_bcq, st_bco;
   // per-read / per-pair arrays (names match CmDev)
   DevBuf rlen, scratch_a, scratch_b /* 2n+1 u32 each, free between batches */, mm_cnt, mm_off, mm_hash, mm_ps, pr_val, pr_kind;
   DevBuf hit_tot, hit_off, round2, rep_cnt, rep_len, hbuf, hcnt, n_pos_hit, ncp, ncn;
@@ -201,7 +205,8 @@ struct cmgpu_ctx {
 
   std::vector<DevBuf *> all_bufs() {
     std::vector<DevBuf *> v = core_bufs();
-    for (CmFqStream &f : fq) for (DevBuf *b : {&f.text, &f.cnt, &f.off, &f.nl, &f.keep, &f.pos, &f.recidx, &f.len, &f.bad, &f.text2, &f.comp, &f.btab, &f.toks, &f.ntok, &f.scan_tmp}) v.push_back(b);
+    for (CmFqStream &f : fq) for (DevBuf *b : {&f.text, &f.cnt, &f.off, &f.nl, &f.keep, &f.pos, &f.recidx, &f.len, &f.bad, &f.text2, &f.comp, &f.btab, &f.toks, &f.ntok, &f.scan_tmp, &f.red_tmp}) v.push_back(b);
+    for (DevBuf *b : {&st_rb0, &st_rb1, &st_ro0, &st_ro1, &st_bcb, &st_bcq, &st_bco}) v.push_back(b);
     for (CmBatchSlot &sl : slots) for (DevBuf *b : {&sl.rb0, &sl.rb1, &sl.ro0, &sl.ro1}) v.push_back(b);
     return v;
   }

@@ -161,7 +161,18 @@ static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int fina
 // the HIP stream a FASTQ stream's scan runs on: one each, so that a host thread per file scans read 1, read 2 and the barcodes side by
 // side (cmgpu_fastq_scan / _scan_bgzf of DIFFERENT streams of one context may be called concurrently; every call ends synchronised)
 static hipStream_t fq_hs(cmgpu_ctx *c, CmFqStream &f) {
-  if (!f.hs && hipStreamCreateWithFlags(&f.hs, hipStreamNonBlocking) != hipSuccess) { f.hs = nullptr; (void)hipGetLastError(); return c->stream; }
+  if (!f.hs) {
+    // (experiment, CM_FQ_PRIO=1: read 2's stream with the highest priority -- streams of one priority share hardware queues, and the traces
+    //  show read 1's and read 2's scans on ONE queue, their kernels one behind the other)
+    const int which = (int)(&f - c->fq);
+    hipError_t e;
+    if (which == 1 && getenv("CM_FQ_PRIO")) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      e = hipStreamCreateWithPriority(&f.hs, hipStreamNonBlocking, atoi(getenv("CM_FQ_PRIO")) > 0 ? hi : lo);
+    } else e = hipStreamCreateWithFlags(&f.hs, hipStreamNonBlocking);
+    if (e != hipSuccess) { f.hs = nullptr; (void)hipGetLastError(); return c->stream; }
+  }
   return f.hs;
 }
 
@@ -353,7 +364,8 @@ static int fq_retain_rest(cmgpu_ctx *c, CmFqStream &f, uint64_t consumed, bool e
     bool blank = true;
     for (uint64_t o = 0; blank && o < rest; o += tail.size()) {
       const size_t m = rest - o < tail.size() ? (size_t)(rest - o) : tail.size();
-      FQCHECK(c, hipMemcpy(tail.data(), (const uint8_t *)f.text.p + consumed + o, m, hipMemcpyDeviceToHost));
+      FQCHECK(c, hipMemcpyAsync(tail.data(), (const uint8_t *)f.text.p + consumed + o, m, hipMemcpyDeviceToHost, fq_hs(c, f)));
+      FQCHECK(c, cm_stream_sync(fq_hs(c, f)));
       for (size_t i = 0; i < m; ++i) { const char ch = tail[i]; blank = blank && (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t'); }
     }
     if (!blank) { cm_set_error(c, "text after the last whole FASTQ record of the file"); return CMGPU_EFORMAT; }
@@ -364,8 +376,8 @@ static int fq_retain_rest(cmgpu_ctx *c, CmFqStream &f, uint64_t consumed, bool e
   if (rest) {
     // (sized like the first buffer: the two swap, and a buffer that is large enough is left alone)
     if (f.text2.cap < rest + 32 && f.text2.ensure(rest + 32 > f.text.cap ? rest + 32 : f.text.cap)) { cm_set_error(c, "out of device memory (FASTQ text)"); return CMGPU_ENOMEM; }
-    FQCHECK(c, hipMemcpyAsync(f.text2.p, (const uint8_t *)f.text.p + consumed, rest, hipMemcpyDeviceToDevice, c->stream));
-    FQCHECK(c, cm_stream_sync(c->stream));
+    FQCHECK(c, hipMemcpyAsync(f.text2.p, (const uint8_t *)f.text.p + consumed, rest, hipMemcpyDeviceToDevice, fq_hs(c, f)));
+    FQCHECK(c, cm_stream_sync(fq_hs(c, f)));
     DevBuf t = f.text; f.text = f.text2; f.text2 = t;
   }
   f.dev_len = rest;
@@ -436,14 +448,17 @@ extern "C" int cmgpu_fastq_scan_bgzf(cmgpu_ctx *c, int stream, const void *block
   return fq_scan_resident(c, stream, out, final_chunk, last_char, n_records);
 }
 
+// (everything here runs on the FASTQ stream's own HIP stream and writes the STAGING buffers st_*: a caller may take the next batch while
+//  another of its threads is inside cmgpu_map_resident / cmgpu_store_append_resident with the committed one -- no null-stream call, which
+//  would wait for the mapping stream, and no hipFree, which waits for the device)
 extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *bytes_consumed) {
   if (!c || stream < 0 || stream > 2 || !bytes_consumed) return CMGPU_EINVAL;
   FQCHECK(c, cm_enter(c));
   CmFqStream &f = c->fq[stream];
-  hipStream_t s = c->stream;
+  hipStream_t s = fq_hs(c, f);
   if (n > f.n_rec) { cm_set_error(c, "more records requested than the chunk holds"); return CMGPU_EINVAL; }
-  DevBuf &bases = stream == 0 ? c->rb0 : stream == 1 ? c->rb1 : c->bcb;
-  DevBuf &offs = stream == 0 ? c->ro0 : stream == 1 ? c->ro1 : c->bco;
+  DevBuf &bases = stream == 0 ? c->st_rb0 : stream == 1 ? c->st_rb1 : c->st_bcb;
+  DevBuf &offs = stream == 0 ? c->st_ro0 : stream == 1 ? c->st_ro1 : c->st_bco;
   f.taken = n;
   f.taken_bases = 0;
   f.taken_max_len = 0;
@@ -453,20 +468,26 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   bool have_last = false;
   if (n == f.n_rec) { if (f.n_raw) { last_raw = f.n_raw - 1; have_last = true; } }
   else if (n > 0) {
-    FQCHECK(c, hipMemcpy(&last_raw, (uint32_t *)f.recidx.p + (n - 1), 4, hipMemcpyDeviceToHost));
+    FQCHECK(c, hipMemcpyAsync(&last_raw, (uint32_t *)f.recidx.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    FQCHECK(c, cm_stream_sync(s));
     have_last = true;
   }
   uint64_t consumed = 0;
   if (have_last) {
     uint32_t endnl = 0;
-    FQCHECK(c, hipMemcpy(&endnl, (uint32_t *)f.nl.p + (4 * (size_t)last_raw + 3), 4, hipMemcpyDeviceToHost));
+    FQCHECK(c, hipMemcpyAsync(&endnl, (uint32_t *)f.nl.p + (4 * (size_t)last_raw + 3), 4, hipMemcpyDeviceToHost, s));
+    FQCHECK(c, cm_stream_sync(s));
     consumed = (uint64_t)endnl + 1;
     if (consumed > f.n_bytes) consumed = f.n_bytes;
   }
   *bytes_consumed = consumed;
   if (offs.ensure(((size_t)n + 1) * 4)) { cm_set_error(c, "out of device memory (read offsets)"); return CMGPU_ENOMEM; }
-  if (n == 0) { FQCHECK(c, hipMemset(offs.p, 0, 4)); return f.dev_mode ? fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec, bytes_consumed) : CMGPU_OK; }
-  if (f.len.ensure(((size_t)n + 1) * 4) || c->scan_tmp.ensure(cm_scan_tmp_words(n) * 4) || f.bad.ensure(4)) {
+  if (n == 0) {
+    FQCHECK(c, hipMemsetAsync(offs.p, 0, 4, s));
+    FQCHECK(c, cm_stream_sync(s));
+    return f.dev_mode ? fq_retain_rest(c, f, consumed, f.final_chunk && n == f.n_rec, bytes_consumed) : CMGPU_OK;
+  }
+  if (f.len.ensure(((size_t)n + 1) * 4) || f.scan_tmp.ensure(cm_scan_tmp_words(n) * 4) || f.bad.ensure(4)) {
     cm_set_error(c, "out of device memory (FASTQ lengths)"); return CMGPU_ENOMEM;
   }
   const dim3 g((n + FQ_BLOCK - 1) / FQ_BLOCK), b(FQ_BLOCK);
@@ -475,21 +496,19 @@ extern "C" int cmgpu_fastq_take(cmgpu_ctx *c, int stream, uint32_t n, uint64_t *
   for (int k = 0; k < 4; ++k) { fmt.start[k] = f.rng_start[k]; fmt.end[k] = f.rng_end[k]; }
   fmt.minus = f.minus ? 1 : 0;
   hipLaunchKernelGGL(k_fq_len, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p, n, fmt, (uint32_t *)f.len.p);
-  cm_scan_u32((const uint32_t *)f.len.p, (uint32_t *)offs.p, n, (uint32_t *)c->scan_tmp.p, s);
+  cm_scan_u32((const uint32_t *)f.len.p, (uint32_t *)offs.p, n, (uint32_t *)f.scan_tmp.p, s);
   size_t tb = 0;
   (void)rocprim::reduce(nullptr, tb, (const uint32_t *)f.len.p, (uint32_t *)f.bad.p, 0u, (size_t)n, FqMaxOp(), s);
-  DevBuf rtmp;
-  if (rtmp.ensure(tb + 256)) { cm_set_error(c, "out of device memory (reduce)"); return CMGPU_ENOMEM; }
-  hipError_t e = rocprim::reduce(rtmp.p, tb, (const uint32_t *)f.len.p, (uint32_t *)f.bad.p, 0u, (size_t)n, FqMaxOp(), s);
+  if (f.red_tmp.ensure(tb + 256)) { cm_set_error(c, "out of device memory (reduce)"); return CMGPU_ENOMEM; }
+  hipError_t e = rocprim::reduce(f.red_tmp.p, tb, (const uint32_t *)f.len.p, (uint32_t *)f.bad.p, 0u, (size_t)n, FqMaxOp(), s);
   uint32_t total = 0, mx = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint32_t *)offs.p + n, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipMemcpyAsync(&mx, f.bad.p, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = cm_stream_sync(s);
-  rtmp.release();
   if (e != hipSuccess) { cm_set_error(c, std::string("FASTQ take: ") + hipGetErrorString(e)); return CMGPU_EHIP; }
-  if (bases.ensure((size_t)total + 16) || (stream == 2 && c->bcq.ensure((size_t)total + 16))) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
+  if (bases.ensure((size_t)total + 16) || (stream == 2 && c->st_bcq.ensure((size_t)total + 16))) { cm_set_error(c, "out of device memory (reads)"); return CMGPU_ENOMEM; }
   hipLaunchKernelGGL(k_fq_gather, g, b, 0, s, (const uint8_t *)f.text.p, (const uint32_t *)f.nl.p, (const uint32_t *)f.recidx.p,
-                     (const uint32_t *)offs.p, n, fmt, (uint8_t *)bases.p, stream == 2 ? (uint8_t *)c->bcq.p : (uint8_t *)nullptr);
+                     (const uint32_t *)offs.p, n, fmt, (uint8_t *)bases.p, stream == 2 ? (uint8_t *)c->st_bcq.p : (uint8_t *)nullptr);
   FQCHECK(c, cm_stream_sync(s));
   f.taken_bases = total;
   f.taken_max_len = mx;
@@ -508,6 +527,11 @@ extern "C" int cmgpu_fastq_commit(cmgpu_ctx *c, uint32_t n, uint32_t first_read_
   if (n > 0x3fffffffu) { cm_set_error(c, "batch too large"); return CMGPU_EINVAL; }
   if (!paired && c->p.split) { cm_set_error(c, "single-end split alignment is not supported"); return CMGPU_EINVAL; }
   if (barcoded && c->wl_size != 0 && c->wl_num_sample == 0) { cm_set_error(c, "barcode abundance not computed"); return CMGPU_EINVAL; }
+  // the taken batch becomes the resident one: the staging buffers and the resident batch's swap (the old batch's buffers take the next
+  // take).  The caller has no cmgpu_map_* call of this context running here.
+  std::swap(c->rb0, c->st_rb0); std::swap(c->ro0, c->st_ro0);
+  if (paired) { std::swap(c->rb1, c->st_rb1); std::swap(c->ro1, c->st_ro1); }
+  if (barcoded) { std::swap(c->bcb, c->st_bcb); std::swap(c->bcq, c->st_bcq); std::swap(c->bco, c->st_bco); }
   c->n_pairs = n;
   c->first_read_id = first_read_id;
   c->single = !paired;
@@ -535,3 +559,8 @@ extern "C" int cmgpu_fastq_set_format(cmgpu_ctx *c, int stream, int n_ranges, co
   if (n_ranges >= 1 && !f.minus && starts[0] == 0 && ends[0] == -1) f.n_ranges = 0;
   return CMGPU_OK;
 }
+
+// the device code of this translation unit is loaded by the HIP runtime at the first launch of one of its kernels (milliseconds to tens of
+// milliseconds for the larger ones): context creation launches this empty kernel so that a job's first batch does not pay for it (cm_api.hip: cm_load_device_code)
+__global__ void k_touch_ingest() {}
+void cm_touch_ingest(hipStream_t s) { hipLaunchKernelGGL(k_touch_ingest, dim3(1), dim3(1), 0, s); }

@@ -36,6 +36,7 @@
 
 #include <atomic>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -242,6 +243,8 @@ struct ParGunzip {
     if (fd >= 0) ::close(fd);
     fd = -1;
     active = false;
+    tk_.reset(); tk_n_ = 0;
+    free(head_.out.p); head_.out.p = nullptr; head_.out.len = head_.out.cap = 0;
   }
 
   // ---- accepted output.  The consumer walks a group's chunks in order and only DECIDES (which decode counts, which window it sees);
@@ -385,6 +388,9 @@ struct ParGunzip {
   }
 
   // the next group of chunks: decoded side by side, walked in order, finished side by side
+  std::unique_ptr<Task[]> tk_;
+  int tk_n_ = 0;
+  Dec head_;
   int fruitless = 0;  // groups in a row none of whose guesses counted (stored blocks: incompressible data): after two, plain serial decoding
   bool produce(unsigned char *dst, size_t want, size_t *got) {
     if (fruitless >= 2) {
@@ -397,10 +403,14 @@ struct ParGunzip {
     // a group: one chunk per thread.  (Three per thread, taken from a counter, to even out the chunks' costs before the group's barrier:
     // measured worse -- 182 MB on 32 threads: decode 207 -> 240 ms, the walk 19 -> 210 ms, .fastq.gz -> BED 0.90 -> 1.47 s; a group's
     // buffers then are gigabytes of fresh pages.)
+    // (the tasks and their output buffers live as long as the file is open: a group's decodes write ~20 MB per chunk, and buffers made
+    //  anew for every group were that many fresh pages to fault in -- and to give back -- per group, by all threads at once)
     const int nt = threads;
-    std::vector<Task> tk((size_t)nt);
+    if (!tk_ || tk_n_ != nt) { tk_.reset(new Task[(size_t)nt]); tk_n_ = nt; }
+    Task *tk = tk_.get();
     int used = 0;
     for (int i = 0; i < nt; ++i) {
+      tk[i].have = false; tk[i].S = tk[i].E = 0; tk[i].ended = false; tk[i].three = false;
       tk[i].r0 = g0 + (size_t)i * kChunk;
       tk[i].r1 = tk[i].r0 + kChunk;
       if (tk[i].r0 >= zn) break;
@@ -411,7 +421,7 @@ struct ParGunzip {
     static const std::vector<uint8_t> dictC = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(255 ^ (k & 255)); return v; }();
     // task 0: the true decode from `pos`; tasks 1..: search + speculative decodes
     const double t_g0 = now();
-    Dec head;
+    Dec &head = head_;
     bool head_ok = true;
     std::vector<std::thread> th;
     std::atomic<int> next_chunk{0};
@@ -459,7 +469,7 @@ struct ParGunzip {
       }
     }
     t_chain += now() - t_c0;
-    finish_pieces(dst, want, got);  // (the tasks' buffers die with this function: nothing may be left pointing at them)
+    finish_pieces(dst, want, got);  // (the tasks' buffers are written again by the next group: nothing may be left pointing at them)
     if (dbg) fprintf(stderr, "[pargz] so far: decode %.3f s, chain %.3f s (incl. mid-group finishes), finish %.3f s\n", t_decode, t_chain, t_finish);
     if (used > 1) fruitless = n_accepted == accepted_before ? fruitless + 1 : 0;
     return true;

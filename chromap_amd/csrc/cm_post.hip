@@ -21,6 +21,9 @@
 #include <string.h>
 #include <cstring>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <rocprim/rocprim.hpp>
 
 #include "cm_ctx.h"
@@ -894,21 +897,60 @@ extern "C" int cmgpu_store_text(cmgpu_ctx *c, char *out, uint64_t capacity) {
   return CMGPU_OK;
 }
 
+// (round 6: this took 89 ms for 246 MB where a bare write() of as many bytes takes 25 -- a 64 MiB page-locked slab costs ~35 ms to allocate
+//  and more to free, and copies and writes took turns.  Now two ordinary 16 MiB slabs: the runtime's own staging buffers bring a copy into
+//  pageable memory at ~25 GB/s, and a second thread writes one slab while the next is being copied.  Several writing threads gain nothing:
+//  buffered writes to one file are serialised by the kernel -- tools/probes/write_probe.cpp, 1 / 4 / 16 threads 25 / 25 / 32 ms per 256 MB)
 extern "C" int cmgpu_store_write_text(cmgpu_ctx *c, const char *path, int append) {
   if (!c || !path) return CMGPU_EINVAL;
   PPCHECK(c, cm_enter(c));
   FILE *f = fopen(path, append ? "ab" : "wb");
   if (!f) { cm_set_error(c, std::string("cannot open ") + path); return CMGPU_EIO; }
-  const size_t slab = 64u << 20;
-  void *h = nullptr;
-  if (hipHostMalloc(&h, slab, hipHostMallocDefault) != hipSuccess) { fclose(f); cm_set_error(c, "pinned staging allocation failed"); return CMGPU_ENOMEM; }
+  const size_t slab = 16u << 20;
+  const uint64_t n_slabs = (c->text_bytes + slab - 1) / slab;
+  std::vector<uint8_t> buf[2];
+  for (int k = 0; k < 2 && (uint64_t)k < n_slabs; ++k) buf[k].resize(n_slabs == 1 ? (size_t)c->text_bytes : slab);
+  // slab i is copied into buf[i & 1] once slab i - 2 has been written out of it
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t copied = 0, written = 0;  // slabs copied / written so far
   bool ok = true;
-  for (uint64_t o = 0; ok && o < c->text_bytes; o += slab) {
+  std::thread writer([&]() {
+    for (uint64_t i = 0; i < n_slabs; ++i) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return copied > i || !ok; });
+        if (!ok) return;
+      }
+      const uint64_t o = i * slab;
+      const size_t m = c->text_bytes - o < slab ? (size_t)(c->text_bytes - o) : slab;
+      const bool w = fwrite(buf[i & 1].data(), 1, m, f) == m;
+      std::lock_guard<std::mutex> lk(mu);
+      if (!w) ok = false;
+      written = i + 1;
+      cv.notify_all();
+      if (!w) return;
+    }
+  });
+  bool copy_failed = false;
+  for (uint64_t i = 0; i < n_slabs; ++i) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return i < 2 || written + 2 > i || !ok; });
+      if (!ok) break;
+    }
+    const uint64_t o = i * slab;
     const size_t m = c->text_bytes - o < slab ? (size_t)(c->text_bytes - o) : slab;
-    ok = hipMemcpy(h, (const uint8_t *)c->text.p + o, m, hipMemcpyDeviceToHost) == hipSuccess && fwrite(h, 1, m, f) == m;
+    const bool cp = hipMemcpy(buf[i & 1].data(), (const uint8_t *)c->text.p + o, m, hipMemcpyDeviceToHost) == hipSuccess;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cp) { ok = false; copy_failed = true; }
+    else copied = i + 1;
+    cv.notify_all();
+    if (!cp) break;
   }
-  (void)hipHostFree(h);
+  writer.join();
   ok = fclose(f) == 0 && ok;
+  if (copy_failed) { (void)hipGetLastError(); cm_set_error(c, "copying the rendered text from the device failed"); return CMGPU_EHIP; }
   if (!ok) { cm_set_error(c, std::string("short write to ") + path); return CMGPU_EIO; }
   return CMGPU_OK;
 }
@@ -928,3 +970,8 @@ void cm_store_split_bc(cmgpu_ctx *c, const void *in32, uint64_t n, hipStream_t s
   hipLaunchKernelGGL(k_pp_split_bc, dim3((unsigned)((n + PP_BLOCK - 1) / PP_BLOCK)), dim3(PP_BLOCK), 0, s, (const uint8_t *)in32, (uint32_t)n,
                      (uint8_t *)c->store.p + c->store_n * 24, (uint64_t *)c->store_bc.p + c->store_n);
 }
+
+// the device code of this translation unit is loaded by the HIP runtime at the first launch of one of its kernels (milliseconds to tens of
+// milliseconds for the larger ones): context creation launches this empty kernel so that a job's first batch does not pay for it (cm_api.hip: cm_load_device_code)
+__global__ void k_touch_post() {}
+void cm_touch_post(hipStream_t s) { hipLaunchKernelGGL(k_touch_post, dim3(1), dim3(1), 0, s); }

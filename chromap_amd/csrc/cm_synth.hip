@@ -628,3 +628,8 @@ extern "C" int cmgpu_generate_resident_batch_indels(cmgpu_ctx *c, uint32_t n_pai
   SYCHECK(c, cm_stream_sync(c->stream));
   return CMGPU_OK;
 }
+
+// the device code of this translation unit is loaded by the HIP runtime at the first launch of one of its kernels (milliseconds to tens of
+// milliseconds for the larger ones): context creation launches this empty kernel so that a job's first batch does not pay for it (cm_api.hip: cm_load_device_code)
+__global__ void k_touch_synth() {}
+void cm_touch_synth(hipStream_t s) { hipLaunchKernelGGL(k_touch_synth, dim3(1), dim3(1), 0, s); }

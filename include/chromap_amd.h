@@ -191,6 +191,12 @@ int cmgpu_set_chr_order(cmgpu_ctx *ctx, const uint32_t *rank, uint32_t n_sequenc
 /* --pairs-natural-chr-order (src/chromap.h:660-664, src/mapping_generator.cc:193-203): rank, over the sequences as the
  * records number them, that decides which end of a pair is written first; cmgpu_write_pairs_ranked orders the header by it. */
 int cmgpu_set_pairs_chr_order(cmgpu_ctx *ctx, const uint32_t *rank, uint32_t n_sequences);
+/* Before there is an index to make a context with: initialises the HIP runtime on the device, loads the library's device
+ * code and maps 2 000 made-up pairs against a made-up 64 kb reference, from FASTQ text to BED text, in a context of its own
+ * that is destroyed again -- hardware queues, scratch memory and sort plans a process otherwise pays for inside its first
+ * batch (tens of milliseconds).  Optional; once per device and process; thread-safe; errors of the dry run are ignored. */
+int cmgpu_warm_up(int device_id);
+
 /* A further context over the SAME resident index and reference (no copy; the parent must outlive it).
  * Contexts are single-caller, so this is how one GPU keeps several batches in flight: one host
  * thread and one context per batch; their kernels share the compute units. */

@@ -7,6 +7,9 @@ D=/tmp/chromap_amd_e2e
 [ -f $D/r1.fq.bgz ] || timeout 600 python tools/e2e_bench.py --gz --reps 1 > $O/e2e.json 2> $O/e2e.log
 export TMPDIR=/tmp; cd /tmp
 rm -f $D/out.bed; sync
+# the CLI's own per-batch times, without the profiler (twice: the second run has the files in the page cache for sure)
+for i in 1 2; do CM_CLI_TIMES=1 $GRAFT_REPO_ROOT/chromap_amd/chromap-amd --preset atac -x $D/g.index -r $D/g.fa -1 $D/r1.fq.bgz -2 $D/r2.fq.bgz -o $D/out.bed 2>&1 | grep -v "^Mapped [0-9]* read" > $O/times$i.log; done
+cat $O/times2.log
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace -o t -- $GRAFT_REPO_ROOT/chromap_amd/chromap-amd --preset atac -x $D/g.index -r $D/g.fa -1 $D/r1.fq.bgz -2 $D/r2.fq.bgz -o $D/out.bed 2> $O/cli.log
 tail -3 $O/cli.log
 python - <<PY
