@@ -287,7 +287,6 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
 
 // Every translation unit's device code, loaded now (the runtime defers it to the first launch: round 6 found 13 ms of a job's first FASTQ
 // scan inside the first prefix sum -- cm_kernels' code object being loaded -- and as much again in the first mapping and post-processing calls)
-void cm_touch_kernels(hipStream_t s);
 void cm_touch_post(hipStream_t s);
 void cm_touch_ingest(hipStream_t s);
 void cm_touch_exchange(hipStream_t s);
@@ -299,8 +298,16 @@ static void cm_load_device_code(hipStream_t s) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   std::call_once(once[dev], [s]() {
     hipLaunchKernelGGL(k_touch_api, dim3(1), dim3(1), 0, s);
-    cm_touch_kernels(s); cm_touch_post(s); cm_touch_ingest(s); cm_touch_exchange(s); cm_touch_synth(s);
+    cm_touch_post(s); cm_touch_ingest(s); cm_touch_exchange(s); cm_touch_synth(s);
+    // (cm_kernels.hip, the largest: through one of its launchers -- a prefix sum of four numbers -- the file itself stays as the
+    //  committed profiles' source hash has it)
+    DevBuf tiny;
+    if (tiny.ensure((8 + 8 + cm_scan_tmp_words(4)) * 4) == 0) {
+      (void)hipMemsetAsync(tiny.p, 0, 64, s);
+      cm_scan_u32((const uint32_t *)tiny.p, (uint32_t *)tiny.p + 8, 4, (uint32_t *)tiny.p + 16, s);
+    }
     (void)hipStreamSynchronize(s);
+    tiny.release();
     (void)hipGetLastError();
   });
 }

@@ -2293,8 +2293,3 @@ void cm_launch_k_probe(const uint64_t *bkt, uint32_t bmask, const uint64_t *hash
   if (partials && counters)
     hipLaunchKernelGGL(k_probe_reduce, dim3(blocks / (CM_BLOCK * 8) + 1), dim3(CM_BLOCK), 0, s, (const uint2 *)partials, blocks, counters);
 }
-
-// the device code of this translation unit is loaded by the HIP runtime at the first launch of one of its kernels (milliseconds to tens of
-// milliseconds for the larger ones): context creation launches this empty kernel so that a job's first batch does not pay for it (cm_api.hip: cm_load_device_code)
-__global__ void k_touch_kernels() {}
-void cm_touch_kernels(hipStream_t s) { hipLaunchKernelGGL(k_touch_kernels, dim3(1), dim3(1), 0, s); }
