@@ -67,6 +67,8 @@ def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000, pairs=None):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_baseline.py"), "--genome", str(args.genome), "--nseq",
            str(args.nseq), "--pairs", str(pairs or args.pairs), "--batches", "2", "--readlen", str(args.readlen), "--preset", args.preset,
            "--seed0", str(seed0), "--indel-rate", str(args.indel_rate)]
+    from chromap_amd.cpus import cpu_budget
+    cmd += ["--threads", str(cpu_budget())]  # (-t for the reference: the processors the container's quota really gives it, not the 256 it reports)
     if repeats:
         cmd += ["--repeats", repeats if isinstance(repeats, str) else ",".join(str(x) for x in repeats)]
     if args.hic >= 0:
@@ -141,7 +143,8 @@ def cpu_baseline_port(g, args):
     o1 = np.empty(n + 1, np.uint32)
     o2 = np.empty(n + 1, np.uint32)
     assert L.cmgpu_download_batch(g.ctx, b1.ctypes.data, o1.ctypes.data, b2.ctypes.data, o2.ctypes.data) == 0
-    cores = len(os.sched_getaffinity(0))
+    from chromap_amd.cpus import cpu_budget
+    cores = cpu_budget()  # (the affinity mask cut to the container's CPU quota: 16 on the measurement boxes, which report 256 hardware threads)
 
     def run(m):
         rec = (ol.OraRecord * m)()

@@ -321,6 +321,10 @@ static int select_device(int device_id) {
   }
   if (device_id < 0 || device_id >= n) { cm_set_error(nullptr, "device_id out of range"); return CMGPU_EINVAL; }
   if (hipSetDevice(device_id) != hipSuccess) { cm_set_error(nullptr, "hipSetDevice failed"); return CMGPU_EHIP; }
+  // (CM_BLOCKING_SYNC=1, before the device's first use by the process: host threads that wait for the device sleep instead of spinning --
+  //  a process with a CPU quota and inflating threads of its own has better use for the processors; 0.1-0.2 ms more per wait)
+  static const bool blocking = getenv("CM_BLOCKING_SYNC") != nullptr;
+  if (blocking) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   (void)hipGetLastError();  // clean slate: cm_stream_sync reports this call's launches only
   return CMGPU_OK;
 }

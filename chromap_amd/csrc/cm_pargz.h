@@ -36,12 +36,17 @@
 
 #include <atomic>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <memory>
 #include <thread>
 #include <vector>
 
 struct ParGunzip {
-  static constexpr size_t kChunk = (size_t)2 << 20;  // compressed bytes per chunk
+  // compressed bytes per chunk (CM_PARGZ_CHUNK_KB: measurements).  A chunk's two decodes write ~11 bytes per compressed byte into buffers
+  // that are reused by every other group: the smaller the chunks, the less memory a short job touches for the first time
+  size_t kChunk = getenv("CM_PARGZ_CHUNK_KB") && atol(getenv("CM_PARGZ_CHUNK_KB")) >= 64 ? (size_t)atol(getenv("CM_PARGZ_CHUNK_KB")) << 10 : (size_t)2 << 20;
   static constexpr uint32_t kWin = 32768;
   const uint8_t *z = nullptr;  // the file, mapped
   size_t zn = 0;
@@ -53,7 +58,87 @@ struct ParGunzip {
   std::vector<uint8_t> win;    // the last <= 32 KiB of accepted output of the current member (its true window)
   uint32_t crc = 0;            // of the current member's accepted output
   uint64_t member_out = 0;
-  std::vector<uint8_t> spill;  // accepted output not yet taken by read()
+  // ---- teams of threads that live as long as the file is open.  (Round 6: a team made anew for every group and every finish -- a finish of
+  // 81 MB whose threads' work adds up to 130 ms took 7-10 ms or 67-93 ms, depending on how long the new threads took to appear: making
+  // a thread maps its stack, which waits for the address space's lock behind the page faults of 60-odd busy threads; more threads made the
+  // whole job slower.)  submit(f): every worker runs f once; wait(): until all have.
+  struct Pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::function<void()> job;
+    uint64_t gen = 0;
+    int running = 0;
+    bool quit = false;
+    void start(int n) {
+      stop();
+      quit = false;
+      for (int i = 0; i < n; ++i)
+        th.emplace_back([this]() {
+          uint64_t seen = 0;
+          for (;;) {
+            std::function<void()> f;
+            {
+              std::unique_lock<std::mutex> lk(m);
+              cv.wait(lk, [&]() { return quit || gen != seen; });
+              if (quit) return;
+              seen = gen;
+              f = job;
+            }
+            f();
+            std::lock_guard<std::mutex> lk(m);
+            if (--running == 0) cv_done.notify_all();
+          }
+        });
+    }
+    void submit(const std::function<void()> &f) {
+      std::lock_guard<std::mutex> lk(m);
+      job = f;
+      running = (int)th.size();
+      ++gen;
+      cv.notify_all();
+    }
+    void wait() {
+      std::unique_lock<std::mutex> lk(m);
+      cv_done.wait(lk, [&]() { return running == 0; });
+    }
+    void stop() {
+      { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); }
+      for (std::thread &x : th) x.join();
+      th.clear();
+      running = 0;
+    }
+    ~Pool() { stop(); }
+  };
+  Pool pool_decode, pool_finish, pool_ahead;  // threads - 1 each (the caller is the team's last member), and the one that decodes ahead
+
+  // accepted output not yet taken by read(): a plain growing buffer (a std::vector would zero-fill hundreds of MB that the finishing
+  // threads are about to write)
+  struct Raw {
+    uint8_t *p = nullptr;
+    size_t len = 0, cap = 0;
+    size_t size() const { return len; }
+    uint8_t *data() { return p; }
+    void clear() { len = 0; }
+    void grow(size_t more) {
+      if (cap - len < more) {
+        size_t nc = cap ? cap : (size_t)64 << 20;
+        while (nc - len < more) nc *= 2;
+        void *q = nullptr;
+        if (posix_memalign(&q, (size_t)2 << 20, nc) != 0 || !q) { fprintf(stderr, "out of memory (gunzip buffers)\n"); abort(); }
+        (void)madvise(q, nc, MADV_HUGEPAGE);
+        if (len) memcpy(q, p, len);
+        free(p);
+        p = static_cast<uint8_t *>(q);
+        cap = nc;
+      }
+      len += more;
+    }
+    Raw() = default;
+    Raw(const Raw &) = delete;
+    Raw &operator=(const Raw &) = delete;
+    ~Raw() { free(p); }
+  } spill;
   size_t spill_off = 0;
   // statistics (tests, --inflate-only)
   uint64_t n_spec = 0, n_accepted = 0, n_serial = 0;
@@ -140,11 +225,18 @@ struct ParGunzip {
       const uint8_t *data() const { return p; }
       size_t size() const { return len; }
       void clear() { len = 0; }
+      // (2 MiB-aligned and advised as huge pages: a short job writes every byte of these buffers for the first time -- 5.6 GB of fresh
+      //  pages for two 928 MB files, the faults of 64+ threads at once; more threads made it SLOWER, 32 -> 48: 0.86 -> 1.27 s end to end)
       void room(size_t more) {
         if (cap - len >= more) return;
-        size_t nc = cap ? cap * 2 : (size_t)8 << 20;
+        size_t nc = cap ? cap * 2 : (size_t)4 << 20;
         while (nc - len < more) nc *= 2;
-        p = static_cast<uint8_t *>(realloc(p, nc));
+        void *q = nullptr;
+        if (posix_memalign(&q, (size_t)2 << 20, nc) != 0 || !q) { fprintf(stderr, "out of memory (gunzip buffers)\n"); abort(); }
+        (void)madvise(q, nc, MADV_HUGEPAGE);
+        if (len) memcpy(q, p, len);
+        free(p);
+        p = static_cast<uint8_t *>(q);
         cap = nc;
       }
       uint8_t &operator[](size_t i) { return p[i]; }
@@ -235,16 +327,21 @@ struct ParGunzip {
     threads = nthreads < 2 ? 2 : (nthreads > 64 ? 64 : nthreads);
     win.clear(); crc = (uint32_t)crc32(0L, Z_NULL, 0); member_out = 0;
     active = true; done = false;
+    pool_decode.start(threads - 1);
+    pool_finish.start(threads - 1);
+    pool_ahead.start(1);
     return true;
   }
   void close() {
+    drop_ahead();  // (a team may still be decoding ahead, out of the mapping below)
+    pool_ahead.stop(); pool_decode.stop(); pool_finish.stop();
     if (z) munmap(const_cast<uint8_t *>(z), zn);
     z = nullptr;
     if (fd >= 0) ::close(fd);
     fd = -1;
     active = false;
-    tk_.reset(); tk_n_ = 0;
-    free(head_.out.p); head_.out.p = nullptr; head_.out.len = head_.out.cap = 0;
+    for (Group &g : grp_) { g.tk.reset(); g.n = 0; free(g.head.out.p); g.head.out.p = nullptr; g.head.out.len = g.head.out.cap = 0; }
+    cur_ = 0;
   }
 
   // ---- accepted output.  The consumer walks a group's chunks in order and only DECIDES (which decode counts, which window it sees);
@@ -294,42 +391,60 @@ struct ParGunzip {
     size_t total = 0;
     std::vector<size_t> at(pieces.size());
     for (size_t i = 0; i < pieces.size(); ++i) { at[i] = total; total += pieces[i].n; }
-    uint8_t *out;
-    if (spill_off >= spill.size() && want - *got >= total) { out = dst + *got; *got += total; }
-    else {
-      if (spill_off >= spill.size()) { spill.clear(); spill_off = 0; }
-      const size_t old = spill.size();
-      spill.resize(old + total);
-      out = spill.data() + old;
-    }
-    // work items of <= 1 MiB so that the threads share a group evenly
-    struct Item { size_t piece, x0, x1; };
+    // work items of <= 1 MiB so that the threads share a group evenly.  The caller's buffer takes the items that fit it whole, in order;
+    // the rest goes to the spill (round 6: a group that did not fit went there whole -- ~340 MB against requests of 256 MB: a zero-filled
+    // resize and a second copy, both by one thread, for every group)
+    struct Item { size_t piece, x0, x1, g; uint8_t *o; };  // g: the item's offset in the group's output; o: where its first byte goes
     std::vector<Item> items;
     for (size_t i = 0; i < pieces.size(); ++i)
-      for (size_t x = 0; x < pieces[i].n; x += (size_t)1 << 20) items.push_back({i, x, x + ((size_t)1 << 20) < pieces[i].n ? x + ((size_t)1 << 20) : pieces[i].n});
+      for (size_t x = 0; x < pieces[i].n; x += (size_t)1 << 20)
+        items.push_back({i, x, x + ((size_t)1 << 20) < pieces[i].n ? x + ((size_t)1 << 20) : pieces[i].n, at[i] + x, nullptr});
+    const size_t room = spill_off >= spill.size() ? want - *got : 0;  // (bytes still in the spill come first: nothing goes to dst then)
+    size_t cut = 0;  // the first `cut` bytes go to dst
+    for (const Item &it : items) { if (it.g + (it.x1 - it.x0) <= room) cut = it.g + (it.x1 - it.x0); else break; }
+    if (spill_off >= spill.size()) { spill.clear(); spill_off = 0; }
+    const size_t spill_old = spill.size();
+    spill.grow(total - cut);
+    for (Item &it : items) it.o = it.g < cut ? dst + *got + it.g : spill.data() + spill_old + (it.g - cut);
+    *got += cut;
     std::vector<uint32_t> icrc(items.size());
     std::atomic<size_t> next{0};
+    static const bool dbg_f = getenv("CM_PARGZ_DEBUG") != nullptr;
+    std::atomic<uint64_t> ns_fill{0}, ns_crc{0};
     auto work = [&]() {
       for (size_t k; (k = next.fetch_add(1)) < items.size();) {
         const Item &it = items[k];
         const Piece &p = pieces[it.piece];
-        uint8_t *o = out + at[it.piece];
-        if (p.b) for (size_t x = it.x0; x < it.x1; ++x) o[x] = fill(p, x);
+        uint8_t *o = it.o - it.x0;
+        const double tf0 = dbg_f ? now() : 0;
+        if (p.b && !p.c) {  // eight bytes at a time where the two decodes agree (a window byte is rare past a chunk's first stretch)
+          const uint8_t *pa = p.a->p, *pb = p.b->p;
+          size_t x = it.x0;
+          for (; x + 8 <= it.x1; x += 8) {
+            uint64_t va, vb;
+            memcpy(&va, pa + x, 8);
+            memcpy(&vb, pb + x, 8);
+            if (va == vb) memcpy(o + x, &va, 8);
+            else for (size_t k = x; k < x + 8; ++k) o[k] = fill(p, k);
+          }
+          for (; x < it.x1; ++x) o[x] = fill(p, x);
+        } else if (p.b) for (size_t x = it.x0; x < it.x1; ++x) o[x] = fill(p, x);
         else memcpy(o + it.x0, p.a->p + it.x0, it.x1 - it.x0);
+        const double tf1 = dbg_f ? now() : 0;
         icrc[k] = (uint32_t)crc32(crc32(0L, Z_NULL, 0), o + it.x0, (uInt)(it.x1 - it.x0));
+        if (dbg_f) { ns_fill += (uint64_t)((tf1 - tf0) * 1e9); ns_crc += (uint64_t)((now() - tf1) * 1e9); }
       }
     };
-    std::vector<std::thread> th;
-    const int nt = (int)(items.size() < (size_t)threads ? items.size() : (size_t)threads);
-    for (int i = 1; i < nt; ++i) th.emplace_back(work);
-    work();
-    for (std::thread &x : th) x.join();
+    if (items.size() > 1) { pool_finish.submit(work); work(); pool_finish.wait(); }
+    else work();
     for (size_t k = 0; k < items.size(); ++k) crc = (uint32_t)crc32_combine(crc, icrc[k], (z_off_t)(items[k].x1 - items[k].x0));
     member_out += total;
     pieces.clear();
     for (Dec::Buf *b : owned) delete b;
     owned.clear();
     t_finish += now() - t_f0;
+    if (dbg_f) fprintf(stderr, "[pargz] finish: %zu MB (%zu to the caller, %zu spilled) in %.1f ms; threads' sums: fill + copy %.1f ms, crc %.1f ms\n", total >> 20, cut >> 20,
+                       (total - cut) >> 20, (now() - t_f0) * 1e3, (double)ns_fill.load() / 1e6, (double)ns_crc.load() / 1e6);
   }
   // a member ended at byte `pos / 8`: trailer check (the pieces must be finished), then the next member's header (or the end of the file)
   bool member_end() {
@@ -377,7 +492,13 @@ struct ParGunzip {
     if (ok) {
       const uint8_t *pa = t.d[0].out.p, *pb = t.d[1].out.p;
       const size_t n = t.d[0].out.len;
-      for (size_t x = 0; x < n; ++x) if ((pa[x] & 128u) && pa[x] == pb[x]) { t.three = true; break; }
+      size_t x = 0;
+      for (; x + 8 <= n && !t.three; x += 8) {  // (text: no byte >= 128 at all)
+        uint64_t va;
+        memcpy(&va, pa + x, 8);
+        if (va & 0x8080808080808080ull) for (size_t k = x; k < x + 8; ++k) if ((pa[k] & 128u) && pa[k] == pb[k]) { t.three = true; break; }
+      }
+      for (; x < n && !t.three; ++x) if ((pa[x] & 128u) && pa[x] == pb[x]) t.three = true;
       if (t.three) {
         ok = t.d[2].start(z, zn, b, dC, kWin) && t.d[2].run(stop) && t.d[2].at == t.E && t.d[2].out.len == n;
         t.d[2].stop();
@@ -388,26 +509,39 @@ struct ParGunzip {
   }
 
   // the next group of chunks: decoded side by side, walked in order, finished side by side
-  std::unique_ptr<Task[]> tk_;
-  int tk_n_ = 0;
-  Dec head_;
+  // ---- a group of chunks: decoded side by side, walked in order, finished side by side.  Two sets of tasks take turns: while the threads
+  // finish group g (fill in, copy, check-sum: 0.15-0.27 s of a 928 MB file's 0.45-0.57 s, round 6), another team already decodes group g + 1
+  // -- where it starts and the window in front of it are known as soon as group g's chain has been walked.
+  // (the tasks and their output buffers live as long as the file is open: a group's decodes write ~20 MB per chunk, and buffers made
+  //  anew for every group were that many fresh pages to fault in -- and to give back -- per group, by all threads at once)
+  struct Group {
+    std::unique_ptr<Task[]> tk;
+    int n = 0, used = 0;
+    Dec head;
+    bool head_ok = true;
+    uint64_t start = 0;          // the bit position the group was decoded from
+    std::vector<uint8_t> w;      // the window its head decode saw
+    bool pending = false;        // being decoded ahead by pool_ahead's thread (waited for by the next produce(), or by close())
+    double t = 0;
+  };
+  Group grp_[2];
+  int cur_ = 0;
   int fruitless = 0;  // groups in a row none of whose guesses counted (stored blocks: incompressible data): after two, plain serial decoding
-  bool produce(unsigned char *dst, size_t want, size_t *got) {
-    if (fruitless >= 2) {
-      if (!serial_to(pos + ((uint64_t)64 << 23), dst, want, got)) return false;
-      finish_pieces(dst, want, got);
-      return true;
-    }
-    const uint64_t accepted_before = n_accepted;
-    const size_t g0 = (size_t)(pos >> 3);
-    // a group: one chunk per thread.  (Three per thread, taken from a counter, to even out the chunks' costs before the group's barrier:
-    // measured worse -- 182 MB on 32 threads: decode 207 -> 240 ms, the walk 19 -> 210 ms, .fastq.gz -> BED 0.90 -> 1.47 s; a group's
-    // buffers then are gigabytes of fresh pages.)
-    // (the tasks and their output buffers live as long as the file is open: a group's decodes write ~20 MB per chunk, and buffers made
-    //  anew for every group were that many fresh pages to fault in -- and to give back -- per group, by all threads at once)
+
+  // one chunk per thread.  (Three per thread, taken from a counter, to even out the chunks' costs before the group's barrier:
+  // measured worse -- 182 MB on 32 threads: decode 207 -> 240 ms, the walk 19 -> 210 ms, .fastq.gz -> BED 0.90 -> 1.47 s.)
+  void decode_group(Group &g, uint64_t from, const std::vector<uint8_t> &window) {
+    static const std::vector<uint8_t> dictA = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(k & 255); return v; }();
+    static const std::vector<uint8_t> dictB = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(128u | (k >> 8)); return v; }();
+    static const std::vector<uint8_t> dictC = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(255 ^ (k & 255)); return v; }();
+    const double t0 = now();
     const int nt = threads;
-    if (!tk_ || tk_n_ != nt) { tk_.reset(new Task[(size_t)nt]); tk_n_ = nt; }
-    Task *tk = tk_.get();
+    if (!g.tk || g.n != nt) { g.tk.reset(new Task[(size_t)nt]); g.n = nt; }
+    g.start = from;
+    g.w = window;
+    g.head_ok = true;
+    const size_t g0 = (size_t)(from >> 3);
+    Task *tk = g.tk.get();
     int used = 0;
     for (int i = 0; i < nt; ++i) {
       tk[i].have = false; tk[i].S = tk[i].E = 0; tk[i].ended = false; tk[i].three = false;
@@ -416,29 +550,49 @@ struct ParGunzip {
       if (tk[i].r0 >= zn) break;
       ++used;
     }
-    static const std::vector<uint8_t> dictA = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(k & 255); return v; }();
-    static const std::vector<uint8_t> dictB = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(128u | (k >> 8)); return v; }();
-    static const std::vector<uint8_t> dictC = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(255 ^ (k & 255)); return v; }();
-    // task 0: the true decode from `pos`; tasks 1..: search + speculative decodes
-    const double t_g0 = now();
-    Dec &head = head_;
-    bool head_ok = true;
-    std::vector<std::thread> th;
+    g.used = used;
+    // task 0: the true decode from `from`; tasks 1..: search + speculative decodes
     std::atomic<int> next_chunk{0};
     auto worker = [&]() {
       for (int i; (i = next_chunk.fetch_add(1)) < used;) {
-        if (i == 0) { head_ok = head.start(z, zn, pos, win.data(), (uint32_t)win.size()) && head.run((uint64_t)tk[0].r1 * 8); continue; }
+        if (i == 0) { g.head_ok = g.head.start(z, zn, from, g.w.data(), (uint32_t)g.w.size()) && g.head.run((uint64_t)tk[0].r1 * 8); continue; }
         Task &t = tk[i];
         const uint64_t b0 = (uint64_t)t.r0 * 8, b1 = (uint64_t)(t.r1 < zn ? t.r1 : zn) * 8;
         for (uint64_t b = b0; b < b1; ++b)
           if (plausible_header(b) && decode_spec(t, b, dictA.data(), dictB.data(), dictC.data())) break;
       }
     };
-    const int nth = used < threads ? used : threads;
-    for (int i = 1; i < nth; ++i) th.emplace_back(worker);
-    worker();
-    for (std::thread &x : th) x.join();
-    t_decode += now() - t_g0;
+    if (used > 1) { pool_decode.submit(worker); worker(); pool_decode.wait(); }
+    else worker();
+    g.t = now() - t0;
+  }
+  void drop_ahead() {
+    for (Group &g : grp_) if (g.pending) { pool_ahead.wait(); g.pending = false; g.head.stop(); }
+  }
+
+  bool produce(unsigned char *dst, size_t want, size_t *got) {
+    if (fruitless >= 2) {
+      drop_ahead();
+      if (!serial_to(pos + ((uint64_t)64 << 23), dst, want, got)) return false;
+      finish_pieces(dst, want, got);
+      return true;
+    }
+    const uint64_t accepted_before = n_accepted;
+    Group &g = grp_[cur_];
+    if (g.pending) {
+      const double tw = now();
+      pool_ahead.wait();
+      g.pending = false;
+      t_decode += now() - tw;  // (what was left of it to wait for)
+      if (g.start != pos || g.w != win) { g.head.stop(); decode_group(g, pos, win); t_decode += g.t; }  // (never seen: the chain left pos / win as handed over)
+    } else {
+      decode_group(g, pos, win);
+      t_decode += g.t;
+    }
+    Task *tk = g.tk.get();
+    const int used = g.used;
+    Dec &head = g.head;
+    const bool head_ok = g.head_ok;
     const double t_c0 = now();
     n_spec += (uint64_t)(used > 1 ? used - 1 : 0);
     if (!head_ok) { head.stop(); error = "invalid deflate data"; return false; }
@@ -469,9 +623,20 @@ struct ParGunzip {
       }
     }
     t_chain += now() - t_c0;
-    finish_pieces(dst, want, got);  // (the tasks' buffers are written again by the next group: nothing may be left pointing at them)
-    if (dbg) fprintf(stderr, "[pargz] so far: decode %.3f s, chain %.3f s (incl. mid-group finishes), finish %.3f s\n", t_decode, t_chain, t_finish);
     if (used > 1) fruitless = n_accepted == accepted_before ? fruitless + 1 : 0;
+    // the next group's decodes start now, from where this one's chain ended, into the other set of buffers ...
+    static const bool no_ahead = getenv("CM_PARGZ_NO_AHEAD") != nullptr;
+    if (!done && fruitless < 2 && !no_ahead) {
+      Group &nx = grp_[1 - cur_];
+      nx.pending = true;
+      const uint64_t from = pos;
+      pool_ahead.submit([this, &nx, from, w = win]() { decode_group(nx, from, w); });
+    }
+    // ... while this one's bytes are filled in, copied and check-summed (its tasks' buffers are written again by the group after next:
+    // nothing may be left pointing at them)
+    finish_pieces(dst, want, got);
+    cur_ = 1 - cur_;
+    if (dbg) fprintf(stderr, "[pargz] so far: decode %.3f s (waited for), chain %.3f s (incl. mid-group finishes), finish %.3f s\n", t_decode, t_chain, t_finish);
     return true;
   }
 

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--batches", type=int, default=2)
     ap.add_argument("--readlen", type=int, default=50)
     ap.add_argument("--dir", default="/tmp/chromap_amd_ref")
-    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    ap.add_argument("--threads", type=int, default=0, help="-t of the reference (0: the processors the container's CPU quota gives this process)")
     ap.add_argument("--preset", default="atac")
     ap.add_argument("--repeats", default="", help="families,copies,element_len,divergence of the planted repeats (bench.py --repeats)")
     ap.add_argument("--indel-rate", type=float, default=0.0)
@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--bgzf-check", action="store_true", help="also run chromap-amd on BGZF-compressed copies of the read files: same output")
     ap.add_argument("--hic", type=float, default=-1.0, help="Hi-C shaped pairs with this fraction of chimeric reads (default: fragments)")
     args = ap.parse_args()
+    if args.threads <= 0:
+        from chromap_amd.cpus import cpu_budget
+        args.threads = cpu_budget()
     rep = None
     if args.repeats.startswith("profile:"):
         rep = args.repeats
