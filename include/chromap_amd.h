@@ -499,11 +499,15 @@ int cmgpu_store_info(const cmgpu_ctx *ctx, uint64_t *n_records, uint64_t *text_b
  *                      Scans (this call and cmgpu_fastq_scan_bgzf) of DIFFERENT streams of one context may be
  *                      made from different host threads at the same time: each stream has a HIP stream and
  *                      scratch of its own; every other call on a context is one thread at a time.
- *   cmgpu_fastq_take   makes the first n of them this stream's part of the resident batch and
+ *   cmgpu_fastq_take   gathers the first n of them as this stream's part of the NEXT batch (staging buffers) and
  *                      returns how many bytes of the chunk they (and skipped records) cover --
  *                      the host resubmits the rest in front of the next chunk.
- *   cmgpu_fastq_commit declares the batch (n records taken from every participating stream);
- *                      cmgpu_map_resident then maps it. */
+ *   cmgpu_fastq_commit declares the batch (n records taken from every participating stream): the staging buffers
+ *                      become the resident batch; cmgpu_map_resident then maps it.
+ * Overlap: scans and takes touch only the streams' own buffers, HIP streams and the staging buffers, so ONE thread may
+ * scan and take the next batch while ANOTHER is inside cmgpu_map_resident / cmgpu_store_append_resident with the
+ * committed one (chromap-amd does; tests/test_gpu_ingest.py::test_next_batch_taken_while_the_last_is_mapped).
+ * cmgpu_fastq_commit itself must not run beside a mapping call of the same context. */
 /* --read-format for one stream (SequenceEffectiveRange, src/sequence_effective_range.h, src/chromap.cc:825-866):
  * up to four [start, end] base ranges (0-based, inclusive, end -1 = last base) are concatenated, then the result is
  * reverse-complemented (bases) / reversed (qualities) when strand is '-'.  Applies to the following cmgpu_fastq_take calls. */

@@ -252,3 +252,101 @@ def test_bgzf_damaged_blocks_are_rejected():
     b, off = _ingest_bgzf(g, blocks, 2)
     assert len(off) - 1 == text.count(b"\n") // 4
     g.close()
+
+
+def test_next_batch_taken_while_the_last_is_mapped():
+    """the CLI's overlap (round 6): cmgpu_fastq_take gathers into staging buffers on the file's own stream, cmgpu_fastq_commit swaps them
+    in -- so a batch may be scanned and taken while another thread maps the committed one.  The records of both batches equal those of the
+    serial order."""
+    import threading
+    from chromap_amd import ChromapGPU, Stats
+    case = "s1_atac"
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    t1, t2 = open(r1, "rb").read(), open(r2, "rb").read()
+    n_all = t1.count(b"\n") // 4
+    half = n_all // 2
+
+    def cut(t, n):  # the first n records / the rest
+        pos = 0
+        for _ in range(4 * n):
+            pos = t.index(b"\n", pos) + 1
+        return t[:pos], t[pos:]
+    a1, b1 = cut(t1, half)
+    a2, b2 = cut(t2, half)
+
+    def records(g):
+        k = g.store_append_resident()
+        return k
+
+    # serial order
+    g = ChromapGPU(datasets.case_index(case), fa, preset=preset, **kw)
+    g.store_clear()
+    for (x1, x2, first) in ((a1, a2, 0), (b1, b2, half)):
+        n = g.fastq_scan(0, x1, True)
+        assert g.fastq_scan(1, x2, True) == n
+        g.fastq_take(0, n); g.fastq_take(1, n)
+        g.fastq_commit(n, first_read_id=first, paired=True)
+        g.map_resident(Stats())
+        g.store_append_resident()
+    g.store_format()
+    want = g.store_text()
+    g.close()
+
+    # the second batch scanned and taken while the first is being mapped
+    g = ChromapGPU(datasets.case_index(case), fa, preset=preset, **kw)
+    g.store_clear()
+    n = g.fastq_scan(0, a1, True)
+    assert g.fastq_scan(1, a2, True) == n
+    g.fastq_take(0, n); g.fastq_take(1, n)
+    g.fastq_commit(n, first_read_id=0, paired=True)
+    err = []
+
+    def work():
+        try:
+            for _ in range(3):  # (several times over: the mapping must not see the staging buffers change under it)
+                g.map_resident(Stats())
+            g.store_append_resident()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+    th = threading.Thread(target=work)
+    th.start()
+    m = g.fastq_scan(0, b1, True)
+    assert g.fastq_scan(1, b2, True) == m
+    g.fastq_take(0, m); g.fastq_take(1, m)
+    th.join()
+    assert not err, err
+    g.fastq_commit(m, first_read_id=half, paired=True)
+    g.map_resident(Stats())
+    g.store_append_resident()
+    g.store_format()
+    got = g.store_text()
+    g.close()
+    assert got == want and len(want) > 1000
+
+
+def test_warm_up_leaves_results_alone():
+    """cmgpu_warm_up (a dry run of the whole path in a context of its own): callable more than once, before or after contexts exist;
+    a golden case maps to its BED afterwards"""
+    import hashlib
+    from chromap_amd import ChromapGPU, Stats, lib
+    L = lib()
+    assert L.cmgpu_warm_up(0) == 0
+    assert L.cmgpu_warm_up(0) == 0
+    assert L.cmgpu_warm_up(99) != 0  # no such device
+    case = "s1_atac"
+    meta = datasets.case_meta(case)
+    fa, r1, r2 = datasets.case_inputs(case)
+    preset, kw = datasets.flags_to_params(meta["chromap_flags"])
+    g = ChromapGPU(datasets.case_index(case), fa, preset=preset, **kw)
+    n = g.fastq_scan(0, open(r1, "rb").read(), True)
+    assert g.fastq_scan(1, open(r2, "rb").read(), True) == n
+    g.fastq_take(0, n); g.fastq_take(1, n)
+    g.fastq_commit(n, paired=True)
+    g.map_resident(Stats())
+    g.store_clear()
+    g.store_append_resident()
+    g.store_format()
+    assert hashlib.md5(g.store_text()).hexdigest() == meta["bed_md5"]
+    g.close()
