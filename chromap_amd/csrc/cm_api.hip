@@ -277,6 +277,13 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   HIPCHECK(c, hipStreamCreate(&c->stream));
   HIPCHECK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));  // same priority as `stream`: a probe stream of higher or lower
                                                                              // priority measured 3-5 % slower end to end
+  // the FASTQ streams' HIP streams, made HERE, right behind the two mapping streams, when the process asks for it (CM_FQ_EARLY=1; chromap-amd sets
+  // it): the runtime spreads streams of one priority over its hardware queues as they are made; made lazily by the first scans, read 1's and
+  // read 2's streams both landed on queue 4 and their inflate kernels ran one behind the other (k_bgzf_tokens 9.2 + 9.2 ms; made here: queues 2
+  // and 4, side by side, BGZF -> BED 0.18 -> 0.17 s).  Not the default for library callers: three more streams ahead of the lanes' shift THEIR queues
+  { const char *e = getenv("CM_FQ_EARLY"); if (e && e[0] != '0')
+    for (int m = 0; m < 3; ++m) if (hipStreamCreateWithFlags(&c->fq[m].hs, hipStreamNonBlocking) != hipSuccess) { c->fq[m].hs = nullptr; (void)hipGetLastError(); }
+  }
   for (hipEvent_t &e : c->chunk_ev) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (c->stats.ensure(CM_ST_N * 8)) return CMGPU_ENOMEM;
   HIPCHECK(c, hipMemset(c->stats.p, 0, CM_ST_N * 8));

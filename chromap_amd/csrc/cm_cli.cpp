@@ -624,6 +624,7 @@ int main(int argc, char **argv) {
   }
   Args a = parse(argc, argv);
   if (a.ref_path.empty() || a.out_path.empty()) die("No reference / output specified!");
+  setenv("CM_FQ_EARLY", "1", 0);  // (the files' HIP streams are made with the context: on hardware queues of their own, cm_api.hip)
   // the HIP runtime and the library's device code come up on a thread of their own while this one reads the reference and the index
   // (an error, e.g. no device, is reported by cmgpu_create below)
   struct Warm {

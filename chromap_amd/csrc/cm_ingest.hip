@@ -161,18 +161,9 @@ static int fq_scan_resident(cmgpu_ctx *c, int stream, uint64_t n_bytes, int fina
 // the HIP stream a FASTQ stream's scan runs on: one each, so that a host thread per file scans read 1, read 2 and the barcodes side by
 // side (cmgpu_fastq_scan / _scan_bgzf of DIFFERENT streams of one context may be called concurrently; every call ends synchronised)
 static hipStream_t fq_hs(cmgpu_ctx *c, CmFqStream &f) {
-  if (!f.hs) {
-    // (experiment, CM_FQ_PRIO=1: read 2's stream with the highest priority -- streams of one priority share hardware queues, and the traces
-    //  show read 1's and read 2's scans on ONE queue, their kernels one behind the other)
-    const int which = (int)(&f - c->fq);
-    hipError_t e;
-    if (which == 1 && getenv("CM_FQ_PRIO")) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      e = hipStreamCreateWithPriority(&f.hs, hipStreamNonBlocking, atoi(getenv("CM_FQ_PRIO")) > 0 ? hi : lo);
-    } else e = hipStreamCreateWithFlags(&f.hs, hipStreamNonBlocking);
-    if (e != hipSuccess) { f.hs = nullptr; (void)hipGetLastError(); return c->stream; }
-  }
+  // (made with the context when the process sets CM_FQ_EARLY, cm_api.hip -- on hardware queues of their own; made here, lazily, read 1's
+  //  and read 2's streams shared a queue.  A priority of its own for read 2's stream did not separate them: measured, no change)
+  if (!f.hs && hipStreamCreateWithFlags(&f.hs, hipStreamNonBlocking) != hipSuccess) { f.hs = nullptr; (void)hipGetLastError(); return c->stream; }
   return f.hs;
 }
 

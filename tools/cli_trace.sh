@@ -16,7 +16,7 @@ python - <<PY
 import csv, glob
 ev = []
 for f in glob.glob('$O/trace/*kernel_trace.csv'):
-    for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:48]))
+    for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:48] + "  s" + r.get("Stream_Id", "?") + " q" + r.get("Queue_Id", "?")))
 for f in glob.glob('$O/trace/*memory_copy_trace.csv'):
     for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + str(r.get("Bytes", r.get("Size", "")))))
 ev.sort()
