@@ -56,6 +56,12 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def host_info():
+    """hardware threads the box reports against the processors the container's CPU quota gives the job (the CPU baseline's threads)"""
+    from chromap_amd.cpus import cpu_budget
+    return {"hardware_threads": os.cpu_count(), "cpu_budget": cpu_budget()}
+
+
 def cpu_baseline_reference(args, repeats=None, tag="", seed0=1000, pairs=None):
     """the reference binary itself (oracle/_ref/chromap, built unchanged from the reference sources; it
     travels with the repo) on the host cores: tools/ref_baseline.py writes the same GRCh38-sized
@@ -729,6 +735,7 @@ def main():
         "counters_per_step": {k: v // steps for k, v in s.items()},
         "mapped_pairs_per_step": mapped // steps, "index_build_s": round(t_index, 1),
         "pairs_mapped_in_process": MAPPED["pairs"], "s3b_label": args.headline_repeats or "headline",
+        "host": host_info(),
     }
     if exchange:
         out["exchange"] = {"ranks": world, "transport": "RCCL (ncclAllGather of counts + grouped ncclSend/ncclRecv) on the mapping stream",

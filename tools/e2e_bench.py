@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from chromap_amd.cpus import cpu_budget  # noqa: E402
 
 
 def write_fastq(path, bases, n, L):
@@ -109,7 +110,8 @@ def main():
         res["bgzf_same_output"] = res["device_ingest_bgzf"]["bed_md5"] == res["device_ingest"]["bed_md5"]
     res["same_output"] = res["device_ingest"]["bed_md5"] == res["host_ingest"]["bed_md5"]
     res["config"] = {"pairs": args.pairs, "readlen": args.readlen, "genome": args.genome,
-                     "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2), "index_bytes": os.path.getsize(idx)}
+                     "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2), "index_bytes": os.path.getsize(idx),
+                     "hardware_threads": os.cpu_count(), "cpu_budget": cpu_budget()}
     print(json.dumps(res))
 
 
