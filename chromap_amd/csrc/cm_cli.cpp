@@ -58,7 +58,11 @@ static unsigned cpu_budget() {
 
 static void die(const std::string &m) {  // ExitWithMessage (utils.h:71-74)
   fprintf(stderr, "%s\n", m.c_str());
-  exit(-1);
+  // (_exit: other threads of the process may be inside the HIP runtime -- the warm-up beside the index read, the worker mapping the last batch
+  //  while this thread found the next one damaged -- and exit() would run the runtime's teardown under them)
+  fflush(stdout);
+  fflush(stderr);
+  _exit(255);
 }
 
 struct FastxReader {

@@ -175,3 +175,63 @@ def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
         open(p, "wb").write(data)
         r = run(p)
         assert r.returncode != 0 and b"corrupted" in r.stderr, name
+
+
+def test_pipelined_gunzip_over_members_threads_and_chunk_sizes(tmp_path):
+    """the round-6 form of cm_pargz.h -- the next group decoded while the last is finished, teams that live with the file, output split
+    between the caller's buffer and the spill -- on files made of members of many sizes (a member's end inside a group, at a group's
+    edge, members smaller than a chunk, a stored member, an empty member), for several team and chunk sizes, with and without decoding
+    ahead: the bytes are Python's gzip.decompress of the same file every time"""
+    import gzip
+    import hashlib
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(2026)
+
+    def fastq_like(n_rec):
+        names = rng.integers(0, 8, n_rec)
+        L = 44
+        seq = np.frombuffer(b"ACGTN", np.uint8)[np.minimum(rng.integers(0, 41, (n_rec, L)) // 10, 4)]
+        qual = (rng.integers(2, 41, (n_rec, L)) + 33).astype(np.uint8)
+        out = bytearray()
+        for i in range(n_rec):
+            out += b"@lane%d:%d\n" % (names[i], i)
+            out += seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n"
+        return bytes(out)
+
+    base = fastq_like(120000)  # ~13 MB of text, cut and repeated below
+    members = []
+    sizes = [len(base), 1, 70_000, 3_000_000, 0, len(base) // 2, 900_000, len(base), 12_345, len(base)]
+    levels = [6, 6, 1, 9, 6, 0, 6, 1, 6, 4]
+    want = bytearray()
+    for sz, lvl in zip(sizes, levels):
+        off = int(rng.integers(0, len(base) - sz + 1)) if sz < len(base) else 0
+        piece = base[off:off + sz]
+        want += piece
+        co = zlib.compressobj(lvl, zlib.DEFLATED, 31)
+        members.append(co.compress(piece) + co.flush())
+    path = str(tmp_path / "members.gz")
+    with open(path, "wb") as f:
+        for m in members:
+            f.write(m)
+    assert os.path.getsize(path) > (16 << 20)
+    data = open(path, "rb").read()
+    assert gzip.decompress(data) == bytes(want)
+    md5 = hashlib.md5(bytes(want)).hexdigest()
+    for threads, chunk_kb, ahead in ((2, 2048, True), (3, 256, True), (4, 64, True), (5, 512, False), (8, 128, True), (2, 64, False)):
+        env = dict(os.environ, CM_PARGZ_THREADS=str(threads), CM_PARGZ_CHUNK_KB=str(chunk_kb))
+        if not ahead:
+            env["CM_PARGZ_NO_AHEAD"] = "1"
+        r = subprocess.run([CLI, "--inflate-only", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, (threads, chunk_kb, ahead, r.stderr[-300:])
+        assert hashlib.md5(r.stdout).hexdigest() == md5, (threads, chunk_kb, ahead)
+        assert r.stderr.strip().splitlines()[-1].startswith(b"pargz"), r.stderr[-200:]
+    # a flipped bit deep inside is an error for every configuration (CRC or invalid data), never different bytes
+    bad = bytearray(data)
+    bad[len(bad) * 2 // 3] ^= 0x10
+    badp = str(tmp_path / "bad.gz")
+    open(badp, "wb").write(bad)
+    for threads, chunk_kb in ((3, 256), (8, 64)):
+        env = dict(os.environ, CM_PARGZ_THREADS=str(threads), CM_PARGZ_CHUNK_KB=str(chunk_kb))
+        r = subprocess.run([CLI, "--inflate-only", badp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode != 0 and b"corrupted" in r.stderr, r.stderr[-300:]
