@@ -260,3 +260,32 @@ def test_cli_reads_large_gzip_with_several_inflating_threads(tmp_path):
         outs[name] = ds.md5(out)
     assert os.path.getsize(out) > 1000000
     assert outs["pargz"] == outs["plain"] and outs["gzread"] == outs["plain"], outs
+
+
+def test_cli_overlapped_batches_equal_the_serial_order(tmp_path):
+    """round 6: the CLI reads, inflates and takes batch i + 1 while a worker maps batch i (staging buffers, cm_ingest.hip), warms the
+    runtime up with a dry run, sizes the record store after the first piece and reads a half-size first piece.  Seven batches of
+    500 000 pairs from plain text and from BGZF (blocks inflated on the device): the BED equals the serial order's
+    (CM_CLI_NO_OVERLAP=1, no dry run, whole first piece) byte for byte, with and without -n 3 sampling"""
+    import sys
+    pre = str(tmp_path / "d")
+    subprocess.check_call([sys.executable, os.path.join(ds.ROOT, "tools", "gen_real.py"), "--out", pre, "--genome", "30000000", "--chroms", "5",
+                           "--pairs", "3300000", "--seed", "606", "--len-min", "50", "--len-max", "50"])
+    sys.path.insert(0, os.path.join(ds.ROOT, "tools"))
+    import bgzf
+    for tag in ("_1", "_2"):
+        bgzf.compress_file(pre + tag + ".fq", pre + tag + ".fq.bgz")
+    idx = pre + ".idx"
+    subprocess.run([CLI, "-i", "-r", pre + ".fa", "-o", idx], check=True, stderr=subprocess.PIPE)
+    serial = {"CM_CLI_NO_OVERLAP": "1", "CM_NO_DRY_RUN": "1", "CM_FIRST_PIECE_DIV": "1", "CM_FQ_EARLY": "0"}
+    for extra in ([], ["-n", "3", "-q", "0"]):
+        outs = {}
+        for name, sfx, env in (("serial_text", ".fq", serial), ("text", ".fq", {}), ("serial_bgzf", ".fq.bgz", serial), ("bgzf", ".fq.bgz", {})):
+            out = str(tmp_path / (name + ".bed"))
+            r = subprocess.run([CLI, "--preset", "atac", "-x", idx, "-r", pre + ".fa", "-1", pre + "_1" + sfx, "-2", pre + "_2" + sfx, "-o", out,
+                                "--batch-pairs", "500000"] + extra, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            assert r.stderr.count(b"Mapped 500000 read pairs.") >= 6, r.stderr.decode()[-800:]
+            outs[name] = ds.md5(out)
+        assert os.path.getsize(out) > 50_000_000
+        assert len(set(outs.values())) == 1, (extra, outs)
