@@ -332,6 +332,10 @@ struct ParGunzip {
     pool_ahead.start(1);
     return true;
   }
+  ParGunzip() = default;
+  ParGunzip(const ParGunzip &) = delete;
+  ParGunzip &operator=(const ParGunzip &) = delete;
+  ~ParGunzip() { close(); }  // (the teams stop before the buffers they write into go)
   void close() {
     drop_ahead();  // (a team may still be decoding ahead, out of the mapping below)
     pool_ahead.stop(); pool_decode.stop(); pool_finish.stop();
