@@ -843,7 +843,10 @@ void cm_fill_dev_range(cmgpu_ctx *c, CmDev &d, uint32_t lo, uint32_t hi) {
     //  groups' time is not the number of reads in flight here)
     d.rs_big = d.hv_big ? (hv_big_area < 7680u ? hv_big_area : 7680u) : 0u;
     if (d.rs_big <= d.rs_max3) d.rs_big = 0;
-    d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : 64u);
+    // the longest list a 16-lane group takes: 64 hits; 96 for reads of 100 bases and more (round 6, `tools/gpu_mid_knob.sh`: 2 x 150 hic reads
+    // carry ~37 hits each with a tail to ~100 -- 64 / 80 / 96 / 112: 102.6 / 101.8 / 110.3 / 101.3 M pairs/s, twice; at 50 bases 96 is neutral on the
+    // headline and the mammalian-like genomes and loses 4 % on the planted repeats).  The classes decide who works on a list, never the result
+    d.hv_mid = c->opt_heavy_mid < 0 ? 0u : (c->opt_heavy_mid > 0 ? (uint32_t)c->opt_heavy_mid : (c->max_read_len >= 100 ? 96u : 64u));
     if (d.hv_mid > 256) d.hv_mid = 256;
     if (d.hv_max[0] == 0) d.hv_mid = 0;
     d.hv_sub = d.hv_max[0] >= 512 ? 256u : 0u;  // (the tests' small size classes: no sub-class)

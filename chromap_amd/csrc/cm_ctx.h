@@ -175,7 +175,7 @@ struct cmgpu_ctx {
   std::vector<cmgpu_ctx *> lanes;    // the further lanes' contexts (views of this context's index, reference, batch and record arrays)
   int shared_children = 0;           // contexts made by cmgpu_create_shared that view this one's buffers (the lanes among them refresh their views)
   cmgpu_ctx *shared_parent = nullptr;
-  int opt_heavy_mid = 0;             // 0: 64 hits; -1: no 16-lane class
+  int opt_heavy_mid = 0;             // 0: 64 hits (96 for reads of 100 bases and more); -1: no 16-lane class
   int opt_heavy_max[3] = {0, 0, 0};  // size classes of the cooperative hit-list kernel (0: the kernel's own)
   int opt_heavy_last = 0;            // heavy-last processing order: 0 auto, 1 always, -1 never
   // candidate arrays sized from the previous batch of the same size (+ 25 %): no host wait for their total; the device checks it
