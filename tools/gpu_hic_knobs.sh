@@ -17,14 +17,15 @@ except Exception as e:
 PY
 }
 run default
+run wave256 heavy_wave_max=256
+run wave384 heavy_wave_max=384
+run cap12 s3b_lane_cap=12
 run cap24 s3b_lane_cap=24
-run cap32 s3b_lane_cap=32
-run cap48 s3b_lane_cap=48
-run mid32 heavy_mid_max=32
-run mid96 heavy_mid_max=96
-run mid128 heavy_mid_max=128
-run nomid heavy_mid_max=-1
-run nomid_cap48 heavy_mid_max=-1 s3b_lane_cap=48
+run last1 heavy_last=1
+run lastm1 heavy_last=-1
 run default2
-run chunks8 mm_chunks=8
-run chunks2 mm_chunks=2
+run lpl1 probe_lookups_per_lane=1
+run lpl4 probe_lookups_per_lane=4
+run tile16 prep_tile_reads=16
+run prefetch0 probe_pair_prefetch=0
+run prefetch1 probe_pair_prefetch=1
