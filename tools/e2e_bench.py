@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--dir", default="/tmp/chromap_amd_e2e")
     ap.add_argument("--gz", action="store_true", help="also time gzip-compressed input (inflated on the host, one thread per file) and BGZF input (on the device)")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--skip-host-ingest", action="store_true", help="a long job: leave the host parser's run out")
     args = ap.parse_args()
     os.makedirs(args.dir, exist_ok=True)
     from chromap_amd import ChromapGPU
@@ -93,7 +94,8 @@ def main():
         res[label] = best
 
     run("device_ingest", r1, r2)
-    run("host_ingest", r1, r2, ["--host-ingest"], reps=1)
+    if not args.skip_host_ingest:
+        run("host_ingest", r1, r2, ["--host-ingest"], reps=1)
     if args.gz:
         for f in (r1, r2):
             subprocess.check_call("gzip -1 -c %s > %s.gz" % (f, f), shell=True)
@@ -108,7 +110,7 @@ def main():
         res["device_ingest_bgzf"]["bgzf_bytes"] = os.path.getsize(r1 + ".bgz") + os.path.getsize(r2 + ".bgz")
         run("device_ingest_bgzf_256MB_pieces", r1 + ".bgz", r2 + ".bgz", ["--ingest-chunk-mb", "256"])
         res["bgzf_same_output"] = res["device_ingest_bgzf"]["bed_md5"] == res["device_ingest"]["bed_md5"]
-    res["same_output"] = res["device_ingest"]["bed_md5"] == res["host_ingest"]["bed_md5"]
+    res["same_output"] = res["device_ingest"]["bed_md5"] == res["host_ingest"]["bed_md5"] if "host_ingest" in res else None
     res["config"] = {"pairs": args.pairs, "readlen": args.readlen, "genome": args.genome,
                      "fastq_bytes": os.path.getsize(r1) + os.path.getsize(r2), "index_bytes": os.path.getsize(idx),
                      "hardware_threads": os.cpu_count(), "cpu_budget": cpu_budget()}
