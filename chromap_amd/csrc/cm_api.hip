@@ -282,6 +282,7 @@ int cm_ctx_init_common(cmgpu_ctx *c, const cmgpu_params *params, int kmer, int w
   // read 2's streams both landed on queue 4 and their inflate kernels ran one behind the other (k_bgzf_tokens 9.2 + 9.2 ms; made here: queues 2
   // and 4, side by side, BGZF -> BED 0.18 -> 0.17 s).  Not the default for library callers: three more streams ahead of the lanes' shift THEIR queues
   { const char *e = getenv("CM_FQ_EARLY"); if (e && e[0] != '0')
+    // (a priority of their own for these streams, highest or lowest: measured on a 32 M-pair job, no difference)
     for (int m = 0; m < 3; ++m) if (hipStreamCreateWithFlags(&c->fq[m].hs, hipStreamNonBlocking) != hipSuccess) { c->fq[m].hs = nullptr; (void)hipGetLastError(); }
   }
   for (hipEvent_t &e : c->chunk_ev) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
