@@ -126,7 +126,6 @@ struct ParGunzip {
         while (nc - len < more) nc *= 2;
         void *q = nullptr;
         if (posix_memalign(&q, (size_t)2 << 20, nc) != 0 || !q) { fprintf(stderr, "out of memory (gunzip buffers)\n"); abort(); }
-        (void)madvise(q, nc, MADV_HUGEPAGE);
         if (len) memcpy(q, p, len);
         free(p);
         p = static_cast<uint8_t *>(q);
@@ -221,19 +220,20 @@ struct ParGunzip {
     struct Buf {
       uint8_t *p = nullptr;
       size_t len = 0, cap = 0;
+      size_t first_cap = (size_t)4 << 20;  // (a chunk's decodes: set to ~6 x the chunk's compressed size -- FASTQ inflates ~5-fold; growing by doubling touched 4 + 8 + 16 MB for 11)
       uint8_t *data() { return p; }
       const uint8_t *data() const { return p; }
       size_t size() const { return len; }
       void clear() { len = 0; }
-      // (2 MiB-aligned and advised as huge pages: a short job writes every byte of these buffers for the first time -- 5.6 GB of fresh
-      //  pages for two 928 MB files, the faults of 64+ threads at once; more threads made it SLOWER, 32 -> 48: 0.86 -> 1.27 s end to end)
+      // (2 MiB-aligned; NOT advised as huge pages: where the system compacts memory on such a fault -- transparent_hugepage/defrag = madvise,
+      //  as on the boxes here -- the faults of a team of threads cost more than the small pages they save: a 40 MB file in this round's
+      //  container, 4 threads: 19 s with the advice, of which 31 s of system time, against 2.5 s for gzread)
       void room(size_t more) {
         if (cap - len >= more) return;
-        size_t nc = cap ? cap * 2 : (size_t)4 << 20;
+        size_t nc = cap ? cap * 2 : first_cap;
         while (nc - len < more) nc *= 2;
         void *q = nullptr;
         if (posix_memalign(&q, (size_t)2 << 20, nc) != 0 || !q) { fprintf(stderr, "out of memory (gunzip buffers)\n"); abort(); }
-        (void)madvise(q, nc, MADV_HUGEPAGE);
         if (len) memcpy(q, p, len);
         free(p);
         p = static_cast<uint8_t *>(q);
@@ -279,6 +279,11 @@ struct ParGunzip {
         if (rc != Z_OK && rc != Z_BUF_ERROR) return false;
         if (rc == Z_BUF_ERROR && s.avail_in == 0 && (size_t)(base + zn - s.next_in) == 0 && s.avail_out != 0) return false;  // truncated
         if ((s.data_type & 128) && !(rc == Z_BUF_ERROR)) {
+          // (the end of the stream's LAST block -- bit 64 -- is not a place to stop: what follows is padding and the trailer, not a block.
+          //  The next call returns Z_STREAM_END.  Round 6: a member whose last block straddled a chunk's end -- ~2 % of members with 2 MiB
+          //  chunks -- stopped here as if more blocks followed, and the decode "from the next block" failed on a valid file; found by
+          //  tests/test_cli_cpu.py::test_pipelined_gunzip_over_members_threads_and_chunk_sizes with 64 KiB chunks)
+          if (s.data_type & 64) continue;
           at = (uint64_t)(s.next_in - base) * 8 - (uint64_t)(s.data_type & 63);
           if (at >= stop) return true;
         }
@@ -313,7 +318,9 @@ struct ParGunzip {
 
   bool open(const char *path, int nthreads) {
     struct stat sb;
-    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < ((size_t)16 << 20)) return false;
+    // (files under 16 MiB: not worth the teams; CM_PARGZ_MIN_KB: the tests' smaller files)
+    const size_t min_bytes = getenv("CM_PARGZ_MIN_KB") ? (size_t)atol(getenv("CM_PARGZ_MIN_KB")) << 10 : (size_t)16 << 20;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < min_bytes) return false;
     fd = ::open(path, O_RDONLY);
     if (fd < 0) return false;
     zn = (size_t)sb.st_size;
@@ -469,7 +476,7 @@ struct ParGunzip {
   // decodes from `pos` with the true window up to the first block boundary at or behind `stop`: the slow path for a stretch no guess covers
   bool serial_to(uint64_t stop, unsigned char *dst, size_t want, size_t *got) {
     Dec d;
-    if (!d.start(z, zn, pos, win.data(), (uint32_t)win.size()) || !d.run(stop)) { d.stop(); error = "invalid deflate data"; return false; }
+    if (!d.start(z, zn, pos, win.data(), (uint32_t)win.size()) || !d.run(stop)) { d.stop(); if (getenv("CM_PARGZ_DEBUG")) fprintf(stderr, "[pargz] serial decode failed from bit %llu to %llu (window %zu bytes)\n", (unsigned long long)pos, (unsigned long long)stop, win.size()); error = "invalid deflate data"; return false; }
     Dec::Buf *keep = new Dec::Buf();
     keep->p = d.out.p; keep->len = d.out.len; keep->cap = d.out.cap;
     d.out.p = nullptr; d.out.len = d.out.cap = 0;
@@ -540,7 +547,12 @@ struct ParGunzip {
     static const std::vector<uint8_t> dictC = [] { std::vector<uint8_t> v(kWin); for (uint32_t k = 0; k < kWin; ++k) v[k] = (uint8_t)(255 ^ (k & 255)); return v; }();
     const double t0 = now();
     const int nt = threads;
-    if (!g.tk || g.n != nt) { g.tk.reset(new Task[(size_t)nt]); g.n = nt; }
+    if (!g.tk || g.n != nt) {
+      g.tk.reset(new Task[(size_t)nt]);
+      g.n = nt;
+      for (int i = 0; i < nt; ++i) for (Dec &d : g.tk[i].d) d.out.first_cap = kChunk * 6;
+      g.head.out.first_cap = kChunk * 6;
+    }
     g.start = from;
     g.w = window;
     g.head_ok = true;
@@ -599,7 +611,7 @@ struct ParGunzip {
     const bool head_ok = g.head_ok;
     const double t_c0 = now();
     n_spec += (uint64_t)(used > 1 ? used - 1 : 0);
-    if (!head_ok) { head.stop(); error = "invalid deflate data"; return false; }
+    if (!head_ok) { head.stop(); if (getenv("CM_PARGZ_DEBUG")) fprintf(stderr, "[pargz] head decode failed from bit %llu (window %zu bytes)\n", (unsigned long long)g.start, g.w.size()); error = "invalid deflate data"; return false; }
     add_piece(&head.out, nullptr, nullptr);
     pos = head.at;
     {

@@ -106,7 +106,7 @@ def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
     import gzip
     import numpy as np
     rng = np.random.default_rng(11)
-    n = 450000
+    n = 150000  # (20 MB of text: CM_PARGZ_MIN_KB lets files of a few MB through and 512 KiB chunks keep several groups -- fresh memory is dear on the CPU box)
     seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, 60))]
     qual = (rng.integers(2, 41, (n, 60)) + 33).astype(np.uint8)
     rec = np.empty((n, 8 + 1 + 60 + 3 + 60 + 1), np.uint8)
@@ -117,7 +117,7 @@ def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
     rec[:, 72:132] = qual
     rec[:, 132] = 10
     text = rec.tobytes()
-    env = dict(os.environ, CM_PARGZ_THREADS="4")
+    env = dict(os.environ, CM_PARGZ_THREADS="4", CM_PARGZ_MIN_KB="2048", CM_PARGZ_CHUNK_KB="512")
 
     def run(path):
         return subprocess.run([CLI, "--inflate-only", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
@@ -132,7 +132,7 @@ def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
         p = str(tmp_path / ("t%d.gz" % lvl))
         with gzip.open(p, "wb", compresslevel=lvl) as g:
             g.write(text)
-        assert os.path.getsize(p) > (16 << 20)
+        assert os.path.getsize(p) > (4 << 20)
         files[lvl] = p
         r = run(p)
         assert r.returncode == 0 and r.stdout == text
@@ -144,19 +144,19 @@ def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
     # members one behind the other: deflate, stored (level 0: no dynamic block to find), deflate
     stored = str(tmp_path / "l0.gz")
     with gzip.open(stored, "wb", compresslevel=0) as g:
-        g.write(text[:20_000_000])
+        g.write(text[:6_000_000])
     cat = str(tmp_path / "cat.gz")
     with open(cat, "wb") as f:
         for p in (files[1], stored, files[6]):
             f.write(open(p, "rb").read())
     r = run(cat)
-    assert r.returncode == 0 and r.stdout == text + text[:20_000_000] + text
+    assert r.returncode == 0 and r.stdout == text + text[:6_000_000] + text
     assert stats(r)["accepted"] > 3
     # binary data (bytes of all values: the third decode that tells a literal >= 128 from a window byte), partly incompressible
     blob = bytearray()
     base = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
     words = [rng.integers(128, 256, int(rng.integers(3, 40)), dtype=np.uint8).tobytes() for _ in range(200)]
-    while len(blob) < 60_000_000:
+    while len(blob) < 20_000_000:
         blob += base[:int(rng.integers(1000, 200000))]
         for _ in range(20000):
             blob += words[int(rng.integers(0, 200))]
@@ -164,12 +164,12 @@ def test_ordinary_gzip_inflated_by_several_threads(tmp_path):
     bz = str(tmp_path / "bin.gz")
     with gzip.open(bz, "wb", compresslevel=6) as g:
         g.write(blob)
-    if os.path.getsize(bz) > (16 << 20):
+    if os.path.getsize(bz) > (4 << 20):
         r = run(bz)
         assert r.returncode == 0 and r.stdout == blob
     # damage: a truncated file, a flipped bit in the middle, a wrong CRC in the trailer
     z = open(files[6], "rb").read()
-    for name, data in (("trunc.gz", z[:-500000]), ("flip.gz", z[:len(z) // 2] + bytes([z[len(z) // 2] ^ 0x10]) + z[len(z) // 2 + 1:]),
+    for name, data in (("trunc.gz", z[:-200000]), ("flip.gz", z[:len(z) // 2] + bytes([z[len(z) // 2] ^ 0x10]) + z[len(z) // 2 + 1:]),
                        ("crc.gz", z[:-6] + bytes([z[-6] ^ 1]) + z[-5:])):
         p = str(tmp_path / name)
         open(p, "wb").write(data)
@@ -199,9 +199,9 @@ def test_pipelined_gunzip_over_members_threads_and_chunk_sizes(tmp_path):
             out += seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n"
         return bytes(out)
 
-    base = fastq_like(120000)  # ~13 MB of text, cut and repeated below
+    base = fastq_like(30000)  # ~3.3 MB of text, cut and repeated below (CM_PARGZ_MIN_KB lets files this small through: fresh memory is dear on the CPU box)
     members = []
-    sizes = [len(base), 1, 70_000, 3_000_000, 0, len(base) // 2, 900_000, len(base), 12_345, len(base)]
+    sizes = [len(base), 1, 70_000, 1_000_000, 0, len(base) // 2, 300_000, len(base), 12_345, len(base)]
     levels = [6, 6, 1, 9, 6, 0, 6, 1, 6, 4]
     want = bytearray()
     for sz, lvl in zip(sizes, levels):
@@ -214,12 +214,12 @@ def test_pipelined_gunzip_over_members_threads_and_chunk_sizes(tmp_path):
     with open(path, "wb") as f:
         for m in members:
             f.write(m)
-    assert os.path.getsize(path) > (16 << 20)
+    assert os.path.getsize(path) > (4 << 20)
     data = open(path, "rb").read()
     assert gzip.decompress(data) == bytes(want)
     md5 = hashlib.md5(bytes(want)).hexdigest()
-    for threads, chunk_kb, ahead in ((2, 2048, True), (3, 256, True), (4, 64, True), (5, 512, False), (8, 128, True), (2, 64, False)):
-        env = dict(os.environ, CM_PARGZ_THREADS=str(threads), CM_PARGZ_CHUNK_KB=str(chunk_kb))
+    for threads, chunk_kb, ahead in ((2, 512, True), (3, 256, True), (4, 64, True), (5, 128, False), (8, 128, True), (2, 64, False)):
+        env = dict(os.environ, CM_PARGZ_THREADS=str(threads), CM_PARGZ_CHUNK_KB=str(chunk_kb), CM_PARGZ_MIN_KB="1024")
         if not ahead:
             env["CM_PARGZ_NO_AHEAD"] = "1"
         r = subprocess.run([CLI, "--inflate-only", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
@@ -232,6 +232,6 @@ def test_pipelined_gunzip_over_members_threads_and_chunk_sizes(tmp_path):
     badp = str(tmp_path / "bad.gz")
     open(badp, "wb").write(bad)
     for threads, chunk_kb in ((3, 256), (8, 64)):
-        env = dict(os.environ, CM_PARGZ_THREADS=str(threads), CM_PARGZ_CHUNK_KB=str(chunk_kb))
+        env = dict(os.environ, CM_PARGZ_THREADS=str(threads), CM_PARGZ_CHUNK_KB=str(chunk_kb), CM_PARGZ_MIN_KB="1024")
         r = subprocess.run([CLI, "--inflate-only", badp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode != 0 and b"corrupted" in r.stderr, r.stderr[-300:]
